@@ -1,0 +1,195 @@
+"""Generate tests/golden/*.npz from the REFERENCE's own modules (build container only).
+
+Run:  PYTHONDONTWRITEBYTECODE=1 python oracle/gen_golden.py
+Needs /root/reference (read-only).  The reference never travels to the GPU box; only the vectors
+written here do.  Inputs: the build's deterministic weights (amuse_amd.weights, seed 0) and seeded
+torch.Generator draws.  Outputs are produced by:
+  * models.latent_diffusion.denoiser.Denoiser          (denoiser.py:16-204)
+  * models.latent_diffusion.vae.MotionPrior.decode      (vae.py:216-278)
+  * models/diffusion/utils/rotation_conversions.py      (vendored pytorch3d snapshot)
+imported through the package shim described in SURVEY.md section 8c (the reference's package
+__init__ chain imports seaborn/timm/... which are not installed).
+The DDIM-50 trajectory fixture drives the reference Denoiser with the oracle's restated scheduler
+(diffusers is not installed) - it pins the network under iteration, not diffusers.
+"""
+import importlib.util
+import json
+import os
+import sys
+import types
+from pathlib import Path
+
+import numpy as np
+import torch
+
+REPO = Path(__file__).resolve().parents[1]
+REF = Path("/root/reference")
+sys.path.insert(0, str(REPO))
+sys.dont_write_bytecode = True
+
+from amuse_amd import weights as wts  # noqa: E402
+from oracle import amuse_oracle as orc  # noqa: E402
+
+
+def _shim():
+    for name, path in (("models", REF / "models"),
+                       ("models.latent_diffusion", REF / "models/latent_diffusion"),
+                       ("models.latent_diffusion.utils", REF / "models/latent_diffusion/utils")):
+        m = types.ModuleType(name)
+        m.__path__ = [str(path)]
+        sys.modules[name] = m
+    from models.latent_diffusion.utils.position_encoding_layer import PositionalEncoding
+    sys.modules["models.latent_diffusion.utils"].PositionalEncoding = PositionalEncoding
+    from models.latent_diffusion.denoiser import Denoiser
+    from models.latent_diffusion.vae import MotionPrior
+    spec = importlib.util.spec_from_file_location("ref_rot", REF / "models/diffusion/utils/rotation_conversions.py")
+    rot = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(rot)
+    return Denoiser, MotionPrior, rot
+
+
+def build_reference():
+    Denoiser, MotionPrior, rot = _shim()
+    base = json.load(open(REF / "configs/base_new.json"))
+    ldm_cfg = json.load(open(REF / "configs/diff_latent_v2.json"))
+    prior_cfg = json.load(open(REF / "configs/prior_emotional_fing.json"))
+    # infer_gesture.yaml overrides (scripts/overrides/infer_gesture.yaml): smplx_rep 6D etc. already the defaults
+    dcfg = dict(ldm_cfg["arch_denoiser"])
+    dcfg["smplx_data"] = base["TRAIN_PARAM"]["latent_diffusion"]["smplx_data"]  # infer_ldm.py:69
+    dcfg["smplx_rep"] = base["TRAIN_PARAM"]["latent_diffusion"]["smplx_rep"]    # infer_ldm.py:72
+    den = Denoiser(dcfg).eval()
+    prior = MotionPrior()
+    prior.setup(None, base, prior_cfg=prior_cfg)
+    prior.eval()
+    return den, prior, rot
+
+
+def load_weights(module, w):
+    sd = module.state_dict()
+    assert list(sd.keys()) == list(w.keys()), "state-dict key list/order mismatch vs amuse_amd.weights spec"
+    for k, v in w.items():
+        assert tuple(sd[k].shape) == tuple(v.shape), (k, sd[k].shape, v.shape)
+    module.load_state_dict({k: torch.from_numpy(v) for k, v in w.items()})
+    for p in module.parameters():
+        p.requires_grad = False
+
+
+def main():
+    out = REPO / "tests/golden"
+    out.mkdir(parents=True, exist_ok=True)
+    torch.manual_seed(0)
+    torch.set_grad_enabled(False)
+    den, prior, rot = build_reference()
+
+    # ---- state-dict spec straight from the reference modules
+    spec = {"denoiser": {k: list(v.shape) for k, v in den.state_dict().items()},
+            "prior": {k: list(v.shape) for k, v in prior.state_dict().items()}}
+    json.dump(spec, open(out / "state_dict_spec.json", "w"), indent=0)
+    wd, wp = wts.make_denoiser_weights(0), wts.make_prior_weights(0)
+    load_weights(den, wd)
+    load_weights(prior, wp)
+    print("denoiser params", sum(p.numel() for p in den.parameters()),
+          "prior params", sum(p.numel() for p in prior.parameters()))
+
+    g = torch.Generator().manual_seed(2024)
+    B = 3
+    con = torch.randn(B, 256, generator=g)
+    emo = torch.randn(B, 256, generator=g)
+    sty = torch.randn(B, 256, generator=g)
+    x_t = torch.randn(B, 1, 128, generator=g)
+    lengths = [300] * B
+
+    # ---- Denoiser: teacher-forced eps_hat at three timesteps, module-level taps at t = 981
+    taps = {}
+    hooks = []
+    def tap(name, seq_first=True):
+        def fn(_m, _i, o):
+            taps[name] = (o.permute(1, 0, 2) if (seq_first and o.dim() == 3) else o).clone().numpy()
+        return fn
+    hooks.append(den.time_embedding.register_forward_hook(tap("time_embedding", False)))
+    for n in ("con", "emo", "sty"):
+        hooks.append(getattr(den, f"emb_proj_{n}").register_forward_hook(tap(f"emb_proj_{n}")))
+    hooks.append(den.query_pos.register_forward_hook(tap("tokens")))
+    hooks.append(den.encoder.input_blocks[0].register_forward_hook(tap("encoder.input_blocks.0")))
+    hooks.append(den.encoder.middle_block.register_forward_hook(tap("encoder.middle_block")))
+    hooks.append(den.encoder.output_blocks[3].register_forward_hook(tap("encoder.output_blocks.3")))
+    d = {"con": con.numpy(), "emo": emo.numpy(), "sty": sty.numpy(), "x_t": x_t[:, 0].numpy()}
+    for t in (981, 501, 1):
+        eps = den(sample=x_t, timestep=torch.tensor(t), con_hidden=con[:, None], emo_hidden=emo[:, None],
+                  sty_hidden=sty[:, None], lengths=lengths)[0]
+        d[f"eps_t{t}"] = eps[:, 0].numpy()
+        if t == 981:
+            for k, v in taps.items():
+                d[f"tap981/{k}"] = v
+    for h in hooks:
+        h.remove()
+    # token-dropping variants (emo / sty None -> S = 4 / 3; denoiser.py:159-171)
+    d["eps_t501_noemo"] = den(sample=x_t, timestep=torch.tensor(501), con_hidden=con[:, None], emo_hidden=None,
+                              sty_hidden=sty[:, None], lengths=lengths)[0][:, 0].numpy()
+    d["eps_t501_consolo"] = den(sample=x_t, timestep=torch.tensor(501), con_hidden=con[:, None], emo_hidden=None,
+                                sty_hidden=None, lengths=lengths)[0][:, 0].numpy()
+    np.savez_compressed(out / "denoiser_steps.npz", **d)
+
+    # ---- DDIM-50 trajectory: reference Denoiser + restated scheduler, explicit x_T, B = 2
+    sched = orc.DDIM()
+    assert sched.timesteps[0] == 981 and sched.timesteps[-1] == 1 and len(sched.timesteps) == 50
+    B2 = 2
+    x = torch.randn(B2, 128, generator=g)
+    tr = {"x_T": x.numpy().copy(), "con": con[:B2].numpy(), "emo": emo[:B2].numpy(), "sty": sty[:B2].numpy()}
+    for i, t in enumerate(sched.timesteps):
+        eps = den(sample=x[:, None], timestep=torch.tensor(t), con_hidden=con[:B2, None], emo_hidden=emo[:B2, None],
+                  sty_hidden=sty[:B2, None], lengths=[300] * B2)[0][:, 0]
+        x = sched.step(eps, t, x)
+        if (i + 1) % 10 == 0:
+            tr[f"x_after_{i + 1}"] = x.numpy().copy()
+    np.savez_compressed(out / "ddim50_traj.npz", **tr)
+
+    # ---- MotionPrior.decode on the DDIM result and on a fresh latent
+    z = torch.stack([x[0], x[1], torch.randn(128, generator=g)])  # (3,128)
+    dtaps = {}
+    hk = [prior.decoder.input_blocks[0].register_forward_hook(
+              lambda _m, _i, o: dtaps.__setitem__("decoder.input_blocks.0", o.permute(1, 0, 2).clone().numpy())),
+          prior.decoder.output_blocks[3].register_forward_hook(
+              lambda _m, _i, o: dtaps.__setitem__("decoder.output_blocks.3", o.permute(1, 0, 2).clone().numpy()))]
+    feats = prior.decode(z[None], [300] * 3)  # (3,300,333)
+    for h in hk:
+        h.remove()
+    feats_ragged = prior.decode(z[None, :2], [300, 173])  # padded keys masked, padded frames zeroed
+    np.savez_compressed(out / "vae_decode.npz", z=z.numpy(), feats=feats.numpy(),
+                        feats_ragged=feats_ragged.numpy(), lengths_ragged=np.array([300, 173]),
+                        **{f"tap/{k}": v[:, ::25].copy() for k, v in dtaps.items()})
+
+    # ---- rotation conversions from the vendored pytorch3d snapshot
+    d6 = torch.randn(2000, 6, generator=g)
+    d6[:50] *= 1e-3
+    d6[50:60, 3:] = d6[50:60, :3] * 2.0 + 1e-4 * torch.randn(10, 3, generator=g)  # nearly parallel a1,a2
+    mat = rot.rotation_6d_to_matrix(d6)
+    # near-pi rotations: axis-angle with |aa| in [pi-1e-3, pi]
+    ax = torch.nn.functional.normalize(torch.randn(200, 3, generator=g), dim=-1)
+    ang = torch.cat([torch.full((100,), np.pi) - 1e-3 * torch.rand(100, generator=g), 3.0 * torch.rand(100, generator=g)])
+    mat_pi = rot.axis_angle_to_matrix(ax * ang[:, None])
+    allm = torch.cat([mat, mat_pi])
+    np.savez_compressed(out / "rotation.npz", d6=d6.numpy(), mat=mat.numpy(), mat_extra=mat_pi.numpy(),
+                        quat_legacy=rot.matrix_to_quaternion(allm).numpy(),
+                        aa_legacy=rot.matrix_to_axis_angle(allm).numpy(),
+                        aa2mat=rot.axis_angle_to_matrix(rot.matrix_to_axis_angle(allm)).numpy())
+
+    # ---- layout facts of the committed sample outputs (viz_dump/test/**/*_motion_smplx.npz)
+    lay = {}
+    for p in sorted((REF / "viz_dump/test").rglob("*_motion_smplx.npz")):
+        z_ = np.load(p, allow_pickle=True)
+        poses = z_["poses"]
+        lay[str(p.relative_to(REF))] = {
+            "fields": {k: [str(z_[k].dtype), list(z_[k].shape)] for k in z_.files},
+            "lower_body_constant": bool(np.all(poses[:, orc.LOWER_BODY] == poses[0, orc.LOWER_BODY])),
+            "trans_zero": bool(np.all(z_["trans"] == 0)),
+            "max_aa_norm": float(np.linalg.norm(poses, axis=-1).max()),
+            "mocap_frame_rate": float(z_["mocap_frame_rate"]),
+        }
+    json.dump(lay, open(out / "npz_layout.json", "w"), indent=1)
+    for f in sorted(out.iterdir()):
+        print(f.name, os.path.getsize(f))
+
+
+if __name__ == "__main__":
+    main()

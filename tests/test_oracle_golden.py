@@ -1,0 +1,170 @@
+"""CPU: the oracle restatement (oracle/amuse_oracle.py) against vectors produced by the REFERENCE's own
+modules (tests/golden/, written by oracle/gen_golden.py).  This is what pins the oracle."""
+import json
+
+import numpy as np
+import pytest
+import torch
+
+from amuse_amd import weights as wts
+from oracle import amuse_oracle as orc
+from conftest import GOLDEN
+
+
+@pytest.fixture(scope="module")
+def Wd():
+    return orc.to_torch(wts.make_denoiser_weights(0))
+
+
+@pytest.fixture(scope="module")
+def Wp():
+    return orc.to_torch(wts.make_prior_weights(0))
+
+
+def test_state_dict_spec_matches_reference():
+    spec = json.load(open(GOLDEN / "state_dict_spec.json"))
+    for tag, mine in (("denoiser", wts.denoiser_param_spec()), ("prior", wts.prior_param_spec())):
+        assert list(spec[tag].keys()) == list(mine.keys())
+        for k, s in mine.items():
+            assert tuple(spec[tag][k]) == tuple(s), k
+    assert len(spec["denoiser"]) == 130  # infer_ldm.py:103 asserts this count
+    assert wts.n_params(wts.make_denoiser_weights(0)) == 2192384
+    assert wts.n_params(wts.make_prior_weights(0)) == 4643277
+
+
+def test_weights_are_deterministic():
+    a, b = wts.make_denoiser_weights(0), wts.make_denoiser_weights(0)
+    assert all(np.array_equal(a[k], b[k]) for k in a)
+    c = wts.make_denoiser_weights(1)
+    assert not np.array_equal(a["encoder.norm.weight"], c["encoder.norm.weight"])
+
+
+def test_denoiser_eps_and_taps(Wd):
+    g = np.load(GOLDEN / "denoiser_steps.npz")
+    con, emo, sty, x = (torch.from_numpy(g[k]) for k in ("con", "emo", "sty", "x_t"))
+    for t in (981, 501, 1):
+        taps = {}
+        eps = orc.denoiser_forward(Wd, x, t, con, emo, sty, taps=taps)
+        assert np.abs(eps.numpy() - g[f"eps_t{t}"]).max() < 1e-5
+        if t == 981:
+            assert np.abs(orc.time_embed(Wd, t).numpy()[None] - g["tap981/time_embedding"]).max() < 2e-6
+            assert np.abs(orc.cond_project(Wd, "emo", emo).numpy()[:, None] - g["tap981/emb_proj_emo"]).max() < 2e-6
+            for k in ("tokens", "encoder.input_blocks.0", "encoder.middle_block", "encoder.output_blocks.3"):
+                assert np.abs(taps[k].numpy() - g[f"tap981/{k}"]).max() < 1e-5, k
+    e4 = orc.denoiser_forward(Wd, x, 501, con, None, sty)
+    e3 = orc.denoiser_forward(Wd, x, 501, con, None, None)
+    assert np.abs(e4.numpy() - g["eps_t501_noemo"]).max() < 1e-5
+    assert np.abs(e3.numpy() - g["eps_t501_consolo"]).max() < 1e-5
+
+
+def test_denoiser_fp64_agrees(Wd):
+    g = np.load(GOLDEN / "denoiser_steps.npz")
+    W64 = {k: v.double() for k, v in Wd.items()}
+    con, emo, sty, x = (torch.from_numpy(g[k]).double() for k in ("con", "emo", "sty", "x_t"))
+    eps = orc.denoiser_forward(W64, x, 501, con, emo, sty)
+    assert np.abs(eps.numpy() - g["eps_t501"]).max() < 1e-5
+
+
+def test_ddim50_trajectory(Wd):
+    g = np.load(GOLDEN / "ddim50_traj.npz")
+    sched = orc.DDIM()
+    assert sched.timesteps == list(range(981, 0, -20))
+    assert sched.init_noise_sigma == 1.0
+    traj = []
+    orc.sample_latents(Wd, sched, *(torch.from_numpy(g[k]) for k in ("con", "emo", "sty", "x_T")), traj=traj)
+    for i in (10, 20, 30, 40, 50):
+        assert np.abs(traj[i - 1].numpy() - g[f"x_after_{i}"]).max() < 1e-4, i
+
+
+def test_scheduler_self_checks():
+    d = orc.DDIM()
+    # eps == 0: x0 = clamp(x / sqrt(abar_t)), x' = sqrt(abar_prev) * x0
+    x = torch.tensor([[0.3, -2.0, 5.0]])
+    t = 981
+    out = d.step(torch.zeros_like(x), t, x)
+    a_t, a_p = d.alphas_cumprod[t], d.alphas_cumprod[t - 20]
+    exp = a_p.sqrt() * (x / a_t.sqrt()).clamp(-1, 1)
+    assert torch.allclose(out, exp, atol=1e-7)
+    # last DDIM step uses final_alpha_cumprod = abar[0] (set_alpha_to_one = false)
+    out = d.step(torch.zeros_like(x), 1, x)
+    exp = d.alphas_cumprod[0].sqrt() * (x / d.alphas_cumprod[1].sqrt()).clamp(-1, 1)
+    assert torch.allclose(out, exp, atol=1e-7)
+    p = orc.DDPM()
+    assert p.timesteps[0] == 999 and p.timesteps[-1] == 0 and len(p.timesteps) == 1000
+    assert not p.needs_noise(0) and p.needs_noise(1)
+    # DDPM posterior mean with eps = 0 and x0-consistency: x = sqrt(abar_t) x0 -> mean = c0 x0 + cx x
+    x0 = torch.tensor([[0.5, -0.25]])
+    t = 500
+    xt = p.alphas_cumprod[t].sqrt() * x0
+    mean = p.step(torch.zeros_like(xt), t, xt, torch.zeros_like(xt))
+    a_t, a_p = p.alphas_cumprod[t].double(), p.alphas_cumprod[t - 1].double()
+    al = a_t / a_p
+    ref = (a_p.sqrt() * (1 - al) / (1 - a_t)) * x0.double() + (al.sqrt() * (1 - a_p) / (1 - a_t)) * xt.double()
+    assert torch.allclose(mean.double(), ref, atol=1e-6)
+
+
+def test_vae_decode(Wp):
+    g = np.load(GOLDEN / "vae_decode.npz")
+    z = torch.from_numpy(g["z"])
+    taps = {}
+    feats = orc.vae_decode(Wp, z, taps=taps)
+    assert feats.shape == (3, 300, 333)
+    assert np.abs(feats.numpy() - g["feats"]).max() < 2e-5
+    for k in ("decoder.input_blocks.0", "decoder.output_blocks.3"):
+        assert np.abs(taps[k].numpy()[:, ::25] - g[f"tap/{k}"]).max() < 2e-5
+    fr = orc.vae_decode(Wp, z[:2], lengths=[300, 173])
+    assert np.abs(fr.numpy() - g["feats_ragged"]).max() < 2e-5
+    assert np.all(fr.numpy()[1, 173:] == 0)
+
+
+def test_rotation_conversions():
+    g = np.load(GOLDEN / "rotation.npz")
+    d6 = torch.from_numpy(g["d6"])
+    mat = orc.rotation_6d_to_matrix(d6)
+    assert np.abs(mat.numpy() - g["mat"]).max() < 1e-6
+    allm = torch.cat([torch.from_numpy(g["mat"]), torch.from_numpy(g["mat_extra"])])
+    ql = orc.matrix_to_quaternion(allm, "legacy")
+    assert np.abs(ql.numpy() - g["quat_legacy"]).max() < 1e-6
+    aal = orc.matrix_to_axis_angle(allm, "legacy")
+    assert np.abs(aal.numpy() - g["aa_legacy"]).max() < 2e-5
+    # candidate-selection variant: pinned as a rotation (and equal to legacy up to quaternion sign)
+    # rows 50:60 are the nearly-parallel (a1, a2) stress inputs: fp32 Gram-Schmidt leaves them
+    # non-orthogonal (b1.b2 ~ 3e-3), so they are checked value-wise above but not "as a rotation".
+    ok = torch.ones(len(allm), dtype=torch.bool)
+    ok[50:60] = False
+    qp = orc.matrix_to_quaternion(allm.double(), "p3d")
+    assert torch.allclose((qp * qp).sum(-1)[ok], torch.ones(int(ok.sum()), dtype=torch.float64), atol=1e-5)
+    same = torch.minimum((qp - ql.double()).abs().max(-1).values, (qp + ql.double()).abs().max(-1).values)
+    assert same[ok].max() < 5e-4   # legacy loses precision near pi (sqrt of small positive part)
+    aap = orc.matrix_to_axis_angle(allm.double(), "p3d")
+    back = orc.axis_angle_to_matrix(aap)
+    assert (back - allm.double())[ok].abs().max() < 1e-5
+    assert np.abs(orc.axis_angle_to_matrix(aal).numpy() - g["aa2mat"]).max() < 1e-5
+    # the deployed variant can return |aa| > pi (committed sample outputs do: npz_layout.json)
+    assert torch.linalg.vector_norm(aap, dim=-1).max() > np.pi
+
+
+def test_npz_layout_contract():
+    lay = json.load(open(GOLDEN / "npz_layout.json"))
+    assert len(lay) == 3
+    f = orc.npz_fields(np.random.default_rng(0).standard_normal((300, 168)).astype(np.float32))
+    for name, facts in lay.items():
+        assert facts["lower_body_constant"] and facts["trans_zero"] and facts["mocap_frame_rate"] == 30.0
+        for k, (dt, shape) in facts["fields"].items():
+            if k in ("gender",):
+                continue
+            assert str(f[k].dtype) == dt and list(f[k].shape) == shape, (name, k)
+    assert max(v["max_aa_norm"] for v in lay.values()) > np.pi
+    assert np.all(f["poses"][:, orc.LOWER_BODY] == f["poses"][0, orc.LOWER_BODY])
+
+
+def test_counter_noise_statistics():
+    z = orc.counter_normal(2024, np.arange(64), 3, 1)
+    assert z.shape == (64, 128) and z.dtype == np.float32
+    assert abs(z.mean()) < 0.05 and abs(z.std() - 1) < 0.05
+    z2 = orc.counter_normal(2024, np.arange(32, 64), 3, 1)
+    assert np.array_equal(z[32:], z2)  # keyed by global clip index: shard-invariant
+    assert not np.array_equal(z, orc.counter_normal(2024, np.arange(64), 4, 1))
+    # Philox4x32-10 known-answer (Random123 kat_vectors: ctr = key = 0)
+    r = orc.philox4x32_10(np.zeros((1, 4), dtype=np.uint64), (0, 0))[0]
+    assert [int(v) for v in r] == [0x6627E8D5, 0xE169C58D, 0xBC57AC4C, 0x9B00DBD8]
