@@ -1,0 +1,74 @@
+"""ctypes binding of libamuse_hip.so (include/amuse_hip.h).
+
+There is NO CPU fallback: if the HIP library is missing or fails to load, importing a symbol from
+here raises.  (The oracle under oracle/ is test infrastructure and is never imported from here.)
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from pathlib import Path
+
+_HERE = Path(__file__).resolve().parent
+LIB_PATH = _HERE / "libamuse_hip.so"
+
+PREC_F32, PREC_BF16 = 0, 1
+QUAT_P3D, QUAT_LEGACY = 0, 1
+ABI_VERSION = 1
+
+EXPORTS = [
+    "amuse_abi_version", "amuse_last_error", "amuse_create", "amuse_destroy", "amuse_set_schedule",
+    "amuse_sample", "amuse_denoise_step", "amuse_vae_decode", "amuse_diffusion_backward",
+    "amuse_counter_normal", "amuse_set_clips_per_group",
+]
+
+
+class AmuseHipError(RuntimeError):
+    pass
+
+
+class Schedule(C.Structure):
+    _fields_ = [("n_steps", C.c_int), ("timesteps", C.POINTER(C.c_int)), ("coef", C.POINTER(C.c_float)),
+                ("freqs", C.POINTER(C.c_float))]
+
+
+_lib = None
+
+
+def load() -> C.CDLL:
+    """Load the shared library and declare every prototype.  Raises if it is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not LIB_PATH.exists():
+        raise AmuseHipError(
+            f"{LIB_PATH} is missing - build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            f"or `make -C amuse_amd/csrc`.  amuse_amd has no CPU fallback.")
+    lib = C.CDLL(str(LIB_PATH))
+    vp, fp, ip = C.c_void_p, C.c_void_p, C.POINTER(C.c_int)  # device pointers travel as void*
+    u64 = C.c_uint64
+    lib.amuse_abi_version.restype = C.c_int
+    lib.amuse_last_error.restype = C.c_char_p
+    lib.amuse_create.restype = vp
+    lib.amuse_create.argtypes = [C.c_int, C.POINTER(C.c_float), C.c_size_t, C.POINTER(C.c_float), C.c_size_t]
+    lib.amuse_destroy.restype = None
+    lib.amuse_destroy.argtypes = [vp]
+    lib.amuse_set_schedule.argtypes = [vp, C.POINTER(Schedule), vp]
+    lib.amuse_sample.argtypes = [vp, fp, fp, fp, C.c_int, C.c_int, u64, u64, fp, fp, fp, fp, vp]
+    lib.amuse_denoise_step.argtypes = [vp, fp, C.c_int, fp, fp, fp, C.c_int, C.c_int, fp, fp, vp]
+    lib.amuse_vae_decode.argtypes = [vp, fp, ip, C.c_int, C.c_int, C.c_int, fp, fp, fp, vp]
+    lib.amuse_diffusion_backward.argtypes = [vp, fp, fp, fp, C.c_int, C.c_int, C.c_int, u64, u64, fp, fp, fp, fp, fp, vp]
+    lib.amuse_counter_normal.argtypes = [vp, u64, u64, C.c_int, C.c_int, C.c_int, fp, vp]
+    lib.amuse_set_clips_per_group.argtypes = [vp, C.c_int]
+    for n in ("amuse_set_schedule", "amuse_sample", "amuse_denoise_step", "amuse_vae_decode",
+              "amuse_diffusion_backward", "amuse_counter_normal", "amuse_set_clips_per_group"):
+        getattr(lib, n).restype = C.c_int
+    if lib.amuse_abi_version() != ABI_VERSION:
+        raise AmuseHipError(f"ABI mismatch: library {lib.amuse_abi_version()} vs binding {ABI_VERSION}")
+    _lib = lib
+    return lib
+
+
+def check(rc: int) -> None:
+    if rc != 0:
+        raise AmuseHipError(f"libamuse_hip error {rc}: {load().amuse_last_error().decode()}")

@@ -1,0 +1,569 @@
+// C ABI of libamuse_hip.so (include/amuse_hip.h): context, weight packing into MFMA-fragment
+// streams, workspace, and the launch sequences.  Host code only - kernels live in k_*.hip.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/amuse_hip.h"
+#include "amuse_dev.hpp"
+#include "amuse_kernels.hpp"
+
+using namespace amuse;
+
+namespace {
+
+thread_local char g_err[512] = "";
+
+int fail(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+#define HIP_TRY(expr)                                                                                   \
+    do {                                                                                                \
+        hipError_t e_ = (expr);                                                                         \
+        if (e_ != hipSuccess) return fail(AMUSE_EHIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+    } while (0)
+
+// ---------------------------------------------------------------- state-dict index (order = reference)
+struct ParamIndex {
+    std::map<std::string, std::pair<size_t, size_t>> m;  // name -> (offset, numel)
+    size_t total = 0;
+    void add(const std::string& n, size_t numel) { m[n] = {total, numel}; total += numel; }
+};
+
+void enc_layer(ParamIndex& P, const std::string& p) {
+    P.add(p + ".self_attn.in_proj_weight", 384 * 128); P.add(p + ".self_attn.in_proj_bias", 384);
+    P.add(p + ".self_attn.out_proj.weight", 128 * 128); P.add(p + ".self_attn.out_proj.bias", 128);
+    P.add(p + ".linear1.weight", 512 * 128); P.add(p + ".linear1.bias", 512);
+    P.add(p + ".linear2.weight", 128 * 512); P.add(p + ".linear2.bias", 128);
+    P.add(p + ".norm1.weight", 128); P.add(p + ".norm1.bias", 128);
+    P.add(p + ".norm2.weight", 128); P.add(p + ".norm2.bias", 128);
+}
+void dec_layer(ParamIndex& P, const std::string& p) {
+    P.add(p + ".self_attn.in_proj_weight", 384 * 128); P.add(p + ".self_attn.in_proj_bias", 384);
+    P.add(p + ".self_attn.out_proj.weight", 128 * 128); P.add(p + ".self_attn.out_proj.bias", 128);
+    P.add(p + ".multihead_attn.in_proj_weight", 384 * 128); P.add(p + ".multihead_attn.in_proj_bias", 384);
+    P.add(p + ".multihead_attn.out_proj.weight", 128 * 128); P.add(p + ".multihead_attn.out_proj.bias", 128);
+    P.add(p + ".linear1.weight", 512 * 128); P.add(p + ".linear1.bias", 512);
+    P.add(p + ".linear2.weight", 128 * 512); P.add(p + ".linear2.bias", 128);
+    for (const char* n : {"norm1", "norm2", "norm3"}) { P.add(p + "." + n + ".weight", 128); P.add(p + "." + n + ".bias", 128); }
+}
+std::string blk_name(const std::string& prefix, int blk) {
+    if (blk < 4) return prefix + ".input_blocks." + std::to_string(blk);
+    if (blk == 4) return prefix + ".middle_block";
+    return prefix + ".output_blocks." + std::to_string(blk - 5);
+}
+void skip_stack(ParamIndex& P, const std::string& prefix, bool dec) {
+    P.add(prefix + ".norm.weight", 128); P.add(prefix + ".norm.bias", 128);
+    for (int b = 0; b < 9; ++b) dec ? dec_layer(P, blk_name(prefix, b)) : enc_layer(P, blk_name(prefix, b));
+    for (int i = 0; i < 4; ++i) {
+        P.add(prefix + ".linear_blocks." + std::to_string(i) + ".weight", 128 * 256);
+        P.add(prefix + ".linear_blocks." + std::to_string(i) + ".bias", 128);
+    }
+}
+ParamIndex denoiser_index() {
+    ParamIndex P;
+    P.add("time_embedding.linear_1.weight", 128 * 256); P.add("time_embedding.linear_1.bias", 128);
+    P.add("time_embedding.linear_2.weight", 128 * 128); P.add("time_embedding.linear_2.bias", 128);
+    for (const char* n : {"con", "emo", "sty"}) {
+        P.add(std::string("emb_proj_") + n + ".1.weight", 128 * 256);
+        P.add(std::string("emb_proj_") + n + ".1.bias", 128);
+    }
+    P.add("query_pos.pe", 500 * 128); P.add("mem_pos.pe", 500 * 128);
+    skip_stack(P, "encoder", false);
+    return P;
+}
+ParamIndex prior_index() {
+    ParamIndex P;
+    P.add("global_motion_token", 2 * 128);
+    P.add("query_pos_encoder.pe", 500 * 128); P.add("query_pos_decoder.pe", 500 * 128);
+    skip_stack(P, "encoder", false);
+    skip_stack(P, "decoder", true);
+    P.add("skel_embedding.weight", 128 * 333); P.add("skel_embedding.bias", 128);
+    P.add("final_layer.weight", 333 * 128); P.add("final_layer.bias", 333);
+    return P;
+}
+struct Params {
+    const ParamIndex& idx;
+    const float* base;
+    const float* get(const std::string& n) const { return base + idx.m.at(n).first; }
+};
+
+// ---------------------------------------------------------------- MFMA-fragment packing (see amuse_dev.hpp)
+uint16_t f2bf(float f) {  // round-to-nearest-even, as v_cvt_pk_bf16_f32
+    uint32_t x;
+    memcpy(&x, &f, 4);
+    if ((x & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((x >> 16) | 0x40);
+    x += 0x7fffu + ((x >> 16) & 1u);
+    return (uint16_t)(x >> 16);
+}
+// W: [n_out x K] row-major.  Appends units for (k-tile outer, out-tile inner).
+void pack_gemm(std::vector<uint4>& out, int prec, const float* W, int n_out, int K, const std::vector<int>& otiles,
+               const std::vector<int>& ktiles) {
+    auto at = [&](int row, int col) -> float { return row < n_out ? W[(size_t)row * K + col] : 0.f; };
+    if (prec == PREC_F32) {
+        for (int t : ktiles)
+            for (int o : otiles)
+                for (int lane = 0; lane < 64; ++lane) {
+                    const int g = lane >> 4, i = lane & 15;
+                    float v[4];
+                    for (int m = 0; m < 4; ++m) v[m] = at(16 * o + i, 16 * t + 4 * g + m);
+                    uint4 u;
+                    memcpy(&u, v, 16);
+                    out.push_back(u);
+                }
+    } else {
+        for (size_t c = 0; c + 1 < ktiles.size(); c += 2) {
+            const int t0 = ktiles[c], t1 = ktiles[c + 1];
+            for (int o : otiles)
+                for (int lane = 0; lane < 64; ++lane) {
+                    const int g = lane >> 4, i = lane & 15;
+                    uint16_t v[8];
+                    for (int e = 0; e < 4; ++e) {
+                        v[e] = f2bf(at(16 * o + i, 16 * t0 + 4 * g + e));
+                        v[4 + e] = f2bf(at(16 * o + i, 16 * t1 + 4 * g + e));
+                    }
+                    uint4 u;
+                    memcpy(&u, v, 16);
+                    out.push_back(u);
+                }
+        }
+    }
+}
+std::vector<int> range(int a, int b) { std::vector<int> r; for (int i = a; i < b; ++i) r.push_back(i); return r; }
+
+void fill_block_pvec(float* pv, const Params& P, const std::string& p, bool dec) {
+    memcpy(pv + PV_IN_B, P.get(p + ".self_attn.in_proj_bias"), 384 * 4);
+    memcpy(pv + PV_OUT_B, P.get(p + ".self_attn.out_proj.bias"), 128 * 4);
+    memcpy(pv + PV_L1_B, P.get(p + ".linear1.bias"), 512 * 4);
+    memcpy(pv + PV_L2_B, P.get(p + ".linear2.bias"), 128 * 4);
+    memcpy(pv + PV_LN1_W, P.get(p + ".norm1.weight"), 128 * 4); memcpy(pv + PV_LN1_B, P.get(p + ".norm1.bias"), 128 * 4);
+    memcpy(pv + PV_LN2_W, P.get(p + ".norm2.weight"), 128 * 4); memcpy(pv + PV_LN2_B, P.get(p + ".norm2.bias"), 128 * 4);
+    if (dec) { memcpy(pv + PV_LN3_W, P.get(p + ".norm3.weight"), 128 * 4); memcpy(pv + PV_LN3_B, P.get(p + ".norm3.bias"), 128 * 4); }
+}
+std::vector<float> build_pvec(const Params& P, const std::string& prefix, bool dec) {
+    std::vector<float> pv(PV_TOTAL, 0.f);
+    for (int b = 0; b < 9; ++b) fill_block_pvec(pv.data() + b * PV_BLOCK, P, blk_name(prefix, b), dec);
+    for (int i = 0; i < 4; ++i)
+        memcpy(pv.data() + PV_SKIP_B + i * 128, P.get(prefix + ".linear_blocks." + std::to_string(i) + ".bias"), 128 * 4);
+    memcpy(pv.data() + PV_FINAL_W, P.get(prefix + ".norm.weight"), 128 * 4);
+    memcpy(pv.data() + PV_FINAL_B, P.get(prefix + ".norm.bias"), 128 * 4);
+    return pv;
+}
+// the per-wave pieces shared by encoder and decoder blocks
+void pack_qkv(std::vector<uint4>& s, int prec, const float* in_w, int h, bool v_separate) {
+    if (v_separate) {  // sampler: q,k tiles as one 4-tile GEMM, then v (operand-swapped on the device)
+        pack_gemm(s, prec, in_w, 384, 128, {2 * h, 2 * h + 1, 8 + 2 * h, 8 + 2 * h + 1}, range(0, 8));
+        pack_gemm(s, prec, in_w, 384, 128, {16 + 2 * h, 16 + 2 * h + 1}, range(0, 8));
+    } else {
+        pack_gemm(s, prec, in_w, 384, 128, {2 * h, 2 * h + 1, 8 + 2 * h, 8 + 2 * h + 1, 16 + 2 * h, 16 + 2 * h + 1}, range(0, 8));
+    }
+}
+void pack_outproj_ffn(std::vector<uint4>& s, int prec, const Params& P, const std::string& p, int w) {
+    pack_gemm(s, prec, P.get(p + ".self_attn.out_proj.weight"), 128, 128, range(0, 8), {2 * w, 2 * w + 1});
+    pack_gemm(s, prec, P.get(p + ".linear1.weight"), 512, 128, range(8 * w, 8 * w + 8), range(0, 8));
+    pack_gemm(s, prec, P.get(p + ".linear2.weight"), 128, 512, range(0, 8), range(8 * w, 8 * w + 8));
+}
+void pack_skiplin(std::vector<uint4>& s, int prec, const Params& P, const std::string& prefix, int i, int w) {
+    pack_gemm(s, prec, P.get(prefix + ".linear_blocks." + std::to_string(i) + ".weight"), 128, 256, range(0, 8),
+              range(4 * w, 4 * w + 4));
+}
+
+template <typename T>
+int upload(T** dst, const void* src, size_t bytes) {
+    HIP_TRY(hipMalloc((void**)dst, bytes));
+    HIP_TRY(hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice));
+    return 0;
+}
+std::vector<float> transpose(const float* w, int rows, int cols) {  // [rows][cols] -> [cols][rows]
+    std::vector<float> t((size_t)rows * cols);
+    for (int r = 0; r < rows; ++r)
+        for (int c = 0; c < cols; ++c) t[(size_t)c * rows + r] = w[(size_t)r * cols + c];
+    return t;
+}
+
+}  // namespace
+
+struct amuse_ctx {
+    int device = 0;
+    int clips_per_group = 0;
+    // denoiser
+    uint4* den_w[2] = {nullptr, nullptr};
+    uint32_t den_wave_units[2] = {0, 0};
+    float* den_pvec = nullptr;
+    float* den_pe = nullptr;           // [500][128]
+    float* den_freqs = nullptr;        // [128]
+    float *te_w1t = nullptr, *te_b1 = nullptr, *te_w2t = nullptr, *te_b2 = nullptr;
+    float* cond_wt[3] = {nullptr, nullptr, nullptr};
+    float* cond_b[3] = {nullptr, nullptr, nullptr};
+    // prior decoder
+    uint4* vae_w[2] = {nullptr, nullptr};
+    uint32_t vae_stage_base[2][kVaeStages];
+    uint32_t vae_stage_units[2][kVaeStages];
+    float *vae_pvec = nullptr, *vae_final_bias = nullptr, *vae_pe = nullptr;
+    float *vae_wv_t = nullptr, *vae_bv = nullptr, *vae_wo_t = nullptr, *vae_bo = nullptr;
+    // schedule
+    int T = 0;
+    int* d_timesteps = nullptr;
+    float *d_coef = nullptr, *d_time_tok = nullptr;
+    int* d_ts1 = nullptr;
+    float *d_tt1 = nullptr, *d_coef1 = nullptr;
+    // workspaces
+    float* cond_tok = nullptr; size_t cond_cap = 0;
+    float* lat_tmp = nullptr; size_t lat_cap = 0;
+    float* vae_ws = nullptr; size_t vae_cap = 0;  // clips
+    int* d_lengths = nullptr; size_t len_cap = 0;
+    std::vector<void*> owned;
+};
+
+namespace {
+constexpr int kVaeChunk = 512;
+constexpr size_t kVaeFloatsPerClip = (size_t)kFrames * kD * (1 + 3 + 1 + 4) + kLayers * kD;  // x, qkv, o, skip, ca
+
+int ensure(float** p, size_t* cap, size_t need_floats) {
+    if (*cap >= need_floats) return 0;
+    if (*p) HIP_TRY(hipFree(*p));
+    *p = nullptr; *cap = 0;
+    HIP_TRY(hipMalloc((void**)p, need_floats * sizeof(float)));
+    *cap = need_floats;
+    return 0;
+}
+
+int build_ctx(amuse_ctx* c, const float* den, const float* pri) {
+    static const ParamIndex DI = denoiser_index(), PI = prior_index();
+    const Params D{DI, den}, Pp{PI, pri};
+    // ---- denoiser weight streams: [wave][per-step units]
+    for (int prec = 0; prec < 2; ++prec) {
+        std::vector<uint4> all;
+        size_t per_wave = 0;
+        for (int w = 0; w < 4; ++w) {
+            std::vector<uint4> s;
+            for (int b = 0; b < 9; ++b) {
+                const std::string p = blk_name("encoder", b);
+                if (b >= 5) pack_skiplin(s, prec, D, "encoder", b - 5, w);
+                pack_qkv(s, prec, D.get(p + ".self_attn.in_proj_weight"), w, true);
+                pack_outproj_ffn(s, prec, D, p, w);
+            }
+            if (w == 0) per_wave = s.size();
+            else if (s.size() != per_wave) return fail(AMUSE_ESTATE, "internal: uneven denoiser wave streams");
+            all.insert(all.end(), s.begin(), s.end());
+        }
+        c->den_wave_units[prec] = (uint32_t)(per_wave / 64);
+        if (upload(&c->den_w[prec], all.data(), all.size() * sizeof(uint4))) return AMUSE_EHIP;
+    }
+    {
+        auto pv = build_pvec(D, "encoder", false);
+        if (upload(&c->den_pvec, pv.data(), pv.size() * 4)) return AMUSE_EHIP;
+        if (upload(&c->den_pe, D.get("query_pos.pe"), 500 * 128 * 4)) return AMUSE_EHIP;
+        float fr[128];
+        for (int k = 0; k < 128; ++k) fr[k] = expf(-logf(10000.f) * (float)k / 128.f);
+        if (upload(&c->den_freqs, fr, sizeof(fr))) return AMUSE_EHIP;
+        auto w1t = transpose(D.get("time_embedding.linear_1.weight"), 128, 256);
+        auto w2t = transpose(D.get("time_embedding.linear_2.weight"), 128, 128);
+        if (upload(&c->te_w1t, w1t.data(), w1t.size() * 4) || upload(&c->te_w2t, w2t.data(), w2t.size() * 4) ||
+            upload(&c->te_b1, D.get("time_embedding.linear_1.bias"), 512) ||
+            upload(&c->te_b2, D.get("time_embedding.linear_2.bias"), 512))
+            return AMUSE_EHIP;
+        const char* names[3] = {"con", "emo", "sty"};
+        for (int n = 0; n < 3; ++n) {
+            auto wt = transpose(D.get(std::string("emb_proj_") + names[n] + ".1.weight"), 128, 256);
+            if (upload(&c->cond_wt[n], wt.data(), wt.size() * 4) ||
+                upload(&c->cond_b[n], D.get(std::string("emb_proj_") + names[n] + ".1.bias"), 512))
+                return AMUSE_EHIP;
+        }
+    }
+    // ---- VAE decoder weight streams: [stage][wave][units]
+    for (int prec = 0; prec < 2; ++prec) {
+        std::vector<uint4> all;
+        for (int st = 0; st < kVaeStages; ++st) {
+            c->vae_stage_base[prec][st] = (uint32_t)(all.size() / 64);
+            size_t per_wave = 0;
+            for (int w = 0; w < 4; ++w) {
+                std::vector<uint4> s;
+                if (st >= 1) {
+                    const int b = st - 1;
+                    pack_outproj_ffn(s, prec, Pp, blk_name("decoder", b), w);
+                    if (b >= 4 && b <= 7) pack_skiplin(s, prec, Pp, "decoder", b - 4, w);
+                }
+                if (st < 9) pack_qkv(s, prec, Pp.get(blk_name("decoder", st) + ".self_attn.in_proj_weight"), w, false);
+                else pack_gemm(s, prec, Pp.get("final_layer.weight"), kFeats, 128, range(6 * w, 6 * w + 6), range(0, 8));
+                if (w == 0) per_wave = s.size();
+                else if (s.size() != per_wave) return fail(AMUSE_ESTATE, "internal: uneven vae wave streams");
+                all.insert(all.end(), s.begin(), s.end());
+            }
+            c->vae_stage_units[prec][st] = (uint32_t)(per_wave / 64);
+        }
+        if (upload(&c->vae_w[prec], all.data(), all.size() * sizeof(uint4))) return AMUSE_EHIP;
+    }
+    {
+        auto pv = build_pvec(Pp, "decoder", true);
+        if (upload(&c->vae_pvec, pv.data(), pv.size() * 4)) return AMUSE_EHIP;
+        std::vector<float> fb(16 * kFeatTiles, 0.f);
+        memcpy(fb.data(), Pp.get("final_layer.bias"), kFeats * 4);
+        if (upload(&c->vae_final_bias, fb.data(), fb.size() * 4)) return AMUSE_EHIP;
+        if (upload(&c->vae_pe, Pp.get("query_pos_decoder.pe"), 500 * 128 * 4)) return AMUSE_EHIP;
+        std::vector<float> wv_t(9 * 128 * 128), wo_t(9 * 128 * 128), bv(9 * 128), bo(9 * 128);
+        for (int b = 0; b < 9; ++b) {
+            const std::string p = blk_name("decoder", b) + ".multihead_attn";
+            auto t1 = transpose(Pp.get(p + ".in_proj_weight") + 256 * 128, 128, 128);
+            auto t2 = transpose(Pp.get(p + ".out_proj.weight"), 128, 128);
+            memcpy(wv_t.data() + (size_t)b * 128 * 128, t1.data(), 128 * 128 * 4);
+            memcpy(wo_t.data() + (size_t)b * 128 * 128, t2.data(), 128 * 128 * 4);
+            memcpy(bv.data() + b * 128, Pp.get(p + ".in_proj_bias") + 256, 512);
+            memcpy(bo.data() + b * 128, Pp.get(p + ".out_proj.bias"), 512);
+        }
+        if (upload(&c->vae_wv_t, wv_t.data(), wv_t.size() * 4) || upload(&c->vae_wo_t, wo_t.data(), wo_t.size() * 4) ||
+            upload(&c->vae_bv, bv.data(), bv.size() * 4) || upload(&c->vae_bo, bo.data(), bo.size() * 4))
+            return AMUSE_EHIP;
+    }
+    HIP_TRY(hipMalloc((void**)&c->d_timesteps, AMUSE_MAX_STEPS * sizeof(int)));
+    HIP_TRY(hipMalloc((void**)&c->d_coef, AMUSE_MAX_STEPS * 8 * sizeof(float)));
+    HIP_TRY(hipMalloc((void**)&c->d_time_tok, AMUSE_MAX_STEPS * kD * sizeof(float)));
+    HIP_TRY(hipMalloc((void**)&c->d_ts1, sizeof(int)));
+    HIP_TRY(hipMalloc((void**)&c->d_tt1, kD * sizeof(float)));
+    HIP_TRY(hipMalloc((void**)&c->d_coef1, 8 * sizeof(float)));
+    HIP_TRY(hipMemset(c->d_coef1, 0, 8 * sizeof(float)));
+    return 0;
+}
+
+int cond_tokens(amuse_ctx* c, const float* con, const float* emo, const float* sty, int B, int* S_out, hipStream_t s) {
+    CondArgs ca{};
+    int n = 0;
+    const float* zs[3] = {con, emo, sty};
+    for (int i = 0; i < 3; ++i)
+        if (zs[i]) { ca.z[n] = zs[i]; ca.wt[n] = c->cond_wt[i]; ca.bias[n] = c->cond_b[i]; ++n; }
+    if (int e = ensure(&c->cond_tok, &c->cond_cap, (size_t)B * 3 * kD)) return e;
+    ca.pe = c->den_pe; ca.out = c->cond_tok; ca.B = B; ca.ncond = n;
+    HIP_TRY(launch_cond_tokens(ca, s));
+    *S_out = 2 + n;
+    return 0;
+}
+
+int pick_group(const amuse_ctx* c, int B, int S) {
+    const int gmax = 16 / S;
+    int g = c->clips_per_group;
+    if (g <= 0) g = (B + 255) / 256;  // one clip tile per CU until the chip is full, then fatten the tiles
+    if (g > gmax) g = gmax;
+    if (g < 1) g = 1;
+    return g;
+}
+
+int check_common(amuse_ctx* c, const float* con, int B, int precision) {
+    if (!c) return fail(AMUSE_EINVAL, "ctx is NULL");
+    if (!con) return fail(AMUSE_EINVAL, "con is NULL (the content embedding is mandatory, denoiser.py:153-157)");
+    if (B < 1) return fail(AMUSE_EINVAL, "B must be >= 1, got %d", B);
+    if (precision != AMUSE_PREC_F32 && precision != AMUSE_PREC_BF16) return fail(AMUSE_EINVAL, "bad precision %d", precision);
+    HIP_TRY(hipSetDevice(c->device));
+    return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int amuse_abi_version(void) { return AMUSE_ABI_VERSION; }
+const char* amuse_last_error(void) { return g_err; }
+
+amuse_ctx* amuse_create(int device, const float* denoiser_params, size_t n_denoiser, const float* prior_params,
+                        size_t n_prior) {
+    if (!denoiser_params || !prior_params) { fail(AMUSE_EINVAL, "NULL parameter array"); return nullptr; }
+    if (n_denoiser != AMUSE_DENOISER_PARAMS || n_prior != AMUSE_PRIOR_PARAMS) {
+        fail(AMUSE_EINVAL, "parameter count mismatch: denoiser %zu (want %u), prior %zu (want %u)", n_denoiser,
+             AMUSE_DENOISER_PARAMS, n_prior, AMUSE_PRIOR_PARAMS);
+        return nullptr;
+    }
+    if (denoiser_index().total != AMUSE_DENOISER_PARAMS || prior_index().total != AMUSE_PRIOR_PARAMS) {
+        fail(AMUSE_ESTATE, "internal: state-dict index does not add up");
+        return nullptr;
+    }
+    hipError_t e = hipSetDevice(device);
+    if (e != hipSuccess) { fail(AMUSE_EHIP, "hipSetDevice(%d): %s", device, hipGetErrorString(e)); return nullptr; }
+    amuse_ctx* c = new amuse_ctx();
+    c->device = device;
+    if (build_ctx(c, denoiser_params, prior_params) != 0) { amuse_destroy(c); return nullptr; }
+    return c;
+}
+
+void amuse_destroy(amuse_ctx* c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    void* ptrs[] = {c->den_w[0], c->den_w[1], c->den_pvec, c->den_pe, c->den_freqs, c->te_w1t, c->te_b1, c->te_w2t,
+                    c->te_b2, c->cond_wt[0], c->cond_wt[1], c->cond_wt[2], c->cond_b[0], c->cond_b[1], c->cond_b[2],
+                    c->vae_w[0], c->vae_w[1], c->vae_pvec, c->vae_final_bias, c->vae_pe, c->vae_wv_t, c->vae_bv,
+                    c->vae_wo_t, c->vae_bo, c->d_timesteps, c->d_coef, c->d_time_tok, c->d_ts1, c->d_tt1, c->d_coef1,
+                    c->cond_tok, c->lat_tmp, c->vae_ws, c->d_lengths};
+    for (void* p : ptrs)
+        if (p) (void)hipFree(p);
+    delete c;
+}
+
+int amuse_set_clips_per_group(amuse_ctx* c, int g) {
+    if (!c) return fail(AMUSE_EINVAL, "ctx is NULL");
+    if (g < 0 || g > 5) return fail(AMUSE_EINVAL, "clips per group must be 0 (auto) .. 5, got %d", g);
+    c->clips_per_group = g;
+    return 0;
+}
+
+int amuse_set_schedule(amuse_ctx* c, const amuse_schedule* s, void* stream) {
+    if (!c || !s) return fail(AMUSE_EINVAL, "NULL argument");
+    if (s->n_steps < 1 || s->n_steps > AMUSE_MAX_STEPS) return fail(AMUSE_EINVAL, "n_steps %d out of range", s->n_steps);
+    if (!s->timesteps || !s->coef) return fail(AMUSE_EINVAL, "schedule tables are NULL");
+    for (int i = 0; i < s->n_steps; ++i) {
+        if (s->timesteps[i] < 0) return fail(AMUSE_EINVAL, "negative timestep at step %d", i);
+        if (!(s->coef[i * 8 + 1] > 0.f)) return fail(AMUSE_EINVAL, "sqrt(alpha_bar) must be > 0 at step %d", i);
+    }
+    HIP_TRY(hipSetDevice(c->device));
+    hipStream_t st = (hipStream_t)stream;
+    HIP_TRY(hipStreamSynchronize(st));
+    HIP_TRY(hipMemcpy(c->d_timesteps, s->timesteps, s->n_steps * sizeof(int), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(c->d_coef, s->coef, (size_t)s->n_steps * 8 * sizeof(float), hipMemcpyHostToDevice));
+    if (s->freqs) HIP_TRY(hipMemcpy(c->den_freqs, s->freqs, 128 * sizeof(float), hipMemcpyHostToDevice));
+    HIP_TRY(launch_time_tokens(c->d_timesteps, s->n_steps, c->den_freqs, c->te_w1t, c->te_b1, c->te_w2t, c->te_b2,
+                               c->den_pe + kD, c->d_time_tok, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    c->T = s->n_steps;
+    return 0;
+}
+
+int amuse_sample(amuse_ctx* c, const float* con, const float* emo, const float* sty, int B, int precision,
+                 uint64_t seed, uint64_t clip_index0, const float* x_init, const float* step_noise,
+                 float* latents_out, float* traj_out, void* stream) {
+    if (int e = check_common(c, con, B, precision)) return e;
+    if (c->T < 1) return fail(AMUSE_ESTATE, "amuse_set_schedule has not been called");
+    if (!latents_out) return fail(AMUSE_EINVAL, "latents_out is NULL");
+    hipStream_t st = (hipStream_t)stream;
+    int S = 0;
+    if (int e = cond_tokens(c, con, emo, sty, B, &S, st)) return e;
+    SampleArgs a{};
+    a.wstream = c->den_w[precision]; a.wave_units = c->den_wave_units[precision];
+    a.pvec = c->den_pvec; a.time_tok = c->d_time_tok; a.cond_tok = c->cond_tok; a.pe0 = c->den_pe;
+    a.coef = c->d_coef; a.x_init = x_init; a.step_noise = step_noise;
+    a.latents_out = latents_out; a.traj_out = traj_out; a.eps_out = nullptr; a.tap_out = nullptr;
+    a.seed = seed; a.clip0 = clip_index0;
+    a.B = B; a.T = c->T; a.S = S; a.G = pick_group(c, B, S); a.no_update = 0;
+    HIP_TRY(launch_sample(a, precision, st));
+    return 0;
+}
+
+int amuse_denoise_step(amuse_ctx* c, const float* x_t, int timestep, const float* con, const float* emo,
+                       const float* sty, int B, int precision, float* eps_out, float* tap_out, void* stream) {
+    if (int e = check_common(c, con, B, precision)) return e;
+    if (!x_t || !eps_out) return fail(AMUSE_EINVAL, "x_t / eps_out is NULL");
+    if (timestep < 0) return fail(AMUSE_EINVAL, "negative timestep");
+    hipStream_t st = (hipStream_t)stream;
+    HIP_TRY(hipMemcpyAsync(c->d_ts1, &timestep, sizeof(int), hipMemcpyHostToDevice, st));
+    HIP_TRY(hipStreamSynchronize(st));  // `timestep` lives on this call's stack
+    HIP_TRY(launch_time_tokens(c->d_ts1, 1, c->den_freqs, c->te_w1t, c->te_b1, c->te_w2t, c->te_b2, c->den_pe + kD,
+                               c->d_tt1, st));
+    int S = 0;
+    if (int e = cond_tokens(c, con, emo, sty, B, &S, st)) return e;
+    SampleArgs a{};
+    a.wstream = c->den_w[precision]; a.wave_units = c->den_wave_units[precision];
+    a.pvec = c->den_pvec; a.time_tok = c->d_tt1; a.cond_tok = c->cond_tok; a.pe0 = c->den_pe;
+    a.coef = c->d_coef1; a.x_init = x_t; a.step_noise = nullptr;
+    a.latents_out = nullptr; a.traj_out = nullptr; a.eps_out = eps_out; a.tap_out = tap_out;
+    a.seed = 0; a.clip0 = 0;
+    a.B = B; a.T = 1; a.S = S; a.G = pick_group(c, B, S); a.no_update = 1;
+    HIP_TRY(launch_sample(a, precision, st));
+    return 0;
+}
+
+int amuse_vae_decode(amuse_ctx* c, const float* z, const int* lengths, int B, int precision, int quat_mode,
+                     float* feats_out, float* poses_out, float* trans_out, void* stream) {
+    if (!c) return fail(AMUSE_EINVAL, "ctx is NULL");
+    if (!z) return fail(AMUSE_EINVAL, "z is NULL");
+    if (B < 1) return fail(AMUSE_EINVAL, "B must be >= 1, got %d", B);
+    if (precision != AMUSE_PREC_F32 && precision != AMUSE_PREC_BF16) return fail(AMUSE_EINVAL, "bad precision %d", precision);
+    if (quat_mode != AMUSE_QUAT_P3D && quat_mode != AMUSE_QUAT_LEGACY) return fail(AMUSE_EINVAL, "bad quat_mode %d", quat_mode);
+    HIP_TRY(hipSetDevice(c->device));
+    hipStream_t st = (hipStream_t)stream;
+    if (lengths) {
+        for (int b = 0; b < B; ++b)
+            if (lengths[b] < 1 || lengths[b] > kFrames) return fail(AMUSE_EINVAL, "lengths[%d] = %d not in 1..300", b, lengths[b]);
+        if (c->len_cap < (size_t)B) {
+            if (c->d_lengths) HIP_TRY(hipFree(c->d_lengths));
+            c->d_lengths = nullptr; c->len_cap = 0;
+            HIP_TRY(hipMalloc((void**)&c->d_lengths, (size_t)B * sizeof(int)));
+            c->len_cap = B;
+        }
+        HIP_TRY(hipMemcpyAsync(c->d_lengths, lengths, (size_t)B * sizeof(int), hipMemcpyHostToDevice, st));
+        HIP_TRY(hipStreamSynchronize(st));
+    }
+    const int chunk = B < kVaeChunk ? B : kVaeChunk;
+    if (c->vae_cap < (size_t)chunk) {
+        if (c->vae_ws) HIP_TRY(hipFree(c->vae_ws));
+        c->vae_ws = nullptr; c->vae_cap = 0;
+        HIP_TRY(hipMalloc((void**)&c->vae_ws, (size_t)chunk * kVaeFloatsPerClip * sizeof(float)));
+        c->vae_cap = chunk;
+    }
+    for (int b0 = 0; b0 < B; b0 += chunk) {
+        const int nb = (B - b0) < chunk ? (B - b0) : chunk;
+        const size_t rows = (size_t)nb * kFrames;
+        float* ws = c->vae_ws;
+        VaeRowsArgs ra{};
+        ra.wstream = c->vae_w[precision];
+        memcpy(ra.stage_base, c->vae_stage_base[precision], sizeof(ra.stage_base));
+        memcpy(ra.stage_units, c->vae_stage_units[precision], sizeof(ra.stage_units));
+        ra.pvec = c->vae_pvec; ra.final_bias = c->vae_final_bias; ra.pe = c->vae_pe;
+        ra.x = ws; ws += rows * kD;
+        ra.q = ws; ws += rows * kD;
+        ra.k = ws; ws += rows * kD;
+        ra.v = ws; ws += rows * kD;
+        float* attn_o = ws; ws += rows * kD;
+        ra.attn_o = attn_o;
+        ra.skip = ws; ws += 4 * rows * kD;
+        float* ca = ws;
+        ra.ca = ca;
+        ra.lengths = lengths ? c->d_lengths + b0 : nullptr;
+        ra.feats_out = feats_out ? feats_out + (size_t)b0 * kFrames * kFeats : nullptr;
+        ra.poses_out = poses_out ? poses_out + (size_t)b0 * kFrames * kJoints * 3 : nullptr;
+        ra.trans_out = trans_out ? trans_out + (size_t)b0 * kFrames * 3 : nullptr;
+        ra.B = nb; ra.quat_mode = quat_mode;
+        HIP_TRY(launch_vae_ca(z + (size_t)b0 * kD, c->vae_wv_t, c->vae_bv, c->vae_wo_t, c->vae_bo, ca, nb, st));
+        VaeAttnArgs aa{};
+        aa.q = ra.q; aa.k = ra.k; aa.v = ra.v; aa.lengths = ra.lengths; aa.o = attn_o; aa.B = nb;
+        for (int stage = 0; stage < kVaeStages; ++stage) {
+            ra.stage = stage;
+            HIP_TRY(launch_vae_rows(ra, precision, st));
+            if (stage < kLayers) HIP_TRY(launch_vae_attn(aa, precision, st));
+        }
+    }
+    return 0;
+}
+
+int amuse_diffusion_backward(amuse_ctx* c, const float* con, const float* emo, const float* sty, int B, int precision,
+                             int quat_mode, uint64_t seed, uint64_t clip_index0, const float* x_init,
+                             const float* step_noise, float* latents_out, float* poses_out, float* trans_out,
+                             void* stream) {
+    if (!c) return fail(AMUSE_EINVAL, "ctx is NULL");
+    if (!poses_out || !trans_out) return fail(AMUSE_EINVAL, "poses_out / trans_out is NULL");
+    float* lat = latents_out;
+    if (!lat) {
+        HIP_TRY(hipSetDevice(c->device));
+        if (int e = ensure(&c->lat_tmp, &c->lat_cap, (size_t)B * kD)) return e;
+        lat = c->lat_tmp;
+    }
+    if (int e = amuse_sample(c, con, emo, sty, B, precision, seed, clip_index0, x_init, step_noise, lat, nullptr, stream))
+        return e;
+    return amuse_vae_decode(c, lat, nullptr, B, precision, quat_mode, nullptr, poses_out, trans_out, stream);
+}
+
+int amuse_counter_normal(amuse_ctx* c, uint64_t seed, uint64_t clip_index0, int B, int step, int rng_stream,
+                         float* out, void* stream) {
+    if (!c || !out) return fail(AMUSE_EINVAL, "NULL argument");
+    if (B < 1) return fail(AMUSE_EINVAL, "B must be >= 1");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(launch_counter_normal(seed, clip_index0, B, step, rng_stream, out, (hipStream_t)stream));
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,85 @@
+// Kernel argument blocks + host-callable launchers (defined in k_*.hip, used by amuse_api.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace amuse {
+
+// ---------------------------------------------------------------- sampling loop (k_sampler.hip)
+struct SampleArgs {
+    const uint4* wstream;     // packed denoiser weights for the chosen precision: [4 waves][wave_units][64] x 16 B
+    uint32_t wave_units;      // 1 KiB units per wave for one pass over the network
+    const float* pvec;        // small fp32 parameters (amuse_dev.hpp PV_* layout)
+    const float* time_tok;    // [T][128]  TimestepEmbedding(t_i) + pe[1]
+    const float* cond_tok;    // [B][S-2][128]  emb_proj_*(cond) + pe[2+n]
+    const float* pe0;         // [128] pe[0]
+    const float* coef;        // [T][8] scheduler coefficients (amuse_hip.h)
+    const float* x_init;      // [B][128] or null
+    const float* step_noise;  // [T][B][128] or null
+    float* latents_out;       // [B][128] or null
+    float* traj_out;          // [T][B][128] or null
+    float* eps_out;           // [B][128] or null: eps_hat of the last step
+    float* tap_out;           // [11][16][128] or null (tile 0, step 0)
+    uint64_t seed;
+    uint64_t clip0;
+    int B, T, S, G;
+    int no_update;            // 1: teacher-forced (no scheduler update)
+};
+hipError_t launch_sample(const SampleArgs& a, int precision, hipStream_t stream);
+constexpr int kSampleLdsBytes = 64 * 1024 + 32 * 1024;  // exchange + skip stack
+
+// ---------------------------------------------------------------- one-off prologue kernels (k_misc.hip)
+// time_tok[i][:] = Linear2(SiLU(Linear1([cos|sin](t_i * freqs)))) + pe1     (embeddings.py:245-322)
+hipError_t launch_time_tokens(const int* timesteps_dev, int T, const float* freqs, const float* w1t,
+                              const float* b1, const float* w2t, const float* b2, const float* pe1,
+                              float* out, hipStream_t stream);
+// cond_tok[b][n][:] = Linear(ReLU(z_n[b])) + pe[2+n]                         (denoiser.py:74-79,153-181)
+struct CondArgs {
+    const float* z[3];     // dev [B][256] for the present conditions, in token order
+    const float* wt[3];    // transposed weights [256][128] matching z[n]
+    const float* bias[3];  // [128]
+    const float* pe;       // query_pos.pe [500][128]
+    float* out;            // [B][ncond][128]
+    int B, ncond;
+};
+hipError_t launch_cond_tokens(const CondArgs& a, hipStream_t stream);
+hipError_t launch_counter_normal(uint64_t seed, uint64_t clip0, int B, int step, int rng_stream, float* out,
+                                 hipStream_t stream);
+
+// ---------------------------------------------------------------- VAE decode (k_vae.hip)
+constexpr int kVaeStages = 10;  // stage 0: PE + QKV(0); stage i+1: post-attention of block i (+ QKV(i+1) | final)
+struct VaeRowsArgs {
+    const uint4* wstream;             // packed decoder weights (per precision)
+    uint32_t stage_base[kVaeStages];  // first unit of each stage
+    uint32_t stage_units[kVaeStages]; // units per wave in each stage
+    const float* pvec;                // decoder small params, PV_* layout
+    const float* final_bias;          // [384] final_layer.bias zero-padded
+    const float* pe;                  // query_pos_decoder.pe [500][128]
+    const float* ca;                  // [B][9][128] cross-attention constant per clip/block
+    const int* lengths;               // dev [B] or null
+    float* x;                         // [B*300][128] residual stream (in place)
+    float* q; float* k; float* v;     // [B][4][300][32]
+    const float* attn_o;              // [B*300][128] attention output (heads concatenated)
+    float* skip;                      // [4][B*300][128]
+    float* feats_out;                 // [B][300][333] or null
+    float* poses_out;                 // [B][300][55][3] or null
+    float* trans_out;                 // [B][300][3] or null
+    int B;
+    int stage;                        // 0..9
+    int quat_mode;
+};
+hipError_t launch_vae_rows(const VaeRowsArgs& a, int precision, hipStream_t stream);
+
+struct VaeAttnArgs {
+    const float* q; const float* k; const float* v;  // [B][4][300][32]; q pre-scaled by 1/sqrt(32)
+    const int* lengths;                               // dev [B] or null
+    float* o;                                         // [B*300][128]
+    int B;
+};
+hipError_t launch_vae_attn(const VaeAttnArgs& a, int precision, hipStream_t stream);
+
+// ca[b][blk][:] = out_proj(v_proj(z[b]))   (cross_attention.py:331-336 with a 1-token memory)
+hipError_t launch_vae_ca(const float* z, const float* wv_t /*[9][128][128]*/, const float* bv /*[9][128]*/,
+                         const float* wo_t, const float* bo, float* ca, int B, hipStream_t stream);
+
+}  // namespace amuse

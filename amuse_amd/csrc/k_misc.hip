@@ -1,0 +1,103 @@
+// One-off prologue kernels: step-invariant work hoisted out of the reference's per-step
+// Denoiser.forward (the reference recomputes all of this every step - SURVEY.md 8a rows A3-A5).
+#include "amuse_dev.hpp"
+#include "amuse_kernels.hpp"
+
+namespace amuse {
+namespace {
+
+// Timesteps (sinusoid, flip_sin_to_cos) + TimestepEmbedding MLP + pe[1]   (embeddings.py:245-322)
+// grid = T, block = 128.  Weights are passed transposed ([in][out]) so lane reads coalesce.
+__global__ __launch_bounds__(128) void k_time_tokens(const int* __restrict__ ts, const float* __restrict__ freqs,
+                                                     const float* __restrict__ w1t, const float* __restrict__ b1,
+                                                     const float* __restrict__ w2t, const float* __restrict__ b2,
+                                                     const float* __restrict__ pe1, float* __restrict__ out) {
+    __shared__ float in[kCond];
+    __shared__ float hid[kD];
+    const int j = threadIdx.x;
+    const float ang = (float)ts[blockIdx.x] * freqs[j];
+    in[j] = cosf(ang);        // [cos | sin]: flip_sin_to_cos = true
+    in[kD + j] = sinf(ang);
+    __syncthreads();
+    float acc = 0.f;
+    for (int k = 0; k < kCond; ++k) acc = fmaf(in[k], w1t[k * kD + j], acc);
+    acc += b1[j];
+    hid[j] = acc / (1.0f + expf(-acc));  // SiLU
+    __syncthreads();
+    float o = 0.f;
+    for (int k = 0; k < kD; ++k) o = fmaf(hid[k], w2t[k * kD + j], o);
+    out[(size_t)blockIdx.x * kD + j] = (o + b2[j]) + pe1[j];
+}
+
+// emb_proj_{con,emo,sty}: Linear(ReLU(z)) + pe[2 + n]   (denoiser.py:74-79,153-181).  grid = B, block = 128
+__global__ __launch_bounds__(128) void k_cond_tokens(CondArgs a) {
+    __shared__ float z[kCond];
+    const int j = threadIdx.x, b = blockIdx.x;
+    for (int n = 0; n < a.ncond; ++n) {
+        __syncthreads();
+        z[j] = fmaxf(a.z[n][(size_t)b * kCond + j], 0.f);
+        z[j + kD] = fmaxf(a.z[n][(size_t)b * kCond + kD + j], 0.f);
+        __syncthreads();
+        float acc = 0.f;
+        const float* wt = a.wt[n];
+        for (int k = 0; k < kCond; ++k) acc = fmaf(z[k], wt[k * kD + j], acc);
+        a.out[((size_t)b * a.ncond + n) * kD + j] = (acc + a.bias[n][j]) + a.pe[(size_t)(2 + n) * kD + j];
+    }
+}
+
+__global__ __launch_bounds__(64) void k_counter_normal(uint64_t seed, uint64_t clip0, int B, int step, int rng_stream,
+                                                       float* out) {
+    const int idx = blockIdx.x * 64 + threadIdx.x;  // one Philox call per 4 features
+    if (idx >= B * 32) return;
+    const int b = idx >> 5, q = idx & 31;
+    st4(out + (size_t)b * kD + 4 * q, counter_normal4(seed, clip0 + (uint64_t)b, (uint32_t)step, (uint32_t)q, (uint32_t)rng_stream));
+}
+
+// cross-attention onto a one-token memory: softmax over a single key == 1, so the layer adds
+// out_proj(v_proj(z)) to every row (cross_attention.py:331-336).  grid = (9, B), block = 128.
+__global__ __launch_bounds__(128) void k_vae_ca(const float* __restrict__ z, const float* __restrict__ wv_t,
+                                                const float* __restrict__ bv, const float* __restrict__ wo_t,
+                                                const float* __restrict__ bo, float* __restrict__ ca) {
+    __shared__ float zs[kD];
+    __shared__ float vs[kD];
+    const int j = threadIdx.x, blk = blockIdx.x, b = blockIdx.y;
+    zs[j] = z[(size_t)b * kD + j];
+    __syncthreads();
+    float acc = 0.f;
+    const float* wv = wv_t + (size_t)blk * kD * kD;
+    for (int k = 0; k < kD; ++k) acc = fmaf(zs[k], wv[k * kD + j], acc);
+    vs[j] = acc + bv[blk * kD + j];
+    __syncthreads();
+    float o = 0.f;
+    const float* wo = wo_t + (size_t)blk * kD * kD;
+    for (int k = 0; k < kD; ++k) o = fmaf(vs[k], wo[k * kD + j], o);
+    ca[((size_t)b * kLayers + blk) * kD + j] = o + bo[blk * kD + j];
+}
+
+}  // namespace
+
+hipError_t launch_time_tokens(const int* timesteps_dev, int T, const float* freqs, const float* w1t, const float* b1,
+                              const float* w2t, const float* b2, const float* pe1, float* out, hipStream_t stream) {
+    hipLaunchKernelGGL(k_time_tokens, dim3(T), dim3(128), 0, stream, timesteps_dev, freqs, w1t, b1, w2t, b2, pe1, out);
+    return hipGetLastError();
+}
+
+hipError_t launch_cond_tokens(const CondArgs& a, hipStream_t stream) {
+    hipLaunchKernelGGL(k_cond_tokens, dim3(a.B), dim3(128), 0, stream, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_counter_normal(uint64_t seed, uint64_t clip0, int B, int step, int rng_stream, float* out,
+                                 hipStream_t stream) {
+    hipLaunchKernelGGL(k_counter_normal, dim3((B * 32 + 63) / 64), dim3(64), 0, stream, seed, clip0, B, step,
+                       rng_stream, out);
+    return hipGetLastError();
+}
+
+hipError_t launch_vae_ca(const float* z, const float* wv_t, const float* bv, const float* wo_t, const float* bo,
+                         float* ca, int B, hipStream_t stream) {
+    hipLaunchKernelGGL(k_vae_ca, dim3(kLayers, B), dim3(128), 0, stream, z, wv_t, bv, wo_t, bo, ca);
+    return hipGetLastError();
+}
+
+}  // namespace amuse

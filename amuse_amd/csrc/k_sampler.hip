@@ -1,0 +1,271 @@
+// Persistent sampling kernel: the WHOLE T-step denoising loop of
+// PretrainedLPDM_v1.diffusion_backward (reference models/latent_diffusion/infer_ldm.py:137-161) in one
+// launch - Denoiser.forward (denoiser.py:135-204: 5-token skip-transformer encoder,
+// cross_attention.py:41-64,259-272) and the diffusers scheduler update fused, latent + activations
+// resident in registers for all T steps, no inter-workgroup communication.
+//
+// Work decomposition (gfx950):
+//   workgroup = 4 wavefronts = one tile of G clips (G*S <= 16 token rows, S = 5 tokens per clip).
+//   All four waves hold the same [16 x 128] residual stream in row-lane layout (amuse_dev.hpp).
+//   wave h owns attention head h end to end:  q_h,k_h,v_h = its 6 of the 24 in_proj output tiles;
+//   scores / softmax / PV are three-or-so MFMAs entirely inside the wave (S^T = K.Q^T, O^T = V^T.P^T
+//   so that softmax runs along registers + two xor-shuffles and the result lands in row-lane
+//   layout); out_proj is split-K over heads, FFN1 is split over output features (wave w owns hidden
+//   features 128w..128w+127) and FFN2 is split-K over exactly those features, so a block needs only
+//   TWO workgroup barriers (the two split-K combines through LDS).  The U-Net skip linears are
+//   split-K as well (wave w takes k-tiles 4w..4w+3 of cat(x, skip)).
+//   Each wave streams only its own quarter of the weights, as one sequential pass per step over a
+//   host-packed stream of 1 KiB units (L2-resident: 7.7 MB fp32 / 3.8 MB bf16 for the network).
+#include "amuse_dev.hpp"
+#include "amuse_kernels.hpp"
+
+namespace amuse {
+
+namespace {
+
+template <int PREC>
+__device__ __forceinline__ void attention_head(const f32x4 (&q)[2], const f32x4 (&k)[2], const f32x4 (&v)[2],
+                                               const bool (&kvalid)[4], f32x4 (&o)[2]) {
+    // S^T[j][i] = sum_d K[j][d] Q[i][d]  ->  lane (g, i) holds S[i][4 g + m]
+    f32x4 st = splat4(0.f);
+    if constexpr (PREC == PREC_F32) {
+#pragma unroll
+        for (int td = 0; td < 2; ++td)
+#pragma unroll
+            for (int m = 0; m < 4; ++m) st = mfma_f32(k[td][m], q[td][m], st);
+    } else {
+        st = mfma_bf16(pack_bf16(k[0], k[1]), pack_bf16(q[0], q[1]), st);
+    }
+    float mx = -INFINITY;
+#pragma unroll
+    for (int m = 0; m < 4; ++m) mx = kvalid[m] ? fmaxf(mx, st[m]) : mx;
+    mx = fmaxf(mx, __shfl_xor(mx, 16));
+    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    f32x4 p;
+    float sum = 0.f;
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+        p[m] = kvalid[m] ? expf(st[m] - mx) : 0.f;
+        sum += p[m];
+    }
+    sum += __shfl_xor(sum, 16);
+    sum += __shfl_xor(sum, 32);
+#pragma unroll
+    for (int m = 0; m < 4; ++m) p[m] = p[m] / sum;
+    // O^T[d][i] = sum_j V[j][d] P[i][j]; v is feature-lane: lane (g, d) holds V[4 g + m][d]
+#pragma unroll
+    for (int td = 0; td < 2; ++td) {
+        o[td] = splat4(0.f);
+        if constexpr (PREC == PREC_F32) {
+#pragma unroll
+            for (int m = 0; m < 4; ++m) o[td] = mfma_f32(v[td][m], p[m], o[td]);
+        } else {
+            o[td] = mfma_bf16(pack_bf16(v[td], splat4(0.f)), pack_bf16(p, splat4(0.f)), o[td]);
+        }
+    }
+}
+
+// One TransformerEncoderLayer.forward_post (cross_attention.py:259-272) on the row-lane tile x.
+template <int PREC>
+__device__ __forceinline__ const uint4* encoder_block(f32x4 (&x)[kTiles], const uint4* __restrict__ w,
+                                                      const float* __restrict__ pv, const bool (&kvalid)[4],
+                                                      f32x4* exch, int& parity, int wave, int lane) {
+    const int g = lane >> 4, r = lane & 15;
+    // ---- in_proj: q_h, k_h (row-lane) and v_h (feature-lane) for head h = wave
+    f32x4 qk[4], v[2];
+#pragma unroll
+    for (int o = 0; o < 2; ++o) {
+        qk[o] = ld4(pv + PV_IN_B + 16 * (2 * wave + o) + 4 * g);
+        qk[2 + o] = ld4(pv + PV_IN_B + kD + 16 * (2 * wave + o) + 4 * g);
+        v[o] = splat4(pv[PV_IN_B + 2 * kD + 16 * (2 * wave + o) + r]);
+    }
+    w = gemm_tiles<PREC, 4, kTiles, false>(qk, x, w);
+    w = gemm_tiles<PREC, 2, kTiles, true>(v, x, w);
+    const float scaling = 0.17677669529663687f;  // sqrt(1/32): q * scaling (F.multi_head_attention_forward)
+    f32x4 q[2] = {qk[0] * scaling, qk[1] * scaling};
+    f32x4 k[2] = {qk[2], qk[3]};
+    f32x4 o[2];
+    attention_head<PREC>(q, k, v, kvalid, o);
+    // ---- out_proj, split-K over heads; combine; residual; LayerNorm1
+    f32x4 part[kTiles];
+#pragma unroll
+    for (int t = 0; t < kTiles; ++t) part[t] = splat4(0.f);
+    w = gemm_tiles<PREC, kTiles, 2, false>(part, o, w);
+    exchange_sum(part, exch, parity, wave, lane);
+#pragma unroll
+    for (int t = 0; t < kTiles; ++t) x[t] = x[t] + (part[t] + ld4(pv + PV_OUT_B + 16 * t + 4 * g));
+    layer_norm_rows(x, pv + PV_LN1_W, pv + PV_LN1_B, g);
+    // ---- FFN: linear1 (this wave's 128 hidden features) -> GELU -> linear2 split-K over them
+    f32x4 hid[kTiles];
+#pragma unroll
+    for (int t = 0; t < kTiles; ++t) hid[t] = ld4(pv + PV_L1_B + 16 * (kTiles * wave + t) + 4 * g);
+    w = gemm_tiles<PREC, kTiles, kTiles, false>(hid, x, w);
+#pragma unroll
+    for (int t = 0; t < kTiles; ++t)
+#pragma unroll
+        for (int m = 0; m < 4; ++m) hid[t][m] = gelu_erf(hid[t][m]);
+#pragma unroll
+    for (int t = 0; t < kTiles; ++t) part[t] = splat4(0.f);
+    w = gemm_tiles<PREC, kTiles, kTiles, false>(part, hid, w);
+    exchange_sum(part, exch, parity, wave, lane);
+#pragma unroll
+    for (int t = 0; t < kTiles; ++t) x[t] = x[t] + (part[t] + ld4(pv + PV_L2_B + 16 * t + 4 * g));
+    layer_norm_rows(x, pv + PV_LN2_W, pv + PV_LN2_B, g);
+    return w;
+}
+
+__device__ __forceinline__ void store_tap(float* tap, int slot, const f32x4 (&x)[kTiles], int g, int r) {
+#pragma unroll
+    for (int t = 0; t < kTiles; ++t) st4(tap + ((size_t)slot * 16 + r) * kD + 16 * t + 4 * g, x[t]);
+}
+
+template <int PREC>
+__global__ __launch_bounds__(256, 1) void k_sample(SampleArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    f32x4* exch = reinterpret_cast<f32x4*>(smem);
+    f32x4* skip = reinterpret_cast<f32x4*>(smem + kExchBytes);  // [4][8 tiles][64 lanes]
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int g = lane >> 4, r = lane & 15;
+    const int S = a.S, R = S * a.G;
+    const int cl = r / S, tok = r - cl * S;
+    const long clip = (long)blockIdx.x * a.G + cl;
+    const bool valid = (r < R) && (clip < (long)a.B);
+    const bool is_lat = valid && tok == 0;
+    // attention key mask for this lane's query row: keys j = 4 g + m of the SAME clip; padding rows
+    // attend to themselves only (keeps them finite, they never touch valid rows)
+    bool kvalid[4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+        const int j = 4 * g + m;
+        kvalid[m] = valid ? (j < R && (j / S) == cl) : (j == r);
+    }
+    f32x4 stat[kTiles], lat[kTiles];
+#pragma unroll
+    for (int t = 0; t < kTiles; ++t) {
+        const int f = 16 * t + 4 * g;
+        stat[t] = splat4(0.f);
+        lat[t] = splat4(0.f);
+        if (valid) {
+            if (tok == 0) {
+                stat[t] = ld4(a.pe0 + f);
+                lat[t] = a.x_init ? ld4(a.x_init + (size_t)clip * kD + f)
+                                  : counter_normal4(a.seed, a.clip0 + (uint64_t)clip, 0u, (uint32_t)(4 * t + g), 0u);
+            } else if (tok >= 2) {
+                stat[t] = ld4(a.cond_tok + ((size_t)clip * (S - 2) + (tok - 2)) * kD + f);
+            }
+        }
+    }
+    const bool tap = a.tap_out != nullptr && blockIdx.x == 0 && wave == 0;
+    int parity = 0;
+    f32x4 eps[kTiles];
+#pragma unroll
+    for (int t = 0; t < kTiles; ++t) eps[t] = splat4(0.f);
+
+#pragma unroll 1
+    for (int step = 0; step < a.T; ++step) {
+        // ---- token assembly (denoiser.py:174,180-181)
+        const float* tt = a.time_tok + (size_t)step * kD;
+        f32x4 x[kTiles];
+#pragma unroll
+        for (int t = 0; t < kTiles; ++t) {
+            const f32x4 tv = ld4(tt + 16 * t + 4 * g);
+            x[t] = !valid ? splat4(0.f) : (tok == 0 ? lat[t] + stat[t] : (tok == 1 ? tv : stat[t]));
+        }
+        if (tap && step == 0) store_tap(a.tap_out, 0, x, g, r);
+        const uint4* w = a.wstream + (size_t)wave * a.wave_units * 64 + lane;
+        // ---- SkipTransformerEncoder.forward (cross_attention.py:41-64)
+#pragma unroll 1
+        for (int blk = 0; blk < kLayers; ++blk) {
+            if (blk >= 5) {  // x = Linear(cat(x, skips.pop())), split-K: wave w takes k-tiles 4w..4w+3
+                f32x4 src[4];
+                const f32x4* sk = skip + (size_t)(8 - blk) * kTiles * 64;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    if (wave < 2) src[i] = (wave == 1) ? x[4 + i] : x[i];
+                    else src[i] = sk[(4 * (wave - 2) + i) * 64 + lane];
+                }
+                f32x4 part[kTiles];
+#pragma unroll
+                for (int t = 0; t < kTiles; ++t) part[t] = splat4(0.f);
+                w = gemm_tiles<PREC, kTiles, 4, false>(part, src, w);
+                exchange_sum(part, exch, parity, wave, lane);
+                const float* sb = a.pvec + PV_SKIP_B + (blk - 5) * kD;
+#pragma unroll
+                for (int t = 0; t < kTiles; ++t) x[t] = part[t] + ld4(sb + 16 * t + 4 * g);
+            }
+            w = encoder_block<PREC>(x, w, a.pvec + blk * PV_BLOCK, kvalid, exch, parity, wave, lane);
+            if (blk < 4 && wave == 0) {
+                f32x4* sk = skip + (size_t)blk * kTiles * 64;
+#pragma unroll
+                for (int t = 0; t < kTiles; ++t) sk[t * 64 + lane] = x[t];
+            }
+            if (tap && step == 0) store_tap(a.tap_out, 1 + blk, x, g, r);
+        }
+        layer_norm_rows(x, a.pvec + PV_FINAL_W, a.pvec + PV_FINAL_B, g);
+        if (tap && step == 0) store_tap(a.tap_out, 10, x, g, r);
+#pragma unroll
+        for (int t = 0; t < kTiles; ++t) eps[t] = x[t];
+        // ---- scheduler.step (diffusers 0.17.1 DDIM / DDPM; amuse_hip.h amuse_schedule)
+        if (!a.no_update) {
+            const float* cf = a.coef + (size_t)step * 8;
+            const float sb = cf[0], sa = cf[1], c0 = cf[2], cx = cf[3], ce = cf[4], sg = cf[5], clipv = cf[6];
+#pragma unroll
+            for (int t = 0; t < kTiles; ++t) {
+                f32x4 z = splat4(0.f);
+                if (sg != 0.f && is_lat) {
+                    z = a.step_noise ? ld4(a.step_noise + ((size_t)step * a.B + clip) * kD + 16 * t + 4 * g)
+                                     : counter_normal4(a.seed, a.clip0 + (uint64_t)clip, (uint32_t)step,
+                                                       (uint32_t)(4 * t + g), 1u);
+                }
+#pragma unroll
+                for (int m = 0; m < 4; ++m) {
+                    const float e = eps[t][m], xl = lat[t][m];
+                    float x0 = __fdiv_rn(__fsub_rn(xl, __fmul_rn(sb, e)), sa);
+                    if (clipv > 0.f) x0 = fminf(fmaxf(x0, -clipv), clipv);
+                    float nx = __fmul_rn(c0, x0);
+                    if (cx != 0.f) nx = __fadd_rn(nx, __fmul_rn(cx, xl));
+                    if (ce != 0.f) nx = __fadd_rn(nx, __fmul_rn(ce, e));
+                    if (sg != 0.f) nx = __fadd_rn(nx, __fmul_rn(sg, z[m]));
+                    lat[t][m] = nx;
+                }
+            }
+            if (a.traj_out && is_lat && wave == 0) {
+#pragma unroll
+                for (int t = 0; t < kTiles; ++t)
+                    st4(a.traj_out + ((size_t)step * a.B + clip) * kD + 16 * t + 4 * g, lat[t]);
+            }
+        }
+    }
+    if (is_lat && wave == 0) {
+#pragma unroll
+        for (int t = 0; t < kTiles; ++t) {
+            if (a.latents_out) st4(a.latents_out + (size_t)clip * kD + 16 * t + 4 * g, lat[t]);
+            if (a.eps_out) st4(a.eps_out + (size_t)clip * kD + 16 * t + 4 * g, eps[t]);
+        }
+    }
+}
+
+}  // namespace
+
+hipError_t launch_sample(const SampleArgs& a, int precision, hipStream_t stream) {
+    const int tiles = (a.B + a.G - 1) / a.G;
+    const dim3 grid(tiles), block(256);
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_sample<PREC_F32>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, kSampleLdsBytes);
+        if (e != hipSuccess) return e;
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_sample<PREC_BF16>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, kSampleLdsBytes);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    if (precision == PREC_F32)
+        hipLaunchKernelGGL(k_sample<PREC_F32>, grid, block, kSampleLdsBytes, stream, a);
+    else
+        hipLaunchKernelGGL(k_sample<PREC_BF16>, grid, block, kSampleLdsBytes, stream, a);
+    return hipGetLastError();
+}
+
+}  // namespace amuse

@@ -1,0 +1,366 @@
+// VAE decode: MotionPrior.decode (reference models/latent_diffusion/vae.py:216-278) =
+// zeros(300,B,128) + learned PE -> SkipTransformerDecoder (cross_attention.py:89-125) of 9
+// TransformerDecoderLayer.forward_post blocks (cross_attention.py:323-345) -> final_layer
+// Linear(128 -> 333), followed by the 6D -> matrix -> axis-angle conversion of infer_ldm.py:168-173.
+//
+// Two kernels alternate (stream-ordered, activations stay in L2/MALL between them):
+//   k_vae_rows  - everything that is independent per frame row, on 16-row tiles with the same
+//                 4-wave split as the sampling kernel (heads / hidden-feature quarters, split-K
+//                 combines through LDS):  [out_proj + LN1 + cross-attn constant + LN2 + FFN + LN3
+//                 (+ skip push / skip linear)] of block i fused with the q,k,v projection of block
+//                 i+1; the last stage fuses decoder.norm + final_layer + the rotation epilogue.
+//   k_vae_attn  - the only S = 300 attention in the system: one workgroup per (clip, head), K_h and
+//                 V_h staged once in LDS, flash-style online softmax, S^T = K.Q^T and O^T = V^T.P^T on
+//                 MFMA so that the softmax runs along registers and O lands in row-lane layout.
+// The one-token cross-attention collapses to a per-clip constant (k_vae_ca in k_misc.hip).
+#include "amuse_dev.hpp"
+#include "amuse_kernels.hpp"
+
+namespace amuse {
+namespace {
+
+constexpr int kRowTiles = 19;       // ceil(300 / 16)
+constexpr int kFeatStride = 388;    // 384 padded features + 4: LDS row stride of the staged feats tile
+constexpr int kRowsLdsBytes = kExchBytes + 16 * kFeatStride * 4;
+
+__device__ __forceinline__ void rot6d_to_axis_angle(const float* d6, int quat_mode, float (&aa)[3]) {
+    // rotation_6d_to_matrix (pytorch3d; vendored copy rotation_conversions.py:512-533)
+    const float a1x = d6[0], a1y = d6[1], a1z = d6[2], a2x = d6[3], a2y = d6[4], a2z = d6[5];
+    const float n1 = fmaxf(sqrtf(a1x * a1x + a1y * a1y + a1z * a1z), 1e-12f);
+    const float b1x = a1x / n1, b1y = a1y / n1, b1z = a1z / n1;
+    const float dt = b1x * a2x + b1y * a2y + b1z * a2z;
+    float b2x = a2x - dt * b1x, b2y = a2y - dt * b1y, b2z = a2z - dt * b1z;
+    const float n2 = fmaxf(sqrtf(b2x * b2x + b2y * b2y + b2z * b2z), 1e-12f);
+    b2x /= n2; b2y /= n2; b2z /= n2;
+    const float b3x = b1y * b2z - b1z * b2y, b3y = b1z * b2x - b1x * b2z, b3z = b1x * b2y - b1y * b2x;
+    const float m00 = b1x, m01 = b1y, m02 = b1z, m10 = b2x, m11 = b2y, m12 = b2z, m20 = b3x, m21 = b3y, m22 = b3z;
+    float qw, qx, qy, qz;
+    if (quat_mode == 1) {  // legacy snapshot: rotation_conversions.py:97-119
+        qw = 0.5f * sqrtf(fmaxf(0.f, 1.f + m00 + m11 + m22));
+        qx = 0.5f * sqrtf(fmaxf(0.f, 1.f + m00 - m11 - m22));
+        qy = 0.5f * sqrtf(fmaxf(0.f, 1.f - m00 + m11 - m22));
+        qz = 0.5f * sqrtf(fmaxf(0.f, 1.f - m00 - m11 + m22));
+        if ((qx < 0.f) != ((m21 - m12) < 0.f)) qx = -qx;
+        if ((qy < 0.f) != ((m02 - m20) < 0.f)) qy = -qy;
+        if ((qz < 0.f) != ((m10 - m01) < 0.f)) qz = -qz;
+    } else {  // pytorch3d >= 0.5: best-conditioned of four candidates, no sign standardisation
+        const float qa0 = sqrtf(fmaxf(0.f, 1.f + m00 + m11 + m22)), qa1 = sqrtf(fmaxf(0.f, 1.f + m00 - m11 - m22));
+        const float qa2 = sqrtf(fmaxf(0.f, 1.f - m00 + m11 - m22)), qa3 = sqrtf(fmaxf(0.f, 1.f - m00 - m11 + m22));
+        int best = 0;
+        float qb = qa0;
+        if (qa1 > qb) { qb = qa1; best = 1; }
+        if (qa2 > qb) { qb = qa2; best = 2; }
+        if (qa3 > qb) { qb = qa3; best = 3; }
+        const float den = 2.0f * fmaxf(qb, 0.1f);
+        if (best == 0) { qw = qa0 * qa0; qx = m21 - m12; qy = m02 - m20; qz = m10 - m01; }
+        else if (best == 1) { qw = m21 - m12; qx = qa1 * qa1; qy = m10 + m01; qz = m02 + m20; }
+        else if (best == 2) { qw = m02 - m20; qx = m10 + m01; qy = qa2 * qa2; qz = m12 + m21; }
+        else { qw = m10 - m01; qx = m20 + m02; qy = m21 + m12; qz = qa3 * qa3; }
+        qw /= den; qx /= den; qy /= den; qz /= den;
+    }
+    // quaternion_to_axis_angle (rotation_conversions.py:480-509)
+    const float nrm = sqrtf(qx * qx + qy * qy + qz * qz);
+    const float half = atan2f(nrm, qw);
+    const float ang = 2.0f * half;
+    const float s = (fabsf(ang) < 1e-6f) ? (0.5f - (ang * ang) / 48.0f) : (sinf(half) / ang);
+    aa[0] = qx / s; aa[1] = qy / s; aa[2] = qz / s;
+}
+
+template <int PREC>
+__global__ __launch_bounds__(256) void k_vae_rows(VaeRowsArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    f32x4* exch = reinterpret_cast<f32x4*>(smem);
+    float* fst = reinterpret_cast<float*>(smem + kExchBytes);  // [16][kFeatStride] staged feats (last stage)
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int g = lane >> 4, r = lane & 15;
+    const int b = blockIdx.x / kRowTiles, rt = blockIdx.x - b * kRowTiles;
+    const int frame = rt * 16 + r;
+    const bool rvalid = frame < kFrames;
+    const size_t row = (size_t)b * kFrames + (rvalid ? frame : 0);
+    const size_t nrows = (size_t)a.B * kFrames;
+    const uint4* w = a.wstream + ((size_t)a.stage_base[a.stage] + (size_t)wave * a.stage_units[a.stage]) * 64 + lane;
+    int parity = 0;
+    f32x4 x[kTiles];
+
+    if (a.stage == 0) {  // queries = zeros + query_pos_decoder.pe[:300]  (vae.py:220,258)
+#pragma unroll
+        for (int t = 0; t < kTiles; ++t)
+            x[t] = rvalid ? ld4(a.pe + (size_t)frame * kD + 16 * t + 4 * g) : splat4(0.f);
+    } else {
+        const int blk = a.stage - 1;
+        const float* pv = a.pvec + blk * PV_BLOCK;
+        f32x4 o[2];
+#pragma unroll
+        for (int t = 0; t < kTiles; ++t) x[t] = rvalid ? ld4(a.x + row * kD + 16 * t + 4 * g) : splat4(0.f);
+#pragma unroll
+        for (int td = 0; td < 2; ++td)
+            o[td] = rvalid ? ld4(a.attn_o + row * kD + 32 * wave + 16 * td + 4 * g) : splat4(0.f);
+        f32x4 part[kTiles];
+        // self-attention out_proj (split-K over heads) + residual + norm1
+#pragma unroll
+        for (int t = 0; t < kTiles; ++t) part[t] = splat4(0.f);
+        w = gemm_tiles<PREC, kTiles, 2, false>(part, o, w);
+        exchange_sum(part, exch, parity, wave, lane);
+#pragma unroll
+        for (int t = 0; t < kTiles; ++t) x[t] = x[t] + (part[t] + ld4(pv + PV_OUT_B + 16 * t + 4 * g));
+        layer_norm_rows(x, pv + PV_LN1_W, pv + PV_LN1_B, g);
+        // cross-attention onto the single latent token == per-clip constant; residual + norm2
+        const float* ca = a.ca + ((size_t)b * kLayers + blk) * kD;
+#pragma unroll
+        for (int t = 0; t < kTiles; ++t) x[t] = x[t] + ld4(ca + 16 * t + 4 * g);
+        layer_norm_rows(x, pv + PV_LN2_W, pv + PV_LN2_B, g);
+        // FFN + residual + norm3
+        f32x4 hid[kTiles];
+#pragma unroll
+        for (int t = 0; t < kTiles; ++t) hid[t] = ld4(pv + PV_L1_B + 16 * (kTiles * wave + t) + 4 * g);
+        w = gemm_tiles<PREC, kTiles, kTiles, false>(hid, x, w);
+#pragma unroll
+        for (int t = 0; t < kTiles; ++t)
+#pragma unroll
+            for (int m = 0; m < 4; ++m) hid[t][m] = gelu_erf(hid[t][m]);
+#pragma unroll
+        for (int t = 0; t < kTiles; ++t) part[t] = splat4(0.f);
+        w = gemm_tiles<PREC, kTiles, kTiles, false>(part, hid, w);
+        exchange_sum(part, exch, parity, wave, lane);
+#pragma unroll
+        for (int t = 0; t < kTiles; ++t) x[t] = x[t] + (part[t] + ld4(pv + PV_L2_B + 16 * t + 4 * g));
+        layer_norm_rows(x, pv + PV_LN3_W, pv + PV_LN3_B, g);
+        if (blk < 4 && wave == 0 && rvalid) {  // xs.append(x)
+            float* sk = a.skip + ((size_t)blk * nrows + row) * kD;
+#pragma unroll
+            for (int t = 0; t < kTiles; ++t) st4(sk + 16 * t + 4 * g, x[t]);
+        }
+        if (blk >= 4 && blk <= 7) {  // x = linear_blocks[blk-4](cat(x, xs.pop())) ahead of output block blk+1
+            const float* sk = a.skip + ((size_t)(7 - blk) * nrows + row) * kD;
+            f32x4 src[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                if (wave < 2) src[i] = (wave == 1) ? x[4 + i] : x[i];
+                else src[i] = rvalid ? ld4(sk + 16 * (4 * (wave - 2) + i) + 4 * g) : splat4(0.f);
+            }
+#pragma unroll
+            for (int t = 0; t < kTiles; ++t) part[t] = splat4(0.f);
+            w = gemm_tiles<PREC, kTiles, 4, false>(part, src, w);
+            exchange_sum(part, exch, parity, wave, lane);
+            const float* sb = a.pvec + PV_SKIP_B + (blk - 4) * kD;
+#pragma unroll
+            for (int t = 0; t < kTiles; ++t) x[t] = part[t] + ld4(sb + 16 * t + 4 * g);
+        }
+    }
+
+    if (a.stage < kLayers) {
+        // residual stream for the next stage + in_proj of block `stage` (this wave's head)
+        if (wave == 0 && rvalid) {
+#pragma unroll
+            for (int t = 0; t < kTiles; ++t) st4(a.x + row * kD + 16 * t + 4 * g, x[t]);
+        }
+        const float* pv = a.pvec + a.stage * PV_BLOCK;
+        f32x4 qkv[6];
+#pragma unroll
+        for (int o = 0; o < 2; ++o) {
+            qkv[o] = ld4(pv + PV_IN_B + 16 * (2 * wave + o) + 4 * g);
+            qkv[2 + o] = ld4(pv + PV_IN_B + kD + 16 * (2 * wave + o) + 4 * g);
+            qkv[4 + o] = ld4(pv + PV_IN_B + 2 * kD + 16 * (2 * wave + o) + 4 * g);
+        }
+        w = gemm_tiles<PREC, 6, kTiles, false>(qkv, x, w);
+        if (rvalid) {
+            const size_t hrow = (((size_t)b * kHeads + wave) * kFrames + frame) * 32;
+            const float scaling = 0.17677669529663687f;
+#pragma unroll
+            for (int td = 0; td < 2; ++td) {
+                st4(a.q + hrow + 16 * td + 4 * g, qkv[td] * scaling);
+                st4(a.k + hrow + 16 * td + 4 * g, qkv[2 + td]);
+                st4(a.v + hrow + 16 * td + 4 * g, qkv[4 + td]);
+            }
+        }
+    } else {
+        // decoder.norm -> final_layer (333 outputs padded to 24 tiles, 6 per wave) -> rotation epilogue
+        layer_norm_rows(x, a.pvec + PV_FINAL_W, a.pvec + PV_FINAL_B, g);
+        f32x4 f[6];
+#pragma unroll
+        for (int o = 0; o < 6; ++o) f[o] = ld4(a.final_bias + 16 * (6 * wave + o) + 4 * g);
+        w = gemm_tiles<PREC, 6, kTiles, false>(f, x, w);
+        const int len = a.lengths ? a.lengths[b] : kFrames;
+        const bool keep = rvalid && frame < len;  // output[~mask.T] = 0 (vae.py:274)
+#pragma unroll
+        for (int o = 0; o < 6; ++o)
+            st4(fst + r * kFeatStride + 16 * (6 * wave + o) + 4 * g, keep ? f[o] : splat4(0.f));
+        __syncthreads();
+        const int tid = threadIdx.x;
+        const int rows_here = min(16, kFrames - rt * 16);
+        const size_t row0 = (size_t)b * kFrames + rt * 16;
+        if (a.feats_out) {
+            for (int i = tid; i < rows_here * kFeats; i += 256) {
+                const int rr = i / kFeats, c = i - rr * kFeats;
+                a.feats_out[(row0 + rr) * kFeats + c] = fst[rr * kFeatStride + c];
+            }
+        }
+        if (a.poses_out) {
+            for (int i = tid; i < rows_here * kJoints; i += 256) {
+                const int rr = i / kJoints, jn = i - rr * kJoints;
+                float aa[3];
+                rot6d_to_axis_angle(fst + rr * kFeatStride + 6 * jn, a.quat_mode, aa);
+                float* dst = a.poses_out + ((row0 + rr) * kJoints + jn) * 3;
+                dst[0] = aa[0]; dst[1] = aa[1]; dst[2] = aa[2];
+            }
+        }
+        if (a.trans_out) {
+            for (int i = tid; i < rows_here * 3; i += 256) {
+                const int rr = i / 3, c = i - rr * 3;
+                a.trans_out[(row0 + rr) * 3 + c] = fst[rr * kFeatStride + 330 + c];
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+constexpr int kKS = 36;              // padded LDS row stride (floats) of the K_h / V_h images
+constexpr int kKeyRows = 320;        // 300 keys padded to 20 tiles (zero rows, masked)
+constexpr int kAttnLdsBytes = 2 * kKeyRows * kKS * 4;
+
+template <int PREC>
+__global__ __launch_bounds__(256) void k_vae_attn(VaeAttnArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* Ks = reinterpret_cast<float*>(smem);
+    float* Vs = Ks + kKeyRows * kKS;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int g = lane >> 4, r = lane & 15;
+    const int bh = blockIdx.x, b = bh / kHeads, h = bh - b * kHeads;
+    const int len = a.lengths ? a.lengths[b] : kFrames;
+    const float* qg = a.q + (size_t)bh * kFrames * 32;
+    const float* kg = a.k + (size_t)bh * kFrames * 32;
+    const float* vg = a.v + (size_t)bh * kFrames * 32;
+    for (int i = threadIdx.x; i < kKeyRows * 8; i += 256) {
+        const int rowi = i >> 3, c4 = (i & 7) * 4;
+        const bool ok = rowi < kFrames;
+        st4(Ks + rowi * kKS + c4, ok ? ld4(kg + rowi * 32 + c4) : splat4(0.f));
+        st4(Vs + rowi * kKS + c4, ok ? ld4(vg + rowi * 32 + c4) : splat4(0.f));
+    }
+    __syncthreads();
+    for (int qt = wave; qt < kRowTiles; qt += 4) {
+        const int fq = qt * 16 + r;
+        const bool qvalid = fq < kFrames;
+        f32x4 q[2];
+#pragma unroll
+        for (int td = 0; td < 2; ++td) q[td] = qvalid ? ld4(qg + fq * 32 + 16 * td + 4 * g) : splat4(0.f);
+        float m_run = -INFINITY, l_run = 0.f;
+        f32x4 o[2] = {splat4(0.f), splat4(0.f)};
+#pragma unroll 1
+        for (int jp = 0; jp < kKeyRows / 32; ++jp) {
+            f32x4 st[2];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const float* kr = Ks + (32 * jp + 16 * u + r) * kKS + 4 * g;
+                const f32x4 k0 = ld4(kr), k1 = ld4(kr + 16);
+                st[u] = splat4(0.f);
+                if constexpr (PREC == PREC_F32) {
+#pragma unroll
+                    for (int m = 0; m < 4; ++m) st[u] = mfma_f32(k0[m], q[0][m], st[u]);
+#pragma unroll
+                    for (int m = 0; m < 4; ++m) st[u] = mfma_f32(k1[m], q[1][m], st[u]);
+                } else {
+                    st[u] = mfma_bf16(pack_bf16(k0, k1), pack_bf16(q[0], q[1]), st[u]);
+                }
+            }
+            // lane (g, i) holds S[i][key = 32 jp + 16 u + 4 g + m]
+            bool ok[2][4];
+            float mx = -INFINITY;
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int m = 0; m < 4; ++m) {
+                    ok[u][m] = (32 * jp + 16 * u + 4 * g + m) < len;
+                    mx = ok[u][m] ? fmaxf(mx, st[u][m]) : mx;
+                }
+            mx = fmaxf(mx, __shfl_xor(mx, 16));
+            mx = fmaxf(mx, __shfl_xor(mx, 32));
+            const float m_new = fmaxf(m_run, mx);
+            const float alpha = (m_new == -INFINITY) ? 1.0f : expf(m_run - m_new);
+            f32x4 p[2];
+            float ps = 0.f;
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int m = 0; m < 4; ++m) {
+                    p[u][m] = ok[u][m] ? expf(st[u][m] - m_new) : 0.f;
+                    ps += p[u][m];
+                }
+            ps += __shfl_xor(ps, 16);
+            ps += __shfl_xor(ps, 32);
+            l_run = l_run * alpha + ps;
+            o[0] *= alpha;
+            o[1] *= alpha;
+            m_run = m_new;
+            // O^T[d][i] += sum_key V[key][d] P[i][key]; A operand lane (g, d): V[32 jp + 16 u + 4 g + m][16 td + d]
+            const float* vr = Vs + (32 * jp + 4 * g) * kKS + r;
+            if constexpr (PREC == PREC_F32) {
+#pragma unroll
+                for (int u = 0; u < 2; ++u)
+#pragma unroll
+                    for (int m = 0; m < 4; ++m) {
+                        const float* vv = vr + (16 * u + m) * kKS;
+                        o[0] = mfma_f32(vv[0], p[u][m], o[0]);
+                        o[1] = mfma_f32(vv[16], p[u][m], o[1]);
+                    }
+            } else {
+                const bf16x8 pb = pack_bf16(p[0], p[1]);
+#pragma unroll
+                for (int td = 0; td < 2; ++td) {
+                    f32x4 lo, hi;
+#pragma unroll
+                    for (int m = 0; m < 4; ++m) {
+                        lo[m] = vr[m * kKS + 16 * td];
+                        hi[m] = vr[(16 + m) * kKS + 16 * td];
+                    }
+                    o[td] = mfma_bf16(pack_bf16(lo, hi), pb, o[td]);
+                }
+            }
+        }
+        if (qvalid) {
+            float* dst = a.o + ((size_t)b * kFrames + fq) * kD + 32 * h + 4 * g;
+            st4(dst, o[0] / l_run);
+            st4(dst + 16, o[1] / l_run);
+        }
+    }
+}
+
+template <typename K>
+hipError_t set_lds(K kern, int bytes) {
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+}
+
+}  // namespace
+
+hipError_t launch_vae_rows(const VaeRowsArgs& a, int precision, hipStream_t stream) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = set_lds(&k_vae_rows<PREC_F32>, kRowsLdsBytes);
+        if (e != hipSuccess) return e;
+        e = set_lds(&k_vae_rows<PREC_BF16>, kRowsLdsBytes);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    const dim3 grid(a.B * kRowTiles), block(256);
+    if (precision == PREC_F32) hipLaunchKernelGGL(k_vae_rows<PREC_F32>, grid, block, kRowsLdsBytes, stream, a);
+    else hipLaunchKernelGGL(k_vae_rows<PREC_BF16>, grid, block, kRowsLdsBytes, stream, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_vae_attn(const VaeAttnArgs& a, int precision, hipStream_t stream) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = set_lds(&k_vae_attn<PREC_F32>, kAttnLdsBytes);
+        if (e != hipSuccess) return e;
+        e = set_lds(&k_vae_attn<PREC_BF16>, kAttnLdsBytes);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    const dim3 grid(a.B * kHeads), block(256);
+    if (precision == PREC_F32) hipLaunchKernelGGL(k_vae_attn<PREC_F32>, grid, block, kAttnLdsBytes, stream, a);
+    else hipLaunchKernelGGL(k_vae_attn<PREC_BF16>, grid, block, kAttnLdsBytes, stream, a);
+    return hipGetLastError();
+}
+
+}  // namespace amuse

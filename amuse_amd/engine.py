@@ -1,0 +1,168 @@
+"""Thin torch-facing wrapper over the C ABI (include/amuse_hip.h).  PyTorch supplies device memory and
+streams only; all compute is in libamuse_hip.so."""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, Optional, Sequence
+
+import numpy as np
+import torch
+
+from . import _lib
+from . import weights as wts
+from .scheduler import ScheduleTable, timestep_freqs
+
+PREC = {"fp32": _lib.PREC_F32, "f32": _lib.PREC_F32, "bf16": _lib.PREC_BF16}
+QUAT = {"p3d": _lib.QUAT_P3D, "legacy": _lib.QUAT_LEGACY}
+
+
+def flatten_state_dict(sd: Dict[str, np.ndarray], spec) -> np.ndarray:
+    """Concatenate tensors in state-dict order (the layout amuse_create expects)."""
+    parts = []
+    for k, shape in spec.items():
+        if k not in sd:
+            raise KeyError(f"key {k} not found in state dict")
+        v = sd[k]
+        v = v.detach().cpu().numpy() if isinstance(v, torch.Tensor) else np.asarray(v)
+        if tuple(v.shape) != tuple(shape):
+            raise ValueError(f"shape mismatch for {k}: {tuple(v.shape)} vs {tuple(shape)}")
+        parts.append(np.ascontiguousarray(v, dtype=np.float32).ravel())
+    return np.concatenate(parts)
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+class HipEngine:
+    """One amuse_ctx on one GPU."""
+
+    def __init__(self, denoiser_sd: Dict[str, np.ndarray], prior_sd: Dict[str, np.ndarray], device="cuda:0"):
+        self.lib = _lib.load()
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise _lib.AmuseHipError("amuse_amd runs on an MI355X (torch device 'cuda:N'); there is no CPU path")
+        den = flatten_state_dict(denoiser_sd, wts.denoiser_param_spec())
+        pri = flatten_state_dict(prior_sd, wts.prior_param_spec())
+        fp = C.POINTER(C.c_float)
+        torch.cuda.init()
+        self.ctx = self.lib.amuse_create(self.device.index or 0, den.ctypes.data_as(fp), den.size,
+                                         pri.ctypes.data_as(fp), pri.size)
+        if not self.ctx:
+            raise _lib.AmuseHipError(f"amuse_create failed: {self.lib.amuse_last_error().decode()}")
+        self.schedule: Optional[ScheduleTable] = None
+
+    def close(self):
+        if getattr(self, "ctx", None):
+            self.lib.amuse_destroy(self.ctx)
+            self.ctx = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ------------------------------------------------------------------
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def _dev(self, t, shape=None) -> Optional[torch.Tensor]:
+        if t is None:
+            return None
+        if not isinstance(t, torch.Tensor):
+            t = torch.as_tensor(np.asarray(t))
+        t = t.to(device=self.device, dtype=torch.float32).contiguous()
+        if shape is not None and tuple(t.shape) != tuple(shape):
+            raise ValueError(f"expected shape {tuple(shape)}, got {tuple(t.shape)}")
+        return t
+
+    def set_clips_per_group(self, g: int):
+        _lib.check(self.lib.amuse_set_clips_per_group(self.ctx, int(g)))
+
+    def set_schedule(self, table: ScheduleTable):
+        ts = np.ascontiguousarray(table.timesteps, dtype=np.int32)
+        cf = np.ascontiguousarray(table.coef, dtype=np.float32)
+        fr = np.ascontiguousarray(timestep_freqs(), dtype=np.float32)
+        s = _lib.Schedule(len(ts), ts.ctypes.data_as(C.POINTER(C.c_int)), cf.ctypes.data_as(C.POINTER(C.c_float)),
+                          fr.ctypes.data_as(C.POINTER(C.c_float)))
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.amuse_set_schedule(self.ctx, C.byref(s), self._stream()))
+        self.schedule = table
+
+    def sample(self, con, emo, sty, precision="fp32", seed=0, clip_index0=0, x_init=None, step_noise=None,
+               return_traj=False):
+        con = self._dev(con)
+        B = con.shape[0]
+        emo, sty = self._dev(emo, (B, 256)) if emo is not None else None, self._dev(sty, (B, 256)) if sty is not None else None
+        x_init = self._dev(x_init, (B, 128)) if x_init is not None else None
+        T = self.schedule.n_steps
+        step_noise = self._dev(step_noise, (T, B, 128)) if step_noise is not None else None
+        lat = torch.empty(B, 128, device=self.device, dtype=torch.float32)
+        traj = torch.empty(T, B, 128, device=self.device, dtype=torch.float32) if return_traj else None
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.amuse_sample(self.ctx, _ptr(con), _ptr(emo), _ptr(sty), B, PREC[precision], seed,
+                                             clip_index0, _ptr(x_init), _ptr(step_noise), _ptr(lat), _ptr(traj),
+                                             self._stream()))
+        return (lat, traj) if return_traj else lat
+
+    def denoise_step(self, x_t, timestep: int, con, emo, sty, precision="fp32", taps=False):
+        con = self._dev(con)
+        B = con.shape[0]
+        x_t = self._dev(x_t, (B, 128))
+        emo = self._dev(emo, (B, 256)) if emo is not None else None
+        sty = self._dev(sty, (B, 256)) if sty is not None else None
+        eps = torch.empty(B, 128, device=self.device, dtype=torch.float32)
+        tap = torch.zeros(11, 16, 128, device=self.device, dtype=torch.float32) if taps else None
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.amuse_denoise_step(self.ctx, _ptr(x_t), int(timestep), _ptr(con), _ptr(emo), _ptr(sty),
+                                                   B, PREC[precision], _ptr(eps), _ptr(tap), self._stream()))
+        return (eps, tap) if taps else eps
+
+    def vae_decode(self, z, lengths: Optional[Sequence[int]] = None, precision="fp32", quat_mode="p3d",
+                   return_feats=False):
+        z = self._dev(z)
+        B = z.shape[0]
+        feats = torch.empty(B, 300, 333, device=self.device, dtype=torch.float32) if return_feats else None
+        poses = torch.empty(B, 300, 55, 3, device=self.device, dtype=torch.float32)
+        trans = torch.empty(B, 300, 3, device=self.device, dtype=torch.float32)
+        lp = None
+        if lengths is not None:
+            la = np.ascontiguousarray(lengths, dtype=np.int32)
+            if la.shape != (B,):
+                raise ValueError("lengths must have one entry per clip")
+            lp = la.ctypes.data_as(C.POINTER(C.c_int))
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.amuse_vae_decode(self.ctx, _ptr(z), lp, B, PREC[precision], QUAT[quat_mode],
+                                                 _ptr(feats), _ptr(poses), _ptr(trans), self._stream()))
+        out = {"poses": poses, "trans": trans}
+        if return_feats:
+            out["feats"] = feats
+        return out
+
+    def diffusion_backward(self, con, emo, sty, precision="fp32", quat_mode="p3d", seed=0, clip_index0=0, x_init=None,
+                           step_noise=None, out=None):
+        con = self._dev(con)
+        B = con.shape[0]
+        emo = self._dev(emo, (B, 256)) if emo is not None else None
+        sty = self._dev(sty, (B, 256)) if sty is not None else None
+        x_init = self._dev(x_init, (B, 128)) if x_init is not None else None
+        T = self.schedule.n_steps
+        step_noise = self._dev(step_noise, (T, B, 128)) if step_noise is not None else None
+        if out is None:
+            out = {"latents": torch.empty(B, 128, device=self.device, dtype=torch.float32),
+                   "poses": torch.empty(B, 300, 55, 3, device=self.device, dtype=torch.float32),
+                   "trans": torch.empty(B, 300, 3, device=self.device, dtype=torch.float32)}
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.amuse_diffusion_backward(self.ctx, _ptr(con), _ptr(emo), _ptr(sty), B, PREC[precision],
+                                                         QUAT[quat_mode], seed, clip_index0, _ptr(x_init),
+                                                         _ptr(step_noise), _ptr(out["latents"]), _ptr(out["poses"]),
+                                                         _ptr(out["trans"]), self._stream()))
+        return out
+
+    def counter_normal(self, seed, clip_index0, B, step, rng_stream):
+        o = torch.empty(B, 128, device=self.device, dtype=torch.float32)
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.amuse_counter_normal(self.ctx, seed, clip_index0, B, step, rng_stream, _ptr(o),
+                                                     self._stream()))
+        return o

@@ -1,0 +1,141 @@
+/*
+ * amuse_hip.h - C ABI of libamuse_hip.so: the MI355X (gfx950) implementation of AMUSE's
+ * latent-diffusion gesture-sampling hot path.
+ *
+ * The reference (kiranchhatre/amuse) has NO native/FFI seam on this path: the boundary is the Python
+ * object protocol of models/latent_diffusion/infer_ldm.py (PretrainedLPDM_v1).  Each entry point
+ * below names the reference interface it replaces (paths relative to the reference root); the
+ * ctypes binding a maintainer adds on the reference side is shown in INTEGRATION.md and shipped in
+ * amuse_amd/_lib.py.
+ *
+ * Conventions
+ *   - plain C: pointers + sizes only, no torch/HIP types in signatures (hipStream_t travels as void*)
+ *   - every `dev` pointer is DEVICE memory on the ctx's GPU, fp32, row-major, caller-owned;
+ *     every `host` pointer is host memory; inputs are never written, outputs are fully overwritten
+ *   - return 0 on success, a negative AMUSE_E* code on failure; amuse_last_error() gives the text
+ *     (thread-local).  No exceptions cross the ABI.
+ *   - one ctx per (GPU, weight set); calls on one ctx must not overlap in time (they share workspace)
+ *   - kernels are enqueued on `stream` (NULL = the legacy default stream) and NOT synchronised
+ *     before returning, except where stated
+ */
+#ifndef AMUSE_HIP_H
+#define AMUSE_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define AMUSE_ABI_VERSION 1
+
+/* architecture the kernels are specialised for (configs/diff_latent_v2.json:23-47,
+ * configs/prior_emotional_fing.json:6-20, configs/base_new.json "train_pose_framelen") */
+#define AMUSE_D_MODEL 128
+#define AMUSE_N_HEADS 4
+#define AMUSE_FF 512
+#define AMUSE_N_LAYERS 9
+#define AMUSE_COND_DIM 256
+#define AMUSE_N_FRAMES 300
+#define AMUSE_N_JOINTS 55
+#define AMUSE_N_FEATS 333
+#define AMUSE_DENOISER_PARAMS 2192384u /* 130 tensors, state-dict order of Denoiser (denoiser.py:16-133) */
+#define AMUSE_PRIOR_PARAMS 4643277u    /* 297 tensors, state-dict order of MotionPrior (vae.py:24-146) */
+#define AMUSE_MAX_STEPS 1000
+
+enum { AMUSE_OK = 0, AMUSE_EINVAL = -1, AMUSE_EHIP = -2, AMUSE_ENOMEM = -3, AMUSE_ESTATE = -4 };
+
+/* arithmetic of the MFMA GEMMs.  F32: fp32 weights/operands (v_mfma_f32_16x16x4_f32, exact fp32
+ * FMA chains) - the parity mode.  BF16: bf16 weights + bf16-rounded operands, fp32 accumulate,
+ * fp32 residual stream / LayerNorm / softmax / scheduler state - the throughput mode. */
+enum { AMUSE_PREC_F32 = 0, AMUSE_PREC_BF16 = 1 };
+
+/* matrix -> quaternion convention of the axis-angle epilogue (infer_ldm.py:172):
+ * P3D   = pytorch3d >= 0.5 candidate selection, no sign standardisation (what the reference's
+ *         committed outputs show: |axis-angle| up to 4.69 > pi);
+ * LEGACY = the snapshot vendored at models/diffusion/utils/rotation_conversions.py:97-119 (q_w >= 0). */
+enum { AMUSE_QUAT_P3D = 0, AMUSE_QUAT_LEGACY = 1 };
+
+typedef struct amuse_ctx amuse_ctx;
+
+/* One denoising schedule = what diffusers' scheduler.set_timesteps + scheduler.step need
+ * (infer_ldm.py:116-125,142-147,160-161).  Per step i the update applied in-kernel is
+ *   x0 = (x - sb*eps) / sa ; if (clip > 0) x0 = clamp(x0, -clip, clip)
+ *   x' = c0*x0 (+ cx*x) (+ ce*eps) (+ sigma*z)
+ * coef[i] = { sb, sa, c0, cx, ce, sigma, clip, 0 }.  DDIM: cx = 0; DDPM: ce = 0.  Terms whose
+ * coefficient is exactly 0 are skipped.  amuse_amd/scheduler.py builds these tables. */
+typedef struct {
+    int n_steps;            /* T, 1..AMUSE_MAX_STEPS */
+    const int* timesteps;   /* host [T]: the integer timestep fed to the time embedding at step i */
+    const float* coef;      /* host [T][8] */
+    const float* freqs;     /* host [128] or NULL: exp(-ln(1e4) k/128), k = 0..127 (embeddings.py:262-267).
+                               The reference evaluates this with torch.exp; a caller that wants bit-equal
+                               time embeddings passes torch's values, NULL = libm expf. */
+} amuse_schedule;
+
+/* Replaces PretrainedLPDM_v1.setup()'s model construction + weight load (infer_ldm.py:66-109) and
+ * PretrainedVAE.load_model (infer_pretrained_vae.py:13-49).  `denoiser_params` / `prior_params`
+ * are HOST fp32 arrays holding every state-dict tensor, concatenated in state-dict order (sizes
+ * must equal AMUSE_DENOISER_PARAMS / AMUSE_PRIOR_PARAMS).  Packs both precisions' MFMA-fragment
+ * weight streams and uploads them.  Returns NULL on failure. */
+amuse_ctx* amuse_create(int device, const float* denoiser_params, size_t n_denoiser,
+                        const float* prior_params, size_t n_prior);
+void amuse_destroy(amuse_ctx* ctx);
+const char* amuse_last_error(void);
+int amuse_abi_version(void);
+
+/* Replaces diffusers.DDIMScheduler(...).set_timesteps(N) (infer_ldm.py:116-123,143-144) and hoists
+ * Timesteps + TimestepEmbedding (embeddings.py:245-322; denoiser.py:146-149) out of the loop: builds
+ * the [T,128] time-token table on the GPU.  Synchronises `stream`. */
+int amuse_set_schedule(amuse_ctx* ctx, const amuse_schedule* sched, void* stream);
+
+/* Replaces the timestep loop of PretrainedLPDM_v1.diffusion_backward (infer_ldm.py:137-161):
+ * initial noise, T x { Denoiser.forward, scheduler.step }.
+ *   con/emo/sty  dev [B][256]; emo and/or sty may be NULL (token dropped, denoiser.py:159-171)
+ *   x_init       dev [B][128] or NULL -> counter-based N(0,1) from (seed, clip_index0 + b)
+ *   step_noise   dev [T][B][128] or NULL -> counter-based; only read at steps with sigma != 0
+ *   latents_out  dev [B][128]  final latents
+ *   traj_out     dev [T][B][128] or NULL: latent after every step (tests)
+ * Uses the schedule set by amuse_set_schedule. */
+int amuse_sample(amuse_ctx* ctx, const float* con, const float* emo, const float* sty, int B,
+                 int precision, uint64_t seed, uint64_t clip_index0, const float* x_init,
+                 const float* step_noise, float* latents_out, float* traj_out, void* stream);
+
+/* Replaces one Denoiser.forward call (denoiser.py:135-204) - teacher-forced single step for tests:
+ * eps_out[B][128] = eps_hat(x_t, timestep, con, emo, sty).  Does not need a schedule.
+ * tap_out (dev, nullable, [11][16][128]): token rows of the first clip tile after token assembly
+ * (slot 0), after each of the 9 blocks (slots 1..9) and after the final LayerNorm (slot 10). */
+int amuse_denoise_step(amuse_ctx* ctx, const float* x_t, int timestep, const float* con,
+                       const float* emo, const float* sty, int B, int precision, float* eps_out,
+                       float* tap_out, void* stream);
+
+/* Replaces PretrainedVAE.get_motion -> MotionPrior.decode (infer_pretrained_vae.py:58-62,
+ * vae.py:216-278) plus the 6D -> matrix -> axis-angle conversion (infer_ldm.py:168-173).
+ *   z          dev [B][128]
+ *   lengths    host [B] or NULL (= all 300): frames >= length are masked as keys and zeroed
+ *   feats_out  dev [B][300][333] or NULL (the raw decoder features)
+ *   poses_out  dev [B][300][55][3], trans_out dev [B][300][3] (either may be NULL) */
+int amuse_vae_decode(amuse_ctx* ctx, const float* z, const int* lengths, int B, int precision,
+                     int quat_mode, float* feats_out, float* poses_out, float* trans_out,
+                     void* stream);
+
+/* Replaces PretrainedLPDM_v1.diffusion_backward end to end (infer_ldm.py:130-178):
+ * amuse_sample followed by amuse_vae_decode on the final latents. */
+int amuse_diffusion_backward(amuse_ctx* ctx, const float* con, const float* emo, const float* sty,
+                             int B, int precision, int quat_mode, uint64_t seed,
+                             uint64_t clip_index0, const float* x_init, const float* step_noise,
+                             float* latents_out, float* poses_out, float* trans_out, void* stream);
+
+/* The build's counter-based normal generator, exposed for tests: out[B][128] for clips
+ * clip_index0..+B, `step`, stream 0 (initial latent) or 1 (ancestral noise). */
+int amuse_counter_normal(amuse_ctx* ctx, uint64_t seed, uint64_t clip_index0, int B, int step,
+                         int rng_stream, float* out, void* stream);
+
+/* Clips per 4-wave workgroup in the sampling kernel: 0 = auto, else 1..3 (x S tokens <= 16 rows). */
+int amuse_set_clips_per_group(amuse_ctx* ctx, int g);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* AMUSE_HIP_H */
