@@ -249,13 +249,17 @@ int build_ctx(amuse_ctx* c, const float* den, const float* pri) {
             std::vector<uint4> s;
             for (int b = 0; b < 9; ++b) {
                 const std::string p = blk_name("encoder", b);
-                if (b >= 5) pack_skiplin(s, prec, D, "encoder", b - 5, w);
+                if (b >= 5) {
+                    pack_skiplin(s, prec, D, "encoder", b - 5, w);
+                    s.insert(s.end(), (size_t)skip_pad_units(prec) * 64, uint4{0, 0, 0, 0});  // ring alignment
+                }
                 pack_qkv(s, prec, D.get(p + ".self_attn.in_proj_weight"), w, true);
                 pack_outproj_ffn(s, prec, D, p, w);
             }
             if (w == 0) per_wave = s.size();
             else if (s.size() != per_wave) return fail(AMUSE_ESTATE, "internal: uneven denoiser wave streams");
             all.insert(all.end(), s.begin(), s.end());
+            all.insert(all.end(), s.begin(), s.begin() + (size_t)kRing * 64);  // ring wrap: tail = head
         }
         c->den_wave_units[prec] = (uint32_t)(per_wave / 64);
         if (upload(&c->den_w[prec], all.data(), all.size() * sizeof(uint4))) return AMUSE_EHIP;
@@ -450,6 +454,27 @@ int amuse_sample(amuse_ctx* c, const float* con, const float* emo, const float* 
     a.latents_out = latents_out; a.traj_out = traj_out; a.eps_out = nullptr; a.tap_out = nullptr;
     a.seed = seed; a.clip0 = clip_index0;
     a.B = B; a.T = c->T; a.S = S; a.G = pick_group(c, B, S); a.no_update = 0;
+    HIP_TRY(launch_sample(a, precision, st));
+    return 0;
+}
+
+int amuse_profile_sample(amuse_ctx* c, const float* con, const float* emo, const float* sty, int B, int precision,
+                         int prof_step, unsigned long long* stamps_out, void* stream) {
+    if (int e = check_common(c, con, B, precision)) return e;
+    if (c->T < 1) return fail(AMUSE_ESTATE, "amuse_set_schedule has not been called");
+    if (!stamps_out || prof_step < 0 || prof_step >= c->T) return fail(AMUSE_EINVAL, "bad stamps_out / prof_step");
+    hipStream_t st = (hipStream_t)stream;
+    int S = 0;
+    if (int e = cond_tokens(c, con, emo, sty, B, &S, st)) return e;
+    if (int e = ensure(&c->lat_tmp, &c->lat_cap, (size_t)B * kD)) return e;
+    HIP_TRY(hipMemsetAsync(stamps_out, 0, 4 * kProfStamps * sizeof(unsigned long long), st));
+    SampleArgs a{};
+    a.wstream = c->den_w[precision]; a.wave_units = c->den_wave_units[precision];
+    a.pvec = c->den_pvec; a.time_tok = c->d_time_tok; a.cond_tok = c->cond_tok; a.pe0 = c->den_pe;
+    a.coef = c->d_coef; a.latents_out = c->lat_tmp;
+    a.seed = 1; a.clip0 = 0;
+    a.B = B; a.T = c->T; a.S = S; a.G = pick_group(c, B, S); a.no_update = 0;
+    a.prof_out = stamps_out; a.prof_step = prof_step;
     HIP_TRY(launch_sample(a, precision, st));
     return 0;
 }

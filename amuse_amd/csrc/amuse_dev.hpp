@@ -105,17 +105,110 @@ __device__ __forceinline__ const uint4* gemm_tiles(f32x4 (&acc)[NO], const f32x4
     }
 }
 
+// ---- software-pipelined variant: the wave's weight stream flows through a ring of R register slots
+// (R x 1 KiB in flight per wave).  Every unit is consumed from its slot and the slot is immediately
+// re-armed with the unit R positions further down the stream, so loads run a full revolution ahead of
+// their use - across GEMM stages, barriers, blocks and denoising steps (the stream is sequential and
+// its first R units are replicated after its end, so the wrap at a step boundary needs no special case).
+// hipcc left to itself serialises this kernel's loads (global_load -> s_waitcnt vmcnt(0) -> v_mfma,
+// one L2 round trip per KiB); the ring is what turns the loop from latency- into bandwidth-bound.
+template <int R>
+struct WRing {
+    uint4 s[R];
+    const uint4* next;  // lane-offset address of the unit that re-arms the next consumed slot
+};
+template <int R>
+__device__ __forceinline__ void ring_fill(WRing<R>& rg, const uint4* w) {
+#pragma unroll
+    for (int i = 0; i < R; ++i) rg.s[i] = w[i * 64];
+    rg.next = w + R * 64;
+}
+// PH = ring phase (slot of the first unit) at entry; the caller tracks it at compile time.
+template <int PREC, int NO, int NK, bool SWAP, int R, int PH>
+__device__ __forceinline__ void gemm_ring(f32x4 (&acc)[NO], const f32x4 (&x)[NK], WRing<R>& rg) {
+    if constexpr (PREC == PREC_F32) {
+#pragma unroll
+        for (int t = 0; t < NK; ++t) {
+#pragma unroll
+            for (int o = 0; o < NO; ++o) {
+                const int slot = (PH + t * NO + o) % R;
+                const uint4 u = rg.s[slot];
+                rg.s[slot] = *rg.next;
+                rg.next += 64;
+                const f32x4 wf = __builtin_bit_cast(f32x4, u);
+#pragma unroll
+                for (int m = 0; m < 4; ++m)
+                    acc[o] = SWAP ? mfma_f32(x[t][m], wf[m], acc[o]) : mfma_f32(wf[m], x[t][m], acc[o]);
+            }
+        }
+    } else {
+        static_assert(NK % 2 == 0, "bf16 units cover k-tile pairs");
+#pragma unroll
+        for (int c = 0; c < NK / 2; ++c) {
+            const bf16x8 xb = pack_bf16(x[2 * c], x[2 * c + 1]);
+#pragma unroll
+            for (int o = 0; o < NO; ++o) {
+                const int slot = (PH + c * NO + o) % R;
+                const uint4 u = rg.s[slot];
+                rg.s[slot] = *rg.next;
+                rg.next += 64;
+                const bf16x8 wf = __builtin_bit_cast(bf16x8, u);
+                acc[o] = SWAP ? mfma_bf16(xb, wf, acc[o]) : mfma_bf16(wf, xb, acc[o]);
+            }
+        }
+    }
+}
+
+// consume N padding units (re-arm their slots, use nothing)
+template <int N, int R, int PH>
+__device__ __forceinline__ void ring_discard(WRing<R>& rg) {
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        rg.s[(PH + i) % R] = *rg.next;
+        rg.next += 64;
+    }
+}
+
 // units (1 KiB) consumed by gemm_tiles<PREC, NO, NK>
 constexpr int gemm_units(int prec, int no, int nk) { return prec == PREC_F32 ? no * nk : no * nk / 2; }
 
+// All-reduce over the four 16-lane rows of a wavefront (lanes l, l^16, l^32, l^48 - the "g" axis of the
+// row-lane layout) in two VALU instructions each: v_permlane16_swap / v_permlane32_swap exchange whole rows
+// between two registers, so (swap(v, v)[0] op swap(v, v)[1]) is the xor-16 resp. xor-32 butterfly without
+// the LDS round trip of ds_bpermute (__shfl_xor).  Every lane ends with the same value, combined in the
+// same order.
+// (Written as inline asm: ROCm 7.2 hipcc folds __builtin_amdgcn_permlane16_swap(u, u)[1] into [0] - it emits
+// v_add v, v3, v3 - whenever both operands carry the same value.  The s_nop covers the "VALU write ->
+// v_permlane*_swap read" hazard, which hipcc does not pad inside an asm statement.)
+__device__ __forceinline__ void swap_rows16(float& a, float& b) {
+    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+}
+__device__ __forceinline__ void swap_rows32(float& a, float& b) {
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+}
+__device__ __forceinline__ float allreduce_g_sum(float v) {
+    float a = v, b = v;
+    swap_rows16(a, b);   // a = [v0 v0 v2 v2], b = [v1 v1 v3 v3] (rows of 16 lanes)
+    float s = a + b, t = s;
+    swap_rows32(s, t);   // s = [lo lo], t = [hi hi]
+    return s + t;
+}
+__device__ __forceinline__ float allreduce_g_max(float v) {
+    float a = v, b = v;
+    swap_rows16(a, b);
+    float s = fmaxf(a, b), t = s;
+    swap_rows32(s, t);
+    return fmaxf(s, t);
+}
+
 // LayerNorm over the 128 features of each row, row-lane layout.  eps 1e-5, biased variance
-// (nn.LayerNorm).  gamma/beta are fp32 [128] in global memory.
+// (nn.LayerNorm).  gamma/beta are fp32 [128] (LDS or global).  FAST: v_rsq_f32 instead of 1/sqrt.
+template <bool FAST = false>
 __device__ __forceinline__ void layer_norm_rows(f32x4 (&x)[kTiles], const float* gamma, const float* beta, int g) {
     float s = 0.f;
 #pragma unroll
     for (int t = 0; t < kTiles; ++t) s += (x[t][0] + x[t][1]) + (x[t][2] + x[t][3]);
-    s += __shfl_xor(s, 16);
-    s += __shfl_xor(s, 32);
+    s = allreduce_g_sum(s);
     const float mean = s * (1.0f / kD);
     float v = 0.f;
 #pragma unroll
@@ -126,9 +219,8 @@ __device__ __forceinline__ void layer_norm_rows(f32x4 (&x)[kTiles], const float*
             v += d * d;
         }
     }
-    v += __shfl_xor(v, 16);
-    v += __shfl_xor(v, 32);
-    const float rstd = 1.0f / sqrtf(v * (1.0f / kD) + 1e-5f);
+    v = allreduce_g_sum(v);
+    const float rstd = FAST ? __builtin_amdgcn_rsqf(v * (1.0f / kD) + 1e-5f) : 1.0f / sqrtf(v * (1.0f / kD) + 1e-5f);
 #pragma unroll
     for (int t = 0; t < kTiles; ++t) {
         const f32x4 ga = ld4(gamma + 16 * t + 4 * g), be = ld4(beta + 16 * t + 4 * g);
@@ -138,25 +230,46 @@ __device__ __forceinline__ void layer_norm_rows(f32x4 (&x)[kTiles], const float*
 }
 
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+// exact-erf GELU through Abramowitz-Stegun 7.1.26 (|erf error| <= 1.5e-7, i.e. fp32 rounding class) with the
+// hardware rcp / exp2: ~14 VALU instead of ~60 for erff.  Used by the bf16 throughput mode.
+__device__ __forceinline__ float gelu_erf_fast(float x) {
+    const float z = fabsf(x) * 0.70710678118654752440f;
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));
+    float p = fmaf(t, 1.061405429f, -1.453152027f);
+    p = fmaf(t, p, 1.421413741f);
+    p = fmaf(t, p, -0.284496736f);
+    p = fmaf(t, p, 0.254829592f);
+    const float e = __builtin_amdgcn_exp2f(-1.44269504088896340736f * z * z);
+    const float erfabs = fmaf(-(p * t), e, 1.0f);
+    const float hx = 0.5f * x;
+    return fmaf(fabsf(hx), erfabs, hx);  // 0.5 x + 0.5 |x| erf(|x|/sqrt2) == 0.5 x (1 + erf(x/sqrt2))
+}
 
 // Split-K combine across the 4 waves of a workgroup: every wave publishes its partial [16 x 128]
 // tile, one barrier, every wave sums all four in the same order (so all waves hold bit-identical
 // copies afterwards).  `exch` = 2 x [4 waves][8 tiles][64 lanes] f32x4, alternated by `parity`, so a
 // single barrier per exchange is enough (WAR on buffer p is separated from its last readers by the
 // barrier of the exchange in between).
+template <int W>
+__device__ __forceinline__ void exchange_combine(f32x4 (&part)[kTiles], const f32x4* buf, int lane) {
+#pragma unroll
+    for (int t = 0; t < kTiles; ++t) {
+        // ((p0 + p1) + p2) + p3 in every wave; the wave's own partial comes from its registers
+        f32x4 p[4];
+#pragma unroll
+        for (int w = 0; w < 4; ++w) p[w] = (w == W) ? part[t] : buf[(w * kTiles + t) * 64 + lane];
+        part[t] = ((p[0] + p[1]) + p[2]) + p[3];
+    }
+}
 __device__ __forceinline__ void exchange_sum(f32x4 (&part)[kTiles], f32x4* exch, int& parity, int wave, int lane) {
     f32x4* buf = exch + parity * (4 * kTiles * 64);
 #pragma unroll
     for (int t = 0; t < kTiles; ++t) buf[(wave * kTiles + t) * 64 + lane] = part[t];
     __syncthreads();
-#pragma unroll
-    for (int t = 0; t < kTiles; ++t) {
-        f32x4 s = buf[(0 * kTiles + t) * 64 + lane];
-        s += buf[(1 * kTiles + t) * 64 + lane];
-        s += buf[(2 * kTiles + t) * 64 + lane];
-        s += buf[(3 * kTiles + t) * 64 + lane];
-        part[t] = s;
-    }
+    if (wave == 0) exchange_combine<0>(part, buf, lane);
+    else if (wave == 1) exchange_combine<1>(part, buf, lane);
+    else if (wave == 2) exchange_combine<2>(part, buf, lane);
+    else exchange_combine<3>(part, buf, lane);
     parity ^= 1;
 }
 constexpr int kExchBytes = 2 * 4 * kTiles * 64 * 16;  // 64 KiB
@@ -178,9 +291,12 @@ __device__ __forceinline__ f32x4 counter_normal4(uint64_t seed, uint64_t clip, u
     float u[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) u[i] = (float)(c[i] >> 8) * 5.9604644775390625e-8f + 2.98023223876953125e-8f;
-    const float r0 = sqrtf(-2.0f * logf(u[0])), r1 = sqrtf(-2.0f * logf(u[2]));
-    const float t0 = 6.28318530717958647692f * u[1], t1 = 6.28318530717958647692f * u[3];
-    return f32x4{r0 * cosf(t0), r0 * sinf(t0), r1 * cosf(t1), r1 * sinf(t1)};
+    // Box-Muller on the hardware transcendentals: v_log_f32 (log2), v_sqrt_f32, v_sin/v_cos_f32 (argument in
+    // revolutions, so sin(2 pi u) is v_sin_f32(u): no range reduction).  r = sqrt(-2 ln u) = sqrt(-2 ln2 log2 u)
+    const float r0 = __builtin_amdgcn_sqrtf(-1.38629436111989061883f * __builtin_amdgcn_logf(u[0]));
+    const float r1 = __builtin_amdgcn_sqrtf(-1.38629436111989061883f * __builtin_amdgcn_logf(u[2]));
+    return f32x4{r0 * __builtin_amdgcn_cosf(u[1]), r0 * __builtin_amdgcn_sinf(u[1]),
+                 r1 * __builtin_amdgcn_cosf(u[3]), r1 * __builtin_amdgcn_sinf(u[3])};
 }
 
 }  // namespace amuse

@@ -7,7 +7,7 @@ namespace amuse {
 
 // ---------------------------------------------------------------- sampling loop (k_sampler.hip)
 struct SampleArgs {
-    const uint4* wstream;     // packed denoiser weights for the chosen precision: [4 waves][wave_units][64] x 16 B
+    const uint4* wstream;     // packed denoiser weights: [4 waves][wave_units + kRing][64] x 16 B (head replicated at the tail)
     uint32_t wave_units;      // 1 KiB units per wave for one pass over the network
     const float* pvec;        // small fp32 parameters (amuse_dev.hpp PV_* layout)
     const float* time_tok;    // [T][128]  TimestepEmbedding(t_i) + pe[1]
@@ -24,9 +24,17 @@ struct SampleArgs {
     uint64_t clip0;
     int B, T, S, G;
     int no_update;            // 1: teacher-forced (no scheduler update)
+    unsigned long long* prof_out;  // [4 waves][kProfStamps] s_memtime stamps of step prof_step, or null
+    int prof_step;
 };
+constexpr int kProfStamps = 128;
 hipError_t launch_sample(const SampleArgs& a, int precision, hipStream_t stream);
-constexpr int kSampleLdsBytes = 64 * 1024 + 32 * 1024;  // exchange + skip stack
+constexpr int kRing = 32;                 // weight-stream ring depth (1 KiB units in flight per wave)
+// the skip linear (8 out tiles x 4 k-tiles per wave) is padded with dummy units to whole ring revolutions
+constexpr int skip_pad_units(int prec) { const int u = (prec == 0) ? 32 : 16; return (kRing - u % kRing) % kRing; }
+constexpr int kEncPv = 1664;              // encoder-block small params kept in LDS (PV_* up to LN2)
+constexpr int kSkipBytes = 32 * 1024;     // U-Net skip stack [4][8][64] f32x4
+constexpr int kSampleLdsBytes = 64 * 1024 + kSkipBytes + (9 * kEncPv + 4 * 128 + 2 * 128) * 4;  // 161,280 B
 
 // ---------------------------------------------------------------- one-off prologue kernels (k_misc.hip)
 // time_tok[i][:] = Linear2(SiLU(Linear1([cos|sin](t_i * freqs)))) + pe1     (embeddings.py:245-322)

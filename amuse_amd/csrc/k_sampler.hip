@@ -39,17 +39,16 @@ __device__ __forceinline__ void attention_head(const f32x4 (&q)[2], const f32x4 
     float mx = -INFINITY;
 #pragma unroll
     for (int m = 0; m < 4; ++m) mx = kvalid[m] ? fmaxf(mx, st[m]) : mx;
-    mx = fmaxf(mx, __shfl_xor(mx, 16));
-    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    mx = allreduce_g_max(mx);
     f32x4 p;
     float sum = 0.f;
 #pragma unroll
     for (int m = 0; m < 4; ++m) {
-        p[m] = kvalid[m] ? expf(st[m] - mx) : 0.f;
+        const float e = (PREC == PREC_F32) ? expf(st[m] - mx) : __builtin_amdgcn_exp2f(1.44269504088896340736f * (st[m] - mx));
+        p[m] = kvalid[m] ? e : 0.f;
         sum += p[m];
     }
-    sum += __shfl_xor(sum, 16);
-    sum += __shfl_xor(sum, 32);
+    sum = allreduce_g_sum(sum);
 #pragma unroll
     for (int m = 0; m < 4; ++m) p[m] = p[m] / sum;
     // O^T[d][i] = sum_j V[j][d] P[i][j]; v is feature-lane: lane (g, d) holds V[4 g + m][d]
@@ -65,12 +64,32 @@ __device__ __forceinline__ void attention_head(const f32x4 (&q)[2], const f32x4 
     }
 }
 
+// optional phase timeline (s_memtime stamps by lane 0 of every wave of workgroup 0 during ONE step);
+// compiled out of the production instantiation
+struct Prof {
+    unsigned long long* out;
+    int idx;
+    bool on;
+};
+template <bool PROF>
+__device__ __forceinline__ void stamp(Prof& pf) {
+    if constexpr (PROF) {
+        if (pf.on) pf.out[pf.idx++] = __builtin_readcyclecounter();
+    }
+}
+
 // One TransformerEncoderLayer.forward_post (cross_attention.py:259-272) on the row-lane tile x.
-template <int PREC>
-__device__ __forceinline__ const uint4* encoder_block(f32x4 (&x)[kTiles], const uint4* __restrict__ w,
-                                                      const float* __restrict__ pv, const bool (&kvalid)[4],
-                                                      f32x4* exch, int& parity, int wave, int lane) {
+template <int PREC, bool PROF>
+__device__ __forceinline__ void encoder_block(f32x4 (&x)[kTiles], WRing<kRing>& rg, const float* pv,
+                                              const bool (&kvalid)[4], f32x4* exch, int& parity, int wave, int lane,
+                                              Prof& pf) {
     const int g = lane >> 4, r = lane & 15;
+    // ring phases of the five GEMMs of a block (compile-time; a block consumes a whole number of revolutions)
+    constexpr int U_QK = gemm_units(PREC, 4, kTiles), U_V = gemm_units(PREC, 2, kTiles);
+    constexpr int U_OUT = gemm_units(PREC, kTiles, 2), U_FF = gemm_units(PREC, kTiles, kTiles);
+    constexpr int P_QK = 0, P_V = (P_QK + U_QK) % kRing, P_OUT = (P_V + U_V) % kRing;
+    constexpr int P_F1 = (P_OUT + U_OUT) % kRing, P_F2 = (P_F1 + U_FF) % kRing;
+    static_assert((P_F2 + U_FF) % kRing == 0, "a block must leave the ring at phase 0");
     // ---- in_proj: q_h, k_h (row-lane) and v_h (feature-lane) for head h = wave
     f32x4 qk[4], v[2];
 #pragma unroll
@@ -79,39 +98,48 @@ __device__ __forceinline__ const uint4* encoder_block(f32x4 (&x)[kTiles], const 
         qk[2 + o] = ld4(pv + PV_IN_B + kD + 16 * (2 * wave + o) + 4 * g);
         v[o] = splat4(pv[PV_IN_B + 2 * kD + 16 * (2 * wave + o) + r]);
     }
-    w = gemm_tiles<PREC, 4, kTiles, false>(qk, x, w);
-    w = gemm_tiles<PREC, 2, kTiles, true>(v, x, w);
+    gemm_ring<PREC, 4, kTiles, false, kRing, P_QK>(qk, x, rg);
+    gemm_ring<PREC, 2, kTiles, true, kRing, P_V>(v, x, rg);
+    stamp<PROF>(pf);  // 1: in_proj done
     const float scaling = 0.17677669529663687f;  // sqrt(1/32): q * scaling (F.multi_head_attention_forward)
     f32x4 q[2] = {qk[0] * scaling, qk[1] * scaling};
     f32x4 k[2] = {qk[2], qk[3]};
     f32x4 o[2];
     attention_head<PREC>(q, k, v, kvalid, o);
+    stamp<PROF>(pf);  // 2: attention done
     // ---- out_proj, split-K over heads; combine; residual; LayerNorm1
     f32x4 part[kTiles];
 #pragma unroll
     for (int t = 0; t < kTiles; ++t) part[t] = splat4(0.f);
-    w = gemm_tiles<PREC, kTiles, 2, false>(part, o, w);
+    gemm_ring<PREC, kTiles, 2, false, kRing, P_OUT>(part, o, rg);
+    stamp<PROF>(pf);  // 3: out_proj partial done
     exchange_sum(part, exch, parity, wave, lane);
+    stamp<PROF>(pf);  // 4: combine 1 done
 #pragma unroll
     for (int t = 0; t < kTiles; ++t) x[t] = x[t] + (part[t] + ld4(pv + PV_OUT_B + 16 * t + 4 * g));
-    layer_norm_rows(x, pv + PV_LN1_W, pv + PV_LN1_B, g);
+    layer_norm_rows<PREC == PREC_BF16>(x, pv + PV_LN1_W, pv + PV_LN1_B, g);
+    stamp<PROF>(pf);  // 5: LN1 done
     // ---- FFN: linear1 (this wave's 128 hidden features) -> GELU -> linear2 split-K over them
     f32x4 hid[kTiles];
 #pragma unroll
     for (int t = 0; t < kTiles; ++t) hid[t] = ld4(pv + PV_L1_B + 16 * (kTiles * wave + t) + 4 * g);
-    w = gemm_tiles<PREC, kTiles, kTiles, false>(hid, x, w);
+    gemm_ring<PREC, kTiles, kTiles, false, kRing, P_F1>(hid, x, rg);
+    stamp<PROF>(pf);  // 6: linear1 done
 #pragma unroll
     for (int t = 0; t < kTiles; ++t)
 #pragma unroll
-        for (int m = 0; m < 4; ++m) hid[t][m] = gelu_erf(hid[t][m]);
+        for (int m = 0; m < 4; ++m) hid[t][m] = (PREC == PREC_F32) ? gelu_erf(hid[t][m]) : gelu_erf_fast(hid[t][m]);
+    stamp<PROF>(pf);  // 7: GELU done
 #pragma unroll
     for (int t = 0; t < kTiles; ++t) part[t] = splat4(0.f);
-    w = gemm_tiles<PREC, kTiles, kTiles, false>(part, hid, w);
+    gemm_ring<PREC, kTiles, kTiles, false, kRing, P_F2>(part, hid, rg);
+    stamp<PROF>(pf);  // 8: linear2 partial done
     exchange_sum(part, exch, parity, wave, lane);
+    stamp<PROF>(pf);  // 9: combine 2 done
 #pragma unroll
     for (int t = 0; t < kTiles; ++t) x[t] = x[t] + (part[t] + ld4(pv + PV_L2_B + 16 * t + 4 * g));
-    layer_norm_rows(x, pv + PV_LN2_W, pv + PV_LN2_B, g);
-    return w;
+    layer_norm_rows<PREC == PREC_BF16>(x, pv + PV_LN2_W, pv + PV_LN2_B, g);
+    stamp<PROF>(pf);  // 10: LN2 done
 }
 
 __device__ __forceinline__ void store_tap(float* tap, int slot, const f32x4 (&x)[kTiles], int g, int r) {
@@ -119,11 +147,20 @@ __device__ __forceinline__ void store_tap(float* tap, int slot, const f32x4 (&x)
     for (int t = 0; t < kTiles; ++t) st4(tap + ((size_t)slot * 16 + r) * kD + 16 * t + 4 * g, x[t]);
 }
 
-template <int PREC>
+template <int PREC, bool PROF>
 __global__ __launch_bounds__(256, 1) void k_sample(SampleArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     f32x4* exch = reinterpret_cast<f32x4*>(smem);
     f32x4* skip = reinterpret_cast<f32x4*>(smem + kExchBytes);  // [4][8 tiles][64 lanes]
+    float* pvl = reinterpret_cast<float*>(smem + kExchBytes + kSkipBytes);  // small params, compact (kEncPv / block)
+    for (int i = threadIdx.x; i < kLayers * kEncPv / 4; i += 256) {
+        const int blk = (4 * i) / kEncPv, off = 4 * i - blk * kEncPv;
+        st4(pvl + 4 * i, ld4(a.pvec + blk * PV_BLOCK + off));
+    }
+    for (int i = threadIdx.x; i < (4 * kD + 2 * kD) / 4; i += 256) st4(pvl + kLayers * kEncPv + 4 * i, ld4(a.pvec + PV_SKIP_B + 4 * i));
+    const float* pv_skip = pvl + kLayers * kEncPv;
+    const float* pv_final = pv_skip + 4 * kD;
+    __syncthreads();
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int g = lane >> 4, r = lane & 15;
@@ -158,10 +195,10 @@ __global__ __launch_bounds__(256, 1) void k_sample(SampleArgs a) {
     }
     const bool tap = a.tap_out != nullptr && blockIdx.x == 0 && wave == 0;
     int parity = 0;
-    f32x4 eps[kTiles];
-#pragma unroll
-    for (int t = 0; t < kTiles; ++t) eps[t] = splat4(0.f);
-
+    const uint4* wbase = a.wstream + (size_t)wave * (a.wave_units + kRing) * 64 + lane;
+    WRing<kRing> rg;
+    ring_fill(rg, wbase);
+    Prof pf{a.prof_out ? a.prof_out + (size_t)wave * kProfStamps : nullptr, 0, false};
 #pragma unroll 1
     for (int step = 0; step < a.T; ++step) {
         // ---- token assembly (denoiser.py:174,180-181)
@@ -173,7 +210,12 @@ __global__ __launch_bounds__(256, 1) void k_sample(SampleArgs a) {
             x[t] = !valid ? splat4(0.f) : (tok == 0 ? lat[t] + stat[t] : (tok == 1 ? tv : stat[t]));
         }
         if (tap && step == 0) store_tap(a.tap_out, 0, x, g, r);
-        const uint4* w = a.wstream + (size_t)wave * a.wave_units * 64 + lane;
+        rg.next = wbase + kRing * 64;  // the ring already holds units 0..R-1 of this step (stream tail = its head)
+        if constexpr (PROF) {
+            pf.on = a.prof_out != nullptr && blockIdx.x == 0 && lane == 0 && step == a.prof_step;
+            pf.idx = 0;
+        }
+        stamp<PROF>(pf);  // 0: step start (token assembly done)
         // ---- SkipTransformerEncoder.forward (cross_attention.py:41-64)
 #pragma unroll 1
         for (int blk = 0; blk < kLayers; ++blk) {
@@ -188,13 +230,16 @@ __global__ __launch_bounds__(256, 1) void k_sample(SampleArgs a) {
                 f32x4 part[kTiles];
 #pragma unroll
                 for (int t = 0; t < kTiles; ++t) part[t] = splat4(0.f);
-                w = gemm_tiles<PREC, kTiles, 4, false>(part, src, w);
+                constexpr int U_SK = gemm_units(PREC, kTiles, 4);
+                gemm_ring<PREC, kTiles, 4, false, kRing, 0>(part, src, rg);
+                ring_discard<skip_pad_units(PREC), kRing, U_SK % kRing>(rg);  // host pads to whole revolutions
                 exchange_sum(part, exch, parity, wave, lane);
-                const float* sb = a.pvec + PV_SKIP_B + (blk - 5) * kD;
+                const float* sb = pv_skip + (blk - 5) * kD;
 #pragma unroll
                 for (int t = 0; t < kTiles; ++t) x[t] = part[t] + ld4(sb + 16 * t + 4 * g);
             }
-            w = encoder_block<PREC>(x, w, a.pvec + blk * PV_BLOCK, kvalid, exch, parity, wave, lane);
+            stamp<PROF>(pf);  // block start (after the skip linear, if any)
+            encoder_block<PREC, PROF>(x, rg, pvl + blk * kEncPv, kvalid, exch, parity, wave, lane, pf);
             if (blk < 4 && wave == 0) {
                 f32x4* sk = skip + (size_t)blk * kTiles * 64;
 #pragma unroll
@@ -202,10 +247,12 @@ __global__ __launch_bounds__(256, 1) void k_sample(SampleArgs a) {
             }
             if (tap && step == 0) store_tap(a.tap_out, 1 + blk, x, g, r);
         }
-        layer_norm_rows(x, a.pvec + PV_FINAL_W, a.pvec + PV_FINAL_B, g);
+        layer_norm_rows<PREC == PREC_BF16>(x, pv_final, pv_final + kD, g);
         if (tap && step == 0) store_tap(a.tap_out, 10, x, g, r);
+        if (a.eps_out && is_lat && wave == 0 && step == a.T - 1) {
 #pragma unroll
-        for (int t = 0; t < kTiles; ++t) eps[t] = x[t];
+            for (int t = 0; t < kTiles; ++t) st4(a.eps_out + (size_t)clip * kD + 16 * t + 4 * g, x[t]);
+        }
         // ---- scheduler.step (diffusers 0.17.1 DDIM / DDPM; amuse_hip.h amuse_schedule)
         if (!a.no_update) {
             const float* cf = a.coef + (size_t)step * 8;
@@ -220,7 +267,7 @@ __global__ __launch_bounds__(256, 1) void k_sample(SampleArgs a) {
                 }
 #pragma unroll
                 for (int m = 0; m < 4; ++m) {
-                    const float e = eps[t][m], xl = lat[t][m];
+                    const float e = x[t][m], xl = lat[t][m];
                     float x0 = __fdiv_rn(__fsub_rn(xl, __fmul_rn(sb, e)), sa);
                     if (clipv > 0.f) x0 = fminf(fmaxf(x0, -clipv), clipv);
                     float nx = __fmul_rn(c0, x0);
@@ -230,6 +277,7 @@ __global__ __launch_bounds__(256, 1) void k_sample(SampleArgs a) {
                     lat[t][m] = nx;
                 }
             }
+            stamp<PROF>(pf);  // scheduler update done
             if (a.traj_out && is_lat && wave == 0) {
 #pragma unroll
                 for (int t = 0; t < kTiles; ++t)
@@ -241,7 +289,6 @@ __global__ __launch_bounds__(256, 1) void k_sample(SampleArgs a) {
 #pragma unroll
         for (int t = 0; t < kTiles; ++t) {
             if (a.latents_out) st4(a.latents_out + (size_t)clip * kD + 16 * t + 4 * g, lat[t]);
-            if (a.eps_out) st4(a.eps_out + (size_t)clip * kD + 16 * t + 4 * g, eps[t]);
         }
     }
 }
@@ -253,18 +300,23 @@ hipError_t launch_sample(const SampleArgs& a, int precision, hipStream_t stream)
     const dim3 grid(tiles), block(256);
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_sample<PREC_F32>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, kSampleLdsBytes);
-        if (e != hipSuccess) return e;
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_sample<PREC_BF16>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, kSampleLdsBytes);
-        if (e != hipSuccess) return e;
+        const void* ks[4] = {reinterpret_cast<const void*>(&k_sample<PREC_F32, false>),
+                             reinterpret_cast<const void*>(&k_sample<PREC_BF16, false>),
+                             reinterpret_cast<const void*>(&k_sample<PREC_F32, true>),
+                             reinterpret_cast<const void*>(&k_sample<PREC_BF16, true>)};
+        for (const void* k : ks) {
+            hipError_t e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, kSampleLdsBytes);
+            if (e != hipSuccess) return e;
+        }
         attr_set = true;
     }
-    if (precision == PREC_F32)
-        hipLaunchKernelGGL(k_sample<PREC_F32>, grid, block, kSampleLdsBytes, stream, a);
-    else
-        hipLaunchKernelGGL(k_sample<PREC_BF16>, grid, block, kSampleLdsBytes, stream, a);
+    if (a.prof_out) {
+        if (precision == PREC_F32) hipLaunchKernelGGL((k_sample<PREC_F32, true>), grid, block, kSampleLdsBytes, stream, a);
+        else hipLaunchKernelGGL((k_sample<PREC_BF16, true>), grid, block, kSampleLdsBytes, stream, a);
+    } else {
+        if (precision == PREC_F32) hipLaunchKernelGGL((k_sample<PREC_F32, false>), grid, block, kSampleLdsBytes, stream, a);
+        else hipLaunchKernelGGL((k_sample<PREC_BF16, false>), grid, block, kSampleLdsBytes, stream, a);
+    }
     return hipGetLastError();
 }
 

