@@ -127,18 +127,24 @@ __device__ __forceinline__ void ring_fill(WRing<R>& rg, const uint4* w) {
 template <int PREC, int NO, int NK, bool SWAP, int R, int PH>
 __device__ __forceinline__ void gemm_ring(f32x4 (&acc)[NO], const f32x4 (&x)[NK], WRing<R>& rg) {
     if constexpr (PREC == PREC_F32) {
+        static_assert(NO % 2 == 0, "output tiles are processed in pairs");
 #pragma unroll
         for (int t = 0; t < NK; ++t) {
 #pragma unroll
-            for (int o = 0; o < NO; ++o) {
-                const int slot = (PH + t * NO + o) % R;
-                const uint4 u = rg.s[slot];
-                rg.s[slot] = *rg.next;
-                rg.next += 64;
-                const f32x4 wf = __builtin_bit_cast(f32x4, u);
+            for (int o = 0; o < NO; o += 2) {
+                // two units at a time, MFMAs alternating between their accumulators: a v_mfma_f32_16x16x4_f32
+                // chain on ONE accumulator pays 40 cycles per instruction instead of the 32-cycle issue rate
+                const int s0 = (PH + t * NO + o) % R, s1 = (PH + t * NO + o + 1) % R;
+                const f32x4 w0 = __builtin_bit_cast(f32x4, rg.s[s0]);
+                const f32x4 w1 = __builtin_bit_cast(f32x4, rg.s[s1]);
+                rg.s[s0] = rg.next[0];
+                rg.s[s1] = rg.next[64];
+                rg.next += 128;
 #pragma unroll
-                for (int m = 0; m < 4; ++m)
-                    acc[o] = SWAP ? mfma_f32(x[t][m], wf[m], acc[o]) : mfma_f32(wf[m], x[t][m], acc[o]);
+                for (int m = 0; m < 4; ++m) {
+                    acc[o] = SWAP ? mfma_f32(x[t][m], w0[m], acc[o]) : mfma_f32(w0[m], x[t][m], acc[o]);
+                    acc[o + 1] = SWAP ? mfma_f32(x[t][m], w1[m], acc[o + 1]) : mfma_f32(w1[m], x[t][m], acc[o + 1]);
+                }
             }
         }
     } else {
@@ -203,8 +209,19 @@ __device__ __forceinline__ float allreduce_g_max(float v) {
 
 // LayerNorm over the 128 features of each row, row-lane layout.  eps 1e-5, biased variance
 // (nn.LayerNorm).  gamma/beta are fp32 [128] (LDS or global).  FAST: v_rsq_f32 instead of 1/sqrt.
+struct LnParams {
+    f32x4 ga[kTiles], be[kTiles];
+};
+// issue the 16 parameter reads early (a phase ahead of their use) so their LDS/L2 latency is off the chain
+__device__ __forceinline__ void ln_params_load(LnParams& p, const float* gamma, const float* beta, int g) {
+#pragma unroll
+    for (int t = 0; t < kTiles; ++t) {
+        p.ga[t] = ld4(gamma + 16 * t + 4 * g);
+        p.be[t] = ld4(beta + 16 * t + 4 * g);
+    }
+}
 template <bool FAST = false>
-__device__ __forceinline__ void layer_norm_rows(f32x4 (&x)[kTiles], const float* gamma, const float* beta, int g) {
+__device__ __forceinline__ void layer_norm_rows(f32x4 (&x)[kTiles], const LnParams& p) {
     float s = 0.f;
 #pragma unroll
     for (int t = 0; t < kTiles; ++t) s += (x[t][0] + x[t][1]) + (x[t][2] + x[t][3]);
@@ -223,10 +240,15 @@ __device__ __forceinline__ void layer_norm_rows(f32x4 (&x)[kTiles], const float*
     const float rstd = FAST ? __builtin_amdgcn_rsqf(v * (1.0f / kD) + 1e-5f) : 1.0f / sqrtf(v * (1.0f / kD) + 1e-5f);
 #pragma unroll
     for (int t = 0; t < kTiles; ++t) {
-        const f32x4 ga = ld4(gamma + 16 * t + 4 * g), be = ld4(beta + 16 * t + 4 * g);
 #pragma unroll
-        for (int m = 0; m < 4; ++m) x[t][m] = (x[t][m] - mean) * rstd * ga[m] + be[m];
+        for (int m = 0; m < 4; ++m) x[t][m] = (x[t][m] - mean) * rstd * p.ga[t][m] + p.be[t][m];
     }
+}
+template <bool FAST = false>
+__device__ __forceinline__ void layer_norm_rows(f32x4 (&x)[kTiles], const float* gamma, const float* beta, int g) {
+    LnParams p;
+    ln_params_load(p, gamma, beta, g);
+    layer_norm_rows<FAST>(x, p);
 }
 
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
@@ -252,13 +274,22 @@ __device__ __forceinline__ float gelu_erf_fast(float x) {
 // barrier of the exchange in between).
 template <int W>
 __device__ __forceinline__ void exchange_combine(f32x4 (&part)[kTiles], const f32x4* buf, int lane) {
+    // reads of the other waves' partials batched 12 at a time (hipcc otherwise emits read-3 / wait / add
+    // groups, one LDS round trip each), then ((p0 + p1) + p2) + p3 with the wave's own partial from registers
 #pragma unroll
-    for (int t = 0; t < kTiles; ++t) {
-        // ((p0 + p1) + p2) + p3 in every wave; the wave's own partial comes from its registers
-        f32x4 p[4];
+    for (int h = 0; h < 2; ++h) {
+        f32x4 p[4][kTiles / 2];
 #pragma unroll
-        for (int w = 0; w < 4; ++w) p[w] = (w == W) ? part[t] : buf[(w * kTiles + t) * 64 + lane];
-        part[t] = ((p[0] + p[1]) + p[2]) + p[3];
+        for (int t = 0; t < kTiles / 2; ++t)
+#pragma unroll
+            for (int w = 0; w < 4; ++w)
+                if (w != W) p[w][t] = buf[(w * kTiles + h * (kTiles / 2) + t) * 64 + lane];
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int t = 0; t < kTiles / 2; ++t) {
+            p[W][t] = part[h * (kTiles / 2) + t];
+            part[h * (kTiles / 2) + t] = ((p[0][t] + p[1][t]) + p[2][t]) + p[3][t];
+        }
     }
 }
 __device__ __forceinline__ void exchange_sum(f32x4 (&part)[kTiles], f32x4* exch, int& parity, int wave, int lane) {

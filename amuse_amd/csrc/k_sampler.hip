@@ -90,20 +90,33 @@ __device__ __forceinline__ void encoder_block(f32x4 (&x)[kTiles], WRing<kRing>& 
     constexpr int P_QK = 0, P_V = (P_QK + U_QK) % kRing, P_OUT = (P_V + U_V) % kRing;
     constexpr int P_F1 = (P_OUT + U_OUT) % kRing, P_F2 = (P_F1 + U_FF) % kRing;
     static_assert((P_F2 + U_FF) % kRing == 0, "a block must leave the ring at phase 0");
+    constexpr bool FAST = (PREC == PREC_BF16);
+    // Small parameters (LDS) are read one phase ahead of their use; biases are added AFTER the GEMM that
+    // they belong to, so no LDS round trip sits in front of a GEMM's first MFMA.
+    f32x4 b_qk[4];
+    float b_v[2];
+#pragma unroll
+    for (int o = 0; o < 2; ++o) {
+        b_qk[o] = ld4(pv + PV_IN_B + 16 * (2 * wave + o) + 4 * g);
+        b_qk[2 + o] = ld4(pv + PV_IN_B + kD + 16 * (2 * wave + o) + 4 * g);
+        b_v[o] = pv[PV_IN_B + 2 * kD + 16 * (2 * wave + o) + r];
+    }
     // ---- in_proj: q_h, k_h (row-lane) and v_h (feature-lane) for head h = wave
     f32x4 qk[4], v[2];
 #pragma unroll
-    for (int o = 0; o < 2; ++o) {
-        qk[o] = ld4(pv + PV_IN_B + 16 * (2 * wave + o) + 4 * g);
-        qk[2 + o] = ld4(pv + PV_IN_B + kD + 16 * (2 * wave + o) + 4 * g);
-        v[o] = splat4(pv[PV_IN_B + 2 * kD + 16 * (2 * wave + o) + r]);
-    }
+    for (int o = 0; o < 4; ++o) qk[o] = splat4(0.f);
+    v[0] = v[1] = splat4(0.f);
     gemm_ring<PREC, 4, kTiles, false, kRing, P_QK>(qk, x, rg);
     gemm_ring<PREC, 2, kTiles, true, kRing, P_V>(v, x, rg);
     stamp<PROF>(pf);  // 1: in_proj done
+    f32x4 b_out[kTiles];
+#pragma unroll
+    for (int t = 0; t < kTiles; ++t) b_out[t] = ld4(pv + PV_OUT_B + 16 * t + 4 * g);
     const float scaling = 0.17677669529663687f;  // sqrt(1/32): q * scaling (F.multi_head_attention_forward)
-    f32x4 q[2] = {qk[0] * scaling, qk[1] * scaling};
-    f32x4 k[2] = {qk[2], qk[3]};
+    f32x4 q[2] = {(qk[0] + b_qk[0]) * scaling, (qk[1] + b_qk[1]) * scaling};
+    f32x4 k[2] = {qk[2] + b_qk[2], qk[3] + b_qk[3]};
+    v[0] += splat4(b_v[0]);
+    v[1] += splat4(b_v[1]);
     f32x4 o[2];
     attention_head<PREC>(q, k, v, kvalid, o);
     stamp<PROF>(pf);  // 2: attention done
@@ -115,30 +128,42 @@ __device__ __forceinline__ void encoder_block(f32x4 (&x)[kTiles], WRing<kRing>& 
     stamp<PROF>(pf);  // 3: out_proj partial done
     exchange_sum(part, exch, parity, wave, lane);
     stamp<PROF>(pf);  // 4: combine 1 done
+    LnParams ln;
+    ln_params_load(ln, pv + PV_LN1_W, pv + PV_LN1_B, g);
 #pragma unroll
-    for (int t = 0; t < kTiles; ++t) x[t] = x[t] + (part[t] + ld4(pv + PV_OUT_B + 16 * t + 4 * g));
-    layer_norm_rows<PREC == PREC_BF16>(x, pv + PV_LN1_W, pv + PV_LN1_B, g);
+    for (int t = 0; t < kTiles; ++t) x[t] = x[t] + (part[t] + b_out[t]);
+    layer_norm_rows<FAST>(x, ln);
     stamp<PROF>(pf);  // 5: LN1 done
     // ---- FFN: linear1 (this wave's 128 hidden features) -> GELU -> linear2 split-K over them
-    f32x4 hid[kTiles];
+    f32x4 hid[kTiles], b_l1[kTiles];
 #pragma unroll
-    for (int t = 0; t < kTiles; ++t) hid[t] = ld4(pv + PV_L1_B + 16 * (kTiles * wave + t) + 4 * g);
+    for (int t = 0; t < kTiles; ++t) {
+        b_l1[t] = ld4(pv + PV_L1_B + 16 * (kTiles * wave + t) + 4 * g);
+        hid[t] = splat4(0.f);
+    }
     gemm_ring<PREC, kTiles, kTiles, false, kRing, P_F1>(hid, x, rg);
     stamp<PROF>(pf);  // 6: linear1 done
 #pragma unroll
     for (int t = 0; t < kTiles; ++t)
 #pragma unroll
-        for (int m = 0; m < 4; ++m) hid[t][m] = (PREC == PREC_F32) ? gelu_erf(hid[t][m]) : gelu_erf_fast(hid[t][m]);
+        for (int m = 0; m < 4; ++m) {
+            const float h = hid[t][m] + b_l1[t][m];
+            hid[t][m] = FAST ? gelu_erf_fast(h) : gelu_erf(h);
+        }
     stamp<PROF>(pf);  // 7: GELU done
 #pragma unroll
-    for (int t = 0; t < kTiles; ++t) part[t] = splat4(0.f);
+    for (int t = 0; t < kTiles; ++t) {
+        b_out[t] = ld4(pv + PV_L2_B + 16 * t + 4 * g);
+        part[t] = splat4(0.f);
+    }
     gemm_ring<PREC, kTiles, kTiles, false, kRing, P_F2>(part, hid, rg);
     stamp<PROF>(pf);  // 8: linear2 partial done
     exchange_sum(part, exch, parity, wave, lane);
     stamp<PROF>(pf);  // 9: combine 2 done
+    ln_params_load(ln, pv + PV_LN2_W, pv + PV_LN2_B, g);
 #pragma unroll
-    for (int t = 0; t < kTiles; ++t) x[t] = x[t] + (part[t] + ld4(pv + PV_L2_B + 16 * t + 4 * g));
-    layer_norm_rows<PREC == PREC_BF16>(x, pv + PV_LN2_W, pv + PV_LN2_B, g);
+    for (int t = 0; t < kTiles; ++t) x[t] = x[t] + (part[t] + b_out[t]);
+    layer_norm_rows<FAST>(x, ln);
     stamp<PROF>(pf);  // 10: LN2 done
 }
 
@@ -199,15 +224,21 @@ __global__ __launch_bounds__(256, 1) void k_sample(SampleArgs a) {
     WRing<kRing> rg;
     ring_fill(rg, wbase);
     Prof pf{a.prof_out ? a.prof_out + (size_t)wave * kProfStamps : nullptr, 0, false};
+    // `stat` of the time-token rows (tok == 1) holds the token of the NEXT step, fetched a whole step ahead
+    if (valid && tok == 1) {
+#pragma unroll
+        for (int t = 0; t < kTiles; ++t) stat[t] = ld4(a.time_tok + 16 * t + 4 * g);
+    }
 #pragma unroll 1
     for (int step = 0; step < a.T; ++step) {
         // ---- token assembly (denoiser.py:174,180-181)
-        const float* tt = a.time_tok + (size_t)step * kD;
         f32x4 x[kTiles];
 #pragma unroll
-        for (int t = 0; t < kTiles; ++t) {
-            const f32x4 tv = ld4(tt + 16 * t + 4 * g);
-            x[t] = !valid ? splat4(0.f) : (tok == 0 ? lat[t] + stat[t] : (tok == 1 ? tv : stat[t]));
+        for (int t = 0; t < kTiles; ++t) x[t] = !valid ? splat4(0.f) : ((tok == 0) ? lat[t] + stat[t] : stat[t]);
+        if (valid && tok == 1) {
+            const float* tt = a.time_tok + (size_t)(step + 1 < a.T ? step + 1 : step) * kD;
+#pragma unroll
+            for (int t = 0; t < kTiles; ++t) stat[t] = ld4(tt + 16 * t + 4 * g);
         }
         if (tap && step == 0) store_tap(a.tap_out, 0, x, g, r);
         rg.next = wbase + kRing * 64;  // the ring already holds units 0..R-1 of this step (stream tail = its head)

@@ -1,0 +1,157 @@
+"""Host-side mirror of the reference's hot-path driver, models/latent_diffusion/infer_ldm.py
+(class PretrainedLPDM_v1): same method names, argument meaning, return layout and error behaviour for the
+path this library accelerates, with the compute routed through libamuse_hip.so.
+
+What is mirrored                                   reference
+  setup(...) -> ldm_epoch                           infer_ldm.py:30-128  (config + checkpoint pick/load + scheduler)
+  diffusion_backward(bsz, z_con, z_emo, z_sty)      infer_ldm.py:130-178 (the hot loop, VAE decode, 6D -> axis-angle)
+  process_loader(data_dict)                         infer_ldm.py:225-414 (latent swapping for the edit tasks; the
+                                                    per-take latents must already be in the dict - see below)
+What is NOT rebuilt (SURVEY.md section 8f "next"): the audio front-end (process_single_seq: kaldi fbank +
+3 x AST) and MotionPrior.encode.  process_single_seq raises unless an `audio_encoder` callable is injected.
+"""
+from __future__ import annotations
+
+import json
+from pathlib import Path
+from typing import Callable, Dict, Optional
+
+import numpy as np
+import torch
+
+from . import checkpoint as ckpt
+from . import scheduler as sch
+from .engine import HipEngine
+
+
+class PretrainedLPDM_v1:
+    def __init__(self, base_prior=None, base_con_ae=None, base_emo_ae=None, base_audio_ae=None,
+                 audio_encoder: Optional[Callable] = None):
+        self.base_vae = base_prior      # kept for signature compatibility (scripts/main.py:217); unused
+        self.audio_encoder = audio_encoder
+        self.engine: Optional[HipEngine] = None
+        self.precision = "fp32"         # "fp32" = parity mode, "bf16" = throughput mode
+        self.sampler = "ddim"           # "ddim" (the reference's entry point) or "ddpm" (BASELINE configs 2/3)
+        self.quat_mode = "p3d"
+        self.seed = 2024                # configs/base_new.json TRAIN_PARAM.seed, scripts/main.py:78
+        self._clip_counter = 0          # advances like the reference's device RNG does between calls
+
+    # ------------------------------------------------------------------ construction
+    def setup(self, config, device, processed, backup_cfg, EXEC_ON_CLUSTER, baseline=False, verbose=False,
+              diffonly=False):
+        self.config, self.device, self.processed = config, device, Path(processed)
+        self.baseline, self.diffonly = baseline, diffonly
+        ld = config["TRAIN_PARAM"]["latent_diffusion"]
+        self.smplx_rep = ld["smplx_rep"]
+        if self.smplx_rep != "6D" or not ld["smplx_data"] or ld["skip_trans"] or ld["train_upper_body"]:
+            raise NotImplementedError("the HIP path covers smplx_data + smplx_rep 6D (333 features) only")
+        if diffonly:
+            raise NotImplementedError("diffusion_only is refused by the reference too (infer_ldm.py:177)")
+        for k in ("style_transfer", "emotion_control", "content_control", "style_Xemo_transfer"):
+            setattr(self, k, config["TRAIN_PARAM"]["test"][k]["use"])
+        self.seq_len = config["DATA_PARAM"]["Bvh"]["train_pose_framelen"]
+        assert self.seq_len == 300, "the decoder kernels are specialised for 300-frame clips (dm/dm.py:91)"
+        self.seed = config["TRAIN_PARAM"].get("seed", 2024)
+        saved = "saved-models" if not EXEC_ON_CLUSTER else "saved-models-new"
+        ep_prior, ep_ldm = ld["pretrained_prior_lpdm_e"], ld["pretrained_ldm_lpdm_e"]
+        assert ep_prior == ep_ldm, "Epochs for prior and ldm should be same"
+        root = self.processed.parents[1]
+        with open(root / f"configs/{ld['arch']}.json", "r") as f:
+            self.ldm_cfg = json.load(f)
+        if backup_cfg is not None:
+            raise NotImplementedError("Backup for LPDM not implemented yet!")
+        model_dir = root / saved / ld["pretrained_lpdm"]
+        lat = ckpt.pick_checkpoint(model_dir, "latdiff", ep_ldm)
+        ldm_epoch = ckpt.epoch_of(lat)
+        pri = ckpt.pick_checkpoint(model_dir, "prior", ldm_epoch if ep_prior == "best" else ep_prior)
+        print("[LDM] <===== Chosen LDM model based on total loss: ", lat, " =====>")
+        print("[LATDIFF] <===== Chosen VAE model based on total loss: ", pri, " =====>")
+        self._build(ckpt.load_denoiser_checkpoint(lat), ckpt.load_prior_checkpoint(pri), device)
+        return ldm_epoch
+
+    @classmethod
+    def from_state_dicts(cls, denoiser_sd: Dict[str, np.ndarray], prior_sd: Dict[str, np.ndarray],
+                         ldm_cfg: Optional[dict] = None, device="cuda:0", seed: int = 2024):
+        self = cls()
+        self.ldm_cfg = ldm_cfg or {"scheduler": dict(sch.DEFAULT_SCHED_CFG, set_alpha_to_one=False, steps_offset=1,
+                                                     num_inference_timesteps=50, eta=0.0),
+                                   "noisy_scheduler": dict(sch.DEFAULT_SCHED_CFG, variance_type="fixed_small",
+                                                           clip_sample=False, prediction_type="epsilon")}
+        self.seq_len, self.seed, self.smplx_rep, self.diffonly = 300, seed, "6D", False
+        for k in ("style_transfer", "emotion_control", "content_control", "style_Xemo_transfer"):
+            setattr(self, k, False)
+        self._build(denoiser_sd, prior_sd, device)
+        return self
+
+    def _build(self, denoiser_sd, prior_sd, device):
+        self.device = torch.device(device)
+        self.engine = HipEngine(denoiser_sd, prior_sd, self.device)
+        self.num_inference_timesteps = self.ldm_cfg["scheduler"]["num_inference_timesteps"]
+        self.eta = self.ldm_cfg["scheduler"]["eta"]
+        self.latent_dim = [1, 128]
+        self._tables = {}
+        self.set_sampler(self.sampler)
+
+    def set_sampler(self, kind: str, num_inference_steps: Optional[int] = None):
+        """"ddim": DDIMScheduler exactly as built at infer_ldm.py:116-123; "ddpm": the ancestral sampler of the
+        training-side DDPMScheduler config (ldm.py:41-49), 1000 steps unless strided."""
+        key = (kind, num_inference_steps)
+        if key not in self._tables:
+            self._tables[key] = sch.from_ldm_cfg(self.ldm_cfg, kind, num_inference_steps)
+        self.sampler = kind
+        self.engine.set_schedule(self._tables[key])
+
+    # ------------------------------------------------------------------ the hot path
+    def diffusion_backward(self, bsz, z_con, z_emo, z_sty, x_init=None, step_noise=None, clip_index0=None):
+        """-> {"poses": (B,300,55,3) f32, "trans": (B,300,3) f32} on self.device (infer_ldm.py:130-178).
+        z_emo / z_sty may be None (the token is dropped, denoiser.py:159-171).  Extra keyword arguments
+        (explicit noise, global clip index for sharded batches) are extensions; the reference draws the
+        initial latent from the device RNG."""
+        if self.diffonly:
+            raise  # noqa: PLE0704 - mirrors the bare `raise` at infer_ldm.py:177
+        assert z_con.shape[0] == bsz, f"bsz {bsz} != z_con batch {z_con.shape[0]}"
+        c0 = self._clip_counter if clip_index0 is None else clip_index0
+        out = self.engine.diffusion_backward(z_con, z_emo, z_sty, self.precision, self.quat_mode, self.seed, c0,
+                                             x_init, step_noise)
+        if clip_index0 is None:
+            self._clip_counter += bsz
+        return {"poses": out["poses"], "trans": out["trans"], "latents": out["latents"]}
+
+    def process_single_seq(self, sliced_chunk, framerate=16000 // 2, baseline=False):
+        """(con, emo, sty), each (1,256) (infer_ldm.py:180-193).  The fbank + 3 x AST front-end is outside the
+        path this library rebuilds; inject `audio_encoder(wave) -> (con, emo, sty)` to use it."""
+        if self.audio_encoder is None:
+            raise NotImplementedError("audio front-end (models/audio AST_EVP) is not part of the HIP hot path; "
+                                      "pass audio_encoder=... or feed precomputed embeddings")
+        con, emo, sty = self.audio_encoder(sliced_chunk)
+        return con.reshape(1, -1), emo.reshape(1, -1), sty.reshape(1, -1)
+
+    def process_loader(self, data_dict):
+        """Latent swapping of the edit tasks (infer_ldm.py:225-414) on takes whose ld_z_con / ld_z_emo / ld_z_sty
+        are already present (the reference computes them with AST + MotionPrior.encode in _loader_helper_v1)."""
+        loader_data = dict()
+        if self.style_transfer:
+            data, info = data_dict["style_transfer"], data_dict["style_transfer_info"]
+            if "," in info:
+                raise NotImplementedError("Multiple style transfer not implemented yet")
+            a1, a2 = info.split("_")[0][1:-1].split("-")
+            for take in [t for t in data[a1].keys() if t in data[a2]]:
+                # NB the reference stores the partner's EMO latent under "sty" and vice versa (infer_ldm.py:371-381)
+                data[a1][take][f"ld_z_sty_{a2}"] = data[a2][take]["ld_z_emo"]
+                data[a1][take][f"ld_z_emo_{a2}"] = data[a2][take]["ld_z_sty"]
+                data[a2][take][f"ld_z_sty_{a1}"] = data[a1][take]["ld_z_emo"]
+                data[a2][take][f"ld_z_emo_{a1}"] = data[a1][take]["ld_z_sty"]
+            loader_data["style_transfer"] = data
+        if self.emotion_control:
+            data, info = data_dict["emotion_control"], data_dict["emotion_control_info"]
+            if "," in info:
+                raise NotImplementedError("Emotion control with multiple actors or multiple content emotions not implemented yet")
+            for actor in data.keys():
+                for take in data[actor].keys():
+                    for other in data[actor].keys():
+                        if other != take:
+                            data[actor][take][f"ld_z_emo_{other}"] = data[actor][other]["ld_z_emo"]
+            loader_data["emotion_control"] = data
+        if self.style_Xemo_transfer:
+            raise NotImplementedError("style_Xemo_transfer needs the dataset-driven loader (out of scope)")
+        return loader_data

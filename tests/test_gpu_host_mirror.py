@@ -1,0 +1,87 @@
+"""GPU: the host-side mirror of the reference interface (PretrainedLPDM_v1 / main.py) drives the HIP path."""
+import json
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _mini_config(tmp_path, model_name="LPDM_test"):
+    """The slice of configs/base_new.json that PretrainedLPDM_v1.setup reads (infer_ldm.py:30-128)."""
+    root = tmp_path / "repo"
+    (root / "configs").mkdir(parents=True)
+    from amuse_amd import scheduler as sch
+    ldm_cfg = {"scheduler": dict(sch.DEFAULT_SCHED_CFG, set_alpha_to_one=False, steps_offset=1,
+                                 num_inference_timesteps=50, eta=0.0),
+               "noisy_scheduler": dict(sch.DEFAULT_SCHED_CFG, variance_type="fixed_small", clip_sample=False,
+                                       prediction_type="epsilon")}
+    json.dump(ldm_cfg, open(root / "configs/diff_latent_v2.json", "w"))
+    cfg = {"TRAIN_PARAM": {"tag": "latent_diffusion", "seed": 2024,
+                           "latent_diffusion": {"smplx_data": True, "smplx_rep": "6D", "skip_trans": False,
+                                                "train_upper_body": False, "arch": "diff_latent_v2",
+                                                "pretrained_lpdm": model_name, "pretrained_prior_lpdm_e": "best",
+                                                "pretrained_ldm_lpdm_e": "best"},
+                           "test": {k: {"use": False} for k in ("style_transfer", "emotion_control", "content_control",
+                                                                 "style_Xemo_transfer")}},
+           "DATA_PARAM": {"Bvh": {"train_pose_framelen": 300}}}
+    processed = root / "data" / "processed"
+    processed.mkdir(parents=True)
+    return cfg, processed, root / "saved-models" / model_name
+
+
+def test_setup_from_reference_checkpoints_and_diffusion_backward(tmp_path):
+    from amuse_amd import checkpoint as ckpt, weights as wts
+    from amuse_amd.infer_ldm import PretrainedLPDM_v1
+    from oracle import amuse_oracle as orc
+    cfg, processed, model_dir = _mini_config(tmp_path)
+    wd, wp = wts.make_denoiser_weights(0), wts.make_prior_weights(0)
+    ckpt.save_reference_format(model_dir, wd, wp, epoch=6000, total=0.0123)
+    m = PretrainedLPDM_v1(base_prior=None)
+    epoch = m.setup(cfg, "cuda:0", processed, None, False, verbose=False, diffonly=False)
+    assert epoch == 6000
+    gen = torch.Generator().manual_seed(11)
+    con, emo, sty, x = (torch.randn(2, n, generator=gen) for n in (256, 256, 256, 128))
+    out = m.diffusion_backward(2, con, emo, sty, x_init=x)
+    assert out["poses"].shape == (2, 300, 55, 3) and out["trans"].shape == (2, 300, 3)
+    assert out["poses"].device.type == "cuda" and out["poses"].dtype == torch.float32
+    ref = orc.diffusion_backward(orc.to_torch(wd), orc.to_torch(wp), orc.DDIM(), con, emo, sty, x)
+    assert float((out["latents"].cpu() - ref["latents"]).abs().max()) < 1e-4
+    assert float((out["trans"].cpu() - ref["trans"]).abs().max()) < 1e-4
+    # z_emo / z_sty = None drop tokens (denoiser.py:159-171)
+    o3 = m.diffusion_backward(2, con, None, None, x_init=x)
+    r3 = orc.diffusion_backward(orc.to_torch(wd), orc.to_torch(wp), orc.DDIM(), con, None, None, x)
+    assert float((o3["latents"].cpu() - r3["latents"]).abs().max()) < 1e-4
+    # successive calls draw fresh noise, like the reference's device RNG; same seed + counter reproduces
+    c0 = m._clip_counter
+    a = m.diffusion_backward(1, con[:1], emo[:1], sty[:1])
+    b = m.diffusion_backward(1, con[:1], emo[:1], sty[:1])
+    assert not torch.equal(a["poses"], b["poses"])
+    m._clip_counter = c0
+    c = m.diffusion_backward(1, con[:1], emo[:1], sty[:1])
+    assert torch.equal(a["poses"], c["poses"])
+    with pytest.raises(AssertionError):
+        m.diffusion_backward(3, con, emo, sty)
+    cfg["TRAIN_PARAM"]["latent_diffusion"]["pretrained_prior_lpdm_e"] = 100
+    with pytest.raises(AssertionError, match="Epochs for prior and ldm should be same"):
+        PretrainedLPDM_v1().setup(cfg, "cuda:0", processed, None, False)
+
+
+def test_cli_infer_and_edit_gesture_write_reference_npz(tmp_path):
+    from amuse_amd import main as cli
+    from amuse_amd.npz_writer import LOWER_BODY_JOINTS
+    gen = np.random.default_rng(0)
+    np.savez(tmp_path / "cond.npz", con=gen.standard_normal((2, 256)).astype(np.float32),
+             emo=gen.standard_normal((2, 256)).astype(np.float32), sty=gen.standard_normal((2, 256)).astype(np.float32),
+             tgt_emo=gen.standard_normal((2, 256)).astype(np.float32))
+    w = cli.main(["--fn", "infer_gesture", "--cond", str(tmp_path / "cond.npz"), "--out", str(tmp_path / "r1")])
+    assert len(w) == 2 and all(p.name.endswith("_motion_smplx.npz") and p.parent.name == "seq_0" for p in w)
+    z = np.load(w[0], allow_pickle=True)
+    assert z["poses"].shape == (300, 55, 3) and z["poses"].dtype == np.float32 and np.all(z["trans"] == 0)
+    assert np.all(z["poses"][:, LOWER_BODY_JOINTS] == z["poses"][0, LOWER_BODY_JOINTS]) and np.isfinite(z["poses"]).all()
+    w2 = cli.main(["--fn", "edit_gesture", "--cond", str(tmp_path / "cond.npz"), "--out", str(tmp_path / "r2"),
+                   "--sampler", "ddpm", "--steps", "100", "--precision", "bf16"])
+    assert len(w2) == 4
+    a, b = np.load(w2[0])["poses"], np.load(w2[1])["poses"]   # same noise, same content/style, other emotion
+    assert np.isfinite(a).all() and np.abs(a - b).max() > 1e-3
