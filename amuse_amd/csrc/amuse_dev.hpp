@@ -112,6 +112,18 @@ __device__ __forceinline__ const uint4* gemm_tiles(f32x4 (&acc)[NO], const f32x4
 // its first R units are replicated after its end, so the wrap at a step boundary needs no special case).
 // hipcc left to itself serialises this kernel's loads (global_load -> s_waitcnt vmcnt(0) -> v_mfma,
 // one L2 round trip per KiB); the ring is what turns the loop from latency- into bandwidth-bound.
+// stream loads: every CU reads every line exactly once per step -> non-temporal (no L1 retention)
+#ifndef AMUSE_STREAM_NT
+#define AMUSE_STREAM_NT 0
+#endif
+__device__ __forceinline__ uint4 ldw(const uint4* p) {
+#if AMUSE_STREAM_NT
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    return __builtin_bit_cast(uint4, __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p)));
+#else
+    return *p;
+#endif
+}
 template <int R>
 struct WRing {
     uint4 s[R];
@@ -120,11 +132,25 @@ struct WRing {
 template <int R>
 __device__ __forceinline__ void ring_fill(WRing<R>& rg, const uint4* w) {
 #pragma unroll
-    for (int i = 0; i < R; ++i) rg.s[i] = w[i * 64];
+    for (int i = 0; i < R; ++i) rg.s[i] = ldw(w + i * 64);
     rg.next = w + R * 64;
 }
+// Issue the next N units of the stream into slots IPH.. (they must have been consumed already).  Decoupling
+// this from consumption lets the loads be ISSUED during the VALU/LDS phases between GEMMs: a wave's
+// global_load blocks at issue once the CU's 64 B/clk load path is saturated, so a GEMM that re-arms every slot
+// as it consumes it runs at load-issue speed, not MFMA speed, while the path idles during the phases in between.
+template <int N, int R, int IPH>
+__device__ __forceinline__ void ring_issue(WRing<R>& rg) {
+    if constexpr (N > 0) {
+#pragma unroll
+        for (int i = 0; i < N; ++i) rg.s[(IPH + i) % R] = ldw(rg.next + i * 64);
+        rg.next += N * 64;
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
 // PH = ring phase (slot of the first unit) at entry; the caller tracks it at compile time.
-template <int PREC, int NO, int NK, bool SWAP, int R, int PH>
+// REARM: re-arm each slot as it is consumed (true) or leave that to later ring_issue calls (false).
+template <int PREC, int NO, int NK, bool SWAP, int R, int PH, bool REARM = true>
 __device__ __forceinline__ void gemm_ring(f32x4 (&acc)[NO], const f32x4 (&x)[NK], WRing<R>& rg) {
     if constexpr (PREC == PREC_F32) {
         static_assert(NO % 2 == 0, "output tiles are processed in pairs");
@@ -137,9 +163,11 @@ __device__ __forceinline__ void gemm_ring(f32x4 (&acc)[NO], const f32x4 (&x)[NK]
                 const int s0 = (PH + t * NO + o) % R, s1 = (PH + t * NO + o + 1) % R;
                 const f32x4 w0 = __builtin_bit_cast(f32x4, rg.s[s0]);
                 const f32x4 w1 = __builtin_bit_cast(f32x4, rg.s[s1]);
-                rg.s[s0] = rg.next[0];
-                rg.s[s1] = rg.next[64];
-                rg.next += 128;
+                if constexpr (REARM) {
+                    rg.s[s0] = ldw(rg.next);
+                    rg.s[s1] = ldw(rg.next + 64);
+                    rg.next += 128;
+                }
 #pragma unroll
                 for (int m = 0; m < 4; ++m) {
                     acc[o] = SWAP ? mfma_f32(x[t][m], w0[m], acc[o]) : mfma_f32(w0[m], x[t][m], acc[o]);
@@ -156,8 +184,10 @@ __device__ __forceinline__ void gemm_ring(f32x4 (&acc)[NO], const f32x4 (&x)[NK]
             for (int o = 0; o < NO; ++o) {
                 const int slot = (PH + c * NO + o) % R;
                 const uint4 u = rg.s[slot];
-                rg.s[slot] = *rg.next;
-                rg.next += 64;
+                if constexpr (REARM) {
+                    rg.s[slot] = ldw(rg.next);
+                    rg.next += 64;
+                }
                 const bf16x8 wf = __builtin_bit_cast(bf16x8, u);
                 acc[o] = SWAP ? mfma_bf16(xb, wf, acc[o]) : mfma_bf16(wf, xb, acc[o]);
             }
@@ -170,7 +200,7 @@ template <int N, int R, int PH>
 __device__ __forceinline__ void ring_discard(WRing<R>& rg) {
 #pragma unroll
     for (int i = 0; i < N; ++i) {
-        rg.s[(PH + i) % R] = *rg.next;
+        rg.s[(PH + i) % R] = ldw(rg.next);
         rg.next += 64;
     }
 }
@@ -272,8 +302,8 @@ __device__ __forceinline__ float gelu_erf_fast(float x) {
 // copies afterwards).  `exch` = 2 x [4 waves][8 tiles][64 lanes] f32x4, alternated by `parity`, so a
 // single barrier per exchange is enough (WAR on buffer p is separated from its last readers by the
 // barrier of the exchange in between).
-template <int W>
-__device__ __forceinline__ void exchange_combine(f32x4 (&part)[kTiles], const f32x4* buf, int lane) {
+template <int W, int NC, int R, int IPH>
+__device__ __forceinline__ void exchange_combine(f32x4 (&part)[kTiles], const f32x4* buf, int lane, WRing<R>* rg) {
     // reads of the other waves' partials batched 12 at a time (hipcc otherwise emits read-3 / wait / add
     // groups, one LDS round trip each), then ((p0 + p1) + p2) + p3 with the wave's own partial from registers
 #pragma unroll
@@ -285,6 +315,10 @@ __device__ __forceinline__ void exchange_combine(f32x4 (&part)[kTiles], const f3
             for (int w = 0; w < 4; ++w)
                 if (w != W) p[w][t] = buf[(w * kTiles + h * (kTiles / 2) + t) * 64 + lane];
         __builtin_amdgcn_sched_barrier(0);
+        if constexpr (NC > 0) {
+            if (h == 0) ring_issue<NC, R, IPH % R>(*rg);
+            else ring_issue<NC, R, (IPH + NC) % R>(*rg);
+        }
 #pragma unroll
         for (int t = 0; t < kTiles / 2; ++t) {
             p[W][t] = part[h * (kTiles / 2) + t];
@@ -292,15 +326,23 @@ __device__ __forceinline__ void exchange_combine(f32x4 (&part)[kTiles], const f3
         }
     }
 }
-__device__ __forceinline__ void exchange_sum(f32x4 (&part)[kTiles], f32x4* exch, int& parity, int wave, int lane) {
+// NI weight-stream units are issued in four chunks spread over the combine (before the LDS writes, before the
+// barrier, and inside each half of the read/add phase); NI = 0: plain combine.
+template <int NI = 0, int R = 1, int IPH = 0>
+__device__ __forceinline__ void exchange_sum(f32x4 (&part)[kTiles], f32x4* exch, int& parity, int wave, int lane,
+                                             WRing<R>* rg = nullptr) {
+    static_assert(NI % 4 == 0, "issue count is split in four chunks");
+    constexpr int NC = NI / 4;
     f32x4* buf = exch + parity * (4 * kTiles * 64);
+    if constexpr (NI > 0) ring_issue<NC, R, IPH % R>(*rg);
 #pragma unroll
     for (int t = 0; t < kTiles; ++t) buf[(wave * kTiles + t) * 64 + lane] = part[t];
+    if constexpr (NI > 0) ring_issue<NC, R, (IPH + NC) % R>(*rg);
     __syncthreads();
-    if (wave == 0) exchange_combine<0>(part, buf, lane);
-    else if (wave == 1) exchange_combine<1>(part, buf, lane);
-    else if (wave == 2) exchange_combine<2>(part, buf, lane);
-    else exchange_combine<3>(part, buf, lane);
+    if (wave == 0) exchange_combine<0, NC, R, IPH + 2 * NC>(part, buf, lane, rg);
+    else if (wave == 1) exchange_combine<1, NC, R, IPH + 2 * NC>(part, buf, lane, rg);
+    else if (wave == 2) exchange_combine<2, NC, R, IPH + 2 * NC>(part, buf, lane, rg);
+    else exchange_combine<3, NC, R, IPH + 2 * NC>(part, buf, lane, rg);
     parity ^= 1;
 }
 constexpr int kExchBytes = 2 * 4 * kTiles * 64 * 16;  // 64 KiB

@@ -27,11 +27,12 @@ struct SampleArgs {
     unsigned long long* prof_out;  // [4 waves][kProfStamps] s_memtime stamps of step prof_step, or null
     int prof_step;
 };
-constexpr int kProfStamps = 128;
+constexpr int kProfStamps = 192;
 hipError_t launch_sample(const SampleArgs& a, int precision, hipStream_t stream);
 constexpr int kRing = 32;                 // weight-stream ring depth (1 KiB units in flight per wave)
-// the skip linear (8 out tiles x 4 k-tiles per wave) is padded with dummy units to whole ring revolutions
-constexpr int skip_pad_units(int prec) { const int u = (prec == 0) ? 32 : 16; return (kRing - u % kRing) % kRing; }
+// fp32: the skip linear (32 units per wave) is a whole ring revolution.  bf16 (16 units) needs no padding either:
+// the decoupled-issue scheme simply leaves half the ring empty for that GEMM (k_sampler.hip).
+constexpr int skip_pad_units(int prec) { return prec == 0 ? (kRing - 32 % kRing) % kRing : 0; }
 constexpr int kEncPv = 1664;              // encoder-block small params kept in LDS (PV_* up to LN2)
 constexpr int kSkipBytes = 32 * 1024;     // U-Net skip stack [4][8][64] f32x4
 constexpr int kSampleLdsBytes = 64 * 1024 + kSkipBytes + (9 * kEncPv + 4 * 128 + 2 * 128) * 4;  // 161,280 B

@@ -23,9 +23,10 @@ namespace amuse {
 
 namespace {
 
-template <int PREC>
+// NC weight-stream units are issued after the score MFMA and again after the softmax (ring_issue, amuse_dev.hpp)
+template <int PREC, int NC, int IPH>
 __device__ __forceinline__ void attention_head(const f32x4 (&q)[2], const f32x4 (&k)[2], const f32x4 (&v)[2],
-                                               const bool (&kvalid)[4], f32x4 (&o)[2]) {
+                                               const bool (&kvalid)[4], f32x4 (&o)[2], WRing<kRing>& rg) {
     // S^T[j][i] = sum_d K[j][d] Q[i][d]  ->  lane (g, i) holds S[i][4 g + m]
     f32x4 st = splat4(0.f);
     if constexpr (PREC == PREC_F32) {
@@ -36,6 +37,7 @@ __device__ __forceinline__ void attention_head(const f32x4 (&q)[2], const f32x4 
     } else {
         st = mfma_bf16(pack_bf16(k[0], k[1]), pack_bf16(q[0], q[1]), st);
     }
+    ring_issue<NC, kRing, IPH % kRing>(rg);
     float mx = -INFINITY;
 #pragma unroll
     for (int m = 0; m < 4; ++m) mx = kvalid[m] ? fmaxf(mx, st[m]) : mx;
@@ -51,6 +53,7 @@ __device__ __forceinline__ void attention_head(const f32x4 (&q)[2], const f32x4 
     sum = allreduce_g_sum(sum);
 #pragma unroll
     for (int m = 0; m < 4; ++m) p[m] = p[m] / sum;
+    ring_issue<NC, kRing, (IPH + NC) % kRing>(rg);
     // O^T[d][i] = sum_j V[j][d] P[i][j]; v is feature-lane: lane (g, d) holds V[4 g + m][d]
 #pragma unroll
     for (int td = 0; td < 2; ++td) {
@@ -82,7 +85,7 @@ __device__ __forceinline__ void stamp(Prof& pf) {
 template <int PREC, bool PROF>
 __device__ __forceinline__ void encoder_block(f32x4 (&x)[kTiles], WRing<kRing>& rg, const float* pv,
                                               const bool (&kvalid)[4], f32x4* exch, int& parity, int wave, int lane,
-                                              Prof& pf) {
+                                              bool next_has_skip, Prof& pf) {
     const int g = lane >> 4, r = lane & 15;
     // ring phases of the five GEMMs of a block (compile-time; a block consumes a whole number of revolutions)
     constexpr int U_QK = gemm_units(PREC, 4, kTiles), U_V = gemm_units(PREC, 2, kTiles);
@@ -91,6 +94,12 @@ __device__ __forceinline__ void encoder_block(f32x4 (&x)[kTiles], WRing<kRing>& 
     constexpr int P_F1 = (P_OUT + U_OUT) % kRing, P_F2 = (P_F1 + U_FF) % kRing;
     static_assert((P_F2 + U_FF) % kRing == 0, "a block must leave the ring at phase 0");
     constexpr bool FAST = (PREC == PREC_BF16);
+    // bf16 mode decouples load issue from consumption (ring_issue): per block the ring (full on entry = in_proj +
+    // out_proj units) is re-armed 8+8+8 units around the attention, 8 during combine 1 (-> holds all of linear1),
+    // 32 inside linear1 (immediately: linear2 needs them next), 32 during combine 2 (-> next block's first 32).
+    // fp32 mode is MFMA-issue-bound and keeps the simple re-arm-at-consumption ring.
+    constexpr bool DELAY = (PREC == PREC_BF16);
+    constexpr int A8 = DELAY ? 8 : 0;
     // Small parameters (LDS) are read one phase ahead of their use; biases are added AFTER the GEMM that
     // they belong to, so no LDS round trip sits in front of a GEMM's first MFMA.
     f32x4 b_qk[4];
@@ -106,8 +115,9 @@ __device__ __forceinline__ void encoder_block(f32x4 (&x)[kTiles], WRing<kRing>& 
 #pragma unroll
     for (int o = 0; o < 4; ++o) qk[o] = splat4(0.f);
     v[0] = v[1] = splat4(0.f);
-    gemm_ring<PREC, 4, kTiles, false, kRing, P_QK>(qk, x, rg);
-    gemm_ring<PREC, 2, kTiles, true, kRing, P_V>(v, x, rg);
+    gemm_ring<PREC, 4, kTiles, false, kRing, P_QK, !DELAY>(qk, x, rg);
+    gemm_ring<PREC, 2, kTiles, true, kRing, P_V, !DELAY>(v, x, rg);
+    ring_issue<A8, kRing, 0>(rg);
     stamp<PROF>(pf);  // 1: in_proj done
     f32x4 b_out[kTiles];
 #pragma unroll
@@ -118,15 +128,15 @@ __device__ __forceinline__ void encoder_block(f32x4 (&x)[kTiles], WRing<kRing>& 
     v[0] += splat4(b_v[0]);
     v[1] += splat4(b_v[1]);
     f32x4 o[2];
-    attention_head<PREC>(q, k, v, kvalid, o);
+    attention_head<PREC, A8, 8>(q, k, v, kvalid, o, rg);
     stamp<PROF>(pf);  // 2: attention done
     // ---- out_proj, split-K over heads; combine; residual; LayerNorm1
     f32x4 part[kTiles];
 #pragma unroll
     for (int t = 0; t < kTiles; ++t) part[t] = splat4(0.f);
-    gemm_ring<PREC, kTiles, 2, false, kRing, P_OUT>(part, o, rg);
+    gemm_ring<PREC, kTiles, 2, false, kRing, P_OUT, !DELAY>(part, o, rg);
     stamp<PROF>(pf);  // 3: out_proj partial done
-    exchange_sum(part, exch, parity, wave, lane);
+    exchange_sum<A8, kRing, 24>(part, exch, parity, wave, lane, &rg);
     stamp<PROF>(pf);  // 4: combine 1 done
     LnParams ln;
     ln_params_load(ln, pv + PV_LN1_W, pv + PV_LN1_B, g);
@@ -141,7 +151,19 @@ __device__ __forceinline__ void encoder_block(f32x4 (&x)[kTiles], WRing<kRing>& 
         b_l1[t] = ld4(pv + PV_L1_B + 16 * (kTiles * wave + t) + 4 * g);
         hid[t] = splat4(0.f);
     }
-    gemm_ring<PREC, kTiles, kTiles, false, kRing, P_F1>(hid, x, rg);
+    if constexpr (PROF && PREC == PREC_BF16) {  // quarter-GEMM stamps (same unit order: k-pair outer)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const f32x4 xs[2] = {x[2 * c], x[2 * c + 1]};
+            if (c == 0) gemm_ring<PREC, kTiles, 2, false, kRing, (P_F1 + 0) % kRing>(hid, xs, rg);
+            if (c == 1) gemm_ring<PREC, kTiles, 2, false, kRing, (P_F1 + 8) % kRing>(hid, xs, rg);
+            if (c == 2) gemm_ring<PREC, kTiles, 2, false, kRing, (P_F1 + 16) % kRing>(hid, xs, rg);
+            if (c == 3) gemm_ring<PREC, kTiles, 2, false, kRing, (P_F1 + 24) % kRing>(hid, xs, rg);
+            if (c < 3) stamp<PROF>(pf);
+        }
+    } else {
+        gemm_ring<PREC, kTiles, kTiles, false, kRing, P_F1>(hid, x, rg);
+    }
     stamp<PROF>(pf);  // 6: linear1 done
 #pragma unroll
     for (int t = 0; t < kTiles; ++t)
@@ -156,9 +178,28 @@ __device__ __forceinline__ void encoder_block(f32x4 (&x)[kTiles], WRing<kRing>& 
         b_out[t] = ld4(pv + PV_L2_B + 16 * t + 4 * g);
         part[t] = splat4(0.f);
     }
-    gemm_ring<PREC, kTiles, kTiles, false, kRing, P_F2>(part, hid, rg);
+    if constexpr (PROF && PREC == PREC_BF16) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const f32x4 xs[2] = {hid[2 * c], hid[2 * c + 1]};
+            if (c == 0) gemm_ring<PREC, kTiles, 2, false, kRing, (P_F2 + 0) % kRing, !DELAY>(part, xs, rg);
+            if (c == 1) gemm_ring<PREC, kTiles, 2, false, kRing, (P_F2 + 8) % kRing, !DELAY>(part, xs, rg);
+            if (c == 2) gemm_ring<PREC, kTiles, 2, false, kRing, (P_F2 + 16) % kRing, !DELAY>(part, xs, rg);
+            if (c == 3) gemm_ring<PREC, kTiles, 2, false, kRing, (P_F2 + 24) % kRing, !DELAY>(part, xs, rg);
+            if (c < 3) stamp<PROF>(pf);
+        }
+    } else {
+        gemm_ring<PREC, kTiles, kTiles, false, kRing, P_F2, !DELAY>(part, hid, rg);
+    }
     stamp<PROF>(pf);  // 8: linear2 partial done
-    exchange_sum(part, exch, parity, wave, lane);
+    if constexpr (DELAY) {
+        // re-arm the ring with the next block's first units: its in_proj + out_proj (32), or - ahead of an output
+        // block - only the 16 skip-linear units (slots 16..31 stay empty; the skip combine re-arms all 32)
+        if (next_has_skip) exchange_sum<16, kRing, 0>(part, exch, parity, wave, lane, &rg);
+        else exchange_sum<32, kRing, 0>(part, exch, parity, wave, lane, &rg);
+    } else {
+        exchange_sum(part, exch, parity, wave, lane);
+    }
     stamp<PROF>(pf);  // 9: combine 2 done
     ln_params_load(ln, pv + PV_LN2_W, pv + PV_LN2_B, g);
 #pragma unroll
@@ -262,15 +303,23 @@ __global__ __launch_bounds__(256, 1) void k_sample(SampleArgs a) {
 #pragma unroll
                 for (int t = 0; t < kTiles; ++t) part[t] = splat4(0.f);
                 constexpr int U_SK = gemm_units(PREC, kTiles, 4);
-                gemm_ring<PREC, kTiles, 4, false, kRing, 0>(part, src, rg);
-                ring_discard<skip_pad_units(PREC), kRing, U_SK % kRing>(rg);  // host pads to whole revolutions
-                exchange_sum(part, exch, parity, wave, lane);
+                if constexpr (PREC == PREC_BF16) {
+                    // the ring holds just the 16 skip-linear units (slots 0..15); the whole ring is re-armed
+                    // during the combine with the block's first 32 units
+                    gemm_ring<PREC, kTiles, 4, false, kRing, 0, false>(part, src, rg);
+                    exchange_sum<32, kRing, 0>(part, exch, parity, wave, lane, &rg);
+                } else {
+                    gemm_ring<PREC, kTiles, 4, false, kRing, 0>(part, src, rg);
+                    ring_discard<skip_pad_units(PREC), kRing, U_SK % kRing>(rg);
+                    exchange_sum(part, exch, parity, wave, lane);
+                }
                 const float* sb = pv_skip + (blk - 5) * kD;
 #pragma unroll
                 for (int t = 0; t < kTiles; ++t) x[t] = part[t] + ld4(sb + 16 * t + 4 * g);
             }
             stamp<PROF>(pf);  // block start (after the skip linear, if any)
-            encoder_block<PREC, PROF>(x, rg, pvl + blk * kEncPv, kvalid, exch, parity, wave, lane, pf);
+            encoder_block<PREC, PROF>(x, rg, pvl + blk * kEncPv, kvalid, exch, parity, wave, lane,
+                                      blk >= 4 && blk < kLayers - 1, pf);
             if (blk < 4 && wave == 0) {
                 f32x4* sk = skip + (size_t)blk * kTiles * 64;
 #pragma unroll

@@ -161,12 +161,12 @@ class HipEngine:
         return out
 
     def profile_sample(self, con, emo, sty, precision="bf16", prof_step=1):
-        """[4 waves][128] s_memtime stamps of one denoising step of workgroup 0 (amuse_profile_sample)."""
+        """[4 waves][192] s_memtime stamps of one denoising step of workgroup 0 (amuse_profile_sample)."""
         con = self._dev(con)
         B = con.shape[0]
         emo = self._dev(emo, (B, 256)) if emo is not None else None
         sty = self._dev(sty, (B, 256)) if sty is not None else None
-        st = torch.zeros(4, 128, device=self.device, dtype=torch.int64)
+        st = torch.zeros(4, 192, device=self.device, dtype=torch.int64)
         with torch.cuda.device(self.device):
             _lib.check(self.lib.amuse_profile_sample(self.ctx, _ptr(con), _ptr(emo), _ptr(sty), B, PREC[precision],
                                                      int(prof_step), _ptr(st), self._stream()))

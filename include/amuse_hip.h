@@ -133,7 +133,7 @@ int amuse_counter_normal(amuse_ctx* ctx, uint64_t seed, uint64_t clip_index0, in
                          int rng_stream, float* out, void* stream);
 
 /* Diagnostics: runs amuse_sample's kernel with s_memtime stamps taken by the 4 waves of workgroup 0
- * during step `prof_step`; stamps_out dev [4][128] uint64 (unused entries 0).  Stamp order: step
+ * during step `prof_step`; stamps_out dev [4][192] uint64 (unused entries 0).  Stamp order: step
  * start, then per block: block start, in_proj, attention, out_proj, combine 1, LN1, linear1, GELU,
  * linear2, combine 2, LN2; finally scheduler update.  Used by tools/ to build profiles/. */
 int amuse_profile_sample(amuse_ctx* ctx, const float* con, const float* emo, const float* sty, int B,
