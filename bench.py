@@ -185,6 +185,23 @@ def main():
             if i >= 2:
                 lat.append((time.perf_counter() - t1) * 1e3)
         line["p50_clip_latency_ms"] = round(statistics.median(lat), 3)
+        # the step time of k_sample does not depend on the clips per workgroup tile (1..3), so 3 clips per CU
+        # cost the same loop time: report that saturating point too (not the headline workload)
+        Bs = 3 * B
+        cs, es, ss = (torch.randn(Bs, 256, generator=gen).to(dev) for _ in range(3))
+        outs = {"latents": torch.empty(Bs, 128, device=dev), "poses": torch.empty(Bs, 300, 55, 3, device=dev),
+                "trans": torch.empty(Bs, 300, 3, device=dev)}
+        ts = []
+        for i in range(4):
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            eng.diffusion_backward(cs, es, ss, args.precision, seed=2024, out=outs)
+            torch.cuda.synchronize()
+            if i >= 1:
+                ts.append(time.perf_counter() - t1)
+        line["saturating_point"] = {"clips_per_gpu": Bs, "frames_per_s": round(Bs * 300 / min(ts), 1),
+                                    "ms_per_job": round(min(ts) * 1e3, 3)}
+        del cs, es, ss, outs
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(B, args.T, wd, wp)
     barrier()
