@@ -27,6 +27,26 @@ FLOP_VAE_DECODE_PER_CLIP = 1.76e9
 MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3}   # MI355X_MICROARCH.md chip-level parameters (dense)
 
 
+def pmc_traffic_bytes(clips, T, precision):
+    """HBM bytes per k_sample launch from the committed rocprofv3 PMC passes (profiles/r01_pmc: separate --pmc
+    runs of tools/run_sample_once.py at the bench shape).  FETCH_SIZE / WRITE_SIZE are in KiB; FETCH_SIZE is
+    doubled per MI355X_MICROARCH.md (gfx950 reports half of a wide coalesced stream).  None if the shape differs."""
+    if (clips, T, precision) != (256, 1000, "bf16"):
+        return None
+    import csv
+    tot = {}
+    for name in ("FETCH_SIZE", "WRITE_SIZE"):
+        f = REPO / "profiles" / "r01_pmc" / f"{name}_counter_collection.csv"
+        if not f.exists():
+            return None
+        v = [float(r["Counter_Value"]) for r in csv.DictReader(open(f))
+             if "k_sample" in r["Kernel_Name"] and r["Counter_Name"] == name]
+        if not v:
+            return None
+        tot[name] = sum(v) / len(v)
+    return int((2 * tot["FETCH_SIZE"] + tot["WRITE_SIZE"]) * 1024)
+
+
 def cpu_baseline(clips, T, wd, wp):
     """The oracle (CPU restatement of the reference's PyTorch path: unfused fp32 torch ops, same
     algorithm) on this box's host cores, on a bounded sample of the same workload."""
@@ -167,7 +187,7 @@ def main():
                        "clips_per_gpu": B, "sampler": f"ddpm-{args.T}", "sharding": f"clip-batch x{world}, no collectives",
                        "mfma_operands": args.precision, "state_and_accumulate": "fp32"},
             "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
-                         "frac": round(achieved / peak, 5), "traffic": None,
+                         "frac": round(achieved / peak, 5), "traffic": pmc_traffic_bytes(B, args.T, args.precision),
                          "kernel": "k_sample (persistent T-step denoising loop)",
                          "kernel_ms": round(k_avg * 1e3, 3),
                          "note": "algorithmic FLOPs = clips x T x 19,120,640; the kernel is bound by the serial "
