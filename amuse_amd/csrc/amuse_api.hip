@@ -173,6 +173,15 @@ void pack_outproj_ffn(std::vector<uint4>& s, int prec, const Params& P, const st
     pack_gemm(s, prec, P.get(p + ".linear1.weight"), 512, 128, range(8 * w, 8 * w + 8), range(0, 8));
     pack_gemm(s, prec, P.get(p + ".linear2.weight"), 128, 512, range(0, 8), range(8 * w, 8 * w + 8));
 }
+// sampler order: out_proj, then the FFN in four interleaved quarters (k_sampler.hip encoder_block)
+void pack_outproj_ffn_quarters(std::vector<uint4>& s, int prec, const Params& P, const std::string& p, int w) {
+    pack_gemm(s, prec, P.get(p + ".self_attn.out_proj.weight"), 128, 128, range(0, 8), {2 * w, 2 * w + 1});
+    for (int q = 0; q < 4; ++q) {
+        const int h0 = 8 * w + 2 * q;
+        pack_gemm(s, prec, P.get(p + ".linear1.weight"), 512, 128, {h0, h0 + 1}, range(0, 8));
+        pack_gemm(s, prec, P.get(p + ".linear2.weight"), 128, 512, range(0, 8), {h0, h0 + 1});
+    }
+}
 void pack_skiplin(std::vector<uint4>& s, int prec, const Params& P, const std::string& prefix, int i, int w) {
     pack_gemm(s, prec, P.get(prefix + ".linear_blocks." + std::to_string(i) + ".weight"), 128, 256, range(0, 8),
               range(4 * w, 4 * w + 4));
@@ -254,7 +263,7 @@ int build_ctx(amuse_ctx* c, const float* den, const float* pri) {
                     s.insert(s.end(), (size_t)skip_pad_units(prec) * 64, uint4{0, 0, 0, 0});  // ring alignment
                 }
                 pack_qkv(s, prec, D.get(p + ".self_attn.in_proj_weight"), w, true);
-                pack_outproj_ffn(s, prec, D, p, w);
+                pack_outproj_ffn_quarters(s, prec, D, p, w);
             }
             if (w == 0) per_wave = s.size();
             else if (s.size() != per_wave) return fail(AMUSE_ESTATE, "internal: uneven denoiser wave streams");
@@ -355,7 +364,9 @@ int cond_tokens(amuse_ctx* c, const float* con, const float* emo, const float* s
 int pick_group(const amuse_ctx* c, int B, int S) {
     const int gmax = 16 / S;
     int g = c->clips_per_group;
-    if (g <= 0) g = (B + 255) / 256;  // one clip tile per CU until the chip is full, then fatten the tiles
+    // auto: fill the 16-row tile.  A step costs the same for 1..gmax clips per workgroup (the per-CU weight stream
+    // is the bound), and fewer workgroups leave each of them more of the L2 bandwidth.
+    if (g <= 0) g = gmax;
     if (g > gmax) g = gmax;
     if (g < 1) g = 1;
     return g;

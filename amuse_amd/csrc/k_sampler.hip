@@ -144,54 +144,41 @@ __device__ __forceinline__ void encoder_block(f32x4 (&x)[kTiles], WRing<kRing>& 
     for (int t = 0; t < kTiles; ++t) x[t] = x[t] + (part[t] + b_out[t]);
     layer_norm_rows<FAST>(x, ln);
     stamp<PROF>(pf);  // 5: LN1 done
-    // ---- FFN: linear1 (this wave's 128 hidden features) -> GELU -> linear2 split-K over them
-    f32x4 hid[kTiles], b_l1[kTiles];
-#pragma unroll
-    for (int t = 0; t < kTiles; ++t) {
-        b_l1[t] = ld4(pv + PV_L1_B + 16 * (kTiles * wave + t) + 4 * g);
-        hid[t] = splat4(0.f);
-    }
-    if constexpr (PROF && PREC == PREC_BF16) {  // quarter-GEMM stamps (same unit order: k-pair outer)
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            const f32x4 xs[2] = {x[2 * c], x[2 * c + 1]};
-            if (c == 0) gemm_ring<PREC, kTiles, 2, false, kRing, (P_F1 + 0) % kRing>(hid, xs, rg);
-            if (c == 1) gemm_ring<PREC, kTiles, 2, false, kRing, (P_F1 + 8) % kRing>(hid, xs, rg);
-            if (c == 2) gemm_ring<PREC, kTiles, 2, false, kRing, (P_F1 + 16) % kRing>(hid, xs, rg);
-            if (c == 3) gemm_ring<PREC, kTiles, 2, false, kRing, (P_F1 + 24) % kRing>(hid, xs, rg);
-            if (c < 3) stamp<PROF>(pf);
-        }
-    } else {
-        gemm_ring<PREC, kTiles, kTiles, false, kRing, P_F1>(hid, x, rg);
-    }
-    stamp<PROF>(pf);  // 6: linear1 done
-#pragma unroll
-    for (int t = 0; t < kTiles; ++t)
-#pragma unroll
-        for (int m = 0; m < 4; ++m) {
-            const float h = hid[t][m] + b_l1[t][m];
-            hid[t][m] = FAST ? gelu_erf_fast(h) : gelu_erf(h);
-        }
-    stamp<PROF>(pf);  // 7: GELU done
+    // ---- FFN in four interleaved quarters: linear1 for 2 of this wave's 8 hidden tiles -> bias + GELU ->
+    // linear2 split-K contribution of exactly those 32 hidden features.  The weight stream is packed in the same
+    // order, so the 32-slot ring (holding quarters 0,1 on entry) is re-armed with quarters 2,3 while quarters 0,1
+    // compute, and the GELU VALU work sits between the MFMA/load bursts instead of after all of them.
+    constexpr int U_Q = gemm_units(PREC, 2, kTiles);  // units of one half-quarter (= gemm_units(PREC, 8, 2))
+    static_assert(U_Q == gemm_units(PREC, kTiles, 2) && P_F1 == 0, "FFN quarter phases");
 #pragma unroll
     for (int t = 0; t < kTiles; ++t) {
         b_out[t] = ld4(pv + PV_L2_B + 16 * t + 4 * g);
         part[t] = splat4(0.f);
     }
-    if constexpr (PROF && PREC == PREC_BF16) {
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            const f32x4 xs[2] = {hid[2 * c], hid[2 * c + 1]};
-            if (c == 0) gemm_ring<PREC, kTiles, 2, false, kRing, (P_F2 + 0) % kRing, !DELAY>(part, xs, rg);
-            if (c == 1) gemm_ring<PREC, kTiles, 2, false, kRing, (P_F2 + 8) % kRing, !DELAY>(part, xs, rg);
-            if (c == 2) gemm_ring<PREC, kTiles, 2, false, kRing, (P_F2 + 16) % kRing, !DELAY>(part, xs, rg);
-            if (c == 3) gemm_ring<PREC, kTiles, 2, false, kRing, (P_F2 + 24) % kRing, !DELAY>(part, xs, rg);
-            if (c < 3) stamp<PROF>(pf);
+    for (int qd = 0; qd < 4; ++qd) {
+        const f32x4 b1a = ld4(pv + PV_L1_B + 16 * (kTiles * wave + 2 * qd) + 4 * g);
+        const f32x4 b1b = ld4(pv + PV_L1_B + 16 * (kTiles * wave + 2 * qd + 1) + 4 * g);
+        f32x4 hq[2] = {splat4(0.f), splat4(0.f)};
+        // fp32: always re-arm at consumption; bf16: quarters 0,1 re-arm (with quarters 2,3), 2,3 leave the ring to
+        // be re-armed during combine 2
+        if (qd == 0) gemm_ring<PREC, 2, kTiles, false, kRing, (0 * U_Q) % kRing, true>(hq, x, rg);
+        if (qd == 1) gemm_ring<PREC, 2, kTiles, false, kRing, (2 * U_Q) % kRing, true>(hq, x, rg);
+        if (qd == 2) gemm_ring<PREC, 2, kTiles, false, kRing, (4 * U_Q) % kRing, !DELAY>(hq, x, rg);
+        if (qd == 3) gemm_ring<PREC, 2, kTiles, false, kRing, (6 * U_Q) % kRing, !DELAY>(hq, x, rg);
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            const float h0 = hq[0][m] + b1a[m], h1 = hq[1][m] + b1b[m];
+            hq[0][m] = FAST ? gelu_erf_fast(h0) : gelu_erf(h0);
+            hq[1][m] = FAST ? gelu_erf_fast(h1) : gelu_erf(h1);
         }
-    } else {
-        gemm_ring<PREC, kTiles, kTiles, false, kRing, P_F2, !DELAY>(part, hid, rg);
+        if (qd == 0) gemm_ring<PREC, kTiles, 2, false, kRing, (1 * U_Q) % kRing, true>(part, hq, rg);
+        if (qd == 1) gemm_ring<PREC, kTiles, 2, false, kRing, (3 * U_Q) % kRing, true>(part, hq, rg);
+        if (qd == 2) gemm_ring<PREC, kTiles, 2, false, kRing, (5 * U_Q) % kRing, !DELAY>(part, hq, rg);
+        if (qd == 3) gemm_ring<PREC, kTiles, 2, false, kRing, (7 * U_Q) % kRing, !DELAY>(part, hq, rg);
+        if (qd < 3) stamp<PROF>(pf);  // 6..8: FFN quarters
     }
-    stamp<PROF>(pf);  // 8: linear2 partial done
+    stamp<PROF>(pf);  // 9: FFN done (linear2 partial)
     if constexpr (DELAY) {
         // re-arm the ring with the next block's first units: its in_proj + out_proj (32), or - ahead of an output
         // block - only the 16 skip-linear units (slots 16..31 stay empty; the skip combine re-arms all 32)

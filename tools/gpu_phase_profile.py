@@ -14,8 +14,8 @@ if len(sys.argv) > 2:
 gen = torch.Generator().manual_seed(2)
 c, e, s = (torch.randn(B, 256, generator=gen).cuda() for _ in range(3))
 names = ["blk_start", "in_proj", "attention", "out_proj", "combine1", "LN1", "linear1", "GELU", "linear2", "combine2", "LN2"]
-names_bf16 = ["blk_start", "in_proj", "attention", "out_proj", "combine1", "LN1", "lin1.q0", "lin1.q1", "lin1.q2", "lin1.q3",
-              "GELU", "lin2.q0", "lin2.q1", "lin2.q2", "lin2.q3", "combine2", "LN2"]
+names = ["blk_start", "in_proj", "attention", "out_proj", "combine1", "LN1", "ffn.q0", "ffn.q1", "ffn.q2", "ffn.q3", "combine2", "LN2"]
+names_bf16 = names
 res = {}
 for prec in ("bf16", "fp32"):
     st = eng.profile_sample(c, e, s, prec, prof_step=3).astype(np.int64)

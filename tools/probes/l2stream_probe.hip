@@ -16,11 +16,11 @@ __global__ __launch_bounds__(1024) void k(const uint4* __restrict__ w, size_t un
     q += DEPTH * 64;
     for (size_t u = DEPTH; u < units_per_wave; u += DEPTH) {
 #pragma unroll
-      for (int i = 0; i < DEPTH; ++i) { acc += r[i].x ^ r[i].w; r[i] = q[i * 64]; }
+      for (int i = 0; i < DEPTH; ++i) { acc += (r[i].x ^ r[i].y) + (r[i].z ^ r[i].w); r[i] = q[i * 64]; }
       q += DEPTH * 64;
     }
 #pragma unroll
-    for (int i = 0; i < DEPTH; ++i) acc += r[i].y;
+    for (int i = 0; i < DEPTH; ++i) acc += (r[i].x ^ r[i].y) + (r[i].z ^ r[i].w);
   }
   unsigned long long t1 = __builtin_readcyclecounter();
   if (acc == 0x12345) sink[0] = acc;
@@ -28,7 +28,7 @@ __global__ __launch_bounds__(1024) void k(const uint4* __restrict__ w, size_t un
 }
 template <int DEPTH> void run(int waves, size_t total_bytes, const uint4* d, unsigned* sink, unsigned long long* cyc, int grid = 256) {
   size_t units_per_wave = total_bytes / 1024 / waves; units_per_wave -= units_per_wave % DEPTH;
-  int passes = 50;
+  int passes = (int)(200.0e6 / total_bytes) + 1;
   k<DEPTH><<<grid, waves * 64>>>(d, units_per_wave, 2, sink, cyc); hipDeviceSynchronize();
   hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b); hipEventRecord(a);
   k<DEPTH><<<grid, waves * 64>>>(d, units_per_wave, passes, sink, cyc); hipEventRecord(b); hipEventSynchronize(b);
@@ -39,5 +39,5 @@ template <int DEPTH> void run(int waves, size_t total_bytes, const uint4* d, uns
 }
 int main() {
   size_t N = 8 << 20; uint4* d; hipMalloc(&d, N); hipMemset(d, 1, N); unsigned* sink; hipMalloc(&sink, 4); unsigned long long* cyc; hipMalloc(&cyc, 8);
-  for (int grid : {1, 8, 32, 86, 256}) for (int waves : {4, 8}) { run<4>(waves, 4 << 20, d, sink, cyc, grid); run<8>(waves, 4 << 20, d, sink, cyc, grid); run<16>(waves, 4 << 20, d, sink, cyc, grid); }
+  for (int grid : {1, 256}) for (size_t kb : {16, 64, 256, 1024, 3800}) for (int waves : {4, 16}) { run<8>(waves, kb << 10, d, sink, cyc, grid); run<32>(waves, kb << 10, d, sink, cyc, grid); }
 }
