@@ -315,6 +315,7 @@ int build_ctx(amuse_ctx* c, const float* den, const float* pri) {
             }
             c->vae_stage_units[prec][st] = (uint32_t)(per_wave / 64);
         }
+        all.insert(all.end(), (size_t)kVaeRing * 64, uint4{0, 0, 0, 0});  // the last wave's ring reads past its slice
         if (upload(&c->vae_w[prec], all.data(), all.size() * sizeof(uint4))) return AMUSE_EHIP;
     }
     {
@@ -364,9 +365,11 @@ int cond_tokens(amuse_ctx* c, const float* con, const float* emo, const float* s
 int pick_group(const amuse_ctx* c, int B, int S) {
     const int gmax = 16 / S;
     int g = c->clips_per_group;
-    // auto: fill the 16-row tile.  A step costs the same for 1..gmax clips per workgroup (the per-CU weight stream
-    // is the bound), and fewer workgroups leave each of them more of the L2 bandwidth.
-    if (g <= 0) g = gmax;
+    // auto: one clip per workgroup tile until every CU has one, then fatten the tiles (a step costs the same for
+    // 1..gmax clips per tile).  With one clip per tile a clip's arithmetic does not depend on its neighbours, so any
+    // sharding of <= 256 clips per GPU reproduces the unsharded result BITWISE; with several clips per tile the
+    // softmax / PV accumulation order depends on the clip's row offset and results agree to rounding only.
+    if (g <= 0) g = (B + 255) / 256;
     if (g > gmax) g = gmax;
     if (g < 1) g = 1;
     return g;

@@ -22,6 +22,7 @@ namespace {
 constexpr int kRowTiles = 19;       // ceil(300 / 16)
 constexpr int kFeatStride = 388;    // 384 padded features + 4: LDS row stride of the staged feats tile
 constexpr int kRowsLdsBytes = kExchBytes + 16 * kFeatStride * 4;
+constexpr int kVR = kVaeRing;       // weight-stream ring depth of k_vae_rows
 
 __device__ __forceinline__ void rot6d_to_axis_angle(const float* d6, int quat_mode, float (&aa)[3]) {
     // rotation_6d_to_matrix (pytorch3d; vendored copy rotation_conversions.py:512-533)
@@ -79,7 +80,17 @@ __global__ __launch_bounds__(256) void k_vae_rows(VaeRowsArgs a) {
     const bool rvalid = frame < kFrames;
     const size_t row = (size_t)b * kFrames + (rvalid ? frame : 0);
     const size_t nrows = (size_t)a.B * kFrames;
+    // this wave's slice of the stage's weight stream, pulled through a register ring (see amuse_dev.hpp: left
+    // to itself hipcc serialises load -> wait -> mfma, one L2 round trip per KiB).  The ring runs up to kVR units
+    // past the slice (into the neighbouring slice; the buffer is padded at its end) - those units are never used.
     const uint4* w = a.wstream + ((size_t)a.stage_base[a.stage] + (size_t)wave * a.stage_units[a.stage]) * 64 + lane;
+    WRing<kVR> rg;
+    ring_fill(rg, w);
+    constexpr int U_O = gemm_units(PREC, kTiles, 2), U_F = gemm_units(PREC, kTiles, kTiles);
+    constexpr int U_S = gemm_units(PREC, kTiles, 4);
+    constexpr int P_O = 0, P_F1 = U_O % kVR, P_F2 = (P_F1 + U_F) % kVR, P_S = (P_F2 + U_F) % kVR;
+    constexpr int P_Q0 = P_S, P_Q1 = (P_S + U_S) % kVR;   // in_proj / final phase without / with a skip linear before
+    bool skipped = false;
     int parity = 0;
     f32x4 x[kTiles];
 
@@ -100,32 +111,32 @@ __global__ __launch_bounds__(256) void k_vae_rows(VaeRowsArgs a) {
         // self-attention out_proj (split-K over heads) + residual + norm1
 #pragma unroll
         for (int t = 0; t < kTiles; ++t) part[t] = splat4(0.f);
-        w = gemm_tiles<PREC, kTiles, 2, false>(part, o, w);
+        gemm_ring<PREC, kTiles, 2, false, kVR, P_O>(part, o, rg);
         exchange_sum(part, exch, parity, wave, lane);
 #pragma unroll
         for (int t = 0; t < kTiles; ++t) x[t] = x[t] + (part[t] + ld4(pv + PV_OUT_B + 16 * t + 4 * g));
-        layer_norm_rows(x, pv + PV_LN1_W, pv + PV_LN1_B, g);
+        layer_norm_rows<PREC == PREC_BF16>(x, pv + PV_LN1_W, pv + PV_LN1_B, g);
         // cross-attention onto the single latent token == per-clip constant; residual + norm2
         const float* ca = a.ca + ((size_t)b * kLayers + blk) * kD;
 #pragma unroll
         for (int t = 0; t < kTiles; ++t) x[t] = x[t] + ld4(ca + 16 * t + 4 * g);
-        layer_norm_rows(x, pv + PV_LN2_W, pv + PV_LN2_B, g);
+        layer_norm_rows<PREC == PREC_BF16>(x, pv + PV_LN2_W, pv + PV_LN2_B, g);
         // FFN + residual + norm3
         f32x4 hid[kTiles];
 #pragma unroll
         for (int t = 0; t < kTiles; ++t) hid[t] = ld4(pv + PV_L1_B + 16 * (kTiles * wave + t) + 4 * g);
-        w = gemm_tiles<PREC, kTiles, kTiles, false>(hid, x, w);
+        gemm_ring<PREC, kTiles, kTiles, false, kVR, P_F1>(hid, x, rg);
 #pragma unroll
         for (int t = 0; t < kTiles; ++t)
 #pragma unroll
-            for (int m = 0; m < 4; ++m) hid[t][m] = gelu_erf(hid[t][m]);
+            for (int m = 0; m < 4; ++m) hid[t][m] = (PREC == PREC_BF16) ? gelu_erf_fast(hid[t][m]) : gelu_erf(hid[t][m]);
 #pragma unroll
         for (int t = 0; t < kTiles; ++t) part[t] = splat4(0.f);
-        w = gemm_tiles<PREC, kTiles, kTiles, false>(part, hid, w);
+        gemm_ring<PREC, kTiles, kTiles, false, kVR, P_F2>(part, hid, rg);
         exchange_sum(part, exch, parity, wave, lane);
 #pragma unroll
         for (int t = 0; t < kTiles; ++t) x[t] = x[t] + (part[t] + ld4(pv + PV_L2_B + 16 * t + 4 * g));
-        layer_norm_rows(x, pv + PV_LN3_W, pv + PV_LN3_B, g);
+        layer_norm_rows<PREC == PREC_BF16>(x, pv + PV_LN3_W, pv + PV_LN3_B, g);
         if (blk < 4 && wave == 0 && rvalid) {  // xs.append(x)
             float* sk = a.skip + ((size_t)blk * nrows + row) * kD;
 #pragma unroll
@@ -141,7 +152,8 @@ __global__ __launch_bounds__(256) void k_vae_rows(VaeRowsArgs a) {
             }
 #pragma unroll
             for (int t = 0; t < kTiles; ++t) part[t] = splat4(0.f);
-            w = gemm_tiles<PREC, kTiles, 4, false>(part, src, w);
+            gemm_ring<PREC, kTiles, 4, false, kVR, P_S>(part, src, rg);
+            skipped = true;
             exchange_sum(part, exch, parity, wave, lane);
             const float* sb = a.pvec + PV_SKIP_B + (blk - 4) * kD;
 #pragma unroll
@@ -163,7 +175,9 @@ __global__ __launch_bounds__(256) void k_vae_rows(VaeRowsArgs a) {
             qkv[2 + o] = ld4(pv + PV_IN_B + kD + 16 * (2 * wave + o) + 4 * g);
             qkv[4 + o] = ld4(pv + PV_IN_B + 2 * kD + 16 * (2 * wave + o) + 4 * g);
         }
-        w = gemm_tiles<PREC, 6, kTiles, false>(qkv, x, w);
+        if (a.stage == 0) gemm_ring<PREC, 6, kTiles, false, kVR, 0>(qkv, x, rg);
+        else if (skipped) gemm_ring<PREC, 6, kTiles, false, kVR, P_Q1>(qkv, x, rg);
+        else gemm_ring<PREC, 6, kTiles, false, kVR, P_Q0>(qkv, x, rg);
         if (rvalid) {
             const size_t hrow = (((size_t)b * kHeads + wave) * kFrames + frame) * 32;
             const float scaling = 0.17677669529663687f;
@@ -176,11 +190,11 @@ __global__ __launch_bounds__(256) void k_vae_rows(VaeRowsArgs a) {
         }
     } else {
         // decoder.norm -> final_layer (333 outputs padded to 24 tiles, 6 per wave) -> rotation epilogue
-        layer_norm_rows(x, a.pvec + PV_FINAL_W, a.pvec + PV_FINAL_B, g);
+        layer_norm_rows<PREC == PREC_BF16>(x, a.pvec + PV_FINAL_W, a.pvec + PV_FINAL_B, g);
         f32x4 f[6];
 #pragma unroll
         for (int o = 0; o < 6; ++o) f[o] = ld4(a.final_bias + 16 * (6 * wave + o) + 4 * g);
-        w = gemm_tiles<PREC, 6, kTiles, false>(f, x, w);
+        gemm_ring<PREC, 6, kTiles, false, kVR, P_Q0>(f, x, rg);
         const int len = a.lengths ? a.lengths[b] : kFrames;
         const bool keep = rvalid && frame < len;  // output[~mask.T] = 0 (vae.py:274)
 #pragma unroll
@@ -274,8 +288,7 @@ __global__ __launch_bounds__(256) void k_vae_attn(VaeAttnArgs a) {
                     ok[u][m] = (32 * jp + 16 * u + 4 * g + m) < len;
                     mx = ok[u][m] ? fmaxf(mx, st[u][m]) : mx;
                 }
-            mx = fmaxf(mx, __shfl_xor(mx, 16));
-            mx = fmaxf(mx, __shfl_xor(mx, 32));
+            mx = allreduce_g_max(mx);
             const float m_new = fmaxf(m_run, mx);
             const float alpha = (m_new == -INFINITY) ? 1.0f : expf(m_run - m_new);
             f32x4 p[2];
@@ -287,8 +300,7 @@ __global__ __launch_bounds__(256) void k_vae_attn(VaeAttnArgs a) {
                     p[u][m] = ok[u][m] ? expf(st[u][m] - m_new) : 0.f;
                     ps += p[u][m];
                 }
-            ps += __shfl_xor(ps, 16);
-            ps += __shfl_xor(ps, 32);
+            ps = allreduce_g_sum(ps);
             l_run = l_run * alpha + ps;
             o[0] *= alpha;
             o[1] *= alpha;
@@ -326,6 +338,128 @@ __global__ __launch_bounds__(256) void k_vae_attn(VaeAttnArgs a) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// bf16 attention: K_h and V_h^T are converted ONCE per workgroup into LDS images that are already MFMA
+// fragments - Kb[key][g] = the 8 bf16 of k-slot group g (d = 4g+e | 16+4g+e-4) of that key row, Vt[pair][td][d][g]
+// = the 8 bf16 of V[key(g,e)][16 td + d] over the 32 keys of a key-tile pair - so the inner loop is
+// one ds_read_b128 per MFMA operand, no packing.  Each wave walks TWO 16-query tiles at a time (shared K/V
+// fragments, two independent MFMA/softmax chains).  Per (q-tile, 32 keys): 2 score MFMAs (K.Q^T, K = d = 32),
+// online softmax on 8 register values + two permlane butterflies, 2 PV MFMAs (V^T.P^T, K = 32 keys).
+constexpr int kPairs = kKeyRows / 32;                        // 10
+constexpr int kAttnBf16LdsBytes = kKeyRows * 64 + kPairs * 2 * 16 * 64;  // 20 KiB + 20 KiB
+
+template <int NQ>
+__device__ __forceinline__ void attn_qtiles_bf16(const uint4* Kb, const uint4* Vt, const float* qg, float* og, int qt0,
+                                                 int len, int g, int r) {
+    constexpr float kLog2e = 1.44269504088896340736f;
+    bf16x8 qb[NQ];
+    float m_run[NQ], l_run[NQ];
+    f32x4 o[NQ][2];
+#pragma unroll
+    for (int n = 0; n < NQ; ++n) {
+        const int fq = (qt0 + 4 * n) * 16 + r;
+        const bool qv = fq < kFrames;
+        const f32x4 q0 = qv ? ld4(qg + fq * 32 + 4 * g) : splat4(0.f);
+        const f32x4 q1 = qv ? ld4(qg + fq * 32 + 16 + 4 * g) : splat4(0.f);
+        qb[n] = pack_bf16(q0, q1);
+        m_run[n] = -INFINITY;
+        l_run[n] = 0.f;
+        o[n][0] = o[n][1] = splat4(0.f);
+    }
+#pragma unroll 1
+    for (int jp = 0; jp < kPairs; ++jp) {
+        const bf16x8 k0 = __builtin_bit_cast(bf16x8, Kb[(32 * jp + r) * 4 + g]);
+        const bf16x8 k1 = __builtin_bit_cast(bf16x8, Kb[(32 * jp + 16 + r) * 4 + g]);
+        const bf16x8 v0 = __builtin_bit_cast(bf16x8, Vt[((jp * 2 + 0) * 16 + r) * 4 + g]);
+        const bf16x8 v1 = __builtin_bit_cast(bf16x8, Vt[((jp * 2 + 1) * 16 + r) * 4 + g]);
+        bool ok[2][4];
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int m = 0; m < 4; ++m) ok[u][m] = (32 * jp + 16 * u + 4 * g + m) < len;
+#pragma unroll
+        for (int n = 0; n < NQ; ++n) {
+            f32x4 st[2];
+            st[0] = mfma_bf16(k0, qb[n], splat4(0.f));  // lane (g, i): S[i][32 jp + 4 g + m]
+            st[1] = mfma_bf16(k1, qb[n], splat4(0.f));  //              S[i][32 jp + 16 + 4 g + m]
+            float mx = -INFINITY;
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int m = 0; m < 4; ++m) {
+                    st[u][m] *= kLog2e;
+                    mx = ok[u][m] ? fmaxf(mx, st[u][m]) : mx;
+                }
+            mx = allreduce_g_max(mx);
+            const float m_new = fmaxf(m_run[n], mx);
+            const float alpha = (m_new == -INFINITY) ? 1.0f : __builtin_amdgcn_exp2f(m_run[n] - m_new);
+            f32x4 p[2];
+            float ps = 0.f;
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int m = 0; m < 4; ++m) {
+                    p[u][m] = ok[u][m] ? __builtin_amdgcn_exp2f(st[u][m] - m_new) : 0.f;
+                    ps += p[u][m];
+                }
+            ps = allreduce_g_sum(ps);
+            l_run[n] = l_run[n] * alpha + ps;
+            m_run[n] = m_new;
+            const bf16x8 pb = pack_bf16(p[0], p[1]);
+            o[n][0] = mfma_bf16(v0, pb, o[n][0] * alpha);  // O^T[d][i] += sum_key V[key][d] P[i][key]
+            o[n][1] = mfma_bf16(v1, pb, o[n][1] * alpha);
+        }
+    }
+#pragma unroll
+    for (int n = 0; n < NQ; ++n) {
+        const int fq = (qt0 + 4 * n) * 16 + r;
+        if (fq < kFrames) {
+            float* dst = og + (size_t)fq * kD + 4 * g;
+            st4(dst, o[n][0] / l_run[n]);
+            st4(dst + 16, o[n][1] / l_run[n]);
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_vae_attn_bf16(VaeAttnArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    uint4* Kb = reinterpret_cast<uint4*>(smem);
+    uint4* Vt = Kb + kKeyRows * 4;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int g = lane >> 4, r = lane & 15;
+    const int bh = blockIdx.x, b = bh / kHeads, h = bh - b * kHeads;
+    const int len = a.lengths ? a.lengths[b] : kFrames;
+    const float* qg = a.q + (size_t)bh * kFrames * 32;
+    const float* kg = a.k + (size_t)bh * kFrames * 32;
+    const float* vg = a.v + (size_t)bh * kFrames * 32;
+    for (int i = threadIdx.x; i < kKeyRows * 4; i += 256) {  // K fragments: item = (key row, slot group)
+        const int row = i >> 2, gg = i & 3;
+        const bool ok = row < kFrames;
+        const f32x4 lo = ok ? ld4(kg + row * 32 + 4 * gg) : splat4(0.f);
+        const f32x4 hi = ok ? ld4(kg + row * 32 + 16 + 4 * gg) : splat4(0.f);
+        Kb[i] = __builtin_bit_cast(uint4, pack_bf16(lo, hi));
+    }
+    for (int i = threadIdx.x; i < kPairs * 2 * 16 * 4; i += 256) {  // V^T fragments: item = ((pair, td), g, d)
+        const int d = i & 15, gg = (i >> 4) & 3, pt = i >> 6;  // pt = jp * 2 + td
+        const int jp = pt >> 1, td = pt & 1;
+        f32x4 lo, hi;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int k0 = 32 * jp + 4 * gg + e, k1 = k0 + 16;
+            lo[e] = k0 < kFrames ? vg[k0 * 32 + 16 * td + d] : 0.f;
+            hi[e] = k1 < kFrames ? vg[k1 * 32 + 16 * td + d] : 0.f;
+        }
+        Vt[(pt * 16 + d) * 4 + gg] = __builtin_bit_cast(uint4, pack_bf16(lo, hi));
+    }
+    __syncthreads();
+    float* og = a.o + (size_t)b * kFrames * kD + 32 * h;
+    // 19 query tiles: wave w owns tiles w, w+4, w+8, w+12 (two pairs) and w+16 (waves 0..2)
+    attn_qtiles_bf16<2>(Kb, Vt, qg, og, wave, len, g, r);
+    attn_qtiles_bf16<2>(Kb, Vt, qg, og, wave + 8, len, g, r);
+    if (wave + 16 < kRowTiles) attn_qtiles_bf16<1>(Kb, Vt, qg, og, wave + 16, len, g, r);
+}
+
 template <typename K>
 hipError_t set_lds(K kern, int bytes) {
     return hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
@@ -353,13 +487,13 @@ hipError_t launch_vae_attn(const VaeAttnArgs& a, int precision, hipStream_t stre
     if (!attr_set) {
         hipError_t e = set_lds(&k_vae_attn<PREC_F32>, kAttnLdsBytes);
         if (e != hipSuccess) return e;
-        e = set_lds(&k_vae_attn<PREC_BF16>, kAttnLdsBytes);
+        e = set_lds(&k_vae_attn_bf16, kAttnBf16LdsBytes);
         if (e != hipSuccess) return e;
         attr_set = true;
     }
     const dim3 grid(a.B * kHeads), block(256);
     if (precision == PREC_F32) hipLaunchKernelGGL(k_vae_attn<PREC_F32>, grid, block, kAttnLdsBytes, stream, a);
-    else hipLaunchKernelGGL(k_vae_attn<PREC_BF16>, grid, block, kAttnLdsBytes, stream, a);
+    else hipLaunchKernelGGL(k_vae_attn_bf16, grid, block, kAttnBf16LdsBytes, stream, a);
     return hipGetLastError();
 }
 
