@@ -162,6 +162,20 @@ def test_ddpm_explicit_noise_vs_oracle(env):
     assert _err(lat, otraj[-1]) < 2e-4 * max(1.0, scale)
 
 
+def test_ddpm1000_fp32_single_clip_vs_oracle(env):
+    """BASELINE config 2 shape: 1 clip, the full 1000-step ancestral DDPM, explicit x_T and per-step noise."""
+    from amuse_amd import scheduler as sch
+    orc, eng, Wd = env["orc"], env["eng"], env["Wd"]
+    gen = torch.Generator().manual_seed(77)
+    c, e, s, x = (torch.randn(1, n, generator=gen) for n in (256, 256, 256, 128))
+    nz = torch.randn(1000, 1, 128, generator=gen)
+    eng.set_schedule(sch.ddpm_table())
+    lat = eng.sample(c, e, s, "fp32", x_init=x, step_noise=nz)
+    ref = orc.sample_latents(Wd, orc.DDPM(), c, e, s, x, nz)
+    scale = float(ref.abs().max())          # random weights drive the latent to rms ~ 30 (no clipping in DDPM)
+    assert _err(lat, ref) < 3e-5 * scale    # measured 1.5e-4 abs on rms 31 (4.6e-6 relative)
+
+
 def test_in_kernel_noise_is_shard_invariant(env):
     """Counter-based noise keyed by the GLOBAL clip index: 8 clips at once == two shards of 4, bitwise."""
     from amuse_amd import scheduler as sch
