@@ -347,6 +347,113 @@ __device__ __forceinline__ void exchange_sum(f32x4 (&part)[kTiles], f32x4* exch,
 }
 constexpr int kExchBytes = 2 * 4 * kTiles * 64 * 16;  // 64 KiB
 
+// ------------------------------------------------------------------------------------------------
+// Split-K combine as reduce-scatter + (LayerNorm) + all-gather.  exchange_sum makes every wave read all
+// partials and then repeat the same residual + LayerNorm on the full [16 x 128] tile - 4x redundant VALU and
+// 32 LDS b128 operations per wave.  Here wave W reduces only ITS two feature tiles (6 writes, 6 reads),
+// normalises them (row statistics of the four 32-feature slices are merged with Chan's parallel-variance
+// formula through a 512-byte LDS table), publishes them (2 writes) and reads the other six (6 reads):
+// 22 LDS operations, a quarter of the adds and of the LayerNorm arithmetic, at the price of two more barriers.
+// All waves end with bit-identical x (everything shared goes through LDS, merges use one fixed order).
+// LDS: A = [4 waves][8 tiles][64] f32x4 (32 KiB) | stats = [4][16] float2 (512 B) | Bq = [8][64] f32x4 (8 KiB);
+// single-buffered: each buffer's last readers are separated from its next writers by a later barrier of the
+// same combine.
+constexpr int kCombA = 4 * kTiles * 64;                 // f32x4 elements
+constexpr int kCombBytes = kCombA * 16 + 4 * 16 * 8 + kTiles * 64 * 16;   // 41,472 B
+
+template <int W, bool DO_LN, bool FAST, int NC, int R, int IPH>
+__device__ __forceinline__ void combine_rs_impl(f32x4 (&part)[kTiles], f32x4 (&x)[kTiles], bool residual,
+                                                const float* bias, const float* gamma, const float* beta,
+                                                char* lds, int lane, WRing<R>* rg) {
+    f32x4* A = reinterpret_cast<f32x4*>(lds);
+    float2* stats = reinterpret_cast<float2*>(lds + kCombA * 16);
+    f32x4* Bq = reinterpret_cast<f32x4*>(lds + kCombA * 16 + 4 * 16 * 8);
+    const int g = lane >> 4, r = lane & 15;
+    constexpr int T0 = 2 * W;
+    if constexpr (NC > 0) ring_issue<NC, R, IPH % R>(*rg);
+#pragma unroll
+    for (int t = 0; t < kTiles; ++t)
+        if (t != T0 && t != T0 + 1) A[(W * kTiles + t) * 64 + lane] = part[t];
+    f32x4 bi[2], ga[2], be[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        bi[i] = ld4(bias + 16 * (T0 + i) + 4 * g);
+        if constexpr (DO_LN) {
+            ga[i] = ld4(gamma + 16 * (T0 + i) + 4 * g);
+            be[i] = ld4(beta + 16 * (T0 + i) + 4 * g);
+        }
+    }
+    __syncthreads();
+    if constexpr (NC > 0) ring_issue<NC, R, (IPH + NC) % R>(*rg);
+    f32x4 y[2];
+    {
+        f32x4 p[4][2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int w = 0; w < 4; ++w)
+                if (w != W) p[w][i] = A[(w * kTiles + T0 + i) * 64 + lane];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            p[W][i] = part[T0 + i];
+            const f32x4 sum = ((p[0][i] + p[1][i]) + p[2][i]) + p[3][i];
+            y[i] = residual ? x[T0 + i] + (sum + bi[i]) : sum + bi[i];
+        }
+    }
+    if constexpr (DO_LN) {
+        // statistics of this wave's 32 features of every row (lanes g = 0..3 of a row hold 8 of them each)
+        float s = ((y[0][0] + y[0][1]) + (y[0][2] + y[0][3])) + ((y[1][0] + y[1][1]) + (y[1][2] + y[1][3]));
+        s = allreduce_g_sum(s);
+        const float mw = s * (1.0f / 32.0f);
+        float m2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                const float d = y[i][m] - mw;
+                m2 += d * d;
+            }
+        m2 = allreduce_g_sum(m2);
+        if (g == 0) stats[W * 16 + r] = float2{mw, m2};
+        __syncthreads();
+        if constexpr (NC > 0) ring_issue<NC, R, (IPH + 2 * NC) % R>(*rg);
+        const float2 s0 = stats[r], s1 = stats[16 + r], s2 = stats[32 + r], s3 = stats[48 + r];
+        const float mean = ((s0.x + s1.x) + (s2.x + s3.x)) * 0.25f;
+        const float d0 = s0.x - mean, d1 = s1.x - mean, d2 = s2.x - mean, d3 = s3.x - mean;
+        const float M2 = ((s0.y + s1.y) + (s2.y + s3.y)) + 32.0f * ((d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3));
+        const float var = M2 * (1.0f / kD) + 1e-5f;
+        const float rstd = FAST ? __builtin_amdgcn_rsqf(var) : 1.0f / sqrtf(var);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int m = 0; m < 4; ++m) y[i][m] = (y[i][m] - mean) * rstd * ga[i][m] + be[i][m];
+    } else {
+        if constexpr (NC > 0) ring_issue<NC, R, (IPH + 2 * NC) % R>(*rg);
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        Bq[(T0 + i) * 64 + lane] = y[i];
+        x[T0 + i] = y[i];
+    }
+    __syncthreads();
+    if constexpr (NC > 0) ring_issue<NC, R, (IPH + 3 * NC) % R>(*rg);
+#pragma unroll
+    for (int t = 0; t < kTiles; ++t)
+        if (t != T0 && t != T0 + 1) x[t] = Bq[t * 64 + lane];
+}
+// x <- [LayerNorm]( [x +] (sum over waves of part) + bias );  NI weight-stream units issued in four chunks
+template <bool DO_LN, bool FAST, int NI = 0, int R = 1, int IPH = 0>
+__device__ __forceinline__ void combine_rs(f32x4 (&part)[kTiles], f32x4 (&x)[kTiles], bool residual, const float* bias,
+                                           const float* gamma, const float* beta, char* lds, int wave, int lane,
+                                           WRing<R>* rg = nullptr) {
+    static_assert(NI % 4 == 0, "issue count is split in four chunks");
+    constexpr int NC = NI / 4;
+    if (wave == 0) combine_rs_impl<0, DO_LN, FAST, NC, R, IPH>(part, x, residual, bias, gamma, beta, lds, lane, rg);
+    else if (wave == 1) combine_rs_impl<1, DO_LN, FAST, NC, R, IPH>(part, x, residual, bias, gamma, beta, lds, lane, rg);
+    else if (wave == 2) combine_rs_impl<2, DO_LN, FAST, NC, R, IPH>(part, x, residual, bias, gamma, beta, lds, lane, rg);
+    else combine_rs_impl<3, DO_LN, FAST, NC, R, IPH>(part, x, residual, bias, gamma, beta, lds, lane, rg);
+}
+
 // ---- counter-based normals: Philox4x32-10, key = seed, counter = (clip, step, feature/4, stream)
 __device__ __forceinline__ void philox4x32_10(uint32_t (&c)[4], uint32_t k0, uint32_t k1) {
 #pragma unroll

@@ -35,7 +35,8 @@ constexpr int kRing = 32;                 // weight-stream ring depth (1 KiB uni
 constexpr int skip_pad_units(int prec) { return prec == 0 ? (kRing - 32 % kRing) % kRing : 0; }
 constexpr int kEncPv = 1664;              // encoder-block small params kept in LDS (PV_* up to LN2)
 constexpr int kSkipBytes = 32 * 1024;     // U-Net skip stack [4][8][64] f32x4
-constexpr int kSampleLdsBytes = 64 * 1024 + kSkipBytes + (9 * kEncPv + 4 * 128 + 2 * 128) * 4;  // 161,280 B
+constexpr int kSampleCombBytes = 4 * 8 * 64 * 16 + 4 * 16 * 8 + 8 * 64 * 16;  // = kCombBytes (amuse_dev.hpp), 41,472 B
+constexpr int kSampleLdsBytes = kSampleCombBytes + kSkipBytes + (9 * kEncPv + 4 * 128 + 2 * 128) * 4;  // 137,216 B
 
 // ---------------------------------------------------------------- one-off prologue kernels (k_misc.hip)
 // time_tok[i][:] = Linear2(SiLU(Linear1([cos|sin](t_i * freqs)))) + pe1     (embeddings.py:245-322)

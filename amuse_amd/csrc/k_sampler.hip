@@ -84,7 +84,7 @@ __device__ __forceinline__ void stamp(Prof& pf) {
 // One TransformerEncoderLayer.forward_post (cross_attention.py:259-272) on the row-lane tile x.
 template <int PREC, bool PROF>
 __device__ __forceinline__ void encoder_block(f32x4 (&x)[kTiles], WRing<kRing>& rg, const float* pv,
-                                              const bool (&kvalid)[4], f32x4* exch, int& parity, int wave, int lane,
+                                              const bool (&kvalid)[4], char* comb, int wave, int lane,
                                               bool next_has_skip, Prof& pf) {
     const int g = lane >> 4, r = lane & 15;
     // ring phases of the five GEMMs of a block (compile-time; a block consumes a whole number of revolutions)
@@ -119,9 +119,6 @@ __device__ __forceinline__ void encoder_block(f32x4 (&x)[kTiles], WRing<kRing>& 
     gemm_ring<PREC, 2, kTiles, true, kRing, P_V, !DELAY>(v, x, rg);
     ring_issue<A8, kRing, 0>(rg);
     stamp<PROF>(pf);  // 1: in_proj done
-    f32x4 b_out[kTiles];
-#pragma unroll
-    for (int t = 0; t < kTiles; ++t) b_out[t] = ld4(pv + PV_OUT_B + 16 * t + 4 * g);
     const float scaling = 0.17677669529663687f;  // sqrt(1/32): q * scaling (F.multi_head_attention_forward)
     f32x4 q[2] = {(qk[0] + b_qk[0]) * scaling, (qk[1] + b_qk[1]) * scaling};
     f32x4 k[2] = {qk[2] + b_qk[2], qk[3] + b_qk[3]};
@@ -136,14 +133,10 @@ __device__ __forceinline__ void encoder_block(f32x4 (&x)[kTiles], WRing<kRing>& 
     for (int t = 0; t < kTiles; ++t) part[t] = splat4(0.f);
     gemm_ring<PREC, kTiles, 2, false, kRing, P_OUT, !DELAY>(part, o, rg);
     stamp<PROF>(pf);  // 3: out_proj partial done
-    exchange_sum<A8, kRing, 24>(part, exch, parity, wave, lane, &rg);
-    stamp<PROF>(pf);  // 4: combine 1 done
-    LnParams ln;
-    ln_params_load(ln, pv + PV_LN1_W, pv + PV_LN1_B, g);
-#pragma unroll
-    for (int t = 0; t < kTiles; ++t) x[t] = x[t] + (part[t] + b_out[t]);
-    layer_norm_rows<FAST>(x, ln);
-    stamp<PROF>(pf);  // 5: LN1 done
+    // x = LN1(x + sum_w part + b_out): reduce-scatter / LayerNorm / all-gather (amuse_dev.hpp combine_rs)
+    combine_rs<true, FAST, A8, kRing, 24>(part, x, true, pv + PV_OUT_B, pv + PV_LN1_W, pv + PV_LN1_B, comb, wave, lane, &rg);
+    stamp<PROF>(pf);  // 4: combine 1 + LN1 done
+    stamp<PROF>(pf);  // 5: (kept for timeline compatibility)
     // ---- FFN in four interleaved quarters: linear1 for 2 of this wave's 8 hidden tiles -> bias + GELU ->
     // linear2 split-K contribution of exactly those 32 hidden features.  The weight stream is packed in the same
     // order, so the 32-slot ring (holding quarters 0,1 on entry) is re-armed with quarters 2,3 while quarters 0,1
@@ -151,10 +144,7 @@ __device__ __forceinline__ void encoder_block(f32x4 (&x)[kTiles], WRing<kRing>& 
     constexpr int U_Q = gemm_units(PREC, 2, kTiles);  // units of one half-quarter (= gemm_units(PREC, 8, 2))
     static_assert(U_Q == gemm_units(PREC, kTiles, 2) && P_F1 == 0, "FFN quarter phases");
 #pragma unroll
-    for (int t = 0; t < kTiles; ++t) {
-        b_out[t] = ld4(pv + PV_L2_B + 16 * t + 4 * g);
-        part[t] = splat4(0.f);
-    }
+    for (int t = 0; t < kTiles; ++t) part[t] = splat4(0.f);
 #pragma unroll
     for (int qd = 0; qd < 4; ++qd) {
         const f32x4 b1a = ld4(pv + PV_L1_B + 16 * (kTiles * wave + 2 * qd) + 4 * g);
@@ -179,19 +169,18 @@ __device__ __forceinline__ void encoder_block(f32x4 (&x)[kTiles], WRing<kRing>& 
         if (qd < 3) stamp<PROF>(pf);  // 6..8: FFN quarters
     }
     stamp<PROF>(pf);  // 9: FFN done (linear2 partial)
+    // x = LN2(x + sum_w part + b_l2).  bf16: the ring is re-armed meanwhile with the next block's first units - its
+    // in_proj + out_proj (32) or, ahead of an output block, only the 16 skip-linear units (slots 16..31 stay empty;
+    // the skip combine re-arms all 32)
     if constexpr (DELAY) {
-        // re-arm the ring with the next block's first units: its in_proj + out_proj (32), or - ahead of an output
-        // block - only the 16 skip-linear units (slots 16..31 stay empty; the skip combine re-arms all 32)
-        if (next_has_skip) exchange_sum<16, kRing, 0>(part, exch, parity, wave, lane, &rg);
-        else exchange_sum<32, kRing, 0>(part, exch, parity, wave, lane, &rg);
+        if (next_has_skip)
+            combine_rs<true, FAST, 16, kRing, 0>(part, x, true, pv + PV_L2_B, pv + PV_LN2_W, pv + PV_LN2_B, comb, wave, lane, &rg);
+        else
+            combine_rs<true, FAST, 32, kRing, 0>(part, x, true, pv + PV_L2_B, pv + PV_LN2_W, pv + PV_LN2_B, comb, wave, lane, &rg);
     } else {
-        exchange_sum(part, exch, parity, wave, lane);
+        combine_rs<true, FAST>(part, x, true, pv + PV_L2_B, pv + PV_LN2_W, pv + PV_LN2_B, comb, wave, lane);
     }
-    stamp<PROF>(pf);  // 9: combine 2 done
-    ln_params_load(ln, pv + PV_LN2_W, pv + PV_LN2_B, g);
-#pragma unroll
-    for (int t = 0; t < kTiles; ++t) x[t] = x[t] + (part[t] + b_out[t]);
-    layer_norm_rows<FAST>(x, ln);
+    stamp<PROF>(pf);  // 9: combine 2 + LN2 done
     stamp<PROF>(pf);  // 10: LN2 done
 }
 
@@ -203,9 +192,9 @@ __device__ __forceinline__ void store_tap(float* tap, int slot, const f32x4 (&x)
 template <int PREC, bool PROF>
 __global__ __launch_bounds__(256, 1) void k_sample(SampleArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    f32x4* exch = reinterpret_cast<f32x4*>(smem);
-    f32x4* skip = reinterpret_cast<f32x4*>(smem + kExchBytes);  // [4][8 tiles][64 lanes]
-    float* pvl = reinterpret_cast<float*>(smem + kExchBytes + kSkipBytes);  // small params, compact (kEncPv / block)
+    char* comb = smem;                                           // split-K combine buffers (kCombBytes)
+    f32x4* skip = reinterpret_cast<f32x4*>(smem + kCombBytes);  // [4][8 tiles][64 lanes]
+    float* pvl = reinterpret_cast<float*>(smem + kCombBytes + kSkipBytes);  // small params, compact (kEncPv / block)
     for (int i = threadIdx.x; i < kLayers * kEncPv / 4; i += 256) {
         const int blk = (4 * i) / kEncPv, off = 4 * i - blk * kEncPv;
         st4(pvl + 4 * i, ld4(a.pvec + blk * PV_BLOCK + off));
@@ -247,7 +236,6 @@ __global__ __launch_bounds__(256, 1) void k_sample(SampleArgs a) {
         }
     }
     const bool tap = a.tap_out != nullptr && blockIdx.x == 0 && wave == 0;
-    int parity = 0;
     const uint4* wbase = a.wstream + (size_t)wave * (a.wave_units + kRing) * 64 + lane;
     WRing<kRing> rg;
     ring_fill(rg, wbase);
@@ -290,22 +278,20 @@ __global__ __launch_bounds__(256, 1) void k_sample(SampleArgs a) {
 #pragma unroll
                 for (int t = 0; t < kTiles; ++t) part[t] = splat4(0.f);
                 constexpr int U_SK = gemm_units(PREC, kTiles, 4);
+                const float* sb = pv_skip + (blk - 5) * kD;
                 if constexpr (PREC == PREC_BF16) {
                     // the ring holds just the 16 skip-linear units (slots 0..15); the whole ring is re-armed
                     // during the combine with the block's first 32 units
                     gemm_ring<PREC, kTiles, 4, false, kRing, 0, false>(part, src, rg);
-                    exchange_sum<32, kRing, 0>(part, exch, parity, wave, lane, &rg);
+                    combine_rs<false, true, 32, kRing, 0>(part, x, false, sb, nullptr, nullptr, comb, wave, lane, &rg);
                 } else {
                     gemm_ring<PREC, kTiles, 4, false, kRing, 0>(part, src, rg);
                     ring_discard<skip_pad_units(PREC), kRing, U_SK % kRing>(rg);
-                    exchange_sum(part, exch, parity, wave, lane);
+                    combine_rs<false, false>(part, x, false, sb, nullptr, nullptr, comb, wave, lane);
                 }
-                const float* sb = pv_skip + (blk - 5) * kD;
-#pragma unroll
-                for (int t = 0; t < kTiles; ++t) x[t] = part[t] + ld4(sb + 16 * t + 4 * g);
             }
             stamp<PROF>(pf);  // block start (after the skip linear, if any)
-            encoder_block<PREC, PROF>(x, rg, pvl + blk * kEncPv, kvalid, exch, parity, wave, lane,
+            encoder_block<PREC, PROF>(x, rg, pvl + blk * kEncPv, kvalid, comb, wave, lane,
                                       blk >= 4 && blk < kLayers - 1, pf);
             if (blk < 4 && wave == 0) {
                 f32x4* sk = skip + (size_t)blk * kTiles * 64;
