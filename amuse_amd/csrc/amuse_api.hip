@@ -173,14 +173,13 @@ void pack_outproj_ffn(std::vector<uint4>& s, int prec, const Params& P, const st
     pack_gemm(s, prec, P.get(p + ".linear1.weight"), 512, 128, range(8 * w, 8 * w + 8), range(0, 8));
     pack_gemm(s, prec, P.get(p + ".linear2.weight"), 128, 512, range(0, 8), range(8 * w, 8 * w + 8));
 }
-// sampler order: out_proj, then the FFN in four interleaved quarters (k_sampler.hip encoder_block)
+// sampler order: out_proj, then the FFN in four software-pipelined quarters (k_sampler.hip encoder_block)
 void pack_outproj_ffn_quarters(std::vector<uint4>& s, int prec, const Params& P, const std::string& p, int w) {
     pack_gemm(s, prec, P.get(p + ".self_attn.out_proj.weight"), 128, 128, range(0, 8), {2 * w, 2 * w + 1});
-    for (int q = 0; q < 4; ++q) {
-        const int h0 = 8 * w + 2 * q;
-        pack_gemm(s, prec, P.get(p + ".linear1.weight"), 512, 128, {h0, h0 + 1}, range(0, 8));
-        pack_gemm(s, prec, P.get(p + ".linear2.weight"), 128, 512, range(0, 8), {h0, h0 + 1});
-    }
+    // software-pipelined order of k_sampler.hip: F1q0 F1q1 F2q0 F1q2 F2q1 F1q3 F2q2 F2q3
+    auto f1 = [&](int q) { const int h0 = 8 * w + 2 * q; pack_gemm(s, prec, P.get(p + ".linear1.weight"), 512, 128, {h0, h0 + 1}, range(0, 8)); };
+    auto f2 = [&](int q) { const int h0 = 8 * w + 2 * q; pack_gemm(s, prec, P.get(p + ".linear2.weight"), 128, 512, range(0, 8), {h0, h0 + 1}); };
+    f1(0); f1(1); f2(0); f1(2); f2(1); f1(3); f2(2); f2(3);
 }
 void pack_skiplin(std::vector<uint4>& s, int prec, const Params& P, const std::string& prefix, int i, int w) {
     pack_gemm(s, prec, P.get(prefix + ".linear_blocks." + std::to_string(i) + ".weight"), 128, 256, range(0, 8),

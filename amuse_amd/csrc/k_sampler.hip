@@ -145,29 +145,39 @@ __device__ __forceinline__ void encoder_block(f32x4 (&x)[kTiles], WRing<kRing>& 
     static_assert(U_Q == gemm_units(PREC, kTiles, 2) && P_F1 == 0, "FFN quarter phases");
 #pragma unroll
     for (int t = 0; t < kTiles; ++t) part[t] = splat4(0.f);
+    // software-pipelined by one quarter: linear1 of quarter q+1 is issued BEFORE the GELU of quarter q, so the
+    // matrix pipe works through it while the VALU evaluates the erf (one wave per SIMD: nothing else would fill
+    // that latency).  Stream order: F1q0 F1q1 F2q0 F1q2 F2q1 F1q3 F2q2 F2q3 (8 / 16 units each).
+    f32x4 hq[4][2];
 #pragma unroll
-    for (int qd = 0; qd < 4; ++qd) {
+    for (int qd = 0; qd < 4; ++qd) hq[qd][0] = hq[qd][1] = splat4(0.f);
+    auto gelu_quarter = [&](int qd) {
         const f32x4 b1a = ld4(pv + PV_L1_B + 16 * (kTiles * wave + 2 * qd) + 4 * g);
         const f32x4 b1b = ld4(pv + PV_L1_B + 16 * (kTiles * wave + 2 * qd + 1) + 4 * g);
-        f32x4 hq[2] = {splat4(0.f), splat4(0.f)};
-        // fp32: always re-arm at consumption; bf16: quarters 0,1 re-arm (with quarters 2,3), 2,3 leave the ring to
-        // be re-armed during combine 2
-        if (qd == 0) gemm_ring<PREC, 2, kTiles, false, kRing, (0 * U_Q) % kRing, true>(hq, x, rg);
-        if (qd == 1) gemm_ring<PREC, 2, kTiles, false, kRing, (2 * U_Q) % kRing, true>(hq, x, rg);
-        if (qd == 2) gemm_ring<PREC, 2, kTiles, false, kRing, (4 * U_Q) % kRing, !DELAY>(hq, x, rg);
-        if (qd == 3) gemm_ring<PREC, 2, kTiles, false, kRing, (6 * U_Q) % kRing, !DELAY>(hq, x, rg);
 #pragma unroll
         for (int m = 0; m < 4; ++m) {
-            const float h0 = hq[0][m] + b1a[m], h1 = hq[1][m] + b1b[m];
-            hq[0][m] = FAST ? gelu_erf_fast(h0) : gelu_erf(h0);
-            hq[1][m] = FAST ? gelu_erf_fast(h1) : gelu_erf(h1);
+            const float h0 = hq[qd][0][m] + b1a[m], h1 = hq[qd][1][m] + b1b[m];
+            hq[qd][0][m] = FAST ? gelu_erf_fast(h0) : gelu_erf(h0);
+            hq[qd][1][m] = FAST ? gelu_erf_fast(h1) : gelu_erf(h1);
         }
-        if (qd == 0) gemm_ring<PREC, kTiles, 2, false, kRing, (1 * U_Q) % kRing, true>(part, hq, rg);
-        if (qd == 1) gemm_ring<PREC, kTiles, 2, false, kRing, (3 * U_Q) % kRing, true>(part, hq, rg);
-        if (qd == 2) gemm_ring<PREC, kTiles, 2, false, kRing, (5 * U_Q) % kRing, !DELAY>(part, hq, rg);
-        if (qd == 3) gemm_ring<PREC, kTiles, 2, false, kRing, (7 * U_Q) % kRing, !DELAY>(part, hq, rg);
-        if (qd < 3) stamp<PROF>(pf);  // 6..8: FFN quarters
-    }
+    };
+    // fp32: always re-arm at consumption; bf16: the first four unit groups re-arm (with the last four), the last
+    // four leave the ring to be re-armed during combine 2
+    gemm_ring<PREC, 2, kTiles, false, kRing, (0 * U_Q) % kRing, true>(hq[0], x, rg);        // F1 q0
+    gemm_ring<PREC, 2, kTiles, false, kRing, (1 * U_Q) % kRing, true>(hq[1], x, rg);        // F1 q1
+    gelu_quarter(0);
+    gemm_ring<PREC, kTiles, 2, false, kRing, (2 * U_Q) % kRing, true>(part, hq[0], rg);     // F2 q0
+    stamp<PROF>(pf);
+    gemm_ring<PREC, 2, kTiles, false, kRing, (3 * U_Q) % kRing, true>(hq[2], x, rg);        // F1 q2
+    gelu_quarter(1);
+    gemm_ring<PREC, kTiles, 2, false, kRing, (4 * U_Q) % kRing, !DELAY>(part, hq[1], rg);   // F2 q1
+    stamp<PROF>(pf);
+    gemm_ring<PREC, 2, kTiles, false, kRing, (5 * U_Q) % kRing, !DELAY>(hq[3], x, rg);      // F1 q3
+    gelu_quarter(2);
+    gemm_ring<PREC, kTiles, 2, false, kRing, (6 * U_Q) % kRing, !DELAY>(part, hq[2], rg);   // F2 q2
+    stamp<PROF>(pf);
+    gelu_quarter(3);
+    gemm_ring<PREC, kTiles, 2, false, kRing, (7 * U_Q) % kRing, !DELAY>(part, hq[3], rg);   // F2 q3
     stamp<PROF>(pf);  // 9: FFN done (linear2 partial)
     // x = LN2(x + sum_w part + b_l2).  bf16: the ring is re-armed meanwhile with the next block's first units - its
     // in_proj + out_proj (32) or, ahead of an output block, only the 16 skip-linear units (slots 16..31 stay empty;
