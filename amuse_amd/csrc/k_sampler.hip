@@ -51,8 +51,11 @@ __device__ __forceinline__ void attention_head(const f32x4 (&q)[2], const f32x4 
         sum += p[m];
     }
     sum = allreduce_g_sum(sum);
+    {
+        const float inv = (PREC == PREC_F32) ? 0.f : __builtin_amdgcn_rcpf(sum);
 #pragma unroll
-    for (int m = 0; m < 4; ++m) p[m] = p[m] / sum;
+        for (int m = 0; m < 4; ++m) p[m] = (PREC == PREC_F32) ? p[m] / sum : p[m] * inv;
+    }
     ring_issue<NC, kRing, (IPH + NC) % kRing>(rg);
     // O^T[d][i] = sum_j V[j][d] P[i][j]; v is feature-lane: lane (g, d) holds V[4 g + m][d]
 #pragma unroll
@@ -320,23 +323,54 @@ __global__ __launch_bounds__(256, 1) void k_sample(SampleArgs a) {
         if (!a.no_update) {
             const float* cf = a.coef + (size_t)step * 8;
             const float sb = cf[0], sa = cf[1], c0 = cf[2], cx = cf[3], ce = cf[4], sg = cf[5], clipv = cf[6];
+            // ancestral noise z for the latent rows.  In-kernel generation is spread over the whole wave: lane L
+            // draws the 4 normals of feature group L % 32 of clip (L / 32) of the tile - ONE Philox call per lane
+            // per two clips instead of eight per lane - and the latent-row lanes fetch their 8 groups by bpermute.
+            // Same counters (global clip, step, feature group) as before, so values are bit-identical.
+            f32x4 zt[kTiles];
+#pragma unroll
+            for (int t = 0; t < kTiles; ++t) zt[t] = splat4(0.f);
+            if (sg != 0.f) {
+                if (a.step_noise) {
+                    if (is_lat) {
+#pragma unroll
+                        for (int t = 0; t < kTiles; ++t)
+                            zt[t] = ld4(a.step_noise + ((size_t)step * a.B + clip) * kD + 16 * t + 4 * g);
+                    }
+                } else {
+#pragma unroll
+                    for (int call = 0; call < 2; ++call) {
+                        if (2 * call < a.G) {
+                            const int cc = 2 * call + (lane >> 5);
+                            const uint64_t gc = a.clip0 + (uint64_t)((long)blockIdx.x * a.G + cc);
+                            const f32x4 n = counter_normal4(a.seed, gc, (uint32_t)step, (uint32_t)(lane & 31), 1u);
+                            const bool mine = (cl >> 1) == call;
+                            const int src = 32 * (cl & 1) + g;
+#pragma unroll
+                            for (int t = 0; t < kTiles; ++t)
+#pragma unroll
+                                for (int m = 0; m < 4; ++m) {
+                                    const float v = __shfl(n[m], src + 4 * t);
+                                    zt[t][m] = mine ? v : zt[t][m];
+                                }
+                        }
+                    }
+                }
+            }
+            constexpr bool FASTU = (PREC == PREC_BF16);  // bf16 mode: reciprocal multiply instead of IEEE division
+            const float inv_sa = 1.0f / sa;
 #pragma unroll
             for (int t = 0; t < kTiles; ++t) {
-                f32x4 z = splat4(0.f);
-                if (sg != 0.f && is_lat) {
-                    z = a.step_noise ? ld4(a.step_noise + ((size_t)step * a.B + clip) * kD + 16 * t + 4 * g)
-                                     : counter_normal4(a.seed, a.clip0 + (uint64_t)clip, (uint32_t)step,
-                                                       (uint32_t)(4 * t + g), 1u);
-                }
 #pragma unroll
                 for (int m = 0; m < 4; ++m) {
                     const float e = x[t][m], xl = lat[t][m];
-                    float x0 = __fdiv_rn(__fsub_rn(xl, __fmul_rn(sb, e)), sa);
+                    const float num = __fsub_rn(xl, __fmul_rn(sb, e));
+                    float x0 = FASTU ? num * inv_sa : __fdiv_rn(num, sa);
                     if (clipv > 0.f) x0 = fminf(fmaxf(x0, -clipv), clipv);
                     float nx = __fmul_rn(c0, x0);
                     if (cx != 0.f) nx = __fadd_rn(nx, __fmul_rn(cx, xl));
                     if (ce != 0.f) nx = __fadd_rn(nx, __fmul_rn(ce, e));
-                    if (sg != 0.f) nx = __fadd_rn(nx, __fmul_rn(sg, z[m]));
+                    if (sg != 0.f) nx = __fadd_rn(nx, __fmul_rn(sg, zt[t][m]));
                     lat[t][m] = nx;
                 }
             }
