@@ -357,6 +357,31 @@ def vae_decode(Wp, z, lengths: Optional[Sequence[int]] = None, emulate_bf16=Fals
     return feats * mask[..., None].to(feats.dtype)
 
 
+def vae_encode(Wp, feats, lengths: Optional[Sequence[int]] = None, emulate_bf16=False):
+    """MotionPrior.encode (vae.py:154-214, MLP_DIST false, learned PE): feats (B,300,333) -> (mu, std), each (B,128).
+    xseq = [2 distribution tokens | skel_embedding(frames)] + PE; SkipTransformerEncoder with key padding mask;
+    mu = token 0, logvar = token 1, std = exp(logvar) ** 0.5.  (latent = mu + std * eps is left to the caller.)"""
+    ops = Ops(emulate_bf16)
+    B, n, _ = feats.shape
+    if lengths is None:
+        lengths = [n] * B
+    mask = torch.arange(n)[None, :] < torch.tensor(list(lengths))[:, None]
+    aug = torch.cat([torch.ones(B, 2, dtype=torch.bool), mask], dim=1)           # (B, 2 + n)
+    x = ops.lin(feats, Wp["skel_embedding.weight"], Wp["skel_embedding.bias"])
+    xseq = torch.cat([Wp["global_motion_token"][None].expand(B, -1, -1).to(x.dtype), x], dim=1)
+    xseq = xseq + Wp["query_pos_encoder.pe"][: n + 2, 0][None]
+    km = None if bool(aug.all()) else aug
+    out = skip_stack(ops, xseq, Wp, "encoder", lambda h, p: enc_block(ops, h, Wp, p, km))
+    mu, logvar = out[:, 0], out[:, 1]
+    return mu, logvar.exp().pow(0.5)
+
+
+def axis_angle_to_rotation_6d(aa):
+    """infer_ldm.py:459-463: axis_angle_to_matrix then matrix_to_rotation_6d (first two rows)."""
+    m = axis_angle_to_matrix(aa)
+    return m[..., :2, :].reshape(*m.shape[:-2], 6)
+
+
 def rotation_6d_to_matrix(d6):
     """pytorch3d rotation_6d_to_matrix (vendored copy: models/diffusion/utils/rotation_conversions.py:512-533)."""
     a1, a2 = d6[..., :3], d6[..., 3:]

@@ -159,6 +159,14 @@ def main():
                         feats_ragged=feats_ragged.numpy(), lengths_ragged=np.array([300, 173]),
                         **{f"tap/{k}": v[:, ::25].copy() for k, v in dtaps.items()})
 
+    # ---- MotionPrior.encode: distribution parameters for full-length and ragged inputs (vae.py:154-214)
+    fe = (0.5 * torch.randn(2, 300, 333, generator=g)).half().float()   # stored as float16: round first
+    _, dist = prior.encode(fe, [300, 300])
+    _, dist_r = prior.encode(fe, [300, 211])
+    np.savez_compressed(out / "vae_encode.npz", feats=fe.numpy().astype(np.float16), mu=dist.loc[0].numpy(),
+                        std=dist.scale[0].numpy(), mu_ragged=dist_r.loc[0].numpy(), std_ragged=dist_r.scale[0].numpy(),
+                        lengths_ragged=np.array([300, 211]))
+
     # ---- rotation conversions from the vendored pytorch3d snapshot
     d6 = torch.randn(2000, 6, generator=g)
     d6[:50] *= 1e-3

@@ -117,6 +117,19 @@ def test_vae_decode(Wp):
     assert np.all(fr.numpy()[1, 173:] == 0)
 
 
+def test_vae_encode(Wp):
+    g = np.load(GOLDEN / "vae_encode.npz")
+    feats = torch.from_numpy(g["feats"].astype(np.float32))
+    mu, std = orc.vae_encode(Wp, feats)
+    assert np.abs(mu.numpy() - g["mu"]).max() < 2e-5 and np.abs(std.numpy() - g["std"]).max() < 2e-5
+    mu, std = orc.vae_encode(Wp, feats, lengths=[300, 211])
+    assert np.abs(mu.numpy() - g["mu_ragged"]).max() < 2e-5 and np.abs(std.numpy() - g["std_ragged"]).max() < 2e-5
+    # axis-angle -> 6D front end of _loader_helper_v1 (infer_ldm.py:459-463) round-trips through the decoder-side conversion
+    aa = 0.8 * torch.randn(50, 3, generator=torch.Generator().manual_seed(0))
+    d6 = orc.axis_angle_to_rotation_6d(aa.double())
+    assert (orc.rotation_6d_to_matrix(d6) - orc.axis_angle_to_matrix(aa.double())).abs().max() < 1e-9
+
+
 def test_rotation_conversions():
     g = np.load(GOLDEN / "rotation.npz")
     d6 = torch.from_numpy(g["d6"])
