@@ -109,7 +109,7 @@ uint16_t f2bf(float f) {  // round-to-nearest-even, as v_cvt_pk_bf16_f32
 // W: [n_out x K] row-major.  Appends units for (k-tile outer, out-tile inner).
 void pack_gemm(std::vector<uint4>& out, int prec, const float* W, int n_out, int K, const std::vector<int>& otiles,
                const std::vector<int>& ktiles) {
-    auto at = [&](int row, int col) -> float { return row < n_out ? W[(size_t)row * K + col] : 0.f; };
+    auto at = [&](int row, int col) -> float { return (row < n_out && col < K) ? W[(size_t)row * K + col] : 0.f; };
     if (prec == PREC_F32) {
         for (int t : ktiles)
             for (int o : otiles)
@@ -219,6 +219,11 @@ struct amuse_ctx {
     uint32_t vae_stage_units[2][kVaeStages];
     float *vae_pvec = nullptr, *vae_final_bias = nullptr, *vae_pe = nullptr;
     float *vae_wv_t = nullptr, *vae_bv = nullptr, *vae_wo_t = nullptr, *vae_bo = nullptr;
+    // prior encoder (MotionPrior.encode)
+    uint4* vaee_w[2] = {nullptr, nullptr};
+    uint32_t vaee_stage_base[2][kVaeStages];
+    uint32_t vaee_stage_units[2][kVaeStages];
+    float *vaee_pvec = nullptr, *vaee_pe = nullptr, *vaee_tok = nullptr, *vaee_emb_bias = nullptr;
     // schedule
     int T = 0;
     int* d_timesteps = nullptr;
@@ -235,7 +240,8 @@ struct amuse_ctx {
 
 namespace {
 constexpr int kVaeChunk = 512;
-constexpr size_t kVaeFloatsPerClip = (size_t)kFrames * kD * (1 + 3 + 1 + 4) + kLayers * kD;  // x, qkv, o, skip, ca
+constexpr int kEncRows = kFrames + 2;  // encoder sequence: 2 distribution tokens + 300 frames
+constexpr size_t kVaeFloatsPerClip = (size_t)kEncRows * kD * (1 + 3 + 1 + 4) + kLayers * kD;  // x, qkv, o, skip, ca | stats
 
 int ensure(float** p, size_t* cap, size_t need_floats) {
     if (*cap >= need_floats) return 0;
@@ -338,6 +344,39 @@ int build_ctx(amuse_ctx* c, const float* den, const float* pri) {
             upload(&c->vae_bv, bv.data(), bv.size() * 4) || upload(&c->vae_bo, bo.data(), bo.size() * 4))
             return AMUSE_EHIP;
     }
+    // ---- VAE encoder weight streams: stage 0 = skel_embedding (K = 333 padded to 22 k-tiles, 2 output tiles per wave)
+    // + in_proj(0); stage i+1 = post-attention of block i (+ skip linear) + in_proj(i+1); stage 9 = post-attention of block 8
+    for (int prec = 0; prec < 2; ++prec) {
+        std::vector<uint4> all;
+        for (int st = 0; st < kVaeStages; ++st) {
+            c->vaee_stage_base[prec][st] = (uint32_t)(all.size() / 64);
+            size_t per_wave = 0;
+            for (int w = 0; w < 4; ++w) {
+                std::vector<uint4> s;
+                if (st == 0) pack_gemm(s, prec, Pp.get("skel_embedding.weight"), 128, kFeats, {2 * w, 2 * w + 1}, range(0, 22));
+                if (st >= 1) {
+                    const int b = st - 1;
+                    pack_outproj_ffn(s, prec, Pp, blk_name("encoder", b), w);
+                    if (b >= 4 && b <= 7) pack_skiplin(s, prec, Pp, "encoder", b - 4, w);
+                }
+                if (st < 9) pack_qkv(s, prec, Pp.get(blk_name("encoder", st) + ".self_attn.in_proj_weight"), w, false);
+                if (w == 0) per_wave = s.size();
+                else if (s.size() != per_wave) return fail(AMUSE_ESTATE, "internal: uneven vae encoder wave streams");
+                all.insert(all.end(), s.begin(), s.end());
+            }
+            c->vaee_stage_units[prec][st] = (uint32_t)(per_wave / 64);
+        }
+        all.insert(all.end(), (size_t)kVaeRing * 64, uint4{0, 0, 0, 0});
+        if (upload(&c->vaee_w[prec], all.data(), all.size() * sizeof(uint4))) return AMUSE_EHIP;
+    }
+    {
+        auto pv = build_pvec(Pp, "encoder", false);
+        if (upload(&c->vaee_pvec, pv.data(), pv.size() * 4) ||
+            upload(&c->vaee_pe, Pp.get("query_pos_encoder.pe"), 500 * 128 * 4) ||
+            upload(&c->vaee_tok, Pp.get("global_motion_token"), 2 * 128 * 4) ||
+            upload(&c->vaee_emb_bias, Pp.get("skel_embedding.bias"), 128 * 4))
+            return AMUSE_EHIP;
+    }
     HIP_TRY(hipMalloc((void**)&c->d_timesteps, AMUSE_MAX_STEPS * sizeof(int)));
     HIP_TRY(hipMalloc((void**)&c->d_coef, AMUSE_MAX_STEPS * 8 * sizeof(float)));
     HIP_TRY(hipMalloc((void**)&c->d_time_tok, AMUSE_MAX_STEPS * kD * sizeof(float)));
@@ -372,6 +411,30 @@ int pick_group(const amuse_ctx* c, int B, int S) {
     if (g > gmax) g = gmax;
     if (g < 1) g = 1;
     return g;
+}
+
+int stage_lengths(amuse_ctx* c, const int* lengths, int B, hipStream_t st) {
+    if (!lengths) return 0;
+    for (int b = 0; b < B; ++b)
+        if (lengths[b] < 1 || lengths[b] > kFrames) return fail(AMUSE_EINVAL, "lengths[%d] = %d not in 1..300", b, lengths[b]);
+    if (c->len_cap < (size_t)B) {
+        if (c->d_lengths) HIP_TRY(hipFree(c->d_lengths));
+        c->d_lengths = nullptr; c->len_cap = 0;
+        HIP_TRY(hipMalloc((void**)&c->d_lengths, (size_t)B * sizeof(int)));
+        c->len_cap = B;
+    }
+    HIP_TRY(hipMemcpyAsync(c->d_lengths, lengths, (size_t)B * sizeof(int), hipMemcpyHostToDevice, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    return 0;
+}
+
+int ensure_vae_ws(amuse_ctx* c, int chunk) {
+    if (c->vae_cap >= (size_t)chunk) return 0;
+    if (c->vae_ws) HIP_TRY(hipFree(c->vae_ws));
+    c->vae_ws = nullptr; c->vae_cap = 0;
+    HIP_TRY(hipMalloc((void**)&c->vae_ws, (size_t)chunk * kVaeFloatsPerClip * sizeof(float)));
+    c->vae_cap = chunk;
+    return 0;
 }
 
 int check_common(amuse_ctx* c, const float* con, int B, int precision) {
@@ -416,7 +479,8 @@ void amuse_destroy(amuse_ctx* c) {
     void* ptrs[] = {c->den_w[0], c->den_w[1], c->den_pvec, c->den_pe, c->den_freqs, c->te_w1t, c->te_b1, c->te_w2t,
                     c->te_b2, c->cond_wt[0], c->cond_wt[1], c->cond_wt[2], c->cond_b[0], c->cond_b[1], c->cond_b[2],
                     c->vae_w[0], c->vae_w[1], c->vae_pvec, c->vae_final_bias, c->vae_pe, c->vae_wv_t, c->vae_bv,
-                    c->vae_wo_t, c->vae_bo, c->d_timesteps, c->d_coef, c->d_time_tok, c->d_ts1, c->d_tt1, c->d_coef1,
+                    c->vae_wo_t, c->vae_bo, c->vaee_w[0], c->vaee_w[1], c->vaee_pvec, c->vaee_pe, c->vaee_tok,
+                    c->vaee_emb_bias, c->d_timesteps, c->d_coef, c->d_time_tok, c->d_ts1, c->d_tt1, c->d_coef1,
                     c->cond_tok, c->lat_tmp, c->vae_ws, c->d_lengths};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
@@ -524,25 +588,9 @@ int amuse_vae_decode(amuse_ctx* c, const float* z, const int* lengths, int B, in
     if (quat_mode != AMUSE_QUAT_P3D && quat_mode != AMUSE_QUAT_LEGACY) return fail(AMUSE_EINVAL, "bad quat_mode %d", quat_mode);
     HIP_TRY(hipSetDevice(c->device));
     hipStream_t st = (hipStream_t)stream;
-    if (lengths) {
-        for (int b = 0; b < B; ++b)
-            if (lengths[b] < 1 || lengths[b] > kFrames) return fail(AMUSE_EINVAL, "lengths[%d] = %d not in 1..300", b, lengths[b]);
-        if (c->len_cap < (size_t)B) {
-            if (c->d_lengths) HIP_TRY(hipFree(c->d_lengths));
-            c->d_lengths = nullptr; c->len_cap = 0;
-            HIP_TRY(hipMalloc((void**)&c->d_lengths, (size_t)B * sizeof(int)));
-            c->len_cap = B;
-        }
-        HIP_TRY(hipMemcpyAsync(c->d_lengths, lengths, (size_t)B * sizeof(int), hipMemcpyHostToDevice, st));
-        HIP_TRY(hipStreamSynchronize(st));
-    }
+    if (int e = stage_lengths(c, lengths, B, st)) return e;
     const int chunk = B < kVaeChunk ? B : kVaeChunk;
-    if (c->vae_cap < (size_t)chunk) {
-        if (c->vae_ws) HIP_TRY(hipFree(c->vae_ws));
-        c->vae_ws = nullptr; c->vae_cap = 0;
-        HIP_TRY(hipMalloc((void**)&c->vae_ws, (size_t)chunk * kVaeFloatsPerClip * sizeof(float)));
-        c->vae_cap = chunk;
-    }
+    if (int e = ensure_vae_ws(c, chunk)) return e;
     for (int b0 = 0; b0 < B; b0 += chunk) {
         const int nb = (B - b0) < chunk ? (B - b0) : chunk;
         const size_t rows = (size_t)nb * kFrames;
@@ -565,15 +613,63 @@ int amuse_vae_decode(amuse_ctx* c, const float* z, const int* lengths, int B, in
         ra.feats_out = feats_out ? feats_out + (size_t)b0 * kFrames * kFeats : nullptr;
         ra.poses_out = poses_out ? poses_out + (size_t)b0 * kFrames * kJoints * 3 : nullptr;
         ra.trans_out = trans_out ? trans_out + (size_t)b0 * kFrames * 3 : nullptr;
-        ra.B = nb; ra.quat_mode = quat_mode;
+        ra.B = nb; ra.quat_mode = quat_mode; ra.tiles = 19;
         HIP_TRY(launch_vae_ca(z + (size_t)b0 * kD, c->vae_wv_t, c->vae_bv, c->vae_wo_t, c->vae_bo, ca, nb, st));
+        VaeAttnArgs aa{};
+        aa.q = ra.q; aa.k = ra.k; aa.v = ra.v; aa.lengths = ra.lengths; aa.o = attn_o; aa.B = nb; aa.q_tiles = 19;
+        for (int stage = 0; stage < kVaeStages; ++stage) {
+            ra.stage = stage;
+            HIP_TRY(launch_vae_rows(ra, precision, false, st));
+            if (stage < kLayers) HIP_TRY(launch_vae_attn(aa, precision, false, st));
+        }
+    }
+    return 0;
+}
+
+int amuse_vae_encode(amuse_ctx* c, const float* feats, const int* lengths, int B, int precision, const float* eps,
+                     float* mu_out, float* std_out, float* latent_out, void* stream) {
+    if (!c) return fail(AMUSE_EINVAL, "ctx is NULL");
+    if (!feats) return fail(AMUSE_EINVAL, "feats is NULL");
+    if (!mu_out && !std_out && !latent_out) return fail(AMUSE_EINVAL, "no output requested");
+    if (B < 1) return fail(AMUSE_EINVAL, "B must be >= 1, got %d", B);
+    if (precision != AMUSE_PREC_F32 && precision != AMUSE_PREC_BF16) return fail(AMUSE_EINVAL, "bad precision %d", precision);
+    HIP_TRY(hipSetDevice(c->device));
+    hipStream_t st = (hipStream_t)stream;
+    if (int e = stage_lengths(c, lengths, B, st)) return e;
+    const int chunk = B < kVaeChunk ? B : kVaeChunk;
+    if (int e = ensure_vae_ws(c, chunk)) return e;
+    for (int b0 = 0; b0 < B; b0 += chunk) {
+        const int nb = (B - b0) < chunk ? (B - b0) : chunk;
+        const size_t rows = (size_t)nb * kEncRows;
+        float* ws = c->vae_ws;
+        VaeRowsArgs ra{};
+        ra.wstream = c->vaee_w[precision];
+        memcpy(ra.stage_base, c->vaee_stage_base[precision], sizeof(ra.stage_base));
+        memcpy(ra.stage_units, c->vaee_stage_units[precision], sizeof(ra.stage_units));
+        ra.pvec = c->vaee_pvec; ra.pe = c->vaee_pe; ra.tok = c->vaee_tok; ra.emb_bias = c->vaee_emb_bias;
+        ra.x = ws; ws += rows * kD;
+        ra.q = ws; ws += rows * kD;
+        ra.k = ws; ws += rows * kD;
+        ra.v = ws; ws += rows * kD;
+        float* attn_o = ws; ws += rows * kD;
+        ra.attn_o = attn_o;
+        ra.skip = ws; ws += 4 * rows * kD;
+        ra.stats_out = ws;  // [nb][2][128] <= the decoder's [nb][9][128] cross-attention slot
+        ra.lengths = lengths ? c->d_lengths + b0 : nullptr;
+        ra.enc_feats = feats + (size_t)b0 * kFrames * kFeats;
+        ra.B = nb;
         VaeAttnArgs aa{};
         aa.q = ra.q; aa.k = ra.k; aa.v = ra.v; aa.lengths = ra.lengths; aa.o = attn_o; aa.B = nb;
         for (int stage = 0; stage < kVaeStages; ++stage) {
             ra.stage = stage;
-            HIP_TRY(launch_vae_rows(ra, precision, st));
-            if (stage < kLayers) HIP_TRY(launch_vae_attn(aa, precision, st));
+            ra.tiles = stage == kVaeStages - 1 ? 1 : 19;       // only the distribution rows leave the last block
+            aa.q_tiles = stage == kLayers - 1 ? 1 : 19;
+            HIP_TRY(launch_vae_rows(ra, precision, true, st));
+            if (stage < kLayers) HIP_TRY(launch_vae_attn(aa, precision, true, st));
         }
+        const size_t o = (size_t)b0 * kD;
+        HIP_TRY(launch_vae_latent(ra.stats_out, eps ? eps + o : nullptr, mu_out ? mu_out + o : nullptr,
+                                  std_out ? std_out + o : nullptr, latent_out ? latent_out + o : nullptr, nb, st));
     }
     return 0;
 }

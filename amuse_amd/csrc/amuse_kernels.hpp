@@ -78,16 +78,26 @@ struct VaeRowsArgs {
     int B;
     int stage;                        // 0..9
     int quat_mode;
+    int tiles;                        // 16-row tiles launched per clip: 19, or 1 for the encoder's last stage
+    // encoder mode only (MotionPrior.encode): rows are [2 distribution tokens | 300 frames], S = 302
+    const float* enc_feats;           // [B][300][333] input motion features
+    const float* tok;                 // global_motion_token [2][128]
+    const float* emb_bias;            // skel_embedding.bias [128]
+    float* stats_out;                 // [B][2][128]: encoder.norm of the distribution rows (mu | logvar)
 };
-hipError_t launch_vae_rows(const VaeRowsArgs& a, int precision, hipStream_t stream);
+hipError_t launch_vae_rows(const VaeRowsArgs& a, int precision, bool enc, hipStream_t stream);
 
 struct VaeAttnArgs {
     const float* q; const float* k; const float* v;  // [B][4][300][32]; q pre-scaled by 1/sqrt(32)
     const int* lengths;                               // dev [B] or null
     float* o;                                         // [B*300][128]
     int B;
+    int q_tiles;                                      // query tiles to produce: 19, or 1 (last encoder block)
 };
-hipError_t launch_vae_attn(const VaeAttnArgs& a, int precision, hipStream_t stream);
+hipError_t launch_vae_attn(const VaeAttnArgs& a, int precision, bool enc, hipStream_t stream);
+// mu = stats[b][0], std = exp(stats[b][1]) ** 0.5, latent = mu + std * eps   (vae.py:209-213)
+hipError_t launch_vae_latent(const float* stats, const float* eps, float* mu, float* std, float* latent, int B,
+                             hipStream_t stream);
 
 // ca[b][blk][:] = out_proj(v_proj(z[b]))   (cross_attention.py:331-336 with a 1-token memory)
 hipError_t launch_vae_ca(const float* z, const float* wv_t /*[9][128][128]*/, const float* bv /*[9][128]*/,

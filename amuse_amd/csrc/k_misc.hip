@@ -74,6 +74,19 @@ __global__ __launch_bounds__(128) void k_vae_ca(const float* __restrict__ z, con
     ca[((size_t)b * kLayers + blk) * kD + j] = o + bo[blk * kD + j];
 }
 
+// MotionPrior.encode tail (vae.py:203-213): mu = dist[0], logvar = dist[1]; std = logvar.exp().pow(0.5);
+// latent = Normal(mu, std).rsample() = mu + std * eps with eps supplied by the caller (or latent = mu when absent)
+__global__ __launch_bounds__(128) void k_vae_latent(const float* __restrict__ stats, const float* __restrict__ eps,
+                                                    float* mu, float* sd, float* latent) {
+#pragma clang fp contract(off)  // mu + std * eps as two rounded operations, like the reference's tensor ops
+    const int b = blockIdx.x, j = threadIdx.x;
+    const float m = stats[((size_t)b * 2 + 0) * kD + j];
+    const float s = sqrtf(expf(stats[((size_t)b * 2 + 1) * kD + j]));
+    if (mu) mu[(size_t)b * kD + j] = m;
+    if (sd) sd[(size_t)b * kD + j] = s;
+    if (latent) latent[(size_t)b * kD + j] = eps ? m + s * eps[(size_t)b * kD + j] : m;
+}
+
 }  // namespace
 
 hipError_t launch_time_tokens(const int* timesteps_dev, int T, const float* freqs, const float* w1t, const float* b1,
@@ -97,6 +110,12 @@ hipError_t launch_counter_normal(uint64_t seed, uint64_t clip0, int B, int step,
 hipError_t launch_vae_ca(const float* z, const float* wv_t, const float* bv, const float* wo_t, const float* bo,
                          float* ca, int B, hipStream_t stream) {
     hipLaunchKernelGGL(k_vae_ca, dim3(kLayers, B), dim3(128), 0, stream, z, wv_t, bv, wo_t, bo, ca);
+    return hipGetLastError();
+}
+
+hipError_t launch_vae_latent(const float* stats, const float* eps, float* mu, float* std, float* latent, int B,
+                             hipStream_t stream) {
+    hipLaunchKernelGGL(k_vae_latent, dim3(B), dim3(128), 0, stream, stats, eps, mu, std, latent);
     return hipGetLastError();
 }
 

@@ -359,6 +359,10 @@ __global__ __launch_bounds__(256, 1) void k_sample(SampleArgs a) {
             }
             constexpr bool FASTU = (PREC == PREC_BF16);  // bf16 mode: reciprocal multiply instead of IEEE division
             const float inv_sa = 1.0f / sa;
+            {
+// each product and sum rounded on its own, like the scheduler's tensor ops (hipcc contracts even __fmul_rn /
+// __fadd_rn pairs into v_fma under its default -ffp-contract=fast)
+#pragma clang fp contract(off)
 #pragma unroll
             for (int t = 0; t < kTiles; ++t) {
 #pragma unroll
@@ -373,6 +377,7 @@ __global__ __launch_bounds__(256, 1) void k_sample(SampleArgs a) {
                     if (sg != 0.f) nx = __fadd_rn(nx, __fmul_rn(sg, zt[t][m]));
                     lat[t][m] = nx;
                 }
+            }
             }
             stamp<PROF>(pf);  // scheduler update done
             if (a.traj_out && is_lat && wave == 0) {

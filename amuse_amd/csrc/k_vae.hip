@@ -67,19 +67,23 @@ __device__ __forceinline__ void rot6d_to_axis_angle(const float* d6, int quat_mo
     aa[0] = qx / s; aa[1] = qy / s; aa[2] = qz / s;
 }
 
-template <int PREC>
+// ENC = false: MotionPrior.decode rows (S = 300).  ENC = true: MotionPrior.encode rows (vae.py:154-214): S = 302 =
+// [2 distribution tokens | 300 embedded frames], TransformerEncoderLayer blocks (no cross-attention, two norms),
+// stage 0 = skel_embedding + token concat + PE, last stage = encoder.norm of the two distribution rows only.
+template <int PREC, bool ENC>
 __global__ __launch_bounds__(256) void k_vae_rows(VaeRowsArgs a) {
+    constexpr int S = ENC ? kFrames + 2 : kFrames;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     f32x4* exch = reinterpret_cast<f32x4*>(smem);
     float* fst = reinterpret_cast<float*>(smem + kExchBytes);  // [16][kFeatStride] staged feats (last stage)
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int g = lane >> 4, r = lane & 15;
-    const int b = blockIdx.x / kRowTiles, rt = blockIdx.x - b * kRowTiles;
+    const int b = blockIdx.x / a.tiles, rt = blockIdx.x - b * a.tiles;
     const int frame = rt * 16 + r;
-    const bool rvalid = frame < kFrames;
-    const size_t row = (size_t)b * kFrames + (rvalid ? frame : 0);
-    const size_t nrows = (size_t)a.B * kFrames;
+    const bool rvalid = frame < S;
+    const size_t row = (size_t)b * S + (rvalid ? frame : 0);
+    const size_t nrows = (size_t)a.B * S;
     // this wave's slice of the stage's weight stream, pulled through a register ring (see amuse_dev.hpp: left
     // to itself hipcc serialises load -> wait -> mfma, one L2 round trip per KiB).  The ring runs up to kVR units
     // past the slice (into the neighbouring slice; the buffer is padded at its end) - those units are never used.
@@ -94,10 +98,39 @@ __global__ __launch_bounds__(256) void k_vae_rows(VaeRowsArgs a) {
     int parity = 0;
     f32x4 x[kTiles];
 
-    if (a.stage == 0) {  // queries = zeros + query_pos_decoder.pe[:300]  (vae.py:220,258)
+    constexpr int kEmbK = 22;  // 333 input features padded to 22 k-tiles (zero weights / zero operands beyond 333)
+    constexpr int P_E = ENC ? gemm_units(PREC, 2, kEmbK) % kVR : 0;  // in_proj phase of stage 0
+    if (a.stage == 0) {
+        if constexpr (ENC) {
+            // xseq = cat(global_motion_token, skel_embedding(features)) + query_pos_encoder.pe[:302]  (vae.py:171-188)
+            const int fi = frame - 2;
+            const bool fvalid = rvalid && fi >= 0;
+            const float* src = a.enc_feats + ((size_t)b * kFrames + (fvalid ? fi : 0)) * kFeats;
+            f32x4 xin[kEmbK];
 #pragma unroll
-        for (int t = 0; t < kTiles; ++t)
-            x[t] = rvalid ? ld4(a.pe + (size_t)frame * kD + 16 * t + 4 * g) : splat4(0.f);
+            for (int t = 0; t < kEmbK; ++t)
+#pragma unroll
+                for (int m = 0; m < 4; ++m) {
+                    const int c = 16 * t + 4 * g + m;
+                    xin[t][m] = (fvalid && c < kFeats) ? src[c] : 0.f;
+                }
+            f32x4 acc[2] = {splat4(0.f), splat4(0.f)};  // this wave's output tiles 2 wave, 2 wave + 1
+            gemm_ring<PREC, 2, kEmbK, false, kVR, 0>(acc, xin, rg);
+            f32x4 part[kTiles];
+#pragma unroll
+            for (int t = 0; t < kTiles; ++t) part[t] = (t >> 1) == wave ? acc[t & 1] : splat4(0.f);
+            exchange_sum(part, exch, parity, wave, lane);  // all-gather of the four waves' tile pairs
+#pragma unroll
+            for (int t = 0; t < kTiles; ++t) {
+                const int c = 16 * t + 4 * g;
+                const f32x4 e = fvalid ? part[t] + ld4(a.emb_bias + c) : ld4(a.tok + (frame & 1) * kD + c);
+                x[t] = rvalid ? e + ld4(a.pe + (size_t)frame * kD + c) : splat4(0.f);
+            }
+        } else {  // queries = zeros + query_pos_decoder.pe[:300]  (vae.py:220,258)
+#pragma unroll
+            for (int t = 0; t < kTiles; ++t)
+                x[t] = rvalid ? ld4(a.pe + (size_t)frame * kD + 16 * t + 4 * g) : splat4(0.f);
+        }
     } else {
         const int blk = a.stage - 1;
         const float* pv = a.pvec + blk * PV_BLOCK;
@@ -116,12 +149,14 @@ __global__ __launch_bounds__(256) void k_vae_rows(VaeRowsArgs a) {
 #pragma unroll
         for (int t = 0; t < kTiles; ++t) x[t] = x[t] + (part[t] + ld4(pv + PV_OUT_B + 16 * t + 4 * g));
         layer_norm_rows<PREC == PREC_BF16>(x, pv + PV_LN1_W, pv + PV_LN1_B, g);
-        // cross-attention onto the single latent token == per-clip constant; residual + norm2
-        const float* ca = a.ca + ((size_t)b * kLayers + blk) * kD;
+        if constexpr (!ENC) {
+            // cross-attention onto the single latent token == per-clip constant; residual + norm2
+            const float* ca = a.ca + ((size_t)b * kLayers + blk) * kD;
 #pragma unroll
-        for (int t = 0; t < kTiles; ++t) x[t] = x[t] + ld4(ca + 16 * t + 4 * g);
-        layer_norm_rows<PREC == PREC_BF16>(x, pv + PV_LN2_W, pv + PV_LN2_B, g);
-        // FFN + residual + norm3
+            for (int t = 0; t < kTiles; ++t) x[t] = x[t] + ld4(ca + 16 * t + 4 * g);
+            layer_norm_rows<PREC == PREC_BF16>(x, pv + PV_LN2_W, pv + PV_LN2_B, g);
+        }
+        // FFN + residual + norm3 (decoder layer) / norm2 (encoder layer, cross_attention.py:259-272)
         f32x4 hid[kTiles];
 #pragma unroll
         for (int t = 0; t < kTiles; ++t) hid[t] = ld4(pv + PV_L1_B + 16 * (kTiles * wave + t) + 4 * g);
@@ -136,7 +171,7 @@ __global__ __launch_bounds__(256) void k_vae_rows(VaeRowsArgs a) {
         exchange_sum(part, exch, parity, wave, lane);
 #pragma unroll
         for (int t = 0; t < kTiles; ++t) x[t] = x[t] + (part[t] + ld4(pv + PV_L2_B + 16 * t + 4 * g));
-        layer_norm_rows<PREC == PREC_BF16>(x, pv + PV_LN3_W, pv + PV_LN3_B, g);
+        layer_norm_rows<PREC == PREC_BF16>(x, pv + (ENC ? PV_LN2_W : PV_LN3_W), pv + (ENC ? PV_LN2_B : PV_LN3_B), g);
         if (blk < 4 && wave == 0 && rvalid) {  // xs.append(x)
             float* sk = a.skip + ((size_t)blk * nrows + row) * kD;
 #pragma unroll
@@ -175,11 +210,11 @@ __global__ __launch_bounds__(256) void k_vae_rows(VaeRowsArgs a) {
             qkv[2 + o] = ld4(pv + PV_IN_B + kD + 16 * (2 * wave + o) + 4 * g);
             qkv[4 + o] = ld4(pv + PV_IN_B + 2 * kD + 16 * (2 * wave + o) + 4 * g);
         }
-        if (a.stage == 0) gemm_ring<PREC, 6, kTiles, false, kVR, 0>(qkv, x, rg);
+        if (a.stage == 0) gemm_ring<PREC, 6, kTiles, false, kVR, P_E>(qkv, x, rg);
         else if (skipped) gemm_ring<PREC, 6, kTiles, false, kVR, P_Q1>(qkv, x, rg);
         else gemm_ring<PREC, 6, kTiles, false, kVR, P_Q0>(qkv, x, rg);
         if (rvalid) {
-            const size_t hrow = (((size_t)b * kHeads + wave) * kFrames + frame) * 32;
+            const size_t hrow = (((size_t)b * kHeads + wave) * S + frame) * 32;
             const float scaling = 0.17677669529663687f;
 #pragma unroll
             for (int td = 0; td < 2; ++td) {
@@ -188,6 +223,13 @@ __global__ __launch_bounds__(256) void k_vae_rows(VaeRowsArgs a) {
                 st4(a.v + hrow + 16 * td + 4 * g, qkv[4 + td]);
             }
         }
+    } else if constexpr (ENC) {
+        // encoder.norm; only the two distribution rows leave the stack: mu = row 0, logvar = row 1 (vae.py:203-207)
+        layer_norm_rows<PREC == PREC_BF16>(x, a.pvec + PV_FINAL_W, a.pvec + PV_FINAL_B, g);
+        if (wave == 0 && rt == 0 && frame < 2) {
+#pragma unroll
+            for (int t = 0; t < kTiles; ++t) st4(a.stats_out + ((size_t)b * 2 + frame) * kD + 16 * t + 4 * g, x[t]);
+        }
     } else {
         // decoder.norm -> final_layer (333 outputs padded to 24 tiles, 6 per wave) -> rotation epilogue
         layer_norm_rows<PREC == PREC_BF16>(x, a.pvec + PV_FINAL_W, a.pvec + PV_FINAL_B, g);
@@ -195,15 +237,15 @@ __global__ __launch_bounds__(256) void k_vae_rows(VaeRowsArgs a) {
 #pragma unroll
         for (int o = 0; o < 6; ++o) f[o] = ld4(a.final_bias + 16 * (6 * wave + o) + 4 * g);
         gemm_ring<PREC, 6, kTiles, false, kVR, P_Q0>(f, x, rg);
-        const int len = a.lengths ? a.lengths[b] : kFrames;
+        const int len = a.lengths ? a.lengths[b] : S;
         const bool keep = rvalid && frame < len;  // output[~mask.T] = 0 (vae.py:274)
 #pragma unroll
         for (int o = 0; o < 6; ++o)
             st4(fst + r * kFeatStride + 16 * (6 * wave + o) + 4 * g, keep ? f[o] : splat4(0.f));
         __syncthreads();
         const int tid = threadIdx.x;
-        const int rows_here = min(16, kFrames - rt * 16);
-        const size_t row0 = (size_t)b * kFrames + rt * 16;
+        const int rows_here = min(16, S - rt * 16);
+        const size_t row0 = (size_t)b * S + rt * 16;
         if (a.feats_out) {
             for (int i = tid; i < rows_here * kFeats; i += 256) {
                 const int rr = i / kFeats, c = i - rr * kFeats;
@@ -233,8 +275,9 @@ constexpr int kKS = 36;              // padded LDS row stride (floats) of the K_
 constexpr int kKeyRows = 320;        // 300 keys padded to 20 tiles (zero rows, masked)
 constexpr int kAttnLdsBytes = 2 * kKeyRows * kKS * 4;
 
-template <int PREC>
+template <int PREC, bool ENC>
 __global__ __launch_bounds__(256) void k_vae_attn(VaeAttnArgs a) {
+    constexpr int S = ENC ? kFrames + 2 : kFrames;  // encode: keys 0,1 = distribution tokens, always valid (vae.py:176-181)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* Ks = reinterpret_cast<float*>(smem);
     float* Vs = Ks + kKeyRows * kKS;
@@ -242,20 +285,20 @@ __global__ __launch_bounds__(256) void k_vae_attn(VaeAttnArgs a) {
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int g = lane >> 4, r = lane & 15;
     const int bh = blockIdx.x, b = bh / kHeads, h = bh - b * kHeads;
-    const int len = a.lengths ? a.lengths[b] : kFrames;
-    const float* qg = a.q + (size_t)bh * kFrames * 32;
-    const float* kg = a.k + (size_t)bh * kFrames * 32;
-    const float* vg = a.v + (size_t)bh * kFrames * 32;
+    const int len = a.lengths ? a.lengths[b] + (ENC ? 2 : 0) : S;
+    const float* qg = a.q + (size_t)bh * S * 32;
+    const float* kg = a.k + (size_t)bh * S * 32;
+    const float* vg = a.v + (size_t)bh * S * 32;
     for (int i = threadIdx.x; i < kKeyRows * 8; i += 256) {
         const int rowi = i >> 3, c4 = (i & 7) * 4;
-        const bool ok = rowi < kFrames;
+        const bool ok = rowi < S;
         st4(Ks + rowi * kKS + c4, ok ? ld4(kg + rowi * 32 + c4) : splat4(0.f));
         st4(Vs + rowi * kKS + c4, ok ? ld4(vg + rowi * 32 + c4) : splat4(0.f));
     }
     __syncthreads();
-    for (int qt = wave; qt < kRowTiles; qt += 4) {
+    for (int qt = wave; qt < a.q_tiles; qt += 4) {
         const int fq = qt * 16 + r;
-        const bool qvalid = fq < kFrames;
+        const bool qvalid = fq < S;
         f32x4 q[2];
 #pragma unroll
         for (int td = 0; td < 2; ++td) q[td] = qvalid ? ld4(qg + fq * 32 + 16 * td + 4 * g) : splat4(0.f);
@@ -331,7 +374,7 @@ __global__ __launch_bounds__(256) void k_vae_attn(VaeAttnArgs a) {
             }
         }
         if (qvalid) {
-            float* dst = a.o + ((size_t)b * kFrames + fq) * kD + 32 * h + 4 * g;
+            float* dst = a.o + ((size_t)b * S + fq) * kD + 32 * h + 4 * g;
             st4(dst, o[0] / l_run);
             st4(dst + 16, o[1] / l_run);
         }
@@ -348,7 +391,7 @@ __global__ __launch_bounds__(256) void k_vae_attn(VaeAttnArgs a) {
 constexpr int kPairs = kKeyRows / 32;                        // 10
 constexpr int kAttnBf16LdsBytes = kKeyRows * 64 + kPairs * 2 * 16 * 64;  // 20 KiB + 20 KiB
 
-template <int NQ>
+template <int NQ, int S>
 __device__ __forceinline__ void attn_qtiles_bf16(const uint4* Kb, const uint4* Vt, const float* qg, float* og, int qt0,
                                                  int len, int g, int r) {
     constexpr float kLog2e = 1.44269504088896340736f;
@@ -358,7 +401,7 @@ __device__ __forceinline__ void attn_qtiles_bf16(const uint4* Kb, const uint4* V
 #pragma unroll
     for (int n = 0; n < NQ; ++n) {
         const int fq = (qt0 + 4 * n) * 16 + r;
-        const bool qv = fq < kFrames;
+        const bool qv = fq < S;
         const f32x4 q0 = qv ? ld4(qg + fq * 32 + 4 * g) : splat4(0.f);
         const f32x4 q1 = qv ? ld4(qg + fq * 32 + 16 + 4 * g) : splat4(0.f);
         qb[n] = pack_bf16(q0, q1);
@@ -413,7 +456,7 @@ __device__ __forceinline__ void attn_qtiles_bf16(const uint4* Kb, const uint4* V
 #pragma unroll
     for (int n = 0; n < NQ; ++n) {
         const int fq = (qt0 + 4 * n) * 16 + r;
-        if (fq < kFrames) {
+        if (fq < S) {
             float* dst = og + (size_t)fq * kD + 4 * g;
             st4(dst, o[n][0] / l_run[n]);
             st4(dst + 16, o[n][1] / l_run[n]);
@@ -421,7 +464,9 @@ __device__ __forceinline__ void attn_qtiles_bf16(const uint4* Kb, const uint4* V
     }
 }
 
+template <bool ENC>
 __global__ __launch_bounds__(256) void k_vae_attn_bf16(VaeAttnArgs a) {
+    constexpr int S = ENC ? kFrames + 2 : kFrames;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     uint4* Kb = reinterpret_cast<uint4*>(smem);
     uint4* Vt = Kb + kKeyRows * 4;
@@ -429,13 +474,13 @@ __global__ __launch_bounds__(256) void k_vae_attn_bf16(VaeAttnArgs a) {
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int g = lane >> 4, r = lane & 15;
     const int bh = blockIdx.x, b = bh / kHeads, h = bh - b * kHeads;
-    const int len = a.lengths ? a.lengths[b] : kFrames;
-    const float* qg = a.q + (size_t)bh * kFrames * 32;
-    const float* kg = a.k + (size_t)bh * kFrames * 32;
-    const float* vg = a.v + (size_t)bh * kFrames * 32;
+    const int len = a.lengths ? a.lengths[b] + (ENC ? 2 : 0) : S;
+    const float* qg = a.q + (size_t)bh * S * 32;
+    const float* kg = a.k + (size_t)bh * S * 32;
+    const float* vg = a.v + (size_t)bh * S * 32;
     for (int i = threadIdx.x; i < kKeyRows * 4; i += 256) {  // K fragments: item = (key row, slot group)
         const int row = i >> 2, gg = i & 3;
-        const bool ok = row < kFrames;
+        const bool ok = row < S;
         const f32x4 lo = ok ? ld4(kg + row * 32 + 4 * gg) : splat4(0.f);
         const f32x4 hi = ok ? ld4(kg + row * 32 + 16 + 4 * gg) : splat4(0.f);
         Kb[i] = __builtin_bit_cast(uint4, pack_bf16(lo, hi));
@@ -447,17 +492,21 @@ __global__ __launch_bounds__(256) void k_vae_attn_bf16(VaeAttnArgs a) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             const int k0 = 32 * jp + 4 * gg + e, k1 = k0 + 16;
-            lo[e] = k0 < kFrames ? vg[k0 * 32 + 16 * td + d] : 0.f;
-            hi[e] = k1 < kFrames ? vg[k1 * 32 + 16 * td + d] : 0.f;
+            lo[e] = k0 < S ? vg[k0 * 32 + 16 * td + d] : 0.f;
+            hi[e] = k1 < S ? vg[k1 * 32 + 16 * td + d] : 0.f;
         }
         Vt[(pt * 16 + d) * 4 + gg] = __builtin_bit_cast(uint4, pack_bf16(lo, hi));
     }
     __syncthreads();
-    float* og = a.o + (size_t)b * kFrames * kD + 32 * h;
+    float* og = a.o + (size_t)b * S * kD + 32 * h;
     // 19 query tiles: wave w owns tiles w, w+4, w+8, w+12 (two pairs) and w+16 (waves 0..2)
-    attn_qtiles_bf16<2>(Kb, Vt, qg, og, wave, len, g, r);
-    attn_qtiles_bf16<2>(Kb, Vt, qg, og, wave + 8, len, g, r);
-    if (wave + 16 < kRowTiles) attn_qtiles_bf16<1>(Kb, Vt, qg, og, wave + 16, len, g, r);
+    if (a.q_tiles == 1) {  // last encoder block: only the distribution rows (tile 0) are consumed downstream
+        if (wave == 0) attn_qtiles_bf16<1, S>(Kb, Vt, qg, og, 0, len, g, r);
+        return;
+    }
+    attn_qtiles_bf16<2, S>(Kb, Vt, qg, og, wave, len, g, r);
+    attn_qtiles_bf16<2, S>(Kb, Vt, qg, og, wave + 8, len, g, r);
+    if (wave + 16 < kRowTiles) attn_qtiles_bf16<1, S>(Kb, Vt, qg, og, wave + 16, len, g, r);
 }
 
 template <typename K>
@@ -467,33 +516,45 @@ hipError_t set_lds(K kern, int bytes) {
 
 }  // namespace
 
-hipError_t launch_vae_rows(const VaeRowsArgs& a, int precision, hipStream_t stream) {
+hipError_t launch_vae_rows(const VaeRowsArgs& a, int precision, bool enc, hipStream_t stream) {
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = set_lds(&k_vae_rows<PREC_F32>, kRowsLdsBytes);
-        if (e != hipSuccess) return e;
-        e = set_lds(&k_vae_rows<PREC_BF16>, kRowsLdsBytes);
+        hipError_t e = set_lds(&k_vae_rows<PREC_F32, false>, kRowsLdsBytes);
+        if (e == hipSuccess) e = set_lds(&k_vae_rows<PREC_BF16, false>, kRowsLdsBytes);
+        if (e == hipSuccess) e = set_lds(&k_vae_rows<PREC_F32, true>, kRowsLdsBytes);
+        if (e == hipSuccess) e = set_lds(&k_vae_rows<PREC_BF16, true>, kRowsLdsBytes);
         if (e != hipSuccess) return e;
         attr_set = true;
     }
-    const dim3 grid(a.B * kRowTiles), block(256);
-    if (precision == PREC_F32) hipLaunchKernelGGL(k_vae_rows<PREC_F32>, grid, block, kRowsLdsBytes, stream, a);
-    else hipLaunchKernelGGL(k_vae_rows<PREC_BF16>, grid, block, kRowsLdsBytes, stream, a);
+    const dim3 grid(a.B * a.tiles), block(256);
+    if (precision == PREC_F32) {
+        if (enc) hipLaunchKernelGGL((k_vae_rows<PREC_F32, true>), grid, block, kRowsLdsBytes, stream, a);
+        else hipLaunchKernelGGL((k_vae_rows<PREC_F32, false>), grid, block, kRowsLdsBytes, stream, a);
+    } else {
+        if (enc) hipLaunchKernelGGL((k_vae_rows<PREC_BF16, true>), grid, block, kRowsLdsBytes, stream, a);
+        else hipLaunchKernelGGL((k_vae_rows<PREC_BF16, false>), grid, block, kRowsLdsBytes, stream, a);
+    }
     return hipGetLastError();
 }
 
-hipError_t launch_vae_attn(const VaeAttnArgs& a, int precision, hipStream_t stream) {
+hipError_t launch_vae_attn(const VaeAttnArgs& a, int precision, bool enc, hipStream_t stream) {
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = set_lds(&k_vae_attn<PREC_F32>, kAttnLdsBytes);
-        if (e != hipSuccess) return e;
-        e = set_lds(&k_vae_attn_bf16, kAttnBf16LdsBytes);
+        hipError_t e = set_lds(&k_vae_attn<PREC_F32, false>, kAttnLdsBytes);
+        if (e == hipSuccess) e = set_lds(&k_vae_attn<PREC_F32, true>, kAttnLdsBytes);
+        if (e == hipSuccess) e = set_lds(&k_vae_attn_bf16<false>, kAttnBf16LdsBytes);
+        if (e == hipSuccess) e = set_lds(&k_vae_attn_bf16<true>, kAttnBf16LdsBytes);
         if (e != hipSuccess) return e;
         attr_set = true;
     }
     const dim3 grid(a.B * kHeads), block(256);
-    if (precision == PREC_F32) hipLaunchKernelGGL(k_vae_attn<PREC_F32>, grid, block, kAttnLdsBytes, stream, a);
-    else hipLaunchKernelGGL(k_vae_attn_bf16, grid, block, kAttnBf16LdsBytes, stream, a);
+    if (precision == PREC_F32) {
+        if (enc) hipLaunchKernelGGL((k_vae_attn<PREC_F32, true>), grid, block, kAttnLdsBytes, stream, a);
+        else hipLaunchKernelGGL((k_vae_attn<PREC_F32, false>), grid, block, kAttnLdsBytes, stream, a);
+    } else {
+        if (enc) hipLaunchKernelGGL(k_vae_attn_bf16<true>, grid, block, kAttnBf16LdsBytes, stream, a);
+        else hipLaunchKernelGGL(k_vae_attn_bf16<false>, grid, block, kAttnBf16LdsBytes, stream, a);
+    }
     return hipGetLastError();
 }
 

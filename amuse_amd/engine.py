@@ -140,6 +140,26 @@ class HipEngine:
             out["feats"] = feats
         return out
 
+    def vae_encode(self, feats, lengths: Optional[Sequence[int]] = None, precision="fp32", eps=None):
+        """MotionPrior.encode (vae.py:154-214): feats (B,300,333) -> {"mu", "std", "latent"} each (B,128);
+        latent = mu + std * eps (Normal.rsample with the caller's draw; eps None -> latent = mu)."""
+        feats = self._dev(feats, None)
+        if feats.dim() != 3 or tuple(feats.shape[1:]) != (300, 333):
+            raise ValueError(f"feats must be (B, 300, 333), got {tuple(feats.shape)}")
+        B = feats.shape[0]
+        eps = self._dev(eps, (B, 128)) if eps is not None else None
+        out = {k: torch.empty(B, 128, device=self.device, dtype=torch.float32) for k in ("mu", "std", "latent")}
+        lp = None
+        if lengths is not None:
+            la = np.ascontiguousarray(lengths, dtype=np.int32)
+            if la.shape != (B,):
+                raise ValueError("lengths must have one entry per clip")
+            lp = la.ctypes.data_as(C.POINTER(C.c_int))
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.amuse_vae_encode(self.ctx, _ptr(feats), lp, B, PREC[precision], _ptr(eps),
+                                                 _ptr(out["mu"]), _ptr(out["std"]), _ptr(out["latent"]), self._stream()))
+        return out
+
     def diffusion_backward(self, con, emo, sty, precision="fp32", quat_mode="p3d", seed=0, clip_index0=0, x_init=None,
                            step_noise=None, out=None):
         con = self._dev(con)

@@ -120,6 +120,18 @@ int amuse_vae_decode(amuse_ctx* ctx, const float* z, const int* lengths, int B, 
                      int quat_mode, float* feats_out, float* poses_out, float* trans_out,
                      void* stream);
 
+/* Replaces PretrainedVAE.get_latent -> MotionPrior.encode (infer_pretrained_vae.py:51-56,
+ * vae.py:154-214; call site infer_ldm.py:465): features -> skel_embedding, two distribution tokens
+ * prepended, learned PE, 9-block skip-transformer encoder with key-padding mask; mu / logvar are the
+ * two distribution rows, std = exp(logvar) ** 0.5, latent = mu + std * eps (Normal.rsample).
+ *   feats      dev [B][300][333] motion features (6D rotations | translation)
+ *   lengths    host [B] or NULL (= all 300): frames >= length are masked as attention keys
+ *   eps        dev [B][128] standard-normal draw for rsample, or NULL (latent_out = mu)
+ *   mu_out, std_out, latent_out   dev [B][128], each nullable (at least one required) */
+int amuse_vae_encode(amuse_ctx* ctx, const float* feats, const int* lengths, int B, int precision,
+                     const float* eps, float* mu_out, float* std_out, float* latent_out,
+                     void* stream);
+
 /* Replaces PretrainedLPDM_v1.diffusion_backward end to end (infer_ldm.py:130-178):
  * amuse_sample followed by amuse_vae_decode on the final latents. */
 int amuse_diffusion_backward(amuse_ctx* ctx, const float* con, const float* emo, const float* sty,

@@ -256,6 +256,63 @@ def test_vae_decode_bf16_bounded(env):
     assert _err(out["feats"], g["feats"]) < 6e-2  # |feats| ~ 3
 
 
+def test_vae_encode_fp32_vs_reference_golden(env):
+    """MotionPrior.encode (vae.py:154-214) through amuse_vae_encode: mu / std against the reference's own module."""
+    orc, eng, Wp = env["orc"], env["eng"], env["Wp"]
+    g = np.load(GOLDEN / "vae_encode.npz")
+    feats = torch.from_numpy(g["feats"].astype(np.float32))
+    out = eng.vae_encode(feats, None, "fp32")
+    assert out["mu"].shape == (2, 128) and out["std"].shape == (2, 128)
+    assert _err(out["mu"], g["mu"]) < 2e-5
+    assert _err(out["std"], g["std"]) < 2e-5 * float(g["std"].max())
+    assert torch.equal(out["latent"], out["mu"])                       # no eps supplied -> latent = mu
+    # ragged: padded frames masked as attention keys, the two distribution tokens always visible (vae.py:176-181)
+    o2 = eng.vae_encode(feats, [300, 211], "fp32")
+    assert _err(o2["mu"], g["mu_ragged"]) < 2e-5
+    assert _err(o2["std"], g["std_ragged"]) < 2e-5 * float(g["std_ragged"].max())
+    assert _err(o2["mu"][1], g["mu"][1]) > 1e-3                        # the mask is live
+    # masked frames are dead inputs
+    f2 = feats.clone()
+    f2[1, 211:] = 7.0
+    o3 = eng.vae_encode(f2, [300, 211], "fp32")
+    assert torch.equal(o3["mu"], o2["mu"]) and torch.equal(o3["std"], o2["std"])
+    # rsample with an explicit draw: latent = mu + std * eps, exactly
+    eps = torch.randn(2, 128, generator=torch.Generator().manual_seed(5))
+    o4 = eng.vae_encode(feats, None, "fp32", eps=eps)
+    assert torch.equal(o4["latent"].cpu(), out["mu"].cpu() + out["std"].cpu() * eps)
+    # more clips than one chunk row group, every clip independent of its neighbours
+    fb = feats[:1].repeat(5, 1, 1)
+    fb[3] = feats[1]
+    o5 = eng.vae_encode(fb, None, "fp32")
+    assert torch.equal(o5["mu"][0], out["mu"][0]) and torch.equal(o5["mu"][3], out["mu"][1])
+    assert torch.equal(o5["mu"][4], out["mu"][0])
+    # oracle on fresh inputs (not the golden draw)
+    f6 = 0.7 * torch.randn(3, 300, 333, generator=torch.Generator().manual_seed(11))
+    mu, std = orc.vae_encode(Wp, f6, [300, 17, 1])
+    o6 = eng.vae_encode(f6, [300, 17, 1], "fp32")
+    assert _err(o6["mu"], mu) < 2e-5 and _err(o6["std"] / std.to(o6["std"].device), torch.ones_like(std)) < 5e-5
+
+
+def test_vae_encode_bf16_bounded(env):
+    eng = env["eng"]
+    g = np.load(GOLDEN / "vae_encode.npz")
+    out = eng.vae_encode(torch.from_numpy(g["feats"].astype(np.float32)), None, "bf16")
+    assert _err(out["mu"], g["mu"]) < 6e-2        # LayerNorm output, |mu| ~ 3
+    assert _err(out["std"] / torch.from_numpy(g["std"]).to(out["std"].device), torch.ones(2, 128)) < 5e-2
+
+
+def test_encode_decode_round_trip_shapes_and_determinism(env):
+    """edit_gesture's data path (infer_ldm.py:459-468): motion -> latent -> motion; deterministic and length-stable."""
+    eng = env["eng"]
+    g = np.load(GOLDEN / "vae_encode.npz")
+    feats = torch.from_numpy(g["feats"].astype(np.float32))
+    a = eng.vae_encode(feats, None, "fp32")
+    b = eng.vae_encode(feats, None, "fp32")
+    assert torch.equal(a["mu"], b["mu"]) and torch.equal(a["std"], b["std"])
+    rec = eng.vae_decode(a["latent"], None, "fp32", return_feats=True)
+    assert rec["feats"].shape == (2, 300, 333) and bool(torch.isfinite(rec["feats"]).all())
+
+
 def test_diffusion_backward_end_to_end_fp32(env):
     """BASELINE config 1 shape: 1 clip, DDIM-50, explicit x_T -> SMPL-X poses; per-joint L2 < 1e-4."""
     from amuse_amd import scheduler as sch
