@@ -674,6 +674,15 @@ int amuse_vae_encode(amuse_ctx* c, const float* feats, const int* lengths, int B
     return 0;
 }
 
+int amuse_smplx_to_feats(amuse_ctx* c, const float* poses, const float* trans, int B, float* feats_out, void* stream) {
+    if (!c) return fail(AMUSE_EINVAL, "ctx is NULL");
+    if (!poses || !trans || !feats_out) return fail(AMUSE_EINVAL, "NULL argument");
+    if (B < 1) return fail(AMUSE_EINVAL, "B must be >= 1, got %d", B);
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(launch_smplx_to_feats(poses, trans, (size_t)B * kFrames, feats_out, (hipStream_t)stream));
+    return 0;
+}
+
 int amuse_diffusion_backward(amuse_ctx* c, const float* con, const float* emo, const float* sty, int B, int precision,
                              int quat_mode, uint64_t seed, uint64_t clip_index0, const float* x_init,
                              const float* step_noise, float* latents_out, float* poses_out, float* trans_out,

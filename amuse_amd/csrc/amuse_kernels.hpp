@@ -95,6 +95,8 @@ struct VaeAttnArgs {
     int q_tiles;                                      // query tiles to produce: 19, or 1 (last encoder block)
 };
 hipError_t launch_vae_attn(const VaeAttnArgs& a, int precision, bool enc, hipStream_t stream);
+// feats[row][0:330] = first two rows of R(axis-angle) per joint, feats[row][330:333] = trans   (infer_ldm.py:459-464)
+hipError_t launch_smplx_to_feats(const float* poses, const float* trans, size_t nrows, float* feats, hipStream_t stream);
 // mu = stats[b][0], std = exp(stats[b][1]) ** 0.5, latent = mu + std * eps   (vae.py:209-213)
 hipError_t launch_vae_latent(const float* stats, const float* eps, float* mu, float* std, float* latent, int B,
                              hipStream_t stream);

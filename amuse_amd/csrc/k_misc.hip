@@ -74,6 +74,38 @@ __global__ __launch_bounds__(128) void k_vae_ca(const float* __restrict__ z, con
     ca[((size_t)b * kLayers + blk) * kD + j] = o + bo[blk * kD + j];
 }
 
+// SMPL-X axis-angle + translation -> the prior's 333 motion features (infer_ldm.py:459-464):
+// axis_angle_to_matrix (= axis_angle_to_quaternion -> quaternion_to_matrix, rotation_conversions.py:425-478, 41-71)
+// then matrix_to_rotation_6d = the first two matrix rows (rotation_conversions.py:536-551).  One thread per (row, joint).
+__global__ __launch_bounds__(256) void k_smplx_to_feats(const float* __restrict__ poses, const float* __restrict__ trans,
+                                                        size_t nrows, float* __restrict__ feats) {
+#pragma clang fp contract(off)
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= nrows * (kJoints + 1)) return;
+    const size_t row = i / (kJoints + 1);
+    const int jn = (int)(i - row * (kJoints + 1));
+    float* dst = feats + row * kFeats;
+    if (jn == kJoints) {
+        const float* t = trans + row * 3;
+        dst[330] = t[0]; dst[331] = t[1]; dst[332] = t[2];
+        return;
+    }
+    const float* aa = poses + (row * kJoints + jn) * 3;
+    const float ax = aa[0], ay = aa[1], az = aa[2];
+    const float ang = sqrtf(ax * ax + ay * ay + az * az);
+    const float half = 0.5f * ang;
+    const float s = (fabsf(ang) < 1e-6f) ? (0.5f - (ang * ang) / 48.0f) : (sinf(half) / ang);
+    const float r = cosf(half), qi = ax * s, qj = ay * s, qk = az * s;
+    const float two_s = 2.0f / (r * r + qi * qi + qj * qj + qk * qk);
+    dst += 6 * jn;
+    dst[0] = 1.0f - two_s * (qj * qj + qk * qk);
+    dst[1] = two_s * (qi * qj - qk * r);
+    dst[2] = two_s * (qi * qk + qj * r);
+    dst[3] = two_s * (qi * qj + qk * r);
+    dst[4] = 1.0f - two_s * (qi * qi + qk * qk);
+    dst[5] = two_s * (qj * qk - qi * r);
+}
+
 // MotionPrior.encode tail (vae.py:203-213): mu = dist[0], logvar = dist[1]; std = logvar.exp().pow(0.5);
 // latent = Normal(mu, std).rsample() = mu + std * eps with eps supplied by the caller (or latent = mu when absent)
 __global__ __launch_bounds__(128) void k_vae_latent(const float* __restrict__ stats, const float* __restrict__ eps,
@@ -110,6 +142,12 @@ hipError_t launch_counter_normal(uint64_t seed, uint64_t clip0, int B, int step,
 hipError_t launch_vae_ca(const float* z, const float* wv_t, const float* bv, const float* wo_t, const float* bo,
                          float* ca, int B, hipStream_t stream) {
     hipLaunchKernelGGL(k_vae_ca, dim3(kLayers, B), dim3(128), 0, stream, z, wv_t, bv, wo_t, bo, ca);
+    return hipGetLastError();
+}
+
+hipError_t launch_smplx_to_feats(const float* poses, const float* trans, size_t nrows, float* feats, hipStream_t stream) {
+    const size_t n = nrows * (kJoints + 1);
+    hipLaunchKernelGGL(k_smplx_to_feats, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, poses, trans, nrows, feats);
     return hipGetLastError();
 }
 

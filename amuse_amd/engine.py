@@ -160,6 +160,18 @@ class HipEngine:
                                                  _ptr(out["mu"]), _ptr(out["std"]), _ptr(out["latent"]), self._stream()))
         return out
 
+    def smplx_to_feats(self, poses, trans):
+        """(B,300,55,3) axis-angle + (B,300,3) translation -> (B,300,333) prior features (infer_ldm.py:459-464)."""
+        poses = self._dev(poses)
+        B = poses.shape[0]
+        if tuple(poses.shape) != (B, 300, 55, 3):
+            raise ValueError(f"poses must be (B, 300, 55, 3), got {tuple(poses.shape)}")
+        trans = self._dev(trans, (B, 300, 3))
+        feats = torch.empty(B, 300, 333, device=self.device, dtype=torch.float32)
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.amuse_smplx_to_feats(self.ctx, _ptr(poses), _ptr(trans), B, _ptr(feats), self._stream()))
+        return feats
+
     def diffusion_backward(self, con, emo, sty, precision="fp32", quat_mode="p3d", seed=0, clip_index0=0, x_init=None,
                            step_noise=None, out=None):
         con = self._dev(con)

@@ -7,8 +7,11 @@ What is mirrored                                   reference
   diffusion_backward(bsz, z_con, z_emo, z_sty)      infer_ldm.py:130-178 (the hot loop, VAE decode, 6D -> axis-angle)
   process_loader(data_dict)                         infer_ldm.py:225-414 (latent swapping for the edit tasks; the
                                                     per-take latents must already be in the dict - see below)
+  _loader_helper_v1(motion, audio)                  infer_ldm.py:416-493 (motion half on the HIP path: 300-frame takes,
+                                                    axis-angle -> 6D, MotionPrior.encode + rsample; the audio half
+                                                    goes through the injected `audio_encoder`)
 What is NOT rebuilt (SURVEY.md section 8f "next"): the audio front-end (process_single_seq: kaldi fbank +
-3 x AST) and MotionPrior.encode.  process_single_seq raises unless an `audio_encoder` callable is injected.
+3 x AST).  process_single_seq raises unless an `audio_encoder` callable is injected.
 """
 from __future__ import annotations
 
@@ -125,6 +128,41 @@ class PretrainedLPDM_v1:
                                       "pass audio_encoder=... or feed precomputed embeddings")
         con, emo, sty = self.audio_encoder(sliced_chunk)
         return con.reshape(1, -1), emo.reshape(1, -1), sty.reshape(1, -1)
+
+    def motion_to_latent(self, motion, sample: bool = True, clip_index0: Optional[int] = None):
+        """The motion half of _loader_helper_v1 (infer_ldm.py:453-465): `motion` (frames, 168) = 55 x 3 SMPL-X
+        axis-angle + 3 translation per frame is cut into whole 300-frame takes, converted to the 333 prior features
+        (axis-angle -> matrix -> 6D) and pushed through MotionPrior.encode; returns z_motion (takes, 128) =
+        Normal(mu, std).rsample() (PretrainedVAE.get_latent, infer_pretrained_vae.py:51-56).  The draw comes from
+        the build's counter-based generator (seed, global take index, step 0, stream 2) instead of the device RNG;
+        sample=False returns mu."""
+        motion = torch.as_tensor(motion)
+        if motion.dim() != 2 or motion.shape[1] != 168:
+            raise ValueError(f"motion must be (frames, 168), got {tuple(motion.shape)}")
+        takes = motion.shape[0] // self.seq_len
+        if takes < 1:
+            raise RuntimeError("stack expects a non-empty TensorList")   # torch.stack([]) at infer_ldm.py:456
+        m = motion[: takes * self.seq_len].reshape(takes, self.seq_len, 168).to(self.device, torch.float32)
+        feats = self.engine.smplx_to_feats(m[..., :165].reshape(takes, self.seq_len, 55, 3), m[..., 165:])
+        eps = None
+        if sample:
+            c0 = self._clip_counter if clip_index0 is None else clip_index0
+            eps = self.engine.counter_normal(self.seed, c0, takes, 0, 2)
+            if clip_index0 is None:
+                self._clip_counter += takes
+        return self.engine.vae_encode(feats, None, self.precision, eps=eps)["latent"]
+
+    def _loader_helper_v1(self, motion, audio):
+        """-> {"z_motion", "z_con", "z_emo", "z_sty"} (infer_ldm.py:416-493).  `audio` is whatever the injected
+        audio_encoder accepts; it returns (con, emo, sty), each (takes_audio, 256) or None."""
+        if self.audio_encoder is None:
+            raise NotImplementedError("audio front-end (models/audio AST_EVP) is not part of the HIP hot path; "
+                                      "pass audio_encoder=... or call motion_to_latent for the motion half")
+        con, emo, sty = self.audio_encoder(audio)
+        z = self.motion_to_latent(motion)
+        n = z.shape[0]
+        return {"z_motion": z, "z_con": con[:n], "z_emo": emo[:n] if emo is not None else None,
+                "z_sty": sty[:n] if sty is not None else None}
 
     def process_loader(self, data_dict):
         """Latent swapping of the edit tasks (infer_ldm.py:225-414) on takes whose ld_z_con / ld_z_emo / ld_z_sty

@@ -132,6 +132,12 @@ int amuse_vae_encode(amuse_ctx* ctx, const float* feats, const int* lengths, int
                      const float* eps, float* mu_out, float* std_out, float* latent_out,
                      void* stream);
 
+/* Replaces the motion preparation of PretrainedLPDM_v1._loader_helper_v1 (infer_ldm.py:459-464):
+ * SMPL-X axis-angle -> rotation matrix -> 6D (first two rows), concatenated with the translation.
+ *   poses dev [B][300][55][3], trans dev [B][300][3]  ->  feats_out dev [B][300][333] */
+int amuse_smplx_to_feats(amuse_ctx* ctx, const float* poses, const float* trans, int B,
+                         float* feats_out, void* stream);
+
 /* Replaces PretrainedLPDM_v1.diffusion_backward end to end (infer_ldm.py:130-178):
  * amuse_sample followed by amuse_vae_decode on the final latents. */
 int amuse_diffusion_backward(amuse_ctx* ctx, const float* con, const float* emo, const float* sty,

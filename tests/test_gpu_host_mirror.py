@@ -68,6 +68,39 @@ def test_setup_from_reference_checkpoints_and_diffusion_backward(tmp_path):
         PretrainedLPDM_v1().setup(cfg, "cuda:0", processed, None, False)
 
 
+def test_loader_helper_motion_to_latent():
+    """_loader_helper_v1's motion half (infer_ldm.py:453-465) on the HIP path vs the oracle's restatement."""
+    from amuse_amd import weights as wts
+    from amuse_amd.infer_ldm import PretrainedLPDM_v1
+    from oracle import amuse_oracle as orc
+    wd, wp = wts.make_denoiser_weights(0), wts.make_prior_weights(0)
+    m = PretrainedLPDM_v1.from_state_dicts(wd, wp, device="cuda:0", seed=7)
+    gen = torch.Generator().manual_seed(4)
+    motion = torch.cat([0.5 * torch.randn(700, 165, generator=gen), torch.randn(700, 3, generator=gen)], -1)
+    z_mu = m.motion_to_latent(motion, sample=False)
+    assert z_mu.shape == (2, 128)                                  # 700 // 300 whole takes, the tail is dropped
+    takes = motion[:600].reshape(2, 300, 168)
+    feats = torch.cat([orc.axis_angle_to_rotation_6d(takes[..., :165].reshape(2, 300, 55, 3)).reshape(2, 300, 330),
+                       takes[..., 165:]], -1)
+    mu, std = orc.vae_encode(orc.to_torch(wp), feats, None)
+    assert float((z_mu.cpu() - mu).abs().max()) < 2e-5
+    c0 = m._clip_counter
+    z = m.motion_to_latent(motion)
+    eps = torch.from_numpy(orc.counter_normal(7, np.arange(c0, c0 + 2), 0, 2))
+    assert m._clip_counter == c0 + 2
+    assert float((z.cpu() - (mu + std * eps)).abs().max()) < 1e-4
+    assert not torch.equal(m.motion_to_latent(motion), z)           # a fresh draw per call, like rsample
+    with pytest.raises(NotImplementedError):
+        m._loader_helper_v1(motion, None)
+    m.audio_encoder = lambda audio: (torch.ones(3, 256), torch.zeros(3, 256), None)
+    out = m._loader_helper_v1(motion, None)
+    assert out["z_motion"].shape == (2, 128) and out["z_con"].shape == (2, 256) and out["z_sty"] is None
+    with pytest.raises(RuntimeError):
+        m.motion_to_latent(motion[:299])
+    with pytest.raises(ValueError):
+        m.motion_to_latent(motion[:, :100])
+
+
 def test_cli_infer_and_edit_gesture_write_reference_npz(tmp_path):
     from amuse_amd import main as cli
     from amuse_amd.npz_writer import LOWER_BODY_JOINTS

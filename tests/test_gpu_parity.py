@@ -301,6 +301,29 @@ def test_vae_encode_bf16_bounded(env):
     assert _err(out["std"] / torch.from_numpy(g["std"]).to(out["std"].device), torch.ones(2, 128)) < 5e-2
 
 
+def test_smplx_to_feats_vs_oracle_and_round_trip(env):
+    """infer_ldm.py:459-464 (axis-angle -> matrix -> 6D | trans) and its inverse at infer_ldm.py:168-173."""
+    orc, eng = env["orc"], env["eng"]
+    gen = torch.Generator().manual_seed(3)
+    poses = 0.6 * torch.randn(2, 300, 55, 3, generator=gen)
+    poses[0, :4] = 0.0                                   # identity rotations: the small-angle branch
+    poses[0, 4, :5] *= 1e-7
+    trans = torch.randn(2, 300, 3, generator=gen)
+    feats = eng.smplx_to_feats(poses, trans).cpu()
+    ref = torch.cat([orc.axis_angle_to_rotation_6d(poses).reshape(2, 300, 330), trans], -1)
+    assert feats.shape == (2, 300, 333)
+    assert torch.equal(feats[..., 330:], trans)
+    assert _err(feats, ref) < 1e-6
+    assert _err(feats, torch.cat([orc.axis_angle_to_rotation_6d(poses.double()).reshape(2, 300, 330), trans.double()], -1)) < 1e-6
+    # the decode-side epilogue inverts it as a rotation (the candidate-selection quaternion may return the
+    # |aa| > pi representative of the same rotation), and value-wise with the legacy quaternion (q_w >= 0)
+    back, _ = orc.feats_to_smplx(feats, "p3d")
+    assert _err(orc.axis_angle_to_matrix(back.double()), orc.axis_angle_to_matrix(poses.double())) < 1e-5
+    back_l, _ = orc.feats_to_smplx(feats.double(), "legacy")
+    sel = torch.linalg.vector_norm(poses, dim=-1) < 3.0
+    assert _err(back_l[sel], poses[sel]) < 1e-4
+
+
 def test_encode_decode_round_trip_shapes_and_determinism(env):
     """edit_gesture's data path (infer_ldm.py:459-468): motion -> latent -> motion; deterministic and length-stable."""
     eng = env["eng"]
