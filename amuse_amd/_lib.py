@@ -20,6 +20,7 @@ EXPORTS = [
     "amuse_abi_version", "amuse_last_error", "amuse_create", "amuse_destroy", "amuse_set_schedule",
     "amuse_sample", "amuse_denoise_step", "amuse_vae_decode", "amuse_vae_encode", "amuse_smplx_to_feats", "amuse_diffusion_backward",
     "amuse_counter_normal", "amuse_set_clips_per_group", "amuse_profile_sample",
+    "amuse_audio_create", "amuse_audio_destroy", "amuse_audio_fbank", "amuse_audio_encode", "amuse_audio_features",
 ]
 
 
@@ -65,6 +66,15 @@ def load() -> C.CDLL:
     lib.amuse_profile_sample.argtypes = [vp, fp, fp, fp, C.c_int, C.c_int, C.c_int, fp, vp]
     for n in ("amuse_set_schedule", "amuse_sample", "amuse_denoise_step", "amuse_vae_decode", "amuse_vae_encode", "amuse_smplx_to_feats",
               "amuse_diffusion_backward", "amuse_counter_normal", "amuse_set_clips_per_group", "amuse_profile_sample"):
+        getattr(lib, n).restype = C.c_int
+    lib.amuse_audio_create.restype = vp
+    lib.amuse_audio_create.argtypes = [C.c_int, fp, fp, fp, C.c_size_t, fp, fp, C.c_float, C.c_float, C.c_int]
+    lib.amuse_audio_destroy.argtypes = [vp]
+    lib.amuse_audio_destroy.restype = None
+    lib.amuse_audio_fbank.argtypes = [vp, fp, C.c_int, C.c_int, fp, vp]
+    lib.amuse_audio_encode.argtypes = [vp, C.c_int, fp, C.c_int, fp, fp, C.c_int, vp]
+    lib.amuse_audio_features.argtypes = [vp, fp, C.c_int, C.c_int, fp, fp, fp, vp]
+    for n in ("amuse_audio_fbank", "amuse_audio_encode", "amuse_audio_features"):
         getattr(lib, n).restype = C.c_int
     if lib.amuse_abi_version() != ABI_VERSION:
         raise AmuseHipError(f"ABI mismatch: library {lib.amuse_abi_version()} vs binding {ABI_VERSION}")

@@ -27,6 +27,13 @@ int fail(int code, const char* fmt, ...) {
     va_end(ap);
     return code;
 }
+}  // namespace
+// the same error slot for the library's other translation units (amuse_audio_api.hip)
+__attribute__((visibility("hidden"))) int amuse_fail_msg(int code, const char* msg) {
+    snprintf(g_err, sizeof(g_err), "%s", msg);
+    return code;
+}
+namespace {
 #define HIP_TRY(expr)                                                                                   \
     do {                                                                                                \
         hipError_t e_ = (expr);                                                                         \

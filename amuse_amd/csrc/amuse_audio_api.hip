@@ -1,0 +1,261 @@
+// C ABI of the audio front-end (include/amuse_hip.h, "Audio front-end"): context, bf16 weight images, workspace and
+// the launch sequence of one AST encoder.  Host code only - kernels live in k_audio.hip.
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstring>
+#include <vector>
+
+#include "../../include/amuse_hip.h"
+#include "amuse_audio.hpp"
+
+using namespace amuse;
+
+int amuse_fail_msg(int code, const char* msg);   // amuse_api.hip: the library's thread-local error slot
+
+namespace {
+
+int failf(int code, const char* fmt, const char* a = "", long b = 0, long c = 0) {
+    char buf[400];
+    snprintf(buf, sizeof(buf), fmt, a, b, c);
+    return amuse_fail_msg(code, buf);
+}
+#define HIP_TRY(expr)                                                                            \
+    do {                                                                                         \
+        hipError_t e_ = (expr);                                                                  \
+        if (e_ != hipSuccess) return failf(AMUSE_EHIP, "%s (line %ld)", hipGetErrorString(e_), __LINE__); \
+    } while (0)
+
+unsigned short f2bf(float f) {  // round-to-nearest-even, as v_cvt_pk_bf16_f32
+    uint32_t x;
+    memcpy(&x, &f, 4);
+    if ((x & 0x7fffffffu) > 0x7f800000u) return (unsigned short)((x >> 16) | 0x40);
+    x += 0x7fffu + ((x >> 16) & 1u);
+    return (unsigned short)(x >> 16);
+}
+
+struct Block {
+    float *n1w, *n1b, *n2w, *n2b, *qkv_b, *proj_b, *fc1_b, *fc2_b;
+    unsigned short *qkv_w, *proj_w, *fc1_w, *fc2_w;
+};
+struct Encoder {
+    float *cls, *dist, *pos, *patch_b, *norm_w, *norm_b, *fh_ln_w, *fh_ln_b, *fh_b;
+    unsigned short *patch_w, *fh_w;
+    Block blk[kAstLayers];
+};
+constexpr int kChunk = 32;   // clips per pass over the network (about 22 MB of workspace per clip)
+
+}  // namespace
+
+struct amuse_audio_ctx {
+    int device = 0;
+    int frame_based = 1;
+    float norm_mean = 0.f, norm_std = 1.f;
+    float *melw = nullptr, *window = nullptr;
+    Encoder enc[3];
+    std::vector<void*> owned;
+    // workspace for `cap` clips
+    int cap = 0;
+    float *X = nullptr, *fbank = nullptr, *pooled = nullptr;
+    unsigned short *H = nullptr, *QK = nullptr, *Vt = nullptr, *O = nullptr, *F = nullptr, *P = nullptr;
+};
+
+namespace {
+
+int up_f32(amuse_audio_ctx* c, float** dst, const float* src, size_t n) {
+    HIP_TRY(hipMalloc((void**)dst, n * sizeof(float)));
+    c->owned.push_back(*dst);
+    HIP_TRY(hipMemcpy(*dst, src, n * sizeof(float), hipMemcpyHostToDevice));
+    return 0;
+}
+int up_bf16(amuse_audio_ctx* c, unsigned short** dst, const float* src, size_t n) {
+    std::vector<unsigned short> h(n);
+    for (size_t i = 0; i < n; ++i) h[i] = f2bf(src[i]);
+    HIP_TRY(hipMalloc((void**)dst, n * 2));
+    c->owned.push_back(*dst);
+    HIP_TRY(hipMemcpy(*dst, h.data(), n * 2, hipMemcpyHostToDevice));
+    return 0;
+}
+
+int build_encoder(amuse_audio_ctx* c, Encoder& E, const float* p) {
+    const size_t D = kAstDim;
+    auto take = [&](size_t n) { const float* q = p; p += n; return q; };
+    if (up_f32(c, &E.cls, take(D), D) || up_f32(c, &E.dist, take(D), D) ||
+        up_f32(c, &E.pos, take((size_t)kAstTokens * D), (size_t)kAstTokens * D) ||
+        up_bf16(c, &E.patch_w, take(D * 256), D * 256) || up_f32(c, &E.patch_b, take(D), D))
+        return AMUSE_EHIP;
+    for (int l = 0; l < kAstLayers; ++l) {
+        Block& b = E.blk[l];
+        if (up_f32(c, &b.n1w, take(D), D) || up_f32(c, &b.n1b, take(D), D) ||
+            up_bf16(c, &b.qkv_w, take(3 * D * D), 3 * D * D) || up_f32(c, &b.qkv_b, take(3 * D), 3 * D) ||
+            up_bf16(c, &b.proj_w, take(D * D), D * D) || up_f32(c, &b.proj_b, take(D), D) ||
+            up_f32(c, &b.n2w, take(D), D) || up_f32(c, &b.n2b, take(D), D) ||
+            up_bf16(c, &b.fc1_w, take((size_t)kAstMlp * D), (size_t)kAstMlp * D) || up_f32(c, &b.fc1_b, take(kAstMlp), kAstMlp) ||
+            up_bf16(c, &b.fc2_w, take(D * kAstMlp), D * kAstMlp) || up_f32(c, &b.fc2_b, take(D), D))
+            return AMUSE_EHIP;
+    }
+    if (up_f32(c, &E.norm_w, take(D), D) || up_f32(c, &E.norm_b, take(D), D) || up_f32(c, &E.fh_ln_w, take(D), D) ||
+        up_f32(c, &E.fh_ln_b, take(D), D) || up_bf16(c, &E.fh_w, take((size_t)kAstFeat * D), (size_t)kAstFeat * D) ||
+        up_f32(c, &E.fh_b, take(kAstFeat), kAstFeat))
+        return AMUSE_EHIP;
+    return 0;
+}
+
+size_t pad128(size_t m) { return (m + 127) / 128 * 128; }
+
+int ensure_ws(amuse_audio_ctx* c, int nb) {
+    if (c->cap >= nb) return 0;
+    void* old[] = {c->X, c->fbank, c->pooled, c->H, c->QK, c->Vt, c->O, c->F, c->P};
+    for (void* p : old)
+        if (p) HIP_TRY(hipFree(p));
+    c->cap = 0;
+    const size_t Mp = pad128((size_t)nb * kAstTokens);
+    HIP_TRY(hipMalloc((void**)&c->X, Mp * kAstDim * 4));
+    HIP_TRY(hipMalloc((void**)&c->fbank, (size_t)nb * kAstFrames * kAstMel * 4));
+    HIP_TRY(hipMalloc((void**)&c->pooled, (size_t)nb * kAstDim * 4));
+    HIP_TRY(hipMalloc((void**)&c->H, Mp * kAstDim * 2));
+    HIP_TRY(hipMalloc((void**)&c->QK, Mp * 2 * kAstDim * 2));
+    HIP_TRY(hipMalloc((void**)&c->Vt, (size_t)nb * kAstDim * kAstKeysPad * 2));
+    HIP_TRY(hipMalloc((void**)&c->O, Mp * kAstDim * 2));
+    HIP_TRY(hipMalloc((void**)&c->F, Mp * kAstMlp * 2));
+    HIP_TRY(hipMalloc((void**)&c->P, pad128((size_t)nb * kAstPatches) * 256 * 2));
+    // rows beyond M are read by the GEMM tiles (results discarded) and the V^T pad columns by the attention (masked):
+    // they only have to be finite
+    HIP_TRY(hipMemset(c->H, 0, Mp * kAstDim * 2));
+    HIP_TRY(hipMemset(c->O, 0, Mp * kAstDim * 2));
+    HIP_TRY(hipMemset(c->F, 0, Mp * kAstMlp * 2));
+    HIP_TRY(hipMemset(c->P, 0, pad128((size_t)nb * kAstPatches) * 256 * 2));
+    HIP_TRY(hipMemset(c->Vt, 0, (size_t)nb * kAstDim * kAstKeysPad * 2));
+    c->cap = nb;
+    return 0;
+}
+
+// one encoder over nb <= cap clips whose fbanks are at `fbank`
+int run_encoder(amuse_audio_ctx* c, const Encoder& E, const float* fbank, int nb, float* feat_out, float* hidden_out,
+                int tap_block, hipStream_t st) {
+    const int M = nb * kAstTokens;
+    HIP_TRY(launch_im2col(fbank, c->P, nb, st));
+    GemmArgs g{};
+    g.A = c->P; g.W = E.patch_w; g.bias = E.patch_b; g.M = nb * kAstPatches; g.N = kAstDim; g.K = 256;
+    g.out_f32 = c->X; g.pos = E.pos;
+    HIP_TRY(launch_gemm(g, EPI_PATCH, st));
+    HIP_TRY(launch_ast_tokens(E.cls, E.dist, E.pos, c->X, nb, st));
+    for (int l = 0; l < kAstLayers; ++l) {
+        const Block& b = E.blk[l];
+        HIP_TRY(launch_ln_bf16(c->X, b.n1w, b.n1b, 1e-6f, c->H, M, st));
+        g = GemmArgs{};
+        g.A = c->H; g.W = b.qkv_w; g.bias = b.qkv_b; g.M = M; g.N = 3 * kAstDim; g.K = kAstDim; g.out_bf16 = c->QK; g.vt = c->Vt;
+        HIP_TRY(launch_gemm(g, EPI_QKV, st));
+        HIP_TRY(launch_ast_attn(c->QK, c->Vt, c->O, nb, st));
+        g = GemmArgs{};
+        g.A = c->O; g.W = b.proj_w; g.bias = b.proj_b; g.M = M; g.N = kAstDim; g.K = kAstDim; g.out_f32 = c->X;
+        HIP_TRY(launch_gemm(g, EPI_RESID_F32, st));
+        HIP_TRY(launch_ln_bf16(c->X, b.n2w, b.n2b, 1e-6f, c->H, M, st));
+        g = GemmArgs{};
+        g.A = c->H; g.W = b.fc1_w; g.bias = b.fc1_b; g.M = M; g.N = kAstMlp; g.K = kAstDim; g.out_bf16 = c->F;
+        HIP_TRY(launch_gemm(g, EPI_GELU_BF16, st));
+        g = GemmArgs{};
+        g.A = c->F; g.W = b.fc2_w; g.bias = b.fc2_b; g.M = M; g.N = kAstDim; g.K = kAstMlp; g.out_f32 = c->X;
+        HIP_TRY(launch_gemm(g, EPI_RESID_F32, st));
+        if (hidden_out && l == tap_block)
+            HIP_TRY(hipMemcpyAsync(hidden_out, c->X, (size_t)M * kAstDim * 4, hipMemcpyDeviceToDevice, st));
+    }
+    HIP_TRY(launch_ast_pool(c->X, E.norm_w, E.norm_b, c->frame_based, c->pooled, nb, st));
+    HIP_TRY(launch_ast_head(c->pooled, E.fh_ln_w, E.fh_ln_b, E.fh_w, E.fh_b, feat_out, nb, st));
+    return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+amuse_audio_ctx* amuse_audio_create(int device, const float* con_params, const float* emo_params, const float* sty_params,
+                                    size_t n_each, const float* mel_banks, const float* window, float norm_mean,
+                                    float norm_std, int frame_based_feats) {
+    if (!con_params || !emo_params || !sty_params || !mel_banks || !window) {
+        failf(AMUSE_EINVAL, "NULL argument%s");
+        return nullptr;
+    }
+    if (n_each != AMUSE_AST_PARAMS) {
+        failf(AMUSE_EINVAL, "%sparameter count mismatch: %ld per encoder (want %ld)", "", (long)n_each, (long)AMUSE_AST_PARAMS);
+        return nullptr;
+    }
+    if (!(norm_std > 0.f)) {
+        failf(AMUSE_EINVAL, "norm_std must be positive%s");
+        return nullptr;
+    }
+    if (hipSetDevice(device) != hipSuccess) {
+        failf(AMUSE_EHIP, "hipSetDevice(%s%ld) failed", "", device);
+        return nullptr;
+    }
+    amuse_audio_ctx* c = new amuse_audio_ctx();
+    c->device = device;
+    c->frame_based = frame_based_feats ? 1 : 0;
+    c->norm_mean = norm_mean;
+    c->norm_std = norm_std;
+    const float* ps[3] = {con_params, emo_params, sty_params};
+    int rc = up_f32(c, &c->melw, mel_banks, (size_t)kAstMel * 257) || up_f32(c, &c->window, window, 400);
+    for (int e = 0; e < 3 && !rc; ++e) rc = build_encoder(c, c->enc[e], ps[e]);
+    if (rc) {
+        amuse_audio_destroy(c);
+        return nullptr;
+    }
+    return c;
+}
+
+void amuse_audio_destroy(amuse_audio_ctx* c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    for (void* p : c->owned) (void)hipFree(p);
+    void* ws[] = {c->X, c->fbank, c->pooled, c->H, c->QK, c->Vt, c->O, c->F, c->P};
+    for (void* p : ws)
+        if (p) (void)hipFree(p);
+    delete c;
+}
+
+int amuse_audio_fbank(amuse_audio_ctx* c, const float* waves, int n_samples, int B, float* fbank_out, void* stream) {
+    if (!c || !waves || !fbank_out) return failf(AMUSE_EINVAL, "NULL argument%s");
+    if (B < 1 || n_samples < 1) return failf(AMUSE_EINVAL, "%sB and n_samples must be >= 1 (got %ld, %ld)", "", B, n_samples);
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(launch_fbank(waves, n_samples, B, c->window, c->melw, c->norm_mean, c->norm_std, fbank_out, (hipStream_t)stream));
+    return 0;
+}
+
+int amuse_audio_encode(amuse_audio_ctx* c, int which, const float* fbank, int B, float* feat_out, float* hidden_out,
+                       int tap_block, void* stream) {
+    if (!c || !fbank || !feat_out) return failf(AMUSE_EINVAL, "NULL argument%s");
+    if (which < 0 || which > 2) return failf(AMUSE_EINVAL, "%sencoder index %ld not in 0..2", "", which);
+    if (B < 1) return failf(AMUSE_EINVAL, "%sB must be >= 1, got %ld", "", B);
+    if (hidden_out && (tap_block < 0 || tap_block >= kAstLayers)) return failf(AMUSE_EINVAL, "%stap_block %ld not in 0..11", "", tap_block);
+    HIP_TRY(hipSetDevice(c->device));
+    const int chunk = B < kChunk ? B : kChunk;
+    if (int e = ensure_ws(c, chunk)) return e;
+    for (int b0 = 0; b0 < B; b0 += chunk) {
+        const int nb = (B - b0) < chunk ? (B - b0) : chunk;
+        if (int e = run_encoder(c, c->enc[which], fbank + (size_t)b0 * kAstFrames * kAstMel, nb, feat_out + (size_t)b0 * kAstFeat,
+                                hidden_out ? hidden_out + (size_t)b0 * kAstTokens * kAstDim : nullptr, tap_block, (hipStream_t)stream))
+            return e;
+    }
+    return 0;
+}
+
+int amuse_audio_features(amuse_audio_ctx* c, const float* waves, int n_samples, int B, float* con_out, float* emo_out,
+                         float* sty_out, void* stream) {
+    if (!c || !waves) return failf(AMUSE_EINVAL, "NULL argument%s");
+    if (B < 1 || n_samples < 1) return failf(AMUSE_EINVAL, "%sB and n_samples must be >= 1 (got %ld, %ld)", "", B, n_samples);
+    HIP_TRY(hipSetDevice(c->device));
+    hipStream_t st = (hipStream_t)stream;
+    const int chunk = B < kChunk ? B : kChunk;
+    if (int e = ensure_ws(c, chunk)) return e;
+    float* outs[3] = {con_out, emo_out, sty_out};
+    for (int b0 = 0; b0 < B; b0 += chunk) {
+        const int nb = (B - b0) < chunk ? (B - b0) : chunk;
+        HIP_TRY(launch_fbank(waves + (size_t)b0 * n_samples, n_samples, nb, c->window, c->melw, c->norm_mean, c->norm_std, c->fbank, st));
+        for (int e = 0; e < 3; ++e)
+            if (outs[e])
+                if (int rc = run_encoder(c, c->enc[e], c->fbank, nb, outs[e] + (size_t)b0 * kAstFeat, nullptr, 0, st)) return rc;
+    }
+    return 0;
+}
+
+}  // extern "C"

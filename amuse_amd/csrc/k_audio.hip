@@ -1,0 +1,510 @@
+// Audio front-end: PretrainedLPDM_v1.process_single_seq (reference
+// models/latent_diffusion/infer_ldm.py:180-193) = kaldi fbank -> pad / normalise -> 3 x ASTModel.forward
+// (models/audio/audio_main_new.py:174-204: DeiT-B distilled ViT over 2 + 12 x 101 tokens) -> feature_head.
+// 260 GFLOP per encoder per clip - 37 x the 1000-step sampler - almost all of it in four GEMM shapes, so this file is
+// a conventional MFMA pipeline rather than the register-resident design of the sampler:
+//   k_fbank        one workgroup per frame: DC removal, pre-emphasis, Hann window, 512-point FFT in LDS, 128 mel bins
+//   k_im2col       16 x 16 stride-10 patches of the [128 x 1024] spectrogram as bf16 rows (K = 256)
+//   k_gemm_bf16    C = A . W^T (+ fused epilogue): 128 x 128 x 64 tiles, bf16 operands through padded LDS images that
+//                  are read back as ready MFMA fragments (one ds_read_b128 per operand), fp32 accumulation.
+//                  Weights are the A operand, so a lane ends up with 4 consecutive FEATURES of one token row: bias,
+//                  GELU, residual and the q / k / v^T split are applied in registers and stored 8 or 16 B wide.
+//   k_ln_bf16      LayerNorm of the fp32 residual stream -> bf16 GEMM operand (one wave per row)
+//   k_ast_attn     flash attention, S = 1214, d = 64: S^T = K.Q^T and O^T = V^T.P^T on v_mfma_f32_16x16x32_bf16 with
+//                  the softmax along registers (the layout of the S = 300 decoder attention, k_vae.hip), K and V^T
+//                  streamed through LDS in 64-key chunks; V is written TRANSPOSED by the qkv epilogue.
+//   k_ast_pool / k_ast_head   final LayerNorm + mean over the patch tokens, feature_head (LayerNorm + Linear 768 -> 256)
+// Arithmetic: bf16 GEMM / attention operands, fp32 accumulation, fp32 residual stream, LayerNorm, softmax and GELU.
+#include "amuse_dev.hpp"
+#include "amuse_audio.hpp"
+
+namespace amuse {
+namespace {
+
+typedef unsigned short bf16raw;
+__device__ __forceinline__ unsigned pack2(float a, float b) {
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{a, b}, bf16x2));
+}
+__device__ __forceinline__ uint2 pack4(f32x4 v) { return uint2{pack2(v[0], v[1]), pack2(v[2], v[3])}; }
+
+// ---------------------------------------------------------------------------------------------- fbank
+// grid (kAstFrames, B), 256 threads.  Frames beyond the waveform are the padding rows of infer_ldm.py:185-188.
+__global__ __launch_bounds__(256) void k_fbank(const float* __restrict__ wave, int n_samples, const float* __restrict__ window,
+                                               const float* __restrict__ melw /*[128][257]*/, float norm_mean, float inv_2std,
+                                               float* __restrict__ out /*[B][1024][128]*/) {
+    __shared__ float re[512], im[512], red[8];
+    const int f = blockIdx.x, b = blockIdx.y, t = threadIdx.x;
+    float* dst = out + ((size_t)b * kAstFrames + f) * kAstMel;
+    const int n_frames = n_samples < 400 ? 0 : 1 + (n_samples - 400) / 160;
+    if (f >= n_frames) {
+        if (t < kAstMel) dst[t] = (0.0f - norm_mean) * inv_2std;
+        return;
+    }
+    const float* src = wave + (size_t)b * n_samples + (size_t)f * 160;
+    const float x0 = t < 400 ? src[t] : 0.f, x1 = t + 256 < 400 ? src[t + 256] : 0.f;
+    float s = x0 + x1;
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    if ((t & 63) == 0) red[t >> 6] = s;
+    __syncthreads();
+    const float mean = ((red[0] + red[1]) + (red[2] + red[3])) * (1.0f / 400.0f);
+    re[t] = x0 - mean;
+    re[t + 256] = (t + 256 < 400) ? x1 - mean : 0.f;
+    __syncthreads();
+    // pre-emphasis against the previous sample (the first against itself), window, bit-reversed scatter for the FFT
+    float y[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int i = t + 256 * h;
+        y[h] = 0.f;
+        if (i < 400) y[h] = (re[i] - 0.97f * re[i > 0 ? i - 1 : 0]) * window[i];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int i = t + 256 * h;
+        const int r = __brev((unsigned)i) >> 23;   // 9-bit reversal
+        re[r] = y[h];
+        im[r] = 0.f;
+    }
+    __syncthreads();
+    for (int len = 2; len <= 512; len <<= 1) {
+        const int half = len >> 1, k = t & (half - 1), base = ((t - k) << 1) + k;
+        float sn, cs;
+        sincospif(-2.0f * (float)k / (float)len, &sn, &cs);
+        const float ur = re[base], ui = im[base], vr = re[base + half], vi = im[base + half];
+        const float tr = vr * cs - vi * sn, ti = vr * sn + vi * cs;
+        __syncthreads();
+        re[base] = ur + tr; im[base] = ui + ti;
+        re[base + half] = ur - tr; im[base + half] = ui - ti;
+        __syncthreads();
+    }
+    // power spectrum (bins 0..256) in place, then the mel filters
+    const float p0 = re[t] * re[t] + im[t] * im[t];
+    const float p256 = re[256] * re[256] + im[256] * im[256];
+    __syncthreads();
+    re[t] = p0;
+    if (t == 0) re[256] = p256;
+    __syncthreads();
+    if (t < kAstMel) {
+        const float* w = melw + (size_t)t * 257;
+        float e = 0.f;
+        for (int k = 0; k < 257; ++k) e += re[k] * w[k];
+        dst[t] = (logf(fmaxf(e, 1.1920929e-07f)) - norm_mean) * inv_2std;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------- im2col
+// patches[b * 1212 + fh * 101 + tw][kh * 16 + kw] = fbank[b][10 tw + kw][10 fh + kh]   (x.unsqueeze(1).transpose(2, 3)
+// then Conv2d(1, 768, 16, stride 10): audio_main_new.py:180-184, 92-96)
+__global__ __launch_bounds__(256) void k_im2col(const float* __restrict__ fbank, bf16raw* __restrict__ patches, int B) {
+    const size_t row = (size_t)blockIdx.x;           // b * 1212 + p
+    const int b = (int)(row / kAstPatches), p = (int)(row - (size_t)b * kAstPatches);
+    const int fh = p / kAstT, tw = p - fh * kAstT;
+    const int kh = threadIdx.x >> 4, kw = threadIdx.x & 15;
+    const float v = fbank[((size_t)b * kAstFrames + 10 * tw + kw) * kAstMel + 10 * fh + kh];
+    typedef __bf16 bf;
+    patches[row * 256 + threadIdx.x] = __builtin_bit_cast(bf16raw, (bf)v);
+}
+
+// cls / distillation rows of the token matrix (audio_main_new.py:185-188)
+__global__ __launch_bounds__(256) void k_ast_tokens(const float* __restrict__ cls, const float* __restrict__ dist,
+                                                    const float* __restrict__ pos, float* __restrict__ X) {
+    const int b = blockIdx.x;
+    for (int i = threadIdx.x; i < 2 * kAstDim; i += 256) {
+        const int r = i / kAstDim, c = i - r * kAstDim;
+        X[((size_t)b * kAstTokens + r) * kAstDim + c] = (r == 0 ? cls[c] : dist[c]) + pos[(size_t)r * kAstDim + c];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------- GEMM
+constexpr int BM = 128, BN = 128, BK = 64;
+constexpr int LDSK = BK + 8;                       // padded row (bf16 elements): 144 B, conflict-free ds_read_b128
+constexpr int kGemmLds = 2 * (BM + BN) * LDSK * 2; // double-buffered A and W tiles: 73,728 B
+
+template <int EPI>
+__global__ __launch_bounds__(256) void k_gemm_bf16(GemmArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    bf16raw* As = reinterpret_cast<bf16raw*>(smem);                    // [2][BM][LDSK]
+    bf16raw* Ws = As + 2 * BM * LDSK;                                  // [2][BN][LDSK]
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int g = lane >> 4, j = lane & 15;
+    const int wm = wave >> 1, wn = wave & 1;
+    // consecutive workgroups walk the N tiles of one M tile: they share the A rows through L2
+    const int tiles_n = a.N / BN;
+    const int tm_idx = blockIdx.x / tiles_n, tn_idx = blockIdx.x - tm_idx * tiles_n;
+    const size_t m0 = (size_t)tm_idx * BM;
+    const int n0 = tn_idx * BN;
+    const bf16raw* Ag = a.A + m0 * a.K;
+    const bf16raw* Wg = a.W + (size_t)n0 * a.K;
+    const int lr = t >> 3, lc = (t & 7) * 8;                          // this thread's 16 B: rows lr + 32 i, k lc..lc+7
+    const bf16raw* ag = Ag + (size_t)lr * a.K + lc;
+    const bf16raw* wg = Wg + (size_t)lr * a.K + lc;
+    const size_t rstep = (size_t)32 * a.K;
+    bf16raw* as = As + (size_t)lr * LDSK + lc;
+    bf16raw* ws = Ws + (size_t)lr * LDSK + lc;
+    uint4 ra0, ra1, ra2, ra3, rw0, rw1, rw2, rw3;
+#define GEMM_GLOAD(k0)                                                     \
+    ra0 = *reinterpret_cast<const uint4*>(ag + (k0));                      \
+    ra1 = *reinterpret_cast<const uint4*>(ag + rstep + (k0));              \
+    ra2 = *reinterpret_cast<const uint4*>(ag + 2 * rstep + (k0));          \
+    ra3 = *reinterpret_cast<const uint4*>(ag + 3 * rstep + (k0));          \
+    rw0 = *reinterpret_cast<const uint4*>(wg + (k0));                      \
+    rw1 = *reinterpret_cast<const uint4*>(wg + rstep + (k0));              \
+    rw2 = *reinterpret_cast<const uint4*>(wg + 2 * rstep + (k0));          \
+    rw3 = *reinterpret_cast<const uint4*>(wg + 3 * rstep + (k0));
+#define GEMM_SSTORE(buf)                                                               \
+    *reinterpret_cast<uint4*>(as + ((buf) * BM + 0) * LDSK) = ra0;                     \
+    *reinterpret_cast<uint4*>(as + ((buf) * BM + 32) * LDSK) = ra1;                    \
+    *reinterpret_cast<uint4*>(as + ((buf) * BM + 64) * LDSK) = ra2;                    \
+    *reinterpret_cast<uint4*>(as + ((buf) * BM + 96) * LDSK) = ra3;                    \
+    *reinterpret_cast<uint4*>(ws + ((buf) * BN + 0) * LDSK) = rw0;                     \
+    *reinterpret_cast<uint4*>(ws + ((buf) * BN + 32) * LDSK) = rw1;                    \
+    *reinterpret_cast<uint4*>(ws + ((buf) * BN + 64) * LDSK) = rw2;                    \
+    *reinterpret_cast<uint4*>(ws + ((buf) * BN + 96) * LDSK) = rw3;
+    f32x4 acc[4][4];   // [feature tile][token tile]: lane (g, j) holds features 4 g + m of token j
+#pragma unroll
+    for (int x = 0; x < 4; ++x)
+#pragma unroll
+        for (int y = 0; y < 4; ++y) acc[x][y] = splat4(0.f);
+    GEMM_GLOAD(0)
+    GEMM_SSTORE(0)
+    __syncthreads();
+    const int nk = a.K / BK;
+    for (int kt = 0; kt < nk; ++kt) {
+        const int buf = kt & 1;
+        const bool more = kt + 1 < nk;
+        if (more) { GEMM_GLOAD((kt + 1) * BK) }
+        const bf16raw* Ab = As + (size_t)buf * BM * LDSK + (size_t)(64 * wm + j) * LDSK + 8 * g;
+        const bf16raw* Wb = Ws + (size_t)buf * BN * LDSK + (size_t)(64 * wn + j) * LDSK + 8 * g;
+#pragma unroll
+        for (int s = 0; s < BK / 32; ++s) {
+            bf16x8 wf[4], af[4];
+#pragma unroll
+            for (int x = 0; x < 4; ++x) {
+                wf[x] = *reinterpret_cast<const bf16x8*>(Wb + (size_t)(16 * x) * LDSK + 32 * s);
+                af[x] = *reinterpret_cast<const bf16x8*>(Ab + (size_t)(16 * x) * LDSK + 32 * s);
+            }
+#pragma unroll
+            for (int x = 0; x < 4; ++x)
+#pragma unroll
+                for (int y = 0; y < 4; ++y) acc[x][y] = mfma_bf16(wf[x], af[y], acc[x][y]);
+        }
+        if (more) {
+            GEMM_SSTORE(buf ^ 1)   // the other buffer was last read before the previous barrier
+            __syncthreads();
+        }
+    }
+#undef GEMM_GLOAD
+#undef GEMM_SSTORE
+    // ---- epilogue: lane (g, j): token row m0 + 64 wm + 16 y + j, features n0 + 64 wn + 16 x + 4 g .. + 3
+#pragma unroll
+    for (int y = 0; y < 4; ++y) {
+        const size_t row = m0 + 64 * wm + 16 * y + j;
+        if (row >= (size_t)a.M) continue;
+#pragma unroll
+        for (int x = 0; x < 4; ++x) {
+            const int n = n0 + 64 * wn + 16 * x + 4 * g;
+            f32x4 v = acc[x][y] + ld4(a.bias + n);
+            if constexpr (EPI == EPI_BF16) {
+                *reinterpret_cast<uint2*>(a.out_bf16 + row * a.N + n) = pack4(v);
+            } else if constexpr (EPI == EPI_GELU_BF16) {
+#pragma unroll
+                for (int m = 0; m < 4; ++m) v[m] = gelu_erf_fast(v[m]);
+                *reinterpret_cast<uint2*>(a.out_bf16 + row * a.N + n) = pack4(v);
+            } else if constexpr (EPI == EPI_RESID_F32) {
+                float* p = a.out_f32 + row * a.N + n;
+                st4(p, ld4(p) + v);
+            } else if constexpr (EPI == EPI_F32) {
+                st4(a.out_f32 + row * a.N + n, v);
+            } else if constexpr (EPI == EPI_PATCH) {
+                // row = b * 1212 + p  ->  token row b * 1214 + 2 + p, + pos_embed[2 + p]
+                const size_t b = row / kAstPatches, p = row - b * kAstPatches;
+                st4(a.out_f32 + (b * kAstTokens + 2 + p) * kAstDim + n, v + ld4(a.pos + (2 + p) * kAstDim + n));
+            } else {  // EPI_QKV: q (pre-scaled by head_dim ** -0.5 = 1/8, exact in bf16) | k row-major, v transposed
+                if (n < kAstDim) {
+                    *reinterpret_cast<uint2*>(a.out_bf16 + row * (2 * kAstDim) + n) = pack4(v * 0.125f);
+                } else if (n < 2 * kAstDim) {
+                    *reinterpret_cast<uint2*>(a.out_bf16 + row * (2 * kAstDim) + n) = pack4(v);
+                } else {
+                    const size_t b = row / kAstTokens, tok = row - b * kAstTokens;
+                    const int hd = n - 2 * kAstDim;   // h * 64 + d
+                    typedef __bf16 bf;
+#pragma unroll
+                    for (int m = 0; m < 4; ++m)
+                        a.vt[((b * kAstDim) + hd + m) * kAstKeysPad + tok] = __builtin_bit_cast(bf16raw, (bf)v[m]);
+                }
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------- LayerNorm rows
+// one wave per row of 768: fp32 in -> bf16 out
+__global__ __launch_bounds__(256) void k_ln_bf16(const float* __restrict__ X, const float* __restrict__ gamma,
+                                                 const float* __restrict__ beta, float eps, bf16raw* __restrict__ out, int M) {
+    const int lane = threadIdx.x & 63;
+    const size_t row = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= (size_t)M) return;
+    const float* x = X + row * kAstDim;
+    f32x4 v[3];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        v[i] = ld4(x + 256 * i + 4 * lane);
+        s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
+    }
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    const float mean = s * (1.0f / kAstDim);
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            const float d = v[i][m] - mean;
+            q += d * d;
+        }
+    for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o);
+    const float rstd = 1.0f / sqrtf(q * (1.0f / kAstDim) + eps);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const f32x4 ga = ld4(gamma + 256 * i + 4 * lane), be = ld4(beta + 256 * i + 4 * lane);
+        f32x4 y;
+#pragma unroll
+        for (int m = 0; m < 4; ++m) y[m] = (v[i][m] - mean) * rstd * ga[m] + be[m];
+        *reinterpret_cast<uint2*>(out + row * kAstDim + 256 * i + 4 * lane) = pack4(y);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------- attention
+constexpr int kKc = 64;                 // keys per LDS chunk
+constexpr int kKS = 64 + 8;             // padded K row (bf16): 144 B
+constexpr int kVS = kKc + 8;            // padded V^T row (bf16): 144 B
+// grid (19 query blocks of 64, 12 heads, B); wave w owns the 16 queries 64 qb + 16 w ..
+__global__ __launch_bounds__(256) void k_ast_attn(const bf16raw* __restrict__ QK /*[M][1536]*/,
+                                                  const bf16raw* __restrict__ Vt /*[B][768][1216]*/,
+                                                  bf16raw* __restrict__ O /*[M][768]*/) {
+    __shared__ __attribute__((aligned(16))) bf16raw Ks[kKc * kKS];
+    __shared__ __attribute__((aligned(16))) bf16raw Vs[64 * kVS];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int g = lane >> 4, j = lane & 15;
+    const int qb = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
+    const size_t row0 = (size_t)b * kAstTokens;
+    const int q = 64 * qb + 16 * wave + j;
+    const bool qv = q < kAstTokens;
+    bf16x8 qf[2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        uint4 u = uint4{0, 0, 0, 0};
+        if (qv) u = *reinterpret_cast<const uint4*>(QK + (row0 + q) * (2 * kAstDim) + 64 * h + 32 * s + 8 * g);
+        qf[s] = __builtin_bit_cast(bf16x8, u);
+    }
+    float m_run = -INFINITY, l_run = 0.f;
+    f32x4 o[4] = {splat4(0.f), splat4(0.f), splat4(0.f), splat4(0.f)};
+    constexpr float kLog2e = 1.44269504088896340736f;
+    const int lr = t >> 3, lc = (t & 7) * 8;
+    const bf16raw* vsrc = Vt + ((size_t)b * kAstDim + 64 * h) * kAstKeysPad;
+    for (int k0 = 0; k0 < kAstKeysPad; k0 += kKc) {
+        __syncthreads();   // previous chunk fully consumed
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int key = k0 + lr + 32 * i;
+            uint4 u = uint4{0, 0, 0, 0};
+            if (key < kAstTokens) u = *reinterpret_cast<const uint4*>(QK + (row0 + key) * (2 * kAstDim) + kAstDim + 64 * h + lc);
+            *reinterpret_cast<uint4*>(Ks + (lr + 32 * i) * kKS + lc) = u;
+            // V^T rows d = lr + 32 i, keys k0 + lc .. + 7
+            *reinterpret_cast<uint4*>(Vs + (lr + 32 * i) * kVS + lc) =
+                *reinterpret_cast<const uint4*>(vsrc + (size_t)(lr + 32 * i) * kAstKeysPad + k0 + lc);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int pr = 0; pr < kKc / 32; ++pr) {   // pairs of 16-key tiles
+            f32x4 st[2];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const bf16raw* kr = Ks + (32 * pr + 16 * u + j) * kKS + 8 * g;
+                st[u] = mfma_bf16(*reinterpret_cast<const bf16x8*>(kr), qf[0], splat4(0.f));
+                st[u] = mfma_bf16(*reinterpret_cast<const bf16x8*>(kr + 32), qf[1], st[u]);
+            }
+            // lane (g, query j): S[j][key = k0 + 32 pr + 16 u + 4 g + m]
+            float mx = -INFINITY;
+            bool ok[2][4];
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int m = 0; m < 4; ++m) {
+                    ok[u][m] = (k0 + 32 * pr + 16 * u + 4 * g + m) < kAstTokens;
+                    st[u][m] *= kLog2e;
+                    mx = ok[u][m] ? fmaxf(mx, st[u][m]) : mx;
+                }
+            mx = allreduce_g_max(mx);
+            const float m_new = fmaxf(m_run, mx);
+            const float alpha = (m_new == -INFINITY) ? 1.0f : __builtin_amdgcn_exp2f(m_run - m_new);
+            f32x4 p[2];
+            float ps = 0.f;
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int m = 0; m < 4; ++m) {
+                    p[u][m] = ok[u][m] ? __builtin_amdgcn_exp2f(st[u][m] - m_new) : 0.f;
+                    ps += p[u][m];
+                }
+            ps = allreduce_g_sum(ps);
+            l_run = l_run * alpha + ps;
+            m_run = m_new;
+            const bf16x8 pb = pack_bf16(p[0], p[1]);   // k-slots (g, e): e < 4 -> tile 0 key 4 g + e, else tile 1 key 4 g + e - 4
+#pragma unroll
+            for (int td = 0; td < 4; ++td) {
+                // A operand lane (g, i = j): V^T[d = 16 td + j][same key permutation]
+                const bf16raw* vr = Vs + (16 * td + j) * kVS + 32 * pr + 4 * g;
+                const uint2 lo = *reinterpret_cast<const uint2*>(vr), hi = *reinterpret_cast<const uint2*>(vr + 16);
+                const bf16x8 vf = __builtin_bit_cast(bf16x8, uint4{lo.x, lo.y, hi.x, hi.y});
+                o[td] = mfma_bf16(vf, pb, o[td] * alpha);
+            }
+        }
+    }
+    if (qv) {
+        const float inv = 1.0f / l_run;
+#pragma unroll
+        for (int td = 0; td < 4; ++td)
+            *reinterpret_cast<uint2*>(O + (row0 + q) * kAstDim + 64 * h + 16 * td + 4 * g) = pack4(o[td] * inv);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------- pooling + head
+// v.norm on every token, then the mean over the 1212 patch tokens (frame_based_feats) or (cls + dist) / 2
+// grid (B), 256 threads = 4 waves striding over the rows; partial sums combined through LDS
+__global__ __launch_bounds__(256) void k_ast_pool(const float* __restrict__ X, const float* __restrict__ gamma,
+                                                  const float* __restrict__ beta, int frame_based, float* __restrict__ pooled) {
+    __shared__ float part[4][kAstDim];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, b = blockIdx.x;
+    const int r0 = frame_based ? 2 : 0, r1 = frame_based ? kAstTokens : 2;
+    f32x4 acc[3] = {splat4(0.f), splat4(0.f), splat4(0.f)};
+    f32x4 ga[3], be[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) { ga[i] = ld4(gamma + 256 * i + 4 * lane); be[i] = ld4(beta + 256 * i + 4 * lane); }
+    for (int r = r0 + wave; r < r1; r += 4) {
+        const float* x = X + ((size_t)b * kAstTokens + r) * kAstDim;
+        f32x4 v[3];
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) { v[i] = ld4(x + 256 * i + 4 * lane); s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]); }
+        for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+        const float mean = s * (1.0f / kAstDim);
+        float q = 0.f;
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int m = 0; m < 4; ++m) { const float d = v[i][m] - mean; q += d * d; }
+        for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o);
+        const float rstd = 1.0f / sqrtf(q * (1.0f / kAstDim) + 1e-6f);
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int m = 0; m < 4; ++m) acc[i][m] += (v[i][m] - mean) * rstd * ga[i][m] + be[i][m];
+    }
+#pragma unroll
+    for (int i = 0; i < 3; ++i) st4(&part[wave][256 * i + 4 * lane], acc[i]);
+    __syncthreads();
+    const float inv = 1.0f / (float)(r1 - r0);
+    for (int c = threadIdx.x; c < kAstDim; c += 256)
+        pooled[(size_t)b * kAstDim + c] = ((part[0][c] + part[1][c]) + (part[2][c] + part[3][c])) * inv;
+}
+
+// feature_head: LayerNorm(768, eps 1e-5) -> Linear(768 -> 256) with bf16-rounded operands, fp32 accumulation
+__global__ __launch_bounds__(256) void k_ast_head(const float* __restrict__ pooled, const float* __restrict__ gamma,
+                                                  const float* __restrict__ beta, const bf16raw* __restrict__ W /*[256][768]*/,
+                                                  const float* __restrict__ bias, float* __restrict__ out /*[B][256]*/) {
+    __shared__ float h[kAstDim];
+    __shared__ float red[2][4];
+    const int t = threadIdx.x, b = blockIdx.x;
+    const float* x = pooled + (size_t)b * kAstDim;
+    float v[3], s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) { v[i] = x[t + 256 * i]; s += v[i]; }
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    if ((t & 63) == 0) red[0][t >> 6] = s;
+    __syncthreads();
+    const float mean = ((red[0][0] + red[0][1]) + (red[0][2] + red[0][3])) * (1.0f / kAstDim);
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) { const float d = v[i] - mean; q += d * d; }
+    for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o);
+    if ((t & 63) == 0) red[1][t >> 6] = q;
+    __syncthreads();
+    const float rstd = 1.0f / sqrtf(((red[1][0] + red[1][1]) + (red[1][2] + red[1][3])) * (1.0f / kAstDim) + 1e-5f);
+    typedef __bf16 bf;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const int c = t + 256 * i;
+        h[c] = (float)(bf)((v[i] - mean) * rstd * gamma[c] + beta[c]);   // GEMM operand rounding
+    }
+    __syncthreads();
+    const bf16raw* w = W + (size_t)t * kAstDim;
+    float acc = 0.f;
+    for (int c = 0; c < kAstDim; c += 8) {
+        const bf16x8 wv = *reinterpret_cast<const bf16x8*>(w + c);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc += (float)wv[e] * h[c + e];
+    }
+    out[(size_t)b * kAstFeat + t] = acc + bias[t];
+}
+
+template <int EPI>
+hipError_t launch_gemm_t(const GemmArgs& a, hipStream_t s) {
+    static bool attr = false;
+    if (!attr) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_bf16<EPI>), hipFuncAttributeMaxDynamicSharedMemorySize, kGemmLds);
+        if (e != hipSuccess) return e;
+        attr = true;
+    }
+    const int tiles_m = (a.M + BM - 1) / BM;
+    hipLaunchKernelGGL(k_gemm_bf16<EPI>, dim3(tiles_m * (a.N / BN)), dim3(256), kGemmLds, s, a);
+    return hipGetLastError();
+}
+
+}  // namespace
+
+hipError_t launch_gemm(const GemmArgs& a, int epi, hipStream_t s) {
+    switch (epi) {
+        case EPI_BF16: return launch_gemm_t<EPI_BF16>(a, s);
+        case EPI_GELU_BF16: return launch_gemm_t<EPI_GELU_BF16>(a, s);
+        case EPI_RESID_F32: return launch_gemm_t<EPI_RESID_F32>(a, s);
+        case EPI_F32: return launch_gemm_t<EPI_F32>(a, s);
+        case EPI_PATCH: return launch_gemm_t<EPI_PATCH>(a, s);
+        default: return launch_gemm_t<EPI_QKV>(a, s);
+    }
+}
+hipError_t launch_fbank(const float* wave, int n_samples, int B, const float* window, const float* melw, float mean, float std,
+                        float* out, hipStream_t s) {
+    hipLaunchKernelGGL(k_fbank, dim3(kAstFrames, B), dim3(256), 0, s, wave, n_samples, window, melw, mean, 1.0f / (2.0f * std), out);
+    return hipGetLastError();
+}
+hipError_t launch_im2col(const float* fbank, unsigned short* patches, int B, hipStream_t s) {
+    hipLaunchKernelGGL(k_im2col, dim3(B * kAstPatches), dim3(256), 0, s, fbank, patches, B);
+    return hipGetLastError();
+}
+hipError_t launch_ast_tokens(const float* cls, const float* dist, const float* pos, float* X, int B, hipStream_t s) {
+    hipLaunchKernelGGL(k_ast_tokens, dim3(B), dim3(256), 0, s, cls, dist, pos, X);
+    return hipGetLastError();
+}
+hipError_t launch_ln_bf16(const float* X, const float* gamma, const float* beta, float eps, unsigned short* out, int M, hipStream_t s) {
+    hipLaunchKernelGGL(k_ln_bf16, dim3((M + 3) / 4), dim3(256), 0, s, X, gamma, beta, eps, out, M);
+    return hipGetLastError();
+}
+hipError_t launch_ast_attn(const unsigned short* QK, const unsigned short* Vt, unsigned short* O, int B, hipStream_t s) {
+    hipLaunchKernelGGL(k_ast_attn, dim3((kAstTokens + 63) / 64, kAstHeads, B), dim3(256), 0, s, QK, Vt, O);
+    return hipGetLastError();
+}
+hipError_t launch_ast_pool(const float* X, const float* gamma, const float* beta, int frame_based, float* pooled, int B, hipStream_t s) {
+    hipLaunchKernelGGL(k_ast_pool, dim3(B), dim3(256), 0, s, X, gamma, beta, frame_based, pooled);
+    return hipGetLastError();
+}
+hipError_t launch_ast_head(const float* pooled, const float* gamma, const float* beta, const unsigned short* W, const float* bias,
+                           float* out, int B, hipStream_t s) {
+    hipLaunchKernelGGL(k_ast_head, dim3(B), dim3(256), 0, s, pooled, gamma, beta, W, bias, out);
+    return hipGetLastError();
+}
+
+}  // namespace amuse

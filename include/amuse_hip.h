@@ -160,6 +160,43 @@ int amuse_profile_sample(amuse_ctx* ctx, const float* con, const float* emo, con
 /* Clips per 4-wave workgroup in the sampling kernel: 0 = auto, else 1..3 (x S tokens <= 16 rows). */
 int amuse_set_clips_per_group(amuse_ctx* ctx, int g);
 
+/* ------------------------------------------------------------------------------------------------
+ * Audio front-end: replaces PretrainedLPDM_v1.process_single_seq
+ * (models/latent_diffusion/infer_ldm.py:180-193) = torchaudio.compliance.kaldi.fbank -> zero-pad / crop to 1024
+ * frames -> (x - mean) / (2 std) -> Pretrained_AST_EVP.get_features (models/audio/infer_pretrained_ast_evp.py:42-46)
+ * -> AST_EVP.eval_func (AST_EVP.py:84-90): three ASTModel encoders (audio_main_new.py:174-204), 'feature' of each.
+ * bf16 GEMM / attention operands, fp32 accumulation and residual stream.
+ *
+ * Parameters: one flat fp32 array per encoder holding the forward-pass tensors of ASTModel in this order (timm 0.4.5
+ * DistilledVisionTransformer names): v.cls_token, v.dist_token, v.pos_embed [1214][768], v.patch_embed.proj.weight
+ * [768][1][16][16], .bias, then for blocks 0..11: norm1.weight, norm1.bias, attn.qkv.weight [2304][768], attn.qkv.bias,
+ * attn.proj.weight, attn.proj.bias, norm2.weight, norm2.bias, mlp.fc1.weight [3072][768], mlp.fc1.bias,
+ * mlp.fc2.weight [768][3072], mlp.fc2.bias; v.norm.weight, v.norm.bias, feature_head.0.weight, .bias,
+ * feature_head.1.weight [256][768], .bias   (AMUSE_AST_PARAMS floats). */
+typedef struct amuse_audio_ctx amuse_audio_ctx;
+#define AMUSE_AST_PARAMS 86385664u
+#define AMUSE_AUDIO_CON 0
+#define AMUSE_AUDIO_EMO 1
+#define AMUSE_AUDIO_STY 2
+/* mel_banks host [128][257], window host [400] (kaldi fbank tables: amuse_amd/audio.py builds them);
+ * norm_mean / norm_std = configs/base_new.json wav_dtw_mfcc.dataset_mean / dataset_std;
+ * frame_based_feats = wav_dtw_mfcc.frame_based_feats (mean over patch tokens) or 0 ((cls + dist) / 2). */
+amuse_audio_ctx* amuse_audio_create(int device, const float* con_params, const float* emo_params,
+                                    const float* sty_params, size_t n_each, const float* mel_banks,
+                                    const float* window, float norm_mean, float norm_std,
+                                    int frame_based_feats);
+void amuse_audio_destroy(amuse_audio_ctx* ctx);
+/* waves dev [B][n_samples] fp32 (16 kHz mono)  ->  fbank_out dev [B][1024][128], normalised and padded */
+int amuse_audio_fbank(amuse_audio_ctx* ctx, const float* waves, int n_samples, int B, float* fbank_out,
+                      void* stream);
+/* One encoder on prepared fbanks: feat_out dev [B][256]; hidden_out (nullable) dev [B][1214][768] receives the
+ * fp32 residual stream after block `tap_block` (0..11) for tests. */
+int amuse_audio_encode(amuse_audio_ctx* ctx, int which, const float* fbank, int B, float* feat_out,
+                       float* hidden_out, int tap_block, void* stream);
+/* process_single_seq for B waveforms: con_out / emo_out / sty_out dev [B][256] (each nullable) */
+int amuse_audio_features(amuse_audio_ctx* ctx, const float* waves, int n_samples, int B, float* con_out,
+                         float* emo_out, float* sty_out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
