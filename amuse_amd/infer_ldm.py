@@ -10,8 +10,9 @@ What is mirrored                                   reference
   _loader_helper_v1(motion, audio)                  infer_ldm.py:416-493 (motion half on the HIP path: 300-frame takes,
                                                     axis-angle -> 6D, MotionPrior.encode + rsample; the audio half
                                                     goes through the injected `audio_encoder`)
-What is NOT rebuilt (SURVEY.md section 8f "next"): the audio front-end (process_single_seq: kaldi fbank +
-3 x AST).  process_single_seq raises unless an `audio_encoder` callable is injected.
+  process_single_seq(wave)                          infer_ldm.py:180-193 (kaldi fbank + 3 x AST on the HIP path,
+                                                    amuse_amd/audio.py, when an AST checkpoint is present; an injected
+                                                    `audio_encoder` callable takes precedence)
 """
 from __future__ import annotations
 
@@ -24,6 +25,7 @@ import torch
 
 from . import checkpoint as ckpt
 from . import scheduler as sch
+from .audio import AudioEngine
 from .engine import HipEngine
 
 
@@ -32,6 +34,7 @@ class PretrainedLPDM_v1:
                  audio_encoder: Optional[Callable] = None):
         self.base_vae = base_prior      # kept for signature compatibility (scripts/main.py:217); unused
         self.audio_encoder = audio_encoder
+        self.audio_engine: Optional[AudioEngine] = None
         self.engine: Optional[HipEngine] = None
         self.precision = "fp32"         # "fp32" = parity mode, "bf16" = throughput mode
         self.sampler = "ddim"           # "ddim" (the reference's entry point) or "ddpm" (BASELINE configs 2/3)
@@ -70,7 +73,22 @@ class PretrainedLPDM_v1:
         print("[LDM] <===== Chosen LDM model based on total loss: ", lat, " =====>")
         print("[LATDIFF] <===== Chosen VAE model based on total loss: ", pri, " =====>")
         self._build(ckpt.load_denoiser_checkpoint(lat), ckpt.load_prior_checkpoint(pri), device)
+        # the audio encoders (infer_ldm.py:111-114): <saved-models>/<TRAIN_PARAM[tag].pretrained_ast>/*.pt
+        wd = config["TRAIN_PARAM"].get("wav_dtw_mfcc", {})
+        ast_name = ld.get("pretrained_ast")
+        if ast_name is not None and (root / saved / ast_name).is_dir():
+            audio_ablation = wd.get("ablation")
+            assert audio_ablation is not None, f"[LPDM EVAL] Audio ablation flag: {audio_ablation}"
+            best = ckpt.pick_ast_checkpoint(root / saved / ast_name, audio_ablation)
+            print("[LATDIFF] (2/3) <===== Chosen AST model: ", best, " , loading state dict... =====>")
+            sds = ckpt.load_ast_checkpoint(best)
+            self.set_audio_encoders(sds["con"], sds["emo"], sds["sty"], wd.get("dataset_mean", -9.173025),
+                                    wd.get("dataset_std", 5.062332), wd.get("frame_based_feats", True))
         return ldm_epoch
+
+    def set_audio_encoders(self, con_sd, emo_sd, sty_sd, norm_mean=-9.173025, norm_std=5.062332, frame_based_feats=True):
+        """Build the HIP audio front-end from three ASTModel state dicts (AST_EVP.{con,emo,sty}_enc)."""
+        self.audio_engine = AudioEngine(con_sd, emo_sd, sty_sd, self.device, norm_mean, norm_std, frame_based_feats)
 
     @classmethod
     def from_state_dicts(cls, denoiser_sd: Dict[str, np.ndarray], prior_sd: Dict[str, np.ndarray],
@@ -121,13 +139,15 @@ class PretrainedLPDM_v1:
         return {"poses": out["poses"], "trans": out["trans"], "latents": out["latents"]}
 
     def process_single_seq(self, sliced_chunk, framerate=16000 // 2, baseline=False):
-        """(con, emo, sty), each (1,256) (infer_ldm.py:180-193).  The fbank + 3 x AST front-end is outside the
-        path this library rebuilds; inject `audio_encoder(wave) -> (con, emo, sty)` to use it."""
-        if self.audio_encoder is None:
-            raise NotImplementedError("audio front-end (models/audio AST_EVP) is not part of the HIP hot path; "
-                                      "pass audio_encoder=... or feed precomputed embeddings")
-        con, emo, sty = self.audio_encoder(sliced_chunk)
-        return con.reshape(1, -1), emo.reshape(1, -1), sty.reshape(1, -1)
+        """(con, emo, sty), each (1,256) (infer_ldm.py:180-193): kaldi fbank -> pad / normalise -> 3 x AST on the HIP
+        path.  `sliced_chunk` is the (C, n) float waveform the reference hands to kaldi.fbank (channel 0 is used)."""
+        if self.audio_encoder is not None:
+            con, emo, sty = self.audio_encoder(sliced_chunk)
+            return con.reshape(1, -1), emo.reshape(1, -1), sty.reshape(1, -1)
+        if self.audio_engine is None:
+            raise NotImplementedError("no audio encoders loaded: setup() found no AST checkpoint; call "
+                                      "set_audio_encoders(...), pass audio_encoder=..., or feed precomputed embeddings")
+        return self.audio_engine.process_single_seq(sliced_chunk, framerate, baseline)
 
     def motion_to_latent(self, motion, sample: bool = True, clip_index0: Optional[int] = None):
         """The motion half of _loader_helper_v1 (infer_ldm.py:453-465): `motion` (frames, 168) = 55 x 3 SMPL-X
@@ -155,10 +175,19 @@ class PretrainedLPDM_v1:
     def _loader_helper_v1(self, motion, audio):
         """-> {"z_motion", "z_con", "z_emo", "z_sty"} (infer_ldm.py:416-493).  `audio` is whatever the injected
         audio_encoder accepts; it returns (con, emo, sty), each (takes_audio, 256) or None."""
-        if self.audio_encoder is None:
-            raise NotImplementedError("audio front-end (models/audio AST_EVP) is not part of the HIP hot path; "
-                                      "pass audio_encoder=... or call motion_to_latent for the motion half")
-        con, emo, sty = self.audio_encoder(audio)
+        if self.audio_encoder is not None:
+            con, emo, sty = self.audio_encoder(audio)
+        elif self.audio_engine is not None:
+            # infer_ldm.py:418-438: audio (C, n) -> n // 160000 chunks.  NB the reference slices audio[:, k:k+160000]
+            # - chunk k starts at SAMPLE k, not at k * 160000 - and that is what is reproduced here.
+            a = torch.as_tensor(audio)
+            chunks = [a[0, k:k + 160000] for k in range(a.shape[1] // 160000)]
+            if not chunks:
+                raise RuntimeError("stack expects a non-empty TensorList")   # torch.stack([]) at infer_ldm.py:436
+            con, emo, sty = self.audio_engine.features(torch.stack(chunks))
+        else:
+            raise NotImplementedError("no audio encoders loaded: call set_audio_encoders(...), pass audio_encoder=..., "
+                                      "or call motion_to_latent for the motion half")
         z = self.motion_to_latent(motion)
         n = z.shape[0]
         return {"z_motion": z, "z_con": con[:n], "z_emo": emo[:n] if emo is not None else None,

@@ -90,3 +90,30 @@ def test_features_batch_and_contract(env):
     assert float((eng.encode("sty", fb).cpu() - ref).abs().max()) < 5e-2 * float(ref.abs().max())
     with pytest.raises(ValueError):
         eng.encode("con", torch.zeros(1, 1000, 128))
+
+
+def test_host_mirror_process_single_seq_and_loader_helper(env):
+    """PretrainedLPDM_v1.process_single_seq / _loader_helper_v1 drive the HIP audio path (infer_ldm.py:180-193, 416-493)."""
+    from amuse_amd import audio_weights as aw, weights as wts
+    from amuse_amd.infer_ldm import PretrainedLPDM_v1
+    eng = env["eng"]
+    m = PretrainedLPDM_v1.from_state_dicts(wts.make_denoiser_weights(0), wts.make_prior_weights(0), device="cuda:0")
+    wave = _waves(160000 * 2 + 5000, 1, seed=21)                       # (C = 1, n)
+    with pytest.raises(NotImplementedError):
+        m.process_single_seq(wave)
+    m.audio_engine = eng                                               # what set_audio_encoders builds
+    con, emo, sty = m.process_single_seq(wave)
+    assert con.shape == emo.shape == sty.shape == (1, 256)
+    ref = eng.features(wave[0][None])
+    assert torch.equal(con, ref[0]) and torch.equal(sty, ref[2])
+    # the result feeds diffusion_backward unchanged
+    out = m.diffusion_backward(1, con, emo, sty)
+    assert out["poses"].shape == (1, 300, 55, 3) and bool(torch.isfinite(out["poses"]).all())
+    # _loader_helper_v1: n // 160000 chunks, chunk k starting at SAMPLE k (the reference's slicing, infer_ldm.py:421)
+    motion = torch.cat([0.3 * torch.randn(600, 165), torch.randn(600, 3)], -1)
+    z = m._loader_helper_v1(motion, wave)
+    assert z["z_motion"].shape == (2, 128) and z["z_con"].shape == (2, 256)
+    c0 = eng.features(wave[0, 0:160000][None])[0]
+    c1 = eng.features(wave[0, 1:160001][None])[0]
+    assert torch.equal(z["z_con"][0], c0[0]) and torch.equal(z["z_con"][1], c1[0])
+    m.audio_engine = None                                              # the fixture owns the engine

@@ -132,3 +132,35 @@ def test_process_loader_swaps_like_the_reference():
     assert out["style_transfer"]["ayana"]["t"]["ld_z_emo_scott"] == 22
     with pytest.raises(NotImplementedError):
         m.process_single_seq(torch.zeros(1, 160000))
+
+
+def test_ast_checkpoint_choice_and_reader(tmp_path, monkeypatch):
+    """infer_pretrained_ast_evp.py:21-39: best emotion accuracy (person accuracy for the identity ablation), epoch-0
+    winners replaced by the first `_1_` file; the state dict is the checkpoint itself, keys `<enc>_enc.<name>`."""
+    from collections import OrderedDict
+
+    import torch
+
+    from amuse_amd import audio_weights as aw, checkpoint as ckpt
+    d = tmp_path / "wav_dtw_mfcc_x"
+    d.mkdir()
+    for name in ("model_e3_loss0.5_tEAcc0.71_tPAcc0.95.pt", "model_e7_loss0.4_tEAcc0.83_tPAcc0.60.pt", "experiment_args.json"):
+        (d / name).write_bytes(b"")
+    assert ckpt.pick_ast_checkpoint(d, "full").name.startswith("model_e7")
+    assert ckpt.pick_ast_checkpoint(d, "identity").name.startswith("model_e3")
+    (d / "model_e0_loss0.9_tEAcc0.99_tPAcc0.10.pt").write_bytes(b"")
+    (d / "model_1_loss0.8_tEAcc0.20_tPAcc0.20.pt").write_bytes(b"")
+    assert "_1_" in ckpt.pick_ast_checkpoint(d, "full").name
+    with pytest.raises(AssertionError):
+        ckpt.pick_ast_checkpoint(d, "bogus")
+    tiny = OrderedDict([("v.cls_token", (1, 1, 4)), ("feature_head.1.weight", (2, 4))])
+    monkeypatch.setattr(aw, "ast_param_spec", lambda: tiny)
+    sds = {e: {k: np.full(s, i, np.float32) for k, s in tiny.items()} for i, e in enumerate(aw.ENCODERS)}
+    path = ckpt.save_ast_reference_format(tmp_path / "out", sds)
+    back = ckpt.load_ast_checkpoint(path)
+    assert set(back) == {"con", "emo", "sty"} and float(back["sty"]["v.cls_token"].max()) == 2.0
+    sd = torch.load(path, weights_only=False)
+    del sd["emo_enc.v.cls_token"]
+    torch.save(sd, path)
+    with pytest.raises(KeyError):
+        ckpt.load_ast_checkpoint(path)
