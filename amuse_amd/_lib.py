@@ -21,6 +21,7 @@ EXPORTS = [
     "amuse_sample", "amuse_denoise_step", "amuse_vae_decode", "amuse_vae_encode", "amuse_smplx_to_feats", "amuse_diffusion_backward",
     "amuse_counter_normal", "amuse_set_clips_per_group", "amuse_profile_sample",
     "amuse_audio_create", "amuse_audio_destroy", "amuse_audio_fbank", "amuse_audio_encode", "amuse_audio_features",
+    "amuse_debug_gemm",
 ]
 
 
@@ -74,7 +75,8 @@ def load() -> C.CDLL:
     lib.amuse_audio_fbank.argtypes = [vp, fp, C.c_int, C.c_int, fp, vp]
     lib.amuse_audio_encode.argtypes = [vp, C.c_int, fp, C.c_int, fp, fp, C.c_int, vp]
     lib.amuse_audio_features.argtypes = [vp, fp, C.c_int, C.c_int, fp, fp, fp, vp]
-    for n in ("amuse_audio_fbank", "amuse_audio_encode", "amuse_audio_features"):
+    lib.amuse_debug_gemm.argtypes = [vp, vp, fp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp]
+    for n in ("amuse_audio_fbank", "amuse_audio_encode", "amuse_audio_features", "amuse_debug_gemm"):
         getattr(lib, n).restype = C.c_int
     if lib.amuse_abi_version() != ABI_VERSION:
         raise AmuseHipError(f"ABI mismatch: library {lib.amuse_abi_version()} vs binding {ABI_VERSION}")

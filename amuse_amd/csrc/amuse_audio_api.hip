@@ -258,4 +258,16 @@ int amuse_audio_features(amuse_audio_ctx* c, const float* waves, int n_samples, 
     return 0;
 }
 
+// GEMM in isolation (tools/gpu_gemm_bench.py, tests): C = A . W^T + bias with epilogue 0 (bf16 out) or 3 (fp32 out);
+// A dev bf16 [M padded to 128][K], W dev bf16 [N][K]
+int amuse_debug_gemm(const void* A, const void* W, const float* bias, int M, int N, int K, int epi, void* out, void* stream) {
+    if (!A || !W || !bias || !out) return failf(AMUSE_EINVAL, "NULL argument%s");
+    if (N % 128 || K % 64 || (epi != EPI_BF16 && epi != EPI_F32)) return failf(AMUSE_EINVAL, "%sbad GEMM shape / epilogue (N %ld K %ld)", "", N, K);
+    GemmArgs g{};
+    g.A = (const unsigned short*)A; g.W = (const unsigned short*)W; g.bias = bias; g.M = M; g.N = N; g.K = K;
+    g.out_bf16 = (unsigned short*)out; g.out_f32 = (float*)out;
+    HIP_TRY(launch_gemm(g, epi, (hipStream_t)stream));
+    return 0;
+}
+
 }  // extern "C"

@@ -131,29 +131,28 @@ __global__ __launch_bounds__(256) void k_gemm_bf16(GemmArgs a) {
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int g = lane >> 4, j = lane & 15;
     const int wm = wave >> 1, wn = wave & 1;
-    // consecutive workgroups walk the N tiles of one M tile: they share the A rows through L2
+    // PERSISTENT: workgroup w computes output tiles w, w + gridDim.x, ... and the k-tile pipeline (global -> registers
+    // -> LDS, one tile ahead) runs straight across output-tile boundaries, so only the first tile of a workgroup pays
+    // the load round trip in the open and every epilogue overlaps the next tile's loads.  With K = 768 a tile is just
+    // 12 k-tiles (~3 us): one workgroup per tile spent as long filling its pipeline as computing.
+    // Consecutive tile indices walk the N tiles of one M tile: concurrent workgroups share the A rows through L2.
     const int tiles_n = a.N / BN;
-    const int tm_idx = blockIdx.x / tiles_n, tn_idx = blockIdx.x - tm_idx * tiles_n;
-    const size_t m0 = (size_t)tm_idx * BM;
-    const int n0 = tn_idx * BN;
-    const bf16raw* Ag = a.A + m0 * a.K;
-    const bf16raw* Wg = a.W + (size_t)n0 * a.K;
+    const int n_tiles = ((a.M + BM - 1) / BM) * tiles_n;
+    const int nk = a.K / BK;
     const int lr = t >> 3, lc = (t & 7) * 8;                          // this thread's 16 B: rows lr + 32 i, k lc..lc+7
-    const bf16raw* ag = Ag + (size_t)lr * a.K + lc;
-    const bf16raw* wg = Wg + (size_t)lr * a.K + lc;
     const size_t rstep = (size_t)32 * a.K;
     bf16raw* as = As + (size_t)lr * LDSK + lc;
     bf16raw* ws = Ws + (size_t)lr * LDSK + lc;
     uint4 ra0, ra1, ra2, ra3, rw0, rw1, rw2, rw3;
-#define GEMM_GLOAD(k0)                                                     \
-    ra0 = *reinterpret_cast<const uint4*>(ag + (k0));                      \
-    ra1 = *reinterpret_cast<const uint4*>(ag + rstep + (k0));              \
-    ra2 = *reinterpret_cast<const uint4*>(ag + 2 * rstep + (k0));          \
-    ra3 = *reinterpret_cast<const uint4*>(ag + 3 * rstep + (k0));          \
-    rw0 = *reinterpret_cast<const uint4*>(wg + (k0));                      \
-    rw1 = *reinterpret_cast<const uint4*>(wg + rstep + (k0));              \
-    rw2 = *reinterpret_cast<const uint4*>(wg + 2 * rstep + (k0));          \
-    rw3 = *reinterpret_cast<const uint4*>(wg + 3 * rstep + (k0));
+#define GEMM_GLOAD(ag, wg)                                                 \
+    ra0 = *reinterpret_cast<const uint4*>(ag);                             \
+    ra1 = *reinterpret_cast<const uint4*>(ag + rstep);                     \
+    ra2 = *reinterpret_cast<const uint4*>(ag + 2 * rstep);                 \
+    ra3 = *reinterpret_cast<const uint4*>(ag + 3 * rstep);                 \
+    rw0 = *reinterpret_cast<const uint4*>(wg);                             \
+    rw1 = *reinterpret_cast<const uint4*>(wg + rstep);                     \
+    rw2 = *reinterpret_cast<const uint4*>(wg + 2 * rstep);                 \
+    rw3 = *reinterpret_cast<const uint4*>(wg + 3 * rstep);
 #define GEMM_SSTORE(buf)                                                               \
     *reinterpret_cast<uint4*>(as + ((buf) * BM + 0) * LDSK) = ra0;                     \
     *reinterpret_cast<uint4*>(as + ((buf) * BM + 32) * LDSK) = ra1;                    \
@@ -163,41 +162,58 @@ __global__ __launch_bounds__(256) void k_gemm_bf16(GemmArgs a) {
     *reinterpret_cast<uint4*>(ws + ((buf) * BN + 32) * LDSK) = rw1;                    \
     *reinterpret_cast<uint4*>(ws + ((buf) * BN + 64) * LDSK) = rw2;                    \
     *reinterpret_cast<uint4*>(ws + ((buf) * BN + 96) * LDSK) = rw3;
-    f32x4 acc[4][4];   // [feature tile][token tile]: lane (g, j) holds features 4 g + m of token j
-#pragma unroll
-    for (int x = 0; x < 4; ++x)
-#pragma unroll
-        for (int y = 0; y < 4; ++y) acc[x][y] = splat4(0.f);
-    GEMM_GLOAD(0)
+    int tile = blockIdx.x;
+    if (tile >= n_tiles) return;
+    auto a_ptr = [&](int tl) { return a.A + ((size_t)(tl / tiles_n) * BM + lr) * a.K + lc; };
+    auto w_ptr = [&](int tl) { return a.W + ((size_t)(tl % tiles_n) * BN + lr) * a.K + lc; };
+    const bf16raw* ag = a_ptr(tile);
+    const bf16raw* wg = w_ptr(tile);
+    GEMM_GLOAD(ag, wg)
     GEMM_SSTORE(0)
     __syncthreads();
-    const int nk = a.K / BK;
-    for (int kt = 0; kt < nk; ++kt) {
-        const int buf = kt & 1;
-        const bool more = kt + 1 < nk;
-        if (more) { GEMM_GLOAD((kt + 1) * BK) }
-        const bf16raw* Ab = As + (size_t)buf * BM * LDSK + (size_t)(64 * wm + j) * LDSK + 8 * g;
-        const bf16raw* Wb = Ws + (size_t)buf * BN * LDSK + (size_t)(64 * wn + j) * LDSK + 8 * g;
+    int buf = 0;
+    while (true) {
+        const int tm_idx = tile / tiles_n, tn_idx = tile - tm_idx * tiles_n;
+        const size_t m0 = (size_t)tm_idx * BM;
+        const int n0 = tn_idx * BN;
+        const int next_tile = tile + gridDim.x;
+        const bool have_next = next_tile < n_tiles;
+        f32x4 acc[4][4];   // [feature tile][token tile]: lane (g, j) holds features 4 g + m of token j
 #pragma unroll
-        for (int s = 0; s < BK / 32; ++s) {
-            bf16x8 wf[4], af[4];
+        for (int x = 0; x < 4; ++x)
 #pragma unroll
-            for (int x = 0; x < 4; ++x) {
-                wf[x] = *reinterpret_cast<const bf16x8*>(Wb + (size_t)(16 * x) * LDSK + 32 * s);
-                af[x] = *reinterpret_cast<const bf16x8*>(Ab + (size_t)(16 * x) * LDSK + 32 * s);
+            for (int y = 0; y < 4; ++y) acc[x][y] = splat4(0.f);
+#pragma unroll 1
+        for (int kt = 0; kt < nk; ++kt) {
+            // the k-tile after this one: the next of this output tile, or the first of the next output tile
+            const bool last = kt + 1 == nk;
+            const bool more = !last || have_next;
+            if (more) {
+                const bf16raw* an = last ? a_ptr(next_tile) : ag + (kt + 1) * BK;
+                const bf16raw* wn_ = last ? w_ptr(next_tile) : wg + (kt + 1) * BK;
+                GEMM_GLOAD(an, wn_)
             }
+            const bf16raw* Ab = As + (size_t)buf * BM * LDSK + (size_t)(64 * wm + j) * LDSK + 8 * g;
+            const bf16raw* Wb = Ws + (size_t)buf * BN * LDSK + (size_t)(64 * wn + j) * LDSK + 8 * g;
 #pragma unroll
-            for (int x = 0; x < 4; ++x)
+            for (int s = 0; s < BK / 32; ++s) {
+                bf16x8 wf[4], af[4];
 #pragma unroll
-                for (int y = 0; y < 4; ++y) acc[x][y] = mfma_bf16(wf[x], af[y], acc[x][y]);
+                for (int x = 0; x < 4; ++x) {
+                    wf[x] = *reinterpret_cast<const bf16x8*>(Wb + (size_t)(16 * x) * LDSK + 32 * s);
+                    af[x] = *reinterpret_cast<const bf16x8*>(Ab + (size_t)(16 * x) * LDSK + 32 * s);
+                }
+#pragma unroll
+                for (int x = 0; x < 4; ++x)
+#pragma unroll
+                    for (int y = 0; y < 4; ++y) acc[x][y] = mfma_bf16(wf[x], af[y], acc[x][y]);
+            }
+            if (more) {
+                GEMM_SSTORE(buf ^ 1)   // the other buffer was last read before the previous barrier
+                __syncthreads();
+                buf ^= 1;
+            }
         }
-        if (more) {
-            GEMM_SSTORE(buf ^ 1)   // the other buffer was last read before the previous barrier
-            __syncthreads();
-        }
-    }
-#undef GEMM_GLOAD
-#undef GEMM_SSTORE
     // ---- epilogue: lane (g, j): token row m0 + 64 wm + 16 y + j, features n0 + 64 wn + 16 x + 4 g .. + 3
 #pragma unroll
     for (int y = 0; y < 4; ++y) {
@@ -238,6 +254,13 @@ __global__ __launch_bounds__(256) void k_gemm_bf16(GemmArgs a) {
             }
         }
     }
+        if (!have_next) break;
+        tile = next_tile;
+        ag = a_ptr(tile);
+        wg = w_ptr(tile);
+    }
+#undef GEMM_GLOAD
+#undef GEMM_SSTORE
 }
 
 // ---------------------------------------------------------------------------------------------- LayerNorm rows
@@ -459,8 +482,9 @@ hipError_t launch_gemm_t(const GemmArgs& a, hipStream_t s) {
         if (e != hipSuccess) return e;
         attr = true;
     }
-    const int tiles_m = (a.M + BM - 1) / BM;
-    hipLaunchKernelGGL(k_gemm_bf16<EPI>, dim3(tiles_m * (a.N / BN)), dim3(256), kGemmLds, s, a);
+    const int n_tiles = ((a.M + BM - 1) / BM) * (a.N / BN);
+    const int resident = 2 * 256;   // two 72 KiB workgroups per CU, 256 CUs: one persistent workgroup per slot
+    hipLaunchKernelGGL(k_gemm_bf16<EPI>, dim3(n_tiles < resident ? n_tiles : resident), dim3(256), kGemmLds, s, a);
     return hipGetLastError();
 }
 

@@ -197,6 +197,12 @@ int amuse_audio_encode(amuse_audio_ctx* ctx, int which, const float* fbank, int 
 int amuse_audio_features(amuse_audio_ctx* ctx, const float* waves, int n_samples, int B, float* con_out,
                          float* emo_out, float* sty_out, void* stream);
 
+/* The front-end's GEMM kernel in isolation, for tests and tools/gpu_gemm_bench.py: out = A . W^T + bias,
+ * A dev bf16 [M rounded up to 256][K], W dev bf16 [N][K] (N % 256 == 0, K % 64 == 0), epi 0: out dev bf16 [M][N],
+ * epi 3: out dev fp32 [M][N]. */
+int amuse_debug_gemm(const void* A, const void* W, const float* bias, int M, int N, int K, int epi,
+                     void* out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,37 @@
+"""k_gemm_bf16 in isolation against torch.matmul (hipBLASLt): correctness and TFLOP/s on the audio front-end's shapes."""
+import ctypes as C
+import sys
+from pathlib import Path
+import torch
+sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
+from amuse_amd import _lib
+lib = _lib.load()
+M = 32 * 1214
+Mp = (M + 255) // 256 * 256
+p = lambda t: C.c_void_p(t.data_ptr())
+for (N, K) in ((2304, 768), (768, 768), (3072, 768), (768, 3072)):
+    a = torch.zeros(Mp, K, device="cuda", dtype=torch.bfloat16)
+    a[:M] = torch.randn(M, K, device="cuda").to(torch.bfloat16)
+    w = (0.05 * torch.randn(N, K, device="cuda")).to(torch.bfloat16)
+    bias = torch.randn(N, device="cuda")
+    out = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
+    _lib.check(lib.amuse_debug_gemm(p(a), p(w), p(bias), M, N, K, 0, p(out), None))
+    ref = (a[:M].float() @ w.float().T + bias)
+    err = float((out.float() - ref).abs().max() / ref.abs().max())
+    for _ in range(3):
+        lib.amuse_debug_gemm(p(a), p(w), p(bias), M, N, K, 0, p(out), None)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(20):
+        lib.amuse_debug_gemm(p(a), p(w), p(bias), M, N, K, 0, p(out), None)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / 20
+    e0.record()
+    for _ in range(20):
+        (a[:M] @ w.T)
+    e1.record()
+    torch.cuda.synchronize()
+    ms_t = e0.elapsed_time(e1) / 20
+    print(f"N={N:5d} K={K:5d}: {ms*1e3:7.1f} us {2*M*N*K/ms/1e9:7.1f} TFLOP/s   (torch {ms_t*1e3:7.1f} us {2*M*N*K/ms_t/1e9:7.1f})   rel err {err:.2e}", flush=True)
