@@ -105,6 +105,7 @@ def main():
     ap.add_argument("--T", type=int, default=1000, help="DDPM steps")
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-audio", action="store_true", help="skip the audio front-end side measurement")
     args = ap.parse_args()
 
     import torch
@@ -222,6 +223,29 @@ def main():
         line["saturating_point"] = {"clips_per_gpu": Bs, "frames_per_s": round(Bs * 300 / min(ts), 1),
                                     "ms_per_job": round(min(ts) * 1e3, 3)}
         del cs, es, ss, outs
+        if world == 1 and not args.no_audio:
+            # side measurement, not part of `value` (whose inputs are the three 256-d embeddings): the
+            # audio front-end that produces them from 10 s of 16 kHz audio - kaldi fbank + 3 x AST, 778 GFLOP per clip
+            from amuse_amd import audio_weights as aw
+            from amuse_amd.audio import AudioEngine
+            aeng = AudioEngine(*(aw.make_ast_weights(0, n) for n in aw.ENCODERS), device=dev)
+            Ba = 32
+            wav = 0.1 * torch.randn(Ba, 160000, generator=gen).to(dev)
+            ta = []
+            for i in range(3):
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                aeng.features(wav)
+                torch.cuda.synchronize()
+                if i >= 1:
+                    ta.append(time.perf_counter() - t1)
+            flop = 3 * 12 * (2 * 1214 * 768 * (2304 + 768 + 2 * 3072) + 4 * 1214 * 1214 * 768)
+            ms_clip = min(ta) * 1e3 / Ba
+            line["audio_frontend"] = {"clips": Ba, "ms_per_clip": round(ms_clip, 3),
+                                      "tflops": round(flop / (ms_clip * 1e-3) / 1e12, 1),
+                                      "frames_per_s_wav_to_smplx": round(300.0 / (ms_clip * 1e-3 + elapsed / args.steps / B), 1)}
+            aeng.close()
+            del aeng, wav
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(B, args.T, wd, wp)
     barrier()
