@@ -124,7 +124,7 @@ constexpr int LDSK = BK + 8;                       // padded row (bf16 elements)
 constexpr int kGemmLds = 2 * (BM + BN) * LDSK * 2; // double-buffered A and W tiles: 73,728 B
 
 template <int EPI>
-__global__ __launch_bounds__(256) void k_gemm_bf16(GemmArgs a) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_gemm_bf16(GemmArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     bf16raw* As = reinterpret_cast<bf16raw*>(smem);                    // [2][BM][LDSK]
     bf16raw* Ws = As + 2 * BM * LDSK;                                  // [2][BN][LDSK]
@@ -143,113 +143,138 @@ __global__ __launch_bounds__(256) void k_gemm_bf16(GemmArgs a) {
     const size_t rstep = (size_t)32 * a.K;
     bf16raw* as = As + (size_t)lr * LDSK + lc;
     bf16raw* ws = Ws + (size_t)lr * LDSK + lc;
-    uint4 ra0, ra1, ra2, ra3, rw0, rw1, rw2, rw3;
-#define GEMM_GLOAD(ag, wg)                                                 \
-    ra0 = *reinterpret_cast<const uint4*>(ag);                             \
-    ra1 = *reinterpret_cast<const uint4*>(ag + rstep);                     \
-    ra2 = *reinterpret_cast<const uint4*>(ag + 2 * rstep);                 \
-    ra3 = *reinterpret_cast<const uint4*>(ag + 3 * rstep);                 \
-    rw0 = *reinterpret_cast<const uint4*>(wg);                             \
-    rw1 = *reinterpret_cast<const uint4*>(wg + rstep);                     \
-    rw2 = *reinterpret_cast<const uint4*>(wg + 2 * rstep);                 \
-    rw3 = *reinterpret_cast<const uint4*>(wg + 3 * rstep);
-#define GEMM_SSTORE(buf)                                                               \
-    *reinterpret_cast<uint4*>(as + ((buf) * BM + 0) * LDSK) = ra0;                     \
-    *reinterpret_cast<uint4*>(as + ((buf) * BM + 32) * LDSK) = ra1;                    \
-    *reinterpret_cast<uint4*>(as + ((buf) * BM + 64) * LDSK) = ra2;                    \
-    *reinterpret_cast<uint4*>(as + ((buf) * BM + 96) * LDSK) = ra3;                    \
-    *reinterpret_cast<uint4*>(ws + ((buf) * BN + 0) * LDSK) = rw0;                     \
-    *reinterpret_cast<uint4*>(ws + ((buf) * BN + 32) * LDSK) = rw1;                    \
-    *reinterpret_cast<uint4*>(ws + ((buf) * BN + 64) * LDSK) = rw2;                    \
-    *reinterpret_cast<uint4*>(ws + ((buf) * BN + 96) * LDSK) = rw3;
+    // global -> register prefetch runs TWO k-tiles ahead (register sets a / b alternate): one k-tile of compute (~0.3 us)
+    // does not cover an L2 / HBM round trip.  nk is even, so output-tile boundaries fall between pairs.
+    uint4 ra0, ra1, ra2, ra3, rw0, rw1, rw2, rw3, rb0, rb1, rb2, rb3, rv0, rv1, rv2, rv3;
+#define GEMM_GLOAD(A0, A1, A2, A3, W0, W1, W2, W3, ag, wg)                 \
+    A0 = *reinterpret_cast<const uint4*>(ag);                              \
+    A1 = *reinterpret_cast<const uint4*>(ag + rstep);                      \
+    A2 = *reinterpret_cast<const uint4*>(ag + 2 * rstep);                  \
+    A3 = *reinterpret_cast<const uint4*>(ag + 3 * rstep);                  \
+    W0 = *reinterpret_cast<const uint4*>(wg);                              \
+    W1 = *reinterpret_cast<const uint4*>(wg + rstep);                      \
+    W2 = *reinterpret_cast<const uint4*>(wg + 2 * rstep);                  \
+    W3 = *reinterpret_cast<const uint4*>(wg + 3 * rstep);
+#define GEMM_SSTORE(A0, A1, A2, A3, W0, W1, W2, W3, buf)                               \
+    *reinterpret_cast<uint4*>(as + ((buf) * BM + 0) * LDSK) = A0;                      \
+    *reinterpret_cast<uint4*>(as + ((buf) * BM + 32) * LDSK) = A1;                     \
+    *reinterpret_cast<uint4*>(as + ((buf) * BM + 64) * LDSK) = A2;                     \
+    *reinterpret_cast<uint4*>(as + ((buf) * BM + 96) * LDSK) = A3;                     \
+    *reinterpret_cast<uint4*>(ws + ((buf) * BN + 0) * LDSK) = W0;                      \
+    *reinterpret_cast<uint4*>(ws + ((buf) * BN + 32) * LDSK) = W1;                     \
+    *reinterpret_cast<uint4*>(ws + ((buf) * BN + 64) * LDSK) = W2;                     \
+    *reinterpret_cast<uint4*>(ws + ((buf) * BN + 96) * LDSK) = W3;
+#define GEMM_COMPUTE(buf)                                                                                   \
+    {                                                                                                       \
+        const bf16raw* Ab = As + (size_t)(buf) * BM * LDSK + (size_t)(64 * wm + j) * LDSK + 8 * g;          \
+        const bf16raw* Wb = Ws + (size_t)(buf) * BN * LDSK + (size_t)(64 * wn + wrow) * LDSK + 8 * g;       \
+        _Pragma("unroll") for (int s = 0; s < BK / 32; ++s) {                                               \
+            bf16x8 wf[4], af[4];                                                                            \
+            _Pragma("unroll") for (int x = 0; x < 4; ++x) {                                                 \
+                wf[x] = *reinterpret_cast<const bf16x8*>(Wb + (size_t)(32 * (x >> 1) + 4 * (x & 1)) * LDSK + 32 * s); \
+                af[x] = *reinterpret_cast<const bf16x8*>(Ab + (size_t)(16 * x) * LDSK + 32 * s);            \
+            }                                                                                               \
+            _Pragma("unroll") for (int x = 0; x < 4; ++x)                                                   \
+                _Pragma("unroll") for (int y = 0; y < 4; ++y) acc[x][y] = mfma_bf16(wf[x], af[y], acc[x][y]); \
+        }                                                                                                   \
+    }
+    // Feature order inside a wave's 64-feature span: MFMA row i of fragment x = 2 p + q is feature 32 p + 8 (i >> 2) + 4 q
+    // + (i & 3), so that the 4 + 4 accumulator values a lane holds for the fragment pair (2 p, 2 p + 1) are EIGHT
+    // consecutive features - one 16-byte bf16 store (two for fp32) instead of two scattered 8-byte ones.
+    const int wrow = 8 * (j >> 2) + (j & 3);
     int tile = blockIdx.x;
     if (tile >= n_tiles) return;
     auto a_ptr = [&](int tl) { return a.A + ((size_t)(tl / tiles_n) * BM + lr) * a.K + lc; };
     auto w_ptr = [&](int tl) { return a.W + ((size_t)(tl % tiles_n) * BN + lr) * a.K + lc; };
     const bf16raw* ag = a_ptr(tile);
     const bf16raw* wg = w_ptr(tile);
-    GEMM_GLOAD(ag, wg)
-    GEMM_SSTORE(0)
+    GEMM_GLOAD(ra0, ra1, ra2, ra3, rw0, rw1, rw2, rw3, ag, wg)
+    GEMM_GLOAD(rb0, rb1, rb2, rb3, rv0, rv1, rv2, rv3, ag + BK, wg + BK)
+    GEMM_SSTORE(ra0, ra1, ra2, ra3, rw0, rw1, rw2, rw3, 0)
     __syncthreads();
-    int buf = 0;
     while (true) {
         const int tm_idx = tile / tiles_n, tn_idx = tile - tm_idx * tiles_n;
         const size_t m0 = (size_t)tm_idx * BM;
         const int n0 = tn_idx * BN;
         const int next_tile = tile + gridDim.x;
         const bool have_next = next_tile < n_tiles;
+        const bf16raw* agn = have_next ? a_ptr(next_tile) : ag;
+        const bf16raw* wgn = have_next ? w_ptr(next_tile) : wg;
         f32x4 acc[4][4];   // [feature tile][token tile]: lane (g, j) holds features 4 g + m of token j
 #pragma unroll
         for (int x = 0; x < 4; ++x)
 #pragma unroll
             for (int y = 0; y < 4; ++y) acc[x][y] = splat4(0.f);
 #pragma unroll 1
-        for (int kt = 0; kt < nk; ++kt) {
-            // the k-tile after this one: the next of this output tile, or the first of the next output tile
-            const bool last = kt + 1 == nk;
-            const bool more = !last || have_next;
+        for (int kt = 0; kt < nk; kt += 2) {
+            // LDS buffer 0 = k-tile kt, register set b = k-tile kt + 1; set a is free
+            const bool wrap = kt + 2 >= nk;               // the k-tiles after this pair belong to the next output tile
+            const bool more = !wrap || have_next;
             if (more) {
-                const bf16raw* an = last ? a_ptr(next_tile) : ag + (kt + 1) * BK;
-                const bf16raw* wn_ = last ? w_ptr(next_tile) : wg + (kt + 1) * BK;
-                GEMM_GLOAD(an, wn_)
+                const bf16raw* an = wrap ? agn : ag + (kt + 2) * BK;
+                const bf16raw* wn_ = wrap ? wgn : wg + (kt + 2) * BK;
+                GEMM_GLOAD(ra0, ra1, ra2, ra3, rw0, rw1, rw2, rw3, an, wn_)
             }
-            const bf16raw* Ab = As + (size_t)buf * BM * LDSK + (size_t)(64 * wm + j) * LDSK + 8 * g;
-            const bf16raw* Wb = Ws + (size_t)buf * BN * LDSK + (size_t)(64 * wn + j) * LDSK + 8 * g;
-#pragma unroll
-            for (int s = 0; s < BK / 32; ++s) {
-                bf16x8 wf[4], af[4];
-#pragma unroll
-                for (int x = 0; x < 4; ++x) {
-                    wf[x] = *reinterpret_cast<const bf16x8*>(Wb + (size_t)(16 * x) * LDSK + 32 * s);
-                    af[x] = *reinterpret_cast<const bf16x8*>(Ab + (size_t)(16 * x) * LDSK + 32 * s);
-                }
-#pragma unroll
-                for (int x = 0; x < 4; ++x)
-#pragma unroll
-                    for (int y = 0; y < 4; ++y) acc[x][y] = mfma_bf16(wf[x], af[y], acc[x][y]);
-            }
+            GEMM_COMPUTE(0)
+            GEMM_SSTORE(rb0, rb1, rb2, rb3, rv0, rv1, rv2, rv3, 1)   // buffer 1 was last read before the previous barrier
+            __syncthreads();
             if (more) {
-                GEMM_SSTORE(buf ^ 1)   // the other buffer was last read before the previous barrier
+                const bf16raw* an = wrap ? agn + BK : ag + (kt + 3) * BK;
+                const bf16raw* wn_ = wrap ? wgn + BK : wg + (kt + 3) * BK;
+                GEMM_GLOAD(rb0, rb1, rb2, rb3, rv0, rv1, rv2, rv3, an, wn_)
+            }
+            GEMM_COMPUTE(1)
+            if (more) {
+                GEMM_SSTORE(ra0, ra1, ra2, ra3, rw0, rw1, rw2, rw3, 0)
                 __syncthreads();
-                buf ^= 1;
             }
         }
-    // ---- epilogue: lane (g, j): token row m0 + 64 wm + 16 y + j, features n0 + 64 wn + 16 x + 4 g .. + 3
+    // ---- epilogue: lane (g, j): token row m0 + 64 wm + 16 y + j, features n0 + 64 wn + 32 p + 8 g .. + 7
 #pragma unroll
     for (int y = 0; y < 4; ++y) {
         const size_t row = m0 + 64 * wm + 16 * y + j;
         if (row >= (size_t)a.M) continue;
 #pragma unroll
-        for (int x = 0; x < 4; ++x) {
-            const int n = n0 + 64 * wn + 16 * x + 4 * g;
-            f32x4 v = acc[x][y] + ld4(a.bias + n);
+        for (int pp = 0; pp < 2; ++pp) {
+            const int n = n0 + 64 * wn + 32 * pp + 8 * g;
+            f32x4 v0 = acc[2 * pp][y] + ld4(a.bias + n), v1 = acc[2 * pp + 1][y] + ld4(a.bias + n + 4);
             if constexpr (EPI == EPI_BF16) {
-                *reinterpret_cast<uint2*>(a.out_bf16 + row * a.N + n) = pack4(v);
+                const uint2 lo = pack4(v0), hi = pack4(v1);
+                *reinterpret_cast<uint4*>(a.out_bf16 + row * a.N + n) = uint4{lo.x, lo.y, hi.x, hi.y};
             } else if constexpr (EPI == EPI_GELU_BF16) {
 #pragma unroll
-                for (int m = 0; m < 4; ++m) v[m] = gelu_erf_fast(v[m]);
-                *reinterpret_cast<uint2*>(a.out_bf16 + row * a.N + n) = pack4(v);
+                for (int m = 0; m < 4; ++m) { v0[m] = gelu_erf_fast(v0[m]); v1[m] = gelu_erf_fast(v1[m]); }
+                const uint2 lo = pack4(v0), hi = pack4(v1);
+                *reinterpret_cast<uint4*>(a.out_bf16 + row * a.N + n) = uint4{lo.x, lo.y, hi.x, hi.y};
             } else if constexpr (EPI == EPI_RESID_F32) {
                 float* p = a.out_f32 + row * a.N + n;
-                st4(p, ld4(p) + v);
+                const f32x4 r0 = ld4(p), r1 = ld4(p + 4);
+                st4(p, r0 + v0);
+                st4(p + 4, r1 + v1);
             } else if constexpr (EPI == EPI_F32) {
-                st4(a.out_f32 + row * a.N + n, v);
+                st4(a.out_f32 + row * a.N + n, v0);
+                st4(a.out_f32 + row * a.N + n + 4, v1);
             } else if constexpr (EPI == EPI_PATCH) {
                 // row = b * 1212 + p  ->  token row b * 1214 + 2 + p, + pos_embed[2 + p]
                 const size_t b = row / kAstPatches, p = row - b * kAstPatches;
-                st4(a.out_f32 + (b * kAstTokens + 2 + p) * kAstDim + n, v + ld4(a.pos + (2 + p) * kAstDim + n));
+                float* dst = a.out_f32 + (b * kAstTokens + 2 + p) * kAstDim + n;
+                const float* ps = a.pos + (2 + p) * kAstDim + n;
+                st4(dst, v0 + ld4(ps));
+                st4(dst + 4, v1 + ld4(ps + 4));
             } else {  // EPI_QKV: q (pre-scaled by head_dim ** -0.5 = 1/8, exact in bf16) | k row-major, v transposed
-                if (n < kAstDim) {
-                    *reinterpret_cast<uint2*>(a.out_bf16 + row * (2 * kAstDim) + n) = pack4(v * 0.125f);
-                } else if (n < 2 * kAstDim) {
-                    *reinterpret_cast<uint2*>(a.out_bf16 + row * (2 * kAstDim) + n) = pack4(v);
+                if (n < 2 * kAstDim) {
+                    const float sc = n < kAstDim ? 0.125f : 1.0f;
+                    const uint2 lo = pack4(v0 * sc), hi = pack4(v1 * sc);
+                    *reinterpret_cast<uint4*>(a.out_bf16 + row * (2 * kAstDim) + n) = uint4{lo.x, lo.y, hi.x, hi.y};
                 } else {
                     const size_t b = row / kAstTokens, tok = row - b * kAstTokens;
                     const int hd = n - 2 * kAstDim;   // h * 64 + d
                     typedef __bf16 bf;
 #pragma unroll
-                    for (int m = 0; m < 4; ++m)
-                        a.vt[((b * kAstDim) + hd + m) * kAstKeysPad + tok] = __builtin_bit_cast(bf16raw, (bf)v[m]);
+                    for (int m = 0; m < 4; ++m) {
+                        a.vt[((b * kAstDim) + hd + m) * kAstKeysPad + tok] = __builtin_bit_cast(bf16raw, (bf)v0[m]);
+                        a.vt[((b * kAstDim) + hd + 4 + m) * kAstKeysPad + tok] = __builtin_bit_cast(bf16raw, (bf)v1[m]);
+                    }
                 }
             }
         }
@@ -261,6 +286,7 @@ __global__ __launch_bounds__(256) void k_gemm_bf16(GemmArgs a) {
     }
 #undef GEMM_GLOAD
 #undef GEMM_SSTORE
+#undef GEMM_COMPUTE
 }
 
 // ---------------------------------------------------------------------------------------------- LayerNorm rows
