@@ -18,7 +18,7 @@ ABI_VERSION = 1
 
 EXPORTS = [
     "amuse_abi_version", "amuse_last_error", "amuse_create", "amuse_destroy", "amuse_set_schedule",
-    "amuse_sample", "amuse_denoise_step", "amuse_vae_decode", "amuse_vae_encode", "amuse_smplx_to_feats", "amuse_diffusion_backward",
+    "amuse_sample", "amuse_denoise_step", "amuse_diffusion_forward", "amuse_vae_decode", "amuse_vae_encode", "amuse_smplx_to_feats", "amuse_diffusion_backward",
     "amuse_counter_normal", "amuse_set_clips_per_group", "amuse_profile_sample",
     "amuse_audio_create", "amuse_audio_destroy", "amuse_audio_fbank", "amuse_audio_encode", "amuse_audio_features",
     "amuse_debug_gemm",
@@ -58,6 +58,8 @@ def load() -> C.CDLL:
     lib.amuse_set_schedule.argtypes = [vp, C.POINTER(Schedule), vp]
     lib.amuse_sample.argtypes = [vp, fp, fp, fp, C.c_int, C.c_int, u64, u64, fp, fp, fp, fp, vp]
     lib.amuse_denoise_step.argtypes = [vp, fp, C.c_int, fp, fp, fp, C.c_int, C.c_int, fp, fp, vp]
+    lib.amuse_diffusion_forward.argtypes = [vp, fp, fp, ip, C.POINTER(C.c_float), C.POINTER(C.c_float), fp, fp, fp, C.c_int, C.c_int, fp, fp, vp]
+    lib.amuse_diffusion_forward.restype = C.c_int
     lib.amuse_vae_decode.argtypes = [vp, fp, ip, C.c_int, C.c_int, C.c_int, fp, fp, fp, vp]
     lib.amuse_vae_encode.argtypes = [vp, fp, ip, C.c_int, C.c_int, fp, fp, fp, fp, vp]
     lib.amuse_smplx_to_feats.argtypes = [vp, fp, fp, C.c_int, fp, vp]
@@ -65,7 +67,7 @@ def load() -> C.CDLL:
     lib.amuse_counter_normal.argtypes = [vp, u64, u64, C.c_int, C.c_int, C.c_int, fp, vp]
     lib.amuse_set_clips_per_group.argtypes = [vp, C.c_int]
     lib.amuse_profile_sample.argtypes = [vp, fp, fp, fp, C.c_int, C.c_int, C.c_int, fp, vp]
-    for n in ("amuse_set_schedule", "amuse_sample", "amuse_denoise_step", "amuse_vae_decode", "amuse_vae_encode", "amuse_smplx_to_feats",
+    for n in ("amuse_set_schedule", "amuse_sample", "amuse_denoise_step", "amuse_diffusion_forward", "amuse_vae_decode", "amuse_vae_encode", "amuse_smplx_to_feats",
               "amuse_diffusion_backward", "amuse_counter_normal", "amuse_set_clips_per_group", "amuse_profile_sample"):
         getattr(lib, n).restype = C.c_int
     lib.amuse_audio_create.restype = vp

@@ -240,6 +240,7 @@ struct amuse_ctx {
     // workspaces
     float* cond_tok = nullptr; size_t cond_cap = 0;
     float* lat_tmp = nullptr; size_t lat_cap = 0;
+    float* fwd_ws = nullptr; size_t fwd_cap = 0;
     float* vae_ws = nullptr; size_t vae_cap = 0;  // clips
     int* d_lengths = nullptr; size_t len_cap = 0;
     std::vector<void*> owned;
@@ -488,7 +489,7 @@ void amuse_destroy(amuse_ctx* c) {
                     c->vae_w[0], c->vae_w[1], c->vae_pvec, c->vae_final_bias, c->vae_pe, c->vae_wv_t, c->vae_bv,
                     c->vae_wo_t, c->vae_bo, c->vaee_w[0], c->vaee_w[1], c->vaee_pvec, c->vaee_pe, c->vaee_tok,
                     c->vaee_emb_bias, c->d_timesteps, c->d_coef, c->d_time_tok, c->d_ts1, c->d_tt1, c->d_coef1,
-                    c->cond_tok, c->lat_tmp, c->vae_ws, c->d_lengths};
+                    c->cond_tok, c->lat_tmp, c->fwd_ws, c->vae_ws, c->d_lengths};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     delete c;
@@ -583,6 +584,39 @@ int amuse_denoise_step(amuse_ctx* c, const float* x_t, int timestep, const float
     a.seed = 0; a.clip0 = 0;
     a.B = B; a.T = 1; a.S = S; a.G = pick_group(c, B, S); a.no_update = 1;
     HIP_TRY(launch_sample(a, precision, st));
+    return 0;
+}
+
+int amuse_diffusion_forward(amuse_ctx* c, const float* z0, const float* noise, const int* timesteps, const float* sqrt_ab,
+                            const float* sqrt_1m_ab, const float* con, const float* emo, const float* sty, int B,
+                            int precision, float* noisy_out, float* noise_pred_out, void* stream) {
+    if (int e = check_common(c, con, B, precision)) return e;
+    if (!z0 || !noise || !timesteps || !sqrt_ab || !sqrt_1m_ab || !noise_pred_out) return fail(AMUSE_EINVAL, "NULL argument");
+    for (int b = 0; b < B; ++b)
+        if (timesteps[b] < 0) return fail(AMUSE_EINVAL, "timesteps[%d] = %d is negative", b, timesteps[b]);
+    hipStream_t st = (hipStream_t)stream;
+    // per-clip scratch: noisy latents, time tokens, the two coefficient vectors and the timesteps
+    if (int e = ensure(&c->fwd_ws, &c->fwd_cap, (size_t)B * (2 * kD + 3))) return e;
+    float* noisy = c->fwd_ws;
+    float* ttok = noisy + (size_t)B * kD;
+    float* sa = ttok + (size_t)B * kD;
+    float* sb = sa + B;
+    int* ts = reinterpret_cast<int*>(sb + B);
+    HIP_TRY(hipMemcpyAsync(ts, timesteps, (size_t)B * sizeof(int), hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(sa, sqrt_ab, (size_t)B * sizeof(float), hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(sb, sqrt_1m_ab, (size_t)B * sizeof(float), hipMemcpyHostToDevice, st));
+    HIP_TRY(hipStreamSynchronize(st));  // the host arrays belong to the caller
+    HIP_TRY(launch_add_noise(z0, noise, sa, sb, noisy, B, st));
+    HIP_TRY(launch_time_tokens(ts, B, c->den_freqs, c->te_w1t, c->te_b1, c->te_w2t, c->te_b2, c->den_pe + kD, ttok, st));
+    int S = 0;
+    if (int e = cond_tokens(c, con, emo, sty, B, &S, st)) return e;
+    SampleArgs a{};
+    a.wstream = c->den_w[precision]; a.wave_units = c->den_wave_units[precision];
+    a.pvec = c->den_pvec; a.time_tok = ttok; a.time_tok_clip = ttok; a.cond_tok = c->cond_tok; a.pe0 = c->den_pe;
+    a.coef = c->d_coef1; a.x_init = noisy; a.eps_out = noise_pred_out;
+    a.B = B; a.T = 1; a.S = S; a.G = pick_group(c, B, S); a.no_update = 1;
+    HIP_TRY(launch_sample(a, precision, st));
+    if (noisy_out) HIP_TRY(hipMemcpyAsync(noisy_out, noisy, (size_t)B * kD * sizeof(float), hipMemcpyDeviceToDevice, st));
     return 0;
 }
 

@@ -11,6 +11,7 @@ struct SampleArgs {
     uint32_t wave_units;      // 1 KiB units per wave for one pass over the network
     const float* pvec;        // small fp32 parameters (amuse_dev.hpp PV_* layout)
     const float* time_tok;    // [T][128]  TimestepEmbedding(t_i) + pe[1]
+    const float* time_tok_clip;  // [B][128] or null: per-clip time token of a teacher-forced step (diffusion_forward)
     const float* cond_tok;    // [B][S-2][128]  emb_proj_*(cond) + pe[2+n]
     const float* pe0;         // [128] pe[0]
     const float* coef;        // [T][8] scheduler coefficients (amuse_hip.h)
@@ -53,6 +54,9 @@ struct CondArgs {
     int B, ncond;
 };
 hipError_t launch_cond_tokens(const CondArgs& a, hipStream_t stream);
+// noisy[b] = sa[b] * z0[b] + sb[b] * noise[b]   (DDPMScheduler.add_noise; call site ldm.py:84)
+hipError_t launch_add_noise(const float* z0, const float* noise, const float* sa, const float* sb, float* out, int B,
+                            hipStream_t stream);
 hipError_t launch_counter_normal(uint64_t seed, uint64_t clip0, int B, int step, int rng_stream, float* out,
                                  hipStream_t stream);
 

@@ -106,6 +106,14 @@ __global__ __launch_bounds__(256) void k_smplx_to_feats(const float* __restrict_
     dst[5] = two_s * (qj * qk - qi * r);
 }
 
+// DDPMScheduler.add_noise (diffusers 0.17.1; call site ldm.py:84): per-clip coefficients from the host table
+__global__ __launch_bounds__(128) void k_add_noise(const float* __restrict__ z0, const float* __restrict__ noise,
+                                                   const float* __restrict__ sa, const float* __restrict__ sb, float* out) {
+#pragma clang fp contract(off)
+    const size_t i = (size_t)blockIdx.x * kD + threadIdx.x;
+    out[i] = sa[blockIdx.x] * z0[i] + sb[blockIdx.x] * noise[i];
+}
+
 // MotionPrior.encode tail (vae.py:203-213): mu = dist[0], logvar = dist[1]; std = logvar.exp().pow(0.5);
 // latent = Normal(mu, std).rsample() = mu + std * eps with eps supplied by the caller (or latent = mu when absent)
 __global__ __launch_bounds__(128) void k_vae_latent(const float* __restrict__ stats, const float* __restrict__ eps,
@@ -148,6 +156,12 @@ hipError_t launch_vae_ca(const float* z, const float* wv_t, const float* bv, con
 hipError_t launch_smplx_to_feats(const float* poses, const float* trans, size_t nrows, float* feats, hipStream_t stream) {
     const size_t n = nrows * (kJoints + 1);
     hipLaunchKernelGGL(k_smplx_to_feats, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, poses, trans, nrows, feats);
+    return hipGetLastError();
+}
+
+hipError_t launch_add_noise(const float* z0, const float* noise, const float* sa, const float* sb, float* out, int B,
+                            hipStream_t stream) {
+    hipLaunchKernelGGL(k_add_noise, dim3(B), dim3(128), 0, stream, z0, noise, sa, sb, out);
     return hipGetLastError();
 }
 

@@ -256,7 +256,8 @@ __global__ __launch_bounds__(256, 1) void k_sample(SampleArgs a) {
     // `stat` of the time-token rows (tok == 1) holds the token of the NEXT step, fetched a whole step ahead
     if (valid && tok == 1) {
 #pragma unroll
-        for (int t = 0; t < kTiles; ++t) stat[t] = ld4(a.time_tok + 16 * t + 4 * g);
+        for (int t = 0; t < kTiles; ++t)
+            stat[t] = ld4((a.time_tok_clip ? a.time_tok_clip + (size_t)clip * kD : a.time_tok) + 16 * t + 4 * g);
     }
 #pragma unroll 1
     for (int step = 0; step < a.T; ++step) {

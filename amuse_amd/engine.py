@@ -119,6 +119,32 @@ class HipEngine:
                                                    B, PREC[precision], _ptr(eps), _ptr(tap), self._stream()))
         return (eps, tap) if taps else eps
 
+    def diffusion_forward(self, z0, noise, timesteps: Sequence[int], con, emo, sty, precision="fp32"):
+        """LatentDiffusionModel.diffusion_forward (ldm.py:71-97), eval semantics: -> {"noisy_latents", "noise_pred"}."""
+        from .scheduler import alphas_cumprod
+        z0 = self._dev(z0)
+        B = z0.shape[0]
+        noise = self._dev(noise, (B, 128))
+        con = self._dev(con, (B, 256))
+        emo = self._dev(emo, (B, 256)) if emo is not None else None
+        sty = self._dev(sty, (B, 256)) if sty is not None else None
+        ts = np.ascontiguousarray(timesteps, dtype=np.int32)
+        if ts.shape != (B,):
+            raise ValueError("timesteps must have one entry per clip")
+        ac = alphas_cumprod()
+        if ts.min() < 0 or ts.max() >= len(ac):
+            raise ValueError(f"timesteps must lie in 0..{len(ac) - 1}")
+        sa = np.ascontiguousarray(np.sqrt(ac[ts]), dtype=np.float32)
+        sb = np.ascontiguousarray(np.sqrt(np.float32(1.0) - ac[ts]), dtype=np.float32)
+        out = {"noisy_latents": torch.empty(B, 128, device=self.device), "noise_pred": torch.empty(B, 128, device=self.device)}
+        fpp = C.POINTER(C.c_float)
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.amuse_diffusion_forward(self.ctx, _ptr(z0), _ptr(noise), ts.ctypes.data_as(C.POINTER(C.c_int)),
+                                                        sa.ctypes.data_as(fpp), sb.ctypes.data_as(fpp), _ptr(con), _ptr(emo),
+                                                        _ptr(sty), B, PREC[precision], _ptr(out["noisy_latents"]),
+                                                        _ptr(out["noise_pred"]), self._stream()))
+        return out
+
     def vae_decode(self, z, lengths: Optional[Sequence[int]] = None, precision="fp32", quat_mode="p3d",
                    return_feats=False):
         z = self._dev(z)

@@ -31,6 +31,13 @@ def _alphas_cumprod(num_train_timesteps, beta_start, beta_end, beta_schedule="sc
     return torch.cumprod(1.0 - betas, dim=0)
 
 
+def alphas_cumprod(**cfg) -> np.ndarray:
+    """float32 alphas_cumprod of the training-side DDPMScheduler (ldm.py:41-49), for add_noise."""
+    c = dict(DEFAULT_SCHED_CFG)
+    c.update(cfg)
+    return _alphas_cumprod(**c).numpy().copy()
+
+
 def timestep_freqs() -> np.ndarray:
     """exp(-ln(1e4) * k / 128), k < 128, evaluated with torch like embeddings.py:262-267."""
     exponent = -math.log(10000) * torch.arange(0, 128, dtype=torch.float32) / 128

@@ -110,6 +110,18 @@ int amuse_denoise_step(amuse_ctx* ctx, const float* x_t, int timestep, const flo
                        const float* emo, const float* sty, int B, int precision, float* eps_out,
                        float* tap_out, void* stream);
 
+/* Replaces the arithmetic of LatentDiffusionModel.diffusion_forward (models/latent_diffusion/ldm.py:71-97), the
+ * training-time twin of the sampling step, in eval semantics (no dropout): noisy = sqrt_ab * z0 + sqrt_1m_ab * noise
+ * (DDPMScheduler.add_noise) and noise_pred = Denoiser(noisy, timesteps, cond) with ONE TIMESTEP PER CLIP.
+ *   z0, noise              dev [B][128]
+ *   timesteps              host [B]   (torch.randint(0, num_train_timesteps, (bsz,)) in the reference)
+ *   sqrt_ab, sqrt_1m_ab    host [B]   sqrt(alphas_cumprod[t_b]), sqrt(1 - alphas_cumprod[t_b])
+ *   noisy_out (nullable), noise_pred_out   dev [B][128] */
+int amuse_diffusion_forward(amuse_ctx* ctx, const float* z0, const float* noise, const int* timesteps,
+                            const float* sqrt_ab, const float* sqrt_1m_ab, const float* con,
+                            const float* emo, const float* sty, int B, int precision, float* noisy_out,
+                            float* noise_pred_out, void* stream);
+
 /* Replaces PretrainedVAE.get_motion -> MotionPrior.decode (infer_pretrained_vae.py:58-62,
  * vae.py:216-278) plus the 6D -> matrix -> axis-angle conversion (infer_ldm.py:168-173).
  *   z          dev [B][128]

@@ -176,10 +176,15 @@ def cond_project(W, name: str, z: torch.Tensor) -> torch.Tensor:
     return torch.relu(z) @ W[f"emb_proj_{name}.1.weight"].T + W[f"emb_proj_{name}.1.bias"]
 
 
-def denoiser_tokens(W, x, t: int, con, emo, sty) -> torch.Tensor:
-    """Token assembly (denoiser.py:144-181): [latent, time, con, (emo), (sty)] + learned PE.  (B,S,128)."""
+def denoiser_tokens(W, x, t, con, emo, sty) -> torch.Tensor:
+    """Token assembly (denoiser.py:144-181): [latent, time, con, (emo), (sty)] + learned PE.  (B,S,128).
+    t: one int for the whole batch (sampling) or a sequence of B ints (training-time diffusion_forward)."""
     B = x.shape[0]
-    toks = [x, time_embed(W, t, x.dtype)[None].expand(B, -1), cond_project(W, "con", con)]
+    if isinstance(t, (int, np.integer)):
+        te = time_embed(W, int(t), x.dtype)[None].expand(B, -1)
+    else:
+        te = torch.stack([time_embed(W, int(ti), x.dtype) for ti in t])
+    toks = [x, te, cond_project(W, "con", con)]
     if emo is not None:
         toks.append(cond_project(W, "emo", emo))
     if sty is not None:
@@ -188,7 +193,7 @@ def denoiser_tokens(W, x, t: int, con, emo, sty) -> torch.Tensor:
     return xs + W["query_pos.pe"][: xs.shape[1], 0][None]
 
 
-def denoiser_forward(W, x, t: int, con, emo, sty, emulate_bf16=False, taps: Optional[dict] = None):
+def denoiser_forward(W, x, t, con, emo, sty, emulate_bf16=False, taps: Optional[dict] = None):
     """eps_hat = Denoiser(x_t, t, con, emo, sty).  x: (B,128), con/emo/sty: (B,256) or None -> (B,128)."""
     ops = Ops(emulate_bf16)
     xs = denoiser_tokens(W, x, t, con, emo, sty)
@@ -450,6 +455,19 @@ def axis_angle_to_matrix(aa):
                      two_s * (i * j + k * r), 1 - two_s * (i * i + k * k), two_s * (j * k - i * r),
                      two_s * (i * k - j * r), two_s * (j * k + i * r), 1 - two_s * (i * i + j * j)), -1)
     return o.reshape(q.shape[:-1] + (3, 3))
+
+
+def diffusion_forward(W, z0, noise, timesteps, con, emo, sty, emulate_bf16=False):
+    """LatentDiffusionModel.diffusion_forward (ldm.py:71-115) in eval semantics (no dropout), with the caller's noise
+    and per-sample timesteps: noisy = sqrt(abar_t) z0 + sqrt(1 - abar_t) noise (DDPMScheduler.add_noise, diffusers
+    0.17.1 - parity unpinned like the other scheduler arithmetic), noise_pred = Denoiser(noisy, t, cond).
+    -> {"noisy_latents", "noise", "noise_pred"}, each (B,128)."""
+    ac = SchedulerBase().alphas_cumprod
+    t = torch.as_tensor(list(timesteps), dtype=torch.long)
+    sa, sb = ac[t].sqrt()[:, None], (1.0 - ac[t]).sqrt()[:, None]
+    noisy = sa * z0 + sb * noise
+    return {"noisy_latents": noisy, "noise": noise,
+            "noise_pred": denoiser_forward(W, noisy, [int(v) for v in t], con, emo, sty, emulate_bf16)}
 
 
 def feats_to_smplx(feats, mode: str = "p3d"):

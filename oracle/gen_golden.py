@@ -128,6 +128,11 @@ def main():
                               sty_hidden=sty[:, None], lengths=lengths)[0][:, 0].numpy()
     d["eps_t501_consolo"] = den(sample=x_t, timestep=torch.tensor(501), con_hidden=con[:, None], emo_hidden=None,
                                 sty_hidden=None, lengths=lengths)[0][:, 0].numpy()
+    # per-sample timesteps, as LatentDiffusionModel.diffusion_forward calls the denoiser (ldm.py:75-97)
+    ts_batch = torch.tensor([7, 640, 999])
+    d["timesteps_batch"] = ts_batch.numpy()
+    d["eps_batch_t"] = den(sample=x_t, timestep=ts_batch, con_hidden=con[:, None], emo_hidden=emo[:, None],
+                           sty_hidden=sty[:, None], lengths=lengths)[0][:, 0].numpy()
     np.savez_compressed(out / "denoiser_steps.npz", **d)
 
     # ---- DDIM-50 trajectory: reference Denoiser + restated scheduler, explicit x_T, B = 2

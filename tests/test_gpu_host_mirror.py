@@ -118,3 +118,33 @@ def test_cli_infer_and_edit_gesture_write_reference_npz(tmp_path):
     assert len(w2) == 4
     a, b = np.load(w2[0])["poses"], np.load(w2[1])["poses"]   # same noise, same content/style, other emotion
     assert np.isfinite(a).all() and np.abs(a - b).max() > 1e-3
+
+
+def test_latent_diffusion_model_mirror():
+    """amuse_amd.ldm.LatentDiffusionModel: diffusion_forward / diffusion_backward of ldm.py:71-153, forward values."""
+    from amuse_amd import weights as wts
+    from amuse_amd.infer_ldm import PretrainedLPDM_v1
+    from amuse_amd.ldm import LatentDiffusionModel
+    from oracle import amuse_oracle as orc
+    wd, wp = wts.make_denoiser_weights(0), wts.make_prior_weights(0)
+    lp = PretrainedLPDM_v1.from_state_dicts(wd, wp, device="cuda:0", seed=3)
+    m = LatentDiffusionModel(lp)
+    gen = torch.Generator().manual_seed(8)
+    z = torch.randn(1, 4, 128, generator=gen)
+    con, emo, sty = (torch.randn(4, 256, generator=gen) for _ in range(3))
+    noise = torch.randn(4, 1, 128, generator=gen)
+    ts = [3, 250, 777, 999]
+    n_set = m.diffusion_forward(z, con, emo, sty, noise=noise, timesteps=ts)
+    assert set(n_set) == {"noise", "noise_prior", "noise_pred", "noise_pred_prior"}
+    assert n_set["noise_pred"].shape == (4, 1, 128) and n_set["noise_prior"] == 0
+    ref = orc.diffusion_forward(orc.to_torch(wd), z[0], noise[:, 0], ts, con, emo, sty)
+    assert float((n_set["noise_pred"][:, 0].cpu() - ref["noise_pred"]).abs().max()) < 1e-5
+    assert torch.equal(n_set["noise"].cpu(), noise)
+    # default draws: reproducible from the seed, different per call
+    a = m.diffusion_forward(z, con, emo, sty)["noise_pred"]
+    b = m.diffusion_forward(z, con, emo, sty)["noise_pred"]
+    assert not torch.equal(a, b)
+    lat = m.diffusion_backward(con, emo, sty, None, 4)
+    assert lat.shape == (1, 4, 128) and bool(torch.isfinite(lat).all())
+    with pytest.raises(NotImplementedError):
+        m.diffusion_forward(z, con, emo, sty, ld_audio_mfcc=torch.zeros(1))

@@ -128,6 +128,30 @@ def test_denoise_step_bf16_blockwise(env):
     assert sorted(errs)[6] < 1e-4, errs   # at least 7 of 9 blocks free of rounding flips
 
 
+def test_diffusion_forward_per_clip_timesteps(env):
+    """amuse_diffusion_forward (ldm.py:71-97): per-clip timesteps vs the reference Denoiser golden and the oracle."""
+    orc, eng, Wd = env["orc"], env["eng"], env["Wd"]
+    g = np.load(GOLDEN / "denoiser_steps.npz")
+    ts = [int(v) for v in g["timesteps_batch"]]
+    # noise = 0 and z0 = x_t / sqrt(abar_t) reproduce the golden's noisy latent
+    ac = orc.SchedulerBase().alphas_cumprod
+    z0 = torch.from_numpy(g["x_t"]) / ac[torch.tensor(ts)].sqrt()[:, None]
+    out = eng.diffusion_forward(z0, torch.zeros(3, 128), ts, g["con"], g["emo"], g["sty"], "fp32")
+    assert _err(out["noisy_latents"], g["x_t"]) < 1e-6
+    assert _err(out["noise_pred"], g["eps_batch_t"]) < 1e-5
+    # general case against the oracle: 70 clips (clip tiles of several kinds), token dropping
+    gen = torch.Generator().manual_seed(17)
+    B = 70
+    z, n, con, emo = (torch.randn(B, d, generator=gen) for d in (128, 128, 256, 256))
+    ts = torch.randint(0, 1000, (B,), generator=gen).tolist()
+    ref = orc.diffusion_forward(Wd, z, n, ts, con, emo, None)
+    out = eng.diffusion_forward(z, n, ts, con, emo, None, "fp32")
+    assert _err(out["noisy_latents"], ref["noisy_latents"]) < 1e-6
+    assert _err(out["noise_pred"], ref["noise_pred"]) < 1e-5
+    with pytest.raises(ValueError):
+        eng.diffusion_forward(z, n, [1000] * B, con, emo, None)
+
+
 def test_ddim50_fp32_matches_reference_trajectory(env):
     from amuse_amd import scheduler as sch
     eng = env["eng"]

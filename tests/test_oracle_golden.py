@@ -181,3 +181,17 @@ def test_counter_noise_statistics():
     # Philox4x32-10 known-answer (Random123 kat_vectors: ctr = key = 0)
     r = orc.philox4x32_10(np.zeros((1, 4), dtype=np.uint64), (0, 0))[0]
     assert [int(v) for v in r] == [0x6627E8D5, 0xE169C58D, 0xBC57AC4C, 0x9B00DBD8]
+
+
+def test_denoiser_per_sample_timesteps(oracle_env=None):
+    """Denoiser with one timestep per sample, as LatentDiffusionModel.diffusion_forward calls it (ldm.py:75-97)."""
+    from amuse_amd import weights as wts
+    from oracle import amuse_oracle as orc
+    g = np.load(GOLDEN / "denoiser_steps.npz")
+    W = orc.to_torch(wts.make_denoiser_weights(0))
+    t = lambda k: torch.from_numpy(g[k])
+    eps = orc.denoiser_forward(W, t("x_t"), [int(v) for v in g["timesteps_batch"]], t("con"), t("emo"), t("sty"))
+    assert float((eps - t("eps_batch_t")).abs().max()) < 1e-5
+    # add_noise + forward: with noise = 0 and t such that sqrt(abar) ~ 1 the noisy latent is the clean one
+    out = orc.diffusion_forward(W, t("x_t"), torch.zeros(3, 128), [0, 0, 0], t("con"), t("emo"), t("sty"))
+    assert float((out["noisy_latents"] - float(orc.SchedulerBase().alphas_cumprod[0].sqrt()) * t("x_t")).abs().max()) < 1e-6
