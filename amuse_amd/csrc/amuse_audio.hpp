@@ -13,7 +13,10 @@ constexpr int kAstKeysPad = 1216;   // V^T rows padded to whole 64-key chunks (t
 enum { EPI_BF16 = 0, EPI_GELU_BF16, EPI_RESID_F32, EPI_F32, EPI_PATCH, EPI_QKV };
 struct GemmArgs {
     const unsigned short* A;     // bf16 [M padded to 128][K]
-    const unsigned short* W;     // bf16 [N][K]   (torch Linear weight layout)
+    const unsigned short* W;     // bf16, PACKED in MFMA-fragment order (amuse_audio_api.hip pack_w): for every 64-feature
+                                 // span, fragment x = 2 p + q (row i <-> feature 32 p + 8 (i >> 2) + 4 q + (i & 3), so that
+                                 // a lane's accumulators of a fragment pair are 8 consecutive features), k-step ks (32 k):
+                                 // unit [64 lanes][8 bf16], lane (g, i) = W[feature][32 ks + 8 g + e]
     const float* bias;           // [N]
     int M, N, K;                 // N % 128 == 0, K % 64 == 0
     unsigned short* out_bf16;    // EPI_BF16 / EPI_GELU_BF16: [M][N]; EPI_QKV: q | k as [M][1536]

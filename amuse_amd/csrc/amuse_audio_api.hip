@@ -68,6 +68,27 @@ int up_f32(amuse_audio_ctx* c, float** dst, const float* src, size_t n) {
     HIP_TRY(hipMemcpy(*dst, src, n * sizeof(float), hipMemcpyHostToDevice));
     return 0;
 }
+// torch Linear weight [N][K] fp32 -> the GEMM's fragment order (amuse_audio.hpp GemmArgs::W)
+std::vector<unsigned short> pack_w(const float* W, int N, int K) {
+    std::vector<unsigned short> out((size_t)N * K);
+    size_t o = 0;
+    for (int sp = 0; sp < N / 64; ++sp)
+        for (int x = 0; x < 4; ++x)
+            for (int ks = 0; ks < K / 32; ++ks)
+                for (int lane = 0; lane < 64; ++lane) {
+                    const int g = lane >> 4, i = lane & 15;
+                    const int f = 64 * sp + 32 * (x >> 1) + 8 * (i >> 2) + 4 * (x & 1) + (i & 3);
+                    for (int e = 0; e < 8; ++e) out[o++] = f2bf(W[(size_t)f * K + 32 * ks + 8 * g + e]);
+                }
+    return out;
+}
+int up_packed(amuse_audio_ctx* c, unsigned short** dst, const float* src, int N, int K) {
+    const std::vector<unsigned short> h = pack_w(src, N, K);
+    HIP_TRY(hipMalloc((void**)dst, h.size() * 2));
+    c->owned.push_back(*dst);
+    HIP_TRY(hipMemcpy(*dst, h.data(), h.size() * 2, hipMemcpyHostToDevice));
+    return 0;
+}
 int up_bf16(amuse_audio_ctx* c, unsigned short** dst, const float* src, size_t n) {
     std::vector<unsigned short> h(n);
     for (size_t i = 0; i < n; ++i) h[i] = f2bf(src[i]);
@@ -82,16 +103,16 @@ int build_encoder(amuse_audio_ctx* c, Encoder& E, const float* p) {
     auto take = [&](size_t n) { const float* q = p; p += n; return q; };
     if (up_f32(c, &E.cls, take(D), D) || up_f32(c, &E.dist, take(D), D) ||
         up_f32(c, &E.pos, take((size_t)kAstTokens * D), (size_t)kAstTokens * D) ||
-        up_bf16(c, &E.patch_w, take(D * 256), D * 256) || up_f32(c, &E.patch_b, take(D), D))
+        up_packed(c, &E.patch_w, take(D * 256), (int)D, 256) || up_f32(c, &E.patch_b, take(D), D))
         return AMUSE_EHIP;
     for (int l = 0; l < kAstLayers; ++l) {
         Block& b = E.blk[l];
         if (up_f32(c, &b.n1w, take(D), D) || up_f32(c, &b.n1b, take(D), D) ||
-            up_bf16(c, &b.qkv_w, take(3 * D * D), 3 * D * D) || up_f32(c, &b.qkv_b, take(3 * D), 3 * D) ||
-            up_bf16(c, &b.proj_w, take(D * D), D * D) || up_f32(c, &b.proj_b, take(D), D) ||
+            up_packed(c, &b.qkv_w, take(3 * D * D), (int)(3 * D), (int)D) || up_f32(c, &b.qkv_b, take(3 * D), 3 * D) ||
+            up_packed(c, &b.proj_w, take(D * D), (int)D, (int)D) || up_f32(c, &b.proj_b, take(D), D) ||
             up_f32(c, &b.n2w, take(D), D) || up_f32(c, &b.n2b, take(D), D) ||
-            up_bf16(c, &b.fc1_w, take((size_t)kAstMlp * D), (size_t)kAstMlp * D) || up_f32(c, &b.fc1_b, take(kAstMlp), kAstMlp) ||
-            up_bf16(c, &b.fc2_w, take(D * kAstMlp), D * kAstMlp) || up_f32(c, &b.fc2_b, take(D), D))
+            up_packed(c, &b.fc1_w, take((size_t)kAstMlp * D), kAstMlp, (int)D) || up_f32(c, &b.fc1_b, take(kAstMlp), kAstMlp) ||
+            up_packed(c, &b.fc2_w, take(D * kAstMlp), (int)D, kAstMlp) || up_f32(c, &b.fc2_b, take(D), D))
             return AMUSE_EHIP;
     }
     if (up_f32(c, &E.norm_w, take(D), D) || up_f32(c, &E.norm_b, take(D), D) || up_f32(c, &E.fh_ln_w, take(D), D) ||
@@ -259,7 +280,7 @@ int amuse_audio_features(amuse_audio_ctx* c, const float* waves, int n_samples, 
 }
 
 // GEMM in isolation (tools/gpu_gemm_bench.py, tests): C = A . W^T + bias with epilogue 0 (bf16 out) or 3 (fp32 out);
-// A dev bf16 [M padded to 128][K], W dev bf16 [N][K]
+// A dev bf16 [M padded to 128][K], W dev bf16 in the kernel's packed fragment order (GemmArgs::W)
 int amuse_debug_gemm(const void* A, const void* W, const float* bias, int M, int N, int K, int epi, void* out, void* stream) {
     if (!A || !W || !bias || !out) return failf(AMUSE_EINVAL, "NULL argument%s");
     if (N % 128 || K % 64 || (epi != EPI_BF16 && epi != EPI_F32)) return failf(AMUSE_EINVAL, "%sbad GEMM shape / epilogue (N %ld K %ld)", "", N, K);

@@ -119,78 +119,78 @@ __global__ __launch_bounds__(256) void k_ast_tokens(const float* __restrict__ cl
 }
 
 // ---------------------------------------------------------------------------------------------- GEMM
+// 128 x 128 x 64 output tiles, four waves of 64 x 64.  What bounds this kernel is LDS bandwidth: with BOTH operands
+// staged through LDS a k-tile costs every wave 16 fragment reads + 8 staging writes of 1 KiB against 32 MFMAs - 135 %
+// of the matrix-pipe time at the measured 114 B/clk (tools/probes/lds_probe.hip; ablation in DESIGN.md 4.4).  The
+// weights are static, so they take the sampler's route instead: packed once on the host into MFMA-fragment order
+// (1 KiB units, amuse_audio_api.hip pack_w) and streamed global -> registers -> MFMA by each wave, one k-tile ahead.
+// Only the activations go through LDS (8 reads + 4 writes per k-tile per wave).
 constexpr int BM = 128, BN = 128, BK = 64;
 constexpr int LDSK = BK + 8;                       // padded row (bf16 elements): 144 B, conflict-free ds_read_b128
-constexpr int kGemmLds = 2 * (BM + BN) * LDSK * 2; // double-buffered A and W tiles: 73,728 B
+constexpr int kGemmLds = 2 * BM * LDSK * 2;        // double-buffered A tile: 36,864 B
 
 template <int EPI>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_gemm_bf16(GemmArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     bf16raw* As = reinterpret_cast<bf16raw*>(smem);                    // [2][BM][LDSK]
-    bf16raw* Ws = As + 2 * BM * LDSK;                                  // [2][BN][LDSK]
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int g = lane >> 4, j = lane & 15;
     const int wm = wave >> 1, wn = wave & 1;
-    // PERSISTENT: workgroup w computes output tiles w, w + gridDim.x, ... and the k-tile pipeline (global -> registers
-    // -> LDS, one tile ahead) runs straight across output-tile boundaries, so only the first tile of a workgroup pays
-    // the load round trip in the open and every epilogue overlaps the next tile's loads.  With K = 768 a tile is just
-    // 12 k-tiles (~3 us): one workgroup per tile spent as long filling its pipeline as computing.
-    // Consecutive tile indices walk the N tiles of one M tile: concurrent workgroups share the A rows through L2.
+    // PERSISTENT: workgroup w computes output tiles w, w + gridDim.x, ... and the k-tile pipeline runs straight across
+    // output-tile boundaries, so only the first tile of a workgroup pays the load round trip in the open and every
+    // epilogue overlaps the next tile's loads.  Consecutive tile indices walk the N tiles of one M tile: concurrent
+    // workgroups share the A rows through L2.
     const int tiles_n = a.N / BN;
     const int n_tiles = ((a.M + BM - 1) / BM) * tiles_n;
     const int nk = a.K / BK;
     const int lr = t >> 3, lc = (t & 7) * 8;                          // this thread's 16 B: rows lr + 32 i, k lc..lc+7
     const size_t rstep = (size_t)32 * a.K;
     bf16raw* as = As + (size_t)lr * LDSK + lc;
-    bf16raw* ws = Ws + (size_t)lr * LDSK + lc;
-    // global -> register prefetch runs TWO k-tiles ahead (register sets a / b alternate): one k-tile of compute (~0.3 us)
-    // does not cover an L2 / HBM round trip.  nk is even, so output-tile boundaries fall between pairs.
-    uint4 ra0, ra1, ra2, ra3, rw0, rw1, rw2, rw3, rb0, rb1, rb2, rb3, rv0, rv1, rv2, rv3;
-#define GEMM_GLOAD(A0, A1, A2, A3, W0, W1, W2, W3, ag, wg)                 \
+    // activations: global -> registers two k-tiles ahead (sets a / b) -> LDS; weights: fragment units one k-tile
+    // ahead (sets 0 / 1), straight into the MFMA
+    uint4 ra0, ra1, ra2, ra3, rb0, rb1, rb2, rb3;
+    uint4 w0[8], w1[8];
+#define GEMM_ALOAD(A0, A1, A2, A3, ag)                                     \
     A0 = *reinterpret_cast<const uint4*>(ag);                              \
     A1 = *reinterpret_cast<const uint4*>(ag + rstep);                      \
     A2 = *reinterpret_cast<const uint4*>(ag + 2 * rstep);                  \
-    A3 = *reinterpret_cast<const uint4*>(ag + 3 * rstep);                  \
-    W0 = *reinterpret_cast<const uint4*>(wg);                              \
-    W1 = *reinterpret_cast<const uint4*>(wg + rstep);                      \
-    W2 = *reinterpret_cast<const uint4*>(wg + 2 * rstep);                  \
-    W3 = *reinterpret_cast<const uint4*>(wg + 3 * rstep);
-#define GEMM_SSTORE(A0, A1, A2, A3, W0, W1, W2, W3, buf)                               \
+    A3 = *reinterpret_cast<const uint4*>(ag + 3 * rstep);
+#define GEMM_ASTORE(A0, A1, A2, A3, buf)                                               \
     *reinterpret_cast<uint4*>(as + ((buf) * BM + 0) * LDSK) = A0;                      \
     *reinterpret_cast<uint4*>(as + ((buf) * BM + 32) * LDSK) = A1;                     \
     *reinterpret_cast<uint4*>(as + ((buf) * BM + 64) * LDSK) = A2;                     \
-    *reinterpret_cast<uint4*>(as + ((buf) * BM + 96) * LDSK) = A3;                     \
-    *reinterpret_cast<uint4*>(ws + ((buf) * BN + 0) * LDSK) = W0;                      \
-    *reinterpret_cast<uint4*>(ws + ((buf) * BN + 32) * LDSK) = W1;                     \
-    *reinterpret_cast<uint4*>(ws + ((buf) * BN + 64) * LDSK) = W2;                     \
-    *reinterpret_cast<uint4*>(ws + ((buf) * BN + 96) * LDSK) = W3;
-#define GEMM_COMPUTE(buf)                                                                                   \
+    *reinterpret_cast<uint4*>(as + ((buf) * BM + 96) * LDSK) = A3;
+    // unit (x, ks) of this wave's 64-feature span: wp + (x * (K / 32) + ks) * 64 lanes; a k-tile = k-steps 2 kt, 2 kt + 1
+#define GEMM_WLOAD(WS, wp, kt)                                                                     \
+    _Pragma("unroll") for (int x = 0; x < 4; ++x) {                                                \
+        WS[2 * x] = wp[((size_t)x * (2 * nk) + 2 * (kt)) * 64];                                    \
+        WS[2 * x + 1] = wp[((size_t)x * (2 * nk) + 2 * (kt) + 1) * 64];                            \
+    }
+#define GEMM_COMPUTE(buf, WS)                                                                               \
     {                                                                                                       \
         const bf16raw* Ab = As + (size_t)(buf) * BM * LDSK + (size_t)(64 * wm + j) * LDSK + 8 * g;          \
-        const bf16raw* Wb = Ws + (size_t)(buf) * BN * LDSK + (size_t)(64 * wn + wrow) * LDSK + 8 * g;       \
         _Pragma("unroll") for (int s = 0; s < BK / 32; ++s) {                                               \
-            bf16x8 wf[4], af[4];                                                                            \
-            _Pragma("unroll") for (int x = 0; x < 4; ++x) {                                                 \
-                wf[x] = *reinterpret_cast<const bf16x8*>(Wb + (size_t)(32 * (x >> 1) + 4 * (x & 1)) * LDSK + 32 * s); \
-                af[x] = *reinterpret_cast<const bf16x8*>(Ab + (size_t)(16 * x) * LDSK + 32 * s);            \
-            }                                                                                               \
+            bf16x8 af[4];                                                                                   \
+            _Pragma("unroll") for (int y = 0; y < 4; ++y)                                                   \
+                af[y] = *reinterpret_cast<const bf16x8*>(Ab + (size_t)(16 * y) * LDSK + 32 * s);            \
             _Pragma("unroll") for (int x = 0; x < 4; ++x)                                                   \
-                _Pragma("unroll") for (int y = 0; y < 4; ++y) acc[x][y] = mfma_bf16(wf[x], af[y], acc[x][y]); \
+                _Pragma("unroll") for (int y = 0; y < 4; ++y)                                               \
+                    acc[x][y] = mfma_bf16(__builtin_bit_cast(bf16x8, WS[2 * x + s]), af[y], acc[x][y]);     \
         }                                                                                                   \
     }
-    // Feature order inside a wave's 64-feature span: MFMA row i of fragment x = 2 p + q is feature 32 p + 8 (i >> 2) + 4 q
-    // + (i & 3), so that the 4 + 4 accumulator values a lane holds for the fragment pair (2 p, 2 p + 1) are EIGHT
-    // consecutive features - one 16-byte bf16 store (two for fp32) instead of two scattered 8-byte ones.
-    const int wrow = 8 * (j >> 2) + (j & 3);
     int tile = blockIdx.x;
     if (tile >= n_tiles) return;
     auto a_ptr = [&](int tl) { return a.A + ((size_t)(tl / tiles_n) * BM + lr) * a.K + lc; };
-    auto w_ptr = [&](int tl) { return a.W + ((size_t)(tl % tiles_n) * BN + lr) * a.K + lc; };
+    // this wave's packed weight span of output tile tl: 64-feature span index = (tl % tiles_n) * 2 + wn
+    auto w_ptr = [&](int tl) {
+        return reinterpret_cast<const uint4*>(a.W) + ((size_t)((tl % tiles_n) * 2 + wn) * 4 * (2 * nk)) * 64 + lane;
+    };
     const bf16raw* ag = a_ptr(tile);
-    const bf16raw* wg = w_ptr(tile);
-    GEMM_GLOAD(ra0, ra1, ra2, ra3, rw0, rw1, rw2, rw3, ag, wg)
-    GEMM_GLOAD(rb0, rb1, rb2, rb3, rv0, rv1, rv2, rv3, ag + BK, wg + BK)
-    GEMM_SSTORE(ra0, ra1, ra2, ra3, rw0, rw1, rw2, rw3, 0)
+    const uint4* wp = w_ptr(tile);
+    GEMM_ALOAD(ra0, ra1, ra2, ra3, ag)
+    GEMM_ALOAD(rb0, rb1, rb2, rb3, ag + BK)
+    GEMM_WLOAD(w0, wp, 0)
+    GEMM_ASTORE(ra0, ra1, ra2, ra3, 0)
     __syncthreads();
     while (true) {
         const int tm_idx = tile / tiles_n, tn_idx = tile - tm_idx * tiles_n;
@@ -199,33 +199,33 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         const int next_tile = tile + gridDim.x;
         const bool have_next = next_tile < n_tiles;
         const bf16raw* agn = have_next ? a_ptr(next_tile) : ag;
-        const bf16raw* wgn = have_next ? w_ptr(next_tile) : wg;
-        f32x4 acc[4][4];   // [feature tile][token tile]: lane (g, j) holds features 4 g + m of token j
+        const uint4* wpn = have_next ? w_ptr(next_tile) : wp;
+        f32x4 acc[4][4];   // [feature fragment][token tile]
 #pragma unroll
         for (int x = 0; x < 4; ++x)
 #pragma unroll
             for (int y = 0; y < 4; ++y) acc[x][y] = splat4(0.f);
 #pragma unroll 1
         for (int kt = 0; kt < nk; kt += 2) {
-            // LDS buffer 0 = k-tile kt, register set b = k-tile kt + 1; set a is free
+            // LDS buffer 0 = A k-tile kt, register set b = A k-tile kt + 1, set a free; w0 = W k-tile kt, w1 free
             const bool wrap = kt + 2 >= nk;               // the k-tiles after this pair belong to the next output tile
             const bool more = !wrap || have_next;
+            GEMM_WLOAD(w1, wp, kt + 1)
             if (more) {
                 const bf16raw* an = wrap ? agn : ag + (kt + 2) * BK;
-                const bf16raw* wn_ = wrap ? wgn : wg + (kt + 2) * BK;
-                GEMM_GLOAD(ra0, ra1, ra2, ra3, rw0, rw1, rw2, rw3, an, wn_)
+                GEMM_ALOAD(ra0, ra1, ra2, ra3, an)
             }
-            GEMM_COMPUTE(0)
-            GEMM_SSTORE(rb0, rb1, rb2, rb3, rv0, rv1, rv2, rv3, 1)   // buffer 1 was last read before the previous barrier
+            GEMM_COMPUTE(0, w0)
+            GEMM_ASTORE(rb0, rb1, rb2, rb3, 1)   // buffer 1 was last read before the previous barrier
             __syncthreads();
             if (more) {
                 const bf16raw* an = wrap ? agn + BK : ag + (kt + 3) * BK;
-                const bf16raw* wn_ = wrap ? wgn + BK : wg + (kt + 3) * BK;
-                GEMM_GLOAD(rb0, rb1, rb2, rb3, rv0, rv1, rv2, rv3, an, wn_)
+                GEMM_ALOAD(rb0, rb1, rb2, rb3, an)
+                if (wrap) { GEMM_WLOAD(w0, wpn, 0) } else { GEMM_WLOAD(w0, wp, kt + 2) }
             }
-            GEMM_COMPUTE(1)
+            GEMM_COMPUTE(1, w1)
             if (more) {
-                GEMM_SSTORE(ra0, ra1, ra2, ra3, rw0, rw1, rw2, rw3, 0)
+                GEMM_ASTORE(ra0, ra1, ra2, ra3, 0)
                 __syncthreads();
             }
         }
@@ -281,11 +281,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     }
         if (!have_next) break;
         tile = next_tile;
-        ag = a_ptr(tile);
-        wg = w_ptr(tile);
+        ag = agn;
+        wp = wpn;
     }
-#undef GEMM_GLOAD
-#undef GEMM_SSTORE
+#undef GEMM_ALOAD
+#undef GEMM_ASTORE
+#undef GEMM_WLOAD
 #undef GEMM_COMPUTE
 }
 
@@ -509,7 +510,7 @@ hipError_t launch_gemm_t(const GemmArgs& a, hipStream_t s) {
         attr = true;
     }
     const int n_tiles = ((a.M + BM - 1) / BM) * (a.N / BN);
-    const int resident = 2 * 256;   // two 72 KiB workgroups per CU, 256 CUs: one persistent workgroup per slot
+    const int resident = 2 * 256;   // two workgroups (8 waves, 2 per SIMD at this register count) per CU, 256 CUs
     hipLaunchKernelGGL(k_gemm_bf16<EPI>, dim3(n_tiles < resident ? n_tiles : resident), dim3(256), kGemmLds, s, a);
     return hipGetLastError();
 }

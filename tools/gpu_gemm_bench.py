@@ -9,22 +9,32 @@ lib = _lib.load()
 M = 32 * 1214
 Mp = (M + 255) // 256 * 256
 p = lambda t: C.c_void_p(t.data_ptr())
+
+
+def pack_w(w):
+    """[N, K] -> the kernel's fragment order: [span][x = (p, q)][k-step][lane = (g, i = (a, b))][e], feature = 64 span +
+    32 p + 8 a + 4 q + b, k = 32 ks + 8 g + e  (amuse_audio_api.hip pack_w)."""
+    N, K = w.shape
+    v = w.view(N // 64, 2, 4, 2, 4, K // 32, 4, 8)          # span, p, a, q, b, ks, g, e
+    return v.permute(0, 1, 3, 5, 6, 2, 4, 7).contiguous().view(-1)
+
 for (N, K) in ((2304, 768), (768, 768), (3072, 768), (768, 3072)):
     a = torch.zeros(Mp, K, device="cuda", dtype=torch.bfloat16)
     a[:M] = torch.randn(M, K, device="cuda").to(torch.bfloat16)
     w = (0.05 * torch.randn(N, K, device="cuda")).to(torch.bfloat16)
     bias = torch.randn(N, device="cuda")
     out = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
-    _lib.check(lib.amuse_debug_gemm(p(a), p(w), p(bias), M, N, K, 0, p(out), None))
+    wpk = pack_w(w)
+    _lib.check(lib.amuse_debug_gemm(p(a), p(wpk), p(bias), M, N, K, 0, p(out), None))
     ref = (a[:M].float() @ w.float().T + bias)
     err = float((out.float() - ref).abs().max() / ref.abs().max())
     for _ in range(3):
-        lib.amuse_debug_gemm(p(a), p(w), p(bias), M, N, K, 0, p(out), None)
+        lib.amuse_debug_gemm(p(a), p(wpk), p(bias), M, N, K, 0, p(out), None)
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(20):
-        lib.amuse_debug_gemm(p(a), p(w), p(bias), M, N, K, 0, p(out), None)
+        lib.amuse_debug_gemm(p(a), p(wpk), p(bias), M, N, K, 0, p(out), None)
     e1.record()
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / 20
