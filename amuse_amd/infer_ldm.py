@@ -29,6 +29,22 @@ from .audio import AudioEngine
 from .engine import HipEngine
 
 
+# dm/utils/ldm_evals.py:79-87: the two BEAT takes per emotion the edit tasks draw on
+TAKES = {"neutral": ["0_9_9", "0_10_10"], "happy": ["0_65_65", "0_66_66"], "angry": ["0_73_73", "0_74_74"],
+         "sad": ["0_81_81", "0_82_82"], "contempt": ["0_87_87", "0_88_88"], "surprise": ["0_95_95", "0_96_96"],
+         "fear": ["0_103_103", "0_104_104"], "disgust": ["0_111_111", "0_112_112"]}
+
+
+def mapinfo2takes(info, trainer=False):
+    """infer_ldm.py:519-528."""
+    if not trainer:
+        info = info.split("_")[1]
+    for emo in ("happy", "sad", "angry", "contempt", "disgust", "surprise", "fear"):
+        if emo in info:
+            return TAKES[emo]
+    raise Exception("Unknown emotion: ", info)
+
+
 class PretrainedLPDM_v1:
     def __init__(self, base_prior=None, base_con_ae=None, base_emo_ae=None, base_audio_ae=None,
                  audio_encoder: Optional[Callable] = None):
@@ -193,16 +209,55 @@ class PretrainedLPDM_v1:
         return {"z_motion": z, "z_con": con[:n], "z_emo": emo[:n] if emo is not None else None,
                 "z_sty": sty[:n] if sty is not None else None}
 
+    def _take_latents(self, entry: dict):
+        """What the reference does per take inside process_loader (infer_ldm.py:300-305, 359-364, 395-399):
+        `_loader_helper_v1(ld_motion, ld_waveform)` -> ld_z / ld_z_con / ld_z_emo / ld_z_sty.  Takes that already carry
+        their latents (precomputed embeddings, no raw data) are left as they are."""
+        if "ld_motion" not in entry or "ld_waveform" not in entry:
+            missing = [k for k in ("ld_z_con", "ld_z_emo", "ld_z_sty") if k not in entry]
+            if missing:
+                raise KeyError(f"take has neither (ld_motion, ld_waveform) nor the latents {missing}")
+            return
+        motion = torch.from_numpy(np.asarray(entry["ld_motion"])) if not isinstance(entry["ld_motion"], torch.Tensor) else entry["ld_motion"]
+        z = self._loader_helper_v1(motion, entry["ld_waveform"])
+        entry["ld_z"], entry["ld_z_con"], entry["ld_z_emo"], entry["ld_z_sty"] = z["z_motion"], z["z_con"], z["z_emo"], z["z_sty"]
+
     def process_loader(self, data_dict):
-        """Latent swapping of the edit tasks (infer_ldm.py:225-414) on takes whose ld_z_con / ld_z_emo / ld_z_sty
-        are already present (the reference computes them with AST + MotionPrior.encode in _loader_helper_v1)."""
+        """Latents + latent swapping of the edit tasks (infer_ldm.py:225-414): style_Xemo_transfer, style_transfer,
+        emotion_control, with the same dictionary keys.  skip_trans / train_upper_body variants are refused in setup
+        like every non-6D configuration."""
         loader_data = dict()
+        if self.style_Xemo_transfer:
+            info, data = data_dict["style_Xemo_transfer_info"], data_dict["style_Xemo_transfer"]
+            if "," in info:
+                raise NotImplementedError("Multiple style transfer not implemented yet")
+            # "[lu-lawrence]_[angry-happy]_*lu_angry_0_73_73*lu_happy_0_65_65*lawrence_angry_0_73_73*lawrence_happy_0_65_65*"
+            a1, a2 = info.split("_")[0][1:-1].split("-")
+            t1, t2, t3, t4 = ("_".join(info.split("*")[k].split("_")[2:]) for k in (1, 2, 3, 4))
+            assert all([t1 == t3, t2 == t4]), "Takes are not the same for style transfer!"
+            assert data[a1][t1]["ld_emo_label"] == data[a2][t1]["ld_emo_label"], \
+                f"Emotion labels are not the same for style transfer! {data[a1][t1]['ld_emo_label']} != {data[a2][t1]['ld_emo_label']}"
+            assert data[a1][t2]["ld_emo_label"] == data[a2][t2]["ld_emo_label"], \
+                f"Emotion labels are not the same for style transfer! {data[a1][t2]['ld_emo_label']} != {data[a2][t2]['ld_emo_label']}"
+            for actor, take in ((a1, t1), (a2, t3), (a1, t2), (a2, t4)):
+                self._take_latents(data[actor][take])
+            for (xa, xt), (ya, yt) in (((a1, t1), (a2, t4)), ((a2, t3), (a1, t2)), ((a1, t2), (a2, t3)), ((a2, t4), (a1, t1))):
+                data[xa][xt][f"ld_z_emo_{ya}_{yt}"] = data[ya][yt]["ld_z_emo"]
+                data[xa][xt][f"ld_z_sty_{ya}_{yt}"] = data[ya][yt]["ld_z_sty"]
+            data["takes"] = f"{t1}*{t2}*{t3}*{t4}"
+            loader_data["style_Xemo_transfer"] = data
         if self.style_transfer:
             data, info = data_dict["style_transfer"], data_dict["style_transfer_info"]
             if "," in info:
                 raise NotImplementedError("Multiple style transfer not implemented yet")
-            a1, a2 = info.split("_")[0][1:-1].split("-")
-            for take in [t for t in data[a1].keys() if t in data[a2]]:
+            a1, a2 = info.split("_")[0][1:-1].split("-")                       # "[ayana-scott]_[fear]"
+            t1, t2 = mapinfo2takes(info)
+            assert data[a1][t1]["ld_emo_label"] == data[a2][t1]["ld_emo_label"] == \
+                   data[a1][t2]["ld_emo_label"] == data[a2][t2]["ld_emo_label"], \
+                   "Emotion labels are not the same for style transfer!"
+            for actor, take in ((a1, t1), (a2, t1), (a1, t2), (a2, t2)):
+                self._take_latents(data[actor][take])
+            for take in (t1, t2):
                 # NB the reference stores the partner's EMO latent under "sty" and vice versa (infer_ldm.py:371-381)
                 data[a1][take][f"ld_z_sty_{a2}"] = data[a2][take]["ld_z_emo"]
                 data[a1][take][f"ld_z_emo_{a2}"] = data[a2][take]["ld_z_sty"]
@@ -215,10 +270,11 @@ class PretrainedLPDM_v1:
                 raise NotImplementedError("Emotion control with multiple actors or multiple content emotions not implemented yet")
             for actor in data.keys():
                 for take in data[actor].keys():
+                    self._take_latents(data[actor][take])
+            for actor in data.keys():
+                for take in data[actor].keys():
                     for other in data[actor].keys():
                         if other != take:
                             data[actor][take][f"ld_z_emo_{other}"] = data[actor][other]["ld_z_emo"]
             loader_data["emotion_control"] = data
-        if self.style_Xemo_transfer:
-            raise NotImplementedError("style_Xemo_transfer needs the dataset-driven loader (out of scope)")
         return loader_data

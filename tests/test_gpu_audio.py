@@ -116,6 +116,12 @@ def test_host_mirror_process_single_seq_and_loader_helper(env):
     c0 = eng.features(wave[0, 0:160000][None])[0]
     c1 = eng.features(wave[0, 1:160001][None])[0]
     assert torch.equal(z["z_con"][0], c0[0]) and torch.equal(z["z_con"][1], c1[0])
+    # process_loader computes the latents itself when the takes carry raw motion + waveform (infer_ldm.py:392-399)
+    m.style_transfer, m.emotion_control, m.style_Xemo_transfer = False, True, False
+    data = {"wayne": {t: {"ld_motion": motion.numpy(), "ld_waveform": _waves(160000, 1, seed=s_)} for t, s_ in (("a", 31), ("b", 32))}}
+    out = m.process_loader({"emotion_control": data, "emotion_control_info": "[wayne]_[happy]_first"})["emotion_control"]
+    assert out["wayne"]["a"]["ld_z"].shape == (2, 128) and out["wayne"]["a"]["ld_z_con"].shape == (1, 256)
+    assert torch.equal(out["wayne"]["a"]["ld_z_emo_b"], out["wayne"]["b"]["ld_z_emo"])
     m.audio_engine = None                                              # the fixture owns the engine
 
 

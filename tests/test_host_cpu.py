@@ -125,11 +125,35 @@ def test_process_loader_swaps_like_the_reference():
     t0 = out["emotion_control"]["wayne"]["take0"]
     assert t0["ld_z_emo_take1"] == 11 and t0["ld_z_emo_take2"] == 12 and "ld_z_emo_take0" not in t0
     m.style_transfer, m.emotion_control = True, False
-    data = {"ayana": {"t": mk(1)}, "scott": {"t": mk(2)}}
+    f1, f2 = "0_103_103", "0_104_104"                      # the two "fear" takes (dm/utils/ldm_evals.py:86)
+    lab = lambda d: dict(d, ld_emo_label="fear")
+    data = {"ayana": {f1: lab(mk(1)), f2: lab(mk(3))}, "scott": {f1: lab(mk(2)), f2: lab(mk(4))}}
     out = m.process_loader({"style_transfer": data, "style_transfer_info": "[ayana-scott]_[fear]"})
     # the reference's crosswise quirk: partner's EMO latent is filed under "sty" (infer_ldm.py:371-381)
-    assert out["style_transfer"]["ayana"]["t"]["ld_z_sty_scott"] == 12
-    assert out["style_transfer"]["ayana"]["t"]["ld_z_emo_scott"] == 22
+    assert out["style_transfer"]["ayana"][f1]["ld_z_sty_scott"] == 12
+    assert out["style_transfer"]["ayana"][f1]["ld_z_emo_scott"] == 22
+    assert out["style_transfer"]["scott"][f2]["ld_z_sty_ayana"] == 13
+    data["scott"][f2]["ld_emo_label"] = "happy"
+    with pytest.raises(AssertionError, match="Emotion labels are not the same"):
+        m.process_loader({"style_transfer": data, "style_transfer_info": "[ayana-scott]_[fear]"})
+    # style x emotion transfer (infer_ldm.py:264-322): four takes named in the info string, emotion AND style swapped
+    m.style_transfer, m.style_Xemo_transfer = False, True
+    ta, th = "0_73_73", "0_65_65"
+    la = lambda d, e: dict(d, ld_emo_label=e)
+    data = {"lu": {ta: la(mk(1), "angry"), th: la(mk(2), "happy")}, "lawrence": {ta: la(mk(3), "angry"), th: la(mk(4), "happy")}}
+    info = "[lu-lawrence]_[angry-happy]_*lu_angry_0_73_73*lu_happy_0_65_65*lawrence_angry_0_73_73*lawrence_happy_0_65_65*"
+    out = m.process_loader({"style_Xemo_transfer": data, "style_Xemo_transfer_info": info})["style_Xemo_transfer"]
+    assert out["takes"] == f"{ta}*{th}*{ta}*{th}"
+    assert out["lu"][ta][f"ld_z_emo_lawrence_{th}"] == 14 and out["lu"][ta][f"ld_z_sty_lawrence_{th}"] == 24
+    assert out["lawrence"][th][f"ld_z_emo_lu_{ta}"] == 11
+    # a take with neither raw data nor latents is an error; unknown emotions as in mapinfo2takes
+    m.style_Xemo_transfer, m.emotion_control = False, True
+    with pytest.raises(KeyError):
+        m.process_loader({"emotion_control": {"wayne": {"t": {"ld_z_con": 1}}}, "emotion_control_info": "[wayne]_[neutral]_first"})
+    from amuse_amd.infer_ldm import mapinfo2takes
+    assert mapinfo2takes("[a-b]_[sad]") == ["0_81_81", "0_82_82"]
+    with pytest.raises(Exception):
+        mapinfo2takes("[a-b]_[bored]")
     with pytest.raises(NotImplementedError):
         m.process_single_seq(torch.zeros(1, 160000))
 
