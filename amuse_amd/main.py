@@ -94,6 +94,7 @@ def main(argv=None):
     ap.add_argument("--device", default="cuda:0")
     ap.add_argument("--seed", type=int, default=2024)
     ap.add_argument("--actor", default="scott")   # hard-coded in the reference (trainer.py:518)
+    ap.add_argument("--betas-from", default=None, help="SMPL-X npz of the actor whose `betas` go into the outputs")
     args = ap.parse_args(argv)
     t0 = time.time()
     fixseed(args.seed)
@@ -127,18 +128,19 @@ def main(argv=None):
     stamp = time.strftime("%Y%m%d-%H%M%S")
     root = Path(args.out) / f"Custom_audios_{stamp}_E{epoch}" / "rep0"
     written = []
+    betas = np.load(args.betas_from, allow_pickle=True)["betas"] if args.betas_from else None
     if args.fn == "infer_gesture":     # trainer.py:516-539: one diffusion_backward(1, ...) per audio
         for i in range(con.shape[0]):
             r = model.diffusion_backward(1, con[i:i + 1], emo[i:i + 1], sty[i:i + 1])
-            written += write_sample(pack_feats(r["poses"], r["trans"]), root / f"rst_{i}", args.actor)
+            written += write_sample(pack_feats(r["poses"], r["trans"]), root / f"rst_{i}", args.actor, betas=betas)
     else:                              # trainer.py:1037-1075: original, then the same with the target's emotion
         for i in range(con.shape[0]):
             c0 = model._clip_counter
             a = model.diffusion_backward(1, con[i:i + 1], emo[i:i + 1], sty[i:i + 1], clip_index0=c0)
             b = model.diffusion_backward(1, con[i:i + 1], tgt[i:i + 1], sty[i:i + 1], clip_index0=c0)
             model._clip_counter += 1
-            written += write_sample(pack_feats(a["poses"], a["trans"]), root / f"pair_{i}" / "rst_0", args.actor)
-            written += write_sample(pack_feats(b["poses"], b["trans"]), root / f"pair_{i}" / "rst_1", args.actor)
+            written += write_sample(pack_feats(a["poses"], a["trans"]), root / f"pair_{i}" / "rst_0", args.actor, betas=betas)
+            written += write_sample(pack_feats(b["poses"], b["trans"]), root / f"pair_{i}" / "rst_1", args.actor, betas=betas)
     torch.cuda.synchronize()
     print(f"[LDM EVAL] {args.fn} done: {len(written)} NPZ files under {root}, total time elapsed: {time.time() - t0:.4f} s")
     return written

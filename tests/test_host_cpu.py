@@ -49,9 +49,14 @@ def test_npz_writer_matches_reference_layout(tmp_path):
     z = np.load(paths[0], allow_pickle=True)
     ref = next(iter(lay.values()))["fields"]
     for k, (dt, shape) in ref.items():
-        if k == "gender":
-            continue
         assert str(z[k].dtype) == dt and list(z[k].shape) == shape, k
+    assert str(z["gender"]) == "male"                       # scott (dm/utils/ldm_evals.py:67-71)
+    from amuse_amd.npz_writer import subject2gender
+    assert subject2gender("miranda") == "female"
+    with pytest.raises(KeyError):
+        subject2gender("nobody")
+    z2 = np.load(write_sample(feats[:1], tmp_path / "rst_1", "miranda", betas=np.arange(300.0))[0], allow_pickle=True)
+    assert str(z2["gender"]) == "female" and np.array_equal(z2["betas"], np.arange(300.0))
     assert np.all(z["trans"] == 0) and float(z["mocap_frame_rate"]) == 30.0
     assert np.all(z["poses"][:, LOWER_BODY_JOINTS] == z["poses"][0, LOWER_BODY_JOINTS])
     other = [j for j in range(55) if j not in LOWER_BODY_JOINTS]
