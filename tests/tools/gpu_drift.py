@@ -3,7 +3,7 @@ fp32-vs-bf16-autocast drift rows), and fp32 DDPM-1000 vs the CPU oracle for one 
 import sys, json
 from pathlib import Path
 import numpy as np, torch
-REPO = Path(__file__).resolve().parents[1]
+REPO = Path(__file__).resolve().parents[2]
 sys.path.insert(0, str(REPO))
 from amuse_amd import weights as wts, scheduler as sch
 from amuse_amd.engine import HipEngine
