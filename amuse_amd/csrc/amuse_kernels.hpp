@@ -61,7 +61,7 @@ hipError_t launch_counter_normal(uint64_t seed, uint64_t clip0, int B, int step,
                                  hipStream_t stream);
 
 // ---------------------------------------------------------------- VAE decode (k_vae.hip)
-constexpr int kVaeRing = 32;    // k_vae_rows weight ring; the packed decoder stream is padded by this many units
+constexpr int kVaeRing = 16;    // k_vae_rows weight ring; the packed decoder stream is padded by this many units
 constexpr int kVaeStages = 10;  // stage 0: PE + QKV(0); stage i+1: post-attention of block i (+ QKV(i+1) | final)
 struct VaeRowsArgs {
     const uint4* wstream;             // packed decoder weights (per precision)

@@ -21,7 +21,10 @@ namespace {
 
 constexpr int kRowTiles = 19;       // ceil(300 / 16)
 constexpr int kFeatStride = 388;    // 384 padded features + 4: LDS row stride of the staged feats tile
-constexpr int kRowsLdsBytes = kExchBytes + 16 * kFeatStride * 4;
+// LDS: the split-K combine buffers (amuse_dev.hpp combine_rs, 41,472 B); the staged feature tile of the last stage
+// (16 x 388 floats) reuses them - every combine is over by then.  Two workgroups fit a CU.
+constexpr int kRowsLdsBytes = kCombBytes;
+static_assert(16 * kFeatStride * 4 <= kCombBytes, "staged feature tile must fit the combine buffers");
 constexpr int kVR = kVaeRing;       // weight-stream ring depth of k_vae_rows
 
 __device__ __forceinline__ void rot6d_to_axis_angle(const float* d6, int quat_mode, float (&aa)[3]) {
@@ -71,11 +74,11 @@ __device__ __forceinline__ void rot6d_to_axis_angle(const float* d6, int quat_mo
 // [2 distribution tokens | 300 embedded frames], TransformerEncoderLayer blocks (no cross-attention, two norms),
 // stage 0 = skel_embedding + token concat + PE, last stage = encoder.norm of the two distribution rows only.
 template <int PREC, bool ENC>
-__global__ __launch_bounds__(256) void k_vae_rows(VaeRowsArgs a) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_vae_rows(VaeRowsArgs a) {
     constexpr int S = ENC ? kFrames + 2 : kFrames;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    f32x4* exch = reinterpret_cast<f32x4*>(smem);
-    float* fst = reinterpret_cast<float*>(smem + kExchBytes);  // [16][kFeatStride] staged feats (last stage)
+    char* comb = smem;
+    float* fst = reinterpret_cast<float*>(smem);  // [16][kFeatStride] staged feats (last stage)
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int g = lane >> 4, r = lane & 15;
@@ -95,7 +98,7 @@ __global__ __launch_bounds__(256) void k_vae_rows(VaeRowsArgs a) {
     constexpr int P_O = 0, P_F1 = U_O % kVR, P_F2 = (P_F1 + U_F) % kVR, P_S = (P_F2 + U_F) % kVR;
     constexpr int P_Q0 = P_S, P_Q1 = (P_S + U_S) % kVR;   // in_proj / final phase without / with a skip linear before
     bool skipped = false;
-    int parity = 0;
+    constexpr bool FAST = (PREC == PREC_BF16);
     f32x4 x[kTiles];
 
     constexpr int kEmbK = 22;  // 333 input features padded to 22 k-tiles (zero weights / zero operands beyond 333)
@@ -119,11 +122,12 @@ __global__ __launch_bounds__(256) void k_vae_rows(VaeRowsArgs a) {
             f32x4 part[kTiles];
 #pragma unroll
             for (int t = 0; t < kTiles; ++t) part[t] = (t >> 1) == wave ? acc[t & 1] : splat4(0.f);
-            exchange_sum(part, exch, parity, wave, lane);  // all-gather of the four waves' tile pairs
+            // all-gather of the four waves' tile pairs (+ skel_embedding.bias)
+            combine_rs<false, FAST>(part, x, false, a.emb_bias, nullptr, nullptr, comb, wave, lane);
 #pragma unroll
             for (int t = 0; t < kTiles; ++t) {
                 const int c = 16 * t + 4 * g;
-                const f32x4 e = fvalid ? part[t] + ld4(a.emb_bias + c) : ld4(a.tok + (frame & 1) * kD + c);
+                const f32x4 e = fvalid ? x[t] : ld4(a.tok + (frame & 1) * kD + c);
                 x[t] = rvalid ? e + ld4(a.pe + (size_t)frame * kD + c) : splat4(0.f);
             }
         } else {  // queries = zeros + query_pos_decoder.pe[:300]  (vae.py:220,258)
@@ -145,10 +149,7 @@ __global__ __launch_bounds__(256) void k_vae_rows(VaeRowsArgs a) {
 #pragma unroll
         for (int t = 0; t < kTiles; ++t) part[t] = splat4(0.f);
         gemm_ring<PREC, kTiles, 2, false, kVR, P_O>(part, o, rg);
-        exchange_sum(part, exch, parity, wave, lane);
-#pragma unroll
-        for (int t = 0; t < kTiles; ++t) x[t] = x[t] + (part[t] + ld4(pv + PV_OUT_B + 16 * t + 4 * g));
-        layer_norm_rows<PREC == PREC_BF16>(x, pv + PV_LN1_W, pv + PV_LN1_B, g);
+        combine_rs<true, FAST>(part, x, true, pv + PV_OUT_B, pv + PV_LN1_W, pv + PV_LN1_B, comb, wave, lane);
         if constexpr (!ENC) {
             // cross-attention onto the single latent token == per-clip constant; residual + norm2
             const float* ca = a.ca + ((size_t)b * kLayers + blk) * kD;
@@ -168,10 +169,8 @@ __global__ __launch_bounds__(256) void k_vae_rows(VaeRowsArgs a) {
 #pragma unroll
         for (int t = 0; t < kTiles; ++t) part[t] = splat4(0.f);
         gemm_ring<PREC, kTiles, kTiles, false, kVR, P_F2>(part, hid, rg);
-        exchange_sum(part, exch, parity, wave, lane);
-#pragma unroll
-        for (int t = 0; t < kTiles; ++t) x[t] = x[t] + (part[t] + ld4(pv + PV_L2_B + 16 * t + 4 * g));
-        layer_norm_rows<PREC == PREC_BF16>(x, pv + (ENC ? PV_LN2_W : PV_LN3_W), pv + (ENC ? PV_LN2_B : PV_LN3_B), g);
+        combine_rs<true, FAST>(part, x, true, pv + PV_L2_B, pv + (ENC ? PV_LN2_W : PV_LN3_W), pv + (ENC ? PV_LN2_B : PV_LN3_B),
+                               comb, wave, lane);
         if (blk < 4 && wave == 0 && rvalid) {  // xs.append(x)
             float* sk = a.skip + ((size_t)blk * nrows + row) * kD;
 #pragma unroll
@@ -189,10 +188,7 @@ __global__ __launch_bounds__(256) void k_vae_rows(VaeRowsArgs a) {
             for (int t = 0; t < kTiles; ++t) part[t] = splat4(0.f);
             gemm_ring<PREC, kTiles, 4, false, kVR, P_S>(part, src, rg);
             skipped = true;
-            exchange_sum(part, exch, parity, wave, lane);
-            const float* sb = a.pvec + PV_SKIP_B + (blk - 4) * kD;
-#pragma unroll
-            for (int t = 0; t < kTiles; ++t) x[t] = part[t] + ld4(sb + 16 * t + 4 * g);
+            combine_rs<false, FAST>(part, x, false, a.pvec + PV_SKIP_B + (blk - 4) * kD, nullptr, nullptr, comb, wave, lane);
         }
     }
 
