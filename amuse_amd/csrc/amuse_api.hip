@@ -5,6 +5,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <string>
@@ -214,6 +215,8 @@ struct amuse_ctx {
     // denoiser
     uint4* den_w[2] = {nullptr, nullptr};
     uint32_t den_wave_units[2] = {0, 0};
+    uint4* den_w8 = nullptr;           // bf16 streams of the 8-wave kernel (k_sampler8.hip)
+    uint32_t den_w8_units[2] = {0, 0}; // per-step units of a group-A / group-B wave
     float* den_pvec = nullptr;
     float* den_pe = nullptr;           // [500][128]
     float* den_freqs = nullptr;        // [128]
@@ -285,6 +288,39 @@ int build_ctx(amuse_ctx* c, const float* den, const float* pri) {
         }
         c->den_wave_units[prec] = (uint32_t)(per_wave / 64);
         if (upload(&c->den_w[prec], all.data(), all.size() * sizeof(uint4))) return AMUSE_EHIP;
+    }
+    {   // 8-wave bf16 kernel: wave w8 = 4 s + h; A waves (s = 0) carry head h + FFN quarters 0,1, B waves quarters 2,3
+        std::vector<uint4> all;
+        for (int w8 = 0; w8 < 8; ++w8) {
+            const int h = w8 & 3, sgrp = w8 >> 2;
+            std::vector<uint4> s;
+            // per block, in issue order (k_sampler8.hip).  A: in_proj q,k | v | out_proj - ahead of an output block
+            // the skip linear takes out_proj's place, which follows as a group of its own.  B: skip linear, then
+            // the FFN slice of head h in the software-pipelined quarter order of the 4-wave kernel.
+            for (int b = 0; b < 9; ++b) {
+                const std::string p = blk_name("encoder", b);
+                auto skip = [&] {
+                    pack_gemm(s, PREC_BF16, D.get("encoder.linear_blocks." + std::to_string(b - 5) + ".weight"), 128, 256,
+                              range(0, 8), {2 * w8, 2 * w8 + 1});
+                };
+                if (sgrp == 0) {
+                    pack_qkv(s, PREC_BF16, D.get(p + ".self_attn.in_proj_weight"), h, true);
+                    if (b >= 5) skip();
+                    pack_gemm(s, PREC_BF16, D.get(p + ".self_attn.out_proj.weight"), 128, 128, range(0, 8), {2 * h, 2 * h + 1});
+                } else {
+                    if (b >= 5) skip();
+                    auto f1 = [&](int q) { const int h0 = 8 * h + 2 * q; pack_gemm(s, PREC_BF16, D.get(p + ".linear1.weight"), 512, 128, {h0, h0 + 1}, range(0, 8)); };
+                    auto f2 = [&](int q) { const int h0 = 8 * h + 2 * q; pack_gemm(s, PREC_BF16, D.get(p + ".linear2.weight"), 128, 512, range(0, 8), {h0, h0 + 1}); };
+                    f1(0); f1(1); f2(0); f1(2); f2(1); f1(3); f2(2); f2(3);
+                }
+            }
+            uint32_t& units = c->den_w8_units[sgrp];
+            if (h == 0) units = (uint32_t)(s.size() / 64);
+            else if (s.size() / 64 != units) return fail(AMUSE_ESTATE, "internal: uneven 8-wave denoiser streams");
+            all.insert(all.end(), s.begin(), s.end());
+            if (sgrp == 0) all.insert(all.end(), s.begin(), s.begin() + (size_t)kRing8 * 64);  // ring wrap: tail = head
+        }
+        if (upload(&c->den_w8, all.data(), all.size() * sizeof(uint4))) return AMUSE_EHIP;
     }
     {
         auto pv = build_pvec(D, "encoder", false);
@@ -421,6 +457,24 @@ int pick_group(const amuse_ctx* c, int B, int S) {
     return g;
 }
 
+// weight stream + kernel choice for one sampling launch: fp32 -> 4-wave parity kernel; bf16 -> 8-wave throughput
+// kernel, unless phase stamps are requested or AMUSE_SAMPLE_WAVES=4 (A/B measurements) asks for the 4-wave one
+bool use_sample8(int precision) {
+    static const bool force4 = [] { const char* e = getenv("AMUSE_SAMPLE_WAVES"); return e && atoi(e) == 4; }();
+    return precision == PREC_BF16 && !force4;
+}
+void set_stream(const amuse_ctx* c, SampleArgs& a, int precision) {
+    a.wstream = c->den_w[precision]; a.wave_units = c->den_wave_units[precision];
+    a.wave_units_a = c->den_w8_units[0]; a.wave_units_b = c->den_w8_units[1];
+}
+hipError_t dispatch_sample(const amuse_ctx* c, SampleArgs& a, int precision, hipStream_t st) {
+    if (use_sample8(precision)) {  // with prof_out: stamps come back as [8 waves][96] in the same 768-entry buffer
+        a.wstream = c->den_w8;
+        return launch_sample8(a, st);
+    }
+    return launch_sample(a, precision, st);
+}
+
 int stage_lengths(amuse_ctx* c, const int* lengths, int B, hipStream_t st) {
     if (!lengths) return 0;
     for (int b = 0; b < B; ++b)
@@ -484,7 +538,7 @@ amuse_ctx* amuse_create(int device, const float* denoiser_params, size_t n_denoi
 void amuse_destroy(amuse_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
-    void* ptrs[] = {c->den_w[0], c->den_w[1], c->den_pvec, c->den_pe, c->den_freqs, c->te_w1t, c->te_b1, c->te_w2t,
+    void* ptrs[] = {c->den_w[0], c->den_w[1], c->den_w8, c->den_pvec, c->den_pe, c->den_freqs, c->te_w1t, c->te_b1, c->te_w2t,
                     c->te_b2, c->cond_wt[0], c->cond_wt[1], c->cond_wt[2], c->cond_b[0], c->cond_b[1], c->cond_b[2],
                     c->vae_w[0], c->vae_w[1], c->vae_pvec, c->vae_final_bias, c->vae_pe, c->vae_wv_t, c->vae_bv,
                     c->vae_wo_t, c->vae_bo, c->vaee_w[0], c->vaee_w[1], c->vaee_pvec, c->vaee_pe, c->vaee_tok,
@@ -533,13 +587,13 @@ int amuse_sample(amuse_ctx* c, const float* con, const float* emo, const float* 
     int S = 0;
     if (int e = cond_tokens(c, con, emo, sty, B, &S, st)) return e;
     SampleArgs a{};
-    a.wstream = c->den_w[precision]; a.wave_units = c->den_wave_units[precision];
+    set_stream(c, a, precision);
     a.pvec = c->den_pvec; a.time_tok = c->d_time_tok; a.cond_tok = c->cond_tok; a.pe0 = c->den_pe;
     a.coef = c->d_coef; a.x_init = x_init; a.step_noise = step_noise;
     a.latents_out = latents_out; a.traj_out = traj_out; a.eps_out = nullptr; a.tap_out = nullptr;
     a.seed = seed; a.clip0 = clip_index0;
     a.B = B; a.T = c->T; a.S = S; a.G = pick_group(c, B, S); a.no_update = 0;
-    HIP_TRY(launch_sample(a, precision, st));
+    HIP_TRY(dispatch_sample(c, a, precision, st));
     return 0;
 }
 
@@ -554,13 +608,13 @@ int amuse_profile_sample(amuse_ctx* c, const float* con, const float* emo, const
     if (int e = ensure(&c->lat_tmp, &c->lat_cap, (size_t)B * kD)) return e;
     HIP_TRY(hipMemsetAsync(stamps_out, 0, 4 * kProfStamps * sizeof(unsigned long long), st));
     SampleArgs a{};
-    a.wstream = c->den_w[precision]; a.wave_units = c->den_wave_units[precision];
+    set_stream(c, a, precision);
     a.pvec = c->den_pvec; a.time_tok = c->d_time_tok; a.cond_tok = c->cond_tok; a.pe0 = c->den_pe;
     a.coef = c->d_coef; a.latents_out = c->lat_tmp;
     a.seed = 1; a.clip0 = 0;
     a.B = B; a.T = c->T; a.S = S; a.G = pick_group(c, B, S); a.no_update = 0;
     a.prof_out = stamps_out; a.prof_step = prof_step;
-    HIP_TRY(launch_sample(a, precision, st));
+    HIP_TRY(dispatch_sample(c, a, precision, st));
     return 0;
 }
 
@@ -577,13 +631,13 @@ int amuse_denoise_step(amuse_ctx* c, const float* x_t, int timestep, const float
     int S = 0;
     if (int e = cond_tokens(c, con, emo, sty, B, &S, st)) return e;
     SampleArgs a{};
-    a.wstream = c->den_w[precision]; a.wave_units = c->den_wave_units[precision];
+    set_stream(c, a, precision);
     a.pvec = c->den_pvec; a.time_tok = c->d_tt1; a.cond_tok = c->cond_tok; a.pe0 = c->den_pe;
     a.coef = c->d_coef1; a.x_init = x_t; a.step_noise = nullptr;
     a.latents_out = nullptr; a.traj_out = nullptr; a.eps_out = eps_out; a.tap_out = tap_out;
     a.seed = 0; a.clip0 = 0;
     a.B = B; a.T = 1; a.S = S; a.G = pick_group(c, B, S); a.no_update = 1;
-    HIP_TRY(launch_sample(a, precision, st));
+    HIP_TRY(dispatch_sample(c, a, precision, st));
     return 0;
 }
 
@@ -611,11 +665,11 @@ int amuse_diffusion_forward(amuse_ctx* c, const float* z0, const float* noise, c
     int S = 0;
     if (int e = cond_tokens(c, con, emo, sty, B, &S, st)) return e;
     SampleArgs a{};
-    a.wstream = c->den_w[precision]; a.wave_units = c->den_wave_units[precision];
+    set_stream(c, a, precision);
     a.pvec = c->den_pvec; a.time_tok = ttok; a.time_tok_clip = ttok; a.cond_tok = c->cond_tok; a.pe0 = c->den_pe;
     a.coef = c->d_coef1; a.x_init = noisy; a.eps_out = noise_pred_out;
     a.B = B; a.T = 1; a.S = S; a.G = pick_group(c, B, S); a.no_update = 1;
-    HIP_TRY(launch_sample(a, precision, st));
+    HIP_TRY(dispatch_sample(c, a, precision, st));
     if (noisy_out) HIP_TRY(hipMemcpyAsync(noisy_out, noisy, (size_t)B * kD * sizeof(float), hipMemcpyDeviceToDevice, st));
     return 0;
 }

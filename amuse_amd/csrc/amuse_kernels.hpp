@@ -9,6 +9,8 @@ namespace amuse {
 struct SampleArgs {
     const uint4* wstream;     // packed denoiser weights: [4 waves][wave_units + kRing][64] x 16 B (head replicated at the tail)
     uint32_t wave_units;      // 1 KiB units per wave for one pass over the network
+    uint32_t wave_units_a, wave_units_b;  // k_sample8: per-step units of a group-A / group-B wave (streams laid out
+                              // [4 A waves][units_a + kRing8] then [4 B waves][units_b])
     const float* pvec;        // small fp32 parameters (amuse_dev.hpp PV_* layout)
     const float* time_tok;    // [T][128]  TimestepEmbedding(t_i) + pe[1]
     const float* time_tok_clip;  // [B][128] or null: per-clip time token of a teacher-forced step (diffusion_forward)
@@ -30,6 +32,9 @@ struct SampleArgs {
 };
 constexpr int kProfStamps = 192;
 hipError_t launch_sample(const SampleArgs& a, int precision, hipStream_t stream);
+// bf16 throughput kernel with 8 waves per workgroup (k_sampler8.hip); no phase-timeline instrumentation
+hipError_t launch_sample8(const SampleArgs& a, hipStream_t stream);
+constexpr int kRing8 = 32;
 constexpr int kRing = 32;                 // weight-stream ring depth (1 KiB units in flight per wave)
 // fp32: the skip linear (32 units per wave) is a whole ring revolution.  bf16 (16 units) needs no padding either:
 // the decoupled-issue scheme simply leaves half the ring empty for that GEMM (k_sampler.hip).
@@ -37,6 +42,8 @@ constexpr int skip_pad_units(int prec) { return prec == 0 ? (kRing - 32 % kRing)
 constexpr int kEncPv = 1664;              // encoder-block small params kept in LDS (PV_* up to LN2)
 constexpr int kSkipBytes = 32 * 1024;     // U-Net skip stack [4][8][64] f32x4
 constexpr int kSampleCombBytes = 4 * 8 * 64 * 16 + 4 * 16 * 8 + 8 * 64 * 16;  // = kCombBytes (amuse_dev.hpp), 41,472 B
+constexpr int kSample8LdsBytes = 8 * 8 * 64 * 16 + 8 * 16 * 8 + 4 * 4 * 64 * 16 + (9 * kEncPv + 4 * 128 + 2 * 128) * 4 +
+                                 2 * 8 * 64 * 16 + 2 * 128 * 4;  // 163,328 B (layout in k_sampler8.hip)
 constexpr int kSampleLdsBytes = kSampleCombBytes + kSkipBytes + (9 * kEncPv + 4 * 128 + 2 * 128) * 4;  // 137,216 B
 
 // ---------------------------------------------------------------- one-off prologue kernels (k_misc.hip)

@@ -1,0 +1,607 @@
+// bf16 throughput variant of the persistent sampling kernel (k_sampler.hip has the design notes and the fp32
+// parity kernel): the same T-step loop of PretrainedLPDM_v1.diffusion_backward (reference
+// models/latent_diffusion/infer_ldm.py:137-161; Denoiser.forward denoiser.py:135-204; encoder blocks
+// cross_attention.py:41-64,259-272; diffusers scheduler step) with EIGHT wavefronts per workgroup instead of four.
+//
+// Why: a wave's global_load blocks at issue while the CU's 64 B/clk vector-memory path is busy, so in the 4-wave
+// kernel the weight fetch (3.9 MB per step and CU) and the MFMA / LDS / barrier chain of the SAME waves add up
+// instead of overlapping.  Here the two halves of a block belong to different waves, and each
+// group fetches its weights while the OTHER group is on the critical path:
+//
+//   wave w8 = 4 s + h.
+//   Group A (s = 0): head h end to end - in_proj, attention, out_proj split-K - and the reduction + LayerNorm1 of
+//     the out_proj combine.  Its 32-unit ring is re-armed with the next block's units during the linear2 combine,
+//     where the A waves only wait for the B waves' result.
+//   Group B (s = 1): the FFN slice of head h (linear1 over hidden tiles 8h..8h+7, linear2 split-K over the same)
+//     and the reduction + LayerNorm2 of the linear2 combine.  Its ring is re-armed with the first half of the
+//     slice while the A waves run attention and the out_proj combine; the second half streams in during the FFN.
+//   U-Net skip linears: split-K over all 8 waves (k-tiles 2 w8, 2 w8 + 1 of cat(x, skip)); the skip stack is kept
+//     as packed bf16 MFMA operands (what the 4-wave kernel's cvt_pk produces from its fp32 copy - same bits).
+//   Token assembly in every wave; final LayerNorm + scheduler update in wave 0, latent in LDS.
+//
+// LDS (163,328 B): combine matrix A8 [8 rows][8 tiles][64] f32x4 - partials off the diagonal, reduced tiles ON the
+// diagonal (slot (t, t)), so the all-gather of one combine never aliases the partial writes of the next - | row
+// statistics | bf16 skip stack | small parameters | static token rows | latent | double-buffered time token.
+#include "amuse_dev.hpp"
+#include "amuse_kernels.hpp"
+
+namespace amuse {
+
+namespace {
+
+constexpr int kR8 = kRing8;
+constexpr int kA8Bytes = 8 * kTiles * 64 * 16;                 // 65,536
+constexpr int kStat8Off = kA8Bytes;                            // [8][16] float2
+constexpr int kSkip8Off = kStat8Off + 8 * 16 * 8;              // [4 levels][4 pairs][64] uint4
+constexpr int kPv8Off = kSkip8Off + 4 * 4 * 64 * 16;
+constexpr int kPv8Floats = kLayers * kEncPv + 4 * kD + 2 * kD;
+constexpr int kTokRows8Off = kPv8Off + kPv8Floats * 4;         // [8 tiles][64] f32x4
+constexpr int kLat8Off = kTokRows8Off + kTiles * 64 * 16;      // [8 tiles][64] f32x4: the latent (rows tok == 0)
+constexpr int kTT8Off = kLat8Off + kTiles * 64 * 16;           // [2][128] float
+static_assert(kTT8Off + 2 * kD * 4 == kSample8LdsBytes, "LDS layout");
+
+using Ring = WRing<kR8>;
+
+__device__ __forceinline__ f32x4* a8_slot(char* lds, int row, int col, int lane) {
+    return reinterpret_cast<f32x4*>(lds) + (row * kTiles + col) * 64 + lane;
+}
+
+// ---- split-K combine over the FOUR partials of one group (A: out_proj, B: linear2): wave h of the group reduces
+// tiles 2h, 2h+1, adds residual + bias, LayerNorm (row statistics merged over the four 32-feature slices with
+// Chan's formula), publishes them on the diagonal; every wave of the workgroup gathers the full tile.
+// The partial of tile t from wave h sits at row (t + 1 + h) & 7 (never the diagonal).
+template <int W, bool FAST>
+__device__ __forceinline__ void combine4_red(f32x4 (&part)[kTiles], f32x4 (&x)[kTiles], const float* bias,
+                                             const float* gamma, const float* beta, char* lds, int lane) {
+    float2* stats = reinterpret_cast<float2*>(lds + kStat8Off);
+    const int g = lane >> 4, r = lane & 15;
+    constexpr int T0 = 2 * W;
+#pragma unroll
+    for (int t = 0; t < kTiles; ++t)
+        if (t != T0 && t != T0 + 1) *a8_slot(lds, (t + 1 + W) & 7, t, lane) = part[t];
+    f32x4 bi[2], ga[2], be[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        bi[i] = ld4(bias + 16 * (T0 + i) + 4 * g);
+        ga[i] = ld4(gamma + 16 * (T0 + i) + 4 * g);
+        be[i] = ld4(beta + 16 * (T0 + i) + 4 * g);
+    }
+    __syncthreads();
+    f32x4 y[2];
+    {
+        f32x4 p[4][2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int w = 0; w < 4; ++w)
+                if (w != W) p[w][i] = *a8_slot(lds, (T0 + i + 1 + w) & 7, T0 + i, lane);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            p[W][i] = part[T0 + i];
+            const f32x4 sum = ((p[0][i] + p[1][i]) + p[2][i]) + p[3][i];
+            y[i] = x[T0 + i] + (sum + bi[i]);
+        }
+    }
+    float s = ((y[0][0] + y[0][1]) + (y[0][2] + y[0][3])) + ((y[1][0] + y[1][1]) + (y[1][2] + y[1][3]));
+    s = allreduce_g_sum(s);
+    const float mw = s * (1.0f / 32.0f);
+    float m2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            const float d = y[i][m] - mw;
+            m2 += d * d;
+        }
+    m2 = allreduce_g_sum(m2);
+    if (g == 0) stats[W * 16 + r] = float2{mw, m2};
+    __syncthreads();
+    const float2 s0 = stats[r], s1 = stats[16 + r], s2 = stats[32 + r], s3 = stats[48 + r];
+    const float mean = ((s0.x + s1.x) + (s2.x + s3.x)) * 0.25f;
+    const float d0 = s0.x - mean, d1 = s1.x - mean, d2 = s2.x - mean, d3 = s3.x - mean;
+    const float M2 = ((s0.y + s1.y) + (s2.y + s3.y)) + 32.0f * ((d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3));
+    const float var = M2 * (1.0f / kD) + 1e-5f;
+    const float rstd = FAST ? __builtin_amdgcn_rsqf(var) : 1.0f / sqrtf(var);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+#pragma unroll
+        for (int m = 0; m < 4; ++m) y[i][m] = (y[i][m] - mean) * rstd * ga[i][m] + be[i][m];
+        *a8_slot(lds, T0 + i, T0 + i, lane) = y[i];
+        x[T0 + i] = y[i];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int t = 0; t < kTiles; ++t)
+        if (t != T0 && t != T0 + 1) x[t] = *a8_slot(lds, t, t, lane);
+    asm volatile("; combine4 case %0" ::"n"(W));  // see combine8_impl
+}
+template <bool FAST>
+__device__ __forceinline__ void combine4_reduce(f32x4 (&part)[kTiles], f32x4 (&x)[kTiles], const float* bias,
+                                                const float* gamma, const float* beta, char* lds, int h, int lane) {
+    if (h == 0) combine4_red<0, FAST>(part, x, bias, gamma, beta, lds, lane);
+    else if (h == 1) combine4_red<1, FAST>(part, x, bias, gamma, beta, lds, lane);
+    else if (h == 2) combine4_red<2, FAST>(part, x, bias, gamma, beta, lds, lane);
+    else combine4_red<3, FAST>(part, x, bias, gamma, beta, lds, lane);
+}
+// the other group's side of the same combine: no partial - the barriers, the gather, and in between the issue of
+// NI weight-stream units into ring slots IPH0.. (these waves are off the critical path here, so their blocking
+// global_load issue costs nothing as long as it fits the reducers' three phases)
+template <int NI, int IPH0>
+__device__ __forceinline__ void combine4_observe(f32x4 (&x)[kTiles], char* lds, int lane, Ring& rg) {
+    static_assert(NI % 4 == 0, "issue count is split in four chunks");
+    constexpr int NC = NI / 4;
+    ring_issue<NC, kR8, IPH0 % kR8>(rg);
+    __syncthreads();
+    ring_issue<NC, kR8, (IPH0 + NC) % kR8>(rg);
+    __syncthreads();
+    ring_issue<NC, kR8, (IPH0 + 2 * NC) % kR8>(rg);
+    __syncthreads();
+#pragma unroll
+    for (int t = 0; t < kTiles; ++t) x[t] = *a8_slot(lds, t, t, lane);
+    ring_issue<NC, kR8, (IPH0 + 3 * NC) % kR8>(rg);
+}
+
+// ---- combine over EIGHT partials: wave W reduces tile W.   x <- [LN]([x +] sum_w part_w + bias)
+template <int W, bool DO_LN, bool FAST>
+__device__ __forceinline__ void combine8_impl(f32x4 (&part)[kTiles], f32x4 (&x)[kTiles], bool residual,
+                                              const float* bias, const float* gamma, const float* beta, char* lds,
+                                              int lane) {
+    float2* stats = reinterpret_cast<float2*>(lds + kStat8Off);
+    const int g = lane >> 4, r = lane & 15;
+#pragma unroll
+    for (int t = 0; t < kTiles; ++t)
+        if (t != W) *a8_slot(lds, W, t, lane) = part[t];
+    const f32x4 bi = ld4(bias + 16 * W + 4 * g);
+    f32x4 ga = splat4(1.f), be = splat4(0.f);
+    if constexpr (DO_LN) {
+        ga = ld4(gamma + 16 * W + 4 * g);
+        be = ld4(beta + 16 * W + 4 * g);
+    }
+    __syncthreads();
+    f32x4 y;
+    {
+        f32x4 p[8];
+#pragma unroll
+        for (int w = 0; w < 8; ++w)
+            if (w != W) p[w] = *a8_slot(lds, w, W, lane);
+        p[W] = part[W];
+        const f32x4 sum = (((p[0] + p[1]) + (p[2] + p[3])) + ((p[4] + p[5]) + (p[6] + p[7])));
+        y = residual ? x[W] + (sum + bi) : sum + bi;
+    }
+    if constexpr (DO_LN) {
+        float s = (y[0] + y[1]) + (y[2] + y[3]);
+        s = allreduce_g_sum(s);
+        const float mw = s * (1.0f / 16.0f);
+        float m2 = 0.f;
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            const float d = y[m] - mw;
+            m2 += d * d;
+        }
+        m2 = allreduce_g_sum(m2);
+        if (g == 0) stats[W * 16 + r] = float2{mw, m2};
+        __syncthreads();
+        float2 st[8];
+#pragma unroll
+        for (int w = 0; w < 8; ++w) st[w] = stats[w * 16 + r];
+        const float mean = (((st[0].x + st[1].x) + (st[2].x + st[3].x)) + ((st[4].x + st[5].x) + (st[6].x + st[7].x))) * 0.125f;
+        float dd = 0.f, mm = 0.f;
+#pragma unroll
+        for (int w = 0; w < 8; ++w) {
+            const float d = st[w].x - mean;
+            dd += d * d;
+            mm += st[w].y;
+        }
+        const float var = (mm + 16.0f * dd) * (1.0f / kD) + 1e-5f;
+        const float rstd = FAST ? __builtin_amdgcn_rsqf(var) : 1.0f / sqrtf(var);
+#pragma unroll
+        for (int m = 0; m < 4; ++m) y[m] = (y[m] - mean) * rstd * ga[m] + be[m];
+    }
+    *a8_slot(lds, W, W, lane) = y;
+    x[W] = y;
+    __syncthreads();
+#pragma unroll
+    for (int t = 0; t < kTiles; ++t)
+        if (t != W) x[t] = *a8_slot(lds, t, t, lane);
+    // keeps SimplifyCFG from sinking the eight cases' x[] stores into one block behind a pointer PHI (which pins
+    // x[] in scratch): an immediate operand cannot be merged
+    asm volatile("; combine8 case %0" ::"n"(W));
+}
+template <bool DO_LN, bool FAST>
+__device__ __forceinline__ void combine8(f32x4 (&part)[kTiles], f32x4 (&x)[kTiles], bool residual, const float* bias,
+                                         const float* gamma, const float* beta, char* lds, int w8, int lane) {
+    switch (w8) {
+        case 0: combine8_impl<0, DO_LN, FAST>(part, x, residual, bias, gamma, beta, lds, lane); break;
+        case 1: combine8_impl<1, DO_LN, FAST>(part, x, residual, bias, gamma, beta, lds, lane); break;
+        case 2: combine8_impl<2, DO_LN, FAST>(part, x, residual, bias, gamma, beta, lds, lane); break;
+        case 3: combine8_impl<3, DO_LN, FAST>(part, x, residual, bias, gamma, beta, lds, lane); break;
+        case 4: combine8_impl<4, DO_LN, FAST>(part, x, residual, bias, gamma, beta, lds, lane); break;
+        case 5: combine8_impl<5, DO_LN, FAST>(part, x, residual, bias, gamma, beta, lds, lane); break;
+        case 6: combine8_impl<6, DO_LN, FAST>(part, x, residual, bias, gamma, beta, lds, lane); break;
+        default: combine8_impl<7, DO_LN, FAST>(part, x, residual, bias, gamma, beta, lds, lane); break;
+    }
+}
+
+__device__ __forceinline__ void attention_head8(const f32x4 (&q)[2], const f32x4 (&k)[2], const f32x4 (&v)[2],
+                                                const bool (&kvalid)[4], f32x4 (&o)[2]) {
+    // S^T[j][i] = sum_d K[j][d] Q[i][d]  ->  lane (g, i) holds S[i][4 g + m]   (k_sampler.hip attention_head)
+    f32x4 st = mfma_bf16(pack_bf16(k[0], k[1]), pack_bf16(q[0], q[1]), splat4(0.f));
+    float mx = -INFINITY;
+#pragma unroll
+    for (int m = 0; m < 4; ++m) mx = kvalid[m] ? fmaxf(mx, st[m]) : mx;
+    mx = allreduce_g_max(mx);
+    f32x4 p;
+    float sum = 0.f;
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+        const float e = __builtin_amdgcn_exp2f(1.44269504088896340736f * (st[m] - mx));
+        p[m] = kvalid[m] ? e : 0.f;
+        sum += p[m];
+    }
+    sum = allreduce_g_sum(sum);
+    const float inv = __builtin_amdgcn_rcpf(sum);
+#pragma unroll
+    for (int m = 0; m < 4; ++m) p[m] *= inv;
+#pragma unroll
+    for (int td = 0; td < 2; ++td)
+        o[td] = mfma_bf16(pack_bf16(v[td], splat4(0.f)), pack_bf16(p, splat4(0.f)), splat4(0.f));
+}
+
+// optional phase timeline: s_memtime stamps by lane 0 of every wave of workgroup 0 during ONE step ([8][96] u64)
+struct Prof8 {
+    unsigned long long* out;
+    int idx;
+    bool on;
+};
+template <bool PROF>
+__device__ __forceinline__ void stamp8(Prof8& pf) {
+    if constexpr (PROF) {
+        if (pf.on) pf.out[pf.idx++] = __builtin_readcyclecounter();
+    }
+}
+
+// bias + exact-erf GELU on one FFN quarter (two hidden tiles); b1 points at this lane's 4 biases of the first tile
+__device__ __forceinline__ void gelu_pair(f32x4 (&hq)[2], const float* b1) {
+    const f32x4 ba = ld4(b1), bb = ld4(b1 + 16);
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+        hq[0][m] = gelu_erf_fast(hq[0][m] + ba[m]);
+        hq[1][m] = gelu_erf_fast(hq[1][m] + bb[m]);
+    }
+}
+
+// One TransformerEncoderLayer.forward_post (cross_attention.py:259-272), A / B role split.  The two roles are
+// separate instantiations (and the whole step loop is instantiated per role, k_sample8 below): sharing one body
+// behind a runtime branch makes hipcc's register allocator spill hundreds of VGPRs at the merges.
+template <bool ROLEA, bool PROF>
+__device__ __forceinline__ void encoder_block8(f32x4 (&x)[kTiles], Ring& rg, const float* pv, const bool (&kvalid)[4],
+                                               char* lds, int h, int lane, bool next_has_skip, Prof8& pf) {
+    constexpr int P = PREC_BF16;
+    const int g = lane >> 4, r = lane & 15;
+    f32x4 part[kTiles];
+    if constexpr (ROLEA) {
+        // ---- ring on entry: in_proj q,k (slots 0..15), v (16..23), out_proj (24..31); nothing is re-armed here
+        f32x4 b_qk[4];
+        float b_v[2];
+#pragma unroll
+        for (int o = 0; o < 2; ++o) {
+            b_qk[o] = ld4(pv + PV_IN_B + 16 * (2 * h + o) + 4 * g);
+            b_qk[2 + o] = ld4(pv + PV_IN_B + kD + 16 * (2 * h + o) + 4 * g);
+            b_v[o] = pv[PV_IN_B + 2 * kD + 16 * (2 * h + o) + r];
+        }
+        f32x4 qk[4], v[2];
+#pragma unroll
+        for (int o = 0; o < 4; ++o) qk[o] = splat4(0.f);
+        v[0] = v[1] = splat4(0.f);
+        gemm_ring<P, 4, kTiles, false, kR8, 0, false>(qk, x, rg);
+        gemm_ring<P, 2, kTiles, true, kR8, 16, false>(v, x, rg);
+        const float scaling = 0.17677669529663687f;  // sqrt(1/32): q * scaling (F.multi_head_attention_forward)
+        f32x4 q[2] = {(qk[0] + b_qk[0]) * scaling, (qk[1] + b_qk[1]) * scaling};
+        f32x4 k[2] = {qk[2] + b_qk[2], qk[3] + b_qk[3]};
+        v[0] += splat4(b_v[0]);
+        v[1] += splat4(b_v[1]);
+        f32x4 o[2];
+        attention_head8(q, k, v, kvalid, o);
+#pragma unroll
+        for (int t = 0; t < kTiles; ++t) part[t] = splat4(0.f);
+        gemm_ring<P, kTiles, 2, false, kR8, 24, false>(part, o, rg);
+        stamp8<PROF>(pf);  // 1: in_proj + attention + out_proj partial
+        combine4_reduce<true>(part, x, pv + PV_OUT_B, pv + PV_LN1_W, pv + PV_LN1_B, lds, h, lane);
+        stamp8<PROF>(pf);  // 2: combine 1
+        stamp8<PROF>(pf);  // 3: (FFN belongs to group B)
+        // ---- off the critical path until the B waves publish LN2: fetch the next block's 32 units meanwhile
+        combine4_observe<32, 0>(x, lds, lane, rg);
+    } else {
+        // ---- ring empty on entry: fetch the first half of this block's FFN slice (F1q0 F1q1 F2q0 F1q2) while
+        // the A waves run attention (24 units) and the out_proj combine (8 units)
+        ring_issue<24, kR8, 0>(rg);
+        stamp8<PROF>(pf);
+        combine4_observe<8, 24>(x, lds, lane, rg);
+        stamp8<PROF>(pf);
+        // ---- FFN slice of head h in four software-pipelined quarters (as k_sampler.hip): linear1 for 2 of the 8
+        // hidden tiles -> bias + GELU -> linear2 split-K contribution of those 32 features.  Stream order
+        // F1q0 F1q1 F2q0 F1q2 | F2q1 F1q3 F2q2 F2q3: the first four groups re-arm their slots with the last four.
+#pragma unroll
+        for (int t = 0; t < kTiles; ++t) part[t] = splat4(0.f);
+        f32x4 hq[4][2];
+#pragma unroll
+        for (int qd = 0; qd < 4; ++qd) hq[qd][0] = hq[qd][1] = splat4(0.f);
+        const float* b1 = pv + PV_L1_B + 16 * kTiles * h + 4 * g;
+        gemm_ring<P, 2, kTiles, false, kR8, 0, true>(hq[0], x, rg);        // F1 q0
+        gemm_ring<P, 2, kTiles, false, kR8, 8, true>(hq[1], x, rg);        // F1 q1
+        gelu_pair(hq[0], b1 + 32 * 0);
+        gemm_ring<P, kTiles, 2, false, kR8, 16, true>(part, hq[0], rg);    // F2 q0
+        gemm_ring<P, 2, kTiles, false, kR8, 24, true>(hq[2], x, rg);       // F1 q2
+        gelu_pair(hq[1], b1 + 32 * 1);
+        gemm_ring<P, kTiles, 2, false, kR8, 0, false>(part, hq[1], rg);    // F2 q1
+        gemm_ring<P, 2, kTiles, false, kR8, 8, false>(hq[3], x, rg);       // F1 q3
+        gelu_pair(hq[2], b1 + 32 * 2);
+        gemm_ring<P, kTiles, 2, false, kR8, 16, false>(part, hq[2], rg);   // F2 q2
+        gelu_pair(hq[3], b1 + 32 * 3);
+        gemm_ring<P, kTiles, 2, false, kR8, 24, false>(part, hq[3], rg);   // F2 q3
+        stamp8<PROF>(pf);  // 3: FFN
+        if (next_has_skip) ring_issue<8, kR8, 0>(rg);  // this wave's share of the next block's skip linear
+        combine4_reduce<true>(part, x, pv + PV_L2_B, pv + PV_LN2_W, pv + PV_LN2_B, lds, h, lane);
+    }
+    stamp8<PROF>(pf);  // 4: combine 2
+}
+
+__device__ __forceinline__ void store_tap8(float* tap, int slot, const f32x4 (&x)[kTiles], int g, int r) {
+#pragma unroll
+    for (int t = 0; t < kTiles; ++t) st4(tap + ((size_t)slot * 16 + r) * kD + 16 * t + 4 * g, x[t]);
+}
+
+// per-lane constants of the tile (row-lane layout: lane (g, r) holds row r)
+struct Lane8 {
+    int lane, g, r, cl, tok;
+    long clip;
+    bool valid, is_lat;
+};
+
+// The whole T-step loop of one role.  Both roles execute the same sequence of workgroup barriers.
+template <bool ROLEA, bool PROF>
+__device__ __forceinline__ void role_loop8(const SampleArgs& a, char* smem, int w8, const Lane8& L) {
+    uint4* skipbf = reinterpret_cast<uint4*>(smem + kSkip8Off);
+    const float* pvl = reinterpret_cast<const float*>(smem + kPv8Off);
+    const f32x4* tokrows = reinterpret_cast<const f32x4*>(smem + kTokRows8Off);
+    f32x4* latl = reinterpret_cast<f32x4*>(smem + kLat8Off);
+    float* ttl = reinterpret_cast<float*>(smem + kTT8Off);
+    const float* pv_skip = pvl + kLayers * kEncPv;
+    const float* pv_final = pv_skip + 4 * kD;
+    const int lane = L.lane, g = L.g, r = L.r, h = w8 & 3;
+    const int S = a.S, R = S * a.G;
+    // attention key mask for this lane's query row: keys j = 4 g + m of the SAME clip; padding rows attend to
+    // themselves only (keeps them finite, they never touch valid rows)
+    bool kvalid[4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+        const int j = 4 * g + m;
+        kvalid[m] = L.valid ? (j < R && (j / S) == L.cl) : (j == r);
+    }
+    const bool tap = ROLEA && a.tap_out != nullptr && blockIdx.x == 0 && w8 == 0;
+    const uint32_t wbase_units = ROLEA ? (uint32_t)w8 * (a.wave_units_a + kR8)
+                                       : 4u * (a.wave_units_a + kR8) + (uint32_t)(w8 - 4) * a.wave_units_b;
+    const uint4* wbase = a.wstream + (size_t)wbase_units * 64 + lane;
+    // A waves enter every block with their 32 units in the ring (the stream's tail repeats its head for the wrap
+    // at a step boundary); B waves enter with an empty ring (their fill is never consumed)
+    Ring rg;
+    ring_fill(rg, wbase);
+    Prof8 pf{a.prof_out ? a.prof_out + (size_t)w8 * 96 : nullptr, 0, false};
+#pragma unroll 1
+    for (int step = 0; step < a.T; ++step) {
+        // ---- token assembly (A waves; a B wave's x is defined by the first combine's gather)
+        f32x4 x[kTiles];
+#pragma unroll
+        for (int t = 0; t < kTiles; ++t) {
+            x[t] = splat4(0.f);
+            if constexpr (ROLEA) {
+                const f32x4 sv = tokrows[t * 64 + lane];
+                // unconditional loads (a divergent branch around them sends x[] to scratch)
+                f32x4 tt = ld4(ttl + (step & 1) * kD + 16 * t + 4 * g);
+                if (a.time_tok_clip) tt = ld4(a.time_tok_clip + (size_t)(L.valid ? L.clip : 0) * kD + 16 * t + 4 * g);
+                x[t] = !L.valid ? splat4(0.f) : (L.tok == 0 ? latl[t * 64 + lane] + sv : (L.tok == 1 ? tt : sv));
+            }
+        }
+        if (tap && step == 0) store_tap8(a.tap_out, 0, x, g, r);
+        // next step's time token -> the other LDS buffer (read a whole step and many barriers later)
+        if (!ROLEA && w8 == 4 && lane < 32 && step + 1 < a.T)
+            st4(ttl + ((step + 1) & 1) * kD + 4 * lane, ld4(a.time_tok + (size_t)(step + 1) * kD + 4 * lane));
+        if constexpr (PROF) {
+            pf.on = a.prof_out != nullptr && blockIdx.x == 0 && lane == 0 && step == a.prof_step;
+            pf.idx = 0;
+        }
+        stamp8<PROF>(pf);  // step start
+        rg.next = ROLEA ? wbase + kR8 * 64 : wbase;  // (A: the ring already holds units 0..31 of this step)
+        // ---- SkipTransformerEncoder.forward (cross_attention.py:41-64)
+#pragma unroll 1
+        for (int blk = 0; blk < kLayers; ++blk) {
+            if (blk >= 5) {  // x = Linear(cat(x, skips.pop())), split-K over 8 waves: k-tiles 2 w8, 2 w8 + 1
+                f32x4 part[kTiles];
+                if constexpr (ROLEA) {
+                    // operand pair by value selects (a branch chain over x[] sends the whole array to scratch)
+                    uint4 xs = __builtin_bit_cast(uint4, pack_bf16(x[0], x[1]));
+#pragma unroll
+                    for (int p = 1; p < 4; ++p) {
+                        const uint4 c = __builtin_bit_cast(uint4, pack_bf16(x[2 * p], x[2 * p + 1]));
+                        const bool m = (h == p);
+                        xs.x = m ? c.x : xs.x; xs.y = m ? c.y : xs.y; xs.z = m ? c.z : xs.z; xs.w = m ? c.w : xs.w;
+                    }
+                    const bf16x8 xb = __builtin_bit_cast(bf16x8, xs);
+                    // the skip linear's units sit in slots 24..31 in place of out_proj, which is fetched right after
+#pragma unroll
+                    for (int o = 0; o < kTiles; ++o)
+                        part[o] = mfma_bf16(__builtin_bit_cast(bf16x8, rg.s[24 + o]), xb, splat4(0.f));
+                    ring_issue<8, kR8, 24>(rg);
+                } else {
+                    // slots 0..7, issued during the previous linear2 combine; operand = the popped skip tiles
+                    const bf16x8 xb = __builtin_bit_cast(bf16x8, skipbf[((8 - blk) * 4 + h) * 64 + lane]);
+#pragma unroll
+                    for (int o = 0; o < kTiles; ++o)
+                        part[o] = mfma_bf16(__builtin_bit_cast(bf16x8, rg.s[o]), xb, splat4(0.f));
+                }
+                combine8<false, true>(part, x, false, pv_skip + (blk - 5) * kD, nullptr, nullptr, smem, w8, lane);
+            }
+            stamp8<PROF>(pf);  // 0: block start (after the skip linear, if any)
+            encoder_block8<ROLEA, PROF>(x, rg, pvl + blk * kEncPv, kvalid, smem, h, lane, blk >= 4 && blk < kLayers - 1, pf);
+            if (!ROLEA && blk < 4 && w8 == 4) {
+#pragma unroll
+                for (int p = 0; p < 4; ++p)
+                    skipbf[(blk * 4 + p) * 64 + lane] = __builtin_bit_cast(uint4, pack_bf16(x[2 * p], x[2 * p + 1]));
+            }
+            if (tap && step == 0) store_tap8(a.tap_out, 1 + blk, x, g, r);
+        }
+        if (ROLEA && w8 == 0) {
+            // final LayerNorm (SkipTransformerEncoder.norm), parameters fetched tile by tile (register pressure)
+            {
+                float sm = 0.f;
+#pragma unroll
+                for (int t = 0; t < kTiles; ++t) sm += (x[t][0] + x[t][1]) + (x[t][2] + x[t][3]);
+                sm = allreduce_g_sum(sm);
+                const float mean = sm * (1.0f / kD);
+                float vs = 0.f;
+#pragma unroll
+                for (int t = 0; t < kTiles; ++t)
+#pragma unroll
+                    for (int m = 0; m < 4; ++m) {
+                        const float d = x[t][m] - mean;
+                        vs += d * d;
+                    }
+                vs = allreduce_g_sum(vs);
+                const float rstd = __builtin_amdgcn_rsqf(vs * (1.0f / kD) + 1e-5f);
+#pragma unroll
+                for (int t = 0; t < kTiles; ++t) {
+                    const f32x4 ga = ld4(pv_final + 16 * t + 4 * g), be = ld4(pv_final + kD + 16 * t + 4 * g);
+#pragma unroll
+                    for (int m = 0; m < 4; ++m) x[t][m] = (x[t][m] - mean) * rstd * ga[m] + be[m];
+                }
+            }
+            if (tap && step == 0) store_tap8(a.tap_out, 10, x, g, r);
+            if (a.eps_out && L.is_lat && step == a.T - 1) {
+#pragma unroll
+                for (int t = 0; t < kTiles; ++t) st4(a.eps_out + (size_t)L.clip * kD + 16 * t + 4 * g, x[t]);
+            }
+            // ---- scheduler.step (diffusers 0.17.1 DDIM / DDPM; amuse_hip.h amuse_schedule) - as k_sampler.hip
+            if (!a.no_update) {
+                const float* cf = a.coef + (size_t)step * 8;
+                const float sb = cf[0], sa = cf[1], c0 = cf[2], cx = cf[3], ce = cf[4], sg = cf[5], clipv = cf[6];
+                // ancestral noise: lane l draws the 4 normals of feature group l % 32 of clip 2 * call + l / 32 of
+                // the tile (one Philox call per lane per two clips); latent-row lanes fetch theirs by shuffle, tile
+                // by tile, so neither the noise nor the latent (LDS) is ever held as a whole in registers
+                f32x4 n0 = splat4(0.f), n1 = splat4(0.f);
+                const bool gen = sg != 0.f && !a.step_noise;
+                if (gen) {
+                    const uint64_t gc0 = a.clip0 + (uint64_t)((long)blockIdx.x * a.G + (lane >> 5));
+                    n0 = counter_normal4(a.seed, gc0, (uint32_t)step, (uint32_t)(lane & 31), 1u);
+                    if (a.G > 2) n1 = counter_normal4(a.seed, gc0 + 2, (uint32_t)step, (uint32_t)(lane & 31), 1u);
+                }
+                const float inv_sa = 1.0f / sa;
+                const int src = 32 * (L.cl & 1) + g;
+                const bool second = (L.cl >> 1) == 1;
+#pragma unroll
+                for (int t = 0; t < kTiles; ++t) {
+                    f32x4 z = splat4(0.f);
+                    if (gen) {
+#pragma unroll
+                        for (int m = 0; m < 4; ++m) {
+                            const float va = __shfl(n0[m], src + 4 * t), vb = __shfl(n1[m], src + 4 * t);
+                            z[m] = second ? vb : va;
+                        }
+                    } else if (sg != 0.f) {
+                        z = ld4(a.step_noise + ((size_t)step * a.B + (L.is_lat ? L.clip : 0)) * kD + 16 * t + 4 * g);
+                    }
+                    f32x4 l = latl[t * 64 + lane];
+                    {
+// each product and sum rounded on its own, like the scheduler's tensor ops (see k_sampler.hip)
+#pragma clang fp contract(off)
+#pragma unroll
+                    for (int m = 0; m < 4; ++m) {
+                        const float e = x[t][m], xl = l[m];
+                        const float num = __fsub_rn(xl, __fmul_rn(sb, e));
+                        float x0 = num * inv_sa;
+                        if (clipv > 0.f) x0 = fminf(fmaxf(x0, -clipv), clipv);
+                        float nx = __fmul_rn(c0, x0);
+                        if (cx != 0.f) nx = __fadd_rn(nx, __fmul_rn(cx, xl));
+                        if (ce != 0.f) nx = __fadd_rn(nx, __fmul_rn(ce, e));
+                        if (sg != 0.f) nx = __fadd_rn(nx, __fmul_rn(sg, z[m]));
+                        l[m] = nx;
+                    }
+                    }
+                    latl[t * 64 + lane] = l;
+                    if (a.traj_out && L.is_lat) st4(a.traj_out + ((size_t)step * a.B + L.clip) * kD + 16 * t + 4 * g, l);
+                }
+            }
+        }
+        stamp8<PROF>(pf);  // scheduler update done (wave 0) / reached the step barrier
+        __syncthreads();  // the updated latent is visible to every wave's token assembly
+    }
+}
+
+template <bool PROF>
+__global__ __launch_bounds__(512) void k_sample8(SampleArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* pvl = reinterpret_cast<float*>(smem + kPv8Off);
+    f32x4* tokrows = reinterpret_cast<f32x4*>(smem + kTokRows8Off);
+    f32x4* latl = reinterpret_cast<f32x4*>(smem + kLat8Off);
+    float* ttl = reinterpret_cast<float*>(smem + kTT8Off);
+    for (int i = threadIdx.x; i < kLayers * kEncPv / 4; i += 512) {
+        const int blk = (4 * i) / kEncPv, off = 4 * i - blk * kEncPv;
+        st4(pvl + 4 * i, ld4(a.pvec + blk * PV_BLOCK + off));
+    }
+    for (int i = threadIdx.x; i < (4 * kD + 2 * kD) / 4; i += 512) st4(pvl + kLayers * kEncPv + 4 * i, ld4(a.pvec + PV_SKIP_B + 4 * i));
+    Lane8 L;
+    L.lane = threadIdx.x & 63;
+    const int w8 = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    L.g = L.lane >> 4;
+    L.r = L.lane & 15;
+    const int S = a.S, R = S * a.G;
+    L.cl = L.r / S;
+    L.tok = L.r - L.cl * S;
+    L.clip = (long)blockIdx.x * a.G + L.cl;
+    L.valid = (L.r < R) && (L.clip < (long)a.B);
+    L.is_lat = L.valid && L.tok == 0;
+    // static token rows (pe[0] under the latent rows, condition tokens; denoiser.py:174,180-181) and the initial
+    // latent -> LDS (registers are the scarce resource at 2 waves / SIMD; wave 0 owns the latent's update)
+    if (w8 == 0) {
+#pragma unroll
+        for (int t = 0; t < kTiles; ++t) {
+            const int f = 16 * t + 4 * L.g;
+            f32x4 sv = splat4(0.f), l0 = splat4(0.f);
+            if (L.valid) {
+                if (L.tok == 0) sv = ld4(a.pe0 + f);
+                else if (L.tok >= 2) sv = ld4(a.cond_tok + ((size_t)L.clip * (S - 2) + (L.tok - 2)) * kD + f);
+            }
+            if (L.is_lat)
+                l0 = a.x_init ? ld4(a.x_init + (size_t)L.clip * kD + f)
+                              : counter_normal4(a.seed, a.clip0 + (uint64_t)L.clip, 0u, (uint32_t)(4 * t + L.g), 0u);
+            tokrows[t * 64 + L.lane] = sv;
+            latl[t * 64 + L.lane] = l0;
+        }
+    }
+    if (w8 == 4 && L.lane < 32 && !a.time_tok_clip) st4(ttl + 4 * L.lane, ld4(a.time_tok + 4 * L.lane));
+    __syncthreads();
+    if (w8 < 4) role_loop8<true, PROF>(a, smem, w8, L);
+    else role_loop8<false, PROF>(a, smem, w8, L);
+    if (L.is_lat && w8 == 0 && a.latents_out) {
+#pragma unroll
+        for (int t = 0; t < kTiles; ++t) st4(a.latents_out + (size_t)L.clip * kD + 16 * t + 4 * L.g, latl[t * 64 + L.lane]);
+    }
+}
+
+}  // namespace
+
+hipError_t launch_sample8(const SampleArgs& a, hipStream_t stream) {
+    const int tiles = (a.B + a.G - 1) / a.G;
+    static bool attr_set = false;
+    if (!attr_set) {
+        for (const void* k : {reinterpret_cast<const void*>(&k_sample8<false>), reinterpret_cast<const void*>(&k_sample8<true>)}) {
+            hipError_t e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, kSample8LdsBytes);
+            if (e != hipSuccess) return e;
+        }
+        attr_set = true;
+    }
+    if (a.prof_out) hipLaunchKernelGGL(k_sample8<true>, dim3(tiles), dim3(512), kSample8LdsBytes, stream, a);
+    else hipLaunchKernelGGL(k_sample8<false>, dim3(tiles), dim3(512), kSample8LdsBytes, stream, a);
+    return hipGetLastError();
+}
+
+}  // namespace amuse
