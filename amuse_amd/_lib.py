@@ -10,7 +10,8 @@ import os
 from pathlib import Path
 
 _HERE = Path(__file__).resolve().parent
-LIB_PATH = _HERE / "libamuse_hip.so"
+# AMUSE_HIP_LIB: load another build of the same C ABI (kernel A/B measurements, tools/build_variant.sh)
+LIB_PATH = Path(os.environ.get("AMUSE_HIP_LIB") or _HERE / "libamuse_hip.so")
 
 PREC_F32, PREC_BF16 = 0, 1
 QUAT_P3D, QUAT_LEGACY = 0, 1

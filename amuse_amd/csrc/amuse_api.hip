@@ -295,24 +295,25 @@ int build_ctx(amuse_ctx* c, const float* den, const float* pri) {
             const int h = w8 & 3, sgrp = w8 >> 2;
             std::vector<uint4> s;
             // per block, in issue order (k_sampler8.hip).  A: in_proj q,k | v | out_proj - ahead of an output block
-            // the skip linear takes out_proj's place, which follows as a group of its own.  B: skip linear, then
-            // the FFN slice of head h in the software-pipelined quarter order of the 4-wave kernel.
+            // the skip linear takes out_proj's place, which follows as a group of its own - then FFN quarters 0,1
+            // as F1a F1b F2a F2b.  B: skip linear, then FFN quarters 2,3.
             for (int b = 0; b < 9; ++b) {
                 const std::string p = blk_name("encoder", b);
                 auto skip = [&] {
                     pack_gemm(s, PREC_BF16, D.get("encoder.linear_blocks." + std::to_string(b - 5) + ".weight"), 128, 256,
                               range(0, 8), {2 * w8, 2 * w8 + 1});
                 };
+                auto f1 = [&](int q) { const int h0 = 8 * h + 2 * q; pack_gemm(s, PREC_BF16, D.get(p + ".linear1.weight"), 512, 128, {h0, h0 + 1}, range(0, 8)); };
+                auto f2 = [&](int q) { const int h0 = 8 * h + 2 * q; pack_gemm(s, PREC_BF16, D.get(p + ".linear2.weight"), 128, 512, range(0, 8), {h0, h0 + 1}); };
+                const int qa = 2 * sgrp, qb = 2 * sgrp + 1;
                 if (sgrp == 0) {
                     pack_qkv(s, PREC_BF16, D.get(p + ".self_attn.in_proj_weight"), h, true);
                     if (b >= 5) skip();
                     pack_gemm(s, PREC_BF16, D.get(p + ".self_attn.out_proj.weight"), 128, 128, range(0, 8), {2 * h, 2 * h + 1});
-                } else {
-                    if (b >= 5) skip();
-                    auto f1 = [&](int q) { const int h0 = 8 * h + 2 * q; pack_gemm(s, PREC_BF16, D.get(p + ".linear1.weight"), 512, 128, {h0, h0 + 1}, range(0, 8)); };
-                    auto f2 = [&](int q) { const int h0 = 8 * h + 2 * q; pack_gemm(s, PREC_BF16, D.get(p + ".linear2.weight"), 128, 512, range(0, 8), {h0, h0 + 1}); };
-                    f1(0); f1(1); f2(0); f1(2); f2(1); f1(3); f2(2); f2(3);
+                } else if (b >= 5) {
+                    skip();
                 }
+                f1(qa); f1(qb); f2(qa); f2(qb);
             }
             uint32_t& units = c->den_w8_units[sgrp];
             if (h == 0) units = (uint32_t)(s.size() / 64);

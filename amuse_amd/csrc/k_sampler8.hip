@@ -9,12 +9,14 @@
 // group fetches its weights while the OTHER group is on the critical path:
 //
 //   wave w8 = 4 s + h.
-//   Group A (s = 0): head h end to end - in_proj, attention, out_proj split-K - and the reduction + LayerNorm1 of
-//     the out_proj combine.  Its 32-unit ring is re-armed with the next block's units during the linear2 combine,
-//     where the A waves only wait for the B waves' result.
-//   Group B (s = 1): the FFN slice of head h (linear1 over hidden tiles 8h..8h+7, linear2 split-K over the same)
-//     and the reduction + LayerNorm2 of the linear2 combine.  Its ring is re-armed with the first half of the
-//     slice while the A waves run attention and the out_proj combine; the second half streams in during the FFN.
+//   Group A (s = 0): head h end to end (in_proj, attention, out_proj split-K) and FFN quarters 0,1 of head h's
+//     slice.  It never reduces: in both combines it publishes its partial and then only waits for the result -
+//     that is where it fetches its weights (the FFN half during the out_proj combine, the next block's attention
+//     weights during the linear2 combine).
+//   Group B (s = 1): reduces + normalises BOTH combines (wave h: feature tiles 2h, 2h+1) and computes FFN quarters
+//     2,3.  It has nothing to do while the A waves run attention - that is where it fetches its FFN half.
+//   So no wave issues a weight load while it is on the critical path (bar the 8-unit skip-linear groups), and the
+//   FFN's MFMA + GELU work is spread over two waves per SIMD.
 //   U-Net skip linears: split-K over all 8 waves (k-tiles 2 w8, 2 w8 + 1 of cat(x, skip)); the skip stack is kept
 //     as packed bf16 MFMA operands (what the 4-wave kernel's cvt_pk produces from its fp32 copy - same bits).
 //   Token assembly in every wave; final LayerNorm + scheduler update in wave 0, latent in LDS.
@@ -42,23 +44,42 @@ static_assert(kTT8Off + 2 * kD * 4 == kSample8LdsBytes, "LDS layout");
 
 using Ring = WRing<kR8>;
 
+// weight-stream units an A wave issues after the first / second barrier of the out_proj (C1) and linear2 (C2)
+// combines; the rest of its 32 follow the gather
+#ifndef AMUSE_C1_N1
+#define AMUSE_C1_N1 12
+#define AMUSE_C1_N2 12
+#endif
+#ifndef AMUSE_C2_N1
+#define AMUSE_C2_N1 12
+#define AMUSE_C2_N2 12
+#endif
+
 __device__ __forceinline__ f32x4* a8_slot(char* lds, int row, int col, int lane) {
     return reinterpret_cast<f32x4*>(lds) + (row * kTiles + col) * 64 + lane;
 }
 
-// ---- split-K combine over the FOUR partials of one group (A: out_proj, B: linear2): wave h of the group reduces
-// tiles 2h, 2h+1, adds residual + bias, LayerNorm (row statistics merged over the four 32-feature slices with
-// Chan's formula), publishes them on the diagonal; every wave of the workgroup gathers the full tile.
-// The partial of tile t from wave h sits at row (t + 1 + h) & 7 (never the diagonal).
-template <int W, bool FAST>
-__device__ __forceinline__ void combine4_red(f32x4 (&part)[kTiles], f32x4 (&x)[kTiles], const float* bias,
-                                             const float* gamma, const float* beta, char* lds, int lane) {
+// ---- split-K combine, B waves reduce.  NP = 4: partials from the A waves only (out_proj); NP = 8: from all waves
+// (linear2).  B wave h reduces feature tiles 2h, 2h+1: residual + bias, LayerNorm (row statistics of the four
+// 32-feature slices merged with Chan's formula), publishes them on the diagonal of A8; every wave gathers.
+// Row of A8 holding writer w's partial of tile t - never the diagonal, and the tile's reducer (wave 4 + t/2) keeps its
+// own partial in registers:
+__device__ __forceinline__ constexpr int part_row(int w, int t) {
+    const int red = 4 + (t >> 1);
+    const int k = w - (w > red ? 1 : 0);
+    return k + (k >= t ? 1 : 0);
+}
+template <int W, int NP, bool FAST>
+__device__ __forceinline__ void combine_red(f32x4 (&part)[kTiles], f32x4 (&x)[kTiles], const float* bias,
+                                            const float* gamma, const float* beta, char* lds, int lane) {
     float2* stats = reinterpret_cast<float2*>(lds + kStat8Off);
     const int g = lane >> 4, r = lane & 15;
     constexpr int T0 = 2 * W;
+    if constexpr (NP == 8) {
 #pragma unroll
-    for (int t = 0; t < kTiles; ++t)
-        if (t != T0 && t != T0 + 1) *a8_slot(lds, (t + 1 + W) & 7, t, lane) = part[t];
+        for (int t = 0; t < kTiles; ++t)
+            if (t != T0 && t != T0 + 1) *a8_slot(lds, part_row(4 + W, t), t, lane) = part[t];
+    }
     f32x4 bi[2], ga[2], be[2];
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
@@ -69,16 +90,21 @@ __device__ __forceinline__ void combine4_red(f32x4 (&part)[kTiles], f32x4 (&x)[k
     __syncthreads();
     f32x4 y[2];
     {
-        f32x4 p[4][2];
+        f32x4 p[NP][2];
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int w = 0; w < 4; ++w)
-                if (w != W) p[w][i] = *a8_slot(lds, (T0 + i + 1 + w) & 7, T0 + i, lane);
+            for (int w = 0; w < NP; ++w)
+                if (w != 4 + W) p[w][i] = *a8_slot(lds, part_row(w, T0 + i), T0 + i, lane);
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-            p[W][i] = part[T0 + i];
-            const f32x4 sum = ((p[0][i] + p[1][i]) + p[2][i]) + p[3][i];
+            f32x4 sum;
+            if constexpr (NP == 8) {
+                p[4 + W][i] = part[T0 + i];
+                sum = ((p[0][i] + p[1][i]) + (p[2][i] + p[3][i])) + ((p[4][i] + p[5][i]) + (p[6][i] + p[7][i]));
+            } else {
+                sum = ((p[0][i] + p[1][i]) + p[2][i]) + p[3][i];
+            }
             y[i] = x[T0 + i] + (sum + bi[i]);
         }
     }
@@ -113,32 +139,32 @@ __device__ __forceinline__ void combine4_red(f32x4 (&part)[kTiles], f32x4 (&x)[k
 #pragma unroll
     for (int t = 0; t < kTiles; ++t)
         if (t != T0 && t != T0 + 1) x[t] = *a8_slot(lds, t, t, lane);
-    asm volatile("; combine4 case %0" ::"n"(W));  // see combine8_impl
+    asm volatile("; combine_red case %0" ::"n"(W));  // see combine8_impl
 }
-template <bool FAST>
-__device__ __forceinline__ void combine4_reduce(f32x4 (&part)[kTiles], f32x4 (&x)[kTiles], const float* bias,
-                                                const float* gamma, const float* beta, char* lds, int h, int lane) {
-    if (h == 0) combine4_red<0, FAST>(part, x, bias, gamma, beta, lds, lane);
-    else if (h == 1) combine4_red<1, FAST>(part, x, bias, gamma, beta, lds, lane);
-    else if (h == 2) combine4_red<2, FAST>(part, x, bias, gamma, beta, lds, lane);
-    else combine4_red<3, FAST>(part, x, bias, gamma, beta, lds, lane);
+template <int NP, bool FAST>
+__device__ __forceinline__ void combine_reduce(f32x4 (&part)[kTiles], f32x4 (&x)[kTiles], const float* bias,
+                                               const float* gamma, const float* beta, char* lds, int h, int lane) {
+    if (h == 0) combine_red<0, NP, FAST>(part, x, bias, gamma, beta, lds, lane);
+    else if (h == 1) combine_red<1, NP, FAST>(part, x, bias, gamma, beta, lds, lane);
+    else if (h == 2) combine_red<2, NP, FAST>(part, x, bias, gamma, beta, lds, lane);
+    else combine_red<3, NP, FAST>(part, x, bias, gamma, beta, lds, lane);
 }
-// the other group's side of the same combine: no partial - the barriers, the gather, and in between the issue of
-// NI weight-stream units into ring slots IPH0.. (these waves are off the critical path here, so their blocking
-// global_load issue costs nothing as long as it fits the reducers' three phases)
-template <int NI, int IPH0>
-__device__ __forceinline__ void combine4_observe(f32x4 (&x)[kTiles], char* lds, int lane, Ring& rg) {
-    static_assert(NI % 4 == 0, "issue count is split in four chunks");
-    constexpr int NC = NI / 4;
-    ring_issue<NC, kR8, IPH0 % kR8>(rg);
+// The A waves' side: publish the partial, then the barriers and the gather - with the issue of N1 + N2 + N3
+// weight-stream units into ring slots IPH0.. in between.  These waves are off the critical path here, so their
+// blocking global_load issue costs nothing as long as it fits the reducers' phases.
+template <int N1, int N2, int N3, int IPH0>
+__device__ __forceinline__ void combine_publish(const f32x4 (&part)[kTiles], f32x4 (&x)[kTiles], char* lds, int h,
+                                                int lane, Ring& rg) {
+#pragma unroll
+    for (int t = 0; t < kTiles; ++t) *a8_slot(lds, h + (h >= t ? 1 : 0), t, lane) = part[t];  // part_row(h, t), h < 4
     __syncthreads();
-    ring_issue<NC, kR8, (IPH0 + NC) % kR8>(rg);
+    ring_issue<N1, kR8, IPH0 % kR8>(rg);
     __syncthreads();
-    ring_issue<NC, kR8, (IPH0 + 2 * NC) % kR8>(rg);
+    ring_issue<N2, kR8, (IPH0 + N1) % kR8>(rg);
     __syncthreads();
 #pragma unroll
     for (int t = 0; t < kTiles; ++t) x[t] = *a8_slot(lds, t, t, lane);
-    ring_issue<NC, kR8, (IPH0 + 3 * NC) % kR8>(rg);
+    ring_issue<N3, kR8, (IPH0 + N1 + N2) % kR8>(rg);
 }
 
 // ---- combine over EIGHT partials: wave W reduces tile W.   x <- [LN]([x +] sum_w part_w + bias)
@@ -270,6 +296,26 @@ __device__ __forceinline__ void gelu_pair(f32x4 (&hq)[2], const float* b1) {
     }
 }
 
+// this wave's two FFN quarters (Q0, Q0 + 1 of head h's slice): linear1 for 2 hidden tiles each -> bias + GELU ->
+// linear2 split-K contribution of those 32 features, software-pipelined by one quarter.  Ring: F1a F1b F2a F2b in
+// slots 0..31, nothing re-armed.
+// LATE8: the last 8 units (F2b) are issued only now, behind the first GEMMs' MFMAs (B waves: their fetch window, the A
+// waves' attention phase, is a little too short for all 32)
+template <int Q0, bool LATE8>
+__device__ __forceinline__ void ffn_half(f32x4 (&part)[kTiles], const f32x4 (&x)[kTiles], Ring& rg, const float* pv,
+                                         int h, int g) {
+    constexpr int P = PREC_BF16;
+    f32x4 ha[2] = {splat4(0.f), splat4(0.f)}, hb[2] = {splat4(0.f), splat4(0.f)};
+    const float* b1 = pv + PV_L1_B + 16 * (kTiles * h + 2 * Q0) + 4 * g;
+    gemm_ring<P, 2, kTiles, false, kR8, 0, false>(ha, x, rg);
+    gemm_ring<P, 2, kTiles, false, kR8, 8, false>(hb, x, rg);
+    if constexpr (LATE8) ring_issue<8, kR8, 24>(rg);
+    gelu_pair(ha, b1);
+    gemm_ring<P, kTiles, 2, false, kR8, 16, false>(part, ha, rg);
+    gelu_pair(hb, b1 + 32);
+    gemm_ring<P, kTiles, 2, false, kR8, 24, false>(part, hb, rg);
+}
+
 // One TransformerEncoderLayer.forward_post (cross_attention.py:259-272), A / B role split.  The two roles are
 // separate instantiations (and the whole step loop is instantiated per role, k_sample8 below): sharing one body
 // behind a runtime branch makes hipcc's register allocator spill hundreds of VGPRs at the merges.
@@ -280,7 +326,7 @@ __device__ __forceinline__ void encoder_block8(f32x4 (&x)[kTiles], Ring& rg, con
     const int g = lane >> 4, r = lane & 15;
     f32x4 part[kTiles];
     if constexpr (ROLEA) {
-        // ---- ring on entry: in_proj q,k (slots 0..15), v (16..23), out_proj (24..31); nothing is re-armed here
+        // ---- ring on entry: in_proj q,k (slots 0..15), v (16..23), out_proj (24..31)
         f32x4 b_qk[4];
         float b_v[2];
 #pragma unroll
@@ -306,42 +352,27 @@ __device__ __forceinline__ void encoder_block8(f32x4 (&x)[kTiles], Ring& rg, con
         for (int t = 0; t < kTiles; ++t) part[t] = splat4(0.f);
         gemm_ring<P, kTiles, 2, false, kR8, 24, false>(part, o, rg);
         stamp8<PROF>(pf);  // 1: in_proj + attention + out_proj partial
-        combine4_reduce<true>(part, x, pv + PV_OUT_B, pv + PV_LN1_W, pv + PV_LN1_B, lds, h, lane);
+        // ---- out_proj combine (B reduces): meanwhile fetch this wave's FFN half
+        combine_publish<AMUSE_C1_N1, AMUSE_C1_N2, 32 - AMUSE_C1_N1 - AMUSE_C1_N2, 0>(part, x, lds, h, lane, rg);
         stamp8<PROF>(pf);  // 2: combine 1
-        stamp8<PROF>(pf);  // 3: (FFN belongs to group B)
-        // ---- off the critical path until the B waves publish LN2: fetch the next block's 32 units meanwhile
-        combine4_observe<32, 0>(x, lds, lane, rg);
-    } else {
-        // ---- ring empty on entry: fetch the first half of this block's FFN slice (F1q0 F1q1 F2q0 F1q2) while
-        // the A waves run attention (24 units) and the out_proj combine (8 units)
-        ring_issue<24, kR8, 0>(rg);
-        stamp8<PROF>(pf);
-        combine4_observe<8, 24>(x, lds, lane, rg);
-        stamp8<PROF>(pf);
-        // ---- FFN slice of head h in four software-pipelined quarters (as k_sampler.hip): linear1 for 2 of the 8
-        // hidden tiles -> bias + GELU -> linear2 split-K contribution of those 32 features.  Stream order
-        // F1q0 F1q1 F2q0 F1q2 | F2q1 F1q3 F2q2 F2q3: the first four groups re-arm their slots with the last four.
 #pragma unroll
         for (int t = 0; t < kTiles; ++t) part[t] = splat4(0.f);
-        f32x4 hq[4][2];
+        ffn_half<0, false>(part, x, rg, pv, h, g);
+        stamp8<PROF>(pf);  // 3: FFN
+        // ---- linear2 combine (B reduces): meanwhile fetch the next block's attention weights
+        combine_publish<AMUSE_C2_N1, AMUSE_C2_N2, 32 - AMUSE_C2_N1 - AMUSE_C2_N2, 0>(part, x, lds, h, lane, rg);
+    } else {
+        // ---- ring empty on entry: fetch this wave's FFN half while the A waves run attention
+        ring_issue<24, kR8, 0>(rg);
+        stamp8<PROF>(pf);
 #pragma unroll
-        for (int qd = 0; qd < 4; ++qd) hq[qd][0] = hq[qd][1] = splat4(0.f);
-        const float* b1 = pv + PV_L1_B + 16 * kTiles * h + 4 * g;
-        gemm_ring<P, 2, kTiles, false, kR8, 0, true>(hq[0], x, rg);        // F1 q0
-        gemm_ring<P, 2, kTiles, false, kR8, 8, true>(hq[1], x, rg);        // F1 q1
-        gelu_pair(hq[0], b1 + 32 * 0);
-        gemm_ring<P, kTiles, 2, false, kR8, 16, true>(part, hq[0], rg);    // F2 q0
-        gemm_ring<P, 2, kTiles, false, kR8, 24, true>(hq[2], x, rg);       // F1 q2
-        gelu_pair(hq[1], b1 + 32 * 1);
-        gemm_ring<P, kTiles, 2, false, kR8, 0, false>(part, hq[1], rg);    // F2 q1
-        gemm_ring<P, 2, kTiles, false, kR8, 8, false>(hq[3], x, rg);       // F1 q3
-        gelu_pair(hq[2], b1 + 32 * 2);
-        gemm_ring<P, kTiles, 2, false, kR8, 16, false>(part, hq[2], rg);   // F2 q2
-        gelu_pair(hq[3], b1 + 32 * 3);
-        gemm_ring<P, kTiles, 2, false, kR8, 24, false>(part, hq[3], rg);   // F2 q3
+        for (int t = 0; t < kTiles; ++t) part[t] = splat4(0.f);
+        combine_reduce<4, true>(part, x, pv + PV_OUT_B, pv + PV_LN1_W, pv + PV_LN1_B, lds, h, lane);
+        stamp8<PROF>(pf);
+        ffn_half<2, true>(part, x, rg, pv, h, g);
         stamp8<PROF>(pf);  // 3: FFN
         if (next_has_skip) ring_issue<8, kR8, 0>(rg);  // this wave's share of the next block's skip linear
-        combine4_reduce<true>(part, x, pv + PV_L2_B, pv + PV_LN2_W, pv + PV_LN2_B, lds, h, lane);
+        combine_reduce<8, true>(part, x, pv + PV_L2_B, pv + PV_LN2_W, pv + PV_LN2_B, lds, h, lane);
     }
     stamp8<PROF>(pf);  // 4: combine 2
 }
@@ -357,10 +388,26 @@ struct Lane8 {
     long clip;
     bool valid, is_lat;
 };
+// Cheap to derive, expensive to keep: held across the block loop these constants get spilled to scratch (the ring
+// leaves no slack), so the step loop re-derives them where it needs them from an opaque copy of the lane id.
+__device__ __forceinline__ Lane8 lane_info(const SampleArgs& a, int lane) {
+    asm volatile("" : "+v"(lane));
+    Lane8 L;
+    L.lane = lane;
+    L.g = lane >> 4;
+    L.r = lane & 15;
+    const int S = a.S, R = S * a.G;
+    L.cl = L.r / S;
+    L.tok = L.r - L.cl * S;
+    L.clip = (long)blockIdx.x * a.G + L.cl;
+    L.valid = (L.r < R) && (L.clip < (long)a.B);
+    L.is_lat = L.valid && L.tok == 0;
+    return L;
+}
 
 // The whole T-step loop of one role.  Both roles execute the same sequence of workgroup barriers.
 template <bool ROLEA, bool PROF>
-__device__ __forceinline__ void role_loop8(const SampleArgs& a, char* smem, int w8, const Lane8& L) {
+__device__ __forceinline__ void role_loop8(const SampleArgs& a, char* smem, int w8, const Lane8& L0) {
     uint4* skipbf = reinterpret_cast<uint4*>(smem + kSkip8Off);
     const float* pvl = reinterpret_cast<const float*>(smem + kPv8Off);
     const f32x4* tokrows = reinterpret_cast<const f32x4*>(smem + kTokRows8Off);
@@ -368,7 +415,7 @@ __device__ __forceinline__ void role_loop8(const SampleArgs& a, char* smem, int 
     float* ttl = reinterpret_cast<float*>(smem + kTT8Off);
     const float* pv_skip = pvl + kLayers * kEncPv;
     const float* pv_final = pv_skip + 4 * kD;
-    const int lane = L.lane, g = L.g, r = L.r, h = w8 & 3;
+    const int lane = L0.lane, g = L0.g, r = L0.r, h = w8 & 3;
     const int S = a.S, R = S * a.G;
     // attention key mask for this lane's query row: keys j = 4 g + m of the SAME clip; padding rows attend to
     // themselves only (keeps them finite, they never touch valid rows)
@@ -376,7 +423,7 @@ __device__ __forceinline__ void role_loop8(const SampleArgs& a, char* smem, int 
 #pragma unroll
     for (int m = 0; m < 4; ++m) {
         const int j = 4 * g + m;
-        kvalid[m] = L.valid ? (j < R && (j / S) == L.cl) : (j == r);
+        kvalid[m] = L0.valid ? (j < R && (j / S) == L0.cl) : (j == r);
     }
     const bool tap = ROLEA && a.tap_out != nullptr && blockIdx.x == 0 && w8 == 0;
     const uint32_t wbase_units = ROLEA ? (uint32_t)w8 * (a.wave_units_a + kR8)
@@ -389,18 +436,20 @@ __device__ __forceinline__ void role_loop8(const SampleArgs& a, char* smem, int 
     Prof8 pf{a.prof_out ? a.prof_out + (size_t)w8 * 96 : nullptr, 0, false};
 #pragma unroll 1
     for (int step = 0; step < a.T; ++step) {
-        // ---- token assembly (A waves; a B wave's x is defined by the first combine's gather)
+        // ---- token assembly (every wave holds the residual stream)
         f32x4 x[kTiles];
+        {
+        const Lane8 L = lane_info(a, lane);
 #pragma unroll
         for (int t = 0; t < kTiles; ++t) {
-            x[t] = splat4(0.f);
-            if constexpr (ROLEA) {
+            {
                 const f32x4 sv = tokrows[t * 64 + lane];
                 // unconditional loads (a divergent branch around them sends x[] to scratch)
                 f32x4 tt = ld4(ttl + (step & 1) * kD + 16 * t + 4 * g);
                 if (a.time_tok_clip) tt = ld4(a.time_tok_clip + (size_t)(L.valid ? L.clip : 0) * kD + 16 * t + 4 * g);
                 x[t] = !L.valid ? splat4(0.f) : (L.tok == 0 ? latl[t * 64 + lane] + sv : (L.tok == 1 ? tt : sv));
             }
+        }
         }
         if (tap && step == 0) store_tap8(a.tap_out, 0, x, g, r);
         // next step's time token -> the other LDS buffer (read a whole step and many barriers later)
@@ -450,85 +499,80 @@ __device__ __forceinline__ void role_loop8(const SampleArgs& a, char* smem, int 
             }
             if (tap && step == 0) store_tap8(a.tap_out, 1 + blk, x, g, r);
         }
-        if (ROLEA && w8 == 0) {
-            // final LayerNorm (SkipTransformerEncoder.norm), parameters fetched tile by tile (register pressure)
-            {
-                float sm = 0.f;
+        // ---- final LayerNorm (SkipTransformerEncoder.norm) + scheduler.step (diffusers 0.17.1 DDIM / DDPM;
+        // amuse_hip.h amuse_schedule), spread over the workgroup: every wave holds the same x, computes the row
+        // statistics for itself, and then owns ONE feature tile (t = w8) of eps_hat and of the latent (LDS).
+        {
+            const Lane8 L = lane_info(a, lane);
+            float sm = 0.f;
 #pragma unroll
-                for (int t = 0; t < kTiles; ++t) sm += (x[t][0] + x[t][1]) + (x[t][2] + x[t][3]);
-                sm = allreduce_g_sum(sm);
-                const float mean = sm * (1.0f / kD);
-                float vs = 0.f;
+            for (int t = 0; t < kTiles; ++t) sm += (x[t][0] + x[t][1]) + (x[t][2] + x[t][3]);
+            sm = allreduce_g_sum(sm);
+            const float mean = sm * (1.0f / kD);
+            float vs = 0.f;
 #pragma unroll
-                for (int t = 0; t < kTiles; ++t)
+            for (int t = 0; t < kTiles; ++t)
 #pragma unroll
-                    for (int m = 0; m < 4; ++m) {
-                        const float d = x[t][m] - mean;
-                        vs += d * d;
-                    }
-                vs = allreduce_g_sum(vs);
-                const float rstd = __builtin_amdgcn_rsqf(vs * (1.0f / kD) + 1e-5f);
+                for (int m = 0; m < 4; ++m) {
+                    const float d = x[t][m] - mean;
+                    vs += d * d;
+                }
+            vs = allreduce_g_sum(vs);
+            const float rstd = __builtin_amdgcn_rsqf(vs * (1.0f / kD) + 1e-5f);
+            if (ROLEA && w8 == 0 && ((tap && step == 0) || (a.eps_out && step == a.T - 1))) {
+                // debugging / teacher-forced outputs want the whole eps_hat tile from one wave
+                f32x4 e[kTiles];
 #pragma unroll
                 for (int t = 0; t < kTiles; ++t) {
                     const f32x4 ga = ld4(pv_final + 16 * t + 4 * g), be = ld4(pv_final + kD + 16 * t + 4 * g);
 #pragma unroll
-                    for (int m = 0; m < 4; ++m) x[t][m] = (x[t][m] - mean) * rstd * ga[m] + be[m];
+                    for (int m = 0; m < 4; ++m) e[t][m] = (x[t][m] - mean) * rstd * ga[m] + be[m];
+                }
+                if (tap && step == 0) store_tap8(a.tap_out, 10, e, g, r);
+                if (a.eps_out && L.is_lat && step == a.T - 1) {
+#pragma unroll
+                    for (int t = 0; t < kTiles; ++t) st4(a.eps_out + (size_t)L.clip * kD + 16 * t + 4 * g, e[t]);
                 }
             }
-            if (tap && step == 0) store_tap8(a.tap_out, 10, x, g, r);
-            if (a.eps_out && L.is_lat && step == a.T - 1) {
-#pragma unroll
-                for (int t = 0; t < kTiles; ++t) st4(a.eps_out + (size_t)L.clip * kD + 16 * t + 4 * g, x[t]);
-            }
-            // ---- scheduler.step (diffusers 0.17.1 DDIM / DDPM; amuse_hip.h amuse_schedule) - as k_sampler.hip
             if (!a.no_update) {
+                // this wave's tile by value selects (no dynamic register index)
+                f32x4 xt = x[0];
+#pragma unroll
+                for (int t = 1; t < kTiles; ++t) {
+                    const bool m = (w8 == t);
+                    xt[0] = m ? x[t][0] : xt[0]; xt[1] = m ? x[t][1] : xt[1];
+                    xt[2] = m ? x[t][2] : xt[2]; xt[3] = m ? x[t][3] : xt[3];
+                }
+                const int f = 16 * w8 + 4 * g;
+                const f32x4 ga = ld4(pv_final + f), be = ld4(pv_final + kD + f);
                 const float* cf = a.coef + (size_t)step * 8;
                 const float sb = cf[0], sa = cf[1], c0 = cf[2], cx = cf[3], ce = cf[4], sg = cf[5], clipv = cf[6];
-                // ancestral noise: lane l draws the 4 normals of feature group l % 32 of clip 2 * call + l / 32 of
-                // the tile (one Philox call per lane per two clips); latent-row lanes fetch theirs by shuffle, tile
-                // by tile, so neither the noise nor the latent (LDS) is ever held as a whole in registers
-                f32x4 n0 = splat4(0.f), n1 = splat4(0.f);
-                const bool gen = sg != 0.f && !a.step_noise;
-                if (gen) {
-                    const uint64_t gc0 = a.clip0 + (uint64_t)((long)blockIdx.x * a.G + (lane >> 5));
-                    n0 = counter_normal4(a.seed, gc0, (uint32_t)step, (uint32_t)(lane & 31), 1u);
-                    if (a.G > 2) n1 = counter_normal4(a.seed, gc0 + 2, (uint32_t)step, (uint32_t)(lane & 31), 1u);
-                }
+                // ancestral noise of the latent rows: counter (global clip, step, feature group) - the values
+                // amuse_counter_normal exposes
+                f32x4 z = splat4(0.f);
+                if (sg != 0.f && L.is_lat)
+                    z = a.step_noise ? ld4(a.step_noise + ((size_t)step * a.B + L.clip) * kD + f)
+                                     : counter_normal4(a.seed, a.clip0 + (uint64_t)L.clip, (uint32_t)step, (uint32_t)(4 * w8 + g), 1u);
                 const float inv_sa = 1.0f / sa;
-                const int src = 32 * (L.cl & 1) + g;
-                const bool second = (L.cl >> 1) == 1;
-#pragma unroll
-                for (int t = 0; t < kTiles; ++t) {
-                    f32x4 z = splat4(0.f);
-                    if (gen) {
-#pragma unroll
-                        for (int m = 0; m < 4; ++m) {
-                            const float va = __shfl(n0[m], src + 4 * t), vb = __shfl(n1[m], src + 4 * t);
-                            z[m] = second ? vb : va;
-                        }
-                    } else if (sg != 0.f) {
-                        z = ld4(a.step_noise + ((size_t)step * a.B + (L.is_lat ? L.clip : 0)) * kD + 16 * t + 4 * g);
-                    }
-                    f32x4 l = latl[t * 64 + lane];
-                    {
+                f32x4 l = latl[w8 * 64 + lane];
+                {
 // each product and sum rounded on its own, like the scheduler's tensor ops (see k_sampler.hip)
 #pragma clang fp contract(off)
 #pragma unroll
-                    for (int m = 0; m < 4; ++m) {
-                        const float e = x[t][m], xl = l[m];
-                        const float num = __fsub_rn(xl, __fmul_rn(sb, e));
-                        float x0 = num * inv_sa;
-                        if (clipv > 0.f) x0 = fminf(fmaxf(x0, -clipv), clipv);
-                        float nx = __fmul_rn(c0, x0);
-                        if (cx != 0.f) nx = __fadd_rn(nx, __fmul_rn(cx, xl));
-                        if (ce != 0.f) nx = __fadd_rn(nx, __fmul_rn(ce, e));
-                        if (sg != 0.f) nx = __fadd_rn(nx, __fmul_rn(sg, z[m]));
-                        l[m] = nx;
-                    }
-                    }
-                    latl[t * 64 + lane] = l;
-                    if (a.traj_out && L.is_lat) st4(a.traj_out + ((size_t)step * a.B + L.clip) * kD + 16 * t + 4 * g, l);
+                for (int m = 0; m < 4; ++m) {
+                    const float e = (xt[m] - mean) * rstd * ga[m] + be[m], xl = l[m];
+                    const float num = __fsub_rn(xl, __fmul_rn(sb, e));
+                    float x0 = num * inv_sa;
+                    if (clipv > 0.f) x0 = fminf(fmaxf(x0, -clipv), clipv);
+                    float nx = __fmul_rn(c0, x0);
+                    if (cx != 0.f) nx = __fadd_rn(nx, __fmul_rn(cx, xl));
+                    if (ce != 0.f) nx = __fadd_rn(nx, __fmul_rn(ce, e));
+                    if (sg != 0.f) nx = __fadd_rn(nx, __fmul_rn(sg, z[m]));
+                    l[m] = nx;
                 }
+                }
+                latl[w8 * 64 + lane] = l;
+                if (a.traj_out && L.is_lat) st4(a.traj_out + ((size_t)step * a.B + L.clip) * kD + f, l);
             }
         }
         stamp8<PROF>(pf);  // scheduler update done (wave 0) / reached the step barrier
@@ -548,17 +592,9 @@ __global__ __launch_bounds__(512) void k_sample8(SampleArgs a) {
         st4(pvl + 4 * i, ld4(a.pvec + blk * PV_BLOCK + off));
     }
     for (int i = threadIdx.x; i < (4 * kD + 2 * kD) / 4; i += 512) st4(pvl + kLayers * kEncPv + 4 * i, ld4(a.pvec + PV_SKIP_B + 4 * i));
-    Lane8 L;
-    L.lane = threadIdx.x & 63;
     const int w8 = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    L.g = L.lane >> 4;
-    L.r = L.lane & 15;
-    const int S = a.S, R = S * a.G;
-    L.cl = L.r / S;
-    L.tok = L.r - L.cl * S;
-    L.clip = (long)blockIdx.x * a.G + L.cl;
-    L.valid = (L.r < R) && (L.clip < (long)a.B);
-    L.is_lat = L.valid && L.tok == 0;
+    const int S = a.S;
+    const Lane8 L = lane_info(a, threadIdx.x & 63);
     // static token rows (pe[0] under the latent rows, condition tokens; denoiser.py:174,180-181) and the initial
     // latent -> LDS (registers are the scarce resource at 2 waves / SIMD; wave 0 owns the latent's update)
     if (w8 == 0) {

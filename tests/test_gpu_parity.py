@@ -232,9 +232,10 @@ def test_in_kernel_noise_equals_explicit_counter_noise(env):
     try:
         for G in (1, 2, 3):
             eng.set_clips_per_group(G)
-            a = eng.sample(c, e, s, "fp32", seed=seed, clip_index0=c0)
-            b = eng.sample(c, e, s, "fp32", x_init=x0, step_noise=nz)
-            assert torch.equal(a, b), G
+            for prec in ("fp32", "bf16"):   # two different kernels (k_sampler.hip / k_sampler8.hip)
+                a = eng.sample(c, e, s, prec, seed=seed, clip_index0=c0)
+                b = eng.sample(c, e, s, prec, x_init=x0, step_noise=nz)
+                assert torch.equal(a, b), (G, prec)
     finally:
         eng.set_clips_per_group(0)
 
