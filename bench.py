@@ -189,11 +189,11 @@ def main():
                        "mfma_operands": args.precision, "state_and_accumulate": "fp32"},
             "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
                          "frac": round(achieved / peak, 5), "traffic": pmc_traffic_bytes(B, args.T, args.precision),
-                         "kernel": "k_sample (persistent T-step denoising loop)",
+                         "kernel": ("k_sample8" if args.precision == "bf16" else "k_sample") + " (persistent T-step denoising loop)",
                          "kernel_ms": round(k_avg * 1e3, 3),
                          "note": "algorithmic FLOPs = clips x T x 19,120,640; the kernel is bound by the serial "
                                  "per-step dependency chain + per-CU L2->CU weight streaming, not by HBM or MFMA "
-                                 "issue (DESIGN.md section 5)"},
+                                 "issue (DESIGN.md sections 4.1, 5)"},
         }
         # single-clip latency (BASELINE configs[1]): B = 1, same sampler
         c1, e1, s1 = con[:1].contiguous(), emo[:1].contiguous(), sty[:1].contiguous()
