@@ -19,7 +19,9 @@
 //   FFN's MFMA + GELU work is spread over two waves per SIMD.
 //   U-Net skip linears: split-K over all 8 waves (k-tiles 2 w8, 2 w8 + 1 of cat(x, skip)); the skip stack is kept
 //     as packed bf16 MFMA operands (what the 4-wave kernel's cvt_pk produces from its fp32 copy - same bits).
-//   Token assembly in every wave; final LayerNorm + scheduler update in wave 0, latent in LDS.
+//   The residual stream travels between waves as packed bf16 MFMA operands (4 x 1 KiB per tile - what every GEMM
+//   consumes); only the reducer of a feature tile keeps it in fp32 (the B waves, two tiles each, in registers).
+//   Final LayerNorm + scheduler update in the B waves on their own tiles; latent in LDS.
 //
 // LDS (163,328 B): combine matrix A8 [8 rows][8 tiles][64] f32x4 - partials off the diagonal, reduced tiles ON the
 // diagonal (slot (t, t)), so the all-gather of one combine never aliases the partial writes of the next - | row
@@ -50,6 +52,10 @@ using Ring = WRing<kR8>;
 #define AMUSE_C1_N1 12
 #define AMUSE_C1_N2 12
 #endif
+// units a B wave issues during the A waves' attention phase; the rest of its 32 follow behind its first FFN MFMAs
+#ifndef AMUSE_B_EARLY
+#define AMUSE_B_EARLY 24
+#endif
 #ifndef AMUSE_C2_N1
 #define AMUSE_C2_N1 12
 #define AMUSE_C2_N2 12
@@ -57,6 +63,21 @@ using Ring = WRing<kR8>;
 
 __device__ __forceinline__ f32x4* a8_slot(char* lds, int row, int col, int lane) {
     return reinterpret_cast<f32x4*>(lds) + (row * kTiles + col) * 64 + lane;
+}
+// packed bf16 operand c (feature tiles 2c, 2c+1 of the residual stream) is published in diagonal slot (c, c)
+__device__ __forceinline__ uint4* xb_slot(char* lds, int c, int lane) {
+    return reinterpret_cast<uint4*>(a8_slot(lds, c, c, lane));
+}
+// acc[o] += W_o . x over the 128 features held as four packed operands; same unit order as gemm_ring (bf16)
+template <int NO, bool SWAP, int PH>
+__device__ __forceinline__ void gemm_xb(f32x4 (&acc)[NO], const bf16x8 (&xb)[4], const Ring& rg) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int o = 0; o < NO; ++o) {
+            const bf16x8 wf = __builtin_bit_cast(bf16x8, rg.s[(PH + c * NO + o) % kR8]);
+            acc[o] = SWAP ? mfma_bf16(xb[c], wf, acc[o]) : mfma_bf16(wf, xb[c], acc[o]);
+        }
 }
 
 // ---- split-K combine, B waves reduce.  NP = 4: partials from the A waves only (out_proj); NP = 8: from all waves
@@ -70,7 +91,7 @@ __device__ __forceinline__ constexpr int part_row(int w, int t) {
     return k + (k >= t ? 1 : 0);
 }
 template <int W, int NP, bool FAST>
-__device__ __forceinline__ void combine_red(f32x4 (&part)[kTiles], f32x4 (&x)[kTiles], const float* bias,
+__device__ __forceinline__ void combine_red(f32x4 (&part)[kTiles], f32x4 (&xo)[2], bf16x8 (&xb)[4], const float* bias,
                                             const float* gamma, const float* beta, char* lds, int lane) {
     float2* stats = reinterpret_cast<float2*>(lds + kStat8Off);
     const int g = lane >> 4, r = lane & 15;
@@ -105,7 +126,7 @@ __device__ __forceinline__ void combine_red(f32x4 (&part)[kTiles], f32x4 (&x)[kT
             } else {
                 sum = ((p[0][i] + p[1][i]) + p[2][i]) + p[3][i];
             }
-            y[i] = x[T0 + i] + (sum + bi[i]);
+            y[i] = xo[i] + (sum + bi[i]);
         }
     }
     float s = ((y[0][0] + y[0][1]) + (y[0][2] + y[0][3])) + ((y[1][0] + y[1][1]) + (y[1][2] + y[1][3]));
@@ -132,28 +153,31 @@ __device__ __forceinline__ void combine_red(f32x4 (&part)[kTiles], f32x4 (&x)[kT
     for (int i = 0; i < 2; ++i) {
 #pragma unroll
         for (int m = 0; m < 4; ++m) y[i][m] = (y[i][m] - mean) * rstd * ga[i][m] + be[i][m];
-        *a8_slot(lds, T0 + i, T0 + i, lane) = y[i];
-        x[T0 + i] = y[i];
+        xo[i] = y[i];
     }
+    // publish the two tiles as ONE packed bf16 operand (k-tile pair W of every following GEMM)
+    xb[W] = pack_bf16(y[0], y[1]);
+    *xb_slot(lds, W, lane) = __builtin_bit_cast(uint4, xb[W]);
     __syncthreads();
 #pragma unroll
-    for (int t = 0; t < kTiles; ++t)
-        if (t != T0 && t != T0 + 1) x[t] = *a8_slot(lds, t, t, lane);
+    for (int c = 0; c < 4; ++c)
+        if (c != W) xb[c] = __builtin_bit_cast(bf16x8, *xb_slot(lds, c, lane));
     asm volatile("; combine_red case %0" ::"n"(W));  // see combine8_impl
 }
 template <int NP, bool FAST>
-__device__ __forceinline__ void combine_reduce(f32x4 (&part)[kTiles], f32x4 (&x)[kTiles], const float* bias,
-                                               const float* gamma, const float* beta, char* lds, int h, int lane) {
-    if (h == 0) combine_red<0, NP, FAST>(part, x, bias, gamma, beta, lds, lane);
-    else if (h == 1) combine_red<1, NP, FAST>(part, x, bias, gamma, beta, lds, lane);
-    else if (h == 2) combine_red<2, NP, FAST>(part, x, bias, gamma, beta, lds, lane);
-    else combine_red<3, NP, FAST>(part, x, bias, gamma, beta, lds, lane);
+__device__ __forceinline__ void combine_reduce(f32x4 (&part)[kTiles], f32x4 (&xo)[2], bf16x8 (&xb)[4],
+                                               const float* bias, const float* gamma, const float* beta, char* lds,
+                                               int h, int lane) {
+    if (h == 0) combine_red<0, NP, FAST>(part, xo, xb, bias, gamma, beta, lds, lane);
+    else if (h == 1) combine_red<1, NP, FAST>(part, xo, xb, bias, gamma, beta, lds, lane);
+    else if (h == 2) combine_red<2, NP, FAST>(part, xo, xb, bias, gamma, beta, lds, lane);
+    else combine_red<3, NP, FAST>(part, xo, xb, bias, gamma, beta, lds, lane);
 }
 // The A waves' side: publish the partial, then the barriers and the gather - with the issue of N1 + N2 + N3
 // weight-stream units into ring slots IPH0.. in between.  These waves are off the critical path here, so their
 // blocking global_load issue costs nothing as long as it fits the reducers' phases.
 template <int N1, int N2, int N3, int IPH0>
-__device__ __forceinline__ void combine_publish(const f32x4 (&part)[kTiles], f32x4 (&x)[kTiles], char* lds, int h,
+__device__ __forceinline__ void combine_publish(const f32x4 (&part)[kTiles], bf16x8 (&xb)[4], char* lds, int h,
                                                 int lane, Ring& rg) {
 #pragma unroll
     for (int t = 0; t < kTiles; ++t) *a8_slot(lds, h + (h >= t ? 1 : 0), t, lane) = part[t];  // part_row(h, t), h < 4
@@ -163,88 +187,39 @@ __device__ __forceinline__ void combine_publish(const f32x4 (&part)[kTiles], f32
     ring_issue<N2, kR8, (IPH0 + N1) % kR8>(rg);
     __syncthreads();
 #pragma unroll
-    for (int t = 0; t < kTiles; ++t) x[t] = *a8_slot(lds, t, t, lane);
+    for (int c = 0; c < 4; ++c) xb[c] = __builtin_bit_cast(bf16x8, *xb_slot(lds, c, lane));
     ring_issue<N3, kR8, (IPH0 + N1 + N2) % kR8>(rg);
 }
 
-// ---- combine over EIGHT partials: wave W reduces tile W.   x <- [LN]([x +] sum_w part_w + bias)
-template <int W, bool DO_LN, bool FAST>
-__device__ __forceinline__ void combine8_impl(f32x4 (&part)[kTiles], f32x4 (&x)[kTiles], bool residual,
-                                              const float* bias, const float* gamma, const float* beta, char* lds,
-                                              int lane) {
-    float2* stats = reinterpret_cast<float2*>(lds + kStat8Off);
-    const int g = lane >> 4, r = lane & 15;
+// ---- skip-linear combine over EIGHT partials: wave W reduces tile W (sum + bias, no LayerNorm, no residual) and
+// publishes it in fp32 on the diagonal; after the closing barrier every wave reads what it needs.
+template <int W>
+__device__ __forceinline__ void combine8_impl(const f32x4 (&part)[kTiles], const float* bias, char* lds, int lane) {
+    const int g = lane >> 4;
 #pragma unroll
     for (int t = 0; t < kTiles; ++t)
         if (t != W) *a8_slot(lds, W, t, lane) = part[t];
     const f32x4 bi = ld4(bias + 16 * W + 4 * g);
-    f32x4 ga = splat4(1.f), be = splat4(0.f);
-    if constexpr (DO_LN) {
-        ga = ld4(gamma + 16 * W + 4 * g);
-        be = ld4(beta + 16 * W + 4 * g);
-    }
     __syncthreads();
-    f32x4 y;
-    {
-        f32x4 p[8];
+    f32x4 p[8];
 #pragma unroll
-        for (int w = 0; w < 8; ++w)
-            if (w != W) p[w] = *a8_slot(lds, w, W, lane);
-        p[W] = part[W];
-        const f32x4 sum = (((p[0] + p[1]) + (p[2] + p[3])) + ((p[4] + p[5]) + (p[6] + p[7])));
-        y = residual ? x[W] + (sum + bi) : sum + bi;
-    }
-    if constexpr (DO_LN) {
-        float s = (y[0] + y[1]) + (y[2] + y[3]);
-        s = allreduce_g_sum(s);
-        const float mw = s * (1.0f / 16.0f);
-        float m2 = 0.f;
-#pragma unroll
-        for (int m = 0; m < 4; ++m) {
-            const float d = y[m] - mw;
-            m2 += d * d;
-        }
-        m2 = allreduce_g_sum(m2);
-        if (g == 0) stats[W * 16 + r] = float2{mw, m2};
-        __syncthreads();
-        float2 st[8];
-#pragma unroll
-        for (int w = 0; w < 8; ++w) st[w] = stats[w * 16 + r];
-        const float mean = (((st[0].x + st[1].x) + (st[2].x + st[3].x)) + ((st[4].x + st[5].x) + (st[6].x + st[7].x))) * 0.125f;
-        float dd = 0.f, mm = 0.f;
-#pragma unroll
-        for (int w = 0; w < 8; ++w) {
-            const float d = st[w].x - mean;
-            dd += d * d;
-            mm += st[w].y;
-        }
-        const float var = (mm + 16.0f * dd) * (1.0f / kD) + 1e-5f;
-        const float rstd = FAST ? __builtin_amdgcn_rsqf(var) : 1.0f / sqrtf(var);
-#pragma unroll
-        for (int m = 0; m < 4; ++m) y[m] = (y[m] - mean) * rstd * ga[m] + be[m];
-    }
-    *a8_slot(lds, W, W, lane) = y;
-    x[W] = y;
+    for (int w = 0; w < 8; ++w)
+        if (w != W) p[w] = *a8_slot(lds, w, W, lane);
+    p[W] = part[W];
+    const f32x4 sum = (((p[0] + p[1]) + (p[2] + p[3])) + ((p[4] + p[5]) + (p[6] + p[7])));
+    *a8_slot(lds, W, W, lane) = sum + bi;
     __syncthreads();
-#pragma unroll
-    for (int t = 0; t < kTiles; ++t)
-        if (t != W) x[t] = *a8_slot(lds, t, t, lane);
-    // keeps SimplifyCFG from sinking the eight cases' x[] stores into one block behind a pointer PHI (which pins
-    // x[] in scratch): an immediate operand cannot be merged
-    asm volatile("; combine8 case %0" ::"n"(W));
 }
-template <bool DO_LN, bool FAST>
-__device__ __forceinline__ void combine8(f32x4 (&part)[kTiles], f32x4 (&x)[kTiles], bool residual, const float* bias,
-                                         const float* gamma, const float* beta, char* lds, int w8, int lane) {
+__device__ __forceinline__ void combine8(const f32x4 (&part)[kTiles], const float* bias, char* lds, int w8, int lane) {
     switch (w8) {
-        case 0: combine8_impl<0, DO_LN, FAST>(part, x, residual, bias, gamma, beta, lds, lane); break;
-        case 1: combine8_impl<1, DO_LN, FAST>(part, x, residual, bias, gamma, beta, lds, lane); break;
-        case 2: combine8_impl<2, DO_LN, FAST>(part, x, residual, bias, gamma, beta, lds, lane); break;
-        case 3: combine8_impl<3, DO_LN, FAST>(part, x, residual, bias, gamma, beta, lds, lane); break;
-        case 4: combine8_impl<4, DO_LN, FAST>(part, x, residual, bias, gamma, beta, lds, lane); break;
-        case 5: combine8_impl<5, DO_LN, FAST>(part, x, residual, bias, gamma, beta, lds, lane); break;
-        case 6: combine8_impl<6, DO_LN, FAST>(part, x, residual, bias, gamma, beta, lds, lane); break;
-        default: combine8_impl<7, DO_LN, FAST>(part, x, residual, bias, gamma, beta, lds, lane); break;
+        case 0: combine8_impl<0>(part, bias, lds, lane); break;
+        case 1: combine8_impl<1>(part, bias, lds, lane); break;
+        case 2: combine8_impl<2>(part, bias, lds, lane); break;
+        case 3: combine8_impl<3>(part, bias, lds, lane); break;
+        case 4: combine8_impl<4>(part, bias, lds, lane); break;
+        case 5: combine8_impl<5>(part, bias, lds, lane); break;
+        case 6: combine8_impl<6>(part, bias, lds, lane); break;
+        default: combine8_impl<7>(part, bias, lds, lane); break;
     }
 }
 
@@ -286,14 +261,12 @@ __device__ __forceinline__ void stamp8(Prof8& pf) {
     }
 }
 
-// bias + exact-erf GELU on one FFN quarter (two hidden tiles); b1 points at this lane's 4 biases of the first tile
+// bias + GELU (amuse_dev.hpp gelu_poly4: the result is an MFMA operand, i.e. rounded to bf16 next) on one FFN
+// quarter (two hidden tiles); b1 points at this lane's 4 biases of the first tile
 __device__ __forceinline__ void gelu_pair(f32x4 (&hq)[2], const float* b1) {
     const f32x4 ba = ld4(b1), bb = ld4(b1 + 16);
-#pragma unroll
-    for (int m = 0; m < 4; ++m) {
-        hq[0][m] = gelu_erf_fast(hq[0][m] + ba[m]);
-        hq[1][m] = gelu_erf_fast(hq[1][m] + bb[m]);
-    }
+    hq[0] = gelu_poly4(hq[0] + ba);
+    hq[1] = gelu_poly4(hq[1] + bb);
 }
 
 // this wave's two FFN quarters (Q0, Q0 + 1 of head h's slice): linear1 for 2 hidden tiles each -> bias + GELU ->
@@ -302,14 +275,14 @@ __device__ __forceinline__ void gelu_pair(f32x4 (&hq)[2], const float* b1) {
 // LATE8: the last 8 units (F2b) are issued only now, behind the first GEMMs' MFMAs (B waves: their fetch window, the A
 // waves' attention phase, is a little too short for all 32)
 template <int Q0, bool LATE8>
-__device__ __forceinline__ void ffn_half(f32x4 (&part)[kTiles], const f32x4 (&x)[kTiles], Ring& rg, const float* pv,
+__device__ __forceinline__ void ffn_half(f32x4 (&part)[kTiles], const bf16x8 (&xb)[4], Ring& rg, const float* pv,
                                          int h, int g) {
     constexpr int P = PREC_BF16;
     f32x4 ha[2] = {splat4(0.f), splat4(0.f)}, hb[2] = {splat4(0.f), splat4(0.f)};
     const float* b1 = pv + PV_L1_B + 16 * (kTiles * h + 2 * Q0) + 4 * g;
-    gemm_ring<P, 2, kTiles, false, kR8, 0, false>(ha, x, rg);
-    gemm_ring<P, 2, kTiles, false, kR8, 8, false>(hb, x, rg);
-    if constexpr (LATE8) ring_issue<8, kR8, 24>(rg);
+    gemm_xb<2, false, 0>(ha, xb, rg);
+    gemm_xb<2, false, 8>(hb, xb, rg);
+    if constexpr (LATE8) ring_issue<32 - AMUSE_B_EARLY, kR8, AMUSE_B_EARLY>(rg);
     gelu_pair(ha, b1);
     gemm_ring<P, kTiles, 2, false, kR8, 16, false>(part, ha, rg);
     gelu_pair(hb, b1 + 32);
@@ -319,9 +292,11 @@ __device__ __forceinline__ void ffn_half(f32x4 (&part)[kTiles], const f32x4 (&x)
 // One TransformerEncoderLayer.forward_post (cross_attention.py:259-272), A / B role split.  The two roles are
 // separate instantiations (and the whole step loop is instantiated per role, k_sample8 below): sharing one body
 // behind a runtime branch makes hipcc's register allocator spill hundreds of VGPRs at the merges.
+// xb: the residual stream as four packed bf16 operands (every wave); xo: this B wave's two feature tiles in fp32.
 template <bool ROLEA, bool PROF>
-__device__ __forceinline__ void encoder_block8(f32x4 (&x)[kTiles], Ring& rg, const float* pv, const bool (&kvalid)[4],
-                                               char* lds, int h, int lane, bool next_has_skip, Prof8& pf) {
+__device__ __forceinline__ void encoder_block8(bf16x8 (&xb)[4], f32x4 (&xo)[2], Ring& rg, const float* pv,
+                                               const bool (&kvalid)[4], char* lds, int h, int lane, bool next_has_skip,
+                                               Prof8& pf) {
     constexpr int P = PREC_BF16;
     const int g = lane >> 4, r = lane & 15;
     f32x4 part[kTiles];
@@ -339,8 +314,8 @@ __device__ __forceinline__ void encoder_block8(f32x4 (&x)[kTiles], Ring& rg, con
 #pragma unroll
         for (int o = 0; o < 4; ++o) qk[o] = splat4(0.f);
         v[0] = v[1] = splat4(0.f);
-        gemm_ring<P, 4, kTiles, false, kR8, 0, false>(qk, x, rg);
-        gemm_ring<P, 2, kTiles, true, kR8, 16, false>(v, x, rg);
+        gemm_xb<4, false, 0>(qk, xb, rg);
+        gemm_xb<2, true, 16>(v, xb, rg);
         const float scaling = 0.17677669529663687f;  // sqrt(1/32): q * scaling (F.multi_head_attention_forward)
         f32x4 q[2] = {(qk[0] + b_qk[0]) * scaling, (qk[1] + b_qk[1]) * scaling};
         f32x4 k[2] = {qk[2] + b_qk[2], qk[3] + b_qk[3]};
@@ -353,33 +328,33 @@ __device__ __forceinline__ void encoder_block8(f32x4 (&x)[kTiles], Ring& rg, con
         gemm_ring<P, kTiles, 2, false, kR8, 24, false>(part, o, rg);
         stamp8<PROF>(pf);  // 1: in_proj + attention + out_proj partial
         // ---- out_proj combine (B reduces): meanwhile fetch this wave's FFN half
-        combine_publish<AMUSE_C1_N1, AMUSE_C1_N2, 32 - AMUSE_C1_N1 - AMUSE_C1_N2, 0>(part, x, lds, h, lane, rg);
+        combine_publish<AMUSE_C1_N1, AMUSE_C1_N2, 32 - AMUSE_C1_N1 - AMUSE_C1_N2, 0>(part, xb, lds, h, lane, rg);
         stamp8<PROF>(pf);  // 2: combine 1
 #pragma unroll
         for (int t = 0; t < kTiles; ++t) part[t] = splat4(0.f);
-        ffn_half<0, false>(part, x, rg, pv, h, g);
+        ffn_half<0, false>(part, xb, rg, pv, h, g);
         stamp8<PROF>(pf);  // 3: FFN
         // ---- linear2 combine (B reduces): meanwhile fetch the next block's attention weights
-        combine_publish<AMUSE_C2_N1, AMUSE_C2_N2, 32 - AMUSE_C2_N1 - AMUSE_C2_N2, 0>(part, x, lds, h, lane, rg);
+        combine_publish<AMUSE_C2_N1, AMUSE_C2_N2, 32 - AMUSE_C2_N1 - AMUSE_C2_N2, 0>(part, xb, lds, h, lane, rg);
     } else {
         // ---- ring empty on entry: fetch this wave's FFN half while the A waves run attention
-        ring_issue<24, kR8, 0>(rg);
+        ring_issue<AMUSE_B_EARLY, kR8, 0>(rg);
         stamp8<PROF>(pf);
 #pragma unroll
         for (int t = 0; t < kTiles; ++t) part[t] = splat4(0.f);
-        combine_reduce<4, true>(part, x, pv + PV_OUT_B, pv + PV_LN1_W, pv + PV_LN1_B, lds, h, lane);
+        combine_reduce<4, true>(part, xo, xb, pv + PV_OUT_B, pv + PV_LN1_W, pv + PV_LN1_B, lds, h, lane);
         stamp8<PROF>(pf);
-        ffn_half<2, true>(part, x, rg, pv, h, g);
+        ffn_half<2, (AMUSE_B_EARLY < 32)>(part, xb, rg, pv, h, g);
         stamp8<PROF>(pf);  // 3: FFN
         if (next_has_skip) ring_issue<8, kR8, 0>(rg);  // this wave's share of the next block's skip linear
-        combine_reduce<8, true>(part, x, pv + PV_L2_B, pv + PV_LN2_W, pv + PV_LN2_B, lds, h, lane);
+        combine_reduce<8, true>(part, xo, xb, pv + PV_L2_B, pv + PV_LN2_W, pv + PV_LN2_B, lds, h, lane);
     }
     stamp8<PROF>(pf);  // 4: combine 2
 }
 
-__device__ __forceinline__ void store_tap8(float* tap, int slot, const f32x4 (&x)[kTiles], int g, int r) {
-#pragma unroll
-    for (int t = 0; t < kTiles; ++t) st4(tap + ((size_t)slot * 16 + r) * kD + 16 * t + 4 * g, x[t]);
+// debugging taps: one feature tile of the [16 x 128] residual stream
+__device__ __forceinline__ void store_tap_tile(float* tap, int slot, int t, const f32x4& v, int g, int r) {
+    st4(tap + ((size_t)slot * 16 + r) * kD + 16 * t + 4 * g, v);
 }
 
 // per-lane constants of the tile (row-lane layout: lane (g, r) holds row r)
@@ -413,6 +388,7 @@ __device__ __forceinline__ void role_loop8(const SampleArgs& a, char* smem, int 
     const f32x4* tokrows = reinterpret_cast<const f32x4*>(smem + kTokRows8Off);
     f32x4* latl = reinterpret_cast<f32x4*>(smem + kLat8Off);
     float* ttl = reinterpret_cast<float*>(smem + kTT8Off);
+    float2* stats = reinterpret_cast<float2*>(smem + kStat8Off);
     const float* pv_skip = pvl + kLayers * kEncPv;
     const float* pv_final = pv_skip + 4 * kD;
     const int lane = L0.lane, g = L0.g, r = L0.r, h = w8 & 3;
@@ -425,7 +401,7 @@ __device__ __forceinline__ void role_loop8(const SampleArgs& a, char* smem, int 
         const int j = 4 * g + m;
         kvalid[m] = L0.valid ? (j < R && (j / S) == L0.cl) : (j == r);
     }
-    const bool tap = ROLEA && a.tap_out != nullptr && blockIdx.x == 0 && w8 == 0;
+    const bool tap = !ROLEA && a.tap_out != nullptr && blockIdx.x == 0;  // the B waves tap their own fp32 tiles
     const uint32_t wbase_units = ROLEA ? (uint32_t)w8 * (a.wave_units_a + kR8)
                                        : 4u * (a.wave_units_a + kR8) + (uint32_t)(w8 - 4) * a.wave_units_b;
     const uint4* wbase = a.wstream + (size_t)wbase_units * 64 + lane;
@@ -436,22 +412,30 @@ __device__ __forceinline__ void role_loop8(const SampleArgs& a, char* smem, int 
     Prof8 pf{a.prof_out ? a.prof_out + (size_t)w8 * 96 : nullptr, 0, false};
 #pragma unroll 1
     for (int step = 0; step < a.T; ++step) {
-        // ---- token assembly (every wave holds the residual stream)
-        f32x4 x[kTiles];
+        // ---- token assembly (denoiser.py:174,180-181): every wave builds the four packed operands, a B wave also
+        // its own two tiles in fp32
+        bf16x8 xb[4];
+        f32x4 xo[2] = {splat4(0.f), splat4(0.f)};
         {
-        const Lane8 L = lane_info(a, lane);
-#pragma unroll
-        for (int t = 0; t < kTiles; ++t) {
-            {
+            const Lane8 L = lane_info(a, lane);
+            auto assemble = [&](int t) -> f32x4 {
                 const f32x4 sv = tokrows[t * 64 + lane];
-                // unconditional loads (a divergent branch around them sends x[] to scratch)
+                // unconditional loads (a divergent branch around them costs registers)
                 f32x4 tt = ld4(ttl + (step & 1) * kD + 16 * t + 4 * g);
                 if (a.time_tok_clip) tt = ld4(a.time_tok_clip + (size_t)(L.valid ? L.clip : 0) * kD + 16 * t + 4 * g);
-                x[t] = !L.valid ? splat4(0.f) : (L.tok == 0 ? latl[t * 64 + lane] + sv : (L.tok == 1 ? tt : sv));
+                return !L.valid ? splat4(0.f) : (L.tok == 0 ? latl[t * 64 + lane] + sv : (L.tok == 1 ? tt : sv));
+            };
+#pragma unroll
+            for (int c = 0; c < 4; ++c) xb[c] = pack_bf16(assemble(2 * c), assemble(2 * c + 1));
+            if constexpr (!ROLEA) {
+                xo[0] = assemble(2 * h);
+                xo[1] = assemble(2 * h + 1);
             }
         }
+        if (tap && step == 0) {
+            store_tap_tile(a.tap_out, 0, 2 * h, xo[0], g, r);
+            store_tap_tile(a.tap_out, 0, 2 * h + 1, xo[1], g, r);
         }
-        if (tap && step == 0) store_tap8(a.tap_out, 0, x, g, r);
         // next step's time token -> the other LDS buffer (read a whole step and many barriers later)
         if (!ROLEA && w8 == 4 && lane < 32 && step + 1 < a.T)
             st4(ttl + ((step + 1) & 1) * kD + 4 * lane, ld4(a.time_tok + (size_t)(step + 1) * kD + 4 * lane));
@@ -467,115 +451,115 @@ __device__ __forceinline__ void role_loop8(const SampleArgs& a, char* smem, int 
             if (blk >= 5) {  // x = Linear(cat(x, skips.pop())), split-K over 8 waves: k-tiles 2 w8, 2 w8 + 1
                 f32x4 part[kTiles];
                 if constexpr (ROLEA) {
-                    // operand pair by value selects (a branch chain over x[] sends the whole array to scratch)
-                    uint4 xs = __builtin_bit_cast(uint4, pack_bf16(x[0], x[1]));
+                    // operand pair h by value selects
+                    uint4 xs = __builtin_bit_cast(uint4, xb[0]);
 #pragma unroll
                     for (int p = 1; p < 4; ++p) {
-                        const uint4 c = __builtin_bit_cast(uint4, pack_bf16(x[2 * p], x[2 * p + 1]));
+                        const uint4 c = __builtin_bit_cast(uint4, xb[p]);
                         const bool m = (h == p);
                         xs.x = m ? c.x : xs.x; xs.y = m ? c.y : xs.y; xs.z = m ? c.z : xs.z; xs.w = m ? c.w : xs.w;
                     }
-                    const bf16x8 xb = __builtin_bit_cast(bf16x8, xs);
+                    const bf16x8 xop = __builtin_bit_cast(bf16x8, xs);
                     // the skip linear's units sit in slots 24..31 in place of out_proj, which is fetched right after
 #pragma unroll
                     for (int o = 0; o < kTiles; ++o)
-                        part[o] = mfma_bf16(__builtin_bit_cast(bf16x8, rg.s[24 + o]), xb, splat4(0.f));
+                        part[o] = mfma_bf16(__builtin_bit_cast(bf16x8, rg.s[24 + o]), xop, splat4(0.f));
                     ring_issue<8, kR8, 24>(rg);
                 } else {
                     // slots 0..7, issued during the previous linear2 combine; operand = the popped skip tiles
-                    const bf16x8 xb = __builtin_bit_cast(bf16x8, skipbf[((8 - blk) * 4 + h) * 64 + lane]);
+                    const bf16x8 xop = __builtin_bit_cast(bf16x8, skipbf[((8 - blk) * 4 + h) * 64 + lane]);
 #pragma unroll
                     for (int o = 0; o < kTiles; ++o)
-                        part[o] = mfma_bf16(__builtin_bit_cast(bf16x8, rg.s[o]), xb, splat4(0.f));
+                        part[o] = mfma_bf16(__builtin_bit_cast(bf16x8, rg.s[o]), xop, splat4(0.f));
                 }
-                combine8<false, true>(part, x, false, pv_skip + (blk - 5) * kD, nullptr, nullptr, smem, w8, lane);
+                combine8(part, pv_skip + (blk - 5) * kD, smem, w8, lane);
+                // the new residual stream is on the diagonal in fp32: pack the operands, B keeps its own tiles
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+                    xb[c] = pack_bf16(*a8_slot(smem, 2 * c, 2 * c, lane), *a8_slot(smem, 2 * c + 1, 2 * c + 1, lane));
+                if constexpr (!ROLEA) {
+                    xo[0] = *a8_slot(smem, 2 * h, 2 * h, lane);
+                    xo[1] = *a8_slot(smem, 2 * h + 1, 2 * h + 1, lane);
+                }
             }
             stamp8<PROF>(pf);  // 0: block start (after the skip linear, if any)
-            encoder_block8<ROLEA, PROF>(x, rg, pvl + blk * kEncPv, kvalid, smem, h, lane, blk >= 4 && blk < kLayers - 1, pf);
+            encoder_block8<ROLEA, PROF>(xb, xo, rg, pvl + blk * kEncPv, kvalid, smem, h, lane, blk >= 4 && blk < kLayers - 1, pf);
             if (!ROLEA && blk < 4 && w8 == 4) {
 #pragma unroll
-                for (int p = 0; p < 4; ++p)
-                    skipbf[(blk * 4 + p) * 64 + lane] = __builtin_bit_cast(uint4, pack_bf16(x[2 * p], x[2 * p + 1]));
+                for (int p = 0; p < 4; ++p) skipbf[(blk * 4 + p) * 64 + lane] = __builtin_bit_cast(uint4, xb[p]);
             }
-            if (tap && step == 0) store_tap8(a.tap_out, 1 + blk, x, g, r);
+            if (tap && step == 0) {
+                store_tap_tile(a.tap_out, 1 + blk, 2 * h, xo[0], g, r);
+                store_tap_tile(a.tap_out, 1 + blk, 2 * h + 1, xo[1], g, r);
+            }
         }
         // ---- final LayerNorm (SkipTransformerEncoder.norm) + scheduler.step (diffusers 0.17.1 DDIM / DDPM;
-        // amuse_hip.h amuse_schedule), spread over the workgroup: every wave holds the same x, computes the row
-        // statistics for itself, and then owns ONE feature tile (t = w8) of eps_hat and of the latent (LDS).
-        {
-            const Lane8 L = lane_info(a, lane);
-            float sm = 0.f;
-#pragma unroll
-            for (int t = 0; t < kTiles; ++t) sm += (x[t][0] + x[t][1]) + (x[t][2] + x[t][3]);
+        // amuse_hip.h amuse_schedule) on the B waves' own tiles; the latent lives in LDS
+        if constexpr (!ROLEA) {
+            float sm = ((xo[0][0] + xo[0][1]) + (xo[0][2] + xo[0][3])) + ((xo[1][0] + xo[1][1]) + (xo[1][2] + xo[1][3]));
             sm = allreduce_g_sum(sm);
-            const float mean = sm * (1.0f / kD);
-            float vs = 0.f;
+            const float mw = sm * (1.0f / 32.0f);
+            float m2 = 0.f;
 #pragma unroll
-            for (int t = 0; t < kTiles; ++t)
+            for (int i = 0; i < 2; ++i)
 #pragma unroll
                 for (int m = 0; m < 4; ++m) {
-                    const float d = x[t][m] - mean;
-                    vs += d * d;
+                    const float d = xo[i][m] - mw;
+                    m2 += d * d;
                 }
-            vs = allreduce_g_sum(vs);
-            const float rstd = __builtin_amdgcn_rsqf(vs * (1.0f / kD) + 1e-5f);
-            if (ROLEA && w8 == 0 && ((tap && step == 0) || (a.eps_out && step == a.T - 1))) {
-                // debugging / teacher-forced outputs want the whole eps_hat tile from one wave
-                f32x4 e[kTiles];
+            m2 = allreduce_g_sum(m2);
+            if (g == 0) stats[h * 16 + r] = float2{mw, m2};
+        }
+        __syncthreads();
+        if constexpr (!ROLEA) {
+            const Lane8 L = lane_info(a, lane);
+            const float2 s0 = stats[r], s1 = stats[16 + r], s2 = stats[32 + r], s3 = stats[48 + r];
+            const float mean = ((s0.x + s1.x) + (s2.x + s3.x)) * 0.25f;
+            const float d0 = s0.x - mean, d1 = s1.x - mean, d2 = s2.x - mean, d3 = s3.x - mean;
+            const float M2 = ((s0.y + s1.y) + (s2.y + s3.y)) + 32.0f * ((d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3));
+            const float rstd = __builtin_amdgcn_rsqf(M2 * (1.0f / kD) + 1e-5f);
+            const float* cf = a.coef + (size_t)step * 8;
+            const float sb = cf[0], sa = cf[1], c0 = cf[2], cx = cf[3], ce = cf[4], sg = cf[5], clipv = cf[6];
+            const float inv_sa = 1.0f / sa;
 #pragma unroll
-                for (int t = 0; t < kTiles; ++t) {
-                    const f32x4 ga = ld4(pv_final + 16 * t + 4 * g), be = ld4(pv_final + kD + 16 * t + 4 * g);
-#pragma unroll
-                    for (int m = 0; m < 4; ++m) e[t][m] = (x[t][m] - mean) * rstd * ga[m] + be[m];
-                }
-                if (tap && step == 0) store_tap8(a.tap_out, 10, e, g, r);
-                if (a.eps_out && L.is_lat && step == a.T - 1) {
-#pragma unroll
-                    for (int t = 0; t < kTiles; ++t) st4(a.eps_out + (size_t)L.clip * kD + 16 * t + 4 * g, e[t]);
-                }
-            }
-            if (!a.no_update) {
-                // this wave's tile by value selects (no dynamic register index)
-                f32x4 xt = x[0];
-#pragma unroll
-                for (int t = 1; t < kTiles; ++t) {
-                    const bool m = (w8 == t);
-                    xt[0] = m ? x[t][0] : xt[0]; xt[1] = m ? x[t][1] : xt[1];
-                    xt[2] = m ? x[t][2] : xt[2]; xt[3] = m ? x[t][3] : xt[3];
-                }
-                const int f = 16 * w8 + 4 * g;
+            for (int i = 0; i < 2; ++i) {
+                const int t = 2 * h + i, f = 16 * t + 4 * g;
                 const f32x4 ga = ld4(pv_final + f), be = ld4(pv_final + kD + f);
-                const float* cf = a.coef + (size_t)step * 8;
-                const float sb = cf[0], sa = cf[1], c0 = cf[2], cx = cf[3], ce = cf[4], sg = cf[5], clipv = cf[6];
-                // ancestral noise of the latent rows: counter (global clip, step, feature group) - the values
-                // amuse_counter_normal exposes
-                f32x4 z = splat4(0.f);
-                if (sg != 0.f && L.is_lat)
-                    z = a.step_noise ? ld4(a.step_noise + ((size_t)step * a.B + L.clip) * kD + f)
-                                     : counter_normal4(a.seed, a.clip0 + (uint64_t)L.clip, (uint32_t)step, (uint32_t)(4 * w8 + g), 1u);
-                const float inv_sa = 1.0f / sa;
-                f32x4 l = latl[w8 * 64 + lane];
-                {
+                f32x4 e;
+#pragma unroll
+                for (int m = 0; m < 4; ++m) e[m] = (xo[i][m] - mean) * rstd * ga[m] + be[m];
+                if (tap && step == 0) store_tap_tile(a.tap_out, 10, t, e, g, r);
+                if (a.eps_out && L.is_lat && step == a.T - 1) st4(a.eps_out + (size_t)L.clip * kD + f, e);
+                if (!a.no_update) {
+                    // ancestral noise of the latent rows: counter (global clip, step, feature group) - the values
+                    // amuse_counter_normal exposes
+                    f32x4 z = splat4(0.f);
+                    if (sg != 0.f && L.is_lat)
+                        z = a.step_noise ? ld4(a.step_noise + ((size_t)step * a.B + L.clip) * kD + f)
+                                         : counter_normal4(a.seed, a.clip0 + (uint64_t)L.clip, (uint32_t)step, (uint32_t)(4 * t + g), 1u);
+                    f32x4 l = latl[t * 64 + lane];
+                    {
 // each product and sum rounded on its own, like the scheduler's tensor ops (see k_sampler.hip)
 #pragma clang fp contract(off)
 #pragma unroll
-                for (int m = 0; m < 4; ++m) {
-                    const float e = (xt[m] - mean) * rstd * ga[m] + be[m], xl = l[m];
-                    const float num = __fsub_rn(xl, __fmul_rn(sb, e));
-                    float x0 = num * inv_sa;
-                    if (clipv > 0.f) x0 = fminf(fmaxf(x0, -clipv), clipv);
-                    float nx = __fmul_rn(c0, x0);
-                    if (cx != 0.f) nx = __fadd_rn(nx, __fmul_rn(cx, xl));
-                    if (ce != 0.f) nx = __fadd_rn(nx, __fmul_rn(ce, e));
-                    if (sg != 0.f) nx = __fadd_rn(nx, __fmul_rn(sg, z[m]));
-                    l[m] = nx;
+                    for (int m = 0; m < 4; ++m) {
+                        const float xl = l[m];
+                        const float num = __fsub_rn(xl, __fmul_rn(sb, e[m]));
+                        float x0 = num * inv_sa;
+                        if (clipv > 0.f) x0 = fminf(fmaxf(x0, -clipv), clipv);
+                        float nx = __fmul_rn(c0, x0);
+                        if (cx != 0.f) nx = __fadd_rn(nx, __fmul_rn(cx, xl));
+                        if (ce != 0.f) nx = __fadd_rn(nx, __fmul_rn(ce, e[m]));
+                        if (sg != 0.f) nx = __fadd_rn(nx, __fmul_rn(sg, z[m]));
+                        l[m] = nx;
+                    }
+                    }
+                    latl[t * 64 + lane] = l;
+                    if (a.traj_out && L.is_lat) st4(a.traj_out + ((size_t)step * a.B + L.clip) * kD + f, l);
                 }
-                }
-                latl[w8 * 64 + lane] = l;
-                if (a.traj_out && L.is_lat) st4(a.traj_out + ((size_t)step * a.B + L.clip) * kD + f, l);
             }
         }
-        stamp8<PROF>(pf);  // scheduler update done (wave 0) / reached the step barrier
+        stamp8<PROF>(pf);  // scheduler update done (B waves) / reached the step barrier
         __syncthreads();  // the updated latent is visible to every wave's token assembly
     }
 }

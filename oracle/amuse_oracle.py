@@ -55,8 +55,12 @@ def to_torch(w: Dict[str, np.ndarray], dtype=torch.float32) -> Dict[str, torch.T
 class Ops:
     """Arithmetic policy: fp32/fp64 exact, or bf16-operand emulation of the MFMA GEMMs."""
 
-    def __init__(self, emulate_bf16: bool = False):
+    def __init__(self, emulate_bf16: bool = False, poly_gelu: bool = False):
         self.emu = emulate_bf16
+        self.poly_gelu = poly_gelu   # model of the 8-wave bf16 sampling kernel's FFN activation (gelu_poly below)
+
+    def act(self, x: torch.Tensor) -> torch.Tensor:
+        return gelu_poly(x) if self.poly_gelu else gelu(x)
 
     def r(self, x: torch.Tensor) -> torch.Tensor:
         return x.to(torch.bfloat16).to(x.dtype) if self.emu else x
@@ -79,6 +83,26 @@ def gelu(x):  # exact erf form, F.gelu default (cross_attention.py:408-409)
     return 0.5 * x * (1.0 + torch.erf(x / math.sqrt(2.0)))
 
 
+_GELU_POLY = (7.975201607e-01, -1.319021881e-01, 1.900408231e-02, -1.993848477e-03, 1.449597330e-04,
+              -6.815091183e-06, 1.840825661e-07, -2.152084733e-09)
+
+
+def gelu_poly(x):
+    """The bf16 sampling kernel's GELU (amuse_amd/csrc/amuse_dev.hpp gelu_poly4), restated so that the block-wise
+    bf16 emulation sees the operands the kernel rounds: erf(a / sqrt2) ~ a P(a^2), a = min(|x|, 3 sqrt2), degree-7
+    minimax P (|erf error| <= 8.7e-5), exactly 1 from the clamp point on.  NOT the reference's activation - that is gelu() above, which
+    every fp32 parity check uses."""
+    x = x.float()
+    a = torch.clamp(x.abs(), max=4.24264068711928514641)
+    s2 = a * a
+    p = torch.full_like(x, _GELU_POLY[-1])
+    for c in _GELU_POLY[-2::-1]:
+        p = p * s2 + c
+    e = torch.clamp(a * p, max=1.0)
+    hx = 0.5 * x
+    return hx.abs() * e + hx
+
+
 def mha_self(ops: Ops, x, W, p, key_mask: Optional[torch.Tensor] = None):
     """nn.MultiheadAttention(128, 4) with q = k = v = x, batch-first (B,S,D).
     key_mask: (B,S) bool, True = key is valid (the reference passes key_padding_mask = ~mask)."""
@@ -99,7 +123,7 @@ def mha_self(ops: Ops, x, W, p, key_mask: Optional[torch.Tensor] = None):
 def enc_block(ops, x, W, p, key_mask=None):
     """TransformerEncoderLayer.forward_post (cross_attention.py:259-272); dropout = identity in eval."""
     x = layer_norm(x + mha_self(ops, x, W, p + ".self_attn", key_mask), W[p + ".norm1.weight"], W[p + ".norm1.bias"])
-    h = gelu(ops.lin(x, W[p + ".linear1.weight"], W[p + ".linear1.bias"]))
+    h = ops.act(ops.lin(x, W[p + ".linear1.weight"], W[p + ".linear1.bias"]))
     x = layer_norm(x + ops.lin(h, W[p + ".linear2.weight"], W[p + ".linear2.bias"]),
                    W[p + ".norm2.weight"], W[p + ".norm2.bias"])
     return x
@@ -194,8 +218,9 @@ def denoiser_tokens(W, x, t, con, emo, sty) -> torch.Tensor:
 
 
 def denoiser_forward(W, x, t, con, emo, sty, emulate_bf16=False, taps: Optional[dict] = None):
-    """eps_hat = Denoiser(x_t, t, con, emo, sty).  x: (B,128), con/emo/sty: (B,256) or None -> (B,128)."""
-    ops = Ops(emulate_bf16)
+    """eps_hat = Denoiser(x_t, t, con, emo, sty).  x: (B,128), con/emo/sty: (B,256) or None -> (B,128).
+    emulate_bf16 models the HIP bf16 sampling kernel: bf16 GEMM operands and its polynomial FFN activation."""
+    ops = Ops(emulate_bf16, poly_gelu=emulate_bf16)
     xs = denoiser_tokens(W, x, t, con, emo, sty)
     if taps is not None:
         taps["tokens"] = xs

@@ -113,7 +113,7 @@ def test_denoise_step_bf16_blockwise(env):
     ref = orc.denoiser_forward(Wd, x, 981, con, emo, sty, emulate_bf16=True)
     assert _err(eps, ref) < 5e-2 and _err(eps, g["eps_t981"]) < 8e-2
     tp = tap.cpu()
-    ops = orc.Ops(True)
+    ops = orc.Ops(True, poly_gelu=True)   # the bf16 sampling kernel's arithmetic (oracle gelu_poly)
     names = [f"encoder.input_blocks.{i}" for i in range(4)] + ["encoder.middle_block"] + \
             [f"encoder.output_blocks.{i}" for i in range(4)]
     errs = []

@@ -195,3 +195,18 @@ def test_denoiser_per_sample_timesteps(oracle_env=None):
     # add_noise + forward: with noise = 0 and t such that sqrt(abar) ~ 1 the noisy latent is the clean one
     out = orc.diffusion_forward(W, t("x_t"), torch.zeros(3, 128), [0, 0, 0], t("con"), t("emo"), t("sty"))
     assert float((out["noisy_latents"] - float(orc.SchedulerBase().alphas_cumprod[0].sqrt()) * t("x_t")).abs().max()) < 1e-6
+
+
+def test_gelu_poly_model_is_close_to_the_reference_activation():
+    """The bf16 sampling kernel's polynomial GELU (oracle gelu_poly = csrc gelu_poly4) against the reference's exact-erf
+    GELU: absolute error bound everywhere, sub-ulp of the bf16 rounding that follows it where activations are large."""
+    import torch
+    from oracle import amuse_oracle as orc
+    x = torch.linspace(-10.0, 10.0, 400001)
+    ref = orc.gelu(x.double())
+    d = (orc.gelu_poly(x).double() - ref).abs()
+    assert float(d.max()) < 2e-4
+    m = (x >= -2.0) & (x <= 4.0)
+    ulp = 2.0 ** (torch.floor(torch.log2(ref.abs().clamp_min(1e-30))) - 7)
+    assert float((d / ulp)[m].max()) < 0.35
+    assert float(orc.gelu_poly(torch.tensor([0.0]))) == 0.0
