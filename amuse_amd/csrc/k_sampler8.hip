@@ -57,8 +57,9 @@ using Ring = WRing<kR8>;
 #define AMUSE_B_EARLY 24
 #endif
 #ifndef AMUSE_C2_N1
+#define AMUSE_C2_N0 12
 #define AMUSE_C2_N1 12
-#define AMUSE_C2_N2 12
+#define AMUSE_C2_N2 8
 #endif
 
 __device__ __forceinline__ f32x4* a8_slot(char* lds, int row, int col, int lane) {
@@ -176,19 +177,22 @@ __device__ __forceinline__ void combine_reduce(f32x4 (&part)[kTiles], f32x4 (&xo
 // The A waves' side: publish the partial, then the barriers and the gather - with the issue of N1 + N2 + N3
 // weight-stream units into ring slots IPH0.. in between.  These waves are off the critical path here, so their
 // blocking global_load issue costs nothing as long as it fits the reducers' phases.
-template <int N1, int N2, int N3, int IPH0>
+// N0 units go out BEFORE the first barrier: free where the A waves arrive early (the linear2 combine - their FFN half
+// is the shorter one), on the critical path where they arrive last (the out_proj combine: N0 = 0).
+template <int N0, int N1, int N2, int N3, int IPH0>
 __device__ __forceinline__ void combine_publish(const f32x4 (&part)[kTiles], bf16x8 (&xb)[4], char* lds, int h,
                                                 int lane, Ring& rg) {
 #pragma unroll
     for (int t = 0; t < kTiles; ++t) *a8_slot(lds, h + (h >= t ? 1 : 0), t, lane) = part[t];  // part_row(h, t), h < 4
+    ring_issue<N0, kR8, IPH0 % kR8>(rg);
     __syncthreads();
-    ring_issue<N1, kR8, IPH0 % kR8>(rg);
+    ring_issue<N1, kR8, (IPH0 + N0) % kR8>(rg);
     __syncthreads();
-    ring_issue<N2, kR8, (IPH0 + N1) % kR8>(rg);
+    ring_issue<N2, kR8, (IPH0 + N0 + N1) % kR8>(rg);
     __syncthreads();
 #pragma unroll
     for (int c = 0; c < 4; ++c) xb[c] = __builtin_bit_cast(bf16x8, *xb_slot(lds, c, lane));
-    ring_issue<N3, kR8, (IPH0 + N1 + N2) % kR8>(rg);
+    ring_issue<N3, kR8, (IPH0 + N0 + N1 + N2) % kR8>(rg);
 }
 
 // ---- skip-linear combine over EIGHT partials: wave W reduces tile W (sum + bias, no LayerNorm, no residual) and
@@ -328,14 +332,14 @@ __device__ __forceinline__ void encoder_block8(bf16x8 (&xb)[4], f32x4 (&xo)[2], 
         gemm_ring<P, kTiles, 2, false, kR8, 24, false>(part, o, rg);
         stamp8<PROF>(pf);  // 1: in_proj + attention + out_proj partial
         // ---- out_proj combine (B reduces): meanwhile fetch this wave's FFN half
-        combine_publish<AMUSE_C1_N1, AMUSE_C1_N2, 32 - AMUSE_C1_N1 - AMUSE_C1_N2, 0>(part, xb, lds, h, lane, rg);
+        combine_publish<0, AMUSE_C1_N1, AMUSE_C1_N2, 32 - AMUSE_C1_N1 - AMUSE_C1_N2, 0>(part, xb, lds, h, lane, rg);
         stamp8<PROF>(pf);  // 2: combine 1
 #pragma unroll
         for (int t = 0; t < kTiles; ++t) part[t] = splat4(0.f);
         ffn_half<0, false>(part, xb, rg, pv, h, g);
         stamp8<PROF>(pf);  // 3: FFN
         // ---- linear2 combine (B reduces): meanwhile fetch the next block's attention weights
-        combine_publish<AMUSE_C2_N1, AMUSE_C2_N2, 32 - AMUSE_C2_N1 - AMUSE_C2_N2, 0>(part, xb, lds, h, lane, rg);
+        combine_publish<AMUSE_C2_N0, AMUSE_C2_N1, AMUSE_C2_N2, 32 - AMUSE_C2_N0 - AMUSE_C2_N1 - AMUSE_C2_N2, 0>(part, xb, lds, h, lane, rg);
     } else {
         // ---- ring empty on entry: fetch this wave's FFN half while the A waves run attention
         ring_issue<AMUSE_B_EARLY, kR8, 0>(rg);
