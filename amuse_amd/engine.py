@@ -219,7 +219,8 @@ class HipEngine:
         return out
 
     def profile_sample(self, con, emo, sty, precision="bf16", prof_step=1):
-        """[4 waves][192] s_memtime stamps of one denoising step of workgroup 0 (amuse_profile_sample)."""
+        """768 s_memtime stamps of one denoising step of workgroup 0 (amuse_profile_sample): [4 waves][192] from the
+        4-wave kernels (fp32), [8 waves][96] flattened into the same buffer from the 8-wave bf16 kernel."""
         con = self._dev(con)
         B = con.shape[0]
         emo = self._dev(emo, (B, 256)) if emo is not None else None

@@ -162,14 +162,18 @@ int amuse_diffusion_backward(amuse_ctx* ctx, const float* con, const float* emo,
 int amuse_counter_normal(amuse_ctx* ctx, uint64_t seed, uint64_t clip_index0, int B, int step,
                          int rng_stream, float* out, void* stream);
 
-/* Diagnostics: runs amuse_sample's kernel with s_memtime stamps taken by the 4 waves of workgroup 0
- * during step `prof_step`; stamps_out dev [4][192] uint64 (unused entries 0).  Stamp order: step
- * start, then per block: block start, in_proj, attention, out_proj, combine 1, LN1, linear1, GELU,
- * linear2, combine 2, LN2; finally scheduler update.  Used by tools/ to build profiles/. */
+/* Diagnostics: runs amuse_sample's kernel with s_memtime stamps taken by the waves of workgroup 0
+ * during step `prof_step`; stamps_out dev 768 x uint64 (unused entries 0).
+ *   fp32 (4-wave kernel, also bf16 with AMUSE_SAMPLE_WAVES=4): [4 waves][192] - step start, then per
+ *     block: block start, in_proj, attention, out_proj, combine 1, LN1, four FFN quarters, combine 2,
+ *     LN2; finally scheduler update.
+ *   bf16 (8-wave kernel): [8 waves][96] - step start, then per block: block start (after the skip linear),
+ *     attention phase, out_proj combine, FFN, linear2 combine; finally scheduler update.
+ * Used by tools/gpu_phase_profile*.py to build profiles/. */
 int amuse_profile_sample(amuse_ctx* ctx, const float* con, const float* emo, const float* sty, int B,
                          int precision, int prof_step, unsigned long long* stamps_out, void* stream);
 
-/* Clips per 4-wave workgroup in the sampling kernel: 0 = auto, else 1..3 (x S tokens <= 16 rows). */
+/* Clips per workgroup tile in the sampling kernels: 0 = auto, else 1..3 (x S tokens <= 16 rows). */
 int amuse_set_clips_per_group(amuse_ctx* ctx, int g);
 
 /* ------------------------------------------------------------------------------------------------

@@ -1,4 +1,7 @@
-"""Phase timeline of one denoising step (s_memtime stamps from the sampling kernel)."""
+"""Phase timeline of one denoising step of the 4-wave sampling kernels (s_memtime stamps): the fp32 parity kernel, and
+the 4-wave bf16 kernel when run with AMUSE_SAMPLE_WAVES=4 (the default bf16 kernel has 8 waves:
+tools/gpu_phase_profile8.py)."""
+import os
 import sys, json
 from pathlib import Path
 import numpy as np, torch
@@ -17,7 +20,7 @@ names = ["blk_start", "in_proj", "attention", "out_proj", "combine1", "LN1", "li
 names = ["blk_start", "in_proj", "attention", "out_proj", "combine1", "LN1", "ffn.q0", "ffn.q1", "ffn.q2", "ffn.q3", "combine2", "LN2"]
 names_bf16 = names
 res = {}
-for prec in ("bf16", "fp32"):
+for prec in (("bf16", "fp32") if os.environ.get("AMUSE_SAMPLE_WAVES") == "4" else ("fp32",)):
     st = eng.profile_sample(c, e, s, prec, prof_step=3).astype(np.int64)
     per = {}
     tot = []
