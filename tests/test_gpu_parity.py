@@ -126,6 +126,16 @@ def test_denoise_step_bf16_blockwise(env):
         errs.append(_err(tp[b + 1, :5][None], orc.enc_block(ops, xin, Wd, n)))
     assert max(errs) < 2e-2, errs
     assert sorted(errs)[6] < 1e-4, errs   # at least 7 of 9 blocks free of rounding flips
+    # token dropping (S = 4 / 3 rows per clip, up to 5 clips per workgroup tile) through the 8-wave kernel, against the
+    # reference goldens with the whole-network bf16 tolerance, for every tiling
+    try:
+        for G in (0, 1, 2, 3):
+            eng.set_clips_per_group(G)
+            assert _err(eng.denoise_step(x, 501, con, None, sty, "bf16"), g["eps_t501_noemo"]) < 8e-2
+            assert _err(eng.denoise_step(x, 501, con, None, None, "bf16"), g["eps_t501_consolo"]) < 8e-2
+            assert _err(eng.denoise_step(x, 501, con, emo, sty, "bf16"), g["eps_t501"]) < 8e-2
+    finally:
+        eng.set_clips_per_group(0)
 
 
 def test_diffusion_forward_per_clip_timesteps(env):
