@@ -91,7 +91,8 @@ __device__ __forceinline__ constexpr int part_row(int w, int t) {
     const int k = w - (w > red ? 1 : 0);
     return k + (k >= t ? 1 : 0);
 }
-template <int W, int NP, bool FAST>
+// LN = false (U-Net skip linear): tiles = sum + bias - no residual, no LayerNorm, and one barrier less.
+template <int W, int NP, bool FAST, bool LN>
 __device__ __forceinline__ void combine_red(f32x4 (&part)[kTiles], f32x4 (&xo)[2], bf16x8 (&xb)[4], const float* bias,
                                             const float* gamma, const float* beta, char* lds, int lane) {
     float2* stats = reinterpret_cast<float2*>(lds + kStat8Off);
@@ -106,8 +107,10 @@ __device__ __forceinline__ void combine_red(f32x4 (&part)[kTiles], f32x4 (&xo)[2
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         bi[i] = ld4(bias + 16 * (T0 + i) + 4 * g);
-        ga[i] = ld4(gamma + 16 * (T0 + i) + 4 * g);
-        be[i] = ld4(beta + 16 * (T0 + i) + 4 * g);
+        if constexpr (LN) {
+            ga[i] = ld4(gamma + 16 * (T0 + i) + 4 * g);
+            be[i] = ld4(beta + 16 * (T0 + i) + 4 * g);
+        }
     }
     __syncthreads();
     f32x4 y[2];
@@ -127,9 +130,10 @@ __device__ __forceinline__ void combine_red(f32x4 (&part)[kTiles], f32x4 (&xo)[2
             } else {
                 sum = ((p[0][i] + p[1][i]) + p[2][i]) + p[3][i];
             }
-            y[i] = xo[i] + (sum + bi[i]);
+            y[i] = LN ? xo[i] + (sum + bi[i]) : sum + bi[i];
         }
     }
+    if constexpr (LN) {
     float s = ((y[0][0] + y[0][1]) + (y[0][2] + y[0][3])) + ((y[1][0] + y[1][1]) + (y[1][2] + y[1][3]));
     s = allreduce_g_sum(s);
     const float mw = s * (1.0f / 32.0f);
@@ -151,11 +155,12 @@ __device__ __forceinline__ void combine_red(f32x4 (&part)[kTiles], f32x4 (&xo)[2
     const float var = M2 * (1.0f / kD) + 1e-5f;
     const float rstd = FAST ? __builtin_amdgcn_rsqf(var) : 1.0f / sqrtf(var);
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int m = 0; m < 4; ++m) y[i][m] = (y[i][m] - mean) * rstd * ga[i][m] + be[i][m];
-        xo[i] = y[i];
     }
+    xo[0] = y[0];
+    xo[1] = y[1];
     // publish the two tiles as ONE packed bf16 operand (k-tile pair W of every following GEMM)
     xb[W] = pack_bf16(y[0], y[1]);
     *xb_slot(lds, W, lane) = __builtin_bit_cast(uint4, xb[W]);
@@ -163,23 +168,25 @@ __device__ __forceinline__ void combine_red(f32x4 (&part)[kTiles], f32x4 (&xo)[2
 #pragma unroll
     for (int c = 0; c < 4; ++c)
         if (c != W) xb[c] = __builtin_bit_cast(bf16x8, *xb_slot(lds, c, lane));
-    asm volatile("; combine_red case %0" ::"n"(W));  // see combine8_impl
+    // keeps SimplifyCFG from sinking the four cases' register-array stores into one block behind a pointer PHI (which
+    // pins the arrays in scratch): an immediate operand cannot be merged
+    asm volatile("; combine_red case %0" ::"n"(W));
 }
-template <int NP, bool FAST>
+template <int NP, bool FAST, bool LN = true>
 __device__ __forceinline__ void combine_reduce(f32x4 (&part)[kTiles], f32x4 (&xo)[2], bf16x8 (&xb)[4],
                                                const float* bias, const float* gamma, const float* beta, char* lds,
                                                int h, int lane) {
-    if (h == 0) combine_red<0, NP, FAST>(part, xo, xb, bias, gamma, beta, lds, lane);
-    else if (h == 1) combine_red<1, NP, FAST>(part, xo, xb, bias, gamma, beta, lds, lane);
-    else if (h == 2) combine_red<2, NP, FAST>(part, xo, xb, bias, gamma, beta, lds, lane);
-    else combine_red<3, NP, FAST>(part, xo, xb, bias, gamma, beta, lds, lane);
+    if (h == 0) combine_red<0, NP, FAST, LN>(part, xo, xb, bias, gamma, beta, lds, lane);
+    else if (h == 1) combine_red<1, NP, FAST, LN>(part, xo, xb, bias, gamma, beta, lds, lane);
+    else if (h == 2) combine_red<2, NP, FAST, LN>(part, xo, xb, bias, gamma, beta, lds, lane);
+    else combine_red<3, NP, FAST, LN>(part, xo, xb, bias, gamma, beta, lds, lane);
 }
 // The A waves' side: publish the partial, then the barriers and the gather - with the issue of N1 + N2 + N3
 // weight-stream units into ring slots IPH0.. in between.  These waves are off the critical path here, so their
 // blocking global_load issue costs nothing as long as it fits the reducers' phases.
 // N0 units go out BEFORE the first barrier: free where the A waves arrive early (the linear2 combine - their FFN half
 // is the shorter one), on the critical path where they arrive last (the out_proj combine: N0 = 0).
-template <int N0, int N1, int N2, int N3, int IPH0>
+template <int N0, int N1, int N2, int N3, int IPH0, bool LN = true>
 __device__ __forceinline__ void combine_publish(const f32x4 (&part)[kTiles], bf16x8 (&xb)[4], char* lds, int h,
                                                 int lane, Ring& rg) {
 #pragma unroll
@@ -187,44 +194,12 @@ __device__ __forceinline__ void combine_publish(const f32x4 (&part)[kTiles], bf1
     ring_issue<N0, kR8, IPH0 % kR8>(rg);
     __syncthreads();
     ring_issue<N1, kR8, (IPH0 + N0) % kR8>(rg);
-    __syncthreads();
+    if constexpr (LN) __syncthreads();   // (the reducers' row-statistics exchange)
     ring_issue<N2, kR8, (IPH0 + N0 + N1) % kR8>(rg);
     __syncthreads();
 #pragma unroll
     for (int c = 0; c < 4; ++c) xb[c] = __builtin_bit_cast(bf16x8, *xb_slot(lds, c, lane));
     ring_issue<N3, kR8, (IPH0 + N0 + N1 + N2) % kR8>(rg);
-}
-
-// ---- skip-linear combine over EIGHT partials: wave W reduces tile W (sum + bias, no LayerNorm, no residual) and
-// publishes it in fp32 on the diagonal; after the closing barrier every wave reads what it needs.
-template <int W>
-__device__ __forceinline__ void combine8_impl(const f32x4 (&part)[kTiles], const float* bias, char* lds, int lane) {
-    const int g = lane >> 4;
-#pragma unroll
-    for (int t = 0; t < kTiles; ++t)
-        if (t != W) *a8_slot(lds, W, t, lane) = part[t];
-    const f32x4 bi = ld4(bias + 16 * W + 4 * g);
-    __syncthreads();
-    f32x4 p[8];
-#pragma unroll
-    for (int w = 0; w < 8; ++w)
-        if (w != W) p[w] = *a8_slot(lds, w, W, lane);
-    p[W] = part[W];
-    const f32x4 sum = (((p[0] + p[1]) + (p[2] + p[3])) + ((p[4] + p[5]) + (p[6] + p[7])));
-    *a8_slot(lds, W, W, lane) = sum + bi;
-    __syncthreads();
-}
-__device__ __forceinline__ void combine8(const f32x4 (&part)[kTiles], const float* bias, char* lds, int w8, int lane) {
-    switch (w8) {
-        case 0: combine8_impl<0>(part, bias, lds, lane); break;
-        case 1: combine8_impl<1>(part, bias, lds, lane); break;
-        case 2: combine8_impl<2>(part, bias, lds, lane); break;
-        case 3: combine8_impl<3>(part, bias, lds, lane); break;
-        case 4: combine8_impl<4>(part, bias, lds, lane); break;
-        case 5: combine8_impl<5>(part, bias, lds, lane); break;
-        case 6: combine8_impl<6>(part, bias, lds, lane); break;
-        default: combine8_impl<7>(part, bias, lds, lane); break;
-    }
 }
 
 __device__ __forceinline__ void attention_head8(const f32x4 (&q)[2], const f32x4 (&k)[2], const f32x4 (&v)[2],
@@ -464,26 +439,19 @@ __device__ __forceinline__ void role_loop8(const SampleArgs& a, char* smem, int 
                         xs.x = m ? c.x : xs.x; xs.y = m ? c.y : xs.y; xs.z = m ? c.z : xs.z; xs.w = m ? c.w : xs.w;
                     }
                     const bf16x8 xop = __builtin_bit_cast(bf16x8, xs);
-                    // the skip linear's units sit in slots 24..31 in place of out_proj, which is fetched right after
+                    // the skip linear's units sit in slots 24..31 in place of out_proj, which is fetched while the
+                    // B waves reduce
 #pragma unroll
                     for (int o = 0; o < kTiles; ++o)
                         part[o] = mfma_bf16(__builtin_bit_cast(bf16x8, rg.s[24 + o]), xop, splat4(0.f));
-                    ring_issue<8, kR8, 24>(rg);
+                    combine_publish<0, 8, 0, 0, 24, false>(part, xb, smem, h, lane, rg);
                 } else {
                     // slots 0..7, issued during the previous linear2 combine; operand = the popped skip tiles
                     const bf16x8 xop = __builtin_bit_cast(bf16x8, skipbf[((8 - blk) * 4 + h) * 64 + lane]);
 #pragma unroll
                     for (int o = 0; o < kTiles; ++o)
                         part[o] = mfma_bf16(__builtin_bit_cast(bf16x8, rg.s[o]), xop, splat4(0.f));
-                }
-                combine8(part, pv_skip + (blk - 5) * kD, smem, w8, lane);
-                // the new residual stream is on the diagonal in fp32: pack the operands, B keeps its own tiles
-#pragma unroll
-                for (int c = 0; c < 4; ++c)
-                    xb[c] = pack_bf16(*a8_slot(smem, 2 * c, 2 * c, lane), *a8_slot(smem, 2 * c + 1, 2 * c + 1, lane));
-                if constexpr (!ROLEA) {
-                    xo[0] = *a8_slot(smem, 2 * h, 2 * h, lane);
-                    xo[1] = *a8_slot(smem, 2 * h + 1, 2 * h + 1, lane);
+                    combine_reduce<8, true, false>(part, xo, xb, pv_skip + (blk - 5) * kD, nullptr, nullptr, smem, h, lane);
                 }
             }
             stamp8<PROF>(pf);  // 0: block start (after the skip linear, if any)
