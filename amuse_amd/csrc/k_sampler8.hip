@@ -240,12 +240,11 @@ __device__ __forceinline__ void stamp8(Prof8& pf) {
     }
 }
 
-// bias + GELU (amuse_dev.hpp gelu_poly4: the result is an MFMA operand, i.e. rounded to bf16 next) on one FFN
-// quarter (two hidden tiles); b1 points at this lane's 4 biases of the first tile
-__device__ __forceinline__ void gelu_pair(f32x4 (&hq)[2], const float* b1) {
-    const f32x4 ba = ld4(b1), bb = ld4(b1 + 16);
-    hq[0] = gelu_poly4(hq[0] + ba);
-    hq[1] = gelu_poly4(hq[1] + bb);
+// GELU (amuse_dev.hpp gelu_poly4: the result is an MFMA operand, i.e. rounded to bf16 next) on one FFN quarter (two
+// hidden tiles); linear1's bias is already in the accumulators (ffn_half)
+__device__ __forceinline__ void gelu_pair(f32x4 (&hq)[2]) {
+    hq[0] = gelu_poly4(hq[0]);
+    hq[1] = gelu_poly4(hq[1]);
 }
 
 // this wave's two FFN quarters (Q0, Q0 + 1 of head h's slice): linear1 for 2 hidden tiles each -> bias + GELU ->
@@ -257,14 +256,15 @@ template <int Q0, bool LATE8>
 __device__ __forceinline__ void ffn_half(f32x4 (&part)[kTiles], const bf16x8 (&xb)[4], Ring& rg, const float* pv,
                                          int h, int g) {
     constexpr int P = PREC_BF16;
-    f32x4 ha[2] = {splat4(0.f), splat4(0.f)}, hb[2] = {splat4(0.f), splat4(0.f)};
+    // accumulators start at linear1's bias (this lane's 4 features of each hidden tile)
     const float* b1 = pv + PV_L1_B + 16 * (kTiles * h + 2 * Q0) + 4 * g;
+    f32x4 ha[2] = {ld4(b1), ld4(b1 + 16)}, hb[2] = {ld4(b1 + 32), ld4(b1 + 48)};
     gemm_xb<2, false, 0>(ha, xb, rg);
     gemm_xb<2, false, 8>(hb, xb, rg);
     if constexpr (LATE8) ring_issue<32 - AMUSE_B_EARLY, kR8, AMUSE_B_EARLY>(rg);
-    gelu_pair(ha, b1);
+    gelu_pair(ha);
     gemm_ring<P, kTiles, 2, false, kR8, 16, false>(part, ha, rg);
-    gelu_pair(hb, b1 + 32);
+    gelu_pair(hb);
     gemm_ring<P, kTiles, 2, false, kR8, 24, false>(part, hb, rg);
 }
 

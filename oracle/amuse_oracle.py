@@ -89,18 +89,17 @@ _GELU_POLY = (7.975201607e-01, -1.319021881e-01, 1.900408231e-02, -1.993848477e-
 
 def gelu_poly(x):
     """The bf16 sampling kernel's GELU (amuse_amd/csrc/amuse_dev.hpp gelu_poly4), restated so that the block-wise
-    bf16 emulation sees the operands the kernel rounds: erf(a / sqrt2) ~ a P(a^2), a = min(|x|, 3 sqrt2), degree-7
-    minimax P (|erf error| <= 8.7e-5), exactly 1 from the clamp point on.  NOT the reference's activation - that is gelu() above, which
-    every fp32 parity check uses."""
+    bf16 emulation sees the operands the kernel rounds: erf(a / sqrt2) ~ a P(a^2), a = clamp(x, +-3 sqrt2), degree-7
+    minimax P (|erf error| <= 8.7e-5, value at the clamp point pinned to 1).  NOT the reference's activation - that is
+    gelu() above, which every fp32 parity check uses."""
     x = x.float()
-    a = torch.clamp(x.abs(), max=4.24264068711928514641)
+    a = torch.clamp(x, min=-4.24264068711928514641, max=4.24264068711928514641)
     s2 = a * a
     p = torch.full_like(x, _GELU_POLY[-1])
     for c in _GELU_POLY[-2::-1]:
         p = p * s2 + c
-    e = torch.clamp(a * p, max=1.0)
     hx = 0.5 * x
-    return hx.abs() * e + hx
+    return hx * (a * p) + hx
 
 
 def mha_self(ops: Ops, x, W, p, key_mask: Optional[torch.Tensor] = None):
