@@ -4,7 +4,7 @@
 // cross_attention.py:41-64,259-272; diffusers scheduler step) with EIGHT wavefronts per workgroup instead of four.
 //
 // Why: a wave's global_load blocks at issue while the CU's 64 B/clk vector-memory path is busy, so in the 4-wave
-// kernel the weight fetch (3.9 MB per step and CU) and the MFMA / LDS / barrier chain of the SAME waves add up
+// kernel the weight fetch (3.8 MB per step and CU) and the MFMA / LDS / barrier chain of the SAME waves add up
 // instead of overlapping.  Here the two halves of a block belong to different waves, and each
 // group fetches its weights while the OTHER group is on the critical path:
 //
@@ -23,9 +23,10 @@
 //   consumes); only the reducer of a feature tile keeps it in fp32 (the B waves, two tiles each, in registers).
 //   Final LayerNorm + scheduler update in the B waves on their own tiles; latent in LDS.
 //
-// LDS (163,328 B): combine matrix A8 [8 rows][8 tiles][64] f32x4 - partials off the diagonal, reduced tiles ON the
-// diagonal (slot (t, t)), so the all-gather of one combine never aliases the partial writes of the next - | row
-// statistics | bf16 skip stack | small parameters | static token rows | latent | double-buffered time token.
+// LDS (163,328 B): combine matrix A8 [8 rows][8 tiles][64] f32x4 - fp32 partials off the diagonal, the published
+// bf16 operands ON it (slots (c, c), c < 4), so the gather of one combine never aliases the partial writes of the
+// next - | row statistics | bf16 skip stack | small parameters | static token rows | latent | double-buffered time
+// token.
 #include "amuse_dev.hpp"
 #include "amuse_kernels.hpp"
 
@@ -35,7 +36,7 @@ namespace {
 
 constexpr int kR8 = kRing8;
 constexpr int kA8Bytes = 8 * kTiles * 64 * 16;                 // 65,536
-constexpr int kStat8Off = kA8Bytes;                            // [8][16] float2
+constexpr int kStat8Off = kA8Bytes;                            // [4 reducers][16 rows] float2 (1 KiB reserved)
 constexpr int kSkip8Off = kStat8Off + 8 * 16 * 8;              // [4 levels][4 pairs][64] uint4
 constexpr int kPv8Off = kSkip8Off + 4 * 4 * 64 * 16;
 constexpr int kPv8Floats = kLayers * kEncPv + 4 * kD + 2 * kD;
@@ -46,8 +47,9 @@ static_assert(kTT8Off + 2 * kD * 4 == kSample8LdsBytes, "LDS layout");
 
 using Ring = WRing<kR8>;
 
-// weight-stream units an A wave issues after the first / second barrier of the out_proj (C1) and linear2 (C2)
-// combines; the rest of its 32 follow the gather
+// Issue split of an A wave's 32 units inside the out_proj (C1) and linear2 (C2) combines: N0 before the first barrier
+// (C2 only - there the A waves arrive early), N1 / N2 after the first / second barrier, the rest after the gather.
+// Defaults from sweeps on MI355X (tools/gpu_variant_sweep.sh); all splits of the same family land within 2 %.
 #ifndef AMUSE_C1_N1
 #define AMUSE_C1_N1 12
 #define AMUSE_C1_N2 12
