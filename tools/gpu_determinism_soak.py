@@ -1,0 +1,27 @@
+"""Race hunt: the 8-wave bf16 sampling kernel must reproduce itself bitwise, launch after launch, for every tiling
+(a data race between its alternating wave groups would show up as a flaky mismatch)."""
+import sys
+from pathlib import Path
+import torch
+REPO = Path(__file__).resolve().parents[1]
+sys.path.insert(0, str(REPO))
+from amuse_amd import weights as wts, scheduler as sch
+from amuse_amd.engine import HipEngine
+eng = HipEngine(wts.make_denoiser_weights(0), wts.make_prior_weights(0))
+gen = torch.Generator().manual_seed(11)
+bad = 0
+for T, tab in ((100, sch.ddpm_table(100)), (50, sch.ddim_table())):
+    eng.set_schedule(tab)
+    for B, G in ((1, 0), (7, 1), (7, 2), (7, 3), (256, 0), (512, 0), (768, 0), (1000, 3)):
+        c, e, s = (torch.randn(B, 256, generator=gen).cuda() for _ in range(3))
+        eng.set_clips_per_group(G)
+        ref = eng.sample(c, e, s, "bf16", seed=5).clone()
+        n = 0
+        for _ in range(24):
+            out = eng.sample(c, e, s, "bf16", seed=5)
+            n += int(not torch.equal(out, ref))
+        bad += n
+        print(f"T={T} B={B} G={G}: {n} mismatching launches of 24; finite={bool(torch.isfinite(ref).all())}", flush=True)
+eng.set_clips_per_group(0)
+print("TOTAL mismatches:", bad)
+sys.exit(1 if bad else 0)
