@@ -368,49 +368,60 @@ __global__ __launch_bounds__(256) void k_ast_attn(const bf16raw* __restrict__ QK
                 *reinterpret_cast<const uint4*>(vsrc + (size_t)(lr + 32 * i) * kAstKeysPad + k0 + lc);
         }
         __syncthreads();
+        // One online-softmax step per 64-key chunk (four 16-key tiles): the per-step fixed costs - two cross-lane
+        // reductions, the rescale of the accumulators, exp2 of the running-max shift - are paid once per 64 keys, the
+        // log2(e) scaling rides in the exp2 argument's fma, and only the chunk that holds the sequence end pays for
+        // key masking.  (This loop is VALU-bound: 16 exp2 + ~50 other VALU per lane against 16 MFMAs.)
+        static_assert(kKc == 64, "one softmax step per chunk");
+        f32x4 st[4];
 #pragma unroll
-        for (int pr = 0; pr < kKc / 32; ++pr) {   // pairs of 16-key tiles
-            f32x4 st[2];
+        for (int u = 0; u < 4; ++u) {
+            const bf16raw* kr = Ks + (16 * u + j) * kKS + 8 * g;
+            st[u] = mfma_bf16(*reinterpret_cast<const bf16x8*>(kr), qf[0], splat4(0.f));
+            st[u] = mfma_bf16(*reinterpret_cast<const bf16x8*>(kr + 32), qf[1], st[u]);
+        }
+        // lane (g, query j): S[j][key = k0 + 16 u + 4 g + m]
+        const bool tail = k0 + kKc > kAstTokens;   // uniform
+        if (tail) {
 #pragma unroll
-            for (int u = 0; u < 2; ++u) {
-                const bf16raw* kr = Ks + (32 * pr + 16 * u + j) * kKS + 8 * g;
-                st[u] = mfma_bf16(*reinterpret_cast<const bf16x8*>(kr), qf[0], splat4(0.f));
-                st[u] = mfma_bf16(*reinterpret_cast<const bf16x8*>(kr + 32), qf[1], st[u]);
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int m = 0; m < 4; ++m)
+                    if (k0 + 16 * u + 4 * g + m >= kAstTokens) st[u][m] = -INFINITY;
+        }
+        float mx = fmaxf(fmaxf(fmaxf(st[0][0], st[0][1]), fmaxf(st[0][2], st[0][3])),
+                         fmaxf(fmaxf(st[1][0], st[1][1]), fmaxf(st[1][2], st[1][3])));
+        mx = fmaxf(mx, fmaxf(fmaxf(fmaxf(st[2][0], st[2][1]), fmaxf(st[2][2], st[2][3])),
+                             fmaxf(fmaxf(st[3][0], st[3][1]), fmaxf(st[3][2], st[3][3]))));
+        mx = allreduce_g_max(mx);
+        const float m_new = fmaxf(m_run, mx);           // raw-score domain; every chunk holds a valid key
+        const float c = m_new * kLog2e;
+        const float alpha = __builtin_amdgcn_exp2f(m_run * kLog2e - c);   // m_run = -inf on the first chunk -> 0
+        f32x4 p[4];
+        float ps = 0.f;
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                p[u][m] = __builtin_amdgcn_exp2f(fmaf(st[u][m], kLog2e, -c));   // masked keys: exp2(-inf) = 0
+                ps += p[u][m];
             }
-            // lane (g, query j): S[j][key = k0 + 32 pr + 16 u + 4 g + m]
-            float mx = -INFINITY;
-            bool ok[2][4];
+        ps = allreduce_g_sum(ps);
+        l_run = l_run * alpha + ps;
+        m_run = m_new;
 #pragma unroll
-            for (int u = 0; u < 2; ++u)
+        for (int td = 0; td < 4; ++td) o[td] *= alpha;
 #pragma unroll
-                for (int m = 0; m < 4; ++m) {
-                    ok[u][m] = (k0 + 32 * pr + 16 * u + 4 * g + m) < kAstTokens;
-                    st[u][m] *= kLog2e;
-                    mx = ok[u][m] ? fmaxf(mx, st[u][m]) : mx;
-                }
-            mx = allreduce_g_max(mx);
-            const float m_new = fmaxf(m_run, mx);
-            const float alpha = (m_new == -INFINITY) ? 1.0f : __builtin_amdgcn_exp2f(m_run - m_new);
-            f32x4 p[2];
-            float ps = 0.f;
-#pragma unroll
-            for (int u = 0; u < 2; ++u)
-#pragma unroll
-                for (int m = 0; m < 4; ++m) {
-                    p[u][m] = ok[u][m] ? __builtin_amdgcn_exp2f(st[u][m] - m_new) : 0.f;
-                    ps += p[u][m];
-                }
-            ps = allreduce_g_sum(ps);
-            l_run = l_run * alpha + ps;
-            m_run = m_new;
-            const bf16x8 pb = pack_bf16(p[0], p[1]);   // k-slots (g, e): e < 4 -> tile 0 key 4 g + e, else tile 1 key 4 g + e - 4
+        for (int pr = 0; pr < 2; ++pr) {
+            // k-slots (g, e): e < 4 -> tile 2 pr key 4 g + e, else tile 2 pr + 1 key 4 g + e - 4
+            const bf16x8 pb = pack_bf16(p[2 * pr], p[2 * pr + 1]);
 #pragma unroll
             for (int td = 0; td < 4; ++td) {
                 // A operand lane (g, i = j): V^T[d = 16 td + j][same key permutation]
                 const bf16raw* vr = Vs + (16 * td + j) * kVS + 32 * pr + 4 * g;
                 const uint2 lo = *reinterpret_cast<const uint2*>(vr), hi = *reinterpret_cast<const uint2*>(vr + 16);
                 const bf16x8 vf = __builtin_bit_cast(bf16x8, uint4{lo.x, lo.y, hi.x, hi.y});
-                o[td] = mfma_bf16(vf, pb, o[td] * alpha);
+                o[td] = mfma_bf16(vf, pb, o[td]);
             }
         }
     }
