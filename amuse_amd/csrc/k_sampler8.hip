@@ -262,11 +262,27 @@ __device__ __forceinline__ void ffn_half(f32x4 (&part)[kTiles], const bf16x8 (&x
     const float* b1 = pv + PV_L1_B + 16 * (kTiles * h + 2 * Q0) + 4 * g;
     f32x4 ha[2] = {ld4(b1), ld4(b1 + 16)}, hb[2] = {ld4(b1 + 32), ld4(b1 + 48)};
     gemm_xb<2, false, 0>(ha, xb, rg);
-    gemm_xb<2, false, 8>(hb, xb, rg);
     if constexpr (LATE8) ring_issue<32 - AMUSE_B_EARLY, kR8, AMUSE_B_EARLY>(rg);
+    __builtin_amdgcn_sched_barrier(0);
+    // An in-order wave that issues its 8 MFMAs back to back waits out the matrix pipe (16 cycles each) before its
+    // first VALU instruction; interleaved 1 : 6 the GELU of one quarter runs in the shadow of the other quarter's
+    // MFMAs (the two are independent).
+    gemm_xb<2, false, 8>(hb, xb, rg);
     gelu_pair(ha);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // 1 MFMA
+        __builtin_amdgcn_sched_group_barrier(0x002, 7, 0);   // 7 VALU
+    }
+    __builtin_amdgcn_sched_barrier(0);
     gemm_ring<P, kTiles, 2, false, kR8, 16, false>(part, ha, rg);
     gelu_pair(hb);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, 7, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
     gemm_ring<P, kTiles, 2, false, kR8, 24, false>(part, hb, rg);
 }
 
