@@ -73,6 +73,16 @@ __device__ __forceinline__ void rot6d_to_axis_angle(const float* d6, int quat_mo
 // ENC = false: MotionPrior.decode rows (S = 300).  ENC = true: MotionPrior.encode rows (vae.py:154-214): S = 302 =
 // [2 distribution tokens | 300 embedded frames], TransformerEncoderLayer blocks (no cross-attention, two norms),
 // stage 0 = skel_embedding + token concat + PE, last stage = encoder.norm of the two distribution rows only.
+// four floats <-> four bf16 (round-to-nearest-even, v_cvt_pk_bf16_f32; widening is exact)
+__device__ __forceinline__ uint2 f32_to_bf16x4(f32x4 v) {
+    const uint4 u = __builtin_bit_cast(uint4, pack_bf16(v, splat4(0.f)));
+    return uint2{u.x, u.y};
+}
+__device__ __forceinline__ f32x4 bf16x4_to_f32(uint2 u) {
+    return f32x4{__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u), __uint_as_float(u.y << 16),
+                 __uint_as_float(u.y & 0xffff0000u)};
+}
+
 template <int PREC, bool ENC>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_vae_rows(VaeRowsArgs a) {
     constexpr int S = ENC ? kFrames + 2 : kFrames;
@@ -142,8 +152,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
         for (int t = 0; t < kTiles; ++t) x[t] = rvalid ? ld4(a.x + row * kD + 16 * t + 4 * g) : splat4(0.f);
 #pragma unroll
-        for (int td = 0; td < 2; ++td)
-            o[td] = rvalid ? ld4(a.attn_o + row * kD + 32 * wave + 16 * td + 4 * g) : splat4(0.f);
+        for (int td = 0; td < 2; ++td) {
+            if constexpr (PREC == PREC_BF16) {
+                // bf16 mode: q, k, v and the attention output travel between the kernels as bf16 - the values the
+                // MFMAs consume anyway (rounded at the same point as before, so results are unchanged), half the bytes
+                const uint2 u = rvalid ? *reinterpret_cast<const uint2*>(reinterpret_cast<const unsigned short*>(a.attn_o) +
+                                                                         row * kD + 32 * wave + 16 * td + 4 * g)
+                                       : uint2{0u, 0u};
+                o[td] = bf16x4_to_f32(u);
+            } else {
+                o[td] = rvalid ? ld4(a.attn_o + row * kD + 32 * wave + 16 * td + 4 * g) : splat4(0.f);
+            }
+        }
         f32x4 part[kTiles];
         // self-attention out_proj (split-K over heads) + residual + norm1
 #pragma unroll
@@ -214,9 +234,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             const float scaling = 0.17677669529663687f;
 #pragma unroll
             for (int td = 0; td < 2; ++td) {
-                st4(a.q + hrow + 16 * td + 4 * g, qkv[td] * scaling);
-                st4(a.k + hrow + 16 * td + 4 * g, qkv[2 + td]);
-                st4(a.v + hrow + 16 * td + 4 * g, qkv[4 + td]);
+                if constexpr (PREC == PREC_BF16) {
+                    const size_t off = hrow + 16 * td + 4 * g;
+                    *reinterpret_cast<uint2*>(reinterpret_cast<unsigned short*>(a.q) + off) = f32_to_bf16x4(qkv[td] * scaling);
+                    *reinterpret_cast<uint2*>(reinterpret_cast<unsigned short*>(a.k) + off) = f32_to_bf16x4(qkv[2 + td]);
+                    *reinterpret_cast<uint2*>(reinterpret_cast<unsigned short*>(a.v) + off) = f32_to_bf16x4(qkv[4 + td]);
+                } else {
+                    st4(a.q + hrow + 16 * td + 4 * g, qkv[td] * scaling);
+                    st4(a.k + hrow + 16 * td + 4 * g, qkv[2 + td]);
+                    st4(a.v + hrow + 16 * td + 4 * g, qkv[4 + td]);
+                }
             }
         }
     } else if constexpr (ENC) {
@@ -388,8 +415,8 @@ constexpr int kPairs = kKeyRows / 32;                        // 10
 constexpr int kAttnBf16LdsBytes = kKeyRows * 64 + kPairs * 2 * 16 * 64;  // 20 KiB + 20 KiB
 
 template <int NQ, int S>
-__device__ __forceinline__ void attn_qtiles_bf16(const uint4* Kb, const uint4* Vt, const float* qg, float* og, int qt0,
-                                                 int len, int g, int r) {
+__device__ __forceinline__ void attn_qtiles_bf16(const uint4* Kb, const uint4* Vt, const unsigned short* qg,
+                                                 unsigned short* og, int qt0, int len, int g, int r) {
     constexpr float kLog2e = 1.44269504088896340736f;
     bf16x8 qb[NQ];
     float m_run[NQ], l_run[NQ];
@@ -398,9 +425,9 @@ __device__ __forceinline__ void attn_qtiles_bf16(const uint4* Kb, const uint4* V
     for (int n = 0; n < NQ; ++n) {
         const int fq = (qt0 + 4 * n) * 16 + r;
         const bool qv = fq < S;
-        const f32x4 q0 = qv ? ld4(qg + fq * 32 + 4 * g) : splat4(0.f);
-        const f32x4 q1 = qv ? ld4(qg + fq * 32 + 16 + 4 * g) : splat4(0.f);
-        qb[n] = pack_bf16(q0, q1);
+        const uint2 q0 = qv ? *reinterpret_cast<const uint2*>(qg + fq * 32 + 4 * g) : uint2{0u, 0u};
+        const uint2 q1 = qv ? *reinterpret_cast<const uint2*>(qg + fq * 32 + 16 + 4 * g) : uint2{0u, 0u};
+        qb[n] = __builtin_bit_cast(bf16x8, uint4{q0.x, q0.y, q1.x, q1.y});
         m_run[n] = -INFINITY;
         l_run[n] = 0.f;
         o[n][0] = o[n][1] = splat4(0.f);
@@ -453,9 +480,9 @@ __device__ __forceinline__ void attn_qtiles_bf16(const uint4* Kb, const uint4* V
     for (int n = 0; n < NQ; ++n) {
         const int fq = (qt0 + 4 * n) * 16 + r;
         if (fq < S) {
-            float* dst = og + (size_t)fq * kD + 4 * g;
-            st4(dst, o[n][0] / l_run[n]);
-            st4(dst + 16, o[n][1] / l_run[n]);
+            unsigned short* dst = og + (size_t)fq * kD + 4 * g;
+            *reinterpret_cast<uint2*>(dst) = f32_to_bf16x4(o[n][0] / l_run[n]);
+            *reinterpret_cast<uint2*>(dst + 16) = f32_to_bf16x4(o[n][1] / l_run[n]);
         }
     }
 }
@@ -471,30 +498,31 @@ __global__ __launch_bounds__(256) void k_vae_attn_bf16(VaeAttnArgs a) {
     const int g = lane >> 4, r = lane & 15;
     const int bh = blockIdx.x, b = bh / kHeads, h = bh - b * kHeads;
     const int len = a.lengths ? a.lengths[b] + (ENC ? 2 : 0) : S;
-    const float* qg = a.q + (size_t)bh * S * 32;
-    const float* kg = a.k + (size_t)bh * S * 32;
-    const float* vg = a.v + (size_t)bh * S * 32;
+    // q, k, v are bf16 here ([B * heads][S][32], written by k_vae_rows<PREC_BF16>), as is the output
+    const unsigned short* qg = reinterpret_cast<const unsigned short*>(a.q) + (size_t)bh * S * 32;
+    const unsigned short* kg = reinterpret_cast<const unsigned short*>(a.k) + (size_t)bh * S * 32;
+    const unsigned short* vg = reinterpret_cast<const unsigned short*>(a.v) + (size_t)bh * S * 32;
     for (int i = threadIdx.x; i < kKeyRows * 4; i += 256) {  // K fragments: item = (key row, slot group)
         const int row = i >> 2, gg = i & 3;
         const bool ok = row < S;
-        const f32x4 lo = ok ? ld4(kg + row * 32 + 4 * gg) : splat4(0.f);
-        const f32x4 hi = ok ? ld4(kg + row * 32 + 16 + 4 * gg) : splat4(0.f);
-        Kb[i] = __builtin_bit_cast(uint4, pack_bf16(lo, hi));
+        const uint2 lo = ok ? *reinterpret_cast<const uint2*>(kg + row * 32 + 4 * gg) : uint2{0u, 0u};
+        const uint2 hi = ok ? *reinterpret_cast<const uint2*>(kg + row * 32 + 16 + 4 * gg) : uint2{0u, 0u};
+        Kb[i] = uint4{lo.x, lo.y, hi.x, hi.y};
     }
     for (int i = threadIdx.x; i < kPairs * 2 * 16 * 4; i += 256) {  // V^T fragments: item = ((pair, td), g, d)
         const int d = i & 15, gg = (i >> 4) & 3, pt = i >> 6;  // pt = jp * 2 + td
         const int jp = pt >> 1, td = pt & 1;
-        f32x4 lo, hi;
+        unsigned lo[4], hi[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             const int k0 = 32 * jp + 4 * gg + e, k1 = k0 + 16;
-            lo[e] = k0 < S ? vg[k0 * 32 + 16 * td + d] : 0.f;
-            hi[e] = k1 < S ? vg[k1 * 32 + 16 * td + d] : 0.f;
+            lo[e] = k0 < S ? vg[k0 * 32 + 16 * td + d] : 0u;
+            hi[e] = k1 < S ? vg[k1 * 32 + 16 * td + d] : 0u;
         }
-        Vt[(pt * 16 + d) * 4 + gg] = __builtin_bit_cast(uint4, pack_bf16(lo, hi));
+        Vt[(pt * 16 + d) * 4 + gg] = uint4{lo[0] | (lo[1] << 16), lo[2] | (lo[3] << 16), hi[0] | (hi[1] << 16), hi[2] | (hi[3] << 16)};
     }
     __syncthreads();
-    float* og = a.o + (size_t)b * S * kD + 32 * h;
+    unsigned short* og = reinterpret_cast<unsigned short*>(a.o) + (size_t)b * S * kD + 32 * h;
     // 19 query tiles: wave w owns tiles w, w+4, w+8, w+12 (two pairs) and w+16 (waves 0..2)
     if (a.q_tiles == 1) {  // last encoder block: only the distribution rows (tile 0) are consumed downstream
         if (wave == 0) attn_qtiles_bf16<1, S>(Kb, Vt, qg, og, 0, len, g, r);
