@@ -182,10 +182,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
         for (int t = 0; t < kTiles; ++t) hid[t] = ld4(pv + PV_L1_B + 16 * (kTiles * wave + t) + 4 * g);
         gemm_ring<PREC, kTiles, kTiles, false, kVR, P_F1>(hid, x, rg);
+        // bf16 mode: the activations are MFMA operands (rounded to bf16 next), so the polynomial GELU of the sampling
+        // kernel serves (amuse_dev.hpp gelu_poly4: |error| <= 1.9e-4, a third of gelu_erf_fast's issue slots)
 #pragma unroll
-        for (int t = 0; t < kTiles; ++t)
+        for (int t = 0; t < kTiles; ++t) {
+            if constexpr (PREC == PREC_BF16) {
+                hid[t] = gelu_poly4(hid[t]);
+            } else {
 #pragma unroll
-            for (int m = 0; m < 4; ++m) hid[t][m] = (PREC == PREC_BF16) ? gelu_erf_fast(hid[t][m]) : gelu_erf(hid[t][m]);
+                for (int m = 0; m < 4; ++m) hid[t][m] = gelu_erf(hid[t][m]);
+            }
+        }
 #pragma unroll
         for (int t = 0; t < kTiles; ++t) part[t] = splat4(0.f);
         gemm_ring<PREC, kTiles, kTiles, false, kVR, P_F2>(part, hid, rg);

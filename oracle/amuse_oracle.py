@@ -57,7 +57,7 @@ class Ops:
 
     def __init__(self, emulate_bf16: bool = False, poly_gelu: bool = False):
         self.emu = emulate_bf16
-        self.poly_gelu = poly_gelu   # model of the 8-wave bf16 sampling kernel's FFN activation (gelu_poly below)
+        self.poly_gelu = poly_gelu   # model of the HIP bf16 mode's FFN activation (gelu_poly below)
 
     def act(self, x: torch.Tensor) -> torch.Tensor:
         return gelu_poly(x) if self.poly_gelu else gelu(x)
@@ -140,7 +140,7 @@ def dec_block(ops, x, z, W, p, key_mask=None):
     x = layer_norm(x + mha_self(ops, x, W, p + ".self_attn", key_mask), W[p + ".norm1.weight"], W[p + ".norm1.bias"])
     ca = cross_attn_const(ops, z, W, p + ".multihead_attn")
     x = layer_norm(x + ca[:, None, :], W[p + ".norm2.weight"], W[p + ".norm2.bias"])
-    h = gelu(ops.lin(x, W[p + ".linear1.weight"], W[p + ".linear1.bias"]))
+    h = ops.act(ops.lin(x, W[p + ".linear1.weight"], W[p + ".linear1.bias"]))
     x = layer_norm(x + ops.lin(h, W[p + ".linear2.weight"], W[p + ".linear2.bias"]),
                    W[p + ".norm3.weight"], W[p + ".norm3.bias"])
     return x
@@ -373,7 +373,7 @@ def sample_latents(W, sched, con, emo, sty, x_init, step_noise=None, emulate_bf1
 # --------------------------------------------------------------------------------------------
 def vae_decode(Wp, z, lengths: Optional[Sequence[int]] = None, emulate_bf16=False, taps: Optional[dict] = None):
     """z: (B,128) -> feats (B,300,333).  Frames >= length are excluded as keys and zeroed on output."""
-    ops = Ops(emulate_bf16)
+    ops = Ops(emulate_bf16, poly_gelu=emulate_bf16)   # the HIP bf16 mode: bf16 GEMM operands + polynomial GELU
     B = z.shape[0]
     if lengths is None:
         lengths = [N_FRAMES] * B
@@ -390,7 +390,7 @@ def vae_encode(Wp, feats, lengths: Optional[Sequence[int]] = None, emulate_bf16=
     """MotionPrior.encode (vae.py:154-214, MLP_DIST false, learned PE): feats (B,300,333) -> (mu, std), each (B,128).
     xseq = [2 distribution tokens | skel_embedding(frames)] + PE; SkipTransformerEncoder with key padding mask;
     mu = token 0, logvar = token 1, std = exp(logvar) ** 0.5.  (latent = mu + std * eps is left to the caller.)"""
-    ops = Ops(emulate_bf16)
+    ops = Ops(emulate_bf16, poly_gelu=emulate_bf16)   # the HIP bf16 mode: bf16 GEMM operands + polynomial GELU
     B, n, _ = feats.shape
     if lengths is None:
         lengths = [n] * B
