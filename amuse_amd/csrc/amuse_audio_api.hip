@@ -44,6 +44,17 @@ struct Encoder {
     Block blk[kAstLayers];
 };
 constexpr int kChunk = 32;   // clips per pass over the network (about 22 MB of workspace per clip)
+// Up to this many clips per call the three encoders (independent networks over the same fbank) run concurrently, each on
+// its own stream and workspace: one encoder's launches leave most of the chip idle there (10 row tiles of 128 tokens per
+// clip against 512 persistent workgroup slots).  Above it every launch fills the GPU and they run back to back.
+constexpr int kConcurrentMax = 8;
+
+// activations of one encoder pass over `cap` clips
+struct Workspace {
+    int cap = 0;
+    float *X = nullptr, *pooled = nullptr;
+    unsigned short *H = nullptr, *QK = nullptr, *Vt = nullptr, *O = nullptr, *F = nullptr, *P = nullptr;
+};
 
 }  // namespace
 
@@ -54,10 +65,11 @@ struct amuse_audio_ctx {
     float *melw = nullptr, *window = nullptr;
     Encoder enc[3];
     std::vector<void*> owned;
-    // workspace for `cap` clips
-    int cap = 0;
-    float *X = nullptr, *fbank = nullptr, *pooled = nullptr;
-    unsigned short *H = nullptr, *QK = nullptr, *Vt = nullptr, *O = nullptr, *F = nullptr, *P = nullptr;
+    Workspace ws[3];             // [0]: every sequential pass; [1], [2]: the concurrent small-batch path
+    float* fbank = nullptr;      // fbanks of one chunk
+    int fbank_cap = 0;
+    hipStream_t side[2] = {nullptr, nullptr};
+    hipEvent_t ev_fork = nullptr, ev_join[2] = {nullptr, nullptr};
 };
 
 namespace {
@@ -124,65 +136,84 @@ int build_encoder(amuse_audio_ctx* c, Encoder& E, const float* p) {
 
 size_t pad128(size_t m) { return (m + 127) / 128 * 128; }
 
-int ensure_ws(amuse_audio_ctx* c, int nb) {
-    if (c->cap >= nb) return 0;
-    void* old[] = {c->X, c->fbank, c->pooled, c->H, c->QK, c->Vt, c->O, c->F, c->P};
+void free_ws(Workspace& w) {
+    void* old[] = {w.X, w.pooled, w.H, w.QK, w.Vt, w.O, w.F, w.P};
     for (void* p : old)
-        if (p) HIP_TRY(hipFree(p));
-    c->cap = 0;
+        if (p) (void)hipFree(p);
+    w = Workspace{};
+}
+int ensure_ws(Workspace& w, int nb) {
+    if (w.cap >= nb) return 0;
+    free_ws(w);
     const size_t Mp = pad128((size_t)nb * kAstTokens);
-    HIP_TRY(hipMalloc((void**)&c->X, Mp * kAstDim * 4));
-    HIP_TRY(hipMalloc((void**)&c->fbank, (size_t)nb * kAstFrames * kAstMel * 4));
-    HIP_TRY(hipMalloc((void**)&c->pooled, (size_t)nb * kAstDim * 4));
-    HIP_TRY(hipMalloc((void**)&c->H, Mp * kAstDim * 2));
-    HIP_TRY(hipMalloc((void**)&c->QK, Mp * 2 * kAstDim * 2));
-    HIP_TRY(hipMalloc((void**)&c->Vt, (size_t)nb * kAstDim * kAstKeysPad * 2));
-    HIP_TRY(hipMalloc((void**)&c->O, Mp * kAstDim * 2));
-    HIP_TRY(hipMalloc((void**)&c->F, Mp * kAstMlp * 2));
-    HIP_TRY(hipMalloc((void**)&c->P, pad128((size_t)nb * kAstPatches) * 256 * 2));
+    HIP_TRY(hipMalloc((void**)&w.X, Mp * kAstDim * 4));
+    HIP_TRY(hipMalloc((void**)&w.pooled, (size_t)nb * kAstDim * 4));
+    HIP_TRY(hipMalloc((void**)&w.H, Mp * kAstDim * 2));
+    HIP_TRY(hipMalloc((void**)&w.QK, Mp * 2 * kAstDim * 2));
+    HIP_TRY(hipMalloc((void**)&w.Vt, (size_t)nb * kAstDim * kAstKeysPad * 2));
+    HIP_TRY(hipMalloc((void**)&w.O, Mp * kAstDim * 2));
+    HIP_TRY(hipMalloc((void**)&w.F, Mp * kAstMlp * 2));
+    HIP_TRY(hipMalloc((void**)&w.P, pad128((size_t)nb * kAstPatches) * 256 * 2));
     // rows beyond M are read by the GEMM tiles (results discarded) and the V^T pad columns by the attention (masked):
     // they only have to be finite
-    HIP_TRY(hipMemset(c->H, 0, Mp * kAstDim * 2));
-    HIP_TRY(hipMemset(c->O, 0, Mp * kAstDim * 2));
-    HIP_TRY(hipMemset(c->F, 0, Mp * kAstMlp * 2));
-    HIP_TRY(hipMemset(c->P, 0, pad128((size_t)nb * kAstPatches) * 256 * 2));
-    HIP_TRY(hipMemset(c->Vt, 0, (size_t)nb * kAstDim * kAstKeysPad * 2));
-    c->cap = nb;
+    HIP_TRY(hipMemset(w.H, 0, Mp * kAstDim * 2));
+    HIP_TRY(hipMemset(w.O, 0, Mp * kAstDim * 2));
+    HIP_TRY(hipMemset(w.F, 0, Mp * kAstMlp * 2));
+    HIP_TRY(hipMemset(w.P, 0, pad128((size_t)nb * kAstPatches) * 256 * 2));
+    HIP_TRY(hipMemset(w.Vt, 0, (size_t)nb * kAstDim * kAstKeysPad * 2));
+    w.cap = nb;
+    return 0;
+}
+int ensure_fbank(amuse_audio_ctx* c, int nb) {
+    if (c->fbank_cap >= nb) return 0;
+    if (c->fbank) HIP_TRY(hipFree(c->fbank));
+    c->fbank = nullptr; c->fbank_cap = 0;
+    HIP_TRY(hipMalloc((void**)&c->fbank, (size_t)nb * kAstFrames * kAstMel * 4));
+    c->fbank_cap = nb;
+    return 0;
+}
+int ensure_side_streams(amuse_audio_ctx* c) {
+    if (c->ev_fork) return 0;
+    for (int i = 0; i < 2; ++i) {
+        HIP_TRY(hipStreamCreateWithFlags(&c->side[i], hipStreamNonBlocking));
+        HIP_TRY(hipEventCreateWithFlags(&c->ev_join[i], hipEventDisableTiming));
+    }
+    HIP_TRY(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
     return 0;
 }
 
 // one encoder over nb <= cap clips whose fbanks are at `fbank`
-int run_encoder(amuse_audio_ctx* c, const Encoder& E, const float* fbank, int nb, float* feat_out, float* hidden_out,
-                int tap_block, hipStream_t st) {
+int run_encoder(const amuse_audio_ctx* c, const Workspace& w, const Encoder& E, const float* fbank, int nb, float* feat_out,
+                float* hidden_out, int tap_block, hipStream_t st) {
     const int M = nb * kAstTokens;
-    HIP_TRY(launch_im2col(fbank, c->P, nb, st));
+    HIP_TRY(launch_im2col(fbank, w.P, nb, st));
     GemmArgs g{};
-    g.A = c->P; g.W = E.patch_w; g.bias = E.patch_b; g.M = nb * kAstPatches; g.N = kAstDim; g.K = 256;
-    g.out_f32 = c->X; g.pos = E.pos;
+    g.A = w.P; g.W = E.patch_w; g.bias = E.patch_b; g.M = nb * kAstPatches; g.N = kAstDim; g.K = 256;
+    g.out_f32 = w.X; g.pos = E.pos;
     HIP_TRY(launch_gemm(g, EPI_PATCH, st));
-    HIP_TRY(launch_ast_tokens(E.cls, E.dist, E.pos, c->X, nb, st));
+    HIP_TRY(launch_ast_tokens(E.cls, E.dist, E.pos, w.X, nb, st));
     for (int l = 0; l < kAstLayers; ++l) {
         const Block& b = E.blk[l];
-        HIP_TRY(launch_ln_bf16(c->X, b.n1w, b.n1b, 1e-6f, c->H, M, st));
+        HIP_TRY(launch_ln_bf16(w.X, b.n1w, b.n1b, 1e-6f, w.H, M, st));
         g = GemmArgs{};
-        g.A = c->H; g.W = b.qkv_w; g.bias = b.qkv_b; g.M = M; g.N = 3 * kAstDim; g.K = kAstDim; g.out_bf16 = c->QK; g.vt = c->Vt;
+        g.A = w.H; g.W = b.qkv_w; g.bias = b.qkv_b; g.M = M; g.N = 3 * kAstDim; g.K = kAstDim; g.out_bf16 = w.QK; g.vt = w.Vt;
         HIP_TRY(launch_gemm(g, EPI_QKV, st));
-        HIP_TRY(launch_ast_attn(c->QK, c->Vt, c->O, nb, st));
+        HIP_TRY(launch_ast_attn(w.QK, w.Vt, w.O, nb, st));
         g = GemmArgs{};
-        g.A = c->O; g.W = b.proj_w; g.bias = b.proj_b; g.M = M; g.N = kAstDim; g.K = kAstDim; g.out_f32 = c->X;
+        g.A = w.O; g.W = b.proj_w; g.bias = b.proj_b; g.M = M; g.N = kAstDim; g.K = kAstDim; g.out_f32 = w.X;
         HIP_TRY(launch_gemm(g, EPI_RESID_F32, st));
-        HIP_TRY(launch_ln_bf16(c->X, b.n2w, b.n2b, 1e-6f, c->H, M, st));
+        HIP_TRY(launch_ln_bf16(w.X, b.n2w, b.n2b, 1e-6f, w.H, M, st));
         g = GemmArgs{};
-        g.A = c->H; g.W = b.fc1_w; g.bias = b.fc1_b; g.M = M; g.N = kAstMlp; g.K = kAstDim; g.out_bf16 = c->F;
+        g.A = w.H; g.W = b.fc1_w; g.bias = b.fc1_b; g.M = M; g.N = kAstMlp; g.K = kAstDim; g.out_bf16 = w.F;
         HIP_TRY(launch_gemm(g, EPI_GELU_BF16, st));
         g = GemmArgs{};
-        g.A = c->F; g.W = b.fc2_w; g.bias = b.fc2_b; g.M = M; g.N = kAstDim; g.K = kAstMlp; g.out_f32 = c->X;
+        g.A = w.F; g.W = b.fc2_w; g.bias = b.fc2_b; g.M = M; g.N = kAstDim; g.K = kAstMlp; g.out_f32 = w.X;
         HIP_TRY(launch_gemm(g, EPI_RESID_F32, st));
         if (hidden_out && l == tap_block)
-            HIP_TRY(hipMemcpyAsync(hidden_out, c->X, (size_t)M * kAstDim * 4, hipMemcpyDeviceToDevice, st));
+            HIP_TRY(hipMemcpyAsync(hidden_out, w.X, (size_t)M * kAstDim * 4, hipMemcpyDeviceToDevice, st));
     }
-    HIP_TRY(launch_ast_pool(c->X, E.norm_w, E.norm_b, c->frame_based, c->pooled, nb, st));
-    HIP_TRY(launch_ast_head(c->pooled, E.fh_ln_w, E.fh_ln_b, E.fh_w, E.fh_b, feat_out, nb, st));
+    HIP_TRY(launch_ast_pool(w.X, E.norm_w, E.norm_b, c->frame_based, w.pooled, nb, st));
+    HIP_TRY(launch_ast_head(w.pooled, E.fh_ln_w, E.fh_ln_b, E.fh_w, E.fh_b, feat_out, nb, st));
     return 0;
 }
 
@@ -228,9 +259,13 @@ void amuse_audio_destroy(amuse_audio_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     for (void* p : c->owned) (void)hipFree(p);
-    void* ws[] = {c->X, c->fbank, c->pooled, c->H, c->QK, c->Vt, c->O, c->F, c->P};
-    for (void* p : ws)
-        if (p) (void)hipFree(p);
+    for (Workspace& w : c->ws) free_ws(w);
+    if (c->fbank) (void)hipFree(c->fbank);
+    for (int i = 0; i < 2; ++i) {
+        if (c->side[i]) (void)hipStreamDestroy(c->side[i]);
+        if (c->ev_join[i]) (void)hipEventDestroy(c->ev_join[i]);
+    }
+    if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     delete c;
 }
 
@@ -250,10 +285,10 @@ int amuse_audio_encode(amuse_audio_ctx* c, int which, const float* fbank, int B,
     if (hidden_out && (tap_block < 0 || tap_block >= kAstLayers)) return failf(AMUSE_EINVAL, "%stap_block %ld not in 0..11", "", tap_block);
     HIP_TRY(hipSetDevice(c->device));
     const int chunk = B < kChunk ? B : kChunk;
-    if (int e = ensure_ws(c, chunk)) return e;
+    if (int e = ensure_ws(c->ws[0], chunk)) return e;
     for (int b0 = 0; b0 < B; b0 += chunk) {
         const int nb = (B - b0) < chunk ? (B - b0) : chunk;
-        if (int e = run_encoder(c, c->enc[which], fbank + (size_t)b0 * kAstFrames * kAstMel, nb, feat_out + (size_t)b0 * kAstFeat,
+        if (int e = run_encoder(c, c->ws[0], c->enc[which], fbank + (size_t)b0 * kAstFrames * kAstMel, nb, feat_out + (size_t)b0 * kAstFeat,
                                 hidden_out ? hidden_out + (size_t)b0 * kAstTokens * kAstDim : nullptr, tap_block, (hipStream_t)stream))
             return e;
     }
@@ -267,14 +302,36 @@ int amuse_audio_features(amuse_audio_ctx* c, const float* waves, int n_samples, 
     HIP_TRY(hipSetDevice(c->device));
     hipStream_t st = (hipStream_t)stream;
     const int chunk = B < kChunk ? B : kChunk;
-    if (int e = ensure_ws(c, chunk)) return e;
     float* outs[3] = {con_out, emo_out, sty_out};
+    if (int e = ensure_fbank(c, chunk)) return e;
+    if (B <= kConcurrentMax) {
+        // fork-join over two side streams (stream-ordered with `st` through events, so the call stays asynchronous and
+        // capturable): fbank on st, then encoder e on stream e with workspace e
+        if (int e = ensure_side_streams(c)) return e;
+        for (int e = 0; e < 3; ++e)
+            if (outs[e])
+                if (int rc = ensure_ws(c->ws[e], B)) return rc;
+        HIP_TRY(launch_fbank(waves, n_samples, B, c->window, c->melw, c->norm_mean, c->norm_std, c->fbank, st));
+        HIP_TRY(hipEventRecord(c->ev_fork, st));
+        for (int e = 1; e < 3; ++e) {
+            if (!outs[e]) continue;
+            HIP_TRY(hipStreamWaitEvent(c->side[e - 1], c->ev_fork, 0));
+            if (int rc = run_encoder(c, c->ws[e], c->enc[e], c->fbank, B, outs[e], nullptr, 0, c->side[e - 1])) return rc;
+            HIP_TRY(hipEventRecord(c->ev_join[e - 1], c->side[e - 1]));
+        }
+        if (outs[0])
+            if (int rc = run_encoder(c, c->ws[0], c->enc[0], c->fbank, B, outs[0], nullptr, 0, st)) return rc;
+        for (int e = 1; e < 3; ++e)
+            if (outs[e]) HIP_TRY(hipStreamWaitEvent(st, c->ev_join[e - 1], 0));
+        return 0;
+    }
+    if (int e = ensure_ws(c->ws[0], chunk)) return e;
     for (int b0 = 0; b0 < B; b0 += chunk) {
         const int nb = (B - b0) < chunk ? (B - b0) : chunk;
         HIP_TRY(launch_fbank(waves + (size_t)b0 * n_samples, n_samples, nb, c->window, c->melw, c->norm_mean, c->norm_std, c->fbank, st));
         for (int e = 0; e < 3; ++e)
             if (outs[e])
-                if (int rc = run_encoder(c, c->enc[e], c->fbank, nb, outs[e] + (size_t)b0 * kAstFeat, nullptr, 0, st)) return rc;
+                if (int rc = run_encoder(c, c->ws[0], c->enc[e], c->fbank, nb, outs[e] + (size_t)b0 * kAstFeat, nullptr, 0, st)) return rc;
     }
     return 0;
 }

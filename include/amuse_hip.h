@@ -209,7 +209,9 @@ int amuse_audio_fbank(amuse_audio_ctx* ctx, const float* waves, int n_samples, i
  * fp32 residual stream after block `tap_block` (0..11) for tests. */
 int amuse_audio_encode(amuse_audio_ctx* ctx, int which, const float* fbank, int B, float* feat_out,
                        float* hidden_out, int tap_block, void* stream);
-/* process_single_seq for B waveforms: con_out / emo_out / sty_out dev [B][256] (each nullable) */
+/* process_single_seq for B waveforms: con_out / emo_out / sty_out dev [B][256] (each nullable).  Stream-ordered on
+ * `stream`; for B <= 8 the three encoders run concurrently on two context-owned side streams, forked from and joined
+ * back into `stream` with events (results identical to the sequential path). */
 int amuse_audio_features(amuse_audio_ctx* ctx, const float* waves, int n_samples, int B, float* con_out,
                          float* emo_out, float* sty_out, void* stream);
 

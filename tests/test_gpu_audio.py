@@ -81,6 +81,16 @@ def test_features_batch_and_contract(env):
     c1, e1, s1 = eng.process_single_seq(torch.stack([w[1], w[2]]))
     assert c1.shape == (1, 256)
     assert torch.equal(c1[0], con[1]) and torch.equal(e1[0], emo[1]) and torch.equal(s1[0], sty[1])
+    # <= 8 clips: the three encoders run concurrently on side streams with their own workspaces; results are those of
+    # the one-encoder-at-a-time path (amuse_audio_encode) and of the sequential large-batch path, bitwise
+    fb3 = eng.fbank(w)
+    for name, got in (("con", con), ("emo", emo), ("sty", sty)):
+        assert torch.equal(eng.encode(name, fb3), got), name
+    w9 = torch.cat([w, _waves(48000, 6, seed=10)])
+    c9, e9, s9 = eng.features(w9)
+    assert torch.equal(c9[:3], con) and torch.equal(e9[:3], emo) and torch.equal(s9[:3], sty)
+    c2, e2, s2 = eng.features(w)      # a second call reuses streams, events and workspaces
+    assert torch.equal(c2, con) and torch.equal(e2, emo) and torch.equal(s2, sty)
     # the two pooling variants of audio_main_new.py:191-201
     from amuse_amd.audio import AudioEngine
     from amuse_amd import audio_weights as aw
