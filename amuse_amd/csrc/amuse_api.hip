@@ -294,24 +294,27 @@ int build_ctx(amuse_ctx* c, const float* den, const float* pri) {
         for (int w8 = 0; w8 < 8; ++w8) {
             const int h = w8 & 3, sgrp = w8 >> 2;
             std::vector<uint4> s;
-            // per block, in issue order (k_sampler8.hip).  A: in_proj q,k | v | out_proj - ahead of an output block
-            // the skip linear takes out_proj's place, which follows as a group of its own - then FFN quarters 0,1
-            // as F1a F1b F2a F2b.  B: skip linear, then FFN quarters 2,3.
+            // per block, in issue order (k_sampler8.hip).  A: out_proj | in_proj q,k | v (ahead of an output block: skip
+            // linear, skip-input half | q,k | v | out_proj), then FFN quarters 0,1 as F1a F1b F2a F2b.  B: [skip linear,
+            // x half], then FFN quarters 2,3.
             for (int b = 0; b < 9; ++b) {
                 const std::string p = blk_name("encoder", b);
-                auto skip = [&] {
-                    pack_gemm(s, PREC_BF16, D.get("encoder.linear_blocks." + std::to_string(b - 5) + ".weight"), 128, 256,
-                              range(0, 8), {2 * w8, 2 * w8 + 1});
-                };
                 auto f1 = [&](int q) { const int h0 = 8 * h + 2 * q; pack_gemm(s, PREC_BF16, D.get(p + ".linear1.weight"), 512, 128, {h0, h0 + 1}, range(0, 8)); };
                 auto f2 = [&](int q) { const int h0 = 8 * h + 2 * q; pack_gemm(s, PREC_BF16, D.get(p + ".linear2.weight"), 128, 512, range(0, 8), {h0, h0 + 1}); };
                 const int qa = 2 * sgrp, qb = 2 * sgrp + 1;
+                const float* wskip = b >= 5 ? D.get("encoder.linear_blocks." + std::to_string(b - 5) + ".weight") : nullptr;
                 if (sgrp == 0) {
+                    // a block's group of 32: 8 leading units, then q, k | v.  The leading 8 are out_proj - or, ahead of an
+                    // output block, the skip-input half (k-tiles 8..15 of cat(x, skip)) of the skip linear for output
+                    // tiles 2h, 2h+1, with out_proj following as a group of its own
+                    const auto outproj = [&] { pack_gemm(s, PREC_BF16, D.get(p + ".self_attn.out_proj.weight"), 128, 128, range(0, 8), {2 * h, 2 * h + 1}); };
+                    if (b >= 5) pack_gemm(s, PREC_BF16, wskip, 128, 256, {2 * h, 2 * h + 1}, range(8, 16));
+                    else outproj();
                     pack_qkv(s, PREC_BF16, D.get(p + ".self_attn.in_proj_weight"), h, true);
-                    if (b >= 5) skip();
-                    pack_gemm(s, PREC_BF16, D.get(p + ".self_attn.out_proj.weight"), 128, 128, range(0, 8), {2 * h, 2 * h + 1});
+                    if (b >= 5) outproj();
                 } else if (b >= 5) {
-                    skip();
+                    // the x half (k-tiles 0..7) of the same two output tiles
+                    pack_gemm(s, PREC_BF16, wskip, 128, 256, {2 * h, 2 * h + 1}, range(0, 8));
                 }
                 f1(qa); f1(qb); f2(qa); f2(qb);
             }

@@ -204,6 +204,44 @@ __device__ __forceinline__ void combine_publish(const f32x4 (&part)[kTiles], bf1
     ring_issue<N3, kR8, (IPH0 + N0 + N1 + N2) % kR8>(rg);
 }
 
+// Slot of the combine matrix through which A wave h hands the skip-input half of the next output block's skip linear
+// (feature tile t = 2h + i) to B wave h: off the diagonal, written after the reducers have read their partials.
+__device__ __forceinline__ f32x4* u_slot(char* lds, int t, int lane) { return a8_slot(lds, t == 6 ? 5 : 6, t, lane); }
+
+// The A waves' side of the linear2 combine: as combine_publish, fetching the next block's group of 32 units - its
+// first 8 units into slots 24..31, then q, k, v into slots 0..23.  In front of an ordinary block the leading 8 are out_proj.
+// In front of an OUTPUT block (cross_attention.py:58-61: x = Linear(cat(x, skips.pop()))) they are this wave's units of
+// the skip linear, and in its waiting time the wave computes u = W[:, 128:] . skip for feature tiles 2h, 2h+1 - the half
+// of the skip linear that does not depend on the current block's result - and hands it to B wave h through u_slot
+// (after the second barrier: the reducers are done with the partials).  out_proj then follows during the skip linear.
+// One body for both cases, the extra work behind a branch that touches no ring slot: separate instantiations of the
+// fetch make hipcc copy the ring registers at the merge - behind an s_waitcnt vmcnt that stalls the wave until its
+// loads have landed, in front of the last barrier.
+template <int N0, int N1, int N2>
+__device__ __forceinline__ void combine_publish_c2(const f32x4 (&part)[kTiles], bf16x8 (&xb)[4], char* lds, int h,
+                                                   int lane, Ring& rg, bool skip_u, const uint4* skip_ops) {
+    static_assert(N0 >= 8 && N0 + N1 + N2 == 32, "the leading 8 units go out before the first barrier");
+#pragma unroll
+    for (int t = 0; t < kTiles; ++t) *a8_slot(lds, h + (h >= t ? 1 : 0), t, lane) = part[t];
+    ring_issue<N0, kR8, 24>(rg);
+    __syncthreads();
+    ring_issue<N1, kR8, (24 + N0) % kR8>(rg);
+    __syncthreads();
+    if (skip_u) {
+        bf16x8 sk[4];
+#pragma unroll
+        for (int p = 0; p < 4; ++p) sk[p] = __builtin_bit_cast(bf16x8, skip_ops[p * 64 + lane]);
+        f32x4 u[2] = {splat4(0.f), splat4(0.f)};
+        gemm_xb<2, false, 24>(u, sk, rg);
+        *u_slot(lds, 2 * h, lane) = u[0];
+        *u_slot(lds, 2 * h + 1, lane) = u[1];
+    }
+    ring_issue<N2, kR8, (24 + N0 + N1) % kR8>(rg);
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < 4; ++c) xb[c] = __builtin_bit_cast(bf16x8, *xb_slot(lds, c, lane));
+}
+
 __device__ __forceinline__ void attention_head8(const f32x4 (&q)[2], const f32x4 (&k)[2], const f32x4 (&v)[2],
                                                 const bool (&kvalid)[4], f32x4 (&o)[2]) {
     // S^T[j][i] = sum_d K[j][d] Q[i][d]  ->  lane (g, i) holds S[i][4 g + m]   (k_sampler.hip attention_head)
@@ -293,7 +331,7 @@ __device__ __forceinline__ void ffn_half(f32x4 (&part)[kTiles], const bf16x8 (&x
 template <bool ROLEA, bool PROF>
 __device__ __forceinline__ void encoder_block8(bf16x8 (&xb)[4], f32x4 (&xo)[2], Ring& rg, const float* pv,
                                                const bool (&kvalid)[4], char* lds, int h, int lane, bool next_has_skip,
-                                               Prof8& pf) {
+                                               const uint4* skip_next, Prof8& pf) {
     constexpr int P = PREC_BF16;
     const int g = lane >> 4, r = lane & 15;
     f32x4 part[kTiles];
@@ -332,7 +370,7 @@ __device__ __forceinline__ void encoder_block8(bf16x8 (&xb)[4], f32x4 (&xo)[2], 
         ffn_half<0, false>(part, xb, rg, pv, h, g);
         stamp8<PROF>(pf);  // 3: FFN
         // ---- linear2 combine (B reduces): meanwhile fetch the next block's attention weights
-        combine_publish<AMUSE_C2_N0, AMUSE_C2_N1, AMUSE_C2_N2, 32 - AMUSE_C2_N0 - AMUSE_C2_N1 - AMUSE_C2_N2, 0>(part, xb, lds, h, lane, rg);
+        combine_publish_c2<AMUSE_C2_N0, AMUSE_C2_N1, 32 - AMUSE_C2_N0 - AMUSE_C2_N1>(part, xb, lds, h, lane, rg, next_has_skip, skip_next);
     } else {
         // ---- ring empty on entry: fetch this wave's FFN half while the A waves run attention
         ring_issue<AMUSE_B_EARLY, kR8, 0>(rg);
@@ -343,7 +381,7 @@ __device__ __forceinline__ void encoder_block8(bf16x8 (&xb)[4], f32x4 (&xo)[2], 
         stamp8<PROF>(pf);
         ffn_half<2, (AMUSE_B_EARLY < 32)>(part, xb, rg, pv, h, g);
         stamp8<PROF>(pf);  // 3: FFN
-        if (next_has_skip) ring_issue<8, kR8, 0>(rg);  // this wave's share of the next block's skip linear
+        if (next_has_skip) ring_issue<8, kR8, 0>(rg);  // the x half of this wave's two output tiles of the next block's skip linear
         combine_reduce<8, true>(part, xo, xb, pv + PV_L2_B, pv + PV_LN2_W, pv + PV_LN2_B, lds, h, lane);
     }
     stamp8<PROF>(pf);  // 4: combine 2
@@ -405,7 +443,13 @@ __device__ __forceinline__ void role_loop8(const SampleArgs& a, char* smem, int 
     // A waves enter every block with their 32 units in the ring (the stream's tail repeats its head for the wrap
     // at a step boundary); B waves enter with an empty ring (their fill is never consumed)
     Ring rg;
-    ring_fill(rg, wbase);
+    if constexpr (ROLEA) {   // unit i of a block's group of 32 lives in slot (24 + i) % 32 (combine_publish_c2)
+#pragma unroll
+        for (int i = 0; i < kR8; ++i) rg.s[(24 + i) % kR8] = ldw(wbase + i * 64);
+        rg.next = wbase + kR8 * 64;
+    } else {
+        ring_fill(rg, wbase);
+    }
     Prof8 pf{a.prof_out ? a.prof_out + (size_t)w8 * 96 : nullptr, 0, false};
 #pragma unroll 1
     for (int step = 0; step < a.T; ++step) {
@@ -445,35 +489,31 @@ __device__ __forceinline__ void role_loop8(const SampleArgs& a, char* smem, int 
         // ---- SkipTransformerEncoder.forward (cross_attention.py:41-64)
 #pragma unroll 1
         for (int blk = 0; blk < kLayers; ++blk) {
-            if (blk >= 5) {  // x = Linear(cat(x, skips.pop())), split-K over 8 waves: k-tiles 2 w8, 2 w8 + 1
-                f32x4 part[kTiles];
+            if (blk >= 5) {
+                // x = Linear(cat(x, skips.pop())) (cross_attention.py:58-61), split over OUTPUT tiles: B wave h computes
+                // its own feature tiles 2h, 2h+1 = bias + u + W[:, :128] . x, where u = W[:, 128:] . skip was prepared by
+                // A wave h during the previous linear2 combine (combine_publish_skipu).  It keeps them as its fp32 tiles
+                // and publishes the packed operand: one barrier and no partial sums (the split-K version of this
+                // 256 -> 128 linear cost 1.8 k cycles, mostly the 8-way reduction).  The A waves fetch out_proj.
+                // Published in row 7 of the combine matrix: not the diagonal, which lagging waves may still be
+                // gathering from the linear2 combine, and not a row the next out_proj combine's partials use.
                 if constexpr (ROLEA) {
-                    // operand pair h by value selects
-                    uint4 xs = __builtin_bit_cast(uint4, xb[0]);
-#pragma unroll
-                    for (int p = 1; p < 4; ++p) {
-                        const uint4 c = __builtin_bit_cast(uint4, xb[p]);
-                        const bool m = (h == p);
-                        xs.x = m ? c.x : xs.x; xs.y = m ? c.y : xs.y; xs.z = m ? c.z : xs.z; xs.w = m ? c.w : xs.w;
-                    }
-                    const bf16x8 xop = __builtin_bit_cast(bf16x8, xs);
-                    // the skip linear's units sit in slots 24..31 in place of out_proj, which is fetched while the
-                    // B waves reduce
-#pragma unroll
-                    for (int o = 0; o < kTiles; ++o)
-                        part[o] = mfma_bf16(__builtin_bit_cast(bf16x8, rg.s[24 + o]), xop, splat4(0.f));
-                    combine_publish<0, 8, 0, 0, 24, false>(part, xb, smem, h, lane, rg);
+                    ring_issue<8, kR8, 24>(rg);
                 } else {
-                    // slots 0..7, issued during the previous linear2 combine; operand = the popped skip tiles
-                    const bf16x8 xop = __builtin_bit_cast(bf16x8, skipbf[((8 - blk) * 4 + h) * 64 + lane]);
-#pragma unroll
-                    for (int o = 0; o < kTiles; ++o)
-                        part[o] = mfma_bf16(__builtin_bit_cast(bf16x8, rg.s[o]), xop, splat4(0.f));
-                    combine_reduce<8, true, false>(part, xo, xb, pv_skip + (blk - 5) * kD, nullptr, nullptr, smem, h, lane);
+                    const float* bs = pv_skip + (blk - 5) * kD + 32 * h + 4 * g;
+                    f32x4 acc[2] = {ld4(bs) + *u_slot(smem, 2 * h, lane), ld4(bs + 16) + *u_slot(smem, 2 * h + 1, lane)};
+                    gemm_xb<2, false, 0>(acc, xb, rg);
+                    xo[0] = acc[0];
+                    xo[1] = acc[1];
+                    *reinterpret_cast<uint4*>(a8_slot(smem, 7, h, lane)) = __builtin_bit_cast(uint4, pack_bf16(acc[0], acc[1]));
                 }
+                __syncthreads();
+#pragma unroll
+                for (int c = 0; c < 4; ++c) xb[c] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(a8_slot(smem, 7, c, lane)));
             }
             stamp8<PROF>(pf);  // 0: block start (after the skip linear, if any)
-            encoder_block8<ROLEA, PROF>(xb, xo, rg, pvl + blk * kEncPv, kvalid, smem, h, lane, blk >= 4 && blk < kLayers - 1, pf);
+            encoder_block8<ROLEA, PROF>(xb, xo, rg, pvl + blk * kEncPv, kvalid, smem, h, lane, blk >= 4 && blk < kLayers - 1,
+                                        skipbf + (7 - blk) * 4 * 64, pf);
             if (!ROLEA && blk < 4 && w8 == 4) {
 #pragma unroll
                 for (int p = 0; p < 4; ++p) skipbf[(blk * 4 + p) * 64 + lane] = __builtin_bit_cast(uint4, xb[p]);
@@ -503,7 +543,7 @@ __device__ __forceinline__ void role_loop8(const SampleArgs& a, char* smem, int 
         __syncthreads();
         if constexpr (!ROLEA) {
             const Lane8 L = lane_info(a, lane);
-            const float2 s0 = stats[r], s1 = stats[16 + r], s2 = stats[32 + r], s3 = stats[48 + r];
+            const float2 s0 = stats[L.r], s1 = stats[16 + L.r], s2 = stats[32 + L.r], s3 = stats[48 + L.r];
             const float mean = ((s0.x + s1.x) + (s2.x + s3.x)) * 0.25f;
             const float d0 = s0.x - mean, d1 = s1.x - mean, d2 = s2.x - mean, d3 = s3.x - mean;
             const float M2 = ((s0.y + s1.y) + (s2.y + s3.y)) + 32.0f * ((d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3));
@@ -513,12 +553,12 @@ __device__ __forceinline__ void role_loop8(const SampleArgs& a, char* smem, int 
             const float inv_sa = 1.0f / sa;
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
-                const int t = 2 * h + i, f = 16 * t + 4 * g;
+                const int t = 2 * h + i, f = 16 * t + 4 * L.g;
                 const f32x4 ga = ld4(pv_final + f), be = ld4(pv_final + kD + f);
                 f32x4 e;
 #pragma unroll
                 for (int m = 0; m < 4; ++m) e[m] = (xo[i][m] - mean) * rstd * ga[m] + be[m];
-                if (tap && step == 0) store_tap_tile(a.tap_out, 10, t, e, g, r);
+                if (tap && step == 0) store_tap_tile(a.tap_out, 10, t, e, L.g, L.r);
                 if (a.eps_out && L.is_lat && step == a.T - 1) st4(a.eps_out + (size_t)L.clip * kD + f, e);
                 if (!a.no_update) {
                     // ancestral noise of the latent rows: counter (global clip, step, feature group) - the values
@@ -526,8 +566,8 @@ __device__ __forceinline__ void role_loop8(const SampleArgs& a, char* smem, int 
                     f32x4 z = splat4(0.f);
                     if (sg != 0.f && L.is_lat)
                         z = a.step_noise ? ld4(a.step_noise + ((size_t)step * a.B + L.clip) * kD + f)
-                                         : counter_normal4(a.seed, a.clip0 + (uint64_t)L.clip, (uint32_t)step, (uint32_t)(4 * t + g), 1u);
-                    f32x4 l = latl[t * 64 + lane];
+                                         : counter_normal4(a.seed, a.clip0 + (uint64_t)L.clip, (uint32_t)step, (uint32_t)(4 * t + L.g), 1u);
+                    f32x4 l = latl[t * 64 + L.lane];
                     {
 // each product and sum rounded on its own, like the scheduler's tensor ops (see k_sampler.hip)
 #pragma clang fp contract(off)
@@ -544,7 +584,7 @@ __device__ __forceinline__ void role_loop8(const SampleArgs& a, char* smem, int 
                         l[m] = nx;
                     }
                     }
-                    latl[t * 64 + lane] = l;
+                    latl[t * 64 + L.lane] = l;
                     if (a.traj_out && L.is_lat) st4(a.traj_out + ((size_t)step * a.B + L.clip) * kD + f, l);
                 }
             }
