@@ -15,10 +15,12 @@
 //     weights during the linear2 combine).
 //   Group B (s = 1): reduces + normalises BOTH combines (wave h: feature tiles 2h, 2h+1) and computes FFN quarters
 //     2,3.  It has nothing to do while the A waves run attention - that is where it fetches its FFN half.
-//   So no wave issues a weight load while it is on the critical path (bar the 8-unit skip-linear groups), and the
+//   So no wave issues a weight load while it is on the critical path (bar the B waves' 8-unit skip-linear groups), and the
 //   FFN's MFMA + GELU work is spread over two waves per SIMD.
-//   U-Net skip linears: split-K over all 8 waves (k-tiles 2 w8, 2 w8 + 1 of cat(x, skip)); the skip stack is kept
-//     as packed bf16 MFMA operands (what the 4-wave kernel's cvt_pk produces from its fp32 copy - same bits).
+//   U-Net skip linears x = Linear(cat(x, skip)): split over OUTPUT tiles - B wave h computes its own feature tiles
+//     2h, 2h+1 from the x half of the weights plus u = W[:, 128:] . skip, which A wave h prepared in its waiting time of
+//     the previous linear2 combine; one barrier, no partial sums.  The skip stack is kept as packed bf16 MFMA
+//     operands (what the 4-wave kernel's cvt_pk produces from its fp32 copy - same bits).
 //   The residual stream travels between waves as packed bf16 MFMA operands (4 x 1 KiB per tile - what every GEMM
 //   consumes); only the reducer of a feature tile keeps it in fp32 (the B waves, two tiles each, in registers).
 //   Final LayerNorm + scheduler update in the B waves on their own tiles; latent in LDS.
@@ -59,9 +61,8 @@ using Ring = WRing<kR8>;
 #define AMUSE_B_EARLY 24
 #endif
 #ifndef AMUSE_C2_N1
-#define AMUSE_C2_N0 12
+#define AMUSE_C2_N0 16
 #define AMUSE_C2_N1 12
-#define AMUSE_C2_N2 8
 #endif
 
 __device__ __forceinline__ f32x4* a8_slot(char* lds, int row, int col, int lane) {
