@@ -58,7 +58,7 @@ using Ring = WRing<kR8>;
 #endif
 // units a B wave issues during the A waves' attention phase; the rest of its 32 follow behind its first FFN MFMAs
 #ifndef AMUSE_B_EARLY
-#define AMUSE_B_EARLY 24
+#define AMUSE_B_EARLY 20
 #endif
 #ifndef AMUSE_C2_N1
 #define AMUSE_C2_N0 16
