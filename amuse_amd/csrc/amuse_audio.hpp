@@ -8,6 +8,7 @@ namespace amuse {
 constexpr int kAstDim = 768, kAstHeads = 12, kAstLayers = 12, kAstMlp = 3072, kAstFeat = 256;
 constexpr int kAstMel = 128, kAstFrames = 1024;
 constexpr int kAstF = 12, kAstT = 101, kAstPatches = kAstF * kAstT, kAstTokens = 2 + kAstPatches;   // 1214
+constexpr int kAstPoolSplit = 16;    // workgroups per clip in k_ast_pool (row slices, added in slice order by k_ast_head)
 constexpr int kAstKeysPad = 1216;   // V^T rows padded to whole 64-key chunks (the pad columns stay zero)
 
 enum { EPI_BF16 = 0, EPI_GELU_BF16, EPI_RESID_F32, EPI_F32, EPI_PATCH, EPI_QKV };
@@ -25,14 +26,14 @@ struct GemmArgs {
     unsigned short* vt;          // EPI_QKV: V^T [B][768][kAstKeysPad]
 };
 hipError_t launch_gemm(const GemmArgs& a, int epi, hipStream_t s);
-hipError_t launch_fbank(const float* wave, int n_samples, int B, const float* window, const float* melw, float mean, float std,
+hipError_t launch_fbank(const float* wave, int n_samples, int B, const float* window, const float* melw_t, const int* mel_range, float mean, float std,
                         float* out, hipStream_t s);
 hipError_t launch_im2col(const float* fbank, unsigned short* patches, int B, hipStream_t s);
 hipError_t launch_ast_tokens(const float* cls, const float* dist, const float* pos, float* X, int B, hipStream_t s);
 hipError_t launch_ln_bf16(const float* X, const float* gamma, const float* beta, float eps, unsigned short* out, int M, hipStream_t s);
 hipError_t launch_ast_attn(const unsigned short* QK, const unsigned short* Vt, unsigned short* O, int B, hipStream_t s);
 hipError_t launch_ast_pool(const float* X, const float* gamma, const float* beta, int frame_based, float* pooled, int B, hipStream_t s);
-hipError_t launch_ast_head(const float* pooled, const float* gamma, const float* beta, const unsigned short* W, const float* bias,
+hipError_t launch_ast_head(const float* pooled, int frame_based, const float* gamma, const float* beta, const unsigned short* W, const float* bias,
                            float* out, int B, hipStream_t s);
 
 }  // namespace amuse

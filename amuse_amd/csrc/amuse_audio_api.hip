@@ -62,7 +62,8 @@ struct amuse_audio_ctx {
     int device = 0;
     int frame_based = 1;
     float norm_mean = 0.f, norm_std = 1.f;
-    float *melw = nullptr, *window = nullptr;
+    float *melw = nullptr, *window = nullptr;   // melw: the mel filter bank TRANSPOSED, [257 bins][128 filters]
+    int* mel_range = nullptr;                   // [128][2]: first / end bin of each filter's support
     Encoder enc[3];
     std::vector<void*> owned;
     Workspace ws[3];             // [0]: every sequential pass; [1], [2]: the concurrent small-batch path
@@ -147,7 +148,7 @@ int ensure_ws(Workspace& w, int nb) {
     free_ws(w);
     const size_t Mp = pad128((size_t)nb * kAstTokens);
     HIP_TRY(hipMalloc((void**)&w.X, Mp * kAstDim * 4));
-    HIP_TRY(hipMalloc((void**)&w.pooled, (size_t)nb * kAstDim * 4));
+    HIP_TRY(hipMalloc((void**)&w.pooled, (size_t)nb * kAstPoolSplit * kAstDim * 4));
     HIP_TRY(hipMalloc((void**)&w.H, Mp * kAstDim * 2));
     HIP_TRY(hipMalloc((void**)&w.QK, Mp * 2 * kAstDim * 2));
     HIP_TRY(hipMalloc((void**)&w.Vt, (size_t)nb * kAstDim * kAstKeysPad * 2));
@@ -213,7 +214,7 @@ int run_encoder(const amuse_audio_ctx* c, const Workspace& w, const Encoder& E, 
             HIP_TRY(hipMemcpyAsync(hidden_out, w.X, (size_t)M * kAstDim * 4, hipMemcpyDeviceToDevice, st));
     }
     HIP_TRY(launch_ast_pool(w.X, E.norm_w, E.norm_b, c->frame_based, w.pooled, nb, st));
-    HIP_TRY(launch_ast_head(w.pooled, E.fh_ln_w, E.fh_ln_b, E.fh_w, E.fh_b, feat_out, nb, st));
+    HIP_TRY(launch_ast_head(w.pooled, c->frame_based, E.fh_ln_w, E.fh_ln_b, E.fh_w, E.fh_b, feat_out, nb, st));
     return 0;
 }
 
@@ -246,7 +247,26 @@ amuse_audio_ctx* amuse_audio_create(int device, const float* con_params, const f
     c->norm_mean = norm_mean;
     c->norm_std = norm_std;
     const float* ps[3] = {con_params, emo_params, sty_params};
-    int rc = up_f32(c, &c->melw, mel_banks, (size_t)kAstMel * 257) || up_f32(c, &c->window, window, 400);
+    // device image of the filter bank: transposed (a bin's 128 weights contiguous) + each filter's support
+    std::vector<float> mel_t((size_t)257 * kAstMel);
+    std::vector<int> mel_rng(2 * kAstMel);
+    for (int m = 0; m < kAstMel; ++m) {
+        int k0 = 257, k1 = 0;
+        for (int k = 0; k < 257; ++k) {
+            const float w = mel_banks[(size_t)m * 257 + k];
+            mel_t[(size_t)k * kAstMel + m] = w;
+            if (w != 0.f) { if (k < k0) k0 = k; k1 = k + 1; }
+        }
+        mel_rng[2 * m] = k0 < k1 ? k0 : 0;
+        mel_rng[2 * m + 1] = k0 < k1 ? k1 : 0;
+    }
+    int rc = up_f32(c, &c->melw, mel_t.data(), mel_t.size()) || up_f32(c, &c->window, window, 400);
+    if (!rc) {
+        float* rng = nullptr;   // (ints travel through the float uploader bit for bit)
+        static_assert(sizeof(int) == sizeof(float), "");
+        rc = up_f32(c, &rng, reinterpret_cast<const float*>(mel_rng.data()), mel_rng.size());
+        c->mel_range = reinterpret_cast<int*>(rng);
+    }
     for (int e = 0; e < 3 && !rc; ++e) rc = build_encoder(c, c->enc[e], ps[e]);
     if (rc) {
         amuse_audio_destroy(c);
@@ -273,7 +293,7 @@ int amuse_audio_fbank(amuse_audio_ctx* c, const float* waves, int n_samples, int
     if (!c || !waves || !fbank_out) return failf(AMUSE_EINVAL, "NULL argument%s");
     if (B < 1 || n_samples < 1) return failf(AMUSE_EINVAL, "%sB and n_samples must be >= 1 (got %ld, %ld)", "", B, n_samples);
     HIP_TRY(hipSetDevice(c->device));
-    HIP_TRY(launch_fbank(waves, n_samples, B, c->window, c->melw, c->norm_mean, c->norm_std, fbank_out, (hipStream_t)stream));
+    HIP_TRY(launch_fbank(waves, n_samples, B, c->window, c->melw, c->mel_range, c->norm_mean, c->norm_std, fbank_out, (hipStream_t)stream));
     return 0;
 }
 
@@ -311,7 +331,7 @@ int amuse_audio_features(amuse_audio_ctx* c, const float* waves, int n_samples, 
         for (int e = 0; e < 3; ++e)
             if (outs[e])
                 if (int rc = ensure_ws(c->ws[e], B)) return rc;
-        HIP_TRY(launch_fbank(waves, n_samples, B, c->window, c->melw, c->norm_mean, c->norm_std, c->fbank, st));
+        HIP_TRY(launch_fbank(waves, n_samples, B, c->window, c->melw, c->mel_range, c->norm_mean, c->norm_std, c->fbank, st));
         HIP_TRY(hipEventRecord(c->ev_fork, st));
         for (int e = 1; e < 3; ++e) {
             if (!outs[e]) continue;
@@ -328,7 +348,7 @@ int amuse_audio_features(amuse_audio_ctx* c, const float* waves, int n_samples, 
     if (int e = ensure_ws(c->ws[0], chunk)) return e;
     for (int b0 = 0; b0 < B; b0 += chunk) {
         const int nb = (B - b0) < chunk ? (B - b0) : chunk;
-        HIP_TRY(launch_fbank(waves + (size_t)b0 * n_samples, n_samples, nb, c->window, c->melw, c->norm_mean, c->norm_std, c->fbank, st));
+        HIP_TRY(launch_fbank(waves + (size_t)b0 * n_samples, n_samples, nb, c->window, c->melw, c->mel_range, c->norm_mean, c->norm_std, c->fbank, st));
         for (int e = 0; e < 3; ++e)
             if (outs[e])
                 if (int rc = run_encoder(c, c->ws[0], c->enc[e], c->fbank, nb, outs[e] + (size_t)b0 * kAstFeat, nullptr, 0, st)) return rc;

@@ -32,7 +32,9 @@ __device__ __forceinline__ uint2 pack4(f32x4 v) { return uint2{pack2(v[0], v[1])
 // ---------------------------------------------------------------------------------------------- fbank
 // grid (kAstFrames, B), 256 threads.  Frames beyond the waveform are the padding rows of infer_ldm.py:185-188.
 __global__ __launch_bounds__(256) void k_fbank(const float* __restrict__ wave, int n_samples, const float* __restrict__ window,
-                                               const float* __restrict__ melw /*[128][257]*/, float norm_mean, float inv_2std,
+                                               const float* __restrict__ melw_t /*[257][128]: transposed*/,
+                                               const int* __restrict__ mel_range /*[128][2]: first bin, end bin of the filter*/,
+                                               float norm_mean, float inv_2std,
                                                float* __restrict__ out /*[B][1024][128]*/) {
     __shared__ float re[512], im[512], red[8];
     const int f = blockIdx.x, b = blockIdx.y, t = threadIdx.x;
@@ -88,9 +90,11 @@ __global__ __launch_bounds__(256) void k_fbank(const float* __restrict__ wave, i
     if (t == 0) re[256] = p256;
     __syncthreads();
     if (t < kAstMel) {
-        const float* w = melw + (size_t)t * 257;
+        // bins in ascending order, as the dense product; the filter's zero bins outside [k0, k1) add nothing.  The
+        // transposed weights make a bin's 128 loads one contiguous 512 B row.
+        const int k0 = mel_range[2 * t], k1 = mel_range[2 * t + 1];
         float e = 0.f;
-        for (int k = 0; k < 257; ++k) e += re[k] * w[k];
+        for (int k = k0; k < k1; ++k) e += re[k] * melw_t[k * kAstMel + t];
         dst[t] = (logf(fmaxf(e, 1.1920929e-07f)) - norm_mean) * inv_2std;
     }
 }
@@ -436,16 +440,20 @@ __global__ __launch_bounds__(256) void k_ast_attn(const bf16raw* __restrict__ QK
 // ---------------------------------------------------------------------------------------------- pooling + head
 // v.norm on every token, then the mean over the 1212 patch tokens (frame_based_feats) or (cls + dist) / 2
 // grid (B), 256 threads = 4 waves striding over the rows; partial sums combined through LDS
+// grid (B, kAstPoolSplit): workgroup y normalises and sums its slice of the rows; k_ast_head adds the slices in a fixed
+// order (one workgroup per clip walking all 1212 rows serially left the pooling at 0.3 ms, whatever the batch).
 __global__ __launch_bounds__(256) void k_ast_pool(const float* __restrict__ X, const float* __restrict__ gamma,
                                                   const float* __restrict__ beta, int frame_based, float* __restrict__ pooled) {
     __shared__ float part[4][kAstDim];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, b = blockIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, b = blockIdx.x, y = blockIdx.y;
     const int r0 = frame_based ? 2 : 0, r1 = frame_based ? kAstTokens : 2;
+    const int chunk = (r1 - r0 + kAstPoolSplit - 1) / kAstPoolSplit;
+    const int c0 = r0 + y * chunk, c1 = min(r1, c0 + chunk);
     f32x4 acc[3] = {splat4(0.f), splat4(0.f), splat4(0.f)};
     f32x4 ga[3], be[3];
 #pragma unroll
     for (int i = 0; i < 3; ++i) { ga[i] = ld4(gamma + 256 * i + 4 * lane); be[i] = ld4(beta + 256 * i + 4 * lane); }
-    for (int r = r0 + wave; r < r1; r += 4) {
+    for (int r = c0 + wave; r < c1; r += 4) {
         const float* x = X + ((size_t)b * kAstTokens + r) * kAstDim;
         f32x4 v[3];
         float s = 0.f;
@@ -468,22 +476,27 @@ __global__ __launch_bounds__(256) void k_ast_pool(const float* __restrict__ X, c
 #pragma unroll
     for (int i = 0; i < 3; ++i) st4(&part[wave][256 * i + 4 * lane], acc[i]);
     __syncthreads();
-    const float inv = 1.0f / (float)(r1 - r0);
     for (int c = threadIdx.x; c < kAstDim; c += 256)
-        pooled[(size_t)b * kAstDim + c] = ((part[0][c] + part[1][c]) + (part[2][c] + part[3][c])) * inv;
+        pooled[((size_t)b * kAstPoolSplit + y) * kAstDim + c] = (part[0][c] + part[1][c]) + (part[2][c] + part[3][c]);
 }
 
 // feature_head: LayerNorm(768, eps 1e-5) -> Linear(768 -> 256) with bf16-rounded operands, fp32 accumulation
-__global__ __launch_bounds__(256) void k_ast_head(const float* __restrict__ pooled, const float* __restrict__ gamma,
+__global__ __launch_bounds__(256) void k_ast_head(const float* __restrict__ pooled /*[B][kAstPoolSplit][768] row sums*/,
+                                                  float inv_rows, const float* __restrict__ gamma,
                                                   const float* __restrict__ beta, const bf16raw* __restrict__ W /*[256][768]*/,
                                                   const float* __restrict__ bias, float* __restrict__ out /*[B][256]*/) {
     __shared__ float h[kAstDim];
     __shared__ float red[2][4];
     const int t = threadIdx.x, b = blockIdx.x;
-    const float* x = pooled + (size_t)b * kAstDim;
+    const float* x = pooled + (size_t)b * kAstPoolSplit * kAstDim;
     float v[3], s = 0.f;
 #pragma unroll
-    for (int i = 0; i < 3; ++i) { v[i] = x[t + 256 * i]; s += v[i]; }
+    for (int i = 0; i < 3; ++i) {   // mean over the pooled rows: the slices of k_ast_pool, added in slice order
+        float a = 0.f;
+        for (int y = 0; y < kAstPoolSplit; ++y) a += x[y * kAstDim + t + 256 * i];
+        v[i] = a * inv_rows;
+        s += v[i];
+    }
     for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
     if ((t & 63) == 0) red[0][t >> 6] = s;
     __syncthreads();
@@ -538,9 +551,9 @@ hipError_t launch_gemm(const GemmArgs& a, int epi, hipStream_t s) {
         default: return launch_gemm_t<EPI_QKV>(a, s);
     }
 }
-hipError_t launch_fbank(const float* wave, int n_samples, int B, const float* window, const float* melw, float mean, float std,
+hipError_t launch_fbank(const float* wave, int n_samples, int B, const float* window, const float* melw, const int* mel_range, float mean, float std,
                         float* out, hipStream_t s) {
-    hipLaunchKernelGGL(k_fbank, dim3(kAstFrames, B), dim3(256), 0, s, wave, n_samples, window, melw, mean, 1.0f / (2.0f * std), out);
+    hipLaunchKernelGGL(k_fbank, dim3(kAstFrames, B), dim3(256), 0, s, wave, n_samples, window, melw, mel_range, mean, 1.0f / (2.0f * std), out);
     return hipGetLastError();
 }
 hipError_t launch_im2col(const float* fbank, unsigned short* patches, int B, hipStream_t s) {
@@ -560,12 +573,13 @@ hipError_t launch_ast_attn(const unsigned short* QK, const unsigned short* Vt, u
     return hipGetLastError();
 }
 hipError_t launch_ast_pool(const float* X, const float* gamma, const float* beta, int frame_based, float* pooled, int B, hipStream_t s) {
-    hipLaunchKernelGGL(k_ast_pool, dim3(B), dim3(256), 0, s, X, gamma, beta, frame_based, pooled);
+    hipLaunchKernelGGL(k_ast_pool, dim3(B, kAstPoolSplit), dim3(256), 0, s, X, gamma, beta, frame_based, pooled);
     return hipGetLastError();
 }
-hipError_t launch_ast_head(const float* pooled, const float* gamma, const float* beta, const unsigned short* W, const float* bias,
-                           float* out, int B, hipStream_t s) {
-    hipLaunchKernelGGL(k_ast_head, dim3(B), dim3(256), 0, s, pooled, gamma, beta, W, bias, out);
+hipError_t launch_ast_head(const float* pooled, int frame_based, const float* gamma, const float* beta, const unsigned short* W,
+                           const float* bias, float* out, int B, hipStream_t s) {
+    const float inv_rows = 1.0f / (float)(frame_based ? kAstTokens - 2 : 2);
+    hipLaunchKernelGGL(k_ast_head, dim3(B), dim3(256), 0, s, pooled, inv_rows, gamma, beta, W, bias, out);
     return hipGetLastError();
 }
 
