@@ -44,11 +44,9 @@ struct Encoder {
     Block blk[kAstLayers];
 };
 constexpr int kChunk = 32;   // clips per pass over the network (about 22 MB of workspace per clip)
-// Up to this many clips per call the three encoders (independent networks over the same fbank) run concurrently, each on
-// its own stream and workspace: one encoder's launches leave most of the chip idle there (10 row tiles of 128 tokens per
-// clip against 512 persistent workgroup slots).  Above it every launch fills the GPU and they run back to back.
-constexpr int kConcurrentMax = 8;
-
+// amuse_audio_features runs the three encoders (independent networks over the same fbank) concurrently, each on its own
+// stream and workspace: at small batches one encoder's launches leave most of the chip idle (10 row tiles of 128 tokens per
+// clip against 512 persistent workgroup slots), at large ones the other encoders' work fills the tail of every launch.
 // activations of one encoder pass over `cap` clips
 struct Workspace {
     int cap = 0;
@@ -66,7 +64,7 @@ struct amuse_audio_ctx {
     int* mel_range = nullptr;                   // [128][2]: first / end bin of each filter's support
     Encoder enc[3];
     std::vector<void*> owned;
-    Workspace ws[3];             // [0]: every sequential pass; [1], [2]: the concurrent small-batch path
+    Workspace ws[3];             // one per encoder stream (amuse_audio_encode uses [0])
     float* fbank = nullptr;      // fbanks of one chunk
     int fbank_cap = 0;
     hipStream_t side[2] = {nullptr, nullptr};
@@ -324,34 +322,26 @@ int amuse_audio_features(amuse_audio_ctx* c, const float* waves, int n_samples, 
     const int chunk = B < kChunk ? B : kChunk;
     float* outs[3] = {con_out, emo_out, sty_out};
     if (int e = ensure_fbank(c, chunk)) return e;
-    if (B <= kConcurrentMax) {
-        // fork-join over two side streams (stream-ordered with `st` through events, so the call stays asynchronous and
-        // capturable): fbank on st, then encoder e on stream e with workspace e
-        if (int e = ensure_side_streams(c)) return e;
-        for (int e = 0; e < 3; ++e)
-            if (outs[e])
-                if (int rc = ensure_ws(c->ws[e], B)) return rc;
-        HIP_TRY(launch_fbank(waves, n_samples, B, c->window, c->melw, c->mel_range, c->norm_mean, c->norm_std, c->fbank, st));
+    if (int e = ensure_side_streams(c)) return e;
+    for (int e = 0; e < 3; ++e)
+        if (outs[e])
+            if (int rc = ensure_ws(c->ws[e], chunk)) return rc;
+    // per chunk: fbank on `st`, then a fork-join over two side streams (stream-ordered with `st` through events, so the
+    // call stays asynchronous and capturable): encoder e on stream e with workspace e
+    for (int b0 = 0; b0 < B; b0 += chunk) {
+        const int nb = (B - b0) < chunk ? (B - b0) : chunk;
+        HIP_TRY(launch_fbank(waves + (size_t)b0 * n_samples, n_samples, nb, c->window, c->melw, c->mel_range, c->norm_mean, c->norm_std, c->fbank, st));
         HIP_TRY(hipEventRecord(c->ev_fork, st));
         for (int e = 1; e < 3; ++e) {
             if (!outs[e]) continue;
             HIP_TRY(hipStreamWaitEvent(c->side[e - 1], c->ev_fork, 0));
-            if (int rc = run_encoder(c, c->ws[e], c->enc[e], c->fbank, B, outs[e], nullptr, 0, c->side[e - 1])) return rc;
+            if (int rc = run_encoder(c, c->ws[e], c->enc[e], c->fbank, nb, outs[e] + (size_t)b0 * kAstFeat, nullptr, 0, c->side[e - 1])) return rc;
             HIP_TRY(hipEventRecord(c->ev_join[e - 1], c->side[e - 1]));
         }
         if (outs[0])
-            if (int rc = run_encoder(c, c->ws[0], c->enc[0], c->fbank, B, outs[0], nullptr, 0, st)) return rc;
+            if (int rc = run_encoder(c, c->ws[0], c->enc[0], c->fbank, nb, outs[0] + (size_t)b0 * kAstFeat, nullptr, 0, st)) return rc;
         for (int e = 1; e < 3; ++e)
-            if (outs[e]) HIP_TRY(hipStreamWaitEvent(st, c->ev_join[e - 1], 0));
-        return 0;
-    }
-    if (int e = ensure_ws(c->ws[0], chunk)) return e;
-    for (int b0 = 0; b0 < B; b0 += chunk) {
-        const int nb = (B - b0) < chunk ? (B - b0) : chunk;
-        HIP_TRY(launch_fbank(waves + (size_t)b0 * n_samples, n_samples, nb, c->window, c->melw, c->mel_range, c->norm_mean, c->norm_std, c->fbank, st));
-        for (int e = 0; e < 3; ++e)
-            if (outs[e])
-                if (int rc = run_encoder(c, c->ws[0], c->enc[e], c->fbank, nb, outs[e] + (size_t)b0 * kAstFeat, nullptr, 0, st)) return rc;
+            if (outs[e]) HIP_TRY(hipStreamWaitEvent(st, c->ev_join[e - 1], 0));   // (also: the next chunk's fbank overwrites c->fbank)
     }
     return 0;
 }

@@ -210,8 +210,8 @@ int amuse_audio_fbank(amuse_audio_ctx* ctx, const float* waves, int n_samples, i
 int amuse_audio_encode(amuse_audio_ctx* ctx, int which, const float* fbank, int B, float* feat_out,
                        float* hidden_out, int tap_block, void* stream);
 /* process_single_seq for B waveforms: con_out / emo_out / sty_out dev [B][256] (each nullable).  Stream-ordered on
- * `stream`; for B <= 8 the three encoders run concurrently on two context-owned side streams, forked from and joined
- * back into `stream` with events (results identical to the sequential path). */
+ * `stream`; the three encoders run concurrently (per chunk of 32 clips) on two context-owned side streams, forked from
+ * and joined back into `stream` with events (results identical to amuse_audio_encode one encoder at a time). */
 int amuse_audio_features(amuse_audio_ctx* ctx, const float* waves, int n_samples, int B, float* con_out,
                          float* emo_out, float* sty_out, void* stream);
 
