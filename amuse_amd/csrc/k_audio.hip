@@ -211,27 +211,25 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             for (int y = 0; y < 4; ++y) acc[x][y] = splat4(0.f);
 #pragma unroll 1
         for (int kt = 0; kt < nk; kt += 2) {
-            // LDS buffer 0 = A k-tile kt, register set b = A k-tile kt + 1, set a free; w0 = W k-tile kt, w1 free
-            const bool wrap = kt + 2 >= nk;               // the k-tiles after this pair belong to the next output tile
-            const bool more = !wrap || have_next;
+            // LDS buffer 0 = A k-tile kt, register set b = A k-tile kt + 1, set a free; w0 = W k-tile kt, w1 free.
+            // NO branch in this body: the next operands' addresses are SELECTED (the k-tiles after this pair belong to
+            // the next output tile when `wrap`; a workgroup's very last pair re-loads its own tile and stores it unused).
+            // (With the loads behind `if (wrap) / if (more)` hipcc's s_waitcnt pass lost the queue positions at the joins
+            // and drained the whole queue, vmcnt(0), inside every iteration.  Removing that changed nothing measurable:
+            // the loop pays about one memory round trip per half iteration either way - see DESIGN.md 4.4.)
+            const bool wrap = kt + 2 >= nk;
+            const bf16raw* an = wrap ? agn : ag + (kt + 2) * BK;
+            const uint4* wq = wrap ? wpn : wp + (size_t)2 * (kt + 2) * 64;
             GEMM_WLOAD(w1, wp, kt + 1)
-            if (more) {
-                const bf16raw* an = wrap ? agn : ag + (kt + 2) * BK;
-                GEMM_ALOAD(ra0, ra1, ra2, ra3, an)
-            }
+            GEMM_ALOAD(ra0, ra1, ra2, ra3, an)
             GEMM_COMPUTE(0, w0)
             GEMM_ASTORE(rb0, rb1, rb2, rb3, 1)   // buffer 1 was last read before the previous barrier
             __syncthreads();
-            if (more) {
-                const bf16raw* an = wrap ? agn + BK : ag + (kt + 3) * BK;
-                GEMM_ALOAD(rb0, rb1, rb2, rb3, an)
-                if (wrap) { GEMM_WLOAD(w0, wpn, 0) } else { GEMM_WLOAD(w0, wp, kt + 2) }
-            }
+            GEMM_ALOAD(rb0, rb1, rb2, rb3, an + BK)
+            GEMM_WLOAD(w0, wq, 0)
             GEMM_COMPUTE(1, w1)
-            if (more) {
-                GEMM_ASTORE(ra0, ra1, ra2, ra3, 0)
-                __syncthreads();
-            }
+            GEMM_ASTORE(ra0, ra1, ra2, ra3, 0)
+            __syncthreads();
         }
     // ---- epilogue: lane (g, j): token row m0 + 64 wm + 16 y + j, features n0 + 64 wn + 32 p + 8 g .. + 7
 #pragma unroll
