@@ -15,6 +15,8 @@
 //                  streamed through LDS in 64-key chunks; V is written TRANSPOSED by the qkv epilogue.
 //   k_ast_pool / k_ast_head   final LayerNorm + mean over the patch tokens, feature_head (LayerNorm + Linear 768 -> 256)
 // Arithmetic: bf16 GEMM / attention operands, fp32 accumulation, fp32 residual stream, LayerNorm, softmax and GELU.
+#include <cstdlib>
+
 #include "amuse_dev.hpp"
 #include "amuse_audio.hpp"
 
@@ -133,7 +135,8 @@ constexpr int BM = 128, BN = 128, BK = 64;
 constexpr int LDSK = BK + 8;                       // padded row (bf16 elements): 144 B, conflict-free ds_read_b128
 constexpr int kGemmLds = 2 * BM * LDSK * 2;        // double-buffered A tile: 36,864 B
 
-template <int EPI>
+// DEEP: the weights run TWO k-tiles ahead of their use (three register sets) instead of one; needs K / 64 divisible by 6.
+template <int EPI, bool DEEP>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_gemm_bf16(GemmArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     bf16raw* As = reinterpret_cast<bf16raw*>(smem);                    // [2][BM][LDSK]
@@ -153,7 +156,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     // activations: global -> registers two k-tiles ahead (sets a / b) -> LDS; weights: fragment units one k-tile
     // ahead (sets 0 / 1), straight into the MFMA
     uint4 ra0, ra1, ra2, ra3, rb0, rb1, rb2, rb3;
-    uint4 w0[8], w1[8];
+    uint4 w0[8], w1[8], w2[DEEP ? 8 : 1];
 #define GEMM_ALOAD(A0, A1, A2, A3, ag)                                     \
     A0 = *reinterpret_cast<const uint4*>(ag);                              \
     A1 = *reinterpret_cast<const uint4*>(ag + rstep);                      \
@@ -169,6 +172,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     _Pragma("unroll") for (int x = 0; x < 4; ++x) {                                                \
         WS[2 * x] = wp[((size_t)x * (2 * nk) + 2 * (kt)) * 64];                                    \
         WS[2 * x + 1] = wp[((size_t)x * (2 * nk) + 2 * (kt) + 1) * 64];                            \
+    }
+    // the same from a pointer to the k-tile's first unit
+#define GEMM_WLOADQ(WS, wq)                                                                        \
+    _Pragma("unroll") for (int x = 0; x < 4; ++x) {                                                \
+        WS[2 * x] = (wq)[((size_t)x * (2 * nk)) * 64];                                             \
+        WS[2 * x + 1] = (wq)[((size_t)x * (2 * nk) + 1) * 64];                                     \
     }
 #define GEMM_COMPUTE(buf, WS)                                                                               \
     {                                                                                                       \
@@ -194,6 +203,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     GEMM_ALOAD(ra0, ra1, ra2, ra3, ag)
     GEMM_ALOAD(rb0, rb1, rb2, rb3, ag + BK)
     GEMM_WLOAD(w0, wp, 0)
+    if constexpr (DEEP) { GEMM_WLOAD(w1, wp, 1) }
     GEMM_ASTORE(ra0, ra1, ra2, ra3, 0)
     __syncthreads();
     while (true) {
@@ -209,6 +219,34 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         for (int x = 0; x < 4; ++x)
 #pragma unroll
             for (int y = 0; y < 4; ++y) acc[x][y] = splat4(0.f);
+        if constexpr (DEEP) {
+            // six k-tiles per trip: LDS buffers alternate (period 2), weight sets rotate (period 3).  On entry: LDS
+            // buffer 0 = A k-tile kt, register set b = A k-tile kt + 1; w0 / w1 = W k-tiles kt / kt + 1, w2 free.
+            // Half d computes k-tile kt + d and fetches A and W of k-tile kt + d + 2 (of the next output tile past nk).
+#define GEMM_HALF(d, buf, WC, WL, RL0, RL1, RL2, RL3, RS0, RS1, RS2, RS3)                                   \
+            {                                                                                               \
+                const int q = kt + (d) + 2;                                                                 \
+                const bool over = q >= nk;                                                                  \
+                const bf16raw* an = over ? agn + (size_t)(q - nk) * BK : ag + (size_t)q * BK;               \
+                const uint4* wq = over ? wpn + (size_t)2 * (q - nk) * 64 : wp + (size_t)2 * q * 64;         \
+                GEMM_WLOADQ(WL, wq)                                                                         \
+                GEMM_ALOAD(RL0, RL1, RL2, RL3, an)                                                          \
+                __builtin_amdgcn_sched_barrier(0);   /* the loads are ISSUED here, not sunk towards their use */ \
+                GEMM_COMPUTE(buf, WC)                                                                       \
+                GEMM_ASTORE(RS0, RS1, RS2, RS3, 1 - (buf))                                                  \
+                __syncthreads();                                                                            \
+            }
+#pragma unroll 1
+            for (int kt = 0; kt < nk; kt += 6) {
+                GEMM_HALF(0, 0, w0, w2, ra0, ra1, ra2, ra3, rb0, rb1, rb2, rb3)
+                GEMM_HALF(1, 1, w1, w0, rb0, rb1, rb2, rb3, ra0, ra1, ra2, ra3)
+                GEMM_HALF(2, 0, w2, w1, ra0, ra1, ra2, ra3, rb0, rb1, rb2, rb3)
+                GEMM_HALF(3, 1, w0, w2, rb0, rb1, rb2, rb3, ra0, ra1, ra2, ra3)
+                GEMM_HALF(4, 0, w1, w0, ra0, ra1, ra2, ra3, rb0, rb1, rb2, rb3)
+                GEMM_HALF(5, 1, w2, w1, rb0, rb1, rb2, rb3, ra0, ra1, ra2, ra3)
+            }
+#undef GEMM_HALF
+        } else {
 #pragma unroll 1
         for (int kt = 0; kt < nk; kt += 2) {
             // LDS buffer 0 = A k-tile kt, register set b = A k-tile kt + 1, set a free; w0 = W k-tile kt, w1 free.
@@ -230,6 +268,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             GEMM_COMPUTE(1, w1)
             GEMM_ASTORE(ra0, ra1, ra2, ra3, 0)
             __syncthreads();
+        }
         }
     // ---- epilogue: lane (g, j): token row m0 + 64 wm + 16 y + j, features n0 + 64 wn + 32 p + 8 g .. + 7
 #pragma unroll
@@ -289,6 +328,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #undef GEMM_ALOAD
 #undef GEMM_ASTORE
 #undef GEMM_WLOAD
+#undef GEMM_WLOADQ
 #undef GEMM_COMPUTE
 }
 
@@ -527,13 +567,18 @@ template <int EPI>
 hipError_t launch_gemm_t(const GemmArgs& a, hipStream_t s) {
     static bool attr = false;
     if (!attr) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_bf16<EPI>), hipFuncAttributeMaxDynamicSharedMemorySize, kGemmLds);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_bf16<EPI, false>), hipFuncAttributeMaxDynamicSharedMemorySize, kGemmLds);
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_bf16<EPI, true>), hipFuncAttributeMaxDynamicSharedMemorySize, kGemmLds);
         if (e != hipSuccess) return e;
         attr = true;
     }
     const int n_tiles = ((a.M + BM - 1) / BM) * (a.N / BN);
     const int resident = 2 * 256;   // two workgroups (8 waves, 2 per SIMD at this register count) per CU, 256 CUs
-    hipLaunchKernelGGL(k_gemm_bf16<EPI>, dim3(n_tiles < resident ? n_tiles : resident), dim3(256), kGemmLds, s, a);
+    const dim3 grid(n_tiles < resident ? n_tiles : resident);
+    static const bool no_deep = [] { const char* e = getenv("AMUSE_GEMM_DEEP"); return e && atoi(e) == 0; }();
+    if ((a.K / BK) % 6 == 0 && !no_deep) hipLaunchKernelGGL((k_gemm_bf16<EPI, true>), grid, dim3(256), kGemmLds, s, a);
+    else hipLaunchKernelGGL((k_gemm_bf16<EPI, false>), grid, dim3(256), kGemmLds, s, a);
     return hipGetLastError();
 }
 
