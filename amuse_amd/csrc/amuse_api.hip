@@ -451,11 +451,15 @@ int cond_tokens(amuse_ctx* c, const float* con, const float* emo, const float* s
 int pick_group(const amuse_ctx* c, int B, int S) {
     const int gmax = 16 / S;
     int g = c->clips_per_group;
-    // auto: one clip per workgroup tile until every CU has one, then fatten the tiles (a step costs the same for
-    // 1..gmax clips per tile).  With one clip per tile a clip's arithmetic does not depend on its neighbours, so any
-    // sharding of <= 256 clips per GPU reproduces the unsharded result BITWISE; with several clips per tile the
-    // softmax / PV accumulation order depends on the clip's row offset and results agree to rounding only.
-    if (g <= 0) g = (B + 255) / 256;
+    // auto: one clip per workgroup tile up to 128 clips, then fatter tiles - a step costs the same for 1..gmax clips per
+    // tile, and 128 busy CUs run it 6-7 % faster than 256: with every CU re-streaming the whole network each step the
+    // 256-workgroup launch sits at the L2's delivery limit (28 TB/s), the 128-workgroup one at half of it
+    // (profiles/r01_batch_sweep.txt: 256 clips 36.0 ms with one clip per tile, 33.6 ms with two or three).
+    // A clip's arithmetic depends on its row offset inside the tile only through rounding (the softmax / PV
+    // accumulation order), so results are reproduced BITWISE by any launch that uses the same clips per tile and puts the
+    // clip in the same slot of its tile - i.e. by shards that start at multiples of g (amuse_amd/shard.py picks g from the
+    // job's TOTAL clip count and aligns the shards) - and to rounding otherwise.
+    if (g <= 0) g = (B + 127) / 128;
     if (g > gmax) g = gmax;
     if (g < 1) g = 1;
     return g;

@@ -9,23 +9,40 @@ from typing import Callable, Dict, Optional, Tuple
 import torch
 
 
-def shard_range(total: int, rank: int, world: int) -> Tuple[int, int]:
-    """Contiguous, balanced: the first (total % world) ranks take one extra clip."""
+def job_clips_per_group(total: int, tokens: int = 5) -> int:
+    """Clips per workgroup tile for a job of `total` clips (the library's auto rule applied to the WHOLE job, not to a
+    shard): ceil(total / 128), at most 16 // tokens.  Every rank sets it (HipEngine.set_clips_per_group) and shards start
+    at multiples of it, so that a clip sits in the same slot of its tile however the job is sharded - which is what makes
+    sharded results BITWISE equal to the single-GPU ones (include/amuse_hip.h amuse_set_clips_per_group)."""
+    return max(1, min(16 // tokens, -(-total // 128)))
+
+
+def shard_range(total: int, rank: int, world: int, align: int = 1) -> Tuple[int, int]:
+    """Contiguous, balanced in units of `align` clips: the first ranks take one extra unit; the last unit may be short."""
     if not (0 <= rank < world):
         raise ValueError(f"rank {rank} out of range for world {world}")
-    base, extra = divmod(total, world)
+    units = -(-total // align)
+    base, extra = divmod(units, world)
     start = rank * base + min(rank, extra)
-    return start, start + base + (1 if rank < extra else 0)
+    stop = start + base + (1 if rank < extra else 0)
+    return min(total, start * align), min(total, stop * align)
 
 
 def sample_sharded(sample_fn: Callable[..., Dict[str, torch.Tensor]], z_con, z_emo, z_sty, rank: int, world: int,
-                   gather: bool = False, group=None) -> Optional[Dict[str, torch.Tensor]]:
+                   gather: bool = False, group=None, set_clips_per_group: Optional[Callable[[int], None]] = None
+                   ) -> Optional[Dict[str, torch.Tensor]]:
     """Run `sample_fn(bsz, con, emo, sty, clip_index0=...)` on this rank's shard of the global batch.
+    set_clips_per_group (e.g. HipEngine.set_clips_per_group): called with job_clips_per_group(total), and the shards are
+                  aligned to it - sharded results are then bitwise those of one GPU running the whole job.
     gather=False: returns the local shard's outputs (stay on this rank's device).
     gather=True : all ranks exchange shards (torch.distributed all_gather_object) and return the full batch
                   in global clip order - for tests and small jobs; large jobs should keep outputs sharded."""
     total = z_con.shape[0]
-    lo, hi = shard_range(total, rank, world)
+    tokens = 3 + (z_emo is not None) + (z_sty is not None)
+    g = job_clips_per_group(total, tokens) if set_clips_per_group is not None else 1
+    if set_clips_per_group is not None:
+        set_clips_per_group(g)
+    lo, hi = shard_range(total, rank, world, align=g)
     sl = lambda t: None if t is None else t[lo:hi]
     out = sample_fn(hi - lo, sl(z_con), sl(z_emo), sl(z_sty), clip_index0=lo) if hi > lo else {}
     if not gather or world == 1:

@@ -193,7 +193,7 @@ def main():
                          "kernel_ms": round(k_avg * 1e3, 3),
                          "note": "algorithmic FLOPs = clips x T x 19,120,640; the kernel is bound by the serial "
                                  "per-step dependency chain + per-CU L2->CU weight streaming (bf16: 3.80 MB per CU "
-                                 "and step = 59.4 k cycles at 64 B/clk, 69 % of the 85.7 k-cycle step; chip-wide 28 TB/s out of L2), not by HBM or "
+                                 "and step = 59.4 k cycles at 64 B/clk, 69 % of the 85.7 k-cycle step; 256 clips run two per tile on 128 CUs = 14 TB/s out of L2), not by HBM or "
                                  "MFMA issue (DESIGN.md sections 4.1, 4.1b, 5)"},
         }
         # single-clip latency (BASELINE configs[1]): B = 1, same sampler

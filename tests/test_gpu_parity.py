@@ -436,7 +436,9 @@ def test_diffusion_backward_end_to_end_fp32(env):
 
 
 def test_full_size_batch_properties(env):
-    """BASELINE config 3 size (256 clips, DDPM-1000, bf16): finite, deterministic, batch-position independent."""
+    """BASELINE config 3 size (256 clips, DDPM-1000, bf16): finite, deterministic, and a clip's result depends on the batch
+    only through its slot inside its workgroup tile (256 clips run two per tile): a tile-aligned sub-batch with the same
+    clips per tile reproduces its rows bitwise."""
     from amuse_amd import scheduler as sch
     eng = env["eng"]
     gen = torch.Generator().manual_seed(3)
@@ -446,9 +448,42 @@ def test_full_size_batch_properties(env):
     b = eng.diffusion_backward(c, e, s, "bf16", seed=2024)
     assert torch.isfinite(a["poses"]).all() and torch.isfinite(a["trans"]).all()
     assert torch.equal(a["poses"], b["poses"])
-    sub = eng.diffusion_backward(c[200:203], e[200:203], s[200:203], "bf16", seed=2024, clip_index0=200)
-    assert torch.equal(sub["latents"], a["latents"][200:203])
-    assert torch.equal(sub["poses"], a["poses"][200:203])
+    from amuse_amd.shard import job_clips_per_group
+    g = job_clips_per_group(256)
+    assert g == 2
+    eng.set_clips_per_group(g)
+    try:
+        sub = eng.diffusion_backward(c[198:204], e[198:204], s[198:204], "bf16", seed=2024, clip_index0=198)
+    finally:
+        eng.set_clips_per_group(0)
+    assert torch.equal(sub["latents"], a["latents"][198:204])
+    assert torch.equal(sub["poses"], a["poses"][198:204])
+
+
+def test_job_level_tiling_makes_shards_bitwise(env):
+    """amuse_amd/shard.py: clips per tile chosen from the job's TOTAL clip count + shards aligned to it => the shards of a
+    300-clip job (three clips per tile) reproduce the single-launch result bitwise, fp32 and bf16."""
+    from amuse_amd import scheduler as sch
+    from amuse_amd.shard import job_clips_per_group, shard_range
+    eng = env["eng"]
+    gen = torch.Generator().manual_seed(17)
+    B = 300
+    c, e, s = (torch.randn(B, 256, generator=gen) for _ in range(3))
+    eng.set_schedule(sch.ddim_table())
+    g = job_clips_per_group(B)
+    assert g == 3
+    for prec in ("fp32", "bf16"):
+        full = eng.diffusion_backward(c, e, s, prec, seed=7)          # auto: ceil(300 / 128) = 3 clips per tile
+        eng.set_clips_per_group(g)
+        try:
+            parts = []
+            for rank in range(4):
+                lo, hi = shard_range(B, rank, 4, align=g)
+                assert lo % g == 0
+                parts.append(eng.diffusion_backward(c[lo:hi], e[lo:hi], s[lo:hi], prec, seed=7, clip_index0=lo)["latents"])
+        finally:
+            eng.set_clips_per_group(0)
+        assert torch.equal(torch.cat(parts), full["latents"]), prec
 
 
 def test_error_conventions(env):

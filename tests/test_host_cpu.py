@@ -73,6 +73,14 @@ def test_shard_range_partitions():
             sizes = [b - a for a, b in r]
             assert max(sizes) - min(sizes) <= 1
     assert shard_range(256, 3, 8) == (96, 128)
+    # shards aligned to the job's clips per workgroup tile (bitwise reproducibility across shardings)
+    from amuse_amd.shard import job_clips_per_group
+    assert [job_clips_per_group(n) for n in (1, 128, 129, 256, 257, 4096)] == [1, 1, 2, 2, 3, 3]
+    assert job_clips_per_group(4096, tokens=3) == 5
+    for total, world, g in ((300, 4, 3), (10, 4, 3), (256, 8, 2), (7, 3, 2)):
+        r = [shard_range(total, k, world, align=g) for k in range(world)]
+        assert r[0][0] == 0 and r[-1][1] == total
+        assert all(a[1] == b[0] for a, b in zip(r, r[1:])) and all(lo % g == 0 for lo, _ in r)
     with pytest.raises(ValueError):
         shard_range(4, 4, 4)
 

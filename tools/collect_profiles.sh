@@ -8,3 +8,4 @@ done
 cp "$(ls -t gpurun_out/prof8/stats/runc/*_kernel_stats.csv | head -1)" profiles/r01_bench_kernel_stats.csv
 tail -1 gpurun_out/bench8.json > profiles/r01_bench_line.json
 grep -v libdrm gpurun_out/prof8/phase8.txt > profiles/r01_k_sample8_phase_timeline.txt
+cp "$(ls -t gpurun_out/prof8/audio_stats/runc/*_kernel_stats.csv | head -1)" profiles/r01_audio_kernel_stats.csv

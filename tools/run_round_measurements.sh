@@ -9,5 +9,6 @@ for grp in FETCH_SIZE WRITE_SIZE "TCC_HIT_sum TCC_MISS_sum" "SQ_WAVE_CYCLES SQ_B
   n=$(echo $grp | cut -d' ' -f1)
   timeout 300 rocprofv3 --pmc $grp --kernel-trace --output-format csv -d gpurun_out/prof8/pmc_$n -- python3 tools/run_sample_once.py 256 bf16 2 > gpurun_out/prof8/pmc_$n.log 2>&1
 done
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof8/audio_stats -- python3 tools/gpu_audio_perf.py 32 > gpurun_out/prof8/audio_stats.log 2>&1
 timeout 100 python tools/gpu_phase_profile8.py 256 > gpurun_out/prof8/phase8.txt 2>&1
 find gpurun_out/prof8 -name "*.csv" | head -30
