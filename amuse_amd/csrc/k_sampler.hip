@@ -326,7 +326,8 @@ __global__ __launch_bounds__(256, 1) void k_sample(SampleArgs a) {
             const float sb = cf[0], sa = cf[1], c0 = cf[2], cx = cf[3], ce = cf[4], sg = cf[5], clipv = cf[6];
             // ancestral noise z for the latent rows.  In-kernel generation is spread over the whole wave: lane L
             // draws the 4 normals of feature group L % 32 of clip (L / 32) of the tile - ONE Philox call per lane
-            // per two clips instead of eight per lane - and the latent-row lanes fetch their 8 groups by bpermute.
+            // per two clips instead of eight per lane (ceil(G / 2) calls: up to 3 for the G = 5 tiles of con-only
+            // conditioning, S = 3) - and the latent-row lanes fetch their 8 groups by bpermute.
             // Same counters (global clip, step, feature group) as before, so values are bit-identical.
             f32x4 zt[kTiles];
 #pragma unroll
@@ -340,7 +341,7 @@ __global__ __launch_bounds__(256, 1) void k_sample(SampleArgs a) {
                     }
                 } else {
 #pragma unroll
-                    for (int call = 0; call < 2; ++call) {
+                    for (int call = 0; call < 3; ++call) {
                         if (2 * call < a.G) {
                             const int cc = 2 * call + (lane >> 5);
                             const uint64_t gc = a.clip0 + (uint64_t)((long)blockIdx.x * a.G + cc);

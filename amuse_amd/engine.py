@@ -51,6 +51,7 @@ class HipEngine:
         if not self.ctx:
             raise _lib.AmuseHipError(f"amuse_create failed: {self.lib.amuse_last_error().decode()}")
         self.schedule: Optional[ScheduleTable] = None
+        self.noisy_cfg: Dict[str, object] = {}   # DDPMScheduler config of add_noise (set_noisy_scheduler)
 
     def close(self):
         if getattr(self, "ctx", None):
@@ -77,6 +78,22 @@ class HipEngine:
             raise ValueError(f"expected shape {tuple(shape)}, got {tuple(t.shape)}")
         return t
 
+    def _cond(self, con, emo, sty):
+        """The three condition embeddings as (B,256) device tensors; a wrong rank / feature count raises here like
+        the reference's Linear(256, 128) would, instead of sending the kernels out of bounds."""
+        con = self._dev(con)
+        if con.dim() != 2 or con.shape[1] != 256:
+            raise ValueError(f"z_con must be (B, 256), got {tuple(con.shape)}")
+        B = con.shape[0]
+        emo = self._dev(emo, (B, 256)) if emo is not None else None
+        sty = self._dev(sty, (B, 256)) if sty is not None else None
+        return con, emo, sty, B
+
+    def set_noisy_scheduler(self, **cfg):
+        """Config of the training-side DDPMScheduler (ldm.py:41-49, configs/diff_latent_v2.json "noisy_scheduler") that
+        diffusion_forward's add_noise coefficients come from; defaults = scheduler.DEFAULT_SCHED_CFG."""
+        self.noisy_cfg = dict(cfg)
+
     def set_clips_per_group(self, g: int):
         _lib.check(self.lib.amuse_set_clips_per_group(self.ctx, int(g)))
 
@@ -92,9 +109,7 @@ class HipEngine:
 
     def sample(self, con, emo, sty, precision="fp32", seed=0, clip_index0=0, x_init=None, step_noise=None,
                return_traj=False):
-        con = self._dev(con)
-        B = con.shape[0]
-        emo, sty = self._dev(emo, (B, 256)) if emo is not None else None, self._dev(sty, (B, 256)) if sty is not None else None
+        con, emo, sty, B = self._cond(con, emo, sty)
         x_init = self._dev(x_init, (B, 128)) if x_init is not None else None
         T = self.schedule.n_steps
         step_noise = self._dev(step_noise, (T, B, 128)) if step_noise is not None else None
@@ -107,11 +122,8 @@ class HipEngine:
         return (lat, traj) if return_traj else lat
 
     def denoise_step(self, x_t, timestep: int, con, emo, sty, precision="fp32", taps=False):
-        con = self._dev(con)
-        B = con.shape[0]
+        con, emo, sty, B = self._cond(con, emo, sty)
         x_t = self._dev(x_t, (B, 128))
-        emo = self._dev(emo, (B, 256)) if emo is not None else None
-        sty = self._dev(sty, (B, 256)) if sty is not None else None
         eps = torch.empty(B, 128, device=self.device, dtype=torch.float32)
         tap = torch.zeros(11, 16, 128, device=self.device, dtype=torch.float32) if taps else None
         with torch.cuda.device(self.device):
@@ -125,13 +137,13 @@ class HipEngine:
         z0 = self._dev(z0)
         B = z0.shape[0]
         noise = self._dev(noise, (B, 128))
-        con = self._dev(con, (B, 256))
-        emo = self._dev(emo, (B, 256)) if emo is not None else None
-        sty = self._dev(sty, (B, 256)) if sty is not None else None
+        con, emo, sty, Bc = self._cond(con, emo, sty)
+        if Bc != B:
+            raise ValueError(f"z_con has {Bc} rows, z0 has {B}")
         ts = np.ascontiguousarray(timesteps, dtype=np.int32)
         if ts.shape != (B,):
             raise ValueError("timesteps must have one entry per clip")
-        ac = alphas_cumprod()
+        ac = alphas_cumprod(**self.noisy_cfg)
         if ts.min() < 0 or ts.max() >= len(ac):
             raise ValueError(f"timesteps must lie in 0..{len(ac) - 1}")
         sa = np.ascontiguousarray(np.sqrt(ac[ts]), dtype=np.float32)
@@ -200,10 +212,7 @@ class HipEngine:
 
     def diffusion_backward(self, con, emo, sty, precision="fp32", quat_mode="p3d", seed=0, clip_index0=0, x_init=None,
                            step_noise=None, out=None):
-        con = self._dev(con)
-        B = con.shape[0]
-        emo = self._dev(emo, (B, 256)) if emo is not None else None
-        sty = self._dev(sty, (B, 256)) if sty is not None else None
+        con, emo, sty, B = self._cond(con, emo, sty)
         x_init = self._dev(x_init, (B, 128)) if x_init is not None else None
         T = self.schedule.n_steps
         step_noise = self._dev(step_noise, (T, B, 128)) if step_noise is not None else None
@@ -221,10 +230,7 @@ class HipEngine:
     def profile_sample(self, con, emo, sty, precision="bf16", prof_step=1):
         """768 s_memtime stamps of one denoising step of workgroup 0 (amuse_profile_sample): [4 waves][192] from the
         4-wave kernels (fp32), [8 waves][96] flattened into the same buffer from the 8-wave bf16 kernel."""
-        con = self._dev(con)
-        B = con.shape[0]
-        emo = self._dev(emo, (B, 256)) if emo is not None else None
-        sty = self._dev(sty, (B, 256)) if sty is not None else None
+        con, emo, sty, B = self._cond(con, emo, sty)
         st = torch.zeros(4, 192, device=self.device, dtype=torch.int64)
         with torch.cuda.device(self.device):
             _lib.check(self.lib.amuse_profile_sample(self.ctx, _ptr(con), _ptr(emo), _ptr(sty), B, PREC[precision],

@@ -78,8 +78,11 @@ class PretrainedLPDM_v1:
         ep_prior, ep_ldm = ld["pretrained_prior_lpdm_e"], ld["pretrained_ldm_lpdm_e"]
         assert ep_prior == ep_ldm, "Epochs for prior and ldm should be same"
         root = self.processed.parents[1]
-        with open(root / f"configs/{ld['arch']}.json", "r") as f:
-            self.ldm_cfg = json.load(f)
+        if config.get("_ldm_cfg_override") is not None:      # amuse_amd.main: <arch>.json merged with diff_o.yaml in memory
+            self.ldm_cfg = config["_ldm_cfg_override"]
+        else:
+            with open(root / f"configs/{ld['arch']}.json", "r") as f:
+                self.ldm_cfg = json.load(f)
         if backup_cfg is not None:
             raise NotImplementedError("Backup for LPDM not implemented yet!")
         model_dir = root / saved / ld["pretrained_lpdm"]
@@ -89,17 +92,25 @@ class PretrainedLPDM_v1:
         print("[LDM] <===== Chosen LDM model based on total loss: ", lat, " =====>")
         print("[LATDIFF] <===== Chosen VAE model based on total loss: ", pri, " =====>")
         self._build(ckpt.load_denoiser_checkpoint(lat), ckpt.load_prior_checkpoint(pri), device)
-        # the audio encoders (infer_ldm.py:111-114): <saved-models>/<TRAIN_PARAM[tag].pretrained_ast>/*.pt
+        # the audio encoders (infer_ldm.py:111-114 -> Pretrained_AST_EVP.get_model, infer_pretrained_ast_evp.py:12-18):
+        # <root>/saved-models/<TRAIN_PARAM[TRAIN_PARAM.tag].pretrained_ast>/*.pt - always under "saved-models", also on
+        # the cluster layout.  The reference fails in iterdir() when the directory is missing; an injected
+        # `audio_encoder` (precomputed embeddings) is the only case where that is not an error here.
         wd = config["TRAIN_PARAM"].get("wav_dtw_mfcc", {})
-        ast_name = ld.get("pretrained_ast")
-        if ast_name is not None and (root / saved / ast_name).is_dir():
+        tag = config["TRAIN_PARAM"].get("tag", "latent_diffusion")
+        ast_name = config["TRAIN_PARAM"].get(tag, {}).get("pretrained_ast")
+        ast_dir = root / "saved-models" / ast_name if ast_name is not None else None
+        if ast_dir is not None and ast_dir.is_dir():
             audio_ablation = wd.get("ablation")
             assert audio_ablation is not None, f"[LPDM EVAL] Audio ablation flag: {audio_ablation}"
-            best = ckpt.pick_ast_checkpoint(root / saved / ast_name, audio_ablation)
+            best = ckpt.pick_ast_checkpoint(ast_dir, audio_ablation)
             print("[LATDIFF] (2/3) <===== Chosen AST model: ", best, " , loading state dict... =====>")
             sds = ckpt.load_ast_checkpoint(best)
             self.set_audio_encoders(sds["con"], sds["emo"], sds["sty"], wd.get("dataset_mean", -9.173025),
                                     wd.get("dataset_std", 5.062332), wd.get("frame_based_feats", True))
+        elif self.audio_encoder is None:
+            raise FileNotFoundError(f"[LATDIFF] AST checkpoint directory {ast_dir} not found (TRAIN_PARAM.{tag}.pretrained_ast); "
+                                    f"construct PretrainedLPDM_v1(audio_encoder=...) to run from precomputed embeddings")
         return ldm_epoch
 
     def set_audio_encoders(self, con_sd, emo_sd, sty_sd, norm_mean=-9.173025, norm_std=5.062332, frame_based_feats=True):
@@ -123,6 +134,10 @@ class PretrainedLPDM_v1:
     def _build(self, denoiser_sd, prior_sd, device):
         self.device = torch.device(device)
         self.engine = HipEngine(denoiser_sd, prior_sd, self.device)
+        ns = self.ldm_cfg.get("noisy_scheduler")
+        if ns is not None:   # add_noise coefficients of diffusion_forward follow the loaded DDPMScheduler config (ldm.py:41-49)
+            self.engine.set_noisy_scheduler(num_train_timesteps=ns["num_train_timesteps"], beta_start=ns["beta_start"],
+                                            beta_end=ns["beta_end"], beta_schedule=ns["beta_schedule"])
         self.num_inference_timesteps = self.ldm_cfg["scheduler"]["num_inference_timesteps"]
         self.eta = self.ldm_cfg["scheduler"]["eta"]
         self.latent_dim = [1, 128]
@@ -139,8 +154,10 @@ class PretrainedLPDM_v1:
         self.engine.set_schedule(self._tables[key])
 
     # ------------------------------------------------------------------ the hot path
-    def diffusion_backward(self, bsz, z_con, z_emo, z_sty, x_init=None, step_noise=None, clip_index0=None):
-        """-> {"poses": (B,300,55,3) f32, "trans": (B,300,3) f32} on self.device (infer_ldm.py:130-178).
+    def diffusion_backward(self, bsz, z_con, z_emo, z_sty, x_init=None, step_noise=None, clip_index0=None,
+                           return_latents=False):
+        """-> {"poses": (B,300,55,3) f32, "trans": (B,300,3) f32} on self.device (infer_ldm.py:130-178) - exactly the
+        reference's two keys unless return_latents asks for the final latents too.
         z_emo / z_sty may be None (the token is dropped, denoiser.py:159-171).  Extra keyword arguments
         (explicit noise, global clip index for sharded batches) are extensions; the reference draws the
         initial latent from the device RNG."""
@@ -152,7 +169,10 @@ class PretrainedLPDM_v1:
                                              x_init, step_noise)
         if clip_index0 is None:
             self._clip_counter += bsz
-        return {"poses": out["poses"], "trans": out["trans"], "latents": out["latents"]}
+        res = {"poses": out["poses"], "trans": out["trans"]}
+        if return_latents:
+            res["latents"] = out["latents"]
+        return res
 
     def process_single_seq(self, sliced_chunk, framerate=16000 // 2, baseline=False):
         """(con, emo, sty), each (1,256) (infer_ldm.py:180-193): kaldi fbank -> pad / normalise -> 3 x AST on the HIP

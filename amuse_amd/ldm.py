@@ -25,7 +25,7 @@ class LatentDiffusionModel:
         self.device = lpdm.device
         self.predict_epsilon = predict_epsilon
         self.lambda_prior = lambda_prior
-        self.num_train_timesteps = 1000
+        self.num_train_timesteps = int(getattr(lpdm, "ldm_cfg", {}).get("noisy_scheduler", {}).get("num_train_timesteps", 1000))
         self.generator = torch.Generator().manual_seed(lpdm.seed)
 
     def diffusion_forward(self, z, ld_audio_con, ld_audio_emo, ld_audio_sty, plot_latent=False, emo_label=None,
@@ -60,9 +60,14 @@ class LatentDiffusionModel:
         """-> latents (1, B, 128) after the DDIM sampler of the inference path (ldm.py:117-153)."""
         if ld_audio_mfcc is not None:
             raise NotImplementedError("LPDM: Baseline audio AE not implemented yet")
+        prev = self.lpdm.sampler
         self.lpdm.set_sampler("ddim")
-        c0 = self.lpdm._clip_counter
-        lat = self.engine.sample(ld_audio_con, ld_audio_emo, ld_audio_sty, self.lpdm.precision, seed=self.lpdm.seed,
-                                 clip_index0=c0, x_init=x_init)
-        self.lpdm._clip_counter += bsz
+        try:
+            c0 = self.lpdm._clip_counter
+            lat = self.engine.sample(ld_audio_con, ld_audio_emo, ld_audio_sty, self.lpdm.precision, seed=self.lpdm.seed,
+                                     clip_index0=c0, x_init=x_init)
+            self.lpdm._clip_counter += bsz
+        finally:
+            if prev != "ddim":
+                self.lpdm.set_sampler(prev)   # the shared lpdm keeps the sampler its owner chose
         return lat[None]

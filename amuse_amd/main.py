@@ -1,16 +1,28 @@
-"""Entry point mirroring the reference's `python main.py --fn {infer_gesture,edit_gesture}`
-(scripts/main.py:226-268 -> trainer.eval_prior_latdiff_forward_backward_v1, scripts/trainer.py:500-554,
-1037-1098) for the part this library rebuilds: condition embeddings in, SMPL-X NPZ files out.
+"""Drop-in for the reference's `python main.py --fn {infer_gesture,edit_gesture} [--cfg base_new.json] [--wandb logger.json]`
+(scripts/main.py:226-268 -> :113-222 -> trainer.eval_prior_latdiff_forward_backward_v1) for the path this library rebuilds:
+WAV files in, SMPL-X NPZ files out, run from a reference-shaped tree.
 
-Inputs, either
-  --audios DIR   10 s WAV files as the reference reads them (infer_gesture: every *.wav, trainer.py:514-521;
-                 edit_gesture: one *_source.wav + one *_target.wav, trainer.py:1041-1053), run through the HIP audio
-                 front-end (fbank + 3 x AST; --ast-dir = the reference's pretrained_ast directory, else random-init), or
-  --cond FILE    the three 256-d speech embeddings per clip precomputed (.npz with `con`, `emo`, `sty` of shape
-                 (N,256); for edit_gesture additionally `tgt_emo`).
-The Blender / ffmpeg rendering is out of scope: the outputs stop at the `*_motion_smplx.npz` files.
+  cd <amuse>/scripts && python -m amuse_amd.main --fn infer_gesture            # like the reference: dirname = cwd.parent
+  python -m amuse_amd.main --fn edit_gesture --root <amuse>                     # or name the tree's root
 
-  python -m amuse_amd.main --fn infer_gesture --audios viz_dump/test/speech --out renders/ [--model-dir saved-models/LPDM_x]
+What is read, exactly as the reference does (scripts/main.py:243-265):
+  <root>/configs/base_new.json (or --cfg)          deep-merged with  <root>/scripts/overrides/<fn>.yaml
+  <root>/configs/diff_latent_v2.json               deep-merged with  <root>/scripts/overrides/diff_o.yaml
+  (prior_emotional_fing.json + prior_o.yaml only carry architecture constants the kernels are specialised for.)
+The merge happens IN MEMORY: the reference rewrites the three JSON files on every start (main.py:263-265, and again
+:22-26); this entry point never writes into the configuration tree.  The merged diff_latent_v2 is handed to
+PretrainedLPDM_v1.setup through `config["_ldm_cfg_override"]`.
+From the merged config: TRAIN_PARAM.baselines.renders.{custom_audios, custom_renders} (infer_gesture, trainer.py:507-508),
+TRAIN_PARAM.test.emotion_control_list.{audios, renders, actor} (edit_gesture, trainer.py:1039-1043),
+TRAIN_PARAM.test.replication_times, TRAIN_PARAM.seed, the checkpoint directories under <root>/saved-models.
+The committed config carries the author's absolute paths (/home/kchhatre/...): --audios / --renders override the two
+directories without touching the files.  Checkpoints: <root>/saved-models/<pretrained_lpdm>/{latdiff,prior}_*.pt and
+<root>/saved-models/<pretrained_ast>/*.pt as the reference expects; --random-init substitutes the deterministic
+random-init weights (no checkpoint ships with the reference) so that the path can be exercised end to end.
+
+Outputs: <renders>/Custom_audios_<stamp>_E<epoch>/rep<i>/rst_<k>/seq_<n>/<actor>_seq_<n>_<rand6>_motion_smplx.npz
+(trainer.py:534-538, visualizer.py:307-364).  Blender / ffmpeg rendering, wandb and the BEAT dataset objects
+(dm.dm, LMDB) are out of scope; dataset-driven edit tasks take the dict `process_loader` receives via --eval-data.
 """
 from __future__ import annotations
 
@@ -24,10 +36,9 @@ import numpy as np
 import torch
 
 from . import audio_weights as aw
-from . import checkpoint as ckpt
 from . import weights as wts
 from .infer_ldm import PretrainedLPDM_v1
-from .npz_writer import pack_feats, write_sample
+from .trainer import trainer
 
 
 def fixseed(seed: int):
@@ -37,112 +48,100 @@ def fixseed(seed: int):
     torch.manual_seed(seed)
 
 
-def build_model(args) -> "tuple[PretrainedLPDM_v1, int]":
-    ldm_cfg = json.load(open(args.ldm_cfg)) if args.ldm_cfg else None
-    if args.model_dir:
-        lat = ckpt.pick_checkpoint(Path(args.model_dir), "latdiff", args.epoch)
-        epoch = ckpt.epoch_of(lat)
-        pri = ckpt.pick_checkpoint(Path(args.model_dir), "prior", epoch if args.epoch == "best" else args.epoch)
-        dsd, psd = ckpt.load_denoiser_checkpoint(lat), ckpt.load_prior_checkpoint(pri)
-    else:
-        print("[amuse_amd] no --model-dir: using the deterministic random-init weights (seed 0)")
-        dsd, psd, epoch = wts.make_denoiser_weights(0), wts.make_prior_weights(0), 0
-    m = PretrainedLPDM_v1.from_state_dicts(dsd, psd, ldm_cfg, args.device, seed=args.seed)
-    m.precision = args.precision
-    m.set_sampler(args.sampler, args.steps)
-    return m, epoch
+def merge_dicts(config: dict, override_dict) -> dict:
+    """scripts/main.py:245-256 (recursive, in place on a shallow copy - nested dicts of `config` are updated)."""
+    def merge_recursive(original, override):
+        for key, value in override.items():
+            if isinstance(value, dict) and key in original and isinstance(original[key], dict):
+                merge_recursive(original[key], value)
+            else:
+                original[key] = value
+    if override_dict is None:
+        return config
+    result = config.copy()
+    merge_recursive(result, override_dict)
+    return result
 
 
-def load_wav(path) -> torch.Tensor:
-    """torchaudio.load semantics (trainer.py:519): (channels, samples) float32 in [-1, 1), native sample rate - the
-    reference does not resample, it feeds whatever rate the file has to a 16 kHz fbank."""
-    from scipy.io import wavfile
-    _, data = wavfile.read(str(path))
-    if data.ndim == 1:
-        data = data[:, None]
-    if data.dtype == np.int16:
-        x = data.astype(np.float32) / 32768.0
-    elif data.dtype == np.int32:
-        x = data.astype(np.float32) / 2147483648.0
-    elif data.dtype == np.uint8:
-        x = (data.astype(np.float32) - 128.0) / 128.0
-    else:
-        x = data.astype(np.float32)
-    return torch.from_numpy(np.ascontiguousarray(x.T))
-
-
-def embed_wav(model: PretrainedLPDM_v1, path):
-    """trainer.py:519-521: load, remove the global mean, process_single_seq."""
-    a = load_wav(path)
-    a = a - a.mean()
-    return model.process_single_seq(a, framerate=16000, baseline=False)
+def load_config(root: Path, fn: str, cfg_path=None):
+    """-> (base config, diff_latent_v2 config), each merged with its override YAML, nothing written back."""
+    import yaml
+    out = []
+    for override, cfg in ((f"{fn}.yaml", cfg_path or root / "configs" / "base_new.json"),
+                          ("diff_o.yaml", root / "configs" / "diff_latent_v2.json")):
+        config_dict = json.load(open(cfg))
+        ov = root / "scripts" / "overrides" / override
+        override_dict = yaml.safe_load(open(ov)) if ov.exists() else None
+        out.append(merge_dicts(config_dict, override_dict))
+    return out[0], out[1]
 
 
 def main(argv=None):
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--fn", required=True, choices=["infer_gesture", "edit_gesture"])
-    ap.add_argument("--cond", default=None, help=".npz with con/emo/sty (N,256) [+ tgt_emo for edit_gesture]")
-    ap.add_argument("--audios", default=None, help="directory of 10 s WAV files (edit_gesture: *_source.wav, *_target.wav)")
-    ap.add_argument("--ast-dir", default=None, help="the reference's pretrained_ast directory (AST_EVP state dict)")
-    ap.add_argument("--out", required=True)
-    ap.add_argument("--model-dir", default=None, help="dir with latdiff_*.pt / prior_*.pt (reference format)")
-    ap.add_argument("--epoch", default="best")
-    ap.add_argument("--ldm-cfg", default=None, help="configs/diff_latent_v2.json of the reference")
+    ap = argparse.ArgumentParser(description="AMUSE (MI355X path)")
+    ap.add_argument("--fn", nargs="*", required=True, help="infer_gesture, edit_gesture")
+    ap.add_argument("--cfg", default=None, help="config file (default <root>/configs/base_new.json)")
+    ap.add_argument("--wandb", default=None, help="accepted for command-line compatibility; wandb is out of scope")
+    ap.add_argument("--root", default=None, help="the reference-shaped tree (default: cwd.parent, scripts/main.py:229)")
+    ap.add_argument("--audios", default=None, help="override custom_audios / emotion_control_list.audios")
+    ap.add_argument("--renders", default=None, help="override custom_renders / emotion_control_list.renders")
+    ap.add_argument("--eval-data", default=None, help="torch-saved dict for process_loader (dataset-driven edit tasks)")
+    ap.add_argument("--epoch", default="6000", help="checkpoint epoch; the reference hard-codes 6000 (main.py:155-157,193); 'best' = lowest total loss")
+    ap.add_argument("--random-init", action="store_true", help="deterministic random-init weights instead of checkpoints")
     ap.add_argument("--sampler", default="ddim", choices=["ddim", "ddpm"])
     ap.add_argument("--steps", type=int, default=None)
     ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16"])
     ap.add_argument("--device", default="cuda:0")
-    ap.add_argument("--seed", type=int, default=2024)
-    ap.add_argument("--actor", default="scott")   # hard-coded in the reference (trainer.py:518)
-    ap.add_argument("--betas-from", default=None, help="SMPL-X npz of the actor whose `betas` go into the outputs")
     args = ap.parse_args(argv)
-    t0 = time.time()
-    fixseed(args.seed)
-    if (args.cond is None) == (args.audios is None):
-        ap.error("give exactly one of --cond and --audios")
-    model, epoch = build_model(args)
-    tgt = None
-    if args.audios is not None:
-        if args.ast_dir:
-            sds = ckpt.load_ast_checkpoint(ckpt.pick_ast_checkpoint(Path(args.ast_dir), "full"))
-        else:
-            print("[amuse_amd] no --ast-dir: using the deterministic random-init AST weights (seed 0)")
-            sds = {n: aw.make_ast_weights(0, n) for n in aw.ENCODERS}
-        model.set_audio_encoders(sds["con"], sds["emo"], sds["sty"])
-        wavs = sorted(Path(args.audios).glob("*.wav"))
-        if args.fn == "edit_gesture":      # trainer.py:1041-1053
-            src = [x for x in wavs if "_source" in x.stem][0]
-            tg = [x for x in wavs if "_target" in x.stem][0]
-            con, emo, sty = embed_wav(model, src)
-            tgt = embed_wav(model, tg)[1]
-        else:
-            if not wavs:
-                raise FileNotFoundError(f"no *.wav under {args.audios}")
-            embs = [embed_wav(model, w) for w in wavs]
-            con, emo, sty = (torch.cat([e[k] for e in embs]) for k in range(3))
+    fn = args.fn[0]
+    if fn not in ("infer_gesture", "edit_gesture"):
+        raise SystemExit(f"--fn {fn}: only infer_gesture and edit_gesture run on this path (train_gesture: amuse_amd.train_gesture)")
+    tic = time.time()
+    dirname = Path(args.root) if args.root else Path.cwd().parent
+    config, ldm_cfg = load_config(dirname, fn, args.cfg)
+    tp = config["TRAIN_PARAM"]
+    assert tp["pretrained_infer"], f"Arg: {fn} and pretrained_infer: {tp['pretrained_infer']} mismatch!"   # main.py:129
+    assert tp["motion_extractor"]["use"] is False, "Motion extractor should be False!"
+    if args.audios or args.renders:
+        r, ecl = tp["baselines"]["renders"], tp["test"].get("emotion_control_list", {})
+        if args.audios:
+            r["custom_audios"], ecl["audios"] = args.audios, args.audios
+        if args.renders:
+            r["custom_renders"], ecl["renders"] = args.renders, args.renders
+    device = torch.device(args.device)
+    processed = dirname / "data" / "BEAT-processed"
+    model_path = dirname / "saved-models"
+    print(f"Experiment init: AMUSE, device: {device}, time: {time.asctime()}")
+    fixseed(tp["seed"])
+    print(f"Inferring for epoch {args.epoch}")
+    tp["latent_diffusion"]["pretrained_prior_lpdm_e"] = args.epoch if args.epoch == "best" else int(args.epoch)
+    tp["latent_diffusion"]["pretrained_ldm_lpdm_e"] = tp["latent_diffusion"]["pretrained_prior_lpdm_e"]
+    baseline, modelversion, diffonly = False, tp["wav_dtw_mfcc"]["ablation"], tp["test"]["diff_only"]
+    audio_list = tp["test"]["audio_list"]["use"]
+    short_audio_list = tp["test"]["audio_list"]["short_audio_list"]
+    if args.random_init:
+        print("[amuse_amd] --random-init: deterministic random-init denoiser / prior / AST weights (seed 0)")
+        model = PretrainedLPDM_v1.from_state_dicts(wts.make_denoiser_weights(0), wts.make_prior_weights(0), ldm_cfg,
+                                                   device, seed=tp["seed"])
+        for k in ("style_transfer", "emotion_control", "content_control", "style_Xemo_transfer"):
+            setattr(model, k, tp["test"][k]["use"])
+        wd = tp["wav_dtw_mfcc"]
+        model.set_audio_encoders(*(aw.make_ast_weights(0, n) for n in aw.ENCODERS), wd.get("dataset_mean", -9.173025),
+                                 wd.get("dataset_std", 5.062332), wd.get("frame_based_feats", True))
+        ldm_epoch = 0
     else:
-        z = np.load(args.cond)
-        con, emo, sty = (torch.from_numpy(z[k]).float() for k in ("con", "emo", "sty"))
-        if args.fn == "edit_gesture":
-            tgt = torch.from_numpy(z["tgt_emo"]).float()
-    stamp = time.strftime("%Y%m%d-%H%M%S")
-    root = Path(args.out) / f"Custom_audios_{stamp}_E{epoch}" / "rep0"
-    written = []
-    betas = np.load(args.betas_from, allow_pickle=True)["betas"] if args.betas_from else None
-    if args.fn == "infer_gesture":     # trainer.py:516-539: one diffusion_backward(1, ...) per audio
-        for i in range(con.shape[0]):
-            r = model.diffusion_backward(1, con[i:i + 1], emo[i:i + 1], sty[i:i + 1])
-            written += write_sample(pack_feats(r["poses"], r["trans"]), root / f"rst_{i}", args.actor, betas=betas)
-    else:                              # trainer.py:1037-1075: original, then the same with the target's emotion
-        for i in range(con.shape[0]):
-            c0 = model._clip_counter
-            a = model.diffusion_backward(1, con[i:i + 1], emo[i:i + 1], sty[i:i + 1], clip_index0=c0)
-            b = model.diffusion_backward(1, con[i:i + 1], tgt[i:i + 1], sty[i:i + 1], clip_index0=c0)
-            model._clip_counter += 1
-            written += write_sample(pack_feats(a["poses"], a["trans"]), root / f"pair_{i}" / "rst_0", args.actor, betas=betas)
-            written += write_sample(pack_feats(b["poses"], b["trans"]), root / f"pair_{i}" / "rst_1", args.actor, betas=betas)
+        config["_ldm_cfg_override"] = ldm_cfg
+        model = PretrainedLPDM_v1(None)
+        ldm_epoch = model.setup(config, device, processed, None, False, baseline, verbose=False, diffonly=diffonly)
+    model.precision = args.precision
+    model.set_sampler(args.sampler, args.steps)
+    eval_loader = torch.load(args.eval_data, weights_only=False) if args.eval_data else None
+    tr = trainer(config, device, train_loader=eval_loader, model_path=model_path, tag="LPDM_infer", logger_cfg=None,
+                 model=model, processed=processed, metricsmodel=None, b_path=None, EXEC_ON_CLUSTER=False,
+                 debug=tp.get("debug", True), pretrained_infer=True)
+    written = tr.eval_prior_latdiff_forward_backward_v1(baseline, ldm_epoch, audio_list, short_audio_list,
+                                                        modelversion=modelversion, ammetric=True)
     torch.cuda.synchronize()
-    print(f"[LDM EVAL] {args.fn} done: {len(written)} NPZ files under {root}, total time elapsed: {time.time() - t0:.4f} s")
+    print(f"AMUSE: ({fn}) completed in: {(time.time() - tic) / 3600} hrs; {len(written)} NPZ files")
     return written
 
 

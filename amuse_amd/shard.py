@@ -44,7 +44,11 @@ def sample_sharded(sample_fn: Callable[..., Dict[str, torch.Tensor]], z_con, z_e
         set_clips_per_group(g)
     lo, hi = shard_range(total, rank, world, align=g)
     sl = lambda t: None if t is None else t[lo:hi]
-    out = sample_fn(hi - lo, sl(z_con), sl(z_emo), sl(z_sty), clip_index0=lo) if hi > lo else {}
+    try:
+        out = sample_fn(hi - lo, sl(z_con), sl(z_emo), sl(z_sty), clip_index0=lo) if hi > lo else {}
+    finally:
+        if set_clips_per_group is not None:
+            set_clips_per_group(0)   # back to the library's per-launch rule: the job's tiling must not leak into later calls
     if not gather or world == 1:
         return out
     import torch.distributed as dist

@@ -3,10 +3,12 @@
 
 One "step" = one full pass of the hot path over one batch of synthetic clips: initial noise ->
 T-step DDPM loop (persistent HIP kernel) -> VAE decode -> 6D->axis-angle, inputs (three 256-d
-condition vectors per clip) already resident in HBM.  Workload at every N: 256 clips per GPU
-(BASELINE configs[2]'s batch of 256 x 10 s clips, 1000-step DDPM, bf16 operands) - weak scaling,
-clips sharded contiguously over ranks, counter-based noise keyed by the global clip index, no
-collective on the data path.
+condition vectors per clip) already resident in HBM.  Workload at every N: BASELINE configs[2] /
+SURVEY.md 8d config 3 - 256 x 10 s clips IN TOTAL, 1000-step DDPM, bf16 operands, sharded 256 / N
+contiguous clips per rank through amuse_amd/shard.py (strong scaling; counter-based noise keyed by
+the global clip index, clips per workgroup tile chosen from the job's total so that shards are
+bitwise the single-GPU result, no collective on the data path).  The weak-scaling figure (256 clips
+PER rank) is reported beside it as `weak_scaling`, never as `value`.
 
   python bench.py [--gpus N --steps K --warmup W]      (N > 1: launched by torch.distributed.run)
 Prints ONE JSON line on rank 0.
@@ -27,24 +29,32 @@ FLOP_VAE_DECODE_PER_CLIP = 1.76e9
 MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3}   # MI355X_MICROARCH.md chip-level parameters (dense)
 
 
+PMC_DIR = "profiles/r02_pmc"
+
+
 def pmc_traffic_bytes(clips, T, precision):
-    """HBM bytes per k_sample launch from the committed rocprofv3 PMC passes (profiles/r01_pmc: separate --pmc
-    runs of tools/run_sample_once.py at the bench shape).  FETCH_SIZE / WRITE_SIZE are in KiB; FETCH_SIZE is
-    doubled per MI355X_MICROARCH.md (gfx950 reports half of a wide coalesced stream).  None if the shape differs."""
+    """HBM bytes per k_sample launch.  NOT measured by this run (PMC counters need rocprofv3 around the process):
+    read from the committed rocprofv3 PMC passes (PMC_DIR, falling back to profiles/r01_pmc: separate --pmc runs of
+    tools/run_sample_once.py at the bench shape); the bench line names the file in roofline.traffic_source.
+    FETCH_SIZE / WRITE_SIZE are in KiB; FETCH_SIZE is doubled per MI355X_MICROARCH.md (gfx950 reports half of a wide
+    coalesced stream).  (None, None) if the shape differs or no pass is committed."""
     if (clips, T, precision) != (256, 1000, "bf16"):
-        return None
+        return None, None
     import csv
     tot = {}
+    d = next((x for x in (PMC_DIR, "profiles/r01_pmc") if (REPO / x / "FETCH_SIZE_counter_collection.csv").exists()), None)
+    if d is None:
+        return None, None
     for name in ("FETCH_SIZE", "WRITE_SIZE"):
-        f = REPO / "profiles" / "r01_pmc" / f"{name}_counter_collection.csv"
+        f = REPO / d / f"{name}_counter_collection.csv"
         if not f.exists():
-            return None
+            return None, None
         v = [float(r["Counter_Value"]) for r in csv.DictReader(open(f))
              if "k_sample" in r["Kernel_Name"] and r["Counter_Name"] == name]
         if not v:
-            return None
+            return None, None
         tot[name] = sum(v) / len(v)
-    return int((2 * tot["FETCH_SIZE"] + tot["WRITE_SIZE"]) * 1024)
+    return int((2 * tot["FETCH_SIZE"] + tot["WRITE_SIZE"]) * 1024), f"{d}/*_counter_collection.csv (committed rocprofv3 --pmc passes, not this run)"
 
 
 def cpu_baseline(clips, T, wd, wp):
@@ -90,7 +100,7 @@ def cpu_baseline(clips, T, wd, wp):
         orc.feats_to_smplx(feats)
         t_dec = (time.perf_counter() - t0) / dec_clips
     total = T * t_step + clips * t_dec
-    return {"value": round(clips * 300 / total, 1), "unit": "frames/s", "cores": threads, "kind": "port",
+    return {"value": round(clips * 300 / total, 1), "unit": "frames/s", "cores": threads, "host_cores": ncpu, "kind": "port",
             "sample": f"oracle/amuse_oracle.py fp32 on {threads} torch threads: {n_steps} of {T} DDPM steps at "
                       f"{clips} clips ({t_step * 1e3:.1f} ms/step) + VAE decode + 6D->axis-angle of {dec_clips} of "
                       f"{clips} clips ({t_dec * 1e3:.1f} ms/clip), extrapolated to the full job"}
@@ -101,16 +111,23 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--clips", type=int, default=256, help="clips per GPU")
+    ap.add_argument("--clips", type=int, default=256, help="clips in the whole job (sharded over the ranks)")
     ap.add_argument("--T", type=int, default=1000, help="DDPM steps")
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--config", default="sample", choices=["sample", "train"],
+                    help="sample: BASELINE configs[2] (the headline metric); train: configs[3] train_gesture data-parallel step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-audio", action="store_true", help="skip the audio front-end side measurement")
+    ap.add_argument("--no-extras", action="store_true", help="headline + roofline only (profiling runs)")
     args = ap.parse_args()
+    if args.config == "train":
+        from amuse_amd import train_gesture
+        return train_gesture.bench_main(args)
 
     import torch
     import torch.distributed as dist
     from amuse_amd import scheduler as sch
+    from amuse_amd import shard
     from amuse_amd import weights as wts
     from amuse_amd.engine import HipEngine
 
@@ -135,15 +152,20 @@ def main():
     wd, wp = wts.make_denoiser_weights(0), wts.make_prior_weights(0)
     eng = HipEngine(wd, wp, dev)
     eng.set_schedule(sch.ddpm_table(args.T))
-    B = args.clips
-    clip0 = rank * B                                    # contiguous shard of the global clip batch
-    gen = torch.Generator().manual_seed(1234 + rank)
-    con, emo, sty = (torch.randn(B, 256, generator=gen).to(dev) for _ in range(3))
-    out = {"latents": torch.empty(B, 128, device=dev), "poses": torch.empty(B, 300, 55, 3, device=dev),
-           "trans": torch.empty(B, 300, 3, device=dev)}
+    total = args.clips
+    gen = torch.Generator().manual_seed(1234)            # every rank draws the SAME global batch and takes its shard
+    con, emo, sty = (torch.randn(total, 256, generator=gen).to(dev) for _ in range(3))
+    g_job = shard.job_clips_per_group(total)
+    lo, hi = shard.shard_range(total, rank, world, align=g_job)
+    B = hi - lo
+    out = {"latents": torch.empty(max(B, 1), 128, device=dev), "poses": torch.empty(max(B, 1), 300, 55, 3, device=dev),
+           "trans": torch.empty(max(B, 1), 300, 3, device=dev)}
 
-    def step():
-        eng.diffusion_backward(con, emo, sty, args.precision, seed=2024, clip_index0=clip0, out=out)
+    def sample_fn(bsz, c, e, s, clip_index0=0):
+        return eng.diffusion_backward(c, e, s, args.precision, seed=2024, clip_index0=clip_index0, out=out)
+
+    def step():   # the product's sharding path: tiling from the job's total, aligned contiguous shard, global clip index
+        shard.sample_sharded(sample_fn, con, emo, sty, rank, world, set_clips_per_group=eng.set_clips_per_group)
 
     for _ in range(args.warmup):
         step()
@@ -157,59 +179,105 @@ def main():
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    assert bool(torch.isfinite(out["poses"]).all())
+    if B > 0:
+        assert bool(torch.isfinite(out["poses"][:B]).all())
 
     # ---- dominant kernel (k_sample: the T-step loop) timed live with HIP events on its launch stream
+    # (HipEngine launches on torch's current stream, which is the stream these events are recorded on)
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     kt = []
+    eng.set_clips_per_group(g_job)
     for _ in range(max(3, min(args.steps, 10))):
+        if B == 0:
+            break
         ev0.record()
-        eng.sample(con, emo, sty, args.precision, seed=2024, clip_index0=clip0)
+        eng.sample(con[lo:hi], emo[lo:hi], sty[lo:hi], args.precision, seed=2024, clip_index0=lo)
         ev1.record()
         ev1.synchronize()
         kt.append(ev0.elapsed_time(ev1) * 1e-3)
-    k_avg = sum(kt) / len(kt)
+    eng.set_clips_per_group(0)
+    k_avg = sum(kt) / len(kt) if kt else float("nan")
+
+    # ---- weak-scaling companion (256 clips PER rank), N > 1 only: same code path, rank r takes clips [r*256, (r+1)*256)
+    weak = None
+    if world > 1:
+        cw, ew, sw = (torch.randn(total, 256, generator=torch.Generator().manual_seed(99 + rank)).to(dev) for _ in range(3))
+        ow = {"latents": torch.empty(total, 128, device=dev), "poses": torch.empty(total, 300, 55, 3, device=dev),
+              "trans": torch.empty(total, 300, 3, device=dev)}
+        eng.diffusion_backward(cw, ew, sw, args.precision, seed=2024, clip_index0=rank * total, out=ow)
+        barrier()
+        t1 = time.perf_counter()
+        for _ in range(3):
+            eng.diffusion_backward(cw, ew, sw, args.precision, seed=2024, clip_index0=rank * total, out=ow)
+        barrier()
+        tw = torch.tensor([time.perf_counter() - t1], device=dev, dtype=torch.float64)
+        dist.all_reduce(tw, op=dist.ReduceOp.MAX)
+        weak = {"clips_per_gpu": total, "frames_per_s": round(total * world * 300 * 3 / float(tw.item()), 1),
+                "ms_per_job": round(float(tw.item()) / 3 * 1e3, 3)}
+        del cw, ew, sw, ow
 
     line = None
     if rank == 0:
-        total_clips = B * world
-        value = total_clips * 300 * args.steps / elapsed
+        value = total * 300 * args.steps / elapsed
         flop = B * args.T * FLOP_PER_CLIP_STEP
         achieved = flop / k_avg / 1e12
         peak = MFMA_PEAK_TFLOPS[args.precision]
+        traffic, traffic_src = pmc_traffic_bytes(B, args.T, args.precision)
+        us_step = k_avg / args.T * 1e6
         line = {
             "metric": "SMPL-X frames/sec (10 s clip, 1000-step DDPM)", "value": round(value, 1), "unit": "frames/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
-            "config": {"workload": f"{B} x 10 s clips per GPU ({total_clips} total), DDPM-{args.T} sampling loop + "
+            "config": {"workload": f"{total} x 10 s clips in total ({B} on rank 0), DDPM-{args.T} sampling loop + "
                                    f"VAE decode (300 frames) + 6D->axis-angle; random-init weights of the "
                                    f"diff_latent_v2 / prior_emotional_fing architecture",
-                       "clips_per_gpu": B, "sampler": f"ddpm-{args.T}", "sharding": f"clip-batch x{world}, no collectives",
+                       "clips_total": total, "clips_rank0": B, "clips_per_tile": g_job, "sampler": f"ddpm-{args.T}",
+                       "sharding": f"clip-batch x{world} through amuse_amd/shard.py, no collectives",
                        "mfma_operands": args.precision, "state_and_accumulate": "fp32"},
             "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
-                         "frac": round(achieved / peak, 5), "traffic": pmc_traffic_bytes(B, args.T, args.precision),
+                         "frac": round(achieved / peak, 5), "traffic": traffic, "traffic_source": traffic_src,
                          "kernel": ("k_sample8" if args.precision == "bf16" else "k_sample") + " (persistent T-step denoising loop)",
                          "kernel_ms": round(k_avg * 1e3, 3),
-                         "note": "algorithmic FLOPs = clips x T x 19,120,640; the kernel is bound by the serial "
-                                 "per-step dependency chain + per-CU L2->CU weight streaming (bf16: 3.80 MB per CU "
-                                 "and step = 59.4 k cycles at 64 B/clk, 69 % of the 85.7 k-cycle step; 256 clips run two per tile on 128 CUs = 14 TB/s out of L2), not by HBM or "
-                                 "MFMA issue (DESIGN.md sections 4.1, 4.1b, 5)"},
+                         "note": f"algorithmic FLOPs = clips x T x 19,120,640 (rank 0's {B} clips); measured {us_step:.2f} us per "
+                                 f"denoising step. The kernel is bound by the serial per-step dependency chain + per-CU "
+                                 f"L2->CU weight streaming (bf16: 3.80 MB per CU and step = 59.4 k cycles at 64 B/clk, a "
+                                 f"floor of ~24.7 us per step at 2.4 GHz), not by HBM or MFMA issue (DESIGN.md 4.1, 4.1b, 5)"},
         }
-        # single-clip latency (BASELINE configs[1]): B = 1, same sampler
+        if weak is not None:
+            line["weak_scaling"] = weak
+    if rank == 0 and not args.no_extras:
+        # single-clip latency (BASELINE configs[1]): B = 1, same sampler, 5 warm-ups, 50 HIP-event-timed repeats
         c1, e1, s1 = con[:1].contiguous(), emo[:1].contiguous(), sty[:1].contiguous()
+        o1 = {"latents": torch.empty(1, 128, device=dev), "poses": torch.empty(1, 300, 55, 3, device=dev),
+              "trans": torch.empty(1, 300, 3, device=dev)}
         lat = []
-        for i in range(12):
-            torch.cuda.synchronize()
-            t1 = time.perf_counter()
-            eng.diffusion_backward(c1, e1, s1, args.precision, seed=2024)
-            torch.cuda.synchronize()
-            if i >= 2:
-                lat.append((time.perf_counter() - t1) * 1e3)
+        for i in range(55):
+            ev0.record()
+            eng.diffusion_backward(c1, e1, s1, args.precision, seed=2024, out=o1)
+            ev1.record()
+            ev1.synchronize()
+            if i >= 5:
+                lat.append(ev0.elapsed_time(ev1))
         line["p50_clip_latency_ms"] = round(statistics.median(lat), 3)
+        line["p50_clip_latency_samples"] = len(lat)
+        # decode alone (MotionPrior.decode + 6D->axis-angle of rank 0's clips), HIP events
+        if B > 0:
+            z = torch.randn(B, 128, generator=gen).to(dev)
+            dt = []
+            for i in range(6):
+                ev0.record()
+                eng.vae_decode(z, None, args.precision)
+                ev1.record()
+                ev1.synchronize()
+                if i >= 1:
+                    dt.append(ev0.elapsed_time(ev1))
+            flop_dec = B * FLOP_VAE_DECODE_PER_CLIP
+            line["decode"] = {"clips": B, "ms": round(min(dt), 3), "tflops": round(flop_dec / (min(dt) * 1e-3) / 1e12, 1),
+                              "frac_of_mfma_peak": round(flop_dec / (min(dt) * 1e-3) / 1e12 / peak, 4)}
         # the step time of k_sample does not depend on the clips per workgroup tile (1..3), so 3 clips per CU
         # cost the same loop time: report that saturating point too (not the headline workload)
-        Bs = 3 * B
+        Bs = 3 * total
         cs, es, ss = (torch.randn(Bs, 256, generator=gen).to(dev) for _ in range(3))
         outs = {"latents": torch.empty(Bs, 128, device=dev), "poses": torch.empty(Bs, 300, 55, 3, device=dev),
                 "trans": torch.empty(Bs, 300, 3, device=dev)}
@@ -244,11 +312,11 @@ def main():
             ms_clip = min(ta) * 1e3 / Ba
             line["audio_frontend"] = {"clips": Ba, "ms_per_clip": round(ms_clip, 3),
                                       "tflops": round(flop / (ms_clip * 1e-3) / 1e12, 1),
-                                      "frames_per_s_wav_to_smplx": round(300.0 / (ms_clip * 1e-3 + elapsed / args.steps / B), 1)}
+                                      "frames_per_s_wav_to_smplx": round(300.0 / (ms_clip * 1e-3 + elapsed / args.steps / total), 1)}
             aeng.close()
             del aeng, wav
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(B, args.T, wd, wp)
+            line["cpu_baseline"] = cpu_baseline(total, args.T, wd, wp)
     barrier()
     if world > 1:
         dist.destroy_process_group()

@@ -173,7 +173,8 @@ int amuse_counter_normal(amuse_ctx* ctx, uint64_t seed, uint64_t clip_index0, in
 int amuse_profile_sample(amuse_ctx* ctx, const float* con, const float* emo, const float* sty, int B,
                          int precision, int prof_step, unsigned long long* stamps_out, void* stream);
 
-/* Clips per workgroup tile in the sampling kernels: 0 = auto = ceil(B / 128), else 1..3 (x S tokens <= 16 rows).
+/* Clips per workgroup tile in the sampling kernels: 0 = auto = ceil(B / 128), else 1..5; the value used is clamped to
+ * 16 / S (S = 5, 4 or 3 tokens per clip: at most 3, 4 or 5 clips share the 16 rows of a tile).
  * Results are bitwise reproducible across launches / shards that use the same value and start at multiples of it
  * (a clip's slot inside its tile decides the rounding of its attention sums); amuse_amd/shard.py applies that rule. */
 int amuse_set_clips_per_group(amuse_ctx* ctx, int g);

@@ -200,6 +200,15 @@ def main():
             "mocap_frame_rate": float(z_["mocap_frame_rate"]),
         }
     json.dump(lay, open(out / "npz_layout.json", "w"), indent=1)
+    # ---- gender / betas the reference's own writer put into those files (visualizer.py:357-362 <- ldm_evals.py:67-71)
+    bet = {}
+    for p in sorted((REF / "viz_dump/test").rglob("*_motion_smplx.npz")):
+        z_ = np.load(p, allow_pickle=True)
+        actor = p.name.split("_")[0]
+        assert actor not in bet or np.array_equal(bet[actor], z_["betas"])
+        bet[actor] = z_["betas"]
+        bet[actor + "_gender"] = z_["gender"]
+    np.savez_compressed(out / "sample_npz_betas.npz", **bet)
     for f in sorted(out.iterdir()):
         print(f.name, os.path.getsize(f))
 

@@ -93,3 +93,55 @@ def test_flatten_state_dict_checks_keys_and_shapes():
     bad["encoder.norm.bias"] = np.zeros(7, np.float32)
     with pytest.raises(ValueError):
         flatten_state_dict(bad, wts.denoiser_param_spec())
+
+
+def test_schedule_known_answers():
+    """Known-answer checks that do not go through the build's own restatement: the public constants of the
+    scaled-linear (Stable-Diffusion) beta schedule the reference configures (configs/diff_latent_v2.json:48-66), the DDIM
+    timestep grid, and the published closed forms - Ho et al. 2020 eq. 6-7 (posterior mean / variance, diffusers'
+    `fixed_small`) and Song et al. 2021 eq. 12 with sigma = 0 - evaluated in float64 from first principles."""
+    from amuse_amd import scheduler as sch
+    ac = sch.alphas_cumprod()
+    assert ac.dtype == np.float32 and ac.shape == (1000,)
+    assert abs(float(ac[0]) - 0.99915) < 1e-6            # 1 - beta_start
+    assert abs(float(ac[999]) - 0.0046601) < 2e-7        # SD's alphas_cumprod[-1] = 0.00466
+    beta = np.linspace(0.00085 ** 0.5, 0.012 ** 0.5, 1000, dtype=np.float64) ** 2
+    assert abs(beta[0] - 0.00085) < 1e-15 and abs(beta[-1] - 0.012) < 1e-15
+    ab = np.cumprod(1.0 - beta)
+    assert np.abs(ac - ab).max() < 1e-6 and (np.abs(ac - ab) / ab).max() < 2e-6   # fp32 cumprod, as diffusers computes it
+    # DDIM-50 grid of the inference scheduler: steps_offset 1, leading spacing -> 981, 961, ..., 1 (infer_ldm.py:143-144)
+    d = sch.ddim_table()
+    assert list(d.timesteps) == list(range(981, 0, -20)) and d.init_noise_sigma == 1.0
+    abp = lambda t: ab[t] if t >= 0 else ab[0]            # set_alpha_to_one False: final_alpha_cumprod = alphas_cumprod[0]
+    for i, t in enumerate(d.timesteps):
+        sb, sa, c0, cx, ce, sg, clip, _ = d.coef[i]
+        tp = int(t) - 20
+        assert abs(sa - ab[t] ** 0.5) < 2e-6 and abs(sb - (1 - ab[t]) ** 0.5) < 2e-6
+        assert abs(c0 - abp(tp) ** 0.5) < 2e-6 and abs(ce - (1 - abp(tp)) ** 0.5) < 2e-6     # eq. 12, sigma = 0
+        assert cx == 0.0 and sg == 0.0 and clip == 1.0                                        # diffusers' clip_sample default
+    # DDPM-1000 ancestral sampler: x_{t-1} = mu~(x_t, x0) + sigma_t z, Ho et al. eq. 6-7
+    p = sch.ddpm_table()
+    assert list(p.timesteps) == list(range(999, -1, -1))
+    for i in (0, 1, 500, 998, 999):
+        t = int(p.timesteps[i])
+        sb, sa, c0, cx, ce, sg, clip, _ = p.coef[i]
+        ab_t, ab_p = ab[t], (ab[t - 1] if t > 0 else 1.0)
+        b_t = 1.0 - ab_t / ab_p
+        assert abs(b_t - beta[t]) < 1e-12
+        # diffusers evaluates these on fp32 tensors: 1 - abar_t cancels near t = 0 (1 - 0.9983 carries 3.5e-5 relative)
+        tol = 2e-6 + 2.5e-7 / (1 - ab_t)
+        assert abs(c0 - ab_p ** 0.5 * b_t / (1 - ab_t)) < tol                                 # eq. 7, x0 coefficient
+        assert abs(cx - (1 - b_t) ** 0.5 * (1 - ab_p) / (1 - ab_t)) < tol                     # eq. 7, x_t coefficient
+        var = (1 - ab_p) / (1 - ab_t) * b_t                                                   # beta~_t ("fixed_small")
+        assert (sg == 0.0) if t == 0 else abs(sg - max(var, 1e-20) ** 0.5) < tol
+        assert ce == 0.0 and clip == 0.0
+    # consistency: if eps_hat is the noise that produced x_t from x0, a noiseless DDIM step lands on the x0 / eps ray
+    rng = np.random.default_rng(1)
+    x0 = np.clip(rng.standard_normal(16), -1, 1)
+    eps = rng.standard_normal(16)
+    i = 25
+    t = int(d.timesteps[i])
+    xt = ab[t] ** 0.5 * x0 + (1 - ab[t]) ** 0.5 * eps
+    sb, sa, c0, cx, ce, sg, clip, _ = d.coef[i].astype(np.float64)
+    nx = c0 * np.clip((xt - sb * eps) / sa, -clip, clip) + ce * eps
+    assert np.abs(nx - (ab[t - 20] ** 0.5 * x0 + (1 - ab[t - 20]) ** 0.5 * eps)).max() < 1e-5

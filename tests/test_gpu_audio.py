@@ -135,25 +135,35 @@ def test_host_mirror_process_single_seq_and_loader_helper(env):
     m.audio_engine = None                                              # the fixture owns the engine
 
 
-def test_cli_infer_and_edit_from_wav_files(tmp_path):
-    """python -m amuse_amd.main --fn {infer,edit}_gesture --audios DIR: WAV in, *_motion_smplx.npz out."""
-    from scipy.io import wavfile
+def test_cli_infer_and_edit_from_a_reference_tree(tmp_path):
+    """`python -m amuse_amd.main --fn {infer,edit}_gesture` from a reference-shaped tree (scripts/main.py:226-268): config +
+    override YAMLs merged in memory, WAVs from the configured directories, NPZs under the reference's directory names."""
+    import hashlib
+
+    from conftest import make_reference_tree
 
     from amuse_amd import main as cli
-    d = tmp_path / "speech"
-    d.mkdir()
-    for name, seed in (("9_x_source.wav", 1), ("9_x_target.wav", 2)):
-        w = (_waves(159744, 1, seed=seed)[0].numpy() * 20000).astype(np.int16)
-        wavfile.write(d / name, 16000, w)
-    a = cli.load_wav(d / "9_x_source.wav")
+    from amuse_amd.trainer import load_wav
+    root = make_reference_tree(tmp_path / "amuse", n_infer_wavs=2)
+    digest = lambda: {str(p): hashlib.sha256(p.read_bytes()).hexdigest() for p in sorted((root / "configs").iterdir())}
+    before = digest()
+    a = load_wav(root / "viz_dump/test/e_speech/9_miranda_source.wav")
     assert a.shape == (1, 159744) and a.dtype == torch.float32 and float(a.abs().max()) <= 1.0
-    w = cli.main(["--fn", "infer_gesture", "--audios", str(d), "--out", str(tmp_path / "r1")])
-    assert len(w) == 2 and all(p.name.endswith("_motion_smplx.npz") for p in w)
+    w = cli.main(["--fn", "infer_gesture", "--root", str(root), "--random-init"])
+    # one diffusion_backward(1, ...) per audio, each visualised as rst_0 / seq_0 (trainer.py:516-539), actor "scott"
+    assert len(w) == 2 and all(p.name.startswith("scott_seq_0_") and p.name.endswith("_motion_smplx.npz") for p in w)
+    rel = w[0].relative_to(root / "viz_dump/test/gesture").parts
+    assert rel[0].startswith("Custom_audios_") and rel[0].endswith("_E0") and rel[1:4] == ("rep0", "rst_0", "seq_0")
     z = np.load(w[0], allow_pickle=True)
-    assert z["poses"].shape == (300, 55, 3) and z["poses"].dtype == np.float32
-    w2 = cli.main(["--fn", "edit_gesture", "--audios", str(d), "--out", str(tmp_path / "r2")])
-    assert len(w2) == 2
+    assert z["poses"].shape == (300, 55, 3) and z["poses"].dtype == np.float32 and str(z["gender"]) == "male"
+    assert not np.array_equal(z["poses"], np.load(w[1])["poses"])
+    w2 = cli.main(["--fn", "edit_gesture", "--root", str(root), "--random-init"])
+    assert [p.parts[-3] for p in w2] == ["rst_0", "rst_1"] and all(p.name.startswith("miranda_seq_0_") for p in w2)
+    assert str(np.load(w2[0], allow_pickle=True)["gender"]) == "female"
     p0, p1 = (np.load(x, allow_pickle=True)["poses"] for x in w2)
-    assert not np.array_equal(p0, p1)          # same content / style / noise, the target's emotion swapped in
+    assert np.isfinite(p0).all() and not np.array_equal(p0, p1)   # fresh noise per call AND the target's emotion
+    assert digest() == before                                       # nothing written into the configuration tree
     with pytest.raises(SystemExit):
-        cli.main(["--fn", "infer_gesture", "--out", str(tmp_path / "r3")])
+        cli.main(["--fn", "train_audio", "--root", str(root)])
+    with pytest.raises(FileNotFoundError):                          # no checkpoints in the tree and no --random-init
+        cli.main(["--fn", "infer_gesture", "--root", str(root)])

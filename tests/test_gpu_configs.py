@@ -1,0 +1,188 @@
+"""GPU tests at the shapes of BASELINE.json's configs that the per-kernel parity tests do not reach:
+
+  config 2  - one clip, 1000-step DDPM, bf16: the 8-wave kernel's OWN trajectory is checked state by state
+              (teacher-forced eps_hat against the bf16-emulating oracle; the in-loop update against the scheduler
+              restatement applied to that eps_hat)
+  config 5  - edit_gesture emotion_control: 16 waveforms -> audio front-end -> 8 x 8 content / emotion swaps = 64 jobs
+              as ONE diffusion_backward launch (scripts/trainer.py:839-901, infer_ldm.py:387-410)
+  bf16 mode - the throughput mode is gated against the fp32 parity mode at <= 2 x the measured drift
+              (profiles/r01_bf16_vs_fp32_drift.json), so a regression of the bf16 kernels fails a test
+"""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _err(a, b):
+    a = a.detach().cpu().double().numpy() if isinstance(a, torch.Tensor) else np.asarray(a, dtype=np.float64)
+    b = b.detach().cpu().double().numpy() if isinstance(b, torch.Tensor) else np.asarray(b, dtype=np.float64)
+    return float(np.abs(a - b).max())
+
+
+@pytest.fixture(scope="module")
+def env():
+    from amuse_amd import weights as wts
+    from amuse_amd.engine import HipEngine
+    from oracle import amuse_oracle as orc
+    wd, wp = wts.make_denoiser_weights(0), wts.make_prior_weights(0)
+    eng = HipEngine(wd, wp, "cuda:0")
+    yield {"eng": eng, "wd": wd, "wp": wp, "Wd": orc.to_torch(wd), "Wp": orc.to_torch(wp), "orc": orc}
+    eng.close()
+
+
+def test_config2_bf16_single_clip_ddpm1000_own_trajectory(env):
+    """BASELINE config 2 through k_sample8 (B = 1, T = 1000, bf16): every 100th state of the kernel's own trajectory."""
+    from amuse_amd import scheduler as sch
+    orc, eng, Wd = env["orc"], env["eng"], env["Wd"]
+    gen = torch.Generator().manual_seed(2024)
+    c, e, s, x = (torch.randn(1, n, generator=gen) for n in (256, 256, 256, 128))
+    nz = torch.randn(1000, 1, 128, generator=gen)
+    tab = sch.ddpm_table()
+    eng.set_schedule(tab)
+    lat, traj = eng.sample(c, e, s, "bf16", x_init=x, step_noise=nz, return_traj=True)
+    traj = traj.cpu()
+    assert torch.equal(lat.cpu(), traj[-1]) and bool(torch.isfinite(traj).all())
+    osched = orc.DDPM()
+    worst_eps, worst_upd = 0.0, 0.0
+    for i in range(0, 1000, 100):
+        xi = x if i == 0 else traj[i - 1]
+        t = int(tab.timesteps[i])
+        eps = eng.denoise_step(xi, t, c, e, s, "bf16").cpu()            # teacher-forced on the kernel's own state
+        ref = orc.denoiser_forward(Wd, xi, t, c, e, s, emulate_bf16=True)
+        worst_eps = max(worst_eps, _err(eps, ref))
+        # the step the loop took from this state == scheduler restatement applied to the teacher-forced eps_hat
+        nxt = osched.step(eps, t, xi, nz[i])
+        scale = max(1.0, float(nxt.abs().max()))
+        worst_upd = max(worst_upd, _err(traj[i], nxt) / scale)
+    assert worst_eps < 5e-2, worst_eps      # whole-network bf16 tolerance (|eps_hat| ~ 3); measured 1-2e-2
+    assert worst_upd < 2e-5, worst_upd      # the in-loop eps_hat IS the teacher-forced one; update in fp32
+    # and the same job through the one-call entry point is deterministic
+    a = eng.diffusion_backward(c, e, s, "bf16", seed=2024)
+    b = eng.diffusion_backward(c, e, s, "bf16", seed=2024)
+    assert torch.equal(a["poses"], b["poses"]) and bool(torch.isfinite(a["poses"]).all())
+
+
+def test_bf16_mode_gated_against_fp32_mode(env):
+    """Same inputs + noise through both modes, 64 clips (tests/tools/gpu_drift.py is the measuring twin).  Bounds are
+    <= 2 x the measured values: DDIM-50 latents rms 0.039 / max 0.23 on rms 0.53; DDPM-1000 latents rms 0.17 on rms 32,
+    pose geodesic median 0.39 deg / p99 3.6 deg."""
+    from amuse_amd import scheduler as sch
+    orc, eng = env["orc"], env["eng"]
+    g = torch.Generator().manual_seed(2024)
+    B = 64
+    c, e, s, x = (torch.randn(B, n, generator=g) for n in (256, 256, 256, 128))
+    eng.set_schedule(sch.ddim_table())
+    a = eng.sample(c, e, s, "fp32", x_init=x).cpu()
+    b = eng.sample(c, e, s, "bf16", x_init=x).cpu()
+    assert float((a - b).pow(2).mean().sqrt()) < 0.08 and float((a - b).abs().max()) < 0.46
+    tab = sch.ddpm_table()
+    eng.set_schedule(tab)
+    nz = torch.randn(tab.n_steps, B, 128, generator=g)
+    a = eng.sample(c, e, s, "fp32", x_init=x, step_noise=nz).cpu()
+    b = eng.sample(c, e, s, "bf16", x_init=x, step_noise=nz).cpu()
+    assert float((a - b).pow(2).mean().sqrt()) < 0.35
+    pa = eng.vae_decode(a, None, "fp32")["poses"].cpu()
+    pb = eng.vae_decode(b, None, "bf16")["poses"].cpu()
+    Ra, Rb = orc.axis_angle_to_matrix(pa.double()), orc.axis_angle_to_matrix(pb.double())
+    ang = torch.acos(((Ra.transpose(-1, -2) @ Rb).diagonal(dim1=-2, dim2=-1).sum(-1) - 1).div(2).clamp(-1, 1)) * 180 / np.pi
+    assert float(ang.median()) < 1.0, float(ang.median())
+    assert float(ang.flatten().kthvalue(int(ang.numel() * 0.99)).values) < 8.0
+
+
+def test_config5_edit_gesture_emotion_control_batch64(env):
+    """16 waveforms -> amuse_audio_features -> 8 x 8 emotion swap -> ONE B = 64 diffusion_backward through the product's
+    edit driver (amuse_amd/trainer.py emotion_control_jobs + run_jobs); DDIM-50 fp32 latents against the oracle for 8 of
+    the 64 jobs; bf16 DDPM-1000 finite and deterministic."""
+    from amuse_amd import audio_weights as aw
+    from amuse_amd.infer_ldm import PretrainedLPDM_v1
+    from amuse_amd.trainer import emotion_control_jobs, run_jobs
+    orc, Wd = env["orc"], env["Wd"]
+    m = PretrainedLPDM_v1.from_state_dicts(env["wd"], env["wp"], device="cuda:0", seed=2024)
+    m.set_audio_encoders(*(aw.make_ast_weights(0, n) for n in aw.ENCODERS))
+    m.emotion_control = True
+    gen = torch.Generator().manual_seed(0)
+    takes = [f"0_{k}_{k}" for k in (9, 65, 73, 81, 87, 95, 103, 111)]       # one take per emotion (ldm_evals.py:79-87)
+    waves = 0.1 * torch.randn(16, 160000, generator=gen)
+    con, emo, sty = m.audio_engine.features(waves)                          # 16 clips through fbank + 3 x AST
+    assert bool(torch.isfinite(con).all() and torch.isfinite(emo).all() and torch.isfinite(sty).all())
+    # the dataset dict process_loader receives (infer_ldm.py:387-410), latents precomputed: content / style of
+    # waveform k, emotion of waveform 8 + k
+    data = {"emotion_control_info": "[scott]_all", "emotion_control": {"scott": {
+        tk: {"ld_z": torch.zeros(1, 128), "ld_z_con": con[k:k + 1], "ld_z_emo": emo[8 + k:9 + k], "ld_z_sty": sty[k:k + 1],
+             "ld_attr": ("scott", "male", "native", "x", "30"), "ld_wav": np.zeros(10000, np.float32),
+             "ld_motion": None} for k, tk in enumerate(takes)}}}
+    loaded = m.process_loader(data)
+    jobs = emotion_control_jobs(loaded["emotion_control"])
+    assert len(jobs) == 64 and sum(j["bsz"] for j in jobs) == 64             # 8 original emotions x 8 swapped (trainer.py:919)
+    m.precision, c0 = "fp32", m._clip_counter
+    m.set_sampler("ddim")
+    res = run_jobs(m, jobs, return_latents=True)
+    assert len(res) == 64 and res[0]["feats"].shape == (1, 300, 168)
+    lat = torch.cat([r["latents"] for r in res]).cpu()
+    x0 = m.engine.counter_normal(m.seed, c0, 64, 0, 0).cpu()
+    for j in range(0, 64, 9):                                                # jobs 0, 9, ..., 63: 8 distinct (take, emotion) pairs
+        job = jobs[j]
+        ref = orc.sample_latents(Wd, orc.DDIM(), job["z_con"].cpu(), job["z_emo"].cpu(), job["z_sty"].cpu(), x0[j:j + 1])
+        assert _err(lat[j:j + 1], ref) < 1e-4, j
+    # swapping changes the motion; the un-swapped job keeps the take's own emotion
+    assert jobs[0]["z_emo_key"] == "ld_z_emo" and torch.equal(jobs[0]["z_emo"], emo[8:9])
+    assert not torch.equal(res[0]["feats"], res[1]["feats"])
+    # throughput mode at this shape: DDPM-1000 bf16
+    m.precision = "bf16"
+    m.set_sampler("ddpm")
+    m._clip_counter = 1000
+    a = run_jobs(m, jobs)
+    m._clip_counter = 1000
+    b = run_jobs(m, jobs)
+    fa, fb = torch.cat([r["feats"] for r in a]), torch.cat([r["feats"] for r in b])
+    assert fa.shape == (64, 300, 168) and bool(torch.isfinite(fa).all()) and torch.equal(fa, fb)
+    m.audio_engine.close()
+
+
+_SHARD_WORKER = r'''
+import os, sys
+import torch, torch.distributed as dist
+sys.path.insert(0, sys.argv[1])
+from amuse_amd import weights as wts, scheduler as sch
+from amuse_amd.engine import HipEngine
+from amuse_amd.shard import sample_sharded
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo", rank=rank, world_size=world)     # one GPU on the test box: both ranks share cuda:0
+eng = HipEngine(wts.make_denoiser_weights(0), wts.make_prior_weights(0), "cuda:0")
+eng.set_schedule(sch.ddpm_table(40))
+g = torch.Generator().manual_seed(3)
+B = 300                                                            # three clips per tile at the job level
+con, emo, sty = (torch.randn(B, 256, generator=g) for _ in range(3))
+def sample_fn(bsz, c, e, s, clip_index0=0):
+    o = eng.diffusion_backward(c, e, s, "bf16", seed=11, clip_index0=clip_index0)
+    return {"latents": o["latents"], "poses": o["poses"][:, :2]}
+full = sample_sharded(sample_fn, con, emo, sty, rank, world, gather=True, set_clips_per_group=eng.set_clips_per_group)
+if rank == 0:
+    single = sample_sharded(sample_fn, con, emo, sty, 0, 1, set_clips_per_group=eng.set_clips_per_group)
+    assert full["latents"].shape == (B, 128)
+    assert torch.equal(full["latents"], single["latents"].cpu()) and torch.equal(full["poses"], single["poses"].cpu())
+    # the job-level tiling did not leak into the context: an unrelated small call is back on the per-launch rule
+    a = eng.sample(con[:5], emo[:5], sty[:5], "bf16", seed=11)
+    eng.set_clips_per_group(1)
+    assert torch.equal(a, eng.sample(con[:5], emo[:5], sty[:5], "bf16", seed=11))
+    print("SHARD_GPU_OK")
+dist.barrier()
+dist.destroy_process_group()
+'''
+
+
+def test_two_process_sharded_job_through_the_hip_engine(tmp_path):
+    """The N > 1 path bench.py --gpus N runs (one process per rank, HipEngine per rank, amuse_amd/shard.py), as two
+    processes on this box's one GPU with gloo for the gather: bitwise the single-process job."""
+    import os, subprocess, sys
+    from conftest import REPO
+    script = tmp_path / "worker.py"
+    script.write_text(_SHARD_WORKER)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29641")
+    procs = [subprocess.Popen([sys.executable, str(script), str(REPO)], env=dict(env, RANK=str(r), WORLD_SIZE="2"),
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(2)]
+    outs = [p.communicate(timeout=600)[0] for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs
+    assert "SHARD_GPU_OK" in outs[0]

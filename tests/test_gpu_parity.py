@@ -209,7 +209,7 @@ def test_ddim50_fp32_matches_reference_trajectory(env):
     assert torch.equal(lat, traj[-1])
     # bf16 throughput mode: measured drift, bounded (O(0.3) on rms 0.64)
     latb = eng.sample(tr["con"], tr["emo"], tr["sty"], "bf16", x_init=tr["x_T"])
-    assert _err(latb, tr["x_after_50"]) < 0.6
+    assert _err(latb, tr["x_after_50"]) < 0.3   # 64-clip statistics are gated in test_gpu_configs.py (rms 0.08 / max 0.46)
 
 
 def test_ddpm_explicit_noise_vs_oracle(env):
@@ -281,8 +281,23 @@ def test_in_kernel_noise_equals_explicit_counter_noise(env):
                 a = eng.sample(c, e, s, prec, seed=seed, clip_index0=c0)
                 b = eng.sample(c, e, s, prec, x_init=x0, step_noise=nz)
                 assert torch.equal(a, b), (G, prec)
+        # token dropping makes room for more clips per 16-row tile: S = 4 (con + sty) -> up to 4, S = 3 (con only) -> up
+        # to 5.  The 4-wave kernel draws the tile's noise in ceil(G / 2) wave-wide Philox calls: the 5th clip of a tile
+        # must get its ancestral noise too (it silently kept z = 0 before), and B = 7 leaves a ragged last tile.
+        for G, (ee, ss) in ((4, (None, s)), (4, (None, None)), (5, (None, None))):
+            eng.set_clips_per_group(G)
+            for prec in ("fp32", "bf16"):
+                a = eng.sample(c, ee, ss, prec, seed=seed, clip_index0=c0)
+                b = eng.sample(c, ee, ss, prec, x_init=x0, step_noise=nz)
+                assert torch.equal(a, b), (G, prec, ee is None, ss is None)
+                eng.set_clips_per_group(1)
+                one = eng.sample(c, ee, ss, prec, seed=seed, clip_index0=c0)     # one clip per tile: same noise, same run
+                eng.set_clips_per_group(G)
+                assert float((a - one).abs().max()) < (1e-3 if prec == "fp32" else 0.5) * max(1.0, float(one.abs().max()))
     finally:
         eng.set_clips_per_group(0)
+    with pytest.raises(Exception):
+        eng.set_clips_per_group(6)
 
 
 def test_vae_decode_fp32_vs_reference_golden(env):

@@ -57,6 +57,19 @@ def test_npz_writer_matches_reference_layout(tmp_path):
         subject2gender("nobody")
     z2 = np.load(write_sample(feats[:1], tmp_path / "rst_1", "miranda", betas=np.arange(300.0))[0], allow_pickle=True)
     assert str(z2["gender"]) == "female" and np.array_equal(z2["betas"], np.arange(300.0))
+    # default = the actor's own shape vector, bit-equal to what the reference's writer put into its committed sample
+    # outputs (tests/golden/sample_npz_betas.npz <- viz_dump/test/**/*_motion_smplx.npz; ldm_evals.py:348-379)
+    gold = np.load(GOLDEN / "sample_npz_betas.npz")
+    from amuse_amd.npz_writer import fetchbetas, subject2genderbeta
+    for actor in ("scott", "miranda"):
+        zz = np.load(write_sample(feats[:1], tmp_path / f"rst_{actor}", actor)[0], allow_pickle=True)
+        assert zz["betas"].dtype == np.float64 and np.array_equal(zz["betas"], gold[actor]), actor
+        assert str(zz["gender"]) == str(gold[actor + "_gender"])
+        g_, b_ = subject2genderbeta(actor)
+        assert g_.dtype == np.dtype("<U7") and np.array_equal(b_, gold[actor])
+    assert np.array_equal(z["betas"], gold["scott"])
+    with pytest.raises(NotImplementedError):                # zhang / jaime / kexin / hanieh have no fit (ldm_evals.py:362-376)
+        fetchbetas("zhang")
     assert np.all(z["trans"] == 0) and float(z["mocap_frame_rate"]) == 30.0
     assert np.all(z["poses"][:, LOWER_BODY_JOINTS] == z["poses"][0, LOWER_BODY_JOINTS])
     other = [j for j in range(55) if j not in LOWER_BODY_JOINTS]
@@ -201,3 +214,114 @@ def test_ast_checkpoint_choice_and_reader(tmp_path, monkeypatch):
     torch.save(sd, path)
     with pytest.raises(KeyError):
         ckpt.load_ast_checkpoint(path)
+
+
+def test_cli_config_is_merged_in_memory_like_scripts_main(tmp_path):
+    """amuse_amd.main.load_config == scripts/main.py:243-265 without the write-back: override YAML deep-merged over the
+    JSON (dicts recurse, leaves replace), the files on disk untouched."""
+    import hashlib
+
+    from conftest import make_reference_tree
+
+    from amuse_amd.main import load_config, merge_dicts
+    root = make_reference_tree(tmp_path / "amuse")
+    before = {p.name: hashlib.sha256(p.read_bytes()).hexdigest() for p in (root / "configs").iterdir()}
+    base, ldm = load_config(root, "infer_gesture")
+    tp = base["TRAIN_PARAM"]
+    assert tp["pretrained_infer"] is True and tp["wav_dtw_mfcc"]["ablation"] == "full"          # replaced leaves
+    assert tp["wav_dtw_mfcc"]["dataset_std"] == 5.062332 and tp["seed"] == 2024                # untouched siblings
+    assert tp["test"]["audio_list"]["use"] is True and tp["test"]["replication_times"] == 1
+    assert tp["latent_diffusion"]["pretrained_lpdm"] == "LPDM_test" and tp["latent_diffusion"]["smplx_rep"] == "6D"
+    assert base["DATA_PARAM"]["Bvh"] == {"train_pose_framelen": 300, "fps": 30, "bvh2smplbvh": False}
+    assert ldm["scheduler"]["num_inference_timesteps"] == 50 and ldm["scheduler"]["steps_offset"] == 1  # diff_o.yaml
+    assert ldm["scheduler"]["beta_end"] == 0.012 and ldm["noisy_scheduler"]["variance_type"] == "fixed_small"
+    edit, _ = load_config(root, "edit_gesture")
+    assert edit["TRAIN_PARAM"]["test"]["emotion_control_list"]["actor"] == "miranda"           # key absent from the JSON
+    assert edit["TRAIN_PARAM"]["test"]["audio_list"]["use"] is False
+    assert {p.name: hashlib.sha256(p.read_bytes()).hexdigest() for p in (root / "configs").iterdir()} == before
+    assert merge_dicts({"a": {"b": 1, "c": 2}, "d": 3}, {"a": {"b": {"x": 1}}, "e": 4}) == {"a": {"b": {"x": 1}, "c": 2}, "d": 3, "e": 4}
+    assert merge_dicts({"a": 1}, None) == {"a": 1}
+
+
+class _StubLPDM:
+    """Records diffusion_backward calls; poses carry the global clip index so that job -> clip mapping is checkable."""
+    def __init__(self):
+        self.device, self._clip_counter, self.calls = torch.device("cpu"), 0, []
+
+    def diffusion_backward(self, bsz, z_con, z_emo, z_sty, clip_index0=None, return_latents=False):
+        assert z_con.shape[0] == bsz
+        c0 = self._clip_counter if clip_index0 is None else clip_index0
+        if clip_index0 is None:
+            self._clip_counter += bsz
+        self.calls.append((bsz, c0, z_emo is None, z_sty is None))
+        idx = torch.arange(c0, c0 + bsz, dtype=torch.float32)
+        out = {"poses": idx[:, None, None, None] + z_con[:, :1, None, None].expand(bsz, 300, 55, 3) * 0,
+               "trans": torch.zeros(bsz, 300, 3)}
+        if return_latents:
+            out["latents"] = idx[:, None].expand(bsz, 128)
+        return out
+
+
+def test_edit_task_job_lists_follow_the_reference_order():
+    """emotion_control / style_transfer / style_Xemo_transfer job construction (trainer.py:559-631,705-772,839-901) and
+    the batched runner's clip bookkeeping, on a stub model."""
+    from amuse_amd.trainer import emotion_control_jobs, run_jobs, style_transfer_jobs, style_Xemo_transfer_jobs, subject_of
+    g = torch.Generator().manual_seed(0)
+    z = lambda n: torch.randn(n, 256, generator=g)
+    attr = lambda a: (a, "male", "native", "x", "30")
+
+    def take(a, n):
+        return {"ld_z": torch.zeros(n, 128), "ld_z_con": z(n), "ld_z_emo": z(n), "ld_z_sty": z(n), "ld_attr": attr(a),
+                "ld_wav": np.arange(n * 10000), "ld_motion": None}
+    # --- emotion control: 8 takes, every take gets the other 7 emotions (infer_ldm.py:403-410)
+    takes = ["0_9_9", "0_65_65", "0_73_73", "0_81_81", "0_87_87", "0_95_95", "0_103_103", "0_111_111"]
+    data = {"wayne": {t: take("wayne", 2 if i else 3) for i, t in enumerate(takes)}}
+    for t in takes:
+        for o in takes:
+            if o != t:
+                data["wayne"][t][f"ld_z_emo_{o}"] = data["wayne"][o]["ld_z_emo"]
+    jobs = emotion_control_jobs(data, "first")
+    assert len(jobs) == 64
+    assert jobs[0]["z_emo_key"] == "ld_z_emo" and jobs[0]["info"] == "wayne male native 30 yrs 9 original neutral"
+    assert jobs[1]["info"] == "wayne male native 30 yrs 9 swap emo happy in element first"
+    assert jobs[0]["bsz"] == 3 and jobs[1]["bsz"] == 2        # the swapped-in emotion latent is shorter ...
+    assert jobs[7]["bsz"] == 2 and jobs[7]["z_con"].shape[0] == 2 and len(jobs[7]["audio"]) == 20000   # ... and it sticks
+    assert subject_of(jobs[0]["info"]) == "wayne"
+    m = _StubLPDM()
+    m._clip_counter = 7
+    rst = run_jobs(m, jobs, return_latents=True)
+    total = sum(j["bsz"] for j in jobs)
+    assert len(m.calls) == 1 and m.calls[0][:2] == (total, 7) and m._clip_counter == 7 + total
+    off = 7
+    for j, r in zip(jobs, rst):
+        assert r["feats"].shape == (j["bsz"], 300, 168) and float(r["feats"][0, 0, 0]) == off and float(r["latents"][-1, 0]) == off + j["bsz"] - 1
+        off += j["bsz"]
+    m2 = _StubLPDM()
+    m2._clip_counter = 7
+    seq = run_jobs(m2, jobs, batched=False)
+    assert len(m2.calls) == 64 and all(torch.equal(a["feats"], b["feats"]) for a, b in zip(rst, seq))
+    # --- style transfer: "[lu-lawrence]" "[angry]" -> 8 jobs, originals then swaps per take; NB the crosswise keys
+    st = {a: {t: take(a, 2) for t in ("0_73_73", "0_74_74")} for a in ("lu", "lawrence")}
+    for t in ("0_73_73", "0_74_74"):
+        for a, b in (("lu", "lawrence"), ("lawrence", "lu")):
+            st[a][t][f"ld_z_sty_{b}"], st[a][t][f"ld_z_emo_{b}"] = st[b][t]["ld_z_emo"], st[b][t]["ld_z_sty"]
+    sj = style_transfer_jobs(st, "[lu-lawrence]", "[angry]")
+    assert [(j["actor"], j["take"], bool(j["swap_info"].startswith("Swapped"))) for j in sj] == \
+        [("lu", "0_73_73", False), ("lawrence", "0_73_73", False), ("lu", "0_73_73", True), ("lawrence", "0_73_73", True),
+         ("lu", "0_74_74", False), ("lawrence", "0_74_74", False), ("lu", "0_74_74", True), ("lawrence", "0_74_74", True)]
+    assert sj[2]["info"] == "Style Transfer - lu male native 30 yrs 73 angry" and torch.equal(sj[2]["z_emo"], st["lu"]["0_73_73"]["ld_z_emo_lawrence"])
+    assert sj[0]["swap_info"] == "Not swapped, original"
+    # --- style X emotion transfer: "[scott-lu]" "[happy-angry]"
+    sx = {a: {t: take(a, 1) for t in ("0_65_65", "0_73_73")} for a in ("scott", "lu")}
+    t1, t2 = "0_65_65", "0_73_73"
+    for (xa, xt), (ya, yt) in ((("scott", t1), ("lu", t2)), (("lu", t1), ("scott", t2)), (("scott", t2), ("lu", t1)), (("lu", t2), ("scott", t1))):
+        sx[xa][xt][f"ld_z_emo_{ya}_{yt}"], sx[xa][xt][f"ld_z_sty_{ya}_{yt}"] = sx[ya][yt]["ld_z_emo"], sx[ya][yt]["ld_z_sty"]
+    sx["takes"] = f"{t1}*{t2}*{t1}*{t2}"
+    xj = style_Xemo_transfer_jobs(sx, "[scott-lu]", "[happy-angry]")
+    assert len(xj) == 8 and xj[2]["swap_info"].startswith("Swapped") and torch.equal(xj[2]["z_sty"], sx["lu"][t2]["ld_z_sty"])
+    assert xj[7]["info"] == "Style X Emo Transfer - lu male native 30 yrs 73 happy-angry"
+    # jobs that drop a token are launched apart, clip indices still in job order
+    mixed = [dict(sj[0]), dict(sj[1], z_emo=None), dict(sj[2])]
+    m3 = _StubLPDM()
+    r3 = run_jobs(m3, mixed)
+    assert sorted(c[1] for c in m3.calls) == [0, 2, 4] and [float(r["feats"][0, 0, 0]) for r in r3] == [0.0, 2.0, 4.0]
