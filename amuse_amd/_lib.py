@@ -20,7 +20,7 @@ ABI_VERSION = 1
 EXPORTS = [
     "amuse_abi_version", "amuse_last_error", "amuse_create", "amuse_destroy", "amuse_set_schedule",
     "amuse_sample", "amuse_denoise_step", "amuse_diffusion_forward", "amuse_vae_decode", "amuse_vae_encode", "amuse_smplx_to_feats", "amuse_diffusion_backward",
-    "amuse_counter_normal", "amuse_set_clips_per_group", "amuse_profile_sample",
+    "amuse_counter_normal", "amuse_set_clips_per_group", "amuse_set_decode_path", "amuse_profile_sample",
     "amuse_audio_create", "amuse_audio_destroy", "amuse_audio_fbank", "amuse_audio_encode", "amuse_audio_features",
     "amuse_debug_gemm",
 ]
@@ -67,9 +67,11 @@ def load() -> C.CDLL:
     lib.amuse_diffusion_backward.argtypes = [vp, fp, fp, fp, C.c_int, C.c_int, C.c_int, u64, u64, fp, fp, fp, fp, fp, vp]
     lib.amuse_counter_normal.argtypes = [vp, u64, u64, C.c_int, C.c_int, C.c_int, fp, vp]
     lib.amuse_set_clips_per_group.argtypes = [vp, C.c_int]
+    lib.amuse_set_decode_path.argtypes = [vp, C.c_int]
     lib.amuse_profile_sample.argtypes = [vp, fp, fp, fp, C.c_int, C.c_int, C.c_int, fp, vp]
     for n in ("amuse_set_schedule", "amuse_sample", "amuse_denoise_step", "amuse_diffusion_forward", "amuse_vae_decode", "amuse_vae_encode", "amuse_smplx_to_feats",
-              "amuse_diffusion_backward", "amuse_counter_normal", "amuse_set_clips_per_group", "amuse_profile_sample"):
+              "amuse_diffusion_backward", "amuse_counter_normal", "amuse_set_clips_per_group", "amuse_set_decode_path",
+              "amuse_profile_sample"):
         getattr(lib, n).restype = C.c_int
     lib.amuse_audio_create.restype = vp
     lib.amuse_audio_create.argtypes = [C.c_int, fp, fp, fp, C.c_size_t, fp, fp, C.c_float, C.c_float, C.c_int]

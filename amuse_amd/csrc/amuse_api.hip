@@ -212,6 +212,7 @@ std::vector<float> transpose(const float* w, int rows, int cols) {  // [rows][co
 struct amuse_ctx {
     int device = 0;
     int clips_per_group = 0;
+    int decode_path = AMUSE_DECODE_AUTO;
     // denoiser
     uint4* den_w[2] = {nullptr, nullptr};
     uint32_t den_wave_units[2] = {0, 0};
@@ -227,6 +228,9 @@ struct amuse_ctx {
     uint4* vae_w[2] = {nullptr, nullptr};
     uint32_t vae_stage_base[2][kVaeStages];
     uint32_t vae_stage_units[2][kVaeStages];
+    uint4* vae_wf = nullptr;           // bf16 stream of the fused decode kernel (k_vae_fused.hip)
+    uint4* vae_skip = nullptr; size_t vae_skip_cap = 0;   // clips
+    float* vae_ca_ws = nullptr; size_t vae_ca_cap = 0;    // clips
     float *vae_pvec = nullptr, *vae_final_bias = nullptr, *vae_pe = nullptr;
     float *vae_wv_t = nullptr, *vae_bv = nullptr, *vae_wo_t = nullptr, *vae_bo = nullptr;
     // prior encoder (MotionPrior.encode)
@@ -371,6 +375,32 @@ int build_ctx(amuse_ctx* c, const float* den, const float* pri) {
         all.insert(all.end(), (size_t)kVaeRing * 64, uint4{0, 0, 0, 0});  // the last wave's ring reads past its slice
         if (upload(&c->vae_w[prec], all.data(), all.size() * sizeof(uint4))) return AMUSE_EHIP;
     }
+    {   // fused decode kernel (k_vae_fused.hip): ONE stream, identical for the four waves, in consumption order
+        std::vector<uint4> s;
+        for (int b = 0; b < 9; ++b) {
+            const std::string p = blk_name("decoder", b);
+            if (b >= 5) {   // skip linear ahead of an output block: the x half (k-tiles 0..7), then the popped-skip half
+                const float* wskip = Pp.get("decoder.linear_blocks." + std::to_string(b - 5) + ".weight");
+                pack_gemm(s, PREC_BF16, wskip, 128, 256, range(0, 8), range(0, 8));
+                pack_gemm(s, PREC_BF16, wskip, 128, 256, range(0, 8), range(8, 16));
+            }
+            const float* in_w = Pp.get(p + ".self_attn.in_proj_weight");
+            for (int h = 0; h < 4; ++h) {   // per head: k | v tiles per k-pair, then q, then out_proj's k-slice of the head
+                pack_gemm(s, PREC_BF16, in_w, 384, 128, {8 + 2 * h, 8 + 2 * h + 1, 16 + 2 * h, 16 + 2 * h + 1}, range(0, 8));
+                pack_gemm(s, PREC_BF16, in_w, 384, 128, {2 * h, 2 * h + 1}, range(0, 8));
+                pack_gemm(s, PREC_BF16, Pp.get(p + ".self_attn.out_proj.weight"), 128, 128, range(0, 8), {2 * h, 2 * h + 1});
+            }
+            for (int ch = 0; ch < 16; ++ch) {   // FFN in 16 chunks of 32 hidden features
+                pack_gemm(s, PREC_BF16, Pp.get(p + ".linear1.weight"), 512, 128, {2 * ch, 2 * ch + 1}, range(0, 8));
+                pack_gemm(s, PREC_BF16, Pp.get(p + ".linear2.weight"), 128, 512, range(0, 8), {2 * ch, 2 * ch + 1});
+            }
+        }
+        for (int j = 0; j < 5; ++j)   // final_layer once per row tile of a wave (24 output tiles in two halves)
+            for (int half = 0; half < 2; ++half)
+                pack_gemm(s, PREC_BF16, Pp.get("final_layer.weight"), kFeats, 128, range(12 * half, 12 * half + 12), range(0, 8));
+        s.insert(s.end(), (size_t)kVaeFusedRing * 64, uint4{0, 0, 0, 0});   // the ring runs past the end
+        if (upload(&c->vae_wf, s.data(), s.size() * sizeof(uint4))) return AMUSE_EHIP;
+    }
     {
         auto pv = build_pvec(Pp, "decoder", true);
         if (upload(&c->vae_pvec, pv.data(), pv.size() * 4)) return AMUSE_EHIP;
@@ -483,6 +513,18 @@ hipError_t dispatch_sample(const amuse_ctx* c, SampleArgs& a, int precision, hip
     return launch_sample(a, precision, st);
 }
 
+// decode path choice: the fused per-clip kernel (bf16 only) occupies one CU per clip, so it wins once there are enough
+// clips to fill a good part of the chip; below that the staged path's 19 workgroups per clip finish sooner.
+// AMUSE_VAE_FUSED=0 / 1 forces the staged / fused path (A/B measurements, tests of both paths).
+constexpr int kFusedMinClips = 24;
+constexpr int kVaeFusedChunk = 4096;
+bool use_vae_fused(const amuse_ctx* c, int precision, int B) {
+    static const int env = [] { const char* e = getenv("AMUSE_VAE_FUSED"); return e ? atoi(e) : -1; }();
+    const int force = c->decode_path == AMUSE_DECODE_STAGED ? 0 : c->decode_path == AMUSE_DECODE_FUSED ? 1 : env;
+    if (precision != PREC_BF16 || force == 0) return false;
+    return force == 1 || B >= kFusedMinClips;
+}
+
 int stage_lengths(amuse_ctx* c, const int* lengths, int B, hipStream_t st) {
     if (!lengths) return 0;
     for (int b = 0; b < B; ++b)
@@ -551,7 +593,7 @@ void amuse_destroy(amuse_ctx* c) {
                     c->vae_w[0], c->vae_w[1], c->vae_pvec, c->vae_final_bias, c->vae_pe, c->vae_wv_t, c->vae_bv,
                     c->vae_wo_t, c->vae_bo, c->vaee_w[0], c->vaee_w[1], c->vaee_pvec, c->vaee_pe, c->vaee_tok,
                     c->vaee_emb_bias, c->d_timesteps, c->d_coef, c->d_time_tok, c->d_ts1, c->d_tt1, c->d_coef1,
-                    c->cond_tok, c->lat_tmp, c->fwd_ws, c->vae_ws, c->d_lengths};
+                    c->cond_tok, c->lat_tmp, c->fwd_ws, c->vae_ws, c->d_lengths, c->vae_wf, c->vae_skip, c->vae_ca_ws};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     delete c;
@@ -561,6 +603,14 @@ int amuse_set_clips_per_group(amuse_ctx* c, int g) {
     if (!c) return fail(AMUSE_EINVAL, "ctx is NULL");
     if (g < 0 || g > 5) return fail(AMUSE_EINVAL, "clips per group must be 0 (auto) .. 5, got %d", g);
     c->clips_per_group = g;
+    return 0;
+}
+
+int amuse_set_decode_path(amuse_ctx* c, int path) {
+    if (!c) return fail(AMUSE_EINVAL, "ctx is NULL");
+    if (path != AMUSE_DECODE_AUTO && path != AMUSE_DECODE_STAGED && path != AMUSE_DECODE_FUSED)
+        return fail(AMUSE_EINVAL, "bad decode path %d", path);
+    c->decode_path = path;
     return 0;
 }
 
@@ -692,6 +742,30 @@ int amuse_vae_decode(amuse_ctx* c, const float* z, const int* lengths, int B, in
     HIP_TRY(hipSetDevice(c->device));
     hipStream_t st = (hipStream_t)stream;
     if (int e = stage_lengths(c, lengths, B, st)) return e;
+    if (use_vae_fused(c, precision, B)) {
+        // bf16 throughput mode from kFusedMinClips clips up: one persistent workgroup per clip (k_vae_fused.hip)
+        const int chunk = B < kVaeFusedChunk ? B : kVaeFusedChunk;
+        if (c->vae_skip_cap < (size_t)chunk) {
+            if (c->vae_skip) HIP_TRY(hipFree(c->vae_skip));
+            c->vae_skip = nullptr; c->vae_skip_cap = 0;
+            HIP_TRY(hipMalloc((void**)&c->vae_skip, (size_t)chunk * kVaeFusedSkipBytesPerClip));
+            c->vae_skip_cap = chunk;
+        }
+        if (int e = ensure(&c->vae_ca_ws, &c->vae_ca_cap, (size_t)chunk * kLayers * kD)) return e;
+        for (int b0 = 0; b0 < B; b0 += chunk) {
+            const int nb = (B - b0) < chunk ? (B - b0) : chunk;
+            HIP_TRY(launch_vae_ca(z + (size_t)b0 * kD, c->vae_wv_t, c->vae_bv, c->vae_wo_t, c->vae_bo, c->vae_ca_ws, nb, st));
+            VaeFusedArgs fa{};
+            fa.wstream = c->vae_wf; fa.pvec = c->vae_pvec; fa.final_bias = c->vae_final_bias; fa.pe = c->vae_pe;
+            fa.ca = c->vae_ca_ws; fa.lengths = lengths ? c->d_lengths + b0 : nullptr; fa.skip = c->vae_skip;
+            fa.feats_out = feats_out ? feats_out + (size_t)b0 * kFrames * kFeats : nullptr;
+            fa.poses_out = poses_out ? poses_out + (size_t)b0 * kFrames * kJoints * 3 : nullptr;
+            fa.trans_out = trans_out ? trans_out + (size_t)b0 * kFrames * 3 : nullptr;
+            fa.B = nb; fa.quat_mode = quat_mode;
+            HIP_TRY(launch_vae_fused(fa, st));
+        }
+        return 0;
+    }
     const int chunk = B < kVaeChunk ? B : kVaeChunk;
     if (int e = ensure_vae_ws(c, chunk)) return e;
     for (int b0 = 0; b0 < B; b0 += chunk) {

@@ -106,6 +106,24 @@ struct VaeAttnArgs {
     int q_tiles;                                      // query tiles to produce: 19, or 1 (last encoder block)
 };
 hipError_t launch_vae_attn(const VaeAttnArgs& a, int precision, bool enc, hipStream_t stream);
+// ---------------------------------------------------------------- fused decode (k_vae_fused.hip): one workgroup per clip
+constexpr int kVaeFusedRing = 16;
+constexpr int kVaeFusedLdsBytes = 4 * 16 * 388 * 4 + 2 * 1920 * 4;   // staging tiles (>= the two K/V images) + block params
+struct VaeFusedArgs {
+    const uint4* wstream;      // bf16 stream in consumption order (amuse_api.hip pack_vae_fused), identical for the 4 waves
+    const float* pvec;         // decoder small params, PV_* layout
+    const float* final_bias;   // [384]
+    const float* pe;           // query_pos_decoder.pe [500][128]
+    const float* ca;           // [B][9][128] cross-attention constant (k_vae_ca)
+    const int* lengths;        // dev [B] or null
+    uint4* skip;               // [B][4 levels][20 tiles][4 k-pairs][64 lanes] packed bf16 operands of the skip stack
+    float* feats_out;          // [B][300][333] or null
+    float* poses_out;          // [B][300][55][3] or null
+    float* trans_out;          // [B][300][3] or null
+    int B, quat_mode;
+};
+constexpr size_t kVaeFusedSkipBytesPerClip = 4 * 20 * 4 * 64 * 16;
+hipError_t launch_vae_fused(const VaeFusedArgs& a, hipStream_t stream);
 // feats[row][0:330] = first two rows of R(axis-angle) per joint, feats[row][330:333] = trans   (infer_ldm.py:459-464)
 hipError_t launch_smplx_to_feats(const float* poses, const float* trans, size_t nrows, float* feats, hipStream_t stream);
 // mu = stats[b][0], std = exp(stats[b][1]) ** 0.5, latent = mu + std * eps   (vae.py:209-213)

@@ -27,62 +27,9 @@ constexpr int kRowsLdsBytes = kCombBytes;
 static_assert(16 * kFeatStride * 4 <= kCombBytes, "staged feature tile must fit the combine buffers");
 constexpr int kVR = kVaeRing;       // weight-stream ring depth of k_vae_rows
 
-__device__ __forceinline__ void rot6d_to_axis_angle(const float* d6, int quat_mode, float (&aa)[3]) {
-    // rotation_6d_to_matrix (pytorch3d; vendored copy rotation_conversions.py:512-533)
-    const float a1x = d6[0], a1y = d6[1], a1z = d6[2], a2x = d6[3], a2y = d6[4], a2z = d6[5];
-    const float n1 = fmaxf(sqrtf(a1x * a1x + a1y * a1y + a1z * a1z), 1e-12f);
-    const float b1x = a1x / n1, b1y = a1y / n1, b1z = a1z / n1;
-    const float dt = b1x * a2x + b1y * a2y + b1z * a2z;
-    float b2x = a2x - dt * b1x, b2y = a2y - dt * b1y, b2z = a2z - dt * b1z;
-    const float n2 = fmaxf(sqrtf(b2x * b2x + b2y * b2y + b2z * b2z), 1e-12f);
-    b2x /= n2; b2y /= n2; b2z /= n2;
-    const float b3x = b1y * b2z - b1z * b2y, b3y = b1z * b2x - b1x * b2z, b3z = b1x * b2y - b1y * b2x;
-    const float m00 = b1x, m01 = b1y, m02 = b1z, m10 = b2x, m11 = b2y, m12 = b2z, m20 = b3x, m21 = b3y, m22 = b3z;
-    float qw, qx, qy, qz;
-    if (quat_mode == 1) {  // legacy snapshot: rotation_conversions.py:97-119
-        qw = 0.5f * sqrtf(fmaxf(0.f, 1.f + m00 + m11 + m22));
-        qx = 0.5f * sqrtf(fmaxf(0.f, 1.f + m00 - m11 - m22));
-        qy = 0.5f * sqrtf(fmaxf(0.f, 1.f - m00 + m11 - m22));
-        qz = 0.5f * sqrtf(fmaxf(0.f, 1.f - m00 - m11 + m22));
-        if ((qx < 0.f) != ((m21 - m12) < 0.f)) qx = -qx;
-        if ((qy < 0.f) != ((m02 - m20) < 0.f)) qy = -qy;
-        if ((qz < 0.f) != ((m10 - m01) < 0.f)) qz = -qz;
-    } else {  // pytorch3d >= 0.5: best-conditioned of four candidates, no sign standardisation
-        const float qa0 = sqrtf(fmaxf(0.f, 1.f + m00 + m11 + m22)), qa1 = sqrtf(fmaxf(0.f, 1.f + m00 - m11 - m22));
-        const float qa2 = sqrtf(fmaxf(0.f, 1.f - m00 + m11 - m22)), qa3 = sqrtf(fmaxf(0.f, 1.f - m00 - m11 + m22));
-        int best = 0;
-        float qb = qa0;
-        if (qa1 > qb) { qb = qa1; best = 1; }
-        if (qa2 > qb) { qb = qa2; best = 2; }
-        if (qa3 > qb) { qb = qa3; best = 3; }
-        const float den = 2.0f * fmaxf(qb, 0.1f);
-        if (best == 0) { qw = qa0 * qa0; qx = m21 - m12; qy = m02 - m20; qz = m10 - m01; }
-        else if (best == 1) { qw = m21 - m12; qx = qa1 * qa1; qy = m10 + m01; qz = m02 + m20; }
-        else if (best == 2) { qw = m02 - m20; qx = m10 + m01; qy = qa2 * qa2; qz = m12 + m21; }
-        else { qw = m10 - m01; qx = m20 + m02; qy = m21 + m12; qz = qa3 * qa3; }
-        qw /= den; qx /= den; qy /= den; qz /= den;
-    }
-    // quaternion_to_axis_angle (rotation_conversions.py:480-509)
-    const float nrm = sqrtf(qx * qx + qy * qy + qz * qz);
-    const float half = atan2f(nrm, qw);
-    const float ang = 2.0f * half;
-    const float s = (fabsf(ang) < 1e-6f) ? (0.5f - (ang * ang) / 48.0f) : (sinf(half) / ang);
-    aa[0] = qx / s; aa[1] = qy / s; aa[2] = qz / s;
-}
-
 // ENC = false: MotionPrior.decode rows (S = 300).  ENC = true: MotionPrior.encode rows (vae.py:154-214): S = 302 =
 // [2 distribution tokens | 300 embedded frames], TransformerEncoderLayer blocks (no cross-attention, two norms),
 // stage 0 = skel_embedding + token concat + PE, last stage = encoder.norm of the two distribution rows only.
-// four floats <-> four bf16 (round-to-nearest-even, v_cvt_pk_bf16_f32; widening is exact)
-__device__ __forceinline__ uint2 f32_to_bf16x4(f32x4 v) {
-    const uint4 u = __builtin_bit_cast(uint4, pack_bf16(v, splat4(0.f)));
-    return uint2{u.x, u.y};
-}
-__device__ __forceinline__ f32x4 bf16x4_to_f32(uint2 u) {
-    return f32x4{__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u), __uint_as_float(u.y << 16),
-                 __uint_as_float(u.y & 0xffff0000u)};
-}
-
 template <int PREC, bool ENC>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_vae_rows(VaeRowsArgs a) {
     constexpr int S = ENC ? kFrames + 2 : kFrames;

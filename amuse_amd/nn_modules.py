@@ -1,0 +1,209 @@
+"""Autograd twins of the two networks on the hot path, for the train_gesture step (BASELINE config 4): `Denoiser`
+(reference models/latent_diffusion/denoiser.py:16-204, trans_enc + learned PE) and `MotionPrior`
+(models/latent_diffusion/vae.py:24-278, encoder_decoder).  Plain torch modules - training is not the accelerated path
+(the HIP kernels are inference-only); what matters here is that
+
+  * `state_dict()` has exactly the reference's keys and shapes (tests/golden/state_dict_spec.json), so checkpoints written
+    by either side load in the other and in the HIP engine (amuse_amd/checkpoint.py, amuse_update_weights), and
+  * the forward pass IS the reference's, dropout included (cross_attention.py:259-272,323-345: attention dropout inside
+    nn.MultiheadAttention, dropout1/2/3 on the residual branches, dropout between the FFN linears) - pinned in eval mode
+    against the golden vectors of the reference modules (tests/test_train_cpu.py).
+"""
+from __future__ import annotations
+
+import math
+from typing import List, Optional, Sequence
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+D, H, FF, L, COND, NFEATS, PE_LEN = 128, 4, 512, 9, 256, 333, 500
+
+
+class LearnedPE(nn.Module):
+    """position_encoding.py:138-159 (PositionEmbeddingLearned1D, sequence-first): x + pe[:len(x)]."""
+
+    def __init__(self, d_model=D, max_len=PE_LEN):
+        super().__init__()
+        self.pe = nn.Parameter(torch.zeros(max_len, 1, d_model))
+        nn.init.uniform_(self.pe)
+
+    def forward(self, x):
+        return x + self.pe[: x.shape[0]]
+
+
+class EncoderLayer(nn.Module):
+    """cross_attention.py:236-272, forward_post (normalize_before False), activation gelu (exact erf)."""
+
+    def __init__(self, d=D, h=H, ff=FF, p=0.1):
+        super().__init__()
+        self.self_attn = nn.MultiheadAttention(d, h, dropout=p)
+        self.linear1, self.linear2 = nn.Linear(d, ff), nn.Linear(ff, d)
+        self.dropout, self.dropout1, self.dropout2 = nn.Dropout(p), nn.Dropout(p), nn.Dropout(p)
+        self.norm1, self.norm2 = nn.LayerNorm(d), nn.LayerNorm(d)
+
+    def forward(self, src, key_padding_mask=None):
+        src2 = self.self_attn(src, src, src, key_padding_mask=key_padding_mask, need_weights=False)[0]
+        src = self.norm1(src + self.dropout1(src2))
+        src2 = self.linear2(self.dropout(F.gelu(self.linear1(src))))
+        return self.norm2(src + self.dropout2(src2))
+
+
+class DecoderLayer(nn.Module):
+    """cross_attention.py:297-345, forward_post: self-attention, cross-attention onto `memory`, FFN; three norms."""
+
+    def __init__(self, d=D, h=H, ff=FF, p=0.1):
+        super().__init__()
+        self.self_attn = nn.MultiheadAttention(d, h, dropout=p)
+        self.multihead_attn = nn.MultiheadAttention(d, h, dropout=p)
+        self.linear1, self.linear2 = nn.Linear(d, ff), nn.Linear(ff, d)
+        self.dropout, self.dropout1, self.dropout2, self.dropout3 = (nn.Dropout(p) for _ in range(4))
+        self.norm1, self.norm2, self.norm3 = nn.LayerNorm(d), nn.LayerNorm(d), nn.LayerNorm(d)
+
+    def forward(self, tgt, memory, tgt_key_padding_mask=None):
+        t2 = self.self_attn(tgt, tgt, tgt, key_padding_mask=tgt_key_padding_mask, need_weights=False)[0]
+        tgt = self.norm1(tgt + self.dropout1(t2))
+        t2 = self.multihead_attn(tgt, memory, memory, need_weights=False)[0]
+        tgt = self.norm2(tgt + self.dropout2(t2))
+        t2 = self.linear2(self.dropout(F.gelu(self.linear1(tgt))))
+        return self.norm3(tgt + self.dropout3(t2))
+
+
+class SkipStack(nn.Module):
+    """SkipTransformerEncoder / SkipTransformerDecoder (cross_attention.py:18-125): 4 input blocks whose outputs are
+    stacked, a middle block, 4 output blocks each preceded by Linear(cat(x, stack.pop())), final LayerNorm."""
+
+    def __init__(self, make_layer, num_layers=L, d=D):
+        super().__init__()
+        assert num_layers % 2 == 1
+        n = (num_layers - 1) // 2
+        self.input_blocks = nn.ModuleList(make_layer() for _ in range(n))
+        self.middle_block = make_layer()
+        self.output_blocks = nn.ModuleList(make_layer() for _ in range(n))
+        self.linear_blocks = nn.ModuleList(nn.Linear(2 * d, d) for _ in range(n))
+        self.norm = nn.LayerNorm(d)
+        for p in self.parameters():                       # _reset_parameters (cross_attention.py:36-39)
+            if p.dim() > 1:
+                nn.init.xavier_uniform_(p)
+
+    def forward(self, x, *args, **kw):
+        xs = []
+        for m in self.input_blocks:
+            x = m(x, *args, **kw)
+            xs.append(x)
+        x = self.middle_block(x, *args, **kw)
+        for m, lin in zip(self.output_blocks, self.linear_blocks):
+            x = lin(torch.cat([x, xs.pop()], dim=-1))
+            x = m(x, *args, **kw)
+        return self.norm(x)
+
+
+class TimestepEmbedding(nn.Module):
+    """embeddings.py:269-322: Linear -> SiLU -> Linear."""
+
+    def __init__(self, channel=COND, time_embed_dim=D):
+        super().__init__()
+        self.linear_1 = nn.Linear(channel, time_embed_dim)
+        self.linear_2 = nn.Linear(time_embed_dim, time_embed_dim)
+
+    def forward(self, sample):
+        return self.linear_2(F.silu(self.linear_1(sample)))
+
+
+def timestep_sinusoid(timesteps: torch.Tensor, dim=COND) -> torch.Tensor:
+    """Timesteps(256, flip_sin_to_cos=True, freq_shift=0) (embeddings.py:245-267 -> get_timestep_embedding): [cos | sin]."""
+    half = dim // 2
+    exponent = -math.log(10000) * torch.arange(0, half, dtype=torch.float32, device=timesteps.device) / (half - 0)
+    emb = timesteps[:, None].float() * torch.exp(exponent)[None, :]
+    return torch.cat([torch.cos(emb), torch.sin(emb)], dim=-1)
+
+
+class Denoiser(nn.Module):
+    """denoiser.py:16-204, arch trans_enc with skip connections, pe_type mld / learned.  130 state-dict entries."""
+
+    def __init__(self, dropout=0.1):
+        super().__init__()
+        self.time_embedding = TimestepEmbedding()
+        self.emb_proj_con = nn.Sequential(nn.ReLU(), nn.Linear(COND, D))
+        self.emb_proj_emo = nn.Sequential(nn.ReLU(), nn.Linear(COND, D))
+        self.emb_proj_sty = nn.Sequential(nn.ReLU(), nn.Linear(COND, D))
+        self.query_pos, self.mem_pos = LearnedPE(), LearnedPE()
+        self.encoder = SkipStack(lambda: EncoderLayer(p=dropout))
+
+    def forward(self, sample, timestep, con_hidden, emo_hidden=None, sty_hidden=None, lengths=None, **kw):
+        """sample (B, 1, 128); timestep (B,) or scalar; *_hidden (B, 256) -> (eps_hat (B, 1, 128),)   (denoiser.py:135-204)."""
+        sample = sample.permute(1, 0, 2)                                   # (1, B, 128)
+        bsz = sample.shape[1]
+        timesteps = torch.as_tensor(timestep, device=sample.device).expand(bsz)
+        time_emb = self.time_embedding(timestep_sinusoid(timesteps).to(sample.dtype)).unsqueeze(0)
+        toks = [time_emb, self.emb_proj_con(con_hidden).unsqueeze(0)]
+        if emo_hidden is not None:
+            toks.append(self.emb_proj_emo(emo_hidden).unsqueeze(0))
+        if sty_hidden is not None:
+            toks.append(self.emb_proj_sty(sty_hidden).unsqueeze(0))
+        xseq = self.query_pos(torch.cat([sample] + toks, dim=0))          # (S, B, 128), latent token first
+        tokens = self.encoder(xseq)
+        return (tokens[: sample.shape[0]].permute(1, 0, 2),)
+
+
+def lengths_to_mask(lengths: Sequence[int], device, max_len: Optional[int] = None) -> torch.Tensor:
+    """temos_utils.py: True where the frame is valid."""
+    lengths = torch.as_tensor(list(lengths), device=device)
+    max_len = max_len or int(lengths.max())
+    return torch.arange(max_len, device=device)[None, :] < lengths[:, None]
+
+
+class MotionPrior(nn.Module):
+    """vae.py:24-278 (emotional prior with finger joints: 333 features, 1 latent token, mld learned PE)."""
+
+    def __init__(self, dropout=0.1):
+        super().__init__()
+        self.global_motion_token = nn.Parameter(torch.randn(2, D))
+        self.query_pos_encoder, self.query_pos_decoder = LearnedPE(), LearnedPE()
+        self.encoder = SkipStack(lambda: EncoderLayer(p=dropout))
+        self.decoder = SkipStack(lambda: DecoderLayer(p=dropout))
+        self.skel_embedding = nn.Linear(NFEATS, D)
+        self.final_layer = nn.Linear(D, NFEATS)
+
+    def encode(self, features, lengths: Optional[List[int]] = None):
+        """features (B, T, 333) -> (latent (1, B, 128) = dist.rsample(), dist = Normal(mu, exp(logvar) ** 0.5))   (vae.py:154-214)."""
+        if lengths is None:
+            lengths = [features.shape[1]] * features.shape[0]
+        bs, nframes, _ = features.shape
+        mask = lengths_to_mask(lengths, features.device, nframes)
+        x = self.skel_embedding(features).permute(1, 0, 2)                 # (T, B, 128)
+        dist = self.global_motion_token[:, None, :].expand(-1, bs, -1)     # (2, B, 128)
+        aug_mask = torch.cat([torch.ones(bs, 2, dtype=torch.bool, device=x.device), mask], 1)
+        xseq = self.query_pos_encoder(torch.cat([dist, x], 0))
+        out = self.encoder(xseq, key_padding_mask=~aug_mask)[:2]
+        mu, logvar = out[0:1], out[1:2]
+        std = logvar.exp().pow(0.5)
+        d = torch.distributions.Normal(mu, std)
+        return d.rsample(), d
+
+    def decode(self, z, lengths: List[int]):
+        """z (1, B, 128) -> feats (B, T, 333), frames beyond a clip's length zeroed   (vae.py:216-278)."""
+        mask = lengths_to_mask(lengths, z.device)
+        bs, nframes = mask.shape
+        queries = self.query_pos_decoder(torch.zeros(nframes, bs, D, device=z.device, dtype=z.dtype))
+        out = self.decoder(queries, z, tgt_key_padding_mask=~mask)
+        out = self.final_layer(out)
+        out = out.masked_fill(~mask.T[:, :, None], 0.0)
+        return out.permute(1, 0, 2)
+
+
+def load_numpy_state(module: nn.Module, sd) -> nn.Module:
+    """Copy a {name: ndarray} state dict (amuse_amd/weights.py, checkpoint.py) into the module; keys / shapes must match."""
+    own = module.state_dict()
+    assert set(own) == set(sd), (sorted(set(own) ^ set(sd))[:6])
+    with torch.no_grad():
+        for k, v in own.items():
+            t = torch.as_tensor(sd[k])
+            assert tuple(t.shape) == tuple(v.shape), (k, tuple(t.shape), tuple(v.shape))
+            v.copy_(t)
+    return module
+
+
+def numpy_state(module: nn.Module):
+    return {k: v.detach().cpu().numpy().copy() for k, v in module.state_dict().items()}

@@ -179,6 +179,14 @@ int amuse_profile_sample(amuse_ctx* ctx, const float* con, const float* emo, con
  * (a clip's slot inside its tile decides the rounding of its attention sums); amuse_amd/shard.py applies that rule. */
 int amuse_set_clips_per_group(amuse_ctx* ctx, int g);
 
+/* Which kernels amuse_vae_decode (and amuse_diffusion_backward) use in bf16 mode.  AUTO: the fused per-clip kernel
+ * (csrc/k_vae_fused.hip: one persistent workgroup per clip, residual stream in registers, K/V of the current head in LDS)
+ * from 24 clips up, the staged kernels (csrc/k_vae.hip) below that; fp32 mode always runs the staged kernels.  Both
+ * compute MotionPrior.decode (vae.py:216-278) with bf16 MFMA operands and fp32 accumulation / residual stream; they differ
+ * in summation order only.  The environment variable AMUSE_VAE_FUSED=0 / 1 overrides AUTO for a whole process. */
+enum { AMUSE_DECODE_AUTO = 0, AMUSE_DECODE_STAGED = 1, AMUSE_DECODE_FUSED = 2 };
+int amuse_set_decode_path(amuse_ctx* ctx, int path);
+
 /* ------------------------------------------------------------------------------------------------
  * Audio front-end: replaces PretrainedLPDM_v1.process_single_seq
  * (models/latent_diffusion/infer_ldm.py:180-193) = torchaudio.compliance.kaldi.fbank -> zero-pad / crop to 1024
