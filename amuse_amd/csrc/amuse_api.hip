@@ -194,9 +194,10 @@ void pack_skiplin(std::vector<uint4>& s, int prec, const Params& P, const std::s
               range(4 * w, 4 * w + 4));
 }
 
+// first call allocates; later calls (amuse_update_weights: same architecture, same sizes) overwrite in place
 template <typename T>
 int upload(T** dst, const void* src, size_t bytes) {
-    HIP_TRY(hipMalloc((void**)dst, bytes));
+    if (!*dst) HIP_TRY(hipMalloc((void**)dst, bytes));
     HIP_TRY(hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice));
     return 0;
 }
@@ -267,11 +268,12 @@ int ensure(float** p, size_t* cap, size_t need_floats) {
     return 0;
 }
 
-int build_ctx(amuse_ctx* c, const float* den, const float* pri) {
-    static const ParamIndex DI = denoiser_index(), PI = prior_index();
-    const Params D{DI, den}, Pp{PI, pri};
+int build_denoiser(amuse_ctx* c, const float* den, int what = 7) {
+    static const ParamIndex DI = denoiser_index();
+    const Params D{DI, den};
     // ---- denoiser weight streams: [wave][per-step units]
     for (int prec = 0; prec < 2; ++prec) {
+        if (!(what & (1 << prec))) continue;   // amuse_update_weights: only the requested precisions are re-packed
         std::vector<uint4> all;
         size_t per_wave = 0;
         for (int w = 0; w < 4; ++w) {
@@ -293,7 +295,7 @@ int build_ctx(amuse_ctx* c, const float* den, const float* pri) {
         c->den_wave_units[prec] = (uint32_t)(per_wave / 64);
         if (upload(&c->den_w[prec], all.data(), all.size() * sizeof(uint4))) return AMUSE_EHIP;
     }
-    {   // 8-wave bf16 kernel: wave w8 = 4 s + h; A waves (s = 0) carry head h + FFN quarters 0,1, B waves quarters 2,3
+    if (what & 2) {   // 8-wave bf16 kernel: wave w8 = 4 s + h; A waves (s = 0) carry head h + FFN quarters 0,1, B waves quarters 2,3
         std::vector<uint4> all;
         for (int w8 = 0; w8 < 8; ++w8) {
             const int h = w8 & 3, sgrp = w8 >> 2;
@@ -351,8 +353,15 @@ int build_ctx(amuse_ctx* c, const float* den, const float* pri) {
                 return AMUSE_EHIP;
         }
     }
+    return 0;
+}
+
+int build_prior(amuse_ctx* c, const float* pri, int what = 7) {
+    static const ParamIndex PI = prior_index();
+    const Params Pp{PI, pri};
     // ---- VAE decoder weight streams: [stage][wave][units]
     for (int prec = 0; prec < 2; ++prec) {
+        if (!(what & (1 << prec))) continue;
         std::vector<uint4> all;
         for (int st = 0; st < kVaeStages; ++st) {
             c->vae_stage_base[prec][st] = (uint32_t)(all.size() / 64);
@@ -375,8 +384,10 @@ int build_ctx(amuse_ctx* c, const float* den, const float* pri) {
         all.insert(all.end(), (size_t)kVaeRing * 64, uint4{0, 0, 0, 0});  // the last wave's ring reads past its slice
         if (upload(&c->vae_w[prec], all.data(), all.size() * sizeof(uint4))) return AMUSE_EHIP;
     }
-    {   // fused decode kernel (k_vae_fused.hip): ONE stream, identical for the four waves, in consumption order
+    if (what & 2) {   // fused decode kernel (k_vae_fused.hip): ONE stream for the four waves, in consumption order, cut
+        // into stages of kVaeFusedStageUnits units (every phase below is a whole number of stages)
         std::vector<uint4> s;
+        const auto pad = [&](int units) { s.insert(s.end(), (size_t)units * 64, uint4{0, 0, 0, 0}); };
         for (int b = 0; b < 9; ++b) {
             const std::string p = blk_name("decoder", b);
             if (b >= 5) {   // skip linear ahead of an output block: the x half (k-tiles 0..7), then the popped-skip half
@@ -385,20 +396,24 @@ int build_ctx(amuse_ctx* c, const float* den, const float* pri) {
                 pack_gemm(s, PREC_BF16, wskip, 128, 256, range(0, 8), range(8, 16));
             }
             const float* in_w = Pp.get(p + ".self_attn.in_proj_weight");
-            for (int h = 0; h < 4; ++h) {   // per head: k | v tiles per k-pair, then q, then out_proj's k-slice of the head
+            for (int h = 0; h < 4; ++h) {   // per head: stage A = k | v tiles per k-pair; stage B = q, out_proj's k-slice
                 pack_gemm(s, PREC_BF16, in_w, 384, 128, {8 + 2 * h, 8 + 2 * h + 1, 16 + 2 * h, 16 + 2 * h + 1}, range(0, 8));
                 pack_gemm(s, PREC_BF16, in_w, 384, 128, {2 * h, 2 * h + 1}, range(0, 8));
                 pack_gemm(s, PREC_BF16, Pp.get(p + ".self_attn.out_proj.weight"), 128, 128, range(0, 8), {2 * h, 2 * h + 1});
             }
-            for (int ch = 0; ch < 16; ++ch) {   // FFN in 16 chunks of 32 hidden features
-                pack_gemm(s, PREC_BF16, Pp.get(p + ".linear1.weight"), 512, 128, {2 * ch, 2 * ch + 1}, range(0, 8));
-                pack_gemm(s, PREC_BF16, Pp.get(p + ".linear2.weight"), 128, 512, range(0, 8), {2 * ch, 2 * ch + 1});
-            }
+            // FFN in 16 chunks of 32 hidden features, software-pipelined: [linear1(0) | pad], 15 x [linear1(i + 1) | linear2(i)],
+            // [linear2(15) | pad]
+            const auto f1 = [&](int ch) { pack_gemm(s, PREC_BF16, Pp.get(p + ".linear1.weight"), 512, 128, {2 * ch, 2 * ch + 1}, range(0, 8)); };
+            const auto f2 = [&](int ch) { pack_gemm(s, PREC_BF16, Pp.get(p + ".linear2.weight"), 128, 512, range(0, 8), {2 * ch, 2 * ch + 1}); };
+            f1(0); pad(8);
+            for (int ch = 0; ch < 15; ++ch) { f1(ch + 1); f2(ch); }
+            f2(15); pad(8);
         }
-        for (int j = 0; j < 5; ++j)   // final_layer once per row tile of a wave (24 output tiles in two halves)
+        for (int j = 0; j < 5; ++j)   // final_layer once per row tile of a wave (24 output tiles in two halves of 3 stages)
             for (int half = 0; half < 2; ++half)
                 pack_gemm(s, PREC_BF16, Pp.get("final_layer.weight"), kFeats, 128, range(12 * half, 12 * half + 12), range(0, 8));
-        s.insert(s.end(), (size_t)kVaeFusedRing * 64, uint4{0, 0, 0, 0});   // the ring runs past the end
+        if (s.size() % ((size_t)kVaeFusedStageUnits * 64) != 0) return fail(AMUSE_ESTATE, "internal: fused decode stream is not whole stages");
+        pad(2 * kVaeFusedStageUnits);   // the fetch runs two stages ahead
         if (upload(&c->vae_wf, s.data(), s.size() * sizeof(uint4))) return AMUSE_EHIP;
     }
     {
@@ -425,6 +440,7 @@ int build_ctx(amuse_ctx* c, const float* den, const float* pri) {
     // ---- VAE encoder weight streams: stage 0 = skel_embedding (K = 333 padded to 22 k-tiles, 2 output tiles per wave)
     // + in_proj(0); stage i+1 = post-attention of block i (+ skip linear) + in_proj(i+1); stage 9 = post-attention of block 8
     for (int prec = 0; prec < 2; ++prec) {
+        if (!(what & (1 << prec)) || !(what & 4)) continue;
         std::vector<uint4> all;
         for (int st = 0; st < kVaeStages; ++st) {
             c->vaee_stage_base[prec][st] = (uint32_t)(all.size() / 64);
@@ -455,6 +471,12 @@ int build_ctx(amuse_ctx* c, const float* den, const float* pri) {
             upload(&c->vaee_emb_bias, Pp.get("skel_embedding.bias"), 128 * 4))
             return AMUSE_EHIP;
     }
+    return 0;
+}
+
+int build_ctx(amuse_ctx* c, const float* den, const float* pri) {
+    if (int e = build_denoiser(c, den)) return e;
+    if (int e = build_prior(c, pri)) return e;
     HIP_TRY(hipMalloc((void**)&c->d_timesteps, AMUSE_MAX_STEPS * sizeof(int)));
     HIP_TRY(hipMalloc((void**)&c->d_coef, AMUSE_MAX_STEPS * 8 * sizeof(float)));
     HIP_TRY(hipMalloc((void**)&c->d_time_tok, AMUSE_MAX_STEPS * kD * sizeof(float)));
@@ -516,7 +538,7 @@ hipError_t dispatch_sample(const amuse_ctx* c, SampleArgs& a, int precision, hip
 // decode path choice: the fused per-clip kernel (bf16 only) occupies one CU per clip, so it wins once there are enough
 // clips to fill a good part of the chip; below that the staged path's 19 workgroups per clip finish sooner.
 // AMUSE_VAE_FUSED=0 / 1 forces the staged / fused path (A/B measurements, tests of both paths).
-constexpr int kFusedMinClips = 24;
+constexpr int kFusedMinClips = 96;   // measured: fused 0.80 ms for any B <= 256; staged 0.67 ms at 64 clips, 1.09 ms at 128
 constexpr int kVaeFusedChunk = 4096;
 bool use_vae_fused(const amuse_ctx* c, int precision, int B) {
     static const int env = [] { const char* e = getenv("AMUSE_VAE_FUSED"); return e ? atoi(e) : -1; }();
@@ -583,6 +605,26 @@ amuse_ctx* amuse_create(int device, const float* denoiser_params, size_t n_denoi
     c->device = device;
     if (build_ctx(c, denoiser_params, prior_params) != 0) { amuse_destroy(c); return nullptr; }
     return c;
+}
+
+int amuse_update_weights(amuse_ctx* c, const float* denoiser_params, size_t n_denoiser, const float* prior_params,
+                         size_t n_prior, int what, void* stream) {
+    if (!c) return fail(AMUSE_EINVAL, "ctx is NULL");
+    if (!denoiser_params && !prior_params) return fail(AMUSE_EINVAL, "nothing to update");
+    if (what < 1 || what > 7 || !(what & 3)) return fail(AMUSE_EINVAL, "bad `what` mask %d", what);
+    if (denoiser_params && n_denoiser != AMUSE_DENOISER_PARAMS)
+        return fail(AMUSE_EINVAL, "denoiser parameter count %zu (want %u)", n_denoiser, AMUSE_DENOISER_PARAMS);
+    if (prior_params && n_prior != AMUSE_PRIOR_PARAMS)
+        return fail(AMUSE_EINVAL, "prior parameter count %zu (want %u)", n_prior, AMUSE_PRIOR_PARAMS);
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize((hipStream_t)stream));   // kernels in flight still read the old streams
+    if (denoiser_params) {
+        if (int e = build_denoiser(c, denoiser_params, what)) return e;
+        c->T = 0;   // the hoisted time-token table belongs to the old time-embedding weights: set the schedule again
+    }
+    if (prior_params)
+        if (int e = build_prior(c, prior_params, what)) return e;
+    return 0;
 }
 
 void amuse_destroy(amuse_ctx* c) {
@@ -751,7 +793,7 @@ int amuse_vae_decode(amuse_ctx* c, const float* z, const int* lengths, int B, in
             HIP_TRY(hipMalloc((void**)&c->vae_skip, (size_t)chunk * kVaeFusedSkipBytesPerClip));
             c->vae_skip_cap = chunk;
         }
-        if (int e = ensure(&c->vae_ca_ws, &c->vae_ca_cap, (size_t)chunk * kLayers * kD)) return e;
+        if (int e = ensure(&c->vae_ca_ws, &c->vae_ca_cap, (size_t)chunk * kLayers * kD + 256)) return e;   // + the DMA's overrun
         for (int b0 = 0; b0 < B; b0 += chunk) {
             const int nb = (B - b0) < chunk ? (B - b0) : chunk;
             HIP_TRY(launch_vae_ca(z + (size_t)b0 * kD, c->vae_wv_t, c->vae_bv, c->vae_wo_t, c->vae_bo, c->vae_ca_ws, nb, st));

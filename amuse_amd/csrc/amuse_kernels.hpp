@@ -107,14 +107,14 @@ struct VaeAttnArgs {
 };
 hipError_t launch_vae_attn(const VaeAttnArgs& a, int precision, bool enc, hipStream_t stream);
 // ---------------------------------------------------------------- fused decode (k_vae_fused.hip): one workgroup per clip
-constexpr int kVaeFusedRing = 16;
-constexpr int kVaeFusedLdsBytes = 4 * 16 * 388 * 4 + 2 * 1920 * 4;   // staging tiles (>= the two K/V images) + block params
+constexpr int kVaeFusedStageUnits = 16;   // the weight stream is consumed in 16 KiB stages (LDS-DMA ring of three)
+constexpr int kVaeFusedLdsBytes = 2 * 40960 + 3 * 16384 + 2 * 8192 + 5120;   // K/V images | weight ring | block params | ca
 struct VaeFusedArgs {
-    const uint4* wstream;      // bf16 stream in consumption order (amuse_api.hip pack_vae_fused), identical for the 4 waves
+    const uint4* wstream;      // bf16 stream in consumption order, whole stages (amuse_api.hip), shared by the 4 waves
     const float* pvec;         // decoder small params, PV_* layout
     const float* final_bias;   // [384]
     const float* pe;           // query_pos_decoder.pe [500][128]
-    const float* ca;           // [B][9][128] cross-attention constant (k_vae_ca)
+    const float* ca;           // [B][9][128] cross-attention constant (k_vae_ca); readable 512 B past the end
     const int* lengths;        // dev [B] or null
     uint4* skip;               // [B][4 levels][20 tiles][4 k-pairs][64 lanes] packed bf16 operands of the skip stack
     float* feats_out;          // [B][300][333] or null

@@ -6,75 +6,152 @@
 // residual stream through HBM between launches (79 MB per attention launch at 256 clips, more than the 32 MB of L2) and
 // re-streams a block's 393 KB of weights once per 16-row tile.  Here a clip never leaves its CU:
 //
-//   * workgroup = one clip = 4 waves, ONE per SIMD (512 registers each); wave w owns the five 16-row tiles w, w+4, .., w+16
-//     (19 real tiles; the 20th is padding that costs nothing - every wave does five) and keeps their fp32 residual stream in
+//   * workgroup = one clip = 8 waves, TWO per SIMD (256 registers each): waves w and w+4 share SIMD w and split its five
+//     16-row tiles 3 + 2 (wave w < 4: tiles w, w+4, w+8; wave w >= 4: tiles w+8, w+12; 19 real tiles, the 20th is padding),
+//     so every SIMD carries the same work and its two waves fill each other's LDS / MFMA-to-VALU / dependency stalls (a
+//     first version with ONE 512-register wave per SIMD and five tiles each ran at a quarter of its instruction-issue
+//     bound: nothing covers a lone wave's stalls).  A wave keeps its tiles' fp32 residual stream in
 //     registers for the whole network, in the row-lane layout of amuse_dev.hpp (accumulators of one GEMM are the operands
 //     of the next).  Row work (projections, FFN, LayerNorm, skip linears, final layer) needs no other wave: no split-K, no
 //     combine, no exchange.
-//   * every weight unit (1 KiB MFMA A-fragment) a wave pulls from L2 feeds FIVE MFMAs (one per row tile, five independent
-//     accumulators - the ILP that keeps the matrix pipe busy with one wave per SIMD); the stream is the same for the four
-//     waves (L1 absorbs most of the re-reads) and runs through a 16-slot register ring, re-armed as it is consumed.
-//   * the only cross-wave traffic is K_h and V_h^T of the current head: written to LDS as ready MFMA fragments (one
-//     ds_write_b128 / two ds_write_b64 per row tile), double-buffered over heads - ONE barrier per head.  Scores
-//     S^T = K.Q^T and O^T = V^T.P^T run on v_mfma_f32_16x16x32_bf16 with the softmax along registers; the attention output
-//     of head h is, unchanged, the B operand of out_proj's k-slice h, accumulated straight into the residual registers.
+//   * weights reach the CU ONCE for the four waves: the stream (4.3 MB bf16, consumption order) is cut into 16 KiB stages
+//     that the waves copy global -> LDS with LDS-DMA (global_load_lds_dwordx4, two 1 KiB pieces per wave and stage) into a
+//     three-buffer ring, two stages ahead of their use; every 1 KiB MFMA A-fragment a wave reads back (one ds_read_b128)
+//     feeds one MFMA per row tile of the wave (independent accumulators).  A stage ends with s_waitcnt vmcnt(2) (everything but the pieces just issued has landed) + s_barrier.
+//     (A per-wave register ring - the sampling kernels' scheme - does not survive here: at 512 registers hipcc moves the
+//     slots through AGPR copies behind s_waitcnt vmcnt(0), one full L2 round trip per 16 units: 1.04 ms per clip against
+//     the 0.19 ms of its MFMAs.)
+//   * code size is a first-order cost: a decoder block unrolled over the five tiles is ~100 KB of straight-line code, more
+//     than the instruction cache, and runs at a few instructions per 100 cycles (measured: the first pass of a loop body
+//     18 k cycles, later passes 4 k).  Everything that is per tile and not a weight-sharing GEMM - attention, LayerNorm, the
+//     last stage - is therefore a RUNTIME loop over the tiles whose body works on tile slot 0 while the register arrays
+//     rotate by one slot per iteration (moves instead of dynamic register indexing).
+//   * the other cross-wave traffic is K_h and V_h^T of the current head: written to LDS as ready MFMA fragments (one
+//     ds_write_b128 / two ds_write_b64 per row tile), double-buffered over heads; the barrier that ends the k,v stage
+//     publishes them.  Scores S^T = K.Q^T and O^T = V^T.P^T run on v_mfma_f32_16x16x32_bf16 with the softmax along
+//     registers, two query tiles at a time on shared K / V fragments; the attention output of head h is, unchanged, the B
+//     operand of out_proj's k-slice h, accumulated straight into the residual registers.
+//   * FFN: 16 chunks of 32 hidden features, software-pipelined - linear1 of chunk i+1 (MFMA) runs beside the GELU of chunk
+//     i (VALU), then linear2 of chunk i accumulates into the residual registers.
 //   * the U-Net skip stack (4 x 300 x 128) goes to global memory as packed bf16 MFMA operands - exactly the rounding the
 //     skip linear applies anyway - written and read back by the same lanes (no synchronisation); 82 MB per 256 clips.
 //   * the one-token cross-attention is the per-clip constant of k_vae_ca (k_misc.hip), as in the staged path.
 //
 // HBM traffic per clip: 320 KB skip write + 320 KB skip read + 201.6 KB poses/trans out + 4.6 KB constants in; weights
-// (3.8 MB bf16 for the whole decoder) come out of L2.
+// come out of L2 (4.3 MB per clip and CU).
 #include "amuse_dev.hpp"
 #include "amuse_kernels.hpp"
+#include <cstdio>
 
 namespace amuse {
 namespace {
 
-constexpr int NT = 5;                     // row tiles per wave
-constexpr int kFR = kVaeFusedRing;        // weight ring depth (units)
+constexpr int kWaves = 8;
 constexpr int kKeyRows = 320;             // 300 keys padded to 20 tiles
 constexpr int kPairs = kKeyRows / 32;     // 10 key-tile pairs
 constexpr int kKvBytes = kKeyRows * 64 + kPairs * 2 * 16 * 64;   // K fragments 20 KiB + V^T fragments 20 KiB
-constexpr int kFeatStride = 388;
-constexpr int kStageBytes = 16 * kFeatStride * 4;                // per-wave staging tile of the last stage
-constexpr int kPvBytes = PV_BLOCK * 4;
-// LDS: [2 x K/V image | 4 x per-wave staging (reuses the K/V images and beyond)] | 2 x block params
-constexpr int kMainBytes = (2 * kKvBytes > 4 * kStageBytes) ? 2 * kKvBytes : 4 * kStageBytes;
-static_assert(kMainBytes + 2 * kPvBytes == kVaeFusedLdsBytes, "LDS layout and amuse_kernels.hpp disagree");
+constexpr int kStage = kVaeFusedStageUnits;                      // 16 units = 16 KiB per stage
+constexpr int kStageBytes = kStage * 1024;
+constexpr int kWBufs = 3;
+constexpr int kPvSlot = 8192;             // one block's small parameters (7,680 B) rounded up to whole DMA pieces
+constexpr int kCaBytes = 5120;            // [9][128] floats rounded up to whole DMA pieces
+constexpr int kQStride = 100;            // staging row stride (floats) of one 96-feature quarter (16 joints) of the last stage
+// LDS map (bytes)
+constexpr int kOffKv = 0;                                  // 2 x K/V images; the last stage's 4 staging tiles reuse it
+constexpr int kOffW = kOffKv + 2 * kKvBytes;               // weight ring
+constexpr int kOffPv = kOffW + kWBufs * kStageBytes;       // 2 x block parameters
+constexpr int kOffCa = kOffPv + 2 * kPvSlot;               // cross-attention constants of the clip
+static_assert(kOffCa + kCaBytes == kVaeFusedLdsBytes, "LDS layout and amuse_kernels.hpp disagree");
+static_assert(kWaves * 16 * kQStride * 4 <= 2 * kKvBytes, "staging tiles must fit the K/V images");
 
-typedef WRing<kFR> Ring;
-
-// ablation switches for timing experiments (tools/build_variant.sh): 1 no weight re-arm loads, 2 no attention, 4 no FFN,
-// 8 no softmax arithmetic (scores fed to PV as they are), 16 no cross-attention constant loads.  0 in the product.
+// ablation switches for timing experiments (tools/build_variant.sh): 2 no attention, 4 no FFN arithmetic,
+// 8 no softmax arithmetic (scores fed to PV as they are).  0 in the product.
 #ifndef AMUSE_FABL
 #define AMUSE_FABL 0
 #endif
+// -DAMUSE_FPROF=1 (variant builds only): wave 0 of workgroup 0 stamps s_memtime at phase boundaries of blocks 1 and 6 and
+// launch_vae_fused prints the deltas (tools/gpu_decode_phases.py)
+#ifndef AMUSE_FPROF
+#define AMUSE_FPROF 0
+#endif
+#if AMUSE_FPROF
+__device__ unsigned long long g_fprof[512];
+__device__ int g_fprof_n;
+#define FSTAMP(tag)                                                                      \
+    do {                                                                                 \
+        if (prof_on) {                                                                   \
+            const int i_ = g_fprof_n;                                                    \
+            if (i_ < 255) { g_fprof[2 * i_] = __builtin_readcyclecounter(); g_fprof[2 * i_ + 1] = (tag); g_fprof_n = i_ + 1; } \
+        }                                                                                \
+    } while (0)
+#else
+#define FSTAMP(tag) do { } while (0)
+#endif
 
-// consume the unit in ring slot `ph` (a compile-time constant after unrolling) and re-arm the slot kFR units ahead
-__device__ __forceinline__ bf16x8 take(Ring& rg, int ph) {
-    const uint4 u = rg.s[ph % kFR];
-    if constexpr (!(AMUSE_FABL & 1)) {
-        rg.s[ph % kFR] = ldw(rg.next);
-        rg.next += 64;
-    }
-    return __builtin_bit_cast(bf16x8, u);
+// ---- LDS-DMA: 64 lanes x 16 B from per-lane global addresses to LDS [dst, dst + 1 KiB), lane-linear.  Inline asm: the
+// compiler neither counts it in its s_waitcnt bookkeeping (its own waits can only become longer, never too short: vmcnt
+// retires in order) nor drains it at barriers; the stage protocol below does the counting.
+__device__ __forceinline__ void glds16(const uint4* gsrc, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(gsrc), "s"(lds_dst)
+                 : "memory");
+}
+__device__ __forceinline__ unsigned lds_addr(const void* p) {
+    return (unsigned)(size_t)(__attribute__((address_space(3))) const void*)p;
 }
 
-// acc[j][o] += W_o . x_j for the NT row tiles of this wave: NC k-tile pairs x NO output tiles, stream order k-pair outer.
-// SWAP: activations are the A operand (result in feature-lane layout: lane (g, f) holds rows 4 g + m of feature f).
-template <int NO, int NC, bool SWAP, int PH>
-__device__ __forceinline__ void gemm5(f32x4 (&acc)[NT][NO], const bf16x8 (&xb)[NT][NC], Ring& rg) {
+struct Stager {
+    const uint4* src;   // this lane's source address of the wave's pieces of the NEXT stage to fetch
+    unsigned dst0;      // LDS byte address of the wave's pieces inside buffer 0
+    const char* ring;   // weight ring base (generic pointer) + lane * 16
+    int widx, ridx;     // buffer the next fetch fills / buffer the current stage reads
+};
+__device__ __forceinline__ void stage_fetch(Stager& s) {
+    const unsigned d = __builtin_amdgcn_readfirstlane(s.dst0 + s.widx * kStageBytes);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) glds16(s.src + i * 64, d + i * 1024);
+    s.src += kStage * 64;
+    s.widx = s.widx == kWBufs - 1 ? 0 : s.widx + 1;
+}
+// end of a stage: all of this wave's DMA except the two pieces of the fetch issued in this stage has landed, its LDS reads
+// and writes are done; after the barrier that holds for every wave - the next stage's buffer is complete, this stage's is free
+__device__ __forceinline__ void stage_end(Stager& s) {
+    asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    s.ridx = s.ridx == kWBufs - 1 ? 0 : s.ridx + 1;
+}
+__device__ __forceinline__ bf16x8 wfrag(const Stager& s, int u) {
+    return __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(s.ring + s.ridx * kStageBytes + u * 1024));
+}
+
+// acc[j][o] += W_o . x_j for the NT row tiles of this wave; units U0.. of the current stage, k-pair outer, output tile inner
+template <int NT, int NO, int NC, int U0>
+__device__ __forceinline__ void gemm5(f32x4 (&acc)[NT][NO], const bf16x8 (&xb)[NT][NC], const Stager& s) {
 #pragma unroll
     for (int c = 0; c < NC; ++c) {
 #pragma unroll
         for (int o = 0; o < NO; ++o) {
-            const bf16x8 wf = take(rg, PH + c * NO + o);
+            const bf16x8 wf = wfrag(s, U0 + c * NO + o);
 #pragma unroll
-            for (int j = 0; j < NT; ++j) acc[j][o] = SWAP ? mfma_bf16(xb[j][c], wf, acc[j][o]) : mfma_bf16(wf, xb[j][c], acc[j][o]);
+            for (int j = 0; j < NT; ++j) acc[j][o] = mfma_bf16(wf, xb[j][c], acc[j][o]);
         }
     }
 }
 
+// x[0] <- x[1] <- ... <- x[NT-1] <- x[0]: NT applications restore the order
+template <int NT>
+__device__ __forceinline__ void rotate_tiles(f32x4 (&x)[NT][kTiles]) {
+#pragma unroll
+    for (int t = 0; t < kTiles; ++t) {
+        const f32x4 first = x[0][t];
+#pragma unroll
+        for (int j = 0; j + 1 < NT; ++j) x[j][t] = x[j + 1][t];
+        x[NT - 1][t] = first;
+    }
+}
+
+template <int NT>
 __device__ __forceinline__ void pack_rows(bf16x8 (&xb)[NT][4], const f32x4 (&x)[NT][kTiles]) {
 #pragma unroll
     for (int j = 0; j < NT; ++j)
@@ -82,96 +159,152 @@ __device__ __forceinline__ void pack_rows(bf16x8 (&xb)[NT][4], const f32x4 (&x)[
         for (int c = 0; c < 4; ++c) xb[j][c] = pack_bf16(x[j][2 * c], x[j][2 * c + 1]);
 }
 
-// softmax(Q K^T) V for one 16-query tile against all keys of head h, K / V^T fragments in LDS.  Two key chunks of five
-// tile pairs (160 keys) each, merged online: the scores of a chunk (40 registers) are complete before its exponentials.
-__device__ __forceinline__ bf16x8 attend(const uint4* Kb, const uint4* Vt, bf16x8 qb, int len, int g, int r) {
-    if constexpr ((AMUSE_FABL & 2) != 0) return qb;
-    float m_run = -INFINITY, l_run = 0.f;
-    f32x4 o[2] = {splat4(0.f), splat4(0.f)};
+// softmax(Q K^T) V for NQ 16-query tiles against all keys of head h, K / V^T fragments in LDS (each fragment is read once
+// for the NQ tiles).  Two key chunks of five tile pairs (160 keys) each, merged online: the scores of a chunk are complete
+// before its exponentials.
+template <int NQ>
+__device__ __forceinline__ void attend(const uint4* Kb, const uint4* Vt, const bf16x8 (&qb)[NQ], bf16x8 (&ob)[NQ], int len,
+                                       int g, int r) {
+    if constexpr ((AMUSE_FABL & 2) != 0) {
+#pragma unroll
+        for (int n = 0; n < NQ; ++n) ob[n] = qb[n];
+        return;
+    }
+    float m_run[NQ], l_run[NQ];
+    f32x4 o[NQ][2];
+#pragma unroll
+    for (int n = 0; n < NQ; ++n) {
+        m_run[n] = -INFINITY;
+        l_run[n] = 0.f;
+        o[n][0] = o[n][1] = splat4(0.f);
+    }
 #pragma unroll
     for (int ch = 0; ch < 2; ++ch) {
-        f32x4 st[10];
+        f32x4 st[NQ][10];
 #pragma unroll
         for (int i = 0; i < 5; ++i) {
             const int jp = 5 * ch + i;
             const bf16x8 k0 = __builtin_bit_cast(bf16x8, Kb[(32 * jp + r) * 4 + g]);
             const bf16x8 k1 = __builtin_bit_cast(bf16x8, Kb[(32 * jp + 16 + r) * 4 + g]);
-            st[2 * i] = mfma_bf16(k0, qb, splat4(0.f));      // lane (g, i): S[query i][key 32 jp + 4 g + m] (log2 units)
-            st[2 * i + 1] = mfma_bf16(k1, qb, splat4(0.f));  //              S[query i][key 32 jp + 16 + 4 g + m]
+#pragma unroll
+            for (int n = 0; n < NQ; ++n) {
+                st[n][2 * i] = mfma_bf16(k0, qb[n], splat4(0.f));      // lane (g, i): S[query i][key 32 jp + 4 g + m] (log2 units)
+                st[n][2 * i + 1] = mfma_bf16(k1, qb[n], splat4(0.f));  //              S[query i][key 32 jp + 16 + 4 g + m]
+            }
         }
-        if (160 * (ch + 1) > len) {  // wave-uniform: only a chunk that holds the sequence end is masked
+        // key-padding mask: only tile pairs that reach past the sequence end are touched (wave-uniform branch per pair; with
+        // len = 300 that is the last pair alone).  The per-lane limit is recomputed here on purpose: hoisted out of the head
+        // loop, the 40 lane masks of a chunk would live in SGPR pairs and spill.
+#pragma unroll
+        for (int i = 0; i < 5; ++i) {
+            const int k0 = 32 * (5 * ch + i);
+            if (k0 + 32 > len) {
+                int lim = len - k0 - 4 * g;   // element (u, m) of the pair is valid iff 16 u + m < lim
+                asm volatile("" : "+v"(lim));
+#pragma unroll
+                for (int n = 0; n < NQ; ++n)
+#pragma unroll
+                    for (int u = 0; u < 2; ++u)
+#pragma unroll
+                        for (int m = 0; m < 4; ++m) st[n][2 * i + u][m] = (16 * u + m < lim) ? st[n][2 * i + u][m] : -INFINITY;
+            }
+        }
+        float msub[NQ], ps[NQ];
+#pragma unroll
+        for (int n = 0; n < NQ; ++n) {
+            float mx = st[n][0][0];
 #pragma unroll
             for (int i = 0; i < 10; ++i)
 #pragma unroll
-                for (int m = 0; m < 4; ++m)
-                    st[i][m] = (160 * ch + 16 * i + 4 * g + m) < len ? st[i][m] : -INFINITY;
+                for (int m = 0; m < 4; ++m) mx = fmaxf(mx, st[n][i][m]);
+            mx = allreduce_g_max(mx);
+            const float m_new = fmaxf(m_run[n], mx);
+            msub[n] = (m_new == -INFINITY) ? 0.f : m_new;   // a fully masked chunk (len <= 160 in chunk 1) adds zeros
+            const float alpha = (m_run[n] == -INFINITY) ? 0.f : __builtin_amdgcn_exp2f(m_run[n] - msub[n]);
+            o[n][0] *= alpha;
+            o[n][1] *= alpha;
+            l_run[n] *= alpha;
+            m_run[n] = m_new;
+            ps[n] = 0.f;
         }
-        float mx = st[0][0];
-#pragma unroll
-        for (int i = 0; i < 10; ++i)
-#pragma unroll
-            for (int m = 0; m < 4; ++m) mx = fmaxf(mx, st[i][m]);
-        mx = allreduce_g_max(mx);
-        const float m_new = fmaxf(m_run, mx);
-        const float msub = (m_new == -INFINITY) ? 0.f : m_new;   // a fully masked chunk (len <= 160 in chunk 1) adds zeros
-        const float alpha = (m_run == -INFINITY) ? 0.f : __builtin_amdgcn_exp2f(m_run - msub);
-        float ps = 0.f;
-        o[0] *= alpha;
-        o[1] *= alpha;
 #pragma unroll
         for (int i = 0; i < 5; ++i) {
             const int jp = 5 * ch + i;
-            f32x4 p0, p1;
-#pragma unroll
-            for (int m = 0; m < 4; ++m) {
-                if constexpr ((AMUSE_FABL & 8) != 0) {
-                    p0[m] = st[2 * i][m];
-                    p1[m] = st[2 * i + 1][m];
-                } else {
-                    p0[m] = __builtin_amdgcn_exp2f(st[2 * i][m] - msub);
-                    p1[m] = __builtin_amdgcn_exp2f(st[2 * i + 1][m] - msub);
-                }
-            }
-            ps += ((p0[0] + p0[1]) + (p0[2] + p0[3])) + ((p1[0] + p1[1]) + (p1[2] + p1[3]));
-            const bf16x8 pb = pack_bf16(p0, p1);
             const bf16x8 v0 = __builtin_bit_cast(bf16x8, Vt[((jp * 2 + 0) * 16 + r) * 4 + g]);
             const bf16x8 v1 = __builtin_bit_cast(bf16x8, Vt[((jp * 2 + 1) * 16 + r) * 4 + g]);
-            o[0] = mfma_bf16(v0, pb, o[0]);   // O^T[d][i] += sum_key V[key][d] P[i][key]
-            o[1] = mfma_bf16(v1, pb, o[1]);
+#pragma unroll
+            for (int n = 0; n < NQ; ++n) {
+                f32x4 p0, p1;
+#pragma unroll
+                for (int m = 0; m < 4; ++m) {
+                    if constexpr ((AMUSE_FABL & 8) != 0) {
+                        p0[m] = st[n][2 * i][m];
+                        p1[m] = st[n][2 * i + 1][m];
+                    } else {
+                        p0[m] = __builtin_amdgcn_exp2f(st[n][2 * i][m] - msub[n]);
+                        p1[m] = __builtin_amdgcn_exp2f(st[n][2 * i + 1][m] - msub[n]);
+                    }
+                }
+                ps[n] += ((p0[0] + p0[1]) + (p0[2] + p0[3])) + ((p1[0] + p1[1]) + (p1[2] + p1[3]));
+                const bf16x8 pb = pack_bf16(p0, p1);
+                o[n][0] = mfma_bf16(v0, pb, o[n][0]);   // O^T[d][i] += sum_key V[key][d] P[i][key]
+                o[n][1] = mfma_bf16(v1, pb, o[n][1]);
+            }
         }
-        l_run = l_run * alpha + ps;
-        m_run = m_new;
+#pragma unroll
+        for (int n = 0; n < NQ; ++n) l_run[n] += ps[n];
     }
-    const float inv = __builtin_amdgcn_rcpf(allreduce_g_sum(l_run));
-    return pack_bf16(o[0] * inv, o[1] * inv);
+#pragma unroll
+    for (int n = 0; n < NQ; ++n) {
+        const float inv = __builtin_amdgcn_rcpf(allreduce_g_sum(l_run[n]));
+        ob[n] = pack_bf16(o[n][0] * inv, o[n][1] * inv);
+    }
 }
 
 // MODE 0: input block (push the skip), 1: middle block, 2: output block (skip linear first)
-template <int MODE>
-__device__ __forceinline__ void decoder_block(f32x4 (&x)[NT][kTiles], Ring& rg, const VaeFusedArgs& a, int blk, int b,
-                                              const float* pv, const float* pv_next_src, float* pv_next_dst, char* kv,
-                                              uint4* skipbuf, int len, int wave, int lane) {
+template <int NT, int MODE>
+__device__ __forceinline__ void decoder_block(f32x4 (&x)[NT][kTiles], Stager& sg, const VaeFusedArgs& a, int blk, int tile0,
+                                              const float* pv, const float* pv_next_src, unsigned pv_next_dst, const float* cal,
+                                              char* kv, uint4* skipbuf, int len, int wave, int lane) {
     const int g = lane >> 4, r = lane & 15;
+    [[maybe_unused]] const bool prof_on = blockIdx.x == 0 && threadIdx.x == 0 && (blk == 1 || blk == 6);
+    FSTAMP(1);   // block start
     bf16x8 xb[NT][4];
     if constexpr (MODE == 2) {
         // x = linear_blocks[blk - 5](cat(x, xs.pop()))   (cross_attention.py:118-120); the popped skip comes back from
-        // global memory as the packed operands this wave stored after input block 8 - blk
-        pack_rows(xb, x);
-        const float* sb = a.pvec + PV_SKIP_B + (blk - 5) * kD;
-#pragma unroll
-        for (int j = 0; j < NT; ++j)
-#pragma unroll
-            for (int t = 0; t < kTiles; ++t) x[j][t] = ld4(sb + 16 * t + 4 * g);
-        gemm5<kTiles, 4, false, 0>(x, xb, rg);
+        // global memory as the packed operands this wave stored after input block 8 - blk.  Four stages: the x half
+        // (k-pairs 0..3), then the skip half.
+        bf16x8 sb[NT][4];
         const uint4* sk = skipbuf + (size_t)(8 - blk) * (20 * 4 * 64);
 #pragma unroll
         for (int j = 0; j < NT; ++j)
 #pragma unroll
-            for (int c = 0; c < 4; ++c) xb[j][c] = __builtin_bit_cast(bf16x8, sk[((wave + 4 * j) * 4 + c) * 64 + lane]);
-        gemm5<kTiles, 4, false, 32>(x, xb, rg);
+            for (int c = 0; c < 4; ++c) sb[j][c] = __builtin_bit_cast(bf16x8, sk[((tile0 + 4 * j) * 4 + c) * 64 + lane]);
+        pack_rows<NT>(xb, x);
+        const float* bias = a.pvec + PV_SKIP_B + (blk - 5) * kD;
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int t = 0; t < kTiles; ++t) x[j][t] = ld4(bias + 16 * t + 4 * g);
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) {
+            stage_fetch(sg);
+#pragma unroll
+            for (int cc = 0; cc < 2; ++cc) {
+                const int c = 2 * (s4 & 1) + cc;
+#pragma unroll
+                for (int o = 0; o < kTiles; ++o) {
+                    const bf16x8 wf = wfrag(sg, cc * kTiles + o);
+#pragma unroll
+                    for (int j = 0; j < NT; ++j) x[j][o] = mfma_bf16(wf, s4 < 2 ? xb[j][c] : sb[j][c], x[j][o]);
+                }
+            }
+            stage_end(sg);
+        }
     }
+    FSTAMP(2);   // skip linear done
     // ---------------- self-attention (cross_attention.py:323-330): x = norm1(x + out_proj(softmax(q k^T) v))
-    pack_rows(xb, x);
+    pack_rows<NT>(xb, x);
 #pragma unroll
     for (int j = 0; j < NT; ++j)
 #pragma unroll
@@ -182,7 +315,9 @@ __device__ __forceinline__ void decoder_block(f32x4 (&x)[NT][kTiles], Ring& rg, 
         char* buf = kv + (h & 1) * kKvBytes;
         uint4* Kb = reinterpret_cast<uint4*>(buf);
         char* Vt = buf + kKeyRows * 64;
-        {   // k, v of this head for the wave's rows -> LDS fragment images
+        // ---- stage A: k, v of this head for the wave's rows -> LDS fragment images (published by the stage's barrier)
+        stage_fetch(sg);
+        {
             f32x4 kk[NT][2], vv[NT][2];
             const f32x4 bk0 = ld4(pv + PV_IN_B + kD + 32 * h + 4 * g), bk1 = ld4(pv + PV_IN_B + kD + 32 * h + 16 + 4 * g);
             const float bv0 = pv[PV_IN_B + 2 * kD + 32 * h + r], bv1 = pv[PV_IN_B + 2 * kD + 32 * h + 16 + r];
@@ -191,25 +326,24 @@ __device__ __forceinline__ void decoder_block(f32x4 (&x)[NT][kTiles], Ring& rg, 
                 kk[j][0] = bk0; kk[j][1] = bk1;
                 vv[j][0] = splat4(bv0); vv[j][1] = splat4(bv1);
             }
-            // stream: per k-pair c: k tiles (2), v tiles (2)
 #pragma unroll
-            for (int c = 0; c < 4; ++c) {
+            for (int c = 0; c < 4; ++c) {   // stream: per k-pair c: k tiles (2), v tiles (2)
 #pragma unroll
                 for (int o = 0; o < 2; ++o) {
-                    const bf16x8 wf = take(rg, 4 * c + o);
+                    const bf16x8 wf = wfrag(sg, 4 * c + o);
 #pragma unroll
                     for (int j = 0; j < NT; ++j) kk[j][o] = mfma_bf16(wf, xb[j][c], kk[j][o]);
                 }
 #pragma unroll
                 for (int o = 0; o < 2; ++o) {
-                    const bf16x8 wf = take(rg, 4 * c + 2 + o);
+                    const bf16x8 wf = wfrag(sg, 4 * c + 2 + o);
 #pragma unroll
                     for (int j = 0; j < NT; ++j) vv[j][o] = mfma_bf16(xb[j][c], wf, vv[j][o]);  // operand-swapped: V^T
                 }
             }
 #pragma unroll
             for (int j = 0; j < NT; ++j) {
-                const int tile = wave + 4 * j;
+                const int tile = tile0 + 4 * j;
                 const bool ok = 16 * tile + r < kFrames;
                 const uint4 kf = __builtin_bit_cast(uint4, pack_bf16(kk[j][0], kk[j][1]));
                 Kb[(16 * tile + r) * 4 + g] = ok ? kf : uint4{0u, 0u, 0u, 0u};
@@ -223,150 +357,254 @@ __device__ __forceinline__ void decoder_block(f32x4 (&x)[NT][kTiles], Ring& rg, 
                 }
             }
         }
-        __syncthreads();
+        FSTAMP(3);   // k, v computed and written
+        stage_end(sg);
+        FSTAMP(4);   // barrier of stage A passed
+        // ---- stage B: q of this head, attention, out_proj's k-slice of the head
         if (h == 0 && pv_next_src) {   // next block's small parameters -> the other LDS slot (free since the last barrier)
-            for (int i = threadIdx.x; i < PV_BLOCK / 4; i += 256) st4(pv_next_dst + 4 * i, ld4(pv_next_src + 4 * i));
+            const unsigned d = __builtin_amdgcn_readfirstlane(pv_next_dst + wave * 1024);
+            glds16(reinterpret_cast<const uint4*>(pv_next_src) + wave * 64 + lane, d);
         }
+        stage_fetch(sg);
         bf16x8 qb[NT];
         {
             f32x4 q[NT][2];
             const f32x4 bq0 = ld4(pv + PV_IN_B + 32 * h + 4 * g), bq1 = ld4(pv + PV_IN_B + 32 * h + 16 + 4 * g);
 #pragma unroll
             for (int j = 0; j < NT; ++j) { q[j][0] = bq0; q[j][1] = bq1; }
-            gemm5<2, 4, false, 16>(q, xb, rg);
+            gemm5<NT, 2, 4, 0>(q, xb, sg);
 #pragma unroll
             for (int j = 0; j < NT; ++j) qb[j] = pack_bf16(q[j][0] * kQScale, q[j][1] * kQScale);
         }
+        FSTAMP(5);   // q
+        // attention, one 16-query tile per iteration of a RUNTIME loop: the tile's q operand is qb[0] and its output enters
+        // ob[] from the top while both arrays rotate by one position per iteration (register moves instead of indexing).
+        // The loop body is the attention's only copy in the instruction stream (see the note on code size at the kernel).
         bf16x8 ob[NT][1];
 #pragma unroll
-        for (int j = 0; j < NT; ++j) {
-            ob[j][0] = attend(Kb, reinterpret_cast<const uint4*>(Vt), qb[j], len, g, r);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        gemm5<kTiles, 1, false, 24>(x, ob, rg);   // out_proj, k-slice of head h, accumulated into the residual
-    }
-    const float* ca = a.ca + ((size_t)b * kLayers + blk) * kD;
+        for (int j = 0; j < NT; ++j) ob[j][0] = qb[j];
+        {
+            const uint4* Vq = reinterpret_cast<const uint4*>(Vt);
+#pragma unroll 1
+            for (int j = 0; j < NT; ++j) {
+                bf16x8 q1[1] = {qb[0]}, o1[1];
+                attend<1>(Kb, Vq, q1, o1, len, g, r);
 #pragma unroll
-    for (int j = 0; j < NT; ++j) {
-        layer_norm_rows<true>(x[j], pv + PV_LN1_W, pv + PV_LN1_B, g);
+                for (int jj = 0; jj + 1 < NT; ++jj) {
+                    qb[jj] = qb[jj + 1];
+                    ob[jj][0] = ob[jj + 1][0];
+                }
+                ob[NT - 1][0] = o1[0];
+            }
+            FSTAMP(7);   // attention of the five tiles
+        }
+        gemm5<NT, kTiles, 1, 8>(x, ob, sg);   // out_proj, k-slice of head h, accumulated into the residual
+        FSTAMP(8);   // out_proj
+        stage_end(sg);
+        FSTAMP(9);   // barrier of stage B passed
+    }
+    const float* ca = cal + blk * kD;
+#pragma unroll 1
+    for (int j = 0; j < NT; ++j) {   // runtime loop, the tiles rotate through x[0]
+        layer_norm_rows<true>(x[0], pv + PV_LN1_W, pv + PV_LN1_B, g);
         // cross-attention onto the single latent token == per-clip constant; x = norm2(x + ca)  (cross_attention.py:331-337)
 #pragma unroll
-        for (int t = 0; t < kTiles; ++t)
-            if constexpr (!(AMUSE_FABL & 16)) x[j][t] += ld4(ca + 16 * t + 4 * g);
-        layer_norm_rows<true>(x[j], pv + PV_LN2_W, pv + PV_LN2_B, g);
+        for (int t = 0; t < kTiles; ++t) x[0][t] += ld4(ca + 16 * t + 4 * g);
+        layer_norm_rows<true>(x[0], pv + PV_LN2_W, pv + PV_LN2_B, g);
+        rotate_tiles<NT>(x);
     }
+    FSTAMP(10);   // norm1, cross-attention constant, norm2
     // ---------------- FFN (cross_attention.py:338-340): x = norm3(x + linear2(gelu(linear1(x)))), 16 chunks of 32 hidden
-    pack_rows(xb, x);
+    // features.  Stages: [linear1(0) | pad], 15 x [linear1(i + 1) | linear2(i)], [linear2(15) | pad]
+    pack_rows<NT>(xb, x);
 #pragma unroll
     for (int j = 0; j < NT; ++j)
 #pragma unroll
         for (int t = 0; t < kTiles; ++t) x[j][t] += ld4(pv + PV_L2_B + 16 * t + 4 * g);
-#pragma unroll 1
-    for (int c = 0; c < ((AMUSE_FABL & 4) ? 0 : 16); ++c) {
-        f32x4 hid[NT][2];
-        const f32x4 b0 = ld4(pv + PV_L1_B + 32 * c + 4 * g), b1 = ld4(pv + PV_L1_B + 32 * c + 16 + 4 * g);
+    f32x4 hid[NT][2];
+    {
+        stage_fetch(sg);
+        const f32x4 b0 = ld4(pv + PV_L1_B + 4 * g), b1 = ld4(pv + PV_L1_B + 16 + 4 * g);
 #pragma unroll
         for (int j = 0; j < NT; ++j) { hid[j][0] = b0; hid[j][1] = b1; }
-        gemm5<2, 4, false, 0>(hid, xb, rg);
-        bf16x8 hb[NT][1];
-#pragma unroll
-        for (int j = 0; j < NT; ++j) hb[j][0] = pack_bf16(gelu_poly4(hid[j][0]), gelu_poly4(hid[j][1]));
-        gemm5<kTiles, 1, false, 8>(x, hb, rg);
+        if constexpr (!(AMUSE_FABL & 4)) gemm5<NT, 2, 4, 0>(hid, xb, sg);
+        stage_end(sg);
+        FSTAMP(11);   // FFN prologue stage
     }
+#pragma unroll 1
+    for (int c = 0; c < 15; ++c) {
+        stage_fetch(sg);
+        f32x4 nxt[NT][2];
+        const f32x4 b0 = ld4(pv + PV_L1_B + 32 * (c + 1) + 4 * g), b1 = ld4(pv + PV_L1_B + 32 * (c + 1) + 16 + 4 * g);
 #pragma unroll
-    for (int j = 0; j < NT; ++j) layer_norm_rows<true>(x[j], pv + PV_LN3_W, pv + PV_LN3_B, g);
+        for (int j = 0; j < NT; ++j) { nxt[j][0] = b0; nxt[j][1] = b1; }
+        bf16x8 hb[NT][1];
+        if constexpr (!(AMUSE_FABL & 4)) {
+            gemm5<NT, 2, 4, 0>(nxt, xb, sg);   // linear1 of the next chunk: MFMAs that do not depend on ...
+#pragma unroll
+            for (int j = 0; j < NT; ++j) hb[j][0] = pack_bf16(gelu_poly4(hid[j][0]), gelu_poly4(hid[j][1]));   // ... this VALU
+            gemm5<NT, kTiles, 1, 8>(x, hb, sg);
+        }
+#pragma unroll
+        for (int j = 0; j < NT; ++j) { hid[j][0] = nxt[j][0]; hid[j][1] = nxt[j][1]; }
+        FSTAMP(12);   // FFN stage compute
+        stage_end(sg);
+        FSTAMP(13);   // FFN stage barrier
+    }
+    {
+        stage_fetch(sg);
+        bf16x8 hb[NT][1];
+        if constexpr (!(AMUSE_FABL & 4)) {
+#pragma unroll
+            for (int j = 0; j < NT; ++j) hb[j][0] = pack_bf16(gelu_poly4(hid[j][0]), gelu_poly4(hid[j][1]));
+            gemm5<NT, kTiles, 1, 0>(x, hb, sg);
+        }
+        stage_end(sg);
+    }
+    FSTAMP(14);   // FFN epilogue stage
+#pragma unroll 1
+    for (int j = 0; j < NT; ++j) {
+        layer_norm_rows<true>(x[0], pv + PV_LN3_W, pv + PV_LN3_B, g);
+        rotate_tiles<NT>(x);
+    }
+    FSTAMP(15);   // norm3
     if constexpr (MODE == 0) {   // xs.append(x): packed operands of the skip linear that pops them
         uint4* sk = skipbuf + (size_t)blk * (20 * 4 * 64);
 #pragma unroll
         for (int j = 0; j < NT; ++j)
 #pragma unroll
             for (int c = 0; c < 4; ++c)
-                sk[((wave + 4 * j) * 4 + c) * 64 + lane] = __builtin_bit_cast(uint4, pack_bf16(x[j][2 * c], x[j][2 * c + 1]));
+                sk[((tile0 + 4 * j) * 4 + c) * 64 + lane] = __builtin_bit_cast(uint4, pack_bf16(x[j][2 * c], x[j][2 * c + 1]));
     }
 }
 
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void k_vae_fused(VaeFusedArgs a) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* kv = smem;
-    float* pvl = reinterpret_cast<float*>(smem + kMainBytes);   // [2][PV_BLOCK]
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+// everything one wave does for its NT row tiles tile0, tile0 + 4, ...
+template <int NT>
+__device__ __forceinline__ void decode_tiles(const VaeFusedArgs& a, char* smem, Stager& sg, int tile0, int b, int len,
+                                             int wave, int lane) {
     const int g = lane >> 4, r = lane & 15;
-    const int b = blockIdx.x;
-    const int len = a.lengths ? a.lengths[b] : kFrames;
+    char* kv = smem + kOffKv;
+    const float* pvl = reinterpret_cast<const float*>(smem + kOffPv);   // [2][kPvSlot / 4]
+    const float* cal = reinterpret_cast<const float*>(smem + kOffCa);   // [9][128]
+    const unsigned lds0 = lds_addr(smem);
     uint4* skipbuf = a.skip + (size_t)b * (4 * 20 * 4 * 64);
-    Ring rg;
-    ring_fill(rg, a.wstream + lane);
-    for (int i = threadIdx.x; i < PV_BLOCK / 4; i += 256) st4(pvl + 4 * i, ld4(a.pvec + 4 * i));
     // queries = zeros + query_pos_decoder.pe[:300]  (vae.py:220,258)
     f32x4 x[NT][kTiles];
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
-        const int frame = 16 * (wave + 4 * j) + r;
+        const int frame = 16 * (tile0 + 4 * j) + r;
 #pragma unroll
         for (int t = 0; t < kTiles; ++t)
             x[j][t] = frame < kFrames ? ld4(a.pe + (size_t)frame * kD + 16 * t + 4 * g) : splat4(0.f);
     }
-    __syncthreads();
+    asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)\n\ts_barrier" ::: "memory");   // parameters, constants and stage 0 are in
 #pragma unroll 1
     for (int blk = 0; blk < 4; ++blk)
-        decoder_block<0>(x, rg, a, blk, b, pvl + (blk & 1) * PV_BLOCK, a.pvec + (blk + 1) * PV_BLOCK,
-                         pvl + ((blk + 1) & 1) * PV_BLOCK, kv, skipbuf, len, wave, lane);
-    decoder_block<1>(x, rg, a, 4, b, pvl, a.pvec + 5 * PV_BLOCK, pvl + PV_BLOCK, kv, skipbuf, len, wave, lane);
+        decoder_block<NT, 0>(x, sg, a, blk, tile0, pvl + (blk & 1) * (kPvSlot / 4), a.pvec + (blk + 1) * PV_BLOCK,
+                             lds0 + kOffPv + ((blk + 1) & 1) * kPvSlot, cal, kv, skipbuf, len, wave, lane);
+    decoder_block<NT, 1>(x, sg, a, 4, tile0, pvl, a.pvec + 5 * PV_BLOCK, lds0 + kOffPv + kPvSlot, cal, kv, skipbuf, len, wave, lane);
 #pragma unroll 1
     for (int blk = 5; blk < kLayers; ++blk)
-        decoder_block<2>(x, rg, a, blk, b, pvl + (blk & 1) * PV_BLOCK, blk + 1 < kLayers ? a.pvec + (blk + 1) * PV_BLOCK : nullptr,
-                         pvl + ((blk + 1) & 1) * PV_BLOCK, kv, skipbuf, len, wave, lane);
-    // ---------------- decoder.norm -> final_layer (333 outputs in 24 tiles) -> rotation epilogue, one row tile at a time
-    __syncthreads();   // the K/V images become the staging tiles
-    float* fst = reinterpret_cast<float*>(smem + wave * kStageBytes);
+        decoder_block<NT, 2>(x, sg, a, blk, tile0, pvl + (blk & 1) * (kPvSlot / 4),
+                             blk + 1 < kLayers ? a.pvec + (blk + 1) * PV_BLOCK : nullptr,
+                             lds0 + kOffPv + ((blk + 1) & 1) * kPvSlot, cal, kv, skipbuf, len, wave, lane);
+    // ---------------- decoder.norm -> final_layer (333 outputs in 24 tiles) -> rotation epilogue.  The stream holds the
+    // final layer five times (once per tile slot of a SIMD): a 3-tile wave consumes slots 0..2 and only passes the stages of
+    // slots 3, 4; a 2-tile wave passes slots 0..2 and consumes 3, 4 - the stage protocol stays in step for all eight waves.
+    // One tile: four quarters of 6 output tiles (96 features = 16 joints; the last one 7 joints + translation), each staged
+    // in a wave-private LDS tile (the K/V images are free: the last barrier of block 8 is behind every wave's last read).
+    float* fst = reinterpret_cast<float*>(smem + kOffKv) + wave * 16 * kQStride;
+    constexpr int kSlot0 = NT == 3 ? 0 : 3;
+#pragma unroll 1
+    for (int slot = 0; slot < 5; ++slot) {
+        if (slot < kSlot0 || slot >= kSlot0 + NT) {   // another wave's slot: keep the stage ring turning
+#pragma unroll 1
+            for (int s6 = 0; s6 < 6; ++s6) {
+                stage_fetch(sg);
+                stage_end(sg);
+            }
+            continue;
+        }
+        const int j = slot - kSlot0;
+        layer_norm_rows<true>(x[0], a.pvec + PV_FINAL_W, a.pvec + PV_FINAL_B, g);
+        bf16x8 xb1[4];
 #pragma unroll
-    for (int j = 0; j < NT; ++j) {
-        layer_norm_rows<true>(x[j], a.pvec + PV_FINAL_W, a.pvec + PV_FINAL_B, g);
-        bf16x8 xb1[1][4];
-#pragma unroll
-        for (int c = 0; c < 4; ++c) xb1[0][c] = pack_bf16(x[j][2 * c], x[j][2 * c + 1]);
-        const int tile = wave + 4 * j;
+        for (int c = 0; c < 4; ++c) xb1[c] = pack_bf16(x[0][2 * c], x[0][2 * c + 1]);
+        rotate_tiles<NT>(x);
+        const int tile = tile0 + 4 * j;
         const int frame = 16 * tile + r;
         const bool keep = frame < kFrames && frame < len;   // output[~mask.T] = 0 (vae.py:274)
+        const int rows_here = min(16, kFrames - 16 * tile);   // <= 0 for the padding tile
+        const size_t row0 = (size_t)b * kFrames + 16 * tile;
 #pragma unroll
-        for (int half = 0; half < 2; ++half) {   // 12 output tiles at a time (stream: per half, k-pair outer)
+        for (int half = 0; half < 2; ++half) {   // 12 output tiles = 48 units = 3 stages (k-pair outer, output tile inner)
             f32x4 f[12];
 #pragma unroll
             for (int o = 0; o < 12; ++o) f[o] = ld4(a.final_bias + 16 * (12 * half + o) + 4 * g);
 #pragma unroll
-            for (int c = 0; c < 4; ++c)
+            for (int s3 = 0; s3 < 3; ++s3) {
+                stage_fetch(sg);
 #pragma unroll
-                for (int o = 0; o < 12; ++o) f[o] = mfma_bf16(take(rg, 12 * c + o), xb1[0][c], f[o]);   // 48 units = 3 ring turns
+                for (int u = 0; u < kStage; ++u) {
+                    const int lin = kStage * s3 + u, c = lin / 12, o = lin - 12 * c;
+                    f[o] = mfma_bf16(wfrag(sg, u), xb1[c], f[o]);
+                }
+                stage_end(sg);
+            }
 #pragma unroll
-            for (int o = 0; o < 12; ++o) st4(fst + r * kFeatStride + 16 * (12 * half + o) + 4 * g, keep ? f[o] : splat4(0.f));
-        }
-        __syncthreads();
-        const int rows_here = min(16, kFrames - 16 * tile);   // <= 0 for the padding tile
-        const size_t row0 = (size_t)b * kFrames + 16 * tile;
-        if (a.feats_out) {
-            for (int i = lane; i < rows_here * kFeats; i += 64) {
-                const int rr = i / kFeats, c = i - rr * kFeats;
-                a.feats_out[(row0 + rr) * kFeats + c] = fst[rr * kFeatStride + c];
+            for (int qq = 0; qq < 2; ++qq) {
+                const int quarter = 2 * half + qq;
+#pragma unroll
+                for (int o = 0; o < 6; ++o) st4(fst + r * kQStride + 16 * o + 4 * g, keep ? f[6 * qq + o] : splat4(0.f));
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the staging tile is wave-private: no barrier
+                const int f0 = 96 * quarter, nfe = quarter == 3 ? kFeats - 288 : 96, njo = quarter == 3 ? kJoints - 48 : 16;
+                if (a.feats_out) {
+                    for (int i = lane; i < rows_here * nfe; i += 64) {
+                        const int rr = i / nfe, c = i - rr * nfe;
+                        a.feats_out[(row0 + rr) * kFeats + f0 + c] = fst[rr * kQStride + c];
+                    }
+                }
+                if (a.poses_out) {
+                    for (int i = lane; i < rows_here * njo; i += 64) {
+                        const int rr = i / njo, jn = i - rr * njo;
+                        float aa[3];
+                        rot6d_to_axis_angle(fst + rr * kQStride + 6 * jn, a.quat_mode, aa);
+                        float* dst = a.poses_out + ((row0 + rr) * kJoints + 16 * quarter + jn) * 3;
+                        dst[0] = aa[0]; dst[1] = aa[1]; dst[2] = aa[2];
+                    }
+                }
+                if (a.trans_out && quarter == 3) {
+                    for (int i = lane; i < rows_here * 3; i += 64) {
+                        const int rr = i / 3, c = i - rr * 3;
+                        a.trans_out[(row0 + rr) * 3 + c] = fst[rr * kQStride + (330 - 288) + c];
+                    }
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             }
         }
-        if (a.poses_out) {
-            for (int i = lane; i < rows_here * kJoints; i += 64) {
-                const int rr = i / kJoints, jn = i - rr * kJoints;
-                float aa[3];
-                rot6d_to_axis_angle(fst + rr * kFeatStride + 6 * jn, a.quat_mode, aa);
-                float* dst = a.poses_out + ((row0 + rr) * kJoints + jn) * 3;
-                dst[0] = aa[0]; dst[1] = aa[1]; dst[2] = aa[2];
-            }
-        }
-        if (a.trans_out) {
-            for (int i = lane; i < rows_here * 3; i += 64) {
-                const int rr = i / 3, c = i - rr * 3;
-                a.trans_out[(row0 + rr) * 3 + c] = fst[rr * kFeatStride + 330 + c];
-            }
-        }
-        __syncthreads();
     }
+}
+
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_vae_fused(VaeFusedArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int b = blockIdx.x;
+    const int len = a.lengths ? a.lengths[b] : kFrames;
+    const unsigned lds0 = lds_addr(smem);
+    // block 0's parameters, the clip's cross-attention constants, then the first two weight stages
+    glds16(reinterpret_cast<const uint4*>(a.pvec) + wave * 64 + lane, lds0 + kOffPv + wave * 1024);
+    if (wave < 5) glds16(reinterpret_cast<const uint4*>(a.ca + (size_t)b * kLayers * kD) + wave * 64 + lane, lds0 + kOffCa + wave * 1024);
+    Stager sg;
+    sg.src = a.wstream + (size_t)wave * 2 * 64 + lane;
+    sg.dst0 = lds0 + kOffW + wave * 2048;
+    sg.ring = smem + kOffW + lane * 16;
+    sg.widx = 0;
+    sg.ridx = 0;
+    stage_fetch(sg);
+    stage_fetch(sg);
+    if (wave < 4) decode_tiles<3>(a, smem, sg, wave, b, len, wave, lane);
+    else decode_tiles<2>(a, smem, sg, wave + 8, b, len, wave, lane);
 }
 
 }  // namespace
@@ -379,7 +617,26 @@ hipError_t launch_vae_fused(const VaeFusedArgs& a, hipStream_t stream) {
         if (e != hipSuccess) return e;
         attr_set = true;
     }
-    hipLaunchKernelGGL(k_vae_fused, dim3(a.B), dim3(256), kVaeFusedLdsBytes, stream, a);
+#if AMUSE_FPROF
+    {
+        int zero = 0;
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(g_fprof_n), &zero, sizeof(int));
+    }
+#endif
+    hipLaunchKernelGGL(k_vae_fused, dim3(a.B), dim3(512), kVaeFusedLdsBytes, stream, a);
+#if AMUSE_FPROF
+    {
+        static int calls = 0;
+        (void)hipStreamSynchronize(stream);
+        unsigned long long h[512];
+        int n = 0;
+        (void)hipMemcpyFromSymbol(&n, HIP_SYMBOL(g_fprof_n), sizeof(int));
+        (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_fprof), sizeof(h));
+        if (++calls == 3) {
+            for (int i = 1; i < n; ++i) fprintf(stderr, "FPROF %3d tag %2llu  +%llu\n", i, h[2 * i + 1], h[2 * i] - h[2 * i - 2]);
+        }
+    }
+#endif
     return hipGetLastError();
 }
 

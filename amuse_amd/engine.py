@@ -53,6 +53,26 @@ class HipEngine:
         self.schedule: Optional[ScheduleTable] = None
         self.noisy_cfg: Dict[str, object] = {}   # DDPMScheduler config of add_noise (set_noisy_scheduler)
 
+    def update_weights(self, denoiser_sd=None, prior_sd=None, what: int = 7):
+        """amuse_update_weights: new state dicts (or pre-flattened float32 arrays in state-dict order) into this context;
+        `what` = AMUSE_UPD_* mask (1 fp32 streams, 2 bf16 streams, 4 prior-encoder streams too).  The current schedule
+        is re-applied after a denoiser update."""
+        fp = C.POINTER(C.c_float)
+
+        def flat(sd, spec):
+            if sd is None:
+                return None
+            a = sd if isinstance(sd, np.ndarray) else flatten_state_dict(sd, spec)
+            return np.ascontiguousarray(a, dtype=np.float32)
+        den, pri = flat(denoiser_sd, wts.denoiser_param_spec()), flat(prior_sd, wts.prior_param_spec())
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.amuse_update_weights(self.ctx, den.ctypes.data_as(fp) if den is not None else None,
+                                                     0 if den is None else den.size,
+                                                     pri.ctypes.data_as(fp) if pri is not None else None,
+                                                     0 if pri is None else pri.size, int(what), self._stream()))
+        if den is not None and self.schedule is not None:
+            self.set_schedule(self.schedule)
+
     def close(self):
         if getattr(self, "ctx", None):
             self.lib.amuse_destroy(self.ctx)
@@ -98,7 +118,7 @@ class HipEngine:
         _lib.check(self.lib.amuse_set_clips_per_group(self.ctx, int(g)))
 
     def set_decode_path(self, path: str = "auto"):
-        """bf16 decode kernels: "auto" (fused per-clip kernel from 24 clips up), "staged", "fused" (amuse_hip.h)."""
+        """bf16 decode kernels: "auto" (fused per-clip kernel from 96 clips up), "staged", "fused" (amuse_hip.h)."""
         _lib.check(self.lib.amuse_set_decode_path(self.ctx, {"auto": 0, "staged": 1, "fused": 2}[path]))
 
     def set_schedule(self, table: ScheduleTable):

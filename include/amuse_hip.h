@@ -81,6 +81,16 @@ typedef struct {
  * weight streams and uploads them.  Returns NULL on failure. */
 amuse_ctx* amuse_create(int device, const float* denoiser_params, size_t n_denoiser,
                         const float* prior_params, size_t n_prior);
+/* New weights into an existing context (same architecture): re-packs and overwrites the weight streams in place.
+ * Replaces what the reference gets for free from sharing nn.Module parameters between its training step and the
+ * in-loop sampler (scripts/trainer.py:411-415: ldm.diffusion_backward + prior.decode on the weights just stepped).
+ * Either array may be NULL (left as is).  `what` limits the host-side packing to what the caller will run:
+ * AMUSE_UPD_F32 | AMUSE_UPD_BF16 = the weight streams of that precision, AMUSE_UPD_ENCODER = MotionPrior.encode's streams
+ * too (a stream that is not re-packed keeps the OLD weights).  Synchronises `stream` first; after a denoiser update the
+ * schedule must be set again (the time-token table is a function of the time-embedding weights). */
+enum { AMUSE_UPD_F32 = 1, AMUSE_UPD_BF16 = 2, AMUSE_UPD_ENCODER = 4, AMUSE_UPD_ALL = 7 };
+int amuse_update_weights(amuse_ctx* ctx, const float* denoiser_params, size_t n_denoiser, const float* prior_params,
+                         size_t n_prior, int what, void* stream);
 void amuse_destroy(amuse_ctx* ctx);
 const char* amuse_last_error(void);
 int amuse_abi_version(void);
@@ -181,7 +191,7 @@ int amuse_set_clips_per_group(amuse_ctx* ctx, int g);
 
 /* Which kernels amuse_vae_decode (and amuse_diffusion_backward) use in bf16 mode.  AUTO: the fused per-clip kernel
  * (csrc/k_vae_fused.hip: one persistent workgroup per clip, residual stream in registers, K/V of the current head in LDS)
- * from 24 clips up, the staged kernels (csrc/k_vae.hip) below that; fp32 mode always runs the staged kernels.  Both
+ * from 96 clips up, the staged kernels (csrc/k_vae.hip) below that; fp32 mode always runs the staged kernels.  Both
  * compute MotionPrior.decode (vae.py:216-278) with bf16 MFMA operands and fp32 accumulation / residual stream; they differ
  * in summation order only.  The environment variable AMUSE_VAE_FUSED=0 / 1 overrides AUTO for a whole process. */
 enum { AMUSE_DECODE_AUTO = 0, AMUSE_DECODE_STAGED = 1, AMUSE_DECODE_FUSED = 2 };

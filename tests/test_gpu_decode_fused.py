@@ -67,7 +67,7 @@ def test_fused_decode_ragged_lengths(env):
 def test_fused_and_staged_decode_agree_and_auto_switches(env):
     eng = env["eng"]
     gen = torch.Generator().manual_seed(6)
-    z = torch.randn(40, 128, generator=gen)
+    z = torch.randn(100, 128, generator=gen)
     eng.set_decode_path("staged")
     s = eng.vae_decode(z, None, "bf16", return_feats=True)
     eng.set_decode_path("fused")
@@ -78,7 +78,7 @@ def test_fused_and_staged_decode_agree_and_auto_switches(env):
     f2 = eng.vae_decode(z, None, "bf16", return_feats=True)
     assert torch.equal(f["feats"], f2["feats"]) and torch.equal(f["poses"], f2["poses"])   # deterministic
     eng.set_decode_path("auto")
-    a = eng.vae_decode(z, None, "bf16", return_feats=True)                 # 40 clips >= 24: fused
+    a = eng.vae_decode(z, None, "bf16", return_feats=True)                 # 100 clips >= 96: fused
     assert torch.equal(a["feats"], f["feats"])
     a8 = eng.vae_decode(z[:8], None, "bf16", return_feats=True)            # 8 clips: staged
     assert torch.equal(a8["feats"], s["feats"][:8])
