@@ -1,0 +1,453 @@
+"""train_gesture (BASELINE config 4): the data-parallel training step of the latent-prior-diffusion model, reference
+scripts/trainer.py:335-498 (`trainer.train_prior_latdiff_forward_backward_v2`) with models/latent_diffusion/ldm.py:71-153
+and models/latent_diffusion/utils/latent_losses.py:8-151.
+
+One process per GPU (torch.distributed, backend "nccl" = RCCL over xGMI; "gloo" in the CPU tests).  Per iteration and rank
+(trainer.py:356-466):
+  motion (B,300,168) axis-angle + translation -> 333 features (axis-angle -> matrix -> 6D)                 :362-368
+  motion_z, dist_m = prior.encode(features);  feats_rst = prior.decode(motion_z)                           :381-382
+  with no_grad: inferred_motion_z = prior.encode(features)        (a second rsample)                       :409-410
+  n_set = ldm.diffusion_forward(inferred_motion_z, con, emo, sty) (noise, per-sample timesteps, add_noise)  :411-412
+  with no_grad: noise2z = ldm.diffusion_backward(...)  (DDIM-50);  noise2feats = prior.decode(noise2z)      :415-417
+  loss = SmoothL1(feats_rst, feats) + 1e-4 KL(dist_m || N(0,1)) + MSE(noise_pred, noise) + SmoothL1(noise2feats, feats)
+         (stage "vae_diffusion", train_lpdm v0, configs/diff_latent_v2.json "losses"; recons_joints is off for SMPL-X data,
+         trainer.py:174; the vertex-displacement terms need the SMPL-X body model assets and are not built)  :451
+  zero_grad; loss.backward(); [DP: ONE all-reduce of the flat fp32 gradient bucket]; AdamW(lr 1e-4).step()  :452-456
+
+What runs where.  The two networks under autograd are plain torch modules (amuse_amd/nn_modules.py - the reference's
+networks key for key).  The no-gradient half of the iteration - the in-loop DDIM-50 sampler (51 denoiser passes in the
+reference) and the decode of its result - is the inference hot path, so it runs on the HIP kernels (amuse_sample +
+amuse_vae_decode) on the weights of the current iteration (amuse_update_weights re-packs them; `sampler_refresh` > 1
+re-packs every n-th iteration only).  Two stated differences there: the HIP sampler has eval semantics (the reference
+leaves dropout live in its inner sampler because the modules are in train mode, trainer.py:357-358) and draws its initial
+latent from the counter-based generator; the term it feeds, gen_feature, carries no gradient (it is computed under no_grad
+in the reference too) - it is logged and added to `total`, nothing else.
+
+Gradient exchange.  All parameters' gradients live in ONE flat fp32 buffer (6,835,661 elements, 27.3 MB; every p.grad is
+a view into it), so the data-parallel step is a single all-reduce(SUM) of that buffer followed by a scale by 1 / world.
+xGMI is point-to-point (7 links per GPU): one 27 MB collective per iteration is the bucket size that keeps every link busy
+with large messages; there is nothing to overlap it with (it needs the complete backward pass) except the HIP weight
+re-pack of the previous step, which is host work.
+"""
+from __future__ import annotations
+
+import os
+import time
+from pathlib import Path
+from typing import Callable, Dict, Iterable, List, Optional
+
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import scheduler as sch
+from .nn_modules import Denoiser, MotionPrior, load_numpy_state
+
+SEQ_LEN = 300
+LOSS_CFG = {"train_lpdm": {"version": "v0"}, "stage": "vae_diffusion", "LAMBDA_PRIOR": 0.0, "LAMBDA_GEN": 1.0,
+            "LAMBDA_LATENT": 1.0, "LAMBDA_KL": 1e-4, "LAMBDA_REC": 1.0, "LAMBDA_JOINT": 1.0, "use_recons_joints": False,
+            "predict_epsilon": True, "vtex_displacement": False}   # configs/diff_latent_v2.json "losses" + trainer.py:174-175
+
+
+# ------------------------------------------------------------------ rotations (pytorch3d.transforms, vendored copy
+# models/diffusion/utils/rotation_conversions.py:425-478, 41-71, 536-551)
+def axis_angle_to_rotation_6d(aa: torch.Tensor) -> torch.Tensor:
+    ang = torch.linalg.vector_norm(aa, dim=-1, keepdim=True)
+    half = 0.5 * ang
+    small = ang.abs() < 1e-6
+    s = torch.where(small, 0.5 - ang * ang / 48.0, torch.sin(half) / torch.where(small, torch.ones_like(ang), ang))
+    q = torch.cat([torch.cos(half), aa * s], dim=-1)
+    r, i, j, k = q.unbind(-1)
+    two_s = 2.0 / (q * q).sum(-1)
+    row0 = torch.stack([1 - two_s * (j * j + k * k), two_s * (i * j - k * r), two_s * (i * k + j * r)], -1)
+    row1 = torch.stack([two_s * (i * j + k * r), 1 - two_s * (i * i + k * k), two_s * (j * k - i * r)], -1)
+    return torch.cat([row0, row1], dim=-1)
+
+
+def motion_to_feats(ld_motion: torch.Tensor) -> torch.Tensor:
+    """(B, S, 168) = 55 x 3 axis-angle ++ 3 translation -> (B, S, 333) = 55 x 6D ++ translation   (trainer.py:362-368)."""
+    poses, trans = ld_motion[..., :-3], ld_motion[..., -3:]
+    rot6 = axis_angle_to_rotation_6d(poses.reshape(*poses.shape[:-1], 55, 3)).reshape(*poses.shape[:-1], 330)
+    return torch.cat([rot6, trans], dim=-1)
+
+
+# ------------------------------------------------------------------ losses (latent_losses.py:8-151, without torchmetrics)
+class LatentPriorLosses:
+    """Stage / version / lambdas of the loss config select the terms exactly as latent_losses.py:36-98 does; update()
+    returns the weighted total of one iteration and accumulates the un-weighted terms, compute() averages them."""
+
+    def __init__(self, cfg: Optional[dict] = None, device="cpu"):
+        c = dict(LOSS_CFG)
+        c.update((cfg or {}).get("losses", cfg or {}))
+        if c.get("vtex_displacement"):
+            raise NotImplementedError("vertex-displacement losses need the SMPL-X body models (trainer.py:91-104); not built")
+        self.cfg, self.d = c, device
+        self.stage, self.version = c["stage"], c["train_lpdm"]["version"]
+        losses = []
+        if self.stage in ("diffusion", "vae_diffusion"):
+            losses.append("inst_loss")
+        if self.stage in ("vae", "vae_diffusion"):
+            losses += ["recons_feature", "recons_joints", "kl_motion"]
+            if self.version == "v0":
+                losses += ["gen_feature", "gen_joints"]
+            elif self.version == "v1":
+                losses.append("latent_feature")
+            else:
+                raise ValueError(f"train_lpdm_version {self.version} not supported, choose: v0 or v1")
+        if self.stage not in ("vae", "diffusion", "vae_diffusion"):
+            raise ValueError(f"Stage {self.stage} not supported")
+        losses.append("total")
+        self.losses = losses
+        self._params = {"inst_loss": 1.0, "kl_motion": c["LAMBDA_KL"], "recons_feature": c["LAMBDA_REC"],
+                        "recons_joints": c["LAMBDA_JOINT"], "gen_feature": c["LAMBDA_GEN"], "gen_joints": c["LAMBDA_JOINT"],
+                        "latent_feature": c["LAMBDA_LATENT"]}
+        self.reset()
+
+    def reset(self):
+        self.sums = {k: torch.zeros((), device=self.d) for k in self.losses}
+        self.count = 0
+
+    def _update_loss(self, name, outputs, inputs):
+        if name == "inst_loss":
+            val = F.mse_loss(outputs, inputs)
+        elif name == "kl_motion":
+            val = torch.distributions.kl_divergence(outputs, inputs).mean()
+        else:
+            val = F.smooth_l1_loss(outputs, inputs)
+        self.sums[name] += val.detach()
+        return self._params[name] * val
+
+    def update(self, rs_set, audio_ablation=None):
+        total = 0.0
+        if self.stage in ("vae", "vae_diffusion"):
+            total = total + self._update_loss("recons_feature", rs_set["m_rst"], rs_set["m_ref"])
+            if self.cfg["use_recons_joints"]:
+                total = total + self._update_loss("recons_joints", rs_set["joints_rst"], rs_set["joints_ref"])
+            if self.cfg["LAMBDA_KL"] != 0.0:
+                total = total + self._update_loss("kl_motion", rs_set["dist_m"], rs_set["dist_ref"])
+        if self.stage in ("diffusion", "vae_diffusion"):
+            if not self.cfg["predict_epsilon"]:
+                raise NotImplementedError("x-prediction (predict_epsilon False) is not configured by the reference")
+            total = total + self._update_loss("inst_loss", rs_set["noise_pred"], rs_set["noise"])
+        if self.stage == "vae_diffusion":
+            if self.version == "v0":
+                if rs_set.get("gen_m_rst") is not None:
+                    total = total + self._update_loss("gen_feature", rs_set["gen_m_rst"], rs_set["m_ref"])
+            else:
+                total = total + self._update_loss("latent_feature", rs_set["lat_rm"], rs_set["lat_m"])
+        self.sums["total"] += total.detach()
+        self.count += 1
+        return total
+
+    def compute(self):
+        return {k: (v / max(self.count, 1)) for k, v in self.sums.items()}
+
+
+# ------------------------------------------------------------------ the ldm wrapper under autograd (ldm.py:16-153)
+class LatentDiffusionTrainModule(nn.Module):
+    """`allmodels["latent_diffusion"]` for training: owns the Denoiser (state-dict prefix `denoiser.`, which is what
+    infer_ldm.py:91-104 strips) and the DDPM noise schedule of add_noise."""
+
+    def __init__(self, ldm_cfg: Optional[dict] = None, dropout: float = 0.1):
+        super().__init__()
+        self.denoiser = Denoiser(dropout=dropout)
+        ns = (ldm_cfg or {}).get("noisy_scheduler", {})
+        keys = ("num_train_timesteps", "beta_start", "beta_end", "beta_schedule")
+        self.register_buffer("alphas_cumprod", torch.from_numpy(sch.alphas_cumprod(**{k: ns[k] for k in keys if k in ns})),
+                             persistent=False)
+        self.num_train_timesteps = int(self.alphas_cumprod.numel())
+
+    def diffusion_forward(self, z, ld_audio_con, ld_audio_emo, ld_audio_sty, lengths=None, ld_audio_mfcc=None, noise=None,
+                          timesteps=None):
+        """z (1, B, 128) -> {"noise", "noise_pred", "noise_prior", "noise_pred_prior"}   (ldm.py:71-115); `noise` /
+        `timesteps` may be given (tests, data-parallel equivalence checks), else torch.randn_like / torch.randint."""
+        if ld_audio_mfcc is not None:
+            raise NotImplementedError("LPDM: Baseline audio AE not implemented yet")
+        z = z.permute(1, 0, 2)
+        bsz = z.shape[0]
+        noise = torch.randn_like(z) if noise is None else noise.to(z)
+        if timesteps is None:
+            timesteps = torch.randint(0, self.num_train_timesteps, (bsz,), device=z.device)
+        timesteps = timesteps.long().to(z.device)
+        ac = self.alphas_cumprod.to(z.device)[timesteps]
+        noisy = ac.sqrt()[:, None, None] * z.clone() + (1 - ac).sqrt()[:, None, None] * noise   # DDPMScheduler.add_noise
+        noise_pred = self.denoiser(noisy, timesteps, ld_audio_con, ld_audio_emo, ld_audio_sty, lengths=lengths)[0]
+        return {"noise": noise, "noise_prior": 0, "noise_pred": noise_pred, "noise_pred_prior": 0}
+
+
+def synthetic_batch(bsz: int, seed: int, device="cpu") -> Dict[str, torch.Tensor]:
+    """ld_motion (B,300,168) axis-angle + translation ~ N(0, 0.1), conditions ~ N(0, 1); the keys of
+    latdiff_long_collate_fn_v1 (dm/dataload.py:287-308) that the iteration reads."""
+    g = torch.Generator().manual_seed(seed)
+    return {"ld_motion": (0.1 * torch.randn(bsz, SEQ_LEN, 168, generator=g)).to(device),
+            "ld_audio_con": torch.randn(bsz, 256, generator=g).to(device), "ld_audio_emo": torch.randn(bsz, 256, generator=g).to(device),
+            "ld_audio_sty": torch.randn(bsz, 256, generator=g).to(device), "ld_attr": [("scott", "male")] * bsz}
+
+
+class GestureTrainer:
+    """The LPDM half of scripts/trainer.py's `trainer` (tag "LPDM"): models {"prior", "ldm"}, LatentPriorLosses, AdamW over
+    both parameter lists (trainer.py:176-182), the iteration of :335-466 and the checkpoint writer of :468-496."""
+
+    def __init__(self, prior: MotionPrior, ldm: LatentDiffusionTrainModule, device, lr: float = 1e-4, loss_cfg: Optional[dict] = None,
+                 inner_sampler: Optional[Callable] = None, process_group=None, world: int = 1, kind: Optional[str] = None):
+        self.model = {"prior": prior.to(device), "ldm": ldm.to(device)}
+        self.device = torch.device(device)
+        self.lpdm_losses = LatentPriorLosses(loss_cfg, self.device)
+        self.inner_sampler = inner_sampler      # (con, emo, sty, bsz) -> noise2feats (B,300,333) or None
+        self.world, self.pg = world, process_group
+        self.kind = kind                        # ablation variant of the LMDB id (trainer.py:393-399): full / emotion / identity
+        self.params: List[nn.Parameter] = list(prior.parameters()) + list(ldm.parameters())   # trainer.py:181
+        # ---- one flat fp32 gradient bucket; every p.grad is a view into it
+        n = sum(p.numel() for p in self.params)
+        self.flat_grad = torch.zeros(n, device=self.device, dtype=torch.float32)
+        off = 0
+        for p in self.params:
+            p.grad = self.flat_grad[off:off + p.numel()].view_as(p)
+            off += p.numel()
+        # parameters the iteration never reaches (denoiser.mem_pos.pe: the trans_enc path uses query_pos only) get no
+        # gradient in the reference (grad stays None after zero_grad(set_to_none=True)), so its AdamW never touches them -
+        # not even with weight decay.  They stay in the bucket (zeros) but out of the optimizer.
+        unused = {id(ldm.denoiser.mem_pos.pe)}
+        self.lpdm_opt = torch.optim.AdamW(lr=lr, params=[p for p in self.params if id(p) not in unused])
+        self.allreduce_ms: List[float] = []
+
+    def n_grad_elements(self) -> int:
+        return int(self.flat_grad.numel())
+
+    # ------------------------------------------------------------------ one iteration (trainer.py:356-456)
+    def forward_losses(self, batch, noise=None, timesteps=None, eps_enc=None, eps_inf=None):
+        prior, ldm = self.model["prior"], self.model["ldm"]
+        motion = motion_to_feats(batch["ld_motion"].to(self.device, torch.float32))
+        lengths = [SEQ_LEN] * motion.shape[0]
+        motion_z, dist_m = prior.encode(motion, lengths)
+        if eps_enc is not None:                       # explicit rsample draw (tests): z = mu + std * eps
+            motion_z = dist_m.loc + dist_m.scale * eps_enc.to(self.device)
+        feats_rst = prior.decode(motion_z, lengths)
+        dist_ref = torch.distributions.Normal(torch.zeros_like(dist_m.loc), torch.ones_like(dist_m.scale))
+        con, emo, sty = batch["ld_audio_con"], batch.get("ld_audio_emo"), batch.get("ld_audio_sty")
+        if self.kind in ("emotion", "baseline"):
+            sty = None
+        elif self.kind == "identity":
+            emo = None
+        con = con.to(self.device)
+        emo = emo.to(self.device) if emo is not None else None
+        sty = sty.to(self.device) if sty is not None else None
+        with torch.no_grad():
+            inferred_z, dist_i = prior.encode(motion, lengths)
+            if eps_inf is not None:
+                inferred_z = dist_i.loc + dist_i.scale * eps_inf.to(self.device)
+        n_set = ldm.diffusion_forward(inferred_z, con, emo, sty, lengths=lengths, noise=noise, timesteps=timesteps)
+        gen = None
+        if self.inner_sampler is not None:            # inverse diffusion (no gradient): the HIP sampler + decode
+            with torch.no_grad():
+                gen = self.inner_sampler(con, emo, sty, motion.shape[0])
+        rs_set = {"m_ref": motion, "m_rst": feats_rst, "dist_m": dist_m, "dist_ref": dist_ref, "noise_pred": n_set["noise_pred"],
+                  "noise": n_set["noise"], "gen_m_rst": gen, "attr": batch.get("ld_attr")}
+        return self.lpdm_losses.update(rs_set)
+
+    def train_step(self, batch, **explicit) -> torch.Tensor:
+        for m in self.model.values():
+            m.train()
+        torch.set_grad_enabled(True)
+        loss = self.forward_losses(batch, **explicit)
+        self.flat_grad.zero_()                        # zero_grad: the views stay attached to the bucket
+        loss.backward()
+        self.allreduce_gradients()
+        self.lpdm_opt.step()
+        return loss.detach()
+
+    def allreduce_gradients(self):
+        if self.world <= 1:
+            return
+        import torch.distributed as dist
+        timed = self.device.type == "cuda"
+        if timed:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+        dist.all_reduce(self.flat_grad, op=dist.ReduceOp.SUM, group=self.pg)   # the iteration's ONE collective
+        self.flat_grad.mul_(1.0 / self.world)
+        if timed:
+            e1.record()
+            self._pending = (e0, e1)
+
+    def pop_allreduce_ms(self) -> Optional[float]:
+        p = getattr(self, "_pending", None)
+        if p is None:
+            return None
+        p[1].synchronize()
+        self._pending = None
+        return p[0].elapsed_time(p[1])
+
+    # ------------------------------------------------------------------ checkpoints (trainer.py:468-496)
+    def save_checkpoint(self, model_path, epoch: int, loss_dict: Optional[dict] = None):
+        """prior_model_NoOpt_..._e<N>.pt {"epoch", "model_state_dict"} and latdiff_model_wOpt_..._e<N>.pt {"epoch",
+        "model_state_dict", "optimizer_state_dict"} with the reference's loss-encoded file names (the readers pick "best"
+        by the `total` field, infer_ldm.py:76-81)."""
+        ld = {k: float(v) for k, v in (loss_dict or self.lpdm_losses.compute()).items()}
+        for k in ("recons_feature", "recons_joints", "kl_motion", "gen_feature", "gen_joints", "inst_loss", "total"):
+            ld.setdefault(k, 0.0)
+        ld.setdefault("rec_vtex_displacement", 0.0)
+        ld.setdefault("gen_vtex_displacement", 0.0)
+        tail = "recF{:.4f}_recJ{:.4f}_kl{:.4f}_genF{:.4f}_genJ{:.4f}_instL{:.4f}_vtexR{:.4f}_vtexG{:.4f}_total{:.4f}_e{}.pt".format(
+            ld["recons_feature"], ld["recons_joints"], ld["kl_motion"], ld["gen_feature"], ld["gen_joints"], ld["inst_loss"],
+            ld["rec_vtex_displacement"], ld["gen_vtex_displacement"], ld["total"], epoch + 1)
+        model_path = Path(model_path)
+        model_path.mkdir(parents=True, exist_ok=True)
+        p1, p2 = model_path / ("prior_model_NoOpt_" + tail), model_path / ("latdiff_model_wOpt_" + tail)
+        torch.save({"epoch": epoch, "model_state_dict": self.model["prior"].state_dict()}, p1)
+        torch.save({"epoch": epoch, "model_state_dict": self.model["ldm"].state_dict(),
+                    "optimizer_state_dict": self.lpdm_opt.state_dict()}, p2)
+        return p1, p2
+
+    # ------------------------------------------------------------------ the epoch loop (trainer.py:353-466)
+    def train_prior_latdiff_forward_backward_v2(self, train_loader: Iterable, epochs: int, model_path=None, model_save_freq: int = 200,
+                                                rank: int = 0, on_iteration: Optional[Callable] = None):
+        iter_start_time = time.time()
+        for epoch in range(epochs):
+            for batch in train_loader:
+                self.train_step(batch)
+                if on_iteration is not None:
+                    on_iteration(self)
+            loss_dict = self.lpdm_losses.compute()
+            self.lpdm_losses.reset()
+            if rank == 0:
+                print(f"[LPDM-T] Epoch: [{epoch + 1}/{epochs}] t: {time.time() - iter_start_time:.4f} s, rec_feat: "
+                      f"{float(loss_dict['recons_feature']):.8f}, kl: {float(loss_dict['kl_motion']):.8f}, inst_loss: "
+                      f"{float(loss_dict['inst_loss']):.8f}, gen_feature: {float(loss_dict['gen_feature']):.8f}, total: "
+                      f"{float(loss_dict['total']):.8f}", flush=True)
+                if model_path is not None and (epoch + 1) % model_save_freq == 0:
+                    print(f"[LPDM-T] Saving model at epoch {epoch + 1}", flush=True)
+                    self.save_checkpoint(model_path, epoch, loss_dict)
+        if rank == 0:
+            print("[LPDM] Training finished, total time elapsed: %4.4f mins" % ((time.time() - iter_start_time) / 60.0))
+
+
+class HipInnerSampler:
+    """ldm.diffusion_backward (DDIM-50, ldm.py:117-153) + prior.decode of its result on the HIP kernels, on the trainer's
+    CURRENT weights.  refresh = n: amuse_update_weights every n-th call (1 = every iteration, the reference's semantics)."""
+
+    def __init__(self, trainer_models: Dict[str, nn.Module], device, precision: str = "bf16", refresh: int = 1, seed: int = 2024,
+                 ldm_cfg: Optional[dict] = None):
+        from .engine import HipEngine
+        self.models, self.precision, self.refresh, self.seed = trainer_models, precision, max(1, refresh), seed
+        self.engine = HipEngine(self._den_state(), self._prior_state(), device)
+        self.engine.set_schedule(sch.from_ldm_cfg(ldm_cfg, "ddim") if ldm_cfg and "scheduler" in ldm_cfg else sch.ddim_table())
+        self.calls, self.clip_counter, self.sync_ms = 0, 0, []
+        self.what = (2 if precision == "bf16" else 1)
+
+    def _den_state(self):
+        return {k: v.detach().cpu().numpy() for k, v in self.models["ldm"].denoiser.state_dict().items()}
+
+    def _prior_state(self):
+        return {k: v.detach().cpu().numpy() for k, v in self.models["prior"].state_dict().items()}
+
+    def __call__(self, con, emo, sty, bsz):
+        if self.calls % self.refresh == 0 and self.calls > 0:
+            t0 = time.perf_counter()
+            self.engine.update_weights(self._den_state(), self._prior_state(), what=self.what)
+            self.sync_ms.append((time.perf_counter() - t0) * 1e3)
+        self.calls += 1
+        lat = self.engine.sample(con, emo, sty, self.precision, seed=self.seed, clip_index0=self.clip_counter)
+        self.clip_counter += bsz
+        return self.engine.vae_decode(lat, None, self.precision, return_feats=True)["feats"]
+
+
+def build_trainer(device, rank: int = 0, world: int = 1, process_group=None, seed: int = 0, use_hip_sampler: bool = True,
+                  dropout: float = 0.1, sampler_refresh: int = 1, ldm_cfg: Optional[dict] = None) -> GestureTrainer:
+    """Random-init prior + ldm (the deterministic weights of amuse_amd/weights.py, identical on every rank - what DDP's
+    initial broadcast gives the reference's DataParallel-less single-GPU run) and the trainer around them."""
+    from . import weights as wts
+    prior = load_numpy_state(MotionPrior(dropout=dropout), wts.make_prior_weights(seed))
+    ldm = LatentDiffusionTrainModule(ldm_cfg, dropout=dropout)
+    load_numpy_state(ldm.denoiser, wts.make_denoiser_weights(seed))
+    tr = GestureTrainer(prior, ldm, device, inner_sampler=None, process_group=process_group, world=world)
+    if use_hip_sampler:
+        if torch.device(device).type != "cuda":
+            raise RuntimeError("the in-loop sampler of train_gesture runs on the HIP kernels: no CPU path (pass use_hip_sampler=False "
+                               "to train without the no-gradient gen_feature term)")
+        tr.inner_sampler = HipInnerSampler(tr.model, device, refresh=sampler_refresh, ldm_cfg=ldm_cfg)
+    return tr
+
+
+def bench_main(args):
+    """`python bench.py --config train [--gpus N]`: iterations/s of the data-parallel step at batch 32 per GPU (weak
+    scaling: the reference's batch_size 32 is per process), all-reduce ms, HIP weight re-pack ms.  Prints one JSON line."""
+    import json
+    import torch.distributed as dist
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py --config train needs an MI355X")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+    torch.manual_seed(1234 + rank)
+    tr = build_trainer(dev, rank, world)
+    bsz = 32
+    batches = [synthetic_batch(bsz, 100 * rank + i, dev) for i in range(4)]
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    ar = []
+    for i in range(args.warmup):
+        tr.train_step(batches[i % 4])
+        tr.pop_allreduce_ms()
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        tr.train_step(batches[i % 4])
+        ms = tr.pop_allreduce_ms()
+        if ms is not None:
+            ar.append(ms)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    if rank == 0:
+        its = args.steps / elapsed
+        ld = {k: round(float(v), 6) for k, v in tr.lpdm_losses.compute().items()}
+        sync = tr.inner_sampler.sync_ms if tr.inner_sampler is not None else []
+        print(json.dumps({
+            "metric": "train_gesture iterations/sec (data-parallel step, batch 32 per GPU)", "value": round(its, 3), "unit": "it/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"train_gesture (configs/diff_latent_v2.json): prior encode/decode + epsilon loss under autograd "
+                                   f"(torch fp32), in-loop DDIM-50 sampler + decode on the HIP kernels (bf16), AdamW(1e-4), one flat "
+                                   f"all-reduce of {tr.n_grad_elements():,} fp32 gradients; batch {bsz} per GPU, {bsz * world} global; "
+                                   f"vertex-displacement loss off (needs SMPL-X assets)",
+                       "batch_per_gpu": bsz, "grad_elements": tr.n_grad_elements()},
+            "samples_per_s": round(its * bsz * world, 1),
+            "allreduce_ms": round(float(np.median(ar)), 3) if ar else None,
+            "hip_weight_repack_ms": round(float(np.median(sync)), 3) if sync else None,
+            "losses": ld}), flush=True)
+    barrier()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def main(argv=None):
+    import argparse
+    ap = argparse.ArgumentParser(description="train_gesture on synthetic data (the BEAT LMDB reader, dm/dataload.py, is out of scope)")
+    ap.add_argument("--epochs", type=int, default=1)
+    ap.add_argument("--iters-per-epoch", type=int, default=8)
+    ap.add_argument("--out", default=None)
+    ap.add_argument("--device", default="cuda:0")
+    args = ap.parse_args(argv)
+    tr = build_trainer(args.device)
+    loader = [synthetic_batch(32, i, args.device) for i in range(args.iters_per_epoch)]
+    tr.train_prior_latdiff_forward_backward_v2(loader, args.epochs, args.out, model_save_freq=1)
+
+
+if __name__ == "__main__":
+    main()

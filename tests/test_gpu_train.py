@@ -1,0 +1,62 @@
+"""GPU: train_gesture's step with the in-loop sampler on the HIP kernels, and amuse_update_weights behind it."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def test_update_weights_equals_a_fresh_context():
+    """amuse_update_weights re-packs in place: afterwards the context is indistinguishable from one created on the new
+    weights (sampling, decode, encode; both precisions; the schedule is re-applied)."""
+    from amuse_amd import scheduler as sch, weights as wts
+    from amuse_amd.engine import HipEngine
+    w0 = (wts.make_denoiser_weights(0), wts.make_prior_weights(0))
+    w1 = (wts.make_denoiser_weights(1), wts.make_prior_weights(1))
+    a, b = HipEngine(*w0), HipEngine(*w1)
+    for e in (a, b):
+        e.set_schedule(sch.ddim_table())
+    gen = torch.Generator().manual_seed(0)
+    c, em, s, x = (torch.randn(100, n, generator=gen) for n in (256, 256, 256, 128))
+    before = a.sample(c, em, s, "bf16", x_init=x)
+    a.update_weights(*w1)
+    for prec in ("fp32", "bf16"):
+        la, lb = a.sample(c, em, s, prec, x_init=x), b.sample(c, em, s, prec, x_init=x)
+        assert torch.equal(la, lb), prec
+        da, db = a.vae_decode(la, None, prec, return_feats=True), b.vae_decode(lb, None, prec, return_feats=True)   # fused path in bf16
+        assert torch.equal(da["feats"], db["feats"]) and torch.equal(da["poses"], db["poses"]), prec
+        assert torch.equal(a.vae_decode(la[:4], [300, 17, 160, 1], prec)["poses"], b.vae_decode(lb[:4], [300, 17, 160, 1], prec)["poses"])
+        f = torch.randn(2, 300, 333, generator=gen)
+        assert torch.equal(a.vae_encode(f, None, prec)["mu"], b.vae_encode(f, None, prec)["mu"])
+    assert not torch.equal(before, a.sample(c, em, s, "bf16", x_init=x))
+    # a partial update (bf16 streams only) leaves the fp32 streams on the old weights - documented, and visible
+    a.update_weights(*w0, what=2)
+    assert torch.equal(a.sample(c, em, s, "bf16", x_init=x), before)
+    assert torch.equal(a.sample(c[:4], em[:4], s[:4], "fp32", x_init=x[:4]), b.sample(c[:4], em[:4], s[:4], "fp32", x_init=x[:4]))   # fp32: still w1
+    with pytest.raises(Exception):
+        a.update_weights(None, None)
+    a.close(); b.close()
+
+
+def test_train_step_with_hip_inner_sampler():
+    from amuse_amd.engine import HipEngine
+    from amuse_amd.train_gesture import build_trainer, synthetic_batch
+    torch.manual_seed(0)
+    tr = build_trainer("cuda:0")
+    batch = synthetic_batch(32, 3, "cuda:0")
+    l0 = float(tr.train_step(batch))
+    ld = {k: float(v) for k, v in tr.lpdm_losses.compute().items()}
+    assert np.isfinite(l0) and ld["gen_feature"] > 0 and np.isfinite(ld["gen_feature"])
+    assert abs(ld["total"] - (ld["recons_feature"] + 1e-4 * ld["kl_motion"] + ld["inst_loss"] + ld["gen_feature"])) < 1e-4 * max(1.0, ld["total"])
+    for _ in range(3):
+        tr.train_step(batch)
+    assert float(tr.lpdm_losses.compute()["recons_feature"]) < ld["recons_feature"]      # the step optimises
+    # the in-loop sampler runs on the CURRENT weights: its context equals a fresh one built from the modules' state
+    s = tr.inner_sampler
+    s.engine.update_weights(s._den_state(), s._prior_state(), what=2)
+    fresh = HipEngine(s._den_state(), s._prior_state())
+    fresh.set_schedule(s.engine.schedule)
+    lat_a = s.engine.sample(batch["ld_audio_con"], batch["ld_audio_emo"], batch["ld_audio_sty"], "bf16", seed=1)
+    lat_b = fresh.sample(batch["ld_audio_con"], batch["ld_audio_emo"], batch["ld_audio_sty"], "bf16", seed=1)
+    assert torch.equal(lat_a, lat_b) and len(s.sync_ms) >= 3
+    fresh.close()

@@ -1,0 +1,152 @@
+"""CPU tests of the train_gesture path (BASELINE config 4): the autograd modules against the reference's golden vectors,
+the loss set, one optimisation step, the checkpoint writer, and the data-parallel gradient exchange (2 ranks, gloo)."""
+import json
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN, REPO
+
+
+@pytest.fixture(scope="module")
+def nets():
+    from amuse_amd import weights as wts
+    from amuse_amd.nn_modules import Denoiser, MotionPrior, load_numpy_state
+    wd, wp = wts.make_denoiser_weights(0), wts.make_prior_weights(0)
+    return load_numpy_state(Denoiser(), wd).eval(), load_numpy_state(MotionPrior(), wp).eval(), wd, wp
+
+
+def test_autograd_modules_are_the_reference_networks(nets):
+    """Same state-dict keys / shapes as the reference modules and, in eval mode, the same numbers as the golden vectors
+    the reference's own Denoiser / MotionPrior produced (oracle/gen_golden.py)."""
+    d, p, wd, wp = nets
+    spec = json.load(open(GOLDEN / "state_dict_spec.json"))
+    assert {k: list(v.shape) for k, v in d.state_dict().items()} == {k: list(v) for k, v in spec["denoiser"].items()}
+    assert {k: list(v.shape) for k, v in p.state_dict().items()} == {k: list(v) for k, v in spec["prior"].items()}
+    assert sum(v.numel() for v in d.parameters()) + sum(v.numel() for v in p.parameters()) == 6835661
+    g = np.load(GOLDEN / "denoiser_steps.npz")
+    x, con, emo, sty = (torch.from_numpy(g[k]) for k in ("x_t", "con", "emo", "sty"))
+    err = lambda a, b: float((a - torch.from_numpy(b)).abs().max())
+    with torch.no_grad():
+        for t in (981, 501, 1):
+            assert err(d(x[:, None], t, con, emo, sty)[0][:, 0], g[f"eps_t{t}"]) < 1e-5
+        assert err(d(x[:, None], 501, con, None, sty)[0][:, 0], g["eps_t501_noemo"]) < 1e-5
+        assert err(d(x[:, None], 501, con, None, None)[0][:, 0], g["eps_t501_consolo"]) < 1e-5
+        assert err(d(x[:, None], torch.from_numpy(g["timesteps_batch"]), con, emo, sty)[0][:, 0], g["eps_batch_t"]) < 1e-5
+        gv = np.load(GOLDEN / "vae_decode.npz")
+        z = torch.from_numpy(gv["z"])
+        assert err(p.decode(z[None], [300] * 3), gv["feats"]) < 2e-5
+        assert err(p.decode(z[None, :2], [300, 173]), gv["feats_ragged"]) < 2e-5
+        ge = np.load(GOLDEN / "vae_encode.npz")
+        fe = torch.from_numpy(ge["feats"].astype(np.float32))
+        lat, dist = p.encode(fe, [300] * fe.shape[0])
+        assert lat.shape == (1, fe.shape[0], 128)
+        assert err(dist.loc[0], ge["mu"]) < 2e-5 and err(dist.scale[0], ge["std"]) < 2e-5
+        _, dr = p.encode(fe, [int(v) for v in ge["lengths_ragged"]])
+        assert err(dr.loc[0], ge["mu_ragged"]) < 2e-5
+
+
+def test_motion_to_feats_matches_oracle():
+    from amuse_amd.train_gesture import motion_to_feats
+    from oracle import amuse_oracle as orc
+    g = torch.Generator().manual_seed(0)
+    m = torch.cat([0.7 * torch.randn(2, 5, 165, generator=g), torch.randn(2, 5, 3, generator=g)], -1)
+    m[0, 0, :3] = 0.0                                                       # the small-angle branch
+    ref = torch.cat([orc.axis_angle_to_rotation_6d(m[..., :165].reshape(2, 5, 55, 3)).reshape(2, 5, 330), m[..., 165:]], -1)
+    assert float((motion_to_feats(m) - ref).abs().max()) < 1e-6
+
+
+def test_loss_set_and_one_training_step(tmp_path):
+    from amuse_amd import checkpoint as ckpt
+    from amuse_amd.train_gesture import LatentPriorLosses, build_trainer, synthetic_batch
+    torch.manual_seed(0)
+    tr = build_trainer("cpu", use_hip_sampler=False)
+    assert tr.n_grad_elements() == 6835661 and tr.lpdm_losses.losses == ["inst_loss", "recons_feature", "recons_joints", "kl_motion",
+                                                                         "gen_feature", "gen_joints", "total"]
+    batch = synthetic_batch(2, 1)
+    before = {k: v.detach().clone() for k, v in tr.model["ldm"].state_dict().items()}
+    loss = tr.train_step(batch)
+    ld = {k: float(v) for k, v in tr.lpdm_losses.compute().items()}
+    assert np.isfinite(float(loss)) and abs(ld["total"] - float(loss)) < 1e-6
+    # total = recons + 1e-4 kl + inst (no inner sampler here -> no gen_feature term)   (latent_losses.py:101-151)
+    assert abs(ld["total"] - (ld["recons_feature"] + 1e-4 * ld["kl_motion"] + ld["inst_loss"])) < 1e-5 * max(1.0, ld["total"])
+    after = tr.model["ldm"].state_dict()
+    assert not torch.equal(before["denoiser.encoder.norm.weight"], after["denoiser.encoder.norm.weight"])
+    assert torch.equal(before["denoiser.mem_pos.pe"], after["denoiser.mem_pos.pe"])   # never reached: no grad, no weight decay
+    # every p.grad is a view of the one flat bucket
+    off = 0
+    for p in tr.params:
+        assert p.grad.data_ptr() == tr.flat_grad.data_ptr() + 4 * off
+        off += p.numel()
+    # checkpoint writer: the reference's file names; the readers pick them up and return the trained weights
+    p1, p2 = tr.save_checkpoint(tmp_path / "LPDM_x", epoch=199)
+    pat = r"_recF\d+\.\d{4}_recJ\d+\.\d{4}_kl\d+\.\d{4}_genF\d+\.\d{4}_genJ\d+\.\d{4}_instL\d+\.\d{4}_vtexR\d+\.\d{4}_vtexG\d+\.\d{4}_total\d+\.\d{4}_e200\.pt$"
+    assert p1.name.startswith("prior_model_NoOpt") and p2.name.startswith("latdiff_model_wOpt") and re.search(pat, p1.name) and re.search(pat, p2.name)
+    lat = ckpt.pick_checkpoint(tmp_path / "LPDM_x", "latdiff", "best")
+    assert lat == p2 and ckpt.epoch_of(lat) == 200
+    dsd = ckpt.load_denoiser_checkpoint(lat)
+    assert np.array_equal(dsd["encoder.norm.weight"], after["denoiser.encoder.norm.weight"].numpy())
+    psd = ckpt.load_prior_checkpoint(ckpt.pick_checkpoint(tmp_path / "LPDM_x", "prior", 200))
+    assert np.array_equal(psd["final_layer.bias"], tr.model["prior"].state_dict()["final_layer.bias"].numpy())
+    assert set(torch.load(p2, weights_only=False)) == {"epoch", "model_state_dict", "optimizer_state_dict"}
+    # the term set follows the config like latent_losses.py:36-56
+    assert LatentPriorLosses({"stage": "diffusion"}).losses == ["inst_loss", "total"]
+    with pytest.raises(NotImplementedError):
+        LatentPriorLosses({"vtex_displacement": True})
+    with pytest.raises(RuntimeError):
+        build_trainer("cpu", use_hip_sampler=True)                          # the in-loop sampler has no CPU path
+
+
+_DP_WORKER = r'''
+import os, sys
+import torch, torch.distributed as dist
+sys.path.insert(0, sys.argv[1])
+from amuse_amd.train_gesture import build_trainer, synthetic_batch
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo", rank=rank, world_size=world)
+torch.set_num_threads(2)
+B = 2                                                   # per rank
+full = synthetic_batch(B * world, 5)
+g = torch.Generator().manual_seed(9)
+noise = torch.randn(B * world, 1, 128, generator=g)
+ts = torch.randint(0, 1000, (B * world,), generator=g)
+e1, e2 = torch.randn(1, B * world, 128, generator=g), torch.randn(1, B * world, 128, generator=g)
+sl = slice(rank * B, (rank + 1) * B)
+shard = {k: (v[sl] if torch.is_tensor(v) else v[sl]) for k, v in full.items()}
+tr = build_trainer("cpu", rank, world, use_hip_sampler=False, dropout=0.0)
+loss = tr.forward_losses(shard, noise=noise[sl], timesteps=ts[sl], eps_enc=e1[:, sl], eps_inf=e2[:, sl])
+tr.flat_grad.zero_(); loss.backward(); tr.allreduce_gradients()
+if rank == 0:
+    ref = build_trainer("cpu", 0, 1, use_hip_sampler=False, dropout=0.0)
+    l1 = ref.forward_losses(full, noise=noise, timesteps=ts, eps_enc=e1, eps_inf=e2)
+    ref.flat_grad.zero_(); l1.backward()
+    d = (tr.flat_grad - ref.flat_grad).abs().max().item()
+    scale = ref.flat_grad.abs().max().item()
+    assert d < 2e-6 * max(1.0, scale), (d, scale)      # mean over the global batch == average of the per-rank means
+    assert ref.flat_grad.abs().sum().item() > 0
+    # after the exchange + the same AdamW step every rank holds the same weights
+tr.lpdm_opt.step()
+w = torch.cat([p.detach().flatten() for p in tr.params])
+ws = [torch.empty_like(w) for _ in range(world)]
+dist.all_gather(ws, w)
+assert all(torch.equal(ws[0], x) for x in ws)
+if rank == 0:
+    print("DP_OK")
+dist.destroy_process_group()
+'''
+
+
+def test_two_rank_gloo_gradients_equal_single_process(tmp_path):
+    script = tmp_path / "worker.py"
+    script.write_text(_DP_WORKER)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29655", OMP_NUM_THREADS="2")
+    procs = [subprocess.Popen([sys.executable, str(script), str(REPO)], env=dict(env, RANK=str(r), WORLD_SIZE="2"),
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(2)]
+    outs = [p.communicate(timeout=900)[0] for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs
+    assert "DP_OK" in outs[0]
