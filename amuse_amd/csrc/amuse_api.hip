@@ -117,33 +117,47 @@ uint16_t f2bf(float f) {  // round-to-nearest-even, as v_cvt_pk_bf16_f32
 // W: [n_out x K] row-major.  Appends units for (k-tile outer, out-tile inner).
 void pack_gemm(std::vector<uint4>& out, int prec, const float* W, int n_out, int K, const std::vector<int>& otiles,
                const std::vector<int>& ktiles) {
+    // (amuse_update_weights calls this once per training iteration: the destination is sized once and filled through a
+    // pointer, rows / columns inside the matrix skip the bounds checks)
+    const size_t nunits = prec == PREC_F32 ? ktiles.size() * otiles.size() : (ktiles.size() / 2) * otiles.size();
+    const size_t base = out.size();
+    out.resize(base + nunits * 64);
+    uint4* dst = out.data() + base;
     auto at = [&](int row, int col) -> float { return (row < n_out && col < K) ? W[(size_t)row * K + col] : 0.f; };
     if (prec == PREC_F32) {
         for (int t : ktiles)
-            for (int o : otiles)
-                for (int lane = 0; lane < 64; ++lane) {
+            for (int o : otiles) {
+                const bool inside = 16 * o + 16 <= n_out && 16 * t + 16 <= K;
+                for (int lane = 0; lane < 64; ++lane, ++dst) {
                     const int g = lane >> 4, i = lane & 15;
                     float v[4];
-                    for (int m = 0; m < 4; ++m) v[m] = at(16 * o + i, 16 * t + 4 * g + m);
-                    uint4 u;
-                    memcpy(&u, v, 16);
-                    out.push_back(u);
+                    if (inside) memcpy(v, W + (size_t)(16 * o + i) * K + 16 * t + 4 * g, 16);
+                    else
+                        for (int m = 0; m < 4; ++m) v[m] = at(16 * o + i, 16 * t + 4 * g + m);
+                    memcpy(dst, v, 16);
                 }
+            }
     } else {
         for (size_t c = 0; c + 1 < ktiles.size(); c += 2) {
             const int t0 = ktiles[c], t1 = ktiles[c + 1];
-            for (int o : otiles)
-                for (int lane = 0; lane < 64; ++lane) {
+            for (int o : otiles) {
+                const bool inside = 16 * o + 16 <= n_out && 16 * t0 + 16 <= K && 16 * t1 + 16 <= K;
+                for (int lane = 0; lane < 64; ++lane, ++dst) {
                     const int g = lane >> 4, i = lane & 15;
                     uint16_t v[8];
-                    for (int e = 0; e < 4; ++e) {
-                        v[e] = f2bf(at(16 * o + i, 16 * t0 + 4 * g + e));
-                        v[4 + e] = f2bf(at(16 * o + i, 16 * t1 + 4 * g + e));
+                    if (inside) {
+                        const float* r0 = W + (size_t)(16 * o + i) * K + 16 * t0 + 4 * g;
+                        const float* r1 = W + (size_t)(16 * o + i) * K + 16 * t1 + 4 * g;
+                        for (int e = 0; e < 4; ++e) { v[e] = f2bf(r0[e]); v[4 + e] = f2bf(r1[e]); }
+                    } else {
+                        for (int e = 0; e < 4; ++e) {
+                            v[e] = f2bf(at(16 * o + i, 16 * t0 + 4 * g + e));
+                            v[4 + e] = f2bf(at(16 * o + i, 16 * t1 + 4 * g + e));
+                        }
                     }
-                    uint4 u;
-                    memcpy(&u, v, 16);
-                    out.push_back(u);
+                    memcpy(dst, v, 16);
                 }
+            }
         }
     }
 }
@@ -274,6 +288,8 @@ int build_denoiser(amuse_ctx* c, const float* den, int what = 7) {
     // ---- denoiser weight streams: [wave][per-step units]
     for (int prec = 0; prec < 2; ++prec) {
         if (!(what & (1 << prec))) continue;   // amuse_update_weights: only the requested precisions are re-packed
+        // the 4-wave bf16 stream only serves A/B runs (AMUSE_SAMPLE_WAVES=4): updates skip it unless that switch is set
+        if (prec == PREC_BF16 && c->den_w[prec] && !getenv("AMUSE_SAMPLE_WAVES")) continue;
         std::vector<uint4> all;
         size_t per_wave = 0;
         for (int w = 0; w < 4; ++w) {

@@ -159,6 +159,11 @@ __device__ __forceinline__ void pack_rows(bf16x8 (&xb)[NT][4], const f32x4 (&x)[
         for (int c = 0; c < 4; ++c) xb[j][c] = pack_bf16(x[j][2 * c], x[j][2 * c + 1]);
 }
 
+// 16-byte slot of lane (g, r) inside a 1 KiB K / V^T fragment.  Lane-linear (4 r + g) makes ds_read_b128 2-way bank
+// conflicted: its four 16-lane groups ({0-3,12-15,20-27}, ...) pair rows r and r + 12 / r + 4 and r + 8 of the same g on
+// the same 16-byte bank quad.  With the row quad r >> 2 in the low bits every group touches 16 distinct quads.
+__device__ __forceinline__ int frag_slot(int g, int r) { return 16 * g + 4 * (r & 3) + (r >> 2); }
+
 // softmax(Q K^T) V for NQ 16-query tiles against all keys of head h, K / V^T fragments in LDS (each fragment is read once
 // for the NQ tiles).  Two key chunks of five tile pairs (160 keys) each, merged online: the scores of a chunk are complete
 // before its exponentials.
@@ -170,6 +175,7 @@ __device__ __forceinline__ void attend(const uint4* Kb, const uint4* Vt, const b
         for (int n = 0; n < NQ; ++n) ob[n] = qb[n];
         return;
     }
+    const int fs = frag_slot(g, r);
     float m_run[NQ], l_run[NQ];
     f32x4 o[NQ][2];
 #pragma unroll
@@ -184,8 +190,8 @@ __device__ __forceinline__ void attend(const uint4* Kb, const uint4* Vt, const b
 #pragma unroll
         for (int i = 0; i < 5; ++i) {
             const int jp = 5 * ch + i;
-            const bf16x8 k0 = __builtin_bit_cast(bf16x8, Kb[(32 * jp + r) * 4 + g]);
-            const bf16x8 k1 = __builtin_bit_cast(bf16x8, Kb[(32 * jp + 16 + r) * 4 + g]);
+            const bf16x8 k0 = __builtin_bit_cast(bf16x8, Kb[(2 * jp) * 64 + fs]);
+            const bf16x8 k1 = __builtin_bit_cast(bf16x8, Kb[(2 * jp + 1) * 64 + fs]);
 #pragma unroll
             for (int n = 0; n < NQ; ++n) {
                 st[n][2 * i] = mfma_bf16(k0, qb[n], splat4(0.f));      // lane (g, i): S[query i][key 32 jp + 4 g + m] (log2 units)
@@ -230,8 +236,8 @@ __device__ __forceinline__ void attend(const uint4* Kb, const uint4* Vt, const b
 #pragma unroll
         for (int i = 0; i < 5; ++i) {
             const int jp = 5 * ch + i;
-            const bf16x8 v0 = __builtin_bit_cast(bf16x8, Vt[((jp * 2 + 0) * 16 + r) * 4 + g]);
-            const bf16x8 v1 = __builtin_bit_cast(bf16x8, Vt[((jp * 2 + 1) * 16 + r) * 4 + g]);
+            const bf16x8 v0 = __builtin_bit_cast(bf16x8, Vt[(jp * 2 + 0) * 64 + fs]);
+            const bf16x8 v1 = __builtin_bit_cast(bf16x8, Vt[(jp * 2 + 1) * 64 + fs]);
 #pragma unroll
             for (int n = 0; n < NQ; ++n) {
                 f32x4 p0, p1;
@@ -346,14 +352,14 @@ __device__ __forceinline__ void decoder_block(f32x4 (&x)[NT][kTiles], Stager& sg
                 const int tile = tile0 + 4 * j;
                 const bool ok = 16 * tile + r < kFrames;
                 const uint4 kf = __builtin_bit_cast(uint4, pack_bf16(kk[j][0], kk[j][1]));
-                Kb[(16 * tile + r) * 4 + g] = ok ? kf : uint4{0u, 0u, 0u, 0u};
+                Kb[tile * 64 + frag_slot(g, r)] = ok ? kf : uint4{0u, 0u, 0u, 0u};
                 // V^T: lane (g, d) holds V[row 4 g + m][16 td + d]; rows beyond the clip are zeroed (0 x p stays 0)
 #pragma unroll
                 for (int td = 0; td < 2; ++td) {
                     f32x4 v = vv[j][td];
 #pragma unroll
                     for (int m = 0; m < 4; ++m) v[m] = (16 * tile + 4 * g + m < kFrames) ? v[m] : 0.f;
-                    *reinterpret_cast<uint2*>(Vt + (((tile >> 1) * 2 + td) * 16 + r) * 64 + g * 16 + (tile & 1) * 8) = f32_to_bf16x4(v);
+                    *reinterpret_cast<uint2*>(Vt + (((tile >> 1) * 2 + td) * 64 + frag_slot(g, r)) * 16 + (tile & 1) * 8) = f32_to_bf16x4(v);
                 }
             }
         }

@@ -17,6 +17,16 @@ def job_clips_per_group(total: int, tokens: int = 5) -> int:
     return max(1, min(16 // tokens, -(-total // 128)))
 
 
+FUSED_DECODE_MIN_CLIPS = 96   # amuse_api.hip kFusedMinClips: the library's per-launch rule for the bf16 decode kernels
+
+
+def job_decode_path(total: int) -> str:
+    """The decode kernels (amuse_hip.h amuse_set_decode_path) a job of `total` clips would get on one GPU.  Like the clips
+    per tile it must be chosen from the WHOLE job, not per shard: the staged and the fused bf16 decode round differently,
+    so a 256-clip job cut into 32-clip shards would otherwise decode on other kernels than the same job on one GPU."""
+    return "fused" if total >= FUSED_DECODE_MIN_CLIPS else "staged"
+
+
 def shard_range(total: int, rank: int, world: int, align: int = 1) -> Tuple[int, int]:
     """Contiguous, balanced in units of `align` clips: the first ranks take one extra unit; the last unit may be short."""
     if not (0 <= rank < world):
@@ -29,11 +39,13 @@ def shard_range(total: int, rank: int, world: int, align: int = 1) -> Tuple[int,
 
 
 def sample_sharded(sample_fn: Callable[..., Dict[str, torch.Tensor]], z_con, z_emo, z_sty, rank: int, world: int,
-                   gather: bool = False, group=None, set_clips_per_group: Optional[Callable[[int], None]] = None
-                   ) -> Optional[Dict[str, torch.Tensor]]:
+                   gather: bool = False, group=None, set_clips_per_group: Optional[Callable[[int], None]] = None,
+                   set_decode_path: Optional[Callable[[str], None]] = None) -> Optional[Dict[str, torch.Tensor]]:
     """Run `sample_fn(bsz, con, emo, sty, clip_index0=...)` on this rank's shard of the global batch.
     set_clips_per_group (e.g. HipEngine.set_clips_per_group): called with job_clips_per_group(total), and the shards are
                   aligned to it - sharded results are then bitwise those of one GPU running the whole job.
+    set_decode_path (e.g. HipEngine.set_decode_path): called with job_decode_path(total) for the same reason; both are
+                  put back to the library's automatic rule afterwards.
     gather=False: returns the local shard's outputs (stay on this rank's device).
     gather=True : all ranks exchange shards (torch.distributed all_gather_object) and return the full batch
                   in global clip order - for tests and small jobs; large jobs should keep outputs sharded."""
@@ -42,6 +54,8 @@ def sample_sharded(sample_fn: Callable[..., Dict[str, torch.Tensor]], z_con, z_e
     g = job_clips_per_group(total, tokens) if set_clips_per_group is not None else 1
     if set_clips_per_group is not None:
         set_clips_per_group(g)
+    if set_decode_path is not None:
+        set_decode_path(job_decode_path(total))
     lo, hi = shard_range(total, rank, world, align=g)
     sl = lambda t: None if t is None else t[lo:hi]
     try:
@@ -49,6 +63,8 @@ def sample_sharded(sample_fn: Callable[..., Dict[str, torch.Tensor]], z_con, z_e
     finally:
         if set_clips_per_group is not None:
             set_clips_per_group(0)   # back to the library's per-launch rule: the job's tiling must not leak into later calls
+        if set_decode_path is not None:
+            set_decode_path("auto")
     if not gather or world == 1:
         return out
     import torch.distributed as dist

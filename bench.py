@@ -165,7 +165,8 @@ def main():
         return eng.diffusion_backward(c, e, s, args.precision, seed=2024, clip_index0=clip_index0, out=out)
 
     def step():   # the product's sharding path: tiling from the job's total, aligned contiguous shard, global clip index
-        shard.sample_sharded(sample_fn, con, emo, sty, rank, world, set_clips_per_group=eng.set_clips_per_group)
+        shard.sample_sharded(sample_fn, con, emo, sty, rank, world, set_clips_per_group=eng.set_clips_per_group,
+                             set_decode_path=eng.set_decode_path)
 
     for _ in range(args.warmup):
         step()

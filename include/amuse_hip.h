@@ -86,7 +86,8 @@ amuse_ctx* amuse_create(int device, const float* denoiser_params, size_t n_denoi
  * in-loop sampler (scripts/trainer.py:411-415: ldm.diffusion_backward + prior.decode on the weights just stepped).
  * Either array may be NULL (left as is).  `what` limits the host-side packing to what the caller will run:
  * AMUSE_UPD_F32 | AMUSE_UPD_BF16 = the weight streams of that precision, AMUSE_UPD_ENCODER = MotionPrior.encode's streams
- * too (a stream that is not re-packed keeps the OLD weights).  Synchronises `stream` first; after a denoiser update the
+ * too.  Small parameters (biases, LayerNorm, embeddings) are always replaced, so after a partial update only the
+ * re-packed precision is valid - running the other one mixes old matrices with new vectors.  Synchronises `stream` first; after a denoiser update the
  * schedule must be set again (the time-token table is a function of the time-embedding weights). */
 enum { AMUSE_UPD_F32 = 1, AMUSE_UPD_BF16 = 2, AMUSE_UPD_ENCODER = 4, AMUSE_UPD_ALL = 7 };
 int amuse_update_weights(amuse_ctx* ctx, const float* denoiser_params, size_t n_denoiser, const float* prior_params,

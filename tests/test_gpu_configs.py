@@ -158,9 +158,11 @@ con, emo, sty = (torch.randn(B, 256, generator=g) for _ in range(3))
 def sample_fn(bsz, c, e, s, clip_index0=0):
     o = eng.diffusion_backward(c, e, s, "bf16", seed=11, clip_index0=clip_index0)
     return {"latents": o["latents"], "poses": o["poses"][:, :2]}
-full = sample_sharded(sample_fn, con, emo, sty, rank, world, gather=True, set_clips_per_group=eng.set_clips_per_group)
+full = sample_sharded(sample_fn, con, emo, sty, rank, world, gather=True, set_clips_per_group=eng.set_clips_per_group,
+                      set_decode_path=eng.set_decode_path)
 if rank == 0:
-    single = sample_sharded(sample_fn, con, emo, sty, 0, 1, set_clips_per_group=eng.set_clips_per_group)
+    single = sample_sharded(sample_fn, con, emo, sty, 0, 1, set_clips_per_group=eng.set_clips_per_group,
+                            set_decode_path=eng.set_decode_path)
     assert full["latents"].shape == (B, 128)
     assert torch.equal(full["latents"], single["latents"].cpu()) and torch.equal(full["poses"], single["poses"].cpu())
     # the job-level tiling did not leak into the context: an unrelated small call is back on the per-launch rule

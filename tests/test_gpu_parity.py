@@ -466,11 +466,15 @@ def test_full_size_batch_properties(env):
     from amuse_amd.shard import job_clips_per_group
     g = job_clips_per_group(256)
     assert g == 2
+    from amuse_amd.shard import job_decode_path
+    assert job_decode_path(256) == "fused" and job_decode_path(6) == "staged"
     eng.set_clips_per_group(g)
+    eng.set_decode_path(job_decode_path(256))   # the job's decode kernels, not the 6-clip launch's own choice
     try:
         sub = eng.diffusion_backward(c[198:204], e[198:204], s[198:204], "bf16", seed=2024, clip_index0=198)
     finally:
         eng.set_clips_per_group(0)
+        eng.set_decode_path("auto")
     assert torch.equal(sub["latents"], a["latents"][198:204])
     assert torch.equal(sub["poses"], a["poses"][198:204])
 

@@ -1,11 +1,22 @@
 #!/bin/bash
-# copy the newest outputs of tools/run_round_measurements.sh from gpurun_out/ into profiles/ (tracked)
+# copy the outputs of tools/run_round_measurements.sh from gpurun_out/<dir> into profiles/ (tracked): collect_profiles.sh <dir> <rNN>
 set -e
 cd "$(dirname "$0")/.."
+O=gpurun_out/$1; R=$2
+mkdir -p profiles/${R}_pmc profiles/${R}_decode_pmc
 for n in FETCH_SIZE WRITE_SIZE TCC_HIT_sum SQ_WAVE_CYCLES SQ_INSTS_MFMA; do
-  cp "$(ls -t gpurun_out/prof8/pmc_$n/runc/*_counter_collection.csv | head -1)" profiles/r01_pmc/${n}_counter_collection.csv
+  f=$(ls -t $O/pmc_$n/*/*_counter_collection.csv 2>/dev/null | head -1); [ -n "$f" ] && cp "$f" profiles/${R}_pmc/${n}_counter_collection.csv
 done
-cp "$(ls -t gpurun_out/prof8/stats/runc/*_kernel_stats.csv | head -1)" profiles/r01_bench_kernel_stats.csv
-tail -1 gpurun_out/bench8.json > profiles/r01_bench_line.json
-grep -v libdrm gpurun_out/prof8/phase8.txt > profiles/r01_k_sample8_phase_timeline.txt
-cp "$(ls -t gpurun_out/prof8/audio_stats/runc/*_kernel_stats.csv | head -1)" profiles/r01_audio_kernel_stats.csv
+for n in FETCH_SIZE WRITE_SIZE SQ_WAVE_CYCLES SQ_INSTS_MFMA; do
+  f=$(ls -t $O/dpmc_$n/*/*_counter_collection.csv 2>/dev/null | head -1); [ -n "$f" ] && cp "$f" profiles/${R}_decode_pmc/${n}_counter_collection.csv
+done
+f=$(ls -t $O/stats/*/*_kernel_stats.csv | head -1); cp "$f" profiles/${R}_bench_kernel_stats.csv
+f=$(ls -t $O/decode_stats/*/*_kernel_stats.csv | head -1); cp "$f" profiles/${R}_decode_kernel_stats.csv
+f=$(ls -t $O/audio_stats/*/*_kernel_stats.csv | head -1); cp "$f" profiles/${R}_audio_kernel_stats.csv
+tail -1 $O/bench.json > profiles/${R}_bench_line.json
+tail -1 $O/train_bench.json > profiles/${R}_train_bench_line.json
+grep -v libdrm $O/phase8.txt > profiles/${R}_k_sample8_phase_timeline.txt
+grep -v libdrm $O/decode_perf.txt > profiles/${R}_decode_perf.txt
+grep -v libdrm $O/batch_sweep.txt > profiles/${R}_batch_sweep.txt
+cp $O/drift.json profiles/${R}_bf16_vs_fp32_drift.json
+cp $O/pytest.txt profiles/${R}_gpu_pytest_tail.txt

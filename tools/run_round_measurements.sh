@@ -1,14 +1,28 @@
+# Round measurements on the GPU box (run through gpurun from the repo root): tests, bench lines, rocprofv3 kernel stats of
+# the bench command, PMC passes (one counter group per run, no tracing domains mixed in), decode / audio / phase timelines.
+# Usage: bash tools/run_round_measurements.sh <out dir under gpurun_out>     then tools/collect_profiles.sh <out dir> <rNN>
 set -x
 cd $GRAFT_REPO_ROOT
-timeout 900 python -m pytest tests -q -m gpu 2>&1 | tail -3
-timeout 600 python bench.py > gpurun_out/bench8.json 2> gpurun_out/bench8.err; tail -2 gpurun_out/bench8.err
+O=gpurun_out/${1:-meas}
 export TMPDIR=/tmp
-rm -rf gpurun_out/prof8 && mkdir -p gpurun_out/prof8
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof8/stats -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-audio > gpurun_out/prof8/stats.log 2>&1
+rm -rf $O && mkdir -p $O
+timeout 1500 python -m pytest tests -q -m gpu 2>&1 | tail -3 > $O/pytest.txt
+timeout 600 python bench.py > $O/bench.json 2> $O/bench.err; tail -2 $O/bench.err
+timeout 300 python bench.py --config train --steps 10 --warmup 3 > $O/train_bench.json 2> $O/train_bench.err
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python3 bench.py --steps 3 --warmup 1 --no-extras > $O/stats.log 2>&1
 for grp in FETCH_SIZE WRITE_SIZE "TCC_HIT_sum TCC_MISS_sum" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_ANY" "SQ_INSTS_MFMA SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_INSTS_SALU"; do
   n=$(echo $grp | cut -d' ' -f1)
-  timeout 300 rocprofv3 --pmc $grp --kernel-trace --output-format csv -d gpurun_out/prof8/pmc_$n -- python3 tools/run_sample_once.py 256 bf16 2 > gpurun_out/prof8/pmc_$n.log 2>&1
+  timeout 300 rocprofv3 --pmc $grp --kernel-trace --output-format csv -d $O/pmc_$n -- python3 tools/run_sample_once.py 256 bf16 2 > $O/pmc_$n.log 2>&1
 done
-timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof8/audio_stats -- python3 tools/gpu_audio_perf.py 32 > gpurun_out/prof8/audio_stats.log 2>&1
-timeout 100 python tools/gpu_phase_profile8.py 256 > gpurun_out/prof8/phase8.txt 2>&1
-find gpurun_out/prof8 -name "*.csv" | head -30
+# decode: kernel stats + counters of the fused kernel at 256 clips
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/decode_stats -- python3 tools/gpu_decode_perf.py 256 > $O/decode_stats.log 2>&1
+for grp in FETCH_SIZE WRITE_SIZE "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_ANY" "SQ_INSTS_MFMA SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE"; do
+  n=$(echo $grp | cut -d' ' -f1)
+  timeout 300 rocprofv3 --pmc $grp --kernel-trace --output-format csv -d $O/dpmc_$n -- python3 tools/gpu_decode_perf.py 256 > $O/dpmc_$n.log 2>&1
+done
+timeout 200 python tools/gpu_decode_perf.py > $O/decode_perf.txt 2>&1
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/audio_stats -- python3 tools/gpu_audio_perf.py 32 > $O/audio_stats.log 2>&1
+timeout 100 python tools/gpu_phase_profile8.py 256 > $O/phase8.txt 2>&1
+timeout 300 python tests/tools/gpu_drift.py > $O/drift.txt 2>&1; cp gpurun_out/drift.json $O/drift.json
+timeout 200 python tools/gpu_perf.py > $O/batch_sweep.txt 2>&1
+find $O -name "*.csv" | head -40
