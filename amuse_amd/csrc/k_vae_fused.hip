@@ -128,14 +128,18 @@ __device__ __forceinline__ bf16x8 wfrag(const Stager& s, int u) {
 // acc[j][o] += W_o . x_j for the NT row tiles of this wave; units U0.. of the current stage, k-pair outer, output tile inner
 template <int NT, int NO, int NC, int U0>
 __device__ __forceinline__ void gemm5(f32x4 (&acc)[NT][NO], const bf16x8 (&xb)[NT][NC], const Stager& s) {
+    // fragments are read two ahead of their MFMAs (a read waited for on the spot costs an LDS round trip per unit)
+    constexpr int NU = NO * NC, PF = 2;
+    bf16x8 wf[NU < PF ? NU : PF];
 #pragma unroll
-    for (int c = 0; c < NC; ++c) {
+    for (int u = 0; u < PF && u < NU; ++u) wf[u] = wfrag(s, U0 + u);
 #pragma unroll
-        for (int o = 0; o < NO; ++o) {
-            const bf16x8 wf = wfrag(s, U0 + c * NO + o);
+    for (int u = 0; u < NU; ++u) {
+        const int c = u / NO, o = u - c * NO;
+        const bf16x8 cur = wf[u % PF];
+        if (u + PF < NU) wf[u % PF] = wfrag(s, U0 + u + PF);
 #pragma unroll
-            for (int j = 0; j < NT; ++j) acc[j][o] = mfma_bf16(wf, xb[j][c], acc[j][o]);
-        }
+        for (int j = 0; j < NT; ++j) acc[j][o] = mfma_bf16(cur, xb[j][c], acc[j][o]);
     }
 }
 
@@ -164,107 +168,80 @@ __device__ __forceinline__ void pack_rows(bf16x8 (&xb)[NT][4], const f32x4 (&x)[
 // the same 16-byte bank quad.  With the row quad r >> 2 in the low bits every group touches 16 distinct quads.
 __device__ __forceinline__ int frag_slot(int g, int r) { return 16 * g + 4 * (r & 3) + (r >> 2); }
 
-// softmax(Q K^T) V for NQ 16-query tiles against all keys of head h, K / V^T fragments in LDS (each fragment is read once
-// for the NQ tiles).  Two key chunks of five tile pairs (160 keys) each, merged online: the scores of a chunk are complete
-// before its exponentials.
-template <int NQ>
-__device__ __forceinline__ void attend(const uint4* Kb, const uint4* Vt, const bf16x8 (&qb)[NQ], bf16x8 (&ob)[NQ], int len,
-                                       int g, int r) {
-    if constexpr ((AMUSE_FABL & 2) != 0) {
-#pragma unroll
-        for (int n = 0; n < NQ; ++n) ob[n] = qb[n];
-        return;
-    }
+// max of three without the v_max_f32 x, x canonicalisation hipcc puts in front of every fmaxf operand (no NaN can reach
+// the scores: finite operands, -inf only through the mask)
+__device__ __forceinline__ float max3(float a, float b, float c) {
+    float d;
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+    return d;
+}
+
+// softmax(Q K^T) V of ONE 16-query tile against all keys of head h, K / V^T fragments in LDS.  Five chunks of two key-tile
+// pairs (64 keys), merged online.  What shapes the loop: a lone ds_read_b128 -> s_waitcnt -> MFMA sequence exposes the whole
+// LDS latency per fragment (the first version did exactly that: 40 round trips per tile, 5 k cycles), and registers are
+// too scarce (x + xb of three tiles = 144 of 256) for hipcc to hoist the reads itself.  So a chunk's four K fragments are
+// read as ONE batch in front of its four score MFMAs, and its four V^T fragments as one batch right behind them - they
+// land while the softmax arithmetic runs.
+__device__ __forceinline__ bf16x8 attend(const uint4* Kb, const uint4* Vt, bf16x8 qb, int len, int g, int r) {
+    if constexpr ((AMUSE_FABL & 2) != 0) return qb;
     const int fs = frag_slot(g, r);
-    float m_run[NQ], l_run[NQ];
-    f32x4 o[NQ][2];
+    float m_run = -INFINITY, l_run = 0.f;
+    f32x4 o[2] = {splat4(0.f), splat4(0.f)};
 #pragma unroll
-    for (int n = 0; n < NQ; ++n) {
-        m_run[n] = -INFINITY;
-        l_run[n] = 0.f;
-        o[n][0] = o[n][1] = splat4(0.f);
-    }
+    for (int ch = 0; ch < kPairs / 2; ++ch) {
+        uint4 kf[4];
 #pragma unroll
-    for (int ch = 0; ch < 2; ++ch) {
-        f32x4 st[NQ][10];
+        for (int i = 0; i < 4; ++i) kf[i] = Kb[(4 * ch + i) * 64 + fs];
+        f32x4 st[4];
 #pragma unroll
-        for (int i = 0; i < 5; ++i) {
-            const int jp = 5 * ch + i;
-            const bf16x8 k0 = __builtin_bit_cast(bf16x8, Kb[(2 * jp) * 64 + fs]);
-            const bf16x8 k1 = __builtin_bit_cast(bf16x8, Kb[(2 * jp + 1) * 64 + fs]);
+        for (int i = 0; i < 4; ++i)   // lane (g, i): S[query i][key 64 ch + 16 i + 4 g + m] (log2 units)
+            st[i] = mfma_bf16(__builtin_bit_cast(bf16x8, kf[i]), qb, splat4(0.f));
+        uint4 vf[4];
 #pragma unroll
-            for (int n = 0; n < NQ; ++n) {
-                st[n][2 * i] = mfma_bf16(k0, qb[n], splat4(0.f));      // lane (g, i): S[query i][key 32 jp + 4 g + m] (log2 units)
-                st[n][2 * i + 1] = mfma_bf16(k1, qb[n], splat4(0.f));  //              S[query i][key 32 jp + 16 + 4 g + m]
+        for (int i = 0; i < 4; ++i) vf[i] = Vt[(4 * ch + i) * 64 + fs];   // (pair, td) = (2 ch + i / 2, i % 2)
+        __builtin_amdgcn_sched_barrier(0);   // keep both batches where they are
+        // key-padding mask: only a chunk that reaches past the sequence end is touched (wave-uniform branch; with len = 300
+        // that is the last chunk alone).  The per-lane limit is recomputed here on purpose: hoisted out of the head loop the
+        // lane masks would live in SGPR pairs and spill.
+        const int k0 = 64 * ch;
+        if (k0 + 64 > len) {
+            int lim = len - k0 - 4 * g;   // element (i, m) of the chunk is valid iff 16 i + m < lim
+            asm volatile("" : "+v"(lim));
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int m = 0; m < 4; ++m) st[i][m] = (16 * i + m < lim) ? st[i][m] : -INFINITY;
+        }
+        float mx = max3(max3(st[0][0], st[0][1], st[0][2]), max3(st[0][3], st[1][0], st[1][1]), max3(st[1][2], st[1][3], st[2][0]));
+        mx = max3(mx, max3(st[2][1], st[2][2], st[2][3]), max3(st[3][0], st[3][1], st[3][2]));
+        mx = allreduce_g_max(max3(mx, st[3][3], m_run));   // m_run is the same in the four lanes of a row
+        const float m_new = mx;
+        const float msub = (m_new == -INFINITY) ? 0.f : m_new;   // a fully masked chunk adds zeros
+        const float alpha = (m_run == -INFINITY) ? 0.f : __builtin_amdgcn_exp2f(m_run - msub);
+        m_run = m_new;
+        f32x4 p[4];
+        float ps = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                if constexpr ((AMUSE_FABL & 8) != 0) p[i][m] = st[i][m];
+                else p[i][m] = __builtin_amdgcn_exp2f(st[i][m] - msub);
             }
+            ps += (p[i][0] + p[i][1]) + (p[i][2] + p[i][3]);
         }
-        // key-padding mask: only tile pairs that reach past the sequence end are touched (wave-uniform branch per pair; with
-        // len = 300 that is the last pair alone).  The per-lane limit is recomputed here on purpose: hoisted out of the head
-        // loop, the 40 lane masks of a chunk would live in SGPR pairs and spill.
+        l_run = l_run * alpha + ps;
+        o[0] *= alpha;
+        o[1] *= alpha;
 #pragma unroll
-        for (int i = 0; i < 5; ++i) {
-            const int k0 = 32 * (5 * ch + i);
-            if (k0 + 32 > len) {
-                int lim = len - k0 - 4 * g;   // element (u, m) of the pair is valid iff 16 u + m < lim
-                asm volatile("" : "+v"(lim));
-#pragma unroll
-                for (int n = 0; n < NQ; ++n)
-#pragma unroll
-                    for (int u = 0; u < 2; ++u)
-#pragma unroll
-                        for (int m = 0; m < 4; ++m) st[n][2 * i + u][m] = (16 * u + m < lim) ? st[n][2 * i + u][m] : -INFINITY;
-            }
+        for (int pr = 0; pr < 2; ++pr) {   // O^T[d][i] += sum_key V[key][d] P[i][key], 32 keys per MFMA
+            const bf16x8 pb = pack_bf16(p[2 * pr], p[2 * pr + 1]);
+            o[0] = mfma_bf16(__builtin_bit_cast(bf16x8, vf[2 * pr]), pb, o[0]);
+            o[1] = mfma_bf16(__builtin_bit_cast(bf16x8, vf[2 * pr + 1]), pb, o[1]);
         }
-        float msub[NQ], ps[NQ];
-#pragma unroll
-        for (int n = 0; n < NQ; ++n) {
-            float mx = st[n][0][0];
-#pragma unroll
-            for (int i = 0; i < 10; ++i)
-#pragma unroll
-                for (int m = 0; m < 4; ++m) mx = fmaxf(mx, st[n][i][m]);
-            mx = allreduce_g_max(mx);
-            const float m_new = fmaxf(m_run[n], mx);
-            msub[n] = (m_new == -INFINITY) ? 0.f : m_new;   // a fully masked chunk (len <= 160 in chunk 1) adds zeros
-            const float alpha = (m_run[n] == -INFINITY) ? 0.f : __builtin_amdgcn_exp2f(m_run[n] - msub[n]);
-            o[n][0] *= alpha;
-            o[n][1] *= alpha;
-            l_run[n] *= alpha;
-            m_run[n] = m_new;
-            ps[n] = 0.f;
-        }
-#pragma unroll
-        for (int i = 0; i < 5; ++i) {
-            const int jp = 5 * ch + i;
-            const bf16x8 v0 = __builtin_bit_cast(bf16x8, Vt[(jp * 2 + 0) * 64 + fs]);
-            const bf16x8 v1 = __builtin_bit_cast(bf16x8, Vt[(jp * 2 + 1) * 64 + fs]);
-#pragma unroll
-            for (int n = 0; n < NQ; ++n) {
-                f32x4 p0, p1;
-#pragma unroll
-                for (int m = 0; m < 4; ++m) {
-                    if constexpr ((AMUSE_FABL & 8) != 0) {
-                        p0[m] = st[n][2 * i][m];
-                        p1[m] = st[n][2 * i + 1][m];
-                    } else {
-                        p0[m] = __builtin_amdgcn_exp2f(st[n][2 * i][m] - msub[n]);
-                        p1[m] = __builtin_amdgcn_exp2f(st[n][2 * i + 1][m] - msub[n]);
-                    }
-                }
-                ps[n] += ((p0[0] + p0[1]) + (p0[2] + p0[3])) + ((p1[0] + p1[1]) + (p1[2] + p1[3]));
-                const bf16x8 pb = pack_bf16(p0, p1);
-                o[n][0] = mfma_bf16(v0, pb, o[n][0]);   // O^T[d][i] += sum_key V[key][d] P[i][key]
-                o[n][1] = mfma_bf16(v1, pb, o[n][1]);
-            }
-        }
-#pragma unroll
-        for (int n = 0; n < NQ; ++n) l_run[n] += ps[n];
     }
-#pragma unroll
-    for (int n = 0; n < NQ; ++n) {
-        const float inv = __builtin_amdgcn_rcpf(allreduce_g_sum(l_run[n]));
-        ob[n] = pack_bf16(o[n][0] * inv, o[n][1] * inv);
-    }
+    const float inv = __builtin_amdgcn_rcpf(allreduce_g_sum(l_run));
+    return pack_bf16(o[0] * inv, o[1] * inv);
 }
 
 // MODE 0: input block (push the skip), 1: middle block, 2: output block (skip linear first)
@@ -393,14 +370,13 @@ __device__ __forceinline__ void decoder_block(f32x4 (&x)[NT][kTiles], Stager& sg
             const uint4* Vq = reinterpret_cast<const uint4*>(Vt);
 #pragma unroll 1
             for (int j = 0; j < NT; ++j) {
-                bf16x8 q1[1] = {qb[0]}, o1[1];
-                attend<1>(Kb, Vq, q1, o1, len, g, r);
+                const bf16x8 o1 = attend(Kb, Vq, qb[0], len, g, r);
 #pragma unroll
                 for (int jj = 0; jj + 1 < NT; ++jj) {
                     qb[jj] = qb[jj + 1];
                     ob[jj][0] = ob[jj + 1][0];
                 }
-                ob[NT - 1][0] = o1[0];
+                ob[NT - 1][0] = o1;
             }
             FSTAMP(7);   // attention of the five tiles
         }
