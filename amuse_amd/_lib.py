@@ -23,6 +23,7 @@ EXPORTS = [
     "amuse_counter_normal", "amuse_set_clips_per_group", "amuse_set_decode_path", "amuse_profile_sample",
     "amuse_audio_create", "amuse_audio_destroy", "amuse_audio_fbank", "amuse_audio_encode", "amuse_audio_features",
     "amuse_debug_gemm",
+    "amuse_debug_tile",
 ]
 
 
@@ -83,7 +84,8 @@ def load() -> C.CDLL:
     lib.amuse_audio_encode.argtypes = [vp, C.c_int, fp, C.c_int, fp, fp, C.c_int, vp]
     lib.amuse_audio_features.argtypes = [vp, fp, C.c_int, C.c_int, fp, fp, fp, vp]
     lib.amuse_debug_gemm.argtypes = [vp, vp, fp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp]
-    for n in ("amuse_audio_fbank", "amuse_audio_encode", "amuse_audio_features", "amuse_debug_gemm"):
+    lib.amuse_debug_tile.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, vp]
+    for n in ("amuse_audio_fbank", "amuse_audio_encode", "amuse_audio_features", "amuse_debug_gemm", "amuse_debug_tile"):
         getattr(lib, n).restype = C.c_int
     if lib.amuse_abi_version() != ABI_VERSION:
         raise AmuseHipError(f"ABI mismatch: library {lib.amuse_abi_version()} vs binding {ABI_VERSION}")

@@ -153,8 +153,10 @@ int ensure_ws(Workspace& w, int nb) {
     HIP_TRY(hipMalloc((void**)&w.O, Mp * kAstDim * 2));
     HIP_TRY(hipMalloc((void**)&w.F, Mp * kAstMlp * 2));
     HIP_TRY(hipMalloc((void**)&w.P, pad128((size_t)nb * kAstPatches) * 256 * 2));
-    // rows beyond M are read by the GEMM tiles (results discarded) and the V^T pad columns by the attention (masked):
-    // they only have to be finite
+    // every activation is tile-major (amuse_audio.hpp), rows padded to the GEMM's 128-token tile.  Pad rows are read by the GEMM
+    // tiles and the LayerNorm (their results stay in pad rows) and the V^T pad columns by the attention (masked): they only
+    // have to be finite
+    HIP_TRY(hipMemset(w.X, 0, Mp * kAstDim * 4));
     HIP_TRY(hipMemset(w.H, 0, Mp * kAstDim * 2));
     HIP_TRY(hipMemset(w.O, 0, Mp * kAstDim * 2));
     HIP_TRY(hipMemset(w.F, 0, Mp * kAstMlp * 2));
@@ -209,7 +211,7 @@ int run_encoder(const amuse_audio_ctx* c, const Workspace& w, const Encoder& E, 
         g.A = w.F; g.W = b.fc2_w; g.bias = b.fc2_b; g.M = M; g.N = kAstDim; g.K = kAstMlp; g.out_f32 = w.X;
         HIP_TRY(launch_gemm(g, EPI_RESID_F32, st));
         if (hidden_out && l == tap_block)
-            HIP_TRY(hipMemcpyAsync(hidden_out, w.X, (size_t)M * kAstDim * 4, hipMemcpyDeviceToDevice, st));
+            HIP_TRY(launch_untile_f32(w.X, hidden_out, M, kAstDim, st));
     }
     HIP_TRY(launch_ast_pool(w.X, E.norm_w, E.norm_b, c->frame_based, w.pooled, nb, st));
     HIP_TRY(launch_ast_head(w.pooled, c->frame_based, E.fh_ln_w, E.fh_ln_b, E.fh_w, E.fh_b, feat_out, nb, st));
@@ -347,14 +349,27 @@ int amuse_audio_features(amuse_audio_ctx* c, const float* waves, int n_samples, 
 }
 
 // GEMM in isolation (tools/gpu_gemm_bench.py, tests): C = A . W^T + bias with epilogue 0 (bf16 out) or 3 (fp32 out);
-// A dev bf16 [M padded to 128][K], W dev bf16 in the kernel's packed fragment order (GemmArgs::W)
+// A dev bf16 TILE-MAJOR [M padded to 128][K] (amuse_debug_tile), W dev bf16 in the kernel's packed fragment order
+// (GemmArgs::W), out tile-major [M padded to 128][N]
 int amuse_debug_gemm(const void* A, const void* W, const float* bias, int M, int N, int K, int epi, void* out, void* stream) {
     if (!A || !W || !bias || !out) return failf(AMUSE_EINVAL, "NULL argument%s");
-    if (N % 128 || K % 64 || (epi != EPI_BF16 && epi != EPI_F32)) return failf(AMUSE_EINVAL, "%sbad GEMM shape / epilogue (N %ld K %ld)", "", N, K);
+    if (M < 1 || N % kGemmTN || K % 64 || (epi != EPI_BF16 && epi != EPI_F32)) return failf(AMUSE_EINVAL, "%sbad GEMM shape / epilogue (N %ld K %ld)", "", N, K);
     GemmArgs g{};
     g.A = (const unsigned short*)A; g.W = (const unsigned short*)W; g.bias = bias; g.M = M; g.N = N; g.K = K;
     g.out_bf16 = (unsigned short*)out; g.out_f32 = (float*)out;
     HIP_TRY(launch_gemm(g, epi, (hipStream_t)stream));
+    return 0;
+}
+
+// what 0: bf16 row-major [M][F] -> tile-major [M padded to 128][F] (pad rows zeroed); 1: bf16 tile-major -> row-major [M][F];
+// 2: fp32 tile-major -> row-major [M][F]
+int amuse_debug_tile(const void* src, void* dst, int M, int F, int what, void* stream) {
+    if (!src || !dst) return failf(AMUSE_EINVAL, "NULL argument%s");
+    if (M < 1 || F < 32 || F % 32 || what < 0 || what > 2) return failf(AMUSE_EINVAL, "%sbad shape / direction (F %ld what %ld)", "", F, what);
+    hipStream_t st = (hipStream_t)stream;
+    if (what == 0) HIP_TRY(launch_tile_bf16((const unsigned short*)src, (unsigned short*)dst, M, F, st));
+    else if (what == 1) HIP_TRY(launch_untile_bf16((const unsigned short*)src, (unsigned short*)dst, M, F, st));
+    else HIP_TRY(launch_untile_f32((const float*)src, (float*)dst, M, F, st));
     return 0;
 }
 

@@ -5,11 +5,11 @@
 // a conventional MFMA pipeline rather than the register-resident design of the sampler:
 //   k_fbank        one workgroup per frame: DC removal, pre-emphasis, Hann window, 512-point FFT in LDS, 128 mel bins
 //   k_im2col       16 x 16 stride-10 patches of the [128 x 1024] spectrogram as bf16 rows (K = 256)
-//   k_gemm_bf16    C = A . W^T (+ fused epilogue): 128 x 128 x 64 tiles, bf16 operands through padded LDS images that
-//                  are read back as ready MFMA fragments (one ds_read_b128 per operand), fp32 accumulation.
-//                  Weights are the A operand, so a lane ends up with 4 consecutive FEATURES of one token row: bias,
-//                  GELU, residual and the q / k / v^T split are applied in registers and stored 8 or 16 B wide.
-//   k_ln_bf16      LayerNorm of the fp32 residual stream -> bf16 GEMM operand (one wave per row)
+//   k_gemm_tm      (k_audio_gemm.hip) C = A . W^T (+ fused epilogue): 256 x 128 x 32 stages by LDS-DMA, fp32 accumulation.
+//                  Weights are the A operand, so a lane ends up with 8 consecutive FEATURES of one token row: bias,
+//                  GELU, residual and the q / k / v^T split are applied in registers.  Its operands and outputs are
+//                  TILE-MAJOR (amuse_audio.hpp): so are the residual stream and every activation in this file.
+//   k_ln_bf16      LayerNorm of the fp32 residual stream -> bf16 GEMM operand (one workgroup per 16-row tile row)
 //   k_ast_attn     flash attention, S = 1214, d = 64: S^T = K.Q^T and O^T = V^T.P^T on v_mfma_f32_16x16x32_bf16 with
 //                  the softmax along registers (the layout of the S = 300 decoder attention, k_vae.hip), K and V^T
 //                  streamed through LDS in 64-key chunks; V is written TRANSPOSED by the qkv epilogue.
@@ -103,7 +103,7 @@ __global__ __launch_bounds__(256) void k_fbank(const float* __restrict__ wave, i
 
 // ---------------------------------------------------------------------------------------------- im2col
 // patches[b * 1212 + fh * 101 + tw][kh * 16 + kw] = fbank[b][10 tw + kw][10 fh + kh]   (x.unsqueeze(1).transpose(2, 3)
-// then Conv2d(1, 768, 16, stride 10): audio_main_new.py:180-184, 92-96)
+// then Conv2d(1, 768, 16, stride 10): audio_main_new.py:180-184, 92-96); tile-major (amuse_audio.hpp)
 __global__ __launch_bounds__(256) void k_im2col(const float* __restrict__ fbank, bf16raw* __restrict__ patches, int B) {
     const size_t row = (size_t)blockIdx.x;           // b * 1212 + p
     const int b = (int)(row / kAstPatches), p = (int)(row - (size_t)b * kAstPatches);
@@ -111,7 +111,7 @@ __global__ __launch_bounds__(256) void k_im2col(const float* __restrict__ fbank,
     const int kh = threadIdx.x >> 4, kw = threadIdx.x & 15;
     const float v = fbank[((size_t)b * kAstFrames + 10 * tw + kw) * kAstMel + 10 * fh + kh];
     typedef __bf16 bf;
-    patches[row * 256 + threadIdx.x] = __builtin_bit_cast(bf16raw, (bf)v);
+    patches[tm_bf16(row, threadIdx.x, 256)] = __builtin_bit_cast(bf16raw, (bf)v);
 }
 
 // cls / distillation rows of the token matrix (audio_main_new.py:185-188)
@@ -120,252 +120,93 @@ __global__ __launch_bounds__(256) void k_ast_tokens(const float* __restrict__ cl
     const int b = blockIdx.x;
     for (int i = threadIdx.x; i < 2 * kAstDim; i += 256) {
         const int r = i / kAstDim, c = i - r * kAstDim;
-        X[((size_t)b * kAstTokens + r) * kAstDim + c] = (r == 0 ? cls[c] : dist[c]) + pos[(size_t)r * kAstDim + c];
+        X[tm_f32((size_t)b * kAstTokens + r, c, kAstDim)] = (r == 0 ? cls[c] : dist[c]) + pos[(size_t)r * kAstDim + c];
     }
-}
-
-// ---------------------------------------------------------------------------------------------- GEMM
-// 128 x 128 x 64 output tiles, four waves of 64 x 64.  What bounds this kernel is LDS bandwidth: with BOTH operands
-// staged through LDS a k-tile costs every wave 16 fragment reads + 8 staging writes of 1 KiB against 32 MFMAs - 135 %
-// of the matrix-pipe time at the measured 114 B/clk (tools/probes/lds_probe.hip; ablation in DESIGN.md 4.4).  The
-// weights are static, so they take the sampler's route instead: packed once on the host into MFMA-fragment order
-// (1 KiB units, amuse_audio_api.hip pack_w) and streamed global -> registers -> MFMA by each wave, one k-tile ahead.
-// Only the activations go through LDS (8 reads + 4 writes per k-tile per wave).
-constexpr int BM = 128, BN = 128, BK = 64;
-constexpr int LDSK = BK + 8;                       // padded row (bf16 elements): 144 B, conflict-free ds_read_b128
-constexpr int kGemmLds = 2 * BM * LDSK * 2;        // double-buffered A tile: 36,864 B
-
-// DEEP: the weights run TWO k-tiles ahead of their use (three register sets) instead of one; needs K / 64 divisible by 6.
-template <int EPI, bool DEEP>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_gemm_bf16(GemmArgs a) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    bf16raw* As = reinterpret_cast<bf16raw*>(smem);                    // [2][BM][LDSK]
-    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    const int g = lane >> 4, j = lane & 15;
-    const int wm = wave >> 1, wn = wave & 1;
-    // PERSISTENT: workgroup w computes output tiles w, w + gridDim.x, ... and the k-tile pipeline runs straight across
-    // output-tile boundaries, so only the first tile of a workgroup pays the load round trip in the open and every
-    // epilogue overlaps the next tile's loads.  Consecutive tile indices walk the N tiles of one M tile: concurrent
-    // workgroups share the A rows through L2.
-    const int tiles_n = a.N / BN;
-    const int n_tiles = ((a.M + BM - 1) / BM) * tiles_n;
-    const int nk = a.K / BK;
-    const int lr = t >> 3, lc = (t & 7) * 8;                          // this thread's 16 B: rows lr + 32 i, k lc..lc+7
-    const size_t rstep = (size_t)32 * a.K;
-    bf16raw* as = As + (size_t)lr * LDSK + lc;
-    // activations: global -> registers two k-tiles ahead (sets a / b) -> LDS; weights: fragment units one k-tile
-    // ahead (sets 0 / 1), straight into the MFMA
-    uint4 ra0, ra1, ra2, ra3, rb0, rb1, rb2, rb3;
-    uint4 w0[8], w1[8], w2[DEEP ? 8 : 1];
-#define GEMM_ALOAD(A0, A1, A2, A3, ag)                                     \
-    A0 = *reinterpret_cast<const uint4*>(ag);                              \
-    A1 = *reinterpret_cast<const uint4*>(ag + rstep);                      \
-    A2 = *reinterpret_cast<const uint4*>(ag + 2 * rstep);                  \
-    A3 = *reinterpret_cast<const uint4*>(ag + 3 * rstep);
-#define GEMM_ASTORE(A0, A1, A2, A3, buf)                                               \
-    *reinterpret_cast<uint4*>(as + ((buf) * BM + 0) * LDSK) = A0;                      \
-    *reinterpret_cast<uint4*>(as + ((buf) * BM + 32) * LDSK) = A1;                     \
-    *reinterpret_cast<uint4*>(as + ((buf) * BM + 64) * LDSK) = A2;                     \
-    *reinterpret_cast<uint4*>(as + ((buf) * BM + 96) * LDSK) = A3;
-    // unit (x, ks) of this wave's 64-feature span: wp + (x * (K / 32) + ks) * 64 lanes; a k-tile = k-steps 2 kt, 2 kt + 1
-#define GEMM_WLOAD(WS, wp, kt)                                                                     \
-    _Pragma("unroll") for (int x = 0; x < 4; ++x) {                                                \
-        WS[2 * x] = wp[((size_t)x * (2 * nk) + 2 * (kt)) * 64];                                    \
-        WS[2 * x + 1] = wp[((size_t)x * (2 * nk) + 2 * (kt) + 1) * 64];                            \
-    }
-    // the same from a pointer to the k-tile's first unit
-#define GEMM_WLOADQ(WS, wq)                                                                        \
-    _Pragma("unroll") for (int x = 0; x < 4; ++x) {                                                \
-        WS[2 * x] = (wq)[((size_t)x * (2 * nk)) * 64];                                             \
-        WS[2 * x + 1] = (wq)[((size_t)x * (2 * nk) + 1) * 64];                                     \
-    }
-#define GEMM_COMPUTE(buf, WS)                                                                               \
-    {                                                                                                       \
-        const bf16raw* Ab = As + (size_t)(buf) * BM * LDSK + (size_t)(64 * wm + j) * LDSK + 8 * g;          \
-        _Pragma("unroll") for (int s = 0; s < BK / 32; ++s) {                                               \
-            bf16x8 af[4];                                                                                   \
-            _Pragma("unroll") for (int y = 0; y < 4; ++y)                                                   \
-                af[y] = *reinterpret_cast<const bf16x8*>(Ab + (size_t)(16 * y) * LDSK + 32 * s);            \
-            _Pragma("unroll") for (int x = 0; x < 4; ++x)                                                   \
-                _Pragma("unroll") for (int y = 0; y < 4; ++y)                                               \
-                    acc[x][y] = mfma_bf16(__builtin_bit_cast(bf16x8, WS[2 * x + s]), af[y], acc[x][y]);     \
-        }                                                                                                   \
-    }
-    int tile = blockIdx.x;
-    if (tile >= n_tiles) return;
-    auto a_ptr = [&](int tl) { return a.A + ((size_t)(tl / tiles_n) * BM + lr) * a.K + lc; };
-    // this wave's packed weight span of output tile tl: 64-feature span index = (tl % tiles_n) * 2 + wn
-    auto w_ptr = [&](int tl) {
-        return reinterpret_cast<const uint4*>(a.W) + ((size_t)((tl % tiles_n) * 2 + wn) * 4 * (2 * nk)) * 64 + lane;
-    };
-    const bf16raw* ag = a_ptr(tile);
-    const uint4* wp = w_ptr(tile);
-    GEMM_ALOAD(ra0, ra1, ra2, ra3, ag)
-    GEMM_ALOAD(rb0, rb1, rb2, rb3, ag + BK)
-    GEMM_WLOAD(w0, wp, 0)
-    if constexpr (DEEP) { GEMM_WLOAD(w1, wp, 1) }
-    GEMM_ASTORE(ra0, ra1, ra2, ra3, 0)
-    __syncthreads();
-    while (true) {
-        const int tm_idx = tile / tiles_n, tn_idx = tile - tm_idx * tiles_n;
-        const size_t m0 = (size_t)tm_idx * BM;
-        const int n0 = tn_idx * BN;
-        const int next_tile = tile + gridDim.x;
-        const bool have_next = next_tile < n_tiles;
-        const bf16raw* agn = have_next ? a_ptr(next_tile) : ag;
-        const uint4* wpn = have_next ? w_ptr(next_tile) : wp;
-        f32x4 acc[4][4];   // [feature fragment][token tile]
-#pragma unroll
-        for (int x = 0; x < 4; ++x)
-#pragma unroll
-            for (int y = 0; y < 4; ++y) acc[x][y] = splat4(0.f);
-        if constexpr (DEEP) {
-            // six k-tiles per trip: LDS buffers alternate (period 2), weight sets rotate (period 3).  On entry: LDS
-            // buffer 0 = A k-tile kt, register set b = A k-tile kt + 1; w0 / w1 = W k-tiles kt / kt + 1, w2 free.
-            // Half d computes k-tile kt + d and fetches A and W of k-tile kt + d + 2 (of the next output tile past nk).
-#define GEMM_HALF(d, buf, WC, WL, RL0, RL1, RL2, RL3, RS0, RS1, RS2, RS3)                                   \
-            {                                                                                               \
-                const int q = kt + (d) + 2;                                                                 \
-                const bool over = q >= nk;                                                                  \
-                const bf16raw* an = over ? agn + (size_t)(q - nk) * BK : ag + (size_t)q * BK;               \
-                const uint4* wq = over ? wpn + (size_t)2 * (q - nk) * 64 : wp + (size_t)2 * q * 64;         \
-                GEMM_WLOADQ(WL, wq)                                                                         \
-                GEMM_ALOAD(RL0, RL1, RL2, RL3, an)                                                          \
-                __builtin_amdgcn_sched_barrier(0);   /* the loads are ISSUED here, not sunk towards their use */ \
-                GEMM_COMPUTE(buf, WC)                                                                       \
-                GEMM_ASTORE(RS0, RS1, RS2, RS3, 1 - (buf))                                                  \
-                __syncthreads();                                                                            \
-            }
-#pragma unroll 1
-            for (int kt = 0; kt < nk; kt += 6) {
-                GEMM_HALF(0, 0, w0, w2, ra0, ra1, ra2, ra3, rb0, rb1, rb2, rb3)
-                GEMM_HALF(1, 1, w1, w0, rb0, rb1, rb2, rb3, ra0, ra1, ra2, ra3)
-                GEMM_HALF(2, 0, w2, w1, ra0, ra1, ra2, ra3, rb0, rb1, rb2, rb3)
-                GEMM_HALF(3, 1, w0, w2, rb0, rb1, rb2, rb3, ra0, ra1, ra2, ra3)
-                GEMM_HALF(4, 0, w1, w0, ra0, ra1, ra2, ra3, rb0, rb1, rb2, rb3)
-                GEMM_HALF(5, 1, w2, w1, rb0, rb1, rb2, rb3, ra0, ra1, ra2, ra3)
-            }
-#undef GEMM_HALF
-        } else {
-#pragma unroll 1
-        for (int kt = 0; kt < nk; kt += 2) {
-            // LDS buffer 0 = A k-tile kt, register set b = A k-tile kt + 1, set a free; w0 = W k-tile kt, w1 free.
-            // NO branch in this body: the next operands' addresses are SELECTED (the k-tiles after this pair belong to
-            // the next output tile when `wrap`; a workgroup's very last pair re-loads its own tile and stores it unused).
-            // (With the loads behind `if (wrap) / if (more)` hipcc's s_waitcnt pass lost the queue positions at the joins
-            // and drained the whole queue, vmcnt(0), inside every iteration.  Removing that changed nothing measurable:
-            // the loop pays about one memory round trip per half iteration either way - see DESIGN.md 4.4.)
-            const bool wrap = kt + 2 >= nk;
-            const bf16raw* an = wrap ? agn : ag + (kt + 2) * BK;
-            const uint4* wq = wrap ? wpn : wp + (size_t)2 * (kt + 2) * 64;
-            GEMM_WLOAD(w1, wp, kt + 1)
-            GEMM_ALOAD(ra0, ra1, ra2, ra3, an)
-            GEMM_COMPUTE(0, w0)
-            GEMM_ASTORE(rb0, rb1, rb2, rb3, 1)   // buffer 1 was last read before the previous barrier
-            __syncthreads();
-            GEMM_ALOAD(rb0, rb1, rb2, rb3, an + BK)
-            GEMM_WLOAD(w0, wq, 0)
-            GEMM_COMPUTE(1, w1)
-            GEMM_ASTORE(ra0, ra1, ra2, ra3, 0)
-            __syncthreads();
-        }
-        }
-    // ---- epilogue: lane (g, j): token row m0 + 64 wm + 16 y + j, features n0 + 64 wn + 32 p + 8 g .. + 7
-#pragma unroll
-    for (int y = 0; y < 4; ++y) {
-        const size_t row = m0 + 64 * wm + 16 * y + j;
-        if (row >= (size_t)a.M) continue;
-#pragma unroll
-        for (int pp = 0; pp < 2; ++pp) {
-            const int n = n0 + 64 * wn + 32 * pp + 8 * g;
-            f32x4 v0 = acc[2 * pp][y] + ld4(a.bias + n), v1 = acc[2 * pp + 1][y] + ld4(a.bias + n + 4);
-            if constexpr (EPI == EPI_BF16) {
-                const uint2 lo = pack4(v0), hi = pack4(v1);
-                *reinterpret_cast<uint4*>(a.out_bf16 + row * a.N + n) = uint4{lo.x, lo.y, hi.x, hi.y};
-            } else if constexpr (EPI == EPI_GELU_BF16) {
-#pragma unroll
-                for (int m = 0; m < 4; ++m) { v0[m] = gelu_erf_fast(v0[m]); v1[m] = gelu_erf_fast(v1[m]); }
-                const uint2 lo = pack4(v0), hi = pack4(v1);
-                *reinterpret_cast<uint4*>(a.out_bf16 + row * a.N + n) = uint4{lo.x, lo.y, hi.x, hi.y};
-            } else if constexpr (EPI == EPI_RESID_F32) {
-                float* p = a.out_f32 + row * a.N + n;
-                const f32x4 r0 = ld4(p), r1 = ld4(p + 4);
-                st4(p, r0 + v0);
-                st4(p + 4, r1 + v1);
-            } else if constexpr (EPI == EPI_F32) {
-                st4(a.out_f32 + row * a.N + n, v0);
-                st4(a.out_f32 + row * a.N + n + 4, v1);
-            } else if constexpr (EPI == EPI_PATCH) {
-                // row = b * 1212 + p  ->  token row b * 1214 + 2 + p, + pos_embed[2 + p]
-                const size_t b = row / kAstPatches, p = row - b * kAstPatches;
-                float* dst = a.out_f32 + (b * kAstTokens + 2 + p) * kAstDim + n;
-                const float* ps = a.pos + (2 + p) * kAstDim + n;
-                st4(dst, v0 + ld4(ps));
-                st4(dst + 4, v1 + ld4(ps + 4));
-            } else {  // EPI_QKV: q (pre-scaled by head_dim ** -0.5 = 1/8, exact in bf16) | k row-major, v transposed
-                if (n < 2 * kAstDim) {
-                    const float sc = n < kAstDim ? 0.125f : 1.0f;
-                    const uint2 lo = pack4(v0 * sc), hi = pack4(v1 * sc);
-                    *reinterpret_cast<uint4*>(a.out_bf16 + row * (2 * kAstDim) + n) = uint4{lo.x, lo.y, hi.x, hi.y};
-                } else {
-                    const size_t b = row / kAstTokens, tok = row - b * kAstTokens;
-                    const int hd = n - 2 * kAstDim;   // h * 64 + d
-                    typedef __bf16 bf;
-#pragma unroll
-                    for (int m = 0; m < 4; ++m) {
-                        a.vt[((b * kAstDim) + hd + m) * kAstKeysPad + tok] = __builtin_bit_cast(bf16raw, (bf)v0[m]);
-                        a.vt[((b * kAstDim) + hd + 4 + m) * kAstKeysPad + tok] = __builtin_bit_cast(bf16raw, (bf)v1[m]);
-                    }
-                }
-            }
-        }
-    }
-        if (!have_next) break;
-        tile = next_tile;
-        ag = agn;
-        wp = wpn;
-    }
-#undef GEMM_ALOAD
-#undef GEMM_ASTORE
-#undef GEMM_WLOAD
-#undef GEMM_WLOADQ
-#undef GEMM_COMPUTE
 }
 
 // ---------------------------------------------------------------------------------------------- LayerNorm rows
-// one wave per row of 768: fp32 in -> bf16 out
+// fp32 tile-major in -> bf16 tile-major out.  One workgroup per 16-row tile row; wave w owns the feature tiles 6 w .. 6 w + 5, so
+// lane (g, j) holds 48 values of row j (features 32 t + 8 g .. + 7) and every load / store of a wave is one contiguous 1 KiB.
+// Row statistics: lane partials -> the four g lanes of a row (two shuffles) -> the four waves through LDS, two passes (mean,
+// then the centred second moment), always in the same order - a row's result does not depend on where in the batch it sits.
 __global__ __launch_bounds__(256) void k_ln_bf16(const float* __restrict__ X, const float* __restrict__ gamma,
-                                                 const float* __restrict__ beta, float eps, bf16raw* __restrict__ out, int M) {
-    const int lane = threadIdx.x & 63;
-    const size_t row = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= (size_t)M) return;
-    const float* x = X + row * kAstDim;
-    f32x4 v[3];
+                                                 const float* __restrict__ beta, float eps, bf16raw* __restrict__ out) {
+    __shared__ float red[2][4][16];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4, j = lane & 15;
+    const size_t tile0 = (size_t)blockIdx.x * (kAstDim / 32) + 6 * wave;
+    const float* x = X + tile0 * 512 + lane * 4;
+    f32x4 v[6][2];
     float s = 0.f;
 #pragma unroll
-    for (int i = 0; i < 3; ++i) {
-        v[i] = ld4(x + 256 * i + 4 * lane);
-        s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
+    for (int t = 0; t < 6; ++t) {
+        v[t][0] = ld4(x + t * 512);
+        v[t][1] = ld4(x + t * 512 + 256);
+        s += ((v[t][0][0] + v[t][0][1]) + (v[t][0][2] + v[t][0][3])) + ((v[t][1][0] + v[t][1][1]) + (v[t][1][2] + v[t][1][3]));
     }
-    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
-    const float mean = s * (1.0f / kAstDim);
+    s += __shfl_xor(s, 16);
+    s += __shfl_xor(s, 32);
+    if (g == 0) red[0][wave][j] = s;
+    __syncthreads();
+    const float mean = ((red[0][0][j] + red[0][1][j]) + (red[0][2][j] + red[0][3][j])) * (1.0f / kAstDim);
     float q = 0.f;
 #pragma unroll
-    for (int i = 0; i < 3; ++i)
+    for (int t = 0; t < 6; ++t)
 #pragma unroll
-        for (int m = 0; m < 4; ++m) {
-            const float d = v[i][m] - mean;
-            q += d * d;
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                const float d = v[t][h][m] - mean;
+                q += d * d;
+            }
+    q += __shfl_xor(q, 16);
+    q += __shfl_xor(q, 32);
+    if (g == 0) red[1][wave][j] = q;
+    __syncthreads();
+    const float rstd = 1.0f / sqrtf(((red[1][0][j] + red[1][1][j]) + (red[1][2][j] + red[1][3][j])) * (1.0f / kAstDim) + eps);
+    bf16raw* o = out + tile0 * 512 + lane * 8;
+#pragma unroll
+    for (int t = 0; t < 6; ++t) {
+        const int f = 32 * (6 * wave + t) + 8 * g;
+        uint2 pk[2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const f32x4 ga = ld4(gamma + f + 4 * h), be = ld4(beta + f + 4 * h);
+            f32x4 y;
+#pragma unroll
+            for (int m = 0; m < 4; ++m) y[m] = (v[t][h][m] - mean) * rstd * ga[m] + be[m];
+            pk[h] = pack4(y);
         }
-    for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o);
-    const float rstd = 1.0f / sqrtf(q * (1.0f / kAstDim) + eps);
-#pragma unroll
-    for (int i = 0; i < 3; ++i) {
-        const f32x4 ga = ld4(gamma + 256 * i + 4 * lane), be = ld4(beta + 256 * i + 4 * lane);
-        f32x4 y;
-#pragma unroll
-        for (int m = 0; m < 4; ++m) y[m] = (v[i][m] - mean) * rstd * ga[m] + be[m];
-        *reinterpret_cast<uint2*>(out + row * kAstDim + 256 * i + 4 * lane) = pack4(y);
+        *reinterpret_cast<uint4*>(o + t * 512) = uint4{pk[0].x, pk[0].y, pk[1].x, pk[1].y};
+    }
+}
+
+// ---------------------------------------------------------------------------------------------- row-major <-> tile-major
+// one workgroup per 16-row tile row; thread = (tile-relative feature octet walk): rows >= M read as zero / are not written
+__global__ __launch_bounds__(256) void k_tile_bf16(const bf16raw* __restrict__ src, bf16raw* __restrict__ dst, int M, int F) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4, j = lane & 15;
+    const size_t row = (size_t)blockIdx.x * 16 + j;
+    for (int ft = wave; ft < F / 32; ft += 4) {
+        uint4 u = uint4{0, 0, 0, 0};
+        if (row < (size_t)M) u = *reinterpret_cast<const uint4*>(src + row * F + 32 * ft + 8 * g);
+        *reinterpret_cast<uint4*>(dst + ((size_t)blockIdx.x * (F / 32) + ft) * 512 + lane * 8) = u;
+    }
+}
+__global__ __launch_bounds__(256) void k_untile_bf16(const bf16raw* __restrict__ src, bf16raw* __restrict__ dst, int M, int F) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4, j = lane & 15;
+    const size_t row = (size_t)blockIdx.x * 16 + j;
+    if (row >= (size_t)M) return;
+    for (int ft = wave; ft < F / 32; ft += 4)
+        *reinterpret_cast<uint4*>(dst + row * F + 32 * ft + 8 * g) =
+            *reinterpret_cast<const uint4*>(src + ((size_t)blockIdx.x * (F / 32) + ft) * 512 + lane * 8);
+}
+__global__ __launch_bounds__(256) void k_untile_f32(const float* __restrict__ src, float* __restrict__ dst, int M, int F) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4, j = lane & 15;
+    const size_t row = (size_t)blockIdx.x * 16 + j;
+    if (row >= (size_t)M) return;
+    for (int ft = wave; ft < F / 32; ft += 4) {
+        const float* t = src + ((size_t)blockIdx.x * (F / 32) + ft) * 512 + lane * 4;
+        st4(dst + row * F + 32 * ft + 8 * g, ld4(t));
+        st4(dst + row * F + 32 * ft + 8 * g + 4, ld4(t + 256));
     }
 }
 
@@ -376,7 +217,7 @@ constexpr int kVS = kKc + 8;            // padded V^T row (bf16): 144 B
 // grid (19 query blocks of 64, 12 heads, B); wave w owns the 16 queries 64 qb + 16 w ..
 __global__ __launch_bounds__(256) void k_ast_attn(const bf16raw* __restrict__ QK /*[M][1536]*/,
                                                   const bf16raw* __restrict__ Vt /*[B][768][1216]*/,
-                                                  bf16raw* __restrict__ O /*[M][768]*/) {
+                                                  bf16raw* __restrict__ O /*tile-major [M][768]*/) {
     __shared__ __attribute__((aligned(16))) bf16raw Ks[kKc * kKS];
     __shared__ __attribute__((aligned(16))) bf16raw Vs[64 * kVS];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
@@ -471,7 +312,7 @@ __global__ __launch_bounds__(256) void k_ast_attn(const bf16raw* __restrict__ QK
         const float inv = 1.0f / l_run;
 #pragma unroll
         for (int td = 0; td < 4; ++td)
-            *reinterpret_cast<uint2*>(O + (row0 + q) * kAstDim + 64 * h + 16 * td + 4 * g) = pack4(o[td] * inv);
+            *reinterpret_cast<uint2*>(O + tm_bf16(row0 + q, 64 * h + 16 * td + 4 * g, kAstDim)) = pack4(o[td] * inv);
     }
 }
 
@@ -492,11 +333,11 @@ __global__ __launch_bounds__(256) void k_ast_pool(const float* __restrict__ X, c
 #pragma unroll
     for (int i = 0; i < 3; ++i) { ga[i] = ld4(gamma + 256 * i + 4 * lane); be[i] = ld4(beta + 256 * i + 4 * lane); }
     for (int r = c0 + wave; r < c1; r += 4) {
-        const float* x = X + ((size_t)b * kAstTokens + r) * kAstDim;
+        const size_t row = (size_t)b * kAstTokens + r;
         f32x4 v[3];
         float s = 0.f;
 #pragma unroll
-        for (int i = 0; i < 3; ++i) { v[i] = ld4(x + 256 * i + 4 * lane); s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]); }
+        for (int i = 0; i < 3; ++i) { v[i] = ld4(X + tm_f32(row, 256 * i + 4 * lane, kAstDim)); s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]); }
         for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
         const float mean = s * (1.0f / kAstDim);
         float q = 0.f;
@@ -563,37 +404,8 @@ __global__ __launch_bounds__(256) void k_ast_head(const float* __restrict__ pool
     out[(size_t)b * kAstFeat + t] = acc + bias[t];
 }
 
-template <int EPI>
-hipError_t launch_gemm_t(const GemmArgs& a, hipStream_t s) {
-    static bool attr = false;
-    if (!attr) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_bf16<EPI, false>), hipFuncAttributeMaxDynamicSharedMemorySize, kGemmLds);
-        if (e == hipSuccess)
-            e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_bf16<EPI, true>), hipFuncAttributeMaxDynamicSharedMemorySize, kGemmLds);
-        if (e != hipSuccess) return e;
-        attr = true;
-    }
-    const int n_tiles = ((a.M + BM - 1) / BM) * (a.N / BN);
-    const int resident = 2 * 256;   // two workgroups (8 waves, 2 per SIMD at this register count) per CU, 256 CUs
-    const dim3 grid(n_tiles < resident ? n_tiles : resident);
-    static const bool no_deep = [] { const char* e = getenv("AMUSE_GEMM_DEEP"); return e && atoi(e) == 0; }();
-    if ((a.K / BK) % 6 == 0 && !no_deep) hipLaunchKernelGGL((k_gemm_bf16<EPI, true>), grid, dim3(256), kGemmLds, s, a);
-    else hipLaunchKernelGGL((k_gemm_bf16<EPI, false>), grid, dim3(256), kGemmLds, s, a);
-    return hipGetLastError();
-}
-
 }  // namespace
 
-hipError_t launch_gemm(const GemmArgs& a, int epi, hipStream_t s) {
-    switch (epi) {
-        case EPI_BF16: return launch_gemm_t<EPI_BF16>(a, s);
-        case EPI_GELU_BF16: return launch_gemm_t<EPI_GELU_BF16>(a, s);
-        case EPI_RESID_F32: return launch_gemm_t<EPI_RESID_F32>(a, s);
-        case EPI_F32: return launch_gemm_t<EPI_F32>(a, s);
-        case EPI_PATCH: return launch_gemm_t<EPI_PATCH>(a, s);
-        default: return launch_gemm_t<EPI_QKV>(a, s);
-    }
-}
 hipError_t launch_fbank(const float* wave, int n_samples, int B, const float* window, const float* melw, const int* mel_range, float mean, float std,
                         float* out, hipStream_t s) {
     hipLaunchKernelGGL(k_fbank, dim3(kAstFrames, B), dim3(256), 0, s, wave, n_samples, window, melw, mel_range, mean, 1.0f / (2.0f * std), out);
@@ -608,7 +420,19 @@ hipError_t launch_ast_tokens(const float* cls, const float* dist, const float* p
     return hipGetLastError();
 }
 hipError_t launch_ln_bf16(const float* X, const float* gamma, const float* beta, float eps, unsigned short* out, int M, hipStream_t s) {
-    hipLaunchKernelGGL(k_ln_bf16, dim3((M + 3) / 4), dim3(256), 0, s, X, gamma, beta, eps, out, M);
+    hipLaunchKernelGGL(k_ln_bf16, dim3((M + 15) / 16), dim3(256), 0, s, X, gamma, beta, eps, out);
+    return hipGetLastError();
+}
+hipError_t launch_tile_bf16(const unsigned short* src, unsigned short* dst, int M, int F, hipStream_t s) {
+    hipLaunchKernelGGL(k_tile_bf16, dim3((M + kGemmTM - 1) / kGemmTM * (kGemmTM / 16)), dim3(256), 0, s, src, dst, M, F);
+    return hipGetLastError();
+}
+hipError_t launch_untile_bf16(const unsigned short* src, unsigned short* dst, int M, int F, hipStream_t s) {
+    hipLaunchKernelGGL(k_untile_bf16, dim3((M + 15) / 16), dim3(256), 0, s, src, dst, M, F);
+    return hipGetLastError();
+}
+hipError_t launch_untile_f32(const float* src, float* dst, int M, int F, hipStream_t s) {
+    hipLaunchKernelGGL(k_untile_f32, dim3((M + 15) / 16), dim3(256), 0, s, src, dst, M, F);
     return hipGetLastError();
 }
 hipError_t launch_ast_attn(const unsigned short* QK, const unsigned short* Vt, unsigned short* O, int B, hipStream_t s) {

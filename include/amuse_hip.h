@@ -237,11 +237,16 @@ int amuse_audio_encode(amuse_audio_ctx* ctx, int which, const float* fbank, int 
 int amuse_audio_features(amuse_audio_ctx* ctx, const float* waves, int n_samples, int B, float* con_out,
                          float* emo_out, float* sty_out, void* stream);
 
-/* The front-end's GEMM kernel in isolation, for tests and tools/gpu_gemm_bench.py: out = A . W^T + bias,
- * A dev bf16 [M rounded up to 256][K], W dev bf16 [N][K] (N % 256 == 0, K % 64 == 0), epi 0: out dev bf16 [M][N],
- * epi 3: out dev fp32 [M][N]. */
+/* The front-end's GEMM kernel in isolation, for tests and tools/gpu_gemm_bench.py: out = A . W^T + bias.
+ * The front-end keeps every GEMM operand TILE-MAJOR in HBM (16-row x 32-feature tiles of 64 lanes x 8 elements, a bf16
+ * tile being one MFMA fragment; amuse_amd/csrc/amuse_audio.hpp): A dev bf16 tile-major [M rounded up to 128][K], W dev
+ * bf16 in the kernel's packed fragment order (amuse_audio_api.hip pack_w), N % 256 == 0, K % 64 == 0;
+ * epi 0: out dev bf16 tile-major [M rounded up to 128][N], epi 3: the same in fp32. */
 int amuse_debug_gemm(const void* A, const void* W, const float* bias, int M, int N, int K, int epi,
                      void* out, void* stream);
+/* Row-major <-> tile-major copies for the above (F % 32 == 0).  what 0: bf16 row-major [M][F] -> tile-major [M rounded up
+ * to 128][F], pad rows zeroed; 1: bf16 tile-major -> row-major [M][F]; 2: fp32 tile-major -> row-major [M][F]. */
+int amuse_debug_tile(const void* src, void* dst, int M, int F, int what, void* stream);
 
 #ifdef __cplusplus
 }

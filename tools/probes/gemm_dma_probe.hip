@@ -1,0 +1,531 @@
+// Candidate GEMM for the audio front-end, in isolation: both operands travel global -> LDS by LDS-DMA
+// (global_load_lds_dwordx4), gathered DIRECTLY into MFMA-fragment order (a fragment = 16 rows x 32 k = 64 lanes x 16 B, and
+// lane (g, j) of the DMA reads row j, k = 8 g .. 8 g + 7 of a row-major matrix), so there is no register staging, no ds_write and
+// every fragment read is a lane-linear ds_read_b128.  256 features x 128 tokens x 32 k per stage (24 fragments = 24 KiB), a
+// ring of three stages per workgroup, one barrier per stage; four waves of 128 x 64 (128 accumulator registers), TWO persistent
+// workgroups per CU so that one's barrier / LDS latency / epilogue runs under the other's MFMAs.
+// C[row][feature] = sum_k X[row][k] W[feature][k]  (bf16 in; fp32 or bf16 out).
+//   hipcc -O3 --offload-arch=gfx950 gemm_dma_probe.hip -o gemm_dma_probe [-DXCD_REMAP=0] [-DNSLOT=3]
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <cmath>
+#include <vector>
+#include <type_traits>
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+#ifndef NSLOT
+#define NSLOT 3
+#endif
+#ifndef ABL
+#define ABL 0   // 1: no DMA (stale LDS), 2: no fragment reads / MFMAs
+#endif
+#ifndef PACKED
+#define PACKED 1   // operands in fragment-major order [row tile][k step][64 lanes][8]: every DMA instruction reads 1 KiB contiguous
+#endif
+#ifndef XCD_REMAP
+#define XCD_REMAP 1
+#endif
+constexpr int TN = 256, TM = 128, BK = 32;
+constexpr int WFR = TN / 16, XFR = TM / 16, SFR = WFR + XFR;   // fragments per stage: 16 + 8
+constexpr int STAGE = SFR * 1024;
+constexpr int LDS_BYTES = NSLOT * STAGE;
+#define CHECK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1); } } while (0)
+
+__device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_dst) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+
+// element (row, f) of an [M][F] matrix in tile-major order: 16-row x 32-feature tiles of 64 lanes x 8 elements - a bf16 tile IS an
+// MFMA fragment, and a lane's 8 consecutive features of one row are contiguous in either precision
+__host__ __device__ inline size_t tm_index(size_t row, int f, int F) {
+  return ((row >> 4) * (F >> 5) + (f >> 5)) * 512 + ((((f & 31) >> 3) << 4) + (row & 15)) * 8 + (f & 7);
+}
+#ifndef SPREAD
+#define SPREAD 1
+#define SPREAD0 0
+#endif
+#ifndef DELAY
+#define DELAY 0   // s_memtime ticks (100 MHz?) an odd workgroup waits before it starts: de-phases the two workgroups of a CU
+#endif
+__device__ __forceinline__ float gelu_erf_fast(float x) {
+  const float z = fabsf(x) * 0.70710678118654752440f;
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));
+  float p = fmaf(t, 1.061405429f, -1.453152027f);
+  p = fmaf(t, p, 1.421413741f); p = fmaf(t, p, -0.284496736f); p = fmaf(t, p, 0.254829592f);
+  const float e = __builtin_amdgcn_exp2f(-1.44269504088896340736f * z * z);
+  const float erfabs = fmaf(-(p * t), e, 1.0f);
+  const float hx = 0.5f * x;
+  return fmaf(fabsf(hx), erfabs, hx);
+}
+__device__ __forceinline__ f32x4 gelu_poly4(f32x4 x) {
+  constexpr float X0 = 4.24264068711928514641f;
+  f32x4 a;
+#pragma unroll
+  for (int m = 0; m < 4; ++m) a[m] = __builtin_amdgcn_fmed3f(x[m], -X0, X0);
+  const f32x4 s = a * a;
+  f32x4 p = f32x4{-2.152084733e-09f, -2.152084733e-09f, -2.152084733e-09f, -2.152084733e-09f};
+  p = p * s + 1.840825661e-07f; p = p * s + -6.815091183e-06f; p = p * s + 1.449597330e-04f; p = p * s + -1.993848477e-03f;
+  p = p * s + 1.900408231e-02f; p = p * s + -1.319021881e-01f; p = p * s + 7.975201607e-01f;
+  const f32x4 hx = 0.5f * x;
+  return hx * (a * p) + hx;
+}
+#ifndef ABL2
+#define ABL2 0
+#endif
+#ifndef NT
+#define NT 1
+#endif
+// fp32 variant: a 16 x 32 tile is two 1 KiB halves [features 8 g + 0..3 | 8 g + 4..7] of 64 lanes x 4 floats, so each of a lane's two
+// 16-byte accesses belongs to a wave-contiguous 1 KiB
+__host__ __device__ inline size_t tm_index_f32(size_t row, int f, int F) {
+  return ((row >> 4) * (F >> 5) + (f >> 5)) * 512 + ((f >> 2) & 1) * 256 + ((((f & 31) >> 3) << 4) + (row & 15)) * 4 + (f & 3);
+}
+#ifndef LOADALL
+#define LOADALL 0
+#endif
+// STORE: 0 none, 1 fp32 [M][N], 2 bf16 [M][N], 3 bf16 tile-major, 4 fp32 tile-major, 5 fp32 tile-major +=
+template <int STORE>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))
+void k_gemm_dma(const unsigned short* __restrict__ X, const unsigned short* __restrict__ W, void* __restrict__ Cout, int M, int N, int K) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6), g = lane >> 4, j = lane & 15;
+  const int wf = wave >> 1, wr = wave & 1;     // feature half (128), token half (64)
+  const int tiles_n = N / TN, tiles_m = (M + TM - 1) / TM, n_tiles = tiles_n * tiles_m, nk = K / BK;
+  int wg = blockIdx.x;
+  if (XCD_REMAP && (gridDim.x % 8) == 0) wg = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);   // neighbours in tile order share an XCD (its L2)
+  if (wg >= n_tiles) return;
+  const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) const void*)smem;
+  // this wave's DMA pieces of a stage: W fragments 4 wave .. + 3, X fragments 2 wave, 2 wave + 1.  Source row of lane (g, j) in W
+  // fragment 2 p + q: feature 32 p + 8 (j / 4) + 4 q + j % 4 - so a lane's accumulators of fragments 2 p, 2 p + 1 are 8 consecutive
+  // features (16-byte bf16 stores)
+  const int wrow = 8 * (j >> 2) + (j & 3);
+  auto w_src = [&](int tile, int i) {   // i = 0..3: fragment 4 wave + i = 2 p + q
+    const int f = 4 * wave + i, n = (tile % tiles_n) * TN + 32 * (f >> 1) + 4 * (f & 1) + wrow;
+    if (PACKED) return W + ((size_t)((tile % tiles_n) * WFR + f) * nk) * 512 + lane * 8;
+    return W + (size_t)n * K + 8 * g;
+  };
+  auto x_src = [&](int tile, int i) {
+    int m = (tile / tiles_n) * TM + 16 * (2 * wave + i) + j;
+    m = m < M ? m : M - 1;
+    if (PACKED) return X + ((size_t)((tile / tiles_n) * XFR + 2 * wave + i) * nk) * 512 + lane * 8;
+    return X + (size_t)m * K + 8 * g;
+  };
+  // fetch cursor: the stage that is issued next
+  int f_tile = wg, f_k = 0, f_slot = 0;
+  const unsigned short *fw[4], *fx[2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) fw[i] = w_src(f_tile, i);
+#pragma unroll
+  for (int i = 0; i < 2; ++i) fx[i] = x_src(f_tile, i);
+  auto fetch = [&]() {
+    const unsigned d = lds0 + f_slot * STAGE;
+    if (!(ABL & 1)) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) glds16(fw[i] + f_k * (PACKED ? 512 : BK), d + (4 * wave + i) * 1024);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) glds16(fx[i] + f_k * (PACKED ? 512 : BK), d + (WFR + 2 * wave + i) * 1024);
+    }
+    f_slot = f_slot == NSLOT - 1 ? 0 : f_slot + 1;
+    if (++f_k == nk) {
+      f_k = 0;
+      const int nt = f_tile + gridDim.x;
+      f_tile = nt < n_tiles ? nt : f_tile;   // past the end: the last tile again (lands in a free slot, never read)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) fw[i] = w_src(f_tile, i);
+#pragma unroll
+      for (int i = 0; i < 2; ++i) fx[i] = x_src(f_tile, i);
+    }
+  };
+#pragma unroll
+  for (int s = 0; s < NSLOT - 1; ++s) fetch();
+  int c_slot = 0;
+  for (int tile = wg; tile < n_tiles; tile += gridDim.x) {
+    f32x4 acc[8][4];
+#pragma unroll
+    for (int x = 0; x < 8; ++x)
+#pragma unroll
+      for (int y = 0; y < 4; ++y) acc[x][y] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+    for (int ks = 0; ks < nk; ++ks) {
+      // own pieces of this stage have landed (the NSLOT - 2 younger stages may still fly), every wave is done with the previous one
+      asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(6 * (NSLOT - 2)) : "memory");
+      fetch();
+      if (ABL & 2) continue;
+      const char* sl = smem + c_slot * STAGE + lane * 16;
+      bf16x8 wfr[8], xfr[4];
+#pragma unroll
+      for (int y = 0; y < 4; ++y) xfr[y] = *reinterpret_cast<const bf16x8*>(sl + (WFR + 4 * wr + y) * 1024);
+#pragma unroll
+      for (int x = 0; x < 8; ++x) wfr[x] = *reinterpret_cast<const bf16x8*>(sl + (8 * wf + x) * 1024);
+      if (LOADALL) __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int x = 0; x < 8; ++x)
+#pragma unroll
+        for (int y = 0; y < 4; ++y) acc[x][y] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wfr[x], xfr[y], acc[x][y], 0, 0, 0);
+      c_slot = c_slot == NSLOT - 1 ? 0 : c_slot + 1;
+    }
+    const int m0 = (tile / tiles_n) * TM + 64 * wr, n0 = (tile % tiles_n) * TN + 128 * wf;
+    if (STORE) {
+#pragma unroll
+      for (int y = 0; y < 4; ++y) {
+        const int row = m0 + 16 * y + j;
+        if (row >= M) continue;
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+          const int f = n0 + 32 * p + 8 * g;
+          if (STORE == 1) {
+            float* c = reinterpret_cast<float*>(Cout) + (size_t)row * N + f;
+            *reinterpret_cast<f32x4*>(c) = acc[2 * p][y];
+            *reinterpret_cast<f32x4*>(c + 4) = acc[2 * p + 1][y];
+          } else if (STORE == 4 || STORE == 5) {
+            float* c = reinterpret_cast<float*>(Cout) + tm_index(row, f, N);
+            f32x4 v0 = acc[2 * p][y], v1 = acc[2 * p + 1][y];
+            if (STORE == 5) { v0 += *reinterpret_cast<f32x4*>(c); v1 += *reinterpret_cast<f32x4*>(c + 4); }
+            *reinterpret_cast<f32x4*>(c) = v0;
+            *reinterpret_cast<f32x4*>(c + 4) = v1;
+          } else if (STORE == 3) {
+            typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+            auto pk = [](float a, float b) { return __builtin_bit_cast(unsigned, bf16x2{(__bf16)a, (__bf16)b}); };
+            const f32x4 v0 = acc[2 * p][y], v1 = acc[2 * p + 1][y];
+            *reinterpret_cast<uint4*>(reinterpret_cast<unsigned short*>(Cout) + tm_index(row, f, N)) =
+                uint4{pk(v0[0], v0[1]), pk(v0[2], v0[3]), pk(v1[0], v1[1]), pk(v1[2], v1[3])};
+          } else {
+            typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+            auto pk = [](float a, float b) { return __builtin_bit_cast(unsigned, bf16x2{(__bf16)a, (__bf16)b}); };
+            const f32x4 v0 = acc[2 * p][y], v1 = acc[2 * p + 1][y];
+            *reinterpret_cast<uint4*>(reinterpret_cast<unsigned short*>(Cout) + (size_t)row * N + f) =
+                uint4{pk(v0[0], v0[1]), pk(v0[2], v0[3]), pk(v1[0], v1[1]), pk(v1[2], v1[3])};
+          }
+        }
+      }
+    } else {
+      float s = 0.f;
+#pragma unroll
+      for (int x = 0; x < 8; ++x)
+#pragma unroll
+        for (int y = 0; y < 4; ++y) s += acc[x][y][0] + acc[x][y][3];
+      if (s == 12345.678f) reinterpret_cast<float*>(Cout)[0] = s;
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the surplus fetches must not outlive the workgroup's LDS
+}
+
+
+// ---- v2: the fragments of stage s + 1 are read into registers WHILE stage s is multiplied (W fragment x right behind its four
+// MFMAs, the X fragments into a second set), so no LDS round trip is exposed; the barrier in front of stage s certifies that stage
+// s + 1 has landed and that every wave holds stage s in registers - its slot is refilled at once (three stages in flight).
+// Epilogue stores are fire-and-forget: the two stages after a tile's epilogue wait with vmcnt(6 + SN) (SN stores sit behind
+// the DMA pieces they need; vmcnt retires in order).
+#ifdef PROF
+__device__ unsigned long long g_prof[16 * 4 * 8];
+#endif
+// the same with a wave-uniform base address (SGPR pair) and one 32-bit lane offset
+__device__ __forceinline__ void glds16s(const void* sbase, unsigned voff, unsigned lds_dst) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds_dst) : "memory");
+}
+template <int STORE>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))
+void k_gemm_dma2(const unsigned short* __restrict__ X, const unsigned short* __restrict__ W, void* __restrict__ Cout, int M, int N, int K) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6), g = lane >> 4, j = lane & 15;
+  const int wf = wave >> 1, wr = wave & 1;
+  const int tiles_n = N / TN, tiles_m = (M + TM - 1) / TM, n_tiles = tiles_n * tiles_m, nk = K / BK;
+  int wg = blockIdx.x;
+  if (XCD_REMAP && (gridDim.x % 8) == 0) wg = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+  if (wg >= n_tiles) return;
+  const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) const void*)smem;
+  const unsigned voff = lane * 16;
+  // fetch cursor (all wave-uniform): the W / X fragment rows this wave fetches, as byte addresses of k-step f_k
+  int f_tile = wg, f_k = 0, f_slot = 0;
+  const size_t frag_row = (size_t)nk * 1024;   // bytes between consecutive fragment rows of a tile-major matrix
+  const char *fw, *fx;
+  auto cursor = [&]() {
+    fw = reinterpret_cast<const char*>(W) + (size_t)((f_tile % tiles_n) * WFR + 4 * wave) * frag_row;
+    fx = reinterpret_cast<const char*>(X) + (size_t)((f_tile / tiles_n) * XFR + 2 * wave) * frag_row;
+  };
+  cursor();
+  // piece i of the wave's six DMA instructions of the next stage to fetch (0..3: W fragment rows, 4..5: X fragment rows)
+  auto fetch_piece = [&](int i) {
+    if (ABL2 & 1) return;
+    const unsigned d = lds0 + f_slot * STAGE;
+    if (i < 4) glds16s(fw + i * frag_row + (size_t)f_k * 1024, voff, d + (4 * wave + i) * 1024);
+    else glds16s(fx + (i - 4) * frag_row + (size_t)f_k * 1024, voff, d + (WFR + 2 * wave + i - 4) * 1024);
+  };
+  auto fetch_advance = [&]() {
+    f_slot = f_slot == NSLOT - 1 ? 0 : f_slot + 1;
+    if (++f_k == nk) {
+      f_k = 0;
+      const int nt = f_tile + gridDim.x;
+      f_tile = nt < n_tiles ? nt : f_tile;
+      cursor();
+    }
+  };
+  auto fetch = [&]() {
+#pragma unroll
+    for (int i = 0; i < 6; ++i) fetch_piece(i);
+    fetch_advance();
+  };
+  if (DELAY && ((blockIdx.x >> 3) & 1)) {
+    const unsigned long long t0 = __builtin_readcyclecounter();
+    while (__builtin_readcyclecounter() - t0 < (unsigned long long)DELAY * (nk / 24)) __builtin_amdgcn_s_sleep(8);
+  }
+  fetch(); fetch(); fetch();
+  asm volatile("s_waitcnt vmcnt(12)\n\ts_barrier" ::: "memory");
+  bf16x8 wc[8], xa[4], xb[4];
+  {
+    const char* sl = smem + lane * 16;
+#pragma unroll
+    for (int y = 0; y < 4; ++y) xa[y] = *reinterpret_cast<const bf16x8*>(sl + (WFR + 4 * wr + y) * 1024);
+#pragma unroll
+    for (int x = 0; x < 8; ++x) wc[x] = *reinterpret_cast<const bf16x8*>(sl + (8 * wf + x) * 1024);
+  }
+  int r_slot = 1;
+  constexpr int SN = (STORE == 3 || STORE >= 6) ? 16 : STORE == 5 ? 32 : 0;   // vector-memory operations of the epilogue that may still be in flight
+  f32x4 acc[8][4];
+#ifdef PROF
+  unsigned long long t_stall = 0, t_work = 0, t_fetch = 0, t_prev = __builtin_readcyclecounter(), t_epi = 0, t_stall_r = 0;
+  unsigned n_iter = 0, n_tile = 0;
+#endif
+  auto half = [&](auto relaxed, bf16x8 (&xc)[4], bf16x8 (&xn)[4]) {
+    constexpr int WAITN = 6 + (decltype(relaxed)::value ? SN : 0);
+#ifdef PROF
+    const unsigned long long ta = __builtin_readcyclecounter();
+#endif
+    if (ABL2 & 4) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(WAITN) : "memory");
+    else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(WAITN) : "memory");
+#ifdef PROF
+    const unsigned long long tb = __builtin_readcyclecounter();
+#endif
+#if !SPREAD
+    fetch();
+#endif
+#ifdef PROF
+    const unsigned long long tc = __builtin_readcyclecounter();
+    t_work += ta - t_prev; t_stall += tb - ta; t_fetch += tc - tb; t_prev = tc; ++n_iter;
+    if (decltype(relaxed)::value) t_stall_r += tb - ta;
+#endif
+    const char* sl = smem + r_slot * STAGE + lane * 16;
+#pragma unroll
+    for (int y = 0; y < 4; ++y) xn[y] = (ABL2 & 2) ? xc[y] : *reinterpret_cast<const bf16x8*>(sl + (WFR + 4 * wr + y) * 1024);
+#pragma unroll
+    for (int x = 0; x < 8; ++x) {
+#pragma unroll
+      for (int y = 0; y < 4; ++y) acc[x][y] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wc[x], xc[y], acc[x][y], 0, 0, 0);
+      if (!(ABL2 & 2)) wc[x] = *reinterpret_cast<const bf16x8*>(sl + (8 * wf + x) * 1024);
+#if SPREAD
+      if (x >= SPREAD0 && x < SPREAD0 + 6) fetch_piece(x - SPREAD0);   // one DMA instruction per MFMA group: a wave blocks at issue while the CU's 64 B/clk path is busy
+      if (x == 7) fetch_advance();
+#endif
+      __builtin_amdgcn_sched_barrier(0);   // (keeps the scheduler from hoisting every read to the top: 48 more live registers)
+    }
+    r_slot = r_slot == NSLOT - 1 ? 0 : r_slot + 1;
+  };
+  bool first = true;
+  for (int tile = wg; tile < n_tiles; tile += gridDim.x) {
+#pragma unroll
+    for (int x = 0; x < 8; ++x)
+#pragma unroll
+      for (int y = 0; y < 4; ++y) acc[x][y] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (first) { half(std::false_type{}, xa, xb); half(std::false_type{}, xb, xa); }
+    else { half(std::true_type{}, xa, xb); half(std::true_type{}, xb, xa); }
+    first = false;
+#pragma unroll 1
+    for (int kp = 2; kp < nk; kp += 2) { half(std::false_type{}, xa, xb); half(std::false_type{}, xb, xa); }
+#ifdef PROF
+    const unsigned long long te0 = __builtin_readcyclecounter();
+#endif
+    const int m0 = (tile / tiles_n) * TM + 64 * wr, n0 = (tile % tiles_n) * TN + 128 * wf;
+    if (STORE) {
+      // tile-major output: the wave's store of (y, p) is one whole 16 x 32 tile - 1 KiB (bf16) / 2 KiB (fp32) contiguous; uniform
+      // tile address + lane offset.  Rows past M exist in the padded buffer.
+#pragma unroll
+      for (int y = 0; y < 4; ++y) {
+        const size_t tile0 = (size_t)((m0 >> 4) + y) * (N >> 5) + (n0 >> 5);
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+          if (STORE == 5) {
+            float* c = reinterpret_cast<float*>(reinterpret_cast<char*>(Cout) + (tile0 + p) * 2048 + voff);
+            f32x4 v0 = acc[2 * p][y], v1 = acc[2 * p + 1][y];
+#if NT & 2
+            v0 += __builtin_nontemporal_load(reinterpret_cast<f32x4*>(c)); v1 += __builtin_nontemporal_load(reinterpret_cast<f32x4*>(c + 256));
+            __builtin_nontemporal_store(v0, reinterpret_cast<f32x4*>(c));
+            __builtin_nontemporal_store(v1, reinterpret_cast<f32x4*>(c + 256));
+#else
+            v0 += *reinterpret_cast<f32x4*>(c); v1 += *reinterpret_cast<f32x4*>(c + 256);
+            *reinterpret_cast<f32x4*>(c) = v0;
+            *reinterpret_cast<f32x4*>(c + 256) = v1;
+#endif
+          } else {
+            typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+            auto pk = [](float a, float b) { return __builtin_bit_cast(unsigned, bf16x2{(__bf16)a, (__bf16)b}); };
+            f32x4 v0 = acc[2 * p][y], v1 = acc[2 * p + 1][y];
+            if (STORE == 6) { v0 = gelu_poly4(v0); v1 = gelu_poly4(v1); }
+            if (STORE == 7) {
+#pragma unroll
+              for (int m = 0; m < 4; ++m) { v0[m] = gelu_erf_fast(v0[m]); v1[m] = gelu_erf_fast(v1[m]); }
+            }
+            typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+            const u32x4 o = u32x4{pk(v0[0], v0[1]), pk(v0[2], v0[3]), pk(v1[0], v1[1]), pk(v1[2], v1[3])};
+            u32x4* dst = reinterpret_cast<u32x4*>(reinterpret_cast<char*>(Cout) + (tile0 + p) * 1024 + voff);
+#if NT & 1
+            __builtin_nontemporal_store(o, dst);
+#else
+            *dst = o;
+#endif
+          }
+        }
+      }
+    } else {
+      float s = 0.f;
+#pragma unroll
+      for (int x = 0; x < 8; ++x)
+#pragma unroll
+        for (int y = 0; y < 4; ++y) s += acc[x][y][0] + acc[x][y][3];
+      if (s == 12345.678f) reinterpret_cast<float*>(Cout)[0] = s;
+    }
+#ifdef PROF
+    { const unsigned long long te1 = __builtin_readcyclecounter(); t_epi += te1 - te0; t_prev = te1; ++n_tile; }
+#endif
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#ifdef PROF
+  if (lane == 0 && blockIdx.x < 16) {
+    unsigned long long* o = g_prof + (blockIdx.x * 4 + wave) * 8;
+    o[0] = t_work; o[1] = t_stall; o[2] = t_fetch; o[3] = n_iter; o[4] = t_epi; o[5] = n_tile; o[6] = t_stall_r;
+  }
+#endif
+}
+
+static unsigned short f2bf(float f) { unsigned u; memcpy(&u, &f, 4); u += 0x7fffu + ((u >> 16) & 1u); return (unsigned short)(u >> 16); }
+static float bf2f(unsigned short h) { unsigned u = (unsigned)h << 16; float f; memcpy(&f, &u, 4); return f; }
+
+template <int STORE>
+static void launch(int grid, const unsigned short* dx, const unsigned short* dw, void* dc, int M, int N, int K) {
+  hipLaunchKernelGGL(k_gemm_dma<STORE>, dim3(grid), dim3(256), LDS_BYTES, 0, dx, dw, dc, M, N, K);
+}
+
+int main(int argc, char** argv) {
+  const int M = argc > 1 ? atoi(argv[1]) : 38848;   // 32 clips x 1214 tokens
+  const int wgs = argc > 2 ? atoi(argv[2]) : 512;
+  const int shapes[4][2] = {{2304, 768}, {768, 768}, {3072, 768}, {768, 3072}};
+  CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_dma<0>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+  CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_dma<1>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+  CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_dma<2>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+  CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_dma<3>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+  CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_dma<4>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+  CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_dma<5>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+  for (const void* f : {reinterpret_cast<const void*>(&k_gemm_dma2<0>), reinterpret_cast<const void*>(&k_gemm_dma2<3>), reinterpret_cast<const void*>(&k_gemm_dma2<5>),
+                        reinterpret_cast<const void*>(&k_gemm_dma2<6>), reinterpret_cast<const void*>(&k_gemm_dma2<7>)})
+    CHECK(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+  for (auto& sh : shapes) {
+    const int N = sh[0], K = sh[1];
+    std::vector<unsigned short> hx((size_t)M * K), hw((size_t)N * K);
+    unsigned s = 1234567u;
+    auto rnd = [&] { s = s * 1664525u + 1013904223u; return ((s >> 8) & 0xffff) / 65536.0f - 0.5f; };
+    for (auto& v : hx) v = f2bf(rnd());
+    for (auto& v : hw) v = f2bf(rnd() * 0.1f);
+    const int Mp = (M + TM - 1) / TM * TM;
+    std::vector<unsigned short> px((size_t)Mp * K), pw((size_t)N * K);
+    if (PACKED) {
+      const int nk = K / 32;
+      for (int rt = 0; rt < Mp / 16; ++rt) for (int ks = 0; ks < nk; ++ks) for (int l = 0; l < 64; ++l) for (int e = 0; e < 8; ++e) {
+        const int row = rt * 16 + (l & 15);
+        px[(((size_t)rt * nk + ks) * 64 + l) * 8 + e] = row < M ? hx[(size_t)row * K + ks * 32 + 8 * (l >> 4) + e] : 0;
+      }
+      for (int ft = 0; ft < N / 16; ++ft) for (int ks = 0; ks < nk; ++ks) for (int l = 0; l < 64; ++l) for (int e = 0; e < 8; ++e) {
+        const int j = l & 15, n = (ft >> 1) * 32 + 4 * (ft & 1) + 8 * (j >> 2) + (j & 3);
+        pw[(((size_t)ft * nk + ks) * 64 + l) * 8 + e] = hw[(size_t)n * K + ks * 32 + 8 * (l >> 4) + e];
+      }
+    }
+    unsigned short *dx, *dw; float* dc;
+    CHECK(hipMalloc(&dx, px.size() * 2)); CHECK(hipMalloc(&dw, hw.size() * 2)); CHECK(hipMalloc(&dc, (size_t)Mp * N * 4));
+    CHECK(hipMemcpy(dx, PACKED ? px.data() : hx.data(), hx.size() * 2, hipMemcpyHostToDevice));
+    CHECK(hipMemcpy(dw, PACKED ? pw.data() : hw.data(), hw.size() * 2, hipMemcpyHostToDevice));
+    const int n_tiles = (N / TN) * ((M + TM - 1) / TM);
+    const int grid = n_tiles < wgs ? n_tiles : wgs;
+    hipEvent_t e0, e1; CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
+    for (int store = 5; store >= 0; --store) {
+      for (int rep = 0; rep < 2; ++rep) {
+        CHECK(hipEventRecord(e0));
+        for (int i = 0; i < 5; ++i) {
+          if (store == 5) launch<5>(grid, dx, dw, dc, M, N, K);
+          else if (store == 4) launch<4>(grid, dx, dw, dc, M, N, K);
+          else if (store == 3) launch<3>(grid, dx, dw, dc, M, N, K);
+          else if (store == 2) launch<2>(grid, dx, dw, dc, M, N, K);
+          else if (store == 1) launch<1>(grid, dx, dw, dc, M, N, K);
+          else launch<0>(grid, dx, dw, dc, M, N, K);
+        }
+        CHECK(hipEventRecord(e1)); CHECK(hipEventSynchronize(e1));
+        CHECK(hipGetLastError());
+        float ms; CHECK(hipEventElapsedTime(&ms, e0, e1));
+        if (rep) printf("N=%d K=%d store=%d: %.1f us  %.0f TFLOP/s\n", N, K, store, ms / 5 * 1e3, 2.0 * M * N * K / (ms / 5 * 1e-3) / 1e12);
+      }
+      if (store == 1 || store == 4) {   // spot check of the fp32 result (incl. the ragged last row tile)
+        double maxerr = 0;
+        for (int q = 0; q < 48; ++q) {
+          const int row = q < 8 ? M - 1 - q * 13 : (q * 4801 + 17) % M, f = (q * 977 + 5) % N;
+          float got; CHECK(hipMemcpy(&got, dc + (store == 4 ? tm_index(row, f, N) : (size_t)row * N + f), 4, hipMemcpyDeviceToHost));
+          double ref = 0; for (int k = 0; k < K; ++k) ref += (double)bf2f(hx[(size_t)row * K + k]) * bf2f(hw[(size_t)f * K + k]);
+          maxerr = fmax(maxerr, fabs(ref - got));
+        }
+        printf("   spot-check max err %.3e\n", maxerr);
+      }
+    }
+    if (PACKED) {
+      const int modes[5] = {7, 6, 5, 3, 0};
+      for (int mi = 0; mi < 5; ++mi) {
+        const int store = modes[mi];
+        if (store == 5) CHECK(hipMemset(dc, 0, (size_t)Mp * N * 4));
+        int launches = 0;
+        for (int rep = 0; rep < 2; ++rep) {
+          CHECK(hipEventRecord(e0));
+          for (int i = 0; i < 5; ++i, ++launches) {
+            if (store == 7) hipLaunchKernelGGL(k_gemm_dma2<7>, dim3(grid), dim3(256), LDS_BYTES, 0, dx, dw, dc, M, N, K);
+            else if (store == 6) hipLaunchKernelGGL(k_gemm_dma2<6>, dim3(grid), dim3(256), LDS_BYTES, 0, dx, dw, dc, M, N, K);
+            else if (store == 5) hipLaunchKernelGGL(k_gemm_dma2<5>, dim3(grid), dim3(256), LDS_BYTES, 0, dx, dw, dc, M, N, K);
+            else if (store == 3) hipLaunchKernelGGL(k_gemm_dma2<3>, dim3(grid), dim3(256), LDS_BYTES, 0, dx, dw, dc, M, N, K);
+            else hipLaunchKernelGGL(k_gemm_dma2<0>, dim3(grid), dim3(256), LDS_BYTES, 0, dx, dw, dc, M, N, K);
+          }
+          CHECK(hipEventRecord(e1)); CHECK(hipEventSynchronize(e1));
+          CHECK(hipGetLastError());
+          float ms; CHECK(hipEventElapsedTime(&ms, e0, e1));
+          if (rep) printf("v2 N=%d K=%d store=%d: %.1f us  %.0f TFLOP/s\n", N, K, store, ms / 5 * 1e3, 2.0 * M * N * K / (ms / 5 * 1e-3) / 1e12);
+        }
+#ifdef PROF
+        {
+          unsigned long long h[16 * 4 * 8];
+          CHECK(hipMemcpyFromSymbol(h, HIP_SYMBOL(g_prof), sizeof h));
+          for (int b = 0; b < 16; b += 9) for (int w = 0; w < 4; w += 3) {
+            const unsigned long long* o = h + (b * 4 + w) * 8;
+            printf("   block %2d wave %d: ticks per stage: work %.0f stall %.0f fetch %.0f (n %llu); per tile: epilogue %.0f, stall in the 2 relaxed stages %.0f (n %llu)\n", b, w,
+                   (double)o[0] / o[3], (double)o[1] / o[3], (double)o[2] / o[3], o[3], (double)o[4] / o[5], (double)o[6] / (o[5] > 1 ? o[5] - 1 : 1), o[5]);
+          }
+        }
+#endif
+        if (store == 5 || store == 3) {
+          double maxerr = 0;
+          for (int q = 0; q < 48; ++q) {
+            const int row = q < 8 ? M - 1 - q * 13 : (q * 4801 + 17) % M, f = (q * 977 + 5) % N;
+            double ref = 0; for (int k = 0; k < K; ++k) ref += (double)bf2f(hx[(size_t)row * K + k]) * bf2f(hw[(size_t)f * K + k]);
+            if (store == 5) {
+              float got; CHECK(hipMemcpy(&got, dc + tm_index_f32(row, f, N), 4, hipMemcpyDeviceToHost));
+              maxerr = fmax(maxerr, fabs(ref - got / launches));
+            } else {
+              unsigned short got; CHECK(hipMemcpy(&got, reinterpret_cast<unsigned short*>(dc) + tm_index(row, f, N), 2, hipMemcpyDeviceToHost));
+              maxerr = fmax(maxerr, fabs(ref - bf2f(got)) / (fabs(ref) + 1.0));
+            }
+          }
+          printf("   v2 spot-check max err %.3e%s\n", maxerr, store == 3 ? " (relative, bf16 output)" : " (sum of launches / launches)");
+        }
+      }
+    }
+    CHECK(hipFree(dx)); CHECK(hipFree(dw)); CHECK(hipFree(dc));
+  }
+  return 0;
+}
