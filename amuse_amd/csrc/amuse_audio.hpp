@@ -9,7 +9,9 @@ constexpr int kAstDim = 768, kAstHeads = 12, kAstLayers = 12, kAstMlp = 3072, kA
 constexpr int kAstMel = 128, kAstFrames = 1024;
 constexpr int kAstF = 12, kAstT = 101, kAstPatches = kAstF * kAstT, kAstTokens = 2 + kAstPatches;   // 1214
 constexpr int kAstPoolSplit = 16;    // workgroups per clip in k_ast_pool (row slices, added in slice order by k_ast_head)
-constexpr int kAstKeysPad = 1216;   // V^T rows padded to whole 64-key chunks (the pad columns stay zero)
+constexpr int kAstRows = 1216;      // row stride of a clip in every activation matrix: 1214 tokens + 2 pad rows = 76 tiles of 16 = 19 of 64,
+                                    // so no 16-row tile, no 64-row wave span and no 64-key attention chunk straddles two clips
+constexpr int kAstKeysPad = kAstRows;
 
 // ---- Tile-major activation layout.  Every matrix the GEMM reads or writes as an operand is stored as 16-row x 32-feature
 // tiles, row tiles outer: tile (row / 16, f / 32) of an [M][F] matrix is 512 consecutive elements.
@@ -36,10 +38,10 @@ struct GemmArgs {
                                  // unit [64 lanes][8 bf16], lane (g, i) = W[feature][32 ks + 8 g + e]
     const float* bias;           // [N]
     int M, N, K;                 // N % 256 == 0, K % 64 == 0
-    unsigned short* out_bf16;    // EPI_BF16 / EPI_GELU_BF16: tile-major [M padded][N]; EPI_QKV: q | k ROW-major [M padded][1536]
-    float* out_f32;              // EPI_RESID_F32 (+=) / EPI_F32: tile-major [M padded][N]; EPI_PATCH: tile-major token matrix [B * 1214 padded][768]
+    unsigned short* out_bf16;    // EPI_BF16 / EPI_GELU_BF16: tile-major [M padded][N]; EPI_QKV: q (pre-scaled) | k tile-major [M padded][1536]
+    float* out_f32;              // EPI_RESID_F32 (+=) / EPI_F32: tile-major [M padded][N]; EPI_PATCH: tile-major token matrix [B * 1216 padded][768]
     const float* pos;            // EPI_PATCH: pos_embed [1214][768]
-    unsigned short* vt;          // EPI_QKV: V^T [B][768][kAstKeysPad]
+    unsigned short* vt;          // EPI_QKV: V^T as a tile-major matrix [B * 768 rows][1216 key slots] (k_ast_attn has the row / slot order)
 };
 hipError_t launch_gemm(const GemmArgs& a, int epi, hipStream_t s);
 hipError_t launch_fbank(const float* wave, int n_samples, int B, const float* window, const float* melw_t, const int* mel_range, float mean, float std,
@@ -50,7 +52,7 @@ hipError_t launch_ln_bf16(const float* X, const float* gamma, const float* beta,
 // row-major <-> tile-major copies (hidden-state tap, amuse_debug_gemm): rows >= M of a tile-major destination are zeroed
 hipError_t launch_tile_bf16(const unsigned short* src, unsigned short* dst, int M, int F, hipStream_t s);
 hipError_t launch_untile_bf16(const unsigned short* src, unsigned short* dst, int M, int F, hipStream_t s);
-hipError_t launch_untile_f32(const float* src, float* dst, int M, int F, hipStream_t s);
+hipError_t launch_untile_f32(const float* src, float* dst, int M, int F, int rows_in, int rows_out, hipStream_t s);
 hipError_t launch_ast_attn(const unsigned short* QK, const unsigned short* Vt, unsigned short* O, int B, hipStream_t s);
 hipError_t launch_ast_pool(const float* X, const float* gamma, const float* beta, int frame_based, float* pooled, int B, hipStream_t s);
 hipError_t launch_ast_head(const float* pooled, int frame_based, const float* gamma, const float* beta, const unsigned short* W, const float* bias,

@@ -144,7 +144,7 @@ void free_ws(Workspace& w) {
 int ensure_ws(Workspace& w, int nb) {
     if (w.cap >= nb) return 0;
     free_ws(w);
-    const size_t Mp = pad128((size_t)nb * kAstTokens);
+    const size_t Mp = pad128((size_t)nb * kAstRows);
     HIP_TRY(hipMalloc((void**)&w.X, Mp * kAstDim * 4));
     HIP_TRY(hipMalloc((void**)&w.pooled, (size_t)nb * kAstPoolSplit * kAstDim * 4));
     HIP_TRY(hipMalloc((void**)&w.H, Mp * kAstDim * 2));
@@ -162,6 +162,7 @@ int ensure_ws(Workspace& w, int nb) {
     HIP_TRY(hipMemset(w.F, 0, Mp * kAstMlp * 2));
     HIP_TRY(hipMemset(w.P, 0, pad128((size_t)nb * kAstPatches) * 256 * 2));
     HIP_TRY(hipMemset(w.Vt, 0, (size_t)nb * kAstDim * kAstKeysPad * 2));
+    HIP_TRY(hipMemset(w.QK, 0, Mp * 2 * kAstDim * 2));
     w.cap = nb;
     return 0;
 }
@@ -186,7 +187,7 @@ int ensure_side_streams(amuse_audio_ctx* c) {
 // one encoder over nb <= cap clips whose fbanks are at `fbank`
 int run_encoder(const amuse_audio_ctx* c, const Workspace& w, const Encoder& E, const float* fbank, int nb, float* feat_out,
                 float* hidden_out, int tap_block, hipStream_t st) {
-    const int M = nb * kAstTokens;
+    const int M = nb * kAstRows;   // a clip owns 1216 rows: 1214 tokens + 2 pad rows
     HIP_TRY(launch_im2col(fbank, w.P, nb, st));
     GemmArgs g{};
     g.A = w.P; g.W = E.patch_w; g.bias = E.patch_b; g.M = nb * kAstPatches; g.N = kAstDim; g.K = 256;
@@ -211,7 +212,7 @@ int run_encoder(const amuse_audio_ctx* c, const Workspace& w, const Encoder& E, 
         g.A = w.F; g.W = b.fc2_w; g.bias = b.fc2_b; g.M = M; g.N = kAstDim; g.K = kAstMlp; g.out_f32 = w.X;
         HIP_TRY(launch_gemm(g, EPI_RESID_F32, st));
         if (hidden_out && l == tap_block)
-            HIP_TRY(launch_untile_f32(w.X, hidden_out, M, kAstDim, st));
+            HIP_TRY(launch_untile_f32(w.X, hidden_out, M, kAstDim, kAstRows, kAstTokens, st));
     }
     HIP_TRY(launch_ast_pool(w.X, E.norm_w, E.norm_b, c->frame_based, w.pooled, nb, st));
     HIP_TRY(launch_ast_head(w.pooled, c->frame_based, E.fh_ln_w, E.fh_ln_b, E.fh_w, E.fh_b, feat_out, nb, st));
@@ -369,7 +370,7 @@ int amuse_debug_tile(const void* src, void* dst, int M, int F, int what, void* s
     hipStream_t st = (hipStream_t)stream;
     if (what == 0) HIP_TRY(launch_tile_bf16((const unsigned short*)src, (unsigned short*)dst, M, F, st));
     else if (what == 1) HIP_TRY(launch_untile_bf16((const unsigned short*)src, (unsigned short*)dst, M, F, st));
-    else HIP_TRY(launch_untile_f32((const float*)src, (float*)dst, M, F, st));
+    else HIP_TRY(launch_untile_f32((const float*)src, (float*)dst, M, F, M, M, st));
     return 0;
 }
 

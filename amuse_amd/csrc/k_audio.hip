@@ -11,8 +11,9 @@
 //                  TILE-MAJOR (amuse_audio.hpp): so are the residual stream and every activation in this file.
 //   k_ln_bf16      LayerNorm of the fp32 residual stream -> bf16 GEMM operand (one workgroup per 16-row tile row)
 //   k_ast_attn     flash attention, S = 1214, d = 64: S^T = K.Q^T and O^T = V^T.P^T on v_mfma_f32_16x16x32_bf16 with
-//                  the softmax along registers (the layout of the S = 300 decoder attention, k_vae.hip), K and V^T
-//                  streamed through LDS in 64-key chunks; V is written TRANSPOSED by the qkv epilogue.
+//                  the softmax along registers (the layout of the S = 300 decoder attention, k_vae.hip), K and V^T tiles
+//                  streamed through LDS by DMA in 64-key chunks; V is written TRANSPOSED by the qkv epilogue.
+// Row space: a clip owns kAstRows = 1216 rows of every activation matrix (1214 tokens + 2 pad rows).
 //   k_ast_pool / k_ast_head   final LayerNorm + mean over the patch tokens, feature_head (LayerNorm + Linear 768 -> 256)
 // Arithmetic: bf16 GEMM / attention operands, fp32 accumulation, fp32 residual stream, LayerNorm, softmax and GELU.
 #include <cstdlib>
@@ -30,6 +31,14 @@ __device__ __forceinline__ unsigned pack2(float a, float b) {
     return __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{a, b}, bf16x2));
 }
 __device__ __forceinline__ uint2 pack4(f32x4 v) { return uint2{pack2(v[0], v[1]), pack2(v[2], v[3])}; }
+// LDS-DMA: 64 lanes x 16 B from (wave-uniform base + 32-bit lane offset) to LDS [dst, dst + 1 KiB), lane-linear (k_audio_gemm.hip)
+__device__ __forceinline__ void glds16s(const void* sbase, unsigned voff, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(voff), "s"(sbase), "s"(lds_dst)
+                 : "memory");
+}
 
 // ---------------------------------------------------------------------------------------------- fbank
 // grid (kAstFrames, B), 256 threads.  Frames beyond the waveform are the padding rows of infer_ldm.py:185-188.
@@ -120,7 +129,7 @@ __global__ __launch_bounds__(256) void k_ast_tokens(const float* __restrict__ cl
     const int b = blockIdx.x;
     for (int i = threadIdx.x; i < 2 * kAstDim; i += 256) {
         const int r = i / kAstDim, c = i - r * kAstDim;
-        X[tm_f32((size_t)b * kAstTokens + r, c, kAstDim)] = (r == 0 ? cls[c] : dist[c]) + pos[(size_t)r * kAstDim + c];
+        X[tm_f32((size_t)b * kAstRows + r, c, kAstDim)] = (r == 0 ? cls[c] : dist[c]) + pos[(size_t)r * kAstDim + c];
     }
 }
 
@@ -199,120 +208,160 @@ __global__ __launch_bounds__(256) void k_untile_bf16(const bf16raw* __restrict__
         *reinterpret_cast<uint4*>(dst + row * F + 32 * ft + 8 * g) =
             *reinterpret_cast<const uint4*>(src + ((size_t)blockIdx.x * (F / 32) + ft) * 512 + lane * 8);
 }
-__global__ __launch_bounds__(256) void k_untile_f32(const float* __restrict__ src, float* __restrict__ dst, int M, int F) {
+// rows_in / rows_out: row stride of a clip in the source / number of its rows that are copied (rows_in == rows_out: a flat matrix)
+__global__ __launch_bounds__(256) void k_untile_f32(const float* __restrict__ src, float* __restrict__ dst, int M, int F, int rows_in, int rows_out) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4, j = lane & 15;
     const size_t row = (size_t)blockIdx.x * 16 + j;
     if (row >= (size_t)M) return;
+    const size_t b = row / rows_in, r = row - b * rows_in;
+    if (r >= (size_t)rows_out) return;
+    float* d = dst + (b * rows_out + r) * F;
     for (int ft = wave; ft < F / 32; ft += 4) {
         const float* t = src + ((size_t)blockIdx.x * (F / 32) + ft) * 512 + lane * 4;
-        st4(dst + row * F + 32 * ft + 8 * g, ld4(t));
-        st4(dst + row * F + 32 * ft + 8 * g + 4, ld4(t + 256));
+        st4(d + 32 * ft + 8 * g, ld4(t));
+        st4(d + 32 * ft + 8 * g + 4, ld4(t + 256));
     }
 }
 
 // ---------------------------------------------------------------------------------------------- attention
-constexpr int kKc = 64;                 // keys per LDS chunk
-constexpr int kKS = 64 + 8;             // padded K row (bf16): 144 B
-constexpr int kVS = kKc + 8;            // padded V^T row (bf16): 144 B
-// grid (19 query blocks of 64, 12 heads, B); wave w owns the 16 queries 64 qb + 16 w ..
-__global__ __launch_bounds__(256) void k_ast_attn(const bf16raw* __restrict__ QK /*[M][1536]*/,
-                                                  const bf16raw* __restrict__ Vt /*[B][768][1216]*/,
-                                                  bf16raw* __restrict__ O /*tile-major [M][768]*/) {
-    __shared__ __attribute__((aligned(16))) bf16raw Ks[kKc * kKS];
-    __shared__ __attribute__((aligned(16))) bf16raw Vs[64 * kVS];
-    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    const int g = lane >> 4, j = lane & 15;
+// Flash attention over one clip's 1214 tokens, head_dim 64; every operand is a tile of a tile-major matrix (amuse_audio.hpp), i.e.
+// a ready MFMA fragment that LDS-DMA copies verbatim:
+//   Q, K   tiles of QK [B * 1216][1536] (q pre-scaled by the qkv epilogue): S^T = K . Q^T, lane (g, query j) holds S[j][key 16 u + 4 g + m]
+//   V^T    tiles of Vt [B * 768][1216 key slots], written by the qkv epilogue's swapped MFMAs: rows in W-fragment order (row 16 F + i of
+//          fragment F <-> feature 32 (F >> 1) + 8 (i >> 2) + 4 (F & 1) + (i & 3)), key slots in the order P comes out of the S^T MFMA
+//          (key 16 a + 4 g + m of a group of 32 -> slot 8 g + 4 a + m): O^T = V^T . P^T needs no data movement at all, and a lane's
+//          accumulators of a fragment pair are 8 consecutive features - O is stored one whole tile per wave instruction.
+// Workgroup = 128 queries of one head (4 waves x 2 query tiles: a K / V^T fragment read feeds two MFMAs); keys in chunks of 64
+// (8 K tiles + 8 V^T tiles = 16 KiB) through a ring of three LDS stages, two chunks in flight, one barrier per chunk.  One
+// online-softmax step per chunk: the per-step fixed costs - two cross-lane reductions, the rescale of the accumulators, exp2 of the
+// running-max shift - are paid once per 64 keys, log2(e) rides in the exp2 argument's fma, only the last chunk masks keys.
+constexpr int kAttnQ = 128;                         // queries per workgroup
+constexpr int kAttnStage = 16 * 1024;
+constexpr int kAttnLds = 3 * kAttnStage;            // 48 KiB: three workgroups per CU
+constexpr int kAttnChunks = kAstRows / 64;          // 19
+__global__ __launch_bounds__(256) void k_ast_attn(const bf16raw* __restrict__ QK, const bf16raw* __restrict__ Vt, bf16raw* __restrict__ O) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int g = lane >> 4;
     const int qb = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
-    const size_t row0 = (size_t)b * kAstTokens;
-    const int q = 64 * qb + 16 * wave + j;
-    const bool qv = q < kAstTokens;
-    bf16x8 qf[2];
+    constexpr int kRowTiles = kAstRows / 16, kQkTiles = 2 * kAstDim / 32, kSlotTiles = kAstRows / 32;   // 76, 48, 38
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) const void*)smem;
+    const unsigned voff = lane * 16;
+    // this wave's DMA pieces of chunk c: K tiles (key tile 4 c + wave, k-step 0 / 1), V^T tiles (row tile 4 h + wave, slot tile 2 c + 0 / 1)
+    const char* ksrc = reinterpret_cast<const char*>(QK) + (((size_t)b * kRowTiles + wave) * kQkTiles + kAstDim / 32 + 2 * h) * 1024;
+    const char* vsrc = reinterpret_cast<const char*>(Vt) + ((size_t)b * (kAstDim / 16) + 4 * h + wave) * kSlotTiles * 1024;
+    auto fetch = [&](int c, int slot) {
+        c = c < kAttnChunks ? c : kAttnChunks - 1;   // past the end: the last chunk again (lands in a free slot, never read)
+        const unsigned d = lds0 + slot * kAttnStage;
+        const char* k = ksrc + (size_t)c * 4 * kQkTiles * 1024;
+        glds16s(k, voff, d + (2 * wave) * 1024);
+        glds16s(k + 1024, voff, d + (2 * wave + 1) * 1024);
+        const char* v = vsrc + (size_t)c * 2 * 1024;
+        glds16s(v, voff, d + (8 + 2 * wave) * 1024);
+        glds16s(v + 1024, voff, d + (8 + 2 * wave + 1) * 1024);
+    };
+    fetch(0, 0);
+    fetch(1, 1);
+    const int qt0 = 8 * qb + 2 * wave;              // this wave's query tiles qt0, qt0 + 1 of the clip's 76
+    bf16x8 qf[2][2];
 #pragma unroll
-    for (int s = 0; s < 2; ++s) {
-        uint4 u = uint4{0, 0, 0, 0};
-        if (qv) u = *reinterpret_cast<const uint4*>(QK + (row0 + q) * (2 * kAstDim) + 64 * h + 32 * s + 8 * g);
-        qf[s] = __builtin_bit_cast(bf16x8, u);
-    }
-    float m_run = -INFINITY, l_run = 0.f;
-    f32x4 o[4] = {splat4(0.f), splat4(0.f), splat4(0.f), splat4(0.f)};
-    constexpr float kLog2e = 1.44269504088896340736f;
-    const int lr = t >> 3, lc = (t & 7) * 8;
-    const bf16raw* vsrc = Vt + ((size_t)b * kAstDim + 64 * h) * kAstKeysPad;
-    for (int k0 = 0; k0 < kAstKeysPad; k0 += kKc) {
-        __syncthreads();   // previous chunk fully consumed
+    for (int q = 0; q < 2; ++q)
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int key = k0 + lr + 32 * i;
+        for (int s = 0; s < 2; ++s) {
             uint4 u = uint4{0, 0, 0, 0};
-            if (key < kAstTokens) u = *reinterpret_cast<const uint4*>(QK + (row0 + key) * (2 * kAstDim) + kAstDim + 64 * h + lc);
-            *reinterpret_cast<uint4*>(Ks + (lr + 32 * i) * kKS + lc) = u;
-            // V^T rows d = lr + 32 i, keys k0 + lc .. + 7
-            *reinterpret_cast<uint4*>(Vs + (lr + 32 * i) * kVS + lc) =
-                *reinterpret_cast<const uint4*>(vsrc + (size_t)(lr + 32 * i) * kAstKeysPad + k0 + lc);
+            if (qt0 + q < kRowTiles)
+                u = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(QK) + (((size_t)b * kRowTiles + qt0 + q) * kQkTiles + 2 * h + s) * 1024 + voff);
+            qf[q][s] = __builtin_bit_cast(bf16x8, u);
         }
-        __syncthreads();
-        // One online-softmax step per 64-key chunk (four 16-key tiles): the per-step fixed costs - two cross-lane
-        // reductions, the rescale of the accumulators, exp2 of the running-max shift - are paid once per 64 keys, the
-        // log2(e) scaling rides in the exp2 argument's fma, and only the chunk that holds the sequence end pays for
-        // key masking.  (This loop is VALU-bound: 16 exp2 + ~50 other VALU per lane against 16 MFMAs.)
-        static_assert(kKc == 64, "one softmax step per chunk");
-        f32x4 st[4];
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (the q loads sit behind the DMA pieces: from here on only DMA is counted)
+    float m_run[2] = {-INFINITY, -INFINITY}, l_run[2] = {0.f, 0.f};
+    f32x4 o[2][4];
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+#pragma unroll
+        for (int td = 0; td < 4; ++td) o[q][td] = splat4(0.f);
+    constexpr float kLog2e = 1.44269504088896340736f;
+    int slot = 0, fslot = 2;
+#pragma unroll 1
+    for (int c = 0; c < kAttnChunks; ++c) {
+        // this wave's pieces of chunk c have landed (chunk c + 1 may still fly), its reads of chunk c - 1 are done; behind the
+        // barrier chunk c is complete and the slot of chunk c - 1 is free for chunk c + 2
+        if (c == 0) asm volatile("s_barrier" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        fetch(c + 2, fslot);
+        fslot = fslot == 2 ? 0 : fslot + 1;
+        const char* sl = smem + slot * kAttnStage + lane * 16;
+        slot = slot == 2 ? 0 : slot + 1;
+        f32x4 st[2][4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            const bf16raw* kr = Ks + (16 * u + j) * kKS + 8 * g;
-            st[u] = mfma_bf16(*reinterpret_cast<const bf16x8*>(kr), qf[0], splat4(0.f));
-            st[u] = mfma_bf16(*reinterpret_cast<const bf16x8*>(kr + 32), qf[1], st[u]);
+            const bf16x8 k0 = *reinterpret_cast<const bf16x8*>(sl + (2 * u) * 1024), k1 = *reinterpret_cast<const bf16x8*>(sl + (2 * u + 1) * 1024);
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                st[q][u] = mfma_bf16(k0, qf[q][0], splat4(0.f));
+                st[q][u] = mfma_bf16(k1, qf[q][1], st[q][u]);
+            }
         }
-        // lane (g, query j): S[j][key = k0 + 16 u + 4 g + m]
-        const bool tail = k0 + kKc > kAstTokens;   // uniform
-        if (tail) {
+        // lane (g, query j): S[j][key = 64 c + 16 u + 4 g + m]
+        if (c == kAttnChunks - 1) {   // keys 1214, 1215 are the clip's pad rows
+#pragma unroll
+            for (int q = 0; q < 2; ++q)
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+#pragma unroll
+                    for (int m = 0; m < 4; ++m)
+                        if (64 * c + 16 * u + 4 * g + m >= kAstTokens) st[q][u][m] = -INFINITY;
+        }
+        bf16x8 pb[2][2];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            float mx = fmaxf(fmaxf(fmaxf(st[q][0][0], st[q][0][1]), fmaxf(st[q][0][2], st[q][0][3])),
+                             fmaxf(fmaxf(st[q][1][0], st[q][1][1]), fmaxf(st[q][1][2], st[q][1][3])));
+            mx = fmaxf(mx, fmaxf(fmaxf(fmaxf(st[q][2][0], st[q][2][1]), fmaxf(st[q][2][2], st[q][2][3])),
+                                 fmaxf(fmaxf(st[q][3][0], st[q][3][1]), fmaxf(st[q][3][2], st[q][3][3]))));
+            mx = allreduce_g_max(mx);
+            const float m_new = fmaxf(m_run[q], mx);           // raw-score domain; every chunk holds a valid key
+            const float cc = m_new * kLog2e;
+            const float alpha = __builtin_amdgcn_exp2f(m_run[q] * kLog2e - cc);   // m_run = -inf on the first chunk -> 0
+            f32x4 p[4];
+            float ps = 0.f;
 #pragma unroll
             for (int u = 0; u < 4; ++u)
 #pragma unroll
-                for (int m = 0; m < 4; ++m)
-                    if (k0 + 16 * u + 4 * g + m >= kAstTokens) st[u][m] = -INFINITY;
+                for (int m = 0; m < 4; ++m) {
+                    p[u][m] = __builtin_amdgcn_exp2f(fmaf(st[q][u][m], kLog2e, -cc));   // masked keys: exp2(-inf) = 0
+                    ps += p[u][m];
+                }
+            ps = allreduce_g_sum(ps);
+            l_run[q] = l_run[q] * alpha + ps;
+            m_run[q] = m_new;
+#pragma unroll
+            for (int td = 0; td < 4; ++td) o[q][td] *= alpha;
+            // k-slots (g, e) of key group pr: e < 4 -> tile 2 pr key 4 g + e, else tile 2 pr + 1 key 4 g + e - 4: the V^T slot order
+            pb[q][0] = pack_bf16(p[0], p[1]);
+            pb[q][1] = pack_bf16(p[2], p[3]);
         }
-        float mx = fmaxf(fmaxf(fmaxf(st[0][0], st[0][1]), fmaxf(st[0][2], st[0][3])),
-                         fmaxf(fmaxf(st[1][0], st[1][1]), fmaxf(st[1][2], st[1][3])));
-        mx = fmaxf(mx, fmaxf(fmaxf(fmaxf(st[2][0], st[2][1]), fmaxf(st[2][2], st[2][3])),
-                             fmaxf(fmaxf(st[3][0], st[3][1]), fmaxf(st[3][2], st[3][3]))));
-        mx = allreduce_g_max(mx);
-        const float m_new = fmaxf(m_run, mx);           // raw-score domain; every chunk holds a valid key
-        const float c = m_new * kLog2e;
-        const float alpha = __builtin_amdgcn_exp2f(m_run * kLog2e - c);   // m_run = -inf on the first chunk -> 0
-        f32x4 p[4];
-        float ps = 0.f;
 #pragma unroll
-        for (int u = 0; u < 4; ++u)
-#pragma unroll
-            for (int m = 0; m < 4; ++m) {
-                p[u][m] = __builtin_amdgcn_exp2f(fmaf(st[u][m], kLog2e, -c));   // masked keys: exp2(-inf) = 0
-                ps += p[u][m];
-            }
-        ps = allreduce_g_sum(ps);
-        l_run = l_run * alpha + ps;
-        m_run = m_new;
-#pragma unroll
-        for (int td = 0; td < 4; ++td) o[td] *= alpha;
-#pragma unroll
-        for (int pr = 0; pr < 2; ++pr) {
-            // k-slots (g, e): e < 4 -> tile 2 pr key 4 g + e, else tile 2 pr + 1 key 4 g + e - 4
-            const bf16x8 pb = pack_bf16(p[2 * pr], p[2 * pr + 1]);
+        for (int pr = 0; pr < 2; ++pr)
 #pragma unroll
             for (int td = 0; td < 4; ++td) {
-                // A operand lane (g, i = j): V^T[d = 16 td + j][same key permutation]
-                const bf16raw* vr = Vs + (16 * td + j) * kVS + 32 * pr + 4 * g;
-                const uint2 lo = *reinterpret_cast<const uint2*>(vr), hi = *reinterpret_cast<const uint2*>(vr + 16);
-                const bf16x8 vf = __builtin_bit_cast(bf16x8, uint4{lo.x, lo.y, hi.x, hi.y});
-                o[td] = mfma_bf16(vf, pb, o[td]);
-            }
-        }
-    }
-    if (qv) {
-        const float inv = 1.0f / l_run;
+                const bf16x8 vf = *reinterpret_cast<const bf16x8*>(sl + (8 + 2 * td + pr) * 1024);
 #pragma unroll
-        for (int td = 0; td < 4; ++td)
-            *reinterpret_cast<uint2*>(O + tm_bf16(row0 + q, 64 * h + 16 * td + 4 * g, kAstDim)) = pack4(o[td] * inv);
+                for (int q = 0; q < 2; ++q) o[q][td] = mfma_bf16(vf, pb[q][pr], o[q][td]);
+            }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the surplus fetches must not outlive the workgroup's LDS
+    // o[q][td][m] = O[query j][feature 64 h + 32 (td >> 1) + 8 g + 4 (td & 1) + m]: the pair td = 2 t, 2 t + 1 is this lane's slot of tile 2 h + t
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        if (qt0 + q >= kRowTiles) continue;
+        const float inv = 1.0f / l_run[q];
+        char* dst = reinterpret_cast<char*>(O) + (((size_t)b * kRowTiles + qt0 + q) * (kAstDim / 32) + 2 * h) * 1024 + voff;
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt) {
+            const uint2 lo = pack4(o[q][2 * tt] * inv), hi = pack4(o[q][2 * tt + 1] * inv);
+            *reinterpret_cast<uint4*>(dst + tt * 1024) = uint4{lo.x, lo.y, hi.x, hi.y};
+        }
     }
 }
 
@@ -333,7 +382,7 @@ __global__ __launch_bounds__(256) void k_ast_pool(const float* __restrict__ X, c
 #pragma unroll
     for (int i = 0; i < 3; ++i) { ga[i] = ld4(gamma + 256 * i + 4 * lane); be[i] = ld4(beta + 256 * i + 4 * lane); }
     for (int r = c0 + wave; r < c1; r += 4) {
-        const size_t row = (size_t)b * kAstTokens + r;
+        const size_t row = (size_t)b * kAstRows + r;
         f32x4 v[3];
         float s = 0.f;
 #pragma unroll
@@ -431,12 +480,12 @@ hipError_t launch_untile_bf16(const unsigned short* src, unsigned short* dst, in
     hipLaunchKernelGGL(k_untile_bf16, dim3((M + 15) / 16), dim3(256), 0, s, src, dst, M, F);
     return hipGetLastError();
 }
-hipError_t launch_untile_f32(const float* src, float* dst, int M, int F, hipStream_t s) {
-    hipLaunchKernelGGL(k_untile_f32, dim3((M + 15) / 16), dim3(256), 0, s, src, dst, M, F);
+hipError_t launch_untile_f32(const float* src, float* dst, int M, int F, int rows_in, int rows_out, hipStream_t s) {
+    hipLaunchKernelGGL(k_untile_f32, dim3((M + 15) / 16), dim3(256), 0, s, src, dst, M, F, rows_in, rows_out);
     return hipGetLastError();
 }
 hipError_t launch_ast_attn(const unsigned short* QK, const unsigned short* Vt, unsigned short* O, int B, hipStream_t s) {
-    hipLaunchKernelGGL(k_ast_attn, dim3((kAstTokens + 63) / 64, kAstHeads, B), dim3(256), 0, s, QK, Vt, O);
+    hipLaunchKernelGGL(k_ast_attn, dim3((kAstRows + kAttnQ - 1) / kAttnQ, kAstHeads, B), dim3(256), kAttnLds, s, QK, Vt, O);
     return hipGetLastError();
 }
 hipError_t launch_ast_pool(const float* X, const float* gamma, const float* beta, int frame_based, float* pooled, int B, hipStream_t s) {

@@ -120,7 +120,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     constexpr int SN = epi_stores<EPI>();
     f32x4 acc[8][4];   // [feature fragment][token fragment]
     // one k-step: xc = this stage's X fragments (registers), xn receives the next stage's
-    auto half = [&](auto relaxed, bf16x8 (&xc)[4], bf16x8 (&xn)[4], int bias_tile) {
+    // swapped: the X fragment is the MFMA's A operand, so a lane ends up with 4 consecutive TOKENS of one feature (the V^T tiles)
+    auto half = [&](auto relaxed, auto swapped, bf16x8 (&xc)[4], bf16x8 (&xn)[4], int bias_tile) {
         constexpr int WAITN = 6 + (decltype(relaxed)::value ? SN : 0);
         // this wave's pieces of the NEXT stage have landed (the two younger stages may still fly) and its reads of this stage are in
         // registers; behind the barrier that holds for every wave: the next stage is complete, this stage's slot is free
@@ -133,7 +134,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
         for (int x = 0; x < 8; ++x) {
 #pragma unroll
-            for (int y = 0; y < 4; ++y) acc[x][y] = mfma_bf16(wc[x], xc[y], acc[x][y]);
+            for (int y = 0; y < 4; ++y)
+                acc[x][y] = decltype(swapped)::value ? mfma_bf16(xc[y], wc[x], acc[x][y]) : mfma_bf16(wc[x], xc[y], acc[x][y]);
             wc[x] = *reinterpret_cast<const bf16x8*>(sl + (8 * wf + x) * 1024);
             if (x < 6) fetch_piece(x);
             if (x == 7) fetch_advance();
@@ -148,21 +150,53 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         for (int x = 0; x < 8; ++x)
 #pragma unroll
             for (int y = 0; y < 4; ++y) acc[x][y] = splat4(0.f);
-        if (first || SN == 0) {
-            half(std::false_type{}, xa, xb, tn);
-            half(std::false_type{}, xb, xa, -1);
+        const bool vt_tile = EPI == EPI_QKV && tn >= 2 * kAstDim / TN;   // (uniform)
+        if (EPI == EPI_QKV && vt_tile) {
+            half(std::false_type{}, std::true_type{}, xa, xb, tn);
+            half(std::false_type{}, std::true_type{}, xb, xa, -1);
+#pragma unroll 1
+            for (int kp = 2; kp < nk; kp += 2) {
+                half(std::false_type{}, std::true_type{}, xa, xb, -1);
+                half(std::false_type{}, std::true_type{}, xb, xa, -1);
+            }
         } else {
-            half(std::true_type{}, xa, xb, tn);
-            half(std::true_type{}, xb, xa, -1);
+            if (first || SN == 0) {
+                half(std::false_type{}, std::false_type{}, xa, xb, tn);
+                half(std::false_type{}, std::false_type{}, xb, xa, -1);
+            } else {
+                half(std::true_type{}, std::false_type{}, xa, xb, tn);
+                half(std::true_type{}, std::false_type{}, xb, xa, -1);
+            }
+#pragma unroll 1
+            for (int kp = 2; kp < nk; kp += 2) {
+                half(std::false_type{}, std::false_type{}, xa, xb, -1);
+                half(std::false_type{}, std::false_type{}, xb, xa, -1);
+            }
         }
         first = false;
-#pragma unroll 1
-        for (int kp = 2; kp < nk; kp += 2) {
-            half(std::false_type{}, xa, xb, -1);
-            half(std::false_type{}, xb, xa, -1);
-        }
         // ---- epilogue: lane (g, j): token row m0 + 16 y + j, features n0 + 32 p + 8 g .. + 7 = acc[2 p][y], acc[2 p + 1][y]
         const int m0 = tm * TM + 64 * wr, n0 = tn * TN + 128 * wf;
+        if (EPI == EPI_QKV && vt_tile) {
+            // V^T (swapped MFMAs): lane (g, j) holds row j of feature fragment x - V^T row 16 F + j, F = the fragment's index among
+            // the 48 of v - and tokens 16 y + 4 g + m of the wave's 64-row span.  Key SLOT order inside 32 keys: key 16 a + 4 g + m ->
+            // slot 8 g + 4 a + m (the order the attention's P operand comes out of its S^T MFMA in), so a lane's values of the
+            // fragment pair y = 2 Y, 2 Y + 1 are 8 consecutive slots and the wave's store is one whole tile of the matrix
+            // [B * 768][1216].  A 64-row span lies inside one clip (1216 = 19 * 64).
+            const float* bw = reinterpret_cast<const float*>(smem + kOffBias) + 128 * wf;
+            const int b = m0 / kAstRows, tok0 = m0 - b * kAstRows;
+            if (m0 >= a.M) continue;   // (the pad half of the last row tile: no clip owns it)
+#pragma unroll
+            for (int x = 0; x < 8; ++x) {
+                const float bv = bw[32 * (x >> 1) + 8 * (j >> 2) + 4 * (x & 1) + (j & 3)];   // fragment row j <-> this feature (pack_w)
+                const size_t rt = (size_t)b * (kAstDim / 16) + ((n0 - 2 * kAstDim) >> 4) + x;   // row tile of the V^T matrix
+#pragma unroll
+                for (int Y = 0; Y < 2; ++Y) {
+                    const f32x4 v0 = acc[x][2 * Y] + splat4(bv), v1 = acc[x][2 * Y + 1] + splat4(bv);
+                    *reinterpret_cast<u32x4*>(reinterpret_cast<char*>(a.vt) + (rt * (kAstRows / 32) + ((tok0 >> 5) + Y)) * 1024 + voff) = pack8(v0, v1);
+                }
+            }
+            continue;
+        }
         const float* bl = reinterpret_cast<const float*>(smem + kOffBias) + 128 * wf + 8 * g;
 #pragma unroll
         for (int y = 0; y < 4; ++y) {
@@ -192,25 +226,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                     // patch row = b * 1212 + q  ->  token row b * 1214 + 2 + q, + pos_embed[2 + q]
                     if (row < (size_t)a.M) {
                         const size_t b = row / kAstPatches, q = row - b * kAstPatches;
-                        float* dst = a.out_f32 + tm_f32(b * kAstTokens + 2 + q, n, kAstDim);
+                        float* dst = a.out_f32 + tm_f32(b * kAstRows + 2 + q, n, kAstDim);
                         const float* ps = a.pos + (2 + q) * kAstDim + n;
                         st4(dst, v0 + ld4(ps));
                         st4(dst + 256, v1 + ld4(ps + 4));
                     }
-                } else {  // EPI_QKV: q (pre-scaled by head_dim ** -0.5 = 1/8, exact in bf16) | k row-major, v transposed
-                    if (n < 2 * kAstDim) {
-                        const float sc = n < kAstDim ? 0.125f : 1.0f;
-                        *reinterpret_cast<u32x4*>(a.out_bf16 + row * (2 * kAstDim) + n) = pack8(v0 * sc, v1 * sc);
-                    } else if (row < (size_t)a.M) {
-                        const size_t b = row / kAstTokens, tok = row - b * kAstTokens;
-                        const int hd = n - 2 * kAstDim;   // h * 64 + d
-                        typedef __bf16 bf;
-#pragma unroll
-                        for (int m = 0; m < 4; ++m) {
-                            a.vt[((b * kAstDim) + hd + m) * kAstKeysPad + tok] = __builtin_bit_cast(bf16raw, (bf)v0[m]);
-                            a.vt[((b * kAstDim) + hd + 4 + m) * kAstKeysPad + tok] = __builtin_bit_cast(bf16raw, (bf)v1[m]);
-                        }
-                    }
+                } else {  // EPI_QKV, q | k tiles: q pre-scaled by head_dim ** -0.5 = 1/8 (exact in bf16); tile-major [M][1536]
+                    const float sc = n < kAstDim ? 0.125f : 1.0f;
+                    const size_t qk0 = (size_t)((m0 >> 4) + y) * (2 * kAstDim / 32) + (n0 >> 5);
+                    *reinterpret_cast<u32x4*>(reinterpret_cast<char*>(a.out_bf16) + (qk0 + p) * 1024 + voff) = pack8(v0 * sc, v1 * sc);
                 }
             }
         }
