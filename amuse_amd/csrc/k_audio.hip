@@ -231,15 +231,20 @@ __global__ __launch_bounds__(256) void k_untile_f32(const float* __restrict__ sr
 //          fragment F <-> feature 32 (F >> 1) + 8 (i >> 2) + 4 (F & 1) + (i & 3)), key slots in the order P comes out of the S^T MFMA
 //          (key 16 a + 4 g + m of a group of 32 -> slot 8 g + 4 a + m): O^T = V^T . P^T needs no data movement at all, and a lane's
 //          accumulators of a fragment pair are 8 consecutive features - O is stored one whole tile per wave instruction.
-// Workgroup = 128 queries of one head (4 waves x 2 query tiles: a K / V^T fragment read feeds two MFMAs); keys in chunks of 64
+// Workgroup = 256 queries of one head (8 waves x 2 query tiles: a K / V^T fragment read feeds two MFMAs); keys in chunks of 64
 // (8 K tiles + 8 V^T tiles = 16 KiB) through a ring of three LDS stages, two chunks in flight, one barrier per chunk.  One
 // online-softmax step per chunk: the per-step fixed costs - two cross-lane reductions, the rescale of the accumulators, exp2 of the
 // running-max shift - are paid once per 64 keys, log2(e) rides in the exp2 argument's fma, only the last chunk masks keys.
-constexpr int kAttnQ = 128;                         // queries per workgroup
+// max of three.  Built with -fno-honor-nans (Makefile): hipcc then drops the v_max_f32 x, x canonicalisation it otherwise puts in
+// front of every fmaxf operand and fuses pairs into v_max3_f32.  NOT inline asm: the hazard recogniser does not see through asm, and
+// a VALU read of an MFMA result needs software wait states - an asm v_max3_f32 right behind the score MFMAs read stale registers.
+__device__ __forceinline__ float max3(float a, float b, float c) { return fmaxf(fmaxf(a, b), c); }
+constexpr int kAttnQ = 256;                         // queries per workgroup: 8 waves x 2 query tiles
 constexpr int kAttnStage = 16 * 1024;
-constexpr int kAttnLds = 3 * kAttnStage;            // 48 KiB: three workgroups per CU
+constexpr int kAttnLds = 3 * kAttnStage;            // 48 KiB; two workgroups per CU (registers: four waves per SIMD)
 constexpr int kAttnChunks = kAstRows / 64;          // 19
-__global__ __launch_bounds__(256) void k_ast_attn(const bf16raw* __restrict__ QK, const bf16raw* __restrict__ Vt, bf16raw* __restrict__ O) {
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_ast_attn(const bf16raw* __restrict__ QK, const bf16raw* __restrict__ Vt,
+                                                                                            bf16raw* __restrict__ O) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const int g = lane >> 4;
@@ -247,22 +252,21 @@ __global__ __launch_bounds__(256) void k_ast_attn(const bf16raw* __restrict__ QK
     constexpr int kRowTiles = kAstRows / 16, kQkTiles = 2 * kAstDim / 32, kSlotTiles = kAstRows / 32;   // 76, 48, 38
     const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) const void*)smem;
     const unsigned voff = lane * 16;
-    // this wave's DMA pieces of chunk c: K tiles (key tile 4 c + wave, k-step 0 / 1), V^T tiles (row tile 4 h + wave, slot tile 2 c + 0 / 1)
-    const char* ksrc = reinterpret_cast<const char*>(QK) + (((size_t)b * kRowTiles + wave) * kQkTiles + kAstDim / 32 + 2 * h) * 1024;
-    const char* vsrc = reinterpret_cast<const char*>(Vt) + ((size_t)b * (kAstDim / 16) + 4 * h + wave) * kSlotTiles * 1024;
+    // this wave's two DMA pieces of chunk c: waves 0..3 the K tiles of key tile 4 c + wave (k-steps 0, 1), waves 4..7 the V^T tiles of row
+    // tile 4 h + wave - 4 (slot tiles 2 c, 2 c + 1); stage layout: K tile (u, s) at 2 u + s, V^T tile (td, pr) at 8 + 2 td + pr
+    const bool kwave = wave < 4;
+    const char* src = kwave ? reinterpret_cast<const char*>(QK) + (((size_t)b * kRowTiles + wave) * kQkTiles + kAstDim / 32 + 2 * h) * 1024
+                            : reinterpret_cast<const char*>(Vt) + ((size_t)b * (kAstDim / 16) + 4 * h + wave - 4) * kSlotTiles * 1024;
+    const size_t cstep = kwave ? (size_t)4 * kQkTiles * 1024 : (size_t)2 * 1024;
     auto fetch = [&](int c, int slot) {
         c = c < kAttnChunks ? c : kAttnChunks - 1;   // past the end: the last chunk again (lands in a free slot, never read)
-        const unsigned d = lds0 + slot * kAttnStage;
-        const char* k = ksrc + (size_t)c * 4 * kQkTiles * 1024;
-        glds16s(k, voff, d + (2 * wave) * 1024);
-        glds16s(k + 1024, voff, d + (2 * wave + 1) * 1024);
-        const char* v = vsrc + (size_t)c * 2 * 1024;
-        glds16s(v, voff, d + (8 + 2 * wave) * 1024);
-        glds16s(v + 1024, voff, d + (8 + 2 * wave + 1) * 1024);
+        const unsigned d = lds0 + slot * kAttnStage + 2 * wave * 1024;
+        glds16s(src + c * cstep, voff, d);
+        glds16s(src + c * cstep + 1024, voff, d + 1024);
     };
     fetch(0, 0);
     fetch(1, 1);
-    const int qt0 = 8 * qb + 2 * wave;              // this wave's query tiles qt0, qt0 + 1 of the clip's 76
+    const int qt0 = 16 * qb + 2 * wave;             // this wave's query tiles qt0, qt0 + 1 of the clip's 76
     bf16x8 qf[2][2];
 #pragma unroll
     for (int q = 0; q < 2; ++q)
@@ -273,36 +277,49 @@ __global__ __launch_bounds__(256) void k_ast_attn(const bf16raw* __restrict__ QK
                 u = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(QK) + (((size_t)b * kRowTiles + qt0 + q) * kQkTiles + 2 * h + s) * 1024 + voff);
             qf[q][s] = __builtin_bit_cast(bf16x8, u);
         }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (the q loads sit behind the DMA pieces: from here on only DMA is counted)
-    float m_run[2] = {-INFINITY, -INFINITY}, l_run[2] = {0.f, 0.f};
+    // the q fragments are waited for HERE (they sit behind the first DMA pieces): an asm that redefines them makes hipcc put its
+    // s_waitcnt in front of the loop instead of a vmcnt(0) in front of the first MFMA of every chunk, which would drain the DMA queue
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+#pragma unroll
+        for (int s = 0; s < 2; ++s) asm volatile("" : "+v"(qf[q][s]));
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // from here on only DMA is counted
+    // Scores arrive in the log2 domain (the qkv epilogue scales q by log2(e) / 8) and RELATIVE to the row's running maximum: the
+    // score MFMAs start from C = -m_run, so in the common case - the maximum did not move - p = exp2 of the MFMA result, no
+    // subtraction, no rescale.  m_run is the true running maximum from chunk 0 on (chunk 0 starts from C = 0 and takes its own).
+    float m_run[2] = {0.f, 0.f}, l_run[2] = {0.f, 0.f};
     f32x4 o[2][4];
 #pragma unroll
     for (int q = 0; q < 2; ++q)
 #pragma unroll
         for (int td = 0; td < 4; ++td) o[q][td] = splat4(0.f);
-    constexpr float kLog2e = 1.44269504088896340736f;
     int slot = 0, fslot = 2;
 #pragma unroll 1
     for (int c = 0; c < kAttnChunks; ++c) {
         // this wave's pieces of chunk c have landed (chunk c + 1 may still fly), its reads of chunk c - 1 are done; behind the
         // barrier chunk c is complete and the slot of chunk c - 1 is free for chunk c + 2
         if (c == 0) asm volatile("s_barrier" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)\n\ts_barrier" ::: "memory");
         fetch(c + 2, fslot);
         fslot = fslot == 2 ? 0 : fslot + 1;
         const char* sl = smem + slot * kAttnStage + lane * 16;
         slot = slot == 2 ? 0 : slot + 1;
         f32x4 st[2][4];
+#ifdef AMUSE_ATTN_NOC
+        const f32x4 c0[2] = {splat4(0.f), splat4(0.f)};
+#else
+        const f32x4 c0[2] = {splat4(-m_run[0]), splat4(-m_run[1])};
+#endif
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const bf16x8 k0 = *reinterpret_cast<const bf16x8*>(sl + (2 * u) * 1024), k1 = *reinterpret_cast<const bf16x8*>(sl + (2 * u + 1) * 1024);
 #pragma unroll
             for (int q = 0; q < 2; ++q) {
-                st[q][u] = mfma_bf16(k0, qf[q][0], splat4(0.f));
+                st[q][u] = mfma_bf16(k0, qf[q][0], c0[q]);
                 st[q][u] = mfma_bf16(k1, qf[q][1], st[q][u]);
             }
         }
-        // lane (g, query j): S[j][key = 64 c + 16 u + 4 g + m]
+        // lane (g, query j): log2-domain S[j][key = 64 c + 16 u + 4 g + m] - m_run[j]
         if (c == kAttnChunks - 1) {   // keys 1214, 1215 are the clip's pad rows
 #pragma unroll
             for (int q = 0; q < 2; ++q)
@@ -315,28 +332,35 @@ __global__ __launch_bounds__(256) void k_ast_attn(const bf16raw* __restrict__ QK
         bf16x8 pb[2][2];
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
-            float mx = fmaxf(fmaxf(fmaxf(st[q][0][0], st[q][0][1]), fmaxf(st[q][0][2], st[q][0][3])),
-                             fmaxf(fmaxf(st[q][1][0], st[q][1][1]), fmaxf(st[q][1][2], st[q][1][3])));
-            mx = fmaxf(mx, fmaxf(fmaxf(fmaxf(st[q][2][0], st[q][2][1]), fmaxf(st[q][2][2], st[q][2][3])),
-                                 fmaxf(fmaxf(st[q][3][0], st[q][3][1]), fmaxf(st[q][3][2], st[q][3][3]))));
-            mx = allreduce_g_max(mx);
-            const float m_new = fmaxf(m_run[q], mx);           // raw-score domain; every chunk holds a valid key
-            const float cc = m_new * kLog2e;
-            const float alpha = __builtin_amdgcn_exp2f(m_run[q] * kLog2e - cc);   // m_run = -inf on the first chunk -> 0
+            float mx = max3(max3(st[q][0][0], st[q][0][1], st[q][0][2]), max3(st[q][0][3], st[q][1][0], st[q][1][1]), max3(st[q][1][2], st[q][1][3], st[q][2][0]));
+            mx = max3(mx, max3(st[q][2][1], st[q][2][2], st[q][2][3]), max3(st[q][3][0], st[q][3][1], st[q][3][2]));
+            mx = allreduce_g_max(fmaxf(mx, st[q][3][3]));   // the same in the four lanes of a row; every chunk holds a valid key
+#ifdef AMUSE_ATTN_NOC
+            if (c > 0) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) st[q][u] -= splat4(m_run[q]);
+                mx -= m_run[q];
+            }
+#endif
+            // the running maximum moves in the first chunks and then hardly ever: shift and rescale only when it moved for some row
+            // of the wave (wave-uniform branch)
+            if (c == 0 || __builtin_amdgcn_ballot_w64(mx > 0.f) != 0) {
+                const float d = c == 0 ? mx : fmaxf(mx, 0.f);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) st[q][u] -= splat4(d);
+                const float alpha = c == 0 ? 0.f : __builtin_amdgcn_exp2f(-d);   // (chunk 0: o = l = 0, and exp2(-d) may overflow)
+                l_run[q] *= alpha;
+#pragma unroll
+                for (int td = 0; td < 4; ++td) o[q][td] *= alpha;
+                m_run[q] += d;
+            }
             f32x4 p[4];
-            float ps = 0.f;
 #pragma unroll
             for (int u = 0; u < 4; ++u)
 #pragma unroll
-                for (int m = 0; m < 4; ++m) {
-                    p[u][m] = __builtin_amdgcn_exp2f(fmaf(st[q][u][m], kLog2e, -cc));   // masked keys: exp2(-inf) = 0
-                    ps += p[u][m];
-                }
-            ps = allreduce_g_sum(ps);
-            l_run[q] = l_run[q] * alpha + ps;
-            m_run[q] = m_new;
-#pragma unroll
-            for (int td = 0; td < 4; ++td) o[q][td] *= alpha;
+                for (int m = 0; m < 4; ++m) p[u][m] = __builtin_amdgcn_exp2f(st[q][u][m]);   // masked keys: exp2(-inf) = 0
+            const f32x4 sv = (p[0] + p[1]) + (p[2] + p[3]);
+            l_run[q] += allreduce_g_sum((sv[0] + sv[1]) + (sv[2] + sv[3]));
             // k-slots (g, e) of key group pr: e < 4 -> tile 2 pr key 4 g + e, else tile 2 pr + 1 key 4 g + e - 4: the V^T slot order
             pb[q][0] = pack_bf16(p[0], p[1]);
             pb[q][1] = pack_bf16(p[2], p[3]);
@@ -485,7 +509,7 @@ hipError_t launch_untile_f32(const float* src, float* dst, int M, int F, int row
     return hipGetLastError();
 }
 hipError_t launch_ast_attn(const unsigned short* QK, const unsigned short* Vt, unsigned short* O, int B, hipStream_t s) {
-    hipLaunchKernelGGL(k_ast_attn, dim3((kAstRows + kAttnQ - 1) / kAttnQ, kAstHeads, B), dim3(256), kAttnLds, s, QK, Vt, O);
+    hipLaunchKernelGGL(k_ast_attn, dim3((kAstRows + kAttnQ - 1) / kAttnQ, kAstHeads, B), dim3(512), kAttnLds, s, QK, Vt, O);
     return hipGetLastError();
 }
 hipError_t launch_ast_pool(const float* X, const float* gamma, const float* beta, int frame_based, float* pooled, int B, hipStream_t s) {

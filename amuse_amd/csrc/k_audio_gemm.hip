@@ -231,8 +231,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                         st4(dst, v0 + ld4(ps));
                         st4(dst + 256, v1 + ld4(ps + 4));
                     }
-                } else {  // EPI_QKV, q | k tiles: q pre-scaled by head_dim ** -0.5 = 1/8 (exact in bf16); tile-major [M][1536]
-                    const float sc = n < kAstDim ? 0.125f : 1.0f;
+                } else {  // EPI_QKV, q | k tiles, tile-major [M][1536]; q pre-scaled by head_dim ** -0.5 * log2(e): the attention's scores are
+                          // exp2 arguments as they leave its MFMAs
+                    const float sc = n < kAstDim ? 0.125f * 1.44269504088896340736f : 1.0f;
                     const size_t qk0 = (size_t)((m0 >> 4) + y) * (2 * kAstDim / 32) + (n0 >> 5);
                     *reinterpret_cast<u32x4*>(reinterpret_cast<char*>(a.out_bf16) + (qk0 + p) * 1024 + voff) = pack8(v0 * sc, v1 * sc);
                 }
