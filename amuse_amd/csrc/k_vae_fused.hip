@@ -168,13 +168,11 @@ __device__ __forceinline__ void pack_rows(bf16x8 (&xb)[NT][4], const f32x4 (&x)[
 // the same 16-byte bank quad.  With the row quad r >> 2 in the low bits every group touches 16 distinct quads.
 __device__ __forceinline__ int frag_slot(int g, int r) { return 16 * g + 4 * (r & 3) + (r >> 2); }
 
-// max of three without the v_max_f32 x, x canonicalisation hipcc puts in front of every fmaxf operand (no NaN can reach
-// the scores: finite operands, -inf only through the mask)
-__device__ __forceinline__ float max3(float a, float b, float c) {
-    float d;
-    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
-    return d;
-}
+// max of three.  The file is built with -fno-honor-nans (Makefile; no NaN can reach the scores: finite operands, -inf only through
+// the mask): hipcc then drops the v_max_f32 x, x canonicalisation it otherwise puts in front of every fmaxf operand and fuses pairs
+// into v_max3_f32.  Not inline asm: the hazard recogniser does not see through asm, and a VALU read of an MFMA result needs
+// software wait states (k_audio.hip's attention read stale score registers through an asm v_max3_f32).
+__device__ __forceinline__ float max3(float a, float b, float c) { return fmaxf(fmaxf(a, b), c); }
 
 // softmax(Q K^T) V of ONE 16-query tile against all keys of head h, K / V^T fragments in LDS.  Five chunks of two key-tile
 // pairs (64 keys), merged online.  What shapes the loop: a lone ds_read_b128 -> s_waitcnt -> MFMA sequence exposes the whole
