@@ -13,6 +13,9 @@ done
 f=$(ls -t $O/stats/*/*_kernel_stats.csv | head -1); cp "$f" profiles/${R}_bench_kernel_stats.csv
 f=$(ls -t $O/decode_stats/*/*_kernel_stats.csv | head -1); cp "$f" profiles/${R}_decode_kernel_stats.csv
 f=$(ls -t $O/audio_stats/*/*_kernel_stats.csv | head -1); cp "$f" profiles/${R}_audio_kernel_stats.csv
+f=$(ls -t $O/audio_one_stats/*/*_kernel_stats.csv | head -1); cp "$f" profiles/${R}_audio_one_encoder_kernel_stats.csv
+grep -v libdrm $O/gemm_bench.txt > profiles/${R}_gemm_bench.txt
+grep -v libdrm $O/audio_perf.txt > profiles/${R}_audio_perf.txt
 tail -1 $O/bench.json > profiles/${R}_bench_line.json
 tail -1 $O/train_bench.json > profiles/${R}_train_bench_line.json
 grep -v libdrm $O/phase8.txt > profiles/${R}_k_sample8_phase_timeline.txt

@@ -22,6 +22,9 @@ for grp in FETCH_SIZE WRITE_SIZE "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUS
 done
 timeout 200 python tools/gpu_decode_perf.py > $O/decode_perf.txt 2>&1
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/audio_stats -- python3 tools/gpu_audio_perf.py 32 > $O/audio_stats.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/audio_one_stats -- python3 tools/gpu_audio_one_encoder.py 32 > $O/audio_one_stats.log 2>&1
+timeout 200 python tools/gpu_gemm_bench.py > $O/gemm_bench.txt 2>&1
+timeout 200 python tools/gpu_audio_perf.py > $O/audio_perf.txt 2>&1
 timeout 100 python tools/gpu_phase_profile8.py 256 > $O/phase8.txt 2>&1
 timeout 300 python tests/tools/gpu_drift.py > $O/drift.txt 2>&1; cp gpurun_out/drift.json $O/drift.json
 timeout 200 python tools/gpu_perf.py > $O/batch_sweep.txt 2>&1
