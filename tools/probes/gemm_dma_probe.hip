@@ -48,6 +48,9 @@ __host__ __device__ inline size_t tm_index(size_t row, int f, int F) {
 #define SPREAD 1
 #define SPREAD0 0
 #endif
+#ifndef DELAY_BIT
+#define DELAY_BIT 8
+#endif
 #ifndef DELAY
 #define DELAY 0   // s_memtime ticks (100 MHz?) an odd workgroup waits before it starts: de-phases the two workgroups of a CU
 #endif
@@ -271,7 +274,7 @@ void k_gemm_dma2(const unsigned short* __restrict__ X, const unsigned short* __r
     for (int i = 0; i < 6; ++i) fetch_piece(i);
     fetch_advance();
   };
-  if (DELAY && ((blockIdx.x >> 3) & 1)) {
+  if (DELAY && ((blockIdx.x >> DELAY_BIT) & 1)) {
     const unsigned long long t0 = __builtin_readcyclecounter();
     while (__builtin_readcyclecounter() - t0 < (unsigned long long)DELAY * (nk / 24)) __builtin_amdgcn_s_sleep(8);
   }
