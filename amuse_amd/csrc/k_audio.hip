@@ -123,13 +123,16 @@ __global__ __launch_bounds__(256) void k_im2col(const float* __restrict__ fbank,
     patches[tm_bf16(row, threadIdx.x, 256)] = __builtin_bit_cast(bf16raw, (bf)v);
 }
 
-// cls / distillation rows of the token matrix (audio_main_new.py:185-188)
+// cls / distillation rows of the token matrix (audio_main_new.py:185-188); the clip's two pad rows (1214, 1215) restart from zero with
+// every call (they are read-modify-written by every block and would otherwise drift from call to call - finite, never reaching a valid
+// row, but not reproducible)
 __global__ __launch_bounds__(256) void k_ast_tokens(const float* __restrict__ cls, const float* __restrict__ dist,
                                                     const float* __restrict__ pos, float* __restrict__ X) {
     const int b = blockIdx.x;
     for (int i = threadIdx.x; i < 2 * kAstDim; i += 256) {
         const int r = i / kAstDim, c = i - r * kAstDim;
         X[tm_f32((size_t)b * kAstRows + r, c, kAstDim)] = (r == 0 ? cls[c] : dist[c]) + pos[(size_t)r * kAstDim + c];
+        X[tm_f32((size_t)b * kAstRows + kAstTokens + r, c, kAstDim)] = 0.f;
     }
 }
 

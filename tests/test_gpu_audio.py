@@ -91,6 +91,13 @@ def test_features_batch_and_contract(env):
     assert torch.equal(c9[:3], con) and torch.equal(e9[:3], emo) and torch.equal(s9[:3], sty)
     c2, e2, s2 = eng.features(w)      # a second call reuses streams, events and workspaces
     assert torch.equal(c2, con) and torch.equal(e2, emo) and torch.equal(s2, sty)
+    # more clips than one pass over the network takes (32): the second chunk reuses the workspace - whose pad rows (2 per clip
+    # of 1216, the GEMM tiles' tail) now hold the first chunk's leftovers - and an odd clip count leaves half a row tile unowned
+    w35 = torch.cat([w9, _waves(48000, 26, seed=11)])
+    c35, e35, s35 = eng.features(w35)
+    assert torch.equal(c35[:9], c9) and torch.equal(e35[:9], e9) and torch.equal(s35[:9], s9)
+    tail = eng.features(w35[32:])
+    assert all(torch.equal(a[32:], b) for a, b in zip((c35, e35, s35), tail)) and bool(torch.isfinite(s35).all())
     # the two pooling variants of audio_main_new.py:191-201
     from amuse_amd.audio import AudioEngine
     from amuse_amd import audio_weights as aw
