@@ -183,7 +183,10 @@ __device__ __forceinline__ float max3(float a, float b, float c) { return fmaxf(
 __device__ __forceinline__ bf16x8 attend(const uint4* Kb, const uint4* Vt, bf16x8 qb, int len, int g, int r) {
     if constexpr ((AMUSE_FABL & 2) != 0) return qb;
     const int fs = frag_slot(g, r);
-    float m_run = -INFINITY, l_run = 0.f;
+    // Scores leave the MFMAs RELATIVE to the row's running maximum (C operand = -m_run; chunk 0 starts from 0 and takes its own
+    // maximum - the sequence has at least one key), so in the common chunk - the maximum did not move for any row of the wave -
+    // p = exp2(result): no subtraction, no rescale (k_audio.hip's attention has the same scheme).
+    float m_run = 0.f, l_run = 0.f;
     f32x4 o[2] = {splat4(0.f), splat4(0.f)};
 #pragma unroll
     for (int ch = 0; ch < kPairs / 2; ++ch) {
@@ -191,9 +194,10 @@ __device__ __forceinline__ bf16x8 attend(const uint4* Kb, const uint4* Vt, bf16x
 #pragma unroll
         for (int i = 0; i < 4; ++i) kf[i] = Kb[(4 * ch + i) * 64 + fs];
         f32x4 st[4];
+        const f32x4 c0 = splat4(-m_run);
 #pragma unroll
-        for (int i = 0; i < 4; ++i)   // lane (g, i): S[query i][key 64 ch + 16 i + 4 g + m] (log2 units)
-            st[i] = mfma_bf16(__builtin_bit_cast(bf16x8, kf[i]), qb, splat4(0.f));
+        for (int i = 0; i < 4; ++i)   // lane (g, i): S[query i][key 64 ch + 16 i + 4 g + m] - m_run (log2 units)
+            st[i] = mfma_bf16(__builtin_bit_cast(bf16x8, kf[i]), qb, c0);
         uint4 vf[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) vf[i] = Vt[(4 * ch + i) * 64 + fs];   // (pair, td) = (2 ch + i / 2, i % 2)
@@ -212,11 +216,19 @@ __device__ __forceinline__ bf16x8 attend(const uint4* Kb, const uint4* Vt, bf16x
         }
         float mx = max3(max3(st[0][0], st[0][1], st[0][2]), max3(st[0][3], st[1][0], st[1][1]), max3(st[1][2], st[1][3], st[2][0]));
         mx = max3(mx, max3(st[2][1], st[2][2], st[2][3]), max3(st[3][0], st[3][1], st[3][2]));
-        mx = allreduce_g_max(max3(mx, st[3][3], m_run));   // m_run is the same in the four lanes of a row
-        const float m_new = mx;
-        const float msub = (m_new == -INFINITY) ? 0.f : m_new;   // a fully masked chunk adds zeros
-        const float alpha = (m_run == -INFINITY) ? 0.f : __builtin_amdgcn_exp2f(m_run - msub);
-        m_run = m_new;
+        mx = allreduce_g_max(fmaxf(mx, st[3][3]));   // the same in the four lanes of a row; -inf for a fully masked chunk (ch > 0 only)
+        if (ch == 0 || __builtin_amdgcn_ballot_w64(mx > 0.f) != 0) {   // (wave-uniform)
+            const float d = ch == 0 ? mx : fmaxf(mx, 0.f);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) st[i] -= splat4(d);
+            if (ch > 0) {
+                const float alpha = __builtin_amdgcn_exp2f(-d);
+                l_run *= alpha;
+                o[0] *= alpha;
+                o[1] *= alpha;
+            }
+            m_run += d;
+        }
         f32x4 p[4];
         float ps = 0.f;
 #pragma unroll
@@ -224,13 +236,11 @@ __device__ __forceinline__ bf16x8 attend(const uint4* Kb, const uint4* Vt, bf16x
 #pragma unroll
             for (int m = 0; m < 4; ++m) {
                 if constexpr ((AMUSE_FABL & 8) != 0) p[i][m] = st[i][m];
-                else p[i][m] = __builtin_amdgcn_exp2f(st[i][m] - msub);
+                else p[i][m] = __builtin_amdgcn_exp2f(st[i][m]);
             }
             ps += (p[i][0] + p[i][1]) + (p[i][2] + p[i][3]);
         }
-        l_run = l_run * alpha + ps;
-        o[0] *= alpha;
-        o[1] *= alpha;
+        l_run += ps;
 #pragma unroll
         for (int pr = 0; pr < 2; ++pr) {   // O^T[d][i] += sum_key V[key][d] P[i][key], 32 keys per MFMA
             const bf16x8 pb = pack_bf16(p[2 * pr], p[2 * pr + 1]);
