@@ -31,6 +31,9 @@ namespace {
 
 typedef unsigned short bf16raw;
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+#ifndef AMUSE_GEMM_CG
+#define AMUSE_GEMM_CG 3   // feature tiles per column group of the tile walk (measured: 3 beats 6 and the plain row-major walk by 1.5 %)
+#endif
 constexpr int TN = kGemmTN, TM = kGemmTM, BK = 32, NSLOT = 3;
 constexpr int WFR = TN / 16, XFR = TM / 16, SFR = WFR + XFR;   // fragments per stage: 16 + 8
 constexpr int STAGE = SFR * 1024;
@@ -82,9 +85,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     int f_tile = wg, f_k = 0, f_slot = 0;
     const size_t frag_row = (size_t)nk * 1024;   // bytes between consecutive fragment rows of a packed / tile-major operand
     const char *fw, *fx;
+    // tile index -> (row tile, feature tile): feature tiles in groups of AMUSE_GEMM_CG, row tiles walked inside a group - the
+    // workgroups of an XCD (a contiguous range of tile indices) then share the W rows of one group in their L2
+    constexpr int CGS = AMUSE_GEMM_CG > 0 ? AMUSE_GEMM_CG : 1;
+    const int cg = (AMUSE_GEMM_CG > 0 && tiles_n % CGS == 0) ? CGS : tiles_n;
+    auto tile_tm = [&](int tile) { return (tile % (tiles_m * cg)) / cg; };
+    auto tile_tn = [&](int tile) { return (tile / (tiles_m * cg)) * cg + tile % cg; };
     auto cursor = [&]() {
-        fw = reinterpret_cast<const char*>(a.W) + (size_t)((f_tile % tiles_n) * WFR + 4 * wave) * frag_row;
-        fx = reinterpret_cast<const char*>(a.A) + (size_t)((f_tile / tiles_n) * XFR + 2 * wave) * frag_row;
+        fw = reinterpret_cast<const char*>(a.W) + (size_t)(tile_tn(f_tile) * WFR + 4 * wave) * frag_row;
+        fx = reinterpret_cast<const char*>(a.A) + (size_t)(tile_tm(f_tile) * XFR + 2 * wave) * frag_row;
     };
     cursor();
     auto fetch_piece = [&](int i) {
@@ -145,7 +154,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     };
     bool first = true;
     for (int tile = wg; tile < n_tiles; tile += gridDim.x) {
-        const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
+        const int tm = tile_tm(tile), tn = tile_tn(tile);
 #pragma unroll
         for (int x = 0; x < 8; ++x)
 #pragma unroll

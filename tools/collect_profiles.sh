@@ -10,6 +10,10 @@ done
 for n in FETCH_SIZE WRITE_SIZE SQ_WAVE_CYCLES SQ_INSTS_MFMA; do
   f=$(ls -t $O/dpmc_$n/*/*_counter_collection.csv 2>/dev/null | head -1); [ -n "$f" ] && cp "$f" profiles/${R}_decode_pmc/${n}_counter_collection.csv
 done
+mkdir -p profiles/${R}_audio_pmc
+for n in FETCH_SIZE WRITE_SIZE SQ_WAVE_CYCLES SQ_INSTS_MFMA; do
+  f=$(ls -t $O/apmc_$n/*/*_counter_collection.csv 2>/dev/null | head -1); [ -n "$f" ] && python3 tools/summarize_pmc.py "$f" > profiles/${R}_audio_pmc/${n}_per_kernel.csv
+done
 f=$(ls -t $O/stats/*/*_kernel_stats.csv | head -1); cp "$f" profiles/${R}_bench_kernel_stats.csv
 f=$(ls -t $O/decode_stats/*/*_kernel_stats.csv | head -1); cp "$f" profiles/${R}_decode_kernel_stats.csv
 f=$(ls -t $O/audio_stats/*/*_kernel_stats.csv | head -1); cp "$f" profiles/${R}_audio_kernel_stats.csv

@@ -23,6 +23,10 @@ done
 timeout 200 python tools/gpu_decode_perf.py > $O/decode_perf.txt 2>&1
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/audio_stats -- python3 tools/gpu_audio_perf.py 32 > $O/audio_stats.log 2>&1
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/audio_one_stats -- python3 tools/gpu_audio_one_encoder.py 32 > $O/audio_one_stats.log 2>&1
+for grp in FETCH_SIZE WRITE_SIZE "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_ANY" "SQ_INSTS_MFMA SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE"; do
+  n=$(echo $grp | cut -d' ' -f1)
+  timeout 300 rocprofv3 --pmc $grp --kernel-trace --output-format csv -d $O/apmc_$n -- python3 tools/gpu_audio_one_encoder.py 32 > $O/apmc_$n.log 2>&1
+done
 timeout 200 python tools/gpu_gemm_bench.py > $O/gemm_bench.txt 2>&1
 timeout 200 python tools/gpu_audio_perf.py > $O/audio_perf.txt 2>&1
 timeout 100 python tools/gpu_phase_profile8.py 256 > $O/phase8.txt 2>&1
