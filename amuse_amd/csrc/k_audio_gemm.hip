@@ -217,8 +217,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 f32x4 v0 = acc[2 * p][y] + ld4(bl + 32 * p), v1 = acc[2 * p + 1][y] + ld4(bl + 32 * p + 4);
                 if constexpr (EPI == EPI_BF16 || EPI == EPI_GELU_BF16) {
                     if constexpr (EPI == EPI_GELU_BF16) {
-#pragma unroll
-                        for (int m = 0; m < 4; ++m) { v0[m] = gelu_erf_fast(v0[m]); v1[m] = gelu_erf_fast(v1[m]); }
+                        // erf-GELU through the clamped odd polynomial of amuse_dev.hpp (|error| <= 1.9e-4, below the bf16 rounding that
+                        // follows): 6.5 issue slots per element against ~11 for the rcp / exp2 form - the epilogue's VALU work runs with
+                        // the matrix pipes idle (profiles/r02_audio_pmc), so it is paid in full
+                        v0 = gelu_poly4(v0);
+                        v1 = gelu_poly4(v1);
                     }
                     __builtin_nontemporal_store(pack8(v0, v1), reinterpret_cast<u32x4*>(reinterpret_cast<char*>(a.out_bf16) + (tile0 + p) * 1024 + voff));
                 } else if constexpr (EPI == EPI_RESID_F32) {
