@@ -405,6 +405,181 @@ void k_gemm_dma2(const unsigned short* __restrict__ X, const unsigned short* __r
 #endif
 }
 
+// ---- v3: ONE workgroup of 8 waves per CU, 256 x 256 tile (32 fragments per stage: a third less DMA per MFMA than two 256 x 128 workgroups)
+template <int STORE>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))
+void k_gemm_dma3(const unsigned short* __restrict__ X, const unsigned short* __restrict__ W, void* __restrict__ Cout, int M, int N, int K) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6), g = lane >> 4, j = lane & 15;
+  const int wf = wave >> 2, wr = wave & 3;
+  constexpr int TM = 256, XFR = 16, SFR = WFR + XFR, STAGE = SFR * 1024;   // (shadow the file-scope tile constants)
+  const int tiles_n = N / TN, tiles_m = (M + TM - 1) / TM, n_tiles = tiles_n * tiles_m, nk = K / BK;
+  int wg = blockIdx.x;
+  if (XCD_REMAP && (gridDim.x % 8) == 0) wg = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+  if (wg >= n_tiles) return;
+  const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) const void*)smem;
+  const unsigned voff = lane * 16;
+  // fetch cursor (all wave-uniform): the W / X fragment rows this wave fetches, as byte addresses of k-step f_k
+  int f_tile = wg, f_k = 0, f_slot = 0;
+  const size_t frag_row = (size_t)nk * 1024;   // bytes between consecutive fragment rows of a tile-major matrix
+  const char *fw, *fx;
+  auto cursor = [&]() {
+    fw = reinterpret_cast<const char*>(W) + (size_t)((f_tile % tiles_n) * WFR + 2 * wave) * frag_row;
+    fx = reinterpret_cast<const char*>(X) + (size_t)((f_tile / tiles_n) * XFR + 2 * wave) * frag_row;
+  };
+  cursor();
+  // piece i of the wave's six DMA instructions of the next stage to fetch (0..3: W fragment rows, 4..5: X fragment rows)
+  auto fetch_piece = [&](int i) {
+    if (ABL2 & 1) return;
+    const unsigned d = lds0 + f_slot * STAGE;
+    if (i < 2) glds16s(fw + i * frag_row + (size_t)f_k * 1024, voff, d + (2 * wave + i) * 1024);
+    else glds16s(fx + (i - 2) * frag_row + (size_t)f_k * 1024, voff, d + (WFR + 2 * wave + i - 2) * 1024);
+  };
+  auto fetch_advance = [&]() {
+    f_slot = f_slot == NSLOT - 1 ? 0 : f_slot + 1;
+    if (++f_k == nk) {
+      f_k = 0;
+      const int nt = f_tile + gridDim.x;
+      f_tile = nt < n_tiles ? nt : f_tile;
+      cursor();
+    }
+  };
+  auto fetch = [&]() {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) fetch_piece(i);
+    fetch_advance();
+  };
+  if (DELAY && ((blockIdx.x >> DELAY_BIT) & 1)) {
+    const unsigned long long t0 = __builtin_readcyclecounter();
+    while (__builtin_readcyclecounter() - t0 < (unsigned long long)DELAY * (nk / 24)) __builtin_amdgcn_s_sleep(8);
+  }
+  fetch(); fetch(); fetch();
+  asm volatile("s_waitcnt vmcnt(8)\n\ts_barrier" ::: "memory");
+  bf16x8 wc[8], xa[4], xb[4];
+  {
+    const char* sl = smem + lane * 16;
+#pragma unroll
+    for (int y = 0; y < 4; ++y) xa[y] = *reinterpret_cast<const bf16x8*>(sl + (WFR + 4 * wr + y) * 1024);
+#pragma unroll
+    for (int x = 0; x < 8; ++x) wc[x] = *reinterpret_cast<const bf16x8*>(sl + (8 * wf + x) * 1024);
+  }
+  int r_slot = 1;
+  constexpr int SN = (STORE == 3 || STORE >= 6) ? 16 : STORE == 5 ? 32 : 0;   // vector-memory operations of the epilogue that may still be in flight
+  f32x4 acc[8][4];
+#ifdef PROF
+  unsigned long long t_stall = 0, t_work = 0, t_fetch = 0, t_prev = __builtin_readcyclecounter(), t_epi = 0, t_stall_r = 0;
+  unsigned n_iter = 0, n_tile = 0;
+#endif
+  auto half = [&](auto relaxed, bf16x8 (&xc)[4], bf16x8 (&xn)[4]) {
+    constexpr int WAITN = 4 + (decltype(relaxed)::value ? SN : 0);
+#ifdef PROF
+    const unsigned long long ta = __builtin_readcyclecounter();
+#endif
+    if (ABL2 & 4) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(WAITN) : "memory");
+    else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(WAITN) : "memory");
+#ifdef PROF
+    const unsigned long long tb = __builtin_readcyclecounter();
+#endif
+#if !SPREAD
+    fetch();
+#endif
+#ifdef PROF
+    const unsigned long long tc = __builtin_readcyclecounter();
+    t_work += ta - t_prev; t_stall += tb - ta; t_fetch += tc - tb; t_prev = tc; ++n_iter;
+    if (decltype(relaxed)::value) t_stall_r += tb - ta;
+#endif
+    const char* sl = smem + r_slot * STAGE + lane * 16;
+#pragma unroll
+    for (int y = 0; y < 4; ++y) xn[y] = (ABL2 & 2) ? xc[y] : *reinterpret_cast<const bf16x8*>(sl + (WFR + 4 * wr + y) * 1024);
+#pragma unroll
+    for (int x = 0; x < 8; ++x) {
+#pragma unroll
+      for (int y = 0; y < 4; ++y) acc[x][y] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wc[x], xc[y], acc[x][y], 0, 0, 0);
+      if (!(ABL2 & 2)) wc[x] = *reinterpret_cast<const bf16x8*>(sl + (8 * wf + x) * 1024);
+#if SPREAD
+      if (x >= SPREAD0 && x < SPREAD0 + 4) fetch_piece(x - SPREAD0);   // one DMA instruction per MFMA group: a wave blocks at issue while the CU's 64 B/clk path is busy
+      if (x == 7) fetch_advance();
+#endif
+      __builtin_amdgcn_sched_barrier(0);   // (keeps the scheduler from hoisting every read to the top: 48 more live registers)
+    }
+    r_slot = r_slot == NSLOT - 1 ? 0 : r_slot + 1;
+  };
+  bool first = true;
+  for (int tile = wg; tile < n_tiles; tile += gridDim.x) {
+#pragma unroll
+    for (int x = 0; x < 8; ++x)
+#pragma unroll
+      for (int y = 0; y < 4; ++y) acc[x][y] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (first) { half(std::false_type{}, xa, xb); half(std::false_type{}, xb, xa); }
+    else { half(std::true_type{}, xa, xb); half(std::true_type{}, xb, xa); }
+    first = false;
+#pragma unroll 1
+    for (int kp = 2; kp < nk; kp += 2) { half(std::false_type{}, xa, xb); half(std::false_type{}, xb, xa); }
+#ifdef PROF
+    const unsigned long long te0 = __builtin_readcyclecounter();
+#endif
+    const int m0 = (tile / tiles_n) * TM + 64 * wr, n0 = (tile % tiles_n) * TN + 128 * wf;   // TM = 256 here
+    if (STORE) {
+      // tile-major output: the wave's store of (y, p) is one whole 16 x 32 tile - 1 KiB (bf16) / 2 KiB (fp32) contiguous; uniform
+      // tile address + lane offset.  Rows past M exist in the padded buffer.
+#pragma unroll
+      for (int y = 0; y < 4; ++y) {
+        const size_t tile0 = (size_t)((m0 >> 4) + y) * (N >> 5) + (n0 >> 5);
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+          if (STORE == 5) {
+            float* c = reinterpret_cast<float*>(reinterpret_cast<char*>(Cout) + (tile0 + p) * 2048 + voff);
+            f32x4 v0 = acc[2 * p][y], v1 = acc[2 * p + 1][y];
+#if NT & 2
+            v0 += __builtin_nontemporal_load(reinterpret_cast<f32x4*>(c)); v1 += __builtin_nontemporal_load(reinterpret_cast<f32x4*>(c + 256));
+            __builtin_nontemporal_store(v0, reinterpret_cast<f32x4*>(c));
+            __builtin_nontemporal_store(v1, reinterpret_cast<f32x4*>(c + 256));
+#else
+            v0 += *reinterpret_cast<f32x4*>(c); v1 += *reinterpret_cast<f32x4*>(c + 256);
+            *reinterpret_cast<f32x4*>(c) = v0;
+            *reinterpret_cast<f32x4*>(c + 256) = v1;
+#endif
+          } else {
+            typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+            auto pk = [](float a, float b) { return __builtin_bit_cast(unsigned, bf16x2{(__bf16)a, (__bf16)b}); };
+            f32x4 v0 = acc[2 * p][y], v1 = acc[2 * p + 1][y];
+            if (STORE == 6) { v0 = gelu_poly4(v0); v1 = gelu_poly4(v1); }
+            if (STORE == 7) {
+#pragma unroll
+              for (int m = 0; m < 4; ++m) { v0[m] = gelu_erf_fast(v0[m]); v1[m] = gelu_erf_fast(v1[m]); }
+            }
+            typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+            const u32x4 o = u32x4{pk(v0[0], v0[1]), pk(v0[2], v0[3]), pk(v1[0], v1[1]), pk(v1[2], v1[3])};
+            u32x4* dst = reinterpret_cast<u32x4*>(reinterpret_cast<char*>(Cout) + (tile0 + p) * 1024 + voff);
+#if NT & 1
+            __builtin_nontemporal_store(o, dst);
+#else
+            *dst = o;
+#endif
+          }
+        }
+      }
+    } else {
+      float s = 0.f;
+#pragma unroll
+      for (int x = 0; x < 8; ++x)
+#pragma unroll
+        for (int y = 0; y < 4; ++y) s += acc[x][y][0] + acc[x][y][3];
+      if (s == 12345.678f) reinterpret_cast<float*>(Cout)[0] = s;
+    }
+#ifdef PROF
+    { const unsigned long long te1 = __builtin_readcyclecounter(); t_epi += te1 - te0; t_prev = te1; ++n_tile; }
+#endif
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#ifdef PROF
+  if (lane == 0 && blockIdx.x < 16) {
+    unsigned long long* o = g_prof + (blockIdx.x * 4 + wave) * 8;
+    o[0] = t_work; o[1] = t_stall; o[2] = t_fetch; o[3] = n_iter; o[4] = t_epi; o[5] = n_tile; o[6] = t_stall_r;
+  }
+#endif
+}
+
 static unsigned short f2bf(float f) { unsigned u; memcpy(&u, &f, 4); u += 0x7fffu + ((u >> 16) & 1u); return (unsigned short)(u >> 16); }
 static float bf2f(unsigned short h) { unsigned u = (unsigned)h << 16; float f; memcpy(&f, &u, 4); return f; }
 
@@ -426,6 +601,8 @@ int main(int argc, char** argv) {
   for (const void* f : {reinterpret_cast<const void*>(&k_gemm_dma2<0>), reinterpret_cast<const void*>(&k_gemm_dma2<3>), reinterpret_cast<const void*>(&k_gemm_dma2<5>),
                         reinterpret_cast<const void*>(&k_gemm_dma2<6>), reinterpret_cast<const void*>(&k_gemm_dma2<7>)})
     CHECK(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+  for (const void* f : {reinterpret_cast<const void*>(&k_gemm_dma3<0>), reinterpret_cast<const void*>(&k_gemm_dma3<3>)})
+    CHECK(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 32 * 1024));
   for (auto& sh : shapes) {
     const int N = sh[0], K = sh[1];
     std::vector<unsigned short> hx((size_t)M * K), hw((size_t)N * K);
@@ -433,7 +610,7 @@ int main(int argc, char** argv) {
     auto rnd = [&] { s = s * 1664525u + 1013904223u; return ((s >> 8) & 0xffff) / 65536.0f - 0.5f; };
     for (auto& v : hx) v = f2bf(rnd());
     for (auto& v : hw) v = f2bf(rnd() * 0.1f);
-    const int Mp = (M + TM - 1) / TM * TM;
+    const int Mp = (M + 255) / 256 * 256;
     std::vector<unsigned short> px((size_t)Mp * K), pw((size_t)N * K);
     if (PACKED) {
       const int nk = K / 32;
@@ -481,6 +658,30 @@ int main(int argc, char** argv) {
       }
     }
     if (PACKED) {
+      const int n_tiles3 = (N / TN) * ((M + 255) / 256), grid3 = n_tiles3 < 256 ? n_tiles3 : 256;
+      for (int store : {3, 0}) {
+        for (int rep = 0; rep < 2; ++rep) {
+          CHECK(hipEventRecord(e0));
+          for (int i = 0; i < 5; ++i) {
+            if (store == 3) hipLaunchKernelGGL(k_gemm_dma3<3>, dim3(grid3), dim3(512), 3 * 32 * 1024, 0, dx, dw, dc, M, N, K);
+            else hipLaunchKernelGGL(k_gemm_dma3<0>, dim3(grid3), dim3(512), 3 * 32 * 1024, 0, dx, dw, dc, M, N, K);
+          }
+          CHECK(hipEventRecord(e1)); CHECK(hipEventSynchronize(e1));
+          CHECK(hipGetLastError());
+          float ms; CHECK(hipEventElapsedTime(&ms, e0, e1));
+          if (rep) printf("v3 N=%d K=%d store=%d: %.1f us  %.0f TFLOP/s\n", N, K, store, ms / 5 * 1e3, 2.0 * M * N * K / (ms / 5 * 1e-3) / 1e12);
+        }
+        if (store == 3) {
+          double maxerr = 0;
+          for (int q = 0; q < 48; ++q) {
+            const int row = q < 8 ? M - 1 - q * 13 : (q * 4801 + 17) % M, f = (q * 977 + 5) % N;
+            double ref = 0; for (int k = 0; k < K; ++k) ref += (double)bf2f(hx[(size_t)row * K + k]) * bf2f(hw[(size_t)f * K + k]);
+            unsigned short got; CHECK(hipMemcpy(&got, reinterpret_cast<unsigned short*>(dc) + tm_index(row, f, N), 2, hipMemcpyDeviceToHost));
+            maxerr = fmax(maxerr, fabs(ref - bf2f(got)) / (fabs(ref) + 1.0));
+          }
+          printf("   v3 spot-check max err %.3e (relative, bf16 output)\n", maxerr);
+        }
+      }
       const int modes[5] = {7, 6, 5, 3, 0};
       for (int mi = 0; mi < 5; ++mi) {
         const int store = modes[mi];
