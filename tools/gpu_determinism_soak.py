@@ -1,5 +1,6 @@
 """Race hunt: the 8-wave bf16 sampling kernel must reproduce itself bitwise, launch after launch, for every tiling
-(a data race between its alternating wave groups would show up as a flaky mismatch)."""
+(a data race between its alternating wave groups would show up as a flaky mismatch); so must the fused decode kernel and the
+audio front-end (DMA rings, hand-counted waits)."""
 import sys
 from pathlib import Path
 import torch
@@ -23,5 +24,25 @@ for T, tab in ((100, sch.ddpm_table(100)), (50, sch.ddim_table())):
         bad += n
         print(f"T={T} B={B} G={G}: {n} mismatching launches of 24; finite={bool(torch.isfinite(ref).all())}", flush=True)
 eng.set_clips_per_group(0)
+# the fused decode kernel and the audio front-end (LDS-DMA rings with hand-counted s_waitcnt: a protocol slip would show up here)
+z = torch.randn(300, 128, generator=gen).cuda()
+eng.set_decode_path("fused")
+ref = eng.vae_decode(z, None, "bf16")["poses"].clone()
+n = sum(int(not torch.equal(eng.vae_decode(z, None, "bf16")["poses"], ref)) for _ in range(16))
+bad += n
+print(f"fused decode, 300 clips: {n} mismatching launches of 16; finite={bool(torch.isfinite(ref).all())}", flush=True)
+eng.set_decode_path("auto")
+from amuse_amd import audio_weights as aw
+from amuse_amd.audio import AudioEngine
+aeng = AudioEngine(*(aw.make_ast_weights(0, k) for k in aw.ENCODERS))
+for B in (1, 3, 34):
+    w = 0.1 * torch.randn(B, 160000, generator=gen).cuda()
+    ref = [t.clone() for t in aeng.features(w)]
+    n = 0
+    for _ in range(8):
+        out = aeng.features(w)
+        n += int(not all(torch.equal(a, b) for a, b in zip(out, ref)))
+    bad += n
+    print(f"audio features, {B} clips: {n} mismatching calls of 8; finite={all(bool(torch.isfinite(t).all()) for t in ref)}", flush=True)
 print("TOTAL mismatches:", bad)
 sys.exit(1 if bad else 0)
