@@ -21,6 +21,7 @@
 //     fire-and-forget: the two stages after an epilogue wait with vmcnt(6 + stores) - vmcnt retires in order, and the DMA pieces
 //     they need are older than the stores.  The bias tile travels by DMA too (an epilogue load would drain the queue).
 // Measured on MI355X, M = 38,848 (32 clips), TFLOP/s with epilogue: see DESIGN.md 4.4.
+#include <cstdlib>
 #include <type_traits>
 
 #include "amuse_dev.hpp"
@@ -34,11 +35,14 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 #ifndef AMUSE_GEMM_CG
 #define AMUSE_GEMM_CG 3   // feature tiles per column group of the tile walk (measured: 3 beats 6 and the plain row-major walk by 1.5 %)
 #endif
-constexpr int TN = kGemmTN, TM = kGemmTM, BK = 32, NSLOT = 3;
+constexpr int TN = kGemmTN, TM = kGemmTM, BK = 32;
 constexpr int WFR = TN / 16, XFR = TM / 16, SFR = WFR + XFR;   // fragments per stage: 16 + 8
 constexpr int STAGE = SFR * 1024;
-constexpr int kOffBias = NSLOT * STAGE;                         // [256] float: the bias of the current tile's features
-constexpr int kGemmTmLds = kOffBias + 1024;                     // 74,752 B: two workgroups per CU
+// ring depth NSLOT: 3 stages = 74,752 B with the bias tile - two workgroups per CU, the production shape; 6 stages = 148,480 B for
+// launches of few tiles (one or two clips: every workgroup has a CU to itself and walks its whole K extent alone, so what paces it
+// is the fetch latency - five stages in flight instead of two: one clip 2.74 -> 2.58 ms for the three encoders).  Same arithmetic either way.
+constexpr int gemm_lds(int nslot) { return nslot * STAGE + 1024; }
+constexpr int kDeepTiles = 128;   // launches of at most this many tiles use the 6-stage ring
 
 __device__ __forceinline__ unsigned pack2(float a, float b) {
     typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -66,8 +70,9 @@ constexpr int epi_stores() {
     return (EPI == EPI_BF16 || EPI == EPI_GELU_BF16) ? 16 : (EPI == EPI_RESID_F32 || EPI == EPI_F32) ? 32 : 0;
 }
 
-template <int EPI>
+template <int EPI, int NSLOT>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_gemm_tm(GemmArgs a) {
+    constexpr int kOffBias = NSLOT * STAGE;   // [256] float: the bias of the current tile's features
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6), g = lane >> 4, j = lane & 15;
     const int wf = wave >> 1, wr = wave & 1;   // feature half (128), token half (64) of the tile
@@ -116,7 +121,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         for (int i = 0; i < 6; ++i) fetch_piece(i);
         fetch_advance();
     }
-    asm volatile("s_waitcnt vmcnt(12)\n\ts_barrier" ::: "memory");
+    asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(6 * (NSLOT - 1)) : "memory");
     bf16x8 wc[8], xa[4], xb[4];
     {
         const char* sl = smem + lane * 16;
@@ -131,8 +136,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     // one k-step: xc = this stage's X fragments (registers), xn receives the next stage's
     // swapped: the X fragment is the MFMA's A operand, so a lane ends up with 4 consecutive TOKENS of one feature (the V^T tiles)
     auto half = [&](auto relaxed, auto swapped, bf16x8 (&xc)[4], bf16x8 (&xn)[4], int bias_tile) {
-        constexpr int WAITN = 6 + (decltype(relaxed)::value ? SN : 0);
-        // this wave's pieces of the NEXT stage have landed (the two younger stages may still fly) and its reads of this stage are in
+        constexpr int WAITN = 6 * (NSLOT - 2) + (decltype(relaxed)::value ? SN : 0);
+        static_assert(WAITN < 64, "vmcnt is a 6-bit counter");
+        // this wave's pieces of the NEXT stage have landed (the NSLOT - 2 younger stages may still fly) and its reads of this stage are in
         // registers; behind the barrier that holds for every wave: the next stage is complete, this stage's slot is free
         asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(WAITN) : "memory");
         if (bias_tile >= 0 && wave == 0)   // (every wave's epilogue reads of the previous tile's bias are in front of this barrier)
@@ -255,18 +261,24 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the surplus fetches must not outlive the workgroup's LDS
 }
 
-template <int EPI>
-hipError_t launch_gemm_t(const GemmArgs& a, hipStream_t s) {
+template <int EPI, int NSLOT>
+hipError_t launch_gemm_n(const GemmArgs& a, int n_tiles, hipStream_t s) {
     static bool attr = false;
     if (!attr) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_tm<EPI>), hipFuncAttributeMaxDynamicSharedMemorySize, kGemmTmLds);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_tm<EPI, NSLOT>), hipFuncAttributeMaxDynamicSharedMemorySize, gemm_lds(NSLOT));
         if (e != hipSuccess) return e;
         attr = true;
     }
-    const int n_tiles = ((a.M + TM - 1) / TM) * (a.N / TN);
     const int resident = 2 * 256;   // two workgroups per CU, 256 CUs
-    hipLaunchKernelGGL(k_gemm_tm<EPI>, dim3(n_tiles < resident ? n_tiles : resident), dim3(256), kGemmTmLds, s, a);
+    hipLaunchKernelGGL((k_gemm_tm<EPI, NSLOT>), dim3(n_tiles < resident ? n_tiles : resident), dim3(256), gemm_lds(NSLOT), s, a);
     return hipGetLastError();
+}
+template <int EPI>
+hipError_t launch_gemm_t(const GemmArgs& a, hipStream_t s) {
+    const int n_tiles = ((a.M + TM - 1) / TM) * (a.N / TN);
+    static const bool no_deep = [] { const char* e = getenv("AMUSE_GEMM_DEEP"); return e && atoi(e) == 0; }();
+    if (n_tiles <= kDeepTiles && !no_deep) return launch_gemm_n<EPI, 6>(a, n_tiles, s);
+    return launch_gemm_n<EPI, 3>(a, n_tiles, s);
 }
 
 }  // namespace
