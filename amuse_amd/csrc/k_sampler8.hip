@@ -487,13 +487,6 @@ __device__ __forceinline__ void role_loop8(const SampleArgs& a, char* smem, int 
         }
         stamp8<PROF>(pf);  // step start
         rg.next = ROLEA ? wbase + kR8 * 64 : wbase;  // (A: the ring already holds units 0..31 of this step)
-        // the step's scheduler coefficients are fetched HERE (uniform: scalar loads) - at the end of the step their latency would sit
-        // on the critical path between the final LayerNorm and the update
-        float sb = 0.f, sa = 1.f, c0 = 0.f, cx = 0.f, ce = 0.f, sg = 0.f, clipv = 0.f;
-        if constexpr (!ROLEA) {
-            const float* cf = a.coef + (size_t)step * 8;
-            sb = cf[0]; sa = cf[1]; c0 = cf[2]; cx = cf[3]; ce = cf[4]; sg = cf[5]; clipv = cf[6];
-        }
         // ---- SkipTransformerEncoder.forward (cross_attention.py:41-64)
 #pragma unroll 1
         for (int blk = 0; blk < kLayers; ++blk) {
@@ -556,6 +549,8 @@ __device__ __forceinline__ void role_loop8(const SampleArgs& a, char* smem, int 
             const float d0 = s0.x - mean, d1 = s1.x - mean, d2 = s2.x - mean, d3 = s3.x - mean;
             const float M2 = ((s0.y + s1.y) + (s2.y + s3.y)) + 32.0f * ((d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3));
             const float rstd = __builtin_amdgcn_rsqf(M2 * (1.0f / kD) + 1e-5f);
+            const float* cf = a.coef + (size_t)step * 8;
+            const float sb = cf[0], sa = cf[1], c0 = cf[2], cx = cf[3], ce = cf[4], sg = cf[5], clipv = cf[6];
             const float inv_sa = 1.0f / sa;
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
