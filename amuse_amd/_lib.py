@@ -18,7 +18,7 @@ QUAT_P3D, QUAT_LEGACY = 0, 1
 ABI_VERSION = 1
 
 EXPORTS = [
-    "amuse_abi_version", "amuse_last_error", "amuse_create", "amuse_update_weights", "amuse_destroy", "amuse_set_schedule",
+    "amuse_abi_version", "amuse_last_error", "amuse_create", "amuse_update_weights", "amuse_update_weights_device", "amuse_destroy", "amuse_set_schedule",
     "amuse_sample", "amuse_denoise_step", "amuse_diffusion_forward", "amuse_vae_decode", "amuse_vae_encode", "amuse_smplx_to_feats", "amuse_diffusion_backward",
     "amuse_counter_normal", "amuse_set_clips_per_group", "amuse_set_decode_path", "amuse_profile_sample",
     "amuse_audio_create", "amuse_audio_destroy", "amuse_audio_fbank", "amuse_audio_encode", "amuse_audio_features",
@@ -57,6 +57,8 @@ def load() -> C.CDLL:
     lib.amuse_create.argtypes = [C.c_int, C.POINTER(C.c_float), C.c_size_t, C.POINTER(C.c_float), C.c_size_t]
     lib.amuse_update_weights.restype = C.c_int
     lib.amuse_update_weights.argtypes = [vp, C.POINTER(C.c_float), C.c_size_t, C.POINTER(C.c_float), C.c_size_t, C.c_int, vp]
+    lib.amuse_update_weights_device.restype = C.c_int
+    lib.amuse_update_weights_device.argtypes = [vp, vp, vp, C.c_int, vp]
     lib.amuse_destroy.restype = None
     lib.amuse_destroy.argtypes = [vp]
     lib.amuse_set_schedule.argtypes = [vp, C.POINTER(Schedule), vp]

@@ -208,9 +208,21 @@ void pack_skiplin(std::vector<uint4>& s, int prec, const Params& P, const std::s
               range(4 * w, 4 * w + 4));
 }
 
+// amuse_update_weights_device learns the packed images' gather maps by running the builders on probe parameters with upload()
+// redirected into host memory, keyed by the context slot the image belongs to
+struct Capture {
+    std::map<void**, std::vector<unsigned char>> bufs;
+};
+thread_local Capture* g_capture = nullptr;
+
 // first call allocates; later calls (amuse_update_weights: same architecture, same sizes) overwrite in place
 template <typename T>
 int upload(T** dst, const void* src, size_t bytes) {
+    if (g_capture) {
+        const unsigned char* b = static_cast<const unsigned char*>(src);
+        g_capture->bufs[reinterpret_cast<void**>(dst)].assign(b, b + bytes);
+        return 0;
+    }
     if (!*dst) HIP_TRY(hipMalloc((void**)dst, bytes));
     HIP_TRY(hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice));
     return 0;
@@ -266,6 +278,9 @@ struct amuse_ctx {
     float* vae_ws = nullptr; size_t vae_cap = 0;  // clips
     int* d_lengths = nullptr; size_t len_cap = 0;
     std::vector<void*> owned;
+    // amuse_update_weights_device: one entry per packed image (built on the first call)
+    struct Repack { void** slot; int* map; size_t n; int prior, bf16, cls; };
+    std::vector<Repack> repack;
 };
 
 namespace {
@@ -643,9 +658,92 @@ int amuse_update_weights(amuse_ctx* c, const float* denoiser_params, size_t n_de
     return 0;
 }
 
+namespace {
+// The gather maps.  Every image the builders upload is a permutation of parameters plus zero padding (the one exception,
+// the timestep frequencies, does not depend on the parameters and is skipped), so three builder runs on probe parameters - byte k
+// of (index + 1), a value bf16 holds exactly - spell out, per image element, which parameter it carries.
+int build_repack_maps(amuse_ctx* c) {
+    struct Img { std::vector<int> map; bool prior; };
+    std::map<void**, Img> imgs;
+    std::vector<float> den(AMUSE_DENOISER_PARAMS), pri(AMUSE_PRIOR_PARAMS);
+    auto is_bf16 = [&](void** slot) {
+        return slot == (void**)&c->den_w[PREC_BF16] || slot == (void**)&c->den_w8 || slot == (void**)&c->vae_w[PREC_BF16] ||
+               slot == (void**)&c->vae_wf || slot == (void**)&c->vaee_w[PREC_BF16];
+    };
+    for (int k = 0; k < 3; ++k) {
+        for (size_t i = 0; i < den.size(); ++i) den[i] = (float)(((i + 1) >> (8 * k)) & 255);
+        for (size_t i = 0; i < pri.size(); ++i) pri[i] = (float)(((i + 1) >> (8 * k)) & 255);
+        for (int which = 0; which < 2; ++which) {
+            Capture cap;
+            g_capture = &cap;
+            const int rc = which == 0 ? build_denoiser(c, den.data(), 7) : build_prior(c, pri.data(), 7);
+            g_capture = nullptr;
+            if (rc) return rc;
+            for (auto& kv : cap.bufs) {
+                if (kv.first == (void**)&c->den_freqs) continue;
+                const bool b16 = is_bf16(kv.first);
+                const size_t n = kv.second.size() / (b16 ? 2 : 4);
+                Img& im = imgs[kv.first];
+                if (k == 0) { im.map.assign(n, 0); im.prior = which == 1; }
+                else if (im.map.size() != n) return fail(AMUSE_ESTATE, "internal: packed image changed size between probe runs");
+                for (size_t j = 0; j < n; ++j) {
+                    float v;
+                    if (b16) {
+                        uint16_t h;
+                        memcpy(&h, kv.second.data() + 2 * j, 2);
+                        const uint32_t u = (uint32_t)h << 16;
+                        memcpy(&v, &u, 4);
+                    } else {
+                        memcpy(&v, kv.second.data() + 4 * j, 4);
+                    }
+                    if (!(v >= 0.f && v <= 255.f && v == (float)(int)v)) return fail(AMUSE_ESTATE, "internal: a packed image is not a gather of the parameters");
+                    im.map[j] |= (int)v << (8 * k);
+                }
+            }
+        }
+    }
+    for (auto& kv : imgs) {
+        void** slot = kv.first;
+        const size_t limit = kv.second.prior ? AMUSE_PRIOR_PARAMS : AMUSE_DENOISER_PARAMS;
+        for (int m : kv.second.map)
+            if (m < 0 || (size_t)m > limit) return fail(AMUSE_ESTATE, "internal: gather index out of range");
+        int cls = 0;   // which AMUSE_UPD_* bits the image needs; 0 = small parameters, always replaced
+        if (slot == (void**)&c->den_w[PREC_F32] || slot == (void**)&c->vae_w[PREC_F32]) cls = AMUSE_UPD_F32;
+        else if (slot == (void**)&c->den_w[PREC_BF16] || slot == (void**)&c->den_w8 || slot == (void**)&c->vae_w[PREC_BF16] || slot == (void**)&c->vae_wf) cls = AMUSE_UPD_BF16;
+        else if (slot == (void**)&c->vaee_w[PREC_F32]) cls = AMUSE_UPD_F32 | AMUSE_UPD_ENCODER;
+        else if (slot == (void**)&c->vaee_w[PREC_BF16]) cls = AMUSE_UPD_BF16 | AMUSE_UPD_ENCODER;
+        int* dmap = nullptr;
+        HIP_TRY(hipMalloc((void**)&dmap, kv.second.map.size() * sizeof(int)));
+        c->owned.push_back(dmap);
+        HIP_TRY(hipMemcpy(dmap, kv.second.map.data(), kv.second.map.size() * sizeof(int), hipMemcpyHostToDevice));
+        c->repack.push_back({slot, dmap, kv.second.map.size(), kv.second.prior ? 1 : 0, is_bf16(slot) ? 1 : 0, cls});
+    }
+    return 0;
+}
+}  // namespace
+
+int amuse_update_weights_device(amuse_ctx* c, const float* denoiser_params_dev, const float* prior_params_dev, int what, void* stream) {
+    if (!c) return fail(AMUSE_EINVAL, "ctx is NULL");
+    if (!denoiser_params_dev && !prior_params_dev) return fail(AMUSE_EINVAL, "nothing to update");
+    if (what < 1 || what > 7 || !(what & 3)) return fail(AMUSE_EINVAL, "bad `what` mask %d", what);
+    HIP_TRY(hipSetDevice(c->device));
+    if (c->repack.empty())
+        if (int e = build_repack_maps(c)) return e;
+    for (const auto& r : c->repack) {
+        const float* src = r.prior ? prior_params_dev : denoiser_params_dev;
+        if (!src || !*r.slot) continue;                 // (an image the context never built, e.g. the 4-wave bf16 stream after an update)
+        if ((r.cls & what) != r.cls) continue;          // every bit the image needs must be requested
+        HIP_TRY(launch_repack(src, r.map, *r.slot, r.n, r.bf16, (hipStream_t)stream));
+    }
+    if (denoiser_params_dev) c->T = 0;   // the hoisted time-token table belongs to the old time-embedding weights: set the schedule again
+    return 0;
+}
+
 void amuse_destroy(amuse_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
+    for (void* p : c->owned)
+        if (p) (void)hipFree(p);
     void* ptrs[] = {c->den_w[0], c->den_w[1], c->den_w8, c->den_pvec, c->den_pe, c->den_freqs, c->te_w1t, c->te_b1, c->te_w2t,
                     c->te_b2, c->cond_wt[0], c->cond_wt[1], c->cond_wt[2], c->cond_b[0], c->cond_b[1], c->cond_b[2],
                     c->vae_w[0], c->vae_w[1], c->vae_pvec, c->vae_final_bias, c->vae_pe, c->vae_wv_t, c->vae_bv,

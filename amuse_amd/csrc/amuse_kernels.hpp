@@ -62,6 +62,7 @@ struct CondArgs {
 };
 hipError_t launch_cond_tokens(const CondArgs& a, hipStream_t stream);
 // noisy[b] = sa[b] * z0[b] + sb[b] * noise[b]   (DDPMScheduler.add_noise; call site ldm.py:84)
+hipError_t launch_repack(const float* params, const int* map, void* dst, size_t n, int bf16, hipStream_t stream);
 hipError_t launch_add_noise(const float* z0, const float* noise, const float* sa, const float* sb, float* out, int B,
                             hipStream_t stream);
 hipError_t launch_counter_normal(uint64_t seed, uint64_t clip0, int B, int step, int rng_stream, float* out,

@@ -159,6 +159,26 @@ hipError_t launch_smplx_to_feats(const float* poses, const float* trans, size_t 
     return hipGetLastError();
 }
 
+// amuse_update_weights_device: a packed image (weight stream, parameter vector, transposed matrix) is a GATHER of the model's
+// parameters - map[j] = 1 + index of the parameter that image element j holds, 0 = padding
+__global__ __launch_bounds__(256) void k_repack(const float* __restrict__ params, const int* __restrict__ map, void* __restrict__ dst, size_t n, int bf16) {
+    for (size_t j = (size_t)blockIdx.x * 256 + threadIdx.x; j < n; j += (size_t)gridDim.x * 256) {
+        const int m = map[j];
+        const float v = m ? params[m - 1] : 0.f;
+        if (bf16) {
+            typedef __bf16 bf;
+            reinterpret_cast<unsigned short*>(dst)[j] = __builtin_bit_cast(unsigned short, (bf)v);   // round-to-nearest-even, as the host packer
+        } else {
+            reinterpret_cast<float*>(dst)[j] = v;
+        }
+    }
+}
+hipError_t launch_repack(const float* params, const int* map, void* dst, size_t n, int bf16, hipStream_t stream) {
+    const size_t blocks = (n + 255) / 256;
+    hipLaunchKernelGGL(k_repack, dim3((unsigned)(blocks < 4096 ? blocks : 4096)), dim3(256), 0, stream, params, map, dst, n, bf16);
+    return hipGetLastError();
+}
+
 hipError_t launch_add_noise(const float* z0, const float* noise, const float* sa, const float* sb, float* out, int B,
                             hipStream_t stream) {
     hipLaunchKernelGGL(k_add_noise, dim3(B), dim3(128), 0, stream, z0, noise, sa, sb, out);

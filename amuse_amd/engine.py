@@ -16,6 +16,17 @@ PREC = {"fp32": _lib.PREC_F32, "f32": _lib.PREC_F32, "bf16": _lib.PREC_BF16}
 QUAT = {"p3d": _lib.QUAT_P3D, "legacy": _lib.QUAT_LEGACY}
 
 
+def flatten_on_device(sd: Dict[str, torch.Tensor], spec) -> torch.Tensor:
+    """The same layout from a module's CUDA state dict, without leaving the device (one torch.cat)."""
+    parts = []
+    for k, shape in spec.items():
+        v = sd[k]
+        if tuple(v.shape) != tuple(shape):
+            raise ValueError(f"shape mismatch for {k}: {tuple(v.shape)} vs {tuple(shape)}")
+        parts.append(v.detach().reshape(-1).to(torch.float32))
+    return torch.cat(parts)
+
+
 def flatten_state_dict(sd: Dict[str, np.ndarray], spec) -> np.ndarray:
     """Concatenate tensors in state-dict order (the layout amuse_create expects)."""
     parts = []
@@ -71,6 +82,21 @@ class HipEngine:
                                                      pri.ctypes.data_as(fp) if pri is not None else None,
                                                      0 if pri is None else pri.size, int(what), self._stream()))
         if den is not None and self.schedule is not None:
+            self.set_schedule(self.schedule)
+
+    def update_weights_device(self, denoiser_flat: Optional[torch.Tensor] = None, prior_flat: Optional[torch.Tensor] = None, what: int = 7):
+        """amuse_update_weights_device: the same from flat float32 CUDA tensors in state-dict order (flatten_on_device) - a gather
+        kernel per packed image, stream-ordered, no host round trip.  The current schedule is re-applied after a denoiser update."""
+        def ptr(t, n):
+            if t is None:
+                return None
+            if not (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous() and t.numel() == n):
+                raise ValueError(f"expected a contiguous float32 CUDA tensor of {n} elements")
+            return C.c_void_p(t.data_ptr())
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.amuse_update_weights_device(self.ctx, ptr(denoiser_flat, 2192384), ptr(prior_flat, 4643277),   # AMUSE_DENOISER_PARAMS / AMUSE_PRIOR_PARAMS
+                                                            int(what), self._stream()))
+        if denoiser_flat is not None and self.schedule is not None:
             self.set_schedule(self.schedule)
 
     def close(self):

@@ -17,7 +17,7 @@ One process per GPU (torch.distributed, backend "nccl" = RCCL over xGMI; "gloo" 
 What runs where.  The two networks under autograd are plain torch modules (amuse_amd/nn_modules.py - the reference's
 networks key for key).  The no-gradient half of the iteration - the in-loop DDIM-50 sampler (51 denoiser passes in the
 reference) and the decode of its result - is the inference hot path, so it runs on the HIP kernels (amuse_sample +
-amuse_vae_decode) on the weights of the current iteration (amuse_update_weights re-packs them; `sampler_refresh` > 1
+amuse_vae_decode) on the weights of the current iteration (amuse_update_weights_device re-packs them on the GPU; `sampler_refresh` > 1
 re-packs every n-th iteration only).  Two stated differences there: the HIP sampler has eval semantics (the reference
 leaves dropout live in its inner sampler because the modules are in train mode, trainer.py:357-358) and draws its initial
 latent from the counter-based generator; the term it feeds, gen_feature, carries no gradient (it is computed under no_grad
@@ -26,8 +26,7 @@ in the reference too) - it is logged and added to `total`, nothing else.
 Gradient exchange.  All parameters' gradients live in ONE flat fp32 buffer (6,835,661 elements, 27.3 MB; every p.grad is
 a view into it), so the data-parallel step is a single all-reduce(SUM) of that buffer followed by a scale by 1 / world.
 xGMI is point-to-point (7 links per GPU): one 27 MB collective per iteration is the bucket size that keeps every link busy
-with large messages; there is nothing to overlap it with (it needs the complete backward pass) except the HIP weight
-re-pack of the previous step, which is host work.
+with large messages; there is nothing to overlap it with (it needs the complete backward pass).
 """
 from __future__ import annotations
 
@@ -335,6 +334,7 @@ class HipInnerSampler:
         self.engine.set_schedule(sch.from_ldm_cfg(ldm_cfg, "ddim") if ldm_cfg and "scheduler" in ldm_cfg else sch.ddim_table())
         self.calls, self.clip_counter, self.sync_ms = 0, 0, []
         self.what = (2 if precision == "bf16" else 1)
+        self.on_device = os.environ.get("AMUSE_TRAIN_REPACK", "device") != "host"   # A/B switch: the host path of amuse_update_weights
 
     def _den_state(self):
         return {k: v.detach().cpu().numpy() for k, v in self.models["ldm"].denoiser.state_dict().items()}
@@ -345,7 +345,15 @@ class HipInnerSampler:
     def __call__(self, con, emo, sty, bsz):
         if self.calls % self.refresh == 0 and self.calls > 0:
             t0 = time.perf_counter()
-            self.engine.update_weights(self._den_state(), self._prior_state(), what=self.what)
+            if self.on_device:
+                # the weights never leave the GPU: one torch.cat per network, then a gather kernel per packed image
+                from .engine import flatten_on_device
+                from . import weights as wts
+                den = flatten_on_device(self.models["ldm"].denoiser.state_dict(), wts.denoiser_param_spec())
+                pri = flatten_on_device(self.models["prior"].state_dict(), wts.prior_param_spec())
+                self.engine.update_weights_device(den, pri, what=self.what)
+            else:
+                self.engine.update_weights(self._den_state(), self._prior_state(), what=self.what)
             self.sync_ms.append((time.perf_counter() - t0) * 1e3)
         self.calls += 1
         lat = self.engine.sample(con, emo, sty, self.precision, seed=self.seed, clip_index0=self.clip_counter)

@@ -37,6 +37,7 @@ hipError_t launch_sample(const SampleArgs&, int, hipStream_t) { return hipSucces
 hipError_t launch_sample8(const SampleArgs&, hipStream_t) { return hipSuccess; }
 hipError_t launch_time_tokens(const int*, int, const float*, const float*, const float*, const float*, const float*, const float*, float*, hipStream_t) { return hipSuccess; }
 hipError_t launch_cond_tokens(const CondArgs&, hipStream_t) { return hipSuccess; }
+hipError_t launch_repack(const float*, const int*, void*, size_t, int, hipStream_t) { return hipSuccess; }
 hipError_t launch_add_noise(const float*, const float*, const float*, const float*, float*, int, hipStream_t) { return hipSuccess; }
 hipError_t launch_counter_normal(uint64_t, uint64_t, int, int, int, float*, hipStream_t) { return hipSuccess; }
 hipError_t launch_vae_rows(const VaeRowsArgs&, int, bool, hipStream_t) { return hipSuccess; }

@@ -90,6 +90,11 @@ int main(int argc, char** argv) {
     REQUIRE(amuse_update_weights(c, den.data(), den.size(), nullptr, 0, AMUSE_UPD_BF16, nullptr) == 0);
     REQUIRE(amuse_update_weights(c, nullptr, 0, pri.data(), pri.size(), AMUSE_UPD_ALL, nullptr) == 0);
     REQUIRE(amuse_update_weights(c, den.data(), 5, nullptr, 0, AMUSE_UPD_ALL, nullptr) != 0);
+    // the device re-pack: builds the gather maps (three probe runs of both builders through the capture hook) on its first call
+    for (int what : {2, 7, 1, 6}) REQUIRE(amuse_update_weights_device(c, den.data(), pri.data(), what, nullptr) == 0);
+    REQUIRE(amuse_update_weights_device(c, den.data(), nullptr, 2, nullptr) == 0);
+    REQUIRE(amuse_update_weights_device(c, nullptr, nullptr, 2, nullptr) != 0);
+    REQUIRE(amuse_update_weights_device(c, den.data(), pri.data(), 4, nullptr) != 0);
     amuse_destroy(c);
     amuse_destroy(nullptr);
     if (with_audio) {

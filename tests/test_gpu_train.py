@@ -37,6 +37,48 @@ def test_update_weights_equals_a_fresh_context():
     a.close(); b.close()
 
 
+def test_update_weights_device_equals_the_host_path():
+    """amuse_update_weights_device (a gather kernel per packed image, maps learnt from probe runs of the builders) leaves the
+    context bitwise where amuse_update_weights / a fresh context on the same values leave it: every mask, both networks, either alone."""
+    from amuse_amd import scheduler as sch, weights as wts
+    from amuse_amd.engine import HipEngine, flatten_state_dict
+    w0 = (wts.make_denoiser_weights(0), wts.make_prior_weights(0))
+    w1 = (wts.make_denoiser_weights(1), wts.make_prior_weights(1))
+    flat = lambda w: (torch.from_numpy(flatten_state_dict(w[0], wts.denoiser_param_spec())).cuda(),
+                      torch.from_numpy(flatten_state_dict(w[1], wts.prior_param_spec())).cuda())
+    f0, f1 = flat(w0), flat(w1)
+    a, b = HipEngine(*w0), HipEngine(*w1)
+    for e in (a, b):
+        e.set_schedule(sch.ddim_table())
+    gen = torch.Generator().manual_seed(0)
+    c, em, s, x = (torch.randn(100, n, generator=gen) for n in (256, 256, 256, 128))
+    before = a.sample(c, em, s, "bf16", x_init=x)
+    a.update_weights_device(*f1)
+    for prec in ("fp32", "bf16"):
+        la, lb = a.sample(c, em, s, prec, x_init=x), b.sample(c, em, s, prec, x_init=x)
+        assert torch.equal(la, lb), prec
+        da, db = a.vae_decode(la, None, prec, return_feats=True), b.vae_decode(lb, None, prec, return_feats=True)
+        assert torch.equal(da["feats"], db["feats"]) and torch.equal(da["poses"], db["poses"]), prec
+        assert torch.equal(a.vae_decode(la[:4], [300, 17, 160, 1], prec)["poses"], b.vae_decode(lb[:4], [300, 17, 160, 1], prec)["poses"])
+        f = torch.randn(2, 300, 333, generator=gen)
+        assert torch.equal(a.vae_encode(f, None, prec)["mu"], b.vae_encode(f, None, prec)["mu"])
+        assert torch.equal(a.denoise_step(x, 501, c, em, s, prec), b.denoise_step(x, 501, c, em, s, prec))
+    # bf16 streams only, the denoiser alone, the prior alone
+    a.update_weights_device(*f0, what=2)
+    assert torch.equal(a.sample(c, em, s, "bf16", x_init=x), before)
+    a.update_weights_device(f1[0], None, what=2)
+    assert torch.equal(a.sample(c, em, s, "bf16", x_init=x), b.sample(c, em, s, "bf16", x_init=x))
+    lat = b.sample(c, em, s, "bf16", x_init=x)
+    assert not torch.equal(a.vae_decode(lat, None, "bf16")["poses"], b.vae_decode(lat, None, "bf16")["poses"])   # (prior still w0)
+    a.update_weights_device(None, f1[1], what=2)
+    assert torch.equal(a.vae_decode(lat, None, "bf16")["poses"], b.vae_decode(lat, None, "bf16")["poses"])
+    with pytest.raises(Exception):
+        a.update_weights_device(None, None)
+    with pytest.raises(ValueError):
+        a.update_weights_device(f1[0][:-1], None)
+    a.close(); b.close()
+
+
 def test_train_step_with_hip_inner_sampler():
     from amuse_amd.engine import HipEngine
     from amuse_amd.train_gesture import build_trainer, synthetic_batch
