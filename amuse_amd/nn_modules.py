@@ -147,11 +147,22 @@ class Denoiser(nn.Module):
         return (tokens[: sample.shape[0]].permute(1, 0, 2),)
 
 
+_MASKS = {}
+
+
 def lengths_to_mask(lengths: Sequence[int], device, max_len: Optional[int] = None) -> torch.Tensor:
-    """temos_utils.py: True where the frame is valid."""
-    lengths = torch.as_tensor(list(lengths), device=device)
-    max_len = max_len or int(lengths.max())
-    return torch.arange(max_len, device=device)[None, :] < lengths[:, None]
+    """temos_utils.py: True where the frame is valid.  Cached per (lengths, device): the list -> tensor upload is a host-to-device copy,
+    which a HIP-graph capture of the training step (train_gesture.py) must not contain; the callers never modify the mask."""
+    key = (tuple(int(v) for v in lengths), str(device), max_len)
+    m = _MASKS.get(key)
+    if m is None:
+        lt = torch.as_tensor(list(key[0]), device=device)
+        n = max_len or int(max(key[0]))
+        m = torch.arange(n, device=device)[None, :] < lt[:, None]
+        if len(_MASKS) > 64:
+            _MASKS.clear()
+        _MASKS[key] = m
+    return m
 
 
 class MotionPrior(nn.Module):
