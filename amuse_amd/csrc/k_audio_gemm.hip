@@ -8,8 +8,8 @@
 //     packed the same way on the host, so every DMA instruction copies 1 KiB of whole cache lines straight into fragment order
 //     and every fragment read is a lane-linear ds_read_b128.  (Gathering fragments from row-major rows - sixteen 64-byte pieces per
 //     instruction - delivered 8.4 TB/s over the chip and capped the kernel at 650 TFLOP/s, where every earlier variant had stalled.)
-//   * 256 features x 128 tokens per workgroup, k-steps of 32: a stage is 24 fragments (24 KiB), a ring of three stages per
-//     workgroup, TWO persistent workgroups per CU (one's barrier and epilogue run under the other's MFMAs).  Four waves of
+//   * 256 features x 128 tokens per workgroup (128 x 128 with a deeper ring for launches of few tiles), k-steps of 32: a stage is
+//     24 fragments (24 KiB), a ring of three stages per workgroup, TWO persistent workgroups per CU (one's barrier and epilogue run under the other's MFMAs).  Four waves of
 //     128 x 64: 128 accumulator registers, 12 fragment reads per 32 MFMAs.
 //   * the fragments of stage s + 1 are read into registers WHILE stage s is multiplied (a W fragment right behind its four MFMAs,
 //     the X fragments into a second set), so no LDS round trip is exposed.  The one barrier per stage certifies that stage s + 1 has
@@ -35,14 +35,16 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 #ifndef AMUSE_GEMM_CG
 #define AMUSE_GEMM_CG 3   // feature tiles per column group of the tile walk (measured: 3 beats 6 and the plain row-major walk by 1.5 %)
 #endif
-constexpr int TN = kGemmTN, TM = kGemmTM, BK = 32;
-constexpr int WFR = TN / 16, XFR = TM / 16, SFR = WFR + XFR;   // fragments per stage: 16 + 8
-constexpr int STAGE = SFR * 1024;
-// ring depth NSLOT: 3 stages = 74,752 B with the bias tile - two workgroups per CU, the production shape; 6 stages = 148,480 B for
-// launches of few tiles (one or two clips: every workgroup has a CU to itself and walks its whole K extent alone, so what paces it
-// is the fetch latency - five stages in flight instead of two: one clip 2.74 -> 2.58 ms for the three encoders).  Same arithmetic either way.
-constexpr int gemm_lds(int nslot) { return nslot * STAGE + 1024; }
-constexpr int kDeepTiles = 128;   // launches of at most this many tiles use the 6-stage ring
+constexpr int TM = kGemmTM, BK = 32, XFR = TM / 16;
+// Two shapes of the same kernel (identical arithmetic per output element: k-steps of 32 in order):
+//   FX = 8  256-feature tiles, a wave holds 8 W fragments; stage = 16 W + 8 X fragments (24 KiB), ring of 3 = 74,752 B with the bias
+//           tile - two workgroups per CU: the production shape;
+//   FX = 4  128-feature tiles, stage = 8 + 8 fragments (16 KiB), ring of 9 = 148,480 B - for launches of few tiles (one or two
+//           clips): every workgroup has a CU to itself and walks its whole K extent alone, so what paces it is the fetch latency;
+//           twice the workgroups and eight stages in flight instead of two.
+constexpr int gemm_stage(int fx) { return (2 * fx + XFR) * 1024; }
+constexpr int gemm_lds(int nslot, int fx) { return nslot * gemm_stage(fx) + 1024; }
+constexpr int kDeepTiles = 128;   // launches of at most this many 256-feature tiles use the narrow, deep shape
 
 __device__ __forceinline__ unsigned pack2(float a, float b) {
     typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -65,17 +67,19 @@ __device__ __forceinline__ void glds16s(const void* sbase, unsigned voff, unsign
 
 // vector-memory operations of an epilogue that may still be in flight when the next tile's first two stages wait (exact and
 // unconditional per wave; 0 = those stages wait strictly)
-template <int EPI>
+template <int EPI, int FX>
 constexpr int epi_stores() {
-    return (EPI == EPI_BF16 || EPI == EPI_GELU_BF16) ? 16 : (EPI == EPI_RESID_F32 || EPI == EPI_F32) ? 32 : 0;
+    return ((EPI == EPI_BF16 || EPI == EPI_GELU_BF16) ? 16 : (EPI == EPI_RESID_F32 || EPI == EPI_F32) ? 32 : 0) * FX / 8;
 }
 
-template <int EPI, int NSLOT>
+template <int EPI, int NSLOT, int FX>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_gemm_tm(GemmArgs a) {
-    constexpr int kOffBias = NSLOT * STAGE;   // [256] float: the bias of the current tile's features
+    constexpr int TN = 32 * FX, WFR = 2 * FX, STAGE = gemm_stage(FX);   // features per tile, W fragments per stage
+    constexpr int WP = FX / 2, PW = WP + 2;                             // this wave's W pieces / all its DMA pieces per stage
+    constexpr int kOffBias = NSLOT * STAGE;                             // [TN] float: the bias of the current tile's features
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6), g = lane >> 4, j = lane & 15;
-    const int wf = wave >> 1, wr = wave & 1;   // feature half (128), token half (64) of the tile
+    const int wf = wave >> 1, wr = wave & 1;   // feature half (16 FX), token half (64) of the tile
     const int N = a.N;
     const int tiles_n = N / TN, tiles_m = (a.M + TM - 1) / TM, n_tiles = tiles_n * tiles_m, nk = a.K / BK;
     // PERSISTENT: workgroup w computes tiles w, w + grid, ...; consecutive tiles walk the N tiles of one M tile.  Workgroups are dealt
@@ -85,8 +89,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     if (wg >= n_tiles) return;
     const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) const void*)smem;
     const unsigned voff = lane * 16;
-    // fetch cursor (wave-uniform): the stage fetched next = k-step f_k of tile f_tile into slot f_slot.  This wave's six DMA pieces
-    // of a stage: W fragment rows 4 wave .. + 3 (pieces 0..3), X fragment rows 2 wave, + 1 (pieces 4, 5).
+    // fetch cursor (wave-uniform): the stage fetched next = k-step f_k of tile f_tile into slot f_slot.  This wave's PW DMA pieces
+    // of a stage: W fragment rows WP wave .. + WP - 1, X fragment rows 2 wave, + 1.
     int f_tile = wg, f_k = 0, f_slot = 0;
     const size_t frag_row = (size_t)nk * 1024;   // bytes between consecutive fragment rows of a packed / tile-major operand
     const char *fw, *fx;
@@ -97,14 +101,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     auto tile_tm = [&](int tile) { return (tile % (tiles_m * cg)) / cg; };
     auto tile_tn = [&](int tile) { return (tile / (tiles_m * cg)) * cg + tile % cg; };
     auto cursor = [&]() {
-        fw = reinterpret_cast<const char*>(a.W) + (size_t)(tile_tn(f_tile) * WFR + 4 * wave) * frag_row;
+        fw = reinterpret_cast<const char*>(a.W) + (size_t)(tile_tn(f_tile) * WFR + WP * wave) * frag_row;
         fx = reinterpret_cast<const char*>(a.A) + (size_t)(tile_tm(f_tile) * XFR + 2 * wave) * frag_row;
     };
     cursor();
     auto fetch_piece = [&](int i) {
         const unsigned d = lds0 + f_slot * STAGE;
-        if (i < 4) glds16s(fw + i * frag_row + (size_t)f_k * 1024, voff, d + (4 * wave + i) * 1024);
-        else glds16s(fx + (i - 4) * frag_row + (size_t)f_k * 1024, voff, d + (WFR + 2 * wave + i - 4) * 1024);
+        if (i < WP) glds16s(fw + i * frag_row + (size_t)f_k * 1024, voff, d + (WP * wave + i) * 1024);
+        else glds16s(fx + (i - WP) * frag_row + (size_t)f_k * 1024, voff, d + (WFR + 2 * wave + i - WP) * 1024);
     };
     auto fetch_advance = [&]() {
         f_slot = f_slot == NSLOT - 1 ? 0 : f_slot + 1;
@@ -118,42 +122,42 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
     for (int s = 0; s < NSLOT; ++s) {
 #pragma unroll
-        for (int i = 0; i < 6; ++i) fetch_piece(i);
+        for (int i = 0; i < PW; ++i) fetch_piece(i);
         fetch_advance();
     }
-    asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(6 * (NSLOT - 1)) : "memory");
-    bf16x8 wc[8], xa[4], xb[4];
+    asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(PW * (NSLOT - 1)) : "memory");
+    bf16x8 wc[FX], xa[4], xb[4];
     {
         const char* sl = smem + lane * 16;
 #pragma unroll
         for (int y = 0; y < 4; ++y) xa[y] = *reinterpret_cast<const bf16x8*>(sl + (WFR + 4 * wr + y) * 1024);
 #pragma unroll
-        for (int x = 0; x < 8; ++x) wc[x] = *reinterpret_cast<const bf16x8*>(sl + (8 * wf + x) * 1024);
+        for (int x = 0; x < FX; ++x) wc[x] = *reinterpret_cast<const bf16x8*>(sl + (FX * wf + x) * 1024);
     }
     int r_slot = 1;
-    constexpr int SN = epi_stores<EPI>();
-    f32x4 acc[8][4];   // [feature fragment][token fragment]
+    constexpr int SN = epi_stores<EPI, FX>();
+    f32x4 acc[FX][4];   // [feature fragment][token fragment]
     // one k-step: xc = this stage's X fragments (registers), xn receives the next stage's
     // swapped: the X fragment is the MFMA's A operand, so a lane ends up with 4 consecutive TOKENS of one feature (the V^T tiles)
     auto half = [&](auto relaxed, auto swapped, bf16x8 (&xc)[4], bf16x8 (&xn)[4], int bias_tile) {
-        constexpr int WAITN = 6 * (NSLOT - 2) + (decltype(relaxed)::value ? SN : 0);
+        constexpr int WAITN = PW * (NSLOT - 2) + (decltype(relaxed)::value ? SN : 0);
         static_assert(WAITN < 64, "vmcnt is a 6-bit counter");
         // this wave's pieces of the NEXT stage have landed (the NSLOT - 2 younger stages may still fly) and its reads of this stage are in
         // registers; behind the barrier that holds for every wave: the next stage is complete, this stage's slot is free
         asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(WAITN) : "memory");
         if (bias_tile >= 0 && wave == 0)   // (every wave's epilogue reads of the previous tile's bias are in front of this barrier)
-            glds16s(a.bias + (size_t)bias_tile * TN, voff, lds0 + kOffBias);
+            glds16s(a.bias + (size_t)bias_tile * TN, (lane % (TN / 4)) * 16, lds0 + kOffBias);   // (TN = 128: the upper lanes repeat the lower half)
         const char* sl = smem + r_slot * STAGE + lane * 16;
 #pragma unroll
         for (int y = 0; y < 4; ++y) xn[y] = *reinterpret_cast<const bf16x8*>(sl + (WFR + 4 * wr + y) * 1024);
 #pragma unroll
-        for (int x = 0; x < 8; ++x) {
+        for (int x = 0; x < FX; ++x) {
 #pragma unroll
             for (int y = 0; y < 4; ++y)
                 acc[x][y] = decltype(swapped)::value ? mfma_bf16(xc[y], wc[x], acc[x][y]) : mfma_bf16(wc[x], xc[y], acc[x][y]);
-            wc[x] = *reinterpret_cast<const bf16x8*>(sl + (8 * wf + x) * 1024);
-            if (x < 6) fetch_piece(x);
-            if (x == 7) fetch_advance();
+            wc[x] = *reinterpret_cast<const bf16x8*>(sl + (FX * wf + x) * 1024);
+            if (x < PW) fetch_piece(x);
+            if (x == FX - 1) fetch_advance();
             __builtin_amdgcn_sched_barrier(0);   // (keeps the scheduler from hoisting every read to the top: 48 more live registers)
         }
         r_slot = r_slot == NSLOT - 1 ? 0 : r_slot + 1;
@@ -162,7 +166,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     for (int tile = wg; tile < n_tiles; tile += gridDim.x) {
         const int tm = tile_tm(tile), tn = tile_tn(tile);
 #pragma unroll
-        for (int x = 0; x < 8; ++x)
+        for (int x = 0; x < FX; ++x)
 #pragma unroll
             for (int y = 0; y < 4; ++y) acc[x][y] = splat4(0.f);
         const bool vt_tile = EPI == EPI_QKV && tn >= 2 * kAstDim / TN;   // (uniform)
@@ -190,18 +194,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         }
         first = false;
         // ---- epilogue: lane (g, j): token row m0 + 16 y + j, features n0 + 32 p + 8 g .. + 7 = acc[2 p][y], acc[2 p + 1][y]
-        const int m0 = tm * TM + 64 * wr, n0 = tn * TN + 128 * wf;
+        const int m0 = tm * TM + 64 * wr, n0 = tn * TN + 16 * FX * wf;
         if (EPI == EPI_QKV && vt_tile) {
             // V^T (swapped MFMAs): lane (g, j) holds row j of feature fragment x - V^T row 16 F + j, F = the fragment's index among
             // the 48 of v - and tokens 16 y + 4 g + m of the wave's 64-row span.  Key SLOT order inside 32 keys: key 16 a + 4 g + m ->
             // slot 8 g + 4 a + m (the order the attention's P operand comes out of its S^T MFMA in), so a lane's values of the
             // fragment pair y = 2 Y, 2 Y + 1 are 8 consecutive slots and the wave's store is one whole tile of the matrix
             // [B * 768][1216].  A 64-row span lies inside one clip (1216 = 19 * 64).
-            const float* bw = reinterpret_cast<const float*>(smem + kOffBias) + 128 * wf;
+            const float* bw = reinterpret_cast<const float*>(smem + kOffBias) + 16 * FX * wf;
             const int b = m0 / kAstRows, tok0 = m0 - b * kAstRows;
             if (m0 >= a.M) continue;   // (the pad half of the last row tile: no clip owns it)
 #pragma unroll
-            for (int x = 0; x < 8; ++x) {
+            for (int x = 0; x < FX; ++x) {
                 const float bv = bw[32 * (x >> 1) + 8 * (j >> 2) + 4 * (x & 1) + (j & 3)];   // fragment row j <-> this feature (pack_w)
                 const size_t rt = (size_t)b * (kAstDim / 16) + ((n0 - 2 * kAstDim) >> 4) + x;   // row tile of the V^T matrix
 #pragma unroll
@@ -212,13 +216,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             }
             continue;
         }
-        const float* bl = reinterpret_cast<const float*>(smem + kOffBias) + 128 * wf + 8 * g;
+        const float* bl = reinterpret_cast<const float*>(smem + kOffBias) + 16 * FX * wf + 8 * g;
 #pragma unroll
         for (int y = 0; y < 4; ++y) {
             const size_t tile0 = (size_t)((m0 >> 4) + y) * (N >> 5) + (n0 >> 5);   // tile-major outputs: tile index of p = 0
             const size_t row = (size_t)m0 + 16 * y + j;
 #pragma unroll
-            for (int p = 0; p < 4; ++p) {
+            for (int p = 0; p < FX / 2; ++p) {
                 const int n = n0 + 32 * p + 8 * g;
                 f32x4 v0 = acc[2 * p][y] + ld4(bl + 32 * p), v1 = acc[2 * p + 1][y] + ld4(bl + 32 * p + 4);
                 if constexpr (EPI == EPI_BF16 || EPI == EPI_GELU_BF16) {
@@ -261,30 +265,31 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the surplus fetches must not outlive the workgroup's LDS
 }
 
-template <int EPI, int NSLOT>
+template <int EPI, int NSLOT, int FX>
 hipError_t launch_gemm_n(const GemmArgs& a, int n_tiles, hipStream_t s) {
     static bool attr = false;
     if (!attr) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_tm<EPI, NSLOT>), hipFuncAttributeMaxDynamicSharedMemorySize, gemm_lds(NSLOT));
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_tm<EPI, NSLOT, FX>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           gemm_lds(NSLOT, FX));
         if (e != hipSuccess) return e;
         attr = true;
     }
     const int resident = 2 * 256;   // two workgroups per CU, 256 CUs
-    hipLaunchKernelGGL((k_gemm_tm<EPI, NSLOT>), dim3(n_tiles < resident ? n_tiles : resident), dim3(256), gemm_lds(NSLOT), s, a);
+    hipLaunchKernelGGL((k_gemm_tm<EPI, NSLOT, FX>), dim3(n_tiles < resident ? n_tiles : resident), dim3(256), gemm_lds(NSLOT, FX), s, a);
     return hipGetLastError();
 }
 template <int EPI>
 hipError_t launch_gemm_t(const GemmArgs& a, hipStream_t s) {
-    const int n_tiles = ((a.M + TM - 1) / TM) * (a.N / TN);
+    const int tiles_m = (a.M + TM - 1) / TM, n_tiles = tiles_m * (a.N / kGemmTN);
     static const bool no_deep = [] { const char* e = getenv("AMUSE_GEMM_DEEP"); return e && atoi(e) == 0; }();
-    if (n_tiles <= kDeepTiles && !no_deep) return launch_gemm_n<EPI, 6>(a, n_tiles, s);
-    return launch_gemm_n<EPI, 3>(a, n_tiles, s);
+    if (n_tiles <= kDeepTiles && !no_deep) return launch_gemm_n<EPI, 9, 4>(a, 2 * n_tiles, s);
+    return launch_gemm_n<EPI, 3, 8>(a, n_tiles, s);
 }
 
 }  // namespace
 
 hipError_t launch_gemm(const GemmArgs& a, int epi, hipStream_t s) {
-    if (a.N % TN || a.K % (2 * BK) || a.M < 1) return hipErrorInvalidValue;
+    if (a.N % kGemmTN || a.K % (2 * BK) || a.M < 1) return hipErrorInvalidValue;
     switch (epi) {
         case EPI_BF16: return launch_gemm_t<EPI_BF16>(a, s);
         case EPI_GELU_BF16: return launch_gemm_t<EPI_GELU_BF16>(a, s);

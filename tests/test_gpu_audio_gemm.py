@@ -85,6 +85,30 @@ def test_gemm_matches_fp32_product_of_the_bf16_operands(lib, M, N, K):
     assert torch.equal(o16, o32.to(torch.bfloat16))
 
 
+def test_small_launch_shape_is_bitwise_the_production_shape(lib):
+    """Launches of few tiles run 128-feature tiles with a nine-stage ring, large ones 256-feature tiles with three stages: a row's
+    result must not depend on which (the audio front-end's features do not depend on the batch size)."""
+    L = lib.load()
+    g = torch.Generator(device="cuda").manual_seed(3)
+    for (N, K) in ((768, 3072), (2304, 768)):
+        Mbig, Msmall = 128 * 70, 1216                                   # 210+ tiles against <= 90 tiles of 256 features
+        a = torch.randn(Mbig, K, device="cuda", generator=g).to(torch.bfloat16)
+        w = (torch.randn(N, K, device="cuda", generator=g) / K ** 0.5).to(torch.bfloat16)
+        bias = torch.randn(N, device="cuda", generator=g)
+        wpk = _pack_w(w)
+        outs = []
+        for M in (Mbig, Msmall):
+            Mp = (M + 127) // 128 * 128
+            at = torch.empty(Mp * K, device="cuda", dtype=torch.bfloat16)
+            lib.check(L.amuse_debug_tile(_p(a[:M].contiguous()), _p(at), M, K, 0, None))
+            ot = torch.empty(Mp * N, device="cuda", dtype=torch.float32)
+            lib.check(L.amuse_debug_gemm(_p(at), _p(wpk), _p(bias), M, N, K, 3, _p(ot), None))
+            o = torch.empty(M, N, device="cuda", dtype=torch.float32)
+            lib.check(L.amuse_debug_tile(_p(ot), _p(o), M, N, 2, None))
+            outs.append(o)
+        assert torch.equal(outs[0][:Msmall], outs[1])
+
+
 def test_gemm_rejects_bad_shapes(lib):
     L = lib.load()
     x = torch.zeros(128 * 64, device="cuda", dtype=torch.bfloat16)
