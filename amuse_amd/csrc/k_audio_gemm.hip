@@ -281,8 +281,8 @@ hipError_t launch_gemm_n(const GemmArgs& a, int n_tiles, hipStream_t s) {
 template <int EPI>
 hipError_t launch_gemm_t(const GemmArgs& a, hipStream_t s) {
     const int tiles_m = (a.M + TM - 1) / TM, n_tiles = tiles_m * (a.N / kGemmTN);
-    static const bool no_deep = [] { const char* e = getenv("AMUSE_GEMM_DEEP"); return e && atoi(e) == 0; }();
-    if (n_tiles <= kDeepTiles && !no_deep) return launch_gemm_n<EPI, 9, 4>(a, 2 * n_tiles, s);
+    static const int deep_tiles = [] { const char* e = getenv("AMUSE_GEMM_DEEP"); return e ? atoi(e) : kDeepTiles; }();   // (0: never)
+    if (n_tiles <= deep_tiles) return launch_gemm_n<EPI, 9, 4>(a, 2 * n_tiles, s);
     return launch_gemm_n<EPI, 3, 8>(a, n_tiles, s);
 }
 
