@@ -735,7 +735,11 @@ int amuse_update_weights_device(amuse_ctx* c, const float* denoiser_params_dev, 
         if ((r.cls & what) != r.cls) continue;          // every bit the image needs must be requested
         HIP_TRY(launch_repack(src, r.map, *r.slot, r.n, r.bf16, (hipStream_t)stream));
     }
-    if (denoiser_params_dev) c->T = 0;   // the hoisted time-token table belongs to the old time-embedding weights: set the schedule again
+    // the hoisted time-token table belongs to the old time-embedding weights: rebuilt here, stream-ordered, from the schedule's
+    // timesteps (still on the device) - no host round trip, the schedule stays set
+    if (denoiser_params_dev && c->T > 0)
+        HIP_TRY(launch_time_tokens(c->d_timesteps, c->T, c->den_freqs, c->te_w1t, c->te_b1, c->te_w2t, c->te_b2, c->den_pe + kD, c->d_time_tok,
+                                   (hipStream_t)stream));
     return 0;
 }
 

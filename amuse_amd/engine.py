@@ -86,7 +86,7 @@ class HipEngine:
 
     def update_weights_device(self, denoiser_flat: Optional[torch.Tensor] = None, prior_flat: Optional[torch.Tensor] = None, what: int = 7):
         """amuse_update_weights_device: the same from flat float32 CUDA tensors in state-dict order (flatten_on_device) - a gather
-        kernel per packed image, stream-ordered, no host round trip.  The current schedule is re-applied after a denoiser update."""
+        kernel per packed image, stream-ordered, no host round trip; the library rebuilds the schedule's time-token table itself."""
         def ptr(t, n):
             if t is None:
                 return None
@@ -96,8 +96,6 @@ class HipEngine:
         with torch.cuda.device(self.device):
             _lib.check(self.lib.amuse_update_weights_device(self.ctx, ptr(denoiser_flat, 2192384), ptr(prior_flat, 4643277),   # AMUSE_DENOISER_PARAMS / AMUSE_PRIOR_PARAMS
                                                             int(what), self._stream()))
-        if denoiser_flat is not None and self.schedule is not None:
-            self.set_schedule(self.schedule)
 
     def close(self):
         if getattr(self, "ctx", None):

@@ -95,7 +95,8 @@ int amuse_update_weights(amuse_ctx* ctx, const float* denoiser_params, size_t n_
 /* The same from DEVICE arrays (fp32, state-dict order, as above), stream-ordered on `stream` with no host round trip: every packed
  * image is a gather of the parameters, so a kernel re-packs (and rounds to bf16) in place.  The gather maps are built on the first
  * call.  This is what train_gesture's in-loop sampler uses every iteration (amuse_amd/train_gesture.py): the host path costs
- * 24-26 ms per call.  Results are bitwise those of amuse_update_weights on the same values. */
+ * 24-26 ms per call.  Results are bitwise those of amuse_update_weights on the same values; the schedule stays set (its time-token
+ * table is rebuilt on the stream). */
 int amuse_update_weights_device(amuse_ctx* ctx, const float* denoiser_params_dev, const float* prior_params_dev, int what,
                                 void* stream);
 void amuse_destroy(amuse_ctx* ctx);
