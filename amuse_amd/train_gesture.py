@@ -446,14 +446,21 @@ def bench_main(args):
 
 def main(argv=None):
     import argparse
-    ap = argparse.ArgumentParser(description="train_gesture on synthetic data (the BEAT LMDB reader, dm/dataload.py, is out of scope)")
+    ap = argparse.ArgumentParser(description="train_gesture: the LPDM iteration on the BEAT latent-diffusion cache (--cache, amuse_amd/dataload.py; "
+                                             "needs `lmdb` + a pyarrow with `deserialize`) or on synthetic batches of the same shape")
+    ap.add_argument("--cache", default=None, help="the LMDB cache directory of dm/dataload.py:113-129 (default: synthetic data)")
+    ap.add_argument("--batch", type=int, default=32)
     ap.add_argument("--epochs", type=int, default=1)
     ap.add_argument("--iters-per-epoch", type=int, default=8)
     ap.add_argument("--out", default=None)
     ap.add_argument("--device", default="cuda:0")
     args = ap.parse_args(argv)
     tr = build_trainer(args.device)
-    loader = [synthetic_batch(32, i, args.device) for i in range(args.iters_per_epoch)]
+    if args.cache:
+        from .dataload import LatentDiffusionCache, make_loader
+        loader = make_loader(LatentDiffusionCache.open(args.cache), args.batch)
+    else:
+        loader = [synthetic_batch(args.batch, i, args.device) for i in range(args.iters_per_epoch)]
     tr.train_prior_latdiff_forward_backward_v2(loader, args.epochs, args.out, model_save_freq=1)
 
 
