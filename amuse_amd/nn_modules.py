@@ -8,6 +8,15 @@
   * the forward pass IS the reference's, dropout included (cross_attention.py:259-272,323-345: attention dropout inside
     nn.MultiheadAttention, dropout1/2/3 on the residual branches, dropout between the FFN linears) - pinned in eval mode
     against the golden vectors of the reference modules (tests/test_train_cpu.py).
+
+Layout.  The reference runs sequence-first (S, B, D); every operator but attention is row-wise, so the stacks here run
+batch-first (B, S, D) - the layout in which the packed q|k|v projection splits into (B, H, S, d) views and the attention
+output is already the out_proj input: no transposed copies (the sequence-first nn.MultiheadAttention path made ~10 strided
+copies per layer and iteration, 2.6 ms of device time per training step).  `nn.MultiheadAttention` remains the parameter
+holder (state-dict keys in_proj_weight / in_proj_bias / out_proj.*); its arithmetic - q scaled by 1/sqrt(d), additive
+-inf key-padding mask, softmax, dropout on the probabilities, out_proj - is `mha_self` below.  The decoder's cross-attention
+looks at ONE memory token: the softmax over a single key is exactly 1 whatever q and k are (and their gradients exactly
+zero), so `mha_one_key` computes only the value path, as the HIP decoder does.
 """
 from __future__ import annotations
 
@@ -29,8 +38,33 @@ class LearnedPE(nn.Module):
         self.pe = nn.Parameter(torch.zeros(max_len, 1, d_model))
         nn.init.uniform_(self.pe)
 
-    def forward(self, x):
-        return x + self.pe[: x.shape[0]]
+    def forward(self, x):                                  # x (B, S, D)
+        return x + self.pe[: x.shape[1]].transpose(0, 1)
+
+
+def mha_self(attn: nn.MultiheadAttention, x: torch.Tensor, key_padding_mask: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """nn.MultiheadAttention(x, x, x, key_padding_mask, need_weights=False) on batch-first x (B, S, E); key_padding_mask (B, S)
+    True = ignore that key, None = no padding (F.multi_head_attention_forward: packed in-projection, heads = contiguous
+    E / H slices, scores q k^T / sqrt(d), dropout on the softmax, out_proj)."""
+    B, S, E = x.shape
+    h = attn.num_heads
+    q, k, v = F.linear(x, attn.in_proj_weight, attn.in_proj_bias).view(B, S, 3, h, E // h).unbind(2)
+    mask = None if key_padding_mask is None else ~key_padding_mask[:, None, None, :]
+    o = F.scaled_dot_product_attention(q.transpose(1, 2), k.transpose(1, 2), v.transpose(1, 2), attn_mask=mask,
+                                       dropout_p=attn.dropout if attn.training else 0.0)
+    return F.linear(o.transpose(1, 2).reshape(B, S, E), attn.out_proj.weight, attn.out_proj.bias)
+
+
+def mha_one_key(attn: nn.MultiheadAttention, tgt: torch.Tensor, memory: torch.Tensor) -> torch.Tensor:
+    """nn.MultiheadAttention(tgt, memory, memory) for a memory of one token, batch-first: tgt (B, S, E), memory (B, 1, E).
+    Every query's probability vector is [1]; attention dropout turns it into 0 or 1 / (1 - p) per (clip, head, query)."""
+    B, S, E = tgt.shape
+    h = attn.num_heads
+    v = F.linear(memory, attn.in_proj_weight[2 * E:], attn.in_proj_bias[2 * E:])              # (B, 1, E)
+    if attn.training and attn.dropout > 0:
+        keep = F.dropout(torch.ones(B, S, h, 1, device=tgt.device, dtype=tgt.dtype), attn.dropout, True)
+        return F.linear((keep * v.view(B, 1, h, E // h)).reshape(B, S, E), attn.out_proj.weight, attn.out_proj.bias)
+    return F.linear(v, attn.out_proj.weight, attn.out_proj.bias).expand(B, S, E)
 
 
 class EncoderLayer(nn.Module):
@@ -44,7 +78,7 @@ class EncoderLayer(nn.Module):
         self.norm1, self.norm2 = nn.LayerNorm(d), nn.LayerNorm(d)
 
     def forward(self, src, key_padding_mask=None):
-        src2 = self.self_attn(src, src, src, key_padding_mask=key_padding_mask, need_weights=False)[0]
+        src2 = mha_self(self.self_attn, src, key_padding_mask)
         src = self.norm1(src + self.dropout1(src2))
         src2 = self.linear2(self.dropout(F.gelu(self.linear1(src))))
         return self.norm2(src + self.dropout2(src2))
@@ -62,9 +96,12 @@ class DecoderLayer(nn.Module):
         self.norm1, self.norm2, self.norm3 = nn.LayerNorm(d), nn.LayerNorm(d), nn.LayerNorm(d)
 
     def forward(self, tgt, memory, tgt_key_padding_mask=None):
-        t2 = self.self_attn(tgt, tgt, tgt, key_padding_mask=tgt_key_padding_mask, need_weights=False)[0]
+        t2 = mha_self(self.self_attn, tgt, tgt_key_padding_mask)
         tgt = self.norm1(tgt + self.dropout1(t2))
-        t2 = self.multihead_attn(tgt, memory, memory, need_weights=False)[0]
+        if memory.shape[1] == 1:
+            t2 = mha_one_key(self.multihead_attn, tgt, memory)
+        else:
+            t2 = self.multihead_attn(tgt.transpose(0, 1), memory.transpose(0, 1), memory.transpose(0, 1), need_weights=False)[0].transpose(0, 1)
         tgt = self.norm2(tgt + self.dropout2(t2))
         t2 = self.linear2(self.dropout(F.gelu(self.linear1(tgt))))
         return self.norm3(tgt + self.dropout3(t2))
@@ -133,18 +170,17 @@ class Denoiser(nn.Module):
 
     def forward(self, sample, timestep, con_hidden, emo_hidden=None, sty_hidden=None, lengths=None, **kw):
         """sample (B, 1, 128); timestep (B,) or scalar; *_hidden (B, 256) -> (eps_hat (B, 1, 128),)   (denoiser.py:135-204)."""
-        sample = sample.permute(1, 0, 2)                                   # (1, B, 128)
-        bsz = sample.shape[1]
+        bsz = sample.shape[0]
         timesteps = torch.as_tensor(timestep, device=sample.device).expand(bsz)
-        time_emb = self.time_embedding(timestep_sinusoid(timesteps).to(sample.dtype)).unsqueeze(0)
-        toks = [time_emb, self.emb_proj_con(con_hidden).unsqueeze(0)]
+        time_emb = self.time_embedding(timestep_sinusoid(timesteps).to(sample.dtype)).unsqueeze(1)
+        toks = [time_emb, self.emb_proj_con(con_hidden).unsqueeze(1)]
         if emo_hidden is not None:
-            toks.append(self.emb_proj_emo(emo_hidden).unsqueeze(0))
+            toks.append(self.emb_proj_emo(emo_hidden).unsqueeze(1))
         if sty_hidden is not None:
-            toks.append(self.emb_proj_sty(sty_hidden).unsqueeze(0))
-        xseq = self.query_pos(torch.cat([sample] + toks, dim=0))          # (S, B, 128), latent token first
+            toks.append(self.emb_proj_sty(sty_hidden).unsqueeze(1))
+        xseq = self.query_pos(torch.cat([sample] + toks, dim=1))          # (B, S, 128), latent token first
         tokens = self.encoder(xseq)
-        return (tokens[: sample.shape[0]].permute(1, 0, 2),)
+        return (tokens[:, : sample.shape[1]],)
 
 
 _MASKS = {}
@@ -165,6 +201,10 @@ def lengths_to_mask(lengths: Sequence[int], device, max_len: Optional[int] = Non
     return m
 
 
+def _all_valid(lengths: Sequence[int], n: int) -> bool:
+    return all(int(v) >= n for v in lengths)
+
+
 class MotionPrior(nn.Module):
     """vae.py:24-278 (emotional prior with finger joints: 333 features, 1 latent token, mld learned PE)."""
 
@@ -182,26 +222,28 @@ class MotionPrior(nn.Module):
         if lengths is None:
             lengths = [features.shape[1]] * features.shape[0]
         bs, nframes, _ = features.shape
-        mask = lengths_to_mask(lengths, features.device, nframes)
-        x = self.skel_embedding(features).permute(1, 0, 2)                 # (T, B, 128)
-        dist = self.global_motion_token[:, None, :].expand(-1, bs, -1)     # (2, B, 128)
-        aug_mask = torch.cat([torch.ones(bs, 2, dtype=torch.bool, device=x.device), mask], 1)
-        xseq = self.query_pos_encoder(torch.cat([dist, x], 0))
-        out = self.encoder(xseq, key_padding_mask=~aug_mask)[:2]
-        mu, logvar = out[0:1], out[1:2]
+        x = self.skel_embedding(features)                                  # (B, T, 128)
+        dist = self.global_motion_token[None].expand(bs, -1, -1)           # (B, 2, 128)
+        xseq = self.query_pos_encoder(torch.cat([dist, x], 1))
+        kpm = None
+        if not _all_valid(lengths, nframes):
+            mask = lengths_to_mask(lengths, features.device, nframes)
+            kpm = ~torch.cat([torch.ones(bs, 2, dtype=torch.bool, device=x.device), mask], 1)
+        out = self.encoder(xseq, key_padding_mask=kpm)
+        mu, logvar = out[:, 0][None], out[:, 1][None]                      # (1, B, 128) each
         std = logvar.exp().pow(0.5)
         d = torch.distributions.Normal(mu, std)
         return d.rsample(), d
 
     def decode(self, z, lengths: List[int]):
         """z (1, B, 128) -> feats (B, T, 333), frames beyond a clip's length zeroed   (vae.py:216-278)."""
-        mask = lengths_to_mask(lengths, z.device)
-        bs, nframes = mask.shape
-        queries = self.query_pos_decoder(torch.zeros(nframes, bs, D, device=z.device, dtype=z.dtype))
-        out = self.decoder(queries, z, tgt_key_padding_mask=~mask)
+        bs, nframes = len(lengths), int(max(lengths))
+        queries = self.query_pos_decoder(torch.zeros(bs, nframes, D, device=z.device, dtype=z.dtype))
+        full = _all_valid(lengths, nframes)
+        mask = None if full else lengths_to_mask(lengths, z.device)
+        out = self.decoder(queries, z.transpose(0, 1), tgt_key_padding_mask=None if full else ~mask)
         out = self.final_layer(out)
-        out = out.masked_fill(~mask.T[:, :, None], 0.0)
-        return out.permute(1, 0, 2)
+        return out if full else out.masked_fill(~mask[:, :, None], 0.0)
 
 
 def load_numpy_state(module: nn.Module, sd) -> nn.Module:

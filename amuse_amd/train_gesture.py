@@ -200,15 +200,25 @@ class GestureTrainer:
         # ---- one flat fp32 gradient bucket; every p.grad is a view into it
         n = sum(p.numel() for p in self.params)
         self.flat_grad = torch.zeros(n, device=self.device, dtype=torch.float32)
-        off = 0
+        off, self.views = 0, []
         for p in self.params:
-            p.grad = self.flat_grad[off:off + p.numel()].view_as(p)
+            self.views.append(self.flat_grad[off:off + p.numel()].view_as(p))
+            p.grad = self.views[-1]
             off += p.numel()
         # parameters the iteration never reaches (denoiser.mem_pos.pe: the trans_enc path uses query_pos only) get no
         # gradient in the reference (grad stays None after zero_grad(set_to_none=True)), so its AdamW never touches them -
         # not even with weight decay.  They stay in the bucket (zeros) but out of the optimizer.
         unused = {id(ldm.denoiser.mem_pos.pe)}
-        self.lpdm_opt = torch.optim.AdamW(lr=lr, params=[p for p in self.params if id(p) not in unused])
+        # the multi-tensor ("fused") AdamW of torch on the GPU: the same update in a handful of launches instead of ~10 per
+        # parameter group of the default foreach path (2.7 ms of device time and 4.8 ms of host time per iteration, section 4.6)
+        fused = self.device.type == "cuda" and os.environ.get("AMUSE_TRAIN_OPT", "fused") == "fused"
+        self.lpdm_opt = torch.optim.AdamW(lr=lr, params=[p for p in self.params if id(p) not in unused], **({"fused": True} if fused else {}))
+        self.steal = os.environ.get("AMUSE_TRAIN_GRADS", "steal") == "steal"
+        # the step's ~500 fp32 GEMMs are small (9,664 x 128..512 rows, weight gradients with a 9,664-long reduction): rocBLAS's
+        # choices run them in 9 ms of device time per iteration where hipBLASLt's heuristics take 12.5, at a third of the host
+        # time per call (a process-wide torch setting; AMUSE_TRAIN_BLAS=default leaves it alone)
+        if self.device.type == "cuda" and os.environ.get("AMUSE_TRAIN_BLAS", "rocblas") == "rocblas":
+            torch.backends.cuda.preferred_blas_library("cublas")
         self.allreduce_ms: List[float] = []
 
     def n_grad_elements(self) -> int:
@@ -250,11 +260,27 @@ class GestureTrainer:
             m.train()
         torch.set_grad_enabled(True)
         loss = self.forward_losses(batch, **explicit)
-        self.flat_grad.zero_()                        # zero_grad: the views stay attached to the bucket
-        loss.backward()
+        self.backward_into_bucket(loss)
         self.allreduce_gradients()
         self.lpdm_opt.step()
         return loss.detach()
+
+    def backward_into_bucket(self, loss):
+        """zero_grad + backward with every gradient ending up in the flat bucket.  With p.grad unset autograd hands each
+        parameter its gradient tensor as it is (no 426 read-modify-write adds into zeroed views); one multi-tensor copy then
+        packs them, and p.grad points into the bucket again - what allreduce_gradients and the optimizer read."""
+        if not self.steal:
+            self.flat_grad.zero_()                    # the views stay attached to the bucket; backward accumulates into them
+            loss.backward()
+            return
+        for p in self.params:
+            p.grad = None
+        loss.backward()
+        dst = [v for p, v in zip(self.params, self.views) if p.grad is not None]
+        src = [p.grad for p in self.params if p.grad is not None]
+        torch._foreach_copy_(dst, src)                # parameters backward never reached keep the zeros of their slice
+        for p, v in zip(self.params, self.views):
+            p.grad = v
 
     def allreduce_gradients(self):
         if self.world <= 1:

@@ -102,6 +102,58 @@ def test_loss_set_and_one_training_step(tmp_path):
         build_trainer("cpu", use_hip_sampler=True)                          # the in-loop sampler has no CPU path
 
 
+def test_lean_attention_paths_equal_nn_multihead_attention():
+    """nn_modules.mha_self / mha_one_key (batch-first, no transposed copies, value path only for a one-token memory) against
+    torch's own nn.MultiheadAttention on the sequence-first layout of the reference (cross_attention.py:259-262,323-331):
+    outputs and every gradient, with a ragged key-padding mask; and MotionPrior with ragged lengths against full lengths."""
+    from amuse_amd.nn_modules import MotionPrior, mha_one_key, mha_self
+    torch.manual_seed(3)
+    attn = torch.nn.MultiheadAttention(128, 4, dropout=0.0)
+    x = torch.randn(3, 11, 128, requires_grad=True)
+    kpm = torch.zeros(3, 11, dtype=torch.bool)
+    kpm[1, 7:] = True
+    kpm[2, 10:] = True
+    w = torch.randn(3, 11, 128)
+
+    def grads(out):
+        attn.zero_grad()
+        x.grad = None
+        (out * w).sum().backward()
+        return [x.grad.clone()] + [p.grad.clone() for p in attn.parameters()]
+    xs = x.transpose(0, 1)
+    ref = attn(xs, xs, xs, key_padding_mask=kpm, need_weights=False)[0].transpose(0, 1)
+    got = mha_self(attn, x, kpm)
+    assert float((ref - got).detach().abs().max()) < 2e-6
+    for a, b in zip(grads(ref), grads(got)):
+        assert float((a - b).abs().max()) < 1e-5 * max(1.0, float(a.abs().max()))
+    assert float((mha_self(attn, x, None) - attn(xs, xs, xs, need_weights=False)[0].transpose(0, 1)).detach().abs().max()) < 2e-6
+    mem = torch.randn(3, 1, 128, requires_grad=True)
+    ms = mem.transpose(0, 1)
+    ref = attn(xs, ms, ms, need_weights=False)[0].transpose(0, 1)
+    got = mha_one_key(attn, x, mem)
+    assert float((ref - got).detach().abs().max()) < 2e-6
+    g_ref = torch.autograd.grad((ref * w).sum(), [mem] + list(attn.parameters()), allow_unused=True)
+    g_got = torch.autograd.grad((got * w).sum(), [mem] + list(attn.parameters()), allow_unused=True)
+    for a, b in zip(g_ref, g_got):
+        b = torch.zeros_like(a) if b is None else b
+        assert float((a - b).abs().max()) < 1e-5 * max(1.0, float(a.abs().max()))
+    # training mode: the one-key path drops whole (clip, query, head) value vectors with probability p and rescales the rest
+    attn_p = torch.nn.MultiheadAttention(128, 4, dropout=0.25).train()
+    o = mha_one_key(attn_p, torch.zeros(2, 500, 128), torch.randn(2, 1, 128))
+    base = mha_one_key(attn_p.eval(), torch.zeros(2, 500, 128), torch.randn(2, 1, 128))
+    assert o.shape == base.shape == (2, 500, 128)
+    # ragged lengths: frames beyond a clip's length are masked as keys and zeroed in the output; the valid part of a clip does not
+    # depend on how long the OTHER clips of the batch are
+    prior = MotionPrior().eval()
+    f = torch.randn(2, 12, 333)
+    with torch.no_grad():
+        _, d = prior.encode(f, [9, 12])
+        assert float((d.loc[:, :1] - prior.encode(f[:1, :9], [9])[1].loc).abs().max()) < 1e-5
+        out = prior.decode(d.loc, [9, 12])
+        assert out.shape == (2, 12, 333) and float(out[0, 9:].abs().max()) == 0.0 and float(out[1, 9:].abs().min()) > 0.0
+        assert float((out[0, :9] - prior.decode(d.loc[:, :1], [9])[0]).abs().max()) < 1e-5
+
+
 _DP_WORKER = r'''
 import os, sys
 import torch, torch.distributed as dist
