@@ -196,9 +196,24 @@ class GestureTrainer:
         self.inner_sampler = inner_sampler      # (con, emo, sty, bsz) -> noise2feats (B,300,333) or None
         self.world, self.pg = world, process_group
         self.kind = kind                        # ablation variant of the LMDB id (trainer.py:393-399): full / emotion / identity
-        self.params: List[nn.Parameter] = list(prior.parameters()) + list(ldm.parameters())   # trainer.py:181
-        # ---- one flat fp32 gradient bucket; every p.grad is a view into it
+        # the parameter lists of trainer.py:181 (prior, then ldm), each in state-dict order - the order of the flat images the
+        # HIP library takes (weights.prior_param_spec / denoiser_param_spec).  Every parameter is a view into ONE flat fp32
+        # buffer laid out that way, so the in-loop sampler's re-pack reads its two networks as slices of it (no per-iteration
+        # torch.cat of 427 tensors), and every p.grad is a view into a second buffer of the same layout: the gradient bucket.
+        from . import weights as wts
+        pn, dn = dict(prior.named_parameters()), dict(ldm.denoiser.named_parameters())
+        self.params: List[nn.Parameter] = [pn[k] for k in wts.prior_param_spec()] + [dn[k] for k in wts.denoiser_param_spec()]
+        assert {id(p) for p in self.params} == {id(p) for m in (prior, ldm) for p in m.parameters()} and len(self.params) == len(pn) + len(dn)
         n = sum(p.numel() for p in self.params)
+        self.n_prior = sum(p.numel() for p in pn.values())
+        self.flat_param = torch.empty(n, device=self.device, dtype=torch.float32)
+        off = 0
+        with torch.no_grad():
+            for p in self.params:
+                v = self.flat_param[off:off + p.numel()].view_as(p)
+                v.copy_(p)
+                p.data = v
+                off += p.numel()
         self.flat_grad = torch.zeros(n, device=self.device, dtype=torch.float32)
         off, self.views = 0, []
         for p in self.params:
@@ -320,8 +335,9 @@ class GestureTrainer:
         model_path = Path(model_path)
         model_path.mkdir(parents=True, exist_ok=True)
         p1, p2 = model_path / ("prior_model_NoOpt_" + tail), model_path / ("latdiff_model_wOpt_" + tail)
-        torch.save({"epoch": epoch, "model_state_dict": self.model["prior"].state_dict()}, p1)
-        torch.save({"epoch": epoch, "model_state_dict": self.model["ldm"].state_dict(),
+        own = lambda m: {k: v.detach().clone() for k, v in m.state_dict().items()}   # not views of the 27 MB flat buffer
+        torch.save({"epoch": epoch, "model_state_dict": own(self.model["prior"])}, p1)
+        torch.save({"epoch": epoch, "model_state_dict": own(self.model["ldm"]),
                     "optimizer_state_dict": self.lpdm_opt.state_dict()}, p2)
         return p1, p2
 
@@ -353,9 +369,10 @@ class HipInnerSampler:
     CURRENT weights.  refresh = n: amuse_update_weights every n-th call (1 = every iteration, the reference's semantics)."""
 
     def __init__(self, trainer_models: Dict[str, nn.Module], device, precision: str = "bf16", refresh: int = 1, seed: int = 2024,
-                 ldm_cfg: Optional[dict] = None):
+                 ldm_cfg: Optional[dict] = None, flat: Optional[tuple] = None):
         from .engine import HipEngine
         self.models, self.precision, self.refresh, self.seed = trainer_models, precision, max(1, refresh), seed
+        self.flat = flat                        # (prior, denoiser) flat fp32 images that ARE the parameters (GestureTrainer.flat_param)
         self.engine = HipEngine(self._den_state(), self._prior_state(), device)
         self.engine.set_schedule(sch.from_ldm_cfg(ldm_cfg, "ddim") if ldm_cfg and "scheduler" in ldm_cfg else sch.ddim_table())
         self.calls, self.clip_counter, self.sync_ms = 0, 0, []
@@ -372,11 +389,14 @@ class HipInnerSampler:
         if self.calls % self.refresh == 0 and self.calls > 0:
             t0 = time.perf_counter()
             if self.on_device:
-                # the weights never leave the GPU: one torch.cat per network, then a gather kernel per packed image
-                from .engine import flatten_on_device
-                from . import weights as wts
-                den = flatten_on_device(self.models["ldm"].denoiser.state_dict(), wts.denoiser_param_spec())
-                pri = flatten_on_device(self.models["prior"].state_dict(), wts.prior_param_spec())
+                # the weights never leave the GPU: the parameters ARE the flat images (or one torch.cat per network), then a gather kernel per packed image
+                if self.flat is not None:
+                    pri, den = self.flat
+                else:
+                    from .engine import flatten_on_device
+                    from . import weights as wts
+                    den = flatten_on_device(self.models["ldm"].denoiser.state_dict(), wts.denoiser_param_spec())
+                    pri = flatten_on_device(self.models["prior"].state_dict(), wts.prior_param_spec())
                 self.engine.update_weights_device(den, pri, what=self.what)
             else:
                 self.engine.update_weights(self._den_state(), self._prior_state(), what=self.what)
@@ -400,7 +420,8 @@ def build_trainer(device, rank: int = 0, world: int = 1, process_group=None, see
         if torch.device(device).type != "cuda":
             raise RuntimeError("the in-loop sampler of train_gesture runs on the HIP kernels: no CPU path (pass use_hip_sampler=False "
                                "to train without the no-gradient gen_feature term)")
-        tr.inner_sampler = HipInnerSampler(tr.model, device, refresh=sampler_refresh, ldm_cfg=ldm_cfg)
+        tr.inner_sampler = HipInnerSampler(tr.model, device, refresh=sampler_refresh, ldm_cfg=ldm_cfg,
+                                           flat=(tr.flat_param[:tr.n_prior], tr.flat_param[tr.n_prior:]))
     return tr
 
 

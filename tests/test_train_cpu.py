@@ -83,6 +83,12 @@ def test_loss_set_and_one_training_step(tmp_path):
     for p in tr.params:
         assert p.grad.data_ptr() == tr.flat_grad.data_ptr() + 4 * off
         off += p.numel()
+    # ... and every parameter a view of one flat buffer that IS the two images the HIP library's re-pack takes (state-dict order)
+    from amuse_amd import weights as wts
+    from amuse_amd.engine import flatten_on_device
+    assert torch.equal(tr.flat_param[:tr.n_prior], flatten_on_device(tr.model["prior"].state_dict(), wts.prior_param_spec()))
+    assert torch.equal(tr.flat_param[tr.n_prior:], flatten_on_device(tr.model["ldm"].denoiser.state_dict(), wts.denoiser_param_spec()))
+    assert all(q.data_ptr() >= tr.flat_param.data_ptr() and q.data_ptr() < tr.flat_param.data_ptr() + 4 * tr.flat_param.numel() for q in tr.params)
     # checkpoint writer: the reference's file names; the readers pick them up and return the trained weights
     p1, p2 = tr.save_checkpoint(tmp_path / "LPDM_x", epoch=199)
     pat = r"_recF\d+\.\d{4}_recJ\d+\.\d{4}_kl\d+\.\d{4}_genF\d+\.\d{4}_genJ\d+\.\d{4}_instL\d+\.\d{4}_vtexR\d+\.\d{4}_vtexG\d+\.\d{4}_total\d+\.\d{4}_e200\.pt$"
