@@ -20,8 +20,11 @@ modules cannot be imported to generate golden vectors:
     triangular filters equally spaced on the mel scale 1127 ln(1 + f / 700) between 20 Hz and Nyquist, log with
     floor FLT_EPSILON).
 Cross-checks the tests do make: ast_forward against the independent implementation of the same published model in
-the ``transformers`` package (ASTModel, weights mapped key by key), kaldi_fbank against a float64 DFT restatement and
-against analytically known inputs (pure tones land in the right mel bin; a constant signal gives the log floor).
+the ``transformers`` package (ASTModel, weights mapped key by key); kaldi_fbank / prepare_fbank against the same package's
+own numpy restatement of torchaudio's kaldi fbank (ASTFeatureExtractor without torchaudio: 3.7e-4 max / 5e-6 mean in the
+log-mel domain on 3-12 s signals, pad-then-normalise included), against a float64 DFT restatement and against analytically
+known inputs (pure tones land in the right mel bin; a constant signal gives the log floor).  Two third-party restatements
+agreeing is evidence, not a pin: neither is the reference's own timm 0.4.5 / torchaudio call.
 """
 from __future__ import annotations
 

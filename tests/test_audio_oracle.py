@@ -57,6 +57,35 @@ def test_fbank_against_float64_dft():
     assert float((fb.double() - ref).abs().max()) < 2e-4
 
 
+def test_fbank_and_normalisation_against_transformers_feature_extractor():
+    """transformers' ASTFeatureExtractor without torchaudio falls back to its own numpy restatement of torchaudio's kaldi fbank
+    (audio_utils.spectrogram: DC removal, pre-emphasis 0.97, hann window, 512-point power spectrum, kaldi mel filters, log with
+    the FLT_EPSILON floor), pads to 1024 frames BEFORE normalising and normalises as (x - mean) / (2 std) - the pipeline of
+    infer_ldm.py:182-190, written by a third party.  The oracle's kaldi_fbank / prepare_fbank must agree with it."""
+    tr = pytest.importorskip("transformers")
+    import warnings
+    import numpy as np
+    from transformers.utils import is_speech_available
+    if is_speech_available():
+        pytest.skip("torchaudio present: the extractor would call it instead of its own restatement")
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")            # 'at least one mel filter has all zero values' (the same filters as Kaldi's)
+        raw = tr.ASTFeatureExtractor(do_normalize=False)
+        norm = tr.ASTFeatureExtractor(do_normalize=True, mean=ao.NORM_MEAN, std=ao.NORM_STD)
+    rs = np.random.RandomState(0)
+    for n, amp in ((159744, 0.1), (48000, 0.02), (192000, 0.3)):       # the reference's e_speech length; shorter; longer than 1024 frames
+        t = np.arange(n) / 16000.0
+        x = (amp * (np.sin(2 * np.pi * 220 * t) + 0.5 * np.sin(2 * np.pi * 1760 * t + 1)) + 0.3 * amp * rs.randn(n)).astype(np.float32)
+        theirs = raw(x, sampling_rate=16000, return_tensors="np")["input_values"][0]
+        mine = ao.kaldi_fbank(torch.from_numpy(x)).numpy()
+        m = min(mine.shape[0], 1024)
+        assert theirs.shape == (1024, 128) and mine.shape[0] == 1 + (n - 400) // 160
+        assert float(np.abs(theirs[:m] - mine[:m]).max()) < 1e-3 and float(np.abs(theirs[:m] - mine[:m]).mean()) < 2e-5
+        assert m == 1024 or float(np.abs(theirs[m:]).max()) == 0.0
+        theirs_n = norm(x, sampling_rate=16000, return_tensors="np")["input_values"][0]
+        assert float(np.abs(theirs_n - ao.prepare_fbank(torch.from_numpy(x)).numpy()).max()) < 1e-4
+
+
 def test_ast_forward_against_transformers_implementation():
     tr = pytest.importorskip("transformers")
     W = ao.to_torch(aw.make_ast_weights(0, "emo"))
