@@ -149,9 +149,13 @@ __device__ __forceinline__ void combine_red(f32x4 (&part)[kTiles], f32x4 (&xo)[2
             m2 += d * d;
         }
     m2 = allreduce_g_sum(m2);
+#ifdef AMUSE_ABL_NOSTATS   // timing ablation (wrong numerics): what the row-statistics exchange and its barrier cost
+    const float2 s0 = float2{mw, m2}, s1 = s0, s2 = s0, s3 = s0;
+#else
     if (g == 0) stats[W * 16 + r] = float2{mw, m2};
     __syncthreads();
     const float2 s0 = stats[r], s1 = stats[16 + r], s2 = stats[32 + r], s3 = stats[48 + r];
+#endif
     const float mean = ((s0.x + s1.x) + (s2.x + s3.x)) * 0.25f;
     const float d0 = s0.x - mean, d1 = s1.x - mean, d2 = s2.x - mean, d3 = s3.x - mean;
     const float M2 = ((s0.y + s1.y) + (s2.y + s3.y)) + 32.0f * ((d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3));
@@ -197,7 +201,9 @@ __device__ __forceinline__ void combine_publish(const f32x4 (&part)[kTiles], bf1
     ring_issue<N0, kR8, IPH0 % kR8>(rg);
     __syncthreads();
     ring_issue<N1, kR8, (IPH0 + N0) % kR8>(rg);
+#ifndef AMUSE_ABL_NOSTATS
     if constexpr (LN) __syncthreads();   // (the reducers' row-statistics exchange)
+#endif
     ring_issue<N2, kR8, (IPH0 + N0 + N1) % kR8>(rg);
     __syncthreads();
 #pragma unroll
@@ -227,7 +233,9 @@ __device__ __forceinline__ void combine_publish_c2(const f32x4 (&part)[kTiles], 
     ring_issue<N0, kR8, 24>(rg);
     __syncthreads();
     ring_issue<N1, kR8, (24 + N0) % kR8>(rg);
+#ifndef AMUSE_ABL_NOSTATS
     __syncthreads();
+#endif
     if (skip_u) {
         bf16x8 sk[4];
 #pragma unroll
