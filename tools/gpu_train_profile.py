@@ -51,7 +51,7 @@ def main():
             tr.train_step(batch)
         torch.cuda.synchronize()
     ev = prof.key_averages()
-    dev_us = sum(e.self_device_time_total for e in ev)
+    dev_us = sum(e.self_device_time_total for e in ev if e.device_type == torch.autograd.DeviceType.CUDA)   # kernel rows only: operator rows repeat them
     launches = sum(e.count for e in ev if e.key in ("hipLaunchKernel", "hipExtModuleLaunchKernel", "hipModuleLaunchKernel",
                                                     "hipExtLaunchKernel", "cudaLaunchKernel"))
     print(f"profiled 3 iterations: device kernel time {dev_us / 3e3:.2f} ms per iteration, {launches // 3} launches per iteration", file=out)
