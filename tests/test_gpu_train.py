@@ -92,12 +92,48 @@ def test_train_step_with_hip_inner_sampler():
     for _ in range(3):
         tr.train_step(batch)
     assert float(tr.lpdm_losses.compute()["recons_feature"]) < ld["recons_feature"]      # the step optimises
-    # the in-loop sampler runs on the CURRENT weights: its context equals a fresh one built from the modules' state
+    # the in-loop sampler runs on the CURRENT weights: after its next call (which re-packs on the GPU straight from the
+    # trainer's flat parameter buffer) its context equals a fresh one built from the modules' state dicts ...
     s = tr.inner_sampler
-    s.engine.update_weights(s._den_state(), s._prior_state(), what=2)
+    assert s.flat is not None and s.on_device
+    s(batch["ld_audio_con"], batch["ld_audio_emo"], batch["ld_audio_sty"], 32)
     fresh = HipEngine(s._den_state(), s._prior_state())
     fresh.set_schedule(s.engine.schedule)
     lat_a = s.engine.sample(batch["ld_audio_con"], batch["ld_audio_emo"], batch["ld_audio_sty"], "bf16", seed=1)
     lat_b = fresh.sample(batch["ld_audio_con"], batch["ld_audio_emo"], batch["ld_audio_sty"], "bf16", seed=1)
-    assert torch.equal(lat_a, lat_b) and len(s.sync_ms) >= 3
+    assert torch.equal(lat_a, lat_b) and len(s.sync_ms) >= 4
+    assert torch.equal(s.engine.vae_decode(lat_a, None, "bf16")["poses"], fresh.vae_decode(lat_b, None, "bf16")["poses"])
+    # ... and so does the host path
+    s.engine.update_weights(s._den_state(), s._prior_state(), what=2)
+    assert torch.equal(s.engine.sample(batch["ld_audio_con"], batch["ld_audio_emo"], batch["ld_audio_sty"], "bf16", seed=1), lat_b)
     fresh.close()
+
+
+def test_gpu_gradients_equal_cpu_gradients():
+    """The step's forward + backward on the GPU (rocBLAS GEMMs, the fused scaled-dot-product kernels, gradients handed over and
+    packed into the bucket) against the same trainer on the CPU: losses and the flat gradient, dropout off, explicit draws."""
+    from amuse_amd.train_gesture import build_trainer, synthetic_batch
+    B = 4
+    g = torch.Generator().manual_seed(11)
+    batch = synthetic_batch(B, 7)
+    noise, ts = torch.randn(B, 1, 128, generator=g), torch.randint(0, 1000, (B,), generator=g)
+    e1, e2 = torch.randn(1, B, 128, generator=g), torch.randn(1, B, 128, generator=g)
+    out = {}
+    for dev in ("cpu", "cuda:0"):
+        tr = build_trainer(dev, use_hip_sampler=False, dropout=0.0)
+        b = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in batch.items()}
+        loss = tr.forward_losses(b, noise=noise.to(dev), timesteps=ts.to(dev), eps_enc=e1.to(dev), eps_inf=e2.to(dev))
+        tr.backward_into_bucket(loss)
+        out[dev] = (float(loss.detach()), tr.flat_grad.detach().cpu().clone(), tr)
+    (lc, gc, _), (lg, gg, trg) = out["cpu"], out["cuda:0"]
+    assert abs(lc - lg) < 2e-5 * max(1.0, abs(lc))
+    scale = float(gc.abs().max())
+    assert scale > 0 and float((gc - gg).abs().max()) < 2e-4 * scale
+    # every p.grad points into the bucket again, and a step moves the flat parameter buffer
+    off = 0
+    for p in trg.params:
+        assert p.grad.data_ptr() == trg.flat_grad.data_ptr() + 4 * off
+        off += p.numel()
+    before = trg.flat_param.clone()
+    trg.lpdm_opt.step()
+    assert not torch.equal(before, trg.flat_param)
