@@ -5,7 +5,7 @@ from __future__ import annotations
 
 import ctypes as C
 import math
-from typing import Dict, Optional, Tuple
+from typing import Dict, Optional, Sequence, Tuple
 
 import numpy as np
 import torch
@@ -109,6 +109,15 @@ class AudioEngine:
             _lib.check(self.lib.amuse_audio_features(self.ctx, _ptr(w), w.shape[1], B, _ptr(outs[0]), _ptr(outs[1]),
                                                      _ptr(outs[2]), self._stream()))
         return tuple(outs)
+
+    def features_ragged(self, waves: Sequence):
+        """process_single_seq for waveforms of DIFFERENT lengths as one batch: a fbank launch per waveform (each is padded /
+        cropped to 1024 frames on its own, as the reference does call by call), then every encoder once over all of them.
+        Row k is bitwise what process_single_seq(waves[k]) returns: a clip's features do not depend on its batch."""
+        if len(waves) == 0:
+            raise ValueError("no waveforms")
+        fb = torch.cat([self.fbank(torch.as_tensor(w)[0] if torch.as_tensor(w).dim() == 2 else w) for w in waves])
+        return tuple(self.encode(which, fb) for which in ("con", "emo", "sty"))
 
     def process_single_seq(self, sliced_chunk, framerate=16000 // 2, baseline=False):
         """(C, n) or (n,) waveform -> (con, emo, sty), each (1, 256) (infer_ldm.py:180-193; channel 0 as kaldi does)."""

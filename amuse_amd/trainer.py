@@ -247,9 +247,19 @@ class trainer:
         self.written += write_sample(sample_dict["feats"], video_dump, subject_of(sample_dict["info"]))
 
     def _embed(self, path, baseline=False):
-        a = load_wav(path)                                                  # trainer.py:519-521
-        a = a - a.mean()
-        return self.model.process_single_seq(a, framerate=16000, baseline=baseline)
+        return self._embed_all([path], baseline)[0]
+
+    def _embed_all(self, paths, baseline=False):
+        """[(con, emo, sty), ...] for a list of WAVs: load, remove the mean (trainer.py:519-521), embed - as one batch where the
+        model offers it (PretrainedLPDM_v1.process_seq_list), else call by call."""
+        waves = []
+        for path in paths:
+            a = load_wav(path)
+            waves.append(a - a.mean())
+        many = getattr(self.model, "process_seq_list", None)
+        if many is not None:
+            return many(waves, framerate=16000, baseline=baseline)
+        return [self.model.process_single_seq(a, framerate=16000, baseline=baseline) for a in waves]
 
     # ------------------------------------------------------------------ infer_gesture
     def _infer_prior_latdiff_from_audio_v1(self, baseline, ldm_epoch, audio_list, short_audio_list, modelversion, ammetric):
@@ -269,7 +279,7 @@ class trainer:
             # every audio's result lands in <rep>/rst_0 and an NPZ of audio k sits beside those of the audios before
             # it (seq_0/<actor>_seq_0_<rand6>_motion_smplx.npz, told apart only by the random tag).  Same layout
             # here; the embeddings of all audios are computed first and the clips are sampled as one launch.
-            embs = [self._embed(a, baseline) for a in audios]
+            embs = self._embed_all(audios, baseline)
             jobs = [_job("scott", a.stem, c, e, s, 1, "scott", None, None, None) for a, (c, e, s) in zip(audios, embs)]
             rst_all = run_jobs(self.model, jobs, batched=self.batched)
             video_dump_r = target_path / f"Custom_audios_{self.stamp}_E{ldm_epoch}" / f"rep{rep_i}"
@@ -330,8 +340,7 @@ class trainer:
                 src_a = [x for x in audios if "_source" in x.stem][0]
                 tgt_a = [x for x in audios if "_target" in x.stem][0]
                 target_path = Path(ecl["renders"])
-                con, emo, sty = self._embed(src_a, baseline)
-                _, tgt_emo, _ = self._embed(tgt_a, baseline)
+                (con, emo, sty), (_, tgt_emo, _) = self._embed_all([src_a, tgt_a], baseline)
                 jobs = [_job(actor, src_a.stem, con, emo, sty, 1, f"Original {actor}"),        # Gesture generation
                         _job(actor, src_a.stem, con, tgt_emo, sty, 1, f"Emotion edited {actor}")]  # Gesture editing
                 rst = run_jobs(self.model, jobs, batched=self.batched)      # fresh noise per job, like the two calls

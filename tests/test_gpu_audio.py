@@ -139,6 +139,15 @@ def test_host_mirror_process_single_seq_and_loader_helper(env):
     out = m.process_loader({"emotion_control": data, "emotion_control_info": "[wayne]_[happy]_first"})["emotion_control"]
     assert out["wayne"]["a"]["ld_z"].shape == (2, 128) and out["wayne"]["a"]["ld_z_con"].shape == (1, 256)
     assert torch.equal(out["wayne"]["a"]["ld_z_emo_b"], out["wayne"]["b"]["ld_z_emo"])
+    # process_seq_list: waveforms of different lengths (shorter and longer than the 1024-frame window, stereo) as ONE batch -
+    # row k bitwise what the call-by-call path of the reference's loop (trainer.py:516-523) gives
+    ragged = [_waves(160000, 1, seed=41), _waves(50000, 2, seed=42), _waves(200000, 1, seed=43), _waves(163840 + 240, 1, seed=44)[0]]
+    many = m.process_seq_list(ragged, framerate=16000)
+    assert len(many) == 4
+    for wv, (c_k, e_k, s_k) in zip(ragged, many):
+        c1_, e1_, s1_ = m.process_single_seq(wv, framerate=16000)
+        assert c_k.shape == (1, 256) and torch.equal(c_k, c1_) and torch.equal(e_k, e1_) and torch.equal(s_k, s1_)
+    assert len(m.process_seq_list(ragged[:1])) == 1
     m.audio_engine = None                                              # the fixture owns the engine
 
 
