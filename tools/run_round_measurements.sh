@@ -8,7 +8,7 @@ export TMPDIR=/tmp
 rm -rf $O && mkdir -p $O
 timeout 1500 python -m pytest tests -q -m gpu 2>&1 | tail -3 > $O/pytest.txt
 timeout 600 python bench.py > $O/bench.json 2> $O/bench.err; tail -2 $O/bench.err
-timeout 300 python bench.py --config train --steps 10 --warmup 3 > $O/train_bench.json 2> $O/train_bench.err
+timeout 300 python bench.py --config train --steps 40 --warmup 10 > $O/train_bench.json 2> $O/train_bench.err
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python3 bench.py --steps 3 --warmup 1 --no-extras > $O/stats.log 2>&1
 for grp in FETCH_SIZE WRITE_SIZE "TCC_HIT_sum TCC_MISS_sum" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_ANY" "SQ_INSTS_MFMA SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_INSTS_SALU"; do
   n=$(echo $grp | cut -d' ' -f1)
