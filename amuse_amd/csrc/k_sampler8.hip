@@ -309,7 +309,11 @@ __device__ __forceinline__ void ffn_half(f32x4 (&part)[kTiles], const bf16x8 (&x
     const float* b1 = pv + PV_L1_B + 16 * (kTiles * h + 2 * Q0) + 4 * g;
     f32x4 ha[2] = {ld4(b1), ld4(b1 + 16)}, hb[2] = {ld4(b1 + 32), ld4(b1 + 48)};
     gemm_xb<2, false, 0>(ha, xb, rg);
+#ifdef AMUSE_ABL_NOLATE   // timing ablation (stale weights): what the B waves' blocking issue of their late units costs the FFN phase
+    if constexpr (LATE8) rg.next += (32 - AMUSE_B_EARLY) * 64;
+#else
     if constexpr (LATE8) ring_issue<32 - AMUSE_B_EARLY, kR8, AMUSE_B_EARLY>(rg);
+#endif
     __builtin_amdgcn_sched_barrier(0);
     // An in-order wave that issues its 8 MFMAs back to back waits out the matrix pipe (16 cycles each) before its
     // first VALU instruction; interleaved 1 : 6 the GELU of one quarter runs in the shadow of the other quarter's
