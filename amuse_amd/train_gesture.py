@@ -234,7 +234,7 @@ class GestureTrainer:
         # time per call (a process-wide torch setting; AMUSE_TRAIN_BLAS=default leaves it alone)
         if self.device.type == "cuda" and os.environ.get("AMUSE_TRAIN_BLAS", "rocblas") == "rocblas":
             torch.backends.cuda.preferred_blas_library("cublas")
-        self.allreduce_ms: List[float] = []
+        self._ar_events: list = []
 
     def n_grad_elements(self) -> int:
         return int(self.flat_grad.numel())
@@ -309,15 +309,18 @@ class GestureTrainer:
         self.flat_grad.mul_(1.0 / self.world)
         if timed:
             e1.record()
-            self._pending = (e0, e1)
+            self._ar_events.append((e0, e1))
+            del self._ar_events[:-256]
 
-    def pop_allreduce_ms(self) -> Optional[float]:
-        p = getattr(self, "_pending", None)
-        if p is None:
-            return None
-        p[1].synchronize()
-        self._pending = None
-        return p[0].elapsed_time(p[1])
+    def pop_allreduce_ms(self) -> List[float]:
+        """Durations (ms) of the all-reduces since the last call, from HIP events.  Call it AFTER a timed region: it waits for the
+        recorded events, and a wait inside the loop would serialise host dispatch and device work of a host-bound step."""
+        ev, self._ar_events = self._ar_events, []
+        out = []
+        for e0, e1 in ev:
+            e1.synchronize()
+            out.append(e0.elapsed_time(e1))
+        return out
 
     # ------------------------------------------------------------------ checkpoints (trainer.py:468-496)
     def save_checkpoint(self, model_path, epoch: int, loss_dict: Optional[dict] = None):
@@ -452,19 +455,16 @@ def bench_main(args):
             dist.barrier()
         torch.cuda.synchronize()
 
-    ar = []
     for i in range(args.warmup):
         tr.train_step(batches[i % 4])
-        tr.pop_allreduce_ms()
     barrier()
+    tr.pop_allreduce_ms()
     t0 = time.perf_counter()
     for i in range(args.steps):
         tr.train_step(batches[i % 4])
-        ms = tr.pop_allreduce_ms()
-        if ms is not None:
-            ar.append(ms)
     barrier()
     elapsed = time.perf_counter() - t0
+    ar = tr.pop_allreduce_ms()                     # event times, read after the timed region (no host sync inside it)
     if world > 1:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)

@@ -193,6 +193,15 @@ w = torch.cat([p.detach().flatten() for p in tr.params])
 ws = [torch.empty_like(w) for _ in range(world)]
 dist.all_gather(ws, w)
 assert all(torch.equal(ws[0], x) for x in ws)
+# the same through train_step itself (gradients handed over, packed into the bucket, exchanged, optimizer): different data and
+# draws per rank, identical weights afterwards
+torch.manual_seed(100 + rank)
+tr.train_step(synthetic_batch(B, 50 + rank))
+assert all(p.grad.data_ptr() == v.data_ptr() for p, v in zip(tr.params, tr.views))
+w = tr.flat_param.detach().clone()
+ws = [torch.empty_like(w) for _ in range(world)]
+dist.all_gather(ws, w)
+assert all(torch.equal(ws[0], x) for x in ws) and tr.pop_allreduce_ms() == []
 if rank == 0:
     print("DP_OK")
 dist.destroy_process_group()
