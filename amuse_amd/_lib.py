@@ -13,9 +13,10 @@ _HERE = Path(__file__).resolve().parent
 # AMUSE_HIP_LIB: load another build of the same C ABI (kernel A/B measurements, tools/build_variant.sh)
 LIB_PATH = Path(os.environ.get("AMUSE_HIP_LIB") or _HERE / "libamuse_hip.so")
 
-PREC_F32, PREC_BF16 = 0, 1
+PREC_F32, PREC_BF16, PREC_F32X = 0, 1, 2
+UPD_F32, UPD_BF16, UPD_ENCODER, UPD_F32X, UPD_ALL = 1, 2, 4, 8, 15
 QUAT_P3D, QUAT_LEGACY = 0, 1
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 EXPORTS = [
     "amuse_abi_version", "amuse_last_error", "amuse_create", "amuse_update_weights", "amuse_update_weights_device", "amuse_destroy", "amuse_set_schedule",
@@ -23,7 +24,7 @@ EXPORTS = [
     "amuse_counter_normal", "amuse_set_clips_per_group", "amuse_set_decode_path", "amuse_profile_sample",
     "amuse_audio_create", "amuse_audio_destroy", "amuse_audio_fbank", "amuse_audio_encode", "amuse_audio_features",
     "amuse_debug_gemm",
-    "amuse_debug_tile",
+    "amuse_debug_tile", "amuse_debug_f16_split",
 ]
 
 
@@ -87,6 +88,8 @@ def load() -> C.CDLL:
     lib.amuse_audio_features.argtypes = [vp, fp, C.c_int, C.c_int, fp, fp, fp, vp]
     lib.amuse_debug_gemm.argtypes = [vp, vp, fp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp]
     lib.amuse_debug_tile.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, vp]
+    lib.amuse_debug_f16_split.argtypes = [C.POINTER(C.c_float), C.c_size_t, C.POINTER(C.c_uint16), C.POINTER(C.c_uint16)]
+    lib.amuse_debug_f16_split.restype = C.c_int
     for n in ("amuse_audio_fbank", "amuse_audio_encode", "amuse_audio_features", "amuse_debug_gemm", "amuse_debug_tile"):
         getattr(lib, n).restype = C.c_int
     if lib.amuse_abi_version() != ABI_VERSION:

@@ -114,12 +114,46 @@ uint16_t f2bf(float f) {  // round-to-nearest-even, as v_cvt_pk_bf16_f32
     x += 0x7fffu + ((x >> 16) & 1u);
     return (uint16_t)(x >> 16);
 }
-// W: [n_out x K] row-major.  Appends units for (k-tile outer, out-tile inner).
+// fp32 -> fp16 bits, round-to-nearest-even with gradual underflow (what v_cvt_pk_f16_f32 / (_Float16) do), and back (exact)
+uint16_t f2h(float f) {
+    uint32_t x;
+    memcpy(&x, &f, 4);
+    const uint16_t sign = (uint16_t)((x >> 16) & 0x8000u);
+    x &= 0x7fffffffu;
+    if (x > 0x7f800000u) return (uint16_t)(sign | 0x7e00u);          // NaN
+    if (x >= 0x477ff000u) return (uint16_t)(sign | 0x7c00u);         // >= 65520 rounds to infinity
+    if (x < 0x38800000u) {                                            // below 2^-14: the result is subnormal (or 2^-14)
+        float a;
+        memcpy(&a, &x, 4);
+        return (uint16_t)(sign | (uint16_t)nearbyintf(a * 16777216.0f));   // units of 2^-24, ties to even
+    }
+    x -= 0x38000000u;                                                 // re-bias the exponent (127 -> 15)
+    x += 0xfffu + ((x >> 13) & 1u);
+    return (uint16_t)(sign | (x >> 13));
+}
+float h2f(uint16_t h) {
+    const uint32_t sign = (uint32_t)(h & 0x8000u) << 16, e = (h >> 10) & 31u, m = h & 0x3ffu;
+    float f;
+    if (e == 0) {
+        f = (float)m * 5.9604644775390625e-8f;                        // m * 2^-24
+        uint32_t u;
+        memcpy(&u, &f, 4);
+        u |= sign;
+        memcpy(&f, &u, 4);
+        return f;
+    }
+    const uint32_t u = sign | (e == 31 ? 0x7f800000u | (m << 13) : ((e + 112u) << 23) | (m << 13));
+    memcpy(&f, &u, 4);
+    return f;
+}
+bool g_probe_f16 = false;   // build_repack_maps: the lo units carry the probe value too (amuse_update_weights_device)
+// W: [n_out x K] row-major.  Appends units for (k-tile outer, out-tile inner); PREC_F16X2: k-tile pair outer, out-tile inner,
+// two units each - hi = rn16(w), lo = rn16(w - hi) (amuse_dev.hpp gemm_ring_s).
 void pack_gemm(std::vector<uint4>& out, int prec, const float* W, int n_out, int K, const std::vector<int>& otiles,
                const std::vector<int>& ktiles) {
     // (amuse_update_weights calls this once per training iteration: the destination is sized once and filled through a
     // pointer, rows / columns inside the matrix skip the bounds checks)
-    const size_t nunits = prec == PREC_F32 ? ktiles.size() * otiles.size() : (ktiles.size() / 2) * otiles.size();
+    const size_t nunits = prec == PREC_BF16 ? (ktiles.size() / 2) * otiles.size() : ktiles.size() * otiles.size();
     const size_t base = out.size();
     out.resize(base + nunits * 64);
     uint4* dst = out.data() + base;
@@ -137,6 +171,24 @@ void pack_gemm(std::vector<uint4>& out, int prec, const float* W, int n_out, int
                     memcpy(dst, v, 16);
                 }
             }
+    } else if (prec == PREC_F16X2) {
+        for (size_t c = 0; c + 1 < ktiles.size(); c += 2) {
+            const int t0 = ktiles[c], t1 = ktiles[c + 1];
+            for (int o : otiles) {
+                for (int lane = 0; lane < 64; ++lane, ++dst) {
+                    const int g = lane >> 4, i = lane & 15;
+                    uint16_t hi[8], lo[8];
+                    for (int e = 0; e < 8; ++e) {
+                        const float w = at(16 * o + i, 16 * (e < 4 ? t0 : t1) + 4 * g + (e & 3));
+                        hi[e] = f2h(w);
+                        lo[e] = g_probe_f16 ? hi[e] : f2h(w - h2f(hi[e]));
+                    }
+                    memcpy(dst, hi, 16);
+                    memcpy(dst + 64, lo, 16);
+                }
+                dst += 64;
+            }
+        }
     } else {
         for (size_t c = 0; c + 1 < ktiles.size(); c += 2) {
             const int t0 = ktiles[c], t1 = ktiles[c + 1];
@@ -241,8 +293,8 @@ struct amuse_ctx {
     int clips_per_group = 0;
     int decode_path = AMUSE_DECODE_AUTO;
     // denoiser
-    uint4* den_w[2] = {nullptr, nullptr};
-    uint32_t den_wave_units[2] = {0, 0};
+    uint4* den_w[3] = {nullptr, nullptr, nullptr};   // 4-wave kernel streams: fp32 | bf16 | split-fp16 (fp32x)
+    uint32_t den_wave_units[3] = {0, 0, 0};
     uint4* den_w8 = nullptr;           // bf16 streams of the 8-wave kernel (k_sampler8.hip)
     uint32_t den_w8_units[2] = {0, 0}; // per-step units of a group-A / group-B wave
     float* den_pvec = nullptr;
@@ -279,7 +331,7 @@ struct amuse_ctx {
     int* d_lengths = nullptr; size_t len_cap = 0;
     std::vector<void*> owned;
     // amuse_update_weights_device: one entry per packed image (built on the first call)
-    struct Repack { void** slot; int* map; size_t n; int prior, bf16, cls; };
+    struct Repack { void** slot; int* map; size_t n; int prior, kind, cls; };
     std::vector<Repack> repack;
 };
 
@@ -297,12 +349,14 @@ int ensure(float** p, size_t* cap, size_t need_floats) {
     return 0;
 }
 
-int build_denoiser(amuse_ctx* c, const float* den, int what = 7) {
+constexpr int kUpdBit[3] = {AMUSE_UPD_F32, AMUSE_UPD_BF16, AMUSE_UPD_F32X};   // per PREC_* index
+
+int build_denoiser(amuse_ctx* c, const float* den, int what = AMUSE_UPD_ALL) {
     static const ParamIndex DI = denoiser_index();
     const Params D{DI, den};
     // ---- denoiser weight streams: [wave][per-step units]
-    for (int prec = 0; prec < 2; ++prec) {
-        if (!(what & (1 << prec))) continue;   // amuse_update_weights: only the requested precisions are re-packed
+    for (int prec = 0; prec < 3; ++prec) {
+        if (!(what & kUpdBit[prec])) continue;   // amuse_update_weights: only the requested precisions are re-packed
         // the 4-wave bf16 stream only serves A/B runs (AMUSE_SAMPLE_WAVES=4): updates skip it unless that switch is set
         if (prec == PREC_BF16 && c->den_w[prec] && !getenv("AMUSE_SAMPLE_WAVES")) continue;
         std::vector<uint4> all;
@@ -387,9 +441,10 @@ int build_denoiser(amuse_ctx* c, const float* den, int what = 7) {
     return 0;
 }
 
-int build_prior(amuse_ctx* c, const float* pri, int what = 7) {
+int build_prior(amuse_ctx* c, const float* pri, int what = AMUSE_UPD_ALL) {
     static const ParamIndex PI = prior_index();
     const Params Pp{PI, pri};
+    if (what & AMUSE_UPD_F32X) what |= AMUSE_UPD_F32;   // fp32x jobs decode / encode with the fp32 kernels (prior_precision)
     // ---- VAE decoder weight streams: [stage][wave][units]
     for (int prec = 0; prec < 2; ++prec) {
         if (!(what & (1 << prec))) continue;
@@ -552,7 +607,7 @@ int pick_group(const amuse_ctx* c, int B, int S) {
 // kernel, unless phase stamps are requested or AMUSE_SAMPLE_WAVES=4 (A/B measurements) asks for the 4-wave one
 bool use_sample8(int precision) {
     static const bool force4 = [] { const char* e = getenv("AMUSE_SAMPLE_WAVES"); return e && atoi(e) == 4; }();
-    return precision == PREC_BF16 && !force4;
+    return precision == PREC_BF16 && !force4;   // (fp32x runs the 4-wave kernel's PREC_F16X2 instantiation)
 }
 void set_stream(const amuse_ctx* c, SampleArgs& a, int precision) {
     a.wstream = c->den_w[precision]; a.wave_units = c->den_wave_units[precision];
@@ -606,16 +661,27 @@ int check_common(amuse_ctx* c, const float* con, int B, int precision) {
     if (!c) return fail(AMUSE_EINVAL, "ctx is NULL");
     if (!con) return fail(AMUSE_EINVAL, "con is NULL (the content embedding is mandatory, denoiser.py:153-157)");
     if (B < 1) return fail(AMUSE_EINVAL, "B must be >= 1, got %d", B);
-    if (precision != AMUSE_PREC_F32 && precision != AMUSE_PREC_BF16) return fail(AMUSE_EINVAL, "bad precision %d", precision);
+    if (precision != AMUSE_PREC_F32 && precision != AMUSE_PREC_BF16 && precision != AMUSE_PREC_F32X)
+        return fail(AMUSE_EINVAL, "bad precision %d", precision);
     HIP_TRY(hipSetDevice(c->device));
     return 0;
 }
+// the prior's kernels have two arithmetic modes: fp32x sampling is decoded / encoded by the fp32 kernels
+int prior_precision(int precision) { return precision == AMUSE_PREC_F32X ? AMUSE_PREC_F32 : precision; }
 
 }  // namespace
 
 extern "C" {
 
 int amuse_abi_version(void) { return AMUSE_ABI_VERSION; }
+int amuse_debug_f16_split(const float* w, size_t n, uint16_t* hi, uint16_t* lo) {
+    if (!w || !hi || !lo) return fail(AMUSE_EINVAL, "NULL argument");
+    for (size_t i = 0; i < n; ++i) {
+        hi[i] = f2h(w[i]);
+        lo[i] = f2h(w[i] - h2f(hi[i]));
+    }
+    return 0;
+}
 const char* amuse_last_error(void) { return g_err; }
 
 amuse_ctx* amuse_create(int device, const float* denoiser_params, size_t n_denoiser, const float* prior_params,
@@ -642,7 +708,7 @@ int amuse_update_weights(amuse_ctx* c, const float* denoiser_params, size_t n_de
                          size_t n_prior, int what, void* stream) {
     if (!c) return fail(AMUSE_EINVAL, "ctx is NULL");
     if (!denoiser_params && !prior_params) return fail(AMUSE_EINVAL, "nothing to update");
-    if (what < 1 || what > 7 || !(what & 3)) return fail(AMUSE_EINVAL, "bad `what` mask %d", what);
+    if (what < 1 || what > AMUSE_UPD_ALL || !(what & (AMUSE_UPD_F32 | AMUSE_UPD_BF16 | AMUSE_UPD_F32X))) return fail(AMUSE_EINVAL, "bad `what` mask %d", what);
     if (denoiser_params && n_denoiser != AMUSE_DENOISER_PARAMS)
         return fail(AMUSE_EINVAL, "denoiser parameter count %zu (want %u)", n_denoiser, AMUSE_DENOISER_PARAMS);
     if (prior_params && n_prior != AMUSE_PRIOR_PARAMS)
@@ -666,9 +732,11 @@ int build_repack_maps(amuse_ctx* c) {
     struct Img { std::vector<int> map; bool prior; };
     std::map<void**, Img> imgs;
     std::vector<float> den(AMUSE_DENOISER_PARAMS), pri(AMUSE_PRIOR_PARAMS);
-    auto is_bf16 = [&](void** slot) {
-        return slot == (void**)&c->den_w[PREC_BF16] || slot == (void**)&c->den_w8 || slot == (void**)&c->vae_w[PREC_BF16] ||
-               slot == (void**)&c->vae_wf || slot == (void**)&c->vaee_w[PREC_BF16];
+    // element type of an image: 0 = fp32, 1 = bf16, 2 = split-fp16 (launch_repack's `kind`)
+    auto kind_of = [&](void** slot) {
+        if (slot == (void**)&c->den_w[PREC_F16X2]) return 2;
+        return (slot == (void**)&c->den_w[PREC_BF16] || slot == (void**)&c->den_w8 || slot == (void**)&c->vae_w[PREC_BF16] ||
+                slot == (void**)&c->vae_wf || slot == (void**)&c->vaee_w[PREC_BF16]) ? 1 : 0;
     };
     for (int k = 0; k < 3; ++k) {
         for (size_t i = 0; i < den.size(); ++i) den[i] = (float)(((i + 1) >> (8 * k)) & 255);
@@ -676,23 +744,29 @@ int build_repack_maps(amuse_ctx* c) {
         for (int which = 0; which < 2; ++which) {
             Capture cap;
             g_capture = &cap;
-            const int rc = which == 0 ? build_denoiser(c, den.data(), 7) : build_prior(c, pri.data(), 7);
+            g_probe_f16 = true;
+            const int rc = which == 0 ? build_denoiser(c, den.data(), AMUSE_UPD_ALL) : build_prior(c, pri.data(), AMUSE_UPD_ALL);
+            g_probe_f16 = false;
             g_capture = nullptr;
             if (rc) return rc;
             for (auto& kv : cap.bufs) {
                 if (kv.first == (void**)&c->den_freqs) continue;
-                const bool b16 = is_bf16(kv.first);
-                const size_t n = kv.second.size() / (b16 ? 2 : 4);
+                const int kind = kind_of(kv.first);
+                const size_t n = kv.second.size() / (kind ? 2 : 4);
                 Img& im = imgs[kv.first];
                 if (k == 0) { im.map.assign(n, 0); im.prior = which == 1; }
                 else if (im.map.size() != n) return fail(AMUSE_ESTATE, "internal: packed image changed size between probe runs");
                 for (size_t j = 0; j < n; ++j) {
                     float v;
-                    if (b16) {
+                    if (kind == 1) {
                         uint16_t h;
                         memcpy(&h, kv.second.data() + 2 * j, 2);
                         const uint32_t u = (uint32_t)h << 16;
                         memcpy(&v, &u, 4);
+                    } else if (kind == 2) {
+                        uint16_t h;
+                        memcpy(&h, kv.second.data() + 2 * j, 2);
+                        v = h2f(h);
                     } else {
                         memcpy(&v, kv.second.data() + 4 * j, 4);
                     }
@@ -709,6 +783,7 @@ int build_repack_maps(amuse_ctx* c) {
             if (m < 0 || (size_t)m > limit) return fail(AMUSE_ESTATE, "internal: gather index out of range");
         int cls = 0;   // which AMUSE_UPD_* bits the image needs; 0 = small parameters, always replaced
         if (slot == (void**)&c->den_w[PREC_F32] || slot == (void**)&c->vae_w[PREC_F32]) cls = AMUSE_UPD_F32;
+        else if (slot == (void**)&c->den_w[PREC_F16X2]) cls = AMUSE_UPD_F32X;
         else if (slot == (void**)&c->den_w[PREC_BF16] || slot == (void**)&c->den_w8 || slot == (void**)&c->vae_w[PREC_BF16] || slot == (void**)&c->vae_wf) cls = AMUSE_UPD_BF16;
         else if (slot == (void**)&c->vaee_w[PREC_F32]) cls = AMUSE_UPD_F32 | AMUSE_UPD_ENCODER;
         else if (slot == (void**)&c->vaee_w[PREC_BF16]) cls = AMUSE_UPD_BF16 | AMUSE_UPD_ENCODER;
@@ -716,7 +791,7 @@ int build_repack_maps(amuse_ctx* c) {
         HIP_TRY(hipMalloc((void**)&dmap, kv.second.map.size() * sizeof(int)));
         c->owned.push_back(dmap);
         HIP_TRY(hipMemcpy(dmap, kv.second.map.data(), kv.second.map.size() * sizeof(int), hipMemcpyHostToDevice));
-        c->repack.push_back({slot, dmap, kv.second.map.size(), kv.second.prior ? 1 : 0, is_bf16(slot) ? 1 : 0, cls});
+        c->repack.push_back({slot, dmap, kv.second.map.size(), kv.second.prior ? 1 : 0, kind_of(slot), cls});
     }
     return 0;
 }
@@ -725,15 +800,16 @@ int build_repack_maps(amuse_ctx* c) {
 int amuse_update_weights_device(amuse_ctx* c, const float* denoiser_params_dev, const float* prior_params_dev, int what, void* stream) {
     if (!c) return fail(AMUSE_EINVAL, "ctx is NULL");
     if (!denoiser_params_dev && !prior_params_dev) return fail(AMUSE_EINVAL, "nothing to update");
-    if (what < 1 || what > 7 || !(what & 3)) return fail(AMUSE_EINVAL, "bad `what` mask %d", what);
+    if (what < 1 || what > AMUSE_UPD_ALL || !(what & (AMUSE_UPD_F32 | AMUSE_UPD_BF16 | AMUSE_UPD_F32X))) return fail(AMUSE_EINVAL, "bad `what` mask %d", what);
     HIP_TRY(hipSetDevice(c->device));
     if (c->repack.empty())
         if (int e = build_repack_maps(c)) return e;
     for (const auto& r : c->repack) {
         const float* src = r.prior ? prior_params_dev : denoiser_params_dev;
         if (!src || !*r.slot) continue;                 // (an image the context never built, e.g. the 4-wave bf16 stream after an update)
-        if ((r.cls & what) != r.cls) continue;          // every bit the image needs must be requested
-        HIP_TRY(launch_repack(src, r.map, *r.slot, r.n, r.bf16, (hipStream_t)stream));
+        const int have = what | ((what & AMUSE_UPD_F32X) && r.prior ? AMUSE_UPD_F32 : 0);   // fp32x jobs use the prior's fp32 streams
+        if ((r.cls & have) != r.cls) continue;          // every bit the image needs must be requested
+        HIP_TRY(launch_repack(src, r.map, *r.slot, r.n, r.kind, (hipStream_t)stream));
     }
     // the hoisted time-token table belongs to the old time-embedding weights: rebuilt here, stream-ordered, from the schedule's
     // timesteps (still on the device) - no host round trip, the schedule stays set
@@ -748,7 +824,7 @@ void amuse_destroy(amuse_ctx* c) {
     (void)hipSetDevice(c->device);
     for (void* p : c->owned)
         if (p) (void)hipFree(p);
-    void* ptrs[] = {c->den_w[0], c->den_w[1], c->den_w8, c->den_pvec, c->den_pe, c->den_freqs, c->te_w1t, c->te_b1, c->te_w2t,
+    void* ptrs[] = {c->den_w[0], c->den_w[1], c->den_w[2], c->den_w8, c->den_pvec, c->den_pe, c->den_freqs, c->te_w1t, c->te_b1, c->te_w2t,
                     c->te_b2, c->cond_wt[0], c->cond_wt[1], c->cond_wt[2], c->cond_b[0], c->cond_b[1], c->cond_b[2],
                     c->vae_w[0], c->vae_w[1], c->vae_pvec, c->vae_final_bias, c->vae_pe, c->vae_wv_t, c->vae_bv,
                     c->vae_wo_t, c->vae_bo, c->vaee_w[0], c->vaee_w[1], c->vaee_pvec, c->vaee_pe, c->vaee_tok,
@@ -897,6 +973,7 @@ int amuse_vae_decode(amuse_ctx* c, const float* z, const int* lengths, int B, in
     if (!c) return fail(AMUSE_EINVAL, "ctx is NULL");
     if (!z) return fail(AMUSE_EINVAL, "z is NULL");
     if (B < 1) return fail(AMUSE_EINVAL, "B must be >= 1, got %d", B);
+    precision = prior_precision(precision);
     if (precision != AMUSE_PREC_F32 && precision != AMUSE_PREC_BF16) return fail(AMUSE_EINVAL, "bad precision %d", precision);
     if (quat_mode != AMUSE_QUAT_P3D && quat_mode != AMUSE_QUAT_LEGACY) return fail(AMUSE_EINVAL, "bad quat_mode %d", quat_mode);
     HIP_TRY(hipSetDevice(c->device));
@@ -969,6 +1046,7 @@ int amuse_vae_encode(amuse_ctx* c, const float* feats, const int* lengths, int B
     if (!feats) return fail(AMUSE_EINVAL, "feats is NULL");
     if (!mu_out && !std_out && !latent_out) return fail(AMUSE_EINVAL, "no output requested");
     if (B < 1) return fail(AMUSE_EINVAL, "B must be >= 1, got %d", B);
+    precision = prior_precision(precision);
     if (precision != AMUSE_PREC_F32 && precision != AMUSE_PREC_BF16) return fail(AMUSE_EINVAL, "bad precision %d", precision);
     HIP_TRY(hipSetDevice(c->device));
     hipStream_t st = (hipStream_t)stream;

@@ -24,9 +24,15 @@ namespace amuse {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
 constexpr int PREC_F32 = 0;
 constexpr int PREC_BF16 = 1;
+// "fp32x": fp32-class results at the 16-bit MFMA rate.  Weights and activations are split into two fp16 pieces each
+// (x = hi + lo with hi = rn16(x), lo = rn16(x - hi): 22 significand bits) and a product is three MFMAs,
+// Wh.xh + Wh.xl + Wl.xh, accumulated in fp32 (the dropped Wl.xl term is 2^-22 relative).  Everything outside the GEMMs
+// (softmax, LayerNorm, erf GELU, scheduler update) is the PREC_F32 code.  Same bytes per weight as fp32.
+constexpr int PREC_F16X2 = 2;
 
 constexpr int kD = 128;       // d_model
 constexpr int kTiles = 8;     // kD / 16
@@ -63,6 +69,21 @@ __device__ __forceinline__ f32x4 mfma_f32(float a, float b, f32x4 c) {
 }
 __device__ __forceinline__ f32x4 mfma_bf16(bf16x8 a, bf16x8 b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ f32x4 mfma_f16(f16x8 a, f16x8 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+}
+// Two feature tiles as one split MFMA operand (k-tile pair): hi = rn16(x) (v_cvt_pk_f16_f32, round-to-nearest-even),
+// lo = rn16(x - hi) - the subtraction is exact in fp32.
+struct F16Pair {
+    f16x8 hi, lo;
+};
+__device__ __forceinline__ F16Pair split_f16(f32x4 a, f32x4 b) {
+    const f32x8 v = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+    F16Pair p;
+    p.hi = __builtin_convertvector(v, f16x8);
+    p.lo = __builtin_convertvector(v - __builtin_convertvector(p.hi, f32x8), f16x8);
+    return p;
 }
 __device__ __forceinline__ bf16x8 pack_bf16(f32x4 lo, f32x4 hi) {
     f32x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
@@ -148,11 +169,49 @@ __device__ __forceinline__ void ring_issue(WRing<R>& rg) {
         __builtin_amdgcn_sched_barrier(0);
     }
 }
+// PREC_F16X2 with the activations already split (one split serves every GEMM that reads the same rows): NP k-tile pairs;
+// per (pair c, output tile o) the stream holds two units, Wh then Wl.  The three MFMAs of a product go out term-major
+// over the output tiles, so consecutive MFMAs never hit the same accumulator.  Small terms first.
+template <int NO, int NP, bool SWAP, int R, int PH, bool REARM = true>
+__device__ __forceinline__ void gemm_ring_s(f32x4 (&acc)[NO], const F16Pair (&xs)[NP], WRing<R>& rg) {
+#pragma unroll
+    for (int c = 0; c < NP; ++c) {
+        f16x8 wh[NO], wl[NO];
+#pragma unroll
+        for (int o = 0; o < NO; ++o) {
+            const int s0 = (PH + 2 * (c * NO + o)) % R, s1 = (PH + 2 * (c * NO + o) + 1) % R;
+            wh[o] = __builtin_bit_cast(f16x8, rg.s[s0]);
+            wl[o] = __builtin_bit_cast(f16x8, rg.s[s1]);
+            if constexpr (REARM) {
+                rg.s[s0] = ldw(rg.next);
+                rg.s[s1] = ldw(rg.next + 64);
+                rg.next += 128;
+            }
+        }
+#pragma unroll
+        for (int o = 0; o < NO; ++o) acc[o] = SWAP ? mfma_f16(xs[c].hi, wl[o], acc[o]) : mfma_f16(wl[o], xs[c].hi, acc[o]);
+#pragma unroll
+        for (int o = 0; o < NO; ++o) acc[o] = SWAP ? mfma_f16(xs[c].lo, wh[o], acc[o]) : mfma_f16(wh[o], xs[c].lo, acc[o]);
+#pragma unroll
+        for (int o = 0; o < NO; ++o) acc[o] = SWAP ? mfma_f16(xs[c].hi, wh[o], acc[o]) : mfma_f16(wh[o], xs[c].hi, acc[o]);
+    }
+}
+template <int NK>
+__device__ __forceinline__ void split_rows(F16Pair (&xs)[NK / 2], const f32x4 (&x)[NK]) {
+#pragma unroll
+    for (int c = 0; c < NK / 2; ++c) xs[c] = split_f16(x[2 * c], x[2 * c + 1]);
+}
+
 // PH = ring phase (slot of the first unit) at entry; the caller tracks it at compile time.
 // REARM: re-arm each slot as it is consumed (true) or leave that to later ring_issue calls (false).
 template <int PREC, int NO, int NK, bool SWAP, int R, int PH, bool REARM = true>
 __device__ __forceinline__ void gemm_ring(f32x4 (&acc)[NO], const f32x4 (&x)[NK], WRing<R>& rg) {
-    if constexpr (PREC == PREC_F32) {
+    if constexpr (PREC == PREC_F16X2) {
+        static_assert(NK % 2 == 0, "f16x2 units cover k-tile pairs");
+        F16Pair xs[NK / 2];
+        split_rows<NK>(xs, x);
+        gemm_ring_s<NO, NK / 2, SWAP, R, PH, REARM>(acc, xs, rg);
+    } else if constexpr (PREC == PREC_F32) {
         static_assert(NO % 2 == 0, "output tiles are processed in pairs");
 #pragma unroll
         for (int t = 0; t < NK; ++t) {
@@ -206,7 +265,8 @@ __device__ __forceinline__ void ring_discard(WRing<R>& rg) {
 }
 
 // units (1 KiB) consumed by gemm_tiles<PREC, NO, NK>
-constexpr int gemm_units(int prec, int no, int nk) { return prec == PREC_F32 ? no * nk : no * nk / 2; }
+// (f16x2: k-tile pairs x two pieces - the fp32 count)
+constexpr int gemm_units(int prec, int no, int nk) { return prec == PREC_BF16 ? no * nk / 2 : no * nk; }
 
 // All-reduce over the four 16-lane rows of a wavefront (lanes l, l^16, l^32, l^48 - the "g" axis of the
 // row-lane layout) in two VALU instructions each: v_permlane16_swap / v_permlane32_swap exchange whole rows

@@ -38,7 +38,7 @@ constexpr int kRing8 = 32;
 constexpr int kRing = 32;                 // weight-stream ring depth (1 KiB units in flight per wave)
 // fp32: the skip linear (32 units per wave) is a whole ring revolution.  bf16 (16 units) needs no padding either:
 // the decoupled-issue scheme simply leaves half the ring empty for that GEMM (k_sampler.hip).
-constexpr int skip_pad_units(int prec) { return prec == 0 ? (kRing - 32 % kRing) % kRing : 0; }
+constexpr int skip_pad_units(int prec) { return prec != 1 ? (kRing - 32 % kRing) % kRing : 0; }
 constexpr int kEncPv = 1664;              // encoder-block small params kept in LDS (PV_* up to LN2)
 constexpr int kSkipBytes = 32 * 1024;     // U-Net skip stack [4][8][64] f32x4
 constexpr int kSampleCombBytes = 4 * 8 * 64 * 16 + 4 * 16 * 8 + 8 * 64 * 16;  // = kCombBytes (amuse_dev.hpp), 41,472 B
@@ -62,7 +62,8 @@ struct CondArgs {
 };
 hipError_t launch_cond_tokens(const CondArgs& a, hipStream_t stream);
 // noisy[b] = sa[b] * z0[b] + sb[b] * noise[b]   (DDPMScheduler.add_noise; call site ldm.py:84)
-hipError_t launch_repack(const float* params, const int* map, void* dst, size_t n, int bf16, hipStream_t stream);
+// kind: 0 = fp32 image, 1 = bf16 image, 2 = split-fp16 image (1 KiB units alternate hi = rn16(w), lo = rn16(w - hi))
+hipError_t launch_repack(const float* params, const int* map, void* dst, size_t n, int kind, hipStream_t stream);
 hipError_t launch_add_noise(const float* z0, const float* noise, const float* sa, const float* sb, float* out, int B,
                             hipStream_t stream);
 hipError_t launch_counter_normal(uint64_t seed, uint64_t clip0, int B, int step, int rng_stream, float* out,

@@ -161,21 +161,26 @@ hipError_t launch_smplx_to_feats(const float* poses, const float* trans, size_t 
 
 // amuse_update_weights_device: a packed image (weight stream, parameter vector, transposed matrix) is a GATHER of the model's
 // parameters - map[j] = 1 + index of the parameter that image element j holds, 0 = padding
-__global__ __launch_bounds__(256) void k_repack(const float* __restrict__ params, const int* __restrict__ map, void* __restrict__ dst, size_t n, int bf16) {
+__global__ __launch_bounds__(256) void k_repack(const float* __restrict__ params, const int* __restrict__ map, void* __restrict__ dst, size_t n, int kind) {
     for (size_t j = (size_t)blockIdx.x * 256 + threadIdx.x; j < n; j += (size_t)gridDim.x * 256) {
         const int m = map[j];
         const float v = m ? params[m - 1] : 0.f;
-        if (bf16) {
+        if (kind == 1) {
             typedef __bf16 bf;
             reinterpret_cast<unsigned short*>(dst)[j] = __builtin_bit_cast(unsigned short, (bf)v);   // round-to-nearest-even, as the host packer
+        } else if (kind == 2) {
+            // split-fp16 image: 1 KiB units (512 elements) alternate hi / lo pieces of the same weights (amuse_api.hip pack_gemm)
+            const _Float16 hi = (_Float16)v;
+            const _Float16 out = ((j >> 9) & 1) ? (_Float16)(v - (float)hi) : hi;
+            reinterpret_cast<unsigned short*>(dst)[j] = __builtin_bit_cast(unsigned short, out);
         } else {
             reinterpret_cast<float*>(dst)[j] = v;
         }
     }
 }
-hipError_t launch_repack(const float* params, const int* map, void* dst, size_t n, int bf16, hipStream_t stream) {
+hipError_t launch_repack(const float* params, const int* map, void* dst, size_t n, int kind, hipStream_t stream) {
     const size_t blocks = (n + 255) / 256;
-    hipLaunchKernelGGL(k_repack, dim3((unsigned)(blocks < 4096 ? blocks : 4096)), dim3(256), 0, stream, params, map, dst, n, bf16);
+    hipLaunchKernelGGL(k_repack, dim3((unsigned)(blocks < 4096 ? blocks : 4096)), dim3(256), 0, stream, params, map, dst, n, kind);
     return hipGetLastError();
 }
 

@@ -28,12 +28,18 @@ template <int PREC, int NC, int IPH>
 __device__ __forceinline__ void attention_head(const f32x4 (&q)[2], const f32x4 (&k)[2], const f32x4 (&v)[2],
                                                const bool (&kvalid)[4], f32x4 (&o)[2], WRing<kRing>& rg) {
     // S^T[j][i] = sum_d K[j][d] Q[i][d]  ->  lane (g, i) holds S[i][4 g + m]
+    constexpr bool EXACT = (PREC != PREC_BF16);   // fp32 / fp32x: libm exp and IEEE division, as torch.softmax
     f32x4 st = splat4(0.f);
     if constexpr (PREC == PREC_F32) {
 #pragma unroll
         for (int td = 0; td < 2; ++td)
 #pragma unroll
             for (int m = 0; m < 4; ++m) st = mfma_f32(k[td][m], q[td][m], st);
+    } else if constexpr (PREC == PREC_F16X2) {
+        const F16Pair ks = split_f16(k[0], k[1]), qs = split_f16(q[0], q[1]);
+        st = mfma_f16(ks.lo, qs.hi, st);
+        st = mfma_f16(ks.hi, qs.lo, st);
+        st = mfma_f16(ks.hi, qs.hi, st);
     } else {
         st = mfma_bf16(pack_bf16(k[0], k[1]), pack_bf16(q[0], q[1]), st);
     }
@@ -46,15 +52,15 @@ __device__ __forceinline__ void attention_head(const f32x4 (&q)[2], const f32x4 
     float sum = 0.f;
 #pragma unroll
     for (int m = 0; m < 4; ++m) {
-        const float e = (PREC == PREC_F32) ? expf(st[m] - mx) : __builtin_amdgcn_exp2f(1.44269504088896340736f * (st[m] - mx));
+        const float e = EXACT ? expf(st[m] - mx) : __builtin_amdgcn_exp2f(1.44269504088896340736f * (st[m] - mx));
         p[m] = kvalid[m] ? e : 0.f;
         sum += p[m];
     }
     sum = allreduce_g_sum(sum);
     {
-        const float inv = (PREC == PREC_F32) ? 0.f : __builtin_amdgcn_rcpf(sum);
+        const float inv = EXACT ? 0.f : __builtin_amdgcn_rcpf(sum);
 #pragma unroll
-        for (int m = 0; m < 4; ++m) p[m] = (PREC == PREC_F32) ? p[m] / sum : p[m] * inv;
+        for (int m = 0; m < 4; ++m) p[m] = EXACT ? p[m] / sum : p[m] * inv;
     }
     ring_issue<NC, kRing, (IPH + NC) % kRing>(rg);
     // O^T[d][i] = sum_j V[j][d] P[i][j]; v is feature-lane: lane (g, d) holds V[4 g + m][d]
@@ -64,6 +70,11 @@ __device__ __forceinline__ void attention_head(const f32x4 (&q)[2], const f32x4 
         if constexpr (PREC == PREC_F32) {
 #pragma unroll
             for (int m = 0; m < 4; ++m) o[td] = mfma_f32(v[td][m], p[m], o[td]);
+        } else if constexpr (PREC == PREC_F16X2) {
+            const F16Pair vs = split_f16(v[td], splat4(0.f)), ps = split_f16(p, splat4(0.f));
+            o[td] = mfma_f16(vs.lo, ps.hi, o[td]);
+            o[td] = mfma_f16(vs.hi, ps.lo, o[td]);
+            o[td] = mfma_f16(vs.hi, ps.hi, o[td]);
         } else {
             o[td] = mfma_bf16(pack_bf16(v[td], splat4(0.f)), pack_bf16(p, splat4(0.f)), o[td]);
         }
@@ -118,8 +129,15 @@ __device__ __forceinline__ void encoder_block(f32x4 (&x)[kTiles], WRing<kRing>& 
 #pragma unroll
     for (int o = 0; o < 4; ++o) qk[o] = splat4(0.f);
     v[0] = v[1] = splat4(0.f);
-    gemm_ring<PREC, 4, kTiles, false, kRing, P_QK, !DELAY>(qk, x, rg);
-    gemm_ring<PREC, 2, kTiles, true, kRing, P_V, !DELAY>(v, x, rg);
+    if constexpr (PREC == PREC_F16X2) {   // one split of the rows serves q, k and v
+        F16Pair xs[kTiles / 2];
+        split_rows<kTiles>(xs, x);
+        gemm_ring_s<4, kTiles / 2, false, kRing, P_QK>(qk, xs, rg);
+        gemm_ring_s<2, kTiles / 2, true, kRing, P_V>(v, xs, rg);
+    } else {
+        gemm_ring<PREC, 4, kTiles, false, kRing, P_QK, !DELAY>(qk, x, rg);
+        gemm_ring<PREC, 2, kTiles, true, kRing, P_V, !DELAY>(v, x, rg);
+    }
     ring_issue<A8, kRing, 0>(rg);
     stamp<PROF>(pf);  // 1: in_proj done
     const float scaling = 0.17677669529663687f;  // sqrt(1/32): q * scaling (F.multi_head_attention_forward)
@@ -166,6 +184,20 @@ __device__ __forceinline__ void encoder_block(f32x4 (&x)[kTiles], WRing<kRing>& 
     };
     // fp32: always re-arm at consumption; bf16: the first four unit groups re-arm (with the last four), the last
     // four leave the ring to be re-armed during combine 2
+    if constexpr (PREC == PREC_F16X2) {   // the four linear1 quarters read the same rows: split them once
+        F16Pair xs[kTiles / 2];
+        split_rows<kTiles>(xs, x);
+        gemm_ring_s<2, kTiles / 2, false, kRing, (0 * U_Q) % kRing>(hq[0], xs, rg);         // F1 q0
+        gemm_ring_s<2, kTiles / 2, false, kRing, (1 * U_Q) % kRing>(hq[1], xs, rg);         // F1 q1
+        gelu_quarter(0);
+        gemm_ring<PREC, kTiles, 2, false, kRing, (2 * U_Q) % kRing, true>(part, hq[0], rg); // F2 q0
+        stamp<PROF>(pf);
+        gemm_ring_s<2, kTiles / 2, false, kRing, (3 * U_Q) % kRing>(hq[2], xs, rg);         // F1 q2
+        gelu_quarter(1);
+        gemm_ring<PREC, kTiles, 2, false, kRing, (4 * U_Q) % kRing, true>(part, hq[1], rg); // F2 q1
+        stamp<PROF>(pf);
+        gemm_ring_s<2, kTiles / 2, false, kRing, (5 * U_Q) % kRing>(hq[3], xs, rg);         // F1 q3
+    } else {
     gemm_ring<PREC, 2, kTiles, false, kRing, (0 * U_Q) % kRing, true>(hq[0], x, rg);        // F1 q0
     gemm_ring<PREC, 2, kTiles, false, kRing, (1 * U_Q) % kRing, true>(hq[1], x, rg);        // F1 q1
     gelu_quarter(0);
@@ -176,6 +208,7 @@ __device__ __forceinline__ void encoder_block(f32x4 (&x)[kTiles], WRing<kRing>& 
     gemm_ring<PREC, kTiles, 2, false, kRing, (4 * U_Q) % kRing, !DELAY>(part, hq[1], rg);   // F2 q1
     stamp<PROF>(pf);
     gemm_ring<PREC, 2, kTiles, false, kRing, (5 * U_Q) % kRing, !DELAY>(hq[3], x, rg);      // F1 q3
+    }
     gelu_quarter(2);
     gemm_ring<PREC, kTiles, 2, false, kRing, (6 * U_Q) % kRing, !DELAY>(part, hq[2], rg);   // F2 q2
     stamp<PROF>(pf);
@@ -404,10 +437,12 @@ hipError_t launch_sample(const SampleArgs& a, int precision, hipStream_t stream)
     const dim3 grid(tiles), block(256);
     static bool attr_set = false;
     if (!attr_set) {
-        const void* ks[4] = {reinterpret_cast<const void*>(&k_sample<PREC_F32, false>),
+        const void* ks[6] = {reinterpret_cast<const void*>(&k_sample<PREC_F32, false>),
                              reinterpret_cast<const void*>(&k_sample<PREC_BF16, false>),
+                             reinterpret_cast<const void*>(&k_sample<PREC_F16X2, false>),
                              reinterpret_cast<const void*>(&k_sample<PREC_F32, true>),
-                             reinterpret_cast<const void*>(&k_sample<PREC_BF16, true>)};
+                             reinterpret_cast<const void*>(&k_sample<PREC_BF16, true>),
+                             reinterpret_cast<const void*>(&k_sample<PREC_F16X2, true>)};
         for (const void* k : ks) {
             hipError_t e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, kSampleLdsBytes);
             if (e != hipSuccess) return e;
@@ -416,9 +451,11 @@ hipError_t launch_sample(const SampleArgs& a, int precision, hipStream_t stream)
     }
     if (a.prof_out) {
         if (precision == PREC_F32) hipLaunchKernelGGL((k_sample<PREC_F32, true>), grid, block, kSampleLdsBytes, stream, a);
+        else if (precision == PREC_F16X2) hipLaunchKernelGGL((k_sample<PREC_F16X2, true>), grid, block, kSampleLdsBytes, stream, a);
         else hipLaunchKernelGGL((k_sample<PREC_BF16, true>), grid, block, kSampleLdsBytes, stream, a);
     } else {
         if (precision == PREC_F32) hipLaunchKernelGGL((k_sample<PREC_F32, false>), grid, block, kSampleLdsBytes, stream, a);
+        else if (precision == PREC_F16X2) hipLaunchKernelGGL((k_sample<PREC_F16X2, false>), grid, block, kSampleLdsBytes, stream, a);
         else hipLaunchKernelGGL((k_sample<PREC_BF16, false>), grid, block, kSampleLdsBytes, stream, a);
     }
     return hipGetLastError();

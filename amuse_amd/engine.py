@@ -12,7 +12,10 @@ from . import _lib
 from . import weights as wts
 from .scheduler import ScheduleTable, timestep_freqs
 
-PREC = {"fp32": _lib.PREC_F32, "f32": _lib.PREC_F32, "bf16": _lib.PREC_BF16}
+# "fp32x": the fast parity mode of the sampling loop (split-fp16 MFMA operands, include/amuse_hip.h AMUSE_PREC_F32X)
+_N_DEN = sum(int(np.prod(s)) for s in wts.denoiser_param_spec().values())   # AMUSE_DENOISER_PARAMS
+_N_PRI = sum(int(np.prod(s)) for s in wts.prior_param_spec().values())      # AMUSE_PRIOR_PARAMS
+PREC = {"fp32": _lib.PREC_F32, "f32": _lib.PREC_F32, "bf16": _lib.PREC_BF16, "fp32x": _lib.PREC_F32X, "f32x": _lib.PREC_F32X}
 QUAT = {"p3d": _lib.QUAT_P3D, "legacy": _lib.QUAT_LEGACY}
 
 
@@ -64,9 +67,9 @@ class HipEngine:
         self.schedule: Optional[ScheduleTable] = None
         self.noisy_cfg: Dict[str, object] = {}   # DDPMScheduler config of add_noise (set_noisy_scheduler)
 
-    def update_weights(self, denoiser_sd=None, prior_sd=None, what: int = 7):
+    def update_weights(self, denoiser_sd=None, prior_sd=None, what: int = _lib.UPD_ALL):
         """amuse_update_weights: new state dicts (or pre-flattened float32 arrays in state-dict order) into this context;
-        `what` = AMUSE_UPD_* mask (1 fp32 streams, 2 bf16 streams, 4 prior-encoder streams too).  The current schedule
+        `what` = AMUSE_UPD_* mask (1 fp32 streams, 2 bf16 streams, 8 fp32x streams, 4 prior-encoder streams too).  The current schedule
         is re-applied after a denoiser update."""
         fp = C.POINTER(C.c_float)
 
@@ -84,7 +87,7 @@ class HipEngine:
         if den is not None and self.schedule is not None:
             self.set_schedule(self.schedule)
 
-    def update_weights_device(self, denoiser_flat: Optional[torch.Tensor] = None, prior_flat: Optional[torch.Tensor] = None, what: int = 7):
+    def update_weights_device(self, denoiser_flat: Optional[torch.Tensor] = None, prior_flat: Optional[torch.Tensor] = None, what: int = _lib.UPD_ALL):
         """amuse_update_weights_device: the same from flat float32 CUDA tensors in state-dict order (flatten_on_device) - a gather
         kernel per packed image, stream-ordered, no host round trip; the library rebuilds the schedule's time-token table itself."""
         def ptr(t, n):
@@ -94,7 +97,7 @@ class HipEngine:
                 raise ValueError(f"expected a contiguous float32 CUDA tensor of {n} elements")
             return C.c_void_p(t.data_ptr())
         with torch.cuda.device(self.device):
-            _lib.check(self.lib.amuse_update_weights_device(self.ctx, ptr(denoiser_flat, 2192384), ptr(prior_flat, 4643277),   # AMUSE_DENOISER_PARAMS / AMUSE_PRIOR_PARAMS
+            _lib.check(self.lib.amuse_update_weights_device(self.ctx, ptr(denoiser_flat, _N_DEN), ptr(prior_flat, _N_PRI),
                                                             int(what), self._stream()))
 
     def close(self):

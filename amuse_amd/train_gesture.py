@@ -224,6 +224,10 @@ class GestureTrainer:
         # gradient in the reference (grad stays None after zero_grad(set_to_none=True)), so its AdamW never touches them -
         # not even with weight decay.  They stay in the bucket (zeros) but out of the optimizer.
         unused = {id(ldm.denoiser.mem_pos.pe)}
+        # ... and so do the projections of a condition token the ablation variant drops (trainer.py:393-399: `emotion` /
+        # `baseline` feed no style token, `identity` no emotion token): their gradients stay None in the reference
+        dropped = {"emotion": ("emb_proj_sty",), "baseline": ("emb_proj_sty",), "identity": ("emb_proj_emo",)}.get(kind or "", ())
+        unused |= {id(p) for n, p in ldm.denoiser.named_parameters() if n.split(".")[0] in dropped}
         # the multi-tensor ("fused") AdamW of torch on the GPU: the same update in a handful of launches instead of ~10 per
         # parameter group of the default foreach path (2.7 ms of device time and 4.8 ms of host time per iteration, section 4.6)
         fused = self.device.type == "cuda" and os.environ.get("AMUSE_TRAIN_OPT", "fused") == "fused"
@@ -349,6 +353,9 @@ class GestureTrainer:
                                                 rank: int = 0, on_iteration: Optional[Callable] = None):
         iter_start_time = time.time()
         for epoch in range(epochs):
+            sampler = getattr(train_loader, "sampler", None)
+            if hasattr(sampler, "set_epoch"):
+                sampler.set_epoch(epoch)   # a DistributedSampler reshuffles per epoch only when told (the reference's DataLoader(shuffle=True) does by itself)
             for batch in train_loader:
                 self.train_step(batch)
                 if on_iteration is not None:
@@ -372,14 +379,15 @@ class HipInnerSampler:
     CURRENT weights.  refresh = n: amuse_update_weights every n-th call (1 = every iteration, the reference's semantics)."""
 
     def __init__(self, trainer_models: Dict[str, nn.Module], device, precision: str = "bf16", refresh: int = 1, seed: int = 2024,
-                 ldm_cfg: Optional[dict] = None, flat: Optional[tuple] = None):
+                 ldm_cfg: Optional[dict] = None, flat: Optional[tuple] = None, rank: int = 0, world: int = 1):
         from .engine import HipEngine
         self.models, self.precision, self.refresh, self.seed = trainer_models, precision, max(1, refresh), seed
         self.flat = flat                        # (prior, denoiser) flat fp32 images that ARE the parameters (GestureTrainer.flat_param)
         self.engine = HipEngine(self._den_state(), self._prior_state(), device)
         self.engine.set_schedule(sch.from_ldm_cfg(ldm_cfg, "ddim") if ldm_cfg and "scheduler" in ldm_cfg else sch.ddim_table())
         self.calls, self.clip_counter, self.sync_ms = 0, 0, []
-        self.what = (2 if precision == "bf16" else 1)
+        self.rank, self.world = rank, world
+        self.what = {"bf16": 2, "fp32x": 8}.get(precision, 1)   # AMUSE_UPD_* mask of the streams this sampler runs
         self.on_device = os.environ.get("AMUSE_TRAIN_REPACK", "device") != "host"   # A/B switch: the host path of amuse_update_weights
 
     def _den_state(self):
@@ -405,8 +413,9 @@ class HipInnerSampler:
                 self.engine.update_weights(self._den_state(), self._prior_state(), what=self.what)
             self.sync_ms.append((time.perf_counter() - t0) * 1e3)
         self.calls += 1
-        lat = self.engine.sample(con, emo, sty, self.precision, seed=self.seed, clip_index0=self.clip_counter)
-        self.clip_counter += bsz
+        # initial latents are keyed by a global clip index: rank r draws clips [counter + r * bsz, counter + (r + 1) * bsz)
+        lat = self.engine.sample(con, emo, sty, self.precision, seed=self.seed, clip_index0=self.clip_counter + self.rank * bsz)
+        self.clip_counter += bsz * self.world
         return self.engine.vae_decode(lat, None, self.precision, return_feats=True)["feats"]
 
 
@@ -424,7 +433,7 @@ def build_trainer(device, rank: int = 0, world: int = 1, process_group=None, see
             raise RuntimeError("the in-loop sampler of train_gesture runs on the HIP kernels: no CPU path (pass use_hip_sampler=False "
                                "to train without the no-gradient gen_feature term)")
         tr.inner_sampler = HipInnerSampler(tr.model, device, refresh=sampler_refresh, ldm_cfg=ldm_cfg,
-                                           flat=(tr.flat_param[:tr.n_prior], tr.flat_param[tr.n_prior:]))
+                                           flat=(tr.flat_param[:tr.n_prior], tr.flat_param[tr.n_prior:]), rank=rank, world=world)
     return tr
 
 
@@ -436,8 +445,8 @@ def bench_main(args):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if world != args.gpus:   # (bench.py starts the ranks itself when it was not launched by torch.distributed.run)
+        raise SystemExit(f"--gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py --config train needs an MI355X")
     torch.cuda.set_device(local_rank)
@@ -492,24 +501,53 @@ def bench_main(args):
 
 
 def main(argv=None):
+    """`python -m amuse_amd.train_gesture [--gpus N]`: one process per GPU.  Under torch.distributed.run this process is a rank
+    (RANK / LOCAL_RANK / WORLD_SIZE); typed directly with --gpus N > 1 it starts the ranks itself (amuse_amd/launch.py)."""
     import argparse
+    import sys
     ap = argparse.ArgumentParser(description="train_gesture: the LPDM iteration on the BEAT latent-diffusion cache (--cache, amuse_amd/dataload.py; "
                                              "needs `lmdb` + a pyarrow with `deserialize`) or on synthetic batches of the same shape")
     ap.add_argument("--cache", default=None, help="the LMDB cache directory of dm/dataload.py:113-129 (default: synthetic data)")
-    ap.add_argument("--batch", type=int, default=32)
+    ap.add_argument("--batch", type=int, default=32, help="per process, like the reference's batch_size")
     ap.add_argument("--epochs", type=int, default=1)
     ap.add_argument("--iters-per-epoch", type=int, default=8)
     ap.add_argument("--out", default=None)
-    ap.add_argument("--device", default="cuda:0")
+    ap.add_argument("--device", default=None, help="default: cuda:<LOCAL_RANK>")
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--seed", type=int, default=2024, help="TRAIN_PARAM.seed (configs/base_new.json)")
     args = ap.parse_args(argv)
-    tr = build_trainer(args.device)
+    from . import launch
+    if args.gpus > 1 and not launch.launched_by_torchrun():
+        return launch.run_ranks("amuse_amd.train_gesture", list(sys.argv[1:] if argv is None else argv), args.gpus, module=True)
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    device = torch.device(args.device or (f"cuda:{local_rank}" if torch.cuda.is_available() else "cpu"))
+    pg = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if device.type == "cuda":
+            torch.cuda.set_device(device)
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            dist.init_process_group("gloo")
+        pg = dist.group.WORLD
+    from .main import fixseed
+    fixseed(args.seed + rank)            # scripts/main.py fixseed(TRAIN_PARAM.seed); per-rank offset: ranks draw different noise / timesteps
+    tr = build_trainer(device, rank, world, process_group=pg, use_hip_sampler=device.type == "cuda")
     if args.cache:
         from .dataload import LatentDiffusionCache, make_loader
-        loader = make_loader(LatentDiffusionCache.open(args.cache), args.batch)
+        loader = make_loader(LatentDiffusionCache.open(args.cache), args.batch, rank=rank, world=world, seed=args.seed)
     else:
-        loader = [synthetic_batch(args.batch, i, args.device) for i in range(args.iters_per_epoch)]
-    tr.train_prior_latdiff_forward_backward_v2(loader, args.epochs, args.out, model_save_freq=1)
+        loader = [synthetic_batch(args.batch, 1000 * rank + i, device) for i in range(args.iters_per_epoch)]
+    tr.train_prior_latdiff_forward_backward_v2(loader, args.epochs, args.out, model_save_freq=1, rank=rank)
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier()
+        dist.destroy_process_group()
+    return 0
 
 
 if __name__ == "__main__":
-    main()
+    raise SystemExit(main())

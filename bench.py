@@ -10,8 +10,10 @@ the global clip index, clips per workgroup tile chosen from the job's total so t
 bitwise the single-GPU result, no collective on the data path).  The weak-scaling figure (256 clips
 PER rank) is reported beside it as `weak_scaling`, never as `value`.
 
-  python bench.py [--gpus N --steps K --warmup W]      (N > 1: launched by torch.distributed.run)
-Prints ONE JSON line on rank 0.
+  python bench.py [--gpus N --steps K --warmup W]
+N > 1: one process per GPU.  Under torch.distributed.run (RANK / WORLD_SIZE in the environment) this process IS a rank;
+typed directly, it starts the N ranks itself as children (amuse_amd/launch.py - before anything touches the GPU) and
+passes rank 0's line through.  Prints ONE JSON line on rank 0.
 """
 import argparse
 import json
@@ -120,6 +122,10 @@ def main():
     ap.add_argument("--no-audio", action="store_true", help="skip the audio front-end side measurement")
     ap.add_argument("--no-extras", action="store_true", help="headline + roofline only (profiling runs)")
     args = ap.parse_args()
+    from amuse_amd import launch
+    if args.gpus > 1 and not launch.launched_by_torchrun():
+        # typed as `python bench.py --gpus N`: this process becomes the launcher of N ranks and never initialises the GPU
+        raise SystemExit(launch.run_ranks(str(Path(__file__).resolve()), sys.argv[1:], args.gpus))
     if args.config == "train":
         from amuse_amd import train_gesture
         return train_gesture.bench_main(args)
@@ -135,7 +141,7 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+        raise SystemExit(f"--gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
     torch.cuda.set_device(local_rank)

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define AMUSE_ABI_VERSION 1
+#define AMUSE_ABI_VERSION 2   /* 2: AMUSE_PREC_F32X, AMUSE_UPD_F32X; tile-major amuse_debug_gemm; clips per group 1..5 */
 
 /* architecture the kernels are specialised for (configs/diff_latent_v2.json:23-47,
  * configs/prior_emotional_fing.json:6-20, configs/base_new.json "train_pose_framelen") */
@@ -48,8 +48,13 @@ enum { AMUSE_OK = 0, AMUSE_EINVAL = -1, AMUSE_EHIP = -2, AMUSE_ENOMEM = -3, AMUS
 
 /* arithmetic of the MFMA GEMMs.  F32: fp32 weights/operands (v_mfma_f32_16x16x4_f32, exact fp32
  * FMA chains) - the parity mode.  BF16: bf16 weights + bf16-rounded operands, fp32 accumulate,
- * fp32 residual stream / LayerNorm / softmax / scheduler state - the throughput mode. */
-enum { AMUSE_PREC_F32 = 0, AMUSE_PREC_BF16 = 1 };
+ * fp32 residual stream / LayerNorm / softmax / scheduler state - the throughput mode.
+ * F32X: the fast parity mode of the sampling loop - every GEMM operand (weights on the host, activations in registers)
+ * is split into two fp16 pieces, x = hi + lo (22 significand bits), and a product is three v_mfma_f32_16x16x32_f16
+ * (Wh.xh + Wh.xl + Wl.xh) accumulated in fp32; softmax, LayerNorm, erf GELU and the scheduler update are the F32 code.
+ * Holds the F32 mode's parity bars (eps_hat <= 1e-5 against the reference's modules) at a fraction of its step time.
+ * amuse_vae_decode / amuse_vae_encode run their F32 kernels when asked for F32X. */
+enum { AMUSE_PREC_F32 = 0, AMUSE_PREC_BF16 = 1, AMUSE_PREC_F32X = 2 };
 
 /* matrix -> quaternion convention of the axis-angle epilogue (infer_ldm.py:172):
  * P3D   = pytorch3d >= 0.5 candidate selection, no sign standardisation (what the reference's
@@ -85,11 +90,11 @@ amuse_ctx* amuse_create(int device, const float* denoiser_params, size_t n_denoi
  * Replaces what the reference gets for free from sharing nn.Module parameters between its training step and the
  * in-loop sampler (scripts/trainer.py:411-415: ldm.diffusion_backward + prior.decode on the weights just stepped).
  * Either array may be NULL (left as is).  `what` limits the host-side packing to what the caller will run:
- * AMUSE_UPD_F32 | AMUSE_UPD_BF16 = the weight streams of that precision, AMUSE_UPD_ENCODER = MotionPrior.encode's streams
- * too.  Small parameters (biases, LayerNorm, embeddings) are always replaced, so after a partial update only the
+ * AMUSE_UPD_F32 | AMUSE_UPD_BF16 | AMUSE_UPD_F32X = the weight streams of that precision (F32X: the sampler's split-fp16
+ * stream and the prior's F32 streams), AMUSE_UPD_ENCODER = MotionPrior.encode's streams too.  Small parameters (biases, LayerNorm, embeddings) are always replaced, so after a partial update only the
  * re-packed precision is valid - running the other one mixes old matrices with new vectors.  Synchronises `stream` first; after a denoiser update the
  * schedule must be set again (the time-token table is a function of the time-embedding weights). */
-enum { AMUSE_UPD_F32 = 1, AMUSE_UPD_BF16 = 2, AMUSE_UPD_ENCODER = 4, AMUSE_UPD_ALL = 7 };
+enum { AMUSE_UPD_F32 = 1, AMUSE_UPD_BF16 = 2, AMUSE_UPD_ENCODER = 4, AMUSE_UPD_F32X = 8, AMUSE_UPD_ALL = 15 };
 int amuse_update_weights(amuse_ctx* ctx, const float* denoiser_params, size_t n_denoiser, const float* prior_params,
                          size_t n_prior, int what, void* stream);
 /* The same from DEVICE arrays (fp32, state-dict order, as above), stream-ordered on `stream` with no host round trip: every packed
@@ -254,6 +259,11 @@ int amuse_debug_gemm(const void* A, const void* W, const float* bias, int M, int
 /* Row-major <-> tile-major copies for the above (F % 32 == 0).  what 0: bf16 row-major [M][F] -> tile-major [M rounded up
  * to 128][F], pad rows zeroed; 1: bf16 tile-major -> row-major [M][F]; 2: fp32 tile-major -> row-major [M][F]. */
 int amuse_debug_tile(const void* src, void* dst, int M, int F, int what, void* stream);
+
+/* The host packer's fp32 -> (hi, lo) fp16 split of AMUSE_PREC_F32X, for tests (host memory, no GPU call):
+ * hi[i] = rn16(w[i]), lo[i] = rn16(w[i] - hi[i]), round-to-nearest-even with gradual underflow - bit for bit what
+ * v_cvt_pk_f16_f32 produces on the device for the activations (and amuse_update_weights_device for the weights). */
+int amuse_debug_f16_split(const float* w, size_t n, uint16_t* hi, uint16_t* lo);
 
 #ifdef __cplusplus
 }

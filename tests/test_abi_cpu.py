@@ -23,7 +23,34 @@ def test_library_exports_every_declared_symbol():
     for name in decl:
         assert hasattr(lib, name), f"{name} declared in amuse_hip.h but not exported"
     assert sorted(_lib.EXPORTS) == decl
-    assert lib.amuse_abi_version() == 1
+    hdr = (REPO / "include/amuse_hip.h").read_text()
+    assert lib.amuse_abi_version() == int(re.search(r"#define AMUSE_ABI_VERSION (\d+)", hdr).group(1)) == _lib.ABI_VERSION == 2
+
+
+def test_f16_split_of_the_fp32x_mode_matches_numpy():
+    """The host packer's hi / lo split (amuse_api.hip f2h / h2f, used for AMUSE_PREC_F32X's weight stream) against numpy's
+    IEEE float16 conversion: normal range, subnormal results, ties, overflow, signed zeros - bit for bit - and the split
+    keeps 22 significand bits."""
+    import ctypes as C
+    from amuse_amd import _lib
+    lib = _lib.load()
+    rng = np.random.default_rng(0)
+    w = np.concatenate([rng.standard_normal(20000).astype(np.float32) * s for s in (1.0, 0.05, 1e-3, 1e-5, 3e-7, 100.0, 3e4)]
+                       + [np.array([0.0, -0.0, 1.0, 1.00048828125, 1.00146484375, 65504.0, 65519.9, 65520.0, -7e4, 6.1035e-5, 5.96e-8,
+                                    2.98e-8, 2.9802325e-8, 8.94e-8, 1e-9], np.float32)])
+    hi, lo = np.zeros(w.size, np.uint16), np.zeros(w.size, np.uint16)
+    f, u = C.POINTER(C.c_float), C.POINTER(C.c_uint16)
+    assert lib.amuse_debug_f16_split(w.ctypes.data_as(f), w.size, hi.ctypes.data_as(u), lo.ctypes.data_as(u)) == 0
+    with np.errstate(over="ignore"):
+        ref_hi = w.astype(np.float16)
+        fin = np.isfinite(ref_hi)
+        ref_lo = (w[fin] - ref_hi[fin].astype(np.float32)).astype(np.float16)
+    assert np.array_equal(hi, ref_hi.view(np.uint16))
+    assert np.array_equal(lo[fin], ref_lo.view(np.uint16))
+    both = hi.view(np.float16)[fin].astype(np.float64) + lo.view(np.float16)[fin].astype(np.float64)
+    # 22 significand bits while the lo piece is a normal fp16 number (|w| >= 2^-2); below that it is subnormal and the
+    # split is exact to half a unit of 2^-24 - MI355X's MFMA keeps subnormal fp16 operands (tools/probes/f16_denorm_probe.hip)
+    assert np.all(np.abs(both - w[fin]) <= np.maximum(2.0 ** -22 * np.abs(w[fin]), 2.0 ** -25))
 
 
 def test_create_rejects_bad_sizes_without_touching_the_gpu():

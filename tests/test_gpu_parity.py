@@ -17,6 +17,10 @@ from conftest import GOLDEN
 
 pytestmark = pytest.mark.gpu
 
+# the two parity modes are held to the SAME bars: "fp32" (v_mfma_f32_16x16x4_f32) and "fp32x" (split-fp16 operands, three
+# v_mfma_f32_16x16x32_f16 per product - include/amuse_hip.h AMUSE_PREC_F32X)
+PARITY = ("fp32", "fp32x")
+
 
 def _conditioning(orc, feats):
     """Per joint: |a1|, |a2 - (b1.a2) b1| (Gram-Schmidt pivots of the 6D rotation) and the margin between
@@ -69,12 +73,13 @@ def test_counter_normal_matches_restatement(env):
     assert abs(z.mean()) < 0.01 and abs(z.std() - 1) < 0.01
 
 
-def test_denoise_step_fp32_vs_reference_golden(env):
+@pytest.mark.parametrize("prec", PARITY)
+def test_denoise_step_fp32_vs_reference_golden(env, prec):
     orc, eng, Wd = env["orc"], env["eng"], env["Wd"]
     g = np.load(GOLDEN / "denoiser_steps.npz")
     con, emo, sty, x = (g[k] for k in ("con", "emo", "sty", "x_t"))
     for t in (981, 501, 1):
-        eps, tap = eng.denoise_step(x, t, con, emo, sty, "fp32", taps=True)
+        eps, tap = eng.denoise_step(x, t, con, emo, sty, prec, taps=True)
         assert _err(eps, g[f"eps_t{t}"]) < 1e-5
         if t == 981:
             tp = tap.cpu().numpy()
@@ -83,11 +88,12 @@ def test_denoise_step_fp32_vs_reference_golden(env):
             assert _err(tp[5, :5], g["tap981/encoder.middle_block"][0]) < 1e-5
             assert _err(tp[9, :5], g["tap981/encoder.output_blocks.3"][0]) < 1e-5
     # token dropping: emo / sty None (denoiser.py:159-171) -> S = 4 / 3
-    assert _err(eng.denoise_step(x, 501, con, None, sty, "fp32"), g["eps_t501_noemo"]) < 1e-5
-    assert _err(eng.denoise_step(x, 501, con, None, None, "fp32"), g["eps_t501_consolo"]) < 1e-5
+    assert _err(eng.denoise_step(x, 501, con, None, sty, prec), g["eps_t501_noemo"]) < 1e-5
+    assert _err(eng.denoise_step(x, 501, con, None, None, prec), g["eps_t501_consolo"]) < 1e-5
 
 
-def test_denoise_step_clip_tiling_is_invisible(env):
+@pytest.mark.parametrize("prec", PARITY)
+def test_denoise_step_clip_tiling_is_invisible(env, prec):
     """1, 2 or 3 clips per workgroup tile, ragged last tile: same numbers."""
     orc, eng, Wd = env["orc"], env["eng"], env["Wd"]
     gen = torch.Generator().manual_seed(1)
@@ -97,7 +103,7 @@ def test_denoise_step_clip_tiling_is_invisible(env):
     try:
         for G in (1, 2, 3):
             eng.set_clips_per_group(G)
-            outs.append(eng.denoise_step(x, 321, c, e, s, "fp32").cpu())
+            outs.append(eng.denoise_step(x, 321, c, e, s, prec).cpu())
             assert _err(outs[-1], ref) < 1e-5
     finally:
         eng.set_clips_per_group(0)
@@ -173,7 +179,8 @@ def test_bf16_kernels_4_and_8_waves_agree(env):
         assert _err(w4["lat"], lat8) < 0.3                     # bf16 drift class over 50 steps (latent rms 0.53)
 
 
-def test_diffusion_forward_per_clip_timesteps(env):
+@pytest.mark.parametrize("prec", PARITY)
+def test_diffusion_forward_per_clip_timesteps(env, prec):
     """amuse_diffusion_forward (ldm.py:71-97): per-clip timesteps vs the reference Denoiser golden and the oracle."""
     orc, eng, Wd = env["orc"], env["eng"], env["Wd"]
     g = np.load(GOLDEN / "denoiser_steps.npz")
@@ -181,7 +188,7 @@ def test_diffusion_forward_per_clip_timesteps(env):
     # noise = 0 and z0 = x_t / sqrt(abar_t) reproduce the golden's noisy latent
     ac = orc.SchedulerBase().alphas_cumprod
     z0 = torch.from_numpy(g["x_t"]) / ac[torch.tensor(ts)].sqrt()[:, None]
-    out = eng.diffusion_forward(z0, torch.zeros(3, 128), ts, g["con"], g["emo"], g["sty"], "fp32")
+    out = eng.diffusion_forward(z0, torch.zeros(3, 128), ts, g["con"], g["emo"], g["sty"], prec)
     assert _err(out["noisy_latents"], g["x_t"]) < 1e-6
     assert _err(out["noise_pred"], g["eps_batch_t"]) < 1e-5
     # general case against the oracle: 70 clips (clip tiles of several kinds), token dropping
@@ -190,20 +197,21 @@ def test_diffusion_forward_per_clip_timesteps(env):
     z, n, con, emo = (torch.randn(B, d, generator=gen) for d in (128, 128, 256, 256))
     ts = torch.randint(0, 1000, (B,), generator=gen).tolist()
     ref = orc.diffusion_forward(Wd, z, n, ts, con, emo, None)
-    out = eng.diffusion_forward(z, n, ts, con, emo, None, "fp32")
+    out = eng.diffusion_forward(z, n, ts, con, emo, None, prec)
     assert _err(out["noisy_latents"], ref["noisy_latents"]) < 1e-6
     assert _err(out["noise_pred"], ref["noise_pred"]) < 1e-5
     with pytest.raises(ValueError):
         eng.diffusion_forward(z, n, [1000] * B, con, emo, None)
 
 
-def test_ddim50_fp32_matches_reference_trajectory(env):
+@pytest.mark.parametrize("prec", PARITY)
+def test_ddim50_fp32_matches_reference_trajectory(env, prec):
     from amuse_amd import scheduler as sch
     eng = env["eng"]
     tr = np.load(GOLDEN / "ddim50_traj.npz")
     eng.set_schedule(sch.ddim_table())
     assert list(eng.schedule.timesteps) == list(range(981, 0, -20))
-    lat, traj = eng.sample(tr["con"], tr["emo"], tr["sty"], "fp32", x_init=tr["x_T"], return_traj=True)
+    lat, traj = eng.sample(tr["con"], tr["emo"], tr["sty"], prec, x_init=tr["x_T"], return_traj=True)
     for i in (10, 20, 30, 40, 50):
         assert _err(traj[i - 1], tr[f"x_after_{i}"]) < 1e-4, i
     assert torch.equal(lat, traj[-1])
@@ -212,7 +220,8 @@ def test_ddim50_fp32_matches_reference_trajectory(env):
     assert _err(latb, tr["x_after_50"]) < 0.3   # 64-clip statistics are gated in test_gpu_configs.py (rms 0.08 / max 0.46)
 
 
-def test_ddpm_explicit_noise_vs_oracle(env):
+@pytest.mark.parametrize("prec", PARITY)
+def test_ddpm_explicit_noise_vs_oracle(env, prec):
     """Ancestral DDPM (strided to 100 steps so the CPU oracle stays fast) with explicit x_T and noise."""
     from amuse_amd import scheduler as sch
     orc, eng, Wd = env["orc"], env["eng"], env["Wd"]
@@ -221,7 +230,7 @@ def test_ddpm_explicit_noise_vs_oracle(env):
     c, e, s, x = (torch.randn(B, n, generator=gen) for n in (256, 256, 256, 128))
     nz = torch.randn(T, B, 128, generator=gen)
     eng.set_schedule(sch.ddpm_table(T))
-    lat, traj = eng.sample(c, e, s, "fp32", x_init=x, step_noise=nz, return_traj=True)
+    lat, traj = eng.sample(c, e, s, prec, x_init=x, step_noise=nz, return_traj=True)
     osched = orc.DDPM(T)
     assert list(eng.schedule.timesteps) == osched.timesteps
     otraj = []
@@ -231,7 +240,8 @@ def test_ddpm_explicit_noise_vs_oracle(env):
     assert _err(lat, otraj[-1]) < 2e-4 * max(1.0, scale)
 
 
-def test_ddpm1000_fp32_single_clip_vs_oracle(env):
+@pytest.mark.parametrize("prec", PARITY)
+def test_ddpm1000_fp32_single_clip_vs_oracle(env, prec):
     """BASELINE config 2 shape: 1 clip, the full 1000-step ancestral DDPM, explicit x_T and per-step noise."""
     from amuse_amd import scheduler as sch
     orc, eng, Wd = env["orc"], env["eng"], env["Wd"]
@@ -239,7 +249,7 @@ def test_ddpm1000_fp32_single_clip_vs_oracle(env):
     c, e, s, x = (torch.randn(1, n, generator=gen) for n in (256, 256, 256, 128))
     nz = torch.randn(1000, 1, 128, generator=gen)
     eng.set_schedule(sch.ddpm_table())
-    lat = eng.sample(c, e, s, "fp32", x_init=x, step_noise=nz)
+    lat = eng.sample(c, e, s, prec, x_init=x, step_noise=nz)
     ref = orc.sample_latents(Wd, orc.DDPM(), c, e, s, x, nz)
     scale = float(ref.abs().max())          # random weights drive the latent to rms ~ 30 (no clipping in DDPM)
     assert _err(lat, ref) < 3e-5 * scale    # measured 1.5e-4 abs on rms 31 (4.6e-6 relative)
@@ -252,7 +262,7 @@ def test_in_kernel_noise_is_shard_invariant(env):
     gen = torch.Generator().manual_seed(9)
     c, e, s = (torch.randn(8, 256, generator=gen) for _ in range(3))
     eng.set_schedule(sch.ddpm_table(50))
-    for prec in ("fp32", "bf16"):
+    for prec in ("fp32", "bf16", "fp32x"):
         full = eng.sample(c, e, s, prec, seed=2024, clip_index0=16)
         a = eng.sample(c[:4], e[:4], s[:4], prec, seed=2024, clip_index0=16)
         b = eng.sample(c[4:], e[4:], s[4:], prec, seed=2024, clip_index0=20)
@@ -277,7 +287,7 @@ def test_in_kernel_noise_equals_explicit_counter_noise(env):
     try:
         for G in (1, 2, 3):
             eng.set_clips_per_group(G)
-            for prec in ("fp32", "bf16"):   # two different kernels (k_sampler.hip / k_sampler8.hip)
+            for prec in ("fp32", "bf16", "fp32x"):   # two different kernels (k_sampler.hip / k_sampler8.hip)
                 a = eng.sample(c, e, s, prec, seed=seed, clip_index0=c0)
                 b = eng.sample(c, e, s, prec, x_init=x0, step_noise=nz)
                 assert torch.equal(a, b), (G, prec)
@@ -286,14 +296,14 @@ def test_in_kernel_noise_equals_explicit_counter_noise(env):
         # must get its ancestral noise too (it silently kept z = 0 before), and B = 7 leaves a ragged last tile.
         for G, (ee, ss) in ((4, (None, s)), (4, (None, None)), (5, (None, None))):
             eng.set_clips_per_group(G)
-            for prec in ("fp32", "bf16"):
+            for prec in ("fp32", "bf16", "fp32x"):
                 a = eng.sample(c, ee, ss, prec, seed=seed, clip_index0=c0)
                 b = eng.sample(c, ee, ss, prec, x_init=x0, step_noise=nz)
                 assert torch.equal(a, b), (G, prec, ee is None, ss is None)
                 eng.set_clips_per_group(1)
                 one = eng.sample(c, ee, ss, prec, seed=seed, clip_index0=c0)     # one clip per tile: same noise, same run
                 eng.set_clips_per_group(G)
-                assert float((a - one).abs().max()) < (1e-3 if prec == "fp32" else 0.5) * max(1.0, float(one.abs().max()))
+                assert float((a - one).abs().max()) < (0.5 if prec == "bf16" else 1e-3) * max(1.0, float(one.abs().max()))
     finally:
         eng.set_clips_per_group(0)
     with pytest.raises(Exception):
@@ -421,14 +431,15 @@ def test_encode_decode_round_trip_shapes_and_determinism(env):
     assert rec["feats"].shape == (2, 300, 333) and bool(torch.isfinite(rec["feats"]).all())
 
 
-def test_diffusion_backward_end_to_end_fp32(env):
+@pytest.mark.parametrize("prec", PARITY)
+def test_diffusion_backward_end_to_end_fp32(env, prec):
     """BASELINE config 1 shape: 1 clip, DDIM-50, explicit x_T -> SMPL-X poses; per-joint L2 < 1e-4."""
     from amuse_amd import scheduler as sch
     orc, eng, Wd, Wp = env["orc"], env["eng"], env["Wd"], env["Wp"]
     gen = torch.Generator().manual_seed(2024)
     c, e, s, x = (torch.randn(1, n, generator=gen) for n in (256, 256, 256, 128))
     eng.set_schedule(sch.ddim_table())
-    out = eng.diffusion_backward(c, e, s, "fp32", x_init=x)
+    out = eng.diffusion_backward(c, e, s, prec, x_init=x)
     ref = orc.diffusion_backward(Wd, Wp, orc.DDIM(), c, e, s, x)
     assert out["poses"].shape == (1, 300, 55, 3) and out["trans"].shape == (1, 300, 3)
     assert _err(out["latents"], ref["latents"]) < 1e-4
@@ -446,7 +457,7 @@ def test_diffusion_backward_end_to_end_fp32(env):
     assert float(((R1 - R2).abs().amax(dim=(-1, -2)) * pivot.clamp(max=1.0)).max()) < 5e-4
     # emotion edit = swap which vector is passed as z_emo (trainer.py:1055-1066): changes the output
     e2 = torch.randn(1, 256, generator=gen)
-    out2 = eng.diffusion_backward(c, e2, s, "fp32", x_init=x)
+    out2 = eng.diffusion_backward(c, e2, s, prec, x_init=x)
     assert _err(out2["poses"], out["poses"]) > 1e-3
 
 
@@ -491,7 +502,7 @@ def test_job_level_tiling_makes_shards_bitwise(env):
     eng.set_schedule(sch.ddim_table())
     g = job_clips_per_group(B)
     assert g == 3
-    for prec in ("fp32", "bf16"):
+    for prec in ("fp32", "bf16", "fp32x"):
         full = eng.diffusion_backward(c, e, s, prec, seed=7)          # auto: ceil(300 / 128) = 3 clips per tile
         eng.set_clips_per_group(g)
         try:

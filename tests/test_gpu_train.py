@@ -20,7 +20,7 @@ def test_update_weights_equals_a_fresh_context():
     c, em, s, x = (torch.randn(100, n, generator=gen) for n in (256, 256, 256, 128))
     before = a.sample(c, em, s, "bf16", x_init=x)
     a.update_weights(*w1)
-    for prec in ("fp32", "bf16"):
+    for prec in ("fp32", "bf16", "fp32x"):
         la, lb = a.sample(c, em, s, prec, x_init=x), b.sample(c, em, s, prec, x_init=x)
         assert torch.equal(la, lb), prec
         da, db = a.vae_decode(la, None, prec, return_feats=True), b.vae_decode(lb, None, prec, return_feats=True)   # fused path in bf16
@@ -54,7 +54,7 @@ def test_update_weights_device_equals_the_host_path():
     c, em, s, x = (torch.randn(100, n, generator=gen) for n in (256, 256, 256, 128))
     before = a.sample(c, em, s, "bf16", x_init=x)
     a.update_weights_device(*f1)
-    for prec in ("fp32", "bf16"):
+    for prec in ("fp32", "bf16", "fp32x"):
         la, lb = a.sample(c, em, s, prec, x_init=x), b.sample(c, em, s, prec, x_init=x)
         assert torch.equal(la, lb), prec
         da, db = a.vae_decode(la, None, prec, return_feats=True), b.vae_decode(lb, None, prec, return_feats=True)
@@ -72,6 +72,14 @@ def test_update_weights_device_equals_the_host_path():
     assert not torch.equal(a.vae_decode(lat, None, "bf16")["poses"], b.vae_decode(lat, None, "bf16")["poses"])   # (prior still w0)
     a.update_weights_device(None, f1[1], what=2)
     assert torch.equal(a.vae_decode(lat, None, "bf16")["poses"], b.vae_decode(lat, None, "bf16")["poses"])
+    # the fp32x mask alone: the sampler's split-fp16 stream and the prior's fp32 streams
+    a.update_weights_device(*f0, what=8)
+    a0 = HipEngine(*w0)
+    a0.set_schedule(sch.ddim_table())
+    l0 = a0.sample(c, em, s, "fp32x", x_init=x)
+    assert torch.equal(a.sample(c, em, s, "fp32x", x_init=x), l0)
+    assert torch.equal(a.vae_decode(l0[:8], None, "fp32x")["poses"], a0.vae_decode(l0[:8], None, "fp32")["poses"])
+    a0.close()
     with pytest.raises(Exception):
         a.update_weights_device(None, None)
     with pytest.raises(ValueError):

@@ -1,0 +1,46 @@
+"""CPU: `bench.py --gpus N` and `python -m amuse_amd.train_gesture --gpus N` typed directly start their own ranks
+(amuse_amd/launch.py) - the parent never needs WORLD_SIZE, the children are real torch.distributed ranks."""
+import json
+import os
+import subprocess
+import sys
+from pathlib import Path
+
+REPO = Path(__file__).resolve().parents[1]
+
+
+def _env():
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    env["OMP_NUM_THREADS"] = "2"
+    return env
+
+
+def test_torchrun_command_shape():
+    from amuse_amd import launch
+    cmd = launch.torchrun_command("bench.py", ["--gpus", "4"], 4, port=29512)
+    assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"] and "--nproc-per-node=4" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[-3:] == ["bench.py", "--gpus", "4"]
+    assert launch.torchrun_command("amuse_amd.train_gesture", [], 2, module=True)[-2:] == ["-m", "amuse_amd.train_gesture"]
+    assert not launch.launched_by_torchrun() or "RANK" in os.environ
+
+
+def test_bench_gpus_2_starts_its_own_ranks():
+    """Without a GPU the CHILDREN refuse ("needs an MI355X") - the parent does not stop at a WORLD_SIZE check."""
+    for extra in ([], ["--config", "train"]):
+        r = subprocess.run([sys.executable, str(REPO / "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", *extra], cwd=REPO,
+                           env=_env(), capture_output=True, text=True, timeout=600)
+        out = r.stdout + r.stderr
+        assert r.returncode != 0
+        assert out.count("needs an MI355X") >= 2, out[-2000:]          # one line per rank
+        assert "WORLD_SIZE" not in out.replace("WORLD_SIZE=2 ranks", "")
+
+
+def test_train_gesture_main_is_data_parallel(tmp_path):
+    """Two gloo ranks on the CPU through the module's own launcher: both train (no HIP sampler on the CPU), rank 0 reports and
+    writes the checkpoints; weights are identical across ranks after the all-reduced steps (checked inside by the 2-rank test of
+    tests/test_train_cpu.py - here: the entry point itself)."""
+    r = subprocess.run([sys.executable, "-m", "amuse_amd.train_gesture", "--gpus", "2", "--batch", "2", "--iters-per-epoch", "2",
+                        "--device", "cpu", "--out", str(tmp_path)], cwd=REPO, env=_env(), capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    assert r.stdout.count("[LPDM-T] Epoch: [1/1]") == 1                # rank 0 only
+    assert len(list(tmp_path.glob("prior_model_NoOpt_*_e1.pt"))) == 1 and len(list(tmp_path.glob("latdiff_model_wOpt_*_e1.pt"))) == 1
