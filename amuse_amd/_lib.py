@@ -24,7 +24,7 @@ EXPORTS = [
     "amuse_counter_normal", "amuse_set_clips_per_group", "amuse_set_decode_path", "amuse_profile_sample",
     "amuse_audio_create", "amuse_audio_destroy", "amuse_audio_fbank", "amuse_audio_encode", "amuse_audio_features",
     "amuse_debug_gemm",
-    "amuse_debug_tile", "amuse_debug_f16_split",
+    "amuse_debug_tile", "amuse_debug_f16_split", "amuse_debug_set_decode_tap",
 ]
 
 
@@ -90,6 +90,8 @@ def load() -> C.CDLL:
     lib.amuse_debug_tile.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, vp]
     lib.amuse_debug_f16_split.argtypes = [C.POINTER(C.c_float), C.c_size_t, C.POINTER(C.c_uint16), C.POINTER(C.c_uint16)]
     lib.amuse_debug_f16_split.restype = C.c_int
+    lib.amuse_debug_set_decode_tap.argtypes = [vp, fp]
+    lib.amuse_debug_set_decode_tap.restype = C.c_int
     for n in ("amuse_audio_fbank", "amuse_audio_encode", "amuse_audio_features", "amuse_debug_gemm", "amuse_debug_tile"):
         getattr(lib, n).restype = C.c_int
     if lib.amuse_abi_version() != ABI_VERSION:

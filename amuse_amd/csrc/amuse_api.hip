@@ -292,6 +292,7 @@ struct amuse_ctx {
     int device = 0;
     int clips_per_group = 0;
     int decode_path = AMUSE_DECODE_AUTO;
+    float* decode_tap = nullptr;       // amuse_debug_set_decode_tap
     // denoiser
     uint4* den_w[3] = {nullptr, nullptr, nullptr};   // 4-wave kernel streams: fp32 | bf16 | split-fp16 (fp32x)
     uint32_t den_wave_units[3] = {0, 0, 0};
@@ -850,6 +851,12 @@ int amuse_set_decode_path(amuse_ctx* c, int path) {
     return 0;
 }
 
+int amuse_debug_set_decode_tap(amuse_ctx* c, float* tap_out) {
+    if (!c) return fail(AMUSE_EINVAL, "ctx is NULL");
+    c->decode_tap = tap_out;
+    return 0;
+}
+
 int amuse_set_schedule(amuse_ctx* c, const amuse_schedule* s, void* stream) {
     if (!c || !s) return fail(AMUSE_EINVAL, "NULL argument");
     if (s->n_steps < 1 || s->n_steps > AMUSE_MAX_STEPS) return fail(AMUSE_EINVAL, "n_steps %d out of range", s->n_steps);
@@ -999,6 +1006,7 @@ int amuse_vae_decode(amuse_ctx* c, const float* z, const int* lengths, int B, in
             fa.poses_out = poses_out ? poses_out + (size_t)b0 * kFrames * kJoints * 3 : nullptr;
             fa.trans_out = trans_out ? trans_out + (size_t)b0 * kFrames * 3 : nullptr;
             fa.B = nb; fa.quat_mode = quat_mode;
+            fa.tap_out = b0 == 0 ? c->decode_tap : nullptr;   // (amuse_debug_set_decode_tap: tests)
             HIP_TRY(launch_vae_fused(fa, st));
         }
         return 0;

@@ -122,6 +122,7 @@ struct VaeFusedArgs {
     float* feats_out;          // [B][300][333] or null
     float* poses_out;          // [B][300][55][3] or null
     float* trans_out;          // [B][300][3] or null
+    float* tap_out;            // [10][300][128] or null: clip 0's fp32 residual stream after blocks 0..8 and after decoder.norm (tests)
     int B, quat_mode;
 };
 constexpr size_t kVaeFusedSkipBytesPerClip = 4 * 20 * 4 * 64 * 16;

@@ -253,7 +253,20 @@ __device__ __forceinline__ bf16x8 attend(const uint4* Kb, const uint4* Vt, bf16x
 }
 
 // MODE 0: input block (push the skip), 1: middle block, 2: output block (skip linear first)
-template <int NT, int MODE>
+// debugging taps (TAP instantiation only, clip 0): the wave's tiles of the fp32 residual stream, row-major [300][128]
+template <int NT>
+__device__ __forceinline__ void store_tap(float* tap, int slot, const f32x4 (&x)[NT][kTiles], int tile0, int g, int r) {
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+        const int frame = 16 * (tile0 + 4 * j) + r;
+        if (frame < kFrames) {
+#pragma unroll
+            for (int t = 0; t < kTiles; ++t) st4(tap + ((size_t)slot * kFrames + frame) * kD + 16 * t + 4 * g, x[j][t]);
+        }
+    }
+}
+
+template <int NT, int MODE, bool TAP>
 __device__ __forceinline__ void decoder_block(f32x4 (&x)[NT][kTiles], Stager& sg, const VaeFusedArgs& a, int blk, int tile0,
                                               const float* pv, const float* pv_next_src, unsigned pv_next_dst, const float* cal,
                                               char* kv, uint4* skipbuf, int len, int wave, int lane) {
@@ -466,10 +479,13 @@ __device__ __forceinline__ void decoder_block(f32x4 (&x)[NT][kTiles], Stager& sg
             for (int c = 0; c < 4; ++c)
                 sk[((tile0 + 4 * j) * 4 + c) * 64 + lane] = __builtin_bit_cast(uint4, pack_bf16(x[j][2 * c], x[j][2 * c + 1]));
     }
+    if constexpr (TAP) {
+        if (a.tap_out && blockIdx.x == 0) store_tap<NT>(a.tap_out, blk, x, tile0, g, r);
+    }
 }
 
 // everything one wave does for its NT row tiles tile0, tile0 + 4, ...
-template <int NT>
+template <int NT, bool TAP>
 __device__ __forceinline__ void decode_tiles(const VaeFusedArgs& a, char* smem, Stager& sg, int tile0, int b, int len,
                                              int wave, int lane) {
     const int g = lane >> 4, r = lane & 15;
@@ -490,12 +506,12 @@ __device__ __forceinline__ void decode_tiles(const VaeFusedArgs& a, char* smem, 
     asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)\n\ts_barrier" ::: "memory");   // parameters, constants and stage 0 are in
 #pragma unroll 1
     for (int blk = 0; blk < 4; ++blk)
-        decoder_block<NT, 0>(x, sg, a, blk, tile0, pvl + (blk & 1) * (kPvSlot / 4), a.pvec + (blk + 1) * PV_BLOCK,
+        decoder_block<NT, 0, TAP>(x, sg, a, blk, tile0, pvl + (blk & 1) * (kPvSlot / 4), a.pvec + (blk + 1) * PV_BLOCK,
                              lds0 + kOffPv + ((blk + 1) & 1) * kPvSlot, cal, kv, skipbuf, len, wave, lane);
-    decoder_block<NT, 1>(x, sg, a, 4, tile0, pvl, a.pvec + 5 * PV_BLOCK, lds0 + kOffPv + kPvSlot, cal, kv, skipbuf, len, wave, lane);
+    decoder_block<NT, 1, TAP>(x, sg, a, 4, tile0, pvl, a.pvec + 5 * PV_BLOCK, lds0 + kOffPv + kPvSlot, cal, kv, skipbuf, len, wave, lane);
 #pragma unroll 1
     for (int blk = 5; blk < kLayers; ++blk)
-        decoder_block<NT, 2>(x, sg, a, blk, tile0, pvl + (blk & 1) * (kPvSlot / 4),
+        decoder_block<NT, 2, TAP>(x, sg, a, blk, tile0, pvl + (blk & 1) * (kPvSlot / 4),
                              blk + 1 < kLayers ? a.pvec + (blk + 1) * PV_BLOCK : nullptr,
                              lds0 + kOffPv + ((blk + 1) & 1) * kPvSlot, cal, kv, skipbuf, len, wave, lane);
     // ---------------- decoder.norm -> final_layer (333 outputs in 24 tiles) -> rotation epilogue.  The stream holds the
@@ -517,6 +533,13 @@ __device__ __forceinline__ void decode_tiles(const VaeFusedArgs& a, char* smem, 
         }
         const int j = slot - kSlot0;
         layer_norm_rows<true>(x[0], a.pvec + PV_FINAL_W, a.pvec + PV_FINAL_B, g);
+        if constexpr (TAP) {   // slot 9: decoder.norm of this tile
+            const int frame_t = 16 * (tile0 + 4 * (slot - kSlot0)) + r;
+            if (a.tap_out && blockIdx.x == 0 && frame_t < kFrames) {
+#pragma unroll
+                for (int t = 0; t < kTiles; ++t) st4(a.tap_out + ((size_t)9 * kFrames + frame_t) * kD + 16 * t + 4 * g, x[0][t]);
+            }
+        }
         bf16x8 xb1[4];
 #pragma unroll
         for (int c = 0; c < 4; ++c) xb1[c] = pack_bf16(x[0][2 * c], x[0][2 * c + 1]);
@@ -575,6 +598,7 @@ __device__ __forceinline__ void decode_tiles(const VaeFusedArgs& a, char* smem, 
     }
 }
 
+template <bool TAP>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_vae_fused(VaeFusedArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63;
@@ -593,8 +617,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     sg.ridx = 0;
     stage_fetch(sg);
     stage_fetch(sg);
-    if (wave < 4) decode_tiles<3>(a, smem, sg, wave, b, len, wave, lane);
-    else decode_tiles<2>(a, smem, sg, wave + 8, b, len, wave, lane);
+    if (wave < 4) decode_tiles<3, TAP>(a, smem, sg, wave, b, len, wave, lane);
+    else decode_tiles<2, TAP>(a, smem, sg, wave + 8, b, len, wave, lane);
 }
 
 }  // namespace
@@ -602,9 +626,10 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 hipError_t launch_vae_fused(const VaeFusedArgs& a, hipStream_t stream) {
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_vae_fused), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           kVaeFusedLdsBytes);
-        if (e != hipSuccess) return e;
+        for (const void* k : {reinterpret_cast<const void*>(&k_vae_fused<false>), reinterpret_cast<const void*>(&k_vae_fused<true>)}) {
+            hipError_t e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, kVaeFusedLdsBytes);
+            if (e != hipSuccess) return e;
+        }
         attr_set = true;
     }
 #if AMUSE_FPROF
@@ -613,7 +638,8 @@ hipError_t launch_vae_fused(const VaeFusedArgs& a, hipStream_t stream) {
         (void)hipMemcpyToSymbol(HIP_SYMBOL(g_fprof_n), &zero, sizeof(int));
     }
 #endif
-    hipLaunchKernelGGL(k_vae_fused, dim3(a.B), dim3(512), kVaeFusedLdsBytes, stream, a);
+    if (a.tap_out) hipLaunchKernelGGL(k_vae_fused<true>, dim3(a.B), dim3(512), kVaeFusedLdsBytes, stream, a);   // the tapped instantiation (tests)
+    else hipLaunchKernelGGL(k_vae_fused<false>, dim3(a.B), dim3(512), kVaeFusedLdsBytes, stream, a);
 #if AMUSE_FPROF
     {
         static int calls = 0;

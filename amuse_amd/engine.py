@@ -209,9 +209,12 @@ class HipEngine:
         return out
 
     def vae_decode(self, z, lengths: Optional[Sequence[int]] = None, precision="fp32", quat_mode="p3d",
-                   return_feats=False):
+                   return_feats=False, return_taps=False):
+        """return_taps (fused bf16 kernel only, tests): out["taps"] = (10, 300, 128) - clip 0's residual stream after decoder
+        blocks 0..8 and after decoder.norm (amuse_debug_set_decode_tap)."""
         z = self._dev(z)
         B = z.shape[0]
+        taps = torch.zeros(10, 300, 128, device=self.device, dtype=torch.float32) if return_taps else None
         feats = torch.empty(B, 300, 333, device=self.device, dtype=torch.float32) if return_feats else None
         poses = torch.empty(B, 300, 55, 3, device=self.device, dtype=torch.float32)
         trans = torch.empty(B, 300, 3, device=self.device, dtype=torch.float32)
@@ -222,9 +225,17 @@ class HipEngine:
                 raise ValueError("lengths must have one entry per clip")
             lp = la.ctypes.data_as(C.POINTER(C.c_int))
         with torch.cuda.device(self.device):
-            _lib.check(self.lib.amuse_vae_decode(self.ctx, _ptr(z), lp, B, PREC[precision], QUAT[quat_mode],
-                                                 _ptr(feats), _ptr(poses), _ptr(trans), self._stream()))
+            if return_taps:
+                _lib.check(self.lib.amuse_debug_set_decode_tap(self.ctx, _ptr(taps)))
+            try:
+                _lib.check(self.lib.amuse_vae_decode(self.ctx, _ptr(z), lp, B, PREC[precision], QUAT[quat_mode],
+                                                     _ptr(feats), _ptr(poses), _ptr(trans), self._stream()))
+            finally:
+                if return_taps:
+                    _lib.check(self.lib.amuse_debug_set_decode_tap(self.ctx, None))
         out = {"poses": poses, "trans": trans}
+        if return_taps:
+            out["taps"] = taps
         if return_feats:
             out["feats"] = feats
         return out

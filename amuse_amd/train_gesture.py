@@ -484,7 +484,8 @@ def bench_main(args):
         sync = tr.inner_sampler.sync_ms if tr.inner_sampler is not None else []
         print(json.dumps({
             "metric": "train_gesture iterations/sec (data-parallel step, batch 32 per GPU)", "value": round(its, 3), "unit": "it/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+            "n_gpus": world, "world_size_seen": dist.get_world_size() if world > 1 else 1, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"train_gesture (configs/diff_latent_v2.json): prior encode/decode + epsilon loss under autograd "
                                    f"(torch fp32), in-loop DDIM-50 sampler + decode on the HIP kernels (bf16), AdamW(1e-4), one flat "

@@ -28,7 +28,11 @@ sys.path.insert(0, str(REPO))
 
 FLOP_PER_CLIP_STEP = 19_120_640          # linears 19,005,440 + attention 115,200
 FLOP_VAE_DECODE_PER_CLIP = 1.76e9
-MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3}   # MI355X_MICROARCH.md chip-level parameters (dense)
+MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3, "fp32x": 2500.0}   # MI355X_MICROARCH.md chip-level parameters (dense; fp32x = fp16 MFMAs)
+KERNEL_NAME = {"bf16": "k_sample8", "fp32": "k_sample<fp32>", "fp32x": "k_sample<f16x2>"}
+# L2 -> CU weight stream per denoising step and CU (every CU re-streams the network each step): bytes per parameter of the MFMA stream
+STREAM_MB_PER_STEP = {"bf16": 3.80, "fp32": 7.60, "fp32x": 7.60}
+CU_LOAD_BYTES_PER_CLK = 64.0
 
 
 PMC_DIR = "profiles/r02_pmc"
@@ -115,7 +119,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--clips", type=int, default=256, help="clips in the whole job (sharded over the ranks)")
     ap.add_argument("--T", type=int, default=1000, help="DDPM steps")
-    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32", "fp32x"])
     ap.add_argument("--config", default="sample", choices=["sample", "train"],
                     help="sample: BASELINE configs[2] (the headline metric); train: configs[3] train_gesture data-parallel step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -231,9 +235,11 @@ def main():
         peak = MFMA_PEAK_TFLOPS[args.precision]
         traffic, traffic_src = pmc_traffic_bytes(B, args.T, args.precision)
         us_step = k_avg / args.T * 1e6
+        clk_ghz = getattr(torch.cuda.get_device_properties(dev), "clock_rate", 2.4e6) / 1e6   # kHz -> GHz (2.4 if torch does not say)
+        stream_floor_us = STREAM_MB_PER_STEP[args.precision] * 1e6 / CU_LOAD_BYTES_PER_CLK / (clk_ghz * 1e9) * 1e6
         line = {
             "metric": "SMPL-X frames/sec (10 s clip, 1000-step DDPM)", "value": round(value, 1), "unit": "frames/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "n_gpus": world, "world_size_seen": dist.get_world_size() if world > 1 else 1, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
             "config": {"workload": f"{total} x 10 s clips in total ({B} on rank 0), DDPM-{args.T} sampling loop + "
@@ -241,15 +247,19 @@ def main():
                                    f"diff_latent_v2 / prior_emotional_fing architecture",
                        "clips_total": total, "clips_rank0": B, "clips_per_tile": g_job, "sampler": f"ddpm-{args.T}",
                        "sharding": f"clip-batch x{world} through amuse_amd/shard.py, no collectives",
+                       "clip_range_per_rank": [list(shard.shard_range(total, r, world, align=g_job)) for r in range(world)],
                        "mfma_operands": args.precision, "state_and_accumulate": "fp32"},
             "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
                          "frac": round(achieved / peak, 5), "traffic": traffic, "traffic_source": traffic_src,
-                         "kernel": ("k_sample8" if args.precision == "bf16" else "k_sample") + " (persistent T-step denoising loop)",
+                         "kernel": KERNEL_NAME[args.precision] + " (persistent T-step denoising loop)",
                          "kernel_ms": round(k_avg * 1e3, 3),
+                         "us_per_denoising_step": round(us_step, 3),
+                         "stream_floor_us_per_step": round(stream_floor_us, 2),
                          "note": f"algorithmic FLOPs = clips x T x 19,120,640 (rank 0's {B} clips); measured {us_step:.2f} us per "
-                                 f"denoising step. The kernel is bound by the serial per-step dependency chain + per-CU "
-                                 f"L2->CU weight streaming (bf16: 3.80 MB per CU and step = 59.4 k cycles at 64 B/clk, a "
-                                 f"floor of ~24.7 us per step at 2.4 GHz), not by HBM or MFMA issue (DESIGN.md 4.1, 4.1b, 5)"},
+                                 f"denoising step = {us_step / stream_floor_us:.2f} x the floor of its L2->CU weight stream "
+                                 f"({STREAM_MB_PER_STEP[args.precision]:.2f} MB per CU and step at {CU_LOAD_BYTES_PER_CLK:.0f} B/clk = "
+                                 f"{stream_floor_us:.1f} us at the {clk_ghz:.2f} GHz this device reports). The kernel is bound by the "
+                                 f"serial per-step dependency chain + that stream, not by HBM or MFMA issue (DESIGN.md 4.1, 4.1b, 5)"},
         }
         if weak is not None:
             line["weak_scaling"] = weak
@@ -299,6 +309,42 @@ def main():
         line["saturating_point"] = {"clips_per_gpu": Bs, "frames_per_s": round(Bs * 300 / min(ts), 1),
                                     "ms_per_job": round(min(ts) * 1e3, 3)}
         del cs, es, ss, outs
+        if world == 1 and B > 0:
+            # parity mode: the SAME job in the fp32x mode (split-fp16 MFMA operands, fp32 everything else) - the mode that
+            # meets the north-star tolerance; eps_err = teacher-forced eps_hat against the reference modules' golden
+            # vectors (tests/golden/denoiser_steps.npz: data, not the oracle), bar 1e-5
+            import numpy as np
+            gold = np.load(REPO / "tests" / "golden" / "denoiser_steps.npz")
+            eps_err = {}
+            for mode in ("fp32x", "fp32", "bf16"):
+                eps_err[mode] = max(float(np.abs(eng.denoise_step(gold["x_t"], t, gold["con"], gold["emo"], gold["sty"], mode).cpu().numpy()
+                                                 - gold[f"eps_t{t}"]).max()) for t in (981, 501, 1))
+
+            def time_job(mode, reps):
+                ts_ = []
+                for i in range(reps + 1):
+                    ev0.record()
+                    eng.diffusion_backward(con[lo:hi], emo[lo:hi], sty[lo:hi], mode, seed=2024, clip_index0=lo, out=out)
+                    ev1.record()
+                    ev1.synchronize()
+                    if i >= 1:
+                        ts_.append(ev0.elapsed_time(ev1))
+                return min(ts_)
+            eng.set_clips_per_group(g_job)
+            ms_x, ms_f = time_job("fp32x", 3), time_job("fp32", 2)
+            line["parity_mode"] = {"precision": "fp32x", "ms_per_job": round(ms_x, 3), "frames_per_s": round(B * 300 / ms_x * 1e3, 1),
+                                   "us_per_denoising_step_incl_decode": round(ms_x / args.T * 1e3, 2),
+                                   "eps_err": eps_err["fp32x"], "eps_bar": 1e-5,
+                                   "fp32_mode": {"ms_per_job": round(ms_f, 3), "frames_per_s": round(B * 300 / ms_f * 1e3, 1), "eps_err": eps_err["fp32"]},
+                                   "bf16_eps_err": eps_err["bf16"],
+                                   "what": "same clips, DDPM-%d + decode + 6D->axis-angle; eps_err = max |eps_hat - reference golden| at t = 981, 501, 1" % args.T}
+            # the sampler the reference ships (infer_ldm.py:116-125): DDIM-50, same clips
+            eng.set_schedule(sch.ddim_table())
+            dd = {mode: time_job(mode, 5) for mode in ("bf16", "fp32x")}
+            line["ddim50"] = {"clips": B, **{f"{m}_ms_per_job": round(v, 3) for m, v in dd.items()},
+                              **{f"{m}_frames_per_s": round(B * 300 / v * 1e3, 1) for m, v in dd.items()}}
+            eng.set_schedule(sch.ddpm_table(args.T))
+            eng.set_clips_per_group(0)
         if world == 1 and not args.no_audio:
             # side measurement, not part of `value` (whose inputs are the three 256-d embeddings): the
             # audio front-end that produces them from 10 s of 16 kHz audio - kaldi fbank + 3 x AST, 778 GFLOP per clip

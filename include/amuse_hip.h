@@ -260,6 +260,11 @@ int amuse_debug_gemm(const void* A, const void* W, const float* bias, int M, int
  * to 128][F], pad rows zeroed; 1: bf16 tile-major -> row-major [M][F]; 2: fp32 tile-major -> row-major [M][F]. */
 int amuse_debug_tile(const void* src, void* dst, int M, int F, int what, void* stream);
 
+/* Debugging taps of the FUSED bf16 decode kernel (k_vae_fused.hip), for tests: while tap_out (dev [10][300][128] fp32) is set,
+ * every fused amuse_vae_decode launch writes clip 0's residual stream after decoder blocks 0..8 (slots 0..8) and after
+ * decoder.norm (slot 9) there, through a separate instantiation of the kernel; NULL switches the taps off again. */
+int amuse_debug_set_decode_tap(amuse_ctx* ctx, float* tap_out);
+
 /* The host packer's fp32 -> (hi, lo) fp16 split of AMUSE_PREC_F32X, for tests (host memory, no GPU call):
  * hi[i] = rn16(w[i]), lo[i] = rn16(w[i] - hi[i]), round-to-nearest-even with gradual underflow - bit for bit what
  * v_cvt_pk_f16_f32 produces on the device for the activations (and amuse_update_weights_device for the weights). */

@@ -73,20 +73,32 @@ def test_bf16_mode_gated_against_fp32_mode(env):
     g = torch.Generator().manual_seed(2024)
     B = 64
     c, e, s, x = (torch.randn(B, n, generator=g) for n in (256, 256, 256, 128))
+    def geodesic_deg(lat_ref, lat_bf16):
+        pa = eng.vae_decode(lat_ref, None, "fp32")["poses"].cpu()
+        pb = eng.vae_decode(lat_bf16, None, "bf16")["poses"].cpu()
+        Ra, Rb = orc.axis_angle_to_matrix(pa.double()), orc.axis_angle_to_matrix(pb.double())
+        return torch.acos(((Ra.transpose(-1, -2) @ Rb).diagonal(dim1=-2, dim2=-1).sum(-1) - 1).div(2).clamp(-1, 1)) * 180 / np.pi
+
     eng.set_schedule(sch.ddim_table())
     a = eng.sample(c, e, s, "fp32", x_init=x).cpu()
     b = eng.sample(c, e, s, "bf16", x_init=x).cpu()
     assert float((a - b).pow(2).mean().sqrt()) < 0.08 and float((a - b).abs().max()) < 0.46
+    # the fast parity mode sits with the fp32 mode, not with bf16: same 64 clips, DDIM-50 latents
+    ax = eng.sample(c, e, s, "fp32x", x_init=x).cpu()
+    assert float((a - ax).abs().max()) < 1e-3, float((a - ax).abs().max())
+    # DDIM-50 is the sampler the reference ships (infer_ldm.py:116-125): its bf16 POSES are gated too - latents of rms 0.53
+    # (no ancestral noise to wash the rounding out) put the decoder's 6D outputs near ill-conditioned Gram-Schmidt pivots, so
+    # the same latent drift costs more degrees than under DDPM-1000: measured median 3.6 deg, p99 30.6 deg; bound <= 2 x
+    ang = geodesic_deg(a, b)
+    assert float(ang.median()) < 7.2, float(ang.median())
+    assert float(ang.flatten().kthvalue(int(ang.numel() * 0.99)).values) < 61.0
     tab = sch.ddpm_table()
     eng.set_schedule(tab)
     nz = torch.randn(tab.n_steps, B, 128, generator=g)
     a = eng.sample(c, e, s, "fp32", x_init=x, step_noise=nz).cpu()
     b = eng.sample(c, e, s, "bf16", x_init=x, step_noise=nz).cpu()
     assert float((a - b).pow(2).mean().sqrt()) < 0.35
-    pa = eng.vae_decode(a, None, "fp32")["poses"].cpu()
-    pb = eng.vae_decode(b, None, "bf16")["poses"].cpu()
-    Ra, Rb = orc.axis_angle_to_matrix(pa.double()), orc.axis_angle_to_matrix(pb.double())
-    ang = torch.acos(((Ra.transpose(-1, -2) @ Rb).diagonal(dim1=-2, dim2=-1).sum(-1) - 1).div(2).clamp(-1, 1)) * 180 / np.pi
+    ang = geodesic_deg(a, b)
     assert float(ang.median()) < 1.0, float(ang.median())
     assert float(ang.flatten().kthvalue(int(ang.numel() * 0.99)).values) < 8.0
 

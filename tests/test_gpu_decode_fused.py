@@ -88,3 +88,95 @@ def test_fused_and_staged_decode_agree_and_auto_switches(env):
     assert _err(eng.vae_decode(g["z"], None, "fp32", return_feats=True)["feats"], g["feats"]) < 2e-5
     with pytest.raises(Exception):
         eng.set_decode_path("nope")
+
+
+# ---- per-block check of the fused kernel: a model of ITS rounding points (what orc.dec_block(Ops(True, poly_gelu=True)) is for
+# the sampler).  The generic bf16 emulation rounds a normalised softmax and q / sqrt(32); the kernel rounds q * (log2 e / sqrt 32),
+# keeps the scores in log2 units, merges 64-key chunks online and rounds the UN-normalised p = exp2(s - running max) of each
+# chunk as the PV operand (k_vae_fused.hip attend), so a check at 1e-4 has to follow that order.
+def _r(x):
+    return x.to(torch.bfloat16).to(torch.float32)
+
+
+def _fused_attention_model(q, k, v, length):
+    """q, k, v: (H, S, 32) fp32 (q already scaled into log2 units and rounded, k / v rounded); online softmax in 64-key chunks."""
+    H, S, _ = q.shape
+    m = torch.zeros(H, S)
+    l = torch.zeros(H, S)
+    o = torch.zeros(H, S, 32)
+    for ch, k0 in enumerate(range(0, length, 64)):
+        k1 = min(k0 + 64, length)
+        st = q @ k[:, k0:k1].transpose(-1, -2) - m[..., None]           # the MFMA's C operand is -m_run
+        mx = st.max(dim=-1).values
+        d = mx if ch == 0 else mx.clamp(min=0.0)
+        st = st - d[..., None]
+        if ch > 0:
+            alpha = torch.exp2(-d)
+            l = l * alpha
+            o = o * alpha[..., None]
+        m = m + d
+        p = torch.exp2(st)
+        l = l + p.sum(-1)
+        o = o + _r(p) @ v[:, k0:k1]
+    return _r(o * (1.0 / l)[..., None])
+
+
+def _fused_block_model(orc, W, blk, x, skip, z, length=300):
+    """One TransformerDecoderLayer.forward_post (cross_attention.py:323-345; + the skip linear in front of an output block,
+    cross_attention.py:118-120) with the fused kernel's operand roundings.  x: (300, 128) fp32 block input."""
+    name = (f"decoder.input_blocks.{blk}" if blk < 4 else "decoder.middle_block" if blk == 4 else f"decoder.output_blocks.{blk - 5}")
+    if blk >= 5:
+        wl, bl = W[f"decoder.linear_blocks.{blk - 5}.weight"], W[f"decoder.linear_blocks.{blk - 5}.bias"]
+        x = _r(torch.cat([x, skip], -1)) @ _r(wl).T + bl
+    p = name + ".self_attn"
+    qkv = _r(x) @ _r(W[p + ".in_proj_weight"]).T + W[p + ".in_proj_bias"]
+    kq = float(np.float32(0.17677669529663687) * np.float32(1.44269504088896340736))
+    sh = lambda t: t.reshape(-1, 4, 32).permute(1, 0, 2)
+    q, k, v = sh(_r(qkv[:, :128] * kq)), sh(_r(qkv[:, 128:256])), sh(_r(qkv[:, 256:]))
+    o = _fused_attention_model(q, k, v, length).permute(1, 0, 2).reshape(-1, 128)
+    x = orc.layer_norm(x + (o @ _r(W[p + ".out_proj.weight"]).T + W[p + ".out_proj.bias"]), W[name + ".norm1.weight"], W[name + ".norm1.bias"])
+    ca = orc.cross_attn_const(orc.Ops(False), z[None], W, name + ".multihead_attn")[0]    # k_vae_ca: fp32
+    x = orc.layer_norm(x + ca[None], W[name + ".norm2.weight"], W[name + ".norm2.bias"])
+    h = orc.gelu_poly(_r(x) @ _r(W[name + ".linear1.weight"]).T + W[name + ".linear1.bias"])
+    x = orc.layer_norm(x + (_r(h) @ _r(W[name + ".linear2.weight"]).T + W[name + ".linear2.bias"]), W[name + ".norm3.weight"], W[name + ".norm3.bias"])
+    return x
+
+
+def test_fused_decode_blockwise_taps(env):
+    """Teacher-forced per block on the kernel's OWN block inputs (taps of clip 0's residual stream): >= 7 of 9 blocks within
+    1e-4 of the model above (a rounding flip of one operand element moves a block by O(1e-3)), every block within 2e-2; the
+    tapped instantiation computes bitwise what the production kernel computes."""
+    orc, eng, Wp = env["orc"], env["eng"], env["Wp"]
+    g = np.load(GOLDEN / "vae_decode.npz")
+    z = torch.from_numpy(g["z"])
+    eng.set_decode_path("fused")
+    plain = eng.vae_decode(z, None, "bf16", return_feats=True)
+    out = eng.vae_decode(z, None, "bf16", return_feats=True, return_taps=True)
+    assert torch.equal(out["feats"], plain["feats"]) and torch.equal(out["poses"], plain["poses"])
+    taps = out["taps"].cpu()
+    assert bool(torch.isfinite(taps).all()) and float(taps[8].abs().max()) > 0.1
+    x0 = Wp["query_pos_decoder.pe"][:300, 0]
+    stats = []
+    for blk in range(9):
+        xin = x0 if blk == 0 else taps[blk - 1]
+        skip = taps[8 - blk] if blk >= 5 else None
+        d = (taps[blk] - _fused_block_model(orc, Wp, blk, xin, skip, z[0])).abs().flatten()
+        stats.append((float(d.median()), float(d.kthvalue(int(d.numel() * 0.99)).values), float(d.max())))
+    print("fused decode, per block (median, p99, max):", stats)
+    # A block rounds ~150 k operand elements to bf16 (q, k, v, p, o, hidden): summation-order noise of 1e-7 flips a few of them
+    # per block, and one flipped q / k element moves its row by O(1e-3) - so the max over 38,400 outputs cannot be held to 1e-4
+    # the way the sampler's 5-token blocks are.  What a wrong weight chunk or a mis-indexed tile cannot hide from: the bulk.
+    assert max(s_[2] for s_ in stats) < 2e-2, stats
+    assert max(s_[0] for s_ in stats) < 1e-5, stats                 # median: every block
+    assert sorted(s_[1] for s_ in stats)[6] < 1e-4, stats           # 99th percentile: at least 7 of 9 blocks
+    # decoder.norm (slot 9) and the final layer on the kernel's own last block
+    fin = orc.layer_norm(taps[8], Wp["decoder.norm.weight"], Wp["decoder.norm.bias"])
+    assert _err(taps[9], fin) < 1e-5
+    feats = _r(taps[9]) @ _r(Wp["final_layer.weight"]).T + Wp["final_layer.bias"]
+    assert _err(out["feats"][0], feats) < 1e-4
+    # ragged clip 0 (173 frames: the key mask inside chunk 2 of 5), same bars on its valid rows
+    outr = eng.vae_decode(z[:1].repeat(2, 1), [173, 300], "bf16", return_feats=True, return_taps=True)
+    tr = outr["taps"].cpu()
+    for blk, xin, skip in ((0, x0, None), (5, tr[4], tr[3])):
+        d = (tr[blk][:173] - _fused_block_model(orc, Wp, blk, xin, skip, z[0], length=173)[:173]).abs().flatten()
+        assert float(d.median()) < 1e-5 and float(d.max()) < 2e-2, (blk, float(d.median()), float(d.max()))

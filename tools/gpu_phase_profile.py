@@ -14,13 +14,14 @@ eng.set_schedule(sch.ddpm_table(50))
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 if len(sys.argv) > 2:
     eng.set_clips_per_group(int(sys.argv[2]))
+precs = sys.argv[3].split(",") if len(sys.argv) > 3 else (("bf16", "fp32") if os.environ.get("AMUSE_SAMPLE_WAVES") == "4" else ("fp32",))
 gen = torch.Generator().manual_seed(2)
 c, e, s = (torch.randn(B, 256, generator=gen).cuda() for _ in range(3))
 names = ["blk_start", "in_proj", "attention", "out_proj", "combine1", "LN1", "linear1", "GELU", "linear2", "combine2", "LN2"]
 names = ["blk_start", "in_proj", "attention", "out_proj", "combine1", "LN1", "ffn.q0", "ffn.q1", "ffn.q2", "ffn.q3", "combine2", "LN2"]
 names_bf16 = names
 res = {}
-for prec in (("bf16", "fp32") if os.environ.get("AMUSE_SAMPLE_WAVES") == "4" else ("fp32",)):
+for prec in precs:   # e.g. "fp32,fp32x"
     st = eng.profile_sample(c, e, s, prec, prof_step=3).astype(np.int64)
     per = {}
     tot = []

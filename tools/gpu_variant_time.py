@@ -1,5 +1,5 @@
 """A/B timing of libamuse_hip*.so variants on ONE box: each variant in its own process (AMUSE_HIP_LIB), repeated in
-rounds so that clock drift hits all of them alike.  Usage: python tools/gpu_variant_time.py [clips ...]"""
+rounds so that clock drift hits all of them alike.  Usage: [AMUSE_VT_PREC=fp32x] python tools/gpu_variant_time.py [clips ...]"""
 import os, subprocess, sys, glob
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if len(sys.argv) > 1 and sys.argv[1] == "--child":
@@ -10,14 +10,15 @@ if len(sys.argv) > 1 and sys.argv[1] == "--child":
     eng = HipEngine(wts.make_denoiser_weights(0), wts.make_prior_weights(0))
     eng.set_schedule(sch.ddpm_table(1000))
     out = []
+    prec = os.environ.get("AMUSE_VT_PREC", "bf16")
     for B in [int(x) for x in sys.argv[2:]]:
         gen = torch.Generator().manual_seed(1)
         c, e, s = (torch.randn(B, 256, generator=gen).cuda() for _ in range(3))
-        eng.sample(c, e, s, "bf16", seed=1); torch.cuda.synchronize()
+        eng.sample(c, e, s, prec, seed=1); torch.cuda.synchronize()
         ts = []
         for _ in range(5):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record(); eng.sample(c, e, s, "bf16", seed=1); e1.record(); torch.cuda.synchronize()
+            e0.record(); eng.sample(c, e, s, prec, seed=1); e1.record(); torch.cuda.synchronize()
             ts.append(e0.elapsed_time(e1))
         out.append(f"B={B}: min {min(ts):.2f} med {sorted(ts)[2]:.2f}")
     print("  ".join(out))
