@@ -298,6 +298,9 @@ struct amuse_ctx {
     uint32_t den_wave_units[3] = {0, 0, 0};
     uint4* den_w8 = nullptr;           // bf16 streams of the 8-wave kernel (k_sampler8.hip)
     uint32_t den_w8_units[2] = {0, 0}; // per-step units of a group-A / group-B wave
+    uint4* den_w8x = nullptr;          // split-fp16 streams of the 8-wave fp32x kernel (k_sampler8x.hip)
+    uint32_t den_w8x_units[2] = {0, 0};
+    uint4* skip_ws = nullptr; size_t skip_ws_tiles = 0;   // k_sample8x: the A waves' copies of the U-Net skip stack
     float* den_pvec = nullptr;
     float* den_pe = nullptr;           // [500][128]
     float* den_freqs = nullptr;        // [128]
@@ -417,6 +420,44 @@ int build_denoiser(amuse_ctx* c, const float* den, int what = AMUSE_UPD_ALL) {
             if (sgrp == 0) all.insert(all.end(), s.begin(), s.begin() + (size_t)kRing8 * 64);  // ring wrap: tail = head
         }
         if (upload(&c->den_w8, all.data(), all.size() * sizeof(uint4))) return AMUSE_EHIP;
+    }
+    if (what & AMUSE_UPD_F32X) {   // 8-wave fp32x kernel: the same roles, split-fp16 units (two per 16 x 32 weight tile: hi, lo)
+        std::vector<uint4> all;
+        for (int w8 = 0; w8 < 8; ++w8) {
+            const int h = w8 & 3, sgrp = w8 >> 2;
+            std::vector<uint4> s;
+            // per block, in issue order (k_sampler8x.hip).  A: lead (out_proj - or, ahead of an output block, the skip-input half
+            // of the skip linear for output tiles 2h, 2h+1) | q,k for k-pairs 0,1 | [out_proj, output blocks] | q,k for k-pairs
+            // 2,3 | v | F1a F1b F2a F2b (FFN quarters 0,1).  B: [skip linear, x half], F1a F1b F2a F2b (quarters 2,3).
+            for (int b = 0; b < 9; ++b) {
+                const std::string p = blk_name("encoder", b);
+                auto f1 = [&](int q) { const int h0 = 8 * h + 2 * q; pack_gemm(s, PREC_F16X2, D.get(p + ".linear1.weight"), 512, 128, {h0, h0 + 1}, range(0, 8)); };
+                auto f2 = [&](int q) { const int h0 = 8 * h + 2 * q; pack_gemm(s, PREC_F16X2, D.get(p + ".linear2.weight"), 128, 512, range(0, 8), {h0, h0 + 1}); };
+                const int qa = 2 * sgrp, qb = 2 * sgrp + 1;
+                const float* wskip = b >= 5 ? D.get("encoder.linear_blocks." + std::to_string(b - 5) + ".weight") : nullptr;
+                if (sgrp == 0) {
+                    const float* in_w = D.get(p + ".self_attn.in_proj_weight");
+                    const std::vector<int> qk_tiles = {2 * h, 2 * h + 1, 8 + 2 * h, 8 + 2 * h + 1};
+                    const auto outproj = [&] { pack_gemm(s, PREC_F16X2, D.get(p + ".self_attn.out_proj.weight"), 128, 128, range(0, 8), {2 * h, 2 * h + 1}); };
+                    if (b >= 5) pack_gemm(s, PREC_F16X2, wskip, 128, 256, {2 * h, 2 * h + 1}, range(8, 16));
+                    else outproj();
+                    pack_gemm(s, PREC_F16X2, in_w, 384, 128, qk_tiles, range(0, 4));
+                    if (b >= 5) outproj();
+                    pack_gemm(s, PREC_F16X2, in_w, 384, 128, qk_tiles, range(4, 8));
+                    pack_gemm(s, PREC_F16X2, in_w, 384, 128, {16 + 2 * h, 16 + 2 * h + 1}, range(0, 8));
+                } else if (b >= 5) {
+                    pack_gemm(s, PREC_F16X2, wskip, 128, 256, {2 * h, 2 * h + 1}, range(0, 8));
+                }
+                f1(qa); f1(qb); f2(qa); f2(qb);
+            }
+            uint32_t& units = c->den_w8x_units[sgrp];
+            if (h == 0) units = (uint32_t)(s.size() / 64);
+            else if (s.size() / 64 != units) return fail(AMUSE_ESTATE, "internal: uneven 8-wave fp32x denoiser streams");
+            all.insert(all.end(), s.begin(), s.end());
+            if (sgrp == 0) all.insert(all.end(), s.begin(), s.begin() + (size_t)kRing8 * 64);  // ring wrap: tail = head
+        }
+        all.insert(all.end(), (size_t)kRing8 * 64, uint4{0, 0, 0, 0});   // the last B wave's initial ring fill reads past its slice
+        if (upload(&c->den_w8x, all.data(), all.size() * sizeof(uint4))) return AMUSE_EHIP;
     }
     {
         auto pv = build_pvec(D, "encoder", false);
@@ -608,14 +649,27 @@ int pick_group(const amuse_ctx* c, int B, int S) {
 // kernel, unless phase stamps are requested or AMUSE_SAMPLE_WAVES=4 (A/B measurements) asks for the 4-wave one
 bool use_sample8(int precision) {
     static const bool force4 = [] { const char* e = getenv("AMUSE_SAMPLE_WAVES"); return e && atoi(e) == 4; }();
-    return precision == PREC_BF16 && !force4;   // (fp32x runs the 4-wave kernel's PREC_F16X2 instantiation)
+    return (precision == PREC_BF16 || precision == PREC_F16X2) && !force4;   // (AMUSE_SAMPLE_WAVES=4: the 4-wave kernels, A/B runs)
 }
 void set_stream(const amuse_ctx* c, SampleArgs& a, int precision) {
     a.wstream = c->den_w[precision]; a.wave_units = c->den_wave_units[precision];
     a.wave_units_a = c->den_w8_units[0]; a.wave_units_b = c->den_w8_units[1];
 }
-hipError_t dispatch_sample(const amuse_ctx* c, SampleArgs& a, int precision, hipStream_t st) {
+hipError_t dispatch_sample(amuse_ctx* c, SampleArgs& a, int precision, hipStream_t st) {
     if (use_sample8(precision)) {  // with prof_out: stamps come back as [8 waves][96] in the same 768-entry buffer
+        if (precision == PREC_F16X2) {
+            const size_t tiles = (size_t)(a.B + a.G - 1) / a.G;
+            if (c->skip_ws_tiles < tiles) {   // the A waves' skip-stack scratch: 128 KiB per tile
+                if (c->skip_ws) { hipError_t e = hipFree(c->skip_ws); if (e != hipSuccess) return e; }
+                c->skip_ws = nullptr; c->skip_ws_tiles = 0;
+                hipError_t e = hipMalloc((void**)&c->skip_ws, tiles * kSample8xSkipBytesPerTile);
+                if (e != hipSuccess) return e;
+                c->skip_ws_tiles = tiles;
+            }
+            a.wstream = c->den_w8x; a.wave_units_a = c->den_w8x_units[0]; a.wave_units_b = c->den_w8x_units[1];
+            a.skip_ws = c->skip_ws;
+            return launch_sample8x(a, st);
+        }
         a.wstream = c->den_w8;
         return launch_sample8(a, st);
     }
@@ -735,7 +789,7 @@ int build_repack_maps(amuse_ctx* c) {
     std::vector<float> den(AMUSE_DENOISER_PARAMS), pri(AMUSE_PRIOR_PARAMS);
     // element type of an image: 0 = fp32, 1 = bf16, 2 = split-fp16 (launch_repack's `kind`)
     auto kind_of = [&](void** slot) {
-        if (slot == (void**)&c->den_w[PREC_F16X2]) return 2;
+        if (slot == (void**)&c->den_w[PREC_F16X2] || slot == (void**)&c->den_w8x) return 2;
         return (slot == (void**)&c->den_w[PREC_BF16] || slot == (void**)&c->den_w8 || slot == (void**)&c->vae_w[PREC_BF16] ||
                 slot == (void**)&c->vae_wf || slot == (void**)&c->vaee_w[PREC_BF16]) ? 1 : 0;
     };
@@ -784,7 +838,7 @@ int build_repack_maps(amuse_ctx* c) {
             if (m < 0 || (size_t)m > limit) return fail(AMUSE_ESTATE, "internal: gather index out of range");
         int cls = 0;   // which AMUSE_UPD_* bits the image needs; 0 = small parameters, always replaced
         if (slot == (void**)&c->den_w[PREC_F32] || slot == (void**)&c->vae_w[PREC_F32]) cls = AMUSE_UPD_F32;
-        else if (slot == (void**)&c->den_w[PREC_F16X2]) cls = AMUSE_UPD_F32X;
+        else if (slot == (void**)&c->den_w[PREC_F16X2] || slot == (void**)&c->den_w8x) cls = AMUSE_UPD_F32X;
         else if (slot == (void**)&c->den_w[PREC_BF16] || slot == (void**)&c->den_w8 || slot == (void**)&c->vae_w[PREC_BF16] || slot == (void**)&c->vae_wf) cls = AMUSE_UPD_BF16;
         else if (slot == (void**)&c->vaee_w[PREC_F32]) cls = AMUSE_UPD_F32 | AMUSE_UPD_ENCODER;
         else if (slot == (void**)&c->vaee_w[PREC_BF16]) cls = AMUSE_UPD_BF16 | AMUSE_UPD_ENCODER;
@@ -825,7 +879,7 @@ void amuse_destroy(amuse_ctx* c) {
     (void)hipSetDevice(c->device);
     for (void* p : c->owned)
         if (p) (void)hipFree(p);
-    void* ptrs[] = {c->den_w[0], c->den_w[1], c->den_w[2], c->den_w8, c->den_pvec, c->den_pe, c->den_freqs, c->te_w1t, c->te_b1, c->te_w2t,
+    void* ptrs[] = {c->den_w[0], c->den_w[1], c->den_w[2], c->den_w8, c->den_w8x, c->skip_ws, c->den_pvec, c->den_pe, c->den_freqs, c->te_w1t, c->te_b1, c->te_w2t,
                     c->te_b2, c->cond_wt[0], c->cond_wt[1], c->cond_wt[2], c->cond_b[0], c->cond_b[1], c->cond_b[2],
                     c->vae_w[0], c->vae_w[1], c->vae_pvec, c->vae_final_bias, c->vae_pe, c->vae_wv_t, c->vae_bv,
                     c->vae_wo_t, c->vae_bo, c->vaee_w[0], c->vaee_w[1], c->vaee_pvec, c->vaee_pe, c->vaee_tok,

@@ -35,6 +35,7 @@ hipError_t hipEventRecord(hipEvent_t, hipStream_t) { return hipSuccess; }
 namespace amuse {
 hipError_t launch_sample(const SampleArgs&, int, hipStream_t) { return hipSuccess; }
 hipError_t launch_sample8(const SampleArgs&, hipStream_t) { return hipSuccess; }
+hipError_t launch_sample8x(const SampleArgs&, hipStream_t) { return hipSuccess; }
 hipError_t launch_time_tokens(const int*, int, const float*, const float*, const float*, const float*, const float*, const float*, float*, hipStream_t) { return hipSuccess; }
 hipError_t launch_cond_tokens(const CondArgs&, hipStream_t) { return hipSuccess; }
 hipError_t launch_repack(const float*, const int*, void*, size_t, int, hipStream_t) { return hipSuccess; }

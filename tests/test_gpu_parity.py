@@ -179,6 +179,39 @@ def test_bf16_kernels_4_and_8_waves_agree(env):
         assert _err(w4["lat"], lat8) < 0.3                     # bf16 drift class over 50 steps (latent rms 0.53)
 
 
+def test_fp32x_kernels_4_and_8_waves_agree(env):
+    """fp32x runs on the 8-wave role-split kernel (k_sampler8x.hip); the 4-wave kernel's PREC_F16X2 instantiation (k_sampler.hip,
+    AMUSE_SAMPLE_WAVES=4) computes the same network with another summation order: both hold the parity bars, so they agree
+    with each other at that level - and they really are two kernels."""
+    import os, subprocess, sys, tempfile
+    from amuse_amd import scheduler as sch
+    eng = env["eng"]
+    g = np.load(GOLDEN / "denoiser_steps.npz")
+    tr = np.load(GOLDEN / "ddim50_traj.npz")
+    eps8 = eng.denoise_step(g["x_t"], 981, g["con"], g["emo"], g["sty"], "fp32x").cpu().numpy()
+    eng.set_schedule(sch.ddim_table())
+    lat8 = eng.sample(tr["con"], tr["emo"], tr["sty"], "fp32x", x_init=tr["x_T"]).cpu().numpy()
+    code = (
+        "import sys, numpy as np, torch\n"
+        "sys.path.insert(0, sys.argv[1])\n"
+        "from amuse_amd import weights as wts, scheduler as sch\n"
+        "from amuse_amd.engine import HipEngine\n"
+        "eng = HipEngine(wts.make_denoiser_weights(0), wts.make_prior_weights(0))\n"
+        "g = np.load(sys.argv[1] + '/tests/golden/denoiser_steps.npz'); tr = np.load(sys.argv[1] + '/tests/golden/ddim50_traj.npz')\n"
+        "eps = eng.denoise_step(g['x_t'], 981, g['con'], g['emo'], g['sty'], 'fp32x').cpu().numpy()\n"
+        "eng.set_schedule(sch.ddim_table())\n"
+        "lat = eng.sample(tr['con'], tr['emo'], tr['sty'], 'fp32x', x_init=tr['x_T']).cpu().numpy()\n"
+        "np.savez(sys.argv[2], eps=eps, lat=lat)\n")
+    repo = str(GOLDEN.parents[1])
+    with tempfile.TemporaryDirectory() as d:
+        out = os.path.join(d, "w4.npz")
+        subprocess.run([sys.executable, "-c", code, repo, out], check=True, env=dict(os.environ, AMUSE_SAMPLE_WAVES="4"), timeout=600)
+        w4 = np.load(out)
+        assert not np.array_equal(w4["eps"], eps8)
+        assert _err(w4["eps"], eps8) < 2e-5 and _err(w4["eps"], g["eps_t981"]) < 1e-5
+        assert _err(w4["lat"], lat8) < 1e-4 and _err(w4["lat"], tr["x_after_50"]) < 1e-4
+
+
 @pytest.mark.parametrize("prec", PARITY)
 def test_diffusion_forward_per_clip_timesteps(env, prec):
     """amuse_diffusion_forward (ldm.py:71-97): per-clip timesteps vs the reference Denoiser golden and the oracle."""
