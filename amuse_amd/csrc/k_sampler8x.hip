@@ -60,6 +60,10 @@ using Ring = WRing<kR8>;
 #ifndef AMUSE_X_B_EARLY
 #define AMUSE_X_B_EARLY 32
 #endif
+// 1: the A waves fetch linear2's units as one burst behind their GELUs instead of re-arming at consumption (ffn_half)
+#ifndef AMUSE_X_A_DEFER
+#define AMUSE_X_A_DEFER 1
+#endif
 
 __device__ __forceinline__ f32x4* a8_slot(char* lds, int row, int col, int lane) {
     return reinterpret_cast<f32x4*>(lds) + (row * kTiles + col) * 64 + lane;
@@ -339,21 +343,39 @@ __device__ __forceinline__ void gelu_pair(f32x4 (&hq)[2]) {
 
 // this wave's two FFN quarters (Q0, Q0 + 1 of head h's slice): linear1 for 2 hidden tiles each -> bias + GELU -> linear2
 // split-K contribution of those 32 features.  Ring on entry: F1a in slots 0..15, F1b in 16..31 (EARLY < 32: the B waves'
-// last units are issued only now); linear2's units are re-armed behind linear1's MFMAs, in the same slots.
-template <int Q0, int EARLY>
-__device__ __forceinline__ void ffn_half(f32x4 (&part)[kTiles], const F16Pair (&xs)[4], Ring& rg, const float* pv, int h, int g) {
+// last units are issued only now).  linear2's 32 units have to come through the load path inside this phase, for both
+// groups (256 KiB per CU = 4.1 k cycles), and the B waves - the reducers of the combine that follows - are the critical ones:
+//   DEFER = false (B): linear2's units are re-armed behind linear1's MFMAs, in the same slots;
+//   DEFER = true (A): the wave leaves the path to the B waves first - both linear1 GEMMs and both GELUs without a load, then its
+//     32 units as one burst.  (With both groups re-arming at consumption the A waves' loads went out first and the B waves sat
+//     3 k cycles in their first GEMM: 9.5 k cycles per FFN phase, the A waves idle for 5 k of them in the combine behind it.)
+template <int Q0, int EARLY, bool DEFER, bool PROF>
+__device__ __forceinline__ void ffn_half(f32x4 (&part)[kTiles], const F16Pair (&xs)[4], Ring& rg, const float* pv, int h, int g, Prof8& pf) {
     const float* b1 = pv + PV_L1_B + 16 * (kTiles * h + 2 * Q0) + 4 * g;
     f32x4 ha[2] = {ld4(b1), ld4(b1 + 16)}, hb[2] = {ld4(b1 + 32), ld4(b1 + 48)};
     if constexpr (EARLY < 32) ring_issue<32 - EARLY, kR8, EARLY>(rg);
-    gemm_xs<2, 4, false, 0, true>(ha, xs, rg);    // F1a; slots 0..15 <- F2a
-    gemm_xs<2, 4, false, 16, true>(hb, xs, rg);   // F1b; slots 16..31 <- F2b
+    gemm_xs<2, 4, false, 0, !DEFER>(ha, xs, rg);    // F1a; (B) slots 0..15 <- F2a
+    stamp8<PROF>(pf);
+    gemm_xs<2, 4, false, 16, !DEFER>(hb, xs, rg);   // F1b; (B) slots 16..31 <- F2b
+    stamp8<PROF>(pf);
     gelu_pair(ha);
-    {
-        const F16Pair hs = split_f16(ha[0], ha[1]);
-        gemm_xs<kTiles, 1, false, 0, false>(part, &hs, rg);
-    }
-    gelu_pair(hb);
-    {
+    stamp8<PROF>(pf);
+    if constexpr (DEFER) {
+        gelu_pair(hb);
+        ring_issue<32, kR8, 0>(rg);
+        stamp8<PROF>(pf);
+        const F16Pair hsa = split_f16(ha[0], ha[1]), hsb = split_f16(hb[0], hb[1]);
+        gemm_xs<kTiles, 1, false, 0, false>(part, &hsa, rg);
+        stamp8<PROF>(pf);
+        gemm_xs<kTiles, 1, false, 16, false>(part, &hsb, rg);
+    } else {
+        {
+            const F16Pair hs = split_f16(ha[0], ha[1]);
+            gemm_xs<kTiles, 1, false, 0, false>(part, &hs, rg);
+        }
+        stamp8<PROF>(pf);
+        gelu_pair(hb);
+        stamp8<PROF>(pf);
         const F16Pair hs = split_f16(hb[0], hb[1]);
         gemm_xs<kTiles, 1, false, 16, false>(part, &hs, rg);
     }
@@ -404,7 +426,7 @@ __device__ __forceinline__ void encoder_block8x(F16Pair (&xs)[4], f32x4 (&xo)[2]
         stamp8<PROF>(pf);  // 2: combine 1
 #pragma unroll
         for (int t = 0; t < kTiles; ++t) part[t] = splat4(0.f);
-        ffn_half<0, 32>(part, xs, rg, pv, h, g);
+        ffn_half<0, 32, AMUSE_X_A_DEFER != 0, PROF>(part, xs, rg, pv, h, g, pf);
         stamp8<PROF>(pf);  // 3: FFN
         // ---- linear2 combine (B reduces): meanwhile fetch the next block's leading units
         combine_publish_c2<AMUSE_X_C2_N1>(part, xs, lds, h, lane, rg, next_has_skip, skip_src);
@@ -416,7 +438,7 @@ __device__ __forceinline__ void encoder_block8x(F16Pair (&xs)[4], f32x4 (&xo)[2]
         for (int t = 0; t < kTiles; ++t) part[t] = splat4(0.f);
         combine_reduce<4>(part, xo, xs, pv + PV_OUT_B, pv + PV_LN1_W, pv + PV_LN1_B, lds, h, lane);
         stamp8<PROF>(pf);
-        ffn_half<2, AMUSE_X_B_EARLY>(part, xs, rg, pv, h, g);
+        ffn_half<2, AMUSE_X_B_EARLY, false, PROF>(part, xs, rg, pv, h, g, pf);
         stamp8<PROF>(pf);  // 3: FFN
         if (next_has_skip) ring_issue<16, kR8, 0>(rg);  // the x half of this wave's two output tiles of the next block's skip linear
         combine_reduce<8>(part, xo, xs, pv + PV_L2_B, pv + PV_LN2_W, pv + PV_LN2_B, lds, h, lane);

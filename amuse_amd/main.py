@@ -76,9 +76,36 @@ def load_config(root: Path, fn: str, cfg_path=None):
     return out[0], out[1]
 
 
+def train_gesture_entry(args, dirname: Path, config: dict):
+    """--fn train_gesture (scripts/main.py:116-155): the LPDM trainer on the latent-diffusion LMDB cache named by the
+    configuration - batch size, epochs, save frequency and cache path from base_new.json + scripts/overrides/train_gesture.yaml -
+    through amuse_amd.train_gesture's own entry point (one process per GPU with --gpus N)."""
+    from . import train_gesture
+    tp = config["TRAIN_PARAM"]
+    assert not tp["pretrained_infer"], f"Arg: train_gesture and pretrained_infer: {tp['pretrained_infer']} mismatch!"   # main.py:126
+    assert tp["motion_extractor"]["use"] is False, "Motion extractor should be False!"
+    ld = tp["latent_diffusion"]
+    assert ld.get("smplx_data", True), "smplx_data must be True!"                                                        # main.py:129
+    argv = ["--batch", str(ld.get("batch_size", 32)), "--epochs", str(args.epochs or ld.get("n_epochs", 12000)),
+            "--save-freq", str(ld.get("model_save_freq", 200)), "--seed", str(tp.get("seed", 2024)), "--gpus", str(args.gpus),
+            "--out", str(dirname / "saved-models")]
+    cache = dirname / "data" / "BEAT-processed" / tp.get("diffusion", {}).get("lmdb_cache", "")
+    if not args.synthetic:
+        if not (cache.is_dir() and tp.get("diffusion", {}).get("lmdb_cache")):
+            raise SystemExit(f"train_gesture: the LMDB cache {cache} does not exist (prepare_data is the reference's job; --synthetic trains "
+                             f"on random batches of the collate function's shapes)")
+        argv += ["--cache", str(cache)]
+    if args.device != "cuda:0":
+        argv += ["--device", args.device]
+    if args.iters_per_epoch:
+        argv += ["--iters-per-epoch", str(args.iters_per_epoch)]
+    print(f"Experiment init: AMUSE, fn: train_gesture, time: {time.asctime()}")
+    return train_gesture.main(argv)
+
+
 def main(argv=None):
     ap = argparse.ArgumentParser(description="AMUSE (MI355X path)")
-    ap.add_argument("--fn", nargs="*", required=True, help="infer_gesture, edit_gesture")
+    ap.add_argument("--fn", nargs="*", required=True, help="infer_gesture, edit_gesture, train_gesture")
     ap.add_argument("--cfg", default=None, help="config file (default <root>/configs/base_new.json)")
     ap.add_argument("--wandb", default=None, help="accepted for command-line compatibility; wandb is out of scope")
     ap.add_argument("--root", default=None, help="the reference-shaped tree (default: cwd.parent, scripts/main.py:229)")
@@ -91,14 +118,20 @@ def main(argv=None):
     ap.add_argument("--steps", type=int, default=None)
     ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16"])
     ap.add_argument("--device", default="cuda:0")
+    ap.add_argument("--gpus", type=int, default=1, help="train_gesture: data-parallel ranks on this node (one process per GPU)")
+    ap.add_argument("--epochs", type=int, default=None, help="train_gesture: override TRAIN_PARAM.latent_diffusion.n_epochs")
+    ap.add_argument("--synthetic", action="store_true", help="train_gesture: synthetic batches instead of the LMDB cache")
+    ap.add_argument("--iters-per-epoch", type=int, default=None, help="train_gesture --synthetic: iterations per epoch")
     args = ap.parse_args(argv)
     fn = args.fn[0]
-    if fn not in ("infer_gesture", "edit_gesture"):
-        raise SystemExit(f"--fn {fn}: only infer_gesture and edit_gesture run on this path (train_gesture: amuse_amd.train_gesture)")
+    if fn not in ("infer_gesture", "edit_gesture", "train_gesture"):
+        raise SystemExit(f"--fn {fn}: infer_gesture, edit_gesture and train_gesture run on this path")
     tic = time.time()
     dirname = Path(args.root) if args.root else Path.cwd().parent
     config, ldm_cfg = load_config(dirname, fn, args.cfg)
     tp = config["TRAIN_PARAM"]
+    if fn == "train_gesture":
+        return train_gesture_entry(args, dirname, config)
     assert tp["pretrained_infer"], f"Arg: {fn} and pretrained_infer: {tp['pretrained_infer']} mismatch!"   # main.py:129
     assert tp["motion_extractor"]["use"] is False, "Motion extractor should be False!"
     if args.audios or args.renders:

@@ -516,6 +516,7 @@ def main(argv=None):
     ap.add_argument("--device", default=None, help="default: cuda:<LOCAL_RANK>")
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--seed", type=int, default=2024, help="TRAIN_PARAM.seed (configs/base_new.json)")
+    ap.add_argument("--save-freq", type=int, default=1, help="checkpoint every N epochs (TRAIN_PARAM.latent_diffusion.model_save_freq: 200)")
     args = ap.parse_args(argv)
     from . import launch
     if args.gpus > 1 and not launch.launched_by_torchrun():
@@ -542,7 +543,7 @@ def main(argv=None):
         loader = make_loader(LatentDiffusionCache.open(args.cache), args.batch, rank=rank, world=world, seed=args.seed)
     else:
         loader = [synthetic_batch(args.batch, 1000 * rank + i, device) for i in range(args.iters_per_epoch)]
-    tr.train_prior_latdiff_forward_backward_v2(loader, args.epochs, args.out, model_save_freq=1, rank=rank)
+    tr.train_prior_latdiff_forward_backward_v2(loader, args.epochs, args.out, model_save_freq=args.save_freq, rank=rank)
     if world > 1:
         import torch.distributed as dist
         dist.barrier()

@@ -44,3 +44,23 @@ def test_train_gesture_main_is_data_parallel(tmp_path):
     assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
     assert r.stdout.count("[LPDM-T] Epoch: [1/1]") == 1                # rank 0 only
     assert len(list(tmp_path.glob("prior_model_NoOpt_*_e1.pt"))) == 1 and len(list(tmp_path.glob("latdiff_model_wOpt_*_e1.pt"))) == 1
+
+
+def test_cli_fn_train_gesture_dispatches_to_the_trainer(tmp_path):
+    """`main.py --fn train_gesture` (scripts/main.py:116-155): configuration-driven (batch size / epochs / save frequency from
+    base_new.json merged with scripts/overrides/train_gesture.yaml, seed from TRAIN_PARAM), refuses a missing LMDB cache, trains on
+    synthetic batches when asked, writes the reference-named checkpoints under <root>/saved-models."""
+    import pytest
+    from conftest import make_reference_tree
+    from amuse_amd import main as cli
+    root = make_reference_tree(tmp_path / "tree")
+    (root / "scripts/overrides/train_gesture.yaml").write_text(
+        "TRAIN_PARAM:\n  latent_diffusion:\n    batch_size: 2\n    n_epochs: 1\n    model_save_freq: 1\n  diffusion:\n    lmdb_cache: BEAT-cache/none\n")
+    with pytest.raises(SystemExit, match="LMDB cache"):
+        cli.main(["--fn", "train_gesture", "--root", str(root), "--device", "cpu"])
+    assert cli.main(["--fn", "train_gesture", "--root", str(root), "--device", "cpu", "--synthetic", "--iters-per-epoch", "2"]) == 0
+    assert len(list((root / "saved-models").glob("latdiff_model_wOpt_*_e1.pt"))) == 1
+    # the inference entry points still refuse a training configuration (pretrained_infer false), as scripts/main.py:126 does
+    (root / "scripts/overrides/infer_gesture.yaml").write_text("TRAIN_PARAM:\n  pretrained_infer: False\n")
+    with pytest.raises(AssertionError, match="mismatch"):
+        cli.main(["--fn", "infer_gesture", "--root", str(root), "--random-init"])
