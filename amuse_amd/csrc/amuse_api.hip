@@ -426,9 +426,9 @@ int build_denoiser(amuse_ctx* c, const float* den, int what = AMUSE_UPD_ALL) {
         for (int w8 = 0; w8 < 8; ++w8) {
             const int h = w8 & 3, sgrp = w8 >> 2;
             std::vector<uint4> s;
-            // per block, in issue order (k_sampler8x.hip).  A: lead (out_proj - or, ahead of an output block, the skip-input half
-            // of the skip linear for output tiles 2h, 2h+1) | q,k for k-pairs 0,1 | [out_proj, output blocks] | q,k for k-pairs
-            // 2,3 | v | F1a F1b F2a F2b (FFN quarters 0,1).  B: [skip linear, x half], F1a F1b F2a F2b (quarters 2,3).
+            // per block, in issue order (k_sampler8x.hip).  A: lead (v - or, ahead of an output block, the skip-input half of the
+            // skip linear for output tiles 2h, 2h+1) | q,k for k-pairs 0,1 | [v, output blocks] | q,k for k-pairs 2,3 | out_proj
+            // | F1a F1b F2a F2b (FFN quarters 0,1).  B: [skip linear, x half], F1a F1b F2a F2b (quarters 2,3).
             for (int b = 0; b < 9; ++b) {
                 const std::string p = blk_name("encoder", b);
                 auto f1 = [&](int q) { const int h0 = 8 * h + 2 * q; pack_gemm(s, PREC_F16X2, D.get(p + ".linear1.weight"), 512, 128, {h0, h0 + 1}, range(0, 8)); };
@@ -439,12 +439,13 @@ int build_denoiser(amuse_ctx* c, const float* den, int what = AMUSE_UPD_ALL) {
                     const float* in_w = D.get(p + ".self_attn.in_proj_weight");
                     const std::vector<int> qk_tiles = {2 * h, 2 * h + 1, 8 + 2 * h, 8 + 2 * h + 1};
                     const auto outproj = [&] { pack_gemm(s, PREC_F16X2, D.get(p + ".self_attn.out_proj.weight"), 128, 128, range(0, 8), {2 * h, 2 * h + 1}); };
+                    const auto vproj = [&] { pack_gemm(s, PREC_F16X2, in_w, 384, 128, {16 + 2 * h, 16 + 2 * h + 1}, range(0, 8)); };
                     if (b >= 5) pack_gemm(s, PREC_F16X2, wskip, 128, 256, {2 * h, 2 * h + 1}, range(8, 16));
-                    else outproj();
+                    else vproj();
                     pack_gemm(s, PREC_F16X2, in_w, 384, 128, qk_tiles, range(0, 4));
-                    if (b >= 5) outproj();
+                    if (b >= 5) vproj();
                     pack_gemm(s, PREC_F16X2, in_w, 384, 128, qk_tiles, range(4, 8));
-                    pack_gemm(s, PREC_F16X2, in_w, 384, 128, {16 + 2 * h, 16 + 2 * h + 1}, range(0, 8));
+                    outproj();
                 } else if (b >= 5) {
                     pack_gemm(s, PREC_F16X2, wskip, 128, 256, {2 * h, 2 * h + 1}, range(0, 8));
                 }

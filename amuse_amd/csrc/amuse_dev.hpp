@@ -357,6 +357,37 @@ __device__ __forceinline__ float gelu_erf_fast(float x) {
     return fmaf(fabsf(hx), erfabs, hx);  // 0.5 x + 0.5 |x| erf(|x|/sqrt2) == 0.5 x (1 + erf(x/sqrt2))
 }
 
+// Branch-free fp32 erf for the fp32x kernels (libm's erff compiles to one divergent branch per element - 24 of them per FFN
+// phase and wave, with live registers spilled around each): |z| < 0.875: z + z P(z^2); otherwise 1 - exp2(Q(min(|z|, 4))) with Q
+// fitted to log2(erfc), both evaluated and selected.  Coefficients from tools/fit_erf.py; max |error| 7.9e-8 (1.3 ulp at 1),
+// relative error <= 9.8e-8 - and the GELU built on it errs by 4.5e-7 at most over [-8, 8], exactly what torch's own fp32
+// 0.5 x (1 + erf(x / sqrt2)) does against float64.
+__device__ __forceinline__ float erf_bf(float z) {
+    const float az = fabsf(z), t = az * az;
+    float p = 8.698958845343441e-05f;
+    p = fmaf(p, t, -0.000821653928142041f);
+    p = fmaf(p, t, 0.005207217764109373f);
+    p = fmaf(p, t, -0.026861771941184998f);
+    p = fmaf(p, t, 0.11283736675977707f);
+    p = fmaf(p, t, -0.37612634897232056f);
+    p = fmaf(p, t, 0.12837916612625122f);
+    const float r1 = fmaf(az, p, az);
+    const float zc = fminf(az, 4.0f);
+    float q = -1.0750341061793733e-08f;
+    q = fmaf(q, zc, 2.5535098302498227e-06f);
+    q = fmaf(q, zc, -6.779012619517744e-05f);
+    q = fmaf(q, zc, 0.0008653029217384756f);
+    q = fmaf(q, zc, -0.0068697636015713215f);
+    q = fmaf(q, zc, 0.038096215575933456f);
+    q = fmaf(q, zc, -0.15873675048351288f);
+    q = fmaf(q, zc, -0.9116426110267639f);
+    q = fmaf(q, zc, -1.6305032968521118f);
+    q = fmaf(q, zc, 0.0004394356219563633f);
+    const float r2 = 1.0f - __builtin_amdgcn_exp2f(q);
+    return copysignf(az < 0.875f ? r1 : r2, z);
+}
+__device__ __forceinline__ float gelu_erf_bf(float x) { return 0.5f * x * (1.0f + erf_bf(x * 0.70710678118654752440f)); }
+
 // GELU for values that are rounded to bf16 right away (the FFN hidden activations of the 8-wave bf16 sampling kernel):
 // erf(a / sqrt2) ~ a P(a^2) with a = clamp(x, +-3 sqrt2) and P of degree 7 (minimax fit with the value at the clamp
 // point pinned to 1, |erf error| <= 8.7e-5) - an odd function, so no abs / sign handling.  No transcendental:

@@ -17,8 +17,9 @@
 //   Group B (s = 1): reduces + normalises both combines (wave h: feature tiles 2h, 2h+1), FFN quarters 2,3; fetches its FFN
 //     half while the A waves run attention.
 //   A unit pair (hi, lo) takes two ring slots, so a 32-slot ring holds HALF of what a window of k_sampler8.hip fetches:
-//   the second half of every group is re-armed at consumption, behind the MFMAs of the first (A: q,k k-pairs 2,3 and v
-//   behind q,k k-pairs 0,1; both groups: linear2 behind linear1).
+//   the second half of every group is re-armed at consumption, behind the MFMAs of the first (A: q,k k-pairs 2,3 behind
+//   k-pairs 0,1 and out_proj behind v; B: linear2 behind linear1 - the A waves fetch their linear2 as one burst behind their
+//   GELUs instead, leaving the path to the reducers first: ffn_half).
 //   U-Net skip linears, residual stream exchange, final LayerNorm + scheduler update: as k_sampler8.hip, with the residual
 //   stream travelling between waves as split operands (8 x 1 KiB: hi on the diagonal slots (c, c), lo on (4 + c, 4 + c)).
 //   The skip stack does not fit the LDS as split operands (32 KiB): every A wave keeps its OWN copy in global memory
@@ -63,6 +64,20 @@ using Ring = WRing<kR8>;
 // 1: the A waves fetch linear2's units as one burst behind their GELUs instead of re-arming at consumption (ffn_half)
 #ifndef AMUSE_X_A_DEFER
 #define AMUSE_X_A_DEFER 1
+#endif
+// s_setprio of the B waves inside their FFN half (they are the reducers of the combine behind it): 73.4 -> 72.6 us per step
+#ifndef AMUSE_X_B_PRIO
+#define AMUSE_X_B_PRIO 3
+#endif
+// erf of the FFN's GELU: 0 branch-free fit (amuse_dev.hpp erf_bf), 1 libm erff, 2 Abramowitz-Stegun on rcp / exp2.  Same-box wall
+// clock of this kernel, us per step: libm 71.4, branch-free 75.3 (the 3 : 1 FFN split of tools/probes/fp32x_ffn_3_1_split ranked
+// them the other way round: 92.2 / 86.3), Abramowitz-Stegun 79.7 on the build before
+#ifndef AMUSE_X_ERF
+#define AMUSE_X_ERF 1
+#endif
+// A waves: 2 = defer both linear2 groups behind both GELUs (one burst), 1 = re-arm the first at consumption and defer the second
+#ifndef AMUSE_X_A_DEFER2
+#define AMUSE_X_A_DEFER2 2
 #endif
 
 __device__ __forceinline__ f32x4* a8_slot(char* lds, int row, int col, int lane) {
@@ -246,11 +261,11 @@ __device__ __forceinline__ void combine_publish_c1(const f32x4 (&part)[kTiles], 
 }
 
 // The A waves' side of the linear2 combine: fetch the next block's leading 32 units - 16 "lead" units into slots 0..15,
-// then q, k for k-pairs 0,1 into slots 16..31.  In front of an ordinary block the lead is out_proj.  In front of an OUTPUT
+// then q, k for k-pairs 0,1 into slots 16..31.  In front of an ordinary block the lead is v.  In front of an OUTPUT
 // block (cross_attention.py:58-61: x = Linear(cat(x, skips.pop()))) it is this wave's units of the skip linear's skip-input
 // half: in its waiting time the wave computes u = W[:, 128:] . skip for feature tiles 2h, 2h+1 - the half of the skip linear
 // that does not depend on the current block's result - from its own copy of the popped level, and hands it to B wave h through
-// u_slot (after the second barrier: the reducers are done with the partials); out_proj then follows during the skip linear.
+// u_slot (after the second barrier: the reducers are done with the partials); v then follows during the skip linear.
 // One body for both cases, the extra work behind a branch that touches no ring slot it does not own (k_sampler8.hip).
 template <int N1>
 __device__ __forceinline__ void combine_publish_c2(const f32x4 (&part)[kTiles], F16Pair (&xs)[4], char* lds, int h, int lane,
@@ -333,10 +348,12 @@ __device__ __forceinline__ void gelu_pair(f32x4 (&hq)[2]) {
     for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int m = 0; m < 4; ++m) {
-#ifdef AMUSE_F32X_FAST_ERF
-            hq[i][m] = gelu_erf_fast(hq[i][m]);
+#if AMUSE_X_ERF == 1
+            hq[i][m] = gelu_erf(hq[i][m]);        // libm erff (one divergent branch per element)
+#elif AMUSE_X_ERF == 2
+            hq[i][m] = gelu_erf_fast(hq[i][m]);   // Abramowitz-Stegun on rcp / exp2
 #else
-            hq[i][m] = gelu_erf(hq[i][m]);
+            hq[i][m] = gelu_erf_bf(hq[i][m]);     // branch-free fit (amuse_dev.hpp erf_bf)
 #endif
         }
 }
@@ -354,7 +371,7 @@ __device__ __forceinline__ void ffn_half(f32x4 (&part)[kTiles], const F16Pair (&
     const float* b1 = pv + PV_L1_B + 16 * (kTiles * h + 2 * Q0) + 4 * g;
     f32x4 ha[2] = {ld4(b1), ld4(b1 + 16)}, hb[2] = {ld4(b1 + 32), ld4(b1 + 48)};
     if constexpr (EARLY < 32) ring_issue<32 - EARLY, kR8, EARLY>(rg);
-    gemm_xs<2, 4, false, 0, !DEFER>(ha, xs, rg);    // F1a; (B) slots 0..15 <- F2a
+    gemm_xs<2, 4, false, 0, !DEFER || AMUSE_X_A_DEFER2 == 1>(ha, xs, rg);    // F1a; (B) slots 0..15 <- F2a
     stamp8<PROF>(pf);
     gemm_xs<2, 4, false, 16, !DEFER>(hb, xs, rg);   // F1b; (B) slots 16..31 <- F2b
     stamp8<PROF>(pf);
@@ -362,7 +379,8 @@ __device__ __forceinline__ void ffn_half(f32x4 (&part)[kTiles], const F16Pair (&
     stamp8<PROF>(pf);
     if constexpr (DEFER) {
         gelu_pair(hb);
-        ring_issue<32, kR8, 0>(rg);
+        if constexpr (AMUSE_X_A_DEFER2 == 1) ring_issue<16, kR8, 16>(rg);
+        else ring_issue<32, kR8, 0>(rg);
         stamp8<PROF>(pf);
         const F16Pair hsa = split_f16(ha[0], ha[1]), hsb = split_f16(hb[0], hb[1]);
         gemm_xs<kTiles, 1, false, 0, false>(part, &hsa, rg);
@@ -391,7 +409,9 @@ __device__ __forceinline__ void encoder_block8x(F16Pair (&xs)[4], f32x4 (&xo)[2]
     const int g = lane >> 4, r = lane & 15;
     f32x4 part[kTiles];
     if constexpr (ROLEA) {
-        // ---- ring on entry: lead = out_proj (slots 0..15), q,k for k-pairs 0,1 (slots 16..31)
+        // ---- ring on entry: lead = v (slots 0..15), q,k for k-pairs 0,1 (slots 16..31).  Two groups are re-armed at
+        // consumption: q,k for k-pairs 2,3 behind k-pairs 0,1 and out_proj behind v - with v's MFMAs between the issue of the
+        // former and its use (in the order q,k | q,k | v two L2 latencies were exposed one after the other: 4.4 k cycles)
         f32x4 b_qk[4];
         float b_v[2];
 #pragma unroll
@@ -404,9 +424,9 @@ __device__ __forceinline__ void encoder_block8x(F16Pair (&xs)[4], f32x4 (&xo)[2]
 #pragma unroll
         for (int o = 0; o < 4; ++o) qk[o] = splat4(0.f);
         v[0] = v[1] = splat4(0.f);
-        gemm_xs<4, 2, false, 16, true>(qk, xs, rg);       // k-pairs 0,1; slots 16..31 <- q,k for k-pairs 2,3
-        gemm_xs<4, 2, false, 16, true>(qk, xs + 2, rg);   // k-pairs 2,3; slots 16..31 <- v
-        gemm_xs<2, 4, true, 16, false>(v, xs, rg);
+        gemm_xs<4, 2, false, 16, true>(qk, xs, rg);        // k-pairs 0,1; slots 16..31 <- q,k for k-pairs 2,3
+        gemm_xs<2, 4, true, 0, true>(v, xs, rg);           // v; slots 0..15 <- out_proj
+        gemm_xs<4, 2, false, 16, false>(qk, xs + 2, rg);   // k-pairs 2,3
         const float scaling = 0.17677669529663687f;  // sqrt(1/32): q * scaling (F.multi_head_attention_forward)
         f32x4 q[2] = {(qk[0] + b_qk[0]) * scaling, (qk[1] + b_qk[1]) * scaling};
         f32x4 k[2] = {qk[2] + b_qk[2], qk[3] + b_qk[3]};
@@ -438,7 +458,9 @@ __device__ __forceinline__ void encoder_block8x(F16Pair (&xs)[4], f32x4 (&xo)[2]
         for (int t = 0; t < kTiles; ++t) part[t] = splat4(0.f);
         combine_reduce<4>(part, xo, xs, pv + PV_OUT_B, pv + PV_LN1_W, pv + PV_LN1_B, lds, h, lane);
         stamp8<PROF>(pf);
+        if constexpr (AMUSE_X_B_PRIO != 0) __builtin_amdgcn_s_setprio(AMUSE_X_B_PRIO);
         ffn_half<2, AMUSE_X_B_EARLY, false, PROF>(part, xs, rg, pv, h, g, pf);
+        if constexpr (AMUSE_X_B_PRIO != 0) __builtin_amdgcn_s_setprio(0);
         stamp8<PROF>(pf);  // 3: FFN
         if (next_has_skip) ring_issue<16, kR8, 0>(rg);  // the x half of this wave's two output tiles of the next block's skip linear
         combine_reduce<8>(part, xo, xs, pv + PV_L2_B, pv + PV_LN2_W, pv + PV_LN2_B, lds, h, lane);
@@ -545,7 +567,7 @@ __device__ __forceinline__ void role_loop8x(const SampleArgs& a, char* smem, int
                 // x = Linear(cat(x, skips.pop())) (cross_attention.py:58-61), split over OUTPUT tiles: B wave h computes its
                 // own feature tiles 2h, 2h+1 = bias + u + W[:, :128] . x, where u = W[:, 128:] . skip was prepared by A wave h
                 // during the previous linear2 combine (combine_publish_c2); it keeps them as its fp32 tiles and publishes
-                // the split operand: one barrier and no partial sums.  The A waves fetch out_proj into the lead slots.
+                // the split operand: one barrier and no partial sums.  The A waves fetch v into the lead slots.
                 if constexpr (ROLEA) {
                     ring_issue<16, kR8, 0>(rg);
                 } else {
