@@ -3,7 +3,23 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <atomic>
+
 namespace amuse {
+
+// Has a launcher's one-off set-up (hipFuncSetAttribute: the dynamic LDS size is a per-DEVICE function attribute) run on the
+// current device?  One bit per device, lock-free: the C ABI allows contexts on several GPUs in one process, and two threads racing
+// through a first launch both do the idempotent set-up.
+struct DeviceOnce {
+    std::atomic<unsigned long long> mask{0};
+    bool done(int* dev) {
+        int d = 0;
+        (void)hipGetDevice(&d);
+        *dev = d;
+        return (mask.load(std::memory_order_acquire) >> (d & 63)) & 1ull;
+    }
+    void set(int dev) { mask.fetch_or(1ull << (dev & 63), std::memory_order_release); }
+};
 
 // ---------------------------------------------------------------- sampling loop (k_sampler.hip)
 struct SampleArgs {

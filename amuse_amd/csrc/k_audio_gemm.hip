@@ -26,6 +26,7 @@
 
 #include "amuse_dev.hpp"
 #include "amuse_audio.hpp"
+#include "amuse_kernels.hpp"   // DeviceOnce
 
 namespace amuse {
 namespace {
@@ -267,12 +268,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 
 template <int EPI, int NSLOT, int FX>
 hipError_t launch_gemm_n(const GemmArgs& a, int n_tiles, hipStream_t s) {
-    static bool attr = false;
-    if (!attr) {
+    static DeviceOnce once;
+    int dev_;
+    if (!once.done(&dev_)) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_tm<EPI, NSLOT, FX>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                            gemm_lds(NSLOT, FX));
         if (e != hipSuccess) return e;
-        attr = true;
+        once.set(dev_);
     }
     const int resident = 2 * 256;   // two workgroups per CU, 256 CUs
     hipLaunchKernelGGL((k_gemm_tm<EPI, NSLOT, FX>), dim3(n_tiles < resident ? n_tiles : resident), dim3(256), gemm_lds(NSLOT, FX), s, a);

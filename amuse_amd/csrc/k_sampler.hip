@@ -462,8 +462,9 @@ __global__ __launch_bounds__(256, 1) void k_sample(SampleArgs a) {
 hipError_t launch_sample(const SampleArgs& a, int precision, hipStream_t stream) {
     const int tiles = (a.B + a.G - 1) / a.G;
     const dim3 grid(tiles), block(256);
-    static bool attr_set = false;
-    if (!attr_set) {
+    static DeviceOnce once;
+    int dev_;
+    if (!once.done(&dev_)) {
         const void* ks[6] = {reinterpret_cast<const void*>(&k_sample<PREC_F32, false>),
                              reinterpret_cast<const void*>(&k_sample<PREC_BF16, false>),
                              reinterpret_cast<const void*>(&k_sample<PREC_F16X2, false>),
@@ -474,7 +475,7 @@ hipError_t launch_sample(const SampleArgs& a, int precision, hipStream_t stream)
             hipError_t e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, kSampleLdsBytes);
             if (e != hipSuccess) return e;
         }
-        attr_set = true;
+        once.set(dev_);
     }
     if (a.prof_out) {
         if (precision == PREC_F32) hipLaunchKernelGGL((k_sample<PREC_F32, true>), grid, block, kSampleLdsBytes, stream, a);

@@ -60,6 +60,10 @@ using Ring = WRing<kR8>;
 #ifndef AMUSE_B_EARLY
 #define AMUSE_B_EARLY 20
 #endif
+// VALU instructions scheduled behind each MFMA while one FFN quarter's GELU overlaps the other quarter's GEMM (ffn_half)
+#ifndef AMUSE_FFN_VALU_PER_MFMA
+#define AMUSE_FFN_VALU_PER_MFMA 7
+#endif
 #ifndef AMUSE_C2_N1
 #define AMUSE_C2_N0 16
 #define AMUSE_C2_N1 12
@@ -323,7 +327,7 @@ __device__ __forceinline__ void ffn_half(f32x4 (&part)[kTiles], const bf16x8 (&x
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // 1 MFMA
-        __builtin_amdgcn_sched_group_barrier(0x002, 7, 0);   // 7 VALU
+        __builtin_amdgcn_sched_group_barrier(0x002, AMUSE_FFN_VALU_PER_MFMA, 0);   // 7 VALU
     }
     __builtin_amdgcn_sched_barrier(0);
     gemm_ring<P, kTiles, 2, false, kR8, 16, false>(part, ha, rg);
@@ -331,7 +335,7 @@ __device__ __forceinline__ void ffn_half(f32x4 (&part)[kTiles], const bf16x8 (&x
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-        __builtin_amdgcn_sched_group_barrier(0x002, 7, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, AMUSE_FFN_VALU_PER_MFMA, 0);
     }
     __builtin_amdgcn_sched_barrier(0);
     gemm_ring<P, kTiles, 2, false, kR8, 24, false>(part, hb, rg);
@@ -654,13 +658,14 @@ __global__ __launch_bounds__(512) void k_sample8(SampleArgs a) {
 
 hipError_t launch_sample8(const SampleArgs& a, hipStream_t stream) {
     const int tiles = (a.B + a.G - 1) / a.G;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static DeviceOnce once;
+    int dev_;
+    if (!once.done(&dev_)) {
         for (const void* k : {reinterpret_cast<const void*>(&k_sample8<false>), reinterpret_cast<const void*>(&k_sample8<true>)}) {
             hipError_t e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, kSample8LdsBytes);
             if (e != hipSuccess) return e;
         }
-        attr_set = true;
+        once.set(dev_);
     }
     if (a.prof_out) hipLaunchKernelGGL(k_sample8<true>, dim3(tiles), dim3(512), kSample8LdsBytes, stream, a);
     else hipLaunchKernelGGL(k_sample8<false>, dim3(tiles), dim3(512), kSample8LdsBytes, stream, a);

@@ -715,13 +715,14 @@ __global__ __launch_bounds__(512) void k_sample8x(SampleArgs a) {
 
 hipError_t launch_sample8x(const SampleArgs& a, hipStream_t stream) {
     const int tiles = (a.B + a.G - 1) / a.G;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static DeviceOnce once;
+    int dev_;
+    if (!once.done(&dev_)) {
         for (const void* k : {reinterpret_cast<const void*>(&k_sample8x<false>), reinterpret_cast<const void*>(&k_sample8x<true>)}) {
             hipError_t e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, kSample8xLdsBytes);
             if (e != hipSuccess) return e;
         }
-        attr_set = true;
+        once.set(dev_);
     }
     if (a.prof_out) hipLaunchKernelGGL(k_sample8x<true>, dim3(tiles), dim3(512), kSample8xLdsBytes, stream, a);
     else hipLaunchKernelGGL(k_sample8x<false>, dim3(tiles), dim3(512), kSample8xLdsBytes, stream, a);

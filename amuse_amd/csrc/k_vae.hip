@@ -495,14 +495,15 @@ hipError_t set_lds(K kern, int bytes) {
 }  // namespace
 
 hipError_t launch_vae_rows(const VaeRowsArgs& a, int precision, bool enc, hipStream_t stream) {
-    static bool attr_set = false;
-    if (!attr_set) {
+    static DeviceOnce once;
+    int dev_;
+    if (!once.done(&dev_)) {
         hipError_t e = set_lds(&k_vae_rows<PREC_F32, false>, kRowsLdsBytes);
         if (e == hipSuccess) e = set_lds(&k_vae_rows<PREC_BF16, false>, kRowsLdsBytes);
         if (e == hipSuccess) e = set_lds(&k_vae_rows<PREC_F32, true>, kRowsLdsBytes);
         if (e == hipSuccess) e = set_lds(&k_vae_rows<PREC_BF16, true>, kRowsLdsBytes);
         if (e != hipSuccess) return e;
-        attr_set = true;
+        once.set(dev_);
     }
     const dim3 grid(a.B * a.tiles), block(256);
     if (precision == PREC_F32) {
@@ -516,14 +517,15 @@ hipError_t launch_vae_rows(const VaeRowsArgs& a, int precision, bool enc, hipStr
 }
 
 hipError_t launch_vae_attn(const VaeAttnArgs& a, int precision, bool enc, hipStream_t stream) {
-    static bool attr_set = false;
-    if (!attr_set) {
+    static DeviceOnce once;
+    int dev_;
+    if (!once.done(&dev_)) {
         hipError_t e = set_lds(&k_vae_attn<PREC_F32, false>, kAttnLdsBytes);
         if (e == hipSuccess) e = set_lds(&k_vae_attn<PREC_F32, true>, kAttnLdsBytes);
         if (e == hipSuccess) e = set_lds(&k_vae_attn_bf16<false>, kAttnBf16LdsBytes);
         if (e == hipSuccess) e = set_lds(&k_vae_attn_bf16<true>, kAttnBf16LdsBytes);
         if (e != hipSuccess) return e;
-        attr_set = true;
+        once.set(dev_);
     }
     const dim3 grid(a.B * kHeads), block(256);
     if (precision == PREC_F32) {

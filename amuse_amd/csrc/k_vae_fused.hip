@@ -624,13 +624,14 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 }  // namespace
 
 hipError_t launch_vae_fused(const VaeFusedArgs& a, hipStream_t stream) {
-    static bool attr_set = false;
-    if (!attr_set) {
+    static DeviceOnce once;
+    int dev_;
+    if (!once.done(&dev_)) {
         for (const void* k : {reinterpret_cast<const void*>(&k_vae_fused<false>), reinterpret_cast<const void*>(&k_vae_fused<true>)}) {
             hipError_t e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, kVaeFusedLdsBytes);
             if (e != hipSuccess) return e;
         }
-        attr_set = true;
+        once.set(dev_);
     }
 #if AMUSE_FPROF
     {

@@ -10,6 +10,13 @@ done
 for n in FETCH_SIZE WRITE_SIZE SQ_WAVE_CYCLES SQ_INSTS_MFMA; do
   f=$(ls -t $O/dpmc_$n/*/*_counter_collection.csv 2>/dev/null | head -1); [ -n "$f" ] && cp "$f" profiles/${R}_decode_pmc/${n}_counter_collection.csv
 done
+mkdir -p profiles/${R}_fp32x_pmc
+for n in FETCH_SIZE WRITE_SIZE SQ_WAVE_CYCLES SQ_INSTS_MFMA; do
+  f=$(ls -t $O/xpmc_$n/*/*_counter_collection.csv 2>/dev/null | head -1); [ -n "$f" ] && cp "$f" profiles/${R}_fp32x_pmc/${n}_counter_collection.csv
+done
+f=$(ls -t $O/x_stats/*/*_kernel_stats.csv 2>/dev/null | head -1); [ -n "$f" ] && cp "$f" profiles/${R}_fp32x_kernel_stats.csv
+[ -f $O/fp32x_perf.txt ] && grep -v libdrm $O/fp32x_perf.txt > profiles/${R}_fp32x_perf.txt
+[ -f $O/phase8x.txt ] && grep -v libdrm $O/phase8x.txt > profiles/${R}_k_sample8x_phase_timeline.txt
 mkdir -p profiles/${R}_audio_pmc
 for n in FETCH_SIZE WRITE_SIZE SQ_WAVE_CYCLES SQ_INSTS_MFMA; do
   f=$(ls -t $O/apmc_$n/*/*_counter_collection.csv 2>/dev/null | head -1); [ -n "$f" ] && python3 tools/summarize_pmc.py "$f" > profiles/${R}_audio_pmc/${n}_per_kernel.csv

@@ -14,6 +14,14 @@ for grp in FETCH_SIZE WRITE_SIZE "TCC_HIT_sum TCC_MISS_sum" "SQ_WAVE_CYCLES SQ_B
   n=$(echo $grp | cut -d' ' -f1)
   timeout 300 rocprofv3 --pmc $grp --kernel-trace --output-format csv -d $O/pmc_$n -- python3 tools/run_sample_once.py 256 bf16 2 > $O/pmc_$n.log 2>&1
 done
+# the fp32x parity mode (k_sample8x): kernel stats + the same counter groups
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/x_stats -- python3 tools/run_sample_once.py 256 fp32x 3 > $O/x_stats.log 2>&1
+for grp in FETCH_SIZE WRITE_SIZE "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_ANY" "SQ_INSTS_MFMA SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_INSTS_SALU"; do
+  n=$(echo $grp | cut -d' ' -f1)
+  timeout 300 rocprofv3 --pmc $grp --kernel-trace --output-format csv -d $O/xpmc_$n -- python3 tools/run_sample_once.py 256 fp32x 2 > $O/xpmc_$n.log 2>&1
+done
+timeout 200 python tools/gpu_fp32x_perf.py 1 256 768 > $O/fp32x_perf.txt 2>&1
+timeout 100 python tools/gpu_phase_profile8.py 256 fp32x > $O/phase8x.txt 2>&1
 # decode: kernel stats + counters of the fused kernel at 256 clips
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/decode_stats -- python3 tools/gpu_decode_perf.py 256 > $O/decode_stats.log 2>&1
 for grp in FETCH_SIZE WRITE_SIZE "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_ANY" "SQ_INSTS_MFMA SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE"; do
