@@ -308,18 +308,18 @@ struct amuse_ctx {
     float* cond_wt[3] = {nullptr, nullptr, nullptr};
     float* cond_b[3] = {nullptr, nullptr, nullptr};
     // prior decoder
-    uint4* vae_w[2] = {nullptr, nullptr};
-    uint32_t vae_stage_base[2][kVaeStages];
-    uint32_t vae_stage_units[2][kVaeStages];
+    uint4* vae_w[3] = {nullptr, nullptr, nullptr};   // fp32 | bf16 | split-fp16 (fp32x)
+    uint32_t vae_stage_base[3][kVaeStages];
+    uint32_t vae_stage_units[3][kVaeStages];
     uint4* vae_wf = nullptr;           // bf16 stream of the fused decode kernel (k_vae_fused.hip)
     uint4* vae_skip = nullptr; size_t vae_skip_cap = 0;   // clips
     float* vae_ca_ws = nullptr; size_t vae_ca_cap = 0;    // clips
     float *vae_pvec = nullptr, *vae_final_bias = nullptr, *vae_pe = nullptr;
     float *vae_wv_t = nullptr, *vae_bv = nullptr, *vae_wo_t = nullptr, *vae_bo = nullptr;
     // prior encoder (MotionPrior.encode)
-    uint4* vaee_w[2] = {nullptr, nullptr};
-    uint32_t vaee_stage_base[2][kVaeStages];
-    uint32_t vaee_stage_units[2][kVaeStages];
+    uint4* vaee_w[3] = {nullptr, nullptr, nullptr};
+    uint32_t vaee_stage_base[3][kVaeStages];
+    uint32_t vaee_stage_units[3][kVaeStages];
     float *vaee_pvec = nullptr, *vaee_pe = nullptr, *vaee_tok = nullptr, *vaee_emb_bias = nullptr;
     // schedule
     int T = 0;
@@ -487,10 +487,9 @@ int build_denoiser(amuse_ctx* c, const float* den, int what = AMUSE_UPD_ALL) {
 int build_prior(amuse_ctx* c, const float* pri, int what = AMUSE_UPD_ALL) {
     static const ParamIndex PI = prior_index();
     const Params Pp{PI, pri};
-    if (what & AMUSE_UPD_F32X) what |= AMUSE_UPD_F32;   // fp32x jobs decode / encode with the fp32 kernels (prior_precision)
     // ---- VAE decoder weight streams: [stage][wave][units]
-    for (int prec = 0; prec < 2; ++prec) {
-        if (!(what & (1 << prec))) continue;
+    for (int prec = 0; prec < 3; ++prec) {
+        if (!(what & kUpdBit[prec])) continue;
         std::vector<uint4> all;
         for (int st = 0; st < kVaeStages; ++st) {
             c->vae_stage_base[prec][st] = (uint32_t)(all.size() / 64);
@@ -568,8 +567,8 @@ int build_prior(amuse_ctx* c, const float* pri, int what = AMUSE_UPD_ALL) {
     }
     // ---- VAE encoder weight streams: stage 0 = skel_embedding (K = 333 padded to 22 k-tiles, 2 output tiles per wave)
     // + in_proj(0); stage i+1 = post-attention of block i (+ skip linear) + in_proj(i+1); stage 9 = post-attention of block 8
-    for (int prec = 0; prec < 2; ++prec) {
-        if (!(what & (1 << prec)) || !(what & 4)) continue;
+    for (int prec = 0; prec < 3; ++prec) {
+        if (!(what & kUpdBit[prec]) || !(what & AMUSE_UPD_ENCODER)) continue;
         std::vector<uint4> all;
         for (int st = 0; st < kVaeStages; ++st) {
             c->vaee_stage_base[prec][st] = (uint32_t)(all.size() / 64);
@@ -722,8 +721,12 @@ int check_common(amuse_ctx* c, const float* con, int B, int precision) {
     HIP_TRY(hipSetDevice(c->device));
     return 0;
 }
-// the prior's kernels have two arithmetic modes: fp32x sampling is decoded / encoded by the fp32 kernels
-int prior_precision(int precision) { return precision == AMUSE_PREC_F32X ? AMUSE_PREC_F32 : precision; }
+// fp32x jobs decode / encode on the PREC_F16X2 instantiations of the staged kernels (k_vae.hip); AMUSE_F32X_DECODE=fp32 sends
+// them to the fp32 kernels instead (A/B measurements)
+int prior_precision(int precision) {
+    static const bool f32 = [] { const char* e = getenv("AMUSE_F32X_DECODE"); return e && std::string(e) == "fp32"; }();
+    return (precision == AMUSE_PREC_F32X && f32) ? AMUSE_PREC_F32 : precision;
+}
 
 }  // namespace
 
@@ -790,7 +793,8 @@ int build_repack_maps(amuse_ctx* c) {
     std::vector<float> den(AMUSE_DENOISER_PARAMS), pri(AMUSE_PRIOR_PARAMS);
     // element type of an image: 0 = fp32, 1 = bf16, 2 = split-fp16 (launch_repack's `kind`)
     auto kind_of = [&](void** slot) {
-        if (slot == (void**)&c->den_w[PREC_F16X2] || slot == (void**)&c->den_w8x) return 2;
+        if (slot == (void**)&c->den_w[PREC_F16X2] || slot == (void**)&c->den_w8x || slot == (void**)&c->vae_w[PREC_F16X2] ||
+            slot == (void**)&c->vaee_w[PREC_F16X2]) return 2;
         return (slot == (void**)&c->den_w[PREC_BF16] || slot == (void**)&c->den_w8 || slot == (void**)&c->vae_w[PREC_BF16] ||
                 slot == (void**)&c->vae_wf || slot == (void**)&c->vaee_w[PREC_BF16]) ? 1 : 0;
     };
@@ -839,7 +843,8 @@ int build_repack_maps(amuse_ctx* c) {
             if (m < 0 || (size_t)m > limit) return fail(AMUSE_ESTATE, "internal: gather index out of range");
         int cls = 0;   // which AMUSE_UPD_* bits the image needs; 0 = small parameters, always replaced
         if (slot == (void**)&c->den_w[PREC_F32] || slot == (void**)&c->vae_w[PREC_F32]) cls = AMUSE_UPD_F32;
-        else if (slot == (void**)&c->den_w[PREC_F16X2] || slot == (void**)&c->den_w8x) cls = AMUSE_UPD_F32X;
+        else if (slot == (void**)&c->den_w[PREC_F16X2] || slot == (void**)&c->den_w8x || slot == (void**)&c->vae_w[PREC_F16X2]) cls = AMUSE_UPD_F32X;
+        else if (slot == (void**)&c->vaee_w[PREC_F16X2]) cls = AMUSE_UPD_F32X | AMUSE_UPD_ENCODER;
         else if (slot == (void**)&c->den_w[PREC_BF16] || slot == (void**)&c->den_w8 || slot == (void**)&c->vae_w[PREC_BF16] || slot == (void**)&c->vae_wf) cls = AMUSE_UPD_BF16;
         else if (slot == (void**)&c->vaee_w[PREC_F32]) cls = AMUSE_UPD_F32 | AMUSE_UPD_ENCODER;
         else if (slot == (void**)&c->vaee_w[PREC_BF16]) cls = AMUSE_UPD_BF16 | AMUSE_UPD_ENCODER;
@@ -863,8 +868,7 @@ int amuse_update_weights_device(amuse_ctx* c, const float* denoiser_params_dev, 
     for (const auto& r : c->repack) {
         const float* src = r.prior ? prior_params_dev : denoiser_params_dev;
         if (!src || !*r.slot) continue;                 // (an image the context never built, e.g. the 4-wave bf16 stream after an update)
-        const int have = what | ((what & AMUSE_UPD_F32X) && r.prior ? AMUSE_UPD_F32 : 0);   // fp32x jobs use the prior's fp32 streams
-        if ((r.cls & have) != r.cls) continue;          // every bit the image needs must be requested
+        if ((r.cls & what) != r.cls) continue;          // every bit the image needs must be requested
         HIP_TRY(launch_repack(src, r.map, *r.slot, r.n, r.kind, (hipStream_t)stream));
     }
     // the hoisted time-token table belongs to the old time-embedding weights: rebuilt here, stream-ordered, from the schedule's
@@ -882,7 +886,7 @@ void amuse_destroy(amuse_ctx* c) {
         if (p) (void)hipFree(p);
     void* ptrs[] = {c->den_w[0], c->den_w[1], c->den_w[2], c->den_w8, c->den_w8x, c->skip_ws, c->den_pvec, c->den_pe, c->den_freqs, c->te_w1t, c->te_b1, c->te_w2t,
                     c->te_b2, c->cond_wt[0], c->cond_wt[1], c->cond_wt[2], c->cond_b[0], c->cond_b[1], c->cond_b[2],
-                    c->vae_w[0], c->vae_w[1], c->vae_pvec, c->vae_final_bias, c->vae_pe, c->vae_wv_t, c->vae_bv,
+                    c->vae_w[0], c->vae_w[1], c->vae_w[2], c->vaee_w[2], c->vae_pvec, c->vae_final_bias, c->vae_pe, c->vae_wv_t, c->vae_bv,
                     c->vae_wo_t, c->vae_bo, c->vaee_w[0], c->vaee_w[1], c->vaee_pvec, c->vaee_pe, c->vaee_tok,
                     c->vaee_emb_bias, c->d_timesteps, c->d_coef, c->d_time_tok, c->d_ts1, c->d_tt1, c->d_coef1,
                     c->cond_tok, c->lat_tmp, c->fwd_ws, c->vae_ws, c->d_lengths, c->vae_wf, c->vae_skip, c->vae_ca_ws};
@@ -1036,7 +1040,7 @@ int amuse_vae_decode(amuse_ctx* c, const float* z, const int* lengths, int B, in
     if (!z) return fail(AMUSE_EINVAL, "z is NULL");
     if (B < 1) return fail(AMUSE_EINVAL, "B must be >= 1, got %d", B);
     precision = prior_precision(precision);
-    if (precision != AMUSE_PREC_F32 && precision != AMUSE_PREC_BF16) return fail(AMUSE_EINVAL, "bad precision %d", precision);
+    if (precision != AMUSE_PREC_F32 && precision != AMUSE_PREC_BF16 && precision != AMUSE_PREC_F32X) return fail(AMUSE_EINVAL, "bad precision %d", precision);
     if (quat_mode != AMUSE_QUAT_P3D && quat_mode != AMUSE_QUAT_LEGACY) return fail(AMUSE_EINVAL, "bad quat_mode %d", quat_mode);
     HIP_TRY(hipSetDevice(c->device));
     hipStream_t st = (hipStream_t)stream;
@@ -1110,7 +1114,7 @@ int amuse_vae_encode(amuse_ctx* c, const float* feats, const int* lengths, int B
     if (!mu_out && !std_out && !latent_out) return fail(AMUSE_EINVAL, "no output requested");
     if (B < 1) return fail(AMUSE_EINVAL, "B must be >= 1, got %d", B);
     precision = prior_precision(precision);
-    if (precision != AMUSE_PREC_F32 && precision != AMUSE_PREC_BF16) return fail(AMUSE_EINVAL, "bad precision %d", precision);
+    if (precision != AMUSE_PREC_F32 && precision != AMUSE_PREC_BF16 && precision != AMUSE_PREC_F32X) return fail(AMUSE_EINVAL, "bad precision %d", precision);
     HIP_TRY(hipSetDevice(c->device));
     hipStream_t st = (hipStream_t)stream;
     if (int e = stage_lengths(c, lengths, B, st)) return e;

@@ -174,26 +174,31 @@ __device__ __forceinline__ void ring_issue(WRing<R>& rg) {
 // over the output tiles, so consecutive MFMAs never hit the same accumulator.  Small terms first.
 template <int NO, int NP, bool SWAP, int R, int PH, bool REARM = true>
 __device__ __forceinline__ void gemm_ring_s(f32x4 (&acc)[NO], const F16Pair (&xs)[NP], WRing<R>& rg) {
+    // output tiles in groups of OG (at most four: eight would keep 64 registers of weight pieces live beside the ring)
+    constexpr int OG = NO % 4 == 0 ? 4 : (NO % 2 == 0 ? 2 : 1);
 #pragma unroll
     for (int c = 0; c < NP; ++c) {
-        f16x8 wh[NO], wl[NO];
 #pragma unroll
-        for (int o = 0; o < NO; ++o) {
-            const int s0 = (PH + 2 * (c * NO + o)) % R, s1 = (PH + 2 * (c * NO + o) + 1) % R;
-            wh[o] = __builtin_bit_cast(f16x8, rg.s[s0]);
-            wl[o] = __builtin_bit_cast(f16x8, rg.s[s1]);
-            if constexpr (REARM) {
-                rg.s[s0] = ldw(rg.next);
-                rg.s[s1] = ldw(rg.next + 64);
-                rg.next += 128;
+        for (int o0 = 0; o0 < NO; o0 += OG) {
+            f16x8 wh[OG], wl[OG];
+#pragma unroll
+            for (int i = 0; i < OG; ++i) {
+                const int s0 = (PH + 2 * (c * NO + o0 + i)) % R, s1 = (PH + 2 * (c * NO + o0 + i) + 1) % R;
+                wh[i] = __builtin_bit_cast(f16x8, rg.s[s0]);
+                wl[i] = __builtin_bit_cast(f16x8, rg.s[s1]);
+                if constexpr (REARM) {
+                    rg.s[s0] = ldw(rg.next);
+                    rg.s[s1] = ldw(rg.next + 64);
+                    rg.next += 128;
+                }
             }
+#pragma unroll
+            for (int i = 0; i < OG; ++i) acc[o0 + i] = SWAP ? mfma_f16(xs[c].hi, wl[i], acc[o0 + i]) : mfma_f16(wl[i], xs[c].hi, acc[o0 + i]);
+#pragma unroll
+            for (int i = 0; i < OG; ++i) acc[o0 + i] = SWAP ? mfma_f16(xs[c].lo, wh[i], acc[o0 + i]) : mfma_f16(wh[i], xs[c].lo, acc[o0 + i]);
+#pragma unroll
+            for (int i = 0; i < OG; ++i) acc[o0 + i] = SWAP ? mfma_f16(xs[c].hi, wh[i], acc[o0 + i]) : mfma_f16(wh[i], xs[c].hi, acc[o0 + i]);
         }
-#pragma unroll
-        for (int o = 0; o < NO; ++o) acc[o] = SWAP ? mfma_f16(xs[c].hi, wl[o], acc[o]) : mfma_f16(wl[o], xs[c].hi, acc[o]);
-#pragma unroll
-        for (int o = 0; o < NO; ++o) acc[o] = SWAP ? mfma_f16(xs[c].lo, wh[o], acc[o]) : mfma_f16(wh[o], xs[c].lo, acc[o]);
-#pragma unroll
-        for (int o = 0; o < NO; ++o) acc[o] = SWAP ? mfma_f16(xs[c].hi, wh[o], acc[o]) : mfma_f16(wh[o], xs[c].hi, acc[o]);
     }
 }
 template <int NK>

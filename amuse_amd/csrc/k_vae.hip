@@ -281,6 +281,7 @@ __global__ __launch_bounds__(256) void k_vae_attn(VaeAttnArgs a) {
         for (int td = 0; td < 2; ++td) q[td] = qvalid ? ld4(qg + fq * 32 + 16 * td + 4 * g) : splat4(0.f);
         float m_run = -INFINITY, l_run = 0.f;
         f32x4 o[2] = {splat4(0.f), splat4(0.f)};
+        [[maybe_unused]] const F16Pair qs = split_f16(q[0], q[1]);
 #pragma unroll 1
         for (int jp = 0; jp < kKeyRows / 32; ++jp) {
             f32x4 st[2];
@@ -294,6 +295,11 @@ __global__ __launch_bounds__(256) void k_vae_attn(VaeAttnArgs a) {
                     for (int m = 0; m < 4; ++m) st[u] = mfma_f32(k0[m], q[0][m], st[u]);
 #pragma unroll
                     for (int m = 0; m < 4; ++m) st[u] = mfma_f32(k1[m], q[1][m], st[u]);
+                } else if constexpr (PREC == PREC_F16X2) {   // fp32x: split operands, three MFMAs (amuse_dev.hpp)
+                    const F16Pair ks = split_f16(k0, k1);
+                    st[u] = mfma_f16(ks.lo, qs.hi, st[u]);
+                    st[u] = mfma_f16(ks.hi, qs.lo, st[u]);
+                    st[u] = mfma_f16(ks.hi, qs.hi, st[u]);
                 } else {
                     st[u] = mfma_bf16(pack_bf16(k0, k1), pack_bf16(q[0], q[1]), st[u]);
                 }
@@ -336,6 +342,21 @@ __global__ __launch_bounds__(256) void k_vae_attn(VaeAttnArgs a) {
                         o[0] = mfma_f32(vv[0], p[u][m], o[0]);
                         o[1] = mfma_f32(vv[16], p[u][m], o[1]);
                     }
+            } else if constexpr (PREC == PREC_F16X2) {
+                const F16Pair ps = split_f16(p[0], p[1]);
+#pragma unroll
+                for (int td = 0; td < 2; ++td) {
+                    f32x4 lo, hi;
+#pragma unroll
+                    for (int m = 0; m < 4; ++m) {
+                        lo[m] = vr[m * kKS + 16 * td];
+                        hi[m] = vr[(16 + m) * kKS + 16 * td];
+                    }
+                    const F16Pair vs = split_f16(lo, hi);
+                    o[td] = mfma_f16(vs.lo, ps.hi, o[td]);
+                    o[td] = mfma_f16(vs.hi, ps.lo, o[td]);
+                    o[td] = mfma_f16(vs.hi, ps.hi, o[td]);
+                }
             } else {
                 const bf16x8 pb = pack_bf16(p[0], p[1]);
 #pragma unroll
@@ -499,6 +520,8 @@ hipError_t launch_vae_rows(const VaeRowsArgs& a, int precision, bool enc, hipStr
     int dev_;
     if (!once.done(&dev_)) {
         hipError_t e = set_lds(&k_vae_rows<PREC_F32, false>, kRowsLdsBytes);
+        if (e == hipSuccess) e = set_lds(&k_vae_rows<PREC_F16X2, false>, kRowsLdsBytes);
+        if (e == hipSuccess) e = set_lds(&k_vae_rows<PREC_F16X2, true>, kRowsLdsBytes);
         if (e == hipSuccess) e = set_lds(&k_vae_rows<PREC_BF16, false>, kRowsLdsBytes);
         if (e == hipSuccess) e = set_lds(&k_vae_rows<PREC_F32, true>, kRowsLdsBytes);
         if (e == hipSuccess) e = set_lds(&k_vae_rows<PREC_BF16, true>, kRowsLdsBytes);
@@ -509,6 +532,9 @@ hipError_t launch_vae_rows(const VaeRowsArgs& a, int precision, bool enc, hipStr
     if (precision == PREC_F32) {
         if (enc) hipLaunchKernelGGL((k_vae_rows<PREC_F32, true>), grid, block, kRowsLdsBytes, stream, a);
         else hipLaunchKernelGGL((k_vae_rows<PREC_F32, false>), grid, block, kRowsLdsBytes, stream, a);
+    } else if (precision == PREC_F16X2) {
+        if (enc) hipLaunchKernelGGL((k_vae_rows<PREC_F16X2, true>), grid, block, kRowsLdsBytes, stream, a);
+        else hipLaunchKernelGGL((k_vae_rows<PREC_F16X2, false>), grid, block, kRowsLdsBytes, stream, a);
     } else {
         if (enc) hipLaunchKernelGGL((k_vae_rows<PREC_BF16, true>), grid, block, kRowsLdsBytes, stream, a);
         else hipLaunchKernelGGL((k_vae_rows<PREC_BF16, false>), grid, block, kRowsLdsBytes, stream, a);
@@ -521,6 +547,8 @@ hipError_t launch_vae_attn(const VaeAttnArgs& a, int precision, bool enc, hipStr
     int dev_;
     if (!once.done(&dev_)) {
         hipError_t e = set_lds(&k_vae_attn<PREC_F32, false>, kAttnLdsBytes);
+        if (e == hipSuccess) e = set_lds(&k_vae_attn<PREC_F16X2, false>, kAttnLdsBytes);
+        if (e == hipSuccess) e = set_lds(&k_vae_attn<PREC_F16X2, true>, kAttnLdsBytes);
         if (e == hipSuccess) e = set_lds(&k_vae_attn<PREC_F32, true>, kAttnLdsBytes);
         if (e == hipSuccess) e = set_lds(&k_vae_attn_bf16<false>, kAttnBf16LdsBytes);
         if (e == hipSuccess) e = set_lds(&k_vae_attn_bf16<true>, kAttnBf16LdsBytes);
@@ -531,6 +559,9 @@ hipError_t launch_vae_attn(const VaeAttnArgs& a, int precision, bool enc, hipStr
     if (precision == PREC_F32) {
         if (enc) hipLaunchKernelGGL((k_vae_attn<PREC_F32, true>), grid, block, kAttnLdsBytes, stream, a);
         else hipLaunchKernelGGL((k_vae_attn<PREC_F32, false>), grid, block, kAttnLdsBytes, stream, a);
+    } else if (precision == PREC_F16X2) {
+        if (enc) hipLaunchKernelGGL((k_vae_attn<PREC_F16X2, true>), grid, block, kAttnLdsBytes, stream, a);
+        else hipLaunchKernelGGL((k_vae_attn<PREC_F16X2, false>), grid, block, kAttnLdsBytes, stream, a);
     } else {
         if (enc) hipLaunchKernelGGL(k_vae_attn_bf16<true>, grid, block, kAttnBf16LdsBytes, stream, a);
         else hipLaunchKernelGGL(k_vae_attn_bf16<false>, grid, block, kAttnBf16LdsBytes, stream, a);

@@ -53,7 +53,7 @@ enum { AMUSE_OK = 0, AMUSE_EINVAL = -1, AMUSE_EHIP = -2, AMUSE_ENOMEM = -3, AMUS
  * is split into two fp16 pieces, x = hi + lo (22 significand bits), and a product is three v_mfma_f32_16x16x32_f16
  * (Wh.xh + Wh.xl + Wl.xh) accumulated in fp32; softmax, LayerNorm, erf GELU and the scheduler update are the F32 code.
  * Holds the F32 mode's parity bars (eps_hat <= 1e-5 against the reference's modules) at a fraction of its step time.
- * amuse_vae_decode / amuse_vae_encode run their F32 kernels when asked for F32X. */
+ * amuse_vae_decode / amuse_vae_encode run the same split arithmetic in their staged kernels (k_vae.hip PREC_F16X2). */
 enum { AMUSE_PREC_F32 = 0, AMUSE_PREC_BF16 = 1, AMUSE_PREC_F32X = 2 };
 
 /* matrix -> quaternion convention of the axis-angle epilogue (infer_ldm.py:172):
@@ -90,8 +90,8 @@ amuse_ctx* amuse_create(int device, const float* denoiser_params, size_t n_denoi
  * Replaces what the reference gets for free from sharing nn.Module parameters between its training step and the
  * in-loop sampler (scripts/trainer.py:411-415: ldm.diffusion_backward + prior.decode on the weights just stepped).
  * Either array may be NULL (left as is).  `what` limits the host-side packing to what the caller will run:
- * AMUSE_UPD_F32 | AMUSE_UPD_BF16 | AMUSE_UPD_F32X = the weight streams of that precision (F32X: the sampler's split-fp16
- * stream and the prior's F32 streams), AMUSE_UPD_ENCODER = MotionPrior.encode's streams too.  Small parameters (biases, LayerNorm, embeddings) are always replaced, so after a partial update only the
+ * AMUSE_UPD_F32 | AMUSE_UPD_BF16 | AMUSE_UPD_F32X = the weight streams of that precision, AMUSE_UPD_ENCODER =
+ * MotionPrior.encode's streams too.  Small parameters (biases, LayerNorm, embeddings) are always replaced, so after a partial update only the
  * re-packed precision is valid - running the other one mixes old matrices with new vectors.  Synchronises `stream` first; after a denoiser update the
  * schedule must be set again (the time-token table is a function of the time-embedding weights). */
 enum { AMUSE_UPD_F32 = 1, AMUSE_UPD_BF16 = 2, AMUSE_UPD_ENCODER = 4, AMUSE_UPD_F32X = 8, AMUSE_UPD_ALL = 15 };

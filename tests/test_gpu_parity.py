@@ -343,20 +343,21 @@ def test_in_kernel_noise_equals_explicit_counter_noise(env):
         eng.set_clips_per_group(6)
 
 
-def test_vae_decode_fp32_vs_reference_golden(env):
+@pytest.mark.parametrize("prec", PARITY)
+def test_vae_decode_fp32_vs_reference_golden(env, prec):
     orc, eng = env["orc"], env["eng"]
     g = np.load(GOLDEN / "vae_decode.npz")
-    out = eng.vae_decode(g["z"], None, "fp32", return_feats=True)
+    out = eng.vae_decode(g["z"], None, prec, return_feats=True)
     assert out["feats"].shape == (3, 300, 333) and out["poses"].shape == (3, 300, 55, 3)
     assert _err(out["feats"], g["feats"]) < 2e-5
     # ragged: padded keys masked, padded frames zeroed (vae.py:217,262,274)
-    o2 = eng.vae_decode(g["z"][:2], [300, 173], "fp32", return_feats=True)
+    o2 = eng.vae_decode(g["z"][:2], [300, 173], prec, return_feats=True)
     assert _err(o2["feats"], g["feats_ragged"]) < 2e-5
     assert float(o2["feats"][1, 173:].abs().max()) == 0.0
     assert float(o2["poses"][1, 173:].abs().max()) == 0.0 and float(o2["trans"][1, 173:].abs().max()) == 0.0
     # rotation epilogue against the oracle applied to the SAME features
     for mode in ("p3d", "legacy"):
-        o = eng.vae_decode(g["z"], None, "fp32", quat_mode=mode, return_feats=True)
+        o = eng.vae_decode(g["z"], None, prec, quat_mode=mode, return_feats=True)
         feats = o["feats"].cpu()
         poses, trans = orc.feats_to_smplx(feats, mode)             # fp32 oracle on the SAME features
         assert torch.equal(o["trans"].cpu(), feats[..., -3:])
@@ -374,7 +375,7 @@ def test_vae_decode_fp32_vs_reference_golden(env):
         R_ref = orc.rotation_6d_to_matrix(feats[..., :-3].reshape(3, 300, 55, 6).double())
         rot_tol = 5e-5 if mode == "p3d" else 2e-3
         assert float((R_gpu - R_ref).abs().amax(dim=(-1, -2))[pivot > 0.1].max()) < rot_tol   # as a rotation, vs fp64
-    assert float(torch.linalg.vector_norm(eng.vae_decode(g["z"], None, "fp32")["poses"], dim=-1).max()) > 0
+    assert float(torch.linalg.vector_norm(eng.vae_decode(g["z"], None, prec)["poses"], dim=-1).max()) > 0
 
 
 def test_vae_decode_bf16_bounded(env):
@@ -384,40 +385,41 @@ def test_vae_decode_bf16_bounded(env):
     assert _err(out["feats"], g["feats"]) < 6e-2  # |feats| ~ 3
 
 
-def test_vae_encode_fp32_vs_reference_golden(env):
+@pytest.mark.parametrize("prec", PARITY)
+def test_vae_encode_fp32_vs_reference_golden(env, prec):
     """MotionPrior.encode (vae.py:154-214) through amuse_vae_encode: mu / std against the reference's own module."""
     orc, eng, Wp = env["orc"], env["eng"], env["Wp"]
     g = np.load(GOLDEN / "vae_encode.npz")
     feats = torch.from_numpy(g["feats"].astype(np.float32))
-    out = eng.vae_encode(feats, None, "fp32")
+    out = eng.vae_encode(feats, None, prec)
     assert out["mu"].shape == (2, 128) and out["std"].shape == (2, 128)
     assert _err(out["mu"], g["mu"]) < 2e-5
     assert _err(out["std"], g["std"]) < 2e-5 * float(g["std"].max())
     assert torch.equal(out["latent"], out["mu"])                       # no eps supplied -> latent = mu
     # ragged: padded frames masked as attention keys, the two distribution tokens always visible (vae.py:176-181)
-    o2 = eng.vae_encode(feats, [300, 211], "fp32")
+    o2 = eng.vae_encode(feats, [300, 211], prec)
     assert _err(o2["mu"], g["mu_ragged"]) < 2e-5
     assert _err(o2["std"], g["std_ragged"]) < 2e-5 * float(g["std_ragged"].max())
     assert _err(o2["mu"][1], g["mu"][1]) > 1e-3                        # the mask is live
     # masked frames are dead inputs
     f2 = feats.clone()
     f2[1, 211:] = 7.0
-    o3 = eng.vae_encode(f2, [300, 211], "fp32")
+    o3 = eng.vae_encode(f2, [300, 211], prec)
     assert torch.equal(o3["mu"], o2["mu"]) and torch.equal(o3["std"], o2["std"])
     # rsample with an explicit draw: latent = mu + std * eps, exactly
     eps = torch.randn(2, 128, generator=torch.Generator().manual_seed(5))
-    o4 = eng.vae_encode(feats, None, "fp32", eps=eps)
+    o4 = eng.vae_encode(feats, None, prec, eps=eps)
     assert torch.equal(o4["latent"].cpu(), out["mu"].cpu() + out["std"].cpu() * eps)
     # more clips than one chunk row group, every clip independent of its neighbours
     fb = feats[:1].repeat(5, 1, 1)
     fb[3] = feats[1]
-    o5 = eng.vae_encode(fb, None, "fp32")
+    o5 = eng.vae_encode(fb, None, prec)
     assert torch.equal(o5["mu"][0], out["mu"][0]) and torch.equal(o5["mu"][3], out["mu"][1])
     assert torch.equal(o5["mu"][4], out["mu"][0])
     # oracle on fresh inputs (not the golden draw)
     f6 = 0.7 * torch.randn(3, 300, 333, generator=torch.Generator().manual_seed(11))
     mu, std = orc.vae_encode(Wp, f6, [300, 17, 1])
-    o6 = eng.vae_encode(f6, [300, 17, 1], "fp32")
+    o6 = eng.vae_encode(f6, [300, 17, 1], prec)
     assert _err(o6["mu"], mu) < 2e-5 and _err(o6["std"] / std.to(o6["std"].device), torch.ones_like(std)) < 5e-5
 
 

@@ -72,13 +72,13 @@ def test_update_weights_device_equals_the_host_path():
     assert not torch.equal(a.vae_decode(lat, None, "bf16")["poses"], b.vae_decode(lat, None, "bf16")["poses"])   # (prior still w0)
     a.update_weights_device(None, f1[1], what=2)
     assert torch.equal(a.vae_decode(lat, None, "bf16")["poses"], b.vae_decode(lat, None, "bf16")["poses"])
-    # the fp32x mask alone: the sampler's split-fp16 stream and the prior's fp32 streams
+    # the fp32x mask alone: the split-fp16 streams of the sampler and of the prior's decoder
     a.update_weights_device(*f0, what=8)
     a0 = HipEngine(*w0)
     a0.set_schedule(sch.ddim_table())
     l0 = a0.sample(c, em, s, "fp32x", x_init=x)
     assert torch.equal(a.sample(c, em, s, "fp32x", x_init=x), l0)
-    assert torch.equal(a.vae_decode(l0[:8], None, "fp32x")["poses"], a0.vae_decode(l0[:8], None, "fp32")["poses"])
+    assert torch.equal(a.vae_decode(l0[:8], None, "fp32x")["poses"], a0.vae_decode(l0[:8], None, "fp32x")["poses"])
     a0.close()
     with pytest.raises(Exception):
         a.update_weights_device(None, None)
