@@ -143,9 +143,9 @@ def _fused_block_model(orc, W, blk, x, skip, z, length=300):
 
 
 def test_fused_decode_blockwise_taps(env):
-    """Teacher-forced per block on the kernel's OWN block inputs (taps of clip 0's residual stream): >= 7 of 9 blocks within
-    1e-4 of the model above (a rounding flip of one operand element moves a block by O(1e-3)), every block within 2e-2; the
-    tapped instantiation computes bitwise what the production kernel computes."""
+    """Teacher-forced per block on the kernel's OWN block inputs (taps of clip 0's residual stream) against the model above:
+    median error below 1e-6 and >= 90 % of the elements within 1e-4 on EVERY block, every element within 2e-2 (a rounding flip
+    of one operand element moves a row by O(1e-3)); the tapped instantiation computes bitwise what the production kernel does."""
     orc, eng, Wp = env["orc"], env["eng"], env["Wp"]
     g = np.load(GOLDEN / "vae_decode.npz")
     z = torch.from_numpy(g["z"])
@@ -161,14 +161,15 @@ def test_fused_decode_blockwise_taps(env):
         xin = x0 if blk == 0 else taps[blk - 1]
         skip = taps[8 - blk] if blk >= 5 else None
         d = (taps[blk] - _fused_block_model(orc, Wp, blk, xin, skip, z[0])).abs().flatten()
-        stats.append((float(d.median()), float(d.kthvalue(int(d.numel() * 0.99)).values), float(d.max())))
-    print("fused decode, per block (median, p99, max):", stats)
+        stats.append((float(d.median()), float((d < 1e-4).float().mean()), float(d.max())))
+    print("fused decode, per block (median, fraction within 1e-4, max):", stats)
     # A block rounds ~150 k operand elements to bf16 (q, k, v, p, o, hidden): summation-order noise of 1e-7 flips a few of them
-    # per block, and one flipped q / k element moves its row by O(1e-3) - so the max over 38,400 outputs cannot be held to 1e-4
-    # the way the sampler's 5-token blocks are.  What a wrong weight chunk or a mis-indexed tile cannot hide from: the bulk.
+    # per block, and one flipped q / k element moves its whole row by O(1e-3) - so the max over 38,400 outputs cannot be held to
+    # 1e-4 the way the sampler's 5-token blocks are (measured: max 1.4e-3 ... 3.9e-3, 99th percentile 6e-5 ... 9e-4).  What a
+    # wrong weight chunk or a mis-indexed tile cannot hide from is the bulk: measured median 1.6e-7 ... 1.8e-7 on every block.
     assert max(s_[2] for s_ in stats) < 2e-2, stats
-    assert max(s_[0] for s_ in stats) < 1e-5, stats                 # median: every block
-    assert sorted(s_[1] for s_ in stats)[6] < 1e-4, stats           # 99th percentile: at least 7 of 9 blocks
+    assert max(s_[0] for s_ in stats) < 1e-6, stats                 # median: every block
+    assert min(s_[1] for s_ in stats) > 0.9, stats                  # >= 90 % of a block's elements within 1e-4: every block
     # decoder.norm (slot 9) and the final layer on the kernel's own last block
     fin = orc.layer_norm(taps[8], Wp["decoder.norm.weight"], Wp["decoder.norm.bias"])
     assert _err(taps[9], fin) < 1e-5
@@ -179,4 +180,4 @@ def test_fused_decode_blockwise_taps(env):
     tr = outr["taps"].cpu()
     for blk, xin, skip in ((0, x0, None), (5, tr[4], tr[3])):
         d = (tr[blk][:173] - _fused_block_model(orc, Wp, blk, xin, skip, z[0], length=173)[:173]).abs().flatten()
-        assert float(d.median()) < 1e-5 and float(d.max()) < 2e-2, (blk, float(d.median()), float(d.max()))
+        assert float(d.median()) < 1e-6 and float(d.max()) < 2e-2, (blk, float(d.median()), float(d.max()))
