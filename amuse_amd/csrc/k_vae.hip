@@ -13,6 +13,8 @@
 //                 V_h staged once in LDS, flash-style online softmax, S^T = K.Q^T and O^T = V^T.P^T on
 //                 MFMA so that the softmax runs along registers and O lands in row-lane layout.
 // The one-token cross-attention collapses to a per-clip constant (k_vae_ca in k_misc.hip).
+#include <cstdlib>
+
 #include "amuse_dev.hpp"
 #include "amuse_kernels.hpp"
 
@@ -508,6 +510,145 @@ __global__ __launch_bounds__(256) void k_vae_attn_bf16(VaeAttnArgs a) {
     if (wave + 16 < kRowTiles) attn_qtiles_bf16<1, S>(Kb, Vt, qg, og, wave + 16, len, g, r);
 }
 
+// ------------------------------------------------------------------------------------------------
+// fp32x attention (AMUSE_PREC_F32X): the layout of the bf16 kernel above with split-fp16 operands.  K_h and V_h^T are
+// split ONCE per workgroup into hi / lo fp16 fragment images in LDS (x = hi + lo, amuse_dev.hpp split_f16), so the inner
+// loop reads ready MFMA operands - one ds_read_b128 each - and only q (once per tile) and p (once per 32 keys) are split in
+// registers; scores and PV are three v_mfma_f32_16x16x32_f16 each (hi.hi + hi.lo + lo.hi, fp32 accumulate), the softmax
+// runs in fp32 in exp2 units (q arrives scaled by 1 / sqrt(32) from k_vae_rows; log2 e is folded in before the split).
+// q, k, v and the output are fp32 in HBM, as in the fp32 mode.
+constexpr int kAttnXLdsBytes = 2 * (kKeyRows * 64 + kPairs * 2 * 16 * 64);   // hi + lo images of K and V^T: 80 KiB
+
+template <int NQ, int S>
+__device__ __forceinline__ void attn_qtiles_x(const uint4* Kh, const uint4* Kl, const uint4* Vh, const uint4* Vl, const float* qg,
+                                              float* og, int qt0, int len, int g, int r) {
+    constexpr float kLog2e = 1.44269504088896340736f;
+    F16Pair qs[NQ];
+    float m_run[NQ], l_run[NQ];
+    f32x4 o[NQ][2];
+#pragma unroll
+    for (int n = 0; n < NQ; ++n) {
+        const int fq = (qt0 + 4 * n) * 16 + r;
+        const bool qv = fq < S;
+        const f32x4 q0 = qv ? ld4(qg + fq * 32 + 4 * g) * kLog2e : splat4(0.f);
+        const f32x4 q1 = qv ? ld4(qg + fq * 32 + 16 + 4 * g) * kLog2e : splat4(0.f);
+        qs[n] = split_f16(q0, q1);
+        m_run[n] = -INFINITY;
+        l_run[n] = 0.f;
+        o[n][0] = o[n][1] = splat4(0.f);
+    }
+#pragma unroll 1
+    for (int jp = 0; jp < kPairs; ++jp) {
+        f16x8 kh[2], kl[2], vh[2], vl[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            kh[u] = __builtin_bit_cast(f16x8, Kh[(32 * jp + 16 * u + r) * 4 + g]);
+            kl[u] = __builtin_bit_cast(f16x8, Kl[(32 * jp + 16 * u + r) * 4 + g]);
+            vh[u] = __builtin_bit_cast(f16x8, Vh[((jp * 2 + u) * 16 + r) * 4 + g]);
+            vl[u] = __builtin_bit_cast(f16x8, Vl[((jp * 2 + u) * 16 + r) * 4 + g]);
+        }
+        bool ok[2][4];
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int m = 0; m < 4; ++m) ok[u][m] = (32 * jp + 16 * u + 4 * g + m) < len;
+#pragma unroll
+        for (int n = 0; n < NQ; ++n) {
+            f32x4 st[2];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {   // lane (g, i): S[i][32 jp + 16 u + 4 g + m], log2 units
+                st[u] = mfma_f16(kl[u], qs[n].hi, splat4(0.f));
+                st[u] = mfma_f16(kh[u], qs[n].lo, st[u]);
+                st[u] = mfma_f16(kh[u], qs[n].hi, st[u]);
+            }
+            float mx = -INFINITY;
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int m = 0; m < 4; ++m) mx = ok[u][m] ? fmaxf(mx, st[u][m]) : mx;
+            mx = allreduce_g_max(mx);
+            const float m_new = fmaxf(m_run[n], mx);
+            const float alpha = (m_new == -INFINITY) ? 1.0f : __builtin_amdgcn_exp2f(m_run[n] - m_new);
+            f32x4 p[2];
+            float ps = 0.f;
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int m = 0; m < 4; ++m) {
+                    p[u][m] = ok[u][m] ? __builtin_amdgcn_exp2f(st[u][m] - m_new) : 0.f;
+                    ps += p[u][m];
+                }
+            ps = allreduce_g_sum(ps);
+            l_run[n] = l_run[n] * alpha + ps;
+            m_run[n] = m_new;
+            const F16Pair pp = split_f16(p[0], p[1]);
+#pragma unroll
+            for (int td = 0; td < 2; ++td) {   // O^T[d][i] += sum_key V[key][d] P[i][key]
+                o[n][td] = mfma_f16(vl[td], pp.hi, o[n][td] * alpha);
+                o[n][td] = mfma_f16(vh[td], pp.lo, o[n][td]);
+                o[n][td] = mfma_f16(vh[td], pp.hi, o[n][td]);
+            }
+        }
+    }
+#pragma unroll
+    for (int n = 0; n < NQ; ++n) {
+        const int fq = (qt0 + 4 * n) * 16 + r;
+        if (fq < S) {
+            float* dst = og + (size_t)fq * kD + 4 * g;
+            st4(dst, o[n][0] / l_run[n]);
+            st4(dst + 16, o[n][1] / l_run[n]);
+        }
+    }
+}
+
+template <bool ENC>
+__global__ __launch_bounds__(256) void k_vae_attn_x(VaeAttnArgs a) {
+    constexpr int S = ENC ? kFrames + 2 : kFrames;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    uint4* Kh = reinterpret_cast<uint4*>(smem);
+    uint4* Kl = Kh + kKeyRows * 4;
+    uint4* Vh = Kl + kKeyRows * 4;
+    uint4* Vl = Vh + kPairs * 2 * 16 * 4;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int g = lane >> 4, r = lane & 15;
+    const int bh = blockIdx.x, b = bh / kHeads, h = bh - b * kHeads;
+    const int len = a.lengths ? a.lengths[b] + (ENC ? 2 : 0) : S;
+    const float* qg = a.q + (size_t)bh * S * 32;
+    const float* kg = a.k + (size_t)bh * S * 32;
+    const float* vg = a.v + (size_t)bh * S * 32;
+    for (int i = threadIdx.x; i < kKeyRows * 4; i += 256) {  // K fragments: item = (key row, slot group)
+        const int row = i >> 2, gg = i & 3;
+        const bool ok = row < S;
+        const F16Pair ks = split_f16(ok ? ld4(kg + row * 32 + 4 * gg) : splat4(0.f), ok ? ld4(kg + row * 32 + 16 + 4 * gg) : splat4(0.f));
+        Kh[i] = __builtin_bit_cast(uint4, ks.hi);
+        Kl[i] = __builtin_bit_cast(uint4, ks.lo);
+    }
+    for (int i = threadIdx.x; i < kPairs * 2 * 16 * 4; i += 256) {  // V^T fragments: item = ((pair, td), g, d)
+        const int d = i & 15, gg = (i >> 4) & 3, pt = i >> 6;  // pt = jp * 2 + td
+        const int jp = pt >> 1, td = pt & 1;
+        f32x4 lo, hi;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int k0 = 32 * jp + 4 * gg + e, k1 = k0 + 16;
+            lo[e] = k0 < S ? vg[k0 * 32 + 16 * td + d] : 0.f;
+            hi[e] = k1 < S ? vg[k1 * 32 + 16 * td + d] : 0.f;
+        }
+        const F16Pair vs = split_f16(lo, hi);
+        Vh[(pt * 16 + d) * 4 + gg] = __builtin_bit_cast(uint4, vs.hi);
+        Vl[(pt * 16 + d) * 4 + gg] = __builtin_bit_cast(uint4, vs.lo);
+    }
+    __syncthreads();
+    float* og = a.o + (size_t)b * S * kD + 32 * h;
+    if (a.q_tiles == 1) {  // last encoder block: only the distribution rows (tile 0) are consumed downstream
+        if (wave == 0) attn_qtiles_x<1, S>(Kh, Kl, Vh, Vl, qg, og, 0, len, g, r);
+        return;
+    }
+    attn_qtiles_x<2, S>(Kh, Kl, Vh, Vl, qg, og, wave, len, g, r);
+    attn_qtiles_x<2, S>(Kh, Kl, Vh, Vl, qg, og, wave + 8, len, g, r);
+    if (wave + 16 < kRowTiles) attn_qtiles_x<1, S>(Kh, Kl, Vh, Vl, qg, og, wave + 16, len, g, r);
+}
+
 template <typename K>
 hipError_t set_lds(K kern, int bytes) {
     return hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
@@ -549,6 +690,8 @@ hipError_t launch_vae_attn(const VaeAttnArgs& a, int precision, bool enc, hipStr
         hipError_t e = set_lds(&k_vae_attn<PREC_F32, false>, kAttnLdsBytes);
         if (e == hipSuccess) e = set_lds(&k_vae_attn<PREC_F16X2, false>, kAttnLdsBytes);
         if (e == hipSuccess) e = set_lds(&k_vae_attn<PREC_F16X2, true>, kAttnLdsBytes);
+        if (e == hipSuccess) e = set_lds(&k_vae_attn_x<false>, kAttnXLdsBytes);
+        if (e == hipSuccess) e = set_lds(&k_vae_attn_x<true>, kAttnXLdsBytes);
         if (e == hipSuccess) e = set_lds(&k_vae_attn<PREC_F32, true>, kAttnLdsBytes);
         if (e == hipSuccess) e = set_lds(&k_vae_attn_bf16<false>, kAttnBf16LdsBytes);
         if (e == hipSuccess) e = set_lds(&k_vae_attn_bf16<true>, kAttnBf16LdsBytes);
@@ -560,8 +703,15 @@ hipError_t launch_vae_attn(const VaeAttnArgs& a, int precision, bool enc, hipStr
         if (enc) hipLaunchKernelGGL((k_vae_attn<PREC_F32, true>), grid, block, kAttnLdsBytes, stream, a);
         else hipLaunchKernelGGL((k_vae_attn<PREC_F32, false>), grid, block, kAttnLdsBytes, stream, a);
     } else if (precision == PREC_F16X2) {
-        if (enc) hipLaunchKernelGGL((k_vae_attn<PREC_F16X2, true>), grid, block, kAttnLdsBytes, stream, a);
-        else hipLaunchKernelGGL((k_vae_attn<PREC_F16X2, false>), grid, block, kAttnLdsBytes, stream, a);
+        // the fragment-image kernel; AMUSE_F32X_ATTN=generic runs the fp32 kernel's PREC_F16X2 instantiation instead (A/B, tests)
+        static const bool generic = [] { const char* e = getenv("AMUSE_F32X_ATTN"); return e && e[0] == 'g'; }();
+        if (generic) {
+            if (enc) hipLaunchKernelGGL((k_vae_attn<PREC_F16X2, true>), grid, block, kAttnLdsBytes, stream, a);
+            else hipLaunchKernelGGL((k_vae_attn<PREC_F16X2, false>), grid, block, kAttnLdsBytes, stream, a);
+        } else {
+            if (enc) hipLaunchKernelGGL(k_vae_attn_x<true>, grid, block, kAttnXLdsBytes, stream, a);
+            else hipLaunchKernelGGL(k_vae_attn_x<false>, grid, block, kAttnXLdsBytes, stream, a);
+        }
     } else {
         if (enc) hipLaunchKernelGGL(k_vae_attn_bf16<true>, grid, block, kAttnBf16LdsBytes, stream, a);
         else hipLaunchKernelGGL(k_vae_attn_bf16<false>, grid, block, kAttnBf16LdsBytes, stream, a);
