@@ -44,11 +44,12 @@ def pmc_traffic_bytes(clips, T, precision):
     tools/run_sample_once.py at the bench shape); the bench line names the file in roofline.traffic_source.
     FETCH_SIZE / WRITE_SIZE are in KiB; FETCH_SIZE is doubled per MI355X_MICROARCH.md (gfx950 reports half of a wide
     coalesced stream).  (None, None) if the shape differs or no pass is committed."""
-    if (clips, T, precision) != (256, 1000, "bf16"):
+    if (clips, T) != (256, 1000) or precision not in ("bf16", "fp32x"):
         return None, None
     import csv
     tot = {}
-    d = next((x for x in (PMC_DIR, "profiles/r01_pmc") if (REPO / x / "FETCH_SIZE_counter_collection.csv").exists()), None)
+    dirs = (PMC_DIR, "profiles/r01_pmc") if precision == "bf16" else (PMC_DIR.replace("_pmc", "_fp32x_pmc"),)
+    d = next((x for x in dirs if (REPO / x / "FETCH_SIZE_counter_collection.csv").exists()), None)
     if d is None:
         return None, None
     for name in ("FETCH_SIZE", "WRITE_SIZE"):
@@ -332,7 +333,26 @@ def main():
                 return min(ts_)
             eng.set_clips_per_group(g_job)
             ms_x, ms_f = time_job("fp32x", 3), time_job("fp32", 2)
+            # its sampling kernel alone (k_sample8x), HIP events; counters from the committed PMC passes of the same shape
+            ktx = []
+            for _ in range(3):
+                ev0.record()
+                eng.sample(con[lo:hi], emo[lo:hi], sty[lo:hi], "fp32x", seed=2024, clip_index0=lo)
+                ev1.record()
+                ev1.synchronize()
+                ktx.append(ev0.elapsed_time(ev1))
+            kx = min(ktx)
+            tfx = B * args.T * FLOP_PER_CLIP_STEP / (kx * 1e-3) / 1e12
+            trx, trx_src = pmc_traffic_bytes(B, args.T, "fp32x")
             line["parity_mode"] = {"precision": "fp32x", "ms_per_job": round(ms_x, 3), "frames_per_s": round(B * 300 / ms_x * 1e3, 1),
+                                   "roofline": {"kernel": "k_sample8x (split-fp16 operands: 3 MFMAs per product)", "kernel_ms": round(kx, 3),
+                                                "us_per_denoising_step": round(kx / args.T * 1e3, 2),
+                                                "achieved_algorithmic_tflops": round(tfx, 1), "mfma_tflops_issued": round(3 * tfx, 1),
+                                                "frac_of_f16_mfma_peak_issued": round(3 * tfx / MFMA_PEAK_TFLOPS["fp32x"], 4),
+                                                "stream_floor_us_per_step": round(STREAM_MB_PER_STEP["fp32x"] * 1e6 / CU_LOAD_BYTES_PER_CLK / (clk_ghz * 1e9) * 1e6, 2),
+                                                "traffic": trx, "traffic_source": trx_src,
+                                                "traffic_note": "7.6 MB of weights per step exceed the 4 MB L2 of an XCD: every XCD re-fetches the stream each "
+                                                                "step (8 x 7.6 MB x T) + the A waves' skip-stack scratch (2 x 16 MB x T) - Infinity-Cache / HBM side, ~1.1 TB/s, not the bound"},
                                    "us_per_denoising_step_incl_decode": round(ms_x / args.T * 1e3, 2),
                                    "eps_err": eps_err["fp32x"], "eps_bar": 1e-5,
                                    "fp32_mode": {"ms_per_job": round(ms_f, 3), "frames_per_s": round(B * 300 / ms_f * 1e3, 1), "eps_err": eps_err["fp32"]},
