@@ -186,8 +186,15 @@ __device__ __forceinline__ bf16x8 attend(const uint4* Kb, const uint4* Vt, bf16x
     // Scores leave the MFMAs RELATIVE to the row's running maximum (C operand = -m_run; chunk 0 starts from 0 and takes its own
     // maximum - the sequence has at least one key), so in the common chunk - the maximum did not move for any row of the wave -
     // p = exp2(result): no subtraction, no rescale (k_audio.hip's attention has the same scheme).
-    float m_run = 0.f, l_run = 0.f;
+    float m_run = 0.f;
     f32x4 o[2] = {splat4(0.f), splat4(0.f)};
+    // The row sums of the softmax ride the matrix pipe: a constant "V^T" fragment whose row d = 0 is all ones makes
+    // O^T[0][i] = sum_key P[i][key] - two MFMAs per chunk instead of sixteen v_add_f32 and a butterfly (the attention is
+    // VALU-bound: 16 quarter-rate v_exp_f32 per lane and chunk are half of it, the rest was max / sum / pack).  What is
+    // summed is the bf16 P the PV product uses.  Lane (g = 0, i) ends up with query i's sum in os[0]; rows d = 4, 8, 12 of the
+    // fragment are zero, so os[0] of the other three lanes of the row is 0 and one butterfly at the end broadcasts it.
+    const bf16x8 ones = __builtin_bit_cast(bf16x8, r == 0 ? uint4{0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u} : uint4{0u, 0u, 0u, 0u});
+    f32x4 os = splat4(0.f);
 #pragma unroll
     for (int ch = 0; ch < kPairs / 2; ++ch) {
         uint4 kf[4];
@@ -214,23 +221,25 @@ __device__ __forceinline__ bf16x8 attend(const uint4* Kb, const uint4* Vt, bf16x
 #pragma unroll
                 for (int m = 0; m < 4; ++m) st[i][m] = (16 * i + m < lim) ? st[i][m] : -INFINITY;
         }
+        // this lane's 16 scores of the chunk; the row's maximum (four lanes) is only formed when it matters: a chunk moves the
+        // running maximum of SOME row of the wave iff some lane holds a positive score (scores are relative to m_run)
         float mx = max3(max3(st[0][0], st[0][1], st[0][2]), max3(st[0][3], st[1][0], st[1][1]), max3(st[1][2], st[1][3], st[2][0]));
         mx = max3(mx, max3(st[2][1], st[2][2], st[2][3]), max3(st[3][0], st[3][1], st[3][2]));
-        mx = allreduce_g_max(fmaxf(mx, st[3][3]));   // the same in the four lanes of a row; -inf for a fully masked chunk (ch > 0 only)
+        mx = fmaxf(mx, st[3][3]);
         if (ch == 0 || __builtin_amdgcn_ballot_w64(mx > 0.f) != 0) {   // (wave-uniform)
+            mx = allreduce_g_max(mx);   // the same in the four lanes of a row; -inf for a fully masked chunk (ch > 0 only)
             const float d = ch == 0 ? mx : fmaxf(mx, 0.f);
 #pragma unroll
             for (int i = 0; i < 4; ++i) st[i] -= splat4(d);
             if (ch > 0) {
                 const float alpha = __builtin_amdgcn_exp2f(-d);
-                l_run *= alpha;
+                os *= alpha;
                 o[0] *= alpha;
                 o[1] *= alpha;
             }
             m_run += d;
         }
         f32x4 p[4];
-        float ps = 0.f;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
 #pragma unroll
@@ -238,17 +247,16 @@ __device__ __forceinline__ bf16x8 attend(const uint4* Kb, const uint4* Vt, bf16x
                 if constexpr ((AMUSE_FABL & 8) != 0) p[i][m] = st[i][m];
                 else p[i][m] = __builtin_amdgcn_exp2f(st[i][m]);
             }
-            ps += (p[i][0] + p[i][1]) + (p[i][2] + p[i][3]);
         }
-        l_run += ps;
 #pragma unroll
         for (int pr = 0; pr < 2; ++pr) {   // O^T[d][i] += sum_key V[key][d] P[i][key], 32 keys per MFMA
             const bf16x8 pb = pack_bf16(p[2 * pr], p[2 * pr + 1]);
             o[0] = mfma_bf16(__builtin_bit_cast(bf16x8, vf[2 * pr]), pb, o[0]);
             o[1] = mfma_bf16(__builtin_bit_cast(bf16x8, vf[2 * pr + 1]), pb, o[1]);
+            os = mfma_bf16(ones, pb, os);
         }
     }
-    const float inv = __builtin_amdgcn_rcpf(allreduce_g_sum(l_run));
+    const float inv = __builtin_amdgcn_rcpf(allreduce_g_sum(os[0]));
     return pack_bf16(o[0] * inv, o[1] * inv);
 }
 

@@ -115,9 +115,9 @@ def _fused_attention_model(q, k, v, length):
             l = l * alpha
             o = o * alpha[..., None]
         m = m + d
-        p = torch.exp2(st)
+        p = _r(torch.exp2(st))                      # the row sums ride the matrix pipe: they add up the bf16 P of the PV product
         l = l + p.sum(-1)
-        o = o + _r(p) @ v[:, k0:k1]
+        o = o + p @ v[:, k0:k1]
     return _r(o * (1.0 / l)[..., None])
 
 
