@@ -173,6 +173,12 @@ def test_cli_infer_and_edit_from_a_reference_tree(tmp_path):
     z = np.load(w[0], allow_pickle=True)
     assert z["poses"].shape == (300, 55, 3) and z["poses"].dtype == np.float32 and str(z["gender"]) == "male"
     assert not np.array_equal(z["poses"], np.load(w[1])["poses"])
+    # --precision fp32x: the same job in the fast parity mode - the same clips and noise, SMPL-X poses within the two modes' conversion
+    # noise of each other (the audio embeddings are bf16-computed and identical in both runs)
+    wx = cli.main(["--fn", "infer_gesture", "--root", str(root), "--random-init", "--precision", "fp32x"])
+    zx = np.load(wx[0], allow_pickle=True)
+    dj = np.linalg.norm(zx["poses"] - z["poses"], axis=-1)
+    assert float(np.median(dj)) < 3e-5 and float((dj < 1e-4).mean()) > 0.95, (float(np.median(dj)), float(dj.max()))
     w2 = cli.main(["--fn", "edit_gesture", "--root", str(root), "--random-init"])
     assert [p.parts[-3] for p in w2] == ["rst_0", "rst_1"] and all(p.name.startswith("miranda_seq_0_") for p in w2)
     assert str(np.load(w2[0], allow_pickle=True)["gender"]) == "female"

@@ -138,6 +138,17 @@ def test_config5_edit_gesture_emotion_control_batch64(env):
         job = jobs[j]
         ref = orc.sample_latents(Wd, orc.DDIM(), job["z_con"].cpu(), job["z_emo"].cpu(), job["z_sty"].cpu(), x0[j:j + 1])
         assert _err(lat[j:j + 1], ref) < 1e-4, j
+    # the same 64 jobs in the fast parity mode (fp32x): same clip indices, same bar against the oracle, and the SMPL-X
+    # features of the whole task within the fp32 run's conversion noise
+    m.precision, m._clip_counter = "fp32x", c0
+    resx = run_jobs(m, jobs, return_latents=True)
+    latx = torch.cat([r["latents"] for r in resx]).cpu()
+    for j in range(0, 64, 9):
+        job = jobs[j]
+        ref = orc.sample_latents(Wd, orc.DDIM(), job["z_con"].cpu(), job["z_emo"].cpu(), job["z_sty"].cpu(), x0[j:j + 1])
+        assert _err(latx[j:j + 1], ref) < 1e-4, j
+    assert _err(latx, lat) < 1e-4
+    m.precision = "fp32"
     # swapping changes the motion; the un-swapped job keeps the take's own emotion
     assert jobs[0]["z_emo_key"] == "ld_z_emo" and torch.equal(jobs[0]["z_emo"], emo[8:9])
     assert not torch.equal(res[0]["feats"], res[1]["feats"])
