@@ -1,4 +1,4 @@
-"""Race hunt: the 8-wave bf16 sampling kernel must reproduce itself bitwise, launch after launch, for every tiling
+"""Race hunt: the 8-wave sampling kernels (bf16 k_sample8, fp32x k_sample8x) must reproduce themselves bitwise, launch after launch, for every tiling
 (a data race between its alternating wave groups would show up as a flaky mismatch); so must the fused decode kernel and the
 audio front-end (DMA rings, hand-counted waits)."""
 import sys
@@ -16,13 +16,14 @@ for T, tab in ((100, sch.ddpm_table(100)), (50, sch.ddim_table())):
     for B, G in ((1, 0), (7, 1), (7, 2), (7, 3), (256, 0), (512, 0), (768, 0), (1000, 3)):
         c, e, s = (torch.randn(B, 256, generator=gen).cuda() for _ in range(3))
         eng.set_clips_per_group(G)
-        ref = eng.sample(c, e, s, "bf16", seed=5).clone()
-        n = 0
-        for _ in range(24):
-            out = eng.sample(c, e, s, "bf16", seed=5)
-            n += int(not torch.equal(out, ref))
-        bad += n
-        print(f"T={T} B={B} G={G}: {n} mismatching launches of 24; finite={bool(torch.isfinite(ref).all())}", flush=True)
+        for prec, reps in (("bf16", 24), ("fp32x", 12)):
+            ref = eng.sample(c, e, s, prec, seed=5).clone()
+            n = 0
+            for _ in range(reps):
+                out = eng.sample(c, e, s, prec, seed=5)
+                n += int(not torch.equal(out, ref))
+            bad += n
+            print(f"T={T} B={B} G={G} {prec}: {n} mismatching launches of {reps}; finite={bool(torch.isfinite(ref).all())}", flush=True)
 eng.set_clips_per_group(0)
 # the fused decode kernel and the audio front-end (LDS-DMA rings with hand-counted s_waitcnt: a protocol slip would show up here)
 z = torch.randn(300, 128, generator=gen).cuda()
@@ -32,6 +33,11 @@ n = sum(int(not torch.equal(eng.vae_decode(z, None, "bf16")["poses"], ref)) for 
 bad += n
 print(f"fused decode, 300 clips: {n} mismatching launches of 16; finite={bool(torch.isfinite(ref).all())}", flush=True)
 eng.set_decode_path("auto")
+# the fp32x decode / encode (staged kernels, split-fp16 fragment images)
+ref = eng.vae_decode(z, [300] * 299 + [123], "fp32x")["poses"].clone()
+n = sum(int(not torch.equal(eng.vae_decode(z, [300] * 299 + [123], "fp32x")["poses"], ref)) for _ in range(6))
+bad += n
+print(f"fp32x decode, 300 clips: {n} mismatching launches of 6; finite={bool(torch.isfinite(ref).all())}", flush=True)
 from amuse_amd import audio_weights as aw
 from amuse_amd.audio import AudioEngine
 aeng = AudioEngine(*(aw.make_ast_weights(0, k) for k in aw.ENCODERS))
