@@ -300,7 +300,6 @@ struct amuse_ctx {
     uint32_t den_w8_units[2] = {0, 0}; // per-step units of a group-A / group-B wave
     uint4* den_w8x = nullptr;          // split-fp16 streams of the 8-wave fp32x kernel (k_sampler8x.hip)
     uint32_t den_w8x_units[2] = {0, 0};
-    uint4* skip_ws = nullptr; size_t skip_ws_tiles = 0;   // k_sample8x: the A waves' copies of the U-Net skip stack
     float* den_pvec = nullptr;
     float* den_pe = nullptr;           // [500][128]
     float* den_freqs = nullptr;        // [128]
@@ -658,16 +657,7 @@ void set_stream(const amuse_ctx* c, SampleArgs& a, int precision) {
 hipError_t dispatch_sample(amuse_ctx* c, SampleArgs& a, int precision, hipStream_t st) {
     if (use_sample8(precision)) {  // with prof_out: stamps come back as [8 waves][96] in the same 768-entry buffer
         if (precision == PREC_F16X2) {
-            const size_t tiles = (size_t)(a.B + a.G - 1) / a.G;
-            if (c->skip_ws_tiles < tiles) {   // the A waves' skip-stack scratch: 128 KiB per tile
-                if (c->skip_ws) { hipError_t e = hipFree(c->skip_ws); if (e != hipSuccess) return e; }
-                c->skip_ws = nullptr; c->skip_ws_tiles = 0;
-                hipError_t e = hipMalloc((void**)&c->skip_ws, tiles * kSample8xSkipBytesPerTile);
-                if (e != hipSuccess) return e;
-                c->skip_ws_tiles = tiles;
-            }
             a.wstream = c->den_w8x; a.wave_units_a = c->den_w8x_units[0]; a.wave_units_b = c->den_w8x_units[1];
-            a.skip_ws = c->skip_ws;
             return launch_sample8x(a, st);
         }
         a.wstream = c->den_w8;
@@ -884,7 +874,7 @@ void amuse_destroy(amuse_ctx* c) {
     (void)hipSetDevice(c->device);
     for (void* p : c->owned)
         if (p) (void)hipFree(p);
-    void* ptrs[] = {c->den_w[0], c->den_w[1], c->den_w[2], c->den_w8, c->den_w8x, c->skip_ws, c->den_pvec, c->den_pe, c->den_freqs, c->te_w1t, c->te_b1, c->te_w2t,
+    void* ptrs[] = {c->den_w[0], c->den_w[1], c->den_w[2], c->den_w8, c->den_w8x, c->den_pvec, c->den_pe, c->den_freqs, c->te_w1t, c->te_b1, c->te_w2t,
                     c->te_b2, c->cond_wt[0], c->cond_wt[1], c->cond_wt[2], c->cond_b[0], c->cond_b[1], c->cond_b[2],
                     c->vae_w[0], c->vae_w[1], c->vae_w[2], c->vaee_w[2], c->vae_pvec, c->vae_final_bias, c->vae_pe, c->vae_wv_t, c->vae_bv,
                     c->vae_wo_t, c->vae_bo, c->vaee_w[0], c->vaee_w[1], c->vaee_pvec, c->vaee_pe, c->vaee_tok,

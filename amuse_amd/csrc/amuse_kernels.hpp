@@ -45,7 +45,6 @@ struct SampleArgs {
     int no_update;            // 1: teacher-forced (no scheduler update)
     unsigned long long* prof_out;  // [4 waves][kProfStamps] s_memtime stamps of step prof_step, or null
     int prof_step;
-    uint4* skip_ws;           // k_sample8x: [tiles][4 A waves][4 levels][8 units][64] x 16 B - each A wave's copy of the U-Net skip stack
 };
 constexpr int kProfStamps = 192;
 hipError_t launch_sample(const SampleArgs& a, int precision, hipStream_t stream);
@@ -53,7 +52,6 @@ hipError_t launch_sample(const SampleArgs& a, int precision, hipStream_t stream)
 hipError_t launch_sample8(const SampleArgs& a, hipStream_t stream);
 // fp32x 8-wave kernel (k_sampler8x.hip); streams laid out like k_sample8's, in split-fp16 units
 hipError_t launch_sample8x(const SampleArgs& a, hipStream_t stream);
-constexpr size_t kSample8xSkipBytesPerTile = 4 * 4 * 8 * 64 * 16;   // 131,072 B
 constexpr int kRing8 = 32;
 constexpr int kRing = 32;                 // weight-stream ring depth (1 KiB units in flight per wave)
 // fp32: the skip linear (32 units per wave) is a whole ring revolution.  bf16 (16 units) needs no padding either:
@@ -64,7 +62,9 @@ constexpr int kSkipBytes = 32 * 1024;     // U-Net skip stack [4][8][64] f32x4
 constexpr int kSampleCombBytes = 4 * 8 * 64 * 16 + 4 * 16 * 8 + 8 * 64 * 16;  // = kCombBytes (amuse_dev.hpp), 41,472 B
 constexpr int kSample8LdsBytes = 8 * 8 * 64 * 16 + 8 * 16 * 8 + 4 * 4 * 64 * 16 + (9 * kEncPv + 4 * 128 + 2 * 128) * 4 +
                                  2 * 8 * 64 * 16 + 2 * 128 * 4;  // 163,328 B (layout in k_sampler8.hip)
-constexpr int kSample8xLdsBytes = kSample8LdsBytes - 4 * 4 * 64 * 16;   // 146,944 B: no skip stack in LDS
+// k_sample8x: combine matrix | statistics | 2 parameter slots of 7 KiB + tail | skip stack (split operands) | token rows | latent | time token
+constexpr int kSample8xLdsBytes = 8 * 8 * 64 * 16 + 8 * 16 * 8 + (2 * 7 * 256 + 4 * 128 + 2 * 128) * 4 + 4 * 8 * 64 * 16 +
+                                  2 * 8 * 64 * 16 + 2 * 128 * 4;   // 134,144 B
 constexpr int kSampleLdsBytes = kSampleCombBytes + kSkipBytes + (9 * kEncPv + 4 * 128 + 2 * 128) * 4;  // 137,216 B
 
 // ---------------------------------------------------------------- one-off prologue kernels (k_misc.hip)

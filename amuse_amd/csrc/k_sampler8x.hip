@@ -22,13 +22,12 @@
 //   GELUs instead, leaving the path to the reducers first: ffn_half).
 //   U-Net skip linears, residual stream exchange, final LayerNorm + scheduler update: as k_sampler8.hip, with the residual
 //   stream travelling between waves as split operands (8 x 1 KiB: hi on the diagonal slots (c, c), lo on (4 + c, 4 + c)).
-//   The skip stack does not fit the LDS as split operands (32 KiB): every A wave keeps its OWN copy in global memory
-//   (SampleArgs::skip_ws, 32 KiB per wave, L2-resident), written in the waiting time of the out_proj combine of the block
-//   that follows the push and read back by the same lanes in the linear2 combine in front of the pop - no cross-wave
-//   traffic through memory, no synchronisation.
+//   The skip stack as split operands (32 KiB) and all nine blocks' small parameters (61.5 KiB) do not fit the LDS together:
+//   the parameters are streamed instead - the current and the next block's in two 7 KiB slots, the next one fetched by LDS-DMA
+//   from the A waves' waiting time in the out_proj combine (combine_publish_c1) - and the skip stack stays in LDS.
 //
-// LDS (146,944 B): combine matrix A8 [8 rows][8 tiles][64] f32x4 | row statistics | small parameters | static token rows |
-// latent | double-buffered time token.
+// LDS (134,144 B): combine matrix A8 [8 rows][8 tiles][64] f32x4 | row statistics | small parameters (2 slots + tail) | skip
+// stack | static token rows | latent | double-buffered time token.
 #include "amuse_dev.hpp"
 #include "amuse_kernels.hpp"
 
@@ -39,9 +38,14 @@ namespace {
 constexpr int kR8 = kRing8;
 constexpr int kA8Bytes = 8 * kTiles * 64 * 16;                 // 65,536
 constexpr int kStat8Off = kA8Bytes;                            // [4 reducers][16 rows] float2 (1 KiB reserved)
+// small parameters: the CURRENT and the NEXT block's (two slots of 7 KiB, filled by LDS-DMA a block ahead) + skip-linear biases +
+// final LayerNorm.  (All nine blocks resident cost 61.5 KiB - the room the skip stack needs as split operands.)
+constexpr int kPvSlotFloats = 7 * 256;                         // kEncPv = 1664 floats rounded up to whole 1 KiB DMA pieces
+static_assert(kPvSlotFloats >= kEncPv && kPvSlotFloats <= PV_BLOCK, "a slot is filled by whole pieces read from the block's own region");
 constexpr int kPv8Off = kStat8Off + 8 * 16 * 8;
-constexpr int kPv8Floats = kLayers * kEncPv + 4 * kD + 2 * kD;
-constexpr int kTokRows8Off = kPv8Off + kPv8Floats * 4;         // [8 tiles][64] f32x4
+constexpr int kPvTail8Off = kPv8Off + 2 * kPvSlotFloats * 4;   // [4][128] skip-linear biases | final LayerNorm weight, bias
+constexpr int kSkip8Off = kPvTail8Off + (4 * kD + 2 * kD) * 4; // [4 levels][4 pairs][hi, lo][64] uint4: the U-Net skip stack, split operands
+constexpr int kTokRows8Off = kSkip8Off + 4 * 8 * 64 * 16;      // [8 tiles][64] f32x4
 constexpr int kLat8Off = kTokRows8Off + kTiles * 64 * 16;      // [8 tiles][64] f32x4: the latent (rows tok == 0)
 constexpr int kTT8Off = kLat8Off + kTiles * 64 * 16;           // [2][128] float
 static_assert(kTT8Off + 2 * kD * 4 == kSample8xLdsBytes, "LDS layout");
@@ -224,33 +228,47 @@ __device__ __forceinline__ f32x4* u_slot(char* lds, int t, int lane) { return a8
 __device__ __forceinline__ uint4* sk_hi_slot(char* lds, int c, int lane) { return reinterpret_cast<uint4*>(a8_slot(lds, 7, c, lane)); }
 __device__ __forceinline__ uint4* sk_lo_slot(char* lds, int c, int lane) { return reinterpret_cast<uint4*>(a8_slot(lds, 5, c, lane)); }
 
-// 16-byte store to this lane's private scratch, read back by the same lane a block or more later.  Inline asm so that hipcc
-// does not know a store is pending: with a visible store it drains the WHOLE vector-memory queue (s_waitcnt vmcnt(0), ring
-// loads included) in front of the next workgroup barrier - the release half of __syncthreads - and the A waves would arrive
-// late at the combine's barriers.  Nothing is released here: no other wave ever reads these addresses.
-__device__ __forceinline__ void store_own(uint4* p, uint4 v) {
-    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-    const u32x4 d = __builtin_bit_cast(u32x4, v);
-    asm volatile("global_store_dwordx4 %0, %1, off" ::"v"(p), "v"(d) : "memory");
+// LDS-DMA: 64 lanes x 16 B from per-lane global addresses to LDS [dst, dst + 1 KiB), lane-linear (k_vae_fused.hip glds16).  Inline
+// asm: hipcc does not count it in its s_waitcnt bookkeeping - its own waits can only become longer, never too short (vmcnt
+// retires in order) - and does not drain it at barriers.  Completion before the data is read: see combine_publish_c1.
+__device__ __forceinline__ void glds16(const uint4* gsrc, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(gsrc), "s"(lds_dst)
+                 : "memory");
+}
+__device__ __forceinline__ unsigned lds_addr(const void* p) {
+    return (unsigned)(size_t)(__attribute__((address_space(3))) const void*)p;
 }
 
 // The A waves' side of the out_proj combine: publish the partial, then the barriers and the gather - with the issue of
-// this wave's first 32 FFN units (linear1 of both quarters) in between, into the whole (empty) ring.  In the block that
-// follows a push (push = true) the wave first stores the block's INPUT operands - the U-Net skip level - to its own
-// scratch in global memory.
+// this wave's first 32 FFN units (linear1 of both quarters) in between, into the whole (empty) ring.  Two more jobs ride here,
+// where these waves only wait:
+//  * in the block that follows a push (push = true) wave h stores pair h of the block's INPUT operands - the U-Net skip level -
+//    into the LDS skip stack (every wave holds all four pairs; the pop, four or more blocks later, reads all eight units);
+//  * the NEXT block's small parameters travel global -> LDS by DMA into the slot the previous block used (pieces 2h, 2h + 1 of 7).
+//    They are older than every ring load this wave issues from here on, and the wave consumes those loads in its FFN half
+//    before it reaches the linear2 combine - so the pieces have landed before that combine's barriers, which is when any wave
+//    first reads the slot (vmcnt retires in order).
 template <int N1, int N2>
 __device__ __forceinline__ void combine_publish_c1(const f32x4 (&part)[kTiles], F16Pair (&xs)[4], char* lds, int h, int lane,
-                                                   Ring& rg, bool push, uint4* skip_dst) {
+                                                   Ring& rg, bool push, uint4* skip_dst, const float* pv_next_src, unsigned pv_next_dst) {
 #pragma unroll
     for (int t = 0; t < kTiles; ++t) *a8_slot(lds, h + (h >= t ? 1 : 0), t, lane) = part[t];  // part_row(h, t), h < 4
-    if (push) {
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            store_own(skip_dst + (2 * c) * 64, __builtin_bit_cast(uint4, xs[c].hi));
-            store_own(skip_dst + (2 * c + 1) * 64, __builtin_bit_cast(uint4, xs[c].lo));
-        }
+    if (push) {   // (a compile-time index per case: xs[h] with a runtime h would put the whole array in scratch)
+        if (h == 0) { skip_dst[0 * 64] = __builtin_bit_cast(uint4, xs[0].hi); skip_dst[1 * 64] = __builtin_bit_cast(uint4, xs[0].lo); }
+        else if (h == 1) { skip_dst[2 * 64] = __builtin_bit_cast(uint4, xs[1].hi); skip_dst[3 * 64] = __builtin_bit_cast(uint4, xs[1].lo); }
+        else if (h == 2) { skip_dst[4 * 64] = __builtin_bit_cast(uint4, xs[2].hi); skip_dst[5 * 64] = __builtin_bit_cast(uint4, xs[2].lo); }
+        else { skip_dst[6 * 64] = __builtin_bit_cast(uint4, xs[3].hi); skip_dst[7 * 64] = __builtin_bit_cast(uint4, xs[3].lo); }
     }
     __syncthreads();
+    {
+        const uint4* src = reinterpret_cast<const uint4*>(pv_next_src) + (2 * h) * 64 + lane;
+        const unsigned dst = __builtin_amdgcn_readfirstlane(pv_next_dst + (2 * h) * 1024);
+        glds16(src, dst);
+        if (h < 3) glds16(src + 64, dst + 1024);
+    }
     ring_issue<N1, kR8, 0>(rg);
     __syncthreads();   // (the reducers' row-statistics exchange)
     ring_issue<N2, kR8, N1>(rg);
@@ -264,7 +282,7 @@ __device__ __forceinline__ void combine_publish_c1(const f32x4 (&part)[kTiles], 
 // then q, k for k-pairs 0,1 into slots 16..31.  In front of an ordinary block the lead is v.  In front of an OUTPUT
 // block (cross_attention.py:58-61: x = Linear(cat(x, skips.pop()))) it is this wave's units of the skip linear's skip-input
 // half: in its waiting time the wave computes u = W[:, 128:] . skip for feature tiles 2h, 2h+1 - the half of the skip linear
-// that does not depend on the current block's result - from its own copy of the popped level, and hands it to B wave h through
+// that does not depend on the current block's result - from the popped level of the LDS skip stack, and hands it to B wave h through
 // u_slot (after the second barrier: the reducers are done with the partials); v then follows during the skip linear.
 // One body for both cases, the extra work behind a branch that touches no ring slot it does not own (k_sampler8.hip).
 template <int N1>
@@ -272,7 +290,7 @@ __device__ __forceinline__ void combine_publish_c2(const f32x4 (&part)[kTiles], 
                                                    Ring& rg, bool skip_u, const uint4* skip_src) {
 #pragma unroll
     for (int t = 0; t < kTiles; ++t) *a8_slot(lds, h + (h >= t ? 1 : 0), t, lane) = part[t];
-    // the popped level first (it is older than anything the ring will ask for), then the lead units
+    // the popped level (all eight split-operand units: the u GEMM runs over the full K), then the lead units
     F16Pair sk[4];
     if (skip_u) {
 #pragma unroll
@@ -405,7 +423,8 @@ __device__ __forceinline__ void ffn_half(f32x4 (&part)[kTiles], const F16Pair (&
 template <bool ROLEA, bool PROF>
 __device__ __forceinline__ void encoder_block8x(F16Pair (&xs)[4], f32x4 (&xo)[2], Ring& rg, const float* pv,
                                                 const bool (&kvalid)[4], char* lds, int h, int lane, bool push, uint4* skip_dst,
-                                                bool next_has_skip, const uint4* skip_src, Prof8& pf) {
+                                                bool next_has_skip, const uint4* skip_src, const float* pv_next_src, unsigned pv_next_dst,
+                                                Prof8& pf) {
     const int g = lane >> 4, r = lane & 15;
     f32x4 part[kTiles];
     if constexpr (ROLEA) {
@@ -442,7 +461,7 @@ __device__ __forceinline__ void encoder_block8x(F16Pair (&xs)[4], f32x4 (&xo)[2]
         }
         stamp8<PROF>(pf);  // 1: in_proj + attention + out_proj partial
         // ---- out_proj combine (B reduces): meanwhile fetch linear1 of this wave's FFN half (and store a pushed skip level)
-        combine_publish_c1<AMUSE_X_C1_N1, AMUSE_X_C1_N2>(part, xs, lds, h, lane, rg, push, skip_dst);
+        combine_publish_c1<AMUSE_X_C1_N1, AMUSE_X_C1_N2>(part, xs, lds, h, lane, rg, push, skip_dst, pv_next_src, pv_next_dst);
         stamp8<PROF>(pf);  // 2: combine 1
 #pragma unroll
         for (int t = 0; t < kTiles; ++t) part[t] = splat4(0.f);
@@ -502,7 +521,7 @@ __device__ __forceinline__ void role_loop8x(const SampleArgs& a, char* smem, int
     f32x4* latl = reinterpret_cast<f32x4*>(smem + kLat8Off);
     float* ttl = reinterpret_cast<float*>(smem + kTT8Off);
     float2* stats = reinterpret_cast<float2*>(smem + kStat8Off);
-    const float* pv_skip = pvl + kLayers * kEncPv;
+    const float* pv_skip = reinterpret_cast<const float*>(smem + kPvTail8Off);
     const float* pv_final = pv_skip + 4 * kD;
     const int lane = L0.lane, g = L0.g, r = L0.r, h = w8 & 3;
     const int S = a.S, R = S * a.G;
@@ -518,8 +537,9 @@ __device__ __forceinline__ void role_loop8x(const SampleArgs& a, char* smem, int
     const uint32_t wbase_units = ROLEA ? (uint32_t)w8 * (a.wave_units_a + kR8)
                                        : 4u * (a.wave_units_a + kR8) + (uint32_t)(w8 - 4) * a.wave_units_b;
     const uint4* wbase = a.wstream + (size_t)wbase_units * 64 + lane;
-    // this A wave's copy of the U-Net skip stack: [tile][4 waves][4 levels][8 units][64 lanes]
-    uint4* skipg = ROLEA ? a.skip_ws + (((size_t)blockIdx.x * 4 + h) * 4 * 8) * 64 + lane : nullptr;
+    uint4* skipl = reinterpret_cast<uint4*>(smem + kSkip8Off) + lane;   // [level][8 units][64 lanes]
+    const unsigned pv_lds0 = lds_addr(smem + kPv8Off);
+    int gblk = 0;   // blocks since the launch: block gblk's parameters sit in slot gblk & 1
     // A waves enter every block with their leading 32 units in the ring (the stream's tail repeats its head for the wrap
     // at a step boundary); B waves enter with an empty ring
     Ring rg;
@@ -590,9 +610,11 @@ __device__ __forceinline__ void role_loop8x(const SampleArgs& a, char* smem, int
             stamp8<PROF>(pf);  // 0: block start (after the skip linear, if any)
             // U-Net wiring: the inputs of blocks 1..4 are the outputs of input blocks 0..3 = skip levels 0..3; output block
             // blk (5..8) pops level 8 - blk, fetched during the linear2 combine of block blk - 1
-            encoder_block8x<ROLEA, PROF>(xs, xo, rg, pvl + blk * kEncPv, kvalid, smem, h, lane, blk >= 1 && blk <= 4,
-                                         skipg + (size_t)(blk - 1) * 8 * 64, blk >= 4 && blk < kLayers - 1,
-                                         skipg + (size_t)(7 - blk) * 8 * 64, pf);
+            const int nblk = blk + 1 == kLayers ? 0 : blk + 1;   // (behind the last step's last block: a fetch nobody reads)
+            encoder_block8x<ROLEA, PROF>(xs, xo, rg, pvl + (gblk & 1) * kPvSlotFloats, kvalid, smem, h, lane, blk >= 1 && blk <= 4,
+                                         skipl + (blk - 1) * 8 * 64, blk >= 4 && blk < kLayers - 1, skipl + (7 - blk) * 8 * 64,
+                                         a.pvec + nblk * PV_BLOCK, pv_lds0 + ((gblk + 1) & 1) * (kPvSlotFloats * 4), pf);
+            ++gblk;
             if (tap && step == 0) {
                 store_tap_tile(a.tap_out, 1 + blk, 2 * h, xo[0], g, r);
                 store_tap_tile(a.tap_out, 1 + blk, 2 * h + 1, xo[1], g, r);
@@ -675,11 +697,9 @@ __global__ __launch_bounds__(512) void k_sample8x(SampleArgs a) {
     f32x4* tokrows = reinterpret_cast<f32x4*>(smem + kTokRows8Off);
     f32x4* latl = reinterpret_cast<f32x4*>(smem + kLat8Off);
     float* ttl = reinterpret_cast<float*>(smem + kTT8Off);
-    for (int i = threadIdx.x; i < kLayers * kEncPv / 4; i += 512) {
-        const int blk = (4 * i) / kEncPv, off = 4 * i - blk * kEncPv;
-        st4(pvl + 4 * i, ld4(a.pvec + blk * PV_BLOCK + off));
-    }
-    for (int i = threadIdx.x; i < (4 * kD + 2 * kD) / 4; i += 512) st4(pvl + kLayers * kEncPv + 4 * i, ld4(a.pvec + PV_SKIP_B + 4 * i));
+    for (int i = threadIdx.x; i < kEncPv / 4; i += 512) st4(pvl + 4 * i, ld4(a.pvec + 4 * i));   // block 0 -> slot 0
+    for (int i = threadIdx.x; i < (4 * kD + 2 * kD) / 4; i += 512)
+        st4(reinterpret_cast<float*>(smem + kPvTail8Off) + 4 * i, ld4(a.pvec + PV_SKIP_B + 4 * i));
     const int w8 = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int S = a.S;
     const Lane8 L = lane_info(a, threadIdx.x & 63);
