@@ -352,7 +352,8 @@ def main():
                                                 "stream_floor_us_per_step": round(STREAM_MB_PER_STEP["fp32x"] * 1e6 / CU_LOAD_BYTES_PER_CLK / (clk_ghz * 1e9) * 1e6, 2),
                                                 "traffic": trx, "traffic_source": trx_src,
                                                 "traffic_note": "7.6 MB of weights per step exceed the 4 MB L2 of an XCD: every XCD re-fetches the stream each "
-                                                                "step (8 x 7.6 MB x T) + the A waves' skip-stack scratch (2 x 16 MB x T) - Infinity-Cache / HBM side, ~1.1 TB/s, not the bound"},
+                                                                "step (8 x 7.6 MB x T = 61 GB per launch, fabric / Infinity-Cache side, ~0.9 TB/s) - not the bound "
+                                                                "(the per-CU load path is); the bf16 stream (3.8 MB) stays L2-resident"},
                                    "us_per_denoising_step_incl_decode": round(ms_x / args.T * 1e3, 2),
                                    "eps_err": eps_err["fp32x"], "eps_bar": 1e-5,
                                    "fp32_mode": {"ms_per_job": round(ms_f, 3), "frames_per_s": round(B * 300 / ms_f * 1e3, 1), "eps_err": eps_err["fp32"]},
