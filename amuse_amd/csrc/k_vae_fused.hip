@@ -129,7 +129,10 @@ __device__ __forceinline__ bf16x8 wfrag(const Stager& s, int u) {
 template <int NT, int NO, int NC, int U0>
 __device__ __forceinline__ void gemm5(f32x4 (&acc)[NT][NO], const bf16x8 (&xb)[NT][NC], const Stager& s) {
     // fragments are read two ahead of their MFMAs (a read waited for on the spot costs an LDS round trip per unit)
-    constexpr int NU = NO * NC, PF = 2;
+#ifndef AMUSE_F_PF
+#define AMUSE_F_PF 2
+#endif
+    constexpr int NU = NO * NC, PF = AMUSE_F_PF;
     bf16x8 wf[NU < PF ? NU : PF];
 #pragma unroll
     for (int u = 0; u < PF && u < NU; ++u) wf[u] = wfrag(s, U0 + u);
