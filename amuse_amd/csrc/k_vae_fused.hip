@@ -74,6 +74,10 @@ static_assert(kWaves * 16 * kQStride * 4 <= 2 * kKvBytes, "staging tiles must fi
 #ifndef AMUSE_FPROF
 #define AMUSE_FPROF 0
 #endif
+// 1: the LayerNorms unrolled over a wave's tiles instead of a runtime loop with rotating registers (A/B)
+#ifndef AMUSE_F_LN_UNROLL
+#define AMUSE_F_LN_UNROLL 0
+#endif
 #if AMUSE_FPROF
 __device__ unsigned long long g_fprof[512];
 __device__ int g_fprof_n;
@@ -418,6 +422,15 @@ __device__ __forceinline__ void decoder_block(f32x4 (&x)[NT][kTiles], Stager& sg
         FSTAMP(9);   // barrier of stage B passed
     }
     const float* ca = cal + blk * kD;
+#if AMUSE_F_LN_UNROLL
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {   // (A/B: unrolled over the tiles, no register rotation, NT copies of the code)
+        layer_norm_rows<true>(x[j], pv + PV_LN1_W, pv + PV_LN1_B, g);
+#pragma unroll
+        for (int t = 0; t < kTiles; ++t) x[j][t] += ld4(ca + 16 * t + 4 * g);
+        layer_norm_rows<true>(x[j], pv + PV_LN2_W, pv + PV_LN2_B, g);
+    }
+#else
 #pragma unroll 1
     for (int j = 0; j < NT; ++j) {   // runtime loop, the tiles rotate through x[0]
         layer_norm_rows<true>(x[0], pv + PV_LN1_W, pv + PV_LN1_B, g);
@@ -427,6 +440,7 @@ __device__ __forceinline__ void decoder_block(f32x4 (&x)[NT][kTiles], Stager& sg
         layer_norm_rows<true>(x[0], pv + PV_LN2_W, pv + PV_LN2_B, g);
         rotate_tiles<NT>(x);
     }
+#endif
     FSTAMP(10);   // norm1, cross-attention constant, norm2
     // ---------------- FFN (cross_attention.py:338-340): x = norm3(x + linear2(gelu(linear1(x)))), 16 chunks of 32 hidden
     // features.  Stages: [linear1(0) | pad], 15 x [linear1(i + 1) | linear2(i)], [linear2(15) | pad]
@@ -476,11 +490,16 @@ __device__ __forceinline__ void decoder_block(f32x4 (&x)[NT][kTiles], Stager& sg
         stage_end(sg);
     }
     FSTAMP(14);   // FFN epilogue stage
+#if AMUSE_F_LN_UNROLL
+#pragma unroll
+    for (int j = 0; j < NT; ++j) layer_norm_rows<true>(x[j], pv + PV_LN3_W, pv + PV_LN3_B, g);
+#else
 #pragma unroll 1
     for (int j = 0; j < NT; ++j) {
         layer_norm_rows<true>(x[0], pv + PV_LN3_W, pv + PV_LN3_B, g);
         rotate_tiles<NT>(x);
     }
+#endif
     FSTAMP(15);   // norm3
     if constexpr (MODE == 0) {   // xs.append(x): packed operands of the skip linear that pops them
         uint4* sk = skipbuf + (size_t)blk * (20 * 4 * 64);
