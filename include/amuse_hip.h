@@ -53,6 +53,9 @@ enum { AMUSE_OK = 0, AMUSE_EINVAL = -1, AMUSE_EHIP = -2, AMUSE_ENOMEM = -3, AMUS
  * is split into two fp16 pieces, x = hi + lo (22 significand bits), and a product is three v_mfma_f32_16x16x32_f16
  * (Wh.xh + Wh.xl + Wl.xh) accumulated in fp32; softmax, LayerNorm, erf GELU and the scheduler update are the F32 code.
  * Holds the F32 mode's parity bars (eps_hat <= 1e-5 against the reference's modules) at a fraction of its step time.
+ * Range: GEMM operands pass through fp16, so activations and weights must stay below 65504 in magnitude (beyond that the hi
+ * piece is infinite) - three orders of magnitude above what this network carries (LayerNorm'd rows, |weights| < 1, latents up to
+ * ~150 under DDPM); small values lose nothing: lo pieces below 2^-14 are fp16 subnormals, which the MI355X MFMA keeps.
  * amuse_vae_decode / amuse_vae_encode run the same split arithmetic in their staged kernels (k_vae.hip PREC_F16X2). */
 enum { AMUSE_PREC_F32 = 0, AMUSE_PREC_BF16 = 1, AMUSE_PREC_F32X = 2 };
 
