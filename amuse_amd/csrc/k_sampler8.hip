@@ -60,6 +60,10 @@ using Ring = WRing<kR8>;
 #ifndef AMUSE_B_EARLY
 #define AMUSE_B_EARLY 20
 #endif
+// s_setprio of the B waves inside their FFN half only (A/B; k_sampler8x.hip gains 1 % from it)
+#ifndef AMUSE_B_FFN_PRIO
+#define AMUSE_B_FFN_PRIO 0
+#endif
 // VALU instructions scheduled behind each MFMA while one FFN quarter's GELU overlaps the other quarter's GEMM (ffn_half)
 #ifndef AMUSE_FFN_VALU_PER_MFMA
 #define AMUSE_FFN_VALU_PER_MFMA 7
@@ -396,7 +400,13 @@ __device__ __forceinline__ void encoder_block8(bf16x8 (&xb)[4], f32x4 (&xo)[2], 
         for (int t = 0; t < kTiles; ++t) part[t] = splat4(0.f);
         combine_reduce<4, true>(part, xo, xb, pv + PV_OUT_B, pv + PV_LN1_W, pv + PV_LN1_B, lds, h, lane);
         stamp8<PROF>(pf);
+#if AMUSE_B_FFN_PRIO
+        __builtin_amdgcn_s_setprio(AMUSE_B_FFN_PRIO);
+#endif
         ffn_half<2, (AMUSE_B_EARLY < 32)>(part, xb, rg, pv, h, g);
+#if AMUSE_B_FFN_PRIO
+        __builtin_amdgcn_s_setprio(0);
+#endif
         stamp8<PROF>(pf);  // 3: FFN
         if (next_has_skip) ring_issue<8, kR8, 0>(rg);  // the x half of this wave's two output tiles of the next block's skip linear
         combine_reduce<8, true>(part, xo, xb, pv + PV_L2_B, pv + PV_LN2_W, pv + PV_LN2_B, lds, h, lane);
