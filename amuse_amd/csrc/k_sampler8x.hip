@@ -479,7 +479,9 @@ __device__ __forceinline__ void encoder_block8x(F16Pair (&xs)[4], f32x4 (&xo)[2]
         stamp8<PROF>(pf);
         if constexpr (AMUSE_X_B_PRIO != 0) __builtin_amdgcn_s_setprio(AMUSE_X_B_PRIO);
         ffn_half<2, AMUSE_X_B_EARLY, false, PROF>(part, xs, rg, pv, h, g, pf);
+#ifndef AMUSE_X_B_PRIO_KEEP   // (A/B: keep the priority through the linear2 combine and the next out_proj combine)
         if constexpr (AMUSE_X_B_PRIO != 0) __builtin_amdgcn_s_setprio(0);
+#endif
         stamp8<PROF>(pf);  // 3: FFN
         if (next_has_skip) ring_issue<16, kR8, 0>(rg);  // the x half of this wave's two output tiles of the next block's skip linear
         combine_reduce<8>(part, xo, xs, pv + PV_L2_B, pv + PV_LN2_W, pv + PV_LN2_B, lds, h, lane);
