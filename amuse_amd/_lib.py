@@ -13,8 +13,8 @@ _HERE = Path(__file__).resolve().parent
 # AMUSE_HIP_LIB: load another build of the same C ABI (kernel A/B measurements, tools/build_variant.sh)
 LIB_PATH = Path(os.environ.get("AMUSE_HIP_LIB") or _HERE / "libamuse_hip.so")
 
-PREC_F32, PREC_BF16, PREC_F32X = 0, 1, 2
-UPD_F32, UPD_BF16, UPD_ENCODER, UPD_F32X, UPD_ALL = 1, 2, 4, 8, 15
+PREC_F32, PREC_BF16, PREC_F32X, PREC_F16 = 0, 1, 2, 3
+UPD_F32, UPD_BF16, UPD_ENCODER, UPD_F32X, UPD_F16, UPD_ALL = 1, 2, 4, 8, 16, 31
 QUAT_P3D, QUAT_LEGACY = 0, 1
 ABI_VERSION = 2
 

@@ -153,7 +153,8 @@ void pack_gemm(std::vector<uint4>& out, int prec, const float* W, int n_out, int
                const std::vector<int>& ktiles) {
     // (amuse_update_weights calls this once per training iteration: the destination is sized once and filled through a
     // pointer, rows / columns inside the matrix skip the bounds checks)
-    const size_t nunits = prec == PREC_BF16 ? (ktiles.size() / 2) * otiles.size() : ktiles.size() * otiles.size();
+    const size_t nunits = is_op16(prec) ? (ktiles.size() / 2) * otiles.size() : ktiles.size() * otiles.size();
+    uint16_t (*const cv16)(float) = prec == PREC_F16 ? f2h : f2bf;   // the one-piece 16-bit formats differ in the conversion only
     const size_t base = out.size();
     out.resize(base + nunits * 64);
     uint4* dst = out.data() + base;
@@ -200,11 +201,11 @@ void pack_gemm(std::vector<uint4>& out, int prec, const float* W, int n_out, int
                     if (inside) {
                         const float* r0 = W + (size_t)(16 * o + i) * K + 16 * t0 + 4 * g;
                         const float* r1 = W + (size_t)(16 * o + i) * K + 16 * t1 + 4 * g;
-                        for (int e = 0; e < 4; ++e) { v[e] = f2bf(r0[e]); v[4 + e] = f2bf(r1[e]); }
+                        for (int e = 0; e < 4; ++e) { v[e] = cv16(r0[e]); v[4 + e] = cv16(r1[e]); }
                     } else {
                         for (int e = 0; e < 4; ++e) {
-                            v[e] = f2bf(at(16 * o + i, 16 * t0 + 4 * g + e));
-                            v[4 + e] = f2bf(at(16 * o + i, 16 * t1 + 4 * g + e));
+                            v[e] = cv16(at(16 * o + i, 16 * t0 + 4 * g + e));
+                            v[4 + e] = cv16(at(16 * o + i, 16 * t1 + 4 * g + e));
                         }
                     }
                     memcpy(dst, v, 16);
@@ -298,6 +299,7 @@ struct amuse_ctx {
     uint32_t den_wave_units[3] = {0, 0, 0};
     uint4* den_w8 = nullptr;           // bf16 streams of the 8-wave kernel (k_sampler8.hip)
     uint32_t den_w8_units[2] = {0, 0}; // per-step units of a group-A / group-B wave
+    uint4* den_w8h = nullptr;          // fp16 streams of the same kernel built for fp16 operands (k_sampler8h.hip, AMUSE_PREC_F16)
     uint4* den_w8x = nullptr;          // split-fp16 streams of the 8-wave fp32x kernel (k_sampler8x.hip)
     uint32_t den_w8x_units[2] = {0, 0};
     float* den_pvec = nullptr;
@@ -311,6 +313,7 @@ struct amuse_ctx {
     uint32_t vae_stage_base[3][kVaeStages];
     uint32_t vae_stage_units[3][kVaeStages];
     uint4* vae_wf = nullptr;           // bf16 stream of the fused decode kernel (k_vae_fused.hip)
+    uint4* vae_wfh = nullptr;          // its fp16 twin (k_vae_fusedh.hip, AMUSE_PREC_F16)
     uint4* vae_skip = nullptr; size_t vae_skip_cap = 0;   // clips
     float* vae_ca_ws = nullptr; size_t vae_ca_cap = 0;    // clips
     float *vae_pvec = nullptr, *vae_final_bias = nullptr, *vae_pe = nullptr;
@@ -352,7 +355,7 @@ int ensure(float** p, size_t* cap, size_t need_floats) {
     return 0;
 }
 
-constexpr int kUpdBit[3] = {AMUSE_UPD_F32, AMUSE_UPD_BF16, AMUSE_UPD_F32X};   // per PREC_* index
+constexpr int kUpdBit[4] = {AMUSE_UPD_F32, AMUSE_UPD_BF16, AMUSE_UPD_F32X, AMUSE_UPD_F16};   // per PREC_* index
 
 int build_denoiser(amuse_ctx* c, const float* den, int what = AMUSE_UPD_ALL) {
     static const ParamIndex DI = denoiser_index();
@@ -383,7 +386,8 @@ int build_denoiser(amuse_ctx* c, const float* den, int what = AMUSE_UPD_ALL) {
         c->den_wave_units[prec] = (uint32_t)(per_wave / 64);
         if (upload(&c->den_w[prec], all.data(), all.size() * sizeof(uint4))) return AMUSE_EHIP;
     }
-    if (what & 2) {   // 8-wave bf16 kernel: wave w8 = 4 s + h; A waves (s = 0) carry head h + FFN quarters 0,1, B waves quarters 2,3
+    for (const int p16 : {PREC_BF16, PREC_F16}) {   // 8-wave throughput kernel (bf16 / fp16 operands): wave w8 = 4 s + h; A waves (s = 0) carry head h + FFN quarters 0,1, B waves quarters 2,3
+        if (!(what & kUpdBit[p16])) continue;
         std::vector<uint4> all;
         for (int w8 = 0; w8 < 8; ++w8) {
             const int h = w8 & 3, sgrp = w8 >> 2;
@@ -393,22 +397,22 @@ int build_denoiser(amuse_ctx* c, const float* den, int what = AMUSE_UPD_ALL) {
             // x half], then FFN quarters 2,3.
             for (int b = 0; b < 9; ++b) {
                 const std::string p = blk_name("encoder", b);
-                auto f1 = [&](int q) { const int h0 = 8 * h + 2 * q; pack_gemm(s, PREC_BF16, D.get(p + ".linear1.weight"), 512, 128, {h0, h0 + 1}, range(0, 8)); };
-                auto f2 = [&](int q) { const int h0 = 8 * h + 2 * q; pack_gemm(s, PREC_BF16, D.get(p + ".linear2.weight"), 128, 512, range(0, 8), {h0, h0 + 1}); };
+                auto f1 = [&](int q) { const int h0 = 8 * h + 2 * q; pack_gemm(s, p16, D.get(p + ".linear1.weight"), 512, 128, {h0, h0 + 1}, range(0, 8)); };
+                auto f2 = [&](int q) { const int h0 = 8 * h + 2 * q; pack_gemm(s, p16, D.get(p + ".linear2.weight"), 128, 512, range(0, 8), {h0, h0 + 1}); };
                 const int qa = 2 * sgrp, qb = 2 * sgrp + 1;
                 const float* wskip = b >= 5 ? D.get("encoder.linear_blocks." + std::to_string(b - 5) + ".weight") : nullptr;
                 if (sgrp == 0) {
                     // a block's group of 32: 8 leading units, then q, k | v.  The leading 8 are out_proj - or, ahead of an
                     // output block, the skip-input half (k-tiles 8..15 of cat(x, skip)) of the skip linear for output
                     // tiles 2h, 2h+1, with out_proj following as a group of its own
-                    const auto outproj = [&] { pack_gemm(s, PREC_BF16, D.get(p + ".self_attn.out_proj.weight"), 128, 128, range(0, 8), {2 * h, 2 * h + 1}); };
-                    if (b >= 5) pack_gemm(s, PREC_BF16, wskip, 128, 256, {2 * h, 2 * h + 1}, range(8, 16));
+                    const auto outproj = [&] { pack_gemm(s, p16, D.get(p + ".self_attn.out_proj.weight"), 128, 128, range(0, 8), {2 * h, 2 * h + 1}); };
+                    if (b >= 5) pack_gemm(s, p16, wskip, 128, 256, {2 * h, 2 * h + 1}, range(8, 16));
                     else outproj();
-                    pack_qkv(s, PREC_BF16, D.get(p + ".self_attn.in_proj_weight"), h, true);
+                    pack_qkv(s, p16, D.get(p + ".self_attn.in_proj_weight"), h, true);
                     if (b >= 5) outproj();
                 } else if (b >= 5) {
                     // the x half (k-tiles 0..7) of the same two output tiles
-                    pack_gemm(s, PREC_BF16, wskip, 128, 256, {2 * h, 2 * h + 1}, range(0, 8));
+                    pack_gemm(s, p16, wskip, 128, 256, {2 * h, 2 * h + 1}, range(0, 8));
                 }
                 f1(qa); f1(qb); f2(qa); f2(qb);
             }
@@ -418,7 +422,7 @@ int build_denoiser(amuse_ctx* c, const float* den, int what = AMUSE_UPD_ALL) {
             all.insert(all.end(), s.begin(), s.end());
             if (sgrp == 0) all.insert(all.end(), s.begin(), s.begin() + (size_t)kRing8 * 64);  // ring wrap: tail = head
         }
-        if (upload(&c->den_w8, all.data(), all.size() * sizeof(uint4))) return AMUSE_EHIP;
+        if (upload(p16 == PREC_BF16 ? &c->den_w8 : &c->den_w8h, all.data(), all.size() * sizeof(uint4))) return AMUSE_EHIP;
     }
     if (what & AMUSE_UPD_F32X) {   // 8-wave fp32x kernel: the same roles, split-fp16 units (two per 16 x 32 weight tile: hi, lo)
         std::vector<uint4> all;
@@ -511,7 +515,8 @@ int build_prior(amuse_ctx* c, const float* pri, int what = AMUSE_UPD_ALL) {
         all.insert(all.end(), (size_t)kVaeRing * 64, uint4{0, 0, 0, 0});  // the last wave's ring reads past its slice
         if (upload(&c->vae_w[prec], all.data(), all.size() * sizeof(uint4))) return AMUSE_EHIP;
     }
-    if (what & 2) {   // fused decode kernel (k_vae_fused.hip): ONE stream for the four waves, in consumption order, cut
+    for (const int p16 : {PREC_BF16, PREC_F16}) {   // fused decode kernel (k_vae_fused.hip; bf16 / fp16 operands): ONE stream for the four waves, in consumption order, cut
+        if (!(what & kUpdBit[p16])) continue;
         // into stages of kVaeFusedStageUnits units (every phase below is a whole number of stages)
         std::vector<uint4> s;
         const auto pad = [&](int units) { s.insert(s.end(), (size_t)units * 64, uint4{0, 0, 0, 0}); };
@@ -519,29 +524,29 @@ int build_prior(amuse_ctx* c, const float* pri, int what = AMUSE_UPD_ALL) {
             const std::string p = blk_name("decoder", b);
             if (b >= 5) {   // skip linear ahead of an output block: the x half (k-tiles 0..7), then the popped-skip half
                 const float* wskip = Pp.get("decoder.linear_blocks." + std::to_string(b - 5) + ".weight");
-                pack_gemm(s, PREC_BF16, wskip, 128, 256, range(0, 8), range(0, 8));
-                pack_gemm(s, PREC_BF16, wskip, 128, 256, range(0, 8), range(8, 16));
+                pack_gemm(s, p16, wskip, 128, 256, range(0, 8), range(0, 8));
+                pack_gemm(s, p16, wskip, 128, 256, range(0, 8), range(8, 16));
             }
             const float* in_w = Pp.get(p + ".self_attn.in_proj_weight");
             for (int h = 0; h < 4; ++h) {   // per head: stage A = k | v tiles per k-pair; stage B = q, out_proj's k-slice
-                pack_gemm(s, PREC_BF16, in_w, 384, 128, {8 + 2 * h, 8 + 2 * h + 1, 16 + 2 * h, 16 + 2 * h + 1}, range(0, 8));
-                pack_gemm(s, PREC_BF16, in_w, 384, 128, {2 * h, 2 * h + 1}, range(0, 8));
-                pack_gemm(s, PREC_BF16, Pp.get(p + ".self_attn.out_proj.weight"), 128, 128, range(0, 8), {2 * h, 2 * h + 1});
+                pack_gemm(s, p16, in_w, 384, 128, {8 + 2 * h, 8 + 2 * h + 1, 16 + 2 * h, 16 + 2 * h + 1}, range(0, 8));
+                pack_gemm(s, p16, in_w, 384, 128, {2 * h, 2 * h + 1}, range(0, 8));
+                pack_gemm(s, p16, Pp.get(p + ".self_attn.out_proj.weight"), 128, 128, range(0, 8), {2 * h, 2 * h + 1});
             }
             // FFN in 16 chunks of 32 hidden features, software-pipelined: [linear1(0) | pad], 15 x [linear1(i + 1) | linear2(i)],
             // [linear2(15) | pad]
-            const auto f1 = [&](int ch) { pack_gemm(s, PREC_BF16, Pp.get(p + ".linear1.weight"), 512, 128, {2 * ch, 2 * ch + 1}, range(0, 8)); };
-            const auto f2 = [&](int ch) { pack_gemm(s, PREC_BF16, Pp.get(p + ".linear2.weight"), 128, 512, range(0, 8), {2 * ch, 2 * ch + 1}); };
+            const auto f1 = [&](int ch) { pack_gemm(s, p16, Pp.get(p + ".linear1.weight"), 512, 128, {2 * ch, 2 * ch + 1}, range(0, 8)); };
+            const auto f2 = [&](int ch) { pack_gemm(s, p16, Pp.get(p + ".linear2.weight"), 128, 512, range(0, 8), {2 * ch, 2 * ch + 1}); };
             f1(0); pad(8);
             for (int ch = 0; ch < 15; ++ch) { f1(ch + 1); f2(ch); }
             f2(15); pad(8);
         }
         for (int j = 0; j < 5; ++j)   // final_layer once per row tile of a wave (24 output tiles in two halves of 3 stages)
             for (int half = 0; half < 2; ++half)
-                pack_gemm(s, PREC_BF16, Pp.get("final_layer.weight"), kFeats, 128, range(12 * half, 12 * half + 12), range(0, 8));
+                pack_gemm(s, p16, Pp.get("final_layer.weight"), kFeats, 128, range(12 * half, 12 * half + 12), range(0, 8));
         if (s.size() % ((size_t)kVaeFusedStageUnits * 64) != 0) return fail(AMUSE_ESTATE, "internal: fused decode stream is not whole stages");
         pad(2 * kVaeFusedStageUnits);   // the fetch runs two stages ahead
-        if (upload(&c->vae_wf, s.data(), s.size() * sizeof(uint4))) return AMUSE_EHIP;
+        if (upload(p16 == PREC_BF16 ? &c->vae_wf : &c->vae_wfh, s.data(), s.size() * sizeof(uint4))) return AMUSE_EHIP;
     }
     {
         auto pv = build_pvec(Pp, "decoder", true);
@@ -648,10 +653,11 @@ int pick_group(const amuse_ctx* c, int B, int S) {
 // kernel, unless phase stamps are requested or AMUSE_SAMPLE_WAVES=4 (A/B measurements) asks for the 4-wave one
 bool use_sample8(int precision) {
     static const bool force4 = [] { const char* e = getenv("AMUSE_SAMPLE_WAVES"); return e && atoi(e) == 4; }();
+    if (precision == PREC_F16) return true;   // (the fp16 throughput mode exists on the 8-wave kernel only)
     return (precision == PREC_BF16 || precision == PREC_F16X2) && !force4;   // (AMUSE_SAMPLE_WAVES=4: the 4-wave kernels, A/B runs)
 }
 void set_stream(const amuse_ctx* c, SampleArgs& a, int precision) {
-    a.wstream = c->den_w[precision]; a.wave_units = c->den_wave_units[precision];
+    if (precision < 3) { a.wstream = c->den_w[precision]; a.wave_units = c->den_wave_units[precision]; }
     a.wave_units_a = c->den_w8_units[0]; a.wave_units_b = c->den_w8_units[1];
 }
 hipError_t dispatch_sample(amuse_ctx* c, SampleArgs& a, int precision, hipStream_t st) {
@@ -659,6 +665,10 @@ hipError_t dispatch_sample(amuse_ctx* c, SampleArgs& a, int precision, hipStream
         if (precision == PREC_F16X2) {
             a.wstream = c->den_w8x; a.wave_units_a = c->den_w8x_units[0]; a.wave_units_b = c->den_w8x_units[1];
             return launch_sample8x(a, st);
+        }
+        if (precision == PREC_F16) {   // the same streams' layout and unit counts, fp16 weights
+            a.wstream = c->den_w8h;
+            return launch_sample8h(a, st);
         }
         a.wstream = c->den_w8;
         return launch_sample8(a, st);
@@ -674,6 +684,7 @@ constexpr int kVaeFusedChunk = 4096;
 bool use_vae_fused(const amuse_ctx* c, int precision, int B) {
     static const int env = [] { const char* e = getenv("AMUSE_VAE_FUSED"); return e ? atoi(e) : -1; }();
     const int force = c->decode_path == AMUSE_DECODE_STAGED ? 0 : c->decode_path == AMUSE_DECODE_FUSED ? 1 : env;
+    if (precision == PREC_F16) return true;   // fp16 decodes on the fused kernel's fp16 build at every batch size (no staged fp16 kernels)
     if (precision != PREC_BF16 || force == 0) return false;
     return force == 1 || B >= kFusedMinClips;
 }
@@ -706,8 +717,7 @@ int check_common(amuse_ctx* c, const float* con, int B, int precision) {
     if (!c) return fail(AMUSE_EINVAL, "ctx is NULL");
     if (!con) return fail(AMUSE_EINVAL, "con is NULL (the content embedding is mandatory, denoiser.py:153-157)");
     if (B < 1) return fail(AMUSE_EINVAL, "B must be >= 1, got %d", B);
-    if (precision != AMUSE_PREC_F32 && precision != AMUSE_PREC_BF16 && precision != AMUSE_PREC_F32X)
-        return fail(AMUSE_EINVAL, "bad precision %d", precision);
+    if (precision < AMUSE_PREC_F32 || precision > AMUSE_PREC_F16) return fail(AMUSE_EINVAL, "bad precision %d", precision);
     HIP_TRY(hipSetDevice(c->device));
     return 0;
 }
@@ -757,7 +767,7 @@ int amuse_update_weights(amuse_ctx* c, const float* denoiser_params, size_t n_de
                          size_t n_prior, int what, void* stream) {
     if (!c) return fail(AMUSE_EINVAL, "ctx is NULL");
     if (!denoiser_params && !prior_params) return fail(AMUSE_EINVAL, "nothing to update");
-    if (what < 1 || what > AMUSE_UPD_ALL || !(what & (AMUSE_UPD_F32 | AMUSE_UPD_BF16 | AMUSE_UPD_F32X))) return fail(AMUSE_EINVAL, "bad `what` mask %d", what);
+    if (what < 1 || what > AMUSE_UPD_ALL || !(what & (AMUSE_UPD_F32 | AMUSE_UPD_BF16 | AMUSE_UPD_F32X | AMUSE_UPD_F16))) return fail(AMUSE_EINVAL, "bad `what` mask %d", what);
     if (denoiser_params && n_denoiser != AMUSE_DENOISER_PARAMS)
         return fail(AMUSE_EINVAL, "denoiser parameter count %zu (want %u)", n_denoiser, AMUSE_DENOISER_PARAMS);
     if (prior_params && n_prior != AMUSE_PRIOR_PARAMS)
@@ -781,10 +791,11 @@ int build_repack_maps(amuse_ctx* c) {
     struct Img { std::vector<int> map; bool prior; };
     std::map<void**, Img> imgs;
     std::vector<float> den(AMUSE_DENOISER_PARAMS), pri(AMUSE_PRIOR_PARAMS);
-    // element type of an image: 0 = fp32, 1 = bf16, 2 = split-fp16 (launch_repack's `kind`)
+    // element type of an image: 0 = fp32, 1 = bf16, 2 = split-fp16, 3 = fp16 (launch_repack's `kind`)
     auto kind_of = [&](void** slot) {
         if (slot == (void**)&c->den_w[PREC_F16X2] || slot == (void**)&c->den_w8x || slot == (void**)&c->vae_w[PREC_F16X2] ||
             slot == (void**)&c->vaee_w[PREC_F16X2]) return 2;
+        if (slot == (void**)&c->den_w8h || slot == (void**)&c->vae_wfh) return 3;
         return (slot == (void**)&c->den_w[PREC_BF16] || slot == (void**)&c->den_w8 || slot == (void**)&c->vae_w[PREC_BF16] ||
                 slot == (void**)&c->vae_wf || slot == (void**)&c->vaee_w[PREC_BF16]) ? 1 : 0;
     };
@@ -813,7 +824,7 @@ int build_repack_maps(amuse_ctx* c) {
                         memcpy(&h, kv.second.data() + 2 * j, 2);
                         const uint32_t u = (uint32_t)h << 16;
                         memcpy(&v, &u, 4);
-                    } else if (kind == 2) {
+                    } else if (kind == 2 || kind == 3) {
                         uint16_t h;
                         memcpy(&h, kv.second.data() + 2 * j, 2);
                         v = h2f(h);
@@ -835,6 +846,7 @@ int build_repack_maps(amuse_ctx* c) {
         if (slot == (void**)&c->den_w[PREC_F32] || slot == (void**)&c->vae_w[PREC_F32]) cls = AMUSE_UPD_F32;
         else if (slot == (void**)&c->den_w[PREC_F16X2] || slot == (void**)&c->den_w8x || slot == (void**)&c->vae_w[PREC_F16X2]) cls = AMUSE_UPD_F32X;
         else if (slot == (void**)&c->vaee_w[PREC_F16X2]) cls = AMUSE_UPD_F32X | AMUSE_UPD_ENCODER;
+        else if (slot == (void**)&c->den_w8h || slot == (void**)&c->vae_wfh) cls = AMUSE_UPD_F16;
         else if (slot == (void**)&c->den_w[PREC_BF16] || slot == (void**)&c->den_w8 || slot == (void**)&c->vae_w[PREC_BF16] || slot == (void**)&c->vae_wf) cls = AMUSE_UPD_BF16;
         else if (slot == (void**)&c->vaee_w[PREC_F32]) cls = AMUSE_UPD_F32 | AMUSE_UPD_ENCODER;
         else if (slot == (void**)&c->vaee_w[PREC_BF16]) cls = AMUSE_UPD_BF16 | AMUSE_UPD_ENCODER;
@@ -851,7 +863,7 @@ int build_repack_maps(amuse_ctx* c) {
 int amuse_update_weights_device(amuse_ctx* c, const float* denoiser_params_dev, const float* prior_params_dev, int what, void* stream) {
     if (!c) return fail(AMUSE_EINVAL, "ctx is NULL");
     if (!denoiser_params_dev && !prior_params_dev) return fail(AMUSE_EINVAL, "nothing to update");
-    if (what < 1 || what > AMUSE_UPD_ALL || !(what & (AMUSE_UPD_F32 | AMUSE_UPD_BF16 | AMUSE_UPD_F32X))) return fail(AMUSE_EINVAL, "bad `what` mask %d", what);
+    if (what < 1 || what > AMUSE_UPD_ALL || !(what & (AMUSE_UPD_F32 | AMUSE_UPD_BF16 | AMUSE_UPD_F32X | AMUSE_UPD_F16))) return fail(AMUSE_EINVAL, "bad `what` mask %d", what);
     HIP_TRY(hipSetDevice(c->device));
     if (c->repack.empty())
         if (int e = build_repack_maps(c)) return e;
@@ -874,7 +886,7 @@ void amuse_destroy(amuse_ctx* c) {
     (void)hipSetDevice(c->device);
     for (void* p : c->owned)
         if (p) (void)hipFree(p);
-    void* ptrs[] = {c->den_w[0], c->den_w[1], c->den_w[2], c->den_w8, c->den_w8x, c->den_pvec, c->den_pe, c->den_freqs, c->te_w1t, c->te_b1, c->te_w2t,
+    void* ptrs[] = {c->den_w[0], c->den_w[1], c->den_w[2], c->den_w8, c->den_w8h, c->den_w8x, c->vae_wfh, c->den_pvec, c->den_pe, c->den_freqs, c->te_w1t, c->te_b1, c->te_w2t,
                     c->te_b2, c->cond_wt[0], c->cond_wt[1], c->cond_wt[2], c->cond_b[0], c->cond_b[1], c->cond_b[2],
                     c->vae_w[0], c->vae_w[1], c->vae_w[2], c->vaee_w[2], c->vae_pvec, c->vae_final_bias, c->vae_pe, c->vae_wv_t, c->vae_bv,
                     c->vae_wo_t, c->vae_bo, c->vaee_w[0], c->vaee_w[1], c->vaee_pvec, c->vaee_pe, c->vaee_tok,
@@ -1030,7 +1042,7 @@ int amuse_vae_decode(amuse_ctx* c, const float* z, const int* lengths, int B, in
     if (!z) return fail(AMUSE_EINVAL, "z is NULL");
     if (B < 1) return fail(AMUSE_EINVAL, "B must be >= 1, got %d", B);
     precision = prior_precision(precision);
-    if (precision != AMUSE_PREC_F32 && precision != AMUSE_PREC_BF16 && precision != AMUSE_PREC_F32X) return fail(AMUSE_EINVAL, "bad precision %d", precision);
+    if (precision < AMUSE_PREC_F32 || precision > AMUSE_PREC_F16) return fail(AMUSE_EINVAL, "bad precision %d", precision);
     if (quat_mode != AMUSE_QUAT_P3D && quat_mode != AMUSE_QUAT_LEGACY) return fail(AMUSE_EINVAL, "bad quat_mode %d", quat_mode);
     HIP_TRY(hipSetDevice(c->device));
     hipStream_t st = (hipStream_t)stream;
@@ -1049,14 +1061,14 @@ int amuse_vae_decode(amuse_ctx* c, const float* z, const int* lengths, int B, in
             const int nb = (B - b0) < chunk ? (B - b0) : chunk;
             HIP_TRY(launch_vae_ca(z + (size_t)b0 * kD, c->vae_wv_t, c->vae_bv, c->vae_wo_t, c->vae_bo, c->vae_ca_ws, nb, st));
             VaeFusedArgs fa{};
-            fa.wstream = c->vae_wf; fa.pvec = c->vae_pvec; fa.final_bias = c->vae_final_bias; fa.pe = c->vae_pe;
+            fa.wstream = precision == PREC_F16 ? c->vae_wfh : c->vae_wf; fa.pvec = c->vae_pvec; fa.final_bias = c->vae_final_bias; fa.pe = c->vae_pe;
             fa.ca = c->vae_ca_ws; fa.lengths = lengths ? c->d_lengths + b0 : nullptr; fa.skip = c->vae_skip;
             fa.feats_out = feats_out ? feats_out + (size_t)b0 * kFrames * kFeats : nullptr;
             fa.poses_out = poses_out ? poses_out + (size_t)b0 * kFrames * kJoints * 3 : nullptr;
             fa.trans_out = trans_out ? trans_out + (size_t)b0 * kFrames * 3 : nullptr;
             fa.B = nb; fa.quat_mode = quat_mode;
             fa.tap_out = b0 == 0 ? c->decode_tap : nullptr;   // (amuse_debug_set_decode_tap: tests)
-            HIP_TRY(launch_vae_fused(fa, st));
+            HIP_TRY(precision == PREC_F16 ? launch_vae_fusedh(fa, st) : launch_vae_fused(fa, st));
         }
         return 0;
     }
@@ -1104,6 +1116,7 @@ int amuse_vae_encode(amuse_ctx* c, const float* feats, const int* lengths, int B
     if (!mu_out && !std_out && !latent_out) return fail(AMUSE_EINVAL, "no output requested");
     if (B < 1) return fail(AMUSE_EINVAL, "B must be >= 1, got %d", B);
     precision = prior_precision(precision);
+    if (precision == AMUSE_PREC_F16) precision = AMUSE_PREC_BF16;   // (MotionPrior.encode has no fp16 kernels: the bf16 ones serve)
     if (precision != AMUSE_PREC_F32 && precision != AMUSE_PREC_BF16 && precision != AMUSE_PREC_F32X) return fail(AMUSE_EINVAL, "bad precision %d", precision);
     HIP_TRY(hipSetDevice(c->device));
     hipStream_t st = (hipStream_t)stream;

@@ -33,6 +33,10 @@ constexpr int PREC_BF16 = 1;
 // Wh.xh + Wh.xl + Wl.xh, accumulated in fp32 (the dropped Wl.xl term is 2^-22 relative).  Everything outside the GEMMs
 // (softmax, LayerNorm, erf GELU, scheduler update) is the PREC_F32 code.  Same bytes per weight as fp32.
 constexpr int PREC_F16X2 = 2;
+// "fp16": the throughput mode with fp16 instead of bf16 operands - the bf16 kernels' instruction stream (one
+// v_mfma_f32_16x16x32_f16 per product, 2 bytes per weight), 11 significand bits instead of 8: an eighth of the bf16 mode's drift
+// against fp32 at the same speed.  Range as for PREC_F16X2 (|operands| < 65504; subnormals kept by the MFMA).
+constexpr int PREC_F16 = 3;
 
 constexpr int kD = 128;       // d_model
 constexpr int kTiles = 8;     // kD / 16
@@ -90,6 +94,24 @@ __device__ __forceinline__ bf16x8 pack_bf16(f32x4 lo, f32x4 hi) {
     return __builtin_convertvector(v, bf16x8);  // v_cvt_pk_bf16_f32, round-to-nearest-even
 }
 
+__device__ __forceinline__ f16x8 pack_f16(f32x4 lo, f32x4 hi) {
+    f32x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return __builtin_convertvector(v, f16x8);  // v_cvt_pk_f16_f32, round-to-nearest-even
+}
+// operand format of the one-piece 16-bit modes (PREC_BF16, PREC_F16): vector type, pack, MFMA
+template <int PREC> struct Op16;
+template <> struct Op16<PREC_BF16> {
+    typedef bf16x8 vec;
+    static __device__ __forceinline__ vec pack(f32x4 lo, f32x4 hi) { return pack_bf16(lo, hi); }
+    static __device__ __forceinline__ f32x4 mfma(vec a, vec b, f32x4 c) { return mfma_bf16(a, b, c); }
+};
+template <> struct Op16<PREC_F16> {
+    typedef f16x8 vec;
+    static __device__ __forceinline__ vec pack(f32x4 lo, f32x4 hi) { return pack_f16(lo, hi); }
+    static __device__ __forceinline__ f32x4 mfma(vec a, vec b, f32x4 c) { return mfma_f16(a, b, c); }
+};
+constexpr bool is_op16(int prec) { return prec == PREC_BF16 || prec == PREC_F16; }
+
 // acc[o] (+)= W_o . x   over NK k-tiles held in x[], consuming the wave's weight stream `w`
 // (already offset by lane).  SWAP = false: row-lane result (weights = A operand).
 // SWAP = true: feature-lane result (activations = A): lane (g, f) holds rows 4 g + m of feature f.
@@ -112,14 +134,15 @@ __device__ __forceinline__ const uint4* gemm_tiles(f32x4 (&acc)[NO], const f32x4
         }
         return w + NK * NO * 64;
     } else {
-        static_assert(NK % 2 == 0, "bf16 units cover k-tile pairs");
+        static_assert(NK % 2 == 0 && is_op16(PREC), "16-bit units cover k-tile pairs");
+        typedef Op16<PREC> Op;
 #pragma unroll
         for (int c = 0; c < NK / 2; ++c) {
-            const bf16x8 xb = pack_bf16(x[2 * c], x[2 * c + 1]);
+            const typename Op::vec xb = Op::pack(x[2 * c], x[2 * c + 1]);
 #pragma unroll
             for (int o = 0; o < NO; ++o) {
-                const bf16x8 wf = *reinterpret_cast<const bf16x8*>(w + (c * NO + o) * 64);
-                acc[o] = SWAP ? mfma_bf16(xb, wf, acc[o]) : mfma_bf16(wf, xb, acc[o]);
+                const typename Op::vec wf = *reinterpret_cast<const typename Op::vec*>(w + (c * NO + o) * 64);
+                acc[o] = SWAP ? Op::mfma(xb, wf, acc[o]) : Op::mfma(wf, xb, acc[o]);
             }
         }
         return w + (NK / 2) * NO * 64;
@@ -240,10 +263,11 @@ __device__ __forceinline__ void gemm_ring(f32x4 (&acc)[NO], const f32x4 (&x)[NK]
             }
         }
     } else {
-        static_assert(NK % 2 == 0, "bf16 units cover k-tile pairs");
+        static_assert(NK % 2 == 0 && is_op16(PREC), "16-bit units cover k-tile pairs");
+        typedef Op16<PREC> Op;
 #pragma unroll
         for (int c = 0; c < NK / 2; ++c) {
-            const bf16x8 xb = pack_bf16(x[2 * c], x[2 * c + 1]);
+            const typename Op::vec xb = Op::pack(x[2 * c], x[2 * c + 1]);
 #pragma unroll
             for (int o = 0; o < NO; ++o) {
                 const int slot = (PH + c * NO + o) % R;
@@ -252,8 +276,8 @@ __device__ __forceinline__ void gemm_ring(f32x4 (&acc)[NO], const f32x4 (&x)[NK]
                     rg.s[slot] = ldw(rg.next);
                     rg.next += 64;
                 }
-                const bf16x8 wf = __builtin_bit_cast(bf16x8, u);
-                acc[o] = SWAP ? mfma_bf16(xb, wf, acc[o]) : mfma_bf16(wf, xb, acc[o]);
+                const typename Op::vec wf = __builtin_bit_cast(typename Op::vec, u);
+                acc[o] = SWAP ? Op::mfma(xb, wf, acc[o]) : Op::mfma(wf, xb, acc[o]);
             }
         }
     }
@@ -271,7 +295,7 @@ __device__ __forceinline__ void ring_discard(WRing<R>& rg) {
 
 // units (1 KiB) consumed by gemm_tiles<PREC, NO, NK>
 // (f16x2: k-tile pairs x two pieces - the fp32 count)
-constexpr int gemm_units(int prec, int no, int nk) { return prec == PREC_BF16 ? no * nk / 2 : no * nk; }
+constexpr int gemm_units(int prec, int no, int nk) { return is_op16(prec) ? no * nk / 2 : no * nk; }
 
 // All-reduce over the four 16-lane rows of a wavefront (lanes l, l^16, l^32, l^48 - the "g" axis of the
 // row-lane layout) in two VALU instructions each: v_permlane16_swap / v_permlane32_swap exchange whole rows
@@ -434,6 +458,27 @@ __device__ __forceinline__ f32x4 gelu_poly4(f32x4 x) {
     p = p * s + splat4(1.900408231e-02f);
     p = p * s + splat4(-1.319021881e-01f);
     p = p * s + splat4(7.975201607e-01f);
+    const f32x4 hx = 0.5f * x;
+    return hx * (a * p) + hx;  // 0.5 x (1 + erf(x / sqrt2))
+}
+
+// The fp16 mode's FFN activation: the same clamped odd polynomial one degree higher (tools/fit_gelu_poly.py 8 3.0): |erf error| <=
+// 3.0e-5, |GELU error| <= 6.3e-5 absolute (at |x| ~ 4, i.e. 1.5e-5 relative) - a tenth of an fp16 ulp of the result it is rounded to.
+__device__ __forceinline__ f32x4 gelu_poly4h(f32x4 x) {
+    constexpr float X0 = 4.24264068711928514641f;
+    f32x4 a;
+#pragma unroll
+    for (int m = 0; m < 4; ++m) a[m] = __builtin_amdgcn_fmed3f(x[m], -X0, X0);
+    const f32x4 s = a * a;
+    f32x4 p = splat4(1.232038360e-10f);
+    p = p * s + splat4(-1.159289287e-08f);
+    p = p * s + splat4(4.817333092e-07f);
+    p = p * s + splat4(-1.179083301e-05f);
+    p = p * s + splat4(1.923068630e-04f);
+    p = p * s + splat4(-2.249475103e-03f);
+    p = p * s + splat4(1.973768137e-02f);
+    p = p * s + splat4(-1.328561008e-01f);
+    p = p * s + splat4(7.978953719e-01f);
     const f32x4 hx = 0.5f * x;
     return hx * (a * p) + hx;  // 0.5 x (1 + erf(x / sqrt2))
 }
@@ -624,6 +669,10 @@ __device__ __forceinline__ f32x4 counter_normal4(uint64_t seed, uint64_t clip, u
 // four floats <-> four bf16 (round-to-nearest-even, v_cvt_pk_bf16_f32; widening is exact)
 __device__ __forceinline__ uint2 f32_to_bf16x4(f32x4 v) {
     const uint4 u = __builtin_bit_cast(uint4, pack_bf16(v, splat4(0.f)));
+    return uint2{u.x, u.y};
+}
+__device__ __forceinline__ uint2 f32_to_f16x4(f32x4 v) {
+    const uint4 u = __builtin_bit_cast(uint4, pack_f16(v, splat4(0.f)));
     return uint2{u.x, u.y};
 }
 __device__ __forceinline__ f32x4 bf16x4_to_f32(uint2 u) {

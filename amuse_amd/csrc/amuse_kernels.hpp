@@ -50,6 +50,7 @@ constexpr int kProfStamps = 192;
 hipError_t launch_sample(const SampleArgs& a, int precision, hipStream_t stream);
 // bf16 throughput kernel with 8 waves per workgroup (k_sampler8.hip); no phase-timeline instrumentation
 hipError_t launch_sample8(const SampleArgs& a, hipStream_t stream);
+hipError_t launch_sample8h(const SampleArgs& a, hipStream_t stream);   // the same kernel on fp16 operands (AMUSE_PREC_F16, k_sampler8h.hip)
 // fp32x 8-wave kernel (k_sampler8x.hip); streams laid out like k_sample8's, in split-fp16 units
 hipError_t launch_sample8x(const SampleArgs& a, hipStream_t stream);
 constexpr int kRing8 = 32;
@@ -83,7 +84,7 @@ struct CondArgs {
 };
 hipError_t launch_cond_tokens(const CondArgs& a, hipStream_t stream);
 // noisy[b] = sa[b] * z0[b] + sb[b] * noise[b]   (DDPMScheduler.add_noise; call site ldm.py:84)
-// kind: 0 = fp32 image, 1 = bf16 image, 2 = split-fp16 image (1 KiB units alternate hi = rn16(w), lo = rn16(w - hi))
+// kind: 0 = fp32 image, 1 = bf16 image, 2 = split-fp16 image (1 KiB units alternate hi = rn16(w), lo = rn16(w - hi)), 3 = fp16 image
 hipError_t launch_repack(const float* params, const int* map, void* dst, size_t n, int kind, hipStream_t stream);
 hipError_t launch_add_noise(const float* z0, const float* noise, const float* sa, const float* sb, float* out, int B,
                             hipStream_t stream);
@@ -148,6 +149,7 @@ struct VaeFusedArgs {
 };
 constexpr size_t kVaeFusedSkipBytesPerClip = 4 * 20 * 4 * 64 * 16;
 hipError_t launch_vae_fused(const VaeFusedArgs& a, hipStream_t stream);
+hipError_t launch_vae_fusedh(const VaeFusedArgs& a, hipStream_t stream);   // fp16 operands (AMUSE_PREC_F16, k_vae_fusedh.hip)
 // feats[row][0:330] = first two rows of R(axis-angle) per joint, feats[row][330:333] = trans   (infer_ldm.py:459-464)
 hipError_t launch_smplx_to_feats(const float* poses, const float* trans, size_t nrows, float* feats, hipStream_t stream);
 // mu = stats[b][0], std = exp(stats[b][1]) ** 0.5, latent = mu + std * eps   (vae.py:209-213)

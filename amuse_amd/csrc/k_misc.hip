@@ -168,6 +168,8 @@ __global__ __launch_bounds__(256) void k_repack(const float* __restrict__ params
         if (kind == 1) {
             typedef __bf16 bf;
             reinterpret_cast<unsigned short*>(dst)[j] = __builtin_bit_cast(unsigned short, (bf)v);   // round-to-nearest-even, as the host packer
+        } else if (kind == 3) {   // fp16 image (AMUSE_PREC_F16)
+            reinterpret_cast<unsigned short*>(dst)[j] = __builtin_bit_cast(unsigned short, (_Float16)v);
         } else if (kind == 2) {
             // split-fp16 image: 1 KiB units (512 elements) alternate hi / lo pieces of the same weights (amuse_api.hip pack_gemm)
             const _Float16 hi = (_Float16)v;

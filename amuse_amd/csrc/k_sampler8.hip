@@ -32,6 +32,27 @@
 #include "amuse_dev.hpp"
 #include "amuse_kernels.hpp"
 
+// This file is compiled twice: as is (bf16 operands: k_sample8 / launch_sample8) and through k_sampler8h.hip with AMUSE_OP_F16
+// defined (fp16 operands, AMUSE_PREC_F16: k_sample8h / launch_sample8h) - the same instruction stream on v_mfma_f32_16x16x32_f16
+// with v_cvt_pk_f16_f32 and a GELU polynomial one degree higher; the stream holds fp16 weights.
+#ifdef AMUSE_OP_F16
+#define OPV f16x8
+#define OP_PACK pack_f16
+#define OP_MFMA mfma_f16
+#define OP_PREC PREC_F16
+#define OP_GELU gelu_poly4h
+#define OP_KERNEL k_sample8h
+#define OP_LAUNCH launch_sample8h
+#else
+#define OPV bf16x8
+#define OP_PACK pack_bf16
+#define OP_MFMA mfma_bf16
+#define OP_PREC PREC_BF16
+#define OP_GELU gelu_poly4
+#define OP_KERNEL k_sample8
+#define OP_LAUNCH launch_sample8
+#endif
+
 namespace amuse {
 
 namespace {
@@ -82,13 +103,13 @@ __device__ __forceinline__ uint4* xb_slot(char* lds, int c, int lane) {
 }
 // acc[o] += W_o . x over the 128 features held as four packed operands; same unit order as gemm_ring (bf16)
 template <int NO, bool SWAP, int PH>
-__device__ __forceinline__ void gemm_xb(f32x4 (&acc)[NO], const bf16x8 (&xb)[4], const Ring& rg) {
+__device__ __forceinline__ void gemm_xb(f32x4 (&acc)[NO], const OPV (&xb)[4], const Ring& rg) {
 #pragma unroll
     for (int c = 0; c < 4; ++c)
 #pragma unroll
         for (int o = 0; o < NO; ++o) {
-            const bf16x8 wf = __builtin_bit_cast(bf16x8, rg.s[(PH + c * NO + o) % kR8]);
-            acc[o] = SWAP ? mfma_bf16(xb[c], wf, acc[o]) : mfma_bf16(wf, xb[c], acc[o]);
+            const OPV wf = __builtin_bit_cast(OPV, rg.s[(PH + c * NO + o) % kR8]);
+            acc[o] = SWAP ? OP_MFMA(xb[c], wf, acc[o]) : OP_MFMA(wf, xb[c], acc[o]);
         }
 }
 
@@ -104,7 +125,7 @@ __device__ __forceinline__ constexpr int part_row(int w, int t) {
 }
 // LN = false (U-Net skip linear): tiles = sum + bias - no residual, no LayerNorm, and one barrier less.
 template <int W, int NP, bool FAST, bool LN>
-__device__ __forceinline__ void combine_red(f32x4 (&part)[kTiles], f32x4 (&xo)[2], bf16x8 (&xb)[4], const float* bias,
+__device__ __forceinline__ void combine_red(f32x4 (&part)[kTiles], f32x4 (&xo)[2], OPV (&xb)[4], const float* bias,
                                             const float* gamma, const float* beta, char* lds, int lane) {
     float2* stats = reinterpret_cast<float2*>(lds + kStat8Off);
     const int g = lane >> 4, r = lane & 15;
@@ -177,18 +198,18 @@ __device__ __forceinline__ void combine_red(f32x4 (&part)[kTiles], f32x4 (&xo)[2
     xo[0] = y[0];
     xo[1] = y[1];
     // publish the two tiles as ONE packed bf16 operand (k-tile pair W of every following GEMM)
-    xb[W] = pack_bf16(y[0], y[1]);
+    xb[W] = OP_PACK(y[0], y[1]);
     *xb_slot(lds, W, lane) = __builtin_bit_cast(uint4, xb[W]);
     __syncthreads();
 #pragma unroll
     for (int c = 0; c < 4; ++c)
-        if (c != W) xb[c] = __builtin_bit_cast(bf16x8, *xb_slot(lds, c, lane));
+        if (c != W) xb[c] = __builtin_bit_cast(OPV, *xb_slot(lds, c, lane));
     // keeps SimplifyCFG from sinking the four cases' register-array stores into one block behind a pointer PHI (which
     // pins the arrays in scratch): an immediate operand cannot be merged
     asm volatile("; combine_red case %0" ::"n"(W));
 }
 template <int NP, bool FAST, bool LN = true>
-__device__ __forceinline__ void combine_reduce(f32x4 (&part)[kTiles], f32x4 (&xo)[2], bf16x8 (&xb)[4],
+__device__ __forceinline__ void combine_reduce(f32x4 (&part)[kTiles], f32x4 (&xo)[2], OPV (&xb)[4],
                                                const float* bias, const float* gamma, const float* beta, char* lds,
                                                int h, int lane) {
     if (h == 0) combine_red<0, NP, FAST, LN>(part, xo, xb, bias, gamma, beta, lds, lane);
@@ -202,7 +223,7 @@ __device__ __forceinline__ void combine_reduce(f32x4 (&part)[kTiles], f32x4 (&xo
 // N0 units go out BEFORE the first barrier: free where the A waves arrive early (the linear2 combine - their FFN half
 // is the shorter one), on the critical path where they arrive last (the out_proj combine: N0 = 0).
 template <int N0, int N1, int N2, int N3, int IPH0, bool LN = true>
-__device__ __forceinline__ void combine_publish(const f32x4 (&part)[kTiles], bf16x8 (&xb)[4], char* lds, int h,
+__device__ __forceinline__ void combine_publish(const f32x4 (&part)[kTiles], OPV (&xb)[4], char* lds, int h,
                                                 int lane, Ring& rg) {
 #pragma unroll
     for (int t = 0; t < kTiles; ++t) *a8_slot(lds, h + (h >= t ? 1 : 0), t, lane) = part[t];  // part_row(h, t), h < 4
@@ -215,7 +236,7 @@ __device__ __forceinline__ void combine_publish(const f32x4 (&part)[kTiles], bf1
     ring_issue<N2, kR8, (IPH0 + N0 + N1) % kR8>(rg);
     __syncthreads();
 #pragma unroll
-    for (int c = 0; c < 4; ++c) xb[c] = __builtin_bit_cast(bf16x8, *xb_slot(lds, c, lane));
+    for (int c = 0; c < 4; ++c) xb[c] = __builtin_bit_cast(OPV, *xb_slot(lds, c, lane));
     ring_issue<N3, kR8, (IPH0 + N0 + N1 + N2) % kR8>(rg);
 }
 
@@ -233,7 +254,7 @@ __device__ __forceinline__ f32x4* u_slot(char* lds, int t, int lane) { return a8
 // fetch make hipcc copy the ring registers at the merge - behind an s_waitcnt vmcnt that stalls the wave until its
 // loads have landed, in front of the last barrier.
 template <int N0, int N1, int N2>
-__device__ __forceinline__ void combine_publish_c2(const f32x4 (&part)[kTiles], bf16x8 (&xb)[4], char* lds, int h,
+__device__ __forceinline__ void combine_publish_c2(const f32x4 (&part)[kTiles], OPV (&xb)[4], char* lds, int h,
                                                    int lane, Ring& rg, bool skip_u, const uint4* skip_ops) {
     static_assert(N0 >= 8 && N0 + N1 + N2 == 32, "the leading 8 units go out before the first barrier");
 #pragma unroll
@@ -245,9 +266,9 @@ __device__ __forceinline__ void combine_publish_c2(const f32x4 (&part)[kTiles], 
     __syncthreads();
 #endif
     if (skip_u) {
-        bf16x8 sk[4];
+        OPV sk[4];
 #pragma unroll
-        for (int p = 0; p < 4; ++p) sk[p] = __builtin_bit_cast(bf16x8, skip_ops[p * 64 + lane]);
+        for (int p = 0; p < 4; ++p) sk[p] = __builtin_bit_cast(OPV, skip_ops[p * 64 + lane]);
         f32x4 u[2] = {splat4(0.f), splat4(0.f)};
         gemm_xb<2, false, 24>(u, sk, rg);
         *u_slot(lds, 2 * h, lane) = u[0];
@@ -256,13 +277,13 @@ __device__ __forceinline__ void combine_publish_c2(const f32x4 (&part)[kTiles], 
     ring_issue<N2, kR8, (24 + N0 + N1) % kR8>(rg);
     __syncthreads();
 #pragma unroll
-    for (int c = 0; c < 4; ++c) xb[c] = __builtin_bit_cast(bf16x8, *xb_slot(lds, c, lane));
+    for (int c = 0; c < 4; ++c) xb[c] = __builtin_bit_cast(OPV, *xb_slot(lds, c, lane));
 }
 
 __device__ __forceinline__ void attention_head8(const f32x4 (&q)[2], const f32x4 (&k)[2], const f32x4 (&v)[2],
                                                 const bool (&kvalid)[4], f32x4 (&o)[2]) {
     // S^T[j][i] = sum_d K[j][d] Q[i][d]  ->  lane (g, i) holds S[i][4 g + m]   (k_sampler.hip attention_head)
-    f32x4 st = mfma_bf16(pack_bf16(k[0], k[1]), pack_bf16(q[0], q[1]), splat4(0.f));
+    f32x4 st = OP_MFMA(OP_PACK(k[0], k[1]), OP_PACK(q[0], q[1]), splat4(0.f));
     float mx = -INFINITY;
 #pragma unroll
     for (int m = 0; m < 4; ++m) mx = kvalid[m] ? fmaxf(mx, st[m]) : mx;
@@ -281,7 +302,7 @@ __device__ __forceinline__ void attention_head8(const f32x4 (&q)[2], const f32x4
     for (int m = 0; m < 4; ++m) p[m] *= inv;
 #pragma unroll
     for (int td = 0; td < 2; ++td)
-        o[td] = mfma_bf16(pack_bf16(v[td], splat4(0.f)), pack_bf16(p, splat4(0.f)), splat4(0.f));
+        o[td] = OP_MFMA(OP_PACK(v[td], splat4(0.f)), OP_PACK(p, splat4(0.f)), splat4(0.f));
 }
 
 // optional phase timeline: s_memtime stamps by lane 0 of every wave of workgroup 0 during ONE step ([8][96] u64)
@@ -297,11 +318,11 @@ __device__ __forceinline__ void stamp8(Prof8& pf) {
     }
 }
 
-// GELU (amuse_dev.hpp gelu_poly4: the result is an MFMA operand, i.e. rounded to bf16 next) on one FFN quarter (two
+// GELU (amuse_dev.hpp OP_GELU: the result is an MFMA operand, i.e. rounded to bf16 next) on one FFN quarter (two
 // hidden tiles); linear1's bias is already in the accumulators (ffn_half)
 __device__ __forceinline__ void gelu_pair(f32x4 (&hq)[2]) {
-    hq[0] = gelu_poly4(hq[0]);
-    hq[1] = gelu_poly4(hq[1]);
+    hq[0] = OP_GELU(hq[0]);
+    hq[1] = OP_GELU(hq[1]);
 }
 
 // this wave's two FFN quarters (Q0, Q0 + 1 of head h's slice): linear1 for 2 hidden tiles each -> bias + GELU ->
@@ -310,9 +331,9 @@ __device__ __forceinline__ void gelu_pair(f32x4 (&hq)[2]) {
 // LATE8: the last 8 units (F2b) are issued only now, behind the first GEMMs' MFMAs (B waves: their fetch window, the A
 // waves' attention phase, is a little too short for all 32)
 template <int Q0, bool LATE8>
-__device__ __forceinline__ void ffn_half(f32x4 (&part)[kTiles], const bf16x8 (&xb)[4], Ring& rg, const float* pv,
+__device__ __forceinline__ void ffn_half(f32x4 (&part)[kTiles], const OPV (&xb)[4], Ring& rg, const float* pv,
                                          int h, int g) {
-    constexpr int P = PREC_BF16;
+    constexpr int P = OP_PREC;
     // accumulators start at linear1's bias (this lane's 4 features of each hidden tile)
     const float* b1 = pv + PV_L1_B + 16 * (kTiles * h + 2 * Q0) + 4 * g;
     f32x4 ha[2] = {ld4(b1), ld4(b1 + 16)}, hb[2] = {ld4(b1 + 32), ld4(b1 + 48)};
@@ -346,14 +367,14 @@ __device__ __forceinline__ void ffn_half(f32x4 (&part)[kTiles], const bf16x8 (&x
 }
 
 // One TransformerEncoderLayer.forward_post (cross_attention.py:259-272), A / B role split.  The two roles are
-// separate instantiations (and the whole step loop is instantiated per role, k_sample8 below): sharing one body
+// separate instantiations (and the whole step loop is instantiated per role, OP_KERNEL below): sharing one body
 // behind a runtime branch makes hipcc's register allocator spill hundreds of VGPRs at the merges.
 // xb: the residual stream as four packed bf16 operands (every wave); xo: this B wave's two feature tiles in fp32.
 template <bool ROLEA, bool PROF>
-__device__ __forceinline__ void encoder_block8(bf16x8 (&xb)[4], f32x4 (&xo)[2], Ring& rg, const float* pv,
+__device__ __forceinline__ void encoder_block8(OPV (&xb)[4], f32x4 (&xo)[2], Ring& rg, const float* pv,
                                                const bool (&kvalid)[4], char* lds, int h, int lane, bool next_has_skip,
                                                const uint4* skip_next, Prof8& pf) {
-    constexpr int P = PREC_BF16;
+    constexpr int P = OP_PREC;
     const int g = lane >> 4, r = lane & 15;
     f32x4 part[kTiles];
     if constexpr (ROLEA) {
@@ -482,7 +503,7 @@ __device__ __forceinline__ void role_loop8(const SampleArgs& a, char* smem, int 
     for (int step = 0; step < a.T; ++step) {
         // ---- token assembly (denoiser.py:174,180-181): every wave builds the four packed operands, a B wave also
         // its own two tiles in fp32
-        bf16x8 xb[4];
+        OPV xb[4];
         f32x4 xo[2] = {splat4(0.f), splat4(0.f)};
         {
             const Lane8 L = lane_info(a, lane);
@@ -494,7 +515,7 @@ __device__ __forceinline__ void role_loop8(const SampleArgs& a, char* smem, int 
                 return !L.valid ? splat4(0.f) : (L.tok == 0 ? latl[t * 64 + lane] + sv : (L.tok == 1 ? tt : sv));
             };
 #pragma unroll
-            for (int c = 0; c < 4; ++c) xb[c] = pack_bf16(assemble(2 * c), assemble(2 * c + 1));
+            for (int c = 0; c < 4; ++c) xb[c] = OP_PACK(assemble(2 * c), assemble(2 * c + 1));
             if constexpr (!ROLEA) {
                 xo[0] = assemble(2 * h);
                 xo[1] = assemble(2 * h + 1);
@@ -532,11 +553,11 @@ __device__ __forceinline__ void role_loop8(const SampleArgs& a, char* smem, int 
                     gemm_xb<2, false, 0>(acc, xb, rg);
                     xo[0] = acc[0];
                     xo[1] = acc[1];
-                    *reinterpret_cast<uint4*>(a8_slot(smem, 7, h, lane)) = __builtin_bit_cast(uint4, pack_bf16(acc[0], acc[1]));
+                    *reinterpret_cast<uint4*>(a8_slot(smem, 7, h, lane)) = __builtin_bit_cast(uint4, OP_PACK(acc[0], acc[1]));
                 }
                 __syncthreads();
 #pragma unroll
-                for (int c = 0; c < 4; ++c) xb[c] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(a8_slot(smem, 7, c, lane)));
+                for (int c = 0; c < 4; ++c) xb[c] = __builtin_bit_cast(OPV, *reinterpret_cast<const uint4*>(a8_slot(smem, 7, c, lane)));
             }
             stamp8<PROF>(pf);  // 0: block start (after the skip linear, if any)
             encoder_block8<ROLEA, PROF>(xb, xo, rg, pvl + blk * kEncPv, kvalid, smem, h, lane, blk >= 4 && blk < kLayers - 1,
@@ -622,7 +643,7 @@ __device__ __forceinline__ void role_loop8(const SampleArgs& a, char* smem, int 
 }
 
 template <bool PROF>
-__global__ __launch_bounds__(512) void k_sample8(SampleArgs a) {
+__global__ __launch_bounds__(512) void OP_KERNEL(SampleArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* pvl = reinterpret_cast<float*>(smem + kPv8Off);
     f32x4* tokrows = reinterpret_cast<f32x4*>(smem + kTokRows8Off);
@@ -666,19 +687,19 @@ __global__ __launch_bounds__(512) void k_sample8(SampleArgs a) {
 
 }  // namespace
 
-hipError_t launch_sample8(const SampleArgs& a, hipStream_t stream) {
+hipError_t OP_LAUNCH(const SampleArgs& a, hipStream_t stream) {
     const int tiles = (a.B + a.G - 1) / a.G;
     static DeviceOnce once;
     int dev_;
     if (!once.done(&dev_)) {
-        for (const void* k : {reinterpret_cast<const void*>(&k_sample8<false>), reinterpret_cast<const void*>(&k_sample8<true>)}) {
+        for (const void* k : {reinterpret_cast<const void*>(&OP_KERNEL<false>), reinterpret_cast<const void*>(&OP_KERNEL<true>)}) {
             hipError_t e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, kSample8LdsBytes);
             if (e != hipSuccess) return e;
         }
         once.set(dev_);
     }
-    if (a.prof_out) hipLaunchKernelGGL(k_sample8<true>, dim3(tiles), dim3(512), kSample8LdsBytes, stream, a);
-    else hipLaunchKernelGGL(k_sample8<false>, dim3(tiles), dim3(512), kSample8LdsBytes, stream, a);
+    if (a.prof_out) hipLaunchKernelGGL(OP_KERNEL<true>, dim3(tiles), dim3(512), kSample8LdsBytes, stream, a);
+    else hipLaunchKernelGGL(OP_KERNEL<false>, dim3(tiles), dim3(512), kSample8LdsBytes, stream, a);
     return hipGetLastError();
 }
 

@@ -43,6 +43,29 @@
 #include "amuse_kernels.hpp"
 #include <cstdio>
 
+// Compiled twice: as is (bf16 operands: k_vae_fused / launch_vae_fused) and through k_vae_fusedh.hip with AMUSE_OP_F16 defined (fp16
+// operands, AMUSE_PREC_F16: k_vae_fusedh / launch_vae_fusedh - the same instruction stream on the fp16 MFMA, fp16 weight stream,
+// K / V^T / skip-stack images in fp16, GELU polynomial one degree higher).
+#ifdef AMUSE_OP_F16
+#define OPV f16x8
+#define OP_PACK pack_f16
+#define OP_MFMA mfma_f16
+#define OP_GELU gelu_poly4h
+#define OP_CVT4 f32_to_f16x4
+#define OP_ONE2 0x3c003c00u
+#define OP_KERNEL k_vae_fusedh
+#define OP_LAUNCH launch_vae_fusedh
+#else
+#define OPV bf16x8
+#define OP_PACK pack_bf16
+#define OP_MFMA mfma_bf16
+#define OP_GELU gelu_poly4
+#define OP_CVT4 f32_to_bf16x4
+#define OP_ONE2 0x3f803f80u
+#define OP_KERNEL k_vae_fused
+#define OP_LAUNCH launch_vae_fused
+#endif
+
 namespace amuse {
 namespace {
 
@@ -70,7 +93,7 @@ static_assert(kWaves * 16 * kQStride * 4 <= 2 * kKvBytes, "staging tiles must fi
 #define AMUSE_FABL 0
 #endif
 // -DAMUSE_FPROF=1 (variant builds only): wave 0 of workgroup 0 stamps s_memtime at phase boundaries of blocks 1 and 6 and
-// launch_vae_fused prints the deltas (tools/gpu_decode_phases.py)
+// OP_LAUNCH prints the deltas (tools/gpu_decode_phases.py)
 #ifndef AMUSE_FPROF
 #define AMUSE_FPROF 0
 #endif
@@ -125,28 +148,28 @@ __device__ __forceinline__ void stage_end(Stager& s) {
     asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)\n\ts_barrier" ::: "memory");
     s.ridx = s.ridx == kWBufs - 1 ? 0 : s.ridx + 1;
 }
-__device__ __forceinline__ bf16x8 wfrag(const Stager& s, int u) {
-    return __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(s.ring + s.ridx * kStageBytes + u * 1024));
+__device__ __forceinline__ OPV wfrag(const Stager& s, int u) {
+    return __builtin_bit_cast(OPV, *reinterpret_cast<const uint4*>(s.ring + s.ridx * kStageBytes + u * 1024));
 }
 
 // acc[j][o] += W_o . x_j for the NT row tiles of this wave; units U0.. of the current stage, k-pair outer, output tile inner
 template <int NT, int NO, int NC, int U0>
-__device__ __forceinline__ void gemm5(f32x4 (&acc)[NT][NO], const bf16x8 (&xb)[NT][NC], const Stager& s) {
+__device__ __forceinline__ void gemm5(f32x4 (&acc)[NT][NO], const OPV (&xb)[NT][NC], const Stager& s) {
     // fragments are read two ahead of their MFMAs (a read waited for on the spot costs an LDS round trip per unit)
 #ifndef AMUSE_F_PF
 #define AMUSE_F_PF 2
 #endif
     constexpr int NU = NO * NC, PF = AMUSE_F_PF;
-    bf16x8 wf[NU < PF ? NU : PF];
+    OPV wf[NU < PF ? NU : PF];
 #pragma unroll
     for (int u = 0; u < PF && u < NU; ++u) wf[u] = wfrag(s, U0 + u);
 #pragma unroll
     for (int u = 0; u < NU; ++u) {
         const int c = u / NO, o = u - c * NO;
-        const bf16x8 cur = wf[u % PF];
+        const OPV cur = wf[u % PF];
         if (u + PF < NU) wf[u % PF] = wfrag(s, U0 + u + PF);
 #pragma unroll
-        for (int j = 0; j < NT; ++j) acc[j][o] = mfma_bf16(cur, xb[j][c], acc[j][o]);
+        for (int j = 0; j < NT; ++j) acc[j][o] = OP_MFMA(cur, xb[j][c], acc[j][o]);
     }
 }
 
@@ -163,11 +186,11 @@ __device__ __forceinline__ void rotate_tiles(f32x4 (&x)[NT][kTiles]) {
 }
 
 template <int NT>
-__device__ __forceinline__ void pack_rows(bf16x8 (&xb)[NT][4], const f32x4 (&x)[NT][kTiles]) {
+__device__ __forceinline__ void pack_rows(OPV (&xb)[NT][4], const f32x4 (&x)[NT][kTiles]) {
 #pragma unroll
     for (int j = 0; j < NT; ++j)
 #pragma unroll
-        for (int c = 0; c < 4; ++c) xb[j][c] = pack_bf16(x[j][2 * c], x[j][2 * c + 1]);
+        for (int c = 0; c < 4; ++c) xb[j][c] = OP_PACK(x[j][2 * c], x[j][2 * c + 1]);
 }
 
 // 16-byte slot of lane (g, r) inside a 1 KiB K / V^T fragment.  Lane-linear (4 r + g) makes ds_read_b128 2-way bank
@@ -187,7 +210,7 @@ __device__ __forceinline__ float max3(float a, float b, float c) { return fmaxf(
 // too scarce (x + xb of three tiles = 144 of 256) for hipcc to hoist the reads itself.  So a chunk's four K fragments are
 // read as ONE batch in front of its four score MFMAs, and its four V^T fragments as one batch right behind them - they
 // land while the softmax arithmetic runs.
-__device__ __forceinline__ bf16x8 attend(const uint4* Kb, const uint4* Vt, bf16x8 qb, int len, int g, int r) {
+__device__ __forceinline__ OPV attend(const uint4* Kb, const uint4* Vt, OPV qb, int len, int g, int r) {
     if constexpr ((AMUSE_FABL & 2) != 0) return qb;
     const int fs = frag_slot(g, r);
     // Scores leave the MFMAs RELATIVE to the row's running maximum (C operand = -m_run; chunk 0 starts from 0 and takes its own
@@ -200,7 +223,7 @@ __device__ __forceinline__ bf16x8 attend(const uint4* Kb, const uint4* Vt, bf16x
     // VALU-bound: 16 quarter-rate v_exp_f32 per lane and chunk are half of it, the rest was max / sum / pack).  What is
     // summed is the bf16 P the PV product uses.  Lane (g = 0, i) ends up with query i's sum in os[0]; rows d = 4, 8, 12 of the
     // fragment are zero, so os[0] of the other three lanes of the row is 0 and one butterfly at the end broadcasts it.
-    const bf16x8 ones = __builtin_bit_cast(bf16x8, r == 0 ? uint4{0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u} : uint4{0u, 0u, 0u, 0u});
+    const OPV ones = __builtin_bit_cast(OPV, r == 0 ? uint4{OP_ONE2, OP_ONE2, OP_ONE2, OP_ONE2} : uint4{0u, 0u, 0u, 0u});
     f32x4 os = splat4(0.f);
 #pragma unroll
     for (int ch = 0; ch < kPairs / 2; ++ch) {
@@ -211,7 +234,7 @@ __device__ __forceinline__ bf16x8 attend(const uint4* Kb, const uint4* Vt, bf16x
         const f32x4 c0 = splat4(-m_run);
 #pragma unroll
         for (int i = 0; i < 4; ++i)   // lane (g, i): S[query i][key 64 ch + 16 i + 4 g + m] - m_run (log2 units)
-            st[i] = mfma_bf16(__builtin_bit_cast(bf16x8, kf[i]), qb, c0);
+            st[i] = OP_MFMA(__builtin_bit_cast(OPV, kf[i]), qb, c0);
         uint4 vf[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) vf[i] = Vt[(4 * ch + i) * 64 + fs];   // (pair, td) = (2 ch + i / 2, i % 2)
@@ -257,14 +280,14 @@ __device__ __forceinline__ bf16x8 attend(const uint4* Kb, const uint4* Vt, bf16x
         }
 #pragma unroll
         for (int pr = 0; pr < 2; ++pr) {   // O^T[d][i] += sum_key V[key][d] P[i][key], 32 keys per MFMA
-            const bf16x8 pb = pack_bf16(p[2 * pr], p[2 * pr + 1]);
-            o[0] = mfma_bf16(__builtin_bit_cast(bf16x8, vf[2 * pr]), pb, o[0]);
-            o[1] = mfma_bf16(__builtin_bit_cast(bf16x8, vf[2 * pr + 1]), pb, o[1]);
-            os = mfma_bf16(ones, pb, os);
+            const OPV pb = OP_PACK(p[2 * pr], p[2 * pr + 1]);
+            o[0] = OP_MFMA(__builtin_bit_cast(OPV, vf[2 * pr]), pb, o[0]);
+            o[1] = OP_MFMA(__builtin_bit_cast(OPV, vf[2 * pr + 1]), pb, o[1]);
+            os = OP_MFMA(ones, pb, os);
         }
     }
     const float inv = __builtin_amdgcn_rcpf(allreduce_g_sum(os[0]));
-    return pack_bf16(o[0] * inv, o[1] * inv);
+    return OP_PACK(o[0] * inv, o[1] * inv);
 }
 
 // MODE 0: input block (push the skip), 1: middle block, 2: output block (skip linear first)
@@ -288,17 +311,17 @@ __device__ __forceinline__ void decoder_block(f32x4 (&x)[NT][kTiles], Stager& sg
     const int g = lane >> 4, r = lane & 15;
     [[maybe_unused]] const bool prof_on = blockIdx.x == 0 && threadIdx.x == 0 && (blk == 1 || blk == 6);
     FSTAMP(1);   // block start
-    bf16x8 xb[NT][4];
+    OPV xb[NT][4];
     if constexpr (MODE == 2) {
         // x = linear_blocks[blk - 5](cat(x, xs.pop()))   (cross_attention.py:118-120); the popped skip comes back from
         // global memory as the packed operands this wave stored after input block 8 - blk.  Four stages: the x half
         // (k-pairs 0..3), then the skip half.
-        bf16x8 sb[NT][4];
+        OPV sb[NT][4];
         const uint4* sk = skipbuf + (size_t)(8 - blk) * (20 * 4 * 64);
 #pragma unroll
         for (int j = 0; j < NT; ++j)
 #pragma unroll
-            for (int c = 0; c < 4; ++c) sb[j][c] = __builtin_bit_cast(bf16x8, sk[((tile0 + 4 * j) * 4 + c) * 64 + lane]);
+            for (int c = 0; c < 4; ++c) sb[j][c] = __builtin_bit_cast(OPV, sk[((tile0 + 4 * j) * 4 + c) * 64 + lane]);
         pack_rows<NT>(xb, x);
         const float* bias = a.pvec + PV_SKIP_B + (blk - 5) * kD;
 #pragma unroll
@@ -313,9 +336,9 @@ __device__ __forceinline__ void decoder_block(f32x4 (&x)[NT][kTiles], Stager& sg
                 const int c = 2 * (s4 & 1) + cc;
 #pragma unroll
                 for (int o = 0; o < kTiles; ++o) {
-                    const bf16x8 wf = wfrag(sg, cc * kTiles + o);
+                    const OPV wf = wfrag(sg, cc * kTiles + o);
 #pragma unroll
-                    for (int j = 0; j < NT; ++j) x[j][o] = mfma_bf16(wf, s4 < 2 ? xb[j][c] : sb[j][c], x[j][o]);
+                    for (int j = 0; j < NT; ++j) x[j][o] = OP_MFMA(wf, s4 < 2 ? xb[j][c] : sb[j][c], x[j][o]);
                 }
             }
             stage_end(sg);
@@ -349,22 +372,22 @@ __device__ __forceinline__ void decoder_block(f32x4 (&x)[NT][kTiles], Stager& sg
             for (int c = 0; c < 4; ++c) {   // stream: per k-pair c: k tiles (2), v tiles (2)
 #pragma unroll
                 for (int o = 0; o < 2; ++o) {
-                    const bf16x8 wf = wfrag(sg, 4 * c + o);
+                    const OPV wf = wfrag(sg, 4 * c + o);
 #pragma unroll
-                    for (int j = 0; j < NT; ++j) kk[j][o] = mfma_bf16(wf, xb[j][c], kk[j][o]);
+                    for (int j = 0; j < NT; ++j) kk[j][o] = OP_MFMA(wf, xb[j][c], kk[j][o]);
                 }
 #pragma unroll
                 for (int o = 0; o < 2; ++o) {
-                    const bf16x8 wf = wfrag(sg, 4 * c + 2 + o);
+                    const OPV wf = wfrag(sg, 4 * c + 2 + o);
 #pragma unroll
-                    for (int j = 0; j < NT; ++j) vv[j][o] = mfma_bf16(xb[j][c], wf, vv[j][o]);  // operand-swapped: V^T
+                    for (int j = 0; j < NT; ++j) vv[j][o] = OP_MFMA(xb[j][c], wf, vv[j][o]);  // operand-swapped: V^T
                 }
             }
 #pragma unroll
             for (int j = 0; j < NT; ++j) {
                 const int tile = tile0 + 4 * j;
                 const bool ok = 16 * tile + r < kFrames;
-                const uint4 kf = __builtin_bit_cast(uint4, pack_bf16(kk[j][0], kk[j][1]));
+                const uint4 kf = __builtin_bit_cast(uint4, OP_PACK(kk[j][0], kk[j][1]));
                 Kb[tile * 64 + frag_slot(g, r)] = ok ? kf : uint4{0u, 0u, 0u, 0u};
                 // V^T: lane (g, d) holds V[row 4 g + m][16 td + d]; rows beyond the clip are zeroed (0 x p stays 0)
 #pragma unroll
@@ -372,7 +395,7 @@ __device__ __forceinline__ void decoder_block(f32x4 (&x)[NT][kTiles], Stager& sg
                     f32x4 v = vv[j][td];
 #pragma unroll
                     for (int m = 0; m < 4; ++m) v[m] = (16 * tile + 4 * g + m < kFrames) ? v[m] : 0.f;
-                    *reinterpret_cast<uint2*>(Vt + (((tile >> 1) * 2 + td) * 64 + frag_slot(g, r)) * 16 + (tile & 1) * 8) = f32_to_bf16x4(v);
+                    *reinterpret_cast<uint2*>(Vt + (((tile >> 1) * 2 + td) * 64 + frag_slot(g, r)) * 16 + (tile & 1) * 8) = OP_CVT4(v);
                 }
             }
         }
@@ -385,7 +408,7 @@ __device__ __forceinline__ void decoder_block(f32x4 (&x)[NT][kTiles], Stager& sg
             glds16(reinterpret_cast<const uint4*>(pv_next_src) + wave * 64 + lane, d);
         }
         stage_fetch(sg);
-        bf16x8 qb[NT];
+        OPV qb[NT];
         {
             f32x4 q[NT][2];
             const f32x4 bq0 = ld4(pv + PV_IN_B + 32 * h + 4 * g), bq1 = ld4(pv + PV_IN_B + 32 * h + 16 + 4 * g);
@@ -393,20 +416,20 @@ __device__ __forceinline__ void decoder_block(f32x4 (&x)[NT][kTiles], Stager& sg
             for (int j = 0; j < NT; ++j) { q[j][0] = bq0; q[j][1] = bq1; }
             gemm5<NT, 2, 4, 0>(q, xb, sg);
 #pragma unroll
-            for (int j = 0; j < NT; ++j) qb[j] = pack_bf16(q[j][0] * kQScale, q[j][1] * kQScale);
+            for (int j = 0; j < NT; ++j) qb[j] = OP_PACK(q[j][0] * kQScale, q[j][1] * kQScale);
         }
         FSTAMP(5);   // q
         // attention, one 16-query tile per iteration of a RUNTIME loop: the tile's q operand is qb[0] and its output enters
         // ob[] from the top while both arrays rotate by one position per iteration (register moves instead of indexing).
         // The loop body is the attention's only copy in the instruction stream (see the note on code size at the kernel).
-        bf16x8 ob[NT][1];
+        OPV ob[NT][1];
 #pragma unroll
         for (int j = 0; j < NT; ++j) ob[j][0] = qb[j];
         {
             const uint4* Vq = reinterpret_cast<const uint4*>(Vt);
 #pragma unroll 1
             for (int j = 0; j < NT; ++j) {
-                const bf16x8 o1 = attend(Kb, Vq, qb[0], len, g, r);
+                const OPV o1 = attend(Kb, Vq, qb[0], len, g, r);
 #pragma unroll
                 for (int jj = 0; jj + 1 < NT; ++jj) {
                     qb[jj] = qb[jj + 1];
@@ -466,11 +489,11 @@ __device__ __forceinline__ void decoder_block(f32x4 (&x)[NT][kTiles], Stager& sg
         const f32x4 b0 = ld4(pv + PV_L1_B + 32 * (c + 1) + 4 * g), b1 = ld4(pv + PV_L1_B + 32 * (c + 1) + 16 + 4 * g);
 #pragma unroll
         for (int j = 0; j < NT; ++j) { nxt[j][0] = b0; nxt[j][1] = b1; }
-        bf16x8 hb[NT][1];
+        OPV hb[NT][1];
         if constexpr (!(AMUSE_FABL & 4)) {
             gemm5<NT, 2, 4, 0>(nxt, xb, sg);   // linear1 of the next chunk: MFMAs that do not depend on ...
 #pragma unroll
-            for (int j = 0; j < NT; ++j) hb[j][0] = pack_bf16(gelu_poly4(hid[j][0]), gelu_poly4(hid[j][1]));   // ... this VALU
+            for (int j = 0; j < NT; ++j) hb[j][0] = OP_PACK(OP_GELU(hid[j][0]), OP_GELU(hid[j][1]));   // ... this VALU
             gemm5<NT, kTiles, 1, 8>(x, hb, sg);
         }
 #pragma unroll
@@ -481,10 +504,10 @@ __device__ __forceinline__ void decoder_block(f32x4 (&x)[NT][kTiles], Stager& sg
     }
     {
         stage_fetch(sg);
-        bf16x8 hb[NT][1];
+        OPV hb[NT][1];
         if constexpr (!(AMUSE_FABL & 4)) {
 #pragma unroll
-            for (int j = 0; j < NT; ++j) hb[j][0] = pack_bf16(gelu_poly4(hid[j][0]), gelu_poly4(hid[j][1]));
+            for (int j = 0; j < NT; ++j) hb[j][0] = OP_PACK(OP_GELU(hid[j][0]), OP_GELU(hid[j][1]));
             gemm5<NT, kTiles, 1, 0>(x, hb, sg);
         }
         stage_end(sg);
@@ -507,7 +530,7 @@ __device__ __forceinline__ void decoder_block(f32x4 (&x)[NT][kTiles], Stager& sg
         for (int j = 0; j < NT; ++j)
 #pragma unroll
             for (int c = 0; c < 4; ++c)
-                sk[((tile0 + 4 * j) * 4 + c) * 64 + lane] = __builtin_bit_cast(uint4, pack_bf16(x[j][2 * c], x[j][2 * c + 1]));
+                sk[((tile0 + 4 * j) * 4 + c) * 64 + lane] = __builtin_bit_cast(uint4, OP_PACK(x[j][2 * c], x[j][2 * c + 1]));
     }
     if constexpr (TAP) {
         if (a.tap_out && blockIdx.x == 0) store_tap<NT>(a.tap_out, blk, x, tile0, g, r);
@@ -570,9 +593,9 @@ __device__ __forceinline__ void decode_tiles(const VaeFusedArgs& a, char* smem, 
                 for (int t = 0; t < kTiles; ++t) st4(a.tap_out + ((size_t)9 * kFrames + frame_t) * kD + 16 * t + 4 * g, x[0][t]);
             }
         }
-        bf16x8 xb1[4];
+        OPV xb1[4];
 #pragma unroll
-        for (int c = 0; c < 4; ++c) xb1[c] = pack_bf16(x[0][2 * c], x[0][2 * c + 1]);
+        for (int c = 0; c < 4; ++c) xb1[c] = OP_PACK(x[0][2 * c], x[0][2 * c + 1]);
         rotate_tiles<NT>(x);
         const int tile = tile0 + 4 * j;
         const int frame = 16 * tile + r;
@@ -590,7 +613,7 @@ __device__ __forceinline__ void decode_tiles(const VaeFusedArgs& a, char* smem, 
 #pragma unroll
                 for (int u = 0; u < kStage; ++u) {
                     const int lin = kStage * s3 + u, c = lin / 12, o = lin - 12 * c;
-                    f[o] = mfma_bf16(wfrag(sg, u), xb1[c], f[o]);
+                    f[o] = OP_MFMA(wfrag(sg, u), xb1[c], f[o]);
                 }
                 stage_end(sg);
             }
@@ -629,7 +652,7 @@ __device__ __forceinline__ void decode_tiles(const VaeFusedArgs& a, char* smem, 
 }
 
 template <bool TAP>
-__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_vae_fused(VaeFusedArgs a) {
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void OP_KERNEL(VaeFusedArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -653,11 +676,11 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 
 }  // namespace
 
-hipError_t launch_vae_fused(const VaeFusedArgs& a, hipStream_t stream) {
+hipError_t OP_LAUNCH(const VaeFusedArgs& a, hipStream_t stream) {
     static DeviceOnce once;
     int dev_;
     if (!once.done(&dev_)) {
-        for (const void* k : {reinterpret_cast<const void*>(&k_vae_fused<false>), reinterpret_cast<const void*>(&k_vae_fused<true>)}) {
+        for (const void* k : {reinterpret_cast<const void*>(&OP_KERNEL<false>), reinterpret_cast<const void*>(&OP_KERNEL<true>)}) {
             hipError_t e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, kVaeFusedLdsBytes);
             if (e != hipSuccess) return e;
         }
@@ -669,8 +692,8 @@ hipError_t launch_vae_fused(const VaeFusedArgs& a, hipStream_t stream) {
         (void)hipMemcpyToSymbol(HIP_SYMBOL(g_fprof_n), &zero, sizeof(int));
     }
 #endif
-    if (a.tap_out) hipLaunchKernelGGL(k_vae_fused<true>, dim3(a.B), dim3(512), kVaeFusedLdsBytes, stream, a);   // the tapped instantiation (tests)
-    else hipLaunchKernelGGL(k_vae_fused<false>, dim3(a.B), dim3(512), kVaeFusedLdsBytes, stream, a);
+    if (a.tap_out) hipLaunchKernelGGL(OP_KERNEL<true>, dim3(a.B), dim3(512), kVaeFusedLdsBytes, stream, a);   // the tapped instantiation (tests)
+    else hipLaunchKernelGGL(OP_KERNEL<false>, dim3(a.B), dim3(512), kVaeFusedLdsBytes, stream, a);
 #if AMUSE_FPROF
     {
         static int calls = 0;

@@ -15,7 +15,9 @@ from .scheduler import ScheduleTable, timestep_freqs
 # "fp32x": the fast parity mode of the sampling loop (split-fp16 MFMA operands, include/amuse_hip.h AMUSE_PREC_F32X)
 _N_DEN = sum(int(np.prod(s)) for s in wts.denoiser_param_spec().values())   # AMUSE_DENOISER_PARAMS
 _N_PRI = sum(int(np.prod(s)) for s in wts.prior_param_spec().values())      # AMUSE_PRIOR_PARAMS
-PREC = {"fp32": _lib.PREC_F32, "f32": _lib.PREC_F32, "bf16": _lib.PREC_BF16, "fp32x": _lib.PREC_F32X, "f32x": _lib.PREC_F32X}
+# "fp16": the throughput mode on fp16 operands (the bf16 kernels' speed, an eighth of their drift; AMUSE_PREC_F16)
+PREC = {"fp32": _lib.PREC_F32, "f32": _lib.PREC_F32, "bf16": _lib.PREC_BF16, "fp32x": _lib.PREC_F32X, "f32x": _lib.PREC_F32X,
+        "fp16": _lib.PREC_F16, "f16": _lib.PREC_F16}
 QUAT = {"p3d": _lib.QUAT_P3D, "legacy": _lib.QUAT_LEGACY}
 
 
@@ -69,7 +71,7 @@ class HipEngine:
 
     def update_weights(self, denoiser_sd=None, prior_sd=None, what: int = _lib.UPD_ALL):
         """amuse_update_weights: new state dicts (or pre-flattened float32 arrays in state-dict order) into this context;
-        `what` = AMUSE_UPD_* mask (1 fp32 streams, 2 bf16 streams, 8 fp32x streams, 4 prior-encoder streams too).  The current schedule
+        `what` = AMUSE_UPD_* mask (1 fp32 streams, 2 bf16 streams, 8 fp32x streams, 16 fp16 streams, 4 prior-encoder streams too).  The current schedule
         is re-applied after a denoiser update."""
         fp = C.POINTER(C.c_float)
 

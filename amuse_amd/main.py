@@ -116,8 +116,8 @@ def main(argv=None):
     ap.add_argument("--random-init", action="store_true", help="deterministic random-init weights instead of checkpoints")
     ap.add_argument("--sampler", default="ddim", choices=["ddim", "ddpm"])
     ap.add_argument("--steps", type=int, default=None)
-    ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16", "fp32x"],
-                    help="fp32: parity mode; fp32x: the same tolerance 2.5 x faster (split-fp16 MFMA operands); bf16: throughput mode")
+    ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16", "fp32x", "fp16"],
+                    help="fp32: parity mode; fp32x: the same tolerance 2.5 x faster (split-fp16 MFMA operands); bf16 / fp16: throughput modes (fp16: the same speed, 8 x less rounding)")
     ap.add_argument("--device", default="cuda:0")
     ap.add_argument("--gpus", type=int, default=1, help="train_gesture: data-parallel ranks on this node (one process per GPU)")
     ap.add_argument("--epochs", type=int, default=None, help="train_gesture: override TRAIN_PARAM.latent_diffusion.n_epochs")

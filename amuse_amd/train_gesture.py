@@ -387,7 +387,7 @@ class HipInnerSampler:
         self.engine.set_schedule(sch.from_ldm_cfg(ldm_cfg, "ddim") if ldm_cfg and "scheduler" in ldm_cfg else sch.ddim_table())
         self.calls, self.clip_counter, self.sync_ms = 0, 0, []
         self.rank, self.world = rank, world
-        self.what = {"bf16": 2, "fp32x": 8}.get(precision, 1)   # AMUSE_UPD_* mask of the streams this sampler runs
+        self.what = {"bf16": 2, "fp32x": 8, "fp16": 16}.get(precision, 1)   # AMUSE_UPD_* mask of the streams this sampler runs
         self.on_device = os.environ.get("AMUSE_TRAIN_REPACK", "device") != "host"   # A/B switch: the host path of amuse_update_weights
 
     def _den_state(self):

@@ -28,10 +28,10 @@ sys.path.insert(0, str(REPO))
 
 FLOP_PER_CLIP_STEP = 19_120_640          # linears 19,005,440 + attention 115,200
 FLOP_VAE_DECODE_PER_CLIP = 1.76e9
-MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3, "fp32x": 2500.0}   # MI355X_MICROARCH.md chip-level parameters (dense; fp32x = fp16 MFMAs)
-KERNEL_NAME = {"bf16": "k_sample8", "fp32": "k_sample<fp32>", "fp32x": "k_sample<f16x2>"}
+MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "fp16": 2500.0, "fp32": 157.3, "fp32x": 2500.0}   # MI355X_MICROARCH.md chip-level parameters (dense; fp32x = fp16 MFMAs)
+KERNEL_NAME = {"bf16": "k_sample8", "fp16": "k_sample8h", "fp32": "k_sample<fp32>", "fp32x": "k_sample<f16x2>"}
 # L2 -> CU weight stream per denoising step and CU (every CU re-streams the network each step): bytes per parameter of the MFMA stream
-STREAM_MB_PER_STEP = {"bf16": 3.80, "fp32": 7.60, "fp32x": 7.60}
+STREAM_MB_PER_STEP = {"bf16": 3.80, "fp16": 3.80, "fp32": 7.60, "fp32x": 7.60}
 CU_LOAD_BYTES_PER_CLK = 64.0
 
 
@@ -120,7 +120,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--clips", type=int, default=256, help="clips in the whole job (sharded over the ranks)")
     ap.add_argument("--T", type=int, default=1000, help="DDPM steps")
-    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32", "fp32x"])
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp16", "fp32", "fp32x"])
     ap.add_argument("--config", default="sample", choices=["sample", "train"],
                     help="sample: BASELINE configs[2] (the headline metric); train: configs[3] train_gesture data-parallel step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -317,7 +317,7 @@ def main():
             import numpy as np
             gold = np.load(REPO / "tests" / "golden" / "denoiser_steps.npz")
             eps_err = {}
-            for mode in ("fp32x", "fp32", "bf16"):
+            for mode in ("fp32x", "fp32", "bf16", "fp16"):
                 eps_err[mode] = max(float(np.abs(eng.denoise_step(gold["x_t"], t, gold["con"], gold["emo"], gold["sty"], mode).cpu().numpy()
                                                  - gold[f"eps_t{t}"]).max()) for t in (981, 501, 1))
 
@@ -359,9 +359,16 @@ def main():
                                    "fp32_mode": {"ms_per_job": round(ms_f, 3), "frames_per_s": round(B * 300 / ms_f * 1e3, 1), "eps_err": eps_err["fp32"]},
                                    "bf16_eps_err": eps_err["bf16"],
                                    "what": "same clips, DDPM-%d + decode + 6D->axis-angle; eps_err = max |eps_hat - reference golden| at t = 981, 501, 1" % args.T}
+            # fp16 throughput mode: the bf16 mode's kernels built for fp16 MFMA operands (same bytes, same MFMA rate, 11 significand
+            # bits instead of 8) - the same job and the same eps_err measure
+            ms_h, ms_b = time_job("fp16", 3), time_job("bf16", 3)
+            line["fp16_mode"] = {"precision": "fp16", "ms_per_job": round(ms_h, 3), "frames_per_s": round(B * 300 / ms_h * 1e3, 1),
+                                 "eps_err": eps_err["fp16"], "bf16_ms_per_job": round(ms_b, 3), "bf16_eps_err": eps_err["bf16"],
+                                 "what": "k_sample8h + k_vae_fusedh: fp16 operands, fp32 accumulate / softmax / LayerNorm / scheduler; "
+                                         "same job and error measure as parity_mode"}
             # the sampler the reference ships (infer_ldm.py:116-125): DDIM-50, same clips
             eng.set_schedule(sch.ddim_table())
-            dd = {mode: time_job(mode, 5) for mode in ("bf16", "fp32x")}
+            dd = {mode: time_job(mode, 5) for mode in ("bf16", "fp16", "fp32x")}
             line["ddim50"] = {"clips": B, **{f"{m}_ms_per_job": round(v, 3) for m, v in dd.items()},
                               **{f"{m}_frames_per_s": round(B * 300 / v * 1e3, 1) for m, v in dd.items()}}
             eng.set_schedule(sch.ddpm_table(args.T))

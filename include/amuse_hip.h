@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define AMUSE_ABI_VERSION 2   /* 2: AMUSE_PREC_F32X, AMUSE_UPD_F32X; tile-major amuse_debug_gemm; clips per group 1..5 */
+#define AMUSE_ABI_VERSION 2   /* 2: AMUSE_PREC_F32X / _F16, AMUSE_UPD_F32X / _F16; tile-major amuse_debug_gemm; clips per group 1..5 */
 
 /* architecture the kernels are specialised for (configs/diff_latent_v2.json:23-47,
  * configs/prior_emotional_fing.json:6-20, configs/base_new.json "train_pose_framelen") */
@@ -56,8 +56,12 @@ enum { AMUSE_OK = 0, AMUSE_EINVAL = -1, AMUSE_EHIP = -2, AMUSE_ENOMEM = -3, AMUS
  * Range: GEMM operands pass through fp16, so activations and weights must stay below 65504 in magnitude (beyond that the hi
  * piece is infinite) - three orders of magnitude above what this network carries (LayerNorm'd rows, |weights| < 1, latents up to
  * ~150 under DDPM); small values lose nothing: lo pieces below 2^-14 are fp16 subnormals, which the MI355X MFMA keeps.
- * amuse_vae_decode / amuse_vae_encode run the same split arithmetic in their staged kernels (k_vae.hip PREC_F16X2). */
-enum { AMUSE_PREC_F32 = 0, AMUSE_PREC_BF16 = 1, AMUSE_PREC_F32X = 2 };
+ * amuse_vae_decode / amuse_vae_encode run the same split arithmetic in their staged kernels (k_vae.hip PREC_F16X2).
+ * F16: the throughput mode on fp16 instead of bf16 operands - the BF16 mode's kernels (8-wave sampler, fused decoder) built for
+ * v_mfma_f32_16x16x32_f16 / v_cvt_pk_f16_f32: same speed, same bytes, 11 significand bits instead of 8 - about an eighth of the BF16
+ * mode's drift against F32.  Range as for F32X.  Decodes on the fused kernel at every batch size; amuse_vae_encode
+ * runs the BF16 kernels. */
+enum { AMUSE_PREC_F32 = 0, AMUSE_PREC_BF16 = 1, AMUSE_PREC_F32X = 2, AMUSE_PREC_F16 = 3 };
 
 /* matrix -> quaternion convention of the axis-angle epilogue (infer_ldm.py:172):
  * P3D   = pytorch3d >= 0.5 candidate selection, no sign standardisation (what the reference's
@@ -93,11 +97,11 @@ amuse_ctx* amuse_create(int device, const float* denoiser_params, size_t n_denoi
  * Replaces what the reference gets for free from sharing nn.Module parameters between its training step and the
  * in-loop sampler (scripts/trainer.py:411-415: ldm.diffusion_backward + prior.decode on the weights just stepped).
  * Either array may be NULL (left as is).  `what` limits the host-side packing to what the caller will run:
- * AMUSE_UPD_F32 | AMUSE_UPD_BF16 | AMUSE_UPD_F32X = the weight streams of that precision, AMUSE_UPD_ENCODER =
+ * AMUSE_UPD_F32 | AMUSE_UPD_BF16 | AMUSE_UPD_F32X | AMUSE_UPD_F16 = the weight streams of that precision, AMUSE_UPD_ENCODER =
  * MotionPrior.encode's streams too.  Small parameters (biases, LayerNorm, embeddings) are always replaced, so after a partial update only the
  * re-packed precision is valid - running the other one mixes old matrices with new vectors.  Synchronises `stream` first; after a denoiser update the
  * schedule must be set again (the time-token table is a function of the time-embedding weights). */
-enum { AMUSE_UPD_F32 = 1, AMUSE_UPD_BF16 = 2, AMUSE_UPD_ENCODER = 4, AMUSE_UPD_F32X = 8, AMUSE_UPD_ALL = 15 };
+enum { AMUSE_UPD_F32 = 1, AMUSE_UPD_BF16 = 2, AMUSE_UPD_ENCODER = 4, AMUSE_UPD_F32X = 8, AMUSE_UPD_F16 = 16, AMUSE_UPD_ALL = 31 };
 int amuse_update_weights(amuse_ctx* ctx, const float* denoiser_params, size_t n_denoiser, const float* prior_params,
                          size_t n_prior, int what, void* stream);
 /* The same from DEVICE arrays (fp32, state-dict order, as above), stream-ordered on `stream` with no host round trip: every packed

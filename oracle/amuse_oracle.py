@@ -55,15 +55,17 @@ def to_torch(w: Dict[str, np.ndarray], dtype=torch.float32) -> Dict[str, torch.T
 class Ops:
     """Arithmetic policy: fp32/fp64 exact, or bf16-operand emulation of the MFMA GEMMs."""
 
-    def __init__(self, emulate_bf16: bool = False, poly_gelu: bool = False):
+    def __init__(self, emulate_bf16: bool = False, poly_gelu: bool = False, fp16: bool = False):
         self.emu = emulate_bf16
-        self.poly_gelu = poly_gelu   # model of the HIP bf16 mode's FFN activation (gelu_poly below)
+        self.poly_gelu = poly_gelu   # model of the HIP 16-bit modes' FFN activation (gelu_poly below)
+        self.fp16 = fp16             # emulate the fp16 throughput mode (AMUSE_PREC_F16) instead of the bf16 one: operands rounded to
+        #                              fp16, GELU polynomial one degree higher (amuse_dev.hpp gelu_poly4h)
 
     def act(self, x: torch.Tensor) -> torch.Tensor:
-        return gelu_poly(x) if self.poly_gelu else gelu(x)
+        return gelu_poly(x, _GELU_POLY_H if self.fp16 else _GELU_POLY) if self.poly_gelu else gelu(x)
 
     def r(self, x: torch.Tensor) -> torch.Tensor:
-        return x.to(torch.bfloat16).to(x.dtype) if self.emu else x
+        return x.to(torch.float16 if self.fp16 else torch.bfloat16).to(x.dtype) if self.emu else x
 
     def lin(self, x, w, b=None):
         y = self.r(x) @ self.r(w).transpose(-1, -2)
@@ -87,7 +89,12 @@ _GELU_POLY = (7.975201607e-01, -1.319021881e-01, 1.900408231e-02, -1.993848477e-
               -6.815091183e-06, 1.840825661e-07, -2.152084733e-09)
 
 
-def gelu_poly(x):
+# the fp16 mode's polynomial (tools/fit_gelu_poly.py 8 3.0), lowest power first
+_GELU_POLY_H = (7.978953719e-01, -1.328561008e-01, 1.973768137e-02, -2.249475103e-03, 1.923068630e-04, -1.179083301e-05, 4.817333092e-07,
+                -1.159289287e-08, 1.232038360e-10)
+
+
+def gelu_poly(x, coeffs=None):
     """The bf16 sampling kernel's GELU (amuse_amd/csrc/amuse_dev.hpp gelu_poly4), restated so that the block-wise
     bf16 emulation sees the operands the kernel rounds: erf(a / sqrt2) ~ a P(a^2), a = clamp(x, +-3 sqrt2), degree-7
     minimax P (|erf error| <= 8.7e-5, value at the clamp point pinned to 1).  NOT the reference's activation - that is
@@ -95,8 +102,9 @@ def gelu_poly(x):
     x = x.float()
     a = torch.clamp(x, min=-4.24264068711928514641, max=4.24264068711928514641)
     s2 = a * a
-    p = torch.full_like(x, _GELU_POLY[-1])
-    for c in _GELU_POLY[-2::-1]:
+    coeffs = _GELU_POLY if coeffs is None else coeffs
+    p = torch.full_like(x, coeffs[-1])
+    for c in coeffs[-2::-1]:
         p = p * s2 + c
     hx = 0.5 * x
     return hx * (a * p) + hx
@@ -216,10 +224,11 @@ def denoiser_tokens(W, x, t, con, emo, sty) -> torch.Tensor:
     return xs + W["query_pos.pe"][: xs.shape[1], 0][None]
 
 
-def denoiser_forward(W, x, t, con, emo, sty, emulate_bf16=False, taps: Optional[dict] = None):
+def denoiser_forward(W, x, t, con, emo, sty, emulate_bf16=False, taps: Optional[dict] = None, fp16=False):
     """eps_hat = Denoiser(x_t, t, con, emo, sty).  x: (B,128), con/emo/sty: (B,256) or None -> (B,128).
-    emulate_bf16 models the HIP bf16 sampling kernel: bf16 GEMM operands and its polynomial FFN activation."""
-    ops = Ops(emulate_bf16, poly_gelu=emulate_bf16)
+    emulate_bf16 models the HIP bf16 sampling kernel: bf16 GEMM operands and its polynomial FFN activation; with fp16 = True
+    the fp16 throughput mode instead (fp16 operands, its polynomial)."""
+    ops = Ops(emulate_bf16 or fp16, poly_gelu=emulate_bf16 or fp16, fp16=fp16)
     xs = denoiser_tokens(W, x, t, con, emo, sty)
     if taps is not None:
         taps["tokens"] = xs
@@ -371,9 +380,9 @@ def sample_latents(W, sched, con, emo, sty, x_init, step_noise=None, emulate_bf1
 # --------------------------------------------------------------------------------------------
 # VAE decode (vae.py:216-278, encoder_decoder arch, learned PE) and rotation conversions
 # --------------------------------------------------------------------------------------------
-def vae_decode(Wp, z, lengths: Optional[Sequence[int]] = None, emulate_bf16=False, taps: Optional[dict] = None):
+def vae_decode(Wp, z, lengths: Optional[Sequence[int]] = None, emulate_bf16=False, taps: Optional[dict] = None, fp16=False):
     """z: (B,128) -> feats (B,300,333).  Frames >= length are excluded as keys and zeroed on output."""
-    ops = Ops(emulate_bf16, poly_gelu=emulate_bf16)   # the HIP bf16 mode: bf16 GEMM operands + polynomial GELU
+    ops = Ops(emulate_bf16 or fp16, poly_gelu=emulate_bf16 or fp16, fp16=fp16)   # the HIP 16-bit modes: rounded GEMM operands + polynomial GELU
     B = z.shape[0]
     if lengths is None:
         lengths = [N_FRAMES] * B

@@ -36,6 +36,7 @@ namespace amuse {
 hipError_t launch_sample(const SampleArgs&, int, hipStream_t) { return hipSuccess; }
 hipError_t launch_sample8(const SampleArgs&, hipStream_t) { return hipSuccess; }
 hipError_t launch_sample8x(const SampleArgs&, hipStream_t) { return hipSuccess; }
+hipError_t launch_sample8h(const SampleArgs&, hipStream_t) { return hipSuccess; }
 hipError_t launch_time_tokens(const int*, int, const float*, const float*, const float*, const float*, const float*, const float*, float*, hipStream_t) { return hipSuccess; }
 hipError_t launch_cond_tokens(const CondArgs&, hipStream_t) { return hipSuccess; }
 hipError_t launch_repack(const float*, const int*, void*, size_t, int, hipStream_t) { return hipSuccess; }
@@ -44,6 +45,7 @@ hipError_t launch_counter_normal(uint64_t, uint64_t, int, int, int, float*, hipS
 hipError_t launch_vae_rows(const VaeRowsArgs&, int, bool, hipStream_t) { return hipSuccess; }
 hipError_t launch_vae_attn(const VaeAttnArgs&, int, bool, hipStream_t) { return hipSuccess; }
 hipError_t launch_vae_fused(const VaeFusedArgs&, hipStream_t) { return hipSuccess; }
+hipError_t launch_vae_fusedh(const VaeFusedArgs&, hipStream_t) { return hipSuccess; }
 hipError_t launch_smplx_to_feats(const float*, const float*, size_t, float*, hipStream_t) { return hipSuccess; }
 hipError_t launch_vae_latent(const float*, const float*, float*, float*, float*, int, hipStream_t) { return hipSuccess; }
 hipError_t launch_vae_ca(const float*, const float*, const float*, const float*, const float*, float*, int, hipStream_t) { return hipSuccess; }

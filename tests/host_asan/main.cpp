@@ -52,7 +52,7 @@ int main(int argc, char** argv) {
     std::vector<int> lengths(BMAX, 300);
     lengths[3] = 1; lengths[5] = 299;
     for (int B : {1, 2, 3, 5, 64, 128, 129, 256, 513, BMAX})
-        for (int prec : {AMUSE_PREC_F32, AMUSE_PREC_BF16, AMUSE_PREC_F32X}) {
+        for (int prec : {AMUSE_PREC_F32, AMUSE_PREC_BF16, AMUSE_PREC_F32X, AMUSE_PREC_F16}) {
             for (int g = 0; g <= 5; ++g) {
                 REQUIRE(amuse_set_clips_per_group(c, g) == 0);
                 REQUIRE(amuse_sample(c, cond.data(), cond.data(), g & 1 ? nullptr : cond.data(), B, prec, 7, 11, nullptr, nullptr, lat.data(), nullptr, nullptr) == 0);
@@ -85,13 +85,13 @@ int main(int argc, char** argv) {
     fill(den, 3, 0.1f);
     for (int what = 1; what <= AMUSE_UPD_ALL; ++what) {
         const int rc = amuse_update_weights(c, den.data(), den.size(), pri.data(), pri.size(), what, nullptr);
-        REQUIRE((what & (AMUSE_UPD_F32 | AMUSE_UPD_BF16 | AMUSE_UPD_F32X)) ? rc == 0 : rc != 0);   // the encoder streams alone are refused
+        REQUIRE((what & (AMUSE_UPD_F32 | AMUSE_UPD_BF16 | AMUSE_UPD_F32X | AMUSE_UPD_F16)) ? rc == 0 : rc != 0);   // the encoder streams alone are refused
     }
     REQUIRE(amuse_update_weights(c, den.data(), den.size(), nullptr, 0, AMUSE_UPD_BF16, nullptr) == 0);
     REQUIRE(amuse_update_weights(c, nullptr, 0, pri.data(), pri.size(), AMUSE_UPD_ALL, nullptr) == 0);
     REQUIRE(amuse_update_weights(c, den.data(), 5, nullptr, 0, AMUSE_UPD_ALL, nullptr) != 0);
     // the device re-pack: builds the gather maps (three probe runs of both builders through the capture hook) on its first call
-    for (int what : {2, 7, 1, 6, 8, 15}) REQUIRE(amuse_update_weights_device(c, den.data(), pri.data(), what, nullptr) == 0);
+    for (int what : {2, 7, 1, 6, 8, 15, 16, 31}) REQUIRE(amuse_update_weights_device(c, den.data(), pri.data(), what, nullptr) == 0);
     REQUIRE(amuse_update_weights_device(c, den.data(), nullptr, 2, nullptr) == 0);
     REQUIRE(amuse_update_weights_device(c, nullptr, nullptr, 2, nullptr) != 0);
     REQUIRE(amuse_update_weights_device(c, den.data(), pri.data(), 4, nullptr) != 0);

@@ -1,4 +1,4 @@
-"""Race hunt: the 8-wave sampling kernels (bf16 k_sample8, fp32x k_sample8x) must reproduce themselves bitwise, launch after launch, for every tiling
+"""Race hunt: the 8-wave sampling kernels (bf16 k_sample8, its fp16 build k_sample8h, fp32x k_sample8x) must reproduce themselves bitwise, launch after launch, for every tiling
 (a data race between its alternating wave groups would show up as a flaky mismatch); so must the fused decode kernel and the
 audio front-end (DMA rings, hand-counted waits)."""
 import sys
@@ -16,7 +16,7 @@ for T, tab in ((100, sch.ddpm_table(100)), (50, sch.ddim_table())):
     for B, G in ((1, 0), (7, 1), (7, 2), (7, 3), (256, 0), (512, 0), (768, 0), (1000, 3)):
         c, e, s = (torch.randn(B, 256, generator=gen).cuda() for _ in range(3))
         eng.set_clips_per_group(G)
-        for prec, reps in (("bf16", 24), ("fp32x", 12)):
+        for prec, reps in (("bf16", 24), ("fp16", 12), ("fp32x", 12)):
             ref = eng.sample(c, e, s, prec, seed=5).clone()
             n = 0
             for _ in range(reps):
@@ -32,6 +32,10 @@ ref = eng.vae_decode(z, None, "bf16")["poses"].clone()
 n = sum(int(not torch.equal(eng.vae_decode(z, None, "bf16")["poses"], ref)) for _ in range(16))
 bad += n
 print(f"fused decode, 300 clips: {n} mismatching launches of 16; finite={bool(torch.isfinite(ref).all())}", flush=True)
+ref = eng.vae_decode(z, None, "fp16")["poses"].clone()
+n = sum(int(not torch.equal(eng.vae_decode(z, None, "fp16")["poses"], ref)) for _ in range(16))
+bad += n
+print(f"fused decode (fp16 build), 300 clips: {n} mismatching launches of 16; finite={bool(torch.isfinite(ref).all())}", flush=True)
 eng.set_decode_path("auto")
 # the fp32x decode / encode (staged kernels, split-fp16 fragment images)
 ref = eng.vae_decode(z, [300] * 299 + [123], "fp32x")["poses"].clone()
