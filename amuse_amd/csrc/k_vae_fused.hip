@@ -419,8 +419,9 @@ __device__ __forceinline__ void decoder_block(f32x4 (&x)[NT][kTiles], Stager& sg
             for (int j = 0; j < NT; ++j) qb[j] = OP_PACK(q[j][0] * kQScale, q[j][1] * kQScale);
         }
         FSTAMP(5);   // q
-        // attention, one 16-query tile per iteration of a RUNTIME loop: the tile's q operand is qb[0] and its output enters
-        // ob[] from the top while both arrays rotate by one position per iteration (register moves instead of indexing).
+        // attention, one 16-query tile per iteration of a RUNTIME loop over ONE rotating array: the tile's q operand leaves
+        // at the front (ob[0]) and its output enters at the back, so after NT iterations ob[] holds the outputs in tile order
+        // (register moves instead of indexing; a second array for the outputs would cost NT more live operands).
         // The loop body is the attention's only copy in the instruction stream (see the note on code size at the kernel).
         OPV ob[NT][1];
 #pragma unroll
@@ -429,12 +430,9 @@ __device__ __forceinline__ void decoder_block(f32x4 (&x)[NT][kTiles], Stager& sg
             const uint4* Vq = reinterpret_cast<const uint4*>(Vt);
 #pragma unroll 1
             for (int j = 0; j < NT; ++j) {
-                const OPV o1 = attend(Kb, Vq, qb[0], len, g, r);
+                const OPV o1 = attend(Kb, Vq, ob[0][0], len, g, r);
 #pragma unroll
-                for (int jj = 0; jj + 1 < NT; ++jj) {
-                    qb[jj] = qb[jj + 1];
-                    ob[jj][0] = ob[jj + 1][0];
-                }
+                for (int jj = 0; jj + 1 < NT; ++jj) ob[jj][0] = ob[jj + 1][0];
                 ob[NT - 1][0] = o1;
             }
             FSTAMP(7);   // attention of the five tiles
@@ -602,7 +600,7 @@ __device__ __forceinline__ void decode_tiles(const VaeFusedArgs& a, char* smem, 
         const bool keep = frame < kFrames && frame < len;   // output[~mask.T] = 0 (vae.py:274)
         const int rows_here = min(16, kFrames - 16 * tile);   // <= 0 for the padding tile
         const size_t row0 = (size_t)b * kFrames + 16 * tile;
-#pragma unroll
+#pragma unroll 1
         for (int half = 0; half < 2; ++half) {   // 12 output tiles = 48 units = 3 stages (k-pair outer, output tile inner)
             f32x4 f[12];
 #pragma unroll

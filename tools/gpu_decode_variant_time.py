@@ -1,5 +1,5 @@
 """A/B timing of the fused decode kernel across libamuse_hip*.so variants on ONE box (each variant in its own process,
-AMUSE_HIP_LIB), three rounds.  Usage: python tools/gpu_decode_variant_time.py [clips ...]"""
+AMUSE_HIP_LIB), two rounds; the bracketed word is a checksum of the poses (equal = bitwise-equal variants).  Usage: python tools/gpu_decode_variant_time.py [clips ...]"""
 import glob, os, subprocess, sys
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if len(sys.argv) > 1 and sys.argv[1] == "--child":
@@ -18,7 +18,8 @@ if len(sys.argv) > 1 and sys.argv[1] == "--child":
             e0.record(); eng.vae_decode(z, None, "bf16"); e1.record(); torch.cuda.synchronize()
             if i >= 2:
                 ts.append(e0.elapsed_time(e1))
-        out.append(f"B={B}: min {min(ts):.3f} med {sorted(ts)[2]:.3f} ms")
+        h = int(eng.vae_decode(z, None, "bf16")["poses"].view(torch.int32).to(torch.int64).sum().item()) & 0xffffffff
+        out.append(f"B={B}: min {min(ts):.3f} med {sorted(ts)[2]:.3f} ms [{h:08x}]")
     print("  ".join(out))
 else:
     clips = sys.argv[1:] or ["1", "256"]

@@ -24,7 +24,7 @@ timeout 200 python tools/gpu_fp32x_perf.py 1 256 768 > $O/fp32x_perf.txt 2>&1
 timeout 100 python tools/gpu_phase_profile8.py 256 fp32x > $O/phase8x.txt 2>&1
 # decode: kernel stats + counters of the fused kernel at 256 clips
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/decode_stats -- python3 tools/gpu_decode_perf.py 256 > $O/decode_stats.log 2>&1
-for grp in FETCH_SIZE WRITE_SIZE "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_ANY" "SQ_INSTS_MFMA SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE"; do
+for grp in FETCH_SIZE WRITE_SIZE "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_ANY" "SQ_INSTS_MFMA SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE" "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA SQ_BUSY_CU_CYCLES" "SQ_INSTS_VALU_TRANS_F32 SQ_INSTS_VALU_FMA_F32 SQ_INSTS_VALU_MUL_F32 SQ_INSTS_VALU_ADD_F32"; do
   n=$(echo $grp | cut -d' ' -f1)
   timeout 300 rocprofv3 --pmc $grp --kernel-trace --output-format csv -d $O/dpmc_$n -- python3 tools/gpu_decode_perf.py 256 > $O/dpmc_$n.log 2>&1
 done
