@@ -140,12 +140,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     f32x4 acc[FX][4];   // [feature fragment][token fragment]
     // one k-step: xc = this stage's X fragments (registers), xn receives the next stage's
     // swapped: the X fragment is the MFMA's A operand, so a lane ends up with 4 consecutive TOKENS of one feature (the V^T tiles)
-    auto half = [&](auto relaxed, auto swapped, bf16x8 (&xc)[4], bf16x8 (&xn)[4], int bias_tile) {
-        constexpr int WAITN = PW * (NSLOT - 2) + (decltype(relaxed)::value ? SN : 0);
-        static_assert(WAITN < 64, "vmcnt is a 6-bit counter");
+    // relaxed (wave-uniform, runtime): the stage waits with the epilogue's stores still in flight.  A branch around the two forms of
+    // the wait and nothing else: as separate instantiations of the whole k-step (strict for the first tile, relaxed behind an
+    // epilogue) the paths met at the k loop with the 32 W-fragment registers allocated differently, and hipcc reconciled them
+    // through scratch - 18 to 34 spilled registers per kernel, reloaded behind a full vmcnt wait once per tile.
+    auto half = [&](bool relaxed, auto swapped, bf16x8 (&xc)[4], bf16x8 (&xn)[4], int bias_tile) {
+        constexpr int WAITN = PW * (NSLOT - 2);
+        static_assert(WAITN + SN < 64, "vmcnt is a 6-bit counter");
         // this wave's pieces of the NEXT stage have landed (the NSLOT - 2 younger stages may still fly) and its reads of this stage are in
         // registers; behind the barrier that holds for every wave: the next stage is complete, this stage's slot is free
-        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(WAITN) : "memory");
+        if (SN > 0 && relaxed) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(WAITN + SN) : "memory");
+        else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(WAITN) : "memory");
         if (bias_tile >= 0 && wave == 0)   // (every wave's epilogue reads of the previous tile's bias are in front of this barrier)
             glds16s(a.bias + (size_t)bias_tile * TN, (lane % (TN / 4)) * 16, lds0 + kOffBias);   // (TN = 128: the upper lanes repeat the lower half)
         const char* sl = smem + r_slot * STAGE + lane * 16;
@@ -172,25 +177,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             for (int y = 0; y < 4; ++y) acc[x][y] = splat4(0.f);
         const bool vt_tile = EPI == EPI_QKV && tn >= 2 * kAstDim / TN;   // (uniform)
         if (EPI == EPI_QKV && vt_tile) {
-            half(std::false_type{}, std::true_type{}, xa, xb, tn);
-            half(std::false_type{}, std::true_type{}, xb, xa, -1);
 #pragma unroll 1
-            for (int kp = 2; kp < nk; kp += 2) {
-                half(std::false_type{}, std::true_type{}, xa, xb, -1);
-                half(std::false_type{}, std::true_type{}, xb, xa, -1);
+            for (int kp = 0; kp < nk; kp += 2) {
+                half(false, std::true_type{}, xa, xb, kp == 0 ? tn : -1);
+                half(false, std::true_type{}, xb, xa, -1);
             }
         } else {
-            if (first || SN == 0) {
-                half(std::false_type{}, std::false_type{}, xa, xb, tn);
-                half(std::false_type{}, std::false_type{}, xb, xa, -1);
-            } else {
-                half(std::true_type{}, std::false_type{}, xa, xb, tn);
-                half(std::true_type{}, std::false_type{}, xb, xa, -1);
-            }
 #pragma unroll 1
-            for (int kp = 2; kp < nk; kp += 2) {
-                half(std::false_type{}, std::false_type{}, xa, xb, -1);
-                half(std::false_type{}, std::false_type{}, xb, xa, -1);
+            for (int kp = 0; kp < nk; kp += 2) {
+                const bool relaxed = kp == 0 && !first;   // the two stages behind an epilogue
+                half(relaxed, std::false_type{}, xa, xb, kp == 0 ? tn : -1);
+                half(relaxed, std::false_type{}, xb, xa, -1);
             }
         }
         first = false;

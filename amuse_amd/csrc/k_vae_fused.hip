@@ -97,6 +97,18 @@ static_assert(kWaves * 16 * kQStride * 4 <= 2 * kKvBytes, "staging tiles must fi
 #ifndef AMUSE_FPROF
 #define AMUSE_FPROF 0
 #endif
+// weight fragments are read from the LDS ring this many units ahead of their MFMAs
+#ifndef AMUSE_F_PF
+#define AMUSE_F_PF 2
+#endif
+// FFN stage scheduling (A/B): 0 as hipcc orders it; bit 0: linear1's MFMAs interleaved with the GELU; bit 1: the 2-tile waves run
+// linear1 last
+#ifndef AMUSE_F_FFN_MIX
+#define AMUSE_F_FFN_MIX 0
+#endif
+#ifndef AMUSE_F_FFN_VALU
+#define AMUSE_F_FFN_VALU 9
+#endif
 // 1: the LayerNorms unrolled over a wave's tiles instead of a runtime loop with rotating registers (A/B)
 #ifndef AMUSE_F_LN_UNROLL
 #define AMUSE_F_LN_UNROLL 0
@@ -152,13 +164,27 @@ __device__ __forceinline__ OPV wfrag(const Stager& s, int u) {
     return __builtin_bit_cast(OPV, *reinterpret_cast<const uint4*>(s.ring + s.ridx * kStageBytes + u * 1024));
 }
 
+// f(u, fragment) for the units U0 .. U0 + NU - 1 of the current stage, the fragments read AMUSE_F_PF units ahead of their use.
+// (Left to hipcc, a unit loop recycles ONE fragment register: read, wait for the whole LDS round trip, MFMAs, next read - the
+// k,v stage ran at a third of its MFMA rate that way.)
+template <int NU, int U0, class F>
+__device__ __forceinline__ void for_units(const Stager& s, F&& f) {
+    constexpr int PF = AMUSE_F_PF < NU ? AMUSE_F_PF : NU;
+    OPV wf[PF];
+#pragma unroll
+    for (int u = 0; u < PF; ++u) wf[u] = wfrag(s, U0 + u);
+#pragma unroll
+    for (int u = 0; u < NU; ++u) {
+        const OPV cur = wf[u % PF];
+        if (u + PF < NU) wf[u % PF] = wfrag(s, U0 + u + PF);
+        f(u, cur);
+    }
+}
+
 // acc[j][o] += W_o . x_j for the NT row tiles of this wave; units U0.. of the current stage, k-pair outer, output tile inner
 template <int NT, int NO, int NC, int U0>
 __device__ __forceinline__ void gemm5(f32x4 (&acc)[NT][NO], const OPV (&xb)[NT][NC], const Stager& s) {
     // fragments are read two ahead of their MFMAs (a read waited for on the spot costs an LDS round trip per unit)
-#ifndef AMUSE_F_PF
-#define AMUSE_F_PF 2
-#endif
     constexpr int NU = NO * NC, PF = AMUSE_F_PF;
     OPV wf[NU < PF ? NU : PF];
 #pragma unroll
@@ -272,10 +298,13 @@ __device__ __forceinline__ OPV attend(const uint4* Kb, const uint4* Vt, OPV qb, 
         f32x4 p[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
+            // (key tile 19 = keys 304..319 lies beyond every sequence - kFrames = 300 -: its probabilities are 0 without asking the
+            // quarter-rate exponential; the mask above has set its scores to -inf, which the row maximum ignores)
+            const bool beyond = 64 * ch + 16 * i >= kFrames;
 #pragma unroll
             for (int m = 0; m < 4; ++m) {
                 if constexpr ((AMUSE_FABL & 8) != 0) p[i][m] = st[i][m];
-                else p[i][m] = __builtin_amdgcn_exp2f(st[i][m]);
+                else p[i][m] = beyond ? 0.f : __builtin_amdgcn_exp2f(st[i][m]);
             }
         }
 #pragma unroll
@@ -331,16 +360,11 @@ __device__ __forceinline__ void decoder_block(f32x4 (&x)[NT][kTiles], Stager& sg
 #pragma unroll
         for (int s4 = 0; s4 < 4; ++s4) {
             stage_fetch(sg);
+            for_units<2 * kTiles, 0>(sg, [&](int u, OPV wf) {
+                const int c = 2 * (s4 & 1) + u / kTiles, o = u % kTiles;
 #pragma unroll
-            for (int cc = 0; cc < 2; ++cc) {
-                const int c = 2 * (s4 & 1) + cc;
-#pragma unroll
-                for (int o = 0; o < kTiles; ++o) {
-                    const OPV wf = wfrag(sg, cc * kTiles + o);
-#pragma unroll
-                    for (int j = 0; j < NT; ++j) x[j][o] = OP_MFMA(wf, s4 < 2 ? xb[j][c] : sb[j][c], x[j][o]);
-                }
-            }
+                for (int j = 0; j < NT; ++j) x[j][o] = OP_MFMA(wf, s4 < 2 ? xb[j][c] : sb[j][c], x[j][o]);
+            });
             stage_end(sg);
         }
     }
@@ -368,21 +392,14 @@ __device__ __forceinline__ void decoder_block(f32x4 (&x)[NT][kTiles], Stager& sg
                 kk[j][0] = bk0; kk[j][1] = bk1;
                 vv[j][0] = splat4(bv0); vv[j][1] = splat4(bv1);
             }
+            for_units<16, 0>(sg, [&](int u, OPV wf) {   // stream: per k-pair c: k tiles (2), v tiles (2)
+                const int c = u >> 2, t = u & 3;
 #pragma unroll
-            for (int c = 0; c < 4; ++c) {   // stream: per k-pair c: k tiles (2), v tiles (2)
-#pragma unroll
-                for (int o = 0; o < 2; ++o) {
-                    const OPV wf = wfrag(sg, 4 * c + o);
-#pragma unroll
-                    for (int j = 0; j < NT; ++j) kk[j][o] = OP_MFMA(wf, xb[j][c], kk[j][o]);
+                for (int j = 0; j < NT; ++j) {
+                    if (t < 2) kk[j][t] = OP_MFMA(wf, xb[j][c], kk[j][t]);
+                    else vv[j][t - 2] = OP_MFMA(xb[j][c], wf, vv[j][t - 2]);   // operand-swapped: V^T
                 }
-#pragma unroll
-                for (int o = 0; o < 2; ++o) {
-                    const OPV wf = wfrag(sg, 4 * c + 2 + o);
-#pragma unroll
-                    for (int j = 0; j < NT; ++j) vv[j][o] = OP_MFMA(xb[j][c], wf, vv[j][o]);  // operand-swapped: V^T
-                }
-            }
+            });
 #pragma unroll
             for (int j = 0; j < NT; ++j) {
                 const int tile = tile0 + 4 * j;
@@ -489,10 +506,36 @@ __device__ __forceinline__ void decoder_block(f32x4 (&x)[NT][kTiles], Stager& sg
         for (int j = 0; j < NT; ++j) { nxt[j][0] = b0; nxt[j][1] = b1; }
         OPV hb[NT][1];
         if constexpr (!(AMUSE_FABL & 4)) {
+#if AMUSE_F_FFN_MIX
+            // The two waves of a SIMD run this stage in lock step (same barrier, same code): MFMA clusters of both, then the GELU
+            // VALU of both - the matrix pipe idles through one, the VALU through the other.  So (a) within a wave linear1's
+            // MFMAs (next chunk, independent of this chunk's GELU) are issued one at a time between groups of GELU VALU
+            // instructions, and (b) the 2-tile waves run the stage in the other order (GELU + linear2 first, linear1 last), which
+            // puts their MFMA cluster beside the 3-tile waves' VALU tail.
+            constexpr bool kL1Last = (AMUSE_F_FFN_MIX & 2) && NT == 2;
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (!kL1Last) gemm5<NT, 2, 4, 0>(nxt, xb, sg);
+#pragma unroll
+            for (int j = 0; j < NT; ++j) hb[j][0] = OP_PACK(OP_GELU(hid[j][0]), OP_GELU(hid[j][1]));
+            if constexpr (!kL1Last) {
+#pragma unroll
+                for (int i = 0; i < 8 * NT; ++i) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                  // 1 MFMA
+                    __builtin_amdgcn_sched_group_barrier(0x002, AMUSE_F_FFN_VALU, 0);   // its share of the GELU
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            gemm5<NT, kTiles, 1, 8>(x, hb, sg);
+            if constexpr (kL1Last) {
+                __builtin_amdgcn_sched_barrier(0);
+                gemm5<NT, 2, 4, 0>(nxt, xb, sg);
+            }
+#else
             gemm5<NT, 2, 4, 0>(nxt, xb, sg);   // linear1 of the next chunk: MFMAs that do not depend on ...
 #pragma unroll
             for (int j = 0; j < NT; ++j) hb[j][0] = OP_PACK(OP_GELU(hid[j][0]), OP_GELU(hid[j][1]));   // ... this VALU
             gemm5<NT, kTiles, 1, 8>(x, hb, sg);
+#endif
         }
 #pragma unroll
         for (int j = 0; j < NT; ++j) { hid[j][0] = nxt[j][0]; hid[j][1] = nxt[j][1]; }
@@ -608,11 +651,10 @@ __device__ __forceinline__ void decode_tiles(const VaeFusedArgs& a, char* smem, 
 #pragma unroll
             for (int s3 = 0; s3 < 3; ++s3) {
                 stage_fetch(sg);
-#pragma unroll
-                for (int u = 0; u < kStage; ++u) {
+                for_units<kStage, 0>(sg, [&](int u, OPV wf) {
                     const int lin = kStage * s3 + u, c = lin / 12, o = lin - 12 * c;
-                    f[o] = OP_MFMA(wfrag(sg, u), xb1[c], f[o]);
-                }
+                    f[o] = OP_MFMA(wf, xb1[c], f[o]);
+                });
                 stage_end(sg);
             }
 #pragma unroll
