@@ -545,7 +545,7 @@ int build_prior(amuse_ctx* c, const float* pri, int what = AMUSE_UPD_ALL) {
             for (int half = 0; half < 2; ++half)
                 pack_gemm(s, p16, Pp.get("final_layer.weight"), kFeats, 128, range(12 * half, 12 * half + 12), range(0, 8));
         if (s.size() % ((size_t)kVaeFusedStageUnits * 64) != 0) return fail(AMUSE_ESTATE, "internal: fused decode stream is not whole stages");
-        pad(5 * kVaeFusedStageUnits);   // the fetch runs up to four stages ahead (k_vae_fused.hip: stage protocol)
+        pad(2 * kVaeFusedStageUnits);   // the fetch runs two stages ahead
         if (upload(p16 == PREC_BF16 ? &c->vae_wf : &c->vae_wfh, s.data(), s.size() * sizeof(uint4))) return AMUSE_EHIP;
     }
     {

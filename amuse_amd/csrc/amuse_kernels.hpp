@@ -131,8 +131,8 @@ struct VaeAttnArgs {
 };
 hipError_t launch_vae_attn(const VaeAttnArgs& a, int precision, bool enc, hipStream_t stream);
 // ---------------------------------------------------------------- fused decode (k_vae_fused.hip): one workgroup per clip
-constexpr int kVaeFusedStageUnits = 16;   // the weight stream is consumed in 16 KiB stages (LDS-DMA ring of six, fetched up to four stages ahead)
-constexpr int kVaeFusedLdsBytes = 40960 + 6 * 16384 + 2 * 8192 + 5120;   // K/V images | weight ring | block params | ca
+constexpr int kVaeFusedStageUnits = 16;   // the weight stream is consumed in 16 KiB stages (LDS-DMA ring of three)
+constexpr int kVaeFusedLdsBytes = 40960 + 3 * 16384 + 2 * 8192 + 5120;   // K/V images of one head | weight ring | block params | ca
 struct VaeFusedArgs {
     const uint4* wstream;      // bf16 stream in consumption order, whole stages (amuse_api.hip), shared by the 4 waves
     const float* pvec;         // decoder small params, PV_* layout

@@ -27,7 +27,7 @@
 //     last stage - is therefore a RUNTIME loop over the tiles whose body works on tile slot 0 while the register arrays
 //     rotate by one slot per iteration (moves instead of dynamic register indexing).
 //   * the other cross-wave traffic is K_h and V_h^T of the current head: written to LDS as ready MFMA fragments (one
-//     ds_write_b128 / two ds_write_b64 per row tile), double-buffered over heads; the barrier that ends the k,v stage
+//     ds_write_b128 / two ds_write_b64 per row tile); the barrier that ends the k,v stage
 //     publishes them.  Scores S^T = K.Q^T and O^T = V^T.P^T run on v_mfma_f32_16x16x32_bf16 with the softmax along
 //     registers, two query tiles at a time on shared K / V fragments; the attention output of head h is, unchanged, the B
 //     operand of out_proj's k-slice h, accumulated straight into the residual registers.
@@ -75,7 +75,7 @@ constexpr int kPairs = kKeyRows / 32;     // 10 key-tile pairs
 constexpr int kKvBytes = kKeyRows * 64 + kPairs * 2 * 16 * 64;   // K fragments 20 KiB + V^T fragments 20 KiB
 constexpr int kStage = kVaeFusedStageUnits;                      // 16 units = 16 KiB per stage
 constexpr int kStageBytes = kStage * 1024;
-constexpr int kWBufs = 6;                 // weight ring: see the stage protocol at stage_fetch
+constexpr int kWBufs = 3;
 constexpr int kPvSlot = 8192;             // one block's small parameters (7,680 B) rounded up to whole DMA pieces
 constexpr int kCaBytes = 5120;            // [9][128] floats rounded up to whole DMA pieces
 constexpr int kQStride = 100;            // staging row stride (floats) of one 96-feature quarter (16 joints) of the last stage
@@ -108,12 +108,6 @@ static_assert(4 * 16 * kQStride * 4 <= kKvBytes, "staging tiles must fit the K/V
 #endif
 #ifndef AMUSE_F_FFN_VALU
 #define AMUSE_F_FFN_VALU 9
-#endif
-// 1: the FFN's middle stages two per barrier (seven double steps instead of fourteen stages).  Measured: no difference
-// (profiles/r03_decode_fused_valu_ab.txt) - the waits at the stage barriers are the SIMD's other wave finishing work that has to be
-// done anyway, not idle time - so the simpler loop stays.  The ring and the protocol carry both.
-#ifndef AMUSE_F_DOUBLE
-#define AMUSE_F_DOUBLE 0
 #endif
 // 1: the LayerNorms unrolled over a wave's tiles instead of a runtime loop with rotating registers (A/B)
 #ifndef AMUSE_F_LN_UNROLL
@@ -160,17 +154,12 @@ __device__ __forceinline__ void stage_fetch(Stager& s) {
     s.src += kStage * 64;
     s.widx = s.widx == kWBufs - 1 ? 0 : s.widx + 1;
 }
-// Stage protocol.  Invariant at the barrier in front of stage t: stages t and t + 1 are complete in the ring (every wave's pieces)
-// and stage t + 2 has been fetched.  A SINGLE stage t fetches stage t + 3 and ends with vmcnt(2): everything but those two pieces has
-// landed - t + 2 included.  A DOUBLE step (the FFN: stages t, t + 1 behind ONE barrier - half the barriers of the phase) fetches t + 3
-// and t + 4 at its start and ends with the same vmcnt(2): t + 3 has had the whole step to land.  Buffers in use at once: t, t + 1
-// (read), t + 2 (landed), t + 3, t + 4 (in flight) - five of the ring's six.
+// end of a stage: all of this wave's DMA except the two pieces of the fetch issued in this stage has landed, its LDS reads
+// and writes are done; after the barrier that holds for every wave - the next stage's buffer is complete, this stage's is free
 __device__ __forceinline__ void stage_end(Stager& s) {
     asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)\n\ts_barrier" ::: "memory");
     s.ridx = s.ridx == kWBufs - 1 ? 0 : s.ridx + 1;
 }
-// between the two stages of a double step: the reads move on to the next buffer, no barrier
-__device__ __forceinline__ void stage_next(Stager& s) { s.ridx = s.ridx == kWBufs - 1 ? 0 : s.ridx + 1; }
 __device__ __forceinline__ OPV wfrag(const Stager& s, int u) {
     return __builtin_bit_cast(OPV, *reinterpret_cast<const uint4*>(s.ring + s.ridx * kStageBytes + u * 1024));
 }
@@ -389,7 +378,7 @@ __device__ __forceinline__ void decoder_block(f32x4 (&x)[NT][kTiles], Stager& sg
     constexpr float kQScale = 0.17677669529663687f * 1.44269504088896340736f;  // 1/sqrt(32) * log2(e): softmax in exp2
 #pragma unroll 1
     for (int h = 0; h < kHeads; ++h) {
-        char* buf = kv;   // one image: the barrier that ends stage B of head h - 1 is behind every wave's last read of it
+        char* buf = kv;   // ONE image: the barrier that ends stage B of head h - 1 is behind every wave's last read of it
         uint4* Kb = reinterpret_cast<uint4*>(buf);
         char* Vt = buf + kKeyRows * 64;
         // ---- stage A: k, v of this head for the wave's rows -> LDS fragment images (published by the stage's barrier)
@@ -508,21 +497,26 @@ __device__ __forceinline__ void decoder_block(f32x4 (&x)[NT][kTiles], Stager& sg
         stage_end(sg);
         FSTAMP(11);   // FFN prologue stage
     }
-    // one stream stage: linear1 of chunk c + 1 (units 0..7) -> nxt, linear2 of chunk c (units 8..15) on GELU(cur)
-    auto ffn_stage = [&](const f32x4 (&cur)[NT][2], f32x4 (&nxt)[NT][2], int c) {
+#pragma unroll 1
+    for (int c = 0; c < 15; ++c) {
+        stage_fetch(sg);
+        f32x4 nxt[NT][2];
         const f32x4 b0 = ld4(pv + PV_L1_B + 32 * (c + 1) + 4 * g), b1 = ld4(pv + PV_L1_B + 32 * (c + 1) + 16 + 4 * g);
 #pragma unroll
         for (int j = 0; j < NT; ++j) { nxt[j][0] = b0; nxt[j][1] = b1; }
         OPV hb[NT][1];
         if constexpr (!(AMUSE_FABL & 4)) {
 #if AMUSE_F_FFN_MIX
-            // (A/B, not adopted: linear1's MFMAs issued one at a time between groups of GELU instructions, and - bit 1 - the 2-tile
-            // waves running linear1 last.  No gain: beside a busy matrix pipe the VALU gets two issue slots per MFMA)
+            // The two waves of a SIMD run this stage in lock step (same barrier, same code): MFMA clusters of both, then the GELU
+            // VALU of both - the matrix pipe idles through one, the VALU through the other.  So (a) within a wave linear1's
+            // MFMAs (next chunk, independent of this chunk's GELU) are issued one at a time between groups of GELU VALU
+            // instructions, and (b) the 2-tile waves run the stage in the other order (GELU + linear2 first, linear1 last), which
+            // puts their MFMA cluster beside the 3-tile waves' VALU tail.
             constexpr bool kL1Last = (AMUSE_F_FFN_MIX & 2) && NT == 2;
             __builtin_amdgcn_sched_barrier(0);
             if constexpr (!kL1Last) gemm5<NT, 2, 4, 0>(nxt, xb, sg);
 #pragma unroll
-            for (int j = 0; j < NT; ++j) hb[j][0] = OP_PACK(OP_GELU(cur[j][0]), OP_GELU(cur[j][1]));
+            for (int j = 0; j < NT; ++j) hb[j][0] = OP_PACK(OP_GELU(hid[j][0]), OP_GELU(hid[j][1]));
             if constexpr (!kL1Last) {
 #pragma unroll
                 for (int i = 0; i < 8 * NT; ++i) {
@@ -539,48 +533,22 @@ __device__ __forceinline__ void decoder_block(f32x4 (&x)[NT][kTiles], Stager& sg
 #else
             gemm5<NT, 2, 4, 0>(nxt, xb, sg);   // linear1 of the next chunk: MFMAs that do not depend on ...
 #pragma unroll
-            for (int j = 0; j < NT; ++j) hb[j][0] = OP_PACK(OP_GELU(cur[j][0]), OP_GELU(cur[j][1]));   // ... this VALU
+            for (int j = 0; j < NT; ++j) hb[j][0] = OP_PACK(OP_GELU(hid[j][0]), OP_GELU(hid[j][1]));   // ... this VALU
             gemm5<NT, kTiles, 1, 8>(x, hb, sg);
 #endif
         }
-    };
-    f32x4 nxt[NT][2];
-#if AMUSE_F_DOUBLE
-    // 14 of the 15 middle stages as seven DOUBLE steps (one barrier per two stages; the chunks alternate between hid and nxt)
-#pragma unroll 1
-    for (int c = 0; c < 14; c += 2) {
-        stage_fetch(sg);
-        stage_fetch(sg);
-        ffn_stage(hid, nxt, c);
-        stage_next(sg);
-        ffn_stage(nxt, hid, c + 1);
-        FSTAMP(12);   // FFN double step compute
-        stage_end(sg);
-        FSTAMP(13);   // FFN double step barrier
-    }
-    stage_fetch(sg);
-    ffn_stage(hid, nxt, 14);
-    stage_end(sg);
-#else
-#pragma unroll 1
-    for (int c = 0; c < 15; ++c) {
-        stage_fetch(sg);
-        ffn_stage(hid, nxt, c);
 #pragma unroll
         for (int j = 0; j < NT; ++j) { hid[j][0] = nxt[j][0]; hid[j][1] = nxt[j][1]; }
         FSTAMP(12);   // FFN stage compute
         stage_end(sg);
         FSTAMP(13);   // FFN stage barrier
     }
-#pragma unroll
-    for (int j = 0; j < NT; ++j) { nxt[j][0] = hid[j][0]; nxt[j][1] = hid[j][1]; }
-#endif
     {
         stage_fetch(sg);
         OPV hb[NT][1];
         if constexpr (!(AMUSE_FABL & 4)) {
 #pragma unroll
-            for (int j = 0; j < NT; ++j) hb[j][0] = OP_PACK(OP_GELU(nxt[j][0]), OP_GELU(nxt[j][1]));
+            for (int j = 0; j < NT; ++j) hb[j][0] = OP_PACK(OP_GELU(hid[j][0]), OP_GELU(hid[j][1]));
             gemm5<NT, kTiles, 1, 0>(x, hb, sg);
         }
         stage_end(sg);
@@ -740,7 +708,6 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     sg.ring = smem + kOffW + lane * 16;
     sg.widx = 0;
     sg.ridx = 0;
-    stage_fetch(sg);
     stage_fetch(sg);
     stage_fetch(sg);
     if (wave < 4) decode_tiles<3, TAP>(a, smem, sg, wave, b, len, wave, lane);
