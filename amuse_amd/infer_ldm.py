@@ -52,7 +52,7 @@ class PretrainedLPDM_v1:
         self.audio_encoder = audio_encoder
         self.audio_engine: Optional[AudioEngine] = None
         self.engine: Optional[HipEngine] = None
-        self.precision = "fp32"         # "fp32" = parity mode, "fp32x" = the same bars on the fp16 MFMA (2.5 x faster), "bf16" = throughput mode
+        self.precision = "fp32"         # "fp32" = parity mode, "fp32x" = the same bars on the fp16 MFMA (2.5 x faster), "bf16" / "fp16" = throughput modes
         self.sampler = "ddim"           # "ddim" (the reference's entry point) or "ddpm" (BASELINE configs 2/3)
         self.quat_mode = "p3d"
         self.seed = 2024                # configs/base_new.json TRAIN_PARAM.seed, scripts/main.py:78

@@ -295,7 +295,7 @@ def test_in_kernel_noise_is_shard_invariant(env):
     gen = torch.Generator().manual_seed(9)
     c, e, s = (torch.randn(8, 256, generator=gen) for _ in range(3))
     eng.set_schedule(sch.ddpm_table(50))
-    for prec in ("fp32", "bf16", "fp32x"):
+    for prec in ("fp32", "bf16", "fp32x", "fp16"):
         full = eng.sample(c, e, s, prec, seed=2024, clip_index0=16)
         a = eng.sample(c[:4], e[:4], s[:4], prec, seed=2024, clip_index0=16)
         b = eng.sample(c[4:], e[4:], s[4:], prec, seed=2024, clip_index0=20)
@@ -320,7 +320,7 @@ def test_in_kernel_noise_equals_explicit_counter_noise(env):
     try:
         for G in (1, 2, 3):
             eng.set_clips_per_group(G)
-            for prec in ("fp32", "bf16", "fp32x"):   # two different kernels (k_sampler.hip / k_sampler8.hip)
+            for prec in ("fp32", "bf16", "fp32x", "fp16"):   # two different kernels (k_sampler.hip / k_sampler8.hip)
                 a = eng.sample(c, e, s, prec, seed=seed, clip_index0=c0)
                 b = eng.sample(c, e, s, prec, x_init=x0, step_noise=nz)
                 assert torch.equal(a, b), (G, prec)
@@ -329,7 +329,7 @@ def test_in_kernel_noise_equals_explicit_counter_noise(env):
         # must get its ancestral noise too (it silently kept z = 0 before), and B = 7 leaves a ragged last tile.
         for G, (ee, ss) in ((4, (None, s)), (4, (None, None)), (5, (None, None))):
             eng.set_clips_per_group(G)
-            for prec in ("fp32", "bf16", "fp32x"):
+            for prec in ("fp32", "bf16", "fp32x", "fp16"):
                 a = eng.sample(c, ee, ss, prec, seed=seed, clip_index0=c0)
                 b = eng.sample(c, ee, ss, prec, x_init=x0, step_noise=nz)
                 assert torch.equal(a, b), (G, prec, ee is None, ss is None)
@@ -537,7 +537,7 @@ def test_job_level_tiling_makes_shards_bitwise(env):
     eng.set_schedule(sch.ddim_table())
     g = job_clips_per_group(B)
     assert g == 3
-    for prec in ("fp32", "bf16", "fp32x"):
+    for prec in ("fp32", "bf16", "fp32x", "fp16"):
         full = eng.diffusion_backward(c, e, s, prec, seed=7)          # auto: ceil(300 / 128) = 3 clips per tile
         eng.set_clips_per_group(g)
         try:
