@@ -309,9 +309,9 @@ struct amuse_ctx {
     float* cond_wt[3] = {nullptr, nullptr, nullptr};
     float* cond_b[3] = {nullptr, nullptr, nullptr};
     // prior decoder
-    uint4* vae_w[3] = {nullptr, nullptr, nullptr};   // fp32 | bf16 | split-fp16 (fp32x)
-    uint32_t vae_stage_base[3][kVaeStages];
-    uint32_t vae_stage_units[3][kVaeStages];
+    uint4* vae_w[4] = {nullptr, nullptr, nullptr, nullptr};   // staged decode streams: fp32 | bf16 | split-fp16 (fp32x) | fp16
+    uint32_t vae_stage_base[4][kVaeStages];
+    uint32_t vae_stage_units[4][kVaeStages];
     uint4* vae_wf = nullptr;           // bf16 stream of the fused decode kernel (k_vae_fused.hip)
     uint4* vae_wfh = nullptr;          // its fp16 twin (k_vae_fusedh.hip, AMUSE_PREC_F16)
     uint4* vae_skip = nullptr; size_t vae_skip_cap = 0;   // clips
@@ -319,9 +319,9 @@ struct amuse_ctx {
     float *vae_pvec = nullptr, *vae_final_bias = nullptr, *vae_pe = nullptr;
     float *vae_wv_t = nullptr, *vae_bv = nullptr, *vae_wo_t = nullptr, *vae_bo = nullptr;
     // prior encoder (MotionPrior.encode)
-    uint4* vaee_w[3] = {nullptr, nullptr, nullptr};
-    uint32_t vaee_stage_base[3][kVaeStages];
-    uint32_t vaee_stage_units[3][kVaeStages];
+    uint4* vaee_w[4] = {nullptr, nullptr, nullptr, nullptr};
+    uint32_t vaee_stage_base[4][kVaeStages];
+    uint32_t vaee_stage_units[4][kVaeStages];
     float *vaee_pvec = nullptr, *vaee_pe = nullptr, *vaee_tok = nullptr, *vaee_emb_bias = nullptr;
     // schedule
     int T = 0;
@@ -491,7 +491,7 @@ int build_prior(amuse_ctx* c, const float* pri, int what = AMUSE_UPD_ALL) {
     static const ParamIndex PI = prior_index();
     const Params Pp{PI, pri};
     // ---- VAE decoder weight streams: [stage][wave][units]
-    for (int prec = 0; prec < 3; ++prec) {
+    for (int prec = 0; prec < 4; ++prec) {
         if (!(what & kUpdBit[prec])) continue;
         std::vector<uint4> all;
         for (int st = 0; st < kVaeStages; ++st) {
@@ -571,7 +571,7 @@ int build_prior(amuse_ctx* c, const float* pri, int what = AMUSE_UPD_ALL) {
     }
     // ---- VAE encoder weight streams: stage 0 = skel_embedding (K = 333 padded to 22 k-tiles, 2 output tiles per wave)
     // + in_proj(0); stage i+1 = post-attention of block i (+ skip linear) + in_proj(i+1); stage 9 = post-attention of block 8
-    for (int prec = 0; prec < 3; ++prec) {
+    for (int prec = 0; prec < 4; ++prec) {
         if (!(what & kUpdBit[prec]) || !(what & AMUSE_UPD_ENCODER)) continue;
         std::vector<uint4> all;
         for (int st = 0; st < kVaeStages; ++st) {
@@ -676,7 +676,7 @@ hipError_t dispatch_sample(amuse_ctx* c, SampleArgs& a, int precision, hipStream
     return launch_sample(a, precision, st);
 }
 
-// decode path choice: the fused per-clip kernel (bf16 only) occupies one CU per clip, so it wins once there are enough
+// decode path choice: the fused per-clip kernel (bf16 / fp16 modes) occupies one CU per clip, so it wins once there are enough
 // clips to fill a good part of the chip; below that the staged path's 19 workgroups per clip finish sooner.
 // AMUSE_VAE_FUSED=0 / 1 forces the staged / fused path (A/B measurements, tests of both paths).
 constexpr int kFusedMinClips = 64;   // measured (profiles/r03_decode_perf.txt): fused 0.61 ms for any B <= 128; staged 0.51 ms at 32 clips, 0.66 ms at 64, 1.07 ms at 128
@@ -684,8 +684,7 @@ constexpr int kVaeFusedChunk = 4096;
 bool use_vae_fused(const amuse_ctx* c, int precision, int B) {
     static const int env = [] { const char* e = getenv("AMUSE_VAE_FUSED"); return e ? atoi(e) : -1; }();
     const int force = c->decode_path == AMUSE_DECODE_STAGED ? 0 : c->decode_path == AMUSE_DECODE_FUSED ? 1 : env;
-    if (precision == PREC_F16) return true;   // fp16 decodes on the fused kernel's fp16 build at every batch size (no staged fp16 kernels)
-    if (precision != PREC_BF16 || force == 0) return false;
+    if (!is_op16(precision) || force == 0) return false;   // (the fused kernel exists in the two one-piece 16-bit formats)
     return force == 1 || B >= kFusedMinClips;
 }
 
@@ -795,7 +794,7 @@ int build_repack_maps(amuse_ctx* c) {
     auto kind_of = [&](void** slot) {
         if (slot == (void**)&c->den_w[PREC_F16X2] || slot == (void**)&c->den_w8x || slot == (void**)&c->vae_w[PREC_F16X2] ||
             slot == (void**)&c->vaee_w[PREC_F16X2]) return 2;
-        if (slot == (void**)&c->den_w8h || slot == (void**)&c->vae_wfh) return 3;
+        if (slot == (void**)&c->den_w8h || slot == (void**)&c->vae_wfh || slot == (void**)&c->vae_w[PREC_F16] || slot == (void**)&c->vaee_w[PREC_F16]) return 3;
         return (slot == (void**)&c->den_w[PREC_BF16] || slot == (void**)&c->den_w8 || slot == (void**)&c->vae_w[PREC_BF16] ||
                 slot == (void**)&c->vae_wf || slot == (void**)&c->vaee_w[PREC_BF16]) ? 1 : 0;
     };
@@ -846,7 +845,8 @@ int build_repack_maps(amuse_ctx* c) {
         if (slot == (void**)&c->den_w[PREC_F32] || slot == (void**)&c->vae_w[PREC_F32]) cls = AMUSE_UPD_F32;
         else if (slot == (void**)&c->den_w[PREC_F16X2] || slot == (void**)&c->den_w8x || slot == (void**)&c->vae_w[PREC_F16X2]) cls = AMUSE_UPD_F32X;
         else if (slot == (void**)&c->vaee_w[PREC_F16X2]) cls = AMUSE_UPD_F32X | AMUSE_UPD_ENCODER;
-        else if (slot == (void**)&c->den_w8h || slot == (void**)&c->vae_wfh) cls = AMUSE_UPD_F16;
+        else if (slot == (void**)&c->den_w8h || slot == (void**)&c->vae_wfh || slot == (void**)&c->vae_w[PREC_F16]) cls = AMUSE_UPD_F16;
+        else if (slot == (void**)&c->vaee_w[PREC_F16]) cls = AMUSE_UPD_F16 | AMUSE_UPD_ENCODER;
         else if (slot == (void**)&c->den_w[PREC_BF16] || slot == (void**)&c->den_w8 || slot == (void**)&c->vae_w[PREC_BF16] || slot == (void**)&c->vae_wf) cls = AMUSE_UPD_BF16;
         else if (slot == (void**)&c->vaee_w[PREC_F32]) cls = AMUSE_UPD_F32 | AMUSE_UPD_ENCODER;
         else if (slot == (void**)&c->vaee_w[PREC_BF16]) cls = AMUSE_UPD_BF16 | AMUSE_UPD_ENCODER;
@@ -888,7 +888,7 @@ void amuse_destroy(amuse_ctx* c) {
         if (p) (void)hipFree(p);
     void* ptrs[] = {c->den_w[0], c->den_w[1], c->den_w[2], c->den_w8, c->den_w8h, c->den_w8x, c->vae_wfh, c->den_pvec, c->den_pe, c->den_freqs, c->te_w1t, c->te_b1, c->te_w2t,
                     c->te_b2, c->cond_wt[0], c->cond_wt[1], c->cond_wt[2], c->cond_b[0], c->cond_b[1], c->cond_b[2],
-                    c->vae_w[0], c->vae_w[1], c->vae_w[2], c->vaee_w[2], c->vae_pvec, c->vae_final_bias, c->vae_pe, c->vae_wv_t, c->vae_bv,
+                    c->vae_w[0], c->vae_w[1], c->vae_w[2], c->vae_w[3], c->vaee_w[2], c->vaee_w[3], c->vae_pvec, c->vae_final_bias, c->vae_pe, c->vae_wv_t, c->vae_bv,
                     c->vae_wo_t, c->vae_bo, c->vaee_w[0], c->vaee_w[1], c->vaee_pvec, c->vaee_pe, c->vaee_tok,
                     c->vaee_emb_bias, c->d_timesteps, c->d_coef, c->d_time_tok, c->d_ts1, c->d_tt1, c->d_coef1,
                     c->cond_tok, c->lat_tmp, c->fwd_ws, c->vae_ws, c->d_lengths, c->vae_wf, c->vae_skip, c->vae_ca_ws};
@@ -1048,7 +1048,7 @@ int amuse_vae_decode(amuse_ctx* c, const float* z, const int* lengths, int B, in
     hipStream_t st = (hipStream_t)stream;
     if (int e = stage_lengths(c, lengths, B, st)) return e;
     if (use_vae_fused(c, precision, B)) {
-        // bf16 throughput mode from kFusedMinClips clips up: one persistent workgroup per clip (k_vae_fused.hip)
+        // bf16 / fp16 throughput modes from kFusedMinClips clips up: one persistent workgroup per clip (k_vae_fused.hip)
         const int chunk = B < kVaeFusedChunk ? B : kVaeFusedChunk;
         if (c->vae_skip_cap < (size_t)chunk) {
             if (c->vae_skip) HIP_TRY(hipFree(c->vae_skip));
@@ -1116,8 +1116,7 @@ int amuse_vae_encode(amuse_ctx* c, const float* feats, const int* lengths, int B
     if (!mu_out && !std_out && !latent_out) return fail(AMUSE_EINVAL, "no output requested");
     if (B < 1) return fail(AMUSE_EINVAL, "B must be >= 1, got %d", B);
     precision = prior_precision(precision);
-    if (precision == AMUSE_PREC_F16) precision = AMUSE_PREC_BF16;   // (MotionPrior.encode has no fp16 kernels: the bf16 ones serve)
-    if (precision != AMUSE_PREC_F32 && precision != AMUSE_PREC_BF16 && precision != AMUSE_PREC_F32X) return fail(AMUSE_EINVAL, "bad precision %d", precision);
+    if (precision < AMUSE_PREC_F32 || precision > AMUSE_PREC_F16) return fail(AMUSE_EINVAL, "bad precision %d", precision);
     HIP_TRY(hipSetDevice(c->device));
     hipStream_t st = (hipStream_t)stream;
     if (int e = stage_lengths(c, lengths, B, st)) return e;

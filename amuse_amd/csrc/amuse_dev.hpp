@@ -679,6 +679,20 @@ __device__ __forceinline__ f32x4 bf16x4_to_f32(uint2 u) {
     return f32x4{__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u), __uint_as_float(u.y << 16),
                  __uint_as_float(u.y & 0xffff0000u)};
 }
+__device__ __forceinline__ f32x4 f16x4_to_f32(uint2 u) {
+    typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+    return __builtin_convertvector(__builtin_bit_cast(f16x4, u), f32x4);   // exact
+}
+// the one-piece 16-bit modes' conversions and FFN activation by precision tag (PREC_BF16 / PREC_F16)
+template <int PREC> __device__ __forceinline__ uint2 f32_to_x16x4(f32x4 v) {
+    if constexpr (PREC == PREC_F16) return f32_to_f16x4(v); else return f32_to_bf16x4(v);
+}
+template <int PREC> __device__ __forceinline__ f32x4 x16x4_to_f32(uint2 u) {
+    if constexpr (PREC == PREC_F16) return f16x4_to_f32(u); else return bf16x4_to_f32(u);
+}
+template <int PREC> __device__ __forceinline__ f32x4 gelu_poly16(f32x4 x) {
+    if constexpr (PREC == PREC_F16) return gelu_poly4h(x); else return gelu_poly4(x);
+}
 
 
 // 6D -> rotation matrix -> quaternion -> axis-angle of one joint (infer_ldm.py:168-173)

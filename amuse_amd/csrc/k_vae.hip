@@ -57,7 +57,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     constexpr int P_O = 0, P_F1 = U_O % kVR, P_F2 = (P_F1 + U_F) % kVR, P_S = (P_F2 + U_F) % kVR;
     constexpr int P_Q0 = P_S, P_Q1 = (P_S + U_S) % kVR;   // in_proj / final phase without / with a skip linear before
     bool skipped = false;
-    constexpr bool FAST = (PREC == PREC_BF16);
+    constexpr bool FAST = is_op16(PREC);
     f32x4 x[kTiles];
 
     constexpr int kEmbK = 22;  // 333 input features padded to 22 k-tiles (zero weights / zero operands beyond 333)
@@ -102,13 +102,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         for (int t = 0; t < kTiles; ++t) x[t] = rvalid ? ld4(a.x + row * kD + 16 * t + 4 * g) : splat4(0.f);
 #pragma unroll
         for (int td = 0; td < 2; ++td) {
-            if constexpr (PREC == PREC_BF16) {
-                // bf16 mode: q, k, v and the attention output travel between the kernels as bf16 - the values the
-                // MFMAs consume anyway (rounded at the same point as before, so results are unchanged), half the bytes
+            if constexpr (is_op16(PREC)) {
+                // bf16 / fp16 modes: q, k, v and the attention output travel between the kernels in the operand format - the values
+                // the MFMAs consume anyway (rounded at the same point as before, so results are unchanged), half the bytes
                 const uint2 u = rvalid ? *reinterpret_cast<const uint2*>(reinterpret_cast<const unsigned short*>(a.attn_o) +
                                                                          row * kD + 32 * wave + 16 * td + 4 * g)
                                        : uint2{0u, 0u};
-                o[td] = bf16x4_to_f32(u);
+                o[td] = x16x4_to_f32<PREC>(u);
             } else {
                 o[td] = rvalid ? ld4(a.attn_o + row * kD + 32 * wave + 16 * td + 4 * g) : splat4(0.f);
             }
@@ -124,7 +124,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             const float* ca = a.ca + ((size_t)b * kLayers + blk) * kD;
 #pragma unroll
             for (int t = 0; t < kTiles; ++t) x[t] = x[t] + ld4(ca + 16 * t + 4 * g);
-            layer_norm_rows<PREC == PREC_BF16>(x, pv + PV_LN2_W, pv + PV_LN2_B, g);
+            layer_norm_rows<is_op16(PREC)>(x, pv + PV_LN2_W, pv + PV_LN2_B, g);
         }
         // FFN + residual + norm3 (decoder layer) / norm2 (encoder layer, cross_attention.py:259-272)
         f32x4 hid[kTiles];
@@ -135,8 +135,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         // kernel serves (amuse_dev.hpp gelu_poly4: |error| <= 1.9e-4, a third of gelu_erf_fast's issue slots)
 #pragma unroll
         for (int t = 0; t < kTiles; ++t) {
-            if constexpr (PREC == PREC_BF16) {
-                hid[t] = gelu_poly4(hid[t]);
+            if constexpr (is_op16(PREC)) {
+                hid[t] = gelu_poly16<PREC>(hid[t]);
             } else {
 #pragma unroll
                 for (int m = 0; m < 4; ++m) hid[t][m] = gelu_erf(hid[t][m]);
@@ -190,11 +190,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             const float scaling = 0.17677669529663687f;
 #pragma unroll
             for (int td = 0; td < 2; ++td) {
-                if constexpr (PREC == PREC_BF16) {
+                if constexpr (is_op16(PREC)) {
                     const size_t off = hrow + 16 * td + 4 * g;
-                    *reinterpret_cast<uint2*>(reinterpret_cast<unsigned short*>(a.q) + off) = f32_to_bf16x4(qkv[td] * scaling);
-                    *reinterpret_cast<uint2*>(reinterpret_cast<unsigned short*>(a.k) + off) = f32_to_bf16x4(qkv[2 + td]);
-                    *reinterpret_cast<uint2*>(reinterpret_cast<unsigned short*>(a.v) + off) = f32_to_bf16x4(qkv[4 + td]);
+                    *reinterpret_cast<uint2*>(reinterpret_cast<unsigned short*>(a.q) + off) = f32_to_x16x4<PREC>(qkv[td] * scaling);
+                    *reinterpret_cast<uint2*>(reinterpret_cast<unsigned short*>(a.k) + off) = f32_to_x16x4<PREC>(qkv[2 + td]);
+                    *reinterpret_cast<uint2*>(reinterpret_cast<unsigned short*>(a.v) + off) = f32_to_x16x4<PREC>(qkv[4 + td]);
                 } else {
                     st4(a.q + hrow + 16 * td + 4 * g, qkv[td] * scaling);
                     st4(a.k + hrow + 16 * td + 4 * g, qkv[2 + td]);
@@ -204,14 +204,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         }
     } else if constexpr (ENC) {
         // encoder.norm; only the two distribution rows leave the stack: mu = row 0, logvar = row 1 (vae.py:203-207)
-        layer_norm_rows<PREC == PREC_BF16>(x, a.pvec + PV_FINAL_W, a.pvec + PV_FINAL_B, g);
+        layer_norm_rows<is_op16(PREC)>(x, a.pvec + PV_FINAL_W, a.pvec + PV_FINAL_B, g);
         if (wave == 0 && rt == 0 && frame < 2) {
 #pragma unroll
             for (int t = 0; t < kTiles; ++t) st4(a.stats_out + ((size_t)b * 2 + frame) * kD + 16 * t + 4 * g, x[t]);
         }
     } else {
         // decoder.norm -> final_layer (333 outputs padded to 24 tiles, 6 per wave) -> rotation epilogue
-        layer_norm_rows<PREC == PREC_BF16>(x, a.pvec + PV_FINAL_W, a.pvec + PV_FINAL_B, g);
+        layer_norm_rows<is_op16(PREC)>(x, a.pvec + PV_FINAL_W, a.pvec + PV_FINAL_B, g);
         f32x4 f[6];
 #pragma unroll
         for (int o = 0; o < 6; ++o) f[o] = ld4(a.final_bias + 16 * (6 * wave + o) + 4 * g);
@@ -391,11 +391,13 @@ __global__ __launch_bounds__(256) void k_vae_attn(VaeAttnArgs a) {
 constexpr int kPairs = kKeyRows / 32;                        // 10
 constexpr int kAttnBf16LdsBytes = kKeyRows * 64 + kPairs * 2 * 16 * 64;  // 20 KiB + 20 KiB
 
-template <int NQ, int S>
+template <int P16, int NQ, int S>   // P16 = PREC_BF16 / PREC_F16: the operand format of q, k, v, p and the output
 __device__ __forceinline__ void attn_qtiles_bf16(const uint4* Kb, const uint4* Vt, const unsigned short* qg,
                                                  unsigned short* og, int qt0, int len, int g, int r) {
     constexpr float kLog2e = 1.44269504088896340736f;
-    bf16x8 qb[NQ];
+    typedef Op16<P16> Op;
+    typedef typename Op::vec OPV;
+    OPV qb[NQ];
     float m_run[NQ], l_run[NQ];
     f32x4 o[NQ][2];
 #pragma unroll
@@ -404,17 +406,17 @@ __device__ __forceinline__ void attn_qtiles_bf16(const uint4* Kb, const uint4* V
         const bool qv = fq < S;
         const uint2 q0 = qv ? *reinterpret_cast<const uint2*>(qg + fq * 32 + 4 * g) : uint2{0u, 0u};
         const uint2 q1 = qv ? *reinterpret_cast<const uint2*>(qg + fq * 32 + 16 + 4 * g) : uint2{0u, 0u};
-        qb[n] = __builtin_bit_cast(bf16x8, uint4{q0.x, q0.y, q1.x, q1.y});
+        qb[n] = __builtin_bit_cast(OPV, uint4{q0.x, q0.y, q1.x, q1.y});
         m_run[n] = -INFINITY;
         l_run[n] = 0.f;
         o[n][0] = o[n][1] = splat4(0.f);
     }
 #pragma unroll 1
     for (int jp = 0; jp < kPairs; ++jp) {
-        const bf16x8 k0 = __builtin_bit_cast(bf16x8, Kb[(32 * jp + r) * 4 + g]);
-        const bf16x8 k1 = __builtin_bit_cast(bf16x8, Kb[(32 * jp + 16 + r) * 4 + g]);
-        const bf16x8 v0 = __builtin_bit_cast(bf16x8, Vt[((jp * 2 + 0) * 16 + r) * 4 + g]);
-        const bf16x8 v1 = __builtin_bit_cast(bf16x8, Vt[((jp * 2 + 1) * 16 + r) * 4 + g]);
+        const OPV k0 = __builtin_bit_cast(OPV, Kb[(32 * jp + r) * 4 + g]);
+        const OPV k1 = __builtin_bit_cast(OPV, Kb[(32 * jp + 16 + r) * 4 + g]);
+        const OPV v0 = __builtin_bit_cast(OPV, Vt[((jp * 2 + 0) * 16 + r) * 4 + g]);
+        const OPV v1 = __builtin_bit_cast(OPV, Vt[((jp * 2 + 1) * 16 + r) * 4 + g]);
         bool ok[2][4];
 #pragma unroll
         for (int u = 0; u < 2; ++u)
@@ -423,8 +425,8 @@ __device__ __forceinline__ void attn_qtiles_bf16(const uint4* Kb, const uint4* V
 #pragma unroll
         for (int n = 0; n < NQ; ++n) {
             f32x4 st[2];
-            st[0] = mfma_bf16(k0, qb[n], splat4(0.f));  // lane (g, i): S[i][32 jp + 4 g + m]
-            st[1] = mfma_bf16(k1, qb[n], splat4(0.f));  //              S[i][32 jp + 16 + 4 g + m]
+            st[0] = Op::mfma(k0, qb[n], splat4(0.f));  // lane (g, i): S[i][32 jp + 4 g + m]
+            st[1] = Op::mfma(k1, qb[n], splat4(0.f));  //              S[i][32 jp + 16 + 4 g + m]
             float mx = -INFINITY;
 #pragma unroll
             for (int u = 0; u < 2; ++u)
@@ -448,9 +450,9 @@ __device__ __forceinline__ void attn_qtiles_bf16(const uint4* Kb, const uint4* V
             ps = allreduce_g_sum(ps);
             l_run[n] = l_run[n] * alpha + ps;
             m_run[n] = m_new;
-            const bf16x8 pb = pack_bf16(p[0], p[1]);
-            o[n][0] = mfma_bf16(v0, pb, o[n][0] * alpha);  // O^T[d][i] += sum_key V[key][d] P[i][key]
-            o[n][1] = mfma_bf16(v1, pb, o[n][1] * alpha);
+            const OPV pb = Op::pack(p[0], p[1]);
+            o[n][0] = Op::mfma(v0, pb, o[n][0] * alpha);  // O^T[d][i] += sum_key V[key][d] P[i][key]
+            o[n][1] = Op::mfma(v1, pb, o[n][1] * alpha);
         }
     }
 #pragma unroll
@@ -458,13 +460,13 @@ __device__ __forceinline__ void attn_qtiles_bf16(const uint4* Kb, const uint4* V
         const int fq = (qt0 + 4 * n) * 16 + r;
         if (fq < S) {
             unsigned short* dst = og + (size_t)fq * kD + 4 * g;
-            *reinterpret_cast<uint2*>(dst) = f32_to_bf16x4(o[n][0] / l_run[n]);
-            *reinterpret_cast<uint2*>(dst + 16) = f32_to_bf16x4(o[n][1] / l_run[n]);
+            *reinterpret_cast<uint2*>(dst) = f32_to_x16x4<P16>(o[n][0] / l_run[n]);
+            *reinterpret_cast<uint2*>(dst + 16) = f32_to_x16x4<P16>(o[n][1] / l_run[n]);
         }
     }
 }
 
-template <bool ENC>
+template <int P16, bool ENC>
 __global__ __launch_bounds__(256) void k_vae_attn_bf16(VaeAttnArgs a) {
     constexpr int S = ENC ? kFrames + 2 : kFrames;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -475,7 +477,7 @@ __global__ __launch_bounds__(256) void k_vae_attn_bf16(VaeAttnArgs a) {
     const int g = lane >> 4, r = lane & 15;
     const int bh = blockIdx.x, b = bh / kHeads, h = bh - b * kHeads;
     const int len = a.lengths ? a.lengths[b] + (ENC ? 2 : 0) : S;
-    // q, k, v are bf16 here ([B * heads][S][32], written by k_vae_rows<PREC_BF16>), as is the output
+    // q, k, v are 16-bit here ([B * heads][S][32], written by k_vae_rows<P16> in its operand format), as is the output
     const unsigned short* qg = reinterpret_cast<const unsigned short*>(a.q) + (size_t)bh * S * 32;
     const unsigned short* kg = reinterpret_cast<const unsigned short*>(a.k) + (size_t)bh * S * 32;
     const unsigned short* vg = reinterpret_cast<const unsigned short*>(a.v) + (size_t)bh * S * 32;
@@ -502,12 +504,12 @@ __global__ __launch_bounds__(256) void k_vae_attn_bf16(VaeAttnArgs a) {
     unsigned short* og = reinterpret_cast<unsigned short*>(a.o) + (size_t)b * S * kD + 32 * h;
     // 19 query tiles: wave w owns tiles w, w+4, w+8, w+12 (two pairs) and w+16 (waves 0..2)
     if (a.q_tiles == 1) {  // last encoder block: only the distribution rows (tile 0) are consumed downstream
-        if (wave == 0) attn_qtiles_bf16<1, S>(Kb, Vt, qg, og, 0, len, g, r);
+        if (wave == 0) attn_qtiles_bf16<P16, 1, S>(Kb, Vt, qg, og, 0, len, g, r);
         return;
     }
-    attn_qtiles_bf16<2, S>(Kb, Vt, qg, og, wave, len, g, r);
-    attn_qtiles_bf16<2, S>(Kb, Vt, qg, og, wave + 8, len, g, r);
-    if (wave + 16 < kRowTiles) attn_qtiles_bf16<1, S>(Kb, Vt, qg, og, wave + 16, len, g, r);
+    attn_qtiles_bf16<P16, 2, S>(Kb, Vt, qg, og, wave, len, g, r);
+    attn_qtiles_bf16<P16, 2, S>(Kb, Vt, qg, og, wave + 8, len, g, r);
+    if (wave + 16 < kRowTiles) attn_qtiles_bf16<P16, 1, S>(Kb, Vt, qg, og, wave + 16, len, g, r);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -666,6 +668,8 @@ hipError_t launch_vae_rows(const VaeRowsArgs& a, int precision, bool enc, hipStr
         if (e == hipSuccess) e = set_lds(&k_vae_rows<PREC_BF16, false>, kRowsLdsBytes);
         if (e == hipSuccess) e = set_lds(&k_vae_rows<PREC_F32, true>, kRowsLdsBytes);
         if (e == hipSuccess) e = set_lds(&k_vae_rows<PREC_BF16, true>, kRowsLdsBytes);
+        if (e == hipSuccess) e = set_lds(&k_vae_rows<PREC_F16, false>, kRowsLdsBytes);
+        if (e == hipSuccess) e = set_lds(&k_vae_rows<PREC_F16, true>, kRowsLdsBytes);
         if (e != hipSuccess) return e;
         once.set(dev_);
     }
@@ -676,6 +680,9 @@ hipError_t launch_vae_rows(const VaeRowsArgs& a, int precision, bool enc, hipStr
     } else if (precision == PREC_F16X2) {
         if (enc) hipLaunchKernelGGL((k_vae_rows<PREC_F16X2, true>), grid, block, kRowsLdsBytes, stream, a);
         else hipLaunchKernelGGL((k_vae_rows<PREC_F16X2, false>), grid, block, kRowsLdsBytes, stream, a);
+    } else if (precision == PREC_F16) {
+        if (enc) hipLaunchKernelGGL((k_vae_rows<PREC_F16, true>), grid, block, kRowsLdsBytes, stream, a);
+        else hipLaunchKernelGGL((k_vae_rows<PREC_F16, false>), grid, block, kRowsLdsBytes, stream, a);
     } else {
         if (enc) hipLaunchKernelGGL((k_vae_rows<PREC_BF16, true>), grid, block, kRowsLdsBytes, stream, a);
         else hipLaunchKernelGGL((k_vae_rows<PREC_BF16, false>), grid, block, kRowsLdsBytes, stream, a);
@@ -693,8 +700,10 @@ hipError_t launch_vae_attn(const VaeAttnArgs& a, int precision, bool enc, hipStr
         if (e == hipSuccess) e = set_lds(&k_vae_attn_x<false>, kAttnXLdsBytes);
         if (e == hipSuccess) e = set_lds(&k_vae_attn_x<true>, kAttnXLdsBytes);
         if (e == hipSuccess) e = set_lds(&k_vae_attn<PREC_F32, true>, kAttnLdsBytes);
-        if (e == hipSuccess) e = set_lds(&k_vae_attn_bf16<false>, kAttnBf16LdsBytes);
-        if (e == hipSuccess) e = set_lds(&k_vae_attn_bf16<true>, kAttnBf16LdsBytes);
+        if (e == hipSuccess) e = set_lds(&k_vae_attn_bf16<PREC_BF16, false>, kAttnBf16LdsBytes);
+        if (e == hipSuccess) e = set_lds(&k_vae_attn_bf16<PREC_BF16, true>, kAttnBf16LdsBytes);
+        if (e == hipSuccess) e = set_lds(&k_vae_attn_bf16<PREC_F16, false>, kAttnBf16LdsBytes);
+        if (e == hipSuccess) e = set_lds(&k_vae_attn_bf16<PREC_F16, true>, kAttnBf16LdsBytes);
         if (e != hipSuccess) return e;
         once.set(dev_);
     }
@@ -712,9 +721,12 @@ hipError_t launch_vae_attn(const VaeAttnArgs& a, int precision, bool enc, hipStr
             if (enc) hipLaunchKernelGGL(k_vae_attn_x<true>, grid, block, kAttnXLdsBytes, stream, a);
             else hipLaunchKernelGGL(k_vae_attn_x<false>, grid, block, kAttnXLdsBytes, stream, a);
         }
+    } else if (precision == PREC_F16) {
+        if (enc) hipLaunchKernelGGL((k_vae_attn_bf16<PREC_F16, true>), grid, block, kAttnBf16LdsBytes, stream, a);
+        else hipLaunchKernelGGL((k_vae_attn_bf16<PREC_F16, false>), grid, block, kAttnBf16LdsBytes, stream, a);
     } else {
-        if (enc) hipLaunchKernelGGL(k_vae_attn_bf16<true>, grid, block, kAttnBf16LdsBytes, stream, a);
-        else hipLaunchKernelGGL(k_vae_attn_bf16<false>, grid, block, kAttnBf16LdsBytes, stream, a);
+        if (enc) hipLaunchKernelGGL((k_vae_attn_bf16<PREC_BF16, true>), grid, block, kAttnBf16LdsBytes, stream, a);
+        else hipLaunchKernelGGL((k_vae_attn_bf16<PREC_BF16, false>), grid, block, kAttnBf16LdsBytes, stream, a);
     }
     return hipGetLastError();
 }

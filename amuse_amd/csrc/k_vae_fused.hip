@@ -85,7 +85,7 @@ constexpr int kOffW = kOffKv + kKvBytes;                   // weight ring
 constexpr int kOffPv = kOffW + kWBufs * kStageBytes;       // 2 x block parameters
 constexpr int kOffCa = kOffPv + 2 * kPvSlot;               // cross-attention constants of the clip
 static_assert(kOffCa + kCaBytes == kVaeFusedLdsBytes, "LDS layout and amuse_kernels.hpp disagree");
-static_assert(4 * 16 * kQStride * 4 <= kKvBytes, "staging tiles must fit the K/V images");
+static_assert((kWaves / 2) * 16 * kQStride * 4 <= kKvBytes, "staging tiles (one per SIMD) must fit the K/V images");
 
 // ablation switches for timing experiments (tools/build_variant.sh): 2 no attention, 4 no FFN arithmetic,
 // 8 no softmax arithmetic (scores fed to PV as they are).  0 in the product.

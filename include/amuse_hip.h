@@ -59,8 +59,8 @@ enum { AMUSE_OK = 0, AMUSE_EINVAL = -1, AMUSE_EHIP = -2, AMUSE_ENOMEM = -3, AMUS
  * amuse_vae_decode / amuse_vae_encode run the same split arithmetic in their staged kernels (k_vae.hip PREC_F16X2).
  * F16: the throughput mode on fp16 instead of bf16 operands - the BF16 mode's kernels (8-wave sampler, fused decoder) built for
  * v_mfma_f32_16x16x32_f16 / v_cvt_pk_f16_f32: same speed, same bytes, 11 significand bits instead of 8 - about an eighth of the BF16
- * mode's drift against F32.  Range as for F32X.  Decodes on the fused kernel at every batch size; amuse_vae_encode
- * runs the BF16 kernels. */
+ * mode's drift against F32.  Range as for F32X.  amuse_vae_decode / amuse_vae_encode: the BF16 mode's kernels
+ * (fused per-clip decoder, staged rows / attention kernels) in their fp16 instantiations, chosen by the same rule. */
 enum { AMUSE_PREC_F32 = 0, AMUSE_PREC_BF16 = 1, AMUSE_PREC_F32X = 2, AMUSE_PREC_F16 = 3 };
 
 /* matrix -> quaternion convention of the axis-angle epilogue (infer_ldm.py:172):
@@ -209,10 +209,10 @@ int amuse_profile_sample(amuse_ctx* ctx, const float* con, const float* emo, con
  * (a clip's slot inside its tile decides the rounding of its attention sums); amuse_amd/shard.py applies that rule. */
 int amuse_set_clips_per_group(amuse_ctx* ctx, int g);
 
-/* Which kernels amuse_vae_decode (and amuse_diffusion_backward) use in bf16 mode.  AUTO: the fused per-clip kernel
+/* Which kernels amuse_vae_decode (and amuse_diffusion_backward) use in the bf16 and fp16 modes.  AUTO: the fused per-clip kernel
  * (csrc/k_vae_fused.hip: one persistent workgroup per clip, residual stream in registers, K/V of the current head in LDS)
  * from 64 clips up, the staged kernels (csrc/k_vae.hip) below that; fp32 mode always runs the staged kernels.  Both
- * compute MotionPrior.decode (vae.py:216-278) with bf16 MFMA operands and fp32 accumulation / residual stream; they differ
+ * compute MotionPrior.decode (vae.py:216-278) with bf16 (fp16) MFMA operands and fp32 accumulation / residual stream; they differ
  * in summation order only.  The environment variable AMUSE_VAE_FUSED=0 / 1 overrides AUTO for a whole process. */
 enum { AMUSE_DECODE_AUTO = 0, AMUSE_DECODE_STAGED = 1, AMUSE_DECODE_FUSED = 2 };
 int amuse_set_decode_path(amuse_ctx* ctx, int path);

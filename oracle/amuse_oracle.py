@@ -395,11 +395,11 @@ def vae_decode(Wp, z, lengths: Optional[Sequence[int]] = None, emulate_bf16=Fals
     return feats * mask[..., None].to(feats.dtype)
 
 
-def vae_encode(Wp, feats, lengths: Optional[Sequence[int]] = None, emulate_bf16=False):
+def vae_encode(Wp, feats, lengths: Optional[Sequence[int]] = None, emulate_bf16=False, fp16=False):
     """MotionPrior.encode (vae.py:154-214, MLP_DIST false, learned PE): feats (B,300,333) -> (mu, std), each (B,128).
     xseq = [2 distribution tokens | skel_embedding(frames)] + PE; SkipTransformerEncoder with key padding mask;
     mu = token 0, logvar = token 1, std = exp(logvar) ** 0.5.  (latent = mu + std * eps is left to the caller.)"""
-    ops = Ops(emulate_bf16, poly_gelu=emulate_bf16)   # the HIP bf16 mode: bf16 GEMM operands + polynomial GELU
+    ops = Ops(emulate_bf16 or fp16, poly_gelu=emulate_bf16 or fp16, fp16=fp16)   # the HIP 16-bit modes: rounded GEMM operands + polynomial GELU
     B, n, _ = feats.shape
     if lengths is None:
         lengths = [n] * B

@@ -111,7 +111,8 @@ def test_fp16_mode_gated_against_fp32_mode(env):
 def test_fp16_fused_decode_vs_golden_and_oracle(env):
     orc, eng, Wp = env["orc"], env["eng"], env["Wp"]
     g = np.load(GOLDEN / "vae_decode.npz")
-    out = eng.vae_decode(g["z"], None, "fp16", return_feats=True)        # fp16 decodes on the fused kernel's fp16 build at any batch size
+    eng.set_decode_path("fused")                                          # (3 clips would run the staged kernels)
+    out = eng.vae_decode(g["z"], None, "fp16", return_feats=True)
     assert out["feats"].shape == (3, 300, 333) and bool(torch.isfinite(out["feats"]).all())
     assert _err(out["feats"], g["feats"]) < 1e-2                          # bf16: 6e-2 (|feats| ~ 3)
     ref = orc.vae_decode(Wp, torch.from_numpy(g["z"]), None, fp16=True)
@@ -124,6 +125,35 @@ def test_fp16_fused_decode_vs_golden_and_oracle(env):
     o2 = eng.vae_decode(z[[1]], [173], "fp16", return_feats=True)
     assert torch.equal(o2["feats"][0], o["feats"][1])
     assert not torch.equal(out["feats"], eng.vae_decode(g["z"], None, "bf16", return_feats=True)["feats"])
+    eng.set_decode_path("auto")
+
+
+def test_fp16_staged_decode_and_encode(env):
+    """Below 64 clips the fp16 mode decodes on the staged kernels' fp16 instantiations (k_vae.hip k_vae_rows<PREC_F16> /
+    k_vae_attn_bf16<PREC_F16>), and MotionPrior.encode runs on them at any size: against the reference goldens at a fraction of
+    the bf16 bounds, against the oracle emulating the roundings, and against the fused kernel (another summation order)."""
+    orc, eng, Wp = env["orc"], env["eng"], env["Wp"]
+    g = np.load(GOLDEN / "vae_decode.npz")
+    z = torch.from_numpy(g["z"])
+    st = eng.vae_decode(z, None, "fp16", return_feats=True)               # 3 clips: staged
+    assert _err(st["feats"], g["feats"]) < 1e-2                            # bf16: 6e-2
+    ref = orc.vae_decode(Wp, z, None, fp16=True)
+    d = (st["feats"].cpu() - ref).abs()
+    assert float(d.max()) < 8e-3 and float(d.mean()) < 8e-4
+    eng.set_decode_path("fused")
+    fu = eng.vae_decode(z, None, "fp16", return_feats=True)
+    eng.set_decode_path("auto")
+    assert not torch.equal(st["feats"], fu["feats"]) and _err(st["feats"], fu["feats"]) < 8e-3
+    o = eng.vae_decode(z, [300, 41, 7], "fp16", return_feats=True)         # ragged, staged
+    assert float(o["feats"][1, 41:].abs().max()) == 0.0 and float(o["poses"][2, 7:].abs().max()) == 0.0
+    ge = np.load(GOLDEN / "vae_encode.npz")
+    feats = torch.from_numpy(ge["feats"].astype(np.float32))
+    out = eng.vae_encode(feats, None, "fp16")
+    assert _err(out["mu"], ge["mu"]) < 1e-2                                # bf16: 6e-2 (|mu| ~ 3)
+    assert _err(out["std"] / torch.from_numpy(ge["std"]).to(out["std"].device), torch.ones(2, 128)) < 1e-2   # bf16: 5e-2
+    mu_ref, std_ref = orc.vae_encode(Wp, feats, None, fp16=True)
+    assert _err(out["mu"], mu_ref) < 8e-3
+    assert not torch.equal(out["mu"], eng.vae_encode(feats, None, "bf16")["mu"])
 
 
 def test_fp16_shards_noise_and_updates_are_bitwise(env):
