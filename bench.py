@@ -280,7 +280,9 @@ def main():
                        "clips_total": world * total, "clips_per_gpu": total, "clips_rank0": B, "clips_per_tile": g_job, "sampler": f"ddpm-{args.T}",
                        "sharding": f"independent clip batches x{world} (global clip indices rank * {total} ...), no collectives",
                        "clip_range_per_rank": [[r * total, (r + 1) * total] for r in range(world)],
-                       "mfma_operands": args.precision, "state_and_accumulate": "fp32"},
+                       "mfma_operands": args.precision, "state_and_accumulate": "fp32",
+                       "scheduler_arithmetic": "diffusers 0.17.1 DDPM (fixed_small) / DDIM restated from the published algorithm - the package "
+                                               "is not in the image, so this part of the parity claim is unpinned (DESIGN.md section 2)"},
             "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
                          "frac": round(achieved / peak, 5), "traffic": traffic, "traffic_source": traffic_src,
                          "kernel": KERNEL_NAME[args.precision] + " (persistent T-step denoising loop)",
