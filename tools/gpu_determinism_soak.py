@@ -42,6 +42,18 @@ ref = eng.vae_decode(z, [300] * 299 + [123], "fp32x")["poses"].clone()
 n = sum(int(not torch.equal(eng.vae_decode(z, [300] * 299 + [123], "fp32x")["poses"], ref)) for _ in range(6))
 bad += n
 print(f"fp32x decode, 300 clips: {n} mismatching launches of 6; finite={bool(torch.isfinite(ref).all())}", flush=True)
+# the staged kernels' fp16 instantiations (decode below 64 clips, encode) and the bf16 ones they are built from
+zs = torch.randn(37, 128, generator=gen).cuda()
+for prec in ("bf16", "fp16"):
+    ref = eng.vae_decode(zs, [300] * 36 + [77], prec, return_feats=True)
+    enc = eng.vae_encode(ref["feats"], None, prec, eps=torch.zeros(37, 128))
+    n = 0
+    for _ in range(8):
+        o = eng.vae_decode(zs, [300] * 36 + [77], prec, return_feats=True)
+        e = eng.vae_encode(ref["feats"], None, prec, eps=torch.zeros(37, 128))
+        n += int(not (torch.equal(o["poses"], ref["poses"]) and torch.equal(e["mu"], enc["mu"]) and torch.equal(e["std"], enc["std"])))
+    bad += n
+    print(f"staged decode + encode, 37 clips, {prec}: {n} mismatching calls of 8; finite={bool(torch.isfinite(ref['poses']).all())}", flush=True)
 from amuse_amd import audio_weights as aw
 from amuse_amd.audio import AudioEngine
 aeng = AudioEngine(*(aw.make_ast_weights(0, k) for k in aw.ENCODERS))
