@@ -182,3 +182,27 @@ def test_fused_decode_blockwise_taps(env):
     for blk, xin, skip in ((0, x0, None), (5, tr[4], tr[3])):
         d = (tr[blk][:173] - _fused_block_model(orc, Wp, blk, xin, skip, z[0], length=173)[:173]).abs().flatten()
         assert float(d.median()) < 1e-6 and float(d.max()) < 2e-2, (blk, float(d.median()), float(d.max()))
+
+
+def test_decode_chunk_boundaries_are_invisible():
+    """amuse_vae_decode walks large batches in chunks (4096 clips on the fused kernel, 512 on the staged ones) that reuse one
+    workspace: clips on both sides of a boundary - with ragged lengths - come out bitwise as in a small batch of their own."""
+    from amuse_amd import weights as wts
+    from amuse_amd.engine import HipEngine
+    eng = HipEngine(wts.make_denoiser_weights(0), wts.make_prior_weights(0), "cuda:0")
+    try:
+        gen = torch.Generator().manual_seed(77)
+        for prec, path, B, edge in (("bf16", "fused", 4100, 4096), ("fp16", "fused", 4100, 4096), ("fp32x", "auto", 520, 512), ("bf16", "staged", 520, 512)):
+            eng.set_decode_path(path)
+            z = torch.randn(B, 128, generator=gen)
+            lens = [300] * B
+            lens[edge - 1], lens[edge], lens[B - 1] = 123, 7, 299
+            big = eng.vae_decode(z, lens, prec)
+            pick = [0, edge - 1, edge, B - 1]
+            small = eng.vae_decode(z[pick], [lens[i] for i in pick], prec)
+            for k, i in enumerate(pick):
+                assert torch.equal(big["poses"][i], small["poses"][k]) and torch.equal(big["trans"][i], small["trans"][k]), (prec, path, i)
+            assert float(big["poses"][edge, 7:].abs().max()) == 0.0 and bool(torch.isfinite(big["poses"]).all())
+    finally:
+        eng.set_decode_path("auto")
+        eng.close()
