@@ -325,3 +325,33 @@ def test_edit_task_job_lists_follow_the_reference_order():
     m3 = _StubLPDM()
     r3 = run_jobs(m3, mixed)
     assert sorted(c[1] for c in m3.calls) == [0, 2, 4] and [float(r["feats"][0, 0, 0]) for r in r3] == [0.0, 2.0, 4.0]
+
+
+def test_shard_range_properties_hypothesis():
+    """Property form of the sharding contract (hypothesis): for any job size, world size and tile alignment the rank ranges
+    partition [0, total) in rank order, every boundary but the last is a multiple of the alignment (so a clip keeps its slot in
+    its tile - what makes shards bitwise the single-GPU result), and the ranks' loads differ by at most one aligned unit."""
+    from hypothesis import given, settings, strategies as st
+    from amuse_amd.shard import shard_range, job_clips_per_group
+
+    @settings(max_examples=300, deadline=None)
+    @given(st.integers(0, 5000), st.integers(1, 16), st.integers(1, 5))
+    def check(total, world, align):
+        ranges = [shard_range(total, r, world, align=align) for r in range(world)]
+        assert ranges[0][0] == 0 and ranges[-1][1] == total
+        for (a0, a1), (b0, b1) in zip(ranges, ranges[1:]):
+            assert a1 == b0 and a0 <= a1
+        for lo, hi in ranges:
+            assert lo % align == 0 or lo == total
+            assert hi % align == 0 or hi == total
+        units = [-(-(hi - lo) // align) for lo, hi in ranges]
+        assert max(units) - min(units) <= 1
+    check()
+
+    @settings(max_examples=200, deadline=None)
+    @given(st.integers(1, 100000), st.integers(3, 5))
+    def tiling(total, tokens):
+        g = job_clips_per_group(total, tokens)
+        assert 1 <= g <= 16 // tokens
+        assert g == 16 // tokens or total <= 128 * g          # more clips per tile only once 128 tiles are full
+    tiling()
