@@ -290,7 +290,13 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     // Scores arrive in the log2 domain (the qkv epilogue scales q by log2(e) / 8) and RELATIVE to the row's running maximum: the
     // score MFMAs start from C = -m_run, so in the common case - the maximum did not move - p = exp2 of the MFMA result, no
     // subtraction, no rescale.  m_run is the true running maximum from chunk 0 on (chunk 0 starts from C = 0 and takes its own).
-    float m_run[2] = {0.f, 0.f}, l_run[2] = {0.f, 0.f};
+    // The row sums ride the matrix pipe (as in k_vae_fused.hip): a constant "V^T" fragment whose row d = 0 is all ones makes
+    // O^T[0][j] = sum_key P[j][key] - two MFMAs per query tile and chunk instead of fifteen adds and a butterfly on a VALU that is
+    // the busier pipe here (5.6 VALU instructions per MFMA).  What is summed is the bf16 P the PV product uses.  Lane (g = 0, j)
+    // collects query j's sum in os[q][0]; the other three lanes of the row hold 0 there and ONE butterfly at the end broadcasts it.
+    const bf16x8 ones = __builtin_bit_cast(bf16x8, (lane & 15) == 0 ? uint4{0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u} : uint4{0u, 0u, 0u, 0u});
+    float m_run[2] = {0.f, 0.f};
+    f32x4 os[2] = {splat4(0.f), splat4(0.f)};
     f32x4 o[2][4];
 #pragma unroll
     for (int q = 0; q < 2; ++q)
@@ -337,7 +343,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         for (int q = 0; q < 2; ++q) {
             float mx = max3(max3(st[q][0][0], st[q][0][1], st[q][0][2]), max3(st[q][0][3], st[q][1][0], st[q][1][1]), max3(st[q][1][2], st[q][1][3], st[q][2][0]));
             mx = max3(mx, max3(st[q][2][1], st[q][2][2], st[q][2][3]), max3(st[q][3][0], st[q][3][1], st[q][3][2]));
-            mx = allreduce_g_max(fmaxf(mx, st[q][3][3]));   // the same in the four lanes of a row; every chunk holds a valid key
+            mx = fmaxf(mx, st[q][3][3]);   // this lane's 16 scores; every chunk holds a valid key
 #ifdef AMUSE_ATTN_NOC
             if (c > 0) {
 #pragma unroll
@@ -345,14 +351,15 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
                 mx -= m_run[q];
             }
 #endif
-            // the running maximum moves in the first chunks and then hardly ever: shift and rescale only when it moved for some row
-            // of the wave (wave-uniform branch)
+            // the running maximum moves in the first chunks and then hardly ever: the row's maximum (four lanes) is formed, and the
+            // scores shifted and the accumulators rescaled, only when SOME lane of the wave holds a positive score (wave-uniform branch)
             if (c == 0 || __builtin_amdgcn_ballot_w64(mx > 0.f) != 0) {
+                mx = allreduce_g_max(mx);   // the same in the four lanes of a row
                 const float d = c == 0 ? mx : fmaxf(mx, 0.f);
 #pragma unroll
                 for (int u = 0; u < 4; ++u) st[q][u] -= splat4(d);
                 const float alpha = c == 0 ? 0.f : __builtin_amdgcn_exp2f(-d);   // (chunk 0: o = l = 0, and exp2(-d) may overflow)
-                l_run[q] *= alpha;
+                os[q] *= alpha;
 #pragma unroll
                 for (int td = 0; td < 4; ++td) o[q][td] *= alpha;
                 m_run[q] += d;
@@ -362,8 +369,6 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
             for (int u = 0; u < 4; ++u)
 #pragma unroll
                 for (int m = 0; m < 4; ++m) p[u][m] = __builtin_amdgcn_exp2f(st[q][u][m]);   // masked keys: exp2(-inf) = 0
-            const f32x4 sv = (p[0] + p[1]) + (p[2] + p[3]);
-            l_run[q] += allreduce_g_sum((sv[0] + sv[1]) + (sv[2] + sv[3]));
             // k-slots (g, e) of key group pr: e < 4 -> tile 2 pr key 4 g + e, else tile 2 pr + 1 key 4 g + e - 4: the V^T slot order
             pb[q][0] = pack_bf16(p[0], p[1]);
             pb[q][1] = pack_bf16(p[2], p[3]);
@@ -376,13 +381,17 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 #pragma unroll
                 for (int q = 0; q < 2; ++q) o[q][td] = mfma_bf16(vf, pb[q][pr], o[q][td]);
             }
+#pragma unroll
+        for (int pr = 0; pr < 2; ++pr)
+#pragma unroll
+            for (int q = 0; q < 2; ++q) os[q] = mfma_bf16(ones, pb[q][pr], os[q]);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the surplus fetches must not outlive the workgroup's LDS
     // o[q][td][m] = O[query j][feature 64 h + 32 (td >> 1) + 8 g + 4 (td & 1) + m]: the pair td = 2 t, 2 t + 1 is this lane's slot of tile 2 h + t
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
         if (qt0 + q >= kRowTiles) continue;
-        const float inv = 1.0f / l_run[q];
+        const float inv = 1.0f / allreduce_g_sum(os[q][0]);
         char* dst = reinterpret_cast<char*>(O) + (((size_t)b * kRowTiles + qt0 + q) * (kAstDim / 32) + 2 * h) * 1024 + voff;
 #pragma unroll
         for (int tt = 0; tt < 2; ++tt) {
