@@ -390,7 +390,10 @@ __global__ __launch_bounds__(256) void k_vae_attn(VaeAttnArgs a) {
 // online softmax on 8 register values + two permlane butterflies, 2 PV MFMAs (V^T.P^T, K = 32 keys).
 constexpr int kPairs = kKeyRows / 32;                        // 10
 constexpr int kAttnBf16LdsBytes = kKeyRows * 64 + kPairs * 2 * 16 * 64;  // 20 KiB + 20 KiB
-constexpr int kAttnSplitMaxClips = 32;   // up to this many clips per launch a (clip, head) pair is five workgroups (below)
+#ifndef AMUSE_ATTN_SPLIT_MAX
+#define AMUSE_ATTN_SPLIT_MAX 48   // measured (profiles/r03_attn_split_threshold.txt): pays up to ~48 clips in bf16 and fp32x, not at 63
+#endif
+constexpr int kAttnSplitMaxClips = AMUSE_ATTN_SPLIT_MAX;   // up to this many clips per launch a (clip, head) pair is five workgroups (below)
 
 template <int P16, int NQ, int S>   // P16 = PREC_BF16 / PREC_F16: the operand format of q, k, v, p and the output
 __device__ __forceinline__ void attn_qtiles_bf16(const uint4* Kb, const uint4* Vt, const unsigned short* qg,
