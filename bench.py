@@ -316,12 +316,12 @@ def main():
         if B > 0:
             z = torch.randn(B, 128, generator=gen).to(dev)
             dt = []
-            for i in range(6):
+            for i in range(48):   # (the single-clip runs before this leave the GPU at a low clock: 0.64 ms kernels need tens of launches to ramp it)
                 ev0.record()
                 eng.vae_decode(z, None, args.precision)
                 ev1.record()
                 ev1.synchronize()
-                if i >= 1:
+                if i >= 32:
                     dt.append(ev0.elapsed_time(ev1))
             flop_dec = B * FLOP_VAE_DECODE_PER_CLIP
             line["decode"] = {"clips": B, "ms": round(min(dt), 3), "tflops": round(flop_dec / (min(dt) * 1e-3) / 1e12, 1),
