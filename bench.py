@@ -404,6 +404,18 @@ def main():
             dd = {mode: time_job(mode, 5) for mode in ("bf16", "fp16", "fp32x")}
             line["ddim50"] = {"clips": B, **{f"{m}_ms_per_job": round(v, 3) for m, v in dd.items()},
                               **{f"{m}_frames_per_s": round(B * 300 / v * 1e3, 1) for m, v in dd.items()}}
+            # ... and as the reference runs it: ONE clip per call (infer_gesture on one 10 s WAV, BASELINE configs[0] / [1] with DDIM-50)
+            eng.set_clips_per_group(0)
+            for mode in ("bf16", "fp32x"):
+                ts1 = []
+                for i in range(25):
+                    ev0.record()
+                    eng.diffusion_backward(c1, e1, s1, mode, seed=2024, out=o1)
+                    ev1.record()
+                    ev1.synchronize()
+                    if i >= 5:
+                        ts1.append(ev0.elapsed_time(ev1))
+                line["ddim50"][f"{mode}_single_clip_ms"] = round(statistics.median(ts1), 3)
             eng.set_schedule(sch.ddpm_table(args.T))
             eng.set_clips_per_group(0)
         if world == 1 and not args.no_audio:
