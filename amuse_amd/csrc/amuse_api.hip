@@ -314,6 +314,8 @@ struct amuse_ctx {
     uint32_t vae_stage_units[4][kVaeStages];
     uint4* vae_wf = nullptr;           // bf16 stream of the fused decode kernel (k_vae_fused.hip)
     uint4* vae_wfh = nullptr;          // its fp16 twin (k_vae_fusedh.hip, AMUSE_PREC_F16)
+    uint4* vae_w8x = nullptr;          // fp32x row stages without split-K (k_vae_rows8.hip): one stream per stage, consumption order
+    uint32_t vae_w8x_base[kVaeStages];
     uint4* vae_skip = nullptr; size_t vae_skip_cap = 0;   // clips
     float* vae_ca_ws = nullptr; size_t vae_ca_cap = 0;    // clips
     float *vae_pvec = nullptr, *vae_final_bias = nullptr, *vae_pe = nullptr;
@@ -515,6 +517,36 @@ int build_prior(amuse_ctx* c, const float* pri, int what = AMUSE_UPD_ALL) {
         all.insert(all.end(), (size_t)kVaeRing * 64, uint4{0, 0, 0, 0});  // the last wave's ring reads past its slice
         if (upload(&c->vae_w[prec], all.data(), all.size() * sizeof(uint4))) return AMUSE_EHIP;
     }
+    if (what & AMUSE_UPD_F32X) {   // fp32x row stages, eight tiles per workgroup (k_vae_rows8.hip): per stage ONE stream in consumption order, 16-unit
+        // (8 hi | lo pairs) LDS stages: every stage is one k-pair x 8 output tiles, or - linear1 - 4 k-pairs x 2 output tiles
+        std::vector<uint4> s;
+        for (int st = 0; st < kVaeStages; ++st) {
+            c->vae_w8x_base[st] = (uint32_t)(s.size() / 64);
+            if (st >= 1) {
+                const int b = st - 1;
+                const std::string p = blk_name("decoder", b);
+                pack_gemm(s, PREC_F16X2, Pp.get(p + ".self_attn.out_proj.weight"), 128, 128, range(0, 8), range(0, 8));
+                for (int ch = 0; ch < 16; ++ch) {
+                    pack_gemm(s, PREC_F16X2, Pp.get(p + ".linear1.weight"), 512, 128, {2 * ch, 2 * ch + 1}, range(0, 8));
+                    pack_gemm(s, PREC_F16X2, Pp.get(p + ".linear2.weight"), 128, 512, range(0, 8), {2 * ch, 2 * ch + 1});
+                }
+                if (b >= 4 && b <= 7) {   // the skip linear ahead of output block b + 1: the x half, then the popped-skip half
+                    const float* wskip = Pp.get("decoder.linear_blocks." + std::to_string(b - 4) + ".weight");
+                    pack_gemm(s, PREC_F16X2, wskip, 128, 256, range(0, 8), range(0, 8));
+                    pack_gemm(s, PREC_F16X2, wskip, 128, 256, range(0, 8), range(8, 16));
+                }
+            }
+            if (st < 9) {
+                const float* in_w = Pp.get(blk_name("decoder", st) + ".self_attn.in_proj_weight");
+                for (int grp = 0; grp < 3; ++grp) pack_gemm(s, PREC_F16X2, in_w, 384, 128, range(8 * grp, 8 * grp + 8), range(0, 8));
+            } else {
+                for (int q = 0; q < 4; ++q) pack_gemm(s, PREC_F16X2, Pp.get("final_layer.weight"), kFeats, 128, range(6 * q, 6 * q + 6), range(0, 8));
+            }
+            if (s.size() % ((size_t)16 * 64) != 0) return fail(AMUSE_ESTATE, "internal: rows8 stream is not whole stages");
+        }
+        s.insert(s.end(), (size_t)2 * 16 * 64, uint4{0, 0, 0, 0});   // the fetch runs two stages ahead
+        if (upload(&c->vae_w8x, s.data(), s.size() * sizeof(uint4))) return AMUSE_EHIP;
+    }
     for (const int p16 : {PREC_BF16, PREC_F16}) {   // fused decode kernel (k_vae_fused.hip; bf16 / fp16 operands): ONE stream for the four waves, in consumption order, cut
         if (!(what & kUpdBit[p16])) continue;
         // into stages of kVaeFusedStageUnits units (every phase below is a whole number of stages)
@@ -681,6 +713,7 @@ hipError_t dispatch_sample(amuse_ctx* c, SampleArgs& a, int precision, hipStream
 // AMUSE_VAE_FUSED=0 / 1 forces the staged / fused path (A/B measurements, tests of both paths).
 constexpr int kFusedMinClips = 64;   // measured (profiles/r03_decode_perf.txt): fused 0.61 ms for any B <= 128; staged 0.51 ms at 32 clips, 0.66 ms at 64, 1.07 ms at 128
 constexpr int kVaeFusedChunk = 4096;
+constexpr int kRows8MinClips = 128;   // from here on (2,432 row tiles = 203 workgroups of 12) k_vae_rows8x replaces k_vae_rows<f16x2>: measured 1.08 vs 0.92 ms at 64 clips, 2.40 vs 3.04 at 256
 bool use_vae_fused(const amuse_ctx* c, int precision, int B) {
     static const int env = [] { const char* e = getenv("AMUSE_VAE_FUSED"); return e ? atoi(e) : -1; }();
     const int force = c->decode_path == AMUSE_DECODE_STAGED ? 0 : c->decode_path == AMUSE_DECODE_FUSED ? 1 : env;
@@ -793,7 +826,7 @@ int build_repack_maps(amuse_ctx* c) {
     // element type of an image: 0 = fp32, 1 = bf16, 2 = split-fp16, 3 = fp16 (launch_repack's `kind`)
     auto kind_of = [&](void** slot) {
         if (slot == (void**)&c->den_w[PREC_F16X2] || slot == (void**)&c->den_w8x || slot == (void**)&c->vae_w[PREC_F16X2] ||
-            slot == (void**)&c->vaee_w[PREC_F16X2]) return 2;
+            slot == (void**)&c->vaee_w[PREC_F16X2] || slot == (void**)&c->vae_w8x) return 2;
         if (slot == (void**)&c->den_w8h || slot == (void**)&c->vae_wfh || slot == (void**)&c->vae_w[PREC_F16] || slot == (void**)&c->vaee_w[PREC_F16]) return 3;
         return (slot == (void**)&c->den_w[PREC_BF16] || slot == (void**)&c->den_w8 || slot == (void**)&c->vae_w[PREC_BF16] ||
                 slot == (void**)&c->vae_wf || slot == (void**)&c->vaee_w[PREC_BF16]) ? 1 : 0;
@@ -843,7 +876,7 @@ int build_repack_maps(amuse_ctx* c) {
             if (m < 0 || (size_t)m > limit) return fail(AMUSE_ESTATE, "internal: gather index out of range");
         int cls = 0;   // which AMUSE_UPD_* bits the image needs; 0 = small parameters, always replaced
         if (slot == (void**)&c->den_w[PREC_F32] || slot == (void**)&c->vae_w[PREC_F32]) cls = AMUSE_UPD_F32;
-        else if (slot == (void**)&c->den_w[PREC_F16X2] || slot == (void**)&c->den_w8x || slot == (void**)&c->vae_w[PREC_F16X2]) cls = AMUSE_UPD_F32X;
+        else if (slot == (void**)&c->den_w[PREC_F16X2] || slot == (void**)&c->den_w8x || slot == (void**)&c->vae_w[PREC_F16X2] || slot == (void**)&c->vae_w8x) cls = AMUSE_UPD_F32X;
         else if (slot == (void**)&c->vaee_w[PREC_F16X2]) cls = AMUSE_UPD_F32X | AMUSE_UPD_ENCODER;
         else if (slot == (void**)&c->den_w8h || slot == (void**)&c->vae_wfh || slot == (void**)&c->vae_w[PREC_F16]) cls = AMUSE_UPD_F16;
         else if (slot == (void**)&c->vaee_w[PREC_F16]) cls = AMUSE_UPD_F16 | AMUSE_UPD_ENCODER;
@@ -888,7 +921,7 @@ void amuse_destroy(amuse_ctx* c) {
         if (p) (void)hipFree(p);
     void* ptrs[] = {c->den_w[0], c->den_w[1], c->den_w[2], c->den_w8, c->den_w8h, c->den_w8x, c->vae_wfh, c->den_pvec, c->den_pe, c->den_freqs, c->te_w1t, c->te_b1, c->te_w2t,
                     c->te_b2, c->cond_wt[0], c->cond_wt[1], c->cond_wt[2], c->cond_b[0], c->cond_b[1], c->cond_b[2],
-                    c->vae_w[0], c->vae_w[1], c->vae_w[2], c->vae_w[3], c->vaee_w[2], c->vaee_w[3], c->vae_pvec, c->vae_final_bias, c->vae_pe, c->vae_wv_t, c->vae_bv,
+                    c->vae_w[0], c->vae_w[1], c->vae_w[2], c->vae_w[3], c->vae_w8x, c->vaee_w[2], c->vaee_w[3], c->vae_pvec, c->vae_final_bias, c->vae_pe, c->vae_wv_t, c->vae_bv,
                     c->vae_wo_t, c->vae_bo, c->vaee_w[0], c->vaee_w[1], c->vaee_pvec, c->vaee_pe, c->vaee_tok,
                     c->vaee_emb_bias, c->d_timesteps, c->d_coef, c->d_time_tok, c->d_ts1, c->d_tt1, c->d_coef1,
                     c->cond_tok, c->lat_tmp, c->fwd_ws, c->vae_ws, c->d_lengths, c->vae_wf, c->vae_skip, c->vae_ca_ws};
@@ -1100,9 +1133,20 @@ int amuse_vae_decode(amuse_ctx* c, const float* z, const int* lengths, int B, in
         HIP_TRY(launch_vae_ca(z + (size_t)b0 * kD, c->vae_wv_t, c->vae_bv, c->vae_wo_t, c->vae_bo, ca, nb, st));
         VaeAttnArgs aa{};
         aa.q = ra.q; aa.k = ra.k; aa.v = ra.v; aa.lengths = ra.lengths; aa.o = attn_o; aa.B = nb; aa.q_tiles = 19;
+        // fp32x: the row stages without split-K, eight tiles per workgroup (k_vae_rows8.hip) - once there are enough tiles to fill the
+        // chip that way; AMUSE_ROWS8=0 / 1 forces the old / new kernel (A/B measurements, tests of both)
+        static const int rows8_env = [] { const char* e = getenv("AMUSE_ROWS8"); return e ? atoi(e) : -1; }();
+        const bool rows8 = precision == PREC_F16X2 && (rows8_env == 1 || (rows8_env != 0 && nb >= kRows8MinClips));
+        VaeRowsArgs r8 = ra;
+        if (rows8) {
+            r8.wstream = c->vae_w8x;
+            memcpy(r8.stage_base, c->vae_w8x_base, sizeof(r8.stage_base));
+        }
         for (int stage = 0; stage < kVaeStages; ++stage) {
             ra.stage = stage;
-            HIP_TRY(launch_vae_rows(ra, precision, false, st));
+            r8.stage = stage;
+            if (rows8) HIP_TRY(launch_vae_rows8x(r8, st));
+            else HIP_TRY(launch_vae_rows(ra, precision, false, st));
             if (stage < kLayers) HIP_TRY(launch_vae_attn(aa, precision, false, st));
         }
     }

@@ -121,6 +121,7 @@ struct VaeRowsArgs {
     float* stats_out;                 // [B][2][128]: encoder.norm of the distribution rows (mu | logvar)
 };
 hipError_t launch_vae_rows(const VaeRowsArgs& a, int precision, bool enc, hipStream_t stream);
+hipError_t launch_vae_rows8x(const VaeRowsArgs& a, hipStream_t stream);   // fp32x decode row stages, eight tiles per workgroup (k_vae_rows8.hip)
 
 struct VaeAttnArgs {
     const float* q; const float* k; const float* v;  // [B][4][300][32]; q pre-scaled by 1/sqrt(32)

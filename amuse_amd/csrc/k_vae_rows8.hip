@@ -1,0 +1,286 @@
+// The row stages of the staged decode (MotionPrior.decode, reference models/latent_diffusion/vae.py:216-278; decoder layer
+// cross_attention.py:323-345; final_layer + 6D -> axis-angle infer_ldm.py:168-173) in the fp32x arithmetic (AMUSE_PREC_F32X: split-fp16
+// operands, three v_mfma_f32_16x16x32_f16 per product, fp32 everything else) WITHOUT split-K: the shape of the fused decoder's row half.
+//
+// k_vae_rows (k_vae.hip) gives a workgroup of four waves ONE 16-row tile: split-K over the waves, two combines per block through LDS, and
+// the stage's weights - 786 KB in this mode - streamed from L2 once per TILE: 42 % of the load-path floor, 230 us per launch at 256 clips.
+// Here a workgroup is eight waves with a tile EACH (128 rows per pass):
+//   * the stage's weights reach the CU once per workgroup: one stream in consumption order, cut into 16 KiB LDS stages (8 unit pairs:
+//     hi | lo fp16 fragments of one 16-feature x 32-k block), copied global -> LDS by LDS-DMA three stages deep (the protocol of
+//     k_vae_fused.hip: two 1 KiB pieces per wave and stage, vmcnt(2) + s_barrier at a stage's end);
+//   * every GEMM is full-K inside the wave, straight into the residual registers - no partial sums, no combine, LayerNorm inside the
+//     wave; the operand rows are split into hi / lo once per GEMM group;
+//   * one stage = [out_proj + norm1 + cross-attention constant + norm2 + FFN + norm3 (+ skip push / skip linear)] of block i and the
+//     q, k, v projection of block i + 1 (or decoder.norm + final_layer + the rotation epilogue), exactly the cut of k_vae_rows, so the
+//     attention kernels between the stages stay as they are.
+// Every LDS stage is either one k-pair x 8 output tiles or (linear1) 4 k-pairs x 2 output tiles; the last stage's 24 output tiles go in
+// four quarters of 6 (one staging tile of 16 x 96 features per wave, as in k_vae_fused.hip).
+#include "amuse_dev.hpp"
+#include "amuse_kernels.hpp"
+
+namespace amuse {
+namespace {
+
+// erf of the FFN activation: 0 = libm erff (as k_vae_rows<f16x2>), 1 = Abramowitz-Stegun 7.1.26 on the hardware rcp / exp2 (|erf error| <= 1.5e-7;
+// amuse_dev.hpp gelu_erf_fast) - this kernel is VALU-throughput-bound where the sampler's critical path was latency-bound
+#ifndef AMUSE_R8_FAST_ERF
+#define AMUSE_R8_FAST_ERF 0
+#endif
+constexpr int kRowTiles = 19;                 // ceil(300 / 16)
+#ifndef AMUSE_R8_WAVES
+#define AMUSE_R8_WAVES 12
+#endif
+constexpr int kWaves = AMUSE_R8_WAVES;      // row tiles per workgroup (8: two waves per SIMD, 12: three - the kernel needs 154 registers)
+constexpr int kDmaWaves = 8;                 // the waves that copy the stream: 16 units per LDS stage, two pieces each
+constexpr int kStage = 16;                    // units per LDS stage (8 hi | lo pairs)
+constexpr int kStageBytes = kStage * 1024;
+constexpr int kWBufs = 3;
+constexpr int kQStride = 100;                 // staging row stride (floats) of one 96-feature quarter of the last stage
+constexpr int kOffW = 0;
+constexpr int kOffStage = kWBufs * kStageBytes;
+constexpr int kRows8LdsBytes = kOffStage + kWaves * 16 * kQStride * 4;
+
+__device__ __forceinline__ void glds16(const uint4* gsrc, unsigned lds_dst) {   // (k_vae_fused.hip: LDS-DMA outside hipcc's waitcnt bookkeeping)
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(gsrc), "s"(lds_dst)
+                 : "memory");
+}
+struct Stager {
+    const uint4* src;   // this lane's source address of the wave's pieces of the NEXT stage to fetch
+    unsigned dst0;      // LDS byte address of the wave's pieces inside buffer 0
+    const char* ring;   // weight ring base (generic pointer) + lane * 16
+    int widx, ridx;     // buffer the next fetch fills / buffer the current stage reads
+    bool dma;           // this wave copies (waves 0..7)
+};
+__device__ __forceinline__ void stage_fetch(Stager& s) {
+    if (s.dma) {   // (wave-uniform; the other waves' vmcnt(2) at the stage's end is trivially true - the barrier is what they need)
+        const unsigned d = __builtin_amdgcn_readfirstlane(s.dst0 + s.widx * kStageBytes);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) glds16(s.src + i * 64, d + i * 1024);
+    }
+    s.src += kStage * 64;
+    s.widx = s.widx == kWBufs - 1 ? 0 : s.widx + 1;
+}
+__device__ __forceinline__ void stage_end(Stager& s) {
+    asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    s.ridx = s.ridx == kWBufs - 1 ? 0 : s.ridx + 1;
+}
+__device__ __forceinline__ f16x8 wfrag(const Stager& s, int u) {
+    return __builtin_bit_cast(f16x8, *reinterpret_cast<const uint4*>(s.ring + s.ridx * kStageBytes + u * 1024));
+}
+// one product of split operands: acc += Wl.xh + Wh.xl + Wh.xh (the term order of gemm_ring_s, amuse_dev.hpp)
+__device__ __forceinline__ f32x4 mfma3(f16x8 wh, f16x8 wl, const F16Pair& x, f32x4 acc) {
+    acc = mfma_f16(wl, x.hi, acc);
+    acc = mfma_f16(wh, x.lo, acc);
+    return mfma_f16(wh, x.hi, acc);
+}
+// the 8 unit pairs of the current LDS stage, pair i -> f(i, hi, lo); the fragments of pair i + 1 are read before pair i's MFMAs
+template <class F>
+__device__ __forceinline__ void for_pairs(Stager& s, F&& f) {
+    stage_fetch(s);
+    f16x8 h = wfrag(s, 0), l = wfrag(s, 1);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const f16x8 ch = h, cl = l;
+        if (i + 1 < 8) { h = wfrag(s, 2 * i + 2); l = wfrag(s, 2 * i + 3); }
+        f(i, ch, cl);
+    }
+    stage_end(s);
+}
+// acc[o] += W[o-tile][k-pairs 0..3] . x over FOUR LDS stages (k-pair outer, 8 output tiles inner)
+__device__ __forceinline__ void gemm_k128_o8(f32x4 (&acc)[8], const F16Pair (&xs)[4], Stager& s) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c) for_pairs(s, [&](int o, f16x8 wh, f16x8 wl) { acc[o] = mfma3(wh, wl, xs[c], acc[o]); });
+}
+__device__ __forceinline__ void split_x(F16Pair (&xs)[4], const f32x4 (&x)[kTiles]) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c) xs[c] = split_f16(x[2 * c], x[2 * c + 1]);
+}
+
+__global__ __launch_bounds__(64 * kWaves) __attribute__((amdgpu_waves_per_eu(kWaves / 4, kWaves / 4))) void k_vae_rows8x(VaeRowsArgs a) {
+    constexpr int S = kFrames;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int g = lane >> 4, r = lane & 15;
+    const int gt = blockIdx.x * kWaves + wave;                 // this wave's (clip, row tile)
+    const bool tvalid = gt < a.B * kRowTiles;                  // (waves beyond the batch only keep the stage protocol turning)
+    const int b = tvalid ? gt / kRowTiles : 0, rt = tvalid ? gt - b * kRowTiles : 0;
+    const int frame = rt * 16 + r;
+    const bool rvalid = tvalid && frame < S;
+    const size_t row = (size_t)b * S + (rvalid ? frame : 0);
+    const size_t nrows = (size_t)a.B * S;
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) const void*)smem;
+    Stager sg;
+    sg.dma = wave < kDmaWaves;
+    sg.src = a.wstream + (size_t)a.stage_base[a.stage] * 64 + (size_t)(wave % kDmaWaves) * 2 * 64 + lane;
+    sg.dst0 = lds0 + kOffW + (wave % kDmaWaves) * 2048;
+    sg.ring = smem + kOffW + lane * 16;
+    sg.widx = 0;
+    sg.ridx = 0;
+    stage_fetch(sg);
+    stage_fetch(sg);
+    f32x4 x[kTiles];
+    if (a.stage == 0) {   // queries = zeros + query_pos_decoder.pe[:300]  (vae.py:220,258)
+#pragma unroll
+        for (int t = 0; t < kTiles; ++t) x[t] = rvalid ? ld4(a.pe + (size_t)frame * kD + 16 * t + 4 * g) : splat4(0.f);
+    } else {
+#pragma unroll
+        for (int t = 0; t < kTiles; ++t) x[t] = rvalid ? ld4(a.x + row * kD + 16 * t + 4 * g) : splat4(0.f);
+    }
+    // (hipcc's own waits cover the loads above; the protocol's first wait: both prefetched stages but the second one's pieces)
+    asm volatile("s_waitcnt vmcnt(2)\n\ts_barrier" ::: "memory");
+    F16Pair xs[4];
+    if (a.stage >= 1) {
+        const int blk = a.stage - 1;
+        const float* pv = a.pvec + blk * PV_BLOCK;
+        // ---- self-attention out_proj + residual + norm1  (cross_attention.py:323-330)
+        {
+            f32x4 o[kTiles];
+#pragma unroll
+            for (int t = 0; t < kTiles; ++t) o[t] = rvalid ? ld4(a.attn_o + row * kD + 16 * t + 4 * g) : splat4(0.f);
+            split_x(xs, o);
+        }
+#pragma unroll
+        for (int t = 0; t < kTiles; ++t) x[t] += ld4(pv + PV_OUT_B + 16 * t + 4 * g);
+        gemm_k128_o8(x, xs, sg);
+        layer_norm_rows<false>(x, pv + PV_LN1_W, pv + PV_LN1_B, g);
+        // ---- cross-attention onto the single latent token == per-clip constant; norm2  (cross_attention.py:331-337)
+        {
+            const float* ca = a.ca + ((size_t)b * kLayers + blk) * kD;
+#pragma unroll
+            for (int t = 0; t < kTiles; ++t) x[t] += ld4(ca + 16 * t + 4 * g);
+        }
+        layer_norm_rows<false>(x, pv + PV_LN2_W, pv + PV_LN2_B, g);
+        // ---- FFN in 16 chunks of 32 hidden features: linear1 (4 k-pairs x 2 tiles: one LDS stage) -> erf-GELU -> linear2's k-pair of
+        // those features (8 output tiles: one LDS stage), accumulated into the residual; norm3  (cross_attention.py:338-340)
+        split_x(xs, x);
+#pragma unroll
+        for (int t = 0; t < kTiles; ++t) x[t] += ld4(pv + PV_L2_B + 16 * t + 4 * g);
+#pragma unroll 1
+        for (int ch = 0; ch < 16; ++ch) {
+            f32x4 hid[2] = {ld4(pv + PV_L1_B + 32 * ch + 4 * g), ld4(pv + PV_L1_B + 32 * ch + 16 + 4 * g)};
+            for_pairs(sg, [&](int i, f16x8 wh, f16x8 wl) { hid[i & 1] = mfma3(wh, wl, xs[i >> 1], hid[i & 1]); });
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int m = 0; m < 4; ++m) hid[i][m] = AMUSE_R8_FAST_ERF ? gelu_erf_fast(hid[i][m]) : gelu_erf(hid[i][m]);
+            const F16Pair hs = split_f16(hid[0], hid[1]);
+            for_pairs(sg, [&](int o, f16x8 wh, f16x8 wl) { x[o] = mfma3(wh, wl, hs, x[o]); });
+        }
+        layer_norm_rows<false>(x, pv + PV_LN3_W, pv + PV_LN3_B, g);
+        // ---- U-Net wiring (cross_attention.py:104-121): input blocks push, the skip linear runs ahead of the next output block
+        if (blk < 4 && rvalid) {
+            float* sk = a.skip + ((size_t)blk * nrows + row) * kD;
+#pragma unroll
+            for (int t = 0; t < kTiles; ++t) st4(sk + 16 * t + 4 * g, x[t]);
+        }
+        if (blk >= 4 && blk <= 7) {   // x = linear_blocks[blk - 4](cat(x, xs.pop()))
+            const float* sk = a.skip + ((size_t)(7 - blk) * nrows + row) * kD;
+            const float* bs = a.pvec + PV_SKIP_B + (blk - 4) * kD;
+            split_x(xs, x);
+#pragma unroll
+            for (int t = 0; t < kTiles; ++t) x[t] = ld4(bs + 16 * t + 4 * g);
+            gemm_k128_o8(x, xs, sg);
+            {
+                f32x4 sv[kTiles];
+#pragma unroll
+                for (int t = 0; t < kTiles; ++t) sv[t] = rvalid ? ld4(sk + 16 * t + 4 * g) : splat4(0.f);
+                split_x(xs, sv);
+            }
+            gemm_k128_o8(x, xs, sg);
+        }
+    }
+    if (a.stage < kLayers) {
+        // ---- residual stream for the next stage + in_proj of block `stage`: q | k | v as three groups of 8 output tiles
+        if (rvalid) {
+#pragma unroll
+            for (int t = 0; t < kTiles; ++t) st4(a.x + row * kD + 16 * t + 4 * g, x[t]);
+        }
+        const float* pv = a.pvec + a.stage * PV_BLOCK;
+        split_x(xs, x);
+        const float scaling = 0.17677669529663687f;   // 1 / sqrt(32): q * scaling (F.multi_head_attention_forward)
+#pragma unroll 1
+        for (int grp = 0; grp < 3; ++grp) {
+            f32x4 acc[8];
+#pragma unroll
+            for (int t = 0; t < 8; ++t) acc[t] = ld4(pv + PV_IN_B + grp * kD + 16 * t + 4 * g);
+            gemm_k128_o8(acc, xs, sg);
+            float* dst = grp == 0 ? a.q : grp == 1 ? a.k : a.v;
+            if (rvalid) {
+#pragma unroll
+                for (int t = 0; t < 8; ++t) {   // output tile t = head t / 2, features 16 (t & 1) ..
+                    const size_t hrow = (((size_t)b * kHeads + (t >> 1)) * S + frame) * 32;
+                    st4(dst + hrow + 16 * (t & 1) + 4 * g, grp == 0 ? acc[t] * scaling : acc[t]);
+                }
+            }
+        }
+    } else {
+        // ---- decoder.norm -> final_layer (333 outputs in 24 tiles, four quarters of 6) -> rotation epilogue
+        layer_norm_rows<false>(x, a.pvec + PV_FINAL_W, a.pvec + PV_FINAL_B, g);
+        split_x(xs, x);
+        float* fst = reinterpret_cast<float*>(smem + kOffStage) + wave * 16 * kQStride;
+        const int len = a.lengths ? a.lengths[b] : S;
+        const bool keep = rvalid && frame < len;   // output[~mask.T] = 0 (vae.py:274)
+        const int rows_here = tvalid ? min(16, S - rt * 16) : 0;
+        const size_t row0 = (size_t)b * S + rt * 16;
+#pragma unroll 1
+        for (int quarter = 0; quarter < 4; ++quarter) {
+            f32x4 f[6];
+#pragma unroll
+            for (int o = 0; o < 6; ++o) f[o] = ld4(a.final_bias + 16 * (6 * quarter + o) + 4 * g);
+#pragma unroll
+            for (int s3 = 0; s3 < 3; ++s3)   // 6 output tiles x 4 k-pairs = 24 pairs = 3 LDS stages (k-pair outer)
+                for_pairs(sg, [&](int i, f16x8 wh, f16x8 wl) {
+                    const int lin = 8 * s3 + i, c = lin / 6, o = lin - 6 * c;
+                    f[o] = mfma3(wh, wl, xs[c], f[o]);
+                });
+#pragma unroll
+            for (int o = 0; o < 6; ++o) st4(fst + r * kQStride + 16 * o + 4 * g, keep ? f[o] : splat4(0.f));
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the staging tile is wave-private: no barrier
+            const int f0 = 96 * quarter, nfe = quarter == 3 ? kFeats - 288 : 96, njo = quarter == 3 ? kJoints - 48 : 16;
+            if (a.feats_out) {
+                for (int i = lane; i < rows_here * nfe; i += 64) {
+                    const int rr = i / nfe, c = i - rr * nfe;
+                    a.feats_out[(row0 + rr) * kFeats + f0 + c] = fst[rr * kQStride + c];
+                }
+            }
+            if (a.poses_out) {
+                for (int i = lane; i < rows_here * njo; i += 64) {
+                    const int rr = i / njo, jn = i - rr * njo;
+                    float aa[3];
+                    rot6d_to_axis_angle(fst + rr * kQStride + 6 * jn, a.quat_mode, aa);
+                    float* dst = a.poses_out + ((row0 + rr) * kJoints + 16 * quarter + jn) * 3;
+                    dst[0] = aa[0]; dst[1] = aa[1]; dst[2] = aa[2];
+                }
+            }
+            if (a.trans_out && quarter == 3) {
+                for (int i = lane; i < rows_here * 3; i += 64) {
+                    const int rr = i / 3, c = i - rr * 3;
+                    a.trans_out[(row0 + rr) * 3 + c] = fst[rr * kQStride + (330 - 288) + c];
+                }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the two surplus fetches must not outlive the workgroup's LDS
+}
+
+}  // namespace
+
+hipError_t launch_vae_rows8x(const VaeRowsArgs& a, hipStream_t stream) {
+    static DeviceOnce once;
+    int dev_;
+    if (!once.done(&dev_)) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_vae_rows8x), hipFuncAttributeMaxDynamicSharedMemorySize, kRows8LdsBytes);
+        if (e != hipSuccess) return e;
+        once.set(dev_);
+    }
+    const int tiles = a.B * kRowTiles;
+    hipLaunchKernelGGL(k_vae_rows8x, dim3((tiles + kWaves - 1) / kWaves), dim3(64 * kWaves), kRows8LdsBytes, stream, a);
+    return hipGetLastError();
+}
+
+}  // namespace amuse
