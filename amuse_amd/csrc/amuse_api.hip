@@ -713,11 +713,18 @@ hipError_t dispatch_sample(amuse_ctx* c, SampleArgs& a, int precision, hipStream
 // AMUSE_VAE_FUSED=0 / 1 forces the staged / fused path (A/B measurements, tests of both paths).
 constexpr int kFusedMinClips = 64;   // measured (profiles/r03_decode_perf.txt): fused 0.61 ms for any B <= 128; staged 0.51 ms at 32 clips, 0.66 ms at 64, 1.07 ms at 128
 constexpr int kVaeFusedChunk = 4096;
-constexpr int kRows8MinClips = 128;   // from here on (2,432 row tiles = 203 workgroups of 12) k_vae_rows8x replaces k_vae_rows<f16x2>: measured 1.08 vs 0.92 ms at 64 clips, 2.40 vs 3.04 at 256
 bool use_vae_fused(const amuse_ctx* c, int precision, int B) {
     static const int env = [] { const char* e = getenv("AMUSE_VAE_FUSED"); return e ? atoi(e) : -1; }();
     const int force = c->decode_path == AMUSE_DECODE_STAGED ? 0 : c->decode_path == AMUSE_DECODE_FUSED ? 1 : env;
     if (!is_op16(precision) || force == 0) return false;   // (the fused kernel exists in the two one-piece 16-bit formats)
+    return force == 1 || B >= kFusedMinClips;
+}
+
+// fp32x decode: the no-split-K row kernel (k_vae_rows8.hip) under the same rule and the same pins as the fused kernel of the 16-bit modes
+bool use_rows8(const amuse_ctx* c, int precision, int B) {
+    static const int env = [] { const char* e = getenv("AMUSE_VAE_FUSED"); return e ? atoi(e) : -1; }();
+    const int force = c->decode_path == AMUSE_DECODE_STAGED ? 0 : c->decode_path == AMUSE_DECODE_FUSED ? 1 : env;
+    if (precision != PREC_F16X2 || force == 0) return false;
     return force == 1 || B >= kFusedMinClips;
 }
 
@@ -1133,10 +1140,10 @@ int amuse_vae_decode(amuse_ctx* c, const float* z, const int* lengths, int B, in
         HIP_TRY(launch_vae_ca(z + (size_t)b0 * kD, c->vae_wv_t, c->vae_bv, c->vae_wo_t, c->vae_bo, ca, nb, st));
         VaeAttnArgs aa{};
         aa.q = ra.q; aa.k = ra.k; aa.v = ra.v; aa.lengths = ra.lengths; aa.o = attn_o; aa.B = nb; aa.q_tiles = 19;
-        // fp32x: the row stages without split-K, eight tiles per workgroup (k_vae_rows8.hip) - once there are enough tiles to fill the
-        // chip that way; AMUSE_ROWS8=0 / 1 forces the old / new kernel (A/B measurements, tests of both)
-        static const int rows8_env = [] { const char* e = getenv("AMUSE_ROWS8"); return e ? atoi(e) : -1; }();
-        const bool rows8 = precision == PREC_F16X2 && (rows8_env == 1 || (rows8_env != 0 && nb >= kRows8MinClips));
+        // fp32x: the row stages without split-K (k_vae_rows8.hip) under the rule of the 16-bit modes' fused kernel - from kFusedMinClips clips
+        // of the CALL (not of the chunk: a job's last chunk must not change kernels), or as amuse_set_decode_path / AMUSE_VAE_FUSED pin it
+        // (FUSED = this kernel, STAGED = k_vae_rows<f16x2>), so that amuse_amd/shard.py's job-level choice keeps fp32x shards bitwise too
+        const bool rows8 = use_rows8(c, precision, B);
         VaeRowsArgs r8 = ra;
         if (rows8) {
             r8.wstream = c->vae_w8x;

@@ -27,10 +27,10 @@ namespace {
 #define AMUSE_R8_FAST_ERF 0
 #endif
 constexpr int kRowTiles = 19;                 // ceil(300 / 16)
-#ifndef AMUSE_R8_WAVES
-#define AMUSE_R8_WAVES 12
+#ifndef AMUSE_R8_NT
+#define AMUSE_R8_NT 1
 #endif
-constexpr int kWaves = AMUSE_R8_WAVES;      // row tiles per workgroup (8: two waves per SIMD, 12: three - the kernel needs 154 registers)
+constexpr int kTilesPerWave = AMUSE_R8_NT;    // row tiles per wave: a weight fragment read from LDS feeds 3 x NT MFMAs
 constexpr int kDmaWaves = 8;                 // the waves that copy the stream: 16 units per LDS stage, two pieces each
 constexpr int kStage = 16;                    // units per LDS stage (8 hi | lo pairs)
 constexpr int kStageBytes = kStage * 1024;
@@ -38,7 +38,7 @@ constexpr int kWBufs = 3;
 constexpr int kQStride = 100;                 // staging row stride (floats) of one 96-feature quarter of the last stage
 constexpr int kOffW = 0;
 constexpr int kOffStage = kWBufs * kStageBytes;
-constexpr int kRows8LdsBytes = kOffStage + kWaves * 16 * kQStride * 4;
+constexpr int rows8_lds_bytes(int waves) { return kOffStage + waves * 16 * kQStride * 4; }
 
 __device__ __forceinline__ void glds16(const uint4* gsrc, unsigned lds_dst) {   // (k_vae_fused.hip: LDS-DMA outside hipcc's waitcnt bookkeeping)
     unsigned keep;
@@ -89,28 +89,47 @@ __device__ __forceinline__ void for_pairs(Stager& s, F&& f) {
     }
     stage_end(s);
 }
-// acc[o] += W[o-tile][k-pairs 0..3] . x over FOUR LDS stages (k-pair outer, 8 output tiles inner)
-__device__ __forceinline__ void gemm_k128_o8(f32x4 (&acc)[8], const F16Pair (&xs)[4], Stager& s) {
+// acc[j][o] += W[o-tile][k-pairs 0..3] . x_j over FOUR LDS stages (k-pair outer, 8 output tiles inner); a fragment pair read from LDS
+// feeds the MFMAs of all NT row tiles of the wave
+template <int NT>
+__device__ __forceinline__ void gemm_k128_o8(f32x4 (&acc)[NT][8], const F16Pair (&xs)[NT][4], Stager& s) {
 #pragma unroll
-    for (int c = 0; c < 4; ++c) for_pairs(s, [&](int o, f16x8 wh, f16x8 wl) { acc[o] = mfma3(wh, wl, xs[c], acc[o]); });
+    for (int c = 0; c < 4; ++c)
+        for_pairs(s, [&](int o, f16x8 wh, f16x8 wl) {
+#pragma unroll
+            for (int j = 0; j < NT; ++j) acc[j][o] = mfma3(wh, wl, xs[j][c], acc[j][o]);
+        });
 }
-__device__ __forceinline__ void split_x(F16Pair (&xs)[4], const f32x4 (&x)[kTiles]) {
+template <int NT>
+__device__ __forceinline__ void split_x(F16Pair (&xs)[NT][4], const f32x4 (&x)[NT][kTiles]) {
 #pragma unroll
-    for (int c = 0; c < 4; ++c) xs[c] = split_f16(x[2 * c], x[2 * c + 1]);
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) xs[j][c] = split_f16(x[j][2 * c], x[j][2 * c + 1]);
 }
 
+// kWaves waves per workgroup (12 = three per SIMD: the kernel needs ~158 registers; 8 for launches of few tiles - the same bits: a tile's
+// arithmetic does not depend on its workgroup), NT row tiles per wave: wave w of workgroup wg owns tiles (wg * kWaves + w) * NT + j
+template <int NT, int kWaves>
 __global__ __launch_bounds__(64 * kWaves) __attribute__((amdgpu_waves_per_eu(kWaves / 4, kWaves / 4))) void k_vae_rows8x(VaeRowsArgs a) {
     constexpr int S = kFrames;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int g = lane >> 4, r = lane & 15;
-    const int gt = blockIdx.x * kWaves + wave;                 // this wave's (clip, row tile)
-    const bool tvalid = gt < a.B * kRowTiles;                  // (waves beyond the batch only keep the stage protocol turning)
-    const int b = tvalid ? gt / kRowTiles : 0, rt = tvalid ? gt - b * kRowTiles : 0;
-    const int frame = rt * 16 + r;
-    const bool rvalid = tvalid && frame < S;
-    const size_t row = (size_t)b * S + (rvalid ? frame : 0);
+    int b[NT], rt[NT], frame[NT];
+    bool tvalid[NT], rvalid[NT];
+    size_t row[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+        const int gt = (blockIdx.x * kWaves + wave) * NT + j;   // this wave's j-th (clip, row tile)
+        tvalid[j] = gt < a.B * kRowTiles;                       // (tiles beyond the batch only keep the stage protocol turning)
+        b[j] = tvalid[j] ? gt / kRowTiles : 0;
+        rt[j] = tvalid[j] ? gt - b[j] * kRowTiles : 0;
+        frame[j] = rt[j] * 16 + r;
+        rvalid[j] = tvalid[j] && frame[j] < S;
+        row[j] = (size_t)b[j] * S + (rvalid[j] ? frame[j] : 0);
+    }
     const size_t nrows = (size_t)a.B * S;
     const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) const void*)smem;
     Stager sg;
@@ -122,165 +141,215 @@ __global__ __launch_bounds__(64 * kWaves) __attribute__((amdgpu_waves_per_eu(kWa
     sg.ridx = 0;
     stage_fetch(sg);
     stage_fetch(sg);
-    f32x4 x[kTiles];
-    if (a.stage == 0) {   // queries = zeros + query_pos_decoder.pe[:300]  (vae.py:220,258)
+    f32x4 x[NT][kTiles];
 #pragma unroll
-        for (int t = 0; t < kTiles; ++t) x[t] = rvalid ? ld4(a.pe + (size_t)frame * kD + 16 * t + 4 * g) : splat4(0.f);
-    } else {
+    for (int j = 0; j < NT; ++j) {
+        // stage 0: queries = zeros + query_pos_decoder.pe[:300]  (vae.py:220,258)
+        const float* src = a.stage == 0 ? a.pe + (size_t)frame[j] * kD : a.x + row[j] * kD;
 #pragma unroll
-        for (int t = 0; t < kTiles; ++t) x[t] = rvalid ? ld4(a.x + row * kD + 16 * t + 4 * g) : splat4(0.f);
+        for (int t = 0; t < kTiles; ++t) x[j][t] = rvalid[j] ? ld4(src + 16 * t + 4 * g) : splat4(0.f);
     }
     // (hipcc's own waits cover the loads above; the protocol's first wait: both prefetched stages but the second one's pieces)
     asm volatile("s_waitcnt vmcnt(2)\n\ts_barrier" ::: "memory");
-    F16Pair xs[4];
+    F16Pair xs[NT][4];
     if (a.stage >= 1) {
         const int blk = a.stage - 1;
         const float* pv = a.pvec + blk * PV_BLOCK;
         // ---- self-attention out_proj + residual + norm1  (cross_attention.py:323-330)
-        {
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
             f32x4 o[kTiles];
 #pragma unroll
-            for (int t = 0; t < kTiles; ++t) o[t] = rvalid ? ld4(a.attn_o + row * kD + 16 * t + 4 * g) : splat4(0.f);
-            split_x(xs, o);
-        }
+            for (int t = 0; t < kTiles; ++t) o[t] = rvalid[j] ? ld4(a.attn_o + row[j] * kD + 16 * t + 4 * g) : splat4(0.f);
 #pragma unroll
-        for (int t = 0; t < kTiles; ++t) x[t] += ld4(pv + PV_OUT_B + 16 * t + 4 * g);
-        gemm_k128_o8(x, xs, sg);
-        layer_norm_rows<false>(x, pv + PV_LN1_W, pv + PV_LN1_B, g);
-        // ---- cross-attention onto the single latent token == per-clip constant; norm2  (cross_attention.py:331-337)
-        {
-            const float* ca = a.ca + ((size_t)b * kLayers + blk) * kD;
+            for (int c = 0; c < 4; ++c) xs[j][c] = split_f16(o[2 * c], o[2 * c + 1]);
 #pragma unroll
-            for (int t = 0; t < kTiles; ++t) x[t] += ld4(ca + 16 * t + 4 * g);
+            for (int t = 0; t < kTiles; ++t) x[j][t] += ld4(pv + PV_OUT_B + 16 * t + 4 * g);
         }
-        layer_norm_rows<false>(x, pv + PV_LN2_W, pv + PV_LN2_B, g);
+        gemm_k128_o8<NT>(x, xs, sg);
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            layer_norm_rows<false>(x[j], pv + PV_LN1_W, pv + PV_LN1_B, g);
+            // cross-attention onto the single latent token == per-clip constant; norm2  (cross_attention.py:331-337)
+            const float* ca = a.ca + ((size_t)b[j] * kLayers + blk) * kD;
+#pragma unroll
+            for (int t = 0; t < kTiles; ++t) x[j][t] += ld4(ca + 16 * t + 4 * g);
+            layer_norm_rows<false>(x[j], pv + PV_LN2_W, pv + PV_LN2_B, g);
+        }
         // ---- FFN in 16 chunks of 32 hidden features: linear1 (4 k-pairs x 2 tiles: one LDS stage) -> erf-GELU -> linear2's k-pair of
         // those features (8 output tiles: one LDS stage), accumulated into the residual; norm3  (cross_attention.py:338-340)
-        split_x(xs, x);
+        split_x<NT>(xs, x);
 #pragma unroll
-        for (int t = 0; t < kTiles; ++t) x[t] += ld4(pv + PV_L2_B + 16 * t + 4 * g);
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int t = 0; t < kTiles; ++t) x[j][t] += ld4(pv + PV_L2_B + 16 * t + 4 * g);
 #pragma unroll 1
         for (int ch = 0; ch < 16; ++ch) {
-            f32x4 hid[2] = {ld4(pv + PV_L1_B + 32 * ch + 4 * g), ld4(pv + PV_L1_B + 32 * ch + 16 + 4 * g)};
-            for_pairs(sg, [&](int i, f16x8 wh, f16x8 wl) { hid[i & 1] = mfma3(wh, wl, xs[i >> 1], hid[i & 1]); });
+            f32x4 hid[NT][2];
+            const f32x4 b0 = ld4(pv + PV_L1_B + 32 * ch + 4 * g), b1 = ld4(pv + PV_L1_B + 32 * ch + 16 + 4 * g);
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+            for (int j = 0; j < NT; ++j) { hid[j][0] = b0; hid[j][1] = b1; }
+            for_pairs(sg, [&](int i, f16x8 wh, f16x8 wl) {
 #pragma unroll
-                for (int m = 0; m < 4; ++m) hid[i][m] = AMUSE_R8_FAST_ERF ? gelu_erf_fast(hid[i][m]) : gelu_erf(hid[i][m]);
-            const F16Pair hs = split_f16(hid[0], hid[1]);
-            for_pairs(sg, [&](int o, f16x8 wh, f16x8 wl) { x[o] = mfma3(wh, wl, hs, x[o]); });
+                for (int j = 0; j < NT; ++j) hid[j][i & 1] = mfma3(wh, wl, xs[j][i >> 1], hid[j][i & 1]);
+            });
+            F16Pair hs[NT];
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int m = 0; m < 4; ++m) hid[j][i][m] = AMUSE_R8_FAST_ERF ? gelu_erf_fast(hid[j][i][m]) : gelu_erf(hid[j][i][m]);
+                hs[j] = split_f16(hid[j][0], hid[j][1]);
+            }
+            for_pairs(sg, [&](int o, f16x8 wh, f16x8 wl) {
+#pragma unroll
+                for (int j = 0; j < NT; ++j) x[j][o] = mfma3(wh, wl, hs[j], x[j][o]);
+            });
         }
-        layer_norm_rows<false>(x, pv + PV_LN3_W, pv + PV_LN3_B, g);
-        // ---- U-Net wiring (cross_attention.py:104-121): input blocks push, the skip linear runs ahead of the next output block
-        if (blk < 4 && rvalid) {
-            float* sk = a.skip + ((size_t)blk * nrows + row) * kD;
 #pragma unroll
-            for (int t = 0; t < kTiles; ++t) st4(sk + 16 * t + 4 * g, x[t]);
+        for (int j = 0; j < NT; ++j) layer_norm_rows<false>(x[j], pv + PV_LN3_W, pv + PV_LN3_B, g);
+        // ---- U-Net wiring (cross_attention.py:104-121): input blocks push, the skip linear runs ahead of the next output block
+        if (blk < 4) {
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                if (!rvalid[j]) continue;
+                float* sk = a.skip + ((size_t)blk * nrows + row[j]) * kD;
+#pragma unroll
+                for (int t = 0; t < kTiles; ++t) st4(sk + 16 * t + 4 * g, x[j][t]);
+            }
         }
         if (blk >= 4 && blk <= 7) {   // x = linear_blocks[blk - 4](cat(x, xs.pop()))
-            const float* sk = a.skip + ((size_t)(7 - blk) * nrows + row) * kD;
             const float* bs = a.pvec + PV_SKIP_B + (blk - 4) * kD;
-            split_x(xs, x);
+            split_x<NT>(xs, x);
 #pragma unroll
-            for (int t = 0; t < kTiles; ++t) x[t] = ld4(bs + 16 * t + 4 * g);
-            gemm_k128_o8(x, xs, sg);
-            {
+            for (int j = 0; j < NT; ++j)
+#pragma unroll
+                for (int t = 0; t < kTiles; ++t) x[j][t] = ld4(bs + 16 * t + 4 * g);
+            gemm_k128_o8<NT>(x, xs, sg);
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                const float* sk = a.skip + ((size_t)(7 - blk) * nrows + row[j]) * kD;
                 f32x4 sv[kTiles];
 #pragma unroll
-                for (int t = 0; t < kTiles; ++t) sv[t] = rvalid ? ld4(sk + 16 * t + 4 * g) : splat4(0.f);
-                split_x(xs, sv);
+                for (int t = 0; t < kTiles; ++t) sv[t] = rvalid[j] ? ld4(sk + 16 * t + 4 * g) : splat4(0.f);
+#pragma unroll
+                for (int c = 0; c < 4; ++c) xs[j][c] = split_f16(sv[2 * c], sv[2 * c + 1]);
             }
-            gemm_k128_o8(x, xs, sg);
+            gemm_k128_o8<NT>(x, xs, sg);
         }
     }
     if (a.stage < kLayers) {
         // ---- residual stream for the next stage + in_proj of block `stage`: q | k | v as three groups of 8 output tiles
-        if (rvalid) {
 #pragma unroll
-            for (int t = 0; t < kTiles; ++t) st4(a.x + row * kD + 16 * t + 4 * g, x[t]);
+        for (int j = 0; j < NT; ++j) {
+            if (!rvalid[j]) continue;
+#pragma unroll
+            for (int t = 0; t < kTiles; ++t) st4(a.x + row[j] * kD + 16 * t + 4 * g, x[j][t]);
         }
         const float* pv = a.pvec + a.stage * PV_BLOCK;
-        split_x(xs, x);
+        split_x<NT>(xs, x);
         const float scaling = 0.17677669529663687f;   // 1 / sqrt(32): q * scaling (F.multi_head_attention_forward)
 #pragma unroll 1
         for (int grp = 0; grp < 3; ++grp) {
-            f32x4 acc[8];
+            f32x4 acc[NT][8];
 #pragma unroll
-            for (int t = 0; t < 8; ++t) acc[t] = ld4(pv + PV_IN_B + grp * kD + 16 * t + 4 * g);
-            gemm_k128_o8(acc, xs, sg);
+            for (int t = 0; t < 8; ++t) {
+                const f32x4 bi = ld4(pv + PV_IN_B + grp * kD + 16 * t + 4 * g);
+#pragma unroll
+                for (int j = 0; j < NT; ++j) acc[j][t] = bi;
+            }
+            gemm_k128_o8<NT>(acc, xs, sg);
             float* dst = grp == 0 ? a.q : grp == 1 ? a.k : a.v;
-            if (rvalid) {
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                if (!rvalid[j]) continue;
 #pragma unroll
                 for (int t = 0; t < 8; ++t) {   // output tile t = head t / 2, features 16 (t & 1) ..
-                    const size_t hrow = (((size_t)b * kHeads + (t >> 1)) * S + frame) * 32;
-                    st4(dst + hrow + 16 * (t & 1) + 4 * g, grp == 0 ? acc[t] * scaling : acc[t]);
+                    const size_t hrow = (((size_t)b[j] * kHeads + (t >> 1)) * S + frame[j]) * 32;
+                    st4(dst + hrow + 16 * (t & 1) + 4 * g, grp == 0 ? acc[j][t] * scaling : acc[j][t]);
                 }
             }
         }
     } else {
         // ---- decoder.norm -> final_layer (333 outputs in 24 tiles, four quarters of 6) -> rotation epilogue
-        layer_norm_rows<false>(x, a.pvec + PV_FINAL_W, a.pvec + PV_FINAL_B, g);
-        split_x(xs, x);
+#pragma unroll
+        for (int j = 0; j < NT; ++j) layer_norm_rows<false>(x[j], a.pvec + PV_FINAL_W, a.pvec + PV_FINAL_B, g);
+        split_x<NT>(xs, x);
         float* fst = reinterpret_cast<float*>(smem + kOffStage) + wave * 16 * kQStride;
-        const int len = a.lengths ? a.lengths[b] : S;
-        const bool keep = rvalid && frame < len;   // output[~mask.T] = 0 (vae.py:274)
-        const int rows_here = tvalid ? min(16, S - rt * 16) : 0;
-        const size_t row0 = (size_t)b * S + rt * 16;
 #pragma unroll 1
         for (int quarter = 0; quarter < 4; ++quarter) {
-            f32x4 f[6];
+            f32x4 f[NT][6];
 #pragma unroll
-            for (int o = 0; o < 6; ++o) f[o] = ld4(a.final_bias + 16 * (6 * quarter + o) + 4 * g);
+            for (int o = 0; o < 6; ++o) {
+                const f32x4 bi = ld4(a.final_bias + 16 * (6 * quarter + o) + 4 * g);
+#pragma unroll
+                for (int j = 0; j < NT; ++j) f[j][o] = bi;
+            }
 #pragma unroll
             for (int s3 = 0; s3 < 3; ++s3)   // 6 output tiles x 4 k-pairs = 24 pairs = 3 LDS stages (k-pair outer)
                 for_pairs(sg, [&](int i, f16x8 wh, f16x8 wl) {
                     const int lin = 8 * s3 + i, c = lin / 6, o = lin - 6 * c;
-                    f[o] = mfma3(wh, wl, xs[c], f[o]);
-                });
 #pragma unroll
-            for (int o = 0; o < 6; ++o) st4(fst + r * kQStride + 16 * o + 4 * g, keep ? f[o] : splat4(0.f));
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the staging tile is wave-private: no barrier
+                    for (int j = 0; j < NT; ++j) f[j][o] = mfma3(wh, wl, xs[j][c], f[j][o]);
+                });
             const int f0 = 96 * quarter, nfe = quarter == 3 ? kFeats - 288 : 96, njo = quarter == 3 ? kJoints - 48 : 16;
-            if (a.feats_out) {
-                for (int i = lane; i < rows_here * nfe; i += 64) {
-                    const int rr = i / nfe, c = i - rr * nfe;
-                    a.feats_out[(row0 + rr) * kFeats + f0 + c] = fst[rr * kQStride + c];
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {   // one tile at a time through the wave's staging tile (wave-private: no barrier)
+                const int len = a.lengths ? a.lengths[b[j]] : S;
+                const bool keep = rvalid[j] && frame[j] < len;   // output[~mask.T] = 0 (vae.py:274)
+                const int rows_here = tvalid[j] ? min(16, S - rt[j] * 16) : 0;
+                const size_t row0 = (size_t)b[j] * S + rt[j] * 16;
+#pragma unroll
+                for (int o = 0; o < 6; ++o) st4(fst + r * kQStride + 16 * o + 4 * g, keep ? f[j][o] : splat4(0.f));
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                if (a.feats_out) {
+                    for (int i = lane; i < rows_here * nfe; i += 64) {
+                        const int rr = i / nfe, c = i - rr * nfe;
+                        a.feats_out[(row0 + rr) * kFeats + f0 + c] = fst[rr * kQStride + c];
+                    }
                 }
-            }
-            if (a.poses_out) {
-                for (int i = lane; i < rows_here * njo; i += 64) {
-                    const int rr = i / njo, jn = i - rr * njo;
-                    float aa[3];
-                    rot6d_to_axis_angle(fst + rr * kQStride + 6 * jn, a.quat_mode, aa);
-                    float* dst = a.poses_out + ((row0 + rr) * kJoints + 16 * quarter + jn) * 3;
-                    dst[0] = aa[0]; dst[1] = aa[1]; dst[2] = aa[2];
+                if (a.poses_out) {
+                    for (int i = lane; i < rows_here * njo; i += 64) {
+                        const int rr = i / njo, jn = i - rr * njo;
+                        float aa[3];
+                        rot6d_to_axis_angle(fst + rr * kQStride + 6 * jn, a.quat_mode, aa);
+                        float* dst = a.poses_out + ((row0 + rr) * kJoints + 16 * quarter + jn) * 3;
+                        dst[0] = aa[0]; dst[1] = aa[1]; dst[2] = aa[2];
+                    }
                 }
-            }
-            if (a.trans_out && quarter == 3) {
-                for (int i = lane; i < rows_here * 3; i += 64) {
-                    const int rr = i / 3, c = i - rr * 3;
-                    a.trans_out[(row0 + rr) * 3 + c] = fst[rr * kQStride + (330 - 288) + c];
+                if (a.trans_out && quarter == 3) {
+                    for (int i = lane; i < rows_here * 3; i += 64) {
+                        const int rr = i / 3, c = i - rr * 3;
+                        a.trans_out[(row0 + rr) * 3 + c] = fst[rr * kQStride + (330 - 288) + c];
+                    }
                 }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the two surplus fetches must not outlive the workgroup's LDS
 }
 
-}  // namespace
-
-hipError_t launch_vae_rows8x(const VaeRowsArgs& a, hipStream_t stream) {
+template <int W>
+hipError_t launch_rows8_w(const VaeRowsArgs& a, hipStream_t stream) {
     static DeviceOnce once;
     int dev_;
     if (!once.done(&dev_)) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_vae_rows8x), hipFuncAttributeMaxDynamicSharedMemorySize, kRows8LdsBytes);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_vae_rows8x<kTilesPerWave, W>), hipFuncAttributeMaxDynamicSharedMemorySize, rows8_lds_bytes(W));
         if (e != hipSuccess) return e;
         once.set(dev_);
     }
-    const int tiles = a.B * kRowTiles;
-    hipLaunchKernelGGL(k_vae_rows8x, dim3((tiles + kWaves - 1) / kWaves), dim3(64 * kWaves), kRows8LdsBytes, stream, a);
+    const int tiles = a.B * kRowTiles, per_wg = W * kTilesPerWave;
+    hipLaunchKernelGGL((k_vae_rows8x<kTilesPerWave, W>), dim3((tiles + per_wg - 1) / per_wg), dim3(64 * W), rows8_lds_bytes(W), stream, a);
     return hipGetLastError();
+}
+}  // namespace
+
+// 12 waves per workgroup once that still fills the chip (128 clips = 203 workgroups), 8 below - measured 1.23 vs 1.37 ms at 128 clips,
+// 1.08 vs 0.92 at 64 (profiles/r03_rows8_variants.txt); both instantiations produce the same bits
+hipError_t launch_vae_rows8x(const VaeRowsArgs& a, hipStream_t stream) {
+    return a.B >= 128 ? launch_rows8_w<12>(a, stream) : launch_rows8_w<8>(a, stream);
 }
 
 }  // namespace amuse

@@ -147,7 +147,8 @@ class HipEngine:
         _lib.check(self.lib.amuse_set_clips_per_group(self.ctx, int(g)))
 
     def set_decode_path(self, path: str = "auto"):
-        """bf16 decode kernels: "auto" (fused per-clip kernel from 64 clips up), "staged", "fused" (amuse_hip.h)."""
+        """decode kernels of the bf16 / fp16 / fp32x modes: "auto" (from 64 clips up the fused per-clip kernel, in fp32x the no-split-K row
+        kernel), "staged", "fused" (amuse_hip.h amuse_set_decode_path)."""
         _lib.check(self.lib.amuse_set_decode_path(self.ctx, {"auto": 0, "staged": 1, "fused": 2}[path]))
 
     def set_schedule(self, table: ScheduleTable):

@@ -17,7 +17,7 @@ def job_clips_per_group(total: int, tokens: int = 5) -> int:
     return max(1, min(16 // tokens, -(-total // 128)))
 
 
-FUSED_DECODE_MIN_CLIPS = 64   # amuse_api.hip kFusedMinClips: the library's per-launch rule for the bf16 / fp16 decode kernels
+FUSED_DECODE_MIN_CLIPS = 64   # amuse_api.hip kFusedMinClips: the library's per-launch rule for the bf16 / fp16 / fp32x decode kernels
 
 
 def job_decode_path(total: int) -> str:

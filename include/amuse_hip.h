@@ -213,7 +213,10 @@ int amuse_set_clips_per_group(amuse_ctx* ctx, int g);
  * (csrc/k_vae_fused.hip: one persistent workgroup per clip, residual stream in registers, K/V of the current head in LDS)
  * from 64 clips up, the staged kernels (csrc/k_vae.hip) below that; fp32 mode always runs the staged kernels.  Both
  * compute MotionPrior.decode (vae.py:216-278) with bf16 (fp16) MFMA operands and fp32 accumulation / residual stream; they differ
- * in summation order only.  The environment variable AMUSE_VAE_FUSED=0 / 1 overrides AUTO for a whole process. */
+ * in summation order only.  The fp32x mode has the same pair of paths under the same rule and the same pins: its staged row kernel
+ * (k_vae_rows<f16x2>: one 16-row tile per workgroup, split-K) below 64 clips, the no-split-K row kernel (csrc/k_vae_rows8.hip: a tile per
+ * wave, weights through LDS once per workgroup; FUSED selects it) from 64 clips up - again the same function in another summation order.
+ * The environment variable AMUSE_VAE_FUSED=0 / 1 overrides AUTO for a whole process. */
 enum { AMUSE_DECODE_AUTO = 0, AMUSE_DECODE_STAGED = 1, AMUSE_DECODE_FUSED = 2 };
 int amuse_set_decode_path(amuse_ctx* ctx, int path);
 
