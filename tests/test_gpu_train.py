@@ -78,7 +78,8 @@ def test_update_weights_device_equals_the_host_path():
     a0.set_schedule(sch.ddim_table())
     l0 = a0.sample(c, em, s, "fp32x", x_init=x)
     assert torch.equal(a.sample(c, em, s, "fp32x", x_init=x), l0)
-    assert torch.equal(a.vae_decode(l0[:8], None, "fp32x")["poses"], a0.vae_decode(l0[:8], None, "fp32x")["poses"])
+    assert torch.equal(a.vae_decode(l0[:8], None, "fp32x")["poses"], a0.vae_decode(l0[:8], None, "fp32x")["poses"])   # k_vae_rows<f16x2>
+    assert torch.equal(a.vae_decode(l0, None, "fp32x")["poses"], a0.vae_decode(l0, None, "fp32x")["poses"])           # 100 clips: k_vae_rows8x's stream
     a0.close()
     with pytest.raises(Exception):
         a.update_weights_device(None, None)
