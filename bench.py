@@ -32,7 +32,7 @@ sys.path.insert(0, str(REPO))
 FLOP_PER_CLIP_STEP = 19_120_640          # linears 19,005,440 + attention 115,200
 FLOP_VAE_DECODE_PER_CLIP = 1.76e9
 MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "fp16": 2500.0, "fp32": 157.3, "fp32x": 2500.0}   # MI355X_MICROARCH.md chip-level parameters (dense; fp32x = fp16 MFMAs)
-KERNEL_NAME = {"bf16": "k_sample8", "fp16": "k_sample8h", "fp32": "k_sample<fp32>", "fp32x": "k_sample<f16x2>"}
+KERNEL_NAME = {"bf16": "k_sample8", "fp16": "k_sample8h", "fp32": "k_sample<fp32>", "fp32x": "k_sample8x"}
 # L2 -> CU weight stream per denoising step and CU (every CU re-streams the network each step): bytes per parameter of the MFMA stream
 STREAM_MB_PER_STEP = {"bf16": 3.80, "fp16": 3.80, "fp32": 7.60, "fp32x": 7.60}
 CU_LOAD_BYTES_PER_CLK = 64.0
