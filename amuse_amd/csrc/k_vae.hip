@@ -615,8 +615,10 @@ __device__ __forceinline__ void attn_qtiles_x(const uint4* Kh, const uint4* Kl, 
     }
 }
 
-template <bool ENC>
-__global__ __launch_bounds__(256) void k_vae_attn_x(VaeAttnArgs a) {
+// NW = 4 or 8 waves per workgroup.  The 80 KiB of fragment images leave room for one workgroup (two at best) per CU, so with four waves the
+// CU runs the attention on 4-8 waves; eight waves share one image and halve a workgroup's time (launch_vae_attn picks NW by the grid).
+template <bool ENC, int NW>
+__global__ __launch_bounds__(64 * NW) void k_vae_attn_x(VaeAttnArgs a) {
     constexpr int S = ENC ? kFrames + 2 : kFrames;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     uint4* Kh = reinterpret_cast<uint4*>(smem);
@@ -631,14 +633,14 @@ __global__ __launch_bounds__(256) void k_vae_attn_x(VaeAttnArgs a) {
     const float* qg = a.q + (size_t)bh * S * 32;
     const float* kg = a.k + (size_t)bh * S * 32;
     const float* vg = a.v + (size_t)bh * S * 32;
-    for (int i = threadIdx.x; i < kKeyRows * 4; i += 256) {  // K fragments: item = (key row, slot group)
+    for (int i = threadIdx.x; i < kKeyRows * 4; i += 64 * NW) {  // K fragments: item = (key row, slot group)
         const int row = i >> 2, gg = i & 3;
         const bool ok = row < S;
         const F16Pair ks = split_f16(ok ? ld4(kg + row * 32 + 4 * gg) : splat4(0.f), ok ? ld4(kg + row * 32 + 16 + 4 * gg) : splat4(0.f));
         Kh[i] = __builtin_bit_cast(uint4, ks.hi);
         Kl[i] = __builtin_bit_cast(uint4, ks.lo);
     }
-    for (int i = threadIdx.x; i < kPairs * 2 * 16 * 4; i += 256) {  // V^T fragments: item = ((pair, td), g, d)
+    for (int i = threadIdx.x; i < kPairs * 2 * 16 * 4; i += 64 * NW) {  // V^T fragments: item = ((pair, td), g, d)
         const int d = i & 15, gg = (i >> 4) & 3, pt = i >> 6;  // pt = jp * 2 + td
         const int jp = pt >> 1, td = pt & 1;
         f32x4 lo, hi;
@@ -660,12 +662,17 @@ __global__ __launch_bounds__(256) void k_vae_attn_x(VaeAttnArgs a) {
     }
     if (gridDim.y > 1) {   // few clips: five workgroups per (clip, head), one query tile per wave (as in k_vae_attn_bf16)
         const int qt = 4 * blockIdx.y + wave;
-        if (qt < kRowTiles) attn_qtiles_x<1, S>(Kh, Kl, Vh, Vl, qg, og, qt, len, g, r);
+        if (wave < 4 && qt < kRowTiles) attn_qtiles_x<1, S>(Kh, Kl, Vh, Vl, qg, og, qt, len, g, r);
         return;
     }
-    attn_qtiles_x<2, S>(Kh, Kl, Vh, Vl, qg, og, wave, len, g, r);
-    attn_qtiles_x<2, S>(Kh, Kl, Vh, Vl, qg, og, wave + 8, len, g, r);
-    if (wave + 16 < kRowTiles) attn_qtiles_x<1, S>(Kh, Kl, Vh, Vl, qg, og, wave + 16, len, g, r);
+    if constexpr (NW == 8) {   // waves 0..3: tile pairs (w, w + 4); waves 4..7: (w + 4, w + 8); tiles 16..18: waves 0..2
+        attn_qtiles_x<2, S>(Kh, Kl, Vh, Vl, qg, og, wave < 4 ? wave : wave + 4, len, g, r);
+        if (wave + 16 < kRowTiles) attn_qtiles_x<1, S>(Kh, Kl, Vh, Vl, qg, og, wave + 16, len, g, r);
+    } else {
+        attn_qtiles_x<2, S>(Kh, Kl, Vh, Vl, qg, og, wave, len, g, r);
+        attn_qtiles_x<2, S>(Kh, Kl, Vh, Vl, qg, og, wave + 8, len, g, r);
+        if (wave + 16 < kRowTiles) attn_qtiles_x<1, S>(Kh, Kl, Vh, Vl, qg, og, wave + 16, len, g, r);
+    }
 }
 
 template <typename K>
@@ -714,8 +721,10 @@ hipError_t launch_vae_attn(const VaeAttnArgs& a, int precision, bool enc, hipStr
         hipError_t e = set_lds(&k_vae_attn<PREC_F32, false>, kAttnLdsBytes);
         if (e == hipSuccess) e = set_lds(&k_vae_attn<PREC_F16X2, false>, kAttnLdsBytes);
         if (e == hipSuccess) e = set_lds(&k_vae_attn<PREC_F16X2, true>, kAttnLdsBytes);
-        if (e == hipSuccess) e = set_lds(&k_vae_attn_x<false>, kAttnXLdsBytes);
-        if (e == hipSuccess) e = set_lds(&k_vae_attn_x<true>, kAttnXLdsBytes);
+        if (e == hipSuccess) e = set_lds(&k_vae_attn_x<false, 4>, kAttnXLdsBytes);
+        if (e == hipSuccess) e = set_lds(&k_vae_attn_x<true, 4>, kAttnXLdsBytes);
+        if (e == hipSuccess) e = set_lds(&k_vae_attn_x<false, 8>, kAttnXLdsBytes);
+        if (e == hipSuccess) e = set_lds(&k_vae_attn_x<true, 8>, kAttnXLdsBytes);
         if (e == hipSuccess) e = set_lds(&k_vae_attn<PREC_F32, true>, kAttnLdsBytes);
         if (e == hipSuccess) e = set_lds(&k_vae_attn_bf16<PREC_BF16, false>, kAttnBf16LdsBytes);
         if (e == hipSuccess) e = set_lds(&k_vae_attn_bf16<PREC_BF16, true>, kAttnBf16LdsBytes);
@@ -736,8 +745,17 @@ hipError_t launch_vae_attn(const VaeAttnArgs& a, int precision, bool enc, hipStr
             if (enc) hipLaunchKernelGGL((k_vae_attn<PREC_F16X2, true>), grid, block, kAttnLdsBytes, stream, a);
             else hipLaunchKernelGGL((k_vae_attn<PREC_F16X2, false>), grid, block, kAttnLdsBytes, stream, a);
         } else {
-            if (enc) hipLaunchKernelGGL(k_vae_attn_x<true>, grid16, block, kAttnXLdsBytes, stream, a);
-            else hipLaunchKernelGGL(k_vae_attn_x<false>, grid16, block, kAttnXLdsBytes, stream, a);
+            // eight waves per workgroup for unsplit launches (measured: decode 2.42 -> 2.30 ms at 256 clips, 0.93 -> 0.86 at 64; the split
+            // launches of small batches keep four: one query tile per wave); AMUSE_ATTNX_WAVES=4 pins four (A/B)
+            static const int nw_env = [] { const char* e = getenv("AMUSE_ATTNX_WAVES"); return e ? atoi(e) : 0; }();
+            const bool w8 = grid16.y == 1 && nw_env != 4;
+            if (w8) {
+                if (enc) hipLaunchKernelGGL((k_vae_attn_x<true, 8>), grid16, dim3(512), kAttnXLdsBytes, stream, a);
+                else hipLaunchKernelGGL((k_vae_attn_x<false, 8>), grid16, dim3(512), kAttnXLdsBytes, stream, a);
+            } else {
+                if (enc) hipLaunchKernelGGL((k_vae_attn_x<true, 4>), grid16, block, kAttnXLdsBytes, stream, a);
+                else hipLaunchKernelGGL((k_vae_attn_x<false, 4>), grid16, block, kAttnXLdsBytes, stream, a);
+            }
         }
     } else if (precision == PREC_F16) {
         if (enc) hipLaunchKernelGGL((k_vae_attn_bf16<PREC_F16, true>), grid16, block, kAttnBf16LdsBytes, stream, a);
