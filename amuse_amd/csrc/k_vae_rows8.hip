@@ -111,7 +111,7 @@ __device__ __forceinline__ void split_x(F16Pair (&xs)[NT][4], const f32x4 (&x)[N
 // kWaves waves per workgroup (12 = three per SIMD: the kernel needs ~158 registers; 8 for launches of few tiles - the same bits: a tile's
 // arithmetic does not depend on its workgroup), NT row tiles per wave: wave w of workgroup wg owns tiles (wg * kWaves + w) * NT + j
 template <int NT, int kWaves>
-__global__ __launch_bounds__(64 * kWaves) __attribute__((amdgpu_waves_per_eu(kWaves / 4, kWaves / 4))) void k_vae_rows8x(VaeRowsArgs a) {
+__global__ __launch_bounds__(64 * kWaves) __attribute__((amdgpu_waves_per_eu((kWaves + 3) / 4, (kWaves + 3) / 4))) void k_vae_rows8x(VaeRowsArgs a) {
     constexpr int S = kFrames;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63;
@@ -346,10 +346,21 @@ hipError_t launch_rows8_w(const VaeRowsArgs& a, hipStream_t stream) {
 }
 }  // namespace
 
-// 12 waves per workgroup once that still fills the chip (128 clips = 203 workgroups), 8 below - measured 1.23 vs 1.37 ms at 128 clips,
-// 1.08 vs 0.92 at 64 (profiles/r03_rows8_variants.txt); both instantiations produce the same bits
+// Waves (= row tiles) per workgroup: the launch's time is its rounds over the chip's 256 CUs times the waves that share a CU's pipes in a
+// round, so the shape is chosen per launch to minimise ceil(workgroups / 256) x waves - 256 clips are 4,864 tiles = 19 per CU: two rounds of
+// 10-wave workgroups (95 % full) instead of two of 12 (58 % in the second).  All instantiations produce the same bits (a tile's arithmetic does
+// not depend on its workgroup).  AMUSE_R8_FORCE_WAVES = 8 / 10 / 12 pins one (A/B).
 hipError_t launch_vae_rows8x(const VaeRowsArgs& a, hipStream_t stream) {
-    return a.B >= 128 ? launch_rows8_w<12>(a, stream) : launch_rows8_w<8>(a, stream);
+    static const int force = [] { const char* e = getenv("AMUSE_R8_FORCE_WAVES"); return e ? atoi(e) : 0; }();
+    const int tiles = a.B * kRowTiles * 1;
+    int best = 12, best_cost = 1 << 30;
+    for (int w : {8, 10, 12}) {
+        const int wgs = (tiles + w * kTilesPerWave - 1) / (w * kTilesPerWave);
+        const int cost = ((wgs + 255) / 256) * w;
+        if (cost <= best_cost) { best_cost = cost; best = w; }   // (ties: the larger workgroup)
+    }
+    if (force == 8 || force == 10 || force == 12) best = force;
+    return best == 8 ? launch_rows8_w<8>(a, stream) : best == 10 ? launch_rows8_w<10>(a, stream) : launch_rows8_w<12>(a, stream);
 }
 
 }  // namespace amuse
