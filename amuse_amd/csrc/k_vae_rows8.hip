@@ -353,14 +353,24 @@ hipError_t launch_rows8_w(const VaeRowsArgs& a, hipStream_t stream) {
 hipError_t launch_vae_rows8x(const VaeRowsArgs& a, hipStream_t stream) {
     static const int force = [] { const char* e = getenv("AMUSE_R8_FORCE_WAVES"); return e ? atoi(e) : 0; }();
     const int tiles = a.B * kRowTiles * 1;
-    int best = 12, best_cost = 1 << 30;
-    for (int w : {8, 10, 12}) {
-        const int wgs = (tiles + w * kTilesPerWave - 1) / (w * kTilesPerWave);
-        const int cost = ((wgs + 255) / 256) * w;
-        if (cost <= best_cost) { best_cost = cost; best = w; }   // (ties: the larger workgroup)
+    // measured (profiles/r03_rows8_variants.txt): 10 waves beat 11 and 12 at equal rounds, 8 and 9 lose except where 8 waves make more
+    // workgroups than CUs busy (launches of up to ~100 clips)
+    int best = 8, best_cost = 1 << 30;
+    if (tiles > 8 * 256) {
+        for (int w : {10, 11, 12}) {
+            const int wgs = (tiles + w * kTilesPerWave - 1) / (w * kTilesPerWave);
+            const int cost = ((wgs + 255) / 256) * w;
+            if (cost < best_cost) { best_cost = cost; best = w; }   // (ties: the smaller workgroup)
+        }
     }
-    if (force == 8 || force == 10 || force == 12) best = force;
-    return best == 8 ? launch_rows8_w<8>(a, stream) : best == 10 ? launch_rows8_w<10>(a, stream) : launch_rows8_w<12>(a, stream);
+    if (force >= 8 && force <= 12) best = force;
+    switch (best) {
+        case 8: return launch_rows8_w<8>(a, stream);
+        case 9: return launch_rows8_w<9>(a, stream);
+        case 10: return launch_rows8_w<10>(a, stream);
+        case 11: return launch_rows8_w<11>(a, stream);
+        default: return launch_rows8_w<12>(a, stream);
+    }
 }
 
 }  // namespace amuse
