@@ -376,6 +376,20 @@ def test_vae_decode_fp32_vs_reference_golden(env, prec):
         rot_tol = 5e-5 if mode == "p3d" else 2e-3
         assert float((R_gpu - R_ref).abs().amax(dim=(-1, -2))[pivot > 0.1].max()) < rot_tol   # as a rotation, vs fp64
     assert float(torch.linalg.vector_norm(eng.vae_decode(g["z"], None, prec)["poses"], dim=-1).max()) > 0
+    if prec == "fp32x":
+        # the same bars on the OTHER pair of fp32x decode kernels - the row stages without split-K (k_vae_rows8.hip; "fused" pins them,
+        # AUTO takes them from 64 clips) and the unsplit eight-wave attention: same function, another summation order
+        try:
+            eng.set_decode_path("fused")
+            o8 = eng.vae_decode(g["z"], None, prec, return_feats=True)
+            assert _err(o8["feats"], g["feats"]) < 2e-5 and not torch.equal(o8["feats"], out["feats"])
+            o8r = eng.vae_decode(g["z"][:2], [300, 173], prec, return_feats=True)
+            assert _err(o8r["feats"], g["feats_ragged"]) < 2e-5
+            assert float(o8r["feats"][1, 173:].abs().max()) == 0.0 and float(o8r["poses"][1, 173:].abs().max()) == 0.0
+            big = eng.vae_decode(torch.from_numpy(g["z"]).repeat(40, 1), None, prec, return_feats=True)   # 120 clips: 10-wave workgroups
+            assert torch.equal(big["feats"][:3], o8["feats"]) and torch.equal(big["feats"][117:], o8["feats"])
+        finally:
+            eng.set_decode_path("auto")
 
 
 def test_vae_decode_bf16_bounded(env):
