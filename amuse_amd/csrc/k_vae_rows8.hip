@@ -4,7 +4,7 @@
 //
 // k_vae_rows (k_vae.hip) gives a workgroup of four waves ONE 16-row tile: split-K over the waves, two combines per block through LDS, and
 // the stage's weights - 786 KB in this mode - streamed from L2 once per TILE: 42 % of the load-path floor, 230 us per launch at 256 clips.
-// Here a workgroup is eight waves with a tile EACH (128 rows per pass):
+// Here a workgroup is eight to twelve waves (chosen per launch, launch_vae_rows8x below) with a tile EACH:
 //   * the stage's weights reach the CU once per workgroup: one stream in consumption order, cut into 16 KiB LDS stages (8 unit pairs:
 //     hi | lo fp16 fragments of one 16-feature x 32-k block), copied global -> LDS by LDS-DMA three stages deep (the protocol of
 //     k_vae_fused.hip: two 1 KiB pieces per wave and stage, vmcnt(2) + s_barrier at a stage's end);
