@@ -187,3 +187,22 @@ def test_fp16_shards_noise_and_updates_are_bitwise(env):
     upd.update_weights_device(*f0, what=16)
     assert torch.equal(upd.sample(c, e, s, "fp16", x_init=x), before)
     fresh.close(); upd.close()
+
+
+def test_fp16_mode_range_headroom(env):
+    """fp16 operands overflow at 65504 where bf16 does not (amuse_hip.h): condition embeddings 30 x the usual scale (token magnitudes in
+    the hundreds - LayerNorm brings every later operand back to O(1)) still sample and decode to finite poses, and stay close to the
+    bf16 mode's result on the same inputs (both are roundings of the same fp32 computation)."""
+    from amuse_amd import scheduler as sch
+    eng = env["eng"]
+    g = torch.Generator().manual_seed(77)
+    c, e, s, x = (30.0 * torch.randn(8, n, generator=g) for n in (256, 256, 256, 128))
+    x = x / 30.0
+    eng.set_schedule(sch.ddim_table())
+    h = eng.diffusion_backward(c, e, s, "fp16", x_init=x)
+    b = eng.diffusion_backward(c, e, s, "bf16", x_init=x)
+    f = eng.diffusion_backward(c, e, s, "fp32", x_init=x)
+    assert bool(torch.isfinite(h["poses"]).all()) and bool(torch.isfinite(h["latents"]).all())
+    dh = float((h["latents"] - f["latents"]).pow(2).mean().sqrt())
+    db = float((b["latents"] - f["latents"]).pow(2).mean().sqrt())
+    assert dh < db, (dh, db)      # closer to the fp32 mode than bf16 is, also at this scale
