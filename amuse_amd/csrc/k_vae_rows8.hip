@@ -352,7 +352,7 @@ hipError_t launch_rows8_w(const VaeRowsArgs& a, hipStream_t stream) {
 // not depend on its workgroup).  AMUSE_R8_FORCE_WAVES = 8 / 10 / 12 pins one (A/B).
 hipError_t launch_vae_rows8x(const VaeRowsArgs& a, hipStream_t stream) {
     static const int force = [] { const char* e = getenv("AMUSE_R8_FORCE_WAVES"); return e ? atoi(e) : 0; }();
-    const int tiles = a.B * kRowTiles * 1;
+    const int tiles = a.B * kRowTiles;
     // measured (profiles/r03_rows8_variants.txt): 10 waves beat 11 and 12 at equal rounds, 8 and 9 lose except where 8 waves make more
     // workgroups than CUs busy (launches of up to ~100 clips)
     int best = 8, best_cost = 1 << 30;
