@@ -80,9 +80,30 @@ def _skip_stack(prefix: str, spec, layer_fn):
         spec[f"{prefix}.linear_blocks.{i}.bias"] = (D_MODEL,)
 
 
-def denoiser_param_spec() -> "OrderedDict[str, Tuple[int, ...]]":
-    """State-dict keys/shapes of the reference ``Denoiser`` (trans_enc, skip connections, learned PE)."""
+# Denoiser variants (denoiser.py:64-66,92-131): `arch` "trans_enc" (skip-transformer encoder over [sample | time, con, emo, sty]) or
+# "trans_dec" (9 plain TransformerDecoderLayers: tgt = the sample, memory = [time, con, emo, sty] + mem_pos);
+# `diffusion_only` (denoiser.py:64-66,177-187,191-199): the sample is the 300 x 333 pose sequence itself, embedded by pose_embd and
+# projected back by pose_proj - the per-step S = 304 / S = 300 transformers of SURVEY.md section 0.2 / Appendix B.
+ARCHS = {"trans_enc": 0, "trans_dec": 1, "trans_enc_pose": 2, "trans_dec_pose": 3}   # include/amuse_hip.h AMUSE_ARCH_*
+
+
+def arch_id(arch: str = "trans_enc", diffusion_only: bool = False) -> int:
+    return ARCHS[arch] + (2 if diffusion_only else 0)
+
+
+def arch_of_id(aid: int):
+    return ("trans_enc", "trans_dec")[aid & 1], bool(aid & 2)
+
+
+def denoiser_param_spec(arch: str = "trans_enc", diffusion_only: bool = False) -> "OrderedDict[str, Tuple[int, ...]]":
+    """State-dict keys/shapes of the reference ``Denoiser``: the shipped configuration (trans_enc, skip connections, learned PE)
+    by default, or one of the variants above (key order = registration order in Denoiser.__init__)."""
     spec: "OrderedDict[str, Tuple[int, ...]]" = OrderedDict()
+    if diffusion_only:
+        spec["pose_embd.weight"] = (D_MODEL, N_FEATS)
+        spec["pose_embd.bias"] = (D_MODEL,)
+        spec["pose_proj.weight"] = (N_FEATS, D_MODEL)
+        spec["pose_proj.bias"] = (N_FEATS,)
     spec["time_embedding.linear_1.weight"] = (D_MODEL, COND_DIM)
     spec["time_embedding.linear_1.bias"] = (D_MODEL,)
     spec["time_embedding.linear_2.weight"] = (D_MODEL, D_MODEL)
@@ -92,7 +113,15 @@ def denoiser_param_spec() -> "OrderedDict[str, Tuple[int, ...]]":
         spec[f"emb_proj_{n}.1.bias"] = (D_MODEL,)
     spec["query_pos.pe"] = (PE_MAX_LEN, 1, D_MODEL)
     spec["mem_pos.pe"] = (PE_MAX_LEN, 1, D_MODEL)
-    _skip_stack("encoder", spec, _enc_layer)
+    if arch == "trans_enc":
+        _skip_stack("encoder", spec, _enc_layer)
+    elif arch == "trans_dec":   # TransformerDecoder registers its layers first, then the norm (cross_attention.py:195-203)
+        for i in range(N_LAYERS):
+            _dec_layer(f"decoder.layers.{i}", spec)
+        spec["decoder.norm.weight"] = (D_MODEL,)
+        spec["decoder.norm.bias"] = (D_MODEL,)
+    else:
+        raise ValueError(f"Not supported architechure{arch}!")
     return spec
 
 
@@ -145,8 +174,9 @@ def make_weights(spec: "OrderedDict[str, Tuple[int, ...]]", seed: int, tag: str)
     return OrderedDict((k, _init_one(seed, f"{tag}/{k}", s)) for k, s in spec.items())
 
 
-def make_denoiser_weights(seed: int = 0) -> Dict[str, np.ndarray]:
-    return make_weights(denoiser_param_spec(), seed, "denoiser")
+def make_denoiser_weights(seed: int = 0, arch: str = "trans_enc", diffusion_only: bool = False) -> Dict[str, np.ndarray]:
+    tag = "denoiser" if (arch == "trans_enc" and not diffusion_only) else f"denoiser/{arch}{'/pose' if diffusion_only else ''}"
+    return make_weights(denoiser_param_spec(arch, diffusion_only), seed, tag)
 
 
 def make_prior_weights(seed: int = 0) -> Dict[str, np.ndarray]:

@@ -10,6 +10,9 @@ What it restates (all citations relative to /root/reference):
   * ``SkipTransformerEncoder`` / ``...Decoder`` and the post-norm layers
                                                            models/latent_diffusion/utils/cross_attention.py:18-125,236-345
   * ``MotionPrior.decode``                                  models/latent_diffusion/vae.py:216-278
+  * the ``Denoiser`` variants - ``arch: "trans_dec"`` (TransformerDecoder over memory = [time, con, emo, sty]) and
+    ``diffusion_only`` (pose_embd / pose_proj around 300 raw-pose frames)   denoiser.py:64-66,116-131,174-204;
+                                                           cross_attention.py:195-234,297-345
   * the sampling loop + output conversion                  models/latent_diffusion/infer_ldm.py:130-178
   * output packing / NPZ post-processing                   scripts/trainer.py:524-526, models/diffusion/viz/visualizer.py:344-364
 
@@ -154,6 +157,29 @@ def dec_block(ops, x, z, W, p, key_mask=None):
     return x
 
 
+def mha(ops: Ops, xq, xkv, W, p):
+    """nn.MultiheadAttention(128, 4)(query = xq, key = value = xkv), batch-first, no masks: xq (B,Sq,D), xkv (B,Sk,D)."""
+    B, Sq, _ = xq.shape
+    Sk = xkv.shape[1]
+    w, b = W[p + ".in_proj_weight"], W[p + ".in_proj_bias"]
+    q = ops.lin(xq, w[:D], b[:D]) * math.sqrt(1.0 / DH)
+    k = ops.lin(xkv, w[D:2 * D], b[D:2 * D])
+    v = ops.lin(xkv, w[2 * D:], b[2 * D:])
+    sh = lambda t, S: t.reshape(B, S, H, DH).permute(0, 2, 1, 3)
+    a = torch.softmax(ops.mm(sh(q, Sq), sh(k, Sk).transpose(-1, -2)), dim=-1)
+    o = ops.mm(a, sh(v, Sk)).permute(0, 2, 1, 3).reshape(B, Sq, D)
+    return ops.lin(o, W[p + ".out_proj.weight"], W[p + ".out_proj.bias"])
+
+
+def dec_block_mem(ops, x, mem, W, p):
+    """TransformerDecoderLayer.forward_post (cross_attention.py:323-345) with a multi-token memory and no masks / positional
+    arguments - how TransformerDecoder.forward (cross_attention.py:205-234) calls it from Denoiser(arch="trans_dec")."""
+    x = layer_norm(x + mha(ops, x, x, W, p + ".self_attn"), W[p + ".norm1.weight"], W[p + ".norm1.bias"])
+    x = layer_norm(x + mha(ops, x, mem, W, p + ".multihead_attn"), W[p + ".norm2.weight"], W[p + ".norm2.bias"])
+    h = ops.act(ops.lin(x, W[p + ".linear1.weight"], W[p + ".linear1.bias"]))
+    return layer_norm(x + ops.lin(h, W[p + ".linear2.weight"], W[p + ".linear2.bias"]), W[p + ".norm3.weight"], W[p + ".norm3.bias"])
+
+
 def skip_stack(ops, x, W, p, block_fn, taps: Optional[dict] = None):
     """SkipTransformerEncoder/Decoder.forward wiring (cross_attention.py:41-64, 89-125)."""
     xs: List[torch.Tensor] = []
@@ -234,6 +260,76 @@ def denoiser_forward(W, x, t, con, emo, sty, emulate_bf16=False, taps: Optional[
         taps["tokens"] = xs
     out = skip_stack(ops, xs, W, "encoder", lambda h, p: enc_block(ops, h, W, p), taps)
     return out[:, 0]
+
+
+def denoiser_memory(W, B, t, con, emo, sty, dtype=torch.float32) -> torch.Tensor:
+    """emb_latent of Denoiser.forward (denoiser.py:146-174): [time, con, (emo), (sty)] -> (B, 2..4, 128), no positions added."""
+    if isinstance(t, (int, np.integer)):
+        te = time_embed(W, int(t), dtype)[None].expand(B, -1)
+    else:
+        te = torch.stack([time_embed(W, int(ti), dtype) for ti in t])
+    toks = [te, cond_project(W, "con", con)]
+    if emo is not None:
+        toks.append(cond_project(W, "emo", emo))
+    if sty is not None:
+        toks.append(cond_project(W, "sty", sty))
+    return torch.stack(toks, dim=1)
+
+
+def denoiser_forward_variant(W, x, t, con, emo, sty, arch="trans_enc", diffusion_only=False, lengths=None,
+                             emulate_bf16=False, fp16=False, taps: Optional[dict] = None):
+    """Denoiser.forward for the variants the shipped configuration does not reach (denoiser.py:174-204).
+      arch "trans_enc", diffusion_only: x (B,300,333) -> pose_embd -> [time, con, emo, sty | 300 frames] + query_pos -> skip encoder
+                                        (no key mask: the padded frames are attended, denoiser.py:182) -> pose_proj of the frame rows;
+      arch "trans_dec":                 tgt = x (B,128) as ONE token (or pose_embd of the 300 frames) + query_pos, memory = the 2..4
+                                        condition tokens + mem_pos; 9 x TransformerDecoderLayer, decoder.norm (+ pose_proj).
+    With diffusion_only the rows of frames >= lengths[b] are zeroed (`sample[~mask.T] = 0`, denoiser.py:187,199)."""
+    ops = Ops(emulate_bf16 or fp16, poly_gelu=emulate_bf16 or fp16, fp16=fp16)
+    B = x.shape[0]
+    mem = denoiser_memory(W, B, t, con, emo, sty, x.dtype)
+    nmem = mem.shape[1]
+    if diffusion_only:
+        h = ops.lin(x, W["pose_embd.weight"], W["pose_embd.bias"])            # (B,300,128)
+    else:
+        h = x[:, None, :]                                                     # (B,1,128)
+    if arch == "trans_enc":
+        assert diffusion_only, "the latent trans_enc configuration is denoiser_forward()"
+        xs = torch.cat([mem, h], dim=1)
+        xs = xs + W["query_pos.pe"][: xs.shape[1], 0][None]
+        if taps is not None:
+            taps["tokens"] = xs
+        out = skip_stack(ops, xs, W, "encoder", lambda a, p: enc_block(ops, a, W, p), taps)[:, nmem:]
+    elif arch == "trans_dec":
+        h = h + W["query_pos.pe"][: h.shape[1], 0][None]
+        mem = mem + W["mem_pos.pe"][:nmem, 0][None]
+        if taps is not None:
+            taps["tokens"], taps["memory"] = h, mem
+        for i in range(L):
+            h = dec_block_mem(ops, h, mem, W, f"decoder.layers.{i}")
+            if taps is not None:
+                taps[f"decoder.layers.{i}"] = h
+        out = layer_norm(h, W["decoder.norm.weight"], W["decoder.norm.bias"])
+    else:
+        raise ValueError(arch)
+    if not diffusion_only:
+        return out[:, 0]
+    out = ops.lin(out, W["pose_proj.weight"], W["pose_proj.bias"])
+    if lengths is not None:
+        keep = torch.arange(out.shape[1])[None, :] < torch.tensor(list(lengths))[:, None]
+        out = out * keep[..., None].to(out.dtype)
+    return out
+
+
+def sample_variant(W, sched, con, emo, sty, x_init, arch, diffusion_only, step_noise=None, traj: Optional[list] = None):
+    """The sampling loop of infer_ldm.py:137-161 around a variant denoiser; x_init (B,128) or (B,300,333)."""
+    x = x_init * sched.init_noise_sigma
+    for i, t in enumerate(sched.timesteps):
+        eps = denoiser_forward_variant(W, x, t, con, emo, sty, arch, diffusion_only)
+        nz = step_noise[i] if (step_noise is not None and sched.needs_noise(t)) else None
+        x = sched.step(eps, t, x, nz)
+        if traj is not None:
+            traj.append(x.clone())
+    return x
 
 
 # --------------------------------------------------------------------------------------------

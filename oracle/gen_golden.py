@@ -48,6 +48,76 @@ def _shim():
     return Denoiser, MotionPrior, rot
 
 
+def build_variant(Denoiser, arch, diffusion_only):
+    """Denoiser(arch_denoiser of configs/diff_latent_v2.json with `arch` / `diffusion_only` overridden), as
+    PretrainedLPDM_v1.setup / LatentDiffusionModel.setup build it (infer_ldm.py:66-73, ldm.py:58-63)."""
+    base = json.load(open(REF / "configs/base_new.json"))
+    dcfg = dict(json.load(open(REF / "configs/diff_latent_v2.json"))["arch_denoiser"])
+    dcfg["smplx_data"] = base["TRAIN_PARAM"]["latent_diffusion"]["smplx_data"]
+    dcfg["smplx_rep"] = base["TRAIN_PARAM"]["latent_diffusion"]["smplx_rep"]
+    dcfg["arch"], dcfg["diffusion_only"] = arch, diffusion_only
+    return Denoiser(dcfg).eval()
+
+
+POSE_ROWS = slice(0, 300, 6)   # frames of the pose-space outputs kept in the fixture (every output row depends on every input)
+
+
+def gen_variants(out, Denoiser):
+    """tests/golden/denoiser_variants.npz: teacher-forced eps_hat of the three Denoiser variants the shipped configuration
+    does not reach - trans_dec (latent), diffusion_only + trans_enc (S = 304), diffusion_only + trans_dec - on the build's
+    deterministic weights: t = 981 / 501 / 1, ragged lengths, token dropping, per-sample timesteps, a DDIM-50 trajectory
+    (reference Denoiser + the restated scheduler).  Pose-space outputs are stored on every 6th frame."""
+    spec, d = {}, {}
+    g = torch.Generator().manual_seed(4202)
+    B = 2
+    con, emo, sty = (torch.randn(B, 256, generator=g) for _ in range(3))
+    x_lat = torch.randn(B, 1, 128, generator=g)
+    x_pose = torch.randn(B, 300, 333, generator=g).half().float()   # stored as float16: round first
+    d.update(con=con.numpy(), emo=emo.numpy(), sty=sty.numpy(), x_lat=x_lat[:, 0].numpy(), x_pose=x_pose.numpy().astype(np.float16))
+    sched = orc.DDIM()
+    for arch, pose in (("trans_dec", False), ("trans_enc", True), ("trans_dec", True)):
+        tag = f"{arch}{'_pose' if pose else ''}"
+        den = build_variant(Denoiser, arch, pose)
+        spec[tag] = {k: list(v.shape) for k, v in den.state_dict().items()}
+        load_weights(den, wts.make_denoiser_weights(0, arch, pose))
+        x = x_pose if pose else x_lat
+        cut = (lambda e: e[:, POSE_ROWS].numpy()) if pose else (lambda e: e[:, 0].numpy())
+        kw = dict(con_hidden=con[:, None], emo_hidden=emo[:, None], sty_hidden=sty[:, None], lengths=[300] * B)
+        taps, hooks = {}, []
+        if arch == "trans_dec":
+            def tap(name):
+                def fn(_m, _i, o):
+                    taps[name] = o.permute(1, 0, 2).clone().numpy()
+                return fn
+            hooks = [den.query_pos.register_forward_hook(tap("tokens")), den.mem_pos.register_forward_hook(tap("memory")),
+                     den.decoder.layers[0].register_forward_hook(tap("decoder.layers.0")),
+                     den.decoder.layers[8].register_forward_hook(tap("decoder.layers.8"))]
+        for t in (981, 501, 1):
+            d[f"{tag}/eps_t{t}"] = cut(den(sample=x, timestep=torch.tensor(t), **kw)[0])
+            if t == 981:
+                for k, v in taps.items():
+                    d[f"{tag}/tap981/{k}"] = v[:, POSE_ROWS] if (pose and k != "memory") else v
+        for h in hooks:
+            h.remove()
+        d[f"{tag}/eps_t501_noemo"] = cut(den(sample=x, timestep=torch.tensor(501), **dict(kw, emo_hidden=None))[0])
+        d[f"{tag}/eps_t501_consolo"] = cut(den(sample=x, timestep=torch.tensor(501), **dict(kw, emo_hidden=None, sty_hidden=None))[0])
+        ts = torch.tensor([7, 640])
+        d[f"{tag}/eps_batch_t"] = cut(den(sample=x, timestep=ts, **kw)[0])
+        if pose:   # sample[~mask.T] = 0 (denoiser.py:187,199); the padded frames stay attended keys
+            d[f"{tag}/eps_t501_ragged"] = cut(den(sample=x, timestep=torch.tensor(501), **dict(kw, lengths=[300, 173]))[0])
+        # DDIM-50: reference Denoiser + restated scheduler, explicit x_T
+        xx = x[:, 0].clone() if not pose else x.clone()
+        for i, t in enumerate(sched.timesteps):
+            eps = den(sample=xx[:, None] if not pose else xx, timestep=torch.tensor(t), **kw)[0]
+            xx = sched.step(eps[:, 0] if not pose else eps, t, xx)
+            if (i + 1) in (10, 50):
+                d[f"{tag}/x_after_{i + 1}"] = xx[:, POSE_ROWS].numpy().copy() if pose else xx.numpy().copy()
+    d["timesteps_batch"] = np.array([7, 640])
+    d["lengths_ragged"] = np.array([300, 173])
+    np.savez_compressed(out / "denoiser_variants.npz", **d)
+    json.dump(spec, open(out / "state_dict_spec_variants.json", "w"), indent=0)
+
+
 def build_reference():
     Denoiser, MotionPrior, rot = _shim()
     base = json.load(open(REF / "configs/base_new.json"))
@@ -79,7 +149,11 @@ def main():
     out.mkdir(parents=True, exist_ok=True)
     torch.manual_seed(0)
     torch.set_grad_enabled(False)
+    if "--variants-only" in sys.argv:   # only tests/golden/denoiser_variants.npz + state_dict_spec_variants.json
+        gen_variants(out, _shim()[0])
+        return
     den, prior, rot = build_reference()
+    gen_variants(out, type(den))
 
     # ---- state-dict spec straight from the reference modules
     spec = {"denoiser": {k: list(v.shape) for k, v in den.state_dict().items()},
