@@ -16,7 +16,8 @@ LIB_PATH = Path(os.environ.get("AMUSE_HIP_LIB") or _HERE / "libamuse_hip.so")
 PREC_F32, PREC_BF16, PREC_F32X, PREC_F16 = 0, 1, 2, 3
 UPD_F32, UPD_BF16, UPD_ENCODER, UPD_F32X, UPD_F16, UPD_ALL = 1, 2, 4, 8, 16, 31
 QUAT_P3D, QUAT_LEGACY = 0, 1
-ABI_VERSION = 2
+ABI_VERSION = 3
+ARCH_ENC, ARCH_DEC, ARCH_ENC_POSE, ARCH_DEC_POSE = 0, 1, 2, 3   # include/amuse_hip.h AMUSE_ARCH_*
 
 EXPORTS = [
     "amuse_abi_version", "amuse_last_error", "amuse_create", "amuse_update_weights", "amuse_update_weights_device", "amuse_destroy", "amuse_set_schedule",
@@ -25,6 +26,7 @@ EXPORTS = [
     "amuse_audio_create", "amuse_audio_destroy", "amuse_audio_fbank", "amuse_audio_encode", "amuse_audio_features",
     "amuse_debug_gemm",
     "amuse_debug_tile", "amuse_debug_f16_split", "amuse_debug_set_decode_tap",
+    "amuse_create_arch", "amuse_denoiser_param_count", "amuse_arch", "amuse_state_dim", "amuse_denoise_step_pose", "amuse_feats_to_smplx",
 ]
 
 
@@ -56,6 +58,18 @@ def load() -> C.CDLL:
     lib.amuse_last_error.restype = C.c_char_p
     lib.amuse_create.restype = vp
     lib.amuse_create.argtypes = [C.c_int, C.POINTER(C.c_float), C.c_size_t, C.POINTER(C.c_float), C.c_size_t]
+    lib.amuse_create_arch.restype = vp
+    lib.amuse_create_arch.argtypes = [C.c_int, C.c_int, C.POINTER(C.c_float), C.c_size_t, C.POINTER(C.c_float), C.c_size_t]
+    lib.amuse_denoiser_param_count.restype = C.c_size_t
+    lib.amuse_denoiser_param_count.argtypes = [C.c_int]
+    lib.amuse_arch.restype = C.c_int
+    lib.amuse_arch.argtypes = [vp]
+    lib.amuse_state_dim.restype = C.c_size_t
+    lib.amuse_state_dim.argtypes = [vp]
+    lib.amuse_denoise_step_pose.restype = C.c_int
+    lib.amuse_denoise_step_pose.argtypes = [vp, fp, C.c_int, fp, fp, fp, ip, C.c_int, C.c_int, fp, vp]
+    lib.amuse_feats_to_smplx.restype = C.c_int
+    lib.amuse_feats_to_smplx.argtypes = [vp, fp, C.c_int, C.c_int, fp, fp, vp]
     lib.amuse_update_weights.restype = C.c_int
     lib.amuse_update_weights.argtypes = [vp, C.POINTER(C.c_float), C.c_size_t, C.POINTER(C.c_float), C.c_size_t, C.c_int, vp]
     lib.amuse_update_weights_device.restype = C.c_int

@@ -1,361 +1,29 @@
 // C ABI of libamuse_hip.so (include/amuse_hip.h): context, weight packing into MFMA-fragment
 // streams, workspace, and the launch sequences.  Host code only - kernels live in k_*.hip.
-#include <hip/hip_runtime.h>
-
-#include <cmath>
-#include <cstdarg>
-#include <cstdio>
-#include <cstdlib>
-#include <cstring>
-#include <map>
-#include <string>
-#include <vector>
-
-#include "../../include/amuse_hip.h"
-#include "amuse_dev.hpp"
-#include "amuse_kernels.hpp"
-
-using namespace amuse;
+#include "amuse_host.hpp"
+#include "amuse_variants.hpp"
 
 namespace {
-
 thread_local char g_err[512] = "";
-
-int fail(int code, const char* fmt, ...) {
+}  // namespace
+int amuse_failf(int code, const char* fmt, ...) {
     va_list ap;
     va_start(ap, fmt);
     vsnprintf(g_err, sizeof(g_err), fmt, ap);
     va_end(ap);
     return code;
 }
-}  // namespace
 // the same error slot for the library's other translation units (amuse_audio_api.hip)
 __attribute__((visibility("hidden"))) int amuse_fail_msg(int code, const char* msg) {
     snprintf(g_err, sizeof(g_err), "%s", msg);
     return code;
 }
-namespace {
-#define HIP_TRY(expr)                                                                                   \
-    do {                                                                                                \
-        hipError_t e_ = (expr);                                                                         \
-        if (e_ != hipSuccess) return fail(AMUSE_EHIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
-    } while (0)
 
-// ---------------------------------------------------------------- state-dict index (order = reference)
-struct ParamIndex {
-    std::map<std::string, std::pair<size_t, size_t>> m;  // name -> (offset, numel)
-    size_t total = 0;
-    void add(const std::string& n, size_t numel) { m[n] = {total, numel}; total += numel; }
-};
-
-void enc_layer(ParamIndex& P, const std::string& p) {
-    P.add(p + ".self_attn.in_proj_weight", 384 * 128); P.add(p + ".self_attn.in_proj_bias", 384);
-    P.add(p + ".self_attn.out_proj.weight", 128 * 128); P.add(p + ".self_attn.out_proj.bias", 128);
-    P.add(p + ".linear1.weight", 512 * 128); P.add(p + ".linear1.bias", 512);
-    P.add(p + ".linear2.weight", 128 * 512); P.add(p + ".linear2.bias", 128);
-    P.add(p + ".norm1.weight", 128); P.add(p + ".norm1.bias", 128);
-    P.add(p + ".norm2.weight", 128); P.add(p + ".norm2.bias", 128);
-}
-void dec_layer(ParamIndex& P, const std::string& p) {
-    P.add(p + ".self_attn.in_proj_weight", 384 * 128); P.add(p + ".self_attn.in_proj_bias", 384);
-    P.add(p + ".self_attn.out_proj.weight", 128 * 128); P.add(p + ".self_attn.out_proj.bias", 128);
-    P.add(p + ".multihead_attn.in_proj_weight", 384 * 128); P.add(p + ".multihead_attn.in_proj_bias", 384);
-    P.add(p + ".multihead_attn.out_proj.weight", 128 * 128); P.add(p + ".multihead_attn.out_proj.bias", 128);
-    P.add(p + ".linear1.weight", 512 * 128); P.add(p + ".linear1.bias", 512);
-    P.add(p + ".linear2.weight", 128 * 512); P.add(p + ".linear2.bias", 128);
-    for (const char* n : {"norm1", "norm2", "norm3"}) { P.add(p + "." + n + ".weight", 128); P.add(p + "." + n + ".bias", 128); }
-}
-std::string blk_name(const std::string& prefix, int blk) {
-    if (blk < 4) return prefix + ".input_blocks." + std::to_string(blk);
-    if (blk == 4) return prefix + ".middle_block";
-    return prefix + ".output_blocks." + std::to_string(blk - 5);
-}
-void skip_stack(ParamIndex& P, const std::string& prefix, bool dec) {
-    P.add(prefix + ".norm.weight", 128); P.add(prefix + ".norm.bias", 128);
-    for (int b = 0; b < 9; ++b) dec ? dec_layer(P, blk_name(prefix, b)) : enc_layer(P, blk_name(prefix, b));
-    for (int i = 0; i < 4; ++i) {
-        P.add(prefix + ".linear_blocks." + std::to_string(i) + ".weight", 128 * 256);
-        P.add(prefix + ".linear_blocks." + std::to_string(i) + ".bias", 128);
-    }
-}
-ParamIndex denoiser_index() {
-    ParamIndex P;
-    P.add("time_embedding.linear_1.weight", 128 * 256); P.add("time_embedding.linear_1.bias", 128);
-    P.add("time_embedding.linear_2.weight", 128 * 128); P.add("time_embedding.linear_2.bias", 128);
-    for (const char* n : {"con", "emo", "sty"}) {
-        P.add(std::string("emb_proj_") + n + ".1.weight", 128 * 256);
-        P.add(std::string("emb_proj_") + n + ".1.bias", 128);
-    }
-    P.add("query_pos.pe", 500 * 128); P.add("mem_pos.pe", 500 * 128);
-    skip_stack(P, "encoder", false);
-    return P;
-}
-ParamIndex prior_index() {
-    ParamIndex P;
-    P.add("global_motion_token", 2 * 128);
-    P.add("query_pos_encoder.pe", 500 * 128); P.add("query_pos_decoder.pe", 500 * 128);
-    skip_stack(P, "encoder", false);
-    skip_stack(P, "decoder", true);
-    P.add("skel_embedding.weight", 128 * 333); P.add("skel_embedding.bias", 128);
-    P.add("final_layer.weight", 333 * 128); P.add("final_layer.bias", 333);
-    return P;
-}
-struct Params {
-    const ParamIndex& idx;
-    const float* base;
-    const float* get(const std::string& n) const { return base + idx.m.at(n).first; }
-};
-
-// ---------------------------------------------------------------- MFMA-fragment packing (see amuse_dev.hpp)
-uint16_t f2bf(float f) {  // round-to-nearest-even, as v_cvt_pk_bf16_f32
-    uint32_t x;
-    memcpy(&x, &f, 4);
-    if ((x & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((x >> 16) | 0x40);
-    x += 0x7fffu + ((x >> 16) & 1u);
-    return (uint16_t)(x >> 16);
-}
-// fp32 -> fp16 bits, round-to-nearest-even with gradual underflow (what v_cvt_pk_f16_f32 / (_Float16) do), and back (exact)
-uint16_t f2h(float f) {
-    uint32_t x;
-    memcpy(&x, &f, 4);
-    const uint16_t sign = (uint16_t)((x >> 16) & 0x8000u);
-    x &= 0x7fffffffu;
-    if (x > 0x7f800000u) return (uint16_t)(sign | 0x7e00u);          // NaN
-    if (x >= 0x477ff000u) return (uint16_t)(sign | 0x7c00u);         // >= 65520 rounds to infinity
-    if (x < 0x38800000u) {                                            // below 2^-14: the result is subnormal (or 2^-14)
-        float a;
-        memcpy(&a, &x, 4);
-        return (uint16_t)(sign | (uint16_t)nearbyintf(a * 16777216.0f));   // units of 2^-24, ties to even
-    }
-    x -= 0x38000000u;                                                 // re-bias the exponent (127 -> 15)
-    x += 0xfffu + ((x >> 13) & 1u);
-    return (uint16_t)(sign | (x >> 13));
-}
-float h2f(uint16_t h) {
-    const uint32_t sign = (uint32_t)(h & 0x8000u) << 16, e = (h >> 10) & 31u, m = h & 0x3ffu;
-    float f;
-    if (e == 0) {
-        f = (float)m * 5.9604644775390625e-8f;                        // m * 2^-24
-        uint32_t u;
-        memcpy(&u, &f, 4);
-        u |= sign;
-        memcpy(&f, &u, 4);
-        return f;
-    }
-    const uint32_t u = sign | (e == 31 ? 0x7f800000u | (m << 13) : ((e + 112u) << 23) | (m << 13));
-    memcpy(&f, &u, 4);
-    return f;
-}
-bool g_probe_f16 = false;   // build_repack_maps: the lo units carry the probe value too (amuse_update_weights_device)
-// W: [n_out x K] row-major.  Appends units for (k-tile outer, out-tile inner); PREC_F16X2: k-tile pair outer, out-tile inner,
-// two units each - hi = rn16(w), lo = rn16(w - hi) (amuse_dev.hpp gemm_ring_s).
-void pack_gemm(std::vector<uint4>& out, int prec, const float* W, int n_out, int K, const std::vector<int>& otiles,
-               const std::vector<int>& ktiles) {
-    // (amuse_update_weights calls this once per training iteration: the destination is sized once and filled through a
-    // pointer, rows / columns inside the matrix skip the bounds checks)
-    const size_t nunits = is_op16(prec) ? (ktiles.size() / 2) * otiles.size() : ktiles.size() * otiles.size();
-    uint16_t (*const cv16)(float) = prec == PREC_F16 ? f2h : f2bf;   // the one-piece 16-bit formats differ in the conversion only
-    const size_t base = out.size();
-    out.resize(base + nunits * 64);
-    uint4* dst = out.data() + base;
-    auto at = [&](int row, int col) -> float { return (row < n_out && col < K) ? W[(size_t)row * K + col] : 0.f; };
-    if (prec == PREC_F32) {
-        for (int t : ktiles)
-            for (int o : otiles) {
-                const bool inside = 16 * o + 16 <= n_out && 16 * t + 16 <= K;
-                for (int lane = 0; lane < 64; ++lane, ++dst) {
-                    const int g = lane >> 4, i = lane & 15;
-                    float v[4];
-                    if (inside) memcpy(v, W + (size_t)(16 * o + i) * K + 16 * t + 4 * g, 16);
-                    else
-                        for (int m = 0; m < 4; ++m) v[m] = at(16 * o + i, 16 * t + 4 * g + m);
-                    memcpy(dst, v, 16);
-                }
-            }
-    } else if (prec == PREC_F16X2) {
-        for (size_t c = 0; c + 1 < ktiles.size(); c += 2) {
-            const int t0 = ktiles[c], t1 = ktiles[c + 1];
-            for (int o : otiles) {
-                for (int lane = 0; lane < 64; ++lane, ++dst) {
-                    const int g = lane >> 4, i = lane & 15;
-                    uint16_t hi[8], lo[8];
-                    for (int e = 0; e < 8; ++e) {
-                        const float w = at(16 * o + i, 16 * (e < 4 ? t0 : t1) + 4 * g + (e & 3));
-                        hi[e] = f2h(w);
-                        lo[e] = g_probe_f16 ? hi[e] : f2h(w - h2f(hi[e]));
-                    }
-                    memcpy(dst, hi, 16);
-                    memcpy(dst + 64, lo, 16);
-                }
-                dst += 64;
-            }
-        }
-    } else {
-        for (size_t c = 0; c + 1 < ktiles.size(); c += 2) {
-            const int t0 = ktiles[c], t1 = ktiles[c + 1];
-            for (int o : otiles) {
-                const bool inside = 16 * o + 16 <= n_out && 16 * t0 + 16 <= K && 16 * t1 + 16 <= K;
-                for (int lane = 0; lane < 64; ++lane, ++dst) {
-                    const int g = lane >> 4, i = lane & 15;
-                    uint16_t v[8];
-                    if (inside) {
-                        const float* r0 = W + (size_t)(16 * o + i) * K + 16 * t0 + 4 * g;
-                        const float* r1 = W + (size_t)(16 * o + i) * K + 16 * t1 + 4 * g;
-                        for (int e = 0; e < 4; ++e) { v[e] = cv16(r0[e]); v[4 + e] = cv16(r1[e]); }
-                    } else {
-                        for (int e = 0; e < 4; ++e) {
-                            v[e] = cv16(at(16 * o + i, 16 * t0 + 4 * g + e));
-                            v[4 + e] = cv16(at(16 * o + i, 16 * t1 + 4 * g + e));
-                        }
-                    }
-                    memcpy(dst, v, 16);
-                }
-            }
-        }
-    }
-}
-std::vector<int> range(int a, int b) { std::vector<int> r; for (int i = a; i < b; ++i) r.push_back(i); return r; }
-
-void fill_block_pvec(float* pv, const Params& P, const std::string& p, bool dec) {
-    memcpy(pv + PV_IN_B, P.get(p + ".self_attn.in_proj_bias"), 384 * 4);
-    memcpy(pv + PV_OUT_B, P.get(p + ".self_attn.out_proj.bias"), 128 * 4);
-    memcpy(pv + PV_L1_B, P.get(p + ".linear1.bias"), 512 * 4);
-    memcpy(pv + PV_L2_B, P.get(p + ".linear2.bias"), 128 * 4);
-    memcpy(pv + PV_LN1_W, P.get(p + ".norm1.weight"), 128 * 4); memcpy(pv + PV_LN1_B, P.get(p + ".norm1.bias"), 128 * 4);
-    memcpy(pv + PV_LN2_W, P.get(p + ".norm2.weight"), 128 * 4); memcpy(pv + PV_LN2_B, P.get(p + ".norm2.bias"), 128 * 4);
-    if (dec) { memcpy(pv + PV_LN3_W, P.get(p + ".norm3.weight"), 128 * 4); memcpy(pv + PV_LN3_B, P.get(p + ".norm3.bias"), 128 * 4); }
-}
-std::vector<float> build_pvec(const Params& P, const std::string& prefix, bool dec) {
-    std::vector<float> pv(PV_TOTAL, 0.f);
-    for (int b = 0; b < 9; ++b) fill_block_pvec(pv.data() + b * PV_BLOCK, P, blk_name(prefix, b), dec);
-    for (int i = 0; i < 4; ++i)
-        memcpy(pv.data() + PV_SKIP_B + i * 128, P.get(prefix + ".linear_blocks." + std::to_string(i) + ".bias"), 128 * 4);
-    memcpy(pv.data() + PV_FINAL_W, P.get(prefix + ".norm.weight"), 128 * 4);
-    memcpy(pv.data() + PV_FINAL_B, P.get(prefix + ".norm.bias"), 128 * 4);
-    return pv;
-}
-// the per-wave pieces shared by encoder and decoder blocks
-void pack_qkv(std::vector<uint4>& s, int prec, const float* in_w, int h, bool v_separate) {
-    if (v_separate) {  // sampler: q,k tiles as one 4-tile GEMM, then v (operand-swapped on the device)
-        pack_gemm(s, prec, in_w, 384, 128, {2 * h, 2 * h + 1, 8 + 2 * h, 8 + 2 * h + 1}, range(0, 8));
-        pack_gemm(s, prec, in_w, 384, 128, {16 + 2 * h, 16 + 2 * h + 1}, range(0, 8));
-    } else {
-        pack_gemm(s, prec, in_w, 384, 128, {2 * h, 2 * h + 1, 8 + 2 * h, 8 + 2 * h + 1, 16 + 2 * h, 16 + 2 * h + 1}, range(0, 8));
-    }
-}
-void pack_outproj_ffn(std::vector<uint4>& s, int prec, const Params& P, const std::string& p, int w) {
-    pack_gemm(s, prec, P.get(p + ".self_attn.out_proj.weight"), 128, 128, range(0, 8), {2 * w, 2 * w + 1});
-    pack_gemm(s, prec, P.get(p + ".linear1.weight"), 512, 128, range(8 * w, 8 * w + 8), range(0, 8));
-    pack_gemm(s, prec, P.get(p + ".linear2.weight"), 128, 512, range(0, 8), range(8 * w, 8 * w + 8));
-}
-// sampler order: out_proj, then the FFN in four software-pipelined quarters (k_sampler.hip encoder_block)
-void pack_outproj_ffn_quarters(std::vector<uint4>& s, int prec, const Params& P, const std::string& p, int w) {
-    pack_gemm(s, prec, P.get(p + ".self_attn.out_proj.weight"), 128, 128, range(0, 8), {2 * w, 2 * w + 1});
-    // software-pipelined order of k_sampler.hip: F1q0 F1q1 F2q0 F1q2 F2q1 F1q3 F2q2 F2q3
-    auto f1 = [&](int q) { const int h0 = 8 * w + 2 * q; pack_gemm(s, prec, P.get(p + ".linear1.weight"), 512, 128, {h0, h0 + 1}, range(0, 8)); };
-    auto f2 = [&](int q) { const int h0 = 8 * w + 2 * q; pack_gemm(s, prec, P.get(p + ".linear2.weight"), 128, 512, range(0, 8), {h0, h0 + 1}); };
-    f1(0); f1(1); f2(0); f1(2); f2(1); f1(3); f2(2); f2(3);
-}
-void pack_skiplin(std::vector<uint4>& s, int prec, const Params& P, const std::string& prefix, int i, int w) {
-    pack_gemm(s, prec, P.get(prefix + ".linear_blocks." + std::to_string(i) + ".weight"), 128, 256, range(0, 8),
-              range(4 * w, 4 * w + 4));
-}
-
-// amuse_update_weights_device learns the packed images' gather maps by running the builders on probe parameters with upload()
-// redirected into host memory, keyed by the context slot the image belongs to
-struct Capture {
-    std::map<void**, std::vector<unsigned char>> bufs;
-};
-thread_local Capture* g_capture = nullptr;
-
-// first call allocates; later calls (amuse_update_weights: same architecture, same sizes) overwrite in place
-template <typename T>
-int upload(T** dst, const void* src, size_t bytes) {
-    if (g_capture) {
-        const unsigned char* b = static_cast<const unsigned char*>(src);
-        g_capture->bufs[reinterpret_cast<void**>(dst)].assign(b, b + bytes);
-        return 0;
-    }
-    if (!*dst) HIP_TRY(hipMalloc((void**)dst, bytes));
-    HIP_TRY(hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice));
-    return 0;
-}
-std::vector<float> transpose(const float* w, int rows, int cols) {  // [rows][cols] -> [cols][rows]
-    std::vector<float> t((size_t)rows * cols);
-    for (int r = 0; r < rows; ++r)
-        for (int c = 0; c < cols; ++c) t[(size_t)c * rows + r] = w[(size_t)r * cols + c];
-    return t;
-}
-
-}  // namespace
-
-struct amuse_ctx {
-    int device = 0;
-    int clips_per_group = 0;
-    int decode_path = AMUSE_DECODE_AUTO;
-    float* decode_tap = nullptr;       // amuse_debug_set_decode_tap
-    // denoiser
-    uint4* den_w[3] = {nullptr, nullptr, nullptr};   // 4-wave kernel streams: fp32 | bf16 | split-fp16 (fp32x)
-    uint32_t den_wave_units[3] = {0, 0, 0};
-    uint4* den_w8 = nullptr;           // bf16 streams of the 8-wave kernel (k_sampler8.hip)
-    uint32_t den_w8_units[2] = {0, 0}; // per-step units of a group-A / group-B wave
-    uint4* den_w8h = nullptr;          // fp16 streams of the same kernel built for fp16 operands (k_sampler8h.hip, AMUSE_PREC_F16)
-    uint4* den_w8x = nullptr;          // split-fp16 streams of the 8-wave fp32x kernel (k_sampler8x.hip)
-    uint32_t den_w8x_units[2] = {0, 0};
-    float* den_pvec = nullptr;
-    float* den_pe = nullptr;           // [500][128]
-    float* den_freqs = nullptr;        // [128]
-    float *te_w1t = nullptr, *te_b1 = nullptr, *te_w2t = nullptr, *te_b2 = nullptr;
-    float* cond_wt[3] = {nullptr, nullptr, nullptr};
-    float* cond_b[3] = {nullptr, nullptr, nullptr};
-    // prior decoder
-    uint4* vae_w[4] = {nullptr, nullptr, nullptr, nullptr};   // staged decode streams: fp32 | bf16 | split-fp16 (fp32x) | fp16
-    uint32_t vae_stage_base[4][kVaeStages];
-    uint32_t vae_stage_units[4][kVaeStages];
-    uint4* vae_wf = nullptr;           // bf16 stream of the fused decode kernel (k_vae_fused.hip)
-    uint4* vae_wfh = nullptr;          // its fp16 twin (k_vae_fusedh.hip, AMUSE_PREC_F16)
-    uint4* vae_w8x = nullptr;          // fp32x row stages without split-K (k_vae_rows8.hip): one stream per stage, consumption order
-    uint32_t vae_w8x_base[kVaeStages];
-    uint4* vae_skip = nullptr; size_t vae_skip_cap = 0;   // clips
-    float* vae_ca_ws = nullptr; size_t vae_ca_cap = 0;    // clips
-    float *vae_pvec = nullptr, *vae_final_bias = nullptr, *vae_pe = nullptr;
-    float *vae_wv_t = nullptr, *vae_bv = nullptr, *vae_wo_t = nullptr, *vae_bo = nullptr;
-    // prior encoder (MotionPrior.encode)
-    uint4* vaee_w[4] = {nullptr, nullptr, nullptr, nullptr};
-    uint32_t vaee_stage_base[4][kVaeStages];
-    uint32_t vaee_stage_units[4][kVaeStages];
-    float *vaee_pvec = nullptr, *vaee_pe = nullptr, *vaee_tok = nullptr, *vaee_emb_bias = nullptr;
-    // schedule
-    int T = 0;
-    int* d_timesteps = nullptr;
-    float *d_coef = nullptr, *d_time_tok = nullptr;
-    int* d_ts1 = nullptr;
-    float *d_tt1 = nullptr, *d_coef1 = nullptr;
-    // workspaces
-    float* cond_tok = nullptr; size_t cond_cap = 0;
-    float* lat_tmp = nullptr; size_t lat_cap = 0;
-    float* fwd_ws = nullptr; size_t fwd_cap = 0;
-    float* vae_ws = nullptr; size_t vae_cap = 0;  // clips
-    int* d_lengths = nullptr; size_t len_cap = 0;
-    std::vector<void*> owned;
-    // amuse_update_weights_device: one entry per packed image (built on the first call)
-    struct Repack { void** slot; int* map; size_t n; int prior, kind, cls; };
-    std::vector<Repack> repack;
-};
 
 namespace {
 constexpr int kVaeChunk = 512;
 constexpr int kEncRows = kFrames + 2;  // encoder sequence: 2 distribution tokens + 300 frames
 constexpr size_t kVaeFloatsPerClip = (size_t)kEncRows * kD * (1 + 3 + 1 + 4) + kLayers * kD;  // x, qkv, o, skip, ca | stats
-
-int ensure(float** p, size_t* cap, size_t need_floats) {
-    if (*cap >= need_floats) return 0;
-    if (*p) HIP_TRY(hipFree(*p));
-    *p = nullptr; *cap = 0;
-    HIP_TRY(hipMalloc((void**)p, need_floats * sizeof(float)));
-    *cap = need_floats;
-    return 0;
-}
 
 constexpr int kUpdBit[4] = {AMUSE_UPD_F32, AMUSE_UPD_BF16, AMUSE_UPD_F32X, AMUSE_UPD_F16};   // per PREC_* index
 
@@ -639,8 +307,9 @@ int build_prior(amuse_ctx* c, const float* pri, int what = AMUSE_UPD_ALL) {
 }
 
 int build_ctx(amuse_ctx* c, const float* den, const float* pri) {
-    if (int e = build_denoiser(c, den)) return e;
-    if (int e = build_prior(c, pri)) return e;
+    if (int e = c->arch == AMUSE_ARCH_ENC ? build_denoiser(c, den) : variant_build(c, den, AMUSE_UPD_ALL)) return e;
+    if (pri)
+        if (int e = build_prior(c, pri)) return e;
     HIP_TRY(hipMalloc((void**)&c->d_timesteps, AMUSE_MAX_STEPS * sizeof(int)));
     HIP_TRY(hipMalloc((void**)&c->d_coef, AMUSE_MAX_STEPS * 8 * sizeof(float)));
     HIP_TRY(hipMalloc((void**)&c->d_time_tok, AMUSE_MAX_STEPS * kD * sizeof(float)));
@@ -658,7 +327,7 @@ int cond_tokens(amuse_ctx* c, const float* con, const float* emo, const float* s
     for (int i = 0; i < 3; ++i)
         if (zs[i]) { ca.z[n] = zs[i]; ca.wt[n] = c->cond_wt[i]; ca.bias[n] = c->cond_b[i]; ++n; }
     if (int e = ensure(&c->cond_tok, &c->cond_cap, (size_t)B * 3 * kD)) return e;
-    ca.pe = c->den_pe; ca.out = c->cond_tok; ca.B = B; ca.ncond = n;
+    ca.pe = c->den_pe; ca.out = c->cond_tok; ca.B = B; ca.ncond = n; ca.pe_base = 2;
     HIP_TRY(launch_cond_tokens(ca, s));
     *S_out = 2 + n;
     return 0;
@@ -782,15 +451,29 @@ int amuse_debug_f16_split(const float* w, size_t n, uint16_t* hi, uint16_t* lo) 
 }
 const char* amuse_last_error(void) { return g_err; }
 
+size_t amuse_denoiser_param_count(int arch) { return arch == AMUSE_ARCH_ENC ? (size_t)AMUSE_DENOISER_PARAMS : variant_param_count(arch); }
+int amuse_arch(const amuse_ctx* c) { return c ? c->arch : AMUSE_EINVAL; }
+size_t amuse_state_dim(const amuse_ctx* c) { return c ? variant_state_dim(c->arch) : 0; }
+
 amuse_ctx* amuse_create(int device, const float* denoiser_params, size_t n_denoiser, const float* prior_params,
                         size_t n_prior) {
-    if (!denoiser_params || !prior_params) { fail(AMUSE_EINVAL, "NULL parameter array"); return nullptr; }
-    if (n_denoiser != AMUSE_DENOISER_PARAMS || n_prior != AMUSE_PRIOR_PARAMS) {
-        fail(AMUSE_EINVAL, "parameter count mismatch: denoiser %zu (want %u), prior %zu (want %u)", n_denoiser,
-             AMUSE_DENOISER_PARAMS, n_prior, AMUSE_PRIOR_PARAMS);
+    if (!prior_params) { fail(AMUSE_EINVAL, "NULL parameter array"); return nullptr; }
+    return amuse_create_arch(device, AMUSE_ARCH_ENC, denoiser_params, n_denoiser, prior_params, n_prior);
+}
+
+amuse_ctx* amuse_create_arch(int device, int arch, const float* denoiser_params, size_t n_denoiser, const float* prior_params,
+                             size_t n_prior) {
+    if (arch < AMUSE_ARCH_ENC || arch > AMUSE_ARCH_DEC_POSE) { fail(AMUSE_EINVAL, "unknown arch %d", arch); return nullptr; }
+    const bool pose = (arch & 2) != 0;
+    if (!denoiser_params || (!prior_params && !pose)) { fail(AMUSE_EINVAL, "NULL parameter array"); return nullptr; }
+    if (n_denoiser != amuse_denoiser_param_count(arch) || (prior_params ? n_prior != AMUSE_PRIOR_PARAMS : n_prior != 0)) {
+        fail(AMUSE_EINVAL, "parameter count mismatch: denoiser %zu (want %zu for arch %d), prior %zu (want %u)", n_denoiser,
+             amuse_denoiser_param_count(arch), arch, n_prior, AMUSE_PRIOR_PARAMS);
         return nullptr;
     }
-    if (denoiser_index().total != AMUSE_DENOISER_PARAMS || prior_index().total != AMUSE_PRIOR_PARAMS) {
+    if (denoiser_index().total != AMUSE_DENOISER_PARAMS || prior_index().total != AMUSE_PRIOR_PARAMS ||
+        variant_param_count(AMUSE_ARCH_DEC) != AMUSE_DENOISER_PARAMS_DEC || variant_param_count(AMUSE_ARCH_ENC_POSE) != AMUSE_DENOISER_PARAMS_ENC_POSE ||
+        variant_param_count(AMUSE_ARCH_DEC_POSE) != AMUSE_DENOISER_PARAMS_DEC_POSE) {
         fail(AMUSE_ESTATE, "internal: state-dict index does not add up");
         return nullptr;
     }
@@ -798,6 +481,8 @@ amuse_ctx* amuse_create(int device, const float* denoiser_params, size_t n_denoi
     if (e != hipSuccess) { fail(AMUSE_EHIP, "hipSetDevice(%d): %s", device, hipGetErrorString(e)); return nullptr; }
     amuse_ctx* c = new amuse_ctx();
     c->device = device;
+    c->arch = arch;
+    c->has_prior = prior_params != nullptr;
     if (build_ctx(c, denoiser_params, prior_params) != 0) { amuse_destroy(c); return nullptr; }
     return c;
 }
@@ -807,14 +492,15 @@ int amuse_update_weights(amuse_ctx* c, const float* denoiser_params, size_t n_de
     if (!c) return fail(AMUSE_EINVAL, "ctx is NULL");
     if (!denoiser_params && !prior_params) return fail(AMUSE_EINVAL, "nothing to update");
     if (what < 1 || what > AMUSE_UPD_ALL || !(what & (AMUSE_UPD_F32 | AMUSE_UPD_BF16 | AMUSE_UPD_F32X | AMUSE_UPD_F16))) return fail(AMUSE_EINVAL, "bad `what` mask %d", what);
-    if (denoiser_params && n_denoiser != AMUSE_DENOISER_PARAMS)
-        return fail(AMUSE_EINVAL, "denoiser parameter count %zu (want %u)", n_denoiser, AMUSE_DENOISER_PARAMS);
+    if (denoiser_params && n_denoiser != amuse_denoiser_param_count(c->arch))
+        return fail(AMUSE_EINVAL, "denoiser parameter count %zu (want %zu)", n_denoiser, amuse_denoiser_param_count(c->arch));
     if (prior_params && n_prior != AMUSE_PRIOR_PARAMS)
         return fail(AMUSE_EINVAL, "prior parameter count %zu (want %u)", n_prior, AMUSE_PRIOR_PARAMS);
+    if (prior_params && !c->has_prior) return fail(AMUSE_ESTATE, "this context was created without MotionPrior weights");
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipStreamSynchronize((hipStream_t)stream));   // kernels in flight still read the old streams
     if (denoiser_params) {
-        if (int e = build_denoiser(c, denoiser_params, what)) return e;
+        if (int e = c->arch == AMUSE_ARCH_ENC ? build_denoiser(c, denoiser_params, what) : variant_build(c, denoiser_params, what)) return e;
         c->T = 0;   // the hoisted time-token table belongs to the old time-embedding weights: set the schedule again
     }
     if (prior_params)
@@ -904,6 +590,7 @@ int amuse_update_weights_device(amuse_ctx* c, const float* denoiser_params_dev, 
     if (!c) return fail(AMUSE_EINVAL, "ctx is NULL");
     if (!denoiser_params_dev && !prior_params_dev) return fail(AMUSE_EINVAL, "nothing to update");
     if (what < 1 || what > AMUSE_UPD_ALL || !(what & (AMUSE_UPD_F32 | AMUSE_UPD_BF16 | AMUSE_UPD_F32X | AMUSE_UPD_F16))) return fail(AMUSE_EINVAL, "bad `what` mask %d", what);
+    if (c->arch != AMUSE_ARCH_ENC || !c->has_prior) return fail(AMUSE_ESTATE, "the device re-pack exists for the shipped configuration (AMUSE_ARCH_ENC) only; use amuse_update_weights");
     HIP_TRY(hipSetDevice(c->device));
     if (c->repack.empty())
         if (int e = build_repack_maps(c)) return e;
@@ -924,6 +611,7 @@ int amuse_update_weights_device(amuse_ctx* c, const float* denoiser_params_dev, 
 void amuse_destroy(amuse_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
+    variant_destroy(c);
     for (void* p : c->owned)
         if (p) (void)hipFree(p);
     void* ptrs[] = {c->den_w[0], c->den_w[1], c->den_w[2], c->den_w8, c->den_w8h, c->den_w8x, c->vae_wfh, c->den_pvec, c->den_pe, c->den_freqs, c->te_w1t, c->te_b1, c->te_w2t,
@@ -972,10 +660,14 @@ int amuse_set_schedule(amuse_ctx* c, const amuse_schedule* s, void* stream) {
     HIP_TRY(hipMemcpy(c->d_timesteps, s->timesteps, s->n_steps * sizeof(int), hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(c->d_coef, s->coef, (size_t)s->n_steps * 8 * sizeof(float), hipMemcpyHostToDevice));
     if (s->freqs) HIP_TRY(hipMemcpy(c->den_freqs, s->freqs, 128 * sizeof(float), hipMemcpyHostToDevice));
-    HIP_TRY(launch_time_tokens(c->d_timesteps, s->n_steps, c->den_freqs, c->te_w1t, c->te_b1, c->te_w2t, c->te_b2,
-                               c->den_pe + kD, c->d_time_tok, st));
-    HIP_TRY(hipStreamSynchronize(st));
     c->T = s->n_steps;
+    if (c->arch != AMUSE_ARCH_ENC) {
+        if (int e = variant_set_schedule(c, st)) { c->T = 0; return e; }
+    } else {
+        HIP_TRY(launch_time_tokens(c->d_timesteps, s->n_steps, c->den_freqs, c->te_w1t, c->te_b1, c->te_w2t, c->te_b2,
+                                   c->den_pe + kD, c->d_time_tok, st));
+    }
+    HIP_TRY(hipStreamSynchronize(st));
     return 0;
 }
 
@@ -986,6 +678,8 @@ int amuse_sample(amuse_ctx* c, const float* con, const float* emo, const float* 
     if (c->T < 1) return fail(AMUSE_ESTATE, "amuse_set_schedule has not been called");
     if (!latents_out) return fail(AMUSE_EINVAL, "latents_out is NULL");
     hipStream_t st = (hipStream_t)stream;
+    if (c->arch != AMUSE_ARCH_ENC)
+        return variant_sample(c, con, emo, sty, B, precision, seed, clip_index0, x_init, step_noise, latents_out, traj_out, st);
     int S = 0;
     if (int e = cond_tokens(c, con, emo, sty, B, &S, st)) return e;
     SampleArgs a{};
@@ -1004,6 +698,7 @@ int amuse_profile_sample(amuse_ctx* c, const float* con, const float* emo, const
     if (int e = check_common(c, con, B, precision)) return e;
     if (c->T < 1) return fail(AMUSE_ESTATE, "amuse_set_schedule has not been called");
     if (!stamps_out || prof_step < 0 || prof_step >= c->T) return fail(AMUSE_EINVAL, "bad stamps_out / prof_step");
+    if (c->arch != AMUSE_ARCH_ENC) return fail(AMUSE_ESTATE, "phase stamps exist for the AMUSE_ARCH_ENC sampling kernels only");
     hipStream_t st = (hipStream_t)stream;
     int S = 0;
     if (int e = cond_tokens(c, con, emo, sty, B, &S, st)) return e;
@@ -1026,6 +721,7 @@ int amuse_denoise_step(amuse_ctx* c, const float* x_t, int timestep, const float
     if (!x_t || !eps_out) return fail(AMUSE_EINVAL, "x_t / eps_out is NULL");
     if (timestep < 0) return fail(AMUSE_EINVAL, "negative timestep");
     hipStream_t st = (hipStream_t)stream;
+    if (c->arch != AMUSE_ARCH_ENC) return variant_denoise(c, x_t, &timestep, false, con, emo, sty, nullptr, B, precision, eps_out, tap_out, st);
     HIP_TRY(hipMemcpyAsync(c->d_ts1, &timestep, sizeof(int), hipMemcpyHostToDevice, st));
     HIP_TRY(hipStreamSynchronize(st));  // `timestep` lives on this call's stack
     HIP_TRY(launch_time_tokens(c->d_ts1, 1, c->den_freqs, c->te_w1t, c->te_b1, c->te_w2t, c->te_b2, c->den_pe + kD,
@@ -1051,6 +747,20 @@ int amuse_diffusion_forward(amuse_ctx* c, const float* z0, const float* noise, c
     for (int b = 0; b < B; ++b)
         if (timesteps[b] < 0) return fail(AMUSE_EINVAL, "timesteps[%d] = %d is negative", b, timesteps[b]);
     hipStream_t st = (hipStream_t)stream;
+    if (c->arch != AMUSE_ARCH_ENC) {   // the same call on a variant's state ([B][state_dim]); its denoiser pass takes the per-clip timesteps
+        const size_t sd = variant_state_dim(c->arch);
+        if (int e = ensure(&c->fwd_ws, &c->fwd_cap, (size_t)B * (sd + 2))) return e;
+        float* noisy_v = c->fwd_ws;
+        float* sa_v = noisy_v + (size_t)B * sd;
+        float* sb_v = sa_v + B;
+        HIP_TRY(hipMemcpyAsync(sa_v, sqrt_ab, (size_t)B * sizeof(float), hipMemcpyHostToDevice, st));
+        HIP_TRY(hipMemcpyAsync(sb_v, sqrt_1m_ab, (size_t)B * sizeof(float), hipMemcpyHostToDevice, st));
+        HIP_TRY(hipStreamSynchronize(st));  // the host arrays belong to the caller
+        HIP_TRY(launch_add_noise(z0, noise, sa_v, sb_v, noisy_v, B, st, (int)sd));
+        if (int e = variant_denoise(c, noisy_v, timesteps, true, con, emo, sty, nullptr, B, precision, noise_pred_out, nullptr, st)) return e;
+        if (noisy_out) HIP_TRY(hipMemcpyAsync(noisy_out, noisy_v, (size_t)B * sd * sizeof(float), hipMemcpyDeviceToDevice, st));
+        return 0;
+    }
     // per-clip scratch: noisy latents, time tokens, the two coefficient vectors and the timesteps
     if (int e = ensure(&c->fwd_ws, &c->fwd_cap, (size_t)B * (2 * kD + 3))) return e;
     float* noisy = c->fwd_ws;
@@ -1079,6 +789,7 @@ int amuse_diffusion_forward(amuse_ctx* c, const float* z0, const float* noise, c
 int amuse_vae_decode(amuse_ctx* c, const float* z, const int* lengths, int B, int precision, int quat_mode,
                      float* feats_out, float* poses_out, float* trans_out, void* stream) {
     if (!c) return fail(AMUSE_EINVAL, "ctx is NULL");
+    if (!c->has_prior) return fail(AMUSE_ESTATE, "this context was created without MotionPrior weights");
     if (!z) return fail(AMUSE_EINVAL, "z is NULL");
     if (B < 1) return fail(AMUSE_EINVAL, "B must be >= 1, got %d", B);
     precision = prior_precision(precision);
@@ -1153,8 +864,8 @@ int amuse_vae_decode(amuse_ctx* c, const float* z, const int* lengths, int B, in
             ra.stage = stage;
             r8.stage = stage;
             if (rows8) HIP_TRY(launch_vae_rows8x(r8, st));
-            else HIP_TRY(launch_vae_rows(ra, precision, false, st));
-            if (stage < kLayers) HIP_TRY(launch_vae_attn(aa, precision, false, st));
+            else HIP_TRY(launch_vae_rows(ra, precision, VAE_MODE_DEC, st));
+            if (stage < kLayers) HIP_TRY(launch_vae_attn(aa, precision, VAE_MODE_DEC, st));
         }
     }
     return 0;
@@ -1163,6 +874,7 @@ int amuse_vae_decode(amuse_ctx* c, const float* z, const int* lengths, int B, in
 int amuse_vae_encode(amuse_ctx* c, const float* feats, const int* lengths, int B, int precision, const float* eps,
                      float* mu_out, float* std_out, float* latent_out, void* stream) {
     if (!c) return fail(AMUSE_EINVAL, "ctx is NULL");
+    if (!c->has_prior) return fail(AMUSE_ESTATE, "this context was created without MotionPrior weights");
     if (!feats) return fail(AMUSE_EINVAL, "feats is NULL");
     if (!mu_out && !std_out && !latent_out) return fail(AMUSE_EINVAL, "no output requested");
     if (B < 1) return fail(AMUSE_EINVAL, "B must be >= 1, got %d", B);
@@ -1199,8 +911,8 @@ int amuse_vae_encode(amuse_ctx* c, const float* feats, const int* lengths, int B
             ra.stage = stage;
             ra.tiles = stage == kVaeStages - 1 ? 1 : 19;       // only the distribution rows leave the last block
             aa.q_tiles = stage == kLayers - 1 ? 1 : 19;
-            HIP_TRY(launch_vae_rows(ra, precision, true, st));
-            if (stage < kLayers) HIP_TRY(launch_vae_attn(aa, precision, true, st));
+            HIP_TRY(launch_vae_rows(ra, precision, VAE_MODE_ENC, st));
+            if (stage < kLayers) HIP_TRY(launch_vae_attn(aa, precision, VAE_MODE_ENC, st));
         }
         const size_t o = (size_t)b0 * kD;
         HIP_TRY(launch_vae_latent(ra.stats_out, eps ? eps + o : nullptr, mu_out ? mu_out + o : nullptr,
@@ -1224,14 +936,17 @@ int amuse_diffusion_backward(amuse_ctx* c, const float* con, const float* emo, c
                              void* stream) {
     if (!c) return fail(AMUSE_EINVAL, "ctx is NULL");
     if (!poses_out || !trans_out) return fail(AMUSE_EINVAL, "poses_out / trans_out is NULL");
+    if (B < 1) return fail(AMUSE_EINVAL, "B must be >= 1, got %d", B);
     float* lat = latents_out;
     if (!lat) {
         HIP_TRY(hipSetDevice(c->device));
-        if (int e = ensure(&c->lat_tmp, &c->lat_cap, (size_t)B * kD)) return e;
+        if (int e = ensure(&c->lat_tmp, &c->lat_cap, (size_t)B * variant_state_dim(c->arch))) return e;
         lat = c->lat_tmp;
     }
     if (int e = amuse_sample(c, con, emo, sty, B, precision, seed, clip_index0, x_init, step_noise, lat, nullptr, stream))
         return e;
+    // diffusion_only: the sampled state IS the feature sequence - no decode (infer_ldm.py:165), only the conversion of :168-173
+    if (c->arch & 2) return amuse_feats_to_smplx(c, lat, B, quat_mode, poses_out, trans_out, stream);
     return amuse_vae_decode(c, lat, nullptr, B, precision, quat_mode, nullptr, poses_out, trans_out, stream);
 }
 
@@ -1240,7 +955,26 @@ int amuse_counter_normal(amuse_ctx* c, uint64_t seed, uint64_t clip_index0, int 
     if (!c || !out) return fail(AMUSE_EINVAL, "NULL argument");
     if (B < 1) return fail(AMUSE_EINVAL, "B must be >= 1");
     HIP_TRY(hipSetDevice(c->device));
-    HIP_TRY(launch_counter_normal(seed, clip_index0, B, step, rng_stream, out, (hipStream_t)stream));
+    HIP_TRY(launch_counter_normal(seed, clip_index0, B, step, rng_stream, out, (hipStream_t)stream, (int)variant_state_dim(c->arch)));
+    return 0;
+}
+
+int amuse_denoise_step_pose(amuse_ctx* c, const float* x_t, int timestep, const float* con, const float* emo, const float* sty,
+                            const int* lengths, int B, int precision, float* eps_out, void* stream) {
+    if (int e = check_common(c, con, B, precision)) return e;
+    if (!(c->arch & 2)) return fail(AMUSE_ESTATE, "amuse_denoise_step_pose needs a pose-space variant (AMUSE_ARCH_ENC_POSE / _DEC_POSE)");
+    if (!x_t || !eps_out) return fail(AMUSE_EINVAL, "x_t / eps_out is NULL");
+    if (timestep < 0) return fail(AMUSE_EINVAL, "negative timestep");
+    return variant_denoise(c, x_t, &timestep, false, con, emo, sty, lengths, B, precision, eps_out, nullptr, (hipStream_t)stream);
+}
+
+int amuse_feats_to_smplx(amuse_ctx* c, const float* feats, int B, int quat_mode, float* poses_out, float* trans_out, void* stream) {
+    if (!c) return fail(AMUSE_EINVAL, "ctx is NULL");
+    if (!feats || (!poses_out && !trans_out)) return fail(AMUSE_EINVAL, "NULL argument");
+    if (B < 1) return fail(AMUSE_EINVAL, "B must be >= 1, got %d", B);
+    if (quat_mode != AMUSE_QUAT_P3D && quat_mode != AMUSE_QUAT_LEGACY) return fail(AMUSE_EINVAL, "bad quat_mode %d", quat_mode);
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(launch_feats_to_smplx(feats, (size_t)B * kFrames, quat_mode, poses_out, trans_out, (hipStream_t)stream));
     return 0;
 }
 

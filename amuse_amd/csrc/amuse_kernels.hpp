@@ -68,7 +68,40 @@ constexpr int kSample8xLdsBytes = 8 * 8 * 64 * 16 + 8 * 16 * 8 + (2 * 7 * 256 + 
                                   2 * 8 * 64 * 16 + 2 * 128 * 4;   // 134,144 B
 constexpr int kSampleLdsBytes = kSampleCombBytes + kSkipBytes + (9 * kEncPv + 4 * 128 + 2 * 128) * 4;  // 137,216 B
 
+// ---------------------------------------------------------------- Denoiser(arch = "trans_dec"), latent sample (k_sampler_dec.hip)
+// per-layer small parameters of a TransformerDecoderLayer with a multi-token memory: the PV_* layout of amuse_dev.hpp up to
+// PV_BLOCK, then the cross-attention's query bias and out_proj bias (its key / value biases live in the hoisted K / V tables)
+constexpr int PVX_CQ_B = 1920, PVX_CO_B = 2048, PVX_BLOCK = 2176;
+constexpr int PVX_FINAL_W = 9 * PVX_BLOCK, PVX_FINAL_B = PVX_FINAL_W + 128, PVX_TOTAL = PVX_FINAL_B + 128;
+// K / V of the memory tokens [time, con, (emo), (sty)] + mem_pos for every layer, hoisted out of the step loop:
+//   key 0 (time): tkv[step or clip][9][2][128];  keys 1..ncond: ckv[clip][ncond][9][2][128]
+struct MemKV {
+    const float* tkv;
+    size_t tkv_clip_stride;   // floats between clips (per-clip timesteps: diffusion_forward), 0 = one entry for all clips
+    const float* ckv;
+    int ncond;                // 1..3
+};
+struct SampleDecArgs {
+    const uint4* wstream;     // [4 waves][wave_units + kRing][64] x 16 B, head replicated at the tail
+    uint32_t wave_units;
+    const float* pvec;        // PVX_* layout
+    const float* pe0;         // query_pos.pe[0] [128]
+    MemKV mem;                // mem.tkv = the table of step 0; step s reads mem.tkv + s * tkv_step_stride
+    size_t tkv_step_stride;
+    const float* coef; const float* x_init; const float* step_noise;
+    float* latents_out; float* traj_out; float* eps_out; float* tap_out;   // tap_out [11][16][128]: tile 0, step 0
+    uint64_t seed, clip0;
+    int B, T, no_update;
+};
+constexpr int kSampleDecLdsBytes = kSampleCombBytes + PVX_TOTAL * 4;   // combine buffers | all small parameters
+hipError_t launch_sample_dec(const SampleDecArgs& a, int precision, hipStream_t stream);
+
 // ---------------------------------------------------------------- one-off prologue kernels (k_misc.hip)
+// kv[n][l][0 | 1][:] = W{k,v}_l tok[n] + b{k,v}_l for the 9 layers' cross-attention in_proj (cross_attention.py:331-336)
+hipError_t launch_mem_kv(const float* tok, int N, const float* wkv_t /*[9][2][128 in][128 out]*/, const float* bkv /*[9][2][128]*/,
+                         float* kv /*[N][9][2][128]*/, hipStream_t stream);
+// poses / trans of a [B][300][333] feature sequence (infer_ldm.py:168-173)
+hipError_t launch_feats_to_smplx(const float* feats, size_t nrows, int quat_mode, float* poses, float* trans, hipStream_t stream);
 // time_tok[i][:] = Linear2(SiLU(Linear1([cos|sin](t_i * freqs)))) + pe1     (embeddings.py:245-322)
 hipError_t launch_time_tokens(const int* timesteps_dev, int T, const float* freqs, const float* w1t,
                               const float* b1, const float* w2t, const float* b2, const float* pe1,
@@ -78,18 +111,19 @@ struct CondArgs {
     const float* z[3];     // dev [B][256] for the present conditions, in token order
     const float* wt[3];    // transposed weights [256][128] matching z[n]
     const float* bias[3];  // [128]
-    const float* pe;       // query_pos.pe [500][128]
+    const float* pe;       // query_pos.pe [500][128] (mem_pos.pe for the trans_dec variants' memory tokens)
     float* out;            // [B][ncond][128]
     int B, ncond;
+    int pe_base;           // position of the first condition token: 2 behind [latent, time], 1 behind [time] (variants)
 };
 hipError_t launch_cond_tokens(const CondArgs& a, hipStream_t stream);
 // noisy[b] = sa[b] * z0[b] + sb[b] * noise[b]   (DDPMScheduler.add_noise; call site ldm.py:84)
 // kind: 0 = fp32 image, 1 = bf16 image, 2 = split-fp16 image (1 KiB units alternate hi = rn16(w), lo = rn16(w - hi)), 3 = fp16 image
 hipError_t launch_repack(const float* params, const int* map, void* dst, size_t n, int kind, hipStream_t stream);
 hipError_t launch_add_noise(const float* z0, const float* noise, const float* sa, const float* sb, float* out, int B,
-                            hipStream_t stream);
+                            hipStream_t stream, int nfeat = 128);
 hipError_t launch_counter_normal(uint64_t seed, uint64_t clip0, int B, int step, int rng_stream, float* out,
-                                 hipStream_t stream);
+                                 hipStream_t stream, int nfeat = 128);
 
 // ---------------------------------------------------------------- VAE decode (k_vae.hip)
 constexpr int kVaeRing = 16;    // k_vae_rows weight ring; the packed decoder stream is padded by this many units
@@ -119,8 +153,23 @@ struct VaeRowsArgs {
     const float* tok;                 // global_motion_token [2][128]
     const float* emb_bias;            // skel_embedding.bias [128]
     float* stats_out;                 // [B][2][128]: encoder.norm of the distribution rows (mu | logvar)
+    // Denoiser diffusion_only modes (VAE_MODE_DEN_E / _D): one denoising step.  enc_feats = x_t [B][300][333], emb_bias = pose_embd.bias,
+    // final_bias = pose_proj.bias (padded), pe = query_pos.pe, feats_out = eps_hat (nullable)
+    int S;                            // DEN_E: rows per clip = npre + 300
+    int npre;                         // DEN_E: condition tokens in front of the frames (2..4)
+    const float* pre_tok_t;           // DEN_E: time token + pe[0], [128] (pre_tok_t_stride 0) or per clip [B][128]
+    size_t pre_tok_t_stride;
+    const float* pre_tok_c;           // DEN_E: [B][npre - 1][128] condition tokens + pe[1..]
+    MemKV mem;                        // DEN_D: hoisted K / V of the memory tokens (mem.tkv = this step's table)
+    const float* coef;                // dev [8]: this step's scheduler row, or null (teacher-forced step: no update)
+    float* x_out;                     // [B][300][333] or null: x_{t-1} (may alias enc_feats)
+    const float* step_noise;          // [B][300][333] this step's explicit noise, or null -> counter-based
+    uint64_t seed, clip0;
+    int step;
 };
-hipError_t launch_vae_rows(const VaeRowsArgs& a, int precision, bool enc, hipStream_t stream);
+// mode: which network the stages run (k_vae.hip M_*)
+constexpr int VAE_MODE_DEC = 0, VAE_MODE_ENC = 1, VAE_MODE_DEN_E = 2, VAE_MODE_DEN_D = 3;
+hipError_t launch_vae_rows(const VaeRowsArgs& a, int precision, int mode, hipStream_t stream);
 hipError_t launch_vae_rows8x(const VaeRowsArgs& a, hipStream_t stream);   // fp32x decode row stages, eight tiles per workgroup (k_vae_rows8.hip)
 
 struct VaeAttnArgs {
@@ -129,8 +178,9 @@ struct VaeAttnArgs {
     float* o;                                         // [B*300][128]
     int B;
     int q_tiles;                                      // query tiles to produce: 19, or 1 (last encoder block)
+    int S;                                            // VAE_MODE_DEN_E: rows per clip (302..304)
 };
-hipError_t launch_vae_attn(const VaeAttnArgs& a, int precision, bool enc, hipStream_t stream);
+hipError_t launch_vae_attn(const VaeAttnArgs& a, int precision, int mode, hipStream_t stream);
 // ---------------------------------------------------------------- fused decode (k_vae_fused.hip): one workgroup per clip
 constexpr int kVaeFusedStageUnits = 16;   // the weight stream is consumed in 16 KiB stages (LDS-DMA ring of three)
 constexpr int kVaeFusedLdsBytes = 40960 + 3 * 16384 + 2 * 8192 + 5120;   // K/V images of one head | weight ring | block params | ca

@@ -41,16 +41,50 @@ __global__ __launch_bounds__(128) void k_cond_tokens(CondArgs a) {
         float acc = 0.f;
         const float* wt = a.wt[n];
         for (int k = 0; k < kCond; ++k) acc = fmaf(z[k], wt[k * kD + j], acc);
-        a.out[((size_t)b * a.ncond + n) * kD + j] = (acc + a.bias[n][j]) + a.pe[(size_t)(2 + n) * kD + j];
+        a.out[((size_t)b * a.ncond + n) * kD + j] = (acc + a.bias[n][j]) + a.pe[(size_t)(a.pe_base + n) * kD + j];
     }
 }
 
 __global__ __launch_bounds__(64) void k_counter_normal(uint64_t seed, uint64_t clip0, int B, int step, int rng_stream,
-                                                       float* out) {
-    const int idx = blockIdx.x * 64 + threadIdx.x;  // one Philox call per 4 features
-    if (idx >= B * 32) return;
-    const int b = idx >> 5, q = idx & 31;
-    st4(out + (size_t)b * kD + 4 * q, counter_normal4(seed, clip0 + (uint64_t)b, (uint32_t)step, (uint32_t)q, (uint32_t)rng_stream));
+                                                       float* out, int nq) {
+    const size_t idx = (size_t)blockIdx.x * 64 + threadIdx.x;  // one Philox call per 4 features
+    if (idx >= (size_t)B * nq) return;
+    const int b = (int)(idx / nq), q = (int)(idx - (size_t)b * nq);
+    st4(out + ((size_t)b * nq + q) * 4, counter_normal4(seed, clip0 + (uint64_t)b, (uint32_t)step, (uint32_t)q, (uint32_t)rng_stream));
+}
+
+// K / V of the trans_dec variants' memory tokens for all nine layers (cross_attention.py:331-336: key = value = memory; the
+// in_proj rows 128..255 / 256..383 of multihead_attn).  grid = (N, 18), block = 128; weights transposed [l][k|v][in][out].
+__global__ __launch_bounds__(128) void k_mem_kv(const float* __restrict__ tok, const float* __restrict__ wkv_t,
+                                                const float* __restrict__ bkv, float* __restrict__ kv) {
+    __shared__ float ts[kD];
+    const int j = threadIdx.x, n = blockIdx.x, lk = blockIdx.y;
+    ts[j] = tok[(size_t)n * kD + j];
+    __syncthreads();
+    const float* w = wkv_t + (size_t)lk * kD * kD;
+    float acc = 0.f;
+    for (int k = 0; k < kD; ++k) acc = fmaf(ts[k], w[k * kD + j], acc);
+    kv[((size_t)n * 2 * kLayers + lk) * kD + j] = acc + bkv[lk * kD + j];
+}
+
+// infer_ldm.py:168-173 on a feature sequence: one thread per (row, joint) + one per row for the translation
+__global__ __launch_bounds__(256) void k_feats_to_smplx(const float* __restrict__ feats, size_t nrows, int quat_mode,
+                                                        float* __restrict__ poses, float* __restrict__ trans) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= nrows * (kJoints + 1)) return;
+    const size_t row = i / (kJoints + 1);
+    const int jn = (int)(i - row * (kJoints + 1));
+    const float* src = feats + row * kFeats;
+    if (jn == kJoints) {
+        if (trans) { trans[row * 3] = src[330]; trans[row * 3 + 1] = src[331]; trans[row * 3 + 2] = src[332]; }
+        return;
+    }
+    if (!poses) return;
+    float d6[6], aa[3];
+    for (int e = 0; e < 6; ++e) d6[e] = src[6 * jn + e];
+    rot6d_to_axis_angle(d6, quat_mode, aa);
+    float* dst = poses + (row * kJoints + jn) * 3;
+    dst[0] = aa[0]; dst[1] = aa[1]; dst[2] = aa[2];
 }
 
 // cross-attention onto a one-token memory: softmax over a single key == 1, so the layer adds
@@ -108,10 +142,12 @@ __global__ __launch_bounds__(256) void k_smplx_to_feats(const float* __restrict_
 
 // DDPMScheduler.add_noise (diffusers 0.17.1; call site ldm.py:84): per-clip coefficients from the host table
 __global__ __launch_bounds__(128) void k_add_noise(const float* __restrict__ z0, const float* __restrict__ noise,
-                                                   const float* __restrict__ sa, const float* __restrict__ sb, float* out) {
+                                                   const float* __restrict__ sa, const float* __restrict__ sb, float* out, int nfeat) {
 #pragma clang fp contract(off)
-    const size_t i = (size_t)blockIdx.x * kD + threadIdx.x;
-    out[i] = sa[blockIdx.x] * z0[i] + sb[blockIdx.x] * noise[i];
+    for (int f = threadIdx.x; f < nfeat; f += 128) {
+        const size_t i = (size_t)blockIdx.x * nfeat + f;
+        out[i] = sa[blockIdx.x] * z0[i] + sb[blockIdx.x] * noise[i];
+    }
 }
 
 // MotionPrior.encode tail (vae.py:203-213): mu = dist[0], logvar = dist[1]; std = logvar.exp().pow(0.5);
@@ -141,9 +177,21 @@ hipError_t launch_cond_tokens(const CondArgs& a, hipStream_t stream) {
 }
 
 hipError_t launch_counter_normal(uint64_t seed, uint64_t clip0, int B, int step, int rng_stream, float* out,
-                                 hipStream_t stream) {
-    hipLaunchKernelGGL(k_counter_normal, dim3((B * 32 + 63) / 64), dim3(64), 0, stream, seed, clip0, B, step,
-                       rng_stream, out);
+                                 hipStream_t stream, int nfeat) {
+    const int nq = nfeat / 4;
+    hipLaunchKernelGGL(k_counter_normal, dim3((unsigned)(((size_t)B * nq + 63) / 64)), dim3(64), 0, stream, seed, clip0, B, step,
+                       rng_stream, out, nq);
+    return hipGetLastError();
+}
+
+hipError_t launch_mem_kv(const float* tok, int N, const float* wkv_t, const float* bkv, float* kv, hipStream_t stream) {
+    hipLaunchKernelGGL(k_mem_kv, dim3(N, 2 * kLayers), dim3(128), 0, stream, tok, wkv_t, bkv, kv);
+    return hipGetLastError();
+}
+
+hipError_t launch_feats_to_smplx(const float* feats, size_t nrows, int quat_mode, float* poses, float* trans, hipStream_t stream) {
+    const size_t n = nrows * (kJoints + 1);
+    hipLaunchKernelGGL(k_feats_to_smplx, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, feats, nrows, quat_mode, poses, trans);
     return hipGetLastError();
 }
 
@@ -187,8 +235,8 @@ hipError_t launch_repack(const float* params, const int* map, void* dst, size_t 
 }
 
 hipError_t launch_add_noise(const float* z0, const float* noise, const float* sa, const float* sb, float* out, int B,
-                            hipStream_t stream) {
-    hipLaunchKernelGGL(k_add_noise, dim3(B), dim3(128), 0, stream, z0, noise, sa, sb, out);
+                            hipStream_t stream, int nfeat) {
+    hipLaunchKernelGGL(k_add_noise, dim3(B), dim3(128), 0, stream, z0, noise, sa, sb, out, nfeat);
     return hipGetLastError();
 }
 

@@ -29,12 +29,26 @@ constexpr int kRowsLdsBytes = kCombBytes;
 static_assert(16 * kFeatStride * 4 <= kCombBytes, "staged feature tile must fit the combine buffers");
 constexpr int kVR = kVaeRing;       // weight-stream ring depth of k_vae_rows
 
-// ENC = false: MotionPrior.decode rows (S = 300).  ENC = true: MotionPrior.encode rows (vae.py:154-214): S = 302 =
+// MODE M_DEC: MotionPrior.decode rows (S = 300).  M_ENC: MotionPrior.encode rows (vae.py:154-214): S = 302 =
 // [2 distribution tokens | 300 embedded frames], TransformerEncoderLayer blocks (no cross-attention, two norms),
 // stage 0 = skel_embedding + token concat + PE, last stage = encoder.norm of the two distribution rows only.
-template <int PREC, bool ENC>
+// M_DEN_E / M_DEN_D: ONE STEP of the Denoiser's diffusion_only variants (denoiser.py:64-66,174-204) on the same stages -
+//   M_DEN_E (arch "trans_enc"): S = npre + 300 rows = [time, con, (emo), (sty) | pose_embd(x_t frames)] + query_pos, the M_ENC
+//     stack (skip encoder, two norms per block) WITHOUT a key mask (denoiser.py:182 passes none);
+//   M_DEN_D (arch "trans_dec"): S = 300 rows = pose_embd(x_t) + query_pos, nine plain TransformerDecoderLayer.forward_post blocks
+//     (no skips): self-attention, cross-attention of every row onto the clip's 2..4 memory tokens (K / V hoisted: MemKV), FFN;
+//   last stage = final norm + pose_proj (128 -> 333) + `sample[~mask.T] = 0` + (optionally) the scheduler update of x_t.
+constexpr int M_DEC = 0, M_ENC = 1, M_DEN_E = 2, M_DEN_D = 3;
+constexpr bool mode_den(int m) { return m == M_DEN_E || m == M_DEN_D; }
+constexpr bool mode_enc_layers(int m) { return m == M_ENC || m == M_DEN_E; }   // two norms per block, no cross-attention
+
+template <int PREC, int MODE>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_vae_rows(VaeRowsArgs a) {
-    constexpr int S = ENC ? kFrames + 2 : kFrames;
+    constexpr bool ENC = MODE == M_ENC;
+    constexpr bool DEN = mode_den(MODE);
+    constexpr bool EMB = ENC || DEN;               // stage 0 embeds 333 input features
+    constexpr bool ENCL = mode_enc_layers(MODE);
+    const int S = MODE == M_DEN_E ? a.S : (ENC ? kFrames + 2 : kFrames);
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* comb = smem;
     float* fst = reinterpret_cast<float*>(smem);  // [16][kFeatStride] staged feats (last stage)
@@ -54,18 +68,22 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     ring_fill(rg, w);
     constexpr int U_O = gemm_units(PREC, kTiles, 2), U_F = gemm_units(PREC, kTiles, kTiles);
     constexpr int U_S = gemm_units(PREC, kTiles, 4);
-    constexpr int P_O = 0, P_F1 = U_O % kVR, P_F2 = (P_F1 + U_F) % kVR, P_S = (P_F2 + U_F) % kVR;
+    constexpr int U_P = gemm_units(PREC, 2, kTiles);   // M_DEN_D: the cross-attention's q of one head
+    constexpr int P_O = 0, P_CQ = U_O % kVR, P_CO = (P_CQ + U_P) % kVR;
+    constexpr int P_F1 = MODE == M_DEN_D ? (P_CO + U_O) % kVR : U_O % kVR, P_F2 = (P_F1 + U_F) % kVR, P_S = (P_F2 + U_F) % kVR;
     constexpr int P_Q0 = P_S, P_Q1 = (P_S + U_S) % kVR;   // in_proj / final phase without / with a skip linear before
     bool skipped = false;
     constexpr bool FAST = is_op16(PREC);
     f32x4 x[kTiles];
 
     constexpr int kEmbK = 22;  // 333 input features padded to 22 k-tiles (zero weights / zero operands beyond 333)
-    constexpr int P_E = ENC ? gemm_units(PREC, 2, kEmbK) % kVR : 0;  // in_proj phase of stage 0
+    constexpr int P_E = EMB ? gemm_units(PREC, 2, kEmbK) % kVR : 0;  // in_proj phase of stage 0
+    const int npre = ENC ? 2 : (MODE == M_DEN_E ? a.npre : 0);   // rows in front of the 300 frames
     if (a.stage == 0) {
-        if constexpr (ENC) {
+        if constexpr (EMB) {
             // xseq = cat(global_motion_token, skel_embedding(features)) + query_pos_encoder.pe[:302]  (vae.py:171-188)
-            const int fi = frame - 2;
+            // Denoiser: cat(emb_latent, pose_embd(sample)) + query_pos (denoiser.py:178-181) / pose_embd(sample) + query_pos (:192-193)
+            const int fi = frame - npre;
             const bool fvalid = rvalid && fi >= 0;
             const float* src = a.enc_feats + ((size_t)b * kFrames + (fvalid ? fi : 0)) * kFeats;
             f32x4 xin[kEmbK];
@@ -83,11 +101,21 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             for (int t = 0; t < kTiles; ++t) part[t] = (t >> 1) == wave ? acc[t & 1] : splat4(0.f);
             // all-gather of the four waves' tile pairs (+ skel_embedding.bias)
             combine_rs<false, FAST>(part, x, false, a.emb_bias, nullptr, nullptr, comb, wave, lane);
+            if constexpr (DEN) {   // the condition tokens arrive with their positions added (k_time_tokens / k_cond_tokens)
+                const float* pt = frame == 0 ? a.pre_tok_t + (size_t)b * a.pre_tok_t_stride
+                                             : a.pre_tok_c + ((size_t)b * (npre - 1) + (frame - 1)) * kD;
+#pragma unroll
+                for (int t = 0; t < kTiles; ++t) {
+                    const int c = 16 * t + 4 * g;
+                    x[t] = fvalid ? x[t] + ld4(a.pe + (size_t)frame * kD + c) : (rvalid ? ld4(pt + c) : splat4(0.f));
+                }
+            } else {
 #pragma unroll
             for (int t = 0; t < kTiles; ++t) {
                 const int c = 16 * t + 4 * g;
                 const f32x4 e = fvalid ? x[t] : ld4(a.tok + (frame & 1) * kD + c);
                 x[t] = rvalid ? e + ld4(a.pe + (size_t)frame * kD + c) : splat4(0.f);
+            }
             }
         } else {  // queries = zeros + query_pos_decoder.pe[:300]  (vae.py:220,258)
 #pragma unroll
@@ -96,7 +124,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         }
     } else {
         const int blk = a.stage - 1;
-        const float* pv = a.pvec + blk * PV_BLOCK;
+        const float* pv = a.pvec + blk * (MODE == M_DEN_D ? PVX_BLOCK : PV_BLOCK);
         f32x4 o[2];
 #pragma unroll
         for (int t = 0; t < kTiles; ++t) x[t] = rvalid ? ld4(a.x + row * kD + 16 * t + 4 * g) : splat4(0.f);
@@ -119,7 +147,61 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         for (int t = 0; t < kTiles; ++t) part[t] = splat4(0.f);
         gemm_ring<PREC, kTiles, 2, false, kVR, P_O>(part, o, rg);
         combine_rs<true, FAST>(part, x, true, pv + PV_OUT_B, pv + PV_LN1_W, pv + PV_LN1_B, comb, wave, lane);
-        if constexpr (!ENC) {
+        if constexpr (MODE == M_DEN_D) {
+            // cross-attention of the tile's rows onto the clip's 2..4 memory tokens (cross_attention.py:337-343): q of head
+            // `wave` (two output tiles, full K), the scores on the VALU (a lane holds 8 of its row's 32 head features), out_proj
+            // split-K over the heads, residual + norm2 - the scheme of k_sampler_dec.hip, K / V from the same hoisted tables
+            const int nmem = 1 + a.mem.ncond;
+            f32x4 mk[4][2], mv[4][2];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if (j < nmem) {
+                    const float* base = j == 0 ? a.mem.tkv + (size_t)b * a.mem.tkv_clip_stride + (size_t)blk * 2 * kD
+                                               : a.mem.ckv + (((size_t)b * a.mem.ncond + (j - 1)) * kLayers + blk) * 2 * kD;
+#pragma unroll
+                    for (int oo = 0; oo < 2; ++oo) {
+                        mk[j][oo] = ld4(base + 32 * wave + 16 * oo + 4 * g);
+                        mv[j][oo] = ld4(base + kD + 32 * wave + 16 * oo + 4 * g);
+                    }
+                } else {
+                    mk[j][0] = mk[j][1] = mv[j][0] = mv[j][1] = splat4(0.f);
+                }
+            }
+            f32x4 q2[2] = {splat4(0.f), splat4(0.f)};
+            gemm_ring<PREC, 2, kTiles, false, kVR, P_CQ>(q2, x, rg);
+#pragma unroll
+            for (int oo = 0; oo < 2; ++oo) q2[oo] = (q2[oo] + ld4(pv + PVX_CQ_B + 16 * (2 * wave + oo) + 4 * g)) * 0.17677669529663687f;
+            float sc[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float d = 0.f;
+#pragma unroll
+                for (int oo = 0; oo < 2; ++oo)
+#pragma unroll
+                    for (int m = 0; m < 4; ++m) d = fmaf(q2[oo][m], mk[j][oo][m], d);
+                sc[j] = allreduce_g_sum(d);
+            }
+            float mx = sc[0];
+#pragma unroll
+            for (int j = 1; j < 4; ++j) mx = j < nmem ? fmaxf(mx, sc[j]) : mx;
+            float pj[4], psum = 0.f;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                pj[j] = j < nmem ? (FAST ? __builtin_amdgcn_exp2f(1.44269504088896340736f * (sc[j] - mx)) : expf(sc[j] - mx)) : 0.f;
+                psum += pj[j];
+            }
+            f32x4 a2[2] = {splat4(0.f), splat4(0.f)};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float w = pj[j] / psum;
+#pragma unroll
+                for (int oo = 0; oo < 2; ++oo) a2[oo] += mv[j][oo] * w;
+            }
+#pragma unroll
+            for (int t = 0; t < kTiles; ++t) part[t] = splat4(0.f);
+            gemm_ring<PREC, kTiles, 2, false, kVR, P_CO>(part, a2, rg);
+            combine_rs<true, FAST>(part, x, true, pv + PVX_CO_B, pv + PV_LN2_W, pv + PV_LN2_B, comb, wave, lane);
+        } else if constexpr (MODE == M_DEC) {
             // cross-attention onto the single latent token == per-clip constant; residual + norm2
             const float* ca = a.ca + ((size_t)b * kLayers + blk) * kD;
 #pragma unroll
@@ -145,14 +227,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
         for (int t = 0; t < kTiles; ++t) part[t] = splat4(0.f);
         gemm_ring<PREC, kTiles, kTiles, false, kVR, P_F2>(part, hid, rg);
-        combine_rs<true, FAST>(part, x, true, pv + PV_L2_B, pv + (ENC ? PV_LN2_W : PV_LN3_W), pv + (ENC ? PV_LN2_B : PV_LN3_B),
+        combine_rs<true, FAST>(part, x, true, pv + PV_L2_B, pv + (ENCL ? PV_LN2_W : PV_LN3_W), pv + (ENCL ? PV_LN2_B : PV_LN3_B),
                                comb, wave, lane);
-        if (blk < 4 && wave == 0 && rvalid) {  // xs.append(x)
+        if (MODE != M_DEN_D && blk < 4 && wave == 0 && rvalid) {  // xs.append(x)
             float* sk = a.skip + ((size_t)blk * nrows + row) * kD;
 #pragma unroll
             for (int t = 0; t < kTiles; ++t) st4(sk + 16 * t + 4 * g, x[t]);
         }
-        if (blk >= 4 && blk <= 7) {  // x = linear_blocks[blk-4](cat(x, xs.pop())) ahead of output block blk+1
+        if (MODE != M_DEN_D && blk >= 4 && blk <= 7) {  // x = linear_blocks[blk-4](cat(x, xs.pop())) ahead of output block blk+1
             const float* sk = a.skip + ((size_t)(7 - blk) * nrows + row) * kD;
             f32x4 src[4];
 #pragma unroll
@@ -174,7 +256,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
             for (int t = 0; t < kTiles; ++t) st4(a.x + row * kD + 16 * t + 4 * g, x[t]);
         }
-        const float* pv = a.pvec + a.stage * PV_BLOCK;
+        const float* pv = a.pvec + a.stage * (MODE == M_DEN_D ? PVX_BLOCK : PV_BLOCK);
         f32x4 qkv[6];
 #pragma unroll
         for (int o = 0; o < 2; ++o) {
@@ -211,13 +293,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         }
     } else {
         // decoder.norm -> final_layer (333 outputs padded to 24 tiles, 6 per wave) -> rotation epilogue
-        layer_norm_rows<is_op16(PREC)>(x, a.pvec + PV_FINAL_W, a.pvec + PV_FINAL_B, g);
+        // (Denoiser: encoder.norm / decoder.norm -> pose_proj -> mask -> eps_hat / scheduler update)
+        layer_norm_rows<is_op16(PREC)>(x, a.pvec + (MODE == M_DEN_D ? PVX_FINAL_W : PV_FINAL_W), a.pvec + (MODE == M_DEN_D ? PVX_FINAL_B : PV_FINAL_B), g);
         f32x4 f[6];
 #pragma unroll
         for (int o = 0; o < 6; ++o) f[o] = ld4(a.final_bias + 16 * (6 * wave + o) + 4 * g);
         gemm_ring<PREC, 6, kTiles, false, kVR, P_Q0>(f, x, rg);
-        const int len = a.lengths ? a.lengths[b] : S;
-        const bool keep = rvalid && frame < len;  // output[~mask.T] = 0 (vae.py:274)
+        const int len = a.lengths ? a.lengths[b] + npre : S;
+        const bool keep = rvalid && frame < len;  // output[~mask.T] = 0 (vae.py:274; denoiser.py:187,199)
 #pragma unroll
         for (int o = 0; o < 6; ++o)
             st4(fst + r * kFeatStride + 16 * (6 * wave + o) + 4 * g, keep ? f[o] : splat4(0.f));
@@ -225,6 +308,41 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         const int tid = threadIdx.x;
         const int rows_here = min(16, S - rt * 16);
         const size_t row0 = (size_t)b * S + rt * 16;
+        if constexpr (DEN) {
+            // eps_hat of the frame rows; then scheduler.step on x_t (amuse_hip.h amuse_schedule; k_sampler.hip's update), element by
+            // element, each read and written by the same thread (x_out may alias x_t)
+            const float* cf = a.coef;
+            const float sb = cf ? cf[0] : 0.f, sa = cf ? cf[1] : 1.f, c0 = cf ? cf[2] : 0.f, cx = cf ? cf[3] : 0.f, ce = cf ? cf[4] : 0.f,
+                        sg = cf ? cf[5] : 0.f, clipv = cf ? cf[6] : 0.f;
+            constexpr bool FASTU = is_op16(PREC);
+            const float inv_sa = 1.0f / sa;
+            for (int i = tid; i < rows_here * kFeats; i += 256) {
+                const int rr = i / kFeats, c = i - rr * kFeats;
+                const int fr = rt * 16 + rr - npre;
+                if (fr < 0) continue;
+                const float e = fst[rr * kFeatStride + c];
+                const size_t idx = ((size_t)b * kFrames + fr) * kFeats + c;
+                if (a.feats_out) a.feats_out[idx] = e;
+                if (a.x_out) {
+#pragma clang fp contract(off)
+                    const float xl = a.enc_feats[idx];
+                    const float num = __fsub_rn(xl, __fmul_rn(sb, e));
+                    float x0 = FASTU ? num * inv_sa : __fdiv_rn(num, sa);
+                    if (clipv > 0.f) x0 = fminf(fmaxf(x0, -clipv), clipv);
+                    float nx = __fmul_rn(c0, x0);
+                    if (cx != 0.f) nx = __fadd_rn(nx, __fmul_rn(cx, xl));
+                    if (ce != 0.f) nx = __fadd_rn(nx, __fmul_rn(ce, e));
+                    if (sg != 0.f) {
+                        const size_t el = (size_t)fr * kFeats + c;   // element of the clip's state: draw el % 4 of counter el / 4
+                        const float z = a.step_noise ? a.step_noise[idx]
+                                                     : counter_normal4(a.seed, a.clip0 + (uint64_t)b, (uint32_t)a.step, (uint32_t)(el >> 2), 1u)[el & 3];
+                        nx = __fadd_rn(nx, __fmul_rn(sg, z));
+                    }
+                    a.x_out[idx] = nx;
+                }
+            }
+            return;
+        }
         if (a.feats_out) {
             for (int i = tid; i < rows_here * kFeats; i += 256) {
                 const int rr = i / kFeats, c = i - rr * kFeats;
@@ -254,9 +372,10 @@ constexpr int kKS = 36;              // padded LDS row stride (floats) of the K_
 constexpr int kKeyRows = 320;        // 300 keys padded to 20 tiles (zero rows, masked)
 constexpr int kAttnLdsBytes = 2 * kKeyRows * kKS * 4;
 
-template <int PREC, bool ENC>
+template <int PREC, int MODE>
 __global__ __launch_bounds__(256) void k_vae_attn(VaeAttnArgs a) {
-    constexpr int S = ENC ? kFrames + 2 : kFrames;  // encode: keys 0,1 = distribution tokens, always valid (vae.py:176-181)
+    constexpr bool ENC = MODE == M_ENC;
+    const int S = MODE == M_DEN_E ? a.S : (ENC ? kFrames + 2 : kFrames);  // encode: keys 0,1 = distribution tokens, always valid (vae.py:176-181)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* Ks = reinterpret_cast<float*>(smem);
     float* Vs = Ks + kKeyRows * kKS;
@@ -264,7 +383,7 @@ __global__ __launch_bounds__(256) void k_vae_attn(VaeAttnArgs a) {
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int g = lane >> 4, r = lane & 15;
     const int bh = blockIdx.x, b = bh / kHeads, h = bh - b * kHeads;
-    const int len = a.lengths ? a.lengths[b] + (ENC ? 2 : 0) : S;
+    const int len = (a.lengths && !mode_den(MODE)) ? a.lengths[b] + (ENC ? 2 : 0) : S;   // (the Denoiser variants pass no key mask)
     const float* qg = a.q + (size_t)bh * S * 32;
     const float* kg = a.k + (size_t)bh * S * 32;
     const float* vg = a.v + (size_t)bh * S * 32;
@@ -395,9 +514,9 @@ constexpr int kAttnBf16LdsBytes = kKeyRows * 64 + kPairs * 2 * 16 * 64;  // 20 K
 #endif
 constexpr int kAttnSplitMaxClips = AMUSE_ATTN_SPLIT_MAX;   // up to this many clips per launch a (clip, head) pair is five workgroups (below)
 
-template <int P16, int NQ, int S>   // P16 = PREC_BF16 / PREC_F16: the operand format of q, k, v, p and the output
+template <int P16, int NQ>   // P16 = PREC_BF16 / PREC_F16: the operand format of q, k, v, p and the output
 __device__ __forceinline__ void attn_qtiles_bf16(const uint4* Kb, const uint4* Vt, const unsigned short* qg,
-                                                 unsigned short* og, int qt0, int len, int g, int r) {
+                                                 unsigned short* og, int qt0, int len, int g, int r, const int S) {
     constexpr float kLog2e = 1.44269504088896340736f;
     typedef Op16<P16> Op;
     typedef typename Op::vec OPV;
@@ -470,9 +589,10 @@ __device__ __forceinline__ void attn_qtiles_bf16(const uint4* Kb, const uint4* V
     }
 }
 
-template <int P16, bool ENC>
+template <int P16, int MODE>
 __global__ __launch_bounds__(256) void k_vae_attn_bf16(VaeAttnArgs a) {
-    constexpr int S = ENC ? kFrames + 2 : kFrames;
+    constexpr bool ENC = MODE == M_ENC;
+    const int S = MODE == M_DEN_E ? a.S : (ENC ? kFrames + 2 : kFrames);
     extern __shared__ __attribute__((aligned(16))) char smem[];
     uint4* Kb = reinterpret_cast<uint4*>(smem);
     uint4* Vt = Kb + kKeyRows * 4;
@@ -480,7 +600,7 @@ __global__ __launch_bounds__(256) void k_vae_attn_bf16(VaeAttnArgs a) {
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int g = lane >> 4, r = lane & 15;
     const int bh = blockIdx.x, b = bh / kHeads, h = bh - b * kHeads;
-    const int len = a.lengths ? a.lengths[b] + (ENC ? 2 : 0) : S;
+    const int len = (a.lengths && !mode_den(MODE)) ? a.lengths[b] + (ENC ? 2 : 0) : S;
     // q, k, v are 16-bit here ([B * heads][S][32], written by k_vae_rows<P16> in its operand format), as is the output
     const unsigned short* qg = reinterpret_cast<const unsigned short*>(a.q) + (size_t)bh * S * 32;
     const unsigned short* kg = reinterpret_cast<const unsigned short*>(a.k) + (size_t)bh * S * 32;
@@ -508,7 +628,7 @@ __global__ __launch_bounds__(256) void k_vae_attn_bf16(VaeAttnArgs a) {
     unsigned short* og = reinterpret_cast<unsigned short*>(a.o) + (size_t)b * S * kD + 32 * h;
     // 19 query tiles: wave w owns tiles w, w+4, w+8, w+12 (two pairs) and w+16 (waves 0..2)
     if (a.q_tiles == 1) {  // last encoder block: only the distribution rows (tile 0) are consumed downstream
-        if (wave == 0 && blockIdx.y == 0) attn_qtiles_bf16<P16, 1, S>(Kb, Vt, qg, og, 0, len, g, r);
+        if (wave == 0 && blockIdx.y == 0) attn_qtiles_bf16<P16, 1>(Kb, Vt, qg, og, 0, len, g, r, S);
         return;
     }
     // Few clips (launch_vae_attn: gridDim.y = 5): a (clip, head) pair is FIVE workgroups, each with the whole K / V image and four
@@ -516,12 +636,12 @@ __global__ __launch_bounds__(256) void k_vae_attn_bf16(VaeAttnArgs a) {
     // where the nine attention launches are 60 % of the decode.  Which workgroup computes a query tile does not change its bits.
     if (gridDim.y > 1) {
         const int qt = 4 * blockIdx.y + wave;
-        if (qt < kRowTiles) attn_qtiles_bf16<P16, 1, S>(Kb, Vt, qg, og, qt, len, g, r);
+        if (qt < kRowTiles) attn_qtiles_bf16<P16, 1>(Kb, Vt, qg, og, qt, len, g, r, S);
         return;
     }
-    attn_qtiles_bf16<P16, 2, S>(Kb, Vt, qg, og, wave, len, g, r);
-    attn_qtiles_bf16<P16, 2, S>(Kb, Vt, qg, og, wave + 8, len, g, r);
-    if (wave + 16 < kRowTiles) attn_qtiles_bf16<P16, 1, S>(Kb, Vt, qg, og, wave + 16, len, g, r);
+    attn_qtiles_bf16<P16, 2>(Kb, Vt, qg, og, wave, len, g, r, S);
+    attn_qtiles_bf16<P16, 2>(Kb, Vt, qg, og, wave + 8, len, g, r, S);
+    if (wave + 16 < kRowTiles) attn_qtiles_bf16<P16, 1>(Kb, Vt, qg, og, wave + 16, len, g, r, S);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -533,9 +653,9 @@ __global__ __launch_bounds__(256) void k_vae_attn_bf16(VaeAttnArgs a) {
 // q, k, v and the output are fp32 in HBM, as in the fp32 mode.
 constexpr int kAttnXLdsBytes = 2 * (kKeyRows * 64 + kPairs * 2 * 16 * 64);   // hi + lo images of K and V^T: 80 KiB
 
-template <int NQ, int S>
+template <int NQ>
 __device__ __forceinline__ void attn_qtiles_x(const uint4* Kh, const uint4* Kl, const uint4* Vh, const uint4* Vl, const float* qg,
-                                              float* og, int qt0, int len, int g, int r) {
+                                              float* og, int qt0, int len, int g, int r, const int S) {
     constexpr float kLog2e = 1.44269504088896340736f;
     F16Pair qs[NQ];
     float m_run[NQ], l_run[NQ];
@@ -617,9 +737,10 @@ __device__ __forceinline__ void attn_qtiles_x(const uint4* Kh, const uint4* Kl, 
 
 // NW = 4 or 8 waves per workgroup.  The 80 KiB of fragment images leave room for one workgroup (two at best) per CU, so with four waves the
 // CU runs the attention on 4-8 waves; eight waves share one image and halve a workgroup's time (launch_vae_attn picks NW by the grid).
-template <bool ENC, int NW>
+template <int MODE, int NW>
 __global__ __launch_bounds__(64 * NW) void k_vae_attn_x(VaeAttnArgs a) {
-    constexpr int S = ENC ? kFrames + 2 : kFrames;
+    constexpr bool ENC = MODE == M_ENC;
+    const int S = MODE == M_DEN_E ? a.S : (ENC ? kFrames + 2 : kFrames);
     extern __shared__ __attribute__((aligned(16))) char smem[];
     uint4* Kh = reinterpret_cast<uint4*>(smem);
     uint4* Kl = Kh + kKeyRows * 4;
@@ -629,7 +750,7 @@ __global__ __launch_bounds__(64 * NW) void k_vae_attn_x(VaeAttnArgs a) {
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int g = lane >> 4, r = lane & 15;
     const int bh = blockIdx.x, b = bh / kHeads, h = bh - b * kHeads;
-    const int len = a.lengths ? a.lengths[b] + (ENC ? 2 : 0) : S;
+    const int len = (a.lengths && !mode_den(MODE)) ? a.lengths[b] + (ENC ? 2 : 0) : S;
     const float* qg = a.q + (size_t)bh * S * 32;
     const float* kg = a.k + (size_t)bh * S * 32;
     const float* vg = a.v + (size_t)bh * S * 32;
@@ -657,21 +778,21 @@ __global__ __launch_bounds__(64 * NW) void k_vae_attn_x(VaeAttnArgs a) {
     __syncthreads();
     float* og = a.o + (size_t)b * S * kD + 32 * h;
     if (a.q_tiles == 1) {  // last encoder block: only the distribution rows (tile 0) are consumed downstream
-        if (wave == 0 && blockIdx.y == 0) attn_qtiles_x<1, S>(Kh, Kl, Vh, Vl, qg, og, 0, len, g, r);
+        if (wave == 0 && blockIdx.y == 0) attn_qtiles_x<1>(Kh, Kl, Vh, Vl, qg, og, 0, len, g, r, S);
         return;
     }
     if (gridDim.y > 1) {   // few clips: five workgroups per (clip, head), one query tile per wave (as in k_vae_attn_bf16)
         const int qt = 4 * blockIdx.y + wave;
-        if (wave < 4 && qt < kRowTiles) attn_qtiles_x<1, S>(Kh, Kl, Vh, Vl, qg, og, qt, len, g, r);
+        if (wave < 4 && qt < kRowTiles) attn_qtiles_x<1>(Kh, Kl, Vh, Vl, qg, og, qt, len, g, r, S);
         return;
     }
     if constexpr (NW == 8) {   // waves 0..3: tile pairs (w, w + 4); waves 4..7: (w + 4, w + 8); tiles 16..18: waves 0..2
-        attn_qtiles_x<2, S>(Kh, Kl, Vh, Vl, qg, og, wave < 4 ? wave : wave + 4, len, g, r);
-        if (wave + 16 < kRowTiles) attn_qtiles_x<1, S>(Kh, Kl, Vh, Vl, qg, og, wave + 16, len, g, r);
+        attn_qtiles_x<2>(Kh, Kl, Vh, Vl, qg, og, wave < 4 ? wave : wave + 4, len, g, r, S);
+        if (wave + 16 < kRowTiles) attn_qtiles_x<1>(Kh, Kl, Vh, Vl, qg, og, wave + 16, len, g, r, S);
     } else {
-        attn_qtiles_x<2, S>(Kh, Kl, Vh, Vl, qg, og, wave, len, g, r);
-        attn_qtiles_x<2, S>(Kh, Kl, Vh, Vl, qg, og, wave + 8, len, g, r);
-        if (wave + 16 < kRowTiles) attn_qtiles_x<1, S>(Kh, Kl, Vh, Vl, qg, og, wave + 16, len, g, r);
+        attn_qtiles_x<2>(Kh, Kl, Vh, Vl, qg, og, wave, len, g, r, S);
+        attn_qtiles_x<2>(Kh, Kl, Vh, Vl, qg, og, wave + 8, len, g, r, S);
+        if (wave + 16 < kRowTiles) attn_qtiles_x<1>(Kh, Kl, Vh, Vl, qg, og, wave + 16, len, g, r, S);
     }
 }
 
@@ -682,89 +803,102 @@ hipError_t set_lds(K kern, int bytes) {
 
 }  // namespace
 
-hipError_t launch_vae_rows(const VaeRowsArgs& a, int precision, bool enc, hipStream_t stream) {
-    static DeviceOnce once;
-    int dev_;
-    if (!once.done(&dev_)) {
-        hipError_t e = set_lds(&k_vae_rows<PREC_F32, false>, kRowsLdsBytes);
-        if (e == hipSuccess) e = set_lds(&k_vae_rows<PREC_F16X2, false>, kRowsLdsBytes);
-        if (e == hipSuccess) e = set_lds(&k_vae_rows<PREC_F16X2, true>, kRowsLdsBytes);
-        if (e == hipSuccess) e = set_lds(&k_vae_rows<PREC_BF16, false>, kRowsLdsBytes);
-        if (e == hipSuccess) e = set_lds(&k_vae_rows<PREC_F32, true>, kRowsLdsBytes);
-        if (e == hipSuccess) e = set_lds(&k_vae_rows<PREC_BF16, true>, kRowsLdsBytes);
-        if (e == hipSuccess) e = set_lds(&k_vae_rows<PREC_F16, false>, kRowsLdsBytes);
-        if (e == hipSuccess) e = set_lds(&k_vae_rows<PREC_F16, true>, kRowsLdsBytes);
-        if (e != hipSuccess) return e;
-        once.set(dev_);
+namespace {
+template <int PREC, int MODE>
+hipError_t rows_one(const VaeRowsArgs& a, hipStream_t stream, bool setup) {
+    if (setup) return set_lds(&k_vae_rows<PREC, MODE>, kRowsLdsBytes);
+    hipLaunchKernelGGL((k_vae_rows<PREC, MODE>), dim3(a.B * a.tiles), dim3(256), kRowsLdsBytes, stream, a);
+    return hipSuccess;
+}
+template <int MODE>
+hipError_t rows_prec(const VaeRowsArgs& a, int precision, hipStream_t stream, bool setup) {
+    if (setup) {
+        hipError_t e = rows_one<PREC_F32, MODE>(a, stream, true);
+        if (e == hipSuccess) e = rows_one<PREC_BF16, MODE>(a, stream, true);
+        if (e == hipSuccess) e = rows_one<PREC_F16X2, MODE>(a, stream, true);
+        if (e == hipSuccess) e = rows_one<PREC_F16, MODE>(a, stream, true);
+        return e;
     }
-    const dim3 grid(a.B * a.tiles), block(256);
-    if (precision == PREC_F32) {
-        if (enc) hipLaunchKernelGGL((k_vae_rows<PREC_F32, true>), grid, block, kRowsLdsBytes, stream, a);
-        else hipLaunchKernelGGL((k_vae_rows<PREC_F32, false>), grid, block, kRowsLdsBytes, stream, a);
-    } else if (precision == PREC_F16X2) {
-        if (enc) hipLaunchKernelGGL((k_vae_rows<PREC_F16X2, true>), grid, block, kRowsLdsBytes, stream, a);
-        else hipLaunchKernelGGL((k_vae_rows<PREC_F16X2, false>), grid, block, kRowsLdsBytes, stream, a);
-    } else if (precision == PREC_F16) {
-        if (enc) hipLaunchKernelGGL((k_vae_rows<PREC_F16, true>), grid, block, kRowsLdsBytes, stream, a);
-        else hipLaunchKernelGGL((k_vae_rows<PREC_F16, false>), grid, block, kRowsLdsBytes, stream, a);
-    } else {
-        if (enc) hipLaunchKernelGGL((k_vae_rows<PREC_BF16, true>), grid, block, kRowsLdsBytes, stream, a);
-        else hipLaunchKernelGGL((k_vae_rows<PREC_BF16, false>), grid, block, kRowsLdsBytes, stream, a);
-    }
-    return hipGetLastError();
+    if (precision == PREC_F32) return rows_one<PREC_F32, MODE>(a, stream, false);
+    if (precision == PREC_F16X2) return rows_one<PREC_F16X2, MODE>(a, stream, false);
+    if (precision == PREC_F16) return rows_one<PREC_F16, MODE>(a, stream, false);
+    return rows_one<PREC_BF16, MODE>(a, stream, false);
+}
+hipError_t rows_mode(const VaeRowsArgs& a, int precision, int mode, hipStream_t stream, bool setup) {
+    if (mode == M_ENC) return rows_prec<M_ENC>(a, precision, stream, setup);
+    if (mode == M_DEN_E) return rows_prec<M_DEN_E>(a, precision, stream, setup);
+    if (mode == M_DEN_D) return rows_prec<M_DEN_D>(a, precision, stream, setup);
+    return rows_prec<M_DEC>(a, precision, stream, setup);
 }
 
-hipError_t launch_vae_attn(const VaeAttnArgs& a, int precision, bool enc, hipStream_t stream) {
-    static DeviceOnce once;
-    int dev_;
-    if (!once.done(&dev_)) {
-        hipError_t e = set_lds(&k_vae_attn<PREC_F32, false>, kAttnLdsBytes);
-        if (e == hipSuccess) e = set_lds(&k_vae_attn<PREC_F16X2, false>, kAttnLdsBytes);
-        if (e == hipSuccess) e = set_lds(&k_vae_attn<PREC_F16X2, true>, kAttnLdsBytes);
-        if (e == hipSuccess) e = set_lds(&k_vae_attn_x<false, 4>, kAttnXLdsBytes);
-        if (e == hipSuccess) e = set_lds(&k_vae_attn_x<true, 4>, kAttnXLdsBytes);
-        if (e == hipSuccess) e = set_lds(&k_vae_attn_x<false, 8>, kAttnXLdsBytes);
-        if (e == hipSuccess) e = set_lds(&k_vae_attn_x<true, 8>, kAttnXLdsBytes);
-        if (e == hipSuccess) e = set_lds(&k_vae_attn<PREC_F32, true>, kAttnLdsBytes);
-        if (e == hipSuccess) e = set_lds(&k_vae_attn_bf16<PREC_BF16, false>, kAttnBf16LdsBytes);
-        if (e == hipSuccess) e = set_lds(&k_vae_attn_bf16<PREC_BF16, true>, kAttnBf16LdsBytes);
-        if (e == hipSuccess) e = set_lds(&k_vae_attn_bf16<PREC_F16, false>, kAttnBf16LdsBytes);
-        if (e == hipSuccess) e = set_lds(&k_vae_attn_bf16<PREC_F16, true>, kAttnBf16LdsBytes);
-        if (e != hipSuccess) return e;
-        once.set(dev_);
+// the three attention kernels (generic fp32 / f16x2, 16-bit fragment images, fp32x fragment images) of one MODE
+template <int MODE>
+hipError_t attn_mode(const VaeAttnArgs& a, int precision, hipStream_t stream, bool setup) {
+    if (setup) {
+        hipError_t e = set_lds(&k_vae_attn<PREC_F32, MODE>, kAttnLdsBytes);
+        if (e == hipSuccess) e = set_lds(&k_vae_attn<PREC_F16X2, MODE>, kAttnLdsBytes);
+        if (e == hipSuccess) e = set_lds(&k_vae_attn_x<MODE, 4>, kAttnXLdsBytes);
+        if (e == hipSuccess) e = set_lds(&k_vae_attn_x<MODE, 8>, kAttnXLdsBytes);
+        if (e == hipSuccess) e = set_lds(&k_vae_attn_bf16<PREC_BF16, MODE>, kAttnBf16LdsBytes);
+        if (e == hipSuccess) e = set_lds(&k_vae_attn_bf16<PREC_F16, MODE>, kAttnBf16LdsBytes);
+        return e;
     }
     const dim3 grid(a.B * kHeads), block(256);
     const dim3 grid16(a.B * kHeads, a.B <= kAttnSplitMaxClips ? 5 : 1);   // the fragment-image kernels (16-bit, fp32x): query tiles over 5 workgroups for small batches
     if (precision == PREC_F32) {
-        if (enc) hipLaunchKernelGGL((k_vae_attn<PREC_F32, true>), grid, block, kAttnLdsBytes, stream, a);
-        else hipLaunchKernelGGL((k_vae_attn<PREC_F32, false>), grid, block, kAttnLdsBytes, stream, a);
+        hipLaunchKernelGGL((k_vae_attn<PREC_F32, MODE>), grid, block, kAttnLdsBytes, stream, a);
     } else if (precision == PREC_F16X2) {
         // the fragment-image kernel; AMUSE_F32X_ATTN=generic runs the fp32 kernel's PREC_F16X2 instantiation instead (A/B, tests)
         static const bool generic = [] { const char* e = getenv("AMUSE_F32X_ATTN"); return e && e[0] == 'g'; }();
         if (generic) {
-            if (enc) hipLaunchKernelGGL((k_vae_attn<PREC_F16X2, true>), grid, block, kAttnLdsBytes, stream, a);
-            else hipLaunchKernelGGL((k_vae_attn<PREC_F16X2, false>), grid, block, kAttnLdsBytes, stream, a);
+            hipLaunchKernelGGL((k_vae_attn<PREC_F16X2, MODE>), grid, block, kAttnLdsBytes, stream, a);
         } else {
             // eight waves per workgroup for unsplit launches (measured: decode 2.42 -> 2.30 ms at 256 clips, 0.93 -> 0.86 at 64; the split
             // launches of small batches keep four: one query tile per wave); AMUSE_ATTNX_WAVES=4 pins four (A/B)
             static const int nw_env = [] { const char* e = getenv("AMUSE_ATTNX_WAVES"); return e ? atoi(e) : 0; }();
             const bool w8 = grid16.y == 1 && nw_env != 4;
-            if (w8) {
-                if (enc) hipLaunchKernelGGL((k_vae_attn_x<true, 8>), grid16, dim3(512), kAttnXLdsBytes, stream, a);
-                else hipLaunchKernelGGL((k_vae_attn_x<false, 8>), grid16, dim3(512), kAttnXLdsBytes, stream, a);
-            } else {
-                if (enc) hipLaunchKernelGGL((k_vae_attn_x<true, 4>), grid16, block, kAttnXLdsBytes, stream, a);
-                else hipLaunchKernelGGL((k_vae_attn_x<false, 4>), grid16, block, kAttnXLdsBytes, stream, a);
-            }
+            if (w8) hipLaunchKernelGGL((k_vae_attn_x<MODE, 8>), grid16, dim3(512), kAttnXLdsBytes, stream, a);
+            else hipLaunchKernelGGL((k_vae_attn_x<MODE, 4>), grid16, block, kAttnXLdsBytes, stream, a);
         }
     } else if (precision == PREC_F16) {
-        if (enc) hipLaunchKernelGGL((k_vae_attn_bf16<PREC_F16, true>), grid16, block, kAttnBf16LdsBytes, stream, a);
-        else hipLaunchKernelGGL((k_vae_attn_bf16<PREC_F16, false>), grid16, block, kAttnBf16LdsBytes, stream, a);
+        hipLaunchKernelGGL((k_vae_attn_bf16<PREC_F16, MODE>), grid16, block, kAttnBf16LdsBytes, stream, a);
     } else {
-        if (enc) hipLaunchKernelGGL((k_vae_attn_bf16<PREC_BF16, true>), grid16, block, kAttnBf16LdsBytes, stream, a);
-        else hipLaunchKernelGGL((k_vae_attn_bf16<PREC_BF16, false>), grid16, block, kAttnBf16LdsBytes, stream, a);
+        hipLaunchKernelGGL((k_vae_attn_bf16<PREC_BF16, MODE>), grid16, block, kAttnBf16LdsBytes, stream, a);
     }
-    return hipGetLastError();
+    return hipSuccess;
+}
+}  // namespace
+
+// mode: VAE_MODE_* (amuse_kernels.hpp) = M_DEC / M_ENC / M_DEN_E / M_DEN_D above
+hipError_t launch_vae_rows(const VaeRowsArgs& a, int precision, int mode, hipStream_t stream) {
+    static DeviceOnce once;
+    int dev_;
+    if (!once.done(&dev_)) {
+        for (int m = 0; m < 4; ++m) {
+            hipError_t e = rows_mode(a, precision, m, stream, true);
+            if (e != hipSuccess) return e;
+        }
+        once.set(dev_);
+    }
+    hipError_t e = rows_mode(a, precision, mode, stream, false);
+    return e != hipSuccess ? e : hipGetLastError();
+}
+
+hipError_t launch_vae_attn(const VaeAttnArgs& a, int precision, int mode, hipStream_t stream) {
+    static DeviceOnce once;
+    int dev_;
+    if (!once.done(&dev_)) {
+        hipError_t e = attn_mode<M_DEC>(a, precision, stream, true);
+        if (e == hipSuccess) e = attn_mode<M_ENC>(a, precision, stream, true);
+        if (e == hipSuccess) e = attn_mode<M_DEN_E>(a, precision, stream, true);
+        if (e != hipSuccess) return e;
+        once.set(dev_);
+    }
+    // (M_DEN_D's self-attention is M_DEC's kernel: S = 300, and the Denoiser passes lengths = NULL - no key mask)
+    hipError_t e = mode == M_ENC ? attn_mode<M_ENC>(a, precision, stream, false)
+                 : mode == M_DEN_E ? attn_mode<M_DEN_E>(a, precision, stream, false)
+                                   : attn_mode<M_DEC>(a, precision, stream, false);
+    return e != hipSuccess ? e : hipGetLastError();
 }
 
 }  // namespace amuse

@@ -51,21 +51,28 @@ def _ptr(t: Optional[torch.Tensor]):
 
 
 class HipEngine:
-    """One amuse_ctx on one GPU."""
+    """One amuse_ctx on one GPU.  `arch` / `diffusion_only` = the Denoiser variant of configs/diff_latent_v2.json "arch_denoiser"
+    (denoiser.py:61,92-131): the shipped ("trans_enc", False) by default; the pose-space variants (diffusion_only) may be built
+    without MotionPrior weights (prior_sd None) - they never decode."""
 
-    def __init__(self, denoiser_sd: Dict[str, np.ndarray], prior_sd: Dict[str, np.ndarray], device="cuda:0"):
+    def __init__(self, denoiser_sd: Dict[str, np.ndarray], prior_sd: Optional[Dict[str, np.ndarray]], device="cuda:0",
+                 arch: str = "trans_enc", diffusion_only: bool = False):
         self.lib = _lib.load()
         self.device = torch.device(device)
         if self.device.type != "cuda":
             raise _lib.AmuseHipError("amuse_amd runs on an MI355X (torch device 'cuda:N'); there is no CPU path")
-        den = flatten_state_dict(denoiser_sd, wts.denoiser_param_spec())
-        pri = flatten_state_dict(prior_sd, wts.prior_param_spec())
+        self.arch, self.diffusion_only = arch, bool(diffusion_only)
+        self.den_spec = wts.denoiser_param_spec(arch, diffusion_only)
+        self.state_shape = (300, 333) if diffusion_only else (128,)
+        den = flatten_state_dict(denoiser_sd, self.den_spec)
+        pri = flatten_state_dict(prior_sd, wts.prior_param_spec()) if prior_sd is not None else None
         fp = C.POINTER(C.c_float)
         torch.cuda.init()
-        self.ctx = self.lib.amuse_create(self.device.index or 0, den.ctypes.data_as(fp), den.size,
-                                         pri.ctypes.data_as(fp), pri.size)
+        self.ctx = self.lib.amuse_create_arch(self.device.index or 0, wts.arch_id(arch, diffusion_only), den.ctypes.data_as(fp), den.size,
+                                              pri.ctypes.data_as(fp) if pri is not None else None, 0 if pri is None else pri.size)
         if not self.ctx:
             raise _lib.AmuseHipError(f"amuse_create failed: {self.lib.amuse_last_error().decode()}")
+        assert self.lib.amuse_state_dim(self.ctx) == int(np.prod(self.state_shape))
         self.schedule: Optional[ScheduleTable] = None
         self.noisy_cfg: Dict[str, object] = {}   # DDPMScheduler config of add_noise (set_noisy_scheduler)
 
@@ -80,7 +87,7 @@ class HipEngine:
                 return None
             a = sd if isinstance(sd, np.ndarray) else flatten_state_dict(sd, spec)
             return np.ascontiguousarray(a, dtype=np.float32)
-        den, pri = flat(denoiser_sd, wts.denoiser_param_spec()), flat(prior_sd, wts.prior_param_spec())
+        den, pri = flat(denoiser_sd, self.den_spec), flat(prior_sd, wts.prior_param_spec())
         with torch.cuda.device(self.device):
             _lib.check(self.lib.amuse_update_weights(self.ctx, den.ctypes.data_as(fp) if den is not None else None,
                                                      0 if den is None else den.size,
@@ -164,22 +171,34 @@ class HipEngine:
     def sample(self, con, emo, sty, precision="fp32", seed=0, clip_index0=0, x_init=None, step_noise=None,
                return_traj=False):
         con, emo, sty, B = self._cond(con, emo, sty)
-        x_init = self._dev(x_init, (B, 128)) if x_init is not None else None
+        ss = self.state_shape
+        x_init = self._dev(x_init, (B, *ss)) if x_init is not None else None
         T = self.schedule.n_steps
-        step_noise = self._dev(step_noise, (T, B, 128)) if step_noise is not None else None
-        lat = torch.empty(B, 128, device=self.device, dtype=torch.float32)
-        traj = torch.empty(T, B, 128, device=self.device, dtype=torch.float32) if return_traj else None
+        step_noise = self._dev(step_noise, (T, B, *ss)) if step_noise is not None else None
+        lat = torch.empty(B, *ss, device=self.device, dtype=torch.float32)
+        traj = torch.empty(T, B, *ss, device=self.device, dtype=torch.float32) if return_traj else None
         with torch.cuda.device(self.device):
             _lib.check(self.lib.amuse_sample(self.ctx, _ptr(con), _ptr(emo), _ptr(sty), B, PREC[precision], seed,
                                              clip_index0, _ptr(x_init), _ptr(step_noise), _ptr(lat), _ptr(traj),
                                              self._stream()))
         return (lat, traj) if return_traj else lat
 
-    def denoise_step(self, x_t, timestep: int, con, emo, sty, precision="fp32", taps=False):
+    def denoise_step(self, x_t, timestep: int, con, emo, sty, precision="fp32", taps=False, lengths: Optional[Sequence[int]] = None):
+        """One Denoiser.forward.  lengths (pose-space variants only): eps rows of frames >= lengths[b] are zeroed (denoiser.py:187,199)."""
         con, emo, sty, B = self._cond(con, emo, sty)
-        x_t = self._dev(x_t, (B, 128))
-        eps = torch.empty(B, 128, device=self.device, dtype=torch.float32)
+        x_t = self._dev(x_t, (B, *self.state_shape))
+        eps = torch.empty(B, *self.state_shape, device=self.device, dtype=torch.float32)
         tap = torch.zeros(11, 16, 128, device=self.device, dtype=torch.float32) if taps else None
+        if lengths is not None:
+            if not self.diffusion_only:
+                raise ValueError("lengths only reach the output of the diffusion_only variants")
+            la = np.ascontiguousarray(lengths, dtype=np.int32)
+            if la.shape != (B,):
+                raise ValueError("lengths must have one entry per clip")
+            with torch.cuda.device(self.device):
+                _lib.check(self.lib.amuse_denoise_step_pose(self.ctx, _ptr(x_t), int(timestep), _ptr(con), _ptr(emo), _ptr(sty),
+                                                            la.ctypes.data_as(C.POINTER(C.c_int)), B, PREC[precision], _ptr(eps), self._stream()))
+            return eps
         with torch.cuda.device(self.device):
             _lib.check(self.lib.amuse_denoise_step(self.ctx, _ptr(x_t), int(timestep), _ptr(con), _ptr(emo), _ptr(sty),
                                                    B, PREC[precision], _ptr(eps), _ptr(tap), self._stream()))
@@ -190,7 +209,10 @@ class HipEngine:
         from .scheduler import alphas_cumprod
         z0 = self._dev(z0)
         B = z0.shape[0]
-        noise = self._dev(noise, (B, 128))
+        ss = self.state_shape
+        if tuple(z0.shape[1:]) != tuple(ss):
+            raise ValueError(f"z0 must be (B, {', '.join(map(str, ss))}), got {tuple(z0.shape)}")
+        noise = self._dev(noise, (B, *ss))
         con, emo, sty, Bc = self._cond(con, emo, sty)
         if Bc != B:
             raise ValueError(f"z_con has {Bc} rows, z0 has {B}")
@@ -202,7 +224,7 @@ class HipEngine:
             raise ValueError(f"timesteps must lie in 0..{len(ac) - 1}")
         sa = np.ascontiguousarray(np.sqrt(ac[ts]), dtype=np.float32)
         sb = np.ascontiguousarray(np.sqrt(np.float32(1.0) - ac[ts]), dtype=np.float32)
-        out = {"noisy_latents": torch.empty(B, 128, device=self.device), "noise_pred": torch.empty(B, 128, device=self.device)}
+        out = {"noisy_latents": torch.empty(B, *ss, device=self.device), "noise_pred": torch.empty(B, *ss, device=self.device)}
         fpp = C.POINTER(C.c_float)
         with torch.cuda.device(self.device):
             _lib.check(self.lib.amuse_diffusion_forward(self.ctx, _ptr(z0), _ptr(noise), ts.ctypes.data_as(C.POINTER(C.c_int)),
@@ -263,6 +285,18 @@ class HipEngine:
                                                  _ptr(out["mu"]), _ptr(out["std"]), _ptr(out["latent"]), self._stream()))
         return out
 
+    def feats_to_smplx(self, feats, quat_mode="p3d"):
+        """(B,300,333) features (6D rotations | translation) -> {"poses": (B,300,55,3), "trans": (B,300,3)} (infer_ldm.py:168-173)."""
+        feats = self._dev(feats)
+        B = feats.shape[0]
+        if tuple(feats.shape) != (B, 300, 333):
+            raise ValueError(f"feats must be (B, 300, 333), got {tuple(feats.shape)}")
+        out = {"poses": torch.empty(B, 300, 55, 3, device=self.device, dtype=torch.float32),
+               "trans": torch.empty(B, 300, 3, device=self.device, dtype=torch.float32)}
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.amuse_feats_to_smplx(self.ctx, _ptr(feats), B, QUAT[quat_mode], _ptr(out["poses"]), _ptr(out["trans"]), self._stream()))
+        return out
+
     def smplx_to_feats(self, poses, trans):
         """(B,300,55,3) axis-angle + (B,300,3) translation -> (B,300,333) prior features (infer_ldm.py:459-464)."""
         poses = self._dev(poses)
@@ -278,11 +312,12 @@ class HipEngine:
     def diffusion_backward(self, con, emo, sty, precision="fp32", quat_mode="p3d", seed=0, clip_index0=0, x_init=None,
                            step_noise=None, out=None):
         con, emo, sty, B = self._cond(con, emo, sty)
-        x_init = self._dev(x_init, (B, 128)) if x_init is not None else None
+        ss = self.state_shape
+        x_init = self._dev(x_init, (B, *ss)) if x_init is not None else None
         T = self.schedule.n_steps
-        step_noise = self._dev(step_noise, (T, B, 128)) if step_noise is not None else None
+        step_noise = self._dev(step_noise, (T, B, *ss)) if step_noise is not None else None
         if out is None:
-            out = {"latents": torch.empty(B, 128, device=self.device, dtype=torch.float32),
+            out = {"latents": torch.empty(B, *ss, device=self.device, dtype=torch.float32),
                    "poses": torch.empty(B, 300, 55, 3, device=self.device, dtype=torch.float32),
                    "trans": torch.empty(B, 300, 3, device=self.device, dtype=torch.float32)}
         with torch.cuda.device(self.device):
@@ -304,7 +339,7 @@ class HipEngine:
         return st.cpu().numpy()
 
     def counter_normal(self, seed, clip_index0, B, step, rng_stream):
-        o = torch.empty(B, 128, device=self.device, dtype=torch.float32)
+        o = torch.empty(B, *self.state_shape, device=self.device, dtype=torch.float32)
         with torch.cuda.device(self.device):
             _lib.check(self.lib.amuse_counter_normal(self.ctx, seed, clip_index0, B, step, rng_stream, _ptr(o),
                                                      self._stream()))

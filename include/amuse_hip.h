@@ -28,7 +28,8 @@
 extern "C" {
 #endif
 
-#define AMUSE_ABI_VERSION 2   /* 2: AMUSE_PREC_F32X / _F16, AMUSE_UPD_F32X / _F16; tile-major amuse_debug_gemm; clips per group 1..5 */
+#define AMUSE_ABI_VERSION 3   /* 3: Denoiser variants (amuse_create_arch, AMUSE_ARCH_*, amuse_denoise_step_pose, amuse_feats_to_smplx);
+                                 2: AMUSE_PREC_F32X / _F16, AMUSE_UPD_F32X / _F16; tile-major amuse_debug_gemm; clips per group 1..5 */
 
 /* architecture the kernels are specialised for (configs/diff_latent_v2.json:23-47,
  * configs/prior_emotional_fing.json:6-20, configs/base_new.json "train_pose_framelen") */
@@ -43,6 +44,23 @@ extern "C" {
 #define AMUSE_DENOISER_PARAMS 2192384u /* 130 tensors, state-dict order of Denoiser (denoiser.py:16-133) */
 #define AMUSE_PRIOR_PARAMS 4643277u    /* 297 tensors, state-dict order of MotionPrior (vae.py:24-146) */
 #define AMUSE_MAX_STEPS 1000
+
+/* Denoiser variants (models/latent_diffusion/denoiser.py:64-66,92-131,174-204): `arch` and `diffusion_only` of
+ * configs/diff_latent_v2.json "arch_denoiser".
+ *   ENC       arch "trans_enc", latent sample: the shipped configuration - 5 tokens [latent, time, con, emo, sty], skip encoder
+ *   DEC       arch "trans_dec", latent sample: tgt = the latent as ONE token (+ query_pos), memory = [time, con, emo, sty]
+ *             (+ mem_pos); 9 TransformerDecoderLayer.forward_post (cross_attention.py:323-345: self-attention, cross-attention
+ *             onto the 2..4 memory tokens, FFN) + decoder.norm
+ *   ENC_POSE  diffusion_only + "trans_enc": the sample is the 300 x 333 pose sequence; [time, con, emo, sty | pose_embd(frames)]
+ *             = S = 304 tokens through the skip encoder (NO key mask, denoiser.py:182), pose_proj of the frame rows
+ *   DEC_POSE  diffusion_only + "trans_dec": tgt = pose_embd(frames) (S = 300), memory as DEC, pose_proj
+ * The per-clip state of the sampling loop is AMUSE_D_MODEL floats for the latent variants and AMUSE_POSE_STATE = 300 * 333 for
+ * the pose-space ones (amuse_state_dim); every `x` / `eps` / noise array below is [B][state_dim]. */
+enum { AMUSE_ARCH_ENC = 0, AMUSE_ARCH_DEC = 1, AMUSE_ARCH_ENC_POSE = 2, AMUSE_ARCH_DEC_POSE = 3 };
+#define AMUSE_POSE_STATE (AMUSE_N_FRAMES * AMUSE_N_FEATS)
+#define AMUSE_DENOISER_PARAMS_DEC 2657536u        /* 176 tensors */
+#define AMUSE_DENOISER_PARAMS_ENC_POSE 2278093u   /* 134 tensors: pose_embd, pose_proj first (denoiser.py:64-66) */
+#define AMUSE_DENOISER_PARAMS_DEC_POSE 2743245u   /* 180 tensors */
 
 enum { AMUSE_OK = 0, AMUSE_EINVAL = -1, AMUSE_EHIP = -2, AMUSE_ENOMEM = -3, AMUSE_ESTATE = -4 };
 
@@ -93,6 +111,15 @@ typedef struct {
  * weight streams and uploads them.  Returns NULL on failure. */
 amuse_ctx* amuse_create(int device, const float* denoiser_params, size_t n_denoiser,
                         const float* prior_params, size_t n_prior);
+/* The same for a Denoiser variant: `denoiser_params` holds the state dict of Denoiser(arch, diffusion_only) in its own
+ * registration order (amuse_denoiser_param_count(arch) floats; amuse_amd/weights.py denoiser_param_spec lists the keys).
+ * prior_params may be NULL (n_prior 0) for the pose-space variants, which never decode (infer_ldm.py:165,177);
+ * amuse_vae_* then fail with AMUSE_ESTATE.  arch AMUSE_ARCH_ENC == amuse_create. */
+amuse_ctx* amuse_create_arch(int device, int arch, const float* denoiser_params, size_t n_denoiser,
+                             const float* prior_params, size_t n_prior);
+size_t amuse_denoiser_param_count(int arch);   /* 0 for an unknown arch */
+int amuse_arch(const amuse_ctx* ctx);
+size_t amuse_state_dim(const amuse_ctx* ctx);  /* floats per clip of the sampled state: 128 or AMUSE_POSE_STATE */
 /* New weights into an existing context (same architecture): re-packs and overwrites the weight streams in place.
  * Replaces what the reference gets for free from sharing nn.Module parameters between its training step and the
  * in-loop sampler (scripts/trainer.py:411-415: ldm.diffusion_backward + prior.decode on the weights just stepped).
@@ -127,7 +154,9 @@ int amuse_set_schedule(amuse_ctx* ctx, const amuse_schedule* sched, void* stream
  *   step_noise   dev [T][B][128] or NULL -> counter-based; only read at steps with sigma != 0
  *   latents_out  dev [B][128]  final latents
  *   traj_out     dev [T][B][128] or NULL: latent after every step (tests)
- * Uses the schedule set by amuse_set_schedule. */
+ * Uses the schedule set by amuse_set_schedule.  Denoiser variants (amuse_create_arch): 128 reads amuse_state_dim(ctx) in every
+ * shape above - the pose-space variants sample the [300][333] feature sequence itself, lengths all 300 as the reference's
+ * loop passes them (infer_ldm.py:135). */
 int amuse_sample(amuse_ctx* ctx, const float* con, const float* emo, const float* sty, int B,
                  int precision, uint64_t seed, uint64_t clip_index0, const float* x_init,
                  const float* step_noise, float* latents_out, float* traj_out, void* stream);
@@ -139,6 +168,12 @@ int amuse_sample(amuse_ctx* ctx, const float* con, const float* emo, const float
 int amuse_denoise_step(amuse_ctx* ctx, const float* x_t, int timestep, const float* con,
                        const float* emo, const float* sty, int B, int precision, float* eps_out,
                        float* tap_out, void* stream);
+
+/* The pose-space variants' teacher-forced step with the `lengths` argument of Denoiser.forward (denoiser.py:135-145,187,199):
+ * eps rows of frames >= lengths[b] are zeroed (`sample[~mask.T] = 0`); the padded frames are still attended (the reference
+ * passes no key mask).  lengths host [B] or NULL (= all 300).  x_t, eps_out dev [B][300][333]. */
+int amuse_denoise_step_pose(amuse_ctx* ctx, const float* x_t, int timestep, const float* con, const float* emo,
+                            const float* sty, const int* lengths, int B, int precision, float* eps_out, void* stream);
 
 /* Replaces the arithmetic of LatentDiffusionModel.diffusion_forward (models/latent_diffusion/ldm.py:71-97), the
  * training-time twin of the sampling step, in eval semantics (no dropout): noisy = sqrt_ab * z0 + sqrt_1m_ab * noise
@@ -187,8 +222,16 @@ int amuse_diffusion_backward(amuse_ctx* ctx, const float* con, const float* emo,
                              uint64_t clip_index0, const float* x_init, const float* step_noise,
                              float* latents_out, float* poses_out, float* trans_out, void* stream);
 
-/* The build's counter-based normal generator, exposed for tests: out[B][128] for clips
- * clip_index0..+B, `step`, stream 0 (initial latent) or 1 (ancestral noise). */
+/* The output conversion of PretrainedLPDM_v1.diffusion_backward alone (infer_ldm.py:168-173): features (6D rotations |
+ * translation) -> SMPL-X axis-angle.  feats dev [B][300][333] -> poses_out dev [B][300][55][3], trans_out dev [B][300][3].
+ * amuse_diffusion_backward of a pose-space variant = amuse_sample + this (the sampled state IS the feature sequence; the
+ * reference itself raises at infer_ldm.py:177 where its decode-free branch would be). */
+int amuse_feats_to_smplx(amuse_ctx* ctx, const float* feats, int B, int quat_mode, float* poses_out, float* trans_out,
+                         void* stream);
+
+/* The build's counter-based normal generator, exposed for tests: out[B][state_dim] for clips
+ * clip_index0..+B, `step`, stream 0 (initial latent) or 1 (ancestral noise).  Element e of a clip's state is draw e % 4 of
+ * Philox counter (clip, step, e / 4, stream). */
 int amuse_counter_normal(amuse_ctx* ctx, uint64_t seed, uint64_t clip_index0, int B, int step,
                          int rng_stream, float* out, void* stream);
 

@@ -1,0 +1,218 @@
+"""GPU parity of the Denoiser VARIANTS (include/amuse_hip.h AMUSE_ARCH_DEC / _ENC_POSE / _DEC_POSE) through the C ABI, against the
+goldens of the reference's own Denoiser class built with arch = "trans_dec" and / or diffusion_only = true
+(tests/golden/denoiser_variants.npz) and against the oracle pinned to them (tests/test_oracle_variants.py).
+Reference: models/latent_diffusion/denoiser.py:64-66,116-131,174-204; utils/cross_attention.py:195-234,297-345.
+
+Bars: the fp32 bars of tests/test_gpu_parity.py, unchanged - teacher-forced eps_hat <= 1e-5 (fp32 and fp32x), DDIM-50 state <= 1e-4;
+the 16-bit modes are held to whole-network bounds (|eps| ~ 3) as there."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN
+
+pytestmark = pytest.mark.gpu
+
+PARITY = ("fp32", "fp32x")
+VARIANTS = (("trans_dec", False), ("trans_enc", True), ("trans_dec", True))
+ROWS = slice(0, 300, 6)
+
+
+def tag_of(arch, pose):
+    return f"{arch}{'_pose' if pose else ''}"
+
+
+def _err(a, b):
+    a = a.detach().cpu().double().numpy() if isinstance(a, torch.Tensor) else np.asarray(a, dtype=np.float64)
+    b = b.detach().cpu().double().numpy() if isinstance(b, torch.Tensor) else np.asarray(b, dtype=np.float64)
+    return float(np.abs(a - b).max())
+
+
+@pytest.fixture(scope="module")
+def g():
+    return np.load(GOLDEN / "denoiser_variants.npz")
+
+
+@pytest.fixture(scope="module", params=VARIANTS, ids=[tag_of(*v) for v in VARIANTS])
+def env(request):
+    from amuse_amd import weights as wts
+    from amuse_amd.engine import HipEngine
+    from oracle import amuse_oracle as orc
+    arch, pose = request.param
+    wd = wts.make_denoiser_weights(0, arch, pose)
+    eng = HipEngine(wd, None if pose else wts.make_prior_weights(0), "cuda:0", arch=arch, diffusion_only=pose)
+    yield {"eng": eng, "W": orc.to_torch(wd), "orc": orc, "arch": arch, "pose": pose, "tag": tag_of(arch, pose)}
+    eng.close()
+
+
+def inputs(g, pose):
+    con, emo, sty = (g[k] for k in ("con", "emo", "sty"))
+    return con, emo, sty, (g["x_pose"].astype(np.float32) if pose else g["x_lat"])
+
+
+def cut(e, pose):
+    e = e.detach().cpu().numpy() if isinstance(e, torch.Tensor) else np.asarray(e)
+    return e[:, ROWS] if pose else e
+
+
+@pytest.mark.parametrize("prec", PARITY)
+def test_variant_eps_vs_reference_golden(env, g, prec):
+    eng, pose, tag = env["eng"], env["pose"], env["tag"]
+    con, emo, sty, x = inputs(g, pose)
+    for t in (981, 501, 1):
+        eps = eng.denoise_step(x, t, con, emo, sty, prec)
+        assert _err(cut(eps, pose), g[f"{tag}/eps_t{t}"]) < 1e-5, t
+    assert _err(cut(eng.denoise_step(x, 501, con, None, sty, prec), pose), g[f"{tag}/eps_t501_noemo"]) < 1e-5    # 3 memory / 3 prefix tokens
+    assert _err(cut(eng.denoise_step(x, 501, con, None, None, prec), pose), g[f"{tag}/eps_t501_consolo"]) < 1e-5  # 2
+    if pose:
+        lens = [int(v) for v in g["lengths_ragged"]]
+        e = eng.denoise_step(x, 501, con, emo, sty, prec, lengths=lens)
+        assert _err(cut(e, pose), g[f"{tag}/eps_t501_ragged"]) < 1e-5
+        assert torch.all(e[1, lens[1]:] == 0) and torch.any(e[1, lens[1] - 1] != 0)
+        with pytest.raises(Exception):   # lengths_to_mask sizes the mask by max(lengths): the reference's indexing needs one full clip
+            eng.denoise_step(x, 501, con, emo, sty, prec, lengths=[200, 173])
+
+
+@pytest.mark.parametrize("prec", PARITY)
+def test_trans_dec_taps_vs_reference_golden(env, g, prec):
+    if env["arch"] != "trans_dec" or env["pose"]:
+        pytest.skip("taps exist for the latent trans_dec kernel")
+    eng, tag = env["eng"], env["tag"]
+    con, emo, sty, x = inputs(g, False)
+    eps, tap = eng.denoise_step(x, 981, con, emo, sty, prec, taps=True)
+    tap = tap.cpu().numpy()
+    B = x.shape[0]
+    assert _err(tap[0, :B], g[f"{tag}/tap981/tokens"][:, 0]) < 1e-6            # x_t + query_pos.pe[0]
+    assert _err(tap[1, :B], g[f"{tag}/tap981/decoder.layers.0"][:, 0]) < 1e-5
+    assert _err(tap[9, :B], g[f"{tag}/tap981/decoder.layers.8"][:, 0]) < 1e-5
+    assert _err(tap[10, :B], eps) == 0.0
+
+
+@pytest.mark.parametrize("prec", PARITY)
+def test_variant_per_clip_timesteps_vs_oracle(env, g, prec):
+    """LatentDiffusionModel.diffusion_forward's call pattern (ldm.py:75-97): one timestep per clip."""
+    eng, orc, W, arch, pose, tag = (env[k] for k in ("eng", "orc", "W", "arch", "pose", "tag"))
+    con, emo, sty, x = inputs(g, pose)
+    ts = [int(v) for v in g["timesteps_batch"]]
+    noise = torch.randn(*x.shape, generator=torch.Generator().manual_seed(5))
+    out = eng.diffusion_forward(x, noise, ts, con, emo, sty, prec)
+    ac = orc.SchedulerBase().alphas_cumprod
+    sh = (-1,) + (1,) * (x.ndim - 1)
+    noisy = ac[ts].sqrt().reshape(sh) * torch.from_numpy(x) + (1 - ac[ts]).sqrt().reshape(sh) * noise
+    assert _err(out["noisy_latents"], noisy) < 1e-6
+    ref = orc.denoiser_forward_variant(W, noisy, ts, *(torch.from_numpy(v) for v in (con, emo, sty)), arch, pose)
+    assert _err(out["noise_pred"], ref) < 1e-5
+    # and against the reference module itself where the noisy input is the golden's x (noise = 0 at sqrt_ab = 1 is not reachable:
+    # the golden's eps_batch_t pins the oracle on the CPU - tests/test_oracle_variants.py)
+
+
+@pytest.mark.parametrize("prec", PARITY)
+def test_variant_ddim50_trajectory_vs_reference_golden(env, g, prec):
+    from amuse_amd import scheduler as sch
+    eng, pose, tag = env["eng"], env["pose"], env["tag"]
+    con, emo, sty, x = inputs(g, pose)
+    eng.set_schedule(sch.ddim_table())
+    lat, traj = eng.sample(con, emo, sty, prec, x_init=x, return_traj=True)
+    for n in (10, 50):
+        assert _err(cut(traj[n - 1], pose), g[f"{tag}/x_after_{n}"]) < 1e-4, n
+    assert torch.equal(lat, traj[-1])
+
+
+def test_variant_sixteen_bit_modes(env, g):
+    """bf16 / fp16 operands: whole-network bounds against the reference's goldens (|eps| ~ 3) - the 16-bit bars of
+    tests/test_gpu_parity.py / test_gpu_fp16.py."""
+    eng, pose, tag = env["eng"], env["pose"], env["tag"]
+    con, emo, sty, x = inputs(g, pose)
+    for prec, bar in (("bf16", 8e-2), ("fp16", 1.5e-2)):
+        for t in (981, 1):
+            e = eng.denoise_step(x, t, con, emo, sty, prec)
+            assert torch.isfinite(e).all()
+            assert _err(cut(e, pose), g[f"{tag}/eps_t{t}"]) < bar, (prec, t)
+
+
+@pytest.mark.parametrize("prec", ("fp32", "bf16"))
+def test_variant_ddpm_in_kernel_noise_shards_and_restatement(env, prec):
+    """Ancestral sampling on a strided DDPM grid: (i) in-kernel counter noise == the same noise passed explicitly, bitwise;
+    (ii) a job split into shards (clip_index0 offsets) == the job in one launch, bitwise; (iii) fp32: the loop vs the oracle's."""
+    from amuse_amd import scheduler as sch
+    eng, orc, W, arch, pose = (env[k] for k in ("eng", "orc", "W", "arch", "pose"))
+    B, T = (5, 4) if pose else (21, 20)
+    gq = torch.Generator().manual_seed(11)
+    con, emo, sty = (torch.randn(B, 256, generator=gq) for _ in range(3))
+    eng.set_schedule(sch.ddpm_table(T))
+    full = eng.sample(con, emo, sty, prec, seed=77, clip_index0=40)
+    x0 = eng.counter_normal(77, 40, B, 0, 0)
+    nz = torch.stack([eng.counter_normal(77, 40, B, s, 1) for s in range(T)])
+    expl = eng.sample(con, emo, sty, prec, x_init=x0, step_noise=nz)
+    assert torch.equal(full, expl)
+    k = 2 if pose else 16
+    parts = torch.cat([eng.sample(con[:k], emo[:k], sty[:k], prec, seed=77, clip_index0=40),
+                       eng.sample(con[k:], emo[k:], sty[k:], prec, seed=77, clip_index0=40 + k)])
+    assert torch.equal(full, parts)
+    ref0 = orc.counter_normal(77, np.arange(40, 40 + B), 0, 0, nfeat=int(np.prod(x0.shape[1:])))
+    assert _err(x0.reshape(B, -1), ref0) < 5e-5   # hardware log2 / sin / cos vs libm
+    if prec == "fp32":
+        sched = orc.DDPM(T)
+        nb = 2
+        ref = orc.sample_variant(W, sched, con[:nb], emo[:nb], sty[:nb], x0[:nb].cpu(), arch, pose, step_noise=nz[:, :nb].cpu())
+        assert _err(expl[:nb], ref) < 2e-4 * float(ref.abs().max())
+
+
+def test_pose_variant_diffusion_backward_converts_the_sampled_features(env):
+    """diffusion_only: no VAE decode (infer_ldm.py:165) - the sampled [300][333] state goes through 6D -> axis-angle (:168-173)."""
+    from amuse_amd import scheduler as sch
+    eng, orc, pose = env["eng"], env["orc"], env["pose"]
+    if not pose:
+        pytest.skip("latent variants decode through MotionPrior (tests below)")
+    gq = torch.Generator().manual_seed(3)
+    con, emo, sty = (torch.randn(2, 256, generator=gq) for _ in range(3))
+    eng.set_schedule(sch.ddim_table(3, num_train_timesteps=1000))
+    out = eng.diffusion_backward(con, emo, sty, "fp32", seed=5)
+    feats = out["latents"].cpu()
+    poses, trans = orc.feats_to_smplx(feats.double())
+    assert torch.equal(out["trans"].cpu(), feats[..., -3:])
+    # as rotations (the axis-angle representation has the 2 pi ambiguity the candidate selection leaves): geodesic distance
+    Rg, Rr = orc.axis_angle_to_matrix(out["poses"].cpu().double()), orc.axis_angle_to_matrix(poses)
+    cosang = ((Rg.transpose(-1, -2) @ Rr).diagonal(dim1=-2, dim2=-1).sum(-1) - 1) / 2
+    ang = torch.acos(cosang.clamp(-1, 1))
+    assert float(ang.median()) < 1e-5 and float(ang.quantile(0.99)) < 1e-3
+    with pytest.raises(Exception):
+        eng.vae_decode(torch.zeros(1, 128))   # built without MotionPrior weights
+
+
+def test_trans_dec_latent_end_to_end_decodes_through_the_prior(env):
+    from amuse_amd import scheduler as sch
+    eng, orc, W, arch, pose = (env[k] for k in ("eng", "orc", "W", "arch", "pose"))
+    if pose:
+        pytest.skip("pose-space variants never decode")
+    from amuse_amd import weights as wts
+    Wp = orc.to_torch(wts.make_prior_weights(0))
+    gq = torch.Generator().manual_seed(9)
+    con, emo, sty = (torch.randn(3, 256, generator=gq) for _ in range(3))
+    x0 = torch.randn(3, 128, generator=gq)
+    eng.set_schedule(sch.ddim_table())
+    for prec in PARITY:
+        out = eng.diffusion_backward(con, emo, sty, prec, x_init=x0)
+        ref = orc.sample_variant(W, orc.DDIM(), con, emo, sty, x0, arch, pose)
+        assert _err(out["latents"], ref) < 1e-4
+        feats = orc.vae_decode(Wp, out["latents"].cpu())
+        assert _err(out["trans"], feats[..., -3:]) < 2e-5
+
+
+def test_variant_weight_update_equals_fresh_context(env, g):
+    from amuse_amd import weights as wts
+    from amuse_amd.engine import HipEngine
+    eng, arch, pose = env["eng"], env["arch"], env["pose"]
+    con, emo, sty, x = inputs(g, pose)
+    w1 = wts.make_denoiser_weights(1, arch, pose)
+    from amuse_amd import scheduler as sch
+    fresh = HipEngine(w1, None if pose else wts.make_prior_weights(0), "cuda:0", arch=arch, diffusion_only=pose)
+    try:
+        fresh.set_schedule(sch.ddim_table())   # (installs torch's timestep frequencies, as every earlier call on `eng` did)
+        eng.set_schedule(sch.ddim_table())
+        eng.update_weights(denoiser_sd=w1)
+        for prec in ("fp32", "fp32x", "bf16", "fp16"):
+            assert torch.equal(eng.denoise_step(x, 501, con, emo, sty, prec), fresh.denoise_step(x, 501, con, emo, sty, prec)), prec
+    finally:
+        fresh.close()
+        eng.update_weights(denoiser_sd=wts.make_denoiser_weights(0, arch, pose))
