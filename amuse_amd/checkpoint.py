@@ -50,9 +50,11 @@ def epoch_of(path: Path) -> int:
     return int(re.search(r"\d+", Path(path).stem.split("_")[-1]).group())
 
 
-def load_denoiser_checkpoint(path: Path) -> Dict[str, np.ndarray]:
+def load_denoiser_checkpoint(path: Path, arch: str = "trans_enc", diffusion_only: bool = False) -> Dict[str, np.ndarray]:
+    """infer_ldm.py:86-104: every `denoiser.*` tensor of the checkpoint, the count asserted against the state dict of
+    Denoiser(arch, diffusion_only) (130 entries for the shipped configuration; 176 / 134 / 180 for the variants)."""
     chk = torch.load(path, map_location="cpu", weights_only=False)
-    spec = wts.denoiser_param_spec()
+    spec = wts.denoiser_param_spec(arch, diffusion_only)
     out, count = {}, 0
     for name, p in chk["model_state_dict"].items():
         if name.startswith("denoiser"):

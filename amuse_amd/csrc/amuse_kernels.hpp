@@ -201,6 +201,27 @@ struct VaeFusedArgs {
 constexpr size_t kVaeFusedSkipBytesPerClip = 4 * 20 * 4 * 64 * 16;
 hipError_t launch_vae_fused(const VaeFusedArgs& a, hipStream_t stream);
 hipError_t launch_vae_fusedh(const VaeFusedArgs& a, hipStream_t stream);   // fp16 operands (AMUSE_PREC_F16, k_vae_fusedh.hip)
+// ---------------------------------------------------------------- fused pose-space denoiser step (k_den_fused.hip): one workgroup per clip
+struct DenFusedArgs {
+    const uint4* wstream;      // 16-bit stream in consumption order, whole stages (amuse_variants.hip)
+    const float* pvec;         // encoder small params, PV_* layout
+    const float* final_bias;   // pose_proj.bias padded to [384]
+    const float* emb_bias;     // pose_embd.bias [128]
+    const float* pe;           // query_pos.pe [500][128]
+    const float* ttok;         // time token + pe[0]: [128] (ttok_stride 0) or one per clip
+    size_t ttok_stride;
+    const float* ctok;         // [B][npre - 1][128] condition tokens + pe[1..]
+    uint4* skip;               // [B][4 levels][20 tiles][4 k-pairs][64 lanes] packed operands of the skip stack
+    float* x;                  // [B][300][333]: x_t; overwritten with x_{t-1} when coef is set
+    float* eps_out;            // [B][300][333] or null
+    const float* coef;         // dev [8]: the step's scheduler row, or null (teacher-forced step)
+    const float* step_noise;   // [B][300][333] or null -> counter-based
+    const int* lengths;        // dev [B] or null
+    uint64_t seed, clip0;
+    int step, B, npre;
+};
+hipError_t launch_den_fused(const DenFusedArgs& a, hipStream_t stream);
+hipError_t launch_den_fusedh(const DenFusedArgs& a, hipStream_t stream);   // fp16 operands (k_den_fusedh.hip)
 // feats[row][0:330] = first two rows of R(axis-angle) per joint, feats[row][330:333] = trans   (infer_ldm.py:459-464)
 hipError_t launch_smplx_to_feats(const float* poses, const float* trans, size_t nrows, float* feats, hipStream_t stream);
 // mu = stats[b][0], std = exp(stats[b][1]) ** 0.5, latent = mu + std * eps   (vae.py:209-213)

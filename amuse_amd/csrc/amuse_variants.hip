@@ -20,6 +20,8 @@ struct amuse_variant {
     float* ckv = nullptr; size_t ckv_cap = 0;     // [B][ncond][9][2][128]
     float* tkv1 = nullptr; size_t tkv1_cap = 0;   // teacher-forced steps: [1 or B][9][2][128]
     float* ws = nullptr; size_t ws_cap = 0;       // pose stages: x, q, k, v, o, 4 skip levels of [B][304][128]
+    uint4* fused_w[2] = {nullptr, nullptr};       // ENC_POSE: the fused step kernel's stream (k_den_fused.hip), bf16 | fp16
+    uint4* skip = nullptr; size_t skip_cap = 0;   // its skip stack, clips
     float* tt = nullptr; size_t tt_cap = 0;       // teacher-forced steps: time tokens [1 or B][128] | device copy of the timesteps
 };
 
@@ -138,9 +140,32 @@ struct PoseStep {
     const float* cond_tok; const float* ckv; const int* lengths_dev;
     int ncond, step; uint64_t seed, clip0;
 };
-int pose_step(amuse_ctx* c, const PoseStep& p, int nb, int precision, hipStream_t st) {
+// the fused per-clip step kernel (16-bit modes, diffusion_only + trans_enc) occupies one CU per clip: it wins from about as many
+// clips as the fused decoder does (amuse_api.hip kFusedMinClips); below that the staged path's 19 workgroups per clip finish sooner.
+// amuse_set_decode_path / AMUSE_VAE_FUSED pin the choice here too (STAGED / FUSED), keyed by the CALL's clip count.
+constexpr int kDenFusedMinClips = 64;
+bool use_den_fused(const amuse_ctx* c, int precision, int B) {
+    static const int env = [] { const char* e = getenv("AMUSE_VAE_FUSED"); return e ? atoi(e) : -1; }();
+    const int force = c->decode_path == AMUSE_DECODE_STAGED ? 0 : c->decode_path == AMUSE_DECODE_FUSED ? 1 : env;
+    if (!is_op16(precision) || c->arch != AMUSE_ARCH_ENC_POSE || force == 0) return false;
+    return force == 1 || B >= kDenFusedMinClips;
+}
+
+int pose_step(amuse_ctx* c, const PoseStep& p, int nb, int precision, bool fused, hipStream_t st) {
     amuse_variant* v = c->var;
     const bool dec = arch_dec(c->arch);
+    if (fused) {
+        DenFusedArgs fa{};
+        fa.wstream = v->fused_w[precision == PREC_F16]; fa.pvec = v->pvec; fa.final_bias = v->final_bias; fa.emb_bias = v->emb_bias;
+        fa.pe = c->den_pe; fa.ttok = p.ttok; fa.ttok_stride = p.ttok_stride; fa.ctok = p.cond_tok; fa.skip = v->skip;
+        fa.eps_out = p.eps_out; fa.coef = p.coef; fa.step_noise = p.step_noise; fa.lengths = p.lengths_dev;
+        fa.seed = p.seed; fa.clip0 = p.clip0; fa.step = p.step; fa.B = nb; fa.npre = 1 + p.ncond;
+        // the kernel updates its state array in place; a teacher-forced step (no coefficients) only reads it
+        if (p.x_out && p.x_out != p.x_in) HIP_TRY(hipMemcpyAsync(p.x_out, p.x_in, (size_t)nb * AMUSE_POSE_STATE * sizeof(float), hipMemcpyDeviceToDevice, st));
+        fa.x = p.x_out ? p.x_out : const_cast<float*>(p.x_in);
+        HIP_TRY(precision == PREC_F16 ? launch_den_fusedh(fa, st) : launch_den_fused(fa, st));
+        return 0;
+    }
     const int npre = dec ? 0 : 1 + p.ncond, S = kFrames + npre;
     const size_t rows = (size_t)nb * S;
     float* ws = v->ws;
@@ -172,7 +197,15 @@ int pose_step(amuse_ctx* c, const PoseStep& p, int nb, int precision, hipStream_
     }
     return 0;
 }
-int ensure_pose_ws(amuse_variant* v, int chunk) {
+int ensure_pose_ws(amuse_variant* v, int chunk, bool fused) {
+    if (fused) {
+        if (v->skip_cap >= (size_t)chunk) return 0;
+        if (v->skip) HIP_TRY(hipFree(v->skip));
+        v->skip = nullptr; v->skip_cap = 0;
+        HIP_TRY(hipMalloc((void**)&v->skip, (size_t)chunk * kVaeFusedSkipBytesPerClip));
+        v->skip_cap = chunk;
+        return 0;
+    }
     return ensure(&v->ws, &v->ws_cap, (size_t)chunk * kPoseWsPerClip);
 }
 }  // namespace
@@ -237,6 +270,42 @@ int variant_build(amuse_ctx* c, const float* den, int what) {
             all.insert(all.end(), (size_t)kVaeRing * 64, uint4{0, 0, 0, 0});   // the last wave's ring reads past its slice
             if (upload(&v->rows_w[prec], all.data(), all.size() * sizeof(uint4))) return AMUSE_EHIP;
         }
+        if (!dec) {
+            // fused step kernel (k_den_fused.hip; bf16 / fp16 operands): ONE stream for the eight waves, in consumption order, cut into
+            // stages of kVaeFusedStageUnits units - the fused decoder's layout (amuse_api.hip) with pose_embd in front and encoder blocks
+            for (const int p16 : {PREC_BF16, PREC_F16}) {
+                if (!(what & kUpdBitV[p16])) continue;
+                std::vector<uint4> s;
+                const auto pad = [&](int units) { s.insert(s.end(), (size_t)units * 64, uint4{0, 0, 0, 0}); };
+                pack_gemm(s, p16, D.get("pose_embd.weight"), 128, kFeats, range(0, 8), range(0, 22));   // 11 k-pairs x 8 output tiles
+                pad(8);
+                for (int b = 0; b < 9; ++b) {
+                    const std::string p = blk_name("encoder", b);
+                    if (b >= 5) {   // skip linear ahead of an output block: the x half (k-tiles 0..7), then the popped-skip half
+                        const float* wskip = D.get("encoder.linear_blocks." + std::to_string(b - 5) + ".weight");
+                        pack_gemm(s, p16, wskip, 128, 256, range(0, 8), range(0, 8));
+                        pack_gemm(s, p16, wskip, 128, 256, range(0, 8), range(8, 16));
+                    }
+                    const float* in_w = D.get(p + ".self_attn.in_proj_weight");
+                    for (int h = 0; h < 4; ++h) {   // per head: stage A = k | v tiles per k-pair; stage B = q, out_proj's k-slice
+                        pack_gemm(s, p16, in_w, 384, 128, {8 + 2 * h, 8 + 2 * h + 1, 16 + 2 * h, 16 + 2 * h + 1}, range(0, 8));
+                        pack_gemm(s, p16, in_w, 384, 128, {2 * h, 2 * h + 1}, range(0, 8));
+                        pack_gemm(s, p16, D.get(p + ".self_attn.out_proj.weight"), 128, 128, range(0, 8), {2 * h, 2 * h + 1});
+                    }
+                    const auto f1 = [&](int ch) { pack_gemm(s, p16, D.get(p + ".linear1.weight"), 512, 128, {2 * ch, 2 * ch + 1}, range(0, 8)); };
+                    const auto f2 = [&](int ch) { pack_gemm(s, p16, D.get(p + ".linear2.weight"), 128, 512, range(0, 8), {2 * ch, 2 * ch + 1}); };
+                    f1(0); pad(8);
+                    for (int ch = 0; ch < 15; ++ch) { f1(ch + 1); f2(ch); }
+                    f2(15); pad(8);
+                }
+                for (int j = 0; j < 5; ++j)   // pose_proj once per row tile of a wave (24 output tiles in two halves of 3 stages)
+                    for (int half = 0; half < 2; ++half)
+                        pack_gemm(s, p16, D.get("pose_proj.weight"), kFeats, 128, range(12 * half, 12 * half + 12), range(0, 8));
+                if (s.size() % ((size_t)kVaeFusedStageUnits * 64) != 0) return fail(AMUSE_ESTATE, "internal: fused denoiser stream is not whole stages");
+                pad(2 * kVaeFusedStageUnits);   // the fetch runs two stages ahead
+                if (upload(&v->fused_w[p16 == PREC_F16], s.data(), s.size() * sizeof(uint4))) return AMUSE_EHIP;
+            }
+        }
         std::vector<float> fb(16 * kFeatTiles, 0.f);
         memcpy(fb.data(), D.get("pose_proj.bias"), kFeats * 4);
         if (upload(&v->final_bias, fb.data(), fb.size() * 4) || upload(&v->emb_bias, D.get("pose_embd.bias"), 128 * 4)) return AMUSE_EHIP;
@@ -280,7 +349,7 @@ void variant_destroy(amuse_ctx* c) {
     amuse_variant* v = c->var;
     if (!v) return;
     void* ptrs[] = {v->dec_w[0], v->dec_w[1], v->dec_w[2], v->dec_w[3], v->rows_w[0], v->rows_w[1], v->rows_w[2], v->rows_w[3], v->pvec, v->m_pe,
-                    v->wkv_t, v->bkv, v->emb_bias, v->final_bias, v->tkv_sched, v->ckv, v->tkv1, v->ws, v->tt};
+                    v->wkv_t, v->bkv, v->emb_bias, v->final_bias, v->tkv_sched, v->ckv, v->tkv1, v->ws, v->tt, v->fused_w[0], v->fused_w[1], v->skip};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     delete v;
@@ -315,8 +384,9 @@ int variant_sample(amuse_ctx* c, const float* con, const float* emo, const float
     const size_t sd = AMUSE_POSE_STATE;
     if (x_init) HIP_TRY(hipMemcpyAsync(out, x_init, (size_t)B * sd * sizeof(float), hipMemcpyDeviceToDevice, st));
     else HIP_TRY(launch_counter_normal(seed, clip0, B, 0, 0, out, st, (int)sd));
-    const int chunk = B < kPoseChunk ? B : kPoseChunk;
-    if (int e = ensure_pose_ws(v, chunk)) return e;
+    const bool fused = use_den_fused(c, precision, B);
+    const int chunk = fused ? B : (B < kPoseChunk ? B : kPoseChunk);
+    if (int e = ensure_pose_ws(v, chunk, fused)) return e;
     for (int step = 0; step < c->T; ++step) {
         for (int b0 = 0; b0 < B; b0 += chunk) {
             const int nb = (B - b0) < chunk ? (B - b0) : chunk;
@@ -330,7 +400,7 @@ int variant_sample(amuse_ctx* c, const float* con, const float* emo, const float
             p.ckv = v->ckv ? v->ckv + (size_t)b0 * ncond * kTkv : nullptr;
             p.lengths_dev = nullptr;   // the sampling loop passes full lengths (infer_ldm.py:135)
             p.ncond = ncond; p.step = step; p.seed = seed; p.clip0 = clip0 + (uint64_t)b0;
-            if (int e = pose_step(c, p, nb, precision, st)) return e;
+            if (int e = pose_step(c, p, nb, precision, fused, st)) return e;
         }
         if (traj_out) HIP_TRY(hipMemcpyAsync(traj_out + (size_t)step * B * sd, out, (size_t)B * sd * sizeof(float), hipMemcpyDeviceToDevice, st));
     }
@@ -368,8 +438,9 @@ int variant_denoise(amuse_ctx* c, const float* x_t, const int* timesteps, bool p
     if (tap_out) return fail(AMUSE_EINVAL, "taps exist for the latent variants only");
     if (int e = stage_lengths_v(c, lengths, B, st)) return e;
     const size_t sd = AMUSE_POSE_STATE;
-    const int chunk = B < kPoseChunk ? B : kPoseChunk;
-    if (int e = ensure_pose_ws(v, chunk)) return e;
+    const bool fused = use_den_fused(c, precision, B);
+    const int chunk = fused ? B : (B < kPoseChunk ? B : kPoseChunk);
+    if (int e = ensure_pose_ws(v, chunk, fused)) return e;
     for (int b0 = 0; b0 < B; b0 += chunk) {
         const int nb = (B - b0) < chunk ? (B - b0) : chunk;
         PoseStep p{};
@@ -380,7 +451,7 @@ int variant_denoise(amuse_ctx* c, const float* x_t, const int* timesteps, bool p
         p.ckv = v->ckv ? v->ckv + (size_t)b0 * ncond * kTkv : nullptr;
         p.lengths_dev = lengths ? c->d_lengths + b0 : nullptr;
         p.ncond = ncond;
-        if (int e = pose_step(c, p, nb, precision, st)) return e;
+        if (int e = pose_step(c, p, nb, precision, fused, st)) return e;
     }
     return 0;
 }

@@ -45,10 +45,34 @@ def mapinfo2takes(info, trainer=False):
     raise Exception("Unknown emotion: ", info)
 
 
+def denoiser_variant(arch_denoiser: Optional[dict]):
+    """(arch, diffusion_only) of configs/<arch>.json "arch_denoiser" (denoiser.py:20-61), refusing what the kernels are not
+    specialised for.  None (a configuration without the section) = the shipped one."""
+    if arch_denoiser is None:
+        return "trans_enc", False
+    a = arch_denoiser
+    arch, pose = a.get("arch", "trans_enc"), bool(a.get("diffusion_only", False))
+    if arch not in ("trans_enc", "trans_dec"):
+        raise ValueError(f"Not supported architechure{arch}!")          # denoiser.py:133
+    want = {"ff_size": 512, "num_layers": 9, "num_heads": 4, "normalize_before": False, "activation": "gelu",
+            "position_embedding": "learned", "cond_dim": 256, "freq_shift": 0, "pe_type": "mld", "flip_sin_to_cos": True}
+    bad = {k: a[k] for k, v in want.items() if k in a and a[k] != v}
+    if "latent_dim" in a and a["latent_dim"][-1] != 128:
+        bad["latent_dim"] = a["latent_dim"]
+    if arch == "trans_enc" and not a.get("ablation_skip_connection", True):
+        bad["ablation_skip_connection"] = False      # nn.TransformerEncoder without skips: not built
+    if arch == "trans_dec" and a.get("return_intermediate_dec", False):
+        bad["return_intermediate_dec"] = True
+    if bad:
+        raise NotImplementedError(f"the HIP kernels are specialised for configs/diff_latent_v2.json's denoiser; unsupported: {bad}")
+    return arch, pose
+
+
 class PretrainedLPDM_v1:
     def __init__(self, base_prior=None, base_con_ae=None, base_emo_ae=None, base_audio_ae=None,
                  audio_encoder: Optional[Callable] = None):
         self.base_vae = base_prior      # kept for signature compatibility (scripts/main.py:217); unused
+        self.arch, self.diffusion_only = "trans_enc", False   # Denoiser variant (setup reads configs/<arch>.json "arch_denoiser")
         self.audio_encoder = audio_encoder
         self.audio_engine: Optional[AudioEngine] = None
         self.engine: Optional[HipEngine] = None
@@ -67,8 +91,6 @@ class PretrainedLPDM_v1:
         self.smplx_rep = ld["smplx_rep"]
         if self.smplx_rep != "6D" or not ld["smplx_data"] or ld["skip_trans"] or ld["train_upper_body"]:
             raise NotImplementedError("the HIP path covers smplx_data + smplx_rep 6D (333 features) only")
-        if diffonly:
-            raise NotImplementedError("diffusion_only is refused by the reference too (infer_ldm.py:177)")
         for k in ("style_transfer", "emotion_control", "content_control", "style_Xemo_transfer"):
             setattr(self, k, config["TRAIN_PARAM"]["test"][k]["use"])
         self.seq_len = config["DATA_PARAM"]["Bvh"]["train_pose_framelen"]
@@ -85,13 +107,14 @@ class PretrainedLPDM_v1:
                 self.ldm_cfg = json.load(f)
         if backup_cfg is not None:
             raise NotImplementedError("Backup for LPDM not implemented yet!")
+        self.arch, self.diffusion_only = denoiser_variant(self.ldm_cfg.get("arch_denoiser"))
         model_dir = root / saved / ld["pretrained_lpdm"]
         lat = ckpt.pick_checkpoint(model_dir, "latdiff", ep_ldm)
         ldm_epoch = ckpt.epoch_of(lat)
         pri = ckpt.pick_checkpoint(model_dir, "prior", ldm_epoch if ep_prior == "best" else ep_prior)
         print("[LDM] <===== Chosen LDM model based on total loss: ", lat, " =====>")
         print("[LATDIFF] <===== Chosen VAE model based on total loss: ", pri, " =====>")
-        self._build(ckpt.load_denoiser_checkpoint(lat), ckpt.load_prior_checkpoint(pri), device)
+        self._build(ckpt.load_denoiser_checkpoint(lat, self.arch, self.diffusion_only), ckpt.load_prior_checkpoint(pri), device)
         # the audio encoders (infer_ldm.py:111-114 -> Pretrained_AST_EVP.get_model, infer_pretrained_ast_evp.py:12-18):
         # <root>/saved-models/<TRAIN_PARAM[TRAIN_PARAM.tag].pretrained_ast>/*.pt - always under "saved-models", also on
         # the cluster layout.  The reference fails in iterdir() when the directory is missing; an injected
@@ -118,14 +141,18 @@ class PretrainedLPDM_v1:
         self.audio_engine = AudioEngine(con_sd, emo_sd, sty_sd, self.device, norm_mean, norm_std, frame_based_feats)
 
     @classmethod
-    def from_state_dicts(cls, denoiser_sd: Dict[str, np.ndarray], prior_sd: Dict[str, np.ndarray],
-                         ldm_cfg: Optional[dict] = None, device="cuda:0", seed: int = 2024):
+    def from_state_dicts(cls, denoiser_sd: Dict[str, np.ndarray], prior_sd: Optional[Dict[str, np.ndarray]],
+                         ldm_cfg: Optional[dict] = None, device="cuda:0", seed: int = 2024, arch: str = "trans_enc",
+                         diffusion_only: bool = False):
+        """arch / diffusion_only: the Denoiser variant the state dict belongs to (configs/diff_latent_v2.json "arch_denoiser");
+        prior_sd may be None for a diffusion_only denoiser, which never decodes."""
         self = cls()
+        self.arch, self.diffusion_only = arch, bool(diffusion_only)
         self.ldm_cfg = ldm_cfg or {"scheduler": dict(sch.DEFAULT_SCHED_CFG, set_alpha_to_one=False, steps_offset=1,
                                                      num_inference_timesteps=50, eta=0.0),
                                    "noisy_scheduler": dict(sch.DEFAULT_SCHED_CFG, variance_type="fixed_small",
                                                            clip_sample=False, prediction_type="epsilon")}
-        self.seq_len, self.seed, self.smplx_rep, self.diffonly = 300, seed, "6D", False
+        self.seq_len, self.seed, self.smplx_rep, self.diffonly = 300, seed, "6D", bool(diffusion_only)
         for k in ("style_transfer", "emotion_control", "content_control", "style_Xemo_transfer"):
             setattr(self, k, False)
         self._build(denoiser_sd, prior_sd, device)
@@ -133,14 +160,14 @@ class PretrainedLPDM_v1:
 
     def _build(self, denoiser_sd, prior_sd, device):
         self.device = torch.device(device)
-        self.engine = HipEngine(denoiser_sd, prior_sd, self.device)
+        self.engine = HipEngine(denoiser_sd, prior_sd, self.device, arch=self.arch, diffusion_only=self.diffusion_only)
         ns = self.ldm_cfg.get("noisy_scheduler")
         if ns is not None:   # add_noise coefficients of diffusion_forward follow the loaded DDPMScheduler config (ldm.py:41-49)
             self.engine.set_noisy_scheduler(num_train_timesteps=ns["num_train_timesteps"], beta_start=ns["beta_start"],
                                             beta_end=ns["beta_end"], beta_schedule=ns["beta_schedule"])
         self.num_inference_timesteps = self.ldm_cfg["scheduler"]["num_inference_timesteps"]
         self.eta = self.ldm_cfg["scheduler"]["eta"]
-        self.latent_dim = [1, 128]
+        self.latent_dim = [300, 333] if self.diffusion_only else [1, 128]   # shape of the sampled state (infer_ldm.py:137-141)
         self._tables = {}
         self.set_sampler(self.sampler)
 
@@ -161,8 +188,11 @@ class PretrainedLPDM_v1:
         z_emo / z_sty may be None (the token is dropped, denoiser.py:159-171).  Extra keyword arguments
         (explicit noise, global clip index for sharded batches) are extensions; the reference draws the
         initial latent from the device RNG."""
-        if self.diffonly:
-            raise  # noqa: PLE0704 - mirrors the bare `raise` at infer_ldm.py:177
+        if self.diffonly and not self.diffusion_only:
+            raise  # noqa: PLE0704 - mirrors the bare `raise` at infer_ldm.py:177: a latent denoiser with the decode switched off
+        # A diffusion_only denoiser samples the [300][333] feature sequence itself (denoiser.py:64-66,177-187); the reference's own loop
+        # cannot run it (its initial noise keeps the latent shape, infer_ldm.py:137-141, and the decode-free branch is a bare
+        # `raise`), so this is where the mirror goes beyond it: the sampled features through the 6D -> axis-angle tail of :168-173.
         assert z_con.shape[0] == bsz, f"bsz {bsz} != z_con batch {z_con.shape[0]}"
         c0 = self._clip_counter if clip_index0 is None else clip_index0
         out = self.engine.diffusion_backward(z_con, z_emo, z_sty, self.precision, self.quat_mode, self.seed, c0,

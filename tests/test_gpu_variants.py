@@ -216,3 +216,95 @@ def test_variant_weight_update_equals_fresh_context(env, g):
     finally:
         fresh.close()
         eng.update_weights(denoiser_sd=wts.make_denoiser_weights(0, arch, pose))
+
+
+@pytest.mark.parametrize("arch,pose", VARIANTS)
+def test_host_mirror_setup_reads_the_denoiser_variant_from_the_config(tmp_path, arch, pose):
+    """PretrainedLPDM_v1.setup with configs/<arch>.json "arch_denoiser" naming a variant (infer_ldm.py:66-73 builds Denoiser from
+    it): the checkpoint's entry count is asserted against THAT state dict (infer_ldm.py:103), diffusion_backward returns the
+    reference's two keys; diffusion_only samples the feature sequence itself (the reference's loop cannot: see the mirror)."""
+    import json
+    from test_gpu_host_mirror import _mini_config
+    from amuse_amd import checkpoint as ckpt, weights as wts
+    from amuse_amd.infer_ldm import PretrainedLPDM_v1
+    from oracle import amuse_oracle as orc
+    cfg, processed, model_dir = _mini_config(tmp_path)
+    p = processed.parents[1] / "configs/diff_latent_v2.json"
+    ldm = json.load(open(p))
+    ldm["arch_denoiser"] = {"nfeats": 201, "latent_dim": [1, 128], "ff_size": 512, "num_layers": 9, "num_heads": 4, "dropout": 0.1,
+                            "arch": arch, "normalize_before": False, "activation": "gelu", "position_embedding": "learned",
+                            "cond_dim": 256, "freq_shift": 0, "ablation_skip_connection": True, "pe_type": "mld",
+                            "flip_sin_to_cos": True, "return_intermediate_dec": False, "diffusion_only": pose}
+    json.dump(ldm, open(p, "w"))
+    wd, wp = wts.make_denoiser_weights(0, arch, pose), wts.make_prior_weights(0)
+    ckpt.save_reference_format(model_dir, wd, wp, epoch=6000, total=0.0123)
+    m = PretrainedLPDM_v1(base_prior=None, audio_encoder=lambda wave: (torch.zeros(1, 256),) * 3)
+    assert m.setup(cfg, "cuda:0", processed, None, False, verbose=False, diffonly=pose) == 6000
+    assert (m.arch, m.diffusion_only) == (arch, pose) and m.latent_dim == ([300, 333] if pose else [1, 128])
+    gen = torch.Generator().manual_seed(11)
+    con, emo, sty = (torch.randn(2, 256, generator=gen) for _ in range(3))
+    x = torch.randn(2, *m.latent_dim, generator=gen)[:, 0] if not pose else torch.randn(2, 300, 333, generator=gen)
+    out = m.diffusion_backward(2, con, emo, sty, x_init=x, return_latents=True)
+    assert set(out) == {"poses", "trans", "latents"} and out["poses"].shape == (2, 300, 55, 3) and out["trans"].shape == (2, 300, 3)
+    ref = orc.sample_variant(orc.to_torch(wd), orc.DDIM(), con, emo, sty, x, arch, pose)
+    assert _err(out["latents"], ref) < 1e-4
+    # a checkpoint of another variant fails the count assertion, as the reference's loader does
+    ckpt.save_reference_format(model_dir, wts.make_denoiser_weights(0), wp, epoch=6000, total=0.0123)
+    with pytest.raises(AssertionError):
+        PretrainedLPDM_v1(audio_encoder=lambda wave: None).setup(cfg, "cuda:0", processed, None, False, diffonly=pose)
+    ldm["arch_denoiser"]["num_layers"] = 7
+    json.dump(ldm, open(p, "w"))
+    with pytest.raises(NotImplementedError):
+        PretrainedLPDM_v1(audio_encoder=lambda wave: None).setup(cfg, "cuda:0", processed, None, False, diffonly=pose)
+
+
+def test_fused_pose_step_kernel_vs_staged_and_golden(g):
+    """k_den_fused (one persistent workgroup per clip, bf16 / fp16 operands; chosen from 64 clips up or pinned) against the staged
+    kernels of the same mode (same arithmetic, other summation order), the reference's goldens (16-bit bars), the ragged-length
+    zeroing, and its own invariants: batch position, in-kernel noise == explicit noise, shards - bitwise."""
+    from amuse_amd import scheduler as sch, weights as wts
+    from amuse_amd.engine import HipEngine
+    arch, pose, tag = "trans_enc", True, "trans_enc_pose"
+    eng = HipEngine(wts.make_denoiser_weights(0, arch, pose), None, "cuda:0", arch=arch, diffusion_only=pose)
+    try:
+        con, emo, sty, x = inputs(g, pose)
+        for prec, bar, close in (("bf16", 8e-2, 6e-2), ("fp16", 1.5e-2, 1e-2)):
+            eng.set_decode_path("staged")
+            es = eng.denoise_step(x, 501, con, emo, sty, prec)
+            eng.set_decode_path("fused")
+            ef = eng.denoise_step(x, 501, con, emo, sty, prec)
+            assert torch.isfinite(ef).all()
+            assert _err(cut(ef, pose), g[f"{tag}/eps_t501"]) < bar, prec
+            assert _err(ef, es) < close and float((ef - es).abs().mean()) < close / 8, prec
+            e3 = eng.denoise_step(x, 501, con, None, sty, prec)                  # S = 303
+            assert _err(cut(e3, pose), g[f"{tag}/eps_t501_noemo"]) < bar
+            e2 = eng.denoise_step(x, 501, con, None, None, prec)                 # S = 302
+            assert _err(cut(e2, pose), g[f"{tag}/eps_t501_consolo"]) < bar
+            lens = [int(v) for v in g["lengths_ragged"]]
+            er = eng.denoise_step(x, 501, con, emo, sty, prec, lengths=lens)
+            assert torch.all(er[1, lens[1]:] == 0) and torch.equal(er[1, :lens[1]], ef[1, :lens[1]]) and torch.equal(er[0], ef[0])
+            # clips are independent of their batch position
+            x5 = np.concatenate([x[1:], x, x[:1]]); c5 = lambda v: np.concatenate([v[1:], v, v[:1]])
+            e5 = eng.denoise_step(x5, 501, c5(con), c5(emo), c5(sty), prec)
+            assert torch.equal(e5[1], ef[0]) and torch.equal(e5[0], ef[1]) and torch.equal(e5[3], ef[0])
+        # sampling: DDIM-10 fused vs staged drift, and the DDPM invariants on the fused kernel
+        B = 3
+        gq = torch.Generator().manual_seed(21)
+        cc, ce, cs = (torch.randn(B, 256, generator=gq) for _ in range(3))
+        x0 = torch.randn(B, 300, 333, generator=gq)
+        eng.set_schedule(sch.ddim_table(10))
+        eng.set_decode_path("staged")
+        ls = eng.sample(cc, ce, cs, "fp16", x_init=x0)
+        l32 = eng.sample(cc, ce, cs, "fp32", x_init=x0)
+        eng.set_decode_path("fused")
+        lf = eng.sample(cc, ce, cs, "fp16", x_init=x0)
+        assert float((lf - l32).abs().max()) < 2 * max(float((ls - l32).abs().max()), 1e-3)   # no worse than the staged fp16 mode's drift
+        eng.set_schedule(sch.ddpm_table(4))
+        full = eng.sample(cc, ce, cs, "bf16", seed=9, clip_index0=100)
+        nz = torch.stack([eng.counter_normal(9, 100, B, s_, 1) for s_ in range(4)])
+        assert torch.equal(full, eng.sample(cc, ce, cs, "bf16", x_init=eng.counter_normal(9, 100, B, 0, 0), step_noise=nz))
+        parts = torch.cat([eng.sample(cc[:1], ce[:1], cs[:1], "bf16", seed=9, clip_index0=100),
+                           eng.sample(cc[1:], ce[1:], cs[1:], "bf16", seed=9, clip_index0=101)])
+        assert torch.equal(full, parts)
+    finally:
+        eng.close()
