@@ -27,6 +27,7 @@ EXPORTS = [
     "amuse_debug_gemm",
     "amuse_debug_tile", "amuse_debug_f16_split", "amuse_debug_set_decode_tap",
     "amuse_create_arch", "amuse_denoiser_param_count", "amuse_arch", "amuse_state_dim", "amuse_denoise_step_pose", "amuse_feats_to_smplx",
+    "amuse_debug_set_ablation",
 ]
 
 
@@ -70,6 +71,8 @@ def load() -> C.CDLL:
     lib.amuse_denoise_step_pose.argtypes = [vp, fp, C.c_int, fp, fp, fp, ip, C.c_int, C.c_int, fp, vp]
     lib.amuse_feats_to_smplx.restype = C.c_int
     lib.amuse_feats_to_smplx.argtypes = [vp, fp, C.c_int, C.c_int, fp, fp, vp]
+    lib.amuse_debug_set_ablation.restype = C.c_int
+    lib.amuse_debug_set_ablation.argtypes = [vp, C.c_int]
     lib.amuse_update_weights.restype = C.c_int
     lib.amuse_update_weights.argtypes = [vp, C.POINTER(C.c_float), C.c_size_t, C.POINTER(C.c_float), C.c_size_t, C.c_int, vp]
     lib.amuse_update_weights_device.restype = C.c_int

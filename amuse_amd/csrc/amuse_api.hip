@@ -646,6 +646,13 @@ int amuse_debug_set_decode_tap(amuse_ctx* c, float* tap_out) {
     return 0;
 }
 
+int amuse_debug_set_ablation(amuse_ctx* c, int mask) {
+    if (!c) return fail(AMUSE_EINVAL, "ctx is NULL");
+    if (mask < 0 || mask > 1) return fail(AMUSE_EINVAL, "bad ablation mask %d", mask);
+    c->ablate = mask;
+    return 0;
+}
+
 int amuse_set_schedule(amuse_ctx* c, const amuse_schedule* s, void* stream) {
     if (!c || !s) return fail(AMUSE_EINVAL, "NULL argument");
     if (s->n_steps < 1 || s->n_steps > AMUSE_MAX_STEPS) return fail(AMUSE_EINVAL, "n_steps %d out of range", s->n_steps);
@@ -819,6 +826,7 @@ int amuse_vae_decode(amuse_ctx* c, const float* z, const int* lengths, int B, in
             fa.trans_out = trans_out ? trans_out + (size_t)b0 * kFrames * 3 : nullptr;
             fa.B = nb; fa.quat_mode = quat_mode;
             fa.tap_out = b0 == 0 ? c->decode_tap : nullptr;   // (amuse_debug_set_decode_tap: tests)
+            fa.ablate_attention = c->ablate & 1;
             HIP_TRY(precision == PREC_F16 ? launch_vae_fusedh(fa, st) : launch_vae_fused(fa, st));
         }
         return 0;

@@ -198,8 +198,104 @@ __device__ __forceinline__ float max3(float a, float b, float c) { return fmaxf(
 // too scarce (x + xb of three tiles = 144 of 256) for hipcc to hoist the reads itself.  So a chunk's four K fragments are
 // read as ONE batch in front of its four score MFMAs, and its four V^T fragments as one batch right behind them - they
 // land while the softmax arithmetic runs.
+#ifndef AMUSE_F_ATTN_PIPE
+#define AMUSE_F_ATTN_PIPE 0
+#endif
+#if AMUSE_F_ATTN_PIPE
+// (-DAMUSE_F_ATTN_PIPE=1, A/B only: bitwise the same outputs, NOT faster - 0.759 -> 0.753 ms per 256-clip decode, inside the noise,
+// profiles/r04_fused_attention_ablation.txt: the loop is bound by the exponentials' issue time, not by the hand-overs this removes.)
+// Software-pipelined over the chunks.  A wave issues in order, so in the plain loop below every chunk starts with four ds_reads and
+// four score MFMAs that wait for them, and the softmax arithmetic behind them waits for the MFMAs: LDS latency + MFMA latency in
+// series with the VALU phase, and the SIMD's other wave - in lock step since the last barrier - is in the same phase.  Here chunk
+// c + 1's K fragments are read at the top of chunk c, its score MFMAs are issued BEHIND chunk c's maximum (they take the updated
+// running maximum as C operand) and IN FRONT of chunk c's exponentials, under which they execute; chunk c's PV MFMAs run under the
+// reads and the maximum of chunk c + 1.
+template <bool NOATTN = false>
 __device__ __forceinline__ OPV attend(const uint4* Kb, const uint4* Vt, OPV qb, int len, int g, int r) {
-    if constexpr ((AMUSE_FABL & 2) != 0) return qb;
+    if constexpr (NOATTN || (AMUSE_FABL & 2) != 0) return qb;
+    const int fs = frag_slot(g, r);
+    float m_run = 0.f;
+    f32x4 o[2] = {splat4(0.f), splat4(0.f)};
+    const OPV ones = __builtin_bit_cast(OPV, r == 0 ? uint4{OP_ONE2, OP_ONE2, OP_ONE2, OP_ONE2} : uint4{0u, 0u, 0u, 0u});
+    f32x4 os = splat4(0.f);
+    f32x4 st[4];
+    {
+        uint4 kf[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) kf[i] = Kb[i * 64 + fs];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) st[i] = OP_MFMA(__builtin_bit_cast(OPV, kf[i]), qb, splat4(0.f));
+    }
+#pragma unroll
+    for (int ch = 0; ch < kPairs / 2; ++ch) {
+        constexpr int kLast = kPairs / 2 - 1;
+        uint4 kf[4], vf[4];
+        if (ch < kLast) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) kf[i] = Kb[(4 * (ch + 1) + i) * 64 + fs];
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) vf[i] = Vt[(4 * ch + i) * 64 + fs];   // (pair, td) = (2 ch + i / 2, i % 2)
+        __builtin_amdgcn_sched_barrier(0);
+        const int k0 = 64 * ch;
+        if (k0 + 64 > len) {
+            int lim = len - k0 - 4 * g;   // element (i, m) of the chunk is valid iff 16 i + m < lim
+            asm volatile("" : "+v"(lim));
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int m = 0; m < 4; ++m) st[i][m] = (16 * i + m < lim) ? st[i][m] : -INFINITY;
+        }
+        float mx = max3(max3(st[0][0], st[0][1], st[0][2]), max3(st[0][3], st[1][0], st[1][1]), max3(st[1][2], st[1][3], st[2][0]));
+        mx = max3(mx, max3(st[2][1], st[2][2], st[2][3]), max3(st[3][0], st[3][1], st[3][2]));
+        mx = fmaxf(mx, st[3][3]);
+        if (ch == 0 || __builtin_amdgcn_ballot_w64(mx > 0.f) != 0) {   // (wave-uniform)
+            mx = allreduce_g_max(mx);
+            const float d = ch == 0 ? mx : fmaxf(mx, 0.f);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) st[i] -= splat4(d);
+            if (ch > 0) {
+                const float alpha = __builtin_amdgcn_exp2f(-d);
+                os *= alpha;
+                o[0] *= alpha;
+                o[1] *= alpha;
+            }
+            m_run += d;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        f32x4 stn[4];
+        if (ch < kLast) {
+            const f32x4 c0 = splat4(-m_run);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) stn[i] = OP_MFMA(__builtin_bit_cast(OPV, kf[i]), qb, c0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        f32x4 p[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const bool beyond = 64 * ch + 16 * i >= kFrames;
+#pragma unroll
+            for (int m = 0; m < 4; ++m) p[i][m] = beyond ? 0.f : __builtin_amdgcn_exp2f(st[i][m]);
+        }
+#pragma unroll
+        for (int pr = 0; pr < 2; ++pr) {
+            const OPV pb = OP_PACK(p[2 * pr], p[2 * pr + 1]);
+            o[0] = OP_MFMA(__builtin_bit_cast(OPV, vf[2 * pr]), pb, o[0]);
+            o[1] = OP_MFMA(__builtin_bit_cast(OPV, vf[2 * pr + 1]), pb, o[1]);
+            os = OP_MFMA(ones, pb, os);
+        }
+        if (ch < kLast) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) st[i] = stn[i];
+        }
+    }
+    const float inv = __builtin_amdgcn_rcpf(allreduce_g_sum(os[0]));
+    return OP_PACK(o[0] * inv, o[1] * inv);
+}
+#else
+template <bool NOATTN = false>
+__device__ __forceinline__ OPV attend(const uint4* Kb, const uint4* Vt, OPV qb, int len, int g, int r) {
+    if constexpr (NOATTN || (AMUSE_FABL & 2) != 0) return qb;
     const int fs = frag_slot(g, r);
     // Scores leave the MFMAs RELATIVE to the row's running maximum (C operand = -m_run; chunk 0 starts from 0 and takes its own
     // maximum - the sequence has at least one key), so in the common chunk - the maximum did not move for any row of the wave -
@@ -282,6 +378,8 @@ __device__ __forceinline__ OPV attend(const uint4* Kb, const uint4* Vt, OPV qb, 
 }
 
 
+#endif
+
 // MODE 0: input block (push the skip), 1: middle block, 2: output block (skip linear first)
 // debugging taps (TAP instantiation only, clip 0): the wave's tiles of the fp32 residual stream, row-major [300][128]
 template <int NT>
@@ -299,7 +397,9 @@ __device__ __forceinline__ void store_tap(float* tap, int slot, const f32x4 (&x)
 // ENCL: a TransformerEncoderLayer (cross_attention.py:259-272: no cross-attention, norm2 behind the FFN) instead of the
 // TransformerDecoderLayer with its one-token memory - the diffusion_only Denoiser's blocks (k_den_fused.hip).  S = rows of the clip
 // (300 frames; 302..304 with the Denoiser's condition tokens in front).  pvec_g: the global parameter vector (skip-linear biases).
-template <int NT, int MODE, bool TAP, bool ENCL = false>
+// NOATTN: the timing ablation behind bench.py's attention-only figure (amuse_debug_set_ablation): the block without its
+// softmax(Q K^T) V - q, k, v, the K / V images, out_proj and every barrier stay, so full - ablated = the attention's time.
+template <int NT, int MODE, bool TAP, bool ENCL = false, bool NOATTN = false>
 __device__ __forceinline__ void decoder_block(f32x4 (&x)[NT][kTiles], Stager& sg, const float* pvec_g, float* tap_out, int blk, int tile0,
                                               const float* pv, const float* pv_next_src, unsigned pv_next_dst, const float* cal,
                                               char* kv, uint4* skipbuf, int len, int wave, int lane, const int S = kFrames) {
@@ -413,7 +513,7 @@ __device__ __forceinline__ void decoder_block(f32x4 (&x)[NT][kTiles], Stager& sg
             const uint4* Vq = reinterpret_cast<const uint4*>(Vt);
 #pragma unroll 1
             for (int j = 0; j < NT; ++j) {
-                const OPV o1 = attend(Kb, Vq, ob[0][0], len, g, r);
+                const OPV o1 = attend<NOATTN>(Kb, Vq, ob[0][0], len, g, r);
 #pragma unroll
                 for (int jj = 0; jj + 1 < NT; ++jj) ob[jj][0] = ob[jj + 1][0];
                 ob[NT - 1][0] = o1;

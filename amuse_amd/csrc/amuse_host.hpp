@@ -288,6 +288,7 @@ struct amuse_ctx {
     int clips_per_group = 0;
     int decode_path = AMUSE_DECODE_AUTO;
     float* decode_tap = nullptr;       // amuse_debug_set_decode_tap
+    int ablate = 0;                    // amuse_debug_set_ablation
     // denoiser
     uint4* den_w[3] = {nullptr, nullptr, nullptr};   // 4-wave kernel streams: fp32 | bf16 | split-fp16 (fp32x)
     uint32_t den_wave_units[3] = {0, 0, 0};

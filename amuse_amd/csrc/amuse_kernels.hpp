@@ -197,6 +197,7 @@ struct VaeFusedArgs {
     float* trans_out;          // [B][300][3] or null
     float* tap_out;            // [10][300][128] or null: clip 0's fp32 residual stream after blocks 0..8 and after decoder.norm (tests)
     int B, quat_mode;
+    int ablate_attention;      // 1: the instantiation without softmax(Q K^T) V (amuse_debug_set_ablation: timing only, wrong outputs)
 };
 constexpr size_t kVaeFusedSkipBytesPerClip = 4 * 20 * 4 * 64 * 16;
 hipError_t launch_vae_fused(const VaeFusedArgs& a, hipStream_t stream);
@@ -219,6 +220,7 @@ struct DenFusedArgs {
     const int* lengths;        // dev [B] or null
     uint64_t seed, clip0;
     int step, B, npre;
+    int ablate_attention;      // as VaeFusedArgs
 };
 hipError_t launch_den_fused(const DenFusedArgs& a, hipStream_t stream);
 hipError_t launch_den_fusedh(const DenFusedArgs& a, hipStream_t stream);   // fp16 operands (k_den_fusedh.hip)

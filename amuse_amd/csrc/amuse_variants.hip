@@ -160,6 +160,7 @@ int pose_step(amuse_ctx* c, const PoseStep& p, int nb, int precision, bool fused
         fa.pe = c->den_pe; fa.ttok = p.ttok; fa.ttok_stride = p.ttok_stride; fa.ctok = p.cond_tok; fa.skip = v->skip;
         fa.eps_out = p.eps_out; fa.coef = p.coef; fa.step_noise = p.step_noise; fa.lengths = p.lengths_dev;
         fa.seed = p.seed; fa.clip0 = p.clip0; fa.step = p.step; fa.B = nb; fa.npre = 1 + p.ncond;
+        fa.ablate_attention = c->ablate & 1;
         // the kernel updates its state array in place; a teacher-forced step (no coefficients) only reads it
         if (p.x_out && p.x_out != p.x_in) HIP_TRY(hipMemcpyAsync(p.x_out, p.x_in, (size_t)nb * AMUSE_POSE_STATE * sizeof(float), hipMemcpyDeviceToDevice, st));
         fa.x = p.x_out ? p.x_out : const_cast<float*>(p.x_in);

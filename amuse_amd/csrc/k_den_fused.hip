@@ -53,7 +53,7 @@ __device__ __forceinline__ void load_xt(f32x4 (&v)[NT][4], const float* xb, int 
     }
 }
 
-template <int NT>
+template <int NT, bool NOATTN>
 __device__ __forceinline__ void den_tiles(const DenFusedArgs& a, char* smem, Stager& sg, int tile0, int b, int wave, int lane) {
     const int g = lane >> 4, r = lane & 15;
     char* kv = smem + kOffKv;
@@ -101,13 +101,13 @@ __device__ __forceinline__ void den_tiles(const DenFusedArgs& a, char* smem, Sta
     const float* nocal = pvl;   // (no cross-attention constants in encoder blocks; never read)
 #pragma unroll 1
     for (int blk = 0; blk < 4; ++blk)
-        decoder_block<NT, 0, false, true>(x, sg, a.pvec, nullptr, blk, tile0, pvl + (blk & 1) * (kPvSlot / 4), a.pvec + (blk + 1) * PV_BLOCK,
+        decoder_block<NT, 0, false, true, NOATTN>(x, sg, a.pvec, nullptr, blk, tile0, pvl + (blk & 1) * (kPvSlot / 4), a.pvec + (blk + 1) * PV_BLOCK,
                                           lds0 + kOffPv + ((blk + 1) & 1) * kPvSlot, nocal, kv, skipbuf, S, wave, lane, S);
-    decoder_block<NT, 1, false, true>(x, sg, a.pvec, nullptr, 4, tile0, pvl, a.pvec + 5 * PV_BLOCK, lds0 + kOffPv + kPvSlot, nocal, kv, skipbuf, S,
+    decoder_block<NT, 1, false, true, NOATTN>(x, sg, a.pvec, nullptr, 4, tile0, pvl, a.pvec + 5 * PV_BLOCK, lds0 + kOffPv + kPvSlot, nocal, kv, skipbuf, S,
                                       wave, lane, S);
 #pragma unroll 1
     for (int blk = 5; blk < kLayers; ++blk)
-        decoder_block<NT, 2, false, true>(x, sg, a.pvec, nullptr, blk, tile0, pvl + (blk & 1) * (kPvSlot / 4),
+        decoder_block<NT, 2, false, true, NOATTN>(x, sg, a.pvec, nullptr, blk, tile0, pvl + (blk & 1) * (kPvSlot / 4),
                                           blk + 1 < kLayers ? a.pvec + (blk + 1) * PV_BLOCK : nullptr,
                                           lds0 + kOffPv + ((blk + 1) & 1) * kPvSlot, nocal, kv, skipbuf, S, wave, lane, S);
     // ---------------- encoder.norm -> pose_proj (333 outputs in 24 tiles) -> mask -> eps_hat / scheduler update.  As in the decode
@@ -190,6 +190,7 @@ __device__ __forceinline__ void den_tiles(const DenFusedArgs& a, char* smem, Sta
     }
 }
 
+template <bool NOATTN>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void OP_KERNEL(DenFusedArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63;
@@ -205,8 +206,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     sg.ridx = 0;
     stage_fetch(sg);
     stage_fetch(sg);
-    if (wave < 4) den_tiles<3>(a, smem, sg, wave, b, wave, lane);
-    else den_tiles<2>(a, smem, sg, wave + 8, b, wave, lane);
+    if (wave < 4) den_tiles<3, NOATTN>(a, smem, sg, wave, b, wave, lane);
+    else den_tiles<2, NOATTN>(a, smem, sg, wave + 8, b, wave, lane);
 }
 
 }  // namespace
@@ -215,11 +216,14 @@ hipError_t OP_LAUNCH(const DenFusedArgs& a, hipStream_t stream) {
     static DeviceOnce once;
     int dev_;
     if (!once.done(&dev_)) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&OP_KERNEL), hipFuncAttributeMaxDynamicSharedMemorySize, kVaeFusedLdsBytes);
-        if (e != hipSuccess) return e;
+        for (const void* k : {reinterpret_cast<const void*>(&OP_KERNEL<false>), reinterpret_cast<const void*>(&OP_KERNEL<true>)}) {
+            hipError_t e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, kVaeFusedLdsBytes);
+            if (e != hipSuccess) return e;
+        }
         once.set(dev_);
     }
-    hipLaunchKernelGGL(OP_KERNEL, dim3(a.B), dim3(512), kVaeFusedLdsBytes, stream, a);
+    if (a.ablate_attention) hipLaunchKernelGGL(OP_KERNEL<true>, dim3(a.B), dim3(512), kVaeFusedLdsBytes, stream, a);   // timing ablation (bench.py)
+    else hipLaunchKernelGGL(OP_KERNEL<false>, dim3(a.B), dim3(512), kVaeFusedLdsBytes, stream, a);
     return hipGetLastError();
 }
 

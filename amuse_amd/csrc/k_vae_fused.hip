@@ -48,7 +48,7 @@ namespace amuse {
 namespace {
 
 // everything one wave does for its NT row tiles tile0, tile0 + 4, ...
-template <int NT, bool TAP>
+template <int NT, bool TAP, bool NOATTN>
 __device__ __forceinline__ void decode_tiles(const VaeFusedArgs& a, char* smem, Stager& sg, int tile0, int b, int len,
                                              int wave, int lane) {
     const int g = lane >> 4, r = lane & 15;
@@ -69,12 +69,12 @@ __device__ __forceinline__ void decode_tiles(const VaeFusedArgs& a, char* smem, 
     asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)\n\ts_barrier" ::: "memory");   // parameters, constants and stage 0 are in
 #pragma unroll 1
     for (int blk = 0; blk < 4; ++blk)
-        decoder_block<NT, 0, TAP>(x, sg, a.pvec, a.tap_out, blk, tile0, pvl + (blk & 1) * (kPvSlot / 4), a.pvec + (blk + 1) * PV_BLOCK,
+        decoder_block<NT, 0, TAP, false, NOATTN>(x, sg, a.pvec, a.tap_out, blk, tile0, pvl + (blk & 1) * (kPvSlot / 4), a.pvec + (blk + 1) * PV_BLOCK,
                              lds0 + kOffPv + ((blk + 1) & 1) * kPvSlot, cal, kv, skipbuf, len, wave, lane);
-    decoder_block<NT, 1, TAP>(x, sg, a.pvec, a.tap_out, 4, tile0, pvl, a.pvec + 5 * PV_BLOCK, lds0 + kOffPv + kPvSlot, cal, kv, skipbuf, len, wave, lane);
+    decoder_block<NT, 1, TAP, false, NOATTN>(x, sg, a.pvec, a.tap_out, 4, tile0, pvl, a.pvec + 5 * PV_BLOCK, lds0 + kOffPv + kPvSlot, cal, kv, skipbuf, len, wave, lane);
 #pragma unroll 1
     for (int blk = 5; blk < kLayers; ++blk)
-        decoder_block<NT, 2, TAP>(x, sg, a.pvec, a.tap_out, blk, tile0, pvl + (blk & 1) * (kPvSlot / 4),
+        decoder_block<NT, 2, TAP, false, NOATTN>(x, sg, a.pvec, a.tap_out, blk, tile0, pvl + (blk & 1) * (kPvSlot / 4),
                              blk + 1 < kLayers ? a.pvec + (blk + 1) * PV_BLOCK : nullptr,
                              lds0 + kOffPv + ((blk + 1) & 1) * kPvSlot, cal, kv, skipbuf, len, wave, lane);
     // ---------------- decoder.norm -> final_layer (333 outputs in 24 tiles) -> rotation epilogue.  The stream holds the
@@ -160,7 +160,7 @@ __device__ __forceinline__ void decode_tiles(const VaeFusedArgs& a, char* smem, 
     }
 }
 
-template <bool TAP>
+template <bool TAP, bool NOATTN = false>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void OP_KERNEL(VaeFusedArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63;
@@ -179,8 +179,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     sg.ridx = 0;
     stage_fetch(sg);
     stage_fetch(sg);
-    if (wave < 4) decode_tiles<3, TAP>(a, smem, sg, wave, b, len, wave, lane);
-    else decode_tiles<2, TAP>(a, smem, sg, wave + 8, b, len, wave, lane);
+    if (wave < 4) decode_tiles<3, TAP, NOATTN>(a, smem, sg, wave, b, len, wave, lane);
+    else decode_tiles<2, TAP, NOATTN>(a, smem, sg, wave + 8, b, len, wave, lane);
 }
 
 }  // namespace
@@ -189,7 +189,8 @@ hipError_t OP_LAUNCH(const VaeFusedArgs& a, hipStream_t stream) {
     static DeviceOnce once;
     int dev_;
     if (!once.done(&dev_)) {
-        for (const void* k : {reinterpret_cast<const void*>(&OP_KERNEL<false>), reinterpret_cast<const void*>(&OP_KERNEL<true>)}) {
+        for (const void* k : {reinterpret_cast<const void*>(&OP_KERNEL<false>), reinterpret_cast<const void*>(&OP_KERNEL<true>),
+                              reinterpret_cast<const void*>(&OP_KERNEL<false, true>)}) {
             hipError_t e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, kVaeFusedLdsBytes);
             if (e != hipSuccess) return e;
         }
@@ -201,7 +202,8 @@ hipError_t OP_LAUNCH(const VaeFusedArgs& a, hipStream_t stream) {
         (void)hipMemcpyToSymbol(HIP_SYMBOL(g_fprof_n), &zero, sizeof(int));
     }
 #endif
-    if (a.tap_out) hipLaunchKernelGGL(OP_KERNEL<true>, dim3(a.B), dim3(512), kVaeFusedLdsBytes, stream, a);   // the tapped instantiation (tests)
+    if (a.ablate_attention) hipLaunchKernelGGL((OP_KERNEL<false, true>), dim3(a.B), dim3(512), kVaeFusedLdsBytes, stream, a);   // timing ablation (bench.py)
+    else if (a.tap_out) hipLaunchKernelGGL(OP_KERNEL<true>, dim3(a.B), dim3(512), kVaeFusedLdsBytes, stream, a);   // the tapped instantiation (tests)
     else hipLaunchKernelGGL(OP_KERNEL<false>, dim3(a.B), dim3(512), kVaeFusedLdsBytes, stream, a);
 #if AMUSE_FPROF
     {

@@ -158,6 +158,10 @@ class HipEngine:
         kernel), "staged", "fused" (amuse_hip.h amuse_set_decode_path)."""
         _lib.check(self.lib.amuse_set_decode_path(self.ctx, {"auto": 0, "staged": 1, "fused": 2}[path]))
 
+    def set_ablation(self, mask: int = 0):
+        """amuse_debug_set_ablation: 1 = the fused kernels run without their S ~ 300 self-attention (timing only: bench.py)."""
+        _lib.check(self.lib.amuse_debug_set_ablation(self.ctx, int(mask)))
+
     def set_schedule(self, table: ScheduleTable):
         ts = np.ascontiguousarray(table.timesteps, dtype=np.int32)
         cf = np.ascontiguousarray(table.coef, dtype=np.float32)

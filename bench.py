@@ -3,15 +3,15 @@
 
 One "step" = one full pass of the hot path over one batch of synthetic clips: initial noise ->
 T-step DDPM loop (persistent HIP kernel) -> VAE decode -> 6D->axis-angle, inputs (three 256-d
-condition vectors per clip) already resident in HBM.  Workload at N = 1: BASELINE configs[2] /
-SURVEY.md 8d config 3 - 256 x 10 s clips, 1000-step DDPM, bf16 operands.  At N > 1 every rank runs
-that workload on its own 256 clips (global clip indices rank * 256 ..., counter-based noise keyed by
-them; no collective on the data path - the path shards over independent clips): `value` = the clips
-of ALL ranks / the slowest rank's time, "scaling": "weak".  The strong-scaling shape BASELINE config 3
-names - the SAME 256 clips in total, 256 / N contiguous clips per rank through amuse_amd/shard.py,
-shards bitwise the single-GPU result - is measured beside it and reported as `strong_scaling`
-(a 1000-step chain costs the same 34 ms for 32 clips as for 256, so that figure is flat in N by
-construction: DESIGN.md section 6).
+condition vectors per clip) already resident in HBM.  Workload at every N: BASELINE configs[2] /
+SURVEY.md 8d config 3 - 256 x 10 s clips IN TOTAL, 1000-step DDPM, bf16 operands - sharded 256 / N
+contiguous clips per rank through amuse_amd/shard.py (tiling and decode kernel chosen from the job's
+total, counter-based noise keyed by the global clip index: every sharding reproduces the single-GPU
+result bitwise; no collective on the data path): `value` = those 256 clips x 300 frames / the slowest
+rank's time, "scaling": "strong".  A 1000-step chain costs the same 34 ms for 32 clips as for 256, so
+that figure is flat in N by construction; the shape in which the path does scale
+- every rank its own 256 clips, global clip indices rank * 256 ... - is measured beside it and reported
+as `weak_scaling`.
 
   python bench.py [--gpus N --steps K --warmup W]
 N > 1: one process per GPU.  Under torch.distributed.run (RANK / WORLD_SIZE in the environment) this process IS a rank;
@@ -31,6 +31,7 @@ sys.path.insert(0, str(REPO))
 
 FLOP_PER_CLIP_STEP = 19_120_640          # linears 19,005,440 + attention 115,200
 FLOP_VAE_DECODE_PER_CLIP = 1.76e9
+FLOP_VAE_ATTN_PER_CLIP = 9 * 4 * 2 * 2 * 300 * 300 * 32   # 414.7 MFLOP: nine blocks x four heads x (Q K^T + P V) at S = 300, dh = 32
 MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "fp16": 2500.0, "fp32": 157.3, "fp32x": 2500.0}   # MI355X_MICROARCH.md chip-level parameters (dense; fp32x = fp16 MFMAs)
 KERNEL_NAME = {"bf16": "k_sample8", "fp16": "k_sample8h", "fp32": "k_sample<fp32>", "fp32x": "k_sample8x"}
 # L2 -> CU weight stream per denoising step and CU (every CU re-streams the network each step): bytes per parameter of the MFMA stream
@@ -76,23 +77,13 @@ def cpu_baseline(clips, T, wd, wp):
     gen = torch.Generator().manual_seed(7)
     con, emo, sty, x = (torch.randn(clips, n, generator=gen) for n in (256, 256, 256, 128))
     sched = orc.DDPM(T)
-    n_steps = 12
+    n_steps = 50
     nz = torch.randn(clips, 128, generator=gen)
-    # torch's default (one thread per hardware thread) oversubscribes these small ops badly on a big host;
-    # pick the fastest of a few thread counts on 2 denoiser passes, then time the sample with it
-    best = (None, float("inf"))
+    # torch's default (one thread per hardware thread) oversubscribes these small ops badly on a big host.  ONE fixed thread
+    # count (16, or every core of a smaller host) and 50 timed steps: rounds 1-3 picked the best of several counts on 2 passes
+    # and timed 12 steps, and the figure wandered by 2 x between runs.
     ncpu = os.cpu_count() or 1
-    with torch.no_grad():
-        for nt in sorted({min(ncpu, v) for v in (8, 16, 32, 64, ncpu)}):
-            torch.set_num_threads(nt)
-            orc.denoiser_forward(Wd, x, 999, con, emo, sty)
-            t0 = time.perf_counter()
-            for _ in range(2):
-                orc.denoiser_forward(Wd, x, 999, con, emo, sty)
-            dt = (time.perf_counter() - t0) / 2
-            if dt < best[1]:
-                best = (nt, dt)
-    threads = best[0]
+    threads = min(16, ncpu)
     torch.set_num_threads(threads)
     with torch.no_grad():
         t0 = time.perf_counter()
@@ -116,12 +107,69 @@ def cpu_baseline(clips, T, wd, wp):
                       f"{clips} clips ({t_dec * 1e3:.1f} ms/clip), extrapolated to the full job"}
 
 
+def diffusion_only_extra(dev, precision, peak):
+    """The Denoiser's diffusion_only variant (denoiser.py:64-66,177-187; arch trans_enc): the transformer BASELINE's north star
+    describes - self-attention over ~300 frames in EVERY denoising step (S = 304 = 4 condition tokens + 300 pose frames), sampled
+    with the reference's DDIM-50.  Reports the job, the step kernel against the MFMA peak, and the attention-only figure
+    (full launch minus the no-attention instantiation, as for `decode.attention`)."""
+    import numpy as np
+    import torch
+    from amuse_amd import scheduler as sch
+    from amuse_amd import weights as wts
+    from amuse_amd.engine import HipEngine
+    S = 304
+    flop_step = 9 * S * 393216 + 4 * S * 65536 + 2 * (2 * 300 * 333 * 128)      # blocks + skip linears + pose_embd / pose_proj
+    flop_attn = 9 * 4 * 2 * 2 * S * S * 32
+    eng = HipEngine(wts.make_denoiser_weights(0, "trans_enc", True), None, dev, arch="trans_enc", diffusion_only=True)
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    out = {"arch": "diffusion_only + trans_enc: S = 304 rows per clip and step (denoiser.py:177-187)", "sampler": "ddim-50", "precision": precision,
+           "flop_per_clip_step": flop_step + flop_attn, "attention_flop_per_clip_step": flop_attn, "jobs": []}
+    try:
+        gold = np.load(REPO / "tests" / "golden" / "denoiser_variants.npz")
+        x = gold["x_pose"].astype(np.float32)
+        out["eps_err_vs_reference_golden"] = {
+            m: max(float(np.abs(eng.denoise_step(x, t, gold["con"], gold["emo"], gold["sty"], m).cpu().numpy()[:, 0:300:6]
+                                - gold[f"trans_enc_pose/eps_t{t}"]).max()) for t in (981, 501, 1)) for m in ("fp32x", precision)}
+        eng.set_schedule(sch.ddim_table())
+        gen = torch.Generator().manual_seed(4321)
+        for B in (64, 256):
+            con, emo, sty = (torch.randn(B, 256, generator=gen).to(dev) for _ in range(3))
+
+            def job_ms(reps=3):
+                ts = []
+                for i in range(reps + 1):
+                    ev0.record()
+                    eng.sample(con, emo, sty, precision, seed=2024)
+                    ev1.record()
+                    ev1.synchronize()
+                    if i >= 1:
+                        ts.append(ev0.elapsed_time(ev1))
+                return min(ts)
+            ms = job_ms()
+            j = {"clips": B, "ms_per_job": round(ms, 3), "ms_per_step": round(ms / 50, 4), "frames_per_s": round(B * 300 / ms * 1e3, 1),
+                 "tflops": round(B * 50 * (flop_step + flop_attn) / (ms * 1e-3) / 1e12, 1),
+                 "frac_of_mfma_peak": round(B * 50 * (flop_step + flop_attn) / (ms * 1e-3) / 1e12 / peak, 4),
+                 "kernel": "k_den_fused (one persistent workgroup per clip and step)" if B >= 64 else "staged k_vae_rows / k_vae_attn"}
+            if B >= 64:
+                eng.set_ablation(1)
+                ms_na = job_ms(2)
+                eng.set_ablation(0)
+                att = (ms - ms_na) / 50
+                j["attention"] = {"ms_per_step": round(att, 4), "tflops": round(B * flop_attn / (att * 1e-3) / 1e12, 1),
+                                  "frac_of_mfma_peak": round(B * flop_attn / (att * 1e-3) / 1e12 / peak, 4),
+                                  "method": "step kernel minus its no-attention instantiation (amuse_debug_set_ablation), HIP events"}
+            out["jobs"].append(j)
+    finally:
+        eng.close()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--clips", type=int, default=256, help="clips per GPU (N > 1: per rank; the strong-scaling companion shards this many over the ranks)")
+    ap.add_argument("--clips", type=int, default=256, help="clips of the job IN TOTAL (sharded over the ranks at N > 1; the weak-scaling companion gives every rank this many)")
     ap.add_argument("--T", type=int, default=1000, help="DDPM steps")
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp16", "fp32", "fp32x"])
     ap.add_argument("--config", default="sample", choices=["sample", "train"],
@@ -191,9 +239,10 @@ def main():
         shard.sample_sharded(sample_fn, con, emo, sty, rank, world, set_clips_per_group=eng.set_clips_per_group,
                              set_decode_path=eng.set_decode_path)
 
+    step = step_strong   # the timed workload at every N: BASELINE config 3 - `total` clips in all, this rank's contiguous shard
     if world > 1:
-        # weak scaling: this rank's own `total` clips (another draw per rank), global clip indices rank * total ...; the same
-        # code path as a whole single-GPU job (tiling and decode kernel chosen from the job's clip count)
+        # weak-scaling companion: this rank's own `total` clips (another draw per rank), global clip indices rank * total ...; the
+        # same code path as a whole single-GPU job (tiling and decode kernel chosen from the job's clip count)
         con_w, emo_w, sty_w = (torch.randn(total, 256, generator=torch.Generator().manual_seed(99 + rank)).to(dev) for _ in range(3))
         out_w = {"latents": torch.empty(total, 128, device=dev), "poses": torch.empty(total, 300, 55, 3, device=dev),
                  "trans": torch.empty(total, 300, 3, device=dev)}
@@ -201,11 +250,9 @@ def main():
         def sample_w(bsz, c, e, s, clip_index0=0):
             return eng.diffusion_backward(c, e, s, args.precision, seed=2024, clip_index0=rank * total + clip_index0, out=out_w)
 
-        def step():
+        def step_weak():
             shard.sample_sharded(sample_w, con_w, emo_w, sty_w, 0, 1, set_clips_per_group=eng.set_clips_per_group,
                                  set_decode_path=eng.set_decode_path)
-    else:
-        step = step_strong
 
     for _ in range(args.warmup):
         step()
@@ -219,29 +266,25 @@ def main():
         t = torch.tensor([elapsed], device=red_dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    if world > 1:
-        assert bool(torch.isfinite(out_w["poses"]).all())
+    assert B == 0 or bool(torch.isfinite(out["poses"][:B]).all())
 
-    # ---- strong-scaling companion, N > 1 only: the SAME `total` clips sharded over the ranks (BASELINE config 3's shape)
-    strong = None
+    # ---- weak-scaling companion, N > 1 only: every rank its own `total` clips (the shape in which the path scales)
+    weak = None
     if world > 1:
-        step_strong()
+        step_weak()
         barrier()
         t1 = time.perf_counter()
         for _ in range(3):
-            step_strong()
+            step_weak()
         barrier()
         tw = torch.tensor([time.perf_counter() - t1], device=red_dev, dtype=torch.float64)
         dist.all_reduce(tw, op=dist.ReduceOp.MAX)
-        strong = {"clips_total": total, "clips_rank0": B, "frames_per_s": round(total * 300 * 3 / float(tw.item()), 1),
-                  "ms_per_job": round(float(tw.item()) / 3 * 1e3, 3),
-                  "clip_range_per_rank": [list(shard.shard_range(total, r, world, align=g_job)) for r in range(world)],
-                  "note": "the T-step chain costs the same time for 32 clips as for 256: flat in N by construction"}
-        assert B == 0 or bool(torch.isfinite(out["poses"][:B]).all())
+        weak = {"clips_total": world * total, "clips_per_gpu": total, "frames_per_s": round(world * total * 300 * 3 / float(tw.item()), 1),
+                "ms_per_job": round(float(tw.item()) / 3 * 1e3, 3),
+                "clip_range_per_rank": [[r * total, (r + 1) * total] for r in range(world)],
+                "note": "independent clip batches per rank, no collective: scales with N because nothing is exchanged"}
+        assert bool(torch.isfinite(out_w["poses"]).all())
         del con_w, emo_w, sty_w, out_w
-        lo, hi, B = 0, total, total   # the figures below describe rank 0's share of the timed (weak) workload: `total` clips
-    elif B > 0:
-        assert bool(torch.isfinite(out["poses"][:B]).all())
 
     # ---- dominant kernel (k_sample: the T-step loop) timed live with HIP events on its launch stream
     # (HipEngine launches on torch's current stream, which is the stream these events are recorded on)
@@ -261,7 +304,7 @@ def main():
 
     line = None
     if rank == 0:
-        value = world * total * 300 * args.steps / elapsed
+        value = total * 300 * args.steps / elapsed
         flop = B * args.T * FLOP_PER_CLIP_STEP
         achieved = flop / k_avg / 1e12
         peak = MFMA_PEAK_TFLOPS[args.precision]
@@ -272,31 +315,32 @@ def main():
         line = {
             "metric": "SMPL-X frames/sec (10 s clip, 1000-step DDPM)", "value": round(value, 1), "unit": "frames/s",
             "n_gpus": world, "world_size_seen": dist.get_world_size() if world > 1 else 1, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
-            "config": {"workload": f"{total} x 10 s clips per GPU ({world * total} in total), DDPM-{args.T} sampling loop + "
+            "config": {"workload": f"{total} x 10 s clips in total ({B} on rank 0), DDPM-{args.T} sampling loop + "
                                    f"VAE decode (300 frames) + 6D->axis-angle; random-init weights of the "
                                    f"diff_latent_v2 / prior_emotional_fing architecture",
-                       "clips_total": world * total, "clips_per_gpu": total, "clips_rank0": B, "clips_per_tile": g_job, "sampler": f"ddpm-{args.T}",
-                       "sharding": f"independent clip batches x{world} (global clip indices rank * {total} ...), no collectives",
-                       "clip_range_per_rank": [[r * total, (r + 1) * total] for r in range(world)],
+                       "clips_total": total, "clips_rank0": B, "clips_per_tile": g_job, "sampler": f"ddpm-{args.T}",
+                       "sharding": f"contiguous clip shards x{world} of ONE {total}-clip job (amuse_amd/shard.py; bitwise the single-GPU result), no collectives",
+                       "clip_range_per_rank": [list(shard.shard_range(total, r, world, align=g_job)) for r in range(world)],
                        "mfma_operands": args.precision, "state_and_accumulate": "fp32",
                        "scheduler_arithmetic": "diffusers 0.17.1 DDPM (fixed_small) / DDIM restated from the published algorithm - the package "
                                                "is not in the image, so this part of the parity claim is unpinned (DESIGN.md section 2)"},
-            "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
+            "roofline": {"bound": "chain+l2_stream", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
                          "frac": round(achieved / peak, 5), "traffic": traffic, "traffic_source": traffic_src,
                          "kernel": KERNEL_NAME[args.precision] + " (persistent T-step denoising loop)",
                          "kernel_ms": round(k_avg * 1e3, 3),
                          "us_per_denoising_step": round(us_step, 3),
                          "stream_floor_us_per_step": round(stream_floor_us, 2),
-                         "note": f"algorithmic FLOPs = clips x T x 19,120,640 (rank 0's {B} clips); measured {us_step:.2f} us per "
+                         "note": f"`bound` names what binds the kernel (the serial per-step dependency chain + the per-CU L2->CU weight stream); "
+                                 f"`frac` stays achieved / dense MFMA peak. Algorithmic FLOPs = clips x T x 19,120,640 (rank 0's {B} clips); measured {us_step:.2f} us per "
                                  f"denoising step = {us_step / stream_floor_us:.2f} x the floor of its L2->CU weight stream "
                                  f"({STREAM_MB_PER_STEP[args.precision]:.2f} MB per CU and step at {CU_LOAD_BYTES_PER_CLK:.0f} B/clk = "
                                  f"{stream_floor_us:.1f} us at the {clk_ghz:.2f} GHz this device reports). The kernel is bound by the "
                                  f"serial per-step dependency chain + that stream, not by HBM or MFMA issue (DESIGN.md 4.1, 4.1b, 5)"},
         }
-        if strong is not None:
-            line["strong_scaling"] = strong
+        if weak is not None:
+            line["weak_scaling"] = weak
     if rank == 0 and not args.no_extras:
         # single-clip latency (BASELINE configs[1]): B = 1, same sampler, 5 warm-ups, 50 HIP-event-timed repeats
         c1, e1, s1 = con[:1].contiguous(), emo[:1].contiguous(), sty[:1].contiguous()
@@ -326,6 +370,27 @@ def main():
             flop_dec = B * FLOP_VAE_DECODE_PER_CLIP
             line["decode"] = {"clips": B, "ms": round(min(dt), 3), "tflops": round(flop_dec / (min(dt) * 1e-3) / 1e12, 1),
                               "frac_of_mfma_peak": round(flop_dec / (min(dt) * 1e-3) / 1e12 / peak, 4)}
+            if args.precision in ("bf16", "fp16") and B >= 64:
+                # attention-only roofline of the S = 300 self-attention (the "fraction of the attention roofline" of BASELINE's north star):
+                # its time = the fused decode launch minus the same launch WITHOUT softmax(Q K^T) V (amuse_debug_set_ablation: a second
+                # instantiation of the kernel - projections, K / V images, out_proj and every barrier stay), both timed here by HIP events
+                eng.set_ablation(1)
+                da = []
+                for i in range(12):
+                    ev0.record()
+                    eng.vae_decode(z, None, args.precision)
+                    ev1.record()
+                    ev1.synchronize()
+                    if i >= 4:
+                        da.append(ev0.elapsed_time(ev1))
+                eng.set_ablation(0)
+                att_ms = min(dt) - min(da)
+                line["decode"]["attention"] = {
+                    "flop_per_clip": FLOP_VAE_ATTN_PER_CLIP, "ms": round(att_ms, 4), "tflops": round(B * FLOP_VAE_ATTN_PER_CLIP / (att_ms * 1e-3) / 1e12, 1),
+                    "frac_of_mfma_peak": round(B * FLOP_VAE_ATTN_PER_CLIP / (att_ms * 1e-3) / 1e12 / peak, 4), "launch_without_attention_ms": round(min(da), 3),
+                    "method": "k_vae_fused launch time minus its no-attention instantiation's, HIP events, same process",
+                    "bound": "transcendental issue: 80 v_exp_f32 per 16-query tile and head against 40 useful MFMAs (dh = 32) - "
+                             "profiles/r04_fused_attention_ablation.txt, DESIGN.md 4.2b"}
         # the step time of k_sample does not depend on the clips per workgroup tile (1..3), so 3 clips per CU
         # cost the same loop time: report that saturating point too (not the headline workload)
         Bs = 3 * total
@@ -418,6 +483,8 @@ def main():
                 line["ddim50"][f"{mode}_single_clip_ms"] = round(statistics.median(ts1), 3)
             eng.set_schedule(sch.ddpm_table(args.T))
             eng.set_clips_per_group(0)
+        if world == 1 and args.precision in ("bf16", "fp16"):
+            line["diffusion_only"] = diffusion_only_extra(dev, args.precision, peak)
         if world == 1 and not args.no_audio:
             # side measurement, not part of `value` (whose inputs are the three 256-d embeddings): the
             # audio front-end that produces them from 10 s of 16 kHz audio - kaldi fbank + 3 x AST, 778 GFLOP per clip

@@ -318,6 +318,11 @@ int amuse_debug_tile(const void* src, void* dst, int M, int F, int what, void* s
  * decoder.norm (slot 9) there, through a separate instantiation of the kernel; NULL switches the taps off again. */
 int amuse_debug_set_decode_tap(amuse_ctx* ctx, float* tap_out);
 
+/* Timing ablation of the fused per-clip kernels (k_vae_fused.hip, k_den_fused.hip), for bench.py's attention-only roofline figure:
+ * mask 1 = launch the instantiation WITHOUT softmax(Q K^T) V (projections, K / V images, out_proj and every barrier stay) - outputs
+ * are wrong by construction; full - ablated launch time = the S ~ 300 self-attention's time.  mask 0 restores the product kernel. */
+int amuse_debug_set_ablation(amuse_ctx* ctx, int mask);
+
 /* The host packer's fp32 -> (hi, lo) fp16 split of AMUSE_PREC_F32X, for tests (host memory, no GPU call):
  * hi[i] = rn16(w[i]), lo[i] = rn16(w[i] - hi[i]), round-to-nearest-even with gradual underflow - bit for bit what
  * v_cvt_pk_f16_f32 produces on the device for the activations (and amuse_update_weights_device for the weights). */

@@ -215,9 +215,9 @@ def test_two_process_sharded_job_through_the_hip_engine(tmp_path):
 
 def test_bench_line_with_two_ranks_sharing_the_gpu():
     """`python bench.py --gpus 2` as typed (the parent starts its own ranks, amuse_amd/launch.py), with AMUSE_BENCH_SHARE_GPU=1 so that
-    both ranks run on this box's one GPU (gloo for the two scalar reductions): the N > 1 logic of bench.py end to end - weak-scaling
-    `value` over both ranks' clips, the strong-scaling companion, clip ranges, one JSON line from rank 0.  (Timings of ranks that
-    share a GPU mean nothing and are not looked at.)"""
+    both ranks run on this box's one GPU (gloo for the two scalar reductions): the N > 1 logic of bench.py end to end - `value` =
+    BASELINE config 3's job (--clips IN TOTAL, sharded over the ranks: "scaling": "strong"), the weak-scaling companion, clip ranges,
+    one JSON line from rank 0.  (Timings of ranks that share a GPU mean nothing and are not looked at.)"""
     import json, os, subprocess, sys
     from conftest import REPO
     env = dict(os.environ, AMUSE_BENCH_SHARE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
@@ -227,10 +227,34 @@ def test_bench_line_with_two_ranks_sharing_the_gpu():
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, r.stdout[-2000:]
     d = json.loads(lines[0])
-    assert d["n_gpus"] == 2 and d["world_size_seen"] == 2 and d["scaling"] == "weak"
-    assert d["config"]["clips_total"] == 128 and d["config"]["clips_per_gpu"] == 64
-    assert d["config"]["clip_range_per_rank"] == [[0, 64], [64, 128]]
-    assert abs(d["value"] - 128 * 300 / (d["ms_per_step"] * 1e-3)) < 1e-3 * d["value"]
-    s = d["strong_scaling"]
-    assert s["clips_total"] == 64 and s["clip_range_per_rank"] == [[0, 32], [32, 64]] and s["frames_per_s"] > 0
-    assert d["roofline"]["frac"] > 0 and d["roofline"]["kernel_ms"] > 0
+    assert d["n_gpus"] == 2 and d["world_size_seen"] == 2 and d["scaling"] == "strong"
+    assert d["config"]["clips_total"] == 64 and d["config"]["clips_rank0"] == 32       # config.clips_total == --clips at every N
+    assert d["config"]["clip_range_per_rank"] == [[0, 32], [32, 64]]
+    assert abs(d["value"] - 64 * 300 / (d["ms_per_step"] * 1e-3)) < 1e-3 * d["value"]
+    w = d["weak_scaling"]
+    assert w["clips_total"] == 128 and w["clips_per_gpu"] == 64 and w["clip_range_per_rank"] == [[0, 64], [64, 128]] and w["frames_per_s"] > 0
+    assert d["roofline"]["frac"] > 0 and d["roofline"]["kernel_ms"] > 0 and d["roofline"]["bound"] == "chain+l2_stream"
+
+
+def test_rccl_world_of_one_all_reduces_the_flat_gradient():
+    """init_process_group("nccl") (= RCCL on ROCm) at world size 1 on the GPU and an all-reduce of the 6,835,661-element flat fp32
+    gradient train_gesture exchanges (amuse_amd/train_gesture.py) - the collective library is loaded and run by something in this
+    tree even on a one-GPU box.  Own process: a process group cannot be re-initialised inside the test session."""
+    import os, subprocess, sys
+    from conftest import REPO
+    code = (
+        "import os, torch, torch.distributed as dist\n"
+        "os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT='29655', RANK='0', WORLD_SIZE='1')\n"
+        "torch.cuda.set_device(0)\n"
+        "dist.init_process_group('nccl', device_id=torch.device('cuda', 0))\n"
+        "g = torch.arange(6835661, device='cuda', dtype=torch.float32) * 1e-6\n"
+        "ref = g.clone()\n"
+        "dist.barrier(); dist.all_reduce(g, op=dist.ReduceOp.SUM); torch.cuda.synchronize()\n"
+        "assert torch.equal(g, ref), 'world of one: SUM must be the identity'\n"
+        "t = torch.tensor([1.5], device='cuda', dtype=torch.float64); dist.all_reduce(t, op=dist.ReduceOp.MAX)\n"
+        "assert float(t.item()) == 1.5\n"
+        "print('RCCL_OK', dist.get_backend(), torch.cuda.nccl.version())\n"
+        "dist.destroy_process_group()\n")
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"), capture_output=True, text=True,
+                       timeout=600, cwd=str(REPO))
+    assert r.returncode == 0 and "RCCL_OK nccl" in r.stdout, (r.stdout[-1000:], r.stderr[-3000:])
