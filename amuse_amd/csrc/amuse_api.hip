@@ -33,8 +33,9 @@ int build_denoiser(amuse_ctx* c, const float* den, int what = AMUSE_UPD_ALL) {
     // ---- denoiser weight streams: [wave][per-step units]
     for (int prec = 0; prec < 3; ++prec) {
         if (!(what & kUpdBit[prec])) continue;   // amuse_update_weights: only the requested precisions are re-packed
-        // the 4-wave bf16 stream only serves A/B runs (AMUSE_SAMPLE_WAVES=4): updates skip it unless that switch is set
-        if (prec == PREC_BF16 && c->den_w[prec] && !getenv("AMUSE_SAMPLE_WAVES")) continue;
+        // the 4-wave bf16 and fp32x streams only serve A/B runs (AMUSE_SAMPLE_WAVES=4; both modes sample on their 8-wave kernels):
+        // updates - host path and, through the probe runs, the device re-pack's gather maps - skip them unless that switch is set
+        if ((prec == PREC_BF16 || prec == PREC_F16X2) && c->den_w[prec] && !getenv("AMUSE_SAMPLE_WAVES")) continue;
         std::vector<uint4> all;
         size_t per_wave = 0;
         for (int w = 0; w < 4; ++w) {

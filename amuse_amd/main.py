@@ -86,15 +86,36 @@ def train_gesture_entry(args, dirname: Path, config: dict):
     assert tp["motion_extractor"]["use"] is False, "Motion extractor should be False!"
     ld = tp["latent_diffusion"]
     assert ld.get("smplx_data", True), "smplx_data must be True!"                                                        # main.py:129
+    # what the configuration asks for beyond the defaults (trainer.py:94-104,177-184): refuse what this path cannot do instead of
+    # silently training another objective
+    if ld.get("optimizer_name", "adamw") != "adamw":
+        raise SystemExit(f"train_gesture: optimizer_name {ld.get('optimizer_name')!r}: the reference's LPDM trainer builds AdamW only (trainer.py:184)")
+    if ld.get("vtex_displacement", False) and not args.skip_vtex_loss:
+        raise SystemExit("train_gesture: TRAIN_PARAM.latent_diffusion.vtex_displacement is True (scripts/overrides/train_gesture.yaml:25): the "
+                         "rec / gen vertex-displacement loss terms need the licensed SMPL-X body models (latent_losses.py:173-250), which this "
+                         "path does not have.  Pass --skip-vtex-loss to train WITHOUT those two terms (checkpoint names then read vtexR0.0000 / "
+                         "vtexG0.0000), or set vtex_displacement: False")
+    if ld.get("vtex_displacement", False):
+        print("[LPDM-T] WARNING: vtex_displacement is True in the configuration but --skip-vtex-loss drops both vertex-displacement terms", flush=True)
+    ldm_cfg = config.get("_ldm_cfg")
     argv = ["--batch", str(ld.get("batch_size", 32)), "--epochs", str(args.epochs or ld.get("n_epochs", 12000)),
             "--save-freq", str(ld.get("model_save_freq", 200)), "--seed", str(tp.get("seed", 2024)), "--gpus", str(args.gpus),
-            "--out", str(dirname / "saved-models")]
+            "--out", str(dirname / "saved-models"), "--lr", repr(float(ld.get("lr_base", 1e-4)))]
+    if ldm_cfg is not None:   # configs/<arch>.json merged with diff_o.yaml: loss weights and both schedulers (the ranks may be other processes)
+        import tempfile
+        f = tempfile.NamedTemporaryFile("w", suffix="_ldm_cfg.json", delete=False)
+        json.dump(ldm_cfg, f)
+        f.close()
+        argv += ["--ldm-cfg", f.name]
     cache = dirname / "data" / "BEAT-processed" / tp.get("diffusion", {}).get("lmdb_cache", "")
     if not args.synthetic:
         if not (cache.is_dir() and tp.get("diffusion", {}).get("lmdb_cache")):
             raise SystemExit(f"train_gesture: the LMDB cache {cache} does not exist (prepare_data is the reference's job; --synthetic trains "
                              f"on random batches of the collate function's shapes)")
-        argv += ["--cache", str(cache)]
+        argv += ["--cache", str(cache)]     # (the ablation variant is derived from this id, trainer.py:396-401)
+    elif tp.get("diffusion", {}).get("lmdb_cache"):
+        from .train_gesture import ablation_kind
+        argv += ["--kind", ablation_kind(tp["diffusion"]["lmdb_cache"])]
     if args.device != "cuda:0":
         argv += ["--device", args.device]
     if args.iters_per_epoch:
@@ -116,13 +137,17 @@ def main(argv=None):
     ap.add_argument("--random-init", action="store_true", help="deterministic random-init weights instead of checkpoints")
     ap.add_argument("--sampler", default="ddim", choices=["ddim", "ddpm"])
     ap.add_argument("--steps", type=int, default=None)
-    ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16", "fp32x", "fp16"],
-                    help="fp32: parity mode; fp32x: the same tolerance 2.5 x faster (split-fp16 MFMA operands); bf16 / fp16: throughput modes (fp16: the same speed, 8 x less rounding)")
+    ap.add_argument("--precision", default="fp32x", choices=["fp32", "bf16", "fp32x", "fp16"],
+                    help="fp32x (default): results match the reference's fp32 modules (eps_hat <= 1e-5) on the 16-bit MFMA; fp32: the same bars on "
+                         "the fp32 MFMA, 2.6 x slower; fp16: the throughput mode (2 x fp32x, ~3e-3 on eps_hat; operands must stay below 65504: an "
+                         "overflow surfaces as a non-finite output); bf16: the same speed with 8 x the rounding - only for activations beyond fp16 range")
     ap.add_argument("--device", default="cuda:0")
     ap.add_argument("--gpus", type=int, default=1, help="train_gesture: data-parallel ranks on this node (one process per GPU)")
     ap.add_argument("--epochs", type=int, default=None, help="train_gesture: override TRAIN_PARAM.latent_diffusion.n_epochs")
     ap.add_argument("--synthetic", action="store_true", help="train_gesture: synthetic batches instead of the LMDB cache")
     ap.add_argument("--iters-per-epoch", type=int, default=None, help="train_gesture --synthetic: iterations per epoch")
+    ap.add_argument("--skip-vtex-loss", action="store_true", help="train_gesture: train without the two vertex-displacement loss terms when the "
+                                                                  "configuration asks for them (they need the SMPL-X body models)")
     args = ap.parse_args(argv)
     fn = args.fn[0]
     if fn not in ("infer_gesture", "edit_gesture", "train_gesture"):
@@ -132,6 +157,7 @@ def main(argv=None):
     config, ldm_cfg = load_config(dirname, fn, args.cfg)
     tp = config["TRAIN_PARAM"]
     if fn == "train_gesture":
+        config["_ldm_cfg"] = ldm_cfg
         return train_gesture_entry(args, dirname, config)
     assert tp["pretrained_infer"], f"Arg: {fn} and pretrained_infer: {tp['pretrained_infer']} mismatch!"   # main.py:129
     assert tp["motion_extractor"]["use"] is False, "Motion extractor should be False!"

@@ -22,8 +22,10 @@ FUSED_DECODE_MIN_CLIPS = 64   # amuse_api.hip kFusedMinClips: the library's per-
 
 def job_decode_path(total: int) -> str:
     """The decode kernels (amuse_hip.h amuse_set_decode_path) a job of `total` clips would get on one GPU.  Like the clips
-    per tile it must be chosen from the WHOLE job, not per shard: the staged and the fused bf16 decode round differently,
-    so a 256-clip job cut into 32-clip shards would otherwise decode on other kernels than the same job on one GPU."""
+    per tile it must be chosen from the WHOLE job, not per shard: each 16-bit mode has a staged and a fused decoder and the
+    fp32x mode two row kernels (k_vae_rows<f16x2> below 64 clips, k_vae_rows8x from 64) that sum in different orders, so a
+    256-clip job cut into 32-clip shards would otherwise decode on other kernels than the same job on one GPU (only the fp32
+    mode has a single decode path)."""
     return "fused" if total >= FUSED_DECODE_MIN_CLIPS else "staged"
 
 

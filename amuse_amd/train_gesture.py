@@ -419,15 +419,36 @@ class HipInnerSampler:
         return self.engine.vae_decode(lat, None, self.precision, return_feats=True)["feats"]
 
 
+def ablation_kind(lmdb_id: Optional[str]) -> Optional[str]:
+    """The ablation variant the reference derives from the LMDB cache id (trainer.py:396-401): full | emotion | identity | baseline."""
+    if not lmdb_id:
+        return None
+    parts = lmdb_id.split("/")[-1].split("_")
+    kind = parts[-3] if len(parts) >= 3 else ""
+    if kind == "feat" and len(parts) >= 5:
+        kind = parts[-5]
+    assert kind in ("full", "emotion", "identity", "baseline"), f"Invalid lmdb_id: {lmdb_id}"
+    return kind
+
+
 def build_trainer(device, rank: int = 0, world: int = 1, process_group=None, seed: int = 0, use_hip_sampler: bool = True,
-                  dropout: float = 0.1, sampler_refresh: int = 1, ldm_cfg: Optional[dict] = None) -> GestureTrainer:
+                  dropout: float = 0.1, sampler_refresh: int = 1, ldm_cfg: Optional[dict] = None, lr: float = 1e-4,
+                  kind: Optional[str] = None) -> GestureTrainer:
     """Random-init prior + ldm (the deterministic weights of amuse_amd/weights.py, identical on every rank - what DDP's
-    initial broadcast gives the reference's DataParallel-less single-GPU run) and the trainer around them."""
+    initial broadcast gives the reference's DataParallel-less single-GPU run) and the trainer around them.
+    lr = TRAIN_PARAM.latent_diffusion.lr_base (trainer.py:181-184); ldm_cfg = configs/<arch>.json merged with diff_o.yaml (its
+    "losses" section weighs the terms, its schedulers drive add_noise and the in-loop sampler); kind = the LMDB id's ablation
+    variant (ablation_kind): the condition the variant never feeds keeps its projection out of the optimizer."""
     from . import weights as wts
     prior = load_numpy_state(MotionPrior(dropout=dropout), wts.make_prior_weights(seed))
     ldm = LatentDiffusionTrainModule(ldm_cfg, dropout=dropout)
     load_numpy_state(ldm.denoiser, wts.make_denoiser_weights(seed))
-    tr = GestureTrainer(prior, ldm, device, inner_sampler=None, process_group=process_group, world=world)
+    assert kind in (None, "full", "emotion", "identity", "baseline"), f"Invalid ablation kind: {kind}"
+    loss_cfg = None
+    if (ldm_cfg or {}).get("losses") is not None:   # trainer.py:175-177: SMPL-X data switches the joints terms off; the vertex terms are not built
+        loss_cfg = dict(ldm_cfg["losses"], use_recons_joints=False, vtex_displacement=False)
+    tr = GestureTrainer(prior, ldm, device, lr=lr, loss_cfg=loss_cfg, inner_sampler=None, process_group=process_group,
+                        world=world, kind=None if kind == "full" else kind)
     if use_hip_sampler:
         if torch.device(device).type != "cuda":
             raise RuntimeError("the in-loop sampler of train_gesture runs on the HIP kernels: no CPU path (pass use_hip_sampler=False "
@@ -517,6 +538,10 @@ def main(argv=None):
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--seed", type=int, default=2024, help="TRAIN_PARAM.seed (configs/base_new.json)")
     ap.add_argument("--save-freq", type=int, default=1, help="checkpoint every N epochs (TRAIN_PARAM.latent_diffusion.model_save_freq: 200)")
+    ap.add_argument("--lr", type=float, default=1e-4, help="TRAIN_PARAM.latent_diffusion.lr_base (AdamW, trainer.py:181-184)")
+    ap.add_argument("--kind", default=None, choices=["full", "emotion", "identity", "baseline"],
+                    help="ablation variant (default: derived from the --cache id like trainer.py:396-401; synthetic data: full)")
+    ap.add_argument("--ldm-cfg", default=None, help="JSON file: configs/<arch>.json merged with diff_o.yaml (losses, schedulers); default: the shipped values")
     args = ap.parse_args(argv)
     from . import launch
     if args.gpus > 1 and not launch.launched_by_torchrun():
@@ -524,7 +549,9 @@ def main(argv=None):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    device = torch.device(args.device or (f"cuda:{local_rank}" if torch.cuda.is_available() else "cpu"))
+    if world > 1 and args.device and args.device.startswith("cuda:"):
+        raise SystemExit(f"--device {args.device} with {world} ranks would put every rank on one GPU: drop the index (rank r uses cuda:<LOCAL_RANK>)")
+    device = torch.device(f"cuda:{local_rank}" if (args.device in (None, "cuda") and torch.cuda.is_available()) else (args.device or "cpu"))
     pg = None
     if world > 1:
         import torch.distributed as dist
@@ -537,7 +564,16 @@ def main(argv=None):
         pg = dist.group.WORLD
     from .main import fixseed
     fixseed(args.seed + rank)            # scripts/main.py fixseed(TRAIN_PARAM.seed); per-rank offset: ranks draw different noise / timesteps
-    tr = build_trainer(device, rank, world, process_group=pg, use_hip_sampler=device.type == "cuda")
+    ldm_cfg = None
+    if args.ldm_cfg:
+        import json
+        ldm_cfg = json.load(open(args.ldm_cfg))
+    kind = args.kind or ablation_kind(args.cache)
+    tr = build_trainer(device, rank, world, process_group=pg, use_hip_sampler=device.type == "cuda", ldm_cfg=ldm_cfg, lr=args.lr, kind=kind)
+    if rank == 0:
+        lc = tr.lpdm_losses.cfg
+        print(f"[LPDM-T] lr {args.lr:g}, ablation kind {kind or 'full'}, loss weights " +
+              ", ".join(f"{k} {lc[k]}" for k in ("LAMBDA_REC", "LAMBDA_KL", "LAMBDA_LATENT", "LAMBDA_GEN")), flush=True)
     if args.cache:
         from .dataload import LatentDiffusionCache, make_loader
         loader = make_loader(LatentDiffusionCache.open(args.cache), args.batch, rank=rank, world=world, seed=args.seed)

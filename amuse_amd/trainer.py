@@ -157,11 +157,12 @@ def run_jobs(model, jobs: List[dict], return_latents: bool = False, batched: boo
     z_sty drops a token, denoiser.py:159-171, which changes the kernel's tile shape); clip indices are assigned in job
     order exactly as the sequential calls would have drawn them.  batched=False: the reference's call pattern.
     What "the same as the sequential calls" means: the same noise (counter-based, keyed by the global clip index) and the same
-    network - bitwise in the fp32 / fp32x modes up to 128 clips per launch (one clip per workgroup tile either way, staged
-    decode), to rounding otherwise: a launch of more than 128 clips packs several clips per tile (the softmax / PV summation
-    order follows a clip's slot, amuse_hip.h amuse_set_clips_per_group), and in bf16 a launch of 64 clips or more decodes
-    on the fused kernel where the sequential calls would take the staged one (other summation order, same operands
-    rounded).  A caller that needs the sequential bits pins both: engine.set_clips_per_group(1), set_decode_path("staged")."""
+    network - bitwise in the fp32 mode up to 128 clips per launch and in the fp32x / bf16 / fp16 modes below 64 clips per launch,
+    to rounding otherwise: a launch of more than 128 clips packs several clips per tile (the softmax / PV summation order
+    follows a clip's slot, amuse_hip.h amuse_set_clips_per_group), and a launch of 64 clips or more decodes on another kernel
+    than the sequential one-clip calls take - bf16 / fp16: the fused per-clip decoder instead of the staged kernels; fp32x: the
+    row stages without split-K (k_vae_rows8x) instead of k_vae_rows<f16x2> - the same operands, another summation order.
+    A caller that needs the sequential bits pins both: engine.set_clips_per_group(1), set_decode_path("staged")."""
     out: List[Optional[dict]] = [None] * len(jobs)
     dev = model.device
     c0 = model._clip_counter

@@ -206,3 +206,36 @@ def test_fp16_mode_range_headroom(env):
     dh = float((h["latents"] - f["latents"]).pow(2).mean().sqrt())
     db = float((b["latents"] - f["latents"]).pow(2).mean().sqrt())
     assert dh < db, (dh, db)      # closer to the fp32 mode than bf16 is, also at this scale
+
+
+def test_fp16_overflow_surfaces_as_non_finite_never_clips(env):
+    """The price of the fp16 mode is range: a GEMM operand beyond 65504 becomes inf in the fp16 pack (v_cvt_pk_f16_f32 rounds to
+    infinity, it does not saturate) and the outputs go non-finite - loudly - where the bf16 mode carries the same inputs.  Through the
+    C ABI: the teacher-forced step, the sampling loop and the decode.  (amuse_hip.h AMUSE_PREC_F16; the policy line of INTEGRATION.md:
+    fp32x to match the reference, fp16 for throughput, bf16 only for activations beyond fp16 range.)"""
+    from amuse_amd import scheduler as sch
+    eng = env["eng"]
+    g = torch.Generator().manual_seed(5)
+    c, e, s, x = (torch.randn(4, n, generator=g) for n in (256, 256, 256, 128))
+    big = x.clone()
+    big[1, 7] = 3.0e5                       # one latent feature of clip 1 beyond fp16 range: the row is an operand of block 0's in_proj
+    h = eng.denoise_step(big, 501, c, e, s, "fp16")
+    assert not bool(torch.isfinite(h[1]).all()), "an fp16 overflow must not be clipped silently"
+    assert bool(torch.isfinite(h[[0, 2, 3]]).all())             # clips are independent: the others are untouched
+    assert torch.equal(h[[0, 2, 3]], eng.denoise_step(x, 501, c, e, s, "fp16")[[0, 2, 3]])
+    assert bool(torch.isfinite(eng.denoise_step(big, 501, c, e, s, "bf16")).all())      # bf16 carries it
+    assert bool(torch.isfinite(eng.denoise_step(big, 501, c, e, s, "fp32x")[[0, 2, 3]]).all())
+    eng.set_schedule(sch.ddim_table(5))
+    lat = eng.sample(c, e, s, "fp16", x_init=big)
+    assert not bool(torch.isfinite(lat[1]).all()) and bool(torch.isfinite(lat[[0, 2, 3]]).all())
+    zbig = torch.randn(64, 128, generator=g)
+    zbig[3] *= 1.0e6                        # the one-token memory of clip 3: its cross-attention constant overflows the first operand pack
+    for path in ("staged", "fused"):
+        eng.set_decode_path(path)
+        out = eng.vae_decode(zbig, None, "fp16", return_feats=True)["feats"]
+        eng.set_decode_path("auto")
+        assert bool(torch.isfinite(out[:3]).all()) and bool(torch.isfinite(out[4:]).all()), path
+        # (LayerNorm of a row dominated by one huge constant is still finite: what must never happen is a silently clipped value)
+        if bool(torch.isfinite(out[3]).all()):
+            ref = eng.vae_decode(zbig, None, "fp32", return_feats=True)["feats"][3]
+            assert float((out[3] - ref).abs().max()) < 0.5, path

@@ -54,12 +54,35 @@ def test_cli_fn_train_gesture_dispatches_to_the_trainer(tmp_path):
     from conftest import make_reference_tree
     from amuse_amd import main as cli
     root = make_reference_tree(tmp_path / "tree")
-    (root / "scripts/overrides/train_gesture.yaml").write_text(
-        "TRAIN_PARAM:\n  latent_diffusion:\n    batch_size: 2\n    n_epochs: 1\n    model_save_freq: 1\n  diffusion:\n    lmdb_cache: BEAT-cache/none\n")
+    ov = ("TRAIN_PARAM:\n  latent_diffusion:\n    batch_size: 2\n    n_epochs: 1\n    model_save_freq: 1\n    lr_base: 0.0003\n"
+          "    vtex_displacement: {vtex}\n    optimizer_name: {opt}\n  diffusion:\n"
+          "    lmdb_cache: BEAT-cache/2023-10-28_30F_fing_smplx_MOSH_identity_v1_feat_based_300\n")
+    (root / "scripts/overrides/train_gesture.yaml").write_text(ov.format(vtex="False", opt="adamw"))
+    (root / "scripts/overrides/diff_o.yaml").write_text("losses:\n  LAMBDA_KL: 0.002\n  LAMBDA_REC: 1.0\n  LAMBDA_GEN: 1.0\n  LAMBDA_LATENT: 1.0\n"
+                                                        "  LAMBDA_JOINT: 1.0\n  LAMBDA_PRIOR: 0.0\n  stage: vae_diffusion\n  train_lpdm:\n    version: v0\n"
+                                                        "  use_recons_joints: true\n  predict_epsilon: true\n")
     with pytest.raises(SystemExit, match="LMDB cache"):
         cli.main(["--fn", "train_gesture", "--root", str(root), "--device", "cpu"])
-    assert cli.main(["--fn", "train_gesture", "--root", str(root), "--device", "cpu", "--synthetic", "--iters-per-epoch", "2"]) == 0
+    import contextlib, io
+    buf = io.StringIO()
+    with contextlib.redirect_stdout(buf):
+        assert cli.main(["--fn", "train_gesture", "--root", str(root), "--device", "cpu", "--synthetic", "--iters-per-epoch", "2"]) == 0
+    # the non-default configuration reaches the trainer: learning rate, the ablation variant of the LMDB id, the loss weights of
+    # configs/diff_latent_v2.json merged with diff_o.yaml (advisor finding, round 3)
+    assert "lr 0.0003, ablation kind identity" in buf.getvalue() and "LAMBDA_KL 0.002" in buf.getvalue(), buf.getvalue()[-800:]
     assert len(list((root / "saved-models").glob("latdiff_model_wOpt_*_e1.pt"))) == 1
+    # what this path cannot do is refused loudly, not silently dropped: the vertex-displacement terms the shipped override asks for ...
+    (root / "scripts/overrides/train_gesture.yaml").write_text(ov.format(vtex="True", opt="adamw"))
+    with pytest.raises(SystemExit, match="vtex_displacement"):
+        cli.main(["--fn", "train_gesture", "--root", str(root), "--device", "cpu", "--synthetic", "--iters-per-epoch", "1"])
+    buf = io.StringIO()
+    with contextlib.redirect_stdout(buf):
+        assert cli.main(["--fn", "train_gesture", "--root", str(root), "--device", "cpu", "--synthetic", "--iters-per-epoch", "1", "--skip-vtex-loss"]) == 0
+    assert "WARNING: vtex_displacement" in buf.getvalue()
+    # ... and another optimizer
+    (root / "scripts/overrides/train_gesture.yaml").write_text(ov.format(vtex="False", opt="sgd"))
+    with pytest.raises(SystemExit, match="optimizer_name"):
+        cli.main(["--fn", "train_gesture", "--root", str(root), "--device", "cpu", "--synthetic"])
     # the inference entry points still refuse a training configuration (pretrained_infer false), as scripts/main.py:126 does
     (root / "scripts/overrides/infer_gesture.yaml").write_text("TRAIN_PARAM:\n  pretrained_infer: False\n")
     with pytest.raises(AssertionError, match="mismatch"):

@@ -258,3 +258,28 @@ def test_latent_diffusion_cache_reader_and_collate():
     tr = build_trainer("cpu", use_hip_sampler=False)
     loss = tr.train_step(next(iter(make_loader(ds, 2, shuffle=False))))
     assert bool(torch.isfinite(loss))
+
+
+def test_ablation_kind_reaches_the_trainer_and_freezes_the_dropped_projection():
+    """The ablation variants of the LMDB id (trainer.py:396-401): `identity` trains without the emotion embedding, `emotion` /
+    `baseline` without the style one - the projection of the condition that is never fed gets no gradient in the reference and,
+    under zero_grad(set_to_none=True), no weight decay either: it must stay bit-identical over optimizer steps (advisor finding)."""
+    from amuse_amd.train_gesture import ablation_kind, build_trainer, synthetic_batch
+    assert ablation_kind("BEAT-cache/2023-10-28_30F_fing_smplx_MOSH_full_v1_feat_based_300") == "full"
+    assert ablation_kind("BEAT-cache/2023-10-28_30F_fing_smplx_MOSH_identity_v1_feat_based_300") == "identity"
+    assert ablation_kind("x/2023_smplx_emotion_v1_300") == "emotion" and ablation_kind(None) is None
+    with pytest.raises(AssertionError, match="Invalid lmdb_id"):
+        ablation_kind("BEAT-cache/none")
+    torch.manual_seed(0)
+    for kind, frozen, live in (("identity", "emb_proj_emo", "emb_proj_sty"), ("emotion", "emb_proj_sty", "emb_proj_emo")):
+        tr = build_trainer("cpu", use_hip_sampler=False, kind=kind, lr=3e-4)
+        assert tr.kind == kind and abs(tr.lpdm_opt.param_groups[0]["lr"] - 3e-4) < 1e-12
+        sd0 = {k: v.detach().clone() for k, v in tr.model["ldm"].state_dict().items()}
+        for i in range(2):
+            tr.train_step(synthetic_batch(2, 10 + i))
+        sd1 = tr.model["ldm"].state_dict()
+        for leaf in ("weight", "bias"):
+            assert torch.equal(sd0[f"denoiser.{frozen}.1.{leaf}"], sd1[f"denoiser.{frozen}.1.{leaf}"]), (kind, frozen)
+            assert not torch.equal(sd0[f"denoiser.{live}.1.{leaf}"], sd1[f"denoiser.{live}.1.{leaf}"]), (kind, live)
+    full = build_trainer("cpu", use_hip_sampler=False, kind="full")
+    assert full.kind is None
