@@ -94,6 +94,28 @@ using Ring = WRing<kR8>;
 #define AMUSE_C2_N1 12
 #endif
 
+#ifdef AMUSE_ABL_C1LITE
+constexpr bool kAblC1Lite = true;
+#else
+constexpr bool kAblC1Lite = false;
+#endif
+#ifdef AMUSE_ABL_C2LITE
+constexpr bool kAblC2Lite = true;
+#else
+constexpr bool kAblC2Lite = false;
+#endif
+// the two halves of C2LITE on their own: only the partial WRITES thinned (W) / only the reducers' READS thinned (R)
+#ifdef AMUSE_ABL_C2LITE_W
+constexpr bool kAblC2W = true;
+#else
+constexpr bool kAblC2W = kAblC2Lite;
+#endif
+#ifdef AMUSE_ABL_C2LITE_R
+constexpr bool kAblC2R = true;
+#else
+constexpr bool kAblC2R = kAblC2Lite;
+#endif
+
 __device__ __forceinline__ f32x4* a8_slot(char* lds, int row, int col, int lane) {
     return reinterpret_cast<f32x4*>(lds) + (row * kTiles + col) * 64 + lane;
 }
@@ -133,7 +155,7 @@ __device__ __forceinline__ void combine_red(f32x4 (&part)[kTiles], f32x4 (&xo)[2
     if constexpr (NP == 8) {
 #pragma unroll
         for (int t = 0; t < kTiles; ++t)
-            if (t != T0 && t != T0 + 1) *a8_slot(lds, part_row(4 + W, t), t, lane) = part[t];
+            if (t != T0 && t != T0 + 1 && (!kAblC2W || t == (T0 + 2) % kTiles)) *a8_slot(lds, part_row(4 + W, t), t, lane) = part[t];
     }
     f32x4 bi[2], ga[2], be[2];
 #pragma unroll
@@ -151,8 +173,12 @@ __device__ __forceinline__ void combine_red(f32x4 (&part)[kTiles], f32x4 (&xo)[2
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int w = 0; w < NP; ++w)
-                if (w != 4 + W) p[w][i] = *a8_slot(lds, part_row(w, T0 + i), T0 + i, lane);
+            for (int w = 0; w < NP; ++w) {
+                // (timing ablations, wrong numerics: ONE partial per tile read instead of NP - 1 - the LDS traffic of a combine whose
+                // GEMM was split over output tiles instead of K: -DAMUSE_ABL_C1LITE out_proj combine, -DAMUSE_ABL_C2LITE linear2 combine)
+                const bool lite = NP == 4 ? kAblC1Lite : kAblC2R;
+                if (w != 4 + W) p[w][i] = (lite && w != 0) ? p[0][i] : *a8_slot(lds, part_row(w, T0 + i), T0 + i, lane);
+            }
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             f32x4 sum;
@@ -226,7 +252,8 @@ template <int N0, int N1, int N2, int N3, int IPH0, bool LN = true>
 __device__ __forceinline__ void combine_publish(const f32x4 (&part)[kTiles], OPV (&xb)[4], char* lds, int h,
                                                 int lane, Ring& rg) {
 #pragma unroll
-    for (int t = 0; t < kTiles; ++t) *a8_slot(lds, h + (h >= t ? 1 : 0), t, lane) = part[t];  // part_row(h, t), h < 4
+    for (int t = 0; t < kTiles; ++t)
+        if (!kAblC1Lite || t == 2 * h) *a8_slot(lds, h + (h >= t ? 1 : 0), t, lane) = part[t];  // part_row(h, t), h < 4
     ring_issue<N0, kR8, IPH0 % kR8>(rg);
     __syncthreads();
     ring_issue<N1, kR8, (IPH0 + N0) % kR8>(rg);
@@ -258,7 +285,8 @@ __device__ __forceinline__ void combine_publish_c2(const f32x4 (&part)[kTiles], 
                                                    int lane, Ring& rg, bool skip_u, const uint4* skip_ops) {
     static_assert(N0 >= 8 && N0 + N1 + N2 == 32, "the leading 8 units go out before the first barrier");
 #pragma unroll
-    for (int t = 0; t < kTiles; ++t) *a8_slot(lds, h + (h >= t ? 1 : 0), t, lane) = part[t];
+    for (int t = 0; t < kTiles; ++t)
+        if (!kAblC2W || t == 2 * h) *a8_slot(lds, h + (h >= t ? 1 : 0), t, lane) = part[t];
     ring_issue<N0, kR8, 24>(rg);
     __syncthreads();
     ring_issue<N1, kR8, (24 + N0) % kR8>(rg);
