@@ -10,6 +10,13 @@ done
 for n in FETCH_SIZE WRITE_SIZE SQ_WAVE_CYCLES SQ_INSTS_MFMA SQ_ACTIVE_INST_VALU SQ_INSTS_VALU_TRANS_F32; do
   f=$(ls -t $O/dpmc_$n/*/*_counter_collection.csv 2>/dev/null | head -1); [ -n "$f" ] && cp "$f" profiles/${R}_decode_pmc/${n}_counter_collection.csv
 done
+mkdir -p profiles/${R}_diffonly_pmc
+for n in FETCH_SIZE WRITE_SIZE SQ_WAVE_CYCLES SQ_INSTS_MFMA SQ_ACTIVE_INST_VALU SQ_INSTS_VALU_TRANS_F32; do
+  f=$(ls -t $O/npmc_$n/*/*_counter_collection.csv 2>/dev/null | head -1); [ -n "$f" ] && python3 tools/summarize_pmc.py "$f" > profiles/${R}_diffonly_pmc/${n}_per_kernel.csv
+done
+f=$(ls -t $O/den_stats/*/*_kernel_stats.csv 2>/dev/null | head -1); [ -n "$f" ] && cp "$f" profiles/${R}_diffonly_kernel_stats.csv
+f=$(ls -t $O/den_staged_stats/*/*_kernel_stats.csv 2>/dev/null | head -1); [ -n "$f" ] && cp "$f" profiles/${R}_diffonly_staged_kernel_stats.csv
+[ -f $O/den_perf.txt ] && grep -v libdrm $O/den_perf.txt > profiles/${R}_diffonly_perf.txt
 mkdir -p profiles/${R}_fp32x_pmc
 for n in FETCH_SIZE WRITE_SIZE SQ_WAVE_CYCLES SQ_INSTS_MFMA; do
   f=$(ls -t $O/xpmc_$n/*/*_counter_collection.csv 2>/dev/null | head -1); [ -n "$f" ] && cp "$f" profiles/${R}_fp32x_pmc/${n}_counter_collection.csv

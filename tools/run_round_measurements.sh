@@ -29,6 +29,14 @@ for grp in FETCH_SIZE WRITE_SIZE "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUS
   timeout 300 rocprofv3 --pmc $grp --kernel-trace --output-format csv -d $O/dpmc_$n -- python3 tools/gpu_decode_perf.py 256 > $O/dpmc_$n.log 2>&1
 done
 timeout 200 python tools/gpu_decode_perf.py > $O/decode_perf.txt 2>&1
+# the diffusion_only denoiser (S = 304 per step): kernel stats + counters of the fused step kernel at 256 clips, staged kernels at 64; per-step times
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/den_stats -- python3 tools/gpu_den_once.py 256 bf16 10 > $O/den_stats.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/den_staged_stats -- python3 tools/gpu_den_once.py 256 bf16 10 staged > $O/den_staged_stats.log 2>&1
+for grp in FETCH_SIZE WRITE_SIZE "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_ANY" "SQ_INSTS_MFMA SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE" "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA SQ_BUSY_CU_CYCLES" "SQ_INSTS_VALU_TRANS_F32 SQ_INSTS_VALU_FMA_F32 SQ_INSTS_VALU_MUL_F32 SQ_INSTS_VALU_ADD_F32"; do
+  n=$(echo $grp | cut -d' ' -f1)
+  timeout 300 rocprofv3 --pmc $grp --kernel-trace --output-format csv -d $O/npmc_$n -- python3 tools/gpu_den_once.py 256 bf16 4 > $O/npmc_$n.log 2>&1
+done
+timeout 400 python tools/gpu_den_perf.py 64 256 > $O/den_perf.txt 2>&1
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/audio_stats -- python3 tools/gpu_audio_perf.py 32 > $O/audio_stats.log 2>&1
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/audio_one_stats -- python3 tools/gpu_audio_one_encoder.py 32 > $O/audio_one_stats.log 2>&1
 for grp in FETCH_SIZE WRITE_SIZE "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_ANY" "SQ_INSTS_MFMA SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE"; do
