@@ -160,6 +160,7 @@ int build_denoiser(amuse_ctx* c, const float* den, int what = AMUSE_UPD_ALL) {
 
 int build_prior(amuse_ctx* c, const float* pri, int what = AMUSE_UPD_ALL) {
     static const ParamIndex PI = prior_index();
+    if (!g_capture) c->vae_c1_valid[0] = c->vae_c1_valid[1] = false;   // block 0's hoisted constant belongs to the old decoder weights
     const Params Pp{PI, pri};
     // ---- VAE decoder weight streams: [stage][wave][units]
     for (int prec = 0; prec < 4; ++prec) {
@@ -595,6 +596,7 @@ int amuse_update_weights_device(amuse_ctx* c, const float* denoiser_params_dev, 
     HIP_TRY(hipSetDevice(c->device));
     if (c->repack.empty())
         if (int e = build_repack_maps(c)) return e;
+    if (prior_params_dev) c->vae_c1_valid[0] = c->vae_c1_valid[1] = false;
     for (const auto& r : c->repack) {
         const float* src = r.prior ? prior_params_dev : denoiser_params_dev;
         if (!src || !*r.slot) continue;                 // (an image the context never built, e.g. the 4-wave bf16 stream after an update)
@@ -620,7 +622,7 @@ void amuse_destroy(amuse_ctx* c) {
                     c->vae_w[0], c->vae_w[1], c->vae_w[2], c->vae_w[3], c->vae_w8x, c->vaee_w[2], c->vaee_w[3], c->vae_pvec, c->vae_final_bias, c->vae_pe, c->vae_wv_t, c->vae_bv,
                     c->vae_wo_t, c->vae_bo, c->vaee_w[0], c->vaee_w[1], c->vaee_pvec, c->vaee_pe, c->vaee_tok,
                     c->vaee_emb_bias, c->d_timesteps, c->d_coef, c->d_time_tok, c->d_ts1, c->d_tt1, c->d_coef1,
-                    c->cond_tok, c->lat_tmp, c->fwd_ws, c->vae_ws, c->d_lengths, c->vae_wf, c->vae_skip, c->vae_ca_ws};
+                    c->cond_tok, c->lat_tmp, c->fwd_ws, c->vae_ws, c->d_lengths, c->vae_wf, c->vae_skip, c->vae_ca_ws, c->vae_c1[0], c->vae_c1[1]};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     delete c;
@@ -816,6 +818,23 @@ int amuse_vae_decode(amuse_ctx* c, const float* z, const int* lengths, int B, in
             c->vae_skip_cap = chunk;
         }
         if (int e = ensure(&c->vae_ca_ws, &c->vae_ca_cap, (size_t)chunk * kLayers * kD + 256)) return e;   // + the DMA's overrun
+        // Block 0's self-attention half does not depend on the latent (k_vae_fused.hip / amuse_fused.hpp decoder_block, c1): computed once
+        // per weight set by the kernel's own tapped instantiation on one clip, stream-ordered in front of the first decode that uses it.
+        // AMUSE_VAE_HOIST=0 switches the hoist off (A/B: same bits, block 0 recomputed per clip).
+        static const bool hoist_on = [] { const char* e = getenv("AMUSE_VAE_HOIST"); return !(e && atoi(e) == 0); }();
+        const int pi = precision == PREC_F16 ? 1 : 0;
+        if (hoist_on && !c->vae_c1_valid[pi] && !c->decode_tap && !(c->ablate & 1)) {
+            constexpr size_t kTapFloats = (size_t)11 * kFrames * kD;
+            if (!c->vae_c1[pi]) HIP_TRY(hipMalloc((void**)&c->vae_c1[pi], ((size_t)kFrames * kD + kTapFloats) * sizeof(float)));
+            float* tap = c->vae_c1[pi] + (size_t)kFrames * kD;
+            HIP_TRY(launch_vae_ca(z, c->vae_wv_t, c->vae_bv, c->vae_wo_t, c->vae_bo, c->vae_ca_ws, 1, st));
+            VaeFusedArgs fa{};
+            fa.wstream = precision == PREC_F16 ? c->vae_wfh : c->vae_wf; fa.pvec = c->vae_pvec; fa.final_bias = c->vae_final_bias; fa.pe = c->vae_pe;
+            fa.ca = c->vae_ca_ws; fa.skip = c->vae_skip; fa.B = 1; fa.quat_mode = quat_mode; fa.tap_out = tap;
+            HIP_TRY(precision == PREC_F16 ? launch_vae_fusedh(fa, st) : launch_vae_fused(fa, st));
+            HIP_TRY(hipMemcpyAsync(c->vae_c1[pi], tap + (size_t)10 * kFrames * kD, (size_t)kFrames * kD * sizeof(float), hipMemcpyDeviceToDevice, st));
+            c->vae_c1_valid[pi] = true;
+        }
         for (int b0 = 0; b0 < B; b0 += chunk) {
             const int nb = (B - b0) < chunk ? (B - b0) : chunk;
             HIP_TRY(launch_vae_ca(z + (size_t)b0 * kD, c->vae_wv_t, c->vae_bv, c->vae_wo_t, c->vae_bo, c->vae_ca_ws, nb, st));
@@ -827,6 +846,7 @@ int amuse_vae_decode(amuse_ctx* c, const float* z, const int* lengths, int B, in
             fa.trans_out = trans_out ? trans_out + (size_t)b0 * kFrames * 3 : nullptr;
             fa.B = nb; fa.quat_mode = quat_mode;
             fa.tap_out = b0 == 0 ? c->decode_tap : nullptr;   // (amuse_debug_set_decode_tap: tests)
+            fa.c1 = (hoist_on && c->vae_c1_valid[pi] && !fa.tap_out) ? c->vae_c1[pi] : nullptr;
             fa.ablate_attention = c->ablate & 1;
             HIP_TRY(precision == PREC_F16 ? launch_vae_fusedh(fa, st) : launch_vae_fused(fa, st));
         }

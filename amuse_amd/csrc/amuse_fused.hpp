@@ -109,6 +109,8 @@ struct Stager {
     const char* ring;   // weight ring base (generic pointer) + lane * 16
     int widx, ridx;     // buffer the next fetch fills / buffer the current stage reads
 };
+// (A wave-uniform source base in SGPRs + a 32-bit lane offset - the saddr form of global_load_lds_dwordx4 - and 32-bit LDS addresses for
+// the ring were tried in round 4 to free the four registers these pointers hold: hipcc's allocation got WORSE, 28 -> 46 spilled registers.)
 __device__ __forceinline__ void stage_fetch(Stager& s) {
     const unsigned d = __builtin_amdgcn_readfirstlane(s.dst0 + s.widx * kStageBytes);
 #pragma unroll
@@ -402,9 +404,16 @@ __device__ __forceinline__ void store_tap(float* tap, int slot, const f32x4 (&x)
 template <int NT, int MODE, bool TAP, bool ENCL = false, bool NOATTN = false>
 __device__ __forceinline__ void decoder_block(f32x4 (&x)[NT][kTiles], Stager& sg, const float* pvec_g, float* tap_out, int blk, int tile0,
                                               const float* pv, const float* pv_next_src, unsigned pv_next_dst, const float* cal,
-                                              char* kv, uint4* skipbuf, int len, int wave, int lane, const int S = kFrames) {
+                                              char* kv, uint4* skipbuf, int len, int wave, int lane, const int S = kFrames,
+                                              const float* c1 = nullptr) {
     const int g = lane >> 4, r = lane & 15;
     [[maybe_unused]] const bool prof_on = blockIdx.x == 0 && threadIdx.x == 0 && (blk == 1 || blk == 6);
+    // c1 (block 0 of the DECODER, full-length clips only): the decoder's input is zeros + query_pos_decoder.pe (vae.py:220,252-259) and the
+    // latent enters through the cross-attention alone, so block 0's self-attention half - q, k, v, softmax(q k^T) v, out_proj, norm1 - is the
+    // same [300][128] array for every clip of a weight set.  The library computes it once per weight set WITH THIS KERNEL (the tapped
+    // instantiation's slot 10: the same instruction stream, hence the same bits) and the block starts from it; ragged clips (another key mask)
+    // take the full path.  The kernel then starts its weight stream behind block 0's eight attention stages (OP_KERNEL).
+    const bool hoist = MODE == 0 && !ENCL && c1 != nullptr;
     FSTAMP(1);   // block start
     OPV xb[NT][4];
     if constexpr (MODE == 2) {
@@ -435,6 +444,18 @@ __device__ __forceinline__ void decoder_block(f32x4 (&x)[NT][kTiles], Stager& sg
         }
     }
     FSTAMP(2);   // skip linear done
+    if (hoist) {
+        if (pv_next_src) {   // (the next block's small parameters: otherwise issued inside the head loop)
+            const unsigned d = __builtin_amdgcn_readfirstlane(pv_next_dst + wave * 1024);
+            glds16(reinterpret_cast<const uint4*>(pv_next_src) + wave * 64 + lane, d);
+        }
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            const int frame = 16 * (tile0 + 4 * j) + r;
+#pragma unroll
+            for (int t = 0; t < kTiles; ++t) x[j][t] = frame < kFrames ? ld4(c1 + (size_t)frame * kD + 16 * t + 4 * g) : splat4(0.f);
+        }
+    } else {
     // ---------------- self-attention (cross_attention.py:323-330): x = norm1(x + out_proj(softmax(q k^T) v))
     pack_rows<NT>(xb, x);
 #pragma unroll
@@ -525,6 +546,7 @@ __device__ __forceinline__ void decoder_block(f32x4 (&x)[NT][kTiles], Stager& sg
         stage_end(sg);
         FSTAMP(9);   // barrier of stage B passed
     }
+    }
     [[maybe_unused]] const float* ca = cal + blk * kD;
     if constexpr (ENCL) {
 #pragma unroll 1
@@ -544,7 +566,14 @@ __device__ __forceinline__ void decoder_block(f32x4 (&x)[NT][kTiles], Stager& sg
 #else
 #pragma unroll 1
     for (int j = 0; j < NT; ++j) {   // runtime loop, the tiles rotate through x[0]
-        layer_norm_rows<true>(x[0], pv + PV_LN1_W, pv + PV_LN1_B, g);
+        if (!hoist) layer_norm_rows<true>(x[0], pv + PV_LN1_W, pv + PV_LN1_B, g);
+        if constexpr (TAP && MODE == 0) {   // slot 10 of the taps: block 0 behind norm1 - what the hoist loads (see c1 above)
+            const int frame = 16 * (tile0 + 4 * j) + r;
+            if (tap_out && blk == 0 && blockIdx.x == 0 && frame < kFrames) {
+#pragma unroll
+                for (int t = 0; t < kTiles; ++t) st4(tap_out + ((size_t)10 * kFrames + frame) * kD + 16 * t + 4 * g, x[0][t]);
+            }
+        }
         // cross-attention onto the single latent token == per-clip constant; x = norm2(x + ca)  (cross_attention.py:331-337)
 #pragma unroll
         for (int t = 0; t < kTiles; ++t) x[0][t] += ld4(ca + 16 * t + 4 * g);

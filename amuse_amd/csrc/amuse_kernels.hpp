@@ -195,7 +195,9 @@ struct VaeFusedArgs {
     float* feats_out;          // [B][300][333] or null
     float* poses_out;          // [B][300][55][3] or null
     float* trans_out;          // [B][300][3] or null
-    float* tap_out;            // [10][300][128] or null: clip 0's fp32 residual stream after blocks 0..8 and after decoder.norm (tests)
+    float* tap_out;            // [11][300][128] or null: clip 0's fp32 residual stream after blocks 0..8, after decoder.norm (tests) and - slot 10 -
+                               // behind block 0's norm1 (what the library keeps as c1)
+    const float* c1;           // [300][128] or null: norm1(PE + SA(PE)) of block 0 for this weight set (full-length clips start from it)
     int B, quat_mode;
     int ablate_attention;      // 1: the instantiation without softmax(Q K^T) V (amuse_debug_set_ablation: timing only, wrong outputs)
 };

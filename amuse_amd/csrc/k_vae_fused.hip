@@ -70,7 +70,8 @@ __device__ __forceinline__ void decode_tiles(const VaeFusedArgs& a, char* smem, 
 #pragma unroll 1
     for (int blk = 0; blk < 4; ++blk)
         decoder_block<NT, 0, TAP, false, NOATTN>(x, sg, a.pvec, a.tap_out, blk, tile0, pvl + (blk & 1) * (kPvSlot / 4), a.pvec + (blk + 1) * PV_BLOCK,
-                             lds0 + kOffPv + ((blk + 1) & 1) * kPvSlot, cal, kv, skipbuf, len, wave, lane);
+                             lds0 + kOffPv + ((blk + 1) & 1) * kPvSlot, cal, kv, skipbuf, len, wave, lane, kFrames,
+                             (blk == 0 && len == kFrames) ? a.c1 : nullptr);
     decoder_block<NT, 1, TAP, false, NOATTN>(x, sg, a.pvec, a.tap_out, 4, tile0, pvl, a.pvec + 5 * PV_BLOCK, lds0 + kOffPv + kPvSlot, cal, kv, skipbuf, len, wave, lane);
 #pragma unroll 1
     for (int blk = 5; blk < kLayers; ++blk)
@@ -172,7 +173,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     glds16(reinterpret_cast<const uint4*>(a.pvec) + wave * 64 + lane, lds0 + kOffPv + wave * 1024);
     if (wave < 5) glds16(reinterpret_cast<const uint4*>(a.ca + (size_t)b * kLayers * kD) + wave * 64 + lane, lds0 + kOffCa + wave * 1024);
     Stager sg;
-    sg.src = a.wstream + (size_t)wave * 2 * 64 + lane;
+    // (a full-length clip with the block-0 constant at hand starts behind block 0's eight attention stages: decoder_block, c1)
+    const size_t skip_units = (a.c1 && len == kFrames) ? (size_t)8 * kStage : 0;
+    sg.src = a.wstream + (skip_units + (size_t)wave * 2) * 64 + lane;
     sg.dst0 = lds0 + kOffW + wave * 2048;
     sg.ring = smem + kOffW + lane * 16;
     sg.widx = 0;

@@ -26,6 +26,11 @@ namespace {
 #ifndef AMUSE_R8_FAST_ERF
 #define AMUSE_R8_FAST_ERF 0
 #endif
+// timing ablations (variant builds only; wrong numerics, the rest of the instruction stream in place): 1 = no erf in the FFN activation,
+// 2 = every weight fragment pair of a stage read ONCE (pair 0) instead of eight times, 4 = one MFMA per product instead of three
+#ifndef AMUSE_R8_ABL
+#define AMUSE_R8_ABL 0
+#endif
 constexpr int kRowTiles = 19;                 // ceil(300 / 16)
 #ifndef AMUSE_R8_NT
 #define AMUSE_R8_NT 1
@@ -72,6 +77,7 @@ __device__ __forceinline__ f16x8 wfrag(const Stager& s, int u) {
 }
 // one product of split operands: acc += Wl.xh + Wh.xl + Wh.xh (the term order of gemm_ring_s, amuse_dev.hpp)
 __device__ __forceinline__ f32x4 mfma3(f16x8 wh, f16x8 wl, const F16Pair& x, f32x4 acc) {
+    if constexpr ((AMUSE_R8_ABL & 4) != 0) return mfma_f16(wh + wl, x.hi + x.lo, acc);
     acc = mfma_f16(wl, x.hi, acc);
     acc = mfma_f16(wh, x.lo, acc);
     return mfma_f16(wh, x.hi, acc);
@@ -84,7 +90,9 @@ __device__ __forceinline__ void for_pairs(Stager& s, F&& f) {
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
         const f16x8 ch = h, cl = l;
-        if (i + 1 < 8) { h = wfrag(s, 2 * i + 2); l = wfrag(s, 2 * i + 3); }
+        if constexpr ((AMUSE_R8_ABL & 2) == 0) {
+            if (i + 1 < 8) { h = wfrag(s, 2 * i + 2); l = wfrag(s, 2 * i + 3); }
+        }
         f(i, ch, cl);
     }
     stage_end(s);
@@ -199,7 +207,8 @@ __global__ __launch_bounds__(64 * kWaves) __attribute__((amdgpu_waves_per_eu((kW
 #pragma unroll
                 for (int i = 0; i < 2; ++i)
 #pragma unroll
-                    for (int m = 0; m < 4; ++m) hid[j][i][m] = AMUSE_R8_FAST_ERF ? gelu_erf_fast(hid[j][i][m]) : gelu_erf(hid[j][i][m]);
+                    for (int m = 0; m < 4; ++m)
+                        hid[j][i][m] = (AMUSE_R8_ABL & 1) ? 0.5f * hid[j][i][m] : (AMUSE_R8_FAST_ERF ? gelu_erf_fast(hid[j][i][m]) : gelu_erf(hid[j][i][m]));
                 hs[j] = split_f16(hid[j][0], hid[j][1]);
             }
             for_pairs(sg, [&](int o, f16x8 wh, f16x8 wl) {

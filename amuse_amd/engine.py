@@ -239,11 +239,11 @@ class HipEngine:
 
     def vae_decode(self, z, lengths: Optional[Sequence[int]] = None, precision="fp32", quat_mode="p3d",
                    return_feats=False, return_taps=False):
-        """return_taps (fused bf16 kernel only, tests): out["taps"] = (10, 300, 128) - clip 0's residual stream after decoder
-        blocks 0..8 and after decoder.norm (amuse_debug_set_decode_tap)."""
+        """return_taps (fused bf16 kernel only, tests): out["taps"] = (11, 300, 128) - clip 0's residual stream after decoder
+        blocks 0..8, after decoder.norm and (slot 10) behind block 0's norm1 (amuse_debug_set_decode_tap)."""
         z = self._dev(z)
         B = z.shape[0]
-        taps = torch.zeros(10, 300, 128, device=self.device, dtype=torch.float32) if return_taps else None
+        taps = torch.zeros(11, 300, 128, device=self.device, dtype=torch.float32) if return_taps else None
         feats = torch.empty(B, 300, 333, device=self.device, dtype=torch.float32) if return_feats else None
         poses = torch.empty(B, 300, 55, 3, device=self.device, dtype=torch.float32)
         trans = torch.empty(B, 300, 3, device=self.device, dtype=torch.float32)

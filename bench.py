@@ -39,7 +39,7 @@ STREAM_MB_PER_STEP = {"bf16": 3.80, "fp16": 3.80, "fp32": 7.60, "fp32x": 7.60}
 CU_LOAD_BYTES_PER_CLK = 64.0
 
 
-PMC_DIR = "profiles/r03_pmc"
+PMC_DIR = "profiles/r04_pmc"
 
 
 def pmc_traffic_bytes(clips, T, precision):

@@ -313,9 +313,10 @@ int amuse_debug_gemm(const void* A, const void* W, const float* bias, int M, int
  * to 128][F], pad rows zeroed; 1: bf16 tile-major -> row-major [M][F]; 2: fp32 tile-major -> row-major [M][F]. */
 int amuse_debug_tile(const void* src, void* dst, int M, int F, int what, void* stream);
 
-/* Debugging taps of the FUSED bf16 decode kernel (k_vae_fused.hip), for tests: while tap_out (dev [10][300][128] fp32) is set,
- * every fused amuse_vae_decode launch writes clip 0's residual stream after decoder blocks 0..8 (slots 0..8) and after
- * decoder.norm (slot 9) there, through a separate instantiation of the kernel; NULL switches the taps off again. */
+/* Debugging taps of the FUSED bf16 decode kernel (k_vae_fused.hip), for tests: while tap_out (dev [11][300][128] fp32) is set,
+ * every fused amuse_vae_decode launch writes clip 0's residual stream after decoder blocks 0..8 (slots 0..8), after
+ * decoder.norm (slot 9) and behind block 0's norm1 (slot 10: norm1(PE + SA(PE)), the per-weight-set constant full-length clips start
+ * from) there, through a separate instantiation of the kernel; NULL switches the taps off again. */
 int amuse_debug_set_decode_tap(amuse_ctx* ctx, float* tap_out);
 
 /* Timing ablation of the fused per-clip kernels (k_vae_fused.hip, k_den_fused.hip), for bench.py's attention-only roofline figure:

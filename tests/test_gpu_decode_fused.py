@@ -208,3 +208,45 @@ def test_decode_chunk_boundaries_are_invisible():
     finally:
         eng.set_decode_path("auto")
         eng.close()
+
+
+def test_block0_hoist_is_bitwise_and_follows_the_weights():
+    """The fused decoder starts full-length clips from norm1(PE + SA(PE)) of block 0 - the same array for every clip of a weight set
+    (the decoder's input is zeros + query_pos_decoder.pe, vae.py:220,252-259; the latent enters through the cross-attention only) -
+    computed once per weight set by the kernel's own tapped instantiation (slot 10).  Bitwise the un-hoisted path (the tapped launch and
+    ragged clips take it), in both 16-bit builds, in mixed batches, and recomputed after a weight update."""
+    from amuse_amd import weights as wts
+    from amuse_amd.engine import HipEngine
+    from oracle import amuse_oracle as orc
+    wd, wp = wts.make_denoiser_weights(0), wts.make_prior_weights(0)
+    eng = HipEngine(wd, wp, "cuda:0")
+    try:
+        eng.set_decode_path("fused")
+        z = torch.randn(5, 128, generator=torch.Generator().manual_seed(3))
+        Wp = orc.to_torch(wp)
+        for prec in ("bf16", "fp16"):
+            plain = eng.vae_decode(z, None, prec, return_feats=True)                       # hoisted
+            tapped = eng.vae_decode(z, None, prec, return_feats=True, return_taps=True)    # the full path for every clip of the launch
+            assert torch.equal(plain["feats"], tapped["feats"]) and torch.equal(plain["poses"], tapped["poses"]), prec
+            mixed = eng.vae_decode(z, [300, 173, 300, 1, 300], prec, return_feats=True)    # clips 0, 2, 4 hoisted, 1 and 3 not
+            assert torch.equal(mixed["feats"][[0, 2, 4]], plain["feats"][[0, 2, 4]]), prec
+            alone = eng.vae_decode(z[1:2], [173], prec, return_feats=True)
+            assert torch.equal(mixed["feats"][1], alone["feats"][0]), prec
+            # slot 10 against the oracle's arithmetic: norm1(x0 + self_attn(x0)), x0 = the positional table (16-bit operand rounding apart)
+            x0 = Wp["query_pos_decoder.pe"][:300, 0][None]
+            p = "decoder.input_blocks.0"
+            ref = orc.layer_norm(x0 + orc.mha_self(orc.Ops(), x0, Wp, p + ".self_attn"), Wp[p + ".norm1.weight"], Wp[p + ".norm1.bias"])[0]
+            d = (tapped["taps"][10].cpu() - ref).abs()
+            assert float(d.max()) < (3e-2 if prec == "bf16" else 5e-3) and float(d.median()) < (3e-3 if prec == "bf16" else 5e-4), (prec, float(d.max()))
+        # new decoder weights: the constant is recomputed (stale, the hoisted launch would differ from the tapped one)
+        wp1 = wts.make_prior_weights(1)
+        eng.update_weights(prior_sd=wp1)
+        a = eng.vae_decode(z, None, "bf16", return_feats=True)
+        b = eng.vae_decode(z, None, "bf16", return_feats=True, return_taps=True)
+        assert torch.equal(a["feats"], b["feats"])
+        fresh = HipEngine(wd, wp1, "cuda:0")
+        fresh.set_decode_path("fused")
+        assert torch.equal(a["feats"], fresh.vae_decode(z, None, "bf16", return_feats=True)["feats"])
+        fresh.close()
+    finally:
+        eng.close()

@@ -9,16 +9,17 @@ if len(sys.argv) > 1 and sys.argv[1] == "--child":
     from amuse_amd.engine import HipEngine
     eng = HipEngine(wts.make_denoiser_weights(0), wts.make_prior_weights(0))
     eng.set_decode_path("fused")
+    PREC = os.environ.get("AMUSE_DV_PREC", "bf16")   # fp32x: the k_vae_rows8x + k_vae_attn_x pair
     out = []
     for B in [int(x) for x in sys.argv[2:]]:
         z = torch.randn(B, 128, generator=torch.Generator().manual_seed(1)).cuda()
         ts = []
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         for i in range(7):
-            e0.record(); eng.vae_decode(z, None, "bf16"); e1.record(); torch.cuda.synchronize()
+            e0.record(); eng.vae_decode(z, None, PREC); e1.record(); torch.cuda.synchronize()
             if i >= 2:
                 ts.append(e0.elapsed_time(e1))
-        h = int(eng.vae_decode(z, None, "bf16")["poses"].view(torch.int32).to(torch.int64).sum().item()) & 0xffffffff
+        h = int(eng.vae_decode(z, None, PREC)["poses"].view(torch.int32).to(torch.int64).sum().item()) & 0xffffffff
         out.append(f"B={B}: min {min(ts):.3f} med {sorted(ts)[2]:.3f} ms [{h:08x}]")
     print("  ".join(out))
 else:
