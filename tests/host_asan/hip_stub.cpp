@@ -40,13 +40,18 @@ hipError_t launch_sample8h(const SampleArgs&, hipStream_t) { return hipSuccess; 
 hipError_t launch_time_tokens(const int*, int, const float*, const float*, const float*, const float*, const float*, const float*, float*, hipStream_t) { return hipSuccess; }
 hipError_t launch_cond_tokens(const CondArgs&, hipStream_t) { return hipSuccess; }
 hipError_t launch_repack(const float*, const int*, void*, size_t, int, hipStream_t) { return hipSuccess; }
-hipError_t launch_add_noise(const float*, const float*, const float*, const float*, float*, int, hipStream_t) { return hipSuccess; }
-hipError_t launch_counter_normal(uint64_t, uint64_t, int, int, int, float*, hipStream_t) { return hipSuccess; }
-hipError_t launch_vae_rows(const VaeRowsArgs&, int, bool, hipStream_t) { return hipSuccess; }
+hipError_t launch_add_noise(const float*, const float*, const float*, const float*, float*, int, hipStream_t, int) { return hipSuccess; }
+hipError_t launch_counter_normal(uint64_t, uint64_t, int, int, int, float*, hipStream_t, int) { return hipSuccess; }
+hipError_t launch_vae_rows(const VaeRowsArgs&, int, int, hipStream_t) { return hipSuccess; }
 hipError_t launch_vae_rows8x(const VaeRowsArgs&, hipStream_t) { return hipSuccess; }
-hipError_t launch_vae_attn(const VaeAttnArgs&, int, bool, hipStream_t) { return hipSuccess; }
+hipError_t launch_vae_attn(const VaeAttnArgs&, int, int, hipStream_t) { return hipSuccess; }
 hipError_t launch_vae_fused(const VaeFusedArgs&, hipStream_t) { return hipSuccess; }
 hipError_t launch_vae_fusedh(const VaeFusedArgs&, hipStream_t) { return hipSuccess; }
+hipError_t launch_den_fused(const DenFusedArgs&, hipStream_t) { return hipSuccess; }
+hipError_t launch_den_fusedh(const DenFusedArgs&, hipStream_t) { return hipSuccess; }
+hipError_t launch_sample_dec(const SampleDecArgs&, int, hipStream_t) { return hipSuccess; }
+hipError_t launch_mem_kv(const float*, int, const float*, const float*, float*, hipStream_t) { return hipSuccess; }
+hipError_t launch_feats_to_smplx(const float*, size_t, int, float*, float*, hipStream_t) { return hipSuccess; }
 hipError_t launch_smplx_to_feats(const float*, const float*, size_t, float*, hipStream_t) { return hipSuccess; }
 hipError_t launch_vae_latent(const float*, const float*, float*, float*, float*, int, hipStream_t) { return hipSuccess; }
 hipError_t launch_vae_ca(const float*, const float*, const float*, const float*, const float*, float*, int, hipStream_t) { return hipSuccess; }

@@ -1,4 +1,4 @@
-// Drives the library's host code (amuse_api.hip, amuse_audio_api.hip) through the C ABI with the stubbed runtime of hip_stub.cpp
+// Drives the library's host code (amuse_api.hip, amuse_variants.hip, amuse_audio_api.hip) through the C ABI with the stubbed runtime of hip_stub.cpp
 // under AddressSanitizer + UBSan: context construction and weight packing (both precisions, encoder streams), re-packing in
 // place, schedules, every entry point's argument checks and workspace growth, the audio context (weight images of three
 // encoders, workspaces for several batch sizes incl. chunking), teardown without leaks of "device" memory.
@@ -97,6 +97,59 @@ int main(int argc, char** argv) {
     REQUIRE(amuse_update_weights_device(c, den.data(), pri.data(), 4, nullptr) != 0);
     amuse_destroy(c);
     amuse_destroy(nullptr);
+    // the Denoiser variants (amuse_variants.hip): construction + packing, schedule, sampling / single steps on both paths of the
+    // pose-space step (staged below 64 clips, fused from there), re-packing, the argument checks of the variant-only entry points
+    REQUIRE(amuse_denoiser_param_count(AMUSE_ARCH_ENC) == AMUSE_DENOISER_PARAMS && amuse_denoiser_param_count(7) == 0);
+    REQUIRE(amuse_create_arch(0, 4, den.data(), den.size(), pri.data(), pri.size()) == nullptr);
+    for (int arch : {AMUSE_ARCH_DEC, AMUSE_ARCH_ENC_POSE, AMUSE_ARCH_DEC_POSE}) {
+        const bool pose = arch != AMUSE_ARCH_DEC;
+        std::vector<float> dv(amuse_denoiser_param_count(arch));
+        fill(dv, 10 + arch, 0.2f);
+        REQUIRE(amuse_create_arch(0, arch, dv.data(), dv.size() - 1, pri.data(), pri.size()) == nullptr);
+        amuse_ctx* v = amuse_create_arch(0, arch, dv.data(), dv.size(), pose ? nullptr : pri.data(), pose ? 0 : pri.size());
+        REQUIRE(v != nullptr);
+        REQUIRE(amuse_arch(v) == arch);
+        const size_t sd = amuse_state_dim(v);
+        REQUIRE(sd == (pose ? (size_t)AMUSE_POSE_STATE : 128u));
+        const int T = 3, VB = 70;
+        std::vector<int> ts{2, 1, 0};
+        std::vector<float> coef((size_t)T * 8, 0.5f);
+        amuse_schedule s{T, ts.data(), coef.data(), nullptr};
+        REQUIRE(amuse_set_schedule(v, &s, nullptr) == 0);
+        std::vector<float> x((size_t)VB * sd), out((size_t)VB * sd), vtraj((size_t)T * VB * sd), vnoise((size_t)T * VB * sd);
+        for (int B : {1, 17, 64, VB})
+            for (int prec : {AMUSE_PREC_F32, AMUSE_PREC_BF16, AMUSE_PREC_F32X, AMUSE_PREC_F16}) {
+                REQUIRE(amuse_sample(v, cond.data(), cond.data(), B & 1 ? nullptr : cond.data(), B, prec, 7, 11, nullptr, nullptr, out.data(), nullptr, nullptr) == 0);
+                REQUIRE(amuse_sample(v, cond.data(), nullptr, nullptr, B, prec, 7, 0, x.data(), vnoise.data(), out.data(), vtraj.data(), nullptr) == 0);
+                REQUIRE(amuse_denoise_step(v, x.data(), 981, cond.data(), cond.data(), cond.data(), B, prec, out.data(), nullptr, nullptr) == 0);
+                REQUIRE(amuse_counter_normal(v, 3, 4, B, 0, 1, out.data(), nullptr) == 0);
+                {
+                    std::vector<int> tsb(B, 2);
+                    std::vector<float> sa(B, 0.9f), sb(B, 0.1f);
+                    REQUIRE(amuse_diffusion_forward(v, x.data(), vnoise.data(), tsb.data(), sa.data(), sb.data(), cond.data(), cond.data(), cond.data(), B, prec,
+                                                    out.data(), vtraj.data(), nullptr) == 0);
+                    REQUIRE(amuse_diffusion_backward(v, cond.data(), cond.data(), cond.data(), B, prec, AMUSE_QUAT_P3D, 1, 2, nullptr, nullptr, out.data(), poses.data(),
+                                                     trans.data(), nullptr) == 0);
+                    REQUIRE(amuse_update_weights_device(v, dv.data(), nullptr, AMUSE_UPD_BF16, nullptr) != 0);   // shipped configuration only
+                }
+                if (pose) {
+                    REQUIRE(amuse_denoise_step_pose(v, x.data(), 5, cond.data(), nullptr, cond.data(), B & 1 ? lengths.data() : nullptr, B, prec, out.data(), nullptr) == 0);
+                    REQUIRE(amuse_vae_decode(v, lat.data(), nullptr, B, prec, AMUSE_QUAT_P3D, feats.data(), poses.data(), trans.data(), nullptr) != 0);   // no prior
+                } else {
+                    REQUIRE(amuse_denoise_step_pose(v, x.data(), 5, cond.data(), nullptr, nullptr, nullptr, B, prec, out.data(), nullptr) != 0);
+                    REQUIRE(amuse_vae_decode(v, out.data(), nullptr, B, prec, AMUSE_QUAT_P3D, feats.data(), poses.data(), trans.data(), nullptr) == 0);
+                }
+            }
+        REQUIRE(amuse_feats_to_smplx(v, feats.data(), 5, AMUSE_QUAT_P3D, poses.data(), trans.data(), nullptr) == 0);
+        REQUIRE(amuse_feats_to_smplx(v, nullptr, 5, AMUSE_QUAT_P3D, poses.data(), trans.data(), nullptr) != 0);
+        REQUIRE(amuse_feats_to_smplx(v, feats.data(), 0, AMUSE_QUAT_P3D, poses.data(), trans.data(), nullptr) != 0);
+        for (int mask : {1, 0}) REQUIRE(amuse_debug_set_ablation(v, mask) == 0);
+        fill(dv, 20 + arch, 0.1f);
+        for (int what : {AMUSE_UPD_F32, AMUSE_UPD_BF16, AMUSE_UPD_F32X, AMUSE_UPD_F16, AMUSE_UPD_ALL})
+            REQUIRE(amuse_update_weights(v, dv.data(), dv.size(), nullptr, 0, what, nullptr) == 0);
+        REQUIRE(amuse_update_weights(v, dv.data(), dv.size() - 1, nullptr, 0, AMUSE_UPD_ALL, nullptr) != 0);
+        amuse_destroy(v);
+    }
     if (with_audio) {
         std::vector<float> ast(AMUSE_AST_PARAMS), mel((size_t)128 * 257), win(400, 0.5f);
         fill(ast, 5, 0.05f);
