@@ -27,23 +27,34 @@ namespace {
 #define AMUSE_R8_FAST_ERF 0
 #endif
 // timing ablations (variant builds only; wrong numerics, the rest of the instruction stream in place): 1 = no erf in the FFN activation,
-// 2 = every weight fragment pair of a stage read ONCE (pair 0) instead of eight times, 4 = one MFMA per product instead of three
+// 2 = every weight fragment pair of a stage read ONCE (pair 0) instead of eight times, 4 = one MFMA per product instead of three,
+// 8 = no activation stores (x, skip, q, k, v), 16 = every activation load from row 0 of clip 0 (cache hits)
 #ifndef AMUSE_R8_ABL
 #define AMUSE_R8_ABL 0
 #endif
+// 1 = the weight stream is copied by ONE extra wave that does nothing else (the row waves never wait on vmcnt after their input loads), and the
+// biases read behind the first activation store come from LDS: on this ISA stores count in vmcnt like loads, so a row wave that also copies
+// (vmcnt(2) at every stage end) or loads a bias behind its q stores sits out every store's round trip to L2 / HBM - 0.43 of the decode's 2.35 ms
+// at 256 clips (profiles/r04_rows8x_store_ablation.txt).  0 = eight of the row waves copy (the round-3 kernel; A/B)
+#ifndef AMUSE_R8_PROD
+#define AMUSE_R8_PROD 1
+#endif
+constexpr bool kProd = AMUSE_R8_PROD != 0;
 constexpr int kRowTiles = 19;                 // ceil(300 / 16)
 #ifndef AMUSE_R8_NT
 #define AMUSE_R8_NT 1
 #endif
 constexpr int kTilesPerWave = AMUSE_R8_NT;    // row tiles per wave: a weight fragment read from LDS feeds 3 x NT MFMAs
-constexpr int kDmaWaves = 8;                 // the waves that copy the stream: 16 units per LDS stage, two pieces each
+// the waves that copy the stream (16 units per LDS stage): eight with two pieces each, four with four in the small workgroups
+constexpr int dma_waves(int waves) { return waves >= 8 ? 8 : 4; }
 constexpr int kStage = 16;                    // units per LDS stage (8 hi | lo pairs)
 constexpr int kStageBytes = kStage * 1024;
 constexpr int kWBufs = 3;
 constexpr int kQStride = 100;                 // staging row stride (floats) of one 96-feature quarter of the last stage
 constexpr int kOffW = 0;
-constexpr int kOffStage = kWBufs * kStageBytes;
-constexpr int rows8_lds_bytes(int waves) { return kOffStage + waves * 16 * kQStride * 4; }
+constexpr int kOffBias = kWBufs * kStageBytes;          // [384] floats: in_proj bias of block `stage` / final_layer.bias (last stage)
+constexpr int kOffStage = kOffBias + 384 * 4;
+constexpr int rows8_lds_bytes(int waves, bool last_stage) { return kOffStage + (last_stage ? waves * 16 * kQStride * 4 : 0); }   // (the staging tiles serve the final stage only)
 
 __device__ __forceinline__ void glds16(const uint4* gsrc, unsigned lds_dst) {   // (k_vae_fused.hip: LDS-DMA outside hipcc's waitcnt bookkeeping)
     unsigned keep;
@@ -52,6 +63,7 @@ __device__ __forceinline__ void glds16(const uint4* gsrc, unsigned lds_dst) {   
                  : "v"(gsrc), "s"(lds_dst)
                  : "memory");
 }
+template <int P>   // P = pieces (1 KiB units) a copying wave moves per stage
 struct Stager {
     const uint4* src;   // this lane's source address of the wave's pieces of the NEXT stage to fetch
     unsigned dst0;      // LDS byte address of the wave's pieces inside buffer 0
@@ -59,20 +71,27 @@ struct Stager {
     int widx, ridx;     // buffer the next fetch fills / buffer the current stage reads
     bool dma;           // this wave copies (waves 0..7)
 };
-__device__ __forceinline__ void stage_fetch(Stager& s) {
-    if (s.dma) {   // (wave-uniform; the other waves' vmcnt(2) at the stage's end is trivially true - the barrier is what they need)
+template <int P>
+__device__ __forceinline__ void stage_fetch(Stager<P>& s) {
+    if constexpr (P == 0) return;
+    if (s.dma) {   // (wave-uniform; the other waves' vmcnt(P) at the stage's end is trivially true - the barrier is what they need)
         const unsigned d = __builtin_amdgcn_readfirstlane(s.dst0 + s.widx * kStageBytes);
 #pragma unroll
-        for (int i = 0; i < 2; ++i) glds16(s.src + i * 64, d + i * 1024);
+        for (int i = 0; i < P; ++i) glds16(s.src + i * 64, d + i * 1024);
     }
     s.src += kStage * 64;
     s.widx = s.widx == kWBufs - 1 ? 0 : s.widx + 1;
 }
-__device__ __forceinline__ void stage_end(Stager& s) {
-    asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+template <int P>
+__device__ __forceinline__ void stage_end(Stager<P>& s) {
+    if constexpr (P == 0) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // (row wave beside a copying wave: no vmcnt)
+    else if constexpr (P == 2) asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    else if constexpr (P == 4) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(16)\n\ts_barrier" ::: "memory");
     s.ridx = s.ridx == kWBufs - 1 ? 0 : s.ridx + 1;
 }
-__device__ __forceinline__ f16x8 wfrag(const Stager& s, int u) {
+template <int P>
+__device__ __forceinline__ f16x8 wfrag(const Stager<P>& s, int u) {
     return __builtin_bit_cast(f16x8, *reinterpret_cast<const uint4*>(s.ring + s.ridx * kStageBytes + u * 1024));
 }
 // one product of split operands: acc += Wl.xh + Wh.xl + Wh.xh (the term order of gemm_ring_s, amuse_dev.hpp)
@@ -83,8 +102,8 @@ __device__ __forceinline__ f32x4 mfma3(f16x8 wh, f16x8 wl, const F16Pair& x, f32
     return mfma_f16(wh, x.hi, acc);
 }
 // the 8 unit pairs of the current LDS stage, pair i -> f(i, hi, lo); the fragments of pair i + 1 are read before pair i's MFMAs
-template <class F>
-__device__ __forceinline__ void for_pairs(Stager& s, F&& f) {
+template <int P, class F>
+__device__ __forceinline__ void for_pairs(Stager<P>& s, F&& f) {
     stage_fetch(s);
     f16x8 h = wfrag(s, 0), l = wfrag(s, 1);
 #pragma unroll
@@ -99,8 +118,8 @@ __device__ __forceinline__ void for_pairs(Stager& s, F&& f) {
 }
 // acc[j][o] += W[o-tile][k-pairs 0..3] . x_j over FOUR LDS stages (k-pair outer, 8 output tiles inner); a fragment pair read from LDS
 // feeds the MFMAs of all NT row tiles of the wave
-template <int NT>
-__device__ __forceinline__ void gemm_k128_o8(f32x4 (&acc)[NT][8], const F16Pair (&xs)[NT][4], Stager& s) {
+template <int NT, int P>
+__device__ __forceinline__ void gemm_k128_o8(f32x4 (&acc)[NT][8], const F16Pair (&xs)[NT][4], Stager<P>& s) {
 #pragma unroll
     for (int c = 0; c < 4; ++c)
         for_pairs(s, [&](int o, f16x8 wh, f16x8 wl) {
@@ -118,8 +137,12 @@ __device__ __forceinline__ void split_x(F16Pair (&xs)[NT][4], const f32x4 (&x)[N
 
 // kWaves waves per workgroup (12 = three per SIMD: the kernel needs ~158 registers; 8 for launches of few tiles - the same bits: a tile's
 // arithmetic does not depend on its workgroup), NT row tiles per wave: wave w of workgroup wg owns tiles (wg * kWaves + w) * NT + j
+// (workgroups of up to six waves go two to a CU: three waves per SIMD either way)
+constexpr int waves_per_eu(int waves) { return waves <= 6 ? 3 : (waves + 3) / 4; }
+constexpr int kProdWaves = kProd ? 1 : 0;   // the copying wave sits behind the kWaves row waves
 template <int NT, int kWaves>
-__global__ __launch_bounds__(64 * kWaves) __attribute__((amdgpu_waves_per_eu((kWaves + 3) / 4, (kWaves + 3) / 4))) void k_vae_rows8x(VaeRowsArgs a) {
+__global__ __launch_bounds__(64 * (kWaves + kProdWaves)) __attribute__((amdgpu_waves_per_eu(waves_per_eu(kWaves + kProdWaves), waves_per_eu(kWaves + kProdWaves)))) void k_vae_rows8x(VaeRowsArgs a) {
+    constexpr int kDmaWaves = dma_waves(kWaves), kPieces = kProd ? 0 : kStage / kDmaWaves;
     constexpr int S = kFrames;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63;
@@ -137,18 +160,53 @@ __global__ __launch_bounds__(64 * kWaves) __attribute__((amdgpu_waves_per_eu((kW
         frame[j] = rt[j] * 16 + r;
         rvalid[j] = tvalid[j] && frame[j] < S;
         row[j] = (size_t)b[j] * S + (rvalid[j] ? frame[j] : 0);
+        if constexpr ((AMUSE_R8_ABL & 16) != 0) row[j] = 0;
     }
+    const bool abl_nostore = (AMUSE_R8_ABL & 8) != 0 && a.stage < 100;   // (runtime-true: the arithmetic in front of the stores stays)
     const size_t nrows = (size_t)a.B * S;
     const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) const void*)smem;
-    Stager sg;
+    Stager<kPieces> sg;
     sg.dma = wave < kDmaWaves;
-    sg.src = a.wstream + (size_t)a.stage_base[a.stage] * 64 + (size_t)(wave % kDmaWaves) * 2 * 64 + lane;
-    sg.dst0 = lds0 + kOffW + (wave % kDmaWaves) * 2048;
+    sg.src = a.wstream + (size_t)a.stage_base[a.stage] * 64 + (size_t)(wave % kDmaWaves) * kPieces * 64 + lane;
+    sg.dst0 = lds0 + kOffW + (wave % kDmaWaves) * kPieces * 1024;
     sg.ring = smem + kOffW + lane * 16;
     sg.widx = 0;
     sg.ridx = 0;
+    if constexpr (kProd) {
+        if (wave == kWaves) {
+            // the copying wave: stage n + 2 goes out when stage n - 1's barrier has passed, stage n's barrier waits for stage n + 1 - the
+            // protocol of the row waves' own copies, 16 pieces per stage in one wave; LDS stages of this launch:
+            const int blk = a.stage - 1;
+            const int nst = 12 + (a.stage >= 1 ? 36 + (blk >= 4 && blk <= 7 ? 8 : 0) : 0);
+            const uint4* src = a.wstream + (size_t)a.stage_base[a.stage] * 64 + lane;
+            int wb = 0;
+            auto fetch = [&]() {
+                const unsigned d = __builtin_amdgcn_readfirstlane(lds0 + kOffW + wb * kStageBytes);
+#pragma unroll
+                for (int i = 0; i < kStage; ++i) glds16(src + i * 64, d + i * 1024);
+                src += kStage * 64;
+                wb = wb == kWBufs - 1 ? 0 : wb + 1;
+            };
+            fetch();
+            fetch();
+            asm volatile("s_waitcnt vmcnt(16)\n\ts_barrier" ::: "memory");
+#pragma unroll 1
+            for (int n = 0; n < nst; ++n) {
+                fetch();
+                asm volatile("s_waitcnt vmcnt(16)\n\ts_barrier" ::: "memory");
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the two surplus fetches must not outlive the workgroup's LDS
+            return;
+        }
+    }
     stage_fetch(sg);
     stage_fetch(sg);
+    // biases read behind the first activation store, from LDS (see AMUSE_R8_PROD): in_proj of block `stage` / final_layer
+    float* lbias = reinterpret_cast<float*>(smem + kOffBias);
+    if (threadIdx.x < 96) st4(lbias + 4 * threadIdx.x, ld4((a.stage < kLayers ? a.pvec + a.stage * PV_BLOCK + PV_IN_B : a.final_bias) + 4 * threadIdx.x));
+    int len[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) len[j] = a.lengths ? a.lengths[b[j]] : S;
     f32x4 x[NT][kTiles];
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
@@ -157,8 +215,18 @@ __global__ __launch_bounds__(64 * kWaves) __attribute__((amdgpu_waves_per_eu((kW
 #pragma unroll
         for (int t = 0; t < kTiles; ++t) x[j][t] = rvalid[j] ? ld4(src + 16 * t + 4 * g) : splat4(0.f);
     }
-    // (hipcc's own waits cover the loads above; the protocol's first wait: both prefetched stages but the second one's pieces)
-    asm volatile("s_waitcnt vmcnt(2)\n\ts_barrier" ::: "memory");
+    // The loads above are consumed HERE on every path: stage 0 does not touch x before its first store, and a load still pending at the
+    // merge in front of the in_proj loop makes hipcc wait there with vmcnt(0) - behind the x / skip stores of every other stage.
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int t = 0; t < kTiles; ++t) asm volatile("" ::"v"(x[j][t]));
+#pragma unroll
+    for (int j = 0; j < NT; ++j) asm volatile("" ::"v"(len[j]));
+    // (the protocol's first wait: both prefetched stages but the second one's pieces)
+    if constexpr (kPieces == 0) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    else if constexpr (kPieces == 2) asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)\n\ts_barrier" ::: "memory");
     F16Pair xs[NT][4];
     if (a.stage >= 1) {
         const int blk = a.stage - 1;
@@ -222,7 +290,7 @@ __global__ __launch_bounds__(64 * kWaves) __attribute__((amdgpu_waves_per_eu((kW
         if (blk < 4) {
 #pragma unroll
             for (int j = 0; j < NT; ++j) {
-                if (!rvalid[j]) continue;
+                if (!rvalid[j] || abl_nostore) continue;
                 float* sk = a.skip + ((size_t)blk * nrows + row[j]) * kD;
 #pragma unroll
                 for (int t = 0; t < kTiles; ++t) st4(sk + 16 * t + 4 * g, x[j][t]);
@@ -252,11 +320,10 @@ __global__ __launch_bounds__(64 * kWaves) __attribute__((amdgpu_waves_per_eu((kW
         // ---- residual stream for the next stage + in_proj of block `stage`: q | k | v as three groups of 8 output tiles
 #pragma unroll
         for (int j = 0; j < NT; ++j) {
-            if (!rvalid[j]) continue;
+            if (!rvalid[j] || abl_nostore) continue;
 #pragma unroll
             for (int t = 0; t < kTiles; ++t) st4(a.x + row[j] * kD + 16 * t + 4 * g, x[j][t]);
         }
-        const float* pv = a.pvec + a.stage * PV_BLOCK;
         split_x<NT>(xs, x);
         const float scaling = 0.17677669529663687f;   // 1 / sqrt(32): q * scaling (F.multi_head_attention_forward)
 #pragma unroll 1
@@ -264,7 +331,7 @@ __global__ __launch_bounds__(64 * kWaves) __attribute__((amdgpu_waves_per_eu((kW
             f32x4 acc[NT][8];
 #pragma unroll
             for (int t = 0; t < 8; ++t) {
-                const f32x4 bi = ld4(pv + PV_IN_B + grp * kD + 16 * t + 4 * g);
+                const f32x4 bi = ld4(lbias + grp * kD + 16 * t + 4 * g);
 #pragma unroll
                 for (int j = 0; j < NT; ++j) acc[j][t] = bi;
             }
@@ -272,7 +339,7 @@ __global__ __launch_bounds__(64 * kWaves) __attribute__((amdgpu_waves_per_eu((kW
             float* dst = grp == 0 ? a.q : grp == 1 ? a.k : a.v;
 #pragma unroll
             for (int j = 0; j < NT; ++j) {
-                if (!rvalid[j]) continue;
+                if (!rvalid[j] || abl_nostore) continue;
 #pragma unroll
                 for (int t = 0; t < 8; ++t) {   // output tile t = head t / 2, features 16 (t & 1) ..
                     const size_t hrow = (((size_t)b[j] * kHeads + (t >> 1)) * S + frame[j]) * 32;
@@ -291,7 +358,7 @@ __global__ __launch_bounds__(64 * kWaves) __attribute__((amdgpu_waves_per_eu((kW
             f32x4 f[NT][6];
 #pragma unroll
             for (int o = 0; o < 6; ++o) {
-                const f32x4 bi = ld4(a.final_bias + 16 * (6 * quarter + o) + 4 * g);
+                const f32x4 bi = ld4(lbias + 16 * (6 * quarter + o) + 4 * g);
 #pragma unroll
                 for (int j = 0; j < NT; ++j) f[j][o] = bi;
             }
@@ -305,8 +372,7 @@ __global__ __launch_bounds__(64 * kWaves) __attribute__((amdgpu_waves_per_eu((kW
             const int f0 = 96 * quarter, nfe = quarter == 3 ? kFeats - 288 : 96, njo = quarter == 3 ? kJoints - 48 : 16;
 #pragma unroll
             for (int j = 0; j < NT; ++j) {   // one tile at a time through the wave's staging tile (wave-private: no barrier)
-                const int len = a.lengths ? a.lengths[b[j]] : S;
-                const bool keep = rvalid[j] && frame[j] < len;   // output[~mask.T] = 0 (vae.py:274)
+                const bool keep = rvalid[j] && frame[j] < len[j];   // output[~mask.T] = 0 (vae.py:274)
                 const int rows_here = tvalid[j] ? min(16, S - rt[j] * 16) : 0;
                 const size_t row0 = (size_t)b[j] * S + rt[j] * 16;
 #pragma unroll
@@ -337,7 +403,7 @@ __global__ __launch_bounds__(64 * kWaves) __attribute__((amdgpu_waves_per_eu((kW
             }
         }
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the two surplus fetches must not outlive the workgroup's LDS
+    if constexpr (!kProd) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the two surplus fetches must not outlive the workgroup's LDS
 }
 
 template <int W>
@@ -345,12 +411,12 @@ hipError_t launch_rows8_w(const VaeRowsArgs& a, hipStream_t stream) {
     static DeviceOnce once;
     int dev_;
     if (!once.done(&dev_)) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_vae_rows8x<kTilesPerWave, W>), hipFuncAttributeMaxDynamicSharedMemorySize, rows8_lds_bytes(W));
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_vae_rows8x<kTilesPerWave, W>), hipFuncAttributeMaxDynamicSharedMemorySize, rows8_lds_bytes(W, true));
         if (e != hipSuccess) return e;
         once.set(dev_);
     }
     const int tiles = a.B * kRowTiles, per_wg = W * kTilesPerWave;
-    hipLaunchKernelGGL((k_vae_rows8x<kTilesPerWave, W>), dim3((tiles + per_wg - 1) / per_wg), dim3(64 * W), rows8_lds_bytes(W), stream, a);
+    hipLaunchKernelGGL((k_vae_rows8x<kTilesPerWave, W>), dim3((tiles + per_wg - 1) / per_wg), dim3(64 * (W + kProdWaves)), rows8_lds_bytes(W, a.stage == kLayers), stream, a);
     return hipGetLastError();
 }
 }  // namespace
@@ -367,18 +433,22 @@ hipError_t launch_vae_rows8x(const VaeRowsArgs& a, hipStream_t stream) {
     int best = 8, best_cost = 1 << 30;
     if (tiles > 8 * 256) {
         for (int w : {10, 11, 12}) {
+            if (kProd && w == 12) continue;   // (12 row waves + the copying wave would be four waves per SIMD: 128 registers)
             const int wgs = (tiles + w * kTilesPerWave - 1) / (w * kTilesPerWave);
             const int cost = ((wgs + 255) / 256) * w;
             if (cost < best_cost) { best_cost = cost; best = w; }   // (ties: the smaller workgroup)
         }
     }
-    if (force >= 8 && force <= 12) best = force;
+    if (force >= 4 && force <= 12 && force != 7 && !(kProd && (force == 6 || force == 12))) best = force;
     switch (best) {
+        case 4: return launch_rows8_w<4>(a, stream);
+        case 5: return launch_rows8_w<5>(a, stream);
+        case 6: return launch_rows8_w<kProd ? 5 : 6>(a, stream);
         case 8: return launch_rows8_w<8>(a, stream);
         case 9: return launch_rows8_w<9>(a, stream);
         case 10: return launch_rows8_w<10>(a, stream);
         case 11: return launch_rows8_w<11>(a, stream);
-        default: return launch_rows8_w<12>(a, stream);
+        default: return launch_rows8_w<kProd ? 11 : 12>(a, stream);
     }
 }
 
