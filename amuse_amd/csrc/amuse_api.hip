@@ -160,7 +160,7 @@ int build_denoiser(amuse_ctx* c, const float* den, int what = AMUSE_UPD_ALL) {
 
 int build_prior(amuse_ctx* c, const float* pri, int what = AMUSE_UPD_ALL) {
     static const ParamIndex PI = prior_index();
-    if (!g_capture) c->vae_c1_valid[0] = c->vae_c1_valid[1] = false;   // block 0's hoisted constant belongs to the old decoder weights
+    if (!g_capture) c->vae_c1_valid[0] = c->vae_c1_valid[1] = c->vae_c1_valid[2] = false;   // block 0's hoisted constant belongs to the old decoder weights
     const Params Pp{PI, pri};
     // ---- VAE decoder weight streams: [stage][wave][units]
     for (int prec = 0; prec < 4; ++prec) {
@@ -596,7 +596,7 @@ int amuse_update_weights_device(amuse_ctx* c, const float* denoiser_params_dev, 
     HIP_TRY(hipSetDevice(c->device));
     if (c->repack.empty())
         if (int e = build_repack_maps(c)) return e;
-    if (prior_params_dev) c->vae_c1_valid[0] = c->vae_c1_valid[1] = false;
+    if (prior_params_dev) c->vae_c1_valid[0] = c->vae_c1_valid[1] = c->vae_c1_valid[2] = false;
     for (const auto& r : c->repack) {
         const float* src = r.prior ? prior_params_dev : denoiser_params_dev;
         if (!src || !*r.slot) continue;                 // (an image the context never built, e.g. the 4-wave bf16 stream after an update)
@@ -622,7 +622,7 @@ void amuse_destroy(amuse_ctx* c) {
                     c->vae_w[0], c->vae_w[1], c->vae_w[2], c->vae_w[3], c->vae_w8x, c->vaee_w[2], c->vaee_w[3], c->vae_pvec, c->vae_final_bias, c->vae_pe, c->vae_wv_t, c->vae_bv,
                     c->vae_wo_t, c->vae_bo, c->vaee_w[0], c->vaee_w[1], c->vaee_pvec, c->vaee_pe, c->vaee_tok,
                     c->vaee_emb_bias, c->d_timesteps, c->d_coef, c->d_time_tok, c->d_ts1, c->d_tt1, c->d_coef1,
-                    c->cond_tok, c->lat_tmp, c->fwd_ws, c->vae_ws, c->d_lengths, c->vae_wf, c->vae_skip, c->vae_ca_ws, c->vae_c1[0], c->vae_c1[1]};
+                    c->cond_tok, c->lat_tmp, c->fwd_ws, c->vae_ws, c->d_lengths, c->vae_wf, c->vae_skip, c->vae_ca_ws, c->vae_c1[0], c->vae_c1[1], c->vae_c1[2]};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     delete c;
@@ -889,7 +889,26 @@ int amuse_vae_decode(amuse_ctx* c, const float* z, const int* lengths, int B, in
             r8.wstream = c->vae_w8x;
             memcpy(r8.stage_base, c->vae_w8x_base, sizeof(r8.stage_base));
         }
-        for (int stage = 0; stage < kVaeStages; ++stage) {
+        // fp32x row stages, all clips full length: block 0's self-attention half is one [300][128] constant per weight set (see the fused
+        // path above) - computed once by these kernels themselves on one clip (a tile's arithmetic does not depend on its launch: same bits),
+        // then every decode starts at stage 1 behind norm1.  Explicit lengths (even all 300) take the full path; AMUSE_VAE_HOIST=0 = off.
+        static const bool hoist8_on = [] { const char* e = getenv("AMUSE_VAE_HOIST"); return !(e && atoi(e) == 0); }();
+        const bool hoist8 = rows8 && hoist8_on && !lengths;
+        if (hoist8 && !c->vae_c1_valid[2]) {
+            if (!c->vae_c1[2]) HIP_TRY(hipMalloc((void**)&c->vae_c1[2], (size_t)kFrames * kD * sizeof(float)));
+            VaeRowsArgs p8 = r8;
+            p8.B = 1; p8.lengths = nullptr; p8.feats_out = p8.poses_out = p8.trans_out = nullptr;
+            VaeAttnArgs pa = aa;
+            pa.B = 1; pa.lengths = nullptr;
+            p8.stage = 0;
+            HIP_TRY(launch_vae_rows8x(p8, st));
+            HIP_TRY(launch_vae_attn(pa, precision, VAE_MODE_DEC, st));
+            p8.stage = 1; p8.c1_out = c->vae_c1[2];
+            HIP_TRY(launch_vae_rows8x(p8, st));
+            c->vae_c1_valid[2] = true;
+        }
+        if (hoist8) r8.c1 = c->vae_c1[2];
+        for (int stage = hoist8 ? 1 : 0; stage < kVaeStages; ++stage) {
             ra.stage = stage;
             r8.stage = stage;
             if (rows8) HIP_TRY(launch_vae_rows8x(r8, st));

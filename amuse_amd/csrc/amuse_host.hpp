@@ -309,8 +309,8 @@ struct amuse_ctx {
     uint32_t vae_stage_units[4][kVaeStages];
     uint4* vae_wf = nullptr;           // bf16 stream of the fused decode kernel (k_vae_fused.hip)
     uint4* vae_wfh = nullptr;          // its fp16 twin (k_vae_fusedh.hip, AMUSE_PREC_F16)
-    float* vae_c1[2] = {nullptr, nullptr};   // block 0's self-attention half of the fused decoder, bf16 | fp16 build: [300][128] (+ the tap scratch behind it)
-    bool vae_c1_valid[2] = {false, false};   // (re)computed by the next fused decode after a weight change
+    float* vae_c1[3] = {nullptr, nullptr, nullptr};   // block 0's self-attention half of the fused decoder, bf16 | fp16 build: [300][128] (+ the tap scratch behind it); [2]: of the fp32x row stages
+    bool vae_c1_valid[3] = {false, false, false};   // (re)computed by the next fused decode after a weight change
     uint4* vae_w8x = nullptr;          // fp32x row stages without split-K (k_vae_rows8.hip): one stream per stage, consumption order
     uint32_t vae_w8x_base[kVaeStages];
     uint4* vae_skip = nullptr; size_t vae_skip_cap = 0;   // clips

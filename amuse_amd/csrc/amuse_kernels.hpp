@@ -148,6 +148,11 @@ struct VaeRowsArgs {
     int stage;                        // 0..9
     int quat_mode;
     int tiles;                        // 16-row tiles launched per clip: 19, or 1 for the encoder's last stage
+    // k_vae_rows8x only: block 0's self-attention half is the same for every full-length clip (the decoder's queries are the positional
+    // table; the latent enters through the cross-attention): stage 1 with c1_out writes LN1(pe + SA(pe)) [300][128] and stops, stage 1
+    // with c1 starts from it (no stage 0, no attention 0, no out_proj / norm1)
+    const float* c1;
+    float* c1_out;
     // encoder mode only (MotionPrior.encode): rows are [2 distribution tokens | 300 frames], S = 302
     const float* enc_feats;           // [B][300][333] input motion features
     const float* tok;                 // global_motion_token [2][128]

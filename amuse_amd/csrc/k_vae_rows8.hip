@@ -167,7 +167,8 @@ __global__ __launch_bounds__(64 * (kWaves + kProdWaves)) __attribute__((amdgpu_w
     const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) const void*)smem;
     Stager<kPieces> sg;
     sg.dma = wave < kDmaWaves;
-    sg.src = a.wstream + (size_t)a.stage_base[a.stage] * 64 + (size_t)(wave % kDmaWaves) * kPieces * 64 + lane;
+    const bool hoisted = a.stage == 1 && a.c1 != nullptr;   // block 0's self-attention half comes as the constant c1 (VaeRowsArgs)
+    sg.src = a.wstream + (size_t)a.stage_base[a.stage] * 64 + (hoisted ? 4 * kStage * 64 : 0) + (size_t)(wave % kDmaWaves) * kPieces * 64 + lane;
     sg.dst0 = lds0 + kOffW + (wave % kDmaWaves) * kPieces * 1024;
     sg.ring = smem + kOffW + lane * 16;
     sg.widx = 0;
@@ -177,8 +178,9 @@ __global__ __launch_bounds__(64 * (kWaves + kProdWaves)) __attribute__((amdgpu_w
             // the copying wave: stage n + 2 goes out when stage n - 1's barrier has passed, stage n's barrier waits for stage n + 1 - the
             // protocol of the row waves' own copies, 16 pieces per stage in one wave; LDS stages of this launch:
             const int blk = a.stage - 1;
-            const int nst = 12 + (a.stage >= 1 ? 36 + (blk >= 4 && blk <= 7 ? 8 : 0) : 0);
-            const uint4* src = a.wstream + (size_t)a.stage_base[a.stage] * 64 + lane;
+            const bool hoisted = a.stage == 1 && a.c1 != nullptr, c1_only = a.stage == 1 && a.c1_out != nullptr;
+            const int nst = c1_only ? 4 : 12 + (a.stage >= 1 ? 36 + (blk >= 4 && blk <= 7 ? 8 : 0) : 0) - (hoisted ? 4 : 0);
+            const uint4* src = a.wstream + (size_t)a.stage_base[a.stage] * 64 + (hoisted ? 4 * kStage * 64 : 0) + lane;   // (hoisted: no out_proj)
             int wb = 0;
             auto fetch = [&]() {
                 const unsigned d = __builtin_amdgcn_readfirstlane(lds0 + kOffW + wb * kStageBytes);
@@ -211,7 +213,7 @@ __global__ __launch_bounds__(64 * (kWaves + kProdWaves)) __attribute__((amdgpu_w
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
         // stage 0: queries = zeros + query_pos_decoder.pe[:300]  (vae.py:220,258)
-        const float* src = a.stage == 0 ? a.pe + (size_t)frame[j] * kD : a.x + row[j] * kD;
+        const float* src = a.stage == 0 ? a.pe + (size_t)frame[j] * kD : hoisted ? a.c1 + (size_t)(rvalid[j] ? frame[j] : 0) * kD : a.x + row[j] * kD;
 #pragma unroll
         for (int t = 0; t < kTiles; ++t) x[j][t] = rvalid[j] ? ld4(src + 16 * t + 4 * g) : splat4(0.f);
     }
@@ -232,6 +234,7 @@ __global__ __launch_bounds__(64 * (kWaves + kProdWaves)) __attribute__((amdgpu_w
         const int blk = a.stage - 1;
         const float* pv = a.pvec + blk * PV_BLOCK;
         // ---- self-attention out_proj + residual + norm1  (cross_attention.py:323-330)
+        if (!hoisted) {
 #pragma unroll
         for (int j = 0; j < NT; ++j) {
             f32x4 o[kTiles];
@@ -244,8 +247,20 @@ __global__ __launch_bounds__(64 * (kWaves + kProdWaves)) __attribute__((amdgpu_w
         }
         gemm_k128_o8<NT>(x, xs, sg);
 #pragma unroll
+        for (int j = 0; j < NT; ++j) layer_norm_rows<false>(x[j], pv + PV_LN1_W, pv + PV_LN1_B, g);
+        if (a.stage == 1 && a.c1_out) {   // the hoisted constant's own computation (one clip): write it and stop
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                if (!rvalid[j]) continue;
+#pragma unroll
+                for (int t = 0; t < kTiles; ++t) st4(a.c1_out + (size_t)frame[j] * kD + 16 * t + 4 * g, x[j][t]);
+            }
+            if constexpr (!kProd) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            return;
+        }
+        }
+#pragma unroll
         for (int j = 0; j < NT; ++j) {
-            layer_norm_rows<false>(x[j], pv + PV_LN1_W, pv + PV_LN1_B, g);
             // cross-attention onto the single latent token == per-clip constant; norm2  (cross_attention.py:331-337)
             const float* ca = a.ca + ((size_t)b[j] * kLayers + blk) * kD;
 #pragma unroll

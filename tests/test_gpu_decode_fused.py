@@ -250,3 +250,33 @@ def test_block0_hoist_is_bitwise_and_follows_the_weights():
         fresh.close()
     finally:
         eng.close()
+
+
+def test_fp32x_row_stages_block0_hoist_is_bitwise_and_follows_the_weights():
+    """The fp32x decode of full-length clips (k_vae_rows8x + k_vae_attn_x) starts at stage 1 from the same block-0 constant, computed once per
+    weight set by the row / attention kernels themselves on one clip.  A call with explicit lengths (even all 300) takes the full path:
+    bitwise equal, also in a batch larger than one chunk of workgroups and after a weight update; and the result still holds the oracle's
+    1e-4 per joint (tests/test_gpu_parity.py has the full-path check)."""
+    from amuse_amd import weights as wts
+    from amuse_amd.engine import HipEngine
+    wd, wp = wts.make_denoiser_weights(0), wts.make_prior_weights(0)
+    eng = HipEngine(wd, wp, "cuda:0")
+    try:
+        eng.set_decode_path("fused")      # (fp32x: the k_vae_rows8x kernel for every batch size)
+        for B in (3, 70):
+            z = torch.randn(B, 128, generator=torch.Generator().manual_seed(B))
+            hoisted = eng.vae_decode(z, None, "fp32x", return_feats=True)
+            full = eng.vae_decode(z, [300] * B, "fp32x", return_feats=True)
+            assert torch.equal(hoisted["feats"], full["feats"]) and torch.equal(hoisted["poses"], full["poses"]), B
+        z = torch.randn(4, 128, generator=torch.Generator().manual_seed(9))
+        eng.update_weights(prior_sd=wts.make_prior_weights(1))
+        a = eng.vae_decode(z, None, "fp32x", return_feats=True)
+        b = eng.vae_decode(z, [300] * 4, "fp32x", return_feats=True)
+        assert torch.equal(a["feats"], b["feats"])
+        fresh = HipEngine(wd, wts.make_prior_weights(1), "cuda:0")
+        fresh.set_decode_path("fused")
+        assert torch.equal(a["feats"], fresh.vae_decode(z, None, "fp32x", return_feats=True)["feats"])
+        fresh.close()
+    finally:
+        eng.close()
+
