@@ -31,6 +31,12 @@
 namespace amuse {
 namespace {
 
+// 1 = the skip stack (78 MB each way at 256 clips, written once and read once 0.1 - 0.5 ms later) goes around the caches with non-temporal
+// stores / loads (A/B; profiles/r04_decode_skip_nt_ab.txt)
+#ifndef AMUSE_F_SKIP_NT
+#define AMUSE_F_SKIP_NT 0
+#endif
+typedef unsigned int u32x4n __attribute__((ext_vector_type(4)));   // (the nontemporal builtins take native vectors)
 constexpr int kWaves = 8;
 constexpr int kKeyRows = 320;             // 300 keys padded to 20 tiles
 constexpr int kPairs = kKeyRows / 32;     // 10 key-tile pairs
@@ -425,7 +431,13 @@ __device__ __forceinline__ void decoder_block(f32x4 (&x)[NT][kTiles], Stager& sg
 #pragma unroll
         for (int j = 0; j < NT; ++j)
 #pragma unroll
-            for (int c = 0; c < 4; ++c) sb[j][c] = __builtin_bit_cast(OPV, sk[((tile0 + 4 * j) * 4 + c) * 64 + lane]);
+            for (int c = 0; c < 4; ++c) {
+#if AMUSE_F_SKIP_NT
+                sb[j][c] = __builtin_bit_cast(OPV, __builtin_nontemporal_load(reinterpret_cast<const u32x4n*>(sk + ((tile0 + 4 * j) * 4 + c) * 64 + lane)));
+#else
+                sb[j][c] = __builtin_bit_cast(OPV, sk[((tile0 + 4 * j) * 4 + c) * 64 + lane]);
+#endif
+            }
         pack_rows<NT>(xb, x);
         const float* bias = pvec_g + PV_SKIP_B + (blk - 5) * kD;
 #pragma unroll
@@ -675,7 +687,13 @@ __device__ __forceinline__ void decoder_block(f32x4 (&x)[NT][kTiles], Stager& sg
         for (int j = 0; j < NT; ++j)
 #pragma unroll
             for (int c = 0; c < 4; ++c)
+            {
+#if AMUSE_F_SKIP_NT
+                __builtin_nontemporal_store(__builtin_bit_cast(u32x4n, OP_PACK(x[j][2 * c], x[j][2 * c + 1])), reinterpret_cast<u32x4n*>(sk + ((tile0 + 4 * j) * 4 + c) * 64 + lane));
+#else
                 sk[((tile0 + 4 * j) * 4 + c) * 64 + lane] = __builtin_bit_cast(uint4, OP_PACK(x[j][2 * c], x[j][2 * c + 1]));
+#endif
+            }
     }
     if constexpr (TAP) {
         if (tap_out && blockIdx.x == 0) store_tap<NT>(tap_out, blk, x, tile0, g, r);
