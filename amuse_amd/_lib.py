@@ -16,7 +16,7 @@ LIB_PATH = Path(os.environ.get("AMUSE_HIP_LIB") or _HERE / "libamuse_hip.so")
 PREC_F32, PREC_BF16, PREC_F32X, PREC_F16 = 0, 1, 2, 3
 UPD_F32, UPD_BF16, UPD_ENCODER, UPD_F32X, UPD_F16, UPD_ALL = 1, 2, 4, 8, 16, 31
 QUAT_P3D, QUAT_LEGACY = 0, 1
-ABI_VERSION = 3
+ABI_VERSION = 4
 ARCH_ENC, ARCH_DEC, ARCH_ENC_POSE, ARCH_DEC_POSE = 0, 1, 2, 3   # include/amuse_hip.h AMUSE_ARCH_*
 
 EXPORTS = [
@@ -28,6 +28,7 @@ EXPORTS = [
     "amuse_debug_tile", "amuse_debug_f16_split", "amuse_debug_set_decode_tap",
     "amuse_create_arch", "amuse_denoiser_param_count", "amuse_arch", "amuse_state_dim", "amuse_denoise_step_pose", "amuse_feats_to_smplx",
     "amuse_debug_set_ablation",
+    "amuse_train_ws_floats", "amuse_train_ln_fwd", "amuse_train_ln_bwd", "amuse_train_bias_gelu_drop_fwd", "amuse_train_bias_gelu_drop_bwd", "amuse_train_colsum",
 ]
 
 
@@ -109,6 +110,17 @@ def load() -> C.CDLL:
     lib.amuse_debug_f16_split.restype = C.c_int
     lib.amuse_debug_set_decode_tap.argtypes = [vp, fp]
     lib.amuse_debug_set_decode_tap.restype = C.c_int
+    # training-step glue (csrc/k_train.hip): raw device addresses (tensor.data_ptr()) as void pointers
+    u64 = C.c_uint64
+    lib.amuse_train_ws_floats.argtypes = []
+    lib.amuse_train_ws_floats.restype = C.c_size_t
+    lib.amuse_train_ln_fwd.argtypes = [vp, vp, vp, vp, vp, C.c_float, u64, u64, C.c_long, vp, vp, vp, vp]
+    lib.amuse_train_ln_bwd.argtypes = [vp, vp, vp, vp, vp, C.c_float, u64, u64, C.c_long, vp, vp, vp, vp, vp, vp, vp]
+    lib.amuse_train_bias_gelu_drop_fwd.argtypes = [vp, vp, C.c_float, u64, u64, C.c_long, C.c_int, vp, vp]
+    lib.amuse_train_bias_gelu_drop_bwd.argtypes = [vp, vp, vp, C.c_float, u64, u64, C.c_long, C.c_int, vp, vp, vp, vp]
+    lib.amuse_train_colsum.argtypes = [vp, C.c_long, C.c_int, vp, vp, vp]
+    for n in ("amuse_train_ln_fwd", "amuse_train_ln_bwd", "amuse_train_bias_gelu_drop_fwd", "amuse_train_bias_gelu_drop_bwd", "amuse_train_colsum"):
+        getattr(lib, n).restype = C.c_int
     for n in ("amuse_audio_fbank", "amuse_audio_encode", "amuse_audio_features", "amuse_debug_gemm", "amuse_debug_tile"):
         getattr(lib, n).restype = C.c_int
     if lib.amuse_abi_version() != ABI_VERSION:

@@ -1,7 +1,7 @@
 """Autograd twins of the two networks on the hot path, for the train_gesture step (BASELINE config 4): `Denoiser`
 (reference models/latent_diffusion/denoiser.py:16-204, trans_enc + learned PE) and `MotionPrior`
-(models/latent_diffusion/vae.py:24-278, encoder_decoder).  Plain torch modules - training is not the accelerated path
-(the HIP kernels are inference-only); what matters here is that
+(models/latent_diffusion/vae.py:24-278, encoder_decoder).  Plain torch modules; on the GPU each transformer layer runs as one autograd.Function
+whose non-GEMM arithmetic is hand-written HIP (train_ops.py, csrc/k_train.hip; AMUSE_TRAIN_FUSED=0 = the eager layers below).  What matters here is that
 
   * `state_dict()` has exactly the reference's keys and shapes (tests/golden/state_dict_spec.json), so checkpoints written
     by either side load in the other and in the HIP engine (amuse_amd/checkpoint.py, amuse_update_weights), and
@@ -26,6 +26,8 @@ from typing import List, Optional, Sequence
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
+
+from . import train_ops
 
 D, H, FF, L, COND, NFEATS, PE_LEN = 128, 4, 512, 9, 256, 333, 500
 
@@ -78,6 +80,8 @@ class EncoderLayer(nn.Module):
         self.norm1, self.norm2 = nn.LayerNorm(d), nn.LayerNorm(d)
 
     def forward(self, src, key_padding_mask=None):
+        if train_ops.usable(src, key_padding_mask):       # one autograd.Function on the HIP glue kernels (train_ops.py); same arithmetic
+            return train_ops.encoder_layer(self, src)
         src2 = mha_self(self.self_attn, src, key_padding_mask)
         src = self.norm1(src + self.dropout1(src2))
         src2 = self.linear2(self.dropout(F.gelu(self.linear1(src))))
@@ -96,6 +100,8 @@ class DecoderLayer(nn.Module):
         self.norm1, self.norm2, self.norm3 = nn.LayerNorm(d), nn.LayerNorm(d), nn.LayerNorm(d)
 
     def forward(self, tgt, memory, tgt_key_padding_mask=None):
+        if memory.shape[1] == 1 and train_ops.usable(tgt, tgt_key_padding_mask):
+            return train_ops.decoder_layer(self, tgt, memory)
         t2 = mha_self(self.self_attn, tgt, tgt_key_padding_mask)
         tgt = self.norm1(tgt + self.dropout1(t2))
         if memory.shape[1] == 1:

@@ -28,7 +28,8 @@
 extern "C" {
 #endif
 
-#define AMUSE_ABI_VERSION 3   /* 3: Denoiser variants (amuse_create_arch, AMUSE_ARCH_*, amuse_denoise_step_pose, amuse_feats_to_smplx);
+#define AMUSE_ABI_VERSION 4   /* 4: amuse_train_* (training-step glue kernels);
+                                 3: Denoiser variants (amuse_create_arch, AMUSE_ARCH_*, amuse_denoise_step_pose, amuse_feats_to_smplx);
                                  2: AMUSE_PREC_F32X / _F16, AMUSE_UPD_F32X / _F16; tile-major amuse_debug_gemm; clips per group 1..5 */
 
 /* architecture the kernels are specialised for (configs/diff_latent_v2.json:23-47,
@@ -328,6 +329,32 @@ int amuse_debug_set_ablation(amuse_ctx* ctx, int mask);
  * hi[i] = rn16(w[i]), lo[i] = rn16(w[i] - hi[i]), round-to-nearest-even with gradual underflow - bit for bit what
  * v_cvt_pk_f16_f32 produces on the device for the activations (and amuse_update_weights_device for the weights). */
 int amuse_debug_f16_split(const float* w, size_t n, uint16_t* hi, uint16_t* lo);
+
+/* ------------------------------------------------------------------ training-step glue (csrc/k_train.hip; amuse_amd/train_ops.py)
+ * The row-wise arithmetic of a transformer layer's forward and backward pass in the train_gesture iteration (reference
+ * scripts/trainer.py:335-498; layers utils/cross_attention.py:259-272,323-345; the reference gets these from torch's eager kernels:
+ * nn.Dropout, the residual add, nn.LayerNorm, F.gelu and the bias gradients' reductions).  fp32, row-major [rows][C]; no context - plain
+ * device pointers and a stream.  Dropout masks are counter-based: element e is draw e % 4 of Philox4x32-10(key seed, counter (e / 4, offset));
+ * the backward calls regenerate the mask from the same (p, seed, offset).  p = 0 is eval mode.
+ * `ws` (amuse_train_ws_floats() floats) holds the partial column sums of a call (deterministic: added up in a fixed order by a second launch) and
+ * must not be shared by calls that may overlap on different streams. */
+size_t amuse_train_ws_floats(void);
+/* out = LayerNorm_128(x + dropout(y + bias)) (x, bias nullable); zhat [rows][128] = the normalised rows and rstd [rows] for the backward
+ * pass (both nullable) */
+int amuse_train_ln_fwd(const float* x, const float* y, const float* bias, const float* gamma, const float* beta, float p, uint64_t seed,
+                       uint64_t offset, long rows, float* out, float* zhat, float* rstd, void* stream);
+/* dz = LayerNorm backward of dout + dout2 (dout2 nullable: the second branch's gradient of a residual stream); dx = dz (nullable),
+ * dy = dz . mask / (1 - p); dgamma, dbeta, dbias = sum_rows dy (each nullable) */
+int amuse_train_ln_bwd(const float* dout, const float* dout2, const float* zhat, const float* rstd, const float* gamma, float p, uint64_t seed, uint64_t offset,
+                       long rows, float* dx, float* dy, float* dgamma, float* dbeta, float* dbias, float* ws, void* stream);
+/* out = dropout(gelu(h + b)), exact erf; h, out [rows][F], F a multiple of 4 up to 1024 */
+int amuse_train_bias_gelu_drop_fwd(const float* h, const float* b, float p, uint64_t seed, uint64_t offset, long rows, int F, float* out,
+                                   void* stream);
+/* dh = da . mask / (1 - p) . gelu'(h + b); db [F] = sum_rows dh */
+int amuse_train_bias_gelu_drop_bwd(const float* da, const float* h, const float* b, float p, uint64_t seed, uint64_t offset, long rows,
+                                   int F, float* dh, float* db, float* ws, void* stream);
+/* out [C] = sum_rows x[r][:] (a bias gradient), C a multiple of 4 up to 1024 */
+int amuse_train_colsum(const float* x, long rows, int C, float* out, float* ws, void* stream);
 
 #ifdef __cplusplus
 }

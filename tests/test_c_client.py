@@ -27,7 +27,7 @@ def _build(tmp_path) -> Path:
 def test_c_client_builds_and_sees_the_error_conventions(tmp_path):
     exe = _build(tmp_path)
     r = subprocess.run([str(exe), "abi"], capture_output=True, text=True, timeout=120)
-    assert r.returncode == 0 and r.stdout.strip() == "ABI_OK 3", (r.stdout, r.stderr)
+    assert r.returncode == 0 and r.stdout.strip() == "ABI_OK 4", (r.stdout, r.stderr)
     assert subprocess.run([str(exe)], capture_output=True).returncode == 2
 
 

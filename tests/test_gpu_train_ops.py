@@ -1,0 +1,176 @@
+"""GPU: the train_gesture step's fused layers (amuse_amd/train_ops.py on csrc/k_train.hip) against the eager layers of nn_modules.py - the
+autograd twins that tests/test_train_cpu.py pins to the reference modules' goldens (utils/cross_attention.py:259-272,323-345)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda:0"
+
+
+def _rel(a, b):
+    return float((a - b).abs().max() / b.abs().max().clamp_min(1e-12))
+
+
+@pytest.fixture()
+def eager_switch():
+    old = os.environ.get("AMUSE_TRAIN_FUSED")
+    yield lambda on: os.environ.__setitem__("AMUSE_TRAIN_FUSED", "1" if on else "0")
+    if old is None:
+        os.environ.pop("AMUSE_TRAIN_FUSED", None)
+    else:
+        os.environ["AMUSE_TRAIN_FUSED"] = old
+
+
+def test_raw_kernels_against_torch():
+    from amuse_amd import train_ops as T
+    g = torch.Generator(device=DEV).manual_seed(0)
+    for rows in (1, 7, 160, 9664):
+        x, y = (torch.randn(rows, 128, device=DEV, generator=g) for _ in range(2))
+        bias, ga, be = (torch.randn(128, device=DEV, generator=g) for _ in range(3))
+        out, zhat, rstd = T.ln_fwd(x, y, bias, ga, be, 0.0, 1, 1)
+        ref = torch.nn.functional.layer_norm(x + y + bias, (128,), ga, be)
+        assert float((out - ref).abs().max()) < 2e-5, rows
+        xr, yr, gr, br, bb = (t.clone().requires_grad_(True) for t in (x, y, ga, be, bias))
+        dout = torch.randn(rows, 128, device=DEV, generator=g)
+        torch.nn.functional.layer_norm(xr + yr + bb, (128,), gr, br).backward(dout)
+        dx, dy, dg, db, dbias = T.ln_bwd(dout * 0.25, zhat, rstd, ga, 0.0, 1, 1, dout2=dout * 0.75)   # (two addends: exact in fp32)
+        assert torch.equal(dx, dy)                                           # p = 0: the mask is all ones
+        for got, want in ((dx, xr.grad), (dg, gr.grad), (db, br.grad), (dbias, bb.grad)):
+            assert _rel(got, want) < 2e-5, rows
+        # FFN activation
+        h, b1 = torch.randn(rows, 512, device=DEV, generator=g) * 2, torch.randn(512, device=DEV, generator=g)
+        a = T.bias_gelu_drop_fwd(h, b1, 0.0, 1, 2)
+        assert float((a - torch.nn.functional.gelu(h + b1)).abs().max()) < 2e-6
+        hr, b1r = h.clone().requires_grad_(True), b1.clone().requires_grad_(True)
+        da = torch.randn(rows, 512, device=DEV, generator=g)
+        torch.nn.functional.gelu(hr + b1r).backward(da)
+        dh, db1 = T.bias_gelu_drop_bwd(da, h, b1, 0.0, 1, 2)
+        assert _rel(dh, hr.grad) < 2e-6 and _rel(db1, b1r.grad) < 2e-5, rows
+        # column sums (in_proj's bias gradient: 384 columns), deterministic
+        q = torch.randn(rows, 384, device=DEV, generator=g)
+        s = T.colsum(q)
+        assert _rel(s, q.double().sum(0).float()) < 1e-5 and torch.equal(s, T.colsum(q))
+
+
+def test_dropout_masks_are_regenerated_by_the_backward_kernels():
+    from amuse_amd import train_ops as T
+    rows, p = 4096, 0.1
+    one = torch.ones(128, device=DEV)
+    zero = torch.zeros(128, device=DEV)
+    # FFN activation: large positive h -> gelu(h) = h, so out / h is the mask / (1 - p)
+    h = torch.full((rows, 512), 30.0, device=DEV)
+    a = T.bias_gelu_drop_fwd(h, torch.zeros(512, device=DEV), p, 7, 3)
+    m = a / 30.0
+    kept = m > 0
+    assert abs(float(kept.float().mean()) - (1 - p)) < 3e-3 and float((m[kept] - 1 / (1 - p)).abs().max()) < 1e-6
+    dh, db = T.bias_gelu_drop_bwd(torch.ones_like(h), h, torch.zeros(512, device=DEV), p, 7, 3)
+    assert torch.equal(dh > 0, kept) and float((dh[kept] - 1 / (1 - p)).abs().max()) < 1e-5 and _rel(db, dh.sum(0)) < 1e-5
+    assert not torch.equal(T.bias_gelu_drop_fwd(h, torch.zeros(512, device=DEV), p, 7, 4) > 0, kept)       # another offset: another mask
+    assert not torch.equal(T.bias_gelu_drop_fwd(h, torch.zeros(512, device=DEV), p, 8, 3) > 0, kept)       # another seed
+    # LayerNorm: x = 0, y = 1: the row is a two-level signal, high where kept
+    y = torch.ones(rows, 128, device=DEV)
+    out, zhat, rstd = T.ln_fwd(None, y, None, one, zero, p, 7, 5)
+    keptl = out > 0
+    assert abs(float(keptl.float().mean()) - (1 - p)) < 5e-3
+    ref = torch.nn.functional.layer_norm(keptl.float() / (1 - p), (128,))
+    ok = keptl.float().sum(1) < 128                                          # (a row with nothing dropped is constant: LayerNorm of it is 0 / eps)
+    assert float((out - ref)[ok].abs().max()) < 1e-4
+    dout = torch.randn(rows, 128, device=DEV, generator=torch.Generator(device=DEV).manual_seed(1))
+    dx, dy, *_ = T.ln_bwd(dout, zhat, rstd, one, p, 7, 5)
+    assert torch.equal(dy != 0, keptl & (dx != 0)) and float((dy - dx * keptl / (1 - p)).abs().max()) < 1e-6
+
+
+def _layers(kind, seed):
+    from amuse_amd import nn_modules as nm
+    torch.manual_seed(seed)
+    m = (nm.EncoderLayer if kind == "enc" else nm.DecoderLayer)(p=0.1).to(DEV)
+    for p in m.parameters():                                                # non-trivial LayerNorm parameters and biases
+        if p.dim() == 1:
+            p.data.normal_(1.0 if p.data.mean() > 0.5 else 0.0, 0.2)
+    return m
+
+
+@pytest.mark.parametrize("kind,B,S", [("enc", 3, 302), ("enc", 32, 5), ("dec", 3, 300), ("dec", 1, 1)])
+def test_fused_layer_equals_the_eager_layer_in_eval_mode(kind, B, S, eager_switch):
+    m = _layers(kind, 1).eval()
+    g = torch.Generator(device=DEV).manual_seed(2)
+    x = torch.randn(B, S, 128, device=DEV, generator=g)
+    mem = torch.randn(B, 1, 128, device=DEV, generator=g)
+    dout = torch.randn(B, S, 128, device=DEV, generator=g)
+    res = {}
+    for on in (False, True):
+        eager_switch(on)
+        xr, mr = x.clone().requires_grad_(True), mem.clone().requires_grad_(True)
+        m.zero_grad(set_to_none=True)
+        out = m(xr) if kind == "enc" else m(xr, mr)
+        out.backward(dout)
+        res[on] = (out.detach(), xr.grad, mr.grad if kind == "dec" else None, {n: p.grad.clone() for n, p in m.named_parameters() if p.grad is not None})
+    (o0, dx0, dm0, g0), (o1, dx1, dm1, g1) = res[False], res[True]
+    assert float((o0 - o1).abs().max()) < 2e-5
+    assert _rel(dx1, dx0) < 2e-4
+    if kind == "dec":
+        assert _rel(dm1, dm0) < 2e-4
+    assert set(g0) == set(g1)
+    for n in g0:
+        assert g1[n].shape == g0[n].shape and _rel(g1[n], g0[n]) < 2e-4, n        # the bar of the round-3 brief: gradients <= 2e-4 . max
+
+
+@pytest.mark.parametrize("kind", ["enc", "dec"])
+def test_fused_layer_in_train_mode_is_consistent_and_unbiased(kind, eager_switch):
+    """Dropout live (p = 0.1 everywhere, attention dropout inside the vendor kernel): the backward pass must see the forward pass's masks -
+    checked by a directional derivative in float32 on a re-seeded replay - and the mean over many masks approaches the eval output."""
+    from amuse_amd import train_ops as T
+    eager_switch(True)
+    m = _layers(kind, 3).train()
+    g = torch.Generator(device=DEV).manual_seed(4)
+    x = torch.randn(2, 40, 128, device=DEV, generator=g)
+    mem = torch.randn(2, 1, 128, device=DEV, generator=g)
+
+    def run(xin, off0):
+        T._OFFSET[0] = off0                                                  # replay the same masks (the vendor kernel's come from torch's generator)
+        torch.manual_seed(11)
+        return m(xin) if kind == "enc" else m(xin, mem)
+
+    xr = x.clone().requires_grad_(True)
+    out = run(xr, 1000)
+    w = torch.randn_like(out)
+    (out * w).sum().backward()
+    assert torch.equal(run(x, 1000), out.detach())                           # same offsets + seed: same masks, bitwise
+    assert not torch.equal(run(x, 2000), out.detach())
+    d = torch.randn_like(x)
+    eps = 1e-2
+    fd = float(((run(x + eps * d, 1000) - run(x - eps * d, 1000)) * w).sum().double()) / (2 * eps)
+    an = float((xr.grad * d).sum().double())
+    assert abs(fd - an) < 2e-2 * max(1.0, abs(an)), (fd, an)
+    m.eval()
+    ref = m(x) if kind == "enc" else m(x, mem)
+    m.train()
+    acc = torch.zeros_like(ref)
+    n = 200
+    for i in range(n):
+        acc += m(x) if kind == "enc" else m(x, mem)
+    # post-norm layers are not linear in the masks; the mean stays within a few percent of the eval output
+    assert float((acc / n - ref).abs().mean() / ref.abs().mean()) < 0.08
+
+
+def test_trainer_step_on_fused_layers_matches_the_eager_step_without_dropout(eager_switch):
+    """One whole train_gesture iteration (prior encode / decode + epsilon loss + AdamW) with dropout 0 on both paths: losses and the flat gradient."""
+    from amuse_amd import train_gesture as tg
+    res = {}
+    for on in (False, True):
+        eager_switch(on)
+        torch.manual_seed(5)
+        tr = tg.build_trainer(DEV, seed=5, use_hip_sampler=False, dropout=0.0)
+        batch = tg.synthetic_batch(4, 7, DEV)
+        noise = torch.randn(4, 1, 128, generator=torch.Generator().manual_seed(1)).to(DEV)
+        ts = torch.tensor([3, 500, 998, 17], device=DEV)
+        eps = torch.randn(1, 4, 128, generator=torch.Generator().manual_seed(2)).to(DEV)
+        loss = tr.forward_losses(batch, noise=noise, timesteps=ts, eps_enc=eps, eps_inf=eps)
+        tr.backward_into_bucket(loss)
+        res[on] = (float(loss), tr.flat_grad.clone())
+    assert abs(res[True][0] - res[False][0]) < 1e-5 * max(1.0, abs(res[False][0]))
+    assert _rel(res[True][1], res[False][1]) < 2e-4
