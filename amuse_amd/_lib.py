@@ -29,11 +29,23 @@ EXPORTS = [
     "amuse_create_arch", "amuse_denoiser_param_count", "amuse_arch", "amuse_state_dim", "amuse_denoise_step_pose", "amuse_feats_to_smplx",
     "amuse_debug_set_ablation",
     "amuse_train_ws_floats", "amuse_train_ln_fwd", "amuse_train_ln_bwd", "amuse_train_bias_gelu_drop_fwd", "amuse_train_bias_gelu_drop_bwd", "amuse_train_colsum",
+    "amuse_train_layer_fwd", "amuse_train_layer_bwd", "amuse_train_linear_fwd", "amuse_train_linear_bwd",
 ]
 
 
 class AmuseHipError(RuntimeError):
     pass
+
+
+_FP = C.c_void_p
+
+
+class TrainLayer(C.Structure):
+    """include/amuse_hip.h `amuse_train_layer` (device addresses as integers: tensor.data_ptr())."""
+    _fields_ = ([("rows", C.c_long), ("B", C.c_int), ("S", C.c_int), ("H", C.c_int), ("ff", C.c_int), ("p", C.c_float), ("p_attn", C.c_float),
+                 ("seed", C.c_uint64), ("off", C.c_uint64 * 5)]
+                + [(n, _FP) for n in ("Wo bo g1 be1 Wv bv Wc bc g2 be2 W1 b1 W2 b2 g3 be3 x o2 mem x1 zh1 r1 c vk xm zh2 r2 h a out zh3 r3 tmp dout dx do2 dmem "
+                                      "dWo dbo dg1 dbe1 dWv dbv dWc dbc dg2 dbe2 dW1 db1 dW2 db2 dg3 dbe3 s128a s128b s512a s512b sdc ws").split()])
 
 
 class Schedule(C.Structure):
@@ -119,7 +131,12 @@ def load() -> C.CDLL:
     lib.amuse_train_bias_gelu_drop_fwd.argtypes = [vp, vp, C.c_float, u64, u64, C.c_long, C.c_int, vp, vp]
     lib.amuse_train_bias_gelu_drop_bwd.argtypes = [vp, vp, vp, C.c_float, u64, u64, C.c_long, C.c_int, vp, vp, vp, vp]
     lib.amuse_train_colsum.argtypes = [vp, C.c_long, C.c_int, vp, vp, vp]
-    for n in ("amuse_train_ln_fwd", "amuse_train_ln_bwd", "amuse_train_bias_gelu_drop_fwd", "amuse_train_bias_gelu_drop_bwd", "amuse_train_colsum"):
+    lib.amuse_train_layer_fwd.argtypes = [C.POINTER(TrainLayer), vp]
+    lib.amuse_train_layer_bwd.argtypes = [C.POINTER(TrainLayer), vp]
+    lib.amuse_train_linear_fwd.argtypes = [vp, vp, vp, C.c_long, C.c_int, C.c_int, vp, vp]
+    lib.amuse_train_linear_bwd.argtypes = [vp, vp, vp, C.c_long, C.c_int, C.c_int, vp, vp, vp, C.c_int, vp, vp]
+    for n in ("amuse_train_ln_fwd", "amuse_train_ln_bwd", "amuse_train_bias_gelu_drop_fwd", "amuse_train_bias_gelu_drop_bwd", "amuse_train_colsum",
+              "amuse_train_layer_fwd", "amuse_train_layer_bwd", "amuse_train_linear_fwd", "amuse_train_linear_bwd"):
         getattr(lib, n).restype = C.c_int
     for n in ("amuse_audio_fbank", "amuse_audio_encode", "amuse_audio_features", "amuse_debug_gemm", "amuse_debug_tile"):
         getattr(lib, n).restype = C.c_int

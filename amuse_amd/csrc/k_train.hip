@@ -13,6 +13,10 @@
 // Dropout masks are counter-based: element e of a call is draw e % 4 of Philox4x32-10(key = seed, counter = (e / 4, offset)) - nothing is stored,
 // the backward kernels regenerate the mask from the same (seed, offset); keep <=> u >= p with u = the draw's top 24 bits / 2^24.
 // Column sums are deterministic: every workgroup writes its partial sums, a one-workgroup launch behind it adds them up in a fixed order.  All arrays fp32, row-major [rows][C]; HBM-bound by construction (each array is read or written once).
+#include <dlfcn.h>
+
+#include <mutex>
+
 #include "amuse_dev.hpp"
 #include "amuse_host.hpp"
 
@@ -99,9 +103,9 @@ __device__ __forceinline__ void workgroup_partial(f32x4 acc, int nc4, int lanes,
     }
 }
 
-__global__ __launch_bounds__(kTrainThreads) void k_train_ln_bwd(const float* __restrict__ dout, const float* __restrict__ dout2, const float* __restrict__ zhat, const float* __restrict__ rstd_in,
+__global__ __launch_bounds__(kTrainThreads) void k_train_ln_bwd(const float* dout, const float* dout2, const float* __restrict__ zhat, const float* __restrict__ rstd_in,
                                                       const float* __restrict__ gamma, uint32_t thr, float scale, uint64_t seed, uint64_t offset, long rows,
-                                                      float* __restrict__ dx, float* __restrict__ dy, float* ws) {
+                                                      float* dx, float* dy, float* ws) {   // (dx may be dout, dy may be dout2: same thread, same elements)
     __shared__ f32x4 red[kTrainThreads];
     const int cg = threadIdx.x & 31, rl = threadIdx.x >> 5;   // 32 row lanes
     const f32x4 ga = ld4(gamma + 4 * cg);
@@ -218,6 +222,47 @@ __global__ __launch_bounds__(kTrainThreads) void k_train_colsum(const float* __r
     workgroup_partial(acc, C4, lanes, ws + (size_t)blockIdx.x * 4 * C4, red);
 }
 
+// ---- small pieces of the layer-level entry points
+// out[r][:] = bias (the C operand of a GEMM with beta = 1: a Linear's bias)
+__global__ __launch_bounds__(256) void k_train_bias_rows(const float* __restrict__ bias, size_t n4, int C4, float* __restrict__ out) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) st4(out + 4 * i, ld4(bias + 4 * (i % C4)));
+}
+// The decoder's cross-attention onto its ONE memory token (cross_attention.py:331-337; nn_modules.mha_one_key): the attention weight of every
+// (clip, query, head) is 1, hit by the attention dropout: vk[b][s][:] = c[b][:] . keep(b, s, head) / (1 - p), c = the memory's value projection.
+// keep(b, s, h) = draw h % 4 of Philox(seed, counter ((b S + s) H + h) / 4, offset).  D = 128, heads of 32 features: one thread = 4 features.
+__device__ __forceinline__ float head_keep(uint64_t seed, uint64_t offset, size_t row, int H, int h, uint32_t thr, float scale) {
+    if (thr == 0) return 1.0f;
+    const size_t e = row * H + h;
+    const uint4 b = drop_bits(seed, offset, e >> 2);
+    const uint32_t d = (e & 3) == 0 ? b.x : (e & 3) == 1 ? b.y : (e & 3) == 2 ? b.z : b.w;
+    return (d >> 8) >= thr ? scale : 0.f;
+}
+__global__ __launch_bounds__(256) void k_train_vk(const float* __restrict__ c, uint32_t thr, float scale, uint64_t seed, uint64_t offset, long rows, int S, int H,
+                                                  float* __restrict__ vk) {
+    const int dh4 = 128 / H / 4;   // float4 groups per head
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < (size_t)rows * 32; i += (size_t)gridDim.x * 256) {
+        const size_t row = i >> 5;
+        const int cg = (int)(i & 31);
+        st4(vk + 4 * i, ld4(c + (row / S) * 128 + 4 * cg) * head_keep(seed, offset, row, H, cg / dh4, thr, scale));
+    }
+}
+// dc[b][:] = sum_s dvk[b][s][:] . keep(b, s, head) / (1 - p): one workgroup per clip, 32 column groups x 8 row lanes
+__global__ __launch_bounds__(256) void k_train_dc(const float* __restrict__ dvk, uint32_t thr, float scale, uint64_t seed, uint64_t offset, int S, int H,
+                                                  float* __restrict__ dc) {
+    __shared__ f32x4 red[256];
+    const int cg = threadIdx.x & 31, rl = threadIdx.x >> 5, dh4 = 128 / H / 4;
+    const size_t row0 = (size_t)blockIdx.x * S;
+    f32x4 acc = splat4(0.f);
+    for (int s0 = rl; s0 < S; s0 += 8) acc += ld4(dvk + (row0 + s0) * 128 + 4 * cg) * head_keep(seed, offset, row0 + s0, H, cg / dh4, thr, scale);
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    if (threadIdx.x < 32) {
+        f32x4 t = red[threadIdx.x];
+        for (int q = 1; q < 8; ++q) t += red[q * 32 + threadIdx.x];
+        st4(dc + (size_t)blockIdx.x * 128 + 4 * threadIdx.x, t);
+    }
+}
+
 int drop_args(float p, uint32_t* thr, float* scale) {
     if (!(p >= 0.f) || p >= 1.f) return fail(AMUSE_EINVAL, "dropout probability %g outside [0, 1)", (double)p);
     *thr = (uint32_t)(p * 16777216.0f);
@@ -227,6 +272,74 @@ int drop_args(float p, uint32_t* thr, float* scale) {
 int grid_for(long rows, int rows_per_wg) {
     const long g = (rows + rows_per_wg - 1) / rows_per_wg;
     return (int)(g < 1 ? 1 : g > kTrainWgs ? kTrainWgs : g);
+}
+
+// ---- rocBLAS for the layer's plain GEMMs (the brief's "library GEMMs"): loaded on first use with dlopen - the inference path of this library has no
+// BLAS dependency - preferring the copy the process already holds (torch's), one handle per device.  Row-major wrappers: C = op(A) . op(B).
+struct Blas {
+    typedef int (*create_t)(void**);
+    typedef int (*set_stream_t)(void*, hipStream_t);
+    typedef int (*sgemm_t)(void*, int, int, int, int, int, const float*, const float*, int, const float*, int, const float*, float*, int);
+    void* lib = nullptr;
+    create_t create = nullptr;
+    set_stream_t set_stream = nullptr;
+    sgemm_t sgemm = nullptr;
+    void* handle[64] = {};
+    std::mutex mu;
+};
+Blas g_blas;
+int blas_handle(hipStream_t st, void** h) {
+    std::lock_guard<std::mutex> lock(g_blas.mu);
+    if (!g_blas.lib) {
+        for (const char* name : {"librocblas.so", "librocblas.so.5", "/opt/rocm/lib/librocblas.so"}) {
+            g_blas.lib = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+            if (g_blas.lib) break;
+        }
+        if (!g_blas.lib) return fail(AMUSE_ESTATE, "the training-step layer entry points need rocBLAS: dlopen(librocblas.so) failed: %s", dlerror());
+        g_blas.create = (Blas::create_t)dlsym(g_blas.lib, "rocblas_create_handle");
+        g_blas.set_stream = (Blas::set_stream_t)dlsym(g_blas.lib, "rocblas_set_stream");
+        g_blas.sgemm = (Blas::sgemm_t)dlsym(g_blas.lib, "rocblas_sgemm");
+        if (!g_blas.create || !g_blas.set_stream || !g_blas.sgemm) return fail(AMUSE_ESTATE, "rocBLAS symbols missing");
+    }
+    int dev = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    dev &= 63;
+    if (!g_blas.handle[dev] && g_blas.create(&g_blas.handle[dev]) != 0) return fail(AMUSE_EHIP, "rocblas_create_handle failed");
+    if (g_blas.set_stream(g_blas.handle[dev], st) != 0) return fail(AMUSE_EHIP, "rocblas_set_stream failed");
+    *h = g_blas.handle[dev];
+    return 0;
+}
+// out[M][N] (+)= op(a) . op(b); a is [M][K] (ta: [K][M]), b is [K][N] (tb: [N][K]), all row-major and dense
+int rm_gemm(void* h, bool ta, bool tb, long M, long N, long K, const float* a, const float* b, float* out, bool accumulate) {
+    const float one = 1.0f, zero = 0.0f;
+    const int rc = g_blas.sgemm(h, tb ? 112 : 111, ta ? 112 : 111, (int)N, (int)M, (int)K, &one, b, (int)(tb ? K : N), a, (int)(ta ? M : K), accumulate ? &one : &zero, out, (int)N);
+    return rc == 0 ? 0 : fail(AMUSE_EHIP, "rocblas_sgemm failed with status %d (M %ld N %ld K %ld)", rc, M, N, K);
+}
+#define TRY(expr) do { if (int e_ = (expr)) return e_; } while (0)
+
+int ln_fwd_launch(const float* x, const float* y, const float* bias, const float* gamma, const float* beta, uint32_t thr, float scale, uint64_t seed, uint64_t off,
+                  long rows, float* out, float* zhat, float* rstd, hipStream_t st) {
+    const long g = (rows + 7) / 8;
+    hipLaunchKernelGGL(k_train_ln_fwd, dim3((unsigned)(g > 4096 ? 4096 : g)), dim3(256), 0, st, x, y, bias, gamma, beta, thr, scale, seed, off, rows, out, zhat, rstd);
+    return 0;
+}
+int ln_bwd_launch(const float* dout, const float* dout2, const float* zhat, const float* rstd, const float* gamma, uint32_t thr, float scale, uint64_t seed, uint64_t off,
+                  long rows, float* dx, float* dy, float* dgamma, float* dbeta, float* dbias, float* ws, hipStream_t st) {
+    const int g = grid_for(rows, 64);
+    hipLaunchKernelGGL(k_train_ln_bwd, dim3(g), dim3(kTrainThreads), 0, st, dout, dout2, zhat, rstd, gamma, thr, scale, seed, off, rows, dx, dy, ws);
+    hipLaunchKernelGGL(k_train_finalize, dim3(1), dim3(kTrainThreads), 0, st, ws, g, dgamma, dbeta, dbias, 384, 128);
+    return 0;
+}
+int colsum_launch(const float* x, long rows, int C, float* out, float* ws, hipStream_t st) {
+    const int g = grid_for(rows, 2 * (kTrainThreads / (C / 4)));
+    hipLaunchKernelGGL(k_train_colsum, dim3(g), dim3(kTrainThreads), 0, st, x, rows, C / 4, ws);
+    hipLaunchKernelGGL(k_train_finalize, dim3(1), dim3(kTrainThreads), 0, st, ws, g, out, (float*)nullptr, (float*)nullptr, C, C);
+    return 0;
+}
+int bias_rows_launch(const float* bias, long rows, int C, float* out, hipStream_t st) {
+    const size_t n4 = (size_t)rows * (C / 4), g = (n4 + 255) / 256;
+    hipLaunchKernelGGL(k_train_bias_rows, dim3((unsigned)(g > 8192 ? 8192 : g)), dim3(256), 0, st, bias, n4, C / 4, out);
+    return 0;
 }
 
 }  // namespace
@@ -295,6 +408,128 @@ int amuse_train_colsum(const float* x, long rows, int C, float* out, float* ws, 
     const int g = grid_for(rows, 2 * (kTrainThreads / (C / 4)));
     hipLaunchKernelGGL(k_train_colsum, dim3(g), dim3(kTrainThreads), 0, (hipStream_t)stream, x, rows, C / 4, ws);
     hipLaunchKernelGGL(k_train_finalize, dim3(1), dim3(kTrainThreads), 0, (hipStream_t)stream, ws, g, out, (float*)nullptr, (float*)nullptr, C, C);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+// ---- layer-level entry points: everything of a transformer layer but its self-attention core in ONE call each way (amuse_hip.h amuse_train_layer)
+int amuse_train_linear_fwd(const float* x, const float* W, const float* b, long rows, int K, int N, float* out, void* stream) {
+    if (!x || !W || !out) return fail(AMUSE_EINVAL, "amuse_train_linear_fwd: NULL argument");
+    if (rows < 1 || K < 1 || N < 4 || (N & 3)) return fail(AMUSE_EINVAL, "rows %ld, K %d, N %d (a multiple of 4)", rows, K, N);
+    hipStream_t st = (hipStream_t)stream;
+    void* h;
+    TRY(blas_handle(st, &h));
+    if (b) bias_rows_launch(b, rows, N, out, st);
+    TRY(rm_gemm(h, false, true, rows, N, K, x, W, out, b != nullptr));
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int amuse_train_linear_bwd(const float* dy, const float* x, const float* W, long rows, int K, int N, float* dW, float* db, float* dx, int accumulate_dx, float* ws,
+                           void* stream) {
+    if (!dy || !x || !W) return fail(AMUSE_EINVAL, "amuse_train_linear_bwd: NULL argument");
+    if (rows < 1 || K < 1 || N < 4 || (N & 3) || N > 1024) return fail(AMUSE_EINVAL, "rows %ld, K %d, N %d (a multiple of 4 up to 1024)", rows, K, N);
+    if (db && !ws) return fail(AMUSE_EINVAL, "the bias gradient needs the workspace");
+    hipStream_t st = (hipStream_t)stream;
+    void* h;
+    TRY(blas_handle(st, &h));
+    if (dW) TRY(rm_gemm(h, true, false, N, K, rows, dy, x, dW, false));          // dW[N][K] = dy^T x
+    if (db) colsum_launch(dy, rows, N, db, ws, st);
+    if (dx) TRY(rm_gemm(h, false, false, rows, K, N, dy, W, dx, accumulate_dx != 0));   // dx[rows][K] (+)= dy W
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+static int layer_check(const amuse_train_layer* L, bool bwd) {
+    if (!L) return fail(AMUSE_EINVAL, "layer is NULL");
+    if (L->rows < 1 || L->B < 1 || L->S < 1 || (long)L->B * L->S != L->rows) return fail(AMUSE_EINVAL, "rows %ld != B %d x S %d", L->rows, L->B, L->S);
+    if (L->H < 1 || 32 % L->H) return fail(AMUSE_EINVAL, "heads %d must divide 32 (128 features, whole float4 groups per head)", L->H);
+    if (L->ff < 4 || L->ff > 1024 || (L->ff & 3)) return fail(AMUSE_EINVAL, "ff %d must be a multiple of 4 up to 1024", L->ff);
+    if (!L->Wo || !L->g1 || !L->be1 || !L->W1 || !L->b1 || !L->W2 || !L->g3 || !L->be3 || !L->x || !L->o2 || !L->x1 || !L->h || !L->a || !L->out || !L->tmp)
+        return fail(AMUSE_EINVAL, "amuse_train_layer: a required pointer is NULL");
+    if (L->mem && (!L->Wv || !L->Wc || !L->g2 || !L->be2 || !L->c || !L->vk || !L->xm)) return fail(AMUSE_EINVAL, "amuse_train_layer: decoder pointers missing");
+    if (bwd) {
+        if (!L->dout || !L->dx || !L->do2 || !L->zh1 || !L->r1 || !L->zh3 || !L->r3 || !L->s128a || !L->s128b || !L->s512a || !L->s512b || !L->ws || !L->dWo || !L->dg1 ||
+            !L->dbe1 || !L->dW1 || !L->db1 || !L->dW2 || !L->dg3 || !L->dbe3)
+            return fail(AMUSE_EINVAL, "amuse_train_layer (backward): a required pointer is NULL");
+        if (L->mem && (!L->zh2 || !L->r2 || !L->sdc || !L->dWv || !L->dbv || !L->dWc || !L->dg2 || !L->dbe2 || !L->dmem))
+            return fail(AMUSE_EINVAL, "amuse_train_layer (backward): decoder pointers missing");
+    }
+    return 0;
+}
+
+int amuse_train_layer_fwd(const amuse_train_layer* L, void* stream) {
+    TRY(layer_check(L, false));
+    uint32_t thr, thr_a; float scale, scale_a;
+    TRY(drop_args(L->p, &thr, &scale));
+    TRY(drop_args(L->p_attn, &thr_a, &scale_a));
+    hipStream_t st = (hipStream_t)stream;
+    void* h;
+    TRY(blas_handle(st, &h));
+    const long rows = L->rows;
+    // x1 = norm1(x + dropout1(o2 Wo^T + bo))
+    TRY(rm_gemm(h, false, true, rows, 128, 128, L->o2, L->Wo, L->tmp, false));
+    ln_fwd_launch(L->x, L->tmp, L->bo, L->g1, L->be1, thr, scale, L->seed, L->off[0], rows, L->x1, L->zh1, L->r1, st);
+    const float* src = L->x1;
+    if (L->mem) {   // xm = norm2(x1 + dropout2(vk Wc^T + bc)), vk = the memory token's value projection under the attention dropout
+        bias_rows_launch(L->bv, L->B, 128, L->c, st);
+        TRY(rm_gemm(h, false, true, L->B, 128, 128, L->mem, L->Wv, L->c, true));
+        const size_t n = (size_t)rows * 32, g = (n + 255) / 256;
+        hipLaunchKernelGGL(k_train_vk, dim3((unsigned)(g > 8192 ? 8192 : g)), dim3(256), 0, st, L->c, thr_a, scale_a, L->seed, L->off[4], rows, L->S, L->H, L->vk);
+        TRY(rm_gemm(h, false, true, rows, 128, 128, L->vk, L->Wc, L->tmp, false));
+        ln_fwd_launch(L->x1, L->tmp, L->bc, L->g2, L->be2, thr, scale, L->seed, L->off[1], rows, L->xm, L->zh2, L->r2, st);
+        src = L->xm;
+    }
+    // out = norm3(src + dropout3(dropout(gelu(src W1^T + b1)) W2^T + b2))
+    TRY(rm_gemm(h, false, true, rows, L->ff, 128, src, L->W1, L->h, false));
+    {
+        const size_t n4 = (size_t)rows * (L->ff / 4), g = (n4 + 255) / 256;
+        hipLaunchKernelGGL(k_train_bgd_fwd, dim3((unsigned)(g > 8192 ? 8192 : g)), dim3(256), 0, st, L->h, L->b1, thr, scale, L->seed, L->off[2], n4, L->ff / 4, L->a);
+    }
+    TRY(rm_gemm(h, false, true, rows, 128, L->ff, L->a, L->W2, L->tmp, false));
+    ln_fwd_launch(src, L->tmp, L->b2, L->g3, L->be3, thr, scale, L->seed, L->off[3], rows, L->out, L->zh3, L->r3, st);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int amuse_train_layer_bwd(const amuse_train_layer* L, void* stream) {
+    TRY(layer_check(L, true));
+    uint32_t thr, thr_a; float scale, scale_a;
+    TRY(drop_args(L->p, &thr, &scale));
+    TRY(drop_args(L->p_attn, &thr_a, &scale_a));
+    hipStream_t st = (hipStream_t)stream;
+    void* h;
+    TRY(blas_handle(st, &h));
+    const long rows = L->rows;
+    const int ff = L->ff;
+    const float* src = L->mem ? L->xm : L->x1;
+    // FFN + last norm: s128a = d(src) through the norm, s128b = d(linear2 output)
+    ln_bwd_launch(L->dout, nullptr, L->zh3, L->r3, L->g3, thr, scale, L->seed, L->off[3], rows, L->s128a, L->s128b, L->dg3, L->dbe3, L->db2, L->ws, st);
+    TRY(rm_gemm(h, true, false, 128, ff, rows, L->s128b, L->a, L->dW2, false));
+    TRY(rm_gemm(h, false, false, rows, ff, 128, L->s128b, L->W2, L->s512a, false));
+    {
+        const int g = grid_for(rows, 2 * (kTrainThreads / (ff / 4)));
+        hipLaunchKernelGGL(k_train_bgd_bwd, dim3(g), dim3(kTrainThreads), 0, st, L->s512a, L->h, L->b1, thr, scale, L->seed, L->off[2], rows, ff / 4, L->s512b, L->ws);
+        hipLaunchKernelGGL(k_train_finalize, dim3(1), dim3(kTrainThreads), 0, st, L->ws, g, L->db1, (float*)nullptr, (float*)nullptr, ff, ff);
+    }
+    TRY(rm_gemm(h, true, false, ff, 128, rows, L->s512b, src, L->dW1, false));
+    TRY(rm_gemm(h, false, false, rows, 128, ff, L->s512b, L->W1, L->s128b, false));      // the FFN branch's gradient of src
+    if (L->mem) {
+        // cross-attention + norm2: s128a <- d(x1), s128b <- d(out_proj output)
+        ln_bwd_launch(L->s128a, L->s128b, L->zh2, L->r2, L->g2, thr, scale, L->seed, L->off[1], rows, L->s128a, L->s128b, L->dg2, L->dbe2, L->dbc, L->ws, st);
+        TRY(rm_gemm(h, true, false, 128, 128, rows, L->s128b, L->vk, L->dWc, false));
+        TRY(rm_gemm(h, false, false, rows, 128, 128, L->s128b, L->Wc, L->do2, false));     // d(vk), parked in do2
+        hipLaunchKernelGGL(k_train_dc, dim3(L->B), dim3(256), 0, st, L->do2, thr_a, scale_a, L->seed, L->off[4], L->S, L->H, L->sdc);
+        TRY(rm_gemm(h, true, false, 128, 128, L->B, L->sdc, L->mem, L->dWv, false));
+        colsum_launch(L->sdc, L->B, 128, L->dbv, L->ws, st);
+        TRY(rm_gemm(h, false, false, L->B, 128, 128, L->sdc, L->Wv, L->dmem, false));
+        ln_bwd_launch(L->s128a, nullptr, L->zh1, L->r1, L->g1, thr, scale, L->seed, L->off[0], rows, L->dx, L->s128b, L->dg1, L->dbe1, L->dbo, L->ws, st);
+    } else {
+        ln_bwd_launch(L->s128a, L->s128b, L->zh1, L->r1, L->g1, thr, scale, L->seed, L->off[0], rows, L->dx, L->s128b, L->dg1, L->dbe1, L->dbo, L->ws, st);
+    }
+    // self-attention's out_proj
+    TRY(rm_gemm(h, true, false, 128, 128, rows, L->s128b, L->o2, L->dWo, false));
+    TRY(rm_gemm(h, false, false, rows, 128, 128, L->s128b, L->Wo, L->do2, false));
     HIP_TRY(hipGetLastError());
     return 0;
 }

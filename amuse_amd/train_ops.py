@@ -1,12 +1,13 @@
 """A transformer layer of the train_gesture step as ONE autograd.Function (BASELINE config 4; reference scripts/trainer.py:335-498 runs
 utils/cross_attention.py:259-272 (TransformerEncoderLayer.forward_post) and :323-345 (TransformerDecoderLayer.forward_post) op by op under
-autograd): the GEMMs stay on rocBLAS (torch.mm / addmm) and the self-attention on the vendor's fused kernel (aten's efficient-attention
-forward / backward ops, called directly), everything between them - biases, the three dropouts, residual adds, LayerNorms, GELU and every
-bias / LayerNorm gradient reduction - runs in the hand-written HIP kernels of csrc/k_train.hip, forward and backward.
+autograd): per direction TWO calls into the library (csrc/k_train.hip: amuse_train_linear_fwd + amuse_train_layer_fwd, amuse_train_layer_bwd +
+amuse_train_linear_bwd) around the vendor's fused self-attention kernel (aten's efficient-attention forward / backward ops, called directly).  Inside
+the calls the plain GEMMs go to rocBLAS straight from C++ and everything between them - biases, the three dropouts, residual adds, LayerNorms, GELU,
+the decoder's one-key cross-attention and every bias / LayerNorm gradient reduction - runs in the hand-written HIP kernels, forward and backward.
 
 Why a Function per layer and not per op: the eager step was host-bound AND device-bound at once (~1,950 launches, ~27 ms of host
-dispatch over ~24 ms of device time per iteration).  Inside `forward` / `backward` nothing is recorded by autograd, so a layer costs ~8 + ~18
-launches with no graph nodes in between instead of ~14 + ~25 with one node each, and the glue's device time (LayerNorm forward / backward, dropout,
+dispatch over ~24 ms of device time per iteration; a torch.mm costs ~19 us of host time where rocblas_sgemm itself takes ~5).  Inside `forward` /
+`backward` nothing is recorded by autograd and the ~8 + ~20 launches of a layer are issued from C++, and the glue's device time (LayerNorm forward / backward, dropout,
 adds, GELU, the bias gradients' column sums: ~9 of the 24 ms) shrinks to one pass over each array.
 
 Dropout: counter-based masks (k_train.hip), keyed by torch's seed of the process (`torch.initial_seed()`: the trainer seeds every rank
@@ -18,6 +19,7 @@ path to them: outputs and every gradient, eval mode exactly the same arithmetic,
 """
 from __future__ import annotations
 
+import ctypes as C
 import os
 from typing import Optional, Tuple
 
@@ -67,6 +69,59 @@ def _p(t: Optional[torch.Tensor]):
 def _c(t: torch.Tensor) -> torch.Tensor:
     assert t.dtype == torch.float32
     return t if t.is_contiguous() else t.contiguous()
+
+
+# ---------------------------------------------------------------------------------------------------- GEMMs
+# The layer's plain GEMMs go to rocBLAS directly (rocblas_sgemm through ctypes, on the copy of librocblas this process has already loaded for
+# torch): enqueueing one costs ~6 us of host time against ~19 for torch.mm / addmm on the same library (tools/probes/train_host/), and the
+# step is host-bound.  AMUSE_TRAIN_GEMM=torch keeps torch.mm (A/B).  Row-major throughout: gemm(a, b, ta, tb) = op(a) . op(b).
+_BLAS = {}
+_OP_N, _OP_T = 111, 112          # rocblas_operation_none / _transpose
+
+
+def _blas(device):
+    b = _BLAS.get(device)
+    if b is None:
+        lib = C.CDLL("librocblas.so")
+        lib.rocblas_create_handle.argtypes = [C.POINTER(C.c_void_p)]
+        lib.rocblas_set_stream.argtypes = [C.c_void_p, C.c_void_p]
+        lib.rocblas_sgemm.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int,
+                                      C.c_void_p, C.c_void_p, C.c_int]
+        h = C.c_void_p()
+        with torch.cuda.device(device):
+            if lib.rocblas_create_handle(C.byref(h)) != 0:
+                raise RuntimeError("rocblas_create_handle failed")
+        b = {"lib": lib, "h": h, "stream": None, "one": C.c_float(1.0), "zero": C.c_float(0.0)}
+        _BLAS[device] = b
+    st = _stream()
+    if b["stream"] != st:
+        if b["lib"].rocblas_set_stream(b["h"], st) != 0:
+            raise RuntimeError("rocblas_set_stream failed")
+        b["stream"] = st
+    return b
+
+
+def _direct_gemm() -> bool:
+    return os.environ.get("AMUSE_TRAIN_GEMM", "rocblas") != "torch"
+
+
+def gemm(a: torch.Tensor, b: torch.Tensor, ta: bool = False, tb: bool = False, out: Optional[torch.Tensor] = None, accumulate: bool = False) -> torch.Tensor:
+    """op(a) . op(b) for contiguous fp32 matrices (row-major), into `out` (+= with accumulate)."""
+    M, K = (a.shape[1], a.shape[0]) if ta else (a.shape[0], a.shape[1])
+    N = b.shape[0] if tb else b.shape[1]
+    assert (b.shape[1] if tb else b.shape[0]) == K and a.is_contiguous() and b.is_contiguous()
+    if out is None:
+        assert not accumulate
+        out = torch.empty(M, N, device=a.device, dtype=torch.float32)
+    if not _direct_gemm():
+        aa, bb = (a.t() if ta else a), (b.t() if tb else b)
+        return torch.addmm(out, aa, bb, out=out) if accumulate else torch.mm(aa, bb, out=out)
+    bl = _blas(a.device)
+    rc = bl["lib"].rocblas_sgemm(bl["h"], _OP_T if tb else _OP_N, _OP_T if ta else _OP_N, N, M, K, C.byref(bl["one"]), b.data_ptr(), b.shape[1],
+                                 a.data_ptr(), a.shape[1], C.byref(bl["one"] if accumulate else bl["zero"]), out.data_ptr(), N)
+    if rc != 0:
+        raise RuntimeError(f"rocblas_sgemm failed with status {rc}")
+    return out
 
 
 # ---------------------------------------------------------------------------------------------------- raw kernels
@@ -124,31 +179,88 @@ def colsum(x):
     return out
 
 
-# ---------------------------------------------------------------------------------------------------- sub-layers (no autograd inside)
+# ---------------------------------------------------------------------------------------------------- layers (no autograd inside)
 _sdpa = torch.ops.aten._scaled_dot_product_efficient_attention
 _sdpa_bwd = torch.ops.aten._scaled_dot_product_efficient_attention_backward
+_ENC_PARAMS = ("Wo", "bo", "g1", "be1", "W1", "b1", "W2", "b2", "g3", "be3")
+_DEC_PARAMS = ("Wo", "bo", "g1", "be1", "Wv", "bv", "Wc", "bc", "g2", "be2", "W1", "b1", "W2", "b2", "g3", "be3")
 
 
-def _self_attn_fwd(x2, B, S, H, Win, bin_, Wo, p_attn):
-    """x2 (B S, 128) -> (y = attention output through out_proj WITHOUT its bias, saved tensors)."""
-    D = x2.shape[1]
-    qkv = torch.addmm(bin_, x2, Win.t())                                       # (rows, 3 D): packed in-projection
-    q, k, v = (t.transpose(1, 2) for t in qkv.view(B, S, 3, H, D // H).unbind(2))   # (B, H, S, d) views
-    out, lse, ps, po = _sdpa(q, k, v, None, True, p_attn, False)
-    o2 = out.transpose(1, 2).reshape(B * S, D)
-    return torch.mm(o2, Wo.t()), (qkv, out, lse, ps, po, o2)
+def _layer_forward(ctx, x, mem, Win, bin_, prm: dict, H: int, p: float, p_attn: float):
+    """One call into the library in front of the attention (packed in-projection), the vendor's attention, one call behind it (amuse_train_layer_fwd)."""
+    B, S, D = x.shape
+    rows, ff, dev = B * S, prm["W1"].shape[0], x.device
+    st = _st(dev)
+    lib, stream = st["lib"], _stream()
+    x2 = _c(x).view(rows, D)
+    keep = any(ctx.needs_input_grad)                       # (no-grad passes - the iteration's second encode - keep nothing beyond the call)
+    qkv = torch.empty(rows, 3 * D, device=dev, dtype=torch.float32)
+    _lib.check(lib.amuse_train_linear_fwd(x2.data_ptr(), Win.data_ptr(), bin_.data_ptr(), rows, D, 3 * D, qkv.data_ptr(), stream))
+    q, k, v = (t.transpose(1, 2) for t in qkv.view(B, S, 3, H, D // H).unbind(2))       # (B, H, S, d) views
+    ao, lse, ps, po = _sdpa(q, k, v, None, True, p_attn, False)
+    o2 = ao.transpose(1, 2).reshape(rows, D)
+    dec = mem is not None
+    n128 = 9 if dec else 6
+    b128 = torch.empty(n128, rows, D, device=dev, dtype=torch.float32)                   # x1 zh1 out zh3 tmp (vk xm zh2) | one spare row block for r1 r2 r3
+    b512 = torch.empty(2, rows, ff, device=dev, dtype=torch.float32)
+    L = _lib.TrainLayer()
+    L.rows, L.B, L.S, L.H, L.ff, L.p, L.p_attn, L.seed = rows, B, S, H, ff, p, p_attn, _seed()
+    for i in range(5):
+        L.off[i] = next_offset()
+    for n, t in prm.items():
+        setattr(L, n, t.data_ptr())
+    L.x, L.o2 = x2.data_ptr(), o2.data_ptr()
+    L.x1, L.zh1, L.out, L.zh3, L.tmp = (b128[i].data_ptr() for i in range(5))
+    rs = b128[n128 - 1].data_ptr()                                                        # the three [rows] vectors of 1 / sigma
+    L.r1, L.r2, L.r3 = rs, rs + 4 * rows, rs + 8 * rows
+    L.h, L.a = b512[0].data_ptr(), b512[1].data_ptr()
+    c = None
+    if dec:
+        mem2 = _c(mem).view(B, D)
+        c = torch.empty(B, D, device=dev, dtype=torch.float32)
+        L.mem, L.c = mem2.data_ptr(), c.data_ptr()
+        L.vk, L.xm, L.zh2 = (b128[i].data_ptr() for i in (5, 6, 7))
+    _lib.check(lib.amuse_train_layer_fwd(C.byref(L), stream))
+    if keep:
+        ctx.save_for_backward(x2, qkv, ao, lse, ps, po, o2, b128, b512, Win, *((mem2, c) if dec else ()), *prm.values())
+        ctx.L, ctx.cfg = L, (B, S, D, H, p_attn, dec, tuple(prm))
+    return b128[2].view(B, S, D)
 
 
-def _self_attn_bwd(dy, x2, B, S, H, Win, Wo, p_attn, saved):
-    """dy = gradient of the out_proj output -> (dx contribution as (d_qkv, Win) for the caller's addmm, dWin, dbin, dWo)."""
-    qkv, out, lse, ps, po, o2 = saved
-    D = x2.shape[1]
-    dWo = torch.mm(dy.t(), o2)
-    do = torch.mm(dy, Wo).view(B, S, H, D // H).transpose(1, 2)
-    q, k, v = (t.transpose(1, 2) for t in qkv.view(B, S, 3, H, D // H).unbind(2))
-    dq, dk, dv, _ = _sdpa_bwd(do, q, k, v, None, out, lse, ps, po, p_attn, (True, True, True, False), False)
-    dqkv = torch.stack([dq.transpose(1, 2), dk.transpose(1, 2), dv.transpose(1, 2)], dim=2).view(B * S, 3 * D)
-    return dqkv, torch.mm(dqkv.t(), x2), colsum(dqkv), dWo
+def _layer_backward(ctx, dout):
+    t = ctx.saved_tensors
+    B, S, D, H, p_attn, dec, names = ctx.cfg
+    x2, qkv, ao, lse, ps, po, o2, b128, b512, Win = t[:10]
+    prm = dict(zip(names, t[12 if dec else 10:]))
+    rows, ff, dev = B * S, b512.shape[2], x2.device
+    st = _st(dev)
+    lib, stream = st["lib"], _stream()
+    L = ctx.L
+    dout = _c(dout).view(rows, D)
+    g128 = torch.empty(4, rows, D, device=dev, dtype=torch.float32)                      # dx do2 s128a s128b
+    g512 = torch.empty(2, rows, ff, device=dev, dtype=torch.float32)
+    sizes = {n: prm[n].numel() for n in names}
+    flat = torch.empty(sum(sizes.values()) + 2 * B * D, device=dev, dtype=torch.float32)   # the layer's parameter gradients (+ d(mem), the d(c) scratch)
+    grads, o = {}, 0
+    for n in names:
+        grads[n] = flat[o:o + sizes[n]].view_as(prm[n])
+        setattr(L, "d" + n, grads[n].data_ptr())
+        o += sizes[n]
+    dmem = flat[o:o + B * D].view(B, 1, D)
+    L.dmem, L.sdc = dmem.data_ptr(), flat[o + B * D:].data_ptr()
+    L.dout = dout.data_ptr()
+    L.dx, L.do2, L.s128a, L.s128b = (g128[i].data_ptr() for i in range(4))
+    L.s512a, L.s512b, L.ws = g512[0].data_ptr(), g512[1].data_ptr(), st["ws"].data_ptr()
+    _lib.check(lib.amuse_train_layer_bwd(C.byref(L), stream))
+    do = g128[1].view(B, S, H, D // H).transpose(1, 2)
+    q, k, v = (u.transpose(1, 2) for u in qkv.view(B, S, 3, H, D // H).unbind(2))
+    dq, dk, dv, _ = _sdpa_bwd(do, q, k, v, None, ao, lse, ps, po, p_attn, (True, True, True, False), False)
+    dqkv = torch.stack([dq.transpose(1, 2), dk.transpose(1, 2), dv.transpose(1, 2)], dim=2).view(rows, 3 * D)
+    dWin = torch.empty_like(Win)
+    dbin = torch.empty(3 * D, device=dev, dtype=torch.float32)
+    _lib.check(lib.amuse_train_linear_bwd(dqkv.data_ptr(), x2.data_ptr(), Win.data_ptr(), rows, D, 3 * D, dWin.data_ptr(), dbin.data_ptr(), g128[0].data_ptr(), 1,
+                                          st["ws"].data_ptr(), stream))
+    return g128[0].view(B, S, D), (dmem if dec else None), dWin, dbin, grads
 
 
 class EncoderLayerFn(torch.autograd.Function):
@@ -156,33 +268,12 @@ class EncoderLayerFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, Win, bin_, Wo, bo, g1, be1, W1, b1, W2, b2, g2, be2, H, p, p_attn):
-        B, S, D = x.shape
-        x2 = _c(x).view(B * S, D)
-        keep = any(ctx.needs_input_grad)          # (no-grad passes - the iteration's second encode - keep nothing)
-        seed, o1, o2_, o3 = _seed(), next_offset(), next_offset(), next_offset()
-        y, sa = _self_attn_fwd(x2, B, S, H, Win, bin_, Wo, p_attn)
-        x1, zh1, r1 = ln_fwd(x2, y, bo, g1, be1, p, seed, o1, keep)
-        h = torch.mm(x1, W1.t())
-        a = bias_gelu_drop_fwd(h, b1, p, seed, o2_)
-        out, zh2, r2 = ln_fwd(x1, torch.mm(a, W2.t()), b2, g2, be2, p, seed, o3, keep)
-        if keep:
-            ctx.save_for_backward(x2, *sa, zh1, r1, x1, h, a, zh2, r2, Win, Wo, g1, W1, b1, W2, g2)
-            ctx.cfg = (B, S, H, p, p_attn, seed, o1, o2_, o3)
-        return out.view(B, S, D)
+        return _layer_forward(ctx, x, None, Win, bin_, dict(zip(_ENC_PARAMS, (Wo, bo, g1, be1, W1, b1, W2, b2, g2, be2))), H, p, p_attn)
 
     @staticmethod
     def backward(ctx, dout):
-        x2, qkv, ao, lse, ps, po, o2, zh1, r1, x1, h, a, zh2, r2, Win, Wo, g1, W1, b1, W2, g2 = ctx.saved_tensors
-        B, S, H, p, p_attn, seed, o1, o2_, o3 = ctx.cfg
-        D = x2.shape[1]
-        dx1, df, dg2, dbe2, db2 = ln_bwd(dout.reshape(B * S, D), zh2, r2, g2, p, seed, o3)
-        dW2 = torch.mm(df.t(), a)
-        dh, db1 = bias_gelu_drop_bwd(torch.mm(df, W2), h, b1, p, seed, o2_)
-        dW1 = torch.mm(dh.t(), x1)
-        dx, dy, dg1, dbe1, dbo = ln_bwd(dx1, zh1, r1, g1, p, seed, o1, dout2=torch.mm(dh, W1))   # (both branches of the residual stream)
-        dqkv, dWin, dbin, dWo = _self_attn_bwd(dy, x2, B, S, H, Win, Wo, p_attn, (qkv, ao, lse, ps, po, o2))
-        dx = torch.addmm(dx, dqkv, Win)
-        return dx.view(B, S, D), dWin, dbin, dWo, dbo, dg1, dbe1, dW1, db1, dW2, db2, dg2, dbe2, None, None, None
+        dx, _, dWin, dbin, g = _layer_backward(ctx, dout)
+        return (dx, dWin, dbin, *(g[n] for n in _ENC_PARAMS), None, None, None)
 
 
 class DecoderLayerFn(torch.autograd.Function):
@@ -192,54 +283,13 @@ class DecoderLayerFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, mem, Win, bin_, Wo, bo, g1, be1, Wv, bv, Wc, bc, g2, be2, W1, b1, W2, b2, g3, be3, H, p, p_attn):
-        B, S, D = x.shape
-        x2 = _c(x).view(B * S, D)
-        mem2 = _c(mem).view(B, D)
-        keep = any(ctx.needs_input_grad)          # (no-grad passes - the iteration's second encode - keep nothing)
-        seed, o1, o2_, o3, o4 = _seed(), next_offset(), next_offset(), next_offset(), next_offset()
-        y, sa = _self_attn_fwd(x2, B, S, H, Win, bin_, Wo, p_attn)
-        x1, zh1, r1 = ln_fwd(x2, y, bo, g1, be1, p, seed, o1, keep)
-        # cross-attention onto the one memory token: value projection, attention dropout on the probability 1 per (clip, query, head), out_proj
-        c = torch.addmm(bv, mem2, Wv.t())                                      # (B, D)
-        if p_attn > 0:
-            kp = torch.nn.functional.dropout(torch.ones(B, S, H, 1, device=x.device, dtype=x.dtype), p_attn, True)
-            vk = (kp * c.view(B, 1, H, D // H)).reshape(B * S, D)
-        else:
-            kp = None
-            vk = c[:, None, :].expand(B, S, D).reshape(B * S, D)
-        xm, zh2, r2 = ln_fwd(x1, torch.mm(vk, Wc.t()), bc, g2, be2, p, seed, o2_, keep)
-        h = torch.mm(xm, W1.t())
-        a = bias_gelu_drop_fwd(h, b1, p, seed, o3)
-        out, zh3, r3 = ln_fwd(xm, torch.mm(a, W2.t()), b2, g3, be3, p, seed, o4, keep)
-        if keep:
-            ctx.save_for_backward(x2, *sa, zh1, r1, mem2, vk, zh2, r2, xm, h, a, zh3, r3, Win, Wo, g1, Wv, Wc, g2, W1, b1, W2, g3,
-                                  *(() if kp is None else (kp,)))
-            ctx.cfg = (B, S, H, p, p_attn, seed, o1, o2_, o3, o4)
-        return out.view(B, S, D)
+        prm = dict(zip(_DEC_PARAMS, (Wo, bo, g1, be1, _c(Wv), _c(bv), Wc, bc, g2, be2, W1, b1, W2, b2, g3, be3)))
+        return _layer_forward(ctx, x, mem, Win, bin_, prm, H, p, p_attn)
 
     @staticmethod
     def backward(ctx, dout):
-        t = ctx.saved_tensors
-        x2, qkv, ao, lse, ps, po, o2, zh1, r1, mem2, vk, zh2, r2, xm, h, a, zh3, r3, Win, Wo, g1, Wv, Wc, g2, W1, b1, W2, g3 = t[:28]
-        kp = t[28] if len(t) > 28 else None
-        B, S, H, p, p_attn, seed, o1, o2_, o3, o4 = ctx.cfg
-        D = x2.shape[1]
-        dxm, df, dg3, dbe3, db2 = ln_bwd(dout.reshape(B * S, D), zh3, r3, g3, p, seed, o4)
-        dW2 = torch.mm(df.t(), a)
-        dh, db1 = bias_gelu_drop_bwd(torch.mm(df, W2), h, b1, p, seed, o3)
-        dW1 = torch.mm(dh.t(), xm)
-        dx1, dyc, dg2, dbe2, dbc = ln_bwd(dxm, zh2, r2, g2, p, seed, o2_, dout2=torch.mm(dh, W1))
-        dWc = torch.mm(dyc.t(), vk)
-        dvk = torch.mm(dyc, Wc)
-        dc = (dvk.view(B, S, H, D // H) * kp).sum(1).view(B, D) if kp is not None else dvk.view(B, S, D).sum(1)
-        dWv = torch.mm(dc.t(), mem2)
-        dbv = dc.sum(0)
-        dmem = torch.mm(dc, Wv)
-        dx, dy, dg1, dbe1, dbo = ln_bwd(dx1, zh1, r1, g1, p, seed, o1)
-        dqkv, dWin, dbin, dWo = _self_attn_bwd(dy, x2, B, S, H, Win, Wo, p_attn, (qkv, ao, lse, ps, po, o2))
-        dx = torch.addmm(dx, dqkv, Win)
-        return (dx.view(B, S, D), dmem.view(B, 1, D), dWin, dbin, dWo, dbo, dg1, dbe1, dWv, dbv, dWc, dbc, dg2, dbe2, dW1, db1, dW2, db2, dg3, dbe3,
-                None, None, None)
+        dx, dmem, dWin, dbin, g = _layer_backward(ctx, dout)
+        return (dx, dmem, dWin, dbin, *(g[n] for n in _DEC_PARAMS), None, None, None)
 
 
 # ---------------------------------------------------------------------------------------------------- module adapters (nn_modules.py)

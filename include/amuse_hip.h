@@ -356,6 +356,38 @@ int amuse_train_bias_gelu_drop_bwd(const float* da, const float* h, const float*
 /* out [C] = sum_rows x[r][:] (a bias gradient), C a multiple of 4 up to 1024 */
 int amuse_train_colsum(const float* x, long rows, int C, float* out, float* ws, void* stream);
 
+/* Layer-level entry points: a whole TransformerEncoderLayer / TransformerDecoderLayer (forward_post, memory of one token) but its self-attention
+ * core, forward and backward, in one call each - the kernels above plus the layer's plain GEMMs on rocBLAS (dlopen'ed on first use; AMUSE_ESTATE if it
+ * cannot be loaded).  The caller computes q | k | v = amuse_train_linear_fwd(x, in_proj), runs its attention on them (o2 = the heads' outputs
+ * concatenated), calls amuse_train_layer_fwd; on the way back amuse_train_layer_bwd returns d(o2) for the attention's backward pass, whose d(q | k | v)
+ * goes through amuse_train_linear_bwd(..., dx = L.dx, accumulate_dx = 1).  Linear weights in PyTorch's [out][in] layout, everything fp32 and dense. */
+typedef struct amuse_train_layer {
+    long rows; int B, S, H, ff;                 /* rows = B x S tokens of 128 features; H heads; ff = linear1's width (multiple of 4, <= 1024) */
+    float p, p_attn;                            /* dropout probabilities: the layer's nn.Dropout modules / the attention's (0 = eval mode) */
+    uint64_t seed, off[5];                      /* mask offsets: [0] behind the self-attention, [1] behind the cross-attention, [2] inside the FFN,
+                                                   [3] behind the FFN, [4] the cross-attention's probabilities */
+    const float *Wo, *bo, *g1, *be1;            /* self_attn.out_proj, norm1 */
+    const float *Wv, *bv, *Wc, *bc, *g2, *be2;  /* decoder layer: multihead_attn's value rows of in_proj, its out_proj, norm2 (NULL for an encoder layer) */
+    const float *W1, *b1, *W2, *b2, *g3, *be3;  /* linear1, linear2, the last norm (an encoder layer's norm2) */
+    const float *x, *o2, *mem;                  /* in: residual stream [rows][128], attention output [rows][128], memory [B][128] (NULL: encoder layer) */
+    float *x1, *zh1, *r1;                       /* kept for the backward pass: behind norm1 ([rows][128], normalised rows, [rows]) */
+    float *c, *vk, *xm, *zh2, *r2;              /* decoder: value projection [B][128], its masked copy [rows][128], behind norm2 */
+    float *h, *a;                               /* [rows][ff]: linear1's output, the FFN activation */
+    float *out, *zh3, *r3;                      /* the layer's output and the last norm's state */
+    float *tmp;                                 /* [rows][128] scratch */
+    const float* dout;                          /* backward in: d(out) */
+    float *dx, *do2, *dmem;                     /* backward out: d(x) WITHOUT the attention's share, d(o2), d(mem) [B][128] */
+    float *dWo, *dbo, *dg1, *dbe1, *dWv, *dbv, *dWc, *dbc, *dg2, *dbe2, *dW1, *db1, *dW2, *db2, *dg3, *dbe3;
+    float *s128a, *s128b, *s512a, *s512b, *sdc; /* backward scratch: 2 x [rows][128], 2 x [rows][ff], [B][128] */
+    float* ws;                                  /* amuse_train_ws_floats() floats */
+} amuse_train_layer;
+int amuse_train_layer_fwd(const amuse_train_layer* layer, void* stream);
+int amuse_train_layer_bwd(const amuse_train_layer* layer, void* stream);
+/* out [rows][N] = x [rows][K] W^T + b (b nullable);  dW [N][K] = dy^T x, db [N] = sum_rows dy, dx [rows][K] (+)= dy W (each output nullable) */
+int amuse_train_linear_fwd(const float* x, const float* W, const float* b, long rows, int K, int N, float* out, void* stream);
+int amuse_train_linear_bwd(const float* dy, const float* x, const float* W, long rows, int K, int N, float* dW, float* db, float* dx,
+                           int accumulate_dx, float* ws, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
