@@ -29,7 +29,7 @@ EXPORTS = [
     "amuse_create_arch", "amuse_denoiser_param_count", "amuse_arch", "amuse_state_dim", "amuse_denoise_step_pose", "amuse_feats_to_smplx",
     "amuse_debug_set_ablation",
     "amuse_train_ws_floats", "amuse_train_ln_fwd", "amuse_train_ln_bwd", "amuse_train_bias_gelu_drop_fwd", "amuse_train_bias_gelu_drop_bwd", "amuse_train_colsum",
-    "amuse_train_layer_fwd", "amuse_train_layer_bwd", "amuse_train_linear_fwd", "amuse_train_linear_bwd",
+    "amuse_train_layer_fwd", "amuse_train_layer_bwd", "amuse_train_linear_fwd", "amuse_train_linear_bwd", "amuse_train_adamw",
 ]
 
 
@@ -131,6 +131,8 @@ def load() -> C.CDLL:
     lib.amuse_train_bias_gelu_drop_fwd.argtypes = [vp, vp, C.c_float, u64, u64, C.c_long, C.c_int, vp, vp]
     lib.amuse_train_bias_gelu_drop_bwd.argtypes = [vp, vp, vp, C.c_float, u64, u64, C.c_long, C.c_int, vp, vp, vp, vp]
     lib.amuse_train_colsum.argtypes = [vp, C.c_long, C.c_int, vp, vp, vp]
+    lib.amuse_train_adamw.argtypes = [vp, vp, vp, vp, C.c_size_t, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, C.c_long, vp]
+    lib.amuse_train_adamw.restype = C.c_int
     lib.amuse_train_layer_fwd.argtypes = [C.POINTER(TrainLayer), vp]
     lib.amuse_train_layer_bwd.argtypes = [C.POINTER(TrainLayer), vp]
     lib.amuse_train_linear_fwd.argtypes = [vp, vp, vp, C.c_long, C.c_int, C.c_int, vp, vp]

@@ -153,6 +153,35 @@ __global__ __launch_bounds__(kTrainThreads) void k_train_finalize(const float* w
     float* outs[3] = {o0, o1, o2};
     sum_partials(ws, n, outs, ncol, C, red);
 }
+// several reductions' partial sums (each in its own region of the workspace) in ONE launch behind a layer's backward pass: workgroup = job
+struct FinJob {
+    const float* ws;
+    float* o[3];
+    int n, ncol, C;
+};
+struct FinJobs {
+    FinJob j[8];
+};
+__global__ __launch_bounds__(kTrainThreads) void k_train_finalize_jobs(FinJobs jobs) {
+    __shared__ f32x4 red[kTrainThreads];
+    const FinJob& J = jobs.j[blockIdx.x];
+    float* outs[3] = {J.o[0], J.o[1], J.o[2]};
+    sum_partials(J.ws, J.n, outs, J.ncol, J.C, red);
+}
+
+// ---- AdamW over a contiguous range of the trainer's flat parameter / gradient buffers (torch.optim.AdamW, amsgrad off: decoupled weight decay, then
+// p -= lr / (1 - b1^t) . m / (sqrt(v) / sqrt(1 - b2^t) + eps)); bc1 = 1 - b1^t and rbc2 = 1 / sqrt(1 - b2^t) come from the host
+__global__ __launch_bounds__(256) void k_train_adamw(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, size_t n,
+                                                     float step_size, float decay, float omb1, float b2, float omb2, float eps, float rbc2) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        const float gi = g[i];
+        const float mi = m[i] + (gi - m[i]) * omb1;
+        const float vi = b2 * v[i] + omb2 * gi * gi;
+        m[i] = mi;
+        v[i] = vi;
+        p[i] = p[i] * decay - step_size * (mi / (sqrtf(vi) * rbc2 + eps));
+    }
+}
 
 // ---- FFN activation: a = dropout(gelu(h + b)), exact erf (F.gelu's default)
 __device__ __forceinline__ float gelu_exact(float u) { return 0.5f * u * (1.0f + erff(u * 0.70710678118654752440f)); }
@@ -323,19 +352,23 @@ int ln_fwd_launch(const float* x, const float* y, const float* bias, const float
     hipLaunchKernelGGL(k_train_ln_fwd, dim3((unsigned)(g > 4096 ? 4096 : g)), dim3(256), 0, st, x, y, bias, gamma, beta, thr, scale, seed, off, rows, out, zhat, rstd);
     return 0;
 }
+// `job` given: the partial sums stay in `ws` (a region of their own) and the job is added up later by ONE k_train_finalize_jobs launch; else right away
 int ln_bwd_launch(const float* dout, const float* dout2, const float* zhat, const float* rstd, const float* gamma, uint32_t thr, float scale, uint64_t seed, uint64_t off,
-                  long rows, float* dx, float* dy, float* dgamma, float* dbeta, float* dbias, float* ws, hipStream_t st) {
+                  long rows, float* dx, float* dy, float* dgamma, float* dbeta, float* dbias, float* ws, hipStream_t st, FinJob* job = nullptr) {
     const int g = grid_for(rows, 64);
     hipLaunchKernelGGL(k_train_ln_bwd, dim3(g), dim3(kTrainThreads), 0, st, dout, dout2, zhat, rstd, gamma, thr, scale, seed, off, rows, dx, dy, ws);
-    hipLaunchKernelGGL(k_train_finalize, dim3(1), dim3(kTrainThreads), 0, st, ws, g, dgamma, dbeta, dbias, 384, 128);
+    if (job) *job = FinJob{ws, {dgamma, dbeta, dbias}, g, 384, 128};
+    else hipLaunchKernelGGL(k_train_finalize, dim3(1), dim3(kTrainThreads), 0, st, ws, g, dgamma, dbeta, dbias, 384, 128);
     return 0;
 }
-int colsum_launch(const float* x, long rows, int C, float* out, float* ws, hipStream_t st) {
+int colsum_launch(const float* x, long rows, int C, float* out, float* ws, hipStream_t st, FinJob* job = nullptr) {
     const int g = grid_for(rows, 2 * (kTrainThreads / (C / 4)));
     hipLaunchKernelGGL(k_train_colsum, dim3(g), dim3(kTrainThreads), 0, st, x, rows, C / 4, ws);
-    hipLaunchKernelGGL(k_train_finalize, dim3(1), dim3(kTrainThreads), 0, st, ws, g, out, (float*)nullptr, (float*)nullptr, C, C);
+    if (job) *job = FinJob{ws, {out, nullptr, nullptr}, g, C, C};
+    else hipLaunchKernelGGL(k_train_finalize, dim3(1), dim3(kTrainThreads), 0, st, ws, g, out, (float*)nullptr, (float*)nullptr, C, C);
     return 0;
 }
+constexpr size_t kWsRegion = (size_t)kTrainWgs * 1024;   // floats per reduction's partial sums
 int bias_rows_launch(const float* bias, long rows, int C, float* out, hipStream_t st) {
     const size_t n4 = (size_t)rows * (C / 4), g = (n4 + 255) / 256;
     hipLaunchKernelGGL(k_train_bias_rows, dim3((unsigned)(g > 8192 ? 8192 : g)), dim3(256), 0, st, bias, n4, C / 4, out);
@@ -349,7 +382,7 @@ using namespace amuse;
 
 extern "C" {
 
-size_t amuse_train_ws_floats(void) { return (size_t)kTrainWgs * 1024; }   // [workgroups][up to 1,024 columns]
+size_t amuse_train_ws_floats(void) { return 8 * kWsRegion; }   // 8 regions of [workgroups][up to 1,024 columns]: one per reduction of a layer's backward pass
 
 int amuse_train_ln_fwd(const float* x, const float* y, const float* bias, const float* gamma, const float* beta, float p, uint64_t seed, uint64_t offset,
                        long rows, float* out, float* zhat, float* rstd, void* stream) {
@@ -408,6 +441,19 @@ int amuse_train_colsum(const float* x, long rows, int C, float* out, float* ws, 
     const int g = grid_for(rows, 2 * (kTrainThreads / (C / 4)));
     hipLaunchKernelGGL(k_train_colsum, dim3(g), dim3(kTrainThreads), 0, (hipStream_t)stream, x, rows, C / 4, ws);
     hipLaunchKernelGGL(k_train_finalize, dim3(1), dim3(kTrainThreads), 0, (hipStream_t)stream, ws, g, out, (float*)nullptr, (float*)nullptr, C, C);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int amuse_train_adamw(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, size_t n, double lr, double beta1, double beta2, double eps,
+                      double weight_decay, long step, void* stream) {
+    if (!param || !grad || !exp_avg || !exp_avg_sq) return fail(AMUSE_EINVAL, "amuse_train_adamw: NULL argument");
+    if (n < 1 || step < 1) return fail(AMUSE_EINVAL, "n %zu, step %ld (1-based)", n, step);
+    // (the scalars in double on the host, as torch's Python optimizer computes them: 1 - 0.999 in fp32 is 4.7e-5 off)
+    const double bc1 = 1.0 - pow(beta1, (double)step), rbc2 = 1.0 / sqrt(1.0 - pow(beta2, (double)step));
+    const size_t g = (n + 255) / 256;
+    hipLaunchKernelGGL(k_train_adamw, dim3((unsigned)(g > 16384 ? 16384 : g)), dim3(256), 0, (hipStream_t)stream, param, grad, exp_avg, exp_avg_sq, n, (float)(lr / bc1),
+                       (float)(1.0 - lr * weight_decay), (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), (float)eps, (float)rbc2);
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -503,30 +549,41 @@ int amuse_train_layer_bwd(const amuse_train_layer* L, void* stream) {
     const long rows = L->rows;
     const int ff = L->ff;
     const float* src = L->mem ? L->xm : L->x1;
+    FinJobs jobs{};
+    int nj = 0;
     // FFN + last norm: s128a = d(src) through the norm, s128b = d(linear2 output)
-    ln_bwd_launch(L->dout, nullptr, L->zh3, L->r3, L->g3, thr, scale, L->seed, L->off[3], rows, L->s128a, L->s128b, L->dg3, L->dbe3, L->db2, L->ws, st);
+    ln_bwd_launch(L->dout, nullptr, L->zh3, L->r3, L->g3, thr, scale, L->seed, L->off[3], rows, L->s128a, L->s128b, L->dg3, L->dbe3, L->db2, L->ws + nj * kWsRegion, st, &jobs.j[nj]);
+    ++nj;
     TRY(rm_gemm(h, true, false, 128, ff, rows, L->s128b, L->a, L->dW2, false));
     TRY(rm_gemm(h, false, false, rows, ff, 128, L->s128b, L->W2, L->s512a, false));
     {
         const int g = grid_for(rows, 2 * (kTrainThreads / (ff / 4)));
-        hipLaunchKernelGGL(k_train_bgd_bwd, dim3(g), dim3(kTrainThreads), 0, st, L->s512a, L->h, L->b1, thr, scale, L->seed, L->off[2], rows, ff / 4, L->s512b, L->ws);
-        hipLaunchKernelGGL(k_train_finalize, dim3(1), dim3(kTrainThreads), 0, st, L->ws, g, L->db1, (float*)nullptr, (float*)nullptr, ff, ff);
+        float* wsj = L->ws + nj * kWsRegion;
+        hipLaunchKernelGGL(k_train_bgd_bwd, dim3(g), dim3(kTrainThreads), 0, st, L->s512a, L->h, L->b1, thr, scale, L->seed, L->off[2], rows, ff / 4, L->s512b, wsj);
+        jobs.j[nj++] = FinJob{wsj, {L->db1, nullptr, nullptr}, g, ff, ff};
     }
     TRY(rm_gemm(h, true, false, ff, 128, rows, L->s512b, src, L->dW1, false));
     TRY(rm_gemm(h, false, false, rows, 128, ff, L->s512b, L->W1, L->s128b, false));      // the FFN branch's gradient of src
     if (L->mem) {
         // cross-attention + norm2: s128a <- d(x1), s128b <- d(out_proj output)
-        ln_bwd_launch(L->s128a, L->s128b, L->zh2, L->r2, L->g2, thr, scale, L->seed, L->off[1], rows, L->s128a, L->s128b, L->dg2, L->dbe2, L->dbc, L->ws, st);
+        ln_bwd_launch(L->s128a, L->s128b, L->zh2, L->r2, L->g2, thr, scale, L->seed, L->off[1], rows, L->s128a, L->s128b, L->dg2, L->dbe2, L->dbc, L->ws + nj * kWsRegion, st,
+                      &jobs.j[nj]);
+        ++nj;
         TRY(rm_gemm(h, true, false, 128, 128, rows, L->s128b, L->vk, L->dWc, false));
         TRY(rm_gemm(h, false, false, rows, 128, 128, L->s128b, L->Wc, L->do2, false));     // d(vk), parked in do2
         hipLaunchKernelGGL(k_train_dc, dim3(L->B), dim3(256), 0, st, L->do2, thr_a, scale_a, L->seed, L->off[4], L->S, L->H, L->sdc);
         TRY(rm_gemm(h, true, false, 128, 128, L->B, L->sdc, L->mem, L->dWv, false));
-        colsum_launch(L->sdc, L->B, 128, L->dbv, L->ws, st);
+        colsum_launch(L->sdc, L->B, 128, L->dbv, L->ws + nj * kWsRegion, st, &jobs.j[nj]);
+        ++nj;
         TRY(rm_gemm(h, false, false, L->B, 128, 128, L->sdc, L->Wv, L->dmem, false));
-        ln_bwd_launch(L->s128a, nullptr, L->zh1, L->r1, L->g1, thr, scale, L->seed, L->off[0], rows, L->dx, L->s128b, L->dg1, L->dbe1, L->dbo, L->ws, st);
+        ln_bwd_launch(L->s128a, nullptr, L->zh1, L->r1, L->g1, thr, scale, L->seed, L->off[0], rows, L->dx, L->s128b, L->dg1, L->dbe1, L->dbo, L->ws + nj * kWsRegion, st,
+                      &jobs.j[nj]);
     } else {
-        ln_bwd_launch(L->s128a, L->s128b, L->zh1, L->r1, L->g1, thr, scale, L->seed, L->off[0], rows, L->dx, L->s128b, L->dg1, L->dbe1, L->dbo, L->ws, st);
+        ln_bwd_launch(L->s128a, L->s128b, L->zh1, L->r1, L->g1, thr, scale, L->seed, L->off[0], rows, L->dx, L->s128b, L->dg1, L->dbe1, L->dbo, L->ws + nj * kWsRegion, st,
+                      &jobs.j[nj]);
     }
+    ++nj;
+    hipLaunchKernelGGL(k_train_finalize_jobs, dim3(nj), dim3(kTrainThreads), 0, st, jobs);   // every column sum of the layer
     // self-attention's out_proj
     TRY(rm_gemm(h, true, false, 128, 128, rows, L->s128b, L->o2, L->dWo, false));
     TRY(rm_gemm(h, false, false, rows, 128, 128, L->s128b, L->Wo, L->do2, false));

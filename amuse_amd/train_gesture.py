@@ -230,8 +230,19 @@ class GestureTrainer:
         unused |= {id(p) for n, p in ldm.denoiser.named_parameters() if n.split(".")[0] in dropped}
         # the multi-tensor ("fused") AdamW of torch on the GPU: the same update in a handful of launches instead of ~10 per
         # parameter group of the default foreach path (2.7 ms of device time and 4.8 ms of host time per iteration, section 4.6)
-        fused = self.device.type == "cuda" and os.environ.get("AMUSE_TRAIN_OPT", "fused") == "fused"
-        self.lpdm_opt = torch.optim.AdamW(lr=lr, params=[p for p in self.params if id(p) not in unused], **({"fused": True} if fused else {}))
+        # ... and on the GPU that update is ONE launch per contiguous run of optimizer parameters in the flat buffers (train_ops.FlatAdamW, csrc/k_train.hip);
+        # AMUSE_TRAIN_OPT=fused / foreach select torch's own implementations (A/B)
+        opt_kind = os.environ.get("AMUSE_TRAIN_OPT", "flat") if self.device.type == "cuda" else "foreach"
+        opt_params = [p for p in self.params if id(p) not in unused]
+        if opt_kind == "flat":
+            from .train_ops import FlatAdamW
+            layout, off = [], 0
+            for p in self.params:
+                layout.append((p, off, p.numel()))
+                off += p.numel()
+            self.lpdm_opt = FlatAdamW(opt_params, self.flat_param, self.flat_grad, layout, lr=lr)
+        else:
+            self.lpdm_opt = torch.optim.AdamW(lr=lr, params=opt_params, **({"fused": True} if opt_kind == "fused" else {}))
         self.steal = os.environ.get("AMUSE_TRAIN_GRADS", "steal") == "steal"
         # the step's ~500 fp32 GEMMs are small (9,664 x 128..512 rows, weight gradients with a 9,664-long reduction): rocBLAS's
         # choices run them in 9 ms of device time per iteration where hipBLASLt's heuristics take 12.5, at a third of the host

@@ -356,6 +356,10 @@ int amuse_train_bias_gelu_drop_bwd(const float* da, const float* h, const float*
 /* out [C] = sum_rows x[r][:] (a bias gradient), C a multiple of 4 up to 1024 */
 int amuse_train_colsum(const float* x, long rows, int C, float* out, float* ws, void* stream);
 
+/* torch.optim.AdamW (amsgrad off) over a contiguous range of flat fp32 buffers, `step` = this update's 1-based count (trainer.py:181-184: the reference's
+ * optimizer over prior + ldm parameters; amuse_amd/train_gesture.py keeps parameters, gradients and both moments in one buffer each) */
+int amuse_train_adamw(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, size_t n, double lr, double beta1, double beta2, double eps,
+                      double weight_decay, long step, void* stream);
 /* Layer-level entry points: a whole TransformerEncoderLayer / TransformerDecoderLayer (forward_post, memory of one token) but its self-attention
  * core, forward and backward, in one call each - the kernels above plus the layer's plain GEMMs on rocBLAS (dlopen'ed on first use; AMUSE_ESTATE if it
  * cannot be loaded).  The caller computes q | k | v = amuse_train_linear_fwd(x, in_proj), runs its attention on them (o2 = the heads' outputs

@@ -174,3 +174,44 @@ def test_trainer_step_on_fused_layers_matches_the_eager_step_without_dropout(eag
         res[on] = (float(loss), tr.flat_grad.clone())
     assert abs(res[True][0] - res[False][0]) < 1e-5 * max(1.0, abs(res[False][0]))
     assert _rel(res[True][1], res[False][1]) < 2e-4
+
+
+def test_flat_adamw_equals_torch_adamw_and_keeps_its_state_layout():
+    """train_ops.FlatAdamW (one launch per contiguous run of the flat buffers) against torch.optim.AdamW on the same parameters and gradients, five
+    steps; a parameter outside the optimizer (the trainer's never-reached mem_pos.pe) is not touched; state_dict() has torch's structure."""
+    from amuse_amd.train_ops import FlatAdamW
+    g = torch.Generator(device=DEV).manual_seed(0)
+    shapes = [(128, 128), (128,), (500, 1, 128), (384, 128), (7,)]
+    n = sum(int(np.prod(s)) for s in shapes)
+    flat_p, flat_g = torch.randn(n, device=DEV, generator=g), torch.zeros(n, device=DEV)
+    params, layout, off = [], [], 0
+    for s in shapes:
+        k = int(np.prod(s))
+        p = torch.nn.Parameter(flat_p[off:off + k].view(s))
+        p.grad = flat_g[off:off + k].view(s)
+        params.append(p)
+        layout.append((p, off, k))
+        off += k
+    skip = params[2]
+    ref_p = [p.detach().clone().requires_grad_(True) for p in params]
+    ref = torch.optim.AdamW([p for p, q in zip(ref_p, params) if q is not skip], lr=3e-3)
+    opt = FlatAdamW([p for p in params if p is not skip], flat_p, flat_g, layout, lr=3e-3)
+    assert len(opt._ranges) == 2
+    before = skip.detach().clone()
+    for it in range(5):
+        flat_g.copy_(torch.randn(n, device=DEV, generator=g))
+        for p, q in zip(ref_p, params):
+            p.grad = q.grad.clone()
+        opt.step()
+        ref.step()
+    for p, q in zip(ref_p, params):
+        if q is skip:
+            assert torch.equal(q.detach(), before)
+        else:
+            assert _rel(q.detach(), p.detach()) < 2e-6
+    sd, rsd = opt.state_dict(), ref.state_dict()
+    assert sd["param_groups"][0]["params"] == rsd["param_groups"][0]["params"] and set(sd["state"]) == set(rsd["state"])
+    for k in sd["state"]:
+        assert float(sd["state"][k]["step"]) == 5.0 and _rel(sd["state"][k]["exp_avg"], rsd["state"][k]["exp_avg"]) < 2e-6
+        assert _rel(sd["state"][k]["exp_avg_sq"], rsd["state"][k]["exp_avg_sq"]) < 2e-6
+
