@@ -8,7 +8,9 @@ export TMPDIR=/tmp
 rm -rf $O && mkdir -p $O
 timeout 1500 python -m pytest tests -q -m gpu 2>&1 | tail -3 > $O/pytest.txt
 timeout 600 python bench.py > $O/bench.json 2> $O/bench.err; tail -2 $O/bench.err
-timeout 300 python bench.py --config train --steps 40 --warmup 10 > $O/train_bench.json 2> $O/train_bench.err
+timeout 300 python bench.py --config train --steps 60 --warmup 15 > $O/train_bench.json 2> $O/train_bench.err
+AMUSE_TRAIN_FUSED=0 timeout 300 python bench.py --config train --steps 60 --warmup 15 > $O/train_bench_eager.json 2> $O/train_bench_eager.err
+timeout 300 python tools/gpu_train_profile.py 32 $O/train_profile.txt > /dev/null 2>&1
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python3 bench.py --steps 3 --warmup 1 --no-extras > $O/stats.log 2>&1
 for grp in FETCH_SIZE WRITE_SIZE "TCC_HIT_sum TCC_MISS_sum" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_ANY" "SQ_INSTS_MFMA SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_INSTS_SALU"; do
   n=$(echo $grp | cut -d' ' -f1)
@@ -37,6 +39,7 @@ for grp in FETCH_SIZE WRITE_SIZE "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUS
   timeout 300 rocprofv3 --pmc $grp --kernel-trace --output-format csv -d $O/npmc_$n -- python3 tools/gpu_den_once.py 256 bf16 4 > $O/npmc_$n.log 2>&1
 done
 timeout 400 python tools/gpu_den_perf.py 64 256 > $O/den_perf.txt 2>&1
+timeout 300 python tools/gpu_dec_perf.py > $O/dec_perf.txt 2>&1
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/audio_stats -- python3 tools/gpu_audio_perf.py 32 > $O/audio_stats.log 2>&1
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/audio_one_stats -- python3 tools/gpu_audio_one_encoder.py 32 > $O/audio_one_stats.log 2>&1
 for grp in FETCH_SIZE WRITE_SIZE "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_ANY" "SQ_INSTS_MFMA SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE"; do
