@@ -137,7 +137,7 @@ class SkipStack(nn.Module):
             xs.append(x)
         x = self.middle_block(x, *args, **kw)
         for m, lin in zip(self.output_blocks, self.linear_blocks):
-            x = lin(torch.cat([x, xs.pop()], dim=-1))
+            x = train_ops.linear(lin, torch.cat([x, xs.pop()], dim=-1))
             x = m(x, *args, **kw)
         return self.norm(x)
 
@@ -228,7 +228,7 @@ class MotionPrior(nn.Module):
         if lengths is None:
             lengths = [features.shape[1]] * features.shape[0]
         bs, nframes, _ = features.shape
-        x = self.skel_embedding(features)                                  # (B, T, 128)
+        x = train_ops.linear(self.skel_embedding, features)                # (B, T, 128)
         dist = self.global_motion_token[None].expand(bs, -1, -1)           # (B, 2, 128)
         xseq = self.query_pos_encoder(torch.cat([dist, x], 1))
         kpm = None

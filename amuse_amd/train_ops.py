@@ -292,6 +292,44 @@ class DecoderLayerFn(torch.autograd.Function):
         return (dx, dmem, dWin, dbin, *(g[n] for n in _DEC_PARAMS), None, None, None)
 
 
+class LinearFn(torch.autograd.Function):
+    """nn.Linear on the library's two entry points (amuse_train_linear_fwd / _bwd: rocBLAS from C++, the bias as the GEMM's C operand, the bias gradient
+    by the deterministic column sum) - the skip linears, embeddings and output layer around the transformer layers."""
+
+    @staticmethod
+    def forward(ctx, x, W, b):
+        N, K = W.shape
+        x2 = _c(x).view(-1, K)
+        rows = x2.shape[0]
+        out = torch.empty(rows, N, device=x.device, dtype=torch.float32)
+        _lib.check(_st(x.device)["lib"].amuse_train_linear_fwd(x2.data_ptr(), W.data_ptr(), _p(b), rows, K, N, out.data_ptr(), _stream()))
+        ctx.save_for_backward(x2, W)
+        ctx.has_bias = b is not None
+        return out.view(*x.shape[:-1], N)
+
+    @staticmethod
+    def backward(ctx, dout):
+        x2, W = ctx.saved_tensors
+        N, K = W.shape
+        st = _st(x2.device)
+        dy = _c(dout).view(-1, N)
+        rows = dy.shape[0]
+        need_x, need_w, need_b = ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.has_bias and ctx.needs_input_grad[2]
+        dx = torch.empty(rows, K, device=dy.device, dtype=torch.float32) if need_x else None
+        dW = torch.empty_like(W) if need_w else None
+        db = torch.empty(N, device=dy.device, dtype=torch.float32) if need_b else None
+        _lib.check(st["lib"].amuse_train_linear_bwd(dy.data_ptr(), x2.data_ptr(), W.data_ptr(), rows, K, N, _p(dW), _p(db), _p(dx), 0, st["ws"].data_ptr(), _stream()))
+        return (None if dx is None else dx.view(*dout.shape[:-1], K)), dW, db
+
+
+def linear(m, x: torch.Tensor) -> torch.Tensor:
+    """nn.Linear `m` on x: the library path for CUDA fp32 inputs whose widths it takes (N a multiple of 4 up to 1024), else F.linear."""
+    N = m.weight.shape[0]
+    if enabled() and x.is_cuda and x.dtype == torch.float32 and N % 4 == 0 and N <= 1024 and m.weight.is_contiguous():
+        return LinearFn.apply(x, m.weight, m.bias)
+    return torch.nn.functional.linear(x, m.weight, m.bias)
+
+
 # ---------------------------------------------------------------------------------------------------- module adapters (nn_modules.py)
 def encoder_layer(m, x: torch.Tensor) -> torch.Tensor:
     a = m.self_attn

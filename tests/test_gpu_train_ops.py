@@ -215,3 +215,21 @@ def test_flat_adamw_equals_torch_adamw_and_keeps_its_state_layout():
         assert float(sd["state"][k]["step"]) == 5.0 and _rel(sd["state"][k]["exp_avg"], rsd["state"][k]["exp_avg"]) < 2e-6
         assert _rel(sd["state"][k]["exp_avg_sq"], rsd["state"][k]["exp_avg_sq"]) < 2e-6
 
+
+@pytest.mark.parametrize("rows,K,N", [(9664, 333, 128), (9600, 256, 128), (32, 256, 128), (5, 128, 384)])
+def test_linear_fn_equals_f_linear(rows, K, N):
+    from amuse_amd import train_ops as T
+    g = torch.Generator(device=DEV).manual_seed(rows)
+    m = torch.nn.Linear(K, N).to(DEV)
+    x = torch.randn(2, rows // 2 if rows % 2 == 0 else rows, K, device=DEV, generator=g) if rows % 2 == 0 else torch.randn(rows, K, device=DEV, generator=g)
+    dout = torch.randn(*x.shape[:-1], N, device=DEV, generator=g)
+    res = []
+    for fn in (lambda t: torch.nn.functional.linear(t, m.weight, m.bias), lambda t: T.linear(m, t)):
+        xr = x.clone().requires_grad_(True)
+        m.zero_grad(set_to_none=True)
+        out = fn(xr)
+        out.backward(dout)
+        res.append((out.detach(), xr.grad, m.weight.grad.clone(), m.bias.grad.clone()))
+    for a, b in zip(res[1], res[0]):
+        assert a.shape == b.shape and _rel(a, b) < 2e-5
+
