@@ -243,9 +243,8 @@ int build_prior(amuse_ctx* c, const float* pri, int what = AMUSE_UPD_ALL) {
             for (int ch = 0; ch < 15; ++ch) { f1(ch + 1); f2(ch); }
             f2(15); pad(8);
         }
-        for (int j = 0; j < 5; ++j)   // final_layer once per row tile of a wave (24 output tiles in two halves of 3 stages)
-            for (int half = 0; half < 2; ++half)
-                pack_gemm(s, p16, Pp.get("final_layer.weight"), kFeats, 128, range(12 * half, 12 * half + 12), range(0, 8));
+        for (int half = 0; half < 2; ++half)   // final_layer ONCE: 24 output tiles in two halves of 48 units (k-pair outer) - the kernel's last stage holds it in LDS whole
+            pack_gemm(s, p16, Pp.get("final_layer.weight"), kFeats, 128, range(12 * half, 12 * half + 12), range(0, 8));
         if (s.size() % ((size_t)kVaeFusedStageUnits * 64) != 0) return fail(AMUSE_ESTATE, "internal: fused decode stream is not whole stages");
         pad(2 * kVaeFusedStageUnits);   // the fetch runs two stages ahead
         if (upload(p16 == PREC_BF16 ? &c->vae_wf : &c->vae_wfh, s.data(), s.size() * sizeof(uint4))) return AMUSE_EHIP;

@@ -53,7 +53,13 @@ constexpr int kOffW = kOffKv + kKvBytes;                   // weight ring
 constexpr int kOffPv = kOffW + kWBufs * kStageBytes;       // 2 x block parameters
 constexpr int kOffCa = kOffPv + 2 * kPvSlot;               // cross-attention constants of the clip
 static_assert(kOffCa + kCaBytes == kVaeFusedLdsBytes, "LDS layout and amuse_kernels.hpp disagree");
-static_assert((kWaves / 2) * 16 * kQStride * 4 <= kKvBytes, "staging tiles (one per SIMD) must fit the K/V images");
+// LDS map of the LAST stage (final_layer / pose_proj; the blocks' map above is dead by then): the projection's whole image (96 units) | one staging
+// tile per wave | its bias + the last norm's parameters.  The kernels are launched with this (larger) size.
+constexpr int kOffFinalW = 0;
+constexpr int kOffFinalStage = 96 * 1024;
+constexpr int kOffFinalPar = kOffFinalStage + kWaves * 16 * kQStride * 4;
+constexpr int kFusedFinalLdsBytes = kOffFinalPar + (384 + 2 * kD) * 4;   // 152,064 B
+static_assert(kFusedFinalLdsBytes >= kVaeFusedLdsBytes && kFusedFinalLdsBytes <= 160 * 1024, "LDS");
 
 // ablation switches for timing experiments (tools/build_variant.sh): 2 no attention, 4 no FFN arithmetic,
 // 8 no softmax arithmetic (scores fed to PV as they are).  0 in the product.

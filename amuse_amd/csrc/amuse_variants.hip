@@ -299,9 +299,8 @@ int variant_build(amuse_ctx* c, const float* den, int what) {
                     for (int ch = 0; ch < 15; ++ch) { f1(ch + 1); f2(ch); }
                     f2(15); pad(8);
                 }
-                for (int j = 0; j < 5; ++j)   // pose_proj once per row tile of a wave (24 output tiles in two halves of 3 stages)
-                    for (int half = 0; half < 2; ++half)
-                        pack_gemm(s, p16, D.get("pose_proj.weight"), kFeats, 128, range(12 * half, 12 * half + 12), range(0, 8));
+                for (int half = 0; half < 2; ++half)   // pose_proj ONCE (24 output tiles in two halves of 48 units): the kernel's last stage holds it in LDS whole
+                    pack_gemm(s, p16, D.get("pose_proj.weight"), kFeats, 128, range(12 * half, 12 * half + 12), range(0, 8));
                 if (s.size() % ((size_t)kVaeFusedStageUnits * 64) != 0) return fail(AMUSE_ESTATE, "internal: fused denoiser stream is not whole stages");
                 pad(2 * kVaeFusedStageUnits);   // the fetch runs two stages ahead
                 if (upload(&v->fused_w[p16 == PREC_F16], s.data(), s.size() * sizeof(uint4))) return AMUSE_EHIP;

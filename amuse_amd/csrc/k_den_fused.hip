@@ -110,10 +110,21 @@ __device__ __forceinline__ void den_tiles(const DenFusedArgs& a, char* smem, Sta
         decoder_block<NT, 2, false, true, NOATTN>(x, sg, a.pvec, nullptr, blk, tile0, pvl + (blk & 1) * (kPvSlot / 4),
                                           blk + 1 < kLayers ? a.pvec + (blk + 1) * PV_BLOCK : nullptr,
                                           lds0 + kOffPv + ((blk + 1) & 1) * kPvSlot, nocal, kv, skipbuf, S, wave, lane, S);
-    // ---------------- encoder.norm -> pose_proj (333 outputs in 24 tiles) -> mask -> eps_hat / scheduler update.  As in the decode
-    // kernel the stream holds the projection once per tile slot of a SIMD; a wave consumes its own slots and passes the others.
-    float* fst = reinterpret_cast<float*>(smem + kOffKv) + (wave & 3) * 16 * kQStride;
-    constexpr int kSlot0 = NT == 3 ? 0 : 3;
+    // ---------------- encoder.norm -> pose_proj (333 outputs in 24 tiles) -> mask -> eps_hat / scheduler update.  As in the decode kernel
+    // (k_vae_fused.hip) the last stage leaves the stage protocol: the whole pose_proj image goes to LDS once, and no wave waits on vmcnt again but for
+    // the x_t (and noise) values of the scheduler update - loaded a quarter tile at a time IN FRONT of that quarter's stores (a load behind a store sits
+    // out the store's round trip: stores count in vmcnt on gfx950).
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    {
+        const uint4* fsrc = sg.src - (size_t)(2 * kStage + 2 * wave) * 64 + (size_t)wave * 12 * 64;
+#pragma unroll
+        for (int i = 0; i < 12; ++i) glds16(fsrc + i * 64, lds0 + kOffFinalW + (wave * 12 + i) * 1024);
+        float* lpar = reinterpret_cast<float*>(smem + kOffFinalPar);
+        const int t = wave * 64 + lane;
+        if (t < 96) st4(lpar + 4 * t, ld4(a.final_bias + 4 * t));
+        else if (t < 160) st4(lpar + 4 * t, ld4(a.pvec + PV_FINAL_W + 4 * (t - 96)));
+        static_assert(PV_FINAL_B == PV_FINAL_W + kD, "the last norm's parameters are read as one run");
+    }
     const int len = a.lengths ? a.lengths[b] : kFrames;
     const float* cf = a.coef;
     const float sb = cf ? cf[0] : 0.f, sa = cf ? cf[1] : 1.f, c0 = cf ? cf[2] : 0.f, cx = cf ? cf[3] : 0.f, ce = cf ? cf[4] : 0.f,
@@ -121,67 +132,79 @@ __device__ __forceinline__ void den_tiles(const DenFusedArgs& a, char* smem, Sta
     const float inv_sa = 1.0f / sa;
     const float* nz = a.step_noise ? a.step_noise + (size_t)b * kFrames * kFeats : nullptr;
     float* eo = a.eps_out ? a.eps_out + (size_t)b * kFrames * kFeats : nullptr;
+    asm volatile("" ::"v"(len), "v"(sb), "v"(sa), "v"(c0), "v"(cx), "v"(ce), "v"(sgm), "v"(clipv));   // (consumed here: nothing stays pending across the stores)
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    const float* lbias = reinterpret_cast<const float*>(smem + kOffFinalPar);
+    const float* lnorm = lbias + 384;
+    const char* wimg = smem + kOffFinalW + lane * 16;
+    float* fst = reinterpret_cast<float*>(smem + kOffFinalStage) + wave * 16 * kQStride;
 #pragma unroll 1
-    for (int slot = 0; slot < 5; ++slot) {
-        if (slot < kSlot0 || slot >= kSlot0 + NT) {   // another wave's slot: keep the stage ring turning
-#pragma unroll 1
-            for (int s6 = 0; s6 < 6; ++s6) {
-                stage_fetch(sg);
-                stage_end(sg);
-            }
+    for (int j = 0; j < NT; ++j) {
+        const int tile = tile0 + 4 * j;
+        const int rows_here = min(16, S - 16 * tile);              // <= 0 for a tile beyond the sequence
+        if (rows_here <= 0) {
+            rotate_tiles<NT>(x);
             continue;
         }
-        const int j = slot - kSlot0;
-        layer_norm_rows<true>(x[0], a.pvec + PV_FINAL_W, a.pvec + PV_FINAL_B, g);
+        layer_norm_rows<true>(x[0], lnorm, lnorm + kD, g);
         OPV xb1[4];
 #pragma unroll
         for (int c = 0; c < 4; ++c) xb1[c] = OP_PACK(x[0][2 * c], x[0][2 * c + 1]);
         rotate_tiles<NT>(x);
-        const int tile = tile0 + 4 * j;
         const int fr_lane = 16 * tile + r - npre;                  // this lane's frame (row r of the tile)
         const bool keep = fr_lane >= 0 && fr_lane < len;           // sample[~mask.T] = 0 (denoiser.py:187)
-        const int rows_here = min(16, S - 16 * tile);              // <= 0 for a tile beyond the sequence
 #pragma unroll 1
-        for (int half = 0; half < 2; ++half) {   // 12 output tiles = 48 units = 3 stages (k-pair outer, output tile inner)
+        for (int half = 0; half < 2; ++half) {   // 12 output tiles x 4 k-pairs = 48 units (k-pair outer, output tile inner)
             f32x4 f[12];
 #pragma unroll
-            for (int o = 0; o < 12; ++o) f[o] = ld4(a.final_bias + 16 * (12 * half + o) + 4 * g);
+            for (int o = 0; o < 12; ++o) f[o] = ld4(lbias + 16 * (12 * half + o) + 4 * g);
 #pragma unroll
-            for (int s3 = 0; s3 < 3; ++s3) {
-                stage_fetch(sg);
-                for_units<kStage, 0>(sg, [&](int u, OPV wf) {
-                    const int lin = kStage * s3 + u, c = lin / 12, o = lin - 12 * c;
-                    f[o] = OP_MFMA(wf, xb1[c], f[o]);
-                });
-                stage_end(sg);
-            }
+            for (int c = 0; c < 4; ++c)
 #pragma unroll
+                for (int o = 0; o < 12; ++o)
+                    f[o] = OP_MFMA(__builtin_bit_cast(OPV, *reinterpret_cast<const uint4*>(wimg + ((half * 4 + c) * 12 + o) * 1024)), xb1[c], f[o]);
+#pragma unroll 1
             for (int qq = 0; qq < 2; ++qq) {
                 const int quarter = 2 * half + qq;
-#pragma unroll
-                for (int o = 0; o < 6; ++o) st4(fst + r * kQStride + 16 * o + 4 * g, keep ? f[6 * qq + o] : splat4(0.f));
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the staging tile is wave-private: no barrier
                 const int f0 = 96 * quarter, nfe = quarter == 3 ? kFeats - 288 : 96;
-                for (int i = lane; i < rows_here * nfe; i += 64) {
-                    const int rr = i / nfe, c = i - rr * nfe;
-                    const int fr = 16 * tile + rr - npre;
-                    if (fr < 0) continue;                        // a condition-token row: its output is dropped (denoiser.py:184)
-                    const float e = fst[rr * kQStride + c];
-                    const size_t el = (size_t)fr * kFeats + f0 + c;
-                    if (eo) eo[el] = e;
-                    if (cf) {   // scheduler.step, the 16-bit modes' form of k_sampler.hip's update (reciprocal multiply)
-#pragma clang fp contract(off)
-                        const float xl = xst[el];
-                        float x0 = (xl - sb * e) * inv_sa;
-                        if (clipv > 0.f) x0 = fminf(fmaxf(x0, -clipv), clipv);
-                        float nx = c0 * x0;
-                        if (cx != 0.f) nx = nx + cx * xl;
-                        if (ce != 0.f) nx = nx + ce * e;
-                        if (sgm != 0.f) {
-                            const float z = nz ? nz[el] : counter_normal4(a.seed, a.clip0 + (uint64_t)b, (uint32_t)a.step, (uint32_t)(el >> 2), 1u)[el & 3];
-                            nx = nx + sgm * z;
+                const int n = rows_here * nfe;
+#pragma unroll
+                for (int o = 0; o < 6; ++o) st4(fst + r * kQStride + 16 * o + 4 * g, keep ? (qq == 0 ? f[o] : f[6 + o]) : splat4(0.f));
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the staging tile is wave-private: no barrier
+                // x_t of a batch of kPer elements per lane first (all in flight together), then their updates and stores
+                constexpr int kPer = 8;
+#pragma unroll 1
+                for (int k0 = 0; k0 < 16 * 96 / 64; k0 += kPer) {
+                    float xv[kPer];
+                    if (cf) {
+#pragma unroll
+                        for (int k = 0; k < kPer; ++k) {
+                            const int i = lane + 64 * (k0 + k), rr = i / nfe, c = i - rr * nfe, fr = 16 * tile + rr - npre;
+                            const bool ok = i < n && fr >= 0;
+                            xv[k] = ok ? xst[(size_t)fr * kFeats + f0 + c] : 0.f;
                         }
-                        xst[el] = nx;
+                    }
+#pragma unroll
+                    for (int k = 0; k < kPer; ++k) {
+                        const int i = lane + 64 * (k0 + k), rr = i / nfe, c = i - rr * nfe, fr = 16 * tile + rr - npre;
+                        if (i >= n || fr < 0) continue;              // (fr < 0: a condition-token row - its output is dropped, denoiser.py:184)
+                        const float e = fst[rr * kQStride + c];
+                        const size_t el = (size_t)fr * kFeats + f0 + c;
+                        if (eo) eo[el] = e;
+                        if (cf) {   // scheduler.step, the 16-bit modes' form of k_sampler.hip's update (reciprocal multiply)
+#pragma clang fp contract(off)
+                            const float xl = xv[k];
+                            float x0 = (xl - sb * e) * inv_sa;
+                            if (clipv > 0.f) x0 = fminf(fmaxf(x0, -clipv), clipv);
+                            float nx = c0 * x0;
+                            if (cx != 0.f) nx = nx + cx * xl;
+                            if (ce != 0.f) nx = nx + ce * e;
+                            if (sgm != 0.f) {   // (explicit noise - tests - is read in place: that path pays a round trip per element)
+                                const float z = nz ? nz[el] : counter_normal4(a.seed, a.clip0 + (uint64_t)b, (uint32_t)a.step, (uint32_t)(el >> 2), 1u)[el & 3];
+                                nx = nx + sgm * z;
+                            }
+                            xst[el] = nx;
+                        }
                     }
                 }
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -217,13 +240,13 @@ hipError_t OP_LAUNCH(const DenFusedArgs& a, hipStream_t stream) {
     int dev_;
     if (!once.done(&dev_)) {
         for (const void* k : {reinterpret_cast<const void*>(&OP_KERNEL<false>), reinterpret_cast<const void*>(&OP_KERNEL<true>)}) {
-            hipError_t e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, kVaeFusedLdsBytes);
+            hipError_t e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, kFusedFinalLdsBytes);
             if (e != hipSuccess) return e;
         }
         once.set(dev_);
     }
-    if (a.ablate_attention) hipLaunchKernelGGL(OP_KERNEL<true>, dim3(a.B), dim3(512), kVaeFusedLdsBytes, stream, a);   // timing ablation (bench.py)
-    else hipLaunchKernelGGL(OP_KERNEL<false>, dim3(a.B), dim3(512), kVaeFusedLdsBytes, stream, a);
+    if (a.ablate_attention) hipLaunchKernelGGL(OP_KERNEL<true>, dim3(a.B), dim3(512), kFusedFinalLdsBytes, stream, a);   // timing ablation (bench.py)
+    else hipLaunchKernelGGL(OP_KERNEL<false>, dim3(a.B), dim3(512), kFusedFinalLdsBytes, stream, a);
     return hipGetLastError();
 }
 

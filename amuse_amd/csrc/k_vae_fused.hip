@@ -78,27 +78,39 @@ __device__ __forceinline__ void decode_tiles(const VaeFusedArgs& a, char* smem, 
         decoder_block<NT, 2, TAP, false, NOATTN>(x, sg, a.pvec, a.tap_out, blk, tile0, pvl + (blk & 1) * (kPvSlot / 4),
                              blk + 1 < kLayers ? a.pvec + (blk + 1) * PV_BLOCK : nullptr,
                              lds0 + kOffPv + ((blk + 1) & 1) * kPvSlot, cal, kv, skipbuf, len, wave, lane);
-    // ---------------- decoder.norm -> final_layer (333 outputs in 24 tiles) -> rotation epilogue.  The stream holds the
-    // final layer five times (once per tile slot of a SIMD): a 3-tile wave consumes slots 0..2 and only passes the stages of
-    // slots 3, 4; a 2-tile wave passes slots 0..2 and consumes 3, 4 - the stage protocol stays in step for all eight waves.
-    // One tile: four quarters of 6 output tiles (96 features = 16 joints; the last one 7 joints + translation), each staged
-    // in a wave-private LDS tile (the K/V images are free: the last barrier of block 8 is behind every wave's last read).
-    float* fst = reinterpret_cast<float*>(smem + kOffKv) + (wave & 3) * 16 * kQStride;   // (waves w and w + 4 are never in a consumed slot at once)
-    constexpr int kSlot0 = NT == 3 ? 0 : 3;
+    // ---------------- decoder.norm -> final_layer (333 outputs in 24 tiles) -> rotation epilogue.
+    // The last stage leaves the stage protocol: the WHOLE final_layer image (96 units, once in the stream) goes to LDS in one go - everything of the
+    // nine blocks is dead by now: K/V images, ring, parameter slots - together with its bias and decoder.norm's parameters, and from there on no wave
+    // touches vmcnt or a barrier again: a tile's 96 MFMAs, its staging tile (wave-private) and its output stores run free.  (On gfx950 stores count in
+    // vmcnt like loads: with the layer streamed through the ring - five copies, 30 stages - every stage end and every bias load sat out the round trip of
+    // the output stores in front of it: 12-14 % of the launch, profiles/r04_decode_output_store_ablation.txt.)
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");   // the ring's two stages ahead have landed; block 8's last LDS reads are done
+    {
+        const uint4* fsrc = sg.src - (size_t)(2 * kStage + 2 * wave) * 64 + (size_t)wave * 12 * 64;   // (sg.src: this wave's pieces of the stage after next)
+#pragma unroll
+        for (int i = 0; i < 12; ++i) glds16(fsrc + i * 64, lds0 + kOffFinalW + (wave * 12 + i) * 1024);
+        float* lpar = reinterpret_cast<float*>(smem + kOffFinalPar);
+        const int t = wave * 64 + lane;
+        if (t < 96) st4(lpar + 4 * t, ld4(a.final_bias + 4 * t));
+        else if (t < 160) st4(lpar + 4 * t, ld4(a.pvec + PV_FINAL_W + 4 * (t - 96)));   // decoder.norm weight | bias (contiguous in the parameter vector)
+        static_assert(PV_FINAL_B == PV_FINAL_W + kD, "decoder.norm parameters are read as one run");
+    }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    const float* lbias = reinterpret_cast<const float*>(smem + kOffFinalPar);
+    const float* lnorm = lbias + 384;
+    const char* wimg = smem + kOffFinalW + lane * 16;
+    float* fst = reinterpret_cast<float*>(smem + kOffFinalStage) + wave * 16 * kQStride;
 #pragma unroll 1
-    for (int slot = 0; slot < 5; ++slot) {
-        if (slot < kSlot0 || slot >= kSlot0 + NT) {   // another wave's slot: keep the stage ring turning
-#pragma unroll 1
-            for (int s6 = 0; s6 < 6; ++s6) {
-                stage_fetch(sg);
-                stage_end(sg);
-            }
+    for (int j = 0; j < NT; ++j) {
+        const int tile = tile0 + 4 * j;
+        const int rows_here = min(16, kFrames - 16 * tile);   // <= 0 for the padding tile
+        if (rows_here <= 0) {
+            rotate_tiles<NT>(x);
             continue;
         }
-        const int j = slot - kSlot0;
-        layer_norm_rows<true>(x[0], a.pvec + PV_FINAL_W, a.pvec + PV_FINAL_B, g);
+        layer_norm_rows<true>(x[0], lnorm, lnorm + kD, g);
         if constexpr (TAP) {   // slot 9: decoder.norm of this tile
-            const int frame_t = 16 * (tile0 + 4 * (slot - kSlot0)) + r;
+            const int frame_t = 16 * tile + r;
             if (a.tap_out && blockIdx.x == 0 && frame_t < kFrames) {
 #pragma unroll
                 for (int t = 0; t < kTiles; ++t) st4(a.tap_out + ((size_t)9 * kFrames + frame_t) * kD + 16 * t + 4 * g, x[0][t]);
@@ -108,25 +120,19 @@ __device__ __forceinline__ void decode_tiles(const VaeFusedArgs& a, char* smem, 
 #pragma unroll
         for (int c = 0; c < 4; ++c) xb1[c] = OP_PACK(x[0][2 * c], x[0][2 * c + 1]);
         rotate_tiles<NT>(x);
-        const int tile = tile0 + 4 * j;
         const int frame = 16 * tile + r;
         const bool keep = frame < kFrames && frame < len;   // output[~mask.T] = 0 (vae.py:274)
-        const int rows_here = min(16, kFrames - 16 * tile);   // <= 0 for the padding tile
         const size_t row0 = (size_t)b * kFrames + 16 * tile;
 #pragma unroll 1
-        for (int half = 0; half < 2; ++half) {   // 12 output tiles = 48 units = 3 stages (k-pair outer, output tile inner)
+        for (int half = 0; half < 2; ++half) {   // 12 output tiles x 4 k-pairs = 48 units (k-pair outer, output tile inner)
             f32x4 f[12];
 #pragma unroll
-            for (int o = 0; o < 12; ++o) f[o] = ld4(a.final_bias + 16 * (12 * half + o) + 4 * g);
+            for (int o = 0; o < 12; ++o) f[o] = ld4(lbias + 16 * (12 * half + o) + 4 * g);
 #pragma unroll
-            for (int s3 = 0; s3 < 3; ++s3) {
-                stage_fetch(sg);
-                for_units<kStage, 0>(sg, [&](int u, OPV wf) {
-                    const int lin = kStage * s3 + u, c = lin / 12, o = lin - 12 * c;
-                    f[o] = OP_MFMA(wf, xb1[c], f[o]);
-                });
-                stage_end(sg);
-            }
+            for (int c = 0; c < 4; ++c)
+#pragma unroll
+                for (int o = 0; o < 12; ++o)
+                    f[o] = OP_MFMA(__builtin_bit_cast(OPV, *reinterpret_cast<const uint4*>(wimg + ((half * 4 + c) * 12 + o) * 1024)), xb1[c], f[o]);
 #pragma unroll
             for (int qq = 0; qq < 2; ++qq) {
                 const int quarter = 2 * half + qq;
@@ -134,13 +140,14 @@ __device__ __forceinline__ void decode_tiles(const VaeFusedArgs& a, char* smem, 
                 for (int o = 0; o < 6; ++o) st4(fst + r * kQStride + 16 * o + 4 * g, keep ? f[6 * qq + o] : splat4(0.f));
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the staging tile is wave-private: no barrier
                 const int f0 = 96 * quarter, nfe = quarter == 3 ? kFeats - 288 : 96, njo = quarter == 3 ? kJoints - 48 : 16;
-                if (a.feats_out) {
+                const bool abl_nostore = (AMUSE_FABL & 16) != 0 && a.B > 0;   // (timing ablation: no output stores)
+                if (a.feats_out && !abl_nostore) {
                     for (int i = lane; i < rows_here * nfe; i += 64) {
                         const int rr = i / nfe, c = i - rr * nfe;
                         a.feats_out[(row0 + rr) * kFeats + f0 + c] = fst[rr * kQStride + c];
                     }
                 }
-                if (a.poses_out) {
+                if (a.poses_out && !abl_nostore) {
                     for (int i = lane; i < rows_here * njo; i += 64) {
                         const int rr = i / njo, jn = i - rr * njo;
                         float aa[3];
@@ -149,7 +156,7 @@ __device__ __forceinline__ void decode_tiles(const VaeFusedArgs& a, char* smem, 
                         dst[0] = aa[0]; dst[1] = aa[1]; dst[2] = aa[2];
                     }
                 }
-                if (a.trans_out && quarter == 3) {
+                if (a.trans_out && quarter == 3 && !abl_nostore) {
                     for (int i = lane; i < rows_here * 3; i += 64) {
                         const int rr = i / 3, c = i - rr * 3;
                         a.trans_out[(row0 + rr) * 3 + c] = fst[rr * kQStride + (330 - 288) + c];
@@ -194,7 +201,7 @@ hipError_t OP_LAUNCH(const VaeFusedArgs& a, hipStream_t stream) {
     if (!once.done(&dev_)) {
         for (const void* k : {reinterpret_cast<const void*>(&OP_KERNEL<false>), reinterpret_cast<const void*>(&OP_KERNEL<true>),
                               reinterpret_cast<const void*>(&OP_KERNEL<false, true>)}) {
-            hipError_t e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, kVaeFusedLdsBytes);
+            hipError_t e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, kFusedFinalLdsBytes);
             if (e != hipSuccess) return e;
         }
         once.set(dev_);
@@ -205,9 +212,9 @@ hipError_t OP_LAUNCH(const VaeFusedArgs& a, hipStream_t stream) {
         (void)hipMemcpyToSymbol(HIP_SYMBOL(g_fprof_n), &zero, sizeof(int));
     }
 #endif
-    if (a.ablate_attention) hipLaunchKernelGGL((OP_KERNEL<false, true>), dim3(a.B), dim3(512), kVaeFusedLdsBytes, stream, a);   // timing ablation (bench.py)
-    else if (a.tap_out) hipLaunchKernelGGL(OP_KERNEL<true>, dim3(a.B), dim3(512), kVaeFusedLdsBytes, stream, a);   // the tapped instantiation (tests)
-    else hipLaunchKernelGGL(OP_KERNEL<false>, dim3(a.B), dim3(512), kVaeFusedLdsBytes, stream, a);
+    if (a.ablate_attention) hipLaunchKernelGGL((OP_KERNEL<false, true>), dim3(a.B), dim3(512), kFusedFinalLdsBytes, stream, a);   // timing ablation (bench.py)
+    else if (a.tap_out) hipLaunchKernelGGL(OP_KERNEL<true>, dim3(a.B), dim3(512), kFusedFinalLdsBytes, stream, a);   // the tapped instantiation (tests)
+    else hipLaunchKernelGGL(OP_KERNEL<false>, dim3(a.B), dim3(512), kFusedFinalLdsBytes, stream, a);
 #if AMUSE_FPROF
     {
         static int calls = 0;
