@@ -508,6 +508,18 @@ def main():
                                       "frames_per_s_wav_to_smplx": round(300.0 / (ms_clip * 1e-3 + elapsed / args.steps / total), 1)}
             aeng.close()
             del aeng, wav
+        if world == 1:
+            # BASELINE config 4 beside the headline: the train_gesture iteration at batch 32 on this GPU - `--config train` in a child process of its own
+            # (the step is host-bound: inside this process, behind the engines above, it measures ~25 % slower than alone); DESIGN.md 4.6
+            import subprocess
+            r = subprocess.run([sys.executable, str(Path(__file__).resolve()), "--config", "train", "--steps", "40", "--warmup", "15"], capture_output=True, text=True,
+                               timeout=600)
+            try:
+                tl = json.loads(r.stdout.strip().splitlines()[-1])
+                line["train_gesture"] = {"batch_per_gpu": 32, "it_per_s": tl["value"], "ms_per_iteration": tl["ms_per_step"], "how": "python bench.py --config train --steps 40 "
+                                         "--warmup 15 as a child process; transformer layers on the library's layer-level entry points (amuse_train_*), DESIGN.md 4.6"}
+            except Exception as e:   # the headline must not depend on the extra
+                line["train_gesture"] = {"error": f"{type(e).__name__}: {e}; stderr tail: {r.stderr[-300:]}"}
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(total, args.T, wd, wp)
     barrier()
