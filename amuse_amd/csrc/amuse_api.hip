@@ -296,6 +296,32 @@ int build_prior(amuse_ctx* c, const float* pri, int what = AMUSE_UPD_ALL) {
         all.insert(all.end(), (size_t)kVaeRing * 64, uint4{0, 0, 0, 0});
         if (upload(&c->vaee_w[prec], all.data(), all.size() * sizeof(uint4))) return AMUSE_EHIP;
     }
+    if ((what & AMUSE_UPD_F32X) && (what & AMUSE_UPD_ENCODER)) {   // encode's stages 1..9 for the fp32x row kernel without split-K (the decoder's stream layout above)
+        std::vector<uint4> s;
+        for (int st = 0; st < kVaeStages; ++st) {
+            c->vaee_w8x_base[st] = (uint32_t)(s.size() / 64);
+            if (st == 0) continue;   // (the embedding stage stays with k_vae_rows<f16x2, M_ENC>)
+            const int b = st - 1;
+            const std::string p = blk_name("encoder", b);
+            pack_gemm(s, PREC_F16X2, Pp.get(p + ".self_attn.out_proj.weight"), 128, 128, range(0, 8), range(0, 8));
+            for (int ch = 0; ch < 16; ++ch) {
+                pack_gemm(s, PREC_F16X2, Pp.get(p + ".linear1.weight"), 512, 128, {2 * ch, 2 * ch + 1}, range(0, 8));
+                pack_gemm(s, PREC_F16X2, Pp.get(p + ".linear2.weight"), 128, 512, range(0, 8), {2 * ch, 2 * ch + 1});
+            }
+            if (b >= 4 && b <= 7) {
+                const float* wskip = Pp.get("encoder.linear_blocks." + std::to_string(b - 4) + ".weight");
+                pack_gemm(s, PREC_F16X2, wskip, 128, 256, range(0, 8), range(0, 8));
+                pack_gemm(s, PREC_F16X2, wskip, 128, 256, range(0, 8), range(8, 16));
+            }
+            if (st < 9) {
+                const float* in_w = Pp.get(blk_name("encoder", st) + ".self_attn.in_proj_weight");
+                for (int grp = 0; grp < 3; ++grp) pack_gemm(s, PREC_F16X2, in_w, 384, 128, range(8 * grp, 8 * grp + 8), range(0, 8));
+            }
+            if (s.size() % ((size_t)16 * 64) != 0) return fail(AMUSE_ESTATE, "internal: rows8 encoder stream is not whole stages");
+        }
+        s.insert(s.end(), (size_t)2 * 16 * 64, uint4{0, 0, 0, 0});   // the fetch runs two stages ahead
+        if (upload(&c->vaee_w8x, s.data(), s.size() * sizeof(uint4))) return AMUSE_EHIP;
+    }
     {
         auto pv = build_pvec(Pp, "encoder", false);
         if (upload(&c->vaee_pvec, pv.data(), pv.size() * 4) ||
@@ -520,7 +546,7 @@ int build_repack_maps(amuse_ctx* c) {
     // element type of an image: 0 = fp32, 1 = bf16, 2 = split-fp16, 3 = fp16 (launch_repack's `kind`)
     auto kind_of = [&](void** slot) {
         if (slot == (void**)&c->den_w[PREC_F16X2] || slot == (void**)&c->den_w8x || slot == (void**)&c->vae_w[PREC_F16X2] ||
-            slot == (void**)&c->vaee_w[PREC_F16X2] || slot == (void**)&c->vae_w8x) return 2;
+            slot == (void**)&c->vaee_w[PREC_F16X2] || slot == (void**)&c->vae_w8x || slot == (void**)&c->vaee_w8x) return 2;
         if (slot == (void**)&c->den_w8h || slot == (void**)&c->vae_wfh || slot == (void**)&c->vae_w[PREC_F16] || slot == (void**)&c->vaee_w[PREC_F16]) return 3;
         return (slot == (void**)&c->den_w[PREC_BF16] || slot == (void**)&c->den_w8 || slot == (void**)&c->vae_w[PREC_BF16] ||
                 slot == (void**)&c->vae_wf || slot == (void**)&c->vaee_w[PREC_BF16]) ? 1 : 0;
@@ -571,7 +597,7 @@ int build_repack_maps(amuse_ctx* c) {
         int cls = 0;   // which AMUSE_UPD_* bits the image needs; 0 = small parameters, always replaced
         if (slot == (void**)&c->den_w[PREC_F32] || slot == (void**)&c->vae_w[PREC_F32]) cls = AMUSE_UPD_F32;
         else if (slot == (void**)&c->den_w[PREC_F16X2] || slot == (void**)&c->den_w8x || slot == (void**)&c->vae_w[PREC_F16X2] || slot == (void**)&c->vae_w8x) cls = AMUSE_UPD_F32X;
-        else if (slot == (void**)&c->vaee_w[PREC_F16X2]) cls = AMUSE_UPD_F32X | AMUSE_UPD_ENCODER;
+        else if (slot == (void**)&c->vaee_w[PREC_F16X2] || slot == (void**)&c->vaee_w8x) cls = AMUSE_UPD_F32X | AMUSE_UPD_ENCODER;
         else if (slot == (void**)&c->den_w8h || slot == (void**)&c->vae_wfh || slot == (void**)&c->vae_w[PREC_F16]) cls = AMUSE_UPD_F16;
         else if (slot == (void**)&c->vaee_w[PREC_F16]) cls = AMUSE_UPD_F16 | AMUSE_UPD_ENCODER;
         else if (slot == (void**)&c->den_w[PREC_BF16] || slot == (void**)&c->den_w8 || slot == (void**)&c->vae_w[PREC_BF16] || slot == (void**)&c->vae_wf) cls = AMUSE_UPD_BF16;
@@ -618,7 +644,7 @@ void amuse_destroy(amuse_ctx* c) {
         if (p) (void)hipFree(p);
     void* ptrs[] = {c->den_w[0], c->den_w[1], c->den_w[2], c->den_w8, c->den_w8h, c->den_w8x, c->vae_wfh, c->den_pvec, c->den_pe, c->den_freqs, c->te_w1t, c->te_b1, c->te_w2t,
                     c->te_b2, c->cond_wt[0], c->cond_wt[1], c->cond_wt[2], c->cond_b[0], c->cond_b[1], c->cond_b[2],
-                    c->vae_w[0], c->vae_w[1], c->vae_w[2], c->vae_w[3], c->vae_w8x, c->vaee_w[2], c->vaee_w[3], c->vae_pvec, c->vae_final_bias, c->vae_pe, c->vae_wv_t, c->vae_bv,
+                    c->vae_w[0], c->vae_w[1], c->vae_w[2], c->vae_w[3], c->vae_w8x, c->vaee_w8x, c->vaee_w[2], c->vaee_w[3], c->vae_pvec, c->vae_final_bias, c->vae_pe, c->vae_wv_t, c->vae_bv,
                     c->vae_wo_t, c->vae_bo, c->vaee_w[0], c->vaee_w[1], c->vaee_pvec, c->vaee_pe, c->vaee_tok,
                     c->vaee_emb_bias, c->d_timesteps, c->d_coef, c->d_time_tok, c->d_ts1, c->d_tt1, c->d_coef1,
                     c->cond_tok, c->lat_tmp, c->fwd_ws, c->vae_ws, c->d_lengths, c->vae_wf, c->vae_skip, c->vae_ca_ws, c->vae_c1[0], c->vae_c1[1], c->vae_c1[2]};
@@ -954,11 +980,21 @@ int amuse_vae_encode(amuse_ctx* c, const float* feats, const int* lengths, int B
         ra.B = nb;
         VaeAttnArgs aa{};
         aa.q = ra.q; aa.k = ra.k; aa.v = ra.v; aa.lengths = ra.lengths; aa.o = attn_o; aa.B = nb;
+        // fp32x from kFusedMinClips clips of the call (or as amuse_set_decode_path pins it - the decode's rule): stages 1..9 on the row kernel without split-K
+        const bool rows8 = use_rows8(c, precision, B) && c->vaee_w8x != nullptr;
+        VaeRowsArgs r8 = ra;
+        if (rows8) {
+            r8.wstream = c->vaee_w8x;
+            memcpy(r8.stage_base, c->vaee_w8x_base, sizeof(r8.stage_base));
+        }
         for (int stage = 0; stage < kVaeStages; ++stage) {
             ra.stage = stage;
             ra.tiles = stage == kVaeStages - 1 ? 1 : 19;       // only the distribution rows leave the last block
             aa.q_tiles = stage == kLayers - 1 ? 1 : 19;
-            HIP_TRY(launch_vae_rows(ra, precision, VAE_MODE_ENC, st));
+            r8.stage = stage;
+            r8.tiles = ra.tiles;
+            if (rows8 && stage >= 1) HIP_TRY(launch_vae_rows8x(r8, st, VAE_MODE_ENC));
+            else HIP_TRY(launch_vae_rows(ra, precision, VAE_MODE_ENC, st));
             if (stage < kLayers) HIP_TRY(launch_vae_attn(aa, precision, VAE_MODE_ENC, st));
         }
         const size_t o = (size_t)b0 * kD;

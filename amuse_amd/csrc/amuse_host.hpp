@@ -313,6 +313,8 @@ struct amuse_ctx {
     bool vae_c1_valid[3] = {false, false, false};   // (re)computed by the next fused decode after a weight change
     uint4* vae_w8x = nullptr;          // fp32x row stages without split-K (k_vae_rows8.hip): one stream per stage, consumption order
     uint32_t vae_w8x_base[kVaeStages];
+    uint4* vaee_w8x = nullptr;         // the same for MotionPrior.encode's stages 1..9 (AMUSE_UPD_ENCODER | AMUSE_UPD_F32X)
+    uint32_t vaee_w8x_base[kVaeStages];
     uint4* vae_skip = nullptr; size_t vae_skip_cap = 0;   // clips
     float* vae_ca_ws = nullptr; size_t vae_ca_cap = 0;    // clips
     float *vae_pvec = nullptr, *vae_final_bias = nullptr, *vae_pe = nullptr;

@@ -175,7 +175,8 @@ struct VaeRowsArgs {
 // mode: which network the stages run (k_vae.hip M_*)
 constexpr int VAE_MODE_DEC = 0, VAE_MODE_ENC = 1, VAE_MODE_DEN_E = 2, VAE_MODE_DEN_D = 3;
 hipError_t launch_vae_rows(const VaeRowsArgs& a, int precision, int mode, hipStream_t stream);
-hipError_t launch_vae_rows8x(const VaeRowsArgs& a, hipStream_t stream);   // fp32x decode row stages, eight tiles per workgroup (k_vae_rows8.hip)
+// fp32x row stages without split-K (k_vae_rows8.hip): decode (every stage) and encode (stages 1..9; mode = VAE_MODE_DEC / _ENC below)
+hipError_t launch_vae_rows8x(const VaeRowsArgs& a, hipStream_t stream, int mode = 0);
 
 struct VaeAttnArgs {
     const float* q; const float* k; const float* v;  // [B][4][300][32]; q pre-scaled by 1/sqrt(32)

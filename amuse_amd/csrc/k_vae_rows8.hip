@@ -140,10 +140,13 @@ __device__ __forceinline__ void split_x(F16Pair (&xs)[NT][4], const f32x4 (&x)[N
 // (workgroups of up to six waves go two to a CU: three waves per SIMD either way)
 constexpr int waves_per_eu(int waves) { return waves <= 6 ? 3 : (waves + 3) / 4; }
 constexpr int kProdWaves = kProd ? 1 : 0;   // the copying wave sits behind the kWaves row waves
-template <int NT, int kWaves>
+// ENC: the stages of MotionPrior.encode behind its embedding stage (vae.py:154-214; encoder layers cross_attention.py:259-272: no cross-attention, two
+// norms): rows are [2 distribution tokens | 300 frames], S = 302; stage 9 ends with encoder.norm and writes the two distribution rows (a.tiles = 1: only
+// tile 0 of a clip is launched).  Stage 0 - skel_embedding over K = 333 - stays with k_vae_rows<f16x2, M_ENC>, same arrays.
+template <int NT, int kWaves, bool ENC>
 __global__ __launch_bounds__(64 * (kWaves + kProdWaves)) __attribute__((amdgpu_waves_per_eu(waves_per_eu(kWaves + kProdWaves), waves_per_eu(kWaves + kProdWaves)))) void k_vae_rows8x(VaeRowsArgs a) {
     constexpr int kDmaWaves = dma_waves(kWaves), kPieces = kProd ? 0 : kStage / kDmaWaves;
-    constexpr int S = kFrames;
+    constexpr int S = ENC ? kFrames + 2 : kFrames;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -154,9 +157,9 @@ __global__ __launch_bounds__(64 * (kWaves + kProdWaves)) __attribute__((amdgpu_w
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
         const int gt = (blockIdx.x * kWaves + wave) * NT + j;   // this wave's j-th (clip, row tile)
-        tvalid[j] = gt < a.B * kRowTiles;                       // (tiles beyond the batch only keep the stage protocol turning)
-        b[j] = tvalid[j] ? gt / kRowTiles : 0;
-        rt[j] = tvalid[j] ? gt - b[j] * kRowTiles : 0;
+        tvalid[j] = gt < a.B * a.tiles;                         // (tiles beyond the batch only keep the stage protocol turning)
+        b[j] = !tvalid[j] ? 0 : a.tiles == 1 ? gt : gt / kRowTiles;   // (a.tiles: 19, or 1 in encode's last stage)
+        rt[j] = tvalid[j] ? gt - b[j] * a.tiles : 0;
         frame[j] = rt[j] * 16 + r;
         rvalid[j] = tvalid[j] && frame[j] < S;
         row[j] = (size_t)b[j] * S + (rvalid[j] ? frame[j] : 0);
@@ -179,7 +182,7 @@ __global__ __launch_bounds__(64 * (kWaves + kProdWaves)) __attribute__((amdgpu_w
             // protocol of the row waves' own copies, 16 pieces per stage in one wave; LDS stages of this launch:
             const int blk = a.stage - 1;
             const bool hoisted = a.stage == 1 && a.c1 != nullptr, c1_only = a.stage == 1 && a.c1_out != nullptr;
-            const int nst = c1_only ? 4 : 12 + (a.stage >= 1 ? 36 + (blk >= 4 && blk <= 7 ? 8 : 0) : 0) - (hoisted ? 4 : 0);
+            const int nst = c1_only ? 4 : (ENC && a.stage == kLayers ? 0 : 12) + (a.stage >= 1 ? 36 + (blk >= 4 && blk <= 7 ? 8 : 0) : 0) - (hoisted ? 4 : 0);
             const uint4* src = a.wstream + (size_t)a.stage_base[a.stage] * 64 + (hoisted ? 4 * kStage * 64 : 0) + lane;   // (hoisted: no out_proj)
             int wb = 0;
             auto fetch = [&]() {
@@ -205,7 +208,8 @@ __global__ __launch_bounds__(64 * (kWaves + kProdWaves)) __attribute__((amdgpu_w
     stage_fetch(sg);
     // biases read behind the first activation store, from LDS (see AMUSE_R8_PROD): in_proj of block `stage` / final_layer
     float* lbias = reinterpret_cast<float*>(smem + kOffBias);
-    if (threadIdx.x < 96) st4(lbias + 4 * threadIdx.x, ld4((a.stage < kLayers ? a.pvec + a.stage * PV_BLOCK + PV_IN_B : a.final_bias) + 4 * threadIdx.x));
+    if (threadIdx.x < 96 && !(ENC && a.stage == kLayers))
+        st4(lbias + 4 * threadIdx.x, ld4((a.stage < kLayers ? a.pvec + a.stage * PV_BLOCK + PV_IN_B : a.final_bias) + 4 * threadIdx.x));
     int len[NT];
 #pragma unroll
     for (int j = 0; j < NT; ++j) len[j] = a.lengths ? a.lengths[b[j]] : S;
@@ -259,6 +263,7 @@ __global__ __launch_bounds__(64 * (kWaves + kProdWaves)) __attribute__((amdgpu_w
             return;
         }
         }
+        if constexpr (!ENC) {
 #pragma unroll
         for (int j = 0; j < NT; ++j) {
             // cross-attention onto the single latent token == per-clip constant; norm2  (cross_attention.py:331-337)
@@ -266,6 +271,7 @@ __global__ __launch_bounds__(64 * (kWaves + kProdWaves)) __attribute__((amdgpu_w
 #pragma unroll
             for (int t = 0; t < kTiles; ++t) x[j][t] += ld4(ca + 16 * t + 4 * g);
             layer_norm_rows<false>(x[j], pv + PV_LN2_W, pv + PV_LN2_B, g);
+        }
         }
         // ---- FFN in 16 chunks of 32 hidden features: linear1 (4 k-pairs x 2 tiles: one LDS stage) -> erf-GELU -> linear2's k-pair of
         // those features (8 output tiles: one LDS stage), accumulated into the residual; norm3  (cross_attention.py:338-340)
@@ -300,7 +306,7 @@ __global__ __launch_bounds__(64 * (kWaves + kProdWaves)) __attribute__((amdgpu_w
             });
         }
 #pragma unroll
-        for (int j = 0; j < NT; ++j) layer_norm_rows<false>(x[j], pv + PV_LN3_W, pv + PV_LN3_B, g);
+        for (int j = 0; j < NT; ++j) layer_norm_rows<false>(x[j], pv + (ENC ? PV_LN2_W : PV_LN3_W), pv + (ENC ? PV_LN2_B : PV_LN3_B), g);   // (an encoder layer's norm2)
         // ---- U-Net wiring (cross_attention.py:104-121): input blocks push, the skip linear runs ahead of the next output block
         if (blk < 4) {
 #pragma unroll
@@ -362,6 +368,16 @@ __global__ __launch_bounds__(64 * (kWaves + kProdWaves)) __attribute__((amdgpu_w
                 }
             }
         }
+    } else if constexpr (ENC) {
+        // ---- encoder.norm of the distribution rows (mu | logvar, vae.py:196-203): rows 0, 1 of a clip's tile 0
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            layer_norm_rows<false>(x[j], a.pvec + PV_FINAL_W, a.pvec + PV_FINAL_B, g);
+            if (tvalid[j] && rt[j] == 0 && r < 2) {
+#pragma unroll
+                for (int t = 0; t < kTiles; ++t) st4(a.stats_out + ((size_t)b[j] * 2 + r) * kD + 16 * t + 4 * g, x[j][t]);
+            }
+        }
     } else {
         // ---- decoder.norm -> final_layer (333 outputs in 24 tiles, four quarters of 6) -> rotation epilogue
 #pragma unroll
@@ -421,18 +437,31 @@ __global__ __launch_bounds__(64 * (kWaves + kProdWaves)) __attribute__((amdgpu_w
     if constexpr (!kProd) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the two surplus fetches must not outlive the workgroup's LDS
 }
 
-template <int W>
+template <int W, bool ENC>
 hipError_t launch_rows8_w(const VaeRowsArgs& a, hipStream_t stream) {
     static DeviceOnce once;
     int dev_;
     if (!once.done(&dev_)) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_vae_rows8x<kTilesPerWave, W>), hipFuncAttributeMaxDynamicSharedMemorySize, rows8_lds_bytes(W, true));
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_vae_rows8x<kTilesPerWave, W, ENC>), hipFuncAttributeMaxDynamicSharedMemorySize, rows8_lds_bytes(W, true));
         if (e != hipSuccess) return e;
         once.set(dev_);
     }
-    const int tiles = a.B * kRowTiles, per_wg = W * kTilesPerWave;
-    hipLaunchKernelGGL((k_vae_rows8x<kTilesPerWave, W>), dim3((tiles + per_wg - 1) / per_wg), dim3(64 * (W + kProdWaves)), rows8_lds_bytes(W, a.stage == kLayers), stream, a);
+    const int tiles = a.B * a.tiles, per_wg = W * kTilesPerWave;
+    hipLaunchKernelGGL((k_vae_rows8x<kTilesPerWave, W, ENC>), dim3((tiles + per_wg - 1) / per_wg), dim3(64 * (W + kProdWaves)), rows8_lds_bytes(W, !ENC && a.stage == kLayers), stream, a);
     return hipGetLastError();
+}
+template <bool ENC>
+hipError_t launch_rows8_mode(const VaeRowsArgs& a, int best, hipStream_t stream) {
+    switch (best) {
+        case 4: return launch_rows8_w<4, ENC>(a, stream);
+        case 5: return launch_rows8_w<5, ENC>(a, stream);
+        case 6: return launch_rows8_w<kProd ? 5 : 6, ENC>(a, stream);
+        case 8: return launch_rows8_w<8, ENC>(a, stream);
+        case 9: return launch_rows8_w<9, ENC>(a, stream);
+        case 10: return launch_rows8_w<10, ENC>(a, stream);
+        case 11: return launch_rows8_w<11, ENC>(a, stream);
+        default: return launch_rows8_w<kProd ? 11 : 12, ENC>(a, stream);
+    }
 }
 }  // namespace
 
@@ -440,9 +469,11 @@ hipError_t launch_rows8_w(const VaeRowsArgs& a, hipStream_t stream) {
 // round, so the shape is chosen per launch to minimise ceil(workgroups / 256) x waves - 256 clips are 4,864 tiles = 19 per CU: two rounds of
 // 10-wave workgroups (95 % full) instead of two of 12 (58 % in the second).  All instantiations produce the same bits (a tile's arithmetic does
 // not depend on its workgroup).  AMUSE_R8_FORCE_WAVES = 8 / 10 / 12 pins one (A/B).
-hipError_t launch_vae_rows8x(const VaeRowsArgs& a, hipStream_t stream) {
+hipError_t launch_vae_rows8x(const VaeRowsArgs& a, hipStream_t stream, int mode) {
     static const int force = [] { const char* e = getenv("AMUSE_R8_FORCE_WAVES"); return e ? atoi(e) : 0; }();
-    const int tiles = a.B * kRowTiles;
+    if (mode != VAE_MODE_DEC && mode != VAE_MODE_ENC) return hipErrorInvalidValue;
+    if (mode == VAE_MODE_ENC && a.stage == 0) return hipErrorInvalidValue;   // (the embedding stage is k_vae_rows<f16x2, M_ENC>'s)
+    const int tiles = a.B * a.tiles;
     // measured (profiles/r03_rows8_variants.txt): 10 waves beat 11 and 12 at equal rounds, 8 and 9 lose except where 8 waves make more
     // workgroups than CUs busy (launches of up to ~100 clips)
     int best = 8, best_cost = 1 << 30;
@@ -455,16 +486,7 @@ hipError_t launch_vae_rows8x(const VaeRowsArgs& a, hipStream_t stream) {
         }
     }
     if (force >= 4 && force <= 12 && force != 7 && !(kProd && (force == 6 || force == 12))) best = force;
-    switch (best) {
-        case 4: return launch_rows8_w<4>(a, stream);
-        case 5: return launch_rows8_w<5>(a, stream);
-        case 6: return launch_rows8_w<kProd ? 5 : 6>(a, stream);
-        case 8: return launch_rows8_w<8>(a, stream);
-        case 9: return launch_rows8_w<9>(a, stream);
-        case 10: return launch_rows8_w<10>(a, stream);
-        case 11: return launch_rows8_w<11>(a, stream);
-        default: return launch_rows8_w<kProd ? 11 : 12>(a, stream);
-    }
+    return mode == VAE_MODE_ENC ? launch_rows8_mode<true>(a, best, stream) : launch_rows8_mode<false>(a, best, stream);
 }
 
 }  // namespace amuse

@@ -43,7 +43,7 @@ hipError_t launch_repack(const float*, const int*, void*, size_t, int, hipStream
 hipError_t launch_add_noise(const float*, const float*, const float*, const float*, float*, int, hipStream_t, int) { return hipSuccess; }
 hipError_t launch_counter_normal(uint64_t, uint64_t, int, int, int, float*, hipStream_t, int) { return hipSuccess; }
 hipError_t launch_vae_rows(const VaeRowsArgs&, int, int, hipStream_t) { return hipSuccess; }
-hipError_t launch_vae_rows8x(const VaeRowsArgs&, hipStream_t) { return hipSuccess; }
+hipError_t launch_vae_rows8x(const VaeRowsArgs&, hipStream_t, int) { return hipSuccess; }
 hipError_t launch_vae_attn(const VaeAttnArgs&, int, int, hipStream_t) { return hipSuccess; }
 hipError_t launch_vae_fused(const VaeFusedArgs&, hipStream_t) { return hipSuccess; }
 hipError_t launch_vae_fusedh(const VaeFusedArgs&, hipStream_t) { return hipSuccess; }

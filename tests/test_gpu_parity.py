@@ -437,6 +437,30 @@ def test_vae_encode_fp32_vs_reference_golden(env, prec):
     assert _err(o6["mu"], mu) < 2e-5 and _err(o6["std"] / std.to(o6["std"].device), torch.ones_like(std)) < 5e-5
 
 
+def test_vae_encode_fp32x_on_the_row_kernel_without_split_k(env):
+    """fp32x encode with stages 1..9 on k_vae_rows8x<ENC> (what a call of >= 64 clips takes; pinned here like the decode's kernel choice): the
+    reference goldens at the fp32 bar, full and ragged, and clip-by-clip equal to itself in a larger batch across workgroup shapes."""
+    eng = env["eng"]
+    g = np.load(GOLDEN / "vae_encode.npz")
+    feats = torch.from_numpy(g["feats"].astype(np.float32))
+    try:
+        eng.set_decode_path("staged")
+        four = eng.vae_encode(feats, [300, 211], "fp32x")
+        eng.set_decode_path("fused")
+        out = eng.vae_encode(feats, None, "fp32x")
+        assert _err(out["mu"], g["mu"]) < 2e-5 and _err(out["std"], g["std"]) < 2e-5 * float(g["std"].max())
+        o2 = eng.vae_encode(feats, [300, 211], "fp32x")
+        assert _err(o2["mu"], g["mu_ragged"]) < 2e-5 and _err(o2["std"], g["std_ragged"]) < 2e-5 * float(g["std_ragged"].max())
+        assert not torch.equal(o2["mu"], four["mu"]) and _err(o2["mu"], four["mu"]) < 2e-5       # really two kernels, the same arithmetic
+        fb = feats[:1].repeat(70, 1, 1)                                                             # 1,330 tiles: ten-wave workgroups, several per clip boundary
+        fb[33] = feats[1]
+        o5 = eng.vae_encode(fb, None, "fp32x")
+        assert torch.equal(o5["mu"][0], out["mu"][0]) and torch.equal(o5["mu"][33], out["mu"][1]) and torch.equal(o5["mu"][69], out["mu"][0])
+        assert torch.equal(o5["std"][33], out["std"][1])
+    finally:
+        eng.set_decode_path("auto")
+
+
 def test_vae_encode_bf16_bounded(env):
     eng = env["eng"]
     g = np.load(GOLDEN / "vae_encode.npz")
