@@ -11,6 +11,8 @@ struct amuse_variant {
     uint4* rows_w[4] = {nullptr, nullptr, nullptr, nullptr};
     uint32_t stage_base[4][kVaeStages];
     uint32_t stage_units[4][kVaeStages];
+    uint4* rows8_w = nullptr;                   // fp32x, diffusion_only + trans_enc: stages 1..8 for the row kernel without split-K (k_vae_rows8.hip, ENC form)
+    uint32_t rows8_base[kVaeStages];
     float* pvec = nullptr;           // PV_* (ENC_POSE) / PVX_* (trans_dec archs) layout
     float* m_pe = nullptr;           // mem_pos.pe [500][128]
     float *wkv_t = nullptr, *bkv = nullptr;       // trans_dec: cross-attention k / v projections [9][2][128 in][128 out], [9][2][128]
@@ -139,11 +141,19 @@ struct PoseStep {
     const float* ttok; size_t ttok_stride; const float* tkv; size_t tkv_clip_stride;
     const float* cond_tok; const float* ckv; const int* lengths_dev;
     int ncond, step; uint64_t seed, clip0;
+    bool rows8;   // fp32x staged step: stages 1..8 on k_vae_rows8x (decided from the CALL's clip count)
 };
 // the fused per-clip step kernel (16-bit modes, diffusion_only + trans_enc) occupies one CU per clip: it wins from about as many
 // clips as the fused decoder does (amuse_api.hip kFusedMinClips); below that the staged path's 19 workgroups per clip finish sooner.
 // amuse_set_decode_path / AMUSE_VAE_FUSED pin the choice here too (STAGED / FUSED), keyed by the CALL's clip count.
 constexpr int kDenFusedMinClips = 64;
+// ... and so does the fp32x row kernel without split-K for the staged step's stages 1..8 (the decode's rule, amuse_api.hip use_rows8)
+bool use_den_rows8(const amuse_ctx* c, int precision, int B) {
+    static const int env = [] { const char* e = getenv("AMUSE_VAE_FUSED"); return e ? atoi(e) : -1; }();
+    const int force = c->decode_path == AMUSE_DECODE_STAGED ? 0 : c->decode_path == AMUSE_DECODE_FUSED ? 1 : env;
+    if (precision != PREC_F16X2 || c->arch != AMUSE_ARCH_ENC_POSE || force == 0 || !c->var->rows8_w) return false;
+    return force == 1 || B >= kDenFusedMinClips;
+}
 bool use_den_fused(const amuse_ctx* c, int precision, int B) {
     static const int env = [] { const char* e = getenv("AMUSE_VAE_FUSED"); return e ? atoi(e) : -1; }();
     const int force = c->decode_path == AMUSE_DECODE_STAGED ? 0 : c->decode_path == AMUSE_DECODE_FUSED ? 1 : env;
@@ -191,9 +201,16 @@ int pose_step(amuse_ctx* c, const PoseStep& p, int nb, int precision, bool fused
     VaeAttnArgs aa{};
     aa.q = ra.q; aa.k = ra.k; aa.v = ra.v; aa.lengths = nullptr; aa.o = attn_o; aa.B = nb; aa.q_tiles = 19; aa.S = S;
     const int mode = dec ? VAE_MODE_DEN_D : VAE_MODE_DEN_E;
+    VaeRowsArgs r8 = ra;
+    if (p.rows8) {   // (fp32x, trans_enc: stages 1..8 are plain encoder-layer stages - the row kernel without split-K, as MotionPrior.encode's)
+        r8.wstream = v->rows8_w;
+        memcpy(r8.stage_base, v->rows8_base, sizeof(r8.stage_base));
+    }
     for (int stage = 0; stage < kVaeStages; ++stage) {
         ra.stage = stage;
-        HIP_TRY(launch_vae_rows(ra, precision, mode, st));
+        r8.stage = stage;
+        if (p.rows8 && stage >= 1 && stage <= 8) HIP_TRY(launch_vae_rows8x(r8, st, VAE_MODE_ENC));
+        else HIP_TRY(launch_vae_rows(ra, precision, mode, st));
         if (stage < kLayers) HIP_TRY(launch_vae_attn(aa, precision, mode, st));
     }
     return 0;
@@ -270,6 +287,30 @@ int variant_build(amuse_ctx* c, const float* den, int what) {
             }
             all.insert(all.end(), (size_t)kVaeRing * 64, uint4{0, 0, 0, 0});   // the last wave's ring reads past its slice
             if (upload(&v->rows_w[prec], all.data(), all.size() * sizeof(uint4))) return AMUSE_EHIP;
+        }
+        if (!dec && (what & AMUSE_UPD_F32X)) {   // fp32x: stages 1..8 once more as ONE stream per stage in consumption order (k_vae_rows8.hip's layout, amuse_api.hip)
+            std::vector<uint4> s;
+            for (int st = 0; st < kVaeStages; ++st) {
+                v->rows8_base[st] = (uint32_t)(s.size() / 64);
+                if (st == 0 || st == 9) continue;   // (pose_embd / pose_proj + update stay with k_vae_rows)
+                const int b = st - 1;
+                const std::string p = blk_name("encoder", b);
+                pack_gemm(s, PREC_F16X2, D.get(p + ".self_attn.out_proj.weight"), 128, 128, range(0, 8), range(0, 8));
+                for (int ch = 0; ch < 16; ++ch) {
+                    pack_gemm(s, PREC_F16X2, D.get(p + ".linear1.weight"), 512, 128, {2 * ch, 2 * ch + 1}, range(0, 8));
+                    pack_gemm(s, PREC_F16X2, D.get(p + ".linear2.weight"), 128, 512, range(0, 8), {2 * ch, 2 * ch + 1});
+                }
+                if (b >= 4 && b <= 7) {
+                    const float* wskip = D.get("encoder.linear_blocks." + std::to_string(b - 4) + ".weight");
+                    pack_gemm(s, PREC_F16X2, wskip, 128, 256, range(0, 8), range(0, 8));
+                    pack_gemm(s, PREC_F16X2, wskip, 128, 256, range(0, 8), range(8, 16));
+                }
+                const float* in_w = D.get(blk_name("encoder", st) + ".self_attn.in_proj_weight");
+                for (int grp = 0; grp < 3; ++grp) pack_gemm(s, PREC_F16X2, in_w, 384, 128, range(8 * grp, 8 * grp + 8), range(0, 8));
+                if (s.size() % ((size_t)16 * 64) != 0) return fail(AMUSE_ESTATE, "internal: rows8 pose-denoiser stream is not whole stages");
+            }
+            s.insert(s.end(), (size_t)2 * 16 * 64, uint4{0, 0, 0, 0});   // the fetch runs two stages ahead
+            if (upload(&v->rows8_w, s.data(), s.size() * sizeof(uint4))) return AMUSE_EHIP;
         }
         if (!dec) {
             // fused step kernel (k_den_fused.hip; bf16 / fp16 operands): ONE stream for the eight waves, in consumption order, cut into
@@ -348,7 +389,7 @@ int variant_build(amuse_ctx* c, const float* den, int what) {
 void variant_destroy(amuse_ctx* c) {
     amuse_variant* v = c->var;
     if (!v) return;
-    void* ptrs[] = {v->dec_w[0], v->dec_w[1], v->dec_w[2], v->dec_w[3], v->rows_w[0], v->rows_w[1], v->rows_w[2], v->rows_w[3], v->pvec, v->m_pe,
+    void* ptrs[] = {v->dec_w[0], v->dec_w[1], v->dec_w[2], v->dec_w[3], v->rows_w[0], v->rows_w[1], v->rows_w[2], v->rows_w[3], v->rows8_w, v->pvec, v->m_pe,
                     v->wkv_t, v->bkv, v->emb_bias, v->final_bias, v->tkv_sched, v->ckv, v->tkv1, v->ws, v->tt, v->fused_w[0], v->fused_w[1], v->skip};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
@@ -385,6 +426,7 @@ int variant_sample(amuse_ctx* c, const float* con, const float* emo, const float
     if (x_init) HIP_TRY(hipMemcpyAsync(out, x_init, (size_t)B * sd * sizeof(float), hipMemcpyDeviceToDevice, st));
     else HIP_TRY(launch_counter_normal(seed, clip0, B, 0, 0, out, st, (int)sd));
     const bool fused = use_den_fused(c, precision, B);
+    const bool rows8 = use_den_rows8(c, precision, B);
     const int chunk = fused ? B : (B < kPoseChunk ? B : kPoseChunk);
     if (int e = ensure_pose_ws(v, chunk, fused)) return e;
     for (int step = 0; step < c->T; ++step) {
@@ -399,7 +441,7 @@ int variant_sample(amuse_ctx* c, const float* con, const float* emo, const float
             p.cond_tok = c->cond_tok + (size_t)b0 * ncond * kD;
             p.ckv = v->ckv ? v->ckv + (size_t)b0 * ncond * kTkv : nullptr;
             p.lengths_dev = nullptr;   // the sampling loop passes full lengths (infer_ldm.py:135)
-            p.ncond = ncond; p.step = step; p.seed = seed; p.clip0 = clip0 + (uint64_t)b0;
+            p.ncond = ncond; p.step = step; p.seed = seed; p.clip0 = clip0 + (uint64_t)b0; p.rows8 = rows8;
             if (int e = pose_step(c, p, nb, precision, fused, st)) return e;
         }
         if (traj_out) HIP_TRY(hipMemcpyAsync(traj_out + (size_t)step * B * sd, out, (size_t)B * sd * sizeof(float), hipMemcpyDeviceToDevice, st));
@@ -439,6 +481,7 @@ int variant_denoise(amuse_ctx* c, const float* x_t, const int* timesteps, bool p
     if (int e = stage_lengths_v(c, lengths, B, st)) return e;
     const size_t sd = AMUSE_POSE_STATE;
     const bool fused = use_den_fused(c, precision, B);
+    const bool rows8 = use_den_rows8(c, precision, B);
     const int chunk = fused ? B : (B < kPoseChunk ? B : kPoseChunk);
     if (int e = ensure_pose_ws(v, chunk, fused)) return e;
     for (int b0 = 0; b0 < B; b0 += chunk) {
@@ -450,7 +493,7 @@ int variant_denoise(amuse_ctx* c, const float* x_t, const int* timesteps, bool p
         p.cond_tok = c->cond_tok + (size_t)b0 * ncond * kD;
         p.ckv = v->ckv ? v->ckv + (size_t)b0 * ncond * kTkv : nullptr;
         p.lengths_dev = lengths ? c->d_lengths + b0 : nullptr;
-        p.ncond = ncond;
+        p.ncond = ncond; p.rows8 = rows8;
         if (int e = pose_step(c, p, nb, precision, fused, st)) return e;
     }
     return 0;

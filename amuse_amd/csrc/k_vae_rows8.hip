@@ -142,11 +142,13 @@ constexpr int waves_per_eu(int waves) { return waves <= 6 ? 3 : (waves + 3) / 4;
 constexpr int kProdWaves = kProd ? 1 : 0;   // the copying wave sits behind the kWaves row waves
 // ENC: the stages of MotionPrior.encode behind its embedding stage (vae.py:154-214; encoder layers cross_attention.py:259-272: no cross-attention, two
 // norms): rows are [2 distribution tokens | 300 frames], S = 302; stage 9 ends with encoder.norm and writes the two distribution rows (a.tiles = 1: only
-// tile 0 of a clip is launched).  Stage 0 - skel_embedding over K = 333 - stays with k_vae_rows<f16x2, M_ENC>, same arrays.
+// tile 0 of a clip is launched).  Stage 0 - skel_embedding over K = 333 - stays with k_vae_rows<f16x2, M_ENC>, same arrays.  The Denoiser's diffusion_only
+// step (denoiser.py:177-187: the same encoder layers over S = a.S rows) runs its stages 1..8 here too; pose_embd and pose_proj + update stay with k_vae_rows.
 template <int NT, int kWaves, bool ENC>
 __global__ __launch_bounds__(64 * (kWaves + kProdWaves)) __attribute__((amdgpu_waves_per_eu(waves_per_eu(kWaves + kProdWaves), waves_per_eu(kWaves + kProdWaves)))) void k_vae_rows8x(VaeRowsArgs a) {
     constexpr int kDmaWaves = dma_waves(kWaves), kPieces = kProd ? 0 : kStage / kDmaWaves;
-    constexpr int S = ENC ? kFrames + 2 : kFrames;
+    // rows per clip: 300 frames; + the two distribution tokens (encode); a.S = condition tokens + 300 (302..304) for the Denoiser's diffusion_only stages
+    const int S = ENC ? (a.S > 0 ? a.S : kFrames + 2) : kFrames;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);

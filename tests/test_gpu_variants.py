@@ -73,6 +73,34 @@ def test_variant_eps_vs_reference_golden(env, g, prec):
             eng.denoise_step(x, 501, con, emo, sty, prec, lengths=[200, 173])
 
 
+def test_pose_step_fp32x_on_the_row_kernel_without_split_k(env, g):
+    """diffusion_only + trans_enc in fp32x with stages 1..8 on k_vae_rows8x (what a call of >= 64 clips takes; pinned here): the reference goldens at the
+    1e-5 bar with 4 / 3 / 2 prefix tokens (S = 304 / 303 / 302) and ragged lengths, another kernel than the four-wave one, a DDIM-50 sampling run, and a
+    clip's result independent of the batch around it."""
+    if env["arch"] != "trans_enc" or not env["pose"]:
+        pytest.skip("the diffusion_only + trans_enc variant")
+    eng, tag = env["eng"], env["tag"]
+    con, emo, sty, x = inputs(g, True)
+    try:
+        eng.set_decode_path("staged")
+        four = eng.denoise_step(x, 501, con, emo, sty, "fp32x")
+        eng.set_decode_path("fused")
+        for t in (981, 501, 1):
+            assert _err(cut(eng.denoise_step(x, t, con, emo, sty, "fp32x"), True), g[f"{tag}/eps_t{t}"]) < 1e-5, t
+        e = eng.denoise_step(x, 501, con, emo, sty, "fp32x")
+        assert not torch.equal(e, four) and _err(e, four) < 1e-5
+        assert _err(cut(eng.denoise_step(x, 501, con, None, sty, "fp32x"), True), g[f"{tag}/eps_t501_noemo"]) < 1e-5
+        assert _err(cut(eng.denoise_step(x, 501, con, None, None, "fp32x"), True), g[f"{tag}/eps_t501_consolo"]) < 1e-5
+        lens = [int(v) for v in g["lengths_ragged"]]
+        assert _err(cut(eng.denoise_step(x, 501, con, emo, sty, "fp32x", lengths=lens), True), g[f"{tag}/eps_t501_ragged"]) < 1e-5
+        n = x.shape[0]
+        rep = lambda a: np.concatenate([a] * 24, 0)                      # 48+ clips: ten-wave workgroups across clip boundaries
+        big = eng.denoise_step(rep(x), 501, rep(con), rep(emo), rep(sty), "fp32x")
+        assert torch.equal(big[:n], e) and torch.equal(big[-n:], e)
+    finally:
+        eng.set_decode_path("auto")
+
+
 @pytest.mark.parametrize("prec", PARITY)
 def test_trans_dec_taps_vs_reference_golden(env, g, prec):
     if env["arch"] != "trans_dec" or env["pose"]:

@@ -22,7 +22,7 @@ for arch in ("trans_enc", "trans_dec"):
         g = torch.Generator().manual_seed(0)
         con, emo, sty = (torch.randn(B, 256, generator=g).cuda() for _ in range(3))
         for prec in ("bf16", "fp16", "fp32x", "fp32"):
-            for path in (("staged", "fused") if (arch == "trans_enc" and prec in ("bf16", "fp16")) else ("staged",)):
+            for path in (("staged", "fused") if (arch == "trans_enc" and prec in ("bf16", "fp16", "fp32x")) else ("staged",)):   # (fp32x "fused" = stages 1..8 on k_vae_rows8x)
                 eng.set_decode_path(path)
                 eng.sample(con, emo, sty, prec, seed=1)
                 torch.cuda.synchronize()
