@@ -62,7 +62,7 @@ constexpr int kFusedFinalLdsBytes = kOffFinalPar + (384 + 2 * kD) * 4;   // 152,
 static_assert(kFusedFinalLdsBytes >= kVaeFusedLdsBytes && kFusedFinalLdsBytes <= 160 * 1024, "LDS");
 
 // ablation switches for timing experiments (tools/build_variant.sh): 2 no attention, 4 no FFN arithmetic,
-// 8 no softmax arithmetic (scores fed to PV as they are).  0 in the product.
+// 8 no softmax arithmetic (scores fed to PV as they are), 16 no output stores (k_vae_fused), 32 no skip-stack stores.  0 in the product.
 #ifndef AMUSE_FABL
 #define AMUSE_FABL 0
 #endif
@@ -687,7 +687,7 @@ __device__ __forceinline__ void decoder_block(f32x4 (&x)[NT][kTiles], Stager& sg
     }
 #endif
     FSTAMP(15);   // norm3
-    if constexpr (MODE == 0) {   // xs.append(x): packed operands of the skip linear that pops them
+    if constexpr (MODE == 0 && (AMUSE_FABL & 32) == 0) {   // xs.append(x): packed operands of the skip linear that pops them  (FABL 32: timing ablation, no push)
         uint4* sk = skipbuf + (size_t)blk * (20 * 4 * 64);
 #pragma unroll
         for (int j = 0; j < NT; ++j)

@@ -170,6 +170,22 @@ def bias_gelu_drop_bwd(da, h, b, p: float, seed: int, off: int):
     return dh, db
 
 
+def attn_fwd(qkv: torch.Tensor, B: int, S: int, p: float, seed: int, off: int, want_mask: bool = False):
+    """qkv (B S, 384) -> (o (B S, 128), lse (B, 4, S)[, keep / (1 - p) (B, 4, S, S)])   csrc/k_train_attn.hip"""
+    qkv = _c(qkv)
+    o = torch.empty(B * S, 128, device=qkv.device, dtype=torch.float32)
+    lse = torch.empty(B, 4, S, device=qkv.device, dtype=torch.float32)
+    mask = torch.ones(B, 4, S, S, device=qkv.device, dtype=torch.float32) if want_mask else None
+    _lib.check(_st(qkv.device)["lib"].amuse_train_attn_fwd(_p(qkv), B, S, float(p), seed, off, _p(o), _p(lse), _p(mask), _stream()))
+    return (o, lse, mask) if want_mask else (o, lse)
+
+
+def attn_bwd(qkv, o, lse, dout, B: int, S: int, p: float, seed: int, off: int) -> torch.Tensor:
+    dqkv = torch.empty_like(qkv)
+    _lib.check(_st(qkv.device)["lib"].amuse_train_attn_bwd(_p(_c(qkv)), _p(o), _p(lse), _p(_c(dout)), B, S, float(p), seed, off, _p(dqkv), _stream()))
+    return dqkv
+
+
 def colsum(x):
     x = _c(x)
     C = x.shape[-1]
@@ -182,6 +198,13 @@ def colsum(x):
 # ---------------------------------------------------------------------------------------------------- layers (no autograd inside)
 _sdpa = torch.ops.aten._scaled_dot_product_efficient_attention
 _sdpa_bwd = torch.ops.aten._scaled_dot_product_efficient_attention_backward
+
+
+def own_attention(S: int, H: int, D: int) -> bool:
+    """The library's attention kernels take 4 heads of 32 and up to 304 tokens (every attention of the training step); AMUSE_TRAIN_ATTN=vendor = aten's op (A/B)."""
+    return os.environ.get("AMUSE_TRAIN_ATTN", "hip") != "vendor" and H == 4 and D == 128 and 1 <= S <= 304
+
+
 _ENC_PARAMS = ("Wo", "bo", "g1", "be1", "W1", "b1", "W2", "b2", "g3", "be3")
 _DEC_PARAMS = ("Wo", "bo", "g1", "be1", "Wv", "bv", "Wc", "bc", "g2", "be2", "W1", "b1", "W2", "b2", "g3", "be3")
 
@@ -196,9 +219,16 @@ def _layer_forward(ctx, x, mem, Win, bin_, prm: dict, H: int, p: float, p_attn: 
     keep = any(ctx.needs_input_grad)                       # (no-grad passes - the iteration's second encode - keep nothing beyond the call)
     qkv = torch.empty(rows, 3 * D, device=dev, dtype=torch.float32)
     _lib.check(lib.amuse_train_linear_fwd(x2.data_ptr(), Win.data_ptr(), bin_.data_ptr(), rows, D, 3 * D, qkv.data_ptr(), stream))
-    q, k, v = (t.transpose(1, 2) for t in qkv.view(B, S, 3, H, D // H).unbind(2))       # (B, H, S, d) views
-    ao, lse, ps, po = _sdpa(q, k, v, None, True, p_attn, False)
-    o2 = ao.transpose(1, 2).reshape(rows, D)
+    own = own_attention(S, H, D)
+    if own:   # the library's fp32 attention (k_train_attn.hip): mask = hash of (seed, offset, clip, head, query, key)
+        seed_a, off_a = _seed(), next_offset()
+        o2, lse = attn_fwd(qkv, B, S, p_attn, seed_a, off_a)
+        ao, ps, po = o2, o2, o2          # (placeholders in the saved list)
+    else:     # the vendor's fused kernel (AMUSE_TRAIN_ATTN=vendor, or shapes the library's kernels do not take)
+        seed_a = off_a = 0
+        q, k, v = (t.transpose(1, 2) for t in qkv.view(B, S, 3, H, D // H).unbind(2))   # (B, H, S, d) views
+        ao, lse, ps, po = _sdpa(q, k, v, None, True, p_attn, False)
+        o2 = ao.transpose(1, 2).reshape(rows, D)
     dec = mem is not None
     n128 = 9 if dec else 6
     b128 = torch.empty(n128, rows, D, device=dev, dtype=torch.float32)                   # x1 zh1 out zh3 tmp (vk xm zh2) | one spare row block for r1 r2 r3
@@ -223,13 +253,13 @@ def _layer_forward(ctx, x, mem, Win, bin_, prm: dict, H: int, p: float, p_attn: 
     _lib.check(lib.amuse_train_layer_fwd(C.byref(L), stream))
     if keep:
         ctx.save_for_backward(x2, qkv, ao, lse, ps, po, o2, b128, b512, Win, *((mem2, c) if dec else ()), *prm.values())
-        ctx.L, ctx.cfg = L, (B, S, D, H, p_attn, dec, tuple(prm))
+        ctx.L, ctx.cfg = L, (B, S, D, H, p_attn, dec, tuple(prm), own, seed_a, off_a)
     return b128[2].view(B, S, D)
 
 
 def _layer_backward(ctx, dout):
     t = ctx.saved_tensors
-    B, S, D, H, p_attn, dec, names = ctx.cfg
+    B, S, D, H, p_attn, dec, names, own, seed_a, off_a = ctx.cfg
     x2, qkv, ao, lse, ps, po, o2, b128, b512, Win = t[:10]
     prm = dict(zip(names, t[12 if dec else 10:]))
     rows, ff, dev = B * S, b512.shape[2], x2.device
@@ -252,10 +282,13 @@ def _layer_backward(ctx, dout):
     L.dx, L.do2, L.s128a, L.s128b = (g128[i].data_ptr() for i in range(4))
     L.s512a, L.s512b, L.ws = g512[0].data_ptr(), g512[1].data_ptr(), st["ws"].data_ptr()
     _lib.check(lib.amuse_train_layer_bwd(C.byref(L), stream))
-    do = g128[1].view(B, S, H, D // H).transpose(1, 2)
-    q, k, v = (u.transpose(1, 2) for u in qkv.view(B, S, 3, H, D // H).unbind(2))
-    dq, dk, dv, _ = _sdpa_bwd(do, q, k, v, None, ao, lse, ps, po, p_attn, (True, True, True, False), False)
-    dqkv = torch.stack([dq.transpose(1, 2), dk.transpose(1, 2), dv.transpose(1, 2)], dim=2).view(rows, 3 * D)
+    if own:
+        dqkv = attn_bwd(qkv, o2, lse, g128[1], B, S, p_attn, seed_a, off_a)
+    else:
+        do = g128[1].view(B, S, H, D // H).transpose(1, 2)
+        q, k, v = (u.transpose(1, 2) for u in qkv.view(B, S, 3, H, D // H).unbind(2))
+        dq, dk, dv, _ = _sdpa_bwd(do, q, k, v, None, ao, lse, ps, po, p_attn, (True, True, True, False), False)
+        dqkv = torch.stack([dq.transpose(1, 2), dk.transpose(1, 2), dv.transpose(1, 2)], dim=2).view(rows, 3 * D)
     dWin = torch.empty_like(Win)
     dbin = torch.empty(3 * D, device=dev, dtype=torch.float32)
     _lib.check(lib.amuse_train_linear_bwd(dqkv.data_ptr(), x2.data_ptr(), Win.data_ptr(), rows, D, 3 * D, dWin.data_ptr(), dbin.data_ptr(), g128[0].data_ptr(), 1,

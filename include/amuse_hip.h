@@ -356,6 +356,13 @@ int amuse_train_bias_gelu_drop_bwd(const float* da, const float* h, const float*
 /* out [C] = sum_rows x[r][:] (a bias gradient), C a multiple of 4 up to 1024 */
 int amuse_train_colsum(const float* x, long rows, int C, float* out, float* ws, void* stream);
 
+/* Self-attention core of a layer (nn.MultiheadAttention between its in- and out-projection, 4 heads of 32, S <= 304 tokens) in fp32 on the matrix cores
+ * (csrc/k_train_attn.hip): o [B S][128] = dropout(softmax(q k^T / sqrt(32))) v per (clip, head) from the packed projections qkv [B S][384] (q | k | v,
+ * heads contiguous 32-column slices), lse [B][4][S] for the backward pass; the backward call returns d(qkv).  The dropout mask is a hash of
+ * (seed, offset, clip, head, query, key): the backward call regenerates it from the same (p, seed, offset).  mask_debug (nullable): [B][4][S][S] keep / (1 - p). */
+int amuse_train_attn_fwd(const float* qkv, int B, int S, float p, uint64_t seed, uint64_t offset, float* o, float* lse, float* mask_debug, void* stream);
+int amuse_train_attn_bwd(const float* qkv, const float* o, const float* lse, const float* dout, int B, int S, float p, uint64_t seed, uint64_t offset,
+                         float* dqkv, void* stream);
 /* torch.optim.AdamW (amsgrad off) over a contiguous range of flat fp32 buffers, `step` = this update's 1-based count (trainer.py:181-184: the reference's
  * optimizer over prior + ldm parameters; amuse_amd/train_gesture.py keeps parameters, gradients and both moments in one buffer each) */
 int amuse_train_adamw(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, size_t n, double lr, double beta1, double beta2, double eps,

@@ -233,3 +233,39 @@ def test_linear_fn_equals_f_linear(rows, K, N):
     for a, b in zip(res[1], res[0]):
         assert a.shape == b.shape and _rel(a, b) < 2e-5
 
+
+@pytest.mark.parametrize("B,S", [(2, 300), (3, 302), (32, 5), (1, 17), (2, 304), (1, 1)])
+def test_attention_kernels_against_torch_math_attention(B, S):
+    """csrc/k_train_attn.hip (fp32 MFMA): o and d(q | k | v) against softmax(q k^T / sqrt(32)) v under autograd, without dropout and with the kernel's own mask."""
+    from amuse_amd import train_ops as T
+    g = torch.Generator(device=DEV).manual_seed(S)
+    qkv = torch.randn(B * S, 384, device=DEV, generator=g)
+    dout = torch.randn(B * S, 128, device=DEV, generator=g)
+
+    def ref(mask):
+        x = qkv.clone().requires_grad_(True)
+        q, k, v = (t.transpose(1, 2) for t in x.view(B, S, 3, 4, 32).unbind(2))          # (B, 4, S, 32)
+        p = torch.softmax(q @ k.transpose(-1, -2) / 32 ** 0.5, dim=-1)
+        if mask is not None:
+            p = p * mask
+        o = (p @ v).transpose(1, 2).reshape(B * S, 128)
+        o.backward(dout)
+        return o.detach(), x.grad
+
+    for pdrop in (0.0, 0.1):
+        o, lse, mask = T.attn_fwd(qkv, B, S, pdrop, 5, 9, want_mask=True)
+        if pdrop == 0.0:
+            assert torch.all(mask == 1.0)
+        elif B * S * S > 2000:
+            kept = (mask > 0).float().mean()
+            assert abs(float(kept) - 0.9) < 0.02 and torch.all((mask == 0) | ((mask - 1 / 0.9).abs() < 1e-6))
+            o_b, _ = T.attn_fwd(qkv, B, S, pdrop, 5, 10)
+            assert not torch.equal(o_b, o)                                               # another offset: another mask
+        o_ref, g_ref = ref(None if pdrop == 0.0 else mask)
+        assert float((o - o_ref).abs().max()) < 2e-5, (pdrop, float((o - o_ref).abs().max()))
+        dqkv = T.attn_bwd(qkv, o, lse, dout, B, S, pdrop, 5, 9)
+        assert _rel(dqkv, g_ref) < 2e-4, (pdrop, _rel(dqkv, g_ref))
+        for sl in (slice(0, 128), slice(128, 256), slice(256, 384)):                      # each of dq, dk, dv on its own scale
+            scale = float(g_ref[:, sl].abs().max())                                       # (one key: the softmax is constant, dq = dk = 0 exactly in the reference)
+            assert float((dqkv[:, sl] - g_ref[:, sl]).abs().max()) < 2e-4 * scale + 1e-6, (pdrop, sl)
+
