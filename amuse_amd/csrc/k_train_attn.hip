@@ -21,13 +21,14 @@
 //     denominator from the undropped P, as torch does.
 // Numerics: true fp32 products and accumulation (the reference's arithmetic up to summation order); tests/test_gpu_train_ops.py holds outputs and all three
 // gradients against torch's math attention (<= 2e-5 / 2e-4 . max) and the dropout path through a mask read back from the kernel.
+#include <cstdlib>
+
 #include "amuse_dev.hpp"
 #include "amuse_host.hpp"
 
 namespace amuse {
 namespace {
 
-constexpr int kAD = 32;            // head width
 constexpr int kAMaxTiles = 19;     // S <= 304
 constexpr int kAImg = kAMaxTiles * 2 * 64;   // f32x4 per image (38,912 B)
 
@@ -42,17 +43,27 @@ __device__ __forceinline__ float keep_scale(uint32_t key, uint32_t bh, int i, in
     return hash32(idx ^ key) >= thr ? scale : 0.f;
 }
 
-// stage rows [0, S) x 32 columns at `src` (row stride `ld` floats) as R / T images; rows >= S are zero.  All threads of the workgroup.
-__device__ __forceinline__ void stage_images(const float* src, int ld, int S, int ntiles, f32x4* R, f32x4* T, float mul = 1.0f) {
-    for (int i = threadIdx.x; i < ntiles * 16 * 8; i += blockDim.x) {
-        const int row = i >> 3, c4 = i & 7;                       // 4 consecutive columns 4 c4 ..
-        const f32x4 v = row < S ? ld4(src + (size_t)row * ld + 4 * c4) * mul : splat4(0.f);
+// stage rows [0, S) x 32 columns at `src` (row stride `ld` floats) as R / T images; rows >= S are zero.  All 512 threads of the workgroup; a thread's
+// (up to five) loads are all in flight before its first LDS write.
+__device__ __forceinline__ void stage_images(const float* src, int ld, int S, int ntiles, f32x4* R, f32x4* T) {
+    constexpr int kMax = (kAMaxTiles * 16 * 8 + 511) / 512;
+    const int n = ntiles * 16 * 8;
+    f32x4 v[kMax];
+#pragma unroll
+    for (int k = 0; k < kMax; ++k) {
+        const int i = threadIdx.x + 512 * k, row = i >> 3, c4 = i & 7;   // 4 consecutive columns 4 c4 ..
+        v[k] = (i < n && row < S) ? ld4(src + (size_t)row * ld + 4 * c4) : splat4(0.f);
+    }
+#pragma unroll
+    for (int k = 0; k < kMax; ++k) {
+        const int i = threadIdx.x + 512 * k, row = i >> 3, c4 = i & 7;
+        if (i >= n) break;
         const int tile = row >> 4, r = row & 15, half = c4 >> 2, g = c4 & 3;
-        if (R) R[(tile * 2 + half) * 64 + 16 * g + r] = v;
+        if (R) R[(tile * 2 + half) * 64 + 16 * g + r] = v[k];
         if (T) {   // element (row, col = 4 c4 + e) -> lane (g' = r / 4, r' = col % 16), slot m = r % 4
             float* t = reinterpret_cast<float*>(T + (tile * 2 + half) * 64 + 16 * (r >> 2)) + (r & 3);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) t[((4 * g + e) & 15) * 4] = v[e];
+            for (int e = 0; e < 4; ++e) t[(4 * g + e) * 4] = v[k][e];
         }
     }
 }
@@ -89,8 +100,8 @@ struct AttnArgs {
 };
 constexpr float kScaleLog2 = 0.17677669529663687f * 1.44269504088896340736f;   // 1 / sqrt(32) . log2 e
 
-// ---------------------------------------------------------------- forward: grid (B 4, 2 query halves), 256 threads
-__global__ __launch_bounds__(256) void k_attn_fwd(AttnArgs a) {
+// ---------------------------------------------------------------- forward: grid (B 4, query parts), eight waves
+__global__ __launch_bounds__(512) void k_attn_fwd(AttnArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     f32x4* RK = reinterpret_cast<f32x4*>(smem);
     f32x4* TV = RK + kAImg;
@@ -101,8 +112,8 @@ __global__ __launch_bounds__(256) void k_attn_fwd(AttnArgs a) {
     stage_images(base + 128, 384, S, nt, RK, nullptr);
     stage_images(base + 256, 384, S, nt, nullptr, TV);
     __syncthreads();
-    const int nwq = 4 * gridDim.y;                                   // query tiles are dealt round-robin over (half, wave)
-    for (int it = blockIdx.y * 4 + wave; it < nt; it += nwq) {
+    const int nw = blockDim.x >> 6, nwq = nw * gridDim.y;           // query tiles are dealt round-robin over (part, wave)
+    for (int it = blockIdx.y * nw + wave; it < nt; it += nwq) {
         const int qi = 16 * it + c;
         f32x4 q[2];
 #pragma unroll
@@ -298,8 +309,10 @@ int amuse_train_attn_fwd(const float* qkv, int B, int S, float p, uint64_t seed,
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_attn_bwd), hipFuncAttributeMaxDynamicSharedMemorySize, kBwdLds));
         once.set(dev_);
     }
-    const int halves = (S > 64 && B * 4 < 512) ? 2 : 1;   // two workgroups per (clip, head) while that fills the chip
-    hipLaunchKernelGGL(k_attn_fwd, dim3(B * 4, halves), dim3(256), kFwdLds, (hipStream_t)stream, a);
+    // two workgroups per (clip, head) while that fills the chip; eight waves each (two per SIMD: one's softmax under the other's MFMAs)
+    static const int env_p = [] { const char* e = getenv("AMUSE_ATTN_FWD_PARTS"); return e ? atoi(e) : 0; }();
+    const int parts = env_p > 0 ? env_p : ((S > 64 && B * 4 < 512) ? 2 : 1);
+    hipLaunchKernelGGL(k_attn_fwd, dim3(B * 4, parts), dim3(512), kFwdLds, (hipStream_t)stream, a);
     HIP_TRY(hipGetLastError());
     return 0;
 }
