@@ -1,7 +1,8 @@
 """A transformer layer of the train_gesture step as ONE autograd.Function (BASELINE config 4; reference scripts/trainer.py:335-498 runs
 utils/cross_attention.py:259-272 (TransformerEncoderLayer.forward_post) and :323-345 (TransformerDecoderLayer.forward_post) op by op under
 autograd): per direction TWO calls into the library (csrc/k_train.hip: amuse_train_linear_fwd + amuse_train_layer_fwd, amuse_train_layer_bwd +
-amuse_train_linear_bwd) around the vendor's fused self-attention kernel (aten's efficient-attention forward / backward ops, called directly).  Inside
+amuse_train_linear_bwd) around the self-attention core - the library's fp32 MFMA kernels (csrc/k_train_attn.hip; AMUSE_TRAIN_ATTN=vendor: aten's
+efficient-attention forward / backward ops, called directly).  Inside
 the calls the plain GEMMs go to rocBLAS straight from C++ and everything between them - biases, the three dropouts, residual adds, LayerNorms, GELU,
 the decoder's one-key cross-attention and every bias / LayerNorm gradient reduction - runs in the hand-written HIP kernels, forward and backward.
 
@@ -12,7 +13,8 @@ adds, GELU, the bias gradients' column sums: ~9 of the 24 ms) shrinks to one pas
 
 Dropout: counter-based masks (k_train.hip), keyed by torch's seed of the process (`torch.initial_seed()`: the trainer seeds every rank
 differently) and a host-side call counter - nothing stored, the backward kernels regenerate them.  The draws differ from nn.Dropout's (another
-generator); the distribution is the same.  Attention dropout stays inside the vendor kernel (its own Philox state, returned and replayed).
+generator); the distribution is the same.  Attention dropout: a hash of (seed, offset, clip, head, query, key) inside the attention kernels (the vendor
+kernel, when selected, keeps its own Philox state, returned and replayed).
 
 The eager layers of nn_modules.py remain the definition (CPU, key-padding masks, AMUSE_TRAIN_FUSED=0); tests/test_gpu_train_ops.py pins this
 path to them: outputs and every gradient, eval mode exactly the same arithmetic, train mode through the masks.
