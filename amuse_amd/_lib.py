@@ -45,7 +45,8 @@ class TrainLayer(C.Structure):
     _fields_ = ([("rows", C.c_long), ("B", C.c_int), ("S", C.c_int), ("H", C.c_int), ("ff", C.c_int), ("p", C.c_float), ("p_attn", C.c_float),
                  ("seed", C.c_uint64), ("off", C.c_uint64 * 5)]
                 + [(n, _FP) for n in ("Wo bo g1 be1 Wv bv Wc bc g2 be2 W1 b1 W2 b2 g3 be3 x o2 mem x1 zh1 r1 c vk xm zh2 r2 h a out zh3 r3 tmp dout dx do2 dmem "
-                                      "dWo dbo dg1 dbe1 dWv dbv dWc dbc dg2 dbe2 dW1 db1 dW2 db2 dg3 dbe3 s128a s128b s512a s512b sdc ws").split()])
+                                      "dWo dbo dg1 dbe1 dWv dbv dWc dbc dg2 dbe2 dW1 db1 dW2 db2 dg3 dbe3 s128a s128b s512a s512b sdc ws Win bin qkv lse dqkv dWin dbin").split()]
+                + [("off_self", C.c_uint64)])
 
 
 class Schedule(C.Structure):

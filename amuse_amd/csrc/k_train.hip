@@ -513,6 +513,11 @@ int amuse_train_layer_fwd(const amuse_train_layer* L, void* stream) {
     void* h;
     TRY(blas_handle(st, &h));
     const long rows = L->rows;
+    if (L->Win) {   // the self-attention in the same call: packed in-projection, then the attention core into o2
+        if (!L->qkv || !L->lse || L->H != 4) return fail(AMUSE_EINVAL, "amuse_train_layer: self-attention asked for without qkv / lse buffers, or heads != 4");
+        TRY(amuse_train_linear_fwd(L->x, L->Win, L->bin, rows, 128, 384, L->qkv, stream));
+        TRY(amuse_train_attn_fwd(L->qkv, L->B, L->S, L->p_attn, L->seed, L->off_self, const_cast<float*>(L->o2), L->lse, nullptr, stream));
+    }
     // x1 = norm1(x + dropout1(o2 Wo^T + bo))
     TRY(rm_gemm(h, false, true, rows, 128, 128, L->o2, L->Wo, L->tmp, false));
     ln_fwd_launch(L->x, L->tmp, L->bo, L->g1, L->be1, thr, scale, L->seed, L->off[0], rows, L->x1, L->zh1, L->r1, st);
@@ -587,6 +592,11 @@ int amuse_train_layer_bwd(const amuse_train_layer* L, void* stream) {
     // self-attention's out_proj
     TRY(rm_gemm(h, true, false, 128, 128, rows, L->s128b, L->o2, L->dWo, false));
     TRY(rm_gemm(h, false, false, rows, 128, 128, L->s128b, L->Wo, L->do2, false));
+    if (L->Win) {   // the attention's backward pass and the in-projection's in the same call
+        if (!L->qkv || !L->lse || !L->dqkv || !L->dWin) return fail(AMUSE_EINVAL, "amuse_train_layer (backward): self-attention buffers missing");
+        TRY(amuse_train_attn_bwd(L->qkv, L->o2, L->lse, L->do2, L->B, L->S, L->p_attn, L->seed, L->off_self, L->dqkv, stream));
+        TRY(amuse_train_linear_bwd(L->dqkv, L->x, L->Win, rows, 128, 384, L->dWin, L->dbin, L->dx, 1, L->ws, stream));
+    }
     HIP_TRY(hipGetLastError());
     return 0;
 }

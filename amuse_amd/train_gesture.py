@@ -520,7 +520,7 @@ def bench_main(args):
             "ms_per_step": round(elapsed / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"train_gesture (configs/diff_latent_v2.json): prior encode/decode + epsilon loss under autograd "
-                                   f"(fp32; transformer layers = one autograd.Function each on the library's layer entry points: HIP glue kernels + rocBLAS GEMMs + the vendor attention op{'' if __import__('amuse_amd.train_ops', fromlist=['x']).enabled() else ' - SWITCHED OFF: eager torch'}), in-loop DDIM-50 sampler + decode on the HIP kernels (bf16), AdamW(1e-4), one flat "
+                                   f"(fp32; transformer layers = one autograd.Function each on the library's layer entry points: HIP glue + fp32 attention kernels, rocBLAS GEMMs{'' if __import__('amuse_amd.train_ops', fromlist=['x']).enabled() else ' - SWITCHED OFF: eager torch'}), in-loop DDIM-50 sampler + decode on the HIP kernels (bf16), AdamW(1e-4), one flat "
                                    f"all-reduce of {tr.n_grad_elements():,} fp32 gradients; batch {bsz} per GPU, {bsz * world} global; "
                                    f"vertex-displacement loss off (needs SMPL-X assets)",
                        "batch_per_gpu": bsz, "grad_elements": tr.n_grad_elements()},

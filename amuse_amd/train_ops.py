@@ -212,7 +212,8 @@ _DEC_PARAMS = ("Wo", "bo", "g1", "be1", "Wv", "bv", "Wc", "bc", "g2", "be2", "W1
 
 
 def _layer_forward(ctx, x, mem, Win, bin_, prm: dict, H: int, p: float, p_attn: float):
-    """One call into the library in front of the attention (packed in-projection), the vendor's attention, one call behind it (amuse_train_layer_fwd)."""
+    """ONE call into the library (amuse_train_layer_fwd: in-projection, attention, the rest of the layer) - or, with aten's attention, the in-projection call, aten's op,
+    and the layer call behind it."""
     B, S, D = x.shape
     rows, ff, dev = B * S, prm["W1"].shape[0], x.device
     st = _st(dev)
@@ -220,14 +221,13 @@ def _layer_forward(ctx, x, mem, Win, bin_, prm: dict, H: int, p: float, p_attn: 
     x2 = _c(x).view(rows, D)
     keep = any(ctx.needs_input_grad)                       # (no-grad passes - the iteration's second encode - keep nothing beyond the call)
     qkv = torch.empty(rows, 3 * D, device=dev, dtype=torch.float32)
-    _lib.check(lib.amuse_train_linear_fwd(x2.data_ptr(), Win.data_ptr(), bin_.data_ptr(), rows, D, 3 * D, qkv.data_ptr(), stream))
     own = own_attention(S, H, D)
-    if own:   # the library's fp32 attention (k_train_attn.hip): mask = hash of (seed, offset, clip, head, query, key)
-        seed_a, off_a = _seed(), next_offset()
-        o2, lse = attn_fwd(qkv, B, S, p_attn, seed_a, off_a)
+    if own:   # the library's fp32 attention (k_train_attn.hip) inside the layer call below: mask = hash of (seed, offset, clip, head, query, key)
+        o2 = torch.empty(rows, D, device=dev, dtype=torch.float32)
+        lse = torch.empty(B, H, S, device=dev, dtype=torch.float32)
         ao, ps, po = o2, o2, o2          # (placeholders in the saved list)
     else:     # the vendor's fused kernel (AMUSE_TRAIN_ATTN=vendor, or shapes the library's kernels do not take)
-        seed_a = off_a = 0
+        _lib.check(lib.amuse_train_linear_fwd(x2.data_ptr(), Win.data_ptr(), bin_.data_ptr(), rows, D, 3 * D, qkv.data_ptr(), stream))
         q, k, v = (t.transpose(1, 2) for t in qkv.view(B, S, 3, H, D // H).unbind(2))   # (B, H, S, d) views
         ao, lse, ps, po = _sdpa(q, k, v, None, True, p_attn, False)
         o2 = ao.transpose(1, 2).reshape(rows, D)
@@ -242,6 +242,8 @@ def _layer_forward(ctx, x, mem, Win, bin_, prm: dict, H: int, p: float, p_attn: 
     for n, t in prm.items():
         setattr(L, n, t.data_ptr())
     L.x, L.o2 = x2.data_ptr(), o2.data_ptr()
+    if own:
+        L.Win, L.bin, L.qkv, L.lse, L.off_self = Win.data_ptr(), bin_.data_ptr(), qkv.data_ptr(), lse.data_ptr(), next_offset()
     L.x1, L.zh1, L.out, L.zh3, L.tmp = (b128[i].data_ptr() for i in range(5))
     rs = b128[n128 - 1].data_ptr()                                                        # the three [rows] vectors of 1 / sigma
     L.r1, L.r2, L.r3 = rs, rs + 4 * rows, rs + 8 * rows
@@ -255,13 +257,13 @@ def _layer_forward(ctx, x, mem, Win, bin_, prm: dict, H: int, p: float, p_attn: 
     _lib.check(lib.amuse_train_layer_fwd(C.byref(L), stream))
     if keep:
         ctx.save_for_backward(x2, qkv, ao, lse, ps, po, o2, b128, b512, Win, *((mem2, c) if dec else ()), *prm.values())
-        ctx.L, ctx.cfg = L, (B, S, D, H, p_attn, dec, tuple(prm), own, seed_a, off_a)
+        ctx.L, ctx.cfg = L, (B, S, D, H, p_attn, dec, tuple(prm), own)
     return b128[2].view(B, S, D)
 
 
 def _layer_backward(ctx, dout):
     t = ctx.saved_tensors
-    B, S, D, H, p_attn, dec, names, own, seed_a, off_a = ctx.cfg
+    B, S, D, H, p_attn, dec, names, own = ctx.cfg
     x2, qkv, ao, lse, ps, po, o2, b128, b512, Win = t[:10]
     prm = dict(zip(names, t[12 if dec else 10:]))
     rows, ff, dev = B * S, b512.shape[2], x2.device
@@ -283,18 +285,20 @@ def _layer_backward(ctx, dout):
     L.dout = dout.data_ptr()
     L.dx, L.do2, L.s128a, L.s128b = (g128[i].data_ptr() for i in range(4))
     L.s512a, L.s512b, L.ws = g512[0].data_ptr(), g512[1].data_ptr(), st["ws"].data_ptr()
-    _lib.check(lib.amuse_train_layer_bwd(C.byref(L), stream))
-    if own:
-        dqkv = attn_bwd(qkv, o2, lse, g128[1], B, S, p_attn, seed_a, off_a)
+    dWin = torch.empty_like(Win)
+    dbin = torch.empty(3 * D, device=dev, dtype=torch.float32)
+    if own:   # one call: the layer, the attention's backward pass and the in-projection's
+        dqkv = torch.empty(rows, 3 * D, device=dev, dtype=torch.float32)
+        L.dqkv, L.dWin, L.dbin = dqkv.data_ptr(), dWin.data_ptr(), dbin.data_ptr()
+        _lib.check(lib.amuse_train_layer_bwd(C.byref(L), stream))
     else:
+        _lib.check(lib.amuse_train_layer_bwd(C.byref(L), stream))
         do = g128[1].view(B, S, H, D // H).transpose(1, 2)
         q, k, v = (u.transpose(1, 2) for u in qkv.view(B, S, 3, H, D // H).unbind(2))
         dq, dk, dv, _ = _sdpa_bwd(do, q, k, v, None, ao, lse, ps, po, p_attn, (True, True, True, False), False)
         dqkv = torch.stack([dq.transpose(1, 2), dk.transpose(1, 2), dv.transpose(1, 2)], dim=2).view(rows, 3 * D)
-    dWin = torch.empty_like(Win)
-    dbin = torch.empty(3 * D, device=dev, dtype=torch.float32)
-    _lib.check(lib.amuse_train_linear_bwd(dqkv.data_ptr(), x2.data_ptr(), Win.data_ptr(), rows, D, 3 * D, dWin.data_ptr(), dbin.data_ptr(), g128[0].data_ptr(), 1,
-                                          st["ws"].data_ptr(), stream))
+        _lib.check(lib.amuse_train_linear_bwd(dqkv.data_ptr(), x2.data_ptr(), Win.data_ptr(), rows, D, 3 * D, dWin.data_ptr(), dbin.data_ptr(), g128[0].data_ptr(), 1,
+                                              st["ws"].data_ptr(), stream))
     return g128[0].view(B, S, D), (dmem if dec else None), dWin, dbin, grads
 
 

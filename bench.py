@@ -517,7 +517,7 @@ def main():
             try:
                 tl = json.loads(r.stdout.strip().splitlines()[-1])
                 line["train_gesture"] = {"batch_per_gpu": 32, "it_per_s": tl["value"], "ms_per_iteration": tl["ms_per_step"], "how": "python bench.py --config train --steps 40 "
-                                         "--warmup 15 as a child process; transformer layers on the library's layer-level entry points (amuse_train_*), DESIGN.md 4.6"}
+                                         "--warmup 15 as a child process; transformer layers (incl. their fp32 attention) on the library's layer-level entry points (amuse_train_*), DESIGN.md 4.6"}
             except Exception as e:   # the headline must not depend on the extra
                 line["train_gesture"] = {"error": f"{type(e).__name__}: {e}; stderr tail: {r.stderr[-300:]}"}
         if world == 1 and not args.no_cpu_baseline:

@@ -391,6 +391,12 @@ typedef struct amuse_train_layer {
     float *dWo, *dbo, *dg1, *dbe1, *dWv, *dbv, *dWc, *dbc, *dg2, *dbe2, *dW1, *db1, *dW2, *db2, *dg3, *dbe3;
     float *s128a, *s128b, *s512a, *s512b, *sdc; /* backward scratch: 2 x [rows][128], 2 x [rows][ff], [B][128] */
     float* ws;                                  /* amuse_train_ws_floats() floats */
+    /* optional: the layer's self-attention inside the same calls (Win != NULL; 4 heads, S <= 304).  Forward: qkv = x Win^T + bin, o2 = attention(qkv)
+     * (o2 then is an OUTPUT buffer), lse kept; backward: d(qkv) from d(o2), dWin / dbin, and dx receives the attention's share too. */
+    const float *Win, *bin;                     /* self_attn.in_proj_weight [384][128], in_proj_bias [384] */
+    float *qkv, *lse;                           /* [rows][384], [B][4][S]: kept for the backward pass */
+    float *dqkv, *dWin, *dbin;                  /* backward: [rows][384] scratch, the in-projection's gradients */
+    uint64_t off_self;                          /* mask offset of the self-attention's dropout */
 } amuse_train_layer;
 int amuse_train_layer_fwd(const amuse_train_layer* layer, void* stream);
 int amuse_train_layer_bwd(const amuse_train_layer* layer, void* stream);
