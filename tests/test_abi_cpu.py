@@ -172,3 +172,36 @@ def test_schedule_known_answers():
     sb, sa, c0, cx, ce, sg, clip, _ = d.coef[i].astype(np.float64)
     nx = c0 * np.clip((xt - sb * eps) / sa, -clip, clip) + ce * eps
     assert np.abs(nx - (ab[t - 20] ** 0.5 * x0 + (1 - ab[t - 20]) ** 0.5 * eps)).max() < 1e-5
+
+
+def test_training_entry_points_validate_their_arguments_without_touching_the_gpu():
+    """The amuse_train_* family (csrc/k_train.hip, k_train_attn.hip) rejects bad shapes / missing pointers with AMUSE_EINVAL and a message before any HIP call."""
+    import ctypes as C
+    from amuse_amd import _lib
+    lib = _lib.load()
+    err = lambda: lib.amuse_last_error().decode()
+    assert lib.amuse_train_ws_floats() >= 8 * 128 * 1024
+    one = 0x1000                                              # (a non-null address that is never dereferenced: every call below fails in its checks)
+    assert lib.amuse_train_ln_fwd(None, None, None, one, one, 0.1, 1, 1, 16, one, None, None, None) != 0 and "must be given" in err()
+    assert lib.amuse_train_ln_fwd(None, one, None, one, one, 0.1, 1, 1, 0, one, None, None, None) != 0 and "rows" in err()
+    assert lib.amuse_train_ln_fwd(None, one, None, one, one, 1.0, 1, 1, 16, one, None, None, None) != 0 and "dropout" in err()
+    assert lib.amuse_train_ln_bwd(one, None, one, one, one, 0.0, 1, 1, 16, None, one, None, None, None, None, None) != 0 and "NULL" in err()
+    assert lib.amuse_train_bias_gelu_drop_fwd(one, one, 0.0, 1, 1, 16, 510, one, None) != 0 and "multiple of 4" in err()
+    assert lib.amuse_train_bias_gelu_drop_bwd(one, one, one, 0.0, 1, 1, 16, 2048, one, one, one, None) != 0
+    assert lib.amuse_train_colsum(one, 16, 6, one, one, None) != 0
+    assert lib.amuse_train_linear_fwd(one, one, None, 16, 128, 333, one, None) != 0 and "multiple of 4" in err()
+    assert lib.amuse_train_linear_bwd(one, one, one, 16, 128, 384, one, one, one, 0, None, None) != 0 and "workspace" in err()
+    assert lib.amuse_train_adamw(one, one, one, one, 0, 1e-4, 0.9, 0.999, 1e-8, 0.01, 1, None) != 0
+    assert lib.amuse_train_adamw(one, one, one, one, 8, 1e-4, 0.9, 0.999, 1e-8, 0.01, 0, None) != 0 and "step" in err()
+    assert lib.amuse_train_attn_fwd(one, 2, 305, 0.0, 1, 1, one, one, None, None) != 0 and "1..304" in err()
+    assert lib.amuse_train_attn_fwd(None, 2, 300, 0.0, 1, 1, one, one, None, None) != 0
+    assert lib.amuse_train_attn_bwd(one, one, one, None, 2, 300, 0.0, 1, 1, one, None) != 0
+    L = _lib.TrainLayer()
+    assert lib.amuse_train_layer_fwd(None, None) != 0 and "NULL" in err()
+    L.rows, L.B, L.S, L.H, L.ff = 600, 2, 299, 4, 512
+    assert lib.amuse_train_layer_fwd(C.byref(L), None) != 0 and "rows" in err()
+    L.S = 300
+    assert lib.amuse_train_layer_fwd(C.byref(L), None) != 0 and "required pointer" in err()
+    L.H = 3
+    assert lib.amuse_train_layer_bwd(C.byref(L), None) != 0 and "heads" in err()
+
