@@ -250,6 +250,7 @@ class GestureTrainer:
         if self.device.type == "cuda" and os.environ.get("AMUSE_TRAIN_BLAS", "rocblas") == "rocblas":
             torch.backends.cuda.preferred_blas_library("cublas")
         self._ar_events: list = []
+        self._side_stream = None
 
     def n_grad_elements(self) -> int:
         return int(self.flat_grad.numel())
@@ -259,11 +260,6 @@ class GestureTrainer:
         prior, ldm = self.model["prior"], self.model["ldm"]
         motion = motion_to_feats(batch["ld_motion"].to(self.device, torch.float32))
         lengths = [SEQ_LEN] * motion.shape[0]
-        motion_z, dist_m = prior.encode(motion, lengths)
-        if eps_enc is not None:                       # explicit rsample draw (tests): z = mu + std * eps
-            motion_z = dist_m.loc + dist_m.scale * eps_enc.to(self.device)
-        feats_rst = prior.decode(motion_z, lengths)
-        dist_ref = torch.distributions.Normal(torch.zeros_like(dist_m.loc), torch.ones_like(dist_m.scale))
         con, emo, sty = batch["ld_audio_con"], batch.get("ld_audio_emo"), batch.get("ld_audio_sty")
         if self.kind in ("emotion", "baseline"):
             sty = None
@@ -272,13 +268,31 @@ class GestureTrainer:
         con = con.to(self.device)
         emo = emo.to(self.device) if emo is not None else None
         sty = sty.to(self.device) if sty is not None else None
+        # The no-gradient half (in-loop DDIM-50 + decode on the HIP kernels: ~1.7 ms of a latency-bound kernel on 16 of the 256 CUs) depends on the weights and the
+        # conditions only: on the GPU it runs on a stream of its own beside the networks' forward pass and is joined in front of the losses.
+        gen, side = None, None
+        if self.inner_sampler is not None:
+            if self.device.type == "cuda" and os.environ.get("AMUSE_TRAIN_SAMPLER_STREAM", "1") != "0":
+                if self._side_stream is None:
+                    self._side_stream = torch.cuda.Stream(self.device)
+                side = self._side_stream
+                side.wait_stream(torch.cuda.current_stream(self.device))     # the weights of the last optimizer step, the conditions
+                with torch.cuda.stream(side), torch.no_grad():
+                    gen = self.inner_sampler(con, emo, sty, motion.shape[0])
+        motion_z, dist_m = prior.encode(motion, lengths)
+        if eps_enc is not None:                       # explicit rsample draw (tests): z = mu + std * eps
+            motion_z = dist_m.loc + dist_m.scale * eps_enc.to(self.device)
+        feats_rst = prior.decode(motion_z, lengths)
+        dist_ref = torch.distributions.Normal(torch.zeros_like(dist_m.loc), torch.ones_like(dist_m.scale))
         with torch.no_grad():
             inferred_z, dist_i = prior.encode(motion, lengths)
             if eps_inf is not None:
                 inferred_z = dist_i.loc + dist_i.scale * eps_inf.to(self.device)
         n_set = ldm.diffusion_forward(inferred_z, con, emo, sty, lengths=lengths, noise=noise, timesteps=timesteps)
-        gen = None
-        if self.inner_sampler is not None:            # inverse diffusion (no gradient): the HIP sampler + decode
+        if side is not None:                          # join: the losses read `gen`, and the optimizer step must not overtake the sampler's reads of the weights
+            torch.cuda.current_stream(self.device).wait_stream(side)
+            gen.record_stream(torch.cuda.current_stream(self.device))
+        elif self.inner_sampler is not None:          # inverse diffusion (no gradient): the HIP sampler + decode
             with torch.no_grad():
                 gen = self.inner_sampler(con, emo, sty, motion.shape[0])
         rs_set = {"m_ref": motion, "m_rst": feats_rst, "dist_m": dist_m, "dist_ref": dist_ref, "noise_pred": n_set["noise_pred"],
