@@ -32,6 +32,7 @@ def _kernels(src, extra=()):
     ("k_vae_fused.hip", ("-fno-honor-nans",), 56),   # fused decoder: cold per-block / per-tile values only (150 before round 3; 21 in the product instantiation, 53 in the tapped one)
     ("k_den_fused.hip", ("-fno-honor-nans",), 32),   # fused pose-space denoiser step (26)
     ("k_train.hip", (), 0),               # training-step glue kernels
+    ("k_train_attn.hip", (), 0),          # training-step attention forward / backward (fp32 MFMA)
 ])
 def test_register_budget_and_spills(src, extra, max_spills):
     for name, (vgprs, spills) in _kernels(src, extra).items():
