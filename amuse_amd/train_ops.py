@@ -1,8 +1,8 @@
 """A transformer layer of the train_gesture step as ONE autograd.Function (BASELINE config 4; reference scripts/trainer.py:335-498 runs
 utils/cross_attention.py:259-272 (TransformerEncoderLayer.forward_post) and :323-345 (TransformerDecoderLayer.forward_post) op by op under
-autograd): per direction TWO calls into the library (csrc/k_train.hip: amuse_train_linear_fwd + amuse_train_layer_fwd, amuse_train_layer_bwd +
-amuse_train_linear_bwd) around the self-attention core - the library's fp32 MFMA kernels (csrc/k_train_attn.hip; AMUSE_TRAIN_ATTN=vendor: aten's
-efficient-attention forward / backward ops, called directly).  Inside
+autograd): per direction ONE call into the library (csrc/k_train.hip: amuse_train_layer_fwd / amuse_train_layer_bwd - the packed in-projection, the
+self-attention core on the library's fp32 MFMA kernels (csrc/k_train_attn.hip), and the rest of the layer; with AMUSE_TRAIN_ATTN=vendor aten's
+efficient-attention forward / backward ops sit between amuse_train_linear_* and amuse_train_layer_* calls instead).  Inside
 the calls the plain GEMMs go to rocBLAS straight from C++ and everything between them - biases, the three dropouts, residual adds, LayerNorms, GELU,
 the decoder's one-key cross-attention and every bias / LayerNorm gradient reduction - runs in the hand-written HIP kernels, forward and backward.
 
