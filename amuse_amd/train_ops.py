@@ -244,16 +244,17 @@ def _layer_forward(ctx, x, mem, Win, bin_, prm: dict, H: int, p: float, p_attn: 
     L.x, L.o2 = x2.data_ptr(), o2.data_ptr()
     if own:
         L.Win, L.bin, L.qkv, L.lse, L.off_self = Win.data_ptr(), bin_.data_ptr(), qkv.data_ptr(), lse.data_ptr(), next_offset()
-    L.x1, L.zh1, L.out, L.zh3, L.tmp = (b128[i].data_ptr() for i in range(5))
-    rs = b128[n128 - 1].data_ptr()                                                        # the three [rows] vectors of 1 / sigma
+    p128, blk = b128.data_ptr(), 4 * rows * D                                             # (addresses by arithmetic: a tensor view per pointer costs ~1 us of host time each)
+    L.x1, L.zh1, L.out, L.zh3, L.tmp = (p128 + i * blk for i in range(5))
+    rs = p128 + (n128 - 1) * blk                                                          # the three [rows] vectors of 1 / sigma
     L.r1, L.r2, L.r3 = rs, rs + 4 * rows, rs + 8 * rows
-    L.h, L.a = b512[0].data_ptr(), b512[1].data_ptr()
+    L.h, L.a = b512.data_ptr(), b512.data_ptr() + 4 * rows * ff
     c = None
     if dec:
         mem2 = _c(mem).view(B, D)
         c = torch.empty(B, D, device=dev, dtype=torch.float32)
         L.mem, L.c = mem2.data_ptr(), c.data_ptr()
-        L.vk, L.xm, L.zh2 = (b128[i].data_ptr() for i in (5, 6, 7))
+        L.vk, L.xm, L.zh2 = (p128 + i * blk for i in (5, 6, 7))
     _lib.check(lib.amuse_train_layer_fwd(C.byref(L), stream))
     if keep:
         ctx.save_for_backward(x2, qkv, ao, lse, ps, po, o2, b128, b512, Win, *((mem2, c) if dec else ()), *prm.values())
@@ -283,8 +284,8 @@ def _layer_backward(ctx, dout):
     dmem = flat[o:o + B * D].view(B, 1, D)
     L.dmem, L.sdc = dmem.data_ptr(), flat[o + B * D:].data_ptr()
     L.dout = dout.data_ptr()
-    L.dx, L.do2, L.s128a, L.s128b = (g128[i].data_ptr() for i in range(4))
-    L.s512a, L.s512b, L.ws = g512[0].data_ptr(), g512[1].data_ptr(), st["ws"].data_ptr()
+    L.dx, L.do2, L.s128a, L.s128b = (g128.data_ptr() + i * 4 * rows * D for i in range(4))
+    L.s512a, L.s512b, L.ws = g512.data_ptr(), g512.data_ptr() + 4 * rows * ff, st["ws"].data_ptr()
     dWin = torch.empty_like(Win)
     dbin = torch.empty(3 * D, device=dev, dtype=torch.float32)
     if own:   # one call: the layer, the attention's backward pass and the in-projection's
