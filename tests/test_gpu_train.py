@@ -146,3 +146,27 @@ def test_gpu_gradients_equal_cpu_gradients():
     before = trg.flat_param.clone()
     trg.lpdm_opt.step()
     assert not torch.equal(before, trg.flat_param)
+
+
+def test_inner_sampler_on_its_own_stream_changes_nothing(monkeypatch):
+    """The no-gradient half (DDIM-50 + decode on the HIP kernels) runs on a side stream beside the forward pass (GestureTrainer.forward_losses); with the
+    same seeds the iteration's loss terms - gen_feature, which only the sampler feeds, first of all - equal the in-line order's, step after step."""
+    from amuse_amd import train_ops
+    from amuse_amd.train_gesture import build_trainer, synthetic_batch
+    res = {}
+    for side in ("1", "0"):
+        monkeypatch.setenv("AMUSE_TRAIN_SAMPLER_STREAM", side)
+        torch.manual_seed(3)
+        train_ops._OFFSET[0] = 0
+        tr = build_trainer("cuda:0", seed=1)
+        terms = []
+        for i in range(3):
+            tr.train_step(synthetic_batch(8, 10 + i, "cuda:0"))
+            terms.append({k: float(v) for k, v in tr.lpdm_losses.compute().items()})
+        res[side] = terms
+        assert (tr._side_stream is not None) == (side == "1")
+    for a, b in zip(res["1"], res["0"]):
+        assert a["gen_feature"] == b["gen_feature"] and a["gen_feature"] > 0
+        for k in a:
+            assert abs(a[k] - b[k]) <= 1e-6 * max(1.0, abs(b[k])), k
+
