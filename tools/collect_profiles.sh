@@ -38,6 +38,7 @@ tail -1 $O/bench.json > profiles/${R}_bench_line.json
 tail -1 $O/train_bench.json > profiles/${R}_train_bench_line.json
 [ -f $O/train_bench_eager.json ] && tail -1 $O/train_bench_eager.json > profiles/${R}_train_bench_line_eager_layers.json
 [ -f $O/train_profile.txt ] && cp $O/train_profile.txt profiles/${R}_train_step_torch_profile.txt
+[ -f $O/train_bench_vendor_attn.json ] && tail -1 $O/train_bench_vendor_attn.json > profiles/${R}_train_bench_line_vendor_attention.json
 [ -f $O/dec_perf.txt ] && grep -v libdrm $O/dec_perf.txt > profiles/${R}_trans_dec_sampler_perf.txt
 grep -v libdrm $O/phase8.txt > profiles/${R}_k_sample8_phase_timeline.txt
 grep -v libdrm $O/decode_perf.txt > profiles/${R}_decode_perf.txt

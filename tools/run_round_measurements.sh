@@ -11,6 +11,9 @@ timeout 600 python bench.py > $O/bench.json 2> $O/bench.err; tail -2 $O/bench.er
 timeout 300 python bench.py --config train --steps 60 --warmup 15 > $O/train_bench.json 2> $O/train_bench.err
 AMUSE_TRAIN_FUSED=0 timeout 300 python bench.py --config train --steps 60 --warmup 15 > $O/train_bench_eager.json 2> $O/train_bench_eager.err
 timeout 300 python tools/gpu_train_profile.py 32 $O/train_profile.txt > /dev/null 2>&1
+AMUSE_TRAIN_ATTN=vendor timeout 300 python bench.py --config train --steps 60 --warmup 15 > $O/train_bench_vendor_attn.json 2> /dev/null
+timeout 200 python tools/gpu_train_attn_perf.py > $O/train_attn_perf.txt 2>&1
+timeout 200 python tools/gpu_encode_fp32x_ab.py > $O/encode_fp32x_ab.txt 2>&1
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python3 bench.py --steps 3 --warmup 1 --no-extras > $O/stats.log 2>&1
 for grp in FETCH_SIZE WRITE_SIZE "TCC_HIT_sum TCC_MISS_sum" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_ANY" "SQ_INSTS_MFMA SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_INSTS_SALU"; do
   n=$(echo $grp | cut -d' ' -f1)
