@@ -242,10 +242,12 @@ __global__ __launch_bounds__(256) void k_untile_f32(const float* __restrict__ sr
 // front of every fmaxf operand and fuses pairs into v_max3_f32.  NOT inline asm: the hazard recogniser does not see through asm, and
 // a VALU read of an MFMA result needs software wait states - an asm v_max3_f32 right behind the score MFMAs read stale registers.
 __device__ __forceinline__ float max3(float a, float b, float c) { return fmaxf(fmaxf(a, b), c); }
-constexpr int kAttnQ = 256;                         // queries per workgroup: 8 waves x 2 query tiles
+constexpr int kAttnQ = 256;                         // queries per workgroup: 8 waves x 2 query tiles (NQ = 1: 128 - a launch of ONE clip, where
+                                                    // 60 workgroups leave most of the chip idle: twice the workgroups, the same bits per query tile)
 constexpr int kAttnStage = 16 * 1024;
 constexpr int kAttnLds = 3 * kAttnStage;            // 48 KiB; two workgroups per CU (registers: four waves per SIMD)
 constexpr int kAttnChunks = kAstRows / 64;          // 19
+template <int NQ>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_ast_attn(const bf16raw* __restrict__ QK, const bf16raw* __restrict__ Vt,
                                                                                             bf16raw* __restrict__ O) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -269,10 +271,10 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     };
     fetch(0, 0);
     fetch(1, 1);
-    const int qt0 = 16 * qb + 2 * wave;             // this wave's query tiles qt0, qt0 + 1 of the clip's 76
-    bf16x8 qf[2][2];
+    const int qt0 = 8 * NQ * qb + NQ * wave;        // this wave's query tiles qt0 (, qt0 + 1) of the clip's 76
+    bf16x8 qf[NQ][2];
 #pragma unroll
-    for (int q = 0; q < 2; ++q)
+    for (int q = 0; q < NQ; ++q)
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
             uint4 u = uint4{0, 0, 0, 0};
@@ -283,7 +285,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     // the q fragments are waited for HERE (they sit behind the first DMA pieces): an asm that redefines them makes hipcc put its
     // s_waitcnt in front of the loop instead of a vmcnt(0) in front of the first MFMA of every chunk, which would drain the DMA queue
 #pragma unroll
-    for (int q = 0; q < 2; ++q)
+    for (int q = 0; q < NQ; ++q)
 #pragma unroll
         for (int s = 0; s < 2; ++s) asm volatile("" : "+v"(qf[q][s]));
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // from here on only DMA is counted
@@ -295,11 +297,16 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     // the busier pipe here (5.6 VALU instructions per MFMA).  What is summed is the bf16 P the PV product uses.  Lane (g = 0, j)
     // collects query j's sum in os[q][0]; the other three lanes of the row hold 0 there and ONE butterfly at the end broadcasts it.
     const bf16x8 ones = __builtin_bit_cast(bf16x8, (lane & 15) == 0 ? uint4{0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u} : uint4{0u, 0u, 0u, 0u});
-    float m_run[2] = {0.f, 0.f};
-    f32x4 os[2] = {splat4(0.f), splat4(0.f)};
-    f32x4 o[2][4];
+    float m_run[NQ];
+    f32x4 os[NQ];
+    f32x4 o[NQ][4];
 #pragma unroll
-    for (int q = 0; q < 2; ++q)
+    for (int q = 0; q < NQ; ++q) {
+        m_run[q] = 0.f;
+        os[q] = splat4(0.f);
+    }
+#pragma unroll
+    for (int q = 0; q < NQ; ++q)
 #pragma unroll
         for (int td = 0; td < 4; ++td) o[q][td] = splat4(0.f);
     int slot = 0, fslot = 2;
@@ -313,17 +320,21 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         fslot = fslot == 2 ? 0 : fslot + 1;
         const char* sl = smem + slot * kAttnStage + lane * 16;
         slot = slot == 2 ? 0 : slot + 1;
-        f32x4 st[2][4];
+        f32x4 st[NQ][4];
 #ifdef AMUSE_ATTN_NOC
-        const f32x4 c0[2] = {splat4(0.f), splat4(0.f)};
+        f32x4 c0[NQ];
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) c0[q] = splat4(0.f);
 #else
-        const f32x4 c0[2] = {splat4(-m_run[0]), splat4(-m_run[1])};
+        f32x4 c0[NQ];
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) c0[q] = splat4(-m_run[q]);
 #endif
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const bf16x8 k0 = *reinterpret_cast<const bf16x8*>(sl + (2 * u) * 1024), k1 = *reinterpret_cast<const bf16x8*>(sl + (2 * u + 1) * 1024);
 #pragma unroll
-            for (int q = 0; q < 2; ++q) {
+            for (int q = 0; q < NQ; ++q) {
                 st[q][u] = mfma_bf16(k0, qf[q][0], c0[q]);
                 st[q][u] = mfma_bf16(k1, qf[q][1], st[q][u]);
             }
@@ -331,16 +342,16 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         // lane (g, query j): log2-domain S[j][key = 64 c + 16 u + 4 g + m] - m_run[j]
         if (c == kAttnChunks - 1) {   // keys 1214, 1215 are the clip's pad rows
 #pragma unroll
-            for (int q = 0; q < 2; ++q)
+            for (int q = 0; q < NQ; ++q)
 #pragma unroll
                 for (int u = 0; u < 4; ++u)
 #pragma unroll
                     for (int m = 0; m < 4; ++m)
                         if (64 * c + 16 * u + 4 * g + m >= kAstTokens) st[q][u][m] = -INFINITY;
         }
-        bf16x8 pb[2][2];
+        bf16x8 pb[NQ][2];
 #pragma unroll
-        for (int q = 0; q < 2; ++q) {
+        for (int q = 0; q < NQ; ++q) {
             float mx = max3(max3(st[q][0][0], st[q][0][1], st[q][0][2]), max3(st[q][0][3], st[q][1][0], st[q][1][1]), max3(st[q][1][2], st[q][1][3], st[q][2][0]));
             mx = max3(mx, max3(st[q][2][1], st[q][2][2], st[q][2][3]), max3(st[q][3][0], st[q][3][1], st[q][3][2]));
             mx = fmaxf(mx, st[q][3][3]);   // this lane's 16 scores; every chunk holds a valid key
@@ -379,17 +390,17 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
             for (int td = 0; td < 4; ++td) {
                 const bf16x8 vf = *reinterpret_cast<const bf16x8*>(sl + (8 + 2 * td + pr) * 1024);
 #pragma unroll
-                for (int q = 0; q < 2; ++q) o[q][td] = mfma_bf16(vf, pb[q][pr], o[q][td]);
+                for (int q = 0; q < NQ; ++q) o[q][td] = mfma_bf16(vf, pb[q][pr], o[q][td]);
             }
 #pragma unroll
         for (int pr = 0; pr < 2; ++pr)
 #pragma unroll
-            for (int q = 0; q < 2; ++q) os[q] = mfma_bf16(ones, pb[q][pr], os[q]);
+            for (int q = 0; q < NQ; ++q) os[q] = mfma_bf16(ones, pb[q][pr], os[q]);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the surplus fetches must not outlive the workgroup's LDS
     // o[q][td][m] = O[query j][feature 64 h + 32 (td >> 1) + 8 g + 4 (td & 1) + m]: the pair td = 2 t, 2 t + 1 is this lane's slot of tile 2 h + t
 #pragma unroll
-    for (int q = 0; q < 2; ++q) {
+    for (int q = 0; q < NQ; ++q) {
         if (qt0 + q >= kRowTiles) continue;
         const float inv = 1.0f / allreduce_g_sum(os[q][0]);
         char* dst = reinterpret_cast<char*>(O) + (((size_t)b * kRowTiles + qt0 + q) * (kAstDim / 32) + 2 * h) * 1024 + voff;
@@ -521,7 +532,11 @@ hipError_t launch_untile_f32(const float* src, float* dst, int M, int F, int row
     return hipGetLastError();
 }
 hipError_t launch_ast_attn(const unsigned short* QK, const unsigned short* Vt, unsigned short* O, int B, hipStream_t s) {
-    hipLaunchKernelGGL(k_ast_attn, dim3((kAstRows + kAttnQ - 1) / kAttnQ, kAstHeads, B), dim3(512), kAttnLds, s, QK, Vt, O);
+    // one query tile per wave for a single clip (120 instead of 60 workgroups: 2.06 -> 2.02 ms for the whole front-end; at two clips already slower); AMUSE_AST_ATTN_NQ pins it (A/B)
+    static const int env = [] { const char* e = getenv("AMUSE_AST_ATTN_NQ"); return e ? atoi(e) : 0; }();
+    const int nq = env == 1 || env == 2 ? env : (B == 1 ? 1 : 2);
+    if (nq == 1) hipLaunchKernelGGL(k_ast_attn<1>, dim3((kAstRows + kAttnQ / 2 - 1) / (kAttnQ / 2), kAstHeads, B), dim3(512), kAttnLds, s, QK, Vt, O);
+    else hipLaunchKernelGGL(k_ast_attn<2>, dim3((kAstRows + kAttnQ - 1) / kAttnQ, kAstHeads, B), dim3(512), kAttnLds, s, QK, Vt, O);
     return hipGetLastError();
 }
 hipError_t launch_ast_pool(const float* X, const float* gamma, const float* beta, int frame_based, float* pooled, int B, hipStream_t s) {
