@@ -14,6 +14,7 @@
 //                 MFMA so that the softmax runs along registers and O lands in row-lane layout.
 // The one-token cross-attention collapses to a per-clip constant (k_vae_ca in k_misc.hip).
 #include <cstdlib>
+#include <type_traits>
 
 #include "amuse_dev.hpp"
 #include "amuse_kernels.hpp"
@@ -534,8 +535,10 @@ __device__ __forceinline__ void attn_qtiles_bf16(const uint4* Kb, const uint4* V
         l_run[n] = 0.f;
         o[n][0] = o[n][1] = splat4(0.f);
     }
-#pragma unroll 1
-    for (int jp = 0; jp < kPairs; ++jp) {
+    // one pair of key tiles.  MASKED (wave-uniform) = the pair reaches past `len`: full pairs run without the compares and selects; a pair in
+    // which no row's running maximum moves keeps alpha = 1 and skips the rescaling (x * 1.0f is x): neither shortcut changes a bit
+    auto pair = [&](int jp, auto masked) {
+        constexpr bool MASKED = decltype(masked)::value;
         const OPV k0 = __builtin_bit_cast(OPV, Kb[(32 * jp + r) * 4 + g]);
         const OPV k1 = __builtin_bit_cast(OPV, Kb[(32 * jp + 16 + r) * 4 + g]);
         const OPV v0 = __builtin_bit_cast(OPV, Vt[((jp * 2 + 0) * 16 + r) * 4 + g]);
@@ -544,7 +547,7 @@ __device__ __forceinline__ void attn_qtiles_bf16(const uint4* Kb, const uint4* V
 #pragma unroll
         for (int u = 0; u < 2; ++u)
 #pragma unroll
-            for (int m = 0; m < 4; ++m) ok[u][m] = (32 * jp + 16 * u + 4 * g + m) < len;
+            for (int m = 0; m < 4; ++m) ok[u][m] = !MASKED || (32 * jp + 16 * u + 4 * g + m) < len;
 #pragma unroll
         for (int n = 0; n < NQ; ++n) {
             f32x4 st[2];
@@ -554,30 +557,39 @@ __device__ __forceinline__ void attn_qtiles_bf16(const uint4* Kb, const uint4* V
 #pragma unroll
             for (int u = 0; u < 2; ++u)
 #pragma unroll
-                for (int m = 0; m < 4; ++m) {
-                    st[u][m] *= kLog2e;
-                    mx = ok[u][m] ? fmaxf(mx, st[u][m]) : mx;
-                }
+                for (int m = 0; m < 4; ++m) mx = ok[u][m] ? fmaxf(mx, st[u][m] * kLog2e) : mx;
             mx = allreduce_g_max(mx);
-            const float m_new = fmaxf(m_run[n], mx);
-            const float alpha = (m_new == -INFINITY) ? 1.0f : __builtin_amdgcn_exp2f(m_run[n] - m_new);
+            float m_new = m_run[n], alpha = 1.0f;
+            if (__builtin_amdgcn_ballot_w64(mx > m_run[n]) != 0) {   // (uniform)
+                m_new = fmaxf(m_run[n], mx);
+                alpha = (m_new == -INFINITY) ? 1.0f : __builtin_amdgcn_exp2f(m_run[n] - m_new);
+                o[n][0] = o[n][0] * alpha;
+                o[n][1] = o[n][1] * alpha;
+                m_run[n] = m_new;
+            }
             f32x4 p[2];
             float ps = 0.f;
 #pragma unroll
             for (int u = 0; u < 2; ++u)
 #pragma unroll
                 for (int m = 0; m < 4; ++m) {
-                    p[u][m] = ok[u][m] ? __builtin_amdgcn_exp2f(st[u][m] - m_new) : 0.f;
+                    // (the maximum is taken over the ROUNDED products, the exponent is one fused multiply-add: the contraction hipcc chose
+                    // for the round-1 kernel, spelled out so that restructuring the loop cannot change the bits)
+                    p[u][m] = ok[u][m] ? __builtin_amdgcn_exp2f(__builtin_fmaf(st[u][m], kLog2e, -m_new)) : 0.f;
                     ps += p[u][m];
                 }
             ps = allreduce_g_sum(ps);
             l_run[n] = l_run[n] * alpha + ps;
-            m_run[n] = m_new;
             const OPV pb = Op::pack(p[0], p[1]);
-            o[n][0] = Op::mfma(v0, pb, o[n][0] * alpha);  // O^T[d][i] += sum_key V[key][d] P[i][key]
-            o[n][1] = Op::mfma(v1, pb, o[n][1] * alpha);
+            o[n][0] = Op::mfma(v0, pb, o[n][0]);  // O^T[d][i] += sum_key V[key][d] P[i][key]
+            o[n][1] = Op::mfma(v1, pb, o[n][1]);
         }
-    }
+    };
+    const int full = min(len / 32, kPairs);   // pairs entirely below len
+#pragma unroll 1
+    for (int jp = 0; jp < full; ++jp) pair(jp, std::false_type{});
+#pragma unroll 1
+    for (int jp = full; jp < kPairs; ++jp) pair(jp, std::true_type{});
 #pragma unroll
     for (int n = 0; n < NQ; ++n) {
         const int fq = (qt0 + 4 * n) * 16 + r;
@@ -671,8 +683,11 @@ __device__ __forceinline__ void attn_qtiles_x(const uint4* Kh, const uint4* Kl, 
         l_run[n] = 0.f;
         o[n][0] = o[n][1] = splat4(0.f);
     }
-#pragma unroll 1
-    for (int jp = 0; jp < kPairs; ++jp) {
+    // one pair of key tiles (32 keys).  MASKED = the pair reaches past `len` (at most the last pair of a full-length clip; wave-uniform): the
+    // full pairs run without the 8 compares and 16 selects.  A pair in which no row's running maximum moves (wave-uniform ballot) keeps
+    // alpha = exp2(0) = 1 and skips the rescaling of o and l - x * 1.0f is x, so both shortcuts leave every bit as it was.
+    auto pair = [&](int jp, auto masked) {
+        constexpr bool MASKED = decltype(masked)::value;
         f16x8 kh[2], kl[2], vh[2], vl[2];
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
@@ -685,7 +700,7 @@ __device__ __forceinline__ void attn_qtiles_x(const uint4* Kh, const uint4* Kl, 
 #pragma unroll
         for (int u = 0; u < 2; ++u)
 #pragma unroll
-            for (int m = 0; m < 4; ++m) ok[u][m] = (32 * jp + 16 * u + 4 * g + m) < len;
+            for (int m = 0; m < 4; ++m) ok[u][m] = !MASKED || (32 * jp + 16 * u + 4 * g + m) < len;
 #pragma unroll
         for (int n = 0; n < NQ; ++n) {
             f32x4 st[2];
@@ -701,8 +716,15 @@ __device__ __forceinline__ void attn_qtiles_x(const uint4* Kh, const uint4* Kl, 
 #pragma unroll
                 for (int m = 0; m < 4; ++m) mx = ok[u][m] ? fmaxf(mx, st[u][m]) : mx;
             mx = allreduce_g_max(mx);
-            const float m_new = fmaxf(m_run[n], mx);
-            const float alpha = (m_new == -INFINITY) ? 1.0f : __builtin_amdgcn_exp2f(m_run[n] - m_new);
+            const bool moved = __builtin_amdgcn_ballot_w64(mx > m_run[n]) != 0;   // (uniform)
+            float m_new = m_run[n], alpha = 1.0f;
+            if (moved) {
+                m_new = fmaxf(m_run[n], mx);
+                alpha = (m_new == -INFINITY) ? 1.0f : __builtin_amdgcn_exp2f(m_run[n] - m_new);
+                o[n][0] = o[n][0] * alpha;
+                o[n][1] = o[n][1] * alpha;
+                m_run[n] = m_new;
+            }
             f32x4 p[2];
             float ps = 0.f;
 #pragma unroll
@@ -714,16 +736,20 @@ __device__ __forceinline__ void attn_qtiles_x(const uint4* Kh, const uint4* Kl, 
                 }
             ps = allreduce_g_sum(ps);
             l_run[n] = l_run[n] * alpha + ps;
-            m_run[n] = m_new;
             const F16Pair pp = split_f16(p[0], p[1]);
 #pragma unroll
             for (int td = 0; td < 2; ++td) {   // O^T[d][i] += sum_key V[key][d] P[i][key]
-                o[n][td] = mfma_f16(vl[td], pp.hi, o[n][td] * alpha);
+                o[n][td] = mfma_f16(vl[td], pp.hi, o[n][td]);
                 o[n][td] = mfma_f16(vh[td], pp.lo, o[n][td]);
                 o[n][td] = mfma_f16(vh[td], pp.hi, o[n][td]);
             }
         }
-    }
+    };
+    const int full = min(len / 32, kPairs);   // pairs entirely below len
+#pragma unroll 1
+    for (int jp = 0; jp < full; ++jp) pair(jp, std::false_type{});
+#pragma unroll 1
+    for (int jp = full; jp < kPairs; ++jp) pair(jp, std::true_type{});
 #pragma unroll
     for (int n = 0; n < NQ; ++n) {
         const int fq = (qt0 + 4 * n) * 16 + r;
