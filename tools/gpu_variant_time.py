@@ -20,7 +20,10 @@ if len(sys.argv) > 1 and sys.argv[1] == "--child":
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record(); eng.sample(c, e, s, prec, seed=1); e1.record(); torch.cuda.synchronize()
             ts.append(e0.elapsed_time(e1))
-        out.append(f"B={B}: min {min(ts):.2f} med {sorted(ts)[2]:.2f}")
+        z = eng.sample(c, e, s, prec, seed=1)
+        z = z[0] if isinstance(z, (tuple, list)) else z
+        h = int(z.contiguous().view(torch.int32).to(torch.int64).sum().item()) & 0xffffffff   # (equal words = bitwise-equal variants)
+        out.append(f"B={B}: min {min(ts):.2f} med {sorted(ts)[2]:.2f} [{h:08x}]")
     print("  ".join(out))
 else:
     clips = sys.argv[1:] or ["1", "256", "768"]
