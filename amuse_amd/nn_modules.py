@@ -222,6 +222,7 @@ class MotionPrior(nn.Module):
         self.decoder = SkipStack(lambda: DecoderLayer(p=dropout))
         self.skel_embedding = nn.Linear(NFEATS, D)
         self.final_layer = nn.Linear(D, NFEATS)
+        self.validate_args = None   # passed to torch.distributions.Normal in encode
 
     def encode(self, features, lengths: Optional[List[int]] = None):
         """features (B, T, 333) -> (latent (1, B, 128) = dist.rsample(), dist = Normal(mu, exp(logvar) ** 0.5))   (vae.py:154-214)."""
@@ -238,7 +239,9 @@ class MotionPrior(nn.Module):
         out = self.encoder(xseq, key_padding_mask=kpm)
         mu, logvar = out[:, 0][None], out[:, 1][None]                      # (1, B, 128) each
         std = logvar.exp().pow(0.5)
-        d = torch.distributions.Normal(mu, std)
+        # validate_args: torch's default (None = on) checks `std > 0` ON THE HOST - two blocking device -> host reads per construction.  The trainer
+        # switches it off (train_gesture.Trainer: the step has no other host synchronisation, and a bad std shows up in the losses it logs)
+        d = torch.distributions.Normal(mu, std, validate_args=self.validate_args)
         return d.rsample(), d
 
     def decode(self, z, lengths: List[int]):

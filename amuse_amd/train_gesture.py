@@ -191,6 +191,11 @@ class GestureTrainer:
     def __init__(self, prior: MotionPrior, ldm: LatentDiffusionTrainModule, device, lr: float = 1e-4, loss_cfg: Optional[dict] = None,
                  inner_sampler: Optional[Callable] = None, process_group=None, world: int = 1, kind: Optional[str] = None):
         self.model = {"prior": prior.to(device), "ldm": ldm.to(device)}
+        # torch.distributions.Normal validates its arguments with blocking device -> host reads (6 per iteration: the host then waits for the previous
+        # iteration's backward + optimizer step before it dispatches anything of the next, tools/probes/train_host/sync_points.py).  Off on the GPU
+        # unless AMUSE_TRAIN_VALIDATE=1; a non-finite or non-positive std still surfaces in the kl_motion loss the trainer logs.
+        if torch.device(device).type == "cuda" and os.environ.get("AMUSE_TRAIN_VALIDATE", "0") != "1":
+            prior.validate_args = False
         self.device = torch.device(device)
         self.lpdm_losses = LatentPriorLosses(loss_cfg, self.device)
         self.inner_sampler = inner_sampler      # (con, emo, sty, bsz) -> noise2feats (B,300,333) or None
@@ -283,7 +288,7 @@ class GestureTrainer:
         if eps_enc is not None:                       # explicit rsample draw (tests): z = mu + std * eps
             motion_z = dist_m.loc + dist_m.scale * eps_enc.to(self.device)
         feats_rst = prior.decode(motion_z, lengths)
-        dist_ref = torch.distributions.Normal(torch.zeros_like(dist_m.loc), torch.ones_like(dist_m.scale))
+        dist_ref = torch.distributions.Normal(torch.zeros_like(dist_m.loc), torch.ones_like(dist_m.scale), validate_args=prior.validate_args)
         with torch.no_grad():
             inferred_z, dist_i = prior.encode(motion, lengths)
             if eps_inf is not None:
