@@ -22,7 +22,8 @@ namespace amuse {
 namespace {
 
 // erf of the FFN activation: 0 = libm erff (as k_vae_rows<f16x2>), 1 = Abramowitz-Stegun 7.1.26 on the hardware rcp / exp2 (|erf error| <= 1.5e-7;
-// amuse_dev.hpp gelu_erf_fast) - this kernel is VALU-throughput-bound where the sampler's critical path was latency-bound
+// amuse_dev.hpp gelu_erf_fast), 2 = the branch-free fit of the fp32x sampler (erf_bf) - re-measured with the copying wave in place: 1.97 / 1.96 / 2.05 ms per 256-clip
+// decode for 0 / 1 / 2 (profiles/r04_rows8x_erf_ab.txt): libm's form stays (the bits of the round-3 kernel)
 #ifndef AMUSE_R8_FAST_ERF
 #define AMUSE_R8_FAST_ERF 0
 #endif
@@ -299,7 +300,7 @@ __global__ __launch_bounds__(64 * (kWaves + kProdWaves)) __attribute__((amdgpu_w
                 for (int i = 0; i < 2; ++i)
 #pragma unroll
                     for (int m = 0; m < 4; ++m)
-                        hid[j][i][m] = (AMUSE_R8_ABL & 1) ? 0.5f * hid[j][i][m] : (AMUSE_R8_FAST_ERF ? gelu_erf_fast(hid[j][i][m]) : gelu_erf(hid[j][i][m]));
+                        hid[j][i][m] = (AMUSE_R8_ABL & 1) ? 0.5f * hid[j][i][m] : (AMUSE_R8_FAST_ERF == 1 ? gelu_erf_fast(hid[j][i][m]) : AMUSE_R8_FAST_ERF == 2 ? gelu_erf_bf(hid[j][i][m]) : gelu_erf(hid[j][i][m]));
                 hs[j] = split_f16(hid[j][0], hid[j][1]);
             }
             for_pairs(sg, [&](int o, f16x8 wh, f16x8 wl) {
