@@ -50,7 +50,12 @@ constexpr int kTilesPerWave = AMUSE_R8_NT;    // row tiles per wave: a weight fr
 constexpr int dma_waves(int waves) { return waves >= 8 ? 8 : 4; }
 constexpr int kStage = 16;                    // units per LDS stage (8 hi | lo pairs)
 constexpr int kStageBytes = kStage * 1024;
-constexpr int kWBufs = 3;
+// LDS stages in the weight ring (the copying wave keeps kWBufs - 1 stages ahead of the stage being read, kWBufs - 2 of them may still be in flight at a stage's end)
+#ifndef AMUSE_R8_BUFS
+#define AMUSE_R8_BUFS 3
+#endif
+constexpr int kWBufs = AMUSE_R8_BUFS;
+static_assert(kWBufs == 3 || (kProd && kWBufs <= 5), "deeper rings: copying-wave protocol only; vmcnt is a 6-bit counter");
 constexpr int kQStride = 100;                 // staging row stride (floats) of one 96-feature quarter of the last stage
 constexpr int kOffW = 0;
 constexpr int kOffBias = kWBufs * kStageBytes;          // [384] floats: in_proj bias of block `stage` / final_layer.bias (last stage)
@@ -187,23 +192,23 @@ __global__ __launch_bounds__(64 * (kWaves + kProdWaves)) __attribute__((amdgpu_w
             const bool hoisted = a.stage == 1 && a.c1 != nullptr, c1_only = a.stage == 1 && a.c1_out != nullptr;
             const int nst = c1_only ? 4 : (ENC && a.stage == kLayers ? 0 : 12) + (a.stage >= 1 ? 36 + (blk >= 4 && blk <= 7 ? 8 : 0) : 0) - (hoisted ? 4 : 0);
             const uint4* src = a.wstream + (size_t)a.stage_base[a.stage] * 64 + (hoisted ? 4 * kStage * 64 : 0) + lane;   // (hoisted: no out_proj)
-            int wb = 0;
+            int wb = 0, left = nst;   // (the kWBufs - 1 fetches past the launch's last stage repeat it: they land in free buffers, nobody reads them)
             auto fetch = [&]() {
                 const unsigned d = __builtin_amdgcn_readfirstlane(lds0 + kOffW + wb * kStageBytes);
 #pragma unroll
                 for (int i = 0; i < kStage; ++i) glds16(src + i * 64, d + i * 1024);
-                src += kStage * 64;
+                if (kWBufs == 3 || --left > 0) src += kStage * 64;
                 wb = wb == kWBufs - 1 ? 0 : wb + 1;
             };
-            fetch();
-            fetch();
-            asm volatile("s_waitcnt vmcnt(16)\n\ts_barrier" ::: "memory");
+#pragma unroll
+            for (int i = 0; i < kWBufs - 1; ++i) fetch();
+            asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(16 * (kWBufs - 2)) : "memory");
 #pragma unroll 1
             for (int n = 0; n < nst; ++n) {
                 fetch();
-                asm volatile("s_waitcnt vmcnt(16)\n\ts_barrier" ::: "memory");
+                asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(16 * (kWBufs - 2)) : "memory");
             }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the two surplus fetches must not outlive the workgroup's LDS
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the surplus fetches must not outlive the workgroup's LDS
             return;
         }
     }
