@@ -343,6 +343,32 @@ def test_in_kernel_noise_equals_explicit_counter_noise(env):
         eng.set_clips_per_group(6)
 
 
+@pytest.mark.parametrize("prec", ["fp32", "fp32x", "bf16"])
+def test_staged_decode_key_mask_edge_lengths(env, prec):
+    """The staged attention kernels treat pairs of key tiles (32 keys) below a clip's length and the pair the length falls into differently:
+    lengths on both sides of those boundaries - 1, 17 (inside the first pair), 32 / 64 / 288 (exactly on a boundary), 33, 173, 300 - against the CPU
+    oracle on the same latents, on the staged kernels and (fp32x) on the unsplit eight-wave attention behind the row kernel without split-K."""
+    orc, eng, Wp = env["orc"], env["eng"], env["Wp"]
+    lengths = [300, 173, 1, 17, 32, 33, 64, 288]
+    z = torch.randn(len(lengths), 128, generator=torch.Generator().manual_seed(11))
+    ref = orc.vae_decode(Wp, z, lengths, emulate_bf16=(prec == "bf16"))
+    tol = 5e-2 if prec == "bf16" else 2e-5
+    for path in ("staged", "fused") if prec == "fp32x" else ("staged",):
+        try:
+            eng.set_decode_path(path)
+            o = eng.vae_decode(z, lengths, prec, return_feats=True)
+        finally:
+            eng.set_decode_path("auto")
+        assert _err(o["feats"], ref) < tol, (path, _err(o["feats"], ref))
+        for b, n in enumerate(lengths):
+            assert float(o["feats"][b, n:].abs().max() if n < 300 else 0.0) == 0.0
+            assert float(o["feats"][b, :n].abs().max()) > 0.0
+        # a clip alone gives the bits it has inside the batch (its mask does not leak into its neighbours' tiles)
+        one = eng.vae_decode(z[3:4], [17], prec, return_feats=True) if path == "staged" else None
+        if one is not None:
+            assert torch.equal(one["feats"][0], o["feats"][3])
+
+
 @pytest.mark.parametrize("prec", PARITY)
 def test_vae_decode_fp32_vs_reference_golden(env, prec):
     orc, eng = env["orc"], env["eng"]
