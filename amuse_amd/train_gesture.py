@@ -248,7 +248,12 @@ class GestureTrainer:
             self.lpdm_opt = FlatAdamW(opt_params, self.flat_param, self.flat_grad, layout, lr=lr)
         else:
             self.lpdm_opt = torch.optim.AdamW(lr=lr, params=opt_params, **({"fused": True} if opt_kind == "fused" else {}))
-        self.steal = os.environ.get("AMUSE_TRAIN_GRADS", "steal") == "steal"
+        # how gradients reach the bucket (AMUSE_TRAIN_GRADS): "steal" (default) - autograd hands every parameter a fresh gradient, one multi-tensor copy packs
+        # them; "sink" - the library's layer calls write their parameter gradients straight into the bucket (train_ops.sink_begin: no AccumulateGrad work, no
+        # copy), the few eager parameters accumulate into its zeroed views; "views" - every gradient accumulates into the zeroed views.  All three fill the
+        # bucket with the same bits (tests/test_gpu_train_ops.py); on the boxes measured the step is device-bound either way (profiles/r04_train_grad_sink_ab.txt)
+        self.grads_mode = os.environ.get("AMUSE_TRAIN_GRADS", "steal")
+        self.steal = self.grads_mode == "steal"
         # the step's ~500 fp32 GEMMs are small (9,664 x 128..512 rows, weight gradients with a 9,664-long reduction): rocBLAS's
         # choices run them in 9 ms of device time per iteration where hipBLASLt's heuristics take 12.5, at a third of the host
         # time per call (a process-wide torch setting; AMUSE_TRAIN_BLAS=default leaves it alone)
@@ -320,6 +325,14 @@ class GestureTrainer:
         packs them, and p.grad points into the bucket again - what allreduce_gradients and the optimizer read."""
         if not self.steal:
             self.flat_grad.zero_()                    # the views stay attached to the bucket; backward accumulates into them
+            if self.grads_mode == "sink":
+                from . import train_ops
+                train_ops.sink_begin(self.flat_param, self.flat_grad)
+                try:
+                    loss.backward()
+                finally:
+                    train_ops.sink_end()
+                return
             loss.backward()
             return
         for p in self.params:

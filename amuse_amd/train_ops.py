@@ -68,6 +68,38 @@ def _p(t: Optional[torch.Tensor]):
     return None if t is None else t.data_ptr()
 
 
+# ---- gradient sink: while a trainer's backward pass runs, the layers' parameter gradients are written by the library STRAIGHT into the trainer's bucket -
+# the flat buffer with the layout of its flat parameter buffer (train_gesture.GestureTrainer) - instead of into fresh tensors that autograd hands to 420
+# AccumulateGrad nodes and the trainer packs with one more copy: a parameter at byte offset o of the parameter buffer has its gradient at offset o of the
+# bucket (also a row slice of a parameter, e.g. the value rows of the decoder's cross-attention in-projection).  The functions return None for a gradient
+# they wrote themselves.  A parameter that gets a second gradient in the same backward pass (no layer of the step does) takes the ordinary path: autograd
+# adds it onto the bucket's view.
+_SINK = None   # [first byte of the parameter buffer, its size in bytes, bucket address - parameter address, {addresses written in this pass}]
+
+
+def sink_begin(flat_param: torch.Tensor, flat_grad: torch.Tensor):
+    global _SINK
+    assert flat_param.is_contiguous() and flat_grad.is_contiguous() and flat_param.shape == flat_grad.shape and flat_param.dtype == flat_grad.dtype == torch.float32
+    _SINK = [flat_param.data_ptr(), flat_param.numel() * 4, flat_grad.data_ptr() - flat_param.data_ptr(), set()]
+
+
+def sink_end():
+    global _SINK
+    _SINK = None
+
+
+def _sink_ptr(t: torch.Tensor) -> int:
+    """Bucket address for the gradient of parameter (slice) t, or 0: no sink active / t outside the parameter buffer / already written in this pass."""
+    s = _SINK
+    if s is None:
+        return 0
+    a = t.data_ptr()
+    if a < s[0] or a >= s[0] + s[1] or a in s[3]:
+        return 0
+    s[3].add(a)
+    return a + s[2]
+
+
 def _c(t: torch.Tensor) -> torch.Tensor:
     assert t.dtype == torch.float32
     return t if t.is_contiguous() else t.contiguous()
@@ -259,6 +291,8 @@ def _layer_forward(ctx, x, mem, Win, bin_, prm: dict, H: int, p: float, p_attn: 
     if keep:
         ctx.save_for_backward(x2, qkv, ao, lse, ps, po, o2, b128, b512, Win, *((mem2, c) if dec else ()), *prm.values())
         ctx.L, ctx.cfg = L, (B, S, D, H, p_attn, dec, tuple(prm), own)
+        ctx.bin_ = bin_   # (address only: the gradient sink; not needed by the arithmetic)
+        ctx.sink_ok = all(ctx.needs_input_grad[2 if dec else 1:-3])   # every parameter of the layer takes a gradient
     return b128[2].view(B, S, D)
 
 
@@ -274,10 +308,15 @@ def _layer_backward(ctx, dout):
     dout = _c(dout).view(rows, D)
     g128 = torch.empty(4, rows, D, device=dev, dtype=torch.float32)                      # dx do2 s128a s128b
     g512 = torch.empty(2, rows, ff, device=dev, dtype=torch.float32)
-    sizes = {n: prm[n].numel() for n in names}
+    sink = {n: _sink_ptr(prm[n]) for n in names} if ctx.sink_ok else dict.fromkeys(names, 0)   # (gradients the library writes into the trainer's bucket itself)
+    sizes = {n: (0 if sink[n] else prm[n].numel()) for n in names}
     flat = torch.empty(sum(sizes.values()) + 2 * B * D, device=dev, dtype=torch.float32)   # the layer's parameter gradients (+ d(mem), the d(c) scratch)
     grads, o = {}, 0
     for n in names:
+        if sink[n]:
+            grads[n] = None
+            setattr(L, "d" + n, sink[n])
+            continue
         grads[n] = flat[o:o + sizes[n]].view_as(prm[n])
         setattr(L, "d" + n, grads[n].data_ptr())
         o += sizes[n]
@@ -286,11 +325,14 @@ def _layer_backward(ctx, dout):
     L.dout = dout.data_ptr()
     L.dx, L.do2, L.s128a, L.s128b = (g128.data_ptr() + i * 4 * rows * D for i in range(4))
     L.s512a, L.s512b, L.ws = g512.data_ptr(), g512.data_ptr() + 4 * rows * ff, st["ws"].data_ptr()
-    dWin = torch.empty_like(Win)
-    dbin = torch.empty(3 * D, device=dev, dtype=torch.float32)
+    bin_ = ctx.bin_
+    pW, pb = (_sink_ptr(Win), _sink_ptr(bin_)) if ctx.sink_ok and bin_ is not None else (0, 0)
+    dWin = None if pW else torch.empty_like(Win)
+    dbin = None if pb else torch.empty(3 * D, device=dev, dtype=torch.float32)
+    pW, pb = pW or dWin.data_ptr(), pb or dbin.data_ptr()
     if own:   # one call: the layer, the attention's backward pass and the in-projection's
         dqkv = torch.empty(rows, 3 * D, device=dev, dtype=torch.float32)
-        L.dqkv, L.dWin, L.dbin = dqkv.data_ptr(), dWin.data_ptr(), dbin.data_ptr()
+        L.dqkv, L.dWin, L.dbin = dqkv.data_ptr(), pW, pb
         _lib.check(lib.amuse_train_layer_bwd(C.byref(L), stream))
     else:
         _lib.check(lib.amuse_train_layer_bwd(C.byref(L), stream))
@@ -298,7 +340,7 @@ def _layer_backward(ctx, dout):
         q, k, v = (u.transpose(1, 2) for u in qkv.view(B, S, 3, H, D // H).unbind(2))
         dq, dk, dv, _ = _sdpa_bwd(do, q, k, v, None, ao, lse, ps, po, p_attn, (True, True, True, False), False)
         dqkv = torch.stack([dq.transpose(1, 2), dk.transpose(1, 2), dv.transpose(1, 2)], dim=2).view(rows, 3 * D)
-        _lib.check(lib.amuse_train_linear_bwd(dqkv.data_ptr(), x2.data_ptr(), Win.data_ptr(), rows, D, 3 * D, dWin.data_ptr(), dbin.data_ptr(), g128[0].data_ptr(), 1,
+        _lib.check(lib.amuse_train_linear_bwd(dqkv.data_ptr(), x2.data_ptr(), Win.data_ptr(), rows, D, 3 * D, pW, pb, g128[0].data_ptr(), 1,
                                               st["ws"].data_ptr(), stream))
     return g128[0].view(B, S, D), (dmem if dec else None), dWin, dbin, grads
 
@@ -345,6 +387,7 @@ class LinearFn(torch.autograd.Function):
         _lib.check(_st(x.device)["lib"].amuse_train_linear_fwd(x2.data_ptr(), W.data_ptr(), _p(b), rows, K, N, out.data_ptr(), _stream()))
         ctx.save_for_backward(x2, W)
         ctx.has_bias = b is not None
+        ctx.b = b   # (address only: the gradient sink)
         return out.view(*x.shape[:-1], N)
 
     @staticmethod
@@ -356,9 +399,11 @@ class LinearFn(torch.autograd.Function):
         rows = dy.shape[0]
         need_x, need_w, need_b = ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.has_bias and ctx.needs_input_grad[2]
         dx = torch.empty(rows, K, device=dy.device, dtype=torch.float32) if need_x else None
-        dW = torch.empty_like(W) if need_w else None
-        db = torch.empty(N, device=dy.device, dtype=torch.float32) if need_b else None
-        _lib.check(st["lib"].amuse_train_linear_bwd(dy.data_ptr(), x2.data_ptr(), W.data_ptr(), rows, K, N, _p(dW), _p(db), _p(dx), 0, st["ws"].data_ptr(), _stream()))
+        pW = _sink_ptr(W) if need_w else 0                      # (the trainer's gradient bucket, see sink_begin)
+        pb = _sink_ptr(ctx.b) if need_b else 0
+        dW = torch.empty_like(W) if need_w and not pW else None
+        db = torch.empty(N, device=dy.device, dtype=torch.float32) if need_b and not pb else None
+        _lib.check(st["lib"].amuse_train_linear_bwd(dy.data_ptr(), x2.data_ptr(), W.data_ptr(), rows, K, N, pW or _p(dW), pb or _p(db), _p(dx), 0, st["ws"].data_ptr(), _stream()))
         return (None if dx is None else dx.view(*dout.shape[:-1], K)), dW, db
 
 

@@ -176,6 +176,37 @@ def test_trainer_step_on_fused_layers_matches_the_eager_step_without_dropout(eag
     assert _rel(res[True][1], res[False][1]) < 2e-4
 
 
+def test_gradient_sink_fills_the_bucket_like_autograd_does(monkeypatch):
+    """AMUSE_TRAIN_GRADS=sink (the GPU default: the layer calls write their parameter gradients straight into the trainer's bucket, train_ops.sink_begin) against
+    "steal" (autograd hands out fresh gradients, one copy packs them) and "views": the same kernels compute the same numbers, so the bucket is BITWISE the
+    same - dropout live, the same seeds - and the parameters after two optimizer steps are too."""
+    from amuse_amd import train_gesture as tg, train_ops
+    res = {}
+    for mode in ("sink", "steal", "views"):
+        monkeypatch.setenv("AMUSE_TRAIN_GRADS", mode)
+        torch.manual_seed(9)
+        train_ops._OFFSET[0] = 0
+        tr = tg.build_trainer(DEV, seed=2, use_hip_sampler=False)
+        assert tr.grads_mode == mode
+        buckets = []
+        for i in range(2):
+            batch = tg.synthetic_batch(4, 20 + i, DEV)
+            noise = torch.randn(4, 1, 128, generator=torch.Generator().manual_seed(1 + i)).to(DEV)
+            ts = torch.tensor([3, 500, 998, 17], device=DEV)
+            eps = torch.randn(1, 4, 128, generator=torch.Generator().manual_seed(2)).to(DEV)
+            tr.train_step(batch, noise=noise, timesteps=ts, eps_enc=eps, eps_inf=eps)
+            buckets.append(tr.flat_grad.clone())
+        res[mode] = (buckets, tr.flat_param.clone())
+        assert train_ops._SINK is None                                      # (the sink is closed outside a backward pass)
+    assert float(res["sink"][0][0].abs().max()) > 0
+    used = res["steal"][0][0] != 0
+    assert float(used.float().mean()) > 0.9                                 # (the bucket really is filled: all but the parameters the step never reaches)
+    for other in ("steal", "views"):
+        for a, b in zip(res["sink"][0], res[other][0]):
+            assert torch.equal(a, b), other
+        assert torch.equal(res["sink"][1], res[other][1]), other
+
+
 def test_flat_adamw_equals_torch_adamw_and_keeps_its_state_layout():
     """train_ops.FlatAdamW (one launch per contiguous run of the flat buffers) against torch.optim.AdamW on the same parameters and gradients, five
     steps; a parameter outside the optimizer (the trainer's never-reached mem_pos.pe) is not touched; state_dict() has torch's structure."""
