@@ -317,6 +317,7 @@ struct Blas {
     std::mutex mu;
 };
 Blas g_blas;
+hipStream_t g_blas_stream[64] = {};
 int blas_handle(hipStream_t st, void** h) {
     std::lock_guard<std::mutex> lock(g_blas.mu);
     if (!g_blas.lib) {
@@ -335,11 +336,119 @@ int blas_handle(hipStream_t st, void** h) {
     dev &= 63;
     if (!g_blas.handle[dev] && g_blas.create(&g_blas.handle[dev]) != 0) return fail(AMUSE_EHIP, "rocblas_create_handle failed");
     if (g_blas.set_stream(g_blas.handle[dev], st) != 0) return fail(AMUSE_EHIP, "rocblas_set_stream failed");
+    g_blas_stream[dev] = st;   // (rm_gemm's own kernels run on the stream the handle was given)
     *h = g_blas.handle[dev];
+    return 0;
+}
+// ---- weight gradients: dW[M][N] = dy^T x over `rows` (dy [rows][M], x [rows][N], row-major).  The outputs are small (128 x 128 .. 512 x 128) and the reduction long
+// (9,600 rows): rocBLAS runs them on 9-27 workgroups with a 3-way global split - ~25 us each, 91 of them per iteration (profiles/r04_train_step_torch_profile.txt).
+// Here the ROWS are cut into chunks so that ~1,000 waves share the work: a wave owns a 32 x 32 block of dW for one chunk, v_mfma_f32_16x16x4_f32 with both operands
+// read straight from the row-major arrays - lane (g, r) of a k-step of 4 rows loads dy[k + g][m0 + 2 r .. + 1] and x[k + g][n0 + 2 r .. + 1] (two 8-byte loads, the 16
+// lanes of a row group contiguous), i.e. MFMA tile t holds the block's rows m0 + 2 i + t (columns likewise): no transpose, no LDS.  The chunks' partial blocks go to
+// a workspace and a second kernel adds them IN ORDER (deterministic, like the step's other reductions).
+constexpr int kWgradMaxChunks = 64;
+constexpr int kWgradRows = 192;                       // rows per chunk (48 k-steps of the fp32 MFMA)
+constexpr size_t kWgradWsFloats = (size_t)4 << 20;   // 16 MB of partial blocks per device
+// STREAM = false: up to ~1,000 waves (one per SIMD); true: more - half of the chunk's loads in flight (~130 registers: three waves per SIMD), every k-step's registers
+// reloaded with the k-step 24 further on as soon as its MFMAs are issued
+template <bool STREAM>
+__global__ __launch_bounds__(256) void k_train_wgrad(const float* __restrict__ dy, const float* __restrict__ x, float* __restrict__ part, int rows, int M, int N) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4, r = lane & 15;
+    const int nbn = N >> 6, bm = blockIdx.x / nbn, bn = blockIdx.x - bm * nbn;
+    const int m0 = (bm << 6) + ((wave >> 1) << 5), n0 = (bn << 6) + ((wave & 1) << 5);
+    const int k0 = blockIdx.y * kWgradRows, k1 = min(rows, k0 + kWgradRows);   // (rows is a multiple of 4)
+    f32x4 acc[2][2] = {{splat4(0.f), splat4(0.f)}, {splat4(0.f), splat4(0.f)}};
+    // A wave is alone on its SIMD (~800 waves per launch), so its loads are its only latency hiding: ALL 96 of the chunk's loads go out before the first
+    // MFMA (192 registers) and the MFMAs follow the data in as it arrives - one memory round trip per launch.  Rows past the chunk's end load a valid row
+    // and count as zero.
+    constexpr int NK = kWgradRows / 4, NL = STREAM ? NK / 2 : NK;
+    float2 a[NL], b[NL];
+    auto fetch = [&](int slot, int u) {
+        const int rc = min(k0 + 4 * u + g, rows - 1);
+        a[slot] = *reinterpret_cast<const float2*>(dy + (size_t)rc * M + m0 + 2 * r);
+        b[slot] = *reinterpret_cast<const float2*>(x + (size_t)rc * N + n0 + 2 * r);
+    };
+    auto multiply = [&](int slot, int u) {
+        if (k0 + 4 * u + g >= k1) a[slot] = float2{0.f, 0.f};
+        acc[0][0] = mfma_f32(a[slot].x, b[slot].x, acc[0][0]);
+        acc[0][1] = mfma_f32(a[slot].x, b[slot].y, acc[0][1]);
+        acc[1][0] = mfma_f32(a[slot].y, b[slot].x, acc[1][0]);
+        acc[1][1] = mfma_f32(a[slot].y, b[slot].y, acc[1][1]);
+    };
+#pragma unroll
+    for (int u = 0; u < NL; ++u) fetch(u, u);
+    __builtin_amdgcn_sched_barrier(0);   // (hipcc otherwise interleaves loads and MFMAs to save registers: 42 instead of ~230, one round trip per k-step)
+    if constexpr (STREAM) {
+#pragma unroll
+        for (int u = 0; u < NL; ++u) {
+            multiply(u, u);
+            fetch(u, u + NL);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int u = 0; u < NL; ++u) multiply(u, u + NL);
+    } else {
+#pragma unroll
+        for (int u = 0; u < NK; ++u) multiply(u, u);
+    }
+    // C fragment: lane (g, r), element v = tile row 4 g + v, tile column r  ->  dW row m0 + 2 (4 g + v) + t, columns n0 + 2 r + {0, 1}
+    float* o = part + (size_t)blockIdx.y * M * N;
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int v = 0; v < 4; ++v)
+            *reinterpret_cast<float2*>(o + (size_t)(m0 + 2 * (4 * g + v) + t) * N + n0 + 2 * r) = float2{acc[t][0][v], acc[t][1][v]};
+}
+// out = the chunks' partial blocks added up in a FIXED order: thread (column c of 64 float4 columns, group q of 4) adds chunks q, q + 4, ... (their loads in
+// flight together), the four groups' sums are added q = 0..3 through LDS
+__global__ __launch_bounds__(256) void k_train_wgrad_sum(const float* __restrict__ part, int chunks, size_t n4, float* __restrict__ out) {
+    __shared__ f32x4 red[3][64];
+    const int c = threadIdx.x & 63, q = threadIdx.x >> 6;
+    const size_t i = (size_t)blockIdx.x * 64 + c;   // (n4 is a multiple of 64)
+    f32x4 v[kWgradMaxChunks / 4];
+#pragma unroll
+    for (int j = 0; j < kWgradMaxChunks / 4; ++j) {
+        const int ch = q + 4 * j;
+        v[j] = ch < chunks ? ld4(part + ((size_t)ch * n4 + i) * 4) : splat4(0.f);
+    }
+    f32x4 s = v[0];
+#pragma unroll
+    for (int j = 1; j < kWgradMaxChunks / 4; ++j) s += v[j];
+    if (q > 0) red[q - 1][c] = s;
+    __syncthreads();
+    if (q == 0) st4(out + 4 * i, ((s + red[0][c]) + red[1][c]) + red[2][c]);
+}
+float* g_wgrad_ws[64] = {};
+// 1 = the kernel above for the shapes it takes, 0 = rocBLAS for everything (AMUSE_TRAIN_WGRAD=vendor; A/B)
+bool own_wgrad() {
+    static const bool on = [] { const char* e = getenv("AMUSE_TRAIN_WGRAD"); return !(e && e[0] == 'v'); }();
+    return on;
+}
+int wgrad_launch(const float* dy, const float* x, float* out, long rows, long M, long N, hipStream_t st) {
+    int dev = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    dev &= 63;
+    if (!g_wgrad_ws[dev]) HIP_TRY(hipMalloc((void**)&g_wgrad_ws[dev], kWgradWsFloats * sizeof(float)));
+    const long blocks = (M >> 6) * (N >> 6), chunks = (rows + kWgradRows - 1) / kWgradRows;
+    float* dst = chunks == 1 ? out : g_wgrad_ws[dev];
+    if (blocks * chunks > 256) hipLaunchKernelGGL(k_train_wgrad<true>, dim3((unsigned)blocks, (unsigned)chunks), dim3(256), 0, st, dy, x, dst, (int)rows, (int)M, (int)N);
+    else hipLaunchKernelGGL(k_train_wgrad<false>, dim3((unsigned)blocks, (unsigned)chunks), dim3(256), 0, st, dy, x, dst, (int)rows, (int)M, (int)N);
+    if (chunks > 1) {
+        const size_t n4 = (size_t)M * N / 4;
+        hipLaunchKernelGGL(k_train_wgrad_sum, dim3((unsigned)(n4 / 64)), dim3(256), 0, st, g_wgrad_ws[dev], (int)chunks, n4, out);
+    }
     return 0;
 }
 // out[M][N] (+)= op(a) . op(b); a is [M][K] (ta: [K][M]), b is [K][N] (tb: [N][K]), all row-major and dense
 int rm_gemm(void* h, bool ta, bool tb, long M, long N, long K, const float* a, const float* b, float* out, bool accumulate) {
+    // (measured, profiles/r04_train_wgrad_kernel_ab.txt: 12 us against 25 for a 128 x 128 gradient over 9,664 rows, 21 against 26 for 384 x 128; the FFN's 512 x 128 are
+    // bound by the fp32 MFMA rate either way - 26 against 27 - and stay with rocBLAS)
+    if (ta && !tb && !accumulate && K >= 1024 && !(K & 3) && !(M & 63) && !(N & 63) && M * N < 65536 && (K + kWgradRows - 1) / kWgradRows <= kWgradMaxChunks &&
+        (size_t)(M * N) * ((K + kWgradRows - 1) / kWgradRows) <= kWgradWsFloats && own_wgrad()) {   // a weight gradient with a long reduction
+        int dev = 0;
+        HIP_TRY(hipGetDevice(&dev));
+        return wgrad_launch(a, b, out, K, M, N, g_blas_stream[dev & 63]);
+    }
     const float one = 1.0f, zero = 0.0f;
     const int rc = g_blas.sgemm(h, tb ? 112 : 111, ta ? 112 : 111, (int)N, (int)M, (int)K, &one, b, (int)(tb ? K : N), a, (int)(ta ? M : K), accumulate ? &one : &zero, out, (int)N);
     return rc == 0 ? 0 : fail(AMUSE_EHIP, "rocblas_sgemm failed with status %d (M %ld N %ld K %ld)", rc, M, N, K);

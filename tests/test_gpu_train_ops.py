@@ -247,7 +247,10 @@ def test_flat_adamw_equals_torch_adamw_and_keeps_its_state_layout():
         assert _rel(sd["state"][k]["exp_avg_sq"], rsd["state"][k]["exp_avg_sq"]) < 2e-6
 
 
-@pytest.mark.parametrize("rows,K,N", [(9664, 333, 128), (9600, 256, 128), (32, 256, 128), (5, 128, 384)])
+@pytest.mark.parametrize("rows,K,N", [(9664, 333, 128), (9600, 256, 128), (32, 256, 128), (5, 128, 384),
+                                      # the library's own weight-gradient kernel (k_train_wgrad: reductions from 1,024 rows, both widths multiples of 64, N x K < 65,536) - a
+                                      # ragged last chunk of 192 rows, one chunk + 4 rows, its streaming instantiation (384 x 128), and its neighbours on rocBLAS
+                                      (9664, 128, 128), (1028, 128, 128), (9664, 128, 384), (2000, 64, 64), (9664, 128, 512), (1020, 128, 128)])
 def test_linear_fn_equals_f_linear(rows, K, N):
     from amuse_amd import train_ops as T
     g = torch.Generator(device=DEV).manual_seed(rows)
@@ -263,6 +266,38 @@ def test_linear_fn_equals_f_linear(rows, K, N):
         res.append((out.detach(), xr.grad, m.weight.grad.clone(), m.bias.grad.clone()))
     for a, b in zip(res[1], res[0]):
         assert a.shape == b.shape and _rel(a, b) < 2e-5
+
+
+def test_weight_gradient_kernel_is_deterministic_and_matches_the_vendor_gemm():
+    """dW = dy^T x on the library's chunked kernel: against float64, the same bits run after run (ordered sums, no atomics), and - in a child process with
+    AMUSE_TRAIN_WGRAD=vendor - rocBLAS's result within fp32 summation noise."""
+    import subprocess, sys
+    from amuse_amd import train_ops as T, _lib
+    st = T._st(torch.device(DEV))
+    rows, N, K = 9664, 128, 128
+    g = torch.Generator().manual_seed(3)
+    dy, x = torch.randn(rows, N, generator=g).to(DEV), torch.randn(rows, K, generator=g).to(DEV)
+    W = torch.zeros(N, K, device=DEV)
+
+    def run():
+        dW = torch.full((N, K), float("nan"), device=DEV)
+        _lib.check(st["lib"].amuse_train_linear_bwd(dy.data_ptr(), x.data_ptr(), W.data_ptr(), rows, K, N, dW.data_ptr(), None, None, 0, st["ws"].data_ptr(),
+                                                    torch.cuda.current_stream().cuda_stream))
+        return dW
+    a, b = run(), run()
+    ref = dy.double().T @ x.double()
+    assert torch.equal(a, b) and bool(torch.isfinite(a).all())
+    assert float((a.double() - ref).abs().max() / ref.abs().max()) < 2e-6
+    code = ("import torch, sys; sys.path.insert(0, %r); from amuse_amd import train_ops as T, _lib; st = T._st(torch.device('cuda:0'));"
+            "g = torch.Generator().manual_seed(3); dy = torch.randn(9664, 128, generator=g).cuda(); x = torch.randn(9664, 128, generator=g).cuda();"
+            "W = torch.zeros(128, 128, device='cuda'); dW = torch.empty(128, 128, device='cuda');"
+            "_lib.check(st['lib'].amuse_train_linear_bwd(dy.data_ptr(), x.data_ptr(), W.data_ptr(), 9664, 128, 128, dW.data_ptr(), None, None, 0, st['ws'].data_ptr(),"
+            "torch.cuda.current_stream().cuda_stream)); torch.save(dW.cpu(), sys.argv[1])") % str(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    out = "/tmp/amuse_wgrad_vendor.pt"
+    subprocess.run([sys.executable, "-c", code, out], check=True, env=dict(os.environ, AMUSE_TRAIN_WGRAD="vendor"))
+    v = torch.load(out)
+    assert not torch.equal(v, a.cpu())                                       # (really the other implementation)
+    assert float((v - a.cpu()).abs().max() / ref.abs().max()) < 2e-6
 
 
 @pytest.mark.parametrize("B,S", [(2, 300), (3, 302), (32, 5), (1, 17), (2, 304), (1, 1)])
