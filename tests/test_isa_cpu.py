@@ -36,7 +36,10 @@ def _kernels(src, extra=()):
 ])
 def test_register_budget_and_spills(src, extra, max_spills):
     for name, (vgprs, spills) in _kernels(src, extra).items():
-        assert vgprs <= 256, (name, vgprs)
+        # (k_train_wgrad<false> keeps all 96 operand loads of its chunk in flight - 192 registers of operands - and runs one wave per SIMD by design: launches of up to
+        # ~1,000 waves; its streaming instantiation for larger launches fits three waves per SIMD)
+        one_wave = src == "k_train.hip" and "k_train_wgradILb0E" in name
+        assert vgprs <= (288 if one_wave else 256), (name, vgprs)
         # (the phase-stamp instantiation of the 8-wave samplers - template argument PROF = true - parks its 64-bit stamp pointer: 2 registers)
         prof = src.startswith("k_sampler8") and "ILb1E" in name
         # (the encoder instantiations of the fp32x row kernel park 14 registers once per launch, outside its stage loops)
