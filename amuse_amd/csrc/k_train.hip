@@ -350,30 +350,37 @@ constexpr int kWgradMaxChunks = 64;
 constexpr int kWgradRows = 192;                       // rows per chunk (48 k-steps of the fp32 MFMA)
 constexpr size_t kWgradWsFloats = (size_t)4 << 20;   // 16 MB of partial blocks per device
 // STREAM = false: up to ~1,000 waves (one per SIMD); true: more - half of the chunk's loads in flight (~130 registers: three waves per SIMD), every k-step's registers
-// reloaded with the k-step 24 further on as soon as its MFMAs are issued
-template <bool STREAM>
+// reloaded with the k-step 24 further on as soon as its MFMAs are issued.  MT = MFMA tiles of the wave's block along m: 2 (32 x 32 per wave, 64 x 64 per workgroup) or
+// 4 (64 x 32 per wave, 128 x 64 per workgroup: half the waves and half the x loads per MFMA for the 512-wide gradients; the m side is then read 16 bytes per lane)
+template <bool STREAM, int MT>
 __global__ __launch_bounds__(256) void k_train_wgrad(const float* __restrict__ dy, const float* __restrict__ x, float* __restrict__ part, int rows, int M, int N) {
+    typedef float avec __attribute__((ext_vector_type(MT)));
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4, r = lane & 15;
     const int nbn = N >> 6, bm = blockIdx.x / nbn, bn = blockIdx.x - bm * nbn;
-    const int m0 = (bm << 6) + ((wave >> 1) << 5), n0 = (bn << 6) + ((wave & 1) << 5);
+    const int m0 = bm * (32 * MT) + (wave >> 1) * (16 * MT), n0 = (bn << 6) + ((wave & 1) << 5);
     const int k0 = blockIdx.y * kWgradRows, k1 = min(rows, k0 + kWgradRows);   // (rows is a multiple of 4)
-    f32x4 acc[2][2] = {{splat4(0.f), splat4(0.f)}, {splat4(0.f), splat4(0.f)}};
+    f32x4 acc[MT][2];
+#pragma unroll
+    for (int t = 0; t < MT; ++t) acc[t][0] = acc[t][1] = splat4(0.f);
     // A wave is alone on its SIMD (~800 waves per launch), so its loads are its only latency hiding: ALL 96 of the chunk's loads go out before the first
     // MFMA (192 registers) and the MFMAs follow the data in as it arrives - one memory round trip per launch.  Rows past the chunk's end load a valid row
     // and count as zero.
     constexpr int NK = kWgradRows / 4, NL = STREAM ? NK / 2 : NK;
-    float2 a[NL], b[NL];
+    avec a[NL];
+    float2 b[NL];
     auto fetch = [&](int slot, int u) {
         const int rc = min(k0 + 4 * u + g, rows - 1);
-        a[slot] = *reinterpret_cast<const float2*>(dy + (size_t)rc * M + m0 + 2 * r);
+        a[slot] = *reinterpret_cast<const avec*>(dy + (size_t)rc * M + m0 + MT * r);
         b[slot] = *reinterpret_cast<const float2*>(x + (size_t)rc * N + n0 + 2 * r);
     };
     auto multiply = [&](int slot, int u) {
-        if (k0 + 4 * u + g >= k1) a[slot] = float2{0.f, 0.f};
-        acc[0][0] = mfma_f32(a[slot].x, b[slot].x, acc[0][0]);
-        acc[0][1] = mfma_f32(a[slot].x, b[slot].y, acc[0][1]);
-        acc[1][0] = mfma_f32(a[slot].y, b[slot].x, acc[1][0]);
-        acc[1][1] = mfma_f32(a[slot].y, b[slot].y, acc[1][1]);
+        const bool dead = k0 + 4 * u + g >= k1;
+#pragma unroll
+        for (int t = 0; t < MT; ++t) {
+            const float at = dead ? 0.f : a[slot][t];
+            acc[t][0] = mfma_f32(at, b[slot].x, acc[t][0]);
+            acc[t][1] = mfma_f32(at, b[slot].y, acc[t][1]);
+        }
     };
 #pragma unroll
     for (int u = 0; u < NL; ++u) fetch(u, u);
@@ -391,13 +398,13 @@ __global__ __launch_bounds__(256) void k_train_wgrad(const float* __restrict__ d
 #pragma unroll
         for (int u = 0; u < NK; ++u) multiply(u, u);
     }
-    // C fragment: lane (g, r), element v = tile row 4 g + v, tile column r  ->  dW row m0 + 2 (4 g + v) + t, columns n0 + 2 r + {0, 1}
+    // C fragment: lane (g, r), element v = tile row 4 g + v, tile column r  ->  dW row m0 + MT (4 g + v) + t, columns n0 + 2 r + {0, 1}
     float* o = part + (size_t)blockIdx.y * M * N;
 #pragma unroll
-    for (int t = 0; t < 2; ++t)
+    for (int t = 0; t < MT; ++t)
 #pragma unroll
         for (int v = 0; v < 4; ++v)
-            *reinterpret_cast<float2*>(o + (size_t)(m0 + 2 * (4 * g + v) + t) * N + n0 + 2 * r) = float2{acc[t][0][v], acc[t][1][v]};
+            *reinterpret_cast<float2*>(o + (size_t)(m0 + MT * (4 * g + v) + t) * N + n0 + 2 * r) = float2{acc[t][0][v], acc[t][1][v]};
 }
 // out = the chunks' partial blocks added up in a FIXED order: thread (column c of 64 float4 columns, group q of 4) adds chunks q, q + 4, ... (their loads in
 // flight together), the four groups' sums are added q = 0..3 through LDS
@@ -424,15 +431,24 @@ bool own_wgrad() {
     static const bool on = [] { const char* e = getenv("AMUSE_TRAIN_WGRAD"); return !(e && e[0] == 'v'); }();
     return on;
 }
+// gradients of at least this many elements go to rocBLAS (AMUSE_TRAIN_WGRAD_MAX; A/B of the wide instantiation)
+long wgrad_max_elems() {
+    static const long v = [] { const char* e = getenv("AMUSE_TRAIN_WGRAD_MAX"); return e ? atol(e) : 131072L; }();
+    return v;
+}
 int wgrad_launch(const float* dy, const float* x, float* out, long rows, long M, long N, hipStream_t st) {
     int dev = 0;
     HIP_TRY(hipGetDevice(&dev));
     dev &= 63;
     if (!g_wgrad_ws[dev]) HIP_TRY(hipMalloc((void**)&g_wgrad_ws[dev], kWgradWsFloats * sizeof(float)));
-    const long blocks = (M >> 6) * (N >> 6), chunks = (rows + kWgradRows - 1) / kWgradRows;
+    const long chunks = (rows + kWgradRows - 1) / kWgradRows;
+    const bool wide = M * N >= 65536 && !(M & 127);
+    const long blocks = wide ? (M >> 7) * (N >> 6) : (M >> 6) * (N >> 6);
     float* dst = chunks == 1 ? out : g_wgrad_ws[dev];
-    if (blocks * chunks > 256) hipLaunchKernelGGL(k_train_wgrad<true>, dim3((unsigned)blocks, (unsigned)chunks), dim3(256), 0, st, dy, x, dst, (int)rows, (int)M, (int)N);
-    else hipLaunchKernelGGL(k_train_wgrad<false>, dim3((unsigned)blocks, (unsigned)chunks), dim3(256), 0, st, dy, x, dst, (int)rows, (int)M, (int)N);
+    const dim3 grid((unsigned)blocks, (unsigned)chunks);
+    if (wide) hipLaunchKernelGGL((k_train_wgrad<true, 4>), grid, dim3(256), 0, st, dy, x, dst, (int)rows, (int)M, (int)N);
+    else if (blocks * chunks > 256) hipLaunchKernelGGL((k_train_wgrad<true, 2>), grid, dim3(256), 0, st, dy, x, dst, (int)rows, (int)M, (int)N);
+    else hipLaunchKernelGGL((k_train_wgrad<false, 2>), grid, dim3(256), 0, st, dy, x, dst, (int)rows, (int)M, (int)N);
     if (chunks > 1) {
         const size_t n4 = (size_t)M * N / 4;
         hipLaunchKernelGGL(k_train_wgrad_sum, dim3((unsigned)(n4 / 64)), dim3(256), 0, st, g_wgrad_ws[dev], (int)chunks, n4, out);
@@ -441,9 +457,9 @@ int wgrad_launch(const float* dy, const float* x, float* out, long rows, long M,
 }
 // out[M][N] (+)= op(a) . op(b); a is [M][K] (ta: [K][M]), b is [K][N] (tb: [N][K]), all row-major and dense
 int rm_gemm(void* h, bool ta, bool tb, long M, long N, long K, const float* a, const float* b, float* out, bool accumulate) {
-    // (measured, profiles/r04_train_wgrad_kernel_ab.txt: 12 us against 25 for a 128 x 128 gradient over 9,664 rows, 21 against 26 for 384 x 128; the FFN's 512 x 128 are
-    // bound by the fp32 MFMA rate either way - 26 against 27 - and stay with rocBLAS)
-    if (ta && !tb && !accumulate && K >= 1024 && !(K & 3) && !(M & 63) && !(N & 63) && M * N < 65536 && (K + kWgradRows - 1) / kWgradRows <= kWgradMaxChunks &&
+    // (measured, profiles/r04_train_wgrad_kernel_ab.txt: 12 us against 25 for a 128 x 128 gradient over 9,664 rows, 21 against 26 for 384 x 128; the FFN's 512 x 128 - bound by
+    // the fp32 MFMA rate and their 13 MB of partial blocks - 25 against 27.5 on the 64 x 32-per-wave instantiation)
+    if (ta && !tb && !accumulate && K >= 1024 && !(K & 3) && !(M & 63) && !(N & 63) && M * N < wgrad_max_elems() && (K + kWgradRows - 1) / kWgradRows <= kWgradMaxChunks &&
         (size_t)(M * N) * ((K + kWgradRows - 1) / kWgradRows) <= kWgradWsFloats && own_wgrad()) {   // a weight gradient with a long reduction
         int dev = 0;
         HIP_TRY(hipGetDevice(&dev));
