@@ -22,14 +22,23 @@ Pinning status
     tests/test_oracle_golden.py checks this restatement against them.
   * ``rotation_6d_to_matrix``, ``quaternion_to_axis_angle`` and the *legacy* ``matrix_to_quaternion``:
     PINNED against the pytorch3d snapshot vendored at models/diffusion/utils/rotation_conversions.py.
-  * Third-party arithmetic that is NOT under /root/reference - PARITY UNPINNED, restated from the
-    published algorithms:
-      - diffusers==0.17.1 (amuse.yml:143) ``DDIMScheduler`` / ``DDPMScheduler``; call sites
-        infer_ldm.py:116-123,142-147,160-161 and ldm.py:41-57.  Self-checks: DDIM timesteps are
-        981,961,...,1; init_noise_sigma == 1.
-      - pytorch3d (unpinned, README.md:105) candidate-selection ``matrix_to_quaternion`` (the
-        committed sample outputs reach |axis-angle| = 4.69 > pi, which only that variant produces).
-        Pinned only *as a rotation* (round trip through axis_angle_to_matrix).
+  * Third-party arithmetic that is NOT under /root/reference (diffusers==0.17.1, amuse.yml:143; pytorch3d, unpinned,
+    README.md:105) - restated from the published algorithms and PINNED against what the reference tree itself holds:
+      - ``matrix_to_axis_angle`` with the candidate-selection ``matrix_to_quaternion``: PINNED by the ``poses`` of the three
+        committed sample outputs viz_dump/test/**/*_motion_smplx.npz (tests/golden/ref_poses.npz; outputs of the deployed
+        pytorch3d at infer_ldm.py:171-172): 49,500 joints reproduce to <= 1e-5 through axis_angle_to_matrix ->
+        matrix_to_axis_angle(.., "p3d"), including all 10 with |aa| > pi, which the vendored ("legacy") variant cannot produce.
+      - ``DDPMScheduler`` (``add_noise``; ancestral ``step`` with fixed_small, no clip, 1000 steps): PINNED against the
+        reference tree's own GaussianDiffusion (models/diffusion/utils/mdm_gaussian_diffusion.py:198-278,323-366,528-533,690;
+        tests/golden/sched_ref.npz): posterior tables for all 1000 t, single-step known answers, a 1000-step trajectory.
+      - ``DDIMScheduler`` (eta 0, steps_offset 1, 50 steps): the update is PINNED against SpacedDiffusion + ddim_sample
+        (mdm_respace.py:64-87, mdm_gaussian_diffusion.py:895-940) on {1,21,..,981}: all 50 steps for
+        set_alpha_to_one=True, 49 of 50 for the reference's set_alpha_to_one=False, without clipping; and with clipping for
+        use_clipped_model_output=True.  TWO conventions remain recollections of the diffusers 0.17.1 source, unpinned:
+        (i) set_alpha_to_one=False -> the last step's alpha_bar_prev is alphas_cumprod[0]; (ii) with clip_sample=True
+        (the default the reference inherits) and use_clipped_model_output=False the direction term uses the UN-clipped
+        eps_hat.  Also not reference-held: torch-fp32 ``cumprod`` for alphas_cumprod (the reference tree's code uses fp64
+        numpy; the difference is <= 7e-6 relative on every coefficient, tests/test_pins_cpu.py).
 
 Everything is written with explicit tensor math (no nn.Module) so that ``emulate_bf16=True`` can round
 exactly the operands the bf16 HIP kernels round (MFMA A/B inputs), giving a tight checker for the
@@ -333,7 +342,7 @@ def sample_variant(W, sched, con, emo, sty, x_init, arch, diffusion_only, step_n
 
 
 # --------------------------------------------------------------------------------------------
-# Schedulers (diffusers 0.17.1 semantics, restated - parity unpinned, see header)
+# Schedulers (diffusers 0.17.1 semantics, restated; pinned against the reference tree's GaussianDiffusion, see header)
 # --------------------------------------------------------------------------------------------
 class SchedulerBase:
     def __init__(self, num_train_timesteps=1000, beta_start=0.00085, beta_end=0.012):
@@ -349,8 +358,9 @@ class DDIM(SchedulerBase):
     """DDIMScheduler as constructed at infer_ldm.py:116-123: clip_sample is NOT passed -> default True."""
 
     def __init__(self, num_inference_steps=50, steps_offset=1, set_alpha_to_one=False, eta=0.0,
-                 clip_sample=True, clip_sample_range=1.0, **kw):
+                 clip_sample=True, clip_sample_range=1.0, use_clipped_model_output=False, **kw):
         super().__init__(**kw)
+        self.use_clipped = use_clipped_model_output   # diffusers' step() argument; the reference leaves it False
         self.final_alpha_cumprod = torch.tensor(1.0) if set_alpha_to_one else self.alphas_cumprod[0]
         self.eta, self.clip, self.clip_range = eta, clip_sample, clip_sample_range
         self.n_inf = num_inference_steps
@@ -367,6 +377,8 @@ class DDIM(SchedulerBase):
         x0 = (x - cast(b_t ** 0.5) * eps) / cast(a_t ** 0.5)
         if self.clip:
             x0 = x0.clamp(-self.clip_range, self.clip_range)
+        if self.use_clipped:
+            eps = (x - cast(a_t ** 0.5) * x0) / cast(b_t ** 0.5)
         var = ((1 - a_prev) / (1 - a_t)) * (1 - a_t / a_prev)
         std = self.eta * var ** 0.5
         direction = cast((1 - a_prev - std ** 2) ** 0.5) * eps
@@ -589,7 +601,7 @@ def axis_angle_to_matrix(aa):
 def diffusion_forward(W, z0, noise, timesteps, con, emo, sty, emulate_bf16=False):
     """LatentDiffusionModel.diffusion_forward (ldm.py:71-115) in eval semantics (no dropout), with the caller's noise
     and per-sample timesteps: noisy = sqrt(abar_t) z0 + sqrt(1 - abar_t) noise (DDPMScheduler.add_noise, diffusers
-    0.17.1 - parity unpinned like the other scheduler arithmetic), noise_pred = Denoiser(noisy, t, cond).
+    0.17.1; pinned against the reference tree's q_sample, tests/test_pins_cpu.py), noise_pred = Denoiser(noisy, t, cond).
     -> {"noisy_latents", "noise", "noise_pred"}, each (B,128)."""
     ac = SchedulerBase().alphas_cumprod
     t = torch.as_tensor(list(timesteps), dtype=torch.long)

@@ -11,6 +11,15 @@ imported through the package shim described in SURVEY.md section 8c (the referen
 __init__ chain imports seaborn/timm/... which are not installed).
 The DDIM-50 trajectory fixture drives the reference Denoiser with the oracle's restated scheduler
 (diffusers is not installed) - it pins the network under iteration, not diffusers.
+Two further fixtures pin the third-party arithmetic from material the reference tree itself holds
+(`--pins-only` writes just these):
+  * tests/golden/ref_poses.npz  - the `poses` arrays of the three committed sample outputs
+    viz_dump/test/**/*_motion_smplx.npz: outputs of the DEPLOYED pytorch3d.matrix_to_axis_angle
+    (infer_ldm.py:171-172), 49,500 joints, 10 of them with |aa| > pi.
+  * tests/golden/sched_ref.npz  - posterior tables, single-step known answers, a DDPM-1000 and two DDIM-50
+    scheduler-only trajectories computed by the reference's own GaussianDiffusion / SpacedDiffusion
+    (models/diffusion/utils/mdm_gaussian_diffusion.py:198-278,343-366,528-549,895-940; mdm_respace.py:64-87) on the
+    scaled_linear betas of configs/diff_latent_v2.json.
 """
 import importlib.util
 import json
@@ -118,6 +127,116 @@ def gen_variants(out, Denoiser):
     json.dump(spec, open(out / "state_dict_spec_variants.json", "w"), indent=0)
 
 
+def _shim_mdm():
+    """models.diffusion.utils.{mdm_gaussian_diffusion, mdm_respace} through the same empty-package shim
+    (the package __init__ chain imports seaborn / timm; these two files need numpy, torch and einops only)."""
+    for name, path in (("models", REF / "models"), ("models.diffusion", REF / "models/diffusion"),
+                       ("models.diffusion.utils", REF / "models/diffusion/utils")):
+        if name not in sys.modules:
+            m = types.ModuleType(name)
+            m.__path__ = [str(path)]
+            sys.modules[name] = m
+    from models.diffusion.utils import mdm_gaussian_diffusion as gdm
+    from models.diffusion.utils import mdm_respace as rsp
+    return gdm, rsp
+
+
+def gen_ref_poses(out):
+    """tests/golden/ref_poses.npz: data the reference's tests/ samples hold - the axis-angle `poses` the deployed
+    pytorch3d wrote (infer_ldm.py:171-172 -> trainer.py:524-526 -> visualizer.py:344-364)."""
+    d = {}
+    for p in sorted((REF / "viz_dump/test").rglob("*_motion_smplx.npz")):
+        z_ = np.load(p, allow_pickle=True)
+        key = p.name.split("_motion_smplx")[0]
+        assert z_["poses"].dtype == np.float32 and z_["poses"].shape == (300, 55, 3)
+        d[key] = z_["poses"]
+    assert len(d) == 3
+    np.savez_compressed(out / "ref_poses.npz", **d)
+
+
+def gen_sched_ref(out):
+    """tests/golden/sched_ref.npz from the reference tree's own Gaussian diffusion code.
+
+    GaussianDiffusion(betas = scaled_linear fp64, EPSILON, FIXED_SMALL): its posterior (mdm_gaussian_diffusion.py:343-366)
+    IS diffusers' DDPMScheduler.step with variance_type fixed_small at 1000 inference steps, its q_sample (:323-341) IS
+    add_noise.  p_sample / p_mean_variance were rewritten upstream around dicts of pose streams and no longer run on a
+    plain tensor, so a step is composed here from the member functions they call - _predict_xstart_from_eps (:528-533),
+    q_posterior_mean_variance (:343-366) - and p_sample's own last line (:690): mean + (t != 0) exp(0.5 logvar) noise.
+    DDIM: SpacedDiffusion on {1, 21, ..., 981} (mdm_respace.py:64-87) + ddim_sample (:895-940, eta = 0), with
+    p_mean_variance overridden to the EPSILON branch of the original (:506-511) because the upstream body is the
+    dict version.  Residual differences to diffusers 0.17.1, stated: (i) the last step's alpha_bar_prev is 1.0 here
+    (diffusers: set_alpha_to_one=True; the reference passes False -> abar[0]), (ii) with clip_denoised=True this code
+    re-derives eps from the clipped x0 (diffusers: use_clipped_model_output=True; the reference leaves it False)."""
+    gdm, rsp = _shim_mdm()
+    betas = np.linspace(0.00085 ** 0.5, 0.012 ** 0.5, 1000, dtype=np.float64) ** 2      # diff_latent_v2.json:48-66
+    kw = dict(betas=betas, model_mean_type=gdm.ModelMeanType.EPSILON, model_var_type=gdm.ModelVarType.FIXED_SMALL,
+              loss_type=gdm.LossType.MSE)
+    gd = gdm.GaussianDiffusion(**kw)
+    d = {"betas": betas, "alphas_cumprod": gd.alphas_cumprod, "posterior_mean_coef1": gd.posterior_mean_coef1,
+         "posterior_mean_coef2": gd.posterior_mean_coef2, "posterior_variance": gd.posterior_variance,
+         "posterior_log_variance_clipped": gd.posterior_log_variance_clipped,
+         "sqrt_recip_alphas_cumprod": gd.sqrt_recip_alphas_cumprod, "sqrt_recipm1_alphas_cumprod": gd.sqrt_recipm1_alphas_cumprod}
+
+    def ddpm_step(x, t, eps, noise):
+        tt = torch.full((x.shape[0],), t, dtype=torch.long)
+        x0 = gd._predict_xstart_from_eps(x, tt, eps)
+        mean, _, logvar = gd.q_posterior_mean_variance(x0, x, tt)
+        return x0, mean, mean + float(t != 0) * torch.exp(0.5 * logvar) * noise
+
+    g = torch.Generator().manual_seed(1105)
+    B = 4
+    x, eps, noise = (torch.randn(B, 128, generator=g) for _ in range(3))
+    d.update(kat_x=x.numpy(), kat_eps=eps.numpy(), kat_noise=noise.numpy(), kat_t=np.array([999, 500, 37, 1, 0]))
+    for t in (999, 500, 37, 1, 0):
+        x0, mean, smp = ddpm_step(x, t, eps, noise)
+        d[f"kat_ddpm_t{t}/x0"], d[f"kat_ddpm_t{t}/mean"], d[f"kat_ddpm_t{t}/sample"] = x0.numpy(), mean.numpy(), smp.numpy()
+    # add_noise (the only DDPMScheduler call the reference makes, ldm.py:84) == q_sample, per-sample timesteps
+    ts = torch.tensor([7, 640, 999, 0])
+    d["q_sample_t"], d["q_sample"] = ts.numpy(), gd.q_sample(x, ts, noise=noise).numpy()
+
+    # DDPM-1000 scheduler-only trajectory: eps_hat == a constant vector (what a Denoiser whose final LayerNorm has weight 0
+    # and bias e produces), ancestral noise from torch.Generator(seed) drawn step by step in loop order -> stored checkpoints
+    B2 = 2
+    gt = torch.Generator().manual_seed(77)
+    e_const = torch.randn(128, generator=gt)
+    xt = torch.randn(B2, 128, generator=gt)
+    d.update(traj_eps_const=e_const.numpy(), traj_x_T=xt.numpy().copy(), traj_noise_seed=np.array(78))
+    gn = torch.Generator().manual_seed(78)
+    for t in range(999, -1, -1):
+        nz = torch.randn(B2, 128, generator=gn)
+        xt = ddpm_step(xt, t, e_const[None].expand(B2, -1), nz)[2]
+        if t in (900, 500, 100, 0):
+            d[f"traj_ddpm_after_t{t}"] = xt.numpy().copy()
+
+    class EpsOnly(rsp.SpacedDiffusion):
+        def p_mean_variance(self, model, x, t, clip_denoised=True, denoised_fn=None, model_kwargs=None):
+            x0 = self._predict_xstart_from_eps(x_t=x, t=t, eps=model(x, t))
+            return {"pred_xstart": x0.clamp(-1, 1) if clip_denoised else x0}
+
+    sd = EpsOnly(use_timesteps=set(range(1, 1000, 20)), **kw)
+    assert sd.timestep_map == list(range(1, 1000, 20))
+    ge = torch.Generator().manual_seed(79)
+    eps_seq = torch.randn(50, B2, 128, generator=ge)      # a different eps_hat per step, same for both runs
+    x_T = torch.randn(B2, 128, generator=ge)
+    d.update(ddim_eps_seq=eps_seq.numpy(), ddim_x_T=x_T.numpy(), ddim_timesteps=np.array(sd.timestep_map[::-1]))
+    for clip in (False, True):
+        xx, tr = x_T.clone(), []
+        for i, idx in enumerate(range(49, -1, -1)):
+            o = sd.ddim_sample(lambda _x, _t: eps_seq[i], xx, torch.full((B2,), idx, dtype=torch.long),
+                               clip_denoised=clip, eta=0.0)
+            xx = o["sample"]
+            tr.append(xx.numpy().copy())
+        d[f"ddim_traj_{'clip' if clip else 'noclip'}"] = np.stack(tr)
+    # the same with eps_hat == the constant vector of the DDPM trajectory above (what the GPU test can drive through the kernels)
+    xx, tr = torch.from_numpy(d["traj_x_T"]).clone(), []
+    for idx in range(49, -1, -1):
+        xx = sd.ddim_sample(lambda _x, _t: e_const[None].expand(B2, -1), xx, torch.full((B2,), idx, dtype=torch.long),
+                            clip_denoised=False, eta=0.0)["sample"]
+        tr.append(xx.numpy().copy())
+    d["ddim_traj_const_noclip"] = np.stack(tr)
+    np.savez_compressed(out / "sched_ref.npz", **d)
+
+
 def build_reference():
     Denoiser, MotionPrior, rot = _shim()
     base = json.load(open(REF / "configs/base_new.json"))
@@ -149,6 +268,10 @@ def main():
     out.mkdir(parents=True, exist_ok=True)
     torch.manual_seed(0)
     torch.set_grad_enabled(False)
+    if "--pins-only" in sys.argv:       # only tests/golden/ref_poses.npz + sched_ref.npz
+        gen_ref_poses(out)
+        gen_sched_ref(out)
+        return
     if "--variants-only" in sys.argv:   # only tests/golden/denoiser_variants.npz + state_dict_spec_variants.json
         gen_variants(out, _shim()[0])
         return
@@ -283,6 +406,8 @@ def main():
         bet[actor] = z_["betas"]
         bet[actor + "_gender"] = z_["gender"]
     np.savez_compressed(out / "sample_npz_betas.npz", **bet)
+    gen_ref_poses(out)
+    gen_sched_ref(out)
     for f in sorted(out.iterdir()):
         print(f.name, os.path.getsize(f))
 
