@@ -324,8 +324,10 @@ def main():
                        "sharding": f"contiguous clip shards x{world} of ONE {total}-clip job (amuse_amd/shard.py; bitwise the single-GPU result), no collectives",
                        "clip_range_per_rank": [list(shard.shard_range(total, r, world, align=g_job)) for r in range(world)],
                        "mfma_operands": args.precision, "state_and_accumulate": "fp32",
-                       "scheduler_arithmetic": "diffusers 0.17.1 DDPM (fixed_small) / DDIM restated from the published algorithm - the package "
-                                               "is not in the image, so this part of the parity claim is unpinned (DESIGN.md section 2)"},
+                       "scheduler_arithmetic": "diffusers 0.17.1 DDPM (fixed_small) / DDIM restated (package not in the image); pinned in-kernel against the "
+                                               "reference tree's own GaussianDiffusion / SpacedDiffusion (tests/test_gpu_pins.py, tests/golden/sched_ref.npz); "
+                                               "unpinned conventions: DDIM last-step alpha_bar_prev = abar[0], un-clipped eps_hat in the DDIM direction term, "
+                                               "fp32 cumprod (DESIGN.md section 2)"},
             "roofline": {"bound": "chain+l2_stream", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
                          "frac": round(achieved / peak, 5), "traffic": traffic, "traffic_source": traffic_src,
                          "kernel": KERNEL_NAME[args.precision] + " (persistent T-step denoising loop)",
