@@ -650,6 +650,8 @@ void amuse_destroy(amuse_ctx* c) {
                     c->cond_tok, c->lat_tmp, c->fwd_ws, c->vae_ws, c->d_lengths, c->vae_wf, c->vae_skip, c->vae_ca_ws, c->vae_c1[0], c->vae_c1[1], c->vae_c1[2]};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
+    for (hipEvent_t e : c->vae_c1_ev)
+        if (e) (void)hipEventDestroy(e);
     delete c;
 }
 
@@ -821,6 +823,22 @@ int amuse_diffusion_forward(amuse_ctx* c, const float* z0, const float* noise, c
     return 0;
 }
 
+namespace {
+// Block 0's hoisted constant (vae_c1) is produced on the stream of the decode that first needed it; the validity flag is host state.  A later decode on
+// ANOTHER stream (the trainer's sampler stream beside the caller's) must not read it before those launches finish: an event marks the producer's place,
+// and a consumer on a different stream waits on it.  Same stream: nothing to do (stream order).
+hipError_t c1_produced(amuse_ctx* c, int i, hipStream_t st) {
+    if (!c->vae_c1_ev[i])
+        if (hipError_t e = hipEventCreateWithFlags(&c->vae_c1_ev[i], hipEventDisableTiming)) return e;
+    c->vae_c1_stream[i] = st;
+    return hipEventRecord(c->vae_c1_ev[i], st);
+}
+hipError_t c1_consumed(amuse_ctx* c, int i, hipStream_t st) {
+    if (!c->vae_c1_ev[i] || c->vae_c1_stream[i] == st) return hipSuccess;
+    return hipStreamWaitEvent(st, c->vae_c1_ev[i], 0);
+}
+}  // namespace
+
 int amuse_vae_decode(amuse_ctx* c, const float* z, const int* lengths, int B, int precision, int quat_mode,
                      float* feats_out, float* poses_out, float* trans_out, void* stream) {
     if (!c) return fail(AMUSE_EINVAL, "ctx is NULL");
@@ -858,8 +876,10 @@ int amuse_vae_decode(amuse_ctx* c, const float* z, const int* lengths, int B, in
             fa.ca = c->vae_ca_ws; fa.skip = c->vae_skip; fa.B = 1; fa.quat_mode = quat_mode; fa.tap_out = tap;
             HIP_TRY(precision == PREC_F16 ? launch_vae_fusedh(fa, st) : launch_vae_fused(fa, st));
             HIP_TRY(hipMemcpyAsync(c->vae_c1[pi], tap + (size_t)10 * kFrames * kD, (size_t)kFrames * kD * sizeof(float), hipMemcpyDeviceToDevice, st));
+            HIP_TRY(c1_produced(c, pi, st));
             c->vae_c1_valid[pi] = true;
         }
+        if (hoist_on && c->vae_c1_valid[pi]) HIP_TRY(c1_consumed(c, pi, st));
         for (int b0 = 0; b0 < B; b0 += chunk) {
             const int nb = (B - b0) < chunk ? (B - b0) : chunk;
             HIP_TRY(launch_vae_ca(z + (size_t)b0 * kD, c->vae_wv_t, c->vae_bv, c->vae_wo_t, c->vae_bo, c->vae_ca_ws, nb, st));
@@ -930,9 +950,10 @@ int amuse_vae_decode(amuse_ctx* c, const float* z, const int* lengths, int B, in
             HIP_TRY(launch_vae_attn(pa, precision, VAE_MODE_DEC, st));
             p8.stage = 1; p8.c1_out = c->vae_c1[2];
             HIP_TRY(launch_vae_rows8x(p8, st));
+            HIP_TRY(c1_produced(c, 2, st));
             c->vae_c1_valid[2] = true;
         }
-        if (hoist8) r8.c1 = c->vae_c1[2];
+        if (hoist8) { HIP_TRY(c1_consumed(c, 2, st)); r8.c1 = c->vae_c1[2]; }
         for (int stage = hoist8 ? 1 : 0; stage < kVaeStages; ++stage) {
             ra.stage = stage;
             r8.stage = stage;

@@ -28,6 +28,7 @@ from __future__ import annotations
 
 import argparse
 import json
+import os
 import random
 import time
 from pathlib import Path
@@ -101,12 +102,14 @@ def train_gesture_entry(args, dirname: Path, config: dict):
     argv = ["--batch", str(ld.get("batch_size", 32)), "--epochs", str(args.epochs or ld.get("n_epochs", 12000)),
             "--save-freq", str(ld.get("model_save_freq", 200)), "--seed", str(tp.get("seed", 2024)), "--gpus", str(args.gpus),
             "--out", str(dirname / "saved-models"), "--lr", repr(float(ld.get("lr_base", 1e-4)))]
+    tmp_cfg = None
     if ldm_cfg is not None:   # configs/<arch>.json merged with diff_o.yaml: loss weights and both schedulers (the ranks may be other processes)
         import tempfile
         f = tempfile.NamedTemporaryFile("w", suffix="_ldm_cfg.json", delete=False)
         json.dump(ldm_cfg, f)
         f.close()
-        argv += ["--ldm-cfg", f.name]
+        tmp_cfg = f.name
+        argv += ["--ldm-cfg", tmp_cfg]
     cache = dirname / "data" / "BEAT-processed" / tp.get("diffusion", {}).get("lmdb_cache", "")
     if not args.synthetic:
         if not (cache.is_dir() and tp.get("diffusion", {}).get("lmdb_cache")):
@@ -121,7 +124,14 @@ def train_gesture_entry(args, dirname: Path, config: dict):
     if args.iters_per_epoch:
         argv += ["--iters-per-epoch", str(args.iters_per_epoch)]
     print(f"Experiment init: AMUSE, fn: train_gesture, time: {time.asctime()}")
-    return train_gesture.main(argv)
+    try:
+        return train_gesture.main(argv)
+    finally:
+        if tmp_cfg is not None:       # (the ranks have finished reading it: main returns after they exit)
+            try:
+                os.unlink(tmp_cfg)
+            except OSError:
+                pass
 
 
 def main(argv=None):

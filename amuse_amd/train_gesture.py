@@ -466,7 +466,7 @@ def ablation_kind(lmdb_id: Optional[str]) -> Optional[str]:
     """The ablation variant the reference derives from the LMDB cache id (trainer.py:396-401): full | emotion | identity | baseline."""
     if not lmdb_id:
         return None
-    parts = lmdb_id.split("/")[-1].split("_")
+    parts = Path(lmdb_id).name.split("_")        # (Path.name: a trailing slash does not leave an empty last component)
     kind = parts[-3] if len(parts) >= 3 else ""
     if kind == "feat" and len(parts) >= 5:
         kind = parts[-5]
@@ -596,11 +596,12 @@ def main(argv=None):
         raise SystemExit(f"--device {args.device} with {world} ranks would put every rank on one GPU: drop the index (rank r uses cuda:<LOCAL_RANK>)")
     device = torch.device(f"cuda:{local_rank}" if (args.device in (None, "cuda") and torch.cuda.is_available()) else (args.device or "cpu"))
     pg = None
+    if device.type == "cuda":
+        torch.cuda.set_device(device)       # also for ONE rank on cuda:N, N > 0: the library's handles and workspaces key on the current device
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if device.type == "cuda":
-            torch.cuda.set_device(device)
             dist.init_process_group("nccl", device_id=device)
         else:
             dist.init_process_group("gloo")

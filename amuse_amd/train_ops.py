@@ -51,8 +51,29 @@ def _st(device):
     return s
 
 
-def _stream():
-    return torch.cuda.current_stream().cuda_stream
+def _stream(device=None):
+    """torch's current stream OF THE TENSORS' DEVICE (not of the process's current device)."""
+    return torch.cuda.current_stream(device).cuda_stream
+
+
+class _on:
+    """Device guard around every library call: the C side (rocBLAS handle, workspaces, kernel launches) keys on hipGetDevice, so the tensors' device
+    must be the current one - also on the autograd thread and for a single rank on cuda:N, N > 0.  One integer compare when it already is."""
+    __slots__ = ("idx", "prev")
+
+    def __init__(self, device):
+        self.idx = torch.device(device).index
+
+    def __enter__(self):
+        self.prev = torch.cuda.current_device()
+        if self.idx is None:
+            self.idx = self.prev
+        if self.prev != self.idx:
+            torch.cuda.set_device(self.idx)
+
+    def __exit__(self, *exc):
+        if self.prev != self.idx:
+            torch.cuda.set_device(self.prev)
 
 
 def _seed() -> int:
@@ -127,7 +148,7 @@ def _blas(device):
                 raise RuntimeError("rocblas_create_handle failed")
         b = {"lib": lib, "h": h, "stream": None, "one": C.c_float(1.0), "zero": C.c_float(0.0)}
         _BLAS[device] = b
-    st = _stream()
+    st = _stream(device)
     if b["stream"] != st:
         if b["lib"].rocblas_set_stream(b["h"], st) != 0:
             raise RuntimeError("rocblas_set_stream failed")
@@ -150,9 +171,10 @@ def gemm(a: torch.Tensor, b: torch.Tensor, ta: bool = False, tb: bool = False, o
     if not _direct_gemm():
         aa, bb = (a.t() if ta else a), (b.t() if tb else b)
         return torch.addmm(out, aa, bb, out=out) if accumulate else torch.mm(aa, bb, out=out)
-    bl = _blas(a.device)
-    rc = bl["lib"].rocblas_sgemm(bl["h"], _OP_T if tb else _OP_N, _OP_T if ta else _OP_N, N, M, K, C.byref(bl["one"]), b.data_ptr(), b.shape[1],
-                                 a.data_ptr(), a.shape[1], C.byref(bl["one"] if accumulate else bl["zero"]), out.data_ptr(), N)
+    with _on(a.device):
+        bl = _blas(a.device)
+        rc = bl["lib"].rocblas_sgemm(bl["h"], _OP_T if tb else _OP_N, _OP_T if ta else _OP_N, N, M, K, C.byref(bl["one"]), b.data_ptr(), b.shape[1],
+                                     a.data_ptr(), a.shape[1], C.byref(bl["one"] if accumulate else bl["zero"]), out.data_ptr(), N)
     if rc != 0:
         raise RuntimeError(f"rocblas_sgemm failed with status {rc}")
     return out
@@ -167,8 +189,9 @@ def ln_fwd(x, y, bias, gamma, beta, p: float, seed: int, off: int, keep: bool = 
     out = torch.empty_like(y)
     zhat = torch.empty_like(y) if keep else None
     rstd = torch.empty(rows, device=y.device, dtype=torch.float32) if keep else None
-    _lib.check(s["lib"].amuse_train_ln_fwd(_p(None if x is None else _c(x)), _p(y), _p(bias), _p(gamma), _p(beta), float(p), seed, off, rows,
-                                           _p(out), _p(zhat), _p(rstd), _stream()))
+    with _on(y.device):
+        _lib.check(s["lib"].amuse_train_ln_fwd(_p(None if x is None else _c(x)), _p(y), _p(bias), _p(gamma), _p(beta), float(p), seed, off, rows,
+                                               _p(out), _p(zhat), _p(rstd), _stream(y.device)))
     return out, zhat, rstd
 
 
@@ -180,8 +203,9 @@ def ln_bwd(dout, zhat, rstd, gamma, p: float, seed: int, off: int, need_dx: bool
     dy = torch.empty_like(dout)
     dx = torch.empty_like(dout) if need_dx else None
     small = torch.empty(3, 128, device=dout.device, dtype=torch.float32)
-    _lib.check(s["lib"].amuse_train_ln_bwd(_p(dout), _p(None if dout2 is None else _c(dout2)), _p(zhat), _p(rstd), _p(gamma), float(p), seed, off, rows, _p(dx), _p(dy), small[0].data_ptr(),
-                                           small[1].data_ptr(), small[2].data_ptr() if need_dbias else None, _p(s["ws"]), _stream()))
+    with _on(dout.device):
+        _lib.check(s["lib"].amuse_train_ln_bwd(_p(dout), _p(None if dout2 is None else _c(dout2)), _p(zhat), _p(rstd), _p(gamma), float(p), seed, off, rows, _p(dx), _p(dy), small[0].data_ptr(),
+                                               small[1].data_ptr(), small[2].data_ptr() if need_dbias else None, _p(s["ws"]), _stream(dout.device)))
     return dx, dy, small[0], small[1], (small[2] if need_dbias else None)
 
 
@@ -189,7 +213,8 @@ def bias_gelu_drop_fwd(h, b, p: float, seed: int, off: int):
     h = _c(h)
     F = h.shape[-1]
     out = torch.empty_like(h)
-    _lib.check(_st(h.device)["lib"].amuse_train_bias_gelu_drop_fwd(_p(h), _p(b), float(p), seed, off, h.numel() // F, F, _p(out), _stream()))
+    with _on(h.device):
+        _lib.check(_st(h.device)["lib"].amuse_train_bias_gelu_drop_fwd(_p(h), _p(b), float(p), seed, off, h.numel() // F, F, _p(out), _stream(h.device)))
     return out
 
 
@@ -199,8 +224,9 @@ def bias_gelu_drop_bwd(da, h, b, p: float, seed: int, off: int):
     s = _st(h.device)
     dh = torch.empty_like(h)
     db = torch.empty(F, device=h.device, dtype=torch.float32)
-    _lib.check(s["lib"].amuse_train_bias_gelu_drop_bwd(_p(da), _p(h), _p(b), float(p), seed, off, h.numel() // F, F, _p(dh), _p(db), _p(s["ws"]),
-                                                      _stream()))
+    with _on(h.device):
+        _lib.check(s["lib"].amuse_train_bias_gelu_drop_bwd(_p(da), _p(h), _p(b), float(p), seed, off, h.numel() // F, F, _p(dh), _p(db), _p(s["ws"]),
+                                                          _stream(h.device)))
     return dh, db
 
 
@@ -210,13 +236,15 @@ def attn_fwd(qkv: torch.Tensor, B: int, S: int, p: float, seed: int, off: int, w
     o = torch.empty(B * S, 128, device=qkv.device, dtype=torch.float32)
     lse = torch.empty(B, 4, S, device=qkv.device, dtype=torch.float32)
     mask = torch.ones(B, 4, S, S, device=qkv.device, dtype=torch.float32) if want_mask else None
-    _lib.check(_st(qkv.device)["lib"].amuse_train_attn_fwd(_p(qkv), B, S, float(p), seed, off, _p(o), _p(lse), _p(mask), _stream()))
+    with _on(qkv.device):
+        _lib.check(_st(qkv.device)["lib"].amuse_train_attn_fwd(_p(qkv), B, S, float(p), seed, off, _p(o), _p(lse), _p(mask), _stream(qkv.device)))
     return (o, lse, mask) if want_mask else (o, lse)
 
 
 def attn_bwd(qkv, o, lse, dout, B: int, S: int, p: float, seed: int, off: int) -> torch.Tensor:
     dqkv = torch.empty_like(qkv)
-    _lib.check(_st(qkv.device)["lib"].amuse_train_attn_bwd(_p(_c(qkv)), _p(o), _p(lse), _p(_c(dout)), B, S, float(p), seed, off, _p(dqkv), _stream()))
+    with _on(qkv.device):
+        _lib.check(_st(qkv.device)["lib"].amuse_train_attn_bwd(_p(_c(qkv)), _p(o), _p(lse), _p(_c(dout)), B, S, float(p), seed, off, _p(dqkv), _stream(qkv.device)))
     return dqkv
 
 
@@ -225,7 +253,8 @@ def colsum(x):
     C = x.shape[-1]
     s = _st(x.device)
     out = torch.empty(C, device=x.device, dtype=torch.float32)
-    _lib.check(s["lib"].amuse_train_colsum(_p(x), x.numel() // C, C, _p(out), _p(s["ws"]), _stream()))
+    with _on(x.device):
+        _lib.check(s["lib"].amuse_train_colsum(_p(x), x.numel() // C, C, _p(out), _p(s["ws"]), _stream(x.device)))
     return out
 
 
@@ -244,12 +273,22 @@ _DEC_PARAMS = ("Wo", "bo", "g1", "be1", "Wv", "bv", "Wc", "bc", "g2", "be2", "W1
 
 
 def _layer_forward(ctx, x, mem, Win, bin_, prm: dict, H: int, p: float, p_attn: float):
+    with _on(x.device):
+        return _layer_forward_on(ctx, x, mem, Win, bin_, prm, H, p, p_attn)
+
+
+def _layer_backward(ctx, dout):
+    with _on(dout.device):
+        return _layer_backward_on(ctx, dout)
+
+
+def _layer_forward_on(ctx, x, mem, Win, bin_, prm: dict, H: int, p: float, p_attn: float):
     """ONE call into the library (amuse_train_layer_fwd: in-projection, attention, the rest of the layer) - or, with aten's attention, the in-projection call, aten's op,
     and the layer call behind it."""
     B, S, D = x.shape
     rows, ff, dev = B * S, prm["W1"].shape[0], x.device
     st = _st(dev)
-    lib, stream = st["lib"], _stream()
+    lib, stream = st["lib"], _stream(dev)
     x2 = _c(x).view(rows, D)
     keep = any(ctx.needs_input_grad)                       # (no-grad passes - the iteration's second encode - keep nothing beyond the call)
     qkv = torch.empty(rows, 3 * D, device=dev, dtype=torch.float32)
@@ -296,14 +335,14 @@ def _layer_forward(ctx, x, mem, Win, bin_, prm: dict, H: int, p: float, p_attn: 
     return b128[2].view(B, S, D)
 
 
-def _layer_backward(ctx, dout):
+def _layer_backward_on(ctx, dout):
     t = ctx.saved_tensors
     B, S, D, H, p_attn, dec, names, own = ctx.cfg
     x2, qkv, ao, lse, ps, po, o2, b128, b512, Win = t[:10]
     prm = dict(zip(names, t[12 if dec else 10:]))
     rows, ff, dev = B * S, b512.shape[2], x2.device
     st = _st(dev)
-    lib, stream = st["lib"], _stream()
+    lib, stream = st["lib"], _stream(dev)
     L = ctx.L
     dout = _c(dout).view(rows, D)
     g128 = torch.empty(4, rows, D, device=dev, dtype=torch.float32)                      # dx do2 s128a s128b
@@ -384,7 +423,8 @@ class LinearFn(torch.autograd.Function):
         x2 = _c(x).view(-1, K)
         rows = x2.shape[0]
         out = torch.empty(rows, N, device=x.device, dtype=torch.float32)
-        _lib.check(_st(x.device)["lib"].amuse_train_linear_fwd(x2.data_ptr(), W.data_ptr(), _p(b), rows, K, N, out.data_ptr(), _stream()))
+        with _on(x.device):
+            _lib.check(_st(x.device)["lib"].amuse_train_linear_fwd(x2.data_ptr(), W.data_ptr(), _p(b), rows, K, N, out.data_ptr(), _stream(x.device)))
         ctx.save_for_backward(x2, W)
         ctx.has_bias = b is not None
         ctx.b = b   # (address only: the gradient sink)
@@ -403,7 +443,9 @@ class LinearFn(torch.autograd.Function):
         pb = _sink_ptr(ctx.b) if need_b else 0
         dW = torch.empty_like(W) if need_w and not pW else None
         db = torch.empty(N, device=dy.device, dtype=torch.float32) if need_b and not pb else None
-        _lib.check(st["lib"].amuse_train_linear_bwd(dy.data_ptr(), x2.data_ptr(), W.data_ptr(), rows, K, N, pW or _p(dW), pb or _p(db), _p(dx), 0, st["ws"].data_ptr(), _stream()))
+        with _on(dy.device):
+            _lib.check(st["lib"].amuse_train_linear_bwd(dy.data_ptr(), x2.data_ptr(), W.data_ptr(), rows, K, N, pW or _p(dW), pb or _p(db), _p(dx), 0, st["ws"].data_ptr(),
+                                                        _stream(dy.device)))
         return (None if dx is None else dx.view(*dout.shape[:-1], K)), dW, db
 
 
@@ -443,6 +485,7 @@ class FlatAdamW(torch.optim.AdamW):
     layout: [(parameter, offset, numel)] of EVERY parameter in the flat buffers, in order."""
 
     def __init__(self, params, flat_param: torch.Tensor, flat_grad: torch.Tensor, layout, **kw):
+        self._ranges = None
         super().__init__(params, **kw)
         assert flat_param.is_cuda and flat_param.dtype == torch.float32 and flat_param.is_contiguous() and flat_grad.shape == flat_param.shape
         self._p, self._g = flat_param, flat_grad
@@ -466,14 +509,49 @@ class FlatAdamW(torch.optim.AdamW):
         assert closure is None
         self._t += 1
         g = self.param_groups[0]
-        lib, stream = _st(self._p.device)["lib"], _stream()
+        dev = self._p.device
+        lib, stream = _st(dev)["lib"], _stream(dev)
         b = self._p.data_ptr()
-        for off, n in self._ranges:
-            _lib.check(lib.amuse_train_adamw(b + 4 * off, self._g.data_ptr() + 4 * off, self._m.data_ptr() + 4 * off, self._v.data_ptr() + 4 * off, n, float(g["lr"]),
-                                             float(g["betas"][0]), float(g["betas"][1]), float(g["eps"]), float(g["weight_decay"]), self._t, stream))
+        with _on(dev):
+            for off, n in self._ranges:
+                _lib.check(lib.amuse_train_adamw(b + 4 * off, self._g.data_ptr() + 4 * off, self._m.data_ptr() + 4 * off, self._v.data_ptr() + 4 * off, n, float(g["lr"]),
+                                                 float(g["betas"][0]), float(g["betas"][1]), float(g["eps"]), float(g["weight_decay"]), self._t, stream))
 
     def state_dict(self):
         for st in self.state.values():
             st["step"] = torch.tensor(float(self._t))
         return super().state_dict()
+
+    @torch.no_grad()
+    def load_state_dict(self, state_dict):
+        """Resume (the `optimizer_state_dict` the checkpoint writer stores, trainer.py:468-496): torch's loader replaces the per-parameter state tensors
+        with copies, which would detach them from the flat buffers the kernel reads - copy the loaded moments INTO the flat buffers, re-create the views and
+        restore the step count the bias correction uses."""
+        mine = list(self.state.keys())                               # parameters in the order torch numbers them
+        views = {p: (st["exp_avg"], st["exp_avg_sq"]) for p, st in self.state.items()}
+        super().load_state_dict(state_dict)
+        steps = set()
+        for p in mine:
+            st = self.state.get(p)
+            m, v = views[p]
+            if st is None or "exp_avg" not in st:                    # a parameter the saved run never stepped
+                m.zero_(), v.zero_()
+                self.state[p] = {"step": torch.tensor(0.0), "exp_avg": m, "exp_avg_sq": v}
+                continue
+            m.copy_(st["exp_avg"]), v.copy_(st["exp_avg_sq"])
+            steps.add(int(float(st["step"])))
+            st["exp_avg"], st["exp_avg_sq"] = m, v
+        steps.discard(0)
+        if len(steps) > 1:
+            raise ValueError(f"FlatAdamW takes ONE step count for all parameters, the state dict holds {sorted(steps)}")
+        self._t = steps.pop() if steps else 0
+
+    def zero_grad(self, set_to_none: bool = False):
+        """The gradients are views of the flat bucket the kernel reads: zero the bucket, never detach the views."""
+        self._g.zero_()
+
+    def add_param_group(self, param_group):
+        if getattr(self, "_ranges", None) is not None:
+            raise NotImplementedError("FlatAdamW is laid out over ONE parameter group at construction")
+        super().add_param_group(param_group)
 

@@ -486,7 +486,10 @@ def main():
             eng.set_schedule(sch.ddpm_table(args.T))
             eng.set_clips_per_group(0)
         if world == 1 and args.precision in ("bf16", "fp16"):
-            line["diffusion_only"] = diffusion_only_extra(dev, args.precision, peak)
+            try:   # the headline must not depend on an extra
+                line["diffusion_only"] = diffusion_only_extra(dev, args.precision, peak)
+            except Exception as e:
+                line["diffusion_only"] = {"error": f"{type(e).__name__}: {e}"}
         if world == 1 and not args.no_audio:
             # side measurement, not part of `value` (whose inputs are the three 256-d embeddings): the
             # audio front-end that produces them from 10 s of 16 kHz audio - kaldi fbank + 3 x AST, 778 GFLOP per clip
@@ -514,14 +517,15 @@ def main():
             # BASELINE config 4 beside the headline: the train_gesture iteration at batch 32 on this GPU - `--config train` in a child process of its own
             # (the step is host-bound: inside this process, behind the engines above, it measures ~25 % slower than alone); DESIGN.md 4.6
             import subprocess
-            r = subprocess.run([sys.executable, str(Path(__file__).resolve()), "--config", "train", "--steps", "40", "--warmup", "15"], capture_output=True, text=True,
-                               timeout=600)
+            r = None
             try:
+                r = subprocess.run([sys.executable, str(Path(__file__).resolve()), "--config", "train", "--steps", "40", "--warmup", "15"], capture_output=True, text=True,
+                                   timeout=600)
                 tl = json.loads(r.stdout.strip().splitlines()[-1])
                 line["train_gesture"] = {"batch_per_gpu": 32, "it_per_s": tl["value"], "ms_per_iteration": tl["ms_per_step"], "how": "python bench.py --config train --steps 40 "
                                          "--warmup 15 as a child process; transformer layers (incl. their fp32 attention) on the library's layer-level entry points (amuse_train_*), DESIGN.md 4.6"}
             except Exception as e:   # the headline must not depend on the extra
-                line["train_gesture"] = {"error": f"{type(e).__name__}: {e}; stderr tail: {r.stderr[-300:]}"}
+                line["train_gesture"] = {"error": f"{type(e).__name__}: {e}; stderr tail: {r.stderr[-300:] if r is not None else ''}"}
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(total, args.T, wd, wp)
     barrier()

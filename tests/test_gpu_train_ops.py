@@ -247,6 +247,87 @@ def test_flat_adamw_equals_torch_adamw_and_keeps_its_state_layout():
         assert _rel(sd["state"][k]["exp_avg_sq"], rsd["state"][k]["exp_avg_sq"]) < 2e-6
 
 
+def _flat_setup(seed, dev=None):
+    dev = dev or DEV
+    g = torch.Generator(device=dev).manual_seed(seed)
+    shapes = [(128, 128), (128,), (384, 128), (7,)]
+    n = sum(int(np.prod(s)) for s in shapes)
+    flat_p, flat_g = torch.randn(n, device=dev, generator=g), torch.zeros(n, device=dev)
+    params, layout, off = [], [], 0
+    for s in shapes:
+        k = int(np.prod(s))
+        p = torch.nn.Parameter(flat_p[off:off + k].view(s))
+        p.grad = flat_g[off:off + k].view(s)
+        params.append(p)
+        layout.append((p, off, k))
+        off += k
+    return g, n, flat_p, flat_g, params, layout
+
+
+def test_flat_adamw_resumes_from_a_saved_state_like_torch_adamw():
+    """optimizer_state_dict round trip (the checkpoint writer stores it, trainer.py:468-496): 3 steps, save, load into a FRESH FlatAdamW and a fresh
+    torch AdamW, 3 more steps on the same gradients -> same parameters; the loaded moments live in the flat buffers the kernel reads, the bias correction
+    continues at step 4, zero_grad keeps the gradient views attached to the bucket."""
+    from amuse_amd.train_ops import FlatAdamW
+    g, n, flat_p, flat_g, params, layout = _flat_setup(3)
+    opt = FlatAdamW(params, flat_p, flat_g, layout, lr=3e-3)
+    for _ in range(3):
+        flat_g.copy_(torch.randn(n, device=DEV, generator=g))
+        opt.step()
+    saved = {"opt": opt.state_dict(), "p": flat_p.clone()}
+    grads = [torch.randn(n, device=DEV, generator=g) for _ in range(3)]
+    # torch's own optimizer resumed from the same dict
+    ref_p = [torch.nn.Parameter(p.detach().clone()) for p in params]
+    ref = torch.optim.AdamW(ref_p, lr=3e-3)
+    ref.load_state_dict(saved["opt"])
+    # a fresh flat optimizer (new buffers, as after a restart)
+    _, _, fp2, fg2, params2, layout2 = _flat_setup(99)
+    fp2.copy_(saved["p"])
+    opt2 = FlatAdamW(params2, fp2, fg2, layout2, lr=3e-3)
+    opt2.load_state_dict(saved["opt"])
+    assert opt2._t == 3
+    for p in params2:
+        st = opt2.state[p]
+        assert st["exp_avg"].data_ptr() >= opt2._m.data_ptr() and st["exp_avg"].data_ptr() < opt2._m.data_ptr() + 4 * n   # still views of the flat buffer
+    assert _rel(opt2._m, opt._m) == 0 and _rel(opt2._v, opt._v) == 0
+    for gr in grads:
+        opt2.zero_grad(set_to_none=True)
+        assert all(p.grad is not None and p.grad.data_ptr() >= fg2.data_ptr() for p in params2) and float(fg2.abs().max()) == 0
+        fg2.copy_(gr)
+        off = 0
+        for p in ref_p:
+            p.grad = gr[off:off + p.numel()].view_as(p).clone()
+            off += p.numel()
+        opt2.step()
+        ref.step()
+    for p, q in zip(ref_p, params2):
+        assert _rel(q.detach(), p.detach()) < 2e-6
+    assert float(opt2.state_dict()["state"][0]["step"]) == 6.0
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs a second GPU")
+def test_layers_on_a_non_current_device():
+    """The library calls run on the TENSORS' device (device guard in train_ops), not on the process's current device: a layer on cuda:1 while cuda:0 is current
+    gives the bits of the same layer on cuda:0."""
+    from amuse_amd import train_ops as T
+    from amuse_amd.nn_modules import EncoderLayer
+    torch.manual_seed(0)
+    m0 = EncoderLayer().to("cuda:0").eval()
+    m1 = EncoderLayer().to("cuda:1").eval()
+    m1.load_state_dict(m0.state_dict())
+    x = torch.randn(3, 5, 128)
+    torch.cuda.set_device(0)
+    outs = []
+    for m, d in ((m0, "cuda:0"), (m1, "cuda:1")):
+        xx = x.to(d).requires_grad_(True)
+        y = T.encoder_layer(m, xx)
+        y.square().sum().backward()
+        outs.append((y.detach().cpu(), xx.grad.cpu(), m.linear1.weight.grad.cpu()))
+    assert torch.cuda.current_device() == 0
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
+
+
 @pytest.mark.parametrize("rows,K,N", [(9664, 333, 128), (9600, 256, 128), (32, 256, 128), (5, 128, 384),
                                       # the library's own weight-gradient kernel (k_train_wgrad: reductions from 1,024 rows, both widths multiples of 64, N x K < 65,536) - a
                                       # ragged last chunk of 192 rows, one chunk + 4 rows, its streaming instantiation (384 x 128), and its neighbours on rocBLAS
