@@ -134,6 +134,34 @@ def train_gesture_entry(args, dirname: Path, config: dict):
                 pass
 
 
+def _launch_ranks(args, argv, dirname: Path):
+    """`--fn infer_gesture | edit_gesture --gpus N` typed directly: this process never touches the GPU; it starts N ranks of this very module as
+    CHILD processes (amuse_amd/launch.py: torch.distributed.run, never exec), hands them ONE time stamp for the output directory and a scratch
+    directory for their manifests, and returns the paths all ranks wrote (rank order = job order)."""
+    import sys
+    import tempfile
+    from datetime import datetime
+    from . import launch
+    av = list(sys.argv[1:] if argv is None else argv)
+    if args.root is None:                      # the ranks start in another process: name the tree explicitly
+        av += ["--root", str(dirname)]
+    with tempfile.TemporaryDirectory(prefix="amuse_ranks_") as md:
+        os.environ["AMUSE_RUN_STAMP"] = os.environ.get("AMUSE_RUN_STAMP") or datetime.now().strftime("%Y%m%d-%H%M%S")
+        os.environ["AMUSE_MANIFEST_DIR"] = md
+        try:
+            rc = launch.run_ranks("amuse_amd.main", av, args.gpus, module=True)
+        finally:
+            os.environ.pop("AMUSE_MANIFEST_DIR", None)
+        if rc != 0:
+            raise SystemExit(rc)
+        written = []
+        for r in range(args.gpus):
+            f = Path(md, f"rank{r}.json")
+            written += [Path(p) for p in json.loads(f.read_text())] if f.exists() else []
+    print(f"AMUSE: ({args.fn[0]}) {args.gpus} ranks wrote {len(written)} NPZ files")
+    return written
+
+
 def main(argv=None):
     ap = argparse.ArgumentParser(description="AMUSE (MI355X path)")
     ap.add_argument("--fn", nargs="*", required=True, help="infer_gesture, edit_gesture, train_gesture")
@@ -152,7 +180,11 @@ def main(argv=None):
                          "the fp32 MFMA, 2.6 x slower; fp16: the throughput mode (2 x fp32x, ~3e-3 on eps_hat; operands must stay below 65504: an "
                          "overflow surfaces as a non-finite output); bf16: the same speed with 8 x the rounding - only for activations beyond fp16 range")
     ap.add_argument("--device", default="cuda:0")
-    ap.add_argument("--gpus", type=int, default=1, help="train_gesture: data-parallel ranks on this node (one process per GPU)")
+    ap.add_argument("--gpus", type=int, default=1, help="one process per GPU on this node: train_gesture = data-parallel ranks (RCCL all-reduce); infer_gesture / "
+                                                         "edit_gesture = the job list cut into contiguous ranges, each rank embeds, samples and writes its own (no collective; "
+                                                         "the NPZ files are byte for byte the single-process run's)")
+    ap.add_argument("--all-pairs", action="store_true", help="edit_gesture: every *_source.wav edited with the emotion of every *_target.wav (S x T jobs) instead of "
+                                                             "the reference's first source / first target pair (sets TRAIN_PARAM.test.emotion_control_list.all_pairs)")
     ap.add_argument("--epochs", type=int, default=None, help="train_gesture: override TRAIN_PARAM.latent_diffusion.n_epochs")
     ap.add_argument("--synthetic", action="store_true", help="train_gesture: synthetic batches instead of the LMDB cache")
     ap.add_argument("--iters-per-epoch", type=int, default=None, help="train_gesture --synthetic: iterations per epoch")
@@ -169,6 +201,29 @@ def main(argv=None):
     if fn == "train_gesture":
         config["_ldm_cfg"] = ldm_cfg
         return train_gesture_entry(args, dirname, config)
+    from . import launch
+    if args.gpus > 1 and not launch.launched_by_torchrun():
+        return _launch_ranks(args, argv, dirname)
+    world, rank, local_rank = (int(os.environ.get(k, d)) for k, d in (("WORLD_SIZE", "1"), ("RANK", "0"), ("LOCAL_RANK", "0")))
+    if world > 1:
+        if args.device not in ("cuda", "cuda:0") and os.environ.get("AMUSE_SHARE_GPU") != "1":
+            raise SystemExit(f"--device {args.device} with {world} ranks would put every rank on one GPU: drop the index (rank r uses cuda:<LOCAL_RANK>)")
+        if os.environ.get("AMUSE_SHARE_GPU") != "1":     # (tests on a one-GPU box: AMUSE_SHARE_GPU=1 keeps every rank on --device)
+            args.device = f"cuda:{local_rank}"
+        torch.cuda.set_device(torch.device(args.device))
+    if args.all_pairs:
+        tp["test"].setdefault("emotion_control_list", {})["all_pairs"] = True
+    pg = False
+    if world > 1 and fn == "edit_gesture" and tp["test"].get("emotion_control_list", {}).get("all_pairs"):
+        # the ONE exchange of the inference path: S sources x T targets - every rank's jobs read most WAVs, so each rank embeds a share and
+        # the embeddings (3 x 256 floats per WAV) are all-gathered.  RCCL between the GPUs; gloo when the ranks share a device (tests).
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if os.environ.get("AMUSE_SHARE_GPU") == "1":
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device(args.device))
+        pg = True
     assert tp["pretrained_infer"], f"Arg: {fn} and pretrained_infer: {tp['pretrained_infer']} mismatch!"   # main.py:129
     assert tp["motion_extractor"]["use"] is False, "Motion extractor should be False!"
     if args.audios or args.renders:
@@ -207,11 +262,17 @@ def main(argv=None):
     eval_loader = torch.load(args.eval_data, weights_only=False) if args.eval_data else None
     tr = trainer(config, device, train_loader=eval_loader, model_path=model_path, tag="LPDM_infer", logger_cfg=None,
                  model=model, processed=processed, metricsmodel=None, b_path=None, EXEC_ON_CLUSTER=False,
-                 debug=tp.get("debug", True), pretrained_infer=True)
+                 debug=tp.get("debug", True), pretrained_infer=True, rank=rank, world=world)
     written = tr.eval_prior_latdiff_forward_backward_v1(baseline, ldm_epoch, audio_list, short_audio_list,
                                                         modelversion=modelversion, ammetric=True)
     torch.cuda.synchronize()
-    print(f"AMUSE: ({fn}) completed in: {(time.time() - tic) / 3600} hrs; {len(written)} NPZ files")
+    print(f"AMUSE: ({fn}) completed in: {(time.time() - tic) / 3600} hrs; {len(written)} NPZ files" + (f" on rank {rank} of {world}" if world > 1 else ""))
+    if world > 1 and os.environ.get("AMUSE_MANIFEST_DIR"):      # the launcher collects what the ranks wrote
+        Path(os.environ["AMUSE_MANIFEST_DIR"], f"rank{rank}.json").write_text(json.dumps([str(p) for p in written]))
+    if pg:
+        import torch.distributed as dist
+        dist.barrier()
+        dist.destroy_process_group()
     return written
 
 

@@ -40,6 +40,29 @@ def shard_range(total: int, rank: int, world: int, align: int = 1) -> Tuple[int,
     return min(total, start * align), min(total, stop * align)
 
 
+def job_range(bszs, rank: int, world: int, align: int = 1) -> Tuple[int, int]:
+    """Contiguous range [ja, jb) of JOBS for this rank, for jobs of bszs[j] clips each laid out back to back (job j's clips have the
+    global indices offs[j] .. offs[j+1]): the clip axis is cut by shard_range(total, rank, world, align) and every cut is moved
+    forward to the next job boundary whose clip offset is a multiple of `align` (the job's clips per tile: a clip then sits in the same
+    slot of its tile as in the single-process launch, which is what keeps sharded results bitwise).  The ranges of ranks 0..world-1
+    are disjoint, ordered and cover every job; a rank may get none."""
+    offs = [0]
+    for b in bszs:
+        offs.append(offs[-1] + int(b))
+    total, n = offs[-1], len(bszs)
+    ok = [j for j in range(n + 1) if offs[j] % align == 0 or j == n]
+
+    def snap(clip):
+        for j in ok:
+            if offs[j] >= clip:
+                return j
+        return n
+    lo, hi = shard_range(total, rank, world, align)
+    ja = 0 if rank == 0 else snap(lo)
+    jb = n if rank == world - 1 else snap(hi)
+    return ja, max(ja, jb)
+
+
 def sample_sharded(sample_fn: Callable[..., Dict[str, torch.Tensor]], z_con, z_emo, z_sty, rank: int, world: int,
                    gather: bool = False, group=None, set_clips_per_group: Optional[Callable[[int], None]] = None,
                    set_decode_path: Optional[Callable[[str], None]] = None) -> Optional[Dict[str, torch.Tensor]]:

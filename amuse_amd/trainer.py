@@ -15,9 +15,21 @@ clip axis and sampled in one launch; job j's clips get the global clip indices t
 handed out had the calls been made one by one, so the batched result is the sequential one (bitwise up to 128 clips per
 launch: one clip per workgroup tile in both cases).  Rendering (Blender / ffmpeg, wav export) is out of scope: outputs
 stop at the `*_motion_smplx.npz` files `CaMNVisualizer.animate_ldm_sample_v1/v2` write first (npz_writer.write_sample).
+
+More than one GPU (`main.py --fn infer_gesture | edit_gesture --gpus N`; the reference refuses multi-GPU inference,
+models/audio/infer_pretrained_ast_evp.py:45): one process per GPU, every rank builds the SAME job list and takes a contiguous
+range of it (shard.job_range; cuts on tile boundaries of the whole launch, clips keep their global indices, tile size and decode
+kernels are pinned to what the single-process launch would pick -> the NPZ bytes are the single-process run's).  A rank embeds only
+the WAVs its own jobs read and writes only its own NPZs, under the names the single-process run would have given them (the random
+file tags are drawn for every job on every rank).  No collective - except the one real exchange of the path: when an edit batch
+crosses MANY sources with MANY targets (emotion_control_list.all_pairs), each rank embeds its share of the WAVs and the 3 x 256
+floats per WAV are all-gathered (torch.distributed: RCCL on the GPUs, gloo on the CPU).
 """
 from __future__ import annotations
 
+import os
+import random
+import string
 import time
 from datetime import datetime
 from pathlib import Path
@@ -58,6 +70,11 @@ def load_wav(path) -> torch.Tensor:
     return torch.from_numpy(np.ascontiguousarray(x.T))
 
 
+def _dist_ready() -> bool:
+    import torch.distributed as dist
+    return dist.is_available() and dist.is_initialized()
+
+
 def _emotion_of_take(take_emo: str) -> str:
     """trainer.py:873,877: [k for k, v in train_takes_dict.items() if f"0_{take_emo}_{take_emo}" in v][0]."""
     return [k for k, v in TAKES.items() if f"0_{take_emo}_{take_emo}" in v][0]
@@ -68,8 +85,51 @@ def _job(actor, take, z_con, z_emo, z_sty, bsz, info, swap_info=None, audio=None
     j = {"actor": actor, "take": take, "bsz": bsz, "z_con": z_con[:bsz], "z_emo": None if z_emo is None else z_emo[:bsz],
          "z_sty": None if z_sty is None else z_sty[:bsz], "info": info, "swap_info": swap_info,
          "audio": None if audio is None else audio[0:bsz * 10000], "src_motion": src_motion}
+    j["no_emo"], j["no_sty"], j["remote"] = z_emo is None, z_sty is None, False
     j.update(extra)
     return j
+
+
+def _remote_job(actor, take, bsz, info, swap_info=None, no_emo=False, no_sty=False, **extra) -> dict:
+    """A job another rank samples: what the job LIST needs of it (clip count, token set, names) without its tensors."""
+    j = {"actor": actor, "take": take, "bsz": int(bsz), "z_con": None, "z_emo": None, "z_sty": None, "info": info,
+         "swap_info": swap_info, "audio": None, "src_motion": None, "no_emo": no_emo, "no_sty": no_sty, "remote": True}
+    j.update(extra)
+    return j
+
+
+def job_runs(jobs: List[dict]):
+    """The launches of run_jobs: [(token-set key, [job indices])], one per contiguous run of jobs with the same set of condition tokens."""
+    groups: Dict[tuple, List[int]] = {}
+    for j, job in enumerate(jobs):
+        # (the tensors decide; the stored flags stand in for them in jobs built without tensors - remote jobs, plan triples)
+        key = (job["no_emo"], job["no_sty"]) if job.get("remote", "z_con" not in job) else (job["z_emo"] is None, job["z_sty"] is None)
+        groups.setdefault(key, []).append(j)
+    runs = []
+    for key, idx in groups.items():
+        start = 0
+        for k in range(1, len(idx) + 1):
+            if k == len(idx) or idx[k] != idx[k - 1] + 1:
+                runs.append((key, idx[start:k]))
+                start = k
+    return runs
+
+
+def local_jobs(jobs_or_specs, rank: int, world: int) -> List[bool]:
+    """Which jobs of the list this rank samples (run by run, shard.job_range on the run's tile size).  Entries: job dicts, or
+    (bsz, no_emo, no_sty) triples when the tensors do not exist yet (the plan comes before the audio front-end)."""
+    from . import shard
+    specs = [j if isinstance(j, dict) else {"bsz": j[0], "no_emo": j[1], "no_sty": j[2]} for j in jobs_or_specs]
+    mine = [world == 1] * len(specs)
+    if world == 1:
+        return mine
+    for (no_emo, no_sty), idx in job_runs(specs):
+        bszs = [specs[j]["bsz"] for j in idx]
+        g = shard.job_clips_per_group(sum(bszs), 5 - no_emo - no_sty)
+        ja, jb = shard.job_range(bszs, rank, world, align=g)
+        for k in range(ja, jb):
+            mine[idx[k]] = True
+    return mine
 
 
 def emotion_control_jobs(data: Dict, take_element: str = "first") -> List[dict]:
@@ -150,7 +210,7 @@ def style_Xemo_transfer_jobs(data: Dict, actors: str, emotion: str) -> List[dict
     return _transfer_jobs(es, a1_attr, a2_attr, "Style X Emo Transfer", emotion, min_over_z=False)
 
 
-def run_jobs(model, jobs: List[dict], return_latents: bool = False, batched: bool = True) -> List[dict]:
+def run_jobs(model, jobs: List[dict], return_latents: bool = False, batched: bool = True, rank: int = 0, world: int = 1) -> List[Optional[dict]]:
     """Sample every job; returns, per job and in job order, the reference's `rst` entry
     {"feats": (bsz,300,168), "audio", "info"[, "swap_info"]} (trainer.py:884-890) [+ "latents"].
     batched=True: ONE diffusion_backward per group of jobs that share the set of condition tokens (a missing z_emo /
@@ -162,7 +222,12 @@ def run_jobs(model, jobs: List[dict], return_latents: bool = False, batched: boo
     follows a clip's slot, amuse_hip.h amuse_set_clips_per_group), and a launch of 64 clips or more decodes on another kernel
     than the sequential one-clip calls take - bf16 / fp16: the fused per-clip decoder instead of the staged kernels; fp32x: the
     row stages without split-K (k_vae_rows8x) instead of k_vae_rows<f16x2> - the same operands, another summation order.
-    A caller that needs the sequential bits pins both: engine.set_clips_per_group(1), set_decode_path("staged")."""
+    A caller that needs the sequential bits pins both: engine.set_clips_per_group(1), set_decode_path("staged").
+    world > 1 (one process per GPU, every rank calls this with the SAME list): each launch of the batched form is cut into `world`
+    contiguous job ranges (shard.job_range) and this rank samples its range only, with the tile size and decode kernels of the WHOLE
+    launch pinned - its results are bitwise the single-process ones; the entries of the other ranks' jobs are None.  Jobs marked
+    `remote` (built without tensors, _remote_job) must fall into other ranks' ranges."""
+    from . import shard
     out: List[Optional[dict]] = [None] * len(jobs)
     dev = model.device
     c0 = model._clip_counter
@@ -177,31 +242,41 @@ def run_jobs(model, jobs: List[dict], return_latents: bool = False, batched: boo
         out[j] = r
 
     if not batched:
+        mine = local_jobs(jobs, rank, world)
         for j, job in enumerate(jobs):
-            o = model.diffusion_backward(job["bsz"], job["z_con"], job["z_emo"], job["z_sty"], return_latents=return_latents)
-            finish(j, o["poses"], o["trans"], o.get("latents"))
-        return out
-    groups: Dict[tuple, List[int]] = {}
-    for j, job in enumerate(jobs):
-        groups.setdefault((job["z_emo"] is None, job["z_sty"] is None), []).append(j)
-    cat = lambda ts: None if ts[0] is None else torch.cat([torch.as_tensor(t).to(dev, torch.float32) for t in ts])
-    for (no_emo, no_sty), idx in groups.items():
-        con, emo, sty = (cat([jobs[j][k] for j in idx]) for k in ("z_con", "z_emo", "z_sty"))
-        # contiguous runs of jobs keep contiguous global clip indices; a group that is not one run is launched per run
-        runs, start = [], 0
-        for k in range(1, len(idx) + 1):
-            if k == len(idx) or idx[k] != idx[k - 1] + 1:
-                runs.append((start, k))
-                start = k
-        pos = np.concatenate([[0], np.cumsum([jobs[j]["bsz"] for j in idx])]).astype(int)
-        for a, b in runs:
-            lo, hi = pos[a], pos[b]
-            sl = lambda t: None if t is None else t[lo:hi]
-            o = model.diffusion_backward(int(hi - lo), sl(con), sl(emo), sl(sty), clip_index0=int(c0 + offs[idx[a]]),
+            if not mine[j]:
+                continue
+            o = model.diffusion_backward(job["bsz"], job["z_con"], job["z_emo"], job["z_sty"], clip_index0=int(c0 + offs[j]),
                                          return_latents=return_latents)
-            for k in range(a, b):
-                s0, s1 = pos[k] - lo, pos[k + 1] - lo
-                finish(idx[k], o["poses"][s0:s1], o["trans"][s0:s1], o["latents"][s0:s1] if return_latents else None)
+            finish(j, o["poses"], o["trans"], o.get("latents"))
+        model._clip_counter = int(c0 + offs[-1])
+        return out
+    cat = lambda ts: None if ts[0] is None else torch.cat([torch.as_tensor(t).to(dev, torch.float32) for t in ts])
+    eng = getattr(model, "engine", None)
+    for (no_emo, no_sty), idx in job_runs(jobs):     # contiguous runs of jobs keep contiguous global clip indices: one launch per run
+        bszs = [jobs[j]["bsz"] for j in idx]
+        ja, jb = 0, len(idx)
+        if world > 1:
+            g = shard.job_clips_per_group(sum(bszs), 5 - no_emo - no_sty)
+            ja, jb = shard.job_range(bszs, rank, world, align=g)
+            if jb == ja:
+                continue
+            if eng is not None:      # the WHOLE launch's tiling and decode kernels, not this shard's
+                eng.set_clips_per_group(g)
+                eng.set_decode_path(shard.job_decode_path(sum(bszs)))
+        sel = idx[ja:jb]
+        assert not any(jobs[j]["remote"] for j in sel), "a job built without its tensors fell into this rank's range"
+        con, emo, sty = (cat([jobs[j][k] for j in sel]) for k in ("z_con", "z_emo", "z_sty"))
+        pos = np.concatenate([[0], np.cumsum([jobs[j]["bsz"] for j in sel])]).astype(int)
+        try:
+            o = model.diffusion_backward(int(pos[-1]), con, emo, sty, clip_index0=int(c0 + offs[sel[0]]), return_latents=return_latents)
+        finally:
+            if world > 1 and eng is not None:
+                eng.set_clips_per_group(0)
+                eng.set_decode_path("auto")
+        for k, j in enumerate(sel):
+            s0, s1 = pos[k], pos[k + 1]
+            finish(j, o["poses"][s0:s1], o["trans"][s0:s1], o["latents"][s0:s1] if return_latents else None)
     model._clip_counter = int(c0 + offs[-1])
     return out
 
@@ -212,13 +287,17 @@ class trainer:
 
     def __init__(self, config, device, train_loader=None, val_loader=None, model_path=None, tag="LPDM_infer",
                  logger_cfg=None, model=None, processed=None, metricsmodel=None, b_path=None, EXEC_ON_CLUSTER=False,
-                 debug=False, pretrained_infer=True, batched=True):
+                 debug=False, pretrained_infer=True, batched=True, rank: Optional[int] = None, world: Optional[int] = None,
+                 stamp: Optional[str] = None):
         if tag != "LPDM_infer" or not pretrained_infer:
             raise NotImplementedError("amuse_amd.trainer mirrors the evaluation entry points (tag LPDM_infer); training: "
                                       "amuse_amd/train_gesture.py")
         self.config, self.device, self.model, self.train_loader = config, device, model, train_loader
         self.tag, self.debug, self.processed, self.EXEC_ON_CLUSTER = tag, debug, processed, EXEC_ON_CLUSTER
         self.batched = batched
+        # one process per GPU (main.py --gpus N -> torch.distributed.run): every rank builds this object over the same configuration
+        self.rank = int(os.environ.get("RANK", "0")) if rank is None else int(rank)
+        self.world = int(os.environ.get("WORLD_SIZE", "1")) if world is None else int(world)
         ld, test = config["TRAIN_PARAM"]["latent_diffusion"], config["TRAIN_PARAM"]["test"]
         self.smplx_data, self.skip_trans = ld["smplx_data"], ld["skip_trans"]
         self.viz_type = ld.get("viz_type", "CaMN")
@@ -226,7 +305,8 @@ class trainer:
         self.model_path_r = Path(model_path) if model_path is not None else Path(".")
         self.model_dir_name = tag + "_" + datetime.now().strftime("%Y%m%d-%H%M%S") + "_" + shuffle_type
         self.model_path = self.model_path_r / f"{self.model_dir_name}_smplx"
-        self.stamp = datetime.now().strftime("%Y%m%d-%H%M%S")
+        # the output directory's time stamp: ONE per run - the launcher hands its own to the ranks (AMUSE_RUN_STAMP)
+        self.stamp = stamp or os.environ.get("AMUSE_RUN_STAMP") or datetime.now().strftime("%Y%m%d-%H%M%S")
         use = lambda k: bool(test.get(k, {}).get("use", False))
         self.style_transfer, self.emotion_control = use("style_transfer"), use("emotion_control")
         self.style_Xemo_transfer, self.content_control = use("style_Xemo_transfer"), use("content_control")
@@ -249,16 +329,20 @@ class trainer:
         self.written: List[Path] = []
 
     # ------------------------------------------------------------------ visualizer stand-in
-    def _animate(self, sample_dict, video_dump):
-        """CaMNVisualizer.animate_ldm_sample_v1 / _v2 up to the NPZ (visualizer.py:298-364)."""
+    def _animate(self, sample_dict, video_dump, n_clips: int = 1):
+        """CaMNVisualizer.animate_ldm_sample_v1 / _v2 up to the NPZ (visualizer.py:298-364).  sample_dict None = a job another rank sampled
+        and writes: only the file tags of its `n_clips` files are drawn (6 characters each, npz_writer.write_sample), so that every
+        rank names ITS files as the single-process run names them."""
+        if sample_dict is None:
+            for _ in range(6 * int(n_clips)):
+                random.choice(string.ascii_uppercase + string.ascii_lowercase + string.digits)
+            return
         self.written += write_sample(sample_dict["feats"], video_dump, subject_of(sample_dict["info"]))
 
     def _embed(self, path, baseline=False):
         return self._embed_all([path], baseline)[0]
 
-    def _embed_all(self, paths, baseline=False):
-        """[(con, emo, sty), ...] for a list of WAVs: load, remove the mean (trainer.py:519-521), embed - as one batch where the
-        model offers it (PretrainedLPDM_v1.process_seq_list), else call by call."""
+    def _embed_some(self, paths, baseline=False):
         waves = []
         for path in paths:
             a = load_wav(path)
@@ -267,6 +351,40 @@ class trainer:
         if many is not None:
             return many(waves, framerate=16000, baseline=baseline)
         return [self.model.process_single_seq(a, framerate=16000, baseline=baseline) for a in waves]
+
+    def _embed_all(self, paths, baseline=False, needed=None, exchange: bool = False):
+        """[(con, emo, sty), ...] for a list of WAVs: load, remove the mean (trainer.py:519-521), embed - as one batch where the
+        model offers it (PretrainedLPDM_v1.process_seq_list), else call by call.  Row k of a batch is bitwise the single call's.
+        needed (more than one rank): the indices this rank's jobs read - only those are embedded, the others come back None.
+        exchange (more than one rank, torch.distributed initialised): the list is cut into contiguous shares, each rank embeds its
+        share and the 3 x 256 floats per WAV are all-gathered - for job lists in which every rank needs most of the WAVs."""
+        n = len(paths)
+        if self.world == 1 or (needed is None and not exchange):
+            return self._embed_some(paths, baseline)
+        if exchange:
+            import torch.distributed as dist
+            from .shard import shard_range
+            assert dist.is_available() and dist.is_initialized(), "exchange=True needs an initialised process group"
+            lo, hi = shard_range(n, self.rank, self.world)
+            mine = self._embed_some(paths[lo:hi], baseline)
+            dev = torch.device("cpu") if dist.get_backend() == "gloo" else torch.device(self.device)
+            per = -(-n // self.world)
+            buf = torch.zeros(per, 3, 256, dtype=torch.float32, device=dev)
+            for k, ces in enumerate(mine):
+                buf[k] = torch.stack([t.reshape(256).to(dev, torch.float32) for t in ces])
+            parts = [torch.empty_like(buf) for _ in range(self.world)]
+            dist.all_gather(parts, buf)
+            out = []
+            for r in range(self.world):
+                a, b = shard_range(n, r, self.world)
+                out += [tuple(parts[r][k, i].reshape(1, 256).to(self.device) for i in range(3)) for k in range(b - a)]
+            return out
+        idx = sorted(set(needed))
+        got = self._embed_some([paths[k] for k in idx], baseline) if idx else []
+        out = [None] * n
+        for k, e in zip(idx, got):
+            out[k] = e
+        return out
 
     # ------------------------------------------------------------------ infer_gesture
     def _infer_prior_latdiff_from_audio_v1(self, baseline, ldm_epoch, audio_list, short_audio_list, modelversion, ammetric):
@@ -281,20 +399,26 @@ class trainer:
             print(f" <===== INIT: AUDIO LIST LPDM EVALUATION, REP {rep_i + 1}/{reps} =====>")
             if baseline:
                 raise Exception("Baseline not implemented")
-            audios = list(audios_r.glob("*.wav"))
+            # (the reference takes the directory's own order, list(glob), which no two file systems need agree on; sorted here: every
+            # rank - and every run - sees ONE order, and a sharded run names and fills its files like the single-process run)
+            audios = sorted(audios_r.glob("*.wav"))
             # the reference embeds + samples + renders audio by audio, re-creating `rst` for each (trainer.py:516), so
             # every audio's result lands in <rep>/rst_0 and an NPZ of audio k sits beside those of the audios before
             # it (seq_0/<actor>_seq_0_<rand6>_motion_smplx.npz, told apart only by the random tag).  Same layout
             # here; the embeddings of all audios are computed first and the clips are sampled as one launch.
-            embs = self._embed_all(audios, baseline)
-            jobs = [_job("scott", a.stem, c, e, s, 1, "scott", None, None, None) for a, (c, e, s) in zip(audios, embs)]
-            rst_all = run_jobs(self.model, jobs, batched=self.batched)
+            # More than one rank: the plan first (which jobs are this rank's), then only this rank's audios through the front-end.
+            mine = local_jobs([(1, False, False)] * len(audios), self.rank, self.world)
+            embs = self._embed_all(audios, baseline, needed=[k for k, m in enumerate(mine) if m])
+            jobs = [_job("scott", a.stem, *embs[k], 1, "scott", None, None, None) if mine[k] else _remote_job("scott", a.stem, 1, "scott")
+                    for k, a in enumerate(audios)]
+            rst_all = run_jobs(self.model, jobs, batched=self.batched, rank=self.rank, world=self.world)
             video_dump_r = target_path / f"Custom_audios_{self.stamp}_E{ldm_epoch}" / f"rep{rep_i}"
             assert self.viz_type in ["CaMN"], "[LDM EVAL] Invalid viz type: [%s]" % self.viz_type
             for sample_dict in rst_all:
                 rst = [sample_dict]
                 for i, sd in enumerate(rst):
-                    print(f"VISUALIZATION: LIST AUDIOS {i} =====>")
+                    if sd is not None:
+                        print(f"VISUALIZATION: LIST AUDIOS {i} =====>")
                     self._animate(sd, video_dump_r / f"rst_{i}")
         print(f"[LDM EVAL] Audio list inference done, total time elapsed: {time.time() - start_time:.4f} s")
 
@@ -326,35 +450,51 @@ class trainer:
                     tasks.append(("emotion_control", run_info, emotion_control_jobs(
                         eval_data["emotion_control"], self.emotion_control_take_element)))
                 for name, run_info, jobs in tasks:
-                    rst = run_jobs(self.model, jobs, batched=self.batched)
+                    # (more than one rank: process_loader above ran on every rank - the latents of a take feed jobs of many ranks -
+                    # and the sampling is cut here; metrics hold this rank's jobs)
+                    rst = run_jobs(self.model, jobs, batched=self.batched, rank=self.rank, world=self.world)
                     self.metrics[name] = [{"actor": j["actor"], "take": j["take"], "swap_info": j["swap_info"] or "",
                                            "rst_info": j["info"], "src_motion": j["src_motion"], "rst_motion": r["feats"],
                                            "audio": j["audio"], "z_con": j["z_con"], "z_emo": j["z_emo"], "z_sty": j["z_sty"]}
-                                          for j, r in zip(jobs, rst)]
+                                          for j, r in zip(jobs, rst) if r is not None]
                     if not metrics_only:
                         video_dump_r = self.model_path / "viz" / f"{name}_{run_info}_{self.stamp}_E{ldm_epoch}" / f"rep{rep_i}"
                         assert self.viz_type in ["CaMN"], "[LDM EVAL] Invalid viz type: [%s]" % self.viz_type
                         for i, sample_dict in enumerate(rst):
-                            self._animate(sample_dict, video_dump_r / f"rst_{i}")
+                            self._animate(sample_dict, video_dump_r / f"rst_{i}", jobs[i]["bsz"])
                         if name == "emotion_control":                       # trainer.py:919
-                            n = len([f for f in video_dump_r.iterdir() if f.is_dir()])
+                            n = len(rst) if self.world > 1 else len([f for f in video_dump_r.iterdir() if f.is_dir()])   # (other ranks may still be writing)
                             assert n == 64, "[LDM EVAL] Invalid number of rst dirs: [%d]" % n
             if self.demo_emotion_control:                                   # trainer.py:1037-1075
                 ecl = test["emotion_control_list"]
                 actor = ecl["actor"]
                 print(f"DEMO EMOTION CONTROL EDITS for {actor} =====>")
-                audios = list(Path(ecl["audios"]).glob("*.wav"))
-                src_a = [x for x in audios if "_source" in x.stem][0]
-                tgt_a = [x for x in audios if "_target" in x.stem][0]
+                audios = sorted(Path(ecl["audios"]).glob("*.wav"))
+                srcs = [x for x in audios if "_source" in x.stem]
+                tgts = [x for x in audios if "_target" in x.stem]
                 target_path = Path(ecl["renders"])
-                (con, emo, sty), (_, tgt_emo, _) = self._embed_all([src_a, tgt_a], baseline)
-                jobs = [_job(actor, src_a.stem, con, emo, sty, 1, f"Original {actor}"),        # Gesture generation
-                        _job(actor, src_a.stem, con, tgt_emo, sty, 1, f"Emotion edited {actor}")]  # Gesture editing
-                rst = run_jobs(self.model, jobs, batched=self.batched)      # fresh noise per job, like the two calls
+                if not ecl.get("all_pairs"):
+                    # the reference: the FIRST source and the FIRST target -> "Original" + "Emotion edited" (trainer.py:1044-1066)
+                    src_a, tgt_a = srcs[0], tgts[0]
+                    wavs = [src_a, tgt_a]
+                    spec = [(f"Original {actor}", 0, 0), (f"Emotion edited {actor}", 0, 1)]                # (info, content/style WAV, emotion WAV)
+                else:
+                    # extension (BASELINE config 5's shape: 8 sources x 8 targets = 64 jobs): EVERY source edited with the emotion of EVERY target
+                    wavs = srcs + tgts
+                    spec = [(f"Emotion edited {actor}", i, len(srcs) + j) for i in range(len(srcs)) for j in range(len(tgts))]
+                mine = local_jobs([(1, False, False)] * len(spec), self.rank, self.world)
+                need = sorted({w for (_, a, b), m in zip(spec, mine) if m for w in (a, b)})
+                # many-to-many: every rank needs most WAVs -> embed a share each and all-gather the embeddings (the path's one exchange)
+                exchange = bool(ecl.get("all_pairs")) and self.world > 1 and _dist_ready()
+                embs = self._embed_all(wavs, baseline, needed=need, exchange=exchange)
+                jobs = [_job(actor, wavs[a].stem, embs[a][0], embs[b][1], embs[a][2], 1, info) if m else _remote_job(actor, wavs[a].stem, 1, info)
+                        for (info, a, b), m in zip(spec, mine)]
+                rst = run_jobs(self.model, jobs, batched=self.batched, rank=self.rank, world=self.world)   # fresh noise per job, like the two calls
                 video_dump_r = target_path / f"Custom_audios_{self.stamp}_E{ldm_epoch}" / f"rep{rep_i}"
                 assert self.viz_type in ["CaMN"], "[LDM EVAL] Invalid viz type: [%s]" % self.viz_type
                 for i, sample_dict in enumerate(rst):
-                    print(f"VISUALIZATION: LIST AUDIOS {i} =====>")
+                    if sample_dict is not None:
+                        print(f"VISUALIZATION: LIST AUDIOS {i} =====>")
                     self._animate(sample_dict, video_dump_r / f"rst_{i}")
                 print(f"END VISUALIZATION: DEMO EMOTION CONTROL {rep_i + 1}/{reps} =====>")
         return self.written

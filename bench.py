@@ -164,6 +164,76 @@ def diffusion_only_extra(dev, precision, peak):
     return out
 
 
+def edit_batch_extra(eng, dev, rank, world, red_dev, share_gpu, precision="bf16", reps=5):
+    """BASELINE config 5's shape on `world` ranks, the way `main.py --fn edit_gesture --all-pairs --gpus N` runs it (amuse_amd/trainer.py): 8 source + 8
+    target waveforms (10 s, 16 kHz, resident in HBM) -> each rank embeds its contiguous share of the 16 WAVs (kaldi fbank + 3 x AST) -> the embeddings
+    (3 x 256 floats per WAV) are all-gathered (RCCL; the path's one exchange) -> 8 x 8 = 64 jobs (content / style of source i, emotion of target j), this
+    rank's contiguous range sampled with DDIM-50 (the reference's edit sampler) and decoded to SMPL-X.  Timed between barriers, max over ranks."""
+    import torch
+    import torch.distributed as dist
+    from amuse_amd import audio_weights as aw
+    from amuse_amd import scheduler as sch
+    from amuse_amd import shard
+    from amuse_amd.audio import AudioEngine
+    aeng = AudioEngine(*(aw.make_ast_weights(0, n) for n in aw.ENCODERS), device=dev)
+    try:
+        gen = torch.Generator().manual_seed(55)
+        wav = (0.1 * torch.randn(16, 160000, generator=gen)).to(dev)          # every rank holds the same 16 waveforms and reads its share
+        wlo, whi = shard.shard_range(16, rank, world)
+        per = -(-16 // world)
+        jobs = [(i, 8 + j) for i in range(8) for j in range(8)]
+        g = shard.job_clips_per_group(64)
+        ja, jb = shard.job_range([1] * 64, rank, world, align=g)
+        eng.set_schedule(sch.ddim_table())
+        gdev = torch.device("cpu") if share_gpu else dev
+
+        def once():
+            emb = torch.zeros(per, 3, 256, device=dev)
+            if whi > wlo:
+                emb[:whi - wlo] = torch.stack(aeng.features(wav[wlo:whi]), dim=1)
+            if world > 1:
+                parts = [torch.empty(per, 3, 256, device=gdev) for _ in range(world)]
+                dist.all_gather(parts, emb.to(gdev))
+                allv = torch.cat([parts[r][:b - a] for r in range(world) for a, b in [shard.shard_range(16, r, world)]]).to(dev)
+            else:
+                allv = emb
+            if jb > ja:
+                ii = torch.tensor([jobs[k][0] for k in range(ja, jb)], device=dev)
+                jj = torch.tensor([jobs[k][1] for k in range(ja, jb)], device=dev)
+                eng.set_clips_per_group(g)
+                eng.set_decode_path(shard.job_decode_path(64))
+                try:
+                    return eng.diffusion_backward(allv[ii, 0], allv[jj, 1], allv[ii, 2], precision, seed=2024, clip_index0=ja)
+                finally:
+                    eng.set_clips_per_group(0)
+                    eng.set_decode_path("auto")
+
+        def bar():
+            if world > 1:
+                dist.barrier()
+            torch.cuda.synchronize()
+        once()
+        ts = []
+        for _ in range(reps):
+            bar()
+            t0 = time.perf_counter()
+            o = once()
+            bar()
+            t = torch.tensor([time.perf_counter() - t0], device=red_dev, dtype=torch.float64)
+            if world > 1:
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            ts.append(float(t.item()))
+        assert o is None or bool(torch.isfinite(o["poses"]).all())
+        ms = statistics.median(ts) * 1e3
+        return {"workload": "16 x 10 s WAVs (8 sources + 8 targets) -> audio front-end -> 8 x 8 = 64 edit jobs, DDIM-50 + decode", "n_gpus": world,
+                "precision": precision, "wavs_per_rank": [list(shard.shard_range(16, r, world)) for r in range(world)],
+                "jobs_per_rank": [list(shard.job_range([1] * 64, r, world, align=g)) for r in range(world)],
+                "exchange": "none (one rank)" if world == 1 else ("all_gather of 16 x 3 x 256 fp32 embeddings, " + ("gloo (ranks share a GPU)" if share_gpu else "RCCL")),
+                "ms_per_batch": round(ms, 3), "frames_per_s": round(64 * 300 / (ms * 1e-3), 1), "reps": reps, "timing": "median, barrier to barrier, max over ranks"}
+    finally:
+        aeng.close()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -286,6 +356,15 @@ def main():
         assert bool(torch.isfinite(out_w["poses"]).all())
         del con_w, emo_w, sty_w, out_w
 
+    # ---- BASELINE config 5 beside the headline, at every N (all ranks take part: audio shares, one all-gather, job ranges)
+    edit_batch = None
+    if not args.no_extras and not args.no_audio and args.precision in ("bf16", "fp16", "fp32x"):
+        try:
+            edit_batch = edit_batch_extra(eng, dev, rank, world, red_dev, share_gpu, args.precision)
+        except Exception as e:          # the headline must not depend on an extra (every rank fails or passes alike: same code, same shapes)
+            edit_batch = {"error": f"{type(e).__name__}: {e}"}
+        eng.set_schedule(sch.ddpm_table(args.T))
+
     # ---- dominant kernel (k_sample: the T-step loop) timed live with HIP events on its launch stream
     # (HipEngine launches on torch's current stream, which is the stream these events are recorded on)
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -343,6 +422,8 @@ def main():
         }
         if weak is not None:
             line["weak_scaling"] = weak
+        if edit_batch is not None:
+            line["edit_batch"] = edit_batch
     if rank == 0 and not args.no_extras:
         # single-clip latency (BASELINE configs[1]): B = 1, same sampler, 5 warm-ups, 50 HIP-event-timed repeats
         c1, e1, s1 = con[:1].contiguous(), emo[:1].contiguous(), sty[:1].contiguous()
