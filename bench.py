@@ -39,72 +39,135 @@ STREAM_MB_PER_STEP = {"bf16": 3.80, "fp16": 3.80, "fp32": 7.60, "fp32x": 7.60}
 CU_LOAD_BYTES_PER_CLK = 64.0
 
 
-PMC_DIR = "profiles/r04_pmc"
+PMC_DIRS = {"bf16": ("profiles/r05_pmc", "profiles/r04_pmc"), "fp32x": ("profiles/r05_fp32x_pmc", "profiles/r04_fp32x_pmc")}
+PMC_KERNEL = {"bf16": "k_sample8", "fp32x": "k_sample8x"}
 
 
 def pmc_traffic_bytes(clips, T, precision):
-    """HBM bytes per k_sample launch.  NOT measured by this run (PMC counters need rocprofv3 around the process):
-    read from the committed rocprofv3 PMC passes (PMC_DIR, falling back to profiles/r01_pmc: separate --pmc runs of
-    tools/run_sample_once.py at the bench shape); the bench line names the file in roofline.traffic_source.
-    FETCH_SIZE / WRITE_SIZE are in KiB; FETCH_SIZE is doubled per MI355X_MICROARCH.md (gfx950 reports half of a wide
-    coalesced stream).  (None, None) if the shape differs or no pass is committed."""
-    if (clips, T) != (256, 1000) or precision not in ("bf16", "fp32x"):
-        return None, None
+    """HBM bytes per k_sample launch.  NOT measured by this run (PMC counters need rocprofv3 around the process): read from the newest committed
+    rocprofv3 PMC passes (separate --pmc runs of tools/run_sample_once.py at the bench shape) - and only if the pass's kernel_id.json (tools/kernel_id.py:
+    sha256 over the kernel's source, its headers and the Makefile, written when the pass was taken) equals the identity of the sampler in THIS tree:
+    a kernel change without a PMC retake returns (None, reason) instead of a stale figure.  FETCH_SIZE / WRITE_SIZE are in KiB; FETCH_SIZE is doubled
+    per MI355X_MICROARCH.md (gfx950 reports half of a wide coalesced stream).  -> (bytes or None, source / reason)."""
+    if (clips, T) != (256, 1000) or precision not in PMC_DIRS:
+        return None, "no committed PMC pass at this shape / precision"
     import csv
-    tot = {}
-    dirs = (PMC_DIR, "profiles/r01_pmc") if precision == "bf16" else (PMC_DIR.replace("_pmc", "_fp32x_pmc"),)
-    d = next((x for x in dirs if (REPO / x / "FETCH_SIZE_counter_collection.csv").exists()), None)
+    sys.path.insert(0, str(REPO / "tools"))
+    from kernel_id import kernel_id
+    d = next((x for x in PMC_DIRS[precision] if (REPO / x / "FETCH_SIZE_counter_collection.csv").exists()), None)
     if d is None:
-        return None, None
+        return None, "no committed PMC pass"
+    idf = REPO / d / "kernel_id.json"
+    if not idf.exists():
+        return None, f"{d} carries no kernel_id.json: cannot tell whether it counted the kernel of this tree"
+    want, have = json.load(open(idf)).get(PMC_KERNEL[precision], {}).get("source_sha256"), kernel_id(PMC_KERNEL[precision])["source_sha256"]
+    if want != have:
+        return None, f"{d} counted {PMC_KERNEL[precision]} built from sources {str(want)[:12]}, this tree's are {have[:12]}: retake the PMC pass (tools/run_round_measurements.sh)"
+    tot = {}
     for name in ("FETCH_SIZE", "WRITE_SIZE"):
         f = REPO / d / f"{name}_counter_collection.csv"
         if not f.exists():
-            return None, None
+            return None, f"{d}/{name}_counter_collection.csv missing"
         v = [float(r["Counter_Value"]) for r in csv.DictReader(open(f))
              if "k_sample" in r["Kernel_Name"] and r["Counter_Name"] == name]
         if not v:
-            return None, None
+            return None, f"{d}: no k_sample rows"
         tot[name] = sum(v) / len(v)
-    return int((2 * tot["FETCH_SIZE"] + tot["WRITE_SIZE"]) * 1024), f"{d}/*_counter_collection.csv (committed rocprofv3 --pmc passes, not this run)"
+    return int((2 * tot["FETCH_SIZE"] + tot["WRITE_SIZE"]) * 1024), f"{d}/*_counter_collection.csv (committed rocprofv3 --pmc passes of the kernel with source id {have[:12]}, not this run)"
+
+
+def host_cpu_info():
+    """(model name, physical cores, logical cpus) from lscpu / /proc/cpuinfo; physical falls back to logical // 2 (SMT) when neither says."""
+    import subprocess
+    logical = os.cpu_count() or 1
+    model, phys = "unknown", None
+    try:
+        out = subprocess.run(["lscpu"], capture_output=True, text=True, timeout=10).stdout
+        kv = {l.split(":", 1)[0].strip(): l.split(":", 1)[1].strip() for l in out.splitlines() if ":" in l}
+        model = kv.get("Model name", model)
+        if "Core(s) per socket" in kv and "Socket(s)" in kv:
+            phys = int(kv["Core(s) per socket"]) * int(kv["Socket(s)"])
+    except Exception:
+        pass
+    if phys is None:
+        try:
+            ids = set()
+            cur = {}
+            for l in open("/proc/cpuinfo"):
+                if ":" in l:
+                    k, v = (x.strip() for x in l.split(":", 1))
+                    cur[k] = v
+                elif cur:
+                    ids.add((cur.get("physical id"), cur.get("core id")))
+                    cur = {}
+            phys = len(ids) if len(ids) > 1 else None
+        except Exception:
+            phys = None
+    return model, int(phys or max(1, logical // 2)), logical
 
 
 def cpu_baseline(clips, T, wd, wp):
-    """The oracle (CPU restatement of the reference's PyTorch path: unfused fp32 torch ops, same
-    algorithm) on this box's host cores, on a bounded sample of the same workload."""
+    """The oracle (CPU restatement of the reference's PyTorch path: unfused fp32 torch ops, same algorithm and op order) on this box's host
+    cores - BASELINE.md section 4's three points, each at `physical cores` threads AND at 16 threads (these small ops do not scale to a
+    big host's core count), medians after warm-ups:
+      (i)   B = 1, DDIM-50 loop + decode + 6D -> axis-angle (config 1)           3 warm-ups + 10 repetitions
+      (ii)  B = `clips`, DDPM: a 20-step slice of the 1000-step loop             3 + 10 slices; the job = T x step + (iii), stated as extrapolated
+      (iii) VAE decode + 6D -> axis-angle of B = `clips` alone                   1 + 3
+    `value` = point (ii)'s whole-job frames/s at the better of the two thread counts."""
     import torch
     from oracle import amuse_oracle as orc
     Wd, Wp = orc.to_torch(wd), orc.to_torch(wp)
+    model, phys, logical = host_cpu_info()
     gen = torch.Generator().manual_seed(7)
     con, emo, sty, x = (torch.randn(clips, n, generator=gen) for n in (256, 256, 256, 128))
-    sched = orc.DDPM(T)
-    n_steps = 50
     nz = torch.randn(clips, 128, generator=gen)
-    # torch's default (one thread per hardware thread) oversubscribes these small ops badly on a big host.  ONE fixed thread
-    # count (16, or every core of a smaller host) and 50 timed steps: rounds 1-3 picked the best of several counts on 2 passes
-    # and timed 12 steps, and the figure wandered by 2 x between runs.
-    ncpu = os.cpu_count() or 1
-    threads = min(16, ncpu)
-    torch.set_num_threads(threads)
+    z = torch.randn(clips, 128, generator=gen)
+    ddpm, ddim = orc.DDPM(T), orc.DDIM()
+    SLICE = 20
+
+    def med(fn, warm, reps):
+        ts = []
+        for i in range(warm + reps):
+            t0 = time.perf_counter()
+            fn()
+            if i >= warm:
+                ts.append(time.perf_counter() - t0)
+        return statistics.median(ts)
+
+    def job1():
+        lat = orc.sample_latents(Wd, ddim, con[:1], emo[:1], sty[:1], x[:1])
+        orc.feats_to_smplx(orc.vae_decode(Wp, lat))
+
+    def slice_ddpm():
+        xx = x
+        for i in range(SLICE):
+            t = ddpm.timesteps[i]
+            xx = ddpm.step(orc.denoiser_forward(Wd, xx, t, con, emo, sty), t, xx, nz)
+
+    def decode_all():
+        orc.feats_to_smplx(orc.vae_decode(Wp, z))
+
+    pts = {}
+    old = torch.get_num_threads()
     with torch.no_grad():
-        t0 = time.perf_counter()
-        for i in range(n_steps + 2):
-            if i == 2:
-                t0 = time.perf_counter()
-            t = sched.timesteps[i]
-            eps = orc.denoiser_forward(Wd, x, t, con, emo, sty)
-            x = sched.step(eps, t, x, nz)
-        t_step = (time.perf_counter() - t0) / n_steps
-        dec_clips = 16
-        z = torch.randn(dec_clips, 128, generator=gen)
-        t0 = time.perf_counter()
-        feats = orc.vae_decode(Wp, z)
-        orc.feats_to_smplx(feats)
-        t_dec = (time.perf_counter() - t0) / dec_clips
-    total = T * t_step + clips * t_dec
-    return {"value": round(clips * 300 / total, 1), "unit": "frames/s", "cores": threads, "host_cores": ncpu, "kind": "port",
-            "sample": f"oracle/amuse_oracle.py fp32 on {threads} torch threads: {n_steps} of {T} DDPM steps at "
-                      f"{clips} clips ({t_step * 1e3:.1f} ms/step) + VAE decode + 6D->axis-angle of {dec_clips} of "
-                      f"{clips} clips ({t_dec * 1e3:.1f} ms/clip), extrapolated to the full job"}
+        for threads in dict.fromkeys((phys, min(16, logical))):
+            torch.set_num_threads(threads)
+            t1 = med(job1, 3, 10)
+            ts = med(slice_ddpm, 3, 10) / SLICE
+            td = med(decode_all, 1, 3)
+            total = T * ts + td
+            pts[threads] = {"threads": threads,
+                            "b1_ddim50_ms_per_clip": round(t1 * 1e3, 2), "b1_ddim50_frames_per_s": round(300 / t1, 1),
+                            f"b{clips}_ddpm_ms_per_step": round(ts * 1e3, 3), f"b{clips}_decode_s": round(td, 3),
+                            f"b{clips}_ddpm{T}_frames_per_s": round(clips * 300 / total, 1), f"b{clips}_ddpm{T}_s_per_job_extrapolated": round(total, 2)}
+    torch.set_num_threads(old)
+    key = f"b{clips}_ddpm{T}_frames_per_s"
+    best = max(pts.values(), key=lambda d: d[key])
+    return {"value": best[key], "unit": "frames/s", "cores": best["threads"], "physical_cores": phys, "host_cores": logical, "cpu_model": model, "kind": "port",
+            "points": list(pts.values()),
+            "sample": f"oracle/amuse_oracle.py, fp32 torch CPU ops, medians: (i) B=1 DDIM-50 whole job, 3 warm-ups + 10 repetitions; (ii) B={clips} DDPM: "
+                      f"{SLICE}-step slices of the {T}-step loop, 3 + 10 slices, job = {T} x step + (iii) (extrapolated); (iii) decode + 6D->axis-angle of "
+                      f"{clips} clips, 1 + 3; each at {phys} threads (physical cores) and at {min(16, logical)}; `value` / `cores` = the faster of the two"}
 
 
 def diffusion_only_extra(dev, precision, peak):

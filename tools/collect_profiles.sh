@@ -4,12 +4,15 @@ set -e
 cd "$(dirname "$0")/.."
 O=gpurun_out/$1; R=$2
 mkdir -p profiles/${R}_pmc profiles/${R}_decode_pmc
-for n in FETCH_SIZE WRITE_SIZE TCC_HIT_sum SQ_WAVE_CYCLES SQ_INSTS_MFMA; do
+for n in FETCH_SIZE WRITE_SIZE TCC_HIT_sum SQ_WAVE_CYCLES SQ_INSTS_MFMA SQ_ACTIVE_INST_VALU; do
   f=$(ls -t $O/pmc_$n/*/*_counter_collection.csv 2>/dev/null | head -1); [ -n "$f" ] && cp "$f" profiles/${R}_pmc/${n}_counter_collection.csv
 done
 for n in FETCH_SIZE WRITE_SIZE SQ_WAVE_CYCLES SQ_INSTS_MFMA SQ_ACTIVE_INST_VALU SQ_INSTS_VALU_TRANS_F32; do
   f=$(ls -t $O/dpmc_$n/*/*_counter_collection.csv 2>/dev/null | head -1); [ -n "$f" ] && cp "$f" profiles/${R}_decode_pmc/${n}_counter_collection.csv
 done
+# identity of the kernels these passes counted (bench.py reports roofline.traffic only if the tree's sampler still has it); taken on the GPU box
+# by run_round_measurements.sh from the very tree that was profiled
+[ -f $O/kernel_id.json ] && cp $O/kernel_id.json profiles/${R}_pmc/kernel_id.json && cp $O/kernel_id.json profiles/${R}_decode_pmc/kernel_id.json
 mkdir -p profiles/${R}_diffonly_pmc
 for n in FETCH_SIZE WRITE_SIZE SQ_WAVE_CYCLES SQ_INSTS_MFMA SQ_ACTIVE_INST_VALU SQ_INSTS_VALU_TRANS_F32; do
   f=$(ls -t $O/npmc_$n/*/*_counter_collection.csv 2>/dev/null | head -1); [ -n "$f" ] && python3 tools/summarize_pmc.py "$f" > profiles/${R}_diffonly_pmc/${n}_per_kernel.csv
@@ -21,6 +24,7 @@ mkdir -p profiles/${R}_fp32x_pmc
 for n in FETCH_SIZE WRITE_SIZE SQ_WAVE_CYCLES SQ_INSTS_MFMA; do
   f=$(ls -t $O/xpmc_$n/*/*_counter_collection.csv 2>/dev/null | head -1); [ -n "$f" ] && cp "$f" profiles/${R}_fp32x_pmc/${n}_counter_collection.csv
 done
+[ -f $O/kernel_id.json ] && cp $O/kernel_id.json profiles/${R}_fp32x_pmc/kernel_id.json
 f=$(ls -t $O/x_stats/*/*_kernel_stats.csv 2>/dev/null | head -1); [ -n "$f" ] && cp "$f" profiles/${R}_fp32x_kernel_stats.csv
 [ -f $O/fp32x_perf.txt ] && grep -v libdrm $O/fp32x_perf.txt > profiles/${R}_fp32x_perf.txt
 [ -f $O/phase8x.txt ] && grep -v libdrm $O/phase8x.txt > profiles/${R}_k_sample8x_phase_timeline.txt

@@ -6,6 +6,7 @@ cd $GRAFT_REPO_ROOT
 O=gpurun_out/${1:-meas}
 export TMPDIR=/tmp
 rm -rf $O && mkdir -p $O
+python tools/kernel_id.py > $O/kernel_id.json     # what the PMC passes below count (collect_profiles.sh files it next to them)
 timeout 1500 python -m pytest tests -q -m gpu 2>&1 | tail -3 > $O/pytest.txt
 timeout 600 python bench.py > $O/bench.json 2> $O/bench.err; tail -2 $O/bench.err
 timeout 300 python bench.py --config train --steps 60 --warmup 15 > $O/train_bench.json 2> $O/train_bench.err
@@ -15,7 +16,7 @@ AMUSE_TRAIN_ATTN=vendor timeout 300 python bench.py --config train --steps 60 --
 timeout 200 python tools/gpu_train_attn_perf.py > $O/train_attn_perf.txt 2>&1
 timeout 200 python tools/gpu_encode_fp32x_ab.py > $O/encode_fp32x_ab.txt 2>&1
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python3 bench.py --steps 3 --warmup 1 --no-extras > $O/stats.log 2>&1
-for grp in FETCH_SIZE WRITE_SIZE "TCC_HIT_sum TCC_MISS_sum" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_ANY" "SQ_INSTS_MFMA SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_INSTS_SALU"; do
+for grp in FETCH_SIZE WRITE_SIZE "TCC_HIT_sum TCC_MISS_sum" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_ANY" "SQ_INSTS_MFMA SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_INSTS_SALU" "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_MISC SQ_BUSY_CU_CYCLES" "SQ_INST_CYCLES_VMEM SQ_WAIT_INST_LDS SQ_INSTS_VALU_TRANS_F32 SQ_INSTS_WAVE32_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE"; do
   n=$(echo $grp | cut -d' ' -f1)
   timeout 300 rocprofv3 --pmc $grp --kernel-trace --output-format csv -d $O/pmc_$n -- python3 tools/run_sample_once.py 256 bf16 2 > $O/pmc_$n.log 2>&1
 done
