@@ -41,7 +41,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from . import scheduler as sch
-from .nn_modules import Denoiser, MotionPrior, load_numpy_state
+from .nn_modules import Denoiser, MotionPrior, load_numpy_state, numpy_state
 
 SEQ_LEN = 300
 LOSS_CFG = {"train_lpdm": {"version": "v0"}, "stage": "vae_diffusion", "LAMBDA_PRIOR": 0.0, "LAMBDA_GEN": 1.0,
@@ -282,7 +282,7 @@ class GestureTrainer:
         # conditions only: on the GPU it runs on a stream of its own beside the networks' forward pass and is joined in front of the losses.
         gen, side = None, None
         if self.inner_sampler is not None:
-            if self.device.type == "cuda" and os.environ.get("AMUSE_TRAIN_SAMPLER_STREAM", "1") != "0":
+            if self.device.type == "cuda" and os.environ.get("AMUSE_TRAIN_SAMPLER_STREAM", "1") != "0" and not getattr(self.inner_sampler, "serial", False):
                 if self._side_stream is None:
                     self._side_stream = torch.cuda.Stream(self.device)
                 side = self._side_stream
@@ -462,6 +462,67 @@ class HipInnerSampler:
         return self.engine.vae_decode(lat, None, self.precision, return_feats=True)["feats"]
 
 
+def numpy_denoiser_state(ldm) -> dict:
+    return {k: v.detach().cpu().numpy() for k, v in ldm.denoiser.state_dict().items()}
+
+
+class TrainModeInnerSampler:
+    """OPT-IN (`--inner-sampler train`, AMUSE_TRAIN_INNER=train): the no-gradient half of an iteration with the reference's own semantics.  The reference calls
+    `ldm.diffusion_backward` (DDIM-50, ldm.py:117-153) and `prior.decode` inside its training loop while both networks are in train() mode
+    (trainer.py:357-358,413-415): every dropout of the Denoiser's nine encoder layers - attention weights, both residual branches, the FFN activation - and of
+    the prior's decoder is LIVE in all 50 denoising steps and in the decode.  HipInnerSampler (the default) runs the persistent eval-mode sampler kernel
+    instead: ~10 x faster and, being deterministic, the better estimate of what the networks generate - a stated difference.  This class is the reference's
+    form: the trainer's own modules as they are (train mode -> dropout through the library's counter-based masks, train_ops / k_train.hip; eval mode -> none),
+    50 x Denoiser.forward + the scheduler row update of amuse_amd/scheduler.py (the arithmetic the sampler kernels apply, tests/test_pins_cpu.py), one decode.
+    Runs on the trainer's stream (the layer calls share the rocBLAS handle with the forward pass).  Initial latents: the library's counter-based normals on the
+    GPU (the HIP sampler's draw for the same clips), torch.randn from a seeded generator on the CPU."""
+    serial = True      # forward_losses: no side stream
+
+    def __init__(self, trainer_models: Dict[str, nn.Module], device, seed: int = 2024, ldm_cfg: Optional[dict] = None, rank: int = 0, world: int = 1,
+                 engine=None):
+        self.models, self.device, self.seed, self.rank, self.world = trainer_models, torch.device(device), seed, rank, world
+        self.table = sch.from_ldm_cfg(ldm_cfg, "ddim") if ldm_cfg and "scheduler" in ldm_cfg else sch.ddim_table()
+        self.coef = torch.as_tensor(self.table.coef)            # (T, 8) host copy: the loop reads python floats, no device sync
+        self.engine = engine                                    # a HipEngine to draw the initial latents from (GPU), or None
+        self.calls, self.clip_counter, self.sync_ms = 0, 0, []
+
+    def initial_latents(self, bsz: int) -> torch.Tensor:
+        c0 = self.clip_counter + self.rank * bsz
+        self.clip_counter += bsz * self.world
+        if self.engine is not None:
+            return self.engine.counter_normal(self.seed, c0, bsz, 0, 0)
+        g = torch.Generator().manual_seed((self.seed * 1000003 + c0) & 0x7FFFFFFF)
+        return torch.randn(bsz, 128, generator=g).to(self.device)
+
+    @staticmethod
+    def scheduler_update(row, x, eps, z=None):
+        """One schedule row [sb, sa, c0, cx, ce, sigma, clip, 0] (include/amuse_hip.h amuse_schedule) in the kernels' operation order."""
+        sb, sa, c0, cx, ce, sg, clipv = (float(v) for v in row[:7])
+        x0 = (x - sb * eps) * (1.0 / sa)
+        if clipv > 0:
+            x0 = x0.clamp(-clipv, clipv)
+        nx = c0 * x0
+        if cx != 0:
+            nx = nx + cx * x
+        if ce != 0:
+            nx = nx + ce * eps
+        if sg != 0:
+            nx = nx + sg * z
+        return nx
+
+    @torch.no_grad()
+    def __call__(self, con, emo, sty, bsz, x_init: Optional[torch.Tensor] = None, return_latents: bool = False):
+        den, prior = self.models["ldm"].denoiser, self.models["prior"]
+        x = (self.initial_latents(bsz) if x_init is None else x_init.to(self.device)) * self.table.init_noise_sigma
+        self.calls += 1
+        for i, t in enumerate(self.table.timesteps):
+            eps = den(x[:, None], int(t), con, emo, sty)[0][:, 0]
+            z = torch.randn_like(x) if float(self.coef[i, 5]) != 0 else None          # (eta > 0 only)
+            x = self.scheduler_update(self.coef[i], x, eps, z)
+        feats = prior.decode(x[None], [SEQ_LEN] * bsz)
+        return (feats, x) if return_latents else feats
+
+
 def ablation_kind(lmdb_id: Optional[str]) -> Optional[str]:
     """The ablation variant the reference derives from the LMDB cache id (trainer.py:396-401): full | emotion | identity | baseline."""
     if not lmdb_id:
@@ -476,7 +537,7 @@ def ablation_kind(lmdb_id: Optional[str]) -> Optional[str]:
 
 def build_trainer(device, rank: int = 0, world: int = 1, process_group=None, seed: int = 0, use_hip_sampler: bool = True,
                   dropout: float = 0.1, sampler_refresh: int = 1, ldm_cfg: Optional[dict] = None, lr: float = 1e-4,
-                  kind: Optional[str] = None) -> GestureTrainer:
+                  kind: Optional[str] = None, inner: Optional[str] = None) -> GestureTrainer:
     """Random-init prior + ldm (the deterministic weights of amuse_amd/weights.py, identical on every rank - what DDP's
     initial broadcast gives the reference's DataParallel-less single-GPU run) and the trainer around them.
     lr = TRAIN_PARAM.latent_diffusion.lr_base (trainer.py:181-184); ldm_cfg = configs/<arch>.json merged with diff_o.yaml (its
@@ -492,7 +553,16 @@ def build_trainer(device, rank: int = 0, world: int = 1, process_group=None, see
         loss_cfg = dict(ldm_cfg["losses"], use_recons_joints=False, vtex_displacement=False)
     tr = GestureTrainer(prior, ldm, device, lr=lr, loss_cfg=loss_cfg, inner_sampler=None, process_group=process_group,
                         world=world, kind=None if kind == "full" else kind)
-    if use_hip_sampler:
+    inner = inner or os.environ.get("AMUSE_TRAIN_INNER", "eval")
+    if inner not in ("eval", "train"):
+        raise ValueError(f"inner sampler {inner!r}: 'eval' (the persistent HIP sampler kernel, default) or 'train' (the reference's train-mode semantics, dropout live)")
+    if inner == "train":      # TrainModeInnerSampler: the modules themselves (any device); on the GPU the initial latents are the HIP sampler's draws
+        eng = None
+        if torch.device(device).type == "cuda":
+            from .engine import HipEngine
+            eng = HipEngine(numpy_denoiser_state(ldm), numpy_state(prior), device)   # (only amuse_counter_normal is used: the HIP sampler's initial latents)
+        tr.inner_sampler = TrainModeInnerSampler(tr.model, device, ldm_cfg=ldm_cfg, rank=rank, world=world, engine=eng)
+    elif use_hip_sampler:
         if torch.device(device).type != "cuda":
             raise RuntimeError("the in-loop sampler of train_gesture runs on the HIP kernels: no CPU path (pass use_hip_sampler=False "
                                "to train without the no-gradient gen_feature term)")
@@ -555,7 +625,11 @@ def bench_main(args):
                                    f"(fp32; transformer layers = one autograd.Function each on the library's layer entry points: HIP glue + fp32 attention kernels, rocBLAS GEMMs{'' if __import__('amuse_amd.train_ops', fromlist=['x']).enabled() else ' - SWITCHED OFF: eager torch'}), in-loop DDIM-50 sampler + decode on the HIP kernels (bf16), AdamW(1e-4), one flat "
                                    f"all-reduce of {tr.n_grad_elements():,} fp32 gradients; batch {bsz} per GPU, {bsz * world} global; "
                                    f"vertex-displacement loss off (needs SMPL-X assets)",
-                       "batch_per_gpu": bsz, "grad_elements": tr.n_grad_elements()},
+                       "batch_per_gpu": bsz, "grad_elements": tr.n_grad_elements(),
+                       "gemm": "rocBLAS (rocblas_sgemm from C++, fp32) for the plain GEMMs; hand-written HIP for the weight-gradient reductions, attention, LayerNorm / "
+                               "dropout / GELU / bias gradients, AdamW",
+                       "inner_sampler": ("train: the reference's train-mode loop, dropout live (TrainModeInnerSampler)" if getattr(tr.inner_sampler, "serial", False)
+                                         else "eval: the persistent HIP sampler kernel (dropout off - the reference's loop runs in train mode; opt in with AMUSE_TRAIN_INNER=train)")},
             "samples_per_s": round(its * bsz * world, 1),
             "allreduce_ms": round(float(np.median(ar)), 3) if ar else None,
             "hip_weight_repack_ms": round(float(np.median(sync)), 3) if sync else None,
@@ -584,6 +658,9 @@ def main(argv=None):
     ap.add_argument("--lr", type=float, default=1e-4, help="TRAIN_PARAM.latent_diffusion.lr_base (AdamW, trainer.py:181-184)")
     ap.add_argument("--kind", default=None, choices=["full", "emotion", "identity", "baseline"],
                     help="ablation variant (default: derived from the --cache id like trainer.py:396-401; synthetic data: full)")
+    ap.add_argument("--inner-sampler", default=None, choices=["eval", "train"],
+                    help="the no-gradient DDIM-50 + decode of every iteration: eval (default) = the persistent HIP sampler kernel, dropout off; train = the "
+                         "reference's semantics (ldm.py:117-153 under model.train(): every dropout live) through the trainer's own modules, ~10 x slower")
     ap.add_argument("--ldm-cfg", default=None, help="JSON file: configs/<arch>.json merged with diff_o.yaml (losses, schedulers); default: the shipped values")
     args = ap.parse_args(argv)
     from . import launch
@@ -613,7 +690,8 @@ def main(argv=None):
         import json
         ldm_cfg = json.load(open(args.ldm_cfg))
     kind = args.kind or ablation_kind(args.cache)
-    tr = build_trainer(device, rank, world, process_group=pg, use_hip_sampler=device.type == "cuda", ldm_cfg=ldm_cfg, lr=args.lr, kind=kind)
+    tr = build_trainer(device, rank, world, process_group=pg, use_hip_sampler=device.type == "cuda", ldm_cfg=ldm_cfg, lr=args.lr, kind=kind,
+                       inner=args.inner_sampler)
     if rank == 0:
         lc = tr.lpdm_losses.cfg
         print(f"[LPDM-T] lr {args.lr:g}, ablation kind {kind or 'full'}, loss weights " +

@@ -170,3 +170,34 @@ def test_inner_sampler_on_its_own_stream_changes_nothing(monkeypatch):
         for k in a:
             assert abs(a[k] - b[k]) <= 1e-6 * max(1.0, abs(b[k])), k
 
+
+
+def test_train_mode_inner_sampler_on_the_gpu():
+    """The opt-in reference-semantics inner sampler (train_gesture.TrainModeInnerSampler) on the GPU: in eval mode its DDIM-50 latents are the persistent
+    HIP sampler's fp32 latents for the SAME clips (both start from the library's counter-based normals: <= 1e-4) and its features the HIP decode's; in
+    train mode the layers' counter-based dropout masks are live (another result, fresh on every call), and an iteration trains with it."""
+    from amuse_amd.train_gesture import HipInnerSampler, TrainModeInnerSampler, build_trainer, synthetic_batch
+    torch.manual_seed(0)
+    tr = build_trainer("cuda:0", inner="train")
+    s = tr.inner_sampler
+    assert isinstance(s, TrainModeInnerSampler) and s.engine is not None
+    batch = synthetic_batch(4, 5, "cuda:0")
+    con, emo, sty = batch["ld_audio_con"], batch["ld_audio_emo"], batch["ld_audio_sty"]
+    hip = HipInnerSampler(tr.model, "cuda:0", precision="fp32")
+    for m in tr.model.values():
+        m.eval()
+    feats, lat = s(con, emo, sty, 4, return_latents=True)              # clips 0..3 of seed 2024
+    lat_hip = hip.engine.sample(con, emo, sty, "fp32", seed=2024, clip_index0=0)
+    assert float((lat - lat_hip).abs().max()) < 1e-4
+    f_hip = hip.engine.vae_decode(lat_hip, None, "fp32", return_feats=True)["feats"]
+    assert float((feats - f_hip).abs().max()) < 2e-4
+    for m in tr.model.values():
+        m.train()
+    s.clip_counter = 0
+    f1 = s(con, emo, sty, 4)
+    s.clip_counter = 0
+    f2 = s(con, emo, sty, 4)
+    assert float((f1 - feats).abs().max()) > 1e-3 and float((f1 - f2).abs().max()) > 1e-3 and bool(torch.isfinite(f1).all())
+    l0 = float(tr.train_step(batch))
+    assert np.isfinite(l0) and float(tr.lpdm_losses.compute()["gen_feature"]) > 0
+    hip.engine.close()

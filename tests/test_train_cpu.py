@@ -283,3 +283,38 @@ def test_ablation_kind_reaches_the_trainer_and_freezes_the_dropped_projection():
             assert not torch.equal(sd0[f"denoiser.{live}.1.{leaf}"], sd1[f"denoiser.{live}.1.{leaf}"]), (kind, live)
     full = build_trainer("cpu", use_hip_sampler=False, kind="full")
     assert full.kind is None
+
+
+def test_train_mode_inner_sampler_is_the_references_loop():
+    """TrainModeInnerSampler (opt-in, `--inner-sampler train`): the no-gradient DDIM-50 + decode of an iteration on the trainer's own modules.
+    eval mode: its latents / features are the oracle's diffusion_backward on the same initial noise (<= 1e-4: the same loop, no dropout);
+    train mode (what the reference's training loop runs, trainer.py:357-358,413-415): dropout is live - another result, fresh masks on every call -
+    and the trainer takes a step with it as the gen_feature term's input."""
+    from amuse_amd.train_gesture import TrainModeInnerSampler, build_trainer, synthetic_batch
+    from oracle import amuse_oracle as orc
+    from amuse_amd import weights as wts
+    torch.manual_seed(0)
+    tr = build_trainer("cpu", inner="train")
+    s = tr.inner_sampler
+    assert isinstance(s, TrainModeInnerSampler) and s.serial and list(s.table.timesteps[:3]) == [981, 961, 941]
+    g = torch.Generator().manual_seed(3)
+    con, emo, sty, x0 = (torch.randn(2, n, generator=g) for n in (256, 256, 256, 128))
+    for m in tr.model.values():
+        m.eval()
+    feats, lat = s(con, emo, sty, 2, x_init=x0, return_latents=True)
+    ref = orc.diffusion_backward(orc.to_torch(wts.make_denoiser_weights(0)), orc.to_torch(wts.make_prior_weights(0)), orc.DDIM(), con, emo, sty, x0)
+    assert float((lat - ref["latents"]).abs().max()) < 1e-4 and float((feats - ref["feats"]).abs().max()) < 2e-4
+    for m in tr.model.values():
+        m.train()
+    f1 = s(con, emo, sty, 2, x_init=x0)
+    f2 = s(con, emo, sty, 2, x_init=x0)
+    assert float((f1 - feats).abs().max()) > 1e-3 and float((f1 - f2).abs().max()) > 1e-3 and bool(torch.isfinite(f1).all())
+    # drawn latents: seeded, per global clip index, advancing
+    a = s.initial_latents(2)
+    b = s.initial_latents(2)
+    assert a.shape == (2, 128) and not torch.equal(a, b)
+    loss = tr.train_step(synthetic_batch(2, 1))
+    ld = {k: float(v) for k, v in tr.lpdm_losses.compute().items()}
+    assert np.isfinite(float(loss)) and ld["gen_feature"] > 0
+    with pytest.raises(ValueError):
+        build_trainer("cpu", inner="bogus")
