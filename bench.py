@@ -125,13 +125,23 @@ def cpu_baseline(clips, T, wd, wp):
     ddpm, ddim = orc.DDPM(T), orc.DDIM()
     SLICE = 20
 
-    def med(fn, warm, reps):
+    BUDGET_S = 8.0        # per point and thread count: 3 warm-ups + 10 repetitions where they fit, never fewer than 1 + 3 (a 128-thread run of these small
+    reps_used = {}        # ops is ~10 x slower than the 16-thread one: the prescribed repetition count alone would take minutes there)
+
+    def med(fn, warm, reps, tag=None):
+        t0 = time.perf_counter()
+        fn()
+        first = time.perf_counter() - t0
+        if first * (warm + reps) > BUDGET_S:
+            warm, reps = 1, max(3, min(reps, int(BUDGET_S / max(first, 1e-9)) - 1))
         ts = []
-        for i in range(warm + reps):
+        for i in range(warm - 1 + reps):           # (the probe above was the first warm-up)
             t0 = time.perf_counter()
             fn()
-            if i >= warm:
+            if i >= warm - 1:
                 ts.append(time.perf_counter() - t0)
+        if tag:
+            reps_used[tag] = f"{warm}+{reps}"
         return statistics.median(ts)
 
     def job1():
@@ -152,9 +162,9 @@ def cpu_baseline(clips, T, wd, wp):
     with torch.no_grad():
         for threads in dict.fromkeys((phys, min(16, logical))):
             torch.set_num_threads(threads)
-            t1 = med(job1, 3, 10)
-            ts = med(slice_ddpm, 3, 10) / SLICE
-            td = med(decode_all, 1, 3)
+            t1 = med(job1, 3, 10, f"b1@{threads}")
+            ts = med(slice_ddpm, 3, 10, f"slice@{threads}") / SLICE
+            td = med(decode_all, 1, 3, f"decode@{threads}")
             total = T * ts + td
             pts[threads] = {"threads": threads,
                             "b1_ddim50_ms_per_clip": round(t1 * 1e3, 2), "b1_ddim50_frames_per_s": round(300 / t1, 1),
@@ -164,10 +174,11 @@ def cpu_baseline(clips, T, wd, wp):
     key = f"b{clips}_ddpm{T}_frames_per_s"
     best = max(pts.values(), key=lambda d: d[key])
     return {"value": best[key], "unit": "frames/s", "cores": best["threads"], "physical_cores": phys, "host_cores": logical, "cpu_model": model, "kind": "port",
-            "points": list(pts.values()),
+            "points": list(pts.values()), "warmups_plus_repetitions": reps_used,
             "sample": f"oracle/amuse_oracle.py, fp32 torch CPU ops, medians: (i) B=1 DDIM-50 whole job, 3 warm-ups + 10 repetitions; (ii) B={clips} DDPM: "
                       f"{SLICE}-step slices of the {T}-step loop, 3 + 10 slices, job = {T} x step + (iii) (extrapolated); (iii) decode + 6D->axis-angle of "
-                      f"{clips} clips, 1 + 3; each at {phys} threads (physical cores) and at {min(16, logical)}; `value` / `cores` = the faster of the two"}
+                      f"{clips} clips, 1 + 3; each at {phys} threads (physical cores) and at {min(16, logical)}; a point whose repetitions would exceed {BUDGET_S:.0f} s runs 1 warm-up + >= 3 "
+                      f"repetitions instead (`warmups_plus_repetitions`); `value` / `cores` = the faster of the two"}
 
 
 def diffusion_only_extra(dev, precision, peak):

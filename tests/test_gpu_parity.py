@@ -589,6 +589,34 @@ def test_full_size_batch_properties(env):
     assert torch.equal(sub["poses"], a["poses"][198:204])
 
 
+@pytest.mark.parametrize("prec", PARITY)
+def test_full_size_batch_values_against_the_oracle(env, prec):
+    """VALUE parity at the exact launch shape bench.py times (BASELINE config 3: 256 clips, DDPM-1000, two clips per tile on 128 workgroups, the job's
+    decode kernels), in both parity modes: four clips of the 256-clip launch - first, second (slot 1 of tile 0), one mid-batch, last - against the CPU oracle
+    run on those clips alone with the SAME counter-based noise (keyed by the global clip index).  Latents <= 3e-5 relative after 1000 steps (the single-clip
+    bar), decoded features <= 1e-4 + the latent difference carried through.  (The bf16 launch of the same shape: test_full_size_batch_properties.)"""
+    from amuse_amd import scheduler as sch
+    orc, eng, Wd, Wp = env["orc"], env["eng"], env["Wd"], env["Wp"]
+    gen = torch.Generator().manual_seed(3)
+    c, e, s = (torch.randn(256, 256, generator=gen) for _ in range(3))
+    eng.set_schedule(sch.ddpm_table())
+    out = eng.diffusion_backward(c, e, s, prec, seed=2024)
+    pick = [0, 1, 131, 255]
+    x0 = torch.from_numpy(orc.counter_normal(2024, np.array(pick), 0, 0))
+    nz = torch.stack([torch.from_numpy(orc.counter_normal(2024, np.array(pick), i, 1)) for i in range(1000)])
+    ref = orc.sample_latents(Wd, orc.DDPM(), c[pick], e[pick], s[pick], x0, nz)
+    scale = float(ref.abs().max())
+    lat = out["latents"][pick].cpu()
+    assert _err(lat, ref) < 3e-5 * scale, (_err(lat, ref), scale)
+    # the decode of the launch, on the launch's own latents (teacher-forced: the 1e-4 pose bar is a statement about the decoder + conversion)
+    f_ref = orc.vae_decode(Wp, lat)
+    f = eng.vae_decode(out["latents"], None, prec, return_feats=True)["feats"][pick].cpu()
+    assert _err(f, f_ref) < 2e-5 * max(1.0, float(f_ref.abs().max()))
+    p_ref, _ = orc.feats_to_smplx(f_ref)
+    d = torch.linalg.vector_norm(out["poses"][pick].cpu() - p_ref, dim=-1)
+    assert float(d.median()) < 3e-5 and float((d < 1e-4).float().mean()) > 0.97, (float(d.median()), float(d.max()))
+
+
 def test_job_level_tiling_makes_shards_bitwise(env):
     """amuse_amd/shard.py: clips per tile chosen from the job's TOTAL clip count + shards aligned to it => the shards of a
     300-clip job (three clips per tile) reproduce the single-launch result bitwise, fp32 and bf16."""
