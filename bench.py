@@ -321,6 +321,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-audio", action="store_true", help="skip the audio front-end side measurement")
     ap.add_argument("--no-extras", action="store_true", help="headline + roofline only (profiling runs)")
+    ap.add_argument("--edit-batch", action="store_true", help="with --no-extras: still run the edit_batch extra (BASELINE config 5's shape, every rank takes part)")
     args = ap.parse_args()
     from amuse_amd import launch
     if args.gpus > 1 and not launch.launched_by_torchrun():
@@ -432,7 +433,7 @@ def main():
 
     # ---- BASELINE config 5 beside the headline, at every N (all ranks take part: audio shares, one all-gather, job ranges)
     edit_batch = None
-    if not args.no_extras and not args.no_audio and args.precision in ("bf16", "fp16", "fp32x"):
+    if (not args.no_extras or args.edit_batch) and not args.no_audio and args.precision in ("bf16", "fp16", "fp32x"):
         try:
             edit_batch = edit_batch_extra(eng, dev, rank, world, red_dev, share_gpu, args.precision)
         except Exception as e:          # the headline must not depend on an extra (every rank fails or passes alike: same code, same shapes)

@@ -236,6 +236,22 @@ def test_bench_line_with_two_ranks_sharing_the_gpu():
     assert d["roofline"]["frac"] > 0 and d["roofline"]["kernel_ms"] > 0 and d["roofline"]["bound"] == "chain+l2_stream"
 
 
+def test_bench_edit_batch_with_two_ranks_sharing_the_gpu():
+    """BASELINE config 5's shape through `bench.py --gpus 2` (AMUSE_BENCH_SHARE_GPU=1: both ranks on this box's GPU, gloo for the exchange): each rank embeds 8 of
+    the 16 WAVs, the embeddings are all-gathered, each rank samples 32 of the 64 jobs."""
+    import json, os, subprocess, sys
+    from conftest import REPO
+    env = dict(os.environ, AMUSE_BENCH_SHARE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, str(REPO / "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--T", "20", "--clips", "64",
+                        "--no-extras", "--edit-batch"], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-3000:])
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
+    eb = d["edit_batch"]
+    assert "error" not in eb, eb
+    assert eb["n_gpus"] == 2 and eb["wavs_per_rank"] == [[0, 8], [8, 16]] and eb["jobs_per_rank"] == [[0, 32], [32, 64]]
+    assert eb["frames_per_s"] > 0 and "all_gather" in eb["exchange"]
+
+
 def test_rccl_world_of_one_all_reduces_the_flat_gradient():
     """init_process_group("nccl") (= RCCL on ROCm) at world size 1 on the GPU and an all-reduce of the 6,835,661-element flat fp32
     gradient train_gesture exchanges (amuse_amd/train_gesture.py) - the collective library is loaded and run by something in this
