@@ -563,8 +563,13 @@ def main():
             torch.cuda.synchronize()
             if i >= 1:
                 ts.append(time.perf_counter() - t1)
+        flop_job = Bs * (args.T * FLOP_PER_CLIP_STEP + FLOP_VAE_DECODE_PER_CLIP)
         line["saturating_point"] = {"clips_per_gpu": Bs, "frames_per_s": round(Bs * 300 / min(ts), 1),
-                                    "ms_per_job": round(min(ts) * 1e3, 3)}
+                                    "ms_per_job": round(min(ts) * 1e3, 3),
+                                    "frac_of_mfma_peak": round(flop_job / min(ts) / 1e12 / MFMA_PEAK_TFLOPS[args.precision], 4),
+                                    "note": "three clips per 16-row tile on all 256 CUs: every further 768 clips add one more round of the same ~35 ms (a 4,096-clip job = 6 rounds, "
+                                            "the last one a third full: 5.9 M frames/s); the two-tile kernel that would lift this was costed at 1.24 x and not built "
+                                            "(profiles/r05_k_sample8_two_tile_ablation.txt)"}
         del cs, es, ss, outs
         if world == 1 and B > 0:
             # parity mode: the SAME job in the fp32x mode (split-fp16 MFMA operands, fp32 everything else) - the mode that
