@@ -146,12 +146,15 @@ def _launch_ranks(args, argv, dirname: Path):
     if args.root is None:                      # the ranks start in another process: name the tree explicitly
         av += ["--root", str(dirname)]
     with tempfile.TemporaryDirectory(prefix="amuse_ranks_") as md:
+        had_stamp = "AMUSE_RUN_STAMP" in os.environ
         os.environ["AMUSE_RUN_STAMP"] = os.environ.get("AMUSE_RUN_STAMP") or datetime.now().strftime("%Y%m%d-%H%M%S")
         os.environ["AMUSE_MANIFEST_DIR"] = md
         try:
             rc = launch.run_ranks("amuse_amd.main", av, args.gpus, module=True)
         finally:
             os.environ.pop("AMUSE_MANIFEST_DIR", None)
+            if not had_stamp:
+                os.environ.pop("AMUSE_RUN_STAMP", None)      # (the stamp is this run's: a later run in the same process draws its own)
         if rc != 0:
             raise SystemExit(rc)
         written = []
