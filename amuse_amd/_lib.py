@@ -62,6 +62,10 @@ def load() -> C.CDLL:
     global _lib
     if _lib is not None:
         return _lib
+    # torch FIRST: it ships its own HIP runtime (torch/lib/libamdhip64.so).  Loaded behind this library - which links the system's - the process would hold two
+    # runtimes, and the second one sees no device ("no ROCm-capable device is detected" from amuse_create in a process that called __graft_entry__.build(), which
+    # loads the library, before anything imported torch).  With torch's copy resident the library binds to it.
+    import torch  # noqa: F401
     if not LIB_PATH.exists():
         raise AmuseHipError(
             f"{LIB_PATH} is missing - build it with `python -c 'import __graft_entry__ as g; g.build()'` "
