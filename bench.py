@@ -571,6 +571,21 @@ def main():
                                             "the last one a third full: 5.9 M frames/s); the two-tile kernel that would lift this was costed at 1.24 x and not built "
                                             "(profiles/r05_k_sample8_two_tile_ablation.txt)"}
         del cs, es, ss, outs
+        if world == 1:   # SURVEY 8d also asks for a point at >= 4,096 clips per GPU: six rounds of 768 clips, the last a third full
+            B4 = 4096
+            c4, e4, s4 = (torch.randn(B4, 256, generator=gen).to(dev) for _ in range(3))
+            o4 = {"latents": torch.empty(B4, 128, device=dev), "poses": torch.empty(B4, 300, 55, 3, device=dev), "trans": torch.empty(B4, 300, 3, device=dev)}
+            t4 = []
+            for i in range(3):
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                eng.diffusion_backward(c4, e4, s4, args.precision, seed=2024, out=o4)
+                torch.cuda.synchronize()
+                if i >= 1:
+                    t4.append(time.perf_counter() - t1)
+            line["saturating_point"]["at_4096_clips"] = {"frames_per_s": round(B4 * 300 / min(t4), 1), "ms_per_job": round(min(t4) * 1e3, 3),
+                                                         "frac_of_mfma_peak": round(B4 * (args.T * FLOP_PER_CLIP_STEP + FLOP_VAE_DECODE_PER_CLIP) / min(t4) / 1e12 / MFMA_PEAK_TFLOPS[args.precision], 4)}
+            del c4, e4, s4, o4
         if world == 1 and B > 0:
             # parity mode: the SAME job in the fp32x mode (split-fp16 MFMA operands, fp32 everything else) - the mode that
             # meets the north-star tolerance; eps_err = teacher-forced eps_hat against the reference modules' golden
