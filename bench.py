@@ -568,7 +568,7 @@ def main():
                                     "ms_per_job": round(min(ts) * 1e3, 3),
                                     "frac_of_mfma_peak": round(flop_job / min(ts) / 1e12 / MFMA_PEAK_TFLOPS[args.precision], 4),
                                     "note": "three clips per 16-row tile on all 256 CUs: every further 768 clips add one more round of the same ~35 ms (a 4,096-clip job = 6 rounds, "
-                                            "the last one a third full: 5.9 M frames/s); the two-tile kernel that would lift this was costed at 1.24 x and not built "
+                                            "the last one a third full: 5.7 M frames/s measured: `at_4096_clips`); the two-tile kernel that would lift this was costed at 1.24 x and not built "
                                             "(profiles/r05_k_sample8_two_tile_ablation.txt)"}
         del cs, es, ss, outs
         if world == 1:   # SURVEY 8d also asks for a point at >= 4,096 clips per GPU: six rounds of 768 clips, the last a third full
