@@ -179,3 +179,36 @@ def test_main_gpus_2_starts_its_own_ranks_for_infer_gesture(tmp_path):
     assert r.returncode != 0
     assert "torch.distributed" in out or "ChildFailedError" in out or "rank" in out.lower(), out[-2000:]
     assert "no HIP" in out or "hip" in out.lower(), out[-2000:]
+
+
+def test_job_range_properties_hypothesis():
+    """shard.job_range / trainer.local_jobs over random job lists: the ranks' ranges are disjoint, ordered and cover every job exactly once; every cut lies on a job
+    boundary whose clip offset is a multiple of the launch's tile size (or at the list's end); one rank takes everything."""
+    from hypothesis import given, settings, strategies as st
+    from amuse_amd import shard
+    from amuse_amd.trainer import job_runs, local_jobs
+
+    @settings(max_examples=200, deadline=None)
+    @given(st.lists(st.tuples(st.integers(1, 9), st.booleans(), st.booleans()), min_size=0, max_size=60), st.integers(1, 9))
+    def check(specs, world):
+        masks = [local_jobs(specs, r, world) for r in range(world)]
+        n = len(specs)
+        assert all(sum(m[j] for m in masks) == 1 for j in range(n))                      # every job on exactly one rank
+        if world == 1:
+            assert masks[0] == [True] * n
+        dicts = [{"bsz": b, "no_emo": e, "no_sty": s} for b, e, s in specs]
+        for (no_emo, no_sty), idx in job_runs(dicts):
+            bszs = [specs[j][0] for j in idx]
+            g = shard.job_clips_per_group(sum(bszs), 5 - no_emo - no_sty)
+            offs = [0]
+            for b in bszs:
+                offs.append(offs[-1] + b)
+            prev_end = 0
+            for r in range(world):
+                ja, jb = shard.job_range(bszs, r, world, align=g)
+                assert ja == prev_end and ja <= jb                                           # contiguous, ordered
+                assert offs[ja] % g == 0 or ja == len(bszs)                                  # cut on a tile boundary of the launch
+                assert [masks[r][idx[k]] for k in range(len(idx))] == [ja <= k < jb for k in range(len(idx))]
+                prev_end = jb
+            assert prev_end == len(bszs)
+    check()
