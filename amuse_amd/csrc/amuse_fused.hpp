@@ -394,6 +394,93 @@ __device__ __forceinline__ OPV attend(const uint4* Kb, const uint4* Vt, OPV qb, 
 
 #endif
 
+// -DAMUSE_F_ATTN_NQ2=1 (A/B; bitwise the same outputs): TWO query tiles of a wave per pass over the keys - a chunk's K / V^T fragments are read from LDS once for both,
+// and the in-order wave holds two independent score -> softmax -> PV chains.  Per tile the arithmetic is attend()'s; the "does any row maximum move" ballot is taken over
+// both tiles (a tile whose maxima stay put is shifted by 0 and rescaled by exp2(0) = 1: exact).
+#ifndef AMUSE_F_ATTN_NQ2
+#define AMUSE_F_ATTN_NQ2 0
+#endif
+template <bool NOATTN = false>
+__device__ __forceinline__ void attend2(const uint4* Kb, const uint4* Vt, OPV (&qo)[2], int len, int g, int r) {
+    if constexpr (NOATTN || (AMUSE_FABL & 2) != 0) return;
+    const int fs = frag_slot(g, r);
+    float m_run[2] = {0.f, 0.f};
+    f32x4 o[2][2] = {{splat4(0.f), splat4(0.f)}, {splat4(0.f), splat4(0.f)}};
+    const OPV ones = __builtin_bit_cast(OPV, r == 0 ? uint4{OP_ONE2, OP_ONE2, OP_ONE2, OP_ONE2} : uint4{0u, 0u, 0u, 0u});
+    f32x4 os[2] = {splat4(0.f), splat4(0.f)};
+#pragma unroll
+    for (int ch = 0; ch < kPairs / 2; ++ch) {
+        uint4 kf[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) kf[i] = Kb[(4 * ch + i) * 64 + fs];
+        f32x4 st[2][4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int n = 0; n < 2; ++n) st[n][i] = OP_MFMA(__builtin_bit_cast(OPV, kf[i]), qo[n], splat4(-m_run[n]));
+        uint4 vf[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) vf[i] = Vt[(4 * ch + i) * 64 + fs];
+        __builtin_amdgcn_sched_barrier(0);
+        const int k0 = 64 * ch;
+        if (k0 + 64 > len) {
+            int lim = len - k0 - 4 * g;
+            asm volatile("" : "+v"(lim));
+#pragma unroll
+            for (int n = 0; n < 2; ++n)
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int m = 0; m < 4; ++m) st[n][i][m] = (16 * i + m < lim) ? st[n][i][m] : -INFINITY;
+        }
+        float mx[2];
+#pragma unroll
+        for (int n = 0; n < 2; ++n) {
+            float a = max3(max3(st[n][0][0], st[n][0][1], st[n][0][2]), max3(st[n][0][3], st[n][1][0], st[n][1][1]), max3(st[n][1][2], st[n][1][3], st[n][2][0]));
+            a = max3(a, max3(st[n][2][1], st[n][2][2], st[n][2][3]), max3(st[n][3][0], st[n][3][1], st[n][3][2]));
+            mx[n] = fmaxf(a, st[n][3][3]);
+        }
+        if (ch == 0 || __builtin_amdgcn_ballot_w64(fmaxf(mx[0], mx[1]) > 0.f) != 0) {   // (wave-uniform)
+#pragma unroll
+            for (int n = 0; n < 2; ++n) {
+                const float mr = allreduce_g_max(mx[n]);
+                const float d = ch == 0 ? mr : fmaxf(mr, 0.f);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) st[n][i] -= splat4(d);
+                if (ch > 0) {
+                    const float alpha = __builtin_amdgcn_exp2f(-d);
+                    os[n] *= alpha;
+                    o[n][0] *= alpha;
+                    o[n][1] *= alpha;
+                }
+                m_run[n] += d;
+            }
+        }
+#pragma unroll
+        for (int n = 0; n < 2; ++n) {
+            f32x4 p[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const bool beyond = 64 * ch + 16 * i >= kFrames;
+#pragma unroll
+                for (int m = 0; m < 4; ++m) p[i][m] = beyond ? 0.f : __builtin_amdgcn_exp2f(st[n][i][m]);
+            }
+#pragma unroll
+            for (int pr = 0; pr < 2; ++pr) {
+                const OPV pb = OP_PACK(p[2 * pr], p[2 * pr + 1]);
+                o[n][0] = OP_MFMA(__builtin_bit_cast(OPV, vf[2 * pr]), pb, o[n][0]);
+                o[n][1] = OP_MFMA(__builtin_bit_cast(OPV, vf[2 * pr + 1]), pb, o[n][1]);
+                os[n] = OP_MFMA(ones, pb, os[n]);
+            }
+        }
+    }
+#pragma unroll
+    for (int n = 0; n < 2; ++n) {
+        const float inv = __builtin_amdgcn_rcpf(allreduce_g_sum(os[n][0]));
+        qo[n] = OP_PACK(o[n][0] * inv, o[n][1] * inv);
+    }
+}
+
 // MODE 0: input block (push the skip), 1: middle block, 2: output block (skip linear first)
 // debugging taps (TAP instantiation only, clip 0): the wave's tiles of the fp32 residual stream, row-major [300][128]
 template <int NT>
@@ -550,6 +637,15 @@ __device__ __forceinline__ void decoder_block(f32x4 (&x)[NT][kTiles], Stager& sg
         for (int j = 0; j < NT; ++j) ob[j][0] = qb[j];
         {
             const uint4* Vq = reinterpret_cast<const uint4*>(Vt);
+#if AMUSE_F_ATTN_NQ2
+            {   // tiles 0, 1 together (one pass over the keys), then - three-tile waves - tile 2 alone
+                OPV pair[2] = {ob[0][0], ob[1][0]};
+                attend2<NOATTN>(Kb, Vq, pair, len, g, r);
+                ob[0][0] = pair[0];
+                ob[1][0] = pair[1];
+                if constexpr (NT == 3) ob[2][0] = attend<NOATTN>(Kb, Vq, ob[2][0], len, g, r);
+            }
+#else
 #pragma unroll 1
             for (int j = 0; j < NT; ++j) {
                 const OPV o1 = attend<NOATTN>(Kb, Vq, ob[0][0], len, g, r);
@@ -557,6 +653,7 @@ __device__ __forceinline__ void decoder_block(f32x4 (&x)[NT][kTiles], Stager& sg
                 for (int jj = 0; jj + 1 < NT; ++jj) ob[jj][0] = ob[jj + 1][0];
                 ob[NT - 1][0] = o1;
             }
+#endif
             FSTAMP(7);   // attention of the five tiles
         }
         gemm5<NT, kTiles, 1, 8>(x, ob, sg);   // out_proj, k-slice of head h, accumulated into the residual
