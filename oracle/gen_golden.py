@@ -234,6 +234,17 @@ def gen_sched_ref(out):
                             clip_denoised=False, eta=0.0)["sample"]
         tr.append(xx.numpy().copy())
     d["ddim_traj_const_noclip"] = np.stack(tr)
+    # eta > 0 (the reference forwards configs/diff_latent_v2.json "eta" to scheduler.step, infer_ldm.py:142-147,160-161): ddim_sample draws its own noise with
+    # th.randn_like(x) - made reproducible by seeding torch's generator in front of every step (the test re-draws the same (2, 128) normals)
+    d["ddim_eta"] = np.array(0.5)
+    d["ddim_eta_seed0"] = np.array(4100)
+    xx, tr = torch.from_numpy(d["traj_x_T"]).clone(), []
+    for i, idx in enumerate(range(49, -1, -1)):
+        torch.manual_seed(4100 + i)
+        xx = sd.ddim_sample(lambda _x, _t: e_const[None].expand(B2, -1), xx, torch.full((B2,), idx, dtype=torch.long),
+                            clip_denoised=False, eta=0.5)["sample"]
+        tr.append(xx.numpy().copy())
+    d["ddim_traj_const_eta"] = np.stack(tr)
     np.savez_compressed(out / "sched_ref.npz", **d)
 
 

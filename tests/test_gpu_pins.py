@@ -107,3 +107,19 @@ def test_add_noise_in_kernel(eng_const, ref):
     out = eng_const.diffusion_forward(torch.from_numpy(ref["kat_x"]), torch.from_numpy(ref["kat_noise"]),
                                       [int(v) for v in ref["q_sample_t"]], con, emo, sty)
     assert np.abs(out["noisy_latents"].cpu().numpy() - ref["q_sample"]).max() < 1e-5
+
+
+@pytest.mark.parametrize("prec", MODES)
+def test_ddim_eta_trajectory_in_kernel(eng_const, ref, prec):
+    """Stochastic DDIM (eta = 0.5) inside the sampler kernel with the explicit per-step noise the reference tree's ddim_sample drew: all 50 steps (set_alpha_to_one=True)."""
+    from amuse_amd.scheduler import ddim_table
+    nz = []
+    for i in range(50):
+        torch.manual_seed(int(ref["ddim_eta_seed0"]) + i)
+        nz.append(torch.randn(2, 128))
+    eng_const.set_schedule(ddim_table(set_alpha_to_one=True, clip_sample=False, eta=float(ref["ddim_eta"])))
+    con, emo, sty = _cond()
+    _, traj = eng_const.sample(con, emo, sty, precision=prec, x_init=torch.from_numpy(ref["traj_x_T"]), step_noise=torch.stack(nz), return_traj=True)
+    traj, want = traj.cpu().numpy(), ref["ddim_traj_const_eta"]
+    for i in range(50):
+        assert np.abs(traj[i] - want[i]).max() < 2e-5 * max(1.0, np.abs(want[i]).max()), i

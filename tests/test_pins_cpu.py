@@ -210,3 +210,33 @@ def test_ddim_shipped_convention_decomposes_into_the_pinned_pieces(ref):
     got_o = o.step(e, 981, x).numpy()
     got_k = kernel_update(a.coef[0], x.numpy(), e.numpy(), None)
     assert np.abs(got_o - got_k).max() < 1e-6
+
+
+def ddim_eta_noise(ref, B=2):
+    """What th.randn_like(x) returned inside the reference tree's ddim_sample at step i (oracle/gen_golden.py seeds torch's generator with seed0 + i in front of it)."""
+    out = []
+    for i in range(50):
+        torch.manual_seed(int(ref["ddim_eta_seed0"]) + i)
+        out.append(torch.randn(B, 128))
+    return torch.stack(out)
+
+
+@pytest.mark.parametrize("alpha_to_one,nsteps", [(True, 50), (False, 49)])
+def test_ddim_eta_trajectory(ref, alpha_to_one, nsteps):
+    """eta = 0.5 (stochastic DDIM; the reference forwards the configured eta to scheduler.step): sigma_t = eta sqrt((1 - abar_prev) / (1 - abar_t)) sqrt(1 - abar_t / abar_prev),
+    direction coefficient sqrt(1 - abar_prev - sigma_t^2), + sigma_t z - oracle and the product's table against SpacedDiffusion.ddim_sample."""
+    eta = float(ref["ddim_eta"])
+    e = np.broadcast_to(ref["traj_eps_const"], (2, 128)).copy()
+    nz = ddim_eta_noise(ref)
+    want = ref["ddim_traj_const_eta"]
+    o = orc.DDIM(set_alpha_to_one=alpha_to_one, clip_sample=False, eta=eta)
+    tab = sch.ddim_table(set_alpha_to_one=alpha_to_one, clip_sample=False, eta=eta)
+    assert tab.needs_noise()[:49].all()
+    xo, xk = torch.from_numpy(ref["traj_x_T"].copy()), ref["traj_x_T"].copy()
+    for i, t in enumerate(o.timesteps[:nsteps]):
+        xo = o.step(torch.from_numpy(e), t, xo, nz[i])
+        xk = kernel_update(tab.coef[i], xk, e, nz[i].numpy())
+        tol = 2e-5 * max(1.0, np.abs(want[i]).max())
+        assert np.abs(xo.numpy() - want[i]).max() < tol, i
+        assert np.abs(xk - want[i]).max() < tol, i
+    assert np.abs(want - ref["ddim_traj_const_noclip"]).max() > 1.0          # (the noise term is not a rounding effect)
