@@ -33,7 +33,7 @@ Pinning status
         tests/golden/sched_ref.npz): posterior tables for all 1000 t, single-step known answers, a 1000-step trajectory.
       - ``DDIMScheduler`` (eta 0, steps_offset 1, 50 steps): the update is PINNED against SpacedDiffusion + ddim_sample
         (mdm_respace.py:64-87, mdm_gaussian_diffusion.py:895-940) on {1,21,..,981}: all 50 steps for
-        set_alpha_to_one=True, 49 of 50 for the reference's set_alpha_to_one=False, without clipping; and with clipping for
+        set_alpha_to_one=True, 49 of 50 for the reference's set_alpha_to_one=False, without clipping, eta = 0 and eta = 0.5; and with clipping for
         use_clipped_model_output=True.  TWO conventions remain recollections of the diffusers 0.17.1 source, unpinned:
         (i) set_alpha_to_one=False -> the last step's alpha_bar_prev is alphas_cumprod[0]; (ii) with clip_sample=True
         (the default the reference inherits) and use_clipped_model_output=False the direction term uses the UN-clipped
