@@ -456,13 +456,29 @@ int wgrad_launch(const float* dy, const float* x, float* out, long rows, long M,
     return 0;
 }
 // out[M][N] (+)= op(a) . op(b); a is [M][K] (ta: [K][M]), b is [K][N] (tb: [N][K]), all row-major and dense
-int rm_gemm(void* h, bool ta, bool tb, long M, long N, long K, const float* a, const float* b, float* out, bool accumulate) {
+// 1 = the library's own LDS-staged fp32-MFMA kernel (k_train_gemm.hip) for the tall projections it takes, 0 = rocBLAS for everything (AMUSE_TRAIN_GEMM=vendor; A/B)
+bool own_gemm() {
+    static const bool on = [] { const char* e = getenv("AMUSE_TRAIN_GEMM"); return !(e && e[0] == 'v'); }();
+    return on;
+}
+int bias_rows_launch(const float* bias, long rows, int C, float* out, hipStream_t st);
+// bias (nullable; [N]): added to every row of the product - by the own kernel's epilogue, or as out's initial contents in front of the library call
+int rm_gemm(void* h, bool ta, bool tb, long M, long N, long K, const float* a, const float* b, float* out, bool accumulate, const float* bias = nullptr) {
+    int dev = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    if (!ta && own_gemm() && train_gemm_tall_takes(M, N, K, tb, bias != nullptr)) {
+        HIP_TRY(launch_train_gemm_tall(a, b, bias, out, M, N, K, tb, accumulate, g_blas_stream[dev & 63]));
+        return 0;
+    }
+    if (bias) {
+        if (accumulate) return fail(AMUSE_EINVAL, "rm_gemm: bias and accumulate together");
+        bias_rows_launch(bias, M, (int)N, out, g_blas_stream[dev & 63]);
+        accumulate = true;
+    }
     // (measured, profiles/r04_train_wgrad_kernel_ab.txt: 12 us against 25 for a 128 x 128 gradient over 9,664 rows, 21 against 26 for 384 x 128; the FFN's 512 x 128 - bound by
     // the fp32 MFMA rate and their 13 MB of partial blocks - 25 against 27.5 on the 64 x 32-per-wave instantiation)
     if (ta && !tb && !accumulate && K >= 1024 && !(K & 3) && !(M & 63) && !(N & 63) && M * N < wgrad_max_elems() && (K + kWgradRows - 1) / kWgradRows <= kWgradMaxChunks &&
         (size_t)(M * N) * ((K + kWgradRows - 1) / kWgradRows) <= kWgradWsFloats && own_wgrad()) {   // a weight gradient with a long reduction
-        int dev = 0;
-        HIP_TRY(hipGetDevice(&dev));
         return wgrad_launch(a, b, out, K, M, N, g_blas_stream[dev & 63]);
     }
     const float one = 1.0f, zero = 0.0f;
@@ -590,8 +606,7 @@ int amuse_train_linear_fwd(const float* x, const float* W, const float* b, long 
     hipStream_t st = (hipStream_t)stream;
     void* h;
     TRY(blas_handle(st, &h));
-    if (b) bias_rows_launch(b, rows, N, out, st);
-    TRY(rm_gemm(h, false, true, rows, N, K, x, W, out, b != nullptr));
+    TRY(rm_gemm(h, false, true, rows, N, K, x, W, out, false, b));
     HIP_TRY(hipGetLastError());
     return 0;
 }

@@ -626,8 +626,8 @@ def bench_main(args):
                                    f"all-reduce of {tr.n_grad_elements():,} fp32 gradients; batch {bsz} per GPU, {bsz * world} global; "
                                    f"vertex-displacement loss off (needs SMPL-X assets)",
                        "batch_per_gpu": bsz, "grad_elements": tr.n_grad_elements(),
-                       "gemm": "rocBLAS (rocblas_sgemm from C++, fp32) for the plain GEMMs; hand-written HIP for the weight-gradient reductions, attention, LayerNorm / "
-                               "dropout / GELU / bias gradients, AdamW",
+                       "gemm": "hand-written HIP (fp32 MFMA) for the tall projections and input gradients (k_train_gemm), the weight-gradient reductions, attention, LayerNorm / "
+                               "dropout / GELU / bias gradients, AdamW; rocBLAS (rocblas_sgemm from C++) for the 333-wide embedding / output layers and the 32-row memory-token projections",
                        "inner_sampler": ("train: the reference's train-mode loop, dropout live (TrainModeInnerSampler)" if getattr(tr.inner_sampler, "serial", False)
                                          else "eval: the persistent HIP sampler kernel (dropout off - the reference's loop runs in train mode; opt in with AMUSE_TRAIN_INNER=train)")},
             "samples_per_s": round(its * bsz * world, 1),

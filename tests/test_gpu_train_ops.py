@@ -381,6 +381,54 @@ def test_weight_gradient_kernel_is_deterministic_and_matches_the_vendor_gemm():
     assert float((v - a.cpu()).abs().max() / ref.abs().max()) < 2e-6
 
 
+_TALL_GEMM_CHILD = r"""
+import sys, torch
+sys.path.insert(0, sys.argv[1])
+from amuse_amd import train_ops as T, _lib
+st = T._st(torch.device('cuda:0')); lib = st['lib']; s = torch.cuda.current_stream().cuda_stream
+res = {}
+for rows, N, K in [(9664, 128, 128), (9600, 384, 128), (9600, 512, 128), (9600, 128, 512), (9600, 128, 256), (1030, 256, 384), (1024, 128, 32)]:
+    g = torch.Generator().manual_seed(rows + N + K)
+    x = torch.randn(rows, K, generator=g).cuda(); W = (torch.randn(N, K, generator=g) / K ** 0.5).cuda(); b = torch.randn(N, generator=g).cuda()
+    dy = torch.randn(rows, N, generator=g).cuda(); dx0 = torch.randn(rows, K, generator=g).cuda()
+    for bias in (True, False):
+        out = torch.full((rows + 1, N), float('nan'), device='cuda')
+        _lib.check(lib.amuse_train_linear_fwd(x.data_ptr(), W.data_ptr(), b.data_ptr() if bias else None, rows, K, N, out.data_ptr(), s))
+        res[(rows, N, K, 'fwd', bias)] = out.cpu()
+    for acc in (0, 1):
+        dx = torch.cat([dx0, torch.full((1, K), float('nan'), device='cuda')])
+        _lib.check(lib.amuse_train_linear_bwd(dy.data_ptr(), x.data_ptr(), W.data_ptr(), rows, K, N, None, None, dx.data_ptr(), acc, st['ws'].data_ptr(), s))
+        res[(rows, N, K, 'dx', acc)] = dx.cpu()
+torch.save(res, sys.argv[2])
+"""
+
+
+def test_tall_projection_kernel_against_float64_and_the_vendor_gemm():
+    """out = x W^T (+ b) and dx (+)= dy W on the library's LDS-staged fp32-MFMA kernel (csrc/k_train_gemm.hip) against float64 and against rocBLAS (AMUSE_TRAIN_GEMM=vendor), each in a child process: the step's shapes, a row count that is no
+    multiple of the 48- / 32-row workgroups, a one-chunk reduction; rows past the end of the arrays are not touched."""
+    import subprocess, sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    got = {}
+    for mode in ("own", "vendor"):
+        out = f"/tmp/amuse_tall_gemm_{mode}.pt"
+        subprocess.run([sys.executable, "-c", _TALL_GEMM_CHILD, repo, out], check=True, env=dict(os.environ, AMUSE_TRAIN_GEMM=mode))
+        got[mode] = torch.load(out)
+    differ = 0
+    for key, own in got["own"].items():
+        rows, N, K, what, flag = key
+        g = torch.Generator().manual_seed(rows + N + K)
+        x = torch.randn(rows, K, generator=g).double(); W = (torch.randn(N, K, generator=g) / K ** 0.5).double(); b = torch.randn(N, generator=g).double()
+        dy = torch.randn(rows, N, generator=g).double(); dx0 = torch.randn(rows, K, generator=g).double()
+        ref = (x @ W.T + (b if flag else 0.0)) if what == "fwd" else (dy @ W + (dx0 if flag else 0.0))
+        assert bool(torch.isnan(own[rows:]).all()), key                       # the guard row behind the array
+        err = float((own[:rows].double() - ref).abs().max() / ref.abs().max())
+        assert err < 2e-6, (key, err)
+        ven = got["vendor"][key]
+        assert float((ven[:rows] - own[:rows]).abs().max() / ref.abs().max()) < 2e-6, key
+        differ += int(not torch.equal(ven[:rows], own[:rows]))
+    assert differ > 0                                                         # (really two implementations)
+
+
 @pytest.mark.parametrize("B,S", [(2, 300), (3, 302), (32, 5), (1, 17), (2, 304), (1, 1)])
 def test_attention_kernels_against_torch_math_attention(B, S):
     """csrc/k_train_attn.hip (fp32 MFMA): o and d(q | k | v) against softmax(q k^T / sqrt(32)) v under autograd, without dropout and with the kernel's own mask."""
