@@ -7,7 +7,7 @@
 //   * workgroup = 48 (or 32) rows x 128 columns, four MFMA waves side by side along N: a wave owns all row tiles x 32 columns = MT x 2 accumulator tiles of
 //     v_mfma_f32_16x16x4_f32 (fp32 products, fp32 accumulate: the arithmetic class of the library GEMM it replaces);
 //   * the k loop runs in chunks of 32: a chunk of a (MT x 16 rows x 128 B) and of b (16 KiB) is copied global -> LDS by LDS-DMA (global_load_lds_dwordx4, one
-//     1 KiB piece = 64 lanes x 16 B per instruction) into a ring of three buffers by two waves that do nothing else, two chunks ahead of the MFMAs;
+//     1 KiB piece = 64 lanes x 16 B per instruction) into a ring of three buffers by four waves that do nothing else, two chunks ahead of the MFMAs;
 //   * the LDS images are lane-linear per piece (all LDS-DMA can write), so the bank-conflict-free order is put into the SOURCE addresses: a 16-byte slot of an
 //     image row sits at slot ^ f(row) (f = (row >> 1) & 7 for the 128-byte rows of a and of b^T; bit 3 of the slot ^ bit 2 of k for the 512-byte rows of b);
 //   * k order inside a 16-wide step: lane (g, r) reads ONE 16-byte slot = k {16 j + 4 g + s}, s = 0..3, of its row and feeds MFMA s with element s - the k index
@@ -17,6 +17,7 @@
 // Bias (forward) and the previous contents of out (accumulating calls) are loaded ahead of the k loop and added behind it (beta C last, as the library GEMM).
 #include "amuse_dev.hpp"
 #include "amuse_kernels.hpp"
+#include <cstdio>
 
 namespace amuse {
 namespace {
@@ -36,10 +37,26 @@ __device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_dst) {   /
                  : "memory");
 }
 
+// -DAMUSE_GEMM_PROF=1 (variant builds only): wave 0 (MFMA) and wave 4 (copying) of the workgroup in the middle of the grid stamp the cycle counter at their phase
+// boundaries; the launcher prints the deltas of its third call
+#ifndef AMUSE_GEMM_PROF
+#define AMUSE_GEMM_PROF 0
+#endif
+#if AMUSE_GEMM_PROF
+__device__ unsigned long long g_gprof[2][64];
+#define GSTAMP(w, i) do { if (prof_on && (i) < 64) g_gprof[w][i] = __builtin_readcyclecounter(); } while (0)
+#else
+#define GSTAMP(w, i) do { } while (0)
+#endif
 template <int n>
 __device__ __forceinline__ void wait_vm_le() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory"); }
-constexpr int kGemmCopyWaves = 2;   // waves 4, 5 of a workgroup only copy: an LDS-DMA instruction costs its wave 60-180 cycles of issue (MI355X_MICROARCH.md), six of them
-                                    // per chunk in front of 48 MFMAs held the matrix pipe at 60 % when the four MFMA waves copied their own pieces
+#ifndef AMUSE_GEMM_COPY_WAVES
+#define AMUSE_GEMM_COPY_WAVES 4
+#endif
+// waves 4 .. of a workgroup only copy: an LDS-DMA instruction costs its wave 100-190 cycles of issue here (cycle stamps, -DAMUSE_GEMM_PROF=1; MI355X_MICROARCH.md has 60-185) -
+// six of them per chunk in front of 48 MFMAs held the matrix pipe at 60 % when the four MFMA waves copied their own pieces, and TWO copying waves (11 pieces each per
+// chunk = ~2,150 cycles against the chunk's 1,536 of MFMAs) were the critical path of every chunk: four (6 x ~150) are not; measured 6-7 % faster than two
+constexpr int kGemmCopyWaves = AMUSE_GEMM_COPY_WAVES;
 // MT = 16-row tiles per workgroup (3: 48 rows, 2: 32 rows); TB: b is [N][K] (out = a b^T), else [K][N]
 // kGemmBufs = LDS buffers of the chunk ring (3: two chunks in flight under the MFMAs of a third; 2: one - and room for four workgroups per CU)
 template <int MT, bool TB, int kGemmBufs>
@@ -48,15 +65,18 @@ __global__ __launch_bounds__(64 * (4 + kGemmCopyWaves)) void k_train_gemm_tall(c
     constexpr int kAPieces = 2 * MT;                // 1 KiB pieces of a chunk of a (8 rows each)
     constexpr int kPieces = kAPieces + 16;          // + the chunk of b
     constexpr int kBuf = kPieces * 1024;
-    constexpr int kPerWave = kPieces / kGemmCopyWaves;   // pieces of a copying wave: piece p belongs to copying wave p % 2
-    static_assert(kPieces % kGemmCopyWaves == 0 && (kGemmBufs - 1) * kPerWave < 64, "pieces per copying wave; vmcnt is a 6-bit counter");
+    constexpr int kPerWave = (kPieces + kGemmCopyWaves - 1) / kGemmCopyWaves;   // pieces of a copying wave: piece p belongs to copying wave p % kGemmCopyWaves (the last ones may hold one less)
+    static_assert(kPerWave * kGemmCopyWaves - kPieces < kGemmCopyWaves && (kGemmBufs - 1) * kPerWave < 64, "pieces per copying wave; vmcnt is a 6-bit counter");
     extern __shared__ __attribute__((aligned(1024))) char smem[];   // kGemmBufs x kBuf
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), g = lane >> 4, r = lane & 15;
     const int m0 = blockIdx.x * (16 * MT), nb0 = blockIdx.y * kGN;
     const int nchunks = K / kGK;
+    [[maybe_unused]] const bool prof_on = blockIdx.x == gridDim.x / 2 && blockIdx.y == 0 && lane == 0 && (wave == 0 || wave == 4);
+    GSTAMP(wave == 0 ? 0 : 1, 0);
     if (wave >= 4) {
         const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) const void*)smem;
         const int cw = wave - 4;
+        const bool full = cw + kGemmCopyWaves * (kPerWave - 1) < kPieces;   // this wave holds kPerWave pieces (else one less)
         // this wave's pieces cw, cw + 2, ...: per-lane source address of chunk 0 (advanced by one chunk per fetch)
         const float* src[kPerWave];
 #pragma unroll
@@ -78,6 +98,7 @@ __global__ __launch_bounds__(64 * (4 + kGemmCopyWaves)) void k_train_gemm_tall(c
 #pragma unroll
             for (int i = 0; i < kPerWave; ++i) {
                 const int p = cw + kGemmCopyWaves * i;
+                if (p >= kPieces) continue;   // (wave-uniform)
                 if constexpr ((AMUSE_GEMM_ABL & 2) == 0) glds16(src[i], d + i * (kGemmCopyWaves * 1024));
                 src[i] += (p < kAPieces || TB) ? kGK : (size_t)kGK * N;
             }
@@ -85,16 +106,19 @@ __global__ __launch_bounds__(64 * (4 + kGemmCopyWaves)) void k_train_gemm_tall(c
 #pragma unroll
         for (int c = 0; c < kGemmBufs - 1; ++c)
             if (c < nchunks) fetch(c);
+        GSTAMP(1, 1);
         int buf = 0;
         for (int c = 0; c < nchunks; ++c) {
             // chunk c has landed: only the chunks issued behind it (up to c + kGemmBufs - 2) may still be in flight.  One barrier per chunk: behind it every MFMA wave
             // has finished chunk c - 1 (its fragment reads have returned), so that chunk's buffer takes chunk c + kGemmBufs - 1 right away
             const int behind = min(nchunks - 1, c + kGemmBufs - 2) - c;
             if (behind == 0) wait_vm_le<0>();
-            else if (behind == 1) wait_vm_le<kPerWave>();
-            else wait_vm_le<2 * kPerWave>();
+            else if (behind == 1) { if (full) wait_vm_le<kPerWave>(); else wait_vm_le<kPerWave - 1>(); }
+            else { if (full) wait_vm_le<2 * kPerWave>(); else wait_vm_le<2 * kPerWave - 2>(); }
             static_assert(kGemmBufs == 2 || kGemmBufs == 3, "the wait counts above");
+            GSTAMP(1, 2 + 2 * c);
             __builtin_amdgcn_s_barrier();
+            GSTAMP(1, 3 + 2 * c);
             if (c + kGemmBufs - 1 < nchunks) fetch(buf == 0 ? kGemmBufs - 1 : buf - 1);
             buf = buf == kGemmBufs - 1 ? 0 : buf + 1;
         }
@@ -123,8 +147,11 @@ __global__ __launch_bounds__(64 * (4 + kGemmCopyWaves)) void k_train_gemm_tall(c
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) acc[mt][0] = acc[mt][1] = splat4(0.f);
     int buf = 0;
+    GSTAMP(0, 1);
     for (int c = 0; c < nchunks; ++c) {
+        GSTAMP(0, 2 + 2 * c);
         __builtin_amdgcn_s_barrier();   // chunk c is in its buffer (the copying waves waited for it)
+        GSTAMP(0, 3 + 2 * c);
         const char* A = smem + buf * kBuf;
         const char* B = A + kAPieces * 1024;
 #pragma unroll
@@ -162,6 +189,7 @@ __global__ __launch_bounds__(64 * (4 + kGemmCopyWaves)) void k_train_gemm_tall(c
         }
         buf = buf == kGemmBufs - 1 ? 0 : buf + 1;
     }
+    GSTAMP(0, 2 + 2 * nchunks);
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
@@ -169,6 +197,11 @@ __global__ __launch_bounds__(64 * (4 + kGemmCopyWaves)) void k_train_gemm_tall(c
             const int m = m0 + 16 * mt + 4 * g + v;
             if (m < M) *reinterpret_cast<float2*>(out + (size_t)m * N + col) = float2{acc[mt][0][v] + init[mt][v].x, acc[mt][1][v] + init[mt][v].y};
         }
+#if AMUSE_GEMM_PROF
+    GSTAMP(0, 3 + 2 * nchunks);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    GSTAMP(0, 4 + 2 * nchunks);
+#endif
 }
 
 }  // namespace
@@ -213,6 +246,22 @@ hipError_t launch_train_gemm_tall(const float* a, const float* b, const float* b
         else AMUSE_GEMM_LAUNCH(2, false, 2);
     }
 #undef AMUSE_GEMM_LAUNCH
+#if AMUSE_GEMM_PROF
+    {
+        static int calls = 0;
+        if (++calls % 50 == 3) {
+            (void)hipStreamSynchronize(stream);
+            unsigned long long h[2][64];
+            (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_gprof), sizeof(h));
+            const int n = (int)(K / kGK);
+            fprintf(stderr, "GPROF M %ld N %ld K %ld tb %d mt %d grid %u x %u: MFMA wave:", M, N, K, (int)tb, mt3 ? 3 : 2, grid.x, grid.y);
+            for (int i = 1; i <= 4 + 2 * n && i < 64; ++i) fprintf(stderr, " %llu", h[0][i] - h[0][i - 1]);
+            fprintf(stderr, " | copy wave (from the MFMA wave's start %lld):", (long long)(h[1][0] - h[0][0]));
+            for (int i = 1; i <= 1 + 2 * n && i < 64; ++i) fprintf(stderr, " %llu", h[1][i] - h[1][i - 1]);
+            fprintf(stderr, "\n");
+        }
+    }
+#endif
     return hipGetLastError();
 }
 
