@@ -466,7 +466,10 @@ int bias_rows_launch(const float* bias, long rows, int C, float* out, hipStream_
 int rm_gemm(void* h, bool ta, bool tb, long M, long N, long K, const float* a, const float* b, float* out, bool accumulate, const float* bias = nullptr) {
     int dev = 0;
     HIP_TRY(hipGetDevice(&dev));
-    if (!ta && own_gemm() && train_gemm_tall_takes(M, N, K, tb, bias != nullptr)) {
+    // (the own kernel copies 16 bytes per lane with LDS-DMA and stores pairs: operands on 16-byte, out / bias on 8-byte boundaries - the Denoiser's weights, views into the
+    // trainer's flat parameter buffer behind the prior's 333-element bias, sit on 4-byte ones)
+    const bool aligned = !(((uintptr_t)a | (uintptr_t)b) & 15) && !(((uintptr_t)out | (uintptr_t)bias) & 7);
+    if (!ta && aligned && own_gemm() && train_gemm_tall_takes(M, N, K, tb, bias != nullptr)) {
         HIP_TRY(launch_train_gemm_tall(a, b, bias, out, M, N, K, tb, accumulate, g_blas_stream[dev & 63]));
         return 0;
     }
