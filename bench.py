@@ -46,7 +46,8 @@ PMC_KERNEL = {"bf16": "k_sample8", "fp32x": "k_sample8x"}
 def pmc_traffic_bytes(clips, T, precision):
     """HBM bytes per k_sample launch.  NOT measured by this run (PMC counters need rocprofv3 around the process): read from the newest committed
     rocprofv3 PMC passes (separate --pmc runs of tools/run_sample_once.py at the bench shape) - and only if the pass's kernel_id.json (tools/kernel_id.py:
-    sha256 over the kernel's source, its headers and the Makefile, written when the pass was taken) equals the identity of the sampler in THIS tree:
+    sha256 over the kernel's source, its headers and the Makefile, and over its compiled object, written when the pass was taken) equals the identity of the sampler in THIS
+    tree - the same build inputs or, failing that, the same object bits:
     a kernel change without a PMC retake returns (None, reason) instead of a stale figure.  FETCH_SIZE / WRITE_SIZE are in KiB; FETCH_SIZE is doubled
     per MI355X_MICROARCH.md (gfx950 reports half of a wide coalesced stream).  -> (bytes or None, source / reason)."""
     if (clips, T) != (256, 1000) or precision not in PMC_DIRS:
@@ -60,9 +61,15 @@ def pmc_traffic_bytes(clips, T, precision):
     idf = REPO / d / "kernel_id.json"
     if not idf.exists():
         return None, f"{d} carries no kernel_id.json: cannot tell whether it counted the kernel of this tree"
-    want, have = json.load(open(idf)).get(PMC_KERNEL[precision], {}).get("source_sha256"), kernel_id(PMC_KERNEL[precision])["source_sha256"]
-    if want != have:
-        return None, f"{d} counted {PMC_KERNEL[precision]} built from sources {str(want)[:12]}, this tree's are {have[:12]}: retake the PMC pass (tools/run_round_measurements.sh)"
+    counted, mine = json.load(open(idf)).get(PMC_KERNEL[precision], {}), kernel_id(PMC_KERNEL[precision])
+    want, have = counted.get("source_sha256"), mine["source_sha256"]
+    # the same build inputs - or the same OBJECT: an edit to a shared header or to the Makefile's file list that leaves the kernel's translation unit compiling to the
+    # same bits has not changed the kernel that was counted
+    same_object = bool(counted.get("object_sha256")) and counted.get("object_sha256") == mine.get("object_sha256")
+    if want != have and not same_object:
+        return None, (f"{d} counted {PMC_KERNEL[precision]} built from sources {str(want)[:12]} (object {str(counted.get('object_sha256'))[:12]}), this tree's are {have[:12]} "
+                      f"(object {str(mine.get('object_sha256'))[:12]}): retake the PMC pass (tools/run_round_measurements.sh)")
+    ident = f"source id {have[:12]}" if want == have else f"object {mine['object_sha256'][:12]} (the counted pass's; source ids differ: {str(want)[:12]} then, {have[:12]} now)"
     tot = {}
     for name in ("FETCH_SIZE", "WRITE_SIZE"):
         f = REPO / d / f"{name}_counter_collection.csv"
@@ -73,7 +80,7 @@ def pmc_traffic_bytes(clips, T, precision):
         if not v:
             return None, f"{d}: no k_sample rows"
         tot[name] = sum(v) / len(v)
-    return int((2 * tot["FETCH_SIZE"] + tot["WRITE_SIZE"]) * 1024), f"{d}/*_counter_collection.csv (committed rocprofv3 --pmc passes of the kernel with source id {have[:12]}, not this run)"
+    return int((2 * tot["FETCH_SIZE"] + tot["WRITE_SIZE"]) * 1024), f"{d}/*_counter_collection.csv (committed rocprofv3 --pmc passes of the kernel with {ident}, not this run)"
 
 
 def host_cpu_info():

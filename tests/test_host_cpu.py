@@ -355,3 +355,27 @@ def test_shard_range_properties_hypothesis():
         assert 1 <= g <= 16 // tokens
         assert g == 16 // tokens or total <= 128 * g          # more clips per tile only once 128 tiles are full
     tiling()
+
+
+def test_bench_reports_pmc_traffic_only_for_the_kernel_that_was_counted(monkeypatch):
+    """bench.py's `roofline.traffic` comes from committed PMC passes, and only while the sampler of this tree IS the one that was counted: the same build inputs
+    (tools/kernel_id.py: source closure + Makefile) or, failing that, the same object bits; anything else gives (None, reason)."""
+    import importlib
+    import json
+    sys.path.insert(0, str(REPO))
+    sys.path.insert(0, str(REPO / "tools"))
+    bench, kid = importlib.import_module("bench"), importlib.import_module("kernel_id")
+    d = next(x for x in bench.PMC_DIRS["bf16"] if (REPO / x / "kernel_id.json").exists())
+    counted = json.load(open(REPO / d / "kernel_id.json"))["k_sample8"]
+    monkeypatch.setattr(kid, "kernel_id", lambda name: dict(counted))                                   # the counted kernel itself
+    v, why = bench.pmc_traffic_bytes(256, 1000, "bf16")
+    assert isinstance(v, int) and v > 1 << 20 and "source id" in why
+    monkeypatch.setattr(kid, "kernel_id", lambda name: {**counted, "source_sha256": "0" * 64})         # a header edit that left the object as it was
+    v, why = bench.pmc_traffic_bytes(256, 1000, "bf16")
+    assert isinstance(v, int) and "object" in why
+    monkeypatch.setattr(kid, "kernel_id", lambda name: {"source_sha256": "0" * 64, "object_sha256": "1" * 64})   # another kernel
+    v, why = bench.pmc_traffic_bytes(256, 1000, "bf16")
+    assert v is None and "retake" in why
+    monkeypatch.setattr(kid, "kernel_id", lambda name: {"source_sha256": "0" * 64})                     # no object at hand, other sources
+    assert bench.pmc_traffic_bytes(256, 1000, "bf16")[0] is None
+    assert bench.pmc_traffic_bytes(64, 1000, "bf16")[0] is None                                          # no pass at that shape
