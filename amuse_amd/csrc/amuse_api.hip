@@ -217,6 +217,33 @@ int build_prior(amuse_ctx* c, const float* pri, int what = AMUSE_UPD_ALL) {
         s.insert(s.end(), (size_t)2 * 16 * 64, uint4{0, 0, 0, 0});   // the fetch runs two stages ahead
         if (upload(&c->vae_w8x, s.data(), s.size() * sizeof(uint4))) return AMUSE_EHIP;
     }
+    if (what & AMUSE_UPD_F32X) {   // fp32x fused decoder (k_vae_fusedx.hip): ONE stream of unit pairs for the clip's eight waves, in consumption order, 16-unit stages
+        std::vector<uint4> s;
+        for (int b = 0; b < 9; ++b) {
+            const std::string p = blk_name("decoder", b);
+            if (b >= 5) {   // skip linear ahead of an output block: the x half (k-pairs 0..3), then the popped-skip half
+                const float* wskip = Pp.get("decoder.linear_blocks." + std::to_string(b - 5) + ".weight");
+                pack_gemm(s, PREC_F16X2, wskip, 128, 256, range(0, 8), range(0, 8));
+                pack_gemm(s, PREC_F16X2, wskip, 128, 256, range(0, 8), range(8, 16));
+            }
+            const float* in_w = Pp.get(p + ".self_attn.in_proj_weight");
+            for (int h = 0; h < 4; ++h) {   // per head: k | v tiles per k-pair (two stages), then q (one stage)
+                pack_gemm(s, PREC_F16X2, in_w, 384, 128, {8 + 2 * h, 8 + 2 * h + 1, 16 + 2 * h, 16 + 2 * h + 1}, range(0, 8));
+                pack_gemm(s, PREC_F16X2, in_w, 384, 128, {2 * h, 2 * h + 1}, range(0, 8));
+            }
+            pack_gemm(s, PREC_F16X2, Pp.get(p + ".self_attn.out_proj.weight"), 128, 128, range(0, 8), range(0, 8));
+            // FFN in 16 chunks of 32 hidden features, linear1 one chunk ahead: linear1(0), 15 x [linear1(ch + 1), linear2(ch)], linear2(15)
+            const auto f1 = [&](int ch) { pack_gemm(s, PREC_F16X2, Pp.get(p + ".linear1.weight"), 512, 128, {2 * ch, 2 * ch + 1}, range(0, 8)); };
+            const auto f2 = [&](int ch) { pack_gemm(s, PREC_F16X2, Pp.get(p + ".linear2.weight"), 128, 512, range(0, 8), {2 * ch, 2 * ch + 1}); };
+            f1(0);
+            for (int ch = 0; ch < 15; ++ch) { f1(ch + 1); f2(ch); }
+            f2(15);
+        }
+        for (int q = 0; q < 4; ++q) pack_gemm(s, PREC_F16X2, Pp.get("final_layer.weight"), kFeats, 128, range(6 * q, 6 * q + 6), range(0, 8));
+        if (s.size() % ((size_t)16 * 64) != 0) return fail(AMUSE_ESTATE, "internal: fused fp32x decode stream is not whole stages");
+        s.insert(s.end(), (size_t)2 * 16 * 64, uint4{0, 0, 0, 0});   // the fetch runs two stages ahead
+        if (upload(&c->vae_wfx, s.data(), s.size() * sizeof(uint4))) return AMUSE_EHIP;
+    }
     for (const int p16 : {PREC_BF16, PREC_F16}) {   // fused decode kernel (k_vae_fused.hip; bf16 / fp16 operands): ONE stream for the four waves, in consumption order, cut
         if (!(what & kUpdBit[p16])) continue;
         // into stages of kVaeFusedStageUnits units (every phase below is a whole number of stages)
@@ -411,7 +438,7 @@ constexpr int kFusedMinClips = 64;   // measured (profiles/r03_decode_perf.txt):
 constexpr int kVaeFusedChunk = 4096;
 bool use_vae_fused(const amuse_ctx* c, int precision, int B) {
     static const int env = [] { const char* e = getenv("AMUSE_VAE_FUSED"); return e ? atoi(e) : -1; }();
-    const int force = c->decode_path == AMUSE_DECODE_STAGED ? 0 : c->decode_path == AMUSE_DECODE_FUSED ? 1 : env;
+    const int force = c->decode_path == AMUSE_DECODE_STAGED ? 0 : (c->decode_path == AMUSE_DECODE_FUSED || c->decode_path == AMUSE_DECODE_CLIP) ? 1 : env;
     if (!is_op16(precision) || force == 0) return false;   // (the fused kernel exists in the two one-piece 16-bit formats)
     return force == 1 || B >= kFusedMinClips;
 }
@@ -419,9 +446,26 @@ bool use_vae_fused(const amuse_ctx* c, int precision, int B) {
 // fp32x decode: the no-split-K row kernel (k_vae_rows8.hip) under the same rule and the same pins as the fused kernel of the 16-bit modes
 bool use_rows8(const amuse_ctx* c, int precision, int B) {
     static const int env = [] { const char* e = getenv("AMUSE_VAE_FUSED"); return e ? atoi(e) : -1; }();
-    const int force = c->decode_path == AMUSE_DECODE_STAGED ? 0 : c->decode_path == AMUSE_DECODE_FUSED ? 1 : env;
+    const int force = c->decode_path == AMUSE_DECODE_STAGED ? 0 : (c->decode_path == AMUSE_DECODE_FUSED || c->decode_path == AMUSE_DECODE_CLIP) ? 1 : env;
     if (precision != PREC_F16X2 || force == 0) return false;
     return force == 1 || B >= kFusedMinClips;
+}
+
+// fp32x decode, third kernel: one persistent workgroup per clip (k_vae_fusedx.hip).  A clip takes ~1.5 ms on its CU whatever the batch, so the kernel wins when the call's
+// clips fill rounds of the chip's 256 CUs - measured against the row / attention launches (profiles/r05_fusedx_decode.txt, ms at 160 / 256 / 384 / 512 / 768 / 1024 clips:
+// 1.49 1.65 3.05 3.18 4.76 6.32 against 1.67 1.86 2.84 3.88 5.81 7.75): from 160 clips in the first round, and in round r >= 2 when at least 164 - 50 (r - 2) clips are in it.
+// amuse_amd/shard.py fusedx_rule is the same function (a sharded job pins the whole job's choice: AMUSE_DECODE_CLIP).  AMUSE_VAE_FUSEDX=0 / 1: never / whenever rows8 would run.
+bool fusedx_rule(int B) {
+    if (B < 160) return false;
+    const int r = (B + 255) / 256, in_last = B - 256 * (r - 1);
+    return r == 1 || in_last >= 164 - 50 * (r - 2);
+}
+bool use_fusedx(const amuse_ctx* c, int precision, int B) {
+    static const int env = [] { const char* e = getenv("AMUSE_VAE_FUSEDX"); return e ? atoi(e) : -1; }();
+    if (precision != PREC_F16X2 || !c->vae_wfx) return false;
+    if (c->decode_path == AMUSE_DECODE_CLIP) return true;
+    if (c->decode_path != AMUSE_DECODE_AUTO || env == 0) return false;
+    return env == 1 ? B >= kFusedMinClips : fusedx_rule(B);
 }
 
 int stage_lengths(amuse_ctx* c, const int* lengths, int B, hipStream_t st) {
@@ -443,7 +487,7 @@ int ensure_vae_ws(amuse_ctx* c, int chunk) {
     if (c->vae_cap >= (size_t)chunk) return 0;
     if (c->vae_ws) HIP_TRY(hipFree(c->vae_ws));
     c->vae_ws = nullptr; c->vae_cap = 0;
-    HIP_TRY(hipMalloc((void**)&c->vae_ws, (size_t)chunk * kVaeFloatsPerClip * sizeof(float)));
+    HIP_TRY(hipMalloc((void**)&c->vae_ws, ((size_t)chunk * kVaeFloatsPerClip + 256) * sizeof(float)));   // (+ 1 KiB: k_vae_fusedx copies a clip's 4.5 KiB of ca in five 1 KiB pieces)
     c->vae_cap = chunk;
     return 0;
 }
@@ -546,7 +590,7 @@ int build_repack_maps(amuse_ctx* c) {
     // element type of an image: 0 = fp32, 1 = bf16, 2 = split-fp16, 3 = fp16 (launch_repack's `kind`)
     auto kind_of = [&](void** slot) {
         if (slot == (void**)&c->den_w[PREC_F16X2] || slot == (void**)&c->den_w8x || slot == (void**)&c->vae_w[PREC_F16X2] ||
-            slot == (void**)&c->vaee_w[PREC_F16X2] || slot == (void**)&c->vae_w8x || slot == (void**)&c->vaee_w8x) return 2;
+            slot == (void**)&c->vaee_w[PREC_F16X2] || slot == (void**)&c->vae_w8x || slot == (void**)&c->vaee_w8x || slot == (void**)&c->vae_wfx) return 2;
         if (slot == (void**)&c->den_w8h || slot == (void**)&c->vae_wfh || slot == (void**)&c->vae_w[PREC_F16] || slot == (void**)&c->vaee_w[PREC_F16]) return 3;
         return (slot == (void**)&c->den_w[PREC_BF16] || slot == (void**)&c->den_w8 || slot == (void**)&c->vae_w[PREC_BF16] ||
                 slot == (void**)&c->vae_wf || slot == (void**)&c->vaee_w[PREC_BF16]) ? 1 : 0;
@@ -596,7 +640,7 @@ int build_repack_maps(amuse_ctx* c) {
             if (m < 0 || (size_t)m > limit) return fail(AMUSE_ESTATE, "internal: gather index out of range");
         int cls = 0;   // which AMUSE_UPD_* bits the image needs; 0 = small parameters, always replaced
         if (slot == (void**)&c->den_w[PREC_F32] || slot == (void**)&c->vae_w[PREC_F32]) cls = AMUSE_UPD_F32;
-        else if (slot == (void**)&c->den_w[PREC_F16X2] || slot == (void**)&c->den_w8x || slot == (void**)&c->vae_w[PREC_F16X2] || slot == (void**)&c->vae_w8x) cls = AMUSE_UPD_F32X;
+        else if (slot == (void**)&c->den_w[PREC_F16X2] || slot == (void**)&c->den_w8x || slot == (void**)&c->vae_w[PREC_F16X2] || slot == (void**)&c->vae_w8x || slot == (void**)&c->vae_wfx) cls = AMUSE_UPD_F32X;
         else if (slot == (void**)&c->vaee_w[PREC_F16X2] || slot == (void**)&c->vaee_w8x) cls = AMUSE_UPD_F32X | AMUSE_UPD_ENCODER;
         else if (slot == (void**)&c->den_w8h || slot == (void**)&c->vae_wfh || slot == (void**)&c->vae_w[PREC_F16]) cls = AMUSE_UPD_F16;
         else if (slot == (void**)&c->vaee_w[PREC_F16]) cls = AMUSE_UPD_F16 | AMUSE_UPD_ENCODER;
@@ -644,7 +688,7 @@ void amuse_destroy(amuse_ctx* c) {
         if (p) (void)hipFree(p);
     void* ptrs[] = {c->den_w[0], c->den_w[1], c->den_w[2], c->den_w8, c->den_w8h, c->den_w8x, c->vae_wfh, c->den_pvec, c->den_pe, c->den_freqs, c->te_w1t, c->te_b1, c->te_w2t,
                     c->te_b2, c->cond_wt[0], c->cond_wt[1], c->cond_wt[2], c->cond_b[0], c->cond_b[1], c->cond_b[2],
-                    c->vae_w[0], c->vae_w[1], c->vae_w[2], c->vae_w[3], c->vae_w8x, c->vaee_w8x, c->vaee_w[2], c->vaee_w[3], c->vae_pvec, c->vae_final_bias, c->vae_pe, c->vae_wv_t, c->vae_bv,
+                    c->vae_w[0], c->vae_w[1], c->vae_w[2], c->vae_w[3], c->vae_w8x, c->vae_wfx, c->vaee_w8x, c->vaee_w[2], c->vaee_w[3], c->vae_pvec, c->vae_final_bias, c->vae_pe, c->vae_wv_t, c->vae_bv,
                     c->vae_wo_t, c->vae_bo, c->vaee_w[0], c->vaee_w[1], c->vaee_pvec, c->vaee_pe, c->vaee_tok,
                     c->vaee_emb_bias, c->d_timesteps, c->d_coef, c->d_time_tok, c->d_ts1, c->d_tt1, c->d_coef1,
                     c->cond_tok, c->lat_tmp, c->fwd_ws, c->vae_ws, c->d_lengths, c->vae_wf, c->vae_skip, c->vae_ca_ws, c->vae_c1[0], c->vae_c1[1], c->vae_c1[2]};
@@ -664,7 +708,7 @@ int amuse_set_clips_per_group(amuse_ctx* c, int g) {
 
 int amuse_set_decode_path(amuse_ctx* c, int path) {
     if (!c) return fail(AMUSE_EINVAL, "ctx is NULL");
-    if (path != AMUSE_DECODE_AUTO && path != AMUSE_DECODE_STAGED && path != AMUSE_DECODE_FUSED)
+    if (path != AMUSE_DECODE_AUTO && path != AMUSE_DECODE_STAGED && path != AMUSE_DECODE_FUSED && path != AMUSE_DECODE_CLIP)
         return fail(AMUSE_EINVAL, "bad decode path %d", path);
     c->decode_path = path;
     return 0;
@@ -929,6 +973,17 @@ int amuse_vae_decode(amuse_ctx* c, const float* z, const int* lengths, int B, in
         // of the CALL (not of the chunk: a job's last chunk must not change kernels), or as amuse_set_decode_path / AMUSE_VAE_FUSED pin it
         // (FUSED = this kernel, STAGED = k_vae_rows<f16x2>), so that amuse_amd/shard.py's job-level choice keeps fp32x shards bitwise too
         const bool rows8 = use_rows8(c, precision, B);
+        // the fp32x decode as ONE persistent workgroup per clip (k_vae_fusedx.hip) where the call's clips fill rounds of the chip (use_fusedx above; keyed by the CALL's clip
+        // count like the other choices); its scratch arrays are this path's attn_o and skip
+        if (use_fusedx(c, precision, B)) {
+            VaeFusedXArgs fx{};
+            fx.wstream = c->vae_wfx; fx.pvec = c->vae_pvec; fx.final_bias = c->vae_final_bias; fx.pe = c->vae_pe; fx.ca = ca; fx.lengths = ra.lengths;
+            fx.skip = ra.skip; fx.obuf = attn_o; fx.feats_out = ra.feats_out; fx.poses_out = ra.poses_out; fx.trans_out = ra.trans_out;
+            fx.tap_out = b0 == 0 ? c->decode_tap : nullptr;
+            fx.B = nb; fx.quat_mode = quat_mode;
+            HIP_TRY(launch_vae_fusedx(fx, st));
+            continue;
+        }
         VaeRowsArgs r8 = ra;
         if (rows8) {
             r8.wstream = c->vae_w8x;

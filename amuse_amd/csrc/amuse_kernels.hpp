@@ -210,6 +210,23 @@ struct VaeFusedArgs {
 constexpr size_t kVaeFusedSkipBytesPerClip = 4 * 20 * 4 * 64 * 16;
 hipError_t launch_vae_fused(const VaeFusedArgs& a, hipStream_t stream);
 hipError_t launch_vae_fusedh(const VaeFusedArgs& a, hipStream_t stream);   // fp16 operands (AMUSE_PREC_F16, k_vae_fusedh.hip)
+// fp32x form of the fused decoder (k_vae_fusedx.hip): split-fp16 operands, the staged fp32x path's arithmetic bit for bit; its scratch arrays are the staged path's
+struct VaeFusedXArgs {
+    const uint4* wstream;      // unit pairs (hi | lo) in consumption order, whole 16 KiB stages (amuse_api.hip)
+    const float* pvec;         // decoder small params, PV_* layout
+    const float* final_bias;   // [384]
+    const float* pe;           // query_pos_decoder.pe [500][128]
+    const float* ca;           // [B][9][128] cross-attention constant (k_vae_ca); readable 512 B past the end
+    const int* lengths;        // dev [B] or null
+    float* skip;               // [4][B * 300][128] fp32 skip stack (the staged path's array)
+    float* obuf;               // [B * 300][128] attention outputs of the current block (the staged path's attn_o)
+    float* feats_out;          // [B][300][333] or null
+    float* poses_out;          // [B][300][55][3] or null
+    float* trans_out;          // [B][300][3] or null
+    float* tap_out;            // [10][300][128] or null: clip 0's fp32 residual stream after blocks 0..8 and after decoder.norm (tests)
+    int B, quat_mode;
+};
+hipError_t launch_vae_fusedx(const VaeFusedXArgs& a, hipStream_t stream);
 // ---------------------------------------------------------------- fused pose-space denoiser step (k_den_fused.hip): one workgroup per clip
 struct DenFusedArgs {
     const uint4* wstream;      // 16-bit stream in consumption order, whole stages (amuse_variants.hip)

@@ -150,13 +150,13 @@ constexpr int kDenFusedMinClips = 64;
 // ... and so does the fp32x row kernel without split-K for the staged step's stages 1..8 (the decode's rule, amuse_api.hip use_rows8)
 bool use_den_rows8(const amuse_ctx* c, int precision, int B) {
     static const int env = [] { const char* e = getenv("AMUSE_VAE_FUSED"); return e ? atoi(e) : -1; }();
-    const int force = c->decode_path == AMUSE_DECODE_STAGED ? 0 : c->decode_path == AMUSE_DECODE_FUSED ? 1 : env;
+    const int force = c->decode_path == AMUSE_DECODE_STAGED ? 0 : (c->decode_path == AMUSE_DECODE_FUSED || c->decode_path == AMUSE_DECODE_CLIP) ? 1 : env;
     if (precision != PREC_F16X2 || c->arch != AMUSE_ARCH_ENC_POSE || force == 0 || !c->var->rows8_w) return false;
     return force == 1 || B >= kDenFusedMinClips;
 }
 bool use_den_fused(const amuse_ctx* c, int precision, int B) {
     static const int env = [] { const char* e = getenv("AMUSE_VAE_FUSED"); return e ? atoi(e) : -1; }();
-    const int force = c->decode_path == AMUSE_DECODE_STAGED ? 0 : c->decode_path == AMUSE_DECODE_FUSED ? 1 : env;
+    const int force = c->decode_path == AMUSE_DECODE_STAGED ? 0 : (c->decode_path == AMUSE_DECODE_FUSED || c->decode_path == AMUSE_DECODE_CLIP) ? 1 : env;
     if (!is_op16(precision) || c->arch != AMUSE_ARCH_ENC_POSE || force == 0) return false;
     return force == 1 || B >= kDenFusedMinClips;
 }

@@ -1,0 +1,738 @@
+// MotionPrior.decode in the PARITY arithmetic (AMUSE_PREC_F32X: split-fp16 operands, three v_mfma_f32_16x16x32_f16 per product, fp32 everything else) as ONE
+// persistent workgroup per clip - the shape of k_vae_fused.hip (reference models/latent_diffusion/vae.py:216-278, cross_attention.py:66-125,297-345,
+// infer_ldm.py:168-173) with the arithmetic of the staged fp32x pair k_vae_rows8x / k_vae_attn_x, which moves q, k, v, o and the residual stream through memory between
+// its 17 launches (3.7 GB per 256-clip decode).
+//
+// What differs from the 16-bit kernel is the register budget: a row tile's fp32 residual stream (32 registers) AND its split operand image (32 more) for the three tiles
+// of a wave do not leave room for accumulators in 256 registers.  So
+//   * q, k, v of a head are projected from the residual registers with the operand split ON THE FLY per k-pair (8 transient registers per tile);
+//   * a head's attention output goes to an L2-resident scratch (the staged path's attn_o array) and out_proj runs behind the head loop, re-reading it one k-pair per
+//     weight stage - every GEMM then accumulates in exactly the order of the staged kernels (k-pair outer, hi.lo + lo.hi + hi.hi), so the result is bitwise theirs;
+//   * for the FFN and the skip linear - where the operand image must survive the accumulation into the residual registers - the three-tile waves park the images of
+//     two tiles in LDS (the K / V image region is free in those phases: 4 waves x 2 tiles x 8 KiB) and read them back as fragments; the third tile's stays in registers;
+//   * the U-Net skip stack is the staged path's fp32 array, written and read back by the same lanes.
+// LDS: K_h / V_h^T hi and lo fragment images 80 KiB | weight ring 3 x 16 KiB | block parameters 2 x 8 KiB | cross-attention constants 5 KiB = 149 KiB.
+// The weight stream is in unit PAIRS (hi | lo, 2 KiB): a 16 KiB LDS stage = 8 pairs; the stage protocol is k_vae_fused.hip's (amuse_fused.hpp Stager).
+#define AMUSE_OP_F16
+#include "amuse_fused.hpp"
+
+namespace amuse {
+namespace {
+
+constexpr int kXKvBytes = 4 * kKeyRows * 64;            // K hi | K lo | V^T hi | V^T lo: 20 KiB each
+constexpr int kXOffKv = 0;
+constexpr int kXOffW = kXOffKv + kXKvBytes;
+constexpr int kXOffPv = kXOffW + kWBufs * kStageBytes;
+constexpr int kXOffCa = kXOffPv + 2 * kPvSlot;
+constexpr int kXLdsBytes = kXOffCa + kCaBytes;           // 152,576 B
+static_assert(kXLdsBytes <= 160 * 1024, "LDS");
+// erf of the FFN activation: 0 = libm erff (the staged kernels' form), 2 = the branch-free fit of the fp32x sampler (amuse_dev.hpp erf_bf: max |error| 7.9e-8)
+#ifndef AMUSE_FX_ERF
+#define AMUSE_FX_ERF 2
+#endif
+#ifndef AMUSE_FX_OPROJ_DMA
+#define AMUSE_FX_OPROJ_DMA 1
+#endif
+#ifndef AMUSE_FX_FFN_PIPE
+#define AMUSE_FX_FFN_PIPE 1
+#endif
+constexpr int kParkTile = 8192;                          // one parked operand image: [4 k-pairs][hi | lo][64 lanes x 16 B]
+
+// one product of split operands, weights as the A operand: acc += Wl.xh + Wh.xl + Wh.xh (the term order of k_vae_rows8x)
+__device__ __forceinline__ f32x4 mfma3(f16x8 wh, f16x8 wl, const F16Pair& x, f32x4 acc) {
+    acc = mfma_f16(wl, x.hi, acc);
+    acc = mfma_f16(wh, x.lo, acc);
+    return mfma_f16(wh, x.hi, acc);
+}
+// the same product with the operands swapped: the accumulator holds the TRANSPOSED tile (rows along the registers) - V^T for the PV product
+__device__ __forceinline__ f32x4 mfma3t(f16x8 wh, f16x8 wl, const F16Pair& x, f32x4 acc) {
+    acc = mfma_f16(x.hi, wl, acc);
+    acc = mfma_f16(x.lo, wh, acc);
+    return mfma_f16(x.hi, wh, acc);
+}
+// the 8 unit pairs of the current LDS stage: f(i, hi, lo); pair i + 1 is read before pair i's MFMAs
+template <bool FETCH = true, class F>
+__device__ __forceinline__ void for_pairs(Stager& s, F&& f) {
+    if constexpr (FETCH) stage_fetch(s);
+    f16x8 h = wfrag(s, 0), l = wfrag(s, 1);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const f16x8 ch = h, cl = l;
+        if (i + 1 < 8) { h = wfrag(s, 2 * i + 2); l = wfrag(s, 2 * i + 3); }
+        f(i, ch, cl);
+    }
+}
+
+// operand images of a wave's NT tiles for a phase that accumulates into the residual registers: tiles [0, PARK) in LDS, the rest in registers
+template <int NT>
+struct Images {
+    static constexpr int PARK = NT == 3 ? 2 : 0;
+    F16Pair reg[NT - PARK][4];
+    char* lds;   // this wave's parking area + lane * 16
+    __device__ __forceinline__ void build(const f32x4 (&x)[NT][kTiles]) {
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const F16Pair p = split_f16(x[j][2 * c], x[j][2 * c + 1]);
+                if (j < PARK) {
+                    *reinterpret_cast<uint4*>(lds + j * kParkTile + (2 * c) * 1024) = __builtin_bit_cast(uint4, p.hi);
+                    *reinterpret_cast<uint4*>(lds + j * kParkTile + (2 * c + 1) * 1024) = __builtin_bit_cast(uint4, p.lo);
+                } else {
+                    reg[j - PARK][c] = p;
+                }
+            }
+    }
+    __device__ __forceinline__ F16Pair get(int j, int c) const {
+        if (j < PARK) {
+            F16Pair p;
+            p.hi = __builtin_bit_cast(f16x8, *reinterpret_cast<const uint4*>(lds + j * kParkTile + (2 * c) * 1024));
+            p.lo = __builtin_bit_cast(f16x8, *reinterpret_cast<const uint4*>(lds + j * kParkTile + (2 * c + 1) * 1024));
+            return p;
+        }
+        return reg[j - PARK][c];
+    }
+};
+
+// softmax(q K^T) V of ONE 16-query tile against the keys of the current head: K / V^T hi and lo fragment images in LDS (bank-conflict-free slot order, amuse_fused.hpp
+// frag_slot), one pair of key tiles (32 keys) per trip, merged online in log2 units.  The loop is VALU-bound (the kernel's SIMDs spend 54 % of their time issuing VALU
+// instructions, 32 % on the matrix pipe - profiles/r05_fusedx_pmc.txt), so it is built like the 16-bit kernels' `attend`: scores leave the MFMAs RELATIVE to the row's
+// running maximum (C operand = -m_run), the maximum's butterfly and the rescale run only in trips that move it (wave-uniform ballot), the row sums ride the matrix pipe
+// on a ones fragment (of the split P the PV product uses), v_max3 without NaN canonicalisation (-fno-honor-nans).  AMUSE_FX_ATTN=0: the staged kernel's loop (A/B).
+#ifndef AMUSE_FX_ATTN
+#define AMUSE_FX_ATTN 1
+#endif
+__device__ __forceinline__ void attend_x(const uint4* Kh, const uint4* Kl, const uint4* Vh, const uint4* Vl, const F16Pair& qs, f32x4 (&o)[2], int len, int g, int r) {
+    const int fs = frag_slot(g, r);
+    o[0] = o[1] = splat4(0.f);
+#if AMUSE_FX_ATTN
+    float m_run = 0.f;
+    f32x4 os = splat4(0.f);
+    const f16x8 ones = __builtin_bit_cast(f16x8, r == 0 ? uint4{OP_ONE2, OP_ONE2, OP_ONE2, OP_ONE2} : uint4{0u, 0u, 0u, 0u});
+    auto pair = [&](int jp, auto first, auto masked) {
+        constexpr bool FIRST = decltype(first)::value, MASKED = decltype(masked)::value;
+        f16x8 kh[2], kl[2], vh[2], vl[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            kh[u] = __builtin_bit_cast(f16x8, Kh[(2 * jp + u) * 64 + fs]);
+            kl[u] = __builtin_bit_cast(f16x8, Kl[(2 * jp + u) * 64 + fs]);
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            vh[u] = __builtin_bit_cast(f16x8, Vh[(2 * jp + u) * 64 + fs]);
+            vl[u] = __builtin_bit_cast(f16x8, Vl[(2 * jp + u) * 64 + fs]);
+        }
+        f32x4 st[2];
+        const f32x4 c0 = splat4(-m_run);
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {   // lane (g, i): S[i][32 jp + 16 u + 4 g + m] - m_run
+            st[u] = mfma_f16(kl[u], qs.hi, c0);
+            st[u] = mfma_f16(kh[u], qs.lo, st[u]);
+            st[u] = mfma_f16(kh[u], qs.hi, st[u]);
+        }
+        if constexpr (MASKED) {
+            int lim = len - 32 * jp - 4 * g;   // element (u, m) is valid iff 16 u + m < lim
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int m = 0; m < 4; ++m) st[u][m] = (16 * u + m < lim) ? st[u][m] : -INFINITY;
+        }
+        float mx = max3(max3(st[0][0], st[0][1], st[0][2]), max3(st[0][3], st[1][0], st[1][1]), fmaxf(st[1][2], st[1][3]));
+        if (FIRST || __builtin_amdgcn_ballot_w64(mx > 0.f) != 0) {   // (wave-uniform) some row's maximum moves
+            mx = allreduce_g_max(mx);
+            const float d = FIRST ? mx : fmaxf(mx, 0.f);
+            st[0] -= splat4(d);
+            st[1] -= splat4(d);
+            if constexpr (!FIRST) {
+                const float alpha = __builtin_amdgcn_exp2f(-d);
+                os *= alpha;
+                o[0] *= alpha;
+                o[1] *= alpha;
+            }
+            m_run += d;
+        }
+        f32x4 p[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int m = 0; m < 4; ++m) p[u][m] = __builtin_amdgcn_exp2f(st[u][m]);
+        const F16Pair pp = split_f16(p[0], p[1]);
+#pragma unroll
+        for (int td = 0; td < 2; ++td) {   // O^T[d][i] += sum_key V[key][d] P[i][key]
+            o[td] = mfma_f16(vl[td], pp.hi, o[td]);
+            o[td] = mfma_f16(vh[td], pp.lo, o[td]);
+            o[td] = mfma_f16(vh[td], pp.hi, o[td]);
+        }
+        os = mfma_f16(ones, pp.lo, os);
+        os = mfma_f16(ones, pp.hi, os);
+    };
+    const int full = min(len / 32, kPairs);   // pairs entirely below len (len >= 1: pair 0 holds a valid key)
+    if (full > 0) pair(0, std::true_type{}, std::false_type{});
+    else pair(0, std::true_type{}, std::true_type{});
+#pragma unroll 1
+    for (int jp = 1; jp < full; ++jp) pair(jp, std::false_type{}, std::false_type{});
+#pragma unroll 1
+    for (int jp = max(full, 1); jp < kPairs; ++jp) pair(jp, std::false_type{}, std::true_type{});
+    const float l = allreduce_g_sum(os[0]);
+    o[0] = o[0] / l;
+    o[1] = o[1] / l;
+#else
+    float m_run = -INFINITY, l_run = 0.f;
+    auto pair = [&](int jp, auto masked) {
+        constexpr bool MASKED = decltype(masked)::value;
+        f16x8 kh[2], kl[2], vh[2], vl[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            kh[u] = __builtin_bit_cast(f16x8, Kh[(2 * jp + u) * 64 + fs]);
+            kl[u] = __builtin_bit_cast(f16x8, Kl[(2 * jp + u) * 64 + fs]);
+            vh[u] = __builtin_bit_cast(f16x8, Vh[(2 * jp + u) * 64 + fs]);
+            vl[u] = __builtin_bit_cast(f16x8, Vl[(2 * jp + u) * 64 + fs]);
+        }
+        bool ok[2][4];
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int m = 0; m < 4; ++m) ok[u][m] = !MASKED || (32 * jp + 16 * u + 4 * g + m) < len;
+        f32x4 st[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            st[u] = mfma_f16(kl[u], qs.hi, splat4(0.f));
+            st[u] = mfma_f16(kh[u], qs.lo, st[u]);
+            st[u] = mfma_f16(kh[u], qs.hi, st[u]);
+        }
+        float mx = -INFINITY;
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int m = 0; m < 4; ++m) mx = ok[u][m] ? fmaxf(mx, st[u][m]) : mx;
+        mx = allreduce_g_max(mx);
+        const bool moved = __builtin_amdgcn_ballot_w64(mx > m_run) != 0;   // (uniform)
+        float m_new = m_run, alpha = 1.0f;
+        if (moved) {
+            m_new = fmaxf(m_run, mx);
+            alpha = (m_new == -INFINITY) ? 1.0f : __builtin_amdgcn_exp2f(m_run - m_new);
+            o[0] = o[0] * alpha;
+            o[1] = o[1] * alpha;
+            m_run = m_new;
+        }
+        f32x4 p[2];
+        float ps = 0.f;
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                p[u][m] = ok[u][m] ? __builtin_amdgcn_exp2f(st[u][m] - m_new) : 0.f;
+                ps += p[u][m];
+            }
+        ps = allreduce_g_sum(ps);
+        l_run = l_run * alpha + ps;
+        const F16Pair pp = split_f16(p[0], p[1]);
+#pragma unroll
+        for (int td = 0; td < 2; ++td) {
+            o[td] = mfma_f16(vl[td], pp.hi, o[td]);
+            o[td] = mfma_f16(vh[td], pp.lo, o[td]);
+            o[td] = mfma_f16(vh[td], pp.hi, o[td]);
+        }
+    };
+    const int full = min(len / 32, kPairs);
+#pragma unroll 1
+    for (int jp = 0; jp < full; ++jp) pair(jp, std::false_type{});
+#pragma unroll 1
+    for (int jp = full; jp < kPairs; ++jp) pair(jp, std::true_type{});
+    o[0] = o[0] / l_run;
+    o[1] = o[1] / l_run;
+#endif
+}
+
+// MODE 0: input block (push the skip), 1: middle block, 2: output block (skip linear first)
+template <int NT, int MODE>
+__device__ __forceinline__ void decoder_block_x(f32x4 (&x)[NT][kTiles], Stager& sg, const VaeFusedXArgs& a, int blk, int tile0, int b, const float* pv, const float* pv_next_src,
+                                                unsigned pv_next_dst, const float* cal, char* smem, int len, int wave, int lane) {
+    const int g = lane >> 4, r = lane & 15;
+    const size_t nrows = (size_t)a.B * kFrames;
+    [[maybe_unused]] const bool prof_on = blockIdx.x == 0 && threadIdx.x == 0 && (blk == 1 || blk == 6);
+    FSTAMP(1);   // block start
+    char* kv = smem + kXOffKv;
+    Images<NT> im;
+    im.lds = kv + (wave & 3) * (2 * kParkTile) + lane * 16;
+    if constexpr (MODE == 2) {
+        // x = linear_blocks[blk - 5](cat(x, xs.pop()))   (cross_attention.py:118-120): eight stages, the x half (k-pairs 0..3), then the popped skip
+        im.build(x);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // (the parked images are wave-private: no barrier)
+        const float* bias = a.pvec + PV_SKIP_B + (blk - 5) * kD;
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int t = 0; t < kTiles; ++t) x[j][t] = ld4(bias + 16 * t + 4 * g);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            F16Pair xc[NT];
+#pragma unroll
+            for (int j = 0; j < NT; ++j) xc[j] = im.get(j, c);
+            for_pairs(sg, [&](int o, f16x8 wh, f16x8 wl) {
+#pragma unroll
+                for (int j = 0; j < NT; ++j) x[j][o] = mfma3(wh, wl, xc[j], x[j][o]);
+            });
+            stage_end(sg);
+        }
+        const float* sk = a.skip + (size_t)(8 - blk) * nrows * kD;
+#pragma unroll 1
+        for (int c = 0; c < 4; ++c) {
+            F16Pair xc[NT];
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                const int frame = 16 * (tile0 + 4 * j) + r;
+                const float* src = sk + ((size_t)b * kFrames + min(frame, kFrames - 1)) * kD + 32 * c + 4 * g;
+                const bool ok = frame < kFrames;
+                xc[j] = split_f16(ok ? ld4(src) : splat4(0.f), ok ? ld4(src + 16) : splat4(0.f));
+            }
+            for_pairs(sg, [&](int o, f16x8 wh, f16x8 wl) {
+#pragma unroll
+                for (int j = 0; j < NT; ++j) x[j][o] = mfma3(wh, wl, xc[j], x[j][o]);
+            });
+            stage_end(sg);
+        }
+    }
+    FSTAMP(2);   // skip linear done
+    // ---------------- self-attention (cross_attention.py:323-330): x = norm1(x + out_proj(softmax(q k^T) v))
+    {
+        uint4* Kh = reinterpret_cast<uint4*>(kv);
+        uint4* Kl = Kh + kKeyRows * 4;
+        uint4* Vh = Kl + kKeyRows * 4;
+        uint4* Vl = Vh + kPairs * 2 * 16 * 4;
+        float* obuf = a.obuf + (size_t)b * kFrames * kD;
+        constexpr float kScaling = 0.17677669529663687f, kLog2e = 1.44269504088896340736f;
+#pragma unroll 1
+        for (int h = 0; h < kHeads; ++h) {
+            // ---- stage A (two LDS stages): k, v of this head -> hi / lo fragment images
+            {
+                f32x4 kk[NT][2], vv[NT][2];
+                const f32x4 bk0 = ld4(pv + PV_IN_B + kD + 32 * h + 4 * g), bk1 = ld4(pv + PV_IN_B + kD + 32 * h + 16 + 4 * g);
+                const float bv0 = pv[PV_IN_B + 2 * kD + 32 * h + r], bv1 = pv[PV_IN_B + 2 * kD + 32 * h + 16 + r];
+#pragma unroll
+                for (int j = 0; j < NT; ++j) {
+                    kk[j][0] = bk0; kk[j][1] = bk1;
+                    vv[j][0] = splat4(bv0); vv[j][1] = splat4(bv1);
+                }
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2) {
+                    F16Pair xc[NT];
+                    for_pairs(sg, [&](int i, f16x8 wh, f16x8 wl) {   // per k-pair c: k tiles (2), v tiles (2)
+                        const int c = 2 * s2 + (i >> 2), t = i & 3;
+                        if (t == 0) {
+#pragma unroll
+                            for (int j = 0; j < NT; ++j) xc[j] = split_f16(x[j][2 * c], x[j][2 * c + 1]);
+                        }
+#pragma unroll
+                        for (int j = 0; j < NT; ++j) {
+                            if (t < 2) kk[j][t] = mfma3(wh, wl, xc[j], kk[j][t]);
+                            else vv[j][t - 2] = mfma3t(wh, wl, xc[j], vv[j][t - 2]);
+                        }
+                    });
+                    if (s2 == 0) stage_end(sg);
+                }
+                FSTAMP(3);   // k, v computed
+#pragma unroll
+                for (int j = 0; j < NT; ++j) {
+                    const int tile = tile0 + 4 * j;
+                    const bool ok = 16 * tile + r < kFrames;
+                    const F16Pair ks = split_f16(ok ? kk[j][0] : splat4(0.f), ok ? kk[j][1] : splat4(0.f));
+                    Kh[tile * 64 + frag_slot(g, r)] = __builtin_bit_cast(uint4, ks.hi);
+                    Kl[tile * 64 + frag_slot(g, r)] = __builtin_bit_cast(uint4, ks.lo);
+                    // V^T: lane (g, d) holds V[16 tile + 4 g + m][16 td + d]; the image slot ((pair, td), d, g) takes keys {32 jp + 4 g + e} | {32 jp + 16 + 4 g + e}
+#pragma unroll
+                    for (int td = 0; td < 2; ++td) {
+                        f32x4 v = vv[j][td];
+#pragma unroll
+                        for (int m = 0; m < 4; ++m) v[m] = (16 * tile + 4 * g + m < kFrames) ? v[m] : 0.f;
+                        const F16Pair vs = split_f16(v, v);   // (both halves the same four values: the low one is written)
+                        const int slot = ((tile >> 1) * 2 + td) * 64 + frag_slot(g, r);
+                        const uint4 hi4 = __builtin_bit_cast(uint4, vs.hi), lo4 = __builtin_bit_cast(uint4, vs.lo);
+                        *reinterpret_cast<uint2*>(reinterpret_cast<char*>(Vh + slot) + (tile & 1) * 8) = uint2{hi4.x, hi4.y};
+                        *reinterpret_cast<uint2*>(reinterpret_cast<char*>(Vl + slot) + (tile & 1) * 8) = uint2{lo4.x, lo4.y};
+                    }
+                }
+                FSTAMP(4);   // images written
+                stage_end(sg);
+                FSTAMP(5);   // barrier of stage A passed
+            }
+            // ---- stage B (one LDS stage): q of this head; attention, a tile at a time; the output to the scratch
+            if (h == 0 && pv_next_src) {   // next block's small parameters -> the other LDS slot
+                const unsigned d = __builtin_amdgcn_readfirstlane(pv_next_dst + wave * 1024);
+                glds16(reinterpret_cast<const uint4*>(pv_next_src) + wave * 64 + lane, d);
+            }
+            F16Pair qs[NT];
+            {
+                f32x4 q[NT][2];
+                const f32x4 bq0 = ld4(pv + PV_IN_B + 32 * h + 4 * g), bq1 = ld4(pv + PV_IN_B + 32 * h + 16 + 4 * g);
+#pragma unroll
+                for (int j = 0; j < NT; ++j) { q[j][0] = bq0; q[j][1] = bq1; }
+                F16Pair xc[NT];
+                for_pairs(sg, [&](int i, f16x8 wh, f16x8 wl) {
+                    const int c = i >> 1, o = i & 1;
+                    if (o == 0) {
+#pragma unroll
+                        for (int j = 0; j < NT; ++j) xc[j] = split_f16(x[j][2 * c], x[j][2 * c + 1]);
+                    }
+#pragma unroll
+                    for (int j = 0; j < NT; ++j) q[j][o] = mfma3(wh, wl, xc[j], q[j][o]);
+                });
+#pragma unroll
+                for (int j = 0; j < NT; ++j) qs[j] = split_f16((q[j][0] * kScaling) * kLog2e, (q[j][1] * kScaling) * kLog2e);
+            }
+            FSTAMP(6);   // q
+#pragma unroll 1
+            for (int j = 0; j < NT; ++j) {   // runtime loop: the attention's only copy in the instruction stream; the tiles rotate through slot 0
+                f32x4 o[2];
+                attend_x(Kh, Kl, Vh, Vl, qs[0], o, len, g, r);
+                const int frame = 16 * (tile0 + 4 * j) + r;
+                if (frame < kFrames) {
+                    float* dst = obuf + (size_t)frame * kD + 32 * h + 4 * g;
+                    st4(dst, o[0]);
+                    st4(dst + 16, o[1]);
+                }
+                const F16Pair first = qs[0];
+#pragma unroll
+                for (int jj = 0; jj + 1 < NT; ++jj) qs[jj] = qs[jj + 1];
+                qs[NT - 1] = first;
+            }
+            FSTAMP(7);   // attention of the wave's tiles, outputs stored
+            stage_end(sg);
+            FSTAMP(8);   // barrier of stage B passed
+        }
+        // ---- out_proj (four LDS stages, k-pair = head): the attention outputs come back from the scratch one k-pair ahead of their stage
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int t = 0; t < kTiles; ++t) x[j][t] += ld4(pv + PV_OUT_B + 16 * t + 4 * g);
+#if !AMUSE_FX_OPROJ_DMA
+        {   // (A/B: plain loads one k-pair ahead)
+        f32x4 ob[NT][2];
+        auto load_o = [&](int c) {
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                const int frame = 16 * (tile0 + 4 * j) + r;
+                const float* src = obuf + (size_t)min(frame, kFrames - 1) * kD + 32 * c + 4 * g;
+                ob[j][0] = ld4(src);
+                ob[j][1] = ld4(src + 16);
+            }
+        };
+        load_o(0);
+#pragma unroll 1
+        for (int c = 0; c < 4; ++c) {
+            F16Pair xc[NT];
+#pragma unroll
+            for (int j = 0; j < NT; ++j) xc[j] = split_f16(ob[j][0], ob[j][1]);
+            if (c + 1 < 4) load_o(c + 1);
+            for_pairs(sg, [&](int o, f16x8 wh, f16x8 wl) {
+#pragma unroll
+                for (int j = 0; j < NT; ++j) x[j][o] = mfma3(wh, wl, xc[j], x[j][o]);
+            });
+            stage_end(sg);
+            FSTAMP(9);
+        }
+        }
+    }
+#else
+        // Plain loads here would be waited for by every stage end (vmcnt retires in order and the stage protocol waits for all but the two newest operations): a full
+        // L2 round trip per stage, 7 % of the block.  So the outputs come back by LDS-DMA into a wave-private double buffer in the (now dead) K / V image region - lane
+        // (g, r) fetches the 16 bytes it would have loaded, one k-pair (head) = 2 NT pieces - issued BEHIND the stage's weight fetch and counted exactly.
+        const unsigned obase = lds_addr(smem) + kXOffKv + (wave < 4 ? wave * 12288 : 49152 + (wave - 4) * 8192);
+        const char* obuf_l = smem + kXOffKv + (wave < 4 ? wave * 12288 : 49152 + (wave - 4) * 8192) + lane * 16;
+        const float* osrc[NT];
+#pragma unroll
+        for (int j = 0; j < NT; ++j) osrc[j] = obuf + (size_t)min(16 * (tile0 + 4 * j) + r, kFrames - 1) * kD + 4 * g;
+        auto fetch_o = [&](int c) {
+            const unsigned d = __builtin_amdgcn_readfirstlane(obase + (c & 1) * (NT * 2048));
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                glds16(reinterpret_cast<const uint4*>(osrc[j] + 32 * c), d + (2 * j) * 1024);
+                glds16(reinterpret_cast<const uint4*>(osrc[j] + 32 * c + 16), d + (2 * j + 1) * 1024);
+            }
+        };
+        fetch_o(0);
+#pragma unroll 1
+        for (int c = 0; c < 4; ++c) {
+            stage_fetch(sg);
+            if (c + 1 < 4) {
+                fetch_o(c + 1);
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 + 2 * NT) : "memory");   // this k-pair's outputs are in (and every older weight stage)
+            } else {
+                asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+            }
+            F16Pair xc[NT];
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                const char* src = obuf_l + (c & 1) * (NT * 2048) + (2 * j) * 1024;
+                xc[j] = split_f16(*reinterpret_cast<const f32x4*>(src), *reinterpret_cast<const f32x4*>(src + 1024));
+            }
+            for_pairs<false>(sg, [&](int o, f16x8 wh, f16x8 wl) {
+#pragma unroll
+                for (int j = 0; j < NT; ++j) x[j][o] = mfma3(wh, wl, xc[j], x[j][o]);
+            });
+            if (c + 1 < 4) {   // (stage_end with the next k-pair's pieces allowed in flight behind this stage's weight fetch)
+                asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(2 + 2 * NT) : "memory");
+                sg.ridx = sg.ridx == kWBufs - 1 ? 0 : sg.ridx + 1;
+            } else {
+                stage_end(sg);
+            }
+            FSTAMP(9);   // an out_proj stage
+        }
+    }
+#endif
+    // ---------------- norm1, the one-token cross-attention (a per-clip constant), norm2  (cross_attention.py:331-337)
+    {
+        const float* ca = cal + blk * kD;
+#pragma unroll 1
+        for (int j = 0; j < NT; ++j) {
+            layer_norm_rows<false>(x[0], pv + PV_LN1_W, pv + PV_LN1_B, g);
+#pragma unroll
+            for (int t = 0; t < kTiles; ++t) x[0][t] += ld4(ca + 16 * t + 4 * g);
+            layer_norm_rows<false>(x[0], pv + PV_LN2_W, pv + PV_LN2_B, g);
+            rotate_tiles<NT>(x);
+        }
+    }
+    FSTAMP(10);   // norm1, cross-attention constant, norm2
+    // ---------------- FFN (cross_attention.py:338-340): x = norm3(x + linear2(gelu(linear1(x)))), 16 chunks of 32 hidden features, two LDS stages each
+    im.build(x);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int t = 0; t < kTiles; ++t) x[j][t] += ld4(pv + PV_L2_B + 16 * t + 4 * g);
+    // Stages: linear1(0), 15 x [linear1(ch + 1), linear2(ch)], linear2(15).  linear1 runs one chunk ahead, so the erf-GELU of chunk ch (VALU) and linear1's MFMAs of chunk
+    // ch + 1 share a stage - and the two waves of a SIMD, in lock step since the last barrier, take them in OPPOSITE order (three-tile waves: MFMAs first; two-tile waves:
+    // GELU first), so that one's matrix-pipe time covers the other's VALU time instead of adding to it (AMUSE_FX_FFN_PIPE=0: the plain order, A/B).
+    f32x4 hid[NT][2];
+    auto lin1 = [&](f32x4 (&acc)[NT][2], int ch) {
+        const f32x4 b0 = ld4(pv + PV_L1_B + 32 * ch + 4 * g), b1 = ld4(pv + PV_L1_B + 32 * ch + 16 + 4 * g);
+#pragma unroll
+        for (int j = 0; j < NT; ++j) { acc[j][0] = b0; acc[j][1] = b1; }
+        F16Pair xc[NT];
+        for_pairs(sg, [&](int i, f16x8 wh, f16x8 wl) {
+            const int c = i >> 1, o = i & 1;
+            if (o == 0) {
+#pragma unroll
+                for (int j = 0; j < NT; ++j) xc[j] = im.get(j, c);
+            }
+#pragma unroll
+            for (int j = 0; j < NT; ++j) acc[j][o] = mfma3(wh, wl, xc[j], acc[j][o]);
+        });
+    };
+    auto gelu_split = [&](F16Pair (&hs)[NT]) {
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int m = 0; m < 4; ++m) hid[j][i][m] = AMUSE_FX_ERF == 2 ? gelu_erf_bf(hid[j][i][m]) : gelu_erf(hid[j][i][m]);
+            hs[j] = split_f16(hid[j][0], hid[j][1]);
+        }
+    };
+    lin1(hid, 0);
+    stage_end(sg);
+#pragma unroll 1
+    for (int ch = 0; ch < 16; ++ch) {
+        F16Pair hs[NT];
+        if (ch < 15) {
+            f32x4 nxt[NT][2];
+            FSTAMP(11);
+            if constexpr (NT == 3 || !AMUSE_FX_FFN_PIPE) {
+                lin1(nxt, ch + 1);
+                __builtin_amdgcn_sched_barrier(0);
+                gelu_split(hs);
+            } else {
+                gelu_split(hs);
+                __builtin_amdgcn_sched_barrier(0);
+                lin1(nxt, ch + 1);
+            }
+            FSTAMP(12);   // linear1 of the next chunk + GELU of this one
+            stage_end(sg);
+            FSTAMP(13);
+#pragma unroll
+            for (int j = 0; j < NT; ++j) { hid[j][0] = nxt[j][0]; hid[j][1] = nxt[j][1]; }
+        } else {
+            gelu_split(hs);
+        }
+        for_pairs(sg, [&](int o, f16x8 wh, f16x8 wl) {
+#pragma unroll
+            for (int j = 0; j < NT; ++j) x[j][o] = mfma3(wh, wl, hs[j], x[j][o]);
+        });
+        FSTAMP(14);   // linear2 of the chunk
+        stage_end(sg);
+        FSTAMP(15);
+    }
+#pragma unroll 1
+    for (int j = 0; j < NT; ++j) {
+        layer_norm_rows<false>(x[0], pv + PV_LN3_W, pv + PV_LN3_B, g);
+        rotate_tiles<NT>(x);
+    }
+    FSTAMP(16);   // norm3
+    if constexpr (MODE == 0) {   // xs.append(x)
+        float* sk = a.skip + (size_t)blk * nrows * kD;
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            const int frame = 16 * (tile0 + 4 * j) + r;
+            if (frame < kFrames) {
+#pragma unroll
+                for (int t = 0; t < kTiles; ++t) st4(sk + ((size_t)b * kFrames + frame) * kD + 16 * t + 4 * g, x[j][t]);
+            }
+        }
+    }
+    if (a.tap_out && b == 0) store_tap<NT>(a.tap_out, blk, x, tile0, g, r);
+}
+
+template <int NT>
+__device__ __forceinline__ void decode_tiles_x(const VaeFusedXArgs& a, char* smem, Stager& sg, int tile0, int b, int len, int wave, int lane) {
+    const int g = lane >> 4, r = lane & 15;
+    const float* pvl = reinterpret_cast<const float*>(smem + kXOffPv);
+    const float* cal = reinterpret_cast<const float*>(smem + kXOffCa);
+    const unsigned lds0 = lds_addr(smem);
+    f32x4 x[NT][kTiles];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+        const int frame = 16 * (tile0 + 4 * j) + r;
+#pragma unroll
+        for (int t = 0; t < kTiles; ++t) x[j][t] = frame < kFrames ? ld4(a.pe + (size_t)frame * kD + 16 * t + 4 * g) : splat4(0.f);
+    }
+    asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)\n\ts_barrier" ::: "memory");   // parameters, constants and stage 0 are in
+#pragma unroll 1
+    for (int blk = 0; blk < 4; ++blk)
+        decoder_block_x<NT, 0>(x, sg, a, blk, tile0, b, pvl + (blk & 1) * (kPvSlot / 4), a.pvec + (blk + 1) * PV_BLOCK, lds0 + kXOffPv + ((blk + 1) & 1) * kPvSlot, cal, smem, len, wave, lane);
+    decoder_block_x<NT, 1>(x, sg, a, 4, tile0, b, pvl, a.pvec + 5 * PV_BLOCK, lds0 + kXOffPv + kPvSlot, cal, smem, len, wave, lane);
+#pragma unroll 1
+    for (int blk = 5; blk < kLayers; ++blk)
+        decoder_block_x<NT, 2>(x, sg, a, blk, tile0, b, pvl + (blk & 1) * (kPvSlot / 4), blk + 1 < kLayers ? a.pvec + (blk + 1) * PV_BLOCK : nullptr,
+                               lds0 + kXOffPv + ((blk + 1) & 1) * kPvSlot, cal, smem, len, wave, lane);
+    // ---------------- decoder.norm -> final_layer (333 outputs in 24 tiles, four quarters of 6: three LDS stages each) -> rotation epilogue
+#pragma unroll 1
+    for (int j = 0; j < NT; ++j) {
+        layer_norm_rows<false>(x[0], a.pvec + PV_FINAL_W, a.pvec + PV_FINAL_B, g);
+        rotate_tiles<NT>(x);
+    }
+    if (a.tap_out && b == 0) store_tap<NT>(a.tap_out, 9, x, tile0, g, r);
+    F16Pair xs[NT][4];
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) xs[j][c] = split_f16(x[j][2 * c], x[j][2 * c + 1]);
+    float* fst = reinterpret_cast<float*>(smem + kXOffKv) + wave * 16 * kQStride;   // one staging tile per wave (the K / V images are dead)
+#pragma unroll 1
+    for (int quarter = 0; quarter < 4; ++quarter) {
+        f32x4 f[NT][6];
+#pragma unroll
+        for (int o = 0; o < 6; ++o) {
+            const f32x4 bi = ld4(a.final_bias + 16 * (6 * quarter + o) + 4 * g);
+#pragma unroll
+            for (int j = 0; j < NT; ++j) f[j][o] = bi;
+        }
+#pragma unroll
+        for (int s3 = 0; s3 < 3; ++s3) {
+            for_pairs(sg, [&](int i, f16x8 wh, f16x8 wl) {
+                const int lin = 8 * s3 + i, c = lin / 6, o = lin - 6 * c;
+#pragma unroll
+                for (int j = 0; j < NT; ++j) f[j][o] = mfma3(wh, wl, xs[j][c], f[j][o]);
+            });
+            stage_end(sg);
+        }
+        const int f0 = 96 * quarter, nfe = quarter == 3 ? kFeats - 288 : 96, njo = quarter == 3 ? kJoints - 48 : 16;
+#pragma unroll 1
+        for (int j = 0; j < NT; ++j) {   // one tile at a time through the wave's staging tile (wave-private: no barrier); the tiles rotate through slot 0
+            const int tile = tile0 + 4 * j;
+            const int frame = 16 * tile + r;
+            const bool keep = frame < kFrames && frame < len;   // output[~mask.T] = 0 (vae.py:274)
+            const int rows_here = min(16, kFrames - 16 * tile);   // <= 0 for the padding tile
+            const size_t row0 = (size_t)b * kFrames + 16 * tile;
+#pragma unroll
+            for (int o = 0; o < 6; ++o) st4(fst + r * kQStride + 16 * o + 4 * g, keep ? f[0][o] : splat4(0.f));
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if (a.feats_out) {
+                for (int i = lane; i < rows_here * nfe; i += 64) {
+                    const int rr = i / nfe, c = i - rr * nfe;
+                    a.feats_out[(row0 + rr) * kFeats + f0 + c] = fst[rr * kQStride + c];
+                }
+            }
+            if (a.poses_out) {
+                for (int i = lane; i < rows_here * njo; i += 64) {
+                    const int rr = i / njo, jn = i - rr * njo;
+                    float aa[3];
+                    rot6d_to_axis_angle(fst + rr * kQStride + 6 * jn, a.quat_mode, aa);
+                    float* dst = a.poses_out + ((row0 + rr) * kJoints + 16 * quarter + jn) * 3;
+                    dst[0] = aa[0]; dst[1] = aa[1]; dst[2] = aa[2];
+                }
+            }
+            if (a.trans_out && quarter == 3) {
+                for (int i = lane; i < rows_here * 3; i += 64) {
+                    const int rr = i / 3, c = i - rr * 3;
+                    a.trans_out[(row0 + rr) * 3 + c] = fst[rr * kQStride + (330 - 288) + c];
+                }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int o = 0; o < 6; ++o) {
+                const f32x4 first = f[0][o];
+#pragma unroll
+                for (int jj = 0; jj + 1 < NT; ++jj) f[jj][o] = f[jj + 1][o];
+                f[NT - 1][o] = first;
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_vae_fusedx(VaeFusedXArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int b = blockIdx.x;
+    const int len = a.lengths ? a.lengths[b] : kFrames;
+    const unsigned lds0 = lds_addr(smem);
+    // block 0's parameters, the clip's cross-attention constants, then the first two weight stages
+    glds16(reinterpret_cast<const uint4*>(a.pvec) + wave * 64 + lane, lds0 + kXOffPv + wave * 1024);
+    if (wave < 5) glds16(reinterpret_cast<const uint4*>(a.ca + (size_t)b * kLayers * kD) + wave * 64 + lane, lds0 + kXOffCa + wave * 1024);
+    Stager sg;
+    sg.src = a.wstream + (size_t)wave * 2 * 64 + lane;
+    sg.dst0 = lds0 + kXOffW + wave * 2048;
+    sg.ring = smem + kXOffW + lane * 16;
+    sg.widx = 0;
+    sg.ridx = 0;
+    stage_fetch(sg);
+    stage_fetch(sg);
+    if (wave < 4) decode_tiles_x<3>(a, smem, sg, wave, b, len, wave, lane);
+    else decode_tiles_x<2>(a, smem, sg, wave + 8, b, len, wave, lane);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the two surplus fetches must not outlive the workgroup's LDS
+}
+
+}  // namespace
+
+hipError_t launch_vae_fusedx(const VaeFusedXArgs& a, hipStream_t stream) {
+    static DeviceOnce once;
+    int dev_;
+    if (!once.done(&dev_)) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_vae_fusedx), hipFuncAttributeMaxDynamicSharedMemorySize, kXLdsBytes);
+        if (e != hipSuccess) return e;
+        once.set(dev_);
+    }
+#if AMUSE_FPROF
+    {
+        int zero = 0;
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(g_fprof_n), &zero, sizeof(int));
+    }
+#endif
+    hipLaunchKernelGGL(k_vae_fusedx, dim3(a.B), dim3(512), kXLdsBytes, stream, a);
+#if AMUSE_FPROF
+    {
+        static int calls = 0;
+        (void)hipStreamSynchronize(stream);
+        unsigned long long h[512];
+        int n = 0;
+        (void)hipMemcpyFromSymbol(&n, HIP_SYMBOL(g_fprof_n), sizeof(int));
+        (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_fprof), sizeof(h));
+        if (++calls == 3) {
+            for (int i = 1; i < n; ++i) fprintf(stderr, "FPROF %3d tag %2llu  +%llu\n", i, h[2 * i + 1], h[2 * i] - h[2 * i - 2]);
+        }
+    }
+#endif
+    return hipGetLastError();
+}
+
+}  // namespace amuse

@@ -155,8 +155,8 @@ class HipEngine:
 
     def set_decode_path(self, path: str = "auto"):
         """decode kernels of the bf16 / fp16 / fp32x modes: "auto" (from 64 clips up the fused per-clip kernel, in fp32x the no-split-K row
-        kernel), "staged", "fused" (amuse_hip.h amuse_set_decode_path)."""
-        _lib.check(self.lib.amuse_set_decode_path(self.ctx, {"auto": 0, "staged": 1, "fused": 2}[path]))
+        kernel), "staged", "fused", "clip" (the fp32x mode's per-clip decoder; "fused" in the other modes) (amuse_hip.h amuse_set_decode_path)."""
+        _lib.check(self.lib.amuse_set_decode_path(self.ctx, {"auto": 0, "staged": 1, "fused": 2, "clip": 3}[path]))
 
     def set_ablation(self, mask: int = 0):
         """amuse_debug_set_ablation: 1 = the fused kernels run without their S ~ 300 self-attention (timing only: bench.py)."""

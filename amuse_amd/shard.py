@@ -20,12 +20,24 @@ def job_clips_per_group(total: int, tokens: int = 5) -> int:
 FUSED_DECODE_MIN_CLIPS = 64   # amuse_api.hip kFusedMinClips: the library's per-launch rule for the bf16 / fp16 / fp32x decode kernels
 
 
+def fusedx_rule(total: int) -> bool:
+    """amuse_api.hip fusedx_rule: does a call of `total` clips decode on the fp32x mode's per-clip kernel (k_vae_fusedx.hip)?  A clip takes ~1.5 ms on its CU whatever
+    the batch, so the kernel wins when the clips fill rounds of the chip's 256 CUs: from 160 clips in the first round, in round r >= 2 with at least 164 - 50 (r - 2)."""
+    if total < 160:
+        return False
+    r = -(-total // 256)
+    return r == 1 or total - 256 * (r - 1) >= 164 - 50 * (r - 2)
+
+
 def job_decode_path(total: int) -> str:
     """The decode kernels (amuse_hip.h amuse_set_decode_path) a job of `total` clips would get on one GPU.  Like the clips
     per tile it must be chosen from the WHOLE job, not per shard: each 16-bit mode has a staged and a fused decoder and the
-    fp32x mode two row kernels (k_vae_rows<f16x2> below 64 clips, k_vae_rows8x from 64) that sum in different orders, so a
-    256-clip job cut into 32-clip shards would otherwise decode on other kernels than the same job on one GPU (only the fp32
-    mode has a single decode path)."""
+    fp32x mode three (k_vae_rows<f16x2> below 64 clips, k_vae_rows8x from 64, the per-clip k_vae_fusedx where the clips fill
+    rounds of the chip) that sum in different orders, so a 256-clip job cut into 32-clip shards would otherwise decode on
+    other kernels than the same job on one GPU (only the fp32 mode has a single decode path).  "clip" means "fused" in the
+    modes that have no third kernel."""
+    if fusedx_rule(total):
+        return "clip"
     return "fused" if total >= FUSED_DECODE_MIN_CLIPS else "staged"
 
 

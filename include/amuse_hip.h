@@ -260,8 +260,12 @@ int amuse_set_clips_per_group(amuse_ctx* ctx, int g);
  * in summation order only.  The fp32x mode has the same pair of paths under the same rule and the same pins: its staged row kernel
  * (k_vae_rows<f16x2>: one 16-row tile per workgroup, split-K) below 64 clips, the no-split-K row kernel (csrc/k_vae_rows8.hip: a tile per
  * wave, weights through LDS once per workgroup; FUSED selects it) from 64 clips up - again the same function in another summation order.
- * The environment variable AMUSE_VAE_FUSED=0 / 1 overrides AUTO for a whole process. */
-enum { AMUSE_DECODE_AUTO = 0, AMUSE_DECODE_STAGED = 1, AMUSE_DECODE_FUSED = 2 };
+ * The environment variable AMUSE_VAE_FUSED=0 / 1 overrides AUTO for a whole process.
+ * CLIP: the fp32x mode's third decoder - one persistent workgroup per clip in the parity arithmetic (csrc/k_vae_fusedx.hip: the residual stream in registers, q / k / v never
+ * leave the CU) - which AUTO takes when the call's clips fill whole rounds of the chip's 256 CUs (from 160 clips; amuse_amd/shard.py fusedx_rule states the rule); in the other
+ * modes CLIP means FUSED.  The three fp32x decoders compute the same function and differ by fp32 rounding (1.5e-6 on features of magnitude 3), so a sharded job pins the
+ * whole job's choice (amuse_amd/shard.py job_decode_path).  AMUSE_VAE_FUSEDX=0 / 1 overrides AUTO's choice of this kernel for a whole process. */
+enum { AMUSE_DECODE_AUTO = 0, AMUSE_DECODE_STAGED = 1, AMUSE_DECODE_FUSED = 2, AMUSE_DECODE_CLIP = 3 };
 int amuse_set_decode_path(amuse_ctx* ctx, int path);
 
 /* ------------------------------------------------------------------------------------------------

@@ -187,13 +187,13 @@ def test_fused_decode_blockwise_taps(env):
 def test_decode_chunk_boundaries_are_invisible():
     """amuse_vae_decode walks large batches in chunks (4096 clips on the fused kernel, 512 on the staged ones) that reuse one
     workspace: clips on both sides of a boundary - with ragged lengths - come out bitwise as in a small batch of their own (decode path
-    pinned: "fused" = the per-clip kernel in the 16-bit modes, the no-split-K row kernel k_vae_rows8x in fp32x)."""
+    pinned: "fused" = the per-clip kernel in the 16-bit modes, the no-split-K row kernel k_vae_rows8x in fp32x; "clip" = the fp32x per-clip kernel k_vae_fusedx)."""
     from amuse_amd import weights as wts
     from amuse_amd.engine import HipEngine
     eng = HipEngine(wts.make_denoiser_weights(0), wts.make_prior_weights(0), "cuda:0")
     try:
         gen = torch.Generator().manual_seed(77)
-        for prec, path, B, edge in (("bf16", "fused", 4100, 4096), ("fp16", "fused", 4100, 4096), ("fp32x", "fused", 520, 512), ("fp32x", "staged", 520, 512),
+        for prec, path, B, edge in (("bf16", "fused", 4100, 4096), ("fp16", "fused", 4100, 4096), ("fp32x", "fused", 520, 512), ("fp32x", "staged", 520, 512), ("fp32x", "clip", 520, 512),
                                     ("bf16", "staged", 520, 512)):
             eng.set_decode_path(path)
             z = torch.randn(B, 128, generator=gen)

@@ -414,6 +414,23 @@ def test_vae_decode_fp32_vs_reference_golden(env, prec):
             assert float(o8r["feats"][1, 173:].abs().max()) == 0.0 and float(o8r["poses"][1, 173:].abs().max()) == 0.0
             big = eng.vae_decode(torch.from_numpy(g["z"]).repeat(40, 1), None, prec, return_feats=True)   # 120 clips: 10-wave workgroups
             assert torch.equal(big["feats"][:3], o8["feats"]) and torch.equal(big["feats"][117:], o8["feats"])
+            # ... and on the THIRD fp32x decoder - one persistent workgroup per clip (k_vae_fusedx.hip; "clip" pins it, AUTO takes it where the clips fill rounds of
+            # the chip): the golden, the ragged golden, the padded frames, and a clip's bits independent of the launch it sits in
+            eng.set_decode_path("clip")
+            oc = eng.vae_decode(g["z"], None, prec, return_feats=True)
+            assert _err(oc["feats"], g["feats"]) < 2e-5 and _err(oc["feats"], o8["feats"]) < 5e-6 and not torch.equal(oc["feats"], o8["feats"])
+            ocr = eng.vae_decode(g["z"][:2], [300, 173], prec, return_feats=True)
+            assert _err(ocr["feats"], g["feats_ragged"]) < 2e-5
+            assert float(ocr["feats"][1, 173:].abs().max()) == 0.0 and float(ocr["poses"][1, 173:].abs().max()) == 0.0 and float(ocr["trans"][1, 173:].abs().max()) == 0.0
+            big = eng.vae_decode(torch.from_numpy(g["z"]).repeat(90, 1), None, prec, return_feats=True)   # 270 clips: a second round of workgroups on the chip
+            assert torch.equal(big["feats"][:3], oc["feats"]) and torch.equal(big["feats"][267:], oc["feats"]) and torch.equal(big["poses"][132:135], oc["poses"])
+            poses, _ = orc.feats_to_smplx(oc["feats"].cpu(), "p3d")                                        # the rotation epilogue on its own features
+            pivot, margin = _conditioning(orc, oc["feats"].cpu())
+            dd = torch.linalg.vector_norm(oc["poses"].cpu() - poses, dim=-1)
+            assert float(dd[margin > 1e-3].max()) < 1e-4 and float(dd[(pivot > 0.1) & (margin > 1e-3)].max()) < 2e-5
+            eng.set_decode_path("auto")                                                                    # AUTO at 256 clips = the per-clip kernel (shard.fusedx_rule)
+            auto = eng.vae_decode(torch.from_numpy(g["z"]).repeat(86, 1)[:256], None, prec, return_feats=True)
+            assert torch.equal(auto["feats"][:3], oc["feats"])
         finally:
             eng.set_decode_path("auto")
 
@@ -577,7 +594,7 @@ def test_full_size_batch_properties(env):
     g = job_clips_per_group(256)
     assert g == 2
     from amuse_amd.shard import job_decode_path
-    assert job_decode_path(256) == "fused" and job_decode_path(6) == "staged"
+    assert job_decode_path(256) == "clip" and job_decode_path(6) == "staged"   # ("clip" = the fused kernel in this mode; the fp32x mode's per-clip decoder)
     eng.set_clips_per_group(g)
     eng.set_decode_path(job_decode_path(256))   # the job's decode kernels, not the 6-clip launch's own choice
     try:

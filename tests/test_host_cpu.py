@@ -379,3 +379,13 @@ def test_bench_reports_pmc_traffic_only_for_the_kernel_that_was_counted(monkeypa
     monkeypatch.setattr(kid, "kernel_id", lambda name: {"source_sha256": "0" * 64})                     # no object at hand, other sources
     assert bench.pmc_traffic_bytes(256, 1000, "bf16")[0] is None
     assert bench.pmc_traffic_bytes(64, 1000, "bf16")[0] is None                                          # no pass at that shape
+
+
+def test_job_decode_path_rule():
+    """amuse_amd/shard.py job_decode_path / fusedx_rule (mirrors amuse_api.hip): staged below 64 clips, the fused / no-split-K kernels from 64, the fp32x per-clip decoder
+    ("clip") where the job's clips fill rounds of the chip's 256 CUs."""
+    from amuse_amd import shard
+    want = {1: "staged", 63: "staged", 64: "fused", 159: "fused", 160: "clip", 256: "clip", 257: "fused", 419: "fused", 420: "clip", 512: "clip", 513: "fused",
+            625: "fused", 626: "clip", 768: "clip", 831: "fused", 832: "clip", 1024: "clip", 1025: "fused", 1038: "clip", 4096: "clip"}
+    assert {n: shard.job_decode_path(n) for n in want} == want
+    assert all(shard.fusedx_rule(n) for n in range(1280, 4097, 7))          # from the sixth round on every count qualifies

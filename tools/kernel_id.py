@@ -10,7 +10,7 @@ from pathlib import Path
 
 CSRC = Path(__file__).resolve().parents[1] / "amuse_amd" / "csrc"
 SOURCES = {"k_sample8": ["k_sampler8.hip"], "k_sample8h": ["k_sampler8.hip", "k_sampler8h.hip"], "k_sample8x": ["k_sampler8x.hip"],
-           "k_sample": ["k_sampler.hip"], "k_vae_fused": ["k_vae_fused.hip"], "k_den_fused": ["k_den_fused.hip"], "k_vae_rows8x": ["k_vae_rows8.hip"]}
+           "k_sample": ["k_sampler.hip"], "k_vae_fused": ["k_vae_fused.hip"], "k_den_fused": ["k_den_fused.hip"], "k_vae_rows8x": ["k_vae_rows8.hip"], "k_vae_fusedx": ["k_vae_fusedx.hip"]}
 
 
 def _closure(files):
