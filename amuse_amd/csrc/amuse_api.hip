@@ -160,7 +160,7 @@ int build_denoiser(amuse_ctx* c, const float* den, int what = AMUSE_UPD_ALL) {
 
 int build_prior(amuse_ctx* c, const float* pri, int what = AMUSE_UPD_ALL) {
     static const ParamIndex PI = prior_index();
-    if (!g_capture) c->vae_c1_valid[0] = c->vae_c1_valid[1] = c->vae_c1_valid[2] = false;   // block 0's hoisted constant belongs to the old decoder weights
+    if (!g_capture) c->vae_c1_valid[0] = c->vae_c1_valid[1] = c->vae_c1_valid[2] = c->vae_c1_valid[3] = false;   // block 0's hoisted constant belongs to the old decoder weights
     const Params Pp{PI, pri};
     // ---- VAE decoder weight streams: [stage][wave][units]
     for (int prec = 0; prec < 4; ++prec) {
@@ -665,7 +665,7 @@ int amuse_update_weights_device(amuse_ctx* c, const float* denoiser_params_dev, 
     HIP_TRY(hipSetDevice(c->device));
     if (c->repack.empty())
         if (int e = build_repack_maps(c)) return e;
-    if (prior_params_dev) c->vae_c1_valid[0] = c->vae_c1_valid[1] = c->vae_c1_valid[2] = false;
+    if (prior_params_dev) c->vae_c1_valid[0] = c->vae_c1_valid[1] = c->vae_c1_valid[2] = c->vae_c1_valid[3] = false;
     for (const auto& r : c->repack) {
         const float* src = r.prior ? prior_params_dev : denoiser_params_dev;
         if (!src || !*r.slot) continue;                 // (an image the context never built, e.g. the 4-wave bf16 stream after an update)
@@ -691,7 +691,7 @@ void amuse_destroy(amuse_ctx* c) {
                     c->vae_w[0], c->vae_w[1], c->vae_w[2], c->vae_w[3], c->vae_w8x, c->vae_wfx, c->vaee_w8x, c->vaee_w[2], c->vaee_w[3], c->vae_pvec, c->vae_final_bias, c->vae_pe, c->vae_wv_t, c->vae_bv,
                     c->vae_wo_t, c->vae_bo, c->vaee_w[0], c->vaee_w[1], c->vaee_pvec, c->vaee_pe, c->vaee_tok,
                     c->vaee_emb_bias, c->d_timesteps, c->d_coef, c->d_time_tok, c->d_ts1, c->d_tt1, c->d_coef1,
-                    c->cond_tok, c->lat_tmp, c->fwd_ws, c->vae_ws, c->d_lengths, c->vae_wf, c->vae_skip, c->vae_ca_ws, c->vae_c1[0], c->vae_c1[1], c->vae_c1[2]};
+                    c->cond_tok, c->lat_tmp, c->fwd_ws, c->vae_ws, c->d_lengths, c->vae_wf, c->vae_skip, c->vae_ca_ws, c->vae_c1[0], c->vae_c1[1], c->vae_c1[2], c->vae_c1[3]};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     for (hipEvent_t e : c->vae_c1_ev)
@@ -976,7 +976,23 @@ int amuse_vae_decode(amuse_ctx* c, const float* z, const int* lengths, int B, in
         // the fp32x decode as ONE persistent workgroup per clip (k_vae_fusedx.hip) where the call's clips fill rounds of the chip (use_fusedx above; keyed by the CALL's clip
         // count like the other choices); its scratch arrays are this path's attn_o and skip
         if (use_fusedx(c, precision, B)) {
+            // block 0's self-attention half is one [300][128] constant per weight set for full-length clips (the decoder's queries are the positional table): computed
+            // once by THIS kernel on one clip (c1_out: the same instruction stream, the same bits), then every full-length clip starts behind norm1 and the kernel's
+            // weight stream behind block 0's sixteen attention stages.  Explicit lengths take the full path; AMUSE_VAE_HOIST=0 = off.
+            static const bool hoistx_on = [] { const char* e = getenv("AMUSE_VAE_HOIST"); return !(e && atoi(e) == 0); }();
+            const bool hoistx = hoistx_on && !lengths && !c->decode_tap;
+            if (hoistx && !c->vae_c1_valid[3]) {
+                if (!c->vae_c1[3]) HIP_TRY(hipMalloc((void**)&c->vae_c1[3], (size_t)kFrames * kD * sizeof(float)));
+                VaeFusedXArgs px{};
+                px.wstream = c->vae_wfx; px.pvec = c->vae_pvec; px.final_bias = c->vae_final_bias; px.pe = c->vae_pe; px.ca = ca;
+                px.skip = ra.skip; px.obuf = attn_o; px.B = 1; px.quat_mode = quat_mode; px.c1_out = c->vae_c1[3];
+                HIP_TRY(launch_vae_fusedx(px, st));
+                HIP_TRY(c1_produced(c, 3, st));
+                c->vae_c1_valid[3] = true;
+            }
+            if (hoistx) HIP_TRY(c1_consumed(c, 3, st));
             VaeFusedXArgs fx{};
+            fx.c1 = hoistx ? c->vae_c1[3] : nullptr;
             fx.wstream = c->vae_wfx; fx.pvec = c->vae_pvec; fx.final_bias = c->vae_final_bias; fx.pe = c->vae_pe; fx.ca = ca; fx.lengths = ra.lengths;
             fx.skip = ra.skip; fx.obuf = attn_o; fx.feats_out = ra.feats_out; fx.poses_out = ra.poses_out; fx.trans_out = ra.trans_out;
             fx.tap_out = b0 == 0 ? c->decode_tap : nullptr;

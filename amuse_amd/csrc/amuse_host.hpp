@@ -309,10 +309,10 @@ struct amuse_ctx {
     uint32_t vae_stage_units[4][kVaeStages];
     uint4* vae_wf = nullptr;           // bf16 stream of the fused decode kernel (k_vae_fused.hip)
     uint4* vae_wfh = nullptr;          // its fp16 twin (k_vae_fusedh.hip, AMUSE_PREC_F16)
-    float* vae_c1[3] = {nullptr, nullptr, nullptr};   // block 0's self-attention half of the fused decoder, bf16 | fp16 build: [300][128] (+ the tap scratch behind it); [2]: of the fp32x row stages
-    bool vae_c1_valid[3] = {false, false, false};   // (re)computed by the next fused decode after a weight change
-    hipEvent_t vae_c1_ev[3] = {nullptr, nullptr, nullptr};     // recorded behind the launches that produced vae_c1[i] ...
-    hipStream_t vae_c1_stream[3] = {nullptr, nullptr, nullptr}; // ... on this stream: a decode on ANOTHER stream waits on the event first
+    float* vae_c1[4] = {nullptr, nullptr, nullptr, nullptr};   // block 0's self-attention half of the fused decoder, bf16 | fp16 build: [300][128] (+ the tap scratch behind it); [2]: of the fp32x row stages
+    bool vae_c1_valid[4] = {false, false, false, false};   // (re)computed by the next fused decode after a weight change
+    hipEvent_t vae_c1_ev[4] = {nullptr, nullptr, nullptr, nullptr};     // recorded behind the launches that produced vae_c1[i] ...
+    hipStream_t vae_c1_stream[4] = {nullptr, nullptr, nullptr, nullptr}; // ... on this stream: a decode on ANOTHER stream waits on the event first
     uint4* vae_w8x = nullptr;          // fp32x row stages without split-K (k_vae_rows8.hip): one stream per stage, consumption order
     uint32_t vae_w8x_base[kVaeStages];
     uint4* vae_wfx = nullptr;          // fp32x fused decoder (k_vae_fusedx.hip): one stream of unit pairs for the whole network, consumption order

@@ -224,6 +224,8 @@ struct VaeFusedXArgs {
     float* poses_out;          // [B][300][55][3] or null
     float* trans_out;          // [B][300][3] or null
     float* tap_out;            // [10][300][128] or null: clip 0's fp32 residual stream after blocks 0..8 and after decoder.norm (tests)
+    const float* c1;           // [300][128] or null: norm1(PE + SA(PE)) of block 0 for this weight set (full-length clips start from it)
+    float* c1_out;             // [300][128] or null: clip 0 writes that array (behind block 0's norm1) - how the library obtains c1
     int B, quat_mode;
 };
 hipError_t launch_vae_fusedx(const VaeFusedXArgs& a, hipStream_t stream);

@@ -247,6 +247,22 @@ def test_block0_hoist_is_bitwise_and_follows_the_weights():
         fresh = HipEngine(wd, wp1, "cuda:0")
         fresh.set_decode_path("fused")
         assert torch.equal(a["feats"], fresh.vae_decode(z, None, "bf16", return_feats=True)["feats"])
+        # the fp32x mode's per-clip decoder (k_vae_fusedx.hip, "clip") has the same hoist: bitwise its full path (explicit lengths, the tapped launch), mixed batches,
+        # and recomputed for the new weights (eng has wp1 by now, like `fresh`)
+        for e in (eng, fresh):
+            e.set_decode_path("clip")
+        plain = eng.vae_decode(z, None, "fp32x", return_feats=True)                              # hoisted
+        full = eng.vae_decode(z, [300] * 5, "fp32x", return_feats=True)                          # explicit lengths: the full path
+        tapped = eng.vae_decode(z, None, "fp32x", return_feats=True, return_taps=True)
+        assert torch.equal(plain["feats"], full["feats"]) and torch.equal(plain["poses"], full["poses"]) and torch.equal(plain["feats"], tapped["feats"])
+        mixed = eng.vae_decode(z, [300, 173, 300, 1, 300], "fp32x", return_feats=True)
+        assert torch.equal(mixed["feats"][[0, 2, 4]], plain["feats"][[0, 2, 4]])
+        assert torch.equal(plain["feats"], fresh.vae_decode(z, None, "fp32x", return_feats=True)["feats"])
+        Wp1 = orc.to_torch(wp1)
+        ref = orc.vae_decode(Wp1, z, None)                                                        # fp32 oracle on the new weights
+        assert _err(plain["feats"], ref) < 2e-5
+        taps_ref = tapped["taps"][:10].cpu()
+        assert bool(torch.isfinite(taps_ref).all()) and float(taps_ref[9].abs().max()) > 0      # slots 0..8: after the blocks; 9: after decoder.norm
         fresh.close()
     finally:
         eng.close()
