@@ -30,9 +30,6 @@ static_assert(kXLdsBytes <= 160 * 1024, "LDS");
 #ifndef AMUSE_FX_ERF
 #define AMUSE_FX_ERF 2
 #endif
-#ifndef AMUSE_FX_OPROJ_DMA
-#define AMUSE_FX_OPROJ_DMA 1
-#endif
 #ifndef AMUSE_FX_FFN_PIPE
 #define AMUSE_FX_FFN_PIPE 1
 #endif
@@ -244,12 +241,25 @@ __device__ __forceinline__ void attend_x(const uint4* Kh, const uint4* Kl, const
 #endif
 }
 
-// MODE 0: input block (push the skip), 1: middle block, 2: output block (skip linear first)
-template <int NT, int MODE>
-__device__ __forceinline__ void decoder_block_x(f32x4 (&x)[NT][kTiles], Stager& sg, const VaeFusedXArgs& a, int blk, int tile0, int b, const float* pv, const float* pv_next_src,
-                                                unsigned pv_next_dst, const float* cal, char* smem, int len, int wave, int lane, const bool hoist = false) {
+// What a block half needs to know about its clip and launch comes from the kernel's argument block through these accessors (kept in the kernarg segment and re-read
+// where needed: as a struct of values they would sit in registers for the whole network).  The decoder (S = 300 rows per clip, a compile-time constant) and one step of
+// the pose-space Denoiser (S = 302..304) share the halves.
+template <class A> struct Geo;
+template <> struct Geo<VaeFusedXArgs> {
+    static __device__ __forceinline__ int S(const VaeFusedXArgs&) { return kFrames; }
+    static __device__ __forceinline__ float* tap(const VaeFusedXArgs& a) { return a.tap_out; }
+    static __device__ __forceinline__ const float* c1(const VaeFusedXArgs& a) { return a.c1; }
+    static __device__ __forceinline__ float* c1_out(const VaeFusedXArgs& a) { return a.c1_out; }
+};
+
+// The ATTENTION half of a block: (MODE 2: the skip linear in front of an output block,) q / k / v of each head from the residual registers, K / V images, attention, the
+// outputs to (a.obuf + row0 * kD).  The residual registers are not changed (MODE 2: replaced by the skip linear's result).  MODE 0: input block, 1: middle block, 2: output block.
+template <int NT, int MODE, class A>
+__device__ __forceinline__ void attn_half_x(f32x4 (&x)[NT][kTiles], Stager& sg, const A& a, int b, int blk, int tile0, const float* pv, const float* pv_next_src, unsigned pv_next_dst,
+                                            char* smem, int len, int wave, int lane) {
     const int g = lane >> 4, r = lane & 15;
-    const size_t nrows = (size_t)a.B * kFrames;
+    const int S = Geo<A>::S(a);
+    const size_t nrows = (size_t)a.B * S, row0 = (size_t)b * S;
     [[maybe_unused]] const bool prof_on = blockIdx.x == 0 && threadIdx.x == 0 && (blk == 1 || blk == 6);
     FSTAMP(1);   // block start
     char* kv = smem + kXOffKv;
@@ -282,8 +292,8 @@ __device__ __forceinline__ void decoder_block_x(f32x4 (&x)[NT][kTiles], Stager& 
 #pragma unroll
             for (int j = 0; j < NT; ++j) {
                 const int frame = 16 * (tile0 + 4 * j) + r;
-                const float* src = sk + ((size_t)b * kFrames + min(frame, kFrames - 1)) * kD + 32 * c + 4 * g;
-                const bool ok = frame < kFrames;
+                const float* src = sk + (row0 + min(frame, S - 1)) * kD + 32 * c + 4 * g;
+                const bool ok = frame < S;
                 xc[j] = split_f16(ok ? ld4(src) : splat4(0.f), ok ? ld4(src + 16) : splat4(0.f));
             }
             for_pairs(sg, [&](int o, f16x8 wh, f16x8 wl) {
@@ -294,24 +304,12 @@ __device__ __forceinline__ void decoder_block_x(f32x4 (&x)[NT][kTiles], Stager& 
         }
     }
     FSTAMP(2);   // skip linear done
-    // ---------------- self-attention (cross_attention.py:323-330): x = norm1(x + out_proj(softmax(q k^T) v))
-    if (hoist) {   // block 0 of a full-length clip: the result behind norm1 is the weight set's constant c1 (see the launcher's caller)
-        if (pv_next_src) {
-            const unsigned d = __builtin_amdgcn_readfirstlane(pv_next_dst + wave * 1024);
-            glds16(reinterpret_cast<const uint4*>(pv_next_src) + wave * 64 + lane, d);
-        }
-#pragma unroll
-        for (int j = 0; j < NT; ++j) {
-            const int frame = 16 * (tile0 + 4 * j) + r;
-#pragma unroll
-            for (int t = 0; t < kTiles; ++t) x[j][t] = frame < kFrames ? ld4(a.c1 + (size_t)frame * kD + 16 * t + 4 * g) : splat4(0.f);
-        }
-    } else {
+    {
         uint4* Kh = reinterpret_cast<uint4*>(kv);
         uint4* Kl = Kh + kKeyRows * 4;
         uint4* Vh = Kl + kKeyRows * 4;
         uint4* Vl = Vh + kPairs * 2 * 16 * 4;
-        float* obuf = a.obuf + (size_t)b * kFrames * kD;
+        float* obuf = (a.obuf + row0 * kD);
         constexpr float kScaling = 0.17677669529663687f, kLog2e = 1.44269504088896340736f;
 #pragma unroll 1
         for (int h = 0; h < kHeads; ++h) {
@@ -346,7 +344,7 @@ __device__ __forceinline__ void decoder_block_x(f32x4 (&x)[NT][kTiles], Stager& 
 #pragma unroll
                 for (int j = 0; j < NT; ++j) {
                     const int tile = tile0 + 4 * j;
-                    const bool ok = 16 * tile + r < kFrames;
+                    const bool ok = 16 * tile + r < S;
                     const F16Pair ks = split_f16(ok ? kk[j][0] : splat4(0.f), ok ? kk[j][1] : splat4(0.f));
                     Kh[tile * 64 + frag_slot(g, r)] = __builtin_bit_cast(uint4, ks.hi);
                     Kl[tile * 64 + frag_slot(g, r)] = __builtin_bit_cast(uint4, ks.lo);
@@ -355,7 +353,7 @@ __device__ __forceinline__ void decoder_block_x(f32x4 (&x)[NT][kTiles], Stager& 
                     for (int td = 0; td < 2; ++td) {
                         f32x4 v = vv[j][td];
 #pragma unroll
-                        for (int m = 0; m < 4; ++m) v[m] = (16 * tile + 4 * g + m < kFrames) ? v[m] : 0.f;
+                        for (int m = 0; m < 4; ++m) v[m] = (16 * tile + 4 * g + m < S) ? v[m] : 0.f;
                         const F16Pair vs = split_f16(v, v);   // (both halves the same four values: the low one is written)
                         const int slot = ((tile >> 1) * 2 + td) * 64 + frag_slot(g, r);
                         const uint4 hi4 = __builtin_bit_cast(uint4, vs.hi), lo4 = __builtin_bit_cast(uint4, vs.lo);
@@ -397,7 +395,7 @@ __device__ __forceinline__ void decoder_block_x(f32x4 (&x)[NT][kTiles], Stager& 
                 f32x4 o[2];
                 attend_x(Kh, Kl, Vh, Vl, qs[0], o, len, g, r);
                 const int frame = 16 * (tile0 + 4 * j) + r;
-                if (frame < kFrames) {
+                if (frame < S) {
                     float* dst = obuf + (size_t)frame * kD + 32 * h + 4 * g;
                     st4(dst, o[0]);
                     st4(dst + 16, o[1]);
@@ -411,40 +409,36 @@ __device__ __forceinline__ void decoder_block_x(f32x4 (&x)[NT][kTiles], Stager& 
             stage_end(sg);
             FSTAMP(8);   // barrier of stage B passed
         }
+    }
+}
+
+// The ROW half of a block: out_proj of the outputs in (a.obuf + row0 * kD) (brought back by counted LDS-DMA), norm1, (decoder layers: the cross-attention constant, norm2,) FFN, the last
+// norm, (MODE 0: the skip push).  ENCL: a TransformerEncoderLayer (cross_attention.py:259-272: two norms) instead of the decoder layer with its one-token memory.
+// hoist (decode, block 0 of a full-length clip): the result behind norm1 is the weight set's constant c1 - no out_proj, no norm1.
+template <int NT, int MODE, bool ENCL, class A>
+__device__ __forceinline__ void row_half_x(f32x4 (&x)[NT][kTiles], Stager& sg, const A& a, int blk, int tile0, int b, const float* pv, const float* cal, char* smem, int wave,
+                                           int lane, const bool hoist = false) {
+    const int g = lane >> 4, r = lane & 15;
+    const int S = Geo<A>::S(a);
+    const size_t nrows = (size_t)a.B * S, row0 = (size_t)b * S;
+    [[maybe_unused]] const bool prof_on = blockIdx.x == 0 && threadIdx.x == 0 && (blk == 1 || blk == 6);
+    char* kv = smem + kXOffKv;
+    Images<NT> im;
+    im.lds = kv + (wave & 3) * (2 * kParkTile) + lane * 16;
+    if (hoist) {
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            const int frame = 16 * (tile0 + 4 * j) + r;
+#pragma unroll
+            for (int t = 0; t < kTiles; ++t) x[j][t] = frame < S ? ld4(Geo<A>::c1(a) + (size_t)frame * kD + 16 * t + 4 * g) : splat4(0.f);
+        }
+    } else {
+        float* obuf = (a.obuf + row0 * kD);
         // ---- out_proj (four LDS stages, k-pair = head): the attention outputs come back from the scratch one k-pair ahead of their stage
 #pragma unroll
         for (int j = 0; j < NT; ++j)
 #pragma unroll
             for (int t = 0; t < kTiles; ++t) x[j][t] += ld4(pv + PV_OUT_B + 16 * t + 4 * g);
-#if !AMUSE_FX_OPROJ_DMA
-        {   // (A/B: plain loads one k-pair ahead)
-        f32x4 ob[NT][2];
-        auto load_o = [&](int c) {
-#pragma unroll
-            for (int j = 0; j < NT; ++j) {
-                const int frame = 16 * (tile0 + 4 * j) + r;
-                const float* src = obuf + (size_t)min(frame, kFrames - 1) * kD + 32 * c + 4 * g;
-                ob[j][0] = ld4(src);
-                ob[j][1] = ld4(src + 16);
-            }
-        };
-        load_o(0);
-#pragma unroll 1
-        for (int c = 0; c < 4; ++c) {
-            F16Pair xc[NT];
-#pragma unroll
-            for (int j = 0; j < NT; ++j) xc[j] = split_f16(ob[j][0], ob[j][1]);
-            if (c + 1 < 4) load_o(c + 1);
-            for_pairs(sg, [&](int o, f16x8 wh, f16x8 wl) {
-#pragma unroll
-                for (int j = 0; j < NT; ++j) x[j][o] = mfma3(wh, wl, xc[j], x[j][o]);
-            });
-            stage_end(sg);
-            FSTAMP(9);
-        }
-        }
-    }
-#else
         // Plain loads here would be waited for by every stage end (vmcnt retires in order and the stage protocol waits for all but the two newest operations): a full
         // L2 round trip per stage, 7 % of the block.  So the outputs come back by LDS-DMA into a wave-private double buffer in the (now dead) K / V image region - lane
         // (g, r) fetches the 16 bytes it would have loaded, one k-pair (head) = 2 NT pieces - issued BEHIND the stage's weight fetch and counted exactly.
@@ -452,7 +446,7 @@ __device__ __forceinline__ void decoder_block_x(f32x4 (&x)[NT][kTiles], Stager& 
         const char* obuf_l = smem + kXOffKv + (wave < 4 ? wave * 12288 : 49152 + (wave - 4) * 8192) + lane * 16;
         const float* osrc[NT];
 #pragma unroll
-        for (int j = 0; j < NT; ++j) osrc[j] = obuf + (size_t)min(16 * (tile0 + 4 * j) + r, kFrames - 1) * kD + 4 * g;
+        for (int j = 0; j < NT; ++j) osrc[j] = obuf + (size_t)min(16 * (tile0 + 4 * j) + r, S - 1) * kD + 4 * g;
         auto fetch_o = [&](int c) {
             const unsigned d = __builtin_amdgcn_readfirstlane(obase + (c & 1) * (NT * 2048));
 #pragma unroll
@@ -490,23 +484,24 @@ __device__ __forceinline__ void decoder_block_x(f32x4 (&x)[NT][kTiles], Stager& 
             FSTAMP(9);   // an out_proj stage
         }
     }
-#endif
     // ---------------- norm1, the one-token cross-attention (a per-clip constant), norm2  (cross_attention.py:331-337)
     {
         const float* ca = cal + blk * kD;
 #pragma unroll 1
         for (int j = 0; j < NT; ++j) {
             if (!hoist) layer_norm_rows<false>(x[0], pv + PV_LN1_W, pv + PV_LN1_B, g);
-            if (a.c1_out && blk == 0 && b == 0) {   // what the hoist loads: block 0 behind norm1 (one-clip launch of the library)
+            if (Geo<A>::c1_out(a) && blk == 0 && b == 0) {   // what the hoist loads: block 0 behind norm1 (one-clip launch of the library)
                 const int frame = 16 * (tile0 + 4 * j) + r;
-                if (frame < kFrames) {
+                if (frame < S) {
 #pragma unroll
-                    for (int t = 0; t < kTiles; ++t) st4(a.c1_out + (size_t)frame * kD + 16 * t + 4 * g, x[0][t]);
+                    for (int t = 0; t < kTiles; ++t) st4(Geo<A>::c1_out(a) + (size_t)frame * kD + 16 * t + 4 * g, x[0][t]);
                 }
             }
+            if constexpr (!ENCL) {
 #pragma unroll
-            for (int t = 0; t < kTiles; ++t) x[0][t] += ld4(ca + 16 * t + 4 * g);
-            layer_norm_rows<false>(x[0], pv + PV_LN2_W, pv + PV_LN2_B, g);
+                for (int t = 0; t < kTiles; ++t) x[0][t] += ld4(ca + 16 * t + 4 * g);
+                layer_norm_rows<false>(x[0], pv + PV_LN2_W, pv + PV_LN2_B, g);
+            }
             rotate_tiles<NT>(x);
         }
     }
@@ -582,7 +577,7 @@ __device__ __forceinline__ void decoder_block_x(f32x4 (&x)[NT][kTiles], Stager& 
     }
 #pragma unroll 1
     for (int j = 0; j < NT; ++j) {
-        layer_norm_rows<false>(x[0], pv + PV_LN3_W, pv + PV_LN3_B, g);
+        layer_norm_rows<false>(x[0], pv + (ENCL ? PV_LN2_W : PV_LN3_W), pv + (ENCL ? PV_LN2_B : PV_LN3_B), g);   // (an encoder layer's norm2)
         rotate_tiles<NT>(x);
     }
     FSTAMP(16);   // norm3
@@ -591,13 +586,13 @@ __device__ __forceinline__ void decoder_block_x(f32x4 (&x)[NT][kTiles], Stager& 
 #pragma unroll
         for (int j = 0; j < NT; ++j) {
             const int frame = 16 * (tile0 + 4 * j) + r;
-            if (frame < kFrames) {
+            if (frame < S) {
 #pragma unroll
-                for (int t = 0; t < kTiles; ++t) st4(sk + ((size_t)b * kFrames + frame) * kD + 16 * t + 4 * g, x[j][t]);
+                for (int t = 0; t < kTiles; ++t) st4(sk + (row0 + frame) * kD + 16 * t + 4 * g, x[j][t]);
             }
         }
     }
-    if (a.tap_out && b == 0) store_tap<NT>(a.tap_out, blk, x, tile0, g, r);
+    if (Geo<A>::tap(a) && b == 0) store_tap<NT>(Geo<A>::tap(a), blk, x, tile0, g, r);   // (decode only)
 }
 
 template <int NT>
@@ -614,15 +609,27 @@ __device__ __forceinline__ void decode_tiles_x(const VaeFusedXArgs& a, char* sme
         for (int t = 0; t < kTiles; ++t) x[j][t] = frame < kFrames ? ld4(a.pe + (size_t)frame * kD + 16 * t + 4 * g) : splat4(0.f);
     }
     asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)\n\ts_barrier" ::: "memory");   // parameters, constants and stage 0 are in
+    const bool hoist = a.c1 != nullptr && len == kFrames;
 #pragma unroll 1
-    for (int blk = 0; blk < 4; ++blk)
-        decoder_block_x<NT, 0>(x, sg, a, blk, tile0, b, pvl + (blk & 1) * (kPvSlot / 4), a.pvec + (blk + 1) * PV_BLOCK, lds0 + kXOffPv + ((blk + 1) & 1) * kPvSlot, cal, smem, len, wave, lane,
-                               blk == 0 && a.c1 != nullptr && len == kFrames);
-    decoder_block_x<NT, 1>(x, sg, a, 4, tile0, b, pvl, a.pvec + 5 * PV_BLOCK, lds0 + kXOffPv + kPvSlot, cal, smem, len, wave, lane);
+    for (int blk = 0; blk < 4; ++blk) {
+        const float* pv = pvl + (blk & 1) * (kPvSlot / 4);
+        const bool h0 = blk == 0 && hoist;
+        if (h0) {   // (the next block's small parameters: otherwise issued inside the head loop)
+            const unsigned d = __builtin_amdgcn_readfirstlane(lds0 + kXOffPv + kPvSlot + wave * 1024);
+            glds16(reinterpret_cast<const uint4*>(a.pvec + PV_BLOCK) + wave * 64 + lane, d);
+        } else {
+            attn_half_x<NT, 0>(x, sg, a, b, blk, tile0, pv, a.pvec + (blk + 1) * PV_BLOCK, lds0 + kXOffPv + ((blk + 1) & 1) * kPvSlot, smem, len, wave, lane);
+        }
+        row_half_x<NT, 0, false>(x, sg, a, blk, tile0, b, pv, cal, smem, wave, lane, h0);
+    }
+    attn_half_x<NT, 1>(x, sg, a, b, 4, tile0, pvl, a.pvec + 5 * PV_BLOCK, lds0 + kXOffPv + kPvSlot, smem, len, wave, lane);
+    row_half_x<NT, 1, false>(x, sg, a, 4, tile0, b, pvl, cal, smem, wave, lane);
 #pragma unroll 1
-    for (int blk = 5; blk < kLayers; ++blk)
-        decoder_block_x<NT, 2>(x, sg, a, blk, tile0, b, pvl + (blk & 1) * (kPvSlot / 4), blk + 1 < kLayers ? a.pvec + (blk + 1) * PV_BLOCK : nullptr,
-                               lds0 + kXOffPv + ((blk + 1) & 1) * kPvSlot, cal, smem, len, wave, lane);
+    for (int blk = 5; blk < kLayers; ++blk) {
+        const float* pv = pvl + (blk & 1) * (kPvSlot / 4);
+        attn_half_x<NT, 2>(x, sg, a, b, blk, tile0, pv, blk + 1 < kLayers ? a.pvec + (blk + 1) * PV_BLOCK : nullptr, lds0 + kXOffPv + ((blk + 1) & 1) * kPvSlot, smem, len, wave, lane);
+        row_half_x<NT, 2, false>(x, sg, a, blk, tile0, b, pv, cal, smem, wave, lane);
+    }
     // ---------------- decoder.norm -> final_layer (333 outputs in 24 tiles, four quarters of 6: three LDS stages each) -> rotation epilogue
 #pragma unroll 1
     for (int j = 0; j < NT; ++j) {
