@@ -455,11 +455,7 @@ bool use_rows8(const amuse_ctx* c, int precision, int B) {
 // clips fill rounds of the chip's 256 CUs - measured against the row / attention launches (profiles/r05_fusedx_decode.txt, ms at 160 / 256 / 384 / 512 / 768 / 1024 clips:
 // 1.49 1.65 3.05 3.18 4.76 6.32 against 1.67 1.86 2.84 3.88 5.81 7.75): from 160 clips in the first round, and in round r >= 2 when at least 164 - 50 (r - 2) clips are in it.
 // amuse_amd/shard.py fusedx_rule is the same function (a sharded job pins the whole job's choice: AMUSE_DECODE_CLIP).  AMUSE_VAE_FUSEDX=0 / 1: never / whenever rows8 would run.
-bool fusedx_rule(int B) {
-    if (B < 160) return false;
-    const int r = (B + 255) / 256, in_last = B - 256 * (r - 1);
-    return r == 1 || in_last >= 164 - 50 * (r - 2);
-}
+// (fusedx_rule itself: amuse_host.hpp - the pose-space Denoiser step uses it too)
 bool use_fusedx(const amuse_ctx* c, int precision, int B) {
     static const int env = [] { const char* e = getenv("AMUSE_VAE_FUSEDX"); return e ? atoi(e) : -1; }();
     if (precision != PREC_F16X2 || !c->vae_wfx) return false;

@@ -280,6 +280,14 @@ std::vector<float> transpose(const float* w, int rows, int cols) {  // [rows][co
 }  // namespace
 
 struct amuse_variant;   // the Denoiser variants' streams and tables (amuse_variants.hip)
+// Do the clips of a call fill rounds of the chip's 256 CUs well enough for the fp32x per-clip kernels (k_vae_fusedx.hip)?  From 160 clips in the first round, in round
+// r >= 2 with at least 164 - 50 (r - 2) clips in it (measured: amuse_api.hip use_fusedx; amuse_amd/shard.py fusedx_rule is the same function)
+inline bool fusedx_rule(int B) {
+    if (B < 160) return false;
+    const int r = (B + 255) / 256, in_last = B - 256 * (r - 1);
+    return r == 1 || in_last >= 164 - 50 * (r - 2);
+}
+
 struct amuse_ctx {
     int device = 0;
     int arch = AMUSE_ARCH_ENC;         // Denoiser variant (amuse_create_arch); anything but AMUSE_ARCH_ENC runs through `var`

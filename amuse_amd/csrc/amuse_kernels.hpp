@@ -229,6 +229,19 @@ struct VaeFusedXArgs {
     int B, quat_mode;
 };
 hipError_t launch_vae_fusedx(const VaeFusedXArgs& a, hipStream_t stream);
+// the blocks of one fp32x step of the pose-space Denoiser (diffusion_only + trans_enc) between the staged step's first and last row stage (k_vae_fusedx.hip k_den_fusedx):
+// per clip, for b = 0..7: the row half of encoder block b (out_proj of the outputs in obuf, norm1, FFN, norm2, skip push), then the attention half of block b + 1 (skip
+// linear in front of output blocks, q / k / v, attention, the outputs to obuf).  In: x = block 0's input, obuf = block 0's attention outputs (stage 0 + its attention
+// launch); out: x = block 8's input, obuf = block 8's attention outputs - what the staged stage 9 (block 8's row half, encoder.norm, pose_proj, the update) reads.
+struct DenFusedXArgs {
+    const uint4* wstream;      // unit pairs in consumption order, whole 16 KiB stages (amuse_variants.hip)
+    const float* pvec;         // the variant's small parameters, PV_* layout
+    float* x;                  // [B * S][128] residual stream
+    float* obuf;               // [B * S][128] attention outputs
+    float* skip;               // [4][B * S][128] fp32 skip stack
+    int B, S;                  // clips; rows per clip (302..304)
+};
+hipError_t launch_den_fusedx(const DenFusedXArgs& a, hipStream_t stream);
 // ---------------------------------------------------------------- fused pose-space denoiser step (k_den_fused.hip): one workgroup per clip
 struct DenFusedArgs {
     const uint4* wstream;      // 16-bit stream in consumption order, whole stages (amuse_variants.hip)

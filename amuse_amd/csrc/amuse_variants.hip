@@ -13,6 +13,7 @@ struct amuse_variant {
     uint32_t stage_units[4][kVaeStages];
     uint4* rows8_w = nullptr;                   // fp32x, diffusion_only + trans_enc: stages 1..8 for the row kernel without split-K (k_vae_rows8.hip, ENC form)
     uint32_t rows8_base[kVaeStages];
+    uint4* fusedx_w = nullptr;                  // fp32x, diffusion_only + trans_enc: the blocks between the first and the last row stage as ONE stream (k_vae_fusedx.hip k_den_fusedx)
     float* pvec = nullptr;           // PV_* (ENC_POSE) / PVX_* (trans_dec archs) layout
     float* m_pe = nullptr;           // mem_pos.pe [500][128]
     float *wkv_t = nullptr, *bkv = nullptr;       // trans_dec: cross-attention k / v projections [9][2][128 in][128 out], [9][2][128]
@@ -142,6 +143,7 @@ struct PoseStep {
     const float* cond_tok; const float* ckv; const int* lengths_dev;
     int ncond, step; uint64_t seed, clip0;
     bool rows8;   // fp32x staged step: stages 1..8 on k_vae_rows8x (decided from the CALL's clip count)
+    bool fusedx;  // ... or, where the call's clips fill rounds of the chip, stages 1..8 and their attention launches as ONE per-clip kernel (k_den_fusedx)
 };
 // the fused per-clip step kernel (16-bit modes, diffusion_only + trans_enc) occupies one CU per clip: it wins from about as many
 // clips as the fused decoder does (amuse_api.hip kFusedMinClips); below that the staged path's 19 workgroups per clip finish sooner.
@@ -159,6 +161,16 @@ bool use_den_fused(const amuse_ctx* c, int precision, int B) {
     const int force = c->decode_path == AMUSE_DECODE_STAGED ? 0 : (c->decode_path == AMUSE_DECODE_FUSED || c->decode_path == AMUSE_DECODE_CLIP) ? 1 : env;
     if (!is_op16(precision) || c->arch != AMUSE_ARCH_ENC_POSE || force == 0) return false;
     return force == 1 || B >= kDenFusedMinClips;
+}
+
+// ... and where the call's clips fill rounds of the chip, the per-clip kernel for the blocks between the first and the last stage (the decode's rule: amuse_host.hpp fusedx_rule;
+// AMUSE_DECODE_CLIP pins it, AMUSE_VAE_FUSEDX=0 / 1 overrides AUTO)
+bool use_den_fusedx(const amuse_ctx* c, int precision, int B) {
+    static const int env = [] { const char* e = getenv("AMUSE_VAE_FUSEDX"); return e ? atoi(e) : -1; }();
+    if (!use_den_rows8(c, precision, B) || !c->var->fusedx_w) return false;
+    if (c->decode_path == AMUSE_DECODE_CLIP) return true;
+    if (c->decode_path != AMUSE_DECODE_AUTO || env == 0) return false;
+    return env == 1 || fusedx_rule(B);
 }
 
 int pose_step(amuse_ctx* c, const PoseStep& p, int nb, int precision, bool fused, hipStream_t st) {
@@ -205,6 +217,17 @@ int pose_step(amuse_ctx* c, const PoseStep& p, int nb, int precision, bool fused
     if (p.rows8) {   // (fp32x, trans_enc: stages 1..8 are plain encoder-layer stages - the row kernel without split-K, as MotionPrior.encode's)
         r8.wstream = v->rows8_w;
         memcpy(r8.stage_base, v->rows8_base, sizeof(r8.stage_base));
+    }
+    if (p.rows8 && p.fusedx && v->fusedx_w) {   // stage 0 + its attention, the per-clip kernel for the blocks in between, stage 9
+        ra.stage = 0;
+        HIP_TRY(launch_vae_rows(ra, precision, mode, st));
+        HIP_TRY(launch_vae_attn(aa, precision, mode, st));
+        DenFusedXArgs fx{};
+        fx.wstream = v->fusedx_w; fx.pvec = v->pvec; fx.x = ra.x; fx.obuf = attn_o; fx.skip = ra.skip; fx.B = nb; fx.S = S;
+        HIP_TRY(launch_den_fusedx(fx, st));
+        ra.stage = kVaeStages - 1;
+        HIP_TRY(launch_vae_rows(ra, precision, mode, st));
+        return 0;
     }
     for (int stage = 0; stage < kVaeStages; ++stage) {
         ra.stage = stage;
@@ -312,6 +335,32 @@ int variant_build(amuse_ctx* c, const float* den, int what) {
             s.insert(s.end(), (size_t)2 * 16 * 64, uint4{0, 0, 0, 0});   // the fetch runs two stages ahead
             if (upload(&v->rows8_w, s.data(), s.size() * sizeof(uint4))) return AMUSE_EHIP;
         }
+        if (!dec && (what & AMUSE_UPD_F32X)) {   // fp32x: the same blocks as ONE stream for the per-clip kernel (k_den_fusedx): for b = 0..7 the row half of block b
+            // (out_proj, the FFN with linear1 one chunk ahead), then the attention half of block b + 1 (skip linear in front of output blocks; per head k | v, then q)
+            std::vector<uint4> s;
+            for (int b = 0; b < 8; ++b) {
+                const std::string p = blk_name("encoder", b);
+                pack_gemm(s, PREC_F16X2, D.get(p + ".self_attn.out_proj.weight"), 128, 128, range(0, 8), range(0, 8));
+                const auto f1 = [&](int ch) { pack_gemm(s, PREC_F16X2, D.get(p + ".linear1.weight"), 512, 128, {2 * ch, 2 * ch + 1}, range(0, 8)); };
+                const auto f2 = [&](int ch) { pack_gemm(s, PREC_F16X2, D.get(p + ".linear2.weight"), 128, 512, range(0, 8), {2 * ch, 2 * ch + 1}); };
+                f1(0);
+                for (int ch = 0; ch < 15; ++ch) { f1(ch + 1); f2(ch); }
+                f2(15);
+                if (b + 1 >= 5) {
+                    const float* wskip = D.get("encoder.linear_blocks." + std::to_string(b + 1 - 5) + ".weight");
+                    pack_gemm(s, PREC_F16X2, wskip, 128, 256, range(0, 8), range(0, 8));
+                    pack_gemm(s, PREC_F16X2, wskip, 128, 256, range(0, 8), range(8, 16));
+                }
+                const float* in_w = D.get(blk_name("encoder", b + 1) + ".self_attn.in_proj_weight");
+                for (int h = 0; h < 4; ++h) {
+                    pack_gemm(s, PREC_F16X2, in_w, 384, 128, {8 + 2 * h, 8 + 2 * h + 1, 16 + 2 * h, 16 + 2 * h + 1}, range(0, 8));
+                    pack_gemm(s, PREC_F16X2, in_w, 384, 128, {2 * h, 2 * h + 1}, range(0, 8));
+                }
+            }
+            if (s.size() % ((size_t)16 * 64) != 0) return fail(AMUSE_ESTATE, "internal: fused fp32x pose-denoiser stream is not whole stages");
+            s.insert(s.end(), (size_t)2 * 16 * 64, uint4{0, 0, 0, 0});   // the fetch runs two stages ahead
+            if (upload(&v->fusedx_w, s.data(), s.size() * sizeof(uint4))) return AMUSE_EHIP;
+        }
         if (!dec) {
             // fused step kernel (k_den_fused.hip; bf16 / fp16 operands): ONE stream for the eight waves, in consumption order, cut into
             // stages of kVaeFusedStageUnits units - the fused decoder's layout (amuse_api.hip) with pose_embd in front and encoder blocks
@@ -389,7 +438,7 @@ int variant_build(amuse_ctx* c, const float* den, int what) {
 void variant_destroy(amuse_ctx* c) {
     amuse_variant* v = c->var;
     if (!v) return;
-    void* ptrs[] = {v->dec_w[0], v->dec_w[1], v->dec_w[2], v->dec_w[3], v->rows_w[0], v->rows_w[1], v->rows_w[2], v->rows_w[3], v->rows8_w, v->pvec, v->m_pe,
+    void* ptrs[] = {v->dec_w[0], v->dec_w[1], v->dec_w[2], v->dec_w[3], v->rows_w[0], v->rows_w[1], v->rows_w[2], v->rows_w[3], v->rows8_w, v->fusedx_w, v->pvec, v->m_pe,
                     v->wkv_t, v->bkv, v->emb_bias, v->final_bias, v->tkv_sched, v->ckv, v->tkv1, v->ws, v->tt, v->fused_w[0], v->fused_w[1], v->skip};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
@@ -441,7 +490,7 @@ int variant_sample(amuse_ctx* c, const float* con, const float* emo, const float
             p.cond_tok = c->cond_tok + (size_t)b0 * ncond * kD;
             p.ckv = v->ckv ? v->ckv + (size_t)b0 * ncond * kTkv : nullptr;
             p.lengths_dev = nullptr;   // the sampling loop passes full lengths (infer_ldm.py:135)
-            p.ncond = ncond; p.step = step; p.seed = seed; p.clip0 = clip0 + (uint64_t)b0; p.rows8 = rows8;
+            p.ncond = ncond; p.step = step; p.seed = seed; p.clip0 = clip0 + (uint64_t)b0; p.rows8 = rows8; p.fusedx = use_den_fusedx(c, precision, B);
             if (int e = pose_step(c, p, nb, precision, fused, st)) return e;
         }
         if (traj_out) HIP_TRY(hipMemcpyAsync(traj_out + (size_t)step * B * sd, out, (size_t)B * sd * sizeof(float), hipMemcpyDeviceToDevice, st));
@@ -493,7 +542,7 @@ int variant_denoise(amuse_ctx* c, const float* x_t, const int* timesteps, bool p
         p.cond_tok = c->cond_tok + (size_t)b0 * ncond * kD;
         p.ckv = v->ckv ? v->ckv + (size_t)b0 * ncond * kTkv : nullptr;
         p.lengths_dev = lengths ? c->d_lengths + b0 : nullptr;
-        p.ncond = ncond; p.rows8 = rows8;
+        p.ncond = ncond; p.rows8 = rows8; p.fusedx = use_den_fusedx(c, precision, B);
         if (int e = pose_step(c, p, nb, precision, fused, st)) return e;
     }
     return 0;

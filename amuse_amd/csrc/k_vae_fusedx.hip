@@ -251,6 +251,12 @@ template <> struct Geo<VaeFusedXArgs> {
     static __device__ __forceinline__ const float* c1(const VaeFusedXArgs& a) { return a.c1; }
     static __device__ __forceinline__ float* c1_out(const VaeFusedXArgs& a) { return a.c1_out; }
 };
+template <> struct Geo<DenFusedXArgs> {
+    static __device__ __forceinline__ int S(const DenFusedXArgs& a) { return a.S; }
+    static __device__ __forceinline__ float* tap(const DenFusedXArgs&) { return nullptr; }
+    static __device__ __forceinline__ const float* c1(const DenFusedXArgs&) { return nullptr; }
+    static __device__ __forceinline__ float* c1_out(const DenFusedXArgs&) { return nullptr; }
+};
 
 // The ATTENTION half of a block: (MODE 2: the skip linear in front of an output block,) q / k / v of each head from the residual registers, K / V images, attention, the
 // outputs to (a.obuf + row0 * kD).  The residual registers are not changed (MODE 2: replaced by the skip linear's result).  MODE 0: input block, 1: middle block, 2: output block.
@@ -730,6 +736,67 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the two surplus fetches must not outlive the workgroup's LDS
 }
 
+// ---- the pose-space Denoiser's step (DenFusedXArgs, amuse_kernels.hpp): encoder blocks, S = 302..304 rows per clip, no key mask (denoiser.py:177-187)
+template <int NT>
+__device__ __forceinline__ void den_tiles_x(const DenFusedXArgs& a, char* smem, Stager& sg, int tile0, int b, int wave, int lane) {
+    const int g = lane >> 4, r = lane & 15;
+    const float* pvl = reinterpret_cast<const float*>(smem + kXOffPv);
+    const unsigned lds0 = lds_addr(smem);
+    const int S = a.S;
+    f32x4 x[NT][kTiles];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+        const int frame = 16 * (tile0 + 4 * j) + r;
+#pragma unroll
+        for (int t = 0; t < kTiles; ++t) x[j][t] = frame < S ? ld4(a.x + ((size_t)b * S + frame) * kD + 16 * t + 4 * g) : splat4(0.f);
+    }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");   // block 0's parameters and stages 0, 1 are in
+    auto next_params = [&](int blk) {   // block blk's small parameters -> LDS slot blk & 1 (free: block blk - 2's last reader is a barrier behind)
+        const unsigned d = __builtin_amdgcn_readfirstlane(lds0 + kXOffPv + (blk & 1) * kPvSlot + wave * 1024);
+        glds16(reinterpret_cast<const uint4*>(a.pvec + (size_t)blk * PV_BLOCK) + wave * 64 + lane, d);
+    };
+#pragma unroll 1
+    for (int blk = 0; blk < 4; ++blk) {   // row halves of the input blocks 0..3 (skip push), attention halves of blocks 1..4
+        next_params(blk + 1);
+        row_half_x<NT, 0, true>(x, sg, a, blk, tile0, b, pvl + (blk & 1) * (kPvSlot / 4), pvl, smem, wave, lane);
+        attn_half_x<NT, 0>(x, sg, a, b, blk + 1, tile0, pvl + ((blk + 1) & 1) * (kPvSlot / 4), nullptr, 0u, smem, S, wave, lane);
+    }
+#pragma unroll 1
+    for (int blk = 4; blk < kLayers - 1; ++blk) {   // row halves of blocks 4..7, attention halves (skip linear first) of the output blocks 5..8
+        next_params(blk + 1);
+        row_half_x<NT, 1, true>(x, sg, a, blk, tile0, b, pvl + (blk & 1) * (kPvSlot / 4), pvl, smem, wave, lane);
+        attn_half_x<NT, 2>(x, sg, a, b, blk + 1, tile0, pvl + ((blk + 1) & 1) * (kPvSlot / 4), nullptr, 0u, smem, S, wave, lane);
+    }
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+        const int frame = 16 * (tile0 + 4 * j) + r;
+        if (frame < S) {
+#pragma unroll
+            for (int t = 0; t < kTiles; ++t) st4(a.x + ((size_t)b * S + frame) * kD + 16 * t + 4 * g, x[j][t]);
+        }
+    }
+}
+
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_den_fusedx(DenFusedXArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int b = blockIdx.x;
+    const unsigned lds0 = lds_addr(smem);
+    glds16(reinterpret_cast<const uint4*>(a.pvec) + wave * 64 + lane, lds0 + kXOffPv + wave * 1024);   // block 0's parameters
+    Stager sg;
+    sg.src = a.wstream + (size_t)wave * 2 * 64 + lane;
+    sg.dst0 = lds0 + kXOffW + wave * 2048;
+    sg.ring = smem + kXOffW + lane * 16;
+    sg.widx = 0;
+    sg.ridx = 0;
+    stage_fetch(sg);
+    stage_fetch(sg);
+    if (wave < 4) den_tiles_x<3>(a, smem, sg, wave, b, wave, lane);
+    else den_tiles_x<2>(a, smem, sg, wave + 8, b, wave, lane);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the two surplus fetches must not outlive the workgroup's LDS
+}
+
 }  // namespace
 
 hipError_t launch_vae_fusedx(const VaeFusedXArgs& a, hipStream_t stream) {
@@ -760,6 +827,18 @@ hipError_t launch_vae_fusedx(const VaeFusedXArgs& a, hipStream_t stream) {
         }
     }
 #endif
+    return hipGetLastError();
+}
+
+hipError_t launch_den_fusedx(const DenFusedXArgs& a, hipStream_t stream) {
+    static DeviceOnce once;
+    int dev_;
+    if (!once.done(&dev_)) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_den_fusedx), hipFuncAttributeMaxDynamicSharedMemorySize, kXLdsBytes);
+        if (e != hipSuccess) return e;
+        once.set(dev_);
+    }
+    hipLaunchKernelGGL(k_den_fusedx, dim3(a.B), dim3(512), kXLdsBytes, stream, a);
     return hipGetLastError();
 }
 

@@ -97,6 +97,22 @@ def test_pose_step_fp32x_on_the_row_kernel_without_split_k(env, g):
         rep = lambda a: np.concatenate([a] * 24, 0)                      # 48+ clips: ten-wave workgroups across clip boundaries
         big = eng.denoise_step(rep(x), 501, rep(con), rep(emo), rep(sty), "fp32x")
         assert torch.equal(big[:n], e) and torch.equal(big[-n:], e)
+        # ... and with the blocks between the first and the last row stage on the per-clip kernel (k_vae_fusedx.hip k_den_fusedx; "clip" pins it, AUTO takes it where the
+        # clips fill rounds of the chip): the same goldens at the same bar, 4 / 3 / 2 prefix tokens, ragged lengths, a clip's bits independent of its launch
+        eng.set_decode_path("clip")
+        for t in (981, 501, 1):
+            assert _err(cut(eng.denoise_step(x, t, con, emo, sty, "fp32x"), True), g[f"{tag}/eps_t{t}"]) < 1e-5, t
+        ec = eng.denoise_step(x, 501, con, emo, sty, "fp32x")
+        assert not torch.equal(ec, e) and _err(ec, e) < 1e-5
+        assert _err(cut(eng.denoise_step(x, 501, con, None, sty, "fp32x"), True), g[f"{tag}/eps_t501_noemo"]) < 1e-5
+        assert _err(cut(eng.denoise_step(x, 501, con, None, None, "fp32x"), True), g[f"{tag}/eps_t501_consolo"]) < 1e-5
+        assert _err(cut(eng.denoise_step(x, 501, con, emo, sty, "fp32x", lengths=lens), True), g[f"{tag}/eps_t501_ragged"]) < 1e-5
+        rep2 = lambda a: np.concatenate([a] * 130, 0)                    # 260+ clips: a second round of workgroups
+        big = eng.denoise_step(rep2(x), 501, rep2(con), rep2(emo), rep2(sty), "fp32x")
+        assert torch.equal(big[:n], ec) and torch.equal(big[-n:], ec)
+        eng.set_decode_path("auto")                                      # AUTO at 256 clips = the per-clip kernel
+        auto = eng.denoise_step(rep2(x)[:256], 501, rep2(con)[:256], rep2(emo)[:256], rep2(sty)[:256], "fp32x")
+        assert torch.equal(auto[:n], ec)
     finally:
         eng.set_decode_path("auto")
 
