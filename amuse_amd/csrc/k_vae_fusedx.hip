@@ -26,7 +26,8 @@ constexpr int kXOffPv = kXOffW + kWBufs * kStageBytes;
 constexpr int kXOffCa = kXOffPv + 2 * kPvSlot;
 constexpr int kXLdsBytes = kXOffCa + kCaBytes;           // 152,576 B
 static_assert(kXLdsBytes <= 160 * 1024, "LDS");
-// erf of the FFN activation: 0 = libm erff (the staged kernels' form), 2 = the branch-free fit of the fp32x sampler (amuse_dev.hpp erf_bf: max |error| 7.9e-8)
+// erf of the FFN activation: 0 = libm erff (the staged kernels' form), 1 = Abramowitz-Stegun 7.1.26 on the hardware rcp / exp2 (gelu_erf_fast: |erf error| <= 1.5e-7),
+// 2 = the branch-free fit of the fp32x sampler (amuse_dev.hpp erf_bf: max |error| 7.9e-8)
 #ifndef AMUSE_FX_ERF
 #define AMUSE_FX_ERF 2
 #endif
@@ -544,7 +545,7 @@ __device__ __forceinline__ void row_half_x(f32x4 (&x)[NT][kTiles], Stager& sg, c
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
-                for (int m = 0; m < 4; ++m) hid[j][i][m] = AMUSE_FX_ERF == 2 ? gelu_erf_bf(hid[j][i][m]) : gelu_erf(hid[j][i][m]);
+                for (int m = 0; m < 4; ++m) hid[j][i][m] = AMUSE_FX_ERF == 2 ? gelu_erf_bf(hid[j][i][m]) : AMUSE_FX_ERF == 1 ? gelu_erf_fast(hid[j][i][m]) : gelu_erf(hid[j][i][m]);
             hs[j] = split_f16(hid[j][0], hid[j][1]);
         }
     };

@@ -49,6 +49,8 @@ hipError_t launch_vae_fused(const VaeFusedArgs&, hipStream_t) { return hipSucces
 hipError_t launch_vae_fusedh(const VaeFusedArgs&, hipStream_t) { return hipSuccess; }
 hipError_t launch_den_fused(const DenFusedArgs&, hipStream_t) { return hipSuccess; }
 hipError_t launch_den_fusedh(const DenFusedArgs&, hipStream_t) { return hipSuccess; }
+hipError_t launch_vae_fusedx(const VaeFusedXArgs&, hipStream_t) { return hipSuccess; }
+hipError_t launch_den_fusedx(const DenFusedXArgs&, hipStream_t) { return hipSuccess; }
 hipError_t launch_sample_dec(const SampleDecArgs&, int, hipStream_t) { return hipSuccess; }
 hipError_t launch_mem_kv(const float*, int, const float*, const float*, float*, hipStream_t) { return hipSuccess; }
 hipError_t launch_feats_to_smplx(const float*, size_t, int, float*, float*, hipStream_t) { return hipSuccess; }

@@ -79,7 +79,8 @@ int main(int argc, char** argv) {
     REQUIRE(amuse_sample(c, cond.data(), nullptr, nullptr, 0, AMUSE_PREC_BF16, 0, 0, nullptr, nullptr, lat.data(), nullptr, nullptr) != 0);
     REQUIRE(amuse_sample(c, cond.data(), nullptr, nullptr, 1, 9, 0, 0, nullptr, nullptr, lat.data(), nullptr, nullptr) != 0);
     REQUIRE(amuse_set_clips_per_group(c, 6) != 0);
-    REQUIRE(amuse_set_decode_path(c, 3) != 0);
+    REQUIRE(amuse_set_decode_path(c, 4) != 0);
+    REQUIRE(amuse_set_decode_path(c, AMUSE_DECODE_CLIP) == 0 && amuse_set_decode_path(c, AMUSE_DECODE_AUTO) == 0);
     REQUIRE(amuse_vae_encode(c, feats.data(), nullptr, 1, AMUSE_PREC_F32, nullptr, nullptr, nullptr, nullptr, nullptr) != 0);
     // re-packing in place: every subset of streams, either array alone
     fill(den, 3, 0.1f);
