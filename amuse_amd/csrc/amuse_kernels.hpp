@@ -229,17 +229,29 @@ struct VaeFusedXArgs {
     int B, quat_mode;
 };
 hipError_t launch_vae_fusedx(const VaeFusedXArgs& a, hipStream_t stream);
-// the blocks of one fp32x step of the pose-space Denoiser (diffusion_only + trans_enc) between the staged step's first and last row stage (k_vae_fusedx.hip k_den_fusedx):
-// per clip, for b = 0..7: the row half of encoder block b (out_proj of the outputs in obuf, norm1, FFN, norm2, skip push), then the attention half of block b + 1 (skip
-// linear in front of output blocks, q / k / v, attention, the outputs to obuf).  In: x = block 0's input, obuf = block 0's attention outputs (stage 0 + its attention
-// launch); out: x = block 8's input, obuf = block 8's attention outputs - what the staged stage 9 (block 8's row half, encoder.norm, pose_proj, the update) reads.
+// one fp32x step of the pose-space Denoiser (diffusion_only + trans_enc; denoiser.py:177-187) as ONE persistent workgroup per clip (k_vae_fusedx.hip k_den_fusedx): pose_embd
+// of x_t, the condition tokens in front, nine encoder blocks (the decode kernel's two block halves with an encoder layer), encoder.norm, pose_proj, the mask, eps_hat and -
+// with coefficients - the scheduler update of x_t in the parity modes' arithmetic (k_vae.hip's last stage).  Scratch: the staged step's attn_o and skip arrays.
 struct DenFusedXArgs {
     const uint4* wstream;      // unit pairs in consumption order, whole 16 KiB stages (amuse_variants.hip)
     const float* pvec;         // the variant's small parameters, PV_* layout
-    float* x;                  // [B * S][128] residual stream
-    float* obuf;               // [B * S][128] attention outputs
+    const float* emb_bias;     // pose_embd.bias [128]
+    const float* final_bias;   // pose_proj.bias padded to [384]
+    const float* pe;           // query_pos.pe [500][128]
+    const float* ttok;         // time token + pe[0]: [128] (ttok_stride 0) or per clip [B][128]
+    size_t ttok_stride;
+    const float* ctok;         // [B][npre - 1][128] condition tokens + pe[1..]
+    const float* x_in;         // [B][300][333] x_t
+    float* x_out;              // [B][300][333] or null: x_{t-1} (may alias x_in)
+    float* eps_out;            // [B][300][333] or null
+    const float* coef;         // dev [8]: this step's scheduler row, or null (teacher-forced step: no update)
+    const float* step_noise;   // [B][300][333] this step's explicit noise, or null -> counter-based
+    const int* lengths;        // dev [B] or null: eps rows of frames >= lengths[b] are zeroed (denoiser.py:187)
+    float* obuf;               // [B * S][128] attention outputs of the current block
     float* skip;               // [4][B * S][128] fp32 skip stack
-    int B, S;                  // clips; rows per clip (302..304)
+    unsigned long long seed, clip0;
+    int step;
+    int B, S, npre;            // clips; rows per clip = npre + 300; condition-token rows in front of the frames (2..4)
 };
 hipError_t launch_den_fusedx(const DenFusedXArgs& a, hipStream_t stream);
 // ---------------------------------------------------------------- fused pose-space denoiser step (k_den_fused.hip): one workgroup per clip

@@ -13,7 +13,7 @@ struct amuse_variant {
     uint32_t stage_units[4][kVaeStages];
     uint4* rows8_w = nullptr;                   // fp32x, diffusion_only + trans_enc: stages 1..8 for the row kernel without split-K (k_vae_rows8.hip, ENC form)
     uint32_t rows8_base[kVaeStages];
-    uint4* fusedx_w = nullptr;                  // fp32x, diffusion_only + trans_enc: the blocks between the first and the last row stage as ONE stream (k_vae_fusedx.hip k_den_fusedx)
+    uint4* fusedx_w = nullptr;                  // fp32x, diffusion_only + trans_enc: the whole step as ONE stream for the per-clip kernel (k_vae_fusedx.hip k_den_fusedx)
     float* pvec = nullptr;           // PV_* (ENC_POSE) / PVX_* (trans_dec archs) layout
     float* m_pe = nullptr;           // mem_pos.pe [500][128]
     float *wkv_t = nullptr, *bkv = nullptr;       // trans_dec: cross-attention k / v projections [9][2][128 in][128 out], [9][2][128]
@@ -143,7 +143,7 @@ struct PoseStep {
     const float* cond_tok; const float* ckv; const int* lengths_dev;
     int ncond, step; uint64_t seed, clip0;
     bool rows8;   // fp32x staged step: stages 1..8 on k_vae_rows8x (decided from the CALL's clip count)
-    bool fusedx;  // ... or, where the call's clips fill rounds of the chip, stages 1..8 and their attention launches as ONE per-clip kernel (k_den_fusedx)
+    bool fusedx;  // ... or, where the call's clips fill rounds of the chip, the whole step as ONE per-clip kernel (k_den_fusedx)
 };
 // the fused per-clip step kernel (16-bit modes, diffusion_only + trans_enc) occupies one CU per clip: it wins from about as many
 // clips as the fused decoder does (amuse_api.hip kFusedMinClips); below that the staged path's 19 workgroups per clip finish sooner.
@@ -218,15 +218,13 @@ int pose_step(amuse_ctx* c, const PoseStep& p, int nb, int precision, bool fused
         r8.wstream = v->rows8_w;
         memcpy(r8.stage_base, v->rows8_base, sizeof(r8.stage_base));
     }
-    if (p.rows8 && p.fusedx && v->fusedx_w) {   // stage 0 + its attention, the per-clip kernel for the blocks in between, stage 9
-        ra.stage = 0;
-        HIP_TRY(launch_vae_rows(ra, precision, mode, st));
-        HIP_TRY(launch_vae_attn(aa, precision, mode, st));
+    if (p.rows8 && p.fusedx && v->fusedx_w) {   // the whole step as one persistent workgroup per clip (its scratch: this path's attn_o and skip arrays)
         DenFusedXArgs fx{};
-        fx.wstream = v->fusedx_w; fx.pvec = v->pvec; fx.x = ra.x; fx.obuf = attn_o; fx.skip = ra.skip; fx.B = nb; fx.S = S;
+        fx.wstream = v->fusedx_w; fx.pvec = v->pvec; fx.emb_bias = v->emb_bias; fx.final_bias = v->final_bias; fx.pe = c->den_pe;
+        fx.ttok = p.ttok; fx.ttok_stride = p.ttok_stride; fx.ctok = p.cond_tok;
+        fx.x_in = p.x_in; fx.x_out = p.x_out; fx.eps_out = p.eps_out; fx.coef = p.coef; fx.step_noise = p.step_noise; fx.lengths = p.lengths_dev;
+        fx.obuf = attn_o; fx.skip = ra.skip; fx.seed = p.seed; fx.clip0 = p.clip0; fx.step = p.step; fx.B = nb; fx.S = S; fx.npre = npre;
         HIP_TRY(launch_den_fusedx(fx, st));
-        ra.stage = kVaeStages - 1;
-        HIP_TRY(launch_vae_rows(ra, precision, mode, st));
         return 0;
     }
     for (int stage = 0; stage < kVaeStages; ++stage) {
@@ -335,28 +333,31 @@ int variant_build(amuse_ctx* c, const float* den, int what) {
             s.insert(s.end(), (size_t)2 * 16 * 64, uint4{0, 0, 0, 0});   // the fetch runs two stages ahead
             if (upload(&v->rows8_w, s.data(), s.size() * sizeof(uint4))) return AMUSE_EHIP;
         }
-        if (!dec && (what & AMUSE_UPD_F32X)) {   // fp32x: the same blocks as ONE stream for the per-clip kernel (k_den_fusedx): for b = 0..7 the row half of block b
-            // (out_proj, the FFN with linear1 one chunk ahead), then the attention half of block b + 1 (skip linear in front of output blocks; per head k | v, then q)
+        if (!dec && (what & AMUSE_UPD_F32X)) {   // fp32x: the whole step as ONE stream of unit pairs for the per-clip kernel (k_vae_fusedx.hip k_den_fusedx): pose_embd (11 k-pairs x 8
+            // output tiles), nine encoder blocks in the fused fp32x decoder's order (amuse_api.hip: skip linear, per head k | v then q, out_proj, the FFN with linear1 one chunk
+            // ahead), pose_proj in four quarters of six output tiles
             std::vector<uint4> s;
-            for (int b = 0; b < 8; ++b) {
+            pack_gemm(s, PREC_F16X2, D.get("pose_embd.weight"), 128, kFeats, range(0, 8), range(0, 22));
+            for (int b = 0; b < 9; ++b) {
                 const std::string p = blk_name("encoder", b);
+                if (b >= 5) {
+                    const float* wskip = D.get("encoder.linear_blocks." + std::to_string(b - 5) + ".weight");
+                    pack_gemm(s, PREC_F16X2, wskip, 128, 256, range(0, 8), range(0, 8));
+                    pack_gemm(s, PREC_F16X2, wskip, 128, 256, range(0, 8), range(8, 16));
+                }
+                const float* in_w = D.get(p + ".self_attn.in_proj_weight");
+                for (int h = 0; h < 4; ++h) {
+                    pack_gemm(s, PREC_F16X2, in_w, 384, 128, {8 + 2 * h, 8 + 2 * h + 1, 16 + 2 * h, 16 + 2 * h + 1}, range(0, 8));
+                    pack_gemm(s, PREC_F16X2, in_w, 384, 128, {2 * h, 2 * h + 1}, range(0, 8));
+                }
                 pack_gemm(s, PREC_F16X2, D.get(p + ".self_attn.out_proj.weight"), 128, 128, range(0, 8), range(0, 8));
                 const auto f1 = [&](int ch) { pack_gemm(s, PREC_F16X2, D.get(p + ".linear1.weight"), 512, 128, {2 * ch, 2 * ch + 1}, range(0, 8)); };
                 const auto f2 = [&](int ch) { pack_gemm(s, PREC_F16X2, D.get(p + ".linear2.weight"), 128, 512, range(0, 8), {2 * ch, 2 * ch + 1}); };
                 f1(0);
                 for (int ch = 0; ch < 15; ++ch) { f1(ch + 1); f2(ch); }
                 f2(15);
-                if (b + 1 >= 5) {
-                    const float* wskip = D.get("encoder.linear_blocks." + std::to_string(b + 1 - 5) + ".weight");
-                    pack_gemm(s, PREC_F16X2, wskip, 128, 256, range(0, 8), range(0, 8));
-                    pack_gemm(s, PREC_F16X2, wskip, 128, 256, range(0, 8), range(8, 16));
-                }
-                const float* in_w = D.get(blk_name("encoder", b + 1) + ".self_attn.in_proj_weight");
-                for (int h = 0; h < 4; ++h) {
-                    pack_gemm(s, PREC_F16X2, in_w, 384, 128, {8 + 2 * h, 8 + 2 * h + 1, 16 + 2 * h, 16 + 2 * h + 1}, range(0, 8));
-                    pack_gemm(s, PREC_F16X2, in_w, 384, 128, {2 * h, 2 * h + 1}, range(0, 8));
-                }
             }
+            for (int q = 0; q < 4; ++q) pack_gemm(s, PREC_F16X2, D.get("pose_proj.weight"), kFeats, 128, range(6 * q, 6 * q + 6), range(0, 8));
             if (s.size() % ((size_t)16 * 64) != 0) return fail(AMUSE_ESTATE, "internal: fused fp32x pose-denoiser stream is not whole stages");
             s.insert(s.end(), (size_t)2 * 16 * 64, uint4{0, 0, 0, 0});   // the fetch runs two stages ahead
             if (upload(&v->fusedx_w, s.data(), s.size() * sizeof(uint4))) return AMUSE_EHIP;

@@ -737,43 +737,162 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the two surplus fetches must not outlive the workgroup's LDS
 }
 
-// ---- the pose-space Denoiser's step (DenFusedXArgs, amuse_kernels.hpp): encoder blocks, S = 302..304 rows per clip, no key mask (denoiser.py:177-187)
+// ---- one step of the pose-space Denoiser (DenFusedXArgs, amuse_kernels.hpp): encoder blocks, S = 302..304 rows per clip, no key mask (denoiser.py:177-187)
+// x_t rows are 1332 B apart, so a lane's four-float groups are only 4-byte aligned: unaligned dwordx4 loads (global memory takes them); the k-pair that reaches past
+// feature 332 is read element-wise under the bound.
+typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
+template <int NT>
+__device__ __forceinline__ void load_xt_pair(f32x4 (&v)[NT][2], const float* xb, int tile0, int r, int g, int npre, int c) {
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+        const int fi = 16 * (tile0 + 4 * j) + r - npre;
+        const bool fv = fi >= 0 && fi < kFrames;
+        const float* row = xb + (size_t)(fv ? fi : 0) * kFeats + 4 * g;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {   // features 32 c + 16 h + 4 g + m
+            const int f = 32 * c + 16 * h;
+            f32x4 t;
+            if (f + 15 < kFeats) {
+                t = *reinterpret_cast<const f32x4u*>(row + f);
+            } else {
+#pragma unroll
+                for (int m = 0; m < 4; ++m) t[m] = (f + 4 * g + m < kFeats) ? row[f + m] : 0.f;
+            }
+            v[j][h] = fv ? t : splat4(0.f);
+        }
+    }
+}
+
 template <int NT>
 __device__ __forceinline__ void den_tiles_x(const DenFusedXArgs& a, char* smem, Stager& sg, int tile0, int b, int wave, int lane) {
     const int g = lane >> 4, r = lane & 15;
     const float* pvl = reinterpret_cast<const float*>(smem + kXOffPv);
     const unsigned lds0 = lds_addr(smem);
-    const int S = a.S;
+    const int S = a.S, npre = a.npre;
+    const float* xin = a.x_in + (size_t)b * kFrames * kFeats;
+    // ---------------- pose_embd (denoiser.py:178): eleven stages of one k-pair x eight output tiles, the operands a stage ahead
     f32x4 x[NT][kTiles];
 #pragma unroll
-    for (int j = 0; j < NT; ++j) {
-        const int frame = 16 * (tile0 + 4 * j) + r;
+    for (int j = 0; j < NT; ++j)
 #pragma unroll
-        for (int t = 0; t < kTiles; ++t) x[j][t] = frame < S ? ld4(a.x + ((size_t)b * S + frame) * kD + 16 * t + 4 * g) : splat4(0.f);
-    }
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");   // block 0's parameters and stages 0, 1 are in
-    auto next_params = [&](int blk) {   // block blk's small parameters -> LDS slot blk & 1 (free: block blk - 2's last reader is a barrier behind)
-        const unsigned d = __builtin_amdgcn_readfirstlane(lds0 + kXOffPv + (blk & 1) * kPvSlot + wave * 1024);
-        glds16(reinterpret_cast<const uint4*>(a.pvec + (size_t)blk * PV_BLOCK) + wave * 64 + lane, d);
-    };
+        for (int t = 0; t < kTiles; ++t) x[j][t] = ld4(a.emb_bias + 16 * t + 4 * g);
+    f32x4 cur[NT][2];
+    load_xt_pair<NT>(cur, xin, tile0, r, g, npre, 0);
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");   // block 0's parameters and weight stages 0, 1 are in
 #pragma unroll 1
-    for (int blk = 0; blk < 4; ++blk) {   // row halves of the input blocks 0..3 (skip push), attention halves of blocks 1..4
-        next_params(blk + 1);
-        row_half_x<NT, 0, true>(x, sg, a, blk, tile0, b, pvl + (blk & 1) * (kPvSlot / 4), pvl, smem, wave, lane);
-        attn_half_x<NT, 0>(x, sg, a, b, blk + 1, tile0, pvl + ((blk + 1) & 1) * (kPvSlot / 4), nullptr, 0u, smem, S, wave, lane);
+    for (int c = 0; c < 11; ++c) {
+        F16Pair xc[NT];
+#pragma unroll
+        for (int j = 0; j < NT; ++j) xc[j] = split_f16(cur[j][0], cur[j][1]);
+        if (c + 1 < 11) load_xt_pair<NT>(cur, xin, tile0, r, g, npre, c + 1);
+        for_pairs(sg, [&](int o, f16x8 wh, f16x8 wl) {
+#pragma unroll
+            for (int j = 0; j < NT; ++j) x[j][o] = mfma3(wh, wl, xc[j], x[j][o]);
+        });
+        stage_end(sg);
     }
-#pragma unroll 1
-    for (int blk = 4; blk < kLayers - 1; ++blk) {   // row halves of blocks 4..7, attention halves (skip linear first) of the output blocks 5..8
-        next_params(blk + 1);
-        row_half_x<NT, 1, true>(x, sg, a, blk, tile0, b, pvl + (blk & 1) * (kPvSlot / 4), pvl, smem, wave, lane);
-        attn_half_x<NT, 2>(x, sg, a, b, blk + 1, tile0, pvl + ((blk + 1) & 1) * (kPvSlot / 4), nullptr, 0u, smem, S, wave, lane);
-    }
+    // xseq = cat(emb_latent, pose_embd(sample)) + query_pos (denoiser.py:180-181); the tokens arrive with their positions added
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
         const int frame = 16 * (tile0 + 4 * j) + r;
-        if (frame < S) {
+        const float* pt = frame == 0 ? a.ttok + (size_t)b * a.ttok_stride : a.ctok + ((size_t)b * (npre - 1) + (frame < npre ? frame - 1 : 0)) * kD;
 #pragma unroll
-            for (int t = 0; t < kTiles; ++t) st4(a.x + ((size_t)b * S + frame) * kD + 16 * t + 4 * g, x[j][t]);
+        for (int t = 0; t < kTiles; ++t) {
+            const int c = 16 * t + 4 * g;
+            x[j][t] = frame >= S ? splat4(0.f) : (frame < npre ? ld4(pt + c) : x[j][t] + ld4(a.pe + (size_t)frame * kD + c));
+        }
+    }
+#pragma unroll 1
+    for (int blk = 0; blk < 4; ++blk) {
+        const float* pv = pvl + (blk & 1) * (kPvSlot / 4);
+        attn_half_x<NT, 0>(x, sg, a, b, blk, tile0, pv, a.pvec + (blk + 1) * PV_BLOCK, lds0 + kXOffPv + ((blk + 1) & 1) * kPvSlot, smem, S, wave, lane);
+        row_half_x<NT, 0, true>(x, sg, a, blk, tile0, b, pv, pvl, smem, wave, lane);
+    }
+    attn_half_x<NT, 1>(x, sg, a, b, 4, tile0, pvl, a.pvec + 5 * PV_BLOCK, lds0 + kXOffPv + kPvSlot, smem, S, wave, lane);
+    row_half_x<NT, 1, true>(x, sg, a, 4, tile0, b, pvl, pvl, smem, wave, lane);
+#pragma unroll 1
+    for (int blk = 5; blk < kLayers; ++blk) {
+        const float* pv = pvl + (blk & 1) * (kPvSlot / 4);
+        attn_half_x<NT, 2>(x, sg, a, b, blk, tile0, pv, blk + 1 < kLayers ? a.pvec + (blk + 1) * PV_BLOCK : nullptr, lds0 + kXOffPv + ((blk + 1) & 1) * kPvSlot, smem, S, wave, lane);
+        row_half_x<NT, 2, true>(x, sg, a, blk, tile0, b, pv, pvl, smem, wave, lane);
+    }
+    // ---------------- encoder.norm -> pose_proj (333 outputs in 24 tiles, four quarters of 6: three LDS stages each) -> mask -> eps_hat / scheduler update (k_vae.hip's last
+    // stage: the parity modes' arithmetic - exact division, no contraction), every element read and written by the wave that owns its row tile (x_out may alias x_in)
+#pragma unroll 1
+    for (int j = 0; j < NT; ++j) {
+        layer_norm_rows<false>(x[0], a.pvec + PV_FINAL_W, a.pvec + PV_FINAL_B, g);
+        rotate_tiles<NT>(x);
+    }
+    F16Pair xs[NT][4];
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) xs[j][c] = split_f16(x[j][2 * c], x[j][2 * c + 1]);
+    float* fst = reinterpret_cast<float*>(smem + kXOffKv) + wave * 16 * kQStride;   // one staging tile per wave (the K / V images are dead)
+    const int len = (a.lengths ? a.lengths[b] : kFrames) + npre;
+    const float* cf = a.coef;
+    const float sb = cf ? cf[0] : 0.f, sa = cf ? cf[1] : 1.f, c0 = cf ? cf[2] : 0.f, cxx = cf ? cf[3] : 0.f, ce = cf ? cf[4] : 0.f, sgm = cf ? cf[5] : 0.f, clipv = cf ? cf[6] : 0.f;
+    const float* nz = a.step_noise ? a.step_noise + (size_t)b * kFrames * kFeats : nullptr;
+    float* eo = a.eps_out ? a.eps_out + (size_t)b * kFrames * kFeats : nullptr;
+    float* xo = (cf && a.x_out) ? a.x_out + (size_t)b * kFrames * kFeats : nullptr;
+#pragma unroll 1
+    for (int quarter = 0; quarter < 4; ++quarter) {
+        f32x4 f[NT][6];
+#pragma unroll
+        for (int o = 0; o < 6; ++o) {
+            const f32x4 bi = ld4(a.final_bias + 16 * (6 * quarter + o) + 4 * g);
+#pragma unroll
+            for (int j = 0; j < NT; ++j) f[j][o] = bi;
+        }
+#pragma unroll
+        for (int s3 = 0; s3 < 3; ++s3) {
+            for_pairs(sg, [&](int i, f16x8 wh, f16x8 wl) {
+                const int lin = 8 * s3 + i, c = lin / 6, o = lin - 6 * c;
+#pragma unroll
+                for (int j = 0; j < NT; ++j) f[j][o] = mfma3(wh, wl, xs[j][c], f[j][o]);
+            });
+            stage_end(sg);
+        }
+        const int f0 = 96 * quarter, nfe = quarter == 3 ? kFeats - 288 : 96;
+#pragma unroll 1
+        for (int j = 0; j < NT; ++j) {   // one tile at a time through the wave's staging tile (wave-private: no barrier); the tiles rotate through slot 0
+            const int tile = tile0 + 4 * j;
+            const int frame = 16 * tile + r;
+            const bool keep = frame < S && frame < len;          // sample[~mask.T] = 0 (denoiser.py:187)
+            const int rows_here = min(16, S - 16 * tile);          // <= 0 for a tile beyond the sequence
+#pragma unroll
+            for (int o = 0; o < 6; ++o) st4(fst + r * kQStride + 16 * o + 4 * g, keep ? f[0][o] : splat4(0.f));
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            for (int i = lane; i < rows_here * nfe; i += 64) {
+                const int rr = i / nfe, c = i - rr * nfe, fr = 16 * tile + rr - npre;
+                if (fr < 0) continue;                              // (a condition-token row: its output is dropped, denoiser.py:184)
+                const float e = fst[rr * kQStride + c];
+                const size_t el = (size_t)fr * kFeats + f0 + c;
+                if (eo) eo[el] = e;
+                if (xo) {
+#pragma clang fp contract(off)
+                    const float xl = xin[el];
+                    const float num = __fsub_rn(xl, __fmul_rn(sb, e));
+                    float x0 = __fdiv_rn(num, sa);
+                    if (clipv > 0.f) x0 = fminf(fmaxf(x0, -clipv), clipv);
+                    float nx = __fmul_rn(c0, x0);
+                    if (cxx != 0.f) nx = __fadd_rn(nx, __fmul_rn(cxx, xl));
+                    if (ce != 0.f) nx = __fadd_rn(nx, __fmul_rn(ce, e));
+                    if (sgm != 0.f) {
+                        const float z = nz ? nz[el] : counter_normal4(a.seed, a.clip0 + (uint64_t)b, (uint32_t)a.step, (uint32_t)(el >> 2), 1u)[el & 3];
+                        nx = __fadd_rn(nx, __fmul_rn(sgm, z));
+                    }
+                    xo[el] = nx;
+                }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int o = 0; o < 6; ++o) {
+                const f32x4 first = f[0][o];
+#pragma unroll
+                for (int jj = 0; jj + 1 < NT; ++jj) f[jj][o] = f[jj + 1][o];
+                f[NT - 1][o] = first;
+            }
         }
     }
 }

@@ -239,7 +239,7 @@ def diffusion_only_extra(dev, precision, peak):
                 j["attention"] = {"ms_per_step": round(att, 4), "tflops": round(B * flop_attn / (att * 1e-3) / 1e12, 1),
                                   "frac_of_mfma_peak": round(B * flop_attn / (att * 1e-3) / 1e12 / peak, 4),
                                   "method": "step kernel minus its no-attention instantiation (amuse_debug_set_ablation), HIP events"}
-            if B == 256 and precision != "fp32x":   # the parity mode's step at the same shape: DDIM-10, per step (stage 0 + the per-clip kernel for the blocks + the last stage)
+            if B == 256 and precision != "fp32x":   # the parity mode's step at the same shape: DDIM-10, per step (k_den_fusedx)
                 eng.set_schedule(sch.ddim_table(10))
                 ts = []
                 for i in range(3):
@@ -251,7 +251,7 @@ def diffusion_only_extra(dev, precision, peak):
                         ts.append(ev0.elapsed_time(ev1) / 10)
                 eng.set_schedule(sch.ddim_table())
                 j["fp32x_ms_per_step"] = round(min(ts), 4)
-                j["fp32x_kernels"] = "pose_embd stage + attention, k_den_fusedx (blocks 0..8 between them, one workgroup per clip), pose_proj + update stage"
+                j["fp32x_kernels"] = "k_den_fusedx: the whole step as one persistent workgroup per clip (pose_embd, nine encoder blocks, pose_proj + scheduler update)"
             out["jobs"].append(j)
     finally:
         eng.close()

@@ -202,6 +202,35 @@ def test_variant_ddpm_in_kernel_noise_shards_and_restatement(env, prec):
         assert _err(expl[:nb], ref) < 2e-4 * float(ref.abs().max())
 
 
+def test_pose_step_fp32x_per_clip_kernel_samples_like_the_launches(env):
+    """diffusion_only + trans_enc, fp32x, the whole step on the per-clip kernel (k_den_fusedx; "clip" pins it): the scheduler update inside it - DDIM with clipping off / on the
+    schedule's terms, and ancestral DDPM with in-kernel counter noise - against the row / attention launches ("fused" pins them) on the same clips: x_0 within 1e-4; in-kernel
+    noise == the same noise passed explicitly, bitwise; a job cut into shards (clip_index0) == the job in one launch, bitwise; ragged lengths through denoise_step."""
+    if env["arch"] != "trans_enc" or not env["pose"]:
+        pytest.skip("the diffusion_only + trans_enc variant")
+    from amuse_amd import scheduler as sch
+    eng = env["eng"]
+    B = 5
+    gq = torch.Generator().manual_seed(13)
+    con, emo, sty = (torch.randn(B, 256, generator=gq) for _ in range(3))
+    try:
+        for table in (sch.ddim_table(6), sch.ddpm_table(4)):
+            eng.set_schedule(table)
+            eng.set_decode_path("fused")
+            want = eng.sample(con, emo, sty, "fp32x", seed=77, clip_index0=40)
+            eng.set_decode_path("clip")
+            got = eng.sample(con, emo, sty, "fp32x", seed=77, clip_index0=40)
+            assert bool(torch.isfinite(got).all()) and _err(got, want) < 1e-4 * max(1.0, float(want.abs().max())) and not torch.equal(got, want)
+            parts = [eng.sample(con[a:b], emo[a:b], sty[a:b], "fp32x", seed=77, clip_index0=40 + a) for a, b in ((0, 2), (2, 5))]
+            assert torch.equal(torch.cat(parts), got)
+        T = 4
+        x0 = eng.counter_normal(77, 40, B, 0, 0)
+        nz = torch.stack([eng.counter_normal(77, 40, B, s, 1) for s in range(T)])
+        assert torch.equal(eng.sample(con, emo, sty, "fp32x", x_init=x0, step_noise=nz), got)     # (the DDPM-4 run above)
+    finally:
+        eng.set_decode_path("auto")
+
+
 def test_pose_variant_diffusion_backward_converts_the_sampled_features(env):
     """diffusion_only: no VAE decode (infer_ldm.py:165) - the sampled [300][333] state goes through 6D -> axis-angle (:168-173)."""
     from amuse_amd import scheduler as sch
