@@ -27,9 +27,15 @@ constexpr int kXOffCa = kXOffPv + 2 * kPvSlot;
 constexpr int kXLdsBytes = kXOffCa + kCaBytes;           // 152,576 B
 static_assert(kXLdsBytes <= 160 * 1024, "LDS");
 // erf of the FFN activation: 0 = libm erff (the staged kernels' form), 1 = Abramowitz-Stegun 7.1.26 on the hardware rcp / exp2 (gelu_erf_fast: |erf error| <= 1.5e-7),
-// 2 = the branch-free fit of the fp32x sampler (amuse_dev.hpp erf_bf: max |error| 7.9e-8)
+// 2 = the branch-free fit of the fp32x sampler (amuse_dev.hpp erf_bf: max |error| 7.9e-8).  All three time the same (1.65 ms per 256-clip decode); the two Horner chains
+// of erf_bf on pairs of values (v_pk_fma_f32) - same bits - are 1 % slower; without any erf the decode takes 1.54 instead of 1.76 ms (no hoist): 0.22 ms of exposed VALU time
 #ifndef AMUSE_FX_ERF
 #define AMUSE_FX_ERF 2
+#endif
+// timing ablations (variant builds only; wrong numerics): 1 = no erf in the FFN activation, 2 = no MFMAs in the FFN (fragment reads, stage protocol and GELU stay),
+// 4 = no softmax arithmetic in the attention (scores fed to PV as they are), 8 = no attention at all (q, k, v, images, barriers stay)
+#ifndef AMUSE_FX_ABL
+#define AMUSE_FX_ABL 0
 #endif
 #ifndef AMUSE_FX_FFN_PIPE
 #define AMUSE_FX_FFN_PIPE 1
@@ -400,7 +406,8 @@ __device__ __forceinline__ void attn_half_x(f32x4 (&x)[NT][kTiles], Stager& sg, 
 #pragma unroll 1
             for (int j = 0; j < NT; ++j) {   // runtime loop: the attention's only copy in the instruction stream; the tiles rotate through slot 0
                 f32x4 o[2];
-                attend_x(Kh, Kl, Vh, Vl, qs[0], o, len, g, r);
+                if constexpr ((AMUSE_FX_ABL & 8) != 0) { o[0] = __builtin_bit_cast(f32x4, qs[0].hi); o[1] = __builtin_bit_cast(f32x4, qs[0].lo); }
+                else attend_x(Kh, Kl, Vh, Vl, qs[0], o, len, g, r);
                 const int frame = 16 * (tile0 + 4 * j) + r;
                 if (frame < S) {
                     float* dst = obuf + (size_t)frame * kD + 32 * h + 4 * g;
@@ -536,7 +543,10 @@ __device__ __forceinline__ void row_half_x(f32x4 (&x)[NT][kTiles], Stager& sg, c
                 for (int j = 0; j < NT; ++j) xc[j] = im.get(j, c);
             }
 #pragma unroll
-            for (int j = 0; j < NT; ++j) acc[j][o] = mfma3(wh, wl, xc[j], acc[j][o]);
+            for (int j = 0; j < NT; ++j) {
+                if constexpr ((AMUSE_FX_ABL & 2) != 0) acc[j][o] += __builtin_bit_cast(f32x4, wh + xc[j].hi);
+                else acc[j][o] = mfma3(wh, wl, xc[j], acc[j][o]);
+            }
         });
     };
     auto gelu_split = [&](F16Pair (&hs)[NT]) {
@@ -545,7 +555,7 @@ __device__ __forceinline__ void row_half_x(f32x4 (&x)[NT][kTiles], Stager& sg, c
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
-                for (int m = 0; m < 4; ++m) hid[j][i][m] = AMUSE_FX_ERF == 2 ? gelu_erf_bf(hid[j][i][m]) : AMUSE_FX_ERF == 1 ? gelu_erf_fast(hid[j][i][m]) : gelu_erf(hid[j][i][m]);
+                for (int m = 0; m < 4; ++m) hid[j][i][m] = (AMUSE_FX_ABL & 1) ? 0.5f * hid[j][i][m] : AMUSE_FX_ERF == 2 ? gelu_erf_bf(hid[j][i][m]) : AMUSE_FX_ERF == 1 ? gelu_erf_fast(hid[j][i][m]) : gelu_erf(hid[j][i][m]);
             hs[j] = split_f16(hid[j][0], hid[j][1]);
         }
     };
@@ -576,7 +586,10 @@ __device__ __forceinline__ void row_half_x(f32x4 (&x)[NT][kTiles], Stager& sg, c
         }
         for_pairs(sg, [&](int o, f16x8 wh, f16x8 wl) {
 #pragma unroll
-            for (int j = 0; j < NT; ++j) x[j][o] = mfma3(wh, wl, hs[j], x[j][o]);
+            for (int j = 0; j < NT; ++j) {
+                if constexpr ((AMUSE_FX_ABL & 2) != 0) x[j][o] += __builtin_bit_cast(f32x4, wh + hs[j].hi);
+                else x[j][o] = mfma3(wh, wl, hs[j], x[j][o]);
+            }
         });
         FSTAMP(14);   // linear2 of the chunk
         stage_end(sg);
