@@ -349,6 +349,33 @@ int build_prior(amuse_ctx* c, const float* pri, int what = AMUSE_UPD_ALL) {
         s.insert(s.end(), (size_t)2 * 16 * 64, uint4{0, 0, 0, 0});   // the fetch runs two stages ahead
         if (upload(&c->vaee_w8x, s.data(), s.size() * sizeof(uint4))) return AMUSE_EHIP;
     }
+    if ((what & AMUSE_UPD_F32X) && (what & AMUSE_UPD_ENCODER)) {   // encode as one persistent workgroup per clip (k_vae_fusedx.hip k_den_fusedx<encode>): skel_embedding, then
+        // the nine encoder blocks in the fused fp32x decoder's order
+        std::vector<uint4> s;
+        pack_gemm(s, PREC_F16X2, Pp.get("skel_embedding.weight"), 128, kFeats, range(0, 8), range(0, 22));
+        for (int b = 0; b < 9; ++b) {
+            const std::string p = blk_name("encoder", b);
+            if (b >= 5) {
+                const float* wskip = Pp.get("encoder.linear_blocks." + std::to_string(b - 5) + ".weight");
+                pack_gemm(s, PREC_F16X2, wskip, 128, 256, range(0, 8), range(0, 8));
+                pack_gemm(s, PREC_F16X2, wskip, 128, 256, range(0, 8), range(8, 16));
+            }
+            const float* in_w = Pp.get(p + ".self_attn.in_proj_weight");
+            for (int h = 0; h < 4; ++h) {
+                pack_gemm(s, PREC_F16X2, in_w, 384, 128, {8 + 2 * h, 8 + 2 * h + 1, 16 + 2 * h, 16 + 2 * h + 1}, range(0, 8));
+                pack_gemm(s, PREC_F16X2, in_w, 384, 128, {2 * h, 2 * h + 1}, range(0, 8));
+            }
+            pack_gemm(s, PREC_F16X2, Pp.get(p + ".self_attn.out_proj.weight"), 128, 128, range(0, 8), range(0, 8));
+            const auto f1 = [&](int ch) { pack_gemm(s, PREC_F16X2, Pp.get(p + ".linear1.weight"), 512, 128, {2 * ch, 2 * ch + 1}, range(0, 8)); };
+            const auto f2 = [&](int ch) { pack_gemm(s, PREC_F16X2, Pp.get(p + ".linear2.weight"), 128, 512, range(0, 8), {2 * ch, 2 * ch + 1}); };
+            f1(0);
+            for (int ch = 0; ch < 15; ++ch) { f1(ch + 1); f2(ch); }
+            f2(15);
+        }
+        if (s.size() % ((size_t)16 * 64) != 0) return fail(AMUSE_ESTATE, "internal: fused fp32x encoder stream is not whole stages");
+        s.insert(s.end(), (size_t)2 * 16 * 64, uint4{0, 0, 0, 0});   // the fetch runs two stages ahead
+        if (upload(&c->vaee_wfx, s.data(), s.size() * sizeof(uint4))) return AMUSE_EHIP;
+    }
     {
         auto pv = build_pvec(Pp, "encoder", false);
         if (upload(&c->vaee_pvec, pv.data(), pv.size() * 4) ||
@@ -586,7 +613,7 @@ int build_repack_maps(amuse_ctx* c) {
     // element type of an image: 0 = fp32, 1 = bf16, 2 = split-fp16, 3 = fp16 (launch_repack's `kind`)
     auto kind_of = [&](void** slot) {
         if (slot == (void**)&c->den_w[PREC_F16X2] || slot == (void**)&c->den_w8x || slot == (void**)&c->vae_w[PREC_F16X2] ||
-            slot == (void**)&c->vaee_w[PREC_F16X2] || slot == (void**)&c->vae_w8x || slot == (void**)&c->vaee_w8x || slot == (void**)&c->vae_wfx) return 2;
+            slot == (void**)&c->vaee_w[PREC_F16X2] || slot == (void**)&c->vae_w8x || slot == (void**)&c->vaee_w8x || slot == (void**)&c->vae_wfx || slot == (void**)&c->vaee_wfx) return 2;
         if (slot == (void**)&c->den_w8h || slot == (void**)&c->vae_wfh || slot == (void**)&c->vae_w[PREC_F16] || slot == (void**)&c->vaee_w[PREC_F16]) return 3;
         return (slot == (void**)&c->den_w[PREC_BF16] || slot == (void**)&c->den_w8 || slot == (void**)&c->vae_w[PREC_BF16] ||
                 slot == (void**)&c->vae_wf || slot == (void**)&c->vaee_w[PREC_BF16]) ? 1 : 0;
@@ -637,7 +664,7 @@ int build_repack_maps(amuse_ctx* c) {
         int cls = 0;   // which AMUSE_UPD_* bits the image needs; 0 = small parameters, always replaced
         if (slot == (void**)&c->den_w[PREC_F32] || slot == (void**)&c->vae_w[PREC_F32]) cls = AMUSE_UPD_F32;
         else if (slot == (void**)&c->den_w[PREC_F16X2] || slot == (void**)&c->den_w8x || slot == (void**)&c->vae_w[PREC_F16X2] || slot == (void**)&c->vae_w8x || slot == (void**)&c->vae_wfx) cls = AMUSE_UPD_F32X;
-        else if (slot == (void**)&c->vaee_w[PREC_F16X2] || slot == (void**)&c->vaee_w8x) cls = AMUSE_UPD_F32X | AMUSE_UPD_ENCODER;
+        else if (slot == (void**)&c->vaee_w[PREC_F16X2] || slot == (void**)&c->vaee_w8x || slot == (void**)&c->vaee_wfx) cls = AMUSE_UPD_F32X | AMUSE_UPD_ENCODER;
         else if (slot == (void**)&c->den_w8h || slot == (void**)&c->vae_wfh || slot == (void**)&c->vae_w[PREC_F16]) cls = AMUSE_UPD_F16;
         else if (slot == (void**)&c->vaee_w[PREC_F16]) cls = AMUSE_UPD_F16 | AMUSE_UPD_ENCODER;
         else if (slot == (void**)&c->den_w[PREC_BF16] || slot == (void**)&c->den_w8 || slot == (void**)&c->vae_w[PREC_BF16] || slot == (void**)&c->vae_wf) cls = AMUSE_UPD_BF16;
@@ -684,7 +711,7 @@ void amuse_destroy(amuse_ctx* c) {
         if (p) (void)hipFree(p);
     void* ptrs[] = {c->den_w[0], c->den_w[1], c->den_w[2], c->den_w8, c->den_w8h, c->den_w8x, c->vae_wfh, c->den_pvec, c->den_pe, c->den_freqs, c->te_w1t, c->te_b1, c->te_w2t,
                     c->te_b2, c->cond_wt[0], c->cond_wt[1], c->cond_wt[2], c->cond_b[0], c->cond_b[1], c->cond_b[2],
-                    c->vae_w[0], c->vae_w[1], c->vae_w[2], c->vae_w[3], c->vae_w8x, c->vae_wfx, c->vaee_w8x, c->vaee_w[2], c->vaee_w[3], c->vae_pvec, c->vae_final_bias, c->vae_pe, c->vae_wv_t, c->vae_bv,
+                    c->vae_w[0], c->vae_w[1], c->vae_w[2], c->vae_w[3], c->vae_w8x, c->vae_wfx, c->vaee_w8x, c->vaee_wfx, c->vaee_w[2], c->vaee_w[3], c->vae_pvec, c->vae_final_bias, c->vae_pe, c->vae_wv_t, c->vae_bv,
                     c->vae_wo_t, c->vae_bo, c->vaee_w[0], c->vaee_w[1], c->vaee_pvec, c->vaee_pe, c->vaee_tok,
                     c->vaee_emb_bias, c->d_timesteps, c->d_coef, c->d_time_tok, c->d_ts1, c->d_tt1, c->d_coef1,
                     c->cond_tok, c->lat_tmp, c->fwd_ws, c->vae_ws, c->d_lengths, c->vae_wf, c->vae_skip, c->vae_ca_ws, c->vae_c1[0], c->vae_c1[1], c->vae_c1[2], c->vae_c1[3]};
@@ -1070,6 +1097,16 @@ int amuse_vae_encode(amuse_ctx* c, const float* feats, const int* lengths, int B
         aa.q = ra.q; aa.k = ra.k; aa.v = ra.v; aa.lengths = ra.lengths; aa.o = attn_o; aa.B = nb;
         // fp32x from kFusedMinClips clips of the call (or as amuse_set_decode_path pins it - the decode's rule): stages 1..9 on the row kernel without split-K
         const bool rows8 = use_rows8(c, precision, B) && c->vaee_w8x != nullptr;
+        if (rows8 && c->vaee_wfx && use_fusedx(c, precision, B)) {   // (the decode's rule and pins) the whole encoder as one persistent workgroup per clip
+            DenFusedXArgs fx{};
+            fx.wstream = c->vaee_wfx; fx.pvec = c->vaee_pvec; fx.emb_bias = c->vaee_emb_bias; fx.pe = c->vaee_pe; fx.ttok = c->vaee_tok;
+            fx.x_in = ra.enc_feats; fx.eps_out = ra.stats_out; fx.lengths = ra.lengths; fx.obuf = attn_o; fx.skip = ra.skip;
+            fx.B = nb; fx.S = kEncRows; fx.npre = 2; fx.encode = 1;
+            HIP_TRY(launch_den_fusedx(fx, st));
+            const size_t o = (size_t)b0 * kD;
+            HIP_TRY(launch_vae_latent(ra.stats_out, eps ? eps + o : nullptr, mu_out ? mu_out + o : nullptr, std_out ? std_out + o : nullptr, latent_out ? latent_out + o : nullptr, nb, st));
+            continue;
+        }
         VaeRowsArgs r8 = ra;
         if (rows8) {
             r8.wstream = c->vaee_w8x;

@@ -323,6 +323,7 @@ struct amuse_ctx {
     hipStream_t vae_c1_stream[4] = {nullptr, nullptr, nullptr, nullptr}; // ... on this stream: a decode on ANOTHER stream waits on the event first
     uint4* vae_w8x = nullptr;          // fp32x row stages without split-K (k_vae_rows8.hip): one stream per stage, consumption order
     uint32_t vae_w8x_base[kVaeStages];
+    uint4* vaee_wfx = nullptr;         // fp32x encoder as one per-clip kernel (k_vae_fusedx.hip k_den_fusedx<encode>): one stream for the whole network
     uint4* vae_wfx = nullptr;          // fp32x fused decoder (k_vae_fusedx.hip): one stream of unit pairs for the whole network, consumption order
     uint4* vaee_w8x = nullptr;         // the same for MotionPrior.encode's stages 1..9 (AMUSE_UPD_ENCODER | AMUSE_UPD_F32X)
     uint32_t vaee_w8x_base[kVaeStages];

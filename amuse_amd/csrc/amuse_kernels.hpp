@@ -252,6 +252,9 @@ struct DenFusedXArgs {
     unsigned long long seed, clip0;
     int step;
     int B, S, npre;            // clips; rows per clip = npre + 300; condition-token rows in front of the frames (2..4)
+    // MotionPrior.encode on the same kernel (vae.py:154-214; encode = 1): x_in = motion features, emb_bias = skel_embedding.bias, pe = query_pos_encoder.pe, ttok = the two
+    // distribution tokens [2][128] (positions added here), npre = 2, S = 302, lengths = key mask over the frames, eps_out = [B][2][128] encoder.norm of the token rows; no pose_proj
+    int encode;
 };
 hipError_t launch_den_fusedx(const DenFusedXArgs& a, hipStream_t stream);
 // ---------------------------------------------------------------- fused pose-space denoiser step (k_den_fused.hip): one workgroup per clip

@@ -776,7 +776,8 @@ __device__ __forceinline__ void load_xt_pair(f32x4 (&v)[NT][2], const float* xb,
     }
 }
 
-template <int NT>
+// ENCM: MotionPrior.encode instead of a Denoiser step (DenFusedXArgs: encode)
+template <int NT, bool ENCM>
 __device__ __forceinline__ void den_tiles_x(const DenFusedXArgs& a, char* smem, Stager& sg, int tile0, int b, int wave, int lane) {
     const int g = lane >> 4, r = lane & 15;
     const float* pvl = reinterpret_cast<const float*>(smem + kXOffPv);
@@ -808,26 +809,47 @@ __device__ __forceinline__ void den_tiles_x(const DenFusedXArgs& a, char* smem, 
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
         const int frame = 16 * (tile0 + 4 * j) + r;
-        const float* pt = frame == 0 ? a.ttok + (size_t)b * a.ttok_stride : a.ctok + ((size_t)b * (npre - 1) + (frame < npre ? frame - 1 : 0)) * kD;
+        if constexpr (ENCM) {   // xseq = cat(global_motion_token, skel_embedding(features)) + query_pos_encoder.pe[:302]  (vae.py:171-188)
 #pragma unroll
-        for (int t = 0; t < kTiles; ++t) {
-            const int c = 16 * t + 4 * g;
-            x[j][t] = frame >= S ? splat4(0.f) : (frame < npre ? ld4(pt + c) : x[j][t] + ld4(a.pe + (size_t)frame * kD + c));
+            for (int t = 0; t < kTiles; ++t) {
+                const int c = 16 * t + 4 * g;
+                const f32x4 e = frame < npre ? ld4(a.ttok + (frame & 1) * kD + c) : x[j][t];
+                x[j][t] = frame < S ? e + ld4(a.pe + (size_t)frame * kD + c) : splat4(0.f);
+            }
+        } else {
+            const float* pt = frame == 0 ? a.ttok + (size_t)b * a.ttok_stride : a.ctok + ((size_t)b * (npre - 1) + (frame < npre ? frame - 1 : 0)) * kD;
+#pragma unroll
+            for (int t = 0; t < kTiles; ++t) {
+                const int c = 16 * t + 4 * g;
+                x[j][t] = frame >= S ? splat4(0.f) : (frame < npre ? ld4(pt + c) : x[j][t] + ld4(a.pe + (size_t)frame * kD + c));
+            }
         }
     }
+    // key mask: the Denoiser passes none; encode masks the padded frames, its two distribution tokens are always visible (vae.py:176-181)
+    const int klen = ENCM ? (a.lengths ? a.lengths[b] : kFrames) + npre : S;
 #pragma unroll 1
     for (int blk = 0; blk < 4; ++blk) {
         const float* pv = pvl + (blk & 1) * (kPvSlot / 4);
-        attn_half_x<NT, 0>(x, sg, a, b, blk, tile0, pv, a.pvec + (blk + 1) * PV_BLOCK, lds0 + kXOffPv + ((blk + 1) & 1) * kPvSlot, smem, S, wave, lane);
+        attn_half_x<NT, 0>(x, sg, a, b, blk, tile0, pv, a.pvec + (blk + 1) * PV_BLOCK, lds0 + kXOffPv + ((blk + 1) & 1) * kPvSlot, smem, klen, wave, lane);
         row_half_x<NT, 0, true>(x, sg, a, blk, tile0, b, pv, pvl, smem, wave, lane);
     }
-    attn_half_x<NT, 1>(x, sg, a, b, 4, tile0, pvl, a.pvec + 5 * PV_BLOCK, lds0 + kXOffPv + kPvSlot, smem, S, wave, lane);
+    attn_half_x<NT, 1>(x, sg, a, b, 4, tile0, pvl, a.pvec + 5 * PV_BLOCK, lds0 + kXOffPv + kPvSlot, smem, klen, wave, lane);
     row_half_x<NT, 1, true>(x, sg, a, 4, tile0, b, pvl, pvl, smem, wave, lane);
 #pragma unroll 1
     for (int blk = 5; blk < kLayers; ++blk) {
         const float* pv = pvl + (blk & 1) * (kPvSlot / 4);
-        attn_half_x<NT, 2>(x, sg, a, b, blk, tile0, pv, blk + 1 < kLayers ? a.pvec + (blk + 1) * PV_BLOCK : nullptr, lds0 + kXOffPv + ((blk + 1) & 1) * kPvSlot, smem, S, wave, lane);
+        attn_half_x<NT, 2>(x, sg, a, b, blk, tile0, pv, blk + 1 < kLayers ? a.pvec + (blk + 1) * PV_BLOCK : nullptr, lds0 + kXOffPv + ((blk + 1) & 1) * kPvSlot, smem, klen, wave, lane);
         row_half_x<NT, 2, true>(x, sg, a, blk, tile0, b, pv, pvl, smem, wave, lane);
+    }
+    if constexpr (ENCM) {   // encoder.norm of the distribution rows (mu | logvar, vae.py:196-203): rows 0, 1 of the clip's tile 0
+        if (tile0 == 0) {
+            layer_norm_rows<false>(x[0], a.pvec + PV_FINAL_W, a.pvec + PV_FINAL_B, g);
+            if (r < 2) {
+#pragma unroll
+                for (int t = 0; t < kTiles; ++t) st4(a.eps_out + ((size_t)b * 2 + r) * kD + 16 * t + 4 * g, x[0][t]);
+            }
+        }
+        return;
     }
     // ---------------- encoder.norm -> pose_proj (333 outputs in 24 tiles, four quarters of 6: three LDS stages each) -> mask -> eps_hat / scheduler update (k_vae.hip's last
     // stage: the parity modes' arithmetic - exact division, no contraction), every element read and written by the wave that owns its row tile (x_out may alias x_in)
@@ -842,7 +864,7 @@ __device__ __forceinline__ void den_tiles_x(const DenFusedXArgs& a, char* smem, 
 #pragma unroll
         for (int c = 0; c < 4; ++c) xs[j][c] = split_f16(x[j][2 * c], x[j][2 * c + 1]);
     float* fst = reinterpret_cast<float*>(smem + kXOffKv) + wave * 16 * kQStride;   // one staging tile per wave (the K / V images are dead)
-    const int len = (a.lengths ? a.lengths[b] : kFrames) + npre;
+    const int len = (a.lengths ? a.lengths[b] : kFrames) + npre;   // (eps rows of masked frames are zeroed: denoiser.py:187)
     const float* cf = a.coef;
     const float sb = cf ? cf[0] : 0.f, sa = cf ? cf[1] : 1.f, c0 = cf ? cf[2] : 0.f, cxx = cf ? cf[3] : 0.f, ce = cf ? cf[4] : 0.f, sgm = cf ? cf[5] : 0.f, clipv = cf ? cf[6] : 0.f;
     const float* nz = a.step_noise ? a.step_noise + (size_t)b * kFrames * kFeats : nullptr;
@@ -910,6 +932,7 @@ __device__ __forceinline__ void den_tiles_x(const DenFusedXArgs& a, char* smem, 
     }
 }
 
+template <bool ENCM>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_den_fusedx(DenFusedXArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63;
@@ -925,8 +948,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     sg.ridx = 0;
     stage_fetch(sg);
     stage_fetch(sg);
-    if (wave < 4) den_tiles_x<3>(a, smem, sg, wave, b, wave, lane);
-    else den_tiles_x<2>(a, smem, sg, wave + 8, b, wave, lane);
+    if (wave < 4) den_tiles_x<3, ENCM>(a, smem, sg, wave, b, wave, lane);
+    else den_tiles_x<2, ENCM>(a, smem, sg, wave + 8, b, wave, lane);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the two surplus fetches must not outlive the workgroup's LDS
 }
 
@@ -967,11 +990,14 @@ hipError_t launch_den_fusedx(const DenFusedXArgs& a, hipStream_t stream) {
     static DeviceOnce once;
     int dev_;
     if (!once.done(&dev_)) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_den_fusedx), hipFuncAttributeMaxDynamicSharedMemorySize, kXLdsBytes);
-        if (e != hipSuccess) return e;
+        for (const void* k : {reinterpret_cast<const void*>(&k_den_fusedx<false>), reinterpret_cast<const void*>(&k_den_fusedx<true>)}) {
+            hipError_t e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, kXLdsBytes);
+            if (e != hipSuccess) return e;
+        }
         once.set(dev_);
     }
-    hipLaunchKernelGGL(k_den_fusedx, dim3(a.B), dim3(512), kXLdsBytes, stream, a);
+    if (a.encode) hipLaunchKernelGGL(k_den_fusedx<true>, dim3(a.B), dim3(512), kXLdsBytes, stream, a);
+    else hipLaunchKernelGGL(k_den_fusedx<false>, dim3(a.B), dim3(512), kXLdsBytes, stream, a);
     return hipGetLastError();
 }
 

@@ -500,6 +500,24 @@ def test_vae_encode_fp32x_on_the_row_kernel_without_split_k(env):
         o5 = eng.vae_encode(fb, None, "fp32x")
         assert torch.equal(o5["mu"][0], out["mu"][0]) and torch.equal(o5["mu"][33], out["mu"][1]) and torch.equal(o5["mu"][69], out["mu"][0])
         assert torch.equal(o5["std"][33], out["std"][1])
+        # ... and as ONE persistent workgroup per clip (k_den_fusedx<encode> in k_vae_fusedx.hip; "clip" pins it, AUTO takes it where the takes fill rounds of the chip):
+        # the same goldens at the same bar, the key mask live, masked frames dead inputs, a take's bits independent of its launch
+        eng.set_decode_path("clip")
+        oc = eng.vae_encode(feats, None, "fp32x")
+        assert _err(oc["mu"], g["mu"]) < 2e-5 and _err(oc["std"], g["std"]) < 2e-5 * float(g["std"].max())
+        assert not torch.equal(oc["mu"], out["mu"]) and _err(oc["mu"], out["mu"]) < 2e-5
+        oc2 = eng.vae_encode(feats, [300, 211], "fp32x")
+        assert _err(oc2["mu"], g["mu_ragged"]) < 2e-5 and _err(oc2["std"], g["std_ragged"]) < 2e-5 * float(g["std_ragged"].max())
+        f2 = feats.clone()
+        f2[1, 211:] = 7.0
+        oc3 = eng.vae_encode(f2, [300, 211], "fp32x")
+        assert torch.equal(oc3["mu"], oc2["mu"]) and torch.equal(oc3["std"], oc2["std"])
+        fb = feats[:1].repeat(270, 1, 1)                                                            # a second round of workgroups on the chip
+        fb[133] = feats[1]
+        oc5 = eng.vae_encode(fb, None, "fp32x")
+        assert torch.equal(oc5["mu"][0], oc["mu"][0]) and torch.equal(oc5["mu"][133], oc["mu"][1]) and torch.equal(oc5["std"][269], oc["std"][0])
+        eng.set_decode_path("auto")                                                                 # AUTO at 256 takes = the per-clip kernel
+        assert torch.equal(eng.vae_encode(fb[:256], None, "fp32x")["mu"][133], oc["mu"][1])
     finally:
         eng.set_decode_path("auto")
 
