@@ -264,7 +264,8 @@ int amuse_set_clips_per_group(amuse_ctx* ctx, int g);
  * CLIP: the fp32x mode's third decoder - one persistent workgroup per clip in the parity arithmetic (csrc/k_vae_fusedx.hip: the residual stream in registers, q / k / v never
  * leave the CU) - which AUTO takes when the call's clips fill whole rounds of the chip's 256 CUs (from 160 clips; amuse_amd/shard.py fusedx_rule states the rule); in the other
  * modes CLIP means FUSED.  The three fp32x decoders compute the same function and differ by fp32 rounding (1.5e-6 on features of magnitude 3), so a sharded job pins the
- * whole job's choice (amuse_amd/shard.py job_decode_path).  AMUSE_VAE_FUSEDX=0 / 1 overrides AUTO's choice of this kernel for a whole process. */
+ * whole job's choice (amuse_amd/shard.py job_decode_path).  amuse_vae_encode and the pose-space Denoiser's step (AMUSE_ARCH_ENC_POSE) have the same third fp32x kernel
+ * under the same rule and pin.  AMUSE_VAE_FUSEDX=0 / 1 overrides AUTO's choice of these kernels for a whole process. */
 enum { AMUSE_DECODE_AUTO = 0, AMUSE_DECODE_STAGED = 1, AMUSE_DECODE_FUSED = 2, AMUSE_DECODE_CLIP = 3 };
 int amuse_set_decode_path(amuse_ctx* ctx, int path);
 
