@@ -55,9 +55,31 @@ __device__ __forceinline__ f32x4 mfma3t(f16x8 wh, f16x8 wl, const F16Pair& x, f3
     return mfma_f16(x.hi, wh, acc);
 }
 // the 8 unit pairs of the current LDS stage: f(i, hi, lo); pair i + 1 is read before pair i's MFMAs
-template <bool FETCH = true, class F>
+// Who copies the weight stream: two pieces of every 16-piece stage per wave, as in the 16-bit kernels.  -DAMUSE_FX_DMA_SPLIT=1 (A/B): the four TWO-tile waves fetch
+// four pieces each and the three-tile waves - the critical path of every stage, the others wait ~1,000 cycles at its barrier - none: bitwise, and flat (1.67 ms per 256-clip
+// decode either way; profiles/r05_fusedx_decode.txt).
+#ifndef AMUSE_FX_DMA_SPLIT
+#define AMUSE_FX_DMA_SPLIT 0
+#endif
+template <int NT> constexpr int kP = AMUSE_FX_DMA_SPLIT ? (NT == 3 ? 0 : 4) : 2;   // pieces per stage of a wave with NT tiles
+template <int NT>
+__device__ __forceinline__ void stage_fetch_x(Stager& s) {
+    if constexpr (kP<NT> > 0) {
+        const unsigned d = __builtin_amdgcn_readfirstlane(s.dst0 + s.widx * kStageBytes);
+#pragma unroll
+        for (int i = 0; i < kP<NT>; ++i) glds16(s.src + i * 64, d + i * 1024);
+        s.src += kStage * 64;
+        s.widx = s.widx == kWBufs - 1 ? 0 : s.widx + 1;
+    }
+}
+template <int NT>
+__device__ __forceinline__ void stage_end_x(Stager& s) {
+    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(kP<NT>) : "memory");
+    s.ridx = s.ridx == kWBufs - 1 ? 0 : s.ridx + 1;
+}
+template <int NT, bool FETCH = true, class F>
 __device__ __forceinline__ void for_pairs(Stager& s, F&& f) {
-    if constexpr (FETCH) stage_fetch(s);
+    if constexpr (FETCH) stage_fetch_x<NT>(s);
     f16x8 h = wfrag(s, 0), l = wfrag(s, 1);
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
@@ -292,11 +314,11 @@ __device__ __forceinline__ void attn_half_x(f32x4 (&x)[NT][kTiles], Stager& sg, 
             F16Pair xc[NT];
 #pragma unroll
             for (int j = 0; j < NT; ++j) xc[j] = im.get(j, c);
-            for_pairs(sg, [&](int o, f16x8 wh, f16x8 wl) {
+            for_pairs<NT>(sg, [&](int o, f16x8 wh, f16x8 wl) {
 #pragma unroll
                 for (int j = 0; j < NT; ++j) x[j][o] = mfma3(wh, wl, xc[j], x[j][o]);
             });
-            stage_end(sg);
+            stage_end_x<NT>(sg);
         }
         const float* sk = a.skip + (size_t)(8 - blk) * nrows * kD;
 #pragma unroll 1
@@ -309,11 +331,11 @@ __device__ __forceinline__ void attn_half_x(f32x4 (&x)[NT][kTiles], Stager& sg, 
                 const bool ok = frame < S;
                 xc[j] = split_f16(ok ? ld4(src) : splat4(0.f), ok ? ld4(src + 16) : splat4(0.f));
             }
-            for_pairs(sg, [&](int o, f16x8 wh, f16x8 wl) {
+            for_pairs<NT>(sg, [&](int o, f16x8 wh, f16x8 wl) {
 #pragma unroll
                 for (int j = 0; j < NT; ++j) x[j][o] = mfma3(wh, wl, xc[j], x[j][o]);
             });
-            stage_end(sg);
+            stage_end_x<NT>(sg);
         }
     }
     FSTAMP(2);   // skip linear done
@@ -339,7 +361,7 @@ __device__ __forceinline__ void attn_half_x(f32x4 (&x)[NT][kTiles], Stager& sg, 
 #pragma unroll
                 for (int s2 = 0; s2 < 2; ++s2) {
                     F16Pair xc[NT];
-                    for_pairs(sg, [&](int i, f16x8 wh, f16x8 wl) {   // per k-pair c: k tiles (2), v tiles (2)
+                    for_pairs<NT>(sg, [&](int i, f16x8 wh, f16x8 wl) {   // per k-pair c: k tiles (2), v tiles (2)
                         const int c = 2 * s2 + (i >> 2), t = i & 3;
                         if (t == 0) {
 #pragma unroll
@@ -351,7 +373,7 @@ __device__ __forceinline__ void attn_half_x(f32x4 (&x)[NT][kTiles], Stager& sg, 
                             else vv[j][t - 2] = mfma3t(wh, wl, xc[j], vv[j][t - 2]);
                         }
                     });
-                    if (s2 == 0) stage_end(sg);
+                    if (s2 == 0) stage_end_x<NT>(sg);
                 }
                 FSTAMP(3);   // k, v computed
 #pragma unroll
@@ -375,7 +397,7 @@ __device__ __forceinline__ void attn_half_x(f32x4 (&x)[NT][kTiles], Stager& sg, 
                     }
                 }
                 FSTAMP(4);   // images written
-                stage_end(sg);
+                stage_end_x<NT>(sg);
                 FSTAMP(5);   // barrier of stage A passed
             }
             // ---- stage B (one LDS stage): q of this head; attention, a tile at a time; the output to the scratch
@@ -390,7 +412,7 @@ __device__ __forceinline__ void attn_half_x(f32x4 (&x)[NT][kTiles], Stager& sg, 
 #pragma unroll
                 for (int j = 0; j < NT; ++j) { q[j][0] = bq0; q[j][1] = bq1; }
                 F16Pair xc[NT];
-                for_pairs(sg, [&](int i, f16x8 wh, f16x8 wl) {
+                for_pairs<NT>(sg, [&](int i, f16x8 wh, f16x8 wl) {
                     const int c = i >> 1, o = i & 1;
                     if (o == 0) {
 #pragma unroll
@@ -420,7 +442,7 @@ __device__ __forceinline__ void attn_half_x(f32x4 (&x)[NT][kTiles], Stager& sg, 
                 qs[NT - 1] = first;
             }
             FSTAMP(7);   // attention of the wave's tiles, outputs stored
-            stage_end(sg);
+            stage_end_x<NT>(sg);
             FSTAMP(8);   // barrier of stage B passed
         }
     }
@@ -472,12 +494,12 @@ __device__ __forceinline__ void row_half_x(f32x4 (&x)[NT][kTiles], Stager& sg, c
         fetch_o(0);
 #pragma unroll 1
         for (int c = 0; c < 4; ++c) {
-            stage_fetch(sg);
+            stage_fetch_x<NT>(sg);
             if (c + 1 < 4) {
                 fetch_o(c + 1);
-                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 + 2 * NT) : "memory");   // this k-pair's outputs are in (and every older weight stage)
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kP<NT> + 2 * NT) : "memory");   // this k-pair's outputs are in (and every older weight stage)
             } else {
-                asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kP<NT>) : "memory");
             }
             F16Pair xc[NT];
 #pragma unroll
@@ -485,15 +507,15 @@ __device__ __forceinline__ void row_half_x(f32x4 (&x)[NT][kTiles], Stager& sg, c
                 const char* src = obuf_l + (c & 1) * (NT * 2048) + (2 * j) * 1024;
                 xc[j] = split_f16(*reinterpret_cast<const f32x4*>(src), *reinterpret_cast<const f32x4*>(src + 1024));
             }
-            for_pairs<false>(sg, [&](int o, f16x8 wh, f16x8 wl) {
+            for_pairs<NT, false>(sg, [&](int o, f16x8 wh, f16x8 wl) {
 #pragma unroll
                 for (int j = 0; j < NT; ++j) x[j][o] = mfma3(wh, wl, xc[j], x[j][o]);
             });
             if (c + 1 < 4) {   // (stage_end with the next k-pair's pieces allowed in flight behind this stage's weight fetch)
-                asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(2 + 2 * NT) : "memory");
+                asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(kP<NT> + 2 * NT) : "memory");
                 sg.ridx = sg.ridx == kWBufs - 1 ? 0 : sg.ridx + 1;
             } else {
-                stage_end(sg);
+                stage_end_x<NT>(sg);
             }
             FSTAMP(9);   // an out_proj stage
         }
@@ -536,7 +558,7 @@ __device__ __forceinline__ void row_half_x(f32x4 (&x)[NT][kTiles], Stager& sg, c
 #pragma unroll
         for (int j = 0; j < NT; ++j) { acc[j][0] = b0; acc[j][1] = b1; }
         F16Pair xc[NT];
-        for_pairs(sg, [&](int i, f16x8 wh, f16x8 wl) {
+        for_pairs<NT>(sg, [&](int i, f16x8 wh, f16x8 wl) {
             const int c = i >> 1, o = i & 1;
             if (o == 0) {
 #pragma unroll
@@ -560,7 +582,7 @@ __device__ __forceinline__ void row_half_x(f32x4 (&x)[NT][kTiles], Stager& sg, c
         }
     };
     lin1(hid, 0);
-    stage_end(sg);
+    stage_end_x<NT>(sg);
 #pragma unroll 1
     for (int ch = 0; ch < 16; ++ch) {
         F16Pair hs[NT];
@@ -577,14 +599,14 @@ __device__ __forceinline__ void row_half_x(f32x4 (&x)[NT][kTiles], Stager& sg, c
                 lin1(nxt, ch + 1);
             }
             FSTAMP(12);   // linear1 of the next chunk + GELU of this one
-            stage_end(sg);
+            stage_end_x<NT>(sg);
             FSTAMP(13);
 #pragma unroll
             for (int j = 0; j < NT; ++j) { hid[j][0] = nxt[j][0]; hid[j][1] = nxt[j][1]; }
         } else {
             gelu_split(hs);
         }
-        for_pairs(sg, [&](int o, f16x8 wh, f16x8 wl) {
+        for_pairs<NT>(sg, [&](int o, f16x8 wh, f16x8 wl) {
 #pragma unroll
             for (int j = 0; j < NT; ++j) {
                 if constexpr ((AMUSE_FX_ABL & 2) != 0) x[j][o] += __builtin_bit_cast(f32x4, wh + hs[j].hi);
@@ -592,7 +614,7 @@ __device__ __forceinline__ void row_half_x(f32x4 (&x)[NT][kTiles], Stager& sg, c
             }
         });
         FSTAMP(14);   // linear2 of the chunk
-        stage_end(sg);
+        stage_end_x<NT>(sg);
         FSTAMP(15);
     }
 #pragma unroll 1
@@ -674,12 +696,12 @@ __device__ __forceinline__ void decode_tiles_x(const VaeFusedXArgs& a, char* sme
         }
 #pragma unroll
         for (int s3 = 0; s3 < 3; ++s3) {
-            for_pairs(sg, [&](int i, f16x8 wh, f16x8 wl) {
+            for_pairs<NT>(sg, [&](int i, f16x8 wh, f16x8 wl) {
                 const int lin = 8 * s3 + i, c = lin / 6, o = lin - 6 * c;
 #pragma unroll
                 for (int j = 0; j < NT; ++j) f[j][o] = mfma3(wh, wl, xs[j][c], f[j][o]);
             });
-            stage_end(sg);
+            stage_end_x<NT>(sg);
         }
         const int f0 = 96 * quarter, nfe = quarter == 3 ? kFeats - 288 : 96, njo = quarter == 3 ? kJoints - 48 : 16;
 #pragma unroll 1
@@ -738,13 +760,14 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     Stager sg;
     // (a full-length clip with the block-0 constant at hand starts behind block 0's sixteen attention stages: decoder_block_x, hoist)
     const size_t skip_units = (a.c1 && len == kFrames) ? (size_t)16 * kStage : 0;
-    sg.src = a.wstream + (skip_units + (size_t)wave * 2) * 64 + lane;
-    sg.dst0 = lds0 + kXOffW + wave * 2048;
+    const int piece0 = AMUSE_FX_DMA_SPLIT ? 4 * (wave & 3) : 2 * wave;   // (the three-tile waves 0..3 copy nothing when the split is on)
+    sg.src = a.wstream + (skip_units + (size_t)piece0) * 64 + lane;
+    sg.dst0 = lds0 + kXOffW + piece0 * 1024;
     sg.ring = smem + kXOffW + lane * 16;
     sg.widx = 0;
     sg.ridx = 0;
-    stage_fetch(sg);
-    stage_fetch(sg);
+    if (wave < 4) { stage_fetch_x<3>(sg); stage_fetch_x<3>(sg); }
+    else { stage_fetch_x<2>(sg); stage_fetch_x<2>(sg); }
     if (wave < 4) decode_tiles_x<3>(a, smem, sg, wave, b, len, wave, lane);
     else decode_tiles_x<2>(a, smem, sg, wave + 8, b, len, wave, lane);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the two surplus fetches must not outlive the workgroup's LDS
@@ -799,11 +822,11 @@ __device__ __forceinline__ void den_tiles_x(const DenFusedXArgs& a, char* smem, 
 #pragma unroll
         for (int j = 0; j < NT; ++j) xc[j] = split_f16(cur[j][0], cur[j][1]);
         if (c + 1 < 11) load_xt_pair<NT>(cur, xin, tile0, r, g, npre, c + 1);
-        for_pairs(sg, [&](int o, f16x8 wh, f16x8 wl) {
+        for_pairs<NT>(sg, [&](int o, f16x8 wh, f16x8 wl) {
 #pragma unroll
             for (int j = 0; j < NT; ++j) x[j][o] = mfma3(wh, wl, xc[j], x[j][o]);
         });
-        stage_end(sg);
+        stage_end_x<NT>(sg);
     }
     // xseq = cat(emb_latent, pose_embd(sample)) + query_pos (denoiser.py:180-181); the tokens arrive with their positions added
 #pragma unroll
@@ -881,12 +904,12 @@ __device__ __forceinline__ void den_tiles_x(const DenFusedXArgs& a, char* smem, 
         }
 #pragma unroll
         for (int s3 = 0; s3 < 3; ++s3) {
-            for_pairs(sg, [&](int i, f16x8 wh, f16x8 wl) {
+            for_pairs<NT>(sg, [&](int i, f16x8 wh, f16x8 wl) {
                 const int lin = 8 * s3 + i, c = lin / 6, o = lin - 6 * c;
 #pragma unroll
                 for (int j = 0; j < NT; ++j) f[j][o] = mfma3(wh, wl, xs[j][c], f[j][o]);
             });
-            stage_end(sg);
+            stage_end_x<NT>(sg);
         }
         const int f0 = 96 * quarter, nfe = quarter == 3 ? kFeats - 288 : 96;
 #pragma unroll 1
@@ -941,13 +964,14 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const unsigned lds0 = lds_addr(smem);
     glds16(reinterpret_cast<const uint4*>(a.pvec) + wave * 64 + lane, lds0 + kXOffPv + wave * 1024);   // block 0's parameters
     Stager sg;
-    sg.src = a.wstream + (size_t)wave * 2 * 64 + lane;
-    sg.dst0 = lds0 + kXOffW + wave * 2048;
+    const int piece0 = AMUSE_FX_DMA_SPLIT ? 4 * (wave & 3) : 2 * wave;
+    sg.src = a.wstream + (size_t)piece0 * 64 + lane;
+    sg.dst0 = lds0 + kXOffW + piece0 * 1024;
     sg.ring = smem + kXOffW + lane * 16;
     sg.widx = 0;
     sg.ridx = 0;
-    stage_fetch(sg);
-    stage_fetch(sg);
+    if (wave < 4) { stage_fetch_x<3>(sg); stage_fetch_x<3>(sg); }
+    else { stage_fetch_x<2>(sg); stage_fetch_x<2>(sg); }
     if (wave < 4) den_tiles_x<3, ENCM>(a, smem, sg, wave, b, wave, lane);
     else den_tiles_x<2, ENCM>(a, smem, sg, wave + 8, b, wave, lane);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the two surplus fetches must not outlive the workgroup's LDS
