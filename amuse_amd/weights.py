@@ -183,5 +183,41 @@ def make_prior_weights(seed: int = 0) -> Dict[str, np.ndarray]:
     return make_weights(prior_param_spec(), seed, "prior")
 
 
+def _joint_rest_6d(seed: int) -> np.ndarray:
+    """55 rest rotations as the 6D representation the decoder emits: the first two ROWS of the matrix (pytorch3d's
+    matrix_to_rotation_6d convention, the inverse of models/diffusion/utils/rotation_conversions.py:480-500).  Joint 0 = identity;
+    most joints turn about a random axis by up to 1 rad; every 7th joint turns by 2.6-2.9 rad about a nearly axis-aligned axis of
+    either sign, the regime in which the deployed matrix_to_axis_angle writes |aa| > pi.  Both groups sit away
+    from the ties of the quaternion candidate selection (w = cos(a/2) against sin(a/2) * max|axis|), where that function jumps."""
+    g = _rng_for(seed, "prior/rest_pose")
+    ax = g.standard_normal((N_JOINTS, 3))
+    ang = g.uniform(0.0, 1.0, N_JOINTS)
+    for n, j in enumerate(range(3, N_JOINTS, 7)):
+        ax[j] = 0.2 * ax[j]
+        ax[j, n % 3] = 1.0 if (n // 3) % 2 == 0 else -1.0
+        ang[j] = g.uniform(2.6, 2.9)
+    ax /= np.linalg.norm(ax, axis=1, keepdims=True)
+    ang[0] = 0.0
+    K = np.zeros((N_JOINTS, 3, 3))
+    K[:, 0, 1], K[:, 0, 2], K[:, 1, 0], K[:, 1, 2], K[:, 2, 0], K[:, 2, 1] = -ax[:, 2], ax[:, 1], ax[:, 2], -ax[:, 0], -ax[:, 1], ax[:, 0]
+    s, c = np.sin(ang)[:, None, None], np.cos(ang)[:, None, None]
+    R = np.eye(3)[None] + s * K + (1 - c) * (K @ K)       # Rodrigues
+    return R[:, :2, :].reshape(N_JOINTS, 6)
+
+
+def make_wellcond_prior_weights(seed: int = 1) -> Dict[str, np.ndarray]:
+    """MotionPrior weights whose decoder emits WELL-CONDITIONED 6D rotations, as a trained decoder does: the random draw of
+    `make_prior_weights(seed)` with final_layer.weight x 0.1 and final_layer.bias = the 6D image of a rest pose per joint (| 0 for the
+    translation), so the Gram-Schmidt pivots of rotation_6d_to_matrix stay >= 0.5 (a plain random draw gives pivots down to 1e-3,
+    which amplify any upstream rounding difference ~1000 x in the pose - a property of random weights, not of the path).
+    Used by the `wellcond` reference-module fixtures (oracle/gen_golden.py --wellcond) and the end-to-end every-joint parity tests."""
+    w = make_prior_weights(seed)
+    w["final_layer.weight"] = np.ascontiguousarray(w["final_layer.weight"] * np.float32(0.1))
+    b = np.zeros(N_FEATS, dtype=np.float32)
+    b[: N_JOINTS * 6] = _joint_rest_6d(seed).reshape(-1).astype(np.float32)
+    w["final_layer.bias"] = b
+    return w
+
+
 def n_params(w: Dict[str, np.ndarray]) -> int:
     return int(sum(v.size for v in w.values()))

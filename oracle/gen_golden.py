@@ -274,6 +274,73 @@ def load_weights(module, w):
         p.requires_grad = False
 
 
+def gen_wellcond(out):
+    """tests/golden/wellcond.npz: the whole path of infer_ldm.py:130-178 on a SECOND weight draw (seed 1) whose decoder emits
+    well-conditioned 6D rotations (weights.make_wellcond_prior_weights), produced by the reference's own modules:
+      reference Denoiser x DDIM-50 (the restated scheduler of the shipped configuration: clip_sample, eta 0, steps_offset 1)
+      -> reference MotionPrior.decode -> vendored rotation_6d_to_matrix -> the p3d matrix_to_axis_angle that tests/golden/ref_poses.npz pins.
+    Two jobs: `full` (B = 4: content, emotion, style) and `noemo` (B = 2: z_emo = None, the S = 4 token-dropping path of
+    denoiser.py:159-171).  Also the per-kernel goldens of that draw: teacher-forced eps_hat at t = 981 / 501 / 1,
+    MotionPrior.decode with ragged lengths, MotionPrior.encode (mu / std, full + ragged)."""
+    den, prior, rot = build_reference()
+    wd, wp = wts.make_denoiser_weights(1), wts.make_wellcond_prior_weights(1)
+    load_weights(den, wd)
+    load_weights(prior, wp)
+    g = torch.Generator().manual_seed(6001)
+    B = 4
+    con, emo, sty = (torch.randn(B, 256, generator=g) for _ in range(3))
+    x_T = torch.randn(B, 128, generator=g)
+    d = {"con": con.numpy(), "emo": emo.numpy(), "sty": sty.numpy(), "x_T": x_T.numpy()}
+    for t in (981, 501, 1):
+        d[f"eps_t{t}"] = den(sample=x_T[:, None], timestep=torch.tensor(t), con_hidden=con[:, None], emo_hidden=emo[:, None],
+                             sty_hidden=sty[:, None], lengths=[300] * B)[0][:, 0].numpy()
+    sched = orc.DDIM()
+
+    def job(tag, sl, use_emo):
+        n = sl.stop - sl.start
+        x = x_T[sl].clone() * sched.init_noise_sigma
+        for i, t in enumerate(sched.timesteps):
+            eps = den(sample=x[:, None], timestep=torch.tensor(t), con_hidden=con[sl, None],
+                      emo_hidden=emo[sl, None] if use_emo else None, sty_hidden=sty[sl, None], lengths=[300] * n)[0][:, 0]
+            x = sched.step(eps, t, x)
+            if i + 1 == 10:
+                d[f"{tag}/x_after_10"] = x.numpy().copy()
+        feats = prior.decode(x[None], [300] * n)                       # PretrainedVAE.get_motion (infer_pretrained_vae.py)
+        rot6d = feats[..., :-3].reshape(n, 300, 55, 6)                 # infer_ldm.py:168-170
+        mat = rot.rotation_6d_to_matrix(rot6d)
+        poses = orc.matrix_to_axis_angle(mat, "p3d")                   # the deployed pytorch3d's function, pinned by ref_poses.npz
+        # conditioning facts of the fixture: the Gram-Schmidt pivots (|a1|, |a2 - (b1.a2) b1|) and the largest rotation angle
+        a1, a2 = rot6d[..., :3], rot6d[..., 3:]
+        b1 = torch.nn.functional.normalize(a1, dim=-1)
+        piv = torch.minimum(a1.norm(dim=-1), (a2 - (b1 * a2).sum(-1, keepdim=True) * b1).norm(dim=-1))
+        print(f"wellcond/{tag}: min pivot {float(piv.min()):.3f}, max |aa| {float(poses.norm(dim=-1).max()):.3f} rad, "
+              f"latent |x| max {float(x.abs().max()):.3f}")
+        # the candidate selection of matrix_to_quaternion is discontinuous where two |q| candidates tie (q <-> -q: the same rotation
+        # written with |aa| on the other side of pi): the fixture must sit away from those ties, by far more than the 1e-4 bar
+        tr = torch.stack([1 + mat[..., 0, 0] + mat[..., 1, 1] + mat[..., 2, 2], 1 + mat[..., 0, 0] - mat[..., 1, 1] - mat[..., 2, 2],
+                          1 - mat[..., 0, 0] + mat[..., 1, 1] - mat[..., 2, 2], 1 - mat[..., 0, 0] - mat[..., 1, 1] + mat[..., 2, 2]], -1)
+        top = tr.clamp(min=0).sqrt().topk(2, dim=-1).values
+        tie = float((top[..., 0] - top[..., 1]).min())
+        print(f"wellcond/{tag}: closest |q| tie {tie:.2e}, joints with |aa| > pi: {int((poses.norm(dim=-1) > np.pi).sum())}")
+        assert float(piv.min()) >= 0.5 and tie > 2e-3, "not well-conditioned"
+        d[f"{tag}/tie_margin"] = np.array(tie)
+        d[f"{tag}/latents"], d[f"{tag}/feats"], d[f"{tag}/poses"] = x.numpy().copy(), feats.numpy(), poses.numpy()
+        d[f"{tag}/min_pivot"] = np.array(float(piv.min()))
+        return x
+
+    lat = job("full", slice(0, 4), True)
+    job("noemo", slice(0, 2), False)
+    # per-kernel goldens of the second draw: ragged decode, encode
+    d["feats_ragged"] = prior.decode(lat[None, :2], [300, 173]).numpy()
+    d["lengths_ragged"] = np.array([300, 173])
+    fe = (0.5 * torch.randn(2, 300, 333, generator=g)).half().float()
+    _, dist = prior.encode(fe, [300, 300])
+    _, dist_r = prior.encode(fe, [300, 211])
+    d.update(enc_feats=fe.numpy().astype(np.float16), mu=dist.loc[0].numpy(), std=dist.scale[0].numpy(),
+             mu_ragged=dist_r.loc[0].numpy(), std_ragged=dist_r.scale[0].numpy(), enc_lengths_ragged=np.array([300, 211]))
+    np.savez_compressed(out / "wellcond.npz", **d)
+
+
 def main():
     out = REPO / "tests/golden"
     out.mkdir(parents=True, exist_ok=True)
@@ -282,6 +349,9 @@ def main():
     if "--pins-only" in sys.argv:       # only tests/golden/ref_poses.npz + sched_ref.npz
         gen_ref_poses(out)
         gen_sched_ref(out)
+        return
+    if "--wellcond" in sys.argv:        # only tests/golden/wellcond.npz (second weight draw, well-conditioned decoder)
+        gen_wellcond(out)
         return
     if "--variants-only" in sys.argv:   # only tests/golden/denoiser_variants.npz + state_dict_spec_variants.json
         gen_variants(out, _shim()[0])
@@ -419,6 +489,7 @@ def main():
     np.savez_compressed(out / "sample_npz_betas.npz", **bet)
     gen_ref_poses(out)
     gen_sched_ref(out)
+    gen_wellcond(out)
     for f in sorted(out.iterdir()):
         print(f.name, os.path.getsize(f))
 

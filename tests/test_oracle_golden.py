@@ -253,3 +253,31 @@ def test_split_precision_emulation(Wd):
     bf16x = eps_err(SplitOps(torch.bfloat16, 2, 3, [(0, 0), (1, 0), (0, 1), (2, 0), (1, 1)]))
     assert f16x2 < 1e-5, f16x2          # measured 3.0e-6 (the fp32 oracle itself: 1.8e-6)
     assert bf16x > 1e-5, bf16x          # measured 2.9e-5
+
+
+def test_wellcond_second_seed_whole_path():
+    """A SECOND weight draw (seed 1) with a well-conditioned decoder (weights.make_wellcond_prior_weights), B = 4 + an emotion-dropped
+    job, fixtures by the reference's own Denoiser / MotionPrior.decode / rotation_6d_to_matrix (oracle/gen_golden.py --wellcond):
+    the oracle's whole path - DDIM-50 -> decode -> 6D -> axis-angle - meets the north star's bar on EVERY joint
+    (infer_ldm.py:130-178), plus the per-kernel goldens of that draw."""
+    g = np.load(GOLDEN / "wellcond.npz")
+    Wd1, Wp1 = orc.to_torch(wts.make_denoiser_weights(1)), orc.to_torch(wts.make_wellcond_prior_weights(1))
+    con, emo, sty, x = (torch.from_numpy(g[k]) for k in ("con", "emo", "sty", "x_T"))
+    for t in (981, 501, 1):
+        assert np.abs(orc.denoiser_forward(Wd1, x, t, con, emo, sty).numpy() - g[f"eps_t{t}"]).max() < 1e-5
+    for tag, n, e in (("full", 4, emo), ("noemo", 2, None)):
+        assert float(g[f"{tag}/min_pivot"]) >= 0.5 and float(g[f"{tag}/tie_margin"]) > 1e-2
+        out = orc.diffusion_backward(Wd1, Wp1, orc.DDIM(), con[:n], None if e is None else e[:n], sty[:n], x[:n])
+        assert np.abs(out["latents"].numpy() - g[f"{tag}/latents"]).max() < 1e-4
+        assert np.abs(out["feats"].numpy() - g[f"{tag}/feats"]).max() < 1e-4
+        d = np.linalg.norm(out["poses"].numpy() - g[f"{tag}/poses"], axis=-1)
+        assert d.shape == (n, 300, 55) and d.max() < 1e-4, d.max()
+        assert (np.linalg.norm(g[f"{tag}/poses"], axis=-1) > np.pi).sum() > 100      # the |aa| > pi regime is in the fixture
+    lat = torch.from_numpy(g["full/latents"])
+    fr = orc.vae_decode(Wp1, lat[:2], [300, 173])
+    assert np.abs(fr.numpy() - g["feats_ragged"]).max() < 2e-5
+    fe = torch.from_numpy(g["enc_feats"].astype(np.float32))
+    for lens, sfx in ((None, ""), ([300, 211], "_ragged")):
+        mu, std = orc.vae_encode(Wp1, fe, lens)
+        assert np.abs(mu.numpy() - g["mu" + sfx]).max() < 2e-5
+        assert np.abs(std.numpy() / g["std" + sfx] - 1).max() < 2e-5
