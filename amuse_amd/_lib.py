@@ -16,13 +16,13 @@ LIB_PATH = Path(os.environ.get("AMUSE_HIP_LIB") or _HERE / "libamuse_hip.so")
 PREC_F32, PREC_BF16, PREC_F32X, PREC_F16 = 0, 1, 2, 3
 UPD_F32, UPD_BF16, UPD_ENCODER, UPD_F32X, UPD_F16, UPD_ALL = 1, 2, 4, 8, 16, 31
 QUAT_P3D, QUAT_LEGACY = 0, 1
-ABI_VERSION = 4
+ABI_VERSION = 5
 ARCH_ENC, ARCH_DEC, ARCH_ENC_POSE, ARCH_DEC_POSE = 0, 1, 2, 3   # include/amuse_hip.h AMUSE_ARCH_*
 
 EXPORTS = [
     "amuse_abi_version", "amuse_last_error", "amuse_create", "amuse_update_weights", "amuse_update_weights_device", "amuse_destroy", "amuse_set_schedule",
     "amuse_sample", "amuse_denoise_step", "amuse_diffusion_forward", "amuse_vae_decode", "amuse_vae_encode", "amuse_smplx_to_feats", "amuse_diffusion_backward",
-    "amuse_counter_normal", "amuse_set_clips_per_group", "amuse_set_decode_path", "amuse_profile_sample",
+    "amuse_counter_normal", "amuse_set_clips_per_group", "amuse_set_decode_path", "amuse_plan", "amuse_debug_last_plan", "amuse_profile_sample",
     "amuse_audio_create", "amuse_audio_destroy", "amuse_audio_fbank", "amuse_audio_encode", "amuse_audio_features",
     "amuse_debug_gemm",
     "amuse_debug_tile", "amuse_debug_f16_split", "amuse_debug_set_decode_tap",
@@ -64,8 +64,12 @@ def load() -> C.CDLL:
         return _lib
     # torch FIRST: it ships its own HIP runtime (torch/lib/libamdhip64.so).  Loaded behind this library - which links the system's - the process would hold two
     # runtimes, and the second one sees no device ("no ROCm-capable device is detected" from amuse_create in a process that called __graft_entry__.build(), which
-    # loads the library, before anything imported torch).  With torch's copy resident the library binds to it.
-    import torch  # noqa: F401
+    # loads the library, before anything imported torch).  With torch's copy resident the library binds to it.  A caller without torch (a plain ctypes user of
+    # include/amuse_hip.h through this loader) has one runtime anyway: the import is attempted, not required ("Linking").
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     if not LIB_PATH.exists():
         raise AmuseHipError(
             f"{LIB_PATH} is missing - build it with `python -c 'import __graft_entry__ as g; g.build()'` "
@@ -110,6 +114,9 @@ def load() -> C.CDLL:
     lib.amuse_set_clips_per_group.argtypes = [vp, C.c_int]
     lib.amuse_set_decode_path.argtypes = [vp, C.c_int]
     lib.amuse_profile_sample.argtypes = [vp, fp, fp, fp, C.c_int, C.c_int, C.c_int, fp, vp]
+    lib.amuse_plan.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, ip, ip, ip, ip]
+    lib.amuse_debug_last_plan.argtypes = [vp, ip, ip, ip, ip]
+    lib.amuse_plan.restype = lib.amuse_debug_last_plan.restype = C.c_int
     for n in ("amuse_set_schedule", "amuse_sample", "amuse_denoise_step", "amuse_diffusion_forward", "amuse_vae_decode", "amuse_vae_encode", "amuse_smplx_to_feats",
               "amuse_diffusion_backward", "amuse_counter_normal", "amuse_set_clips_per_group", "amuse_set_decode_path",
               "amuse_profile_sample"):
@@ -159,3 +166,15 @@ def load() -> C.CDLL:
 def check(rc: int) -> None:
     if rc != 0:
         raise AmuseHipError(f"libamuse_hip error {rc}: {load().amuse_last_error().decode()}")
+
+
+DECODE_PATHS = ("auto", "staged", "fused", "clip")   # include/amuse_hip.h AMUSE_DECODE_*
+
+
+def plan(clips_total: int, precision: int = PREC_BF16, tokens: int = 5, arch: int = ARCH_ENC) -> dict:
+    """amuse_plan (include/amuse_hip.h): the kernels a job of `clips_total` clips takes - {"clips_per_group": int, "decode_path" / "encode_path" /
+    "step_path": "staged" | "fused" | "clip"}.  The library's own rule, no GPU needed; nothing in Python restates it."""
+    out = [C.c_int(0) for _ in range(4)]
+    check(load().amuse_plan(int(arch), int(precision), int(clips_total), int(tokens), *(C.byref(o) for o in out)))
+    return {"clips_per_group": out[0].value, "decode_path": DECODE_PATHS[out[1].value], "encode_path": DECODE_PATHS[out[2].value],
+            "step_path": DECODE_PATHS[out[3].value]}

@@ -30,12 +30,9 @@ constexpr int kUpdBit[4] = {AMUSE_UPD_F32, AMUSE_UPD_BF16, AMUSE_UPD_F32X, AMUSE
 int build_denoiser(amuse_ctx* c, const float* den, int what = AMUSE_UPD_ALL) {
     static const ParamIndex DI = denoiser_index();
     const Params D{DI, den};
-    // ---- denoiser weight streams: [wave][per-step units]
-    for (int prec = 0; prec < 3; ++prec) {
+    // ---- weight stream of the 4-wave kernel (k_sampler.hip: the fp32 parity mode; every other mode samples on an 8-wave kernel): [wave][per-step units]
+    for (const int prec : {PREC_F32}) {
         if (!(what & kUpdBit[prec])) continue;   // amuse_update_weights: only the requested precisions are re-packed
-        // the 4-wave bf16 and fp32x streams only serve A/B runs (AMUSE_SAMPLE_WAVES=4; both modes sample on their 8-wave kernels):
-        // updates - host path and, through the probe runs, the device re-pack's gather maps - skip them unless that switch is set
-        if ((prec == PREC_BF16 || prec == PREC_F16X2) && c->den_w[prec] && !getenv("AMUSE_SAMPLE_WAVES")) continue;
         std::vector<uint4> all;
         size_t per_wave = 0;
         for (int w = 0; w < 4; ++w) {
@@ -414,30 +411,20 @@ int cond_tokens(amuse_ctx* c, const float* con, const float* emo, const float* s
     return 0;
 }
 
-int pick_group(const amuse_ctx* c, int B, int S) {
+// clips per workgroup tile: the pin (amuse_set_clips_per_group) or the plan's rule (amuse_host.hpp plan_clips_per_group).  A clip's arithmetic depends on its row offset
+// inside the tile only through rounding (the softmax / PV accumulation order), so results are reproduced BITWISE by any launch that uses the same clips per tile and puts
+// the clip in the same slot of its tile - i.e. by shards that start at multiples of g (amuse_amd/shard.py takes g from amuse_plan for the job's TOTAL clip count and aligns
+// the shards) - and to rounding otherwise.
+int pick_group(amuse_ctx* c, int B, int S) {
     const int gmax = 16 / S;
-    int g = c->clips_per_group;
-    // auto: one clip per workgroup tile up to 128 clips, then fatter tiles - a step costs the same for 1..gmax clips per
-    // tile, and 128 busy CUs run it 6-7 % faster than 256: with every CU re-streaming the whole network each step the
-    // 256-workgroup launch sits at the L2's delivery limit (28 TB/s), the 128-workgroup one at half of it
-    // (profiles/r01_batch_sweep.txt: 256 clips 36.0 ms with one clip per tile, 33.6 ms with two or three).
-    // A clip's arithmetic depends on its row offset inside the tile only through rounding (the softmax / PV
-    // accumulation order), so results are reproduced BITWISE by any launch that uses the same clips per tile and puts the
-    // clip in the same slot of its tile - i.e. by shards that start at multiples of g (amuse_amd/shard.py picks g from the
-    // job's TOTAL clip count and aligns the shards) - and to rounding otherwise.
-    if (g <= 0) g = (B + 127) / 128;
+    int g = c->clips_per_group > 0 ? c->clips_per_group : plan_clips_per_group(AMUSE_ARCH_ENC, B, S);
     if (g > gmax) g = gmax;
-    if (g < 1) g = 1;
+    c->last_plan[0] = g;
     return g;
 }
 
-// weight stream + kernel choice for one sampling launch: fp32 -> 4-wave parity kernel; bf16 -> 8-wave throughput
-// kernel, unless phase stamps are requested or AMUSE_SAMPLE_WAVES=4 (A/B measurements) asks for the 4-wave one
-bool use_sample8(int precision) {
-    static const bool force4 = [] { const char* e = getenv("AMUSE_SAMPLE_WAVES"); return e && atoi(e) == 4; }();
-    if (precision == PREC_F16) return true;   // (the fp16 throughput mode exists on the 8-wave kernel only)
-    return (precision == PREC_BF16 || precision == PREC_F16X2) && !force4;   // (AMUSE_SAMPLE_WAVES=4: the 4-wave kernels, A/B runs)
-}
+// kernel choice for one sampling launch: fp32 -> the 4-wave parity kernel (k_sampler.hip); fp32x / bf16 / fp16 -> the 8-wave kernels
+bool use_sample8(int precision) { return precision != PREC_F32; }
 void set_stream(const amuse_ctx* c, SampleArgs& a, int precision) {
     if (precision < 3) { a.wstream = c->den_w[precision]; a.wave_units = c->den_wave_units[precision]; }
     a.wave_units_a = c->den_w8_units[0]; a.wave_units_b = c->den_w8_units[1];
@@ -458,37 +445,18 @@ hipError_t dispatch_sample(amuse_ctx* c, SampleArgs& a, int precision, hipStream
     return launch_sample(a, precision, st);
 }
 
-// decode path choice: the fused per-clip kernel (bf16 / fp16 modes) occupies one CU per clip, so it wins once there are enough
-// clips to fill a good part of the chip; below that the staged path's 19 workgroups per clip finish sooner.
-// AMUSE_VAE_FUSED=0 / 1 forces the staged / fused path (A/B measurements, tests of both paths).
-constexpr int kFusedMinClips = 64;   // measured (profiles/r03_decode_perf.txt): fused 0.61 ms for any B <= 128; staged 0.51 ms at 32 clips, 0.66 ms at 64, 1.07 ms at 128
+// decode / encode kernels of a call: the pin (amuse_set_decode_path) or the plan (amuse_host.hpp plan_decode_path / plan_encode_path), recorded for amuse_debug_last_plan
 constexpr int kVaeFusedChunk = 4096;
-bool use_vae_fused(const amuse_ctx* c, int precision, int B) {
-    static const int env = [] { const char* e = getenv("AMUSE_VAE_FUSED"); return e ? atoi(e) : -1; }();
-    const int force = c->decode_path == AMUSE_DECODE_STAGED ? 0 : (c->decode_path == AMUSE_DECODE_FUSED || c->decode_path == AMUSE_DECODE_CLIP) ? 1 : env;
-    if (!is_op16(precision) || force == 0) return false;   // (the fused kernel exists in the two one-piece 16-bit formats)
-    return force == 1 || B >= kFusedMinClips;
+int decode_path_of(amuse_ctx* c, int precision, int B) {
+    int path = resolve_path(c->decode_path, plan_decode_path(precision, B), precision);
+    if (path == AMUSE_DECODE_CLIP && !c->vae_wfx) path = AMUSE_DECODE_FUSED;
+    return c->last_plan[1] = path;
 }
-
-// fp32x decode: the no-split-K row kernel (k_vae_rows8.hip) under the same rule and the same pins as the fused kernel of the 16-bit modes
-bool use_rows8(const amuse_ctx* c, int precision, int B) {
-    static const int env = [] { const char* e = getenv("AMUSE_VAE_FUSED"); return e ? atoi(e) : -1; }();
-    const int force = c->decode_path == AMUSE_DECODE_STAGED ? 0 : (c->decode_path == AMUSE_DECODE_FUSED || c->decode_path == AMUSE_DECODE_CLIP) ? 1 : env;
-    if (precision != PREC_F16X2 || force == 0) return false;
-    return force == 1 || B >= kFusedMinClips;
-}
-
-// fp32x decode, third kernel: one persistent workgroup per clip (k_vae_fusedx.hip).  A clip takes ~1.5 ms on its CU whatever the batch, so the kernel wins when the call's
-// clips fill rounds of the chip's 256 CUs - measured against the row / attention launches (profiles/r05_fusedx_decode.txt, ms at 160 / 256 / 384 / 512 / 768 / 1024 clips:
-// 1.49 1.65 3.05 3.18 4.76 6.32 against 1.67 1.86 2.84 3.88 5.81 7.75): from 160 clips in the first round, and in round r >= 2 when at least 164 - 50 (r - 2) clips are in it.
-// amuse_amd/shard.py fusedx_rule is the same function (a sharded job pins the whole job's choice: AMUSE_DECODE_CLIP).  AMUSE_VAE_FUSEDX=0 / 1: never / whenever rows8 would run.
-// (fusedx_rule itself: amuse_host.hpp - the pose-space Denoiser step uses it too)
-bool use_fusedx(const amuse_ctx* c, int precision, int B) {
-    static const int env = [] { const char* e = getenv("AMUSE_VAE_FUSEDX"); return e ? atoi(e) : -1; }();
-    if (precision != PREC_F16X2 || !c->vae_wfx) return false;
-    if (c->decode_path == AMUSE_DECODE_CLIP) return true;
-    if (c->decode_path != AMUSE_DECODE_AUTO || env == 0) return false;
-    return env == 1 ? B >= kFusedMinClips : fusedx_rule(B);
+int encode_path_of(amuse_ctx* c, int precision, int B) {
+    int path = precision == AMUSE_PREC_F32X ? resolve_path(c->decode_path, plan_encode_path(precision, B), precision) : AMUSE_DECODE_STAGED;
+    if (path == AMUSE_DECODE_CLIP && !c->vaee_wfx) path = AMUSE_DECODE_FUSED;
+    if (path == AMUSE_DECODE_FUSED && !c->vaee_w8x) path = AMUSE_DECODE_STAGED;
+    return c->last_plan[2] = path;
 }
 
 int stage_lengths(amuse_ctx* c, const int* lengths, int B, hipStream_t st) {
@@ -523,13 +491,6 @@ int check_common(amuse_ctx* c, const float* con, int B, int precision) {
     HIP_TRY(hipSetDevice(c->device));
     return 0;
 }
-// fp32x jobs decode / encode on the PREC_F16X2 instantiations of the staged kernels (k_vae.hip); AMUSE_F32X_DECODE=fp32 sends
-// them to the fp32 kernels instead (A/B measurements)
-int prior_precision(int precision) {
-    static const bool f32 = [] { const char* e = getenv("AMUSE_F32X_DECODE"); return e && std::string(e) == "fp32"; }();
-    return (precision == AMUSE_PREC_F32X && f32) ? AMUSE_PREC_F32 : precision;
-}
-
 }  // namespace
 
 extern "C" {
@@ -737,6 +698,27 @@ int amuse_set_decode_path(amuse_ctx* c, int path) {
     return 0;
 }
 
+int amuse_plan(int arch, int precision, int clips_total, int tokens, int* clips_per_group, int* decode_path, int* encode_path, int* step_path) {
+    if (arch < AMUSE_ARCH_ENC || arch > AMUSE_ARCH_DEC_POSE) return fail(AMUSE_EINVAL, "bad arch %d", arch);
+    if (precision < AMUSE_PREC_F32 || precision > AMUSE_PREC_F16) return fail(AMUSE_EINVAL, "bad precision %d", precision);
+    if (clips_total < 1) return fail(AMUSE_EINVAL, "clips_total must be >= 1, got %d", clips_total);
+    if (tokens < 3 || tokens > 5) return fail(AMUSE_EINVAL, "tokens must be 3..5 (latent + time + content [+ emotion] [+ style]), got %d", tokens);
+    if (clips_per_group) *clips_per_group = plan_clips_per_group(arch, clips_total, tokens);
+    if (decode_path) *decode_path = plan_decode_path(precision, clips_total);
+    if (encode_path) *encode_path = plan_encode_path(precision, clips_total);
+    if (step_path) *step_path = plan_step_path(arch, precision, clips_total);
+    return 0;
+}
+
+int amuse_debug_last_plan(const amuse_ctx* c, int* clips_per_group, int* decode_path, int* encode_path, int* step_path) {
+    if (!c) return fail(AMUSE_EINVAL, "ctx is NULL");
+    if (clips_per_group) *clips_per_group = c->last_plan[0];
+    if (decode_path) *decode_path = c->last_plan[1];
+    if (encode_path) *encode_path = c->last_plan[2];
+    if (step_path) *step_path = c->last_plan[3];
+    return 0;
+}
+
 int amuse_debug_set_decode_tap(amuse_ctx* c, float* tap_out) {
     if (!c) return fail(AMUSE_EINVAL, "ctx is NULL");
     c->decode_tap = tap_out;
@@ -912,13 +894,13 @@ int amuse_vae_decode(amuse_ctx* c, const float* z, const int* lengths, int B, in
     if (!c->has_prior) return fail(AMUSE_ESTATE, "this context was created without MotionPrior weights");
     if (!z) return fail(AMUSE_EINVAL, "z is NULL");
     if (B < 1) return fail(AMUSE_EINVAL, "B must be >= 1, got %d", B);
-    precision = prior_precision(precision);
     if (precision < AMUSE_PREC_F32 || precision > AMUSE_PREC_F16) return fail(AMUSE_EINVAL, "bad precision %d", precision);
     if (quat_mode != AMUSE_QUAT_P3D && quat_mode != AMUSE_QUAT_LEGACY) return fail(AMUSE_EINVAL, "bad quat_mode %d", quat_mode);
     HIP_TRY(hipSetDevice(c->device));
     hipStream_t st = (hipStream_t)stream;
     if (int e = stage_lengths(c, lengths, B, st)) return e;
-    if (use_vae_fused(c, precision, B)) {
+    const int path = decode_path_of(c, precision, B);
+    if (is_op16(precision) && path != AMUSE_DECODE_STAGED) {
         // bf16 / fp16 throughput modes from kFusedMinClips clips up: one persistent workgroup per clip (k_vae_fused.hip)
         const int chunk = B < kVaeFusedChunk ? B : kVaeFusedChunk;
         if (c->vae_skip_cap < (size_t)chunk) {
@@ -929,11 +911,10 @@ int amuse_vae_decode(amuse_ctx* c, const float* z, const int* lengths, int B, in
         }
         if (int e = ensure(&c->vae_ca_ws, &c->vae_ca_cap, (size_t)chunk * kLayers * kD + 256)) return e;   // + the DMA's overrun
         // Block 0's self-attention half does not depend on the latent (k_vae_fused.hip / amuse_fused.hpp decoder_block, c1): computed once
-        // per weight set by the kernel's own tapped instantiation on one clip, stream-ordered in front of the first decode that uses it.
-        // AMUSE_VAE_HOIST=0 switches the hoist off (A/B: same bits, block 0 recomputed per clip).
-        static const bool hoist_on = [] { const char* e = getenv("AMUSE_VAE_HOIST"); return !(e && atoi(e) == 0); }();
+        // per weight set by the kernel's own tapped instantiation on one clip, stream-ordered in front of the first decode that uses it
+        // (the same bits as recomputing block 0 per clip: profiles/r04_decode_hoist_ab.txt).
         const int pi = precision == PREC_F16 ? 1 : 0;
-        if (hoist_on && !c->vae_c1_valid[pi] && !c->decode_tap && !(c->ablate & 1)) {
+        if (!c->vae_c1_valid[pi] && !c->decode_tap && !(c->ablate & 1)) {
             constexpr size_t kTapFloats = (size_t)11 * kFrames * kD;
             if (!c->vae_c1[pi]) HIP_TRY(hipMalloc((void**)&c->vae_c1[pi], ((size_t)kFrames * kD + kTapFloats) * sizeof(float)));
             float* tap = c->vae_c1[pi] + (size_t)kFrames * kD;
@@ -946,7 +927,7 @@ int amuse_vae_decode(amuse_ctx* c, const float* z, const int* lengths, int B, in
             HIP_TRY(c1_produced(c, pi, st));
             c->vae_c1_valid[pi] = true;
         }
-        if (hoist_on && c->vae_c1_valid[pi]) HIP_TRY(c1_consumed(c, pi, st));
+        if (c->vae_c1_valid[pi]) HIP_TRY(c1_consumed(c, pi, st));
         for (int b0 = 0; b0 < B; b0 += chunk) {
             const int nb = (B - b0) < chunk ? (B - b0) : chunk;
             HIP_TRY(launch_vae_ca(z + (size_t)b0 * kD, c->vae_wv_t, c->vae_bv, c->vae_wo_t, c->vae_bo, c->vae_ca_ws, nb, st));
@@ -958,7 +939,7 @@ int amuse_vae_decode(amuse_ctx* c, const float* z, const int* lengths, int B, in
             fa.trans_out = trans_out ? trans_out + (size_t)b0 * kFrames * 3 : nullptr;
             fa.B = nb; fa.quat_mode = quat_mode;
             fa.tap_out = b0 == 0 ? c->decode_tap : nullptr;   // (amuse_debug_set_decode_tap: tests)
-            fa.c1 = (hoist_on && c->vae_c1_valid[pi] && !fa.tap_out) ? c->vae_c1[pi] : nullptr;
+            fa.c1 = (c->vae_c1_valid[pi] && !fa.tap_out) ? c->vae_c1[pi] : nullptr;
             fa.ablate_attention = c->ablate & 1;
             HIP_TRY(precision == PREC_F16 ? launch_vae_fusedh(fa, st) : launch_vae_fused(fa, st));
         }
@@ -992,18 +973,16 @@ int amuse_vae_decode(amuse_ctx* c, const float* z, const int* lengths, int B, in
         HIP_TRY(launch_vae_ca(z + (size_t)b0 * kD, c->vae_wv_t, c->vae_bv, c->vae_wo_t, c->vae_bo, ca, nb, st));
         VaeAttnArgs aa{};
         aa.q = ra.q; aa.k = ra.k; aa.v = ra.v; aa.lengths = ra.lengths; aa.o = attn_o; aa.B = nb; aa.q_tiles = 19;
-        // fp32x: the row stages without split-K (k_vae_rows8.hip) under the rule of the 16-bit modes' fused kernel - from kFusedMinClips clips
-        // of the CALL (not of the chunk: a job's last chunk must not change kernels), or as amuse_set_decode_path / AMUSE_VAE_FUSED pin it
-        // (FUSED = this kernel, STAGED = k_vae_rows<f16x2>), so that amuse_amd/shard.py's job-level choice keeps fp32x shards bitwise too
-        const bool rows8 = use_rows8(c, precision, B);
-        // the fp32x decode as ONE persistent workgroup per clip (k_vae_fusedx.hip) where the call's clips fill rounds of the chip (use_fusedx above; keyed by the CALL's clip
-        // count like the other choices); its scratch arrays are this path's attn_o and skip
-        if (use_fusedx(c, precision, B)) {
+        // fp32x: the row stages without split-K (k_vae_rows8.hip; FUSED) or the split-K row kernel k_vae_rows<f16x2> (STAGED), chosen from the clips of the CALL (not of the
+        // chunk: a job's last chunk must not change kernels) or as amuse_set_decode_path pins it, so that a job-level choice (amuse_plan) keeps fp32x shards bitwise too
+        const bool rows8 = precision == PREC_F16X2 && path != AMUSE_DECODE_STAGED;
+        // the fp32x decode as ONE persistent workgroup per clip (k_vae_fusedx.hip; CLIP) where the call's clips fill rounds of the chip; its scratch arrays are this path's
+        // attn_o and skip
+        if (precision == PREC_F16X2 && path == AMUSE_DECODE_CLIP) {
             // block 0's self-attention half is one [300][128] constant per weight set for full-length clips (the decoder's queries are the positional table): computed
             // once by THIS kernel on one clip (c1_out: the same instruction stream, the same bits), then every full-length clip starts behind norm1 and the kernel's
-            // weight stream behind block 0's sixteen attention stages.  Explicit lengths take the full path; AMUSE_VAE_HOIST=0 = off.
-            static const bool hoistx_on = [] { const char* e = getenv("AMUSE_VAE_HOIST"); return !(e && atoi(e) == 0); }();
-            const bool hoistx = hoistx_on && !lengths && !c->decode_tap;
+            // weight stream behind block 0's sixteen attention stages.  Explicit lengths take the full path.
+            const bool hoistx = !lengths && !c->decode_tap;
             if (hoistx && !c->vae_c1_valid[3]) {
                 if (!c->vae_c1[3]) HIP_TRY(hipMalloc((void**)&c->vae_c1[3], (size_t)kFrames * kD * sizeof(float)));
                 VaeFusedXArgs px{};
@@ -1030,9 +1009,8 @@ int amuse_vae_decode(amuse_ctx* c, const float* z, const int* lengths, int B, in
         }
         // fp32x row stages, all clips full length: block 0's self-attention half is one [300][128] constant per weight set (see the fused
         // path above) - computed once by these kernels themselves on one clip (a tile's arithmetic does not depend on its launch: same bits),
-        // then every decode starts at stage 1 behind norm1.  Explicit lengths (even all 300) take the full path; AMUSE_VAE_HOIST=0 = off.
-        static const bool hoist8_on = [] { const char* e = getenv("AMUSE_VAE_HOIST"); return !(e && atoi(e) == 0); }();
-        const bool hoist8 = rows8 && hoist8_on && !lengths;
+        // then every decode starts at stage 1 behind norm1.  Explicit lengths (even all 300) take the full path.
+        const bool hoist8 = rows8 && !lengths;
         if (hoist8 && !c->vae_c1_valid[2]) {
             if (!c->vae_c1[2]) HIP_TRY(hipMalloc((void**)&c->vae_c1[2], (size_t)kFrames * kD * sizeof(float)));
             VaeRowsArgs p8 = r8;
@@ -1066,7 +1044,6 @@ int amuse_vae_encode(amuse_ctx* c, const float* feats, const int* lengths, int B
     if (!feats) return fail(AMUSE_EINVAL, "feats is NULL");
     if (!mu_out && !std_out && !latent_out) return fail(AMUSE_EINVAL, "no output requested");
     if (B < 1) return fail(AMUSE_EINVAL, "B must be >= 1, got %d", B);
-    precision = prior_precision(precision);
     if (precision < AMUSE_PREC_F32 || precision > AMUSE_PREC_F16) return fail(AMUSE_EINVAL, "bad precision %d", precision);
     HIP_TRY(hipSetDevice(c->device));
     hipStream_t st = (hipStream_t)stream;
@@ -1096,8 +1073,9 @@ int amuse_vae_encode(amuse_ctx* c, const float* feats, const int* lengths, int B
         VaeAttnArgs aa{};
         aa.q = ra.q; aa.k = ra.k; aa.v = ra.v; aa.lengths = ra.lengths; aa.o = attn_o; aa.B = nb;
         // fp32x from kFusedMinClips clips of the call (or as amuse_set_decode_path pins it - the decode's rule): stages 1..9 on the row kernel without split-K
-        const bool rows8 = use_rows8(c, precision, B) && c->vaee_w8x != nullptr;
-        if (rows8 && c->vaee_wfx && use_fusedx(c, precision, B)) {   // (the decode's rule and pins) the whole encoder as one persistent workgroup per clip
+        const int epath = encode_path_of(c, precision, B);
+        const bool rows8 = epath != AMUSE_DECODE_STAGED;
+        if (epath == AMUSE_DECODE_CLIP) {   // (the decode's rule and pins) the whole encoder as one persistent workgroup per clip
             DenFusedXArgs fx{};
             fx.wstream = c->vaee_wfx; fx.pvec = c->vaee_pvec; fx.emb_bias = c->vaee_emb_bias; fx.pe = c->vaee_pe; fx.ttok = c->vaee_tok;
             fx.x_in = ra.enc_feats; fx.eps_out = ra.stats_out; fx.lengths = ra.lengths; fx.obuf = attn_o; fx.skip = ra.skip;

@@ -156,31 +156,13 @@ __device__ __forceinline__ const uint4* gemm_tiles(f32x4 (&acc)[NO], const f32x4
 // its first R units are replicated after its end, so the wrap at a step boundary needs no special case).
 // hipcc left to itself serialises this kernel's loads (global_load -> s_waitcnt vmcnt(0) -> v_mfma,
 // one L2 round trip per KiB); the ring is what turns the loop from latency- into bandwidth-bound.
-// stream loads: every CU reads every line exactly once per step -> non-temporal (no L1 retention)
-#ifndef AMUSE_STREAM_NT
-#define AMUSE_STREAM_NT 0
-#endif
+// Stream loads are plain loads: non-temporal ones (whole stream, or only the `lo` units of a split-fp16 stream so that the `hi` half alone
+// competes for an XCD's 4 MB L2) measured SLOWER (profiles/r04_fp32x_lo_nt_ab.txt) - a non-temporal line is not kept for the XCD's other 31
+// CUs, which then fetch it over the fabric themselves.
 __device__ __forceinline__ uint4 ldw(const uint4* p) {
-#if AMUSE_STREAM_NT
-    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-    return __builtin_bit_cast(uint4, __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p)));
-#else
     return *p;
-#endif
 }
-// -DAMUSE_LO_NT=1 (A/B, k_sampler8x.hip only): the `lo` units of a split-fp16 stream (odd stream positions) are loaded non-temporally, so
-// that only the `hi` half (3.8 MB) competes for an XCD's 4 MB L2 - measured SLOWER (profiles/r04_fp32x_lo_nt_ab.txt): a non-temporal line is
-// not kept for the XCD's other 31 CUs, which then fetch it over the fabric themselves
-#ifndef AMUSE_LO_NT
-#define AMUSE_LO_NT 0
-#endif
 __device__ __forceinline__ uint4 ldw_pos(const uint4* p, int pos) {
-#if AMUSE_LO_NT
-    if (pos & 1) {
-        typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-        return __builtin_bit_cast(uint4, __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p)));
-    }
-#endif
     return ldw(p);
 }
 template <int R>
@@ -437,11 +419,8 @@ __device__ __forceinline__ float gelu_erf_bf(float x) { return 0.5f * x * (1.0f 
 // point pinned to 1, |erf error| <= 8.7e-5) - an odd function, so no abs / sign handling.  No transcendental:
 // v_med3 + mul / fma, which hipcc packs two floats at a time (v_pk_fma_f32) - 6.5 issue slots per element against
 // about 17 for gelu_erf_fast.  |GELU error| <= 1.9e-4 absolute, <= 0.33 bf16 ulp for x in [-2, 4].
-// -DAMUSE_GELU_SCALAR=1: the same polynomial on four scalar chains (v_fma_f32 instead of v_pk_fma_f32; needs -fno-slp-vectorize
-// to stay scalar) - the A/B the microarchitecture guide's "packed f32 beside MFMAs is an anti-lever" asks for
-#ifndef AMUSE_GELU_SCALAR
-#define AMUSE_GELU_SCALAR 0
-#endif
+// (The same polynomial on four scalar chains - v_fma_f32 instead of v_pk_fma_f32, the A/B the microarchitecture guide's "packed f32 beside
+// MFMAs is an anti-lever" asks for - measured no faster: profiles/r03_k_sample8_packed_f32_ab.txt, r05_k_sample8_noslp_ab.txt.)
 __device__ __forceinline__ float gelu_poly1(float x) {
     constexpr float X0 = 4.24264068711928514641f;
     const float a = __builtin_amdgcn_fmed3f(x, -X0, X0), s = a * a;
@@ -457,9 +436,6 @@ __device__ __forceinline__ float gelu_poly1(float x) {
     return fmaf(hx, a * p, hx);
 }
 __device__ __forceinline__ f32x4 gelu_poly4(f32x4 x) {
-#if AMUSE_GELU_SCALAR
-    return f32x4{gelu_poly1(x[0]), gelu_poly1(x[1]), gelu_poly1(x[2]), gelu_poly1(x[3])};
-#endif
     constexpr float X0 = 4.24264068711928514641f;
     f32x4 a;
 #pragma unroll

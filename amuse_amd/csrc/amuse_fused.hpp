@@ -31,12 +31,8 @@
 namespace amuse {
 namespace {
 
-// 1 = the skip stack (78 MB each way at 256 clips, written once and read once 0.1 - 0.5 ms later) goes around the caches with non-temporal
-// stores / loads (A/B; profiles/r04_decode_skip_nt_ab.txt)
-#ifndef AMUSE_F_SKIP_NT
-#define AMUSE_F_SKIP_NT 0
-#endif
-typedef unsigned int u32x4n __attribute__((ext_vector_type(4)));   // (the nontemporal builtins take native vectors)
+// (The skip stack - 78 MB each way at 256 clips, written once and read once 0.1 - 0.5 ms later - goes through the caches: non-temporal
+// stores / loads measured flat, profiles/r04_decode_skip_nt_ab.txt.)
 constexpr int kWaves = 8;
 constexpr int kKeyRows = 320;             // 300 keys padded to 20 tiles
 constexpr int kPairs = kKeyRows / 32;     // 10 key-tile pairs
@@ -61,32 +57,13 @@ constexpr int kOffFinalPar = kOffFinalStage + kWaves * 16 * kQStride * 4;
 constexpr int kFusedFinalLdsBytes = kOffFinalPar + (384 + 2 * kD) * 4;   // 152,064 B
 static_assert(kFusedFinalLdsBytes >= kVaeFusedLdsBytes && kFusedFinalLdsBytes <= 160 * 1024, "LDS");
 
-// ablation switches for timing experiments (tools/build_variant.sh): 2 no attention, 4 no FFN arithmetic,
-// 8 no softmax arithmetic (scores fed to PV as they are), 16 no output stores (k_vae_fused), 32 no skip-stack stores.  0 in the product.
-#ifndef AMUSE_FABL
-#define AMUSE_FABL 0
-#endif
 // -DAMUSE_FPROF=1 (variant builds only): wave 0 of workgroup 0 stamps s_memtime at phase boundaries of blocks 1 and 6 and
 // OP_LAUNCH prints the deltas (tools/gpu_decode_phases.py)
 #ifndef AMUSE_FPROF
 #define AMUSE_FPROF 0
 #endif
 // weight fragments are read from the LDS ring this many units ahead of their MFMAs
-#ifndef AMUSE_F_PF
-#define AMUSE_F_PF 2
-#endif
-// FFN stage scheduling (A/B): 0 as hipcc orders it; bit 0: linear1's MFMAs interleaved with the GELU; bit 1: the 2-tile waves run
-// linear1 last
-#ifndef AMUSE_F_FFN_MIX
-#define AMUSE_F_FFN_MIX 0
-#endif
-#ifndef AMUSE_F_FFN_VALU
-#define AMUSE_F_FFN_VALU 9
-#endif
-// 1: the LayerNorms unrolled over a wave's tiles instead of a runtime loop with rotating registers (A/B)
-#ifndef AMUSE_F_LN_UNROLL
-#define AMUSE_F_LN_UNROLL 0
-#endif
+constexpr int kFragAhead = 2;
 #if AMUSE_FPROF
 __device__ unsigned long long g_fprof[512];
 __device__ int g_fprof_n;
@@ -140,12 +117,12 @@ __device__ __forceinline__ OPV wfrag(const Stager& s, int u) {
     return __builtin_bit_cast(OPV, *reinterpret_cast<const uint4*>(s.ring + s.ridx * kStageBytes + u * 1024));
 }
 
-// f(u, fragment) for the units U0 .. U0 + NU - 1 of the current stage, the fragments read AMUSE_F_PF units ahead of their use.
+// f(u, fragment) for the units U0 .. U0 + NU - 1 of the current stage, the fragments read kFragAhead units ahead of their use.
 // (Left to hipcc, a unit loop recycles ONE fragment register: read, wait for the whole LDS round trip, MFMAs, next read - the
 // k,v stage ran at a third of its MFMA rate that way.)
 template <int NU, int U0, class F>
 __device__ __forceinline__ void for_units(const Stager& s, F&& f) {
-    constexpr int PF = AMUSE_F_PF < NU ? AMUSE_F_PF : NU;
+    constexpr int PF = kFragAhead < NU ? kFragAhead : NU;
     OPV wf[PF];
 #pragma unroll
     for (int u = 0; u < PF; ++u) wf[u] = wfrag(s, U0 + u);
@@ -161,7 +138,7 @@ __device__ __forceinline__ void for_units(const Stager& s, F&& f) {
 template <int NT, int NO, int NC, int U0>
 __device__ __forceinline__ void gemm5(f32x4 (&acc)[NT][NO], const OPV (&xb)[NT][NC], const Stager& s) {
     // fragments are read two ahead of their MFMAs (a read waited for on the spot costs an LDS round trip per unit)
-    constexpr int NU = NO * NC, PF = AMUSE_F_PF;
+    constexpr int NU = NO * NC, PF = kFragAhead;
     OPV wf[NU < PF ? NU : PF];
 #pragma unroll
     for (int u = 0; u < PF && u < NU; ++u) wf[u] = wfrag(s, U0 + u);
@@ -212,104 +189,9 @@ __device__ __forceinline__ float max3(float a, float b, float c) { return fmaxf(
 // too scarce (x + xb of three tiles = 144 of 256) for hipcc to hoist the reads itself.  So a chunk's four K fragments are
 // read as ONE batch in front of its four score MFMAs, and its four V^T fragments as one batch right behind them - they
 // land while the softmax arithmetic runs.
-#ifndef AMUSE_F_ATTN_PIPE
-#define AMUSE_F_ATTN_PIPE 0
-#endif
-#if AMUSE_F_ATTN_PIPE
-// (-DAMUSE_F_ATTN_PIPE=1, A/B only: bitwise the same outputs, NOT faster - 0.759 -> 0.753 ms per 256-clip decode, inside the noise,
-// profiles/r04_fused_attention_ablation.txt: the loop is bound by the exponentials' issue time, not by the hand-overs this removes.)
-// Software-pipelined over the chunks.  A wave issues in order, so in the plain loop below every chunk starts with four ds_reads and
-// four score MFMAs that wait for them, and the softmax arithmetic behind them waits for the MFMAs: LDS latency + MFMA latency in
-// series with the VALU phase, and the SIMD's other wave - in lock step since the last barrier - is in the same phase.  Here chunk
-// c + 1's K fragments are read at the top of chunk c, its score MFMAs are issued BEHIND chunk c's maximum (they take the updated
-// running maximum as C operand) and IN FRONT of chunk c's exponentials, under which they execute; chunk c's PV MFMAs run under the
-// reads and the maximum of chunk c + 1.
 template <bool NOATTN = false>
 __device__ __forceinline__ OPV attend(const uint4* Kb, const uint4* Vt, OPV qb, int len, int g, int r) {
-    if constexpr (NOATTN || (AMUSE_FABL & 2) != 0) return qb;
-    const int fs = frag_slot(g, r);
-    float m_run = 0.f;
-    f32x4 o[2] = {splat4(0.f), splat4(0.f)};
-    const OPV ones = __builtin_bit_cast(OPV, r == 0 ? uint4{OP_ONE2, OP_ONE2, OP_ONE2, OP_ONE2} : uint4{0u, 0u, 0u, 0u});
-    f32x4 os = splat4(0.f);
-    f32x4 st[4];
-    {
-        uint4 kf[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) kf[i] = Kb[i * 64 + fs];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) st[i] = OP_MFMA(__builtin_bit_cast(OPV, kf[i]), qb, splat4(0.f));
-    }
-#pragma unroll
-    for (int ch = 0; ch < kPairs / 2; ++ch) {
-        constexpr int kLast = kPairs / 2 - 1;
-        uint4 kf[4], vf[4];
-        if (ch < kLast) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) kf[i] = Kb[(4 * (ch + 1) + i) * 64 + fs];
-        }
-#pragma unroll
-        for (int i = 0; i < 4; ++i) vf[i] = Vt[(4 * ch + i) * 64 + fs];   // (pair, td) = (2 ch + i / 2, i % 2)
-        __builtin_amdgcn_sched_barrier(0);
-        const int k0 = 64 * ch;
-        if (k0 + 64 > len) {
-            int lim = len - k0 - 4 * g;   // element (i, m) of the chunk is valid iff 16 i + m < lim
-            asm volatile("" : "+v"(lim));
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int m = 0; m < 4; ++m) st[i][m] = (16 * i + m < lim) ? st[i][m] : -INFINITY;
-        }
-        float mx = max3(max3(st[0][0], st[0][1], st[0][2]), max3(st[0][3], st[1][0], st[1][1]), max3(st[1][2], st[1][3], st[2][0]));
-        mx = max3(mx, max3(st[2][1], st[2][2], st[2][3]), max3(st[3][0], st[3][1], st[3][2]));
-        mx = fmaxf(mx, st[3][3]);
-        if (ch == 0 || __builtin_amdgcn_ballot_w64(mx > 0.f) != 0) {   // (wave-uniform)
-            mx = allreduce_g_max(mx);
-            const float d = ch == 0 ? mx : fmaxf(mx, 0.f);
-#pragma unroll
-            for (int i = 0; i < 4; ++i) st[i] -= splat4(d);
-            if (ch > 0) {
-                const float alpha = __builtin_amdgcn_exp2f(-d);
-                os *= alpha;
-                o[0] *= alpha;
-                o[1] *= alpha;
-            }
-            m_run += d;
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        f32x4 stn[4];
-        if (ch < kLast) {
-            const f32x4 c0 = splat4(-m_run);
-#pragma unroll
-            for (int i = 0; i < 4; ++i) stn[i] = OP_MFMA(__builtin_bit_cast(OPV, kf[i]), qb, c0);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        f32x4 p[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const bool beyond = 64 * ch + 16 * i >= kFrames;
-#pragma unroll
-            for (int m = 0; m < 4; ++m) p[i][m] = beyond ? 0.f : __builtin_amdgcn_exp2f(st[i][m]);
-        }
-#pragma unroll
-        for (int pr = 0; pr < 2; ++pr) {
-            const OPV pb = OP_PACK(p[2 * pr], p[2 * pr + 1]);
-            o[0] = OP_MFMA(__builtin_bit_cast(OPV, vf[2 * pr]), pb, o[0]);
-            o[1] = OP_MFMA(__builtin_bit_cast(OPV, vf[2 * pr + 1]), pb, o[1]);
-            os = OP_MFMA(ones, pb, os);
-        }
-        if (ch < kLast) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) st[i] = stn[i];
-        }
-    }
-    const float inv = __builtin_amdgcn_rcpf(allreduce_g_sum(os[0]));
-    return OP_PACK(o[0] * inv, o[1] * inv);
-}
-#else
-template <bool NOATTN = false>
-__device__ __forceinline__ OPV attend(const uint4* Kb, const uint4* Vt, OPV qb, int len, int g, int r) {
-    if constexpr (NOATTN || (AMUSE_FABL & 2) != 0) return qb;
+    if constexpr (NOATTN) return qb;
     const int fs = frag_slot(g, r);
     // Scores leave the MFMAs RELATIVE to the row's running maximum (C operand = -m_run; chunk 0 starts from 0 and takes its own
     // maximum - the sequence has at least one key), so in the common chunk - the maximum did not move for any row of the wave -
@@ -375,8 +257,7 @@ __device__ __forceinline__ OPV attend(const uint4* Kb, const uint4* Vt, OPV qb, 
             const bool beyond = 64 * ch + 16 * i >= kFrames;
 #pragma unroll
             for (int m = 0; m < 4; ++m) {
-                if constexpr ((AMUSE_FABL & 8) != 0) p[i][m] = st[i][m];
-                else p[i][m] = beyond ? 0.f : __builtin_amdgcn_exp2f(st[i][m]);
+                p[i][m] = beyond ? 0.f : __builtin_amdgcn_exp2f(st[i][m]);
             }
         }
 #pragma unroll
@@ -389,96 +270,6 @@ __device__ __forceinline__ OPV attend(const uint4* Kb, const uint4* Vt, OPV qb, 
     }
     const float inv = __builtin_amdgcn_rcpf(allreduce_g_sum(os[0]));
     return OP_PACK(o[0] * inv, o[1] * inv);
-}
-
-
-#endif
-
-// -DAMUSE_F_ATTN_NQ2=1 (A/B; bitwise the same outputs): TWO query tiles of a wave per pass over the keys - a chunk's K / V^T fragments are read from LDS once for both,
-// and the in-order wave holds two independent score -> softmax -> PV chains.  Per tile the arithmetic is attend()'s; the "does any row maximum move" ballot is taken over
-// both tiles (a tile whose maxima stay put is shifted by 0 and rescaled by exp2(0) = 1: exact).
-#ifndef AMUSE_F_ATTN_NQ2
-#define AMUSE_F_ATTN_NQ2 0
-#endif
-template <bool NOATTN = false>
-__device__ __forceinline__ void attend2(const uint4* Kb, const uint4* Vt, OPV (&qo)[2], int len, int g, int r) {
-    if constexpr (NOATTN || (AMUSE_FABL & 2) != 0) return;
-    const int fs = frag_slot(g, r);
-    float m_run[2] = {0.f, 0.f};
-    f32x4 o[2][2] = {{splat4(0.f), splat4(0.f)}, {splat4(0.f), splat4(0.f)}};
-    const OPV ones = __builtin_bit_cast(OPV, r == 0 ? uint4{OP_ONE2, OP_ONE2, OP_ONE2, OP_ONE2} : uint4{0u, 0u, 0u, 0u});
-    f32x4 os[2] = {splat4(0.f), splat4(0.f)};
-#pragma unroll
-    for (int ch = 0; ch < kPairs / 2; ++ch) {
-        uint4 kf[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) kf[i] = Kb[(4 * ch + i) * 64 + fs];
-        f32x4 st[2][4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int n = 0; n < 2; ++n) st[n][i] = OP_MFMA(__builtin_bit_cast(OPV, kf[i]), qo[n], splat4(-m_run[n]));
-        uint4 vf[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) vf[i] = Vt[(4 * ch + i) * 64 + fs];
-        __builtin_amdgcn_sched_barrier(0);
-        const int k0 = 64 * ch;
-        if (k0 + 64 > len) {
-            int lim = len - k0 - 4 * g;
-            asm volatile("" : "+v"(lim));
-#pragma unroll
-            for (int n = 0; n < 2; ++n)
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-#pragma unroll
-                    for (int m = 0; m < 4; ++m) st[n][i][m] = (16 * i + m < lim) ? st[n][i][m] : -INFINITY;
-        }
-        float mx[2];
-#pragma unroll
-        for (int n = 0; n < 2; ++n) {
-            float a = max3(max3(st[n][0][0], st[n][0][1], st[n][0][2]), max3(st[n][0][3], st[n][1][0], st[n][1][1]), max3(st[n][1][2], st[n][1][3], st[n][2][0]));
-            a = max3(a, max3(st[n][2][1], st[n][2][2], st[n][2][3]), max3(st[n][3][0], st[n][3][1], st[n][3][2]));
-            mx[n] = fmaxf(a, st[n][3][3]);
-        }
-        if (ch == 0 || __builtin_amdgcn_ballot_w64(fmaxf(mx[0], mx[1]) > 0.f) != 0) {   // (wave-uniform)
-#pragma unroll
-            for (int n = 0; n < 2; ++n) {
-                const float mr = allreduce_g_max(mx[n]);
-                const float d = ch == 0 ? mr : fmaxf(mr, 0.f);
-#pragma unroll
-                for (int i = 0; i < 4; ++i) st[n][i] -= splat4(d);
-                if (ch > 0) {
-                    const float alpha = __builtin_amdgcn_exp2f(-d);
-                    os[n] *= alpha;
-                    o[n][0] *= alpha;
-                    o[n][1] *= alpha;
-                }
-                m_run[n] += d;
-            }
-        }
-#pragma unroll
-        for (int n = 0; n < 2; ++n) {
-            f32x4 p[4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const bool beyond = 64 * ch + 16 * i >= kFrames;
-#pragma unroll
-                for (int m = 0; m < 4; ++m) p[i][m] = beyond ? 0.f : __builtin_amdgcn_exp2f(st[n][i][m]);
-            }
-#pragma unroll
-            for (int pr = 0; pr < 2; ++pr) {
-                const OPV pb = OP_PACK(p[2 * pr], p[2 * pr + 1]);
-                o[n][0] = OP_MFMA(__builtin_bit_cast(OPV, vf[2 * pr]), pb, o[n][0]);
-                o[n][1] = OP_MFMA(__builtin_bit_cast(OPV, vf[2 * pr + 1]), pb, o[n][1]);
-                os[n] = OP_MFMA(ones, pb, os[n]);
-            }
-        }
-    }
-#pragma unroll
-    for (int n = 0; n < 2; ++n) {
-        const float inv = __builtin_amdgcn_rcpf(allreduce_g_sum(os[n][0]));
-        qo[n] = OP_PACK(o[n][0] * inv, o[n][1] * inv);
-    }
 }
 
 // MODE 0: input block (push the skip), 1: middle block, 2: output block (skip linear first)
@@ -525,11 +316,7 @@ __device__ __forceinline__ void decoder_block(f32x4 (&x)[NT][kTiles], Stager& sg
         for (int j = 0; j < NT; ++j)
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
-#if AMUSE_F_SKIP_NT
-                sb[j][c] = __builtin_bit_cast(OPV, __builtin_nontemporal_load(reinterpret_cast<const u32x4n*>(sk + ((tile0 + 4 * j) * 4 + c) * 64 + lane)));
-#else
                 sb[j][c] = __builtin_bit_cast(OPV, sk[((tile0 + 4 * j) * 4 + c) * 64 + lane]);
-#endif
             }
         pack_rows<NT>(xb, x);
         const float* bias = pvec_g + PV_SKIP_B + (blk - 5) * kD;
@@ -637,15 +424,6 @@ __device__ __forceinline__ void decoder_block(f32x4 (&x)[NT][kTiles], Stager& sg
         for (int j = 0; j < NT; ++j) ob[j][0] = qb[j];
         {
             const uint4* Vq = reinterpret_cast<const uint4*>(Vt);
-#if AMUSE_F_ATTN_NQ2
-            {   // tiles 0, 1 together (one pass over the keys), then - three-tile waves - tile 2 alone
-                OPV pair[2] = {ob[0][0], ob[1][0]};
-                attend2<NOATTN>(Kb, Vq, pair, len, g, r);
-                ob[0][0] = pair[0];
-                ob[1][0] = pair[1];
-                if constexpr (NT == 3) ob[2][0] = attend<NOATTN>(Kb, Vq, ob[2][0], len, g, r);
-            }
-#else
 #pragma unroll 1
             for (int j = 0; j < NT; ++j) {
                 const OPV o1 = attend<NOATTN>(Kb, Vq, ob[0][0], len, g, r);
@@ -653,7 +431,6 @@ __device__ __forceinline__ void decoder_block(f32x4 (&x)[NT][kTiles], Stager& sg
                 for (int jj = 0; jj + 1 < NT; ++jj) ob[jj][0] = ob[jj + 1][0];
                 ob[NT - 1][0] = o1;
             }
-#endif
             FSTAMP(7);   // attention of the five tiles
         }
         gemm5<NT, kTiles, 1, 8>(x, ob, sg);   // out_proj, k-slice of head h, accumulated into the residual
@@ -670,15 +447,6 @@ __device__ __forceinline__ void decoder_block(f32x4 (&x)[NT][kTiles], Stager& sg
             rotate_tiles<NT>(x);
         }
     } else {
-#if AMUSE_F_LN_UNROLL
-#pragma unroll
-    for (int j = 0; j < NT; ++j) {   // (A/B: unrolled over the tiles, no register rotation, NT copies of the code)
-        layer_norm_rows<true>(x[j], pv + PV_LN1_W, pv + PV_LN1_B, g);
-#pragma unroll
-        for (int t = 0; t < kTiles; ++t) x[j][t] += ld4(ca + 16 * t + 4 * g);
-        layer_norm_rows<true>(x[j], pv + PV_LN2_W, pv + PV_LN2_B, g);
-    }
-#else
 #pragma unroll 1
     for (int j = 0; j < NT; ++j) {   // runtime loop, the tiles rotate through x[0]
         if (!hoist) layer_norm_rows<true>(x[0], pv + PV_LN1_W, pv + PV_LN1_B, g);
@@ -695,7 +463,6 @@ __device__ __forceinline__ void decoder_block(f32x4 (&x)[NT][kTiles], Stager& sg
         layer_norm_rows<true>(x[0], pv + PV_LN2_W, pv + PV_LN2_B, g);
         rotate_tiles<NT>(x);
     }
-#endif
     }
     FSTAMP(10);   // norm1, cross-attention constant, norm2
     // ---------------- FFN (cross_attention.py:338-340): x = norm3(x + linear2(gelu(linear1(x)))), 16 chunks of 32 hidden
@@ -711,7 +478,7 @@ __device__ __forceinline__ void decoder_block(f32x4 (&x)[NT][kTiles], Stager& sg
         const f32x4 b0 = ld4(pv + PV_L1_B + 4 * g), b1 = ld4(pv + PV_L1_B + 16 + 4 * g);
 #pragma unroll
         for (int j = 0; j < NT; ++j) { hid[j][0] = b0; hid[j][1] = b1; }
-        if constexpr (!(AMUSE_FABL & 4)) gemm5<NT, 2, 4, 0>(hid, xb, sg);
+        gemm5<NT, 2, 4, 0>(hid, xb, sg);
         stage_end(sg);
         FSTAMP(11);   // FFN prologue stage
     }
@@ -723,38 +490,10 @@ __device__ __forceinline__ void decoder_block(f32x4 (&x)[NT][kTiles], Stager& sg
 #pragma unroll
         for (int j = 0; j < NT; ++j) { nxt[j][0] = b0; nxt[j][1] = b1; }
         OPV hb[NT][1];
-        if constexpr (!(AMUSE_FABL & 4)) {
-#if AMUSE_F_FFN_MIX
-            // The two waves of a SIMD run this stage in lock step (same barrier, same code): MFMA clusters of both, then the GELU
-            // VALU of both - the matrix pipe idles through one, the VALU through the other.  So (a) within a wave linear1's
-            // MFMAs (next chunk, independent of this chunk's GELU) are issued one at a time between groups of GELU VALU
-            // instructions, and (b) the 2-tile waves run the stage in the other order (GELU + linear2 first, linear1 last), which
-            // puts their MFMA cluster beside the 3-tile waves' VALU tail.
-            constexpr bool kL1Last = (AMUSE_F_FFN_MIX & 2) && NT == 2;
-            __builtin_amdgcn_sched_barrier(0);
-            if constexpr (!kL1Last) gemm5<NT, 2, 4, 0>(nxt, xb, sg);
+        gemm5<NT, 2, 4, 0>(nxt, xb, sg);   // linear1 of the next chunk: MFMAs that do not depend on ...
 #pragma unroll
-            for (int j = 0; j < NT; ++j) hb[j][0] = OP_PACK(OP_GELU(hid[j][0]), OP_GELU(hid[j][1]));
-            if constexpr (!kL1Last) {
-#pragma unroll
-                for (int i = 0; i < 8 * NT; ++i) {
-                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                  // 1 MFMA
-                    __builtin_amdgcn_sched_group_barrier(0x002, AMUSE_F_FFN_VALU, 0);   // its share of the GELU
-                }
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            gemm5<NT, kTiles, 1, 8>(x, hb, sg);
-            if constexpr (kL1Last) {
-                __builtin_amdgcn_sched_barrier(0);
-                gemm5<NT, 2, 4, 0>(nxt, xb, sg);
-            }
-#else
-            gemm5<NT, 2, 4, 0>(nxt, xb, sg);   // linear1 of the next chunk: MFMAs that do not depend on ...
-#pragma unroll
-            for (int j = 0; j < NT; ++j) hb[j][0] = OP_PACK(OP_GELU(hid[j][0]), OP_GELU(hid[j][1]));   // ... this VALU
-            gemm5<NT, kTiles, 1, 8>(x, hb, sg);
-#endif
-        }
+        for (int j = 0; j < NT; ++j) hb[j][0] = OP_PACK(OP_GELU(hid[j][0]), OP_GELU(hid[j][1]));   // ... this VALU
+        gemm5<NT, kTiles, 1, 8>(x, hb, sg);
 #pragma unroll
         for (int j = 0; j < NT; ++j) { hid[j][0] = nxt[j][0]; hid[j][1] = nxt[j][1]; }
         FSTAMP(12);   // FFN stage compute
@@ -764,38 +503,27 @@ __device__ __forceinline__ void decoder_block(f32x4 (&x)[NT][kTiles], Stager& sg
     {
         stage_fetch(sg);
         OPV hb[NT][1];
-        if constexpr (!(AMUSE_FABL & 4)) {
 #pragma unroll
-            for (int j = 0; j < NT; ++j) hb[j][0] = OP_PACK(OP_GELU(hid[j][0]), OP_GELU(hid[j][1]));
-            gemm5<NT, kTiles, 1, 0>(x, hb, sg);
-        }
+        for (int j = 0; j < NT; ++j) hb[j][0] = OP_PACK(OP_GELU(hid[j][0]), OP_GELU(hid[j][1]));
+        gemm5<NT, kTiles, 1, 0>(x, hb, sg);
         stage_end(sg);
     }
     FSTAMP(14);   // FFN epilogue stage
     constexpr int kLnW = ENCL ? PV_LN2_W : PV_LN3_W, kLnB = ENCL ? PV_LN2_B : PV_LN3_B;
-#if AMUSE_F_LN_UNROLL
-#pragma unroll
-    for (int j = 0; j < NT; ++j) layer_norm_rows<true>(x[j], pv + kLnW, pv + kLnB, g);
-#else
 #pragma unroll 1
     for (int j = 0; j < NT; ++j) {
         layer_norm_rows<true>(x[0], pv + kLnW, pv + kLnB, g);
         rotate_tiles<NT>(x);
     }
-#endif
     FSTAMP(15);   // norm3
-    if constexpr (MODE == 0 && (AMUSE_FABL & 32) == 0) {   // xs.append(x): packed operands of the skip linear that pops them  (FABL 32: timing ablation, no push)
+    if constexpr (MODE == 0) {   // xs.append(x): packed operands of the skip linear that pops them
         uint4* sk = skipbuf + (size_t)blk * (20 * 4 * 64);
 #pragma unroll
         for (int j = 0; j < NT; ++j)
 #pragma unroll
             for (int c = 0; c < 4; ++c)
             {
-#if AMUSE_F_SKIP_NT
-                __builtin_nontemporal_store(__builtin_bit_cast(u32x4n, OP_PACK(x[j][2 * c], x[j][2 * c + 1])), reinterpret_cast<u32x4n*>(sk + ((tile0 + 4 * j) * 4 + c) * 64 + lane));
-#else
                 sk[((tile0 + 4 * j) * 4 + c) * 64 + lane] = __builtin_bit_cast(uint4, OP_PACK(x[j][2 * c], x[j][2 * c + 1]));
-#endif
             }
     }
     if constexpr (TAP) {

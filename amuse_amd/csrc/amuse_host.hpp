@@ -280,12 +280,45 @@ std::vector<float> transpose(const float* w, int rows, int cols) {  // [rows][co
 }  // namespace
 
 struct amuse_variant;   // the Denoiser variants' streams and tables (amuse_variants.hip)
-// Do the clips of a call fill rounds of the chip's 256 CUs well enough for the fp32x per-clip kernels (k_vae_fusedx.hip)?  From 160 clips in the first round, in round
-// r >= 2 with at least 164 - 50 (r - 2) clips in it (measured: amuse_api.hip use_fusedx; amuse_amd/shard.py fusedx_rule is the same function)
-inline bool fusedx_rule(int B) {
+// ---- The launch plan: ONE statement of which kernels a job takes (exported as amuse_plan, include/amuse_hip.h; amuse_amd/shard.py and
+// tests/c_client call that - nothing restates these rules).  Every choice is keyed by the clip count of the CALL / the JOB, never of a chunk or a shard.
+constexpr int kFusedMinClips = 64;   // the per-clip 16-bit kernels occupy one CU per clip: they win once the clips fill a good part of the chip (profiles/r03_decode_perf.txt:
+                                     // fused 0.61 ms for any B <= 128; staged 0.51 ms at 32 clips, 0.66 ms at 64, 1.07 ms at 128)
+// Do the clips fill rounds of the chip's 256 CUs well enough for the fp32x per-clip kernels (k_vae_fusedx.hip)?  A clip takes ~1.5 ms on its CU whatever the batch: from 160
+// clips in the first round, in round r >= 2 with at least 164 - 50 (r - 2) clips in it (profiles/r05_fusedx_decode.txt, ms at 160 / 256 / 384 / 512 / 768 / 1024 clips:
+// 1.49 1.65 3.05 3.18 4.76 6.32 against 1.67 1.86 2.84 3.88 5.81 7.75 on the row / attention launches)
+inline bool fills_rounds(int B) {
     if (B < 160) return false;
     const int r = (B + 255) / 256, in_last = B - 256 * (r - 1);
     return r == 1 || in_last >= 164 - 50 * (r - 2);
+}
+// clips per 16-row tile of the latent trans_enc sampler (k_sampler*.hip); the other Denoiser variants have no such choice (1).  One clip per tile up to 128 clips, then fatter
+// tiles: a step costs the same for 1..16/tokens clips per tile, and 128 busy CUs run it 6-7 % faster than 256 - with every CU re-streaming the whole network each step the
+// 256-workgroup launch sits at the L2's delivery limit (profiles/r01_batch_sweep.txt: 256 clips 36.0 ms with one clip per tile, 33.6 ms with two or three).
+inline int plan_clips_per_group(int arch, int B, int tokens) {
+    if (arch != AMUSE_ARCH_ENC) return 1;
+    const int gmax = 16 / tokens;
+    int g = (B + 127) / 128;
+    if (g > gmax) g = gmax;
+    return g < 1 ? 1 : g;
+}
+// MotionPrior.decode: fp32 has one kernel family (STAGED); bf16 / fp16: the fused per-clip kernel (k_vae_fused.hip) from kFusedMinClips; fp32x: the per-clip kernel
+// (k_vae_fusedx.hip, CLIP) where the clips fill rounds, else the no-split-K row kernel (k_vae_rows8.hip, FUSED) from kFusedMinClips, else the split-K row kernel (STAGED)
+inline int plan_decode_path(int precision, int B) {
+    if (precision == AMUSE_PREC_F32) return AMUSE_DECODE_STAGED;
+    if (precision == AMUSE_PREC_F32X && fills_rounds(B)) return AMUSE_DECODE_CLIP;
+    return B >= kFusedMinClips ? AMUSE_DECODE_FUSED : AMUSE_DECODE_STAGED;
+}
+// MotionPrior.encode: only the fp32x mode has more than the staged kernels (the decode's rule)
+inline int plan_encode_path(int precision, int B) { return precision == AMUSE_PREC_F32X ? plan_decode_path(precision, B) : AMUSE_DECODE_STAGED; }
+// one Denoiser step of the pose-space trans_enc variant (S = 304 rows per clip): the decode's rule on k_den_fused / k_vae_rows8x<ENC> / k_den_fusedx; the other variants: STAGED
+inline int plan_step_path(int arch, int precision, int B) { return arch == AMUSE_ARCH_ENC_POSE ? plan_decode_path(precision, B) : AMUSE_DECODE_STAGED; }
+// a pin (amuse_set_decode_path) against what the precision has: FUSED = the fused kernel of the 16-bit modes / the row kernel without split-K of fp32x; CLIP = fp32x's
+// per-clip kernel, FUSED in the modes that have no third kernel; fp32 has one family
+inline int resolve_path(int pin, int planned, int precision) {
+    if (pin == AMUSE_DECODE_AUTO) return planned;
+    if (precision == AMUSE_PREC_F32 || pin == AMUSE_DECODE_STAGED) return AMUSE_DECODE_STAGED;
+    return (pin == AMUSE_DECODE_CLIP && precision == AMUSE_PREC_F32X) ? AMUSE_DECODE_CLIP : AMUSE_DECODE_FUSED;
 }
 
 struct amuse_ctx {
@@ -295,6 +328,7 @@ struct amuse_ctx {
     bool has_prior = true;             // pose-space variants may be created without MotionPrior weights
     int clips_per_group = 0;
     int decode_path = AMUSE_DECODE_AUTO;
+    int last_plan[4] = {0, 0, 0, 0};   // amuse_debug_last_plan: clips per tile / decode / encode / step path the last call of each kind actually took
     float* decode_tap = nullptr;       // amuse_debug_set_decode_tap
     int ablate = 0;                    // amuse_debug_set_ablation
     // denoiser

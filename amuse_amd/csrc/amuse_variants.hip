@@ -145,32 +145,15 @@ struct PoseStep {
     bool rows8;   // fp32x staged step: stages 1..8 on k_vae_rows8x (decided from the CALL's clip count)
     bool fusedx;  // ... or, where the call's clips fill rounds of the chip, the whole step as ONE per-clip kernel (k_den_fusedx)
 };
-// the fused per-clip step kernel (16-bit modes, diffusion_only + trans_enc) occupies one CU per clip: it wins from about as many
-// clips as the fused decoder does (amuse_api.hip kFusedMinClips); below that the staged path's 19 workgroups per clip finish sooner.
-// amuse_set_decode_path / AMUSE_VAE_FUSED pin the choice here too (STAGED / FUSED), keyed by the CALL's clip count.
-constexpr int kDenFusedMinClips = 64;
-// ... and so does the fp32x row kernel without split-K for the staged step's stages 1..8 (the decode's rule, amuse_api.hip use_rows8)
-bool use_den_rows8(const amuse_ctx* c, int precision, int B) {
-    static const int env = [] { const char* e = getenv("AMUSE_VAE_FUSED"); return e ? atoi(e) : -1; }();
-    const int force = c->decode_path == AMUSE_DECODE_STAGED ? 0 : (c->decode_path == AMUSE_DECODE_FUSED || c->decode_path == AMUSE_DECODE_CLIP) ? 1 : env;
-    if (precision != PREC_F16X2 || c->arch != AMUSE_ARCH_ENC_POSE || force == 0 || !c->var->rows8_w) return false;
-    return force == 1 || B >= kDenFusedMinClips;
-}
-bool use_den_fused(const amuse_ctx* c, int precision, int B) {
-    static const int env = [] { const char* e = getenv("AMUSE_VAE_FUSED"); return e ? atoi(e) : -1; }();
-    const int force = c->decode_path == AMUSE_DECODE_STAGED ? 0 : (c->decode_path == AMUSE_DECODE_FUSED || c->decode_path == AMUSE_DECODE_CLIP) ? 1 : env;
-    if (!is_op16(precision) || c->arch != AMUSE_ARCH_ENC_POSE || force == 0) return false;
-    return force == 1 || B >= kDenFusedMinClips;
-}
-
-// ... and where the call's clips fill rounds of the chip, the per-clip kernel for the blocks between the first and the last stage (the decode's rule: amuse_host.hpp fusedx_rule;
-// AMUSE_DECODE_CLIP pins it, AMUSE_VAE_FUSEDX=0 / 1 overrides AUTO)
-bool use_den_fusedx(const amuse_ctx* c, int precision, int B) {
-    static const int env = [] { const char* e = getenv("AMUSE_VAE_FUSEDX"); return e ? atoi(e) : -1; }();
-    if (!use_den_rows8(c, precision, B) || !c->var->fusedx_w) return false;
-    if (c->decode_path == AMUSE_DECODE_CLIP) return true;
-    if (c->decode_path != AMUSE_DECODE_AUTO || env == 0) return false;
-    return env == 1 || fusedx_rule(B);
+// kernels of one pose-space Denoiser step: the pin (amuse_set_decode_path) or the plan (amuse_host.hpp plan_step_path), keyed by the CALL's clip count: the fused
+// per-clip step kernel of the 16-bit modes (k_den_fused.hip), fp32x's row kernel without split-K for the staged step's stages 1..8 (FUSED) and its per-clip kernel
+// (k_den_fusedx, CLIP) where the clips fill rounds of the chip - AMUSE_ARCH_ENC_POSE only; everything else is staged
+int step_path_of(amuse_ctx* c, int precision, int B) {
+    int path = resolve_path(c->decode_path, plan_step_path(c->arch, precision, B), precision);
+    if (c->arch != AMUSE_ARCH_ENC_POSE) path = AMUSE_DECODE_STAGED;
+    if (path == AMUSE_DECODE_CLIP && !c->var->fusedx_w) path = AMUSE_DECODE_FUSED;
+    if (path == AMUSE_DECODE_FUSED && precision == PREC_F16X2 && !c->var->rows8_w) path = AMUSE_DECODE_STAGED;
+    return c->last_plan[3] = path;
 }
 
 int pose_step(amuse_ctx* c, const PoseStep& p, int nb, int precision, bool fused, hipStream_t st) {
@@ -475,8 +458,10 @@ int variant_sample(amuse_ctx* c, const float* con, const float* emo, const float
     const size_t sd = AMUSE_POSE_STATE;
     if (x_init) HIP_TRY(hipMemcpyAsync(out, x_init, (size_t)B * sd * sizeof(float), hipMemcpyDeviceToDevice, st));
     else HIP_TRY(launch_counter_normal(seed, clip0, B, 0, 0, out, st, (int)sd));
-    const bool fused = use_den_fused(c, precision, B);
-    const bool rows8 = use_den_rows8(c, precision, B);
+    const int spath = step_path_of(c, precision, B);
+    const bool fused = is_op16(precision) && spath != AMUSE_DECODE_STAGED;        // k_den_fused
+    const bool rows8 = precision == PREC_F16X2 && spath != AMUSE_DECODE_STAGED;   // k_vae_rows8x<ENC> for stages 1..8
+    const bool fusedx = precision == PREC_F16X2 && spath == AMUSE_DECODE_CLIP;    // k_den_fusedx
     const int chunk = fused ? B : (B < kPoseChunk ? B : kPoseChunk);
     if (int e = ensure_pose_ws(v, chunk, fused)) return e;
     for (int step = 0; step < c->T; ++step) {
@@ -491,7 +476,7 @@ int variant_sample(amuse_ctx* c, const float* con, const float* emo, const float
             p.cond_tok = c->cond_tok + (size_t)b0 * ncond * kD;
             p.ckv = v->ckv ? v->ckv + (size_t)b0 * ncond * kTkv : nullptr;
             p.lengths_dev = nullptr;   // the sampling loop passes full lengths (infer_ldm.py:135)
-            p.ncond = ncond; p.step = step; p.seed = seed; p.clip0 = clip0 + (uint64_t)b0; p.rows8 = rows8; p.fusedx = use_den_fusedx(c, precision, B);
+            p.ncond = ncond; p.step = step; p.seed = seed; p.clip0 = clip0 + (uint64_t)b0; p.rows8 = rows8; p.fusedx = fusedx;
             if (int e = pose_step(c, p, nb, precision, fused, st)) return e;
         }
         if (traj_out) HIP_TRY(hipMemcpyAsync(traj_out + (size_t)step * B * sd, out, (size_t)B * sd * sizeof(float), hipMemcpyDeviceToDevice, st));
@@ -530,8 +515,10 @@ int variant_denoise(amuse_ctx* c, const float* x_t, const int* timesteps, bool p
     if (tap_out) return fail(AMUSE_EINVAL, "taps exist for the latent variants only");
     if (int e = stage_lengths_v(c, lengths, B, st)) return e;
     const size_t sd = AMUSE_POSE_STATE;
-    const bool fused = use_den_fused(c, precision, B);
-    const bool rows8 = use_den_rows8(c, precision, B);
+    const int spath = step_path_of(c, precision, B);
+    const bool fused = is_op16(precision) && spath != AMUSE_DECODE_STAGED;        // k_den_fused
+    const bool rows8 = precision == PREC_F16X2 && spath != AMUSE_DECODE_STAGED;   // k_vae_rows8x<ENC> for stages 1..8
+    const bool fusedx = precision == PREC_F16X2 && spath == AMUSE_DECODE_CLIP;    // k_den_fusedx
     const int chunk = fused ? B : (B < kPoseChunk ? B : kPoseChunk);
     if (int e = ensure_pose_ws(v, chunk, fused)) return e;
     for (int b0 = 0; b0 < B; b0 += chunk) {
@@ -543,7 +530,7 @@ int variant_denoise(amuse_ctx* c, const float* x_t, const int* timesteps, bool p
         p.cond_tok = c->cond_tok + (size_t)b0 * ncond * kD;
         p.ckv = v->ckv ? v->ckv + (size_t)b0 * ncond * kTkv : nullptr;
         p.lengths_dev = lengths ? c->d_lengths + b0 : nullptr;
-        p.ncond = ncond; p.rows8 = rows8; p.fusedx = use_den_fusedx(c, precision, B);
+        p.ncond = ncond; p.rows8 = rows8; p.fusedx = fusedx;
         if (int e = pose_step(c, p, nb, precision, fused, st)) return e;
     }
     return 0;

@@ -321,15 +321,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         const char* sl = smem + slot * kAttnStage + lane * 16;
         slot = slot == 2 ? 0 : slot + 1;
         f32x4 st[NQ][4];
-#ifdef AMUSE_ATTN_NOC
-        f32x4 c0[NQ];
-#pragma unroll
-        for (int q = 0; q < NQ; ++q) c0[q] = splat4(0.f);
-#else
         f32x4 c0[NQ];
 #pragma unroll
         for (int q = 0; q < NQ; ++q) c0[q] = splat4(-m_run[q]);
-#endif
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const bf16x8 k0 = *reinterpret_cast<const bf16x8*>(sl + (2 * u) * 1024), k1 = *reinterpret_cast<const bf16x8*>(sl + (2 * u + 1) * 1024);
@@ -355,13 +349,6 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
             float mx = max3(max3(st[q][0][0], st[q][0][1], st[q][0][2]), max3(st[q][0][3], st[q][1][0], st[q][1][1]), max3(st[q][1][2], st[q][1][3], st[q][2][0]));
             mx = max3(mx, max3(st[q][2][1], st[q][2][2], st[q][2][3]), max3(st[q][3][0], st[q][3][1], st[q][3][2]));
             mx = fmaxf(mx, st[q][3][3]);   // this lane's 16 scores; every chunk holds a valid key
-#ifdef AMUSE_ATTN_NOC
-            if (c > 0) {
-#pragma unroll
-                for (int u = 0; u < 4; ++u) st[q][u] -= splat4(m_run[q]);
-                mx -= m_run[q];
-            }
-#endif
             // the running maximum moves in the first chunks and then hardly ever: the row's maximum (four lanes) is formed, and the
             // scores shifted and the accumulators rescaled, only when SOME lane of the wave holds a positive score (wave-uniform branch)
             if (c == 0 || __builtin_amdgcn_ballot_w64(mx > 0.f) != 0) {
@@ -532,9 +519,8 @@ hipError_t launch_untile_f32(const float* src, float* dst, int M, int F, int row
     return hipGetLastError();
 }
 hipError_t launch_ast_attn(const unsigned short* QK, const unsigned short* Vt, unsigned short* O, int B, hipStream_t s) {
-    // one query tile per wave for a single clip (120 instead of 60 workgroups: 2.06 -> 2.02 ms for the whole front-end; at two clips already slower); AMUSE_AST_ATTN_NQ pins it (A/B)
-    static const int env = [] { const char* e = getenv("AMUSE_AST_ATTN_NQ"); return e ? atoi(e) : 0; }();
-    const int nq = env == 1 || env == 2 ? env : (B == 1 ? 1 : 2);
+    // one query tile per wave for a single clip (120 instead of 60 workgroups: 2.06 -> 2.02 ms for the whole front-end; at two clips already slower: profiles/r04_audio_attn_nq_ab.txt)
+    const int nq = B == 1 ? 1 : 2;
     if (nq == 1) hipLaunchKernelGGL(k_ast_attn<1>, dim3((kAstRows + kAttnQ / 2 - 1) / (kAttnQ / 2), kAstHeads, B), dim3(512), kAttnLds, s, QK, Vt, O);
     else hipLaunchKernelGGL(k_ast_attn<2>, dim3((kAstRows + kAttnQ - 1) / kAttnQ, kAstHeads, B), dim3(512), kAttnLds, s, QK, Vt, O);
     return hipGetLastError();

@@ -33,9 +33,7 @@ namespace {
 
 typedef unsigned short bf16raw;
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-#ifndef AMUSE_GEMM_CG
-#define AMUSE_GEMM_CG 3   // feature tiles per column group of the tile walk (measured: 3 beats 6 and the plain row-major walk by 1.5 %)
-#endif
+constexpr int kGemmColGroup = 3;   // feature tiles per column group of the tile walk (measured: 3 beats 6 and the plain row-major walk by 1.5 %)
 constexpr int TM = kGemmTM, BK = 32, XFR = TM / 16;
 // Two shapes of the same kernel (identical arithmetic per output element: k-steps of 32 in order):
 //   FX = 8  256-feature tiles, a wave holds 8 W fragments; stage = 16 W + 8 X fragments (24 KiB), ring of 3 = 74,752 B with the bias
@@ -95,10 +93,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     int f_tile = wg, f_k = 0, f_slot = 0;
     const size_t frag_row = (size_t)nk * 1024;   // bytes between consecutive fragment rows of a packed / tile-major operand
     const char *fw, *fx;
-    // tile index -> (row tile, feature tile): feature tiles in groups of AMUSE_GEMM_CG, row tiles walked inside a group - the
+    // tile index -> (row tile, feature tile): feature tiles in groups of kGemmColGroup, row tiles walked inside a group - the
     // workgroups of an XCD (a contiguous range of tile indices) then share the W rows of one group in their L2
-    constexpr int CGS = AMUSE_GEMM_CG > 0 ? AMUSE_GEMM_CG : 1;
-    const int cg = (AMUSE_GEMM_CG > 0 && tiles_n % CGS == 0) ? CGS : tiles_n;
+    constexpr int CGS = kGemmColGroup;
+    const int cg = tiles_n % CGS == 0 ? CGS : tiles_n;
     auto tile_tm = [&](int tile) { return (tile % (tiles_m * cg)) / cg; };
     auto tile_tn = [&](int tile) { return (tile / (tiles_m * cg)) * cg + tile % cg; };
     auto cursor = [&]() {
@@ -280,7 +278,7 @@ hipError_t launch_gemm_n(const GemmArgs& a, int n_tiles, hipStream_t s) {
 template <int EPI>
 hipError_t launch_gemm_t(const GemmArgs& a, hipStream_t s) {
     const int tiles_m = (a.M + TM - 1) / TM, n_tiles = tiles_m * (a.N / kGemmTN);
-    static const int deep_tiles = [] { const char* e = getenv("AMUSE_GEMM_DEEP"); return e ? atoi(e) : kDeepTiles; }();   // (0: never)
+    constexpr int deep_tiles = kDeepTiles;
     if (n_tiles <= deep_tiles) return launch_gemm_n<EPI, 9, 4>(a, 2 * n_tiles, s);
     return launch_gemm_n<EPI, 3, 8>(a, n_tiles, s);
 }

@@ -109,13 +109,9 @@ __device__ __forceinline__ void encoder_block(f32x4 (&x)[kTiles], WRing<kRing>& 
     static_assert((P_F2 + U_FF) % kRing == 0, "a block must leave the ring at phase 0");
     constexpr bool FAST = (PREC == PREC_BF16);
     // GELU: libm erff in both parity modes.  (Measured on one box, 256 clips, fp32x: erff 96.3 ms per 1000 steps; the
-    // Abramowitz-Stegun form on the hardware rcp / exp2 that the 4-wave bf16 kernel uses - -DAMUSE_F32X_FAST_ERF=1 - 102.0 ms:
+    // Abramowitz-Stegun form on the hardware rcp / exp2 that the 4-wave bf16 kernel uses 102.0 ms:
     // its two quarter-rate transcendentals per element sit on the wave's critical path, erff's plain fma chains do not.)
-#ifdef AMUSE_F32X_FAST_ERF
-    constexpr bool FAST_ACT = (PREC != PREC_F32);
-#else
     constexpr bool FAST_ACT = (PREC == PREC_BF16);
-#endif
     // bf16 mode decouples load issue from consumption (ring_issue): per block the ring (full on entry = in_proj +
     // out_proj units) is re-armed 8+8+8 units around the attention, 8 during combine 1 (-> holds all of linear1),
     // 32 inside linear1 (immediately: linear2 needs them next), 32 during combine 2 (-> next block's first 32).
@@ -124,15 +120,10 @@ __device__ __forceinline__ void encoder_block(f32x4 (&x)[kTiles], WRing<kRing>& 
     constexpr int A8 = DELAY ? 8 : 0;
     // fp32x is bound by the CU's 64 B/clk load path (7.6 MB per step = 119 k cycles): GEMMs that re-arm as they consume run
     // at that rate, and the path idles through the attention arithmetic and the two combines (55 k cycles per step).
-    // -DAMUSE_F32X_DELAY=1 lets the GEMM in front of each of those phases leave its slots empty and the phase re-arm them
-    // (v around the softmax, out_proj inside combine 1, the last two linear2 quarters inside combine 2) - and is SLOWER
-    // (105.6 against 102.0 ms per 1000 steps, same box): with one wave per SIMD a wave blocked at load issue inside a combine
+    // Letting the GEMM in front of each of those phases leave its slots empty and the phase re-arm them was measured SLOWER
+    // (105.6 against 102.0 ms per 1000 steps, docs/history.md): with one wave per SIMD a wave blocked at load issue inside a combine
     // arrives late at its barriers, so issue time and chain time still add up - the way out is the 8-wave
-    // role split, not the placement of the issue.
-#ifndef AMUSE_F32X_DELAY
-#define AMUSE_F32X_DELAY 0
-#endif
-    constexpr bool XD = (PREC == PREC_F16X2) && AMUSE_F32X_DELAY;
+    // role split (k_sampler8x.hip), not the placement of the issue.
     // Small parameters (LDS) are read one phase ahead of their use; biases are added AFTER the GEMM that
     // they belong to, so no LDS round trip sits in front of a GEMM's first MFMA.
     f32x4 b_qk[4];
@@ -152,7 +143,7 @@ __device__ __forceinline__ void encoder_block(f32x4 (&x)[kTiles], WRing<kRing>& 
         F16Pair xs[kTiles / 2];
         split_rows<kTiles>(xs, x);
         gemm_ring_s<4, kTiles / 2, false, kRing, P_QK>(qk, xs, rg);
-        gemm_ring_s<2, kTiles / 2, true, kRing, P_V, !XD>(v, xs, rg);
+        gemm_ring_s<2, kTiles / 2, true, kRing, P_V, true>(v, xs, rg);
     } else {
         gemm_ring<PREC, 4, kTiles, false, kRing, P_QK, !DELAY>(qk, x, rg);
         gemm_ring<PREC, 2, kTiles, true, kRing, P_V, !DELAY>(v, x, rg);
@@ -165,18 +156,16 @@ __device__ __forceinline__ void encoder_block(f32x4 (&x)[kTiles], WRing<kRing>& 
     v[0] += splat4(b_v[0]);
     v[1] += splat4(b_v[1]);
     f32x4 o[2];
-    if constexpr (XD) attention_head<PREC, 8, P_V>(q, k, v, kvalid, o, rg);   // re-arms v's 16 slots
-    else attention_head<PREC, A8, 8>(q, k, v, kvalid, o, rg);
+    attention_head<PREC, A8, 8>(q, k, v, kvalid, o, rg);
     stamp<PROF>(pf);  // 2: attention done
     // ---- out_proj, split-K over heads; combine; residual; LayerNorm1
     f32x4 part[kTiles];
 #pragma unroll
     for (int t = 0; t < kTiles; ++t) part[t] = splat4(0.f);
-    gemm_ring<PREC, kTiles, 2, false, kRing, P_OUT, !DELAY && !XD>(part, o, rg);
+    gemm_ring<PREC, kTiles, 2, false, kRing, P_OUT, !DELAY>(part, o, rg);
     stamp<PROF>(pf);  // 3: out_proj partial done
     // x = LN1(x + sum_w part + b_out): reduce-scatter / LayerNorm / all-gather (amuse_dev.hpp combine_rs)
-    if constexpr (XD) combine_rs<true, FAST, 16, kRing, P_OUT>(part, x, true, pv + PV_OUT_B, pv + PV_LN1_W, pv + PV_LN1_B, comb, wave, lane, &rg);
-    else combine_rs<true, FAST, A8, kRing, 24>(part, x, true, pv + PV_OUT_B, pv + PV_LN1_W, pv + PV_LN1_B, comb, wave, lane, &rg);
+    combine_rs<true, FAST, A8, kRing, 24>(part, x, true, pv + PV_OUT_B, pv + PV_LN1_W, pv + PV_LN1_B, comb, wave, lane, &rg);
     stamp<PROF>(pf);  // 4: combine 1 + LN1 done
     stamp<PROF>(pf);  // 5: (kept for timeline compatibility)
     // ---- FFN in four interleaved quarters: linear1 for 2 of this wave's 8 hidden tiles -> bias + GELU ->
@@ -231,10 +220,10 @@ __device__ __forceinline__ void encoder_block(f32x4 (&x)[kTiles], WRing<kRing>& 
     gemm_ring<PREC, 2, kTiles, false, kRing, (5 * U_Q) % kRing, !DELAY>(hq[3], x, rg);      // F1 q3
     }
     gelu_quarter(2);
-    gemm_ring<PREC, kTiles, 2, false, kRing, (6 * U_Q) % kRing, !DELAY && !XD>(part, hq[2], rg);   // F2 q2
+    gemm_ring<PREC, kTiles, 2, false, kRing, (6 * U_Q) % kRing, !DELAY>(part, hq[2], rg);   // F2 q2
     stamp<PROF>(pf);
     gelu_quarter(3);
-    gemm_ring<PREC, kTiles, 2, false, kRing, (7 * U_Q) % kRing, !DELAY && !XD>(part, hq[3], rg);   // F2 q3
+    gemm_ring<PREC, kTiles, 2, false, kRing, (7 * U_Q) % kRing, !DELAY>(part, hq[3], rg);   // F2 q3
     stamp<PROF>(pf);  // 9: FFN done (linear2 partial)
     // x = LN2(x + sum_w part + b_l2).  bf16: the ring is re-armed meanwhile with the next block's first units - its
     // in_proj + out_proj (32) or, ahead of an output block, only the 16 skip-linear units (slots 16..31 stay empty;
@@ -244,8 +233,6 @@ __device__ __forceinline__ void encoder_block(f32x4 (&x)[kTiles], WRing<kRing>& 
             combine_rs<true, FAST, 16, kRing, 0>(part, x, true, pv + PV_L2_B, pv + PV_LN2_W, pv + PV_LN2_B, comb, wave, lane, &rg);
         else
             combine_rs<true, FAST, 32, kRing, 0>(part, x, true, pv + PV_L2_B, pv + PV_LN2_W, pv + PV_LN2_B, comb, wave, lane, &rg);
-    } else if constexpr (XD) {
-        combine_rs<true, FAST, 32, kRing, 0>(part, x, true, pv + PV_L2_B, pv + PV_LN2_W, pv + PV_LN2_B, comb, wave, lane, &rg);
     } else {
         combine_rs<true, FAST>(part, x, true, pv + PV_L2_B, pv + PV_LN2_W, pv + PV_LN2_B, comb, wave, lane);
     }
@@ -354,10 +341,6 @@ __global__ __launch_bounds__(256, 1) void k_sample(SampleArgs a) {
                     // during the combine with the block's first 32 units
                     gemm_ring<PREC, kTiles, 4, false, kRing, 0, false>(part, src, rg);
                     combine_rs<false, true, 32, kRing, 0>(part, x, false, sb, nullptr, nullptr, comb, wave, lane, &rg);
-                } else if constexpr (PREC == PREC_F16X2 && AMUSE_F32X_DELAY) {
-                    // 32 units = the whole ring, consumed without re-arming; the combine re-arms it with the block's q, k units
-                    gemm_ring<PREC, kTiles, 4, false, kRing, 0, false>(part, src, rg);
-                    combine_rs<false, false, 32, kRing, 0>(part, x, false, sb, nullptr, nullptr, comb, wave, lane, &rg);
                 } else {
                     gemm_ring<PREC, kTiles, 4, false, kRing, 0>(part, src, rg);
                     ring_discard<skip_pad_units(PREC), kRing, U_SK % kRing>(rg);
@@ -459,33 +442,24 @@ __global__ __launch_bounds__(256, 1) void k_sample(SampleArgs a) {
 
 }  // namespace
 
+// The 4-wave kernel serves the fp32 parity mode only: bf16 / fp16 / fp32x sample on the 8-wave kernels (k_sampler8.hip, k_sampler8x.hip).  The template stays
+// parametric in PREC (its building blocks in amuse_dev.hpp are shared with k_sampler_dec.hip and k_vae.hip, which instantiate every mode); the bf16 and fp32x
+// instantiations of THIS kernel and their agreement tests with the 8-wave kernels are shelved under tools/probes/sampler_4wave/.
 hipError_t launch_sample(const SampleArgs& a, int precision, hipStream_t stream) {
+    if (precision != PREC_F32) return hipErrorInvalidValue;
     const int tiles = (a.B + a.G - 1) / a.G;
     const dim3 grid(tiles), block(256);
     static DeviceOnce once;
     int dev_;
     if (!once.done(&dev_)) {
-        const void* ks[6] = {reinterpret_cast<const void*>(&k_sample<PREC_F32, false>),
-                             reinterpret_cast<const void*>(&k_sample<PREC_BF16, false>),
-                             reinterpret_cast<const void*>(&k_sample<PREC_F16X2, false>),
-                             reinterpret_cast<const void*>(&k_sample<PREC_F32, true>),
-                             reinterpret_cast<const void*>(&k_sample<PREC_BF16, true>),
-                             reinterpret_cast<const void*>(&k_sample<PREC_F16X2, true>)};
-        for (const void* k : ks) {
+        for (const void* k : {reinterpret_cast<const void*>(&k_sample<PREC_F32, false>), reinterpret_cast<const void*>(&k_sample<PREC_F32, true>)}) {
             hipError_t e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, kSampleLdsBytes);
             if (e != hipSuccess) return e;
         }
         once.set(dev_);
     }
-    if (a.prof_out) {
-        if (precision == PREC_F32) hipLaunchKernelGGL((k_sample<PREC_F32, true>), grid, block, kSampleLdsBytes, stream, a);
-        else if (precision == PREC_F16X2) hipLaunchKernelGGL((k_sample<PREC_F16X2, true>), grid, block, kSampleLdsBytes, stream, a);
-        else hipLaunchKernelGGL((k_sample<PREC_BF16, true>), grid, block, kSampleLdsBytes, stream, a);
-    } else {
-        if (precision == PREC_F32) hipLaunchKernelGGL((k_sample<PREC_F32, false>), grid, block, kSampleLdsBytes, stream, a);
-        else if (precision == PREC_F16X2) hipLaunchKernelGGL((k_sample<PREC_F16X2, false>), grid, block, kSampleLdsBytes, stream, a);
-        else hipLaunchKernelGGL((k_sample<PREC_BF16, false>), grid, block, kSampleLdsBytes, stream, a);
-    }
+    if (a.prof_out) hipLaunchKernelGGL((k_sample<PREC_F32, true>), grid, block, kSampleLdsBytes, stream, a);
+    else hipLaunchKernelGGL((k_sample<PREC_F32, false>), grid, block, kSampleLdsBytes, stream, a);
     return hipGetLastError();
 }
 

@@ -72,49 +72,13 @@ using Ring = WRing<kR8>;
 
 // Issue split of an A wave's 32 units inside the out_proj (C1) and linear2 (C2) combines: N0 before the first barrier
 // (C2 only - there the A waves arrive early), N1 / N2 after the first / second barrier, the rest after the gather.
-// Defaults from sweeps on MI355X (tools/gpu_variant_sweep.sh); all splits of the same family land within 2 %.
-#ifndef AMUSE_C1_N1
-#define AMUSE_C1_N1 12
-#define AMUSE_C1_N2 12
-#endif
+// Values from sweeps on MI355X (rounds 1-4, docs/history.md 4.1b); all splits of the same family land within 2 %.
+constexpr int kC1N1 = 12, kC1N2 = 12;
+constexpr int kC2N0 = 16, kC2N1 = 12;
 // units a B wave issues during the A waves' attention phase; the rest of its 32 follow behind its first FFN MFMAs
-#ifndef AMUSE_B_EARLY
-#define AMUSE_B_EARLY 20
-#endif
-// s_setprio of the B waves inside their FFN half only (A/B; k_sampler8x.hip gains 1 % from it)
-#ifndef AMUSE_B_FFN_PRIO
-#define AMUSE_B_FFN_PRIO 0
-#endif
+constexpr int kBEarly = 20;
 // VALU instructions scheduled behind each MFMA while one FFN quarter's GELU overlaps the other quarter's GEMM (ffn_half)
-#ifndef AMUSE_FFN_VALU_PER_MFMA
-#define AMUSE_FFN_VALU_PER_MFMA 7
-#endif
-#ifndef AMUSE_C2_N1
-#define AMUSE_C2_N0 16
-#define AMUSE_C2_N1 12
-#endif
-
-#ifdef AMUSE_ABL_C1LITE
-constexpr bool kAblC1Lite = true;
-#else
-constexpr bool kAblC1Lite = false;
-#endif
-#ifdef AMUSE_ABL_C2LITE
-constexpr bool kAblC2Lite = true;
-#else
-constexpr bool kAblC2Lite = false;
-#endif
-// the two halves of C2LITE on their own: only the partial WRITES thinned (W) / only the reducers' READS thinned (R)
-#ifdef AMUSE_ABL_C2LITE_W
-constexpr bool kAblC2W = true;
-#else
-constexpr bool kAblC2W = kAblC2Lite;
-#endif
-#ifdef AMUSE_ABL_C2LITE_R
-constexpr bool kAblC2R = true;
-#else
-constexpr bool kAblC2R = kAblC2Lite;
-#endif
+constexpr int kFfnValuPerMfma = 7;
 
 __device__ __forceinline__ f32x4* a8_slot(char* lds, int row, int col, int lane) {
     return reinterpret_cast<f32x4*>(lds) + (row * kTiles + col) * 64 + lane;
@@ -155,7 +119,7 @@ __device__ __forceinline__ void combine_red(f32x4 (&part)[kTiles], f32x4 (&xo)[2
     if constexpr (NP == 8) {
 #pragma unroll
         for (int t = 0; t < kTiles; ++t)
-            if (t != T0 && t != T0 + 1 && (!kAblC2W || t == (T0 + 2) % kTiles)) *a8_slot(lds, part_row(4 + W, t), t, lane) = part[t];
+            if (t != T0 && t != T0 + 1) *a8_slot(lds, part_row(4 + W, t), t, lane) = part[t];
     }
     f32x4 bi[2], ga[2], be[2];
 #pragma unroll
@@ -174,10 +138,7 @@ __device__ __forceinline__ void combine_red(f32x4 (&part)[kTiles], f32x4 (&xo)[2
         for (int i = 0; i < 2; ++i)
 #pragma unroll
             for (int w = 0; w < NP; ++w) {
-                // (timing ablations, wrong numerics: ONE partial per tile read instead of NP - 1 - the LDS traffic of a combine whose
-                // GEMM was split over output tiles instead of K: -DAMUSE_ABL_C1LITE out_proj combine, -DAMUSE_ABL_C2LITE linear2 combine)
-                const bool lite = NP == 4 ? kAblC1Lite : kAblC2R;
-                if (w != 4 + W) p[w][i] = (lite && w != 0) ? p[0][i] : *a8_slot(lds, part_row(w, T0 + i), T0 + i, lane);
+                if (w != 4 + W) p[w][i] = *a8_slot(lds, part_row(w, T0 + i), T0 + i, lane);
             }
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
@@ -204,13 +165,9 @@ __device__ __forceinline__ void combine_red(f32x4 (&part)[kTiles], f32x4 (&xo)[2
             m2 += d * d;
         }
     m2 = allreduce_g_sum(m2);
-#ifdef AMUSE_ABL_NOSTATS   // timing ablation (wrong numerics): what the row-statistics exchange and its barrier cost
-    const float2 s0 = float2{mw, m2}, s1 = s0, s2 = s0, s3 = s0;
-#else
     if (g == 0) stats[W * 16 + r] = float2{mw, m2};
     __syncthreads();
     const float2 s0 = stats[r], s1 = stats[16 + r], s2 = stats[32 + r], s3 = stats[48 + r];
-#endif
     const float mean = ((s0.x + s1.x) + (s2.x + s3.x)) * 0.25f;
     const float d0 = s0.x - mean, d1 = s1.x - mean, d2 = s2.x - mean, d3 = s3.x - mean;
     const float M2 = ((s0.y + s1.y) + (s2.y + s3.y)) + 32.0f * ((d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3));
@@ -253,13 +210,11 @@ __device__ __forceinline__ void combine_publish(const f32x4 (&part)[kTiles], OPV
                                                 int lane, Ring& rg) {
 #pragma unroll
     for (int t = 0; t < kTiles; ++t)
-        if (!kAblC1Lite || t == 2 * h) *a8_slot(lds, h + (h >= t ? 1 : 0), t, lane) = part[t];  // part_row(h, t), h < 4
+        *a8_slot(lds, h + (h >= t ? 1 : 0), t, lane) = part[t];  // part_row(h, t), h < 4
     ring_issue<N0, kR8, IPH0 % kR8>(rg);
     __syncthreads();
     ring_issue<N1, kR8, (IPH0 + N0) % kR8>(rg);
-#ifndef AMUSE_ABL_NOSTATS
     if constexpr (LN) __syncthreads();   // (the reducers' row-statistics exchange)
-#endif
     ring_issue<N2, kR8, (IPH0 + N0 + N1) % kR8>(rg);
     __syncthreads();
 #pragma unroll
@@ -286,13 +241,11 @@ __device__ __forceinline__ void combine_publish_c2(const f32x4 (&part)[kTiles], 
     static_assert(N0 >= 8 && N0 + N1 + N2 == 32, "the leading 8 units go out before the first barrier");
 #pragma unroll
     for (int t = 0; t < kTiles; ++t)
-        if (!kAblC2W || t == 2 * h) *a8_slot(lds, h + (h >= t ? 1 : 0), t, lane) = part[t];
+        *a8_slot(lds, h + (h >= t ? 1 : 0), t, lane) = part[t];
     ring_issue<N0, kR8, 24>(rg);
     __syncthreads();
     ring_issue<N1, kR8, (24 + N0) % kR8>(rg);
-#ifndef AMUSE_ABL_NOSTATS
     __syncthreads();
-#endif
     if (skip_u) {
         OPV sk[4];
 #pragma unroll
@@ -366,11 +319,7 @@ __device__ __forceinline__ void ffn_half(f32x4 (&part)[kTiles], const OPV (&xb)[
     const float* b1 = pv + PV_L1_B + 16 * (kTiles * h + 2 * Q0) + 4 * g;
     f32x4 ha[2] = {ld4(b1), ld4(b1 + 16)}, hb[2] = {ld4(b1 + 32), ld4(b1 + 48)};
     gemm_xb<2, false, 0>(ha, xb, rg);
-#ifdef AMUSE_ABL_NOLATE   // timing ablation (stale weights): what the B waves' blocking issue of their late units costs the FFN phase
-    if constexpr (LATE8) rg.next += (32 - AMUSE_B_EARLY) * 64;
-#else
-    if constexpr (LATE8) ring_issue<32 - AMUSE_B_EARLY, kR8, AMUSE_B_EARLY>(rg);
-#endif
+    if constexpr (LATE8) ring_issue<32 - kBEarly, kR8, kBEarly>(rg);
     __builtin_amdgcn_sched_barrier(0);
     // An in-order wave that issues its 8 MFMAs back to back waits out the matrix pipe (16 cycles each) before its
     // first VALU instruction; interleaved 1 : 6 the GELU of one quarter runs in the shadow of the other quarter's
@@ -380,7 +329,7 @@ __device__ __forceinline__ void ffn_half(f32x4 (&part)[kTiles], const OPV (&xb)[
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // 1 MFMA
-        __builtin_amdgcn_sched_group_barrier(0x002, AMUSE_FFN_VALU_PER_MFMA, 0);   // 7 VALU
+        __builtin_amdgcn_sched_group_barrier(0x002, kFfnValuPerMfma, 0);   // 7 VALU
     }
     __builtin_amdgcn_sched_barrier(0);
     gemm_ring<P, kTiles, 2, false, kR8, 16, false>(part, ha, rg);
@@ -388,7 +337,7 @@ __device__ __forceinline__ void ffn_half(f32x4 (&part)[kTiles], const OPV (&xb)[
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-        __builtin_amdgcn_sched_group_barrier(0x002, AMUSE_FFN_VALU_PER_MFMA, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, kFfnValuPerMfma, 0);
     }
     __builtin_amdgcn_sched_barrier(0);
     gemm_ring<P, kTiles, 2, false, kR8, 24, false>(part, hb, rg);
@@ -433,29 +382,23 @@ __device__ __forceinline__ void encoder_block8(OPV (&xb)[4], f32x4 (&xo)[2], Rin
         gemm_ring<P, kTiles, 2, false, kR8, 24, false>(part, o, rg);
         stamp8<PROF>(pf);  // 1: in_proj + attention + out_proj partial
         // ---- out_proj combine (B reduces): meanwhile fetch this wave's FFN half
-        combine_publish<0, AMUSE_C1_N1, AMUSE_C1_N2, 32 - AMUSE_C1_N1 - AMUSE_C1_N2, 0>(part, xb, lds, h, lane, rg);
+        combine_publish<0, kC1N1, kC1N2, 32 - kC1N1 - kC1N2, 0>(part, xb, lds, h, lane, rg);
         stamp8<PROF>(pf);  // 2: combine 1
 #pragma unroll
         for (int t = 0; t < kTiles; ++t) part[t] = splat4(0.f);
         ffn_half<0, false>(part, xb, rg, pv, h, g);
         stamp8<PROF>(pf);  // 3: FFN
         // ---- linear2 combine (B reduces): meanwhile fetch the next block's attention weights
-        combine_publish_c2<AMUSE_C2_N0, AMUSE_C2_N1, 32 - AMUSE_C2_N0 - AMUSE_C2_N1>(part, xb, lds, h, lane, rg, next_has_skip, skip_next);
+        combine_publish_c2<kC2N0, kC2N1, 32 - kC2N0 - kC2N1>(part, xb, lds, h, lane, rg, next_has_skip, skip_next);
     } else {
         // ---- ring empty on entry: fetch this wave's FFN half while the A waves run attention
-        ring_issue<AMUSE_B_EARLY, kR8, 0>(rg);
+        ring_issue<kBEarly, kR8, 0>(rg);
         stamp8<PROF>(pf);
 #pragma unroll
         for (int t = 0; t < kTiles; ++t) part[t] = splat4(0.f);
         combine_reduce<4, true>(part, xo, xb, pv + PV_OUT_B, pv + PV_LN1_W, pv + PV_LN1_B, lds, h, lane);
         stamp8<PROF>(pf);
-#if AMUSE_B_FFN_PRIO
-        __builtin_amdgcn_s_setprio(AMUSE_B_FFN_PRIO);
-#endif
-        ffn_half<2, (AMUSE_B_EARLY < 32)>(part, xb, rg, pv, h, g);
-#if AMUSE_B_FFN_PRIO
-        __builtin_amdgcn_s_setprio(0);
-#endif
+        ffn_half<2, (kBEarly < 32)>(part, xb, rg, pv, h, g);
         stamp8<PROF>(pf);  // 3: FFN
         if (next_has_skip) ring_issue<8, kR8, 0>(rg);  // the x half of this wave's two output tiles of the next block's skip linear
         combine_reduce<8, true>(part, xo, xb, pv + PV_L2_B, pv + PV_LN2_W, pv + PV_LN2_B, lds, h, lane);

@@ -54,35 +54,14 @@ using Ring = WRing<kR8>;
 
 // Issue split of an A wave's 32 units inside the out_proj (C1) and linear2 (C2) combines: N0 before the first barrier,
 // N1 / N2 after the first / second barrier, the rest after the gather.
-#ifndef AMUSE_X_C1_N1
-#define AMUSE_X_C1_N1 12
-#define AMUSE_X_C1_N2 12
-#endif
-#ifndef AMUSE_X_C2_N1
-#define AMUSE_X_C2_N1 8
-#endif
-// units a B wave issues during the A waves' attention phase; the rest of its first 32 follow behind its first FFN MFMAs
-#ifndef AMUSE_X_B_EARLY
-#define AMUSE_X_B_EARLY 32
-#endif
-// 1: the A waves fetch linear2's units as one burst behind their GELUs instead of re-arming at consumption (ffn_half)
-#ifndef AMUSE_X_A_DEFER
-#define AMUSE_X_A_DEFER 1
-#endif
+constexpr int kXC1N1 = 12, kXC1N2 = 12, kXC2N1 = 8;
+// units a B wave issues during the A waves' attention phase (all 32 of its linear1)
+constexpr int kXBEarly = 32;
 // s_setprio of the B waves inside their FFN half (they are the reducers of the combine behind it): 73.4 -> 72.6 us per step
-#ifndef AMUSE_X_B_PRIO
-#define AMUSE_X_B_PRIO 3
-#endif
-// erf of the FFN's GELU: 0 branch-free fit (amuse_dev.hpp erf_bf), 1 libm erff, 2 Abramowitz-Stegun on rcp / exp2.  Same-box wall
-// clock of this kernel, us per step: libm 71.4, branch-free 75.3 (the 3 : 1 FFN split of tools/probes/fp32x_ffn_3_1_split ranked
-// them the other way round: 92.2 / 86.3), Abramowitz-Stegun 79.7 on the build before
-#ifndef AMUSE_X_ERF
-#define AMUSE_X_ERF 1
-#endif
-// A waves: 2 = defer both linear2 groups behind both GELUs (one burst), 1 = re-arm the first at consumption and defer the second
-#ifndef AMUSE_X_A_DEFER2
-#define AMUSE_X_A_DEFER2 2
-#endif
+constexpr int kXBPrio = 3;
+// The A waves fetch linear2's units as ONE burst behind both GELUs instead of re-arming at consumption (ffn_half, DEFER).  The FFN's
+// GELU takes libm erff: same-box wall clock of this kernel, us per step: libm 71.4, the branch-free fit (amuse_dev.hpp erf_bf) 75.3,
+// Abramowitz-Stegun on rcp / exp2 79.7 (docs/history.md; the 3 : 1 FFN split of tools/probes/fp32x_ffn_3_1_split ranked them the other way round).
 
 __device__ __forceinline__ f32x4* a8_slot(char* lds, int row, int col, int lane) {
     return reinterpret_cast<f32x4*>(lds) + (row * kTiles + col) * 64 + lane;
@@ -366,13 +345,7 @@ __device__ __forceinline__ void gelu_pair(f32x4 (&hq)[2]) {
     for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int m = 0; m < 4; ++m) {
-#if AMUSE_X_ERF == 1
             hq[i][m] = gelu_erf(hq[i][m]);        // libm erff (one divergent branch per element)
-#elif AMUSE_X_ERF == 2
-            hq[i][m] = gelu_erf_fast(hq[i][m]);   // Abramowitz-Stegun on rcp / exp2
-#else
-            hq[i][m] = gelu_erf_bf(hq[i][m]);     // branch-free fit (amuse_dev.hpp erf_bf)
-#endif
         }
 }
 
@@ -389,7 +362,7 @@ __device__ __forceinline__ void ffn_half(f32x4 (&part)[kTiles], const F16Pair (&
     const float* b1 = pv + PV_L1_B + 16 * (kTiles * h + 2 * Q0) + 4 * g;
     f32x4 ha[2] = {ld4(b1), ld4(b1 + 16)}, hb[2] = {ld4(b1 + 32), ld4(b1 + 48)};
     if constexpr (EARLY < 32) ring_issue<32 - EARLY, kR8, EARLY>(rg);
-    gemm_xs<2, 4, false, 0, !DEFER || AMUSE_X_A_DEFER2 == 1>(ha, xs, rg);    // F1a; (B) slots 0..15 <- F2a
+    gemm_xs<2, 4, false, 0, !DEFER>(ha, xs, rg);    // F1a; (B) slots 0..15 <- F2a
     stamp8<PROF>(pf);
     gemm_xs<2, 4, false, 16, !DEFER>(hb, xs, rg);   // F1b; (B) slots 16..31 <- F2b
     stamp8<PROF>(pf);
@@ -397,8 +370,7 @@ __device__ __forceinline__ void ffn_half(f32x4 (&part)[kTiles], const F16Pair (&
     stamp8<PROF>(pf);
     if constexpr (DEFER) {
         gelu_pair(hb);
-        if constexpr (AMUSE_X_A_DEFER2 == 1) ring_issue<16, kR8, 16>(rg);
-        else ring_issue<32, kR8, 0>(rg);
+        ring_issue<32, kR8, 0>(rg);
         stamp8<PROF>(pf);
         const F16Pair hsa = split_f16(ha[0], ha[1]), hsb = split_f16(hb[0], hb[1]);
         gemm_xs<kTiles, 1, false, 0, false>(part, &hsa, rg);
@@ -461,27 +433,25 @@ __device__ __forceinline__ void encoder_block8x(F16Pair (&xs)[4], f32x4 (&xo)[2]
         }
         stamp8<PROF>(pf);  // 1: in_proj + attention + out_proj partial
         // ---- out_proj combine (B reduces): meanwhile fetch linear1 of this wave's FFN half (and store a pushed skip level)
-        combine_publish_c1<AMUSE_X_C1_N1, AMUSE_X_C1_N2>(part, xs, lds, h, lane, rg, push, skip_dst, pv_next_src, pv_next_dst);
+        combine_publish_c1<kXC1N1, kXC1N2>(part, xs, lds, h, lane, rg, push, skip_dst, pv_next_src, pv_next_dst);
         stamp8<PROF>(pf);  // 2: combine 1
 #pragma unroll
         for (int t = 0; t < kTiles; ++t) part[t] = splat4(0.f);
-        ffn_half<0, 32, AMUSE_X_A_DEFER != 0, PROF>(part, xs, rg, pv, h, g, pf);
+        ffn_half<0, 32, true, PROF>(part, xs, rg, pv, h, g, pf);
         stamp8<PROF>(pf);  // 3: FFN
         // ---- linear2 combine (B reduces): meanwhile fetch the next block's leading units
-        combine_publish_c2<AMUSE_X_C2_N1>(part, xs, lds, h, lane, rg, next_has_skip, skip_src);
+        combine_publish_c2<kXC2N1>(part, xs, lds, h, lane, rg, next_has_skip, skip_src);
     } else {
         // ---- ring empty on entry: fetch linear1 of this wave's FFN half while the A waves run attention
-        ring_issue<AMUSE_X_B_EARLY, kR8, 0>(rg);
+        ring_issue<kXBEarly, kR8, 0>(rg);
         stamp8<PROF>(pf);
 #pragma unroll
         for (int t = 0; t < kTiles; ++t) part[t] = splat4(0.f);
         combine_reduce<4>(part, xo, xs, pv + PV_OUT_B, pv + PV_LN1_W, pv + PV_LN1_B, lds, h, lane);
         stamp8<PROF>(pf);
-        if constexpr (AMUSE_X_B_PRIO != 0) __builtin_amdgcn_s_setprio(AMUSE_X_B_PRIO);
-        ffn_half<2, AMUSE_X_B_EARLY, false, PROF>(part, xs, rg, pv, h, g, pf);
-#ifndef AMUSE_X_B_PRIO_KEEP   // (A/B: keep the priority through the linear2 combine and the next out_proj combine)
-        if constexpr (AMUSE_X_B_PRIO != 0) __builtin_amdgcn_s_setprio(0);
-#endif
+        __builtin_amdgcn_s_setprio(kXBPrio);
+        ffn_half<2, kXBEarly, false, PROF>(part, xs, rg, pv, h, g, pf);
+        __builtin_amdgcn_s_setprio(0);
         stamp8<PROF>(pf);  // 3: FFN
         if (next_has_skip) ring_issue<16, kR8, 0>(rg);  // the x half of this wave's two output tiles of the next block's skip linear
         combine_reduce<8>(part, xo, xs, pv + PV_L2_B, pv + PV_LN2_W, pv + PV_LN2_B, lds, h, lane);

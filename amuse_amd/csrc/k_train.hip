@@ -431,11 +431,8 @@ bool own_wgrad() {
     static const bool on = [] { const char* e = getenv("AMUSE_TRAIN_WGRAD"); return !(e && e[0] == 'v'); }();
     return on;
 }
-// gradients of at least this many elements go to rocBLAS (AMUSE_TRAIN_WGRAD_MAX; A/B of the wide instantiation)
-long wgrad_max_elems() {
-    static const long v = [] { const char* e = getenv("AMUSE_TRAIN_WGRAD_MAX"); return e ? atol(e) : 131072L; }();
-    return v;
-}
+// gradients of at least this many elements go to rocBLAS
+constexpr long wgrad_max_elems() { return 131072L; }
 int wgrad_launch(const float* dy, const float* x, float* out, long rows, long M, long N, hipStream_t st) {
     int dev = 0;
     HIP_TRY(hipGetDevice(&dev));

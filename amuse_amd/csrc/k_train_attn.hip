@@ -29,10 +29,6 @@
 namespace amuse {
 namespace {
 
-// timing ablations (variant builds; wrong results): 1 = the forward's key loop runs one tile instead of all, 2 = no K / V staging
-#ifndef AMUSE_ATTN_ABL
-#define AMUSE_ATTN_ABL 0
-#endif
 constexpr int kAMaxTiles = 19;     // S <= 304
 constexpr int kAImg = kAMaxTiles * 2 * 64;   // f32x4 per image (38,912 B)
 
@@ -113,10 +109,8 @@ __global__ __launch_bounds__(512) void k_attn_fwd(AttnArgs a) {
     const int bh = blockIdx.x, b = bh >> 2, h = bh & 3;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4, c = lane & 15;
     const float* base = a.qkv + (size_t)b * S * 384 + 32 * h;
-    if constexpr ((AMUSE_ATTN_ABL & 2) == 0) {
-        stage_images(base + 128, 384, S, nt, RK, nullptr);
-        stage_images(base + 256, 384, S, nt, nullptr, TV);
-    }
+    stage_images(base + 128, 384, S, nt, RK, nullptr);
+    stage_images(base + 256, 384, S, nt, nullptr, TV);
     __syncthreads();
     const int nw = blockDim.x >> 6, nwq = nw * gridDim.y;           // query tiles are dealt round-robin over (part, wave)
     for (int it = blockIdx.y * nw + wave; it < nt; it += nwq) {
@@ -126,7 +120,7 @@ __global__ __launch_bounds__(512) void k_attn_fwd(AttnArgs a) {
         for (int hh = 0; hh < 2; ++hh) q[hh] = qi < S ? ld4(base + (size_t)qi * 384 + 16 * hh + 4 * g) : splat4(0.f);
         float m_run = -INFINITY, l_run = 0.f;
         f32x4 o[2] = {splat4(0.f), splat4(0.f)};
-        for (int jt = 0; jt < ((AMUSE_ATTN_ABL & 1) ? 1 : nt); ++jt) {
+        for (int jt = 0; jt < nt; ++jt) {
             f32x4 s = dot32(RK, jt, q, splat4(0.f), lane) * kScaleLog2;   // lane (g, c): S[query c][keys 16 jt + 4 g + m], log2 units
             float mx = -INFINITY;
 #pragma unroll
@@ -316,8 +310,7 @@ int amuse_train_attn_fwd(const float* qkv, int B, int S, float p, uint64_t seed,
         once.set(dev_);
     }
     // two workgroups per (clip, head) while that fills the chip; eight waves each (two per SIMD: one's softmax under the other's MFMAs)
-    static const int env_p = [] { const char* e = getenv("AMUSE_ATTN_FWD_PARTS"); return e ? atoi(e) : 0; }();
-    const int parts = env_p > 0 ? env_p : ((S > 64 && B * 4 < 512) ? 2 : 1);
+    const int parts = (S > 64 && B * 4 < 512) ? 2 : 1;
     hipLaunchKernelGGL(k_attn_fwd, dim3(B * 4, parts), dim3(512), kFwdLds, (hipStream_t)stream, a);
     HIP_TRY(hipGetLastError());
     return 0;

@@ -23,10 +23,6 @@ namespace amuse {
 namespace {
 
 constexpr int kGN = 128, kGK = 32;
-// timing ablations (variant builds only; wrong numerics): 1 = no MFMAs / fragment reads (copies, barriers, epilogue stay), 2 = no copies
-#ifndef AMUSE_GEMM_ABL
-#define AMUSE_GEMM_ABL 0
-#endif
 // (a chunk of b is 16 KiB either way: 128 rows (n) x 128 B, or 32 rows (k) x 512 B)
 
 __device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_dst) {   // (k_vae_fused.hip: LDS-DMA outside hipcc's waitcnt bookkeeping)
@@ -37,26 +33,12 @@ __device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_dst) {   /
                  : "memory");
 }
 
-// -DAMUSE_GEMM_PROF=1 (variant builds only): wave 0 (MFMA) and wave 4 (copying) of the workgroup in the middle of the grid stamp the cycle counter at their phase
-// boundaries; the launcher prints the deltas of its third call
-#ifndef AMUSE_GEMM_PROF
-#define AMUSE_GEMM_PROF 0
-#endif
-#if AMUSE_GEMM_PROF
-__device__ unsigned long long g_gprof[2][64];
-#define GSTAMP(w, i) do { if (prof_on && (i) < 64) g_gprof[w][i] = __builtin_readcyclecounter(); } while (0)
-#else
-#define GSTAMP(w, i) do { } while (0)
-#endif
 template <int n>
 __device__ __forceinline__ void wait_vm_le() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory"); }
-#ifndef AMUSE_GEMM_COPY_WAVES
-#define AMUSE_GEMM_COPY_WAVES 4
-#endif
-// waves 4 .. of a workgroup only copy: an LDS-DMA instruction costs its wave 100-190 cycles of issue here (cycle stamps, -DAMUSE_GEMM_PROF=1; MI355X_MICROARCH.md has 60-185) -
+// waves 4 .. of a workgroup only copy: an LDS-DMA instruction costs its wave 100-190 cycles of issue here (cycle stamps of round 5, profiles/r05_train_gemm_ab.txt; MI355X_MICROARCH.md has 60-185) -
 // six of them per chunk in front of 48 MFMAs held the matrix pipe at 60 % when the four MFMA waves copied their own pieces, and TWO copying waves (11 pieces each per
 // chunk = ~2,150 cycles against the chunk's 1,536 of MFMAs) were the critical path of every chunk: four (6 x ~150) are not; measured 6-7 % faster than two
-constexpr int kGemmCopyWaves = AMUSE_GEMM_COPY_WAVES;
+constexpr int kGemmCopyWaves = 4;
 // MT = 16-row tiles per workgroup (3: 48 rows, 2: 32 rows); TB: b is [N][K] (out = a b^T), else [K][N]
 // kGemmBufs = LDS buffers of the chunk ring (3: two chunks in flight under the MFMAs of a third; 2: one - and room for four workgroups per CU)
 template <int MT, bool TB, int kGemmBufs>
@@ -72,7 +54,6 @@ __global__ __launch_bounds__(64 * (4 + kGemmCopyWaves)) void k_train_gemm_tall(c
     const int m0 = blockIdx.x * (16 * MT), nb0 = blockIdx.y * kGN;
     const int nchunks = K / kGK;
     [[maybe_unused]] const bool prof_on = blockIdx.x == gridDim.x / 2 && blockIdx.y == 0 && lane == 0 && (wave == 0 || wave == 4);
-    GSTAMP(wave == 0 ? 0 : 1, 0);
     if (wave >= 4) {
         const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) const void*)smem;
         const int cw = wave - 4;
@@ -99,14 +80,13 @@ __global__ __launch_bounds__(64 * (4 + kGemmCopyWaves)) void k_train_gemm_tall(c
             for (int i = 0; i < kPerWave; ++i) {
                 const int p = cw + kGemmCopyWaves * i;
                 if (p >= kPieces) continue;   // (wave-uniform)
-                if constexpr ((AMUSE_GEMM_ABL & 2) == 0) glds16(src[i], d + i * (kGemmCopyWaves * 1024));
+                glds16(src[i], d + i * (kGemmCopyWaves * 1024));
                 src[i] += (p < kAPieces || TB) ? kGK : (size_t)kGK * N;
             }
         };
 #pragma unroll
         for (int c = 0; c < kGemmBufs - 1; ++c)
             if (c < nchunks) fetch(c);
-        GSTAMP(1, 1);
         int buf = 0;
         for (int c = 0; c < nchunks; ++c) {
             // chunk c has landed: only the chunks issued behind it (up to c + kGemmBufs - 2) may still be in flight.  One barrier per chunk: behind it every MFMA wave
@@ -116,9 +96,7 @@ __global__ __launch_bounds__(64 * (4 + kGemmCopyWaves)) void k_train_gemm_tall(c
             else if (behind == 1) { if (full) wait_vm_le<kPerWave>(); else wait_vm_le<kPerWave - 1>(); }
             else { if (full) wait_vm_le<2 * kPerWave>(); else wait_vm_le<2 * kPerWave - 2>(); }
             static_assert(kGemmBufs == 2 || kGemmBufs == 3, "the wait counts above");
-            GSTAMP(1, 2 + 2 * c);
             __builtin_amdgcn_s_barrier();
-            GSTAMP(1, 3 + 2 * c);
             if (c + kGemmBufs - 1 < nchunks) fetch(buf == 0 ? kGemmBufs - 1 : buf - 1);
             buf = buf == kGemmBufs - 1 ? 0 : buf + 1;
         }
@@ -147,15 +125,12 @@ __global__ __launch_bounds__(64 * (4 + kGemmCopyWaves)) void k_train_gemm_tall(c
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) acc[mt][0] = acc[mt][1] = splat4(0.f);
     int buf = 0;
-    GSTAMP(0, 1);
     for (int c = 0; c < nchunks; ++c) {
-        GSTAMP(0, 2 + 2 * c);
         __builtin_amdgcn_s_barrier();   // chunk c is in its buffer (the copying waves waited for it)
-        GSTAMP(0, 3 + 2 * c);
         const char* A = smem + buf * kBuf;
         const char* B = A + kAPieces * 1024;
 #pragma unroll
-        for (int j = 0; j < ((AMUSE_GEMM_ABL & 1) ? 0 : 2); ++j) {
+        for (int j = 0; j < 2; ++j) {
             f32x4 af[MT];
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
@@ -189,7 +164,6 @@ __global__ __launch_bounds__(64 * (4 + kGemmCopyWaves)) void k_train_gemm_tall(c
         }
         buf = buf == kGemmBufs - 1 ? 0 : buf + 1;
     }
-    GSTAMP(0, 2 + 2 * nchunks);
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
@@ -197,11 +171,6 @@ __global__ __launch_bounds__(64 * (4 + kGemmCopyWaves)) void k_train_gemm_tall(c
             const int m = m0 + 16 * mt + 4 * g + v;
             if (m < M) *reinterpret_cast<float2*>(out + (size_t)m * N + col) = float2{acc[mt][0][v] + init[mt][v].x, acc[mt][1][v] + init[mt][v].y};
         }
-#if AMUSE_GEMM_PROF
-    GSTAMP(0, 3 + 2 * nchunks);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    GSTAMP(0, 4 + 2 * nchunks);
-#endif
 }
 
 }  // namespace
@@ -209,20 +178,18 @@ __global__ __launch_bounds__(64 * (4 + kGemmCopyWaves)) void k_train_gemm_tall(c
 // Which of the step's projections run here: every tall one the tiling covers.  Back to back on hot operands rocBLAS is 20-25 % faster on the un-biased forward
 // projections with 384 / 512 outputs (and slower on everything else: biased calls, every input gradient dy W); inside the training step - operands produced by the
 // kernel in front, the library's code objects alternating with ours - the step is fastest with ALL of them here: 13.0-13.1 ms of device time per iteration against
-// 13.6-15.0 with rocBLAS and 13.9-14.2 with a per-shape mix (profiles/r05_train_gemm_ab.txt).  AMUSE_TRAIN_GEMM=vendor: rocBLAS for everything (A/B).
+// 13.6-15.0 with rocBLAS and 13.9-14.2 with a per-shape mix (profiles/r05_train_gemm_ab.txt).
 bool train_gemm_tall_takes(long M, long N, long K, bool /*tb*/, bool /*bias*/) { return M >= 1024 && !(N & 127) && !(K & 31) && N <= 4096 && K <= 4096; }
 
 // out[M][N] = (bias | accumulate: out) + a . (tb ? b^T : b); the caller has checked train_gemm_tall_takes
 hipError_t launch_train_gemm_tall(const float* a, const float* b, const float* bias, float* out, long M, long N, long K, bool tb, bool accumulate, hipStream_t stream) {
     // 48-row workgroups unless 32-row ones fill the chip better (a launch is MFMA-bound: its time is the busiest CU's tiles)
-    static const int force = [] { const char* e = getenv("AMUSE_TRAIN_GEMM_MT"); return e ? atoi(e) : 0; }();
     const long wg3 = ((M + 47) / 48) * (N / kGN), wg2 = ((M + 31) / 32) * (N / kGN);
     const long cost3 = ((wg3 + 255) / 256) * 3, cost2 = ((wg2 + 255) / 256) * 2;
-    const bool mt3 = force ? force == 3 : cost3 <= cost2;
+    const bool mt3 = cost3 <= cost2;
     const dim3 grid((unsigned)((M + (mt3 ? 47 : 31)) / (mt3 ? 48 : 32)), (unsigned)(N / kGN)), block(64 * (4 + kGemmCopyWaves));
     const int acc = accumulate ? 1 : 0;
-    static const int bufs = [] { const char* e = getenv("AMUSE_TRAIN_GEMM_BUFS"); return e && atoi(e) == 2 ? 2 : 3; }();
-    const size_t lds = (size_t)bufs * ((mt3 ? 6 : 4) + 16) * 1024;
+    const size_t lds = (size_t)3 * ((mt3 ? 6 : 4) + 16) * 1024;   // three chunk buffers: two chunks in flight under the MFMAs of a third (two measured slower, r05_train_gemm_ab.txt)
     static DeviceOnce once;
     int dev_;
     if (!once.done(&dev_)) {
@@ -233,35 +200,11 @@ hipError_t launch_train_gemm_tall(const float* a, const float* b, const float* b
         }
         once.set(dev_);
     }
-#define AMUSE_GEMM_LAUNCH(MT_, TB_, NB_) hipLaunchKernelGGL((k_train_gemm_tall<MT_, TB_, NB_>), grid, block, lds, stream, a, b, bias, out, (int)M, (int)N, (int)K, acc)
-    if (bufs == 3) {
-        if (mt3 && tb) AMUSE_GEMM_LAUNCH(3, true, 3);
-        else if (mt3) AMUSE_GEMM_LAUNCH(3, false, 3);
-        else if (tb) AMUSE_GEMM_LAUNCH(2, true, 3);
-        else AMUSE_GEMM_LAUNCH(2, false, 3);
-    } else {
-        if (mt3 && tb) AMUSE_GEMM_LAUNCH(3, true, 2);
-        else if (mt3) AMUSE_GEMM_LAUNCH(3, false, 2);
-        else if (tb) AMUSE_GEMM_LAUNCH(2, true, 2);
-        else AMUSE_GEMM_LAUNCH(2, false, 2);
-    }
-#undef AMUSE_GEMM_LAUNCH
-#if AMUSE_GEMM_PROF
-    {
-        static int calls = 0;
-        if (++calls % 50 == 3) {
-            (void)hipStreamSynchronize(stream);
-            unsigned long long h[2][64];
-            (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_gprof), sizeof(h));
-            const int n = (int)(K / kGK);
-            fprintf(stderr, "GPROF M %ld N %ld K %ld tb %d mt %d grid %u x %u: MFMA wave:", M, N, K, (int)tb, mt3 ? 3 : 2, grid.x, grid.y);
-            for (int i = 1; i <= 4 + 2 * n && i < 64; ++i) fprintf(stderr, " %llu", h[0][i] - h[0][i - 1]);
-            fprintf(stderr, " | copy wave (from the MFMA wave's start %lld):", (long long)(h[1][0] - h[0][0]));
-            for (int i = 1; i <= 1 + 2 * n && i < 64; ++i) fprintf(stderr, " %llu", h[1][i] - h[1][i - 1]);
-            fprintf(stderr, "\n");
-        }
-    }
-#endif
+    auto go = [&](auto kernel) { hipLaunchKernelGGL(kernel, grid, block, lds, stream, a, b, bias, out, (int)M, (int)N, (int)K, acc); };
+    if (mt3 && tb) go(k_train_gemm_tall<3, true, 3>);
+    else if (mt3) go(k_train_gemm_tall<3, false, 3>);
+    else if (tb) go(k_train_gemm_tall<2, true, 3>);
+    else go(k_train_gemm_tall<2, false, 3>);
     return hipGetLastError();
 }
 

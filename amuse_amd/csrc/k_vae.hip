@@ -510,10 +510,7 @@ __global__ __launch_bounds__(256) void k_vae_attn(VaeAttnArgs a) {
 // online softmax on 8 register values + two permlane butterflies, 2 PV MFMAs (V^T.P^T, K = 32 keys).
 constexpr int kPairs = kKeyRows / 32;                        // 10
 constexpr int kAttnBf16LdsBytes = kKeyRows * 64 + kPairs * 2 * 16 * 64;  // 20 KiB + 20 KiB
-#ifndef AMUSE_ATTN_SPLIT_MAX
-#define AMUSE_ATTN_SPLIT_MAX 48   // measured (profiles/r03_attn_split_threshold.txt): pays up to ~48 clips in bf16 and fp32x, not at 63
-#endif
-constexpr int kAttnSplitMaxClips = AMUSE_ATTN_SPLIT_MAX;   // up to this many clips per launch a (clip, head) pair is five workgroups (below)
+constexpr int kAttnSplitMaxClips = 48;   // up to this many clips per launch a (clip, head) pair is five workgroups (below); measured (profiles/r03_attn_split_threshold.txt): pays up to ~48 clips in bf16 and fp32x, not at 63
 
 template <int P16, int NQ>   // P16 = PREC_BF16 / PREC_F16: the operand format of q, k, v, p and the output
 __device__ __forceinline__ void attn_qtiles_bf16(const uint4* Kb, const uint4* Vt, const unsigned short* qg,
@@ -874,18 +871,10 @@ hipError_t attn_mode(const VaeAttnArgs& a, int precision, hipStream_t stream, bo
     if (precision == PREC_F32) {
         hipLaunchKernelGGL((k_vae_attn<PREC_F32, MODE>), grid, block, kAttnLdsBytes, stream, a);
     } else if (precision == PREC_F16X2) {
-        // the fragment-image kernel; AMUSE_F32X_ATTN=generic runs the fp32 kernel's PREC_F16X2 instantiation instead (A/B, tests)
-        static const bool generic = [] { const char* e = getenv("AMUSE_F32X_ATTN"); return e && e[0] == 'g'; }();
-        if (generic) {
-            hipLaunchKernelGGL((k_vae_attn<PREC_F16X2, MODE>), grid, block, kAttnLdsBytes, stream, a);
-        } else {
-            // eight waves per workgroup for unsplit launches (measured: decode 2.42 -> 2.30 ms at 256 clips, 0.93 -> 0.86 at 64; the split
-            // launches of small batches keep four: one query tile per wave); AMUSE_ATTNX_WAVES=4 pins four (A/B)
-            static const int nw_env = [] { const char* e = getenv("AMUSE_ATTNX_WAVES"); return e ? atoi(e) : 0; }();
-            const bool w8 = grid16.y == 1 && nw_env != 4;
-            if (w8) hipLaunchKernelGGL((k_vae_attn_x<MODE, 8>), grid16, dim3(512), kAttnXLdsBytes, stream, a);
-            else hipLaunchKernelGGL((k_vae_attn_x<MODE, 4>), grid16, block, kAttnXLdsBytes, stream, a);
-        }
+        // the fragment-image kernel: eight waves per workgroup for unsplit launches (measured: decode 2.42 -> 2.30 ms at 256 clips, 0.93 -> 0.86 at 64); the split
+        // launches of small batches keep four: one query tile per wave
+        if (grid16.y == 1) hipLaunchKernelGGL((k_vae_attn_x<MODE, 8>), grid16, dim3(512), kAttnXLdsBytes, stream, a);
+        else hipLaunchKernelGGL((k_vae_attn_x<MODE, 4>), grid16, block, kAttnXLdsBytes, stream, a);
     } else if (precision == PREC_F16) {
         hipLaunchKernelGGL((k_vae_attn_bf16<PREC_F16, MODE>), grid16, block, kAttnBf16LdsBytes, stream, a);
     } else {

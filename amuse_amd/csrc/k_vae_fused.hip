@@ -140,14 +140,13 @@ __device__ __forceinline__ void decode_tiles(const VaeFusedArgs& a, char* smem, 
                 for (int o = 0; o < 6; ++o) st4(fst + r * kQStride + 16 * o + 4 * g, keep ? f[6 * qq + o] : splat4(0.f));
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the staging tile is wave-private: no barrier
                 const int f0 = 96 * quarter, nfe = quarter == 3 ? kFeats - 288 : 96, njo = quarter == 3 ? kJoints - 48 : 16;
-                const bool abl_nostore = (AMUSE_FABL & 16) != 0 && a.B > 0;   // (timing ablation: no output stores)
-                if (a.feats_out && !abl_nostore) {
+                if (a.feats_out) {
                     for (int i = lane; i < rows_here * nfe; i += 64) {
                         const int rr = i / nfe, c = i - rr * nfe;
                         a.feats_out[(row0 + rr) * kFeats + f0 + c] = fst[rr * kQStride + c];
                     }
                 }
-                if (a.poses_out && !abl_nostore) {
+                if (a.poses_out) {
                     for (int i = lane; i < rows_here * njo; i += 64) {
                         const int rr = i / njo, jn = i - rr * njo;
                         float aa[3];
@@ -156,7 +155,7 @@ __device__ __forceinline__ void decode_tiles(const VaeFusedArgs& a, char* smem, 
                         dst[0] = aa[0]; dst[1] = aa[1]; dst[2] = aa[2];
                     }
                 }
-                if (a.trans_out && quarter == 3 && !abl_nostore) {
+                if (a.trans_out && quarter == 3) {
                     for (int i = lane; i < rows_here * 3; i += 64) {
                         const int rr = i / 3, c = i - rr * 3;
                         a.trans_out[(row0 + rr) * 3 + c] = fst[rr * kQStride + (330 - 288) + c];

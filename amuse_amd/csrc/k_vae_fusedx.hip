@@ -26,20 +26,8 @@ constexpr int kXOffPv = kXOffW + kWBufs * kStageBytes;
 constexpr int kXOffCa = kXOffPv + 2 * kPvSlot;
 constexpr int kXLdsBytes = kXOffCa + kCaBytes;           // 152,576 B
 static_assert(kXLdsBytes <= 160 * 1024, "LDS");
-// erf of the FFN activation: 0 = libm erff (the staged kernels' form), 1 = Abramowitz-Stegun 7.1.26 on the hardware rcp / exp2 (gelu_erf_fast: |erf error| <= 1.5e-7),
-// 2 = the branch-free fit of the fp32x sampler (amuse_dev.hpp erf_bf: max |error| 7.9e-8).  All three time the same (1.65 ms per 256-clip decode); the two Horner chains
-// of erf_bf on pairs of values (v_pk_fma_f32) - same bits - are 1 % slower; without any erf the decode takes 1.54 instead of 1.76 ms (no hoist): 0.22 ms of exposed VALU time
-#ifndef AMUSE_FX_ERF
-#define AMUSE_FX_ERF 2
-#endif
-// timing ablations (variant builds only; wrong numerics): 1 = no erf in the FFN activation, 2 = no MFMAs in the FFN (fragment reads, stage protocol and GELU stay),
-// 4 = no softmax arithmetic in the attention (scores fed to PV as they are), 8 = no attention at all (q, k, v, images, barriers stay)
-#ifndef AMUSE_FX_ABL
-#define AMUSE_FX_ABL 0
-#endif
-#ifndef AMUSE_FX_FFN_PIPE
-#define AMUSE_FX_FFN_PIPE 1
-#endif
+// erf of the FFN activation: the branch-free fit (amuse_dev.hpp erf_bf: max |error| 7.9e-8).  libm erff and Abramowitz-Stegun 7.1.26 on the hardware rcp / exp2 time the same
+// (1.65 ms per 256-clip decode); without any erf the decode takes 1.54 instead of 1.76 ms (no hoist): 0.22 ms of exposed VALU time (profiles/r05_fusedx_decode.txt).
 constexpr int kParkTile = 8192;                          // one parked operand image: [4 k-pairs][hi | lo][64 lanes x 16 B]
 
 // one product of split operands, weights as the A operand: acc += Wl.xh + Wh.xl + Wh.xh (the term order of k_vae_rows8x)
@@ -55,26 +43,20 @@ __device__ __forceinline__ f32x4 mfma3t(f16x8 wh, f16x8 wl, const F16Pair& x, f3
     return mfma_f16(x.hi, wh, acc);
 }
 // the 8 unit pairs of the current LDS stage: f(i, hi, lo); pair i + 1 is read before pair i's MFMAs
-// Who copies the weight stream: two pieces of every 16-piece stage per wave, as in the 16-bit kernels.  -DAMUSE_FX_DMA_SPLIT=1 (A/B): the four TWO-tile waves fetch
-// four pieces each and the three-tile waves - the critical path of every stage, the others wait ~1,000 cycles at its barrier - none: bitwise, and flat (1.67 ms per 256-clip
-// decode either way; profiles/r05_fusedx_decode.txt).
-#ifndef AMUSE_FX_DMA_SPLIT
-#define AMUSE_FX_DMA_SPLIT 0
-#endif
-template <int NT> constexpr int kP = AMUSE_FX_DMA_SPLIT ? (NT == 3 ? 0 : 4) : 2;   // pieces per stage of a wave with NT tiles
+// Who copies the weight stream: two pieces of every 16-piece stage per wave, as in the 16-bit kernels.  (Leaving the copies to the four TWO-tile waves - the three-tile waves
+// are the critical path of every stage - is bitwise the same and flat: 1.67 ms per 256-clip decode either way, profiles/r05_fusedx_decode.txt.)
+constexpr int kP = 2;   // pieces per stage and wave
 template <int NT>
 __device__ __forceinline__ void stage_fetch_x(Stager& s) {
-    if constexpr (kP<NT> > 0) {
-        const unsigned d = __builtin_amdgcn_readfirstlane(s.dst0 + s.widx * kStageBytes);
+    const unsigned d = __builtin_amdgcn_readfirstlane(s.dst0 + s.widx * kStageBytes);
 #pragma unroll
-        for (int i = 0; i < kP<NT>; ++i) glds16(s.src + i * 64, d + i * 1024);
-        s.src += kStage * 64;
-        s.widx = s.widx == kWBufs - 1 ? 0 : s.widx + 1;
-    }
+    for (int i = 0; i < kP; ++i) glds16(s.src + i * 64, d + i * 1024);
+    s.src += kStage * 64;
+    s.widx = s.widx == kWBufs - 1 ? 0 : s.widx + 1;
 }
 template <int NT>
 __device__ __forceinline__ void stage_end_x(Stager& s) {
-    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(kP<NT>) : "memory");
+    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(kP) : "memory");
     s.ridx = s.ridx == kWBufs - 1 ? 0 : s.ridx + 1;
 }
 template <int NT, bool FETCH = true, class F>
@@ -124,14 +106,10 @@ struct Images {
 // frag_slot), one pair of key tiles (32 keys) per trip, merged online in log2 units.  The loop is VALU-bound (the kernel's SIMDs spend 54 % of their time issuing VALU
 // instructions, 32 % on the matrix pipe - profiles/r05_fusedx_pmc.txt), so it is built like the 16-bit kernels' `attend`: scores leave the MFMAs RELATIVE to the row's
 // running maximum (C operand = -m_run), the maximum's butterfly and the rescale run only in trips that move it (wave-uniform ballot), the row sums ride the matrix pipe
-// on a ones fragment (of the split P the PV product uses), v_max3 without NaN canonicalisation (-fno-honor-nans).  AMUSE_FX_ATTN=0: the staged kernel's loop (A/B).
-#ifndef AMUSE_FX_ATTN
-#define AMUSE_FX_ATTN 1
-#endif
+// on a ones fragment (of the split P the PV product uses), v_max3 without NaN canonicalisation (-fno-honor-nans).
 __device__ __forceinline__ void attend_x(const uint4* Kh, const uint4* Kl, const uint4* Vh, const uint4* Vl, const F16Pair& qs, f32x4 (&o)[2], int len, int g, int r) {
     const int fs = frag_slot(g, r);
     o[0] = o[1] = splat4(0.f);
-#if AMUSE_FX_ATTN
     float m_run = 0.f;
     f32x4 os = splat4(0.f);
     const f16x8 ones = __builtin_bit_cast(f16x8, r == 0 ? uint4{OP_ONE2, OP_ONE2, OP_ONE2, OP_ONE2} : uint4{0u, 0u, 0u, 0u});
@@ -202,72 +180,6 @@ __device__ __forceinline__ void attend_x(const uint4* Kh, const uint4* Kl, const
     const float l = allreduce_g_sum(os[0]);
     o[0] = o[0] / l;
     o[1] = o[1] / l;
-#else
-    float m_run = -INFINITY, l_run = 0.f;
-    auto pair = [&](int jp, auto masked) {
-        constexpr bool MASKED = decltype(masked)::value;
-        f16x8 kh[2], kl[2], vh[2], vl[2];
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            kh[u] = __builtin_bit_cast(f16x8, Kh[(2 * jp + u) * 64 + fs]);
-            kl[u] = __builtin_bit_cast(f16x8, Kl[(2 * jp + u) * 64 + fs]);
-            vh[u] = __builtin_bit_cast(f16x8, Vh[(2 * jp + u) * 64 + fs]);
-            vl[u] = __builtin_bit_cast(f16x8, Vl[(2 * jp + u) * 64 + fs]);
-        }
-        bool ok[2][4];
-#pragma unroll
-        for (int u = 0; u < 2; ++u)
-#pragma unroll
-            for (int m = 0; m < 4; ++m) ok[u][m] = !MASKED || (32 * jp + 16 * u + 4 * g + m) < len;
-        f32x4 st[2];
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            st[u] = mfma_f16(kl[u], qs.hi, splat4(0.f));
-            st[u] = mfma_f16(kh[u], qs.lo, st[u]);
-            st[u] = mfma_f16(kh[u], qs.hi, st[u]);
-        }
-        float mx = -INFINITY;
-#pragma unroll
-        for (int u = 0; u < 2; ++u)
-#pragma unroll
-            for (int m = 0; m < 4; ++m) mx = ok[u][m] ? fmaxf(mx, st[u][m]) : mx;
-        mx = allreduce_g_max(mx);
-        const bool moved = __builtin_amdgcn_ballot_w64(mx > m_run) != 0;   // (uniform)
-        float m_new = m_run, alpha = 1.0f;
-        if (moved) {
-            m_new = fmaxf(m_run, mx);
-            alpha = (m_new == -INFINITY) ? 1.0f : __builtin_amdgcn_exp2f(m_run - m_new);
-            o[0] = o[0] * alpha;
-            o[1] = o[1] * alpha;
-            m_run = m_new;
-        }
-        f32x4 p[2];
-        float ps = 0.f;
-#pragma unroll
-        for (int u = 0; u < 2; ++u)
-#pragma unroll
-            for (int m = 0; m < 4; ++m) {
-                p[u][m] = ok[u][m] ? __builtin_amdgcn_exp2f(st[u][m] - m_new) : 0.f;
-                ps += p[u][m];
-            }
-        ps = allreduce_g_sum(ps);
-        l_run = l_run * alpha + ps;
-        const F16Pair pp = split_f16(p[0], p[1]);
-#pragma unroll
-        for (int td = 0; td < 2; ++td) {
-            o[td] = mfma_f16(vl[td], pp.hi, o[td]);
-            o[td] = mfma_f16(vh[td], pp.lo, o[td]);
-            o[td] = mfma_f16(vh[td], pp.hi, o[td]);
-        }
-    };
-    const int full = min(len / 32, kPairs);
-#pragma unroll 1
-    for (int jp = 0; jp < full; ++jp) pair(jp, std::false_type{});
-#pragma unroll 1
-    for (int jp = full; jp < kPairs; ++jp) pair(jp, std::true_type{});
-    o[0] = o[0] / l_run;
-    o[1] = o[1] / l_run;
-#endif
 }
 
 // What a block half needs to know about its clip and launch comes from the kernel's argument block through these accessors (kept in the kernarg segment and re-read
@@ -428,8 +340,7 @@ __device__ __forceinline__ void attn_half_x(f32x4 (&x)[NT][kTiles], Stager& sg, 
 #pragma unroll 1
             for (int j = 0; j < NT; ++j) {   // runtime loop: the attention's only copy in the instruction stream; the tiles rotate through slot 0
                 f32x4 o[2];
-                if constexpr ((AMUSE_FX_ABL & 8) != 0) { o[0] = __builtin_bit_cast(f32x4, qs[0].hi); o[1] = __builtin_bit_cast(f32x4, qs[0].lo); }
-                else attend_x(Kh, Kl, Vh, Vl, qs[0], o, len, g, r);
+                attend_x(Kh, Kl, Vh, Vl, qs[0], o, len, g, r);
                 const int frame = 16 * (tile0 + 4 * j) + r;
                 if (frame < S) {
                     float* dst = obuf + (size_t)frame * kD + 32 * h + 4 * g;
@@ -497,9 +408,9 @@ __device__ __forceinline__ void row_half_x(f32x4 (&x)[NT][kTiles], Stager& sg, c
             stage_fetch_x<NT>(sg);
             if (c + 1 < 4) {
                 fetch_o(c + 1);
-                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kP<NT> + 2 * NT) : "memory");   // this k-pair's outputs are in (and every older weight stage)
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kP + 2 * NT) : "memory");   // this k-pair's outputs are in (and every older weight stage)
             } else {
-                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kP<NT>) : "memory");
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kP) : "memory");
             }
             F16Pair xc[NT];
 #pragma unroll
@@ -512,7 +423,7 @@ __device__ __forceinline__ void row_half_x(f32x4 (&x)[NT][kTiles], Stager& sg, c
                 for (int j = 0; j < NT; ++j) x[j][o] = mfma3(wh, wl, xc[j], x[j][o]);
             });
             if (c + 1 < 4) {   // (stage_end with the next k-pair's pieces allowed in flight behind this stage's weight fetch)
-                asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(kP<NT> + 2 * NT) : "memory");
+                asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(kP + 2 * NT) : "memory");
                 sg.ridx = sg.ridx == kWBufs - 1 ? 0 : sg.ridx + 1;
             } else {
                 stage_end_x<NT>(sg);
@@ -551,7 +462,7 @@ __device__ __forceinline__ void row_half_x(f32x4 (&x)[NT][kTiles], Stager& sg, c
         for (int t = 0; t < kTiles; ++t) x[j][t] += ld4(pv + PV_L2_B + 16 * t + 4 * g);
     // Stages: linear1(0), 15 x [linear1(ch + 1), linear2(ch)], linear2(15).  linear1 runs one chunk ahead, so the erf-GELU of chunk ch (VALU) and linear1's MFMAs of chunk
     // ch + 1 share a stage - and the two waves of a SIMD, in lock step since the last barrier, take them in OPPOSITE order (three-tile waves: MFMAs first; two-tile waves:
-    // GELU first), so that one's matrix-pipe time covers the other's VALU time instead of adding to it (AMUSE_FX_FFN_PIPE=0: the plain order, A/B).
+    // GELU first), so that one's matrix-pipe time covers the other's VALU time instead of adding to it.
     f32x4 hid[NT][2];
     auto lin1 = [&](f32x4 (&acc)[NT][2], int ch) {
         const f32x4 b0 = ld4(pv + PV_L1_B + 32 * ch + 4 * g), b1 = ld4(pv + PV_L1_B + 32 * ch + 16 + 4 * g);
@@ -566,8 +477,7 @@ __device__ __forceinline__ void row_half_x(f32x4 (&x)[NT][kTiles], Stager& sg, c
             }
 #pragma unroll
             for (int j = 0; j < NT; ++j) {
-                if constexpr ((AMUSE_FX_ABL & 2) != 0) acc[j][o] += __builtin_bit_cast(f32x4, wh + xc[j].hi);
-                else acc[j][o] = mfma3(wh, wl, xc[j], acc[j][o]);
+                acc[j][o] = mfma3(wh, wl, xc[j], acc[j][o]);
             }
         });
     };
@@ -577,7 +487,7 @@ __device__ __forceinline__ void row_half_x(f32x4 (&x)[NT][kTiles], Stager& sg, c
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
-                for (int m = 0; m < 4; ++m) hid[j][i][m] = (AMUSE_FX_ABL & 1) ? 0.5f * hid[j][i][m] : AMUSE_FX_ERF == 2 ? gelu_erf_bf(hid[j][i][m]) : AMUSE_FX_ERF == 1 ? gelu_erf_fast(hid[j][i][m]) : gelu_erf(hid[j][i][m]);
+                for (int m = 0; m < 4; ++m) hid[j][i][m] = gelu_erf_bf(hid[j][i][m]);
             hs[j] = split_f16(hid[j][0], hid[j][1]);
         }
     };
@@ -589,7 +499,7 @@ __device__ __forceinline__ void row_half_x(f32x4 (&x)[NT][kTiles], Stager& sg, c
         if (ch < 15) {
             f32x4 nxt[NT][2];
             FSTAMP(11);
-            if constexpr (NT == 3 || !AMUSE_FX_FFN_PIPE) {
+            if constexpr (NT == 3) {
                 lin1(nxt, ch + 1);
                 __builtin_amdgcn_sched_barrier(0);
                 gelu_split(hs);
@@ -609,8 +519,7 @@ __device__ __forceinline__ void row_half_x(f32x4 (&x)[NT][kTiles], Stager& sg, c
         for_pairs<NT>(sg, [&](int o, f16x8 wh, f16x8 wl) {
 #pragma unroll
             for (int j = 0; j < NT; ++j) {
-                if constexpr ((AMUSE_FX_ABL & 2) != 0) x[j][o] += __builtin_bit_cast(f32x4, wh + hs[j].hi);
-                else x[j][o] = mfma3(wh, wl, hs[j], x[j][o]);
+                x[j][o] = mfma3(wh, wl, hs[j], x[j][o]);
             }
         });
         FSTAMP(14);   // linear2 of the chunk
@@ -760,7 +669,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     Stager sg;
     // (a full-length clip with the block-0 constant at hand starts behind block 0's sixteen attention stages: decoder_block_x, hoist)
     const size_t skip_units = (a.c1 && len == kFrames) ? (size_t)16 * kStage : 0;
-    const int piece0 = AMUSE_FX_DMA_SPLIT ? 4 * (wave & 3) : 2 * wave;   // (the three-tile waves 0..3 copy nothing when the split is on)
+    const int piece0 = 2 * wave;
     sg.src = a.wstream + (skip_units + (size_t)piece0) * 64 + lane;
     sg.dst0 = lds0 + kXOffW + piece0 * 1024;
     sg.ring = smem + kXOffW + lane * 16;
@@ -964,7 +873,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const unsigned lds0 = lds_addr(smem);
     glds16(reinterpret_cast<const uint4*>(a.pvec) + wave * 64 + lane, lds0 + kXOffPv + wave * 1024);   // block 0's parameters
     Stager sg;
-    const int piece0 = AMUSE_FX_DMA_SPLIT ? 4 * (wave & 3) : 2 * wave;
+    const int piece0 = 2 * wave;
     sg.src = a.wstream + (size_t)piece0 * 64 + lane;
     sg.dst0 = lds0 + kXOffW + piece0 * 1024;
     sg.ring = smem + kXOffW + lane * 16;

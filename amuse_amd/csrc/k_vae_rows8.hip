@@ -21,40 +21,21 @@
 namespace amuse {
 namespace {
 
-// erf of the FFN activation: 0 = libm erff (as k_vae_rows<f16x2>), 1 = Abramowitz-Stegun 7.1.26 on the hardware rcp / exp2 (|erf error| <= 1.5e-7;
-// amuse_dev.hpp gelu_erf_fast), 2 = the branch-free fit of the fp32x sampler (erf_bf) - re-measured with the copying wave in place: 1.97 / 1.96 / 2.05 ms per 256-clip
-// decode for 0 / 1 / 2 (profiles/r04_rows8x_erf_ab.txt): libm's form stays (the bits of the round-3 kernel)
-#ifndef AMUSE_R8_FAST_ERF
-#define AMUSE_R8_FAST_ERF 0
-#endif
-// timing ablations (variant builds only; wrong numerics, the rest of the instruction stream in place): 1 = no erf in the FFN activation,
-// 2 = every weight fragment pair of a stage read ONCE (pair 0) instead of eight times, 4 = one MFMA per product instead of three,
-// 8 = no activation stores (x, skip, q, k, v), 16 = every activation load from row 0 of clip 0 (cache hits)
-#ifndef AMUSE_R8_ABL
-#define AMUSE_R8_ABL 0
-#endif
-// 1 = the weight stream is copied by ONE extra wave that does nothing else (the row waves never wait on vmcnt after their input loads), and the
+// erf of the FFN activation: libm erff (as k_vae_rows<f16x2>; the bits of the round-3 kernel).  Abramowitz-Stegun 7.1.26 on the hardware rcp / exp2 and the branch-free
+// fit of the fp32x sampler time 1.96 / 2.05 against 1.97 ms per 256-clip decode (profiles/r04_rows8x_erf_ab.txt).
+// kProd: the weight stream is copied by ONE extra wave that does nothing else (the row waves never wait on vmcnt after their input loads), and the
 // biases read behind the first activation store come from LDS: on this ISA stores count in vmcnt like loads, so a row wave that also copies
 // (vmcnt(2) at every stage end) or loads a bias behind its q stores sits out every store's round trip to L2 / HBM - 0.43 of the decode's 2.35 ms
-// at 256 clips (profiles/r04_rows8x_store_ablation.txt).  0 = eight of the row waves copy (the round-3 kernel; A/B)
-#ifndef AMUSE_R8_PROD
-#define AMUSE_R8_PROD 1
-#endif
-constexpr bool kProd = AMUSE_R8_PROD != 0;
+// at 256 clips (profiles/r04_rows8x_store_ablation.txt; false = eight of the row waves copy, the round-3 kernel).
+constexpr bool kProd = true;
 constexpr int kRowTiles = 19;                 // ceil(300 / 16)
-#ifndef AMUSE_R8_NT
-#define AMUSE_R8_NT 1
-#endif
-constexpr int kTilesPerWave = AMUSE_R8_NT;    // row tiles per wave: a weight fragment read from LDS feeds 3 x NT MFMAs
+constexpr int kTilesPerWave = 1;              // row tiles per wave: a weight fragment read from LDS feeds 3 x NT MFMAs
 // the waves that copy the stream (16 units per LDS stage): eight with two pieces each, four with four in the small workgroups
 constexpr int dma_waves(int waves) { return waves >= 8 ? 8 : 4; }
 constexpr int kStage = 16;                    // units per LDS stage (8 hi | lo pairs)
 constexpr int kStageBytes = kStage * 1024;
 // LDS stages in the weight ring (the copying wave keeps kWBufs - 1 stages ahead of the stage being read, kWBufs - 2 of them may still be in flight at a stage's end)
-#ifndef AMUSE_R8_BUFS
-#define AMUSE_R8_BUFS 3
-#endif
-constexpr int kWBufs = AMUSE_R8_BUFS;
+constexpr int kWBufs = 3;                     // (deeper rings measured flat: profiles/r04_rows8x_ring_depth_ab.txt)
 static_assert(kWBufs == 3 || (kProd && kWBufs <= 5), "deeper rings: copying-wave protocol only; vmcnt is a 6-bit counter");
 constexpr int kQStride = 100;                 // staging row stride (floats) of one 96-feature quarter of the last stage
 constexpr int kOffW = 0;
@@ -102,7 +83,6 @@ __device__ __forceinline__ f16x8 wfrag(const Stager<P>& s, int u) {
 }
 // one product of split operands: acc += Wl.xh + Wh.xl + Wh.xh (the term order of gemm_ring_s, amuse_dev.hpp)
 __device__ __forceinline__ f32x4 mfma3(f16x8 wh, f16x8 wl, const F16Pair& x, f32x4 acc) {
-    if constexpr ((AMUSE_R8_ABL & 4) != 0) return mfma_f16(wh + wl, x.hi + x.lo, acc);
     acc = mfma_f16(wl, x.hi, acc);
     acc = mfma_f16(wh, x.lo, acc);
     return mfma_f16(wh, x.hi, acc);
@@ -115,9 +95,7 @@ __device__ __forceinline__ void for_pairs(Stager<P>& s, F&& f) {
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
         const f16x8 ch = h, cl = l;
-        if constexpr ((AMUSE_R8_ABL & 2) == 0) {
-            if (i + 1 < 8) { h = wfrag(s, 2 * i + 2); l = wfrag(s, 2 * i + 3); }
-        }
+        if (i + 1 < 8) { h = wfrag(s, 2 * i + 2); l = wfrag(s, 2 * i + 3); }
         f(i, ch, cl);
     }
     stage_end(s);
@@ -171,9 +149,7 @@ __global__ __launch_bounds__(64 * (kWaves + kProdWaves)) __attribute__((amdgpu_w
         frame[j] = rt[j] * 16 + r;
         rvalid[j] = tvalid[j] && frame[j] < S;
         row[j] = (size_t)b[j] * S + (rvalid[j] ? frame[j] : 0);
-        if constexpr ((AMUSE_R8_ABL & 16) != 0) row[j] = 0;
     }
-    const bool abl_nostore = (AMUSE_R8_ABL & 8) != 0 && a.stage < 100;   // (runtime-true: the arithmetic in front of the stores stays)
     const size_t nrows = (size_t)a.B * S;
     const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) const void*)smem;
     Stager<kPieces> sg;
@@ -214,7 +190,7 @@ __global__ __launch_bounds__(64 * (kWaves + kProdWaves)) __attribute__((amdgpu_w
     }
     stage_fetch(sg);
     stage_fetch(sg);
-    // biases read behind the first activation store, from LDS (see AMUSE_R8_PROD): in_proj of block `stage` / final_layer
+    // biases read behind the first activation store, from LDS (see kProd): in_proj of block `stage` / final_layer
     float* lbias = reinterpret_cast<float*>(smem + kOffBias);
     if (threadIdx.x < 96 && !(ENC && a.stage == kLayers))
         st4(lbias + 4 * threadIdx.x, ld4((a.stage < kLayers ? a.pvec + a.stage * PV_BLOCK + PV_IN_B : a.final_bias) + 4 * threadIdx.x));
@@ -305,7 +281,7 @@ __global__ __launch_bounds__(64 * (kWaves + kProdWaves)) __attribute__((amdgpu_w
                 for (int i = 0; i < 2; ++i)
 #pragma unroll
                     for (int m = 0; m < 4; ++m)
-                        hid[j][i][m] = (AMUSE_R8_ABL & 1) ? 0.5f * hid[j][i][m] : (AMUSE_R8_FAST_ERF == 1 ? gelu_erf_fast(hid[j][i][m]) : AMUSE_R8_FAST_ERF == 2 ? gelu_erf_bf(hid[j][i][m]) : gelu_erf(hid[j][i][m]));
+                        hid[j][i][m] = gelu_erf(hid[j][i][m]);
                 hs[j] = split_f16(hid[j][0], hid[j][1]);
             }
             for_pairs(sg, [&](int o, f16x8 wh, f16x8 wl) {
@@ -319,7 +295,7 @@ __global__ __launch_bounds__(64 * (kWaves + kProdWaves)) __attribute__((amdgpu_w
         if (blk < 4) {
 #pragma unroll
             for (int j = 0; j < NT; ++j) {
-                if (!rvalid[j] || abl_nostore) continue;
+                if (!rvalid[j]) continue;
                 float* sk = a.skip + ((size_t)blk * nrows + row[j]) * kD;
 #pragma unroll
                 for (int t = 0; t < kTiles; ++t) st4(sk + 16 * t + 4 * g, x[j][t]);
@@ -349,7 +325,7 @@ __global__ __launch_bounds__(64 * (kWaves + kProdWaves)) __attribute__((amdgpu_w
         // ---- residual stream for the next stage + in_proj of block `stage`: q | k | v as three groups of 8 output tiles
 #pragma unroll
         for (int j = 0; j < NT; ++j) {
-            if (!rvalid[j] || abl_nostore) continue;
+            if (!rvalid[j]) continue;
 #pragma unroll
             for (int t = 0; t < kTiles; ++t) st4(a.x + row[j] * kD + 16 * t + 4 * g, x[j][t]);
         }
@@ -368,7 +344,7 @@ __global__ __launch_bounds__(64 * (kWaves + kProdWaves)) __attribute__((amdgpu_w
             float* dst = grp == 0 ? a.q : grp == 1 ? a.k : a.v;
 #pragma unroll
             for (int j = 0; j < NT; ++j) {
-                if (!rvalid[j] || abl_nostore) continue;
+                if (!rvalid[j]) continue;
 #pragma unroll
                 for (int t = 0; t < 8; ++t) {   // output tile t = head t / 2, features 16 (t & 1) ..
                     const size_t hrow = (((size_t)b[j] * kHeads + (t >> 1)) * S + frame[j]) * 32;
@@ -476,9 +452,8 @@ hipError_t launch_rows8_mode(const VaeRowsArgs& a, int best, hipStream_t stream)
 // Waves (= row tiles) per workgroup: the launch's time is its rounds over the chip's 256 CUs times the waves that share a CU's pipes in a
 // round, so the shape is chosen per launch to minimise ceil(workgroups / 256) x waves - 256 clips are 4,864 tiles = 19 per CU: two rounds of
 // 10-wave workgroups (95 % full) instead of two of 12 (58 % in the second).  All instantiations produce the same bits (a tile's arithmetic does
-// not depend on its workgroup).  AMUSE_R8_FORCE_WAVES = 8 / 10 / 12 pins one (A/B).
+// not depend on its workgroup).
 hipError_t launch_vae_rows8x(const VaeRowsArgs& a, hipStream_t stream, int mode) {
-    static const int force = [] { const char* e = getenv("AMUSE_R8_FORCE_WAVES"); return e ? atoi(e) : 0; }();
     if (mode != VAE_MODE_DEC && mode != VAE_MODE_ENC) return hipErrorInvalidValue;
     if (mode == VAE_MODE_ENC && a.stage == 0) return hipErrorInvalidValue;   // (the embedding stage is k_vae_rows<f16x2, M_ENC>'s)
     const int tiles = a.B * a.tiles;
@@ -493,7 +468,6 @@ hipError_t launch_vae_rows8x(const VaeRowsArgs& a, hipStream_t stream, int mode)
             if (cost < best_cost) { best_cost = cost; best = w; }   // (ties: the smaller workgroup)
         }
     }
-    if (force >= 4 && force <= 12 && force != 7 && !(kProd && (force == 6 || force == 12))) best = force;
     return mode == VAE_MODE_ENC ? launch_rows8_mode<true>(a, best, stream) : launch_rows8_mode<false>(a, best, stream);
 }
 

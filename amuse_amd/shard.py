@@ -8,37 +8,31 @@ from typing import Callable, Dict, Optional, Tuple
 
 import torch
 
-
-def job_clips_per_group(total: int, tokens: int = 5) -> int:
-    """Clips per workgroup tile for a job of `total` clips (the library's auto rule applied to the WHOLE job, not to a
-    shard): ceil(total / 128), at most 16 // tokens.  Every rank sets it (HipEngine.set_clips_per_group) and shards start
-    at multiples of it, so that a clip sits in the same slot of its tile however the job is sharded - which is what makes
-    sharded results BITWISE equal to the single-GPU ones (include/amuse_hip.h amuse_set_clips_per_group)."""
-    return max(1, min(16 // tokens, -(-total // 128)))
+from . import _lib
 
 
-FUSED_DECODE_MIN_CLIPS = 64   # amuse_api.hip kFusedMinClips: the library's per-launch rule for the bf16 / fp16 / fp32x decode kernels
+def job_plan(total: int, tokens: int = 5, precision: int = _lib.PREC_F32X, arch: int = _lib.ARCH_ENC) -> Dict[str, object]:
+    """The launch plan of a JOB of `total` clips, from the library itself (include/amuse_hip.h amuse_plan; no GPU needed) - nothing here restates
+    its rules.  Every rank applies the WHOLE job's plan to its shard:
+      "clips_per_group"  clips per workgroup tile (HipEngine.set_clips_per_group); shards start at multiples of it, so that a clip sits in the same
+                         slot of its tile however the job is sharded - which is what makes sharded results BITWISE equal to the single-GPU ones;
+      "decode_path"      the decode / encode / pose-step kernel family (HipEngine.set_decode_path): the modes' kernel families sum in different orders,
+                         so a 256-clip job cut into 32-clip shards would otherwise decode on other kernels than the same job on one GPU.
+    The default precision is fp32x, whose rule is the superset ("clip" where the clips fill rounds of the chip, "fused" from 64 clips, else "staged"):
+    pinned on a context it resolves to the right family in every mode ("clip" means "fused" in the 16-bit modes, everything means "staged" in fp32 -
+    csrc/amuse_host.hpp resolve_path), so one pin serves a job whatever precision its calls use."""
+    return _lib.plan(total, precision, tokens, arch)
 
 
-def fusedx_rule(total: int) -> bool:
-    """amuse_api.hip fusedx_rule: does a call of `total` clips decode on the fp32x mode's per-clip kernel (k_vae_fusedx.hip)?  A clip takes ~1.5 ms on its CU whatever
-    the batch, so the kernel wins when the clips fill rounds of the chip's 256 CUs: from 160 clips in the first round, in round r >= 2 with at least 164 - 50 (r - 2)."""
-    if total < 160:
-        return False
-    r = -(-total // 256)
-    return r == 1 or total - 256 * (r - 1) >= 164 - 50 * (r - 2)
-
-
-def job_decode_path(total: int) -> str:
-    """The decode kernels (amuse_hip.h amuse_set_decode_path) a job of `total` clips would get on one GPU.  Like the clips
-    per tile it must be chosen from the WHOLE job, not per shard: each 16-bit mode has a staged and a fused decoder and the
-    fp32x mode three (k_vae_rows<f16x2> below 64 clips, k_vae_rows8x from 64, the per-clip k_vae_fusedx where the clips fill
-    rounds of the chip) that sum in different orders, so a 256-clip job cut into 32-clip shards would otherwise decode on
-    other kernels than the same job on one GPU (only the fp32 mode has a single decode path).  "clip" means "fused" in the
-    modes that have no third kernel."""
-    if fusedx_rule(total):
-        return "clip"
-    return "fused" if total >= FUSED_DECODE_MIN_CLIPS else "staged"
+def all_ranks_ok(ok: bool, device, group=None) -> bool:
+    """Agree on a per-rank outcome BEFORE the next collective: an all-reduce (MIN) of an ok flag.  A rank whose share of the work raised (OOM, an audio-engine
+    error on its WAVs) must not skip a collective its peers then block in forever - every rank calls this with its own flag and acts on the common answer."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()):
+        return ok
+    f = torch.tensor([1.0 if ok else 0.0], device=torch.device("cpu") if dist.get_backend(group) == "gloo" else device)
+    dist.all_reduce(f, op=dist.ReduceOp.MIN, group=group)
+    return bool(f.item() == 1.0)
 
 
 def shard_range(total: int, rank: int, world: int, align: int = 1) -> Tuple[int, int]:
@@ -79,20 +73,21 @@ def sample_sharded(sample_fn: Callable[..., Dict[str, torch.Tensor]], z_con, z_e
                    gather: bool = False, group=None, set_clips_per_group: Optional[Callable[[int], None]] = None,
                    set_decode_path: Optional[Callable[[str], None]] = None) -> Optional[Dict[str, torch.Tensor]]:
     """Run `sample_fn(bsz, con, emo, sty, clip_index0=...)` on this rank's shard of the global batch.
-    set_clips_per_group (e.g. HipEngine.set_clips_per_group): called with job_clips_per_group(total), and the shards are
+    set_clips_per_group (e.g. HipEngine.set_clips_per_group): called with job_plan(total)["clips_per_group"], and the shards are
                   aligned to it - sharded results are then bitwise those of one GPU running the whole job.
-    set_decode_path (e.g. HipEngine.set_decode_path): called with job_decode_path(total) for the same reason; both are
+    set_decode_path (e.g. HipEngine.set_decode_path): called with job_plan(total)["decode_path"] for the same reason; both are
                   put back to the library's automatic rule afterwards.
     gather=False: returns the local shard's outputs (stay on this rank's device).
     gather=True : all ranks exchange shards (torch.distributed all_gather_object) and return the full batch
                   in global clip order - for tests and small jobs; large jobs should keep outputs sharded."""
     total = z_con.shape[0]
     tokens = 3 + (z_emo is not None) + (z_sty is not None)
-    g = job_clips_per_group(total, tokens) if set_clips_per_group is not None else 1
+    plan = job_plan(total, tokens)
+    g = plan["clips_per_group"] if set_clips_per_group is not None else 1
     if set_clips_per_group is not None:
         set_clips_per_group(g)
     if set_decode_path is not None:
-        set_decode_path(job_decode_path(total))
+        set_decode_path(plan["decode_path"])
     lo, hi = shard_range(total, rank, world, align=g)
     sl = lambda t: None if t is None else t[lo:hi]
     try:

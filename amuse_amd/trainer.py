@@ -125,7 +125,7 @@ def local_jobs(jobs_or_specs, rank: int, world: int) -> List[bool]:
         return mine
     for (no_emo, no_sty), idx in job_runs(specs):
         bszs = [specs[j]["bsz"] for j in idx]
-        g = shard.job_clips_per_group(sum(bszs), 5 - no_emo - no_sty)
+        g = shard.job_plan(sum(bszs), 5 - no_emo - no_sty)["clips_per_group"]
         ja, jb = shard.job_range(bszs, rank, world, align=g)
         for k in range(ja, jb):
             mine[idx[k]] = True
@@ -257,13 +257,13 @@ def run_jobs(model, jobs: List[dict], return_latents: bool = False, batched: boo
         bszs = [jobs[j]["bsz"] for j in idx]
         ja, jb = 0, len(idx)
         if world > 1:
-            g = shard.job_clips_per_group(sum(bszs), 5 - no_emo - no_sty)
+            g = shard.job_plan(sum(bszs), 5 - no_emo - no_sty)["clips_per_group"]
             ja, jb = shard.job_range(bszs, rank, world, align=g)
             if jb == ja:
                 continue
             if eng is not None:      # the WHOLE launch's tiling and decode kernels, not this shard's
                 eng.set_clips_per_group(g)
-                eng.set_decode_path(shard.job_decode_path(sum(bszs)))
+                eng.set_decode_path(shard.job_plan(sum(bszs))["decode_path"])
         sel = idx[ja:jb]
         assert not any(jobs[j]["remote"] for j in sel), "a job built without its tensors fell into this rank's range"
         con, emo, sty = (cat([jobs[j][k] for j in sel]) for k in ("z_con", "z_emo", "z_sty"))
@@ -365,8 +365,15 @@ class trainer:
             import torch.distributed as dist
             from .shard import shard_range
             assert dist.is_available() and dist.is_initialized(), "exchange=True needs an initialised process group"
+            from .shard import all_ranks_ok
             lo, hi = shard_range(n, self.rank, self.world)
-            mine = self._embed_some(paths[lo:hi], baseline)
+            mine, err = None, None
+            try:
+                mine = self._embed_some(paths[lo:hi], baseline)
+            except Exception as e:  # noqa: BLE001 - agreed on below, then raised on EVERY rank: no rank may enter the all_gather alone
+                err = e
+            if not all_ranks_ok(err is None, torch.device(self.device)):
+                raise err if err is not None else RuntimeError("another rank failed to embed its share of the WAVs; not entering the all_gather")
             dev = torch.device("cpu") if dist.get_backend() == "gloo" else torch.device(self.device)
             per = -(-n // self.world)
             buf = torch.zeros(per, 3, 256, dtype=torch.float32, device=dev)

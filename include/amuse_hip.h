@@ -28,7 +28,8 @@
 extern "C" {
 #endif
 
-#define AMUSE_ABI_VERSION 4   /* 4: amuse_train_* (training-step glue kernels);
+#define AMUSE_ABI_VERSION 5   /* 5: amuse_plan / amuse_debug_last_plan (the launch plan); the process-wide environment overrides of kernel choices are gone;
+                                 4: amuse_train_* (training-step glue kernels);
                                  3: Denoiser variants (amuse_create_arch, AMUSE_ARCH_*, amuse_denoise_step_pose, amuse_feats_to_smplx);
                                  2: AMUSE_PREC_F32X / _F16, AMUSE_UPD_F32X / _F16; tile-major amuse_debug_gemm; clips per group 1..5 */
 
@@ -238,7 +239,7 @@ int amuse_counter_normal(amuse_ctx* ctx, uint64_t seed, uint64_t clip_index0, in
 
 /* Diagnostics: runs amuse_sample's kernel with s_memtime stamps taken by the waves of workgroup 0
  * during step `prof_step`; stamps_out dev 768 x uint64 (unused entries 0).
- *   fp32 (4-wave kernel, also bf16 with AMUSE_SAMPLE_WAVES=4): [4 waves][192] - step start, then per
+ *   fp32 (4-wave kernel): [4 waves][192] - step start, then per
  *     block: block start, in_proj, attention, out_proj, combine 1, LN1, four FFN quarters, combine 2,
  *     LN2; finally scheduler update.
  *   bf16 (8-wave kernel): [8 waves][96] - step start, then per block: block start (after the skip linear),
@@ -247,27 +248,35 @@ int amuse_counter_normal(amuse_ctx* ctx, uint64_t seed, uint64_t clip_index0, in
 int amuse_profile_sample(amuse_ctx* ctx, const float* con, const float* emo, const float* sty, int B,
                          int precision, int prof_step, unsigned long long* stamps_out, void* stream);
 
-/* Clips per workgroup tile in the sampling kernels: 0 = auto = ceil(B / 128), else 1..5; the value used is clamped to
- * 16 / S (S = 5, 4 or 3 tokens per clip: at most 3, 4 or 5 clips share the 16 rows of a tile).
+/* Clips per workgroup tile in the sampling kernels: 0 = auto (amuse_plan's clips_per_group for the CALL's clip count), else 1..5; the value used is
+ * clamped to 16 / S (S = 5, 4 or 3 tokens per clip: at most 3, 4 or 5 clips share the 16 rows of a tile).
  * Results are bitwise reproducible across launches / shards that use the same value and start at multiples of it
  * (a clip's slot inside its tile decides the rounding of its attention sums); amuse_amd/shard.py applies that rule. */
 int amuse_set_clips_per_group(amuse_ctx* ctx, int g);
 
-/* Which kernels amuse_vae_decode (and amuse_diffusion_backward) use in the bf16 and fp16 modes.  AUTO: the fused per-clip kernel
- * (csrc/k_vae_fused.hip: one persistent workgroup per clip, residual stream in registers, K/V of the current head in LDS)
- * from 64 clips up, the staged kernels (csrc/k_vae.hip) below that; fp32 mode always runs the staged kernels.  Both
- * compute MotionPrior.decode (vae.py:216-278) with bf16 (fp16) MFMA operands and fp32 accumulation / residual stream; they differ
- * in summation order only.  The fp32x mode has the same pair of paths under the same rule and the same pins: its staged row kernel
- * (k_vae_rows<f16x2>: one 16-row tile per workgroup, split-K) below 64 clips, the no-split-K row kernel (csrc/k_vae_rows8.hip: a tile per
- * wave, weights through LDS once per workgroup; FUSED selects it) from 64 clips up - again the same function in another summation order.
- * The environment variable AMUSE_VAE_FUSED=0 / 1 overrides AUTO for a whole process.
- * CLIP: the fp32x mode's third decoder - one persistent workgroup per clip in the parity arithmetic (csrc/k_vae_fusedx.hip: the residual stream in registers, q / k / v never
- * leave the CU) - which AUTO takes when the call's clips fill whole rounds of the chip's 256 CUs (from 160 clips; amuse_amd/shard.py fusedx_rule states the rule); in the other
- * modes CLIP means FUSED.  The three fp32x decoders compute the same function and differ by fp32 rounding (1.5e-6 on features of magnitude 3), so a sharded job pins the
- * whole job's choice (amuse_amd/shard.py job_decode_path).  amuse_vae_encode and the pose-space Denoiser's step (AMUSE_ARCH_ENC_POSE) have the same third fp32x kernel
- * under the same rule and pin.  AMUSE_VAE_FUSEDX=0 / 1 overrides AUTO's choice of these kernels for a whole process. */
+/* Which kernels amuse_vae_decode (and amuse_diffusion_backward), amuse_vae_encode and the pose-space Denoiser's step use.  Every mode but fp32 has more
+ * than one kernel family for MotionPrior.decode (vae.py:216-278); they compute the same function and differ in summation order only (fp32x: 1.5e-6 on
+ * features of magnitude 3):
+ *   STAGED  the row / attention launches of csrc/k_vae.hip (one 16-row tile per workgroup, split-K); the only family of the fp32 mode.
+ *   FUSED   bf16 / fp16: the fused per-clip kernel (csrc/k_vae_fused.hip: one persistent workgroup per clip, residual stream in registers, K/V of the
+ *           current head in LDS); fp32x: the row kernel without split-K (csrc/k_vae_rows8.hip: a tile per wave, weights through LDS once per workgroup).
+ *   CLIP    fp32x: one persistent workgroup per clip in the parity arithmetic (csrc/k_vae_fusedx.hip: q / k / v never leave the CU); FUSED elsewhere.
+ *   AUTO    what amuse_plan returns for the CALL's clip count: FUSED from 64 clips, in fp32x CLIP where the clips fill rounds of the chip's 256 CUs.
+ * A sharded job pins the WHOLE job's choice (amuse_plan on the job's total) on every shard, so shards reproduce the single-GPU bits. */
 enum { AMUSE_DECODE_AUTO = 0, AMUSE_DECODE_STAGED = 1, AMUSE_DECODE_FUSED = 2, AMUSE_DECODE_CLIP = 3 };
 int amuse_set_decode_path(amuse_ctx* ctx, int path);
+
+/* The launch plan of a JOB - the single statement of the library's kernel-choice rules (csrc/amuse_host.hpp plan_*); needs no GPU and no context.
+ * For a job of clips_total clips of `tokens` tokens each (5 = latent + time + content + emotion + style; 4 / 3 with emotion / style dropped), Denoiser
+ * variant `arch`, mode `precision`:
+ *   *clips_per_group  clips per 16-row tile of the latent trans_enc sampler (1 for the other variants): what amuse_sample takes on AUTO for a call of
+ *                     that many clips, and the alignment of shard starts (amuse_set_clips_per_group on every shard)
+ *   *decode_path / *encode_path / *step_path   AMUSE_DECODE_STAGED / _FUSED / _CLIP: what amuse_vae_decode / amuse_vae_encode / one pose-space Denoiser
+ *                     step take on AUTO for a call of that many clips (amuse_set_decode_path with the job's decode_path on every shard)
+ * Any output pointer may be NULL.  amuse_debug_last_plan reports what the last amuse_sample / amuse_vae_decode / amuse_vae_encode / pose-space step of a
+ * context ACTUALLY took (0 = none yet); tests/test_plan_cpu.py sweeps 1..8192 clips and holds the two equal. */
+int amuse_plan(int arch, int precision, int clips_total, int tokens, int* clips_per_group, int* decode_path, int* encode_path, int* step_path);
+int amuse_debug_last_plan(const amuse_ctx* ctx, int* clips_per_group, int* decode_path, int* encode_path, int* step_path);
 
 /* ------------------------------------------------------------------------------------------------
  * Audio front-end: replaces PretrainedLPDM_v1.process_single_seq

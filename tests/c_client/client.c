@@ -2,9 +2,11 @@
  * with a C FFI sees of libamuse_hip.so.  Test infrastructure (tests/test_c_client.py builds and runs it).
  *
  *   client abi                      version + error convention, touches no GPU
+ *   client plan CLIPS PREC TOKENS   amuse_plan of a job (the library's kernel-choice rule; no GPU): "PLAN g decode encode step"
  *   client run DIR B SEED           DIR/den.f32, prior.f32 (host fp32 parameter images, state-dict order), sched.bin
  *                                   (int32 T, int32 timesteps[T], float coef[T][8], float freqs[128]), cond.f32 ([3][B][256]) ->
- *                                   amuse_create, amuse_set_schedule, amuse_diffusion_backward (bf16, counter-based noise) ->
+ *                                   amuse_create, amuse_set_schedule, the job's amuse_plan pinned as a sharding caller does,
+ *                                   amuse_diffusion_backward (bf16, counter-based noise) ->
  *                                   DIR/out_latents.f32 [B][128], out_poses.f32 [B][300][55][3], out_trans.f32 [B][300][3]
  */
 #include <stdio.h>
@@ -81,6 +83,15 @@ int main(int argc, char** argv) {
         printf("ABI_OK %d\n", amuse_abi_version());
         return 0;
     }
+    if (argc == 5 && strcmp(argv[1], "plan") == 0) {
+        int g = -1, dp = -1, ep = -1, sp = -1;
+        if (amuse_plan(AMUSE_ARCH_ENC, atoi(argv[3]), atoi(argv[2]), atoi(argv[4]), &g, &dp, &ep, &sp) != 0) {
+            fprintf(stderr, "amuse_plan: %s\n", amuse_last_error());
+            return 1;
+        }
+        printf("PLAN %d %d %d %d\n", g, dp, ep, sp);
+        return 0;
+    }
     if (argc == 5 && strcmp(argv[1], "run") == 0) {
         const char* dir = argv[2];
         const int B = atoi(argv[3]);
@@ -92,6 +103,7 @@ int main(int argc, char** argv) {
         char* sched_raw;
         float* cond;
         float *d_cond, *d_lat, *d_poses, *d_trans;
+        int g = 0, dpath = 0;
         amuse_schedule s;
         amuse_ctx* ctx;
         if (B < 1 || T < 1 || T > AMUSE_MAX_STEPS) return 2;
@@ -107,6 +119,10 @@ int main(int argc, char** argv) {
             return 1;
         }
         check(amuse_set_schedule(ctx, &s, NULL), "amuse_set_schedule");
+        /* the job's launch plan, pinned the way a caller that shards the job over GPUs pins it on every shard (here: one shard = the job) */
+        check(amuse_plan(AMUSE_ARCH_ENC, AMUSE_PREC_BF16, B, 5, &g, &dpath, NULL, NULL), "amuse_plan");
+        check(amuse_set_clips_per_group(ctx, g), "amuse_set_clips_per_group");
+        check(amuse_set_decode_path(ctx, dpath), "amuse_set_decode_path");
         d_cond = to_device(cond, 3u * (size_t)B * AMUSE_COND_DIM);
         if (hipMalloc((void**)&d_lat, sizeof(float) * (size_t)B * AMUSE_D_MODEL) != 0 ||
             hipMalloc((void**)&d_poses, sizeof(float) * (size_t)B * AMUSE_N_FRAMES * AMUSE_N_JOINTS * 3u) != 0 ||
@@ -132,6 +148,6 @@ int main(int argc, char** argv) {
         printf("RUN_OK B=%d T=%d\n", B, T);
         return 0;
     }
-    fprintf(stderr, "usage: client abi | client run DIR B SEED\n");
+    fprintf(stderr, "usage: client abi | client plan CLIPS PREC TOKENS | client run DIR B SEED\n");
     return 2;
 }

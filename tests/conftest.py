@@ -26,6 +26,21 @@ def pytest_collection_modifyitems(config, items):
             it.add_marker(skip)
 
 
+@pytest.fixture(scope="session")
+def host_asan_build(tmp_path_factory):
+    """tests/host_asan/build.sh once per session: the library's host code + the stubbed HIP runtime under ASan / UBSan -> directory holding `host_asan`
+    (tests/test_host_asan.py) and `plan_sweep` (tests/test_plan_cpu.py)."""
+    import shutil
+    import subprocess
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    if not (shutil.which(hipcc) or os.path.exists(hipcc)):
+        pytest.skip("hipcc not available")
+    out = tmp_path_factory.mktemp("host_asan")
+    build = subprocess.run(["bash", str(REPO / "tests" / "host_asan" / "build.sh"), str(out)], capture_output=True, text=True, timeout=900)
+    assert build.returncode == 0, build.stdout[-2000:] + build.stderr[-2000:]
+    return out
+
+
 def make_reference_tree(root: Path, n_infer_wavs: int = 2):
     """A reference-shaped checkout (configs/, scripts/overrides/, viz_dump/test/{speech,e_speech}) holding the slices of
     configs/base_new.json, diff_latent_v2.json and the override YAMLs that the infer / edit entry points read

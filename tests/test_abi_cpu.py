@@ -24,7 +24,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, name), f"{name} declared in amuse_hip.h but not exported"
     assert sorted(_lib.EXPORTS) == decl
     hdr = (REPO / "include/amuse_hip.h").read_text()
-    assert lib.amuse_abi_version() == int(re.search(r"#define AMUSE_ABI_VERSION (\d+)", hdr).group(1)) == _lib.ABI_VERSION == 4
+    assert lib.amuse_abi_version() == int(re.search(r"#define AMUSE_ABI_VERSION (\d+)", hdr).group(1)) == _lib.ABI_VERSION == 5
 
 
 def test_f16_split_of_the_fp32x_mode_matches_numpy():

@@ -27,8 +27,16 @@ def _build(tmp_path) -> Path:
 def test_c_client_builds_and_sees_the_error_conventions(tmp_path):
     exe = _build(tmp_path)
     r = subprocess.run([str(exe), "abi"], capture_output=True, text=True, timeout=120)
-    assert r.returncode == 0 and r.stdout.strip() == "ABI_OK 4", (r.stdout, r.stderr)
+    assert r.returncode == 0 and r.stdout.strip() == "ABI_OK 5", (r.stdout, r.stderr)
     assert subprocess.run([str(exe)], capture_output=True).returncode == 2
+    # the launch plan from plain C == the Python mirror's (both are calls of amuse_plan; neither restates the rule)
+    from amuse_amd import _lib
+    for clips, prec, tokens in ((1, 0, 5), (64, 1, 5), (200, 2, 4), (256, 2, 5), (300, 3, 3), (4096, 2, 5)):
+        r = subprocess.run([str(exe), "plan", str(clips), str(prec), str(tokens)], capture_output=True, text=True, timeout=60)
+        p = _lib.plan(clips, prec, tokens)
+        want = f"PLAN {p['clips_per_group']} " + " ".join(str(_lib.DECODE_PATHS.index(p[k])) for k in ("decode_path", "encode_path", "step_path"))
+        assert r.returncode == 0 and r.stdout.strip() == want, (r.stdout, r.stderr, want)
+    assert subprocess.run([str(exe), "plan", "0", "0", "5"], capture_output=True).returncode == 1
 
 
 @pytest.mark.gpu

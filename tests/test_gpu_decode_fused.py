@@ -299,7 +299,7 @@ def test_fp32x_row_stages_block0_hoist_is_bitwise_and_follows_the_weights():
 
 
 def test_fp32x_shards_decode_on_the_whole_jobs_kernels():
-    """A 192-clip fp32x job decodes on the per-clip kernel (amuse_amd/shard.py job_decode_path -> "clip"); cut into two 96-clip shards - each of which would pick the
+    """A 192-clip fp32x job decodes on the per-clip kernel (amuse_plan -> "clip"); cut into two 96-clip shards - each of which would pick the
     row / attention launches on its own - it must give the same bits once the job's choice is pinned, and other bits without the pin (two kernels, same function)."""
     from amuse_amd import shard, weights as wts
     from amuse_amd.engine import HipEngine
@@ -307,8 +307,8 @@ def test_fp32x_shards_decode_on_the_whole_jobs_kernels():
     try:
         z = torch.randn(192, 128, generator=torch.Generator().manual_seed(21))
         whole = eng.vae_decode(z, None, "fp32x", return_feats=True)                        # AUTO: 192 clips -> the per-clip kernel
-        assert shard.job_decode_path(192) == "clip" and shard.job_decode_path(96) == "fused"
-        eng.set_decode_path(shard.job_decode_path(192))
+        assert shard.job_plan(192)["decode_path"] == "clip" and shard.job_plan(96)["decode_path"] == "fused"
+        eng.set_decode_path(shard.job_plan(192)["decode_path"])
         parts = [eng.vae_decode(z[a:a + 96], None, "fp32x", return_feats=True) for a in (0, 96)]
         assert torch.equal(torch.cat([p["feats"] for p in parts]), whole["feats"]) and torch.equal(torch.cat([p["poses"] for p in parts]), whole["poses"])
         eng.set_decode_path("auto")

@@ -13,10 +13,8 @@ HERE = Path(__file__).resolve().parent / "host_asan"
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 
 
-@pytest.mark.skipif(not (shutil.which(HIPCC) or os.path.exists(HIPCC)), reason="hipcc not available")
-def test_host_code_is_clean_under_asan_and_ubsan(tmp_path):
-    build = subprocess.run(["bash", str(HERE / "build.sh"), str(tmp_path)], capture_output=True, text=True, timeout=600)
-    assert build.returncode == 0, build.stdout[-2000:] + build.stderr[-2000:]
+def test_host_code_is_clean_under_asan_and_ubsan(host_asan_build):
+    tmp_path = host_asan_build
     env = dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=0", UBSAN_OPTIONS="print_stacktrace=1:halt_on_error=1")
     run = subprocess.run([str(tmp_path / "host_asan"), "1"], capture_output=True, text=True, timeout=900, env=env, cwd=str(tmp_path))
     assert run.returncode == 0 and "HOST ASAN OK (audio 1)" in run.stdout, run.stdout[-3000:] + run.stderr[-3000:]

@@ -87,9 +87,9 @@ def test_shard_range_partitions():
             assert max(sizes) - min(sizes) <= 1
     assert shard_range(256, 3, 8) == (96, 128)
     # shards aligned to the job's clips per workgroup tile (bitwise reproducibility across shardings)
-    from amuse_amd.shard import job_clips_per_group
-    assert [job_clips_per_group(n) for n in (1, 128, 129, 256, 257, 4096)] == [1, 1, 2, 2, 3, 3]
-    assert job_clips_per_group(4096, tokens=3) == 5
+    from amuse_amd.shard import job_plan
+    assert [job_plan(n)["clips_per_group"] for n in (1, 128, 129, 256, 257, 4096)] == [1, 1, 2, 2, 3, 3]
+    assert job_plan(4096, tokens=3)["clips_per_group"] == 5
     for total, world, g in ((300, 4, 3), (10, 4, 3), (256, 8, 2), (7, 3, 2)):
         r = [shard_range(total, k, world, align=g) for k in range(world)]
         assert r[0][0] == 0 and r[-1][1] == total
@@ -332,7 +332,7 @@ def test_shard_range_properties_hypothesis():
     partition [0, total) in rank order, every boundary but the last is a multiple of the alignment (so a clip keeps its slot in
     its tile - what makes shards bitwise the single-GPU result), and the ranks' loads differ by at most one aligned unit."""
     from hypothesis import given, settings, strategies as st
-    from amuse_amd.shard import shard_range, job_clips_per_group
+    from amuse_amd.shard import shard_range, job_plan
 
     @settings(max_examples=300, deadline=None)
     @given(st.integers(0, 5000), st.integers(1, 16), st.integers(1, 5))
@@ -351,7 +351,7 @@ def test_shard_range_properties_hypothesis():
     @settings(max_examples=200, deadline=None)
     @given(st.integers(1, 100000), st.integers(3, 5))
     def tiling(total, tokens):
-        g = job_clips_per_group(total, tokens)
+        g = job_plan(total, tokens)["clips_per_group"]
         assert 1 <= g <= 16 // tokens
         assert g == 16 // tokens or total <= 128 * g          # more clips per tile only once 128 tiles are full
     tiling()
@@ -381,11 +381,25 @@ def test_bench_reports_pmc_traffic_only_for_the_kernel_that_was_counted(monkeypa
     assert bench.pmc_traffic_bytes(64, 1000, "bf16")[0] is None                                          # no pass at that shape
 
 
-def test_job_decode_path_rule():
-    """amuse_amd/shard.py job_decode_path / fusedx_rule (mirrors amuse_api.hip): staged below 64 clips, the fused / no-split-K kernels from 64, the fp32x per-clip decoder
-    ("clip") where the job's clips fill rounds of the chip's 256 CUs."""
-    from amuse_amd import shard
+def test_job_plan_known_values():
+    """amuse_plan (the library's own rule, through shard.job_plan - nothing in Python restates it; tests/test_plan_cpu.py sweeps it against what the entry points
+    take): known values of the fp32x rule - staged below 64 clips, the no-split-K kernels from 64, the per-clip decoder ("clip") where the job's clips fill rounds of
+    the chip's 256 CUs - and its per-precision forms."""
+    from amuse_amd import _lib, shard
     want = {1: "staged", 63: "staged", 64: "fused", 159: "fused", 160: "clip", 256: "clip", 257: "fused", 419: "fused", 420: "clip", 512: "clip", 513: "fused",
             625: "fused", 626: "clip", 768: "clip", 831: "fused", 832: "clip", 1024: "clip", 1025: "fused", 1038: "clip", 4096: "clip"}
-    assert {n: shard.job_decode_path(n) for n in want} == want
-    assert all(shard.fusedx_rule(n) for n in range(1280, 4097, 7))          # from the sixth round on every count qualifies
+    assert {n: shard.job_plan(n)["decode_path"] for n in want} == want
+    assert all(shard.job_plan(n)["decode_path"] == "clip" for n in range(1280, 4097, 7))          # from the sixth round on every count qualifies
+    for n, w in want.items():
+        assert shard.job_plan(n, precision=_lib.PREC_F32)["decode_path"] == "staged"
+        for prec in (_lib.PREC_BF16, _lib.PREC_F16):
+            p = shard.job_plan(n, precision=prec)
+            assert p["decode_path"] == ("staged" if n < 64 else "fused") and p["encode_path"] == "staged"
+        px = shard.job_plan(n)
+        assert px["encode_path"] == w and px["step_path"] == "staged"                               # (the latent Denoiser has no per-step choice)
+        assert shard.job_plan(n, arch=_lib.ARCH_ENC_POSE)["step_path"] == w and shard.job_plan(n, arch=_lib.ARCH_ENC_POSE)["clips_per_group"] == 1
+        assert shard.job_plan(n, arch=_lib.ARCH_DEC_POSE)["step_path"] == "staged"
+    with pytest.raises(_lib.AmuseHipError):
+        shard.job_plan(0)
+    with pytest.raises(_lib.AmuseHipError):
+        shard.job_plan(8, tokens=6)

@@ -87,3 +87,14 @@ def test_cli_fn_train_gesture_dispatches_to_the_trainer(tmp_path):
     (root / "scripts/overrides/infer_gesture.yaml").write_text("TRAIN_PARAM:\n  pretrained_infer: False\n")
     with pytest.raises(AssertionError, match="mismatch"):
         cli.main(["--fn", "infer_gesture", "--root", str(root), "--random-init"])
+
+
+def test_multigpu_preflight_protocol_on_gloo():
+    """tools/multigpu_preflight.py (what to run first when a multi-GPU node appears): its launcher + step protocol with 2 gloo ranks on the CPU -
+    init, barrier, the 6,835,661-float all-reduce of train_gesture, the 3 x 256-float all-gather of the all-pairs edit batch; one JSON record, rc 0."""
+    r = subprocess.run([sys.executable, str(REPO / "tools" / "multigpu_preflight.py"), "--gpus", "2", "--cpu"], cwd=REPO, env=_env(),
+                       capture_output=True, text=True, timeout=600)
+    rec = [json.loads(l) for l in r.stdout.splitlines() if l.startswith('{"tool": "multigpu_preflight"')]
+    assert r.returncode == 0 and len(rec) == 1, (r.stdout[-1500:], r.stderr[-1500:])
+    assert rec[0]["ok"] and rec[0]["world"] == 2 and [s["step"] for s in rec[0]["steps"]] == ["init", "barrier", "all_reduce", "all_gather"]
+    assert all(s["ok"] for s in rec[0]["steps"]) and rec[0]["steps"][2]["floats"] == 6835661

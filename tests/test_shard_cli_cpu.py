@@ -147,14 +147,14 @@ def test_job_range_cuts_on_tile_boundaries():
     from amuse_amd import shard
     from amuse_amd.trainer import local_jobs
     # 300 one-clip jobs with five tokens: ceil(300 / 128) = 3 clips per tile -> cuts at multiples of 3
-    g = shard.job_clips_per_group(300, 5)
+    g = shard.job_plan(300, 5)["clips_per_group"]
     assert g == 3
     cuts = [shard.job_range([1] * 300, r, 4, align=g) for r in range(4)]
     assert cuts[0][0] == 0 and cuts[-1][1] == 300 and all(a[1] == b[0] for a, b in zip(cuts, cuts[1:]))
     assert all(a % g == 0 for a, _ in cuts)
     # jobs of unequal size: a cut only where the clip offset is a multiple of the tile
     bszs = [2, 2, 1, 3, 2, 2, 4, 1, 1, 2] * 20      # 400 clips -> 4 clips per tile (3 tokens allow 5; ceil(400 / 128) = 4)
-    g = shard.job_clips_per_group(sum(bszs), 3)
+    g = shard.job_plan(sum(bszs), 3)["clips_per_group"]
     offs = [0]
     for b in bszs:
         offs.append(offs[-1] + b)
@@ -199,7 +199,7 @@ def test_job_range_properties_hypothesis():
         dicts = [{"bsz": b, "no_emo": e, "no_sty": s} for b, e, s in specs]
         for (no_emo, no_sty), idx in job_runs(dicts):
             bszs = [specs[j][0] for j in idx]
-            g = shard.job_clips_per_group(sum(bszs), 5 - no_emo - no_sty)
+            g = shard.job_plan(sum(bszs), 5 - no_emo - no_sty)["clips_per_group"]
             offs = [0]
             for b in bszs:
                 offs.append(offs[-1] + b)

@@ -1,4 +1,4 @@
-"""One fp32x step of the pose-space Denoiser (diffusion_only + trans_enc, S = 304) with its blocks on the per-clip kernel (csrc/k_vae_fusedx.hip k_den_fusedx, AMUSE_VAE_FUSEDX=1)
+"""One fp32x step of the pose-space Denoiser (diffusion_only + trans_enc, S = 304) with its blocks on the per-clip kernel (csrc/k_vae_fusedx.hip k_den_fusedx, amuse_set_decode_path CLIP)
 against the row / attention launches (=0): teacher-forced eps_hat of 256 clips compared, and ms per step over a DDIM-10 loop (HIP events).  One process per mode.
 Usage: python tools/gpu_den_fusedx_check.py [clips]"""
 import os, subprocess, sys
@@ -11,6 +11,7 @@ if len(sys.argv) > 1 and sys.argv[1] == "--child":
     from amuse_amd.engine import HipEngine
     out, B = sys.argv[2], int(sys.argv[3])
     eng = HipEngine(wts.make_denoiser_weights(0, "trans_enc", True), None, "cuda:0", arch="trans_enc", diffusion_only=True)
+    eng.set_decode_path(os.environ.get("FX_PATH", "auto"))   # the parent pins the kernel family per child process
     g = torch.Generator().manual_seed(0)
     con, emo, sty = (torch.randn(B, 256, generator=g).cuda() for _ in range(3))
     x = torch.randn(B, 300, 333, generator=g).cuda()
@@ -36,7 +37,7 @@ else:
     B = sys.argv[1] if len(sys.argv) > 1 else "256"
     outs = {}
     for mode in ("staged", "fusedx"):
-        env = dict(os.environ, AMUSE_VAE_FUSEDX="1" if mode == "fusedx" else "0")
+        env = dict(os.environ, FX_PATH="clip" if mode == "fusedx" else "fused")
         out = f"/tmp/denfx_{mode}.npz"
         print(f"--- {mode}", flush=True)
         r = subprocess.run([sys.executable, __file__, "--child", out, B], env=env, capture_output=True, text=True)

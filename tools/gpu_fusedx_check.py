@@ -1,4 +1,4 @@
-"""fp32x decode as one persistent workgroup per clip (csrc/k_vae_fusedx.hip, AMUSE_VAE_FUSEDX=1) against the staged fp32x path (k_vae_rows8x + k_vae_attn_x): the two must
+"""fp32x decode as one persistent workgroup per clip (csrc/k_vae_fusedx.hip, amuse_set_decode_path CLIP) against the staged fp32x path (k_vae_rows8x + k_vae_attn_x): the two must
 produce the same bits (full-length and ragged clips); ms per decode by HIP events.  Each mode in its own process (the switch is read once).
 Usage: python tools/gpu_fusedx_check.py [clips ...]"""
 import os, subprocess, sys
@@ -11,6 +11,7 @@ if len(sys.argv) > 1 and sys.argv[1] == "--child":
     from amuse_amd.engine import HipEngine
     out = sys.argv[2]
     eng = HipEngine(wts.make_denoiser_weights(0), wts.make_prior_weights(0))
+    eng.set_decode_path(os.environ.get("FX_PATH", "auto"))   # the parent pins the kernel family per child process
     res = {}
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     for B in [int(v) for v in sys.argv[3:]]:
@@ -35,7 +36,7 @@ else:
     outs = {}
     for mode in ("staged", "fusedx"):
         env = dict(os.environ)
-        env["AMUSE_VAE_FUSEDX"] = "1" if mode == "fusedx" else "0"
+        env["FX_PATH"] = "clip" if mode == "fusedx" else "fused"
         out = f"/tmp/fusedx_{mode}.npz"
         print(f"--- {mode}", flush=True)
         r = subprocess.run([sys.executable, __file__, "--child", out, *Bs], env=env, capture_output=True, text=True)

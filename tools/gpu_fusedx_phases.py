@@ -1,5 +1,5 @@
 """Phase timeline of the fused fp32x decoder (libamuse_hip built with -DAMUSE_FPROF=1 for k_vae_fusedx.hip: tools/build_variant.sh fxprof k_vae_fusedx.hip "-DAMUSE_FPROF=1 -fno-honor-nans"):
-AMUSE_VAE_FUSEDX=1 AMUSE_HIP_LIB=amuse_amd/libamuse_hip_fxprof.so python tools/gpu_fusedx_phases.py 2>&1 | python tools/gpu_fusedx_phases.py --sum"""
+AMUSE_HIP_LIB=amuse_amd/libamuse_hip_fxprof.so python tools/gpu_fusedx_phases.py 2>&1 | python tools/gpu_fusedx_phases.py --sum"""
 import sys
 if '--sum' in sys.argv:
     import collections
@@ -21,6 +21,7 @@ sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
 from amuse_amd import weights as wts
 from amuse_amd.engine import HipEngine
 eng = HipEngine(wts.make_denoiser_weights(0), wts.make_prior_weights(0))
+eng.set_decode_path("clip")
 z = torch.randn(256, 128, generator=torch.Generator().manual_seed(1)).cuda()
 for i in range(4):
     eng.vae_decode(z, None, "fp32x")

@@ -1,6 +1,5 @@
-"""Phase timeline of one denoising step of the 4-wave sampling kernels (s_memtime stamps): the fp32 parity kernel, and
-the 4-wave bf16 kernel when run with AMUSE_SAMPLE_WAVES=4 (the default bf16 kernel has 8 waves:
-tools/gpu_phase_profile8.py)."""
+"""Phase timeline of one denoising step of the 4-wave sampling kernel (s_memtime stamps): the fp32 parity kernel
+(the 8-wave kernels of the other modes: tools/gpu_phase_profile8.py)."""
 import os
 import sys, json
 from pathlib import Path
@@ -14,7 +13,7 @@ eng.set_schedule(sch.ddpm_table(50))
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 if len(sys.argv) > 2:
     eng.set_clips_per_group(int(sys.argv[2]))
-precs = sys.argv[3].split(",") if len(sys.argv) > 3 else (("bf16", "fp32") if os.environ.get("AMUSE_SAMPLE_WAVES") == "4" else ("fp32",))
+precs = sys.argv[3].split(",") if len(sys.argv) > 3 else ("fp32",)
 gen = torch.Generator().manual_seed(2)
 c, e, s = (torch.randn(B, 256, generator=gen).cuda() for _ in range(3))
 names = ["blk_start", "in_proj", "attention", "out_proj", "combine1", "LN1", "linear1", "GELU", "linear2", "combine2", "LN2"]

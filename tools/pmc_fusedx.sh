@@ -1,5 +1,5 @@
 cd $GRAFT_REPO_ROOT
-export TMPDIR=/tmp AMUSE_VAE_FUSEDX=1
+export TMPDIR=/tmp
 O=gpurun_out/fx_pmc
 rm -rf $O && mkdir -p $O
 i=0
