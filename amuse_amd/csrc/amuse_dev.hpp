@@ -165,6 +165,14 @@ __device__ __forceinline__ uint4 ldw(const uint4* p) {
 __device__ __forceinline__ uint4 ldw_pos(const uint4* p, int pos) {
     return ldw(p);
 }
+// Lazy rescaling in the online-softmax loops whose scores leave the MFMA relative to the running maximum (amuse_fused.hpp attend, k_vae_fusedx.hip attend_x, k_audio.hip):
+// a chunk only moves a tile's running maxima when some score exceeds its row's by more than kAttnTau log2 units.  Until then p = exp2(s - m_run) may reach 2^kAttnTau
+// instead of 1 - harmless: bf16 / fp16 / fp32 keep their relative precision there (fp16: 2^6 is far from 65504), the row sums carry the same scale and the final division
+// removes it.  With the rule of rounds 2-5 (threshold 0) the "rare" rescale ran in nearly every chunk - 16 rows x 64 fresh keys almost always hold some new row maximum
+// (record statistics: probability 1 / (chunk + 1) per row) - and cost ~35 VALU instructions beside the chunk's own ~30: measured on MI355X (round 6,
+// profiles/r06_attention_lazy_rescale.txt) the decoder's S = 300 attention went from 0.27 to 0.31 of the MFMA peak.  Thresholds 4 .. 12 time the same and give the same bits on
+// the test data (no chunk behind the first moves a maximum by 16 x).
+constexpr float kAttnTau = 6.0f;
 template <int R>
 struct WRing {
     uint4 s[R];

@@ -189,6 +189,7 @@ __device__ __forceinline__ float max3(float a, float b, float c) { return fmaxf(
 // too scarce (x + xb of three tiles = 144 of 256) for hipcc to hoist the reads itself.  So a chunk's four K fragments are
 // read as ONE batch in front of its four score MFMAs, and its four V^T fragments as one batch right behind them - they
 // land while the softmax arithmetic runs.
+// (lazy rescaling of the running maxima: kAttnTau, amuse_dev.hpp)
 template <bool NOATTN = false>
 __device__ __forceinline__ OPV attend(const uint4* Kb, const uint4* Vt, OPV qb, int len, int g, int r) {
     if constexpr (NOATTN) return qb;
@@ -236,7 +237,7 @@ __device__ __forceinline__ OPV attend(const uint4* Kb, const uint4* Vt, OPV qb, 
         float mx = max3(max3(st[0][0], st[0][1], st[0][2]), max3(st[0][3], st[1][0], st[1][1]), max3(st[1][2], st[1][3], st[2][0]));
         mx = max3(mx, max3(st[2][1], st[2][2], st[2][3]), max3(st[3][0], st[3][1], st[3][2]));
         mx = fmaxf(mx, st[3][3]);
-        if (ch == 0 || __builtin_amdgcn_ballot_w64(mx > 0.f) != 0) {   // (wave-uniform)
+        if (ch == 0 || __builtin_amdgcn_ballot_w64(mx > kAttnTau) != 0) {   // (wave-uniform)
             mx = allreduce_g_max(mx);   // the same in the four lanes of a row; -inf for a fully masked chunk (ch > 0 only)
             const float d = ch == 0 ? mx : fmaxf(mx, 0.f);
 #pragma unroll

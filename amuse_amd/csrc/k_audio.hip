@@ -351,7 +351,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
             mx = fmaxf(mx, st[q][3][3]);   // this lane's 16 scores; every chunk holds a valid key
             // the running maximum moves in the first chunks and then hardly ever: the row's maximum (four lanes) is formed, and the
             // scores shifted and the accumulators rescaled, only when SOME lane of the wave holds a positive score (wave-uniform branch)
-            if (c == 0 || __builtin_amdgcn_ballot_w64(mx > 0.f) != 0) {
+            if (c == 0 || __builtin_amdgcn_ballot_w64(mx > kAttnTau) != 0) {   // (lazy rescaling: amuse_dev.hpp kAttnTau)
                 mx = allreduce_g_max(mx);   // the same in the four lanes of a row
                 const float d = c == 0 ? mx : fmaxf(mx, 0.f);
 #pragma unroll

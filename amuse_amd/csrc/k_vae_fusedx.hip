@@ -142,7 +142,7 @@ __device__ __forceinline__ void attend_x(const uint4* Kh, const uint4* Kl, const
                 for (int m = 0; m < 4; ++m) st[u][m] = (16 * u + m < lim) ? st[u][m] : -INFINITY;
         }
         float mx = max3(max3(st[0][0], st[0][1], st[0][2]), max3(st[0][3], st[1][0], st[1][1]), fmaxf(st[1][2], st[1][3]));
-        if (FIRST || __builtin_amdgcn_ballot_w64(mx > 0.f) != 0) {   // (wave-uniform) some row's maximum moves
+        if (FIRST || __builtin_amdgcn_ballot_w64(mx > kAttnTau) != 0) {   // (wave-uniform) some row's maximum moves by more than 2^kAttnTau (lazy rescaling, amuse_dev.hpp)
             mx = allreduce_g_max(mx);
             const float d = FIRST ? mx : fmaxf(mx, 0.f);
             st[0] -= splat4(d);

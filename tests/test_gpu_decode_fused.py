@@ -98,6 +98,9 @@ def _r(x):
     return x.to(torch.bfloat16).to(torch.float32)
 
 
+ATTN_TAU = 6.0   # amuse_dev.hpp kAttnTau
+
+
 def _fused_attention_model(q, k, v, length):
     """q, k, v: (H, S, 32) fp32 (q already scaled into log2 units and rounded, k / v rounded); online softmax in 64-key chunks."""
     H, S, _ = q.shape
@@ -108,7 +111,15 @@ def _fused_attention_model(q, k, v, length):
         k1 = min(k0 + 64, length)
         st = q @ k[:, k0:k1].transpose(-1, -2) - m[..., None]           # the MFMA's C operand is -m_run
         mx = st.max(dim=-1).values
-        d = mx if ch == 0 else mx.clamp(min=0.0)
+        if ch == 0:
+            d = mx
+        else:
+            # lazy rescaling (amuse_dev.hpp kAttnTau): the maxima of a wave's 16-row tile move - for every row of the tile - only when SOME row's chunk maximum
+            # exceeds its running one by more than TAU log2 units (the kernel's wave-uniform ballot)
+            Sp = -(-S // 16) * 16
+            trig = torch.nn.functional.pad(mx, (0, Sp - S), value=-1e30).reshape(H, Sp // 16, 16).gt(ATTN_TAU).any(-1)
+            trig = trig[..., None].expand(H, Sp // 16, 16).reshape(H, Sp)[:, :S]
+            d = torch.where(trig, mx.clamp(min=0.0), torch.zeros_like(mx))
         st = st - d[..., None]
         if ch > 0:
             alpha = torch.exp2(-d)
