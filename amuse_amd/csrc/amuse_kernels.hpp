@@ -282,6 +282,8 @@ hipError_t launch_den_fusedh(const DenFusedArgs& a, hipStream_t stream);   // fp
 // feats[row][0:330] = first two rows of R(axis-angle) per joint, feats[row][330:333] = trans   (infer_ldm.py:459-464)
 // training step (k_train_gemm.hip): out[M][N] = (bias | accumulate: out) + a[M][K] . (tb ? b[N][K]^T : b[K][N]) for the tall fp32 projections it takes
 bool train_gemm_tall_takes(long M, long N, long K, bool tb, bool bias);
+// ... and for every other shape / transpose of the step (the 333-wide layers, 32- and 160-row projections, weight gradients): the same file's generic kernel
+hipError_t launch_train_gemm_any(const float* a, const float* b, const float* bias, float* out, long M, long N, long K, bool ta, bool tb, bool accumulate, hipStream_t stream);
 hipError_t launch_train_gemm_tall(const float* a, const float* b, const float* bias, float* out, long M, long N, long K, bool tb, bool accumulate, hipStream_t stream);
 hipError_t launch_smplx_to_feats(const float* poses, const float* trans, size_t nrows, float* feats, hipStream_t stream);
 // mu = stats[b][0], std = exp(stats[b][1]) ** 0.5, latent = mu + std * eps   (vae.py:209-213)

@@ -13,7 +13,6 @@
 // Dropout masks are counter-based: element e of a call is draw e % 4 of Philox4x32-10(key = seed, counter = (e / 4, offset)) - nothing is stored,
 // the backward kernels regenerate the mask from the same (seed, offset); keep <=> u >= p with u = the draw's top 24 bits / 2^24.
 // Column sums are deterministic: every workgroup writes its partial sums, a one-workgroup launch behind it adds them up in a fixed order.  All arrays fp32, row-major [rows][C]; HBM-bound by construction (each array is read or written once).
-#include <dlfcn.h>
 
 #include <mutex>
 
@@ -303,41 +302,15 @@ int grid_for(long rows, int rows_per_wg) {
     return (int)(g < 1 ? 1 : g > kTrainWgs ? kTrainWgs : g);
 }
 
-// ---- rocBLAS for the layer's plain GEMMs (the brief's "library GEMMs"): loaded on first use with dlopen - the inference path of this library has no
-// BLAS dependency - preferring the copy the process already holds (torch's), one handle per device.  Row-major wrappers: C = op(A) . op(B).
-struct Blas {
-    typedef int (*create_t)(void**);
-    typedef int (*set_stream_t)(void*, hipStream_t);
-    typedef int (*sgemm_t)(void*, int, int, int, int, int, const float*, const float*, int, const float*, int, const float*, float*, int);
-    void* lib = nullptr;
-    create_t create = nullptr;
-    set_stream_t set_stream = nullptr;
-    sgemm_t sgemm = nullptr;
-    void* handle[64] = {};
-    std::mutex mu;
-};
-Blas g_blas;
+// ---- the layer's plain GEMMs run on the library's own fp32-MFMA kernels (k_train_gemm.hip: the tall projections; the generic kernel for every other shape) and on the
+// chunked weight-gradient kernel below: no vendor BLAS anywhere in the library (rounds 2-5 sent the 333-wide, 32-row and 160-row shapes to a dlopen'ed rocBLAS).
+// blas_handle keeps its name from then: it records the stream of the call for rm_gemm.
 hipStream_t g_blas_stream[64] = {};
 int blas_handle(hipStream_t st, void** h) {
-    std::lock_guard<std::mutex> lock(g_blas.mu);
-    if (!g_blas.lib) {
-        for (const char* name : {"librocblas.so", "librocblas.so.5", "/opt/rocm/lib/librocblas.so"}) {
-            g_blas.lib = dlopen(name, RTLD_NOW | RTLD_LOCAL);
-            if (g_blas.lib) break;
-        }
-        if (!g_blas.lib) return fail(AMUSE_ESTATE, "the training-step layer entry points need rocBLAS: dlopen(librocblas.so) failed: %s", dlerror());
-        g_blas.create = (Blas::create_t)dlsym(g_blas.lib, "rocblas_create_handle");
-        g_blas.set_stream = (Blas::set_stream_t)dlsym(g_blas.lib, "rocblas_set_stream");
-        g_blas.sgemm = (Blas::sgemm_t)dlsym(g_blas.lib, "rocblas_sgemm");
-        if (!g_blas.create || !g_blas.set_stream || !g_blas.sgemm) return fail(AMUSE_ESTATE, "rocBLAS symbols missing");
-    }
     int dev = 0;
     HIP_TRY(hipGetDevice(&dev));
-    dev &= 63;
-    if (!g_blas.handle[dev] && g_blas.create(&g_blas.handle[dev]) != 0) return fail(AMUSE_EHIP, "rocblas_create_handle failed");
-    if (g_blas.set_stream(g_blas.handle[dev], st) != 0) return fail(AMUSE_EHIP, "rocblas_set_stream failed");
-    g_blas_stream[dev] = st;   // (rm_gemm's own kernels run on the stream the handle was given)
-    *h = g_blas.handle[dev];
+    g_blas_stream[dev & 63] = st;
+    *h = nullptr;
     return 0;
 }
 // ---- weight gradients: dW[M][N] = dy^T x over `rows` (dy [rows][M], x [rows][N], row-major).  The outputs are small (128 x 128 .. 512 x 128) and the reduction long
@@ -426,12 +399,7 @@ __global__ __launch_bounds__(256) void k_train_wgrad_sum(const float* __restrict
     if (q == 0) st4(out + 4 * i, ((s + red[0][c]) + red[1][c]) + red[2][c]);
 }
 float* g_wgrad_ws[64] = {};
-// 1 = the kernel above for the shapes it takes, 0 = rocBLAS for everything (AMUSE_TRAIN_WGRAD=vendor; A/B)
-bool own_wgrad() {
-    static const bool on = [] { const char* e = getenv("AMUSE_TRAIN_WGRAD"); return !(e && e[0] == 'v'); }();
-    return on;
-}
-// gradients of at least this many elements go to rocBLAS
+// gradients of at least this many elements go to the generic kernel (k_train_gemm.hip)
 constexpr long wgrad_max_elems() { return 131072L; }
 int wgrad_launch(const float* dy, const float* x, float* out, long rows, long M, long N, hipStream_t st) {
     int dev = 0;
@@ -453,11 +421,6 @@ int wgrad_launch(const float* dy, const float* x, float* out, long rows, long M,
     return 0;
 }
 // out[M][N] (+)= op(a) . op(b); a is [M][K] (ta: [K][M]), b is [K][N] (tb: [N][K]), all row-major and dense
-// 1 = the library's own LDS-staged fp32-MFMA kernel (k_train_gemm.hip) for the tall projections it takes, 0 = rocBLAS for everything (AMUSE_TRAIN_GEMM=vendor; A/B)
-bool own_gemm() {
-    static const bool on = [] { const char* e = getenv("AMUSE_TRAIN_GEMM"); return !(e && e[0] == 'v'); }();
-    return on;
-}
 int bias_rows_launch(const float* bias, long rows, int C, float* out, hipStream_t st);
 // bias (nullable; [N]): added to every row of the product - by the own kernel's epilogue, or as out's initial contents in front of the library call
 int rm_gemm(void* h, bool ta, bool tb, long M, long N, long K, const float* a, const float* b, float* out, bool accumulate, const float* bias = nullptr) {
@@ -466,24 +429,19 @@ int rm_gemm(void* h, bool ta, bool tb, long M, long N, long K, const float* a, c
     // (the own kernel copies 16 bytes per lane with LDS-DMA and stores pairs: operands on 16-byte, out / bias on 8-byte boundaries - the Denoiser's weights, views into the
     // trainer's flat parameter buffer behind the prior's 333-element bias, sit on 4-byte ones)
     const bool aligned = !(((uintptr_t)a | (uintptr_t)b) & 15) && !(((uintptr_t)out | (uintptr_t)bias) & 7);
-    if (!ta && aligned && own_gemm() && train_gemm_tall_takes(M, N, K, tb, bias != nullptr)) {
+    if (!ta && aligned && train_gemm_tall_takes(M, N, K, tb, bias != nullptr)) {
         HIP_TRY(launch_train_gemm_tall(a, b, bias, out, M, N, K, tb, accumulate, g_blas_stream[dev & 63]));
         return 0;
     }
-    if (bias) {
-        if (accumulate) return fail(AMUSE_EINVAL, "rm_gemm: bias and accumulate together");
-        bias_rows_launch(bias, M, (int)N, out, g_blas_stream[dev & 63]);
-        accumulate = true;
-    }
+    if (bias && accumulate) return fail(AMUSE_EINVAL, "rm_gemm: bias and accumulate together");
     // (measured, profiles/r04_train_wgrad_kernel_ab.txt: 12 us against 25 for a 128 x 128 gradient over 9,664 rows, 21 against 26 for 384 x 128; the FFN's 512 x 128 - bound by
     // the fp32 MFMA rate and their 13 MB of partial blocks - 25 against 27.5 on the 64 x 32-per-wave instantiation)
     if (ta && !tb && !accumulate && K >= 1024 && !(K & 3) && !(M & 63) && !(N & 63) && M * N < wgrad_max_elems() && (K + kWgradRows - 1) / kWgradRows <= kWgradMaxChunks &&
-        (size_t)(M * N) * ((K + kWgradRows - 1) / kWgradRows) <= kWgradWsFloats && own_wgrad()) {   // a weight gradient with a long reduction
+        (size_t)(M * N) * ((K + kWgradRows - 1) / kWgradRows) <= kWgradWsFloats && !bias) {   // a weight gradient with a long reduction
         return wgrad_launch(a, b, out, K, M, N, g_blas_stream[dev & 63]);
     }
-    const float one = 1.0f, zero = 0.0f;
-    const int rc = g_blas.sgemm(h, tb ? 112 : 111, ta ? 112 : 111, (int)N, (int)M, (int)K, &one, b, (int)(tb ? K : N), a, (int)(ta ? M : K), accumulate ? &one : &zero, out, (int)N);
-    return rc == 0 ? 0 : fail(AMUSE_EHIP, "rocblas_sgemm failed with status %d (M %ld N %ld K %ld)", rc, M, N, K);
+    HIP_TRY(launch_train_gemm_any(a, b, bias, out, M, N, K, ta, tb, accumulate, g_blas_stream[dev & 63]));   // every other shape: 333-wide, 32 / 160 rows, short or wide gradients
+    return 0;
 }
 #define TRY(expr) do { if (int e_ = (expr)) return e_; } while (0)
 
@@ -507,6 +465,31 @@ int colsum_launch(const float* x, long rows, int C, float* out, float* ws, hipSt
     hipLaunchKernelGGL(k_train_colsum, dim3(g), dim3(kTrainThreads), 0, st, x, rows, C / 4, ws);
     if (job) *job = FinJob{ws, {out, nullptr, nullptr}, g, C, C};
     else hipLaunchKernelGGL(k_train_finalize, dim3(1), dim3(kTrainThreads), 0, st, ws, g, out, (float*)nullptr, (float*)nullptr, C, C);
+    return 0;
+}
+// column sums for ANY width (the 333-wide output layer's bias gradient): block (column block of 64, row chunk) -> ws[chunk][C], then the chunks in order
+__global__ __launch_bounds__(256) void k_train_colsum_any(const float* __restrict__ x, long rows, int C, int chunks, float* __restrict__ ws) {
+    __shared__ float red[4][64];
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63), q = threadIdx.x >> 6;
+    const long per = (rows + chunks - 1) / chunks, r0 = (long)blockIdx.y * per, r1 = r0 + per < rows ? r0 + per : rows;
+    float s = 0.f;
+    if (c < C)
+        for (long r = r0 + q; r < r1; r += 4) s += x[(size_t)r * C + c];
+    red[q][threadIdx.x & 63] = s;
+    __syncthreads();
+    if (q == 0 && c < C) ws[(size_t)blockIdx.y * C + c] = ((red[0][threadIdx.x] + red[1][threadIdx.x]) + red[2][threadIdx.x]) + red[3][threadIdx.x];
+}
+__global__ __launch_bounds__(256) void k_train_colsum_any_fin(const float* __restrict__ ws, int chunks, int C, float* __restrict__ out) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    float s = ws[c];
+    for (int k = 1; k < chunks; ++k) s += ws[(size_t)k * C + c];
+    out[c] = s;
+}
+int colsum_any_launch(const float* x, long rows, int C, float* out, float* ws, hipStream_t st) {
+    const int chunks = (int)(rows < 64 ? 1 : rows / 64 > kTrainWgs ? kTrainWgs : rows / 64);
+    hipLaunchKernelGGL(k_train_colsum_any, dim3((unsigned)((C + 63) / 64), (unsigned)chunks), dim3(256), 0, st, x, rows, C, chunks, ws);
+    hipLaunchKernelGGL(k_train_colsum_any_fin, dim3((unsigned)((C + 255) / 256)), dim3(256), 0, st, ws, chunks, C, out);
     return 0;
 }
 constexpr size_t kWsRegion = (size_t)kTrainWgs * 1024;   // floats per reduction's partial sums
@@ -602,7 +585,7 @@ int amuse_train_adamw(float* param, const float* grad, float* exp_avg, float* ex
 // ---- layer-level entry points: everything of a transformer layer but its self-attention core in ONE call each way (amuse_hip.h amuse_train_layer)
 int amuse_train_linear_fwd(const float* x, const float* W, const float* b, long rows, int K, int N, float* out, void* stream) {
     if (!x || !W || !out) return fail(AMUSE_EINVAL, "amuse_train_linear_fwd: NULL argument");
-    if (rows < 1 || K < 1 || N < 4 || (N & 3)) return fail(AMUSE_EINVAL, "rows %ld, K %d, N %d (a multiple of 4)", rows, K, N);
+    if (rows < 1 || K < 1 || N < 1) return fail(AMUSE_EINVAL, "rows %ld, K %d, N %d", rows, K, N);
     hipStream_t st = (hipStream_t)stream;
     void* h;
     TRY(blas_handle(st, &h));
@@ -614,13 +597,13 @@ int amuse_train_linear_fwd(const float* x, const float* W, const float* b, long 
 int amuse_train_linear_bwd(const float* dy, const float* x, const float* W, long rows, int K, int N, float* dW, float* db, float* dx, int accumulate_dx, float* ws,
                            void* stream) {
     if (!dy || !x || !W) return fail(AMUSE_EINVAL, "amuse_train_linear_bwd: NULL argument");
-    if (rows < 1 || K < 1 || N < 4 || (N & 3) || N > 1024) return fail(AMUSE_EINVAL, "rows %ld, K %d, N %d (a multiple of 4 up to 1024)", rows, K, N);
+    if (rows < 1 || K < 1 || N < 1 || N > 1024) return fail(AMUSE_EINVAL, "rows %ld, K %d, N %d (up to 1024)", rows, K, N);
     if (db && !ws) return fail(AMUSE_EINVAL, "the bias gradient needs the workspace");
     hipStream_t st = (hipStream_t)stream;
     void* h;
     TRY(blas_handle(st, &h));
     if (dW) TRY(rm_gemm(h, true, false, N, K, rows, dy, x, dW, false));          // dW[N][K] = dy^T x
-    if (db) colsum_launch(dy, rows, N, db, ws, st);
+    if (db) { if (N & 3) colsum_any_launch(dy, rows, N, db, ws, st); else colsum_launch(dy, rows, N, db, ws, st); }
     if (dx) TRY(rm_gemm(h, false, false, rows, K, N, dy, W, dx, accumulate_dx != 0));   // dx[rows][K] (+)= dy W
     HIP_TRY(hipGetLastError());
     return 0;

@@ -17,6 +17,7 @@
 // Bias (forward) and the previous contents of out (accumulating calls) are loaded ahead of the k loop and added behind it (beta C last, as the library GEMM).
 #include "amuse_dev.hpp"
 #include "amuse_kernels.hpp"
+#include <algorithm>
 #include <cstdio>
 
 namespace amuse {
@@ -173,6 +174,113 @@ __global__ __launch_bounds__(64 * (4 + kGemmCopyWaves)) void k_train_gemm_tall(c
         }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------------------------------------------
+// Every OTHER GEMM of the step (the ones rocBLAS ran through round 5): the 333-wide embedding / output layers (skel_embedding, final_layer: K or N = 333 - no
+// 16-byte rows, no multiple of 32), the 32-row memory projections of the decoder's one-key cross-attention, the Denoiser's 160-row layers, and every weight
+// gradient the chunked kernel of k_train.hip does not take.  One kernel for any shape and both transposes:
+//     out[M][N] (+)= opA . opB (+ bias),   opA(m, k) = TA ? a[k][m] : a[m][k],   opB(k, n) = TB ? b[n][k] : b[k][n],   fp32 operands, v_mfma_f32_16x16x4_f32
+// 64 x 64 output tile per workgroup (four waves, 32 x 32 each = 2 x 2 accumulator tiles), k in steps of 16 through LDS: every thread loads 4 + 4 elements per step
+// (bounds-checked, zero beyond the edges; along the operand's contiguous axis, so a step reads whole 64-byte segments) into [k][row] images with a 65-float
+// stride, and a fragment is one ds_read_b32 per MFMA.  Long reductions over few output tiles (weight gradients: K = 9,600 rows into 333 x 128) are cut along k
+// over gridDim.z into partial tiles that k_gemm_any_sum adds up in a fixed order (deterministic).  These are the small GEMMs of the step - tens of microseconds
+// in total - so the kernel is built for coverage and determinism, not for the last percent: the tall projections stay on k_train_gemm_tall above.
+// T = output tile side of a workgroup: 64 (four waves of 32 x 32, k steps of 16) or - for problems whose 64-tiles could not fill the chip: the 32- and 160-row
+// GEMMs - 32 (four waves of 16 x 16, k steps of 32: four times the workgroups, a quarter of the dependent MFMAs per step).  Either way a thread moves 4 + 4
+// elements per step, and the loads of step i + 1 are in flight while the MFMAs of step i run (these GEMMs are latency chains: 4 .. 32 steps).
+template <bool TA, bool TB, int T>
+__global__ __launch_bounds__(256) void k_train_gemm_any(const float* __restrict__ a, const float* __restrict__ b, const float* __restrict__ bias, float* __restrict__ out,
+                                                        int M, int N, int K, int kchunk, int accumulate, float* __restrict__ part) {
+    constexpr int KS = 1024 / T, kStride = T + 1, NW = T / 32;   // k step; LDS row stride; accumulator tiles per wave and side
+    __shared__ float As[KS * kStride], Bs[KS * kStride];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, r = lane & 15;
+    const int m0 = blockIdx.x * T, n0 = blockIdx.y * T;
+    const int k_lo = blockIdx.z * kchunk, k_hi = min(K, k_lo + kchunk);
+    const int wm = (T / 2) * (wave >> 1), wn = (T / 2) * (wave & 1);
+    f32x4 acc[NW][NW];
+#pragma unroll
+    for (int i = 0; i < NW; ++i)
+#pragma unroll
+        for (int j = 0; j < NW; ++j) acc[i][j] = splat4(0.f);
+    // an operand whose contiguous axis is k (a [M][K], b [N][K]): thread = (row, four k's); contiguous along m / n (a [K][M], b [K][N]): thread = (k, four rows)
+    constexpr int kPerRow = KS / 4, rPerK = T / 4;
+    const int kc_row = tid / kPerRow, kc_k = (tid % kPerRow) * 4, mc_k = tid / rPerK, mc_row = (tid % rPerK) * 4;
+    float va[4], vb[4];
+    auto load = [&](int k0) {
+        if constexpr (!TA) {
+            const int m = m0 + kc_row;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) va[e] = (m < M && k0 + kc_k + e < k_hi) ? a[(size_t)m * K + k0 + kc_k + e] : 0.f;
+        } else {
+            const int k = k0 + mc_k;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) va[e] = (k < k_hi && m0 + mc_row + e < M) ? a[(size_t)k * M + m0 + mc_row + e] : 0.f;
+        }
+        if constexpr (TB) {
+            const int n = n0 + kc_row;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) vb[e] = (n < N && k0 + kc_k + e < k_hi) ? b[(size_t)n * K + k0 + kc_k + e] : 0.f;
+        } else {
+            const int k = k0 + mc_k;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) vb[e] = (k < k_hi && n0 + mc_row + e < N) ? b[(size_t)k * N + n0 + mc_row + e] : 0.f;
+        }
+    };
+    if (k_lo < k_hi) load(k_lo);
+    for (int k0 = k_lo; k0 < k_hi; k0 += KS) {
+        __syncthreads();   // (the previous step's fragments have been read)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            if constexpr (!TA) As[(kc_k + e) * kStride + kc_row] = va[e];
+            else As[mc_k * kStride + mc_row + e] = va[e];
+            if constexpr (TB) Bs[(kc_k + e) * kStride + kc_row] = vb[e];
+            else Bs[mc_k * kStride + mc_row + e] = vb[e];
+        }
+        __syncthreads();
+        if (k0 + KS < k_hi) load(k0 + KS);   // in flight under this step's MFMAs
+#pragma unroll
+        for (int s = 0; s < KS / 4; ++s) {   // MFMA s: k = k0 + 4 s + g on both operands
+            float af[NW], bf[NW];
+#pragma unroll
+            for (int i = 0; i < NW; ++i) {
+                af[i] = As[(4 * s + g) * kStride + wm + 16 * i + r];
+                bf[i] = Bs[(4 * s + g) * kStride + wn + 16 * i + r];
+            }
+#pragma unroll
+            for (int i = 0; i < NW; ++i)
+#pragma unroll
+                for (int j = 0; j < NW; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i], bf[j], acc[i][j], 0, 0, 0);
+        }
+    }
+    // C / D layout of the 16 x 16 tile: lane (g, r) holds rows 4 g + v, column r
+    float* dst = gridDim.z > 1 ? part + (size_t)blockIdx.z * M * N : out;
+#pragma unroll
+    for (int i = 0; i < NW; ++i)
+#pragma unroll
+        for (int j = 0; j < NW; ++j) {
+            const int n = n0 + wn + 16 * j + r;
+            if (n >= N) continue;
+            const float bv = (bias && gridDim.z == 1) ? bias[n] : 0.f;
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                const int m = m0 + wm + 16 * i + 4 * g + v;
+                if (m >= M) continue;
+                float* o = dst + (size_t)m * N + n;
+                *o = (gridDim.z == 1 && accumulate ? *o : 0.f) + acc[i][j][v] + bv;
+            }
+        }
+}
+// out (+)= sum over the k chunks' partial tiles, chunk 0 first (+ bias per column)
+__global__ __launch_bounds__(256) void k_gemm_any_sum(const float* __restrict__ part, int chunks, size_t mn, int N, const float* __restrict__ bias, int accumulate, float* __restrict__ out) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < mn; i += (size_t)gridDim.x * 256) {
+        float s = part[i];
+        for (int c = 1; c < chunks; ++c) s += part[(size_t)c * mn + i];
+        out[i] = (accumulate ? out[i] : 0.f) + s + (bias ? bias[i % N] : 0.f);
+    }
+}
+float* g_any_ws[64] = {};
+constexpr size_t kAnyWsFloats = (size_t)4 << 20;   // 16 MB of partial tiles per device
+
 }  // namespace
 
 // Which of the step's projections run here: every tall one the tiling covers.  Back to back on hot operands rocBLAS is 20-25 % faster on the un-biased forward
@@ -205,6 +313,54 @@ hipError_t launch_train_gemm_tall(const float* a, const float* b, const float* b
     else if (mt3) go(k_train_gemm_tall<3, false, 3>);
     else if (tb) go(k_train_gemm_tall<2, true, 3>);
     else go(k_train_gemm_tall<2, false, 3>);
+    return hipGetLastError();
+}
+
+// out[M][N] (+)= op(a) . op(b) (+ bias[N]) for ANY shape (see above).  Workspace of partial tiles: allocated on the device's first long-reduction call.
+hipError_t launch_train_gemm_any(const float* a, const float* b, const float* bias, float* out, long M, long N, long K, bool ta, bool tb, bool accumulate, hipStream_t stream) {
+    // 32 x 32 tiles where 64 x 64 ones could not fill the chip (the 32- and 160-row GEMMs)
+    const bool small = ((M + 63) / 64) * ((N + 63) / 64) < 128;
+    const int T = small ? 32 : 64, KS = 1024 / T;
+    const unsigned gx = (unsigned)((M + T - 1) / T), gy = (unsigned)((N + T - 1) / T);
+    // cut the reduction when the output tiles alone cannot fill the chip: chunks of >= 256 k's (multiples of the k step), at most 64, bounded by the workspace
+    int chunks = 1;
+    if ((long)gx * gy < 128 && K >= 1024) {
+        chunks = (int)std::min<long>({64L, K / 256, (long)(512 / ((long)gx * gy)), (long)(kAnyWsFloats / (size_t)(M * N))});
+        if (chunks < 1) chunks = 1;
+    }
+    int kchunk = (int)((K + chunks - 1) / chunks);
+    kchunk = (kchunk + KS - 1) / KS * KS;
+    chunks = (int)((K + kchunk - 1) / kchunk);
+    float* part = nullptr;
+    if (chunks > 1) {
+        int dev = 0;
+        hipError_t e = hipGetDevice(&dev);
+        if (e != hipSuccess) return e;
+        dev &= 63;
+        if (!g_any_ws[dev]) {
+            e = hipMalloc((void**)&g_any_ws[dev], kAnyWsFloats * sizeof(float));
+            if (e != hipSuccess) return e;
+        }
+        part = g_any_ws[dev];
+    }
+    const dim3 grid(gx, gy, (unsigned)chunks), block(256);
+    const int acc = accumulate ? 1 : 0;
+    auto go = [&](auto kernel) { hipLaunchKernelGGL(kernel, grid, block, 0, stream, a, b, bias, out, (int)M, (int)N, (int)K, kchunk, acc, part); };
+    if (small) {
+        if (ta && tb) go(k_train_gemm_any<true, true, 32>);
+        else if (ta) go(k_train_gemm_any<true, false, 32>);
+        else if (tb) go(k_train_gemm_any<false, true, 32>);
+        else go(k_train_gemm_any<false, false, 32>);
+    } else {
+        if (ta && tb) go(k_train_gemm_any<true, true, 64>);
+        else if (ta) go(k_train_gemm_any<true, false, 64>);
+        else if (tb) go(k_train_gemm_any<false, true, 64>);
+        else go(k_train_gemm_any<false, false, 64>);
+    }
+    if (chunks > 1) {
+        const size_t mn = (size_t)M * N;
+        hipLaunchKernelGGL(k_gemm_any_sum, dim3((unsigned)std::min<size_t>((mn + 255) / 256, 2048)), block, 0, stream, part, chunks, mn, (int)N, bias, acc, out);
+    }
     return hipGetLastError();
 }
 

@@ -151,7 +151,7 @@ class TimestepEmbedding(nn.Module):
         self.linear_2 = nn.Linear(time_embed_dim, time_embed_dim)
 
     def forward(self, sample):
-        return self.linear_2(F.silu(self.linear_1(sample)))
+        return train_ops.linear(self.linear_2, F.silu(train_ops.linear(self.linear_1, sample)))
 
 
 def timestep_sinusoid(timesteps: torch.Tensor, dim=COND) -> torch.Tensor:
@@ -179,11 +179,12 @@ class Denoiser(nn.Module):
         bsz = sample.shape[0]
         timesteps = torch.as_tensor(timestep, device=sample.device).expand(bsz)
         time_emb = self.time_embedding(timestep_sinusoid(timesteps).to(sample.dtype)).unsqueeze(1)
-        toks = [time_emb, self.emb_proj_con(con_hidden).unsqueeze(1)]
+        proj = lambda seq, z: train_ops.linear(seq[1], F.relu(z))           # nn.Sequential(ReLU, Linear) (denoiser.py:85-90): the Linear on the library's GEMM
+        toks = [time_emb, proj(self.emb_proj_con, con_hidden).unsqueeze(1)]
         if emo_hidden is not None:
-            toks.append(self.emb_proj_emo(emo_hidden).unsqueeze(1))
+            toks.append(proj(self.emb_proj_emo, emo_hidden).unsqueeze(1))
         if sty_hidden is not None:
-            toks.append(self.emb_proj_sty(sty_hidden).unsqueeze(1))
+            toks.append(proj(self.emb_proj_sty, sty_hidden).unsqueeze(1))
         xseq = self.query_pos(torch.cat([sample] + toks, dim=1))          # (B, S, 128), latent token first
         tokens = self.encoder(xseq)
         return (tokens[:, : sample.shape[1]],)
@@ -251,7 +252,7 @@ class MotionPrior(nn.Module):
         full = _all_valid(lengths, nframes)
         mask = None if full else lengths_to_mask(lengths, z.device)
         out = self.decoder(queries, z.transpose(0, 1), tgt_key_padding_mask=None if full else ~mask)
-        out = self.final_layer(out)
+        out = train_ops.linear(self.final_layer, out)
         return out if full else out.masked_fill(~mask[:, :, None], 0.0)
 
 

@@ -254,7 +254,7 @@ class GestureTrainer:
         # bucket with the same bits (tests/test_gpu_train_ops.py); on the boxes measured the step is device-bound either way (profiles/r04_train_grad_sink_ab.txt)
         self.grads_mode = os.environ.get("AMUSE_TRAIN_GRADS", "steal")
         self.steal = self.grads_mode == "steal"
-        # the step's ~500 fp32 GEMMs are small (9,664 x 128..512 rows, weight gradients with a 9,664-long reduction): rocBLAS's
+        # (eager fallback layers only - AMUSE_TRAIN_FUSED=0 / CPU: the library's own GEMMs need no BLAS)  the step's ~500 fp32 GEMMs are small: rocBLAS's
         # choices run them in 9 ms of device time per iteration where hipBLASLt's heuristics take 12.5, at a third of the host
         # time per call (a process-wide torch setting; AMUSE_TRAIN_BLAS=default leaves it alone)
         if self.device.type == "cuda" and os.environ.get("AMUSE_TRAIN_BLAS", "rocblas") == "rocblas":
@@ -622,12 +622,15 @@ def bench_main(args):
             "ms_per_step": round(elapsed / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"train_gesture (configs/diff_latent_v2.json): prior encode/decode + epsilon loss under autograd "
-                                   f"(fp32; transformer layers = one autograd.Function each on the library's layer entry points: HIP glue + fp32 attention kernels, rocBLAS GEMMs{'' if __import__('amuse_amd.train_ops', fromlist=['x']).enabled() else ' - SWITCHED OFF: eager torch'}), in-loop DDIM-50 sampler + decode on the HIP kernels (bf16), AdamW(1e-4), one flat "
+                                   f"(fp32; transformer layers = one autograd.Function each on the library's layer entry points: HIP glue, fp32 attention and fp32-MFMA GEMM kernels - no vendor BLAS{'' if __import__('amuse_amd.train_ops', fromlist=['x']).enabled() else ' - SWITCHED OFF: eager torch'}), in-loop DDIM-50 sampler + decode on the HIP kernels (bf16), AdamW(1e-4), one flat "
                                    f"all-reduce of {tr.n_grad_elements():,} fp32 gradients; batch {bsz} per GPU, {bsz * world} global; "
                                    f"vertex-displacement loss off (needs SMPL-X assets)",
                        "batch_per_gpu": bsz, "grad_elements": tr.n_grad_elements(),
-                       "gemm": "hand-written HIP (fp32 MFMA) for the tall projections and input gradients (k_train_gemm), the weight-gradient reductions, attention, LayerNorm / "
-                               "dropout / GELU / bias gradients, AdamW; rocBLAS (rocblas_sgemm from C++) for the 333-wide embedding / output layers and the 32-row memory-token projections",
+                       "gemm": "own",
+                       "gemm_detail": "hand-written HIP (fp32 MFMA) for every GEMM of the networks: the tall projections and input gradients (k_train_gemm_tall), the chunked "
+                                      "weight-gradient reductions (k_train_wgrad), and the generic kernel (k_train_gemm_any) for the 333-wide embedding / output layers, the 32-row "
+                                      "condition / memory projections and the Denoiser's 160-row layers; attention, LayerNorm / dropout / GELU / bias gradients, AdamW hand-written too; "
+                                      "the library links and loads no vendor BLAS (torch's own ops remain only in the loss arithmetic)",
                        "inner_sampler": ("train: the reference's train-mode loop, dropout live (TrainModeInnerSampler)" if getattr(tr.inner_sampler, "serial", False)
                                          else "eval: the persistent HIP sampler kernel (dropout off - the reference's loop runs in train mode; opt in with AMUSE_TRAIN_INNER=train)")},
             "samples_per_s": round(its * bsz * world, 1),

@@ -3,7 +3,7 @@ utils/cross_attention.py:259-272 (TransformerEncoderLayer.forward_post) and :323
 autograd): per direction ONE call into the library (csrc/k_train.hip: amuse_train_layer_fwd / amuse_train_layer_bwd - the packed in-projection, the
 self-attention core on the library's fp32 MFMA kernels (csrc/k_train_attn.hip), and the rest of the layer; with AMUSE_TRAIN_ATTN=vendor aten's
 efficient-attention forward / backward ops sit between amuse_train_linear_* and amuse_train_layer_* calls instead).  Inside
-the calls the plain GEMMs go to rocBLAS straight from C++ and everything between them - biases, the three dropouts, residual adds, LayerNorms, GELU,
+the calls the plain GEMMs run on the library's own fp32-MFMA kernels (csrc/k_train_gemm.hip; no vendor BLAS) and everything between them - biases, the three dropouts, residual adds, LayerNorms, GELU,
 the decoder's one-key cross-attention and every bias / LayerNorm gradient reduction - runs in the hand-written HIP kernels, forward and backward.
 
 Why a Function per layer and not per op: the eager step was host-bound AND device-bound at once (~1,950 launches, ~27 ms of host
@@ -124,60 +124,6 @@ def _sink_ptr(t: torch.Tensor) -> int:
 def _c(t: torch.Tensor) -> torch.Tensor:
     assert t.dtype == torch.float32
     return t if t.is_contiguous() else t.contiguous()
-
-
-# ---------------------------------------------------------------------------------------------------- GEMMs
-# The layer's plain GEMMs go to rocBLAS directly (rocblas_sgemm through ctypes, on the copy of librocblas this process has already loaded for
-# torch): enqueueing one costs ~6 us of host time against ~19 for torch.mm / addmm on the same library (tools/probes/train_host/), and the
-# step is host-bound.  AMUSE_TRAIN_GEMM=torch keeps torch.mm (A/B).  Row-major throughout: gemm(a, b, ta, tb) = op(a) . op(b).
-_BLAS = {}
-_OP_N, _OP_T = 111, 112          # rocblas_operation_none / _transpose
-
-
-def _blas(device):
-    b = _BLAS.get(device)
-    if b is None:
-        lib = C.CDLL("librocblas.so")
-        lib.rocblas_create_handle.argtypes = [C.POINTER(C.c_void_p)]
-        lib.rocblas_set_stream.argtypes = [C.c_void_p, C.c_void_p]
-        lib.rocblas_sgemm.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int,
-                                      C.c_void_p, C.c_void_p, C.c_int]
-        h = C.c_void_p()
-        with torch.cuda.device(device):
-            if lib.rocblas_create_handle(C.byref(h)) != 0:
-                raise RuntimeError("rocblas_create_handle failed")
-        b = {"lib": lib, "h": h, "stream": None, "one": C.c_float(1.0), "zero": C.c_float(0.0)}
-        _BLAS[device] = b
-    st = _stream(device)
-    if b["stream"] != st:
-        if b["lib"].rocblas_set_stream(b["h"], st) != 0:
-            raise RuntimeError("rocblas_set_stream failed")
-        b["stream"] = st
-    return b
-
-
-def _direct_gemm() -> bool:
-    return os.environ.get("AMUSE_TRAIN_GEMM", "rocblas") != "torch"
-
-
-def gemm(a: torch.Tensor, b: torch.Tensor, ta: bool = False, tb: bool = False, out: Optional[torch.Tensor] = None, accumulate: bool = False) -> torch.Tensor:
-    """op(a) . op(b) for contiguous fp32 matrices (row-major), into `out` (+= with accumulate)."""
-    M, K = (a.shape[1], a.shape[0]) if ta else (a.shape[0], a.shape[1])
-    N = b.shape[0] if tb else b.shape[1]
-    assert (b.shape[1] if tb else b.shape[0]) == K and a.is_contiguous() and b.is_contiguous()
-    if out is None:
-        assert not accumulate
-        out = torch.empty(M, N, device=a.device, dtype=torch.float32)
-    if not _direct_gemm():
-        aa, bb = (a.t() if ta else a), (b.t() if tb else b)
-        return torch.addmm(out, aa, bb, out=out) if accumulate else torch.mm(aa, bb, out=out)
-    with _on(a.device):
-        bl = _blas(a.device)
-        rc = bl["lib"].rocblas_sgemm(bl["h"], _OP_T if tb else _OP_N, _OP_T if ta else _OP_N, N, M, K, C.byref(bl["one"]), b.data_ptr(), b.shape[1],
-                                     a.data_ptr(), a.shape[1], C.byref(bl["one"] if accumulate else bl["zero"]), out.data_ptr(), N)
-    if rc != 0:
-        raise RuntimeError(f"rocblas_sgemm failed with status {rc}")
-    return out
 
 
 # ---------------------------------------------------------------------------------------------------- raw kernels
@@ -414,8 +360,8 @@ class DecoderLayerFn(torch.autograd.Function):
 
 
 class LinearFn(torch.autograd.Function):
-    """nn.Linear on the library's two entry points (amuse_train_linear_fwd / _bwd: rocBLAS from C++, the bias as the GEMM's C operand, the bias gradient
-    by the deterministic column sum) - the skip linears, embeddings and output layer around the transformer layers."""
+    """nn.Linear on the library's two entry points (amuse_train_linear_fwd / _bwd: the library's own fp32-MFMA GEMMs, the bias in the GEMM's epilogue, the bias
+    gradient by the deterministic column sum) - the skip linears, embeddings, condition projections and output layer around the transformer layers."""
 
     @staticmethod
     def forward(ctx, x, W, b):
@@ -450,9 +396,10 @@ class LinearFn(torch.autograd.Function):
 
 
 def linear(m, x: torch.Tensor) -> torch.Tensor:
-    """nn.Linear `m` on x: the library path for CUDA fp32 inputs whose widths it takes (N a multiple of 4 up to 1024), else F.linear."""
+    """nn.Linear `m` on x: the library path for CUDA fp32 inputs (any width up to 1024 outputs: the tall projections on k_train_gemm_tall, every other shape -
+    the 333-wide embedding / output layers, the Denoiser's 32-row condition projections - on the generic fp32-MFMA kernel), else F.linear."""
     N = m.weight.shape[0]
-    if enabled() and x.is_cuda and x.dtype == torch.float32 and N % 4 == 0 and N <= 1024 and m.weight.is_contiguous():
+    if enabled() and x.is_cuda and x.dtype == torch.float32 and N <= 1024 and m.weight.is_contiguous():
         return LinearFn.apply(x, m.weight, m.bias)
     return torch.nn.functional.linear(x, m.weight, m.bias)
 

@@ -15,7 +15,7 @@ timeout 300 python tools/gpu_train_profile.py 32 $O/train_profile.txt > /dev/nul
 AMUSE_TRAIN_ATTN=vendor timeout 300 python bench.py --config train --steps 60 --warmup 15 > $O/train_bench_vendor_attn.json 2> /dev/null
 timeout 200 python tools/gpu_train_attn_perf.py > $O/train_attn_perf.txt 2>&1
 timeout 300 python tools/probes/train_host/gemm_time.py > $O/train_gemm_time.txt 2>&1          # own tall GEMM against rocBLAS, per call
-AMUSE_TRAIN_GEMM=vendor timeout 300 python tools/gpu_train_profile.py 32 $O/train_profile_vendor_gemm.txt > /dev/null 2>&1
+
 [ -x tools/probes/mfma_f32_rate_probe ] && timeout 60 ./tools/probes/mfma_f32_rate_probe > $O/mfma_f32_rate_probe.txt 2>&1
 timeout 200 python tools/gpu_encode_fp32x_ab.py > $O/encode_fp32x_ab.txt 2>&1
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python3 bench.py --steps 3 --warmup 1 --no-extras > $O/stats.log 2>&1
