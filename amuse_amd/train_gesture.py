@@ -189,7 +189,8 @@ class GestureTrainer:
     both parameter lists (trainer.py:176-182), the iteration of :335-466 and the checkpoint writer of :468-496."""
 
     def __init__(self, prior: MotionPrior, ldm: LatentDiffusionTrainModule, device, lr: float = 1e-4, loss_cfg: Optional[dict] = None,
-                 inner_sampler: Optional[Callable] = None, process_group=None, world: int = 1, kind: Optional[str] = None):
+                 inner_sampler: Optional[Callable] = None, process_group=None, world: int = 1, kind: Optional[str] = None,
+                 grads_mode: str = "steal", sampler_stream: bool = True, optimizer: str = "flat"):
         self.model = {"prior": prior.to(device), "ldm": ldm.to(device)}
         # torch.distributions.Normal validates its arguments with blocking device -> host reads (6 per iteration: the host then waits for the previous
         # iteration's backward + optimizer step before it dispatches anything of the next, tools/probes/train_host/sync_points.py).  Off on the GPU
@@ -236,8 +237,8 @@ class GestureTrainer:
         # the multi-tensor ("fused") AdamW of torch on the GPU: the same update in a handful of launches instead of ~10 per
         # parameter group of the default foreach path (2.7 ms of device time and 4.8 ms of host time per iteration, section 4.6)
         # ... and on the GPU that update is ONE launch per contiguous run of optimizer parameters in the flat buffers (train_ops.FlatAdamW, csrc/k_train.hip);
-        # AMUSE_TRAIN_OPT=fused / foreach select torch's own implementations (A/B)
-        opt_kind = os.environ.get("AMUSE_TRAIN_OPT", "flat") if self.device.type == "cuda" else "foreach"
+        # optimizer = "fused" / "foreach" select torch's own implementations (A/B: tools/gpu_train_variants.py)
+        opt_kind = optimizer if self.device.type == "cuda" else "foreach"
         opt_params = [p for p in self.params if id(p) not in unused]
         if opt_kind == "flat":
             from .train_ops import FlatAdamW
@@ -248,16 +249,18 @@ class GestureTrainer:
             self.lpdm_opt = FlatAdamW(opt_params, self.flat_param, self.flat_grad, layout, lr=lr)
         else:
             self.lpdm_opt = torch.optim.AdamW(lr=lr, params=opt_params, **({"fused": True} if opt_kind == "fused" else {}))
-        # how gradients reach the bucket (AMUSE_TRAIN_GRADS): "steal" (default) - autograd hands every parameter a fresh gradient, one multi-tensor copy packs
+        # how gradients reach the bucket (grads_mode): "steal" (default) - autograd hands every parameter a fresh gradient, one multi-tensor copy packs
         # them; "sink" - the library's layer calls write their parameter gradients straight into the bucket (train_ops.sink_begin: no AccumulateGrad work, no
         # copy), the few eager parameters accumulate into its zeroed views; "views" - every gradient accumulates into the zeroed views.  All three fill the
         # bucket with the same bits (tests/test_gpu_train_ops.py); on the boxes measured the step is device-bound either way (profiles/r04_train_grad_sink_ab.txt)
-        self.grads_mode = os.environ.get("AMUSE_TRAIN_GRADS", "steal")
+        assert grads_mode in ("steal", "sink", "views"), grads_mode
+        self.grads_mode = grads_mode
+        self.sampler_stream = sampler_stream       # the no-gradient half on a stream of its own beside the forward pass (False: in line; tests)
         self.steal = self.grads_mode == "steal"
         # (eager fallback layers only - AMUSE_TRAIN_FUSED=0 / CPU: the library's own GEMMs need no BLAS)  the step's ~500 fp32 GEMMs are small: rocBLAS's
         # choices run them in 9 ms of device time per iteration where hipBLASLt's heuristics take 12.5, at a third of the host
-        # time per call (a process-wide torch setting; AMUSE_TRAIN_BLAS=default leaves it alone)
-        if self.device.type == "cuda" and os.environ.get("AMUSE_TRAIN_BLAS", "rocblas") == "rocblas":
+        # time per call (a process-wide torch setting)
+        if self.device.type == "cuda":
             torch.backends.cuda.preferred_blas_library("cublas")
         self._ar_events: list = []
         self._side_stream = None
@@ -282,7 +285,7 @@ class GestureTrainer:
         # conditions only: on the GPU it runs on a stream of its own beside the networks' forward pass and is joined in front of the losses.
         gen, side = None, None
         if self.inner_sampler is not None:
-            if self.device.type == "cuda" and os.environ.get("AMUSE_TRAIN_SAMPLER_STREAM", "1") != "0" and not getattr(self.inner_sampler, "serial", False):
+            if self.device.type == "cuda" and self.sampler_stream and not getattr(self.inner_sampler, "serial", False):
                 if self._side_stream is None:
                     self._side_stream = torch.cuda.Stream(self.device)
                 side = self._side_stream
@@ -431,7 +434,7 @@ class HipInnerSampler:
         self.calls, self.clip_counter, self.sync_ms = 0, 0, []
         self.rank, self.world = rank, world
         self.what = {"bf16": 2, "fp32x": 8, "fp16": 16}.get(precision, 1)   # AMUSE_UPD_* mask of the streams this sampler runs
-        self.on_device = os.environ.get("AMUSE_TRAIN_REPACK", "device") != "host"   # A/B switch: the host path of amuse_update_weights
+        self.on_device = True      # re-pack on the GPU straight from the trainer's flat parameter buffer (False: the host path of amuse_update_weights; tests)
 
     def _den_state(self):
         return {k: v.detach().cpu().numpy() for k, v in self.models["ldm"].denoiser.state_dict().items()}
@@ -537,7 +540,8 @@ def ablation_kind(lmdb_id: Optional[str]) -> Optional[str]:
 
 def build_trainer(device, rank: int = 0, world: int = 1, process_group=None, seed: int = 0, use_hip_sampler: bool = True,
                   dropout: float = 0.1, sampler_refresh: int = 1, ldm_cfg: Optional[dict] = None, lr: float = 1e-4,
-                  kind: Optional[str] = None, inner: Optional[str] = None) -> GestureTrainer:
+                  kind: Optional[str] = None, inner: Optional[str] = None, grads_mode: str = "steal", sampler_stream: bool = True,
+                  optimizer: str = "flat") -> GestureTrainer:
     """Random-init prior + ldm (the deterministic weights of amuse_amd/weights.py, identical on every rank - what DDP's
     initial broadcast gives the reference's DataParallel-less single-GPU run) and the trainer around them.
     lr = TRAIN_PARAM.latent_diffusion.lr_base (trainer.py:181-184); ldm_cfg = configs/<arch>.json merged with diff_o.yaml (its
@@ -552,7 +556,7 @@ def build_trainer(device, rank: int = 0, world: int = 1, process_group=None, see
     if (ldm_cfg or {}).get("losses") is not None:   # trainer.py:175-177: SMPL-X data switches the joints terms off; the vertex terms are not built
         loss_cfg = dict(ldm_cfg["losses"], use_recons_joints=False, vtex_displacement=False)
     tr = GestureTrainer(prior, ldm, device, lr=lr, loss_cfg=loss_cfg, inner_sampler=None, process_group=process_group,
-                        world=world, kind=None if kind == "full" else kind)
+                        world=world, kind=None if kind == "full" else kind, grads_mode=grads_mode, sampler_stream=sampler_stream, optimizer=optimizer)
     inner = inner or os.environ.get("AMUSE_TRAIN_INNER", "eval")
     if inner not in ("eval", "train"):
         raise ValueError(f"inner sampler {inner!r}: 'eval' (the persistent HIP sampler kernel, default) or 'train' (the reference's train-mode semantics, dropout live)")

@@ -1,7 +1,7 @@
 """A transformer layer of the train_gesture step as ONE autograd.Function (BASELINE config 4; reference scripts/trainer.py:335-498 runs
 utils/cross_attention.py:259-272 (TransformerEncoderLayer.forward_post) and :323-345 (TransformerDecoderLayer.forward_post) op by op under
 autograd): per direction ONE call into the library (csrc/k_train.hip: amuse_train_layer_fwd / amuse_train_layer_bwd - the packed in-projection, the
-self-attention core on the library's fp32 MFMA kernels (csrc/k_train_attn.hip), and the rest of the layer; with AMUSE_TRAIN_ATTN=vendor aten's
+self-attention core on the library's fp32 MFMA kernels (csrc/k_train_attn.hip), and the rest of the layer; for attention shapes the library's kernels do not take, aten's
 efficient-attention forward / backward ops sit between amuse_train_linear_* and amuse_train_layer_* calls instead).  Inside
 the calls the plain GEMMs run on the library's own fp32-MFMA kernels (csrc/k_train_gemm.hip; no vendor BLAS) and everything between them - biases, the three dropouts, residual adds, LayerNorms, GELU,
 the decoder's one-key cross-attention and every bias / LayerNorm gradient reduction - runs in the hand-written HIP kernels, forward and backward.
@@ -210,8 +210,8 @@ _sdpa_bwd = torch.ops.aten._scaled_dot_product_efficient_attention_backward
 
 
 def own_attention(S: int, H: int, D: int) -> bool:
-    """The library's attention kernels take 4 heads of 32 and up to 304 tokens (every attention of the training step); AMUSE_TRAIN_ATTN=vendor = aten's op (A/B)."""
-    return os.environ.get("AMUSE_TRAIN_ATTN", "hip") != "vendor" and H == 4 and D == 128 and 1 <= S <= 304
+    """The library's attention kernels take 4 heads of 32 and up to 304 tokens (every attention of the training step); other shapes fall back to aten's op."""
+    return H == 4 and D == 128 and 1 <= S <= 304
 
 
 _ENC_PARAMS = ("Wo", "bo", "g1", "be1", "W1", "b1", "W2", "b2", "g3", "be3")
@@ -243,7 +243,7 @@ def _layer_forward_on(ctx, x, mem, Win, bin_, prm: dict, H: int, p: float, p_att
         o2 = torch.empty(rows, D, device=dev, dtype=torch.float32)
         lse = torch.empty(B, H, S, device=dev, dtype=torch.float32)
         ao, ps, po = o2, o2, o2          # (placeholders in the saved list)
-    else:     # the vendor's fused kernel (AMUSE_TRAIN_ATTN=vendor, or shapes the library's kernels do not take)
+    else:     # the vendor's fused kernel (shapes the library's kernels do not take)
         _lib.check(lib.amuse_train_linear_fwd(x2.data_ptr(), Win.data_ptr(), bin_.data_ptr(), rows, D, 3 * D, qkv.data_ptr(), stream))
         q, k, v = (t.transpose(1, 2) for t in qkv.view(B, S, 3, H, D // H).unbind(2))   # (B, H, S, d) views
         ao, lse, ps, po = _sdpa(q, k, v, None, True, p_attn, False)

@@ -155,10 +155,9 @@ def test_inner_sampler_on_its_own_stream_changes_nothing(monkeypatch):
     from amuse_amd.train_gesture import build_trainer, synthetic_batch
     res = {}
     for side in ("1", "0"):
-        monkeypatch.setenv("AMUSE_TRAIN_SAMPLER_STREAM", side)
         torch.manual_seed(3)
         train_ops._OFFSET[0] = 0
-        tr = build_trainer("cuda:0", seed=1)
+        tr = build_trainer("cuda:0", seed=1, sampler_stream=side == "1")
         terms = []
         for i in range(3):
             tr.train_step(synthetic_batch(8, 10 + i, "cuda:0"))

@@ -177,16 +177,15 @@ def test_trainer_step_on_fused_layers_matches_the_eager_step_without_dropout(eag
 
 
 def test_gradient_sink_fills_the_bucket_like_autograd_does(monkeypatch):
-    """AMUSE_TRAIN_GRADS=sink (the GPU default: the layer calls write their parameter gradients straight into the trainer's bucket, train_ops.sink_begin) against
+    """grads_mode "sink" (the layer calls write their parameter gradients straight into the trainer's bucket, train_ops.sink_begin) against
     "steal" (autograd hands out fresh gradients, one copy packs them) and "views": the same kernels compute the same numbers, so the bucket is BITWISE the
     same - dropout live, the same seeds - and the parameters after two optimizer steps are too."""
     from amuse_amd import train_gesture as tg, train_ops
     res = {}
     for mode in ("sink", "steal", "views"):
-        monkeypatch.setenv("AMUSE_TRAIN_GRADS", mode)
         torch.manual_seed(9)
         train_ops._OFFSET[0] = 0
-        tr = tg.build_trainer(DEV, seed=2, use_hip_sampler=False)
+        tr = tg.build_trainer(DEV, seed=2, use_hip_sampler=False, grads_mode=mode)
         assert tr.grads_mode == mode
         buckets = []
         for i in range(2):

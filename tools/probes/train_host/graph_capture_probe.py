@@ -11,13 +11,12 @@ import torch
 
 sys.path.insert(0, str(Path(__file__).resolve().parents[3]))
 mode = sys.argv[1] if len(sys.argv) > 1 else "sink"
-os.environ["AMUSE_TRAIN_GRADS"] = mode
 from amuse_amd import train_gesture as tg  # noqa: E402
 
 dev = torch.device("cuda:0")
 torch.manual_seed(1)
 for with_sampler in (False, True):
-    tr = tg.build_trainer(dev, 0, 1, use_hip_sampler=with_sampler)
+    tr = tg.build_trainer(dev, 0, 1, use_hip_sampler=with_sampler, grads_mode=mode)
     for m in tr.model.values():
         m.eval()                                   # dropout off: the bucket of a replay must equal the eager one
     batch = tg.synthetic_batch(32, 0, dev)

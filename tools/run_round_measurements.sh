@@ -12,7 +12,6 @@ timeout 600 python bench.py > $O/bench.json 2> $O/bench.err; tail -2 $O/bench.er
 timeout 300 python bench.py --config train --steps 60 --warmup 15 > $O/train_bench.json 2> $O/train_bench.err
 AMUSE_TRAIN_FUSED=0 timeout 300 python bench.py --config train --steps 60 --warmup 15 > $O/train_bench_eager.json 2> $O/train_bench_eager.err
 timeout 300 python tools/gpu_train_profile.py 32 $O/train_profile.txt > /dev/null 2>&1
-AMUSE_TRAIN_ATTN=vendor timeout 300 python bench.py --config train --steps 60 --warmup 15 > $O/train_bench_vendor_attn.json 2> /dev/null
 timeout 200 python tools/gpu_train_attn_perf.py > $O/train_attn_perf.txt 2>&1
 timeout 300 python tools/probes/train_host/gemm_time.py > $O/train_gemm_time.txt 2>&1          # own tall GEMM against rocBLAS, per call
 
