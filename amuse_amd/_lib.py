@@ -29,7 +29,7 @@ EXPORTS = [
     "amuse_create_arch", "amuse_denoiser_param_count", "amuse_arch", "amuse_state_dim", "amuse_denoise_step_pose", "amuse_feats_to_smplx",
     "amuse_debug_set_ablation",
     "amuse_train_ws_floats", "amuse_train_ln_fwd", "amuse_train_ln_bwd", "amuse_train_bias_gelu_drop_fwd", "amuse_train_bias_gelu_drop_bwd", "amuse_train_colsum",
-    "amuse_train_layer_fwd", "amuse_train_layer_bwd", "amuse_train_linear_fwd", "amuse_train_linear_bwd", "amuse_train_adamw", "amuse_train_attn_fwd", "amuse_train_attn_bwd",
+    "amuse_train_layer_fwd", "amuse_train_layer_bwd", "amuse_train_linear_fwd", "amuse_train_linear_bwd", "amuse_train_adamw", "amuse_train_adamw_dev", "amuse_train_epoch_advance", "amuse_train_epoch_set", "amuse_train_attn_fwd", "amuse_train_attn_bwd",
 ]
 
 
@@ -148,6 +148,10 @@ def load() -> C.CDLL:
     lib.amuse_train_attn_fwd.restype = lib.amuse_train_attn_bwd.restype = C.c_int
     lib.amuse_train_adamw.argtypes = [vp, vp, vp, vp, C.c_size_t, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, C.c_long, vp]
     lib.amuse_train_adamw.restype = C.c_int
+    lib.amuse_train_adamw_dev.argtypes = [vp, vp, vp, vp, C.c_size_t, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, vp, vp, C.c_int, vp]
+    lib.amuse_train_epoch_advance.argtypes = [C.c_uint, vp]
+    lib.amuse_train_epoch_set.argtypes = [C.c_uint, vp]
+    lib.amuse_train_adamw_dev.restype = lib.amuse_train_epoch_advance.restype = lib.amuse_train_epoch_set.restype = C.c_int
     lib.amuse_train_layer_fwd.argtypes = [C.POINTER(TrainLayer), vp]
     lib.amuse_train_layer_bwd.argtypes = [C.POINTER(TrainLayer), vp]
     lib.amuse_train_linear_fwd.argtypes = [vp, vp, vp, C.c_long, C.c_int, C.c_int, vp, vp]

@@ -280,6 +280,8 @@ struct DenFusedArgs {
 hipError_t launch_den_fused(const DenFusedArgs& a, hipStream_t stream);
 hipError_t launch_den_fusedh(const DenFusedArgs& a, hipStream_t stream);   // fp16 operands (k_den_fusedh.hip)
 // feats[row][0:330] = first two rows of R(axis-angle) per joint, feats[row][330:333] = trans   (infer_ldm.py:459-464)
+// training step (k_train.hip): the per-device dropout epoch word every mask-drawing kernel reads (0 unless a captured step advances it)
+uint32_t* train_epoch_ptr();
 // training step (k_train_gemm.hip): out[M][N] = (bias | accumulate: out) + a[M][K] . (tb ? b[N][K]^T : b[K][N]) for the tall fp32 projections it takes
 bool train_gemm_tall_takes(long M, long N, long K, bool tb, bool bias);
 // ... and for every other shape / transpose of the step (the 333-wide layers, 32- and 160-row projections, weight gradients): the same file's generic kernel

@@ -44,8 +44,9 @@ __device__ __forceinline__ float half_wave_sum(float v) {   // over the 32 lanes
 // ---- LayerNorm over C = 128: a half wave per row (lane & 31 = the row's 4-column group), 8 rows per workgroup and iteration
 __global__ __launch_bounds__(256) void k_train_ln_fwd(const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ bias,
                                                       const float* __restrict__ gamma, const float* __restrict__ beta, uint32_t thr, float scale,
-                                                      uint64_t seed, uint64_t offset, long rows, float* __restrict__ out, float* __restrict__ zhat,
+                                                      uint64_t seed, uint64_t offset, const uint32_t* __restrict__ epoch, long rows, float* __restrict__ out, float* __restrict__ zhat,
                                                       float* __restrict__ rstd_out) {
+    offset += (uint64_t)*epoch << 32;   // the device-side dropout epoch (train_epoch_ptr): fresh masks per replay of a captured step
     const int cg = threadIdx.x & 31, rl = threadIdx.x >> 5;
     const f32x4 bi = bias ? ld4(bias + 4 * cg) : splat4(0.f), ga = ld4(gamma + 4 * cg), be = ld4(beta + 4 * cg);
     for (long r = (long)blockIdx.x * 8 + rl; r < rows; r += (long)gridDim.x * 8) {
@@ -103,8 +104,9 @@ __device__ __forceinline__ void workgroup_partial(f32x4 acc, int nc4, int lanes,
 }
 
 __global__ __launch_bounds__(kTrainThreads) void k_train_ln_bwd(const float* dout, const float* dout2, const float* __restrict__ zhat, const float* __restrict__ rstd_in,
-                                                      const float* __restrict__ gamma, uint32_t thr, float scale, uint64_t seed, uint64_t offset, long rows,
-                                                      float* dx, float* dy, float* ws) {   // (dx may be dout, dy may be dout2: same thread, same elements)
+                                                      const float* __restrict__ gamma, uint32_t thr, float scale, uint64_t seed, uint64_t offset, const uint32_t* __restrict__ epoch, long rows,
+                                                      float* dx, float* dy, float* ws) {
+    offset += (uint64_t)*epoch << 32;   // the device-side dropout epoch (train_epoch_ptr): fresh masks per replay of a captured step   // (dx may be dout, dy may be dout2: same thread, same elements)
     __shared__ f32x4 red[kTrainThreads];
     const int cg = threadIdx.x & 31, rl = threadIdx.x >> 5;   // 32 row lanes
     const f32x4 ga = ld4(gamma + 4 * cg);
@@ -182,13 +184,34 @@ __global__ __launch_bounds__(256) void k_train_adamw(float* __restrict__ p, cons
     }
 }
 
+// The same update with the step count on the DEVICE (a training step captured as a HIP graph: the host's count is frozen at capture): k_train_adamw_scalars
+// advances *step and leaves {lr / (1 - b1^t), 1 / sqrt(1 - b2^t)} - computed in double like the host path - in scal[0..1]; the update kernel reads them.
+__global__ void k_train_adamw_scalars(long* step, double lr, double b1, double b2, float* scal) {
+    const long t = ++*step;
+    scal[0] = (float)(lr / (1.0 - pow(b1, (double)t)));
+    scal[1] = (float)(1.0 / sqrt(1.0 - pow(b2, (double)t)));
+}
+__global__ __launch_bounds__(256) void k_train_adamw_dev(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, size_t n,
+                                                         const float* __restrict__ scal, float decay, float omb1, float b2, float omb2, float eps) {
+    const float step_size = scal[0], rbc2 = scal[1];
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        const float gi = g[i];
+        const float mi = m[i] + (gi - m[i]) * omb1;
+        const float vi = b2 * v[i] + omb2 * gi * gi;
+        m[i] = mi;
+        v[i] = vi;
+        p[i] = p[i] * decay - step_size * (mi / (sqrtf(vi) * rbc2 + eps));
+    }
+}
+
 // ---- FFN activation: a = dropout(gelu(h + b)), exact erf (F.gelu's default)
 __device__ __forceinline__ float gelu_exact(float u) { return 0.5f * u * (1.0f + erff(u * 0.70710678118654752440f)); }
 __device__ __forceinline__ float gelu_grad(float u) {
     return 0.5f * (1.0f + erff(u * 0.70710678118654752440f)) + u * 0.39894228040143267794f * expf(-0.5f * u * u);
 }
 __global__ __launch_bounds__(256) void k_train_bgd_fwd(const float* __restrict__ h, const float* __restrict__ b, uint32_t thr, float scale, uint64_t seed,
-                                                       uint64_t offset, size_t n4, int F4, float* __restrict__ out) {
+                                                       uint64_t offset, const uint32_t* __restrict__ epoch, size_t n4, int F4, float* __restrict__ out) {
+    offset += (uint64_t)*epoch << 32;   // the device-side dropout epoch (train_epoch_ptr): fresh masks per replay of a captured step
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
         const f32x4 u = ld4(h + 4 * i) + ld4(b + 4 * (i % F4));
         const f32x4 g = f32x4{gelu_exact(u[0]), gelu_exact(u[1]), gelu_exact(u[2]), gelu_exact(u[3])};
@@ -197,7 +220,8 @@ __global__ __launch_bounds__(256) void k_train_bgd_fwd(const float* __restrict__
 }
 // column sums ride along: a thread owns one 4-column group (F4 <= 256 groups) for all its rows - 1,024 / F4 row lanes per workgroup
 __global__ __launch_bounds__(kTrainThreads) void k_train_bgd_bwd(const float* __restrict__ da, const float* __restrict__ h, const float* __restrict__ b, uint32_t thr,
-                                                       float scale, uint64_t seed, uint64_t offset, long rows, int F4, float* __restrict__ dh, float* ws) {
+                                                       float scale, uint64_t seed, uint64_t offset, const uint32_t* __restrict__ epoch, long rows, int F4, float* __restrict__ dh, float* ws) {
+    offset += (uint64_t)*epoch << 32;   // the device-side dropout epoch (train_epoch_ptr): fresh masks per replay of a captured step
     __shared__ f32x4 red[kTrainThreads];
     const int lanes = kTrainThreads / F4;
     const int cg = threadIdx.x % F4, rl = threadIdx.x / F4;
@@ -265,8 +289,9 @@ __device__ __forceinline__ float head_keep(uint64_t seed, uint64_t offset, size_
     const uint32_t d = (e & 3) == 0 ? b.x : (e & 3) == 1 ? b.y : (e & 3) == 2 ? b.z : b.w;
     return (d >> 8) >= thr ? scale : 0.f;
 }
-__global__ __launch_bounds__(256) void k_train_vk(const float* __restrict__ c, uint32_t thr, float scale, uint64_t seed, uint64_t offset, long rows, int S, int H,
+__global__ __launch_bounds__(256) void k_train_vk(const float* __restrict__ c, uint32_t thr, float scale, uint64_t seed, uint64_t offset, const uint32_t* __restrict__ epoch, long rows, int S, int H,
                                                   float* __restrict__ vk) {
+    offset += (uint64_t)*epoch << 32;   // the device-side dropout epoch (train_epoch_ptr): fresh masks per replay of a captured step
     const int dh4 = 128 / H / 4;   // float4 groups per head
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < (size_t)rows * 32; i += (size_t)gridDim.x * 256) {
         const size_t row = i >> 5;
@@ -275,8 +300,9 @@ __global__ __launch_bounds__(256) void k_train_vk(const float* __restrict__ c, u
     }
 }
 // dc[b][:] = sum_s dvk[b][s][:] . keep(b, s, head) / (1 - p): one workgroup per clip, 32 column groups x 8 row lanes
-__global__ __launch_bounds__(256) void k_train_dc(const float* __restrict__ dvk, uint32_t thr, float scale, uint64_t seed, uint64_t offset, int S, int H,
+__global__ __launch_bounds__(256) void k_train_dc(const float* __restrict__ dvk, uint32_t thr, float scale, uint64_t seed, uint64_t offset, const uint32_t* __restrict__ epoch, int S, int H,
                                                   float* __restrict__ dc) {
+    offset += (uint64_t)*epoch << 32;   // the device-side dropout epoch (train_epoch_ptr): fresh masks per replay of a captured step
     __shared__ f32x4 red[256];
     const int cg = threadIdx.x & 31, rl = threadIdx.x >> 5, dh4 = 128 / H / 4;
     const size_t row0 = (size_t)blockIdx.x * S;
@@ -297,6 +323,23 @@ int drop_args(float p, uint32_t* thr, float* scale) {
     *scale = 1.0f / (1.0f - p);
     return 0;
 }
+// ---- the dropout epoch: ONE device word per GPU that every mask-drawing kernel adds into the high half of its Philox counter's offset.  It stays 0 in eager
+// training (the host hands every call a fresh offset); a training step captured as a HIP graph replays with FROZEN host offsets, so the graph ends with
+// k_train_epoch_add and every replay draws fresh masks (amuse_train_epoch_advance; forward and backward of one step see the same value).
+uint32_t* g_train_epoch[64] = {};
+__global__ void k_train_epoch_set(uint32_t* e, uint32_t add, uint32_t set, int do_set) { *e = do_set ? set : *e + add; }
+}  // namespace
+uint32_t* train_epoch_ptr() {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+    dev &= 63;
+    if (!g_train_epoch[dev]) {
+        if (hipMalloc((void**)&g_train_epoch[dev], 256) != hipSuccess) return nullptr;
+        if (hipMemset(g_train_epoch[dev], 0, 256) != hipSuccess) return nullptr;
+    }
+    return g_train_epoch[dev];
+}
+namespace {
 int grid_for(long rows, int rows_per_wg) {
     const long g = (rows + rows_per_wg - 1) / rows_per_wg;
     return (int)(g < 1 ? 1 : g > kTrainWgs ? kTrainWgs : g);
@@ -448,14 +491,14 @@ int rm_gemm(void* h, bool ta, bool tb, long M, long N, long K, const float* a, c
 int ln_fwd_launch(const float* x, const float* y, const float* bias, const float* gamma, const float* beta, uint32_t thr, float scale, uint64_t seed, uint64_t off,
                   long rows, float* out, float* zhat, float* rstd, hipStream_t st) {
     const long g = (rows + 7) / 8;
-    hipLaunchKernelGGL(k_train_ln_fwd, dim3((unsigned)(g > 4096 ? 4096 : g)), dim3(256), 0, st, x, y, bias, gamma, beta, thr, scale, seed, off, rows, out, zhat, rstd);
+    hipLaunchKernelGGL(k_train_ln_fwd, dim3((unsigned)(g > 4096 ? 4096 : g)), dim3(256), 0, st, x, y, bias, gamma, beta, thr, scale, seed, off, train_epoch_ptr(), rows, out, zhat, rstd);
     return 0;
 }
 // `job` given: the partial sums stay in `ws` (a region of their own) and the job is added up later by ONE k_train_finalize_jobs launch; else right away
 int ln_bwd_launch(const float* dout, const float* dout2, const float* zhat, const float* rstd, const float* gamma, uint32_t thr, float scale, uint64_t seed, uint64_t off,
                   long rows, float* dx, float* dy, float* dgamma, float* dbeta, float* dbias, float* ws, hipStream_t st, FinJob* job = nullptr) {
     const int g = grid_for(rows, 64);
-    hipLaunchKernelGGL(k_train_ln_bwd, dim3(g), dim3(kTrainThreads), 0, st, dout, dout2, zhat, rstd, gamma, thr, scale, seed, off, rows, dx, dy, ws);
+    hipLaunchKernelGGL(k_train_ln_bwd, dim3(g), dim3(kTrainThreads), 0, st, dout, dout2, zhat, rstd, gamma, thr, scale, seed, off, train_epoch_ptr(), rows, dx, dy, ws);
     if (job) *job = FinJob{ws, {dgamma, dbeta, dbias}, g, 384, 128};
     else hipLaunchKernelGGL(k_train_finalize, dim3(1), dim3(kTrainThreads), 0, st, ws, g, dgamma, dbeta, dbias, 384, 128);
     return 0;
@@ -515,7 +558,7 @@ int amuse_train_ln_fwd(const float* x, const float* y, const float* bias, const 
     uint32_t thr; float scale;
     if (int e = drop_args(p, &thr, &scale)) return e;
     const long g = (rows + 7) / 8;
-    hipLaunchKernelGGL(k_train_ln_fwd, dim3((unsigned)(g > 4096 ? 4096 : g)), dim3(256), 0, (hipStream_t)stream, x, y, bias, gamma, beta, thr, scale, seed, offset, rows,
+    hipLaunchKernelGGL(k_train_ln_fwd, dim3((unsigned)(g > 4096 ? 4096 : g)), dim3(256), 0, (hipStream_t)stream, x, y, bias, gamma, beta, thr, scale, seed, offset, train_epoch_ptr(), rows,
                        out, zhat, rstd);
     HIP_TRY(hipGetLastError());
     return 0;
@@ -528,7 +571,7 @@ int amuse_train_ln_bwd(const float* dout, const float* dout2, const float* zhat,
     uint32_t thr; float scale;
     if (int e = drop_args(p, &thr, &scale)) return e;
     const int g = grid_for(rows, 64);
-    hipLaunchKernelGGL(k_train_ln_bwd, dim3(g), dim3(kTrainThreads), 0, (hipStream_t)stream, dout, dout2, zhat, rstd, gamma, thr, scale, seed, offset, rows, dx, dy, ws);
+    hipLaunchKernelGGL(k_train_ln_bwd, dim3(g), dim3(kTrainThreads), 0, (hipStream_t)stream, dout, dout2, zhat, rstd, gamma, thr, scale, seed, offset, train_epoch_ptr(), rows, dx, dy, ws);
     hipLaunchKernelGGL(k_train_finalize, dim3(1), dim3(kTrainThreads), 0, (hipStream_t)stream, ws, g, dgamma, dbeta, dbias, 384, 128);
     HIP_TRY(hipGetLastError());
     return 0;
@@ -541,7 +584,7 @@ int amuse_train_bias_gelu_drop_fwd(const float* h, const float* b, float p, uint
     if (int e = drop_args(p, &thr, &scale)) return e;
     const size_t n4 = (size_t)rows * (F / 4);
     const size_t g = (n4 + 255) / 256;
-    hipLaunchKernelGGL(k_train_bgd_fwd, dim3((unsigned)(g > 8192 ? 8192 : g)), dim3(256), 0, (hipStream_t)stream, h, b, thr, scale, seed, offset, n4, F / 4, out);
+    hipLaunchKernelGGL(k_train_bgd_fwd, dim3((unsigned)(g > 8192 ? 8192 : g)), dim3(256), 0, (hipStream_t)stream, h, b, thr, scale, seed, offset, train_epoch_ptr(), n4, F / 4, out);
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -553,7 +596,7 @@ int amuse_train_bias_gelu_drop_bwd(const float* da, const float* h, const float*
     uint32_t thr; float scale;
     if (int e = drop_args(p, &thr, &scale)) return e;
     const int g = grid_for(rows, 2 * (kTrainThreads / (F / 4)));
-    hipLaunchKernelGGL(k_train_bgd_bwd, dim3(g), dim3(kTrainThreads), 0, (hipStream_t)stream, da, h, b, thr, scale, seed, offset, rows, F / 4, dh, ws);
+    hipLaunchKernelGGL(k_train_bgd_bwd, dim3(g), dim3(kTrainThreads), 0, (hipStream_t)stream, da, h, b, thr, scale, seed, offset, train_epoch_ptr(), rows, F / 4, dh, ws);
     hipLaunchKernelGGL(k_train_finalize, dim3(1), dim3(kTrainThreads), 0, (hipStream_t)stream, ws, g, db, (float*)nullptr, (float*)nullptr, F, F);
     HIP_TRY(hipGetLastError());
     return 0;
@@ -578,6 +621,33 @@ int amuse_train_adamw(float* param, const float* grad, float* exp_avg, float* ex
     const size_t g = (n + 255) / 256;
     hipLaunchKernelGGL(k_train_adamw, dim3((unsigned)(g > 16384 ? 16384 : g)), dim3(256), 0, (hipStream_t)stream, param, grad, exp_avg, exp_avg_sq, n, (float)(lr / bc1),
                        (float)(1.0 - lr * weight_decay), (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), (float)eps, (float)rbc2);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int amuse_train_adamw_dev(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, size_t n, double lr, double beta1, double beta2, double eps,
+                          double weight_decay, long* step_dev, float* scal_dev, int advance, void* stream) {
+    if (!param || !grad || !exp_avg || !exp_avg_sq || !step_dev || !scal_dev) return fail(AMUSE_EINVAL, "amuse_train_adamw_dev: NULL argument");
+    if (n < 1) return fail(AMUSE_EINVAL, "n %zu", n);
+    if (advance) hipLaunchKernelGGL(k_train_adamw_scalars, dim3(1), dim3(1), 0, (hipStream_t)stream, step_dev, lr, beta1, beta2, scal_dev);
+    const size_t g = (n + 255) / 256;
+    hipLaunchKernelGGL(k_train_adamw_dev, dim3((unsigned)(g > 16384 ? 16384 : g)), dim3(256), 0, (hipStream_t)stream, param, grad, exp_avg, exp_avg_sq, n, scal_dev,
+                       (float)(1.0 - lr * weight_decay), (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), (float)eps);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int amuse_train_epoch_advance(unsigned add, void* stream) {
+    uint32_t* e = train_epoch_ptr();
+    if (!e) return fail(AMUSE_EHIP, "no device word for the dropout epoch");
+    hipLaunchKernelGGL(k_train_epoch_set, dim3(1), dim3(1), 0, (hipStream_t)stream, e, (uint32_t)add, 0u, 0);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+int amuse_train_epoch_set(unsigned value, void* stream) {
+    uint32_t* e = train_epoch_ptr();
+    if (!e) return fail(AMUSE_EHIP, "no device word for the dropout epoch");
+    hipLaunchKernelGGL(k_train_epoch_set, dim3(1), dim3(1), 0, (hipStream_t)stream, e, 0u, (uint32_t)value, 1);
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -649,7 +719,7 @@ int amuse_train_layer_fwd(const amuse_train_layer* L, void* stream) {
         bias_rows_launch(L->bv, L->B, 128, L->c, st);
         TRY(rm_gemm(h, false, true, L->B, 128, 128, L->mem, L->Wv, L->c, true));
         const size_t n = (size_t)rows * 32, g = (n + 255) / 256;
-        hipLaunchKernelGGL(k_train_vk, dim3((unsigned)(g > 8192 ? 8192 : g)), dim3(256), 0, st, L->c, thr_a, scale_a, L->seed, L->off[4], rows, L->S, L->H, L->vk);
+        hipLaunchKernelGGL(k_train_vk, dim3((unsigned)(g > 8192 ? 8192 : g)), dim3(256), 0, st, L->c, thr_a, scale_a, L->seed, L->off[4], train_epoch_ptr(), rows, L->S, L->H, L->vk);
         TRY(rm_gemm(h, false, true, rows, 128, 128, L->vk, L->Wc, L->tmp, false));
         ln_fwd_launch(L->x1, L->tmp, L->bc, L->g2, L->be2, thr, scale, L->seed, L->off[1], rows, L->xm, L->zh2, L->r2, st);
         src = L->xm;
@@ -658,7 +728,7 @@ int amuse_train_layer_fwd(const amuse_train_layer* L, void* stream) {
     TRY(rm_gemm(h, false, true, rows, L->ff, 128, src, L->W1, L->h, false));
     {
         const size_t n4 = (size_t)rows * (L->ff / 4), g = (n4 + 255) / 256;
-        hipLaunchKernelGGL(k_train_bgd_fwd, dim3((unsigned)(g > 8192 ? 8192 : g)), dim3(256), 0, st, L->h, L->b1, thr, scale, L->seed, L->off[2], n4, L->ff / 4, L->a);
+        hipLaunchKernelGGL(k_train_bgd_fwd, dim3((unsigned)(g > 8192 ? 8192 : g)), dim3(256), 0, st, L->h, L->b1, thr, scale, L->seed, L->off[2], train_epoch_ptr(), n4, L->ff / 4, L->a);
     }
     TRY(rm_gemm(h, false, true, rows, 128, L->ff, L->a, L->W2, L->tmp, false));
     ln_fwd_launch(src, L->tmp, L->b2, L->g3, L->be3, thr, scale, L->seed, L->off[3], rows, L->out, L->zh3, L->r3, st);
@@ -687,7 +757,7 @@ int amuse_train_layer_bwd(const amuse_train_layer* L, void* stream) {
     {
         const int g = grid_for(rows, 2 * (kTrainThreads / (ff / 4)));
         float* wsj = L->ws + nj * kWsRegion;
-        hipLaunchKernelGGL(k_train_bgd_bwd, dim3(g), dim3(kTrainThreads), 0, st, L->s512a, L->h, L->b1, thr, scale, L->seed, L->off[2], rows, ff / 4, L->s512b, wsj);
+        hipLaunchKernelGGL(k_train_bgd_bwd, dim3(g), dim3(kTrainThreads), 0, st, L->s512a, L->h, L->b1, thr, scale, L->seed, L->off[2], train_epoch_ptr(), rows, ff / 4, L->s512b, wsj);
         jobs.j[nj++] = FinJob{wsj, {L->db1, nullptr, nullptr}, g, ff, ff};
     }
     TRY(rm_gemm(h, true, false, ff, 128, rows, L->s512b, src, L->dW1, false));
@@ -699,7 +769,7 @@ int amuse_train_layer_bwd(const amuse_train_layer* L, void* stream) {
         ++nj;
         TRY(rm_gemm(h, true, false, 128, 128, rows, L->s128b, L->vk, L->dWc, false));
         TRY(rm_gemm(h, false, false, rows, 128, 128, L->s128b, L->Wc, L->do2, false));     // d(vk), parked in do2
-        hipLaunchKernelGGL(k_train_dc, dim3(L->B), dim3(256), 0, st, L->do2, thr_a, scale_a, L->seed, L->off[4], L->S, L->H, L->sdc);
+        hipLaunchKernelGGL(k_train_dc, dim3(L->B), dim3(256), 0, st, L->do2, thr_a, scale_a, L->seed, L->off[4], train_epoch_ptr(), L->S, L->H, L->sdc);
         TRY(rm_gemm(h, true, false, 128, 128, L->B, L->sdc, L->mem, L->dWv, false));
         colsum_launch(L->sdc, L->B, 128, L->dbv, L->ws + nj * kWsRegion, st, &jobs.j[nj]);
         ++nj;

@@ -97,11 +97,13 @@ struct AttnArgs {
     int B, S;
     uint32_t thr, key;
     float drop_scale;
+    const uint32_t* epoch;   // the device-side dropout epoch (k_train.hip train_epoch_ptr): mixed into the key, fresh masks per replay of a captured step
 };
 constexpr float kScaleLog2 = 0.17677669529663687f * 1.44269504088896340736f;   // 1 / sqrt(32) . log2 e
 
 // ---------------------------------------------------------------- forward: grid (B 4, query parts), eight waves
 __global__ __launch_bounds__(512) void k_attn_fwd(AttnArgs a) {
+    a.key ^= hash32(*a.epoch * 0x9E3779B9u + 0x85EBCA6Bu) * (*a.epoch != 0u);   // (epoch 0: the key as the host made it)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     f32x4* RK = reinterpret_cast<f32x4*>(smem);
     f32x4* TV = RK + kAImg;
@@ -181,6 +183,7 @@ __device__ __forceinline__ void stage_rowterms(const AttnArgs& a, int b, int h, 
 
 // ---------------------------------------------------------------- backward: grid 2 B 4 workgroups of 512 threads
 __global__ __launch_bounds__(512) void k_attn_bwd(AttnArgs a) {
+    a.key ^= hash32(*a.epoch * 0x9E3779B9u + 0x85EBCA6Bu) * (*a.epoch != 0u);   // (epoch 0: the key as the host made it)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int S = a.S, nt = (S + 15) >> 4;
     const int nbh = a.B * 4;
@@ -288,6 +291,8 @@ int attn_args(AttnArgs* a, const float* qkv, float* o, float* lse, const float* 
     uint64_t k = seed * 0x9E3779B97F4A7C15ull + offset * 0xD1B54A32D192ED03ull;
     k ^= k >> 29;
     a->key = (uint32_t)(k ^ (k >> 32));
+    a->epoch = train_epoch_ptr();
+    if (!a->epoch) return fail(AMUSE_EHIP, "attention: no device word for the dropout epoch");
     return 0;
 }
 

@@ -104,7 +104,11 @@ class LatentPriorLosses:
         self.reset()
 
     def reset(self):
-        self.sums = {k: torch.zeros((), device=self.d) for k in self.losses}
+        if getattr(self, "sums", None) is not None:      # in place: a captured training step (GestureTrainer.enable_graph) accumulates into THESE tensors
+            for v in self.sums.values():
+                v.zero_()
+        else:
+            self.sums = {k: torch.zeros((), device=self.d) for k in self.losses}
         self.count = 0
 
     def _update_loss(self, name, outputs, inputs):
@@ -316,11 +320,81 @@ class GestureTrainer:
         for m in self.model.values():
             m.train()
         torch.set_grad_enabled(True)
+        if self._graph is not None and not explicit and self._graph_takes(batch):
+            return self._graphed_step(batch)
+        if self._graph is not None:                 # an eager step between replays: the device-side step count is the optimizer's truth while a graph exists
+            self.lpdm_opt.sync_step()
         loss = self.forward_losses(batch, **explicit)
         self.backward_into_bucket(loss)
         self.allreduce_gradients()
         self.lpdm_opt.step()
+        if self._graph is not None:
+            self.lpdm_opt.push_step()
         return loss.detach()
+
+    # ------------------------------------------------------------------ the iteration as two HIP graphs (GPU)
+    _graph = None
+
+    def enable_graph(self, batch) -> bool:
+        """Capture the iteration at `batch`'s shapes as TWO HIP graphs - forward + losses + backward into the bucket (+ the side-stream sampler), and the optimizer
+        step - with the gradient all-reduce between them as an ordinary call; later train_step(batch) calls of those shapes copy the batch into the captured
+        buffers and replay (other shapes / explicit draws run eagerly).  What makes a replay a NEW iteration: torch's graph-safe generator for the step's draws
+        (noise, timesteps, the two rsamples, the sampler's initial latents), the library's device-side dropout epoch (amuse_train_epoch_advance at the end of the
+        second graph) and AdamW's device-side step count (FlatAdamW.step_dev).  Needs the gradient-sink path (the library writes gradients straight into the bucket:
+        tools/probes/train_host/graph_capture_probe.py - replays bitwise the eager step) and the flat optimizer.  Call it after a few eager steps (workspaces exist).
+        Returns False - and leaves the trainer eager - where the step is not capturable (CPU, another optimizer, a train-mode inner sampler)."""
+        from . import _lib as _libmod
+        from . import train_ops
+        if (self.device.type != "cuda" or not isinstance(self.lpdm_opt, train_ops.FlatAdamW) or getattr(self.inner_sampler, "serial", False) or not train_ops.enabled()
+                or getattr(self.inner_sampler, "refresh", 1) != 1):
+            return False
+        for m in self.model.values():
+            m.train()
+        torch.set_grad_enabled(True)
+        self.grads_mode, self.steal = "sink", False
+        if self.inner_sampler is not None:
+            self.inner_sampler.graph_safe = True     # initial latents from torch's generator (advances per replay) instead of the host-side clip counter
+        keys = [k for k in ("ld_motion", "ld_audio_con", "ld_audio_emo", "ld_audio_sty") if batch.get(k) is not None]
+        static = {k: batch[k].to(self.device).clone() for k in keys}
+        static["ld_attr"] = batch.get("ld_attr")
+        lib = train_ops._st(self.device)["lib"]
+        self.lpdm_opt.push_step()
+        count0 = self.lpdm_losses.count
+        torch.cuda.synchronize(self.device)
+        g1, g2 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+        try:
+            with torch.cuda.graph(g1):
+                loss = self.forward_losses(static)
+                self.backward_into_bucket(loss)
+                out = loss.detach()
+            self.allreduce_gradients()
+            with torch.cuda.graph(g2, pool=g1.pool()):
+                self.lpdm_opt.step_dev()
+                with train_ops._on(self.device):
+                    _libmod.check(lib.amuse_train_epoch_advance(1, torch.cuda.current_stream(self.device).cuda_stream))
+        except Exception:
+            self._graph = None
+            raise
+        self.lpdm_losses.count = count0              # (a capture records the launches, it does not run them: no iteration happened)
+        self._graph = {"g1": g1, "g2": g2, "static": static, "keys": keys, "loss": out}
+        return True
+
+    def _graph_takes(self, batch) -> bool:
+        st = self._graph["static"]
+        return all((batch.get(k) is not None) == (k in self._graph["keys"]) and (batch.get(k) is None or tuple(batch[k].shape) == tuple(st[k].shape))
+                   for k in ("ld_motion", "ld_audio_con", "ld_audio_emo", "ld_audio_sty"))
+
+    def _graphed_step(self, batch) -> torch.Tensor:
+        g = self._graph
+        for k in g["keys"]:
+            g["static"][k].copy_(batch[k], non_blocking=True)
+        g["g1"].replay()
+        self.allreduce_gradients()
+        g["g2"].replay()
+        self.lpdm_losses.count += 1
+        if self.inner_sampler is not None:
+            self.inner_sampler.calls += 1
+        return g["loss"]
 
     def backward_into_bucket(self, loss):
         """zero_grad + backward with every gradient ending up in the flat bucket.  With p.grad unset autograd hands each
@@ -404,6 +478,16 @@ class GestureTrainer:
                 sampler.set_epoch(epoch)   # a DistributedSampler reshuffles per epoch only when told (the reference's DataLoader(shuffle=True) does by itself)
             for batch in train_loader:
                 self.train_step(batch)
+                self._steps_done = getattr(self, "_steps_done", 0) + 1
+                if getattr(self, "use_graph", False) and self._graph is None and self._steps_done == 3:
+                    try:                               # from the fourth iteration on: two graph replays per step instead of ~1,300 launches (enable_graph)
+                        ok = self.enable_graph(batch)
+                    except Exception as e:  # noqa: BLE001 - training goes on eagerly
+                        ok = False
+                        print(f"[LPDM-T] HIP-graph capture of the iteration failed ({type(e).__name__}: {str(e)[:160]}): staying eager", flush=True)
+                    self.use_graph = ok
+                    if rank == 0:
+                        print(f"[LPDM-T] iteration {'captured as two HIP graphs around the gradient all-reduce' if ok else 'runs eagerly'}", flush=True)
                 if on_iteration is not None:
                     on_iteration(self)
             loss_dict = self.lpdm_losses.compute()
@@ -459,6 +543,11 @@ class HipInnerSampler:
                 self.engine.update_weights(self._den_state(), self._prior_state(), what=self.what)
             self.sync_ms.append((time.perf_counter() - t0) * 1e3)
         self.calls += 1
+        if getattr(self, "graph_safe", False):
+            # inside a captured training step (GestureTrainer.enable_graph) the host-side clip counter would be frozen: the initial latents come from torch's
+            # generator on the device, whose state the graph advances per replay
+            lat = self.engine.sample(con, emo, sty, self.precision, seed=self.seed, x_init=torch.randn(bsz, 128, device=self.engine.device))
+            return self.engine.vae_decode(lat, None, self.precision, return_feats=True)["feats"]
         # initial latents are keyed by a global clip index: rank r draws clips [counter + r * bsz, counter + (r + 1) * bsz)
         lat = self.engine.sample(con, emo, sty, self.precision, seed=self.seed, clip_index0=self.clip_counter + self.rank * bsz)
         self.clip_counter += bsz * self.world
@@ -604,6 +693,16 @@ def bench_main(args):
 
     for i in range(args.warmup):
         tr.train_step(batches[i % 4])
+    # the iteration as two HIP graphs around the all-reduce (GestureTrainer.enable_graph): the host's ~1,300 launches per step become two replays
+    graphed, graph_note = False, "--no-graph"
+    if not getattr(args, "no_graph", False):
+        try:
+            graphed = tr.enable_graph(batches[0])
+            graph_note = "captured" if graphed else "not capturable in this configuration: eager"
+        except Exception as e:  # noqa: BLE001 - the bench falls back to the eager step and says so
+            graphed, graph_note = False, f"capture failed ({type(e).__name__}: {str(e)[:200]}): eager"
+        for i in range(3):
+            tr.train_step(batches[i % 4])
     barrier()
     tr.pop_allreduce_ms()
     t0 = time.perf_counter()
@@ -630,6 +729,9 @@ def bench_main(args):
                                    f"all-reduce of {tr.n_grad_elements():,} fp32 gradients; batch {bsz} per GPU, {bsz * world} global; "
                                    f"vertex-displacement loss off (needs SMPL-X assets)",
                        "batch_per_gpu": bsz, "grad_elements": tr.n_grad_elements(),
+                       "hip_graph": graphed, "hip_graph_note": graph_note + (" - forward + losses + backward (+ the side-stream sampler) and the optimizer step replayed as two HIP graphs "
+                                                                          "around the all-reduce; fresh draws per replay: torch's graph-safe generator, the library's device-side dropout "
+                                                                          "epoch and AdamW step count" if graphed else ""),
                        "gemm": "own",
                        "gemm_detail": "hand-written HIP (fp32 MFMA) for every GEMM of the networks: the tall projections and input gradients (k_train_gemm_tall), the chunked "
                                       "weight-gradient reductions (k_train_wgrad), and the generic kernel (k_train_gemm_any) for the 333-wide embedding / output layers, the 32-row "
@@ -668,6 +770,7 @@ def main(argv=None):
     ap.add_argument("--inner-sampler", default=None, choices=["eval", "train"],
                     help="the no-gradient DDIM-50 + decode of every iteration: eval (default) = the persistent HIP sampler kernel, dropout off; train = the "
                          "reference's semantics (ldm.py:117-153 under model.train(): every dropout live) through the trainer's own modules, ~10 x slower")
+    ap.add_argument("--no-graph", action="store_true", help="keep the iteration eager (default on the GPU: captured as two HIP graphs after three eager iterations)")
     ap.add_argument("--ldm-cfg", default=None, help="JSON file: configs/<arch>.json merged with diff_o.yaml (losses, schedulers); default: the shipped values")
     args = ap.parse_args(argv)
     from . import launch
@@ -699,10 +802,19 @@ def main(argv=None):
     kind = args.kind or ablation_kind(args.cache)
     tr = build_trainer(device, rank, world, process_group=pg, use_hip_sampler=device.type == "cuda", ldm_cfg=ldm_cfg, lr=args.lr, kind=kind,
                        inner=args.inner_sampler)
+    tr.use_graph = device.type == "cuda" and not args.no_graph
     if rank == 0:
         lc = tr.lpdm_losses.cfg
         print(f"[LPDM-T] lr {args.lr:g}, ablation kind {kind or 'full'}, loss weights " +
               ", ".join(f"{k} {lc[k]}" for k in ("LAMBDA_REC", "LAMBDA_KL", "LAMBDA_LATENT", "LAMBDA_GEN")), flush=True)
+        if tr.inner_sampler is None:
+            print("[LPDM-T] inner sampler: none (CPU run: the no-gradient gen_feature term is off)", flush=True)
+        elif getattr(tr.inner_sampler, "serial", False):
+            print("[LPDM-T] inner sampler: train - the reference's semantics (ldm.py:117-153 and prior.decode under model.train(): every dropout live), on the trainer's own modules", flush=True)
+        else:
+            print("[LPDM-T] inner sampler: eval - DDIM-50 + decode on the persistent HIP sampler kernel with dropout OFF.  DEVIATION from the reference, whose loop runs under "
+                  "model.train() with every dropout live (scripts/trainer.py:357-358,413-415): the gen_feature loss term sees un-dropped samples.  "
+                  "--inner-sampler train (or AMUSE_TRAIN_INNER=train) selects the reference's semantics, ~10 x slower.", flush=True)
     if args.cache:
         from .dataload import LatentDiffusionCache, make_loader
         loader = make_loader(LatentDiffusionCache.open(args.cache), args.batch, rank=rank, world=world, seed=args.seed)

@@ -438,6 +438,8 @@ class FlatAdamW(torch.optim.AdamW):
         self._p, self._g = flat_param, flat_grad
         self._m, self._v = torch.zeros_like(flat_param), torch.zeros_like(flat_param)
         self._t = 0
+        self._t_dev = torch.zeros(1, dtype=torch.int64, device=flat_param.device)    # step_dev(): the step count and the two bias-correction scalars on the device
+        self._scal = torch.zeros(2, dtype=torch.float32, device=flat_param.device)
         mine = {id(p) for g in self.param_groups for p in g["params"]}
         assert len(self.param_groups) == 1 and not self.param_groups[0].get("amsgrad") and not self.param_groups[0].get("maximize")
         self._ranges = []
@@ -464,7 +466,30 @@ class FlatAdamW(torch.optim.AdamW):
                 _lib.check(lib.amuse_train_adamw(b + 4 * off, self._g.data_ptr() + 4 * off, self._m.data_ptr() + 4 * off, self._v.data_ptr() + 4 * off, n, float(g["lr"]),
                                                  float(g["betas"][0]), float(g["betas"][1]), float(g["eps"]), float(g["weight_decay"]), self._t, stream))
 
+    @torch.no_grad()
+    def step_dev(self):
+        """The same update with the step count kept ON THE DEVICE (amuse_train_adamw_dev): capturable in a HIP graph - every replay advances the count by one.
+        The host's count follows through `sync_step()` (state_dict calls it)."""
+        g = self.param_groups[0]
+        dev = self._p.device
+        lib, stream = _st(dev)["lib"], _stream(dev)
+        b = self._p.data_ptr()
+        with _on(dev):
+            for i, (off, n) in enumerate(self._ranges):
+                _lib.check(lib.amuse_train_adamw_dev(b + 4 * off, self._g.data_ptr() + 4 * off, self._m.data_ptr() + 4 * off, self._v.data_ptr() + 4 * off, n, float(g["lr"]),
+                                                     float(g["betas"][0]), float(g["betas"][1]), float(g["eps"]), float(g["weight_decay"]), self._t_dev.data_ptr(),
+                                                     self._scal.data_ptr(), int(i == 0), stream))
+
+    def push_step(self):
+        """host count -> device (before a graph with step_dev() is captured / replayed for the first time)"""
+        self._t_dev.fill_(self._t)
+
+    def sync_step(self):
+        """device count -> host (after replays of a captured step_dev())"""
+        self._t = max(self._t, int(self._t_dev.item()))
+
     def state_dict(self):
+        self.sync_step()
         for st in self.state.values():
             st["step"] = torch.tensor(float(self._t))
         return super().state_dict()
@@ -492,6 +517,7 @@ class FlatAdamW(torch.optim.AdamW):
         if len(steps) > 1:
             raise ValueError(f"FlatAdamW takes ONE step count for all parameters, the state dict holds {sorted(steps)}")
         self._t = steps.pop() if steps else 0
+        self._t_dev.fill_(self._t)
 
     def zero_grad(self, set_to_none: bool = False):
         """The gradients are views of the flat bucket the kernel reads: zero the bucket, never detach the views."""

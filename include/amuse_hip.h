@@ -381,9 +381,20 @@ int amuse_train_attn_bwd(const float* qkv, const float* o, const float* lse, con
  * optimizer over prior + ldm parameters; amuse_amd/train_gesture.py keeps parameters, gradients and both moments in one buffer each) */
 int amuse_train_adamw(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, size_t n, double lr, double beta1, double beta2, double eps,
                       double weight_decay, long step, void* stream);
+/* The same update with the step count on the DEVICE - for a training step captured as a HIP graph, whose host-side count is frozen at capture:
+ * advance != 0 first adds 1 to *step_dev and leaves the two bias-correction scalars (computed in double, as the host path does) in scal_dev[0..1]; the update
+ * then reads them.  One advancing call per optimizer step, advance = 0 for the step's further ranges.  step_dev, scal_dev: device memory (8 + 8 bytes). */
+int amuse_train_adamw_dev(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, size_t n, double lr, double beta1, double beta2, double eps,
+                          double weight_decay, long* step_dev, float* scal_dev, int advance, void* stream);
+/* The dropout epoch: one device word per GPU that every mask-drawing kernel of the training step (LayerNorm / FFN / value-path dropouts, the attention's hash)
+ * mixes into its counter.  It is 0 unless advanced - eager training hands every call a fresh (seed, offset) from the host.  A step captured as a HIP graph
+ * replays with the offsets it was captured with, so the graph ends with amuse_train_epoch_advance(1): every replay then draws fresh masks, and the forward and
+ * backward halves of one step still see the same value.  amuse_train_epoch_set pins it (tests, resuming). */
+int amuse_train_epoch_advance(unsigned add, void* stream);
+int amuse_train_epoch_set(unsigned value, void* stream);
 /* Layer-level entry points: a whole TransformerEncoderLayer / TransformerDecoderLayer (forward_post, memory of one token) but its self-attention
- * core, forward and backward, in one call each - the kernels above plus the layer's plain GEMMs on rocBLAS (dlopen'ed on first use; AMUSE_ESTATE if it
- * cannot be loaded).  The caller computes q | k | v = amuse_train_linear_fwd(x, in_proj), runs its attention on them (o2 = the heads' outputs
+ * core, forward and backward, in one call each - the kernels above plus the layer's plain GEMMs on the library's own fp32-MFMA kernels
+ * (csrc/k_train_gemm.hip; no vendor BLAS).  The caller computes q | k | v = amuse_train_linear_fwd(x, in_proj), runs its attention on them (o2 = the heads' outputs
  * concatenated), calls amuse_train_layer_fwd; on the way back amuse_train_layer_bwd returns d(o2) for the attention's backward pass, whose d(q | k | v)
  * goes through amuse_train_linear_bwd(..., dx = L.dx, accumulate_dx = 1).  Linear weights in PyTorch's [out][in] layout, everything fp32 and dense. */
 typedef struct amuse_train_layer {

