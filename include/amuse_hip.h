@@ -28,6 +28,16 @@
 extern "C" {
 #endif
 
+/* Switches.  Kernel choices are API, not environment: amuse_set_decode_path / amuse_set_clips_per_group pin them per context, amuse_plan states the library's own rule.
+ * The library reads NO environment variable.  What is left in the whole package (INTEGRATION.md has the same table):
+ *   build macro  AMUSE_OP_F16          the declared second compilation of the three 16-bit kernels for fp16 operands (csrc/k_sampler8h.hip, k_vae_fusedh.hip, k_den_fusedh.hip)
+ *   build macro  AMUSE_FPROF=1         variant builds only (tools/build_variant.sh): s_memtime phase stamps of the fused per-clip kernels
+ *   environment  AMUSE_HIP_LIB         amuse_amd/_lib.py: load another build of this ABI (kernel A/B measurements)
+ *   environment  AMUSE_SHARE_GPU=1     amuse_amd/main.py: every --gpus rank stays on --device (two-process tests on a one-GPU box)
+ *   environment  AMUSE_RUN_STAMP, AMUSE_MANIFEST_DIR   launcher -> rank hand-over inside amuse_amd/main.py (not set by users)
+ *   environment  AMUSE_TRAIN_FUSED=0, AMUSE_TRAIN_VALIDATE=1, AMUSE_TRAIN_INNER=train   train_gesture: eager layers / torch's distribution checks / the reference's
+ *                                      train-mode inner sampler (amuse_amd/train_ops.py, train_gesture.py)
+ * The ~30 environment switches and 51 -DAMUSE_* macros of rounds 1-5 (A/B residue) were retired in round 6: tools/probes/retired_switches/. */
 #define AMUSE_ABI_VERSION 5   /* 5: amuse_plan / amuse_debug_last_plan (the launch plan); the process-wide environment overrides of kernel choices are gone;
                                  4: amuse_train_* (training-step glue kernels);
                                  3: Denoiser variants (amuse_create_arch, AMUSE_ARCH_*, amuse_denoise_step_pose, amuse_feats_to_smplx);

@@ -189,7 +189,8 @@ def test_training_entry_points_validate_their_arguments_without_touching_the_gpu
     assert lib.amuse_train_bias_gelu_drop_fwd(one, one, 0.0, 1, 1, 16, 510, one, None) != 0 and "multiple of 4" in err()
     assert lib.amuse_train_bias_gelu_drop_bwd(one, one, one, 0.0, 1, 1, 16, 2048, one, one, one, None) != 0
     assert lib.amuse_train_colsum(one, 16, 6, one, one, None) != 0
-    assert lib.amuse_train_linear_fwd(one, one, None, 16, 128, 333, one, None) != 0 and "multiple of 4" in err()
+    assert lib.amuse_train_linear_fwd(one, one, None, 16, 128, 0, one, None) != 0 and "N 0" in err()      # (any width >= 1 is taken since round 6: N = 333 included)
+    assert lib.amuse_train_linear_bwd(one, one, one, 16, 128, 2048, one, one, one, 0, one, None) != 0 and "up to 1024" in err()
     assert lib.amuse_train_linear_bwd(one, one, one, 16, 128, 384, one, one, one, 0, None, None) != 0 and "workspace" in err()
     assert lib.amuse_train_adamw(one, one, one, one, 0, 1e-4, 0.9, 0.999, 1e-8, 0.01, 1, None) != 0
     assert lib.amuse_train_adamw(one, one, one, one, 8, 1e-4, 0.9, 0.999, 1e-8, 0.01, 0, None) != 0 and "step" in err()

@@ -42,7 +42,10 @@ tail -1 $O/bench.json > profiles/${R}_bench_line.json
 tail -1 $O/train_bench.json > profiles/${R}_train_bench_line.json
 [ -f $O/train_bench_eager.json ] && tail -1 $O/train_bench_eager.json > profiles/${R}_train_bench_line_eager_layers.json
 [ -f $O/train_profile.txt ] && cp $O/train_profile.txt profiles/${R}_train_step_torch_profile.txt
-[ -f $O/train_gemm_time.txt ] && cp $O/train_gemm_time.txt profiles/${R}_train_gemm_per_call.txt
+[ -f $O/train_gemm_time.txt ] && grep -v libdrm $O/train_gemm_time.txt > profiles/${R}_train_gemm_per_call.txt
+[ -f $O/train_bench_nograph.json ] && tail -1 $O/train_bench_nograph.json > profiles/${R}_train_bench_line_no_graph.json
+[ -f $O/multigpu_preflight_world1.txt ] && grep multigpu_preflight $O/multigpu_preflight_world1.txt > profiles/${R}_multigpu_preflight_world1.json
+[ -f $O/attend32_probe.txt ] && cp $O/attend32_probe.txt profiles/${R}_attend32_probe_runs.txt
 [ -f $O/train_profile_vendor_gemm.txt ] && cp $O/train_profile_vendor_gemm.txt profiles/${R}_train_step_torch_profile_vendor_gemm.txt
 [ -f $O/mfma_f32_rate_probe.txt ] && cp $O/mfma_f32_rate_probe.txt profiles/${R}_mfma_f32_rate_probe.txt
 [ -f $O/train_bench_vendor_attn.json ] && tail -1 $O/train_bench_vendor_attn.json > profiles/${R}_train_bench_line_vendor_attention.json
