@@ -39,14 +39,14 @@ STREAM_MB_PER_STEP = {"bf16": 3.80, "fp16": 3.80, "fp32": 7.60, "fp32x": 7.60}
 CU_LOAD_BYTES_PER_CLK = 64.0
 
 
-PMC_DIRS = {"bf16": ("profiles/r05_pmc", "profiles/r04_pmc"), "fp32x": ("profiles/r05_fp32x_pmc", "profiles/r04_fp32x_pmc")}
+PMC_DIRS = {"bf16": ("profiles/r06_pmc", "profiles/r05_pmc"), "fp32x": ("profiles/r06_fp32x_pmc", "profiles/r05_fp32x_pmc")}
 PMC_KERNEL = {"bf16": "k_sample8", "fp32x": "k_sample8x"}
 
 
 def pmc_traffic_bytes(clips, T, precision):
     """HBM bytes per k_sample launch.  NOT measured by this run (PMC counters need rocprofv3 around the process): read from the newest committed
     rocprofv3 PMC passes (separate --pmc runs of tools/run_sample_once.py at the bench shape) - and only if the pass's kernel_id.json (tools/kernel_id.py:
-    sha256 over the kernel's source, its headers and the Makefile, and over its compiled object, written when the pass was taken) equals the identity of the sampler in THIS
+    sha256 over the kernel's source, its headers and the Makefile, and over the kernel's machine code read out of the libamuse_hip.so that is loaded, written when the pass was taken) equals the identity of the sampler in THIS
     tree - the same build inputs or, failing that, the same object bits:
     a kernel change without a PMC retake returns (None, reason) instead of a stale figure.  FETCH_SIZE / WRITE_SIZE are in KiB; FETCH_SIZE is doubled
     per MI355X_MICROARCH.md (gfx950 reports half of a wide coalesced stream).  -> (bytes or None, source / reason)."""

@@ -26,15 +26,72 @@ def _closure(files):
     return seen + ["Makefile"]
 
 
+# kernel name -> what its (mangled) device symbol contains.  The product instantiation only: k_sample8<false> (no phase stamps), etc.
+SYMBOLS = {"k_sample8": "9k_sample8ILb0E", "k_sample8h": "10k_sample8hILb0E", "k_sample8x": "10k_sample8xILb0E", "k_sample": "8k_sampleILi0ELb0E", "k_vae_fused": "11k_vae_fusedILb0ELb0E",
+           "k_den_fused": "11k_den_fusedILb0E", "k_vae_rows8x": "12k_vae_rows8x", "k_vae_fusedx": "12k_vae_fusedx"}
+LIB = CSRC.parent / "libamuse_hip.so"
+
+
+def device_text_sha256(lib_path, symbol_part: str):
+    """sha256 over the machine code of every gfx950 device function of `lib_path` whose symbol contains `symbol_part` - read out of the library that is LOADED, not out
+    of an object file that may or may not be what was linked: the offload bundles (__CLANG_OFFLOAD_BUNDLE__, uncompressed) of the .so hold one ELF code object per
+    translation unit; its symbol table gives address and size of each kernel's text.  None if the library or the symbol is not there."""
+    import struct
+    try:
+        d = Path(lib_path).read_bytes()
+    except OSError:
+        return None
+    found = []
+    i = d.find(b"__CLANG_OFFLOAD_BUNDLE__")
+    while i >= 0:
+        n = struct.unpack_from("<Q", d, i + 24)[0]
+        p = i + 32
+        for _ in range(n):
+            off, size, ts = struct.unpack_from("<QQQ", d, p)
+            p += 24
+            triple = d[p:p + ts]
+            p += ts
+            if b"gfx950" not in triple or size == 0:
+                continue
+            e = d[i + off:i + off + size]
+            if e[:4] != b"\x7fELF":
+                continue
+            shoff, shentsize, shnum = struct.unpack_from("<Q", e, 0x28)[0], struct.unpack_from("<H", e, 0x3A)[0], struct.unpack_from("<H", e, 0x3C)[0]
+            secs = [struct.unpack_from("<IIQQQQIIQQ", e, shoff + k * shentsize) for k in range(shnum)]
+            for sec in secs:
+                if sec[1] != 2:          # SHT_SYMTAB
+                    continue
+                strtab = secs[sec[6]]
+                for k in range(sec[5] // 24):
+                    st_name, st_info, _o, st_shndx, st_value, st_size = struct.unpack_from("<IBBHQQ", e, sec[4] + 24 * k)
+                    if (st_info & 15) != 2 or st_size == 0 or st_shndx >= shnum:      # STT_FUNC
+                        continue
+                    nm = e[strtab[4] + st_name:e.index(b"\0", strtab[4] + st_name)]
+                    if symbol_part.encode() in nm and not nm.endswith(b".kd"):
+                        text = secs[st_shndx]
+                        a = text[4] + (st_value - text[3])
+                        found.append((nm, e[a:a + st_size]))
+        i = d.find(b"__CLANG_OFFLOAD_BUNDLE__", i + 1)
+    if not found:
+        return None
+    h = hashlib.sha256()
+    for nm, code in sorted(found):
+        h.update(nm + b"\0" + code)
+    return h.hexdigest()
+
+
 def kernel_id(name: str) -> dict:
     h = hashlib.sha256()
     files = _closure(SOURCES[name])
     for f in files:
         h.update(f.encode() + b"\0" + (CSRC / f).read_bytes() + b"\0")
     out = {"kernel": name, "inputs": files, "source_sha256": h.hexdigest()}
-    obj = CSRC / (SOURCES[name][-1].replace(".hip", ".o"))
-    if obj.exists():
-        out["object_sha256"] = hashlib.sha256(obj.read_bytes()).hexdigest()     # informative: same toolchain + same inputs -> same object
+    # the identity that counts: the machine code of the kernel inside the library that gets LOADED (same toolchain + same inputs -> same text; an edit to a shared
+    # header that leaves the kernel's code as it was does not change it; a stale .o on disk cannot fake it)
+    code = device_text_sha256(LIB, SYMBOLS[name])
+    if code:
+        out["object_sha256"] = code
+        out["object_is"] = f"device text of *{SYMBOLS[name]}* in amuse_amd/libamuse_hip.so"
     return out
 
 
