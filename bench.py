@@ -597,8 +597,8 @@ def main():
                     "flop_per_clip": FLOP_VAE_ATTN_PER_CLIP, "ms": round(att_ms, 4), "tflops": round(B * FLOP_VAE_ATTN_PER_CLIP / (att_ms * 1e-3) / 1e12, 1),
                     "frac_of_mfma_peak": round(B * FLOP_VAE_ATTN_PER_CLIP / (att_ms * 1e-3) / 1e12 / peak, 4), "launch_without_attention_ms": round(min(da), 3),
                     "method": "k_vae_fused launch time minus its no-attention instantiation's, HIP events, same process",
-                    "bound": "transcendental issue: 80 v_exp_f32 per 16-query tile and head against 40 useful MFMAs (dh = 32) - "
-                             "profiles/r04_fused_attention_ablation.txt, DESIGN.md 4.2b"}
+                    "bound": "transcendental issue: 80 v_exp_f32 per 16-query tile and head against 40 useful MFMAs (dh = 32); lazy rescaling of the running maxima since round 6 "
+                             "(0.27 -> 0.31); the 32x32x16 one-wave-per-SIMD regime probed at 0.32-0.37: profiles/r06_attention_lazy_rescale.txt, r06_attend32_probe.txt, DESIGN.md 4.2"}
         # the step time of k_sample does not depend on the clips per workgroup tile (1..3), so 3 clips per CU
         # cost the same loop time: report that saturating point too (not the headline workload)
         Bs = 3 * total
