@@ -14,7 +14,6 @@ from typing import Callable, Dict, List, Optional
 
 import numpy as np
 import torch
-from torch.nn.utils.rnn import pad_sequence
 
 
 class LatentDiffusionCache(torch.utils.data.Dataset):
@@ -56,17 +55,22 @@ class LatentDiffusionCache(torch.utils.data.Dataset):
                 "ld_attr": s_attr}
 
 
+_STACKED = ("ld_motion", "ld_audio_con", "ld_audio_emo", "ld_audio_sty", "ld_emo_label")   # per-sample tensors of one shape each
+
+
 def latdiff_long_collate_fn_v1(batch: List[Dict[str, object]]) -> Dict[str, object]:
-    """dataload.py:287-308: motions / embeddings / labels stacked, raw audio zero-padded to the longest clip of the batch."""
-    motion = torch.stack([b["ld_motion"] for b in batch])
-    audio_length = [b["ld_audio"].shape[0] for b in batch]
-    audio_pad = pad_sequence([torch.from_numpy(np.copy(b["ld_audio"])) for b in batch], batch_first=True)
-    assert motion.shape[0] == audio_pad.shape[0], "Motion and audio batch size mismatch"
-    assert all(x.shape[0] == max(audio_length) for x in audio_pad), "Padded audio length not equal"
-    return {"ld_motion": motion, "ld_audio": audio_pad, "ld_audio_length": torch.from_numpy(np.array(audio_length)),
-            "ld_audio_con": torch.stack([b["ld_audio_con"] for b in batch]), "ld_audio_emo": torch.stack([b["ld_audio_emo"] for b in batch]),
-            "ld_audio_sty": torch.stack([b["ld_audio_sty"] for b in batch]), "ld_emo_label": torch.stack([b["ld_emo_label"] for b in batch]),
-            "ld_attr": [b["ld_attr"] for b in batch]}
+    """The collate contract of dm/dataload.py:287-308 (the dict keys ARE the interface of the training iteration): fixed-shape entries stacked along a new batch
+    axis, the raw waveforms right-padded with zeros to the longest of the batch (`ld_audio`, with the true lengths in `ld_audio_length`), attributes as a list."""
+    n = len(batch)
+    out: Dict[str, object] = {key: torch.stack([sample[key] for sample in batch]) for key in _STACKED}
+    lengths = np.fromiter((sample["ld_audio"].shape[0] for sample in batch), dtype=np.int64, count=n)
+    waves = torch.zeros(n, int(lengths.max()), *np.shape(batch[0]["ld_audio"])[1:], dtype=torch.from_numpy(np.asarray(batch[0]["ld_audio"])).dtype)
+    for row, sample in enumerate(batch):
+        waves[row, : lengths[row]] = torch.from_numpy(np.array(sample["ld_audio"]))
+    if out["ld_motion"].shape[0] != waves.shape[0]:
+        raise ValueError(f"collate: {out['ld_motion'].shape[0]} motions but {waves.shape[0]} waveforms")
+    out.update(ld_audio=waves, ld_audio_length=torch.from_numpy(lengths), ld_attr=[sample["ld_attr"] for sample in batch])
+    return out
 
 
 def make_loader(dataset, batch_size: int, rank: int = 0, world: int = 1, shuffle: bool = True, seed: int = 0, num_workers: int = 0):
