@@ -519,8 +519,7 @@ class HipInnerSampler:
         self.rank, self.world = rank, world
         # the in-loop decode shares the GPU with the networks' forward pass (side stream): the per-clip kernel keeps it on `bsz` CUs (0.51 ms on 32 of 256) where the staged
         # launches AUTO would take below 64 clips spread over all of them (0.42 ms of 19 chip-wide launches in the forward pass's way)
-        if os.environ.get("AMUSE_PROBE_INNER_DECODE", "fused") == "fused":
-            self.engine.set_decode_path("fused")
+        self.engine.set_decode_path("fused")
         self.what = {"bf16": 2, "fp32x": 8, "fp16": 16}.get(precision, 1)   # AMUSE_UPD_* mask of the streams this sampler runs
         self.on_device = True      # re-pack on the GPU straight from the trainer's flat parameter buffer (False: the host path of amuse_update_weights; tests)
 

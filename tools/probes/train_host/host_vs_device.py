@@ -1,6 +1,6 @@
 """Is the training step host- or device-bound?  Host: wall time of the dispatch loop alone (no synchronisation inside, the device's queue drained before it starts
 and the loop short enough not to fill it); device: the same iterations' kernel time with the queue kept full (HIP events around the loop after a run-ahead of 10).
-Usage: python tools/probes/train_host/host_vs_device.py"""
+Usage: python tools/probes/train_host/host_vs_device.py [graph]      (graph: the iteration as two HIP graphs, GestureTrainer.enable_graph)"""
 import sys, time
 from pathlib import Path
 import torch
@@ -13,7 +13,21 @@ tr = build_trainer(dev, 0, 1)
 batches = [synthetic_batch(32, i, dev) for i in range(4)]
 for i in range(15):
     tr.train_step(batches[i % 4])
+if len(sys.argv) > 1 and sys.argv[1] == "graph":
+    print("graph mode:", tr.enable_graph(batches[0]), flush=True)
+    for i in range(4):
+        tr.train_step(batches[i % 4])
 torch.cuda.synchronize()
+# the host's own cost of one iteration: an idle device, one train_step, the time until the call returns (nothing to wait behind), then drain
+ret = []
+for i in range(12):
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    tr.train_step(batches[i % 4])
+    ret.append((time.perf_counter() - t0) * 1e3)
+torch.cuda.synchronize()
+ret.sort()
+print(f"one iteration on an idle device: train_step returns after {ret[len(ret) // 2]:.2f} ms (median of 12; min {ret[0]:.2f}, max {ret[-1]:.2f})", flush=True)
 for rnd in range(3):
     n = 40
     t0 = time.perf_counter()
