@@ -160,15 +160,43 @@ struct FinJob {
     float* o[3];
     int n, ncol, C;
 };
-struct FinJobs {
-    FinJob j[8];
+// a weight gradient's chunk partials (k_train_wgrad below) waiting to be added up: workgroups blk0 .. of the layer's one summing launch
+struct WsumJob {
+    const float* part;
+    float* out;
+    int chunks;
+    unsigned n4, blk0;
 };
-__global__ __launch_bounds__(kTrainThreads) void k_train_finalize_jobs(FinJobs jobs) {
+// Every reduction a layer's backward pass leaves behind - the column sums of its norms / biases AND the chunk sums of its weight gradients - added up by ONE
+// launch at the layer's end (k_train_layer_sums: workgroup = a column-sum job, or 256 float4 columns of a weight gradient) instead of 6-8 launches of ~5 us
+// spread through the layer.  The arithmetic of each sum is what the stand-alone launches do (k_train_finalize, k_train_wgrad_sum): same order, same bits.
+struct LayerSums {
+    FinJob j[8];
+    WsumJob w[6];
+    int nj, nw;
+    unsigned blocks;   // of the weight-gradient jobs so far
+};
+__device__ __forceinline__ void wgrad_sum_256(const float* __restrict__ part, int chunks, size_t n4, size_t i, int c, int q, f32x4* red, float* __restrict__ out);
+__global__ __launch_bounds__(kTrainThreads) void k_train_layer_sums(LayerSums s) {
     __shared__ f32x4 red[kTrainThreads];
-    const FinJob& J = jobs.j[blockIdx.x];
-    float* outs[3] = {J.o[0], J.o[1], J.o[2]};
-    sum_partials(J.ws, J.n, outs, J.ncol, J.C, red);
+    if ((int)blockIdx.x < s.nj) {
+        const FinJob& J = s.j[blockIdx.x];
+        float* outs[3] = {J.o[0], J.o[1], J.o[2]};
+        sum_partials(J.ws, J.n, outs, J.ncol, J.C, red);
+        return;
+    }
+    const unsigned b = blockIdx.x - s.nj;
+    int k = 0;
+    for (int i = 1; i < s.nw; ++i)
+        if (b >= s.w[i].blk0) k = i;
+    const WsumJob W = s.w[k];
+    // four groups of 256 threads, each what one workgroup of k_train_wgrad_sum is: 64 float4 columns
+    const int sub = threadIdx.x >> 8, t = threadIdx.x & 255;
+    wgrad_sum_256(W.part, W.chunks, W.n4, ((size_t)(b - W.blk0) * 4 + sub) * 64 + (t & 63), t & 63, t >> 6, red + sub * 192, W.out);
 }
+// the layer whose backward pass is being issued by this thread (amuse_train_layer_bwd): its reductions are parked here instead of being launched one by one
+thread_local LayerSums* g_layer_sums = nullptr;
+thread_local size_t g_layer_ws_used = 0;   // floats of the weight-gradient workspace holding parked partials
 
 // ---- AdamW over a contiguous range of the trainer's flat parameter / gradient buffers (torch.optim.AdamW, amsgrad off: decoupled weight decay, then
 // p -= lr / (1 - b1^t) . m / (sqrt(v) / sqrt(1 - b2^t) + eps)); bc1 = 1 - b1^t and rbc2 = 1 / sqrt(1 - b2^t) come from the host
@@ -364,7 +392,7 @@ int blas_handle(hipStream_t st, void** h) {
 // a workspace and a second kernel adds them IN ORDER (deterministic, like the step's other reductions).
 constexpr int kWgradMaxChunks = 64;
 constexpr int kWgradRows = 192;                       // rows per chunk (48 k-steps of the fp32 MFMA)
-constexpr size_t kWgradWsFloats = (size_t)4 << 20;   // 16 MB of partial blocks per device
+constexpr size_t kWgradWsFloats = (size_t)16 << 20;   // 64 MB of partial blocks per device: every weight gradient of one layer (10.7 M floats at 9,600 rows) until the layer's summing launch
 // STREAM = false: up to ~1,000 waves (one per SIMD); true: more - half of the chunk's loads in flight (~130 registers: three waves per SIMD), every k-step's registers
 // reloaded with the k-step 24 further on as soon as its MFMAs are issued.  MT = MFMA tiles of the wave's block along m: 2 (32 x 32 per wave, 64 x 64 per workgroup) or
 // 4 (64 x 32 per wave, 128 x 64 per workgroup: half the waves and half the x loads per MFMA for the 512-wide gradients; the m side is then read 16 bytes per lane)
@@ -423,23 +451,26 @@ __global__ __launch_bounds__(256) void k_train_wgrad(const float* __restrict__ d
             *reinterpret_cast<float2*>(o + (size_t)(m0 + MT * (4 * g + v) + t) * N + n0 + 2 * r) = float2{acc[t][0][v], acc[t][1][v]};
 }
 // out = the chunks' partial blocks added up in a FIXED order: thread (column c of 64 float4 columns, group q of 4) adds chunks q, q + 4, ... (their loads in
-// flight together), the four groups' sums are added q = 0..3 through LDS
-__global__ __launch_bounds__(256) void k_train_wgrad_sum(const float* __restrict__ part, int chunks, size_t n4, float* __restrict__ out) {
-    __shared__ f32x4 red[3][64];
-    const int c = threadIdx.x & 63, q = threadIdx.x >> 6;
-    const size_t i = (size_t)blockIdx.x * 64 + c;   // (n4 is a multiple of 64)
+// flight together), the four groups' sums are added q = 0..3 through LDS (red: 3 x 64 float4).  i = the thread's float4 column (whole groups of 64 are in or out)
+__device__ __forceinline__ void wgrad_sum_256(const float* __restrict__ part, int chunks, size_t n4, size_t i, int c, int q, f32x4* red, float* __restrict__ out) {
+    const bool in = i < n4;
     f32x4 v[kWgradMaxChunks / 4];
 #pragma unroll
     for (int j = 0; j < kWgradMaxChunks / 4; ++j) {
         const int ch = q + 4 * j;
-        v[j] = ch < chunks ? ld4(part + ((size_t)ch * n4 + i) * 4) : splat4(0.f);
+        v[j] = (in && ch < chunks) ? ld4(part + ((size_t)ch * n4 + i) * 4) : splat4(0.f);
     }
     f32x4 s = v[0];
 #pragma unroll
     for (int j = 1; j < kWgradMaxChunks / 4; ++j) s += v[j];
-    if (q > 0) red[q - 1][c] = s;
+    if (q > 0) red[(q - 1) * 64 + c] = s;
     __syncthreads();
-    if (q == 0) st4(out + 4 * i, ((s + red[0][c]) + red[1][c]) + red[2][c]);
+    if (q == 0 && in) st4(out + 4 * i, ((s + red[c]) + red[64 + c]) + red[128 + c]);
+}
+__global__ __launch_bounds__(256) void k_train_wgrad_sum(const float* __restrict__ part, int chunks, size_t n4, float* __restrict__ out) {
+    __shared__ f32x4 red[3 * 64];
+    const int c = threadIdx.x & 63;
+    wgrad_sum_256(part, chunks, n4, (size_t)blockIdx.x * 64 + c, c, threadIdx.x >> 6, red, out);   // (n4 is a multiple of 64)
 }
 float* g_wgrad_ws[64] = {};
 // gradients of at least this many elements go to the generic kernel (k_train_gemm.hip)
@@ -452,14 +483,25 @@ int wgrad_launch(const float* dy, const float* x, float* out, long rows, long M,
     const long chunks = (rows + kWgradRows - 1) / kWgradRows;
     const bool wide = M * N >= 65536 && !(M & 127);
     const long blocks = wide ? (M >> 7) * (N >> 6) : (M >> 6) * (N >> 6);
-    float* dst = chunks == 1 ? out : g_wgrad_ws[dev];
+    // partials: behind the ones a layer has parked (g_layer_ws_used; 0 outside amuse_train_layer_bwd)
+    const size_t need = (size_t)chunks * M * N;
+    if (chunks > 1 && g_layer_ws_used + need > kWgradWsFloats) return fail(AMUSE_EINVAL, "weight-gradient workspace: %zu + %zu floats of %zu", g_layer_ws_used, need, kWgradWsFloats);
+    float* part = g_wgrad_ws[dev] + g_layer_ws_used;
+    float* dst = chunks == 1 ? out : part;
     const dim3 grid((unsigned)blocks, (unsigned)chunks);
     if (wide) hipLaunchKernelGGL((k_train_wgrad<true, 4>), grid, dim3(256), 0, st, dy, x, dst, (int)rows, (int)M, (int)N);
     else if (blocks * chunks > 256) hipLaunchKernelGGL((k_train_wgrad<true, 2>), grid, dim3(256), 0, st, dy, x, dst, (int)rows, (int)M, (int)N);
     else hipLaunchKernelGGL((k_train_wgrad<false, 2>), grid, dim3(256), 0, st, dy, x, dst, (int)rows, (int)M, (int)N);
     if (chunks > 1) {
         const size_t n4 = (size_t)M * N / 4;
-        hipLaunchKernelGGL(k_train_wgrad_sum, dim3((unsigned)(n4 / 64)), dim3(256), 0, st, g_wgrad_ws[dev], (int)chunks, n4, out);
+        LayerSums* S = g_layer_sums;
+        if (S && S->nw < 6) {   // inside a layer's backward pass: added up by the layer's one summing launch
+            S->w[S->nw++] = WsumJob{part, out, (int)chunks, (unsigned)n4, S->blocks};
+            S->blocks += (unsigned)((n4 + 255) / 256);
+            g_layer_ws_used += need;
+        } else {
+            hipLaunchKernelGGL(k_train_wgrad_sum, dim3((unsigned)(n4 / 64)), dim3(256), 0, st, part, (int)chunks, n4, out);
+        }
     }
     return 0;
 }
@@ -506,6 +548,7 @@ int ln_bwd_launch(const float* dout, const float* dout2, const float* zhat, cons
 int colsum_launch(const float* x, long rows, int C, float* out, float* ws, hipStream_t st, FinJob* job = nullptr) {
     const int g = grid_for(rows, 2 * (kTrainThreads / (C / 4)));
     hipLaunchKernelGGL(k_train_colsum, dim3(g), dim3(kTrainThreads), 0, st, x, rows, C / 4, ws);
+    if (!job && g_layer_sums && g_layer_sums->nj < 8) job = &g_layer_sums->j[g_layer_sums->nj++];   // (a layer's backward pass: the caller gave a region of its own)
     if (job) *job = FinJob{ws, {out, nullptr, nullptr}, g, C, C};
     else hipLaunchKernelGGL(k_train_finalize, dim3(1), dim3(kTrainThreads), 0, st, ws, g, out, (float*)nullptr, (float*)nullptr, C, C);
     return 0;
@@ -747,10 +790,16 @@ int amuse_train_layer_bwd(const amuse_train_layer* L, void* stream) {
     const long rows = L->rows;
     const int ff = L->ff;
     const float* src = L->mem ? L->xm : L->x1;
-    FinJobs jobs{};
-    int nj = 0;
+    // the layer's reductions (column sums of norms / biases, chunk sums of weight gradients) are parked in `sums` by the launches below and added up by ONE launch
+    // at the end; nothing inside the layer reads a parameter gradient
+    LayerSums sums{};
+    struct Park {
+        explicit Park(LayerSums* s) { g_layer_sums = s; g_layer_ws_used = 0; }
+        ~Park() { g_layer_sums = nullptr; g_layer_ws_used = 0; }
+    } park(&sums);
+    int& nj = sums.nj;
     // FFN + last norm: s128a = d(src) through the norm, s128b = d(linear2 output)
-    ln_bwd_launch(L->dout, nullptr, L->zh3, L->r3, L->g3, thr, scale, L->seed, L->off[3], rows, L->s128a, L->s128b, L->dg3, L->dbe3, L->db2, L->ws + nj * kWsRegion, st, &jobs.j[nj]);
+    ln_bwd_launch(L->dout, nullptr, L->zh3, L->r3, L->g3, thr, scale, L->seed, L->off[3], rows, L->s128a, L->s128b, L->dg3, L->dbe3, L->db2, L->ws + nj * kWsRegion, st, &sums.j[nj]);
     ++nj;
     TRY(rm_gemm(h, true, false, 128, ff, rows, L->s128b, L->a, L->dW2, false));
     TRY(rm_gemm(h, false, false, rows, ff, 128, L->s128b, L->W2, L->s512a, false));
@@ -758,38 +807,38 @@ int amuse_train_layer_bwd(const amuse_train_layer* L, void* stream) {
         const int g = grid_for(rows, 2 * (kTrainThreads / (ff / 4)));
         float* wsj = L->ws + nj * kWsRegion;
         hipLaunchKernelGGL(k_train_bgd_bwd, dim3(g), dim3(kTrainThreads), 0, st, L->s512a, L->h, L->b1, thr, scale, L->seed, L->off[2], train_epoch_ptr(), rows, ff / 4, L->s512b, wsj);
-        jobs.j[nj++] = FinJob{wsj, {L->db1, nullptr, nullptr}, g, ff, ff};
+        sums.j[nj++] = FinJob{wsj, {L->db1, nullptr, nullptr}, g, ff, ff};
     }
     TRY(rm_gemm(h, true, false, ff, 128, rows, L->s512b, src, L->dW1, false));
     TRY(rm_gemm(h, false, false, rows, 128, ff, L->s512b, L->W1, L->s128b, false));      // the FFN branch's gradient of src
     if (L->mem) {
         // cross-attention + norm2: s128a <- d(x1), s128b <- d(out_proj output)
         ln_bwd_launch(L->s128a, L->s128b, L->zh2, L->r2, L->g2, thr, scale, L->seed, L->off[1], rows, L->s128a, L->s128b, L->dg2, L->dbe2, L->dbc, L->ws + nj * kWsRegion, st,
-                      &jobs.j[nj]);
+                      &sums.j[nj]);
         ++nj;
         TRY(rm_gemm(h, true, false, 128, 128, rows, L->s128b, L->vk, L->dWc, false));
         TRY(rm_gemm(h, false, false, rows, 128, 128, L->s128b, L->Wc, L->do2, false));     // d(vk), parked in do2
         hipLaunchKernelGGL(k_train_dc, dim3(L->B), dim3(256), 0, st, L->do2, thr_a, scale_a, L->seed, L->off[4], train_epoch_ptr(), L->S, L->H, L->sdc);
         TRY(rm_gemm(h, true, false, 128, 128, L->B, L->sdc, L->mem, L->dWv, false));
-        colsum_launch(L->sdc, L->B, 128, L->dbv, L->ws + nj * kWsRegion, st, &jobs.j[nj]);
+        colsum_launch(L->sdc, L->B, 128, L->dbv, L->ws + nj * kWsRegion, st, &sums.j[nj]);
         ++nj;
         TRY(rm_gemm(h, false, false, L->B, 128, 128, L->sdc, L->Wv, L->dmem, false));
         ln_bwd_launch(L->s128a, nullptr, L->zh1, L->r1, L->g1, thr, scale, L->seed, L->off[0], rows, L->dx, L->s128b, L->dg1, L->dbe1, L->dbo, L->ws + nj * kWsRegion, st,
-                      &jobs.j[nj]);
+                      &sums.j[nj]);
     } else {
         ln_bwd_launch(L->s128a, L->s128b, L->zh1, L->r1, L->g1, thr, scale, L->seed, L->off[0], rows, L->dx, L->s128b, L->dg1, L->dbe1, L->dbo, L->ws + nj * kWsRegion, st,
-                      &jobs.j[nj]);
+                      &sums.j[nj]);
     }
     ++nj;
-    hipLaunchKernelGGL(k_train_finalize_jobs, dim3(nj), dim3(kTrainThreads), 0, st, jobs);   // every column sum of the layer
     // self-attention's out_proj
     TRY(rm_gemm(h, true, false, 128, 128, rows, L->s128b, L->o2, L->dWo, false));
     TRY(rm_gemm(h, false, false, rows, 128, 128, L->s128b, L->Wo, L->do2, false));
     if (L->Win) {   // the attention's backward pass and the in-projection's in the same call
         if (!L->qkv || !L->lse || !L->dqkv || !L->dWin) return fail(AMUSE_EINVAL, "amuse_train_layer (backward): self-attention buffers missing");
         TRY(amuse_train_attn_bwd(L->qkv, L->o2, L->lse, L->do2, L->B, L->S, L->p_attn, L->seed, L->off_self, L->dqkv, stream));
-        TRY(amuse_train_linear_bwd(L->dqkv, L->x, L->Win, rows, 128, 384, L->dWin, L->dbin, L->dx, 1, L->ws, stream));
+        TRY(amuse_train_linear_bwd(L->dqkv, L->x, L->Win, rows, 128, 384, L->dWin, L->dbin, L->dx, 1, L->ws + nj * kWsRegion, stream));
     }
+    hipLaunchKernelGGL(k_train_layer_sums, dim3((unsigned)nj + sums.blocks), dim3(kTrainThreads), 0, st, sums);   // every column sum and weight gradient of the layer
     HIP_TRY(hipGetLastError());
     return 0;
 }

@@ -108,6 +108,7 @@ def test_train_step_with_hip_inner_sampler():
     s(batch["ld_audio_con"], batch["ld_audio_emo"], batch["ld_audio_sty"], 32)
     fresh = HipEngine(s._den_state(), s._prior_state())
     fresh.set_schedule(s.engine.schedule)
+    fresh.set_decode_path("fused")                    # (the in-loop sampler pins the per-clip decode kernel: HipInnerSampler.__init__)
     lat_a = s.engine.sample(batch["ld_audio_con"], batch["ld_audio_emo"], batch["ld_audio_sty"], "bf16", seed=1)
     lat_b = fresh.sample(batch["ld_audio_con"], batch["ld_audio_emo"], batch["ld_audio_sty"], "bf16", seed=1)
     assert torch.equal(lat_a, lat_b) and len(s.sync_ms) >= 4
