@@ -38,7 +38,7 @@ __device__ __forceinline__ uint32_t hash32(uint32_t x) {   // lowbias32 (Chris W
 }
 // mask . 1 / (1 - p) of element (row i, key j) of (clip, head) bh; thr = p 2^32 (0: no dropout)
 __device__ __forceinline__ float keep_scale(uint32_t key, uint32_t bh, int i, int j, uint32_t thr, float scale) {
-    if (thr == 0) return 1.0f;
+    // (thr == 0, no dropout: every hash passes and scale is 1 - no special case, so that the callers' key loops stay free of branches)
     const uint32_t idx = (bh * 512u + (uint32_t)i) * 512u + (uint32_t)j;   // S <= 304 < 512
     return hash32(idx ^ key) >= thr ? scale : 0.f;
 }
@@ -102,6 +102,9 @@ struct AttnArgs {
 constexpr float kScaleLog2 = 0.17677669529663687f * 1.44269504088896340736f;   // 1 / sqrt(32) . log2 e
 
 // ---------------------------------------------------------------- forward: grid (B 4, query parts), eight waves
+// MASK_OUT: the tests' instantiation that also writes the keep mask (a store behind a branch per element inside the key loop - kept out of the product's loop, whose
+// MFMAs and softmax arithmetic then sit in ONE basic block for the scheduler)
+template <bool MASK_OUT>
 __global__ __launch_bounds__(512) void k_attn_fwd(AttnArgs a) {
     a.key ^= hash32(*a.epoch * 0x9E3779B9u + 0x85EBCA6Bu) * (*a.epoch != 0u);   // (epoch 0: the key as the host made it)
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -122,8 +125,12 @@ __global__ __launch_bounds__(512) void k_attn_fwd(AttnArgs a) {
         for (int hh = 0; hh < 2; ++hh) q[hh] = qi < S ? ld4(base + (size_t)qi * 384 + 16 * hh + 4 * g) : splat4(0.f);
         float m_run = -INFINITY, l_run = 0.f;
         f32x4 o[2] = {splat4(0.f), splat4(0.f)};
+        // the scores of key tile jt + 1 are issued (8 dependent MFMAs, ~290 cycles of the matrix pipe) BEFORE the softmax arithmetic of tile jt, which they run under;
+        // the last iteration's look-ahead recomputes its own tile (no branch in the loop body)
+        f32x4 s_next = dot32(RK, 0, q, splat4(0.f), lane);
         for (int jt = 0; jt < nt; ++jt) {
-            f32x4 s = dot32(RK, jt, q, splat4(0.f), lane) * kScaleLog2;   // lane (g, c): S[query c][keys 16 jt + 4 g + m], log2 units
+            f32x4 s = s_next * kScaleLog2;                                // lane (g, c): S[query c][keys 16 jt + 4 g + m], log2 units
+            s_next = dot32(RK, min(jt + 1, nt - 1), q, splat4(0.f), lane);
             float mx = -INFINITY;
 #pragma unroll
             for (int m = 0; m < 4; ++m) {
@@ -141,7 +148,8 @@ __global__ __launch_bounds__(512) void k_attn_fwd(AttnArgs a) {
                 ps += p[m];
                 const float ks = keep_scale(a.key, bh, qi, 16 * jt + 4 * g + m, a.thr, a.drop_scale);
                 p[m] *= ks;
-                if (a.mask_out && qi < S && 16 * jt + 4 * g + m < S) a.mask_out[((size_t)bh * S + qi) * S + 16 * jt + 4 * g + m] = ks;   // (tests)
+                if constexpr (MASK_OUT)
+                    if (qi < S && 16 * jt + 4 * g + m < S) a.mask_out[((size_t)bh * S + qi) * S + 16 * jt + 4 * g + m] = ks;   // (tests)
             }
             ps = allreduce_g_sum(ps);
             l_run = l_run * alpha + ps;
@@ -310,13 +318,18 @@ int amuse_train_attn_fwd(const float* qkv, int B, int S, float p, uint64_t seed,
     static DeviceOnce once;
     int dev_;
     if (!once.done(&dev_)) {
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_attn_fwd), hipFuncAttributeMaxDynamicSharedMemorySize, kFwdLds));
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_attn_fwd<false>), hipFuncAttributeMaxDynamicSharedMemorySize, kFwdLds));
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_attn_bwd), hipFuncAttributeMaxDynamicSharedMemorySize, kBwdLds));
         once.set(dev_);
     }
     // two workgroups per (clip, head) while that fills the chip; eight waves each (two per SIMD: one's softmax under the other's MFMAs)
     const int parts = (S > 64 && B * 4 < 512) ? 2 : 1;
-    hipLaunchKernelGGL(k_attn_fwd, dim3(B * 4, parts), dim3(512), kFwdLds, (hipStream_t)stream, a);
+    if (mask_debug) {
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_attn_fwd<true>), hipFuncAttributeMaxDynamicSharedMemorySize, kFwdLds));
+        hipLaunchKernelGGL(k_attn_fwd<true>, dim3(B * 4, parts), dim3(512), kFwdLds, (hipStream_t)stream, a);
+    } else {
+        hipLaunchKernelGGL(k_attn_fwd<false>, dim3(B * 4, parts), dim3(512), kFwdLds, (hipStream_t)stream, a);
+    }
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -329,7 +342,7 @@ int amuse_train_attn_bwd(const float* qkv, const float* o, const float* lse, con
     static DeviceOnce once;
     int dev_;
     if (!once.done(&dev_)) {
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_attn_fwd), hipFuncAttributeMaxDynamicSharedMemorySize, kFwdLds));
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_attn_fwd<false>), hipFuncAttributeMaxDynamicSharedMemorySize, kFwdLds));
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_attn_bwd), hipFuncAttributeMaxDynamicSharedMemorySize, kBwdLds));
         once.set(dev_);
     }
