@@ -49,6 +49,25 @@ def _once(key, fn):
     return _ORACLE[key]
 
 
+def _ddpm1000_jobs(orc, Wd):
+    """The two 1000-step oracle runs of this file as ONE (the oracle's cost is per step, not per clip: ~75 s of CPU, shared by both tests and both parity modes):
+    rows 0..3 = clips 0, 1, 131, 255 of the 256-clip job with the counter-based noise of seed 2024 (keyed by the global clip index), row 4 = the single clip with
+    explicit x_T and per-step noise."""
+    def make():
+        gen = torch.Generator().manual_seed(3)
+        c, e, s = (torch.randn(256, 256, generator=gen) for _ in range(3))
+        pick = [0, 1, 131, 255]
+        x0 = torch.from_numpy(orc.counter_normal(2024, np.array(pick), 0, 0))
+        nz = torch.stack([torch.from_numpy(orc.counter_normal(2024, np.array(pick), i, 1)) for i in range(1000)])
+        gen1 = torch.Generator().manual_seed(77)
+        c1, e1, s1, x1 = (torch.randn(1, n, generator=gen1) for n in (256, 256, 256, 128))
+        nz1 = torch.randn(1000, 1, 128, generator=gen1)
+        ref = orc.sample_latents(Wd, orc.DDPM(), torch.cat([c[pick], c1]), torch.cat([e[pick], e1]), torch.cat([s[pick], s1]), torch.cat([x0.to(x1.dtype), x1]),
+                                 torch.cat([nz.to(nz1.dtype), nz1], 1))
+        return {"full": (c, e, s), "pick": pick, "single": (c1, e1, s1, x1, nz1), "ref": ref}
+    return _once("ddpm1000", make)
+
+
 def _err(a, b):
     a = a.detach().cpu().double().numpy() if isinstance(a, torch.Tensor) else np.asarray(a, dtype=np.float64)
     b = b.detach().cpu().double().numpy() if isinstance(b, torch.Tensor) else np.asarray(b, dtype=np.float64)
@@ -219,12 +238,11 @@ def test_ddpm1000_fp32_single_clip_vs_oracle(env, prec):
     """BASELINE config 2 shape: 1 clip, the full 1000-step ancestral DDPM, explicit x_T and per-step noise."""
     from amuse_amd import scheduler as sch
     orc, eng, Wd = env["orc"], env["eng"], env["Wd"]
-    gen = torch.Generator().manual_seed(77)
-    c, e, s, x = (torch.randn(1, n, generator=gen) for n in (256, 256, 256, 128))
-    nz = torch.randn(1000, 1, 128, generator=gen)
+    j = _ddpm1000_jobs(orc, Wd)
+    c, e, s, x, nz = j["single"]
     eng.set_schedule(sch.ddpm_table())
     lat = eng.sample(c, e, s, prec, x_init=x, step_noise=nz)
-    ref = _once("ddpm1000_single", lambda: orc.sample_latents(Wd, orc.DDPM(), c, e, s, x, nz))   # (40 s of CPU: shared by both parity modes)
+    ref = j["ref"][4:]
     scale = float(ref.abs().max())          # random weights drive the latent to rms ~ 30 (no clipping in DDPM)
     assert _err(lat, ref) < 3e-5 * scale    # measured 1.5e-4 abs on rms 31 (4.6e-6 relative)
 
@@ -572,14 +590,12 @@ def test_full_size_batch_values_against_the_oracle(env, prec):
     bar), decoded features <= 1e-4 + the latent difference carried through.  (The bf16 launch of the same shape: test_full_size_batch_properties.)"""
     from amuse_amd import scheduler as sch
     orc, eng, Wd, Wp = env["orc"], env["eng"], env["Wd"], env["Wp"]
-    gen = torch.Generator().manual_seed(3)
-    c, e, s = (torch.randn(256, 256, generator=gen) for _ in range(3))
+    j = _ddpm1000_jobs(orc, Wd)
+    c, e, s = j["full"]
+    pick = j["pick"]
     eng.set_schedule(sch.ddpm_table())
     out = eng.diffusion_backward(c, e, s, prec, seed=2024)
-    pick = [0, 1, 131, 255]
-    x0 = torch.from_numpy(orc.counter_normal(2024, np.array(pick), 0, 0))
-    nz = torch.stack([torch.from_numpy(orc.counter_normal(2024, np.array(pick), i, 1)) for i in range(1000)])
-    ref = _once("ddpm1000_full_size", lambda: orc.sample_latents(Wd, orc.DDPM(), c[pick], e[pick], s[pick], x0, nz))   # (75 s of CPU: shared by both parity modes)
+    ref = j["ref"][:4]
     scale = float(ref.abs().max())
     lat = out["latents"][pick].cpu()
     assert _err(lat, ref) < 3e-5 * scale, (_err(lat, ref), scale)
