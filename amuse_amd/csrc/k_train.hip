@@ -15,6 +15,7 @@
 // Column sums are deterministic: every workgroup writes its partial sums, a one-workgroup launch behind it adds them up in a fixed order.  All arrays fp32, row-major [rows][C]; HBM-bound by construction (each array is read or written once).
 
 #include <mutex>
+#include <type_traits>
 
 #include "amuse_dev.hpp"
 #include "amuse_host.hpp"
@@ -391,7 +392,7 @@ int blas_handle(hipStream_t st, void** h) {
 // lanes of a row group contiguous), i.e. MFMA tile t holds the block's rows m0 + 2 i + t (columns likewise): no transpose, no LDS.  The chunks' partial blocks go to
 // a workspace and a second kernel adds them IN ORDER (deterministic, like the step's other reductions).
 constexpr int kWgradMaxChunks = 64;
-constexpr int kWgradRows = 192;                       // rows per chunk (48 k-steps of the fp32 MFMA)
+constexpr int kWgradRows = 192;                       // rows per chunk (48 k-steps of the fp32 MFMA; 304-row chunks - one wave per SIMD at 9,600 rows - measured slower: 22.9 against 21.9 us)
 constexpr size_t kWgradWsFloats = (size_t)16 << 20;   // 64 MB of partial blocks per device: every weight gradient of one layer (10.7 M floats at 9,600 rows) until the layer's summing launch
 // STREAM = false: up to ~1,000 waves (one per SIMD); true: more - half of the chunk's loads in flight (~130 registers: three waves per SIMD), every k-step's registers
 // reloaded with the k-step 24 further on as soon as its MFMAs are issued.  MT = MFMA tiles of the wave's block along m: 2 (32 x 32 per wave, 64 x 64 per workgroup) or
@@ -410,38 +411,57 @@ __global__ __launch_bounds__(256) void k_train_wgrad(const float* __restrict__ d
     // MFMA (192 registers) and the MFMAs follow the data in as it arrives - one memory round trip per launch.  Rows past the chunk's end load a valid row
     // and count as zero.
     constexpr int NK = kWgradRows / 4, NL = STREAM ? NK / 2 : NK;
-    avec a[NL];
-    float2 b[NL];
-    auto fetch = [&](int slot, int u) {
-        const int rc = min(k0 + 4 * u + g, rows - 1);
-        a[slot] = *reinterpret_cast<const avec*>(dy + (size_t)rc * M + m0 + MT * r);
-        b[slot] = *reinterpret_cast<const float2*>(x + (size_t)rc * N + n0 + 2 * r);
-    };
-    auto multiply = [&](int slot, int u) {
-        const bool dead = k0 + 4 * u + g >= k1;
+    // fp32-input MFMAs hide no VALU work (profiles/r06_mfma_valu_samewave_probe.txt: every vector instruction beside them adds its ~6 cycles), and per-lane 64-bit
+    // addresses + the row clamp + the dead-row selects were ~9 vector instructions per k-step beside its 4-8 MFMAs (+30-40 % of the launch).  A FULL chunk (all
+    // 192 rows inside: every chunk at 9,600 rows) therefore reads through a wave-uniform row pointer + ONE per-lane offset (scalar address arithmetic, the loads'
+    // saddr form) and multiplies unconditionally; only a ragged last chunk takes the clamped / selected path.
+    const unsigned la = 4u * (unsigned)(g * M + m0 + MT * r), lb = 4u * (unsigned)(g * N + n0 + 2 * r);   // bytes; unsigned 32-bit: the loads' scalar-base + vector-offset form
+    const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(dy + (size_t)k0 * M), 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x + (size_t)k0 * N), 0, 0x7fffffff, 0x00020000);
+    auto run = [&](auto full_tag) {
+        constexpr bool FULL = decltype(full_tag)::value;
+        avec a[NL];
+        float2 b[NL];
+        auto fetch = [&](int slot, int u) {
+            if constexpr (FULL) {
+                // buffer loads: descriptor = the chunk's first row (wave-uniform), the k-step in the SCALAR offset, the lane's part in the one vector offset
+                if constexpr (MT == 4) a[slot] = __builtin_bit_cast(avec, __builtin_amdgcn_raw_buffer_load_b128(ra, (int)la, (int)((unsigned)(16 * u) * (unsigned)M), 0));
+                else a[slot] = __builtin_bit_cast(avec, __builtin_amdgcn_raw_buffer_load_b64(ra, (int)la, (int)((unsigned)(16 * u) * (unsigned)M), 0));
+                b[slot] = __builtin_bit_cast(float2, __builtin_amdgcn_raw_buffer_load_b64(rb, (int)lb, (int)((unsigned)(16 * u) * (unsigned)N), 0));
+            } else {
+                const int rc = min(k0 + 4 * u + g, rows - 1);
+                a[slot] = *reinterpret_cast<const avec*>(dy + (size_t)rc * M + m0 + MT * r);
+                b[slot] = *reinterpret_cast<const float2*>(x + (size_t)rc * N + n0 + 2 * r);
+            }
+        };
+        auto multiply = [&](int slot, int u) {
+            const bool dead = !FULL && k0 + 4 * u + g >= k1;
 #pragma unroll
-        for (int t = 0; t < MT; ++t) {
-            const float at = dead ? 0.f : a[slot][t];
-            acc[t][0] = mfma_f32(at, b[slot].x, acc[t][0]);
-            acc[t][1] = mfma_f32(at, b[slot].y, acc[t][1]);
+            for (int t = 0; t < MT; ++t) {
+                const float at = dead ? 0.f : a[slot][t];
+                acc[t][0] = mfma_f32(at, b[slot].x, acc[t][0]);
+                acc[t][1] = mfma_f32(at, b[slot].y, acc[t][1]);
+            }
+        };
+#pragma unroll
+        for (int u = 0; u < NL; ++u) fetch(u, u);
+        __builtin_amdgcn_sched_barrier(0);   // (hipcc otherwise interleaves loads and MFMAs to save registers: 42 instead of ~230, one round trip per k-step)
+        if constexpr (STREAM) {
+#pragma unroll
+            for (int u = 0; u < NL; ++u) {
+                multiply(u, u);
+                fetch(u, u + NL);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#pragma unroll
+            for (int u = 0; u < NL; ++u) multiply(u, u + NL);
+        } else {
+#pragma unroll
+            for (int u = 0; u < NK; ++u) multiply(u, u);
         }
     };
-#pragma unroll
-    for (int u = 0; u < NL; ++u) fetch(u, u);
-    __builtin_amdgcn_sched_barrier(0);   // (hipcc otherwise interleaves loads and MFMAs to save registers: 42 instead of ~230, one round trip per k-step)
-    if constexpr (STREAM) {
-#pragma unroll
-        for (int u = 0; u < NL; ++u) {
-            multiply(u, u);
-            fetch(u, u + NL);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-#pragma unroll
-        for (int u = 0; u < NL; ++u) multiply(u, u + NL);
-    } else {
-#pragma unroll
-        for (int u = 0; u < NK; ++u) multiply(u, u);
-    }
+    if (k0 + kWgradRows <= rows) run(std::true_type{});
+    else run(std::false_type{});
     // C fragment: lane (g, r), element v = tile row 4 g + v, tile column r  ->  dW row m0 + MT (4 g + v) + t, columns n0 + 2 r + {0, 1}
     float* o = part + (size_t)blockIdx.y * M * N;
 #pragma unroll
