@@ -28,7 +28,7 @@ EXPORTS = [
     "amuse_debug_tile", "amuse_debug_f16_split", "amuse_debug_set_decode_tap",
     "amuse_create_arch", "amuse_denoiser_param_count", "amuse_arch", "amuse_state_dim", "amuse_denoise_step_pose", "amuse_feats_to_smplx",
     "amuse_debug_set_ablation",
-    "amuse_train_ws_floats", "amuse_train_ln_fwd", "amuse_train_ln_bwd", "amuse_train_bias_gelu_drop_fwd", "amuse_train_bias_gelu_drop_bwd", "amuse_train_colsum",
+    "amuse_train_ws_floats", "amuse_train_set_lane", "amuse_train_ln_fwd", "amuse_train_ln_bwd", "amuse_train_bias_gelu_drop_fwd", "amuse_train_bias_gelu_drop_bwd", "amuse_train_colsum",
     "amuse_train_layer_fwd", "amuse_train_layer_bwd", "amuse_train_linear_fwd", "amuse_train_linear_bwd", "amuse_train_adamw", "amuse_train_adamw_dev", "amuse_train_epoch_advance", "amuse_train_epoch_set", "amuse_train_attn_fwd", "amuse_train_attn_bwd",
 ]
 
@@ -138,6 +138,8 @@ def load() -> C.CDLL:
     u64 = C.c_uint64
     lib.amuse_train_ws_floats.argtypes = []
     lib.amuse_train_ws_floats.restype = C.c_size_t
+    lib.amuse_train_set_lane.argtypes = [C.c_int]
+    lib.amuse_train_set_lane.restype = C.c_int
     lib.amuse_train_ln_fwd.argtypes = [vp, vp, vp, vp, vp, C.c_float, u64, u64, C.c_long, vp, vp, vp, vp]
     lib.amuse_train_ln_bwd.argtypes = [vp, vp, vp, vp, vp, C.c_float, u64, u64, C.c_long, vp, vp, vp, vp, vp, vp, vp]
     lib.amuse_train_bias_gelu_drop_fwd.argtypes = [vp, vp, C.c_float, u64, u64, C.c_long, C.c_int, vp, vp]

@@ -492,21 +492,26 @@ __global__ __launch_bounds__(256) void k_train_wgrad_sum(const float* __restrict
     const int c = threadIdx.x & 63;
     wgrad_sum_256(part, chunks, n4, (size_t)blockIdx.x * 64 + c, c, threadIdx.x >> 6, red, out);   // (n4 is a multiple of 64)
 }
-float* g_wgrad_ws[64] = {};
+// Two chains of layers may be in flight on two streams of a device (the trainer runs the Denoiser's forward / backward pass beside the prior's): every scratch buffer
+// of this file and of k_train_gemm.hip exists once per LANE, a small integer the calling thread sets in front of its calls (amuse_train_set_lane; 0 unless told otherwise)
+constexpr int kTrainLanes = 2;
+thread_local int g_train_lane = 0;
+float* g_wgrad_ws[64][kTrainLanes] = {};
 // gradients of at least this many elements go to the generic kernel (k_train_gemm.hip)
 constexpr long wgrad_max_elems() { return 131072L; }
 int wgrad_launch(const float* dy, const float* x, float* out, long rows, long M, long N, hipStream_t st) {
     int dev = 0;
     HIP_TRY(hipGetDevice(&dev));
     dev &= 63;
-    if (!g_wgrad_ws[dev]) HIP_TRY(hipMalloc((void**)&g_wgrad_ws[dev], kWgradWsFloats * sizeof(float)));
+    const int lane = g_train_lane;
+    if (!g_wgrad_ws[dev][lane]) HIP_TRY(hipMalloc((void**)&g_wgrad_ws[dev][lane], kWgradWsFloats * sizeof(float)));
     const long chunks = (rows + kWgradRows - 1) / kWgradRows;
     const bool wide = M * N >= 65536 && !(M & 127);
     const long blocks = wide ? (M >> 7) * (N >> 6) : (M >> 6) * (N >> 6);
     // partials: behind the ones a layer has parked (g_layer_ws_used; 0 outside amuse_train_layer_bwd)
     const size_t need = (size_t)chunks * M * N;
     if (chunks > 1 && g_layer_ws_used + need > kWgradWsFloats) return fail(AMUSE_EINVAL, "weight-gradient workspace: %zu + %zu floats of %zu", g_layer_ws_used, need, kWgradWsFloats);
-    float* part = g_wgrad_ws[dev] + g_layer_ws_used;
+    float* part = g_wgrad_ws[dev][lane] + g_layer_ws_used;
     float* dst = chunks == 1 ? out : part;
     const dim3 grid((unsigned)blocks, (unsigned)chunks);
     if (wide) hipLaunchKernelGGL((k_train_wgrad<true, 4>), grid, dim3(256), 0, st, dy, x, dst, (int)rows, (int)M, (int)N);
@@ -606,11 +611,18 @@ int bias_rows_launch(const float* bias, long rows, int C, float* out, hipStream_
 }
 
 }  // namespace
+int train_lane() { return g_train_lane; }   // (k_train_gemm.hip's split-k workspace)
 }  // namespace amuse
 
 using namespace amuse;
 
 extern "C" {
+
+int amuse_train_set_lane(int lane) {
+    if (lane < 0 || lane >= kTrainLanes) return fail(AMUSE_EINVAL, "lane %d (0 .. %d)", lane, kTrainLanes - 1);
+    g_train_lane = lane;
+    return 0;
+}
 
 size_t amuse_train_ws_floats(void) { return 8 * kWsRegion; }   // 8 regions of [workgroups][up to 1,024 columns]: one per reduction of a layer's backward pass
 

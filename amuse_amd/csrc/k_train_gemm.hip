@@ -278,10 +278,11 @@ __global__ __launch_bounds__(256) void k_gemm_any_sum(const float* __restrict__ 
         out[i] = (accumulate ? out[i] : 0.f) + s + (bias ? bias[i % N] : 0.f);
     }
 }
-float* g_any_ws[64] = {};
+float* g_any_ws[64][2] = {};   // per device and lane (k_train.hip train_lane)
 constexpr size_t kAnyWsFloats = (size_t)4 << 20;   // 16 MB of partial tiles per device
 
 }  // namespace
+int train_lane();   // (k_train.hip: the calling thread's scratch lane)
 
 // Which of the step's projections run here: every tall one the tiling covers.  Back to back on hot operands rocBLAS is 20-25 % faster on the un-biased forward
 // projections with 384 / 512 outputs (and slower on everything else: biased calls, every input gradient dy W); inside the training step - operands produced by the
@@ -337,11 +338,12 @@ hipError_t launch_train_gemm_any(const float* a, const float* b, const float* bi
         hipError_t e = hipGetDevice(&dev);
         if (e != hipSuccess) return e;
         dev &= 63;
-        if (!g_any_ws[dev]) {
-            e = hipMalloc((void**)&g_any_ws[dev], kAnyWsFloats * sizeof(float));
+        const int lane = train_lane() & 1;
+        if (!g_any_ws[dev][lane]) {
+            e = hipMalloc((void**)&g_any_ws[dev][lane], kAnyWsFloats * sizeof(float));
             if (e != hipSuccess) return e;
         }
-        part = g_any_ws[dev];
+        part = g_any_ws[dev][lane];
     }
     const dim3 grid(gx, gy, (unsigned)chunks), block(256);
     const int acc = accumulate ? 1 : 0;

@@ -30,6 +30,7 @@ with large messages; there is nothing to overlap it with (it needs the complete 
 """
 from __future__ import annotations
 
+import contextlib
 import os
 import time
 from pathlib import Path
@@ -194,7 +195,7 @@ class GestureTrainer:
 
     def __init__(self, prior: MotionPrior, ldm: LatentDiffusionTrainModule, device, lr: float = 1e-4, loss_cfg: Optional[dict] = None,
                  inner_sampler: Optional[Callable] = None, process_group=None, world: int = 1, kind: Optional[str] = None,
-                 grads_mode: str = "steal", sampler_stream: bool = True, optimizer: str = "flat"):
+                 grads_mode: str = "steal", sampler_stream: bool = True, optimizer: str = "flat", denoiser_stream: bool = True):
         self.model = {"prior": prior.to(device), "ldm": ldm.to(device)}
         # torch.distributions.Normal validates its arguments with blocking device -> host reads (6 per iteration: the host then waits for the previous
         # iteration's backward + optimizer step before it dispatches anything of the next, tools/probes/train_host/sync_points.py).  Off on the GPU
@@ -268,6 +269,8 @@ class GestureTrainer:
             torch.backends.cuda.preferred_blas_library("cublas")
         self._ar_events: list = []
         self._side_stream = None
+        self.denoiser_stream = denoiser_stream     # the Denoiser's forward / backward chain on a stream of its own beside the prior's (False: in line; tests)
+        self._den_stream = None
 
     def n_grad_elements(self) -> int:
         return int(self.flat_grad.numel())
@@ -296,16 +299,32 @@ class GestureTrainer:
                 side.wait_stream(torch.cuda.current_stream(self.device))     # the weights of the last optimizer step, the conditions
                 with torch.cuda.stream(side), torch.no_grad():
                     gen = self.inner_sampler(con, emo, sty, motion.shape[0])
+        # The Denoiser's chain (the no-gradient encode that feeds it, its forward pass and - autograd runs a node's backward pass on its forward pass's stream - its
+        # backward pass) shares nothing with the prior's encode -> decode chain but the inputs: 160-row layers, ~1.4 ms of launches that each leave most of the chip
+        # idle.  On the GPU it is issued on a stream of its own (scratch lane 1 of the library, train_ops.register_lane) beside the prior's 9,600-row kernels.
+        den = None
+        if self.device.type == "cuda" and self.denoiser_stream and _train_ops_enabled():
+            if self._den_stream is None:
+                from . import train_ops
+                self._den_stream = torch.cuda.Stream(self.device)
+                train_ops.register_lane(self._den_stream, 1)
+            den = self._den_stream
+            den.wait_stream(torch.cuda.current_stream(self.device))          # motion, the conditions, the weights
         motion_z, dist_m = prior.encode(motion, lengths)
         if eps_enc is not None:                       # explicit rsample draw (tests): z = mu + std * eps
             motion_z = dist_m.loc + dist_m.scale * eps_enc.to(self.device)
         feats_rst = prior.decode(motion_z, lengths)
         dist_ref = torch.distributions.Normal(torch.zeros_like(dist_m.loc), torch.ones_like(dist_m.scale), validate_args=prior.validate_args)
-        with torch.no_grad():
-            inferred_z, dist_i = prior.encode(motion, lengths)
-            if eps_inf is not None:
-                inferred_z = dist_i.loc + dist_i.scale * eps_inf.to(self.device)
-        n_set = ldm.diffusion_forward(inferred_z, con, emo, sty, lengths=lengths, noise=noise, timesteps=timesteps)
+        with (torch.cuda.stream(den) if den is not None else contextlib.nullcontext()):
+            with torch.no_grad():
+                inferred_z, dist_i = prior.encode(motion, lengths)
+                if eps_inf is not None:
+                    inferred_z = dist_i.loc + dist_i.scale * eps_inf.to(self.device)
+            n_set = ldm.diffusion_forward(inferred_z, con, emo, sty, lengths=lengths, noise=noise, timesteps=timesteps)
+        if den is not None:                           # join in front of the losses (the backward pass forks and joins by itself: autograd's stream semantics)
+            torch.cuda.current_stream(self.device).wait_stream(den)
+            for t in (n_set["noise_pred"], n_set["noise"]):
+                t.record_stream(torch.cuda.current_stream(self.device))
         if side is not None:                          # join: the losses read `gen`, and the optimizer step must not overtake the sampler's reads of the weights
             torch.cuda.current_stream(self.device).wait_stream(side)
             gen.record_stream(torch.cuda.current_stream(self.device))
@@ -618,6 +637,11 @@ class TrainModeInnerSampler:
         return (feats, x) if return_latents else feats
 
 
+def _train_ops_enabled() -> bool:
+    from . import train_ops
+    return train_ops.enabled()
+
+
 def ablation_kind(lmdb_id: Optional[str]) -> Optional[str]:
     """The ablation variant the reference derives from the LMDB cache id (trainer.py:396-401): full | emotion | identity | baseline."""
     if not lmdb_id:
@@ -633,7 +657,7 @@ def ablation_kind(lmdb_id: Optional[str]) -> Optional[str]:
 def build_trainer(device, rank: int = 0, world: int = 1, process_group=None, seed: int = 0, use_hip_sampler: bool = True,
                   dropout: float = 0.1, sampler_refresh: int = 1, ldm_cfg: Optional[dict] = None, lr: float = 1e-4,
                   kind: Optional[str] = None, inner: Optional[str] = None, grads_mode: str = "steal", sampler_stream: bool = True,
-                  optimizer: str = "flat") -> GestureTrainer:
+                  optimizer: str = "flat", denoiser_stream: bool = True) -> GestureTrainer:
     """Random-init prior + ldm (the deterministic weights of amuse_amd/weights.py, identical on every rank - what DDP's
     initial broadcast gives the reference's DataParallel-less single-GPU run) and the trainer around them.
     lr = TRAIN_PARAM.latent_diffusion.lr_base (trainer.py:181-184); ldm_cfg = configs/<arch>.json merged with diff_o.yaml (its
@@ -648,7 +672,7 @@ def build_trainer(device, rank: int = 0, world: int = 1, process_group=None, see
     if (ldm_cfg or {}).get("losses") is not None:   # trainer.py:175-177: SMPL-X data switches the joints terms off; the vertex terms are not built
         loss_cfg = dict(ldm_cfg["losses"], use_recons_joints=False, vtex_displacement=False)
     tr = GestureTrainer(prior, ldm, device, lr=lr, loss_cfg=loss_cfg, inner_sampler=None, process_group=process_group,
-                        world=world, kind=None if kind == "full" else kind, grads_mode=grads_mode, sampler_stream=sampler_stream, optimizer=optimizer)
+                        world=world, kind=None if kind == "full" else kind, grads_mode=grads_mode, sampler_stream=sampler_stream, optimizer=optimizer, denoiser_stream=denoiser_stream)
     inner = inner or os.environ.get("AMUSE_TRAIN_INNER", "eval")
     if inner not in ("eval", "train"):
         raise ValueError(f"inner sampler {inner!r}: 'eval' (the persistent HIP sampler kernel, default) or 'train' (the reference's train-mode semantics, dropout live)")

@@ -23,6 +23,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+import threading
 from typing import Optional, Tuple
 
 import torch
@@ -42,11 +43,38 @@ def usable(x: torch.Tensor, mask) -> bool:
     return enabled() and x.is_cuda and x.dtype == torch.float32 and mask is None and x.shape[-1] == 128
 
 
+# ---- lanes: two chains of layers may be in flight on two streams of a device (the trainer issues the Denoiser's forward / backward pass on a stream of its own
+# beside the prior's).  Every scratch buffer - this module's column-sum workspace, the library's split-k partials - exists once per LANE; a stream registered with
+# register_lane runs on lane 1, every other stream on lane 0.  Autograd runs a node's backward pass on the stream of its forward pass, so both directions of a
+# chain land on the chain's lane without the layer functions knowing about it.
+_LANES: dict = {}
+_TLS = threading.local()
+
+
+def register_lane(stream: "torch.cuda.Stream", lane: int = 1):
+    assert lane in (0, 1)
+    _LANES[int(stream.cuda_stream)] = lane
+
+
+def _lane(device) -> int:
+    return _LANES.get(torch.cuda.current_stream(device).cuda_stream, 0) if _LANES else 0
+
+
+class _State(dict):
+    """{"lib", "ws" (the CURRENT lane's column-sum workspace), "ws_all"}"""
+
+    def __getitem__(self, k):
+        if k == "ws":
+            return dict.__getitem__(self, "ws_all")[_lane(dict.__getitem__(self, "device"))]
+        return dict.__getitem__(self, k)
+
+
 def _st(device):
     s = _STATE.get(device)
     if s is None:
         lib = _lib.load()
-        s = {"lib": lib, "ws": torch.empty(int(lib.amuse_train_ws_floats()), device=device, dtype=torch.float32)}
+        n = int(lib.amuse_train_ws_floats())
+        s = _State(lib=lib, device=device, ws_all=[torch.empty(n, device=device, dtype=torch.float32) for _ in range(2)])
         _STATE[device] = s
     return s
 
@@ -70,6 +98,11 @@ class _on:
             self.idx = self.prev
         if self.prev != self.idx:
             torch.cuda.set_device(self.idx)
+        if _LANES or getattr(_TLS, "lane", 0):      # the library's scratch lane of this thread follows the current stream (one dict lookup; nothing while no lane is registered)
+            lane = _LANES.get(torch.cuda.current_stream(self.idx).cuda_stream, 0)
+            if lane != getattr(_TLS, "lane", 0):
+                _lib.check(_lib.load().amuse_train_set_lane(lane))
+                _TLS.lane = lane
 
     def __exit__(self, *exc):
         if self.prev != self.idx:

@@ -363,6 +363,10 @@ int amuse_debug_f16_split(const float* w, size_t n, uint16_t* hi, uint16_t* lo);
  * `ws` (amuse_train_ws_floats() floats) holds the partial column sums of a call (deterministic: added up in a fixed order by a second launch) and
  * must not be shared by calls that may overlap on different streams. */
 size_t amuse_train_ws_floats(void);
+/* The library's OWN scratch (split-k partials of the weight gradients and of the generic GEMM) exists once per device and LANE (0 or 1): calls that may overlap on two
+ * streams of a device - the trainer issues the Denoiser's forward / backward pass beside the prior's - run on different lanes.  Sets the lane of the CALLING THREAD for
+ * its following amuse_train_* calls (initially 0). */
+int amuse_train_set_lane(int lane);
 /* out = LayerNorm_128(x + dropout(y + bias)) (x, bias nullable); zhat [rows][128] = the normalised rows and rstd [rows] for the backward
  * pass (both nullable) */
 int amuse_train_ln_fwd(const float* x, const float* y, const float* bias, const float* gamma, const float* beta, float p, uint64_t seed,
