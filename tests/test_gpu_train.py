@@ -172,6 +172,30 @@ def test_inner_sampler_on_its_own_stream_changes_nothing(monkeypatch):
 
 
 
+def test_denoiser_chain_on_its_own_stream_changes_nothing():
+    """The Denoiser's chain (the no-gradient encode that feeds it, its forward and backward pass) is issued on a stream of its own beside the prior's
+    (GestureTrainer.forward_losses; scratch lane 1 of the library): with the same seeds, the iteration's loss terms AND every parameter after three optimizer
+    steps are BITWISE those of the in-line order - same kernels, same operands, another stream."""
+    from amuse_amd import train_ops
+    from amuse_amd.train_gesture import build_trainer, synthetic_batch
+    res = {}
+    for den in (True, False):
+        torch.manual_seed(3)
+        train_ops._OFFSET[0] = 0
+        tr = build_trainer("cuda:0", seed=1, denoiser_stream=den, grads_mode="sink")
+        terms = []
+        for i in range(3):
+            tr.train_step(synthetic_batch(32, 10 + i, "cuda:0"))
+            terms.append({k: float(v) for k, v in tr.lpdm_losses.compute().items()})
+        torch.cuda.synchronize()
+        res[den] = (terms, tr.flat_param.detach().clone(), tr.flat_grad.detach().clone())
+        assert (tr._den_stream is not None) == den
+    for a, b in zip(res[True][0], res[False][0]):
+        assert a == b
+    assert torch.equal(res[True][1], res[False][1]) and torch.equal(res[True][2], res[False][2])
+    assert float(res[True][2].abs().max()) > 0
+
+
 def test_train_mode_inner_sampler_on_the_gpu():
     """The opt-in reference-semantics inner sampler (train_gesture.TrainModeInnerSampler) on the GPU: in eval mode its DDIM-50 latents are the persistent
     HIP sampler's fp32 latents for the SAME clips (both start from the library's counter-based normals: <= 1e-4) and its features the HIP decode's; in
