@@ -48,6 +48,11 @@ tail -1 $O/train_bench.json > profiles/${R}_train_bench_line.json
 [ -f $O/attend32_probe.txt ] && cp $O/attend32_probe.txt profiles/${R}_attend32_probe_runs.txt
 [ -f $O/train_profile_vendor_gemm.txt ] && cp $O/train_profile_vendor_gemm.txt profiles/${R}_train_step_torch_profile_vendor_gemm.txt
 [ -f $O/mfma_f32_rate_probe.txt ] && cp $O/mfma_f32_rate_probe.txt profiles/${R}_mfma_f32_rate_probe.txt
+[ -f $O/mfma_valu_coissue_probe.txt ] && cp $O/mfma_valu_coissue_probe.txt profiles/${R}_mfma_valu_coissue_probe.txt
+[ -f $O/mfma_valu_samewave_probe.txt ] && cp $O/mfma_valu_samewave_probe.txt profiles/${R}_mfma_valu_samewave_probe.txt
+[ -f $O/train_host_vs_device.txt ] && cp $O/train_host_vs_device.txt profiles/${R}_train_host_vs_device.txt
+f=$(ls -t $O/train_stats/*/*_kernel_stats.csv 2>/dev/null | head -1); [ -n "$f" ] && python3 tools/probes/train_host/kernel_stats_per_iteration.py "$f" 40 60 > profiles/${R}_train_kernels_per_iteration.txt
+[ -f $O/train_attn_perf.txt ] && grep -v libdrm $O/train_attn_perf.txt > profiles/${R}_train_attention_per_call.txt
 [ -f $O/train_bench_vendor_attn.json ] && tail -1 $O/train_bench_vendor_attn.json > profiles/${R}_train_bench_line_vendor_attention.json
 [ -f $O/dec_perf.txt ] && grep -v libdrm $O/dec_perf.txt > profiles/${R}_trans_dec_sampler_perf.txt
 grep -v libdrm $O/phase8.txt > profiles/${R}_k_sample8_phase_timeline.txt
