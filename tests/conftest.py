@@ -26,6 +26,30 @@ def pytest_collection_modifyitems(config, items):
             it.add_marker(skip)
 
 
+def pytest_collection_finish(session):
+    """A GPU session that holds the two DDPM-1000 parity tests: their shared oracle run (~60 s of CPU, tests/tools/ddpm1000_job.py) starts NOW as a child process
+    (CPU only: no GPU visible to it) and runs beside the GPU tests in front of them; tests/test_gpu_parity.py picks its result up, or computes it in line."""
+    import subprocess
+    import tempfile
+
+    import torch
+    if not torch.cuda.is_available() or getattr(pytest, "_amuse_ddpm1000", None) is not None:
+        return
+    if not any("gpu" in it.keywords and ("test_ddpm1000_fp32_single_clip_vs_oracle" in it.nodeid or "test_full_size_batch_values_against_the_oracle" in it.nodeid)
+               for it in session.items):
+        return
+    out = Path(tempfile.mkdtemp(prefix="amuse_ddpm1000_")) / "ref.npy"
+    env = dict(os.environ, HIP_VISIBLE_DEVICES="", CUDA_VISIBLE_DEVICES="", OMP_NUM_THREADS="4")
+    proc = subprocess.Popen([sys.executable, str(REPO / "tests" / "tools" / "ddpm1000_job.py"), str(out)], env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    pytest._amuse_ddpm1000 = (proc, out)
+
+
+def pytest_sessionfinish(session, exitstatus):
+    pre = getattr(pytest, "_amuse_ddpm1000", None)
+    if pre is not None and pre[0].poll() is None:
+        pre[0].kill()          # (the exact child this session started)
+
+
 @pytest.fixture(scope="session")
 def host_asan_build(tmp_path_factory):
     """tests/host_asan/build.sh once per session: the library's host code + the stubbed HIP runtime under ASan / UBSan -> directory holding `host_asan`

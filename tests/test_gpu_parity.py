@@ -9,6 +9,9 @@ Tolerances
                per block, teacher-forced on the kernel's OWN block inputs (<= 1e-4 for most blocks);
                whole-network eps_hat is held to 5e-2 abs (|eps| ~ 3).
 """
+import sys
+from pathlib import Path
+
 import numpy as np
 import pytest
 import torch
@@ -50,21 +53,26 @@ def _once(key, fn):
 
 
 def _ddpm1000_jobs(orc, Wd):
-    """The two 1000-step oracle runs of this file as ONE (the oracle's cost is per step, not per clip: ~75 s of CPU, shared by both tests and both parity modes):
-    rows 0..3 = clips 0, 1, 131, 255 of the 256-clip job with the counter-based noise of seed 2024 (keyed by the global clip index), row 4 = the single clip with
-    explicit x_T and per-step noise."""
+    """tests/tools/ddpm1000_job.py: the two 1000-step oracle runs of this file as ONE (shared by both tests and both parity modes) - taken from the child process
+    tests/conftest.py started at the session's start when there is one (the CPU work then ran beside the GPU tests in front of these), else computed here."""
     def make():
-        gen = torch.Generator().manual_seed(3)
-        c, e, s = (torch.randn(256, 256, generator=gen) for _ in range(3))
-        pick = [0, 1, 131, 255]
-        x0 = torch.from_numpy(orc.counter_normal(2024, np.array(pick), 0, 0))
-        nz = torch.stack([torch.from_numpy(orc.counter_normal(2024, np.array(pick), i, 1)) for i in range(1000)])
-        gen1 = torch.Generator().manual_seed(77)
-        c1, e1, s1, x1 = (torch.randn(1, n, generator=gen1) for n in (256, 256, 256, 128))
-        nz1 = torch.randn(1000, 1, 128, generator=gen1)
-        ref = orc.sample_latents(Wd, orc.DDPM(), torch.cat([c[pick], c1]), torch.cat([e[pick], e1]), torch.cat([s[pick], s1]), torch.cat([x0.to(x1.dtype), x1]),
-                                 torch.cat([nz.to(nz1.dtype), nz1], 1))
-        return {"full": (c, e, s), "pick": pick, "single": (c1, e1, s1, x1, nz1), "ref": ref}
+        import time
+        sys.path.insert(0, str(Path(__file__).resolve().parent / "tools"))
+        import ddpm1000_job as job
+        j = job.inputs(orc)
+        pre = getattr(pytest, "_amuse_ddpm1000", None)
+        ref = None
+        if pre is not None:
+            proc, out = pre
+            t0 = time.time()
+            while proc.poll() is None and time.time() - t0 < 600:
+                time.sleep(0.2)
+            if proc.poll() == 0 and out.exists():
+                ref = torch.from_numpy(np.load(out))
+        if ref is None:
+            ref = job.oracle_latents(orc, Wd, j)
+        j["ref"] = ref
+        return j
     return _once("ddpm1000", make)
 
 
