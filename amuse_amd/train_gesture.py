@@ -759,6 +759,9 @@ def bench_main(args):
                        "hip_graph": graphed, "hip_graph_note": graph_note + (" - forward + losses + backward (+ the side-stream sampler) and the optimizer step replayed as two HIP graphs "
                                                                           "around the all-reduce; fresh draws per replay: torch's graph-safe generator, the library's device-side dropout "
                                                                           "epoch and AdamW step count" if graphed else ""),
+                       "streams": ("three: the prior's encode -> decode chain, the Denoiser's chain (no-gradient encode, forward, backward; library scratch lane 1), the "
+                                   "no-gradient sampler + decode - forked and joined inside the iteration (parallel branches of the graph)") if tr._den_stream is not None
+                                  else "the networks' chain + the no-gradient sampler's side stream",
                        "gemm": "own",
                        "gemm_detail": "hand-written HIP (fp32 MFMA) for every GEMM of the networks: the tall projections and input gradients (k_train_gemm_tall), the chunked "
                                       "weight-gradient reductions (k_train_wgrad), and the generic kernel (k_train_gemm_any) for the 333-wide embedding / output layers, the 32-row "
