@@ -107,7 +107,8 @@ __device__ __forceinline__ void workgroup_partial(f32x4 acc, int nc4, int lanes,
 __global__ __launch_bounds__(kTrainThreads) void k_train_ln_bwd(const float* dout, const float* dout2, const float* __restrict__ zhat, const float* __restrict__ rstd_in,
                                                       const float* __restrict__ gamma, uint32_t thr, float scale, uint64_t seed, uint64_t offset, const uint32_t* __restrict__ epoch, long rows,
                                                       float* dx, float* dy, float* ws) {
-    offset += (uint64_t)*epoch << 32;   // the device-side dropout epoch (train_epoch_ptr): fresh masks per replay of a captured step   // (dx may be dout, dy may be dout2: same thread, same elements)
+    // (dx may be dout, dy may be dout2: same thread, same elements)
+    offset += (uint64_t)*epoch << 32;   // the device-side dropout epoch (train_epoch_ptr): fresh masks per replay of a captured step
     __shared__ f32x4 red[kTrainThreads];
     const int cg = threadIdx.x & 31, rl = threadIdx.x >> 5;   // 32 row lanes
     const f32x4 ga = ld4(gamma + 4 * cg);
