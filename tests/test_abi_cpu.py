@@ -181,6 +181,8 @@ def test_training_entry_points_validate_their_arguments_without_touching_the_gpu
     lib = _lib.load()
     err = lambda: lib.amuse_last_error().decode()
     assert lib.amuse_train_ws_floats() >= 8 * 128 * 1024
+    assert lib.amuse_train_set_lane(2) != 0 and "lane" in err() and lib.amuse_train_set_lane(-1) != 0          # two scratch lanes per device: 0 and 1
+    assert lib.amuse_train_set_lane(1) == 0 and lib.amuse_train_set_lane(0) == 0
     one = 0x1000                                              # (a non-null address that is never dereferenced: every call below fails in its checks)
     assert lib.amuse_train_ln_fwd(None, None, None, one, one, 0.1, 1, 1, 16, one, None, None, None) != 0 and "must be given" in err()
     assert lib.amuse_train_ln_fwd(None, one, None, one, one, 0.1, 1, 1, 0, one, None, None, None) != 0 and "rows" in err()
