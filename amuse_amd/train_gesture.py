@@ -304,11 +304,15 @@ class GestureTrainer:
         # idle.  On the GPU it is issued on a stream of its own (scratch lane 1 of the library, train_ops.register_lane) beside the prior's 9,600-row kernels.
         den = None
         if self.device.type == "cuda" and self.denoiser_stream and _train_ops_enabled():
+            from . import train_ops
             if self._den_stream is None:
-                from . import train_ops
                 self._den_stream = torch.cuda.Stream(self.device)
-                train_ops.register_lane(self._den_stream, 1)
             den = self._den_stream
+            if den.cuda_stream == torch.cuda.current_stream(self.device).cuda_stream:
+                den = None                            # (the pool handed this trainer the stream it is running on: nothing to fork onto)
+            else:
+                train_ops.register_lane(den, 1)       # (every iteration: the one lane-1 stream of the process is this trainer's)
+        if den is not None:
             den.wait_stream(torch.cuda.current_stream(self.device))          # motion, the conditions, the weights
         motion_z, dist_m = prior.encode(motion, lengths)
         if eps_enc is not None:                       # explicit rsample draw (tests): z = mu + std * eps

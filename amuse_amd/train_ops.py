@@ -52,8 +52,13 @@ _TLS = threading.local()
 
 
 def register_lane(stream: "torch.cuda.Stream", lane: int = 1):
+    """`stream` is THE stream of lane `lane` from now on (one at a time: torch hands out streams from a pool of 32 per device, so a handle registered by a
+    trainer long gone may come back as somebody's main or capture stream - a stale entry would put two concurrent chains on one lane)."""
     assert lane in (0, 1)
-    _LANES[int(stream.cuda_stream)] = lane
+    h = int(stream.cuda_stream)
+    if _LANES.get(h) != lane or len(_LANES) != 1:
+        _LANES.clear()
+        _LANES[h] = lane
 
 
 def _lane(device) -> int:
