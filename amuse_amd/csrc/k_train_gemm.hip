@@ -42,6 +42,9 @@ __device__ __forceinline__ void wait_vm_le() { asm volatile("s_waitcnt vmcnt(%0)
 constexpr int kGemmCopyWaves = 4;
 // MT = 16-row tiles per workgroup (3: 48 rows, 2: 32 rows); TB: b is [N][K] (out = a b^T), else [K][N]
 // kGemmBufs = LDS buffers of the chunk ring (3: two chunks in flight under the MFMAs of a third; 2: one - and room for four workgroups per CU)
+// (Round 6: a workgroup walking SEVERAL row tiles as one stream of chunks - 512 resident workgroups, the next tile's first chunks fetched under the current tile's
+// last MFMAs and epilogue - measured no faster: 20.2 against 19.6 us at 9,600 x 512 x 128, 15.1 against 15.6 at 384 wide; the one-tile launch's dynamic balance is
+// worth what the saved prologues are.)
 template <int MT, bool TB, int kGemmBufs>
 __global__ __launch_bounds__(64 * (4 + kGemmCopyWaves)) void k_train_gemm_tall(const float* __restrict__ a, const float* __restrict__ b, const float* __restrict__ bias, float* __restrict__ out,
                                                          int M, int N, int K, int accumulate) {
