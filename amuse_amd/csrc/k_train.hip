@@ -109,7 +109,7 @@ __global__ __launch_bounds__(kTrainThreads) void k_train_ln_bwd(const float* dou
                                                       float* dx, float* dy, float* ws) {
     // (dx may be dout, dy may be dout2: same thread, same elements)
     offset += (uint64_t)*epoch << 32;   // the device-side dropout epoch (train_epoch_ptr): fresh masks per replay of a captured step
-    __shared__ f32x4 red[kTrainThreads];
+    __shared__ f32x4 red[3 * kTrainThreads];
     const int cg = threadIdx.x & 31, rl = threadIdx.x >> 5;   // 32 row lanes
     const f32x4 ga = ld4(gamma + 4 * cg);
     f32x4 sg = splat4(0.f), sb = splat4(0.f), sy = splat4(0.f);
@@ -144,12 +144,19 @@ __global__ __launch_bounds__(kTrainThreads) void k_train_ln_bwd(const float* dou
             }
         }
     }
-    float* wrow = ws + (size_t)blockIdx.x * 384;
-    workgroup_partial(sg, 32, 32, wrow, red);
+    // the workgroup's three partial rows at once: threads 0..31 add up sg's 32 row lanes, 32..63 sb's, 64..95 sy's - each in row-lane order, as workgroup_partial does
+    // (one barrier and one pass of 32 dependent LDS reads instead of three of each)
+    red[threadIdx.x] = sg;
+    red[kTrainThreads + threadIdx.x] = sb;
+    red[2 * kTrainThreads + threadIdx.x] = sy;
     __syncthreads();
-    workgroup_partial(sb, 32, 32, wrow + 128, red);
-    __syncthreads();
-    workgroup_partial(sy, 32, 32, wrow + 256, red);
+    if (threadIdx.x < 96) {
+        const int which = threadIdx.x >> 5, c = threadIdx.x & 31;
+        const f32x4* src = red + which * kTrainThreads;
+        f32x4 sum = src[c];
+        for (int q = 1; q < 32; ++q) sum += src[q * 32 + c];
+        st4(ws + (size_t)blockIdx.x * 384 + which * 128 + 4 * c, sum);
+    }
 }
 __global__ __launch_bounds__(kTrainThreads) void k_train_finalize(const float* ws, int n, float* o0, float* o1, float* o2, int ncol, int C) {
     __shared__ f32x4 red[kTrainThreads];
