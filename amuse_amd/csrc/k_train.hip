@@ -400,7 +400,9 @@ int blas_handle(hipStream_t st, void** h) {
 // lanes of a row group contiguous), i.e. MFMA tile t holds the block's rows m0 + 2 i + t (columns likewise): no transpose, no LDS.  The chunks' partial blocks go to
 // a workspace and a second kernel adds them IN ORDER (deterministic, like the step's other reductions).
 constexpr int kWgradMaxChunks = 64;
-constexpr int kWgradRows = 192;                       // rows per chunk (48 k-steps of the fp32 MFMA; 304-row chunks - one wave per SIMD at 9,600 rows - measured slower: 22.9 against 21.9 us)
+constexpr int kWgradRows = 192;                       // rows per chunk (48 k-steps of the fp32 MFMA; 304-row chunks - one wave per SIMD at 9,600 rows - measured slower: 22.9 against 21.9 us;
+                                                      // so did a workgroup's four waves taking four consecutive chunks of ONE block and adding them up through LDS - a quarter of the partials, but no
+                                                      // operand shared between the waves any more: 26.8 us)
 constexpr size_t kWgradWsFloats = (size_t)16 << 20;   // 64 MB of partial blocks per device: every weight gradient of one layer (10.7 M floats at 9,600 rows) until the layer's summing launch
 // STREAM = false: up to ~1,000 waves (one per SIMD); true: more - half of the chunk's loads in flight (~130 registers: three waves per SIMD), every k-step's registers
 // reloaded with the k-step 24 further on as soon as its MFMAs are issued.  MT = MFMA tiles of the wave's block along m: 2 (32 x 32 per wave, 64 x 64 per workgroup) or
