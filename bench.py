@@ -370,6 +370,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-audio", action="store_true", help="skip the audio front-end side measurement")
     ap.add_argument("--no-extras", action="store_true", help="headline + roofline only (profiling runs)")
+    ap.add_argument("--no-torch-baseline", dest="no_torch_baseline", action="store_true", help="skip the PyTorch-ROCm eager restatement of the job (torch_eager_baseline, ~3 s)")
     ap.add_argument("--no-graph", dest="no_graph", action="store_true", help="--config train: the eager step instead of the two captured HIP graphs (A/B)")
     ap.add_argument("--edit-batch", action="store_true", help="with --no-extras: still run the edit_batch extra (BASELINE config 5's shape, every rank takes part)")
     args = ap.parse_args()
@@ -759,6 +760,16 @@ def main():
                 line["train_gesture"] = {"error": f"{type(e).__name__}: {e}; stderr tail: {r.stderr[-300:] if r is not None else ''}"}
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(total, args.T, wd, wp)
+        if world == 1 and not args.no_torch_baseline and args.T == 1000:
+            # the reference's own FORM of this job on this GPU: PyTorch-ROCm eager modules in a Python denoising loop (tools/gpu_torch_eager_baseline.py - the build's torch
+            # twins of the reference modules on torch's stock layers; the reference itself cannot travel to the GPU box).  ~2 s per job + a 20-step warm-up.
+            try:
+                sys.path.insert(0, str(REPO / "tools"))
+                from gpu_torch_eager_baseline import WHAT, measure
+                tb = measure(total, dev, samplers=("DDPM-1000",), precisions=("fp32",), repeats=1)[0]
+                line["torch_eager_baseline"] = dict(tb, what=WHAT, speedup_of_value=round(line["value"] / tb["frames_per_s"], 1))
+            except Exception as e:   # the headline must not depend on the extra
+                line["torch_eager_baseline"] = {"error": f"{type(e).__name__}: {e}"}
     if line is not None:
         # every headline carries its parity-grade twin at the TOP level (the driver's parsed block keeps top-level scalars and `config`):
         # `value` is the configuration BASELINE.json names (bf16 operands); the mode that meets the north star's "< 1e-4" is fp32x
@@ -766,7 +777,8 @@ def main():
         twin = {"headline_precision": args.precision, "headline_eps_err_vs_reference": pm.get("bf16_eps_err") if args.precision == "bf16" else None,
                 "parity_precision": pm.get("precision"), "parity_frames_per_s": pm.get("frames_per_s"), "parity_ms_per_job": pm.get("ms_per_job"),
                 "parity_eps_err_vs_reference": pm.get("eps_err"), "parity_pose_l2_max_vs_reference": pm.get("pose_l2_max"),
-                "attention_frac_of_mfma_peak": att.get("frac_of_mfma_peak")}
+                "attention_frac_of_mfma_peak": att.get("frac_of_mfma_peak"),
+                "vs_torch_eager_same_gpu": line.get("torch_eager_baseline", {}).get("speedup_of_value")}
         line.update({k: v for k, v in twin.items()})
         line["config"]["parity_twin"] = twin
     barrier()

@@ -24,6 +24,7 @@ timeout 300 python tools/multigpu_preflight.py --gpus 1 > $O/multigpu_preflight_
 for m in eager graph; do echo "== $m"; timeout 200 python tools/probes/train_host/host_vs_device.py $m 2>&1 | grep -v "libdrm\|Warning\|warn"; done > $O/train_host_vs_device.txt
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/train_stats -- python3 bench.py --config train --steps 30 --warmup 10 --no-graph > $O/train_stats.log 2>&1
 timeout 200 python tools/gpu_encode_fp32x_ab.py > $O/encode_fp32x_ab.txt 2>&1
+timeout 300 python tools/gpu_torch_eager_baseline.py 256 2>&1 | grep -v libdrm > $O/torch_eager_baseline.txt     # the reference's own form of the job (PyTorch-ROCm eager twins) on this GPU
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python3 bench.py --steps 3 --warmup 1 --no-extras > $O/stats.log 2>&1
 for grp in FETCH_SIZE WRITE_SIZE "TCC_HIT_sum TCC_MISS_sum" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_ANY" "SQ_INSTS_MFMA SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_INSTS_SALU" "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_MISC SQ_BUSY_CU_CYCLES" "SQ_INST_CYCLES_VMEM SQ_WAIT_INST_LDS SQ_INSTS_VALU_TRANS_F32 SQ_INSTS_WAVE32_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE"; do
   n=$(echo $grp | cut -d' ' -f1)
