@@ -475,3 +475,52 @@ def test_attention_kernels_against_torch_math_attention(B, S):
             scale = float(g_ref[:, sl].abs().max())                                       # (one key: the softmax is constant, dq = dk = 0 exactly in the reference)
             assert float((dqkv[:, sl] - g_ref[:, sl]).abs().max()) < 2e-4 * scale + 1e-6, (pdrop, sl)
 
+
+
+def test_two_layer_chains_on_two_streams_do_not_share_scratch():
+    """Two chains of 9,600-row layers - forward AND backward, the chunked weight gradients with their split-k partials and the layers' summing launches included - in
+    flight on two streams of the device at once (stream 1 registered as scratch lane 1: train_ops.register_lane; the library's workspaces exist once per lane,
+    amuse_train_set_lane) give bitwise what each chain gives alone.  (The trainer's own second chain, the Denoiser's, has 160-row layers and never reaches the chunked
+    weight-gradient kernel: this is the test that lane 1 of THAT workspace works.)"""
+    from amuse_amd import train_ops
+    B, S = 32, 300
+    g = torch.Generator(device=DEV).manual_seed(5)
+    chains = []
+    for k in range(2):
+        m = _layers("enc" if k == 0 else "dec", 2).train()
+        x = torch.randn(B, S, 128, device=DEV, generator=g)
+        mem = torch.randn(B, 1, 128, device=DEV, generator=g)
+        dout = torch.randn(B, S, 128, device=DEV, generator=g)
+        chains.append((m, x, mem, dout, k))
+
+    def run(chain, off0):
+        m, x, mem, dout, k = chain
+        train_ops._OFFSET[0] = off0                     # the same dropout offsets in both runs
+        xr = x.clone().requires_grad_(True)
+        m.zero_grad(set_to_none=True)
+        out = m(xr) if k == 0 else m(xr, mem)
+        out.backward(dout)
+        return [out.detach().clone(), xr.grad.clone()] + [p.grad.clone() for p in m.parameters() if p.grad is not None]
+
+    torch.manual_seed(11)
+    alone = [run(c, 1000 * (i + 1)) for i, c in enumerate(chains)]
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream(DEV)
+    train_ops.register_lane(side, 1)
+    main = torch.cuda.current_stream(DEV)
+    both = [None, None]
+    try:
+        for rep in range(3):                            # a few rounds: the two chains' launches interleave differently every time
+            torch.cuda._sleep(60_000_000)               # ~25 ms on the main stream, the side stream behind it: BOTH chains are fully enqueued when they start, so they do run
+            side.wait_stream(main)                      # side by side (an eager host would otherwise finish issuing one before the other begins)
+            with torch.cuda.stream(side):
+                both[1] = run(chains[1], 2000)
+            both[0] = run(chains[0], 1000)
+            main.wait_stream(side)
+            torch.cuda.synchronize()
+            for a, b in zip(alone, both):
+                assert len(a) == len(b)
+                for ta, tb in zip(a, b):
+                    assert torch.equal(ta, tb)
+    finally:
+        train_ops._LANES.clear()
