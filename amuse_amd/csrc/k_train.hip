@@ -14,6 +14,7 @@
 // the backward kernels regenerate the mask from the same (seed, offset); keep <=> u >= p with u = the draw's top 24 bits / 2^24.
 // Column sums are deterministic: every workgroup writes its partial sums, a one-workgroup launch behind it adds them up in a fixed order.  All arrays fp32, row-major [rows][C]; HBM-bound by construction (each array is read or written once).
 
+#include <algorithm>
 #include <mutex>
 #include <type_traits>
 
@@ -413,7 +414,7 @@ __global__ __launch_bounds__(256) void k_train_wgrad(const float* __restrict__ d
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4, r = lane & 15;
     const int nbn = N >> 6, bm = blockIdx.x / nbn, bn = blockIdx.x - bm * nbn;
     const int m0 = bm * (32 * MT) + (wave >> 1) * (16 * MT), n0 = (bn << 6) + ((wave & 1) << 5);
-    const int k0 = blockIdx.y * kWgradRows, k1 = min(rows, k0 + kWgradRows);   // (rows is a multiple of 4)
+    int k0 = blockIdx.y * kWgradRows, k1 = min(rows, k0 + kWgradRows);   // (rows is a multiple of 4); the workgroup's chunks blockIdx.y, blockIdx.y + gridDim.y, ... (one up to 12,288 rows)
     f32x4 acc[MT][2];
 #pragma unroll
     for (int t = 0; t < MT; ++t) acc[t][0] = acc[t][1] = splat4(0.f);
@@ -426,8 +427,8 @@ __global__ __launch_bounds__(256) void k_train_wgrad(const float* __restrict__ d
     // 192 rows inside: every chunk at 9,600 rows) therefore reads through a wave-uniform row pointer + ONE per-lane offset (scalar address arithmetic, the loads'
     // saddr form) and multiplies unconditionally; only a ragged last chunk takes the clamped / selected path.
     const unsigned la = 4u * (unsigned)(g * M + m0 + MT * r), lb = 4u * (unsigned)(g * N + n0 + 2 * r);   // bytes; unsigned 32-bit: the loads' scalar-base + vector-offset form
-    const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(dy + (size_t)k0 * M), 0, 0x7fffffff, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x + (size_t)k0 * N), 0, 0x7fffffff, 0x00020000);
+    __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(dy + (size_t)k0 * M), 0, 0x7fffffff, 0x00020000);
+    __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x + (size_t)k0 * N), 0, 0x7fffffff, 0x00020000);
     auto run = [&](auto full_tag) {
         constexpr bool FULL = decltype(full_tag)::value;
         avec a[NL];
@@ -470,8 +471,15 @@ __global__ __launch_bounds__(256) void k_train_wgrad(const float* __restrict__ d
             for (int u = 0; u < NK; ++u) multiply(u, u);
         }
     };
-    if (k0 + kWgradRows <= rows) run(std::true_type{});
-    else run(std::false_type{});
+    for (;;) {
+        if (k0 + kWgradRows <= rows) run(std::true_type{});
+        else run(std::false_type{});
+        k0 += gridDim.y * kWgradRows;      // more than 64 chunks (batches beyond 12,288 rows): the workgroup goes on with chunk + 64, ... into the same accumulators
+        if (k0 >= rows) break;
+        k1 = min(rows, k0 + kWgradRows);
+        ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(dy + (size_t)k0 * M), 0, 0x7fffffff, 0x00020000);
+        rb = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x + (size_t)k0 * N), 0, 0x7fffffff, 0x00020000);
+    }
     // C fragment: lane (g, r), element v = tile row 4 g + v, tile column r  ->  dW row m0 + MT (4 g + v) + t, columns n0 + 2 r + {0, 1}
     float* o = part + (size_t)blockIdx.y * M * N;
 #pragma unroll
@@ -515,7 +523,7 @@ int wgrad_launch(const float* dy, const float* x, float* out, long rows, long M,
     dev &= 63;
     const int lane = g_train_lane;
     if (!g_wgrad_ws[dev][lane]) HIP_TRY(hipMalloc((void**)&g_wgrad_ws[dev][lane], kWgradWsFloats * sizeof(float)));
-    const long chunks = (rows + kWgradRows - 1) / kWgradRows;
+    const long chunks = std::min<long>((rows + kWgradRows - 1) / kWgradRows, kWgradMaxChunks);   // partial blocks (a workgroup takes every 64th chunk beyond that)
     const bool wide = M * N >= 65536 && !(M & 127);
     const long blocks = wide ? (M >> 7) * (N >> 6) : (M >> 6) * (N >> 6);
     // partials: behind the ones a layer has parked (g_layer_ws_used; 0 outside amuse_train_layer_bwd)
@@ -556,8 +564,8 @@ int rm_gemm(void* h, bool ta, bool tb, long M, long N, long K, const float* a, c
     if (bias && accumulate) return fail(AMUSE_EINVAL, "rm_gemm: bias and accumulate together");
     // (measured, profiles/r04_train_wgrad_kernel_ab.txt: 12 us against 25 for a 128 x 128 gradient over 9,664 rows, 21 against 26 for 384 x 128; the FFN's 512 x 128 - bound by
     // the fp32 MFMA rate and their 13 MB of partial blocks - 25 against 27.5 on the 64 x 32-per-wave instantiation)
-    if (ta && !tb && !accumulate && K >= 1024 && !(K & 3) && !(M & 63) && !(N & 63) && M * N < wgrad_max_elems() && (K + kWgradRows - 1) / kWgradRows <= kWgradMaxChunks &&
-        (size_t)(M * N) * ((K + kWgradRows - 1) / kWgradRows) <= kWgradWsFloats && !bias) {   // a weight gradient with a long reduction
+    if (ta && !tb && !accumulate && K >= 1024 && !(K & 3) && !(M & 63) && !(N & 63) && M * N < wgrad_max_elems() &&
+        (size_t)(M * N) * std::min<long>((K + kWgradRows - 1) / kWgradRows, kWgradMaxChunks) <= kWgradWsFloats && !bias) {   // a weight gradient with a long reduction
         return wgrad_launch(a, b, out, K, M, N, g_blas_stream[dev & 63]);
     }
     HIP_TRY(launch_train_gemm_any(a, b, bias, out, M, N, K, ta, tb, accumulate, g_blas_stream[dev & 63]));   // every other shape: 333-wide, 32 / 160 rows, short or wide gradients

@@ -714,7 +714,7 @@ def bench_main(args):
         dist.init_process_group("nccl", device_id=dev)
     torch.manual_seed(1234 + rank)
     tr = build_trainer(dev, rank, world)
-    bsz = 32
+    bsz = int(getattr(args, "train_batch", 32) or 32)     # BASELINE config 4: 32 per process (the reference's batch_size); --train-batch: a larger one as a further point
     batches = [synthetic_batch(bsz, 100 * rank + i, dev) for i in range(4)]
 
     def barrier():
@@ -751,7 +751,7 @@ def bench_main(args):
         ld = {k: round(float(v), 6) for k, v in tr.lpdm_losses.compute().items()}
         sync = tr.inner_sampler.sync_ms if tr.inner_sampler is not None else []
         print(json.dumps({
-            "metric": "train_gesture iterations/sec (data-parallel step, batch 32 per GPU)", "value": round(its, 3), "unit": "it/s",
+            "metric": f"train_gesture iterations/sec (data-parallel step, batch {bsz} per GPU)", "value": round(its, 3), "unit": "it/s",
             "n_gpus": world, "world_size_seen": dist.get_world_size() if world > 1 else 1, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",

@@ -370,6 +370,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-audio", action="store_true", help="skip the audio front-end side measurement")
     ap.add_argument("--no-extras", action="store_true", help="headline + roofline only (profiling runs)")
+    ap.add_argument("--train-batch", dest="train_batch", type=int, default=32, help="--config train: clips per GPU and iteration (BASELINE config 4: 32)")
     ap.add_argument("--no-torch-baseline", dest="no_torch_baseline", action="store_true", help="skip the PyTorch-ROCm eager restatement of the job (torch_eager_baseline, ~3 s)")
     ap.add_argument("--no-graph", dest="no_graph", action="store_true", help="--config train: the eager step instead of the two captured HIP graphs (A/B)")
     ap.add_argument("--edit-batch", action="store_true", help="with --no-extras: still run the edit_batch extra (BASELINE config 5's shape, every rank takes part)")

@@ -404,8 +404,9 @@ def _lib_check(rc):
 
 # the tall projections of the 27 transformer layers (k_train_gemm_tall) | every other shape of the step on the generic kernel (k_train_gemm_any): the 333-wide
 # embedding / output layers (no 16-byte rows), the Denoiser's 32-row condition projections and 160-row layers, a 1-row call, ragged everything
+# (13,444 and 38,400 rows: more than 64 chunks of the weight-gradient kernel - a workgroup goes on with every 64th chunk: batches beyond 12,288 rows)
 _LINEAR_SHAPES = [(9664, 128, 128), (9600, 384, 128), (9600, 512, 128), (9600, 128, 512), (9600, 128, 256), (1030, 256, 384), (1024, 128, 32),
-                  (9600, 128, 333), (9600, 333, 128), (32, 128, 256), (32, 128, 128), (160, 384, 128), (160, 128, 512), (1, 5, 3), (77, 130, 67), (3000, 65, 1000)]
+                  (9600, 128, 333), (9600, 333, 128), (13444, 128, 128), (38400, 512, 128), (32, 128, 256), (32, 128, 128), (160, 384, 128), (160, 128, 512), (1, 5, 3), (77, 130, 67), (3000, 65, 1000)]
 
 
 @pytest.mark.parametrize("rows,N,K", _LINEAR_SHAPES)

@@ -50,6 +50,7 @@ tail -1 $O/train_bench.json > profiles/${R}_train_bench_line.json
 [ -f $O/mfma_f32_rate_probe.txt ] && cp $O/mfma_f32_rate_probe.txt profiles/${R}_mfma_f32_rate_probe.txt
 [ -f $O/mfma_valu_coissue_probe.txt ] && cp $O/mfma_valu_coissue_probe.txt profiles/${R}_mfma_valu_coissue_probe.txt
 [ -f $O/mfma_valu_samewave_probe.txt ] && cp $O/mfma_valu_samewave_probe.txt profiles/${R}_mfma_valu_samewave_probe.txt
+[ -f $O/train_batch_sweep.jsonl ] && python3 -c "import json,sys; [print(d['config']['batch_per_gpu'], d['value'], d['ms_per_step'], round(d['samples_per_s'])) for d in map(json.loads, open(sys.argv[1]))]" $O/train_batch_sweep.jsonl > profiles/${R}_train_batch_sweep_latest.txt
 [ -f $O/torch_eager_baseline.txt ] && cp $O/torch_eager_baseline.txt profiles/${R}_torch_eager_baseline.txt
 [ -f $O/train_host_vs_device.txt ] && cp $O/train_host_vs_device.txt profiles/${R}_train_host_vs_device.txt
 f=$(ls -t $O/train_stats/*/*_kernel_stats.csv 2>/dev/null | head -1); [ -n "$f" ] && python3 tools/probes/train_host/kernel_stats_per_iteration.py "$f" 40 60 > profiles/${R}_train_kernels_per_iteration.txt

@@ -14,6 +14,7 @@ AMUSE_TRAIN_FUSED=0 timeout 300 python bench.py --config train --steps 60 --warm
 timeout 300 python tools/gpu_train_profile.py 32 $O/train_profile.txt > /dev/null 2>&1
 timeout 200 python tools/gpu_train_attn_perf.py > $O/train_attn_perf.txt 2>&1
 timeout 300 python bench.py --config train --steps 60 --warmup 15 --no-graph > $O/train_bench_nograph.json 2> /dev/null
+for b in 32 64 128 256 512; do timeout 300 python bench.py --config train --train-batch $b --steps 30 --warmup 8 2>/dev/null | tail -1; done > $O/train_batch_sweep.jsonl   # samples/s against the batch (config 4 is 32)
 timeout 300 python tools/probes/train_host/gemm_time.py > $O/train_gemm_time.txt 2>&1          # the library's own GEMMs against torch's, per call
 timeout 300 python tools/multigpu_preflight.py --gpus 1 > $O/multigpu_preflight_world1.txt 2>&1   # RCCL world of one: init, barrier, all-reduce, all-gather, bitwise shard check
 (cd tools/probes/attend_32x32 && for B in 256 1024 4096; do for f in ./attend32_v12_t*_probe; do timeout 120 $f $B 50; done; done) > $O/attend32_probe.txt 2>&1
