@@ -34,6 +34,7 @@ extern "C" {
  *   build macro  AMUSE_FPROF=1         variant builds only (tools/build_variant.sh): s_memtime phase stamps of the fused per-clip kernels
  *   environment  AMUSE_HIP_LIB         amuse_amd/_lib.py: load another build of this ABI (kernel A/B measurements)
  *   environment  AMUSE_SHARE_GPU=1     amuse_amd/main.py: every --gpus rank stays on --device (two-process tests on a one-GPU box)
+ *   environment  AMUSE_BENCH_SHARE_GPU=1   bench.py: --gpus N ranks on one GPU over gloo (the two-rank bench tests on a one-GPU box)
  *   environment  AMUSE_RUN_STAMP, AMUSE_MANIFEST_DIR   launcher -> rank hand-over inside amuse_amd/main.py (not set by users)
  *   environment  AMUSE_TRAIN_FUSED=0, AMUSE_TRAIN_VALIDATE=1, AMUSE_TRAIN_INNER=train   train_gesture: eager layers / torch's distribution checks / the reference's
  *                                      train-mode inner sampler (amuse_amd/train_ops.py, train_gesture.py)
