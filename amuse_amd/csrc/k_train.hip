@@ -809,8 +809,7 @@ int amuse_train_layer_fwd(const amuse_train_layer* L, void* stream) {
     ln_fwd_launch(L->x, L->tmp, L->bo, L->g1, L->be1, thr, scale, L->seed, L->off[0], rows, L->x1, L->zh1, L->r1, st);
     const float* src = L->x1;
     if (L->mem) {   // xm = norm2(x1 + dropout2(vk Wc^T + bc)), vk = the memory token's value projection under the attention dropout
-        bias_rows_launch(L->bv, L->B, 128, L->c, st);
-        TRY(rm_gemm(h, false, true, L->B, 128, 128, L->mem, L->Wv, L->c, true));
+        TRY(rm_gemm(h, false, true, L->B, 128, 128, L->mem, L->Wv, L->c, false, L->bv));   // (the bias in the generic kernel's epilogue: one launch; product + bias = bias + product, the same bits as pre-filling c)
         const size_t n = (size_t)rows * 32, g = (n + 255) / 256;
         hipLaunchKernelGGL(k_train_vk, dim3((unsigned)(g > 8192 ? 8192 : g)), dim3(256), 0, st, L->c, thr_a, scale_a, L->seed, L->off[4], train_epoch_ptr(), rows, L->S, L->H, L->vk);
         TRY(rm_gemm(h, false, true, rows, 128, 128, L->vk, L->Wc, L->tmp, false));
