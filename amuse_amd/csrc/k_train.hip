@@ -515,6 +515,29 @@ __global__ __launch_bounds__(256) void k_train_wgrad_sum(const float* __restrict
 constexpr int kTrainLanes = 2;
 thread_local int g_train_lane = 0;
 float* g_wgrad_ws[64][kTrainLanes] = {};
+// a stream of the library's own per device and lane for the decoder layers' memory-token branch (amuse_train_layer_bwd), with the one fork / join event pair it needs;
+// created on the first (eager) call, so that a later graph capture of the step finds them
+struct MemSide {
+    hipStream_t st;
+    hipEvent_t fork, join;
+    bool ok;
+};
+MemSide g_mem_side[64][kTrainLanes] = {};
+std::mutex g_mem_side_mu;
+int mem_side(MemSide** out) {
+    int dev = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lock(g_mem_side_mu);
+    MemSide& m = g_mem_side[dev & 63][g_train_lane];
+    if (!m.ok) {
+        HIP_TRY(hipStreamCreateWithFlags(&m.st, hipStreamNonBlocking));
+        HIP_TRY(hipEventCreateWithFlags(&m.fork, hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&m.join, hipEventDisableTiming));
+        m.ok = true;
+    }
+    *out = &m;
+    return 0;
+}
 // gradients of at least this many elements go to the generic kernel (k_train_gemm.hip)
 constexpr long wgrad_max_elems() { return 131072L; }
 int wgrad_launch(const float* dy, const float* x, float* out, long rows, long M, long N, hipStream_t st) {
@@ -847,6 +870,7 @@ int amuse_train_layer_bwd(const amuse_train_layer* L, void* stream) {
         ~Park() { g_layer_sums = nullptr; g_layer_ws_used = 0; }
     } park(&sums);
     int& nj = sums.nj;
+    MemSide* side = nullptr;
     // FFN + last norm: s128a = d(src) through the norm, s128b = d(linear2 output)
     ln_bwd_launch(L->dout, nullptr, L->zh3, L->r3, L->g3, thr, scale, L->seed, L->off[3], rows, L->s128a, L->s128b, L->dg3, L->dbe3, L->db2, L->ws + nj * kWsRegion, st, &sums.j[nj]);
     ++nj;
@@ -866,12 +890,25 @@ int amuse_train_layer_bwd(const amuse_train_layer* L, void* stream) {
                       &sums.j[nj]);
         ++nj;
         TRY(rm_gemm(h, true, false, 128, 128, rows, L->s128b, L->vk, L->dWc, false));
-        TRY(rm_gemm(h, false, false, rows, 128, 128, L->s128b, L->Wc, L->do2, false));     // d(vk), parked in do2
-        hipLaunchKernelGGL(k_train_dc, dim3(L->B), dim3(256), 0, st, L->do2, thr_a, scale_a, L->seed, L->off[4], train_epoch_ptr(), L->S, L->H, L->sdc);
-        TRY(rm_gemm(h, true, false, 128, 128, L->B, L->sdc, L->mem, L->dWv, false));
-        colsum_launch(L->sdc, L->B, 128, L->dbv, L->ws + nj * kWsRegion, st, &sums.j[nj]);
+        // The memory token's branch - d(c) per clip, dWv, dbv, d(mem): four launches over 32 rows, 5-13 us each of mostly latency - feeds nothing inside the layer.  In
+        // the tall layers it runs on a stream of the library's own beside the rest of the layer (forked here, joined in front of the layer's summing launch); d(vk) then
+        // sits in the forward pass's scratch `tmp`, because `do2` is written again further down.
+        if (rows >= 1024) TRY(mem_side(&side));
+        float* dvk = side ? L->tmp : L->do2;
+        TRY(rm_gemm(h, false, false, rows, 128, 128, L->s128b, L->Wc, dvk, false));     // d(vk)
+        hipStream_t ms = st;
+        if (side) {
+            ms = side->st;
+            HIP_TRY(hipEventRecord(side->fork, st));
+            HIP_TRY(hipStreamWaitEvent(ms, side->fork, 0));
+        }
+        hipLaunchKernelGGL(k_train_dc, dim3(L->B), dim3(256), 0, ms, dvk, thr_a, scale_a, L->seed, L->off[4], train_epoch_ptr(), L->S, L->H, L->sdc);
+        if (side) HIP_TRY(launch_train_gemm_any(L->sdc, L->mem, nullptr, L->dWv, 128, 128, L->B, true, false, false, ms));
+        else TRY(rm_gemm(h, true, false, 128, 128, L->B, L->sdc, L->mem, L->dWv, false));
+        colsum_launch(L->sdc, L->B, 128, L->dbv, L->ws + nj * kWsRegion, ms, &sums.j[nj]);
         ++nj;
-        TRY(rm_gemm(h, false, false, L->B, 128, 128, L->sdc, L->Wv, L->dmem, false));
+        if (side) HIP_TRY(launch_train_gemm_any(L->sdc, L->Wv, nullptr, L->dmem, L->B, 128, 128, false, false, false, ms));
+        else TRY(rm_gemm(h, false, false, L->B, 128, 128, L->sdc, L->Wv, L->dmem, false));
         ln_bwd_launch(L->s128a, nullptr, L->zh1, L->r1, L->g1, thr, scale, L->seed, L->off[0], rows, L->dx, L->s128b, L->dg1, L->dbe1, L->dbo, L->ws + nj * kWsRegion, st,
                       &sums.j[nj]);
     } else {
@@ -886,6 +923,10 @@ int amuse_train_layer_bwd(const amuse_train_layer* L, void* stream) {
         if (!L->qkv || !L->lse || !L->dqkv || !L->dWin) return fail(AMUSE_EINVAL, "amuse_train_layer (backward): self-attention buffers missing");
         TRY(amuse_train_attn_bwd(L->qkv, L->o2, L->lse, L->do2, L->B, L->S, L->p_attn, L->seed, L->off_self, L->dqkv, stream));
         TRY(amuse_train_linear_bwd(L->dqkv, L->x, L->Win, rows, 128, 384, L->dWin, L->dbin, L->dx, 1, L->ws + nj * kWsRegion, stream));
+    }
+    if (side) {   // join: the summing launch reads the branch's column sums, the caller d(mem)
+        HIP_TRY(hipEventRecord(side->join, side->st));
+        HIP_TRY(hipStreamWaitEvent(st, side->join, 0));
     }
     hipLaunchKernelGGL(k_train_layer_sums, dim3((unsigned)nj + sums.blocks), dim3(kTrainThreads), 0, st, sums);   // every column sum and weight gradient of the layer
     HIP_TRY(hipGetLastError());
