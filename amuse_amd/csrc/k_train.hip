@@ -890,6 +890,8 @@ int amuse_train_layer_bwd(const amuse_train_layer* L, void* stream) {
                       &sums.j[nj]);
         ++nj;
         TRY(rm_gemm(h, true, false, 128, 128, rows, L->s128b, L->vk, L->dWc, false));
+        // (The same fork in the FORWARD pass - vk produced on the side stream under the self-attention half - measured 10 % SLOWER: a cross-queue edge of a replayed graph
+        // takes on the order of 100 us to propagate, harmless here where the join has a whole layer of slack, fatal there where it has 40 us.)
         // The memory token's branch - d(c) per clip, dWv, dbv, d(mem): four launches over 32 rows, 5-13 us each of mostly latency - feeds nothing inside the layer.  In
         // the tall layers it runs on a stream of the library's own beside the rest of the layer (forked here, joined in front of the layer's summing launch); d(vk) then
         // sits in the forward pass's scratch `tmp`, because `do2` is written again further down.
