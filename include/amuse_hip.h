@@ -439,6 +439,8 @@ typedef struct amuse_train_layer {
     uint64_t off_self;                          /* mask offset of the self-attention's dropout */
 } amuse_train_layer;
 int amuse_train_layer_fwd(const amuse_train_layer* layer, void* stream);
+/* (amuse_train_layer_bwd of a decoder layer with >= 1,024 rows issues the memory token's branch - d(c), dWv, dbv, d(mem) - on a stream of the library's own, forked from
+ * and joined back into `stream` inside the call: everything is complete in `stream` order when the call returns, also under stream capture) */
 int amuse_train_layer_bwd(const amuse_train_layer* layer, void* stream);
 /* out [rows][N] = x [rows][K] W^T + b (b nullable);  dW [N][K] = dy^T x, db [N] = sum_rows dy, dx [rows][K] (+)= dy W (each output nullable) */
 int amuse_train_linear_fwd(const float* x, const float* W, const float* b, long rows, int K, int N, float* out, void* stream);
